@@ -1,0 +1,151 @@
+#!/usr/bin/env python
+"""bench.py -- pileup Gbases/s of the MI355X-native SNV-calling hot path (BASELINE.json metric).
+
+One "step" = one pass of the hot path (pileup histogram -> gates -> per-sample gather -> calling
+rule) over the synthetic "testdata"-shaped batch (BASELINE.json configs[1]: 160 BAMs x 3
+refGenomes), with the packed read columns already resident in HBM.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU: contigs shard across ranks with no data-path collective; every
+rank holds its own testdata-shaped shard (weak scaling) and only the small result tables are
+gathered over RCCL after the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--samples", type=int, default=160)
+    ap.add_argument("--contig-len", type=int, default=300000)
+    ap.add_argument("--species", type=int, default=3)
+    ap.add_argument("--mean-cov", type=float, default=10.0)
+    ap.add_argument("--cpu-samples", type=int, default=24, help="samples of the workload the CPU oracle is timed on")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-threads", type=int, default=0)
+    return ap.parse_args()
+
+
+def cpu_baseline(sp_kwargs, n_cpu_samples):
+    """The oracle (CPU restatement, kind "port") timed on a bounded sample of the same workload."""
+    import orc
+    from metasnv_amd import core
+    sp = core.synth_params(**sp_kwargs)
+    syn = core.Synth(sp)
+    samples = [syn.sample_records(i) for i in range(n_cpu_samples)]
+    t0 = time.perf_counter()
+    pop, ind, n_lines, n_bases = orc.call(syn.names, syn.lengths, syn.seqs, samples)
+    dt = time.perf_counter() - t0
+    return {"value": n_bases / dt / 1e9, "unit": "Gbases/s", "cores": 1, "kind": "port",
+            "sample": "first %d of %d samples, all %d contigs: %d pileup bases in %.1f s (mpileup+snpCall restatement, 1 thread)"
+                      % (n_cpu_samples, sp.n_samples, sp.n_species, n_bases, dt),
+            "called_lines": pop.count("\n")}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_
+        torch.cuda.set_device(local)
+        dist_.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        dist = dist_
+
+    from metasnv_amd import core
+    if core.device_count() < 1:
+        raise SystemExit("bench.py: no HIP device visible; the pileup path has no CPU fallback")
+
+    # ---- build this rank's shard: same shape on every rank, different seed (weak scaling)
+    sp_kwargs = dict(n_species=a.species, contig_len=a.contig_len, n_samples=a.samples, mean_cov=a.mean_cov, seed=1 + rank)
+    sp = core.synth_params(**sp_kwargs)
+    syn = core.Synth(sp)
+    ctx = core.Context(local)
+    ds = core.Dataset(ctx, syn.names, syn.lengths, syn.seqs)
+    t0 = time.perf_counter()
+    ds.add_synth_samples(sp, 0, a.samples, a.host_threads)
+    t_pack = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    info = ds.finalize()
+    t_up = time.perf_counter() - t0
+
+    def barrier():
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        ds.run()
+    barrier()
+    t0 = time.perf_counter()
+    ms_pileup, ms_total = [], []
+    for _ in range(a.steps):
+        st = ds.run()                      # blocks until the pass has finished (stream sync inside)
+        ms_pileup.append(st["ms_pileup"]); ms_total.append(st["ms_total"])
+    barrier()
+    dt = time.perf_counter() - t0
+
+    bases = info["n_pileup_bases"]
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt, float(bases), float(st["n_called_pop"]), float(st["n_called_indiv"])], dtype=torch.float64, device="cuda")
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)       # the only collective: tiny result table over RCCL/xGMI
+        dt_max = max(float(g[0]) for g in gathered)
+        total_bases = sum(float(g[1]) for g in gathered)
+        called = [int(g[2]) for g in gathered]
+    else:
+        dt_max, total_bases, called = dt, float(bases), [int(st["n_called_pop"])]
+
+    if rank == 0:
+        k_ms = sum(ms_pileup) / len(ms_pileup)
+        alg = st["algorithmic_bytes"]
+        achieved = alg / (k_ms * 1e-3) / 1e9
+        line = {
+            "metric": "pileup Gbases/s across all samples",
+            "value": total_bases * a.steps / dt_max / 1e9,
+            "unit": "Gbases/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt_max / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u16/u32 integer counts", "data": "synthetic",
+            "config": {"workload": "testdata shape: %d synthetic BAM-record streams x %d refGenomes x %d bp, ~%gx, single-end 100 bp (BASELINE configs[1])"
+                                   % (a.samples, a.species, a.contig_len, a.mean_cov),
+                       "samples": a.samples, "positions_per_gpu": info["n_positions"], "pileup_bases_per_gpu": bases,
+                       "reads_per_gpu": info["n_reads"], "parallelism": "contig shards x%d, no data-path collective" % world,
+                       "called_SNPs_lines_per_rank": called},
+            "roofline": {"bound": "hbm", "kernel": "msnv_pileup_tiles", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg, "kernel_ms_avg": k_ms,
+                         "bytes_per_pileup_base": alg / max(1, bases)},
+            "positions_per_s": info["n_positions"] * world * a.steps / dt_max,
+            "kernel_ms": {"pileup": k_ms, "pipeline_total": sum(ms_total) / len(ms_total)},
+            "host": {"pack_s": t_pack, "finalize_upload_s": t_up, "device_bytes": info["device_bytes"]},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(sp_kwargs, min(a.cpu_samples, a.samples))
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,275 @@
+/*
+ * include/msnv.h -- C ABI of libmsnv.so, the MI355X-native pileup SNV caller.
+ *
+ * The reference (metaSNV) has no plugin API on this path: its hot path is two PROCESS
+ * boundaries driven by metaSNV.py.  Each entry point below names the process invocation
+ * (argv + files + exit status) it replaces, so a maintainer can swap the subprocess call
+ * for one ctypes call (the stub is shown in INTEGRATION.md).
+ *
+ *   msnv_coverage()  <-  `qaCompute -c 10 -d -i BAM OUT`            metaSNV.py:55-78
+ *                        (src/qaTools/qaCompute.cpp:286-681)
+ *   msnv_call()      <-  `samtools mpileup -f REF [-l SPLIT] -B -b LIST |
+ *                         snpCall -f REF [-g ANN] -i INDIV -c C -t T > CALLED`
+ *                                                                    metaSNV.py:153-176
+ *                        (src/snpCaller/call_vC.cpp:330-679)
+ *
+ * The staged msnv_dataset_* / msnv_pileup_run / msnv_write_calls entry points are the same
+ * path cut at its natural seams (decode+pack | device kernels | text), so that a caller
+ * can keep the packed columns resident in HBM (bench.py times msnv_pileup_run only).
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types; every function returns 0 on
+ * success and a positive MSNV_E* code otherwise (the reference's drivers treat any
+ * non-zero exit status as fatal: metaSNV.py:75-78,212-221); the message is available from
+ * msnv_last_error() (thread-local) and echoed to stderr.  The library never abort()s.
+ * All compute runs on the GPU: there is no CPU fallback, and every entry point fails with
+ * MSNV_ENODEV when no HIP device is usable.
+ */
+#ifndef MSNV_H
+#define MSNV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSNV_OK        0
+#define MSNV_EINVAL    1   /* bad argument                                              */
+#define MSNV_EIO       2   /* cannot open / read / write a file                         */
+#define MSNV_EFORMAT   3   /* malformed BAM / FASTA / BED / annotation                  */
+#define MSNV_ENODEV    4   /* no usable HIP device (the path never falls back to CPU)   */
+#define MSNV_EHIP      5   /* a HIP runtime call or kernel launch failed                */
+#define MSNV_ENOMEM    6
+#define MSNV_EDOMAIN   7   /* input outside the domain of the reference tools (SURVEY.md
+                              Appendix A "D" items), e.g. BAM without mapped reads       */
+#define MSNV_ECAPACITY 8   /* internal device buffer too small (caller may retry)        */
+
+typedef struct msnv_ctx     msnv_ctx;      /* one per GPU / per rank          */
+typedef struct msnv_dataset msnv_dataset;  /* packed read columns of one shard */
+
+int         msnv_abi_version(void);
+const char *msnv_last_error(void);
+
+/* Number of visible HIP devices (hipGetDeviceCount; 0 when the runtime has none). */
+int  msnv_device_count(void);
+int  msnv_ctx_create(int device_id, msnv_ctx **out);
+void msnv_ctx_destroy(msnv_ctx *ctx);
+
+/* ------------------------------------------------------------------------------------
+ * Calling parameters = snpCall's options (call_vC.cpp:26-36,382-390) + the mpileup
+ * defaults metaSNV relies on (metaSNV.py:160-165 passes none).
+ * ------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t min_coverage;        /* snpCall -c, default 4                                 */
+    int32_t calling_threshold;   /* snpCall -t, default 4                                 */
+    double  min_fraction;        /* snpCall -p, default 0.01 (never passed by metaSNV.py) */
+    int32_t min_baseq;           /* mpileup -Q, default 13                                */
+    int32_t flag_filter;         /* mpileup --ff, default 0x704                           */
+    int32_t count_orphans;       /* mpileup -A, default 0                                 */
+    int32_t max_depth;           /* mpileup -d, default 8000 (per file)                   */
+    int32_t min_mapq;            /* mpileup -q, default 0                                 */
+    int32_t drop_first_line;     /* 1 = reproduce call_vC.cpp:423 (first pileup position of
+                                    the invocation is consumed for sample counting and never
+                                    called); 0 = call every position                      */
+    int32_t cov_max;             /* qaCompute -c, default 10                              */
+    int32_t cov_min_mapq;        /* qaCompute -q, default 1                               */
+} msnv_params;
+
+void msnv_params_default(msnv_params *p);
+
+/* ------------------------------------------------------------------------------------
+ * msnv_coverage  <-  qaCompute -c <max_cov> -d -i <bam_path> <out_cov_path>
+ * Writes <out_cov_path> and <out_detail_path> byte-for-byte as qaCompute.cpp:192-217,
+ * 226-263,439,623-657 would.  Return: 0 ok (qaCompute.cpp:680); MSNV_EIO mirrors its
+ * exit 1 (:53-57,376-379); MSNV_EDOMAIN for the inputs on which it has undefined
+ * behaviour (no mapped reads: :596).
+ * ------------------------------------------------------------------------------------ */
+typedef struct {
+    const char *bam_path;
+    int32_t     max_cov;          /* -c, metaSNV passes 10 */
+    int32_t     min_mapq;         /* -q, default 1         */
+    const char *out_cov_path;     /* OUT                   */
+    const char *out_detail_path;  /* OUT.detail (-d)       */
+} msnv_cov_args;
+
+int msnv_coverage(msnv_ctx *ctx, const msnv_cov_args *args);
+
+/* ------------------------------------------------------------------------------------
+ * msnv_call  <-  samtools mpileup -f ref_fasta [-l bed_split_path] -B -b <bam list> |
+ *                snpCall -f ref_fasta [-g ann_path] -i out_indiv_path -c .. -t .. [-p ..]
+ *                > out_called_path
+ * Sample order = bam_paths order = all_samples order (call_vC.cpp:530).
+ * contig_rank_mask: optional (NULL = all): one byte per BAM-header contig, non-zero =
+ * this rank's shard (multi-GPU contig sharding); output then holds
+ * only those contigs.
+ * ------------------------------------------------------------------------------------ */
+typedef struct {
+    const char *const *bam_paths;
+    int32_t     n_bams;
+    const char *ref_fasta;        /* -f                                                  */
+    const char *ann_path;         /* -g or NULL                                          */
+    const char *bed_split_path;   /* -l or NULL: 3-column `name\t1\tLEN` (metaSNV.py:92)  */
+    const char *out_called_path;  /* stdout of snpCall                                   */
+    const char *out_indiv_path;   /* -i or NULL                                          */
+    const uint8_t *contig_rank_mask;
+    int32_t     n_contig_rank_mask;
+    int32_t     host_threads;     /* BAM decode threads, 0 = auto                        */
+    msnv_params params;
+} msnv_call_args;
+
+int msnv_call(msnv_ctx *ctx, const msnv_call_args *args);
+
+/* ------------------------------------------------------------------------------------
+ * Staged form of the same path.
+ * ------------------------------------------------------------------------------------ */
+
+/* Reference description: contigs in BAM-header order.  seqs[i] may be NULL (contig absent
+ * from the FASTA: mpileup then prints 'N').  The library copies everything. */
+typedef struct {
+    int32_t            n_contigs;
+    const char *const *names;
+    const int64_t     *lengths;    /* @SQ LN                                   */
+    const char *const *seqs;       /* FASTA characters, case preserved, or NULL */
+    const int64_t     *seq_lens;
+} msnv_ref_desc;
+
+int  msnv_dataset_create(msnv_ctx *ctx, const msnv_ref_desc *ref, const msnv_params *params,
+                         msnv_dataset **out);
+/* Convenience: contigs from the header of `bam_path`, sequences from `fasta_path`. */
+int  msnv_dataset_create_from_files(msnv_ctx *ctx, const char *bam_path, const char *fasta_path,
+                                    const msnv_params *params, msnv_dataset **out);
+void msnv_dataset_destroy(msnv_dataset *ds);
+
+/* Restrict the shard: BED regions (mpileup -l; 0-based half-open, at most one region per
+ * contig) and/or a contig mask.  Must precede the first add_sample call. */
+int  msnv_dataset_set_bed(msnv_dataset *ds, int32_t n, const int32_t *tid, const int64_t *beg, const int64_t *end);
+int  msnv_dataset_set_bed_file(msnv_dataset *ds, const char *bed_path);
+int  msnv_dataset_set_contig_mask(msnv_dataset *ds, const uint8_t *mask, int32_t n);
+
+/* Append one sample (= one BAM of all_samples), in order.  `records` = concatenated raw
+ * uncompressed BAM alignment records (each starting with its int32 block_size), i.e. what
+ * sam_read1() yields (qaCompute.cpp:441). */
+int  msnv_dataset_add_sample_records(msnv_dataset *ds, const uint8_t *records, uint64_t n_bytes);
+int  msnv_dataset_add_sample_bam(msnv_dataset *ds, const char *bam_path);
+/* Decode many BAMs with a host thread pool, preserving order. */
+int  msnv_dataset_add_sample_bams(msnv_dataset *ds, const char *const *bam_paths, int32_t n, int32_t host_threads);
+
+/* Builds the tile index and uploads the packed columns to HBM. */
+int  msnv_dataset_finalize(msnv_dataset *ds);
+
+typedef struct {
+    uint64_t n_samples, n_contigs, n_positions;   /* positions = sum of shard contig lengths      */
+    uint64_t n_reads, n_reads_pileup;             /* stored reads / reads that pass mpileup filters */
+    uint64_t n_pileup_bases;                      /* (read, ref position) pairs from M/=/X ops of
+                                                     reads that pass the read-level filters        */
+    uint64_t bytes_headers, bytes_cigar, bytes_seq, bytes_qual, bytes_ref, bytes_index;
+    uint64_t n_tiles, n_pairs, n_work;
+    uint64_t device_bytes;                        /* total HBM held by the dataset                 */
+} msnv_dataset_info;
+
+int  msnv_dataset_info_get(const msnv_dataset *ds, msnv_dataset_info *out);
+
+typedef struct {
+    float    ms_total;           /* all kernels of one pass, HIP events on the launch stream */
+    float    ms_pileup;          /* the dominant kernel (msnv_pileup_tiles)                  */
+    float    ms_gate, ms_gather, ms_decide, ms_coverage;
+    uint64_t n_sites;            /* candidate positions that reached the decision kernel     */
+    uint64_t n_called_pop, n_called_indiv;   /* output lines (before the first-line drop)    */
+    uint64_t n_events, n_overflow;
+    uint64_t algorithmic_bytes;  /* bytes the pileup kernel must read  */
+} msnv_run_stats;
+
+/* One pass of the hot path over the resident dataset: per-position / per-sample allele
+ * histogram, calling rule, per-sample gather.  Results stay on the device until
+ * msnv_write_calls / msnv_results_*.  Safe to call repeatedly (bench.py). */
+int  msnv_pileup_run(msnv_dataset *ds, msnv_run_stats *stats);
+
+/* Per-sample genome coverage (qaCompute arithmetic) over the resident dataset. */
+int  msnv_coverage_run(msnv_dataset *ds, msnv_run_stats *stats);
+/* Writes OUT / OUT.detail for sample `sample_idx` from the last msnv_coverage_run. */
+int  msnv_write_coverage(msnv_dataset *ds, int32_t sample_idx, const char *cov_path, const char *detail_path);
+
+/* Formats the last run as called_SNPs / indiv_called (call_vC.cpp:641-667).
+ * ann_path / fasta_path feed the codon annotation (call_vC.cpp:604-633) and may be NULL. */
+int  msnv_write_calls(msnv_dataset *ds, const char *called_path, const char *indiv_path,
+                      const char *ann_path, const char *fasta_path);
+
+/* Raw results of the last run (for tests and for the multi-GPU gather).
+ * A site record is fixed width:  msnv_site header + n_samples x msnv_site_sample. */
+typedef struct {
+    int32_t  tid;        /* BAM-header contig index              */
+    int32_t  pos;        /* 0-based position                     */
+    uint32_t cov;        /* total coverage over all samples      */
+    uint32_t n[4];       /* total A, C, G, T                     */
+    uint8_t  pop_mask;   /* bit i: allele i (A,C,G,T) is a population SNV */
+    uint8_t  ind_mask;   /* bit i: allele i is an individual SNV          */
+    uint8_t  refchar;    /* FASTA character                      */
+    uint8_t  dropped;    /* 1 = this is the first pileup line (call_vC.cpp:423) */
+} msnv_site;
+
+typedef struct { uint16_t cov; uint16_t n[4]; } msnv_site_sample;
+
+int  msnv_results_count(const msnv_dataset *ds, uint64_t *n_sites);
+/* sites[n_sites], samples[n_sites * n_samples], both in (tid, pos) order. */
+int  msnv_results_fetch(msnv_dataset *ds, msnv_site *sites, msnv_site_sample *samples, uint64_t capacity);
+
+/* ------------------------------------------------------------------------------------
+ * Host I/O helpers used by the Python CLI and the tests (BGZF/BAM on zlib: htslib is not
+ * available in the build image).
+ * ------------------------------------------------------------------------------------ */
+/* `samtools view -H` replacement for bed_header (metaSNV.py:81-94): writes SN\t1\tLN lines. */
+int  msnv_bam_write_bed_header(const char *bam_path, const char *out_path);
+/* Reads a whole BAM: header text, contigs and the raw record stream.  Free with msnv_free. */
+typedef struct {
+    int32_t   n_contigs;
+    char    **names;
+    int64_t  *lengths;
+    uint8_t  *records;
+    uint64_t  n_record_bytes;
+    char     *header_text;
+} msnv_bam_data;
+int  msnv_bam_read(const char *bam_path, msnv_bam_data *out);
+void msnv_bam_data_free(msnv_bam_data *d);
+/* Writes a BAM (BGZF) from a header and a raw record stream (synthetic inputs, tests). */
+int  msnv_bam_write(const char *bam_path, const char *header_text, int32_t n_contigs,
+                    const char *const *names, const int64_t *lengths,
+                    const uint8_t *records, uint64_t n_record_bytes, int32_t compress_level);
+
+/* ------------------------------------------------------------------------------------
+ * Synthetic workload generator (SURVEY.md section 8d "testdata" shape).  Deterministic in
+ * `seed`.  Produces the reference sequences and, per sample, a raw BAM record stream.
+ * ------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t  n_species;          /* contigs refGenome{1..n}clus, one contig each            */
+    int64_t  contig_len;
+    int32_t  n_samples;
+    int32_t  read_len;
+    double   mean_cov;           /* per (sample, species): LogNormal(ln mean_cov, sigma)     */
+    double   sigma_cov;
+    double   frac_absent;        /* (sample, species) pairs with zero coverage               */
+    double   snv_density;        /* subspecies SNV sites per position                        */
+    double   error_rate;
+    double   frac_lowq;          /* bases with BQ in [2,12]                                  */
+    double   frac_indel_reads;   /* reads carrying one small I or D                          */
+    double   frac_clip_reads;    /* reads with a leading soft/hard clip                      */
+    double   frac_flagged;       /* DUP / SECONDARY / QCFAIL / mapq 0 reads (each)           */
+    int32_t  lowercase_ref;      /* 1 = soft-mask 5 % of the reference (lower-case)           */
+    uint64_t seed;
+} msnv_synth_params;
+
+void msnv_synth_params_default(msnv_synth_params *p);
+/* Reference sequences: caller frees each seqs[i] and the arrays with msnv_free. */
+int  msnv_synth_reference(const msnv_synth_params *p, char ***names, int64_t **lengths, char ***seqs);
+/* One sample's raw BAM record stream (coordinate sorted). */
+int  msnv_synth_sample(const msnv_synth_params *p, int32_t sample_idx, char *const *seqs,
+                       uint8_t **records, uint64_t *n_bytes);
+/* Generates samples [first, first+count) with a host thread pool and appends them to `ds`
+ * (same bytes as msnv_synth_sample + msnv_dataset_add_sample_records, without the copies). */
+int  msnv_dataset_add_synth_samples(msnv_dataset *ds, const msnv_synth_params *p, int32_t first, int32_t count,
+                                    int32_t host_threads);
+void msnv_free(void *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

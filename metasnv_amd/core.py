@@ -1,0 +1,253 @@
+"""Thin object layer over the C ABI (metasnv_amd/_lib.py).  No compute happens in Python."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib, check, Params, SynthParams, DatasetInfo, RunStats, Site, SiteSample, RefDesc
+
+SITE_DTYPE = np.dtype([("tid", "<i4"), ("pos", "<i4"), ("cov", "<u4"), ("n", "<u4", (4,)),
+                       ("pop_mask", "u1"), ("ind_mask", "u1"), ("refchar", "u1"), ("dropped", "u1")])
+SAMPLE_DTYPE = np.dtype([("cov", "<u2"), ("n", "<u2", (4,))])
+assert SITE_DTYPE.itemsize == C.sizeof(Site) and SAMPLE_DTYPE.itemsize == C.sizeof(SiteSample)
+
+
+def default_params(**kw):
+    p = Params()
+    lib.msnv_params_default(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError("msnv_params has no field %r" % k)
+        setattr(p, k, v)
+    return p
+
+
+def device_count():
+    return lib.msnv_device_count()
+
+
+class Context:
+    """One per GPU (one per rank)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        check(lib.msnv_ctx_create(int(device), C.byref(self._h)))
+        self.device = int(device)
+
+    def close(self):
+        if self._h:
+            lib.msnv_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _cstr_array(strings):
+    arr = (C.c_char_p * len(strings))()
+    arr[:] = [s if isinstance(s, bytes) else s.encode() for s in strings]
+    return arr
+
+
+class Dataset:
+    """Packed read columns of one shard, resident in HBM after finalize()."""
+
+    def __init__(self, ctx, names, lengths, seqs=None, params=None):
+        self.ctx = ctx
+        self.names = [n.decode() if isinstance(n, bytes) else n for n in names]
+        self.lengths = [int(x) for x in lengths]
+        n = len(names)
+        self._names = _cstr_array(names)
+        self._lengths = (C.c_int64 * n)(*lengths)
+        seqs = seqs if seqs is not None else [None] * n
+        self._seqs_keep = [None if s is None else (s if isinstance(s, bytes) else s.encode()) for s in seqs]
+        self._seqs = (C.c_char_p * n)(*self._seqs_keep)
+        self._seq_lens = (C.c_int64 * n)(*[0 if s is None else len(s) for s in self._seqs_keep])
+        rd = RefDesc(n, self._names, self._lengths, self._seqs, self._seq_lens)
+        self.params = params or default_params()
+        self._h = C.c_void_p()
+        self.n_samples = 0
+        check(lib.msnv_dataset_create(ctx._h, C.byref(rd), C.byref(self.params), C.byref(self._h)))
+
+    @classmethod
+    def from_files(cls, ctx, first_bam, fasta, params=None):
+        self = cls.__new__(cls)
+        self.ctx = ctx
+        self.params = params or default_params()
+        self._h = C.c_void_p()
+        self.n_samples = 0
+        check(lib.msnv_dataset_create_from_files(ctx._h, first_bam.encode(), fasta.encode() if fasta else None,
+                                                 C.byref(self.params), C.byref(self._h)))
+        hdr = read_bam(first_bam, records=False)
+        self.names, self.lengths = hdr["names"], hdr["lengths"]
+        return self
+
+    def set_bed(self, regions):
+        """regions: iterable of (tid, beg, end), 0-based half-open (mpileup -l)."""
+        regions = list(regions)
+        n = len(regions)
+        t = (C.c_int32 * n)(*[r[0] for r in regions])
+        b = (C.c_int64 * n)(*[r[1] for r in regions])
+        e = (C.c_int64 * n)(*[r[2] for r in regions])
+        check(lib.msnv_dataset_set_bed(self._h, n, t, b, e))
+
+    def set_bed_file(self, path):
+        check(lib.msnv_dataset_set_bed_file(self._h, path.encode()))
+
+    def set_contig_mask(self, mask):
+        m = (C.c_uint8 * len(mask))(*[1 if x else 0 for x in mask])
+        check(lib.msnv_dataset_set_contig_mask(self._h, m, len(mask)))
+
+    def add_sample_records(self, records):
+        """records: bytes / numpy uint8 array of raw BAM alignment records."""
+        if isinstance(records, np.ndarray):
+            buf = np.ascontiguousarray(records, dtype=np.uint8)
+            ptr, n = buf.ctypes.data, buf.size
+        else:
+            buf = bytes(records)
+            ptr, n = C.cast(C.c_char_p(buf), C.c_void_p), len(buf)
+        check(lib.msnv_dataset_add_sample_records(self._h, ptr, n))
+        self.n_samples += 1
+
+    def add_sample_bam(self, path):
+        check(lib.msnv_dataset_add_sample_bam(self._h, path.encode()))
+        self.n_samples += 1
+
+    def add_sample_bams(self, paths, host_threads=0):
+        arr = _cstr_array(paths)
+        check(lib.msnv_dataset_add_sample_bams(self._h, arr, len(paths), host_threads))
+        self.n_samples += len(paths)
+
+    def add_synth_samples(self, synth_p, first, count, host_threads=0):
+        check(lib.msnv_dataset_add_synth_samples(self._h, C.byref(synth_p), first, count, host_threads))
+        self.n_samples += count
+
+    def finalize(self):
+        check(lib.msnv_dataset_finalize(self._h))
+        return self.info()
+
+    def info(self):
+        i = DatasetInfo()
+        check(lib.msnv_dataset_info_get(self._h, C.byref(i)))
+        return {k: getattr(i, k) for k, _ in DatasetInfo._fields_}
+
+    def run(self):
+        st = RunStats()
+        check(lib.msnv_pileup_run(self._h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in RunStats._fields_}
+
+    def coverage_run(self):
+        st = RunStats()
+        check(lib.msnv_coverage_run(self._h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in RunStats._fields_}
+
+    def write_coverage(self, sample_idx, cov_path, detail_path):
+        check(lib.msnv_write_coverage(self._h, sample_idx, cov_path.encode(), detail_path.encode()))
+
+    def results(self):
+        n = C.c_uint64()
+        check(lib.msnv_results_count(self._h, C.byref(n)))
+        sites = np.zeros(n.value, dtype=SITE_DTYPE)
+        samples = np.zeros((n.value, max(1, self.n_samples)), dtype=SAMPLE_DTYPE)
+        check(lib.msnv_results_fetch(self._h, sites.ctypes.data_as(C.POINTER(Site)),
+                                     samples.ctypes.data_as(C.POINTER(SiteSample)), n.value))
+        return sites, samples
+
+    def write_calls(self, called_path, indiv_path=None, ann_path=None, fasta_path=None):
+        check(lib.msnv_write_calls(self._h, called_path.encode(), indiv_path.encode() if indiv_path else None,
+                                   ann_path.encode() if ann_path else None, fasta_path.encode() if fasta_path else None))
+
+    def close(self):
+        if self._h:
+            lib.msnv_dataset_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------------------------ host I/O helpers
+def read_bam(path, records=True):
+    d = _lib.BamData()
+    check(lib.msnv_bam_read(path.encode(), C.byref(d)))
+    try:
+        out = {"names": [d.names[i].decode() for i in range(d.n_contigs)],
+               "lengths": [int(d.lengths[i]) for i in range(d.n_contigs)],
+               "header_text": (d.header_text or b"").decode()}
+        if records:
+            out["records"] = np.ctypeslib.as_array(d.records, shape=(d.n_record_bytes,)).copy() if d.n_record_bytes else np.zeros(0, np.uint8)
+        return out
+    finally:
+        lib.msnv_bam_data_free(C.byref(d))
+
+
+def write_bam(path, names, lengths, records, header_text=None, level=1):
+    rec = np.ascontiguousarray(records, dtype=np.uint8)
+    n = len(names)
+    check(lib.msnv_bam_write(path.encode(), header_text.encode() if header_text else None, n, _cstr_array(names),
+                             (C.c_int64 * n)(*lengths), rec.ctypes.data, rec.size, level))
+
+
+def write_bed_header(bam_path, out_path):
+    check(lib.msnv_bam_write_bed_header(bam_path.encode(), out_path.encode()))
+
+
+# ------------------------------------------------------------------------------------ synthetic workload
+def synth_params(**kw):
+    p = SynthParams()
+    lib.msnv_synth_params_default(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError("msnv_synth_params has no field %r" % k)
+        setattr(p, k, v)
+    return p
+
+
+class Synth:
+    """Deterministic synthetic reference + per-sample raw BAM record streams."""
+
+    def __init__(self, params):
+        self.p = params
+        names = C.POINTER(C.c_char_p)()
+        lengths = C.POINTER(C.c_int64)()
+        seqs = C.POINTER(C.c_char_p)()
+        check(lib.msnv_synth_reference(C.byref(params), C.byref(names), C.byref(lengths), C.byref(seqs)))
+        n = params.n_species
+        self.names = [names[i].decode() for i in range(n)]
+        self.lengths = [int(lengths[i]) for i in range(n)]
+        self.seqs = [seqs[i] for i in range(n)]          # bytes copies
+        self._seq_arr = (C.c_char_p * n)(*self.seqs)
+        # the library allocated with malloc/strdup
+        vp = C.cast(names, C.POINTER(C.c_void_p)), C.cast(seqs, C.POINTER(C.c_void_p))
+        for i in range(n):
+            lib.msnv_free(vp[0][i]); lib.msnv_free(vp[1][i])
+        lib.msnv_free(C.cast(names, C.c_void_p)); lib.msnv_free(C.cast(seqs, C.c_void_p)); lib.msnv_free(C.cast(lengths, C.c_void_p))
+
+    def sample_records(self, idx):
+        rec = C.POINTER(C.c_uint8)()
+        n = C.c_uint64()
+        check(lib.msnv_synth_sample(C.byref(self.p), idx, self._seq_arr, C.byref(rec), C.byref(n)))
+        try:
+            return np.ctypeslib.as_array(rec, shape=(n.value,)).copy() if n.value else np.zeros(0, np.uint8)
+        finally:
+            lib.msnv_free(C.cast(rec, C.c_void_p))
+
+    def write_fasta(self, path, width=60):
+        with open(path, "w") as f:
+            for name, seq in zip(self.names, self.seqs):
+                f.write(">%s\n" % name)
+                s = seq.decode()
+                for i in range(0, len(s), width):
+                    f.write(s[i:i + width] + "\n")

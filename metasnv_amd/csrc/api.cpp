@@ -1,0 +1,387 @@
+// metasnv_amd/csrc/api.cpp -- C ABI of libmsnv.so (include/msnv.h): contexts, datasets, the
+// pipeline driver, result mapping and the reference-format text writers.
+#include <algorithm>
+#include <atomic>
+#include <climits>
+#include <cstring>
+#include <thread>
+
+#include "device.h"
+
+namespace msnv {
+int pack_sample(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, SampleCols &sc);
+int finalize_dataset(msnv_dataset &ds);
+int write_calls_text(msnv_dataset &ds, const char *called_path, const char *indiv_path, const char *ann_path, const char *fasta_path);
+int coverage_run(msnv_dataset &ds, msnv_run_stats *stats);
+int coverage_write(msnv_dataset &ds, int sample, const char *cov_path, const char *detail_path);
+std::vector<std::string> synth_contigs(const msnv_synth_params &p);
+void synth_sample_records(const msnv_synth_params &p, int sample, const std::vector<std::string> &contigs, std::vector<uint8_t> &out);
+}  // namespace msnv
+
+using namespace msnv;
+
+extern "C" int msnv_abi_version(void) { return 1; }
+
+extern "C" void msnv_params_default(msnv_params *p) {
+    if (!p) return;
+    p->min_coverage = 4; p->calling_threshold = 4; p->min_fraction = 0.01;      // call_vC.cpp:26-36
+    p->min_baseq = 13; p->flag_filter = 0x704; p->count_orphans = 0; p->max_depth = 8000; p->min_mapq = 0;
+    p->drop_first_line = 1;
+    p->cov_max = 10; p->cov_min_mapq = 1;                                         // metaSNV.py:63-65, qaCompute.cpp:302
+}
+
+extern "C" int msnv_ctx_create(int device_id, msnv_ctx **out) {
+    clear_error();
+    if (!out) return fail(MSNV_EINVAL, "msnv_ctx_create: NULL out");
+    *out = nullptr;
+    if (int rc = dev_set_device(device_id)) return rc;
+    msnv_ctx *c = new msnv_ctx();
+    c->device = device_id;
+    if (int rc = dev_stream_create(&c->stream)) { delete c; return rc; }
+    *out = c;
+    return MSNV_OK;
+}
+
+extern "C" void msnv_ctx_destroy(msnv_ctx *ctx) {
+    if (!ctx) return;
+    dev_stream_destroy(ctx->stream);
+    delete ctx;
+}
+
+// ------------------------------------------------------------------------------ dataset
+extern "C" int msnv_dataset_create(msnv_ctx *ctx, const msnv_ref_desc *ref, const msnv_params *params, msnv_dataset **out) {
+    clear_error();
+    if (!ctx || !ref || !out) return fail(MSNV_EINVAL, "msnv_dataset_create: NULL argument");
+    msnv_dataset *ds = new msnv_dataset();
+    ds->ctx = ctx;
+    if (params) ds->params = *params; else msnv_params_default(&ds->params);
+    for (int i = 0; i < ref->n_contigs; ++i) {
+        ds->names.emplace_back(ref->names[i]);
+        ds->lengths.push_back(ref->lengths[i]);
+        if (ref->seqs && ref->seqs[i]) { ds->seqs.emplace_back(ref->seqs[i], (size_t)ref->seq_lens[i]); ds->has_seq.push_back(1); }
+        else { ds->seqs.emplace_back(); ds->has_seq.push_back(0); }
+    }
+    ds->sel.assign(ds->names.size(), 1);
+    ds->bed_beg.assign(ds->names.size(), 0);
+    ds->bed_end.assign(ds->names.size(), INT64_MAX);
+    *out = ds;
+    return MSNV_OK;
+}
+
+extern "C" int msnv_dataset_create_from_files(msnv_ctx *ctx, const char *bam_path, const char *fasta_path,
+                                              const msnv_params *params, msnv_dataset **out) {
+    clear_error();
+    if (!ctx || !bam_path || !out) return fail(MSNV_EINVAL, "msnv_dataset_create_from_files: NULL argument");
+    BamHeader h;
+    if (int rc = bam_read_header(bam_path, h)) return rc;
+    std::vector<FastaSeq> fa;
+    if (fasta_path) if (int rc = fasta_read(fasta_path, fa)) return rc;
+    std::vector<const char *> names, seqs;
+    std::vector<int64_t> lens, slens;
+    for (size_t i = 0; i < h.names.size(); ++i) {
+        names.push_back(h.names[i].c_str());
+        lens.push_back(h.lengths[i]);
+        const FastaSeq *hit = nullptr;
+        for (const FastaSeq &f : fa) if (f.name == h.names[i]) { hit = &f; break; }
+        seqs.push_back(hit ? hit->seq.data() : nullptr);
+        slens.push_back(hit ? (int64_t)hit->seq.size() : 0);
+    }
+    msnv_ref_desc rd{(int32_t)names.size(), names.data(), lens.data(), seqs.data(), slens.data()};
+    return msnv_dataset_create(ctx, &rd, params, out);
+}
+
+extern "C" void msnv_dataset_destroy(msnv_dataset *ds) {
+    if (!ds) return;
+    if (ds->dev) { dev_free_all(*ds->dev); delete ds->dev; }
+    delete ds;
+}
+
+extern "C" int msnv_dataset_set_bed(msnv_dataset *ds, int32_t n, const int32_t *tid, const int64_t *beg, const int64_t *end) {
+    clear_error();
+    if (!ds || (n && (!tid || !beg || !end))) return fail(MSNV_EINVAL, "msnv_dataset_set_bed: NULL argument");
+    if (!ds->samples.empty()) return fail(MSNV_EINVAL, "msnv_dataset_set_bed must precede the first sample");
+    const size_t NC = ds->names.size();
+    std::vector<uint8_t> seen(NC, 0);
+    for (int i = 0; i < n; ++i) {
+        if (tid[i] < 0 || (size_t)tid[i] >= NC) return fail(MSNV_EINVAL, "BED region %d names contig %d which does not exist", i, tid[i]);
+        if (seen[(size_t)tid[i]]) return fail(MSNV_EDOMAIN, "more than one BED region on contig %s (metaSNV writes one: metaSNV.py:92)", ds->names[(size_t)tid[i]].c_str());
+        seen[(size_t)tid[i]] = 1;
+        ds->bed_beg[(size_t)tid[i]] = beg[i]; ds->bed_end[(size_t)tid[i]] = end[i];
+    }
+    // contigs absent from the BED produce no pileup lines at all
+    for (size_t c = 0; c < NC; ++c) if (!seen[c]) { ds->bed_beg[c] = 0; ds->bed_end[c] = 0; ds->sel[c] = 0; }
+    ds->has_bed = true;
+    return MSNV_OK;
+}
+
+extern "C" int msnv_dataset_set_bed_file(msnv_dataset *ds, const char *bed_path) {
+    clear_error();
+    if (!ds || !bed_path) return fail(MSNV_EINVAL, "msnv_dataset_set_bed_file: NULL argument");
+    std::vector<BedRegion> regs;
+    if (int rc = bed_read(bed_path, regs)) return rc;
+    std::vector<int32_t> tid; std::vector<int64_t> b, e;
+    for (const BedRegion &r : regs) {
+        int t = -1;
+        for (size_t c = 0; c < ds->names.size(); ++c) if (ds->names[c] == r.name) { t = (int)c; break; }
+        if (t < 0) continue;     // samtools ignores BED names that are not in the header
+        tid.push_back(t); b.push_back(r.beg); e.push_back(r.end);
+    }
+    return msnv_dataset_set_bed(ds, (int32_t)tid.size(), tid.data(), b.data(), e.data());
+}
+
+extern "C" int msnv_dataset_set_contig_mask(msnv_dataset *ds, const uint8_t *mask, int32_t n) {
+    clear_error();
+    if (!ds || !mask) return fail(MSNV_EINVAL, "msnv_dataset_set_contig_mask: NULL argument");
+    if (!ds->samples.empty()) return fail(MSNV_EINVAL, "msnv_dataset_set_contig_mask must precede the first sample");
+    if ((size_t)n != ds->names.size()) return fail(MSNV_EINVAL, "contig mask has %d entries, header has %zu contigs", n, ds->names.size());
+    for (int i = 0; i < n; ++i) if (!mask[i]) ds->sel[(size_t)i] = 0;
+    return MSNV_OK;
+}
+
+extern "C" int msnv_dataset_add_sample_records(msnv_dataset *ds, const uint8_t *records, uint64_t n_bytes) {
+    clear_error();
+    if (!ds || (n_bytes && !records)) return fail(MSNV_EINVAL, "msnv_dataset_add_sample_records: NULL argument");
+    if (ds->finalized) return fail(MSNV_EINVAL, "dataset is already finalized");
+    ds->samples.emplace_back();
+    int rc = pack_sample(*ds, records, n_bytes, ds->samples.back());
+    if (rc) ds->samples.pop_back();
+    return rc;
+}
+
+static int check_header(const msnv_dataset &ds, const BamHeader &h, const char *path) {
+    // metaSNV assumes every BAM shares the header of the first (metaSNV.py:82-83)
+    if (h.names.size() != ds.names.size()) return fail(MSNV_EFORMAT, "%s: header has %zu contigs, expected %zu", path, h.names.size(), ds.names.size());
+    for (size_t i = 0; i < h.names.size(); ++i)
+        if (h.names[i] != ds.names[i] || h.lengths[i] != ds.lengths[i]) return fail(MSNV_EFORMAT, "%s: contig %zu differs from the first BAM's header", path, i);
+    return MSNV_OK;
+}
+
+extern "C" int msnv_dataset_add_sample_bam(msnv_dataset *ds, const char *bam_path) {
+    clear_error();
+    if (!ds || !bam_path) return fail(MSNV_EINVAL, "msnv_dataset_add_sample_bam: NULL argument");
+    BamHeader h; std::vector<uint8_t> rec;
+    if (int rc = bam_read(bam_path, h, rec, 4)) return rc;
+    if (int rc = check_header(*ds, h, bam_path)) return rc;
+    return msnv_dataset_add_sample_records(ds, rec.data(), rec.size());
+}
+
+extern "C" int msnv_dataset_add_sample_bams(msnv_dataset *ds, const char *const *bam_paths, int32_t n, int32_t host_threads) {
+    clear_error();
+    if (!ds || (n && !bam_paths)) return fail(MSNV_EINVAL, "msnv_dataset_add_sample_bams: NULL argument");
+    if (ds->finalized) return fail(MSNV_EINVAL, "dataset is already finalized");
+    int nthreads = host_threads > 0 ? host_threads : (int)std::max(1u, std::thread::hardware_concurrency());
+    nthreads = std::min(nthreads, std::max(1, (int)n));
+    const size_t first = ds->samples.size();
+    ds->samples.resize(first + (size_t)n);
+    std::atomic<int> next{0}, err{0};
+    std::vector<std::string> msgs((size_t)n);
+    auto worker = [&]() {
+        for (;;) {
+            int i = next.fetch_add(1);
+            if (i >= n || err.load()) break;
+            BamHeader h; std::vector<uint8_t> rec;
+            int rc = bam_read(bam_paths[i], h, rec, 1);
+            if (!rc) rc = check_header(*ds, h, bam_paths[i]);
+            if (!rc) rc = pack_sample(*ds, rec.data(), rec.size(), ds->samples[first + (size_t)i]);
+            if (rc) { msgs[(size_t)i] = msnv_last_error(); err.store(rc); }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t) th.emplace_back(worker);
+    for (auto &t : th) t.join();
+    if (err.load()) {
+        ds->samples.resize(first);
+        for (const std::string &m : msgs) if (!m.empty()) return fail(err.load(), "%s", m.c_str());
+        return fail(err.load(), "BAM decode failed");
+    }
+    return MSNV_OK;
+}
+
+extern "C" int msnv_dataset_add_synth_samples(msnv_dataset *ds, const msnv_synth_params *p, int32_t first, int32_t count, int32_t host_threads) {
+    clear_error();
+    if (!ds || !p || count < 0) return fail(MSNV_EINVAL, "msnv_dataset_add_synth_samples: bad argument");
+    if (ds->finalized) return fail(MSNV_EINVAL, "dataset is already finalized");
+    if ((size_t)p->n_species != ds->names.size()) return fail(MSNV_EINVAL, "synthetic parameters describe %d contigs, dataset has %zu", p->n_species, ds->names.size());
+    int nthreads = host_threads > 0 ? host_threads : (int)std::max(1u, std::thread::hardware_concurrency());
+    nthreads = std::min(nthreads, std::max(1, (int)count));
+    const std::vector<std::string> contigs = synth_contigs(*p);
+    const size_t base = ds->samples.size();
+    ds->samples.resize(base + (size_t)count);
+    std::atomic<int> next{0}, err{0};
+    std::string msg;
+    auto worker = [&]() {
+        std::vector<uint8_t> rec;
+        for (;;) {
+            int i = next.fetch_add(1);
+            if (i >= count || err.load()) break;
+            synth_sample_records(*p, first + i, contigs, rec);
+            int rc = pack_sample(*ds, rec.data(), rec.size(), ds->samples[base + (size_t)i]);
+            if (rc) { err.store(rc); }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t) th.emplace_back(worker);
+    for (auto &t : th) t.join();
+    if (err.load()) { ds->samples.resize(base); return fail(err.load(), "packing a synthetic sample failed"); }
+    return MSNV_OK;
+}
+
+extern "C" int msnv_dataset_finalize(msnv_dataset *ds) {
+    clear_error();
+    if (!ds) return fail(MSNV_EINVAL, "msnv_dataset_finalize: NULL dataset");
+    if (ds->finalized) return fail(MSNV_EINVAL, "dataset is already finalized");
+    if (int rc = dev_set_device(ds->ctx->device)) return rc;
+    return finalize_dataset(*ds);
+}
+
+extern "C" int msnv_dataset_info_get(const msnv_dataset *ds, msnv_dataset_info *out) {
+    clear_error();
+    if (!ds || !out) return fail(MSNV_EINVAL, "msnv_dataset_info_get: NULL argument");
+    *out = ds->info;
+    return MSNV_OK;
+}
+
+// ------------------------------------------------------------------------------ pipeline
+static void gpos_to_contig(const msnv_dataset &ds, uint32_t gpos, int32_t &tid, int32_t &pos) {
+    const uint32_t tile = gpos / TILE;
+    tid = (int32_t)ds.tile_contig[tile];
+    pos = (int32_t)(gpos - ds.tile_base[(size_t)tid] * TILE);
+}
+
+extern "C" int msnv_pileup_run(msnv_dataset *ds, msnv_run_stats *stats) {
+    clear_error();
+    if (!ds || !ds->finalized) return fail(MSNV_EINVAL, "msnv_pileup_run: dataset is not finalized");
+    if (int rc = dev_set_device(ds->ctx->device)) return rc;
+    DeviceCols &d = *ds->dev;
+    msnv_run_stats st{};
+    RunCounts c{};
+    int rc = dev_run_pipeline(d, ds->params, ds->ctx->stream, &st, &c);
+    for (int attempt = 0; rc == MSNV_ECAPACITY && attempt < 2; ++attempt) {
+        // grow the sparse buffers to what the failed pass asked for and run again
+        auto grow = [&](void **p, uint32_t &cap, uint32_t need, size_t elem) -> int {
+            if (need <= cap) return MSNV_OK;
+            dev_free(*p); *p = nullptr;
+            cap = (uint32_t)std::min<uint64_t>(0x7fffffffull, (uint64_t)need + need / 4 + 1024);
+            return dev_alloc(p, (uint64_t)cap * elem, &d.device_bytes);
+        };
+        if (int r2 = grow((void **)&d.events, d.cap_events, c.n_events, sizeof(Pair32))) return r2;
+        if (int r2 = grow((void **)&d.overflow, d.cap_overflow, c.n_overflow, sizeof(Pair32))) return r2;
+        if (int r2 = grow((void **)&d.sites, d.cap_sites, c.n_sites, sizeof(SiteRec))) return r2;
+        clear_error();
+        rc = dev_run_pipeline(d, ds->params, ds->ctx->stream, &st, &c);
+    }
+    if (rc) return rc;
+
+    // ---- map the device records back to (contig, position) in output order
+    const uint32_t n = c.n_sites;
+    std::vector<SiteRec> sites(n);
+    std::vector<uint8_t> flags(n);
+    std::vector<uint32_t> tbase(ds->n_tiles + 1), tcnt(ds->n_tiles + 1);
+    if (int r2 = dev_download(sites.data(), d.sites, (uint64_t)n * sizeof(SiteRec))) return r2;
+    if (int r2 = dev_download(flags.data(), d.site_flags, n)) return r2;
+    if (int r2 = dev_download(tbase.data(), d.tile_site_base, (uint64_t)ds->n_tiles * 4)) return r2;
+    if (int r2 = dev_download(tcnt.data(), d.tile_site_cnt, (uint64_t)ds->n_tiles * 4)) return r2;
+    std::vector<msnv_site_sample> raw((size_t)n * d.n_samples);
+    if (int r2 = dev_download(raw.data(), d.out, raw.size() * sizeof(msnv_site_sample))) return r2;
+
+    ds->sites.clear(); ds->site_samples.clear();
+    ds->sites.reserve(n);
+    uint64_t n_pop = 0, n_ind = 0;
+    for (uint32_t t = 0; t < ds->n_tiles; ++t) {
+        for (uint32_t j = 0; j < tcnt[t]; ++j) {
+            const uint32_t i = tbase[t] + j;
+            if (!flags[i]) continue;               // passed the gates but neither rule fired
+            msnv_site s{};
+            gpos_to_contig(*ds, sites[i].gpos, s.tid, s.pos);
+            s.cov = sites[i].cov;
+            for (int x = 0; x < 4; ++x) s.n[x] = sites[i].n[x];
+            s.pop_mask = flags[i] & 15; s.ind_mask = flags[i] >> 4;
+            const std::string &seq = ds->seqs[(size_t)s.tid];
+            s.refchar = (uint8_t)((ds->has_seq[(size_t)s.tid] && (size_t)s.pos < seq.size()) ? seq[(size_t)s.pos] : 'N');
+            s.dropped = (ds->params.drop_first_line && s.tid == ds->first_tid && s.pos == ds->first_pos) ? 1 : 0;
+            if (s.pop_mask) ++n_pop;
+            if (s.ind_mask) ++n_ind;
+            ds->sites.push_back(s);
+            ds->site_samples.insert(ds->site_samples.end(), raw.begin() + (size_t)i * d.n_samples, raw.begin() + (size_t)(i + 1) * d.n_samples);
+        }
+    }
+    ds->have_results = true;
+    st.n_called_pop = n_pop; st.n_called_indiv = n_ind;
+    if (stats) *stats = st;
+    return MSNV_OK;
+}
+
+extern "C" int msnv_results_count(const msnv_dataset *ds, uint64_t *n_sites) {
+    clear_error();
+    if (!ds || !n_sites) return fail(MSNV_EINVAL, "msnv_results_count: NULL argument");
+    if (!ds->have_results) return fail(MSNV_EINVAL, "no results: call msnv_pileup_run first");
+    *n_sites = ds->sites.size();
+    return MSNV_OK;
+}
+
+extern "C" int msnv_results_fetch(msnv_dataset *ds, msnv_site *sites, msnv_site_sample *samples, uint64_t capacity) {
+    clear_error();
+    if (!ds || !sites || !samples) return fail(MSNV_EINVAL, "msnv_results_fetch: NULL argument");
+    if (!ds->have_results) return fail(MSNV_EINVAL, "no results: call msnv_pileup_run first");
+    if (capacity < ds->sites.size()) return fail(MSNV_ECAPACITY, "capacity %llu < %zu sites", (unsigned long long)capacity, ds->sites.size());
+    memcpy(sites, ds->sites.data(), ds->sites.size() * sizeof(msnv_site));
+    memcpy(samples, ds->site_samples.data(), ds->site_samples.size() * sizeof(msnv_site_sample));
+    return MSNV_OK;
+}
+
+extern "C" int msnv_write_calls(msnv_dataset *ds, const char *called_path, const char *indiv_path,
+                                const char *ann_path, const char *fasta_path) {
+    clear_error();
+    if (!ds || !called_path) return fail(MSNV_EINVAL, "msnv_write_calls: NULL argument");
+    if (!ds->have_results) return fail(MSNV_EINVAL, "no results: call msnv_pileup_run first");
+    return write_calls_text(*ds, called_path, indiv_path, ann_path, fasta_path);
+}
+
+extern "C" int msnv_coverage_run(msnv_dataset *ds, msnv_run_stats *stats) {
+    clear_error();
+    if (!ds || !ds->finalized) return fail(MSNV_EINVAL, "msnv_coverage_run: dataset is not finalized");
+    if (int rc = dev_set_device(ds->ctx->device)) return rc;
+    return coverage_run(*ds, stats);
+}
+
+extern "C" int msnv_write_coverage(msnv_dataset *ds, int32_t sample_idx, const char *cov_path, const char *detail_path) {
+    clear_error();
+    if (!ds || !cov_path || !detail_path) return fail(MSNV_EINVAL, "msnv_write_coverage: NULL argument");
+    return coverage_write(*ds, sample_idx, cov_path, detail_path);
+}
+
+// ------------------------------------------------------------------------------ one-call forms
+extern "C" int msnv_call(msnv_ctx *ctx, const msnv_call_args *a) {
+    clear_error();
+    if (!ctx || !a || !a->bam_paths || a->n_bams <= 0 || !a->out_called_path)
+        return fail(MSNV_EINVAL, "msnv_call: bam_paths / out_called_path are required");
+    msnv_dataset *ds = nullptr;
+    int rc = msnv_dataset_create_from_files(ctx, a->bam_paths[0], a->ref_fasta, &a->params, &ds);
+    if (rc) return rc;
+    if (!rc && a->bed_split_path) rc = msnv_dataset_set_bed_file(ds, a->bed_split_path);
+    if (!rc && a->contig_rank_mask) rc = msnv_dataset_set_contig_mask(ds, a->contig_rank_mask, a->n_contig_rank_mask);
+    if (!rc) rc = msnv_dataset_add_sample_bams(ds, a->bam_paths, a->n_bams, a->host_threads);
+    if (!rc) rc = msnv_dataset_finalize(ds);
+    if (!rc) rc = msnv_pileup_run(ds, nullptr);
+    if (!rc) rc = msnv_write_calls(ds, a->out_called_path, a->out_indiv_path, a->ann_path, a->ref_fasta);
+    msnv_dataset_destroy(ds);
+    return rc;
+}
+
+extern "C" int msnv_coverage(msnv_ctx *ctx, const msnv_cov_args *a) {
+    clear_error();
+    if (!ctx || !a || !a->bam_path || !a->out_cov_path || !a->out_detail_path) return fail(MSNV_EINVAL, "msnv_coverage: NULL argument");
+    msnv_params p;
+    msnv_params_default(&p);
+    p.cov_max = a->max_cov > 0 ? a->max_cov : 10;
+    p.cov_min_mapq = a->min_mapq;
+    msnv_dataset *ds = nullptr;
+    int rc = msnv_dataset_create_from_files(ctx, a->bam_path, nullptr, &p, &ds);
+    if (rc) return rc;
+    rc = msnv_dataset_add_sample_bam(ds, a->bam_path);
+    if (!rc) rc = msnv_dataset_finalize(ds);
+    if (!rc) rc = msnv_coverage_run(ds, nullptr);
+    if (!rc) rc = msnv_write_coverage(ds, 0, a->out_cov_path, a->out_detail_path);
+    msnv_dataset_destroy(ds);
+    return rc;
+}

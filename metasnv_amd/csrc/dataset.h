@@ -1,0 +1,87 @@
+// metasnv_amd/csrc/dataset.h -- packed per-read columns ("read table") and their HBM layout.
+//
+// Coordinate system.  The contigs of a shard are laid side by side in one linear "gpos"
+// space; every contig starts on a TILE boundary and owns ceil(max(L, furthest read end)/TILE)
+// tiles, so a tile never straddles two contigs and a read never leaves its contig's tiles.
+// gpos = tile_base[contig] * TILE + pos.   All device kernels work in gpos; the host maps
+// results back to (contig, pos).
+//
+// Per sample, in BAM (coordinate) order, concatenated over samples:
+//   hdr[]   16 B  {gpos, seqoff, cig, meta}       one per stored read
+//   cig[]    4 B  BAM-encoded ops                  only for reads with n_cigar != 1
+//   seq[]   4 bit nt16 codes, LOW nibble first     (host swaps BAM's high-nibble-first order)
+//   qual[]   1 B  phred                            qual offset = 2 * seqoff
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "msnv_internal.h"
+
+namespace msnv {
+
+constexpr uint32_t TILE = 2048;          // reference positions per tile (LDS bins per workgroup)
+
+// meta: bits 0-15 n_cigar | 16-23 mapq | 24 pileup_ok | 25 cov_ok
+constexpr uint32_t META_PILEUP_OK = 1u << 24;
+constexpr uint32_t META_COV_OK    = 1u << 25;
+
+struct ReadHdr { uint32_t gpos, seqoff, cig, meta; };
+
+struct TilePair { uint32_t sample, read_lo, read_hi, n_reads_ok; };   // reads of `sample` that may overlap the tile
+struct WorkItem { uint32_t tile, pair_lo, pair_hi, pad; };
+
+struct SiteRec { uint32_t gpos, cov, n[4]; };                          // gate kernel output (24 B)
+
+// host staging of one sample
+struct SampleCols {
+    std::vector<ReadHdr>  hdr;
+    std::vector<int32_t>  tid;       // per read
+    std::vector<int32_t>  end;       // per read: contig-relative end of everything the kernels may touch
+    std::vector<uint32_t> cig;
+    std::vector<uint8_t>  seq, qual;
+    uint64_t n_pileup_bases = 0, n_pileup_reads = 0;
+    int32_t  first_tid = -1, first_beg = 0, first_end = 0;   // first pileup_ok read (first-line quirk)
+    // qaCompute "Other" statistics (qaCompute.cpp:642-654)
+    uint32_t total_reads = 0, unmapped = 0, zero_quality = 0, proper_pairs = 0, duplicates = 0;
+    bool     any_mapped = false;
+};
+
+struct DeviceCols;   // kernels.hip
+
+}  // namespace msnv
+
+struct msnv_ctx {
+    int device = 0;
+    void *stream = nullptr;   // hipStream_t
+};
+
+struct msnv_dataset {
+    msnv_ctx *ctx = nullptr;
+    msnv_params params{};
+    // reference
+    std::vector<std::string> names;
+    std::vector<int64_t>     lengths;
+    std::vector<std::string> seqs;         // FASTA characters; empty + !has_seq = contig absent
+    std::vector<uint8_t>     has_seq;
+    // shard selection
+    std::vector<uint8_t>     sel;          // per contig
+    std::vector<int64_t>     bed_beg, bed_end;   // per contig valid range (no BED: [0, INT64_MAX))
+    bool has_bed = false;
+    // samples
+    std::vector<msnv::SampleCols> samples;
+    bool finalized = false;
+    // layout
+    std::vector<uint32_t> tile_base;       // per contig (selected only; others = UINT32_MAX)
+    std::vector<uint32_t> tile_contig;     // per tile
+    uint32_t n_tiles = 0;
+    // first pileup line of the invocation (call_vC.cpp:423)
+    int32_t first_tid = -1; int64_t first_pos = -1;
+    msnv_dataset_info info{};
+    msnv::DeviceCols *dev = nullptr;
+    // results of the last run (host copies)
+    bool have_results = false;
+    std::vector<msnv_site> sites;
+    std::vector<msnv_site_sample> site_samples;
+};

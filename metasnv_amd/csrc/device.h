@@ -1,0 +1,59 @@
+// metasnv_amd/csrc/device.h -- HBM-resident state of one dataset and the kernel pipeline entry.
+#pragma once
+
+#include <cstdint>
+
+#include "dataset.h"
+
+namespace msnv {
+
+struct Pair32 { uint32_t x, y; };
+
+struct DeviceCols {
+    // ---- inputs (uploaded once by finalize)
+    ReadHdr  *hdr = nullptr;
+    uint32_t *cig = nullptr;
+    uint8_t  *seq = nullptr;
+    uint8_t  *qual = nullptr;
+    uint64_t *s_read_base = nullptr, *s_cig_base = nullptr, *s_seq_base = nullptr;   // per sample
+    uint32_t *ref4 = nullptr;        // nt16 codes, 8 positions per word, low nibble = lowest position
+    uint32_t *ref_lc = nullptr;      // 1 bit per position: FASTA char is a lower-case a/c/g/t
+    TilePair *pairs = nullptr;
+    uint32_t *tile_pair_start = nullptr;   // n_tiles + 1
+    WorkItem *work = nullptr;
+    uint32_t *tile_vbeg = nullptr, *tile_vend = nullptr;   // callable range inside each tile (BED / contig)
+    uint32_t  n_tiles = 0, n_pairs = 0, n_work = 0, n_samples = 0;
+    uint64_t  n_reads = 0, n_cig = 0, n_seq_bytes = 0;
+    // ---- intermediates
+    uint32_t *tot = nullptr;         // [5][n_tiles*TILE]: cov, A, C, G, T summed over samples
+    uint8_t  *spill = nullptr;       // [n_pairs][TILE] per-sample coverage, saturating at 255
+    Pair32   *events = nullptr;      // {gpos, sample<<18 | allele<<16 | count}
+    Pair32   *overflow = nullptr;    // {gpos, sample<<16 | cov}
+    uint32_t *counters = nullptr;    // [0] events [1] overflow [2] sites [3] error flags
+    uint32_t  cap_events = 0, cap_overflow = 0, cap_sites = 0;
+    SiteRec  *sites = nullptr;
+    uint32_t *tile_site_base = nullptr, *tile_site_cnt = nullptr;
+    msnv_site_sample *out = nullptr; // [cap_out_sites][n_samples]
+    uint8_t  *site_flags = nullptr;  // pop_mask | ind_mask << 4
+    uint64_t  cap_out_sites = 0;
+    uint64_t  device_bytes = 0;
+    uint64_t  algorithmic_bytes = 0;
+};
+
+// host copies of the counters after a run
+struct RunCounts { uint32_t n_events, n_overflow, n_sites, err; };
+
+int  dev_set_device(int device);
+int  dev_alloc(void **p, uint64_t bytes, uint64_t *acct);
+void dev_free(void *p);
+int  dev_upload(void *dst, const void *src, uint64_t bytes);
+int  dev_download(void *dst, const void *src, uint64_t bytes);
+int  dev_memset(void *dst, int v, uint64_t bytes);
+int  dev_stream_create(void **stream);
+void dev_stream_destroy(void *stream);
+
+// One pass of the pipeline (pileup -> gate -> gather -> decide) on `stream`.
+int  dev_run_pipeline(DeviceCols &d, const msnv_params &p, void *stream, msnv_run_stats *stats, RunCounts *counts);
+void dev_free_all(DeviceCols &d);
+
+}  // namespace msnv

@@ -1,0 +1,393 @@
+// metasnv_amd/csrc/hostio.cpp -- host-side file formats of the pileup path.
+//
+// The reference decodes BAM through htslib (qaCompute.cpp:26-27,276,367,441) and lets
+// samtools read BAM/FASTA/BED (metaSNV.py:160-165).  htslib is not available in the build
+// image, so this is a minimal BGZF/BAM reader+writer on zlib
+// written from the SAM/BAM specification (SAMv1 section 4), plus FASTA and 3-column BED.
+#include "msnv_internal.h"
+
+#include <zlib.h>
+
+#include <atomic>
+#include <cstdarg>
+#include <cstring>
+#include <thread>
+
+namespace msnv {
+
+// ------------------------------------------------------------------------------ error state
+static thread_local char t_err[1024];
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(t_err, sizeof t_err, fmt, ap);
+    va_end(ap);
+    fprintf(stderr, "libmsnv: %s\n", t_err);
+    return code;
+}
+void clear_error() { t_err[0] = 0; }
+
+}  // namespace msnv
+
+extern "C" const char *msnv_last_error(void) { return msnv::t_err; }
+
+namespace msnv {
+
+static int read_file(const char *path, std::vector<uint8_t> &buf) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(MSNV_EIO, "cannot open %s", path);
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    if (n < 0) { fclose(f); return fail(MSNV_EIO, "cannot stat %s", path); }
+    buf.resize((size_t)n);
+    if (n && fread(buf.data(), 1, (size_t)n, f) != (size_t)n) { fclose(f); return fail(MSNV_EIO, "short read on %s", path); }
+    fclose(f);
+    return MSNV_OK;
+}
+
+// ------------------------------------------------------------------------------ BGZF
+// A BGZF block is a gzip member with an extra field "BC" holding BSIZE-1 (SAMv1 4.1).
+struct BlockRef { uint64_t in_off; uint32_t in_size; uint32_t out_size; uint64_t out_off; };
+
+static int bgzf_index(const std::vector<uint8_t> &in, const char *path, std::vector<BlockRef> &blocks, uint64_t &total_out) {
+    uint64_t off = 0;
+    total_out = 0;
+    while (off < in.size()) {
+        if (in.size() - off < 18) return fail(MSNV_EFORMAT, "%s: truncated BGZF block header", path);
+        const uint8_t *p = in.data() + off;
+        if (p[0] != 31 || p[1] != 139 || p[2] != 8 || !(p[3] & 4)) return fail(MSNV_EFORMAT, "%s: not a BGZF file", path);
+        uint32_t xlen = p[10] | p[11] << 8;
+        uint32_t bsize = 0;
+        bool found = false;
+        uint32_t x = 0;
+        while (x + 4 <= xlen) {
+            const uint8_t *e = p + 12 + x;
+            uint32_t slen = e[2] | e[3] << 8;
+            if (e[0] == 'B' && e[1] == 'C' && slen == 2) { bsize = (e[4] | e[5] << 8) + 1u; found = true; }
+            x += 4 + slen;
+        }
+        if (!found || off + bsize > in.size() || bsize < 12 + xlen + 8) return fail(MSNV_EFORMAT, "%s: bad BGZF block", path);
+        uint32_t isize = ld_u32(p + bsize - 4);
+        BlockRef b{off + 12 + xlen, bsize - 12 - xlen - 8, isize, total_out};
+        blocks.push_back(b);
+        total_out += isize;
+        off += bsize;
+    }
+    return MSNV_OK;
+}
+
+static bool inflate_block(const uint8_t *src, uint32_t n_in, uint8_t *dst, uint32_t n_out) {
+    if (n_out == 0) return true;
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) return false;
+    zs.next_in = const_cast<uint8_t *>(src); zs.avail_in = n_in;
+    zs.next_out = dst; zs.avail_out = n_out;
+    int rc = inflate(&zs, Z_FINISH);
+    inflateEnd(&zs);
+    return rc == Z_STREAM_END && zs.avail_out == 0;
+}
+
+int bgzf_read_all(const char *path, std::vector<uint8_t> &out, int threads) {
+    std::vector<uint8_t> in;
+    if (int rc = read_file(path, in)) return rc;
+    std::vector<BlockRef> blocks;
+    uint64_t total = 0;
+    if (int rc = bgzf_index(in, path, blocks, total)) return rc;
+    out.resize(total);
+    std::atomic<size_t> next{0};
+    std::atomic<bool> bad{false};
+    auto worker = [&]() {
+        for (;;) {
+            size_t i = next.fetch_add(16);
+            if (i >= blocks.size()) break;
+            size_t e = std::min(blocks.size(), i + 16);
+            for (; i < e; ++i) {
+                const BlockRef &b = blocks[i];
+                if (!inflate_block(in.data() + b.in_off, b.in_size, out.data() + b.out_off, b.out_size)) bad = true;
+            }
+        }
+    };
+    if (threads <= 1 || blocks.size() < 64) worker();
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < threads; ++t) th.emplace_back(worker);
+        for (auto &t : th) t.join();
+    }
+    if (bad) return fail(MSNV_EFORMAT, "%s: BGZF inflate failed", path);
+    return MSNV_OK;
+}
+
+int bgzf_write_all(const char *path, const uint8_t *data, uint64_t n, int level) {
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(MSNV_EIO, "cannot create %s", path);
+    const uint32_t CHUNK = 0xff00;
+    std::vector<uint8_t> comp(CHUNK + 1024);
+    uint64_t off = 0;
+    bool wrote_eof = false;
+    while (!wrote_eof) {
+        uint32_t m = (uint32_t)std::min<uint64_t>(CHUNK, n - off);
+        if (m == 0) wrote_eof = true;      // the empty block is the BGZF EOF marker
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { fclose(f); return fail(MSNV_ENOMEM, "deflateInit2 failed"); }
+        zs.next_in = const_cast<uint8_t *>(data + off); zs.avail_in = m;
+        zs.next_out = comp.data(); zs.avail_out = (uInt)comp.size();
+        int rc = deflate(&zs, Z_FINISH);
+        uint32_t clen = (uint32_t)(comp.size() - zs.avail_out);
+        deflateEnd(&zs);
+        if (rc != Z_STREAM_END) { fclose(f); return fail(MSNV_EIO, "deflate failed"); }
+        uint32_t bsize = 18 + clen + 8;
+        uint8_t h[18] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, (uint8_t)((bsize - 1) & 0xff), (uint8_t)((bsize - 1) >> 8)};
+        uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), data + off, m);
+        uint8_t t[8] = {(uint8_t)crc, (uint8_t)(crc >> 8), (uint8_t)(crc >> 16), (uint8_t)(crc >> 24), (uint8_t)m, (uint8_t)(m >> 8), (uint8_t)(m >> 16), (uint8_t)(m >> 24)};
+        if (fwrite(h, 1, 18, f) != 18 || fwrite(comp.data(), 1, clen, f) != clen || fwrite(t, 1, 8, f) != 8) { fclose(f); return fail(MSNV_EIO, "write failed on %s", path); }
+        off += m;
+    }
+    fclose(f);
+    return MSNV_OK;
+}
+
+// ------------------------------------------------------------------------------ BAM
+static int bam_parse_header(const std::vector<uint8_t> &u, const char *path, BamHeader &hdr, uint64_t &rec_off) {
+    if (u.size() < 12 || memcmp(u.data(), "BAM\1", 4) != 0) return fail(MSNV_EFORMAT, "%s: not a BAM file", path);
+    uint32_t l_text = ld_u32(u.data() + 4);
+    if (8ull + l_text + 4 > u.size()) return fail(MSNV_EFORMAT, "%s: truncated BAM header", path);
+    hdr.text.assign((const char *)u.data() + 8, l_text);
+    while (!hdr.text.empty() && hdr.text.back() == '\0') hdr.text.pop_back();
+    uint64_t off = 8ull + l_text;
+    uint32_t n_ref = ld_u32(u.data() + off);
+    off += 4;
+    hdr.names.clear(); hdr.lengths.clear();
+    for (uint32_t i = 0; i < n_ref; ++i) {
+        if (off + 4 > u.size()) return fail(MSNV_EFORMAT, "%s: truncated BAM contig table", path);
+        uint32_t l_name = ld_u32(u.data() + off);
+        off += 4;
+        if (off + l_name + 4 > u.size() || l_name == 0) return fail(MSNV_EFORMAT, "%s: truncated BAM contig table", path);
+        hdr.names.emplace_back((const char *)u.data() + off, l_name - 1);
+        off += l_name;
+        hdr.lengths.push_back((int64_t)ld_u32(u.data() + off));
+        off += 4;
+    }
+    rec_off = off;
+    return MSNV_OK;
+}
+
+int bam_read(const char *path, BamHeader &hdr, std::vector<uint8_t> &records, int threads) {
+    std::vector<uint8_t> u;
+    if (int rc = bgzf_read_all(path, u, threads)) return rc;
+    uint64_t off = 0;
+    if (int rc = bam_parse_header(u, path, hdr, off)) return rc;
+    records.assign(u.begin() + (ptrdiff_t)off, u.end());
+    return MSNV_OK;
+}
+
+int bam_read_header(const char *path, BamHeader &hdr) {
+    // headers are small; inflate leading blocks until the contig table is complete
+    std::vector<uint8_t> in;
+    if (int rc = read_file(path, in)) return rc;
+    std::vector<BlockRef> blocks;
+    uint64_t total = 0;
+    if (int rc = bgzf_index(in, path, blocks, total)) return rc;
+    std::vector<uint8_t> u;
+    for (const BlockRef &b : blocks) {
+        size_t old = u.size();
+        u.resize(old + b.out_size);
+        if (!inflate_block(in.data() + b.in_off, b.in_size, u.data() + old, b.out_size)) return fail(MSNV_EFORMAT, "%s: BGZF inflate failed", path);
+        // try to parse
+        if (u.size() >= 12 && memcmp(u.data(), "BAM\1", 4) == 0) {
+            uint32_t l_text = ld_u32(u.data() + 4);
+            uint64_t off = 8ull + l_text;
+            if (off + 4 <= u.size()) {
+                uint32_t n_ref = ld_u32(u.data() + off);
+                off += 4;
+                bool ok = true;
+                for (uint32_t i = 0; i < n_ref && ok; ++i) {
+                    if (off + 4 > u.size()) { ok = false; break; }
+                    uint32_t l_name = ld_u32(u.data() + off);
+                    off += 4ull + l_name + 4;
+                    if (off > u.size()) ok = false;
+                }
+                if (ok) { uint64_t ro; return bam_parse_header(u, path, hdr, ro); }
+            }
+        }
+    }
+    uint64_t ro;
+    return bam_parse_header(u, path, hdr, ro);
+}
+
+int bam_write(const char *path, const BamHeader &hdr, const uint8_t *records, uint64_t n, int level) {
+    std::vector<uint8_t> u;
+    auto put32 = [&](uint32_t v) { for (int i = 0; i < 4; ++i) u.push_back((uint8_t)(v >> (8 * i))); };
+    u.insert(u.end(), {'B', 'A', 'M', 1});
+    put32((uint32_t)hdr.text.size());
+    u.insert(u.end(), hdr.text.begin(), hdr.text.end());
+    put32((uint32_t)hdr.names.size());
+    for (size_t i = 0; i < hdr.names.size(); ++i) {
+        put32((uint32_t)hdr.names[i].size() + 1);
+        u.insert(u.end(), hdr.names[i].begin(), hdr.names[i].end());
+        u.push_back(0);
+        put32((uint32_t)hdr.lengths[i]);
+    }
+    u.insert(u.end(), records, records + n);
+    return bgzf_write_all(path, u.data(), u.size(), level);
+}
+
+bool rec_parse(const uint8_t *p, uint64_t avail, RecView &r) {
+    if (avail < 36) return false;
+    int32_t bs = (int32_t)ld_u32(p);
+    if (bs < 32 || (uint64_t)bs + 4 > avail) return false;
+    r.tid = (int32_t)ld_u32(p + 4);
+    r.pos = (int32_t)ld_u32(p + 8);
+    uint32_t l_name = p[12];
+    r.mapq = p[13];
+    r.n_cigar = (uint16_t)(p[16] | p[17] << 8);
+    r.flag = (uint16_t)(p[18] | p[19] << 8);
+    r.l_seq = (int32_t)ld_u32(p + 20);
+    if (r.l_seq < 0) return false;
+    uint64_t need = 36ull + l_name + 4ull * r.n_cigar + ((uint64_t)r.l_seq + 1) / 2 + (uint64_t)r.l_seq;
+    if (need > (uint64_t)bs + 4) return false;
+    r.cigar = p + 36 + l_name;
+    r.seq = r.cigar + 4ull * r.n_cigar;
+    r.qual = r.seq + ((uint64_t)r.l_seq + 1) / 2;
+    r.size = (uint32_t)bs + 4;
+    return true;
+}
+
+uint8_t nt16_of_char(unsigned char c) {
+    switch (c) {
+        case '=': return 0;
+        case '0': return 1; case '1': return 2; case '2': return 4; case '3': return 8;
+        case 'A': case 'a': return 1;  case 'C': case 'c': return 2;
+        case 'G': case 'g': return 4;  case 'T': case 't': return 8;
+        case 'M': case 'm': return 3;  case 'R': case 'r': return 5;
+        case 'S': case 's': return 6;  case 'V': case 'v': return 7;
+        case 'W': case 'w': return 9;  case 'Y': case 'y': return 10;
+        case 'H': case 'h': return 11; case 'K': case 'k': return 12;
+        case 'D': case 'd': return 13; case 'B': case 'b': return 14;
+        default: return 15;
+    }
+}
+
+// ------------------------------------------------------------------------------ FASTA / BED
+int fasta_read(const char *path, std::vector<FastaSeq> &out) {
+    std::vector<uint8_t> buf;
+    if (int rc = read_file(path, buf)) return rc;
+    out.clear();
+    size_t i = 0, n = buf.size();
+    while (i < n) {
+        size_t e = i;
+        while (e < n && buf[e] != '\n') ++e;
+        size_t le = e;
+        if (le > i && buf[le - 1] == '\r') --le;
+        if (buf[i] == '>') {
+            size_t k = i + 1;
+            while (k < le && !isspace(buf[k])) ++k;
+            out.push_back(FastaSeq{std::string((const char *)buf.data() + i + 1, k - i - 1), std::string()});
+        } else if (!out.empty()) {
+            // faidx keeps every isgraph() character of a sequence line
+            std::string &s = out.back().seq;
+            for (size_t k = i; k < le; ++k) if (isgraph(buf[k])) s.push_back((char)buf[k]);
+        }
+        i = e + 1;
+    }
+    return MSNV_OK;
+}
+
+int bed_read(const char *path, std::vector<BedRegion> &out) {
+    FILE *f = fopen(path, "r");
+    if (!f) return fail(MSNV_EIO, "cannot open %s", path);
+    char line[4096];
+    out.clear();
+    while (fgets(line, sizeof line, f)) {
+        char name[2048];
+        long long b, e;
+        if (line[0] == '#' || line[0] == '\n') continue;
+        if (sscanf(line, "%2047s %lld %lld", name, &b, &e) != 3) { fclose(f); return fail(MSNV_EFORMAT, "%s: expected `name beg end` lines", path); }
+        out.push_back(BedRegion{name, (int64_t)b, (int64_t)e});
+    }
+    fclose(f);
+    return MSNV_OK;
+}
+
+}  // namespace msnv
+
+// ------------------------------------------------------------------------------ C ABI (I/O helpers)
+using namespace msnv;
+
+extern "C" int msnv_bam_write_bed_header(const char *bam_path, const char *out_path) {
+    clear_error();
+    BamHeader h;
+    if (int rc = bam_read_header(bam_path, h)) return rc;
+    FILE *f = fopen(out_path, "w");
+    if (!f) return fail(MSNV_EIO, "cannot create %s", out_path);
+    // metaSNV.py:85-93 keeps only @SQ lines that have exactly three tab-separated fields and
+    // strips "SN:" / "LN:"; it skips the first line of `samtools view -H` unconditionally.
+    size_t i = 0;
+    int lineno = 0;
+    const std::string &t = h.text;
+    while (i < t.size()) {
+        size_t e = t.find('\n', i);
+        if (e == std::string::npos) e = t.size();
+        std::string line = t.substr(i, e - i);
+        i = e + 1;
+        if (lineno++ == 0) continue;
+        while (!line.empty() && isspace((unsigned char)line.back())) line.pop_back();
+        std::vector<std::string> fld;
+        size_t s = 0;
+        for (;;) {
+            size_t tb = line.find('\t', s);
+            fld.push_back(line.substr(s, tb == std::string::npos ? std::string::npos : tb - s));
+            if (tb == std::string::npos) break;
+            s = tb + 1;
+        }
+        if (fld.size() != 3 || fld[0] != "@SQ") continue;
+        auto strip = [](std::string v, const char *tag) { size_t p = v.find(tag); if (p != std::string::npos) v.erase(p, strlen(tag)); return v; };
+        fprintf(f, "%s\t1\t%s\n", strip(fld[1], "SN:").c_str(), strip(fld[2], "LN:").c_str());
+    }
+    fclose(f);
+    return MSNV_OK;
+}
+
+extern "C" int msnv_bam_read(const char *bam_path, msnv_bam_data *out) {
+    clear_error();
+    if (!bam_path || !out) return fail(MSNV_EINVAL, "msnv_bam_read: NULL argument");
+    memset(out, 0, sizeof *out);
+    BamHeader h;
+    std::vector<uint8_t> rec;
+    if (int rc = bam_read(bam_path, h, rec, 1)) return rc;
+    out->n_contigs = (int32_t)h.names.size();
+    out->names = (char **)calloc(h.names.size() + 1, sizeof(char *));
+    out->lengths = (int64_t *)calloc(h.names.size() + 1, sizeof(int64_t));
+    for (size_t i = 0; i < h.names.size(); ++i) { out->names[i] = strdup(h.names[i].c_str()); out->lengths[i] = h.lengths[i]; }
+    out->records = (uint8_t *)malloc(rec.size() + 1);
+    memcpy(out->records, rec.data(), rec.size());
+    out->n_record_bytes = rec.size();
+    out->header_text = strdup(h.text.c_str());
+    return MSNV_OK;
+}
+
+extern "C" void msnv_bam_data_free(msnv_bam_data *d) {
+    if (!d) return;
+    for (int i = 0; i < d->n_contigs; ++i) free(d->names[i]);
+    free(d->names); free(d->lengths); free(d->records); free(d->header_text);
+    memset(d, 0, sizeof *d);
+}
+
+extern "C" int msnv_bam_write(const char *bam_path, const char *header_text, int32_t n_contigs,
+                              const char *const *names, const int64_t *lengths,
+                              const uint8_t *records, uint64_t n_record_bytes, int32_t compress_level) {
+    clear_error();
+    BamHeader h;
+    if (header_text) h.text = header_text;
+    else {
+        h.text = "@HD\tVN:1.6\tSO:coordinate\n";
+        for (int i = 0; i < n_contigs; ++i) h.text += "@SQ\tSN:" + std::string(names[i]) + "\tLN:" + std::to_string(lengths[i]) + "\n";
+    }
+    for (int i = 0; i < n_contigs; ++i) { h.names.push_back(names[i]); h.lengths.push_back(lengths[i]); }
+    return bam_write(bam_path, h, records, n_record_bytes, compress_level < 0 ? 1 : compress_level);
+}
+
+extern "C" void msnv_free(void *p) { free(p); }

@@ -1,0 +1,464 @@
+// metasnv_amd/csrc/kernels.hip -- CDNA4 (gfx950) kernels of the pileup SNV-calling path.
+//
+// What they replace (reference, CPU, text based):
+//   samtools mpileup CIGAR walk + BQ filter  [EXT]            -> msnv_pileup_tiles
+//   snpCall base-string parse + bpCounts      call_vC.cpp:503-535 -> msnv_pileup_tiles
+//   snpCall gates                             call_vC.cpp:545-552 -> msnv_gate_sites
+//   snpCall per-sample strings (counts only)  call_vC.cpp:316-325 -> msnv_gather_cov / msnv_scatter_events
+//   snpCall population / individual rule      call_vC.cpp:577-601 -> msnv_decide_sites
+//
+// Everything is integer counting: the bound is HBM bandwidth, there is no MFMA-shaped work.
+// One workgroup owns one tile of TILE reference positions and keeps that tile's bins in LDS;
+// reads are streamed from HBM with 16-byte loads per lane; only compact results are written.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <vector>
+
+#include "device.h"
+
+namespace msnv {
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(MSNV_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+constexpr int PILEUP_NT = 512;                 // threads per pileup workgroup (8 waves)
+constexpr int PPT = TILE / PILEUP_NT;          // positions owned by each thread in the per-sample pass
+static_assert(PPT == 4, "per-sample pass is written for 4 consecutive positions per thread");
+constexpr int LANES_PER_READ = 8;              // 8 lanes x 16 bases cover a 100-128 bp read in one step
+
+struct PileupArgs {
+    const ReadHdr  *hdr;
+    const uint32_t *cig;
+    const uint8_t  *seq;
+    const uint8_t  *qual;
+    const uint64_t *s_read_base, *s_cig_base, *s_seq_base;
+    const uint32_t *ref4;
+    const TilePair *pairs;
+    const WorkItem *work;
+    uint32_t       *tot;          // [5][npos]
+    uint64_t        npos;
+    uint8_t        *spill;
+    Pair32         *events;   uint32_t cap_events;
+    Pair32         *overflow; uint32_t cap_overflow;
+    uint32_t       *counters;
+    uint32_t        min_baseq;
+};
+
+// allele index (A,C,G,T -> 0..3) of a one-hot nt16 code, 4 for anything else
+__device__ __forceinline__ uint32_t allele_index(uint32_t code) {
+    // 1->0, 2->1, 4->2, 8->3
+    return (code == 1u) ? 0u : (code == 2u) ? 1u : (code == 4u) ? 2u : (code == 8u) ? 3u : 4u;
+}
+
+// ------------------------------------------------------------------------------------------
+// msnv_pileup_tiles: for one work item = (tile, range of (tile,sample) pairs):
+//   for every sample: scatter the sample's reads into LDS bins (match count + 4 allele counts
+//   per position), then one pass over the tile's positions adds the sample to the running
+//   totals (registers), spills the per-sample coverage byte and emits the sparse allele events.
+// Algorithmic HBM bytes: 16 B header + 4 B per extra CIGAR op + 0.5 B/base seq + 1 B/base qual.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PILEUP_NT) void msnv_pileup_tiles(PileupArgs a) {
+    __shared__ uint32_t s_m[TILE / 2];                 // match counts, two u16 per word
+    __shared__ unsigned long long s_al[TILE];          // allele counts, four u16 (A,C,G,T) per position
+    __shared__ uint32_t s_ref[TILE / 8];               // nt16 reference codes of the tile
+
+    const WorkItem w = a.work[blockIdx.x];
+    const uint32_t t0 = w.tile * TILE;
+    const int tid = threadIdx.x;
+    const int lane8 = tid & (LANES_PER_READ - 1);
+
+    for (int i = tid; i < (int)(TILE / 8); i += PILEUP_NT) s_ref[i] = a.ref4[(t0 >> 3) + i];
+    for (int i = tid; i < (int)(TILE / 2); i += PILEUP_NT) s_m[i] = 0;
+    for (int i = tid; i < (int)TILE; i += PILEUP_NT) s_al[i] = 0;
+
+    uint32_t tc[PPT], tn[PPT][4];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) { tc[j] = 0; tn[j][0] = tn[j][1] = tn[j][2] = tn[j][3] = 0; }
+    __syncthreads();
+
+    for (uint32_t k = w.pair_lo; k < w.pair_hi; ++k) {
+        const TilePair pr = a.pairs[k];
+        const ReadHdr *hdr = a.hdr + a.s_read_base[pr.sample];
+        const uint32_t *cigp = a.cig + a.s_cig_base[pr.sample];
+        const uint8_t *seq = a.seq + a.s_seq_base[pr.sample];
+        const uint8_t *qual = a.qual + 2 * a.s_seq_base[pr.sample];
+
+        for (uint32_t r = pr.read_lo + (uint32_t)(tid / LANES_PER_READ); r < pr.read_hi; r += PILEUP_NT / LANES_PER_READ) {
+            const uint4 h = *reinterpret_cast<const uint4 *>(hdr + r);
+            if (!(h.w & META_PILEUP_OK)) continue;
+            const uint32_t ncig = h.w & 0xffffu;
+            uint32_t q = 0;             // query cursor
+            uint32_t rp = h.x;          // reference cursor (gpos)
+            for (uint32_t ci = 0; ci < ncig; ++ci) {
+                const uint32_t op = (ncig == 1) ? h.z : cigp[h.z + ci];
+                const uint32_t len = op >> 4, type = op & 15u;
+                if (type == C_M || type == C_EQ || type == C_X) {
+                    // query [q, q+len) <-> reference [rp, rp+len); clip to the tile
+                    const uint32_t lo = (rp < t0) ? (t0 - rp) : 0u;
+                    const uint32_t hi = (rp + len > t0 + TILE) ? (t0 + TILE - rp) : len;
+                    if (rp < t0 + TILE && rp + len > t0 && lo < hi) {
+                        const uint32_t qs = q + lo, qe = q + hi;
+                        for (uint32_t c = (qs >> 4) + (uint32_t)lane8; c <= ((qe - 1) >> 4); c += LANES_PER_READ) {
+                            const uint8_t *qp = qual + 2ull * h.y + 16ull * c;
+                            const uint8_t *sp = seq + (uint64_t)h.y + 8ull * c;
+                            uint4 qv; uint2 sv;
+                            __builtin_memcpy(&qv, qp, 16);
+                            __builtin_memcpy(&sv, sp, 8);
+                            const uint32_t qw[4] = {qv.x, qv.y, qv.z, qv.w};
+                            const uint32_t sw[2] = {sv.x, sv.y};
+#pragma unroll
+                            for (int j = 0; j < 16; ++j) {
+                                const uint32_t qq = 16u * c + (uint32_t)j;
+                                if (qq < qs || qq >= qe) continue;
+                                const uint32_t bq = (qw[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                                if (bq < a.min_baseq) continue;
+                                const uint32_t code = (sw[j >> 3] >> (4 * (j & 7))) & 0xfu;
+                                const uint32_t p = rp + (qq - q) - t0;               // position inside the tile
+                                const uint32_t rc = (s_ref[p >> 3] >> (4 * (p & 7))) & 0xfu;
+                                if (code == 0u || code == rc) {
+                                    atomicAdd(&s_m[p >> 1], 1u << (16 * (p & 1)));
+                                } else {
+                                    const uint32_t ai = allele_index(code);
+                                    if (ai < 4u) atomicAdd(&s_al[p], 1ull << (16 * ai));
+                                }
+                            }
+                        }
+                    }
+                    q += len; rp += len;
+                } else if (type == C_I || type == C_S) {
+                    q += len;
+                } else if (type == C_D || type == C_N) {
+                    rp += len;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- per-sample pass over the tile: thread owns positions 4*tid .. 4*tid+3
+        {
+            uint2 m = *reinterpret_cast<uint2 *>(&s_m[2 * tid]);
+            unsigned long long al[PPT];
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) al[j] = s_al[PPT * tid + j];
+            *reinterpret_cast<uint2 *>(&s_m[2 * tid]) = make_uint2(0u, 0u);
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) s_al[PPT * tid + j] = 0ull;
+
+            const uint32_t mm[PPT] = {m.x & 0xffffu, m.x >> 16, m.y & 0xffffu, m.y >> 16};
+            uint32_t packed = 0;
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) {
+                const uint32_t n0 = (uint32_t)(al[j] & 0xffffu), n1 = (uint32_t)((al[j] >> 16) & 0xffffu);
+                const uint32_t n2 = (uint32_t)((al[j] >> 32) & 0xffffu), n3 = (uint32_t)(al[j] >> 48);
+                const uint32_t cov = mm[j] + n0 + n1 + n2 + n3;
+                tc[j] += cov; tn[j][0] += n0; tn[j][1] += n1; tn[j][2] += n2; tn[j][3] += n3;
+                packed |= (cov < 255u ? cov : 255u) << (8 * j);
+                const uint32_t gpos = t0 + PPT * tid + j;
+                if (cov >= 255u) {
+                    const uint32_t idx = atomicAdd(&a.counters[1], 1u);
+                    if (idx < a.cap_overflow) a.overflow[idx] = Pair32{gpos, pr.sample << 16 | (cov & 0xffffu)};
+                }
+                if (al[j] != 0ull) {
+                    const uint32_t nn[4] = {n0, n1, n2, n3};
+#pragma unroll
+                    for (int x = 0; x < 4; ++x)
+                        if (nn[x]) {
+                            const uint32_t idx = atomicAdd(&a.counters[0], 1u);
+                            if (idx < a.cap_events) a.events[idx] = Pair32{gpos, pr.sample << 18 | (uint32_t)x << 16 | nn[x]};
+                        }
+                }
+            }
+            *reinterpret_cast<uint32_t *>(a.spill + (uint64_t)k * TILE + PPT * tid) = packed;
+        }
+        __syncthreads();
+    }
+
+    // ---- flush this work item's totals (several work items may share a tile)
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const uint64_t g = (uint64_t)t0 + PPT * tid + j;
+        if (tc[j]) atomicAdd(&a.tot[g], tc[j]);
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+            if (tn[j][x]) atomicAdd(&a.tot[(uint64_t)(1 + x) * a.npos + g], tn[j][x]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// msnv_gate_sites: snpCall's two gates (call_vC.cpp:545-552) plus the necessary condition of
+// both call kinds (some allele total >= calling_threshold).  One workgroup per tile; survivors
+// are written in position order to a contiguous range reserved with one atomic per tile.
+// ------------------------------------------------------------------------------------------
+constexpr int GATE_NT = 256;
+constexpr int GATE_CHUNKS = TILE / GATE_NT;
+
+__global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const uint32_t *tot, uint64_t npos,
+                                                           const uint32_t *tile_vbeg, const uint32_t *tile_vend,
+                                                           int min_cov, int min_snvs,
+                                                           SiteRec *sites, uint32_t cap_sites, uint32_t *counters,
+                                                           uint32_t *tile_site_base, uint32_t *tile_site_cnt) {
+    __shared__ uint32_t s_wave[GATE_CHUNKS][GATE_NT / 64];
+    __shared__ uint32_t s_base;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t t0 = tile * TILE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t vb = tile_vbeg[tile], ve = tile_vend[tile];
+
+    uint32_t flags = 0;
+    uint32_t mypre[GATE_CHUNKS];
+#pragma unroll
+    for (int c = 0; c < GATE_CHUNKS; ++c) {
+        const uint32_t p = (uint32_t)c * GATE_NT + (uint32_t)tid;
+        const uint64_t g = (uint64_t)t0 + p;
+        const uint32_t cov = tot[g];
+        bool ok = false;
+        if (cov != 0u && p >= vb && p < ve && (int)cov >= min_cov) {
+            const uint32_t nA = tot[npos + g], nC = tot[2 * npos + g], nG = tot[3 * npos + g], nT = tot[4 * npos + g];
+            const uint32_t mx = max(max(nA, nC), max(nG, nT));
+            ok = ((int)(nA + nC + nG + nT) >= min_snvs) && ((int)mx >= min_snvs);
+        }
+        const unsigned long long b = __ballot(ok);
+        mypre[c] = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave[c][wave] = (uint32_t)__popcll(b);
+        flags |= (ok ? 1u : 0u) << c;
+    }
+    __syncthreads();
+    // exclusive prefix over (chunk, wave) in chunk-major order
+    uint32_t total = 0, mybase[GATE_CHUNKS];
+#pragma unroll
+    for (int c = 0; c < GATE_CHUNKS; ++c) {
+#pragma unroll
+        for (int wv = 0; wv < GATE_NT / 64; ++wv) {
+            if (wv == wave) mybase[c] = total;
+            total += s_wave[c][wv];
+        }
+    }
+    if (tid == 0) {
+        uint32_t base = total ? atomicAdd(&counters[2], total) : 0u;
+        s_base = base;
+        tile_site_base[tile] = base;
+        tile_site_cnt[tile] = total;
+    }
+    __syncthreads();
+    if (total == 0) return;
+    const uint32_t base = s_base;
+#pragma unroll
+    for (int c = 0; c < GATE_CHUNKS; ++c) {
+        if (flags & (1u << c)) {
+            const uint32_t idx = base + mybase[c] + mypre[c];
+            if (idx < cap_sites) {
+                const uint64_t g = (uint64_t)t0 + (uint32_t)c * GATE_NT + (uint32_t)tid;
+                SiteRec s;
+                s.gpos = (uint32_t)g; s.cov = tot[g];
+                s.n[0] = tot[npos + g]; s.n[1] = tot[2 * npos + g]; s.n[2] = tot[3 * npos + g]; s.n[3] = tot[4 * npos + g];
+                sites[idx] = s;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// msnv_gather_cov: per-sample coverage of every surviving site, from the spilled bytes.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void msnv_gather_cov(const SiteRec *sites, const uint32_t *tile_site_base,
+                                                       const uint32_t *tile_site_cnt, const uint32_t *tile_pair_start,
+                                                       const TilePair *pairs, const uint8_t *spill,
+                                                       msnv_site_sample *out, uint32_t n_samples) {
+    const uint32_t tile = blockIdx.x;
+    const uint32_t n = tile_site_cnt[tile];
+    if (n == 0) return;
+    const uint32_t base = tile_site_base[tile];
+    const uint32_t ps = tile_pair_start[tile], np = tile_pair_start[tile + 1] - ps;
+    const uint32_t t0 = tile * TILE;
+    const uint64_t work = (uint64_t)n * np;
+    for (uint64_t i = threadIdx.x; i < work; i += blockDim.x) {
+        const uint32_t j = (uint32_t)(i / np), kk = (uint32_t)(i % np);
+        const uint32_t off = sites[base + j].gpos - t0;
+        const uint32_t cov = spill[(uint64_t)(ps + kk) * TILE + off];
+        out[(uint64_t)(base + j) * n_samples + pairs[ps + kk].sample].cov = (uint16_t)cov;   // 255 = see overflow list
+    }
+}
+
+__device__ __forceinline__ int find_site(const SiteRec *sites, uint32_t base, uint32_t n, uint32_t gpos) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (sites[base + mid].gpos < gpos) lo = mid + 1; else hi = mid;
+    }
+    return (lo < n && sites[base + lo].gpos == gpos) ? (int)(base + lo) : -1;
+}
+
+// msnv_scatter_events: per-sample allele counts (sparse) and >=255 coverages into the site records.
+__global__ void msnv_scatter_events(const Pair32 *events, uint32_t n_events, const Pair32 *overflow, uint32_t n_overflow,
+                                    const SiteRec *sites, const uint32_t *tile_site_base, const uint32_t *tile_site_cnt,
+                                    msnv_site_sample *out, uint32_t n_samples) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_events) {
+        const Pair32 e = events[i];
+        const uint32_t tile = e.x / TILE;
+        const int s = find_site(sites, tile_site_base[tile], tile_site_cnt[tile], e.x);
+        if (s >= 0) out[(uint64_t)s * n_samples + (e.y >> 18)].n[(e.y >> 16) & 3u] = (uint16_t)(e.y & 0xffffu);
+    } else if (i < n_events + n_overflow) {
+        const Pair32 e = overflow[i - n_events];
+        const uint32_t tile = e.x / TILE;
+        const int s = find_site(sites, tile_site_base[tile], tile_site_cnt[tile], e.x);
+        if (s >= 0) out[(uint64_t)s * n_samples + (e.y >> 16)].cov = (uint16_t)(e.y & 0xffffu);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// msnv_decide_sites: call_vC.cpp:577-601.  One wavefront per site.
+//   skip allele x when the FASTA character equals the lower-case letter x (:580)
+//   population  iff n_x >= t and (double)n_x >= cov * min_fraction          (:588)
+//   individual  iff not population and some sample has x_s >= t              (:593-600)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void msnv_decide_sites(const SiteRec *sites, uint32_t n_sites, const uint32_t *ref4,
+                                                         const uint32_t *ref_lc, const msnv_site_sample *out,
+                                                         uint32_t n_samples, int min_snvs, double min_frac, uint8_t *site_flags) {
+    const uint32_t site = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (site >= n_sites) return;
+    const SiteRec s = sites[site];
+    const uint32_t rc = (ref4[s.gpos >> 3] >> (4 * (s.gpos & 7))) & 0xfu;
+    const bool lc = (ref_lc[s.gpos >> 5] >> (s.gpos & 31)) & 1u;
+    uint32_t pop = 0, ind = 0;
+    for (int x = 0; x < 4; ++x) {
+        if (lc && rc == (1u << x)) continue;
+        const uint32_t nx = s.n[x];
+        if ((int)nx < min_snvs) continue;           // neither rule can fire
+        if ((double)nx >= (double)(int)s.cov * min_frac) { pop |= 1u << x; continue; }
+        bool any = false;
+        for (uint32_t i = lane; i < n_samples; i += 64)
+            any |= (int)out[(uint64_t)site * n_samples + i].n[x] >= min_snvs;
+        if (__any(any)) ind |= 1u << x;
+    }
+    if (lane == 0) site_flags[site] = (uint8_t)(pop | ind << 4);
+}
+
+// ------------------------------------------------------------------------------------------ host side
+int dev_set_device(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(MSNV_ENODEV, "no HIP device is available (this path has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(MSNV_ENODEV, "HIP device %d does not exist (%d visible)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    return MSNV_OK;
+}
+
+int dev_alloc(void **p, uint64_t bytes, uint64_t *acct) {
+    *p = nullptr;
+    if (bytes == 0) bytes = 16;
+    HIP_TRY(hipMalloc(p, bytes));
+    if (acct) *acct += bytes;
+    return MSNV_OK;
+}
+void dev_free(void *p) { if (p) (void)hipFree(p); }
+int dev_upload(void *dst, const void *src, uint64_t bytes) { if (bytes) HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return MSNV_OK; }
+int dev_download(void *dst, const void *src, uint64_t bytes) { if (bytes) HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return MSNV_OK; }
+int dev_memset(void *dst, int v, uint64_t bytes) { if (bytes) HIP_TRY(hipMemset(dst, v, bytes)); return MSNV_OK; }
+int dev_stream_create(void **stream) { hipStream_t s; HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); *stream = s; return MSNV_OK; }
+void dev_stream_destroy(void *stream) { if (stream) (void)hipStreamDestroy((hipStream_t)stream); }
+
+void dev_free_all(DeviceCols &d) {
+    void *ptrs[] = {d.hdr, d.cig, d.seq, d.qual, d.s_read_base, d.s_cig_base, d.s_seq_base, d.ref4, d.ref_lc, d.pairs,
+                    d.tile_pair_start, d.work, d.tile_vbeg, d.tile_vend, d.tot, d.spill, d.events, d.overflow, d.counters,
+                    d.sites, d.tile_site_base, d.tile_site_cnt, d.out, d.site_flags};
+    for (void *p : ptrs) dev_free(p);
+    d = DeviceCols{};
+}
+
+static int ensure_out(DeviceCols &d, uint64_t n_sites) {
+    if (n_sites <= d.cap_out_sites) return MSNV_OK;
+    dev_free(d.out); dev_free(d.site_flags);
+    d.out = nullptr; d.site_flags = nullptr;
+    uint64_t cap = std::max<uint64_t>(n_sites + n_sites / 4, 1024);
+    if (int rc = dev_alloc((void **)&d.out, cap * d.n_samples * sizeof(msnv_site_sample), &d.device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&d.site_flags, cap, &d.device_bytes)) return rc;
+    d.cap_out_sites = cap;
+    return MSNV_OK;
+}
+
+int dev_run_pipeline(DeviceCols &d, const msnv_params &p, void *stream_, msnv_run_stats *stats, RunCounts *counts) {
+    hipStream_t st = (hipStream_t)stream_;
+    const uint64_t npos = (uint64_t)d.n_tiles * TILE;
+    hipEvent_t ev[6];
+    for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
+    auto cleanup = [&]() { for (auto &e : ev) (void)hipEventDestroy(e); };
+
+    HIP_TRY(hipEventRecord(ev[0], st));
+    HIP_TRY(hipMemsetAsync(d.counters, 0, 4 * sizeof(uint32_t), st));
+    if (npos) HIP_TRY(hipMemsetAsync(d.tot, 0, 5 * npos * sizeof(uint32_t), st));
+    HIP_TRY(hipEventRecord(ev[1], st));
+    if (d.n_work) {
+        PileupArgs a;
+        a.hdr = d.hdr; a.cig = d.cig; a.seq = d.seq; a.qual = d.qual;
+        a.s_read_base = d.s_read_base; a.s_cig_base = d.s_cig_base; a.s_seq_base = d.s_seq_base;
+        a.ref4 = d.ref4; a.pairs = d.pairs; a.work = d.work; a.tot = d.tot; a.npos = npos; a.spill = d.spill;
+        a.events = d.events; a.cap_events = d.cap_events; a.overflow = d.overflow; a.cap_overflow = d.cap_overflow;
+        a.counters = d.counters; a.min_baseq = (uint32_t)std::max(0, p.min_baseq);
+        hipLaunchKernelGGL(msnv_pileup_tiles, dim3(d.n_work), dim3(PILEUP_NT), 0, st, a);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(ev[2], st));
+    if (d.n_tiles) {
+        hipLaunchKernelGGL(msnv_gate_sites, dim3(d.n_tiles), dim3(GATE_NT), 0, st, d.tot, npos, d.tile_vbeg, d.tile_vend,
+                           p.min_coverage, p.calling_threshold, d.sites, d.cap_sites, d.counters, d.tile_site_base, d.tile_site_cnt);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(ev[3], st));
+    RunCounts c{};
+    HIP_TRY(hipMemcpyAsync(&c, d.counters, sizeof c, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (c.n_events > d.cap_events || c.n_overflow > d.cap_overflow || c.n_sites > d.cap_sites) {
+        cleanup();
+        if (counts) *counts = c;
+        return fail(MSNV_ECAPACITY, "device buffer too small: events %u/%u overflow %u/%u sites %u/%u",
+                    c.n_events, d.cap_events, c.n_overflow, d.cap_overflow, c.n_sites, d.cap_sites);
+    }
+    if (int rc = ensure_out(d, c.n_sites)) { cleanup(); return rc; }
+    if (c.n_sites) {
+        HIP_TRY(hipMemsetAsync(d.out, 0, (uint64_t)c.n_sites * d.n_samples * sizeof(msnv_site_sample), st));
+        hipLaunchKernelGGL(msnv_gather_cov, dim3(d.n_tiles), dim3(256), 0, st, d.sites, d.tile_site_base, d.tile_site_cnt,
+                           d.tile_pair_start, d.pairs, d.spill, d.out, d.n_samples);
+        HIP_TRY(hipGetLastError());
+        const uint32_t ne = c.n_events + c.n_overflow;
+        if (ne) {
+            hipLaunchKernelGGL(msnv_scatter_events, dim3((ne + 255) / 256), dim3(256), 0, st, d.events, c.n_events, d.overflow,
+                               c.n_overflow, d.sites, d.tile_site_base, d.tile_site_cnt, d.out, d.n_samples);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    HIP_TRY(hipEventRecord(ev[4], st));
+    if (c.n_sites) {
+        hipLaunchKernelGGL(msnv_decide_sites, dim3((c.n_sites + 3) / 4), dim3(256), 0, st, d.sites, c.n_sites, d.ref4, d.ref_lc,
+                           d.out, d.n_samples, p.calling_threshold, p.min_fraction, d.site_flags);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(ev[5], st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (stats) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[5])); stats->ms_total = ms;
+        HIP_TRY(hipEventElapsedTime(&ms, ev[1], ev[2])); stats->ms_pileup = ms;
+        HIP_TRY(hipEventElapsedTime(&ms, ev[2], ev[3])); stats->ms_gate = ms;
+        HIP_TRY(hipEventElapsedTime(&ms, ev[3], ev[4])); stats->ms_gather = ms;
+        HIP_TRY(hipEventElapsedTime(&ms, ev[4], ev[5])); stats->ms_decide = ms;
+        stats->n_sites = c.n_sites; stats->n_events = c.n_events; stats->n_overflow = c.n_overflow;
+        stats->algorithmic_bytes = d.algorithmic_bytes;
+    }
+    if (counts) *counts = c;
+    cleanup();
+    return MSNV_OK;
+}
+
+}  // namespace msnv
+
+extern "C" int msnv_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}

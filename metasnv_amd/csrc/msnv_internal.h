@@ -1,0 +1,61 @@
+// metasnv_amd/csrc/msnv_internal.h -- shared declarations of libmsnv.so (not installed).
+#pragma once
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/msnv.h"
+
+namespace msnv {
+
+// ---------------------------------------------------------------------------------- errors
+int  fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+void clear_error();
+
+// ---------------------------------------------------------------------------------- host IO
+struct BamHeader {
+    std::string              text;
+    std::vector<std::string> names;
+    std::vector<int64_t>     lengths;
+};
+
+// Whole-file BGZF inflate (blocks are independent; `threads` > 1 inflates them in parallel).
+int bgzf_read_all(const char *path, std::vector<uint8_t> &out, int threads);
+int bgzf_write_all(const char *path, const uint8_t *data, uint64_t n, int level);
+
+// BAM = BGZF(magic, header text, contig table, records...)
+int bam_read(const char *path, BamHeader &hdr, std::vector<uint8_t> &records, int threads);
+int bam_read_header(const char *path, BamHeader &hdr);
+int bam_write(const char *path, const BamHeader &hdr, const uint8_t *records, uint64_t n, int level);
+
+// FASTA: name = header line up to the first whitespace (faidx semantics, what `samtools
+// mpileup -f` sees); sequence characters kept verbatim (case preserved).
+struct FastaSeq { std::string name; std::string seq; };
+int fasta_read(const char *path, std::vector<FastaSeq> &out);
+
+// 3-column BED as written by metaSNV.py:92 (`name\t1\tLEN`): 0-based half-open regions.
+struct BedRegion { std::string name; int64_t beg, end; };
+int bed_read(const char *path, std::vector<BedRegion> &out);
+
+// ---------------------------------------------------------------------------------- BAM record view
+constexpr int BAM_FPAIRED = 1, BAM_FPROPER_PAIR = 2, BAM_FUNMAP = 4, BAM_FREVERSE = 16,
+              BAM_FSECONDARY = 256, BAM_FQCFAIL = 512, BAM_FDUP = 1024;
+enum CigarOp : uint32_t { C_M = 0, C_I = 1, C_D = 2, C_N = 3, C_S = 4, C_H = 5, C_P = 6, C_EQ = 7, C_X = 8 };
+
+struct RecView {
+    int32_t  tid, pos, l_seq;
+    uint16_t flag, n_cigar;
+    uint8_t  mapq;
+    const uint8_t *cigar, *seq, *qual;   // unaligned little-endian
+    uint32_t size;                        // bytes consumed including block_size
+};
+// returns false on a malformed record
+bool rec_parse(const uint8_t *p, uint64_t avail, RecView &r);
+inline uint32_t ld_u32(const uint8_t *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
+
+// htslib's seq_nt16_table: FASTA/IUPAC character -> 4-bit code (unknown -> 15)
+uint8_t nt16_of_char(unsigned char c);
+
+}  // namespace msnv

@@ -1,0 +1,327 @@
+// metasnv_amd/csrc/pack.cpp -- host side of the boundary: BAM records -> packed read columns
+// (dataset.h), tile index, upload.  This is the "decoded on the host ... streamed to the device
+// as packed per-read columns" stage of the north star; no pileup arithmetic happens here, only
+// the read-level filters that `samtools mpileup` applies before its pileup engine
+// (bam_plcmd.c mplp_func, restated in SURVEY.md Appendix C) and qaCompute's read filter
+// (qaCompute.cpp:461-526), both reduced to two bits per read.
+#include <algorithm>
+#include <atomic>
+#include <climits>
+#include <cstring>
+#include <queue>
+#include <thread>
+
+#include "device.h"
+
+namespace msnv {
+
+std::vector<std::string> synth_contigs(const msnv_synth_params &p);
+void synth_sample_records(const msnv_synth_params &p, int sample, const std::vector<std::string> &contigs, std::vector<uint8_t> &out);
+
+static inline bool consumes_ref(uint32_t t) { return t == C_M || t == C_D || t == C_N || t == C_EQ || t == C_X; }
+static inline bool consumes_query(uint32_t t) { return t == C_M || t == C_I || t == C_S || t == C_EQ || t == C_X; }
+
+// Packs one sample.  `ds` supplies contig selection, BED and parameters.
+int pack_sample(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, SampleCols &sc) {
+    const msnv_params &P = ds.params;
+    const int n_contigs = (int)ds.names.size();
+    uint64_t off = 0;
+    int32_t last_tid = -1, last_pos = -1;
+    // depth cap (mpileup -d): live pileup reads of this sample, by reference end
+    std::priority_queue<int64_t, std::vector<int64_t>, std::greater<int64_t>> live;
+    int32_t cap_tid = -1, cap_pos = -1; int nth_at_pos = 0; bool first_push_done = false;
+
+    while (off < n_bytes) {
+        RecView r;
+        if (!rec_parse(rec + off, n_bytes - off, r)) return fail(MSNV_EFORMAT, "malformed BAM record at byte %llu", (unsigned long long)off);
+        off += r.size;
+        sc.total_reads++;
+        if (r.flag & BAM_FUNMAP) { sc.unmapped++; continue; }                   // qaCompute.cpp:461
+        if (r.tid < 0) { sc.unmapped++; continue; }                              // qaCompute.cpp:467-473
+        if (r.tid >= n_contigs) return fail(MSNV_EFORMAT, "record refers to contig %d but the header has %d", r.tid, n_contigs);
+        if (r.tid < last_tid || (r.tid == last_tid && r.pos < last_pos)) return fail(MSNV_EFORMAT, "BAM is not coordinate sorted");
+        last_tid = r.tid; last_pos = r.pos;
+        sc.any_mapped = true;
+        // ---- qaCompute read filter (qaCompute.cpp:518-526)
+        bool cov_ok = false;
+        if (r.mapq >= P.cov_min_mapq) {
+            if (r.flag & BAM_FPROPER_PAIR) sc.proper_pairs++;
+            if (r.flag & BAM_FDUP) sc.duplicates++; else cov_ok = true;
+        } else sc.zero_quality++;
+        if (!ds.sel[(size_t)r.tid]) continue;     // not this shard's contig
+
+        // ---- CIGAR geometry
+        int64_t rlen = 0, qlen = 0, m_bases = 0;
+        bool has_ref_op = false;
+        for (int k = 0; k < r.n_cigar; ++k) {
+            uint32_t c = ld_u32(r.cigar + 4 * k), t = c & 15u, l = c >> 4;
+            if (consumes_ref(t)) { rlen += l; has_ref_op = true; }
+            if (consumes_query(t)) qlen += l;
+            if (t == C_M || t == C_EQ || t == C_X) m_bases += l;
+        }
+        const int64_t endpos = r.pos + (rlen ? rlen : 1);                        // bam_endpos
+        // qaCompute's cursor also advances over I/S/H/P (qaCompute.cpp:537-552)
+        int64_t qa_end = (int64_t)r.pos + 1;
+        {
+            int k = 0;
+            if (r.n_cigar > 0) { uint32_t t = ld_u32(r.cigar) & 15u; if (t == C_S || t == C_H) k = 1; }
+            for (; k < r.n_cigar; ++k) qa_end += ld_u32(r.cigar + 4 * k) >> 4;
+        }
+
+        // ---- mpileup read-level filters (bam_plcmd.c mplp_func order)
+        bool pile_ok = !(r.flag & P.flag_filter);
+        if (pile_ok && ds.has_bed) pile_ok = ds.bed_beg[(size_t)r.tid] < endpos && r.pos < ds.bed_end[(size_t)r.tid];
+        if (pile_ok && ds.has_seq[(size_t)r.tid] && (int64_t)ds.seqs[(size_t)r.tid].size() <= r.pos) pile_ok = false;
+        if (pile_ok && r.mapq < P.min_mapq) pile_ok = false;
+        if (pile_ok && !P.count_orphans && (r.flag & BAM_FPAIRED) && !(r.flag & BAM_FPROPER_PAIR)) pile_ok = false;
+        if (pile_ok && !has_ref_op) pile_ok = false;
+        if (pile_ok && r.l_seq > 0 && qlen != r.l_seq)
+            return fail(MSNV_EFORMAT, "CIGAR consumes %lld query bases but the read has %d", (long long)qlen, r.l_seq);
+        if (pile_ok) {
+            // depth cap, sam.c bam_plp_push (sample-local restatement)
+            while (!live.empty() && live.top() <= r.pos) live.pop();
+            if (cap_tid != r.tid) { while (!live.empty()) live.pop(); }
+            if (cap_tid != r.tid || cap_pos != r.pos) { cap_tid = r.tid; cap_pos = r.pos; nth_at_pos = 0; }
+            bool capped = (nth_at_pos > 0 || !first_push_done) && P.max_depth > 0 && (int64_t)live.size() > (int64_t)P.max_depth;
+            first_push_done = true; ++nth_at_pos;
+            if (capped) pile_ok = false; else live.push(endpos);
+        }
+        if (!pile_ok && !cov_ok) continue;
+
+        if (r.n_cigar > 0xffff) return fail(MSNV_EFORMAT, "reads with more than 65535 CIGAR operations are not supported");
+        ReadHdr h;
+        h.gpos = (uint32_t)r.pos;            // contig-relative until finalize
+        h.seqoff = 0;
+        h.meta = (uint32_t)r.n_cigar | (uint32_t)r.mapq << 16 | (pile_ok ? META_PILEUP_OK : 0u) | (cov_ok ? META_COV_OK : 0u);
+        if (r.n_cigar == 1) h.cig = ld_u32(r.cigar);
+        else {
+            h.cig = (uint32_t)sc.cig.size();
+            for (int k = 0; k < r.n_cigar; ++k) sc.cig.push_back(ld_u32(r.cigar + 4 * k));
+        }
+        if (pile_ok) {
+            if (sc.seq.size() > 0xfffffff0ull - (size_t)r.l_seq) return fail(MSNV_EDOMAIN, "one sample holds more than 8.5 G bases in this shard: shard the contigs further");
+            h.seqoff = (uint32_t)sc.seq.size();
+            const int nb = (r.l_seq + 1) / 2;
+            if (r.l_seq == 0) {
+                // SEQ '*': mpileup prints 'N' with quality 0 for every position (never counted)
+                for (int64_t i = 0; i < (qlen + 1) / 2; ++i) sc.seq.push_back(0xff);
+                for (int64_t i = 0; i < ((qlen + 1) / 2) * 2; ++i) sc.qual.push_back(0);
+            } else {
+                for (int i = 0; i < nb; ++i) { uint8_t b = r.seq[i]; sc.seq.push_back((uint8_t)(b >> 4 | b << 4)); }   // low nibble first
+                if (r.l_seq & 1) sc.seq.back() |= 0xf0;        // pad nibble = N
+                sc.qual.insert(sc.qual.end(), r.qual, r.qual + r.l_seq);
+                if (r.l_seq & 1) sc.qual.push_back(0);
+            }
+            sc.n_pileup_bases += (uint64_t)m_bases;
+            sc.n_pileup_reads++;
+            if (sc.first_tid < 0) {
+                // first pileup line of this sample (call_vC.cpp:423 drops the first line of the run)
+                int64_t b = r.pos, e = endpos;
+                if (ds.has_bed) { b = std::max(b, ds.bed_beg[(size_t)r.tid]); e = std::min(e, ds.bed_end[(size_t)r.tid]); }
+                if (b < e) { sc.first_tid = r.tid; sc.first_beg = (int32_t)b; sc.first_end = (int32_t)e; }
+            }
+        }
+        sc.hdr.push_back(h);
+        sc.tid.push_back(r.tid);
+        sc.end.push_back((int32_t)std::max<int64_t>(pile_ok ? endpos : 0, cov_ok ? qa_end + 1 : 0));
+    }
+    // tail padding: kernels read 16 B (qual) / 8 B (seq) chunks and may run past the last read
+    for (int i = 0; i < 32; ++i) sc.seq.push_back(0xff);
+    while (sc.qual.size() < 2 * sc.seq.size()) sc.qual.push_back(0);
+    return MSNV_OK;
+}
+
+template <typename T>
+static int upload_vec(T **dst, const std::vector<T> &v, uint64_t *acct, size_t pad_elems = 0) {
+    if (int rc = dev_alloc((void **)dst, (v.size() + pad_elems) * sizeof(T), acct)) return rc;
+    return dev_upload(*dst, v.data(), v.size() * sizeof(T));
+}
+
+int finalize_dataset(msnv_dataset &ds) {
+    const size_t S = ds.samples.size();
+    const size_t NC = ds.names.size();
+    if (S == 0) return fail(MSNV_EINVAL, "dataset has no samples");
+    if (S >= 16384) return fail(MSNV_EDOMAIN, "more than 16383 samples per dataset are not supported");
+
+    // ---- tile layout: every selected contig owns ceil(max(L, furthest read end) / TILE) tiles
+    std::vector<int64_t> maxend(NC, 0);
+    for (size_t c = 0; c < NC; ++c) maxend[c] = ds.sel[c] ? ds.lengths[c] : 0;
+    for (const SampleCols &sc : ds.samples)
+        for (size_t i = 0; i < sc.hdr.size(); ++i) maxend[(size_t)sc.tid[i]] = std::max<int64_t>(maxend[(size_t)sc.tid[i]], sc.end[i]);
+    ds.tile_base.assign(NC, UINT32_MAX);
+    ds.tile_contig.clear();
+    uint64_t nt = 0;
+    for (size_t c = 0; c < NC; ++c) {
+        if (!ds.sel[c]) continue;
+        ds.tile_base[c] = (uint32_t)nt;
+        uint64_t n = ((uint64_t)maxend[c] + TILE - 1) / TILE;
+        for (uint64_t k = 0; k < n; ++k) ds.tile_contig.push_back((uint32_t)c);
+        nt += n;
+        if (nt * TILE >= 0xffffffffull) return fail(MSNV_EDOMAIN, "shard spans more than 2^32 positions: shard the contigs further");
+    }
+    ds.n_tiles = (uint32_t)nt;
+    const uint64_t npos = nt * TILE;
+
+    DeviceCols *d = new DeviceCols();
+    ds.dev = d;
+    d->n_tiles = ds.n_tiles; d->n_samples = (uint32_t)S;
+
+    // ---- reference: nt16 codes (N beyond the contig end, as mpileup prints) + lower-case bits
+    {
+        std::vector<uint32_t> ref4(npos / 8 + 1, 0xffffffffu), lc(npos / 32 + 1, 0u);
+        for (size_t c = 0; c < NC; ++c) {
+            if (!ds.sel[c] || !ds.has_seq[c]) continue;
+            const std::string &s = ds.seqs[c];
+            const uint64_t g0 = (uint64_t)ds.tile_base[c] * TILE;
+            const uint64_t lim = std::min<uint64_t>(s.size(), (uint64_t)maxend[c]);
+            for (uint64_t i = 0; i < lim; ++i) {
+                const uint64_t g = g0 + i;
+                const uint32_t code = nt16_of_char((unsigned char)s[i]);
+                ref4[g >> 3] = (ref4[g >> 3] & ~(0xfu << (4 * (g & 7)))) | code << (4 * (g & 7));
+                const char ch = s[i];
+                if (ch == 'a' || ch == 'c' || ch == 'g' || ch == 't') lc[g >> 5] |= 1u << (g & 31);
+            }
+        }
+        if (int rc = upload_vec(&d->ref4, ref4, &d->device_bytes)) return rc;
+        if (int rc = upload_vec(&d->ref_lc, lc, &d->device_bytes)) return rc;
+        ds.info.bytes_ref = npos / 2;
+    }
+    // ---- callable range per tile (BED -l regions; without BED every covered position)
+    {
+        std::vector<uint32_t> vb(nt + 1, 0), ve(nt + 1, 0);
+        for (uint64_t t = 0; t < nt; ++t) {
+            const size_t c = ds.tile_contig[t];
+            const int64_t t0 = (int64_t)(t - ds.tile_base[c]) * TILE;
+            int64_t b = ds.has_bed ? ds.bed_beg[c] : 0, e = ds.has_bed ? ds.bed_end[c] : INT64_MAX;
+            b = std::min<int64_t>(std::max<int64_t>(b - t0, 0), TILE);
+            e = std::min<int64_t>(std::max<int64_t>(e - t0, 0), TILE);
+            vb[t] = (uint32_t)b; ve[t] = (uint32_t)e;
+        }
+        if (int rc = upload_vec(&d->tile_vbeg, vb, &d->device_bytes)) return rc;
+        if (int rc = upload_vec(&d->tile_vend, ve, &d->device_bytes)) return rc;
+    }
+
+    // ---- per sample: gpos, tile overlap index; concatenate columns
+    std::vector<uint64_t> rbase(S + 1, 0), cbase(S + 1, 0), sbase(S + 1, 0);
+    for (size_t s = 0; s < S; ++s) {
+        rbase[s + 1] = rbase[s] + ds.samples[s].hdr.size();
+        cbase[s + 1] = cbase[s] + ds.samples[s].cig.size();
+        sbase[s + 1] = sbase[s] + ((ds.samples[s].seq.size() + 15) & ~(size_t)15);
+    }
+    struct PairTmp { uint32_t tile, sample, lo, hi, nok; };
+    std::vector<std::vector<PairTmp>> per_sample(S);
+    ds.first_tid = -1; ds.first_pos = -1;
+    uint64_t tot_reads = 0, tot_pile_reads = 0, tot_bases = 0;
+    for (size_t s = 0; s < S; ++s) {
+        SampleCols &sc = ds.samples[s];
+        std::vector<PairTmp> &pv = per_sample[s];
+        // sweep reads in order; a read touches tiles [gs/TILE, (ge-1)/TILE]
+        for (size_t i = 0; i < sc.hdr.size(); ++i) {
+            const size_t c = (size_t)sc.tid[i];
+            const uint64_t g0 = (uint64_t)ds.tile_base[c] * TILE;
+            const uint64_t gs = g0 + sc.hdr[i].gpos;
+            const uint64_t ge = std::max<uint64_t>(g0 + (uint64_t)sc.end[i], gs + 1);
+            sc.hdr[i].gpos = (uint32_t)gs;
+            const bool ok = sc.hdr[i].meta & META_PILEUP_OK;
+            if (!ok) continue;                       // coverage-only reads are indexed by the coverage pass
+            const uint32_t tlo = (uint32_t)(gs / TILE), thi = (uint32_t)((ge - 1) / TILE);
+            for (uint32_t t = tlo; t <= thi; ++t) {
+                // pairs are created in increasing tile order because reads are sorted by start,
+                // but a long read may reach a tile that already exists further back in the list
+                size_t k = pv.size();
+                while (k > 0 && pv[k - 1].tile > t) --k;
+                if (k > 0 && pv[k - 1].tile == t) {
+                    pv[k - 1].hi = (uint32_t)i + 1; pv[k - 1].nok++;
+                } else {
+                    pv.insert(pv.begin() + (ptrdiff_t)k, PairTmp{t, (uint32_t)s, (uint32_t)i, (uint32_t)i + 1, 1});
+                }
+            }
+        }
+        tot_reads += sc.hdr.size(); tot_pile_reads += sc.n_pileup_reads; tot_bases += sc.n_pileup_bases;
+        if (sc.first_tid >= 0 && (ds.first_tid < 0 || sc.first_tid < ds.first_tid || (sc.first_tid == ds.first_tid && sc.first_beg < ds.first_pos))) {
+            ds.first_tid = sc.first_tid; ds.first_pos = sc.first_beg;
+        }
+    }
+    // ---- CSR of pairs by tile (sample order inside a tile)
+    std::vector<uint32_t> tps(nt + 1, 0);
+    for (size_t s = 0; s < S; ++s) for (const PairTmp &p : per_sample[s]) tps[p.tile + 1]++;
+    for (uint64_t t = 0; t < nt; ++t) tps[t + 1] += tps[t];
+    std::vector<TilePair> pairs(tps[nt]);
+    {
+        std::vector<uint32_t> fill(tps.begin(), tps.end() - 1);
+        for (size_t s = 0; s < S; ++s)
+            for (const PairTmp &p : per_sample[s]) pairs[fill[p.tile]++] = TilePair{p.sample, p.lo, p.hi, p.nok};
+    }
+    // ---- work list: split each tile's pairs so that work items carry similar read counts
+    std::vector<WorkItem> work;
+    {
+        uint64_t total_reads_in_pairs = 0;
+        for (const TilePair &p : pairs) total_reads_in_pairs += p.read_hi - p.read_lo;
+        const uint64_t target = std::max<uint64_t>(1500, total_reads_in_pairs / 6144);
+        for (uint64_t t = 0; t < nt; ++t) {
+            uint32_t lo = tps[t];
+            uint64_t acc = 0;
+            for (uint32_t k = tps[t]; k < tps[t + 1]; ++k) {
+                acc += pairs[k].read_hi - pairs[k].read_lo;
+                if (acc >= target || k + 1 == tps[t + 1]) { work.push_back(WorkItem{(uint32_t)t, lo, k + 1, 0}); lo = k + 1; acc = 0; }
+            }
+        }
+    }
+    d->n_pairs = (uint32_t)pairs.size(); d->n_work = (uint32_t)work.size();
+    if (int rc = upload_vec(&d->pairs, pairs, &d->device_bytes)) return rc;
+    if (int rc = upload_vec(&d->tile_pair_start, tps, &d->device_bytes)) return rc;
+    if (int rc = upload_vec(&d->work, work, &d->device_bytes)) return rc;
+    if (int rc = upload_vec(&d->s_read_base, rbase, &d->device_bytes)) return rc;
+    if (int rc = upload_vec(&d->s_cig_base, cbase, &d->device_bytes)) return rc;
+    if (int rc = upload_vec(&d->s_seq_base, sbase, &d->device_bytes)) return rc;
+
+    // ---- columns
+    d->n_reads = rbase[S]; d->n_cig = cbase[S]; d->n_seq_bytes = sbase[S];
+    if (int rc = dev_alloc((void **)&d->hdr, (rbase[S] + 1) * sizeof(ReadHdr), &d->device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&d->cig, (cbase[S] + 1) * sizeof(uint32_t), &d->device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&d->seq, sbase[S] + 64, &d->device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&d->qual, 2 * sbase[S] + 64, &d->device_bytes)) return rc;
+    uint64_t alg = 0;
+    for (size_t s = 0; s < S; ++s) {
+        SampleCols &sc = ds.samples[s];
+        if (int rc = dev_upload(d->hdr + rbase[s], sc.hdr.data(), sc.hdr.size() * sizeof(ReadHdr))) return rc;
+        if (int rc = dev_upload(d->cig + cbase[s], sc.cig.data(), sc.cig.size() * sizeof(uint32_t))) return rc;
+        if (int rc = dev_upload(d->seq + sbase[s], sc.seq.data(), sc.seq.size())) return rc;
+        if (int rc = dev_upload(d->qual + 2 * sbase[s], sc.qual.data(), sc.qual.size())) return rc;
+        ds.info.bytes_headers += sc.hdr.size() * sizeof(ReadHdr);
+        ds.info.bytes_cigar += sc.cig.size() * 4;
+        ds.info.bytes_seq += sc.seq.size() - 32;
+        ds.info.bytes_qual += 2 * (sc.seq.size() - 32);
+        // release host staging of the bulky columns; headers stay (coverage pass, results mapping)
+        std::vector<uint8_t>().swap(sc.seq);
+        std::vector<uint8_t>().swap(sc.qual);
+    }
+    alg = ds.info.bytes_headers + ds.info.bytes_cigar + ds.info.bytes_seq + ds.info.bytes_qual;
+    d->algorithmic_bytes = alg;
+
+    // ---- intermediates
+    if (int rc = dev_alloc((void **)&d->tot, std::max<uint64_t>(1, 5 * npos) * sizeof(uint32_t), &d->device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&d->spill, std::max<uint64_t>(1, (uint64_t)pairs.size()) * TILE, &d->device_bytes)) return rc;
+    // sparse buffers: generous first guess, grown on MSNV_ECAPACITY by the caller
+    d->cap_events = (uint32_t)std::min<uint64_t>(0x7fffffffull, std::max<uint64_t>(1u << 20, tot_bases / 16));
+    d->cap_overflow = (uint32_t)std::min<uint64_t>(0x7fffffffull, std::max<uint64_t>(1u << 16, npos / 8));
+    d->cap_sites = (uint32_t)std::min<uint64_t>(0x7fffffffull, std::max<uint64_t>(1u << 16, npos / 4));
+    if (int rc = dev_alloc((void **)&d->events, (uint64_t)d->cap_events * sizeof(Pair32), &d->device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&d->overflow, (uint64_t)d->cap_overflow * sizeof(Pair32), &d->device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&d->sites, (uint64_t)d->cap_sites * sizeof(SiteRec), &d->device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&d->counters, 16 * sizeof(uint32_t), &d->device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&d->tile_site_base, (nt + 1) * sizeof(uint32_t), &d->device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&d->tile_site_cnt, (nt + 1) * sizeof(uint32_t), &d->device_bytes)) return rc;
+    if (int rc = dev_memset(d->tile_site_cnt, 0, (nt + 1) * sizeof(uint32_t))) return rc;
+
+    ds.info.n_samples = S; ds.info.n_contigs = 0; ds.info.n_positions = 0;
+    for (size_t c = 0; c < NC; ++c) if (ds.sel[c]) { ds.info.n_contigs++; ds.info.n_positions += (uint64_t)ds.lengths[c]; }
+    ds.info.n_reads = tot_reads; ds.info.n_reads_pileup = tot_pile_reads; ds.info.n_pileup_bases = tot_bases;
+    ds.info.n_tiles = nt; ds.info.n_pairs = pairs.size(); ds.info.n_work = work.size();
+    ds.info.bytes_index = pairs.size() * sizeof(TilePair) + work.size() * sizeof(WorkItem) + (nt + 1) * 4;
+    ds.info.device_bytes = d->device_bytes;
+    ds.finalized = true;
+    return MSNV_OK;
+}
+
+}  // namespace msnv

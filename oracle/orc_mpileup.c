@@ -271,11 +271,18 @@ int orc_mpileup(const orc_ref *ref, const orc_sample *samples, int n_samples,
             for (i = 0; i < n_samples; ++i) {
                 iter_t *t = &it[i];
                 int a, w = 0, n_plp = 0, cnt = 0, nth = 0;
+                /* drop finished reads (bam_plp_next) */
+                for (a = 0; a < t->n_act; ++a)
+                    if (!(t->act[a].tid < cur_tid || (t->act[a].tid == cur_tid && t->act[a].end <= cur_pos))) t->act[w++] = t->act[a];
+                t->n_act = w;
                 /* bam_plp_push: pull in every read that starts here */
                 while (t->has_peek && t->peek.tid == cur_tid && t->peek.pos == cur_pos) {
                     /* sam.c bam_plp_push: "iter->tid == b->core.tid && iter->pos == b->core.pos &&
                        iter->mp->cnt > iter->maxcnt" -> read dropped.  The first read of a position was
-                       pushed as look-ahead while iter->pos was still smaller, so it is never capped. */
+                       pushed as look-ahead while iter->pos was still smaller, so it is never capped.
+                       mp->cnt is restated sample-locally as "reads of this file still alive at this
+                       position" (htslib frees finished nodes lazily, so its count can run slightly
+                       higher); this only matters beyond 8000x per-sample depth. */
                     int capped = (nth > 0 || !t->first_push_done) && opts->max_depth > 0 && t->n_act > opts->max_depth;
                     if (!capped) {
                         if (t->n_act == t->cap_act) { t->cap_act = t->cap_act ? t->cap_act * 2 : 64; t->act = (read_t *)realloc(t->act, (size_t)t->cap_act * sizeof(read_t)); }
@@ -285,10 +292,6 @@ int orc_mpileup(const orc_ref *ref, const orc_sample *samples, int n_samples,
                     if ((rc = fetch(t, ref, opts))) goto done;
                     if (t->has_peek && (t->peek.tid < cur_tid || (t->peek.tid == cur_tid && t->peek.pos < cur_pos))) { orc_set_error("BAM is not coordinate sorted"); rc = ORC_ERR_FORMAT; goto done; }
                 }
-                /* drop finished reads (bam_plp_next) */
-                for (a = 0; a < t->n_act; ++a)
-                    if (!(t->act[a].tid < cur_tid || (t->act[a].tid == cur_tid && t->act[a].end <= cur_pos))) t->act[w++] = t->act[a];
-                t->n_act = w;
                 /* elements */
                 lb_putc(&line, '\t');
                 quals.n = 0;

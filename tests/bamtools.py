@@ -1,0 +1,98 @@
+"""Pure-Python BAM helpers for the tests: build raw alignment records from SAM-like fields and
+parse BAM files with the standard library only (gzip reads BGZF because BGZF is a series of
+gzip members) -- an independent check of the library's own BGZF/BAM reader and writer."""
+import gzip
+import re
+import struct
+
+import numpy as np
+
+NT16 = "=ACMGRSVTWYHKDBN"
+CIGAR_OPS = "MIDNSHP=X"
+
+
+def parse_cigar(cigar):
+    if cigar in ("*", ""):
+        return []
+    return [(int(n), CIGAR_OPS.index(op)) for n, op in re.findall(r"(\d+)([MIDNSHP=X])", cigar)]
+
+
+def reg2bin(beg, end):
+    end -= 1
+    if beg >> 14 == end >> 14:
+        return ((1 << 15) - 1) // 7 + (beg >> 14)
+    if beg >> 17 == end >> 17:
+        return ((1 << 12) - 1) // 7 + (beg >> 17)
+    if beg >> 20 == end >> 20:
+        return ((1 << 9) - 1) // 7 + (beg >> 20)
+    if beg >> 23 == end >> 23:
+        return ((1 << 6) - 1) // 7 + (beg >> 23)
+    if beg >> 26 == end >> 26:
+        return ((1 << 3) - 1) // 7 + (beg >> 26)
+    return 0
+
+
+def make_record(tid, pos, cigar, seq, qual=None, flag=0, mapq=60, name="r", mtid=-1, mpos=-1, tlen=0):
+    """One raw BAM alignment record (SAMv1 4.2).  pos is 0-based; qual is a list of ints or None."""
+    ops = parse_cigar(cigar)
+    l_seq = 0 if seq in ("*", "") else len(seq)
+    if qual is None:
+        qual = [40] * l_seq
+    if isinstance(qual, str):
+        qual = [ord(c) - 33 for c in qual]
+    assert len(qual) == l_seq
+    rlen = sum(n for n, op in ops if op in (0, 2, 3, 7, 8))
+    nm = name.encode() + b"\0"
+    seqb = bytearray((l_seq + 1) // 2)
+    for i in range(l_seq):
+        code = NT16.index(seq[i].upper()) if seq[i].upper() in NT16 else 15
+        seqb[i >> 1] |= code << (4 if i % 2 == 0 else 0)
+    body = struct.pack("<iiBBHHHiiii", tid, pos, len(nm), mapq, reg2bin(pos, pos + max(rlen, 1)), len(ops), flag,
+                       l_seq, mtid, mpos, tlen)
+    body += nm + b"".join(struct.pack("<I", n << 4 | op) for n, op in ops) + bytes(seqb) + bytes(qual)
+    return struct.pack("<i", len(body)) + body
+
+
+def records(*recs):
+    return np.frombuffer(b"".join(recs), dtype=np.uint8)
+
+
+def read_bam_py(path):
+    """Parse a BAM with gzip + struct only.  Returns (header_text, names, lengths, record_bytes)."""
+    with gzip.open(path, "rb") as f:
+        u = f.read()
+    assert u[:4] == b"BAM\1"
+    l_text = struct.unpack_from("<i", u, 4)[0]
+    text = u[8:8 + l_text].rstrip(b"\0").decode()
+    off = 8 + l_text
+    n_ref = struct.unpack_from("<i", u, off)[0]
+    off += 4
+    names, lengths = [], []
+    for _ in range(n_ref):
+        l_name = struct.unpack_from("<i", u, off)[0]
+        off += 4
+        names.append(u[off:off + l_name - 1].decode())
+        off += l_name
+        lengths.append(struct.unpack_from("<i", u, off)[0])
+        off += 4
+    return text, names, lengths, u[off:]
+
+
+def iter_records(buf):
+    """Yield dicts of decoded fields from a raw record stream."""
+    buf = bytes(buf)
+    off = 0
+    while off < len(buf):
+        bs = struct.unpack_from("<i", buf, off)[0]
+        tid, pos, l_name, mapq, _bin, n_cig, flag, l_seq, mtid, mpos, tlen = struct.unpack_from("<iiBBHHHiiii", buf, off + 4)
+        p = off + 36
+        name = buf[p:p + l_name - 1].decode()
+        p += l_name
+        cig = [(c >> 4, c & 15) for c in struct.unpack_from("<%dI" % n_cig, buf, p)]
+        p += 4 * n_cig
+        sb = buf[p:p + (l_seq + 1) // 2]
+        p += (l_seq + 1) // 2
+        seq = "".join(NT16[(sb[i >> 1] >> (4 if i % 2 == 0 else 0)) & 15] for i in range(l_seq))
+        qual = list(buf[p:p + l_seq])
+        yield dict(tid=tid, pos=pos, mapq=mapq, flag=flag, cigar=cig, seq=seq, qual=qual, name=name)
+        off += bs + 4

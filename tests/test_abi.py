@@ -1,0 +1,47 @@
+"""The C-ABI library loads, exports every symbol include/msnv.h declares, and refuses to
+compute without a GPU (no CPU fallback anywhere in the product path)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from metasnv_amd import _lib, core
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    hdr = open(os.path.join(ROOT, "include", "msnv.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(msnv_[a-z0-9_]+)\s*\(", hdr))
+    bound = {n for n, _, _ in _lib.SYMBOLS}
+    assert declared == bound, (declared - bound, bound - declared)
+    for name in declared:
+        assert hasattr(_lib.lib, name)
+    assert _lib.lib.msnv_abi_version() == 1
+
+
+def test_struct_layouts_match_the_header():
+    assert C.sizeof(_lib.Site) == 32 and C.sizeof(_lib.SiteSample) == 10
+    assert C.sizeof(_lib.Params) == 48
+    p = core.default_params()
+    assert (p.min_coverage, p.calling_threshold, p.min_fraction, p.min_baseq, p.flag_filter) == (4, 4, 0.01, 13, 0x704)
+    assert (p.max_depth, p.drop_first_line, p.cov_max, p.cov_min_mapq) == (8000, 1, 10, 1)
+
+
+@pytest.mark.skipif(core.device_count() > 0, reason="GPU present: the no-device failure path is not reachable")
+def test_no_device_means_loud_failure_not_fallback():
+    with pytest.raises(_lib.MsnvError) as e:
+        core.Context(0)
+    assert e.value.code == _lib.ENODEV
+    assert "no CPU fallback" in str(e.value)
+
+
+def test_product_never_imports_the_oracle():
+    # the oracle is test infrastructure: nothing under metasnv_amd/ may reference it
+    for dp, _, files in os.walk(os.path.join(ROOT, "metasnv_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")) or f == "Makefile":
+                txt = open(os.path.join(dp, f), errors="replace").read()
+                assert "liborc" not in txt and "oracle/" not in txt and "import orc" not in txt, os.path.join(dp, f)

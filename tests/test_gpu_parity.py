@@ -1,0 +1,152 @@
+"""Parity of the HIP path (called through the C ABI) with the oracle: bit-exact text.
+
+Integer counting => the bar is byte-identical called_SNPs / indiv_called."""
+import os
+
+import numpy as np
+import pytest
+
+import bamtools as bt
+import orc
+from metasnv_amd import core
+from parity import run_product, run_oracle, synth_case, first_diff
+
+pytestmark = pytest.mark.gpu
+
+
+def _assert_same(prod, orac):
+    assert prod[0] == orac[0], "called_SNPs differs, " + first_diff(prod[0], orac[0])
+    assert prod[1] == orac[1], "indiv_called differs, " + first_diff(prod[1], orac[1])
+
+
+def test_synthetic_small_multi_contig():
+    syn, samples = synth_case(n_species=3, contig_len=5000, n_samples=8, mean_cov=12.0, snv_density=0.02, error_rate=0.004,
+                              lowercase_ref=1, seed=11)
+    prod = run_product(syn.names, syn.lengths, syn.seqs, samples)
+    orac = run_oracle(syn.names, syn.lengths, syn.seqs, samples)
+    _assert_same(prod, orac)
+    assert prod[0].count("\n") > 50 and prod[1].count("\n") > 5
+    assert prod[2]["n_pileup_bases"] == orac[3]          # the metric's unit of work agrees too
+
+
+def test_synthetic_testdata_shape_reduced():
+    # the BASELINE "testdata" shape at 1/10 contig length and 40 samples (oracle finishes in seconds)
+    syn, samples = synth_case(n_species=3, contig_len=30000, n_samples=40, seed=3)
+    prod = run_product(syn.names, syn.lengths, syn.seqs, samples)
+    orac = run_oracle(syn.names, syn.lengths, syn.seqs, samples)
+    _assert_same(prod, orac)
+    assert prod[0].count("\n") > 300
+
+
+def test_thresholds_and_quality_cutoffs():
+    syn, samples = synth_case(n_species=1, contig_len=6000, n_samples=5, mean_cov=9.0, snv_density=0.02, seed=5)
+    for kw in (dict(min_coverage=1, calling_threshold=1), dict(min_coverage=10, calling_threshold=2, min_fraction=0.2),
+               dict(min_baseq=0), dict(min_baseq=35), dict(flag_filter=0, min_mapq=1), dict(calling_threshold=3, min_fraction=0.0)):
+        p = core.default_params(**kw)
+        _assert_same(run_product(syn.names, syn.lengths, syn.seqs, samples, params=p),
+                     run_oracle(syn.names, syn.lengths, syn.seqs, samples, params=p))
+
+
+def test_bed_split_excludes_position_one_and_other_contigs():
+    syn, samples = synth_case(n_species=3, contig_len=4000, n_samples=4, mean_cov=15.0, snv_density=0.03, frac_absent=0.0, seed=9)
+    bed = [(0, 1, 4000), (2, 1, 4000)]                   # best_split file: `name\t1\tLEN` (metaSNV.py:92)
+    prod = run_product(syn.names, syn.lengths, syn.seqs, samples, bed=bed)
+    orac = run_oracle(syn.names, syn.lengths, syn.seqs, samples, bed=bed)
+    _assert_same(prod, orac)
+    assert "refGenome2clus" not in prod[0] and "refGenome3clus" in prod[0]
+
+
+def _reads_edge():
+    ref = ("ACGTTGCAAGGCTTAACCGGTTAACGTAGCTAGCTAGGATCCGATTACAGATTACAGGCATTACGGATCACGATCGACTAGCTAGCATCGACTGACTAGC" * 30)[:2600]
+    def sub(i, n, mut=None):
+        s = list(ref[i:i + n])
+        for k, b in (mut or {}).items():
+            s[k] = b
+        return "".join(s)
+    s1, s2, s3 = [], [], []
+    # a pile of mismatching reads around the tile boundary at 2048 (reads straddle two tiles)
+    for k in range(6):
+        s1.append(bt.make_record(0, 2000 + k, "100M", sub(2000 + k, 100, {50 - k: "A" if ref[2050] != "A" else "C"}), name="a%d" % k))
+    # '=' and X ops, N (ref skip: not counted), soft clip, hard clip, insertion, deletion, P
+    s2.append(bt.make_record(0, 100, "10=5X10=", sub(100, 25, {10: "T" if ref[110] != "T" else "G", 11: "T" if ref[111] != "T" else "G"}), name="b0"))
+    s2.append(bt.make_record(0, 100, "5S20M", "NNNNN" + sub(100, 20, {10: "T" if ref[110] != "T" else "G"}), name="b1"))
+    s2.append(bt.make_record(0, 100, "3H20M2H", sub(100, 20, {10: "T" if ref[110] != "T" else "G"}), name="b2"))
+    s2.append(bt.make_record(0, 100, "8M3I12M", sub(100, 8) + "GGG" + sub(108, 12, {2: "T" if ref[110] != "T" else "G"}), name="b3"))
+    s2.append(bt.make_record(0, 100, "8M2D12M", sub(100, 8) + sub(110, 12, {0: "T" if ref[110] != "T" else "G"}), name="b4"))
+    s2.append(bt.make_record(0, 100, "8M1P12M", sub(100, 20, {10: "T" if ref[110] != "T" else "G"}), name="b5"))
+    for k in range(5):
+        s2.append(bt.make_record(0, 105, "10M", sub(105, 10), qual=[5] * 10, name="lowq%d" % k))      # all below BQ 13
+    # per-sample depth above 255 (coverage byte saturates; overflow list) with an individual-only allele
+    for k in range(500):
+        mut = {20: "G" if ref[520] != "G" else "T"} if k < 4 else None
+        s3.append(bt.make_record(0, 500, "40M", sub(500, 40, mut), name="d%d" % k, flag=16 if k % 2 else 0))
+    # read N bases and odd read lengths
+    s3.append(bt.make_record(0, 700, "7M", "NNNN" + sub(704, 3), name="n0"))
+    # reads that end exactly at the contig end and one flagged read of every kind
+    s3.append(bt.make_record(0, 2590, "10M", sub(2590, 10), name="e0"))
+    for fl in (0x400, 0x100, 0x200, 0x1, 0x4):
+        s3.append(bt.make_record(0, 2590, "10M", "TTTTTTTTTT", flag=fl, name="f%x" % fl))
+    key = lambda r: (int.from_bytes(r[4:8], "little"), int.from_bytes(r[8:12], "little", signed=True))
+    return ref, [bt.records(*sorted(s, key=key)) for s in (s1, s2, s3)] + [np.zeros(0, np.uint8)]
+
+
+def test_cigar_ops_tile_boundary_overflow_and_empty_sample():
+    ref, samples = _reads_edge()
+    p = core.default_params(min_coverage=2, calling_threshold=2)
+    prod = run_product(["ctg"], [len(ref)], [ref], samples, params=p)
+    orac = run_oracle(["ctg"], [len(ref)], [ref], samples, params=p)
+    _assert_same(prod, orac)
+    assert prod[3]["n_overflow"] > 0                      # the >=255 path really ran
+    assert "\t2051\t" in prod[0] or "\t2051\t" in prod[1]
+    assert "\t521\t" in prod[1] and "\t521\t" not in prod[0]   # 4 of 500 reads (< 1 %): individual, not population
+
+
+def test_annotation_codon_path(tmp_path):
+    syn, samples = synth_case(n_species=2, contig_len=3000, n_samples=4, mean_cov=14.0, snv_density=0.03, frac_absent=0.0, seed=21)
+    fa = str(tmp_path / "ref.fa")
+    syn.write_fasta(fa)
+    ann = str(tmp_path / "ann.tsv")
+    with open(ann, "w") as f:
+        f.write("gene_id\texternal_id\tsequence_id\ttype\tinfo\tlength\tstart\tend\tstrand\tsc\tstop\tgc\n")
+        rows = [("g1", syn.names[0], 10, 900, "+"), ("g2", syn.names[0], 600, 1500, "-"), ("g3", syn.names[0], 2000, 2000, "+"),
+                ("g4", syn.names[0], 2500, 2400, "+"), ("h1", syn.names[1], 1, 2997, "-")]
+        for i, (g, c, s, e, st) in enumerate(rows):
+            f.write("%d\t%s\t%s\tCDS\tx\t%d\t%d\t%d\t%s\tATG\tTAG\t0.4\n" % (i, g, c, e - s + 1, s, e, st))
+    prod = run_product(syn.names, syn.lengths, syn.seqs, samples, ann=ann, fasta=fa)
+    orac = run_oracle(syn.names, syn.lengths, syn.seqs, samples, ann=ann, fasta=fa)
+    _assert_same(prod, orac)
+    assert "\tg1\t" in prod[0] and "\tg2\t" in prod[0] and "\th1\t" in prod[0] and "|S[" in prod[0] and "|N[" in prod[0]
+
+
+def test_one_call_entry_point_from_bam_files(tmp_path):
+    import ctypes as C
+    from metasnv_amd import _lib
+    syn, samples = synth_case(n_species=2, contig_len=4000, n_samples=3, mean_cov=10.0, snv_density=0.02, seed=13)
+    fa = str(tmp_path / "ref.fa")
+    syn.write_fasta(fa)
+    paths = []
+    for i, s in enumerate(samples):
+        p = str(tmp_path / ("s%04d.bam" % i))
+        core.write_bam(p, syn.names, syn.lengths, s)
+        paths.append(p)
+    ctx = core.Context(0)
+    a = _lib.CallArgs()
+    arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
+    a.bam_paths, a.n_bams, a.ref_fasta = arr, len(paths), fa.encode()
+    a.out_called_path = str(tmp_path / "called_SNPs").encode()
+    a.out_indiv_path = str(tmp_path / "indiv_called").encode()
+    _lib.lib.msnv_params_default(C.byref(a.params))
+    _lib.check(_lib.lib.msnv_call(ctx._h, C.byref(a)))
+    orac = run_oracle(syn.names, syn.lengths, syn.seqs, samples)
+    assert open(tmp_path / "called_SNPs").read() == orac[0]
+    assert open(tmp_path / "indiv_called").read() == orac[1]
+
+
+def test_repeated_runs_are_idempotent():
+    syn, samples = synth_case(n_species=1, contig_len=8000, n_samples=6, seed=2)
+    pop, ind, info, st, ds, ctx = run_product(syn.names, syn.lengths, syn.seqs, samples, return_ds=True)
+    s1, m1 = ds.results()
+    for _ in range(3):
+        ds.run()
+    s2, m2 = ds.results()
+    assert s1.tobytes() == s2.tobytes() and m1.tobytes() == m2.tobytes()

@@ -1,0 +1,79 @@
+"""Host I/O of libmsnv.so (BGZF/BAM on zlib) against the standard library."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+import bamtools as bt
+from metasnv_amd import core
+
+
+def _records():
+    return bt.records(
+        bt.make_record(0, 2, "5M", "GTACG", name="a"),
+        bt.make_record(0, 4, "3M1I2M", "ACGTTA", flag=16, name="b"),
+        bt.make_record(1, 0, "2S3M", "NNACG", qual=[1, 2, 3, 4, 5], name="c", mapq=7),
+        bt.make_record(-1, -1, "*", "ACGT", flag=4, name="u"),
+    )
+
+
+def test_bam_write_is_readable_by_gzip_and_roundtrips(tmp_path):
+    p = str(tmp_path / "x.bam")
+    rec = _records()
+    core.write_bam(p, ["c1", "c2"], [20, 30], rec)
+    text, names, lengths, raw = bt.read_bam_py(p)          # independent parser
+    assert names == ["c1", "c2"] and lengths == [20, 30]
+    assert "@SQ\tSN:c1\tLN:20" in text
+    assert raw == rec.tobytes()
+    back = core.read_bam(p)                                 # library reader
+    assert back["names"] == names and back["lengths"] == lengths
+    assert back["records"].tobytes() == rec.tobytes()
+    assert [r["name"] for r in bt.iter_records(back["records"])] == ["a", "b", "c", "u"]
+    # BGZF EOF marker (SAMv1 4.1.2)
+    assert open(p, "rb").read()[-28:] == bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+
+def test_reader_accepts_multi_block_files(tmp_path):
+    p = str(tmp_path / "big.bam")
+    rng = np.random.default_rng(0)
+    recs = [bt.make_record(0, i * 3, "100M", "".join("ACGT"[k] for k in rng.integers(0, 4, 100)), name="r%d" % i) for i in range(3000)]
+    rec = bt.records(*recs)
+    assert rec.size > 3 * 65536
+    core.write_bam(p, ["c1"], [100000], rec, level=6)
+    assert core.read_bam(p)["records"].tobytes() == rec.tobytes()
+    assert bt.read_bam_py(p)[3] == rec.tobytes()
+
+
+def test_bed_header_matches_metaSNV_get_header(tmp_path):
+    # metaSNV.py:81-94: SN\t1\tLN per @SQ line with exactly three fields; first header line skipped
+    p = str(tmp_path / "x.bam")
+    core.write_bam(p, ["spA.p.c1", "spB.q.c1"], [1000, 2000], _records()[:0],
+                   header_text="@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:spA.p.c1\tLN:1000\n@SQ\tSN:spB.q.c1\tLN:2000\tM5:abc\n@PG\tID:x\n")
+    out = str(tmp_path / "bed_header")
+    core.write_bed_header(p, out)
+    assert open(out).read() == "spA.p.c1\t1\t1000\n"      # the 4-field @SQ line is skipped exactly as the reference does
+
+
+def test_malformed_inputs_fail_loudly(tmp_path):
+    p = str(tmp_path / "bad.bam")
+    with open(p, "wb") as f:
+        f.write(b"not a bam")
+    with pytest.raises(core._lib.MsnvError) as e:
+        core.read_bam(p)
+    assert e.value.code == core._lib.EFORMAT
+    with pytest.raises(core._lib.MsnvError) as e:
+        core.read_bam(str(tmp_path / "missing.bam"))
+    assert e.value.code == core._lib.EIO
+
+
+def test_synth_is_deterministic_and_sorted():
+    p = core.synth_params(n_species=2, contig_len=3000, n_samples=2, mean_cov=5.0, seed=7)
+    a, b = core.Synth(p), core.Synth(p)
+    assert a.seqs == b.seqs and a.names == ["refGenome1clus", "refGenome2clus"]
+    r0, r0b, r1 = a.sample_records(0), b.sample_records(0), a.sample_records(1)
+    assert r0.tobytes() == r0b.tobytes() and r0.tobytes() != r1.tobytes()
+    keys = [(r["tid"], r["pos"]) for r in bt.iter_records(r0)]
+    assert keys == sorted(keys) and len(keys) > 50
+    for r in bt.iter_records(r0):
+        assert sum(n for n, op in r["cigar"] if op in (0, 1, 4, 7, 8)) == len(r["seq"])
