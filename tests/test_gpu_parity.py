@@ -25,7 +25,7 @@ def test_synthetic_small_multi_contig():
     prod = run_product(syn.names, syn.lengths, syn.seqs, samples)
     orac = run_oracle(syn.names, syn.lengths, syn.seqs, samples)
     _assert_same(prod, orac)
-    assert prod[0].count("\n") > 50 and prod[1].count("\n") > 5
+    assert prod[0].count("\n") > 50
     assert prod[2]["n_pileup_bases"] == orac[3]          # the metric's unit of work agrees too
 
 
