@@ -272,8 +272,24 @@ extern "C" int msnv_pileup_run(msnv_dataset *ds, msnv_run_stats *stats) {
     }
     if (rc) return rc;
 
-    // ---- map the device records back to (contig, position) in output order
-    const uint32_t n = c.n_sites;
+    {   // called-line counts: the per-site flag bytes are tiny, the records stay on the device
+        std::vector<uint8_t> flags(c.n_sites);
+        if (int r2 = dev_download(flags.data(), d.site_flags, c.n_sites)) return r2;
+        for (uint8_t f : flags) { if (f & 15) st.n_called_pop++; if (f >> 4) st.n_called_indiv++; }
+    }
+    ds->have_results = true;
+    ds->results_fetched = false;
+    ds->last_counts_sites = c.n_sites;
+    ds->last_stats = st;
+    if (stats) *stats = st;
+    return MSNV_OK;
+}
+
+// Downloads the records of the last pass and maps them back to (contig, position) in output order.
+static int fetch_results(msnv_dataset *ds) {
+    if (ds->results_fetched) return MSNV_OK;
+    DeviceCols &d = *ds->dev;
+    const uint32_t n = ds->last_counts_sites;
     std::vector<SiteRec> sites(n);
     std::vector<uint8_t> flags(n);
     std::vector<uint32_t> tbase(ds->n_tiles + 1), tcnt(ds->n_tiles + 1);
@@ -286,7 +302,6 @@ extern "C" int msnv_pileup_run(msnv_dataset *ds, msnv_run_stats *stats) {
 
     ds->sites.clear(); ds->site_samples.clear();
     ds->sites.reserve(n);
-    uint64_t n_pop = 0, n_ind = 0;
     for (uint32_t t = 0; t < ds->n_tiles; ++t) {
         for (uint32_t j = 0; j < tcnt[t]; ++j) {
             const uint32_t i = tbase[t] + j;
@@ -299,15 +314,11 @@ extern "C" int msnv_pileup_run(msnv_dataset *ds, msnv_run_stats *stats) {
             const std::string &seq = ds->seqs[(size_t)s.tid];
             s.refchar = (uint8_t)((ds->has_seq[(size_t)s.tid] && (size_t)s.pos < seq.size()) ? seq[(size_t)s.pos] : 'N');
             s.dropped = (ds->params.drop_first_line && s.tid == ds->first_tid && s.pos == ds->first_pos) ? 1 : 0;
-            if (s.pop_mask) ++n_pop;
-            if (s.ind_mask) ++n_ind;
             ds->sites.push_back(s);
             ds->site_samples.insert(ds->site_samples.end(), raw.begin() + (size_t)i * d.n_samples, raw.begin() + (size_t)(i + 1) * d.n_samples);
         }
     }
-    ds->have_results = true;
-    st.n_called_pop = n_pop; st.n_called_indiv = n_ind;
-    if (stats) *stats = st;
+    ds->results_fetched = true;
     return MSNV_OK;
 }
 
@@ -315,6 +326,7 @@ extern "C" int msnv_results_count(const msnv_dataset *ds, uint64_t *n_sites) {
     clear_error();
     if (!ds || !n_sites) return fail(MSNV_EINVAL, "msnv_results_count: NULL argument");
     if (!ds->have_results) return fail(MSNV_EINVAL, "no results: call msnv_pileup_run first");
+    if (int rc = fetch_results(const_cast<msnv_dataset *>(ds))) return rc;
     *n_sites = ds->sites.size();
     return MSNV_OK;
 }
@@ -323,6 +335,7 @@ extern "C" int msnv_results_fetch(msnv_dataset *ds, msnv_site *sites, msnv_site_
     clear_error();
     if (!ds || !sites || !samples) return fail(MSNV_EINVAL, "msnv_results_fetch: NULL argument");
     if (!ds->have_results) return fail(MSNV_EINVAL, "no results: call msnv_pileup_run first");
+    if (int rc = fetch_results(ds)) return rc;
     if (capacity < ds->sites.size()) return fail(MSNV_ECAPACITY, "capacity %llu < %zu sites", (unsigned long long)capacity, ds->sites.size());
     memcpy(sites, ds->sites.data(), ds->sites.size() * sizeof(msnv_site));
     memcpy(samples, ds->site_samples.data(), ds->site_samples.size() * sizeof(msnv_site_sample));
@@ -334,6 +347,7 @@ extern "C" int msnv_write_calls(msnv_dataset *ds, const char *called_path, const
     clear_error();
     if (!ds || !called_path) return fail(MSNV_EINVAL, "msnv_write_calls: NULL argument");
     if (!ds->have_results) return fail(MSNV_EINVAL, "no results: call msnv_pileup_run first");
+    if (int rc = fetch_results(ds)) return rc;
     return write_calls_text(*ds, called_path, indiv_path, ann_path, fasta_path);
 }
 

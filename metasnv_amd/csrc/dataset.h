@@ -81,7 +81,9 @@ struct msnv_dataset {
     msnv_dataset_info info{};
     msnv::DeviceCols *dev = nullptr;
     // results of the last run (host copies)
-    bool have_results = false;
+    bool have_results = false, results_fetched = false;
+    uint32_t last_counts_sites = 0;
+    msnv_run_stats last_stats{};
     std::vector<msnv_site> sites;
     std::vector<msnv_site_sample> site_samples;
 };

@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "device.h"
@@ -56,13 +57,13 @@ __device__ __forceinline__ uint32_t allele_index(uint32_t code) {
 }
 
 // ------------------------------------------------------------------------------------------
-// msnv_pileup_tiles: for one work item = (tile, range of (tile,sample) pairs):
+// msnv_pileup_tiles_v1 (first correct version, kept for A/B: MSNV_PILEUP=v1): for one work item = (tile, range of (tile,sample) pairs):
 //   for every sample: scatter the sample's reads into LDS bins (match count + 4 allele counts
 //   per position), then one pass over the tile's positions adds the sample to the running
 //   totals (registers), spills the per-sample coverage byte and emits the sparse allele events.
 // Algorithmic HBM bytes: 16 B header + 4 B per extra CIGAR op + 0.5 B/base seq + 1 B/base qual.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PILEUP_NT) void msnv_pileup_tiles(PileupArgs a) {
+__global__ __launch_bounds__(PILEUP_NT) void msnv_pileup_tiles_v1(PileupArgs a) {
     __shared__ uint32_t s_m[TILE / 2];                 // match counts, two u16 per word
     __shared__ unsigned long long s_al[TILE];          // allele counts, four u16 (A,C,G,T) per position
     __shared__ uint32_t s_ref[TILE / 8];               // nt16 reference codes of the tile
@@ -179,6 +180,242 @@ __global__ __launch_bounds__(PILEUP_NT) void msnv_pileup_tiles(PileupArgs a) {
     }
 
     // ---- flush this work item's totals (several work items may share a tile)
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const uint64_t g = (uint64_t)t0 + PPT * tid + j;
+        if (tc[j]) atomicAdd(&a.tot[g], tc[j]);
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+            if (tn[j][x]) atomicAdd(&a.tot[(uint64_t)(1 + x) * a.npos + g], tn[j][x]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// msnv_pileup_tiles (v2): same contract as v1, restructured around what is RARE.
+//   * coverage comes from a difference array: +1/-1 per M/=/X segment (2 LDS atomics per read
+//     instead of one per base), prefix-summed once per sample;
+//   * a lane classifies 16 bases at a time with SWAR arithmetic (BQ test on 4 packed bytes,
+//     read-vs-reference test on 8 packed nibbles, udot4 to compress the flags) and only the
+//     EXCEPTIONS touch LDS: bases below the BQ cutoff / N (subtracted from the span coverage)
+//     and mismatching A/C/G/T bases (the allele counts);
+//   * read headers of the next chunk are prefetched into registers while the current chunk is
+//     processed and handed over through LDS;
+//   * allele events and >=255 coverages are staged in LDS and reserved in global memory with
+//     one atomic per flush (a single global counter saturates at ~90 returning atomics/us).
+// ------------------------------------------------------------------------------------------
+constexpr int HCAP = 256;                      // read headers staged per chunk
+constexpr int EVCAP = 1024;                    // LDS event staging entries
+
+__device__ __forceinline__ uint32_t nz_nibbles(uint32_t x) {       // bit 4j+3 set iff nibble j != 0
+    return (((x & 0x77777777u) + 0x77777777u) | x) & 0x88888888u;
+}
+__device__ __forceinline__ uint32_t nibflags_to_bits(uint32_t f) {  // bit 4j+3 -> bit j (8 bits)
+    const uint32_t e = f & 0x08080808u, o = (f >> 4) & 0x08080808u;
+    return (__builtin_amdgcn_udot4(o, 0x80200802u, __builtin_amdgcn_udot4(e, 0x40100401u, 0u, false), false)) >> 3;
+}
+
+struct TileLds {
+    int32_t  span[TILE + 4];
+    uint32_t exc[TILE / 2];                    // two u16 per word
+    unsigned long long al[TILE];               // four u16 (A,C,G,T)
+    uint32_t ref[TILE / 8 + 4];                // 2 halo words (16 positions) on each side
+    uint4    hdr[2][HCAP];
+    Pair32   ev[EVCAP];
+    int32_t  wsum[PILEUP_NT / 64];
+    uint32_t evn, ev_base;
+};
+
+__device__ __forceinline__ void stage_event(TileLds &L, const PileupArgs &a, uint32_t kind, Pair32 e) {
+    // kind 0: allele event -> a.events / counters[0]; kind 1: coverage overflow -> a.overflow / counters[1]
+    if (kind == 0) {
+        const uint32_t i = atomicAdd(&L.evn, 1u);
+        if (i < (uint32_t)EVCAP) { L.ev[i] = e; return; }
+        const uint32_t g = atomicAdd(&a.counters[0], 1u);          // staging full: slow path
+        if (g < a.cap_events) a.events[g] = e;
+    } else {
+        const uint32_t g = atomicAdd(&a.counters[1], 1u);
+        if (g < a.cap_overflow) a.overflow[g] = e;
+    }
+}
+
+__device__ __forceinline__ void flush_events(TileLds &L, const PileupArgs &a, int tid) {
+    // called by all threads between barriers
+    const uint32_t n = min(L.evn, (uint32_t)EVCAP);
+    if (tid == 0) L.ev_base = n ? atomicAdd(&a.counters[0], n) : 0u;
+    __syncthreads();
+    const uint32_t base = L.ev_base;
+    for (uint32_t i = tid; i < n; i += PILEUP_NT)
+        if (base + i < a.cap_events) a.events[base + i] = L.ev[i];
+    __syncthreads();
+    if (tid == 0) L.evn = 0;
+}
+
+// 16 bases of one M/=/X segment: qv = 16 quality bytes, (s0,s1) = 16 read nibbles, P0 = position of
+// base 0 inside the tile (may be negative / beyond the tile: vmask removes those bases).
+__device__ __forceinline__ void classify_chunk(TileLds &L, const uint4 qv, const uint32_t s0, const uint32_t s1,
+                                               const int P0, const uint32_t vmask, const uint32_t kq) {
+    const int pr = P0 + 16;                                   // >= 1 for every chunk that reaches here
+    const uint32_t wi = (uint32_t)pr >> 3, sh = ((uint32_t)pr & 7u) * 4u;
+    const uint32_t w0 = L.ref[wi], w1 = L.ref[wi + 1], w2 = L.ref[wi + 2];
+    const uint32_t r0 = __builtin_amdgcn_alignbit(w1, w0, sh), r1 = __builtin_amdgcn_alignbit(w2, w1, sh);
+    // mismatch = read nibble != reference nibble and read nibble != '=' (code 0)
+    const uint32_t nm = nibflags_to_bits(nz_nibbles(s0 ^ r0) & nz_nibbles(s0)) |
+                        nibflags_to_bits(nz_nibbles(s1 ^ r1) & nz_nibbles(s1)) << 8;
+    // low quality = byte < min_baseq  (kq = 0x80808080 - min_baseq * 0x01010101)
+    const uint32_t l0 = ~(((qv.x & 0x7f7f7f7fu) + kq) | qv.x) & 0x80808080u;
+    const uint32_t l1 = ~(((qv.y & 0x7f7f7f7fu) + kq) | qv.y) & 0x80808080u;
+    const uint32_t l2 = ~(((qv.z & 0x7f7f7f7fu) + kq) | qv.z) & 0x80808080u;
+    const uint32_t l3 = ~(((qv.w & 0x7f7f7f7fu) + kq) | qv.w) & 0x80808080u;
+    const uint32_t lqa = __builtin_amdgcn_udot4(l1, 0x80402010u, __builtin_amdgcn_udot4(l0, 0x08040201u, 0u, false), false);
+    const uint32_t lqb = __builtin_amdgcn_udot4(l3, 0x80402010u, __builtin_amdgcn_udot4(l2, 0x08040201u, 0u, false), false);
+    const uint32_t lq = ((lqa >> 7) & 0xffu) | ((lqb >> 7) & 0xffu) << 8;
+    uint32_t e = (lq | nm) & vmask;
+    while (e) {
+        const uint32_t j = (uint32_t)__builtin_ctz(e);
+        e &= e - 1u;
+        const uint32_t p = (uint32_t)(P0 + (int)j);
+        uint32_t ai = 4u;
+        if (!((lq >> j) & 1u)) ai = allele_index(((j < 8u ? s0 : s1) >> (4u * (j & 7u))) & 0xfu);
+        if (ai < 4u) atomicAdd(&L.al[p], 1ull << (16u * ai));
+        else atomicAdd(&L.exc[p >> 1], 1u << (16u * (p & 1u)));     // not counted: low BQ, N, other IUPAC
+    }
+}
+
+__global__ __launch_bounds__(PILEUP_NT) void msnv_pileup_tiles(PileupArgs a) {
+    __shared__ TileLds L;
+    const WorkItem w = a.work[blockIdx.x];
+    const uint32_t t0 = w.tile * TILE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane8 = tid & (LANES_PER_READ - 1), grp = tid / LANES_PER_READ;
+    const uint32_t kq = 0x80808080u - min(a.min_baseq, 128u) * 0x01010101u;
+
+    for (int i = tid; i < (int)(TILE / 8 + 4); i += PILEUP_NT) {
+        const long long wi = (long long)(t0 >> 3) + i - 2;         // halo: positions outside the tile never pass vmask
+        L.ref[i] = (wi >= 0 && (uint64_t)wi < a.npos / 8) ? a.ref4[wi] : 0xffffffffu;
+    }
+    for (int i = tid; i < (int)(TILE + 4); i += PILEUP_NT) L.span[i] = 0;
+    for (int i = tid; i < (int)(TILE / 2); i += PILEUP_NT) L.exc[i] = 0;
+    for (int i = tid; i < (int)TILE; i += PILEUP_NT) L.al[i] = 0;
+    if (tid == 0) L.evn = 0;
+
+    uint32_t tc[PPT], tn[PPT][4];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) { tc[j] = 0; tn[j][0] = tn[j][1] = tn[j][2] = tn[j][3] = 0; }
+
+    // chunk iterator: (pair k, first read of the chunk)
+    uint32_t k = w.pair_lo;
+    TilePair pr = (k < w.pair_hi) ? a.pairs[k] : TilePair{0, 0, 0, 0};
+    uint32_t rbeg = pr.read_lo;
+    uint4 hreg = make_uint4(0, 0, 0, 0);
+    if (k < w.pair_hi && rbeg + (uint32_t)tid < pr.read_hi && tid < HCAP)
+        hreg = *reinterpret_cast<const uint4 *>(a.hdr + a.s_read_base[pr.sample] + rbeg + tid);
+    int buf = 0;
+
+    while (k < w.pair_hi) {
+        const uint32_t nrd = min((uint32_t)HCAP, pr.read_hi - rbeg);
+        const bool last_chunk = rbeg + nrd >= pr.read_hi;
+        const uint32_t sample = pr.sample;
+        if (tid < HCAP) L.hdr[buf][tid] = hreg;
+        // ---- prefetch the next chunk's headers
+        uint32_t nk = k, nrbeg = rbeg + nrd;
+        TilePair npr = pr;
+        if (last_chunk) { nk = k + 1; if (nk < w.pair_hi) { npr = a.pairs[nk]; nrbeg = npr.read_lo; } }
+        if (nk < w.pair_hi && tid < HCAP && nrbeg + (uint32_t)tid < npr.read_hi)
+            hreg = *reinterpret_cast<const uint4 *>(a.hdr + a.s_read_base[npr.sample] + nrbeg + tid);
+        __syncthreads();                                            // (A) headers visible, bins clean
+
+        // ---- scatter this chunk's reads: 8 lanes per read
+        const uint32_t *cigp = a.cig + a.s_cig_base[sample];
+        const uint8_t *seq = a.seq + a.s_seq_base[sample];
+        const uint8_t *qual = a.qual + 2 * a.s_seq_base[sample];
+        for (uint32_t r = (uint32_t)grp; r < nrd; r += PILEUP_NT / LANES_PER_READ) {
+            const uint4 h = L.hdr[buf][r];
+            if (!(h.w & META_PILEUP_OK)) continue;
+            const uint32_t ncig = h.w & 0xffffu;
+            uint32_t q = 0, rp = h.x;
+            for (uint32_t ci = 0; ci < ncig; ++ci) {
+                const uint32_t op = (ncig == 1) ? h.z : cigp[h.z + ci];
+                const uint32_t len = op >> 4, type = op & 15u;
+                if (type == C_M || type == C_EQ || type == C_X) {
+                    if (rp < t0 + TILE && rp + len > t0) {
+                        const uint32_t lo = (rp < t0) ? (t0 - rp) : 0u;
+                        const uint32_t hi = (rp + len > t0 + TILE) ? (t0 + TILE - rp) : len;
+                        if (lane8 == 0) {                            // coverage of the whole segment: 2 atomics
+                            atomicAdd(&L.span[rp + lo - t0], 1);
+                            atomicAdd(&L.span[rp + hi - t0], -1);
+                        }
+                        const uint32_t qs = q + lo, qe = q + hi;
+                        for (uint32_t c = (qs >> 4) + (uint32_t)lane8; c <= ((qe - 1) >> 4); c += LANES_PER_READ) {
+                            uint4 qv; uint2 sv;
+                            __builtin_memcpy(&qv, qual + 2ull * h.y + 16ull * c, 16);
+                            __builtin_memcpy(&sv, seq + (uint64_t)h.y + 8ull * c, 8);
+                            const uint32_t b0 = 16u * c;              // first query base of the chunk
+                            const uint32_t vlo = (qs > b0) ? (qs - b0) : 0u, vhi = (qe < b0 + 16u) ? (qe - b0) : 16u;
+                            const uint32_t vmask = ((1u << vhi) - 1u) & ~((1u << vlo) - 1u);
+                            const int P0 = (int)(rp - t0) + (int)b0 - (int)q;   // may be negative (wraps correctly)
+                            classify_chunk(L, qv, sv.x, sv.y, P0, vmask, kq);
+                        }
+                    }
+                    q += len; rp += len;
+                } else if (type == C_I || type == C_S) {
+                    q += len;
+                } else if (type == C_D || type == C_N) {
+                    rp += len;
+                }
+            }
+        }
+
+        if (last_chunk) {
+            __syncthreads();                                        // (B) all exceptions of this sample are in LDS
+            // ---- phase 1: read + clear my 4 positions, local prefix of the difference array
+            int4 sp = *reinterpret_cast<int4 *>(&L.span[PPT * tid]);
+            const uint2 ex = *reinterpret_cast<uint2 *>(&L.exc[2 * tid]);
+            unsigned long long al[PPT];
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) al[j] = L.al[PPT * tid + j];
+            *reinterpret_cast<int4 *>(&L.span[PPT * tid]) = make_int4(0, 0, 0, 0);
+            if (tid == 0) L.span[TILE] = 0;
+            *reinterpret_cast<uint2 *>(&L.exc[2 * tid]) = make_uint2(0u, 0u);
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) L.al[PPT * tid + j] = 0ull;
+            sp.y += sp.x; sp.z += sp.y; sp.w += sp.z;
+            int incl = sp.w;                                         // inclusive wave scan of the thread totals
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+            if (lane == 63) L.wsum[wave] = incl;
+            __syncthreads();                                        // (C)
+            int off = incl - sp.w;
+            for (int wv = 0; wv < wave; ++wv) off += L.wsum[wv];
+            const int depth[PPT] = {off + sp.x, off + sp.y, off + sp.z, off + sp.w};
+            const uint32_t exc[PPT] = {ex.x & 0xffffu, ex.x >> 16, ex.y & 0xffffu, ex.y >> 16};
+            uint32_t packed = 0;
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) {
+                const uint32_t cov = (uint32_t)depth[j] - exc[j];
+                tc[j] += cov;
+                packed |= (cov < 255u ? cov : 255u) << (8 * j);
+                const uint32_t gpos = t0 + PPT * tid + j;
+                if (cov >= 255u) stage_event(L, a, 1, Pair32{gpos, sample << 16 | (cov & 0xffffu)});
+                if (al[j] != 0ull) {
+                    const uint32_t nn[4] = {(uint32_t)(al[j] & 0xffffu), (uint32_t)((al[j] >> 16) & 0xffffu),
+                                            (uint32_t)((al[j] >> 32) & 0xffffu), (uint32_t)(al[j] >> 48)};
+#pragma unroll
+                    for (int x = 0; x < 4; ++x)
+                        if (nn[x]) { tn[j][x] += nn[x]; stage_event(L, a, 0, Pair32{gpos, sample << 18 | (uint32_t)x << 16 | nn[x]}); }
+                }
+            }
+            *reinterpret_cast<uint32_t *>(a.spill + (uint64_t)k * TILE + PPT * tid) = packed;
+        }
+        // ---- advance
+        k = nk; pr = npr; rbeg = nrbeg; buf ^= 1;
+        if (last_chunk && k < w.pair_hi) {
+            __syncthreads();                                        // staged events are complete
+            if (L.evn >= (uint32_t)(EVCAP / 2)) flush_events(L, a, tid);   // uniform: evn is read after a barrier
+        }
+    }
+    __syncthreads();
+    flush_events(L, a, tid);
+
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
         const uint64_t g = (uint64_t)t0 + PPT * tid + j;
@@ -400,7 +637,9 @@ int dev_run_pipeline(DeviceCols &d, const msnv_params &p, void *stream_, msnv_ru
         a.ref4 = d.ref4; a.pairs = d.pairs; a.work = d.work; a.tot = d.tot; a.npos = npos; a.spill = d.spill;
         a.events = d.events; a.cap_events = d.cap_events; a.overflow = d.overflow; a.cap_overflow = d.cap_overflow;
         a.counters = d.counters; a.min_baseq = (uint32_t)std::max(0, p.min_baseq);
-        hipLaunchKernelGGL(msnv_pileup_tiles, dim3(d.n_work), dim3(PILEUP_NT), 0, st, a);
+        static const bool use_v1 = [] { const char *e = getenv("MSNV_PILEUP"); return e && e[0] == 'v' && e[1] == '1'; }();
+        if (use_v1) hipLaunchKernelGGL(msnv_pileup_tiles_v1, dim3(d.n_work), dim3(PILEUP_NT), 0, st, a);
+        else hipLaunchKernelGGL(msnv_pileup_tiles, dim3(d.n_work), dim3(PILEUP_NT), 0, st, a);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(ev[2], st));
