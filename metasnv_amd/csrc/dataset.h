@@ -23,13 +23,16 @@ namespace msnv {
 
 constexpr uint32_t TILE = 2048;          // reference positions per tile (LDS bins per workgroup)
 
-// meta: bits 0-15 n_cigar | 16-23 mapq | 24 pileup_ok | 25 cov_ok
+// meta: bits 0-15 n_cigar | 16-23 mapq | 24 pileup_ok | 25 cov_ok | 26 fast
 constexpr uint32_t META_PILEUP_OK = 1u << 24;
 constexpr uint32_t META_COV_OK    = 1u << 25;
+constexpr uint32_t META_FAST      = 1u << 26;   // pileup_ok, exactly one M/=/X op of at most 128 bases
+constexpr uint32_t NARROW_MAX_DEPTH = 255;   // (tile, sample) pairs below this depth use byte-wide LDS bins
 
 struct ReadHdr { uint32_t gpos, seqoff, cig, meta; };
 
-struct TilePair { uint32_t sample, read_lo, read_hi, n_reads_ok; };   // reads of `sample` that may overlap the tile
+struct TilePair { uint32_t sample, read_lo, read_hi, max_depth; };    // reads of `sample` that may overlap the tile;
+                                                                        // max_depth = upper bound of the per-position depth
 struct WorkItem { uint32_t tile, pair_lo, pair_hi, pad; };
 
 struct SiteRec { uint32_t gpos, cov, n[4]; };                          // gate kernel output (24 B)
@@ -39,6 +42,7 @@ struct SampleCols {
     std::vector<ReadHdr>  hdr;
     std::vector<int32_t>  tid;       // per read
     std::vector<int32_t>  end;       // per read: contig-relative end of everything the kernels may touch
+    std::vector<uint16_t> depth;     // per read: pileup reads alive when this one starts (saturating)
     std::vector<uint32_t> cig;
     std::vector<uint8_t>  seq, qual;
     uint64_t n_pileup_bases = 0, n_pileup_reads = 0;

@@ -22,7 +22,7 @@ struct DeviceCols {
     uint32_t *tile_pair_start = nullptr;   // n_tiles + 1
     WorkItem *work = nullptr;
     uint32_t *tile_vbeg = nullptr, *tile_vend = nullptr;   // callable range inside each tile (BED / contig)
-    uint32_t  n_tiles = 0, n_pairs = 0, n_work = 0, n_samples = 0;
+    uint32_t  n_tiles = 0, n_pairs = 0, n_work = 0, n_work_narrow = 0, n_samples = 0;   // work[0..n_work_narrow) = narrow items
     uint64_t  n_reads = 0, n_cig = 0, n_seq_bytes = 0;
     // ---- intermediates
     uint32_t *tot = nullptr;         // [5][n_tiles*TILE]: cov, A, C, G, T summed over samples

@@ -427,6 +427,278 @@ __global__ __launch_bounds__(PILEUP_NT) void msnv_pileup_tiles(PileupArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// msnv_pileup_tiles_narrow: the same algorithm as msnv_pileup_tiles for (tile, sample) pairs
+// whose per-position depth is known (host bound) to stay below 255, which lets every LDS bin be
+// ONE BYTE:
+//   start[p] / end[p]  M/=/X segments that begin at / end before p  (coverage = running sum)
+//   exc[p]             bases not counted (BQ below cutoff, N, other IUPAC)
+//   al[p]              4 bytes: mismatching A, C, G, T
+// 23 KB of LDS and 256 threads per workgroup -> several resident workgroups per CU.
+// The kernel is instruction-issue bound (rocprof: SIMDs ~100 % busy, HBM far from saturated), so
+// the hot loop is written to minimise instructions per base:
+//   * fast path (single M/=/X op, <= 128 bases; host sets META_FAST) is branch free: clipping is
+//     done with min/max, out-of-range lanes get an empty valid-mask and load from a safe address;
+//   * all loads of a 128-read chunk are issued before the first one is consumed;
+//   * BQ cutoff: host clamps qualities to <= 127, so 4 bytes are tested with one add + one and-not;
+//   * '=' read codes are rewritten by the host, so match = nibble equality (one xor);
+//   * flag bits are compressed with v_dot4_u32_u8; low-quality bases reach the byte bins through
+//     5 unconditional LDS atomics per 16-base chunk (multiply-spread of 4 flag bits into 4 bytes);
+//   * the per-sample prefix sum uses DPP row shifts; allele totals go straight to global memory.
+// ------------------------------------------------------------------------------------------
+constexpr int N_NT = 256;
+constexpr int N_PPT = TILE / N_NT;             // 8 positions per thread in the per-sample pass
+constexpr int N_GROUPS = N_NT / LANES_PER_READ;
+constexpr int N_HCAP = 128;
+constexpr int N_ROUNDS = N_HCAP / N_GROUPS;    // 4
+constexpr int N_EVCAP = 512;
+static_assert(N_PPT == 8, "narrow per-sample pass is written for 8 positions per thread");
+
+struct NarrowLds {
+    uint32_t start[TILE / 4 + 4];
+    uint32_t end[TILE / 4 + 4];
+    uint32_t exc[TILE / 4 + 16];               // 4 halo words (16 positions) in front, 9+ behind
+    uint32_t al[TILE];
+    uint32_t ref[TILE / 8 + 4];
+    uint4    hdr[2][N_HCAP];
+    Pair32   ev[N_EVCAP];
+    int32_t  wsum[N_NT / 64];
+    uint32_t evn, ev_base;
+};
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_add(int x) {
+    return x + __builtin_amdgcn_update_dpp(0, x, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ int wave_inclusive_scan(int x) {      // LLVM's DPP scan sequence (gfx9)
+    x = dpp_add<0x111, 0xf>(x);   // row_shr:1
+    x = dpp_add<0x112, 0xf>(x);   // row_shr:2
+    x = dpp_add<0x114, 0xf>(x);   // row_shr:4
+    x = dpp_add<0x118, 0xf>(x);   // row_shr:8
+    x = dpp_add<0x142, 0xa>(x);   // row_bcast:15 -> rows 1 and 3
+    x = dpp_add<0x143, 0xc>(x);   // row_bcast:31 -> rows 2 and 3
+    return x;
+}
+
+// 16 bases -> LDS byte bins.  qv: 16 qualities (<= 127 each), (s0,s1): 16 read nibbles (no code 0),
+// P0: tile position of base 0 (>= -15), vmask: bases that belong to this segment and tile.
+__device__ __forceinline__ void narrow_classify(NarrowLds &L, const uint4 qv, const uint32_t s0, const uint32_t s1,
+                                                const int P0, const uint32_t vmask, const uint32_t kq) {
+    const uint32_t pr = (uint32_t)(P0 + 16);
+    const uint32_t wi = pr >> 3, sh = (pr & 7u) * 4u;
+    const uint32_t w0 = L.ref[wi], w1 = L.ref[wi + 1], w2 = L.ref[wi + 2];
+    const uint32_t r0 = __builtin_amdgcn_alignbit(w1, w0, sh), r1 = __builtin_amdgcn_alignbit(w2, w1, sh);
+    const uint32_t nm = nibflags_to_bits(nz_nibbles(s0 ^ r0)) | nibflags_to_bits(nz_nibbles(s1 ^ r1)) << 8;
+    const uint32_t l0 = ~(qv.x + kq) & 0x80808080u, l1 = ~(qv.y + kq) & 0x80808080u;
+    const uint32_t l2 = ~(qv.z + kq) & 0x80808080u, l3 = ~(qv.w + kq) & 0x80808080u;
+    const uint32_t lqa = __builtin_amdgcn_udot4(l1, 0x80402010u, __builtin_amdgcn_udot4(l0, 0x08040201u, 0u, false), false);
+    const uint32_t lqb = __builtin_amdgcn_udot4(l3, 0x80402010u, __builtin_amdgcn_udot4(l2, 0x08040201u, 0u, false), false);
+    const uint32_t lq = ((lqa >> 7) | (lqb << 1)) & vmask;            // lqa: bits 7..14, lqb: bits 7..14 -> 8..15
+    const uint32_t m = lq << (pr & 3u);                                // <= 19 bits, aligned to the byte-bin words
+    const uint32_t wb = pr >> 2;
+#pragma unroll
+    for (int w = 0; w < 5; ++w)
+        atomicAdd(&L.exc[wb + w], (((m >> (4 * w)) & 0xfu) * 0x00204081u) & 0x01010101u);
+    uint32_t e = nm & vmask & ~lq;
+    while (e) {
+        const uint32_t j = (uint32_t)__builtin_ctz(e);
+        e &= e - 1u;
+        const uint32_t ai = allele_index(((j < 8u ? s0 : s1) >> (4u * (j & 7u))) & 0xfu);
+        const uint32_t p = (uint32_t)(P0 + (int)j);
+        if (ai < 4u) atomicAdd(&L.al[p], 1u << (8u * ai));
+        else { const uint32_t pp = p + 16u; atomicAdd(&L.exc[pp >> 2], 1u << (8u * (pp & 3u))); }   // N / other IUPAC
+    }
+}
+
+__device__ __forceinline__ void narrow_flush_events(NarrowLds &L, const PileupArgs &a, int tid) {
+    const uint32_t n = min(L.evn, (uint32_t)N_EVCAP);
+    if (tid == 0) L.ev_base = n ? atomicAdd(&a.counters[0], n) : 0u;
+    __syncthreads();
+    const uint32_t base = L.ev_base;
+    for (uint32_t i = tid; i < n; i += N_NT)
+        if (base + i < a.cap_events) a.events[base + i] = L.ev[i];
+    __syncthreads();
+    if (tid == 0) L.evn = 0;
+}
+
+__device__ __forceinline__ void narrow_emit(NarrowLds &L, const PileupArgs &a, uint32_t gpos, uint32_t sample, uint32_t word) {
+    while (word) {                                                   // rare: a mismatching allele at this position
+        const uint32_t x = (uint32_t)__builtin_ctz(word) >> 3;
+        const uint32_t n = (word >> (8u * x)) & 0xffu;
+        word &= ~(0xffu << (8u * x));
+        atomicAdd(&a.tot[(uint64_t)(1u + x) * a.npos + gpos], n);
+        const Pair32 e{gpos, sample << 18 | x << 16 | n};
+        const uint32_t i = atomicAdd(&L.evn, 1u);
+        if (i < (uint32_t)N_EVCAP) L.ev[i] = e;
+        else { const uint32_t g = atomicAdd(&a.counters[0], 1u); if (g < a.cap_events) a.events[g] = e; }
+    }
+}
+
+__global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow(PileupArgs a) {
+    __shared__ NarrowLds L;
+    const WorkItem w = a.work[blockIdx.x];
+    const uint32_t t0 = w.tile * TILE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane8 = tid & (LANES_PER_READ - 1), grp = tid / LANES_PER_READ;
+    const uint32_t kq = 0x80808080u - min(a.min_baseq, 128u) * 0x01010101u;
+    const int b0 = 16 * lane8;
+
+    for (int i = tid; i < (int)(TILE / 8 + 4); i += N_NT) {
+        const long long wi = (long long)(t0 >> 3) + i - 2;
+        L.ref[i] = (wi >= 0 && (uint64_t)wi < a.npos / 8) ? a.ref4[wi] : 0xffffffffu;
+    }
+    for (int i = tid; i < (int)(TILE / 4 + 4); i += N_NT) { L.start[i] = 0; L.end[i] = 0; }
+    for (int i = tid; i < (int)(TILE / 4 + 16); i += N_NT) L.exc[i] = 0;
+    for (int i = tid; i < (int)TILE; i += N_NT) L.al[i] = 0;
+    if (tid == 0) L.evn = 0;
+
+    uint32_t tc[N_PPT];
+#pragma unroll
+    for (int j = 0; j < N_PPT; ++j) tc[j] = 0;
+
+    uint32_t k = w.pair_lo;
+    TilePair pr = (k < w.pair_hi) ? a.pairs[k] : TilePair{0, 0, 0, 0};
+    uint32_t rbeg = pr.read_lo;
+    uint4 hreg = make_uint4(0, 0, 0, 0);
+    if (k < w.pair_hi && tid < N_HCAP && rbeg + (uint32_t)tid < pr.read_hi)
+        hreg = *reinterpret_cast<const uint4 *>(a.hdr + a.s_read_base[pr.sample] + rbeg + tid);
+    int buf = 0;
+
+    while (k < w.pair_hi) {
+        const uint32_t nrd = min((uint32_t)N_HCAP, pr.read_hi - rbeg);
+        const bool last_chunk = rbeg + nrd >= pr.read_hi;
+        const uint32_t sample = pr.sample;
+        if (tid < N_HCAP) L.hdr[buf][tid] = hreg;                    // slots beyond nrd hold meta = 0
+        uint32_t nk = k, nrbeg = rbeg + nrd;
+        TilePair npr = pr;
+        if (last_chunk) { nk = k + 1; if (nk < w.pair_hi) { npr = a.pairs[nk]; nrbeg = npr.read_lo; } }
+        hreg = make_uint4(0, 0, 0, 0);
+        if (nk < w.pair_hi && tid < N_HCAP && nrbeg + (uint32_t)tid < npr.read_hi)
+            hreg = *reinterpret_cast<const uint4 *>(a.hdr + a.s_read_base[npr.sample] + nrbeg + tid);
+        __syncthreads();                                            // (A)
+
+        const uint8_t *seq = a.seq + a.s_seq_base[sample];
+        const uint8_t *qual = a.qual + 2 * a.s_seq_base[sample];
+
+        // ---- fast path, branch free: one 16-base chunk per lane and round, loads issued together
+        uint4 qv[N_ROUNDS]; uint2 sv[N_ROUNDS]; int P0[N_ROUNDS]; uint32_t vm[N_ROUNDS]; uint32_t slow = 0;
+#pragma unroll
+        for (int i = 0; i < N_ROUNDS; ++i) {
+            const uint4 h = L.hdr[buf][grp + i * N_GROUPS];
+            const bool fast = (h.w & META_FAST) != 0u;
+            slow |= ((h.w & (META_PILEUP_OK | META_FAST)) == META_PILEUP_OK) ? (1u << i) : 0u;
+            const int s = (int)(h.x - t0);                            // tile position of query base 0 (wraps correctly)
+            const int len = (int)(h.z >> 4);
+            const int lo = max(0, -s), hi = min(len, (int)TILE - s); // segment bases inside the tile: [lo, hi)
+            if (fast && lane8 == 0 && lo < hi) {
+                const uint32_t sa = (uint32_t)(s + lo), sb = (uint32_t)(s + hi);
+                atomicAdd(&L.start[sa >> 2], 1u << (8u * (sa & 3u)));
+                atomicAdd(&L.end[sb >> 2], 1u << (8u * (sb & 3u)));
+            }
+            __builtin_memcpy(&qv[i], qual + 2ull * h.y + (uint32_t)b0, 16);      // h.y = 0 for empty slots: safe address
+            __builtin_memcpy(&sv[i], seq + (uint64_t)h.y + (uint32_t)(b0 >> 1), 8);
+            const int vlo = min(max(lo - b0, 0), 16), vhi = min(max(hi - b0, 0), 16);
+            const uint32_t mk = ((1u << vhi) - 1u) & ~((1u << vlo) - 1u);           // empty when vhi <= vlo
+            vm[i] = fast ? mk : 0u;
+            P0[i] = vm[i] ? s + b0 : 0;                              // keeps every LDS index of an empty lane in range
+        }
+#pragma unroll
+        for (int i = 0; i < N_ROUNDS; ++i)
+            if (__any(vm[i] != 0u)) narrow_classify(L, qv[i], sv[i].x, sv[i].y, P0[i], vm[i], kq);
+
+        // ---- general path: several CIGAR ops or long reads
+        if (slow) {
+            const uint32_t *cigp = a.cig + a.s_cig_base[sample];
+#pragma unroll 1
+            for (int i = 0; i < N_ROUNDS; ++i) {
+                if (!(slow & (1u << i))) continue;
+                const uint4 h = L.hdr[buf][grp + i * N_GROUPS];
+                const uint32_t ncig = h.w & 0xffffu;
+                uint32_t q = 0, rp = h.x;
+                for (uint32_t ci = 0; ci < ncig; ++ci) {
+                    const uint32_t op = (ncig == 1) ? h.z : cigp[h.z + ci];
+                    const uint32_t len = op >> 4, type = op & 15u;
+                    if (type == C_M || type == C_EQ || type == C_X) {
+                        if (rp < t0 + TILE && rp + len > t0) {
+                            const uint32_t lo = (rp < t0) ? (t0 - rp) : 0u;
+                            const uint32_t hi = (rp + len > t0 + TILE) ? (t0 + TILE - rp) : len;
+                            if (lane8 == 0) {
+                                const uint32_t sa = rp + lo - t0, sb = rp + hi - t0;
+                                atomicAdd(&L.start[sa >> 2], 1u << (8u * (sa & 3u)));
+                                atomicAdd(&L.end[sb >> 2], 1u << (8u * (sb & 3u)));
+                            }
+                            const uint32_t qs = q + lo, qe = q + hi;
+                            for (uint32_t c = (qs >> 4) + (uint32_t)lane8; c <= ((qe - 1) >> 4); c += LANES_PER_READ) {
+                                uint4 qq; uint2 ss;
+                                __builtin_memcpy(&qq, qual + 2ull * h.y + 16ull * c, 16);
+                                __builtin_memcpy(&ss, seq + (uint64_t)h.y + 8ull * c, 8);
+                                const uint32_t c0 = 16u * c;
+                                const uint32_t vlo = (qs > c0) ? (qs - c0) : 0u, vhi = (qe < c0 + 16u) ? (qe - c0) : 16u;
+                                narrow_classify(L, qq, ss.x, ss.y, (int)(rp - t0) + (int)c0 - (int)q,
+                                                ((1u << vhi) - 1u) & ~((1u << vlo) - 1u), kq);
+                            }
+                        }
+                        q += len; rp += len;
+                    } else if (type == C_I || type == C_S) q += len;
+                    else if (type == C_D || type == C_N) rp += len;
+                }
+            }
+        }
+
+        if (last_chunk) {
+            __syncthreads();                                        // (B)
+            const uint2 st = *reinterpret_cast<uint2 *>(&L.start[2 * tid]);
+            const uint2 en = *reinterpret_cast<uint2 *>(&L.end[2 * tid]);
+            const uint2 ex = *reinterpret_cast<uint2 *>(&L.exc[2 * tid + 4]);
+            const uint4 a0 = *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid]);
+            const uint4 a1 = *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid + 4]);
+            *reinterpret_cast<uint2 *>(&L.start[2 * tid]) = make_uint2(0u, 0u);
+            *reinterpret_cast<uint2 *>(&L.end[2 * tid]) = make_uint2(0u, 0u);
+            *reinterpret_cast<uint2 *>(&L.exc[2 * tid + 4]) = make_uint2(0u, 0u);
+            if (tid == 0) { L.end[TILE / 4] = 0; L.exc[TILE / 4 + 4] = 0; }
+            const uint32_t anyal = a0.x | a0.y | a0.z | a0.w | a1.x | a1.y | a1.z | a1.w;
+            if (anyal) {
+                *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid]) = make_uint4(0u, 0u, 0u, 0u);
+                *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid + 4]) = make_uint4(0u, 0u, 0u, 0u);
+            }
+            const int mine = (int)(__builtin_amdgcn_udot4(st.x, 0x01010101u, __builtin_amdgcn_udot4(st.y, 0x01010101u, 0u, false), false)) -
+                             (int)(__builtin_amdgcn_udot4(en.x, 0x01010101u, __builtin_amdgcn_udot4(en.y, 0x01010101u, 0u, false), false));
+            const int incl = wave_inclusive_scan(mine);
+            if (lane == 63) L.wsum[wave] = incl;
+            __syncthreads();                                        // (C)
+            int d = incl - mine;
+            for (int wv = 0; wv < wave; ++wv) d += L.wsum[wv];
+            uint32_t packed[2] = {0u, 0u};
+#pragma unroll
+            for (int j = 0; j < N_PPT; ++j) {
+                const uint32_t sw = (j < 4) ? st.x : st.y, ew = (j < 4) ? en.x : en.y, xw = (j < 4) ? ex.x : ex.y;
+                d += (int)((sw >> (8 * (j & 3))) & 0xffu) - (int)((ew >> (8 * (j & 3))) & 0xffu);
+                const uint32_t cov = (uint32_t)d - ((xw >> (8 * (j & 3))) & 0xffu);
+                tc[j] += cov;
+                packed[j >> 2] |= (cov & 0xffu) << (8 * (j & 3));
+            }
+            *reinterpret_cast<uint2 *>(a.spill + (uint64_t)k * TILE + N_PPT * tid) = make_uint2(packed[0], packed[1]);
+            if (anyal) {
+                const uint32_t g0 = t0 + N_PPT * tid;
+                narrow_emit(L, a, g0 + 0, sample, a0.x); narrow_emit(L, a, g0 + 1, sample, a0.y);
+                narrow_emit(L, a, g0 + 2, sample, a0.z); narrow_emit(L, a, g0 + 3, sample, a0.w);
+                narrow_emit(L, a, g0 + 4, sample, a1.x); narrow_emit(L, a, g0 + 5, sample, a1.y);
+                narrow_emit(L, a, g0 + 6, sample, a1.z); narrow_emit(L, a, g0 + 7, sample, a1.w);
+            }
+        }
+        k = nk; pr = npr; rbeg = nrbeg; buf ^= 1;
+        if (last_chunk && k < w.pair_hi) {
+            __syncthreads();
+            if (L.evn >= (uint32_t)(N_EVCAP / 2)) narrow_flush_events(L, a, tid);
+        }
+    }
+    __syncthreads();
+    narrow_flush_events(L, a, tid);
+#pragma unroll
+    for (int j = 0; j < N_PPT; ++j)
+        if (tc[j]) atomicAdd(&a.tot[(uint64_t)t0 + N_PPT * tid + j], tc[j]);
+}
+
+// ------------------------------------------------------------------------------------------
 // msnv_gate_sites: snpCall's two gates (call_vC.cpp:545-552) plus the necessary condition of
 // both call kinds (some allele total >= calling_threshold).  One workgroup per tile; survivors
 // are written in position order to a contiguous range reserved with one atomic per tile.
@@ -638,8 +910,18 @@ int dev_run_pipeline(DeviceCols &d, const msnv_params &p, void *stream_, msnv_ru
         a.events = d.events; a.cap_events = d.cap_events; a.overflow = d.overflow; a.cap_overflow = d.cap_overflow;
         a.counters = d.counters; a.min_baseq = (uint32_t)std::max(0, p.min_baseq);
         static const bool use_v1 = [] { const char *e = getenv("MSNV_PILEUP"); return e && e[0] == 'v' && e[1] == '1'; }();
+        static const bool use_v2 = [] { const char *e = getenv("MSNV_PILEUP"); return e && e[0] == 'v' && e[1] == '2'; }();
         if (use_v1) hipLaunchKernelGGL(msnv_pileup_tiles_v1, dim3(d.n_work), dim3(PILEUP_NT), 0, st, a);
-        else hipLaunchKernelGGL(msnv_pileup_tiles, dim3(d.n_work), dim3(PILEUP_NT), 0, st, a);
+        else if (use_v2) hipLaunchKernelGGL(msnv_pileup_tiles, dim3(d.n_work), dim3(PILEUP_NT), 0, st, a);
+        else {
+            // narrow work items (byte bins) first, wide ones (16-bit bins) after; they touch disjoint pairs
+            if (d.n_work_narrow) hipLaunchKernelGGL(msnv_pileup_tiles_narrow, dim3(d.n_work_narrow), dim3(N_NT), 0, st, a);
+            if (d.n_work > d.n_work_narrow) {
+                PileupArgs b = a;
+                b.work = d.work + d.n_work_narrow;
+                hipLaunchKernelGGL(msnv_pileup_tiles, dim3(d.n_work - d.n_work_narrow), dim3(PILEUP_NT), 0, st, b);
+            }
+        }
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(ev[2], st));

@@ -21,6 +21,36 @@ void synth_sample_records(const msnv_synth_params &p, int sample, const std::vec
 static inline bool consumes_ref(uint32_t t) { return t == C_M || t == C_D || t == C_N || t == C_EQ || t == C_X; }
 static inline bool consumes_query(uint32_t t) { return t == C_M || t == C_I || t == C_S || t == C_EQ || t == C_X; }
 
+static bool has_eq_code(const uint8_t *seq, int l_seq) {
+    for (int i = 0; i < l_seq; ++i) if (((seq[i >> 1] >> ((~i & 1) << 2)) & 0xf) == 0) return true;
+    return false;
+}
+
+// A read base stored as '=' (nt16 code 0) always counts as a match in mpileup (pileup_seq: `c == '='`).
+// The device kernels test "read code == reference code" only, so the host replaces every '=' that sits
+// in an M/=/X segment by the reference code of its position (N where the FASTA has no base): same result,
+// one test less per base on the device.  Bases outside M/=/X segments are never looked at.
+static void rewrite_eq_codes(const msnv_dataset &ds, const RecView &r, uint8_t *packed /* low nibble first */) {
+    const std::string &ref = ds.seqs[(size_t)r.tid];
+    const bool has = ds.has_seq[(size_t)r.tid];
+    int64_t rp = r.pos; int q = 0;
+    for (int k = 0; k < r.n_cigar; ++k) {
+        const uint32_t c = ld_u32(r.cigar + 4 * k), t = c & 15u, l = c >> 4;
+        if (t == C_M || t == C_EQ || t == C_X) {
+            for (uint32_t j = 0; j < l; ++j, ++q, ++rp) {
+                const int sh = (q & 1) * 4;
+                if (((packed[q >> 1] >> sh) & 0xf) == 0) {
+                    const uint8_t code = (has && rp >= 0 && (size_t)rp < ref.size()) ? nt16_of_char((unsigned char)ref[(size_t)rp]) : 15;
+                    packed[q >> 1] = (uint8_t)((packed[q >> 1] & ~(0xf << sh)) | (code ? code : 15) << sh);
+                }
+            }
+        } else {
+            if (consumes_ref(t)) rp += l;
+            if (consumes_query(t)) q += (int)l;
+        }
+    }
+}
+
 // Packs one sample.  `ds` supplies contig selection, BED and parameters.
 int pack_sample(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, SampleCols &sc) {
     const msnv_params &P = ds.params;
@@ -86,14 +116,18 @@ int pack_sample(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, Sa
             first_push_done = true; ++nth_at_pos;
             if (capped) pile_ok = false; else live.push(endpos);
         }
+        const uint16_t depth_here = (uint16_t)std::min<size_t>(live.size(), 0xffff);
         if (!pile_ok && !cov_ok) continue;
 
-        if (r.n_cigar > 0xffff) return fail(MSNV_EFORMAT, "reads with more than 65535 CIGAR operations are not supported");
         ReadHdr h;
         h.gpos = (uint32_t)r.pos;            // contig-relative until finalize
         h.seqoff = 0;
         h.meta = (uint32_t)r.n_cigar | (uint32_t)r.mapq << 16 | (pile_ok ? META_PILEUP_OK : 0u) | (cov_ok ? META_COV_OK : 0u);
-        if (r.n_cigar == 1) h.cig = ld_u32(r.cigar);
+        if (r.n_cigar == 1) {
+            h.cig = ld_u32(r.cigar);
+            const uint32_t t = h.cig & 15u;
+            if (pile_ok && (t == C_M || t == C_EQ || t == C_X) && (h.cig >> 4) <= 128u) h.meta |= META_FAST;
+        }
         else {
             h.cig = (uint32_t)sc.cig.size();
             for (int k = 0; k < r.n_cigar; ++k) sc.cig.push_back(ld_u32(r.cigar + 4 * k));
@@ -108,8 +142,11 @@ int pack_sample(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, Sa
                 for (int64_t i = 0; i < ((qlen + 1) / 2) * 2; ++i) sc.qual.push_back(0);
             } else {
                 for (int i = 0; i < nb; ++i) { uint8_t b = r.seq[i]; sc.seq.push_back((uint8_t)(b >> 4 | b << 4)); }   // low nibble first
+                if (has_eq_code(r.seq, r.l_seq)) rewrite_eq_codes(ds, r, sc.seq.data() + h.seqoff);
                 if (r.l_seq & 1) sc.seq.back() |= 0xf0;        // pad nibble = N
-                sc.qual.insert(sc.qual.end(), r.qual, r.qual + r.l_seq);
+                // qualities above 127 (0xff = "not stored") pass every cutoff mpileup accepts; clamping them to
+                // 127 keeps the comparison result and lets the device test four bytes with one add
+                for (int i = 0; i < r.l_seq; ++i) sc.qual.push_back(r.qual[i] > 127 ? 127 : r.qual[i]);
                 if (r.l_seq & 1) sc.qual.push_back(0);
             }
             sc.n_pileup_bases += (uint64_t)m_bases;
@@ -123,6 +160,7 @@ int pack_sample(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, Sa
         }
         sc.hdr.push_back(h);
         sc.tid.push_back(r.tid);
+        sc.depth.push_back(pile_ok ? depth_here : 0);
         sc.end.push_back((int32_t)std::max<int64_t>(pile_ok ? endpos : 0, cov_ok ? qa_end + 1 : 0));
     }
     // tail padding: kernels read 16 B (qual) / 8 B (seq) chunks and may run past the last read
@@ -208,7 +246,7 @@ int finalize_dataset(msnv_dataset &ds) {
         cbase[s + 1] = cbase[s] + ds.samples[s].cig.size();
         sbase[s + 1] = sbase[s] + ((ds.samples[s].seq.size() + 15) & ~(size_t)15);
     }
-    struct PairTmp { uint32_t tile, sample, lo, hi, nok; };
+    struct PairTmp { uint32_t tile, sample, lo, hi, maxd; };
     std::vector<std::vector<PairTmp>> per_sample(S);
     ds.first_tid = -1; ds.first_pos = -1;
     uint64_t tot_reads = 0, tot_pile_reads = 0, tot_bases = 0;
@@ -231,11 +269,16 @@ int finalize_dataset(msnv_dataset &ds) {
                 size_t k = pv.size();
                 while (k > 0 && pv[k - 1].tile > t) --k;
                 if (k > 0 && pv[k - 1].tile == t) {
-                    pv[k - 1].hi = (uint32_t)i + 1; pv[k - 1].nok++;
+                    pv[k - 1].hi = (uint32_t)i + 1;
                 } else {
-                    pv.insert(pv.begin() + (ptrdiff_t)k, PairTmp{t, (uint32_t)s, (uint32_t)i, (uint32_t)i + 1, 1});
+                    pv.insert(pv.begin() + (ptrdiff_t)k, PairTmp{t, (uint32_t)s, (uint32_t)i, (uint32_t)i + 1, 0});
                 }
             }
+        }
+        for (PairTmp &p : pv) {       // depth bound: every read alive inside the tile was alive when one of [lo,hi) started
+            uint32_t m = 0;
+            for (uint32_t i = p.lo; i < p.hi; ++i) m = std::max<uint32_t>(m, sc.depth[i]);
+            p.maxd = m;
         }
         tot_reads += sc.hdr.size(); tot_pile_reads += sc.n_pileup_reads; tot_bases += sc.n_pileup_bases;
         if (sc.first_tid >= 0 && (ds.first_tid < 0 || sc.first_tid < ds.first_tid || (sc.first_tid == ds.first_tid && sc.first_beg < ds.first_pos))) {
@@ -250,7 +293,10 @@ int finalize_dataset(msnv_dataset &ds) {
     {
         std::vector<uint32_t> fill(tps.begin(), tps.end() - 1);
         for (size_t s = 0; s < S; ++s)
-            for (const PairTmp &p : per_sample[s]) pairs[fill[p.tile]++] = TilePair{p.sample, p.lo, p.hi, p.nok};
+            for (const PairTmp &p : per_sample[s]) pairs[fill[p.tile]++] = TilePair{p.sample, p.lo, p.hi, p.maxd};
+        // inside a tile: narrow pairs (every per-position count fits a byte) first, then wide ones
+        for (uint64_t t = 0; t < nt; ++t)
+            std::stable_partition(pairs.begin() + tps[t], pairs.begin() + tps[t + 1], [](const TilePair &p) { return p.max_depth < NARROW_MAX_DEPTH; });
     }
     // ---- work list: split each tile's pairs so that work items carry similar read counts
     std::vector<WorkItem> work;
@@ -258,14 +304,19 @@ int finalize_dataset(msnv_dataset &ds) {
         uint64_t total_reads_in_pairs = 0;
         for (const TilePair &p : pairs) total_reads_in_pairs += p.read_hi - p.read_lo;
         const uint64_t target = std::max<uint64_t>(1500, total_reads_in_pairs / 6144);
+        std::vector<WorkItem> wide;
         for (uint64_t t = 0; t < nt; ++t) {
             uint32_t lo = tps[t];
             uint64_t acc = 0;
             for (uint32_t k = tps[t]; k < tps[t + 1]; ++k) {
                 acc += pairs[k].read_hi - pairs[k].read_lo;
-                if (acc >= target || k + 1 == tps[t + 1]) { work.push_back(WorkItem{(uint32_t)t, lo, k + 1, 0}); lo = k + 1; acc = 0; }
+                const bool narrow = pairs[k].max_depth < NARROW_MAX_DEPTH;
+                const bool boundary = k + 1 == tps[t + 1] || (narrow != (pairs[k + 1].max_depth < NARROW_MAX_DEPTH));
+                if (acc >= target || boundary) { (narrow ? work : wide).push_back(WorkItem{(uint32_t)t, lo, k + 1, 0}); lo = k + 1; acc = 0; }
             }
         }
+        d->n_work_narrow = (uint32_t)work.size();
+        work.insert(work.end(), wide.begin(), wide.end());
     }
     d->n_pairs = (uint32_t)pairs.size(); d->n_work = (uint32_t)work.size();
     if (int rc = upload_vec(&d->pairs, pairs, &d->device_bytes)) return rc;
