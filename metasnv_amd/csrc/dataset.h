@@ -26,14 +26,19 @@ constexpr uint32_t TILE = 2048;          // reference positions per tile (LDS bi
 // meta: bits 0-15 n_cigar | 16-23 mapq | 24 pileup_ok | 25 cov_ok | 26 fast
 constexpr uint32_t META_PILEUP_OK = 1u << 24;
 constexpr uint32_t META_COV_OK    = 1u << 25;
-constexpr uint32_t META_FAST      = 1u << 26;   // pileup_ok, exactly one M/=/X op of at most 128 bases
+constexpr uint32_t SEG_MAX = 128;            // bases per segment piece = 8 lanes x 16 bases
 constexpr uint32_t NARROW_MAX_DEPTH = 255;   // (tile, sample) pairs below this depth use byte-wide LDS bins
 
 struct ReadHdr { uint32_t gpos, seqoff, cig, meta; };
 
 struct TilePair { uint32_t sample, read_lo, read_hi, max_depth; };    // reads of `sample` that may overlap the tile;
                                                                         // max_depth = upper bound of the per-position depth
-struct WorkItem { uint32_t tile, pair_lo, pair_hi, pad; };
+struct WorkItem { uint32_t tile, pair_lo, pair_hi, chunk_lo, chunk_hi, pad[3]; };
+// One chunk = up to CHUNK_READS consecutive reads of one (tile, sample) pair, with everything the
+// kernel needs to start loading (no dependent scalar loads on the critical path).
+constexpr uint32_t CHUNK_READS = 128;
+constexpr uint32_t MAX_CHUNKS_PER_ITEM = 64;
+struct ChunkDesc { uint64_t hdr_base, seq_base; uint32_t sample, pair, nrd_flags, pad; };   // nrd | last_chunk << 16
 
 struct SiteRec { uint32_t gpos, cov, n[4]; };                          // gate kernel output (24 B)
 
@@ -43,8 +48,8 @@ struct SampleCols {
     std::vector<int32_t>  tid;       // per read
     std::vector<int32_t>  end;       // per read: contig-relative end of everything the kernels may touch
     std::vector<uint16_t> depth;     // per read: pileup reads alive when this one starts (saturating)
-    std::vector<uint32_t> cig;
     std::vector<uint8_t>  seq, qual;
+    std::vector<int32_t>  cov_tid, cov_beg, cov_end;   // qaCompute M intervals (index space), reads that pass its filter
     uint64_t n_pileup_bases = 0, n_pileup_reads = 0;
     int32_t  first_tid = -1, first_beg = 0, first_end = 0;   // first pileup_ok read (first-line quirk)
     // qaCompute "Other" statistics (qaCompute.cpp:642-654)

@@ -12,18 +12,18 @@ struct Pair32 { uint32_t x, y; };
 struct DeviceCols {
     // ---- inputs (uploaded once by finalize)
     ReadHdr  *hdr = nullptr;
-    uint32_t *cig = nullptr;
     uint8_t  *seq = nullptr;
     uint8_t  *qual = nullptr;
-    uint64_t *s_read_base = nullptr, *s_cig_base = nullptr, *s_seq_base = nullptr;   // per sample
+    uint64_t *s_read_base = nullptr, *s_seq_base = nullptr;   // per sample
     uint32_t *ref4 = nullptr;        // nt16 codes, 8 positions per word, low nibble = lowest position
     uint32_t *ref_lc = nullptr;      // 1 bit per position: FASTA char is a lower-case a/c/g/t
     TilePair *pairs = nullptr;
     uint32_t *tile_pair_start = nullptr;   // n_tiles + 1
     WorkItem *work = nullptr;
+    ChunkDesc *chunks = nullptr;
     uint32_t *tile_vbeg = nullptr, *tile_vend = nullptr;   // callable range inside each tile (BED / contig)
     uint32_t  n_tiles = 0, n_pairs = 0, n_work = 0, n_work_narrow = 0, n_samples = 0;   // work[0..n_work_narrow) = narrow items
-    uint64_t  n_reads = 0, n_cig = 0, n_seq_bytes = 0;
+    uint64_t  n_reads = 0, n_seq_bytes = 0;
     // ---- intermediates
     uint32_t *tot = nullptr;         // [5][n_tiles*TILE]: cov, A, C, G, T summed over samples
     uint8_t  *spill = nullptr;       // [n_pairs][TILE] per-sample coverage, saturating at 255

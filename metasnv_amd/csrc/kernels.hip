@@ -27,20 +27,18 @@ namespace msnv {
         if (e_ != hipSuccess) return fail(MSNV_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
-constexpr int PILEUP_NT = 512;                 // threads per pileup workgroup (8 waves)
-constexpr int PPT = TILE / PILEUP_NT;          // positions owned by each thread in the per-sample pass
-static_assert(PPT == 4, "per-sample pass is written for 4 consecutive positions per thread");
-constexpr int LANES_PER_READ = 8;              // 8 lanes x 16 bases cover a 100-128 bp read in one step
+constexpr int LANES_PER_READ = 8;              // 8 lanes x 16 bases = one segment piece (<= SEG_MAX bases)
+static_assert(LANES_PER_READ * 16 == SEG_MAX, "segment pieces are sized for 8 lanes of 16 bases");
 
 struct PileupArgs {
-    const ReadHdr  *hdr;
-    const uint32_t *cig;
+    const ReadHdr  *hdr;          // one 16-byte header per M/=/X segment piece: {gpos, seqoff, length, meta}
     const uint8_t  *seq;
     const uint8_t  *qual;
-    const uint64_t *s_read_base, *s_cig_base, *s_seq_base;
+    const uint64_t *s_read_base, *s_seq_base;
     const uint32_t *ref4;
     const TilePair *pairs;
     const WorkItem *work;
+    const ChunkDesc *chunks;
     uint32_t       *tot;          // [5][npos]
     uint64_t        npos;
     uint8_t        *spill;
@@ -48,164 +46,13 @@ struct PileupArgs {
     Pair32         *overflow; uint32_t cap_overflow;
     uint32_t       *counters;
     uint32_t        min_baseq;
+    uint32_t        ablate;       // timing experiments only (MSNV_ABLATE); 0 in production
 };
 
 // allele index (A,C,G,T -> 0..3) of a one-hot nt16 code, 4 for anything else
 __device__ __forceinline__ uint32_t allele_index(uint32_t code) {
-    // 1->0, 2->1, 4->2, 8->3
     return (code == 1u) ? 0u : (code == 2u) ? 1u : (code == 4u) ? 2u : (code == 8u) ? 3u : 4u;
 }
-
-// ------------------------------------------------------------------------------------------
-// msnv_pileup_tiles_v1 (first correct version, kept for A/B: MSNV_PILEUP=v1): for one work item = (tile, range of (tile,sample) pairs):
-//   for every sample: scatter the sample's reads into LDS bins (match count + 4 allele counts
-//   per position), then one pass over the tile's positions adds the sample to the running
-//   totals (registers), spills the per-sample coverage byte and emits the sparse allele events.
-// Algorithmic HBM bytes: 16 B header + 4 B per extra CIGAR op + 0.5 B/base seq + 1 B/base qual.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PILEUP_NT) void msnv_pileup_tiles_v1(PileupArgs a) {
-    __shared__ uint32_t s_m[TILE / 2];                 // match counts, two u16 per word
-    __shared__ unsigned long long s_al[TILE];          // allele counts, four u16 (A,C,G,T) per position
-    __shared__ uint32_t s_ref[TILE / 8];               // nt16 reference codes of the tile
-
-    const WorkItem w = a.work[blockIdx.x];
-    const uint32_t t0 = w.tile * TILE;
-    const int tid = threadIdx.x;
-    const int lane8 = tid & (LANES_PER_READ - 1);
-
-    for (int i = tid; i < (int)(TILE / 8); i += PILEUP_NT) s_ref[i] = a.ref4[(t0 >> 3) + i];
-    for (int i = tid; i < (int)(TILE / 2); i += PILEUP_NT) s_m[i] = 0;
-    for (int i = tid; i < (int)TILE; i += PILEUP_NT) s_al[i] = 0;
-
-    uint32_t tc[PPT], tn[PPT][4];
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) { tc[j] = 0; tn[j][0] = tn[j][1] = tn[j][2] = tn[j][3] = 0; }
-    __syncthreads();
-
-    for (uint32_t k = w.pair_lo; k < w.pair_hi; ++k) {
-        const TilePair pr = a.pairs[k];
-        const ReadHdr *hdr = a.hdr + a.s_read_base[pr.sample];
-        const uint32_t *cigp = a.cig + a.s_cig_base[pr.sample];
-        const uint8_t *seq = a.seq + a.s_seq_base[pr.sample];
-        const uint8_t *qual = a.qual + 2 * a.s_seq_base[pr.sample];
-
-        for (uint32_t r = pr.read_lo + (uint32_t)(tid / LANES_PER_READ); r < pr.read_hi; r += PILEUP_NT / LANES_PER_READ) {
-            const uint4 h = *reinterpret_cast<const uint4 *>(hdr + r);
-            if (!(h.w & META_PILEUP_OK)) continue;
-            const uint32_t ncig = h.w & 0xffffu;
-            uint32_t q = 0;             // query cursor
-            uint32_t rp = h.x;          // reference cursor (gpos)
-            for (uint32_t ci = 0; ci < ncig; ++ci) {
-                const uint32_t op = (ncig == 1) ? h.z : cigp[h.z + ci];
-                const uint32_t len = op >> 4, type = op & 15u;
-                if (type == C_M || type == C_EQ || type == C_X) {
-                    // query [q, q+len) <-> reference [rp, rp+len); clip to the tile
-                    const uint32_t lo = (rp < t0) ? (t0 - rp) : 0u;
-                    const uint32_t hi = (rp + len > t0 + TILE) ? (t0 + TILE - rp) : len;
-                    if (rp < t0 + TILE && rp + len > t0 && lo < hi) {
-                        const uint32_t qs = q + lo, qe = q + hi;
-                        for (uint32_t c = (qs >> 4) + (uint32_t)lane8; c <= ((qe - 1) >> 4); c += LANES_PER_READ) {
-                            const uint8_t *qp = qual + 2ull * h.y + 16ull * c;
-                            const uint8_t *sp = seq + (uint64_t)h.y + 8ull * c;
-                            uint4 qv; uint2 sv;
-                            __builtin_memcpy(&qv, qp, 16);
-                            __builtin_memcpy(&sv, sp, 8);
-                            const uint32_t qw[4] = {qv.x, qv.y, qv.z, qv.w};
-                            const uint32_t sw[2] = {sv.x, sv.y};
-#pragma unroll
-                            for (int j = 0; j < 16; ++j) {
-                                const uint32_t qq = 16u * c + (uint32_t)j;
-                                if (qq < qs || qq >= qe) continue;
-                                const uint32_t bq = (qw[j >> 2] >> (8 * (j & 3))) & 0xffu;
-                                if (bq < a.min_baseq) continue;
-                                const uint32_t code = (sw[j >> 3] >> (4 * (j & 7))) & 0xfu;
-                                const uint32_t p = rp + (qq - q) - t0;               // position inside the tile
-                                const uint32_t rc = (s_ref[p >> 3] >> (4 * (p & 7))) & 0xfu;
-                                if (code == 0u || code == rc) {
-                                    atomicAdd(&s_m[p >> 1], 1u << (16 * (p & 1)));
-                                } else {
-                                    const uint32_t ai = allele_index(code);
-                                    if (ai < 4u) atomicAdd(&s_al[p], 1ull << (16 * ai));
-                                }
-                            }
-                        }
-                    }
-                    q += len; rp += len;
-                } else if (type == C_I || type == C_S) {
-                    q += len;
-                } else if (type == C_D || type == C_N) {
-                    rp += len;
-                }
-            }
-        }
-        __syncthreads();
-
-        // ---- per-sample pass over the tile: thread owns positions 4*tid .. 4*tid+3
-        {
-            uint2 m = *reinterpret_cast<uint2 *>(&s_m[2 * tid]);
-            unsigned long long al[PPT];
-#pragma unroll
-            for (int j = 0; j < PPT; ++j) al[j] = s_al[PPT * tid + j];
-            *reinterpret_cast<uint2 *>(&s_m[2 * tid]) = make_uint2(0u, 0u);
-#pragma unroll
-            for (int j = 0; j < PPT; ++j) s_al[PPT * tid + j] = 0ull;
-
-            const uint32_t mm[PPT] = {m.x & 0xffffu, m.x >> 16, m.y & 0xffffu, m.y >> 16};
-            uint32_t packed = 0;
-#pragma unroll
-            for (int j = 0; j < PPT; ++j) {
-                const uint32_t n0 = (uint32_t)(al[j] & 0xffffu), n1 = (uint32_t)((al[j] >> 16) & 0xffffu);
-                const uint32_t n2 = (uint32_t)((al[j] >> 32) & 0xffffu), n3 = (uint32_t)(al[j] >> 48);
-                const uint32_t cov = mm[j] + n0 + n1 + n2 + n3;
-                tc[j] += cov; tn[j][0] += n0; tn[j][1] += n1; tn[j][2] += n2; tn[j][3] += n3;
-                packed |= (cov < 255u ? cov : 255u) << (8 * j);
-                const uint32_t gpos = t0 + PPT * tid + j;
-                if (cov >= 255u) {
-                    const uint32_t idx = atomicAdd(&a.counters[1], 1u);
-                    if (idx < a.cap_overflow) a.overflow[idx] = Pair32{gpos, pr.sample << 16 | (cov & 0xffffu)};
-                }
-                if (al[j] != 0ull) {
-                    const uint32_t nn[4] = {n0, n1, n2, n3};
-#pragma unroll
-                    for (int x = 0; x < 4; ++x)
-                        if (nn[x]) {
-                            const uint32_t idx = atomicAdd(&a.counters[0], 1u);
-                            if (idx < a.cap_events) a.events[idx] = Pair32{gpos, pr.sample << 18 | (uint32_t)x << 16 | nn[x]};
-                        }
-                }
-            }
-            *reinterpret_cast<uint32_t *>(a.spill + (uint64_t)k * TILE + PPT * tid) = packed;
-        }
-        __syncthreads();
-    }
-
-    // ---- flush this work item's totals (several work items may share a tile)
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-        const uint64_t g = (uint64_t)t0 + PPT * tid + j;
-        if (tc[j]) atomicAdd(&a.tot[g], tc[j]);
-#pragma unroll
-        for (int x = 0; x < 4; ++x)
-            if (tn[j][x]) atomicAdd(&a.tot[(uint64_t)(1 + x) * a.npos + g], tn[j][x]);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// msnv_pileup_tiles (v2): same contract as v1, restructured around what is RARE.
-//   * coverage comes from a difference array: +1/-1 per M/=/X segment (2 LDS atomics per read
-//     instead of one per base), prefix-summed once per sample;
-//   * a lane classifies 16 bases at a time with SWAR arithmetic (BQ test on 4 packed bytes,
-//     read-vs-reference test on 8 packed nibbles, udot4 to compress the flags) and only the
-//     EXCEPTIONS touch LDS: bases below the BQ cutoff / N (subtracted from the span coverage)
-//     and mismatching A/C/G/T bases (the allele counts);
-//   * read headers of the next chunk are prefetched into registers while the current chunk is
-//     processed and handed over through LDS;
-//   * allele events and >=255 coverages are staged in LDS and reserved in global memory with
-//     one atomic per flush (a single global counter saturates at ~90 returning atomics/us).
-// ------------------------------------------------------------------------------------------
-constexpr int HCAP = 256;                      // read headers staged per chunk
-constexpr int EVCAP = 1024;                    // LDS event staging entries
-
 __device__ __forceinline__ uint32_t nz_nibbles(uint32_t x) {       // bit 4j+3 set iff nibble j != 0
     return (((x & 0x77777777u) + 0x77777777u) | x) & 0x88888888u;
 }
@@ -213,257 +60,15 @@ __device__ __forceinline__ uint32_t nibflags_to_bits(uint32_t f) {  // bit 4j+3 
     const uint32_t e = f & 0x08080808u, o = (f >> 4) & 0x08080808u;
     return (__builtin_amdgcn_udot4(o, 0x80200802u, __builtin_amdgcn_udot4(e, 0x40100401u, 0u, false), false)) >> 3;
 }
-
-struct TileLds {
-    int32_t  span[TILE + 4];
-    uint32_t exc[TILE / 2];                    // two u16 per word
-    unsigned long long al[TILE];               // four u16 (A,C,G,T)
-    uint32_t ref[TILE / 8 + 4];                // 2 halo words (16 positions) on each side
-    uint4    hdr[2][HCAP];
-    Pair32   ev[EVCAP];
-    int32_t  wsum[PILEUP_NT / 64];
-    uint32_t evn, ev_base;
-};
-
-__device__ __forceinline__ void stage_event(TileLds &L, const PileupArgs &a, uint32_t kind, Pair32 e) {
-    // kind 0: allele event -> a.events / counters[0]; kind 1: coverage overflow -> a.overflow / counters[1]
-    if (kind == 0) {
-        const uint32_t i = atomicAdd(&L.evn, 1u);
-        if (i < (uint32_t)EVCAP) { L.ev[i] = e; return; }
-        const uint32_t g = atomicAdd(&a.counters[0], 1u);          // staging full: slow path
-        if (g < a.cap_events) a.events[g] = e;
-    } else {
-        const uint32_t g = atomicAdd(&a.counters[1], 1u);
-        if (g < a.cap_overflow) a.overflow[g] = e;
-    }
-}
-
-__device__ __forceinline__ void flush_events(TileLds &L, const PileupArgs &a, int tid) {
-    // called by all threads between barriers
-    const uint32_t n = min(L.evn, (uint32_t)EVCAP);
-    if (tid == 0) L.ev_base = n ? atomicAdd(&a.counters[0], n) : 0u;
-    __syncthreads();
-    const uint32_t base = L.ev_base;
-    for (uint32_t i = tid; i < n; i += PILEUP_NT)
-        if (base + i < a.cap_events) a.events[base + i] = L.ev[i];
-    __syncthreads();
-    if (tid == 0) L.evn = 0;
-}
-
-// 16 bases of one M/=/X segment: qv = 16 quality bytes, (s0,s1) = 16 read nibbles, P0 = position of
-// base 0 inside the tile (may be negative / beyond the tile: vmask removes those bases).
-__device__ __forceinline__ void classify_chunk(TileLds &L, const uint4 qv, const uint32_t s0, const uint32_t s1,
-                                               const int P0, const uint32_t vmask, const uint32_t kq) {
-    const int pr = P0 + 16;                                   // >= 1 for every chunk that reaches here
-    const uint32_t wi = (uint32_t)pr >> 3, sh = ((uint32_t)pr & 7u) * 4u;
-    const uint32_t w0 = L.ref[wi], w1 = L.ref[wi + 1], w2 = L.ref[wi + 2];
-    const uint32_t r0 = __builtin_amdgcn_alignbit(w1, w0, sh), r1 = __builtin_amdgcn_alignbit(w2, w1, sh);
-    // mismatch = read nibble != reference nibble and read nibble != '=' (code 0)
-    const uint32_t nm = nibflags_to_bits(nz_nibbles(s0 ^ r0) & nz_nibbles(s0)) |
-                        nibflags_to_bits(nz_nibbles(s1 ^ r1) & nz_nibbles(s1)) << 8;
-    // low quality = byte < min_baseq  (kq = 0x80808080 - min_baseq * 0x01010101)
-    const uint32_t l0 = ~(((qv.x & 0x7f7f7f7fu) + kq) | qv.x) & 0x80808080u;
-    const uint32_t l1 = ~(((qv.y & 0x7f7f7f7fu) + kq) | qv.y) & 0x80808080u;
-    const uint32_t l2 = ~(((qv.z & 0x7f7f7f7fu) + kq) | qv.z) & 0x80808080u;
-    const uint32_t l3 = ~(((qv.w & 0x7f7f7f7fu) + kq) | qv.w) & 0x80808080u;
+// 16 quality bytes (each <= 127, host clamps) -> 16-bit mask of bytes below the cutoff
+// kq = 0x80808080 - min_baseq * 0x01010101: bit 7 of (byte + kq) is set iff byte >= min_baseq
+__device__ __forceinline__ uint32_t lowq_mask(const uint4 qv, const uint32_t kq) {
+    const uint32_t l0 = ~(qv.x + kq) & 0x80808080u, l1 = ~(qv.y + kq) & 0x80808080u;
+    const uint32_t l2 = ~(qv.z + kq) & 0x80808080u, l3 = ~(qv.w + kq) & 0x80808080u;
     const uint32_t lqa = __builtin_amdgcn_udot4(l1, 0x80402010u, __builtin_amdgcn_udot4(l0, 0x08040201u, 0u, false), false);
     const uint32_t lqb = __builtin_amdgcn_udot4(l3, 0x80402010u, __builtin_amdgcn_udot4(l2, 0x08040201u, 0u, false), false);
-    const uint32_t lq = ((lqa >> 7) & 0xffu) | ((lqb >> 7) & 0xffu) << 8;
-    uint32_t e = (lq | nm) & vmask;
-    while (e) {
-        const uint32_t j = (uint32_t)__builtin_ctz(e);
-        e &= e - 1u;
-        const uint32_t p = (uint32_t)(P0 + (int)j);
-        uint32_t ai = 4u;
-        if (!((lq >> j) & 1u)) ai = allele_index(((j < 8u ? s0 : s1) >> (4u * (j & 7u))) & 0xfu);
-        if (ai < 4u) atomicAdd(&L.al[p], 1ull << (16u * ai));
-        else atomicAdd(&L.exc[p >> 1], 1u << (16u * (p & 1u)));     // not counted: low BQ, N, other IUPAC
-    }
+    return ((lqa >> 7) & 0xffu) | ((lqb << 1) & 0xff00u);
 }
-
-__global__ __launch_bounds__(PILEUP_NT) void msnv_pileup_tiles(PileupArgs a) {
-    __shared__ TileLds L;
-    const WorkItem w = a.work[blockIdx.x];
-    const uint32_t t0 = w.tile * TILE;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lane8 = tid & (LANES_PER_READ - 1), grp = tid / LANES_PER_READ;
-    const uint32_t kq = 0x80808080u - min(a.min_baseq, 128u) * 0x01010101u;
-
-    for (int i = tid; i < (int)(TILE / 8 + 4); i += PILEUP_NT) {
-        const long long wi = (long long)(t0 >> 3) + i - 2;         // halo: positions outside the tile never pass vmask
-        L.ref[i] = (wi >= 0 && (uint64_t)wi < a.npos / 8) ? a.ref4[wi] : 0xffffffffu;
-    }
-    for (int i = tid; i < (int)(TILE + 4); i += PILEUP_NT) L.span[i] = 0;
-    for (int i = tid; i < (int)(TILE / 2); i += PILEUP_NT) L.exc[i] = 0;
-    for (int i = tid; i < (int)TILE; i += PILEUP_NT) L.al[i] = 0;
-    if (tid == 0) L.evn = 0;
-
-    uint32_t tc[PPT], tn[PPT][4];
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) { tc[j] = 0; tn[j][0] = tn[j][1] = tn[j][2] = tn[j][3] = 0; }
-
-    // chunk iterator: (pair k, first read of the chunk)
-    uint32_t k = w.pair_lo;
-    TilePair pr = (k < w.pair_hi) ? a.pairs[k] : TilePair{0, 0, 0, 0};
-    uint32_t rbeg = pr.read_lo;
-    uint4 hreg = make_uint4(0, 0, 0, 0);
-    if (k < w.pair_hi && rbeg + (uint32_t)tid < pr.read_hi && tid < HCAP)
-        hreg = *reinterpret_cast<const uint4 *>(a.hdr + a.s_read_base[pr.sample] + rbeg + tid);
-    int buf = 0;
-
-    while (k < w.pair_hi) {
-        const uint32_t nrd = min((uint32_t)HCAP, pr.read_hi - rbeg);
-        const bool last_chunk = rbeg + nrd >= pr.read_hi;
-        const uint32_t sample = pr.sample;
-        if (tid < HCAP) L.hdr[buf][tid] = hreg;
-        // ---- prefetch the next chunk's headers
-        uint32_t nk = k, nrbeg = rbeg + nrd;
-        TilePair npr = pr;
-        if (last_chunk) { nk = k + 1; if (nk < w.pair_hi) { npr = a.pairs[nk]; nrbeg = npr.read_lo; } }
-        if (nk < w.pair_hi && tid < HCAP && nrbeg + (uint32_t)tid < npr.read_hi)
-            hreg = *reinterpret_cast<const uint4 *>(a.hdr + a.s_read_base[npr.sample] + nrbeg + tid);
-        __syncthreads();                                            // (A) headers visible, bins clean
-
-        // ---- scatter this chunk's reads: 8 lanes per read
-        const uint32_t *cigp = a.cig + a.s_cig_base[sample];
-        const uint8_t *seq = a.seq + a.s_seq_base[sample];
-        const uint8_t *qual = a.qual + 2 * a.s_seq_base[sample];
-        for (uint32_t r = (uint32_t)grp; r < nrd; r += PILEUP_NT / LANES_PER_READ) {
-            const uint4 h = L.hdr[buf][r];
-            if (!(h.w & META_PILEUP_OK)) continue;
-            const uint32_t ncig = h.w & 0xffffu;
-            uint32_t q = 0, rp = h.x;
-            for (uint32_t ci = 0; ci < ncig; ++ci) {
-                const uint32_t op = (ncig == 1) ? h.z : cigp[h.z + ci];
-                const uint32_t len = op >> 4, type = op & 15u;
-                if (type == C_M || type == C_EQ || type == C_X) {
-                    if (rp < t0 + TILE && rp + len > t0) {
-                        const uint32_t lo = (rp < t0) ? (t0 - rp) : 0u;
-                        const uint32_t hi = (rp + len > t0 + TILE) ? (t0 + TILE - rp) : len;
-                        if (lane8 == 0) {                            // coverage of the whole segment: 2 atomics
-                            atomicAdd(&L.span[rp + lo - t0], 1);
-                            atomicAdd(&L.span[rp + hi - t0], -1);
-                        }
-                        const uint32_t qs = q + lo, qe = q + hi;
-                        for (uint32_t c = (qs >> 4) + (uint32_t)lane8; c <= ((qe - 1) >> 4); c += LANES_PER_READ) {
-                            uint4 qv; uint2 sv;
-                            __builtin_memcpy(&qv, qual + 2ull * h.y + 16ull * c, 16);
-                            __builtin_memcpy(&sv, seq + (uint64_t)h.y + 8ull * c, 8);
-                            const uint32_t b0 = 16u * c;              // first query base of the chunk
-                            const uint32_t vlo = (qs > b0) ? (qs - b0) : 0u, vhi = (qe < b0 + 16u) ? (qe - b0) : 16u;
-                            const uint32_t vmask = ((1u << vhi) - 1u) & ~((1u << vlo) - 1u);
-                            const int P0 = (int)(rp - t0) + (int)b0 - (int)q;   // may be negative (wraps correctly)
-                            classify_chunk(L, qv, sv.x, sv.y, P0, vmask, kq);
-                        }
-                    }
-                    q += len; rp += len;
-                } else if (type == C_I || type == C_S) {
-                    q += len;
-                } else if (type == C_D || type == C_N) {
-                    rp += len;
-                }
-            }
-        }
-
-        if (last_chunk) {
-            __syncthreads();                                        // (B) all exceptions of this sample are in LDS
-            // ---- phase 1: read + clear my 4 positions, local prefix of the difference array
-            int4 sp = *reinterpret_cast<int4 *>(&L.span[PPT * tid]);
-            const uint2 ex = *reinterpret_cast<uint2 *>(&L.exc[2 * tid]);
-            unsigned long long al[PPT];
-#pragma unroll
-            for (int j = 0; j < PPT; ++j) al[j] = L.al[PPT * tid + j];
-            *reinterpret_cast<int4 *>(&L.span[PPT * tid]) = make_int4(0, 0, 0, 0);
-            if (tid == 0) L.span[TILE] = 0;
-            *reinterpret_cast<uint2 *>(&L.exc[2 * tid]) = make_uint2(0u, 0u);
-#pragma unroll
-            for (int j = 0; j < PPT; ++j) L.al[PPT * tid + j] = 0ull;
-            sp.y += sp.x; sp.z += sp.y; sp.w += sp.z;
-            int incl = sp.w;                                         // inclusive wave scan of the thread totals
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
-            if (lane == 63) L.wsum[wave] = incl;
-            __syncthreads();                                        // (C)
-            int off = incl - sp.w;
-            for (int wv = 0; wv < wave; ++wv) off += L.wsum[wv];
-            const int depth[PPT] = {off + sp.x, off + sp.y, off + sp.z, off + sp.w};
-            const uint32_t exc[PPT] = {ex.x & 0xffffu, ex.x >> 16, ex.y & 0xffffu, ex.y >> 16};
-            uint32_t packed = 0;
-#pragma unroll
-            for (int j = 0; j < PPT; ++j) {
-                const uint32_t cov = (uint32_t)depth[j] - exc[j];
-                tc[j] += cov;
-                packed |= (cov < 255u ? cov : 255u) << (8 * j);
-                const uint32_t gpos = t0 + PPT * tid + j;
-                if (cov >= 255u) stage_event(L, a, 1, Pair32{gpos, sample << 16 | (cov & 0xffffu)});
-                if (al[j] != 0ull) {
-                    const uint32_t nn[4] = {(uint32_t)(al[j] & 0xffffu), (uint32_t)((al[j] >> 16) & 0xffffu),
-                                            (uint32_t)((al[j] >> 32) & 0xffffu), (uint32_t)(al[j] >> 48)};
-#pragma unroll
-                    for (int x = 0; x < 4; ++x)
-                        if (nn[x]) { tn[j][x] += nn[x]; stage_event(L, a, 0, Pair32{gpos, sample << 18 | (uint32_t)x << 16 | nn[x]}); }
-                }
-            }
-            *reinterpret_cast<uint32_t *>(a.spill + (uint64_t)k * TILE + PPT * tid) = packed;
-        }
-        // ---- advance
-        k = nk; pr = npr; rbeg = nrbeg; buf ^= 1;
-        if (last_chunk && k < w.pair_hi) {
-            __syncthreads();                                        // staged events are complete
-            if (L.evn >= (uint32_t)(EVCAP / 2)) flush_events(L, a, tid);   // uniform: evn is read after a barrier
-        }
-    }
-    __syncthreads();
-    flush_events(L, a, tid);
-
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-        const uint64_t g = (uint64_t)t0 + PPT * tid + j;
-        if (tc[j]) atomicAdd(&a.tot[g], tc[j]);
-#pragma unroll
-        for (int x = 0; x < 4; ++x)
-            if (tn[j][x]) atomicAdd(&a.tot[(uint64_t)(1 + x) * a.npos + g], tn[j][x]);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// msnv_pileup_tiles_narrow: the same algorithm as msnv_pileup_tiles for (tile, sample) pairs
-// whose per-position depth is known (host bound) to stay below 255, which lets every LDS bin be
-// ONE BYTE:
-//   start[p] / end[p]  M/=/X segments that begin at / end before p  (coverage = running sum)
-//   exc[p]             bases not counted (BQ below cutoff, N, other IUPAC)
-//   al[p]              4 bytes: mismatching A, C, G, T
-// 23 KB of LDS and 256 threads per workgroup -> several resident workgroups per CU.
-// The kernel is instruction-issue bound (rocprof: SIMDs ~100 % busy, HBM far from saturated), so
-// the hot loop is written to minimise instructions per base:
-//   * fast path (single M/=/X op, <= 128 bases; host sets META_FAST) is branch free: clipping is
-//     done with min/max, out-of-range lanes get an empty valid-mask and load from a safe address;
-//   * all loads of a 128-read chunk are issued before the first one is consumed;
-//   * BQ cutoff: host clamps qualities to <= 127, so 4 bytes are tested with one add + one and-not;
-//   * '=' read codes are rewritten by the host, so match = nibble equality (one xor);
-//   * flag bits are compressed with v_dot4_u32_u8; low-quality bases reach the byte bins through
-//     5 unconditional LDS atomics per 16-base chunk (multiply-spread of 4 flag bits into 4 bytes);
-//   * the per-sample prefix sum uses DPP row shifts; allele totals go straight to global memory.
-// ------------------------------------------------------------------------------------------
-constexpr int N_NT = 256;
-constexpr int N_PPT = TILE / N_NT;             // 8 positions per thread in the per-sample pass
-constexpr int N_GROUPS = N_NT / LANES_PER_READ;
-constexpr int N_HCAP = 128;
-constexpr int N_ROUNDS = N_HCAP / N_GROUPS;    // 4
-constexpr int N_EVCAP = 512;
-static_assert(N_PPT == 8, "narrow per-sample pass is written for 8 positions per thread");
-
-struct NarrowLds {
-    uint32_t start[TILE / 4 + 4];
-    uint32_t end[TILE / 4 + 4];
-    uint32_t exc[TILE / 4 + 16];               // 4 halo words (16 positions) in front, 9+ behind
-    uint32_t al[TILE];
-    uint32_t ref[TILE / 8 + 4];
-    uint4    hdr[2][N_HCAP];
-    Pair32   ev[N_EVCAP];
-    int32_t  wsum[N_NT / 64];
-    uint32_t evn, ev_base;
-};
 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_add(int x) {
@@ -479,8 +84,237 @@ __device__ __forceinline__ int wave_inclusive_scan(int x) {      // LLVM's DPP s
     return x;
 }
 
+// ------------------------------------------------------------------------------------------
+// msnv_pileup_tiles_wide: one work item = (tile, range of (tile,sample) pairs) of ANY depth.
+//   for every sample: the sample's segment pieces are classified 16 bases per lane with SWAR
+//   arithmetic; coverage is a difference array (+1/-1 per piece, prefix-summed once per sample);
+//   only EXCEPTIONS touch the per-position bins: bases below the BQ cutoff / N (subtracted from
+//   the span coverage) and mismatching A/C/G/T bases (allele counts).  16-bit bins.
+//   Then one pass over the tile adds the sample to the running totals (registers), spills the
+//   per-sample coverage byte (>= 255 goes to an overflow list) and emits the sparse allele events.
+// Algorithmic HBM bytes: 16 B per segment piece + 0.5 B/base seq + 1 B/base qual.
+// ------------------------------------------------------------------------------------------
+constexpr int W_NT = 512;
+constexpr int W_PPT = TILE / W_NT;             // 4
+constexpr int W_HCAP = 256;
+constexpr int W_EVCAP = 1024;
+static_assert(W_PPT == 4, "wide per-sample pass is written for 4 positions per thread");
+
+struct WideLds {
+    int32_t  span[TILE + 4];
+    uint32_t exc[TILE / 2];                    // two u16 per word
+    unsigned long long al[TILE];               // four u16 (A,C,G,T)
+    uint32_t ref[TILE / 8 + 4];                // 2 halo words (16 positions) on each side
+    uint4    hdr[2][W_HCAP];
+    Pair32   ev[W_EVCAP];
+    int32_t  wsum[W_NT / 64];
+    uint32_t evn, ev_base;
+};
+
+template <typename LDS, int NT, int CAP>
+__device__ __forceinline__ void flush_events(LDS &L, const PileupArgs &a, int tid) {
+    const uint32_t n = min(L.evn, (uint32_t)CAP);              // called by all threads between barriers
+    if (tid == 0) L.ev_base = n ? atomicAdd(&a.counters[0], n) : 0u;
+    __syncthreads();
+    const uint32_t base = L.ev_base;
+    for (uint32_t i = tid; i < n; i += NT)
+        if (base + i < a.cap_events) a.events[base + i] = L.ev[i];
+    __syncthreads();
+    if (tid == 0) L.evn = 0;
+}
+
+template <typename LDS, int CAP>
+__device__ __forceinline__ void stage_allele_event(LDS &L, const PileupArgs &a, Pair32 e) {
+    const uint32_t i = atomicAdd(&L.evn, 1u);
+    if (i < (uint32_t)CAP) { L.ev[i] = e; return; }
+    const uint32_t g = atomicAdd(&a.counters[0], 1u);          // staging full: slow path
+    if (g < a.cap_events) a.events[g] = e;
+}
+
+__device__ __forceinline__ void wide_classify(WideLds &L, const uint4 qv, const uint32_t s0, const uint32_t s1,
+                                              const int P0, const uint32_t vmask, const uint32_t kq) {
+    const uint32_t pr = (uint32_t)(P0 + 16);
+    const uint32_t wi = pr >> 3, sh = (pr & 7u) * 4u;
+    const uint32_t w0 = L.ref[wi], w1 = L.ref[wi + 1], w2 = L.ref[wi + 2];
+    const uint32_t r0 = __builtin_amdgcn_alignbit(w1, w0, sh), r1 = __builtin_amdgcn_alignbit(w2, w1, sh);
+    const uint32_t nm = nibflags_to_bits(nz_nibbles(s0 ^ r0)) | nibflags_to_bits(nz_nibbles(s1 ^ r1)) << 8;
+    const uint32_t lq = lowq_mask(qv, kq);
+    uint32_t e = (lq | nm) & vmask;
+    while (e) {
+        const uint32_t j = (uint32_t)__builtin_ctz(e);
+        e &= e - 1u;
+        const uint32_t p = (uint32_t)(P0 + (int)j);
+        uint32_t ai = 4u;
+        if (!((lq >> j) & 1u)) ai = allele_index(((j < 8u ? s0 : s1) >> (4u * (j & 7u))) & 0xfu);
+        if (ai < 4u) atomicAdd(&L.al[p], 1ull << (16u * ai));
+        else atomicAdd(&L.exc[p >> 1], 1u << (16u * (p & 1u)));     // not counted: low BQ, N, other IUPAC
+    }
+}
+
+__global__ __launch_bounds__(W_NT) void msnv_pileup_tiles_wide(PileupArgs a) {
+    __shared__ WideLds L;
+    const WorkItem w = a.work[blockIdx.x];
+    const uint32_t t0 = w.tile * TILE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane8 = tid & (LANES_PER_READ - 1), grp = tid / LANES_PER_READ;
+    const uint32_t kq = 0x80808080u - min(a.min_baseq, 128u) * 0x01010101u;
+    const int b0 = 16 * lane8;
+
+    for (int i = tid; i < (int)(TILE / 8 + 4); i += W_NT) {
+        const long long wi = (long long)(t0 >> 3) + i - 2;         // halo: positions outside the tile never pass vmask
+        L.ref[i] = (wi >= 0 && (uint64_t)wi < a.npos / 8) ? a.ref4[wi] : 0xffffffffu;
+    }
+    for (int i = tid; i < (int)(TILE + 4); i += W_NT) L.span[i] = 0;
+    for (int i = tid; i < (int)(TILE / 2); i += W_NT) L.exc[i] = 0;
+    for (int i = tid; i < (int)TILE; i += W_NT) L.al[i] = 0;
+    if (tid == 0) L.evn = 0;
+
+    uint32_t tc[W_PPT], tn[W_PPT][4];
+#pragma unroll
+    for (int j = 0; j < W_PPT; ++j) { tc[j] = 0; tn[j][0] = tn[j][1] = tn[j][2] = tn[j][3] = 0; }
+
+    uint32_t k = w.pair_lo;
+    TilePair pr = (k < w.pair_hi) ? a.pairs[k] : TilePair{0, 0, 0, 0};
+    uint32_t rbeg = pr.read_lo;
+    uint4 hreg = make_uint4(0, 0, 0, 0);
+    if (k < w.pair_hi && tid < W_HCAP && rbeg + (uint32_t)tid < pr.read_hi)
+        hreg = *reinterpret_cast<const uint4 *>(a.hdr + a.s_read_base[pr.sample] + rbeg + tid);
+    int buf = 0;
+
+    while (k < w.pair_hi) {
+        const uint32_t nrd = min((uint32_t)W_HCAP, pr.read_hi - rbeg);
+        const bool last_chunk = rbeg + nrd >= pr.read_hi;
+        const uint32_t sample = pr.sample;
+        if (tid < W_HCAP) L.hdr[buf][tid] = hreg;                   // slots beyond nrd hold meta = 0
+        uint32_t nk = k, nrbeg = rbeg + nrd;
+        TilePair npr = pr;
+        if (last_chunk) { nk = k + 1; if (nk < w.pair_hi) { npr = a.pairs[nk]; nrbeg = npr.read_lo; } }
+        hreg = make_uint4(0, 0, 0, 0);
+        if (nk < w.pair_hi && tid < W_HCAP && nrbeg + (uint32_t)tid < npr.read_hi)
+            hreg = *reinterpret_cast<const uint4 *>(a.hdr + a.s_read_base[npr.sample] + nrbeg + tid);
+        __syncthreads();                                            // (A) headers visible, bins clean
+
+        const uint8_t *seq = a.seq + a.s_seq_base[sample];
+        const uint8_t *qual = a.qual + 2 * a.s_seq_base[sample];
+        for (uint32_t r = (uint32_t)grp; r < nrd; r += W_NT / LANES_PER_READ) {
+            const uint4 h = L.hdr[buf][r];
+            if (!(h.w & META_PILEUP_OK)) continue;
+            const int s = (int)(h.x - t0), len = (int)h.z;
+            const int lo = max(0, -s), hi = min(len, (int)TILE - s);
+            if (lo >= hi) continue;
+            if (lane8 == 0) { atomicAdd(&L.span[s + lo], 1); atomicAdd(&L.span[s + hi], -1); }
+            const int vlo = min(max(lo - b0, 0), 16), vhi = min(max(hi - b0, 0), 16);
+            if (vlo >= vhi) continue;
+            uint4 qv; uint2 sv;
+            __builtin_memcpy(&qv, qual + 2ull * h.y + (uint32_t)b0, 16);
+            __builtin_memcpy(&sv, seq + (uint64_t)h.y + (uint32_t)(b0 >> 1), 8);
+            wide_classify(L, qv, sv.x, sv.y, s + b0, ((1u << vhi) - 1u) & ~((1u << vlo) - 1u), kq);
+        }
+
+        if (last_chunk) {
+            __syncthreads();                                        // (B) all exceptions of this sample are in LDS
+            int4 sp = *reinterpret_cast<int4 *>(&L.span[W_PPT * tid]);
+            const uint2 ex = *reinterpret_cast<uint2 *>(&L.exc[2 * tid]);
+            unsigned long long al[W_PPT];
+#pragma unroll
+            for (int j = 0; j < W_PPT; ++j) al[j] = L.al[W_PPT * tid + j];
+            *reinterpret_cast<int4 *>(&L.span[W_PPT * tid]) = make_int4(0, 0, 0, 0);
+            if (tid == 0) L.span[TILE] = 0;
+            *reinterpret_cast<uint2 *>(&L.exc[2 * tid]) = make_uint2(0u, 0u);
+#pragma unroll
+            for (int j = 0; j < W_PPT; ++j) L.al[W_PPT * tid + j] = 0ull;
+            sp.y += sp.x; sp.z += sp.y; sp.w += sp.z;
+            const int incl = wave_inclusive_scan(sp.w);
+            if (lane == 63) L.wsum[wave] = incl;
+            __syncthreads();                                        // (C)
+            int off = incl - sp.w;
+            for (int wv = 0; wv < wave; ++wv) off += L.wsum[wv];
+            const int depth[W_PPT] = {off + sp.x, off + sp.y, off + sp.z, off + sp.w};
+            const uint32_t exc[W_PPT] = {ex.x & 0xffffu, ex.x >> 16, ex.y & 0xffffu, ex.y >> 16};
+            uint32_t packed = 0;
+#pragma unroll
+            for (int j = 0; j < W_PPT; ++j) {
+                const uint32_t cov = (uint32_t)depth[j] - exc[j];
+                tc[j] += cov;
+                packed |= (cov < 255u ? cov : 255u) << (8 * j);
+                const uint32_t gpos = t0 + W_PPT * tid + j;
+                if (cov >= 255u) {
+                    const uint32_t g = atomicAdd(&a.counters[1], 1u);
+                    if (g < a.cap_overflow) a.overflow[g] = Pair32{gpos, sample << 16 | (cov & 0xffffu)};
+                }
+                if (al[j] != 0ull) {
+                    const uint32_t nn[4] = {(uint32_t)(al[j] & 0xffffu), (uint32_t)((al[j] >> 16) & 0xffffu),
+                                            (uint32_t)((al[j] >> 32) & 0xffffu), (uint32_t)(al[j] >> 48)};
+#pragma unroll
+                    for (int x = 0; x < 4; ++x)
+                        if (nn[x]) {
+                            tn[j][x] += nn[x];
+                            stage_allele_event<WideLds, W_EVCAP>(L, a, Pair32{gpos, sample << 18 | (uint32_t)x << 16 | nn[x]});
+                        }
+                }
+            }
+            *reinterpret_cast<uint32_t *>(a.spill + (uint64_t)k * TILE + W_PPT * tid) = packed;
+        }
+        k = nk; pr = npr; rbeg = nrbeg; buf ^= 1;
+        if (last_chunk && k < w.pair_hi) {
+            __syncthreads();                                        // staged events are complete
+            if (L.evn >= (uint32_t)(W_EVCAP / 2)) flush_events<WideLds, W_NT, W_EVCAP>(L, a, tid);
+        }
+    }
+    __syncthreads();
+    flush_events<WideLds, W_NT, W_EVCAP>(L, a, tid);
+
+#pragma unroll
+    for (int j = 0; j < W_PPT; ++j) {
+        const uint64_t g = (uint64_t)t0 + W_PPT * tid + j;
+        if (tc[j]) atomicAdd(&a.tot[g], tc[j]);
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+            if (tn[j][x]) atomicAdd(&a.tot[(uint64_t)(1 + x) * a.npos + g], tn[j][x]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// msnv_pileup_tiles_narrow: the same algorithm for (tile, sample) pairs whose per-position depth is
+// known (host bound) to stay below 255, which lets every LDS bin be ONE BYTE:
+//   start[p] / end[p]  segment pieces that begin at / end before p  (coverage = running sum)
+//   exc[p]             bases not counted (BQ below cutoff, N, other IUPAC)
+//   al[p]              4 bytes: mismatching A, C, G, T
+// ~25 KB of LDS and 256 threads per workgroup -> several resident workgroups per CU.
+// The hot loop is written to minimise instructions per base (rocprof: the SIMDs, not HBM, are busy):
+//   * every header is one segment piece of <= 128 aligned bases (the host resolves the CIGAR), so
+//     there is exactly one code path and it is branch free: clipping by min/max, empty lanes get an
+//     empty valid-mask and load from a safe address;
+//   * chunk descriptors are staged in LDS, headers are prefetched one chunk ahead, and all data
+//     loads of a 128-piece chunk are issued before the first one is consumed;
+//   * BQ cutoff: 4 bytes per add + and-not; match = nibble equality (host rewrites '=');
+//   * flag bits are compressed with v_dot4_u32_u8; low-quality bases reach the byte bins through
+//     5 unconditional LDS atomics per 16-base chunk (multiply-spread of 4 flag bits into 4 bytes);
+//   * the per-sample prefix sum uses DPP row shifts; allele totals go straight to global memory.
+// ------------------------------------------------------------------------------------------
+constexpr int N_NT = 256;
+constexpr int N_PPT = TILE / N_NT;             // 8 positions per thread in the per-sample pass
+constexpr int N_GROUPS = N_NT / LANES_PER_READ;
+constexpr int N_HCAP = CHUNK_READS;
+constexpr int N_ROUNDS = N_HCAP / N_GROUPS;    // 4
+constexpr int N_EVCAP = 512;
+static_assert(N_PPT == 8, "narrow per-sample pass is written for 8 positions per thread");
+
+struct NarrowLds {
+    uint32_t start[TILE / 4 + 4];
+    uint32_t end[TILE / 4 + 4];
+    uint32_t exc[TILE / 4 + 16];               // 4 halo words (16 positions) in front, 9+ behind
+    uint32_t al[TILE];
+    uint32_t ref[TILE / 8 + 4];
+    uint4    hdr[2][N_HCAP];
+    Pair32   ev[N_EVCAP];
+    ChunkDesc desc[MAX_CHUNKS_PER_ITEM];
+    int32_t  wsum[N_NT / 64];
+    uint32_t evn, ev_base;
+};
+
 // 16 bases -> LDS byte bins.  qv: 16 qualities (<= 127 each), (s0,s1): 16 read nibbles (no code 0),
-// P0: tile position of base 0 (>= -15), vmask: bases that belong to this segment and tile.
+// P0: tile position of base 0 (>= -15), vmask: bases that belong to this piece and tile.
 __device__ __forceinline__ void narrow_classify(NarrowLds &L, const uint4 qv, const uint32_t s0, const uint32_t s1,
                                                 const int P0, const uint32_t vmask, const uint32_t kq) {
     const uint32_t pr = (uint32_t)(P0 + 16);
@@ -488,11 +322,7 @@ __device__ __forceinline__ void narrow_classify(NarrowLds &L, const uint4 qv, co
     const uint32_t w0 = L.ref[wi], w1 = L.ref[wi + 1], w2 = L.ref[wi + 2];
     const uint32_t r0 = __builtin_amdgcn_alignbit(w1, w0, sh), r1 = __builtin_amdgcn_alignbit(w2, w1, sh);
     const uint32_t nm = nibflags_to_bits(nz_nibbles(s0 ^ r0)) | nibflags_to_bits(nz_nibbles(s1 ^ r1)) << 8;
-    const uint32_t l0 = ~(qv.x + kq) & 0x80808080u, l1 = ~(qv.y + kq) & 0x80808080u;
-    const uint32_t l2 = ~(qv.z + kq) & 0x80808080u, l3 = ~(qv.w + kq) & 0x80808080u;
-    const uint32_t lqa = __builtin_amdgcn_udot4(l1, 0x80402010u, __builtin_amdgcn_udot4(l0, 0x08040201u, 0u, false), false);
-    const uint32_t lqb = __builtin_amdgcn_udot4(l3, 0x80402010u, __builtin_amdgcn_udot4(l2, 0x08040201u, 0u, false), false);
-    const uint32_t lq = ((lqa >> 7) | (lqb << 1)) & vmask;            // lqa: bits 7..14, lqb: bits 7..14 -> 8..15
+    const uint32_t lq = lowq_mask(qv, kq) & vmask;
     const uint32_t m = lq << (pr & 3u);                                // <= 19 bits, aligned to the byte-bin words
     const uint32_t wb = pr >> 2;
 #pragma unroll
@@ -509,27 +339,13 @@ __device__ __forceinline__ void narrow_classify(NarrowLds &L, const uint4 qv, co
     }
 }
 
-__device__ __forceinline__ void narrow_flush_events(NarrowLds &L, const PileupArgs &a, int tid) {
-    const uint32_t n = min(L.evn, (uint32_t)N_EVCAP);
-    if (tid == 0) L.ev_base = n ? atomicAdd(&a.counters[0], n) : 0u;
-    __syncthreads();
-    const uint32_t base = L.ev_base;
-    for (uint32_t i = tid; i < n; i += N_NT)
-        if (base + i < a.cap_events) a.events[base + i] = L.ev[i];
-    __syncthreads();
-    if (tid == 0) L.evn = 0;
-}
-
 __device__ __forceinline__ void narrow_emit(NarrowLds &L, const PileupArgs &a, uint32_t gpos, uint32_t sample, uint32_t word) {
     while (word) {                                                   // rare: a mismatching allele at this position
         const uint32_t x = (uint32_t)__builtin_ctz(word) >> 3;
         const uint32_t n = (word >> (8u * x)) & 0xffu;
         word &= ~(0xffu << (8u * x));
         atomicAdd(&a.tot[(uint64_t)(1u + x) * a.npos + gpos], n);
-        const Pair32 e{gpos, sample << 18 | x << 16 | n};
-        const uint32_t i = atomicAdd(&L.evn, 1u);
-        if (i < (uint32_t)N_EVCAP) L.ev[i] = e;
-        else { const uint32_t g = atomicAdd(&a.counters[0], 1u); if (g < a.cap_events) a.events[g] = e; }
+        stage_allele_event<NarrowLds, N_EVCAP>(L, a, Pair32{gpos, sample << 18 | x << 16 | n});
     }
 }
 
@@ -555,96 +371,61 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow(PileupArgs a) {
 #pragma unroll
     for (int j = 0; j < N_PPT; ++j) tc[j] = 0;
 
-    uint32_t k = w.pair_lo;
-    TilePair pr = (k < w.pair_hi) ? a.pairs[k] : TilePair{0, 0, 0, 0};
-    uint32_t rbeg = pr.read_lo;
+    // chunk descriptors of this work item -> LDS (no dependent scalar loads inside the loop)
+    const uint32_t nch = w.chunk_hi - w.chunk_lo;
+    for (uint32_t i = tid; i < nch * 2; i += N_NT)
+        reinterpret_cast<uint4 *>(L.desc)[i] = reinterpret_cast<const uint4 *>(a.chunks + w.chunk_lo)[i];
+    __syncthreads();
     uint4 hreg = make_uint4(0, 0, 0, 0);
-    if (k < w.pair_hi && tid < N_HCAP && rbeg + (uint32_t)tid < pr.read_hi)
-        hreg = *reinterpret_cast<const uint4 *>(a.hdr + a.s_read_base[pr.sample] + rbeg + tid);
+    if (nch && tid < N_HCAP && (uint32_t)tid < (L.desc[0].nrd_flags & 0xffffu))
+        hreg = *reinterpret_cast<const uint4 *>(a.hdr + L.desc[0].hdr_base + tid);
     int buf = 0;
 
-    while (k < w.pair_hi) {
-        const uint32_t nrd = min((uint32_t)N_HCAP, pr.read_hi - rbeg);
-        const bool last_chunk = rbeg + nrd >= pr.read_hi;
-        const uint32_t sample = pr.sample;
+    for (uint32_t c = 0; c < nch; ++c) {
+        const ChunkDesc cd = L.desc[c];
+        const bool last_chunk = (cd.nrd_flags >> 16) != 0u;
+        const uint32_t sample = cd.sample, k = cd.pair;
         if (tid < N_HCAP) L.hdr[buf][tid] = hreg;                    // slots beyond nrd hold meta = 0
-        uint32_t nk = k, nrbeg = rbeg + nrd;
-        TilePair npr = pr;
-        if (last_chunk) { nk = k + 1; if (nk < w.pair_hi) { npr = a.pairs[nk]; nrbeg = npr.read_lo; } }
         hreg = make_uint4(0, 0, 0, 0);
-        if (nk < w.pair_hi && tid < N_HCAP && nrbeg + (uint32_t)tid < npr.read_hi)
-            hreg = *reinterpret_cast<const uint4 *>(a.hdr + a.s_read_base[npr.sample] + nrbeg + tid);
+        if (!(a.ablate & 8) && c + 1 < nch && tid < N_HCAP && (uint32_t)tid < (L.desc[c + 1].nrd_flags & 0xffffu))
+            hreg = *reinterpret_cast<const uint4 *>(a.hdr + L.desc[c + 1].hdr_base + tid);
         __syncthreads();                                            // (A)
 
-        const uint8_t *seq = a.seq + a.s_seq_base[sample];
-        const uint8_t *qual = a.qual + 2 * a.s_seq_base[sample];
+        const uint8_t *seq = a.seq + cd.seq_base;
+        const uint8_t *qual = a.qual + 2 * cd.seq_base;
 
-        // ---- fast path, branch free: one 16-base chunk per lane and round, loads issued together
-        uint4 qv[N_ROUNDS]; uint2 sv[N_ROUNDS]; int P0[N_ROUNDS]; uint32_t vm[N_ROUNDS]; uint32_t slow = 0;
+        // one 16-base chunk per lane and round, loads issued together, no branches
+        uint4 qv[N_ROUNDS]; uint2 sv[N_ROUNDS]; int P0[N_ROUNDS]; uint32_t vm[N_ROUNDS];
 #pragma unroll
         for (int i = 0; i < N_ROUNDS; ++i) {
             const uint4 h = L.hdr[buf][grp + i * N_GROUPS];
-            const bool fast = (h.w & META_FAST) != 0u;
-            slow |= ((h.w & (META_PILEUP_OK | META_FAST)) == META_PILEUP_OK) ? (1u << i) : 0u;
-            const int s = (int)(h.x - t0);                            // tile position of query base 0 (wraps correctly)
-            const int len = (int)(h.z >> 4);
-            const int lo = max(0, -s), hi = min(len, (int)TILE - s); // segment bases inside the tile: [lo, hi)
-            if (fast && lane8 == 0 && lo < hi) {
+            const bool ok = (h.w & META_PILEUP_OK) != 0u;
+            const int s = (int)(h.x - t0);                            // tile position of piece base 0 (wraps correctly)
+            const int len = (int)h.z;
+            const int lo = max(0, -s), hi = min(len, (int)TILE - s); // piece bases inside the tile: [lo, hi)
+            if (ok && lane8 == 0 && lo < hi) {
                 const uint32_t sa = (uint32_t)(s + lo), sb = (uint32_t)(s + hi);
                 atomicAdd(&L.start[sa >> 2], 1u << (8u * (sa & 3u)));
                 atomicAdd(&L.end[sb >> 2], 1u << (8u * (sb & 3u)));
             }
+            if (a.ablate & 4) { qv[i] = make_uint4(h.x, h.y, h.z, h.w); sv[i] = make_uint2(h.x, h.y); }
+            else {
             __builtin_memcpy(&qv[i], qual + 2ull * h.y + (uint32_t)b0, 16);      // h.y = 0 for empty slots: safe address
             __builtin_memcpy(&sv[i], seq + (uint64_t)h.y + (uint32_t)(b0 >> 1), 8);
+            }
             const int vlo = min(max(lo - b0, 0), 16), vhi = min(max(hi - b0, 0), 16);
             const uint32_t mk = ((1u << vhi) - 1u) & ~((1u << vlo) - 1u);           // empty when vhi <= vlo
-            vm[i] = fast ? mk : 0u;
+            vm[i] = ok ? mk : 0u;
             P0[i] = vm[i] ? s + b0 : 0;                              // keeps every LDS index of an empty lane in range
         }
 #pragma unroll
         for (int i = 0; i < N_ROUNDS; ++i)
-            if (__any(vm[i] != 0u)) narrow_classify(L, qv[i], sv[i].x, sv[i].y, P0[i], vm[i], kq);
-
-        // ---- general path: several CIGAR ops or long reads
-        if (slow) {
-            const uint32_t *cigp = a.cig + a.s_cig_base[sample];
-#pragma unroll 1
-            for (int i = 0; i < N_ROUNDS; ++i) {
-                if (!(slow & (1u << i))) continue;
-                const uint4 h = L.hdr[buf][grp + i * N_GROUPS];
-                const uint32_t ncig = h.w & 0xffffu;
-                uint32_t q = 0, rp = h.x;
-                for (uint32_t ci = 0; ci < ncig; ++ci) {
-                    const uint32_t op = (ncig == 1) ? h.z : cigp[h.z + ci];
-                    const uint32_t len = op >> 4, type = op & 15u;
-                    if (type == C_M || type == C_EQ || type == C_X) {
-                        if (rp < t0 + TILE && rp + len > t0) {
-                            const uint32_t lo = (rp < t0) ? (t0 - rp) : 0u;
-                            const uint32_t hi = (rp + len > t0 + TILE) ? (t0 + TILE - rp) : len;
-                            if (lane8 == 0) {
-                                const uint32_t sa = rp + lo - t0, sb = rp + hi - t0;
-                                atomicAdd(&L.start[sa >> 2], 1u << (8u * (sa & 3u)));
-                                atomicAdd(&L.end[sb >> 2], 1u << (8u * (sb & 3u)));
-                            }
-                            const uint32_t qs = q + lo, qe = q + hi;
-                            for (uint32_t c = (qs >> 4) + (uint32_t)lane8; c <= ((qe - 1) >> 4); c += LANES_PER_READ) {
-                                uint4 qq; uint2 ss;
-                                __builtin_memcpy(&qq, qual + 2ull * h.y + 16ull * c, 16);
-                                __builtin_memcpy(&ss, seq + (uint64_t)h.y + 8ull * c, 8);
-                                const uint32_t c0 = 16u * c;
-                                const uint32_t vlo = (qs > c0) ? (qs - c0) : 0u, vhi = (qe < c0 + 16u) ? (qe - c0) : 16u;
-                                narrow_classify(L, qq, ss.x, ss.y, (int)(rp - t0) + (int)c0 - (int)q,
-                                                ((1u << vhi) - 1u) & ~((1u << vlo) - 1u), kq);
-                            }
-                        }
-                        q += len; rp += len;
-                    } else if (type == C_I || type == C_S) q += len;
-                    else if (type == C_D || type == C_N) rp += len;
-                }
+            if (__any(vm[i] != 0u)) {
+                if (a.ablate & 1) { asm volatile("" :: "v"(qv[i].x), "v"(qv[i].y), "v"(qv[i].z), "v"(qv[i].w), "v"(sv[i].x), "v"(sv[i].y)); }
+                else narrow_classify(L, qv[i], sv[i].x, sv[i].y, P0[i], vm[i], kq);
             }
-        }
 
-        if (last_chunk) {
+        if (last_chunk && !(a.ablate & 2)) {
             __syncthreads();                                        // (B)
             const uint2 st = *reinterpret_cast<uint2 *>(&L.start[2 * tid]);
             const uint2 en = *reinterpret_cast<uint2 *>(&L.end[2 * tid]);
@@ -685,14 +466,14 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow(PileupArgs a) {
                 narrow_emit(L, a, g0 + 6, sample, a1.z); narrow_emit(L, a, g0 + 7, sample, a1.w);
             }
         }
-        k = nk; pr = npr; rbeg = nrbeg; buf ^= 1;
-        if (last_chunk && k < w.pair_hi) {
+        buf ^= 1;
+        if (last_chunk && c + 1 < nch) {
             __syncthreads();
-            if (L.evn >= (uint32_t)(N_EVCAP / 2)) narrow_flush_events(L, a, tid);
+            if (L.evn >= (uint32_t)(N_EVCAP / 2)) flush_events<NarrowLds, N_NT, N_EVCAP>(L, a, tid);
         }
     }
     __syncthreads();
-    narrow_flush_events(L, a, tid);
+    flush_events<NarrowLds, N_NT, N_EVCAP>(L, a, tid);
 #pragma unroll
     for (int j = 0; j < N_PPT; ++j)
         if (tc[j]) atomicAdd(&a.tot[(uint64_t)t0 + N_PPT * tid + j], tc[j]);
@@ -873,8 +654,8 @@ int dev_stream_create(void **stream) { hipStream_t s; HIP_TRY(hipStreamCreateWit
 void dev_stream_destroy(void *stream) { if (stream) (void)hipStreamDestroy((hipStream_t)stream); }
 
 void dev_free_all(DeviceCols &d) {
-    void *ptrs[] = {d.hdr, d.cig, d.seq, d.qual, d.s_read_base, d.s_cig_base, d.s_seq_base, d.ref4, d.ref_lc, d.pairs,
-                    d.tile_pair_start, d.work, d.tile_vbeg, d.tile_vend, d.tot, d.spill, d.events, d.overflow, d.counters,
+    void *ptrs[] = {d.hdr, d.seq, d.qual, d.s_read_base, d.s_seq_base, d.ref4, d.ref_lc, d.pairs,
+                    d.tile_pair_start, d.work, d.chunks, d.tile_vbeg, d.tile_vend, d.tot, d.spill, d.events, d.overflow, d.counters,
                     d.sites, d.tile_site_base, d.tile_site_cnt, d.out, d.site_flags};
     for (void *p : ptrs) dev_free(p);
     d = DeviceCols{};
@@ -904,23 +685,20 @@ int dev_run_pipeline(DeviceCols &d, const msnv_params &p, void *stream_, msnv_ru
     HIP_TRY(hipEventRecord(ev[1], st));
     if (d.n_work) {
         PileupArgs a;
-        a.hdr = d.hdr; a.cig = d.cig; a.seq = d.seq; a.qual = d.qual;
-        a.s_read_base = d.s_read_base; a.s_cig_base = d.s_cig_base; a.s_seq_base = d.s_seq_base;
-        a.ref4 = d.ref4; a.pairs = d.pairs; a.work = d.work; a.tot = d.tot; a.npos = npos; a.spill = d.spill;
+        a.hdr = d.hdr; a.seq = d.seq; a.qual = d.qual;
+        a.s_read_base = d.s_read_base; a.s_seq_base = d.s_seq_base;
+        a.ref4 = d.ref4; a.pairs = d.pairs; a.work = d.work; a.chunks = d.chunks; a.tot = d.tot; a.npos = npos; a.spill = d.spill;
         a.events = d.events; a.cap_events = d.cap_events; a.overflow = d.overflow; a.cap_overflow = d.cap_overflow;
         a.counters = d.counters; a.min_baseq = (uint32_t)std::max(0, p.min_baseq);
-        static const bool use_v1 = [] { const char *e = getenv("MSNV_PILEUP"); return e && e[0] == 'v' && e[1] == '1'; }();
-        static const bool use_v2 = [] { const char *e = getenv("MSNV_PILEUP"); return e && e[0] == 'v' && e[1] == '2'; }();
-        if (use_v1) hipLaunchKernelGGL(msnv_pileup_tiles_v1, dim3(d.n_work), dim3(PILEUP_NT), 0, st, a);
-        else if (use_v2) hipLaunchKernelGGL(msnv_pileup_tiles, dim3(d.n_work), dim3(PILEUP_NT), 0, st, a);
-        else {
-            // narrow work items (byte bins) first, wide ones (16-bit bins) after; they touch disjoint pairs
-            if (d.n_work_narrow) hipLaunchKernelGGL(msnv_pileup_tiles_narrow, dim3(d.n_work_narrow), dim3(N_NT), 0, st, a);
-            if (d.n_work > d.n_work_narrow) {
-                PileupArgs b = a;
-                b.work = d.work + d.n_work_narrow;
-                hipLaunchKernelGGL(msnv_pileup_tiles, dim3(d.n_work - d.n_work_narrow), dim3(PILEUP_NT), 0, st, b);
-            }
+        { const char *e = getenv("MSNV_ABLATE"); a.ablate = e ? (uint32_t)atoi(e) : 0u; }
+        static const bool all_wide = [] { const char *e = getenv("MSNV_PILEUP"); return e && e[0] == 'w'; }();   // A/B: MSNV_PILEUP=wide
+        const uint32_t n_narrow = all_wide ? 0u : d.n_work_narrow;
+        // narrow work items (byte bins) and wide ones (16-bit bins) touch disjoint (tile, sample) pairs
+        if (n_narrow) hipLaunchKernelGGL(msnv_pileup_tiles_narrow, dim3(n_narrow), dim3(N_NT), 0, st, a);
+        if (d.n_work > n_narrow) {
+            PileupArgs b = a;
+            b.work = d.work + n_narrow;
+            hipLaunchKernelGGL(msnv_pileup_tiles_wide, dim3(d.n_work - n_narrow), dim3(W_NT), 0, st, b);
         }
         HIP_TRY(hipGetLastError());
     }

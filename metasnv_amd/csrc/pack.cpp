@@ -21,36 +21,6 @@ void synth_sample_records(const msnv_synth_params &p, int sample, const std::vec
 static inline bool consumes_ref(uint32_t t) { return t == C_M || t == C_D || t == C_N || t == C_EQ || t == C_X; }
 static inline bool consumes_query(uint32_t t) { return t == C_M || t == C_I || t == C_S || t == C_EQ || t == C_X; }
 
-static bool has_eq_code(const uint8_t *seq, int l_seq) {
-    for (int i = 0; i < l_seq; ++i) if (((seq[i >> 1] >> ((~i & 1) << 2)) & 0xf) == 0) return true;
-    return false;
-}
-
-// A read base stored as '=' (nt16 code 0) always counts as a match in mpileup (pileup_seq: `c == '='`).
-// The device kernels test "read code == reference code" only, so the host replaces every '=' that sits
-// in an M/=/X segment by the reference code of its position (N where the FASTA has no base): same result,
-// one test less per base on the device.  Bases outside M/=/X segments are never looked at.
-static void rewrite_eq_codes(const msnv_dataset &ds, const RecView &r, uint8_t *packed /* low nibble first */) {
-    const std::string &ref = ds.seqs[(size_t)r.tid];
-    const bool has = ds.has_seq[(size_t)r.tid];
-    int64_t rp = r.pos; int q = 0;
-    for (int k = 0; k < r.n_cigar; ++k) {
-        const uint32_t c = ld_u32(r.cigar + 4 * k), t = c & 15u, l = c >> 4;
-        if (t == C_M || t == C_EQ || t == C_X) {
-            for (uint32_t j = 0; j < l; ++j, ++q, ++rp) {
-                const int sh = (q & 1) * 4;
-                if (((packed[q >> 1] >> sh) & 0xf) == 0) {
-                    const uint8_t code = (has && rp >= 0 && (size_t)rp < ref.size()) ? nt16_of_char((unsigned char)ref[(size_t)rp]) : 15;
-                    packed[q >> 1] = (uint8_t)((packed[q >> 1] & ~(0xf << sh)) | (code ? code : 15) << sh);
-                }
-            }
-        } else {
-            if (consumes_ref(t)) rp += l;
-            if (consumes_query(t)) q += (int)l;
-        }
-    }
-}
-
 // Packs one sample.  `ds` supplies contig selection, BED and parameters.
 int pack_sample(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, SampleCols &sc) {
     const msnv_params &P = ds.params;
@@ -90,13 +60,6 @@ int pack_sample(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, Sa
             if (t == C_M || t == C_EQ || t == C_X) m_bases += l;
         }
         const int64_t endpos = r.pos + (rlen ? rlen : 1);                        // bam_endpos
-        // qaCompute's cursor also advances over I/S/H/P (qaCompute.cpp:537-552)
-        int64_t qa_end = (int64_t)r.pos + 1;
-        {
-            int k = 0;
-            if (r.n_cigar > 0) { uint32_t t = ld_u32(r.cigar) & 15u; if (t == C_S || t == C_H) k = 1; }
-            for (; k < r.n_cigar; ++k) qa_end += ld_u32(r.cigar + 4 * k) >> 4;
-        }
 
         // ---- mpileup read-level filters (bam_plcmd.c mplp_func order)
         bool pile_ok = !(r.flag & P.flag_filter);
@@ -119,49 +82,71 @@ int pack_sample(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, Sa
         const uint16_t depth_here = (uint16_t)std::min<size_t>(live.size(), 0xffff);
         if (!pile_ok && !cov_ok) continue;
 
-        ReadHdr h;
-        h.gpos = (uint32_t)r.pos;            // contig-relative until finalize
-        h.seqoff = 0;
-        h.meta = (uint32_t)r.n_cigar | (uint32_t)r.mapq << 16 | (pile_ok ? META_PILEUP_OK : 0u) | (cov_ok ? META_COV_OK : 0u);
-        if (r.n_cigar == 1) {
-            h.cig = ld_u32(r.cigar);
-            const uint32_t t = h.cig & 15u;
-            if (pile_ok && (t == C_M || t == C_EQ || t == C_X) && (h.cig >> 4) <= 128u) h.meta |= META_FAST;
+        if (cov_ok) {
+            // qaCompute's M intervals in its own index space (qaCompute.cpp:530-552): index = pos + 1, a leading
+            // S/H op is skipped without advancing, every other non-M op advances the cursor
+            int64_t pp = (int64_t)r.pos + 1;
+            int k = 0;
+            if (r.n_cigar > 0) { const uint32_t t = ld_u32(r.cigar) & 15u; if (t == C_S || t == C_H) k = 1; }
+            for (; k < r.n_cigar; ++k) {
+                const uint32_t c = ld_u32(r.cigar + 4 * k), t = c & 15u, l = c >> 4;
+                if (t == C_M) { sc.cov_tid.push_back(r.tid); sc.cov_beg.push_back((int32_t)pp); sc.cov_end.push_back((int32_t)(pp + l)); }
+                pp += l;
+            }
         }
-        else {
-            h.cig = (uint32_t)sc.cig.size();
-            for (int k = 0; k < r.n_cigar; ++k) sc.cig.push_back(ld_u32(r.cigar + 4 * k));
+        if (!pile_ok) continue;
+
+        // ---- one 16-byte header per M/=/X segment piece of at most SEG_MAX bases; only aligned bases are shipped
+        sc.n_pileup_bases += (uint64_t)m_bases;
+        sc.n_pileup_reads++;
+        if (sc.first_tid < 0) {
+            // first pileup line of this sample (call_vC.cpp:423 drops the first line of the run)
+            int64_t b = r.pos, e = endpos;
+            if (ds.has_bed) { b = std::max(b, ds.bed_beg[(size_t)r.tid]); e = std::min(e, ds.bed_end[(size_t)r.tid]); }
+            if (b < e) { sc.first_tid = r.tid; sc.first_beg = (int32_t)b; sc.first_end = (int32_t)e; }
         }
-        if (pile_ok) {
-            if (sc.seq.size() > 0xfffffff0ull - (size_t)r.l_seq) return fail(MSNV_EDOMAIN, "one sample holds more than 8.5 G bases in this shard: shard the contigs further");
-            h.seqoff = (uint32_t)sc.seq.size();
-            const int nb = (r.l_seq + 1) / 2;
-            if (r.l_seq == 0) {
-                // SEQ '*': mpileup prints 'N' with quality 0 for every position (never counted)
-                for (int64_t i = 0; i < (qlen + 1) / 2; ++i) sc.seq.push_back(0xff);
-                for (int64_t i = 0; i < ((qlen + 1) / 2) * 2; ++i) sc.qual.push_back(0);
+        if (r.l_seq == 0) continue;      // SEQ '*': every base prints as 'N' with quality 0 -> never counted
+        const std::string &refseq = ds.seqs[(size_t)r.tid];
+        const bool has_ref = ds.has_seq[(size_t)r.tid];
+        int64_t rp = r.pos; int64_t q = 0;
+        for (int k = 0; k < r.n_cigar; ++k) {
+            const uint32_t c = ld_u32(r.cigar + 4 * k), t = c & 15u, l = c >> 4;
+            if (t == C_M || t == C_EQ || t == C_X) {
+                for (uint32_t off = 0; off < l; off += SEG_MAX) {
+                    const uint32_t n = std::min<uint32_t>(SEG_MAX, l - off);
+                    if (sc.seq.size() > 0xffffff00ull) return fail(MSNV_EDOMAIN, "one sample holds more than 8.5 G aligned bases in this shard: shard the contigs further");
+                    ReadHdr h;
+                    h.gpos = (uint32_t)(rp + off);        // contig-relative until finalize
+                    h.seqoff = (uint32_t)sc.seq.size();
+                    h.cig = n;                            // segment length in bases
+                    h.meta = META_PILEUP_OK | (uint32_t)r.mapq << 16;
+                    sc.seq.resize(sc.seq.size() + (n + 1) / 2, 0xff);        // pad nibble = N
+                    uint8_t *dst = sc.seq.data() + h.seqoff;
+                    for (uint32_t j = 0; j < n; ++j) {
+                        const int64_t qq = q + off + j;
+                        uint32_t code = (r.seq[qq >> 1] >> ((~qq & 1) << 2)) & 0xfu;
+                        if (code == 0) {          // '=' always counts as a match (pileup_seq): ship the reference code instead
+                            const int64_t g = rp + off + j;
+                            code = (has_ref && g >= 0 && (size_t)g < refseq.size()) ? nt16_of_char((unsigned char)refseq[(size_t)g]) : 15u;
+                            if (code == 0) code = 15u;
+                        }
+                        const int sh = (int)(j & 1u) * 4;
+                        dst[j >> 1] = (uint8_t)((dst[j >> 1] & ~(0xf << sh)) | code << sh);      // low nibble first
+                        // qualities above 127 (0xff = "not stored") pass every cutoff; clamping keeps the comparison
+                        sc.qual.push_back(r.qual[qq] > 127 ? 127 : r.qual[qq]);
+                    }
+                    if (n & 1u) sc.qual.push_back(0);
+                    sc.hdr.push_back(h);
+                    sc.tid.push_back(r.tid);
+                    sc.depth.push_back(depth_here);
+                    sc.end.push_back((int32_t)(rp + off + n));
+                }
+                rp += l; q += l;
             } else {
-                for (int i = 0; i < nb; ++i) { uint8_t b = r.seq[i]; sc.seq.push_back((uint8_t)(b >> 4 | b << 4)); }   // low nibble first
-                if (has_eq_code(r.seq, r.l_seq)) rewrite_eq_codes(ds, r, sc.seq.data() + h.seqoff);
-                if (r.l_seq & 1) sc.seq.back() |= 0xf0;        // pad nibble = N
-                // qualities above 127 (0xff = "not stored") pass every cutoff mpileup accepts; clamping them to
-                // 127 keeps the comparison result and lets the device test four bytes with one add
-                for (int i = 0; i < r.l_seq; ++i) sc.qual.push_back(r.qual[i] > 127 ? 127 : r.qual[i]);
-                if (r.l_seq & 1) sc.qual.push_back(0);
-            }
-            sc.n_pileup_bases += (uint64_t)m_bases;
-            sc.n_pileup_reads++;
-            if (sc.first_tid < 0) {
-                // first pileup line of this sample (call_vC.cpp:423 drops the first line of the run)
-                int64_t b = r.pos, e = endpos;
-                if (ds.has_bed) { b = std::max(b, ds.bed_beg[(size_t)r.tid]); e = std::min(e, ds.bed_end[(size_t)r.tid]); }
-                if (b < e) { sc.first_tid = r.tid; sc.first_beg = (int32_t)b; sc.first_end = (int32_t)e; }
+                if (consumes_ref(t)) rp += l;
+                if (consumes_query(t)) q += l;
             }
         }
-        sc.hdr.push_back(h);
-        sc.tid.push_back(r.tid);
-        sc.depth.push_back(pile_ok ? depth_here : 0);
-        sc.end.push_back((int32_t)std::max<int64_t>(pile_ok ? endpos : 0, cov_ok ? qa_end + 1 : 0));
     }
     // tail padding: kernels read 16 B (qual) / 8 B (seq) chunks and may run past the last read
     for (int i = 0; i < 32; ++i) sc.seq.push_back(0xff);
@@ -185,7 +170,11 @@ int finalize_dataset(msnv_dataset &ds) {
     std::vector<int64_t> maxend(NC, 0);
     for (size_t c = 0; c < NC; ++c) maxend[c] = ds.sel[c] ? ds.lengths[c] : 0;
     for (const SampleCols &sc : ds.samples)
+    {
         for (size_t i = 0; i < sc.hdr.size(); ++i) maxend[(size_t)sc.tid[i]] = std::max<int64_t>(maxend[(size_t)sc.tid[i]], sc.end[i]);
+        for (size_t i = 0; i < sc.cov_tid.size(); ++i)
+            if (ds.sel[(size_t)sc.cov_tid[i]]) maxend[(size_t)sc.cov_tid[i]] = std::max<int64_t>(maxend[(size_t)sc.cov_tid[i]], (int64_t)sc.cov_beg[i] + 1);
+    }
     ds.tile_base.assign(NC, UINT32_MAX);
     ds.tile_contig.clear();
     uint64_t nt = 0;
@@ -240,10 +229,9 @@ int finalize_dataset(msnv_dataset &ds) {
     }
 
     // ---- per sample: gpos, tile overlap index; concatenate columns
-    std::vector<uint64_t> rbase(S + 1, 0), cbase(S + 1, 0), sbase(S + 1, 0);
+    std::vector<uint64_t> rbase(S + 1, 0), sbase(S + 1, 0);
     for (size_t s = 0; s < S; ++s) {
         rbase[s + 1] = rbase[s] + ds.samples[s].hdr.size();
-        cbase[s + 1] = cbase[s] + ds.samples[s].cig.size();
         sbase[s + 1] = sbase[s] + ((ds.samples[s].seq.size() + 15) & ~(size_t)15);
     }
     struct PairTmp { uint32_t tile, sample, lo, hi, maxd; };
@@ -260,8 +248,6 @@ int finalize_dataset(msnv_dataset &ds) {
             const uint64_t gs = g0 + sc.hdr[i].gpos;
             const uint64_t ge = std::max<uint64_t>(g0 + (uint64_t)sc.end[i], gs + 1);
             sc.hdr[i].gpos = (uint32_t)gs;
-            const bool ok = sc.hdr[i].meta & META_PILEUP_OK;
-            if (!ok) continue;                       // coverage-only reads are indexed by the coverage pass
             const uint32_t tlo = (uint32_t)(gs / TILE), thi = (uint32_t)((ge - 1) / TILE);
             for (uint32_t t = tlo; t <= thi; ++t) {
                 // pairs are created in increasing tile order because reads are sorted by start,
@@ -307,40 +293,55 @@ int finalize_dataset(msnv_dataset &ds) {
         std::vector<WorkItem> wide;
         for (uint64_t t = 0; t < nt; ++t) {
             uint32_t lo = tps[t];
-            uint64_t acc = 0;
+            uint64_t acc = 0, nch = 0;
             for (uint32_t k = tps[t]; k < tps[t + 1]; ++k) {
-                acc += pairs[k].read_hi - pairs[k].read_lo;
+                const uint32_t nr = pairs[k].read_hi - pairs[k].read_lo;
+                acc += nr; nch += (nr + CHUNK_READS - 1) / CHUNK_READS;
                 const bool narrow = pairs[k].max_depth < NARROW_MAX_DEPTH;
                 const bool boundary = k + 1 == tps[t + 1] || (narrow != (pairs[k + 1].max_depth < NARROW_MAX_DEPTH));
-                if (acc >= target || boundary) { (narrow ? work : wide).push_back(WorkItem{(uint32_t)t, lo, k + 1, 0}); lo = k + 1; acc = 0; }
+                const uint64_t next_ch = boundary ? 0 : (pairs[k + 1].read_hi - pairs[k + 1].read_lo + CHUNK_READS - 1) / CHUNK_READS;
+                if (acc >= target || boundary || nch + next_ch > MAX_CHUNKS_PER_ITEM) {
+                    (narrow ? work : wide).push_back(WorkItem{(uint32_t)t, lo, k + 1, 0, 0, {0, 0, 0}}); lo = k + 1; acc = 0; nch = 0;
+                }
             }
         }
         d->n_work_narrow = (uint32_t)work.size();
         work.insert(work.end(), wide.begin(), wide.end());
     }
+    // ---- chunk descriptors of the narrow work items
+    std::vector<ChunkDesc> chunks;
+    for (uint32_t wi = 0; wi < d->n_work_narrow; ++wi) {
+        WorkItem &w = work[wi];
+        w.chunk_lo = (uint32_t)chunks.size();
+        for (uint32_t k = w.pair_lo; k < w.pair_hi; ++k) {
+            const TilePair &p = pairs[k];
+            for (uint32_t r = p.read_lo; r < p.read_hi; r += CHUNK_READS) {
+                const uint32_t n = std::min<uint32_t>(CHUNK_READS, p.read_hi - r);
+                chunks.push_back(ChunkDesc{rbase[p.sample] + r, sbase[p.sample], p.sample, k, n | (r + n >= p.read_hi ? 1u << 16 : 0u), 0});
+            }
+        }
+        w.chunk_hi = (uint32_t)chunks.size();
+    }
+    if (int rc = upload_vec(&d->chunks, chunks, &d->device_bytes, 1)) return rc;
     d->n_pairs = (uint32_t)pairs.size(); d->n_work = (uint32_t)work.size();
     if (int rc = upload_vec(&d->pairs, pairs, &d->device_bytes)) return rc;
     if (int rc = upload_vec(&d->tile_pair_start, tps, &d->device_bytes)) return rc;
     if (int rc = upload_vec(&d->work, work, &d->device_bytes)) return rc;
     if (int rc = upload_vec(&d->s_read_base, rbase, &d->device_bytes)) return rc;
-    if (int rc = upload_vec(&d->s_cig_base, cbase, &d->device_bytes)) return rc;
     if (int rc = upload_vec(&d->s_seq_base, sbase, &d->device_bytes)) return rc;
 
     // ---- columns
-    d->n_reads = rbase[S]; d->n_cig = cbase[S]; d->n_seq_bytes = sbase[S];
+    d->n_reads = rbase[S]; d->n_seq_bytes = sbase[S];
     if (int rc = dev_alloc((void **)&d->hdr, (rbase[S] + 1) * sizeof(ReadHdr), &d->device_bytes)) return rc;
-    if (int rc = dev_alloc((void **)&d->cig, (cbase[S] + 1) * sizeof(uint32_t), &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->seq, sbase[S] + 64, &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->qual, 2 * sbase[S] + 64, &d->device_bytes)) return rc;
     uint64_t alg = 0;
     for (size_t s = 0; s < S; ++s) {
         SampleCols &sc = ds.samples[s];
         if (int rc = dev_upload(d->hdr + rbase[s], sc.hdr.data(), sc.hdr.size() * sizeof(ReadHdr))) return rc;
-        if (int rc = dev_upload(d->cig + cbase[s], sc.cig.data(), sc.cig.size() * sizeof(uint32_t))) return rc;
         if (int rc = dev_upload(d->seq + sbase[s], sc.seq.data(), sc.seq.size())) return rc;
         if (int rc = dev_upload(d->qual + 2 * sbase[s], sc.qual.data(), sc.qual.size())) return rc;
         ds.info.bytes_headers += sc.hdr.size() * sizeof(ReadHdr);
-        ds.info.bytes_cigar += sc.cig.size() * 4;
         ds.info.bytes_seq += sc.seq.size() - 32;
         ds.info.bytes_qual += 2 * (sc.seq.size() - 32);
         // release host staging of the bulky columns; headers stay (coverage pass, results mapping)
@@ -369,7 +370,7 @@ int finalize_dataset(msnv_dataset &ds) {
     for (size_t c = 0; c < NC; ++c) if (ds.sel[c]) { ds.info.n_contigs++; ds.info.n_positions += (uint64_t)ds.lengths[c]; }
     ds.info.n_reads = tot_reads; ds.info.n_reads_pileup = tot_pile_reads; ds.info.n_pileup_bases = tot_bases;
     ds.info.n_tiles = nt; ds.info.n_pairs = pairs.size(); ds.info.n_work = work.size();
-    ds.info.bytes_index = pairs.size() * sizeof(TilePair) + work.size() * sizeof(WorkItem) + (nt + 1) * 4;
+    ds.info.bytes_index = pairs.size() * sizeof(TilePair) + work.size() * sizeof(WorkItem) + chunks.size() * sizeof(ChunkDesc) + (nt + 1) * 4;
     ds.info.device_bytes = d->device_bytes;
     ds.finalized = true;
     return MSNV_OK;
