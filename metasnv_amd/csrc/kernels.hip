@@ -326,8 +326,10 @@ __device__ __forceinline__ void narrow_classify(NarrowLds &L, const uint4 qv, co
     const uint32_t m = lq << (pr & 3u);                                // <= 19 bits, aligned to the byte-bin words
     const uint32_t wb = pr >> 2;
 #pragma unroll
-    for (int w = 0; w < 5; ++w)
-        atomicAdd(&L.exc[wb + w], (((m >> (4 * w)) & 0xfu) * 0x00204081u) & 0x01010101u);
+    for (int w = 0; w < 5; ++w) {
+        const uint32_t v = (((m >> (4 * w)) & 0xfu) * 0x00204081u) & 0x01010101u;
+        if (v) atomicAdd(&L.exc[wb + w], v);                          // zero adds would only add LDS bank conflicts
+    }
     uint32_t e = nm & vmask & ~lq;
     while (e) {
         const uint32_t j = (uint32_t)__builtin_ctz(e);
@@ -336,16 +338,6 @@ __device__ __forceinline__ void narrow_classify(NarrowLds &L, const uint4 qv, co
         const uint32_t p = (uint32_t)(P0 + (int)j);
         if (ai < 4u) atomicAdd(&L.al[p], 1u << (8u * ai));
         else { const uint32_t pp = p + 16u; atomicAdd(&L.exc[pp >> 2], 1u << (8u * (pp & 3u))); }   // N / other IUPAC
-    }
-}
-
-__device__ __forceinline__ void narrow_emit(NarrowLds &L, const PileupArgs &a, uint32_t gpos, uint32_t sample, uint32_t word) {
-    while (word) {                                                   // rare: a mismatching allele at this position
-        const uint32_t x = (uint32_t)__builtin_ctz(word) >> 3;
-        const uint32_t n = (word >> (8u * x)) & 0xffu;
-        word &= ~(0xffu << (8u * x));
-        atomicAdd(&a.tot[(uint64_t)(1u + x) * a.npos + gpos], n);
-        stage_allele_event<NarrowLds, N_EVCAP>(L, a, Pair32{gpos, sample << 18 | x << 16 | n});
     }
 }
 
@@ -390,6 +382,7 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow(PileupArgs a) {
         if (!(a.ablate & 8) && c + 1 < nch && tid < N_HCAP && (uint32_t)tid < (L.desc[c + 1].nrd_flags & 0xffffu))
             hreg = *reinterpret_cast<const uint4 *>(a.hdr + L.desc[c + 1].hdr_base + tid);
         __syncthreads();                                            // (A)
+        if (L.evn >= (uint32_t)(N_EVCAP / 2)) flush_events<NarrowLds, N_NT, N_EVCAP>(L, a, tid);   // uniform: every append precedes (A)
 
         const uint8_t *seq = a.seq + cd.seq_base;
         const uint8_t *qual = a.qual + 2 * cd.seq_base;
@@ -458,19 +451,30 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow(PileupArgs a) {
                 packed[j >> 2] |= (cov & 0xffu) << (8 * (j & 3));
             }
             *reinterpret_cast<uint2 *>(a.spill + (uint64_t)k * TILE + N_PPT * tid) = make_uint2(packed[0], packed[1]);
-            if (anyal) {
-                const uint32_t g0 = t0 + N_PPT * tid;
-                narrow_emit(L, a, g0 + 0, sample, a0.x); narrow_emit(L, a, g0 + 1, sample, a0.y);
-                narrow_emit(L, a, g0 + 2, sample, a0.z); narrow_emit(L, a, g0 + 3, sample, a0.w);
-                narrow_emit(L, a, g0 + 4, sample, a1.x); narrow_emit(L, a, g0 + 5, sample, a1.y);
-                narrow_emit(L, a, g0 + 6, sample, a1.z); narrow_emit(L, a, g0 + 7, sample, a1.w);
+            if (anyal) {                                            // rare: some position of mine saw a mismatching allele
+                const uint32_t alw[N_PPT] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                uint32_t pm = 0;
+#pragma unroll
+                for (int j = 0; j < N_PPT; ++j) pm |= (alw[j] ? 1u : 0u) << j;
+                while (pm) {
+                    const uint32_t j = (uint32_t)__builtin_ctz(pm);
+                    pm &= pm - 1u;
+                    uint32_t word = alw[0];
+#pragma unroll
+                    for (int q = 1; q < N_PPT; ++q) word = (j == (uint32_t)q) ? alw[q] : word;
+                    const uint32_t gpos = t0 + N_PPT * tid + j;
+#pragma unroll
+                    for (uint32_t x = 0; x < 4; ++x) {
+                        const uint32_t n = (word >> (8u * x)) & 0xffu;
+                        if (n) {
+                            atomicAdd(&a.tot[(uint64_t)(1u + x) * a.npos + gpos], n);
+                            stage_allele_event<NarrowLds, N_EVCAP>(L, a, Pair32{gpos, sample << 18 | x << 16 | n});
+                        }
+                    }
+                }
             }
         }
         buf ^= 1;
-        if (last_chunk && c + 1 < nch) {
-            __syncthreads();
-            if (L.evn >= (uint32_t)(N_EVCAP / 2)) flush_events<NarrowLds, N_NT, N_EVCAP>(L, a, tid);
-        }
     }
     __syncthreads();
     flush_events<NarrowLds, N_NT, N_EVCAP>(L, a, tid);
