@@ -37,7 +37,7 @@ struct WorkItem { uint32_t tile, pair_lo, pair_hi, chunk_lo, chunk_hi, pad[3]; }
 // One chunk = up to CHUNK_READS consecutive reads of one (tile, sample) pair, with everything the
 // kernel needs to start loading (no dependent scalar loads on the critical path).
 constexpr uint32_t CHUNK_READS = 128;
-constexpr uint32_t MAX_CHUNKS_PER_ITEM = 64;
+constexpr uint32_t MAX_CHUNKS_PER_ITEM = 32;
 struct ChunkDesc { uint64_t hdr_base, seq_base; uint32_t sample, pair, nrd_flags, pad; };   // nrd | last_chunk << 16
 
 struct SiteRec { uint32_t gpos, cov, n[4]; };                          // gate kernel output (24 B)

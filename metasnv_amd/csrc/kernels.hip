@@ -104,7 +104,7 @@ struct WideLds {
     int32_t  span[TILE + 4];
     uint32_t exc[TILE / 2];                    // two u16 per word
     unsigned long long al[TILE];               // four u16 (A,C,G,T)
-    uint32_t ref[TILE / 8 + 4];                // 2 halo words (16 positions) on each side
+    uint32_t ref[TILE / 8 + 4];
     uint4    hdr[2][W_HCAP];
     Pair32   ev[W_EVCAP];
     int32_t  wsum[W_NT / 64];
@@ -132,8 +132,8 @@ __device__ __forceinline__ void stage_allele_event(LDS &L, const PileupArgs &a, 
 }
 
 __device__ __forceinline__ void wide_classify(WideLds &L, const uint4 qv, const uint32_t s0, const uint32_t s1,
-                                              const int P0, const uint32_t vmask, const uint32_t kq) {
-    const uint32_t pr = (uint32_t)(P0 + 16);
+                                              const uint32_t P0, const uint32_t vmask, const uint32_t kq) {
+    const uint32_t pr = P0;
     const uint32_t wi = pr >> 3, sh = (pr & 7u) * 4u;
     const uint32_t w0 = L.ref[wi], w1 = L.ref[wi + 1], w2 = L.ref[wi + 2];
     const uint32_t r0 = __builtin_amdgcn_alignbit(w1, w0, sh), r1 = __builtin_amdgcn_alignbit(w2, w1, sh);
@@ -143,7 +143,7 @@ __device__ __forceinline__ void wide_classify(WideLds &L, const uint4 qv, const 
     while (e) {
         const uint32_t j = (uint32_t)__builtin_ctz(e);
         e &= e - 1u;
-        const uint32_t p = (uint32_t)(P0 + (int)j);
+        const uint32_t p = P0 + j;
         uint32_t ai = 4u;
         if (!((lq >> j) & 1u)) ai = allele_index(((j < 8u ? s0 : s1) >> (4u * (j & 7u))) & 0xfu);
         if (ai < 4u) atomicAdd(&L.al[p], 1ull << (16u * ai));
@@ -160,10 +160,8 @@ __global__ __launch_bounds__(W_NT) void msnv_pileup_tiles_wide(PileupArgs a) {
     const uint32_t kq = 0x80808080u - min(a.min_baseq, 128u) * 0x01010101u;
     const int b0 = 16 * lane8;
 
-    for (int i = tid; i < (int)(TILE / 8 + 4); i += W_NT) {
-        const long long wi = (long long)(t0 >> 3) + i - 2;         // halo: positions outside the tile never pass vmask
-        L.ref[i] = (wi >= 0 && (uint64_t)wi < a.npos / 8) ? a.ref4[wi] : 0xffffffffu;
-    }
+    for (int i = tid; i < (int)(TILE / 8 + 4); i += W_NT)
+        L.ref[i] = (i < (int)(TILE / 8)) ? a.ref4[(t0 >> 3) + i] : 0xffffffffu;
     for (int i = tid; i < (int)(TILE + 4); i += W_NT) L.span[i] = 0;
     for (int i = tid; i < (int)(TILE / 2); i += W_NT) L.exc[i] = 0;
     for (int i = tid; i < (int)TILE; i += W_NT) L.al[i] = 0;
@@ -199,16 +197,14 @@ __global__ __launch_bounds__(W_NT) void msnv_pileup_tiles_wide(PileupArgs a) {
         for (uint32_t r = (uint32_t)grp; r < nrd; r += W_NT / LANES_PER_READ) {
             const uint4 h = L.hdr[buf][r];
             if (!(h.w & META_PILEUP_OK)) continue;
-            const int s = (int)(h.x - t0), len = (int)h.z;
-            const int lo = max(0, -s), hi = min(len, (int)TILE - s);
-            if (lo >= hi) continue;
-            if (lane8 == 0) { atomicAdd(&L.span[s + lo], 1); atomicAdd(&L.span[s + hi], -1); }
-            const int vlo = min(max(lo - b0, 0), 16), vhi = min(max(hi - b0, 0), 16);
-            if (vlo >= vhi) continue;
+            const uint32_t s = h.x - t0, len = h.z;                   // a piece never leaves its tile
+            if (lane8 == 0) { atomicAdd(&L.span[s], 1); atomicAdd(&L.span[s + len], -1); }
+            const int vhi = min(max((int)len - b0, 0), 16);
+            if (vhi <= 0) continue;
             uint4 qv; uint2 sv;
             __builtin_memcpy(&qv, qual + 2ull * h.y + (uint32_t)b0, 16);
             __builtin_memcpy(&sv, seq + (uint64_t)h.y + (uint32_t)(b0 >> 1), 8);
-            wide_classify(L, qv, sv.x, sv.y, s + b0, ((1u << vhi) - 1u) & ~((1u << vlo) - 1u), kq);
+            wide_classify(L, qv, sv.x, sv.y, s + (uint32_t)b0, (1u << vhi) - 1u, kq);
         }
 
         if (last_chunk) {
@@ -297,13 +293,14 @@ constexpr int N_PPT = TILE / N_NT;             // 8 positions per thread in the 
 constexpr int N_GROUPS = N_NT / LANES_PER_READ;
 constexpr int N_HCAP = CHUNK_READS;
 constexpr int N_ROUNDS = N_HCAP / N_GROUPS;    // 4
-constexpr int N_EVCAP = 512;
+constexpr int N_EVCAP = 256;
+
 static_assert(N_PPT == 8, "narrow per-sample pass is written for 8 positions per thread");
 
 struct NarrowLds {
     uint32_t start[TILE / 4 + 4];
     uint32_t end[TILE / 4 + 4];
-    uint32_t exc[TILE / 4 + 16];               // 4 halo words (16 positions) in front, 9+ behind
+    uint32_t exc[TILE / 4 + 8];                // lanes past the end of a piece may address up to 4 words beyond
     uint32_t al[TILE];
     uint32_t ref[TILE / 8 + 4];
     uint4    hdr[2][N_HCAP];
@@ -314,10 +311,10 @@ struct NarrowLds {
 };
 
 // 16 bases -> LDS byte bins.  qv: 16 qualities (<= 127 each), (s0,s1): 16 read nibbles (no code 0),
-// P0: tile position of base 0 (>= -15), vmask: bases that belong to this piece and tile.
+// P0: tile position of base 0 (pieces never leave their tile), vmask: bases that exist in this piece.
 __device__ __forceinline__ void narrow_classify(NarrowLds &L, const uint4 qv, const uint32_t s0, const uint32_t s1,
-                                                const int P0, const uint32_t vmask, const uint32_t kq) {
-    const uint32_t pr = (uint32_t)(P0 + 16);
+                                                const uint32_t P0, const uint32_t vmask, const uint32_t kq) {
+    const uint32_t pr = P0;
     const uint32_t wi = pr >> 3, sh = (pr & 7u) * 4u;
     const uint32_t w0 = L.ref[wi], w1 = L.ref[wi + 1], w2 = L.ref[wi + 2];
     const uint32_t r0 = __builtin_amdgcn_alignbit(w1, w0, sh), r1 = __builtin_amdgcn_alignbit(w2, w1, sh);
@@ -335,12 +332,74 @@ __device__ __forceinline__ void narrow_classify(NarrowLds &L, const uint4 qv, co
         const uint32_t j = (uint32_t)__builtin_ctz(e);
         e &= e - 1u;
         const uint32_t ai = allele_index(((j < 8u ? s0 : s1) >> (4u * (j & 7u))) & 0xfu);
-        const uint32_t p = (uint32_t)(P0 + (int)j);
+        const uint32_t p = P0 + j;
         if (ai < 4u) atomicAdd(&L.al[p], 1u << (8u * ai));
-        else { const uint32_t pp = p + 16u; atomicAdd(&L.exc[pp >> 2], 1u << (8u * (pp & 3u))); }   // N / other IUPAC
+        else atomicAdd(&L.exc[p >> 2], 1u << (8u * (p & 3u)));          // N / other IUPAC
     }
 }
 
+// Per-sample pass of the narrow kernel: prefix sum of start/end -> depth, minus the not-counted bases;
+// adds the sample to the running totals, spills the per-sample coverage bytes, emits allele events,
+// and leaves every bin zero for the next sample.  Called by all threads; contains barriers (B), (C).
+__device__ __forceinline__ void narrow_pass(NarrowLds &L, const PileupArgs &a, uint32_t (&tc)[N_PPT], const uint32_t t0,
+                                            const int tid, const int lane, const int wave, const uint32_t sample, const uint32_t k) {
+    __syncthreads();                                        // (B)
+    const uint2 st = *reinterpret_cast<uint2 *>(&L.start[2 * tid]);
+    const uint2 en = *reinterpret_cast<uint2 *>(&L.end[2 * tid]);
+    const uint2 ex = *reinterpret_cast<uint2 *>(&L.exc[2 * tid]);
+    const uint4 a0 = *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid]);
+    const uint4 a1 = *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid + 4]);
+    *reinterpret_cast<uint2 *>(&L.start[2 * tid]) = make_uint2(0u, 0u);
+    *reinterpret_cast<uint2 *>(&L.end[2 * tid]) = make_uint2(0u, 0u);
+    *reinterpret_cast<uint2 *>(&L.exc[2 * tid]) = make_uint2(0u, 0u);
+    if (tid == 0) L.end[TILE / 4] = 0;
+    const uint32_t anyal = a0.x | a0.y | a0.z | a0.w | a1.x | a1.y | a1.z | a1.w;
+    if (anyal) {
+        *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid]) = make_uint4(0u, 0u, 0u, 0u);
+        *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid + 4]) = make_uint4(0u, 0u, 0u, 0u);
+    }
+    const int mine = (int)(__builtin_amdgcn_udot4(st.x, 0x01010101u, __builtin_amdgcn_udot4(st.y, 0x01010101u, 0u, false), false)) -
+                     (int)(__builtin_amdgcn_udot4(en.x, 0x01010101u, __builtin_amdgcn_udot4(en.y, 0x01010101u, 0u, false), false));
+    const int incl = wave_inclusive_scan(mine);
+    if (lane == 63) L.wsum[wave] = incl;
+    __syncthreads();                                        // (C)
+    int d = incl - mine;
+    for (int wv = 0; wv < wave; ++wv) d += L.wsum[wv];
+    uint32_t packed[2] = {0u, 0u};
+#pragma unroll
+    for (int j = 0; j < N_PPT; ++j) {
+        const uint32_t sw = (j < 4) ? st.x : st.y, ew = (j < 4) ? en.x : en.y, xw = (j < 4) ? ex.x : ex.y;
+        d += (int)((sw >> (8 * (j & 3))) & 0xffu) - (int)((ew >> (8 * (j & 3))) & 0xffu);
+        const uint32_t cov = (uint32_t)d - ((xw >> (8 * (j & 3))) & 0xffu);
+        tc[j] += cov;
+        packed[j >> 2] |= (cov & 0xffu) << (8 * (j & 3));
+    }
+    *reinterpret_cast<uint2 *>(a.spill + (uint64_t)k * TILE + N_PPT * tid) = make_uint2(packed[0], packed[1]);
+    if (anyal) {                                            // rare: some position of mine saw a mismatching allele
+        const uint32_t alw[N_PPT] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        uint32_t pm = 0;
+#pragma unroll
+        for (int j = 0; j < N_PPT; ++j) pm |= (alw[j] ? 1u : 0u) << j;
+        while (pm) {
+            const uint32_t j = (uint32_t)__builtin_ctz(pm);
+            pm &= pm - 1u;
+            uint32_t word = alw[0];
+#pragma unroll
+            for (int q = 1; q < N_PPT; ++q) word = (j == (uint32_t)q) ? alw[q] : word;
+            const uint32_t gpos = t0 + N_PPT * tid + j;
+#pragma unroll
+            for (uint32_t x = 0; x < 4; ++x) {
+                const uint32_t n = (word >> (8u * x)) & 0xffu;
+                if (n) {
+                    atomicAdd(&a.tot[(uint64_t)(1u + x) * a.npos + gpos], n);
+                    stage_allele_event<NarrowLds, N_EVCAP>(L, a, Pair32{gpos, sample << 18 | x << 16 | n});
+                }
+            }
+        }
+    }
+}
+
+template <int N_BATCH>                         // rounds whose loads are in flight together
 __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow(PileupArgs a) {
     __shared__ NarrowLds L;
     const WorkItem w = a.work[blockIdx.x];
@@ -350,12 +409,10 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow(PileupArgs a) {
     const uint32_t kq = 0x80808080u - min(a.min_baseq, 128u) * 0x01010101u;
     const int b0 = 16 * lane8;
 
-    for (int i = tid; i < (int)(TILE / 8 + 4); i += N_NT) {
-        const long long wi = (long long)(t0 >> 3) + i - 2;
-        L.ref[i] = (wi >= 0 && (uint64_t)wi < a.npos / 8) ? a.ref4[wi] : 0xffffffffu;
-    }
+    for (int i = tid; i < (int)(TILE / 8 + 4); i += N_NT)
+        L.ref[i] = (i < (int)(TILE / 8)) ? a.ref4[(t0 >> 3) + i] : 0xffffffffu;
     for (int i = tid; i < (int)(TILE / 4 + 4); i += N_NT) { L.start[i] = 0; L.end[i] = 0; }
-    for (int i = tid; i < (int)(TILE / 4 + 16); i += N_NT) L.exc[i] = 0;
+    for (int i = tid; i < (int)(TILE / 4 + 8); i += N_NT) L.exc[i] = 0;
     for (int i = tid; i < (int)TILE; i += N_NT) L.al[i] = 0;
     if (tid == 0) L.evn = 0;
 
@@ -387,93 +444,38 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow(PileupArgs a) {
         const uint8_t *seq = a.seq + cd.seq_base;
         const uint8_t *qual = a.qual + 2 * cd.seq_base;
 
-        // one 16-base chunk per lane and round, loads issued together, no branches
-        uint4 qv[N_ROUNDS]; uint2 sv[N_ROUNDS]; int P0[N_ROUNDS]; uint32_t vm[N_ROUNDS];
+        // one 16-base chunk per lane and round; the loads of N_BATCH rounds are issued together; no branches
 #pragma unroll
-        for (int i = 0; i < N_ROUNDS; ++i) {
-            const uint4 h = L.hdr[buf][grp + i * N_GROUPS];
-            const bool ok = (h.w & META_PILEUP_OK) != 0u;
-            const int s = (int)(h.x - t0);                            // tile position of piece base 0 (wraps correctly)
-            const int len = (int)h.z;
-            const int lo = max(0, -s), hi = min(len, (int)TILE - s); // piece bases inside the tile: [lo, hi)
-            if (ok && lane8 == 0 && lo < hi) {
-                const uint32_t sa = (uint32_t)(s + lo), sb = (uint32_t)(s + hi);
-                atomicAdd(&L.start[sa >> 2], 1u << (8u * (sa & 3u)));
-                atomicAdd(&L.end[sb >> 2], 1u << (8u * (sb & 3u)));
-            }
-            if (a.ablate & 4) { qv[i] = make_uint4(h.x, h.y, h.z, h.w); sv[i] = make_uint2(h.x, h.y); }
-            else {
-            __builtin_memcpy(&qv[i], qual + 2ull * h.y + (uint32_t)b0, 16);      // h.y = 0 for empty slots: safe address
-            __builtin_memcpy(&sv[i], seq + (uint64_t)h.y + (uint32_t)(b0 >> 1), 8);
-            }
-            const int vlo = min(max(lo - b0, 0), 16), vhi = min(max(hi - b0, 0), 16);
-            const uint32_t mk = ((1u << vhi) - 1u) & ~((1u << vlo) - 1u);           // empty when vhi <= vlo
-            vm[i] = ok ? mk : 0u;
-            P0[i] = vm[i] ? s + b0 : 0;                              // keeps every LDS index of an empty lane in range
-        }
+        for (int bi = 0; bi < N_ROUNDS; bi += N_BATCH) {
+            uint4 qv[N_BATCH]; uint2 sv[N_BATCH]; uint32_t P0[N_BATCH]; uint32_t vm[N_BATCH];
 #pragma unroll
-        for (int i = 0; i < N_ROUNDS; ++i)
-            if (__any(vm[i] != 0u)) {
-                if (a.ablate & 1) { asm volatile("" :: "v"(qv[i].x), "v"(qv[i].y), "v"(qv[i].z), "v"(qv[i].w), "v"(sv[i].x), "v"(sv[i].y)); }
-                else narrow_classify(L, qv[i], sv[i].x, sv[i].y, P0[i], vm[i], kq);
-            }
-
-        if (last_chunk && !(a.ablate & 2)) {
-            __syncthreads();                                        // (B)
-            const uint2 st = *reinterpret_cast<uint2 *>(&L.start[2 * tid]);
-            const uint2 en = *reinterpret_cast<uint2 *>(&L.end[2 * tid]);
-            const uint2 ex = *reinterpret_cast<uint2 *>(&L.exc[2 * tid + 4]);
-            const uint4 a0 = *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid]);
-            const uint4 a1 = *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid + 4]);
-            *reinterpret_cast<uint2 *>(&L.start[2 * tid]) = make_uint2(0u, 0u);
-            *reinterpret_cast<uint2 *>(&L.end[2 * tid]) = make_uint2(0u, 0u);
-            *reinterpret_cast<uint2 *>(&L.exc[2 * tid + 4]) = make_uint2(0u, 0u);
-            if (tid == 0) { L.end[TILE / 4] = 0; L.exc[TILE / 4 + 4] = 0; }
-            const uint32_t anyal = a0.x | a0.y | a0.z | a0.w | a1.x | a1.y | a1.z | a1.w;
-            if (anyal) {
-                *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid]) = make_uint4(0u, 0u, 0u, 0u);
-                *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid + 4]) = make_uint4(0u, 0u, 0u, 0u);
-            }
-            const int mine = (int)(__builtin_amdgcn_udot4(st.x, 0x01010101u, __builtin_amdgcn_udot4(st.y, 0x01010101u, 0u, false), false)) -
-                             (int)(__builtin_amdgcn_udot4(en.x, 0x01010101u, __builtin_amdgcn_udot4(en.y, 0x01010101u, 0u, false), false));
-            const int incl = wave_inclusive_scan(mine);
-            if (lane == 63) L.wsum[wave] = incl;
-            __syncthreads();                                        // (C)
-            int d = incl - mine;
-            for (int wv = 0; wv < wave; ++wv) d += L.wsum[wv];
-            uint32_t packed[2] = {0u, 0u};
-#pragma unroll
-            for (int j = 0; j < N_PPT; ++j) {
-                const uint32_t sw = (j < 4) ? st.x : st.y, ew = (j < 4) ? en.x : en.y, xw = (j < 4) ? ex.x : ex.y;
-                d += (int)((sw >> (8 * (j & 3))) & 0xffu) - (int)((ew >> (8 * (j & 3))) & 0xffu);
-                const uint32_t cov = (uint32_t)d - ((xw >> (8 * (j & 3))) & 0xffu);
-                tc[j] += cov;
-                packed[j >> 2] |= (cov & 0xffu) << (8 * (j & 3));
-            }
-            *reinterpret_cast<uint2 *>(a.spill + (uint64_t)k * TILE + N_PPT * tid) = make_uint2(packed[0], packed[1]);
-            if (anyal) {                                            // rare: some position of mine saw a mismatching allele
-                const uint32_t alw[N_PPT] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-                uint32_t pm = 0;
-#pragma unroll
-                for (int j = 0; j < N_PPT; ++j) pm |= (alw[j] ? 1u : 0u) << j;
-                while (pm) {
-                    const uint32_t j = (uint32_t)__builtin_ctz(pm);
-                    pm &= pm - 1u;
-                    uint32_t word = alw[0];
-#pragma unroll
-                    for (int q = 1; q < N_PPT; ++q) word = (j == (uint32_t)q) ? alw[q] : word;
-                    const uint32_t gpos = t0 + N_PPT * tid + j;
-#pragma unroll
-                    for (uint32_t x = 0; x < 4; ++x) {
-                        const uint32_t n = (word >> (8u * x)) & 0xffu;
-                        if (n) {
-                            atomicAdd(&a.tot[(uint64_t)(1u + x) * a.npos + gpos], n);
-                            stage_allele_event<NarrowLds, N_EVCAP>(L, a, Pair32{gpos, sample << 18 | x << 16 | n});
-                        }
-                    }
+            for (int i = 0; i < N_BATCH; ++i) {
+                const uint4 h = L.hdr[buf][grp + (bi + i) * N_GROUPS];   // all zero for empty slots
+                const uint32_t len = h.z;
+                const uint32_t s = len ? h.x - t0 : 0u;                  // piece start inside the tile
+                if (len && lane8 == 0) {
+                    const uint32_t sb = s + len;
+                    atomicAdd(&L.start[s >> 2], 1u << (8u * (s & 3u)));
+                    atomicAdd(&L.end[sb >> 2], 1u << (8u * (sb & 3u)));
                 }
+                if (a.ablate & 4) { qv[i] = make_uint4(h.x, h.y, h.z, h.w); sv[i] = make_uint2(h.x, h.y); }
+                else {
+                __builtin_memcpy(&qv[i], qual + 2ull * h.y + (uint32_t)b0, 16);      // h.y = 0 for empty slots: safe address
+                __builtin_memcpy(&sv[i], seq + (uint64_t)h.y + (uint32_t)(b0 >> 1), 8);
+                }
+                const int vhi = min(max((int)len - b0, 0), 16);
+                vm[i] = (1u << vhi) - 1u;                                // empty for lanes past the end of the piece
+                P0[i] = vm[i] ? s + (uint32_t)b0 : 0u;                   // keeps every LDS index of an empty lane in range
             }
+#pragma unroll
+            for (int i = 0; i < N_BATCH; ++i)
+                if (__any(vm[i] != 0u)) {
+                    if (a.ablate & 1) { asm volatile("" :: "v"(qv[i].x), "v"(qv[i].y), "v"(qv[i].z), "v"(qv[i].w), "v"(sv[i].x), "v"(sv[i].y)); }
+                    else narrow_classify(L, qv[i], sv[i].x, sv[i].y, P0[i], vm[i], kq);
+                }
         }
+
+        if (last_chunk && !(a.ablate & 2)) narrow_pass(L, a, tc, t0, tid, lane, wave, sample, k);
         buf ^= 1;
     }
     __syncthreads();
@@ -698,7 +700,12 @@ int dev_run_pipeline(DeviceCols &d, const msnv_params &p, void *stream_, msnv_ru
         static const bool all_wide = [] { const char *e = getenv("MSNV_PILEUP"); return e && e[0] == 'w'; }();   // A/B: MSNV_PILEUP=wide
         const uint32_t n_narrow = all_wide ? 0u : d.n_work_narrow;
         // narrow work items (byte bins) and wide ones (16-bit bins) touch disjoint (tile, sample) pairs
-        if (n_narrow) hipLaunchKernelGGL(msnv_pileup_tiles_narrow, dim3(n_narrow), dim3(N_NT), 0, st, a);
+        static const int batch = [] { const char *e = getenv("MSNV_BATCH"); return e ? atoi(e) : 2; }();              // A/B: MSNV_BATCH=1|2|4
+        if (n_narrow) {
+            if (batch == 1) hipLaunchKernelGGL(msnv_pileup_tiles_narrow<1>, dim3(n_narrow), dim3(N_NT), 0, st, a);
+            else if (batch == 4) hipLaunchKernelGGL(msnv_pileup_tiles_narrow<4>, dim3(n_narrow), dim3(N_NT), 0, st, a);
+            else hipLaunchKernelGGL(msnv_pileup_tiles_narrow<2>, dim3(n_narrow), dim3(N_NT), 0, st, a);
+        }
         if (d.n_work > n_narrow) {
             PileupArgs b = a;
             b.work = d.work + n_narrow;

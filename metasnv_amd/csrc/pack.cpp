@@ -112,8 +112,10 @@ int pack_sample(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, Sa
         for (int k = 0; k < r.n_cigar; ++k) {
             const uint32_t c = ld_u32(r.cigar + 4 * k), t = c & 15u, l = c >> 4;
             if (t == C_M || t == C_EQ || t == C_X) {
-                for (uint32_t off = 0; off < l; off += SEG_MAX) {
-                    const uint32_t n = std::min<uint32_t>(SEG_MAX, l - off);
+                for (uint32_t off = 0, n = 0; off < l; off += n) {
+                    // a piece never crosses a tile boundary (contigs start on tile boundaries), so the device
+                    // needs no clipping and every piece belongs to exactly one (tile, sample) pair
+                    n = std::min<uint32_t>(std::min<uint32_t>(SEG_MAX, l - off), TILE - (uint32_t)((rp + off) % TILE));
                     if (sc.seq.size() > 0xffffff00ull) return fail(MSNV_EDOMAIN, "one sample holds more than 8.5 G aligned bases in this shard: shard the contigs further");
                     ReadHdr h;
                     h.gpos = (uint32_t)(rp + off);        // contig-relative until finalize
@@ -146,6 +148,25 @@ int pack_sample(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, Sa
                 if (consumes_ref(t)) rp += l;
                 if (consumes_query(t)) q += l;
             }
+        }
+    }
+    // ---- group the pieces by tile (stable: read order inside a tile); reads are sorted by start, so this
+    // only moves the few pieces of reads that run into the next tile
+    {
+        const size_t n = sc.hdr.size();
+        bool sorted = true;
+        for (size_t i = 1; i < n && sorted; ++i)
+            sorted = sc.tid[i - 1] < sc.tid[i] || (sc.tid[i - 1] == sc.tid[i] && sc.hdr[i - 1].gpos / TILE <= sc.hdr[i].gpos / TILE);
+        if (!sorted) {
+            std::vector<uint32_t> idx(n);
+            for (size_t i = 0; i < n; ++i) idx[i] = (uint32_t)i;
+            std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) {
+                if (sc.tid[x] != sc.tid[y]) return sc.tid[x] < sc.tid[y];
+                return sc.hdr[x].gpos / TILE < sc.hdr[y].gpos / TILE;
+            });
+            std::vector<ReadHdr> h2(n); std::vector<int32_t> t2(n), e2(n); std::vector<uint16_t> d2(n);
+            for (size_t i = 0; i < n; ++i) { h2[i] = sc.hdr[idx[i]]; t2[i] = sc.tid[idx[i]]; e2[i] = sc.end[idx[i]]; d2[i] = sc.depth[idx[i]]; }
+            sc.hdr.swap(h2); sc.tid.swap(t2); sc.end.swap(e2); sc.depth.swap(d2);
         }
     }
     // tail padding: kernels read 16 B (qual) / 8 B (seq) chunks and may run past the last read
@@ -241,25 +262,14 @@ int finalize_dataset(msnv_dataset &ds) {
     for (size_t s = 0; s < S; ++s) {
         SampleCols &sc = ds.samples[s];
         std::vector<PairTmp> &pv = per_sample[s];
-        // sweep reads in order; a read touches tiles [gs/TILE, (ge-1)/TILE]
+        // pieces are grouped by tile: one pair per run
         for (size_t i = 0; i < sc.hdr.size(); ++i) {
             const size_t c = (size_t)sc.tid[i];
-            const uint64_t g0 = (uint64_t)ds.tile_base[c] * TILE;
-            const uint64_t gs = g0 + sc.hdr[i].gpos;
-            const uint64_t ge = std::max<uint64_t>(g0 + (uint64_t)sc.end[i], gs + 1);
+            const uint64_t gs = (uint64_t)ds.tile_base[c] * TILE + sc.hdr[i].gpos;
             sc.hdr[i].gpos = (uint32_t)gs;
-            const uint32_t tlo = (uint32_t)(gs / TILE), thi = (uint32_t)((ge - 1) / TILE);
-            for (uint32_t t = tlo; t <= thi; ++t) {
-                // pairs are created in increasing tile order because reads are sorted by start,
-                // but a long read may reach a tile that already exists further back in the list
-                size_t k = pv.size();
-                while (k > 0 && pv[k - 1].tile > t) --k;
-                if (k > 0 && pv[k - 1].tile == t) {
-                    pv[k - 1].hi = (uint32_t)i + 1;
-                } else {
-                    pv.insert(pv.begin() + (ptrdiff_t)k, PairTmp{t, (uint32_t)s, (uint32_t)i, (uint32_t)i + 1, 0});
-                }
-            }
+            const uint32_t t = (uint32_t)(gs / TILE);
+            if (!pv.empty() && pv.back().tile == t) pv.back().hi = (uint32_t)i + 1;
+            else pv.push_back(PairTmp{t, (uint32_t)s, (uint32_t)i, (uint32_t)i + 1, 0});
         }
         for (PairTmp &p : pv) {       // depth bound: every read alive inside the tile was alive when one of [lo,hi) started
             uint32_t m = 0;
