@@ -95,4 +95,6 @@ struct msnv_dataset {
     msnv_run_stats last_stats{};
     std::vector<msnv_site> sites;
     std::vector<msnv_site_sample> site_samples;
+    bool have_coverage = false;
+    std::vector<unsigned long long> cov_acc;   // [sample][contig][1 + COV_BINS]
 };

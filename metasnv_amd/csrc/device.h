@@ -36,6 +36,16 @@ struct DeviceCols {
     msnv_site_sample *out = nullptr; // [cap_out_sites][n_samples]
     uint8_t  *site_flags = nullptr;  // pop_mask | ind_mask << 4
     uint64_t  cap_out_sites = 0;
+    // ---- genome coverage (qaCompute path)
+    Pair32   *cov_iv = nullptr;          // {gbeg, gend}: +1 at gbeg, -1 at gend (index space of qaCompute.cpp:530-552)
+    uint64_t *s_cov_base = nullptr;      // per sample
+    TilePair *cov_pairs = nullptr;
+    WorkItem *cov_work = nullptr;
+    uint32_t *tile_len = nullptr;        // scanned indices of each tile (i < contig length)
+    uint32_t *tile_contig_dev = nullptr;
+    unsigned long long *cov_acc = nullptr;   // [sample][contig][1 + COV_BINS]: covSum, hist[0..]
+    uint32_t  n_cov_pairs = 0, n_cov_work = 0, n_contigs = 0;
+    uint64_t  n_cov_iv = 0;
     uint64_t  device_bytes = 0;
     uint64_t  algorithmic_bytes = 0;
 };
@@ -53,6 +63,8 @@ int  dev_stream_create(void **stream);
 void dev_stream_destroy(void *stream);
 
 // One pass of the pipeline (pileup -> gate -> gather -> decide) on `stream`.
+constexpr int COV_BINS = 16;            // histogram bins kept on the device (qaCompute -c <= 15)
+int  dev_run_coverage(DeviceCols &d, int max_cov, void *stream, msnv_run_stats *stats);
 int  dev_run_pipeline(DeviceCols &d, const msnv_params &p, void *stream, msnv_run_stats *stats, RunCounts *counts);
 void dev_free_all(DeviceCols &d);
 

@@ -212,8 +212,4 @@ int write_calls_text(msnv_dataset &ds, const char *called_path, const char *indi
     return rc;
 }
 
-// ---- genome coverage (qaCompute path): filled in by coverage.hip
-int coverage_run(msnv_dataset &, msnv_run_stats *) { return fail(MSNV_EINVAL, "coverage kernels are not built into this library yet"); }
-int coverage_write(msnv_dataset &, int, const char *, const char *) { return fail(MSNV_EINVAL, "coverage kernels are not built into this library yet"); }
-
 }  // namespace msnv

@@ -636,6 +636,74 @@ __global__ __launch_bounds__(256) void msnv_decide_sites(const SiteRec *sites, u
     if (lane == 0) site_flags[site] = (uint8_t)(pop | ind << 4);
 }
 
+// ------------------------------------------------------------------------------------------
+// msnv_coverage_tiles: qaCompute's per-contig coverage arithmetic (qaCompute.cpp:530-552 scatter,
+// :142-165 prefix sum + histogram) for every sample, tile by tile.
+//   per (tile, sample): +1/-1 of every M interval into an LDS difference array (intervals that
+//   started in an earlier tile enter at index 0), DPP prefix sum, then for every scanned index
+//   (i < contig length) covSum += cov and hist[min(cov, max_cov)]++, reduced per wave and added
+//   to the (sample, contig) accumulators with 64-bit atomics.
+// Algorithmic HBM bytes: 8 B per M interval.
+// ------------------------------------------------------------------------------------------
+constexpr int C_NT = 256;
+constexpr int C_PPT = TILE / C_NT;             // 8
+
+__device__ __forceinline__ int wave_reduce_add(int x) {
+    x = wave_inclusive_scan(x);
+    return __builtin_amdgcn_readlane(x, 63);
+}
+
+__global__ __launch_bounds__(C_NT) void msnv_coverage_tiles(const Pair32 *iv, const uint64_t *s_cov_base, const TilePair *pairs,
+                                                            const WorkItem *work, const uint32_t *tile_len, const uint32_t *tile_contig,
+                                                            unsigned long long *acc, uint32_t n_contigs, int max_cov) {
+    __shared__ int s_d[TILE + 4];
+    __shared__ int s_w[C_NT / 64];
+    const WorkItem w = work[blockIdx.x];
+    const uint32_t t0 = w.tile * TILE, tl = tile_len[w.tile], contig = tile_contig[w.tile];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < (int)(TILE + 4); i += C_NT) s_d[i] = 0;
+    __syncthreads();
+    for (uint32_t k = w.pair_lo; k < w.pair_hi; ++k) {
+        const TilePair pr = pairs[k];
+        const Pair32 *v = iv + s_cov_base[pr.sample];
+        for (uint32_t i = pr.read_lo + (uint32_t)tid; i < pr.read_hi; i += C_NT) {
+            const Pair32 x = v[i];
+            if (x.y <= t0 || x.x >= t0 + TILE) continue;
+            atomicAdd(&s_d[x.x > t0 ? x.x - t0 : 0u], 1);
+            if (x.y < t0 + TILE) atomicAdd(&s_d[x.y - t0], -1);
+        }
+        __syncthreads();
+        int4 d0 = *reinterpret_cast<int4 *>(&s_d[C_PPT * tid]);
+        int4 d1 = *reinterpret_cast<int4 *>(&s_d[C_PPT * tid + 4]);
+        *reinterpret_cast<int4 *>(&s_d[C_PPT * tid]) = make_int4(0, 0, 0, 0);
+        *reinterpret_cast<int4 *>(&s_d[C_PPT * tid + 4]) = make_int4(0, 0, 0, 0);
+        d0.y += d0.x; d0.z += d0.y; d0.w += d0.z; d1.x += d0.w; d1.y += d1.x; d1.z += d1.y; d1.w += d1.z;
+        const int incl = wave_inclusive_scan(d1.w);
+        if (lane == 63) s_w[wave] = incl;
+        __syncthreads();
+        int off = incl - d1.w;
+        for (int wv = 0; wv < wave; ++wv) off += s_w[wv];
+        const int cv[C_PPT] = {off + d0.x, off + d0.y, off + d0.z, off + d0.w, off + d1.x, off + d1.y, off + d1.z, off + d1.w};
+        unsigned long long hp = 0;          // 16 bins x 4 bits (at most 8 positions per thread)
+        int csum = 0;
+#pragma unroll
+        for (int j = 0; j < C_PPT; ++j) {
+            if ((uint32_t)(C_PPT * tid + j) < tl) {
+                csum += cv[j];
+                hp += 1ull << (4 * min(cv[j], max_cov));
+            }
+        }
+        unsigned long long *dst = acc + ((uint64_t)pr.sample * n_contigs + contig) * (1 + COV_BINS);
+        const int ws = wave_reduce_add(csum);
+        if (lane == 0 && ws) atomicAdd(&dst[0], (unsigned long long)(long long)ws);
+        for (int b = 0; b <= max_cov; ++b) {
+            const int wb = wave_reduce_add((int)((hp >> (4 * b)) & 15ull));
+            if (lane == 0 && wb) atomicAdd(&dst[1 + b], (unsigned long long)wb);
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------ host side
 int dev_set_device(int device) {
     int n = 0;
@@ -662,7 +730,8 @@ void dev_stream_destroy(void *stream) { if (stream) (void)hipStreamDestroy((hipS
 void dev_free_all(DeviceCols &d) {
     void *ptrs[] = {d.hdr, d.seq, d.qual, d.s_read_base, d.s_seq_base, d.ref4, d.ref_lc, d.pairs,
                     d.tile_pair_start, d.work, d.chunks, d.tile_vbeg, d.tile_vend, d.tot, d.spill, d.events, d.overflow, d.counters,
-                    d.sites, d.tile_site_base, d.tile_site_cnt, d.out, d.site_flags};
+                    d.sites, d.tile_site_base, d.tile_site_cnt, d.out, d.site_flags,
+                    d.cov_iv, d.s_cov_base, d.cov_pairs, d.cov_work, d.tile_len, d.tile_contig_dev, d.cov_acc};
     for (void *p : ptrs) dev_free(p);
     d = DeviceCols{};
 }
@@ -762,6 +831,27 @@ int dev_run_pipeline(DeviceCols &d, const msnv_params &p, void *stream_, msnv_ru
     }
     if (counts) *counts = c;
     cleanup();
+    return MSNV_OK;
+}
+
+int dev_run_coverage(DeviceCols &d, int max_cov, void *stream_, msnv_run_stats *stats) {
+    hipStream_t st = (hipStream_t)stream_;
+    if (max_cov < 1 || max_cov >= COV_BINS) return fail(MSNV_EINVAL, "coverage histogram cutoff must be in [1, %d]", COV_BINS - 1);
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, st));
+    HIP_TRY(hipMemsetAsync(d.cov_acc, 0, (uint64_t)d.n_samples * d.n_contigs * (1 + COV_BINS) * sizeof(unsigned long long), st));
+    if (d.n_cov_work) {
+        hipLaunchKernelGGL(msnv_coverage_tiles, dim3(d.n_cov_work), dim3(C_NT), 0, st, d.cov_iv, d.s_cov_base, d.cov_pairs, d.cov_work,
+                           d.tile_len, d.tile_contig_dev, d.cov_acc, d.n_contigs, max_cov);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(e1, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (stats) stats->ms_coverage = ms;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return MSNV_OK;
 }
 

@@ -90,7 +90,13 @@ int pack_sample(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, Sa
             if (r.n_cigar > 0) { const uint32_t t = ld_u32(r.cigar) & 15u; if (t == C_S || t == C_H) k = 1; }
             for (; k < r.n_cigar; ++k) {
                 const uint32_t c = ld_u32(r.cigar + 4 * k), t = c & 15u, l = c >> 4;
-                if (t == C_M) { sc.cov_tid.push_back(r.tid); sc.cov_beg.push_back((int32_t)pp); sc.cov_end.push_back((int32_t)(pp + l)); }
+                if (t == C_M && ds.sel[(size_t)r.tid]) {
+                    // `++entireChr[pp]` with pp >= chrSize writes past the scanned range and the matching
+                    // `--entireChr[chrSize-1]` drives the coverage negative (qaCompute.cpp:542-549): undefined there
+                    if (pp >= ds.lengths[(size_t)r.tid])
+                        return fail(MSNV_EDOMAIN, "read at %s:%d aligns at or beyond the contig end (qaCompute: undefined behaviour)", ds.names[(size_t)r.tid].c_str(), r.pos + 1);
+                    sc.cov_tid.push_back(r.tid); sc.cov_beg.push_back((int32_t)pp); sc.cov_end.push_back((int32_t)(pp + l));
+                }
                 pp += l;
             }
         }
@@ -360,6 +366,67 @@ int finalize_dataset(msnv_dataset &ds) {
     }
     alg = ds.info.bytes_headers + ds.info.bytes_cigar + ds.info.bytes_seq + ds.info.bytes_qual;
     d->algorithmic_bytes = alg;
+
+    // ---- genome coverage index: intervals of qaCompute's difference array, grouped by tile
+    {
+        std::vector<Pair32> iv;
+        std::vector<uint64_t> cvbase(S + 1, 0);
+        struct CP { uint32_t tile, sample, lo, hi; };
+        std::vector<std::vector<CP>> per(S);
+        for (size_t s = 0; s < S; ++s) {
+            const SampleCols &sc = ds.samples[s];
+            uint32_t n_here = 0;
+            for (size_t i = 0; i < sc.cov_tid.size(); ++i) {
+                const size_t c = (size_t)sc.cov_tid[i];
+                const int64_t L = ds.lengths[c];
+                const int64_t b = sc.cov_beg[i];
+                const int64_t e = sc.cov_end[i] >= L ? L - 1 : sc.cov_end[i];       // qaCompute.cpp:544-549
+                if (b >= e) continue;
+                const uint64_t g0 = (uint64_t)ds.tile_base[c] * TILE;
+                const uint32_t idx = n_here++;
+                iv.push_back(Pair32{(uint32_t)(g0 + (uint64_t)b), (uint32_t)(g0 + (uint64_t)e)});
+                std::vector<CP> &pv = per[s];
+                for (uint32_t t = (uint32_t)((g0 + b) / TILE); t <= (uint32_t)((g0 + e - 1) / TILE); ++t) {
+                    size_t k = pv.size();
+                    while (k > 0 && pv[k - 1].tile > t) --k;
+                    if (k > 0 && pv[k - 1].tile == t) pv[k - 1].hi = idx + 1;
+                    else pv.insert(pv.begin() + (ptrdiff_t)k, CP{t, (uint32_t)s, idx, idx + 1});
+                }
+            }
+            cvbase[s + 1] = cvbase[s] + n_here;
+        }
+        std::vector<uint32_t> cps(nt + 1, 0);
+        for (size_t s = 0; s < S; ++s) for (const CP &p : per[s]) cps[p.tile + 1]++;
+        for (uint64_t t = 0; t < nt; ++t) cps[t + 1] += cps[t];
+        std::vector<TilePair> cpairs(cps[nt]);
+        {
+            std::vector<uint32_t> fill(cps.begin(), cps.end() - 1);
+            for (size_t s = 0; s < S; ++s) for (const CP &p : per[s]) cpairs[fill[p.tile]++] = TilePair{p.sample, p.lo, p.hi, 0};
+        }
+        std::vector<WorkItem> cwork;
+        for (uint64_t t = 0; t < nt; ++t) {
+            uint32_t lo = cps[t]; uint64_t acc = 0;
+            for (uint32_t k = cps[t]; k < cps[t + 1]; ++k) {
+                acc += cpairs[k].read_hi - cpairs[k].read_lo;
+                if (acc >= 4096 || k + 1 == cps[t + 1]) { cwork.push_back(WorkItem{(uint32_t)t, lo, k + 1, 0, 0, {0, 0, 0}}); lo = k + 1; acc = 0; }
+            }
+        }
+        std::vector<uint32_t> tlen(nt + 1, 0), tcont(nt + 1, 0);
+        for (uint64_t t = 0; t < nt; ++t) {
+            const size_t c = ds.tile_contig[t];
+            const int64_t t0 = (int64_t)(t - ds.tile_base[c]) * TILE;
+            tlen[t] = (uint32_t)std::min<int64_t>(std::max<int64_t>(ds.lengths[c] - t0, 0), TILE);
+            tcont[t] = (uint32_t)c;
+        }
+        d->n_cov_iv = iv.size(); d->n_cov_pairs = (uint32_t)cpairs.size(); d->n_cov_work = (uint32_t)cwork.size(); d->n_contigs = (uint32_t)NC;
+        if (int rc = upload_vec(&d->cov_iv, iv, &d->device_bytes, 1)) return rc;
+        if (int rc = upload_vec(&d->s_cov_base, cvbase, &d->device_bytes)) return rc;
+        if (int rc = upload_vec(&d->cov_pairs, cpairs, &d->device_bytes, 1)) return rc;
+        if (int rc = upload_vec(&d->cov_work, cwork, &d->device_bytes, 1)) return rc;
+        if (int rc = upload_vec(&d->tile_len, tlen, &d->device_bytes)) return rc;
+        if (int rc = upload_vec(&d->tile_contig_dev, tcont, &d->device_bytes)) return rc;
+        if (int rc = dev_alloc((void **)&d->cov_acc, (uint64_t)S * NC * (1 + COV_BINS) * sizeof(unsigned long long), &d->device_bytes)) return rc;
+    }
 
     // ---- intermediates
     if (int rc = dev_alloc((void **)&d->tot, std::max<uint64_t>(1, 5 * npos) * sizeof(uint32_t), &d->device_bytes)) return rc;

@@ -111,7 +111,7 @@ int orc_qacompute(const orc_ref *head, const orc_sample *sample, int max_cov, in
                         if ((op & 15) != 0) {
                             pp = pp + (op >> 4);
                         } else {
-                            if (pp > chrSize) { orc_set_error("read starts beyond the contig end (reference: out-of-bounds write)"); free(entireChr); free(coverageHist); fclose(out); fclose(detail); return ORC_ERR_DOMAIN; }
+                            if (pp >= chrSize) { orc_set_error("read aligns at or beyond the contig end (reference: out-of-bounds write / negative coverage)"); free(entireChr); free(coverageHist); fclose(out); fclose(detail); return ORC_ERR_DOMAIN; }
                             ++entireChr[pp];
                             pp = pp + (op >> 4);
                             if (pp >= chrSize) --entireChr[chrSize - 1];

@@ -150,3 +150,79 @@ def test_repeated_runs_are_idempotent():
         ds.run()
     s2, m2 = ds.results()
     assert s1.tobytes() == s2.tobytes() and m1.tobytes() == m2.tobytes()
+
+
+def _coverage_both(names, lengths, samples, tmp_path, params=None):
+    ctx = core.Context(0)
+    ds = core.Dataset(ctx, names, lengths, None, params)
+    for s in samples:
+        ds.add_sample_records(s)
+    ds.finalize()
+    st = ds.coverage_run()
+    out = []
+    for i, s in enumerate(samples):
+        cp, dp = str(tmp_path / ("s%d.cov" % i)), str(tmp_path / ("s%d.cov.detail" % i))
+        ds.write_coverage(i, cp, dp)
+        p = params or core.default_params()
+        out.append(((open(cp).read(), open(dp).read()), orc.qacompute(names, lengths, s, max_cov=p.cov_max, min_mapq=p.cov_min_mapq)))
+    ds.close(); ctx.close()
+    return out, st
+
+
+def test_coverage_matches_qacompute_restatement(tmp_path):
+    syn, samples = synth_case(n_species=3, contig_len=7000, n_samples=5, mean_cov=6.0, frac_absent=0.3, seed=17)
+    # header contigs before, between and after the covered ones print zero rows (printSkipped)
+    names = ["empty.a"] + syn.names[:2] + ["empty.b", syn.names[2], "empty.c"]
+    lengths = [1234] + syn.lengths[:2] + [99, syn.lengths[2], 5000]
+    remap = {0: 1, 1: 2, 2: 4}
+    fixed = []
+    for s in samples:
+        b = bytearray(s.tobytes())
+        off = 0
+        while off < len(b):
+            bs = int.from_bytes(b[off:off + 4], "little")
+            tid = int.from_bytes(b[off + 4:off + 8], "little", signed=True)
+            b[off + 4:off + 8] = remap[tid].to_bytes(4, "little", signed=True)
+            off += bs + 4
+        fixed.append(np.frombuffer(bytes(b), dtype=np.uint8))
+    fixed = [s for s in fixed if s.size]
+    res, st = _coverage_both(names, lengths, fixed, tmp_path)
+    for (got, want) in res:
+        assert got[0] == want[0]
+        assert got[1] == want[1]
+    assert "empty.a\t1234\t0.00000" in res[0][0][0]
+
+
+def test_coverage_cigar_quirks_and_filters(tmp_path):
+    L = 300
+    ref = "ACGT" * 75
+    rec = [
+        bt.make_record(0, 10, "5S20M", "N" * 5 + ref[10:30]),                       # leading clip skipped without advancing
+        bt.make_record(0, 10, "10M5I10M", ref[10:20] + "GGGGG" + ref[20:30]),       # insertion advances the cursor
+        bt.make_record(0, 12, "10M4D10M", ref[12:22] + ref[26:36]),
+        bt.make_record(0, 15, "8=4X8=", ref[15:35]),                                # '=' / 'X' blocks are never counted
+        bt.make_record(0, 20, "10M3S", ref[20:30] + "NNN"),
+        bt.make_record(0, 30, "20M", ref[30:50], mapq=0),                           # sub-par mapping quality
+        bt.make_record(0, 30, "20M", ref[30:50], flag=0x400),                       # duplicate
+        bt.make_record(0, 30, "20M", ref[30:50], flag=0x100 | 0x200 | 0x1),         # secondary/QC-fail/orphan ARE counted
+        bt.make_record(0, 280, "19M", ref[280:299]),                                # hangs into the clamp at L-1
+        bt.make_record(0, 285, "14M", ref[285:299]),
+        bt.make_record(-1, -1, "*", "ACGT", flag=4),
+    ]
+    s1 = bt.records(*rec)
+    s2 = bt.records(*[bt.make_record(1, 5 * k, "50M", "A" * 50, name="k%d" % k) for k in range(60)])     # depth well above -c 10
+    res, st = _coverage_both(["c1", "c2"], [L, 400], [s1, s2], tmp_path)
+    for (got, want) in res:
+        assert got[0] == want[0]
+        assert got[1] == want[1]
+    for p in (core.default_params(cov_max=3, cov_min_mapq=0), core.default_params(cov_max=15)):
+        for (got, want) in _coverage_both(["c1", "c2"], [L, 400], [s1, s2], tmp_path, p)[0]:
+            assert got == want
+
+
+def test_coverage_domain_errors_are_reported():
+    ctx = core.Context(0)
+    ds = core.Dataset(ctx, ["c1"], [100], None)
+    with pytest.raises(core._lib.MsnvError) as e:
+        ds.add_sample_records(bt.records(bt.make_record(0, 99, "5M", "ACGTA")))      # index 100 >= length
+    assert e.value.code == core._lib.EDOMAIN
