@@ -209,6 +209,15 @@ typedef struct {
 
 typedef struct { uint16_t cov; uint16_t n[4]; } msnv_site_sample;
 
+/* First pileup line of this dataset's invocation (the one call_vC.cpp:423 drops); tid = -1 if no read passes. */
+int  msnv_dataset_first_line(const msnv_dataset *ds, int32_t *tid, int32_t *pos);
+/* Formats site records that did not come from a local run (multi-GPU: records gathered from the
+ * ranks over RCCL) exactly as msnv_write_calls does.  Records must be in (tid, pos) order. */
+int  msnv_write_calls_records(const msnv_ref_desc *ref, int32_t n_samples, const msnv_site *sites,
+                              const msnv_site_sample *samples, uint64_t n_sites,
+                              const char *called_path, const char *indiv_path,
+                              const char *ann_path, const char *fasta_path);
+
 int  msnv_results_count(const msnv_dataset *ds, uint64_t *n_sites);
 /* sites[n_sites], samples[n_sites * n_samples], both in (tid, pos) order. */
 int  msnv_results_fetch(msnv_dataset *ds, msnv_site *sites, msnv_site_sample *samples, uint64_t capacity);

@@ -107,6 +107,8 @@ SYMBOLS = [
     ("msnv_coverage_run", C.c_int, [_vp, P(RunStats)]),
     ("msnv_write_coverage", C.c_int, [_vp, C.c_int32, C.c_char_p, C.c_char_p]),
     ("msnv_write_calls", C.c_int, [_vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]),
+    ("msnv_dataset_first_line", C.c_int, [_vp, P(C.c_int32), P(C.c_int32)]),
+    ("msnv_write_calls_records", C.c_int, [P(RefDesc), C.c_int32, P(Site), P(SiteSample), C.c_uint64, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]),
     ("msnv_results_count", C.c_int, [_vp, P(C.c_uint64)]),
     ("msnv_results_fetch", C.c_int, [_vp, P(Site), P(SiteSample), C.c_uint64]),
     ("msnv_bam_write_bed_header", C.c_int, [C.c_char_p, C.c_char_p]),

@@ -162,6 +162,11 @@ class Dataset:
                                      samples.ctypes.data_as(C.POINTER(SiteSample)), n.value))
         return sites, samples
 
+    def first_line(self):
+        t, p = C.c_int32(), C.c_int32()
+        check(lib.msnv_dataset_first_line(self._h, C.byref(t), C.byref(p)))
+        return t.value, p.value
+
     def write_calls(self, called_path, indiv_path=None, ann_path=None, fasta_path=None):
         check(lib.msnv_write_calls(self._h, called_path.encode(), indiv_path.encode() if indiv_path else None,
                                    ann_path.encode() if ann_path else None, fasta_path.encode() if fasta_path else None))
@@ -176,6 +181,20 @@ class Dataset:
             self.close()
         except Exception:
             pass
+
+
+def write_calls_records(names, n_samples, sites, samples, called_path, indiv_path=None, ann_path=None, fasta_path=None):
+    """Format gathered site records (numpy arrays of SITE_DTYPE / SAMPLE_DTYPE) as called_SNPs / indiv_called."""
+    n = len(names)
+    arr = _cstr_array(names)
+    lens = (C.c_int64 * n)(*([0] * n))
+    rd = RefDesc(n, arr, lens, None, None)
+    sites = np.ascontiguousarray(sites, dtype=SITE_DTYPE)
+    samples = np.ascontiguousarray(samples, dtype=SAMPLE_DTYPE).reshape(len(sites), max(1, n_samples) if len(sites) else 0)
+    check(lib.msnv_write_calls_records(C.byref(rd), n_samples, sites.ctypes.data_as(C.POINTER(Site)),
+                                       samples.ctypes.data_as(C.POINTER(SiteSample)), len(sites), called_path.encode(),
+                                       indiv_path.encode() if indiv_path else None, ann_path.encode() if ann_path else None,
+                                       fasta_path.encode() if fasta_path else None))
 
 
 # ------------------------------------------------------------------------------------ host I/O helpers

@@ -351,6 +351,30 @@ extern "C" int msnv_write_calls(msnv_dataset *ds, const char *called_path, const
     return write_calls_text(*ds, called_path, indiv_path, ann_path, fasta_path);
 }
 
+extern "C" int msnv_dataset_first_line(const msnv_dataset *ds, int32_t *tid, int32_t *pos) {
+    clear_error();
+    if (!ds || !tid || !pos) return fail(MSNV_EINVAL, "msnv_dataset_first_line: NULL argument");
+    if (!ds->finalized) return fail(MSNV_EINVAL, "msnv_dataset_first_line: dataset is not finalized");
+    *tid = ds->first_tid; *pos = (int32_t)ds->first_pos;
+    return MSNV_OK;
+}
+
+extern "C" int msnv_write_calls_records(const msnv_ref_desc *ref, int32_t n_samples, const msnv_site *sites,
+                                        const msnv_site_sample *samples, uint64_t n_sites,
+                                        const char *called_path, const char *indiv_path,
+                                        const char *ann_path, const char *fasta_path) {
+    clear_error();
+    if (!ref || !called_path || n_samples < 0 || (n_sites && (!sites || !samples))) return fail(MSNV_EINVAL, "msnv_write_calls_records: bad argument");
+    msnv_dataset tmp;                       // formatter state only: names, sample count, records
+    for (int i = 0; i < ref->n_contigs; ++i) tmp.names.emplace_back(ref->names[i]);
+    tmp.samples.resize((size_t)n_samples);
+    tmp.sites.assign(sites, sites + n_sites);
+    tmp.site_samples.assign(samples, samples + n_sites * (uint64_t)n_samples);
+    for (uint64_t i = 0; i < n_sites; ++i)
+        if (sites[i].tid < 0 || sites[i].tid >= ref->n_contigs) return fail(MSNV_EINVAL, "record %llu names contig %d", (unsigned long long)i, sites[i].tid);
+    return write_calls_text(tmp, called_path, indiv_path, ann_path, fasta_path);
+}
+
 extern "C" int msnv_coverage_run(msnv_dataset *ds, msnv_run_stats *stats) {
     clear_error();
     if (!ds || !ds->finalized) return fail(MSNV_EINVAL, "msnv_coverage_run: dataset is not finalized");
