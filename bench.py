@@ -25,6 +25,19 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
 
 
+def measured_traffic(samples, species, contig_len, mean_cov):
+    """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/
+    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 read correction applied).
+    Only valid for the workload it was collected on; anything else reports null."""
+    try:
+        p = json.load(open(os.path.join(ROOT, "profiles", "r01b_pmc_pileup_narrow.json")))
+        if (samples, species, contig_len, mean_cov) == (160, 3, 300000, 10.0):
+            return p["hbm_traffic"]["total_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -133,7 +146,7 @@ def main():
                        "reads_per_gpu": info["n_reads"], "parallelism": "contig shards x%d, no data-path collective" % world,
                        "called_SNPs_lines_per_rank": called},
             "roofline": {"bound": "hbm", "kernel": "msnv_pileup_tiles", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(a.samples, a.species, a.contig_len, a.mean_cov),
                          "algorithmic_bytes_per_launch": alg, "kernel_ms_avg": k_ms,
                          "bytes_per_pileup_base": alg / max(1, bases)},
             "positions_per_s": info["n_positions"] * world * a.steps / dt_max,
