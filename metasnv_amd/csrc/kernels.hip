@@ -463,13 +463,21 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow(PileupArgs a) {
                     atomicAdd(&L.start[s >> 2], 1u << (8u * (s & 3u)));
                     atomicAdd(&L.end[sb >> 2], 1u << (8u * (sb & 3u)));
                 }
+                const int vhi = min(max((int)len - b0, 0), 16);
+                qv[i] = make_uint4(0, 0, 0, 0); sv[i] = make_uint2(0, 0);
                 if (a.ablate & 4) { qv[i] = make_uint4(h.x, h.y, h.z, h.w); sv[i] = make_uint2(h.x, h.y); }
                 else {
                 const uint32_t so = (a.ablate & 16) ? (h.y & 0x3fffu) : h.y;          // timing experiment: L2-resident loads
-                __builtin_memcpy(&qv[i], qual + 2ull * so + (uint32_t)b0, 16);       // h.y = 0 for empty slots: safe address
+                if (vhi > 0) {                                                       // lanes past the end of the piece load nothing
+                if (a.ablate & 256) {                                                // timing experiment: aligned addresses
+                    qv[i] = *reinterpret_cast<const uint4 *>(qual + ((2ull * so + (uint32_t)b0) & ~15ull));
+                    sv[i] = *reinterpret_cast<const uint2 *>(seq + (((uint64_t)so + (uint32_t)(b0 >> 1)) & ~7ull));
+                } else {
+                __builtin_memcpy(&qv[i], qual + 2ull * so + (uint32_t)b0, 16);
                 __builtin_memcpy(&sv[i], seq + (uint64_t)so + (uint32_t)(b0 >> 1), 8);
                 }
-                const int vhi = min(max((int)len - b0, 0), 16);
+                }
+                }
                 vm[i] = (1u << vhi) - 1u;                                // empty for lanes past the end of the piece
                 const int n0 = min(vhi, 8), n1 = max(vhi - 8, 0);        // the same mask per dword of 8 nibbles
                 vn0[i] = (n0 == 8) ? 0x88888888u : (((1u << (4 * n0)) - 1u) & 0x88888888u);
@@ -485,6 +493,131 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow(PileupArgs a) {
         }
 
         if (last_chunk && !(a.ablate & 2)) narrow_pass(L, a, tc, t0, tid, lane, wave, sample, k);
+        buf ^= 1;
+    }
+    __syncthreads();
+    flush_events<NarrowLds, N_NT, N_EVCAP>(L, a, tid);
+#pragma unroll
+    for (int j = 0; j < N_PPT; ++j)
+        if (tc[j]) atomicAdd(&a.tot[(uint64_t)t0 + N_PPT * tid + j], tc[j]);
+}
+
+// ------------------------------------------------------------------------------------------
+// msnv_pileup_tiles_narrow32: msnv_pileup_tiles_narrow with FOUR lanes per piece and 32 bases per lane.
+// Perturbation runs on the 16-base kernel showed the vector-memory (TA/L1) path to be the most
+// sensitive resource (+1 sixteen-byte load per round: +15 % time; +25 % VALU: +4 %).  32 bases per lane
+// need 3 wide loads (2 x 16 B quality, 1 x 16 B bases) where two 16-base lanes need 4, and the header
+// decode / reference alignment / exception spreading are paid once per 32 bases.
+// ------------------------------------------------------------------------------------------
+constexpr int N32_LANES = 4;
+constexpr int N32_GROUPS = N_NT / N32_LANES;   // 64 pieces per round
+constexpr int N32_ROUNDS = N_HCAP / N32_GROUPS;   // 2
+static_assert(N32_LANES * 32 == SEG_MAX && N32_ROUNDS == 2, "narrow32 is written for 128-base pieces, 128-piece chunks");
+
+__device__ __forceinline__ void narrow_classify32(NarrowLds &L, const uint4 qa, const uint4 qb, const uint4 sq, const uint32_t P0,
+                                                  const int vhi, const uint32_t kq) {
+    const uint32_t wi = P0 >> 3, sh = (P0 & 7u) * 4u;
+    const uint32_t w0 = L.ref[wi], w1 = L.ref[wi + 1], w2 = L.ref[wi + 2], w3 = L.ref[wi + 3], w4 = L.ref[wi + 4];
+    const uint32_t vmask = (vhi >= 32) ? 0xffffffffu : ((1u << vhi) - 1u);
+    const uint32_t lq = (lowq_mask(qa, kq) | lowq_mask(qb, kq) << 16) & vmask;
+    const unsigned long long m = (unsigned long long)lq << (P0 & 7u);      // <= 39 bits: five groups of 8 byte bins
+#pragma unroll
+    for (int w = 0; w < 5; ++w) {
+        const uint32_t byte = (uint32_t)(m >> (8 * w)) & 0xffu;
+        if (byte) atomicAdd(&L.exc[wi + w], L.spread[byte]);
+    }
+    const uint32_t sw[4] = {sq.x, sq.y, sq.z, sq.w};
+    const uint32_t rw[4] = {__builtin_amdgcn_alignbit(w1, w0, sh), __builtin_amdgcn_alignbit(w2, w1, sh),
+                            __builtin_amdgcn_alignbit(w3, w2, sh), __builtin_amdgcn_alignbit(w4, w3, sh)};
+    uint32_t e[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int n = min(max(vhi - 8 * k, 0), 8);
+        const uint32_t vn = (n == 8) ? 0x88888888u : (((1u << (4 * n)) - 1u) & 0x88888888u);
+        e[k] = nz_nibbles(sw[k] ^ rw[k]) & vn;
+    }
+    while (e[0] | e[1] | e[2] | e[3]) {                              // mismatches (rare)
+        const int k = e[0] ? 0 : e[1] ? 1 : e[2] ? 2 : 3;
+        const uint32_t ew = e[0] ? e[0] : e[1] ? e[1] : e[2] ? e[2] : e[3];
+        const uint32_t b = (uint32_t)__builtin_ctz(ew);
+        if (k == 0) e[0] &= e[0] - 1u; else if (k == 1) e[1] &= e[1] - 1u; else if (k == 2) e[2] &= e[2] - 1u; else e[3] &= e[3] - 1u;
+        const uint32_t j = (b >> 2) + 8u * (uint32_t)k;
+        if ((lq >> j) & 1u) continue;                                  // below the BQ cutoff: already in exc
+        const uint32_t word = (k == 0) ? sw[0] : (k == 1) ? sw[1] : (k == 2) ? sw[2] : sw[3];
+        const uint32_t code = (word >> (b - 3u)) & 0xfu;
+        const uint32_t p = P0 + j;
+        if ((code & (code - 1u)) == 0u) atomicAdd(&L.al[p], 1u << (8u * (uint32_t)__builtin_ctz(code)));
+        else atomicAdd(&L.exc[p >> 3], 1ull << (8u * (p & 7u)));
+    }
+}
+
+__global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32(PileupArgs a) {
+    __shared__ NarrowLds L;
+    const WorkItem w = a.work[blockIdx.x];
+    const uint32_t t0 = w.tile * TILE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane4 = tid & (N32_LANES - 1), grp = tid / N32_LANES;
+    const uint32_t kq = 0x80808080u - min(a.min_baseq, 128u) * 0x01010101u;
+    const int b0 = 32 * lane4;
+
+    for (int i = tid; i < (int)(TILE / 8 + 4); i += N_NT)
+        L.ref[i] = (i < (int)(TILE / 8)) ? a.ref4[(t0 >> 3) + i] : 0xffffffffu;
+    for (int i = tid; i < (int)(TILE / 4 + 4); i += N_NT) { L.start[i] = 0; L.end[i] = 0; }
+    for (int i = tid; i < (int)(TILE / 8 + 4); i += N_NT) L.exc[i] = 0;
+    L.spread[tid] = ((unsigned long long)((((uint32_t)tid >> 4) * 0x00204081u) & 0x01010101u) << 32) | (((uint32_t)tid & 0xfu) * 0x00204081u & 0x01010101u);
+    for (int i = tid; i < (int)TILE; i += N_NT) L.al[i] = 0;
+    if (tid == 0) L.evn = 0;
+    uint32_t tc[N_PPT];
+#pragma unroll
+    for (int j = 0; j < N_PPT; ++j) tc[j] = 0;
+
+    const uint32_t nch = w.chunk_hi - w.chunk_lo;
+    for (uint32_t i = tid; i < nch * 2; i += N_NT)
+        reinterpret_cast<uint4 *>(L.desc)[i] = reinterpret_cast<const uint4 *>(a.chunks + w.chunk_lo)[i];
+    __syncthreads();
+    uint4 hreg = make_uint4(0, 0, 0, 0);
+    if (nch && tid < N_HCAP && (uint32_t)tid < (L.desc[0].nrd_flags & 0xffffu))
+        hreg = *reinterpret_cast<const uint4 *>(a.hdr + L.desc[0].hdr_base + tid);
+    int buf = 0;
+
+    for (uint32_t c = 0; c < nch; ++c) {
+        const ChunkDesc cd = L.desc[c];
+        const bool last_chunk = (cd.nrd_flags >> 16) != 0u;
+        if (tid < N_HCAP) L.hdr[buf][tid] = hreg;                    // slots beyond nrd hold meta = 0
+        hreg = make_uint4(0, 0, 0, 0);
+        if (c + 1 < nch && tid < N_HCAP && (uint32_t)tid < (L.desc[c + 1].nrd_flags & 0xffffu))
+            hreg = *reinterpret_cast<const uint4 *>(a.hdr + L.desc[c + 1].hdr_base + tid);
+        __syncthreads();                                            // (A)
+        if (L.evn >= (uint32_t)(N_EVCAP / 2)) flush_events<NarrowLds, N_NT, N_EVCAP>(L, a, tid);
+
+        const uint8_t *seq = a.seq + cd.seq_base;
+        const uint8_t *qual = a.qual + 2 * cd.seq_base;
+        uint4 qa[N32_ROUNDS], qb[N32_ROUNDS], sq[N32_ROUNDS]; uint32_t P0[N32_ROUNDS]; int vh[N32_ROUNDS];
+#pragma unroll
+        for (int i = 0; i < N32_ROUNDS; ++i) {
+            const uint4 h = L.hdr[buf][grp + i * N32_GROUPS];        // all zero for empty slots
+            const uint32_t len = h.z;
+            const uint32_t s = len ? h.x - t0 : 0u;
+            if (len && lane4 == 0) {
+                const uint32_t sb = s + len;
+                atomicAdd(&L.start[s >> 2], 1u << (8u * (s & 3u)));
+                atomicAdd(&L.end[sb >> 2], 1u << (8u * (sb & 3u)));
+            }
+            vh[i] = min(max((int)len - b0, 0), 32);
+            qa[i] = make_uint4(0, 0, 0, 0); qb[i] = qa[i]; sq[i] = qa[i];
+            if (vh[i] > 0) {                                         // lanes past the end of the piece load nothing
+                const uint8_t *qp = qual + 2ull * h.y + (uint32_t)b0;
+                __builtin_memcpy(&qa[i], qp, 16);
+                if (vh[i] > 16) __builtin_memcpy(&qb[i], qp + 16, 16);
+                __builtin_memcpy(&sq[i], seq + (uint64_t)h.y + (uint32_t)(b0 >> 1), 16);
+            }
+            P0[i] = vh[i] > 0 ? s + (uint32_t)b0 : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < N32_ROUNDS; ++i)
+            if (__any(vh[i] > 0)) narrow_classify32(L, qa[i], qb[i], sq[i], P0[i], vh[i], kq);
+
+        if (last_chunk) narrow_pass(L, a, tc, t0, tid, lane, wave, cd.sample, cd.pair);
         buf ^= 1;
     }
     __syncthreads();
@@ -907,10 +1040,11 @@ int dev_run_pipeline(DeviceCols &d, const msnv_params &p, void *stream_, msnv_ru
         static const bool all_wide = [] { const char *e = getenv("MSNV_PILEUP"); return e && e[0] == 'w'; }();   // A/B: MSNV_PILEUP=wide
         const uint32_t n_narrow = all_wide ? 0u : d.n_work_narrow;
         // narrow work items (byte bins) and wide ones (16-bit bins) touch disjoint (tile, sample) pairs
-        static const int batch = [] { const char *e = getenv("MSNV_BATCH"); return e ? atoi(e) : 0; }();              // A/B: MSNV_BATCH=0 (ping-pong) |1|2|4
+        static const int batch = [] { const char *e = getenv("MSNV_BATCH"); return e ? atoi(e) : 32; }();             // A/B: MSNV_BATCH=32 (default: 32 bases per lane) | 0 (ping-pong) |1|2|4
         if (n_narrow) {
             static const int dynlds = [] { const char *e = getenv("MSNV_DYNLDS"); return e ? atoi(e) : 0; }();   // occupancy experiment
-            if (batch == 0) hipLaunchKernelGGL(msnv_pileup_tiles_narrow_pp, dim3(n_narrow), dim3(N_NT), dynlds, st, a);
+            if (batch == 32) hipLaunchKernelGGL(msnv_pileup_tiles_narrow32, dim3(n_narrow), dim3(N_NT), dynlds, st, a);
+            else if (batch == 0) hipLaunchKernelGGL(msnv_pileup_tiles_narrow_pp, dim3(n_narrow), dim3(N_NT), dynlds, st, a);
             else if (batch == 1) hipLaunchKernelGGL(msnv_pileup_tiles_narrow<1>, dim3(n_narrow), dim3(N_NT), 0, st, a);
             else if (batch == 4) hipLaunchKernelGGL(msnv_pileup_tiles_narrow<4>, dim3(n_narrow), dim3(N_NT), 0, st, a);
             else hipLaunchKernelGGL(msnv_pileup_tiles_narrow<2>, dim3(n_narrow), dim3(N_NT), dynlds, st, a);
