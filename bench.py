@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--contig-len", type=int, default=300000)
     ap.add_argument("--species", type=int, default=3)
     ap.add_argument("--mean-cov", type=float, default=10.0)
-    ap.add_argument("--cpu-samples", type=int, default=24, help="samples of the workload the CPU oracle is timed on")
+    ap.add_argument("--cpu-samples", type=int, default=64, help="samples of the workload the CPU oracle is timed on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-threads", type=int, default=0)
     return ap.parse_args()
@@ -145,7 +145,7 @@ def main():
                        "samples": a.samples, "positions_per_gpu": info["n_positions"], "pileup_bases_per_gpu": bases,
                        "reads_per_gpu": info["n_reads"], "parallelism": "contig shards x%d, no data-path collective" % world,
                        "called_SNPs_lines_per_rank": called},
-            "roofline": {"bound": "hbm", "kernel": "msnv_pileup_tiles", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "msnv_pileup_tiles_narrow32", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(a.samples, a.species, a.contig_len, a.mean_cov),
                          "algorithmic_bytes_per_launch": alg, "kernel_ms_avg": k_ms,
                          "bytes_per_pileup_base": alg / max(1, bases)},

@@ -46,7 +46,6 @@ struct PileupArgs {
     Pair32         *overflow; uint32_t cap_overflow;
     uint32_t       *counters;
     uint32_t        min_baseq;
-    uint32_t        ablate;       // timing experiments only (MSNV_ABLATE); 0 in production
 };
 
 // allele index (A,C,G,T -> 0..3) of a one-hot nt16 code, 4 for anything else
@@ -271,28 +270,29 @@ __global__ __launch_bounds__(W_NT) void msnv_pileup_tiles_wide(PileupArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// msnv_pileup_tiles_narrow: the same algorithm for (tile, sample) pairs whose per-position depth is
-// known (host bound) to stay below 255, which lets every LDS bin be ONE BYTE:
+// Narrow path = the dominant kernel (msnv_pileup_tiles_narrow32 below): the same algorithm for
+// (tile, sample) pairs whose per-position depth is known (host bound) to stay below 255, which lets
+// every LDS bin be ONE BYTE:
 //   start[p] / end[p]  segment pieces that begin at / end before p  (coverage = running sum)
 //   exc[p]             bases not counted (BQ below cutoff, N, other IUPAC)
 //   al[p]              4 bytes: mismatching A, C, G, T
-// ~25 KB of LDS and 256 threads per workgroup -> several resident workgroups per CU.
-// The hot loop is written to minimise instructions per base (rocprof: the SIMDs, not HBM, are busy):
-//   * every header is one segment piece of <= 128 aligned bases (the host resolves the CIGAR), so
-//     there is exactly one code path and it is branch free: clipping by min/max, empty lanes get an
-//     empty valid-mask and load from a safe address;
+// ~24 KB of LDS and 256 threads per workgroup -> 6 resident workgroups per CU.
+// The hot loop is written to minimise instructions and vector-memory operations per base:
+//   * every header is one segment piece of <= 128 aligned bases inside one tile (the host resolves
+//     the CIGAR and splits at tile boundaries): one code path, no clipping, no branches on data;
 //   * chunk descriptors are staged in LDS, headers are prefetched one chunk ahead, and all data
 //     loads of a 128-piece chunk are issued before the first one is consumed;
-//   * BQ cutoff: 4 bytes per add + and-not; match = nibble equality (host rewrites '=');
-//   * flag bits are compressed with v_dot4_u32_u8; low-quality bases reach the byte bins through
-//     5 unconditional LDS atomics per 16-base chunk (multiply-spread of 4 flag bits into 4 bytes);
-//   * the per-sample prefix sum uses DPP row shifts; allele totals go straight to global memory.
+//   * BQ cutoff: 4 bytes per add + and-not (host clamps qualities to <= 127); match = nibble equality
+//     against the LDS-staged reference (host rewrites '=' codes); BQ flags compressed with
+//     v_dot4_u32_u8; mismatch flags stay in the nibble domain (they are rare);
+//   * low-quality bases reach the byte bins 8 positions at a time: a 256-entry LDS table turns 8 flag
+//     bits into 8 bytes for one 64-bit LDS atomic, skipped when zero;
+//   * the per-sample prefix sum uses DPP row shifts; allele totals go straight to global memory and
+//     allele events are staged in LDS (one returning global atomic per flush).
 // ------------------------------------------------------------------------------------------
 constexpr int N_NT = 256;
 constexpr int N_PPT = TILE / N_NT;             // 8 positions per thread in the per-sample pass
-constexpr int N_GROUPS = N_NT / LANES_PER_READ;
 constexpr int N_HCAP = CHUNK_READS;
-constexpr int N_ROUNDS = N_HCAP / N_GROUPS;    // 4
 constexpr int N_EVCAP = 256;
 
 static_assert(N_PPT == 8, "narrow per-sample pass is written for 8 positions per thread");
@@ -310,37 +310,6 @@ struct NarrowLds {
     int32_t  wsum[N_NT / 64];
     uint32_t evn, ev_base;
 };
-
-// 16 bases -> LDS byte bins.  qv: 16 qualities (<= 127 each), (s0,s1): 16 read nibbles (no code 0),
-// P0: tile position of base 0 (pieces never leave their tile), vmask: bases that exist in this piece,
-// (vn0,vn1): the same mask in the nibble domain (bit 4j+3 of the dword holding base j).
-__device__ __forceinline__ void narrow_classify(NarrowLds &L, const uint4 qv, const uint32_t s0, const uint32_t s1,
-                                                const uint32_t P0, const uint32_t vmask, const uint32_t vn0, const uint32_t vn1,
-                                                const uint32_t kq) {
-    const uint32_t wi = P0 >> 3, sh = (P0 & 7u) * 4u;
-    const uint32_t w0 = L.ref[wi], w1 = L.ref[wi + 1], w2 = L.ref[wi + 2];
-    const uint32_t r0 = __builtin_amdgcn_alignbit(w1, w0, sh), r1 = __builtin_amdgcn_alignbit(w2, w1, sh);
-    // low-quality bases: 16 flag bits -> up to 3 groups of 8 byte bins; the table turns 8 bits into 8 bytes
-    const uint32_t lq = lowq_mask(qv, kq) & vmask;
-    const uint32_t m = lq << (P0 & 7u);                                // <= 23 bits
-    if (m & 0xffu) atomicAdd(&L.exc[wi], L.spread[m & 0xffu]);
-    if (m & 0xff00u) atomicAdd(&L.exc[wi + 1], L.spread[(m >> 8) & 0xffu]);
-    if (m >> 16) atomicAdd(&L.exc[wi + 2], L.spread[m >> 16]);
-    // mismatches (rare): nibble-domain flags, no compression
-    uint32_t e0 = nz_nibbles(s0 ^ r0) & vn0, e1 = nz_nibbles(s1 ^ r1) & vn1;
-    while (e0 | e1) {
-        const bool first = e0 != 0u;
-        const uint32_t ew = first ? e0 : e1;
-        const uint32_t b = (uint32_t)__builtin_ctz(ew);                // 4*j + 3 inside the dword
-        if (first) e0 &= e0 - 1u; else e1 &= e1 - 1u;
-        const uint32_t j = (b >> 2) + (first ? 0u : 8u);
-        if ((lq >> j) & 1u) continue;                                  // below the BQ cutoff: already in exc
-        const uint32_t code = ((first ? s0 : s1) >> (b - 3u)) & 0xfu;
-        const uint32_t p = P0 + j;
-        if ((code & (code - 1u)) == 0u) atomicAdd(&L.al[p], 1u << (8u * (uint32_t)__builtin_ctz(code)));   // A,C,G,T = 1,2,4,8
-        else atomicAdd(&L.exc[p >> 3], 1ull << (8u * (p & 7u)));      // N / other IUPAC: not counted
-    }
-}
 
 // Per-sample pass of the narrow kernel: prefix sum of start/end -> depth, minus the not-counted bases;
 // adds the sample to the running totals, spills the per-sample coverage bytes, emits allele events,
@@ -403,111 +372,12 @@ __device__ __forceinline__ void narrow_pass(NarrowLds &L, const PileupArgs &a, u
     }
 }
 
-template <int N_BATCH>                         // rounds whose loads are in flight together
-__global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow(PileupArgs a) {
-    __shared__ NarrowLds L;
-    const WorkItem w = a.work[blockIdx.x];
-    const uint32_t t0 = w.tile * TILE;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lane8 = tid & (LANES_PER_READ - 1), grp = tid / LANES_PER_READ;
-    const uint32_t kq = 0x80808080u - min(a.min_baseq, 128u) * 0x01010101u;
-    const int b0 = 16 * lane8;
-
-    for (int i = tid; i < (int)(TILE / 8 + 4); i += N_NT)
-        L.ref[i] = (i < (int)(TILE / 8)) ? a.ref4[(t0 >> 3) + i] : 0xffffffffu;
-    for (int i = tid; i < (int)(TILE / 4 + 4); i += N_NT) { L.start[i] = 0; L.end[i] = 0; }
-    for (int i = tid; i < (int)(TILE / 8 + 4); i += N_NT) L.exc[i] = 0;
-    L.spread[tid] = ((unsigned long long)((((uint32_t)tid >> 4) * 0x00204081u) & 0x01010101u) << 32) | (((uint32_t)tid & 0xfu) * 0x00204081u & 0x01010101u);
-    for (int i = tid; i < (int)TILE; i += N_NT) L.al[i] = 0;
-    if (tid == 0) L.evn = 0;
-
-    uint32_t tc[N_PPT];
-#pragma unroll
-    for (int j = 0; j < N_PPT; ++j) tc[j] = 0;
-
-    // chunk descriptors of this work item -> LDS (no dependent scalar loads inside the loop)
-    const uint32_t nch = w.chunk_hi - w.chunk_lo;
-    for (uint32_t i = tid; i < nch * 2; i += N_NT)
-        reinterpret_cast<uint4 *>(L.desc)[i] = reinterpret_cast<const uint4 *>(a.chunks + w.chunk_lo)[i];
-    __syncthreads();
-    uint4 hreg = make_uint4(0, 0, 0, 0);
-    if (nch && tid < N_HCAP && (uint32_t)tid < (L.desc[0].nrd_flags & 0xffffu))
-        hreg = *reinterpret_cast<const uint4 *>(a.hdr + L.desc[0].hdr_base + tid);
-    int buf = 0;
-
-    for (uint32_t c = 0; c < nch; ++c) {
-        const ChunkDesc cd = L.desc[c];
-        const bool last_chunk = (cd.nrd_flags >> 16) != 0u;
-        const uint32_t sample = cd.sample, k = cd.pair;
-        if (tid < N_HCAP) L.hdr[buf][tid] = hreg;                    // slots beyond nrd hold meta = 0
-        hreg = make_uint4(0, 0, 0, 0);
-        if (!(a.ablate & 8) && c + 1 < nch && tid < N_HCAP && (uint32_t)tid < (L.desc[c + 1].nrd_flags & 0xffffu))
-            hreg = *reinterpret_cast<const uint4 *>(a.hdr + L.desc[c + 1].hdr_base + tid);
-        __syncthreads();                                            // (A)
-        if (L.evn >= (uint32_t)(N_EVCAP / 2)) flush_events<NarrowLds, N_NT, N_EVCAP>(L, a, tid);   // uniform: every append precedes (A)
-
-        const uint8_t *seq = a.seq + cd.seq_base;
-        const uint8_t *qual = a.qual + 2 * cd.seq_base;
-
-        // one 16-base chunk per lane and round; the loads of N_BATCH rounds are issued together; no branches
-#pragma unroll
-        for (int bi = 0; bi < N_ROUNDS; bi += N_BATCH) {
-            uint4 qv[N_BATCH]; uint2 sv[N_BATCH]; uint32_t P0[N_BATCH], vm[N_BATCH], vn0[N_BATCH], vn1[N_BATCH];
-#pragma unroll
-            for (int i = 0; i < N_BATCH; ++i) {
-                const uint4 h = L.hdr[buf][grp + (bi + i) * N_GROUPS];   // all zero for empty slots
-                const uint32_t len = h.z;
-                const uint32_t s = len ? h.x - t0 : 0u;                  // piece start inside the tile
-                if (len && lane8 == 0) {
-                    const uint32_t sb = s + len;
-                    atomicAdd(&L.start[s >> 2], 1u << (8u * (s & 3u)));
-                    atomicAdd(&L.end[sb >> 2], 1u << (8u * (sb & 3u)));
-                }
-                const int vhi = min(max((int)len - b0, 0), 16);
-                qv[i] = make_uint4(0, 0, 0, 0); sv[i] = make_uint2(0, 0);
-                if (a.ablate & 4) { qv[i] = make_uint4(h.x, h.y, h.z, h.w); sv[i] = make_uint2(h.x, h.y); }
-                else {
-                const uint32_t so = (a.ablate & 16) ? (h.y & 0x3fffu) : h.y;          // timing experiment: L2-resident loads
-                if (vhi > 0) {                                                       // lanes past the end of the piece load nothing
-                if (a.ablate & 256) {                                                // timing experiment: aligned addresses
-                    qv[i] = *reinterpret_cast<const uint4 *>(qual + ((2ull * so + (uint32_t)b0) & ~15ull));
-                    sv[i] = *reinterpret_cast<const uint2 *>(seq + (((uint64_t)so + (uint32_t)(b0 >> 1)) & ~7ull));
-                } else {
-                __builtin_memcpy(&qv[i], qual + 2ull * so + (uint32_t)b0, 16);
-                __builtin_memcpy(&sv[i], seq + (uint64_t)so + (uint32_t)(b0 >> 1), 8);
-                }
-                }
-                }
-                vm[i] = (1u << vhi) - 1u;                                // empty for lanes past the end of the piece
-                const int n0 = min(vhi, 8), n1 = max(vhi - 8, 0);        // the same mask per dword of 8 nibbles
-                vn0[i] = (n0 == 8) ? 0x88888888u : (((1u << (4 * n0)) - 1u) & 0x88888888u);
-                vn1[i] = (n1 == 8) ? 0x88888888u : (((1u << (4 * n1)) - 1u) & 0x88888888u);
-                P0[i] = vm[i] ? s + (uint32_t)b0 : 0u;                   // keeps every LDS index of an empty lane in range
-            }
-#pragma unroll
-            for (int i = 0; i < N_BATCH; ++i)
-                if (__any(vm[i] != 0u)) {
-                    if (a.ablate & 1) { asm volatile("" :: "v"(qv[i].x), "v"(qv[i].y), "v"(qv[i].z), "v"(qv[i].w), "v"(sv[i].x), "v"(sv[i].y)); }
-                    else narrow_classify(L, qv[i], sv[i].x, sv[i].y, P0[i], vm[i], vn0[i], vn1[i], kq);
-                }
-        }
-
-        if (last_chunk && !(a.ablate & 2)) narrow_pass(L, a, tc, t0, tid, lane, wave, sample, k);
-        buf ^= 1;
-    }
-    __syncthreads();
-    flush_events<NarrowLds, N_NT, N_EVCAP>(L, a, tid);
-#pragma unroll
-    for (int j = 0; j < N_PPT; ++j)
-        if (tc[j]) atomicAdd(&a.tot[(uint64_t)t0 + N_PPT * tid + j], tc[j]);
-}
-
 // ------------------------------------------------------------------------------------------
-// msnv_pileup_tiles_narrow32: msnv_pileup_tiles_narrow with FOUR lanes per piece and 32 bases per lane.
-// Perturbation runs on the 16-base kernel showed the vector-memory (TA/L1) path to be the most
-// sensitive resource (+1 sixteen-byte load per round: +15 % time; +25 % VALU: +4 %).  32 bases per lane
-// need 3 wide loads (2 x 16 B quality, 1 x 16 B bases) where two 16-base lanes need 4, and the header
-// decode / reference alignment / exception spreading are paid once per 32 bases.
+// msnv_pileup_tiles_narrow32: FOUR lanes per piece, 32 bases per lane.
+// Perturbation runs on the earlier 16-bases-per-lane kernel showed the vector-memory (TA/L1) path to be
+// the most sensitive resource (+1 sixteen-byte load per round: +15 % time; +25 % VALU: +4 %).  32 bases
+// per lane need 3 wide loads (2 x 16 B quality, 1 x 16 B bases) where two 16-base lanes need 4, and the
+// header decode / reference alignment / exception spreading are paid once per 32 bases (-9 % time).
 // ------------------------------------------------------------------------------------------
 constexpr int N32_LANES = 4;
 constexpr int N32_GROUPS = N_NT / N32_LANES;   // 64 pieces per round
@@ -620,135 +490,6 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32(PileupArgs a)
         if (last_chunk) narrow_pass(L, a, tc, t0, tid, lane, wave, cd.sample, cd.pair);
         buf ^= 1;
     }
-    __syncthreads();
-    flush_events<NarrowLds, N_NT, N_EVCAP>(L, a, tid);
-#pragma unroll
-    for (int j = 0; j < N_PPT; ++j)
-        if (tc[j]) atomicAdd(&a.tot[(uint64_t)t0 + N_PPT * tid + j], tc[j]);
-}
-
-// ------------------------------------------------------------------------------------------
-// msnv_pileup_tiles_narrow_pp: ping-pong (software pipelined) form of msnv_pileup_tiles_narrow.
-// Ablations showed the phases of the un-pipelined kernel ADD UP (skeleton 0.14 + load issue 0.21 +
-// HBM 0.17 + classify 0.14 + pass 0.16 ms): the resident workgroups run phase-locked, so memory idles
-// while everyone computes.  Here every wave keeps the NEXT chunk's qualities/bases in flight while it
-// classifies the current one.  Two register sets alternate roles (the loop is unrolled by two, so no
-// register copies force an early wait), headers are staged three chunks deep.
-// ------------------------------------------------------------------------------------------
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // native vectors: usable as inline-asm register operands
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-
-// The data loads are issued through inline asm so that the compiler's s_waitcnt pass does not see
-// them: it would otherwise wait vmcnt(0) at the first use of ANY loaded register and drain the
-// prefetch (cdna_hip_programming.md section 5.7).  PP_WAIT is the matching manual wait: it is placed
-// right before the next issue, one whole step after the loads it guards, and takes the registers as
-// in/out operands so no use can be scheduled above it.
-#define PP_ISSUE(Q, S, hbuf, cdesc)                                                                      \
-    {                                                                                                    \
-        const uint8_t *seq_ = a.seq + (cdesc).seq_base;                                                  \
-        const uint8_t *qual_ = a.qual + 2 * (cdesc).seq_base;                                            \
-        _Pragma("unroll") for (int i = 0; i < N_ROUNDS; ++i) {                                           \
-            const uint32_t off_ = (hbuf)[grp + i * N_GROUPS].y;      /* 0 for empty slots: safe address */ \
-            const uint8_t *qp_ = qual_ + 2ull * off_ + (uint32_t)b0;                                      \
-            const uint8_t *sp_ = seq_ + (uint64_t)off_ + (uint32_t)(b0 >> 1);                             \
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(Q[i]) : "v"(qp_) : "memory");          \
-            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(S[i]) : "v"(sp_) : "memory");          \
-        }                                                                                                \
-    }
-#define PP_WAIT(Q, S)                                                                                    \
-    asm volatile("s_waitcnt vmcnt(0)"                                                                    \
-                 : "+v"(Q[0]), "+v"(Q[1]), "+v"(Q[2]), "+v"(Q[3]), "+v"(S[0]), "+v"(S[1]), "+v"(S[2]), "+v"(S[3]) :: "memory")
-
-__device__ __forceinline__ void pp_consume(NarrowLds &L, const uint4 (&hb)[N_HCAP], const uint32_t t0, const int grp, const int lane8,
-                                           const int b0, const u32x4 (&qv)[N_ROUNDS], const u32x2 (&sv)[N_ROUNDS], const uint32_t kq) {
-#pragma unroll
-    for (int i = 0; i < N_ROUNDS; ++i) {
-        const uint4 h = hb[grp + i * N_GROUPS];
-        const uint32_t len = h.z;
-        const uint32_t s = len ? h.x - t0 : 0u;
-        if (len && lane8 == 0) {
-            const uint32_t sb = s + len;
-            atomicAdd(&L.start[s >> 2], 1u << (8u * (s & 3u)));
-            atomicAdd(&L.end[sb >> 2], 1u << (8u * (sb & 3u)));
-        }
-        const int vhi = min(max((int)len - b0, 0), 16);
-        const uint32_t vm = (1u << vhi) - 1u;
-        const int n0 = min(vhi, 8), n1 = max(vhi - 8, 0);
-        const uint32_t vn0 = (n0 == 8) ? 0x88888888u : (((1u << (4 * n0)) - 1u) & 0x88888888u);
-        const uint32_t vn1 = (n1 == 8) ? 0x88888888u : (((1u << (4 * n1)) - 1u) & 0x88888888u);
-        if (__any(vm != 0u)) narrow_classify(L, make_uint4(qv[i].x, qv[i].y, qv[i].z, qv[i].w), sv[i].x, sv[i].y, vm ? s + (uint32_t)b0 : 0u, vm, vn0, vn1, kq);
-    }
-}
-
-__global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow_pp(PileupArgs a) {
-    __shared__ NarrowLds L;
-    __shared__ uint4 s_hdr3[N_HCAP];                              // third header buffer (L.hdr holds two)
-    const WorkItem w = a.work[blockIdx.x];
-    const uint32_t t0 = w.tile * TILE;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lane8 = tid & (LANES_PER_READ - 1), grp = tid / LANES_PER_READ;
-    const uint32_t kq = 0x80808080u - min(a.min_baseq, 128u) * 0x01010101u;
-    const int b0 = 16 * lane8;
-
-    for (int i = tid; i < (int)(TILE / 8 + 4); i += N_NT)
-        L.ref[i] = (i < (int)(TILE / 8)) ? a.ref4[(t0 >> 3) + i] : 0xffffffffu;
-    for (int i = tid; i < (int)(TILE / 4 + 4); i += N_NT) { L.start[i] = 0; L.end[i] = 0; }
-    for (int i = tid; i < (int)(TILE / 8 + 4); i += N_NT) L.exc[i] = 0;
-    L.spread[tid] = ((unsigned long long)((((uint32_t)tid >> 4) * 0x00204081u) & 0x01010101u) << 32) | (((uint32_t)tid & 0xfu) * 0x00204081u & 0x01010101u);
-    for (int i = tid; i < (int)TILE; i += N_NT) L.al[i] = 0;
-    if (tid == 0) L.evn = 0;
-    uint32_t tc[N_PPT];
-#pragma unroll
-    for (int j = 0; j < N_PPT; ++j) tc[j] = 0;
-
-    const uint32_t nch = w.chunk_hi - w.chunk_lo;
-    for (uint32_t i = tid; i < nch * 2; i += N_NT)
-        reinterpret_cast<uint4 *>(L.desc)[i] = reinterpret_cast<const uint4 *>(a.chunks + w.chunk_lo)[i];
-    __syncthreads();
-    if (nch == 0) return;
-
-    auto load_hdr = [&](uint32_t c) -> uint4 {
-        uint4 h = make_uint4(0, 0, 0, 0);
-        if (c < nch && tid < N_HCAP && (uint32_t)tid < (L.desc[c].nrd_flags & 0xffffu))
-            h = *reinterpret_cast<const uint4 *>(a.hdr + L.desc[c].hdr_base + tid);
-        return h;
-    };
-    // header buffers: chunk c lives in H[c % 3]
-#define HB(i) ((i) == 0 ? L.hdr[0] : (i) == 1 ? L.hdr[1] : s_hdr3)
-    uint4 hreg = load_hdr(0);
-    if (tid < N_HCAP) L.hdr[0][tid] = hreg;
-    hreg = load_hdr(1);
-    __syncthreads();
-    static_assert(N_ROUNDS == 4, "PP_WAIT's operand list is written for 4 rounds");
-    u32x4 QA[N_ROUNDS], QB[N_ROUNDS]; u32x2 SA[N_ROUNDS], SB[N_ROUNDS];
-    PP_ISSUE(QA, SA, L.hdr[0], L.desc[0]);
-
-    // one step: chunk c is in flight in X (headers in H[hb]); stage c+1, issue it into Y, then consume X
-#define PP_STEP(QX, SX, QY, SY, hb, hn)                                                                  \
-    {                                                                                                    \
-        const ChunkDesc cd = L.desc[c];                                                                  \
-        if (c + 1 < nch) { if (tid < N_HCAP) HB(hn)[tid] = hreg; hreg = load_hdr(c + 2); }               \
-        __syncthreads();                                          /* (A) next headers visible; bins clean */ \
-        if (L.evn >= (uint32_t)(N_EVCAP / 2)) flush_events<NarrowLds, N_NT, N_EVCAP>(L, a, tid);         \
-        PP_WAIT(QX, SX);                                          /* chunk c's data: issued one step ago */ \
-        if (c + 1 < nch) PP_ISSUE(QY, SY, HB(hn), L.desc[c + 1]);                                        \
-        pp_consume(L, HB(hb), t0, grp, lane8, b0, QX, SX, kq);                                                \
-        if ((cd.nrd_flags >> 16) != 0u) narrow_pass(L, a, tc, t0, tid, lane, wave, cd.sample, cd.pair);  \
-        ++c;                                                                                             \
-    }
-    uint32_t c = 0;
-    while (c < nch) {                                              // 6 steps = one full rotation of (A,B) x (H0,H1,H2)
-        PP_STEP(QA, SA, QB, SB, 0, 1); if (c >= nch) break;
-        PP_STEP(QB, SB, QA, SA, 1, 2); if (c >= nch) break;
-        PP_STEP(QA, SA, QB, SB, 2, 0); if (c >= nch) break;
-        PP_STEP(QB, SB, QA, SA, 0, 1); if (c >= nch) break;
-        PP_STEP(QA, SA, QB, SB, 1, 2); if (c >= nch) break;
-        PP_STEP(QB, SB, QA, SA, 2, 0);
-    }
-#undef PP_STEP
-#undef PP_ISSUE
-#undef PP_WAIT
-#undef HB
     __syncthreads();
     flush_events<NarrowLds, N_NT, N_EVCAP>(L, a, tid);
 #pragma unroll
@@ -1036,19 +777,10 @@ int dev_run_pipeline(DeviceCols &d, const msnv_params &p, void *stream_, msnv_ru
         a.ref4 = d.ref4; a.pairs = d.pairs; a.work = d.work; a.chunks = d.chunks; a.tot = d.tot; a.npos = npos; a.spill = d.spill;
         a.events = d.events; a.cap_events = d.cap_events; a.overflow = d.overflow; a.cap_overflow = d.cap_overflow;
         a.counters = d.counters; a.min_baseq = (uint32_t)std::max(0, p.min_baseq);
-        { const char *e = getenv("MSNV_ABLATE"); a.ablate = e ? (uint32_t)atoi(e) : 0u; }
         static const bool all_wide = [] { const char *e = getenv("MSNV_PILEUP"); return e && e[0] == 'w'; }();   // A/B: MSNV_PILEUP=wide
         const uint32_t n_narrow = all_wide ? 0u : d.n_work_narrow;
         // narrow work items (byte bins) and wide ones (16-bit bins) touch disjoint (tile, sample) pairs
-        static const int batch = [] { const char *e = getenv("MSNV_BATCH"); return e ? atoi(e) : 32; }();             // A/B: MSNV_BATCH=32 (default: 32 bases per lane) | 0 (ping-pong) |1|2|4
-        if (n_narrow) {
-            static const int dynlds = [] { const char *e = getenv("MSNV_DYNLDS"); return e ? atoi(e) : 0; }();   // occupancy experiment
-            if (batch == 32) hipLaunchKernelGGL(msnv_pileup_tiles_narrow32, dim3(n_narrow), dim3(N_NT), dynlds, st, a);
-            else if (batch == 0) hipLaunchKernelGGL(msnv_pileup_tiles_narrow_pp, dim3(n_narrow), dim3(N_NT), dynlds, st, a);
-            else if (batch == 1) hipLaunchKernelGGL(msnv_pileup_tiles_narrow<1>, dim3(n_narrow), dim3(N_NT), 0, st, a);
-            else if (batch == 4) hipLaunchKernelGGL(msnv_pileup_tiles_narrow<4>, dim3(n_narrow), dim3(N_NT), 0, st, a);
-            else hipLaunchKernelGGL(msnv_pileup_tiles_narrow<2>, dim3(n_narrow), dim3(N_NT), dynlds, st, a);
-        }
+        if (n_narrow) hipLaunchKernelGGL(msnv_pileup_tiles_narrow32, dim3(n_narrow), dim3(N_NT), 0, st, a);
         if (d.n_work > n_narrow) {
             PileupArgs b = a;
             b.work = d.work + n_narrow;
