@@ -270,13 +270,9 @@ extern "C" int msnv_pileup_run(msnv_dataset *ds, msnv_run_stats *stats) {
         clear_error();
         rc = dev_run_pipeline(d, ds->params, ds->ctx->stream, &st, &c);
     }
+    if (rc == MSNV_ECAPACITY) return fail(rc, "%s", msnv_last_error());
     if (rc) return rc;
 
-    {   // called-line counts: the per-site flag bytes are tiny, the records stay on the device
-        std::vector<uint8_t> flags(c.n_sites);
-        if (int r2 = dev_download(flags.data(), d.site_flags, c.n_sites)) return r2;
-        for (uint8_t f : flags) { if (f & 15) st.n_called_pop++; if (f >> 4) st.n_called_indiv++; }
-    }
     ds->have_results = true;
     ds->results_fetched = false;
     ds->last_counts_sites = c.n_sites;

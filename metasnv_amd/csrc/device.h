@@ -35,7 +35,7 @@ struct DeviceCols {
     uint32_t *tile_site_base = nullptr, *tile_site_cnt = nullptr;
     msnv_site_sample *out = nullptr; // [cap_out_sites][n_samples]
     uint8_t  *site_flags = nullptr;  // pop_mask | ind_mask << 4
-    uint64_t  cap_out_sites = 0;
+    uint64_t  cap_out_sites = 0, last_sites = 0;
     // ---- genome coverage (qaCompute path)
     Pair32   *cov_iv = nullptr;          // {gbeg, gend}: +1 at gbeg, -1 at gend (index space of qaCompute.cpp:530-552)
     uint64_t *s_cov_base = nullptr;      // per sample

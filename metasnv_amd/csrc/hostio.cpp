@@ -26,6 +26,13 @@ int fail(int code, const char *fmt, ...) {
     fprintf(stderr, "libmsnv: %s\n", t_err);
     return code;
 }
+int fail_quiet(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(t_err, sizeof t_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
 void clear_error() { t_err[0] = 0; }
 
 }  // namespace msnv

@@ -576,11 +576,18 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const uint32_t *tot, 
 __global__ __launch_bounds__(256) void msnv_gather_cov(const SiteRec *sites, const uint32_t *tile_site_base,
                                                        const uint32_t *tile_site_cnt, const uint32_t *tile_pair_start,
                                                        const TilePair *pairs, const uint8_t *spill,
-                                                       msnv_site_sample *out, uint32_t n_samples) {
+                                                       msnv_site_sample *out, uint32_t n_samples, uint32_t cap_out) {
     const uint32_t tile = blockIdx.x;
     const uint32_t n = tile_site_cnt[tile];
     if (n == 0) return;
     const uint32_t base = tile_site_base[tile];
+    if (base + n > cap_out) return;                     // the host sees the site count and retries with a larger buffer
+    {   // zero this tile's rows (10 B per (site, sample)), then fill in the coverages
+        uint16_t *row = reinterpret_cast<uint16_t *>(out + (uint64_t)base * n_samples);
+        const uint64_t nh = (uint64_t)n * n_samples * (sizeof(msnv_site_sample) / 2);
+        for (uint64_t i = threadIdx.x; i < nh; i += blockDim.x) row[i] = 0;
+        __syncthreads();
+    }
     const uint32_t ps = tile_pair_start[tile], np = tile_pair_start[tile + 1] - ps;
     const uint32_t t0 = tile * TILE;
     const uint64_t work = (uint64_t)n * np;
@@ -602,20 +609,23 @@ __device__ __forceinline__ int find_site(const SiteRec *sites, uint32_t base, ui
 }
 
 // msnv_scatter_events: per-sample allele counts (sparse) and >=255 coverages into the site records.
-__global__ void msnv_scatter_events(const Pair32 *events, uint32_t n_events, const Pair32 *overflow, uint32_t n_overflow,
-                                    const SiteRec *sites, const uint32_t *tile_site_base, const uint32_t *tile_site_cnt,
-                                    msnv_site_sample *out, uint32_t n_samples) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_events) {
-        const Pair32 e = events[i];
-        const uint32_t tile = e.x / TILE;
-        const int s = find_site(sites, tile_site_base[tile], tile_site_cnt[tile], e.x);
-        if (s >= 0) out[(uint64_t)s * n_samples + (e.y >> 18)].n[(e.y >> 16) & 3u] = (uint16_t)(e.y & 0xffffu);
-    } else if (i < n_events + n_overflow) {
-        const Pair32 e = overflow[i - n_events];
-        const uint32_t tile = e.x / TILE;
-        const int s = find_site(sites, tile_site_base[tile], tile_site_cnt[tile], e.x);
-        if (s >= 0) out[(uint64_t)s * n_samples + (e.y >> 16)].cov = (uint16_t)(e.y & 0xffffu);
+__global__ void msnv_scatter_events(const Pair32 *events, const Pair32 *overflow, const uint32_t *counters, uint32_t cap_events,
+                                    uint32_t cap_overflow, const SiteRec *sites, const uint32_t *tile_site_base,
+                                    const uint32_t *tile_site_cnt, msnv_site_sample *out, uint32_t n_samples, uint32_t cap_out) {
+    const uint32_t n_events = min(counters[0], cap_events), n_overflow = min(counters[1], cap_overflow);
+    if (counters[2] > cap_out) return;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_events + n_overflow; i += gridDim.x * blockDim.x) {
+        if (i < n_events) {
+            const Pair32 e = events[i];
+            const uint32_t tile = e.x / TILE;
+            const int s = find_site(sites, tile_site_base[tile], tile_site_cnt[tile], e.x);
+            if (s >= 0) out[(uint64_t)s * n_samples + (e.y >> 18)].n[(e.y >> 16) & 3u] = (uint16_t)(e.y & 0xffffu);
+        } else {
+            const Pair32 e = overflow[i - n_events];
+            const uint32_t tile = e.x / TILE;
+            const int s = find_site(sites, tile_site_base[tile], tile_site_cnt[tile], e.x);
+            if (s >= 0) out[(uint64_t)s * n_samples + (e.y >> 16)].cov = (uint16_t)(e.y & 0xffffu);
+        }
     }
 }
 
@@ -625,27 +635,42 @@ __global__ void msnv_scatter_events(const Pair32 *events, uint32_t n_events, con
 //   population  iff n_x >= t and (double)n_x >= cov * min_fraction          (:588)
 //   individual  iff not population and some sample has x_s >= t              (:593-600)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void msnv_decide_sites(const SiteRec *sites, uint32_t n_sites, const uint32_t *ref4,
-                                                         const uint32_t *ref_lc, const msnv_site_sample *out,
+__global__ __launch_bounds__(256) void msnv_decide_sites(const SiteRec *sites, uint32_t *counters, uint32_t cap_sites, uint32_t cap_out,
+                                                         const uint32_t *ref4, const uint32_t *ref_lc, const msnv_site_sample *out,
                                                          uint32_t n_samples, int min_snvs, double min_frac, uint8_t *site_flags) {
-    const uint32_t site = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    __shared__ uint32_t s_pop, s_ind;
+    if (threadIdx.x == 0) { s_pop = 0; s_ind = 0; }
+    __syncthreads();
+    const uint32_t n_sites = counters[2];
     const int lane = threadIdx.x & 63;
-    if (site >= n_sites) return;
-    const SiteRec s = sites[site];
-    const uint32_t rc = (ref4[s.gpos >> 3] >> (4 * (s.gpos & 7))) & 0xfu;
-    const bool lc = (ref_lc[s.gpos >> 5] >> (s.gpos & 31)) & 1u;
-    uint32_t pop = 0, ind = 0;
-    for (int x = 0; x < 4; ++x) {
-        if (lc && rc == (1u << x)) continue;
-        const uint32_t nx = s.n[x];
-        if ((int)nx < min_snvs) continue;           // neither rule can fire
-        if ((double)nx >= (double)(int)s.cov * min_frac) { pop |= 1u << x; continue; }
-        bool any = false;
-        for (uint32_t i = lane; i < n_samples; i += 64)
-            any |= (int)out[(uint64_t)site * n_samples + i].n[x] >= min_snvs;
-        if (__any(any)) ind |= 1u << x;
+    if (n_sites <= cap_sites && n_sites <= cap_out) {
+        for (uint32_t site = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); site < n_sites; site += gridDim.x * (blockDim.x >> 6)) {
+            const SiteRec s = sites[site];
+            const uint32_t rc = (ref4[s.gpos >> 3] >> (4 * (s.gpos & 7))) & 0xfu;
+            const bool lc = (ref_lc[s.gpos >> 5] >> (s.gpos & 31)) & 1u;
+            uint32_t pop = 0, ind = 0;
+            for (int x = 0; x < 4; ++x) {
+                if (lc && rc == (1u << x)) continue;
+                const uint32_t nx = s.n[x];
+                if ((int)nx < min_snvs) continue;           // neither rule can fire
+                if ((double)nx >= (double)(int)s.cov * min_frac) { pop |= 1u << x; continue; }
+                bool any = false;
+                for (uint32_t i = lane; i < n_samples; i += 64)
+                    any |= (int)out[(uint64_t)site * n_samples + i].n[x] >= min_snvs;
+                if (__any(any)) ind |= 1u << x;
+            }
+            if (lane == 0) {
+                site_flags[site] = (uint8_t)(pop | ind << 4);
+                if (pop) atomicAdd(&s_pop, 1u);
+                if (ind) atomicAdd(&s_ind, 1u);
+            }
+        }
     }
-    if (lane == 0) site_flags[site] = (uint8_t)(pop | ind << 4);
+    __syncthreads();
+    if (threadIdx.x == 0) {                                 // output-line tallies: one global atomic per workgroup
+        if (s_pop) atomicAdd(&counters[4], s_pop);
+        if (s_ind) atomicAdd(&counters[5], s_ind);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -767,7 +792,7 @@ int dev_run_pipeline(DeviceCols &d, const msnv_params &p, void *stream_, msnv_ru
     auto cleanup = [&]() { for (auto &e : ev) (void)hipEventDestroy(e); };
 
     HIP_TRY(hipEventRecord(ev[0], st));
-    HIP_TRY(hipMemsetAsync(d.counters, 0, 4 * sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(d.counters, 0, 8 * sizeof(uint32_t), st));
     if (npos) HIP_TRY(hipMemsetAsync(d.tot, 0, 5 * npos * sizeof(uint32_t), st));
     HIP_TRY(hipEventRecord(ev[1], st));
     if (d.n_work) {
@@ -795,36 +820,34 @@ int dev_run_pipeline(DeviceCols &d, const msnv_params &p, void *stream_, msnv_ru
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(ev[3], st));
-    RunCounts c{};
-    HIP_TRY(hipMemcpyAsync(&c, d.counters, sizeof c, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    if (c.n_events > d.cap_events || c.n_overflow > d.cap_overflow || c.n_sites > d.cap_sites) {
-        cleanup();
-        if (counts) *counts = c;
-        return fail(MSNV_ECAPACITY, "device buffer too small: events %u/%u overflow %u/%u sites %u/%u",
-                    c.n_events, d.cap_events, c.n_overflow, d.cap_overflow, c.n_sites, d.cap_sites);
-    }
-    if (int rc = ensure_out(d, c.n_sites)) { cleanup(); return rc; }
-    if (c.n_sites) {
-        HIP_TRY(hipMemsetAsync(d.out, 0, (uint64_t)c.n_sites * d.n_samples * sizeof(msnv_site_sample), st));
+    // the tail runs on device-side counts: no host round trip inside a pass
+    if (int rc = ensure_out(d, std::max<uint64_t>(d.last_sites + d.last_sites / 2, 4096))) { cleanup(); return rc; }
+    const uint32_t cap_out = (uint32_t)std::min<uint64_t>(d.cap_out_sites, 0xffffffffull);
+    if (d.n_tiles) {
         hipLaunchKernelGGL(msnv_gather_cov, dim3(d.n_tiles), dim3(256), 0, st, d.sites, d.tile_site_base, d.tile_site_cnt,
-                           d.tile_pair_start, d.pairs, d.spill, d.out, d.n_samples);
+                           d.tile_pair_start, d.pairs, d.spill, d.out, d.n_samples, cap_out);
         HIP_TRY(hipGetLastError());
-        const uint32_t ne = c.n_events + c.n_overflow;
-        if (ne) {
-            hipLaunchKernelGGL(msnv_scatter_events, dim3((ne + 255) / 256), dim3(256), 0, st, d.events, c.n_events, d.overflow,
-                               c.n_overflow, d.sites, d.tile_site_base, d.tile_site_cnt, d.out, d.n_samples);
-            HIP_TRY(hipGetLastError());
-        }
+        hipLaunchKernelGGL(msnv_scatter_events, dim3(1024), dim3(256), 0, st, d.events, d.overflow, d.counters, d.cap_events,
+                           d.cap_overflow, d.sites, d.tile_site_base, d.tile_site_cnt, d.out, d.n_samples, cap_out);
+        HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(ev[4], st));
-    if (c.n_sites) {
-        hipLaunchKernelGGL(msnv_decide_sites, dim3((c.n_sites + 3) / 4), dim3(256), 0, st, d.sites, c.n_sites, d.ref4, d.ref_lc,
-                           d.out, d.n_samples, p.calling_threshold, p.min_fraction, d.site_flags);
-        HIP_TRY(hipGetLastError());
-    }
+    hipLaunchKernelGGL(msnv_decide_sites, dim3(512), dim3(256), 0, st, d.sites, d.counters, d.cap_sites, cap_out, d.ref4, d.ref_lc,
+                       d.out, d.n_samples, p.calling_threshold, p.min_fraction, d.site_flags);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev[5], st));
+    uint32_t cnt[8] = {0};
+    HIP_TRY(hipMemcpyAsync(cnt, d.counters, sizeof cnt, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    RunCounts c{cnt[0], cnt[1], cnt[2], cnt[3]};
+    d.last_sites = c.n_sites;
+    if (c.n_events > d.cap_events || c.n_overflow > d.cap_overflow || c.n_sites > d.cap_sites || c.n_sites > d.cap_out_sites) {
+        cleanup();
+        if (counts) *counts = c;
+        return fail_quiet(MSNV_ECAPACITY, "device buffer too small: events %u/%u overflow %u/%u sites %u/%u out %u/%llu",
+                    c.n_events, d.cap_events, c.n_overflow, d.cap_overflow, c.n_sites, d.cap_sites, c.n_sites,
+                    (unsigned long long)d.cap_out_sites);
+    }
     if (stats) {
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[5])); stats->ms_total = ms;
@@ -833,6 +856,7 @@ int dev_run_pipeline(DeviceCols &d, const msnv_params &p, void *stream_, msnv_ru
         HIP_TRY(hipEventElapsedTime(&ms, ev[3], ev[4])); stats->ms_gather = ms;
         HIP_TRY(hipEventElapsedTime(&ms, ev[4], ev[5])); stats->ms_decide = ms;
         stats->n_sites = c.n_sites; stats->n_events = c.n_events; stats->n_overflow = c.n_overflow;
+        stats->n_called_pop = cnt[4]; stats->n_called_indiv = cnt[5];
         stats->algorithmic_bytes = d.algorithmic_bytes;
     }
     if (counts) *counts = c;

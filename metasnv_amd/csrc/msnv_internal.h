@@ -12,6 +12,7 @@ namespace msnv {
 
 // ---------------------------------------------------------------------------------- errors
 int  fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+int  fail_quiet(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));   // sets the message, prints nothing
 void clear_error();
 
 // ---------------------------------------------------------------------------------- host IO
