@@ -281,3 +281,54 @@ def test_cli_project_layout_and_contents(tmp_path, capsys):
     # an existing project directory is refused exactly like the reference (metaSNV.py:278-280)
     with pytest.raises(SystemExit):
         cli.main([proj, lst, fa])
+
+
+def test_full_testdata_shape_properties():
+    """BASELINE configs[1] at full size (160 samples x 3 x 300 kb, 1.5 G pileup bases): too big for the
+    oracle to finish in seconds, so the HIP path is checked through size-independent properties."""
+    sp = core.synth_params(seed=1)
+    syn = core.Synth(sp)
+    ctx = core.Context(0)
+
+    def run(sample_ids):
+        ds = core.Dataset(ctx, syn.names, syn.lengths, syn.seqs)
+        for i in sample_ids:
+            ds.add_synth_samples(sp, i, 1, 0)
+        info = ds.finalize()
+        st = ds.run()
+        sites, samples = ds.results()
+        st2 = ds.run()                                     # idempotence: a second pass over resident columns
+        s2, m2 = ds.results()
+        assert s2.tobytes() == sites.tobytes() and m2.tobytes() == samples.tobytes()
+        ds.close()
+        return info, st, sites, samples
+
+    ids = list(range(sp.n_samples))
+    info, st, sites, samples = run(ids)
+    assert info["n_samples"] == 160 and info["n_positions"] == 900000 and info["n_pileup_bases"] > 1.2e9
+    assert 3000 < st["n_called_pop"] < 20000
+    # conservation: the per-sample columns add up to the totals the calling rule saw
+    assert (samples["cov"].astype(np.int64).sum(axis=1) == sites["cov"]).all()
+    for x in range(4):
+        called = ((sites["pop_mask"] | sites["ind_mask"]) >> x) & 1 == 1
+        assert (samples["n"][:, :, x].astype(np.int64).sum(axis=1)[called] == sites["n"][called, x]).all()
+    # sites come out in (contig, position) order without duplicates
+    key = sites["tid"].astype(np.int64) << 32 | sites["pos"]
+    assert (np.diff(key) > 0).all()
+    # per-sample independence: a run over a subset of the samples reproduces those samples' columns
+    sub = ids[10:30]
+    _, _, s_sub, m_sub = run(sub)
+    pos_full = {(int(t), int(p)): i for i, (t, p) in enumerate(zip(sites["tid"], sites["pos"]))}
+    hits = 0
+    for j, (t, p) in enumerate(zip(s_sub["tid"], s_sub["pos"])):
+        i = pos_full.get((int(t), int(p)))
+        if i is None:
+            continue
+        hits += 1
+        assert (m_sub["cov"][j] == samples["cov"][i, 10:30]).all()
+        both = (int(s_sub["pop_mask"][j]) | int(s_sub["ind_mask"][j])) & (int(sites["pop_mask"][i]) | int(sites["ind_mask"][i]))
+        for x in range(4):
+            if (both >> x) & 1:
+                assert (m_sub["n"][j, :, x] == samples["n"][i, 10:30, x]).all()
+    assert hits > 500
+    ctx.close()
