@@ -51,6 +51,7 @@ struct SampleCols {
     std::vector<uint8_t>  seq, qual;
     std::vector<int32_t>  cov_tid, cov_beg, cov_end;   // qaCompute M intervals (index space), reads that pass its filter
     uint64_t n_pileup_bases = 0, n_pileup_reads = 0;
+    uint64_t alg_seq_bytes = 0, alg_qual_bytes = 0;   // shipped bytes without alignment padding
     int32_t  first_tid = -1, first_beg = 0, first_end = 0;   // first pileup_ok read (first-line quirk)
     // qaCompute "Other" statistics (qaCompute.cpp:642-654)
     uint32_t total_reads = 0, unmapped = 0, zero_quality = 0, proper_pairs = 0, duplicates = 0;

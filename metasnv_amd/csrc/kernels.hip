@@ -476,10 +476,10 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32(PileupArgs a)
             vh[i] = min(max((int)len - b0, 0), 32);
             qa[i] = make_uint4(0, 0, 0, 0); qb[i] = qa[i]; sq[i] = qa[i];
             if (vh[i] > 0) {                                         // lanes past the end of the piece load nothing
-                const uint8_t *qp = qual + 2ull * h.y + (uint32_t)b0;
-                __builtin_memcpy(&qa[i], qp, 16);
-                if (vh[i] > 16) __builtin_memcpy(&qb[i], qp + 16, 16);
-                __builtin_memcpy(&sq[i], seq + (uint64_t)h.y + (uint32_t)(b0 >> 1), 16);
+                const uint4 *qp = reinterpret_cast<const uint4 *>(qual + 2ull * h.y + (uint32_t)b0);   // pieces are 16-byte aligned
+                qa[i] = qp[0];
+                if (vh[i] > 16) qb[i] = qp[1];
+                sq[i] = *reinterpret_cast<const uint4 *>(seq + (uint64_t)h.y + (uint32_t)(b0 >> 1));
             }
             P0[i] = vh[i] > 0 ? s + (uint32_t)b0 : 0u;
         }
