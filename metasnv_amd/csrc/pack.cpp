@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <atomic>
 #include <climits>
+#include <cstdlib>
 #include <cstring>
 #include <queue>
 #include <thread>
@@ -309,7 +310,9 @@ int finalize_dataset(msnv_dataset &ds) {
     {
         uint64_t total_reads_in_pairs = 0;
         for (const TilePair &p : pairs) total_reads_in_pairs += p.read_hi - p.read_lo;
-        const uint64_t target = std::max<uint64_t>(1500, total_reads_in_pairs / 6144);
+        // work item size: pieces per workgroup.  MSNV_ITEM_PIECES overrides (tuning experiments).
+        uint64_t target = std::max<uint64_t>(1500, total_reads_in_pairs / 6144);
+        if (const char *e = getenv("MSNV_ITEM_PIECES")) target = std::max<uint64_t>(64, (uint64_t)atoll(e));
         std::vector<WorkItem> wide;
         for (uint64_t t = 0; t < nt; ++t) {
             uint32_t lo = tps[t];
