@@ -209,6 +209,14 @@ typedef struct {
 
 typedef struct { uint16_t cov; uint16_t n[4]; } msnv_site_sample;
 
+/* Gene / codon annotation of one site (snpCall -g, call_vC.cpp:567-574,604-633), computed on the device.
+ * gene = index of the annotation row (file order, rows with start > end excluded) or -1.
+ * codon[x] for allele x (A,C,G,T): {flags, len_old | len_new << 4, old[3], new[3]}. */
+#define MSNV_ANN_VALID      1
+#define MSNV_ANN_CIRCULAR   2   /* gene with start == end: the reference drops the allele */
+#define MSNV_ANN_SYNONYMOUS 4
+typedef struct { int32_t gene; uint8_t codon[4][8]; } msnv_site_ann;
+
 /* First pileup line of this dataset's invocation (the one call_vC.cpp:423 drops); tid = -1 if no read passes. */
 int  msnv_dataset_first_line(const msnv_dataset *ds, int32_t *tid, int32_t *pos);
 /* Formats site records that did not come from a local run (multi-GPU: records gathered from the
@@ -216,7 +224,13 @@ int  msnv_dataset_first_line(const msnv_dataset *ds, int32_t *tid, int32_t *pos)
 int  msnv_write_calls_records(const msnv_ref_desc *ref, int32_t n_samples, const msnv_site *sites,
                               const msnv_site_sample *samples, uint64_t n_sites,
                               const char *called_path, const char *indiv_path,
-                              const char *ann_path, const char *fasta_path);
+                              const char *ann_path, const char *fasta_path, const msnv_site_ann *ann);
+
+/* Runs the annotation kernel over the sites of the last msnv_pileup_run.  The gene table and the codon genome are
+ * parsed and uploaded on the first call for a given (ann_path, fasta_path) and stay resident; ms_kernel may be NULL. */
+int  msnv_annotate_run(msnv_dataset *ds, const char *ann_path, const char *fasta_path, double *ms_kernel);
+/* ann[n_sites] in the order of msnv_results_fetch. */
+int  msnv_results_fetch_ann(msnv_dataset *ds, msnv_site_ann *ann, uint64_t capacity);
 
 int  msnv_results_count(const msnv_dataset *ds, uint64_t *n_sites);
 /* sites[n_sites], samples[n_sites * n_samples], both in (tid, pos) order. */

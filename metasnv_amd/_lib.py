@@ -67,6 +67,10 @@ class SiteSample(C.Structure):
     _fields_ = [("cov", C.c_uint16), ("n", C.c_uint16 * 4)]
 
 
+class SiteAnn(C.Structure):
+    _fields_ = [("gene", C.c_int32), ("codon", (C.c_uint8 * 8) * 4)]
+
+
 class BamData(C.Structure):
     _fields_ = [("n_contigs", C.c_int32), ("names", C.POINTER(C.c_char_p)), ("lengths", C.POINTER(C.c_int64)),
                 ("records", C.POINTER(C.c_uint8)), ("n_record_bytes", C.c_uint64), ("header_text", C.c_char_p)]
@@ -108,7 +112,9 @@ SYMBOLS = [
     ("msnv_write_coverage", C.c_int, [_vp, C.c_int32, C.c_char_p, C.c_char_p]),
     ("msnv_write_calls", C.c_int, [_vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]),
     ("msnv_dataset_first_line", C.c_int, [_vp, P(C.c_int32), P(C.c_int32)]),
-    ("msnv_write_calls_records", C.c_int, [P(RefDesc), C.c_int32, P(Site), P(SiteSample), C.c_uint64, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]),
+    ("msnv_write_calls_records", C.c_int, [P(RefDesc), C.c_int32, P(Site), P(SiteSample), C.c_uint64, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, P(SiteAnn)]),
+    ("msnv_annotate_run", C.c_int, [_vp, C.c_char_p, C.c_char_p, P(C.c_double)]),
+    ("msnv_results_fetch_ann", C.c_int, [_vp, P(SiteAnn), C.c_uint64]),
     ("msnv_results_count", C.c_int, [_vp, P(C.c_uint64)]),
     ("msnv_results_fetch", C.c_int, [_vp, P(Site), P(SiteSample), C.c_uint64]),
     ("msnv_bam_write_bed_header", C.c_int, [C.c_char_p, C.c_char_p]),

@@ -4,12 +4,13 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import lib, check, Params, SynthParams, DatasetInfo, RunStats, Site, SiteSample, RefDesc
+from ._lib import lib, check, Params, SynthParams, DatasetInfo, RunStats, Site, SiteSample, SiteAnn, RefDesc
 
 SITE_DTYPE = np.dtype([("tid", "<i4"), ("pos", "<i4"), ("cov", "<u4"), ("n", "<u4", (4,)),
                        ("pop_mask", "u1"), ("ind_mask", "u1"), ("refchar", "u1"), ("dropped", "u1")])
 SAMPLE_DTYPE = np.dtype([("cov", "<u2"), ("n", "<u2", (4,))])
-assert SITE_DTYPE.itemsize == C.sizeof(Site) and SAMPLE_DTYPE.itemsize == C.sizeof(SiteSample)
+ANN_DTYPE = np.dtype([("gene", "<i4"), ("codon", "u1", (4, 8))])
+assert SITE_DTYPE.itemsize == C.sizeof(Site) and SAMPLE_DTYPE.itemsize == C.sizeof(SiteSample) and ANN_DTYPE.itemsize == C.sizeof(SiteAnn)
 
 
 def default_params(**kw):
@@ -162,6 +163,16 @@ class Dataset:
                                      samples.ctypes.data_as(C.POINTER(SiteSample)), n.value))
         return sites, samples
 
+    def annotate(self, ann_path, fasta_path):
+        """Gene / codon annotation of the last run's sites on the device; returns (records, kernel ms)."""
+        ms = C.c_double()
+        check(lib.msnv_annotate_run(self._h, ann_path.encode(), fasta_path.encode(), C.byref(ms)))
+        n = C.c_uint64()
+        check(lib.msnv_results_count(self._h, C.byref(n)))
+        ann = np.zeros(n.value, dtype=ANN_DTYPE)
+        check(lib.msnv_results_fetch_ann(self._h, ann.ctypes.data_as(C.POINTER(SiteAnn)), n.value))
+        return ann, ms.value
+
     def first_line(self):
         t, p = C.c_int32(), C.c_int32()
         check(lib.msnv_dataset_first_line(self._h, C.byref(t), C.byref(p)))
@@ -183,8 +194,9 @@ class Dataset:
             pass
 
 
-def write_calls_records(names, n_samples, sites, samples, called_path, indiv_path=None, ann_path=None, fasta_path=None):
-    """Format gathered site records (numpy arrays of SITE_DTYPE / SAMPLE_DTYPE) as called_SNPs / indiv_called."""
+def write_calls_records(names, n_samples, sites, samples, called_path, indiv_path=None, ann_path=None, fasta_path=None, ann=None):
+    """Format gathered site records (numpy arrays of SITE_DTYPE / SAMPLE_DTYPE) as called_SNPs / indiv_called.
+    With ann_path the gathered device annotation records (ANN_DTYPE, Dataset.annotate) are required."""
     n = len(names)
     arr = _cstr_array(names)
     lens = (C.c_int64 * n)(*([0] * n))
@@ -194,7 +206,8 @@ def write_calls_records(names, n_samples, sites, samples, called_path, indiv_pat
     check(lib.msnv_write_calls_records(C.byref(rd), n_samples, sites.ctypes.data_as(C.POINTER(Site)),
                                        samples.ctypes.data_as(C.POINTER(SiteSample)), len(sites), called_path.encode(),
                                        indiv_path.encode() if indiv_path else None, ann_path.encode() if ann_path else None,
-                                       fasta_path.encode() if fasta_path else None))
+                                       fasta_path.encode() if fasta_path else None,
+                                       np.ascontiguousarray(ann, dtype=ANN_DTYPE).ctypes.data_as(C.POINTER(SiteAnn)) if ann is not None else None))
 
 
 # ------------------------------------------------------------------------------------ host I/O helpers

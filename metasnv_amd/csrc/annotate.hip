@@ -1,0 +1,160 @@
+// metasnv_amd/csrc/annotate.hip -- gene / codon annotation of the called sites on the device (snpCall -g).
+//
+//   gene of a position      call_vC.cpp:567-574  (boost::icl split_interval_map, first gene in file order)
+//   codon of every allele   call_vC.cpp:604-633  (Genome::getSequence gene.h:79-92, revComplement :299-314,
+//                                                 codon table gene.h:3-25)
+//
+// The host flattens the gene map into disjoint runs of the linear position space (ann_tables.cpp); one thread
+// per site record does the binary search and the codon arithmetic.  The work is a few hundred bytes per
+// called site, three orders of magnitude below the pileup traffic: latency-bound, no roofline of its own.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "device.h"
+
+namespace msnv {
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(MSNV_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// Amino acids by codon index a*16+b*4+c with A0 C1 G2 T3 (gene.h:3-25 re-ordered; X = stop).
+__constant__ char k_amino[65] = "KNKNTTTTRSRSIIMIQHQHPPPPRRRRLLLLEDEDAAAAGGGGVVVVXYXYSSSSXCWCLFLF";
+
+// A codon the reference's table does not hold (length != 3 after the reverse complement dropped a
+// letter, or an 'N' inside) maps to '\0' (std::map::operator[], call_vC.cpp:627).
+__device__ __forceinline__ char amino_of(const char *c, int len) {
+    if (len != 3) return 0;
+    int idx = 0;
+    for (int k = 0; k < 3; ++k) {
+        const int v = c[k] == 'A' ? 0 : c[k] == 'C' ? 1 : c[k] == 'G' ? 2 : c[k] == 'T' ? 3 : -1;
+        if (v < 0) return 0;
+        idx = idx * 4 + v;
+    }
+    return k_amino[idx];
+}
+
+__device__ __forceinline__ int rev_comp3(const char *in, char *out) {
+    int m = 0;
+    for (int i = 2; i >= 0; --i) {
+        const char c = in[i];
+        if (c == 'A') out[m++] = 'T'; else if (c == 'T') out[m++] = 'A';
+        else if (c == 'C') out[m++] = 'G'; else if (c == 'G') out[m++] = 'C';
+    }
+    return m;
+}
+
+__global__ __launch_bounds__(256) void msnv_annotate_sites(const SiteRec *__restrict__ sites, const uint8_t *__restrict__ site_flags, uint32_t n_sites,
+                                                           const uint32_t *__restrict__ seg_beg, const uint32_t *__restrict__ seg_end,
+                                                           const int32_t *__restrict__ seg_gene, uint32_t n_seg,
+                                                           const AnnGene *__restrict__ genes, const AnnContig *__restrict__ contigs,
+                                                           const uint8_t *__restrict__ codons, uint32_t drop_gpos,
+                                                           msnv_site_ann *__restrict__ out, uint32_t *__restrict__ err) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_sites) return;
+    msnv_site_ann r;
+    r.gene = -1;
+    for (int x = 0; x < 4; ++x) for (int k = 0; k < 8; ++k) r.codon[x][k] = 0;
+    const uint32_t fl = site_flags[i];
+    const uint32_t gpos = sites[i].gpos;
+    if (fl && n_seg) {
+        uint32_t lo = 0, hi = n_seg;                         // number of runs with beg <= gpos
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (seg_beg[mid] <= gpos) lo = mid + 1; else hi = mid; }
+        if (lo && gpos < seg_end[lo - 1]) {
+            const int32_t gi = seg_gene[lo - 1];
+            const AnnGene g = genes[gi];
+            const AnnContig c = contigs[g.contig];
+            r.gene = gi;
+            const int64_t pos = (int64_t)gpos - c.goff;
+            const uint32_t emit = (fl | (fl >> 4)) & 15;
+            const char letter[4] = {'A', 'C', 'G', 'T'};
+            for (int x = 0; x < 4; ++x) {
+                if (!((emit >> x) & 1)) continue;
+                uint8_t *o = r.codon[x];
+                if (!(g.flags & ANN_GENE_LINEAR)) { o[0] = MSNV_ANN_VALID | MSNV_ANN_CIRCULAR; continue; }   // :614-617
+                const int cp = (int)((pos - g.start) % 3);                                                   // :611
+                const int64_t cs = pos - cp;
+                if (c.cg_len < 0 || cs + 2 > c.cg_len) {     // the reference dereferences map::end() / writes into an empty string
+                    if (gpos != drop_gpos) atomicMin(&err[c.cg_len < 0 ? 0 : 1], gpos);
+                    continue;
+                }
+                char oldc[3], newc[3], t[3];
+                for (int k = 0; k < 3; ++k) {
+                    const int64_t q = cs + k;
+                    uint32_t code = 0;                      // gene.h:88 reads zero bits at index == length
+                    if (q < c.cg_len) { const int64_t b = c.cg_base + q; code = (codons[b >> 1] >> ((b & 1) * 4)) & 7; }
+                    oldc[k] = newc[k] = code == 0 ? 'A' : code == 1 ? 'T' : code == 2 ? 'C' : code == 3 ? 'G' : code == 4 ? 'N' : '?';   // gene.h:28
+                }
+                newc[cp] = letter[x];                                                                        // :619
+                int n_old = 3, n_new = 3;
+                if (g.flags & ANN_GENE_MINUS) {                                                              // :621-624
+                    n_old = rev_comp3(oldc, t); for (int k = 0; k < n_old; ++k) oldc[k] = t[k];
+                    n_new = rev_comp3(newc, t); for (int k = 0; k < n_new; ++k) newc[k] = t[k];
+                }
+                o[0] = MSNV_ANN_VALID | (amino_of(newc, n_new) == amino_of(oldc, n_old) ? MSNV_ANN_SYNONYMOUS : 0);
+                o[1] = (uint8_t)(n_old | n_new << 4);
+                for (int k = 0; k < n_old; ++k) o[2 + k] = (uint8_t)oldc[k];
+                for (int k = 0; k < n_new; ++k) o[5 + k] = (uint8_t)newc[k];
+            }
+        }
+    }
+    out[i] = r;
+}
+
+int dev_ann_upload(DeviceCols &d, const AnnHost &h) {
+    AnnDev &a = d.ann;
+    void *old[] = {a.seg_beg, a.seg_end, a.seg_gene, a.genes, a.contigs, a.codons};
+    for (void *p : old) dev_free(p);
+    a.seg_beg = a.seg_end = nullptr; a.seg_gene = nullptr; a.genes = nullptr; a.contigs = nullptr; a.codons = nullptr;
+    a.ready = false;
+    a.n_seg = (uint32_t)h.seg_beg.size();
+    auto up = [&](void **dst, const void *src, uint64_t bytes) -> int {
+        if (int rc = dev_alloc(dst, bytes, &d.device_bytes)) return rc;
+        return dev_upload(*dst, src, bytes);
+    };
+    if (int rc = up((void **)&a.seg_beg, h.seg_beg.data(), h.seg_beg.size() * 4)) return rc;
+    if (int rc = up((void **)&a.seg_end, h.seg_end.data(), h.seg_end.size() * 4)) return rc;
+    if (int rc = up((void **)&a.seg_gene, h.seg_gene.data(), h.seg_gene.size() * 4)) return rc;
+    if (int rc = up((void **)&a.genes, h.genes.data(), h.genes.size() * sizeof(AnnGene))) return rc;
+    if (int rc = up((void **)&a.contigs, h.contigs.data(), h.contigs.size() * sizeof(AnnContig))) return rc;
+    if (int rc = up((void **)&a.codons, h.codons.data(), h.codons.size())) return rc;
+    if (!a.err) if (int rc = dev_alloc((void **)&a.err, 2 * sizeof(uint32_t), &d.device_bytes)) return rc;
+    a.ready = true;
+    return MSNV_OK;
+}
+
+int dev_annotate(DeviceCols &d, uint32_t n_sites, uint32_t drop_gpos, void *stream_, double *ms, uint32_t err_gpos[2]) {
+    hipStream_t st = (hipStream_t)stream_;
+    AnnDev &a = d.ann;
+    if (!a.ready) return fail(MSNV_EINVAL, "internal: annotation tables are not on the device");
+    if (n_sites > a.cap_out || !a.out) {
+        dev_free(a.out); a.out = nullptr;
+        const uint64_t cap = std::max<uint64_t>((uint64_t)n_sites + n_sites / 4, 1024);
+        if (int rc = dev_alloc((void **)&a.out, cap * sizeof(msnv_site_ann), &d.device_bytes)) return rc;
+        a.cap_out = cap;
+    }
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    hipError_t he = hipMemsetAsync(a.err, 0xff, 2 * sizeof(uint32_t), st);
+    if (he == hipSuccess) he = hipEventRecord(e0, st);
+    if (he == hipSuccess && n_sites) {
+        hipLaunchKernelGGL(msnv_annotate_sites, dim3((n_sites + 255) / 256), dim3(256), 0, st, d.sites, d.site_flags, n_sites,
+                           a.seg_beg, a.seg_end, a.seg_gene, a.n_seg, a.genes, a.contigs, a.codons, drop_gpos, a.out, a.err);
+        he = hipGetLastError();
+    }
+    if (he == hipSuccess) he = hipEventRecord(e1, st);
+    if (he == hipSuccess) he = hipMemcpyAsync(err_gpos, a.err, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+    if (he == hipSuccess) he = hipStreamSynchronize(st);
+    float t = 0;
+    if (he == hipSuccess) he = hipEventElapsedTime(&t, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (he != hipSuccess) return fail(MSNV_EHIP, "annotation kernel: %s", hipGetErrorString(he));
+    if (ms) *ms = t;
+    return MSNV_OK;
+}
+
+}  // namespace msnv

@@ -11,7 +11,8 @@
 namespace msnv {
 int pack_sample(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, SampleCols &sc);
 int finalize_dataset(msnv_dataset &ds);
-int write_calls_text(msnv_dataset &ds, const char *called_path, const char *indiv_path, const char *ann_path, const char *fasta_path);
+int write_calls_text(msnv_dataset &ds, const char *called_path, const char *indiv_path,
+                     const msnv_site_ann *ann, const std::vector<std::string> *gene_names);
 int coverage_run(msnv_dataset &ds, msnv_run_stats *stats);
 int coverage_write(msnv_dataset &ds, int sample, const char *cov_path, const char *detail_path);
 std::vector<std::string> synth_contigs(const msnv_synth_params &p);
@@ -275,6 +276,7 @@ extern "C" int msnv_pileup_run(msnv_dataset *ds, msnv_run_stats *stats) {
 
     ds->have_results = true;
     ds->results_fetched = false;
+    ds->ann_valid = false;
     ds->last_counts_sites = c.n_sites;
     ds->last_stats = st;
     if (stats) *stats = st;
@@ -296,7 +298,7 @@ static int fetch_results(msnv_dataset *ds) {
     std::vector<msnv_site_sample> raw((size_t)n * d.n_samples);
     if (int r2 = dev_download(raw.data(), d.out, raw.size() * sizeof(msnv_site_sample))) return r2;
 
-    ds->sites.clear(); ds->site_samples.clear();
+    ds->sites.clear(); ds->site_samples.clear(); ds->site_dev_index.clear();
     ds->sites.reserve(n);
     for (uint32_t t = 0; t < ds->n_tiles; ++t) {
         for (uint32_t j = 0; j < tcnt[t]; ++j) {
@@ -311,6 +313,7 @@ static int fetch_results(msnv_dataset *ds) {
             s.refchar = (uint8_t)((ds->has_seq[(size_t)s.tid] && (size_t)s.pos < seq.size()) ? seq[(size_t)s.pos] : 'N');
             s.dropped = (ds->params.drop_first_line && s.tid == ds->first_tid && s.pos == ds->first_pos) ? 1 : 0;
             ds->sites.push_back(s);
+            ds->site_dev_index.push_back(i);
             ds->site_samples.insert(ds->site_samples.end(), raw.begin() + (size_t)i * d.n_samples, raw.begin() + (size_t)(i + 1) * d.n_samples);
         }
     }
@@ -338,13 +341,76 @@ extern "C" int msnv_results_fetch(msnv_dataset *ds, msnv_site *sites, msnv_site_
     return MSNV_OK;
 }
 
+// ---- gene / codon annotation (snpCall -g): tables are built once per (annotation, FASTA) pair and stay on the device
+static int annotate_sites(msnv_dataset *ds, const char *ann_path, const char *fasta_path, double *ms_kernel) {
+    if (!ann_path || !fasta_path) return fail(MSNV_EINVAL, "annotation needs both the gene table and the FASTA (call_vC.cpp:448)");
+    if (int rc = dev_set_device(ds->ctx->device)) return rc;
+    DeviceCols &d = *ds->dev;
+    const std::string key = std::string(ann_path) + "\n" + fasta_path;
+    if (!d.ann.ready || d.ann.key != key) {
+        Annotation an;
+        if (int rc = load_annotation(ann_path, fasta_path, an)) return rc;
+        AnnHost h;
+        if (int rc = ann_build(*ds, an, h)) return rc;
+        if (int rc = dev_ann_upload(d, h)) return rc;
+        ann_gene_names(an, ds->names, d.ann.gene_names);
+        d.ann.key = key;
+    }
+    uint32_t drop_gpos = UINT32_MAX;
+    if (ds->params.drop_first_line && ds->first_tid >= 0 && ds->tile_base[(size_t)ds->first_tid] != UINT32_MAX)
+        drop_gpos = ds->tile_base[(size_t)ds->first_tid] * TILE + (uint32_t)ds->first_pos;
+    uint32_t err[2] = {UINT32_MAX, UINT32_MAX};
+    if (int rc = dev_annotate(d, ds->last_counts_sites, drop_gpos, ds->ctx->stream, ms_kernel, err)) return rc;
+    for (int k = 0; k < 2; ++k) {
+        if (err[k] == UINT32_MAX) continue;
+        int32_t tid, pos;
+        gpos_to_contig(*ds, err[k], tid, pos);
+        return fail(MSNV_EDOMAIN, k == 0 ? "contig %s has genes but no FASTA record (position %d; reference: undefined behaviour)"
+                                         : "codon at %s:%d runs past the contig end (reference: undefined behaviour)",
+                    ds->names[(size_t)tid].c_str(), pos + 1);
+    }
+    ds->ann_valid = true;
+    return MSNV_OK;
+}
+
+static int fetch_ann(msnv_dataset *ds, std::vector<msnv_site_ann> &out) {
+    if (int rc = fetch_results(ds)) return rc;
+    std::vector<msnv_site_ann> raw(ds->last_counts_sites);
+    if (int rc = dev_download(raw.data(), ds->dev->ann.out, raw.size() * sizeof(msnv_site_ann))) return rc;
+    out.resize(ds->sites.size());
+    for (size_t i = 0; i < out.size(); ++i) out[i] = raw[ds->site_dev_index[i]];
+    return MSNV_OK;
+}
+
+extern "C" int msnv_annotate_run(msnv_dataset *ds, const char *ann_path, const char *fasta_path, double *ms_kernel) {
+    clear_error();
+    if (!ds) return fail(MSNV_EINVAL, "msnv_annotate_run: NULL argument");
+    if (!ds->have_results) return fail(MSNV_EINVAL, "no results: call msnv_pileup_run first");
+    return annotate_sites(ds, ann_path, fasta_path, ms_kernel);
+}
+
+extern "C" int msnv_results_fetch_ann(msnv_dataset *ds, msnv_site_ann *ann, uint64_t capacity) {
+    clear_error();
+    if (!ds || !ann) return fail(MSNV_EINVAL, "msnv_results_fetch_ann: NULL argument");
+    if (!ds->have_results || !ds->ann_valid) return fail(MSNV_EINVAL, "no annotation: call msnv_annotate_run after msnv_pileup_run");
+    std::vector<msnv_site_ann> v;
+    if (int rc = fetch_ann(ds, v)) return rc;
+    if (capacity < v.size()) return fail(MSNV_ECAPACITY, "capacity %llu < %zu sites", (unsigned long long)capacity, v.size());
+    if (!v.empty()) memcpy(ann, v.data(), v.size() * sizeof(msnv_site_ann));
+    return MSNV_OK;
+}
+
 extern "C" int msnv_write_calls(msnv_dataset *ds, const char *called_path, const char *indiv_path,
                                 const char *ann_path, const char *fasta_path) {
     clear_error();
     if (!ds || !called_path) return fail(MSNV_EINVAL, "msnv_write_calls: NULL argument");
     if (!ds->have_results) return fail(MSNV_EINVAL, "no results: call msnv_pileup_run first");
     if (int rc = fetch_results(ds)) return rc;
-    return write_calls_text(*ds, called_path, indiv_path, ann_path, fasta_path);
+    if (!(ann_path && fasta_path)) return write_calls_text(*ds, called_path, indiv_path, nullptr, nullptr);   // call_vC.cpp:448
+    if (int rc = annotate_sites(ds, ann_path, fasta_path, nullptr)) return rc;
+    std::vector<msnv_site_ann> ann;
+    if (int rc = fetch_ann(ds, ann)) return rc;
+    return write_calls_text(*ds, called_path, indiv_path, ann.data(), &ds->dev->ann.gene_names);
 }
 
 extern "C" int msnv_dataset_first_line(const msnv_dataset *ds, int32_t *tid, int32_t *pos) {
@@ -358,9 +424,11 @@ extern "C" int msnv_dataset_first_line(const msnv_dataset *ds, int32_t *tid, int
 extern "C" int msnv_write_calls_records(const msnv_ref_desc *ref, int32_t n_samples, const msnv_site *sites,
                                         const msnv_site_sample *samples, uint64_t n_sites,
                                         const char *called_path, const char *indiv_path,
-                                        const char *ann_path, const char *fasta_path) {
+                                        const char *ann_path, const char *fasta_path, const msnv_site_ann *ann) {
     clear_error();
     if (!ref || !called_path || n_samples < 0 || (n_sites && (!sites || !samples))) return fail(MSNV_EINVAL, "msnv_write_calls_records: bad argument");
+    const bool annotated = ann_path && fasta_path;
+    if (annotated && n_sites && !ann) return fail(MSNV_EINVAL, "msnv_write_calls_records: annotation records are required with ann_path (the annotation is computed on the device)");
     msnv_dataset tmp;                       // formatter state only: names, sample count, records
     for (int i = 0; i < ref->n_contigs; ++i) tmp.names.emplace_back(ref->names[i]);
     tmp.samples.resize((size_t)n_samples);
@@ -368,7 +436,14 @@ extern "C" int msnv_write_calls_records(const msnv_ref_desc *ref, int32_t n_samp
     tmp.site_samples.assign(samples, samples + n_sites * (uint64_t)n_samples);
     for (uint64_t i = 0; i < n_sites; ++i)
         if (sites[i].tid < 0 || sites[i].tid >= ref->n_contigs) return fail(MSNV_EINVAL, "record %llu names contig %d", (unsigned long long)i, sites[i].tid);
-    return write_calls_text(tmp, called_path, indiv_path, ann_path, fasta_path);
+    if (!annotated) return write_calls_text(tmp, called_path, indiv_path, nullptr, nullptr);
+    Annotation an;                          // gene names only; the codon work was done on the ranks' devices
+    if (int rc = load_annotation(ann_path, nullptr, an)) return rc;
+    std::vector<std::string> gene_names;
+    ann_gene_names(an, tmp.names, gene_names);
+    for (uint64_t i = 0; i < n_sites; ++i)
+        if (ann[i].gene >= (int32_t)gene_names.size()) return fail(MSNV_EINVAL, "annotation record %llu names gene %d of %zu", (unsigned long long)i, ann[i].gene, gene_names.size());
+    return write_calls_text(tmp, called_path, indiv_path, ann, &gene_names);
 }
 
 extern "C" int msnv_coverage_run(msnv_dataset *ds, msnv_run_stats *stats) {

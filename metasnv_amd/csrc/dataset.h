@@ -96,6 +96,8 @@ struct msnv_dataset {
     msnv_run_stats last_stats{};
     std::vector<msnv_site> sites;
     std::vector<msnv_site_sample> site_samples;
+    std::vector<uint32_t> site_dev_index;      // host record -> device site record
+    bool ann_valid = false;                    // the device holds annotation records of the last run
     bool have_coverage = false;
     std::vector<unsigned long long> cov_acc;   // [sample][contig][1 + COV_BINS]
 };

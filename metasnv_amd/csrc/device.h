@@ -3,11 +3,41 @@
 
 #include <cstdint>
 
+#include <string>
+#include <vector>
+
 #include "dataset.h"
 
 namespace msnv {
 
 struct Pair32 { uint32_t x, y; };
+
+// ---- gene / codon annotation tables (ann_tables.cpp builds them, msnv_annotate_sites reads them)
+constexpr uint8_t ANN_GENE_MINUS = 1, ANN_GENE_LINEAR = 2;       // strand '-', start < end (call_vC.cpp:609)
+struct AnnGene   { int64_t start; int32_t contig; uint32_t flags; };          // start is contig-relative (may be -1)
+struct AnnContig { int64_t cg_base, cg_len; uint32_t goff, pad; };            // codon genome: base index, length (-1: absent)
+struct AnnHost {
+    std::vector<uint32_t> seg_beg, seg_end;     // disjoint, sorted runs of the linear position space
+    std::vector<int32_t>  seg_gene;
+    std::vector<AnnGene>  genes;
+    std::vector<AnnContig> contigs;
+    std::vector<uint8_t>  codons;               // 4-bit codes, gene.h numbering A0 T1 C2 G3 N4
+};
+struct AnnDev {
+    uint32_t *seg_beg = nullptr, *seg_end = nullptr; int32_t *seg_gene = nullptr;
+    AnnGene *genes = nullptr; AnnContig *contigs = nullptr; uint8_t *codons = nullptr;
+    uint32_t n_seg = 0;
+    msnv_site_ann *out = nullptr; uint64_t cap_out = 0;
+    uint32_t *err = nullptr;                    // [0] first position whose contig has genes but no FASTA record, [1] codon past the end
+    bool ready = false;
+    std::string key;                            // ann_path + '\n' + fasta_path the tables were built from
+    std::vector<std::string> gene_names;
+};
+int  ann_build(msnv_dataset &ds, const Annotation &an, AnnHost &h);
+void ann_gene_names(const Annotation &an, const std::vector<std::string> &contigs, std::vector<std::string> &out);
+int  dev_ann_upload(DeviceCols &d, const AnnHost &h);
+// Annotates the d.last_sites device site records; err_gpos[k] = UINT32_MAX when error kind k did not occur.
+int  dev_annotate(DeviceCols &d, uint32_t n_sites, uint32_t drop_gpos, void *stream, double *ms, uint32_t err_gpos[2]);
 
 struct DeviceCols {
     // ---- inputs (uploaded once by finalize)
@@ -48,6 +78,7 @@ struct DeviceCols {
     uint64_t  n_cov_iv = 0;
     uint64_t  device_bytes = 0;
     uint64_t  algorithmic_bytes = 0;
+    AnnDev    ann;
 };
 
 // host copies of the counters after a run

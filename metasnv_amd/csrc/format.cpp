@@ -16,14 +16,6 @@ namespace msnv {
 
 namespace {
 
-struct GeneRow { long start, end; std::string name; char strand; };
-
-struct Annotation {
-    bool active = false;
-    std::map<std::string, std::vector<GeneRow>> genes;      // per contig, file order, start<=end only
-    std::map<std::string, std::string> genome;              // per contig: characters as gene.h stores them
-};
-
 // gene.h:28-36,67: anything that is not A/T/C/G/N is stored as 'A'
 inline char genome_char(char c) { return (c == 'A' || c == 'T' || c == 'C' || c == 'G' || c == 'N') ? c : 'A'; }
 
@@ -34,6 +26,8 @@ const char *split_tab(const char *s, std::string &tok) {      // call_vC.cpp:92-
     tok.assign(s, std::min<size_t>((size_t)(e - s), 10000));
     return *e == '\t' ? e + 1 : e;
 }
+
+}  // namespace
 
 int load_annotation(const char *ann_path, const char *fasta_path, Annotation &an) {
     FILE *fg = fopen(ann_path, "r");
@@ -73,6 +67,7 @@ int load_annotation(const char *ann_path, const char *fasta_path, Annotation &an
 
     // ---- genome characters exactly as indexGenomeAndGenes reads them (:165-193): every fgets
     // chunk loses its last character; the header is the whole line after '>'.
+    if (!fasta_path) { an.active = true; return MSNV_OK; }   // gene rows only (formatter on the gathering rank)
     FILE *fa = fopen(fasta_path, "r");
     if (!fa) return fail(MSNV_EIO, "Cannot open %s", fasta_path);
     std::string name, genome;
@@ -94,39 +89,21 @@ int load_annotation(const char *ann_path, const char *fasta_path, Annotation &an
     return MSNV_OK;
 }
 
+namespace {
+
 inline void put_u32(std::string &o, uint32_t v) {
     char b[12]; int n = 0;
     do { b[n++] = (char)('0' + v % 10); v /= 10; } while (v);
     while (n) o.push_back(b[--n]);
 }
 
-void rev_comp(std::string &c) {                             // call_vC.cpp:299-314
-    std::string r;
-    for (size_t i = c.size(); i-- > 0;) {
-        if (c[i] == 'A') r += 'T'; else if (c[i] == 'T') r += 'A'; else if (c[i] == 'C') r += 'G'; else if (c[i] == 'G') r += 'C';
-    }
-    c = r;
-}
-
-char codon_aa(const std::string &c) {                       // gene.h:3-25; unknown -> '\0' (:627)
-    static const struct { const char *c; char aa; } T[] = {
-        {"TAA",'X'},{"TGA",'X'},{"TAG",'X'},{"GCT",'A'},{"GCC",'A'},{"GCA",'A'},{"GCG",'A'},{"CGT",'R'},{"CGC",'R'},{"CGA",'R'},
-        {"CGG",'R'},{"AGA",'R'},{"AGG",'R'},{"AAT",'N'},{"AAC",'N'},{"GAT",'D'},{"GAC",'D'},{"TGT",'C'},{"TGC",'C'},{"CAA",'Q'},
-        {"CAG",'Q'},{"GAA",'E'},{"GAG",'E'},{"GGT",'G'},{"GGC",'G'},{"GGA",'G'},{"GGG",'G'},{"CAT",'H'},{"CAC",'H'},{"ATT",'I'},
-        {"ATC",'I'},{"ATA",'I'},{"TTA",'L'},{"TTG",'L'},{"CTT",'L'},{"CTC",'L'},{"CTA",'L'},{"CTG",'L'},{"AAA",'K'},{"AAG",'K'},
-        {"ATG",'M'},{"TTT",'F'},{"TTC",'F'},{"CCT",'P'},{"CCC",'P'},{"CCA",'P'},{"CCG",'P'},{"TCT",'S'},{"TCC",'S'},{"TCA",'S'},
-        {"TCG",'S'},{"AGT",'S'},{"AGC",'S'},{"ACT",'T'},{"ACC",'T'},{"ACA",'T'},{"ACG",'T'},{"TGG",'W'},{"TAT",'Y'},{"TAC",'Y'},
-        {"GTA",'V'},{"GTG",'V'},{"GTT",'V'},{"GTC",'V'}};
-    for (const auto &e : T) if (c == e.c) return e.aa;
-    return '\0';
-}
-
 }  // namespace
 
-int write_calls_text(msnv_dataset &ds, const char *called_path, const char *indiv_path, const char *ann_path, const char *fasta_path) {
-    Annotation an;
-    if (ann_path && fasta_path) if (int rc = load_annotation(ann_path, fasta_path, an)) return rc;   // call_vC.cpp:448
-
+// Text of called_SNPs / indiv_called from the device records.  `ann` (optional) holds the gene / codon
+// annotation computed on the device (msnv_annotate_sites), one record per site; `gene_names` maps its gene
+// index to the annotation's gene name column.
+int write_calls_text(msnv_dataset &ds, const char *called_path, const char *indiv_path,
+                     const msnv_site_ann *ann, const std::vector<std::string> *gene_names) {
     FILE *fp = fopen(called_path, "wt");
     if (!fp) return fail(MSNV_EIO, "Cannot open %s", called_path);
     FILE *fi = indiv_path ? fopen(indiv_path, "wt") : nullptr;
@@ -135,53 +112,38 @@ int write_calls_text(msnv_dataset &ds, const char *called_path, const char *indi
     const size_t S = ds.samples.size();
     static const int order[4] = {0, 1, 3, 2};               // alleles are emitted a, c, t, g (:561)
     static const char letter[4] = {'A', 'C', 'G', 'T'};
-    std::string pop, ind, head, covs, entry;
-    int cur_tid = -1;
-    const std::vector<GeneRow> *genes = nullptr;
-    const std::string *genome = nullptr;
-    int rc = MSNV_OK;
+    std::string pop, ind, head, entry;
 
-    for (size_t i = 0; i < ds.sites.size() && !rc; ++i) {
+    for (size_t i = 0; i < ds.sites.size(); ++i) {
         const msnv_site &s = ds.sites[i];
         if (s.dropped) continue;                              // call_vC.cpp:423
         const msnv_site_sample *ss = &ds.site_samples[i * S];
         const std::string &cname = ds.names[(size_t)s.tid];
-        if (s.tid != cur_tid) {
-            cur_tid = s.tid; genes = nullptr; genome = nullptr;
-            if (an.active) {
-                auto g = an.genes.find(cname);
-                if (g != an.genes.end()) {
-                    genes = &g->second;
-                    auto q = an.genome.find(cname);
-                    if (q != an.genome.end()) genome = &q->second;
-                }
-            }
-        }
-        const GeneRow *gene = nullptr;
-        if (genes) for (const GeneRow &g : *genes) if (g.start <= s.pos && s.pos <= g.end) { gene = &g; break; }   // first in file order
+        const msnv_site_ann *an = ann ? &ann[i] : nullptr;
+        const bool in_gene = an && an->gene >= 0;
 
         pop.clear(); ind.clear();
         bool write = false;
-        for (int oi = 0; oi < 4 && !rc; ++oi) {
+        for (int oi = 0; oi < 4; ++oi) {
             const int x = order[oi];
             const bool is_pop = (s.pop_mask >> x) & 1, is_ind = (s.ind_mask >> x) & 1;
             if (!is_pop && !is_ind) continue;
             if (is_pop) write = true;
             entry.clear();
             put_u32(entry, s.n[x]); entry.push_back('|'); entry.push_back(letter[x]); entry.push_back('|');
-            if (gene) {
-                if (!(gene->start < gene->end)) continue;    // "circular": the allele vanishes (:614-617)
-                if (!genome) { rc = fail(MSNV_EDOMAIN, "contig %s has genes but no FASTA record (reference: undefined behaviour)", cname.c_str()); break; }
-                const int cp = (int)((s.pos - gene->start) % 3);
-                const long cs = s.pos - cp;
-                if (cs + 2 > (long)genome->size()) { rc = fail(MSNV_EDOMAIN, "codon at %s:%d runs past the contig end (reference: undefined behaviour)", cname.c_str(), s.pos + 1); break; }
-                std::string oldc, newc;
-                for (long k = cs; k <= cs + 2; ++k) oldc.push_back((size_t)k < genome->size() ? (*genome)[(size_t)k] : 'A');   // gene.h:88 reads zero bits past the end
-                newc = oldc;
-                newc[(size_t)cp] = letter[x];
-                if (gene->strand == '-') { rev_comp(oldc); rev_comp(newc); }
-                entry.push_back(codon_aa(newc) == codon_aa(oldc) ? 'S' : 'N');
-                entry.push_back('['); entry += oldc; entry.push_back('-'); entry += newc; entry += "]|";
+            if (in_gene) {
+                const uint8_t *c = an->codon[x];             // {flags, lengths, old[3], new[3]}
+                if (!(c[0] & MSNV_ANN_VALID)) {               // only a rank-local first line that is not the global one gets here
+                    fclose(fp); if (fi) fclose(fi);
+                    return fail(MSNV_EDOMAIN, "no codon for %s:%d (contig without FASTA record or codon past its end; reference: undefined behaviour)", cname.c_str(), s.pos + 1);
+                }
+                if (c[0] & MSNV_ANN_CIRCULAR) continue;       // "circular": the allele vanishes (:614-617)
+                entry.push_back((c[0] & MSNV_ANN_SYNONYMOUS) ? 'S' : 'N');
+                entry.push_back('[');
+                entry.append(reinterpret_cast<const char *>(c + 2), (size_t)(c[1] & 15));
+                entry.push_back('-');
+                entry.append(reinterpret_cast<const char *>(c + 5), (size_t)(c[1] >> 4));
+                entry += "]|";
             } else {
                 entry += ".|";
             }
@@ -189,10 +151,11 @@ int write_calls_text(msnv_dataset &ds, const char *called_path, const char *indi
             std::string &dst = is_pop ? pop : ind;
             dst.push_back(','); dst += entry;
         }
-        if (rc) break;
         if (!write && ind.empty()) continue;
         head.clear();
-        head += cname; head.push_back('\t'); head += gene ? gene->name : std::string("-"); head.push_back('\t');
+        head += cname; head.push_back('\t');
+        head += (in_gene && gene_names && (size_t)an->gene < gene_names->size()) ? (*gene_names)[(size_t)an->gene] : std::string("-");
+        head.push_back('\t');
         put_u32(head, (uint32_t)s.pos + 1); head.push_back('\t'); head.push_back((char)s.refchar); head.push_back('\t');
         for (size_t k = 0; k < S; ++k) { if (k) head.push_back('|'); put_u32(head, ss[k].cov); }
         head.push_back('\t');
@@ -209,7 +172,7 @@ int write_calls_text(msnv_dataset &ds, const char *called_path, const char *indi
     }
     fclose(fp);
     if (fi) fclose(fi);
-    return rc;
+    return MSNV_OK;
 }
 
 }  // namespace msnv

@@ -770,6 +770,8 @@ void dev_free_all(DeviceCols &d) {
                     d.sites, d.tile_site_base, d.tile_site_cnt, d.out, d.site_flags,
                     d.cov_iv, d.s_cov_base, d.cov_pairs, d.cov_work, d.tile_len, d.tile_contig_dev, d.cov_acc};
     for (void *p : ptrs) dev_free(p);
+    void *aptrs[] = {d.ann.seg_beg, d.ann.seg_end, d.ann.seg_gene, d.ann.genes, d.ann.contigs, d.ann.codons, d.ann.out, d.ann.err};
+    for (void *p : aptrs) dev_free(p);
     d = DeviceCols{};
 }
 

@@ -3,6 +3,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -39,6 +40,17 @@ int fasta_read(const char *path, std::vector<FastaSeq> &out);
 // 3-column BED as written by metaSNV.py:92 (`name\t1\tLEN`): 0-based half-open regions.
 struct BedRegion { std::string name; int64_t beg, end; };
 int bed_read(const char *path, std::vector<BedRegion> &out);
+
+// ---------------------------------------------------------------------------------- gene annotation (parsing only)
+// --db_ann rows as snpCall keeps them (call_vC.cpp:116-199,205-284): per contig in file order, start<=end only,
+// and the genome characters as gene.h stores them (anything but A/T/C/G/N is 'A').
+struct GeneRow { long start, end; std::string name; char strand; };
+struct Annotation {
+    bool active = false;
+    std::map<std::string, std::vector<GeneRow>> genes;
+    std::map<std::string, std::string> genome;
+};
+int load_annotation(const char *ann_path, const char *fasta_path, Annotation &an);
 
 // ---------------------------------------------------------------------------------- BAM record view
 constexpr int BAM_FPAIRED = 1, BAM_FPROPER_PAIR = 2, BAM_FUNMAP = 4, BAM_FREVERSE = 16,

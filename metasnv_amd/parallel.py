@@ -118,11 +118,12 @@ def gather_bytes(blob):
     return [o[:c].cpu().numpy() for o, c in zip(out, counts)]
 
 
-def gather_sites(sites, samples, first_line):
+def gather_sites(sites, samples, first_line, ann=None):
     """Gathers the called-site records of every rank and merges them in (tid, pos) order.
     first_line: this rank's (tid, pos) of the first pileup line, tid = -1 if none.  Only the globally
     first line is the one the reference drops (call_vC.cpp:423), so the `dropped` mark of every other
-    rank-local first line is cleared.  Every rank returns the merged arrays."""
+    rank-local first line is cleared.  Every rank returns the merged arrays; with `ann` (the device
+    annotation records of this rank's sites) the merged annotation records are appended to the tuple."""
     from .core import SITE_DTYPE, SAMPLE_DTYPE
     n_samples = samples.shape[1] if samples.ndim == 2 and samples.shape[0] else 0
     parts_s = gather_bytes(np.ascontiguousarray(sites).view(np.uint8))
@@ -138,7 +139,12 @@ def gather_sites(sites, samples, first_line):
         if (int(all_sites["tid"][i]), int(all_sites["pos"][i])) != gfirst:
             all_sites["dropped"][i] = 0
     order = np.lexsort((all_sites["pos"], all_sites["tid"]))
-    return all_sites[order], all_samples[order], gfirst
+    if ann is None:
+        return all_sites[order], all_samples[order], gfirst
+    from .core import ANN_DTYPE
+    parts_a = gather_bytes(np.ascontiguousarray(ann, dtype=ANN_DTYPE).view(np.uint8))
+    all_ann = np.concatenate([p.view(ANN_DTYPE) for p in parts_a]) if parts_a else np.zeros(0, ANN_DTYPE)
+    return all_sites[order], all_samples[order], gfirst, all_ann[order]
 
 
 def sharded_call(ctx, names, lengths, seqs, add_samples, params=None, species_weight=None,
@@ -154,8 +160,13 @@ def sharded_call(ctx, names, lengths, seqs, add_samples, params=None, species_we
     info = ds.finalize()
     stats = ds.run()
     sites, samples = ds.results()
-    merged_sites, merged_samples, gfirst = gather_sites(sites, samples, ds.first_line())
+    merged_ann = None
+    if ann_path and fasta_path:                      # codon annotation runs on every rank's device, records are gathered
+        ann, _ = ds.annotate(ann_path, fasta_path)
+        merged_sites, merged_samples, gfirst, merged_ann = gather_sites(sites, samples, ds.first_line(), ann)
+    else:
+        merged_sites, merged_samples, gfirst = gather_sites(sites, samples, ds.first_line())
     if _rank == 0 and called_path:
-        core.write_calls_records(names, ds.n_samples, merged_sites, merged_samples, called_path, indiv_path, ann_path, fasta_path)
+        core.write_calls_records(names, ds.n_samples, merged_sites, merged_samples, called_path, indiv_path, ann_path, fasta_path, merged_ann)
     ds.close()
     return merged_sites, merged_samples, info, stats

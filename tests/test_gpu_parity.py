@@ -118,6 +118,90 @@ def test_annotation_codon_path(tmp_path):
     assert "\tg1\t" in prod[0] and "\tg2\t" in prod[0] and "\th1\t" in prod[0] and "|S[" in prod[0] and "|N[" in prod[0]
 
 
+def _write_ann(path, rows):
+    with open(path, "w") as f:
+        f.write("gene_id\texternal_id\tsequence_id\ttype\tinfo\tlength\tstart\tend\tstrand\tsc\tstop\tgc\n")
+        for i, (g, c, s, e, st) in enumerate(rows):
+            f.write("%d\t%s\t%s\tCDS\tx\t%d\t%d\t%d\t%s\tATG\tTAG\t0.4\n" % (i, g, c, e - s + 1, s, e, st))
+
+
+def _write_fasta(path, names, seqs, width=60):
+    with open(path, "w") as f:
+        for n, s in zip(names, seqs):
+            f.write(">%s\n" % n)
+            s = s.decode()
+            for i in range(0, len(s), width):
+                f.write(s[i:i + width] + "\n")
+
+
+def test_annotation_random_gene_tables_and_odd_codons(tmp_path):
+    """Device gene lookup + codon arithmetic against the oracle: overlapping / nested genes in random file
+    order, both strands, start column 0 (start = -1), N and lower-case letters inside codons (gene.h stores
+    lower case as 'A'; the reverse complement drops N), genes on a contig listed after a gene-less one."""
+    import random
+    rnd = random.Random(5)
+    syn, samples = synth_case(n_species=3, contig_len=4000, n_samples=5, mean_cov=12.0, snv_density=0.04, frac_absent=0.0, seed=33)
+    seqs = []
+    for s in syn.seqs:
+        b = bytearray(s)
+        for _ in range(150):
+            b[rnd.randrange(len(b))] = ord("N")
+        for _ in range(300):
+            k = rnd.randrange(len(b))
+            b[k] = ord(chr(b[k]).lower())
+        seqs.append(bytes(b))
+    fa = str(tmp_path / "ref.fa")
+    _write_fasta(fa, syn.names, seqs)
+    rows = [("z0", syn.names[0], 0, 700, "-")]
+    for c in (0, 2):                                       # contig 1 has no genes
+        for k in range(40):
+            a = rnd.randrange(1, 3900)
+            rows.append(("g%d_%d" % (c, k), syn.names[c], a, min(3990, a + rnd.randrange(0, 600)), rnd.choice("+-")))
+    ann = str(tmp_path / "ann.tsv")
+    _write_ann(ann, rows)
+    prod = run_product(syn.names, syn.lengths, seqs, samples, ann=ann, fasta=fa)
+    orac = run_oracle(syn.names, syn.lengths, seqs, samples, ann=ann, fasta=fa)
+    _assert_same(prod, orac)
+    import re
+    assert "\tz0\t" in prod[0]
+    assert re.search(r"\[[ACGT]{0,2}-", prod[0] + prod[1])      # a codon that lost a letter in the reverse complement
+    assert re.search(r"\[[ACGT]*N", prod[0] + prod[1])          # an N printed on the + strand
+
+
+def test_annotation_records_path_equals_file_path(tmp_path):
+    """Multi-GPU formatter path: annotation records fetched from the device and handed to
+    msnv_write_calls_records give the same text as msnv_write_calls."""
+    syn, samples = synth_case(n_species=2, contig_len=3000, n_samples=4, mean_cov=14.0, snv_density=0.03, frac_absent=0.0, seed=21)
+    fa = str(tmp_path / "ref.fa")
+    syn.write_fasta(fa)
+    ann = str(tmp_path / "ann.tsv")
+    _write_ann(ann, [("g1", syn.names[0], 10, 900, "+"), ("g2", syn.names[0], 600, 1500, "-"), ("h1", syn.names[1], 1, 2997, "-")])
+    pop, ind, info, st, ds, ctx = run_product(syn.names, syn.lengths, syn.seqs, samples, ann=ann, fasta=fa, return_ds=True)
+    sites, smp = ds.results()
+    recs, ms = ds.annotate(ann, fa)
+    assert len(recs) == len(sites) and (recs["gene"] >= 0).any() and ms >= 0
+    core.write_calls_records(syn.names, ds.n_samples, sites, smp, str(tmp_path / "p"), str(tmp_path / "i"), ann, fa, recs)
+    assert open(tmp_path / "p").read() == pop and open(tmp_path / "i").read() == ind
+    with pytest.raises(Exception):                          # the annotation is never recomputed on the host
+        core.write_calls_records(syn.names, ds.n_samples, sites, smp, str(tmp_path / "p2"), None, ann, fa, None)
+
+
+def test_annotation_domain_errors_match_the_oracle(tmp_path):
+    """A contig with gene rows but no FASTA record makes the reference dereference map::end():
+    both the oracle and the device path refuse (MSNV_EDOMAIN)."""
+    import orc
+    syn, samples = synth_case(n_species=2, contig_len=3000, n_samples=4, mean_cov=14.0, snv_density=0.03, frac_absent=0.0, seed=21)
+    fa = str(tmp_path / "ref.fa")
+    _write_fasta(fa, syn.names[:1], syn.seqs[:1])
+    ann = str(tmp_path / "ann.tsv")
+    _write_ann(ann, [("g1", syn.names[0], 10, 900, "+"), ("h1", syn.names[1], 1, 2997, "-")])
+    with pytest.raises(orc.OrcError):
+        run_oracle(syn.names, syn.lengths, syn.seqs, samples, ann=ann, fasta=fa)
+    with pytest.raises(Exception) as ei:
+        run_product(syn.names, syn.lengths, syn.seqs, samples, ann=ann, fasta=fa)
+    assert "FASTA" in str(ei.value)
+
+
 def test_one_call_entry_point_from_bam_files(tmp_path):
     import ctypes as C
     from metasnv_amd import _lib
