@@ -33,7 +33,7 @@ struct ReadHdr { uint32_t gpos, seqoff, cig, meta; };
 
 struct TilePair { uint32_t sample, read_lo, read_hi, max_depth; };    // reads of `sample` that may overlap the tile;
                                                                         // max_depth = upper bound of the per-position depth
-struct WorkItem { uint32_t tile, pair_lo, pair_hi, chunk_lo, chunk_hi, pad[3]; };
+struct WorkItem { uint32_t tile, pair_lo, pair_hi, chunk_lo, chunk_hi, slot, pad[2]; };   // slot: row of the coverage partials (tile-major)
 // One chunk = up to CHUNK_READS consecutive reads of one (tile, sample) pair, with everything the
 // kernel needs to start loading (no dependent scalar loads on the critical path).
 constexpr uint32_t CHUNK_READS = 128;

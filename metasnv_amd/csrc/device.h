@@ -55,7 +55,9 @@ struct DeviceCols {
     uint32_t  n_tiles = 0, n_pairs = 0, n_work = 0, n_work_narrow = 0, n_samples = 0;   // work[0..n_work_narrow) = narrow items
     uint64_t  n_reads = 0, n_seq_bytes = 0;
     // ---- intermediates
-    uint32_t *tot = nullptr;         // [5][n_tiles*TILE]: cov, A, C, G, T summed over samples
+    uint32_t *tot = nullptr;         // [4][n_tiles*TILE]: mismatching A, C, G, T summed over samples
+    uint32_t *part = nullptr;        // [n_work][TILE]: coverage partial of every work item (slots are tile-major)
+    uint32_t *tile_slot_start = nullptr;   // n_tiles + 1
     uint8_t  *spill = nullptr;       // [n_pairs][TILE] per-sample coverage, saturating at 255
     Pair32   *events = nullptr;      // {gpos, sample<<18 | allele<<16 | count}
     Pair32   *overflow = nullptr;    // {gpos, sample<<16 | cov}

@@ -39,7 +39,8 @@ struct PileupArgs {
     const TilePair *pairs;
     const WorkItem *work;
     const ChunkDesc *chunks;
-    uint32_t       *tot;          // [5][npos]
+    uint32_t       *tot;          // [4][npos]: A, C, G, T mismatch totals over all samples (atomics, sparse)
+    uint32_t       *part;         // [work item slot][TILE]: coverage summed over the item's samples (plain stores)
     uint64_t        npos;
     uint8_t        *spill;
     Pair32         *events;   uint32_t cap_events;
@@ -58,6 +59,12 @@ __device__ __forceinline__ uint32_t nz_nibbles(uint32_t x) {       // bit 4j+3 s
 __device__ __forceinline__ uint32_t nibflags_to_bits(uint32_t f) {  // bit 4j+3 -> bit j (8 bits)
     const uint32_t e = f & 0x08080808u, o = (f >> 4) & 0x08080808u;
     return (__builtin_amdgcn_udot4(o, 0x80200802u, __builtin_amdgcn_udot4(e, 0x40100401u, 0u, false), false)) >> 3;
+}
+// A register-resident uint4 whose value does not matter (an empty asm "defines" it): lets predicated loads skip the zero fill.
+__device__ __forceinline__ uint4 any_uint4() {
+    uint4 v;
+    asm volatile("" : "=v"(v.x), "=v"(v.y), "=v"(v.z), "=v"(v.w));
+    return v;
 }
 // 16 quality bytes (each <= 127, host clamps) -> 16-bit mask of bytes below the cutoff
 // kq = 0x80808080 - min_baseq * 0x01010101: bit 7 of (byte + kq) is set iff byte >= min_baseq
@@ -259,13 +266,13 @@ __global__ __launch_bounds__(W_NT) void msnv_pileup_tiles_wide(PileupArgs a) {
     __syncthreads();
     flush_events<WideLds, W_NT, W_EVCAP>(L, a, tid);
 
+    *reinterpret_cast<uint4 *>(a.part + (uint64_t)w.slot * TILE + W_PPT * tid) = make_uint4(tc[0], tc[1], tc[2], tc[3]);
 #pragma unroll
     for (int j = 0; j < W_PPT; ++j) {
         const uint64_t g = (uint64_t)t0 + W_PPT * tid + j;
-        if (tc[j]) atomicAdd(&a.tot[g], tc[j]);
 #pragma unroll
         for (int x = 0; x < 4; ++x)
-            if (tn[j][x]) atomicAdd(&a.tot[(uint64_t)(1 + x) * a.npos + g], tn[j][x]);
+            if (tn[j][x]) atomicAdd(&a.tot[(uint64_t)x * a.npos + g], tn[j][x]);
     }
 }
 
@@ -364,7 +371,7 @@ __device__ __forceinline__ void narrow_pass(NarrowLds &L, const PileupArgs &a, u
             for (uint32_t x = 0; x < 4; ++x) {
                 const uint32_t n = (word >> (8u * x)) & 0xffu;
                 if (n) {
-                    atomicAdd(&a.tot[(uint64_t)(1u + x) * a.npos + gpos], n);
+                    atomicAdd(&a.tot[(uint64_t)x * a.npos + gpos], n);
                     stage_allele_event<NarrowLds, N_EVCAP>(L, a, Pair32{gpos, sample << 18 | x << 16 | n});
                 }
             }
@@ -474,7 +481,7 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32(PileupArgs a)
                 atomicAdd(&L.end[sb >> 2], 1u << (8u * (sb & 3u)));
             }
             vh[i] = min(max((int)len - b0, 0), 32);
-            qa[i] = make_uint4(0, 0, 0, 0); qb[i] = qa[i]; sq[i] = qa[i];
+            qa[i] = any_uint4(); qb[i] = any_uint4(); sq[i] = any_uint4();   // never observed: vh masks every use
             if (vh[i] > 0) {                                         // lanes past the end of the piece load nothing
                 const uint4 *qp = reinterpret_cast<const uint4 *>(qual + 2ull * h.y + (uint32_t)b0);   // pieces are 16-byte aligned
                 qa[i] = qp[0];
@@ -492,9 +499,9 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32(PileupArgs a)
     }
     __syncthreads();
     flush_events<NarrowLds, N_NT, N_EVCAP>(L, a, tid);
-#pragma unroll
-    for (int j = 0; j < N_PPT; ++j)
-        if (tc[j]) atomicAdd(&a.tot[(uint64_t)t0 + N_PPT * tid + j], tc[j]);
+    uint4 *pp = reinterpret_cast<uint4 *>(a.part + (uint64_t)w.slot * TILE + N_PPT * tid);   // this item's coverage partial
+    pp[0] = make_uint4(tc[0], tc[1], tc[2], tc[3]);
+    pp[1] = make_uint4(tc[4], tc[5], tc[6], tc[7]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -505,7 +512,7 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32(PileupArgs a)
 constexpr int GATE_NT = 256;
 constexpr int GATE_CHUNKS = TILE / GATE_NT;
 
-__global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const uint32_t *tot, uint64_t npos,
+__global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const uint32_t *tot, const uint32_t *part, const uint32_t *tile_slot_start, uint64_t npos,
                                                            const uint32_t *tile_vbeg, const uint32_t *tile_vend,
                                                            int min_cov, int min_snvs,
                                                            SiteRec *sites, uint32_t cap_sites, uint32_t *counters,
@@ -517,16 +524,24 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const uint32_t *tot, 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t vb = tile_vbeg[tile], ve = tile_vend[tile];
 
+    const uint32_t slot_lo = tile_slot_start[tile], slot_hi = tile_slot_start[tile + 1];
     uint32_t flags = 0;
-    uint32_t mypre[GATE_CHUNKS];
+    uint32_t mypre[GATE_CHUNKS], covs[GATE_CHUNKS];
+#pragma unroll
+    for (int c = 0; c < GATE_CHUNKS; ++c) covs[c] = 0;
+    for (uint32_t s = slot_lo; s < slot_hi; ++s) {           // coverage = sum of the tile's work-item partials
+        const uint32_t *pp = part + (uint64_t)s * TILE + tid;
+#pragma unroll
+        for (int c = 0; c < GATE_CHUNKS; ++c) covs[c] += pp[c * GATE_NT];
+    }
 #pragma unroll
     for (int c = 0; c < GATE_CHUNKS; ++c) {
         const uint32_t p = (uint32_t)c * GATE_NT + (uint32_t)tid;
         const uint64_t g = (uint64_t)t0 + p;
-        const uint32_t cov = tot[g];
+        const uint32_t cov = covs[c];
         bool ok = false;
         if (cov != 0u && p >= vb && p < ve && (int)cov >= min_cov) {
-            const uint32_t nA = tot[npos + g], nC = tot[2 * npos + g], nG = tot[3 * npos + g], nT = tot[4 * npos + g];
+            const uint32_t nA = tot[g], nC = tot[npos + g], nG = tot[2 * npos + g], nT = tot[3 * npos + g];
             const uint32_t mx = max(max(nA, nC), max(nG, nT));
             ok = ((int)(nA + nC + nG + nT) >= min_snvs) && ((int)mx >= min_snvs);
         }
@@ -562,8 +577,8 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const uint32_t *tot, 
             if (idx < cap_sites) {
                 const uint64_t g = (uint64_t)t0 + (uint32_t)c * GATE_NT + (uint32_t)tid;
                 SiteRec s;
-                s.gpos = (uint32_t)g; s.cov = tot[g];
-                s.n[0] = tot[npos + g]; s.n[1] = tot[2 * npos + g]; s.n[2] = tot[3 * npos + g]; s.n[3] = tot[4 * npos + g];
+                s.gpos = (uint32_t)g; s.cov = covs[c];
+                s.n[0] = tot[g]; s.n[1] = tot[npos + g]; s.n[2] = tot[2 * npos + g]; s.n[3] = tot[3 * npos + g];
                 sites[idx] = s;
             }
         }
@@ -766,7 +781,7 @@ void dev_stream_destroy(void *stream) { if (stream) (void)hipStreamDestroy((hipS
 
 void dev_free_all(DeviceCols &d) {
     void *ptrs[] = {d.hdr, d.seq, d.qual, d.s_read_base, d.s_seq_base, d.ref4, d.ref_lc, d.pairs,
-                    d.tile_pair_start, d.work, d.chunks, d.tile_vbeg, d.tile_vend, d.tot, d.spill, d.events, d.overflow, d.counters,
+                    d.tile_pair_start, d.work, d.chunks, d.tile_vbeg, d.tile_vend, d.tot, d.part, d.tile_slot_start, d.spill, d.events, d.overflow, d.counters,
                     d.sites, d.tile_site_base, d.tile_site_cnt, d.out, d.site_flags,
                     d.cov_iv, d.s_cov_base, d.cov_pairs, d.cov_work, d.tile_len, d.tile_contig_dev, d.cov_acc};
     for (void *p : ptrs) dev_free(p);
@@ -795,13 +810,13 @@ int dev_run_pipeline(DeviceCols &d, const msnv_params &p, void *stream_, msnv_ru
 
     HIP_TRY(hipEventRecord(ev[0], st));
     HIP_TRY(hipMemsetAsync(d.counters, 0, 8 * sizeof(uint32_t), st));
-    if (npos) HIP_TRY(hipMemsetAsync(d.tot, 0, 5 * npos * sizeof(uint32_t), st));
+    if (npos) HIP_TRY(hipMemsetAsync(d.tot, 0, 4 * npos * sizeof(uint32_t), st));
     HIP_TRY(hipEventRecord(ev[1], st));
     if (d.n_work) {
         PileupArgs a;
         a.hdr = d.hdr; a.seq = d.seq; a.qual = d.qual;
         a.s_read_base = d.s_read_base; a.s_seq_base = d.s_seq_base;
-        a.ref4 = d.ref4; a.pairs = d.pairs; a.work = d.work; a.chunks = d.chunks; a.tot = d.tot; a.npos = npos; a.spill = d.spill;
+        a.ref4 = d.ref4; a.pairs = d.pairs; a.work = d.work; a.chunks = d.chunks; a.tot = d.tot; a.part = d.part; a.npos = npos; a.spill = d.spill;
         a.events = d.events; a.cap_events = d.cap_events; a.overflow = d.overflow; a.cap_overflow = d.cap_overflow;
         a.counters = d.counters; a.min_baseq = (uint32_t)std::max(0, p.min_baseq);
         static const bool all_wide = [] { const char *e = getenv("MSNV_PILEUP"); return e && e[0] == 'w'; }();   // A/B: MSNV_PILEUP=wide
@@ -817,7 +832,7 @@ int dev_run_pipeline(DeviceCols &d, const msnv_params &p, void *stream_, msnv_ru
     }
     HIP_TRY(hipEventRecord(ev[2], st));
     if (d.n_tiles) {
-        hipLaunchKernelGGL(msnv_gate_sites, dim3(d.n_tiles), dim3(GATE_NT), 0, st, d.tot, npos, d.tile_vbeg, d.tile_vend,
+        hipLaunchKernelGGL(msnv_gate_sites, dim3(d.n_tiles), dim3(GATE_NT), 0, st, d.tot, d.part, d.tile_slot_start, npos, d.tile_vbeg, d.tile_vend,
                            p.min_coverage, p.calling_threshold, d.sites, d.cap_sites, d.counters, d.tile_site_base, d.tile_site_cnt);
         HIP_TRY(hipGetLastError());
     }

@@ -324,12 +324,22 @@ int finalize_dataset(msnv_dataset &ds) {
                 const bool boundary = k + 1 == tps[t + 1] || (narrow != (pairs[k + 1].max_depth < NARROW_MAX_DEPTH));
                 const uint64_t next_ch = boundary ? 0 : (pairs[k + 1].read_hi - pairs[k + 1].read_lo + CHUNK_READS - 1) / CHUNK_READS;
                 if (acc >= target || boundary || nch + next_ch > MAX_CHUNKS_PER_ITEM) {
-                    (narrow ? work : wide).push_back(WorkItem{(uint32_t)t, lo, k + 1, 0, 0, {0, 0, 0}}); lo = k + 1; acc = 0; nch = 0;
+                    (narrow ? work : wide).push_back(WorkItem{(uint32_t)t, lo, k + 1, 0, 0, 0, {0, 0}}); lo = k + 1; acc = 0; nch = 0;
                 }
             }
         }
         d->n_work_narrow = (uint32_t)work.size();
         work.insert(work.end(), wide.begin(), wide.end());
+    }
+    // ---- coverage partials: one row per work item, rows of a tile contiguous (the gate kernel sums them)
+    {
+        std::vector<uint32_t> tss(nt + 1, 0);
+        for (const WorkItem &w : work) ++tss[w.tile + 1];
+        for (uint64_t t = 0; t < nt; ++t) tss[t + 1] += tss[t];
+        std::vector<uint32_t> fill(tss.begin(), tss.end() - 1);
+        for (WorkItem &w : work) w.slot = fill[w.tile]++;
+        if (int rc = upload_vec(&d->tile_slot_start, tss, &d->device_bytes)) return rc;
+        if (int rc = dev_alloc((void **)&d->part, std::max<uint64_t>(1, work.size()) * TILE * sizeof(uint32_t), &d->device_bytes)) return rc;
     }
     // ---- chunk descriptors of the narrow work items
     std::vector<ChunkDesc> chunks;
@@ -415,7 +425,7 @@ int finalize_dataset(msnv_dataset &ds) {
             uint32_t lo = cps[t]; uint64_t acc = 0;
             for (uint32_t k = cps[t]; k < cps[t + 1]; ++k) {
                 acc += cpairs[k].read_hi - cpairs[k].read_lo;
-                if (acc >= 4096 || k + 1 == cps[t + 1]) { cwork.push_back(WorkItem{(uint32_t)t, lo, k + 1, 0, 0, {0, 0, 0}}); lo = k + 1; acc = 0; }
+                if (acc >= 4096 || k + 1 == cps[t + 1]) { cwork.push_back(WorkItem{(uint32_t)t, lo, k + 1, 0, 0, 0, {0, 0}}); lo = k + 1; acc = 0; }
             }
         }
         std::vector<uint32_t> tlen(nt + 1, 0), tcont(nt + 1, 0);
@@ -436,7 +446,7 @@ int finalize_dataset(msnv_dataset &ds) {
     }
 
     // ---- intermediates
-    if (int rc = dev_alloc((void **)&d->tot, std::max<uint64_t>(1, 5 * npos) * sizeof(uint32_t), &d->device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&d->tot, std::max<uint64_t>(1, 4 * npos) * sizeof(uint32_t), &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->spill, std::max<uint64_t>(1, (uint64_t)pairs.size()) * TILE, &d->device_bytes)) return rc;
     // sparse buffers: generous first guess, grown on MSNV_ECAPACITY by the caller
     d->cap_events = (uint32_t)std::min<uint64_t>(0x7fffffffull, std::max<uint64_t>(1u << 20, tot_bases / 16));

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""profiles/summarize.py DIR TAG -- condense rocprofv3 CSV output (collect.sh) into two small files:
+gpurun_out/TAG_kernel_stats.csv (per-kernel calls / total / average ns) and gpurun_out/TAG_pmc.json
+(per-kernel average counter values per launch + the HBM traffic of the dominant kernel, with the gfx950
+FETCH_SIZE correction of MI355X_MICROARCH.md applied: KiB units, reads doubled)."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+d, tag = sys.argv[1], sys.argv[2]
+out_dir = os.path.dirname(os.path.abspath(d))
+
+# ---- kernel trace -> stats
+rows = defaultdict(list)
+for f in glob.glob(os.path.join(d, "trace", "**", "*kernel_trace.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        rows[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+with open(os.path.join(out_dir, tag + "_kernel_stats.csv"), "w") as f:
+    f.write("kernel,calls,total_ns,avg_ns,min_ns,max_ns\n")
+    for k, v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
+        f.write('"%s",%d,%d,%.1f,%d,%d\n' % (k, len(v), sum(v), sum(v) / len(v), min(v), max(v)))
+
+# ---- counters
+acc = defaultdict(lambda: defaultdict(lambda: defaultdict(float)))      # kernel -> counter -> dispatch -> value
+for f in glob.glob(os.path.join(d, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        acc[r["Kernel_Name"]][r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+pmc = {}
+for k, cs in acc.items():
+    pmc[k] = {c: {"avg_per_launch": sum(v.values()) / len(v), "launches": len(v)} for c, v in cs.items()}
+res = {"counters": pmc}
+dom = [k for k in pmc if "pileup_tiles_narrow32" in k]
+if dom and "FETCH_SIZE" in pmc[dom[0]] and "WRITE_SIZE" in pmc[dom[0]]:
+    fe = pmc[dom[0]]["FETCH_SIZE"]["avg_per_launch"] * 1024.0
+    wr = pmc[dom[0]]["WRITE_SIZE"]["avg_per_launch"] * 1024.0
+    res["kernel"] = "msnv_pileup_tiles_narrow32"
+    res["hbm_traffic"] = {"fetch_bytes_raw": fe, "fetch_bytes_corrected_x2": 2 * fe, "write_bytes": wr,
+                          "total_bytes_per_launch": 2 * fe + wr,
+                          "note": "FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of a wide coalesced stream "
+                                  "(MI355X_MICROARCH.md section HBM), so reads are doubled; separate --pmc passes with --kernel-trace only"}
+json.dump(res, open(os.path.join(out_dir, tag + "_pmc.json"), "w"), indent=1)
+print(json.dumps(res.get("hbm_traffic", {}), indent=1))
