@@ -186,7 +186,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "msnv_pileup_tiles_narrow32", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(a.samples, a.species, a.contig_len, a.mean_cov),
                          "algorithmic_bytes_per_launch": alg, "kernel_ms_avg": k_ms,
-                         "bytes_per_pileup_base": alg / max(1, bases)},
+                         "bytes_per_pileup_base": alg / max(1, bases),
+                         "algorithmic_definition": "SURVEY.md 8d: per pileup read 16 B header + 4 B per CIGAR op + 0.5 B/base + 1 B/base quality",
+                         "shipped_bytes_per_launch": info["bytes_headers"] + info["bytes_seq"] + info["bytes_qual"]},
             "positions_per_s": info["n_positions"] * world * a.steps / dt_max,
             "kernel_ms": {"pileup": k_ms, "pipeline_total": sum(ms_total) / len(ms_total)},
             "host": {"pack_s": t_pack, "finalize_upload_s": t_up, "device_bytes": info["device_bytes"]},

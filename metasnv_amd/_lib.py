@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmsnv.so")
+LIB_PATH = os.environ.get("MSNV_LIBRARY") or os.path.join(_HERE, "csrc", "libmsnv.so")   # MSNV_LIBRARY: developer A/B of two builds
 
 
 class MsnvError(RuntimeError):

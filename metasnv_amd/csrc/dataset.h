@@ -30,6 +30,7 @@ constexpr uint32_t SEG_MAX = 128;            // bases per segment piece = 8 lane
 constexpr uint32_t NARROW_MAX_DEPTH = 255;   // (tile, sample) pairs below this depth use byte-wide LDS bins
 
 struct ReadHdr { uint32_t gpos, seqoff, cig, meta; };
+struct PieceHdr { uint32_t w0, seqoff8; };                             // narrow kernel: start in tile | length << 11; seq byte offset / 8
 
 struct TilePair { uint32_t sample, read_lo, read_hi, max_depth; };    // reads of `sample` that may overlap the tile;
                                                                         // max_depth = upper bound of the per-position depth
@@ -52,6 +53,7 @@ struct SampleCols {
     std::vector<int32_t>  cov_tid, cov_beg, cov_end;   // qaCompute M intervals (index space), reads that pass its filter
     uint64_t n_pileup_bases = 0, n_pileup_reads = 0;
     uint64_t alg_seq_bytes = 0, alg_qual_bytes = 0;   // shipped bytes without alignment padding
+    uint64_t alg_8d_bytes = 0, alg_cigar_bytes = 0;   // SURVEY.md section 8d accounting (per pileup read)
     int32_t  first_tid = -1, first_beg = 0, first_end = 0;   // first pileup_ok read (first-line quirk)
     // qaCompute "Other" statistics (qaCompute.cpp:642-654)
     uint32_t total_reads = 0, unmapped = 0, zero_quality = 0, proper_pairs = 0, duplicates = 0;

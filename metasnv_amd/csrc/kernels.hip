@@ -32,6 +32,7 @@ static_assert(LANES_PER_READ * 16 == SEG_MAX, "segment pieces are sized for 8 la
 
 struct PileupArgs {
     const ReadHdr  *hdr;          // one 16-byte header per M/=/X segment piece: {gpos, seqoff, length, meta}
+    const PieceHdr *hdr8;         // the same pieces, tile-local 8-byte form: {start | length << 11, seqoff / 8}
     const uint8_t  *seq;
     const uint8_t  *qual;
     const uint64_t *s_read_base, *s_seq_base;
@@ -311,7 +312,7 @@ struct NarrowLds {
     unsigned long long spread[256];            // spread[b]: byte k = bit k of b (flag bits -> byte-bin increments)
     uint32_t al[TILE];
     uint32_t ref[TILE / 8 + 4];
-    uint4    hdr[2][N_HCAP];
+    uint2    hdr[2][N_HCAP];
     Pair32   ev[N_EVCAP];
     ChunkDesc desc[MAX_CHUNKS_PER_ITEM];
     int32_t  wsum[N_NT / 64];
@@ -452,18 +453,18 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32(PileupArgs a)
     for (uint32_t i = tid; i < nch * 2; i += N_NT)
         reinterpret_cast<uint4 *>(L.desc)[i] = reinterpret_cast<const uint4 *>(a.chunks + w.chunk_lo)[i];
     __syncthreads();
-    uint4 hreg = make_uint4(0, 0, 0, 0);
+    uint2 hreg = make_uint2(0, 0);
     if (nch && tid < N_HCAP && (uint32_t)tid < (L.desc[0].nrd_flags & 0xffffu))
-        hreg = *reinterpret_cast<const uint4 *>(a.hdr + L.desc[0].hdr_base + tid);
+        hreg = *reinterpret_cast<const uint2 *>(a.hdr8 + L.desc[0].hdr_base + tid);
     int buf = 0;
 
     for (uint32_t c = 0; c < nch; ++c) {
         const ChunkDesc cd = L.desc[c];
         const bool last_chunk = (cd.nrd_flags >> 16) != 0u;
-        if (tid < N_HCAP) L.hdr[buf][tid] = hreg;                    // slots beyond nrd hold meta = 0
-        hreg = make_uint4(0, 0, 0, 0);
+        if (tid < N_HCAP) L.hdr[buf][tid] = hreg;                    // slots beyond nrd hold length 0
+        hreg = make_uint2(0, 0);
         if (c + 1 < nch && tid < N_HCAP && (uint32_t)tid < (L.desc[c + 1].nrd_flags & 0xffffu))
-            hreg = *reinterpret_cast<const uint4 *>(a.hdr + L.desc[c + 1].hdr_base + tid);
+            hreg = *reinterpret_cast<const uint2 *>(a.hdr8 + L.desc[c + 1].hdr_base + tid);
         __syncthreads();                                            // (A)
         if (L.evn >= (uint32_t)(N_EVCAP / 2)) flush_events<NarrowLds, N_NT, N_EVCAP>(L, a, tid);
 
@@ -472,9 +473,10 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32(PileupArgs a)
         uint4 qa[N32_ROUNDS], qb[N32_ROUNDS], sq[N32_ROUNDS]; uint32_t P0[N32_ROUNDS]; int vh[N32_ROUNDS];
 #pragma unroll
         for (int i = 0; i < N32_ROUNDS; ++i) {
-            const uint4 h = L.hdr[buf][grp + i * N32_GROUPS];        // all zero for empty slots
-            const uint32_t len = h.z;
-            const uint32_t s = len ? h.x - t0 : 0u;
+            const uint2 h = L.hdr[buf][grp + i * N32_GROUPS];        // all zero for empty slots
+            const uint32_t len = h.x >> 11;
+            const uint32_t s = h.x & (TILE - 1u);
+            const uint64_t so = (uint64_t)h.y << 3;                  // seq byte offset of the piece inside the sample
             if (len && lane4 == 0) {
                 const uint32_t sb = s + len;
                 atomicAdd(&L.start[s >> 2], 1u << (8u * (s & 3u)));
@@ -483,10 +485,10 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32(PileupArgs a)
             vh[i] = min(max((int)len - b0, 0), 32);
             qa[i] = any_uint4(); qb[i] = any_uint4(); sq[i] = any_uint4();   // never observed: vh masks every use
             if (vh[i] > 0) {                                         // lanes past the end of the piece load nothing
-                const uint4 *qp = reinterpret_cast<const uint4 *>(qual + 2ull * h.y + (uint32_t)b0);   // pieces are 16-byte aligned
-                qa[i] = qp[0];
-                if (vh[i] > 16) qb[i] = qp[1];
-                sq[i] = *reinterpret_cast<const uint4 *>(seq + (uint64_t)h.y + (uint32_t)(b0 >> 1));
+                const uint8_t *qp = qual + 2ull * so + (uint32_t)b0;       // pieces start on 16-byte (qual) / 8-byte (seq) boundaries
+                __builtin_memcpy(&qa[i], qp, 16);
+                if (vh[i] > 16) __builtin_memcpy(&qb[i], qp + 16, 16);
+                __builtin_memcpy(&sq[i], seq + so + (uint32_t)(b0 >> 1), 16);
             }
             P0[i] = vh[i] > 0 ? s + (uint32_t)b0 : 0u;
         }
@@ -780,7 +782,7 @@ int dev_stream_create(void **stream) { hipStream_t s; HIP_TRY(hipStreamCreateWit
 void dev_stream_destroy(void *stream) { if (stream) (void)hipStreamDestroy((hipStream_t)stream); }
 
 void dev_free_all(DeviceCols &d) {
-    void *ptrs[] = {d.hdr, d.seq, d.qual, d.s_read_base, d.s_seq_base, d.ref4, d.ref_lc, d.pairs,
+    void *ptrs[] = {d.hdr, d.hdr8, d.seq, d.qual, d.s_read_base, d.s_seq_base, d.ref4, d.ref_lc, d.pairs,
                     d.tile_pair_start, d.work, d.chunks, d.tile_vbeg, d.tile_vend, d.tot, d.part, d.tile_slot_start, d.spill, d.events, d.overflow, d.counters,
                     d.sites, d.tile_site_base, d.tile_site_cnt, d.out, d.site_flags,
                     d.cov_iv, d.s_cov_base, d.cov_pairs, d.cov_work, d.tile_len, d.tile_contig_dev, d.cov_acc};
@@ -814,7 +816,7 @@ int dev_run_pipeline(DeviceCols &d, const msnv_params &p, void *stream_, msnv_ru
     HIP_TRY(hipEventRecord(ev[1], st));
     if (d.n_work) {
         PileupArgs a;
-        a.hdr = d.hdr; a.seq = d.seq; a.qual = d.qual;
+        a.hdr = d.hdr; a.hdr8 = d.hdr8; a.seq = d.seq; a.qual = d.qual;
         a.s_read_base = d.s_read_base; a.s_seq_base = d.s_seq_base;
         a.ref4 = d.ref4; a.pairs = d.pairs; a.work = d.work; a.chunks = d.chunks; a.tot = d.tot; a.part = d.part; a.npos = npos; a.spill = d.spill;
         a.events = d.events; a.cap_events = d.cap_events; a.overflow = d.overflow; a.cap_overflow = d.cap_overflow;

@@ -16,6 +16,11 @@
 
 namespace msnv {
 
+// Piece alignment in the seq column (bytes; the qual column is twice that).  Measured on one box, pileup kernel:
+// 16 -> 0.725 ms, 8 -> 0.665, 4 -> 0.664, 2 -> 0.651, 1 -> 0.672: padding is HBM traffic, misalignment costs the
+// vector-memory path about as much as it saves below 8.  The compact headers store seq offsets in 8-byte units.
+constexpr uint32_t seq_align = 8;
+
 std::vector<std::string> synth_contigs(const msnv_synth_params &p);
 void synth_sample_records(const msnv_synth_params &p, int sample, const std::vector<std::string> &contigs, std::vector<uint8_t> &out);
 
@@ -106,6 +111,10 @@ int pack_sample(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, Sa
         // ---- one 16-byte header per M/=/X segment piece of at most SEG_MAX bases; only aligned bases are shipped
         sc.n_pileup_bases += (uint64_t)m_bases;
         sc.n_pileup_reads++;
+        // algorithmic bytes of a read = 16 B header + 4 B per CIGAR op + 4-bit bases + 1 B qualities
+        // (only the aligned bases are counted; clipped / inserted bases are not shipped)
+        sc.alg_8d_bytes += 16u + 4u * r.n_cigar + ((uint64_t)m_bases + 1) / 2 + (uint64_t)m_bases;
+        sc.alg_cigar_bytes += 4u * r.n_cigar;
         if (sc.first_tid < 0) {
             // first pileup line of this sample (call_vC.cpp:423 drops the first line of the run)
             int64_t b = r.pos, e = endpos;
@@ -145,9 +154,8 @@ int pack_sample(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, Sa
                         // qualities above 127 (0xff = "not stored") pass every cutoff; clamping keeps the comparison
                         sc.qual.push_back(r.qual[qq] > 127 ? 127 : r.qual[qq]);
                     }
-                    // every piece starts on an 8-byte (seq) / 16-byte (qual) boundary: aligned 16-byte loads are
-                    // measurably cheaper on the vector-memory path than byte-offset ones
-                    while (sc.seq.size() & 7u) sc.seq.push_back(0xff);
+                    // every piece starts on an 8-byte (seq) / 16-byte (qual) boundary
+                    while (sc.seq.size() & (seq_align - 1u)) sc.seq.push_back(0xff);
                     while (sc.qual.size() < 2 * sc.seq.size()) sc.qual.push_back(0);
                     sc.hdr.push_back(h);
                     sc.tid.push_back(r.tid);
@@ -366,23 +374,30 @@ int finalize_dataset(msnv_dataset &ds) {
     // ---- columns
     d->n_reads = rbase[S]; d->n_seq_bytes = sbase[S];
     if (int rc = dev_alloc((void **)&d->hdr, (rbase[S] + 1) * sizeof(ReadHdr), &d->device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&d->hdr8, (rbase[S] + 1) * sizeof(PieceHdr), &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->seq, sbase[S] + 64, &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->qual, 2 * sbase[S] + 64, &d->device_bytes)) return rc;
     uint64_t alg = 0;
     for (size_t s = 0; s < S; ++s) {
         SampleCols &sc = ds.samples[s];
         if (int rc = dev_upload(d->hdr + rbase[s], sc.hdr.data(), sc.hdr.size() * sizeof(ReadHdr))) return rc;
+        {   // compact tile-local headers of the narrow kernel: {start in tile | length << 11, seq offset / 8}
+            std::vector<PieceHdr> h8(sc.hdr.size());
+            for (size_t i = 0; i < sc.hdr.size(); ++i) h8[i] = PieceHdr{(sc.hdr[i].gpos % TILE) | sc.hdr[i].cig << 11, sc.hdr[i].seqoff >> 3};
+            if (int rc = dev_upload(d->hdr8 + rbase[s], h8.data(), h8.size() * sizeof(PieceHdr))) return rc;
+        }
         if (int rc = dev_upload(d->seq + sbase[s], sc.seq.data(), sc.seq.size())) return rc;
         if (int rc = dev_upload(d->qual + 2 * sbase[s], sc.qual.data(), sc.qual.size())) return rc;
-        ds.info.bytes_headers += sc.hdr.size() * sizeof(ReadHdr);
+        ds.info.bytes_headers += sc.hdr.size() * sizeof(PieceHdr);
+        ds.info.bytes_cigar += sc.alg_cigar_bytes;
+        alg += sc.alg_8d_bytes;
         ds.info.bytes_seq += sc.alg_seq_bytes;
         ds.info.bytes_qual += sc.alg_qual_bytes;
         // release host staging of the bulky columns; headers stay (coverage pass, results mapping)
         std::vector<uint8_t>().swap(sc.seq);
         std::vector<uint8_t>().swap(sc.qual);
     }
-    alg = ds.info.bytes_headers + ds.info.bytes_cigar + ds.info.bytes_seq + ds.info.bytes_qual;
-    d->algorithmic_bytes = alg;
+    d->algorithmic_bytes = alg;                  // SURVEY.md section 8d figure; the shipped bytes are bytes_headers + bytes_seq + bytes_qual
 
     // ---- genome coverage index: intervals of qaCompute's difference array, grouped by tile
     {
