@@ -82,6 +82,7 @@ struct DeviceCols {
     uint64_t  device_bytes = 0;
     uint64_t  algorithmic_bytes = 0;
     AnnDev    ann;
+    void     *timing_events[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // hipEvent_t, reused by every pass
 };
 
 // host copies of the counters after a run

@@ -590,26 +590,28 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const uint32_t *tot, 
 // ------------------------------------------------------------------------------------------
 // msnv_gather_cov: per-sample coverage of every surviving site, from the spilled bytes.
 // ------------------------------------------------------------------------------------------
+constexpr uint32_t GATHER_SPLIT = 4;
 __global__ __launch_bounds__(256) void msnv_gather_cov(const SiteRec *sites, const uint32_t *tile_site_base,
                                                        const uint32_t *tile_site_cnt, const uint32_t *tile_pair_start,
                                                        const TilePair *pairs, const uint8_t *spill,
                                                        msnv_site_sample *out, uint32_t n_samples, uint32_t cap_out) {
-    const uint32_t tile = blockIdx.x;
+    const uint32_t tile = blockIdx.x / GATHER_SPLIT, part = blockIdx.x % GATHER_SPLIT;   // a tile's sites are dealt to GATHER_SPLIT workgroups
     const uint32_t n = tile_site_cnt[tile];
-    if (n == 0) return;
+    if (n <= part) return;
     const uint32_t base = tile_site_base[tile];
     if (base + n > cap_out) return;                     // the host sees the site count and retries with a larger buffer
-    {   // zero this tile's rows (10 B per (site, sample)), then fill in the coverages
-        uint16_t *row = reinterpret_cast<uint16_t *>(out + (uint64_t)base * n_samples);
-        const uint64_t nh = (uint64_t)n * n_samples * (sizeof(msnv_site_sample) / 2);
-        for (uint64_t i = threadIdx.x; i < nh; i += blockDim.x) row[i] = 0;
-        __syncthreads();
-    }
     const uint32_t ps = tile_pair_start[tile], np = tile_pair_start[tile + 1] - ps;
     const uint32_t t0 = tile * TILE;
-    const uint64_t work = (uint64_t)n * np;
+    const uint32_t row_hw = n_samples * (uint32_t)(sizeof(msnv_site_sample) / 2);
+    for (uint32_t j = part; j < n; j += GATHER_SPLIT) {  // zero my rows (10 B per (site, sample)), then fill in the coverages
+        uint16_t *row = reinterpret_cast<uint16_t *>(out + (uint64_t)(base + j) * n_samples);
+        for (uint32_t i = threadIdx.x; i < row_hw; i += blockDim.x) row[i] = 0;
+    }
+    __syncthreads();
+    const uint32_t mine = (n - part + GATHER_SPLIT - 1) / GATHER_SPLIT;
+    const uint64_t work = (uint64_t)mine * np;
     for (uint64_t i = threadIdx.x; i < work; i += blockDim.x) {
-        const uint32_t j = (uint32_t)(i / np), kk = (uint32_t)(i % np);
+        const uint32_t j = part + (uint32_t)(i / np) * GATHER_SPLIT, kk = (uint32_t)(i % np);
         const uint32_t off = sites[base + j].gpos - t0;
         const uint32_t cov = spill[(uint64_t)(ps + kk) * TILE + off];
         out[(uint64_t)(base + j) * n_samples + pairs[ps + kk].sample].cov = (uint16_t)cov;   // 255 = see overflow list
@@ -789,6 +791,7 @@ void dev_free_all(DeviceCols &d) {
     for (void *p : ptrs) dev_free(p);
     void *aptrs[] = {d.ann.seg_beg, d.ann.seg_end, d.ann.seg_gene, d.ann.genes, d.ann.contigs, d.ann.codons, d.ann.out, d.ann.err};
     for (void *p : aptrs) dev_free(p);
+    for (void *e : d.timing_events) if (e) (void)hipEventDestroy((hipEvent_t)e);
     d = DeviceCols{};
 }
 
@@ -806,9 +809,12 @@ static int ensure_out(DeviceCols &d, uint64_t n_sites) {
 int dev_run_pipeline(DeviceCols &d, const msnv_params &p, void *stream_, msnv_run_stats *stats, RunCounts *counts) {
     hipStream_t st = (hipStream_t)stream_;
     const uint64_t npos = (uint64_t)d.n_tiles * TILE;
-    hipEvent_t ev[6];
-    for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
-    auto cleanup = [&]() { for (auto &e : ev) (void)hipEventDestroy(e); };
+    hipEvent_t ev[6];                                      // created once per dataset: event create / destroy costs host time in every pass
+    for (int i = 0; i < 6; ++i) {
+        if (!d.timing_events[i]) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); d.timing_events[i] = e; }
+        ev[i] = (hipEvent_t)d.timing_events[i];
+    }
+    auto cleanup = [] {};
 
     HIP_TRY(hipEventRecord(ev[0], st));
     HIP_TRY(hipMemsetAsync(d.counters, 0, 8 * sizeof(uint32_t), st));
@@ -843,7 +849,7 @@ int dev_run_pipeline(DeviceCols &d, const msnv_params &p, void *stream_, msnv_ru
     if (int rc = ensure_out(d, std::max<uint64_t>(d.last_sites + d.last_sites / 2, 4096))) { cleanup(); return rc; }
     const uint32_t cap_out = (uint32_t)std::min<uint64_t>(d.cap_out_sites, 0xffffffffull);
     if (d.n_tiles) {
-        hipLaunchKernelGGL(msnv_gather_cov, dim3(d.n_tiles), dim3(256), 0, st, d.sites, d.tile_site_base, d.tile_site_cnt,
+        hipLaunchKernelGGL(msnv_gather_cov, dim3(d.n_tiles * GATHER_SPLIT), dim3(256), 0, st, d.sites, d.tile_site_base, d.tile_site_cnt,
                            d.tile_pair_start, d.pairs, d.spill, d.out, d.n_samples, cap_out);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(msnv_scatter_events, dim3(1024), dim3(256), 0, st, d.events, d.overflow, d.counters, d.cap_events,

@@ -1,0 +1,14 @@
+import sys, os
+sys.path.insert(0, os.getcwd())
+from metasnv_amd import core
+sp = core.synth_params(n_species=3, contig_len=300000, n_samples=160, mean_cov=10.0, seed=1)
+syn = core.Synth(sp); ctx = core.Context(0)
+ds = core.Dataset(ctx, syn.names, syn.lengths, syn.seqs)
+ds.add_synth_samples(sp, 0, 160, 0); ds.finalize()
+for _ in range(3): ds.run()
+acc = {}
+for _ in range(20):
+    st = ds.run()
+    for k in ("ms_total", "ms_pileup", "ms_gate", "ms_gather", "ms_decide"):
+        acc[k] = acc.get(k, 0) + st[k] / 20
+print({k: round(v, 4) for k, v in acc.items()})
