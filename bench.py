@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-annotation", action="store_true", help="skip the --db_ann codon-annotation kernel (BASELINE configs[4]) after the timed region")
     ap.add_argument("--host-threads", type=int, default=0)
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal of the N>1 path on a box with fewer GPUs than ranks)")
     return ap.parse_args()
 
 
@@ -101,8 +102,13 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist_
-        torch.cuda.set_device(local)
-        dist_.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if a.dist_backend == "nccl":
+            torch.cuda.set_device(local)
+            dist_.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:                                   # rehearsal: ranks may share a GPU, the 4-number table travels over gloo
+            local = local % max(1, torch.cuda.device_count())
+            torch.cuda.set_device(local)
+            dist_.init_process_group(backend=a.dist_backend)
         dist = dist_
 
     from metasnv_amd import core
@@ -157,7 +163,8 @@ def main():
     bases = info["n_pileup_bases"]
     if dist is not None:
         import torch
-        t = torch.tensor([dt, float(bases), float(st["n_called_pop"]), float(st["n_called_indiv"])], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, float(bases), float(st["n_called_pop"]), float(st["n_called_indiv"])], dtype=torch.float64,
+                         device="cuda" if a.dist_backend == "nccl" else "cpu")
         gathered = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(gathered, t)       # the only collective: tiny result table over RCCL/xGMI
         dt_max = max(float(g[0]) for g in gathered)
