@@ -186,6 +186,10 @@ int  msnv_pileup_run(msnv_dataset *ds, msnv_run_stats *stats);
 
 /* Per-sample genome coverage (qaCompute arithmetic) over the resident dataset. */
 int  msnv_coverage_run(msnv_dataset *ds, msnv_run_stats *stats);
+/* Both passes over the same resident columns (BASELINE configs[2]: qaCompute + snpCall fused on the device):
+ * replaces running `qaCompute` per BAM (metaSNV.py:63-65) and then `samtools mpileup | snpCall` (:160-176) on
+ * the same files.  Either stats pointer may be NULL. */
+int  msnv_fused_run(msnv_dataset *ds, msnv_run_stats *pileup_stats, msnv_run_stats *coverage_stats);
 /* Writes OUT / OUT.detail for sample `sample_idx` from the last msnv_coverage_run. */
 int  msnv_write_coverage(msnv_dataset *ds, int32_t sample_idx, const char *cov_path, const char *detail_path);
 

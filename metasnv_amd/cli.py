@@ -131,6 +131,35 @@ def execute_snp_call(args, ctx, ifile, ofile, split):           # metaSNV.py:153
         ds.close()
 
 
+def fused_cov_and_call(args, ctx):
+    """Single-GPU, unsplit run: qaCompute (metaSNV.py:55-78) and mpileup | snpCall (:153-221) from ONE dataset, so
+    every BAM is inflated, packed and uploaded once.  Writes the same files in the same places as the two steps."""
+    from . import core
+    bams = read_sample_list(args.all_samples)
+    cov_dir, snp_dir = os.path.join(args.project_dir, 'cov'), os.path.join(args.project_dir, 'snpCaller')
+    mkdir_p(cov_dir); mkdir_p(snp_dir)
+    params = core.default_params(min_coverage=args.min_pos_cov, calling_threshold=args.min_pos_snvs, cov_max=10, cov_min_mapq=1)
+    ds = core.Dataset.from_files(ctx, bams[0], args.ref_db, params)
+    try:
+        ds.add_sample_bams(bams, args.threads)
+        ds.finalize()
+        ds.fused_run()
+        for i, b in enumerate(bams):
+            out = os.path.join(cov_dir, os.path.basename(b) + '.cov')
+            ds.write_coverage(i, out, out + '.detail')
+            print("Printing details in {}!".format(out + '.detail'))      # qaCompute.cpp:387
+        compute_summary(args)
+        get_header(args)
+        shutil.copy(args.all_samples, args.project_dir + '/all_samples')
+        ds.write_calls(os.path.join(snp_dir, "called_SNPs"), os.path.join(snp_dir, "indiv_called"), args.db_ann or None, args.ref_db)
+    except core._lib.MsnvError as e:
+        sys.stderr.write(str(e) + "\n")
+        sys.stderr.write("SNV calling failed")
+        sys.exit(1)
+    finally:
+        ds.close()
+
+
 def snp_call(args, ctx, rank=0, world=1):                       # metaSNV.py:179-221
     out_dir = os.path.join(args.project_dir, 'snpCaller')
     mkdir_p(out_dir)
@@ -202,6 +231,10 @@ def main(argv=None):
             sys.stderr.write("\nERROR:  {}\n\nSOLUTION: run on a node with an AMD Instinct GPU (there is no CPU fallback)\n\n".format(e))
             parallel.abort(1)
 
+    if world == 1 and args.n_splits <= 1 and not args.use_prev_cov and not args.print_commands:
+        fused_cov_and_call(args, ctx)                           # BASELINE configs[2]: one decode, both passes on the device
+        parallel.finalize()
+        return
     if not args.use_prev_cov:
         compute_opt(args, ctx, rank, world)
         parallel.barrier()

@@ -151,6 +151,12 @@ class Dataset:
         check(lib.msnv_coverage_run(self._h, C.byref(st)))
         return {k: getattr(st, k) for k, _ in RunStats._fields_}
 
+    def fused_run(self):
+        """Coverage (qaCompute) and SNV calling over the same resident columns; returns (pileup stats, coverage stats)."""
+        sp, sc = RunStats(), RunStats()
+        check(lib.msnv_fused_run(self._h, C.byref(sp), C.byref(sc)))
+        return ({k: getattr(sp, k) for k, _ in RunStats._fields_}, {k: getattr(sc, k) for k, _ in RunStats._fields_})
+
     def write_coverage(self, sample_idx, cov_path, detail_path):
         check(lib.msnv_write_coverage(self._h, sample_idx, cov_path.encode(), detail_path.encode()))
 

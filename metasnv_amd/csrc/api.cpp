@@ -453,6 +453,13 @@ extern "C" int msnv_coverage_run(msnv_dataset *ds, msnv_run_stats *stats) {
     return coverage_run(*ds, stats);
 }
 
+// BASELINE configs[2]: qaCompute + snpCall from ONE resident dataset (the BAMs are decoded, packed and uploaded once;
+// the two passes have different read filters and index spaces, so they stay two kernels over shared columns).
+extern "C" int msnv_fused_run(msnv_dataset *ds, msnv_run_stats *pileup_stats, msnv_run_stats *coverage_stats) {
+    if (int rc = msnv_coverage_run(ds, coverage_stats)) return rc;
+    return msnv_pileup_run(ds, pileup_stats);
+}
+
 extern "C" int msnv_write_coverage(msnv_dataset *ds, int32_t sample_idx, const char *cov_path, const char *detail_path) {
     clear_error();
     if (!ds || !cov_path || !detail_path) return fail(MSNV_EINVAL, "msnv_write_coverage: NULL argument");

@@ -45,3 +45,12 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")) or f == "Makefile":
                 txt = open(os.path.join(dp, f), errors="replace").read()
                 assert "liborc" not in txt and "oracle/" not in txt and "import orc" not in txt, os.path.join(dp, f)
+
+
+def test_drop_in_executables_exist_and_print_usage():
+    import subprocess
+    from metasnv_amd import _lib
+    tools = os.path.join(os.path.dirname(_lib.LIB_PATH), "tools")
+    for exe in ("msnv_qacompute", "msnv_snpcall"):
+        r = subprocess.run([os.path.join(tools, exe)], capture_output=True, text=True)
+        assert r.returncode == 1 and "Usage" in r.stderr       # qaCompute.cpp:356-359: wrong argument count -> usage, exit 1

@@ -325,6 +325,54 @@ def _write_inputs(tmp_path, syn, samples):
     return fa, paths, lst
 
 
+def test_config3_shape_fused_coverage_and_calls(tmp_path):
+    """BASELINE configs[2] at reduced size: many species, every sample carries a random subset of them,
+    qaCompute + snpCall from ONE resident dataset (msnv_fused_run), both checked against the oracle."""
+    syn, samples = synth_case(n_species=24, contig_len=3000, n_samples=12, mean_cov=9.0, snv_density=0.02, frac_absent=0.6,
+                              lowercase_ref=1, seed=303)
+    ctx = core.Context(0)
+    ds = core.Dataset(ctx, syn.names, syn.lengths, syn.seqs)
+    for s in samples:
+        ds.add_sample_records(s)
+    info = ds.finalize()
+    st_p, st_c = ds.fused_run()
+    pp, ip = str(tmp_path / "called"), str(tmp_path / "indiv")
+    ds.write_calls(pp, ip)
+    orac = run_oracle(syn.names, syn.lengths, syn.seqs, samples)
+    _assert_same((open(pp).read(), open(ip).read()), orac)
+    for i, s in enumerate(samples):
+        cp, dp = str(tmp_path / ("s%d.cov" % i)), str(tmp_path / ("s%d.cov.detail" % i))
+        if s.size == 0:
+            continue
+        ds.write_coverage(i, cp, dp)
+        want = orc.qacompute(syn.names, syn.lengths, s)
+        assert open(cp).read() == want[0] and open(dp).read() == want[1]
+    assert st_p["n_called_pop"] == orac[0].count("\n") and info["n_contigs"] == 24
+    ds.close(); ctx.close()
+
+
+def test_process_level_drop_ins(tmp_path):
+    """msnv_qacompute (argv of qaCompute as metaSNV.py:63-65 passes it) and msnv_snpcall (the mpileup | snpCall pipe
+    of metaSNV.py:160-176 as one process, population lines on stdout) against the oracle."""
+    import subprocess
+    tools = os.path.join(os.path.dirname(core._lib.LIB_PATH), "tools")
+    syn, samples = synth_case(n_species=2, contig_len=4000, n_samples=3, mean_cov=10.0, snv_density=0.02, seed=13)
+    fa, paths, lst = _write_inputs(tmp_path, syn, samples)
+    out = str(tmp_path / "s0.cov")
+    r = subprocess.run([os.path.join(tools, "msnv_qacompute"), "-c", "10", "-d", "-i", paths[0], out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == "Printing details in %s.detail!\n" % out
+    want = orc.qacompute(syn.names, syn.lengths, samples[0])
+    assert open(out).read() == want[0] and open(out + ".detail").read() == want[1]
+    indiv = str(tmp_path / "indiv_called")
+    r = subprocess.run([os.path.join(tools, "msnv_snpcall"), "-f", fa, "-b", lst, "-i", indiv, "-c", "4", "-t", "4"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    orac = run_oracle(syn.names, syn.lengths, syn.seqs, samples)
+    assert r.stdout == orac[0] and open(indiv).read() == orac[1]
+    r = subprocess.run([os.path.join(tools, "msnv_qacompute"), "-c", "10", "-d", "-i", str(tmp_path / "missing.bam"), out], capture_output=True, text=True)
+    assert r.returncode == 1                              # qaCompute.cpp:376-379
+
+
 def test_cli_project_layout_and_contents(tmp_path, capsys):
     from metasnv_amd import cli, tables
     syn, samples = synth_case(n_species=3, contig_len=4000, n_samples=4, mean_cov=12.0, snv_density=0.03, frac_absent=0.0, seed=31)
