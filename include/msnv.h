@@ -120,6 +120,29 @@ typedef struct {
 int msnv_call(msnv_ctx *ctx, const msnv_call_args *args);
 
 /* ------------------------------------------------------------------------------------
+ * Next row of the path: metaSNV_Filtering.py filter_two
+ * (metaSNV_Filtering.py:156-242) -- position filter and allele frequencies of the called
+ * positions, computed on the device for all species of interest in one pass over the files.
+ * ------------------------------------------------------------------------------------ */
+typedef struct {
+    const char        *species;     /* TaxID = contig name up to the first '.' (:172)              */
+    int32_t            n_soi;       /* samples of interest of this species (relevant_taxa, :111-145) */
+    const int32_t     *soi;         /* their indices in all_samples order (:180-181)                */
+    const char *const *soi_names;   /* header of <species>.filtered.freq (:203)                     */
+} msnv_filter_species;
+
+/* snp_paths: the snpCaller/called* (or indiv*) files, in the order they are to be read.  Writes
+ * out_dir/<species>.filtered.freq for every species with at least one surviving position (-c min_cov_c,
+ * -p min_prop_p; defaults 5.0 and 0.50).  n_positions_kept / ms_kernel may be NULL. */
+/* repr() of a Python float, the text metaSNV_Filtering.py:231 prints for a frequency (shortest digits that
+ * round-trip; exponent form below 1e-4 and from 1e16).  Returns the length, or -1 when cap is too small. */
+int msnv_format_float(double x, char *buf, int32_t cap);
+
+int msnv_filter_files(msnv_ctx *ctx, const char *const *snp_paths, int32_t n_paths, int32_t n_samples,
+                      const msnv_filter_species *species, int32_t n_species, double min_cov_c, double min_prop_p,
+                      const char *out_dir, uint64_t *n_positions_kept, double *ms_kernel);
+
+/* ------------------------------------------------------------------------------------
  * Staged form of the same path.
  * ------------------------------------------------------------------------------------ */
 

@@ -71,6 +71,10 @@ class SiteAnn(C.Structure):
     _fields_ = [("gene", C.c_int32), ("codon", (C.c_uint8 * 8) * 4)]
 
 
+class FilterSpecies(C.Structure):
+    _fields_ = [("species", C.c_char_p), ("n_soi", C.c_int32), ("soi", C.POINTER(C.c_int32)), ("soi_names", C.POINTER(C.c_char_p))]
+
+
 class BamData(C.Structure):
     _fields_ = [("n_contigs", C.c_int32), ("names", C.POINTER(C.c_char_p)), ("lengths", C.POINTER(C.c_int64)),
                 ("records", C.POINTER(C.c_uint8)), ("n_record_bytes", C.c_uint64), ("header_text", C.c_char_p)]
@@ -118,6 +122,9 @@ SYMBOLS = [
     ("msnv_results_fetch_ann", C.c_int, [_vp, P(SiteAnn), C.c_uint64]),
     ("msnv_results_count", C.c_int, [_vp, P(C.c_uint64)]),
     ("msnv_results_fetch", C.c_int, [_vp, P(Site), P(SiteSample), C.c_uint64]),
+    ("msnv_format_float", C.c_int, [C.c_double, C.c_char_p, C.c_int32]),
+    ("msnv_filter_files", C.c_int, [_vp, P(C.c_char_p), C.c_int32, C.c_int32, P(FilterSpecies), C.c_int32, C.c_double, C.c_double,
+                                   C.c_char_p, P(C.c_uint64), P(C.c_double)]),
     ("msnv_bam_write_bed_header", C.c_int, [C.c_char_p, C.c_char_p]),
     ("msnv_bam_read", C.c_int, [C.c_char_p, P(BamData)]),
     ("msnv_bam_data_free", None, [P(BamData)]),

@@ -7,6 +7,7 @@
 #include <thread>
 
 #include "device.h"
+#include "filter.h"
 
 namespace msnv {
 int pack_sample(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, SampleCols &sc);
@@ -464,6 +465,48 @@ extern "C" int msnv_write_coverage(msnv_dataset *ds, int32_t sample_idx, const c
     clear_error();
     if (!ds || !cov_path || !detail_path) return fail(MSNV_EINVAL, "msnv_write_coverage: NULL argument");
     return coverage_write(*ds, sample_idx, cov_path, detail_path);
+}
+
+// ------------------------------------------------------------------------------ filter_two (section 8 f1)
+namespace msnv {
+int filter_files(msnv_ctx *ctx, const char *const *paths, int n_paths, uint32_t n_samples, const FilterSpecies &sp,
+                 double min_cov, double min_prop, const char *out_dir, uint64_t *n_lines_kept, double *ms_kernel);
+}
+namespace msnv { void py_repr(double x, std::string &out); }
+extern "C" int msnv_format_float(double x, char *buf, int32_t cap) {
+    std::string s;
+    py_repr(x, s);
+    if (!buf || (int32_t)s.size() + 1 > cap) return -1;
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return (int)s.size();
+}
+
+extern "C" int msnv_filter_files(msnv_ctx *ctx, const char *const *snp_paths, int32_t n_paths, int32_t n_samples,
+                                 const msnv_filter_species *species, int32_t n_species, double min_cov_c, double min_prop_p,
+                                 const char *out_dir, uint64_t *n_positions_kept, double *ms_kernel) {
+    clear_error();
+    if (!ctx || n_paths < 0 || (n_paths && !snp_paths) || n_samples <= 0 || n_species < 0 || (n_species && !species) || !out_dir)
+        return fail(MSNV_EINVAL, "msnv_filter_files: bad argument");
+    if (int rc = dev_set_device(ctx->device)) return rc;
+    FilterSpecies sp;
+    sp.soi_off.push_back(0);
+    for (int i = 0; i < n_species; ++i) {
+        const msnv_filter_species &s = species[i];
+        if (!s.species || s.n_soi <= 0 || !s.soi || !s.soi_names)
+            return fail(MSNV_EINVAL, "msnv_filter_files: species %d has no samples of interest (the reference divides by their number)", i);
+        sp.name.emplace_back(s.species);
+        sp.soi_names.emplace_back();
+        for (int k = 0; k < s.n_soi; ++k) {
+            if (s.soi[k] < 0 || s.soi[k] >= n_samples) return fail(MSNV_EINVAL, "msnv_filter_files: sample index %d out of range", s.soi[k]);
+            sp.soi_idx.push_back((uint32_t)s.soi[k]);
+            sp.soi_names.back().emplace_back(s.soi_names[k]);
+        }
+        sp.soi_off.push_back((uint32_t)sp.soi_idx.size());
+    }
+    if (ms_kernel) *ms_kernel = 0;
+    if (n_positions_kept) *n_positions_kept = 0;
+    if (!n_species) return MSNV_OK;
+    return filter_files(ctx, snp_paths, n_paths, (uint32_t)n_samples, sp, min_cov_c, min_prop_p, out_dir, n_positions_kept, ms_kernel);
 }
 
 // ------------------------------------------------------------------------------ one-call forms

@@ -65,6 +65,57 @@ def main():
         os.makedirs(os.path.join(f, sub), exist_ok=True)
     env = dict(os.environ)
     subprocess.check_call([sys.executable, os.path.join(REF, "metaSNV_Filtering.py"), f], cwd=os.path.dirname(f), env=env, stdout=subprocess.DEVNULL)
+    # ---- second Filtering case (section 8 f1): three species, six samples, random counts that exercise repr() of
+    # the frequencies (exponent form below 1e-4, 16-17 significant digits), zero coverages, the -c / -p gates, --ind
+    import json
+    import random
+    import importlib.util
+    rnd = random.Random(11)
+    f2 = os.path.join(OUT, "filtering2", "proj")
+    names = ["s%d.bam" % i for i in range(6)]
+    w(os.path.join(f2, "all_samples"), "".join("/data/run/%s\n" % n for n in names))
+    covtab = "\t" + "\t".join(names) + "\nTaxId\t" + "\t".join(["Average_cov"] * 6) + "\n"
+    pertab = "\t" + "\t".join(names) + "\nTaxId\t" + "\t".join(["Percentage_1x"] * 6) + "\n"
+    rows = {"spA": ([9.5, 0.5, 7.25, 6.0, 1.0, 12.0], [80, 5, 55.5, 41, 30, 99]),
+            "spB": ([2.0, 2.0, 2.0, 2.0, 2.0, 2.0], [50, 50, 50, 50, 50, 50]),
+            "spC": ([1.0, 30.0, 0.0, 25.5, 0.0, 0.0], [10, 90, 0, 70, 0, 0]),
+            "spD": ([3.0, 3.0, 3.0, 3.0, 3.0, 3.0], [9, 9, 9, 9, 9, 9])}
+    for sp, (c, p) in rows.items():
+        covtab += sp + "\t" + "\t".join("%f" % x for x in c) + "\n"
+        pertab += sp + "\t" + "\t".join("%f" % x for x in p) + "\n"
+    w(os.path.join(f2, "proj.all_cov.tab"), covtab)
+    w(os.path.join(f2, "proj.all_perc.tab"), pertab)
+
+    def snp_lines(n_lines, seed):
+        r = random.Random(seed)
+        out = ""
+        contigs = ["spA.p.c1", "spA.p.c2", "spB.q.c1", "spC", "spD.x", "spE.y"]
+        for k in range(n_lines):
+            ctg = contigs[min(len(contigs) - 1, k * len(contigs) // n_lines)]
+            cov = [r.choice([0, 0, 1, 2, 3, 4, 5, 6, 7, 9, 13, 40, 97, 1000, 29989, 200003]) for _ in range(6)]
+            ents = []
+            for alt in r.sample("ACGT", r.choice([1, 1, 1, 2, 3])):
+                cnt = [r.randint(0, c) if c else 0 for c in cov]
+                tag = r.choice([".", ".", "S[GCT-GCC]", "N[ATG-ACG]", "N[TA-TC]"])
+                ents.append("%d|%s|%s|%s" % (sum(cnt), alt, tag, "|".join(map(str, cnt))))
+            out += "%s\t%s\t%d\t%s\t%s\t%s\n" % (ctg, r.choice(["-", "gene%d" % k]), 10 + 3 * k, r.choice("ACGTacgtN"),
+                                                 "|".join(map(str, cov)), ",".join(ents))
+        return out
+    tiny = "spA.p.c2\tgeneT\t9001\tA\t200003|29989|200003|1000|97|13\t3|C|.|1|0|2|0|0|0,31|G|N[TA-TC]|7|3|1|5|9|6\n"   # 1/200003 -> repr in exponent form
+    w(os.path.join(f2, "snpCaller", "called_SNPs.best_split_0"), snp_lines(120, 1) + tiny)
+    w(os.path.join(f2, "snpCaller", "indiv_called.best_split_0"), snp_lines(60, 2))
+    subprocess.check_call([sys.executable, os.path.join(REF, "metaSNV_Filtering.py"), f2, "-m", "2", "-d", "1", "-b", "10", "-c", "3", "-p", "0.4", "--ind"],
+                          cwd=os.path.dirname(f2), env=env, stdout=subprocess.DEVNULL)
+    # FILTER I known answers for a few threshold sets (relevant_taxa of the reference module, imported here only)
+    spec = importlib.util.spec_from_file_location("ref_filtering", os.path.join(REF, "metaSNV_Filtering.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    answers = []
+    for (b, d, m) in [(40.0, 5.0, 2), (10.0, 1.0, 2), (50.0, 2.0, 6), (0.0, 0.0, 1), (95.0, 10.0, 1)]:
+        ns = type("A", (), {})()
+        ns.coverage_file, ns.percentage_file, ns.b, ns.d, ns.m = os.path.join(f2, "proj.all_cov.tab"), os.path.join(f2, "proj.all_perc.tab"), b, d, m
+        answers.append({"b": b, "d": d, "m": m, "SoI": mod.relevant_taxa(ns)["SoI"]})
+    w(os.path.join(OUT, "filtering2", "relevant_taxa.json"), json.dumps(answers, indent=1, sort_keys=True))
     print("goldens written to", OUT)
 
 

@@ -373,6 +373,63 @@ def test_process_level_drop_ins(tmp_path):
     assert r.returncode == 1                              # qaCompute.cpp:376-379
 
 
+@pytest.mark.parametrize("case,argv", [("filtering", []), ("filtering2", ["-m", "2", "-d", "1", "-b", "10", "-c", "3", "-p", "0.4", "--ind"])])
+def test_filtering_on_device_matches_reference_outputs(tmp_path, golden_dir, case, argv):
+    """metaSNV_Filtering.py filter_two on the device: the project directories under
+    tests/golden/python_callers/filtering* hold the inputs and the outputs the reference script produced."""
+    import filecmp
+    import shutil
+    from metasnv_amd import filtering
+    src = os.path.join(golden_dir, "python_callers", case, "proj")
+    proj = str(tmp_path / "proj")
+    shutil.copytree(src, proj)
+    shutil.rmtree(os.path.join(proj, "filtered"))
+    filtering.main([proj] + argv)
+    for sub in ("pop", "ind"):
+        want_dir, got_dir = os.path.join(src, "filtered", sub), os.path.join(proj, "filtered", sub)
+        want = sorted(os.listdir(want_dir)) if os.path.isdir(want_dir) else []
+        got = sorted(os.listdir(got_dir)) if os.path.isdir(got_dir) else []
+        assert got == want
+        for f in want:
+            assert open(os.path.join(got_dir, f)).read() == open(os.path.join(want_dir, f)).read(), f
+
+
+def test_filtering_of_pipeline_output_matches_python_restatement(tmp_path):
+    """Filtering of OUR called_SNPs (160-column-style lines from the device) against a plain-Python evaluation of the
+    reference's formulas (metaSNV_Filtering.py:183-231) on the same text."""
+    from metasnv_amd import cli, filtering
+    syn, samples = synth_case(n_species=3, contig_len=5000, n_samples=6, mean_cov=12.0, snv_density=0.03, frac_absent=0.1, seed=77)
+    fa, paths, lst = _write_inputs(tmp_path, syn, samples)
+    proj = str(tmp_path / "outf")
+    cli.main([proj, lst, fa])
+    filtering.main([proj, "-m", "2", "-d", "2", "-b", "20", "-c", "4", "-p", "0.5", "--ind"])
+    soi = filtering.relevant_taxa(os.path.join(proj, "outf.all_cov.tab"), os.path.join(proj, "outf.all_perc.tab"), 20.0, 2.0, 2)["SoI"]
+    header = [p.split("/")[-1] for p in open(os.path.join(proj, "all_samples")).read().splitlines()]
+    assert soi
+    for sub, fname in (("pop", "called_SNPs"), ("ind", "indiv_called")):
+        for sp, names in soi.items():
+            idx = [header.index(n) for n in names]
+            want = ""
+            for line in open(os.path.join(proj, "snpCaller", fname)):
+                w = line.split()
+                if w[0].split(".")[0] != sp:
+                    continue
+                cov = list(map(int, w[4].split("|")))
+                good = sum(1 for i in idx if not (cov[i] < 4.0 or cov[i] == 0))
+                if float(good) / len(idx) < 0.5:
+                    continue
+                for snp in w[5].split(","):
+                    x = snp.split("|")
+                    c = list(map(float, x[3:]))
+                    fr = [c[i] / cov[i] if (cov[i] >= 4.0 and cov[i] != 0) else -1 for i in idx]
+                    want += ":".join(w[:4]) + ">" + x[1] + ":" + x[2] + "\t" + "\t".join(str(v) for v in fr) + "\n"
+            path = os.path.join(proj, "filtered", sub, sp + ".filtered.freq")
+            if want:
+                assert open(path).read() == "\t" + "\t".join(names) + "\n" + want
+            else:
+                assert not os.path.exists(path)
+
+
 def test_cli_project_layout_and_contents(tmp_path, capsys):
     from metasnv_amd import cli, tables
     syn, samples = synth_case(n_species=3, contig_len=4000, n_samples=4, mean_cov=12.0, snv_density=0.03, frac_absent=0.0, seed=31)
