@@ -142,6 +142,11 @@ def _load():
         raise ImportError(
             "metasnv_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # multi-rank runs exchange tables through torch.distributed: torch ships its own libamdhip64, and two HIP
+        # runtimes in one process do not both see the GPU.  Importing torch first makes libmsnv.so bind to the
+        # runtime torch already loaded (same SONAME).
+        import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, res, args in SYMBOLS:
         fn = getattr(lib, name)          # AttributeError here = the .so does not match include/msnv.h

@@ -26,10 +26,14 @@ def init_from_env():
     if _world > 1 and _dist is None:
         import torch
         import torch.distributed as dist
-        if torch.cuda.is_available():
+        if torch.cuda.is_available() and os.environ.get("MSNV_DIST_BACKEND", "nccl") == "nccl":
             torch.cuda.set_device(_local)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", _local))
         else:
+            # no GPU (CPU tests of the gather logic), or MSNV_DIST_BACKEND=gloo: rehearsal of the N-rank product path
+            # on a box with fewer GPUs than ranks -- the ranks share the visible GPUs, the tables travel over gloo
+            if torch.cuda.is_available():
+                _local = _local % torch.cuda.device_count()
             dist.init_process_group(backend="gloo")
         _dist = dist
     return _rank, _world, _local

@@ -430,6 +430,32 @@ def test_filtering_of_pipeline_output_matches_python_restatement(tmp_path):
                 assert not os.path.exists(path)
 
 
+def test_two_rank_sharded_call_with_annotation(tmp_path):
+    """The N-rank product path (contig mask per rank, kernels on the GPU, gather of site + annotation records, rank 0
+    writes the files) rehearsed with two ranks sharing this GPU (tables over gloo): output equals the oracle's
+    single-process text, and the shards partition the positions."""
+    import subprocess
+    import sys
+    sp = core.synth_params(n_species=5, contig_len=4000, n_samples=6, mean_cov=11.0, snv_density=0.03, frac_absent=0.2, seed=55)
+    syn = core.Synth(sp)
+    samples = [syn.sample_records(i) for i in range(sp.n_samples)]
+    fa, ann = str(tmp_path / "ref.fa"), str(tmp_path / "ann.tsv")
+    syn.write_fasta(fa)
+    _write_ann(ann, [("a1", syn.names[0], 5, 1800, "+"), ("a2", syn.names[0], 1500, 3600, "-"), ("c1", syn.names[2], 100, 3999, "-"),
+                     ("e1", syn.names[4], 1, 900, "+"), ("e2", syn.names[4], 2000, 2000, "+")])
+    env = dict(os.environ, MSNV_DIST_BACKEND="gloo")
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_shard_worker.py")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", worker, str(tmp_path)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    orac = run_oracle(syn.names, syn.lengths, syn.seqs, samples, ann=ann, fasta=fa)
+    assert open(tmp_path / "called_SNPs").read() == orac[0]
+    assert open(tmp_path / "indiv_called").read() == orac[1]
+    info = [list(map(int, open(tmp_path / ("rank%d.info" % k)).read().split())) for k in (0, 1)]
+    assert info[0][0] + info[1][0] == sum(syn.lengths) and info[0][0] > 0 and info[1][0] > 0
+    assert info[0][1] + info[1][1] == orac[3]
+
+
 def test_cli_project_layout_and_contents(tmp_path, capsys):
     from metasnv_amd import cli, tables
     syn, samples = synth_case(n_species=3, contig_len=4000, n_samples=4, mean_cov=12.0, snv_density=0.03, frac_absent=0.0, seed=31)
