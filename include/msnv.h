@@ -195,7 +195,7 @@ int  msnv_dataset_info_get(const msnv_dataset *ds, msnv_dataset_info *out);
 typedef struct {
     float    ms_total;           /* all kernels of one pass, HIP events on the launch stream */
     float    ms_pileup;          /* the dominant kernel (msnv_pileup_tiles)                  */
-    float    ms_gate, ms_gather, ms_decide, ms_coverage;
+    float    ms_gate, ms_gather, ms_decide, ms_coverage;   /* the tail split is recorded only with MSNV_PHASE_TIMES=1 (event records cost stream time) */
     uint64_t n_sites;            /* candidate positions that reached the decision kernel     */
     uint64_t n_called_pop, n_called_indiv;   /* output lines (before the first-line drop)    */
     uint64_t n_events, n_overflow;

@@ -844,7 +844,10 @@ int dev_run_pipeline(DeviceCols &d, const msnv_params &p, void *stream_, msnv_ru
                            p.min_coverage, p.calling_threshold, d.sites, d.cap_sites, d.counters, d.tile_site_base, d.tile_site_cnt);
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipEventRecord(ev[3], st));
+    // every event record costs ~6 us of stream time (the next kernel waits for the marker): the per-phase split of
+    // the tail is only recorded on request (MSNV_PHASE_TIMES=1, profiles/phase_times.py)
+    static const bool phase_times = [] { const char *e = getenv("MSNV_PHASE_TIMES"); return e && e[0] == '1'; }();
+    if (phase_times) HIP_TRY(hipEventRecord(ev[3], st));
     // the tail runs on device-side counts: no host round trip inside a pass
     if (int rc = ensure_out(d, std::max<uint64_t>(d.last_sites + d.last_sites / 2, 4096))) { cleanup(); return rc; }
     const uint32_t cap_out = (uint32_t)std::min<uint64_t>(d.cap_out_sites, 0xffffffffull);
@@ -856,7 +859,7 @@ int dev_run_pipeline(DeviceCols &d, const msnv_params &p, void *stream_, msnv_ru
                            d.cap_overflow, d.sites, d.tile_site_base, d.tile_site_cnt, d.out, d.n_samples, cap_out);
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipEventRecord(ev[4], st));
+    if (phase_times) HIP_TRY(hipEventRecord(ev[4], st));
     hipLaunchKernelGGL(msnv_decide_sites, dim3(512), dim3(256), 0, st, d.sites, d.counters, d.cap_sites, cap_out, d.ref4, d.ref_lc,
                        d.out, d.n_samples, p.calling_threshold, p.min_fraction, d.site_flags);
     HIP_TRY(hipGetLastError());
@@ -877,9 +880,11 @@ int dev_run_pipeline(DeviceCols &d, const msnv_params &p, void *stream_, msnv_ru
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[5])); stats->ms_total = ms;
         HIP_TRY(hipEventElapsedTime(&ms, ev[1], ev[2])); stats->ms_pileup = ms;
-        HIP_TRY(hipEventElapsedTime(&ms, ev[2], ev[3])); stats->ms_gate = ms;
-        HIP_TRY(hipEventElapsedTime(&ms, ev[3], ev[4])); stats->ms_gather = ms;
-        HIP_TRY(hipEventElapsedTime(&ms, ev[4], ev[5])); stats->ms_decide = ms;
+        if (phase_times) {
+            HIP_TRY(hipEventElapsedTime(&ms, ev[2], ev[3])); stats->ms_gate = ms;
+            HIP_TRY(hipEventElapsedTime(&ms, ev[3], ev[4])); stats->ms_gather = ms;
+            HIP_TRY(hipEventElapsedTime(&ms, ev[4], ev[5])); stats->ms_decide = ms;
+        }
         stats->n_sites = c.n_sites; stats->n_events = c.n_events; stats->n_overflow = c.n_overflow;
         stats->n_called_pop = cnt[4]; stats->n_called_indiv = cnt[5];
         stats->algorithmic_bytes = d.algorithmic_bytes;

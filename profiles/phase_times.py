@@ -1,4 +1,5 @@
 import sys, os
+os.environ["MSNV_PHASE_TIMES"] = "1"
 sys.path.insert(0, os.getcwd())
 from metasnv_amd import core
 sp = core.synth_params(n_species=3, contig_len=300000, n_samples=160, mean_cov=10.0, seed=1)
