@@ -101,6 +101,61 @@ def test_cigar_ops_tile_boundary_overflow_and_empty_sample():
     assert "\t521\t" in prod[1] and "\t521\t" not in prod[0]   # 4 of 500 reads (< 1 %): individual, not population
 
 
+def test_many_samples_more_than_one_wave_of_columns():
+    """300 samples (more than 256 columns: every 64-lane sample loop wraps several times), shallow coverage."""
+    syn, samples = synth_case(n_species=1, contig_len=2500, n_samples=300, mean_cov=3.0, snv_density=0.05, frac_absent=0.3, seed=300)
+    p = core.default_params(min_coverage=4, calling_threshold=3)
+    prod = run_product(syn.names, syn.lengths, syn.seqs, samples, params=p)
+    orac = run_oracle(syn.names, syn.lengths, syn.seqs, samples, params=p)
+    _assert_same(prod, orac)
+    assert prod[0].count("\n") > 20
+
+
+def test_long_reads_span_pieces_and_tiles():
+    """Reads of several thousand bases: each is cut into many 128-base pieces, crosses tile boundaries (2048) and carries
+    indels, soft clips and '=' / 'X' ops; a second sample holds short reads on the same contig."""
+    import random
+    rnd = random.Random(9)
+    L = 9000
+    ref = "".join(rnd.choice("ACGT") for _ in range(L))
+    def long_read(start, n_ref, name):
+        cigar, seq, pos = [], [], start
+        cigar.append("7S"); seq.append("".join(rnd.choice("ACGT") for _ in range(7)))
+        left = n_ref
+        while left > 0:
+            m = min(left, rnd.randrange(150, 900))
+            op = rnd.choice("MMM=X") if m < 400 else "M"
+            chunk = list(ref[pos:pos + m])
+            if op != "=":
+                for _ in range(max(1, m // 60)):
+                    k = rnd.randrange(m)
+                    chunk[k] = rnd.choice("ACGT")
+            cigar.append("%d%s" % (m, op)); seq.append("".join(chunk)); pos += m; left -= m
+            if left > 0:
+                if rnd.random() < 0.5:
+                    n = rnd.randrange(1, 6); cigar.append("%dI" % n); seq.append("".join(rnd.choice("ACGT") for _ in range(n)))
+                else:
+                    n = min(left, rnd.randrange(1, 9)); cigar.append("%dD" % n); pos += n; left -= n
+        return bt.make_record(0, start, "".join(cigar), "".join(seq), qual=[rnd.choice([5, 20, 30, 38]) for _ in range(sum(len(s) for s in seq))], name=name)
+    long_sample = sorted([long_read(rnd.randrange(0, 3000), rnd.randrange(2500, 5500), "L%d" % k) for k in range(12)],
+                         key=lambda r: int.from_bytes(r[8:12], "little", signed=True))
+    short = []
+    for k in range(400):
+        s = rnd.randrange(0, L - 100)
+        q = list(ref[s:s + 100])
+        if k % 3 != 1:
+            gpos = (s + 50) // 40 * 40                   # shared mutation positions -> many called sites
+            q[gpos - s] = "A" if ref[gpos] != "A" else "C"
+        short.append(bt.make_record(0, s, "100M", "".join(q), name="s%d" % k))
+    short.sort(key=lambda r: int.from_bytes(r[8:12], "little", signed=True))
+    samples = [bt.records(*long_sample), bt.records(*short)]
+    p = core.default_params(min_coverage=3, calling_threshold=2)
+    prod = run_product(["ctg"], [L], [ref], samples, params=p)
+    orac = run_oracle(["ctg"], [L], [ref], samples, params=p)
+    _assert_same(prod, orac)
+    assert prod[0].count("\n") > 30, prod[0].count("\n")
+
+
 def test_annotation_codon_path(tmp_path):
     syn, samples = synth_case(n_species=2, contig_len=3000, n_samples=4, mean_cov=14.0, snv_density=0.03, frac_absent=0.0, seed=21)
     fa = str(tmp_path / "ref.fa")
