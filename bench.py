@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--contig-len", type=int, default=300000)
     ap.add_argument("--species", type=int, default=3)
     ap.add_argument("--mean-cov", type=float, default=10.0)
+    ap.add_argument("--read-len", type=int, default=100, help="synthetic read length (BASELINE: 100)")
     ap.add_argument("--cpu-samples", type=int, default=64, help="samples of the workload the CPU oracle is timed on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-annotation", action="store_true", help="skip the --db_ann codon-annotation kernel (BASELINE configs[4]) after the timed region")
@@ -117,6 +118,8 @@ def main():
 
     # ---- build this rank's shard: same shape on every rank, different seed (weak scaling)
     sp_kwargs = dict(n_species=a.species, contig_len=a.contig_len, n_samples=a.samples, mean_cov=a.mean_cov, seed=1 + rank)
+    if a.read_len != 100:
+        sp_kwargs["read_len"] = a.read_len
     sp = core.synth_params(**sp_kwargs)
     syn = core.Synth(sp)
     ctx = core.Context(local)
@@ -185,8 +188,8 @@ def main():
             "ms_per_step": dt_max / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u16/u32 integer counts", "data": "synthetic",
-            "config": {"workload": "testdata shape: %d synthetic BAM-record streams x %d refGenomes x %d bp, ~%gx, single-end 100 bp (BASELINE configs[1])"
-                                   % (a.samples, a.species, a.contig_len, a.mean_cov),
+            "config": {"workload": "testdata shape: %d synthetic BAM-record streams x %d refGenomes x %d bp, ~%gx, single-end %d bp (BASELINE configs[1])"
+                                   % (a.samples, a.species, a.contig_len, a.mean_cov, a.read_len),
                        "samples": a.samples, "positions_per_gpu": info["n_positions"], "pileup_bases_per_gpu": bases,
                        "reads_per_gpu": info["n_reads"], "parallelism": "contig shards x%d, no data-path collective" % world,
                        "called_SNPs_lines_per_rank": called},

@@ -30,9 +30,19 @@ constexpr uint32_t SEG_MAX = 128;            // bases per segment piece = 8 lane
 constexpr uint32_t NARROW_MAX_DEPTH = 255;   // (tile, sample) pairs below this depth use byte-wide LDS bins
 
 struct ReadHdr { uint32_t gpos, seqoff, cig, meta; };
-struct PieceHdr { uint32_t w0, seqoff8; };                             // narrow kernel: start in tile | length << 11; seq byte offset / 8
+struct PieceHdr { uint32_t w0, seqoff8; };
+// Dense layout: the pieces of one (sample, tile) pair are packed back to back (each starts on an even base) into a
+// stream of 32-base blocks; a block holds the tail / middle of one piece (segment A, bits [0, nA)) and at most the
+// head of the next one (segment B, bits [sB, 32), sB = nA rounded up to even, always running to the block end).
+//   bits  0-10  P0A   tile-relative position of bit 0 of segment A
+//   bits 11-16  nA    bases of segment A (0..32)
+//   bits 17-28  PBv   (position of B's first base) - sB + 32, or BLK_NO_B
+//   bit  29/30/31     segment A starts a piece here / segment A ends its piece here / segment B ends its piece here
+constexpr uint32_t BLK_NO_B = 0xfffu, BLK_START_A = 1u << 29, BLK_END_A = 1u << 30, BLK_END_B = 1u << 31;
+constexpr uint32_t BLK_EMPTY = BLK_NO_B << 17;
+constexpr int DENSE_CHUNK_BLOCKS = 512;   // blocks per chunk descriptor (two rounds of 256 lanes)                             // narrow kernel: start in tile | length << 11; seq byte offset / 8
 
-struct TilePair { uint32_t sample, read_lo, read_hi, max_depth; };    // reads of `sample` that may overlap the tile;
+struct TilePair { uint32_t sample, read_lo, read_hi, max_depth, blk_lo, nblk, seq0, pad; };    // reads of `sample` that may overlap the tile;
                                                                         // max_depth = upper bound of the per-position depth
 struct WorkItem { uint32_t tile, pair_lo, pair_hi, chunk_lo, chunk_hi, slot, pad[2]; };   // slot: row of the coverage partials (tile-major)
 // One chunk = up to CHUNK_READS consecutive reads of one (tile, sample) pair, with everything the
@@ -50,6 +60,9 @@ struct SampleCols {
     std::vector<int32_t>  end;       // per read: contig-relative end of everything the kernels may touch
     std::vector<uint16_t> depth;     // per read: pileup reads alive when this one starts (saturating)
     std::vector<uint8_t>  seq, qual;
+    // dense layout (pack.cpp: relayout_dense): per (contig, tile) run of pieces a stream of 32-base blocks
+    std::vector<uint32_t> blk;            // one descriptor per block (BLK_* fields)
+    std::vector<uint32_t> run_blk_lo, run_nblk, run_seq0;   // per run, in run order: first block, block count, seq byte offset
     std::vector<int32_t>  cov_tid, cov_beg, cov_end;   // qaCompute M intervals (index space), reads that pass its filter
     uint64_t n_pileup_bases = 0, n_pileup_reads = 0;
     uint64_t alg_seq_bytes = 0, alg_qual_bytes = 0;   // shipped bytes without alignment padding

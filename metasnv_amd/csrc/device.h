@@ -42,7 +42,9 @@ int  dev_annotate(DeviceCols &d, uint32_t n_sites, uint32_t drop_gpos, void *str
 struct DeviceCols {
     // ---- inputs (uploaded once by finalize)
     ReadHdr  *hdr = nullptr;         // 16-byte piece headers (wide kernel)
-    PieceHdr *hdr8 = nullptr;        // 8-byte tile-local piece headers (narrow kernel)
+    PieceHdr *hdr8 = nullptr;        // 8-byte tile-local piece headers (narrow32 kernel, MSNV_LAYOUT=pieces)
+    uint32_t *blk = nullptr;         // dense layout: one descriptor per 32-base block (dense kernel)
+    bool      dense = true;
     uint8_t  *seq = nullptr;
     uint8_t  *qual = nullptr;
     uint64_t *s_read_base = nullptr, *s_seq_base = nullptr;   // per sample

@@ -32,6 +32,7 @@ static_assert(LANES_PER_READ * 16 == SEG_MAX, "segment pieces are sized for 8 la
 
 struct PileupArgs {
     const ReadHdr  *hdr;          // one 16-byte header per M/=/X segment piece: {gpos, seqoff, length, meta}
+    const uint32_t *blk;          // dense layout: one descriptor per 32-base block
     const PieceHdr *hdr8;         // the same pieces, tile-local 8-byte form: {start | length << 11, seqoff / 8}
     const uint8_t  *seq;
     const uint8_t  *qual;
@@ -322,17 +323,18 @@ struct NarrowLds {
 // Per-sample pass of the narrow kernel: prefix sum of start/end -> depth, minus the not-counted bases;
 // adds the sample to the running totals, spills the per-sample coverage bytes, emits allele events,
 // and leaves every bin zero for the next sample.  Called by all threads; contains barriers (B), (C).
-__device__ __forceinline__ void narrow_pass(NarrowLds &L, const PileupArgs &a, uint32_t (&tc)[N_PPT], const uint32_t t0,
+template <typename LDS, int EXC_PAD>
+__device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_t (&tc)[N_PPT], const uint32_t t0,
                                             const int tid, const int lane, const int wave, const uint32_t sample, const uint32_t k) {
     __syncthreads();                                        // (B)
     const uint2 st = *reinterpret_cast<uint2 *>(&L.start[2 * tid]);
     const uint2 en = *reinterpret_cast<uint2 *>(&L.end[2 * tid]);
-    const uint2 ex = *reinterpret_cast<uint2 *>(&L.exc[tid]);
+    const uint2 ex = *reinterpret_cast<uint2 *>(&L.exc[EXC_PAD + tid]);
     const uint4 a0 = *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid]);
     const uint4 a1 = *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid + 4]);
     *reinterpret_cast<uint2 *>(&L.start[2 * tid]) = make_uint2(0u, 0u);
     *reinterpret_cast<uint2 *>(&L.end[2 * tid]) = make_uint2(0u, 0u);
-    L.exc[tid] = 0ull;
+    L.exc[EXC_PAD + tid] = 0ull;
     if (tid == 0) L.end[TILE / 4] = 0;
     const uint32_t anyal = a0.x | a0.y | a0.z | a0.w | a1.x | a1.y | a1.z | a1.w;
     if (anyal) {
@@ -373,7 +375,7 @@ __device__ __forceinline__ void narrow_pass(NarrowLds &L, const PileupArgs &a, u
                 const uint32_t n = (word >> (8u * x)) & 0xffu;
                 if (n) {
                     atomicAdd(&a.tot[(uint64_t)x * a.npos + gpos], n);
-                    stage_allele_event<NarrowLds, N_EVCAP>(L, a, Pair32{gpos, sample << 18 | x << 16 | n});
+                    stage_allele_event<LDS, N_EVCAP>(L, a, Pair32{gpos, sample << 18 | x << 16 | n});
                 }
             }
         }
@@ -496,11 +498,166 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32(PileupArgs a)
         for (int i = 0; i < N32_ROUNDS; ++i)
             if (__any(vh[i] > 0)) narrow_classify32(L, qa[i], qb[i], sq[i], P0[i], vh[i], kq);
 
-        if (last_chunk) narrow_pass(L, a, tc, t0, tid, lane, wave, cd.sample, cd.pair);
+        if (last_chunk) narrow_pass<NarrowLds, 0>(L, a, tc, t0, tid, lane, wave, cd.sample, cd.pair);
         buf ^= 1;
     }
     __syncthreads();
     flush_events<NarrowLds, N_NT, N_EVCAP>(L, a, tid);
+    uint4 *pp = reinterpret_cast<uint4 *>(a.part + (uint64_t)w.slot * TILE + N_PPT * tid);   // this item's coverage partial
+    pp[0] = make_uint4(tc[0], tc[1], tc[2], tc[3]);
+    pp[1] = make_uint4(tc[4], tc[5], tc[6], tc[7]);
+}
+
+// ------------------------------------------------------------------------------------------
+// msnv_pileup_tiles_dense: the narrow algorithm over the DENSE layout (dataset.h: BLK_*, pack.cpp: relayout_dense).
+// The pieces of a (sample, tile) pair form a stream of 32-base blocks without alignment padding; ONE lane owns ONE
+// block: 2 x 16 B of qualities + 16 B of bases, all 16-byte aligned and contiguous across the wavefront, and a 4-byte
+// descriptor (no LDS staging of headers).  A block holds bits [0, nA) of one piece and at most bits [sB, 32) of the
+// next, so the classification runs on up to two (position of bit 0, bit range) segments; the position of bit 0 of the
+// second segment may be up to 32 before the tile start, which is why the reference words and the exception bins carry
+// 32 positions of front padding.  Versus the per-piece layout: no padding bytes (-6 % HBM traffic) and no idle lanes
+// behind short pieces.  Measured (same box, pileup kernel, ms): reads of 50 bases: pieces 0.802 / dense 0.658;
+// 100: 0.670 / 0.677; 150: 0.618 / 0.672; 250: 0.567 / 0.645 -- the second segment costs what the padding saves at
+// 100 bases and more, so finalize picks this layout only for short pieces (pack.cpp: layout choice).
+// ------------------------------------------------------------------------------------------
+constexpr int D_PAD = 4;                       // 4 exception words / reference words = 32 positions of front padding
+struct DenseLds {
+    uint32_t start[TILE / 4 + 4];
+    uint32_t end[TILE / 4 + 4];
+    unsigned long long exc[TILE / 8 + D_PAD + 8];
+    unsigned long long spread[256];
+    uint32_t al[TILE];
+    uint32_t ref[TILE / 8 + D_PAD + 8];
+    Pair32   ev[N_EVCAP];
+    ChunkDesc desc[MAX_CHUNKS_PER_ITEM];
+    int32_t  wsum[N_NT / 64];
+    uint32_t evn, ev_base;
+};
+
+// nibble flags (bit 4j+3) of the bases j in [lo, hi) of the 8-base word k
+__device__ __forceinline__ uint32_t range_nibbles(const int lo, const int hi, const int k) {
+    const int h = min(max(hi - 8 * k, 0), 8), l = min(max(lo - 8 * k, 0), 8);
+    const uint32_t below_h = (h == 8) ? 0xffffffffu : ((1u << (4 * h)) - 1u);
+    const uint32_t below_l = (l == 8) ? 0xffffffffu : ((1u << (4 * l)) - 1u);
+    return below_h & ~below_l & 0x88888888u;
+}
+
+// One segment of a block: bits [lo, hi) lie at padded positions P + j (padded = tile position + 32).
+__device__ __forceinline__ void dense_segment(DenseLds &L, const uint4 sq, const uint32_t lq, const uint32_t P, const int lo, const int hi) {
+    const uint32_t wi = P >> 3, sh = (P & 7u) * 4u;
+    const uint32_t below_hi = (hi >= 32) ? 0xffffffffu : ((1u << hi) - 1u);
+    const uint32_t below_lo = (lo >= 32) ? 0xffffffffu : ((1u << lo) - 1u);
+    const uint32_t lqm = lq & below_hi & ~below_lo;
+    const unsigned long long m = (unsigned long long)lqm << (P & 7u);
+#pragma unroll
+    for (int w = 0; w < 5; ++w) {
+        const uint32_t byte = (uint32_t)(m >> (8 * w)) & 0xffu;
+        if (byte) atomicAdd(&L.exc[wi + w], L.spread[byte]);
+    }
+    const uint32_t w0 = L.ref[wi], w1 = L.ref[wi + 1], w2 = L.ref[wi + 2], w3 = L.ref[wi + 3], w4 = L.ref[wi + 4];
+    const uint32_t sw[4] = {sq.x, sq.y, sq.z, sq.w};
+    const uint32_t rw[4] = {__builtin_amdgcn_alignbit(w1, w0, sh), __builtin_amdgcn_alignbit(w2, w1, sh),
+                            __builtin_amdgcn_alignbit(w3, w2, sh), __builtin_amdgcn_alignbit(w4, w3, sh)};
+    uint32_t e[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e[k] = nz_nibbles(sw[k] ^ rw[k]) & range_nibbles(lo, hi, k);
+    while (e[0] | e[1] | e[2] | e[3]) {                              // mismatches (rare)
+        const int k = e[0] ? 0 : e[1] ? 1 : e[2] ? 2 : 3;
+        const uint32_t ew = e[0] ? e[0] : e[1] ? e[1] : e[2] ? e[2] : e[3];
+        const uint32_t b = (uint32_t)__builtin_ctz(ew);
+        if (k == 0) e[0] &= e[0] - 1u; else if (k == 1) e[1] &= e[1] - 1u; else if (k == 2) e[2] &= e[2] - 1u; else e[3] &= e[3] - 1u;
+        const uint32_t j = (b >> 2) + 8u * (uint32_t)k;
+        if ((lq >> j) & 1u) continue;                                  // below the BQ cutoff: already in exc
+        const uint32_t word = (k == 0) ? sw[0] : (k == 1) ? sw[1] : (k == 2) ? sw[2] : sw[3];
+        const uint32_t code = (word >> (b - 3u)) & 0xfu;
+        const uint32_t pp = P + j;                                     // padded position of the base
+        if ((code & (code - 1u)) == 0u) atomicAdd(&L.al[pp - 32u], 1u << (8u * (uint32_t)__builtin_ctz(code)));
+        else atomicAdd(&L.exc[pp >> 3], 1ull << (8u * (pp & 7u)));
+    }
+}
+
+__global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_dense(PileupArgs a) {
+    __shared__ DenseLds L;
+    const WorkItem w = a.work[blockIdx.x];
+    const uint32_t t0 = w.tile * TILE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t kq = 0x80808080u - min(a.min_baseq, 128u) * 0x01010101u;
+
+    for (int i = tid; i < (int)(TILE / 8 + D_PAD + 8); i += N_NT) {
+        const int r = i - D_PAD;
+        L.ref[i] = (r >= 0 && r < (int)(TILE / 8)) ? a.ref4[(t0 >> 3) + r] : 0xffffffffu;
+        L.exc[i] = 0;
+    }
+    for (int i = tid; i < (int)(TILE / 4 + 4); i += N_NT) { L.start[i] = 0; L.end[i] = 0; }
+    L.spread[tid] = ((unsigned long long)((((uint32_t)tid >> 4) * 0x00204081u) & 0x01010101u) << 32) | (((uint32_t)tid & 0xfu) * 0x00204081u & 0x01010101u);
+    for (int i = tid; i < (int)TILE; i += N_NT) L.al[i] = 0;
+    if (tid == 0) L.evn = 0;
+    uint32_t tc[N_PPT];
+#pragma unroll
+    for (int j = 0; j < N_PPT; ++j) tc[j] = 0;
+
+    const uint32_t nch = w.chunk_hi - w.chunk_lo;
+    for (uint32_t i = tid; i < nch * 2; i += N_NT)
+        reinterpret_cast<uint4 *>(L.desc)[i] = reinterpret_cast<const uint4 *>(a.chunks + w.chunk_lo)[i];
+    __syncthreads();
+    constexpr int ROUNDS = DENSE_CHUNK_BLOCKS / N_NT;           // 2
+    uint32_t dnext[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        dnext[r] = BLK_EMPTY;
+        if (nch && (uint32_t)(r * N_NT + tid) < (L.desc[0].nrd_flags & 0xffffu)) dnext[r] = a.blk[L.desc[0].hdr_base + (uint32_t)(r * N_NT + tid)];
+    }
+
+    for (uint32_t c = 0; c < nch; ++c) {
+        const ChunkDesc cd = L.desc[c];
+        const bool last_chunk = (cd.nrd_flags >> 16) != 0u;
+        const uint32_t nblk = cd.nrd_flags & 0xffffu;
+        uint32_t dcur[ROUNDS];
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            dcur[r] = dnext[r];
+            dnext[r] = BLK_EMPTY;
+            if (c + 1 < nch && (uint32_t)(r * N_NT + tid) < (L.desc[c + 1].nrd_flags & 0xffffu))
+                dnext[r] = a.blk[L.desc[c + 1].hdr_base + (uint32_t)(r * N_NT + tid)];
+        }
+        __syncthreads();                                            // (A) bins of the previous sample are zeroed
+        if (L.evn >= (uint32_t)(N_EVCAP / 2)) flush_events<DenseLds, N_NT, N_EVCAP>(L, a, tid);
+
+        const uint8_t *seq = a.seq + cd.seq_base;
+        const uint8_t *qual = a.qual + 2 * cd.seq_base;
+        uint4 qa[ROUNDS], qb[ROUNDS], sq[ROUNDS];
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const uint32_t b = (uint32_t)(r * N_NT + tid);
+            qa[r] = any_uint4(); qb[r] = any_uint4(); sq[r] = any_uint4();   // never observed: an empty descriptor masks every use
+            if (b < nblk) {
+                const uint4 *qp = reinterpret_cast<const uint4 *>(qual + 32ull * b);
+                qa[r] = qp[0]; qb[r] = qp[1];
+                sq[r] = *reinterpret_cast<const uint4 *>(seq + 16ull * b);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            if (!__any((uint32_t)(r * N_NT + tid) < nblk)) continue;
+            const uint32_t d = dcur[r];
+            const uint32_t P0A = d & 2047u, nA = (d >> 11) & 63u, PBv = (d >> 17) & 0xfffu;
+            const bool hasB = PBv != BLK_NO_B;
+            const uint32_t sB = (nA + 1u) & ~1u;
+            if (d & BLK_START_A) atomicAdd(&L.start[P0A >> 2], 1u << (8u * (P0A & 3u)));
+            if (d & BLK_END_A) { const uint32_t e = P0A + nA; atomicAdd(&L.end[e >> 2], 1u << (8u * (e & 3u))); }
+            if (hasB) {
+                const uint32_t s = PBv + sB - 32u;
+                atomicAdd(&L.start[s >> 2], 1u << (8u * (s & 3u)));
+                if (d & BLK_END_B) { const uint32_t e = PBv; atomicAdd(&L.end[e >> 2], 1u << (8u * (e & 3u))); }   // s + (32 - sB) = PBv
+            }
+            const uint32_t lq = lowq_mask(qa[r], kq) | lowq_mask(qb[r], kq) << 16;
+            dense_segment(L, sq[r], lq, P0A + 32u, 0, (int)nA);
+            if (__any(hasB)) dense_segment(L, sq[r], lq, hasB ? PBv : 32u, hasB ? (int)sB : 32, 32);
+        }
+        if (last_chunk) narrow_pass<DenseLds, D_PAD>(L, a, tc, t0, tid, lane, wave, cd.sample, cd.pair);
+    }
+    __syncthreads();
+    flush_events<DenseLds, N_NT, N_EVCAP>(L, a, tid);
     uint4 *pp = reinterpret_cast<uint4 *>(a.part + (uint64_t)w.slot * TILE + N_PPT * tid);   // this item's coverage partial
     pp[0] = make_uint4(tc[0], tc[1], tc[2], tc[3]);
     pp[1] = make_uint4(tc[4], tc[5], tc[6], tc[7]);
@@ -784,7 +941,7 @@ int dev_stream_create(void **stream) { hipStream_t s; HIP_TRY(hipStreamCreateWit
 void dev_stream_destroy(void *stream) { if (stream) (void)hipStreamDestroy((hipStream_t)stream); }
 
 void dev_free_all(DeviceCols &d) {
-    void *ptrs[] = {d.hdr, d.hdr8, d.seq, d.qual, d.s_read_base, d.s_seq_base, d.ref4, d.ref_lc, d.pairs,
+    void *ptrs[] = {d.hdr, d.hdr8, d.blk, d.seq, d.qual, d.s_read_base, d.s_seq_base, d.ref4, d.ref_lc, d.pairs,
                     d.tile_pair_start, d.work, d.chunks, d.tile_vbeg, d.tile_vend, d.tot, d.part, d.tile_slot_start, d.spill, d.events, d.overflow, d.counters,
                     d.sites, d.tile_site_base, d.tile_site_cnt, d.out, d.site_flags,
                     d.cov_iv, d.s_cov_base, d.cov_pairs, d.cov_work, d.tile_len, d.tile_contig_dev, d.cov_acc};
@@ -822,7 +979,7 @@ int dev_run_pipeline(DeviceCols &d, const msnv_params &p, void *stream_, msnv_ru
     HIP_TRY(hipEventRecord(ev[1], st));
     if (d.n_work) {
         PileupArgs a;
-        a.hdr = d.hdr; a.hdr8 = d.hdr8; a.seq = d.seq; a.qual = d.qual;
+        a.hdr = d.hdr; a.hdr8 = d.hdr8; a.blk = d.blk; a.seq = d.seq; a.qual = d.qual;
         a.s_read_base = d.s_read_base; a.s_seq_base = d.s_seq_base;
         a.ref4 = d.ref4; a.pairs = d.pairs; a.work = d.work; a.chunks = d.chunks; a.tot = d.tot; a.part = d.part; a.npos = npos; a.spill = d.spill;
         a.events = d.events; a.cap_events = d.cap_events; a.overflow = d.overflow; a.cap_overflow = d.cap_overflow;
@@ -830,7 +987,8 @@ int dev_run_pipeline(DeviceCols &d, const msnv_params &p, void *stream_, msnv_ru
         static const bool all_wide = [] { const char *e = getenv("MSNV_PILEUP"); return e && e[0] == 'w'; }();   // A/B: MSNV_PILEUP=wide
         const uint32_t n_narrow = all_wide ? 0u : d.n_work_narrow;
         // narrow work items (byte bins) and wide ones (16-bit bins) touch disjoint (tile, sample) pairs
-        if (n_narrow) hipLaunchKernelGGL(msnv_pileup_tiles_narrow32, dim3(n_narrow), dim3(N_NT), 0, st, a);
+        if (n_narrow && d.dense) hipLaunchKernelGGL(msnv_pileup_tiles_dense, dim3(n_narrow), dim3(N_NT), 0, st, a);
+        else if (n_narrow) hipLaunchKernelGGL(msnv_pileup_tiles_narrow32, dim3(n_narrow), dim3(N_NT), 0, st, a);
         if (d.n_work > n_narrow) {
             PileupArgs b = a;
             b.work = d.work + n_narrow;

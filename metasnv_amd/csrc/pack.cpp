@@ -21,6 +21,80 @@ namespace msnv {
 // vector-memory path about as much as it saves below 8.  The compact headers store seq offsets in 8-byte units.
 constexpr uint32_t seq_align = 8;
 
+// Layout of the narrow path: padded per-piece columns (msnv_pileup_tiles_narrow32) or the dense block stream
+// (msnv_pileup_tiles_dense: no alignment padding, every lane owns 32 real bases, but up to two segments per block).
+// Dense wins for short pieces (50-base reads: -18 % kernel time), loses from ~100 bases on (kernels.hip), so the
+// dataset picks it when the mean piece is shorter than 72 bases.  MSNV_LAYOUT=pieces|dense overrides.
+static bool layout_dense(uint64_t n_pieces, uint64_t n_bases) {
+    const char *e = getenv("MSNV_LAYOUT");
+    if (e && e[0] == 'p') return false;
+    if (e && e[0] == 'd') return true;
+    return n_pieces && n_bases / n_pieces < 72;
+}
+
+// Rewrites seq / qual of one sample into the dense block streams (dataset.h) and fills blk / run_*.
+// hdr must already be grouped by (contig, tile); hdr[i].gpos is still contig-relative (contigs start on tile boundaries).
+static void relayout_dense(SampleCols &sc) {
+    const size_t n = sc.hdr.size();
+    std::vector<uint8_t> nseq, nqual;
+    nseq.reserve(sc.seq.size()); nqual.reserve(sc.qual.size());
+    sc.blk.clear(); sc.run_blk_lo.clear(); sc.run_nblk.clear(); sc.run_seq0.clear();
+    size_t i = 0;
+    while (i < n) {
+        size_t j = i;
+        while (j < n && sc.tid[j] == sc.tid[i] && sc.hdr[j].gpos / TILE == sc.hdr[i].gpos / TILE) ++j;
+        const uint32_t blk0 = (uint32_t)sc.blk.size();
+        const size_t seq0 = nseq.size();                       // multiple of 16 bytes
+        uint64_t cursor = 0;                                   // bases from the start of this run's stream
+        auto block = [&](uint64_t b) -> uint32_t & {
+            while (sc.blk.size() <= blk0 + b) sc.blk.push_back(BLK_EMPTY);
+            return sc.blk[blk0 + b];
+        };
+        for (size_t k = i; k < j; ++k) {
+            ReadHdr &h = sc.hdr[k];
+            const uint32_t len = h.cig, P = h.gpos % TILE;
+            cursor = (cursor + 1) & ~1ull;
+            uint64_t b = cursor / 32; uint32_t o = (uint32_t)(cursor % 32);
+            if (o != 0) {
+                const uint32_t cur = block(b);
+                const bool has_b = ((cur >> 17) & 0xfffu) != BLK_NO_B;
+                if (has_b || len < 32 - o) { cursor = (b + 1) * 32; ++b; o = 0; }      // a second head, or one that ends inside the block: fresh block
+            }
+            // copy the piece: seq nibbles are byte aligned at both ends (even cursor), qualities 1:1
+            const size_t so = seq0 + cursor / 2, qo = 2 * seq0 + cursor;
+            if (nseq.size() < so + (len + 1) / 2) nseq.resize(so + (len + 1) / 2, 0xff);
+            if (nqual.size() < qo + len) nqual.resize(qo + len, 0);
+            memcpy(nseq.data() + so, sc.seq.data() + h.seqoff, (len + 1) / 2);
+            if (len & 1u) nseq[so + len / 2] |= 0xf0;           // the pad nibble of an odd piece reads as N
+            memcpy(nqual.data() + qo, sc.qual.data() + 2 * (size_t)h.seqoff, len);
+            h.seqoff = (uint32_t)so;                           // (sample-relative; the wide kernel reads pieces through it)
+            // descriptors
+            uint32_t done = 0;
+            if (o != 0) {                                      // head of the piece = segment B of block b
+                uint32_t &w = block(b);
+                w = (w & ~(0xfffu << 17)) | ((P - o + 32u) << 17);
+                done = 32 - o;
+                if (done == len) w |= BLK_END_B;
+                ++b;
+            }
+            bool first = (o == 0);
+            while (done < len) {
+                const uint32_t na = std::min<uint32_t>(32, len - done);
+                uint32_t &w = block(b);
+                w = (w & (0xfffu << 17)) | (P + done) | na << 11 | (first ? BLK_START_A : 0u) | (done + na == len ? BLK_END_A : 0u);
+                first = false; done += na; ++b;
+            }
+            cursor += len;
+        }
+        const uint32_t nb = (uint32_t)sc.blk.size() - blk0;
+        nseq.resize(seq0 + (size_t)nb * 16, 0xff);
+        nqual.resize(2 * seq0 + (size_t)nb * 32, 0);
+        sc.run_blk_lo.push_back(blk0); sc.run_nblk.push_back(nb); sc.run_seq0.push_back((uint32_t)seq0);
+        i = j;
+    }
+    sc.seq.swap(nseq); sc.qual.swap(nqual);
+}
+
 std::vector<std::string> synth_contigs(const msnv_synth_params &p);
 void synth_sample_records(const msnv_synth_params &p, int sample, const std::vector<std::string> &contigs, std::vector<uint8_t> &out);
 
@@ -269,12 +343,24 @@ int finalize_dataset(msnv_dataset &ds) {
     }
 
     // ---- per sample: gpos, tile overlap index; concatenate columns
-    std::vector<uint64_t> rbase(S + 1, 0), sbase(S + 1, 0);
+    uint64_t all_pieces = 0, all_bases = 0;
+    for (const SampleCols &sc : ds.samples) { all_pieces += sc.hdr.size(); all_bases += sc.n_pileup_bases; }
+    const bool dense = layout_dense(all_pieces, all_bases);
+    d->dense = dense;
+    if (dense) {
+        for (SampleCols &sc : ds.samples) {
+            relayout_dense(sc);
+            for (int i = 0; i < 32; ++i) sc.seq.push_back(0xff);     // tail padding as in pack_sample
+            while (sc.qual.size() < 2 * sc.seq.size()) sc.qual.push_back(0);
+        }
+    }
+    std::vector<uint64_t> rbase(S + 1, 0), sbase(S + 1, 0), bbase(S + 1, 0);
     for (size_t s = 0; s < S; ++s) {
+        bbase[s + 1] = bbase[s] + ds.samples[s].blk.size();
         rbase[s + 1] = rbase[s] + ds.samples[s].hdr.size();
         sbase[s + 1] = sbase[s] + ((ds.samples[s].seq.size() + 15) & ~(size_t)15);
     }
-    struct PairTmp { uint32_t tile, sample, lo, hi, maxd; };
+    struct PairTmp { uint32_t tile, sample, lo, hi, maxd, run; };
     std::vector<std::vector<PairTmp>> per_sample(S);
     ds.first_tid = -1; ds.first_pos = -1;
     uint64_t tot_reads = 0, tot_pile_reads = 0, tot_bases = 0;
@@ -288,7 +374,7 @@ int finalize_dataset(msnv_dataset &ds) {
             sc.hdr[i].gpos = (uint32_t)gs;
             const uint32_t t = (uint32_t)(gs / TILE);
             if (!pv.empty() && pv.back().tile == t) pv.back().hi = (uint32_t)i + 1;
-            else pv.push_back(PairTmp{t, (uint32_t)s, (uint32_t)i, (uint32_t)i + 1, 0});
+            else pv.push_back(PairTmp{t, (uint32_t)s, (uint32_t)i, (uint32_t)i + 1, 0, (uint32_t)pv.size()});
         }
         for (PairTmp &p : pv) {       // depth bound: every read alive inside the tile was alive when one of [lo,hi) started
             uint32_t m = 0;
@@ -308,7 +394,15 @@ int finalize_dataset(msnv_dataset &ds) {
     {
         std::vector<uint32_t> fill(tps.begin(), tps.end() - 1);
         for (size_t s = 0; s < S; ++s)
-            for (const PairTmp &p : per_sample[s]) pairs[fill[p.tile]++] = TilePair{p.sample, p.lo, p.hi, p.maxd};
+            for (const PairTmp &p : per_sample[s]) {
+                const SampleCols &sc = ds.samples[s];
+                TilePair tp{p.sample, p.lo, p.hi, p.maxd, 0, 0, 0, 0};
+                if (dense) {
+                    if (p.run >= sc.run_nblk.size()) return fail(MSNV_EINVAL, "internal: dense runs and tile pairs disagree");
+                    tp.blk_lo = sc.run_blk_lo[p.run]; tp.nblk = sc.run_nblk[p.run]; tp.seq0 = sc.run_seq0[p.run];
+                }
+                pairs[fill[p.tile]++] = tp;
+            }
         // inside a tile: narrow pairs (every per-position count fits a byte) first, then wide ones
         for (uint64_t t = 0; t < nt; ++t)
             std::stable_partition(pairs.begin() + tps[t], pairs.begin() + tps[t + 1], [](const TilePair &p) { return p.max_depth < NARROW_MAX_DEPTH; });
@@ -322,15 +416,20 @@ int finalize_dataset(msnv_dataset &ds) {
         uint64_t target = std::max<uint64_t>(1500, total_reads_in_pairs / 6144);
         if (const char *e = getenv("MSNV_ITEM_PIECES")) target = std::max<uint64_t>(64, (uint64_t)atoll(e));
         std::vector<WorkItem> wide;
+        auto chunks_of = [&](const TilePair &q) -> uint64_t {
+            const bool nar = q.max_depth < NARROW_MAX_DEPTH;
+            if (dense && nar) return (q.nblk + DENSE_CHUNK_BLOCKS - 1) / DENSE_CHUNK_BLOCKS;
+            return (q.read_hi - q.read_lo + CHUNK_READS - 1) / CHUNK_READS;
+        };
         for (uint64_t t = 0; t < nt; ++t) {
             uint32_t lo = tps[t];
             uint64_t acc = 0, nch = 0;
             for (uint32_t k = tps[t]; k < tps[t + 1]; ++k) {
                 const uint32_t nr = pairs[k].read_hi - pairs[k].read_lo;
-                acc += nr; nch += (nr + CHUNK_READS - 1) / CHUNK_READS;
+                acc += nr; nch += chunks_of(pairs[k]);
                 const bool narrow = pairs[k].max_depth < NARROW_MAX_DEPTH;
                 const bool boundary = k + 1 == tps[t + 1] || (narrow != (pairs[k + 1].max_depth < NARROW_MAX_DEPTH));
-                const uint64_t next_ch = boundary ? 0 : (pairs[k + 1].read_hi - pairs[k + 1].read_lo + CHUNK_READS - 1) / CHUNK_READS;
+                const uint64_t next_ch = boundary ? 0 : chunks_of(pairs[k + 1]);
                 if (acc >= target || boundary || nch + next_ch > MAX_CHUNKS_PER_ITEM) {
                     (narrow ? work : wide).push_back(WorkItem{(uint32_t)t, lo, k + 1, 0, 0, 0, {0, 0}}); lo = k + 1; acc = 0; nch = 0;
                 }
@@ -356,6 +455,14 @@ int finalize_dataset(msnv_dataset &ds) {
         w.chunk_lo = (uint32_t)chunks.size();
         for (uint32_t k = w.pair_lo; k < w.pair_hi; ++k) {
             const TilePair &p = pairs[k];
+            if (dense) {        // chunk = up to DENSE_CHUNK_BLOCKS blocks of the pair's stream: {first block, seq byte offset of that block}
+                for (uint32_t b = 0; b < p.nblk; b += DENSE_CHUNK_BLOCKS) {
+                    const uint32_t n = std::min<uint32_t>(DENSE_CHUNK_BLOCKS, p.nblk - b);
+                    chunks.push_back(ChunkDesc{bbase[p.sample] + p.blk_lo + b, sbase[p.sample] + p.seq0 + 16ull * b, p.sample, k,
+                                               n | (b + n >= p.nblk ? 1u << 16 : 0u), 0});
+                }
+                continue;
+            }
             for (uint32_t r = p.read_lo; r < p.read_hi; r += CHUNK_READS) {
                 const uint32_t n = std::min<uint32_t>(CHUNK_READS, p.read_hi - r);
                 chunks.push_back(ChunkDesc{rbase[p.sample] + r, sbase[p.sample], p.sample, k, n | (r + n >= p.read_hi ? 1u << 16 : 0u), 0});
@@ -374,21 +481,26 @@ int finalize_dataset(msnv_dataset &ds) {
     // ---- columns
     d->n_reads = rbase[S]; d->n_seq_bytes = sbase[S];
     if (int rc = dev_alloc((void **)&d->hdr, (rbase[S] + 1) * sizeof(ReadHdr), &d->device_bytes)) return rc;
-    if (int rc = dev_alloc((void **)&d->hdr8, (rbase[S] + 1) * sizeof(PieceHdr), &d->device_bytes)) return rc;
-    if (int rc = dev_alloc((void **)&d->seq, sbase[S] + 64, &d->device_bytes)) return rc;
-    if (int rc = dev_alloc((void **)&d->qual, 2 * sbase[S] + 64, &d->device_bytes)) return rc;
+    if (!dense) if (int rc = dev_alloc((void **)&d->hdr8, (rbase[S] + 1) * sizeof(PieceHdr), &d->device_bytes)) return rc;
+    if (dense) if (int rc = dev_alloc((void **)&d->blk, (bbase[S] + 1) * sizeof(uint32_t), &d->device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&d->seq, sbase[S] + 256, &d->device_bytes)) return rc;     // lanes past the end of the last piece read on
+    if (int rc = dev_alloc((void **)&d->qual, 2 * sbase[S] + 512, &d->device_bytes)) return rc;
     uint64_t alg = 0;
     for (size_t s = 0; s < S; ++s) {
         SampleCols &sc = ds.samples[s];
         if (int rc = dev_upload(d->hdr + rbase[s], sc.hdr.data(), sc.hdr.size() * sizeof(ReadHdr))) return rc;
-        {   // compact tile-local headers of the narrow kernel: {start in tile | length << 11, seq offset / 8}
+        if (dense) {
+            if (int rc = dev_upload(d->blk + bbase[s], sc.blk.data(), sc.blk.size() * sizeof(uint32_t))) return rc;
+            ds.info.bytes_headers += sc.blk.size() * sizeof(uint32_t);
+            std::vector<uint32_t>().swap(sc.blk);
+        } else {   // compact tile-local headers of the narrow kernel: {start in tile | length << 11, seq offset / 8}
             std::vector<PieceHdr> h8(sc.hdr.size());
             for (size_t i = 0; i < sc.hdr.size(); ++i) h8[i] = PieceHdr{(sc.hdr[i].gpos % TILE) | sc.hdr[i].cig << 11, sc.hdr[i].seqoff >> 3};
             if (int rc = dev_upload(d->hdr8 + rbase[s], h8.data(), h8.size() * sizeof(PieceHdr))) return rc;
         }
         if (int rc = dev_upload(d->seq + sbase[s], sc.seq.data(), sc.seq.size())) return rc;
         if (int rc = dev_upload(d->qual + 2 * sbase[s], sc.qual.data(), sc.qual.size())) return rc;
-        ds.info.bytes_headers += sc.hdr.size() * sizeof(PieceHdr);
+        if (!dense) ds.info.bytes_headers += sc.hdr.size() * sizeof(PieceHdr);
         ds.info.bytes_cigar += sc.alg_cigar_bytes;
         alg += sc.alg_8d_bytes;
         ds.info.bytes_seq += sc.alg_seq_bytes;
@@ -433,7 +545,7 @@ int finalize_dataset(msnv_dataset &ds) {
         std::vector<TilePair> cpairs(cps[nt]);
         {
             std::vector<uint32_t> fill(cps.begin(), cps.end() - 1);
-            for (size_t s = 0; s < S; ++s) for (const CP &p : per[s]) cpairs[fill[p.tile]++] = TilePair{p.sample, p.lo, p.hi, 0};
+            for (size_t s = 0; s < S; ++s) for (const CP &p : per[s]) cpairs[fill[p.tile]++] = TilePair{p.sample, p.lo, p.hi, 0, 0, 0, 0, 0};
         }
         std::vector<WorkItem> cwork;
         for (uint64_t t = 0; t < nt; ++t) {

@@ -156,6 +156,19 @@ def test_long_reads_span_pieces_and_tiles():
     assert prod[0].count("\n") > 30, prod[0].count("\n")
 
 
+@pytest.mark.parametrize("read_len", [36, 50, 75])
+def test_short_reads_use_the_dense_block_layout(read_len):
+    """Mean piece length below 72 bases -> finalize packs the dense 32-base block stream and msnv_pileup_tiles_dense
+    runs (two segments per block, pieces that start mid-block, odd lengths with a pad nibble, fresh-block rule)."""
+    syn, samples = synth_case(n_species=2, contig_len=6000, n_samples=7, mean_cov=14.0, snv_density=0.03, read_len=read_len,
+                              lowercase_ref=1, seed=500 + read_len)
+    prod = run_product(syn.names, syn.lengths, syn.seqs, samples)
+    orac = run_oracle(syn.names, syn.lengths, syn.seqs, samples)
+    _assert_same(prod, orac)
+    assert prod[0].count("\n") > 50
+    assert prod[2]["bytes_headers"] * 8 < prod[2]["n_pileup_bases"] * 2     # 4 B per 32-base block, not 8 B per short piece
+
+
 def test_annotation_codon_path(tmp_path):
     syn, samples = synth_case(n_species=2, contig_len=3000, n_samples=4, mean_cov=14.0, snv_density=0.03, frac_absent=0.0, seed=21)
     fa = str(tmp_path / "ref.fa")
