@@ -142,6 +142,17 @@ int msnv_filter_files(msnv_ctx *ctx, const char *const *snp_paths, int32_t n_pat
                       const msnv_filter_species *species, int32_t n_species, double min_cov_c, double min_prop_p,
                       const char *out_dir, uint64_t *n_positions_kept, double *ms_kernel);
 
+/* metaSNV_DistDiv.py --dist (computeDist, metaSNV_DistDiv.py:105-124): pairwise sample
+ * distances of one species' *.filtered.freq table on the device, bit-exact with pandas (NaN-skipping mean whose sum is
+ * numpy's pairwise summation).  Writes the manhattan (mean |f1 - f2|) and the allele (share of positions with
+ * |f1 - f2| > threshold, 0.6 in the reference) matrices as DataFrame.to_csv(sep='\t') does.  Out pointers may be NULL. */
+/* The value pandas' default CSV float converter (precise_xstrtod) gives `text` -- what computeDist sees after
+ * pd.read_table; not always the correctly rounded one.  Returns 0, or MSNV_EFORMAT when text is not a plain number. */
+int msnv_parse_float(const char *text, double *value);
+
+int msnv_dist_file(msnv_ctx *ctx, const char *freq_path, const char *mann_path, const char *allele_path, double threshold,
+                   int32_t *n_samples, uint64_t *n_positions, double *ms_kernel);
+
 /* ------------------------------------------------------------------------------------
  * Staged form of the same path.
  * ------------------------------------------------------------------------------------ */

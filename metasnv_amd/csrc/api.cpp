@@ -509,6 +509,28 @@ extern "C" int msnv_filter_files(msnv_ctx *ctx, const char *const *snp_paths, in
     return filter_files(ctx, snp_paths, n_paths, (uint32_t)n_samples, sp, min_cov_c, min_prop_p, out_dir, n_positions_kept, ms_kernel);
 }
 
+// ------------------------------------------------------------------------------ --dist (section 8 f3)
+namespace msnv {
+int dist_file(msnv_ctx *ctx, const char *freq_path, const char *mann_path, const char *allele_path, double threshold,
+              int32_t *n_samples_out, uint64_t *n_pos_out, double *ms_kernel);
+}
+namespace msnv { bool pandas_strtod(const char *s, const char *end, double &out); }
+extern "C" int msnv_parse_float(const char *text, double *value) {
+    clear_error();
+    if (!text || !value) return fail(MSNV_EINVAL, "msnv_parse_float: NULL argument");
+    if (!pandas_strtod(text, text + strlen(text), *value)) return fail_quiet(MSNV_EFORMAT, "'%s' is not a plain number", text);
+    return MSNV_OK;
+}
+
+extern "C" int msnv_dist_file(msnv_ctx *ctx, const char *freq_path, const char *mann_path, const char *allele_path, double threshold,
+                              int32_t *n_samples, uint64_t *n_positions, double *ms_kernel) {
+    clear_error();
+    if (!ctx || !freq_path || !mann_path || !allele_path) return fail(MSNV_EINVAL, "msnv_dist_file: NULL argument");
+    if (int rc = dev_set_device(ctx->device)) return rc;
+    if (ms_kernel) *ms_kernel = 0;
+    return dist_file(ctx, freq_path, mann_path, allele_path, threshold, n_samples, n_positions, ms_kernel);
+}
+
 // ------------------------------------------------------------------------------ one-call forms
 extern "C" int msnv_call(msnv_ctx *ctx, const msnv_call_args *a) {
     clear_error();

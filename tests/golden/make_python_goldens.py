@@ -106,6 +106,23 @@ def main():
     w(os.path.join(f2, "snpCaller", "indiv_called.best_split_0"), snp_lines(60, 2))
     subprocess.check_call([sys.executable, os.path.join(REF, "metaSNV_Filtering.py"), f2, "-m", "2", "-d", "1", "-b", "10", "-c", "3", "-p", "0.4", "--ind"],
                           cwd=os.path.dirname(f2), env=env, stdout=subprocess.DEVNULL)
+    # ---- metaSNV_DistDiv.py --dist (section 8 f3) on a copy of the filtered tables just produced + a longer synthetic
+    # table that makes numpy's pairwise summation recurse (> 128 rows)
+    dd = os.path.join(OUT, "distdiv", "proj")
+    shutil.copytree(os.path.join(f2, "filtered", "pop"), os.path.join(dd, "filtered", "pop"))
+    for t in ("proj.all_cov.tab", "proj.all_perc.tab"):
+        shutil.copy(os.path.join(f2, t), os.path.join(dd, t))
+    w(os.path.join(dd, "bed_header"), "spA.p.c1\t1\t1000\n")
+    big = "\t" + "\t".join(names) + "\n"
+    for k in range(700):
+        vals = []
+        for s in range(6):
+            c = rnd.choice([0, 3, 7, 40, 97, 1000, 29989])
+            vals.append("-1" if (c == 0 or rnd.random() < 0.15 or s == 4) else repr(rnd.randint(0, c) / c))
+        big += "spZ.c:-:%d:A>T:.\t%s\n" % (k + 1, "\t".join(vals))
+    w(os.path.join(dd, "filtered", "pop", "spZ.filtered.freq"), big)
+    subprocess.check_call([sys.executable, os.path.join(REF, "metaSNV_DistDiv.py"), "--filt", os.path.join(dd, "filtered", "pop"), "--dist"],
+                          cwd=os.path.dirname(dd), env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     # FILTER I known answers for a few threshold sets (relevant_taxa of the reference module, imported here only)
     spec = importlib.util.spec_from_file_location("ref_filtering", os.path.join(REF, "metaSNV_Filtering.py"))
     mod = importlib.util.module_from_spec(spec)

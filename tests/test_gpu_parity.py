@@ -524,6 +524,54 @@ def test_two_rank_sharded_call_with_annotation(tmp_path):
     assert info[0][1] + info[1][1] == orac[3]
 
 
+def test_distances_on_device_match_reference_outputs(tmp_path, golden_dir):
+    """metaSNV_DistDiv.py --dist on the device: tests/golden/python_callers/distdiv holds the
+    *.filtered.freq inputs and the .mann.dist / .allele.dist files the reference script (pandas) wrote for them."""
+    import shutil
+    from metasnv_amd import distdiv
+    src = os.path.join(golden_dir, "python_callers", "distdiv", "proj")
+    proj = str(tmp_path / "proj")
+    shutil.copytree(src, proj)
+    shutil.rmtree(os.path.join(proj, "distances"))
+    distdiv.main(["--filt", os.path.join(proj, "filtered", "pop"), "--dist"])
+    want = sorted(os.listdir(os.path.join(src, "distances")))
+    assert sorted(os.listdir(os.path.join(proj, "distances"))) == want and len(want) == 8
+    for f in want:
+        assert open(os.path.join(proj, "distances", f)).read() == open(os.path.join(src, "distances", f)).read(), f
+
+
+def test_distances_random_tables_against_pandas(tmp_path):
+    """The same arithmetic evaluated live with pandas (metaSNV_DistDiv.py:105-124 restated in four lines): table lengths
+    around numpy's pairwise-summation block boundaries, NaN-heavy columns, an all-NaN sample."""
+    import random
+    import numpy as np
+    pd = pytest.importorskip("pandas")
+    from metasnv_amd import _lib
+    ctx = core.Context(0)
+    rnd = random.Random(4)
+    for n_pos, S in [(1, 3), (7, 4), (8, 4), (9, 5), (127, 6), (128, 6), (129, 6), (136, 3), (257, 5), (1000, 9), (2049, 4), (5003, 12)]:
+        names = ["smp%d.bam" % i for i in range(S)]
+        path = str(tmp_path / ("t%d.filtered.freq" % n_pos))
+        with open(path, "w") as f:
+            f.write("\t" + "\t".join(names) + "\n")
+            for k in range(n_pos):
+                vals = []
+                for s in range(S):
+                    c = rnd.choice([1, 3, 7, 40, 97, 1000, 29989, 200003])
+                    vals.append("-1" if (rnd.random() < (0.6 if s == 1 else 0.1) or (s == 2 and S > 4)) else repr(rnd.randint(0, c) / c))
+                f.write("c:-:%d:A>T:.\t%s\n" % (k + 1, "\t".join(vals)))
+        mp, ap = path + ".mann", path + ".allele"
+        _lib.check(_lib.lib.msnv_dist_file(ctx._h, path.encode(), mp.encode(), ap.encode(), 0.6, None, None, None))
+        data = pd.read_table(path, index_col=0, na_values=['-1']).T
+        dist = pd.DataFrame([[np.abs(data.iloc[i] - data.iloc[j]).mean() for i in range(len(data))] for j in range(len(data))], index=data.index, columns=data.index)
+        dist.to_csv(mp + ".want", sep='\t')
+        dist = pd.DataFrame([[(np.abs(data.iloc[i] - data.iloc[j]) > .6).mean() for i in range(len(data))] for j in range(len(data))], index=data.index, columns=data.index)
+        dist.to_csv(ap + ".want", sep='\t')
+        assert open(mp).read() == open(mp + ".want").read(), (n_pos, S)
+        assert open(ap).read() == open(ap + ".want").read(), (n_pos, S)
+    ctx.close()
+
+
 def test_cli_project_layout_and_contents(tmp_path, capsys):
     from metasnv_amd import cli, tables
     syn, samples = synth_case(n_species=3, contig_len=4000, n_samples=4, mean_cov=12.0, snv_density=0.03, frac_absent=0.0, seed=31)

@@ -84,3 +84,27 @@ def test_relevant_taxa_matches_reference_answers(golden_dir):
     for a in json.load(open(os.path.join(g, "relevant_taxa.json"))):
         got = filtering.relevant_taxa(os.path.join(g, "proj", "proj.all_cov.tab"), os.path.join(g, "proj", "proj.all_perc.tab"), a["b"], a["d"], a["m"])
         assert got["SoI"] == a["SoI"], a
+
+
+def test_float_parse_matches_pandas_default_converter():
+    """computeDist reads the frequencies with pd.read_table (metaSNV_DistDiv.py:116), whose default converter is not
+    correctly rounded; the library reproduces it (it decides the last digit of the printed distances)."""
+    import ctypes as C
+    import io
+    import random
+    pd = pytest.importorskip("pandas")
+    from metasnv_amd._lib import lib
+    rnd = random.Random(8)
+    toks = ["0.0", "1.0", "0.5", "0.42857142857142855", "0.04748407749508153", "4.999925001124983e-06", "1e-05", "0.1", "0.30000000000000004",
+            "123456789.12345678", "9.999850002249966e-06", "0.9999999999999999", "1e-10", "2.5e-05", "7", "12345678901234567890", "0.000123"]
+    toks += [repr(rnd.randint(0, c) / c) for c in [rnd.randint(1, 300000) for _ in range(4000)]]
+    toks += [repr(rnd.random() * 10 ** rnd.randint(-9, 6)) for _ in range(2000)]
+    want = pd.read_csv(io.StringIO("x\n" + "\n".join(toks) + "\n"), dtype=float)["x"].values
+    v = C.c_double()
+    off = 0
+    for tok, w in zip(toks, want):
+        assert lib.msnv_parse_float(tok.encode(), C.byref(v)) == 0, tok
+        assert v.value == w, (tok, repr(v.value), repr(w))
+        off += v.value != float(tok)
+    assert off > 100                                # the converter really is inexact: this is not strtod
+    assert lib.msnv_parse_float(b"abc", C.byref(v)) != 0 and lib.msnv_parse_float(b"1.5x", C.byref(v)) != 0
