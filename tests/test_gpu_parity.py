@@ -169,6 +169,42 @@ def test_short_reads_use_the_dense_block_layout(read_len):
     assert prod[2]["bytes_headers"] * 8 < prod[2]["n_pileup_bases"] * 2     # 4 B per 32-base block, not 8 B per short piece
 
 
+def _random_flagged_samples(seed, L=3000, n_reads=700, n_samples=3):
+    import random
+    rnd = random.Random(seed)
+    ref = "".join(rnd.choice("ACGT") for _ in range(L))
+    samples = []
+    for s in range(n_samples):
+        recs = []
+        for k in range(n_reads):
+            st = rnd.randrange(0, L - 80)
+            n = rnd.randrange(30, 80)
+            q = list(ref[st:st + n])
+            g = (st + n // 2) // 25 * 25
+            if st <= g < st + n and k % 2 == 0:
+                q[g - st] = "T" if ref[g] != "T" else "G"
+            flag = rnd.choice([0, 0, 16, 0x1 | 0x2 | 0x40, 0x1 | 0x2 | 0x80 | 16, 0x1 | 0x40, 0x1 | 0x80 | 0x8, 0x400, 0x100, 0x800, 0x200])
+            recs.append((st, bt.make_record(0, st, "%dM" % n, "".join(q), flag=flag, mapq=rnd.choice([0, 1, 5, 20, 60, 60]),
+                                            qual=[rnd.choice([2, 12, 13, 14, 30, 40]) for _ in range(n)], name="r%d_%d" % (s, k))))
+        recs.sort(key=lambda t: t[0])
+        samples.append(bt.records(*[r for _, r in recs]))
+    return ref, samples
+
+
+def test_read_filters_orphans_mapq_and_depth_cap():
+    """samtools' read-level filters as mpileup applies them before the pileup (Appendix C): flag filter 0x704, orphans
+    (paired but not proper) dropped unless count_orphans, min MAPQ, and the per-file depth cap (-d) in several settings."""
+    ref, samples = _random_flagged_samples(71)
+    for kw in (dict(), dict(count_orphans=1), dict(min_mapq=2), dict(min_mapq=21, count_orphans=1), dict(flag_filter=0x400),
+               dict(max_depth=9), dict(max_depth=3, count_orphans=1), dict(max_depth=1)):
+        p = core.default_params(min_coverage=3, calling_threshold=2, **kw)
+        prod = run_product(["ctg"], [len(ref)], [ref], samples, params=p)
+        orac = run_oracle(["ctg"], [len(ref)], [ref], samples, params=p)
+        _assert_same(prod, orac)
+        assert prod[2]["n_pileup_bases"] == orac[3], kw
+    assert prod[0].count("\n") + prod[1].count("\n") > 0
+
+
 def test_annotation_codon_path(tmp_path):
     syn, samples = synth_case(n_species=2, contig_len=3000, n_samples=4, mean_cov=14.0, snv_density=0.03, frac_absent=0.0, seed=21)
     fa = str(tmp_path / "ref.fa")
