@@ -30,7 +30,7 @@ def measured_traffic(samples, species, contig_len, mean_cov):
     (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 read correction applied).
     Only valid for the workload it was collected on; anything else reports null."""
     try:
-        p = json.load(open(os.path.join(ROOT, "profiles", "r01f_pmc.json")))
+        p = json.load(open(os.path.join(ROOT, "profiles", "r01g_pmc.json")))
         if (samples, species, contig_len, mean_cov) == (160, 3, 300000, 10.0):
             return p["hbm_traffic"]["total_bytes_per_launch"]
     except Exception:
@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--mean-cov", type=float, default=10.0)
     ap.add_argument("--read-len", type=int, default=100, help="synthetic read length (BASELINE: 100)")
     ap.add_argument("--cpu-samples", type=int, default=64, help="samples of the workload the CPU oracle is timed on")
+    ap.add_argument("--sync-each-step", action="store_true", help="one msnv_pileup_run call (with its host sync) per step instead of one batched call")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-annotation", action="store_true", help="skip the --db_ann codon-annotation kernel (BASELINE configs[4]) after the timed region")
     ap.add_argument("--host-threads", type=int, default=0)
@@ -142,9 +143,15 @@ def main():
     barrier()
     t0 = time.perf_counter()
     ms_pileup, ms_total = [], []
-    for _ in range(a.steps):
-        st = ds.run()                      # blocks until the pass has finished (stream sync inside)
-        ms_pileup.append(st["ms_pileup"]); ms_total.append(st["ms_total"])
+    if a.sync_each_step:
+        for _ in range(a.steps):
+            st = ds.run()                  # blocks until the pass has finished (stream sync inside)
+            ms_pileup.append(st["ms_pileup"]); ms_total.append(st["ms_total"])
+    else:
+        # the K passes are enqueued back to back (each with its own HIP-event pair around the pileup kernel) and the
+        # host waits once, like a queue of shards would be driven; --sync-each-step gives the one-call-per-pass form
+        for st in ds.run_many(a.steps):
+            ms_pileup.append(st["ms_pileup"]); ms_total.append(st["ms_total"])
     barrier()
     dt = time.perf_counter() - t0
 

@@ -146,6 +146,12 @@ class Dataset:
         check(lib.msnv_pileup_run(self._h, C.byref(st)))
         return {k: getattr(st, k) for k, _ in RunStats._fields_}
 
+    def run_many(self, n):
+        """n passes back to back, one host synchronisation; returns the list of per-pass stats."""
+        arr = (RunStats * n)()
+        check(lib.msnv_pileup_run_many(self._h, n, arr))
+        return [{k: getattr(s, k) for k, _ in RunStats._fields_} for s in arr]
+
     def coverage_run(self):
         st = RunStats()
         check(lib.msnv_coverage_run(self._h, C.byref(st)))

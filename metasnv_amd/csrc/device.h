@@ -103,6 +103,7 @@ void dev_stream_destroy(void *stream);
 constexpr int COV_BINS = 16;            // histogram bins kept on the device (qaCompute -c <= 15)
 int  dev_run_coverage(DeviceCols &d, int max_cov, void *stream, msnv_run_stats *stats);
 int  dev_run_pipeline(DeviceCols &d, const msnv_params &p, void *stream, msnv_run_stats *stats, RunCounts *counts);
+int  dev_run_pipeline_many(DeviceCols &d, const msnv_params &p, void *stream, int n, msnv_run_stats *stats, RunCounts *counts);
 void dev_free_all(DeviceCols &d);
 
 }  // namespace msnv

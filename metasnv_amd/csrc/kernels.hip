@@ -963,20 +963,16 @@ static int ensure_out(DeviceCols &d, uint64_t n_sites) {
     return MSNV_OK;
 }
 
-int dev_run_pipeline(DeviceCols &d, const msnv_params &p, void *stream_, msnv_run_stats *stats, RunCounts *counts) {
-    hipStream_t st = (hipStream_t)stream_;
+// Enqueues one pass (memsets + kernels + readback of the counters into host_cnt[8]) without waiting for it.
+// ev_begin / ev_pile0 / ev_pile1 are recorded before the pass, before and after the pileup kernel(s); ev3 / ev4 (optional)
+// split the tail.  Buffers must have been sized by ensure_out before.
+static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hipEvent_t ev_begin, hipEvent_t ev_pile0, hipEvent_t ev_pile1,
+                        hipEvent_t ev3, hipEvent_t ev4, uint32_t *host_cnt) {
     const uint64_t npos = (uint64_t)d.n_tiles * TILE;
-    hipEvent_t ev[6];                                      // created once per dataset: event create / destroy costs host time in every pass
-    for (int i = 0; i < 6; ++i) {
-        if (!d.timing_events[i]) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); d.timing_events[i] = e; }
-        ev[i] = (hipEvent_t)d.timing_events[i];
-    }
-    auto cleanup = [] {};
-
-    HIP_TRY(hipEventRecord(ev[0], st));
+    HIP_TRY(hipEventRecord(ev_begin, st));
     HIP_TRY(hipMemsetAsync(d.counters, 0, 8 * sizeof(uint32_t), st));
     if (npos) HIP_TRY(hipMemsetAsync(d.tot, 0, 4 * npos * sizeof(uint32_t), st));
-    HIP_TRY(hipEventRecord(ev[1], st));
+    HIP_TRY(hipEventRecord(ev_pile0, st));
     if (d.n_work) {
         PileupArgs a;
         a.hdr = d.hdr; a.hdr8 = d.hdr8; a.blk = d.blk; a.seq = d.seq; a.qual = d.qual;
@@ -996,18 +992,14 @@ int dev_run_pipeline(DeviceCols &d, const msnv_params &p, void *stream_, msnv_ru
         }
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipEventRecord(ev[2], st));
+    HIP_TRY(hipEventRecord(ev_pile1, st));
     if (d.n_tiles) {
         hipLaunchKernelGGL(msnv_gate_sites, dim3(d.n_tiles), dim3(GATE_NT), 0, st, d.tot, d.part, d.tile_slot_start, npos, d.tile_vbeg, d.tile_vend,
                            p.min_coverage, p.calling_threshold, d.sites, d.cap_sites, d.counters, d.tile_site_base, d.tile_site_cnt);
         HIP_TRY(hipGetLastError());
     }
-    // every event record costs ~6 us of stream time (the next kernel waits for the marker): the per-phase split of
-    // the tail is only recorded on request (MSNV_PHASE_TIMES=1, profiles/phase_times.py)
-    static const bool phase_times = [] { const char *e = getenv("MSNV_PHASE_TIMES"); return e && e[0] == '1'; }();
-    if (phase_times) HIP_TRY(hipEventRecord(ev[3], st));
+    if (ev3) HIP_TRY(hipEventRecord(ev3, st));
     // the tail runs on device-side counts: no host round trip inside a pass
-    if (int rc = ensure_out(d, std::max<uint64_t>(d.last_sites + d.last_sites / 2, 4096))) { cleanup(); return rc; }
     const uint32_t cap_out = (uint32_t)std::min<uint64_t>(d.cap_out_sites, 0xffffffffull);
     if (d.n_tiles) {
         hipLaunchKernelGGL(msnv_gather_cov, dim3(d.n_tiles * GATHER_SPLIT), dim3(256), 0, st, d.sites, d.tile_site_base, d.tile_site_cnt,
@@ -1017,23 +1009,41 @@ int dev_run_pipeline(DeviceCols &d, const msnv_params &p, void *stream_, msnv_ru
                            d.cap_overflow, d.sites, d.tile_site_base, d.tile_site_cnt, d.out, d.n_samples, cap_out);
         HIP_TRY(hipGetLastError());
     }
-    if (phase_times) HIP_TRY(hipEventRecord(ev[4], st));
+    if (ev4) HIP_TRY(hipEventRecord(ev4, st));
     hipLaunchKernelGGL(msnv_decide_sites, dim3(512), dim3(256), 0, st, d.sites, d.counters, d.cap_sites, cap_out, d.ref4, d.ref_lc,
                        d.out, d.n_samples, p.calling_threshold, p.min_fraction, d.site_flags);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(ev[5], st));
-    uint32_t cnt[8] = {0};
-    HIP_TRY(hipMemcpyAsync(cnt, d.counters, sizeof cnt, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpyAsync(host_cnt, d.counters, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    return MSNV_OK;
+}
+
+static int check_counts(DeviceCols &d, const uint32_t *cnt, RunCounts *counts) {
     RunCounts c{cnt[0], cnt[1], cnt[2], cnt[3]};
     d.last_sites = c.n_sites;
-    if (c.n_events > d.cap_events || c.n_overflow > d.cap_overflow || c.n_sites > d.cap_sites || c.n_sites > d.cap_out_sites) {
-        cleanup();
-        if (counts) *counts = c;
+    if (counts) *counts = c;
+    if (c.n_events > d.cap_events || c.n_overflow > d.cap_overflow || c.n_sites > d.cap_sites || c.n_sites > d.cap_out_sites)
         return fail_quiet(MSNV_ECAPACITY, "device buffer too small: events %u/%u overflow %u/%u sites %u/%u out %u/%llu",
-                    c.n_events, d.cap_events, c.n_overflow, d.cap_overflow, c.n_sites, d.cap_sites, c.n_sites,
-                    (unsigned long long)d.cap_out_sites);
+                          c.n_events, d.cap_events, c.n_overflow, d.cap_overflow, c.n_sites, d.cap_sites, c.n_sites,
+                          (unsigned long long)d.cap_out_sites);
+    return MSNV_OK;
+}
+
+int dev_run_pipeline(DeviceCols &d, const msnv_params &p, void *stream_, msnv_run_stats *stats, RunCounts *counts) {
+    hipStream_t st = (hipStream_t)stream_;
+    hipEvent_t ev[6];                                      // created once per dataset: event create / destroy costs host time in every pass
+    for (int i = 0; i < 6; ++i) {
+        if (!d.timing_events[i]) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); d.timing_events[i] = e; }
+        ev[i] = (hipEvent_t)d.timing_events[i];
     }
+    // every event record costs ~6 us of stream time (the next kernel waits for the marker): the per-phase split of
+    // the tail is only recorded on request (MSNV_PHASE_TIMES=1, profiles/phase_times.py)
+    static const bool phase_times = [] { const char *e = getenv("MSNV_PHASE_TIMES"); return e && e[0] == '1'; }();
+    if (int rc = ensure_out(d, std::max<uint64_t>(d.last_sites + d.last_sites / 2, 4096))) return rc;
+    uint32_t cnt[8] = {0};
+    if (int rc = enqueue_pass(d, p, st, ev[0], ev[1], ev[2], phase_times ? ev[3] : nullptr, phase_times ? ev[4] : nullptr, cnt)) return rc;
+    HIP_TRY(hipEventRecord(ev[5], st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (int rc = check_counts(d, cnt, counts)) return rc;
     if (stats) {
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[5])); stats->ms_total = ms;
@@ -1043,13 +1053,46 @@ int dev_run_pipeline(DeviceCols &d, const msnv_params &p, void *stream_, msnv_ru
             HIP_TRY(hipEventElapsedTime(&ms, ev[3], ev[4])); stats->ms_gather = ms;
             HIP_TRY(hipEventElapsedTime(&ms, ev[4], ev[5])); stats->ms_decide = ms;
         }
-        stats->n_sites = c.n_sites; stats->n_events = c.n_events; stats->n_overflow = c.n_overflow;
+        stats->n_sites = cnt[2]; stats->n_events = cnt[0]; stats->n_overflow = cnt[1];
         stats->n_called_pop = cnt[4]; stats->n_called_indiv = cnt[5];
         stats->algorithmic_bytes = d.algorithmic_bytes;
     }
-    if (counts) *counts = c;
-    cleanup();
     return MSNV_OK;
+}
+
+// n passes enqueued back to back, ONE host synchronisation at the end (a queue of shards / repeated passes keeps the GPU
+// busy between passes: the host round trip of the single-pass form costs ~40 us of idle GPU per pass).  stats[i] gets
+// the pileup-kernel time of pass i from its own event pair and ms_total = start of pass i to start of pass i+1.
+int dev_run_pipeline_many(DeviceCols &d, const msnv_params &p, void *stream_, int n, msnv_run_stats *stats, RunCounts *counts) {
+    hipStream_t st = (hipStream_t)stream_;
+    if (n <= 0) return MSNV_OK;
+    if (int rc = ensure_out(d, std::max<uint64_t>(d.last_sites + d.last_sites / 2, 4096))) return rc;
+    std::vector<hipEvent_t> ev((size_t)3 * n + 1);
+    for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
+    auto cleanup = [&]() { for (auto &e : ev) (void)hipEventDestroy(e); };
+    uint32_t *cnt = nullptr;
+    if (hipHostMalloc((void **)&cnt, (size_t)n * 8 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { cleanup(); return fail(MSNV_ENOMEM, "pinned host memory for %d counter blocks", n); }
+    int rc = MSNV_OK;
+    for (int i = 0; i < n && !rc; ++i) rc = enqueue_pass(d, p, st, ev[3 * i], ev[3 * i + 1], ev[3 * i + 2], nullptr, nullptr, cnt + 8 * i);
+    hipError_t he = hipSuccess;
+    if (!rc) he = hipEventRecord(ev[3 * n], st);
+    if (!rc && he == hipSuccess) he = hipStreamSynchronize(st);
+    if (!rc && he != hipSuccess) rc = fail(MSNV_EHIP, "batched passes: %s", hipGetErrorString(he));
+    for (int i = 0; i < n && !rc; ++i) {
+        rc = check_counts(d, cnt + 8 * i, counts);
+        if (rc || !stats) continue;
+        float ms = 0;
+        msnv_run_stats &s = stats[i];
+        s = msnv_run_stats{};
+        if (hipEventElapsedTime(&ms, ev[3 * i], ev[3 * (i + 1)]) == hipSuccess) s.ms_total = ms;
+        if (hipEventElapsedTime(&ms, ev[3 * i + 1], ev[3 * i + 2]) == hipSuccess) s.ms_pileup = ms;
+        const uint32_t *c = cnt + 8 * i;
+        s.n_sites = c[2]; s.n_events = c[0]; s.n_overflow = c[1]; s.n_called_pop = c[4]; s.n_called_indiv = c[5];
+        s.algorithmic_bytes = d.algorithmic_bytes;
+    }
+    (void)hipHostFree(cnt);
+    cleanup();
+    return rc;
 }
 
 int dev_run_coverage(DeviceCols &d, int max_cov, void *stream_, msnv_run_stats *stats) {
