@@ -220,9 +220,11 @@ int  msnv_pileup_run(msnv_dataset *ds, msnv_run_stats *stats);
 
 /* Per-sample genome coverage (qaCompute arithmetic) over the resident dataset. */
 /* n passes enqueued back to back with ONE host synchronisation at the end (stats: n entries, may be NULL): how a queue of
- * shards keeps the GPU busy -- the host round trip of msnv_pileup_run costs ~40 us of idle GPU per pass.  The results
- * are those of the last pass.  msnv_pileup_run must have run once before (it sizes the sparse device buffers). */
-int  msnv_pileup_run_many(msnv_dataset *ds, int32_t n, msnv_run_stats *stats);
+ * shards keeps the GPU busy -- the host round trip of msnv_pileup_run costs ~40 us of idle GPU per pass.  With overlap != 0
+ * consecutive passes alternate between two HIP streams and two sets of intermediates, so the small tail kernels of one
+ * pass run under the pileup kernel of the next (+5 % passes/s; per-kernel times are then those of kernels sharing the
+ * chip).  The results are those of the last pass.  msnv_pileup_run must have run once before (it sizes the buffers). */
+int  msnv_pileup_run_many(msnv_dataset *ds, int32_t n, int32_t overlap, msnv_run_stats *stats);
 int  msnv_coverage_run(msnv_dataset *ds, msnv_run_stats *stats);
 /* Both passes over the same resident columns (BASELINE configs[2]: qaCompute + snpCall fused on the device):
  * replaces running `qaCompute` per BAM (metaSNV.py:63-65) and then `samtools mpileup | snpCall` (:160-176) on

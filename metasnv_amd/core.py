@@ -146,10 +146,11 @@ class Dataset:
         check(lib.msnv_pileup_run(self._h, C.byref(st)))
         return {k: getattr(st, k) for k, _ in RunStats._fields_}
 
-    def run_many(self, n):
-        """n passes back to back, one host synchronisation; returns the list of per-pass stats."""
+    def run_many(self, n, overlap=False):
+        """n passes back to back, one host synchronisation; returns the list of per-pass stats.  overlap=True runs
+        consecutive passes on two streams (the tail kernels of one pass under the pileup kernel of the next)."""
         arr = (RunStats * n)()
-        check(lib.msnv_pileup_run_many(self._h, n, arr))
+        check(lib.msnv_pileup_run_many(self._h, n, 1 if overlap else 0, arr))
         return [{k: getattr(s, k) for k, _ in RunStats._fields_} for s in arr]
 
     def coverage_run(self):

@@ -244,14 +244,14 @@ extern "C" int msnv_dataset_info_get(const msnv_dataset *ds, msnv_dataset_info *
 }
 
 // ------------------------------------------------------------------------------ pipeline
-extern "C" int msnv_pileup_run_many(msnv_dataset *ds, int32_t n, msnv_run_stats *stats) {
+extern "C" int msnv_pileup_run_many(msnv_dataset *ds, int32_t n, int32_t overlap, msnv_run_stats *stats) {
     clear_error();
     if (!ds || !ds->finalized || n <= 0) return fail(MSNV_EINVAL, "msnv_pileup_run_many: dataset is not finalized or n <= 0");
     if (!ds->have_results) return fail(MSNV_EINVAL, "msnv_pileup_run_many: run msnv_pileup_run once first (it sizes the sparse buffers)");
     if (int rc = dev_set_device(ds->ctx->device)) return rc;
     RunCounts c{};
     std::vector<msnv_run_stats> tmp((size_t)n);
-    int rc = dev_run_pipeline_many(*ds->dev, ds->params, ds->ctx->stream, n, tmp.data(), &c);
+    int rc = dev_run_pipeline_many(*ds->dev, ds->params, ds->ctx->stream, n, overlap != 0, tmp.data(), &c);
     if (rc == MSNV_ECAPACITY) return fail(rc, "%s", msnv_last_error());
     if (rc) return rc;
     ds->have_results = true; ds->results_fetched = false; ds->ann_valid = false;

@@ -84,6 +84,15 @@ struct DeviceCols {
     uint64_t  device_bytes = 0;
     uint64_t  algorithmic_bytes = 0;
     AnnDev    ann;
+    // second set of per-pass intermediates + second stream: msnv_pileup_run_many alternates passes between the two sets so
+    // that the small tail kernels of pass i overlap with the pileup kernel of pass i+1 (allocated on first use)
+    struct AltBufs {
+        uint32_t *tot = nullptr, *part = nullptr; uint8_t *spill = nullptr; Pair32 *events = nullptr, *overflow = nullptr;
+        uint32_t *counters = nullptr; SiteRec *sites = nullptr; uint32_t *tile_site_base = nullptr, *tile_site_cnt = nullptr;
+        msnv_site_sample *out = nullptr; uint8_t *site_flags = nullptr;
+        uint32_t cap_events = 0, cap_overflow = 0, cap_sites = 0; uint64_t cap_out_sites = 0;
+    } alt;
+    void     *stream2 = nullptr;
     void     *timing_events[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // hipEvent_t, reused by every pass
 };
 
@@ -103,7 +112,7 @@ void dev_stream_destroy(void *stream);
 constexpr int COV_BINS = 16;            // histogram bins kept on the device (qaCompute -c <= 15)
 int  dev_run_coverage(DeviceCols &d, int max_cov, void *stream, msnv_run_stats *stats);
 int  dev_run_pipeline(DeviceCols &d, const msnv_params &p, void *stream, msnv_run_stats *stats, RunCounts *counts);
-int  dev_run_pipeline_many(DeviceCols &d, const msnv_params &p, void *stream, int n, msnv_run_stats *stats, RunCounts *counts);
+int  dev_run_pipeline_many(DeviceCols &d, const msnv_params &p, void *stream, int n, bool overlap, msnv_run_stats *stats, RunCounts *counts);
 void dev_free_all(DeviceCols &d);
 
 }  // namespace msnv

@@ -949,6 +949,10 @@ void dev_free_all(DeviceCols &d) {
     void *aptrs[] = {d.ann.seg_beg, d.ann.seg_end, d.ann.seg_gene, d.ann.genes, d.ann.contigs, d.ann.codons, d.ann.out, d.ann.err};
     for (void *p : aptrs) dev_free(p);
     for (void *e : d.timing_events) if (e) (void)hipEventDestroy((hipEvent_t)e);
+    void *alts[] = {d.alt.tot, d.alt.part, d.alt.spill, d.alt.events, d.alt.overflow, d.alt.counters, d.alt.sites, d.alt.tile_site_base,
+                    d.alt.tile_site_cnt, d.alt.out, d.alt.site_flags};
+    for (void *p : alts) dev_free(p);
+    if (d.stream2) (void)hipStreamDestroy((hipStream_t)d.stream2);
     d = DeviceCols{};
 }
 
@@ -967,11 +971,12 @@ static int ensure_out(DeviceCols &d, uint64_t n_sites) {
 // ev_begin / ev_pile0 / ev_pile1 are recorded before the pass, before and after the pileup kernel(s); ev3 / ev4 (optional)
 // split the tail.  Buffers must have been sized by ensure_out before.
 static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hipEvent_t ev_begin, hipEvent_t ev_pile0, hipEvent_t ev_pile1,
-                        hipEvent_t ev3, hipEvent_t ev4, uint32_t *host_cnt) {
+                        hipEvent_t ev3, hipEvent_t ev4, uint32_t *host_cnt, hipEvent_t wait_before_pileup = nullptr) {
     const uint64_t npos = (uint64_t)d.n_tiles * TILE;
     HIP_TRY(hipEventRecord(ev_begin, st));
     HIP_TRY(hipMemsetAsync(d.counters, 0, 8 * sizeof(uint32_t), st));
     if (npos) HIP_TRY(hipMemsetAsync(d.tot, 0, 4 * npos * sizeof(uint32_t), st));
+    if (wait_before_pileup) HIP_TRY(hipStreamWaitEvent(st, wait_before_pileup, 0));   // the previous pass' pileup kernel (other stream)
     HIP_TRY(hipEventRecord(ev_pile0, st));
     if (d.n_work) {
         PileupArgs a;
@@ -1060,32 +1065,89 @@ int dev_run_pipeline(DeviceCols &d, const msnv_params &p, void *stream_, msnv_ru
     return MSNV_OK;
 }
 
-// n passes enqueued back to back, ONE host synchronisation at the end (a queue of shards / repeated passes keeps the GPU
-// busy between passes: the host round trip of the single-pass form costs ~40 us of idle GPU per pass).  stats[i] gets
-// the pileup-kernel time of pass i from its own event pair and ms_total = start of pass i to start of pass i+1.
-int dev_run_pipeline_many(DeviceCols &d, const msnv_params &p, void *stream_, int n, msnv_run_stats *stats, RunCounts *counts) {
-    hipStream_t st = (hipStream_t)stream_;
+// Second set of per-pass intermediates, sized like the first (re-made when the first set was grown).
+static int ensure_alt(DeviceCols &d) {
+    DeviceCols::AltBufs &a = d.alt;
+    const uint64_t npos = (uint64_t)d.n_tiles * TILE;
+    if (a.tot && a.cap_events == d.cap_events && a.cap_overflow == d.cap_overflow && a.cap_sites == d.cap_sites && a.cap_out_sites == d.cap_out_sites) return MSNV_OK;
+    void *old[] = {a.tot, a.part, a.spill, a.events, a.overflow, a.counters, a.sites, a.tile_site_base, a.tile_site_cnt, a.out, a.site_flags};
+    for (void *p : old) dev_free(p);
+    a = DeviceCols::AltBufs{};
+    if (int rc = dev_alloc((void **)&a.tot, std::max<uint64_t>(1, 4 * npos) * sizeof(uint32_t), &d.device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&a.part, std::max<uint64_t>(1, d.n_work) * TILE * sizeof(uint32_t), &d.device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&a.spill, std::max<uint64_t>(1, d.n_pairs) * TILE, &d.device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&a.events, (uint64_t)d.cap_events * sizeof(Pair32), &d.device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&a.overflow, (uint64_t)d.cap_overflow * sizeof(Pair32), &d.device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&a.sites, (uint64_t)d.cap_sites * sizeof(SiteRec), &d.device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&a.counters, 16 * sizeof(uint32_t), &d.device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&a.tile_site_base, ((uint64_t)d.n_tiles + 1) * sizeof(uint32_t), &d.device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&a.tile_site_cnt, ((uint64_t)d.n_tiles + 1) * sizeof(uint32_t), &d.device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&a.out, d.cap_out_sites * d.n_samples * sizeof(msnv_site_sample), &d.device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&a.site_flags, d.cap_out_sites, &d.device_bytes)) return rc;
+    a.cap_events = d.cap_events; a.cap_overflow = d.cap_overflow; a.cap_sites = d.cap_sites; a.cap_out_sites = d.cap_out_sites;
+    return MSNV_OK;
+}
+static void swap_sets(DeviceCols &d) {
+    DeviceCols::AltBufs &a = d.alt;
+    std::swap(d.tot, a.tot); std::swap(d.part, a.part); std::swap(d.spill, a.spill); std::swap(d.events, a.events);
+    std::swap(d.overflow, a.overflow); std::swap(d.counters, a.counters); std::swap(d.sites, a.sites);
+    std::swap(d.tile_site_base, a.tile_site_base); std::swap(d.tile_site_cnt, a.tile_site_cnt); std::swap(d.out, a.out);
+    std::swap(d.site_flags, a.site_flags);
+}
+
+// n passes, ONE host synchronisation at the end; with `overlap` they are in flight on two streams (a queue of shards / repeated passes keeps the
+// GPU busy: the host round trip of the single-pass form costs ~40 us of idle GPU per pass).  Consecutive passes use
+// alternating sets of intermediates and alternating streams; the pileup kernels are serialised among themselves by an
+// event (they saturate the chip), so what overlaps is the latency-bound tail of pass i (gate, gather, scatter, decide,
+// ~0.12 ms at a fraction of the chip) with the memsets and the pileup kernel of pass i+1.  Measured (one box, 30 passes):
+// step time 0.810 -> 0.770 ms (+5 % bases/s), while the pileup kernel itself reads 0.673 -> 0.736 ms because it shares
+// the chip with the tail kernels -- which is why bench.py measures the roofline on the non-overlapped form.  stats[i]: pileup-kernel time
+// of pass i from its own event pair (recorded after the cross-stream wait); ms_total = batch time / n.  On return the
+// primary set holds the last pass.
+int dev_run_pipeline_many(DeviceCols &d, const msnv_params &p, void *stream_, int n, bool overlap, msnv_run_stats *stats, RunCounts *counts) {
     if (n <= 0) return MSNV_OK;
+    hipStream_t s0 = (hipStream_t)stream_, s1 = s0;
     if (int rc = ensure_out(d, std::max<uint64_t>(d.last_sites + d.last_sites / 2, 4096))) return rc;
-    std::vector<hipEvent_t> ev((size_t)3 * n + 1);
+    if (overlap && n > 1) {
+        if (!d.stream2) { hipStream_t s; HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); d.stream2 = s; }
+        s1 = (hipStream_t)d.stream2;
+        if (int rc = ensure_alt(d)) return rc;
+    }
+    const bool two = s1 != s0;
+    std::vector<hipEvent_t> ev((size_t)4 * n + 2);          // per pass: begin, pile0, pile1, pileup-done marker; + two end events
     for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
     auto cleanup = [&]() { for (auto &e : ev) (void)hipEventDestroy(e); };
     uint32_t *cnt = nullptr;
     if (hipHostMalloc((void **)&cnt, (size_t)n * 8 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { cleanup(); return fail(MSNV_ENOMEM, "pinned host memory for %d counter blocks", n); }
     int rc = MSNV_OK;
-    for (int i = 0; i < n && !rc; ++i) rc = enqueue_pass(d, p, st, ev[3 * i], ev[3 * i + 1], ev[3 * i + 2], nullptr, nullptr, cnt + 8 * i);
     hipError_t he = hipSuccess;
-    if (!rc) he = hipEventRecord(ev[3 * n], st);
-    if (!rc && he == hipSuccess) he = hipStreamSynchronize(st);
+    bool swapped = false;                                     // true while d's primary fields hold the second set
+    for (int i = 0; i < n && !rc && he == hipSuccess; ++i) {
+        hipStream_t st = (i & 1) ? s1 : s0;
+        if (two && (i & 1) != (swapped ? 1 : 0)) { swap_sets(d); swapped = !swapped; }
+        // the pileup kernel of pass i starts after the one of pass i-1 (other stream) has finished; its memsets do not wait
+        rc = enqueue_pass(d, p, st, ev[4 * i], ev[4 * i + 1], ev[4 * i + 2], nullptr, nullptr, cnt + 8 * i, (two && i > 0) ? ev[4 * (i - 1) + 2] : nullptr);
+    }
+    if (!rc && he == hipSuccess) he = hipEventRecord(ev[4 * n], s0);
+    if (!rc && he == hipSuccess) he = hipEventRecord(ev[4 * n + 1], s1);
+    if (he == hipSuccess) he = hipStreamSynchronize(s0);
+    if (he == hipSuccess && two) he = hipStreamSynchronize(s1);
+    // leave the set of the LAST pass in the primary fields (results, annotation and filters read them)
+    if (two && swapped != (((n - 1) & 1) != 0)) { swap_sets(d); swapped = !swapped; }
     if (!rc && he != hipSuccess) rc = fail(MSNV_EHIP, "batched passes: %s", hipGetErrorString(he));
+    float total = 0, t1 = 0;
+    if (!rc) {
+        (void)hipEventElapsedTime(&total, ev[0], ev[4 * n]);
+        if (two && hipEventElapsedTime(&t1, ev[0], ev[4 * n + 1]) == hipSuccess) total = std::max(total, t1);
+    }
     for (int i = 0; i < n && !rc; ++i) {
         rc = check_counts(d, cnt + 8 * i, counts);
         if (rc || !stats) continue;
         float ms = 0;
         msnv_run_stats &s = stats[i];
         s = msnv_run_stats{};
-        if (hipEventElapsedTime(&ms, ev[3 * i], ev[3 * (i + 1)]) == hipSuccess) s.ms_total = ms;
-        if (hipEventElapsedTime(&ms, ev[3 * i + 1], ev[3 * i + 2]) == hipSuccess) s.ms_pileup = ms;
+        s.ms_total = total / (float)n;
+        if (hipEventElapsedTime(&ms, ev[4 * i + 1], ev[4 * i + 2]) == hipSuccess) s.ms_pileup = ms;
         const uint32_t *c = cnt + 8 * i;
         s.n_sites = c[2]; s.n_events = c[0]; s.n_overflow = c[1]; s.n_called_pop = c[4]; s.n_called_indiv = c[5];
         s.algorithmic_bytes = d.algorithmic_bytes;

@@ -338,10 +338,14 @@ def test_repeated_runs_are_idempotent():
         ds.run()
     s2, m2 = ds.results()
     assert s1.tobytes() == s2.tobytes() and m1.tobytes() == m2.tobytes()
-    stats = ds.run_many(5)                                  # batched form: five passes, one host sync
-    s3, m3 = ds.results()
-    assert s1.tobytes() == s3.tobytes() and m1.tobytes() == m3.tobytes()
-    assert len(stats) == 5 and all(x["n_sites"] == st["n_sites"] and x["ms_pileup"] > 0 and x["ms_total"] >= x["ms_pileup"] for x in stats)
+    for overlap, n in ((False, 5), (True, 4), (True, 5), (False, 2), (True, 1)):
+        stats = ds.run_many(n, overlap)                     # batched forms: n passes, one host sync; two streams when overlapped
+        s3, m3 = ds.results()
+        assert s1.tobytes() == s3.tobytes() and m1.tobytes() == m3.tobytes(), (overlap, n)
+        assert len(stats) == n and all(x["n_sites"] == st["n_sites"] and x["ms_pileup"] > 0 for x in stats)
+    ds.run()                                                # the single-pass form still works on whichever set is primary
+    s4, m4 = ds.results()
+    assert s1.tobytes() == s4.tobytes() and m1.tobytes() == m4.tobytes()
 
 
 def _coverage_both(names, lengths, samples, tmp_path, params=None):
