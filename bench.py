@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--read-len", type=int, default=100, help="synthetic read length (BASELINE: 100)")
     ap.add_argument("--cpu-samples", type=int, default=64, help="samples of the workload the CPU oracle is timed on")
     ap.add_argument("--sync-each-step", action="store_true", help="one msnv_pileup_run call (with its host sync) per step instead of one batched call")
+    ap.add_argument("--no-overlap-extra", action="store_true", help="skip the extra timed batch with overlapped passes (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-annotation", action="store_true", help="skip the --db_ann codon-annotation kernel (BASELINE configs[4]) after the timed region")
     ap.add_argument("--host-threads", type=int, default=0)
@@ -158,7 +159,7 @@ def main():
     # the same K passes with the tails overlapped on a second stream (reported beside the main line, never as `value`:
     # the roofline above is measured on kernels that have the chip to themselves)
     overlapped = None
-    if not a.sync_each_step:
+    if not a.sync_each_step and not a.no_overlap_extra:
         ds.run_many(2, overlap=True)       # untimed: allocates the second set of per-pass intermediates and the second stream
         barrier()
         t0o = time.perf_counter()
