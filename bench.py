@@ -169,6 +169,14 @@ def main():
         overlapped = {"ms_per_step": dto / a.steps * 1e3, "pileup_kernel_ms_sharing_the_chip": sum(x["ms_pileup"] for x in so) / len(so),
                       "per_gpu_value": info["n_pileup_bases"] * a.steps / dto / 1e9, "unit": "Gbases/s"}
 
+    cov_extra = None
+    if rank == 0:
+        # the qaCompute half of the path on the same resident columns (msnv_coverage_tiles), outside the timed region
+        ms = []
+        for _ in range(5):
+            ms.append(ds.coverage_run()["ms_coverage"])
+        cov_extra = {"kernel_ms": sum(ms[1:]) / len(ms[1:]), "bytes_per_M_interval": 8, "intervals": info["n_reads_pileup"]}
+
     ann_extra = None
     if not a.no_annotation and rank == 0:
         # configs[4]: gene / codon annotation of the called sites on the device (outside the timed region)
@@ -226,6 +234,8 @@ def main():
         }
         if overlapped:
             line["overlapped_passes"] = overlapped
+        if cov_extra:
+            line["coverage_pass"] = cov_extra
         if ann_extra:
             line["annotation"] = ann_extra
         if not a.no_cpu_baseline and world == 1:

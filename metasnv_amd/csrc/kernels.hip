@@ -871,10 +871,12 @@ __global__ __launch_bounds__(C_NT) void msnv_coverage_tiles(const Pair32 *iv, co
                                                             unsigned long long *acc, uint32_t n_contigs, int max_cov) {
     __shared__ int s_d[TILE + 4];
     __shared__ int s_w[C_NT / 64];
+    __shared__ int s_acc[2][COV_BINS + 2];
     const WorkItem w = work[blockIdx.x];
     const uint32_t t0 = w.tile * TILE, tl = tile_len[w.tile], contig = tile_contig[w.tile];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < (int)(TILE + 4); i += C_NT) s_d[i] = 0;
+    if (tid < 2 * (COV_BINS + 2)) (&s_acc[0][0])[tid] = 0;
     __syncthreads();
     for (uint32_t k = w.pair_lo; k < w.pair_hi; ++k) {
         const TilePair pr = pairs[k];
@@ -906,14 +908,23 @@ __global__ __launch_bounds__(C_NT) void msnv_coverage_tiles(const Pair32 *iv, co
                 hp += 1ull << (4 * min(cv[j], max_cov));
             }
         }
-        unsigned long long *dst = acc + ((uint64_t)pr.sample * n_contigs + contig) * (1 + COV_BINS);
+        // reduce inside the workgroup first (wave DPP reduction, then LDS), so that one pair costs 1 + max_cov + 1 global
+        // atomics instead of that many per wavefront (the accumulators are 64-bit atomics at the memory side: they, not
+        // the arithmetic, bounded this kernel); s_acc is double-buffered so the flush needs no barrier of its own
+        int *sa = s_acc[k & 1u];
         const int ws = wave_reduce_add(csum);
-        if (lane == 0 && ws) atomicAdd(&dst[0], (unsigned long long)(long long)ws);
+        if (lane == 0 && ws) atomicAdd(&sa[0], ws);
         for (int b = 0; b <= max_cov; ++b) {
             const int wb = wave_reduce_add((int)((hp >> (4 * b)) & 15ull));
-            if (lane == 0 && wb) atomicAdd(&dst[1 + b], (unsigned long long)wb);
+            if (lane == 0 && wb) atomicAdd(&sa[1 + b], wb);
         }
         __syncthreads();
+        if (tid <= max_cov + 1) {
+            const int v = sa[tid];
+            sa[tid] = 0;
+            unsigned long long *dst = acc + ((uint64_t)pr.sample * n_contigs + contig) * (1 + COV_BINS);
+            if (v) atomicAdd(&dst[tid], (unsigned long long)(long long)v);
+        }
     }
 }
 
