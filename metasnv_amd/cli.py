@@ -121,7 +121,8 @@ def execute_snp_call(args, ctx, ifile, ofile, split):           # metaSNV.py:153
             ds.set_bed_file(split)
         ds.add_sample_bams(bams, args.threads)
         ds.finalize()
-        ds.run()
+        st = ds.run()
+        _write_metrics({"mode": "call", "split": split or "", "pileup": st, "dataset": ds.info()})
         ds.write_calls(ofile, ifile, args.db_ann or None, args.ref_db)
         return 0
     except core._lib.MsnvError as e:
@@ -129,6 +130,16 @@ def execute_snp_call(args, ctx, ifile, ofile, split):           # metaSNV.py:153
         return e.code
     finally:
         ds.close()
+
+
+def _write_metrics(obj):
+    """Kernel timings / counts of the run as JSON when MSNV_METRICS names a file (the reference has no metrics output;
+    nothing is written into the project directory unless asked)."""
+    path = os.environ.get("MSNV_METRICS")
+    if path:
+        import json
+        with open(path, "a") as f:
+            f.write(json.dumps(obj) + "\n")
 
 
 def fused_cov_and_call(args, ctx):
@@ -143,7 +154,8 @@ def fused_cov_and_call(args, ctx):
     try:
         ds.add_sample_bams(bams, args.threads)
         ds.finalize()
-        ds.fused_run()
+        st_p, st_c = ds.fused_run()
+        _write_metrics({"mode": "fused", "pileup": st_p, "coverage": st_c, "dataset": ds.info()})
         for i, b in enumerate(bams):
             out = os.path.join(cov_dir, os.path.basename(b) + '.cov')
             ds.write_coverage(i, out, out + '.detail')
