@@ -65,6 +65,7 @@ struct DeviceCols {
     Pair32   *events = nullptr;      // {gpos, sample<<18 | allele<<16 | count}
     Pair32   *overflow = nullptr;    // {gpos, sample<<16 | cov}
     uint32_t *counters = nullptr;    // [0] events [1] overflow [2] sites [3] error flags
+    uint32_t *ind_bits = nullptr;    // 1 bit per position: candidate of the individual rule (gate kernel)
     uint32_t  cap_events = 0, cap_overflow = 0, cap_sites = 0;
     SiteRec  *sites = nullptr;
     uint32_t *tile_site_base = nullptr, *tile_site_cnt = nullptr;
@@ -89,7 +90,7 @@ struct DeviceCols {
     struct AltBufs {
         uint32_t *tot = nullptr, *part = nullptr; uint8_t *spill = nullptr; Pair32 *events = nullptr, *overflow = nullptr;
         uint32_t *counters = nullptr; SiteRec *sites = nullptr; uint32_t *tile_site_base = nullptr, *tile_site_cnt = nullptr;
-        msnv_site_sample *out = nullptr; uint8_t *site_flags = nullptr;
+        msnv_site_sample *out = nullptr; uint8_t *site_flags = nullptr; uint32_t *ind_bits = nullptr;
         uint32_t cap_events = 0, cap_overflow = 0, cap_sites = 0; uint64_t cap_out_sites = 0;
     } alt;
     void     *stream2 = nullptr;

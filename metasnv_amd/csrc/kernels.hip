@@ -49,6 +49,8 @@ struct PileupArgs {
     Pair32         *overflow; uint32_t cap_overflow;
     uint32_t       *counters;
     uint32_t        min_baseq;
+    uint32_t       *ind_bits;     // 1 bit per position: some sample holds >= min_snvs reads of one mismatching allele
+    uint32_t        min_snvs;
 };
 
 // allele index (A,C,G,T -> 0..3) of a one-hot nt16 code, 4 for anything else
@@ -253,6 +255,7 @@ __global__ __launch_bounds__(W_NT) void msnv_pileup_tiles_wide(PileupArgs a) {
                     for (int x = 0; x < 4; ++x)
                         if (nn[x]) {
                             tn[j][x] += nn[x];
+                            if (nn[x] >= a.min_snvs) atomicOr(&a.ind_bits[gpos >> 5], 1u << (gpos & 31u));
                             stage_allele_event<WideLds, W_EVCAP>(L, a, Pair32{gpos, sample << 18 | (uint32_t)x << 16 | nn[x]});
                         }
                 }
@@ -375,6 +378,7 @@ __device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_
                 const uint32_t n = (word >> (8u * x)) & 0xffu;
                 if (n) {
                     atomicAdd(&a.tot[(uint64_t)x * a.npos + gpos], n);
+                    if (n >= a.min_snvs) atomicOr(&a.ind_bits[gpos >> 5], 1u << (gpos & 31u));   // rare: candidate of the individual rule
                     stage_allele_event<LDS, N_EVCAP>(L, a, Pair32{gpos, sample << 18 | x << 16 | n});
                 }
             }
@@ -664,8 +668,12 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_dense(PileupArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// msnv_gate_sites: snpCall's two gates (call_vC.cpp:545-552) plus the necessary condition of
-// both call kinds (some allele total >= calling_threshold).  One workgroup per tile; survivors
+// msnv_gate_sites: snpCall's two gates (call_vC.cpp:545-552) plus what either call kind needs of some allele x
+// (call_vC.cpp:588,593-600): n_x >= calling_threshold and (n_x >= cov * min_fraction  -- the population rule --  or
+// the position's individual-candidate bit, set by the pileup kernels when one sample holds >= calling_threshold reads of
+// a mismatching allele).  Only the case-sensitive skip-same-base rule is left to msnv_decide_sites, so the candidates
+// are essentially the called positions (10 773 -> 6 2xx on the benchmark shape; 51 903 -> 6 2xx with 320 samples, where
+// error alleles alone reach the threshold at many positions).  One workgroup per tile; survivors
 // are written in position order to a contiguous range reserved with one atomic per tile.
 // ------------------------------------------------------------------------------------------
 constexpr int GATE_NT = 256;
@@ -673,7 +681,7 @@ constexpr int GATE_CHUNKS = TILE / GATE_NT;
 
 __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const uint32_t *tot, const uint32_t *part, const uint32_t *tile_slot_start, uint64_t npos,
                                                            const uint32_t *tile_vbeg, const uint32_t *tile_vend,
-                                                           int min_cov, int min_snvs,
+                                                           int min_cov, int min_snvs, double min_frac, const uint32_t *ind_bits,
                                                            SiteRec *sites, uint32_t cap_sites, uint32_t *counters,
                                                            uint32_t *tile_site_base, uint32_t *tile_site_cnt) {
     __shared__ uint32_t s_wave[GATE_CHUNKS][GATE_NT / 64];
@@ -701,8 +709,13 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const uint32_t *tot, 
         bool ok = false;
         if (cov != 0u && p >= vb && p < ve && (int)cov >= min_cov) {
             const uint32_t nA = tot[g], nC = tot[npos + g], nG = tot[2 * npos + g], nT = tot[3 * npos + g];
-            const uint32_t mx = max(max(nA, nC), max(nG, nT));
-            ok = ((int)(nA + nC + nG + nT) >= min_snvs) && ((int)mx >= min_snvs);
+            if ((int)(nA + nC + nG + nT) >= min_snvs) {                      // call_vC.cpp:550
+                const bool ind = (ind_bits[g >> 5] >> (g & 31u)) & 1u;
+                const double lim = (double)(int)cov * min_frac;                // same arithmetic as msnv_decide_sites
+                const uint32_t nn[4] = {nA, nC, nG, nT};
+#pragma unroll
+                for (int x = 0; x < 4; ++x) ok |= (int)nn[x] >= min_snvs && (ind || (double)nn[x] >= lim);
+            }
         }
         const unsigned long long b = __ballot(ok);
         mypre[c] = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
@@ -961,7 +974,7 @@ void dev_free_all(DeviceCols &d) {
     for (void *p : aptrs) dev_free(p);
     for (void *e : d.timing_events) if (e) (void)hipEventDestroy((hipEvent_t)e);
     void *alts[] = {d.alt.tot, d.alt.part, d.alt.spill, d.alt.events, d.alt.overflow, d.alt.counters, d.alt.sites, d.alt.tile_site_base,
-                    d.alt.tile_site_cnt, d.alt.out, d.alt.site_flags};
+                    d.alt.tile_site_cnt, d.alt.out, d.alt.site_flags, d.alt.ind_bits, d.ind_bits};
     for (void *p : alts) dev_free(p);
     if (d.stream2) (void)hipStreamDestroy((hipStream_t)d.stream2);
     d = DeviceCols{};
@@ -987,6 +1000,7 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
     HIP_TRY(hipEventRecord(ev_begin, st));
     HIP_TRY(hipMemsetAsync(d.counters, 0, 8 * sizeof(uint32_t), st));
     if (npos) HIP_TRY(hipMemsetAsync(d.tot, 0, 4 * npos * sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(d.ind_bits, 0, (npos / 32 + 1) * sizeof(uint32_t), st));
     if (wait_before_pileup) HIP_TRY(hipStreamWaitEvent(st, wait_before_pileup, 0));   // the previous pass' pileup kernel (other stream)
     HIP_TRY(hipEventRecord(ev_pile0, st));
     if (d.n_work) {
@@ -996,6 +1010,7 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
         a.ref4 = d.ref4; a.pairs = d.pairs; a.work = d.work; a.chunks = d.chunks; a.tot = d.tot; a.part = d.part; a.npos = npos; a.spill = d.spill;
         a.events = d.events; a.cap_events = d.cap_events; a.overflow = d.overflow; a.cap_overflow = d.cap_overflow;
         a.counters = d.counters; a.min_baseq = (uint32_t)std::max(0, p.min_baseq);
+        a.ind_bits = d.ind_bits; a.min_snvs = (uint32_t)std::max(0, p.calling_threshold);
         static const bool all_wide = [] { const char *e = getenv("MSNV_PILEUP"); return e && e[0] == 'w'; }();   // A/B: MSNV_PILEUP=wide
         const uint32_t n_narrow = all_wide ? 0u : d.n_work_narrow;
         // narrow work items (byte bins) and wide ones (16-bit bins) touch disjoint (tile, sample) pairs
@@ -1011,7 +1026,7 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
     HIP_TRY(hipEventRecord(ev_pile1, st));
     if (d.n_tiles) {
         hipLaunchKernelGGL(msnv_gate_sites, dim3(d.n_tiles), dim3(GATE_NT), 0, st, d.tot, d.part, d.tile_slot_start, npos, d.tile_vbeg, d.tile_vend,
-                           p.min_coverage, p.calling_threshold, d.sites, d.cap_sites, d.counters, d.tile_site_base, d.tile_site_cnt);
+                           p.min_coverage, p.calling_threshold, p.min_fraction, d.ind_bits, d.sites, d.cap_sites, d.counters, d.tile_site_base, d.tile_site_cnt);
         HIP_TRY(hipGetLastError());
     }
     if (ev3) HIP_TRY(hipEventRecord(ev3, st));
@@ -1081,7 +1096,7 @@ static int ensure_alt(DeviceCols &d) {
     DeviceCols::AltBufs &a = d.alt;
     const uint64_t npos = (uint64_t)d.n_tiles * TILE;
     if (a.tot && a.cap_events == d.cap_events && a.cap_overflow == d.cap_overflow && a.cap_sites == d.cap_sites && a.cap_out_sites == d.cap_out_sites) return MSNV_OK;
-    void *old[] = {a.tot, a.part, a.spill, a.events, a.overflow, a.counters, a.sites, a.tile_site_base, a.tile_site_cnt, a.out, a.site_flags};
+    void *old[] = {a.tot, a.part, a.spill, a.events, a.overflow, a.counters, a.sites, a.tile_site_base, a.tile_site_cnt, a.out, a.site_flags, a.ind_bits};
     for (void *p : old) dev_free(p);
     a = DeviceCols::AltBufs{};
     if (int rc = dev_alloc((void **)&a.tot, std::max<uint64_t>(1, 4 * npos) * sizeof(uint32_t), &d.device_bytes)) return rc;
@@ -1091,6 +1106,7 @@ static int ensure_alt(DeviceCols &d) {
     if (int rc = dev_alloc((void **)&a.overflow, (uint64_t)d.cap_overflow * sizeof(Pair32), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.sites, (uint64_t)d.cap_sites * sizeof(SiteRec), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.counters, 16 * sizeof(uint32_t), &d.device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&a.ind_bits, (npos / 32 + 1) * sizeof(uint32_t), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.tile_site_base, ((uint64_t)d.n_tiles + 1) * sizeof(uint32_t), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.tile_site_cnt, ((uint64_t)d.n_tiles + 1) * sizeof(uint32_t), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.out, d.cap_out_sites * d.n_samples * sizeof(msnv_site_sample), &d.device_bytes)) return rc;
@@ -1103,7 +1119,7 @@ static void swap_sets(DeviceCols &d) {
     std::swap(d.tot, a.tot); std::swap(d.part, a.part); std::swap(d.spill, a.spill); std::swap(d.events, a.events);
     std::swap(d.overflow, a.overflow); std::swap(d.counters, a.counters); std::swap(d.sites, a.sites);
     std::swap(d.tile_site_base, a.tile_site_base); std::swap(d.tile_site_cnt, a.tile_site_cnt); std::swap(d.out, a.out);
-    std::swap(d.site_flags, a.site_flags);
+    std::swap(d.site_flags, a.site_flags); std::swap(d.ind_bits, a.ind_bits);
 }
 
 // n passes, ONE host synchronisation at the end; with `overlap` they are in flight on two streams (a queue of shards / repeated passes keeps the

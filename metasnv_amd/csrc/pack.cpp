@@ -413,7 +413,11 @@ int finalize_dataset(msnv_dataset &ds) {
         uint64_t total_reads_in_pairs = 0;
         for (const TilePair &p : pairs) total_reads_in_pairs += p.read_hi - p.read_lo;
         // work item size: pieces per workgroup.  MSNV_ITEM_PIECES overrides (tuning experiments).
-        uint64_t target = std::max<uint64_t>(1500, total_reads_in_pairs / 6144);
+        // ~1000 pieces (a few (tile, sample) pairs) per workgroup: measured on the benchmark shape (16 M pieces, one box,
+        // pileup kernel): 400 -> 0.616 ms, 700 -> 0.614, 1000 -> 0.599-0.615, 1500 -> 0.608-0.633, 2628 -> 0.636-0.644.
+        // Small items keep the last wave of workgroups short (an item of 2600 pieces runs ~190 us of a 640 us kernel);
+        // below ~700 the per-item costs (LDS init, partial row, gate summing more rows) take over.
+        uint64_t target = std::max<uint64_t>(1000, total_reads_in_pairs / 16384);
         if (const char *e = getenv("MSNV_ITEM_PIECES")) target = std::max<uint64_t>(64, (uint64_t)atoll(e));
         std::vector<WorkItem> wide;
         auto chunks_of = [&](const TilePair &q) -> uint64_t {
@@ -583,6 +587,7 @@ int finalize_dataset(msnv_dataset &ds) {
     if (int rc = dev_alloc((void **)&d->overflow, (uint64_t)d->cap_overflow * sizeof(Pair32), &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->sites, (uint64_t)d->cap_sites * sizeof(SiteRec), &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->counters, 16 * sizeof(uint32_t), &d->device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&d->ind_bits, (npos / 32 + 1) * sizeof(uint32_t), &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->tile_site_base, (nt + 1) * sizeof(uint32_t), &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->tile_site_cnt, (nt + 1) * sizeof(uint32_t), &d->device_bytes)) return rc;
     if (int rc = dev_memset(d->tile_site_cnt, 0, (nt + 1) * sizeof(uint32_t))) return rc;

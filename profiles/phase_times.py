@@ -2,10 +2,10 @@ import sys, os
 os.environ["MSNV_PHASE_TIMES"] = "1"
 sys.path.insert(0, os.getcwd())
 from metasnv_amd import core
-sp = core.synth_params(n_species=3, contig_len=300000, n_samples=160, mean_cov=10.0, seed=1)
+sp = core.synth_params(n_species=3, contig_len=300000, n_samples=int(os.environ.get("NS", "160")), mean_cov=10.0, seed=1)
 syn = core.Synth(sp); ctx = core.Context(0)
 ds = core.Dataset(ctx, syn.names, syn.lengths, syn.seqs)
-ds.add_synth_samples(sp, 0, 160, 0); ds.finalize()
+ds.add_synth_samples(sp, 0, sp.n_samples, 0); ds.finalize()
 for _ in range(3): ds.run()
 acc = {}
 for _ in range(20):
