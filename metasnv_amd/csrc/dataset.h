@@ -44,7 +44,7 @@ constexpr int DENSE_CHUNK_BLOCKS = 512;   // blocks per chunk descriptor (two ro
 
 struct TilePair { uint32_t sample, read_lo, read_hi, max_depth, blk_lo, nblk, seq0, pad; };    // reads of `sample` that may overlap the tile;
                                                                         // max_depth = upper bound of the per-position depth
-struct WorkItem { uint32_t tile, pair_lo, pair_hi, chunk_lo, chunk_hi, slot, pad[2]; };   // slot: row of the coverage partials (tile-major)
+struct WorkItem { uint32_t tile, pair_lo, pair_hi, chunk_lo, chunk_hi, slot, part_lo, part_hi; };   // slot: row of the coverage partials (tile-major); part_lo/hi: byte offset of the row
 // One chunk = up to CHUNK_READS consecutive reads of one (tile, sample) pair, with everything the
 // kernel needs to start loading (no dependent scalar loads on the critical path).
 constexpr uint32_t CHUNK_READS = 128;

@@ -59,13 +59,17 @@ struct DeviceCols {
     uint64_t  n_reads = 0, n_seq_bytes = 0;
     // ---- intermediates
     uint32_t *tot = nullptr;         // [4][n_tiles*TILE]: mismatching A, C, G, T summed over samples
-    uint32_t *part = nullptr;        // [n_work][TILE]: coverage partial of every work item (slots are tile-major)
+    uint8_t  *part = nullptr;        // coverage partial row of every work item (tile-major; u16 per position for narrow items, u32 for wide)
+    uint64_t *slot_off = nullptr;    // byte offset of every row; n_work + 1
+    uint32_t *tile_slot_wide = nullptr;   // first wide row of every tile
+    uint64_t  part_bytes = 0;
     uint32_t *tile_slot_start = nullptr;   // n_tiles + 1
     uint8_t  *spill = nullptr;       // [n_pairs][TILE] per-sample coverage, saturating at 255
     Pair32   *events = nullptr;      // {gpos, sample<<18 | allele<<16 | count}
     Pair32   *overflow = nullptr;    // {gpos, sample<<16 | cov}
     uint32_t *counters = nullptr;    // [0] events [1] overflow [2] sites [3] error flags
     uint32_t *ind_bits = nullptr;    // 1 bit per position: candidate of the individual rule (gate kernel)
+    unsigned long long *site_bits = nullptr;   // 1 bit per position: is a site (written by the gate kernel for every tile)
     uint32_t  cap_events = 0, cap_overflow = 0, cap_sites = 0;
     SiteRec  *sites = nullptr;
     uint32_t *tile_site_base = nullptr, *tile_site_cnt = nullptr;
@@ -88,9 +92,9 @@ struct DeviceCols {
     // second set of per-pass intermediates + second stream: msnv_pileup_run_many alternates passes between the two sets so
     // that the small tail kernels of pass i overlap with the pileup kernel of pass i+1 (allocated on first use)
     struct AltBufs {
-        uint32_t *tot = nullptr, *part = nullptr; uint8_t *spill = nullptr; Pair32 *events = nullptr, *overflow = nullptr;
+        uint32_t *tot = nullptr; uint8_t *part = nullptr; uint8_t *spill = nullptr; Pair32 *events = nullptr, *overflow = nullptr;
         uint32_t *counters = nullptr; SiteRec *sites = nullptr; uint32_t *tile_site_base = nullptr, *tile_site_cnt = nullptr;
-        msnv_site_sample *out = nullptr; uint8_t *site_flags = nullptr; uint32_t *ind_bits = nullptr;
+        msnv_site_sample *out = nullptr; uint8_t *site_flags = nullptr; uint32_t *ind_bits = nullptr; unsigned long long *site_bits = nullptr;
         uint32_t cap_events = 0, cap_overflow = 0, cap_sites = 0; uint64_t cap_out_sites = 0;
     } alt;
     void     *stream2 = nullptr;

@@ -42,7 +42,7 @@ struct PileupArgs {
     const WorkItem *work;
     const ChunkDesc *chunks;
     uint32_t       *tot;          // [4][npos]: A, C, G, T mismatch totals over all samples (atomics, sparse)
-    uint32_t       *part;         // [work item slot][TILE]: coverage summed over the item's samples (plain stores)
+    uint8_t        *part;         // coverage summed over the item's samples, one row per work item (plain stores)
     uint64_t        npos;
     uint8_t        *spill;
     Pair32         *events;   uint32_t cap_events;
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(W_NT) void msnv_pileup_tiles_wide(PileupArgs a) {
     __syncthreads();
     flush_events<WideLds, W_NT, W_EVCAP>(L, a, tid);
 
-    *reinterpret_cast<uint4 *>(a.part + (uint64_t)w.slot * TILE + W_PPT * tid) = make_uint4(tc[0], tc[1], tc[2], tc[3]);
+    *reinterpret_cast<uint4 *>(a.part + ((uint64_t)w.part_hi << 32 | w.part_lo) + 4u * W_PPT * tid) = make_uint4(tc[0], tc[1], tc[2], tc[3]);   // u32 row
 #pragma unroll
     for (int j = 0; j < W_PPT; ++j) {
         const uint64_t g = (uint64_t)t0 + W_PPT * tid + j;
@@ -507,9 +507,9 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32(PileupArgs a)
     }
     __syncthreads();
     flush_events<NarrowLds, N_NT, N_EVCAP>(L, a, tid);
-    uint4 *pp = reinterpret_cast<uint4 *>(a.part + (uint64_t)w.slot * TILE + N_PPT * tid);   // this item's coverage partial
-    pp[0] = make_uint4(tc[0], tc[1], tc[2], tc[3]);
-    pp[1] = make_uint4(tc[4], tc[5], tc[6], tc[7]);
+    // this item's coverage partial: 8 positions x u16 (an item holds <= 32 pairs of depth < 255)
+    *reinterpret_cast<uint4 *>(a.part + ((uint64_t)w.part_hi << 32 | w.part_lo) + 2u * N_PPT * tid) =
+        make_uint4(tc[0] | tc[1] << 16, tc[2] | tc[3] << 16, tc[4] | tc[5] << 16, tc[6] | tc[7] << 16);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -662,9 +662,9 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_dense(PileupArgs a) {
     }
     __syncthreads();
     flush_events<DenseLds, N_NT, N_EVCAP>(L, a, tid);
-    uint4 *pp = reinterpret_cast<uint4 *>(a.part + (uint64_t)w.slot * TILE + N_PPT * tid);   // this item's coverage partial
-    pp[0] = make_uint4(tc[0], tc[1], tc[2], tc[3]);
-    pp[1] = make_uint4(tc[4], tc[5], tc[6], tc[7]);
+    // this item's coverage partial: 8 positions x u16 (an item holds <= 32 pairs of depth < 255)
+    *reinterpret_cast<uint4 *>(a.part + ((uint64_t)w.part_hi << 32 | w.part_lo) + 2u * N_PPT * tid) =
+        make_uint4(tc[0] | tc[1] << 16, tc[2] | tc[3] << 16, tc[4] | tc[5] << 16, tc[6] | tc[7] << 16);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -679,10 +679,11 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_dense(PileupArgs a) {
 constexpr int GATE_NT = 256;
 constexpr int GATE_CHUNKS = TILE / GATE_NT;
 
-__global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const uint32_t *tot, const uint32_t *part, const uint32_t *tile_slot_start, uint64_t npos,
+__global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const uint32_t *tot, const uint8_t *part, const uint64_t *slot_off, const uint32_t *tile_slot_start,
+                                                           const uint32_t *tile_slot_wide, uint64_t npos,
                                                            const uint32_t *tile_vbeg, const uint32_t *tile_vend,
                                                            int min_cov, int min_snvs, double min_frac, const uint32_t *ind_bits,
-                                                           SiteRec *sites, uint32_t cap_sites, uint32_t *counters,
+                                                           unsigned long long *site_bits, SiteRec *sites, uint32_t cap_sites, uint32_t *counters,
                                                            uint32_t *tile_site_base, uint32_t *tile_site_cnt) {
     __shared__ uint32_t s_wave[GATE_CHUNKS][GATE_NT / 64];
     __shared__ uint32_t s_base;
@@ -696,8 +697,14 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const uint32_t *tot, 
     uint32_t mypre[GATE_CHUNKS], covs[GATE_CHUNKS];
 #pragma unroll
     for (int c = 0; c < GATE_CHUNKS; ++c) covs[c] = 0;
-    for (uint32_t s = slot_lo; s < slot_hi; ++s) {           // coverage = sum of the tile's work-item partials
-        const uint32_t *pp = part + (uint64_t)s * TILE + tid;
+    const uint32_t slot_w = tile_slot_wide[tile];
+    for (uint32_t s = slot_lo; s < slot_w; ++s) {            // coverage = sum of the tile's work-item partials: u16 rows ...
+        const uint16_t *pp = reinterpret_cast<const uint16_t *>(part + slot_off[s]) + tid;
+#pragma unroll
+        for (int c = 0; c < GATE_CHUNKS; ++c) covs[c] += pp[c * GATE_NT];
+    }
+    for (uint32_t s = slot_w; s < slot_hi; ++s) {            // ... and the u32 rows of the wide items
+        const uint32_t *pp = reinterpret_cast<const uint32_t *>(part + slot_off[s]) + tid;
 #pragma unroll
         for (int c = 0; c < GATE_CHUNKS; ++c) covs[c] += pp[c * GATE_NT];
     }
@@ -718,6 +725,7 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const uint32_t *tot, 
             }
         }
         const unsigned long long b = __ballot(ok);
+        if (lane == 0) site_bits[(g - (uint64_t)lane) >> 6] = b;       // 1 bit per position: is a site (msnv_scatter_events filters on it)
         mypre[c] = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
         if (lane == 0) s_wave[c][wave] = (uint32_t)__popcll(b);
         flags |= (ok ? 1u : 0u) << c;
@@ -799,18 +807,20 @@ __device__ __forceinline__ int find_site(const SiteRec *sites, uint32_t base, ui
 
 // msnv_scatter_events: per-sample allele counts (sparse) and >=255 coverages into the site records.
 __global__ void msnv_scatter_events(const Pair32 *events, const Pair32 *overflow, const uint32_t *counters, uint32_t cap_events,
-                                    uint32_t cap_overflow, const SiteRec *sites, const uint32_t *tile_site_base,
+                                    uint32_t cap_overflow, const unsigned long long *site_bits, const SiteRec *sites, const uint32_t *tile_site_base,
                                     const uint32_t *tile_site_cnt, msnv_site_sample *out, uint32_t n_samples, uint32_t cap_out) {
     const uint32_t n_events = min(counters[0], cap_events), n_overflow = min(counters[1], cap_overflow);
     if (counters[2] > cap_out) return;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_events + n_overflow; i += gridDim.x * blockDim.x) {
         if (i < n_events) {
             const Pair32 e = events[i];
+            if (!((site_bits[e.x >> 6] >> (e.x & 63u)) & 1ull)) continue;      // most events are sequencing errors at positions that are not sites
             const uint32_t tile = e.x / TILE;
             const int s = find_site(sites, tile_site_base[tile], tile_site_cnt[tile], e.x);
             if (s >= 0) out[(uint64_t)s * n_samples + (e.y >> 18)].n[(e.y >> 16) & 3u] = (uint16_t)(e.y & 0xffffu);
         } else {
             const Pair32 e = overflow[i - n_events];
+            if (!((site_bits[e.x >> 6] >> (e.x & 63u)) & 1ull)) continue;
             const uint32_t tile = e.x / TILE;
             const int s = find_site(sites, tile_site_base[tile], tile_site_cnt[tile], e.x);
             if (s >= 0) out[(uint64_t)s * n_samples + (e.y >> 16)].cov = (uint16_t)(e.y & 0xffffu);
@@ -966,7 +976,7 @@ void dev_stream_destroy(void *stream) { if (stream) (void)hipStreamDestroy((hipS
 
 void dev_free_all(DeviceCols &d) {
     void *ptrs[] = {d.hdr, d.hdr8, d.blk, d.seq, d.qual, d.s_read_base, d.s_seq_base, d.ref4, d.ref_lc, d.pairs,
-                    d.tile_pair_start, d.work, d.chunks, d.tile_vbeg, d.tile_vend, d.tot, d.part, d.tile_slot_start, d.spill, d.events, d.overflow, d.counters,
+                    d.tile_pair_start, d.work, d.chunks, d.tile_vbeg, d.tile_vend, d.tot, d.part, d.tile_slot_start, d.tile_slot_wide, d.slot_off, d.spill, d.events, d.overflow, d.counters,
                     d.sites, d.tile_site_base, d.tile_site_cnt, d.out, d.site_flags,
                     d.cov_iv, d.s_cov_base, d.cov_pairs, d.cov_work, d.tile_len, d.tile_contig_dev, d.cov_acc};
     for (void *p : ptrs) dev_free(p);
@@ -974,7 +984,7 @@ void dev_free_all(DeviceCols &d) {
     for (void *p : aptrs) dev_free(p);
     for (void *e : d.timing_events) if (e) (void)hipEventDestroy((hipEvent_t)e);
     void *alts[] = {d.alt.tot, d.alt.part, d.alt.spill, d.alt.events, d.alt.overflow, d.alt.counters, d.alt.sites, d.alt.tile_site_base,
-                    d.alt.tile_site_cnt, d.alt.out, d.alt.site_flags, d.alt.ind_bits, d.ind_bits};
+                    d.alt.tile_site_cnt, d.alt.out, d.alt.site_flags, d.alt.ind_bits, d.ind_bits, d.alt.site_bits, d.site_bits};
     for (void *p : alts) dev_free(p);
     if (d.stream2) (void)hipStreamDestroy((hipStream_t)d.stream2);
     d = DeviceCols{};
@@ -1011,8 +1021,7 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
         a.events = d.events; a.cap_events = d.cap_events; a.overflow = d.overflow; a.cap_overflow = d.cap_overflow;
         a.counters = d.counters; a.min_baseq = (uint32_t)std::max(0, p.min_baseq);
         a.ind_bits = d.ind_bits; a.min_snvs = (uint32_t)std::max(0, p.calling_threshold);
-        static const bool all_wide = [] { const char *e = getenv("MSNV_PILEUP"); return e && e[0] == 'w'; }();   // A/B: MSNV_PILEUP=wide
-        const uint32_t n_narrow = all_wide ? 0u : d.n_work_narrow;
+        const uint32_t n_narrow = d.n_work_narrow;
         // narrow work items (byte bins) and wide ones (16-bit bins) touch disjoint (tile, sample) pairs
         if (n_narrow && d.dense) hipLaunchKernelGGL(msnv_pileup_tiles_dense, dim3(n_narrow), dim3(N_NT), 0, st, a);
         else if (n_narrow) hipLaunchKernelGGL(msnv_pileup_tiles_narrow32, dim3(n_narrow), dim3(N_NT), 0, st, a);
@@ -1025,8 +1034,8 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
     }
     HIP_TRY(hipEventRecord(ev_pile1, st));
     if (d.n_tiles) {
-        hipLaunchKernelGGL(msnv_gate_sites, dim3(d.n_tiles), dim3(GATE_NT), 0, st, d.tot, d.part, d.tile_slot_start, npos, d.tile_vbeg, d.tile_vend,
-                           p.min_coverage, p.calling_threshold, p.min_fraction, d.ind_bits, d.sites, d.cap_sites, d.counters, d.tile_site_base, d.tile_site_cnt);
+        hipLaunchKernelGGL(msnv_gate_sites, dim3(d.n_tiles), dim3(GATE_NT), 0, st, d.tot, d.part, d.slot_off, d.tile_slot_start, d.tile_slot_wide, npos, d.tile_vbeg, d.tile_vend,
+                           p.min_coverage, p.calling_threshold, p.min_fraction, d.ind_bits, d.site_bits, d.sites, d.cap_sites, d.counters, d.tile_site_base, d.tile_site_cnt);
         HIP_TRY(hipGetLastError());
     }
     if (ev3) HIP_TRY(hipEventRecord(ev3, st));
@@ -1037,7 +1046,7 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
                            d.tile_pair_start, d.pairs, d.spill, d.out, d.n_samples, cap_out);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(msnv_scatter_events, dim3(1024), dim3(256), 0, st, d.events, d.overflow, d.counters, d.cap_events,
-                           d.cap_overflow, d.sites, d.tile_site_base, d.tile_site_cnt, d.out, d.n_samples, cap_out);
+                           d.cap_overflow, d.site_bits, d.sites, d.tile_site_base, d.tile_site_cnt, d.out, d.n_samples, cap_out);
         HIP_TRY(hipGetLastError());
     }
     if (ev4) HIP_TRY(hipEventRecord(ev4, st));
@@ -1096,17 +1105,18 @@ static int ensure_alt(DeviceCols &d) {
     DeviceCols::AltBufs &a = d.alt;
     const uint64_t npos = (uint64_t)d.n_tiles * TILE;
     if (a.tot && a.cap_events == d.cap_events && a.cap_overflow == d.cap_overflow && a.cap_sites == d.cap_sites && a.cap_out_sites == d.cap_out_sites) return MSNV_OK;
-    void *old[] = {a.tot, a.part, a.spill, a.events, a.overflow, a.counters, a.sites, a.tile_site_base, a.tile_site_cnt, a.out, a.site_flags, a.ind_bits};
+    void *old[] = {a.tot, a.part, a.spill, a.events, a.overflow, a.counters, a.sites, a.tile_site_base, a.tile_site_cnt, a.out, a.site_flags, a.ind_bits, a.site_bits};
     for (void *p : old) dev_free(p);
     a = DeviceCols::AltBufs{};
     if (int rc = dev_alloc((void **)&a.tot, std::max<uint64_t>(1, 4 * npos) * sizeof(uint32_t), &d.device_bytes)) return rc;
-    if (int rc = dev_alloc((void **)&a.part, std::max<uint64_t>(1, d.n_work) * TILE * sizeof(uint32_t), &d.device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&a.part, d.part_bytes, &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.spill, std::max<uint64_t>(1, d.n_pairs) * TILE, &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.events, (uint64_t)d.cap_events * sizeof(Pair32), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.overflow, (uint64_t)d.cap_overflow * sizeof(Pair32), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.sites, (uint64_t)d.cap_sites * sizeof(SiteRec), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.counters, 16 * sizeof(uint32_t), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.ind_bits, (npos / 32 + 1) * sizeof(uint32_t), &d.device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&a.site_bits, (npos / 64 + 1) * sizeof(unsigned long long), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.tile_site_base, ((uint64_t)d.n_tiles + 1) * sizeof(uint32_t), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.tile_site_cnt, ((uint64_t)d.n_tiles + 1) * sizeof(uint32_t), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.out, d.cap_out_sites * d.n_samples * sizeof(msnv_site_sample), &d.device_bytes)) return rc;
@@ -1119,7 +1129,7 @@ static void swap_sets(DeviceCols &d) {
     std::swap(d.tot, a.tot); std::swap(d.part, a.part); std::swap(d.spill, a.spill); std::swap(d.events, a.events);
     std::swap(d.overflow, a.overflow); std::swap(d.counters, a.counters); std::swap(d.sites, a.sites);
     std::swap(d.tile_site_base, a.tile_site_base); std::swap(d.tile_site_cnt, a.tile_site_cnt); std::swap(d.out, a.out);
-    std::swap(d.site_flags, a.site_flags); std::swap(d.ind_bits, a.ind_bits);
+    std::swap(d.site_flags, a.site_flags); std::swap(d.ind_bits, a.ind_bits); std::swap(d.site_bits, a.site_bits);
 }
 
 // n passes, ONE host synchronisation at the end; with `overlap` they are in flight on two streams (a queue of shards / repeated passes keeps the

@@ -435,22 +435,35 @@ int finalize_dataset(msnv_dataset &ds) {
                 const bool boundary = k + 1 == tps[t + 1] || (narrow != (pairs[k + 1].max_depth < NARROW_MAX_DEPTH));
                 const uint64_t next_ch = boundary ? 0 : chunks_of(pairs[k + 1]);
                 if (acc >= target || boundary || nch + next_ch > MAX_CHUNKS_PER_ITEM) {
-                    (narrow ? work : wide).push_back(WorkItem{(uint32_t)t, lo, k + 1, 0, 0, 0, {0, 0}}); lo = k + 1; acc = 0; nch = 0;
+                    (narrow ? work : wide).push_back(WorkItem{(uint32_t)t, lo, k + 1, 0, 0, 0, 0, 0}); lo = k + 1; acc = 0; nch = 0;
                 }
             }
         }
         d->n_work_narrow = (uint32_t)work.size();
         work.insert(work.end(), wide.begin(), wide.end());
     }
-    // ---- coverage partials: one row per work item, rows of a tile contiguous (the gate kernel sums them)
+    // ---- coverage partials: one row per work item (u16 per position for narrow items: <= 32 pairs x 254; u32 for wide
+    // ones), rows of a tile contiguous with the narrow rows first (the gate kernel sums them)
     {
-        std::vector<uint32_t> tss(nt + 1, 0);
+        std::vector<uint32_t> tss(nt + 1, 0), twide(nt + 1, 0);
         for (const WorkItem &w : work) ++tss[w.tile + 1];
         for (uint64_t t = 0; t < nt; ++t) tss[t + 1] += tss[t];
         std::vector<uint32_t> fill(tss.begin(), tss.end() - 1);
-        for (WorkItem &w : work) w.slot = fill[w.tile]++;
+        std::vector<uint8_t> slot_wide(work.size(), 0);
+        for (size_t i = 0; i < work.size(); ++i) { work[i].slot = fill[work[i].tile]++; slot_wide[work[i].slot] = i >= d->n_work_narrow; }
+        std::vector<uint64_t> off(work.size() + 1, 0);
+        for (size_t s = 0; s < work.size(); ++s) off[s + 1] = off[s] + (uint64_t)TILE * (slot_wide[s] ? 4u : 2u);
+        for (WorkItem &w : work) { w.part_lo = (uint32_t)off[w.slot]; w.part_hi = (uint32_t)(off[w.slot] >> 32); }
+        for (uint64_t t = 0; t < nt; ++t) {                    // first wide row of every tile (narrow rows come first)
+            uint32_t s = tss[t];
+            while (s < tss[t + 1] && !slot_wide[s]) ++s;
+            twide[t] = s;
+        }
+        d->part_bytes = std::max<uint64_t>(16, off[work.size()]);
         if (int rc = upload_vec(&d->tile_slot_start, tss, &d->device_bytes)) return rc;
-        if (int rc = dev_alloc((void **)&d->part, std::max<uint64_t>(1, work.size()) * TILE * sizeof(uint32_t), &d->device_bytes)) return rc;
+        if (int rc = upload_vec(&d->tile_slot_wide, twide, &d->device_bytes)) return rc;
+        if (int rc = upload_vec(&d->slot_off, off, &d->device_bytes)) return rc;
+        if (int rc = dev_alloc((void **)&d->part, d->part_bytes, &d->device_bytes)) return rc;
     }
     // ---- chunk descriptors of the narrow work items
     std::vector<ChunkDesc> chunks;
@@ -556,7 +569,7 @@ int finalize_dataset(msnv_dataset &ds) {
             uint32_t lo = cps[t]; uint64_t acc = 0;
             for (uint32_t k = cps[t]; k < cps[t + 1]; ++k) {
                 acc += cpairs[k].read_hi - cpairs[k].read_lo;
-                if (acc >= 4096 || k + 1 == cps[t + 1]) { cwork.push_back(WorkItem{(uint32_t)t, lo, k + 1, 0, 0, 0, {0, 0}}); lo = k + 1; acc = 0; }
+                if (acc >= 4096 || k + 1 == cps[t + 1]) { cwork.push_back(WorkItem{(uint32_t)t, lo, k + 1, 0, 0, 0, 0, 0}); lo = k + 1; acc = 0; }
             }
         }
         std::vector<uint32_t> tlen(nt + 1, 0), tcont(nt + 1, 0);
@@ -588,6 +601,7 @@ int finalize_dataset(msnv_dataset &ds) {
     if (int rc = dev_alloc((void **)&d->sites, (uint64_t)d->cap_sites * sizeof(SiteRec), &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->counters, 16 * sizeof(uint32_t), &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->ind_bits, (npos / 32 + 1) * sizeof(uint32_t), &d->device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&d->site_bits, (npos / 64 + 1) * sizeof(unsigned long long), &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->tile_site_base, (nt + 1) * sizeof(uint32_t), &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->tile_site_cnt, (nt + 1) * sizeof(uint32_t), &d->device_bytes)) return rc;
     if (int rc = dev_memset(d->tile_site_cnt, 0, (nt + 1) * sizeof(uint32_t))) return rc;
