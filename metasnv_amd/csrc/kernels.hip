@@ -698,15 +698,24 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const uint32_t *tot, 
 #pragma unroll
     for (int c = 0; c < GATE_CHUNKS; ++c) covs[c] = 0;
     const uint32_t slot_w = tile_slot_wide[tile];
-    for (uint32_t s = slot_lo; s < slot_w; ++s) {            // coverage = sum of the tile's work-item partials: u16 rows ...
-        const uint16_t *pp = reinterpret_cast<const uint16_t *>(part + slot_off[s]) + tid;
+    // coverage = sum of the tile's work-item partials.  The rows of a tile are contiguous (u16 rows first, then the u32
+    // rows of wide items), so the addresses need no per-row lookup and the loads of several rows are in flight together.
+    if (slot_w > slot_lo) {
+        const uint16_t *p16 = reinterpret_cast<const uint16_t *>(part + slot_off[slot_lo]) + tid;
+        const uint32_t n16 = slot_w - slot_lo;
+#pragma unroll 4
+        for (uint32_t s = 0; s < n16; ++s) {
 #pragma unroll
-        for (int c = 0; c < GATE_CHUNKS; ++c) covs[c] += pp[c * GATE_NT];
+            for (int c = 0; c < GATE_CHUNKS; ++c) covs[c] += p16[(uint64_t)s * TILE + c * GATE_NT];
+        }
     }
-    for (uint32_t s = slot_w; s < slot_hi; ++s) {            // ... and the u32 rows of the wide items
-        const uint32_t *pp = reinterpret_cast<const uint32_t *>(part + slot_off[s]) + tid;
+    if (slot_hi > slot_w) {
+        const uint32_t *p32 = reinterpret_cast<const uint32_t *>(part + slot_off[slot_w]) + tid;
+        const uint32_t n32 = slot_hi - slot_w;
+        for (uint32_t s = 0; s < n32; ++s) {
 #pragma unroll
-        for (int c = 0; c < GATE_CHUNKS; ++c) covs[c] += pp[c * GATE_NT];
+            for (int c = 0; c < GATE_CHUNKS; ++c) covs[c] += p32[(uint64_t)s * TILE + c * GATE_NT];
+        }
     }
 #pragma unroll
     for (int c = 0; c < GATE_CHUNKS; ++c) {
