@@ -70,6 +70,7 @@ struct DeviceCols {
     uint32_t *counters = nullptr;    // [0] events [1] overflow [2] sites [3] error flags
     uint32_t *ind_bits = nullptr;    // 1 bit per position: candidate of the individual rule (gate kernel)
     unsigned long long *site_bits = nullptr;   // 1 bit per position: is a site (written by the gate kernel for every tile)
+    uint32_t *site_rank = nullptr;   // per 64 positions: index of their first site (tiles with sites only)
     uint32_t  cap_events = 0, cap_overflow = 0, cap_sites = 0;
     SiteRec  *sites = nullptr;
     uint32_t *tile_site_base = nullptr, *tile_site_cnt = nullptr;
@@ -94,7 +95,7 @@ struct DeviceCols {
     struct AltBufs {
         uint32_t *tot = nullptr; uint8_t *part = nullptr; uint8_t *spill = nullptr; Pair32 *events = nullptr, *overflow = nullptr;
         uint32_t *counters = nullptr; SiteRec *sites = nullptr; uint32_t *tile_site_base = nullptr, *tile_site_cnt = nullptr;
-        msnv_site_sample *out = nullptr; uint8_t *site_flags = nullptr; uint32_t *ind_bits = nullptr; unsigned long long *site_bits = nullptr;
+        msnv_site_sample *out = nullptr; uint8_t *site_flags = nullptr; uint32_t *ind_bits = nullptr; unsigned long long *site_bits = nullptr; uint32_t *site_rank = nullptr;
         uint32_t cap_events = 0, cap_overflow = 0, cap_sites = 0; uint64_t cap_out_sites = 0;
     } alt;
     void     *stream2 = nullptr;

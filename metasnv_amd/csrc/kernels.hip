@@ -683,7 +683,7 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const uint32_t *tot, 
                                                            const uint32_t *tile_slot_wide, uint64_t npos,
                                                            const uint32_t *tile_vbeg, const uint32_t *tile_vend,
                                                            int min_cov, int min_snvs, double min_frac, const uint32_t *ind_bits,
-                                                           unsigned long long *site_bits, SiteRec *sites, uint32_t cap_sites, uint32_t *counters,
+                                                           unsigned long long *site_bits, uint32_t *site_rank, SiteRec *sites, uint32_t cap_sites, uint32_t *counters,
                                                            uint32_t *tile_site_base, uint32_t *tile_site_cnt) {
     __shared__ uint32_t s_wave[GATE_CHUNKS][GATE_NT / 64];
     __shared__ uint32_t s_base;
@@ -761,6 +761,8 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const uint32_t *tot, 
     const uint32_t base = s_base;
 #pragma unroll
     for (int c = 0; c < GATE_CHUNKS; ++c) {
+        // index of the first site of this wavefront's 64 positions: an event finds its site as rank + popcount of the lower bits
+        if (lane == 0) site_rank[((uint64_t)t0 + (uint32_t)c * GATE_NT + (uint32_t)tid) >> 6] = base + mybase[c];
         if (flags & (1u << c)) {
             const uint32_t idx = base + mybase[c] + mypre[c];
             if (idx < cap_sites) {
@@ -805,35 +807,19 @@ __global__ __launch_bounds__(256) void msnv_gather_cov(const SiteRec *sites, con
     }
 }
 
-__device__ __forceinline__ int find_site(const SiteRec *sites, uint32_t base, uint32_t n, uint32_t gpos) {
-    uint32_t lo = 0, hi = n;
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (sites[base + mid].gpos < gpos) lo = mid + 1; else hi = mid;
-    }
-    return (lo < n && sites[base + lo].gpos == gpos) ? (int)(base + lo) : -1;
-}
-
 // msnv_scatter_events: per-sample allele counts (sparse) and >=255 coverages into the site records.
 __global__ void msnv_scatter_events(const Pair32 *events, const Pair32 *overflow, const uint32_t *counters, uint32_t cap_events,
-                                    uint32_t cap_overflow, const unsigned long long *site_bits, const SiteRec *sites, const uint32_t *tile_site_base,
-                                    const uint32_t *tile_site_cnt, msnv_site_sample *out, uint32_t n_samples, uint32_t cap_out) {
+                                    uint32_t cap_overflow, const unsigned long long *site_bits, const uint32_t *site_rank,
+                                    msnv_site_sample *out, uint32_t n_samples, uint32_t cap_out) {
     const uint32_t n_events = min(counters[0], cap_events), n_overflow = min(counters[1], cap_overflow);
     if (counters[2] > cap_out) return;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_events + n_overflow; i += gridDim.x * blockDim.x) {
-        if (i < n_events) {
-            const Pair32 e = events[i];
-            if (!((site_bits[e.x >> 6] >> (e.x & 63u)) & 1ull)) continue;      // most events are sequencing errors at positions that are not sites
-            const uint32_t tile = e.x / TILE;
-            const int s = find_site(sites, tile_site_base[tile], tile_site_cnt[tile], e.x);
-            if (s >= 0) out[(uint64_t)s * n_samples + (e.y >> 18)].n[(e.y >> 16) & 3u] = (uint16_t)(e.y & 0xffffu);
-        } else {
-            const Pair32 e = overflow[i - n_events];
-            if (!((site_bits[e.x >> 6] >> (e.x & 63u)) & 1ull)) continue;
-            const uint32_t tile = e.x / TILE;
-            const int s = find_site(sites, tile_site_base[tile], tile_site_cnt[tile], e.x);
-            if (s >= 0) out[(uint64_t)s * n_samples + (e.y >> 16)].cov = (uint16_t)(e.y & 0xffffu);
-        }
+        const Pair32 e = (i < n_events) ? events[i] : overflow[i - n_events];
+        const unsigned long long w = site_bits[e.x >> 6], bit = 1ull << (e.x & 63u);
+        if (!(w & bit)) continue;                  // most events are sequencing errors at positions that are not sites
+        const uint32_t s = site_rank[e.x >> 6] + (uint32_t)__popcll(w & (bit - 1ull));
+        if (i < n_events) out[(uint64_t)s * n_samples + (e.y >> 18)].n[(e.y >> 16) & 3u] = (uint16_t)(e.y & 0xffffu);
+        else out[(uint64_t)s * n_samples + (e.y >> 16)].cov = (uint16_t)(e.y & 0xffffu);
     }
 }
 
@@ -993,7 +979,7 @@ void dev_free_all(DeviceCols &d) {
     for (void *p : aptrs) dev_free(p);
     for (void *e : d.timing_events) if (e) (void)hipEventDestroy((hipEvent_t)e);
     void *alts[] = {d.alt.tot, d.alt.part, d.alt.spill, d.alt.events, d.alt.overflow, d.alt.counters, d.alt.sites, d.alt.tile_site_base,
-                    d.alt.tile_site_cnt, d.alt.out, d.alt.site_flags, d.alt.ind_bits, d.ind_bits, d.alt.site_bits, d.site_bits};
+                    d.alt.tile_site_cnt, d.alt.out, d.alt.site_flags, d.alt.ind_bits, d.ind_bits, d.alt.site_bits, d.site_bits, d.alt.site_rank, d.site_rank};
     for (void *p : alts) dev_free(p);
     if (d.stream2) (void)hipStreamDestroy((hipStream_t)d.stream2);
     d = DeviceCols{};
@@ -1044,7 +1030,7 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
     HIP_TRY(hipEventRecord(ev_pile1, st));
     if (d.n_tiles) {
         hipLaunchKernelGGL(msnv_gate_sites, dim3(d.n_tiles), dim3(GATE_NT), 0, st, d.tot, d.part, d.slot_off, d.tile_slot_start, d.tile_slot_wide, npos, d.tile_vbeg, d.tile_vend,
-                           p.min_coverage, p.calling_threshold, p.min_fraction, d.ind_bits, d.site_bits, d.sites, d.cap_sites, d.counters, d.tile_site_base, d.tile_site_cnt);
+                           p.min_coverage, p.calling_threshold, p.min_fraction, d.ind_bits, d.site_bits, d.site_rank, d.sites, d.cap_sites, d.counters, d.tile_site_base, d.tile_site_cnt);
         HIP_TRY(hipGetLastError());
     }
     if (ev3) HIP_TRY(hipEventRecord(ev3, st));
@@ -1055,7 +1041,7 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
                            d.tile_pair_start, d.pairs, d.spill, d.out, d.n_samples, cap_out);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(msnv_scatter_events, dim3(1024), dim3(256), 0, st, d.events, d.overflow, d.counters, d.cap_events,
-                           d.cap_overflow, d.site_bits, d.sites, d.tile_site_base, d.tile_site_cnt, d.out, d.n_samples, cap_out);
+                           d.cap_overflow, d.site_bits, d.site_rank, d.out, d.n_samples, cap_out);
         HIP_TRY(hipGetLastError());
     }
     if (ev4) HIP_TRY(hipEventRecord(ev4, st));
@@ -1114,7 +1100,7 @@ static int ensure_alt(DeviceCols &d) {
     DeviceCols::AltBufs &a = d.alt;
     const uint64_t npos = (uint64_t)d.n_tiles * TILE;
     if (a.tot && a.cap_events == d.cap_events && a.cap_overflow == d.cap_overflow && a.cap_sites == d.cap_sites && a.cap_out_sites == d.cap_out_sites) return MSNV_OK;
-    void *old[] = {a.tot, a.part, a.spill, a.events, a.overflow, a.counters, a.sites, a.tile_site_base, a.tile_site_cnt, a.out, a.site_flags, a.ind_bits, a.site_bits};
+    void *old[] = {a.tot, a.part, a.spill, a.events, a.overflow, a.counters, a.sites, a.tile_site_base, a.tile_site_cnt, a.out, a.site_flags, a.ind_bits, a.site_bits, a.site_rank};
     for (void *p : old) dev_free(p);
     a = DeviceCols::AltBufs{};
     if (int rc = dev_alloc((void **)&a.tot, std::max<uint64_t>(1, 4 * npos) * sizeof(uint32_t), &d.device_bytes)) return rc;
@@ -1126,6 +1112,7 @@ static int ensure_alt(DeviceCols &d) {
     if (int rc = dev_alloc((void **)&a.counters, 16 * sizeof(uint32_t), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.ind_bits, (npos / 32 + 1) * sizeof(uint32_t), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.site_bits, (npos / 64 + 1) * sizeof(unsigned long long), &d.device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&a.site_rank, (npos / 64 + 1) * sizeof(uint32_t), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.tile_site_base, ((uint64_t)d.n_tiles + 1) * sizeof(uint32_t), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.tile_site_cnt, ((uint64_t)d.n_tiles + 1) * sizeof(uint32_t), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.out, d.cap_out_sites * d.n_samples * sizeof(msnv_site_sample), &d.device_bytes)) return rc;
@@ -1138,7 +1125,7 @@ static void swap_sets(DeviceCols &d) {
     std::swap(d.tot, a.tot); std::swap(d.part, a.part); std::swap(d.spill, a.spill); std::swap(d.events, a.events);
     std::swap(d.overflow, a.overflow); std::swap(d.counters, a.counters); std::swap(d.sites, a.sites);
     std::swap(d.tile_site_base, a.tile_site_base); std::swap(d.tile_site_cnt, a.tile_site_cnt); std::swap(d.out, a.out);
-    std::swap(d.site_flags, a.site_flags); std::swap(d.ind_bits, a.ind_bits); std::swap(d.site_bits, a.site_bits);
+    std::swap(d.site_flags, a.site_flags); std::swap(d.ind_bits, a.ind_bits); std::swap(d.site_bits, a.site_bits); std::swap(d.site_rank, a.site_rank);
 }
 
 // n passes, ONE host synchronisation at the end; with `overlap` they are in flight on two streams (a queue of shards / repeated passes keeps the

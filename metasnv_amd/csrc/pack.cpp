@@ -604,6 +604,7 @@ int finalize_dataset(msnv_dataset &ds) {
     if (int rc = dev_alloc((void **)&d->counters, 16 * sizeof(uint32_t), &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->ind_bits, (npos / 32 + 1) * sizeof(uint32_t), &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->site_bits, (npos / 64 + 1) * sizeof(unsigned long long), &d->device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&d->site_rank, (npos / 64 + 1) * sizeof(uint32_t), &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->tile_site_base, (nt + 1) * sizeof(uint32_t), &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->tile_site_cnt, (nt + 1) * sizeof(uint32_t), &d->device_bytes)) return rc;
     if (int rc = dev_memset(d->tile_site_cnt, 0, (nt + 1) * sizeof(uint32_t))) return rc;
