@@ -59,6 +59,8 @@ struct DeviceCols {
     uint64_t  n_reads = 0, n_seq_bytes = 0;
     // ---- intermediates
     uint32_t *tot = nullptr;         // [4][n_tiles*TILE]: mismatching A, C, G, T summed over samples
+    uint32_t *active_tiles = nullptr; // tiles that hold work items (gate / gather run over these only)
+    uint32_t  n_active_tiles = 0;
     uint8_t  *part = nullptr;        // coverage partial row of every work item (tile-major; u16 per position for narrow items, u32 for wide)
     uint64_t *slot_off = nullptr;    // byte offset of every row; n_work + 1
     uint32_t *tile_slot_wide = nullptr;   // first wide row of every tile

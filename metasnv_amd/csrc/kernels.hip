@@ -679,22 +679,22 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_dense(PileupArgs a) {
 constexpr int GATE_NT = 256;
 constexpr int GATE_CHUNKS = TILE / GATE_NT;
 
-__global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const uint32_t *tot, const uint8_t *part, const uint64_t *slot_off, const uint32_t *tile_slot_start,
+__global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(uint32_t *tot, const uint8_t *part, const uint64_t *slot_off, const uint32_t *tile_slot_start,
                                                            const uint32_t *tile_slot_wide, uint64_t npos,
                                                            const uint32_t *tile_vbeg, const uint32_t *tile_vend,
                                                            int min_cov, int min_snvs, double min_frac, const uint32_t *ind_bits,
                                                            unsigned long long *site_bits, uint32_t *site_rank, SiteRec *sites, uint32_t cap_sites, uint32_t *counters,
-                                                           uint32_t *tile_site_base, uint32_t *tile_site_cnt) {
+                                                           uint32_t *tile_site_base, uint32_t *tile_site_cnt, const uint32_t *active_tiles) {
     __shared__ uint32_t s_wave[GATE_CHUNKS][GATE_NT / 64];
     __shared__ uint32_t s_base;
-    const uint32_t tile = blockIdx.x;
+    const uint32_t tile = active_tiles[blockIdx.x];           // tiles that hold work items; the others have no coverage
     const uint32_t t0 = tile * TILE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t vb = tile_vbeg[tile], ve = tile_vend[tile];
 
     const uint32_t slot_lo = tile_slot_start[tile], slot_hi = tile_slot_start[tile + 1];
     uint32_t flags = 0;
-    uint32_t mypre[GATE_CHUNKS], covs[GATE_CHUNKS];
+    uint32_t mypre[GATE_CHUNKS], covs[GATE_CHUNKS], nal[GATE_CHUNKS][4];
 #pragma unroll
     for (int c = 0; c < GATE_CHUNKS; ++c) covs[c] = 0;
     const uint32_t slot_w = tile_slot_wide[tile];
@@ -723,14 +723,21 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const uint32_t *tot, 
         const uint64_t g = (uint64_t)t0 + p;
         const uint32_t cov = covs[c];
         bool ok = false;
-        if (cov != 0u && p >= vb && p < ve && (int)cov >= min_cov) {
+        nal[c][0] = nal[c][1] = nal[c][2] = nal[c][3] = 0;
+        if (cov != 0u) {                                              // mismatching bases are counted bases: no coverage, no allele totals
             const uint32_t nA = tot[g], nC = tot[npos + g], nG = tot[2 * npos + g], nT = tot[3 * npos + g];
-            if ((int)(nA + nC + nG + nT) >= min_snvs) {                      // call_vC.cpp:550
+            nal[c][0] = nA; nal[c][1] = nC; nal[c][2] = nG; nal[c][3] = nT;
+            // the totals are consumed here and here only: leave them zero for the next pass (no 16 B/position memset per pass,
+            // which is what a large sparse reference would mostly pay for)
+            if (nA) tot[g] = 0;
+            if (nC) tot[npos + g] = 0;
+            if (nG) tot[2 * npos + g] = 0;
+            if (nT) tot[3 * npos + g] = 0;
+            if (p >= vb && p < ve && (int)cov >= min_cov && (int)(nA + nC + nG + nT) >= min_snvs) {   // call_vC.cpp:547,550
                 const bool ind = (ind_bits[g >> 5] >> (g & 31u)) & 1u;
                 const double lim = (double)(int)cov * min_frac;                // same arithmetic as msnv_decide_sites
-                const uint32_t nn[4] = {nA, nC, nG, nT};
 #pragma unroll
-                for (int x = 0; x < 4; ++x) ok |= (int)nn[x] >= min_snvs && (ind || (double)nn[x] >= lim);
+                for (int x = 0; x < 4; ++x) ok |= (int)nal[c][x] >= min_snvs && (ind || (double)nal[c][x] >= lim);
             }
         }
         const unsigned long long b = __ballot(ok);
@@ -769,7 +776,7 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const uint32_t *tot, 
                 const uint64_t g = (uint64_t)t0 + (uint32_t)c * GATE_NT + (uint32_t)tid;
                 SiteRec s;
                 s.gpos = (uint32_t)g; s.cov = covs[c];
-                s.n[0] = tot[g]; s.n[1] = tot[npos + g]; s.n[2] = tot[2 * npos + g]; s.n[3] = tot[3 * npos + g];
+                s.n[0] = nal[c][0]; s.n[1] = nal[c][1]; s.n[2] = nal[c][2]; s.n[3] = nal[c][3];
                 sites[idx] = s;
             }
         }
@@ -783,8 +790,8 @@ constexpr uint32_t GATHER_SPLIT = 4;
 __global__ __launch_bounds__(256) void msnv_gather_cov(const SiteRec *sites, const uint32_t *tile_site_base,
                                                        const uint32_t *tile_site_cnt, const uint32_t *tile_pair_start,
                                                        const TilePair *pairs, const uint8_t *spill,
-                                                       msnv_site_sample *out, uint32_t n_samples, uint32_t cap_out) {
-    const uint32_t tile = blockIdx.x / GATHER_SPLIT, part = blockIdx.x % GATHER_SPLIT;   // a tile's sites are dealt to GATHER_SPLIT workgroups
+                                                       msnv_site_sample *out, uint32_t n_samples, uint32_t cap_out, const uint32_t *active_tiles) {
+    const uint32_t tile = active_tiles[blockIdx.x / GATHER_SPLIT], part = blockIdx.x % GATHER_SPLIT;   // a tile's sites are dealt to GATHER_SPLIT workgroups
     const uint32_t n = tile_site_cnt[tile];
     if (n <= part) return;
     const uint32_t base = tile_site_base[tile];
@@ -979,7 +986,7 @@ void dev_free_all(DeviceCols &d) {
     for (void *p : aptrs) dev_free(p);
     for (void *e : d.timing_events) if (e) (void)hipEventDestroy((hipEvent_t)e);
     void *alts[] = {d.alt.tot, d.alt.part, d.alt.spill, d.alt.events, d.alt.overflow, d.alt.counters, d.alt.sites, d.alt.tile_site_base,
-                    d.alt.tile_site_cnt, d.alt.out, d.alt.site_flags, d.alt.ind_bits, d.ind_bits, d.alt.site_bits, d.site_bits, d.alt.site_rank, d.site_rank};
+                    d.alt.tile_site_cnt, d.alt.out, d.alt.site_flags, d.alt.ind_bits, d.ind_bits, d.alt.site_bits, d.site_bits, d.alt.site_rank, d.site_rank, d.active_tiles};
     for (void *p : alts) dev_free(p);
     if (d.stream2) (void)hipStreamDestroy((hipStream_t)d.stream2);
     d = DeviceCols{};
@@ -1004,7 +1011,7 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
     const uint64_t npos = (uint64_t)d.n_tiles * TILE;
     HIP_TRY(hipEventRecord(ev_begin, st));
     HIP_TRY(hipMemsetAsync(d.counters, 0, 8 * sizeof(uint32_t), st));
-    if (npos) HIP_TRY(hipMemsetAsync(d.tot, 0, 4 * npos * sizeof(uint32_t), st));
+    // d.tot needs no memset: it is zero after finalize and msnv_gate_sites zeroes what a pass has written
     HIP_TRY(hipMemsetAsync(d.ind_bits, 0, (npos / 32 + 1) * sizeof(uint32_t), st));
     if (wait_before_pileup) HIP_TRY(hipStreamWaitEvent(st, wait_before_pileup, 0));   // the previous pass' pileup kernel (other stream)
     HIP_TRY(hipEventRecord(ev_pile0, st));
@@ -1028,17 +1035,17 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(ev_pile1, st));
-    if (d.n_tiles) {
-        hipLaunchKernelGGL(msnv_gate_sites, dim3(d.n_tiles), dim3(GATE_NT), 0, st, d.tot, d.part, d.slot_off, d.tile_slot_start, d.tile_slot_wide, npos, d.tile_vbeg, d.tile_vend,
-                           p.min_coverage, p.calling_threshold, p.min_fraction, d.ind_bits, d.site_bits, d.site_rank, d.sites, d.cap_sites, d.counters, d.tile_site_base, d.tile_site_cnt);
+    if (d.n_active_tiles) {
+        hipLaunchKernelGGL(msnv_gate_sites, dim3(d.n_active_tiles), dim3(GATE_NT), 0, st, d.tot, d.part, d.slot_off, d.tile_slot_start, d.tile_slot_wide, npos, d.tile_vbeg, d.tile_vend,
+                           p.min_coverage, p.calling_threshold, p.min_fraction, d.ind_bits, d.site_bits, d.site_rank, d.sites, d.cap_sites, d.counters, d.tile_site_base, d.tile_site_cnt, d.active_tiles);
         HIP_TRY(hipGetLastError());
     }
     if (ev3) HIP_TRY(hipEventRecord(ev3, st));
     // the tail runs on device-side counts: no host round trip inside a pass
     const uint32_t cap_out = (uint32_t)std::min<uint64_t>(d.cap_out_sites, 0xffffffffull);
-    if (d.n_tiles) {
-        hipLaunchKernelGGL(msnv_gather_cov, dim3(d.n_tiles * GATHER_SPLIT), dim3(256), 0, st, d.sites, d.tile_site_base, d.tile_site_cnt,
-                           d.tile_pair_start, d.pairs, d.spill, d.out, d.n_samples, cap_out);
+    if (d.n_active_tiles) {
+        hipLaunchKernelGGL(msnv_gather_cov, dim3(d.n_active_tiles * GATHER_SPLIT), dim3(256), 0, st, d.sites, d.tile_site_base, d.tile_site_cnt,
+                           d.tile_pair_start, d.pairs, d.spill, d.out, d.n_samples, cap_out, d.active_tiles);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(msnv_scatter_events, dim3(1024), dim3(256), 0, st, d.events, d.overflow, d.counters, d.cap_events,
                            d.cap_overflow, d.site_bits, d.site_rank, d.out, d.n_samples, cap_out);
@@ -1104,6 +1111,7 @@ static int ensure_alt(DeviceCols &d) {
     for (void *p : old) dev_free(p);
     a = DeviceCols::AltBufs{};
     if (int rc = dev_alloc((void **)&a.tot, std::max<uint64_t>(1, 4 * npos) * sizeof(uint32_t), &d.device_bytes)) return rc;
+    if (int rc = dev_memset(a.tot, 0, std::max<uint64_t>(1, 4 * npos) * sizeof(uint32_t))) return rc;
     if (int rc = dev_alloc((void **)&a.part, d.part_bytes, &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.spill, std::max<uint64_t>(1, d.n_pairs) * TILE, &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.events, (uint64_t)d.cap_events * sizeof(Pair32), &d.device_bytes)) return rc;
@@ -1115,6 +1123,8 @@ static int ensure_alt(DeviceCols &d) {
     if (int rc = dev_alloc((void **)&a.site_rank, (npos / 64 + 1) * sizeof(uint32_t), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.tile_site_base, ((uint64_t)d.n_tiles + 1) * sizeof(uint32_t), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.tile_site_cnt, ((uint64_t)d.n_tiles + 1) * sizeof(uint32_t), &d.device_bytes)) return rc;
+    if (int rc = dev_memset(a.tile_site_cnt, 0, ((uint64_t)d.n_tiles + 1) * sizeof(uint32_t))) return rc;
+    if (int rc = dev_memset(a.tile_site_base, 0, ((uint64_t)d.n_tiles + 1) * sizeof(uint32_t))) return rc;
     if (int rc = dev_alloc((void **)&a.out, d.cap_out_sites * d.n_samples * sizeof(msnv_site_sample), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.site_flags, d.cap_out_sites, &d.device_bytes)) return rc;
     a.cap_events = d.cap_events; a.cap_overflow = d.cap_overflow; a.cap_sites = d.cap_sites; a.cap_out_sites = d.cap_out_sites;

@@ -461,6 +461,10 @@ int finalize_dataset(msnv_dataset &ds) {
             while (s < tss[t + 1] && !slot_wide[s]) ++s;
             twide[t] = s;
         }
+        std::vector<uint32_t> active;
+        for (uint64_t t = 0; t < nt; ++t) if (tss[t + 1] > tss[t]) active.push_back((uint32_t)t);
+        d->n_active_tiles = (uint32_t)active.size();
+        if (int rc = upload_vec(&d->active_tiles, active, &d->device_bytes, 1)) return rc;
         d->part_bytes = std::max<uint64_t>(16, off[work.size()]);
         if (int rc = upload_vec(&d->tile_slot_start, tss, &d->device_bytes)) return rc;
         if (int rc = upload_vec(&d->tile_slot_wide, twide, &d->device_bytes)) return rc;
@@ -593,6 +597,7 @@ int finalize_dataset(msnv_dataset &ds) {
 
     // ---- intermediates
     if (int rc = dev_alloc((void **)&d->tot, std::max<uint64_t>(1, 4 * npos) * sizeof(uint32_t), &d->device_bytes)) return rc;
+    if (int rc = dev_memset(d->tot, 0, std::max<uint64_t>(1, 4 * npos) * sizeof(uint32_t))) return rc;   // the gate kernel keeps it zero between passes
     if (int rc = dev_alloc((void **)&d->spill, std::max<uint64_t>(1, (uint64_t)pairs.size()) * TILE, &d->device_bytes)) return rc;
     // sparse buffers: generous first guess, grown on MSNV_ECAPACITY by the caller
     d->cap_events = (uint32_t)std::min<uint64_t>(0x7fffffffull, std::max<uint64_t>(1u << 20, tot_bases / 16));
@@ -608,6 +613,7 @@ int finalize_dataset(msnv_dataset &ds) {
     if (int rc = dev_alloc((void **)&d->tile_site_base, (nt + 1) * sizeof(uint32_t), &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->tile_site_cnt, (nt + 1) * sizeof(uint32_t), &d->device_bytes)) return rc;
     if (int rc = dev_memset(d->tile_site_cnt, 0, (nt + 1) * sizeof(uint32_t))) return rc;
+    if (int rc = dev_memset(d->tile_site_base, 0, (nt + 1) * sizeof(uint32_t))) return rc;
 
     ds.info.n_samples = S; ds.info.n_contigs = 0; ds.info.n_positions = 0;
     for (size_t c = 0; c < NC; ++c) if (ds.sel[c]) { ds.info.n_contigs++; ds.info.n_positions += (uint64_t)ds.lengths[c]; }
