@@ -101,6 +101,8 @@ struct DeviceCols {
         uint32_t cap_events = 0, cap_overflow = 0, cap_sites = 0; uint64_t cap_out_sites = 0;
     } alt;
     void     *stream2 = nullptr;
+    std::vector<void *> event_pool;          // hipEvent_t of msnv_pileup_run_many
+    uint32_t *pinned_cnt = nullptr; size_t pinned_cnt_cap = 0;   // pinned host blocks for the per-pass counters
     void     *timing_events[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // hipEvent_t, reused by every pass
 };
 

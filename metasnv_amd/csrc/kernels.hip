@@ -985,6 +985,8 @@ void dev_free_all(DeviceCols &d) {
     void *aptrs[] = {d.ann.seg_beg, d.ann.seg_end, d.ann.seg_gene, d.ann.genes, d.ann.contigs, d.ann.codons, d.ann.out, d.ann.err};
     for (void *p : aptrs) dev_free(p);
     for (void *e : d.timing_events) if (e) (void)hipEventDestroy((hipEvent_t)e);
+    for (void *e : d.event_pool) (void)hipEventDestroy((hipEvent_t)e);
+    if (d.pinned_cnt) (void)hipHostFree(d.pinned_cnt);
     void *alts[] = {d.alt.tot, d.alt.part, d.alt.spill, d.alt.events, d.alt.overflow, d.alt.counters, d.alt.sites, d.alt.tile_site_base,
                     d.alt.tile_site_cnt, d.alt.out, d.alt.site_flags, d.alt.ind_bits, d.ind_bits, d.alt.site_bits, d.site_bits, d.alt.site_rank, d.site_rank, d.active_tiles};
     for (void *p : alts) dev_free(p);
@@ -1157,11 +1159,18 @@ int dev_run_pipeline_many(DeviceCols &d, const msnv_params &p, void *stream_, in
         if (int rc = ensure_alt(d)) return rc;
     }
     const bool two = s1 != s0;
-    std::vector<hipEvent_t> ev((size_t)4 * n + 2);          // per pass: begin, pile0, pile1, pileup-done marker; + two end events
-    for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
-    auto cleanup = [&]() { for (auto &e : ev) (void)hipEventDestroy(e); };
-    uint32_t *cnt = nullptr;
-    if (hipHostMalloc((void **)&cnt, (size_t)n * 8 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { cleanup(); return fail(MSNV_ENOMEM, "pinned host memory for %d counter blocks", n); }
+    // events and the pinned counter blocks are pooled in the dataset: creating ~4n events and a pinned buffer per call
+    // costs about a millisecond of host time before the first pass is even enqueued
+    while (d.event_pool.size() < (size_t)4 * n + 2) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); d.event_pool.push_back(e); }
+    hipEvent_t *ev = reinterpret_cast<hipEvent_t *>(d.event_pool.data());
+    auto cleanup = [] {};
+    if (d.pinned_cnt_cap < (size_t)n) {
+        if (d.pinned_cnt) (void)hipHostFree(d.pinned_cnt);
+        d.pinned_cnt = nullptr; d.pinned_cnt_cap = 0;
+        if (hipHostMalloc((void **)&d.pinned_cnt, (size_t)n * 8 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return fail(MSNV_ENOMEM, "pinned host memory for %d counter blocks", n);
+        d.pinned_cnt_cap = (size_t)n;
+    }
+    uint32_t *cnt = d.pinned_cnt;
     int rc = MSNV_OK;
     hipError_t he = hipSuccess;
     bool swapped = false;                                     // true while d's primary fields hold the second set
@@ -1195,7 +1204,6 @@ int dev_run_pipeline_many(DeviceCols &d, const msnv_params &p, void *stream_, in
         s.n_sites = c[2]; s.n_events = c[0]; s.n_overflow = c[1]; s.n_called_pop = c[4]; s.n_called_indiv = c[5];
         s.algorithmic_bytes = d.algorithmic_bytes;
     }
-    (void)hipHostFree(cnt);
     cleanup();
     return rc;
 }
