@@ -38,6 +38,27 @@ def test_no_device_means_loud_failure_not_fallback():
     assert "no CPU fallback" in str(e.value)
 
 
+@pytest.mark.skipif(core.device_count() > 0, reason="GPU present: the no-device failure path is not reachable")
+def test_drivers_refuse_to_run_without_a_gpu(tmp_path, golden_dir):
+    """metaSNV_Filtering / metaSNV_DistDiv mirrors: FILTER I and argument handling are host logic, everything that
+    computes needs the device -- they stop with an error instead of computing on the CPU."""
+    import shutil
+    from metasnv_amd import filtering, distdiv
+    proj = str(tmp_path / "proj")
+    shutil.copytree(os.path.join(golden_dir, "python_callers", "filtering2", "proj"), proj)
+    with pytest.raises(SystemExit) as e:
+        filtering.main([proj, "-m", "2", "-d", "1", "-b", "10"])
+    assert "no CPU fallback" in str(e.value)
+    dd = str(tmp_path / "dd" / "proj")                        # the table names derive from the directory name
+    shutil.copytree(os.path.join(golden_dir, "python_callers", "distdiv", "proj"), dd)
+    with pytest.raises(SystemExit) as e:
+        distdiv.main(["--filt", os.path.join(dd, "filtered", "pop"), "--dist"])
+    assert "no CPU fallback" in str(e.value)
+    with pytest.raises(SystemExit) as e:                       # options that are not built are refused, not skipped
+        distdiv.main(["--filt", os.path.join(dd, "filtered", "pop"), "--div"])
+    assert "not built" in str(e.value)
+
+
 def test_product_never_imports_the_oracle():
     # the oracle is test infrastructure: nothing under metasnv_amd/ may reference it
     for dp, _, files in os.walk(os.path.join(ROOT, "metasnv_amd")):
