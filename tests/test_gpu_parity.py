@@ -658,6 +658,26 @@ def test_cli_project_layout_and_contents(tmp_path, capsys):
         cli.main([proj, lst, fa])
 
 
+def test_full_testdata_shape_bit_exact(tmp_path):
+    """BASELINE configs[1] at FULL size (160 samples x 3 refGenomes x 300 kb, 1.49 G pileup bases): called_SNPs and
+    indiv_called of the HIP path are byte-identical to the oracle's (the single-threaded oracle needs ~35 s for it)."""
+    sp = core.synth_params(seed=1)
+    syn = core.Synth(sp)
+    samples = [syn.sample_records(i) for i in range(sp.n_samples)]
+    ctx = core.Context(0)
+    ds = core.Dataset(ctx, syn.names, syn.lengths, syn.seqs)
+    ds.add_synth_samples(sp, 0, sp.n_samples, 0)           # the same generator as sample_records, packed inside the library
+    info = ds.finalize()
+    st = ds.run()
+    pp, ip = str(tmp_path / "called_SNPs"), str(tmp_path / "indiv_called")
+    ds.write_calls(pp, ip)
+    ds.close(); ctx.close()
+    orac = run_oracle(syn.names, syn.lengths, syn.seqs, samples)
+    assert info["n_pileup_bases"] == orac[3] and info["n_samples"] == 160
+    _assert_same((open(pp).read(), open(ip).read()), orac)
+    assert st["n_called_pop"] == orac[0].count("\n") > 5000
+
+
 def test_full_testdata_shape_properties():
     """BASELINE configs[1] at full size (160 samples x 3 x 300 kb, 1.5 G pileup bases): too big for the
     oracle to finish in seconds, so the HIP path is checked through size-independent properties."""
