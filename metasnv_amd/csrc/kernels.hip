@@ -988,7 +988,7 @@ void dev_free_all(DeviceCols &d) {
     for (void *e : d.event_pool) (void)hipEventDestroy((hipEvent_t)e);
     if (d.pinned_cnt) (void)hipHostFree(d.pinned_cnt);
     void *alts[] = {d.alt.tot, d.alt.part, d.alt.spill, d.alt.events, d.alt.overflow, d.alt.counters, d.alt.sites, d.alt.tile_site_base,
-                    d.alt.tile_site_cnt, d.alt.out, d.alt.site_flags, d.alt.ind_bits, d.ind_bits, d.alt.site_bits, d.site_bits, d.alt.site_rank, d.site_rank, d.active_tiles};
+                    d.alt.tile_site_cnt, d.alt.out, d.alt.site_flags, d.alt.site_bits, d.site_bits, d.alt.site_rank, d.site_rank, d.active_tiles};
     for (void *p : alts) dev_free(p);
     if (d.stream2) (void)hipStreamDestroy((hipStream_t)d.stream2);
     d = DeviceCols{};
@@ -1012,9 +1012,8 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
                         hipEvent_t ev3, hipEvent_t ev4, uint32_t *host_cnt, hipEvent_t wait_before_pileup = nullptr) {
     const uint64_t npos = (uint64_t)d.n_tiles * TILE;
     HIP_TRY(hipEventRecord(ev_begin, st));
-    HIP_TRY(hipMemsetAsync(d.counters, 0, 8 * sizeof(uint32_t), st));
     // d.tot needs no memset: it is zero after finalize and msnv_gate_sites zeroes what a pass has written
-    HIP_TRY(hipMemsetAsync(d.ind_bits, 0, (npos / 32 + 1) * sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(d.counters, 0, (16 + npos / 32 + 1) * sizeof(uint32_t), st));   // counters + individual-candidate bits (one allocation)
     if (wait_before_pileup) HIP_TRY(hipStreamWaitEvent(st, wait_before_pileup, 0));   // the previous pass' pileup kernel (other stream)
     HIP_TRY(hipEventRecord(ev_pile0, st));
     if (d.n_work) {
@@ -1109,7 +1108,7 @@ static int ensure_alt(DeviceCols &d) {
     DeviceCols::AltBufs &a = d.alt;
     const uint64_t npos = (uint64_t)d.n_tiles * TILE;
     if (a.tot && a.cap_events == d.cap_events && a.cap_overflow == d.cap_overflow && a.cap_sites == d.cap_sites && a.cap_out_sites == d.cap_out_sites) return MSNV_OK;
-    void *old[] = {a.tot, a.part, a.spill, a.events, a.overflow, a.counters, a.sites, a.tile_site_base, a.tile_site_cnt, a.out, a.site_flags, a.ind_bits, a.site_bits, a.site_rank};
+    void *old[] = {a.tot, a.part, a.spill, a.events, a.overflow, a.counters, a.sites, a.tile_site_base, a.tile_site_cnt, a.out, a.site_flags, a.site_bits, a.site_rank};
     for (void *p : old) dev_free(p);
     a = DeviceCols::AltBufs{};
     if (int rc = dev_alloc((void **)&a.tot, std::max<uint64_t>(1, 4 * npos) * sizeof(uint32_t), &d.device_bytes)) return rc;
@@ -1119,8 +1118,8 @@ static int ensure_alt(DeviceCols &d) {
     if (int rc = dev_alloc((void **)&a.events, (uint64_t)d.cap_events * sizeof(Pair32), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.overflow, (uint64_t)d.cap_overflow * sizeof(Pair32), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.sites, (uint64_t)d.cap_sites * sizeof(SiteRec), &d.device_bytes)) return rc;
-    if (int rc = dev_alloc((void **)&a.counters, 16 * sizeof(uint32_t), &d.device_bytes)) return rc;
-    if (int rc = dev_alloc((void **)&a.ind_bits, (npos / 32 + 1) * sizeof(uint32_t), &d.device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&a.counters, (16 + npos / 32 + 1) * sizeof(uint32_t), &d.device_bytes)) return rc;
+    a.ind_bits = a.counters + 16;
     if (int rc = dev_alloc((void **)&a.site_bits, (npos / 64 + 1) * sizeof(unsigned long long), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.site_rank, (npos / 64 + 1) * sizeof(uint32_t), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.tile_site_base, ((uint64_t)d.n_tiles + 1) * sizeof(uint32_t), &d.device_bytes)) return rc;
