@@ -26,18 +26,18 @@ def build_parser():                                            # metaSNV_DistDiv
     return p
 
 
-def file_check(args):                                          # metaSNV_DistDiv.py:62-78
-    args.projdir = '/'.join(args.filt.rstrip('/').split('/')[:-2])
-    args.pars = args.filt.rstrip('/').split('/')[-2].strip('filtered')
-    args.coverage_file = args.projdir + '/' + args.projdir.split('/')[-1] + '.all_cov.tab'
-    args.percentage_file = args.projdir + '/' + args.projdir.split('/')[-1] + '.all_perc.tab'
+def file_check(args):                                          # metaSNV_DistDiv.py:62-78 (same messages, same exit)
+    parts = args.filt.rstrip('/').split('/')
+    args.projdir = '/'.join(parts[:-2])                        # .../<proj>/filtered<pars>/pop -> <proj>
+    args.pars = parts[-2].strip('filtered')
+    stem = args.projdir + '/' + args.projdir.split('/')[-1]
+    args.coverage_file, args.percentage_file = stem + '.all_cov.tab', stem + '.all_perc.tab'
     args.bedfile = args.projdir + '/' + 'bed_header'
+    needed = (args.coverage_file, args.percentage_file, args.bedfile)
     print("Checking for necessary input files...")
-    if os.path.isfile(args.coverage_file) and os.path.isfile(args.percentage_file) and os.path.isfile(args.bedfile):
-        print("found: '{}' \nfound:'{}' \nfound:'{}'".format(args.coverage_file, args.percentage_file, args.bedfile))
-    else:
-        sys.exit("\nERROR: No such file '{}',\nERROR: No such file '{}',\nERROR: No such file '{}'".format(
-            args.coverage_file, args.percentage_file, args.bedfile))
+    if not all(os.path.isfile(n) for n in needed):
+        sys.exit("\nERROR: No such file '{}',\nERROR: No such file '{}',\nERROR: No such file '{}'".format(*needed))
+    print("found: '{}' \nfound:'{}' \nfound:'{}'".format(*needed))
 
 
 def compute_dist(ctx, filt_file, outdir, threshold=.6):        # metaSNV_DistDiv.py:113-124

@@ -32,38 +32,34 @@ def build_parser():                                            # metaSNV_Filteri
     return p
 
 
-def file_check(args):                                          # metaSNV_Filtering.py:57-75
+def file_check(args):                                          # metaSNV_Filtering.py:57-75 (same messages, same exits)
     args.projdir = args.projdir.rstrip('/')
-    args.coverage_file = args.projdir + '/' + args.projdir.split('/')[-1] + '.all_cov.tab'
-    args.percentage_file = args.projdir + '/' + args.projdir.split('/')[-1] + '.all_perc.tab'
+    stem = args.projdir + '/' + args.projdir.split('/')[-1]
+    args.coverage_file, args.percentage_file = stem + '.all_cov.tab', stem + '.all_perc.tab'
     args.all_samples = args.projdir + '/' + 'all_samples'
     print("Checking for necessary input files...")
-    if os.path.isfile(args.coverage_file) and os.path.isfile(args.percentage_file):
-        print("found: '{}' \nfound:'{}'".format(args.coverage_file, args.percentage_file))
-    else:
-        sys.exit("\nERROR: No such file '{}',\nERROR: No such file '{}'".format(args.coverage_file, args.percentage_file))
-    if os.path.isfile(args.all_samples):
-        print("found: '{}'\n".format(args.all_samples))
-    else:
+    tables = (args.coverage_file, args.percentage_file)
+    if not all(os.path.isfile(t) for t in tables):
+        sys.exit("\nERROR: No such file '{}',\nERROR: No such file '{}'".format(*tables))
+    print("found: '{}' \nfound:'{}'".format(*tables))
+    if not os.path.isfile(args.all_samples):
         sys.exit("\nERROR: No such file '{}'".format(args.all_samples))
+    print("found: '{}'\n".format(args.all_samples))
 
 
-def print_arguments(args):                                     # metaSNV_Filtering.py:78-95
+_OPTION_LABELS = (('b', "threshold: percentage covered (breadth) {}"), ('d', "threshold: average coverage (depth) {}"),
+                  ('m', "threshold: Min. number samples_of_interest per taxid_of_interest {}"),
+                  ('c', "threshold: Min. position coverage per sample within samples_of_interest {}"),
+                  ('p', "threshold: Min. proportion of covered samples in samples_of_interest {}"),
+                  ('ind', "Compute indiv SNVs : {}"), ('n_threads', "Number of parallel processes : {}"))
+
+
+def print_arguments(args):                                     # metaSNV_Filtering.py:78-95: falsy options are not echoed
     print("Options:")
-    if args.b:
-        print("threshold: percentage covered (breadth) {}".format(args.b))
-    if args.d:
-        print("threshold: average coverage (depth) {}".format(args.d))
-    if args.m:
-        print("threshold: Min. number samples_of_interest per taxid_of_interest {}".format(args.m))
-    if args.c:
-        print("threshold: Min. position coverage per sample within samples_of_interest {}".format(args.c))
-    if args.p:
-        print("threshold: Min. proportion of covered samples in samples_of_interest {}".format(args.p))
-    if args.ind:
-        print("Compute indiv SNVs : {}".format(args.ind))
-    if args.n_threads:
-        print("Number of parallel processes : {}".format(args.n_threads))
+    for attr, label in _OPTION_LABELS:
+        value = getattr(args, attr)
+        if value:
+            print(label.format(value))
     print("")
 
 
