@@ -215,18 +215,37 @@ int pack_sample(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, Sa
                     sc.seq.resize(sc.seq.size() + (n + 1) / 2, 0xff);        // pad nibble = N
                     sc.alg_seq_bytes += (n + 1) / 2; sc.alg_qual_bytes += n;    // algorithmic bytes exclude the alignment padding
                     uint8_t *dst = sc.seq.data() + h.seqoff;
-                    for (uint32_t j = 0; j < n; ++j) {
-                        const int64_t qq = q + off + j;
-                        uint32_t code = (r.seq[qq >> 1] >> ((~qq & 1) << 2)) & 0xfu;
-                        if (code == 0) {          // '=' always counts as a match (pileup_seq): ship the reference code instead
-                            const int64_t g = rp + off + j;
-                            code = (has_ref && g >= 0 && (size_t)g < refseq.size()) ? nt16_of_char((unsigned char)refseq[(size_t)g]) : 15u;
-                            if (code == 0) code = 15u;
+                    // BAM packs base 2i in the HIGH nibble; the device wants base j of the piece in nibble j, low first.
+                    // Whole bytes at a time; a '=' base (code 0, rare) sends the piece through the per-base path below.
+                    const int64_t q0 = q + off;
+                    const uint8_t *src = r.seq + (q0 >> 1);
+                    bool has_eq = false;
+                    if (!(q0 & 1)) {
+                        for (uint32_t i = 0; i < n / 2; ++i) { const uint8_t b = src[i]; has_eq |= !(b & 0xf0u) || !(b & 0x0fu); dst[i] = (uint8_t)(b >> 4 | b << 4); }
+                        if (n & 1u) { const uint8_t b = (uint8_t)(src[n / 2] >> 4); has_eq |= !b; dst[n / 2] = (uint8_t)(0xf0u | b); }
+                    } else {
+                        for (uint32_t i = 0; i < n / 2; ++i) { const uint8_t lo = src[i] & 0x0fu, hi = src[i + 1] & 0xf0u; has_eq |= !lo || !hi; dst[i] = (uint8_t)(lo | hi); }
+                        if (n & 1u) { const uint8_t lo = src[n / 2] & 0x0fu; has_eq |= !lo; dst[n / 2] = (uint8_t)(0xf0u | lo); }
+                    }
+                    if (has_eq) {
+                        for (uint32_t j = 0; j < n; ++j) {
+                            const int64_t qq = q0 + j;
+                            uint32_t code = (r.seq[qq >> 1] >> ((~qq & 1) << 2)) & 0xfu;
+                            if (code == 0) {      // '=' always counts as a match (pileup_seq): ship the reference code instead
+                                const int64_t g = rp + off + j;
+                                code = (has_ref && g >= 0 && (size_t)g < refseq.size()) ? nt16_of_char((unsigned char)refseq[(size_t)g]) : 15u;
+                                if (code == 0) code = 15u;
+                            }
+                            const int sh = (int)(j & 1u) * 4;
+                            dst[j >> 1] = (uint8_t)((dst[j >> 1] & ~(0xf << sh)) | code << sh);  // low nibble first
                         }
-                        const int sh = (int)(j & 1u) * 4;
-                        dst[j >> 1] = (uint8_t)((dst[j >> 1] & ~(0xf << sh)) | code << sh);      // low nibble first
-                        // qualities above 127 (0xff = "not stored") pass every cutoff; clamping keeps the comparison
-                        sc.qual.push_back(r.qual[qq] > 127 ? 127 : r.qual[qq]);
+                    }
+                    {   // qualities above 127 (0xff = "not stored") pass every cutoff; clamping keeps the comparison
+                        const size_t qs = sc.qual.size();
+                        sc.qual.resize(qs + n);
+                        uint8_t *qd = sc.qual.data() + qs;
+                        const uint8_t *qsrc = r.qual + q0;
+                        for (uint32_t j = 0; j < n; ++j) qd[j] = qsrc[j] > 127 ? 127 : qsrc[j];
                     }
                     // every piece starts on an 8-byte (seq) / 16-byte (qual) boundary
                     while (sc.seq.size() & (seq_align - 1u)) sc.seq.push_back(0xff);
