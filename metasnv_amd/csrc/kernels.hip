@@ -386,6 +386,19 @@ __device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_
     }
 }
 
+// Ring refill of the chunk descriptors, called by every thread right after barrier (A) of chunk c: every
+// MAX_CHUNKS_PER_ITEM / 2 chunks the half of the ring that holds finished chunks [c - H, c) receives [c + H, c + 2H).
+// Those slots are next read at chunk c + H - 1 (prefetch of c + H), i.e. after at least one more barrier.
+__device__ __forceinline__ void desc_refill(ChunkDesc *ring, const ChunkDesc *src, const uint32_t c, const uint32_t nch, const int tid) {
+    constexpr uint32_t H = MAX_CHUNKS_PER_ITEM / 2;
+    if (c == 0u || (c % H) != 0u || c + H >= nch) return;
+    const uint32_t first = c + H, n = min(H, nch - first);
+    if ((uint32_t)tid < 2u * n) {
+        const uint32_t d = first + (uint32_t)tid / 2u;
+        reinterpret_cast<uint4 *>(ring + d % MAX_CHUNKS_PER_ITEM)[tid & 1] = reinterpret_cast<const uint4 *>(src + d)[tid & 1];
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // msnv_pileup_tiles_narrow32: FOUR lanes per piece, 32 bases per lane.
 // Perturbation runs on the earlier 16-bases-per-lane kernel showed the vector-memory (TA/L1) path to be
@@ -456,7 +469,9 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32(PileupArgs a)
     for (int j = 0; j < N_PPT; ++j) tc[j] = 0;
 
     const uint32_t nch = w.chunk_hi - w.chunk_lo;
-    for (uint32_t i = tid; i < nch * 2; i += N_NT)
+    // the chunk descriptors go through a ring of MAX_CHUNKS_PER_ITEM LDS slots: one deep (sample, tile) pair alone can
+    // hold more chunks than that, so half of the ring is refilled every MAX_CHUNKS_PER_ITEM / 2 chunks (desc_refill)
+    for (uint32_t i = tid; i < min(nch, (uint32_t)MAX_CHUNKS_PER_ITEM) * 2; i += N_NT)
         reinterpret_cast<uint4 *>(L.desc)[i] = reinterpret_cast<const uint4 *>(a.chunks + w.chunk_lo)[i];
     __syncthreads();
     uint2 hreg = make_uint2(0, 0);
@@ -465,13 +480,14 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32(PileupArgs a)
     int buf = 0;
 
     for (uint32_t c = 0; c < nch; ++c) {
-        const ChunkDesc cd = L.desc[c];
+        const ChunkDesc cd = L.desc[c % MAX_CHUNKS_PER_ITEM];
         const bool last_chunk = (cd.nrd_flags >> 16) != 0u;
         if (tid < N_HCAP) L.hdr[buf][tid] = hreg;                    // slots beyond nrd hold length 0
         hreg = make_uint2(0, 0);
-        if (c + 1 < nch && tid < N_HCAP && (uint32_t)tid < (L.desc[c + 1].nrd_flags & 0xffffu))
-            hreg = *reinterpret_cast<const uint2 *>(a.hdr8 + L.desc[c + 1].hdr_base + tid);
+        if (c + 1 < nch && tid < N_HCAP && (uint32_t)tid < (L.desc[(c + 1) % MAX_CHUNKS_PER_ITEM].nrd_flags & 0xffffu))
+            hreg = *reinterpret_cast<const uint2 *>(a.hdr8 + L.desc[(c + 1) % MAX_CHUNKS_PER_ITEM].hdr_base + tid);
         __syncthreads();                                            // (A)
+        desc_refill(L.desc, a.chunks + w.chunk_lo, c, nch, tid);
         if (L.evn >= (uint32_t)(N_EVCAP / 2)) flush_events<NarrowLds, N_NT, N_EVCAP>(L, a, tid);
 
         const uint8_t *seq = a.seq + cd.seq_base;
@@ -601,7 +617,9 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_dense(PileupArgs a) {
     for (int j = 0; j < N_PPT; ++j) tc[j] = 0;
 
     const uint32_t nch = w.chunk_hi - w.chunk_lo;
-    for (uint32_t i = tid; i < nch * 2; i += N_NT)
+    // the chunk descriptors go through a ring of MAX_CHUNKS_PER_ITEM LDS slots: one deep (sample, tile) pair alone can
+    // hold more chunks than that, so half of the ring is refilled every MAX_CHUNKS_PER_ITEM / 2 chunks (desc_refill)
+    for (uint32_t i = tid; i < min(nch, (uint32_t)MAX_CHUNKS_PER_ITEM) * 2; i += N_NT)
         reinterpret_cast<uint4 *>(L.desc)[i] = reinterpret_cast<const uint4 *>(a.chunks + w.chunk_lo)[i];
     __syncthreads();
     constexpr int ROUNDS = DENSE_CHUNK_BLOCKS / N_NT;           // 2
@@ -613,7 +631,7 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_dense(PileupArgs a) {
     }
 
     for (uint32_t c = 0; c < nch; ++c) {
-        const ChunkDesc cd = L.desc[c];
+        const ChunkDesc cd = L.desc[c % MAX_CHUNKS_PER_ITEM];
         const bool last_chunk = (cd.nrd_flags >> 16) != 0u;
         const uint32_t nblk = cd.nrd_flags & 0xffffu;
         uint32_t dcur[ROUNDS];
@@ -621,10 +639,11 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_dense(PileupArgs a) {
         for (int r = 0; r < ROUNDS; ++r) {
             dcur[r] = dnext[r];
             dnext[r] = BLK_EMPTY;
-            if (c + 1 < nch && (uint32_t)(r * N_NT + tid) < (L.desc[c + 1].nrd_flags & 0xffffu))
-                dnext[r] = a.blk[L.desc[c + 1].hdr_base + (uint32_t)(r * N_NT + tid)];
+            if (c + 1 < nch && (uint32_t)(r * N_NT + tid) < (L.desc[(c + 1) % MAX_CHUNKS_PER_ITEM].nrd_flags & 0xffffu))
+                dnext[r] = a.blk[L.desc[(c + 1) % MAX_CHUNKS_PER_ITEM].hdr_base + (uint32_t)(r * N_NT + tid)];
         }
         __syncthreads();                                            // (A) bins of the previous sample are zeroed
+        desc_refill(L.desc, a.chunks + w.chunk_lo, c, nch, tid);
         if (L.evn >= (uint32_t)(N_EVCAP / 2)) flush_events<DenseLds, N_NT, N_EVCAP>(L, a, tid);
 
         const uint8_t *seq = a.seq + cd.seq_base;

@@ -205,6 +205,19 @@ def test_read_filters_orphans_mapq_and_depth_cap():
     assert prod[0].count("\n") + prod[1].count("\n") > 0
 
 
+@pytest.mark.parametrize("layout", ["pieces", "dense"])
+def test_deep_pairs_with_more_chunks_than_the_descriptor_ring(layout, monkeypatch):
+    """A (sample, tile) pair just below the byte-bin depth limit with short reads holds far more 128-piece chunks than the
+    32 chunk descriptors a workgroup keeps in LDS (they go through a ring); mixed with pairs above the limit (wide kernel)."""
+    monkeypatch.setenv("MSNV_LAYOUT", layout)
+    syn, samples = synth_case(n_species=1, contig_len=5000, n_samples=5, mean_cov=170.0, sigma_cov=0.25, read_len=40, snv_density=0.02,
+                              frac_absent=0.0, seed=808)
+    prod = run_product(syn.names, syn.lengths, syn.seqs, samples)
+    orac = run_oracle(syn.names, syn.lengths, syn.seqs, samples)
+    _assert_same(prod, orac)
+    assert prod[2]["n_pileup_bases"] == orac[3] and prod[0].count("\n") > 20
+
+
 def test_annotation_codon_path(tmp_path):
     syn, samples = synth_case(n_species=2, contig_len=3000, n_samples=4, mean_cov=14.0, snv_density=0.03, frac_absent=0.0, seed=21)
     fa = str(tmp_path / "ref.fa")
