@@ -220,13 +220,13 @@ __global__ __launch_bounds__(W_NT) void msnv_pileup_tiles_wide(PileupArgs a) {
         if (last_chunk) {
             __syncthreads();                                        // (B) all exceptions of this sample are in LDS
             int4 sp = *reinterpret_cast<int4 *>(&L.span[W_PPT * tid]);
-            const uint2 ex = *reinterpret_cast<uint2 *>(&L.exc[tid]);
+            const uint2 ex = *reinterpret_cast<uint2 *>(&L.exc[2 * tid]);   // two u16 per word: words 2 tid, 2 tid + 1 hold my 4 positions
             unsigned long long al[W_PPT];
 #pragma unroll
             for (int j = 0; j < W_PPT; ++j) al[j] = L.al[W_PPT * tid + j];
             *reinterpret_cast<int4 *>(&L.span[W_PPT * tid]) = make_int4(0, 0, 0, 0);
             if (tid == 0) L.span[TILE] = 0;
-            L.exc[tid] = 0ull;
+            *reinterpret_cast<uint2 *>(&L.exc[2 * tid]) = make_uint2(0u, 0u);
 #pragma unroll
             for (int j = 0; j < W_PPT; ++j) L.al[W_PPT * tid + j] = 0ull;
             sp.y += sp.x; sp.z += sp.y; sp.w += sp.z;

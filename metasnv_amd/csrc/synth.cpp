@@ -114,13 +114,15 @@ void synth_sample_records(const msnv_synth_params &p, int sample, const std::vec
             int64_t pos = starts[(size_t)i];
             int rl = p.read_len;
             cigar.clear();
+            // offset of the indel inside the aligned part: 10 .. rl-21 for the usual read lengths, 2 .. rl-7 for reads below 40 bases
+            auto indel_at = [&](int len) { return len >= 40 ? 10 + (int)r.below((uint32_t)(len - 30)) : 2 + (int)r.below((uint32_t)std::max(1, len - 8)); };
             double u = r.uni();
             // CIGAR mix of SURVEY.md 8(d): M only | 5S..M | one I | one D | 3H..M
             int lead_clip = 0, hard = 0, ins_at = -1, ins_len = 0, del_at = -1, del_len = 0;
             if (u < p.frac_clip_reads * 0.8) lead_clip = 5;
             else if (u < p.frac_clip_reads) hard = 3;
-            else if (u < p.frac_clip_reads + p.frac_indel_reads * 0.57) { ins_len = 1 + (int)r.below(3); ins_at = 10 + (int)r.below((uint32_t)(rl - 30)); }
-            else if (u < p.frac_clip_reads + p.frac_indel_reads) { del_len = 1 + (int)r.below(3); del_at = 10 + (int)r.below((uint32_t)(rl - 30)); }
+            else if (u < p.frac_clip_reads + p.frac_indel_reads * 0.57) { ins_len = 1 + (int)r.below(3); ins_at = indel_at(rl); }
+            else if (u < p.frac_clip_reads + p.frac_indel_reads) { del_len = 1 + (int)r.below(3); del_at = indel_at(rl); }
             int l_seq = rl - hard;
             codes.assign((size_t)l_seq, 15); quals.assign((size_t)l_seq, 0);
             int q = 0; int64_t rp = pos;
