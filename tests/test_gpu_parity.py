@@ -740,3 +740,15 @@ def test_full_testdata_shape_properties():
                 assert (m_sub["n"][j, :, x] == samples["n"][i, 10:30, x]).all()
     assert hits > 500
     ctx.close()
+
+
+def test_randomised_parity_sweep(monkeypatch):
+    """A slice of the randomised sweep (tests/fuzz_parity.py: generator and caller parameters, read lengths 20-400, coverages
+    0.5-300x, both data layouts, BED splits, fused coverage, device annotation, batched / overlapped passes).  The full
+    sweep (thousands of cases) found the descriptor-ring and wide-kernel bugs this file now has regression tests for."""
+    import fuzz_parity
+    monkeypatch.delenv("MSNV_LAYOUT", raising=False)
+    try:
+        assert fuzz_parity.sweep(70, 2024, verbose=False) == 0
+    finally:
+        os.environ.pop("MSNV_LAYOUT", None)
