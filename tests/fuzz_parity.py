@@ -27,7 +27,8 @@ def sweep(n_cases, seed, verbose=True):
                   error_rate=rnd.choice([0.0, 0.001, 0.02]), frac_lowq=rnd.choice([0.0, 0.1, 0.5]), frac_indel_reads=rnd.choice([0.0, 0.04, 0.3]),
                   frac_clip_reads=rnd.choice([0.0, 0.03, 0.3]), frac_flagged=rnd.choice([0.0, 0.03]), lowercase_ref=rnd.choice([0, 1]), seed=rnd.randrange(1 << 30))
         pk = dict(min_coverage=rnd.choice([1, 4, 4, 10]), calling_threshold=rnd.choice([1, 2, 4, 4]), min_fraction=rnd.choice([0.01, 0.01, 0.2, 0.0]),
-                  min_baseq=rnd.choice([0, 13, 13, 30]))
+                  min_baseq=rnd.choice([0, 13, 13, 30]), max_depth=rnd.choice([8000, 8000, 8000, 60, 7]), min_mapq=rnd.choice([0, 0, 1, 30]),
+                  count_orphans=rnd.choice([0, 1]), flag_filter=rnd.choice([0x704, 0x704, 0x400, 0]))
         os.environ["MSNV_LAYOUT"] = rnd.choice(["pieces", "dense"])
         sp = core.synth_params(**kw)
         syn = core.Synth(sp)
