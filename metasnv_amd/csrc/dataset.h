@@ -59,6 +59,7 @@ struct SampleCols {
     std::vector<int32_t>  tid;       // per read
     std::vector<int32_t>  end;       // per read: contig-relative end of everything the kernels may touch
     std::vector<uint16_t> depth;     // per read: pileup reads alive when this one starts (saturating)
+    std::vector<uint16_t> grp;       // per piece: 0, or 1 + group of a deep (contig, tile) run that was split (pack.cpp: split_deep_runs)
     std::vector<uint8_t>  seq, qual;
     // dense layout (pack.cpp: relayout_dense): per (contig, tile) run of pieces a stream of 32-base blocks
     std::vector<uint32_t> blk;            // one descriptor per block (BLK_* fields)

@@ -328,7 +328,8 @@ struct NarrowLds {
 // and leaves every bin zero for the next sample.  Called by all threads; contains barriers (B), (C).
 template <typename LDS, int EXC_PAD>
 __device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_t (&tc)[N_PPT], const uint32_t t0,
-                                            const int tid, const int lane, const int wave, const uint32_t sample, const uint32_t k) {
+                                            const int tid, const int lane, const int wave, const uint32_t sample, const uint32_t k,
+                                            const uint32_t split) {
     __syncthreads();                                        // (B)
     const uint2 st = *reinterpret_cast<uint2 *>(&L.start[2 * tid]);
     const uint2 en = *reinterpret_cast<uint2 *>(&L.end[2 * tid]);
@@ -378,7 +379,8 @@ __device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_
                 const uint32_t n = (word >> (8u * x)) & 0xffu;
                 if (n) {
                     atomicAdd(&a.tot[(uint64_t)x * a.npos + gpos], n);
-                    if (n >= a.min_snvs) atomicOr(&a.ind_bits[gpos >> 5], 1u << (gpos & 31u));   // rare: candidate of the individual rule
+                    // candidate of the individual rule; a sample that was split into several pairs may reach the threshold only in sum
+                    if (n >= a.min_snvs || split) atomicOr(&a.ind_bits[gpos >> 5], 1u << (gpos & 31u));
                     stage_allele_event<LDS, N_EVCAP>(L, a, Pair32{gpos, sample << 18 | x << 16 | n});
                 }
             }
@@ -518,7 +520,7 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32(PileupArgs a)
         for (int i = 0; i < N32_ROUNDS; ++i)
             if (__any(vh[i] > 0)) narrow_classify32(L, qa[i], qb[i], sq[i], P0[i], vh[i], kq);
 
-        if (last_chunk) narrow_pass<NarrowLds, 0>(L, a, tc, t0, tid, lane, wave, cd.sample, cd.pair);
+        if (last_chunk) narrow_pass<NarrowLds, 0>(L, a, tc, t0, tid, lane, wave, cd.sample, cd.pair, cd.pad);
         buf ^= 1;
     }
     __syncthreads();
@@ -677,7 +679,7 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_dense(PileupArgs a) {
             dense_segment(L, sq[r], lq, P0A + 32u, 0, (int)nA);
             if (__any(hasB)) dense_segment(L, sq[r], lq, hasB ? PBv : 32u, hasB ? (int)sB : 32, 32);
         }
-        if (last_chunk) narrow_pass<DenseLds, D_PAD>(L, a, tc, t0, tid, lane, wave, cd.sample, cd.pair);
+        if (last_chunk) narrow_pass<DenseLds, D_PAD>(L, a, tc, t0, tid, lane, wave, cd.sample, cd.pair, cd.pad);
     }
     __syncthreads();
     flush_events<DenseLds, N_NT, N_EVCAP>(L, a, tid);
@@ -803,6 +805,13 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(uint32_t *tot, const 
 }
 
 // ------------------------------------------------------------------------------------------
+// The u16 fields of the site records are summed with 32-bit atomics on the aligned word that holds them (sums stay below
+// 65536: the depth cap is 8000), so that a sample which was split into several (sample, tile) pairs adds up.
+__device__ __forceinline__ void add_u16(uint16_t *field, uint32_t v) {
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(field);
+    atomicAdd(reinterpret_cast<uint32_t *>(addr & ~(uintptr_t)3), v << (8u * (uint32_t)(addr & 2u)));
+}
+
 // msnv_gather_cov: per-sample coverage of every surviving site, from the spilled bytes.
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t GATHER_SPLIT = 4;
@@ -829,7 +838,10 @@ __global__ __launch_bounds__(256) void msnv_gather_cov(const SiteRec *sites, con
         const uint32_t j = part + (uint32_t)(i / np) * GATHER_SPLIT, kk = (uint32_t)(i % np);
         const uint32_t off = sites[base + j].gpos - t0;
         const uint32_t cov = spill[(uint64_t)(ps + kk) * TILE + off];
-        out[(uint64_t)(base + j) * n_samples + pairs[ps + kk].sample].cov = (uint16_t)cov;   // 255 = see overflow list
+        const TilePair pr = pairs[ps + kk];
+        uint16_t *dst = &out[(uint64_t)(base + j) * n_samples + pr.sample].cov;
+        if (pr.pad) add_u16(dst, cov);                      // one of several pairs of this sample: the groups add up
+        else *dst = (uint16_t)cov;                          // 255 = see overflow list (wide kernel only)
     }
 }
 
@@ -844,7 +856,7 @@ __global__ void msnv_scatter_events(const Pair32 *events, const Pair32 *overflow
         const unsigned long long w = site_bits[e.x >> 6], bit = 1ull << (e.x & 63u);
         if (!(w & bit)) continue;                  // most events are sequencing errors at positions that are not sites
         const uint32_t s = site_rank[e.x >> 6] + (uint32_t)__popcll(w & (bit - 1ull));
-        if (i < n_events) out[(uint64_t)s * n_samples + (e.y >> 18)].n[(e.y >> 16) & 3u] = (uint16_t)(e.y & 0xffffu);
+        if (i < n_events) add_u16(&out[(uint64_t)s * n_samples + (e.y >> 18)].n[(e.y >> 16) & 3u], e.y & 0xffffu);   // one event per (site, pair, allele)
         else out[(uint64_t)s * n_samples + (e.y >> 16)].cov = (uint16_t)(e.y & 0xffffu);
     }
 }

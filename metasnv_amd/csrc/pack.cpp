@@ -32,6 +32,65 @@ static bool layout_dense(uint64_t n_pieces, uint64_t n_bases) {
     return n_pieces && n_bases / n_pieces < 72;
 }
 
+// A (contig, tile) run of one sample whose depth can reach NARROW_MAX_DEPTH does not fit the byte bins of the narrow
+// kernels.  Instead of a second kernel with wider bins, the run is dealt into groups of pieces that each stay below the
+// limit (round robin in start order, verified with an exact sweep, more groups if needed); every group becomes its own
+// (sample, tile) pair and the per-sample results are summed on the device (gather / scatter accumulate).  Pieces of a
+// group are made contiguous.  MSNV_DEEP=wide keeps such runs whole for msnv_pileup_tiles_wide instead.
+static bool deep_runs_split() {
+    const char *e = getenv("MSNV_DEEP");                     // read per dataset (tests switch it)
+    return !(e && e[0] == 'w');
+}
+static void split_deep_runs(SampleCols &sc) {
+    const size_t n = sc.hdr.size();
+    sc.grp.assign(n, 0);
+    if (!deep_runs_split()) return;
+    struct Ev { uint32_t pos; int32_t delta; uint32_t g; };
+    std::vector<Ev> ev;
+    std::vector<uint32_t> cur, mx, order;
+    size_t i = 0;
+    while (i < n) {
+        size_t j = i;
+        while (j < n && sc.tid[j] == sc.tid[i] && sc.hdr[j].gpos / TILE == sc.hdr[i].gpos / TILE) ++j;
+        uint32_t bound = 0;
+        for (size_t k = i; k < j; ++k) bound = std::max<uint32_t>(bound, sc.depth[k]);
+        if (bound >= NARROW_MAX_DEPTH) {
+            const size_t m = j - i;
+            auto sweep = [&](uint32_t G) -> uint32_t {            // largest per-position depth of any group
+                ev.clear();
+                for (size_t k = 0; k < m; ++k) {
+                    const ReadHdr &h = sc.hdr[i + k];
+                    ev.push_back(Ev{h.gpos, +1, (uint32_t)(k % G)});
+                    ev.push_back(Ev{h.gpos + h.cig, -1, (uint32_t)(k % G)});
+                }
+                std::sort(ev.begin(), ev.end(), [](const Ev &a, const Ev &b) { return a.pos != b.pos ? a.pos < b.pos : a.delta < b.delta; });
+                cur.assign(G, 0); mx.assign(G, 0);
+                for (const Ev &e : ev) { cur[e.g] += (uint32_t)e.delta; mx[e.g] = std::max(mx[e.g], cur[e.g]); }
+                return *std::max_element(mx.begin(), mx.end());
+            };
+            const uint32_t exact = sweep(1);
+            if (exact < NARROW_MAX_DEPTH) {
+                for (size_t k = i; k < j; ++k) sc.depth[k] = (uint16_t)exact;        // the start-time bound was pessimistic
+            } else {
+                uint32_t G = exact / 200 + 1;
+                while (sweep(G) >= NARROW_MAX_DEPTH) ++G;
+                std::vector<uint32_t> gmax = mx;
+                order.resize(m);
+                for (size_t k = 0; k < m; ++k) order[k] = (uint32_t)k;
+                std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return a % G < b % G; });
+                std::vector<ReadHdr> h2(m); std::vector<int32_t> t2(m), e2(m);
+                for (size_t k = 0; k < m; ++k) { h2[k] = sc.hdr[i + order[k]]; t2[k] = sc.tid[i + order[k]]; e2[k] = sc.end[i + order[k]]; }
+                for (size_t k = 0; k < m; ++k) {
+                    sc.hdr[i + k] = h2[k]; sc.tid[i + k] = t2[k]; sc.end[i + k] = e2[k];
+                    sc.grp[i + k] = (uint16_t)(1 + order[k] % G);
+                    sc.depth[i + k] = (uint16_t)gmax[order[k] % G];
+                }
+            }
+        }
+        i = j;
+    }
+}
+
 // Rewrites seq / qual of one sample into the dense block streams (dataset.h) and fills blk / run_*.
 // hdr must already be grouped by (contig, tile); hdr[i].gpos is still contig-relative (contigs start on tile boundaries).
 static void relayout_dense(SampleCols &sc) {
@@ -42,7 +101,7 @@ static void relayout_dense(SampleCols &sc) {
     size_t i = 0;
     while (i < n) {
         size_t j = i;
-        while (j < n && sc.tid[j] == sc.tid[i] && sc.hdr[j].gpos / TILE == sc.hdr[i].gpos / TILE) ++j;
+        while (j < n && sc.tid[j] == sc.tid[i] && sc.hdr[j].gpos / TILE == sc.hdr[i].gpos / TILE && sc.grp[j] == sc.grp[i]) ++j;
         const uint32_t blk0 = (uint32_t)sc.blk.size();
         const size_t seq0 = nseq.size();                       // multiple of 16 bytes
         uint64_t cursor = 0;                                   // bases from the start of this run's stream
@@ -362,6 +421,7 @@ int finalize_dataset(msnv_dataset &ds) {
     }
 
     // ---- per sample: gpos, tile overlap index; concatenate columns
+    for (SampleCols &sc : ds.samples) split_deep_runs(sc);
     uint64_t all_pieces = 0, all_bases = 0;
     for (const SampleCols &sc : ds.samples) { all_pieces += sc.hdr.size(); all_bases += sc.n_pileup_bases; }
     const bool dense = layout_dense(all_pieces, all_bases);
@@ -379,7 +439,7 @@ int finalize_dataset(msnv_dataset &ds) {
         rbase[s + 1] = rbase[s] + ds.samples[s].hdr.size();
         sbase[s + 1] = sbase[s] + ((ds.samples[s].seq.size() + 15) & ~(size_t)15);
     }
-    struct PairTmp { uint32_t tile, sample, lo, hi, maxd, run; };
+    struct PairTmp { uint32_t tile, sample, lo, hi, maxd, run, grp; };
     std::vector<std::vector<PairTmp>> per_sample(S);
     ds.first_tid = -1; ds.first_pos = -1;
     uint64_t tot_reads = 0, tot_pile_reads = 0, tot_bases = 0;
@@ -392,8 +452,8 @@ int finalize_dataset(msnv_dataset &ds) {
             const uint64_t gs = (uint64_t)ds.tile_base[c] * TILE + sc.hdr[i].gpos;
             sc.hdr[i].gpos = (uint32_t)gs;
             const uint32_t t = (uint32_t)(gs / TILE);
-            if (!pv.empty() && pv.back().tile == t) pv.back().hi = (uint32_t)i + 1;
-            else pv.push_back(PairTmp{t, (uint32_t)s, (uint32_t)i, (uint32_t)i + 1, 0, (uint32_t)pv.size()});
+            if (!pv.empty() && pv.back().tile == t && pv.back().grp == sc.grp[i]) pv.back().hi = (uint32_t)i + 1;
+            else pv.push_back(PairTmp{t, (uint32_t)s, (uint32_t)i, (uint32_t)i + 1, 0, (uint32_t)pv.size(), sc.grp[i]});
         }
         for (PairTmp &p : pv) {       // depth bound: every read alive inside the tile was alive when one of [lo,hi) started
             uint32_t m = 0;
@@ -415,7 +475,7 @@ int finalize_dataset(msnv_dataset &ds) {
         for (size_t s = 0; s < S; ++s)
             for (const PairTmp &p : per_sample[s]) {
                 const SampleCols &sc = ds.samples[s];
-                TilePair tp{p.sample, p.lo, p.hi, p.maxd, 0, 0, 0, 0};
+                TilePair tp{p.sample, p.lo, p.hi, p.maxd, 0, 0, 0, p.grp ? 1u : 0u};      // pad = 1: one of several pairs of this sample in the tile
                 if (dense) {
                     if (p.run >= sc.run_nblk.size()) return fail(MSNV_EINVAL, "internal: dense runs and tile pairs disagree");
                     tp.blk_lo = sc.run_blk_lo[p.run]; tp.nblk = sc.run_nblk[p.run]; tp.seq0 = sc.run_seq0[p.run];
@@ -501,13 +561,13 @@ int finalize_dataset(msnv_dataset &ds) {
                 for (uint32_t b = 0; b < p.nblk; b += DENSE_CHUNK_BLOCKS) {
                     const uint32_t n = std::min<uint32_t>(DENSE_CHUNK_BLOCKS, p.nblk - b);
                     chunks.push_back(ChunkDesc{bbase[p.sample] + p.blk_lo + b, sbase[p.sample] + p.seq0 + 16ull * b, p.sample, k,
-                                               n | (b + n >= p.nblk ? 1u << 16 : 0u), 0});
+                                               n | (b + n >= p.nblk ? 1u << 16 : 0u), p.pad});
                 }
                 continue;
             }
             for (uint32_t r = p.read_lo; r < p.read_hi; r += CHUNK_READS) {
                 const uint32_t n = std::min<uint32_t>(CHUNK_READS, p.read_hi - r);
-                chunks.push_back(ChunkDesc{rbase[p.sample] + r, sbase[p.sample], p.sample, k, n | (r + n >= p.read_hi ? 1u << 16 : 0u), 0});
+                chunks.push_back(ChunkDesc{rbase[p.sample] + r, sbase[p.sample], p.sample, k, n | (r + n >= p.read_hi ? 1u << 16 : 0u), p.pad});
             }
         }
         w.chunk_hi = (uint32_t)chunks.size();

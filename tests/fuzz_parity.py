@@ -30,6 +30,7 @@ def sweep(n_cases, seed, verbose=True):
                   min_baseq=rnd.choice([0, 13, 13, 30]), max_depth=rnd.choice([8000, 8000, 8000, 60, 7]), min_mapq=rnd.choice([0, 0, 1, 30]),
                   count_orphans=rnd.choice([0, 1]), flag_filter=rnd.choice([0x704, 0x704, 0x400, 0]))
         os.environ["MSNV_LAYOUT"] = rnd.choice(["pieces", "dense"])
+        deep_mode = os.environ.get("MSNV_DEEP", "split")
         sp = core.synth_params(**kw)
         syn = core.Synth(sp)
         samples = [syn.sample_records(i) for i in range(sp.n_samples)]

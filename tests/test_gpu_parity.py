@@ -90,13 +90,20 @@ def _reads_edge():
     return ref, [bt.records(*sorted(s, key=key)) for s in (s1, s2, s3)] + [np.zeros(0, np.uint8)]
 
 
-def test_cigar_ops_tile_boundary_overflow_and_empty_sample():
+@pytest.mark.parametrize("deep", ["split", "wide"])
+def test_cigar_ops_tile_boundary_overflow_and_empty_sample(deep, monkeypatch):
+    """deep = how the 500-read pile of sample 3 (depth above the byte bins) is handled: split into groups of reads that each
+    stay below 255 and summed per sample on the device (default), or kept whole for the 16-bit kernel (MSNV_DEEP=wide)."""
+    monkeypatch.setenv("MSNV_DEEP", deep)
     ref, samples = _reads_edge()
     p = core.default_params(min_coverage=2, calling_threshold=2)
     prod = run_product(["ctg"], [len(ref)], [ref], samples, params=p)
     orac = run_oracle(["ctg"], [len(ref)], [ref], samples, params=p)
     _assert_same(prod, orac)
-    assert prod[3]["n_overflow"] > 0                      # the >=255 path really ran
+    if deep == "wide":
+        assert prod[3]["n_overflow"] > 0                  # the >= 255 path of the wide kernel really ran
+    else:
+        assert prod[3]["n_overflow"] == 0 and prod[2]["n_pairs"] >= 6   # 2 tiles x 2 shallow samples + >= 3 groups of the deep one
     assert "\t2051\t" in prod[0] or "\t2051\t" in prod[1]
     assert "\t521\t" in prod[1] and "\t521\t" not in prod[0]   # 4 of 500 reads (< 1 %): individual, not population
 
