@@ -759,3 +759,64 @@ def test_randomised_parity_sweep(monkeypatch):
         assert fuzz_parity.sweep(70, 2024, verbose=False) == 0
     finally:
         os.environ.pop("MSNV_LAYOUT", None)
+
+
+def test_filtering_random_tables_against_python_formulas(tmp_path):
+    """FILTER II on random called_SNPs-like text (zero coverages, huge coverages -> exponent-form repr, several alleles per
+    line, species not of interest, thresholds on both sides of every gate) against the reference's formulas
+    (metaSNV_Filtering.py:183-231) evaluated in Python on the same text."""
+    import random
+    from metasnv_amd import filtering
+    rnd = random.Random(12)
+    for trial in range(6):
+        S = rnd.choice([2, 5, 9])
+        names = ["s%d.bam" % i for i in range(S)]
+        species = ["spA", "spB", "spC"]
+        proj = str(tmp_path / ("t%d" % trial) / "proj")
+        os.makedirs(os.path.join(proj, "snpCaller"))
+        open(os.path.join(proj, "all_samples"), "w").write("".join("/d/%s\n" % n for n in names))
+        cov = "\t" + "\t".join(names) + "\nTaxId\t" + "\t".join(["Average_cov"] * S) + "\n"
+        per = "\t" + "\t".join(names) + "\nTaxId\t" + "\t".join(["Percentage_1x"] * S) + "\n"
+        for sp in species:
+            cov += sp + "\t" + "\t".join("%f" % rnd.choice([0.0, 1.5, 6.0, 20.0]) for _ in range(S)) + "\n"
+            per += sp + "\t" + "\t".join("%f" % rnd.choice([5.0, 45.0, 90.0]) for _ in range(S)) + "\n"
+        open(os.path.join(proj, "proj.all_cov.tab"), "w").write(cov)
+        open(os.path.join(proj, "proj.all_perc.tab"), "w").write(per)
+        lines = ""
+        for k in range(150):
+            ctg = rnd.choice(["spA.c1", "spA.c2", "spB", "spC.x.y", "spD.z"])
+            c = [rnd.choice([0, 0, 1, 3, 4, 5, 6, 9, 40, 1000, 200003]) for _ in range(S)]
+            ents = []
+            for alt in rnd.sample("ACGT", rnd.choice([1, 1, 2, 3])):
+                n = [rnd.randint(0, x) if x else 0 for x in c]
+                ents.append("%d|%s|%s|%s" % (sum(n), alt, rnd.choice([".", "S[GCT-GCC]", "N[TA-TC]"]), "|".join(map(str, n))))
+            lines += "%s\t%s\t%d\t%s\t%s\t%s\n" % (ctg, rnd.choice(["-", "g%d" % k]), 5 + 2 * k, rnd.choice("ACGTn"), "|".join(map(str, c)), ",".join(ents))
+        open(os.path.join(proj, "snpCaller", "called_SNPs"), "w").write(lines)
+        open(os.path.join(proj, "snpCaller", "indiv_called"), "w").write("")
+        b, d, m, cc, p = rnd.choice([10.0, 40.0]), rnd.choice([1.0, 5.0]), rnd.choice([1, 2]), rnd.choice([1.0, 5.0]), rnd.choice([0.2, 0.5, 0.9])
+        filtering.main([proj, "-b", str(b), "-d", str(d), "-m", str(m), "-c", str(cc), "-p", str(p)])
+        soi = filtering.relevant_taxa(os.path.join(proj, "proj.all_cov.tab"), os.path.join(proj, "proj.all_perc.tab"), b, d, m)["SoI"]
+        for sp in species:
+            path = os.path.join(proj, "filtered", "pop", sp + ".filtered.freq")
+            if sp not in soi:
+                assert not os.path.exists(path)
+                continue
+            idx = [names.index(n) for n in soi[sp]]
+            want = ""
+            for line in lines.splitlines():
+                w = line.split()
+                if w[0].split(".")[0] != sp:
+                    continue
+                c = list(map(int, w[4].split("|")))
+                good = sum(1 for i in idx if not (c[i] < cc or c[i] == 0))
+                if float(good) / len(idx) < p:
+                    continue
+                for snp in w[5].split(","):
+                    x = snp.split("|")
+                    n = list(map(float, x[3:]))
+                    fr = [n[i] / c[i] if (c[i] >= cc and c[i] != 0) else -1 for i in idx]
+                    want += ":".join(w[:4]) + ">" + x[1] + ":" + x[2] + "\t" + "\t".join(str(v) for v in fr) + "\n"
+            if want:
+                assert open(path).read() == "\t" + "\t".join(soi[sp]) + "\n" + want, (trial, sp)
+            else:
+                assert not os.path.exists(path)
