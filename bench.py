@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--species", type=int, default=3)
     ap.add_argument("--mean-cov", type=float, default=10.0)
     ap.add_argument("--read-len", type=int, default=100, help="synthetic read length (BASELINE: 100)")
+    ap.add_argument("--error-rate", type=float, default=None, help="synthetic sequencing error rate (BASELINE: 0.001)")
     ap.add_argument("--cpu-samples", type=int, default=64, help="samples of the workload the CPU oracle is timed on")
     ap.add_argument("--sync-each-step", action="store_true", help="one msnv_pileup_run call (with its host sync) per step instead of one batched call")
     ap.add_argument("--no-overlap-extra", action="store_true", help="skip the extra timed batch with overlapped passes (profiling runs)")
@@ -122,6 +123,8 @@ def main():
     sp_kwargs = dict(n_species=a.species, contig_len=a.contig_len, n_samples=a.samples, mean_cov=a.mean_cov, seed=1 + rank)
     if a.read_len != 100:
         sp_kwargs["read_len"] = a.read_len
+    if a.error_rate is not None:
+        sp_kwargs["error_rate"] = a.error_rate
     sp = core.synth_params(**sp_kwargs)
     syn = core.Synth(sp)
     ctx = core.Context(local)

@@ -33,7 +33,8 @@ static bool layout_dense(uint64_t n_pieces, uint64_t n_bases) {
 }
 
 // A (contig, tile) run of one sample whose depth can reach NARROW_MAX_DEPTH does not fit the byte bins of the narrow
-// kernels.  Instead of a second kernel with wider bins, the run is dealt into groups of pieces that each stay below the
+// kernels, and the kernels slow down well before that (8 samples at ~100x: 0.531 ms unsplit, 0.336 ms when runs deeper than
+// 192 are dealt into groups of <= 128; at ~400x 2.68 ms with groups of 240, 1.66 ms with groups of 128).  Instead of a second kernel with wider bins, the run is dealt into groups of pieces that each stay below the
 // limit (round robin in start order, verified with an exact sweep, more groups if needed); every group becomes its own
 // (sample, tile) pair and the per-sample results are summed on the device (gather / scatter accumulate).  Pieces of a
 // group are made contiguous.  MSNV_DEEP=wide keeps such runs whole for msnv_pileup_tiles_wide instead.
@@ -54,7 +55,8 @@ static void split_deep_runs(SampleCols &sc) {
         while (j < n && sc.tid[j] == sc.tid[i] && sc.hdr[j].gpos / TILE == sc.hdr[i].gpos / TILE) ++j;
         uint32_t bound = 0;
         for (size_t k = i; k < j; ++k) bound = std::max<uint32_t>(bound, sc.depth[k]);
-        if (bound >= NARROW_MAX_DEPTH) {
+        static const uint32_t split_at = [] { const char *e = getenv("MSNV_SPLIT_AT"); const int v = e ? atoi(e) : 192; return (uint32_t)std::min<int>((int)NARROW_MAX_DEPTH, std::max(32, v)); }();
+        if (bound >= split_at) {
             const size_t m = j - i;
             auto sweep = [&](uint32_t G) -> uint32_t {            // largest per-position depth of any group
                 ev.clear();
@@ -69,10 +71,11 @@ static void split_deep_runs(SampleCols &sc) {
                 return *std::max_element(mx.begin(), mx.end());
             };
             const uint32_t exact = sweep(1);
-            if (exact < NARROW_MAX_DEPTH) {
+            if (exact < split_at) {
                 for (size_t k = i; k < j; ++k) sc.depth[k] = (uint16_t)exact;        // the start-time bound was pessimistic
             } else {
-                uint32_t G = exact / 200 + 1;
+                static const uint32_t group_depth = [] { const char *e = getenv("MSNV_GROUP_DEPTH"); const int v = e ? atoi(e) : 128; return (uint32_t)std::min(250, std::max(16, v)); }();
+                uint32_t G = exact / group_depth + 1;
                 while (sweep(G) >= NARROW_MAX_DEPTH) ++G;
                 std::vector<uint32_t> gmax = mx;
                 order.resize(m);
