@@ -57,6 +57,13 @@ struct PileupArgs {
 __device__ __forceinline__ uint32_t allele_index(uint32_t code) {
     return (code == 1u) ? 0u : (code == 2u) ? 1u : (code == 4u) ? 2u : (code == 8u) ? 3u : 4u;
 }
+__device__ __forceinline__ uint32_t nz_bytes(uint32_t x) {         // bit 8j+7 set iff byte j != 0
+    return (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;
+}
+__device__ __forceinline__ uint32_t count_nz_bytes(const uint4 a, const uint4 b) {
+    return (uint32_t)__popc(nz_bytes(a.x) | nz_bytes(a.y) >> 1 | nz_bytes(a.z) >> 2 | nz_bytes(a.w) >> 3 |
+                            nz_bytes(b.x) >> 4 | nz_bytes(b.y) >> 5 | nz_bytes(b.z) >> 6 | nz_bytes(b.w) >> 7);
+}
 __device__ __forceinline__ uint32_t nz_nibbles(uint32_t x) {       // bit 4j+3 set iff nibble j != 0
     return (((x & 0x77777777u) + 0x77777777u) | x) & 0x88888888u;
 }
@@ -320,7 +327,7 @@ struct NarrowLds {
     Pair32   ev[N_EVCAP];
     ChunkDesc desc[MAX_CHUNKS_PER_ITEM];
     int32_t  wsum[N_NT / 64];
-    uint32_t evn, ev_base;
+    uint32_t evn, ev_base, evpass[2];
 };
 
 // Per-sample pass of the narrow kernel: prefix sum of start/end -> depth, minus the not-counted bases;
@@ -329,7 +336,7 @@ struct NarrowLds {
 template <typename LDS, int EXC_PAD>
 __device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_t (&tc)[N_PPT], const uint32_t t0,
                                             const int tid, const int lane, const int wave, const uint32_t sample, const uint32_t k,
-                                            const uint32_t split) {
+                                            const uint32_t split, const uint32_t par) {
     __syncthreads();                                        // (B)
     const uint2 st = *reinterpret_cast<uint2 *>(&L.start[2 * tid]);
     const uint2 en = *reinterpret_cast<uint2 *>(&L.end[2 * tid]);
@@ -344,7 +351,9 @@ __device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_
     if (anyal) {
         *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid]) = make_uint4(0u, 0u, 0u, 0u);
         *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid + 4]) = make_uint4(0u, 0u, 0u, 0u);
+        atomicAdd(&L.evpass[par], count_nz_bytes(a0, a1));  // allele events of my positions
     }
+    if (tid == 0 && L.evn) atomicAdd(&L.evpass[par], L.evn);   // + what is staged (stable here: staging happens after (C), flushes at (A))
     const int mine = (int)(__builtin_amdgcn_udot4(st.x, 0x01010101u, __builtin_amdgcn_udot4(st.y, 0x01010101u, 0u, false), false)) -
                      (int)(__builtin_amdgcn_udot4(en.x, 0x01010101u, __builtin_amdgcn_udot4(en.y, 0x01010101u, 0u, false), false));
     const int incl = wave_inclusive_scan(mine);
@@ -352,6 +361,12 @@ __device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_
     __syncthreads();                                        // (C)
     int d = incl - mine;
     for (int wv = 0; wv < wave; ++wv) d += L.wsum[wv];
+    // The events of this pass fit the staging buffer (one returning global atomic per flush), or -- noisy reads,
+    // block-uniform decision -- the pass reserves its range of the event list at once and every thread writes its
+    // events at its prefix-sum offset.  Either way no thread ever needs an atomic of its own on the list counter.
+    const uint32_t staged_and_pass = __builtin_amdgcn_readfirstlane(L.evpass[par]);
+    if (tid == 0) L.evpass[par ^ 1u] = 0u;                  // the other counter serves the next pass, which starts behind barrier (A)
+    const bool direct = staged_and_pass > (uint32_t)N_EVCAP;
     uint32_t packed[2] = {0u, 0u};
 #pragma unroll
     for (int j = 0; j < N_PPT; ++j) {
@@ -362,6 +377,14 @@ __device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_
         packed[j >> 2] |= (cov & 0xffu) << (8 * (j & 3));
     }
     *reinterpret_cast<uint2 *>(a.spill + (uint64_t)k * TILE + N_PPT * tid) = make_uint2(packed[0], packed[1]);
+    uint32_t gofs = 0;
+    if (direct) {                                           // one reservation per wave: exclusive prefix of the lanes' event counts
+        const uint32_t myev = count_nz_bytes(a0, a1);
+        const uint32_t ei = (uint32_t)wave_inclusive_scan((int)myev);
+        uint32_t wbase = 0;
+        if (lane == 63 && ei) wbase = atomicAdd(&a.counters[0], ei);
+        gofs = (uint32_t)__builtin_amdgcn_readlane((int)wbase, 63) + ei - myev;
+    }
     if (anyal) {                                            // rare: some position of mine saw a mismatching allele
         const uint32_t alw[N_PPT] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
         uint32_t pm = 0;
@@ -381,7 +404,9 @@ __device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_
                     atomicAdd(&a.tot[(uint64_t)x * a.npos + gpos], n);
                     // candidate of the individual rule; a sample that was split into several pairs may reach the threshold only in sum
                     if (n >= a.min_snvs || split) atomicOr(&a.ind_bits[gpos >> 5], 1u << (gpos & 31u));
-                    stage_allele_event<LDS, N_EVCAP>(L, a, Pair32{gpos, sample << 18 | x << 16 | n});
+                    const Pair32 e{gpos, sample << 18 | x << 16 | n};
+                    if (direct) { if (gofs < a.cap_events) a.events[gofs] = e; ++gofs; }
+                    else stage_allele_event<LDS, N_EVCAP>(L, a, e);
                 }
             }
         }
@@ -465,8 +490,8 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32(PileupArgs a)
     for (int i = tid; i < (int)(TILE / 8 + 4); i += N_NT) L.exc[i] = 0;
     L.spread[tid] = ((unsigned long long)((((uint32_t)tid >> 4) * 0x00204081u) & 0x01010101u) << 32) | (((uint32_t)tid & 0xfu) * 0x00204081u & 0x01010101u);
     for (int i = tid; i < (int)TILE; i += N_NT) L.al[i] = 0;
-    if (tid == 0) L.evn = 0;
-    uint32_t tc[N_PPT];
+    if (tid == 0) { L.evn = 0; L.evpass[0] = 0; L.evpass[1] = 0; }
+    uint32_t tc[N_PPT], npass = 0;
 #pragma unroll
     for (int j = 0; j < N_PPT; ++j) tc[j] = 0;
 
@@ -520,7 +545,7 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32(PileupArgs a)
         for (int i = 0; i < N32_ROUNDS; ++i)
             if (__any(vh[i] > 0)) narrow_classify32(L, qa[i], qb[i], sq[i], P0[i], vh[i], kq);
 
-        if (last_chunk) narrow_pass<NarrowLds, 0>(L, a, tc, t0, tid, lane, wave, cd.sample, cd.pair, cd.pad);
+        if (last_chunk) narrow_pass<NarrowLds, 0>(L, a, tc, t0, tid, lane, wave, cd.sample, cd.pair, cd.pad, npass++ & 1u);
         buf ^= 1;
     }
     __syncthreads();
@@ -553,7 +578,7 @@ struct DenseLds {
     Pair32   ev[N_EVCAP];
     ChunkDesc desc[MAX_CHUNKS_PER_ITEM];
     int32_t  wsum[N_NT / 64];
-    uint32_t evn, ev_base;
+    uint32_t evn, ev_base, evpass[2];
 };
 
 // nibble flags (bit 4j+3) of the bases j in [lo, hi) of the 8-base word k
@@ -613,8 +638,8 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_dense(PileupArgs a) {
     for (int i = tid; i < (int)(TILE / 4 + 4); i += N_NT) { L.start[i] = 0; L.end[i] = 0; }
     L.spread[tid] = ((unsigned long long)((((uint32_t)tid >> 4) * 0x00204081u) & 0x01010101u) << 32) | (((uint32_t)tid & 0xfu) * 0x00204081u & 0x01010101u);
     for (int i = tid; i < (int)TILE; i += N_NT) L.al[i] = 0;
-    if (tid == 0) L.evn = 0;
-    uint32_t tc[N_PPT];
+    if (tid == 0) { L.evn = 0; L.evpass[0] = 0; L.evpass[1] = 0; }
+    uint32_t tc[N_PPT], npass = 0;
 #pragma unroll
     for (int j = 0; j < N_PPT; ++j) tc[j] = 0;
 
@@ -679,7 +704,7 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_dense(PileupArgs a) {
             dense_segment(L, sq[r], lq, P0A + 32u, 0, (int)nA);
             if (__any(hasB)) dense_segment(L, sq[r], lq, hasB ? PBv : 32u, hasB ? (int)sB : 32, 32);
         }
-        if (last_chunk) narrow_pass<DenseLds, D_PAD>(L, a, tc, t0, tid, lane, wave, cd.sample, cd.pair, cd.pad);
+        if (last_chunk) narrow_pass<DenseLds, D_PAD>(L, a, tc, t0, tid, lane, wave, cd.sample, cd.pair, cd.pad, npass++ & 1u);
     }
     __syncthreads();
     flush_events<DenseLds, N_NT, N_EVCAP>(L, a, tid);

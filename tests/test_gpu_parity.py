@@ -225,6 +225,22 @@ def test_deep_pairs_with_more_chunks_than_the_descriptor_ring(layout, monkeypatc
     assert prod[2]["n_pileup_bases"] == orac[3] and prod[0].count("\n") > 20
 
 
+@pytest.mark.parametrize("layout", ["pieces", "dense"])
+def test_noisy_reads_reserve_their_event_ranges_per_pass(layout, monkeypatch):
+    """Several per cent of mismatching bases: one per-sample pass of a tile emits more allele events (2048 positions x
+    depth x error rate) than the 256-entry LDS staging buffer holds, so the pass reserves its range of the event list per
+    wave and writes at prefix-sum offsets; passes that fit (shallow samples) keep staging -- both paths in one run."""
+    monkeypatch.setenv("MSNV_LAYOUT", layout)
+    syn, samples = synth_case(n_species=2, contig_len=9000, n_samples=9, mean_cov=25.0, sigma_cov=1.0, snv_density=0.02,
+                              error_rate=0.06, frac_absent=0.0, seed=4242)
+    prod = run_product(syn.names, syn.lengths, syn.seqs, samples)
+    orac = run_oracle(syn.names, syn.lengths, syn.seqs, samples)
+    _assert_same(prod, orac)
+    assert prod[2]["n_pileup_bases"] == orac[3]
+    assert prod[3]["n_events"] > 9 * 9 * 256                          # well beyond what staging alone could take per pass
+    assert prod[0].count("\n") > 200
+
+
 def test_annotation_codon_path(tmp_path):
     syn, samples = synth_case(n_species=2, contig_len=3000, n_samples=4, mean_cov=14.0, snv_density=0.03, frac_absent=0.0, seed=21)
     fa = str(tmp_path / "ref.fa")
