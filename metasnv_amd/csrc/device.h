@@ -107,6 +107,12 @@ struct DeviceCols {
 };
 
 // host copies of the counters after a run
+// The allele-event list is cut into EV_LISTS equal sub-lists, each with its own fill counter on its own 64-byte line
+// (work item i appends to sub-list i % EV_LISTS): returning atomics on ONE address serialise device-wide, and reads with
+// several per cent of mismatches append often enough for that to dominate the pileup kernel.
+constexpr uint32_t EV_LISTS = 32, EV_CNT_STRIDE = 16;
+constexpr uint32_t CNT_WORDS = 16 + EV_LISTS * EV_CNT_STRIDE;   // counters[0..15], then the sub-list counters; ind_bits follow
+
 struct RunCounts { uint32_t n_events, n_overflow, n_sites, err; };
 
 int  dev_set_device(int device);

@@ -45,9 +45,10 @@ struct PileupArgs {
     uint8_t        *part;         // coverage summed over the item's samples, one row per work item (plain stores)
     uint64_t        npos;
     uint8_t        *spill;
-    Pair32         *events;   uint32_t cap_events;
+    Pair32         *events;   uint32_t cap_events;   // this work item's sub-list (ev_list) and the capacity of ONE sub-list
     Pair32         *overflow; uint32_t cap_overflow;
     uint32_t       *counters;
+    uint32_t       *ev_count;     // set by ev_list() inside the kernel
     uint32_t        min_baseq;
     uint32_t       *ind_bits;     // 1 bit per position: some sample holds >= min_snvs reads of one mismatching allele
     uint32_t        min_snvs;
@@ -128,10 +129,17 @@ struct WideLds {
     uint32_t evn, ev_base;
 };
 
+// Work item i appends to sub-list i % EV_LISTS (device.h): base pointer and fill counter of that sub-list.
+__device__ __forceinline__ void ev_list(PileupArgs &a) {
+    const uint32_t k = blockIdx.x % EV_LISTS;
+    a.events += (uint64_t)k * a.cap_events;
+    a.ev_count = a.counters + 16u + k * EV_CNT_STRIDE;
+}
+
 template <typename LDS, int NT, int CAP>
 __device__ __forceinline__ void flush_events(LDS &L, const PileupArgs &a, int tid) {
     const uint32_t n = min(L.evn, (uint32_t)CAP);              // called by all threads between barriers
-    if (tid == 0) L.ev_base = n ? atomicAdd(&a.counters[0], n) : 0u;
+    if (tid == 0) L.ev_base = n ? atomicAdd(a.ev_count, n) : 0u;
     __syncthreads();
     const uint32_t base = L.ev_base;
     for (uint32_t i = tid; i < n; i += NT)
@@ -144,7 +152,7 @@ template <typename LDS, int CAP>
 __device__ __forceinline__ void stage_allele_event(LDS &L, const PileupArgs &a, Pair32 e) {
     const uint32_t i = atomicAdd(&L.evn, 1u);
     if (i < (uint32_t)CAP) { L.ev[i] = e; return; }
-    const uint32_t g = atomicAdd(&a.counters[0], 1u);          // staging full: slow path
+    const uint32_t g = atomicAdd(a.ev_count, 1u);               // staging full: slow path
     if (g < a.cap_events) a.events[g] = e;
 }
 
@@ -169,6 +177,7 @@ __device__ __forceinline__ void wide_classify(WideLds &L, const uint4 qv, const 
 }
 
 __global__ __launch_bounds__(W_NT) void msnv_pileup_tiles_wide(PileupArgs a) {
+    ev_list(a);
     __shared__ WideLds L;
     const WorkItem w = a.work[blockIdx.x];
     const uint32_t t0 = w.tile * TILE;
@@ -382,7 +391,7 @@ __device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_
         const uint32_t myev = count_nz_bytes(a0, a1);
         const uint32_t ei = (uint32_t)wave_inclusive_scan((int)myev);
         uint32_t wbase = 0;
-        if (lane == 63 && ei) wbase = atomicAdd(&a.counters[0], ei);
+        if (lane == 63 && ei) wbase = atomicAdd(a.ev_count, ei);
         gofs = (uint32_t)__builtin_amdgcn_readlane((int)wbase, 63) + ei - myev;
     }
     if (anyal) {                                            // rare: some position of mine saw a mismatching allele
@@ -476,6 +485,7 @@ __device__ __forceinline__ void narrow_classify32(NarrowLds &L, const uint4 qa, 
 }
 
 __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32(PileupArgs a) {
+    ev_list(a);
     __shared__ NarrowLds L;
     const WorkItem w = a.work[blockIdx.x];
     const uint32_t t0 = w.tile * TILE;
@@ -624,6 +634,7 @@ __device__ __forceinline__ void dense_segment(DenseLds &L, const uint4 sq, const
 }
 
 __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_dense(PileupArgs a) {
+    ev_list(a);
     __shared__ DenseLds L;
     const WorkItem w = a.work[blockIdx.x];
     const uint32_t t0 = w.tile * TILE;
@@ -871,19 +882,24 @@ __global__ __launch_bounds__(256) void msnv_gather_cov(const SiteRec *sites, con
 }
 
 // msnv_scatter_events: per-sample allele counts (sparse) and >=255 coverages into the site records.
-__global__ void msnv_scatter_events(const Pair32 *events, const Pair32 *overflow, const uint32_t *counters, uint32_t cap_events,
+__global__ void msnv_scatter_events(const Pair32 *events, const Pair32 *overflow, const uint32_t *counters, uint32_t cap_list,
                                     uint32_t cap_overflow, const unsigned long long *site_bits, const uint32_t *site_rank,
                                     msnv_site_sample *out, uint32_t n_samples, uint32_t cap_out) {
-    const uint32_t n_events = min(counters[0], cap_events), n_overflow = min(counters[1], cap_overflow);
     if (counters[2] > cap_out) return;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_events + n_overflow; i += gridDim.x * blockDim.x) {
-        const Pair32 e = (i < n_events) ? events[i] : overflow[i - n_events];
+    auto apply = [&](const Pair32 e, const bool allele) {
         const unsigned long long w = site_bits[e.x >> 6], bit = 1ull << (e.x & 63u);
-        if (!(w & bit)) continue;                  // most events are sequencing errors at positions that are not sites
+        if (!(w & bit)) return;                    // most events are sequencing errors at positions that are not sites
         const uint32_t s = site_rank[e.x >> 6] + (uint32_t)__popcll(w & (bit - 1ull));
-        if (i < n_events) add_u16(&out[(uint64_t)s * n_samples + (e.y >> 18)].n[(e.y >> 16) & 3u], e.y & 0xffffu);   // one event per (site, pair, allele)
+        if (allele) add_u16(&out[(uint64_t)s * n_samples + (e.y >> 18)].n[(e.y >> 16) & 3u], e.y & 0xffffu);   // one event per (site, pair, allele)
         else out[(uint64_t)s * n_samples + (e.y >> 16)].cov = (uint16_t)(e.y & 0xffffu);
-    }
+    };
+    // grid = (blocks per sub-list, EV_LISTS)
+    const uint32_t k = blockIdx.y, n_k = min(counters[16u + k * EV_CNT_STRIDE], cap_list);
+    const Pair32 *list = events + (uint64_t)k * cap_list;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_k; i += gridDim.x * blockDim.x) apply(list[i], true);
+    const uint32_t n_overflow = min(counters[1], cap_overflow);
+    for (uint32_t i = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < n_overflow; i += gridDim.x * gridDim.y * blockDim.x)
+        apply(overflow[i], false);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -894,9 +910,17 @@ __global__ void msnv_scatter_events(const Pair32 *events, const Pair32 *overflow
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void msnv_decide_sites(const SiteRec *sites, uint32_t *counters, uint32_t cap_sites, uint32_t cap_out,
                                                          const uint32_t *ref4, const uint32_t *ref_lc, const msnv_site_sample *out,
-                                                         uint32_t n_samples, int min_snvs, double min_frac, uint8_t *site_flags) {
+                                                         uint32_t n_samples, int min_snvs, double min_frac, uint8_t *site_flags, uint32_t cap_list) {
     __shared__ uint32_t s_pop, s_ind;
     if (threadIdx.x == 0) { s_pop = 0; s_ind = 0; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // counters[0] for the host: the number of allele events, or -- when a sub-list overflowed -- the total capacity
+        // that would have held the fullest one (the host grows the list to that and runs the pass again)
+        unsigned long long total = 0; uint32_t fullest = 0;
+        for (uint32_t k = 0; k < EV_LISTS; ++k) { const uint32_t c = counters[16u + k * EV_CNT_STRIDE]; total += c; fullest = max(fullest, c); }
+        if (fullest > cap_list) total = (unsigned long long)fullest * EV_LISTS;
+        counters[0] = (uint32_t)min(total, 0xffffffffull);
+    }
     __syncthreads();
     const uint32_t n_sites = counters[2];
     const int lane = threadIdx.x & 63;
@@ -1069,7 +1093,7 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
     const uint64_t npos = (uint64_t)d.n_tiles * TILE;
     HIP_TRY(hipEventRecord(ev_begin, st));
     // d.tot needs no memset: it is zero after finalize and msnv_gate_sites zeroes what a pass has written
-    HIP_TRY(hipMemsetAsync(d.counters, 0, (16 + npos / 32 + 1) * sizeof(uint32_t), st));   // counters + individual-candidate bits (one allocation)
+    HIP_TRY(hipMemsetAsync(d.counters, 0, (CNT_WORDS + npos / 32 + 1) * sizeof(uint32_t), st));   // counters + individual-candidate bits (one allocation)
     if (wait_before_pileup) HIP_TRY(hipStreamWaitEvent(st, wait_before_pileup, 0));   // the previous pass' pileup kernel (other stream)
     HIP_TRY(hipEventRecord(ev_pile0, st));
     if (d.n_work) {
@@ -1077,7 +1101,7 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
         a.hdr = d.hdr; a.hdr8 = d.hdr8; a.blk = d.blk; a.seq = d.seq; a.qual = d.qual;
         a.s_read_base = d.s_read_base; a.s_seq_base = d.s_seq_base;
         a.ref4 = d.ref4; a.pairs = d.pairs; a.work = d.work; a.chunks = d.chunks; a.tot = d.tot; a.part = d.part; a.npos = npos; a.spill = d.spill;
-        a.events = d.events; a.cap_events = d.cap_events; a.overflow = d.overflow; a.cap_overflow = d.cap_overflow;
+        a.events = d.events; a.cap_events = d.cap_events / EV_LISTS; a.ev_count = nullptr; a.overflow = d.overflow; a.cap_overflow = d.cap_overflow;
         a.counters = d.counters; a.min_baseq = (uint32_t)std::max(0, p.min_baseq);
         a.ind_bits = d.ind_bits; a.min_snvs = (uint32_t)std::max(0, p.calling_threshold);
         const uint32_t n_narrow = d.n_work_narrow;
@@ -1104,13 +1128,13 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
         hipLaunchKernelGGL(msnv_gather_cov, dim3(d.n_active_tiles * GATHER_SPLIT), dim3(256), 0, st, d.sites, d.tile_site_base, d.tile_site_cnt,
                            d.tile_pair_start, d.pairs, d.spill, d.out, d.n_samples, cap_out, d.active_tiles);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(msnv_scatter_events, dim3(1024), dim3(256), 0, st, d.events, d.overflow, d.counters, d.cap_events,
+        hipLaunchKernelGGL(msnv_scatter_events, dim3(1024 / EV_LISTS, EV_LISTS), dim3(256), 0, st, d.events, d.overflow, d.counters, d.cap_events / EV_LISTS,
                            d.cap_overflow, d.site_bits, d.site_rank, d.out, d.n_samples, cap_out);
         HIP_TRY(hipGetLastError());
     }
     if (ev4) HIP_TRY(hipEventRecord(ev4, st));
     hipLaunchKernelGGL(msnv_decide_sites, dim3(512), dim3(256), 0, st, d.sites, d.counters, d.cap_sites, cap_out, d.ref4, d.ref_lc,
-                       d.out, d.n_samples, p.calling_threshold, p.min_fraction, d.site_flags);
+                       d.out, d.n_samples, p.calling_threshold, p.min_fraction, d.site_flags, d.cap_events / EV_LISTS);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(host_cnt, d.counters, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     return MSNV_OK;
@@ -1120,7 +1144,7 @@ static int check_counts(DeviceCols &d, const uint32_t *cnt, RunCounts *counts) {
     RunCounts c{cnt[0], cnt[1], cnt[2], cnt[3]};
     d.last_sites = c.n_sites;
     if (counts) *counts = c;
-    if (c.n_events > d.cap_events || c.n_overflow > d.cap_overflow || c.n_sites > d.cap_sites || c.n_sites > d.cap_out_sites)
+    if (c.n_events > d.cap_events / EV_LISTS * EV_LISTS || c.n_overflow > d.cap_overflow || c.n_sites > d.cap_sites || c.n_sites > d.cap_out_sites)
         return fail_quiet(MSNV_ECAPACITY, "device buffer too small: events %u/%u overflow %u/%u sites %u/%u out %u/%llu",
                           c.n_events, d.cap_events, c.n_overflow, d.cap_overflow, c.n_sites, d.cap_sites, c.n_sites,
                           (unsigned long long)d.cap_out_sites);
@@ -1174,8 +1198,8 @@ static int ensure_alt(DeviceCols &d) {
     if (int rc = dev_alloc((void **)&a.events, (uint64_t)d.cap_events * sizeof(Pair32), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.overflow, (uint64_t)d.cap_overflow * sizeof(Pair32), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.sites, (uint64_t)d.cap_sites * sizeof(SiteRec), &d.device_bytes)) return rc;
-    if (int rc = dev_alloc((void **)&a.counters, (16 + npos / 32 + 1) * sizeof(uint32_t), &d.device_bytes)) return rc;
-    a.ind_bits = a.counters + 16;
+    if (int rc = dev_alloc((void **)&a.counters, (CNT_WORDS + npos / 32 + 1) * sizeof(uint32_t), &d.device_bytes)) return rc;
+    a.ind_bits = a.counters + CNT_WORDS;
     if (int rc = dev_alloc((void **)&a.site_bits, (npos / 64 + 1) * sizeof(unsigned long long), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.site_rank, (npos / 64 + 1) * sizeof(uint32_t), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.tile_site_base, ((uint64_t)d.n_tiles + 1) * sizeof(uint32_t), &d.device_bytes)) return rc;

@@ -689,8 +689,8 @@ int finalize_dataset(msnv_dataset &ds) {
     if (int rc = dev_alloc((void **)&d->overflow, (uint64_t)d->cap_overflow * sizeof(Pair32), &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->sites, (uint64_t)d->cap_sites * sizeof(SiteRec), &d->device_bytes)) return rc;
     // counters and the individual-candidate bits share one allocation: one memset per pass clears both
-    if (int rc = dev_alloc((void **)&d->counters, (16 + npos / 32 + 1) * sizeof(uint32_t), &d->device_bytes)) return rc;
-    d->ind_bits = d->counters + 16;
+    if (int rc = dev_alloc((void **)&d->counters, (CNT_WORDS + npos / 32 + 1) * sizeof(uint32_t), &d->device_bytes)) return rc;
+    d->ind_bits = d->counters + CNT_WORDS;
     if (int rc = dev_alloc((void **)&d->site_bits, (npos / 64 + 1) * sizeof(unsigned long long), &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->site_rank, (npos / 64 + 1) * sizeof(uint32_t), &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->tile_site_base, (nt + 1) * sizeof(uint32_t), &d->device_bytes)) return rc;
