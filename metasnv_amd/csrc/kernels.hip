@@ -335,47 +335,41 @@ struct NarrowLds {
     uint2    hdr[2][N_HCAP];
     Pair32   ev[N_EVCAP];
     ChunkDesc desc[MAX_CHUNKS_PER_ITEM];
-    int32_t  wsum[N_NT / 64];
-    uint32_t evn, ev_base, evpass[2];
+    uint32_t carry[N_NT / 64 + 1];             // depth at the left edge of each wavefront's quarter of the tile ([4]: scratch for pieces that end at the tile end)
+    uint32_t evn, ev_base;
 };
 
 // Per-sample pass of the narrow kernel: prefix sum of start/end -> depth, minus the not-counted bases;
 // adds the sample to the running totals, spills the per-sample coverage bytes, emits allele events,
-// and leaves every bin zero for the next sample.  Called by all threads; contains barriers (B), (C).
+// and leaves every bin zero for the next sample.  Called by all threads; contains barrier (B) only:
+// wavefront w owns positions [512 w, 512 w + 512) and knows the depth at its left edge from L.carry[w] (the pieces that
+// cover position 512 w - 1, counted while they were classified), so the prefix sum never leaves the wavefront; allele
+// events are placed per wavefront too (one LDS reservation in the staging buffer, or -- staging full, noisy reads --
+// one reservation in the event list; the lanes write at their prefix-sum offsets).
 template <typename LDS, int EXC_PAD>
 __device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_t (&tc)[N_PPT], const uint32_t t0,
                                             const int tid, const int lane, const int wave, const uint32_t sample, const uint32_t k,
-                                            const uint32_t split, const uint32_t par) {
+                                            const uint32_t split) {
     __syncthreads();                                        // (B)
     const uint2 st = *reinterpret_cast<uint2 *>(&L.start[2 * tid]);
     const uint2 en = *reinterpret_cast<uint2 *>(&L.end[2 * tid]);
     const uint2 ex = *reinterpret_cast<uint2 *>(&L.exc[EXC_PAD + tid]);
     const uint4 a0 = *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid]);
     const uint4 a1 = *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid + 4]);
+    int d = (int)L.carry[wave];
     *reinterpret_cast<uint2 *>(&L.start[2 * tid]) = make_uint2(0u, 0u);
     *reinterpret_cast<uint2 *>(&L.end[2 * tid]) = make_uint2(0u, 0u);
     L.exc[EXC_PAD + tid] = 0ull;
+    if (lane == 0) L.carry[wave] = 0u;
     if (tid == 0) L.end[TILE / 4] = 0;
     const uint32_t anyal = a0.x | a0.y | a0.z | a0.w | a1.x | a1.y | a1.z | a1.w;
     if (anyal) {
         *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid]) = make_uint4(0u, 0u, 0u, 0u);
         *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid + 4]) = make_uint4(0u, 0u, 0u, 0u);
-        atomicAdd(&L.evpass[par], count_nz_bytes(a0, a1));  // allele events of my positions
     }
-    if (tid == 0 && L.evn) atomicAdd(&L.evpass[par], L.evn);   // + what is staged (stable here: staging happens after (C), flushes at (A))
     const int mine = (int)(__builtin_amdgcn_udot4(st.x, 0x01010101u, __builtin_amdgcn_udot4(st.y, 0x01010101u, 0u, false), false)) -
                      (int)(__builtin_amdgcn_udot4(en.x, 0x01010101u, __builtin_amdgcn_udot4(en.y, 0x01010101u, 0u, false), false));
-    const int incl = wave_inclusive_scan(mine);
-    if (lane == 63) L.wsum[wave] = incl;
-    __syncthreads();                                        // (C)
-    int d = incl - mine;
-    for (int wv = 0; wv < wave; ++wv) d += L.wsum[wv];
-    // The events of this pass fit the staging buffer (one returning global atomic per flush), or -- noisy reads,
-    // block-uniform decision -- the pass reserves its range of the event list at once and every thread writes its
-    // events at its prefix-sum offset.  Either way no thread ever needs an atomic of its own on the list counter.
-    const uint32_t staged_and_pass = __builtin_amdgcn_readfirstlane(L.evpass[par]);
-    if (tid == 0) L.evpass[par ^ 1u] = 0u;                  // the other counter serves the next pass, which starts behind barrier (A)
-    const bool direct = staged_and_pass > (uint32_t)N_EVCAP;
+    d += wave_inclusive_scan(mine) - mine;
     uint32_t packed[2] = {0u, 0u};
 #pragma unroll
     for (int j = 0; j < N_PPT; ++j) {
@@ -386,15 +380,20 @@ __device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_
         packed[j >> 2] |= (cov & 0xffu) << (8 * (j & 3));
     }
     *reinterpret_cast<uint2 *>(a.spill + (uint64_t)k * TILE + N_PPT * tid) = make_uint2(packed[0], packed[1]);
-    uint32_t gofs = 0;
-    if (direct) {                                           // one reservation per wave: exclusive prefix of the lanes' event counts
-        const uint32_t myev = count_nz_bytes(a0, a1);
-        const uint32_t ei = (uint32_t)wave_inclusive_scan((int)myev);
-        uint32_t wbase = 0;
-        if (lane == 63 && ei) wbase = atomicAdd(a.ev_count, ei);
-        gofs = (uint32_t)__builtin_amdgcn_readlane((int)wbase, 63) + ei - myev;
+    if (!__any(anyal != 0u)) return;                        // no mismatching allele in this wavefront's 512 positions
+    // ---- allele events of the wavefront: exclusive prefix of the lanes' event counts (non-zero allele bytes)
+    const uint32_t myev = count_nz_bytes(a0, a1);
+    const uint32_t ei = (uint32_t)wave_inclusive_scan((int)myev);
+    uint32_t res = 0;
+    if (lane == 63) {
+        const uint32_t old = atomicAdd(&L.evn, ei);
+        if (old + ei <= (uint32_t)N_EVCAP) res = old;                             // staged: flushed behind a later barrier (A)
+        else { atomicSub(&L.evn, ei); res = 0x80000000u | atomicAdd(a.ev_count, ei); }   // straight into the list
     }
-    if (anyal) {                                            // rare: some position of mine saw a mismatching allele
+    res = (uint32_t)__builtin_amdgcn_readlane((int)res, 63);
+    const bool direct = (res & 0x80000000u) != 0u;
+    uint32_t slot = (res & 0x7fffffffu) + ei - myev;
+    if (anyal) {
         const uint32_t alw[N_PPT] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
         uint32_t pm = 0;
 #pragma unroll
@@ -414,8 +413,9 @@ __device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_
                     // candidate of the individual rule; a sample that was split into several pairs may reach the threshold only in sum
                     if (n >= a.min_snvs || split) atomicOr(&a.ind_bits[gpos >> 5], 1u << (gpos & 31u));
                     const Pair32 e{gpos, sample << 18 | x << 16 | n};
-                    if (direct) { if (gofs < a.cap_events) a.events[gofs] = e; ++gofs; }
-                    else stage_allele_event<LDS, N_EVCAP>(L, a, e);
+                    if (direct) { if (slot < a.cap_events) a.events[slot] = e; }
+                    else L.ev[slot] = e;
+                    ++slot;
                 }
             }
         }
@@ -500,8 +500,9 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32(PileupArgs a)
     for (int i = tid; i < (int)(TILE / 8 + 4); i += N_NT) L.exc[i] = 0;
     L.spread[tid] = ((unsigned long long)((((uint32_t)tid >> 4) * 0x00204081u) & 0x01010101u) << 32) | (((uint32_t)tid & 0xfu) * 0x00204081u & 0x01010101u);
     for (int i = tid; i < (int)TILE; i += N_NT) L.al[i] = 0;
-    if (tid == 0) { L.evn = 0; L.evpass[0] = 0; L.evpass[1] = 0; }
-    uint32_t tc[N_PPT], npass = 0;
+    if (tid == 0) L.evn = 0;
+    if (tid < N_NT / 64 + 1) L.carry[tid] = 0;
+    uint32_t tc[N_PPT];
 #pragma unroll
     for (int j = 0; j < N_PPT; ++j) tc[j] = 0;
 
@@ -526,6 +527,11 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32(PileupArgs a)
         __syncthreads();                                            // (A)
         desc_refill(L.desc, a.chunks + w.chunk_lo, c, nch, tid);
         if (L.evn >= (uint32_t)(N_EVCAP / 2)) flush_events<NarrowLds, N_NT, N_EVCAP>(L, a, tid);
+        if (tid < N_HCAP) {                                          // a piece that covers the last position before a wavefront's
+            const uint32_t hx = L.hdr[buf][tid].x;                   // quarter of the tile feeds that quarter's carry (narrow_pass)
+            const uint32_t s = hx & (TILE - 1u), sb = s + (hx >> 11);
+            if ((s >> 9) != (sb >> 9)) atomicAdd(&L.carry[sb >> 9], 1u);
+        }
 
         const uint8_t *seq = a.seq + cd.seq_base;
         const uint8_t *qual = a.qual + 2 * cd.seq_base;
@@ -555,7 +561,7 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32(PileupArgs a)
         for (int i = 0; i < N32_ROUNDS; ++i)
             if (__any(vh[i] > 0)) narrow_classify32(L, qa[i], qb[i], sq[i], P0[i], vh[i], kq);
 
-        if (last_chunk) narrow_pass<NarrowLds, 0>(L, a, tc, t0, tid, lane, wave, cd.sample, cd.pair, cd.pad, npass++ & 1u);
+        if (last_chunk) narrow_pass<NarrowLds, 0>(L, a, tc, t0, tid, lane, wave, cd.sample, cd.pair, cd.pad);
         buf ^= 1;
     }
     __syncthreads();
@@ -587,8 +593,8 @@ struct DenseLds {
     uint32_t ref[TILE / 8 + D_PAD + 8];
     Pair32   ev[N_EVCAP];
     ChunkDesc desc[MAX_CHUNKS_PER_ITEM];
-    int32_t  wsum[N_NT / 64];
-    uint32_t evn, ev_base, evpass[2];
+    uint32_t carry[N_NT / 64 + 1];             // depth at the left edge of each wavefront's quarter of the tile ([4]: scratch for pieces that end at the tile end)
+    uint32_t evn, ev_base;
 };
 
 // nibble flags (bit 4j+3) of the bases j in [lo, hi) of the 8-base word k
@@ -649,8 +655,9 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_dense(PileupArgs a) {
     for (int i = tid; i < (int)(TILE / 4 + 4); i += N_NT) { L.start[i] = 0; L.end[i] = 0; }
     L.spread[tid] = ((unsigned long long)((((uint32_t)tid >> 4) * 0x00204081u) & 0x01010101u) << 32) | (((uint32_t)tid & 0xfu) * 0x00204081u & 0x01010101u);
     for (int i = tid; i < (int)TILE; i += N_NT) L.al[i] = 0;
-    if (tid == 0) { L.evn = 0; L.evpass[0] = 0; L.evpass[1] = 0; }
-    uint32_t tc[N_PPT], npass = 0;
+    if (tid == 0) L.evn = 0;
+    if (tid < N_NT / 64 + 1) L.carry[tid] = 0;
+    uint32_t tc[N_PPT];
 #pragma unroll
     for (int j = 0; j < N_PPT; ++j) tc[j] = 0;
 
@@ -706,8 +713,11 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_dense(PileupArgs a) {
             const uint32_t sB = (nA + 1u) & ~1u;
             if (d & BLK_START_A) atomicAdd(&L.start[P0A >> 2], 1u << (8u * (P0A & 3u)));
             if (d & BLK_END_A) { const uint32_t e = P0A + nA; atomicAdd(&L.end[e >> 2], 1u << (8u * (e & 3u))); }
+            // a segment that covers the last position before a wavefront's quarter of the tile feeds that quarter's carry
+            if (d != BLK_EMPTY && (P0A >> 9) != ((P0A + nA) >> 9)) atomicAdd(&L.carry[(P0A + nA) >> 9], 1u);
             if (hasB) {
                 const uint32_t s = PBv + sB - 32u;
+                if ((s >> 9) != (PBv >> 9)) atomicAdd(&L.carry[PBv >> 9], 1u);
                 atomicAdd(&L.start[s >> 2], 1u << (8u * (s & 3u)));
                 if (d & BLK_END_B) { const uint32_t e = PBv; atomicAdd(&L.end[e >> 2], 1u << (8u * (e & 3u))); }   // s + (32 - sB) = PBv
             }
@@ -715,7 +725,7 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_dense(PileupArgs a) {
             dense_segment(L, sq[r], lq, P0A + 32u, 0, (int)nA);
             if (__any(hasB)) dense_segment(L, sq[r], lq, hasB ? PBv : 32u, hasB ? (int)sB : 32, 32);
         }
-        if (last_chunk) narrow_pass<DenseLds, D_PAD>(L, a, tc, t0, tid, lane, wave, cd.sample, cd.pair, cd.pad, npass++ & 1u);
+        if (last_chunk) narrow_pass<DenseLds, D_PAD>(L, a, tc, t0, tid, lane, wave, cd.sample, cd.pair, cd.pad);
     }
     __syncthreads();
     flush_events<DenseLds, N_NT, N_EVCAP>(L, a, tid);
