@@ -347,7 +347,7 @@ struct NarrowLds {
 // events are placed per wavefront too (one LDS reservation in the staging buffer, or -- staging full, noisy reads --
 // one reservation in the event list; the lanes write at their prefix-sum offsets).
 template <typename LDS, int EXC_PAD>
-__device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_t (&tc)[N_PPT], const uint32_t t0,
+__device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_t (&tc)[N_PPT / 2], const uint32_t t0,
                                             const int tid, const int lane, const int wave, const uint32_t sample, const uint32_t k,
                                             const uint32_t split) {
     __syncthreads();                                        // (B)
@@ -369,17 +369,16 @@ __device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_
     }
     const int mine = (int)(__builtin_amdgcn_udot4(st.x, 0x01010101u, __builtin_amdgcn_udot4(st.y, 0x01010101u, 0u, false), false)) -
                      (int)(__builtin_amdgcn_udot4(en.x, 0x01010101u, __builtin_amdgcn_udot4(en.y, 0x01010101u, 0u, false), false));
-    d += wave_inclusive_scan(mine) - mine;
-    uint32_t packed[2] = {0u, 0u};
-#pragma unroll
-    for (int j = 0; j < N_PPT; ++j) {
-        const uint32_t sw = (j < 4) ? st.x : st.y, ew = (j < 4) ? en.x : en.y, xw = (j < 4) ? ex.x : ex.y;
-        d += (int)((sw >> (8 * (j & 3))) & 0xffu) - (int)((ew >> (8 * (j & 3))) & 0xffu);
-        const uint32_t cov = (uint32_t)d - ((xw >> (8 * (j & 3))) & 0xffu);
-        tc[j] += cov;
-        packed[j >> 2] |= (cov & 0xffu) << (8 * (j & 3));
-    }
-    *reinterpret_cast<uint2 *>(a.spill + (uint64_t)k * TILE + N_PPT * tid) = make_uint2(packed[0], packed[1]);
+    d += wave_inclusive_scan(mine) - mine;                  // depth just left of my 8 positions
+    // SWAR prefix sum: (d + starts - ends) * 0x01010101 holds the depth of 4 positions in its 4 bytes -- byte k of x * 0x01010101
+    // is the sum of bytes 0..k of x, and the identity is exact mod 2^32 whatever the intermediate borrows because every true
+    // depth is in [0, 255) (host bound).  Minus the not-counted bases = the per-sample coverage bytes = the spill words.
+    const uint32_t v0 = ((uint32_t)d + st.x - en.x) * 0x01010101u;
+    const uint32_t v1 = ((v0 >> 24) + st.y - en.y) * 0x01010101u;
+    const uint32_t c0 = v0 - ex.x, c1 = v1 - ex.y;
+    tc[0] += c0 & 0x00ff00ffu; tc[1] += (c0 >> 8) & 0x00ff00ffu;   // running totals, two u16 per register: positions (0,2) (1,3) (4,6) (5,7)
+    tc[2] += c1 & 0x00ff00ffu; tc[3] += (c1 >> 8) & 0x00ff00ffu;
+    *reinterpret_cast<uint2 *>(a.spill + (uint64_t)k * TILE + N_PPT * tid) = make_uint2(c0, c1);
     if (!__any(anyal != 0u)) return;                        // no mismatching allele in this wavefront's 512 positions
     // ---- allele events of the wavefront: exclusive prefix of the lanes' event counts (non-zero allele bytes)
     const uint32_t myev = count_nz_bytes(a0, a1);
@@ -502,9 +501,7 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32(PileupArgs a)
     for (int i = tid; i < (int)TILE; i += N_NT) L.al[i] = 0;
     if (tid == 0) L.evn = 0;
     if (tid < N_NT / 64 + 1) L.carry[tid] = 0;
-    uint32_t tc[N_PPT];
-#pragma unroll
-    for (int j = 0; j < N_PPT; ++j) tc[j] = 0;
+    uint32_t tc[N_PPT / 2] = {0u, 0u, 0u, 0u};                  // coverage totals of my 8 positions over the item's samples (u16 pairs)
 
     const uint32_t nch = w.chunk_hi - w.chunk_lo;
     // the chunk descriptors go through a ring of MAX_CHUNKS_PER_ITEM LDS slots: one deep (sample, tile) pair alone can
@@ -568,7 +565,7 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32(PileupArgs a)
     flush_events<NarrowLds, N_NT, N_EVCAP>(L, a, tid);
     // this item's coverage partial: 8 positions x u16 (an item holds <= 32 pairs of depth < 255)
     *reinterpret_cast<uint4 *>(a.part + ((uint64_t)w.part_hi << 32 | w.part_lo) + 2u * N_PPT * tid) =
-        make_uint4(tc[0] | tc[1] << 16, tc[2] | tc[3] << 16, tc[4] | tc[5] << 16, tc[6] | tc[7] << 16);
+        make_uint4((tc[0] & 0xffffu) | tc[1] << 16, tc[0] >> 16 | (tc[1] & 0xffff0000u), (tc[2] & 0xffffu) | tc[3] << 16, tc[2] >> 16 | (tc[3] & 0xffff0000u));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -657,9 +654,7 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_dense(PileupArgs a) {
     for (int i = tid; i < (int)TILE; i += N_NT) L.al[i] = 0;
     if (tid == 0) L.evn = 0;
     if (tid < N_NT / 64 + 1) L.carry[tid] = 0;
-    uint32_t tc[N_PPT];
-#pragma unroll
-    for (int j = 0; j < N_PPT; ++j) tc[j] = 0;
+    uint32_t tc[N_PPT / 2] = {0u, 0u, 0u, 0u};                  // coverage totals of my 8 positions over the item's samples (u16 pairs)
 
     const uint32_t nch = w.chunk_hi - w.chunk_lo;
     // the chunk descriptors go through a ring of MAX_CHUNKS_PER_ITEM LDS slots: one deep (sample, tile) pair alone can
@@ -731,7 +726,7 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_dense(PileupArgs a) {
     flush_events<DenseLds, N_NT, N_EVCAP>(L, a, tid);
     // this item's coverage partial: 8 positions x u16 (an item holds <= 32 pairs of depth < 255)
     *reinterpret_cast<uint4 *>(a.part + ((uint64_t)w.part_hi << 32 | w.part_lo) + 2u * N_PPT * tid) =
-        make_uint4(tc[0] | tc[1] << 16, tc[2] | tc[3] << 16, tc[4] | tc[5] << 16, tc[6] | tc[7] << 16);
+        make_uint4((tc[0] & 0xffffu) | tc[1] << 16, tc[0] >> 16 | (tc[1] & 0xffff0000u), (tc[2] & 0xffffu) | tc[3] << 16, tc[2] >> 16 | (tc[3] & 0xffff0000u));
 }
 
 // ------------------------------------------------------------------------------------------
