@@ -468,15 +468,15 @@ __device__ __forceinline__ void narrow_classify32(NarrowLds &L, const uint4 qa, 
         const uint32_t vn = (n == 8) ? 0x88888888u : (((1u << (4 * n)) - 1u) & 0x88888888u);
         e[k] = nz_nibbles(sw[k] ^ rw[k]) & vn;
     }
-    while (e[0] | e[1] | e[2] | e[3]) {                              // mismatches (rare)
-        const int k = e[0] ? 0 : e[1] ? 1 : e[2] ? 2 : 3;
-        const uint32_t ew = e[0] ? e[0] : e[1] ? e[1] : e[2] ? e[2] : e[3];
-        const uint32_t b = (uint32_t)__builtin_ctz(ew);
-        if (k == 0) e[0] &= e[0] - 1u; else if (k == 1) e[1] &= e[1] - 1u; else if (k == 2) e[2] &= e[2] - 1u; else e[3] &= e[3] - 1u;
-        const uint32_t j = (b >> 2) + 8u * (uint32_t)k;
+    // mismatch flags of the four words in ONE register: bit 4 j + k <-> base 8 k + j (flag bits 4 j + 3 shifted down by 3 - k)
+    uint32_t E = (e[0] >> 3) | (e[1] >> 2) | (e[2] >> 1) | e[3];
+    while (E) {                                                      // mismatches (rare)
+        const uint32_t b = (uint32_t)__builtin_ctz(E);
+        E &= E - 1u;
+        const uint32_t k = b & 3u, jn = b >> 2, j = jn + 8u * k;
         if ((lq >> j) & 1u) continue;                                  // below the BQ cutoff: already in exc
-        const uint32_t word = (k == 0) ? sw[0] : (k == 1) ? sw[1] : (k == 2) ? sw[2] : sw[3];
-        const uint32_t code = (word >> (b - 3u)) & 0xfu;
+        const uint32_t word = (k == 0u) ? sw[0] : (k == 1u) ? sw[1] : (k == 2u) ? sw[2] : sw[3];
+        const uint32_t code = (word >> (4u * jn)) & 0xfu;
         const uint32_t p = P0 + j;
         if ((code & (code - 1u)) == 0u) atomicAdd(&L.al[p], 1u << (8u * (uint32_t)__builtin_ctz(code)));
         else atomicAdd(&L.exc[p >> 3], 1ull << (8u * (p & 7u)));
