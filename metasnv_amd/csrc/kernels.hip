@@ -461,12 +461,14 @@ __device__ __forceinline__ void narrow_classify32(NarrowLds &L, const uint4 qa, 
     const uint32_t sw[4] = {sq.x, sq.y, sq.z, sq.w};
     const uint32_t rw[4] = {__builtin_amdgcn_alignbit(w1, w0, sh), __builtin_amdgcn_alignbit(w2, w1, sh),
                             __builtin_amdgcn_alignbit(w3, w2, sh), __builtin_amdgcn_alignbit(w4, w3, sh)};
+    // the host fills the alignment padding behind a piece (up to the next 16 bases) with the reference it is compared with
+    // here, so mismatch flags are masked per 16 bases: words 0-1 exist when the lane has any base, words 2-3 beyond 16
+    const uint32_t v01 = (vhi > 0) ? 0x88888888u : 0u, v23 = (vhi > 16) ? 0x88888888u : 0u;
     uint32_t e[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int n = min(max(vhi - 8 * k, 0), 8);
-        const uint32_t vn = (n == 8) ? 0x88888888u : (((1u << (4 * n)) - 1u) & 0x88888888u);
-        e[k] = nz_nibbles(sw[k] ^ rw[k]) & vn;
+        const uint32_t x = sw[k] ^ rw[k];
+        e[k] = (((x & 0x77777777u) + 0x77777777u) | x) & (k < 2 ? v01 : v23);
     }
     // mismatch flags of the four words in ONE register: bit 4 j + k <-> base 8 k + j (flag bits 4 j + 3 shifted down by 3 - k)
     uint32_t E = (e[0] >> 3) | (e[1] >> 2) | (e[2] >> 1) | e[3];
@@ -621,15 +623,14 @@ __device__ __forceinline__ void dense_segment(DenseLds &L, const uint4 sq, const
     uint32_t e[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) e[k] = nz_nibbles(sw[k] ^ rw[k]) & range_nibbles(lo, hi, k);
-    while (e[0] | e[1] | e[2] | e[3]) {                              // mismatches (rare)
-        const int k = e[0] ? 0 : e[1] ? 1 : e[2] ? 2 : 3;
-        const uint32_t ew = e[0] ? e[0] : e[1] ? e[1] : e[2] ? e[2] : e[3];
-        const uint32_t b = (uint32_t)__builtin_ctz(ew);
-        if (k == 0) e[0] &= e[0] - 1u; else if (k == 1) e[1] &= e[1] - 1u; else if (k == 2) e[2] &= e[2] - 1u; else e[3] &= e[3] - 1u;
-        const uint32_t j = (b >> 2) + 8u * (uint32_t)k;
+    uint32_t E = (e[0] >> 3) | (e[1] >> 2) | (e[2] >> 1) | e[3];     // bit 4 j + k <-> base 8 k + j (narrow_classify32)
+    while (E) {                                                      // mismatches (rare)
+        const uint32_t b = (uint32_t)__builtin_ctz(E);
+        E &= E - 1u;
+        const uint32_t k = b & 3u, jn = b >> 2, j = jn + 8u * k;
         if ((lq >> j) & 1u) continue;                                  // below the BQ cutoff: already in exc
-        const uint32_t word = (k == 0) ? sw[0] : (k == 1) ? sw[1] : (k == 2) ? sw[2] : sw[3];
-        const uint32_t code = (word >> (b - 3u)) & 0xfu;
+        const uint32_t word = (k == 0u) ? sw[0] : (k == 1u) ? sw[1] : (k == 2u) ? sw[2] : sw[3];
+        const uint32_t code = (word >> (4u * jn)) & 0xfu;
         const uint32_t pp = P + j;                                     // padded position of the base
         if ((code & (code - 1u)) == 0u) atomicAdd(&L.al[pp - 32u], 1u << (8u * (uint32_t)__builtin_ctz(code)));
         else atomicAdd(&L.exc[pp >> 3], 1ull << (8u * (pp & 7u)));

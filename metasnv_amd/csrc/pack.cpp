@@ -389,8 +389,9 @@ int finalize_dataset(msnv_dataset &ds) {
     d->n_tiles = ds.n_tiles; d->n_samples = (uint32_t)S;
 
     // ---- reference: nt16 codes (N beyond the contig end, as mpileup prints) + lower-case bits
+    std::vector<uint32_t> ref4(npos / 8 + 1, 0xffffffffu);
     {
-        std::vector<uint32_t> ref4(npos / 8 + 1, 0xffffffffu), lc(npos / 32 + 1, 0u);
+        std::vector<uint32_t> lc(npos / 32 + 1, 0u);
         for (size_t c = 0; c < NC; ++c) {
             if (!ds.sel[c] || !ds.has_seq[c]) continue;
             const std::string &s = ds.seqs[c];
@@ -455,6 +456,19 @@ int finalize_dataset(msnv_dataset &ds) {
             const uint64_t gs = (uint64_t)ds.tile_base[c] * TILE + sc.hdr[i].gpos;
             sc.hdr[i].gpos = (uint32_t)gs;
             const uint32_t t = (uint32_t)(gs / TILE);
+            static_assert(seq_align == 8, "msnv_pileup_tiles_narrow32 masks mismatch flags per 16 bases = one 8-byte alignment unit");
+            if (!dense) {
+                // The alignment padding behind a piece (up to the next 16 bases) reads as the reference the kernel compares
+                // it with (N beyond the tile): msnv_pileup_tiles_narrow32 then masks mismatch flags per 16 bases, not per base.
+                const uint32_t len = sc.hdr[i].cig, stop = (len + 2u * seq_align - 1u) & ~(2u * seq_align - 1u);
+                uint8_t *sp = sc.seq.data() + sc.hdr[i].seqoff;
+                for (uint32_t j = len; j < stop; ++j) {
+                    const uint64_t g = gs + j;
+                    const uint32_t code = (gs % TILE + j < TILE) ? (ref4[g >> 3] >> (4 * (g & 7))) & 0xfu : 0xfu;
+                    const int sh = (int)(j & 1u) * 4;
+                    sp[j >> 1] = (uint8_t)((sp[j >> 1] & ~(0xf << sh)) | code << sh);
+                }
+            }
             if (!pv.empty() && pv.back().tile == t && pv.back().grp == sc.grp[i]) pv.back().hi = (uint32_t)i + 1;
             else pv.push_back(PairTmp{t, (uint32_t)s, (uint32_t)i, (uint32_t)i + 1, 0, (uint32_t)pv.size(), sc.grp[i]});
         }
