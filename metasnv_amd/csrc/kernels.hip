@@ -341,7 +341,7 @@ struct NarrowLds {
 
 // Per-sample pass of the narrow kernel: prefix sum of start/end -> depth, minus the not-counted bases;
 // adds the sample to the running totals, spills the per-sample coverage bytes, emits allele events,
-// and leaves every bin zero for the next sample.  Called by all threads; contains barrier (B) only:
+// and leaves every bin zero for the next sample.  Called by all threads right behind barrier (B); no barrier inside:
 // wavefront w owns positions [512 w, 512 w + 512) and knows the depth at its left edge from L.carry[w] (the pieces that
 // cover position 512 w - 1, counted while they were classified), so the prefix sum never leaves the wavefront; allele
 // events are placed per wavefront too (one LDS reservation in the staging buffer, or -- staging full, noisy reads --
@@ -350,23 +350,15 @@ template <typename LDS, int EXC_PAD>
 __device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_t (&tc)[N_PPT / 2], const uint32_t t0,
                                             const int tid, const int lane, const int wave, const uint32_t sample, const uint32_t k,
                                             const uint32_t split) {
-    __syncthreads();                                        // (B)
     const uint2 st = *reinterpret_cast<uint2 *>(&L.start[2 * tid]);
     const uint2 en = *reinterpret_cast<uint2 *>(&L.end[2 * tid]);
     const uint2 ex = *reinterpret_cast<uint2 *>(&L.exc[EXC_PAD + tid]);
-    const uint4 a0 = *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid]);
-    const uint4 a1 = *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid + 4]);
     int d = (int)L.carry[wave];
     *reinterpret_cast<uint2 *>(&L.start[2 * tid]) = make_uint2(0u, 0u);
     *reinterpret_cast<uint2 *>(&L.end[2 * tid]) = make_uint2(0u, 0u);
     L.exc[EXC_PAD + tid] = 0ull;
     if (lane == 0) L.carry[wave] = 0u;
     if (tid == 0) L.end[TILE / 4] = 0;
-    const uint32_t anyal = a0.x | a0.y | a0.z | a0.w | a1.x | a1.y | a1.z | a1.w;
-    if (anyal) {
-        *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid]) = make_uint4(0u, 0u, 0u, 0u);
-        *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid + 4]) = make_uint4(0u, 0u, 0u, 0u);
-    }
     const int mine = (int)(__builtin_amdgcn_udot4(st.x, 0x01010101u, __builtin_amdgcn_udot4(st.y, 0x01010101u, 0u, false), false)) -
                      (int)(__builtin_amdgcn_udot4(en.x, 0x01010101u, __builtin_amdgcn_udot4(en.y, 0x01010101u, 0u, false), false));
     d += wave_inclusive_scan(mine) - mine;                  // depth just left of my 8 positions
@@ -379,10 +371,19 @@ __device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_
     tc[0] += c0 & 0x00ff00ffu; tc[1] += (c0 >> 8) & 0x00ff00ffu;   // running totals, two u16 per register: positions (0,2) (1,3) (4,6) (5,7)
     tc[2] += c1 & 0x00ff00ffu; tc[3] += (c1 >> 8) & 0x00ff00ffu;
     *reinterpret_cast<uint2 *>(a.spill + (uint64_t)k * TILE + N_PPT * tid) = make_uint2(c0, c1);
-    if (!__any(anyal != 0u)) return;                        // no mismatching allele in this wavefront's 512 positions
-    // ---- allele events of the wavefront: exclusive prefix of the lanes' event counts (non-zero allele bytes)
-    const uint32_t myev = count_nz_bytes(a0, a1);
-    const uint32_t ei = (uint32_t)wave_inclusive_scan((int)myev);
+    // ---- allele events.  The allele bins are only looked at here, and word by word again when events are written: the
+    // registers of the next chunk's column loads are live across this pass.
+    uint32_t pm = 0, myev;                                   // positions of mine with a mismatching allele; (position, allele) events
+    {
+        const uint4 a0 = *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid]);
+        const uint4 a1 = *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid + 4]);
+        const uint32_t alw[N_PPT] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+        for (int j = 0; j < N_PPT; ++j) pm |= (alw[j] ? 1u : 0u) << j;
+        myev = count_nz_bytes(a0, a1);
+    }
+    if (!__any(pm != 0u)) return;                            // no mismatching allele in this wavefront's 512 positions
+    const uint32_t ei = (uint32_t)wave_inclusive_scan((int)myev);   // exclusive prefix of the lanes' event counts = their slots
     uint32_t res = 0;
     if (lane == 63) {
         const uint32_t old = atomicAdd(&L.evn, ei);
@@ -392,30 +393,23 @@ __device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_
     res = (uint32_t)__builtin_amdgcn_readlane((int)res, 63);
     const bool direct = (res & 0x80000000u) != 0u;
     uint32_t slot = (res & 0x7fffffffu) + ei - myev;
-    if (anyal) {
-        const uint32_t alw[N_PPT] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-        uint32_t pm = 0;
+    while (pm) {
+        const uint32_t j = (uint32_t)__builtin_ctz(pm);
+        pm &= pm - 1u;
+        const uint32_t word = L.al[N_PPT * tid + j];
+        L.al[N_PPT * tid + j] = 0u;
+        const uint32_t gpos = t0 + N_PPT * tid + j;
 #pragma unroll
-        for (int j = 0; j < N_PPT; ++j) pm |= (alw[j] ? 1u : 0u) << j;
-        while (pm) {
-            const uint32_t j = (uint32_t)__builtin_ctz(pm);
-            pm &= pm - 1u;
-            uint32_t word = alw[0];
-#pragma unroll
-            for (int q = 1; q < N_PPT; ++q) word = (j == (uint32_t)q) ? alw[q] : word;
-            const uint32_t gpos = t0 + N_PPT * tid + j;
-#pragma unroll
-            for (uint32_t x = 0; x < 4; ++x) {
-                const uint32_t n = (word >> (8u * x)) & 0xffu;
-                if (n) {
-                    atomicAdd(&a.tot[(uint64_t)x * a.npos + gpos], n);
-                    // candidate of the individual rule; a sample that was split into several pairs may reach the threshold only in sum
-                    if (n >= a.min_snvs || split) atomicOr(&a.ind_bits[gpos >> 5], 1u << (gpos & 31u));
-                    const Pair32 e{gpos, sample << 18 | x << 16 | n};
-                    if (direct) { if (slot < a.cap_events) a.events[slot] = e; }
-                    else L.ev[slot] = e;
-                    ++slot;
-                }
+        for (uint32_t x = 0; x < 4; ++x) {
+            const uint32_t n = (word >> (8u * x)) & 0xffu;
+            if (n) {
+                atomicAdd(&a.tot[(uint64_t)x * a.npos + gpos], n);
+                // candidate of the individual rule; a sample that was split into several pairs may reach the threshold only in sum
+                if (n >= a.min_snvs || split) atomicOr(&a.ind_bits[gpos >> 5], 1u << (gpos & 31u));
+                const Pair32 e{gpos, sample << 18 | x << 16 | n};
+                if (direct) { if (slot < a.cap_events) a.events[slot] = e; }
+                else L.ev[slot] = e;
+                ++slot;
             }
         }
     }
@@ -511,41 +505,30 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32(PileupArgs a)
     for (uint32_t i = tid; i < min(nch, (uint32_t)MAX_CHUNKS_PER_ITEM) * 2; i += N_NT)
         reinterpret_cast<uint4 *>(L.desc)[i] = reinterpret_cast<const uint4 *>(a.chunks + w.chunk_lo)[i];
     __syncthreads();
-    uint2 hreg = make_uint2(0, 0);
-    if (nch && tid < N_HCAP && (uint32_t)tid < (L.desc[0].nrd_flags & 0xffffu))
-        hreg = *reinterpret_cast<const uint2 *>(a.hdr8 + L.desc[0].hdr_base + tid);
-    int buf = 0;
-
-    for (uint32_t c = 0; c < nch; ++c) {
-        const ChunkDesc cd = L.desc[c % MAX_CHUNKS_PER_ITEM];
-        const bool last_chunk = (cd.nrd_flags >> 16) != 0u;
-        if (tid < N_HCAP) L.hdr[buf][tid] = hreg;                    // slots beyond nrd hold length 0
-        hreg = make_uint2(0, 0);
-        if (c + 1 < nch && tid < N_HCAP && (uint32_t)tid < (L.desc[(c + 1) % MAX_CHUNKS_PER_ITEM].nrd_flags & 0xffffu))
-            hreg = *reinterpret_cast<const uint2 *>(a.hdr8 + L.desc[(c + 1) % MAX_CHUNKS_PER_ITEM].hdr_base + tid);
-        __syncthreads();                                            // (A)
-        desc_refill(L.desc, a.chunks + w.chunk_lo, c, nch, tid);
-        if (L.evn >= (uint32_t)(N_EVCAP / 2)) flush_events<NarrowLds, N_NT, N_EVCAP>(L, a, tid);
-        if (tid < N_HCAP) {                                          // a piece that covers the last position before a wavefront's
-            const uint32_t hx = L.hdr[buf][tid].x;                   // quarter of the tile feeds that quarter's carry (narrow_pass)
-            const uint32_t s = hx & (TILE - 1u), sb = s + (hx >> 11);
-            if ((s >> 9) != (sb >> 9)) atomicAdd(&L.carry[sb >> 9], 1u);
-        }
-
-        const uint8_t *seq = a.seq + cd.seq_base;
-        const uint8_t *qual = a.qual + 2 * cd.seq_base;
-        uint4 qa[N32_ROUNDS], qb[N32_ROUNDS], sq[N32_ROUNDS]; uint32_t P0[N32_ROUNDS]; int vh[N32_ROUNDS];
+    // Headers of chunk c sit in L.hdr[c & 1]: written at the end of iteration c - 1 (chunk 0: here) from the registers that
+    // prefetched them one iteration earlier, visible behind barrier (B) of that iteration.  The column loads of chunk c + 1
+    // are issued right behind that barrier: when chunk c closes its (sample, tile) pair they are in flight while the
+    // per-sample pass runs (what a shallow pair needs: its chunk iteration is otherwise one exposed dependent-load latency).
+    auto load_hdr = [&](const uint32_t c) -> uint2 {
+        uint2 h = make_uint2(0, 0);                                   // slots beyond nrd hold length 0
+        if (c < nch && tid < N_HCAP && (uint32_t)tid < (L.desc[c % MAX_CHUNKS_PER_ITEM].nrd_flags & 0xffffu))
+            h = *reinterpret_cast<const uint2 *>(a.hdr8 + L.desc[c % MAX_CHUNKS_PER_ITEM].hdr_base + tid);
+        return h;
+    };
+    uint2 hreg = load_hdr(0);
+    if (tid < N_HCAP) L.hdr[0][tid] = hreg;
+    hreg = load_hdr(1);
+    uint4 qa[N32_ROUNDS], qb[N32_ROUNDS], sq[N32_ROUNDS]; uint32_t P0[N32_ROUNDS]; int vh[N32_ROUNDS];
+    auto issue_loads = [&](const uint32_t c) {
+        const uint64_t sbase = L.desc[c % MAX_CHUNKS_PER_ITEM].seq_base;
+        const uint8_t *seq = a.seq + sbase;
+        const uint8_t *qual = a.qual + 2 * sbase;
 #pragma unroll
         for (int i = 0; i < N32_ROUNDS; ++i) {
-            const uint2 h = L.hdr[buf][grp + i * N32_GROUPS];        // all zero for empty slots
+            const uint2 h = L.hdr[c & 1u][grp + i * N32_GROUPS];     // all zero for empty slots
             const uint32_t len = h.x >> 11;
             const uint32_t s = h.x & (TILE - 1u);
             const uint64_t so = (uint64_t)h.y << 3;                  // seq byte offset of the piece inside the sample
-            if (len && lane4 == 0) {
-                const uint32_t sb = s + len;
-                atomicAdd(&L.start[s >> 2], 1u << (8u * (s & 3u)));
-                atomicAdd(&L.end[sb >> 2], 1u << (8u * (sb & 3u)));
-            }
             vh[i] = min(max((int)len - b0, 0), 32);
             qa[i] = any_uint4(); qb[i] = any_uint4(); sq[i] = any_uint4();   // never observed: vh masks every use
             if (vh[i] > 0) {                                         // lanes past the end of the piece load nothing
@@ -556,12 +539,37 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32(PileupArgs a)
             }
             P0[i] = vh[i] > 0 ? s + (uint32_t)b0 : 0u;
         }
+    };
+    __syncthreads();
+    if (nch) issue_loads(0u);
+    bool prev_last = false;                                          // the bins start out zero
+
+    for (uint32_t c = 0; c < nch; ++c) {
+        const ChunkDesc cd = L.desc[c % MAX_CHUNKS_PER_ITEM];
+        const bool last_chunk = (cd.nrd_flags >> 16) != 0u;
+        if (prev_last) __syncthreads();                              // (A): the pass of the previous pair left every bin zero
+        desc_refill(L.desc, a.chunks + w.chunk_lo, c, nch, tid);
+        if (L.evn >= (uint32_t)(N_EVCAP / 2)) flush_events<NarrowLds, N_NT, N_EVCAP>(L, a, tid);
+        if (tid < N_HCAP) {
+            const uint32_t hx = L.hdr[c & 1u][tid].x;
+            const uint32_t s = hx & (TILE - 1u), sb = s + (hx >> 11);
+            if (sb != s) {                                           // coverage difference array: +1 at the start, -1 behind the end
+                atomicAdd(&L.start[s >> 2], 1u << (8u * (s & 3u)));
+                atomicAdd(&L.end[sb >> 2], 1u << (8u * (sb & 3u)));
+                // a piece that covers the last position before a wavefront's quarter of the tile feeds that quarter's carry
+                if ((s >> 9) != (sb >> 9)) atomicAdd(&L.carry[sb >> 9], 1u);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < N32_ROUNDS; ++i)
             if (__any(vh[i] > 0)) narrow_classify32(L, qa[i], qb[i], sq[i], P0[i], vh[i], kq);
 
+        if (tid < N_HCAP) L.hdr[(c + 1u) & 1u][tid] = hreg;          // headers of chunk c + 1 (zeros behind the last chunk)
+        hreg = load_hdr(c + 2u);
+        __syncthreads();                                            // (B): this chunk is in the bins; the next chunk's headers are visible
+        if (c + 1u < nch) issue_loads(c + 1u);                       // in flight under the per-sample pass
         if (last_chunk) narrow_pass<NarrowLds, 0>(L, a, tc, t0, tid, lane, wave, cd.sample, cd.pair, cd.pad);
-        buf ^= 1;
+        prev_last = last_chunk;
     }
     __syncthreads();
     flush_events<NarrowLds, N_NT, N_EVCAP>(L, a, tid);
@@ -721,7 +729,10 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_dense(PileupArgs a) {
             dense_segment(L, sq[r], lq, P0A + 32u, 0, (int)nA);
             if (__any(hasB)) dense_segment(L, sq[r], lq, hasB ? PBv : 32u, hasB ? (int)sB : 32, 32);
         }
-        if (last_chunk) narrow_pass<DenseLds, D_PAD>(L, a, tc, t0, tid, lane, wave, cd.sample, cd.pair, cd.pad);
+        if (last_chunk) {
+            __syncthreads();                                        // (B)
+            narrow_pass<DenseLds, D_PAD>(L, a, tc, t0, tid, lane, wave, cd.sample, cd.pair, cd.pad);
+        }
     }
     __syncthreads();
     flush_events<DenseLds, N_NT, N_EVCAP>(L, a, tid);
