@@ -241,6 +241,22 @@ def test_noisy_reads_reserve_their_event_ranges_per_pass(layout, monkeypatch):
     assert prod[0].count("\n") > 200
 
 
+@pytest.mark.parametrize("layout", ["pieces", "dense"])
+def test_shallow_cohort_and_contigs_shorter_than_a_tile(layout, monkeypatch):
+    """Many samples at ~1x over contigs of a few hundred bases: every (sample, tile) pair is a single short chunk, so each
+    chunk closes its pair and the next pair's column loads are issued under the per-sample pass (narrow32), work items hold
+    the maximum of 32 pairs, most tiles are mostly empty, and some samples have no read at all on a contig."""
+    monkeypatch.setenv("MSNV_LAYOUT", layout)
+    syn, samples = synth_case(n_species=40, contig_len=420, n_samples=120, mean_cov=1.2, sigma_cov=0.8, snv_density=0.05,
+                              frac_absent=0.2, seed=1601)
+    p = core.default_params(min_coverage=3, calling_threshold=2)
+    prod = run_product(syn.names, syn.lengths, syn.seqs, samples, params=p)
+    orac = run_oracle(syn.names, syn.lengths, syn.seqs, samples, params=p)
+    _assert_same(prod, orac)
+    assert prod[2]["n_pileup_bases"] == orac[3]
+    assert prod[2]["n_pairs"] > 2000 and prod[0].count("\n") > 100
+
+
 def test_annotation_codon_path(tmp_path):
     syn, samples = synth_case(n_species=2, contig_len=3000, n_samples=4, mean_cov=14.0, snv_density=0.03, frac_absent=0.0, seed=21)
     fa = str(tmp_path / "ref.fa")
