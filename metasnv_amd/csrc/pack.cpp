@@ -699,6 +699,7 @@ int finalize_dataset(msnv_dataset &ds) {
     if (int rc = dev_alloc((void **)&d->spill, std::max<uint64_t>(1, (uint64_t)pairs.size()) * TILE, &d->device_bytes)) return rc;
     // sparse buffers: generous first guess, grown on MSNV_ECAPACITY by the caller
     d->cap_events = (uint32_t)std::min<uint64_t>(0x7fffffffull, std::max<uint64_t>(1u << 20, tot_bases / 16));
+    if (const char *e = getenv("MSNV_CAP_EVENTS")) d->cap_events = (uint32_t)std::max<long long>(EV_LISTS, atoll(e));   // tests: force the grow-and-rerun path
     d->cap_overflow = (uint32_t)std::min<uint64_t>(0x7fffffffull, std::max<uint64_t>(1u << 16, npos / 8));
     d->cap_sites = (uint32_t)std::min<uint64_t>(0x7fffffffull, std::max<uint64_t>(1u << 16, npos / 4));
     if (int rc = dev_alloc((void **)&d->events, (uint64_t)d->cap_events * sizeof(Pair32), &d->device_bytes)) return rc;

@@ -257,6 +257,18 @@ def test_shallow_cohort_and_contigs_shorter_than_a_tile(layout, monkeypatch):
     assert prod[2]["n_pairs"] > 2000 and prod[0].count("\n") > 100
 
 
+def test_event_list_grows_when_a_sub_list_overflows(monkeypatch):
+    """The allele-event list is 32 sub-lists with their own counters; a pass that overflows one reports the capacity the
+    fullest asked for, the host grows the list and runs the pass again (msnv_pileup_run) -- same records, same event count."""
+    syn, samples = synth_case(n_species=2, contig_len=7000, n_samples=8, mean_cov=14.0, snv_density=0.03, error_rate=0.01, seed=909)
+    ref_run = run_product(syn.names, syn.lengths, syn.seqs, samples)
+    monkeypatch.setenv("MSNV_CAP_EVENTS", "1024")                    # 32 events per sub-list: every list overflows
+    prod = run_product(syn.names, syn.lengths, syn.seqs, samples)
+    orac = run_oracle(syn.names, syn.lengths, syn.seqs, samples)
+    _assert_same(prod, orac)
+    assert prod[3]["n_events"] == ref_run[3]["n_events"] > 4096
+
+
 def test_annotation_codon_path(tmp_path):
     syn, samples = synth_case(n_species=2, contig_len=3000, n_samples=4, mean_cov=14.0, snv_density=0.03, frac_absent=0.0, seed=21)
     fa = str(tmp_path / "ref.fa")
