@@ -219,7 +219,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt_max / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u16/u32 integer counts", "data": "synthetic",
+            "dtype": "u8", "data": "synthetic",
             "config": {"workload": "testdata shape: %d synthetic BAM-record streams x %d refGenomes x %d bp, ~%gx, single-end %d bp (BASELINE configs[1])"
                                    % (a.samples, a.species, a.contig_len, a.mean_cov, a.read_len),
                        "samples": a.samples, "positions_per_gpu": info["n_positions"], "pileup_bases_per_gpu": bases,
