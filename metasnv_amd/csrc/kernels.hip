@@ -4,7 +4,7 @@
 //   samtools mpileup CIGAR walk + BQ filter  [EXT]            -> msnv_pileup_tiles
 //   snpCall base-string parse + bpCounts      call_vC.cpp:503-535 -> msnv_pileup_tiles
 //   snpCall gates                             call_vC.cpp:545-552 -> msnv_gate_sites
-//   snpCall per-sample strings (counts only)  call_vC.cpp:316-325 -> msnv_gather_cov / msnv_scatter_events
+//   snpCall per-sample strings (counts only)  call_vC.cpp:316-325 -> msnv_gather_scatter
 //   snpCall population / individual rule      call_vC.cpp:577-601 -> msnv_decide_sites
 //
 // Everything is integer counting: the bound is HBM bandwidth, there is no MFMA-shaped work.
@@ -758,7 +758,8 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(uint32_t *tot, const 
                                                            const uint32_t *tile_vbeg, const uint32_t *tile_vend,
                                                            int min_cov, int min_snvs, double min_frac, const uint32_t *ind_bits,
                                                            unsigned long long *site_bits, uint32_t *site_rank, SiteRec *sites, uint32_t cap_sites, uint32_t *counters,
-                                                           uint32_t *tile_site_base, uint32_t *tile_site_cnt, const uint32_t *active_tiles) {
+                                                           uint32_t *tile_site_base, uint32_t *tile_site_cnt, const uint32_t *active_tiles,
+                                                           msnv_site_sample *out, uint32_t n_samples, uint32_t cap_out) {
     __shared__ uint32_t s_wave[GATE_CHUNKS][GATE_NT / 64];
     __shared__ uint32_t s_base;
     const uint32_t tile = active_tiles[blockIdx.x];           // tiles that hold work items; the others have no coverage
@@ -815,7 +816,7 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(uint32_t *tot, const 
             }
         }
         const unsigned long long b = __ballot(ok);
-        if (lane == 0) site_bits[(g - (uint64_t)lane) >> 6] = b;       // 1 bit per position: is a site (msnv_scatter_events filters on it)
+        if (lane == 0) site_bits[(g - (uint64_t)lane) >> 6] = b;       // 1 bit per position: is a site (the scatter half of msnv_gather_scatter filters on it)
         mypre[c] = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
         if (lane == 0) s_wave[c][wave] = (uint32_t)__popcll(b);
         flags |= (ok ? 1u : 0u) << c;
@@ -840,6 +841,12 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(uint32_t *tot, const 
     __syncthreads();
     if (total == 0) return;
     const uint32_t base = s_base;
+    if ((uint64_t)base + total <= cap_out) {                         // else: the host sees the site count and runs again with a larger buffer
+        // the per-sample records of this tile's sites start out zero: gather and scatter (one launch, side by side) only add to them
+        uint16_t *rows = reinterpret_cast<uint16_t *>(out + (uint64_t)base * n_samples);
+        const uint64_t nhw = (uint64_t)total * n_samples * (sizeof(msnv_site_sample) / 2);
+        for (uint64_t i = (uint64_t)tid; i < nhw; i += GATE_NT) rows[i] = 0;
+    }
 #pragma unroll
     for (int c = 0; c < GATE_CHUNKS; ++c) {
         // index of the first site of this wavefront's 64 positions: an event finds its site as rank + popcount of the lower bits
@@ -865,58 +872,65 @@ __device__ __forceinline__ void add_u16(uint16_t *field, uint32_t v) {
     atomicAdd(reinterpret_cast<uint32_t *>(addr & ~(uintptr_t)3), v << (8u * (uint32_t)(addr & 2u)));
 }
 
-// msnv_gather_cov: per-sample coverage of every surviving site, from the spilled bytes.
+// tail of a pass: per-sample coverages (gather half) and allele counts (scatter half) of the surviving sites.
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t GATHER_SPLIT = 4;
-__global__ __launch_bounds__(256) void msnv_gather_cov(const SiteRec *sites, const uint32_t *tile_site_base,
-                                                       const uint32_t *tile_site_cnt, const uint32_t *tile_pair_start,
-                                                       const TilePair *pairs, const uint8_t *spill,
-                                                       msnv_site_sample *out, uint32_t n_samples, uint32_t cap_out, const uint32_t *active_tiles) {
-    const uint32_t tile = active_tiles[blockIdx.x / GATHER_SPLIT], part = blockIdx.x % GATHER_SPLIT;   // a tile's sites are dealt to GATHER_SPLIT workgroups
-    const uint32_t n = tile_site_cnt[tile];
+constexpr uint32_t SCATTER_BLOCKS_PER_LIST = 32;
+struct TailArgs {
+    const SiteRec *sites; const uint32_t *tile_site_base, *tile_site_cnt, *tile_pair_start; const TilePair *pairs; const uint8_t *spill;
+    msnv_site_sample *out; uint32_t n_samples, cap_out; const uint32_t *active_tiles; uint32_t n_gather_blocks;
+    const Pair32 *events, *overflow; const uint32_t *counters; uint32_t cap_list, cap_overflow;
+    const unsigned long long *site_bits; const uint32_t *site_rank;
+};
+
+__device__ __forceinline__ void gather_cov_block(const TailArgs &a, const uint32_t bid) {
+    const uint32_t tile = a.active_tiles[bid / GATHER_SPLIT], part = bid % GATHER_SPLIT;   // a tile's sites are dealt to GATHER_SPLIT workgroups
+    const uint32_t n = a.tile_site_cnt[tile];
     if (n <= part) return;
-    const uint32_t base = tile_site_base[tile];
-    if (base + n > cap_out) return;                     // the host sees the site count and retries with a larger buffer
-    const uint32_t ps = tile_pair_start[tile], np = tile_pair_start[tile + 1] - ps;
+    const uint32_t base = a.tile_site_base[tile];
+    if (base + n > a.cap_out) return;                   // the host sees the site count and retries with a larger buffer
+    const uint32_t ps = a.tile_pair_start[tile], np = a.tile_pair_start[tile + 1] - ps;
     const uint32_t t0 = tile * TILE;
-    const uint32_t row_hw = n_samples * (uint32_t)(sizeof(msnv_site_sample) / 2);
-    for (uint32_t j = part; j < n; j += GATHER_SPLIT) {  // zero my rows (10 B per (site, sample)), then fill in the coverages
-        uint16_t *row = reinterpret_cast<uint16_t *>(out + (uint64_t)(base + j) * n_samples);
-        for (uint32_t i = threadIdx.x; i < row_hw; i += blockDim.x) row[i] = 0;
-    }
-    __syncthreads();
     const uint32_t mine = (n - part + GATHER_SPLIT - 1) / GATHER_SPLIT;
     const uint64_t work = (uint64_t)mine * np;
     for (uint64_t i = threadIdx.x; i < work; i += blockDim.x) {
         const uint32_t j = part + (uint32_t)(i / np) * GATHER_SPLIT, kk = (uint32_t)(i % np);
-        const uint32_t off = sites[base + j].gpos - t0;
-        const uint32_t cov = spill[(uint64_t)(ps + kk) * TILE + off];
-        const TilePair pr = pairs[ps + kk];
-        uint16_t *dst = &out[(uint64_t)(base + j) * n_samples + pr.sample].cov;
+        const uint32_t off = a.sites[base + j].gpos - t0;
+        const uint32_t cov = a.spill[(uint64_t)(ps + kk) * TILE + off];
+        const TilePair pr = a.pairs[ps + kk];
+        uint16_t *dst = &a.out[(uint64_t)(base + j) * a.n_samples + pr.sample].cov;
         if (pr.pad) add_u16(dst, cov);                      // one of several pairs of this sample: the groups add up
-        else *dst = (uint16_t)cov;                          // 255 = see overflow list (wide kernel only)
+        else if (cov != 255u) *dst = (uint16_t)cov;         // 255 (wide kernel only): the overflow list holds the value, the scatter half writes it
     }
 }
 
-// msnv_scatter_events: per-sample allele counts (sparse) and >=255 coverages into the site records.
-__global__ void msnv_scatter_events(const Pair32 *events, const Pair32 *overflow, const uint32_t *counters, uint32_t cap_list,
-                                    uint32_t cap_overflow, const unsigned long long *site_bits, const uint32_t *site_rank,
-                                    msnv_site_sample *out, uint32_t n_samples, uint32_t cap_out) {
-    if (counters[2] > cap_out) return;
+__device__ __forceinline__ void scatter_events_block(const TailArgs &a, const uint32_t bx, const uint32_t k) {
+    if (a.counters[2] > a.cap_out) return;
     auto apply = [&](const Pair32 e, const bool allele) {
-        const unsigned long long w = site_bits[e.x >> 6], bit = 1ull << (e.x & 63u);
+        const unsigned long long w = a.site_bits[e.x >> 6], bit = 1ull << (e.x & 63u);
         if (!(w & bit)) return;                    // most events are sequencing errors at positions that are not sites
-        const uint32_t s = site_rank[e.x >> 6] + (uint32_t)__popcll(w & (bit - 1ull));
-        if (allele) add_u16(&out[(uint64_t)s * n_samples + (e.y >> 18)].n[(e.y >> 16) & 3u], e.y & 0xffffu);   // one event per (site, pair, allele)
-        else out[(uint64_t)s * n_samples + (e.y >> 16)].cov = (uint16_t)(e.y & 0xffffu);
+        const uint32_t s = a.site_rank[e.x >> 6] + (uint32_t)__popcll(w & (bit - 1ull));
+        if (allele) add_u16(&a.out[(uint64_t)s * a.n_samples + (e.y >> 18)].n[(e.y >> 16) & 3u], e.y & 0xffffu);   // one event per (site, pair, allele)
+        else a.out[(uint64_t)s * a.n_samples + (e.y >> 16)].cov = (uint16_t)(e.y & 0xffffu);
     };
-    // grid = (blocks per sub-list, EV_LISTS)
-    const uint32_t k = blockIdx.y, n_k = min(counters[16u + k * EV_CNT_STRIDE], cap_list);
-    const Pair32 *list = events + (uint64_t)k * cap_list;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_k; i += gridDim.x * blockDim.x) apply(list[i], true);
-    const uint32_t n_overflow = min(counters[1], cap_overflow);
-    for (uint32_t i = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < n_overflow; i += gridDim.x * gridDim.y * blockDim.x)
-        apply(overflow[i], false);
+    const uint32_t n_k = min(a.counters[16u + k * EV_CNT_STRIDE], a.cap_list);
+    const Pair32 *list = a.events + (uint64_t)k * a.cap_list;
+    for (uint32_t i = bx * blockDim.x + threadIdx.x; i < n_k; i += SCATTER_BLOCKS_PER_LIST * blockDim.x) apply(list[i], true);
+    const uint32_t n_overflow = min(a.counters[1], a.cap_overflow);
+    for (uint32_t i = (k * SCATTER_BLOCKS_PER_LIST + bx) * blockDim.x + threadIdx.x; i < n_overflow; i += SCATTER_BLOCKS_PER_LIST * EV_LISTS * blockDim.x)
+        apply(a.overflow[i], false);
+}
+
+// msnv_gather_scatter: one launch, two independent halves working on the zeroed (msnv_gate_sites) per-sample records.
+//   blocks [0, n_gather_blocks): per-sample coverage of every surviving site, from the spilled bytes;
+//   the other SCATTER_BLOCKS_PER_LIST x EV_LISTS blocks: per-sample allele counts from the event sub-lists (sparse) and the
+//   >= 255 coverages of the wide kernel from the overflow list.
+__global__ __launch_bounds__(256) void msnv_gather_scatter(TailArgs a) {
+    if (blockIdx.x < a.n_gather_blocks) gather_cov_block(a, blockIdx.x);
+    else {
+        const uint32_t b = blockIdx.x - a.n_gather_blocks;
+        scatter_events_block(a, b % SCATTER_BLOCKS_PER_LIST, b / SCATTER_BLOCKS_PER_LIST);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1133,20 +1147,23 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(ev_pile1, st));
+    const uint32_t cap_out = (uint32_t)std::min<uint64_t>(d.cap_out_sites, 0xffffffffull);
     if (d.n_active_tiles) {
         hipLaunchKernelGGL(msnv_gate_sites, dim3(d.n_active_tiles), dim3(GATE_NT), 0, st, d.tot, d.part, d.slot_off, d.tile_slot_start, d.tile_slot_wide, npos, d.tile_vbeg, d.tile_vend,
-                           p.min_coverage, p.calling_threshold, p.min_fraction, d.ind_bits, d.site_bits, d.site_rank, d.sites, d.cap_sites, d.counters, d.tile_site_base, d.tile_site_cnt, d.active_tiles);
+                           p.min_coverage, p.calling_threshold, p.min_fraction, d.ind_bits, d.site_bits, d.site_rank, d.sites, d.cap_sites, d.counters, d.tile_site_base, d.tile_site_cnt, d.active_tiles,
+                           d.out, d.n_samples, cap_out);
         HIP_TRY(hipGetLastError());
     }
     if (ev3) HIP_TRY(hipEventRecord(ev3, st));
     // the tail runs on device-side counts: no host round trip inside a pass
-    const uint32_t cap_out = (uint32_t)std::min<uint64_t>(d.cap_out_sites, 0xffffffffull);
     if (d.n_active_tiles) {
-        hipLaunchKernelGGL(msnv_gather_cov, dim3(d.n_active_tiles * GATHER_SPLIT), dim3(256), 0, st, d.sites, d.tile_site_base, d.tile_site_cnt,
-                           d.tile_pair_start, d.pairs, d.spill, d.out, d.n_samples, cap_out, d.active_tiles);
-        HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(msnv_scatter_events, dim3(1024 / EV_LISTS, EV_LISTS), dim3(256), 0, st, d.events, d.overflow, d.counters, d.cap_events / EV_LISTS,
-                           d.cap_overflow, d.site_bits, d.site_rank, d.out, d.n_samples, cap_out);
+        TailArgs ta;
+        ta.sites = d.sites; ta.tile_site_base = d.tile_site_base; ta.tile_site_cnt = d.tile_site_cnt; ta.tile_pair_start = d.tile_pair_start;
+        ta.pairs = d.pairs; ta.spill = d.spill; ta.out = d.out; ta.n_samples = d.n_samples; ta.cap_out = cap_out; ta.active_tiles = d.active_tiles;
+        ta.n_gather_blocks = d.n_active_tiles * GATHER_SPLIT;
+        ta.events = d.events; ta.overflow = d.overflow; ta.counters = d.counters; ta.cap_list = d.cap_events / EV_LISTS; ta.cap_overflow = d.cap_overflow;
+        ta.site_bits = d.site_bits; ta.site_rank = d.site_rank;
+        hipLaunchKernelGGL(msnv_gather_scatter, dim3(ta.n_gather_blocks + SCATTER_BLOCKS_PER_LIST * EV_LISTS), dim3(256), 0, st, ta);
         HIP_TRY(hipGetLastError());
     }
     if (ev4) HIP_TRY(hipEventRecord(ev4, st));
