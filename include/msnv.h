@@ -153,6 +153,20 @@ int msnv_parse_float(const char *text, double *value);
 int msnv_dist_file(msnv_ctx *ctx, const char *freq_path, const char *mann_path, const char *allele_path, double threshold,
                    int32_t *n_samples, uint64_t *n_positions, double *ms_kernel);
 
+/* subpopr's raw-SNV consumers.
+ *
+ * msnv_genotyping_subset -- src/subpopr/inst/getGenotypingSNVSubset.py:20-48: the positions listed in every
+ * <species>_hap_positions.tab (field 2 = contig:gene:pos:base), then one scan of the called_SNPs* files that copies each
+ * line whose contig:pos is wanted into out_dir/<species>.pos of every species that listed it.  The path lists are read
+ * in the order given (the reference walks glob.glob's directory order).  Text only: runs without a device.
+ *
+ * msnv_snv_allele_freq -- src/subpopr/inst/convertSNVtoAlleleFreq.py:7-24: writes <pos_path>.freq, one row per allele
+ * of every line: id contig:gene:pos:base, then per sample -1 (coverage below min_depth) or count / coverage * 100,
+ * computed on the device and printed like str(float).  Every line of one file must list the same number of samples. */
+int msnv_genotyping_subset(const char *const *hap_paths, int32_t n_hap, const char *const *snp_paths, int32_t n_snp,
+                           const char *out_dir, uint64_t *n_positions, uint64_t *n_lines_written);
+int msnv_snv_allele_freq(msnv_ctx *ctx, const char *pos_path, int32_t min_depth, uint64_t *n_rows, double *ms_kernel);
+
 /* ------------------------------------------------------------------------------------
  * Staged form of the same path.
  * ------------------------------------------------------------------------------------ */

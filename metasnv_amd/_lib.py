@@ -125,6 +125,8 @@ SYMBOLS = [
     ("msnv_results_fetch", C.c_int, [_vp, P(Site), P(SiteSample), C.c_uint64]),
     ("msnv_parse_float", C.c_int, [C.c_char_p, P(C.c_double)]),
     ("msnv_dist_file", C.c_int, [_vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_double, P(C.c_int32), P(C.c_uint64), P(C.c_double)]),
+    ("msnv_genotyping_subset", C.c_int, [P(C.c_char_p), C.c_int32, P(C.c_char_p), C.c_int32, C.c_char_p, P(C.c_uint64), P(C.c_uint64)]),
+    ("msnv_snv_allele_freq", C.c_int, [_vp, C.c_char_p, C.c_int32, P(C.c_uint64), P(C.c_double)]),
     ("msnv_format_float", C.c_int, [C.c_double, C.c_char_p, C.c_int32]),
     ("msnv_filter_files", C.c_int, [_vp, P(C.c_char_p), C.c_int32, C.c_int32, P(FilterSpecies), C.c_int32, C.c_double, C.c_double,
                                    C.c_char_p, P(C.c_uint64), P(C.c_double)]),
