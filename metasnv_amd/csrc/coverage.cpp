@@ -12,8 +12,11 @@ int coverage_run(msnv_dataset &ds, msnv_run_stats *stats) {
     msnv_run_stats st{};
     if (int rc = dev_run_coverage(d, ds.params.cov_max, ds.ctx->stream, &st)) return rc;
     const size_t n = (size_t)d.n_samples * d.n_contigs * (1 + COV_BINS);
-    ds.cov_acc.assign(n, 0);
-    if (int rc = dev_download(ds.cov_acc.data(), d.cov_acc, n * sizeof(unsigned long long))) return rc;
+    std::vector<unsigned long long> copies((size_t)d.cov_copies * n);
+    if (int rc = dev_download(copies.data(), d.cov_acc, copies.size() * sizeof(unsigned long long))) return rc;
+    ds.cov_acc.assign(n, 0);                                 // tile t added to copy t % cov_copies (device.h)
+    for (uint32_t k = 0; k < d.cov_copies; ++k)
+        for (size_t i = 0; i < n; ++i) ds.cov_acc[i] += copies[(size_t)k * n + i];
     ds.have_coverage = true;
     if (stats) stats->ms_coverage = st.ms_coverage;
     return MSNV_OK;

@@ -86,7 +86,8 @@ struct DeviceCols {
     WorkItem *cov_work = nullptr;
     uint32_t *tile_len = nullptr;        // scanned indices of each tile (i < contig length)
     uint32_t *tile_contig_dev = nullptr;
-    unsigned long long *cov_acc = nullptr;   // [sample][contig][1 + COV_BINS]: covSum, hist[0..]
+    unsigned long long *cov_acc = nullptr;   // [copy][sample][contig][1 + COV_BINS]: covSum, hist[0..]; tile t adds to copy t % cov_copies
+    uint32_t  cov_copies = 1;                // (the tiles of a long contig would otherwise queue up on one 64-byte line); summed on the host
     uint32_t  n_cov_pairs = 0, n_cov_work = 0, n_contigs = 0;
     uint64_t  n_cov_iv = 0;
     uint64_t  device_bytes = 0;

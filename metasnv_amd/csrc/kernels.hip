@@ -1004,36 +1004,51 @@ __device__ __forceinline__ int wave_reduce_add(int x) {
 
 __global__ __launch_bounds__(C_NT) void msnv_coverage_tiles(const Pair32 *iv, const uint64_t *s_cov_base, const TilePair *pairs,
                                                             const WorkItem *work, const uint32_t *tile_len, const uint32_t *tile_contig,
-                                                            unsigned long long *acc, uint32_t n_contigs, int max_cov) {
-    __shared__ int s_d[TILE + 4];
-    __shared__ int s_w[C_NT / 64];
+                                                            unsigned long long *acc, uint32_t n_contigs, int max_cov, uint32_t n_samples, uint32_t n_copies) {
+    // One barrier per (tile, sample) pair: the difference array, the quarter-boundary carries and the workgroup accumulators
+    // are double-buffered, so pair k + 1 scatters while slower wavefronts still scan pair k, and the accumulators of pair k
+    // are flushed behind the barrier of pair k + 1.  Wavefront w scans positions [512 w, 512 w + 512) on its own: the depth
+    // at its left edge is the number of intervals that cover position 512 w - 1, counted while they are scattered.
+    __shared__ int s_d[2][TILE + 4];
+    __shared__ int s_carry[2][C_NT / 64 + 1];
     __shared__ int s_acc[2][COV_BINS + 2];
     const WorkItem w = work[blockIdx.x];
     const uint32_t t0 = w.tile * TILE, tl = tile_len[w.tile], contig = tile_contig[w.tile];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < (int)(TILE + 4); i += C_NT) s_d[i] = 0;
+    for (int i = tid; i < 2 * (int)(TILE + 4); i += C_NT) (&s_d[0][0])[i] = 0;
     if (tid < 2 * (COV_BINS + 2)) (&s_acc[0][0])[tid] = 0;
+    if (tid < 2 * (C_NT / 64 + 1)) (&s_carry[0][0])[tid] = 0;
     __syncthreads();
+    auto flush = [&](const uint32_t b, const uint32_t sample) {   // threads 0 .. max_cov + 1: covSum and the histogram bins
+        const int v = s_acc[b][tid];
+        s_acc[b][tid] = 0;
+        unsigned long long *dst = acc + (((uint64_t)(w.tile % n_copies) * n_samples + sample) * n_contigs + contig) * (1 + COV_BINS);
+        if (v) atomicAdd(&dst[tid], (unsigned long long)(long long)v);
+    };
+    uint32_t prev_sample = 0;
     for (uint32_t k = w.pair_lo; k < w.pair_hi; ++k) {
+        const uint32_t b = k & 1u;
         const TilePair pr = pairs[k];
         const Pair32 *v = iv + s_cov_base[pr.sample];
         for (uint32_t i = pr.read_lo + (uint32_t)tid; i < pr.read_hi; i += C_NT) {
             const Pair32 x = v[i];
             if (x.y <= t0 || x.x >= t0 + TILE) continue;
-            atomicAdd(&s_d[x.x > t0 ? x.x - t0 : 0u], 1);
-            if (x.y < t0 + TILE) atomicAdd(&s_d[x.y - t0], -1);
+            const uint32_t s = x.x > t0 ? x.x - t0 : 0u, e = min(x.y - t0, TILE);   // intervals that started in an earlier tile enter at 0
+            atomicAdd(&s_d[b][s], 1);
+            if (e < TILE) atomicAdd(&s_d[b][e], -1);
+            for (uint32_t q = (s >> 9) + 1u; q <= min(e >> 9, 3u); ++q) atomicAdd(&s_carry[b][q], 1);
         }
         __syncthreads();
-        int4 d0 = *reinterpret_cast<int4 *>(&s_d[C_PPT * tid]);
-        int4 d1 = *reinterpret_cast<int4 *>(&s_d[C_PPT * tid + 4]);
-        *reinterpret_cast<int4 *>(&s_d[C_PPT * tid]) = make_int4(0, 0, 0, 0);
-        *reinterpret_cast<int4 *>(&s_d[C_PPT * tid + 4]) = make_int4(0, 0, 0, 0);
+        if (k > w.pair_lo && tid <= max_cov + 1) flush(b ^ 1u, prev_sample);
+        prev_sample = pr.sample;
+        int4 d0 = *reinterpret_cast<int4 *>(&s_d[b][C_PPT * tid]);
+        int4 d1 = *reinterpret_cast<int4 *>(&s_d[b][C_PPT * tid + 4]);
+        int off = s_carry[b][wave];
+        *reinterpret_cast<int4 *>(&s_d[b][C_PPT * tid]) = make_int4(0, 0, 0, 0);
+        *reinterpret_cast<int4 *>(&s_d[b][C_PPT * tid + 4]) = make_int4(0, 0, 0, 0);
+        if (lane == 0) s_carry[b][wave] = 0;
         d0.y += d0.x; d0.z += d0.y; d0.w += d0.z; d1.x += d0.w; d1.y += d1.x; d1.z += d1.y; d1.w += d1.z;
-        const int incl = wave_inclusive_scan(d1.w);
-        if (lane == 63) s_w[wave] = incl;
-        __syncthreads();
-        int off = incl - d1.w;
-        for (int wv = 0; wv < wave; ++wv) off += s_w[wv];
+        off += wave_inclusive_scan(d1.w) - d1.w;
         const int cv[C_PPT] = {off + d0.x, off + d0.y, off + d0.z, off + d0.w, off + d1.x, off + d1.y, off + d1.z, off + d1.w};
         unsigned long long hp = 0;          // 16 bins x 4 bits (at most 8 positions per thread)
         int csum = 0;
@@ -1046,22 +1061,26 @@ __global__ __launch_bounds__(C_NT) void msnv_coverage_tiles(const Pair32 *iv, co
         }
         // reduce inside the workgroup first (wave DPP reduction, then LDS), so that one pair costs 1 + max_cov + 1 global
         // atomics instead of that many per wavefront (the accumulators are 64-bit atomics at the memory side: they, not
-        // the arithmetic, bounded this kernel); s_acc is double-buffered so the flush needs no barrier of its own
-        int *sa = s_acc[k & 1u];
+        // the arithmetic, bounded this kernel)
+        int *sa = s_acc[b];
         const int ws = wave_reduce_add(csum);
         if (lane == 0 && ws) atomicAdd(&sa[0], ws);
-        for (int b = 0; b <= max_cov; ++b) {
-            const int wb = wave_reduce_add((int)((hp >> (4 * b)) & 15ull));
-            if (lane == 0 && wb) atomicAdd(&sa[1 + b], wb);
-        }
-        __syncthreads();
-        if (tid <= max_cov + 1) {
-            const int v = sa[tid];
-            sa[tid] = 0;
-            unsigned long long *dst = acc + ((uint64_t)pr.sample * n_contigs + contig) * (1 + COV_BINS);
-            if (v) atomicAdd(&dst[tid], (unsigned long long)(long long)v);
+        // histogram: three bins per register in 10-bit fields (a wavefront adds at most 64 x 8 = 512 per bin), so the
+        // max_cov + 1 bins cost a third of the wave reductions
+        for (int q = 0; 3 * q <= max_cov; ++q) {
+            const uint32_t x = (uint32_t)(hp >> (12 * q)) & 0xfffu;
+            const uint32_t wq = (uint32_t)wave_reduce_add((int)((x & 0xfu) | (x & 0xf0u) << 6 | (x & 0xf00u) << 12));
+            if (lane == 0 && wq) {
+#pragma unroll
+                for (int f = 0; f < 3; ++f) {
+                    const int wb = (int)((wq >> (10 * f)) & 0x3ffu);
+                    if (wb) atomicAdd(&sa[1 + 3 * q + f], wb);      // bins beyond max_cov are empty
+                }
+            }
         }
     }
+    __syncthreads();
+    if (w.pair_hi > w.pair_lo && tid <= max_cov + 1) flush((w.pair_hi - 1u) & 1u, prev_sample);
 }
 
 // ------------------------------------------------------------------------------------------ host side
@@ -1327,10 +1346,10 @@ int dev_run_coverage(DeviceCols &d, int max_cov, void *stream_, msnv_run_stats *
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, st));
-    HIP_TRY(hipMemsetAsync(d.cov_acc, 0, (uint64_t)d.n_samples * d.n_contigs * (1 + COV_BINS) * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(d.cov_acc, 0, (uint64_t)d.cov_copies * d.n_samples * d.n_contigs * (1 + COV_BINS) * sizeof(unsigned long long), st));
     if (d.n_cov_work) {
         hipLaunchKernelGGL(msnv_coverage_tiles, dim3(d.n_cov_work), dim3(C_NT), 0, st, d.cov_iv, d.s_cov_base, d.cov_pairs, d.cov_work,
-                           d.tile_len, d.tile_contig_dev, d.cov_acc, d.n_contigs, max_cov);
+                           d.tile_len, d.tile_contig_dev, d.cov_acc, d.n_contigs, max_cov, d.n_samples, d.cov_copies);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(e1, st));

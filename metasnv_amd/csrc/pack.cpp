@@ -669,11 +669,12 @@ int finalize_dataset(msnv_dataset &ds) {
             for (size_t s = 0; s < S; ++s) for (const CP &p : per[s]) cpairs[fill[p.tile]++] = TilePair{p.sample, p.lo, p.hi, 0, 0, 0, 0, 0};
         }
         std::vector<WorkItem> cwork;
+        static const uint64_t cov_item_intervals = [] { const char *e = getenv("MSNV_COV_ITEM"); const long long v = e ? atoll(e) : 1024; return (uint64_t)(v > 0 ? v : 1024); }();   // intervals per coverage work item: 4096 -> 0.173 ms, 2048 -> 0.149, 1024 -> 0.143, 512 -> 0.143, 256 -> 0.151 (benchmark shape)
         for (uint64_t t = 0; t < nt; ++t) {
             uint32_t lo = cps[t]; uint64_t acc = 0;
             for (uint32_t k = cps[t]; k < cps[t + 1]; ++k) {
                 acc += cpairs[k].read_hi - cpairs[k].read_lo;
-                if (acc >= 4096 || k + 1 == cps[t + 1]) { cwork.push_back(WorkItem{(uint32_t)t, lo, k + 1, 0, 0, 0, 0, 0}); lo = k + 1; acc = 0; }
+                if (acc >= cov_item_intervals || k + 1 == cps[t + 1]) { cwork.push_back(WorkItem{(uint32_t)t, lo, k + 1, 0, 0, 0, 0, 0}); lo = k + 1; acc = 0; }
             }
         }
         std::vector<uint32_t> tlen(nt + 1, 0), tcont(nt + 1, 0);
@@ -690,7 +691,10 @@ int finalize_dataset(msnv_dataset &ds) {
         if (int rc = upload_vec(&d->cov_work, cwork, &d->device_bytes, 1)) return rc;
         if (int rc = upload_vec(&d->tile_len, tlen, &d->device_bytes)) return rc;
         if (int rc = upload_vec(&d->tile_contig_dev, tcont, &d->device_bytes)) return rc;
-        if (int rc = dev_alloc((void **)&d->cov_acc, (uint64_t)S * NC * (1 + COV_BINS) * sizeof(unsigned long long), &d->device_bytes)) return rc;
+        // accumulator copies: as many as fit 64 MB, at most 8 (many contigs = few tiles per contig = little contention anyway)
+        const uint64_t acc_bytes = (uint64_t)S * NC * (1 + COV_BINS) * sizeof(unsigned long long);
+        d->cov_copies = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(8, (64ull << 20) / std::max<uint64_t>(1, acc_bytes)));
+        if (int rc = dev_alloc((void **)&d->cov_acc, d->cov_copies * acc_bytes, &d->device_bytes)) return rc;
     }
 
     // ---- intermediates
