@@ -926,11 +926,9 @@ __device__ __forceinline__ void scatter_events_block(const TailArgs &a, const ui
 //   the other SCATTER_BLOCKS_PER_LIST x EV_LISTS blocks: per-sample allele counts from the event sub-lists (sparse) and the
 //   >= 255 coverages of the wide kernel from the overflow list.
 __global__ __launch_bounds__(256) void msnv_gather_scatter(TailArgs a) {
-    if (blockIdx.x < a.n_gather_blocks) gather_cov_block(a, blockIdx.x);
-    else {
-        const uint32_t b = blockIdx.x - a.n_gather_blocks;
-        scatter_events_block(a, b % SCATTER_BLOCKS_PER_LIST, b / SCATTER_BLOCKS_PER_LIST);
-    }
+    constexpr uint32_t n_scatter = SCATTER_BLOCKS_PER_LIST * EV_LISTS;     // dispatched first: the longer-running half
+    if (blockIdx.x < n_scatter) scatter_events_block(a, blockIdx.x % SCATTER_BLOCKS_PER_LIST, blockIdx.x / SCATTER_BLOCKS_PER_LIST);
+    else gather_cov_block(a, blockIdx.x - n_scatter);
 }
 
 // ------------------------------------------------------------------------------------------
