@@ -63,7 +63,8 @@ struct DeviceCols {
     uint32_t  n_active_tiles = 0;
     uint8_t  *part = nullptr;        // coverage partial row of every work item (tile-major; u16 per position for narrow items, u32 for wide)
     uint64_t *slot_off = nullptr;    // byte offset of every row; n_work + 1
-    uint32_t *tile_slot_wide = nullptr;   // first wide row of every tile
+    uint32_t *tile_slot_u16 = nullptr;    // first u16 row of every tile (u8 rows come first)
+    uint32_t *tile_slot_wide = nullptr;   // first wide (u32) row of every tile
     uint64_t  part_bytes = 0;
     uint32_t *tile_slot_start = nullptr;   // n_tiles + 1
     uint8_t  *spill = nullptr;       // [n_pairs][TILE] per-sample coverage, saturating at 255

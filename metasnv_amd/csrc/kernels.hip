@@ -415,6 +415,20 @@ __device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_
     }
 }
 
+// This item's coverage partial: 8 positions per thread, u8 when the host bounded the item's summed depth below 256 (bit 0 of
+// part_lo), else u16 (an item holds <= 32 pairs of depth < 255).  tc: u16 pairs for positions (0,2) (1,3) (4,6) (5,7).
+__device__ __forceinline__ void store_part_row(uint8_t *part, const WorkItem &w, const uint32_t (&tc)[N_PPT / 2], const int tid) {
+    uint8_t *row = part + ((uint64_t)w.part_hi << 32 | (w.part_lo & ~1u));
+    if (w.part_lo & 1u) {
+        const uint32_t lo = (tc[0] & 0xffu) | (tc[1] & 0xffu) << 8 | (tc[0] >> 16 & 0xffu) << 16 | (tc[1] >> 16) << 24;
+        const uint32_t hi = (tc[2] & 0xffu) | (tc[3] & 0xffu) << 8 | (tc[2] >> 16 & 0xffu) << 16 | (tc[3] >> 16) << 24;
+        *reinterpret_cast<uint2 *>(row + N_PPT * tid) = make_uint2(lo, hi);
+    } else {
+        *reinterpret_cast<uint4 *>(row + 2u * N_PPT * tid) =
+            make_uint4((tc[0] & 0xffffu) | tc[1] << 16, tc[0] >> 16 | (tc[1] & 0xffff0000u), (tc[2] & 0xffffu) | tc[3] << 16, tc[2] >> 16 | (tc[3] & 0xffff0000u));
+    }
+}
+
 // Ring refill of the chunk descriptors, called by every thread right after barrier (A) of chunk c: every
 // MAX_CHUNKS_PER_ITEM / 2 chunks the half of the ring that holds finished chunks [c - H, c) receives [c + H, c + 2H).
 // Those slots are next read at chunk c + H - 1 (prefetch of c + H), i.e. after at least one more barrier.
@@ -573,9 +587,7 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32(PileupArgs a)
     }
     __syncthreads();
     flush_events<NarrowLds, N_NT, N_EVCAP>(L, a, tid);
-    // this item's coverage partial: 8 positions x u16 (an item holds <= 32 pairs of depth < 255)
-    *reinterpret_cast<uint4 *>(a.part + ((uint64_t)w.part_hi << 32 | w.part_lo) + 2u * N_PPT * tid) =
-        make_uint4((tc[0] & 0xffffu) | tc[1] << 16, tc[0] >> 16 | (tc[1] & 0xffff0000u), (tc[2] & 0xffffu) | tc[3] << 16, tc[2] >> 16 | (tc[3] & 0xffff0000u));
+    store_part_row(a.part, w, tc, tid);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -736,9 +748,7 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_dense(PileupArgs a) {
     }
     __syncthreads();
     flush_events<DenseLds, N_NT, N_EVCAP>(L, a, tid);
-    // this item's coverage partial: 8 positions x u16 (an item holds <= 32 pairs of depth < 255)
-    *reinterpret_cast<uint4 *>(a.part + ((uint64_t)w.part_hi << 32 | w.part_lo) + 2u * N_PPT * tid) =
-        make_uint4((tc[0] & 0xffffu) | tc[1] << 16, tc[0] >> 16 | (tc[1] & 0xffff0000u), (tc[2] & 0xffffu) | tc[3] << 16, tc[2] >> 16 | (tc[3] & 0xffff0000u));
+    store_part_row(a.part, w, tc, tid);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -754,7 +764,7 @@ constexpr int GATE_NT = 256;
 constexpr int GATE_CHUNKS = TILE / GATE_NT;
 
 __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(uint32_t *tot, const uint8_t *part, const uint64_t *slot_off, const uint32_t *tile_slot_start,
-                                                           const uint32_t *tile_slot_wide, uint64_t npos,
+                                                           const uint32_t *tile_slot_u16, const uint32_t *tile_slot_wide, uint64_t npos,
                                                            const uint32_t *tile_vbeg, const uint32_t *tile_vend,
                                                            int min_cov, int min_snvs, double min_frac, const uint32_t *ind_bits,
                                                            unsigned long long *site_bits, uint32_t *site_rank, SiteRec *sites, uint32_t cap_sites, uint32_t *counters,
@@ -772,12 +782,21 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(uint32_t *tot, const 
     uint32_t mypre[GATE_CHUNKS], covs[GATE_CHUNKS], nal[GATE_CHUNKS][4];
 #pragma unroll
     for (int c = 0; c < GATE_CHUNKS; ++c) covs[c] = 0;
-    const uint32_t slot_w = tile_slot_wide[tile];
-    // coverage = sum of the tile's work-item partials.  The rows of a tile are contiguous (u16 rows first, then the u32
-    // rows of wide items), so the addresses need no per-row lookup and the loads of several rows are in flight together.
-    if (slot_w > slot_lo) {
-        const uint16_t *p16 = reinterpret_cast<const uint16_t *>(part + slot_off[slot_lo]) + tid;
-        const uint32_t n16 = slot_w - slot_lo;
+    const uint32_t slot_16 = tile_slot_u16[tile], slot_w = tile_slot_wide[tile];
+    // coverage = sum of the tile's work-item partials.  The rows of a tile are contiguous (u8 rows, then u16 rows, then the
+    // u32 rows of wide items), so the addresses need no per-row lookup and the loads of several rows are in flight together.
+    if (slot_16 > slot_lo) {
+        const uint8_t *p8 = part + slot_off[slot_lo] + tid;
+        const uint32_t n8 = slot_16 - slot_lo;
+#pragma unroll 4
+        for (uint32_t s = 0; s < n8; ++s) {
+#pragma unroll
+            for (int c = 0; c < GATE_CHUNKS; ++c) covs[c] += p8[(uint64_t)s * TILE + c * GATE_NT];
+        }
+    }
+    if (slot_w > slot_16) {
+        const uint16_t *p16 = reinterpret_cast<const uint16_t *>(part + slot_off[slot_16]) + tid;
+        const uint32_t n16 = slot_w - slot_16;
 #pragma unroll 4
         for (uint32_t s = 0; s < n16; ++s) {
 #pragma unroll
@@ -1106,7 +1125,7 @@ void dev_stream_destroy(void *stream) { if (stream) (void)hipStreamDestroy((hipS
 
 void dev_free_all(DeviceCols &d) {
     void *ptrs[] = {d.hdr, d.hdr8, d.blk, d.seq, d.qual, d.s_read_base, d.s_seq_base, d.ref4, d.ref_lc, d.pairs,
-                    d.tile_pair_start, d.work, d.chunks, d.tile_vbeg, d.tile_vend, d.tot, d.part, d.tile_slot_start, d.tile_slot_wide, d.slot_off, d.spill, d.events, d.overflow, d.counters,
+                    d.tile_pair_start, d.work, d.chunks, d.tile_vbeg, d.tile_vend, d.tot, d.part, d.tile_slot_start, d.tile_slot_u16, d.tile_slot_wide, d.slot_off, d.spill, d.events, d.overflow, d.counters,
                     d.sites, d.tile_site_base, d.tile_site_cnt, d.out, d.site_flags,
                     d.cov_iv, d.s_cov_base, d.cov_pairs, d.cov_work, d.tile_len, d.tile_contig_dev, d.cov_acc};
     for (void *p : ptrs) dev_free(p);
@@ -1166,7 +1185,7 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
     HIP_TRY(hipEventRecord(ev_pile1, st));
     const uint32_t cap_out = (uint32_t)std::min<uint64_t>(d.cap_out_sites, 0xffffffffull);
     if (d.n_active_tiles) {
-        hipLaunchKernelGGL(msnv_gate_sites, dim3(d.n_active_tiles), dim3(GATE_NT), 0, st, d.tot, d.part, d.slot_off, d.tile_slot_start, d.tile_slot_wide, npos, d.tile_vbeg, d.tile_vend,
+        hipLaunchKernelGGL(msnv_gate_sites, dim3(d.n_active_tiles), dim3(GATE_NT), 0, st, d.tot, d.part, d.slot_off, d.tile_slot_start, d.tile_slot_u16, d.tile_slot_wide, npos, d.tile_vbeg, d.tile_vend,
                            p.min_coverage, p.calling_threshold, p.min_fraction, d.ind_bits, d.site_bits, d.site_rank, d.sites, d.cap_sites, d.counters, d.tile_site_base, d.tile_site_cnt, d.active_tiles,
                            d.out, d.n_samples, cap_out);
         HIP_TRY(hipGetLastError());

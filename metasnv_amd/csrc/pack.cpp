@@ -542,21 +542,36 @@ int finalize_dataset(msnv_dataset &ds) {
         d->n_work_narrow = (uint32_t)work.size();
         work.insert(work.end(), wide.begin(), wide.end());
     }
-    // ---- coverage partials: one row per work item (u16 per position for narrow items: <= 32 pairs x 254; u32 for wide
-    // ones), rows of a tile contiguous with the narrow rows first (the gate kernel sums them)
+    // ---- coverage partials: one row of TILE counters per work item, rows of a tile contiguous (the gate kernel sums them):
+    // u8 rows first (narrow items whose pairs' depth bounds add up to < 256: most of them at ~10x), then u16 rows (the other
+    // narrow items: <= 32 pairs x 254), then the u32 rows of wide items.  Bit 0 of part_lo marks a u8 row.
     {
-        std::vector<uint32_t> tss(nt + 1, 0), twide(nt + 1, 0);
+        std::vector<uint32_t> tss(nt + 1, 0), t16(nt + 1, 0), twide(nt + 1, 0);
         for (const WorkItem &w : work) ++tss[w.tile + 1];
         for (uint64_t t = 0; t < nt; ++t) tss[t + 1] += tss[t];
+        std::vector<uint8_t> cls(work.size(), 0);
+        for (size_t i = 0; i < work.size(); ++i) {
+            if (i >= d->n_work_narrow) { cls[i] = 2; continue; }
+            uint64_t bound = 0;
+            for (uint32_t k = work[i].pair_lo; k < work[i].pair_hi; ++k) bound += pairs[k].max_depth;
+            cls[i] = bound < 256 ? 0 : 1;
+        }
         std::vector<uint32_t> fill(tss.begin(), tss.end() - 1);
-        std::vector<uint8_t> slot_wide(work.size(), 0);
-        for (size_t i = 0; i < work.size(); ++i) { work[i].slot = fill[work[i].tile]++; slot_wide[work[i].slot] = i >= d->n_work_narrow; }
+        std::vector<uint8_t> slot_cls(work.size(), 0);
+        for (int c = 0; c < 3; ++c)
+            for (size_t i = 0; i < work.size(); ++i)
+                if (cls[i] == c) { work[i].slot = fill[work[i].tile]++; slot_cls[work[i].slot] = (uint8_t)c; }
         std::vector<uint64_t> off(work.size() + 1, 0);
-        for (size_t s = 0; s < work.size(); ++s) off[s + 1] = off[s] + (uint64_t)TILE * (slot_wide[s] ? 4u : 2u);
-        for (WorkItem &w : work) { w.part_lo = (uint32_t)off[w.slot]; w.part_hi = (uint32_t)(off[w.slot] >> 32); }
-        for (uint64_t t = 0; t < nt; ++t) {                    // first wide row of every tile (narrow rows come first)
+        for (size_t s = 0; s < work.size(); ++s) off[s + 1] = off[s] + ((uint64_t)TILE << slot_cls[s]);
+        for (size_t i = 0; i < work.size(); ++i) {
+            WorkItem &w = work[i];
+            w.part_lo = (uint32_t)off[w.slot] | (cls[i] == 0 ? 1u : 0u); w.part_hi = (uint32_t)(off[w.slot] >> 32);
+        }
+        for (uint64_t t = 0; t < nt; ++t) {                    // first u16 row and first u32 row of every tile
             uint32_t s = tss[t];
-            while (s < tss[t + 1] && !slot_wide[s]) ++s;
+            while (s < tss[t + 1] && slot_cls[s] < 1) ++s;
+            t16[t] = s;
+            while (s < tss[t + 1] && slot_cls[s] < 2) ++s;
             twide[t] = s;
         }
         std::vector<uint32_t> active;
@@ -565,6 +580,7 @@ int finalize_dataset(msnv_dataset &ds) {
         if (int rc = upload_vec(&d->active_tiles, active, &d->device_bytes, 1)) return rc;
         d->part_bytes = std::max<uint64_t>(16, off[work.size()]);
         if (int rc = upload_vec(&d->tile_slot_start, tss, &d->device_bytes)) return rc;
+        if (int rc = upload_vec(&d->tile_slot_u16, t16, &d->device_bytes)) return rc;
         if (int rc = upload_vec(&d->tile_slot_wide, twide, &d->device_bytes)) return rc;
         if (int rc = upload_vec(&d->slot_off, off, &d->device_bytes)) return rc;
         if (int rc = dev_alloc((void **)&d->part, d->part_bytes, &d->device_bytes)) return rc;
