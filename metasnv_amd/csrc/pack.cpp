@@ -517,7 +517,6 @@ int finalize_dataset(msnv_dataset &ds) {
         // Items stay in tile order: dispatching the longest items first (shorter last wave of workgroups) measured 3 % SLOWER
         // (0.595 -> 0.612 ms) -- neighbouring items of a tile share the reference and the allele-total lines in L2.
         uint64_t target = 1000;
-        (void)total_reads_in_pairs;
         if (const char *e = getenv("MSNV_ITEM_PIECES")) target = std::max<uint64_t>(64, (uint64_t)atoll(e));
         std::vector<WorkItem> wide;
         auto chunks_of = [&](const TilePair &q) -> uint64_t {
@@ -525,11 +524,23 @@ int finalize_dataset(msnv_dataset &ds) {
             if (dense && nar) return (q.nblk + DENSE_CHUNK_BLOCKS - 1) / DENSE_CHUNK_BLOCKS;
             return (q.read_hi - q.read_lo + CHUNK_READS - 1) / CHUNK_READS;
         };
+        // Taper: the items of the last tiles are cut smaller, so that the last wave of workgroups (dispatch is in index order)
+        // ends on short items.  MSNV_ITEM_TAPER=0 switches it off.
+        static const bool taper = [] { const char *e = getenv("MSNV_ITEM_TAPER"); return !(e && e[0] == '0'); }();
+        double f1 = 0.80, f2 = 0.92, f3 = 0.97;
+        if (const char *e = getenv("MSNV_TAPER_AT")) sscanf(e, "%lf,%lf,%lf", &f1, &f2, &f3);
+        const uint64_t base_target = target;
+        uint64_t seen = 0;
         for (uint64_t t = 0; t < nt; ++t) {
             uint32_t lo = tps[t];
             uint64_t acc = 0, nch = 0;
+            if (taper && total_reads_in_pairs) {
+                const double done = (double)seen / (double)total_reads_in_pairs;
+                target = done > f3 ? std::max<uint64_t>(64, base_target / 8) : done > f2 ? std::max<uint64_t>(64, base_target / 4) : done > f1 ? std::max<uint64_t>(64, base_target / 2) : base_target;
+            }
             for (uint32_t k = tps[t]; k < tps[t + 1]; ++k) {
                 const uint32_t nr = pairs[k].read_hi - pairs[k].read_lo;
+                seen += nr;
                 acc += nr; nch += chunks_of(pairs[k]);
                 const bool narrow = pairs[k].max_depth < NARROW_MAX_DEPTH;
                 const bool boundary = k + 1 == tps[t + 1] || (narrow != (pairs[k + 1].max_depth < NARROW_MAX_DEPTH));
