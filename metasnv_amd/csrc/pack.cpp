@@ -526,7 +526,7 @@ int finalize_dataset(msnv_dataset &ds) {
         };
         // Taper: the items of the last tiles are cut smaller, so that the last wave of workgroups (dispatch is in index order)
         // ends on short items.  MSNV_ITEM_TAPER=0 switches it off.
-        static const bool taper = [] { const char *e = getenv("MSNV_ITEM_TAPER"); return !(e && e[0] == '0'); }();
+        const bool taper = [] { const char *e = getenv("MSNV_ITEM_TAPER"); return !(e && e[0] == '0'); }();   // read per dataset (tests switch it)
         double f1 = 0.80, f2 = 0.92, f3 = 0.97;
         if (const char *e = getenv("MSNV_TAPER_AT")) sscanf(e, "%lf,%lf,%lf", &f1, &f2, &f3);
         const uint64_t base_target = target;
@@ -696,7 +696,7 @@ int finalize_dataset(msnv_dataset &ds) {
             for (size_t s = 0; s < S; ++s) for (const CP &p : per[s]) cpairs[fill[p.tile]++] = TilePair{p.sample, p.lo, p.hi, 0, 0, 0, 0, 0};
         }
         std::vector<WorkItem> cwork;
-        static const uint64_t cov_item_intervals = [] { const char *e = getenv("MSNV_COV_ITEM"); const long long v = e ? atoll(e) : 1024; return (uint64_t)(v > 0 ? v : 1024); }();   // intervals per coverage work item: 4096 -> 0.173 ms, 2048 -> 0.149, 1024 -> 0.143, 512 -> 0.143, 256 -> 0.151 (benchmark shape)
+        const uint64_t cov_item_intervals = [] { const char *e = getenv("MSNV_COV_ITEM"); const long long v = e ? atoll(e) : 1024; return (uint64_t)(v > 0 ? v : 1024); }();   // intervals per coverage work item: 4096 -> 0.173 ms, 2048 -> 0.149, 1024 -> 0.143, 512 -> 0.143, 256 -> 0.151 (benchmark shape)
         for (uint64_t t = 0; t < nt; ++t) {
             uint32_t lo = cps[t]; uint64_t acc = 0;
             for (uint32_t k = cps[t]; k < cps[t + 1]; ++k) {

@@ -269,6 +269,22 @@ def test_event_list_grows_when_a_sub_list_overflows(monkeypatch):
     assert prod[3]["n_events"] == ref_run[3]["n_events"] > 4096
 
 
+@pytest.mark.parametrize("knobs", [dict(MSNV_ITEM_PIECES="64"), dict(MSNV_ITEM_PIECES="300", MSNV_ITEM_TAPER="0"),
+                                   dict(MSNV_ITEM_PIECES="5000"), dict(MSNV_TAPER_AT="0.1,0.3,0.5"), dict(MSNV_COV_ITEM="7")])
+def test_results_do_not_depend_on_the_work_decomposition(knobs, monkeypatch, tmp_path):
+    """Work items of 64 ... 5000 pieces, with and without the taper of the last tiles, tiny coverage items: the cut of the
+    (tile, sample) pairs into workgroups changes partial rows, event sub-lists and row types (u8 / u16), never the output."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    syn, samples = synth_case(n_species=3, contig_len=7000, n_samples=24, mean_cov=11.0, sigma_cov=0.9, snv_density=0.02, seed=606)
+    prod = run_product(syn.names, syn.lengths, syn.seqs, samples)
+    orac = run_oracle(syn.names, syn.lengths, syn.seqs, samples)
+    _assert_same(prod, orac)
+    assert prod[0].count("\n") > 100
+    for (got, exp) in _coverage_both(syn.names, syn.lengths, samples[:4], tmp_path)[0]:
+        assert got == exp
+
+
 def test_annotation_codon_path(tmp_path):
     syn, samples = synth_case(n_species=2, contig_len=3000, n_samples=4, mean_cov=14.0, snv_density=0.03, frac_absent=0.0, seed=21)
     fa = str(tmp_path / "ref.fa")
