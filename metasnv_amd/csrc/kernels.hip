@@ -761,7 +761,8 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_dense(PileupArgs a) {
 // are written in position order to a contiguous range reserved with one atomic per tile.
 // ------------------------------------------------------------------------------------------
 constexpr int GATE_NT = 256;
-constexpr int GATE_CHUNKS = TILE / GATE_NT;
+constexpr int GATE_PPT = TILE / GATE_NT;       // 8 consecutive positions per thread: one 8 / 16 / 32-byte load per row and thread
+static_assert(GATE_PPT == 8, "the gate kernel is written for 8 positions per thread (one site_bits word per 8 lanes)");
 
 __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(uint32_t *tot, const uint8_t *part, const uint64_t *slot_off, const uint32_t *tile_slot_start,
                                                            const uint32_t *tile_slot_u16, const uint32_t *tile_slot_wide, uint64_t npos,
@@ -770,86 +771,101 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(uint32_t *tot, const 
                                                            unsigned long long *site_bits, uint32_t *site_rank, SiteRec *sites, uint32_t cap_sites, uint32_t *counters,
                                                            uint32_t *tile_site_base, uint32_t *tile_site_cnt, const uint32_t *active_tiles,
                                                            msnv_site_sample *out, uint32_t n_samples, uint32_t cap_out) {
-    __shared__ uint32_t s_wave[GATE_CHUNKS][GATE_NT / 64];
+    __shared__ uint32_t s_wave[GATE_NT / 64];
     __shared__ uint32_t s_base;
     const uint32_t tile = active_tiles[blockIdx.x];           // tiles that hold work items; the others have no coverage
     const uint32_t t0 = tile * TILE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t vb = tile_vbeg[tile], ve = tile_vend[tile];
+    const uint32_t p0 = (uint32_t)GATE_PPT * (uint32_t)tid;    // my positions: p0 .. p0 + 7
+    const uint64_t g0 = (uint64_t)t0 + p0;
 
     const uint32_t slot_lo = tile_slot_start[tile], slot_hi = tile_slot_start[tile + 1];
-    uint32_t flags = 0;
-    uint32_t mypre[GATE_CHUNKS], covs[GATE_CHUNKS], nal[GATE_CHUNKS][4];
-#pragma unroll
-    for (int c = 0; c < GATE_CHUNKS; ++c) covs[c] = 0;
     const uint32_t slot_16 = tile_slot_u16[tile], slot_w = tile_slot_wide[tile];
+    uint32_t covs[GATE_PPT];
+#pragma unroll
+    for (int j = 0; j < GATE_PPT; ++j) covs[j] = 0;
     // coverage = sum of the tile's work-item partials.  The rows of a tile are contiguous (u8 rows, then u16 rows, then the
     // u32 rows of wide items), so the addresses need no per-row lookup and the loads of several rows are in flight together.
     if (slot_16 > slot_lo) {
-        const uint8_t *p8 = part + slot_off[slot_lo] + tid;
+        const uint8_t *p8 = part + slot_off[slot_lo] + p0;
         const uint32_t n8 = slot_16 - slot_lo;
+        // u8 rows are summed two positions per register (u16 halves: positions (0,2) (1,3) (4,6) (5,7)); widened every 255 rows
+        for (uint32_t r0 = 0; r0 < n8; r0 += 255u) {
+            uint32_t h[4] = {0u, 0u, 0u, 0u};
+            const uint32_t r1 = min(n8, r0 + 255u);
 #pragma unroll 4
-        for (uint32_t s = 0; s < n8; ++s) {
-#pragma unroll
-            for (int c = 0; c < GATE_CHUNKS; ++c) covs[c] += p8[(uint64_t)s * TILE + c * GATE_NT];
+            for (uint32_t s = r0; s < r1; ++s) {
+                const uint2 v = *reinterpret_cast<const uint2 *>(p8 + (uint64_t)s * TILE);
+                h[0] += v.x & 0x00ff00ffu; h[1] += (v.x >> 8) & 0x00ff00ffu;
+                h[2] += v.y & 0x00ff00ffu; h[3] += (v.y >> 8) & 0x00ff00ffu;
+            }
+            covs[0] += h[0] & 0xffffu; covs[2] += h[0] >> 16; covs[1] += h[1] & 0xffffu; covs[3] += h[1] >> 16;
+            covs[4] += h[2] & 0xffffu; covs[6] += h[2] >> 16; covs[5] += h[3] & 0xffffu; covs[7] += h[3] >> 16;
         }
     }
     if (slot_w > slot_16) {
-        const uint16_t *p16 = reinterpret_cast<const uint16_t *>(part + slot_off[slot_16]) + tid;
+        const uint8_t *p16 = part + slot_off[slot_16] + 2u * p0;
         const uint32_t n16 = slot_w - slot_16;
-#pragma unroll 4
+#pragma unroll 2
         for (uint32_t s = 0; s < n16; ++s) {
-#pragma unroll
-            for (int c = 0; c < GATE_CHUNKS; ++c) covs[c] += p16[(uint64_t)s * TILE + c * GATE_NT];
+            const uint4 v = *reinterpret_cast<const uint4 *>(p16 + (uint64_t)s * 2u * TILE);
+            covs[0] += v.x & 0xffffu; covs[1] += v.x >> 16; covs[2] += v.y & 0xffffu; covs[3] += v.y >> 16;
+            covs[4] += v.z & 0xffffu; covs[5] += v.z >> 16; covs[6] += v.w & 0xffffu; covs[7] += v.w >> 16;
         }
     }
     if (slot_hi > slot_w) {
-        const uint32_t *p32 = reinterpret_cast<const uint32_t *>(part + slot_off[slot_w]) + tid;
+        const uint8_t *p32 = part + slot_off[slot_w] + 4u * p0;
         const uint32_t n32 = slot_hi - slot_w;
         for (uint32_t s = 0; s < n32; ++s) {
-#pragma unroll
-            for (int c = 0; c < GATE_CHUNKS; ++c) covs[c] += p32[(uint64_t)s * TILE + c * GATE_NT];
+            const uint4 v0 = *reinterpret_cast<const uint4 *>(p32 + (uint64_t)s * 4u * TILE);
+            const uint4 v1 = *reinterpret_cast<const uint4 *>(p32 + (uint64_t)s * 4u * TILE + 16);
+            covs[0] += v0.x; covs[1] += v0.y; covs[2] += v0.z; covs[3] += v0.w;
+            covs[4] += v1.x; covs[5] += v1.y; covs[6] += v1.z; covs[7] += v1.w;
         }
     }
+    // allele totals of my positions: 4 x (8 x u32); consumed here and here only, so they are left zero for the next pass
+    // (no 16 B/position memset per pass, which is what a large sparse reference would mostly pay for)
+    uint32_t nal[4][GATE_PPT];
 #pragma unroll
-    for (int c = 0; c < GATE_CHUNKS; ++c) {
-        const uint32_t p = (uint32_t)c * GATE_NT + (uint32_t)tid;
-        const uint64_t g = (uint64_t)t0 + p;
-        const uint32_t cov = covs[c];
-        bool ok = false;
-        nal[c][0] = nal[c][1] = nal[c][2] = nal[c][3] = 0;
-        if (cov != 0u) {                                              // mismatching bases are counted bases: no coverage, no allele totals
-            const uint32_t nA = tot[g], nC = tot[npos + g], nG = tot[2 * npos + g], nT = tot[3 * npos + g];
-            nal[c][0] = nA; nal[c][1] = nC; nal[c][2] = nG; nal[c][3] = nT;
-            // the totals are consumed here and here only: leave them zero for the next pass (no 16 B/position memset per pass,
-            // which is what a large sparse reference would mostly pay for)
-            if (nA) tot[g] = 0;
-            if (nC) tot[npos + g] = 0;
-            if (nG) tot[2 * npos + g] = 0;
-            if (nT) tot[3 * npos + g] = 0;
-            if (p >= vb && p < ve && (int)cov >= min_cov && (int)(nA + nC + nG + nT) >= min_snvs) {   // call_vC.cpp:547,550
-                const bool ind = (ind_bits[g >> 5] >> (g & 31u)) & 1u;
-                const double lim = (double)(int)cov * min_frac;                // same arithmetic as msnv_decide_sites
-#pragma unroll
-                for (int x = 0; x < 4; ++x) ok |= (int)nal[c][x] >= min_snvs && (ind || (double)nal[c][x] >= lim);
-            }
-        }
-        const unsigned long long b = __ballot(ok);
-        if (lane == 0) site_bits[(g - (uint64_t)lane) >> 6] = b;       // 1 bit per position: is a site (the scatter half of msnv_gather_scatter filters on it)
-        mypre[c] = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
-        if (lane == 0) s_wave[c][wave] = (uint32_t)__popcll(b);
-        flags |= (ok ? 1u : 0u) << c;
+    for (int x = 0; x < 4; ++x) {
+        uint32_t *tp = tot + (uint64_t)x * npos + g0;
+        const uint4 a = *reinterpret_cast<const uint4 *>(tp), b = *reinterpret_cast<const uint4 *>(tp + 4);
+        nal[x][0] = a.x; nal[x][1] = a.y; nal[x][2] = a.z; nal[x][3] = a.w; nal[x][4] = b.x; nal[x][5] = b.y; nal[x][6] = b.z; nal[x][7] = b.w;
+        if (a.x | a.y | a.z | a.w) *reinterpret_cast<uint4 *>(tp) = make_uint4(0u, 0u, 0u, 0u);
+        if (b.x | b.y | b.z | b.w) *reinterpret_cast<uint4 *>(tp + 4) = make_uint4(0u, 0u, 0u, 0u);
     }
+    const uint32_t indb = reinterpret_cast<const uint8_t *>(ind_bits)[g0 >> 3];   // individual-candidate bits of my 8 positions
+    uint32_t okm = 0;
+#pragma unroll
+    for (int j = 0; j < GATE_PPT; ++j) {
+        const uint32_t p = p0 + (uint32_t)j, cov = covs[j];
+        // mismatching bases are counted bases: no coverage, no allele totals (a stale total can not exist: they are zeroed above)
+        if (cov != 0u && p >= vb && p < ve && (int)cov >= min_cov &&
+            (int)(nal[0][j] + nal[1][j] + nal[2][j] + nal[3][j]) >= min_snvs) {                          // call_vC.cpp:547,550
+            const bool ind = (indb >> j) & 1u;
+            const double lim = (double)(int)cov * min_frac;                // same arithmetic as msnv_decide_sites
+            bool ok = false;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) ok |= (int)nal[x][j] >= min_snvs && (ind || (double)nal[x][j] >= lim);
+            okm |= (ok ? 1u : 0u) << j;
+        }
+    }
+    // 1 bit per position: is a site (the scatter half of msnv_gather_scatter filters on it).  One 64-bit word = 8 lanes.
+    {
+        unsigned long long w = (unsigned long long)okm << (8u * ((uint32_t)lane & 7u));
+        w |= __shfl_xor(w, 1); w |= __shfl_xor(w, 2); w |= __shfl_xor(w, 4);
+        if ((lane & 7) == 0) site_bits[g0 >> 6] = w;
+    }
+    const uint32_t mycnt = (uint32_t)__popc(okm);
+    const uint32_t incl = (uint32_t)wave_inclusive_scan((int)mycnt);
+    if (lane == 63) s_wave[wave] = incl;
     __syncthreads();
-    // exclusive prefix over (chunk, wave) in chunk-major order
-    uint32_t total = 0, mybase[GATE_CHUNKS];
+    uint32_t total = 0, mybase = incl - mycnt;                 // exclusive prefix in position order
 #pragma unroll
-    for (int c = 0; c < GATE_CHUNKS; ++c) {
-#pragma unroll
-        for (int wv = 0; wv < GATE_NT / 64; ++wv) {
-            if (wv == wave) mybase[c] = total;
-            total += s_wave[c][wv];
-        }
+    for (int wv = 0; wv < GATE_NT / 64; ++wv) {
+        if (wv < wave) mybase += s_wave[wv];
+        total += s_wave[wv];
     }
     if (tid == 0) {
         uint32_t base = total ? atomicAdd(&counters[2], total) : 0u;
@@ -866,19 +882,19 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(uint32_t *tot, const 
         const uint64_t nhw = (uint64_t)total * n_samples * (sizeof(msnv_site_sample) / 2);
         for (uint64_t i = (uint64_t)tid; i < nhw; i += GATE_NT) rows[i] = 0;
     }
+    // index of the first site of every 64 positions: an event finds its site as rank + popcount of the lower bits
+    if ((lane & 7) == 0) site_rank[g0 >> 6] = base + mybase;
+    uint32_t idx = base + mybase;
 #pragma unroll
-    for (int c = 0; c < GATE_CHUNKS; ++c) {
-        // index of the first site of this wavefront's 64 positions: an event finds its site as rank + popcount of the lower bits
-        if (lane == 0) site_rank[((uint64_t)t0 + (uint32_t)c * GATE_NT + (uint32_t)tid) >> 6] = base + mybase[c];
-        if (flags & (1u << c)) {
-            const uint32_t idx = base + mybase[c] + mypre[c];
+    for (int j = 0; j < GATE_PPT; ++j) {
+        if (okm & (1u << j)) {
             if (idx < cap_sites) {
-                const uint64_t g = (uint64_t)t0 + (uint32_t)c * GATE_NT + (uint32_t)tid;
                 SiteRec s;
-                s.gpos = (uint32_t)g; s.cov = covs[c];
-                s.n[0] = nal[c][0]; s.n[1] = nal[c][1]; s.n[2] = nal[c][2]; s.n[3] = nal[c][3];
+                s.gpos = (uint32_t)(g0 + (uint32_t)j); s.cov = covs[j];
+                s.n[0] = nal[0][j]; s.n[1] = nal[1][j]; s.n[2] = nal[2][j]; s.n[3] = nal[3][j];
                 sites[idx] = s;
             }
+            ++idx;
         }
     }
 }
