@@ -1174,7 +1174,7 @@ static int ensure_out(DeviceCols &d, uint64_t n_sites) {
 static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hipEvent_t ev_begin, hipEvent_t ev_pile0, hipEvent_t ev_pile1,
                         hipEvent_t ev3, hipEvent_t ev4, uint32_t *host_cnt, hipEvent_t wait_before_pileup = nullptr) {
     const uint64_t npos = (uint64_t)d.n_tiles * TILE;
-    HIP_TRY(hipEventRecord(ev_begin, st));
+    if (ev_begin) HIP_TRY(hipEventRecord(ev_begin, st));
     // d.tot needs no memset: it is zero after finalize and msnv_gate_sites zeroes what a pass has written
     HIP_TRY(hipMemsetAsync(d.counters, 0, (CNT_WORDS + npos / 32 + 1) * sizeof(uint32_t), st));   // counters + individual-candidate bits (one allocation)
     if (wait_before_pileup) HIP_TRY(hipStreamWaitEvent(st, wait_before_pileup, 0));   // the previous pass' pileup kernel (other stream)
@@ -1343,7 +1343,8 @@ int dev_run_pipeline_many(DeviceCols &d, const msnv_params &p, void *stream_, in
         hipStream_t st = (i & 1) ? s1 : s0;
         if (two && (i & 1) != (swapped ? 1 : 0)) { swap_sets(d); swapped = !swapped; }
         // the pileup kernel of pass i starts after the one of pass i-1 (other stream) has finished; its memsets do not wait
-        rc = enqueue_pass(d, p, st, ev[4 * i], ev[4 * i + 1], ev[4 * i + 2], nullptr, nullptr, cnt + 8 * i, (two && i > 0) ? ev[4 * (i - 1) + 2] : nullptr);
+        // (only the first pass records a begin event: every event record costs stream time)
+        rc = enqueue_pass(d, p, st, i == 0 ? ev[0] : nullptr, ev[4 * i + 1], ev[4 * i + 2], nullptr, nullptr, cnt + 8 * i, (two && i > 0) ? ev[4 * (i - 1) + 2] : nullptr);
     }
     if (!rc && he == hipSuccess) he = hipEventRecord(ev[4 * n], s0);
     if (!rc && he == hipSuccess) he = hipEventRecord(ev[4 * n + 1], s1);
