@@ -118,6 +118,7 @@ constexpr uint32_t CNT_WORDS = 16 + EV_LISTS * EV_CNT_STRIDE;   // counters[0..1
 struct RunCounts { uint32_t n_events, n_overflow, n_sites, err; };
 
 int  dev_set_device(int device);
+uint32_t dev_resident_workgroups(uint32_t per_cu);   // compute units of the current device x per_cu (256 CUs when the query fails)
 int  dev_alloc(void **p, uint64_t bytes, uint64_t *acct);
 void dev_free(void *p);
 int  dev_upload(void *dst, const void *src, uint64_t bytes);

@@ -1117,6 +1117,13 @@ __global__ __launch_bounds__(C_NT) void msnv_coverage_tiles(const Pair32 *iv, co
 }
 
 // ------------------------------------------------------------------------------------------ host side
+uint32_t dev_resident_workgroups(uint32_t per_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount <= 0) return 256u * per_cu;
+    return (uint32_t)prop.multiProcessorCount * per_cu;
+}
+
 int dev_set_device(int device) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(MSNV_ENODEV, "no HIP device is available (this path has no CPU fallback)");

@@ -525,18 +525,22 @@ int finalize_dataset(msnv_dataset &ds) {
             return (q.read_hi - q.read_lo + CHUNK_READS - 1) / CHUNK_READS;
         };
         // Taper: the items of the last tiles are cut smaller, so that the last wave of workgroups (dispatch is in index order)
-        // ends on short items.  MSNV_ITEM_TAPER=0 switches it off.
+        // ends on short items.  The thresholds are in units of one full wave of workgroups (resident workgroups x pieces per
+        // item), not fractions of the dataset: on the benchmark shape (16 M pieces) they are the last 20 / 8 / 3 %, at
+        // BASELINE configs[2] scale (514 M pieces) the last 0.6 % -- tapering a fixed fraction there cost 5 %.
+        // MSNV_ITEM_TAPER=0 switches it off; MSNV_TAPER_AT=u1,u2,u3 moves the thresholds.
         const bool taper = [] { const char *e = getenv("MSNV_ITEM_TAPER"); return !(e && e[0] == '0'); }();   // read per dataset (tests switch it)
-        double f1 = 0.80, f2 = 0.92, f3 = 0.97;
-        if (const char *e = getenv("MSNV_TAPER_AT")) sscanf(e, "%lf,%lf,%lf", &f1, &f2, &f3);
+        double u1 = 1.8, u2 = 0.73, u3 = 0.27;
+        if (const char *e = getenv("MSNV_TAPER_AT")) sscanf(e, "%lf,%lf,%lf", &u1, &u2, &u3);
         const uint64_t base_target = target;
+        const double wave_pieces = (double)dev_resident_workgroups(7) * (double)base_target;   // 7 workgroups of 256 threads per CU (kernels.hip)
         uint64_t seen = 0;
         for (uint64_t t = 0; t < nt; ++t) {
             uint32_t lo = tps[t];
             uint64_t acc = 0, nch = 0;
             if (taper && total_reads_in_pairs) {
-                const double done = (double)seen / (double)total_reads_in_pairs;
-                target = done > f3 ? std::max<uint64_t>(64, base_target / 8) : done > f2 ? std::max<uint64_t>(64, base_target / 4) : done > f1 ? std::max<uint64_t>(64, base_target / 2) : base_target;
+                const double left = (double)(total_reads_in_pairs - seen) / wave_pieces;
+                target = left < u3 ? std::max<uint64_t>(64, base_target / 8) : left < u2 ? std::max<uint64_t>(64, base_target / 4) : left < u1 ? std::max<uint64_t>(64, base_target / 2) : base_target;
             }
             for (uint32_t k = tps[t]; k < tps[t + 1]; ++k) {
                 const uint32_t nr = pairs[k].read_hi - pairs[k].read_lo;

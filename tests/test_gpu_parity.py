@@ -270,7 +270,7 @@ def test_event_list_grows_when_a_sub_list_overflows(monkeypatch):
 
 
 @pytest.mark.parametrize("knobs", [dict(MSNV_ITEM_PIECES="64"), dict(MSNV_ITEM_PIECES="300", MSNV_ITEM_TAPER="0"),
-                                   dict(MSNV_ITEM_PIECES="5000"), dict(MSNV_TAPER_AT="0.1,0.3,0.5"), dict(MSNV_COV_ITEM="7")])
+                                   dict(MSNV_ITEM_PIECES="5000"), dict(MSNV_TAPER_AT="900,300,100"), dict(MSNV_COV_ITEM="7")])
 def test_results_do_not_depend_on_the_work_decomposition(knobs, monkeypatch, tmp_path):
     """Work items of 64 ... 5000 pieces, with and without the taper of the last tiles, tiny coverage items: the cut of the
     (tile, sample) pairs into workgroups changes partial rows, event sub-lists and row types (u8 / u16), never the output."""
