@@ -315,6 +315,11 @@ static int fetch_results(msnv_dataset *ds) {
     if (int r2 = dev_download(tcnt.data(), d.tile_site_cnt, (uint64_t)ds->n_tiles * 4)) return r2;
     std::vector<msnv_site_sample> raw((size_t)n * d.n_samples);
     if (int r2 = dev_download(raw.data(), d.out, raw.size() * sizeof(msnv_site_sample))) return r2;
+    {   // the per-sample coverage is a column of its own on the device (device.h): merged into the records here
+        std::vector<uint16_t> cov((size_t)n * d.n_samples);
+        if (int r2 = dev_download(cov.data(), d.cov_col, cov.size() * sizeof(uint16_t))) return r2;
+        for (size_t i = 0; i < raw.size(); ++i) raw[i].cov = cov[i];
+    }
 
     ds->sites.clear(); ds->site_samples.clear(); ds->site_dev_index.clear();
     ds->sites.reserve(n);

@@ -77,7 +77,9 @@ struct DeviceCols {
     uint32_t  cap_events = 0, cap_overflow = 0, cap_sites = 0;
     SiteRec  *sites = nullptr;
     uint32_t *tile_site_base = nullptr, *tile_site_cnt = nullptr;
-    msnv_site_sample *out = nullptr; // [cap_out_sites][n_samples]
+    msnv_site_sample *out = nullptr; // [cap_out_sites][n_samples]: allele counts per sample; the .cov field is filled in when the host fetches
+    uint16_t *cov_col = nullptr;     // [cap_out_sites][n_samples]: per-sample coverage, a column of its own on the device (two-byte stores
+                                     // into 10-byte records are partial-line writes: gather/scatter launch 41 -> 37 us)
     uint8_t  *site_flags = nullptr;  // pop_mask | ind_mask << 4
     uint64_t  cap_out_sites = 0, last_sites = 0;
     // ---- genome coverage (qaCompute path)
@@ -99,7 +101,7 @@ struct DeviceCols {
     struct AltBufs {
         uint32_t *tot = nullptr; uint8_t *part = nullptr; uint8_t *spill = nullptr; Pair32 *events = nullptr, *overflow = nullptr;
         uint32_t *counters = nullptr; SiteRec *sites = nullptr; uint32_t *tile_site_base = nullptr, *tile_site_cnt = nullptr;
-        msnv_site_sample *out = nullptr; uint8_t *site_flags = nullptr; uint32_t *ind_bits = nullptr; unsigned long long *site_bits = nullptr; uint32_t *site_rank = nullptr;
+        msnv_site_sample *out = nullptr; uint16_t *cov_col = nullptr; uint8_t *site_flags = nullptr; uint32_t *ind_bits = nullptr; unsigned long long *site_bits = nullptr; uint32_t *site_rank = nullptr;
         uint32_t cap_events = 0, cap_overflow = 0, cap_sites = 0; uint64_t cap_out_sites = 0;
     } alt;
     void     *stream2 = nullptr;

@@ -770,7 +770,7 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(uint32_t *tot, const 
                                                            int min_cov, int min_snvs, double min_frac, const uint32_t *ind_bits,
                                                            unsigned long long *site_bits, uint32_t *site_rank, SiteRec *sites, uint32_t cap_sites, uint32_t *counters,
                                                            uint32_t *tile_site_base, uint32_t *tile_site_cnt, const uint32_t *active_tiles,
-                                                           msnv_site_sample *out, uint32_t n_samples, uint32_t cap_out) {
+                                                           msnv_site_sample *out, uint16_t *cov_col, uint32_t n_samples, uint32_t cap_out) {
     __shared__ uint32_t s_wave[GATE_NT / 64];
     __shared__ uint32_t s_base;
     const uint32_t tile = active_tiles[blockIdx.x];           // tiles that hold work items; the others have no coverage
@@ -881,6 +881,8 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(uint32_t *tot, const 
         uint16_t *rows = reinterpret_cast<uint16_t *>(out + (uint64_t)base * n_samples);
         const uint64_t nhw = (uint64_t)total * n_samples * (sizeof(msnv_site_sample) / 2);
         for (uint64_t i = (uint64_t)tid; i < nhw; i += GATE_NT) rows[i] = 0;
+        uint16_t *crow = cov_col + (uint64_t)base * n_samples;      // samples without reads in this tile keep coverage 0
+        for (uint64_t i = (uint64_t)tid; i < (uint64_t)total * n_samples; i += GATE_NT) crow[i] = 0;
     }
     // index of the first site of every 64 positions: an event finds its site as rank + popcount of the lower bits
     if ((lane & 7) == 0) site_rank[g0 >> 6] = base + mybase;
@@ -913,7 +915,7 @@ constexpr uint32_t GATHER_SPLIT = 4;
 constexpr uint32_t SCATTER_BLOCKS_PER_LIST = 32;
 struct TailArgs {
     const SiteRec *sites; const uint32_t *tile_site_base, *tile_site_cnt, *tile_pair_start; const TilePair *pairs; const uint8_t *spill;
-    msnv_site_sample *out; uint32_t n_samples, cap_out; const uint32_t *active_tiles; uint32_t n_gather_blocks;
+    msnv_site_sample *out; uint16_t *cov_col; uint32_t n_samples, cap_out; const uint32_t *active_tiles; uint32_t n_gather_blocks;
     const Pair32 *events, *overflow; const uint32_t *counters; uint32_t cap_list, cap_overflow;
     const unsigned long long *site_bits; const uint32_t *site_rank;
 };
@@ -933,7 +935,7 @@ __device__ __forceinline__ void gather_cov_block(const TailArgs &a, const uint32
         const uint32_t off = a.sites[base + j].gpos - t0;
         const uint32_t cov = a.spill[(uint64_t)(ps + kk) * TILE + off];
         const TilePair pr = a.pairs[ps + kk];
-        uint16_t *dst = &a.out[(uint64_t)(base + j) * a.n_samples + pr.sample].cov;
+        uint16_t *dst = &a.cov_col[(uint64_t)(base + j) * a.n_samples + pr.sample];
         if (pr.pad) add_u16(dst, cov);                      // one of several pairs of this sample: the groups add up
         else if (cov != 255u) *dst = (uint16_t)cov;         // 255 (wide kernel only): the overflow list holds the value, the scatter half writes it
     }
@@ -946,7 +948,7 @@ __device__ __forceinline__ void scatter_events_block(const TailArgs &a, const ui
         if (!(w & bit)) return;                    // most events are sequencing errors at positions that are not sites
         const uint32_t s = a.site_rank[e.x >> 6] + (uint32_t)__popcll(w & (bit - 1ull));
         if (allele) add_u16(&a.out[(uint64_t)s * a.n_samples + (e.y >> 18)].n[(e.y >> 16) & 3u], e.y & 0xffffu);   // one event per (site, pair, allele)
-        else a.out[(uint64_t)s * a.n_samples + (e.y >> 16)].cov = (uint16_t)(e.y & 0xffffu);
+        else a.cov_col[(uint64_t)s * a.n_samples + (e.y >> 16)] = (uint16_t)(e.y & 0xffffu);
     };
     const uint32_t n_k = min(a.counters[16u + k * EV_CNT_STRIDE], a.cap_list);
     const Pair32 *list = a.events + (uint64_t)k * a.cap_list;
@@ -1149,7 +1151,7 @@ void dev_stream_destroy(void *stream) { if (stream) (void)hipStreamDestroy((hipS
 void dev_free_all(DeviceCols &d) {
     void *ptrs[] = {d.hdr, d.hdr8, d.blk, d.seq, d.qual, d.s_read_base, d.s_seq_base, d.ref4, d.ref_lc, d.pairs,
                     d.tile_pair_start, d.work, d.chunks, d.tile_vbeg, d.tile_vend, d.tot, d.part, d.tile_slot_start, d.tile_slot_u16, d.tile_slot_wide, d.slot_off, d.spill, d.events, d.overflow, d.counters,
-                    d.sites, d.tile_site_base, d.tile_site_cnt, d.out, d.site_flags,
+                    d.sites, d.tile_site_base, d.tile_site_cnt, d.out, d.cov_col, d.site_flags,
                     d.cov_iv, d.s_cov_base, d.cov_pairs, d.cov_work, d.tile_len, d.tile_contig_dev, d.cov_acc};
     for (void *p : ptrs) dev_free(p);
     void *aptrs[] = {d.ann.seg_beg, d.ann.seg_end, d.ann.seg_gene, d.ann.genes, d.ann.contigs, d.ann.codons, d.ann.out, d.ann.err};
@@ -1158,7 +1160,7 @@ void dev_free_all(DeviceCols &d) {
     for (void *e : d.event_pool) (void)hipEventDestroy((hipEvent_t)e);
     if (d.pinned_cnt) (void)hipHostFree(d.pinned_cnt);
     void *alts[] = {d.alt.tot, d.alt.part, d.alt.spill, d.alt.events, d.alt.overflow, d.alt.counters, d.alt.sites, d.alt.tile_site_base,
-                    d.alt.tile_site_cnt, d.alt.out, d.alt.site_flags, d.alt.site_bits, d.site_bits, d.alt.site_rank, d.site_rank, d.active_tiles};
+                    d.alt.tile_site_cnt, d.alt.out, d.alt.cov_col, d.alt.site_flags, d.alt.site_bits, d.site_bits, d.alt.site_rank, d.site_rank, d.active_tiles};
     for (void *p : alts) dev_free(p);
     if (d.stream2) (void)hipStreamDestroy((hipStream_t)d.stream2);
     d = DeviceCols{};
@@ -1166,10 +1168,11 @@ void dev_free_all(DeviceCols &d) {
 
 static int ensure_out(DeviceCols &d, uint64_t n_sites) {
     if (n_sites <= d.cap_out_sites) return MSNV_OK;
-    dev_free(d.out); dev_free(d.site_flags);
-    d.out = nullptr; d.site_flags = nullptr;
+    dev_free(d.out); dev_free(d.cov_col); dev_free(d.site_flags);
+    d.out = nullptr; d.cov_col = nullptr; d.site_flags = nullptr;
     uint64_t cap = std::max<uint64_t>(n_sites + n_sites / 4, 1024);
     if (int rc = dev_alloc((void **)&d.out, cap * d.n_samples * sizeof(msnv_site_sample), &d.device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&d.cov_col, cap * d.n_samples * sizeof(uint16_t) + 16, &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d.site_flags, cap, &d.device_bytes)) return rc;
     d.cap_out_sites = cap;
     return MSNV_OK;
@@ -1210,7 +1213,7 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
     if (d.n_active_tiles) {
         hipLaunchKernelGGL(msnv_gate_sites, dim3(d.n_active_tiles), dim3(GATE_NT), 0, st, d.tot, d.part, d.slot_off, d.tile_slot_start, d.tile_slot_u16, d.tile_slot_wide, npos, d.tile_vbeg, d.tile_vend,
                            p.min_coverage, p.calling_threshold, p.min_fraction, d.ind_bits, d.site_bits, d.site_rank, d.sites, d.cap_sites, d.counters, d.tile_site_base, d.tile_site_cnt, d.active_tiles,
-                           d.out, d.n_samples, cap_out);
+                           d.out, d.cov_col, d.n_samples, cap_out);
         HIP_TRY(hipGetLastError());
     }
     if (ev3) HIP_TRY(hipEventRecord(ev3, st));
@@ -1218,7 +1221,7 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
     if (d.n_active_tiles) {
         TailArgs ta;
         ta.sites = d.sites; ta.tile_site_base = d.tile_site_base; ta.tile_site_cnt = d.tile_site_cnt; ta.tile_pair_start = d.tile_pair_start;
-        ta.pairs = d.pairs; ta.spill = d.spill; ta.out = d.out; ta.n_samples = d.n_samples; ta.cap_out = cap_out; ta.active_tiles = d.active_tiles;
+        ta.pairs = d.pairs; ta.spill = d.spill; ta.out = d.out; ta.cov_col = d.cov_col; ta.n_samples = d.n_samples; ta.cap_out = cap_out; ta.active_tiles = d.active_tiles;
         ta.n_gather_blocks = d.n_active_tiles * GATHER_SPLIT;
         ta.events = d.events; ta.overflow = d.overflow; ta.counters = d.counters; ta.cap_list = d.cap_events / EV_LISTS; ta.cap_overflow = d.cap_overflow;
         ta.site_bits = d.site_bits; ta.site_rank = d.site_rank;
@@ -1281,7 +1284,7 @@ static int ensure_alt(DeviceCols &d) {
     DeviceCols::AltBufs &a = d.alt;
     const uint64_t npos = (uint64_t)d.n_tiles * TILE;
     if (a.tot && a.cap_events == d.cap_events && a.cap_overflow == d.cap_overflow && a.cap_sites == d.cap_sites && a.cap_out_sites == d.cap_out_sites) return MSNV_OK;
-    void *old[] = {a.tot, a.part, a.spill, a.events, a.overflow, a.counters, a.sites, a.tile_site_base, a.tile_site_cnt, a.out, a.site_flags, a.site_bits, a.site_rank};
+    void *old[] = {a.tot, a.part, a.spill, a.events, a.overflow, a.counters, a.sites, a.tile_site_base, a.tile_site_cnt, a.out, a.cov_col, a.site_flags, a.site_bits, a.site_rank};
     for (void *p : old) dev_free(p);
     a = DeviceCols::AltBufs{};
     if (int rc = dev_alloc((void **)&a.tot, std::max<uint64_t>(1, 4 * npos) * sizeof(uint32_t), &d.device_bytes)) return rc;
@@ -1300,6 +1303,7 @@ static int ensure_alt(DeviceCols &d) {
     if (int rc = dev_memset(a.tile_site_cnt, 0, ((uint64_t)d.n_tiles + 1) * sizeof(uint32_t))) return rc;
     if (int rc = dev_memset(a.tile_site_base, 0, ((uint64_t)d.n_tiles + 1) * sizeof(uint32_t))) return rc;
     if (int rc = dev_alloc((void **)&a.out, d.cap_out_sites * d.n_samples * sizeof(msnv_site_sample), &d.device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&a.cov_col, d.cap_out_sites * d.n_samples * sizeof(uint16_t) + 16, &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.site_flags, d.cap_out_sites, &d.device_bytes)) return rc;
     a.cap_events = d.cap_events; a.cap_overflow = d.cap_overflow; a.cap_sites = d.cap_sites; a.cap_out_sites = d.cap_out_sites;
     return MSNV_OK;
@@ -1308,7 +1312,7 @@ static void swap_sets(DeviceCols &d) {
     DeviceCols::AltBufs &a = d.alt;
     std::swap(d.tot, a.tot); std::swap(d.part, a.part); std::swap(d.spill, a.spill); std::swap(d.events, a.events);
     std::swap(d.overflow, a.overflow); std::swap(d.counters, a.counters); std::swap(d.sites, a.sites);
-    std::swap(d.tile_site_base, a.tile_site_base); std::swap(d.tile_site_cnt, a.tile_site_cnt); std::swap(d.out, a.out);
+    std::swap(d.tile_site_base, a.tile_site_base); std::swap(d.tile_site_cnt, a.tile_site_cnt); std::swap(d.out, a.out); std::swap(d.cov_col, a.cov_col);
     std::swap(d.site_flags, a.site_flags); std::swap(d.ind_bits, a.ind_bits); std::swap(d.site_bits, a.site_bits); std::swap(d.site_rank, a.site_rank);
 }
 
