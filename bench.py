@@ -97,11 +97,34 @@ def synth_annotation(syn, path, seed=7):
     return n
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launcher_command(n, argv, port=None):
+    """`python bench.py --gpus N` outside torchrun: the N rank processes are started as a CHILD (torch.distributed.run, one
+    rank per GPU, rendezvous on 127.0.0.1) before this process has made any HIP / torch.cuda call -- a process that has
+    touched the GPU must never exec another program on this pool -- and the parent only forwards the child's exit code."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+            "--master-port", str(port or _free_port()), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import subprocess
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.call(launcher_command(a.gpus, sys.argv[1:]), env=env))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world and rank == 0:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d; the launcher's world size is what runs\n" % (a.gpus, world))
     dist = None
     if world > 1:
         import torch
@@ -196,21 +219,27 @@ def main():
                          "kernel_ms": sum(ms) / len(ms), "first_call_s_incl_parse_upload": t_first}
 
     bases = info["n_pileup_bases"]
+    k_ms = sum(ms_pileup) / len(ms_pileup)
+    alg = st["algorithmic_bytes"]
+    slowest = 0
     if dist is not None:
         import torch
-        t = torch.tensor([dt, float(bases), float(st["n_called_pop"]), float(st["n_called_indiv"])], dtype=torch.float64,
+        t = torch.tensor([dt, float(bases), float(st["n_called_pop"]), float(st["n_called_indiv"]), k_ms, float(alg)], dtype=torch.float64,
                          device="cuda" if a.dist_backend == "nccl" else "cpu")
         gathered = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(gathered, t)       # the only collective: tiny result table over RCCL/xGMI
         dt_max = max(float(g[0]) for g in gathered)
         total_bases = sum(float(g[1]) for g in gathered)
         called = [int(g[2]) for g in gathered]
+        # the roofline of the job is the one of its slowest rank (lowest achieved bandwidth of the dominant kernel)
+        per_rank_gbs = [float(g[5]) / (float(g[4]) * 1e-3) / 1e9 for g in gathered]
+        slowest = min(range(world), key=lambda r: per_rank_gbs[r])
+        k_ms, alg = float(gathered[slowest][4]), int(gathered[slowest][5])
     else:
         dt_max, total_bases, called = dt, float(bases), [int(st["n_called_pop"])]
+        per_rank_gbs = [alg / (k_ms * 1e-3) / 1e9]
 
     if rank == 0:
-        k_ms = sum(ms_pileup) / len(ms_pileup)
-        alg = st["algorithmic_bytes"]
         achieved = alg / (k_ms * 1e-3) / 1e9
         line = {
             "metric": "pileup Gbases/s across all samples",
@@ -226,8 +255,9 @@ def main():
                        "reads_per_gpu": info["n_reads"], "parallelism": "contig shards x%d, no data-path collective" % world,
                        "called_SNPs_lines_per_rank": called},
             "roofline": {"bound": "hbm", "kernel": "msnv_pileup_tiles_narrow32", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(a.samples, a.species, a.contig_len, a.mean_cov),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(a.samples, a.species, a.contig_len, a.mean_cov) if world == 1 else None,
                          "algorithmic_bytes_per_launch": alg, "kernel_ms_avg": k_ms,
+                         "rank": slowest, "achieved_per_rank": per_rank_gbs,
                          "bytes_per_pileup_base": alg / max(1, bases),
                          "algorithmic_definition": "SURVEY.md 8d: per pileup read 16 B header + 4 B per CIGAR op + 0.5 B/base + 1 B/base quality",
                          "shipped_bytes_per_launch": info["bytes_headers"] + info["bytes_seq"] + info["bytes_qual"]},

@@ -275,8 +275,40 @@ typedef struct { uint16_t cov; uint16_t n[4]; } msnv_site_sample;
 #define MSNV_ANN_SYNONYMOUS 4
 typedef struct { int32_t gene; uint8_t codon[4][8]; } msnv_site_ann;
 
+/* ------------------------------------------------------------------------------------
+ * Multi-GPU form of the two invocations above (the reference's counterpart is its pool of
+ * processes, metaSNV.py:55-78,196-215, where every split process inflates every BAM in full).  The BAMs are dealt to the
+ * ranks for decoding -- every file is inflated exactly once in the whole job -- each decoder deals the records to the
+ * rank that owns their contig (msnv_records_partition; the exchange is an all-to-all over RCCL, metasnv_amd/parallel.py),
+ * every rank runs the kernels over its contigs, and rank 0 receives the small tables: site records (msnv_results_fetch ->
+ * msnv_write_calls_records) and coverage accumulators (msnv_coverage_fetch -> msnv_write_coverage_records).
+ * ------------------------------------------------------------------------------------ */
+/* qaCompute's read bookkeeping for the "Other" block of OUT (qaCompute.cpp:461-473,518-526,642-654). */
+typedef struct { uint32_t total_reads, unmapped, zero_quality, proper_pairs, duplicates, any_mapped; } msnv_sample_stats;
+#define MSNV_COV_WORDS 17   /* per (sample, contig): covSum, hist[0..15] (qaCompute.cpp:142-165) */
+
+/* Deals one sample's raw record stream to n_parts parts: a mapped record goes to part contig_owner[tid] (-1 = nobody),
+ * order preserved; unmapped records are counted and dropped.  out: n_bytes bytes, receives the parts back to back;
+ * part_bytes[n_parts] their sizes; stats (may be NULL) the sample's qaCompute statistics over ALL records. */
+int  msnv_records_partition(const uint8_t *records, uint64_t n_bytes, const int32_t *contig_owner, int32_t n_contigs,
+                            int32_t n_parts, int32_t cov_min_mapq, uint8_t *out, uint64_t *part_bytes, msnv_sample_stats *stats);
+/* Statistics of sample `sample_idx` as counted while it was packed (only over the records this dataset was given). */
+int  msnv_dataset_sample_stats(const msnv_dataset *ds, int32_t sample_idx, msnv_sample_stats *out);
+/* Accumulators of the last msnv_coverage_run: acc[n_samples][n_contigs][MSNV_COV_WORDS], zeros for contigs outside the shard. */
+int  msnv_coverage_fetch(msnv_dataset *ds, uint64_t *acc, uint64_t capacity_words);
+/* Writes OUT / OUT.detail of one sample from gathered accumulators acc[n_contigs][MSNV_COV_WORDS] exactly as
+ * msnv_write_coverage does (qaCompute.cpp:192-217,226-263,439,623-657). */
+int  msnv_write_coverage_records(const msnv_ref_desc *ref, int32_t max_cov, const msnv_sample_stats *stats, const uint64_t *acc,
+                                 const char *cov_path, const char *detail_path);
+
 /* First pileup line of this dataset's invocation (the one call_vC.cpp:423 drops); tid = -1 if no read passes. */
 int  msnv_dataset_first_line(const msnv_dataset *ds, int32_t *tid, int32_t *pos);
+/* Per contig (n = header contigs): position of the first pileup line of an invocation that starts at that contig, -1 when
+ * no read of this dataset piles up there -- without -l (first_any) and under metaSNV's split BED `name 1 LEN`, which
+ * excludes position 0 (first_from1; metaSNV.py:92).  Lets a driver that holds ONE resident dataset write every
+ * best_split_K output with the first line that split's own snpCall process would have dropped (call_vC.cpp:423).
+ * Only valid for datasets created without a BED restriction. */
+int  msnv_dataset_first_lines(const msnv_dataset *ds, int32_t *first_any, int32_t *first_from1, int32_t n);
 /* Formats site records that did not come from a local run (multi-GPU: records gathered from the
  * ranks over RCCL) exactly as msnv_write_calls does.  Records must be in (tid, pos) order. */
 int  msnv_write_calls_records(const msnv_ref_desc *ref, int32_t n_samples, const msnv_site *sites,

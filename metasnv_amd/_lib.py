@@ -71,6 +71,13 @@ class SiteAnn(C.Structure):
     _fields_ = [("gene", C.c_int32), ("codon", (C.c_uint8 * 8) * 4)]
 
 
+class SampleStats(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("total_reads", "unmapped", "zero_quality", "proper_pairs", "duplicates", "any_mapped")]
+
+
+COV_WORDS = 17
+
+
 class FilterSpecies(C.Structure):
     _fields_ = [("species", C.c_char_p), ("n_soi", C.c_int32), ("soi", C.POINTER(C.c_int32)), ("soi_names", C.POINTER(C.c_char_p))]
 
@@ -118,7 +125,12 @@ SYMBOLS = [
     ("msnv_write_coverage", C.c_int, [_vp, C.c_int32, C.c_char_p, C.c_char_p]),
     ("msnv_write_calls", C.c_int, [_vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]),
     ("msnv_dataset_first_line", C.c_int, [_vp, P(C.c_int32), P(C.c_int32)]),
+    ("msnv_dataset_first_lines", C.c_int, [_vp, P(C.c_int32), P(C.c_int32), C.c_int32]),
     ("msnv_write_calls_records", C.c_int, [P(RefDesc), C.c_int32, P(Site), P(SiteSample), C.c_uint64, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, P(SiteAnn)]),
+    ("msnv_records_partition", C.c_int, [_vp, C.c_uint64, P(C.c_int32), C.c_int32, C.c_int32, C.c_int32, _vp, P(C.c_uint64), P(SampleStats)]),
+    ("msnv_dataset_sample_stats", C.c_int, [_vp, C.c_int32, P(SampleStats)]),
+    ("msnv_coverage_fetch", C.c_int, [_vp, P(C.c_uint64), C.c_uint64]),
+    ("msnv_write_coverage_records", C.c_int, [P(RefDesc), C.c_int32, P(SampleStats), P(C.c_uint64), C.c_char_p, C.c_char_p]),
     ("msnv_annotate_run", C.c_int, [_vp, C.c_char_p, C.c_char_p, P(C.c_double)]),
     ("msnv_results_fetch_ann", C.c_int, [_vp, P(SiteAnn), C.c_uint64]),
     ("msnv_results_count", C.c_int, [_vp, P(C.c_uint64)]),

@@ -11,8 +11,9 @@ that metaSNV_Filtering.py / metaSNV_DistDiv.py consume the results unchanged:
     DIR/all_samples
 
 Where the reference forks one process per BAM / per split (multiprocessing.Pool, metaSNV.py:58,197),
-this driver makes one library call per step and the GPU does the work.  Under torch.distributed
-(one rank per GPU) the splits / BAMs are dealt to the ranks (metasnv_amd/parallel.py).
+this driver builds ONE resident dataset per rank -- every BAM is decoded once, by one rank -- and writes
+every cov/ file and every split's output from it.  Under torch.distributed (one rank per GPU) the contigs
+are sharded over the ranks and the tables gathered to rank 0 (metasnv_amd/parallel.py).
 """
 import argparse
 import glob
@@ -38,33 +39,10 @@ def read_sample_list(path):
         return [line.rstrip() for line in f if line.rstrip()]
 
 
-def compute_opt(args, ctx, rank=0, world=1):                    # metaSNV.py:55-78 (qaCompute -c 10 -d -i per BAM)
-    from . import core
+def print_coverage_commands(args):                              # metaSNV.py:55-78 with --print-commands
     out_dir = os.path.join(args.project_dir, 'cov')
-    mkdir_p(out_dir)
-    bams = read_sample_list(args.all_samples)
-    mine = [b for i, b in enumerate(bams) if i % world == rank]
-    if args.print_commands:
-        for b in bams:
-            print("msnv_coverage -c 10 -d -i {} {}/{}.cov".format(b, out_dir, os.path.basename(b)))
-        return
-    if not mine:
-        return
-    # all BAMs of this rank share one header (metaSNV.py:82-83): one dataset, one device pass
-    ds = core.Dataset.from_files(ctx, mine[0], None, core.default_params(cov_max=10, cov_min_mapq=1))
-    try:
-        ds.add_sample_bams(mine, args.threads)
-        ds.finalize()
-        ds.coverage_run()
-        for i, b in enumerate(mine):
-            out = os.path.join(out_dir, os.path.basename(b) + '.cov')
-            ds.write_coverage(i, out, out + '.detail')
-            print("Printing details in {}!".format(out + '.detail'))      # qaCompute.cpp:387
-    except core._lib.MsnvError as e:
-        sys.stderr.write("Failure in sample set starting at {}\n{}\n".format(mine[0], e))
-        sys.exit(1)
-    finally:
-        ds.close()
+    for b in read_sample_list(args.all_samples):
+        print("msnv_coverage -c 10 -d -i {} {}/{}.cov".format(b, out_dir, os.path.basename(b)))
 
 
 def compute_summary(args):                                      # metaSNV.py:97-125
@@ -106,30 +84,14 @@ def split_opt(args):                                            # metaSNV.py:128
                        args.ctg_len, args.n_splits, os.path.join(args.project_dir, "bestsplits", "best_split"))
 
 
-def execute_snp_call(args, ctx, ifile, ofile, split):           # metaSNV.py:153-176 (mpileup | snpCall)
-    from . import core
-    bams = read_sample_list(args.all_samples)
-    if args.print_commands:
-        print("msnv_call -f {} {}{}-b {} -i {} -c {} -t {} > {}".format(
+def print_call_commands(args):                                  # metaSNV.py:153-221 with --print-commands
+    out_dir = os.path.join(args.project_dir, 'snpCaller')
+    splits = sorted(glob.glob('{}/bestsplits/best_split_*'.format(args.project_dir))) if args.n_splits > 1 else [None]
+    for split in splits:
+        sfx = '.' + os.path.basename(split) if split else ''
+        print("msnv_snpcall -f {} {}{}-b {} -i {}/indiv_called{} -c {} -t {} > {}/called_SNPs{}".format(
             args.ref_db, "-g {} ".format(args.db_ann) if args.db_ann else "", "-l {} ".format(split) if split else "",
-            args.all_samples, ifile, args.min_pos_cov, args.min_pos_snvs, ofile))
-        return 0
-    params = core.default_params(min_coverage=args.min_pos_cov, calling_threshold=args.min_pos_snvs)
-    ds = core.Dataset.from_files(ctx, bams[0], args.ref_db, params)
-    try:
-        if split:
-            ds.set_bed_file(split)
-        ds.add_sample_bams(bams, args.threads)
-        ds.finalize()
-        st = ds.run()
-        _write_metrics({"mode": "call", "split": split or "", "pileup": st, "dataset": ds.info()})
-        ds.write_calls(ofile, ifile, args.db_ann or None, args.ref_db)
-        return 0
-    except core._lib.MsnvError as e:
-        sys.stderr.write(str(e) + "\n")
-        return e.code
-    finally:
-        ds.close()
+            args.all_samples, out_dir, sfx, args.min_pos_cov, args.min_pos_snvs, out_dir, sfx))
 
 
 def _write_metrics(obj):
@@ -142,58 +104,67 @@ def _write_metrics(obj):
             f.write(json.dumps(obj) + "\n")
 
 
-def fused_cov_and_call(args, ctx):
-    """Single-GPU, unsplit run: qaCompute (metaSNV.py:55-78) and mpileup | snpCall (:153-221) from ONE dataset, so
-    every BAM is inflated, packed and uploaded once.  Writes the same files in the same places as the two steps."""
-    from . import core
+def read_split_file(path):
+    """Contig names of a best_split_K file (createOptimumSplit.py:54-62 copies bed_header lines `SN\t1\tLN`)."""
+    names = []
+    for line in open(path):
+        w = line.rstrip("\n").split("\t")
+        if len(w) >= 3:
+            if w[1] != "1":
+                raise ValueError("{}: split regions other than `name 1 LEN` are not what metaSNV writes (metaSNV.py:92)".format(path))
+            names.append(w[0])
+    return names
+
+
+def resident_run(args, ctx, rank, world):
+    """metaSNV.py:55-78 (qaCompute per BAM), :97-150 (summary, tables, split plan) and :153-221 (mpileup | snpCall per split)
+    from ONE resident dataset per rank: every BAM is inflated, packed and uploaded once in the whole job -- by one rank --
+    whatever --threads / --n_splits / the number of ranks are (the reference decodes every BAM 1 + n_splits times).
+    Same files in the same places; rank 0 writes them."""
+    from . import core, parallel
     bams = read_sample_list(args.all_samples)
     cov_dir, snp_dir = os.path.join(args.project_dir, 'cov'), os.path.join(args.project_dir, 'snpCaller')
-    mkdir_p(cov_dir); mkdir_p(snp_dir)
     params = core.default_params(min_coverage=args.min_pos_cov, calling_threshold=args.min_pos_snvs, cov_max=10, cov_min_mapq=1)
-    ds = core.Dataset.from_files(ctx, bams[0], args.ref_db, params)
+
+    def between_passes(res):
+        if rank == 0:
+            mkdir_p(cov_dir); mkdir_p(snp_dir)
+            if not args.use_prev_cov:
+                for i, b in enumerate(bams):
+                    out = os.path.join(cov_dir, os.path.basename(b) + '.cov')
+                    core.write_coverage_records(res["names"], res["lengths"], params.cov_max, res["stats"][i], res["acc"][i], out, out + '.detail')
+                    print("Printing details in {}!".format(out + '.detail'))      # qaCompute.cpp:387
+                compute_summary(args)
+            get_header(args)
+            if args.n_splits > 1:
+                split_opt(args)
+            shutil.copy(args.all_samples, args.project_dir + '/all_samples')
+        parallel.barrier()
+
     try:
-        ds.add_sample_bams(bams, args.threads)
-        ds.finalize()
-        st_p, st_c = ds.fused_run()
-        _write_metrics({"mode": "fused", "pileup": st_p, "coverage": st_c, "dataset": ds.info()})
-        for i, b in enumerate(bams):
-            out = os.path.join(cov_dir, os.path.basename(b) + '.cov')
-            ds.write_coverage(i, out, out + '.detail')
-            print("Printing details in {}!".format(out + '.detail'))      # qaCompute.cpp:387
-        compute_summary(args)
-        get_header(args)
-        shutil.copy(args.all_samples, args.project_dir + '/all_samples')
-        ds.write_calls(os.path.join(snp_dir, "called_SNPs"), os.path.join(snp_dir, "indiv_called"), args.db_ann or None, args.ref_db)
+        res = parallel.resident_project_run(ctx, bams[0], args.ref_db, bams, params, batch=max(1, args.threads),
+                                            want_coverage=not args.use_prev_cov, ann_path=args.db_ann or None, after_coverage=between_passes)
     except core._lib.MsnvError as e:
         sys.stderr.write(str(e) + "\n")
         sys.stderr.write("SNV calling failed")
-        sys.exit(1)
-    finally:
-        ds.close()
-
-
-def snp_call(args, ctx, rank=0, world=1):                       # metaSNV.py:179-221
-    out_dir = os.path.join(args.project_dir, 'snpCaller')
-    mkdir_p(out_dir)
-    if rank == 0:
-        shutil.copy(args.all_samples, args.project_dir + '/all_samples')
-    indiv_out = os.path.join(out_dir, "indiv_called")
-    called = os.path.join(out_dir, "called_SNPs")
-    if args.n_splits > 1:
-        splits = sorted(glob.glob('{}/bestsplits/best_split_*'.format(args.project_dir)))
-        for i, split in enumerate(splits):
-            if i % world != rank:
-                continue                                        # splits are whole species: shards need no exchange
-            v = execute_snp_call(args, ctx, '{}.{}'.format(indiv_out, os.path.basename(split)),
-                                 '{}.{}'.format(called, os.path.basename(split)), split)
-            if v:
-                sys.stderr.write("SNV calling failed")
-                sys.exit(1)
-    elif rank == 0:
-        v = execute_snp_call(args, ctx, indiv_out, called, None)
-        if v:
-            sys.stderr.write("SNV calling failed")
-            sys.exit(1)
+        parallel.abort(1)
+    _write_metrics(res["metrics"])
+    if rank != 0:
+        return
+    try:
+        if args.n_splits > 1:
+            for split in sorted(glob.glob('{}/bestsplits/best_split_*'.format(args.project_dir))):
+                sites, samples, ann = parallel.split_view(res, read_split_file(split))
+                sfx = '.' + os.path.basename(split)
+                core.write_calls_records(res["names"], res["n_samples"], sites, samples, os.path.join(snp_dir, "called_SNPs" + sfx),
+                                         os.path.join(snp_dir, "indiv_called" + sfx), args.db_ann or None, args.ref_db, ann)
+        else:
+            core.write_calls_records(res["names"], res["n_samples"], res["sites"], res["samples"], os.path.join(snp_dir, "called_SNPs"),
+                                     os.path.join(snp_dir, "indiv_called"), args.db_ann or None, args.ref_db, res["ann"])
+    except (core._lib.MsnvError, ValueError) as e:
+        sys.stderr.write(str(e) + "\n")
+        sys.stderr.write("SNV calling failed")
+        parallel.abort(1)
 
 
 def build_parser():                                             # metaSNV.py:225-247
@@ -204,7 +175,7 @@ def build_parser():                                             # metaSNV.py:225
     p.add_argument('--db_ann', metavar='DB_ANN_FILE', default='', help='Database gene annotation.')
     p.add_argument('--print-commands', default=False, action='store_true', help='Instead of executing the commands, simply print them out')
     p.add_argument('--threads', metavar='INT', default=1, type=int,
-                   help='Host threads for BAM decoding. Will create same number of splits, unless n_splits set differently.')
+                   help='Host threads for BAM decoding (per rank). Will create same number of splits, unless n_splits set differently.')
     p.add_argument('--n_splits', metavar='INT', default=1, type=int, help='Number of bins to split ref into')
     p.add_argument('--use_prev_cov', default=False, action="store_true",
                    help='Use "cov/" and "outputs.all_cov.tab" and "outputs.all_perc.tab" data produced by previous metaSNV run')
@@ -243,23 +214,18 @@ def main(argv=None):
             sys.stderr.write("\nERROR:  {}\n\nSOLUTION: run on a node with an AMD Instinct GPU (there is no CPU fallback)\n\n".format(e))
             parallel.abort(1)
 
-    if world == 1 and args.n_splits <= 1 and not args.use_prev_cov and not args.print_commands:
-        fused_cov_and_call(args, ctx)                           # BASELINE configs[2]: one decode, both passes on the device
+    if args.print_commands:                                     # metaSNV.py --print-commands: nothing runs
+        if rank == 0:
+            if not args.use_prev_cov:
+                print_coverage_commands(args)
+                compute_summary(args)                           # exits like the reference when cov/ is still empty
+            get_header(args)
+            if args.n_splits > 1:
+                split_opt(args)
+            print_call_commands(args)
         parallel.finalize()
         return
-    if not args.use_prev_cov:
-        compute_opt(args, ctx, rank, world)
-        parallel.barrier()
-        if rank == 0:
-            compute_summary(args)
-    parallel.barrier()
-    if rank == 0:
-        get_header(args)
-        if args.n_splits > 1:
-            split_opt(args)
-    args.ctg_len = os.path.join(args.project_dir, 'bed_header')
-    parallel.barrier()
-    snp_call(args, ctx, rank, world)
+    resident_run(args, ctx, rank, world)
     parallel.barrier()
     parallel.finalize()
 

@@ -4,12 +4,13 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import lib, check, Params, SynthParams, DatasetInfo, RunStats, Site, SiteSample, SiteAnn, RefDesc
+from ._lib import lib, check, Params, SynthParams, DatasetInfo, RunStats, Site, SiteSample, SiteAnn, RefDesc, SampleStats, COV_WORDS
 
 SITE_DTYPE = np.dtype([("tid", "<i4"), ("pos", "<i4"), ("cov", "<u4"), ("n", "<u4", (4,)),
                        ("pop_mask", "u1"), ("ind_mask", "u1"), ("refchar", "u1"), ("dropped", "u1")])
 SAMPLE_DTYPE = np.dtype([("cov", "<u2"), ("n", "<u2", (4,))])
 ANN_DTYPE = np.dtype([("gene", "<i4"), ("codon", "u1", (4, 8))])
+STATS_FIELDS = [n for n, _ in SampleStats._fields_]
 assert SITE_DTYPE.itemsize == C.sizeof(Site) and SAMPLE_DTYPE.itemsize == C.sizeof(SiteSample) and ANN_DTYPE.itemsize == C.sizeof(SiteAnn)
 
 
@@ -164,6 +165,17 @@ class Dataset:
         check(lib.msnv_fused_run(self._h, C.byref(sp), C.byref(sc)))
         return ({k: getattr(sp, k) for k, _ in RunStats._fields_}, {k: getattr(sc, k) for k, _ in RunStats._fields_})
 
+    def coverage_accumulators(self):
+        """[n_samples][n_contigs][COV_WORDS] uint64 of the last coverage run (zeros for contigs outside the shard)."""
+        acc = np.zeros((max(1, self.n_samples), len(self.names), COV_WORDS), dtype=np.uint64)
+        check(lib.msnv_coverage_fetch(self._h, acc.ctypes.data_as(C.POINTER(C.c_uint64)), acc.size))
+        return acc
+
+    def sample_stats(self, sample_idx):
+        st = SampleStats()
+        check(lib.msnv_dataset_sample_stats(self._h, sample_idx, C.byref(st)))
+        return np.array([getattr(st, k) for k in STATS_FIELDS], dtype=np.uint32)
+
     def write_coverage(self, sample_idx, cov_path, detail_path):
         check(lib.msnv_write_coverage(self._h, sample_idx, cov_path.encode(), detail_path.encode()))
 
@@ -190,6 +202,13 @@ class Dataset:
         t, p = C.c_int32(), C.c_int32()
         check(lib.msnv_dataset_first_line(self._h, C.byref(t), C.byref(p)))
         return t.value, p.value
+
+    def first_lines(self):
+        """Per contig: first pileup line without -l / under metaSNV's `name 1 LEN` split BED (-1 = none); int32 arrays."""
+        n = len(self.names)
+        a, b = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        check(lib.msnv_dataset_first_lines(self._h, a.ctypes.data_as(C.POINTER(C.c_int32)), b.ctypes.data_as(C.POINTER(C.c_int32)), n))
+        return a, b
 
     def write_calls(self, called_path, indiv_path=None, ann_path=None, fasta_path=None):
         check(lib.msnv_write_calls(self._h, called_path.encode(), indiv_path.encode() if indiv_path else None,
@@ -221,6 +240,32 @@ def write_calls_records(names, n_samples, sites, samples, called_path, indiv_pat
                                        indiv_path.encode() if indiv_path else None, ann_path.encode() if ann_path else None,
                                        fasta_path.encode() if fasta_path else None,
                                        np.ascontiguousarray(ann, dtype=ANN_DTYPE).ctypes.data_as(C.POINTER(SiteAnn)) if ann is not None else None))
+
+
+def write_coverage_records(names, lengths, max_cov, stats, acc, cov_path, detail_path):
+    """OUT / OUT.detail of one sample from gathered accumulators acc[n_contigs][COV_WORDS] and its statistics (STATS_FIELDS order)."""
+    n = len(names)
+    rd = RefDesc(n, _cstr_array(names), (C.c_int64 * n)(*[int(x) for x in lengths]), None, None)
+    st = SampleStats(*[int(x) for x in stats])
+    a = np.ascontiguousarray(acc, dtype=np.uint64).reshape(n, COV_WORDS)
+    check(lib.msnv_write_coverage_records(C.byref(rd), int(max_cov), C.byref(st), a.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                          cov_path.encode(), detail_path.encode()))
+
+
+def partition_records(records, contig_owner, n_parts, cov_min_mapq=1):
+    """Deals a sample's raw record stream (uint8 array) to n_parts parts by contig owner.  Returns (list of uint8 arrays, stats)."""
+    rec = np.ascontiguousarray(records, dtype=np.uint8)
+    owner = np.ascontiguousarray(contig_owner, dtype=np.int32)
+    out = np.empty(rec.size, dtype=np.uint8)
+    sizes = (C.c_uint64 * n_parts)()
+    st = SampleStats()
+    check(lib.msnv_records_partition(rec.ctypes.data, rec.size, owner.ctypes.data_as(C.POINTER(C.c_int32)), owner.size, n_parts,
+                                     int(cov_min_mapq), out.ctypes.data, sizes, C.byref(st)))
+    parts, o = [], 0
+    for k in range(n_parts):
+        parts.append(out[o:o + sizes[k]])
+        o += sizes[k]
+    return parts, np.array([getattr(st, k) for k in STATS_FIELDS], dtype=np.uint32)
 
 
 # ------------------------------------------------------------------------------------ host I/O helpers

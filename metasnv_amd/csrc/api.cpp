@@ -444,6 +444,23 @@ extern "C" int msnv_dataset_first_line(const msnv_dataset *ds, int32_t *tid, int
     return MSNV_OK;
 }
 
+extern "C" int msnv_dataset_first_lines(const msnv_dataset *ds, int32_t *first_any, int32_t *first_from1, int32_t n) {
+    clear_error();
+    if (!ds || !first_any || !first_from1) return fail(MSNV_EINVAL, "msnv_dataset_first_lines: NULL argument");
+    if ((size_t)n != ds->names.size()) return fail(MSNV_EINVAL, "msnv_dataset_first_lines: %d entries, header has %zu contigs", n, ds->names.size());
+    if (ds->has_bed) return fail(MSNV_EINVAL, "msnv_dataset_first_lines: the dataset was restricted with a BED file");
+    for (int c = 0; c < n; ++c) { first_any[c] = -1; first_from1[c] = -1; }
+    for (const SampleCols &sc : ds->samples) {
+        if (sc.first_any.empty()) continue;
+        for (int c = 0; c < n; ++c) {
+            const int32_t a = sc.first_any[(size_t)c], b = sc.first_from1[(size_t)c];
+            if (a >= 0 && (first_any[c] < 0 || a < first_any[c])) first_any[c] = a;
+            if (b >= 0 && (first_from1[c] < 0 || b < first_from1[c])) first_from1[c] = b;
+        }
+    }
+    return MSNV_OK;
+}
+
 extern "C" int msnv_write_calls_records(const msnv_ref_desc *ref, int32_t n_samples, const msnv_site *sites,
                                         const msnv_site_sample *samples, uint64_t n_sites,
                                         const char *called_path, const char *indiv_path,
@@ -487,6 +504,54 @@ extern "C" int msnv_write_coverage(msnv_dataset *ds, int32_t sample_idx, const c
     clear_error();
     if (!ds || !cov_path || !detail_path) return fail(MSNV_EINVAL, "msnv_write_coverage: NULL argument");
     return coverage_write(*ds, sample_idx, cov_path, detail_path);
+}
+
+// ------------------------------------------------------------------------------ multi-GPU: decode sharding + gathered coverage
+namespace msnv {
+int records_partition(const uint8_t *rec, uint64_t n_bytes, const int32_t *owner, int n_contigs, int n_parts, int cov_min_mapq,
+                      uint8_t *out, uint64_t *part_bytes, msnv_sample_stats &st);
+int coverage_write_rows(const std::vector<std::string> &names, const std::vector<int64_t> &lengths, int max_cov, const msnv_sample_stats &sc,
+                        const unsigned long long *acc, const char *cov_path, const char *detail_path, int sample);
+}
+static_assert(MSNV_COV_WORDS == 1 + COV_BINS, "msnv.h and device.h disagree on the accumulator width");
+
+extern "C" int msnv_records_partition(const uint8_t *records, uint64_t n_bytes, const int32_t *contig_owner, int32_t n_contigs,
+                                      int32_t n_parts, int32_t cov_min_mapq, uint8_t *out, uint64_t *part_bytes, msnv_sample_stats *stats) {
+    clear_error();
+    if ((n_bytes && (!records || !out)) || !contig_owner || n_contigs < 0 || n_parts <= 0 || !part_bytes)
+        return fail(MSNV_EINVAL, "msnv_records_partition: bad argument");
+    msnv_sample_stats st{};
+    const int rc = records_partition(records, n_bytes, contig_owner, n_contigs, n_parts, cov_min_mapq, out, part_bytes, st);
+    if (!rc && stats) *stats = st;
+    return rc;
+}
+
+extern "C" int msnv_dataset_sample_stats(const msnv_dataset *ds, int32_t sample_idx, msnv_sample_stats *out) {
+    clear_error();
+    if (!ds || !out) return fail(MSNV_EINVAL, "msnv_dataset_sample_stats: NULL argument");
+    if (sample_idx < 0 || (size_t)sample_idx >= ds->samples.size()) return fail(MSNV_EINVAL, "sample index %d out of range", sample_idx);
+    *out = ds->samples[(size_t)sample_idx].st;
+    return MSNV_OK;
+}
+
+extern "C" int msnv_coverage_fetch(msnv_dataset *ds, uint64_t *acc, uint64_t capacity_words) {
+    clear_error();
+    if (!ds || !acc) return fail(MSNV_EINVAL, "msnv_coverage_fetch: NULL argument");
+    if (!ds->have_coverage) return fail(MSNV_EINVAL, "no coverage results: call msnv_coverage_run first");
+    if (capacity_words < ds->cov_acc.size()) return fail(MSNV_ECAPACITY, "capacity %llu < %zu words", (unsigned long long)capacity_words, ds->cov_acc.size());
+    static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "accumulators are 64-bit");
+    memcpy(acc, ds->cov_acc.data(), ds->cov_acc.size() * sizeof(uint64_t));
+    return MSNV_OK;
+}
+
+extern "C" int msnv_write_coverage_records(const msnv_ref_desc *ref, int32_t max_cov, const msnv_sample_stats *stats, const uint64_t *acc,
+                                           const char *cov_path, const char *detail_path) {
+    clear_error();
+    if (!ref || !stats || !acc || !cov_path || !detail_path || ref->n_contigs < 0 || (ref->n_contigs && (!ref->names || !ref->lengths)))
+        return fail(MSNV_EINVAL, "msnv_write_coverage_records: bad argument");
+    std::vector<std::string> names; std::vector<int64_t> lens;
+    for (int i = 0; i < ref->n_contigs; ++i) { names.emplace_back(ref->names[i]); lens.push_back(ref->lengths[i]); }
+    return coverage_write_rows(names, lens, max_cov, *stats, reinterpret_cast<const unsigned long long *>(acc), cov_path, detail_path, 0);
 }
 
 // ------------------------------------------------------------------------------ filter_two (section 8 f1)

@@ -22,36 +22,34 @@ int coverage_run(msnv_dataset &ds, msnv_run_stats *stats) {
     return MSNV_OK;
 }
 
-int coverage_write(msnv_dataset &ds, int sample, const char *cov_path, const char *detail_path) {
-    if (!ds.have_coverage) return fail(MSNV_EINVAL, "no coverage results: call msnv_coverage_run first");
-    if (sample < 0 || (size_t)sample >= ds.samples.size()) return fail(MSNV_EINVAL, "sample index %d out of range", sample);
-    const SampleCols &sc = ds.samples[(size_t)sample];
+// OUT / OUT.detail of one sample from its accumulator rows acc[contig][1 + COV_BINS] and its read statistics.
+int coverage_write_rows(const std::vector<std::string> &names, const std::vector<int64_t> &lengths, int max_cov, const msnv_sample_stats &sc,
+                        const unsigned long long *acc, const char *cov_path, const char *detail_path, int sample) {
+    if (max_cov < 1 || max_cov >= COV_BINS) return fail(MSNV_EINVAL, "coverage histogram cutoff must be in [1, %d]", COV_BINS - 1);
     // a BAM without mapped reads makes qaCompute read target_name[-1] (qaCompute.cpp:596)
     if (!sc.any_mapped) return fail(MSNV_EDOMAIN, "sample %d has no mapped reads (qaCompute: undefined behaviour, README.md:59)", sample);
     FILE *out = fopen(cov_path, "wt");
     if (!out) return fail(MSNV_EIO, "qaCompute: Filed to create output file %s", cov_path);
     FILE *det = fopen(detail_path, "wt");
     if (!det) { fclose(out); return fail(MSNV_EIO, "qaCompute: Unable to create detailed output file %s", detail_path); }
-    const int max_cov = ds.params.cov_max;
-    const size_t NC = ds.names.size();
+    const size_t NC = names.size();
     std::vector<unsigned long long> global_hist((size_t)max_cov + 1, 0);
     unsigned long long total_len = 0;
     fprintf(out, "Chromosome\tSeq_lem\tAvg_Cov\n");                                  // qaCompute.cpp:439
     for (size_t c = 0; c < NC; ++c) {
-        total_len += (unsigned long long)ds.lengths[c];                                // :425-427
+        total_len += (unsigned long long)lengths[c];                                    // :425-427
         // contigs without reads print zeros through printSkipped (:226-263); contigs with reads through
-        // compute_print_cov (:192-217): the same bytes when the sums are zero.  Contigs outside this
-        // shard carry zeros too (multi-GPU: each rank writes only its own contigs' rows elsewhere).
-        const unsigned long long *a = &ds.cov_acc[((size_t)sample * NC + c) * (1 + COV_BINS)];
-        const int L = (int)ds.lengths[c];
-        fprintf(det, "%s\t%d\t", ds.names[c].c_str(), L);
+        // compute_print_cov (:192-217): the same bytes when the sums are zero.
+        const unsigned long long *a = acc + c * (1 + COV_BINS);
+        const int L = (int)lengths[c];
+        fprintf(det, "%s\t%d\t", names[c].c_str(), L);
         for (int k = 1; k <= max_cov; ++k) {
             unsigned long long cum = 0;
             for (int x = k; x <= max_cov; ++x) cum += a[1 + x];
             fprintf(det, "%d\t", (int)cum);
         }
         fprintf(det, "\n");
-        fprintf(out, "%s\t%d\t%3.5f\n", ds.names[c].c_str(), L, L ? (double)a[0] / L : 0.0);
+        fprintf(out, "%s\t%d\t%3.5f\n", names[c].c_str(), L, L ? (double)a[0] / L : 0.0);
         for (int x = 1; x <= max_cov; ++x) global_hist[(size_t)x] += a[1 + x];
     }
     fprintf(out, "\nCov*X\tPercentage\tNr. of bases\n");                                // :623-640
@@ -73,6 +71,14 @@ int coverage_write(msnv_dataset &ds, int sample, const char *cov_path, const cha
     fprintf(out, "Percentage of proper pairs: %3.5f\n", pp);
     fclose(out); fclose(det);
     return MSNV_OK;
+}
+
+int coverage_write(msnv_dataset &ds, int sample, const char *cov_path, const char *detail_path) {
+    if (!ds.have_coverage) return fail(MSNV_EINVAL, "no coverage results: call msnv_coverage_run first");
+    if (sample < 0 || (size_t)sample >= ds.samples.size()) return fail(MSNV_EINVAL, "sample index %d out of range", sample);
+    // contigs outside this shard carry zeros (multi-GPU: the ranks' accumulators are summed before rank 0 writes, parallel.py)
+    return coverage_write_rows(ds.names, ds.lengths, ds.params.cov_max, ds.samples[(size_t)sample].st,
+                               &ds.cov_acc[(size_t)sample * ds.names.size() * (1 + COV_BINS)], cov_path, detail_path, sample);
 }
 
 }  // namespace msnv

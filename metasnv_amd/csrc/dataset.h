@@ -69,9 +69,8 @@ struct SampleCols {
     uint64_t alg_seq_bytes = 0, alg_qual_bytes = 0;   // shipped bytes without alignment padding
     uint64_t alg_8d_bytes = 0, alg_cigar_bytes = 0;   // SURVEY.md section 8d accounting (per pileup read)
     int32_t  first_tid = -1, first_beg = 0, first_end = 0;   // first pileup_ok read (first-line quirk)
-    // qaCompute "Other" statistics (qaCompute.cpp:642-654)
-    uint32_t total_reads = 0, unmapped = 0, zero_quality = 0, proper_pairs = 0, duplicates = 0;
-    bool     any_mapped = false;
+    std::vector<int32_t> first_any, first_from1;             // per contig (empty = no pileup read): first pileup line without -l / with `name 1 LEN`
+    msnv_sample_stats st{};          // qaCompute "Other" statistics (qaCompute.cpp:642-654), counted over every record of the BAM
 };
 
 struct DeviceCols;   // kernels.hip

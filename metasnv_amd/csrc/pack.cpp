@@ -163,6 +163,52 @@ void synth_sample_records(const msnv_synth_params &p, int sample, const std::vec
 static inline bool consumes_ref(uint32_t t) { return t == C_M || t == C_D || t == C_N || t == C_EQ || t == C_X; }
 static inline bool consumes_query(uint32_t t) { return t == C_M || t == C_I || t == C_S || t == C_EQ || t == C_X; }
 
+// qaCompute's per-read bookkeeping (qaCompute.cpp:461-473 unmapped, :518-526 MAPQ / duplicate filter): the "Other" block of
+// OUT counts every record of the BAM, whatever shard it belongs to.  Returns false for reads qaCompute skips as unmapped;
+// cov_ok = the read enters the coverage difference array.
+static inline bool read_stats(const RecView &r, int cov_min_mapq, msnv_sample_stats &st, bool &cov_ok) {
+    cov_ok = false;
+    st.total_reads++;
+    if ((r.flag & BAM_FUNMAP) || r.tid < 0) { st.unmapped++; return false; }
+    st.any_mapped = 1;
+    if (r.mapq >= cov_min_mapq) {
+        if (r.flag & BAM_FPROPER_PAIR) st.proper_pairs++;
+        if (r.flag & BAM_FDUP) st.duplicates++; else cov_ok = true;
+    } else st.zero_quality++;
+    return true;
+}
+
+// Multi-GPU decode sharding (msnv.h: msnv_records_partition): one walk over a sample's record stream that deals the
+// mapped records to the rank owning their contig (order preserved inside a part) and counts qaCompute's statistics.
+int records_partition(const uint8_t *rec, uint64_t n_bytes, const int32_t *owner, int n_contigs, int n_parts, int cov_min_mapq,
+                      uint8_t *out, uint64_t *part_bytes, msnv_sample_stats &st) {
+    std::vector<uint64_t> size((size_t)n_parts, 0);
+    st = msnv_sample_stats{};
+    for (int pass = 0; pass < 2; ++pass) {
+        std::vector<uint64_t> cur((size_t)n_parts, 0);
+        if (pass == 1) { uint64_t o = 0; for (int k = 0; k < n_parts; ++k) { cur[(size_t)k] = o; o += size[(size_t)k]; } }
+        uint64_t off = 0;
+        while (off < n_bytes) {
+            RecView r;
+            if (!rec_parse(rec + off, n_bytes - off, r)) return fail(MSNV_EFORMAT, "malformed BAM record at byte %llu", (unsigned long long)off);
+            const uint8_t *src = rec + off;
+            off += r.size;
+            if (pass == 0) {
+                bool cov_ok;
+                if (!read_stats(r, cov_min_mapq, st, cov_ok)) continue;
+                if (r.tid >= n_contigs) return fail(MSNV_EFORMAT, "record refers to contig %d but the header has %d", r.tid, n_contigs);
+            } else if ((r.flag & BAM_FUNMAP) || r.tid < 0) continue;
+            const int32_t k = owner[r.tid];
+            if (k < 0) continue;                                  // contig outside every shard (BED split)
+            if (k >= n_parts) return fail(MSNV_EINVAL, "contig %d is owned by part %d of %d", r.tid, k, n_parts);
+            if (pass == 0) size[(size_t)k] += r.size;
+            else { memcpy(out + cur[(size_t)k], src, r.size); cur[(size_t)k] += r.size; }
+        }
+    }
+    for (int k = 0; k < n_parts; ++k) part_bytes[k] = size[(size_t)k];
+    return MSNV_OK;
+}
+
 // Packs one sample.  `ds` supplies contig selection, BED and parameters.
 int pack_sample(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, SampleCols &sc) {
     const msnv_params &P = ds.params;
@@ -177,19 +223,11 @@ int pack_sample(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, Sa
         RecView r;
         if (!rec_parse(rec + off, n_bytes - off, r)) return fail(MSNV_EFORMAT, "malformed BAM record at byte %llu", (unsigned long long)off);
         off += r.size;
-        sc.total_reads++;
-        if (r.flag & BAM_FUNMAP) { sc.unmapped++; continue; }                   // qaCompute.cpp:461
-        if (r.tid < 0) { sc.unmapped++; continue; }                              // qaCompute.cpp:467-473
+        bool cov_ok = false;
+        if (!read_stats(r, P.cov_min_mapq, sc.st, cov_ok)) continue;             // unmapped (qaCompute.cpp:461-473)
         if (r.tid >= n_contigs) return fail(MSNV_EFORMAT, "record refers to contig %d but the header has %d", r.tid, n_contigs);
         if (r.tid < last_tid || (r.tid == last_tid && r.pos < last_pos)) return fail(MSNV_EFORMAT, "BAM is not coordinate sorted");
         last_tid = r.tid; last_pos = r.pos;
-        sc.any_mapped = true;
-        // ---- qaCompute read filter (qaCompute.cpp:518-526)
-        bool cov_ok = false;
-        if (r.mapq >= P.cov_min_mapq) {
-            if (r.flag & BAM_FPROPER_PAIR) sc.proper_pairs++;
-            if (r.flag & BAM_FDUP) sc.duplicates++; else cov_ok = true;
-        } else sc.zero_quality++;
         if (!ds.sel[(size_t)r.tid]) continue;     // not this shard's contig
 
         // ---- CIGAR geometry
@@ -257,6 +295,12 @@ int pack_sample(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, Sa
             if (ds.has_bed) { b = std::max(b, ds.bed_beg[(size_t)r.tid]); e = std::min(e, ds.bed_end[(size_t)r.tid]); }
             if (b < e) { sc.first_tid = r.tid; sc.first_beg = (int32_t)b; sc.first_end = (int32_t)e; }
         }
+        // per contig: the first pileup line of an invocation that starts at this contig -- without -l, and with metaSNV's
+        // split BED `name 1 LEN` (0-based [1, LEN): position 0 is excluded, metaSNV.py:92).  The driver derives the dropped
+        // first line of every best_split_K file from these when all splits are written from one resident dataset.
+        if (sc.first_any.empty()) { sc.first_any.assign((size_t)n_contigs, -1); sc.first_from1.assign((size_t)n_contigs, -1); }
+        if (sc.first_any[(size_t)r.tid] < 0) sc.first_any[(size_t)r.tid] = r.pos;
+        if (sc.first_from1[(size_t)r.tid] < 0 && endpos > 1) sc.first_from1[(size_t)r.tid] = std::max<int32_t>(r.pos, 1);
         if (r.l_seq == 0) continue;      // SEQ '*': every base prints as 'N' with quality 0 -> never counted
         const std::string &refseq = ds.seqs[(size_t)r.tid];
         const bool has_ref = ds.has_seq[(size_t)r.tid];

@@ -3,10 +3,13 @@ ROCm; "gloo" when no GPU is visible, which is how the CPU tests run it).
 
 The path shards by CONTIG: reference positions are independent, the reference
 already bins whole species for its process pool (src/createOptimumSplit.py:46-62), and every rank
-sees all samples but only its contigs' reads.  There is no data-path collective.  The one exchange
-is the final GATHER of small result tables to rank 0:
-  * coverage accumulators: fixed size per (sample, contig) -> all_gather of equal tensors;
-  * called-site records: variable length -> all_gather of the counts, then a padded all_gather.
+sees all samples but only its contigs' reads.  The kernels need no collective.  Two exchanges frame them:
+  * before: the BAMs are dealt to the ranks for DECODING (every file is inflated once in the whole job; the
+    reference's split processes each inflate every BAM, metaSNV.py:196-215) and the decoded records travel to
+    the rank that owns their contig -- one all_to_all of byte streams per batch of BAMs (exchange_records);
+  * after: the GATHER of small result tables to rank 0:
+      - coverage accumulators: fixed size per (sample, contig) -> all_gather of equal tensors, summed;
+      - called-site records: variable length -> all_gather of the counts, then a padded all_gather.
 """
 import os
 import sys
@@ -122,6 +125,91 @@ def gather_bytes(blob):
     return [o[:c].cpu().numpy() for o, c in zip(out, counts)]
 
 
+def exchange_records(parts):
+    """All-to-all of byte streams: parts[q] (1-D uint8 array) goes to rank q; returns the list of the arrays this rank
+    received, indexed by sender.  Sizes travel first (one all_to_all of `world` int64), then the bytes."""
+    if _dist is None:
+        return [np.ascontiguousarray(parts[0], dtype=np.uint8)]
+    import torch
+    dev = _device()
+    sizes = [int(np.asarray(p).size) for p in parts]
+    ts = torch.tensor(sizes, dtype=torch.int64, device=dev)
+    tr = torch.zeros(_world, dtype=torch.int64, device=dev)
+    _dist.all_to_all_single(tr, ts)
+    rsizes = [int(x) for x in tr.cpu().tolist()]
+    send = np.concatenate([np.ascontiguousarray(p, dtype=np.uint8).reshape(-1) for p in parts]) if sum(sizes) else np.zeros(0, np.uint8)
+    tsend = torch.from_numpy(send).to(dev)
+    trecv = torch.empty(sum(rsizes), dtype=torch.uint8, device=dev)
+    _dist.all_to_all_single(trecv, tsend, output_split_sizes=rsizes, input_split_sizes=sizes)
+    got = trecv.cpu().numpy()
+    out, o = [], 0
+    for n in rsizes:
+        out.append(got[o:o + n])
+        o += n
+    return out
+
+
+def deal_samples(n_samples, batch):
+    """Decode schedule: rounds of world x batch consecutive samples; in a round, rank r decodes samples
+    base + r * batch .. base + (r + 1) * batch - 1.  Yields (base, list of (sample, decoder rank))."""
+    step = _world * batch
+    for base in range(0, n_samples, step):
+        yield base, [(i, (i - base) // batch) for i in range(base, min(n_samples, base + step))]
+
+
+def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=None, metrics=None):
+    """Decode-sharded input of one dataset per rank: every BAM is read and inflated by ONE rank, its records are dealt by
+    contig owner (core.partition_records) and exchanged, and every rank appends all samples in all_samples order holding
+    only its contigs' records.  Returns stats[n_samples][6] (qaCompute's per-BAM statistics, counted by the decoder and
+    all-gathered).  read_records(path) -> uint8 array replaces the BAM reader in tests."""
+    from . import core
+    n = len(bam_paths)
+    if _world == 1 and read_records is None:             # nothing to exchange: decode + pack inside the library's thread pool
+        ds.add_sample_bams(bam_paths, batch)
+        if metrics is not None:
+            metrics["inflated_record_bytes"] = None
+        return np.stack([ds.sample_stats(i) for i in range(n)]) if n else np.zeros((0, len(core.STATS_FIELDS)), np.uint32)
+    if read_records is None:
+        read_records = lambda path: core.read_bam(path)["records"]
+    stats = np.zeros((n, len(core.STATS_FIELDS)), dtype=np.uint32)
+    inflated = 0
+    for base, plan in deal_samples(n, batch):
+        mine = [i for i, r in plan if r == _rank]
+        # decode my samples of this round and deal every one of them to the owners
+        per_dest = [[] for _ in range(_world)]          # per destination rank: (sample, bytes) in sample order
+        if len(mine) > 1:                                # the library releases the GIL: one decode thread per BAM of the round
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=len(mine)) as ex:
+                decoded = list(ex.map(read_records, [bam_paths[i] for i in mine]))
+        else:
+            decoded = [read_records(bam_paths[i]) for i in mine]
+        for i, rec in zip(mine, decoded):
+            inflated += int(rec.size)
+            parts, st = core.partition_records(rec, owner, _world, cov_min_mapq)
+            stats[i] = st
+            for q in range(_world):
+                per_dest[q].append(parts[q])
+        # one exchange per round: [sizes of my samples' parts | bytes], per destination
+        send = []
+        for q in range(_world):
+            hdr = np.array([p.size for p in per_dest[q]], dtype=np.int64).view(np.uint8)
+            send.append(np.concatenate([hdr] + per_dest[q]) if per_dest[q] else np.zeros(0, np.uint8))
+        got = exchange_records(send)
+        # unpack in sample order: sender r holds samples base + r * batch ...
+        for i, r in plan:
+            k = i - base - r * batch                     # index among the sender's samples of this round
+            blob = got[r]
+            n_from = len([1 for j, rr in plan if rr == r])
+            sizes = blob[:8 * n_from].view(np.int64)
+            o = 8 * n_from + int(sizes[:k].sum())
+            ds.add_sample_records(blob[o:o + int(sizes[k])])
+    allstats = gather_fixed(stats)
+    stats = np.maximum.reduce(allstats) if len(allstats) > 1 else stats      # every row is non-zero on exactly one rank
+    if metrics is not None:
+        metrics["inflated_record_bytes"] = inflated
+    return stats
+
+
 def gather_sites(sites, samples, first_line, ann=None):
     """Gathers the called-site records of every rank and merges them in (tid, pos) order.
     first_line: this rank's (tid, pos) of the first pileup line, tid = -1 if none.  Only the globally
@@ -149,6 +237,70 @@ def gather_sites(sites, samples, first_line, ann=None):
     parts_a = gather_bytes(np.ascontiguousarray(ann, dtype=ANN_DTYPE).view(np.uint8))
     all_ann = np.concatenate([p.view(ANN_DTYPE) for p in parts_a]) if parts_a else np.zeros(0, ANN_DTYPE)
     return all_sites[order], all_samples[order], gfirst, all_ann[order]
+
+
+def resident_project_run(ctx, first_bam, fasta_path, bam_paths, params, batch=1, want_coverage=True, ann_path=None,
+                         after_coverage=None, species_weight=None):
+    """ONE resident dataset per rank for a whole metaSNV.py run, whatever the number of ranks and splits (the reference forks
+    one qaCompute process per BAM, metaSNV.py:55-78, and one `mpileup | snpCall` process per split, :196-221, each of which
+    inflates every BAM again): contigs are sharded over the ranks by species (LPT), the BAMs are dealt to the ranks for
+    decoding and their records exchanged (feed_sharded), every rank runs coverage and then calling [+ annotation] over its
+    contigs, and every rank receives the summed coverage accumulators and the merged site records (rank 0 writes the files).
+
+    after_coverage(result) is called on every rank between the two passes -- the driver writes cov/, the tables and the
+    split plan there -- and must contain its own barriers.  Returns a dict:
+      names, lengths, n_samples, stats[n_samples][6], acc[n_samples][n_contigs][17] (None without coverage),
+      sites / samples / ann (merged, (tid, pos) order, `dropped` marks the global first line), first_any / first_from1
+      (per contig, see core.Dataset.first_lines), metrics."""
+    from . import core
+    ds = core.Dataset.from_files(ctx, first_bam, fasta_path, params)
+    names, lengths = ds.names, ds.lengths
+    owner = shard_contigs(names, lengths, _world, species_weight)
+    if _world > 1:
+        ds.set_contig_mask([o == _rank for o in owner])
+    metrics = {"rank": _rank, "world": _world, "contigs": int(sum(1 for o in owner if o == _rank))}
+    res = {"names": names, "lengths": lengths, "n_samples": len(bam_paths), "metrics": metrics, "acc": None}
+    try:
+        res["stats"] = feed_sharded(ds, bam_paths, owner, params.cov_min_mapq, batch, metrics=metrics)
+        metrics["dataset"] = ds.finalize()
+        if want_coverage:
+            metrics["coverage"] = ds.coverage_run()
+            # every rank holds zeros outside its contigs, so the sum over ranks is the whole table
+            res["acc"] = sum(a.astype(np.uint64) for a in gather_fixed(ds.coverage_accumulators()))
+        if after_coverage:
+            after_coverage(res)
+        metrics["pileup"] = ds.run()
+        sites, samples = ds.results()
+        if ann_path and fasta_path:
+            ann, _ = ds.annotate(ann_path, fasta_path)
+            res["sites"], res["samples"], res["gfirst"], res["ann"] = gather_sites(sites, samples, ds.first_line(), ann)
+        else:
+            res["sites"], res["samples"], res["gfirst"] = gather_sites(sites, samples, ds.first_line())
+            res["ann"] = None
+        fa, f1 = ds.first_lines()                      # -1 outside this rank's contigs: the owner's value is the maximum
+        res["first_any"] = np.maximum.reduce(gather_fixed(fa))
+        res["first_from1"] = np.maximum.reduce(gather_fixed(f1))
+        # per-rank inflated bytes for the report (SURVEY.md section 8 f2: the host stage shards with the ranks)
+        infl = gather_fixed(np.array([metrics.get("inflated_record_bytes") or 0], dtype=np.int64))
+        metrics["inflated_record_bytes_per_rank"] = [int(x[0]) for x in infl]
+    finally:
+        ds.close()
+    return res
+
+
+def split_view(res, split_contigs):
+    """The records of one best_split_K invocation (`samtools mpileup -l best_split_K ... | snpCall`, metaSNV.py:160-176) cut
+    out of a whole-run result: sites on the split's contigs at 0-based positions >= 1 (the split file's lines are
+    `name 1 LEN`, parsed as BED [1, LEN): metaSNV.py:92), with the split's OWN first pileup line marked as dropped
+    (call_vC.cpp:423; lines come in BAM-header order whatever the order of the split file)."""
+    tid_of = {n: i for i, n in enumerate(res["names"])}
+    tids = sorted(tid_of[n] for n in split_contigs if n in tid_of)          # samtools ignores names that are not in the header
+    sites, samples, ann = res["sites"], res["samples"], res["ann"]
+    keep = np.isin(sites["tid"], np.array(tids, dtype=np.int64)) & (sites["pos"] >= 1)
+    s = sites[keep].copy()
+    first = next(((t, int(res["first_from1"][t])) for t in tids if res["first_from1"][t] >= 0), (-1, -1))
+    s["dropped"] = ((s["tid"] == first[0]) & (s["pos"] == first[1])).astype(np.uint8)
+    return s, samples[keep], (ann[keep] if ann is not None else None)
 
 
 def sharded_call(ctx, names, lengths, seqs, add_samples, params=None, species_weight=None,

@@ -648,6 +648,85 @@ def test_two_rank_sharded_call_with_annotation(tmp_path):
     assert info[0][1] + info[1][1] == orac[3]
 
 
+def _torchrun(n, script_args, env=None, timeout=900):
+    import socket
+    import subprocess
+    import sys
+    so = socket.socket(); so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]; so.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port)] + script_args
+    return subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1", **(env or {})), capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("extra", [[], ["--n_splits", "3"], ["--threads", "2", "--db_ann", "ANN"]])
+def test_launcher_metasnv_py_under_two_ranks_matches_the_oracle(tmp_path, extra):
+    """The LAUNCHER (metaSNV.py, reference argv) under torchrun with two ranks sharing this GPU (tables over gloo): contigs
+    are sharded over the ranks, every BAM is decoded by ONE rank and its records exchanged, rank 0 writes the project.
+    called_SNPs / indiv_called (unsplit, per best_split_K, with --db_ann) and every cov/ file equal the oracle's bytes, and
+    each rank inflated about half of the job's record bytes (metaSNV.py:179-221 is the pool this replaces)."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    syn, samples = synth_case(n_species=6, contig_len=3500, n_samples=8, mean_cov=11.0, snv_density=0.03, frac_absent=0.15, seed=91)
+    fa, paths, lst = _write_inputs(tmp_path, syn, samples)
+    ann = None
+    if "ANN" in extra:
+        ann = str(tmp_path / "ann.tsv")
+        _write_ann(ann, [("a1", syn.names[0], 5, 1800, "+"), ("a2", syn.names[0], 1500, 3300, "-"), ("c1", syn.names[2], 100, 3400, "-"),
+                         ("e1", syn.names[4], 1, 900, "+"), ("f1", syn.names[5], 10, 3000, "-")])
+        extra = [ann if x == "ANN" else x for x in extra]
+    proj, met = str(tmp_path / "proj"), str(tmp_path / "metrics.jsonl")
+    r = _torchrun(2, [os.path.join(root, "metaSNV.py"), proj, lst, fa] + extra, env=dict(MSNV_DIST_BACKEND="gloo", MSNV_METRICS=met))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    n_splits = 3 if "--n_splits" in extra else (2 if "--threads" in extra else 1)
+    if n_splits == 1:
+        orac = run_oracle(syn.names, syn.lengths, syn.seqs, samples, ann=ann, fasta=fa)
+        assert open(os.path.join(proj, "snpCaller", "called_SNPs")).read() == orac[0]
+        assert open(os.path.join(proj, "snpCaller", "indiv_called")).read() == orac[1]
+        assert orac[0].count("\n") > 50
+    else:
+        splits = sorted(os.listdir(os.path.join(proj, "bestsplits")))
+        assert splits == ["best_split_%d" % k for k in range(n_splits)]
+        seen, total = [], 0
+        for sp in splits:
+            bed = [(syn.names.index(l.split()[0]), int(l.split()[1]), int(l.split()[2])) for l in open(os.path.join(proj, "bestsplits", sp))]
+            seen += [b[0] for b in bed]
+            o = run_oracle(syn.names, syn.lengths, syn.seqs, samples, bed=bed, ann=ann, fasta=fa)
+            assert open(os.path.join(proj, "snpCaller", "called_SNPs." + sp)).read() == o[0], sp
+            assert open(os.path.join(proj, "snpCaller", "indiv_called." + sp)).read() == o[1], sp
+            total += o[0].count("\n")
+        assert sorted(seen) == list(range(6)) and total > 50
+    for i, p in enumerate(paths):
+        want = orc.qacompute(syn.names, syn.lengths, samples[i])
+        base = os.path.join(proj, "cov", os.path.basename(p) + ".cov")
+        assert open(base).read() == want[0] and open(base + ".detail").read() == want[1]
+        assert os.path.exists(base + ".summary")
+    assert open(os.path.join(proj, "all_samples")).read() == open(lst).read()
+    m = [json.loads(l) for l in open(met)]
+    assert sorted(x["rank"] for x in m) == [0, 1] and all(x["world"] == 2 and x["contigs"] == 3 for x in m)
+    per_rank = m[0]["inflated_record_bytes_per_rank"]
+    total_bytes = sum(s.size for s in samples)
+    assert sum(per_rank) == total_bytes and max(per_rank) <= 0.75 * total_bytes      # 8 BAMs of unequal size over 2 ranks
+    assert sum(x["dataset"]["n_positions"] for x in m) == sum(syn.lengths)
+
+
+def test_bench_gpus_2_starts_two_ranks_by_itself():
+    """`python bench.py --gpus 2` outside torchrun spawns the two rank processes itself (before any GPU call) and the
+    rank-0 line reports n_gpus 2, both ranks' line counts and the slowest rank's roofline (gloo rehearsal: one GPU)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "3", "--warmup", "1",
+                        "--samples", "24", "--contig-len", "60000", "--no-cpu-baseline", "--no-annotation", "--no-overlap-extra"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and len(line["config"]["called_SNPs_lines_per_rank"]) == 2
+    assert len(line["roofline"]["achieved_per_rank"]) == 2 and line["roofline"]["achieved"] == min(line["roofline"]["achieved_per_rank"])
+    assert line["value"] > 0 and line["scaling"] == "weak"
+
+
 def test_distances_on_device_match_reference_outputs(tmp_path, golden_dir):
     """metaSNV_DistDiv.py --dist on the device: tests/golden/python_callers/distdiv holds the
     *.filtered.freq inputs and the .mann.dist / .allele.dist files the reference script (pandas) wrote for them."""

@@ -6,6 +6,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 import orc
 import recparse
@@ -56,3 +57,71 @@ def test_two_rank_gather_reproduces_the_full_output(tmp_path):
     assert open(os.path.join(work, "out_ind")).read() == ind
     g = open(os.path.join(work, "gfirst")).read().split()
     assert g[:2] == ["0", "0"] and g[2] == "0"          # rank-local first lines were un-dropped, (0,0) is not a called site
+
+
+def _records(buf):
+    """[(tid, bytes)] of a raw BAM record stream."""
+    out, o = [], 0
+    b = bytes(buf)
+    while o < len(b):
+        n = int.from_bytes(b[o:o + 4], "little")
+        out.append((int.from_bytes(b[o + 4:o + 8], "little", signed=True), b[o:o + 4 + n]))
+        o += 4 + n
+    return out
+
+
+@pytest.mark.parametrize("batch", [1, 2])
+def test_two_rank_decode_sharding_deals_every_record_to_its_owner(tmp_path, batch):
+    """parallel.feed_sharded over gloo: each sample is read by exactly one rank (per-rank decoded bytes ~ 1/N of the job),
+    and after the all-to-all every rank holds, per sample and in order, exactly the records of the contigs it owns."""
+    work = str(tmp_path)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_feed_worker.py"), work, str(batch)]
+    r = subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+    sp = core.synth_params(n_species=5, contig_len=2500, n_samples=7, mean_cov=6.0, frac_absent=0.3, seed=77)
+    syn = core.Synth(sp)
+    owner = np.load(os.path.join(work, "owner.npy"))
+    assert set(owner.tolist()) == {0, 1}
+    dec = [np.load(os.path.join(work, "decoded%d.npy" % k)).tolist() for k in (0, 1)]
+    assert sorted(dec[0] + dec[1]) == list(range(sp.n_samples))                  # every BAM decoded once in the whole job
+    assert abs(len(dec[0]) - len(dec[1])) <= batch
+    total = 0
+    nbytes = [int(open(os.path.join(work, "n%d" % k)).read().split()[1]) for k in (0, 1)]
+    for i in range(sp.n_samples):
+        full = syn.sample_records(i)
+        total += full.size
+        recs = _records(full)
+        for k in (0, 1):
+            got = np.fromfile(os.path.join(work, "r%d_s%d.bin" % (k, i)), dtype=np.uint8)
+            want = b"".join(b for t, b in recs if t >= 0 and owner[t] == k)
+            assert bytes(got) == want, (i, k)
+        # statistics counted by the decoder reach every rank
+        parts, st = core.partition_records(full, owner, 2, 1)
+        for k in (0, 1):
+            assert (np.load(os.path.join(work, "stats%d.npy" % k))[i] == st).all()
+        assert st[0] == len(recs)
+    assert nbytes[0] + nbytes[1] == total and max(nbytes) <= 0.75 * total
+
+
+def test_partition_counts_qacompute_statistics_and_drops_unmapped():
+    from bamtools import make_record
+    recs = [make_record(0, 5, "10M", "A" * 10),
+            make_record(0, 7, "10M", "A" * 10, flag=2, mapq=0),               # mapq 0: "sub-par"
+            make_record(1, 3, "10M", "A" * 10, flag=0x400 | 2),              # duplicate, proper pair
+            make_record(2, 9, "10M", "A" * 10),
+            make_record(-1, -1, "*", "A" * 10, flag=4, mapq=0)]              # unmapped
+    buf = np.frombuffer(b"".join(recs), dtype=np.uint8)
+    parts, st = core.partition_records(buf, [1, 0, -1], 2, 1)
+    assert bytes(parts[0]) == recs[2] and bytes(parts[1]) == recs[0] + recs[1]
+    assert dict(zip(core.STATS_FIELDS, st.tolist())) == dict(total_reads=5, unmapped=1, zero_quality=1, proper_pairs=1, duplicates=1, any_mapped=1)
+
+
+def test_bench_launcher_command_starts_n_ranks():
+    sys.path.insert(0, ROOT)
+    import importlib
+    bench = importlib.import_module("bench")
+    cmd = bench.launcher_command(4, ["--gpus", "4", "--steps", "2"], port=29999)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "2"]
+    assert os.path.samefile(cmd[cmd.index("29999") + 1], os.path.join(ROOT, "bench.py"))
