@@ -73,6 +73,10 @@ typedef struct {
                                     called); 0 = call every position                      */
     int32_t cov_max;             /* qaCompute -c, default 10                              */
     int32_t cov_min_mapq;        /* qaCompute -q, default 1                               */
+    int32_t ignore_overlaps;     /* mpileup -x, default 0: the overlapping-mate quality tweak is ON, as in the
+                                    reference's command line (metaSNV.py:160-165 passes no -x)             */
+    int32_t token_limit;         /* snpCall's per-token character limit (call_vC.cpp:482: 10000): a sample's
+                                    base string is cut there, bases behind the cut are not counted; 0 = unlimited */
 } msnv_params;
 
 void msnv_params_default(msnv_params *p);
@@ -181,6 +185,8 @@ typedef struct {
     const int64_t     *seq_lens;
 } msnv_ref_desc;
 
+/* ctx may be NULL: the dataset then serves the host-stage entry points only (add_sample_*, pileup_qualities,
+ * sample_stats, first_lines) and msnv_dataset_finalize fails with MSNV_ENODEV -- nothing is ever computed on the CPU. */
 int  msnv_dataset_create(msnv_ctx *ctx, const msnv_ref_desc *ref, const msnv_params *params,
                          msnv_dataset **out);
 /* Convenience: contigs from the header of `bam_path`, sequences from `fasta_path`. */
@@ -201,6 +207,12 @@ int  msnv_dataset_add_sample_records(msnv_dataset *ds, const uint8_t *records, u
 int  msnv_dataset_add_sample_bam(msnv_dataset *ds, const char *bam_path);
 /* Decode many BAMs with a host thread pool, preserving order. */
 int  msnv_dataset_add_sample_bams(msnv_dataset *ds, const char *const *bam_paths, int32_t n, int32_t host_threads);
+
+/* Host-stage seam (tests, A/B against `samtools mpileup` text): writes to `out` (n_bytes) the same record stream with the
+ * base qualities as the pileup engine sees them -- after the overlapping-mate tweak (unless params.ignore_overlaps) and
+ * with the bases behind params.token_limit characters of a sample's base string set to quality 0 -- under this dataset's
+ * read filters, BED and contig mask.  Does not add a sample. */
+int  msnv_dataset_pileup_qualities(const msnv_dataset *ds, const uint8_t *records, uint64_t n_bytes, uint8_t *out);
 
 /* Builds the tile index and uploads the packed columns to HBM. */
 int  msnv_dataset_finalize(msnv_dataset *ds);
@@ -368,6 +380,8 @@ typedef struct {
     double   frac_flagged;       /* DUP / SECONDARY / QCFAIL / mapq 0 reads (each)           */
     int32_t  lowercase_ref;      /* 1 = soft-mask 5 % of the reference (lower-case)           */
     uint64_t seed;
+    double   frac_paired;        /* 0 (default, the BASELINE testdata shape is single-end): fraction of read starts that
+                                    become a proper pair whose mates mostly overlap on the reference               */
 } msnv_synth_params;
 
 void msnv_synth_params_default(msnv_synth_params *p);

@@ -24,7 +24,7 @@ class Params(C.Structure):
     _fields_ = [("min_coverage", C.c_int32), ("calling_threshold", C.c_int32), ("min_fraction", C.c_double),
                 ("min_baseq", C.c_int32), ("flag_filter", C.c_int32), ("count_orphans", C.c_int32),
                 ("max_depth", C.c_int32), ("min_mapq", C.c_int32), ("drop_first_line", C.c_int32),
-                ("cov_max", C.c_int32), ("cov_min_mapq", C.c_int32)]
+                ("cov_max", C.c_int32), ("cov_min_mapq", C.c_int32), ("ignore_overlaps", C.c_int32), ("token_limit", C.c_int32)]
 
 
 class CovArgs(C.Structure):
@@ -92,7 +92,7 @@ class SynthParams(C.Structure):
                 ("mean_cov", C.c_double), ("sigma_cov", C.c_double), ("frac_absent", C.c_double),
                 ("snv_density", C.c_double), ("error_rate", C.c_double), ("frac_lowq", C.c_double),
                 ("frac_indel_reads", C.c_double), ("frac_clip_reads", C.c_double), ("frac_flagged", C.c_double),
-                ("lowercase_ref", C.c_int32), ("seed", C.c_uint64)]
+                ("lowercase_ref", C.c_int32), ("seed", C.c_uint64), ("frac_paired", C.c_double)]
 
 
 # every symbol include/msnv.h declares: (name, restype, argtypes)
@@ -116,6 +116,7 @@ SYMBOLS = [
     ("msnv_dataset_add_sample_records", C.c_int, [_vp, _vp, C.c_uint64]),
     ("msnv_dataset_add_sample_bam", C.c_int, [_vp, C.c_char_p]),
     ("msnv_dataset_add_sample_bams", C.c_int, [_vp, P(C.c_char_p), C.c_int32, C.c_int32]),
+    ("msnv_dataset_pileup_qualities", C.c_int, [_vp, _vp, C.c_uint64, _vp]),
     ("msnv_dataset_finalize", C.c_int, [_vp]),
     ("msnv_dataset_info_get", C.c_int, [_vp, P(DatasetInfo)]),
     ("msnv_pileup_run", C.c_int, [_vp, P(RunStats)]),

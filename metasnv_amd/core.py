@@ -78,7 +78,7 @@ class Dataset:
         self.params = params or default_params()
         self._h = C.c_void_p()
         self.n_samples = 0
-        check(lib.msnv_dataset_create(ctx._h, C.byref(rd), C.byref(self.params), C.byref(self._h)))
+        check(lib.msnv_dataset_create(ctx._h if ctx is not None else None, C.byref(rd), C.byref(self.params), C.byref(self._h)))
 
     @classmethod
     def from_files(cls, ctx, first_bam, fasta, params=None):
@@ -119,6 +119,13 @@ class Dataset:
             ptr, n = C.cast(C.c_char_p(buf), C.c_void_p), len(buf)
         check(lib.msnv_dataset_add_sample_records(self._h, ptr, n))
         self.n_samples += 1
+
+    def pileup_qualities(self, records):
+        """The record stream with the base qualities as the pileup engine sees them (overlap tweak, token limit)."""
+        rec = np.ascontiguousarray(records, dtype=np.uint8)
+        out = np.empty_like(rec)
+        check(lib.msnv_dataset_pileup_qualities(self._h, rec.ctypes.data, rec.size, out.ctypes.data))
+        return out
 
     def add_sample_bam(self, path):
         check(lib.msnv_dataset_add_sample_bam(self._h, path.encode()))

@@ -11,6 +11,7 @@
 
 namespace msnv {
 int pack_sample(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, SampleCols &sc);
+int pileup_qualities(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, uint8_t *out);
 int finalize_dataset(msnv_dataset &ds);
 int write_calls_text(msnv_dataset &ds, const char *called_path, const char *indiv_path,
                      const msnv_site_ann *ann, const std::vector<std::string> *gene_names);
@@ -22,7 +23,7 @@ void synth_sample_records(const msnv_synth_params &p, int sample, const std::vec
 
 using namespace msnv;
 
-extern "C" int msnv_abi_version(void) { return 1; }
+extern "C" int msnv_abi_version(void) { return 2; }
 
 extern "C" void msnv_params_default(msnv_params *p) {
     if (!p) return;
@@ -30,6 +31,8 @@ extern "C" void msnv_params_default(msnv_params *p) {
     p->min_baseq = 13; p->flag_filter = 0x704; p->count_orphans = 0; p->max_depth = 8000; p->min_mapq = 0;
     p->drop_first_line = 1;
     p->cov_max = 10; p->cov_min_mapq = 1;                                         // metaSNV.py:63-65, qaCompute.cpp:302
+    p->ignore_overlaps = 0;                                                       // no -x in metaSNV.py:160-165
+    p->token_limit = 10000;                                                       // call_vC.cpp:481-483
 }
 
 extern "C" int msnv_ctx_create(int device_id, msnv_ctx **out) {
@@ -53,10 +56,17 @@ extern "C" void msnv_ctx_destroy(msnv_ctx *ctx) {
 // ------------------------------------------------------------------------------ dataset
 extern "C" int msnv_dataset_create(msnv_ctx *ctx, const msnv_ref_desc *ref, const msnv_params *params, msnv_dataset **out) {
     clear_error();
-    if (!ctx || !ref || !out) return fail(MSNV_EINVAL, "msnv_dataset_create: NULL argument");
+    if (!ref || !out) return fail(MSNV_EINVAL, "msnv_dataset_create: NULL argument");      // ctx may be NULL: host-stage-only dataset
+    msnv_params P;
+    if (params) P = *params; else msnv_params_default(&P);
+    // per-sample counts are 16-bit on the device (msnv_site_sample): the depth cap keeps them there
+    if (P.max_depth < 1 || P.max_depth > 65535) return fail(MSNV_EINVAL, "max_depth (mpileup -d) must be in [1, 65535], got %d", P.max_depth);
+    if (P.cov_max < 1 || P.cov_max >= COV_BINS) return fail(MSNV_EINVAL, "cov_max (qaCompute -c) must be in [1, %d], got %d", COV_BINS - 1, P.cov_max);
+    if (P.min_coverage < 0 || P.calling_threshold < 0 || P.min_baseq < 0 || P.min_mapq < 0 || P.cov_min_mapq < 0 || P.token_limit < 0 || !(P.min_fraction >= 0.0))
+        return fail(MSNV_EINVAL, "negative cutoff in msnv_params");
     msnv_dataset *ds = new msnv_dataset();
     ds->ctx = ctx;
-    if (params) ds->params = *params; else msnv_params_default(&ds->params);
+    ds->params = P;
     for (int i = 0; i < ref->n_contigs; ++i) {
         ds->names.emplace_back(ref->names[i]);
         ds->lengths.push_back(ref->lengths[i]);
@@ -73,7 +83,7 @@ extern "C" int msnv_dataset_create(msnv_ctx *ctx, const msnv_ref_desc *ref, cons
 extern "C" int msnv_dataset_create_from_files(msnv_ctx *ctx, const char *bam_path, const char *fasta_path,
                                               const msnv_params *params, msnv_dataset **out) {
     clear_error();
-    if (!ctx || !bam_path || !out) return fail(MSNV_EINVAL, "msnv_dataset_create_from_files: NULL argument");
+    if (!bam_path || !out) return fail(MSNV_EINVAL, "msnv_dataset_create_from_files: NULL argument");
     BamHeader h;
     if (int rc = bam_read_header(bam_path, h)) return rc;
     std::vector<FastaSeq> fa;
@@ -148,6 +158,12 @@ extern "C" int msnv_dataset_add_sample_records(msnv_dataset *ds, const uint8_t *
     int rc = pack_sample(*ds, records, n_bytes, ds->samples.back());
     if (rc) ds->samples.pop_back();
     return rc;
+}
+
+extern "C" int msnv_dataset_pileup_qualities(const msnv_dataset *ds, const uint8_t *records, uint64_t n_bytes, uint8_t *out) {
+    clear_error();
+    if (!ds || (n_bytes && (!records || !out))) return fail(MSNV_EINVAL, "msnv_dataset_pileup_qualities: NULL argument");
+    return pileup_qualities(*ds, records, n_bytes, out);
 }
 
 static int check_header(const msnv_dataset &ds, const BamHeader &h, const char *path) {
@@ -232,6 +248,7 @@ extern "C" int msnv_dataset_finalize(msnv_dataset *ds) {
     clear_error();
     if (!ds) return fail(MSNV_EINVAL, "msnv_dataset_finalize: NULL dataset");
     if (ds->finalized) return fail(MSNV_EINVAL, "dataset is already finalized");
+    if (!ds->ctx) return fail(MSNV_ENODEV, "this dataset was created without a device context: only the host-stage entry points work on it (no CPU fallback)");
     if (int rc = dev_set_device(ds->ctx->device)) return rc;
     return finalize_dataset(*ds);
 }

@@ -256,6 +256,8 @@ bool rec_parse(const uint8_t *p, uint64_t avail, RecView &r) {
     if (r.l_seq < 0) return false;
     uint64_t need = 36ull + l_name + 4ull * r.n_cigar + ((uint64_t)r.l_seq + 1) / 2 + (uint64_t)r.l_seq;
     if (need > (uint64_t)bs + 4) return false;
+    r.mtid = (int32_t)ld_u32(p + 24); r.mpos = (int32_t)ld_u32(p + 28); r.tlen = (int32_t)ld_u32(p + 32);
+    r.qname = p + 36; r.l_name = l_name;
     r.cigar = p + 36 + l_name;
     r.seq = r.cigar + 4ull * r.n_cigar;
     r.qual = r.seq + ((uint64_t)r.l_seq + 1) / 2;

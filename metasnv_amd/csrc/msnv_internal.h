@@ -53,7 +53,7 @@ struct Annotation {
 int load_annotation(const char *ann_path, const char *fasta_path, Annotation &an);
 
 // ---------------------------------------------------------------------------------- BAM record view
-constexpr int BAM_FPAIRED = 1, BAM_FPROPER_PAIR = 2, BAM_FUNMAP = 4, BAM_FREVERSE = 16,
+constexpr int BAM_FPAIRED = 1, BAM_FPROPER_PAIR = 2, BAM_FUNMAP = 4, BAM_FMUNMAP = 8, BAM_FREVERSE = 16,
               BAM_FSECONDARY = 256, BAM_FQCFAIL = 512, BAM_FDUP = 1024;
 enum CigarOp : uint32_t { C_M = 0, C_I = 1, C_D = 2, C_N = 3, C_S = 4, C_H = 5, C_P = 6, C_EQ = 7, C_X = 8 };
 
@@ -62,6 +62,8 @@ struct RecView {
     uint16_t flag, n_cigar;
     uint8_t  mapq;
     const uint8_t *cigar, *seq, *qual;   // unaligned little-endian
+    const uint8_t *qname; uint32_t l_name;   // NUL-terminated read name, l_name includes the NUL
+    int32_t  mtid, mpos, tlen;            // mate contig / position, template length
     uint32_t size;                        // bytes consumed including block_size
 };
 // returns false on a malformed record

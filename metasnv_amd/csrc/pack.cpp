@@ -11,6 +11,7 @@
 #include <cstring>
 #include <queue>
 #include <thread>
+#include <unordered_map>
 
 #include "device.h"
 
@@ -209,35 +210,215 @@ int records_partition(const uint8_t *rec, uint64_t n_bytes, const int32_t *owner
     return MSNV_OK;
 }
 
-// Packs one sample.  `ds` supplies contig selection, BED and parameters.
-int pack_sample(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, SampleCols &sc) {
+// ---------------------------------------------------------------------------------- overlapping mates
+// `samtools mpileup` without -x (metaSNV.py:160-165) lets htslib's pileup engine edit the base qualities of proper-pair
+// mates that overlap on the reference before the -Q cutoff sees them (sam.c overlap_push / tweak_overlap_quality, htslib
+// >= 1.10): where both mates have an aligned base at a reference position, agreeing bases give min(200, qa + qb) to the
+// mate that was pushed first and 0 to the other; disagreeing bases give 0.8 * q (truncated) to the one of higher quality
+// (ties: the first) and 0 to the other.  So each template counts once per position, and snpCall's counts depend on it.
+//
+// The engine walks the two CIGARs with a shared reference cursor t: x = first match position of a at or after t,
+// y = first match position of b at or after x, the pair is edited iff x == y, then t = y + 1.  Consequence kept here:
+// behind a stretch where a has bases and b has none (deletion / skip in b), b's next base is never edited.
+struct MatchCursor {           // the M/=/X bases of one alignment in reference order
+    const RecView &r; int k = 0; int64_t op_ref, op_q; int64_t ref = -1, q = -1;
+    explicit MatchCursor(const RecView &rv) : r(rv), op_ref(rv.pos), op_q(0) {}
+    // first match base at a reference position >= target; false when the alignment has none left
+    bool seek(const int64_t target) {
+        for (; k < r.n_cigar; ++k) {
+            const uint32_t c = ld_u32(r.cigar + 4 * k), t = c & 15u; const int64_t l = c >> 4;
+            if (t == C_M || t == C_EQ || t == C_X) {
+                if (target < op_ref + l) { ref = std::max(target, op_ref); q = op_q + (ref - op_ref); return true; }
+                op_ref += l; op_q += l;
+            } else {
+                if (t == C_D || t == C_N) op_ref += l;
+                if (t == C_I || t == C_S) op_q += l;
+            }
+        }
+        return false;
+    }
+};
+
+static void tweak_overlapping_mates(const RecView &a, uint8_t *qa, const RecView &b, uint8_t *qb) {
+    if (a.l_seq == 0 || b.l_seq == 0) return;
+    MatchCursor ca(a), cb(b);
+    int64_t t = b.pos;
+    while (ca.seek(t) && cb.seek(ca.ref)) {
+        t = cb.ref + 1;
+        if (ca.ref != cb.ref) continue;
+        if (ca.q >= a.l_seq || cb.q >= b.l_seq) return;
+        const uint32_t ba = (a.seq[ca.q >> 1] >> ((~ca.q & 1) << 2)) & 0xfu, bb = (b.seq[cb.q >> 1] >> ((~cb.q & 1) << 2)) & 0xfu;
+        uint8_t &x = qa[ca.q], &y = qb[cb.q];
+        if (ba == bb) { const int sum = (int)x + (int)y; x = (uint8_t)(sum > 200 ? 200 : sum); y = 0; }
+        else if (x >= y) { x = (uint8_t)(0.8 * x); y = 0; }
+        else { y = (uint8_t)(0.8 * y); x = 0; }
+    }
+}
+
+// One filtered read of pass 1, kept for pass 2 (packing).
+struct KeptRead { uint64_t off; int64_t endpos; uint16_t depth_here; bool pile_ok, cov_ok; };
+
+// ---------------------------------------------------------------------------------- snpCall's token limit
+// snpCall copies every tab-separated field of a pileup line through a 10000-character token (call_vC.cpp:92-111,481-483):
+// a sample's base string is CUT there and the bases behind the cut are never counted (SURVEY.md Appendix A "D1").  With
+// mpileup -d 8000 that takes a stack of reads starting at one position (`^]` costs two characters per read start) or
+// thousands of indel suffixes, but the reference's counts are what they are.  The string itself is never built here: where
+// a sample's string can reach the limit at all (upper bound kept by the caller's sweep), the characters of every element
+// are counted in pileup order -- [^ mapq] base|*|<> [+n ins | -n del] [$], elements below -Q are not printed at all
+// (bam_plcmd.c pileup_seq and the text loop) -- and a base whose character lies at or behind the limit gets quality 0, so
+// the device leaves it out exactly like a base below the cutoff.  Nothing else of a cut element can be counted: what
+// follows a base inside its element (indel suffix, $) is skipped by snpCall's parser anyway (call_vC.cpp:506-523).
+static uint32_t decimal_digits(uint32_t v) { uint32_t d = 1; while (v >= 10) { v /= 10; ++d; } return d; }
+
+static uint32_t max_element_chars(const RecView &r) {
+    uint64_t ins = 0, del = 0;
+    for (int k = 0; k < r.n_cigar; ++k) {
+        const uint32_t c = ld_u32(r.cigar + 4 * k), t = c & 15u;
+        if (t == C_I) ins += c >> 4;                       // consecutive insertions around a P op print as one suffix
+        else if (t == C_D) del = std::max<uint64_t>(del, c >> 4);
+    }
+    return (uint32_t)std::min<uint64_t>(0x7fffffffu, 4 + 11 + std::max(ins, del));
+}
+
+template <typename MutableQual>
+static void apply_token_limit(const msnv_params &P, const uint8_t *rec, uint64_t n_bytes, const std::vector<KeptRead> &kept, MutableQual &mutable_qual) {
+    struct Act { RecView r; int64_t end; uint32_t maxc; int k; int64_t x, y; };
+    std::vector<Act> act;                                   // pileup reads alive at the current position, in push (= file) order
+    uint64_t bound = 0;
+    const uint64_t limit = (uint64_t)P.token_limit;
+    size_t next = 0;
+    while (next < kept.size() && !kept[next].pile_ok) ++next;
+    int32_t tid = -1; int64_t pos = 0;
+    auto peek = [&](RecView &r) { rec_parse(rec + kept[next].off, n_bytes - kept[next].off, r); };
+    while (next < kept.size() || !act.empty()) {
+        RecView nr{};
+        if (next < kept.size()) peek(nr);
+        if (act.empty()) {
+            if (next >= kept.size()) break;
+            tid = nr.tid; pos = nr.pos;
+        }
+        // reads that start here
+        while (next < kept.size() && nr.tid == tid && nr.pos == pos) {
+            Act a{nr, kept[next].endpos, max_element_chars(nr), 0, nr.pos, 0};
+            for (; a.k < nr.n_cigar; ++a.k) {               // cursor on the first reference-consuming op (sam.c resolve_cigar2)
+                const uint32_t c = ld_u32(nr.cigar + 4 * a.k), t = c & 15u;
+                if (consumes_ref(t)) break;
+                if (t == C_I || t == C_S) a.y += c >> 4;
+            }
+            act.push_back(a); bound += a.maxc;
+            do ++next; while (next < kept.size() && !kept[next].pile_ok);
+            if (next < kept.size()) peek(nr);
+        }
+        if (bound >= limit) {
+            uint64_t off = 0;                               // characters of this sample's base string so far
+            for (Act &a : act) {
+                const RecView &r = a.r;
+                bool found = false;
+                while (a.k < r.n_cigar) {                   // advance to the op that holds `pos`
+                    const uint32_t c = ld_u32(r.cigar + 4 * a.k), t = c & 15u; const int64_t l = c >> 4;
+                    if (consumes_ref(t) && pos < a.x + l) { found = true; break; }
+                    if (consumes_ref(t)) a.x += l;
+                    if (consumes_query(t)) a.y += l;
+                    ++a.k;
+                }
+                if (!found) continue;
+                const uint32_t c = ld_u32(r.cigar + 4 * a.k), t = c & 15u; const int64_t l = c >> 4;
+                const bool is_del = !(t == C_M || t == C_EQ || t == C_X);
+                const int64_t qpos = is_del ? a.y : a.y + (pos - a.x);
+                int64_t indel = 0;
+                if (!is_del && a.x + l - 1 == pos && a.k + 1 < r.n_cigar) {
+                    const uint32_t c2 = ld_u32(r.cigar + 4 * (a.k + 1)), t2 = c2 & 15u;
+                    if (t2 == C_D) indel = -(int64_t)(c2 >> 4);
+                    else if (t2 == C_I) indel = c2 >> 4;
+                    else if (t2 == C_P && a.k + 2 < r.n_cigar) {
+                        for (int k = a.k + 2; k < r.n_cigar; ++k) {
+                            const uint32_t c3 = ld_u32(r.cigar + 4 * k), t3 = c3 & 15u;
+                            if (t3 == C_I) indel += c3 >> 4;
+                            else if (t3 == C_D || t3 == C_M || t3 == C_N || t3 == C_EQ || t3 == C_X) break;
+                        }
+                    }
+                }
+                uint8_t *q = (r.l_seq > 0) ? mutable_qual(r) : nullptr;
+                const int qv = (q && qpos < r.l_seq) ? q[qpos] : 0;
+                if (qv < P.min_baseq) continue;             // not printed at all
+                const bool head = pos == r.pos, tail = pos == a.end - 1;
+                if (!is_del && off + (head ? 2u : 0u) >= limit && q) q[qpos] = 0;      // the base's own character is cut off
+                const uint64_t n_indel = (uint64_t)(indel < 0 ? -indel : indel);
+                off += (head ? 2u : 0u) + 1u + (indel ? 1u + decimal_digits((uint32_t)n_indel) + n_indel : 0u) + (tail ? 1u : 0u);
+            }
+        }
+        // next position: the following one while reads are alive, else the next read's start
+        ++pos;
+        size_t w = 0;
+        for (size_t i = 0; i < act.size(); ++i) { if (act[i].end > pos) act[w++] = act[i]; else bound -= act[i].maxc; }
+        act.resize(w);
+        if (bound < limit) {                                // nothing to count before the next read arrives
+            RecView r2{};
+            if (next < kept.size()) peek(r2);
+            if (next >= kept.size() || r2.tid != tid) { act.clear(); bound = 0; }
+            else if (r2.pos > pos) {
+                pos = r2.pos;
+                w = 0;
+                for (size_t i = 0; i < act.size(); ++i) { if (act[i].end > pos) act[w++] = act[i]; else bound -= act[i].maxc; }
+                act.resize(w);
+            }
+        }
+    }
+}
+
+struct NameKey {
+    const uint8_t *p; uint32_t n;
+    bool operator==(const NameKey &o) const { return n == o.n && memcmp(p, o.p, n) == 0; }
+};
+struct NameHash {
+    size_t operator()(const NameKey &k) const { uint64_t h = 1469598103934665603ull; for (uint32_t i = 0; i < k.n; ++i) { h ^= k.p[i]; h *= 1099511628211ull; } return (size_t)h; }
+};
+
+// Pass 1 of packing a sample: the read-level filters of both tools and everything that edits base qualities BEFORE the
+// pileup is counted (the overlapping-mate tweak, the token limit), on a private copy of the record stream (`patched`,
+// left empty when nothing was edited).  kept: the reads pass 2 packs, in file order.
+static int filter_and_edit(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, msnv_sample_stats &st,
+                           std::vector<KeptRead> &kept, std::vector<uint8_t> &patched) {
     const msnv_params &P = ds.params;
     const int n_contigs = (int)ds.names.size();
     uint64_t off = 0;
     int32_t last_tid = -1, last_pos = -1;
     // depth cap (mpileup -d): live pileup reads of this sample, by reference end
-    std::priority_queue<int64_t, std::vector<int64_t>, std::greater<int64_t>> live;
+    typedef std::pair<int64_t, uint32_t> LiveRead;                  // {reference end, upper bound of its pileup element's characters}
+    std::priority_queue<LiveRead, std::vector<LiveRead>, std::greater<LiveRead>> live;
+    uint64_t live_chars = 0;                                        // upper bound of this sample's base-string length at the current position
+    bool token_limit_in_reach = false;
     int32_t cap_tid = -1, cap_pos = -1; int nth_at_pos = 0; bool first_push_done = false;
+    auto mutable_qual = [&](const RecView &r) -> uint8_t * {
+        if (patched.empty()) patched.assign(rec, rec + n_bytes);
+        return patched.data() + (r.qual - rec);
+    };
+    // qname -> the mate that was pushed first and still waits for its partner (htslib's overlap hash).  An entry is
+    // visible while its read is alive in the pileup (end > start of the read being pushed); htslib drops it a few pushes
+    // later, which can only matter for templates with three or more alignments in the file.
+    struct Waiting { uint64_t off; int32_t tid; int64_t end; };
+    std::unordered_map<NameKey, Waiting, NameHash> waiting;
+    size_t waiting_sweep_at = 8192;
 
     while (off < n_bytes) {
         RecView r;
         if (!rec_parse(rec + off, n_bytes - off, r)) return fail(MSNV_EFORMAT, "malformed BAM record at byte %llu", (unsigned long long)off);
+        const uint64_t rec_off = off;
         off += r.size;
         bool cov_ok = false;
-        if (!read_stats(r, P.cov_min_mapq, sc.st, cov_ok)) continue;             // unmapped (qaCompute.cpp:461-473)
+        if (!read_stats(r, P.cov_min_mapq, st, cov_ok)) continue;                // unmapped (qaCompute.cpp:461-473)
         if (r.tid >= n_contigs) return fail(MSNV_EFORMAT, "record refers to contig %d but the header has %d", r.tid, n_contigs);
         if (r.tid < last_tid || (r.tid == last_tid && r.pos < last_pos)) return fail(MSNV_EFORMAT, "BAM is not coordinate sorted");
         last_tid = r.tid; last_pos = r.pos;
         if (!ds.sel[(size_t)r.tid]) continue;     // not this shard's contig
 
         // ---- CIGAR geometry
-        int64_t rlen = 0, qlen = 0, m_bases = 0;
+        int64_t rlen = 0, qlen = 0;
         bool has_ref_op = false;
         for (int k = 0; k < r.n_cigar; ++k) {
             uint32_t c = ld_u32(r.cigar + 4 * k), t = c & 15u, l = c >> 4;
             if (consumes_ref(t)) { rlen += l; has_ref_op = true; }
             if (consumes_query(t)) qlen += l;
-            if (t == C_M || t == C_EQ || t == C_X) m_bases += l;
         }
         const int64_t endpos = r.pos + (rlen ? rlen : 1);                        // bam_endpos
 
@@ -252,15 +433,80 @@ int pack_sample(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, Sa
             return fail(MSNV_EFORMAT, "CIGAR consumes %lld query bases but the read has %d", (long long)qlen, r.l_seq);
         if (pile_ok) {
             // depth cap, sam.c bam_plp_push (sample-local restatement)
-            while (!live.empty() && live.top() <= r.pos) live.pop();
-            if (cap_tid != r.tid) { while (!live.empty()) live.pop(); }
+            while (!live.empty() && live.top().first <= r.pos) { live_chars -= live.top().second; live.pop(); }
+            if (cap_tid != r.tid) { while (!live.empty()) live.pop(); live_chars = 0; }
             if (cap_tid != r.tid || cap_pos != r.pos) { cap_tid = r.tid; cap_pos = r.pos; nth_at_pos = 0; }
             bool capped = (nth_at_pos > 0 || !first_push_done) && P.max_depth > 0 && (int64_t)live.size() > (int64_t)P.max_depth;
             first_push_done = true; ++nth_at_pos;
-            if (capped) pile_ok = false; else live.push(endpos);
+            if (capped) {
+                pile_ok = false;
+                if (!P.ignore_overlaps) waiting.erase(NameKey{r.qname, r.l_name});     // overlap_remove of a capped read
+            } else {
+                const uint32_t mc = max_element_chars(r);
+                live.push(LiveRead{endpos, mc});
+                live_chars += mc;
+                if (P.token_limit > 0 && live_chars >= (uint64_t)P.token_limit) token_limit_in_reach = true;
+            }
         }
         const uint16_t depth_here = (uint16_t)std::min<size_t>(live.size(), 0xffff);
+        if (pile_ok && !P.ignore_overlaps && !(r.flag & BAM_FMUNMAP) && (r.flag & BAM_FPROPER_PAIR) &&
+            !((r.mtid >= 0 && r.tid != r.mtid) || (std::llabs((long long)r.tlen) >= 2ll * r.l_seq && r.mpos >= endpos))) {
+            // sam.c overlap_push: the mate waiting under this name gets its overlap with this read edited; otherwise this
+            // read waits for its mate when that one is still to come (mate position at or after this one, or unknown)
+            const NameKey key{r.qname, r.l_name};
+            auto it = waiting.find(key);
+            if (it != waiting.end() && (it->second.tid != r.tid || it->second.end <= r.pos)) { waiting.erase(it); it = waiting.end(); }
+            if (it != waiting.end()) {
+                RecView a;
+                rec_parse(rec + it->second.off, n_bytes - it->second.off, a);
+                uint8_t *qa = mutable_qual(a), *qb = mutable_qual(r);
+                tweak_overlapping_mates(a, qa, r, qb);
+                waiting.erase(it);
+            } else if (r.mpos >= r.pos || ((r.flag & BAM_FPAIRED) && r.mpos == -1)) {
+                waiting.emplace(key, Waiting{rec_off, r.tid, endpos});
+                if (waiting.size() >= waiting_sweep_at) {                      // drop the entries no later read can see
+                    for (auto w = waiting.begin(); w != waiting.end();) w = (w->second.tid != r.tid || w->second.end <= r.pos) ? waiting.erase(w) : std::next(w);
+                    waiting_sweep_at = std::max<size_t>(8192, 2 * waiting.size());
+                }
+            }
+        }
         if (!pile_ok && !cov_ok) continue;
+        kept.push_back(KeptRead{rec_off, endpos, depth_here, pile_ok, cov_ok});
+    }
+    if (token_limit_in_reach) apply_token_limit(P, rec, n_bytes, kept, mutable_qual);
+    return MSNV_OK;
+}
+
+// The record stream with the base qualities as the pileup engine sees them (msnv.h: msnv_dataset_pileup_qualities).
+int pileup_qualities(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, uint8_t *out) {
+    msnv_sample_stats st{};
+    std::vector<KeptRead> kept;
+    std::vector<uint8_t> patched;
+    if (int rc = filter_and_edit(ds, rec, n_bytes, st, kept, patched)) return rc;
+    if (n_bytes) memcpy(out, patched.empty() ? rec : patched.data(), n_bytes);
+    return MSNV_OK;
+}
+
+// Packs one sample.  `ds` supplies contig selection, BED and parameters.
+int pack_sample(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, SampleCols &sc) {
+    const int n_contigs = (int)ds.names.size();
+    std::vector<KeptRead> kept;
+    std::vector<uint8_t> patched;                 // copy of the record stream with edited qualities (empty: nothing was edited)
+    if (int rc = filter_and_edit(ds, rec, n_bytes, sc.st, kept, patched)) return rc;
+    const uint8_t *qual_base = patched.empty() ? rec : patched.data();          // qualities as the pileup sees them
+
+    for (const KeptRead &kr : kept) {
+        RecView r;
+        rec_parse(rec + kr.off, n_bytes - kr.off, r);
+        const bool pile_ok = kr.pile_ok, cov_ok = kr.cov_ok;
+        const int64_t endpos = kr.endpos;
+        const uint16_t depth_here = kr.depth_here;
+        const uint8_t *r_qual = qual_base + (r.qual - rec);
+        int64_t m_bases = 0;
+        for (int k = 0; k < r.n_cigar; ++k) {
+            const uint32_t c = ld_u32(r.cigar + 4 * k), t = c & 15u;
+            if (t == C_M || t == C_EQ || t == C_X) m_bases += c >> 4;
+        }
 
         if (cov_ok) {
             // qaCompute's M intervals in its own index space (qaCompute.cpp:530-552): index = pos + 1, a leading
@@ -350,7 +596,7 @@ int pack_sample(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, Sa
                         const size_t qs = sc.qual.size();
                         sc.qual.resize(qs + n);
                         uint8_t *qd = sc.qual.data() + qs;
-                        const uint8_t *qsrc = r.qual + q0;
+                        const uint8_t *qsrc = r_qual + q0;
                         for (uint32_t j = 0; j < n; ++j) qd[j] = qsrc[j] > 127 ? 127 : qsrc[j];
                     }
                     // every piece starts on an 8-byte (seq) / 16-byte (qual) boundary

@@ -107,11 +107,29 @@ void synth_sample_records(const msnv_synth_params &p, int sample, const std::vec
         std::vector<SnvSite> sites = synth_sites(p, k, seq.data());
         std::vector<uint8_t> site_alt((size_t)L, 0), site_car((size_t)L, 0);
         for (const SnvSite &s : sites) { site_alt[(size_t)s.pos] = s.alt; site_car[(size_t)s.pos] = (uint8_t)(s.carrier + 1); }
+        if (p.frac_paired > 0) n_reads = (int64_t)((double)n_reads / (1.0 + p.frac_paired));     // a fragment yields two reads
         std::vector<int64_t> starts((size_t)n_reads);
         for (auto &s : starts) s = (int64_t)(r.uni() * (double)(L - p.read_len - 4));
         std::sort(starts.begin(), starts.end());
-        for (int64_t i = 0; i < n_reads; ++i) {
-            int64_t pos = starts[(size_t)i];
+        // paired-end variant (frac_paired > 0; the default workload is single-end and its bytes do not change): a start
+        // becomes a proper pair with probability frac_paired -- second mate 0 .. 2 read lengths downstream, so most pairs
+        // overlap on the reference (what mpileup's overlap handling is about); 4 % of the pairs lose the PROPER_PAIR bit (orphans)
+        struct Job { int64_t pos, mpos; uint32_t pair_flags; int32_t tlen; uint64_t name; };
+        std::vector<Job> jobs;
+        jobs.reserve(starts.size());
+        for (int64_t st : starts) {
+            if (p.frac_paired > 0 && r.uni() < p.frac_paired) {
+                const int64_t d = (int64_t)r.below((uint32_t)(2 * p.read_len)), m = std::min<int64_t>(st + d, L - p.read_len - 4);
+                const uint32_t proper = r.uni() < 0.04 ? 0u : (uint32_t)BAM_FPROPER_PAIR;
+                const int32_t tl = (int32_t)(m + p.read_len - st);
+                jobs.push_back(Job{st, m, (uint32_t)BAM_FPAIRED | proper | 0x20u | 0x40u, tl, serial});
+                jobs.push_back(Job{m, st, (uint32_t)BAM_FPAIRED | proper | (uint32_t)BAM_FREVERSE | 0x80u, -tl, serial});
+                ++serial;
+            } else jobs.push_back(Job{st, -1, 0u, 0, serial++});
+        }
+        if (p.frac_paired > 0) std::stable_sort(jobs.begin(), jobs.end(), [](const Job &a, const Job &b) { return a.pos < b.pos; });
+        for (const Job &job : jobs) {
+            int64_t pos = job.pos;
             int rl = p.read_len;
             cigar.clear();
             // offset of the indel inside the aligned part: 10 .. rl-21 for the usual read lengths, 2 .. rl-7 for reads below 40 bases
@@ -160,6 +178,7 @@ void synth_sample_records(const msnv_synth_params &p, int sample, const std::vec
             for (int j = 0; j < l_seq; ++j)
                 quals[(size_t)j] = (uint8_t)(r.uni() < p.frac_lowq ? 2 + r.below(11) : 30 + r.below(11));
             uint32_t flag = r.uni() < 0.5 ? BAM_FREVERSE : 0;
+            if (job.pair_flags) flag = job.pair_flags;
             uint32_t mapq = 60;
             double f = r.uni();
             if (f < p.frac_flagged) flag |= BAM_FDUP;
@@ -168,7 +187,7 @@ void synth_sample_records(const msnv_synth_params &p, int sample, const std::vec
             else if (f < 4.5 * p.frac_flagged) mapq = 0;
             // ---- serialise (SAMv1 4.2)
             char name[32];
-            int l_name = snprintf(name, sizeof name, "s%dr%llu", sample, (unsigned long long)serial++) + 1;
+            int l_name = snprintf(name, sizeof name, "s%dr%llu", sample, (unsigned long long)job.name) + 1;
             uint32_t bs = 32 + (uint32_t)l_name + 4u * (uint32_t)cigar.size() + (uint32_t)(l_seq + 1) / 2 + (uint32_t)l_seq;
             put32(out, bs);
             put32(out, (uint32_t)k); put32(out, (uint32_t)pos);
@@ -176,7 +195,7 @@ void synth_sample_records(const msnv_synth_params &p, int sample, const std::vec
             put16(out, (uint32_t)reg2bin(pos, rp > pos ? rp : pos + 1));
             put16(out, (uint32_t)cigar.size()); put16(out, flag);
             put32(out, (uint32_t)l_seq);
-            put32(out, 0xffffffffu); put32(out, 0xffffffffu); put32(out, 0);
+            put32(out, job.pair_flags ? (uint32_t)k : 0xffffffffu); put32(out, (uint32_t)job.mpos); put32(out, (uint32_t)job.tlen);
             out.insert(out.end(), name, name + l_name);
             for (uint32_t c : cigar) put32(out, c);
             for (int j = 0; j < l_seq; j += 2) out.push_back((uint8_t)(codes[(size_t)j] << 4 | (j + 1 < l_seq ? codes[(size_t)j + 1] : 0)));
@@ -200,6 +219,7 @@ extern "C" void msnv_synth_params_default(msnv_synth_params *p) {
     p->mean_cov = 10.0; p->sigma_cov = 0.5; p->frac_absent = 0.10; p->snv_density = 0.007;
     p->error_rate = 0.001; p->frac_lowq = 0.10; p->frac_indel_reads = 0.035; p->frac_clip_reads = 0.025;
     p->frac_flagged = 0.01; p->lowercase_ref = 0; p->seed = 1;
+    p->frac_paired = 0.0;
 }
 
 extern "C" int msnv_synth_reference(const msnv_synth_params *p, char ***names, int64_t **lengths, char ***seqs) {

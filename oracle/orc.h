@@ -65,6 +65,7 @@ typedef struct {
     int  count_orphans;  /* -A, default 0: PAIRED && !PROPER_PAIR reads are dropped     */
     int  max_depth;      /* -d, default 8000 per file                                   */
     int  min_mapq;       /* -q, default 0                                               */
+    int  ignore_overlaps;/* -x, default 0: overlapping mates are quality-tweaked        */
     /* optional BED (-l): regions are 0-based half-open; NULL/0 = none                 */
     int             n_bed;
     const int      *bed_tid;

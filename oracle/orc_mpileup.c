@@ -7,9 +7,15 @@
  * from this image, and the reference pins no version; this file restates the published
  * algorithm of samtools/htslib >= 1.10 (bam_plcmd.c: mplp_func, mpileup text loop,
  * pileup_seq; htslib sam.c: bam_plp_push, bam_plp_next, resolve_cigar2, bam_endpos) as
- * summarised in SURVEY.md Appendix C.  The overlapping-mate quality tweak
- * (bam_mplp_init_overlaps) is NOT restated: it is version dependent
- * and the parity fixtures use reads it does not touch (single-end / non-overlapping).
+ * summarised in SURVEY.md Appendix C, including the overlapping-mate quality tweak that
+ * mpileup applies unless -x is given (bam_mplp_init_overlaps; sam.c overlap_push,
+ * tweak_overlap_quality, cigar_iref2iseq_set / _next) -- metaSNV.py:160-165 passes no -x.
+ * The tweak is restated LITERALLY here (cursor functions and loop as in sam.c); the product
+ * (metasnv_amd/csrc/pack.cpp) uses an independent closed form of the same loop.
+ * Not modelled: htslib applies the tweak when the SECOND mate is pushed, which (one read of look-ahead) can be before or
+ * after a deletion element of the first mate was printed; such an element prints the quality of the base behind the
+ * deletion, so its quality character -- and whether -Q keeps the '*' -- may differ from samtools' text.  snpCall ignores
+ * '*' (call_vC.cpp:517-521), so no count depends on it.
  */
 #include "orc.h"
 
@@ -54,6 +60,8 @@ typedef struct {
     uint16_t flag, n_cigar;
     uint8_t mapq;
     const uint8_t *cigar, *seq, *qual;
+    const char *qname; int32_t mtid, mpos, isize;
+    int in_olap;            /* this read is the value of its qname's entry in the overlap hash */
     int64_t end;            /* bam_endpos */
     /* resolve_cigar2 cursor */
     int k; int64_t x; int32_t y;
@@ -71,6 +79,8 @@ static int parse_record(const uint8_t *p, uint64_t avail, read_t *r, uint64_t *c
     l_name = p[12]; r->mapq = p[13];
     r->n_cigar = rd_u16(p + 16); r->flag = rd_u16(p + 18);
     r->l_seq = rd_i32(p + 20);
+    r->mtid = rd_i32(p + 24); r->mpos = rd_i32(p + 28); r->isize = rd_i32(p + 32);
+    r->qname = (const char *)(p + 36); r->in_olap = 0;
     r->cigar = p + 36 + l_name;
     r->seq = r->cigar + 4 * (size_t)r->n_cigar;
     r->qual = r->seq + ((size_t)r->l_seq + 1) / 2;
@@ -96,11 +106,117 @@ static int has_ref_op(const read_t *r) {
 /* ------------------------------------------------------------ per-sample iterator */
 typedef struct {
     const orc_sample *s;
+    const uint8_t *rec;      /* the sample's records: a private mutable copy when the overlap tweak is on */
+    uint8_t *copy;
     uint64_t off;
     read_t   peek; int has_peek;
     read_t  *act; int n_act, cap_act;
     int      first_push_done;
 } iter_t;
+
+/* ------------------------------------------------------------ overlapping mates (sam.c) */
+/* cigar_iref2iseq_set: find the first CMATCH at or after *iref, set the cursor.  Returns 0 (BAM_CMATCH), -1 no more / not covered. */
+static int iref2iseq_set(const read_t *r, int *kc, int64_t *icig, int64_t *iseq, int64_t *iref) {
+    int64_t pos = *iref;
+    if (pos < 0) return -1;
+    *icig = 0; *iseq = 0; *iref = 0; *kc = 0;
+    while (*kc < r->n_cigar) {
+        uint32_t c = cig(r, *kc); int op = c & 15; int64_t n = c >> 4;
+        if (op == CS) { (*kc)++; *iseq += n; *icig = 0; continue; }
+        if (op == CH || op == CP) { (*kc)++; *icig = 0; continue; }
+        if (op == CM || op == CEQ || op == CX) {
+            pos -= n;
+            if (pos < 0) { *icig = n + pos; *iseq += *icig; *iref += *icig; return 0; }
+            (*kc)++; *iseq += n; *icig = 0; *iref += n;
+            continue;
+        }
+        if (op == CI) { (*kc)++; *iseq += n; *icig = 0; continue; }
+        if (op == CD || op == CN) {
+            pos -= n;
+            if (pos < 0) pos = 0;
+            (*kc)++; *icig = 0; *iref += n;
+            continue;
+        }
+        return -2;
+    }
+    *iseq = -1;
+    return -1;
+}
+/* cigar_iref2iseq_next: the next CMATCH base */
+static int iref2iseq_next(const read_t *r, int *kc, int64_t *icig, int64_t *iseq, int64_t *iref) {
+    while (*kc < r->n_cigar) {
+        uint32_t c = cig(r, *kc); int op = c & 15; int64_t n = c >> 4;
+        if (op == CM || op == CEQ || op == CX) {
+            if (*icig >= n - 1) { *icig = -1; (*kc)++; continue; }
+            (*iseq)++; (*icig)++; (*iref)++;
+            return 0;
+        }
+        if (op == CD || op == CN) { (*kc)++; *iref += n; *icig = -1; continue; }
+        if (op == CI) { (*kc)++; *iseq += n; *icig = -1; continue; }
+        if (op == CS) { (*kc)++; *iseq += n; *icig = -1; continue; }
+        if (op == CH || op == CP) { (*kc)++; *icig = -1; continue; }
+        return -2;
+    }
+    *iseq = -1; *iref = -1;
+    return -1;
+}
+static int seqi_raw(const read_t *r, int64_t i) { return (r->seq[i >> 1] >> ((~i & 1) << 2)) & 0xf; }
+
+/* tweak_overlap_quality(a, b): a = the mate that was pushed first, b = the one being pushed */
+static void tweak_overlap_quality(read_t *a, read_t *b) {
+    uint8_t *a_qual = (uint8_t *)a->qual, *b_qual = (uint8_t *)b->qual;
+    int a_k, b_k; int64_t a_icig, a_iseq, b_icig, b_iseq;
+    int64_t iref = b->pos, a_iref = iref - a->pos, b_iref = iref - b->pos;
+    int a_ret = iref2iseq_set(a, &a_k, &a_icig, &a_iseq, &a_iref);
+    int b_ret;
+    if (a_ret < 0) return;
+    b_ret = iref2iseq_set(b, &b_k, &b_icig, &b_iseq, &b_iref);
+    if (b_ret < 0) return;
+    for (;;) {
+        while (a_ret >= 0 && a_iref >= 0 && a_iref < iref - a->pos) a_ret = iref2iseq_next(a, &a_k, &a_icig, &a_iseq, &a_iref);
+        if (a_ret < 0) break;
+        if (iref < a_iref + a->pos) iref = a_iref + a->pos;
+        while (b_ret >= 0 && b_iref >= 0 && b_iref < iref - b->pos) b_ret = iref2iseq_next(b, &b_k, &b_icig, &b_iseq, &b_iref);
+        if (b_ret < 0) break;
+        if (iref < b_iref + b->pos) iref = b_iref + b->pos;
+        iref++;
+        if (a_iref + a->pos != b_iref + b->pos) continue;      /* only CMATCH positions */
+        if (a_iseq > a->l_seq || b_iseq > b->l_seq) return;
+        if (a_iseq >= a->l_seq || b_iseq >= b->l_seq) return;  /* (SEQ '*': nothing to tweak) */
+        if (seqi_raw(a, a_iseq) == seqi_raw(b, b_iseq)) {
+            int qual = a_qual[a_iseq] + b_qual[b_iseq];        /* very confident about this base */
+            a_qual[a_iseq] = (uint8_t)(qual > 200 ? 200 : qual);
+            b_qual[b_iseq] = 0;
+        } else if (a_qual[a_iseq] >= b_qual[b_iseq]) {
+            a_qual[a_iseq] = (uint8_t)(0.8 * a_qual[a_iseq]);  /* not so confident about a_qual anymore given the mismatch */
+            b_qual[b_iseq] = 0;
+        } else {
+            b_qual[b_iseq] = (uint8_t)(0.8 * b_qual[b_iseq]);
+            a_qual[a_iseq] = 0;
+        }
+    }
+}
+
+/* overlap_push: called for the node bam_plp_push has just accepted (t->act[t->n_act - 1]).
+ * The hash (qname -> node) is modelled as holding a read while it is alive in this restatement's pileup buffer, i.e.
+ * while end > start of the read being pushed; htslib drops the entry a few pushes later (when the position behind the
+ * read's end has been emitted), which can only matter for templates with three or more alignments in the file. */
+static void overlap_push(iter_t *t) {
+    read_t *node = &t->act[t->n_act - 1];
+    int a;
+    if ((node->flag & 8 /* MUNMAP */) || !(node->flag & BAM_FPROPER_PAIR)) return;
+    if ((node->mtid >= 0 && node->tid != node->mtid) ||
+        (llabs((long long)node->isize) >= 2 * (long long)node->l_seq && node->mpos >= node->end)) return;   /* no overlap possible */
+    for (a = 0; a < t->n_act - 1; ++a) {
+        read_t *x = &t->act[a];
+        if (x->in_olap && strcmp(x->qname, node->qname) == 0) {
+            tweak_overlap_quality(x, node);
+            x->in_olap = 0;
+            return;
+        }
+    }
+    if (node->mpos >= node->pos || ((node->flag & BAM_FPAIRED) && node->mpos == -1)) node->in_olap = 1;   /* only reads whose mate is still to arrive */
+}
 
 static int bed_overlap(const orc_mpileup_opts *o, int tid, int64_t beg, int64_t end) {
     int i;
@@ -114,7 +230,7 @@ static int fetch(iter_t *it, const orc_ref *ref, const orc_mpileup_opts *o) {
     it->has_peek = 0;
     while (it->off < it->s->n_bytes) {
         read_t r; uint64_t used;
-        if (parse_record(it->s->records + it->off, it->s->n_bytes - it->off, &r, &used)) { orc_set_error("corrupt BAM record"); return ORC_ERR_FORMAT; }
+        if (parse_record(it->rec + it->off, it->s->n_bytes - it->off, &r, &used)) { orc_set_error("corrupt BAM record"); return ORC_ERR_FORMAT; }
         it->off += used;
         if (r.tid < 0 || (r.flag & BAM_FUNMAP)) continue;
         if (o->flag_filter & r.flag) continue;
@@ -226,6 +342,7 @@ static void pileup_seq(lbuf *b, const read_t *r, const elem_t *p, int64_t pos, c
 void orc_mpileup_default_opts(orc_mpileup_opts *o) {
     memset(o, 0, sizeof *o);
     o->min_baseq = 13; o->flag_filter = 0x704; o->count_orphans = 0; o->max_depth = 8000; o->min_mapq = 0;
+    o->ignore_overlaps = 0;      /* mpileup -x is not passed (metaSNV.py:160-165) */
 }
 
 /* statistics of the last orc_mpileup call (test/bench bookkeeping, not reference behaviour) */
@@ -241,7 +358,16 @@ int orc_mpileup(const orc_ref *ref, const orc_sample *samples, int n_samples,
     int cur_tid = -1; int64_t cur_pos = -1;
     g_n_lines = g_n_bases = 0;
     if (!it) return ORC_ERR_NOMEM;
-    for (i = 0; i < n_samples; ++i) { it[i].s = &samples[i]; if ((rc = fetch(&it[i], ref, opts))) goto done; }
+    for (i = 0; i < n_samples; ++i) {
+        it[i].s = &samples[i]; it[i].rec = samples[i].records;
+        if (!opts->ignore_overlaps && samples[i].n_bytes) {           /* the tweak edits qualities: work on a copy (bam_copy1 in bam_plp_push) */
+            it[i].copy = (uint8_t *)malloc(samples[i].n_bytes);
+            if (!it[i].copy) { rc = ORC_ERR_NOMEM; goto done; }
+            memcpy(it[i].copy, samples[i].records, samples[i].n_bytes);
+            it[i].rec = it[i].copy;
+        }
+        if ((rc = fetch(&it[i], ref, opts))) goto done;
+    }
 
     for (;;) {
         /* next position = bam_mplp_auto: the smallest (tid,pos) any iterator reports */
@@ -287,6 +413,9 @@ int orc_mpileup(const orc_ref *ref, const orc_sample *samples, int n_samples,
                     if (!capped) {
                         if (t->n_act == t->cap_act) { t->cap_act = t->cap_act ? t->cap_act * 2 : 64; t->act = (read_t *)realloc(t->act, (size_t)t->cap_act * sizeof(read_t)); }
                         t->act[t->n_act++] = t->peek;
+                        if (!opts->ignore_overlaps) overlap_push(t);
+                    } else if (!opts->ignore_overlaps) {                 /* overlap_remove(iter, b) of a capped read: its qname leaves the hash */
+                        for (a = 0; a < t->n_act; ++a) if (t->act[a].in_olap && strcmp(t->act[a].qname, t->peek.qname) == 0) t->act[a].in_olap = 0;
                     }
                     t->first_push_done = 1; ++nth;
                     if ((rc = fetch(t, ref, opts))) goto done;
@@ -332,7 +461,7 @@ int orc_mpileup(const orc_ref *ref, const orc_sample *samples, int n_samples,
         }
     }
 done:
-    for (i = 0; i < n_samples; ++i) free(it[i].act);
+    for (i = 0; i < n_samples; ++i) { free(it[i].act); free(it[i].copy); }
     free(it); free(line.p); free(quals.p);
     return rc;
 }

@@ -25,10 +25,10 @@ def sweep(n_cases, seed, verbose=True):
         kw = dict(n_species=n_species, contig_len=contig_len, n_samples=n_samples, mean_cov=mean_cov, read_len=min(read_len, contig_len),
                   sigma_cov=rnd.choice([0.1, 0.5, 1.0]), frac_absent=rnd.choice([0.0, 0.1, 0.5]), snv_density=rnd.choice([0.0, 0.007, 0.05]),
                   error_rate=rnd.choice([0.0, 0.001, 0.02]), frac_lowq=rnd.choice([0.0, 0.1, 0.5]), frac_indel_reads=rnd.choice([0.0, 0.04, 0.3]),
-                  frac_clip_reads=rnd.choice([0.0, 0.03, 0.3]), frac_flagged=rnd.choice([0.0, 0.03]), lowercase_ref=rnd.choice([0, 1]), seed=rnd.randrange(1 << 30))
+                  frac_clip_reads=rnd.choice([0.0, 0.03, 0.3]), frac_flagged=rnd.choice([0.0, 0.03]), lowercase_ref=rnd.choice([0, 1]), frac_paired=rnd.choice([0.0, 0.0, 0.5, 1.0]), seed=rnd.randrange(1 << 30))
         pk = dict(min_coverage=rnd.choice([1, 4, 4, 10]), calling_threshold=rnd.choice([1, 2, 4, 4]), min_fraction=rnd.choice([0.01, 0.01, 0.2, 0.0]),
                   min_baseq=rnd.choice([0, 13, 13, 30]), max_depth=rnd.choice([8000, 8000, 8000, 60, 7]), min_mapq=rnd.choice([0, 0, 1, 30]),
-                  count_orphans=rnd.choice([0, 1]), flag_filter=rnd.choice([0x704, 0x704, 0x400, 0]))
+                  count_orphans=rnd.choice([0, 1]), flag_filter=rnd.choice([0x704, 0x704, 0x400, 0]), ignore_overlaps=rnd.choice([0, 0, 0, 1]))
         os.environ["MSNV_LAYOUT"] = rnd.choice(["pieces", "dense"])
         deep_mode = os.environ.get("MSNV_DEEP", "split")
         sp = core.synth_params(**kw)

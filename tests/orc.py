@@ -21,7 +21,7 @@ class OrcSample(C.Structure):
 
 class MpOpts(C.Structure):
     _fields_ = [("min_baseq", C.c_int), ("flag_filter", C.c_int), ("count_orphans", C.c_int), ("max_depth", C.c_int),
-                ("min_mapq", C.c_int), ("n_bed", C.c_int), ("bed_tid", C.POINTER(C.c_int)),
+                ("min_mapq", C.c_int), ("ignore_overlaps", C.c_int), ("n_bed", C.c_int), ("bed_tid", C.POINTER(C.c_int)),
                 ("bed_beg", C.POINTER(C.c_int64)), ("bed_end", C.POINTER(C.c_int64))]
 
 

@@ -30,7 +30,8 @@ def run_product(names, lengths, seqs, samples, bed=None, params=None, ann=None, 
 
 def run_oracle(names, lengths, seqs, samples, bed=None, params=None, ann=None, fasta=None):
     p = params or core.default_params()
-    mp = dict(min_baseq=p.min_baseq, flag_filter=p.flag_filter, count_orphans=p.count_orphans, max_depth=p.max_depth, min_mapq=p.min_mapq)
+    mp = dict(min_baseq=p.min_baseq, flag_filter=p.flag_filter, count_orphans=p.count_orphans, max_depth=p.max_depth, min_mapq=p.min_mapq,
+              ignore_overlaps=p.ignore_overlaps)
     sc = dict(min_coverage=p.min_coverage, calling_threshold=p.calling_threshold, calling_min_fraction=p.min_fraction)
     pop, ind, nl, nb = orc.call(names, lengths, seqs, samples, bed=bed, fasta=fasta if ann else None, genes=ann, mp=mp, sc=sc)
     if not p.drop_first_line:

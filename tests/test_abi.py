@@ -19,12 +19,12 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert declared == bound, (declared - bound, bound - declared)
     for name in declared:
         assert hasattr(_lib.lib, name)
-    assert _lib.lib.msnv_abi_version() == 1
+    assert _lib.lib.msnv_abi_version() == 2
 
 
 def test_struct_layouts_match_the_header():
     assert C.sizeof(_lib.Site) == 32 and C.sizeof(_lib.SiteSample) == 10
-    assert C.sizeof(_lib.Params) == 48
+    assert C.sizeof(_lib.Params) == 56
     p = core.default_params()
     assert (p.min_coverage, p.calling_threshold, p.min_fraction, p.min_baseq, p.flag_filter) == (4, 4, 0.01, 13, 0x704)
     assert (p.max_depth, p.drop_first_line, p.cov_max, p.cov_min_mapq) == (8000, 1, 10, 1)
@@ -75,3 +75,13 @@ def test_drop_in_executables_exist_and_print_usage():
     for exe in ("msnv_qacompute", "msnv_snpcall"):
         r = subprocess.run([os.path.join(tools, exe)], capture_output=True, text=True)
         assert r.returncode == 1 and "Usage" in r.stderr       # qaCompute.cpp:356-359: wrong argument count -> usage, exit 1
+
+
+def test_parameters_are_validated_when_a_dataset_is_created():
+    """Per-sample counts are 16-bit on the device: a depth cap outside [1, 65535] is refused, and so are histogram cutoffs the
+    device does not hold and negative thresholds (host-only dataset: no GPU needed to be told so)."""
+    for bad in (dict(max_depth=0), dict(max_depth=70000), dict(cov_max=16), dict(cov_max=0), dict(min_coverage=-1), dict(min_fraction=-0.5)):
+        with pytest.raises(_lib.MsnvError) as e:
+            core.Dataset(None, ["c"], [10], None, core.default_params(**bad))
+        assert e.value.code == _lib.EINVAL, bad
+    core.Dataset(None, ["c"], [10], None, core.default_params(max_depth=65535, cov_max=15)).close()

@@ -176,6 +176,41 @@ def test_short_reads_use_the_dense_block_layout(read_len):
     assert prod[2]["bytes_headers"] * 8 < prod[2]["n_pileup_bases"] * 2     # 4 B per 32-base block, not 8 B per short piece
 
 
+@pytest.mark.parametrize("layout", ["pieces", "dense"])
+def test_proper_pairs_with_overlapping_mates(layout, monkeypatch):
+    """Paired-end input, most mates overlapping on the reference: mpileup (no -x, metaSNV.py:160-165) counts a template once
+    per position (sam.c tweak_overlap_quality).  The host stage edits the qualities before packing; called_SNPs and
+    indiv_called equal the oracle's with the tweak on (default) and with -x, and the two differ."""
+    monkeypatch.setenv("MSNV_LAYOUT", layout)
+    syn, samples = synth_case(n_species=2, contig_len=9000, n_samples=6, mean_cov=16.0, snv_density=0.03, frac_paired=0.8,
+                              read_len=100 if layout == "pieces" else 50, seed=77)
+    texts = []
+    for x in (0, 1):
+        p = core.default_params(ignore_overlaps=x)
+        prod = run_product(syn.names, syn.lengths, syn.seqs, samples, params=p)
+        orac = run_oracle(syn.names, syn.lengths, syn.seqs, samples, params=p)
+        _assert_same(prod, orac)
+        assert prod[2]["n_pileup_bases"] == orac[3]
+        texts.append(prod[0])
+    assert texts[0] != texts[1] and texts[0].count("\n") > 100
+
+
+def test_token_limit_of_snpcall_cuts_a_deep_stack_like_the_reference():
+    """call_vC.cpp:481-483: a sample's base string is cut at 10000 characters.  A stack of ~5600 reads starting at one position
+    (3 characters per read start) passes the limit; the host stage takes the bases behind the cut out of the pileup and the
+    device counts (deep pair, split into byte-bin groups) equal the oracle's, which builds and cuts the text like snpCall."""
+    from test_overlap_host import _stack
+    ref, s = _stack(11)
+    other = bt.records(bt.make_record(0, 90, "60M", ref[90:150], name="o1"), bt.make_record(0, 95, "60M", ref[95:155], name="o2"))
+    p = core.default_params(min_coverage=1, calling_threshold=2)
+    prod = run_product(["c1"], [len(ref)], [ref], [other, s], params=p)
+    orac = run_oracle(["c1"], [len(ref)], [ref], [other, s], params=p)
+    _assert_same(prod, orac)
+    assert prod[0].count("\n") > 30
+    p0 = core.default_params(min_coverage=1, calling_threshold=2, token_limit=0)         # every base counted: not what snpCall does
+    assert run_product(["c1"], [len(ref)], [ref], [other, s], params=p0)[0] != prod[0]
+
+
 def _random_flagged_samples(seed, L=3000, n_reads=700, n_samples=3):
     import random
     rnd = random.Random(seed)

@@ -66,3 +66,54 @@ def test_lowercase_and_N_reference_and_read_N():
     bases = [c[4] for c in cols]
     # read N vs ref g -> 'N' (ignored by snpCall); read N vs ref N -> match; read A vs ref N -> 'A'
     assert bases[0] == "^]." and bases[2] == "N" and bases[3] == "." and bases[4] == "A" and bases[7] == ".$"
+
+
+# ---------------------------------------------------------------------------------- overlapping mates
+# mpileup without -x (metaSNV.py:160-165): htslib edits the qualities of proper-pair mates where both have an aligned base
+# (sam.c tweak_overlap_quality).  Hand-derived: agreeing bases -> min(200, qa + qb) on the mate pushed first, 0 on the
+# other; disagreeing -> 0.8 q (truncated) on the higher-quality one (tie: the first), 0 on the other; -Q 13 then drops
+# the zeroed element together with its ^ / $ markers.
+def _pair(a_seq, a_q, b_seq, b_q, a_pos=2, b_pos=4, a_cig="6M", b_cig="6M", tlen=8, a_flag=99, b_flag=147, b_name="p"):
+    return bt.records(bt.make_record(0, a_pos, a_cig, a_seq, qual=a_q, flag=a_flag, name="p", mtid=0, mpos=b_pos, tlen=tlen),
+                      bt.make_record(0, b_pos, b_cig, b_seq, qual=b_q, flag=b_flag, name=b_name, mtid=0, mpos=a_pos, tlen=-tlen))
+
+
+def _lines(sample, **mp):
+    return orc.mpileup_text(["c1"], [20], [REF], [sample], mp=mp or None).split("\n")[:-1]
+
+
+def test_overlapping_mates_agreeing_bases_count_once_with_summed_quality():
+    s = _pair("GTACGT", [30] * 6, "ACGTAC", [20] * 6)
+    assert _lines(s) == ["c1\t3\tG\t1\t^].\t?", "c1\t4\tT\t1\t.\t?",
+                         "c1\t5\tA\t1\t.\tS", "c1\t6\tC\t1\t.\tS", "c1\t7\tG\t1\t.\tS", "c1\t8\tT\t1\t.$\tS",      # 30 + 20 = 50 -> 'S'; the mate's ^] went with it
+                         "c1\t9\tA\t1\t,\t5", "c1\t10\tC\t1\t,$\t5"]
+    # -x switches the tweak off: both mates are printed
+    assert _lines(s, ignore_overlaps=1)[2:6] == ["c1\t5\tA\t2\t.^],\t?5", "c1\t6\tC\t2\t.,\t?5", "c1\t7\tG\t2\t.,\t?5", "c1\t8\tT\t2\t.$,\t?5"]
+
+
+def test_overlapping_mates_disagreeing_bases_keep_the_better_one_at_80_percent():
+    # reference position 6 (C): first mate reads A (q30), second mate C (q35) -> second keeps int(0.8 * 35) = 28 -> '='
+    assert _lines(_pair("GTAAGT", [30] * 6, "ACGTAC", [35] * 6))[3] == "c1\t6\tC\t1\t,\t="
+    # tie: the mate pushed first keeps int(0.8 * 30) = 24 -> '9'
+    assert _lines(_pair("GTAAGT", [30] * 6, "ACGTAC", [30] * 6))[3] == "c1\t6\tC\t1\tA\t9"
+    # 0.8 * 15 = 12 < 13: a disagreeing pair of two q15 bases disappears altogether
+    assert _lines(_pair("GTAAGT", [15] * 6, "ACGTAC", [15] * 6))[3] == "c1\t6\tC\t0\t*\t*"
+
+
+def test_overlapping_mates_quality_cap_and_unpaired_reads():
+    assert _lines(_pair("GTACGT", [120] * 6, "ACGTAC", [110] * 6))[2] == "c1\t5\tA\t1\t.\t~"          # min(200, 230) prints as '~'
+    both = ["c1\t5\tA\t2\t.^],\t?5"]
+    assert _lines(_pair("GTACGT", [30] * 6, "ACGTAC", [20] * 6, b_name="other"))[2:3] == both        # different templates
+    assert _lines(_pair("GTACGT", [30] * 6, "ACGTAC", [20] * 6, a_flag=0, b_flag=16))[2:3] == both   # not flagged as a proper pair
+    assert _lines(_pair("GTACGT", [30] * 6, "ACGTAC", [20] * 6, a_flag=99 | 8))[2:3] == both          # first mate says "mate unmapped": it never waits
+
+
+def test_overlapping_mates_first_base_behind_a_gap_of_the_second_mate_is_left_alone():
+    # first mate 10M at 1..10; second mate 2M2D4M from 3: htslib's shared cursor skips the second mate's first base behind
+    # its deletion (position 7), so both mates are counted there; a gap in the FIRST mate has no such effect
+    a = _pair("ACGTACGTAC", [30] * 10, "GTGTAC", [20] * 6, a_pos=0, b_pos=2, a_cig="10M", b_cig="2M2D4M", tlen=10)
+    got = _lines(a)
+    assert got[2:4] == ["c1\t3\tG\t1\t.\tS", "c1\t4\tT\t1\t.\tS"]
+    assert got[6] == "c1\t7\tG\t2\t.,\t?5" and got[7:] == ["c1\t8\tT\t1\t.\tS", "c1\t9\tA\t1\t.\tS", "c1\t10\tC\t1\t.$\tS"]
+    b = _pair("ACGTGTAC", [30] * 8, "GTACGTAC", [20] * 8, a_pos=0, b_pos=2, a_cig="4M2D4M", b_cig="8M", tlen=10)
+    assert _lines(b)[6] == "c1\t7\tG\t1\t.\tS"
