@@ -70,6 +70,7 @@ struct SampleCols {
     uint64_t alg_8d_bytes = 0, alg_cigar_bytes = 0;   // SURVEY.md section 8d accounting (per pileup read)
     int32_t  first_tid = -1, first_beg = 0, first_end = 0;   // first pileup_ok read (first-line quirk)
     std::vector<int32_t> first_any, first_from1;             // per contig (empty = no pileup read): first pileup line without -l / with `name 1 LEN`
+    bool     warned_beyond_end = false;   // qaCompute cursor beyond a contig end: reported once per sample
     msnv_sample_stats st{};          // qaCompute "Other" statistics (qaCompute.cpp:642-654), counted over every record of the BAM
 };
 

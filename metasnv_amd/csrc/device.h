@@ -70,8 +70,12 @@ struct DeviceCols {
     uint8_t  *spill = nullptr;       // [n_pairs][TILE] per-sample coverage, saturating at 255
     Pair32   *events = nullptr;      // {gpos, sample<<18 | allele<<16 | count}
     Pair32   *overflow = nullptr;    // {gpos, sample<<16 | cov}
-    uint32_t *counters = nullptr;    // [0] events [1] overflow [2] sites [3] error flags
-    uint32_t *ind_bits = nullptr;    // 1 bit per position: candidate of the individual rule (gate kernel)
+    uint32_t *counters = nullptr;    // two blocks of CNT_WORDS ([0] events [1] overflow [2] sites [4] pop lines [5] indiv lines, then the event
+                                     // sub-list counters): consecutive passes alternate, the gate kernel of a pass zeroes the other block
+    uint32_t  cnt_parity = 0;        // block the NEXT pass uses
+    uint32_t *ind4 = nullptr;        // 4 bits per position: some sample holds >= calling_threshold reads of mismatching A / C / G / T
+    uint32_t *unc_bits = nullptr;    // 1 bit per position: a sample split into several pairs holds a mismatching allele (follows ind4 in its allocation)
+    bool      any_split = false;     // some (sample, tile) run was dealt into several pairs: the calling rule then needs the summed per-sample records
     unsigned long long *site_bits = nullptr;   // 1 bit per position: is a site (written by the gate kernel for every tile)
     uint32_t *site_rank = nullptr;   // per 64 positions: index of their first site (tiles with sites only)
     uint32_t  cap_events = 0, cap_overflow = 0, cap_sites = 0;
@@ -101,8 +105,8 @@ struct DeviceCols {
     struct AltBufs {
         uint32_t *tot = nullptr; uint8_t *part = nullptr; uint8_t *spill = nullptr; Pair32 *events = nullptr, *overflow = nullptr;
         uint32_t *counters = nullptr; SiteRec *sites = nullptr; uint32_t *tile_site_base = nullptr, *tile_site_cnt = nullptr;
-        msnv_site_sample *out = nullptr; uint16_t *cov_col = nullptr; uint8_t *site_flags = nullptr; uint32_t *ind_bits = nullptr; unsigned long long *site_bits = nullptr; uint32_t *site_rank = nullptr;
-        uint32_t cap_events = 0, cap_overflow = 0, cap_sites = 0; uint64_t cap_out_sites = 0;
+        msnv_site_sample *out = nullptr; uint16_t *cov_col = nullptr; uint8_t *site_flags = nullptr; uint32_t *ind4 = nullptr, *unc_bits = nullptr; unsigned long long *site_bits = nullptr; uint32_t *site_rank = nullptr;
+        uint32_t cap_events = 0, cap_overflow = 0, cap_sites = 0, cnt_parity = 0; uint64_t cap_out_sites = 0;
     } alt;
     void     *stream2 = nullptr;
     std::vector<void *> event_pool;          // hipEvent_t of msnv_pileup_run_many

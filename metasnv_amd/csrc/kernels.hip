@@ -50,7 +50,8 @@ struct PileupArgs {
     uint32_t       *counters;
     uint32_t       *ev_count;     // set by ev_list() inside the kernel
     uint32_t        min_baseq;
-    uint32_t       *ind_bits;     // 1 bit per position: some sample holds >= min_snvs reads of one mismatching allele
+    uint32_t       *ind4;         // 4 bits per position (A, C, G, T): some sample holds >= min_snvs reads of that mismatching allele
+    uint32_t       *unc_bits;     // 1 bit per position: a sample that was split into several pairs holds the allele (it may reach the threshold only in sum)
     uint32_t        min_snvs;
 };
 
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(W_NT) void msnv_pileup_tiles_wide(PileupArgs a) {
                     for (int x = 0; x < 4; ++x)
                         if (nn[x]) {
                             tn[j][x] += nn[x];
-                            if (nn[x] >= a.min_snvs) atomicOr(&a.ind_bits[gpos >> 5], 1u << (gpos & 31u));
+                            if (nn[x] >= a.min_snvs) atomicOr(&a.ind4[gpos >> 3], 1u << (4u * (gpos & 7u) + (uint32_t)x));
                             stage_allele_event<WideLds, W_EVCAP>(L, a, Pair32{gpos, sample << 18 | (uint32_t)x << 16 | nn[x]});
                         }
                 }
@@ -404,8 +405,10 @@ __device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_
             const uint32_t n = (word >> (8u * x)) & 0xffu;
             if (n) {
                 atomicAdd(&a.tot[(uint64_t)x * a.npos + gpos], n);
-                // candidate of the individual rule; a sample that was split into several pairs may reach the threshold only in sum
-                if (n >= a.min_snvs || split) atomicOr(&a.ind_bits[gpos >> 5], 1u << (gpos & 31u));
+                // the individual rule's "some sample holds >= t reads of x"; a sample that was split into several pairs may reach
+                // the threshold only in sum: those positions are marked and decided from the per-sample records (msnv_decide_sites)
+                if (n >= a.min_snvs) atomicOr(&a.ind4[gpos >> 3], 1u << (4u * (gpos & 7u) + x));
+                else if (split) atomicOr(&a.unc_bits[gpos >> 5], 1u << (gpos & 31u));
                 const Pair32 e{gpos, sample << 18 | x << 16 | n};
                 if (direct) { if (slot < a.cap_events) a.events[slot] = e; }
                 else L.ev[slot] = e;
@@ -764,13 +767,30 @@ constexpr int GATE_NT = 256;
 constexpr int GATE_PPT = TILE / GATE_NT;       // 8 consecutive positions per thread: one 8 / 16 / 32-byte load per row and thread
 static_assert(GATE_PPT == 8, "the gate kernel is written for 8 positions per thread (one site_bits word per 8 lanes)");
 
-__global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(uint32_t *tot, const uint8_t *part, const uint64_t *slot_off, const uint32_t *tile_slot_start,
-                                                           const uint32_t *tile_slot_u16, const uint32_t *tile_slot_wide, uint64_t npos,
-                                                           const uint32_t *tile_vbeg, const uint32_t *tile_vend,
-                                                           int min_cov, int min_snvs, double min_frac, const uint32_t *ind_bits,
-                                                           unsigned long long *site_bits, uint32_t *site_rank, SiteRec *sites, uint32_t cap_sites, uint32_t *counters,
-                                                           uint32_t *tile_site_base, uint32_t *tile_site_cnt, const uint32_t *active_tiles,
-                                                           msnv_site_sample *out, uint16_t *cov_col, uint32_t n_samples, uint32_t cap_out) {
+struct GateArgs {
+    uint32_t *tot; const uint8_t *part; const uint64_t *slot_off; const uint32_t *tile_slot_start, *tile_slot_u16, *tile_slot_wide; uint64_t npos;
+    const uint32_t *tile_vbeg, *tile_vend; int min_cov, min_snvs; double min_frac;
+    uint32_t *ind4, *unc_bits;                 // read and left zero for the next pass
+    const uint32_t *ref4, *ref_lc;
+    unsigned long long *site_bits; uint32_t *site_rank; SiteRec *sites; uint32_t cap_sites; uint32_t *counters, *counters_next;
+    uint32_t *tile_site_base, *tile_site_cnt; const uint32_t *active_tiles;
+    msnv_site_sample *out; uint16_t *cov_col; uint8_t *site_flags; uint32_t n_samples, cap_out;
+    uint32_t decide_here;                      // 1: no sample is split into several pairs, so the calling rule is applied right here
+};
+
+__global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
+    uint32_t *const tot = a.tot; const uint8_t *const part = a.part; const uint64_t *const slot_off = a.slot_off;
+    const uint32_t *const tile_slot_start = a.tile_slot_start, *const tile_slot_u16 = a.tile_slot_u16, *const tile_slot_wide = a.tile_slot_wide;
+    const uint64_t npos = a.npos; const uint32_t *const tile_vbeg = a.tile_vbeg, *const tile_vend = a.tile_vend;
+    const int min_cov = a.min_cov, min_snvs = a.min_snvs; const double min_frac = a.min_frac;
+    unsigned long long *const site_bits = a.site_bits; uint32_t *const site_rank = a.site_rank; SiteRec *const sites = a.sites;
+    const uint32_t cap_sites = a.cap_sites; uint32_t *const counters = a.counters; uint32_t *const tile_site_base = a.tile_site_base, *const tile_site_cnt = a.tile_site_cnt;
+    const uint32_t *const active_tiles = a.active_tiles; msnv_site_sample *const out = a.out; uint16_t *const cov_col = a.cov_col;
+    const uint32_t n_samples = a.n_samples, cap_out = a.cap_out;
+    __shared__ uint32_t s_pop, s_ind;
+    if (threadIdx.x == 0) { s_pop = 0; s_ind = 0; }
+    // the counter block of the NEXT pass (the passes of a dataset alternate between two blocks: no memset between passes)
+    if (blockIdx.x == 0) for (uint32_t i = threadIdx.x; i < CNT_WORDS; i += GATE_NT) a.counters_next[i] = 0u;
     __shared__ uint32_t s_wave[GATE_NT / 64];
     __shared__ uint32_t s_base;
     const uint32_t tile = active_tiles[blockIdx.x];           // tiles that hold work items; the others have no coverage
@@ -794,8 +814,20 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(uint32_t *tot, const 
         for (uint32_t r0 = 0; r0 < n8; r0 += 255u) {
             uint32_t h[4] = {0u, 0u, 0u, 0u};
             const uint32_t r1 = min(n8, r0 + 255u);
+            // the kernel is latency-bound (under two workgroups per CU): 16 row loads in flight per thread
+            uint32_t s = r0;
+            for (; s + 16u <= r1; s += 16u) {
+                uint2 v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const uint2 *>(p8 + (uint64_t)(s + (uint32_t)u) * TILE);
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    h[0] += v[u].x & 0x00ff00ffu; h[1] += (v[u].x >> 8) & 0x00ff00ffu;
+                    h[2] += v[u].y & 0x00ff00ffu; h[3] += (v[u].y >> 8) & 0x00ff00ffu;
+                }
+            }
 #pragma unroll 4
-            for (uint32_t s = r0; s < r1; ++s) {
+            for (; s < r1; ++s) {
                 const uint2 v = *reinterpret_cast<const uint2 *>(p8 + (uint64_t)s * TILE);
                 h[0] += v.x & 0x00ff00ffu; h[1] += (v.x >> 8) & 0x00ff00ffu;
                 h[2] += v.y & 0x00ff00ffu; h[3] += (v.y >> 8) & 0x00ff00ffu;
@@ -835,20 +867,38 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(uint32_t *tot, const 
         if (a.x | a.y | a.z | a.w) *reinterpret_cast<uint4 *>(tp) = make_uint4(0u, 0u, 0u, 0u);
         if (b.x | b.y | b.z | b.w) *reinterpret_cast<uint4 *>(tp + 4) = make_uint4(0u, 0u, 0u, 0u);
     }
-    const uint32_t indb = reinterpret_cast<const uint8_t *>(ind_bits)[g0 >> 3];   // individual-candidate bits of my 8 positions
-    uint32_t okm = 0;
+    // individual-rule bits of my 8 positions (4 per position) and the "split sample" marks; consumed here and here only, so they
+    // are left zero for the next pass like the allele totals
+    const uint32_t ind4w = a.ind4[g0 >> 3];
+    if (ind4w) a.ind4[g0 >> 3] = 0u;
+    const uint32_t uncb = reinterpret_cast<const uint8_t *>(a.unc_bits)[g0 >> 3];
+    if (uncb) reinterpret_cast<uint8_t *>(a.unc_bits)[g0 >> 3] = 0;
+    const uint32_t refw = a.ref4[g0 >> 3];                                  // nt16 codes of my 8 positions
+    const uint32_t lcb = reinterpret_cast<const uint8_t *>(a.ref_lc)[g0 >> 3];   // FASTA character is a lower-case a / c / g / t
+    uint32_t okm = 0, flw[2] = {0u, 0u};                                    // site mask; pop | ind << 4 of my 8 positions, one byte each
 #pragma unroll
     for (int j = 0; j < GATE_PPT; ++j) {
         const uint32_t p = p0 + (uint32_t)j, cov = covs[j];
         // mismatching bases are counted bases: no coverage, no allele totals (a stale total can not exist: they are zeroed above)
         if (cov != 0u && p >= vb && p < ve && (int)cov >= min_cov &&
             (int)(nal[0][j] + nal[1][j] + nal[2][j] + nal[3][j]) >= min_snvs) {                          // call_vC.cpp:547,550
-            const bool ind = (indb >> j) & 1u;
-            const double lim = (double)(int)cov * min_frac;                // same arithmetic as msnv_decide_sites
+            const uint32_t indx = (ind4w >> (4 * j)) & 15u;
+            const bool unc = (uncb >> j) & 1u;
+            const double lim = (double)(int)cov * min_frac;                // call_vC.cpp:588
+            const uint32_t rc = (refw >> (4 * j)) & 15u;
+            const bool lc = (lcb >> j) & 1u;
             bool ok = false;
+            uint32_t pop = 0, ind = 0;
 #pragma unroll
-            for (int x = 0; x < 4; ++x) ok |= (int)nal[x][j] >= min_snvs && (ind || (double)nal[x][j] >= lim);
+            for (int x = 0; x < 4; ++x) {
+                if ((int)nal[x][j] < min_snvs) continue;                   // neither rule can fire (call_vC.cpp:588,593-600)
+                const bool is_pop = (double)nal[x][j] >= lim, is_ind = (indx >> x) & 1u;
+                ok |= is_pop || is_ind || unc;
+                if (lc && rc == (1u << x)) continue;                       // skip-same-base, case-sensitive (call_vC.cpp:580)
+                if (is_pop) pop |= 1u << x; else if (is_ind) ind |= 1u << x;
+            }
             okm |= (ok ? 1u : 0u) << j;
+            flw[j >> 2] |= (pop | ind << 4) << (8 * (j & 3));
         }
     }
     // 1 bit per position: is a site (the scatter half of msnv_gather_scatter filters on it).  One 64-bit word = 8 lanes.
@@ -873,8 +923,19 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(uint32_t *tot, const 
         tile_site_base[tile] = base;
         tile_site_cnt[tile] = total;
     }
+    if (a.decide_here && okm) {                                           // output-line tallies (before the first-line drop)
+        uint32_t np = 0, ni = 0;
+#pragma unroll
+        for (int j = 0; j < GATE_PPT; ++j) { const uint32_t f = (flw[j >> 2] >> (8 * (j & 3))) & 0xffu; np += (f & 15u) ? 1u : 0u; ni += (f >> 4) ? 1u : 0u; }
+        if (np) atomicAdd(&s_pop, np);
+        if (ni) atomicAdd(&s_ind, ni);
+    }
     __syncthreads();
     if (total == 0) return;
+    if (tid == 0 && a.decide_here) {
+        if (s_pop) atomicAdd(&counters[4], s_pop);
+        if (s_ind) atomicAdd(&counters[5], s_ind);
+    }
     const uint32_t base = s_base;
     if ((uint64_t)base + total <= cap_out) {                         // else: the host sees the site count and runs again with a larger buffer
         // the per-sample records of this tile's sites start out zero: gather and scatter (one launch, side by side) only add to them
@@ -895,6 +956,7 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(uint32_t *tot, const 
                 s.gpos = (uint32_t)(g0 + (uint32_t)j); s.cov = covs[j];
                 s.n[0] = nal[0][j]; s.n[1] = nal[1][j]; s.n[2] = nal[2][j]; s.n[3] = nal[3][j];
                 sites[idx] = s;
+                if (a.decide_here && idx < cap_out) a.site_flags[idx] = (uint8_t)((flw[j >> 2] >> (8 * (j & 3))) & 0xffu);
             }
             ++idx;
         }
@@ -916,7 +978,7 @@ constexpr uint32_t SCATTER_BLOCKS_PER_LIST = 32;
 struct TailArgs {
     const SiteRec *sites; const uint32_t *tile_site_base, *tile_site_cnt, *tile_pair_start; const TilePair *pairs; const uint8_t *spill;
     msnv_site_sample *out; uint16_t *cov_col; uint32_t n_samples, cap_out; const uint32_t *active_tiles; uint32_t n_gather_blocks;
-    const Pair32 *events, *overflow; const uint32_t *counters; uint32_t cap_list, cap_overflow;
+    const Pair32 *events, *overflow; uint32_t *counters; uint32_t cap_list, cap_overflow;
     const unsigned long long *site_bits; const uint32_t *site_rank;
 };
 
@@ -952,7 +1014,26 @@ __device__ __forceinline__ void scatter_events_block(const TailArgs &a, const ui
     };
     const uint32_t n_k = min(a.counters[16u + k * EV_CNT_STRIDE], a.cap_list);
     const Pair32 *list = a.events + (uint64_t)k * a.cap_list;
-    for (uint32_t i = bx * blockDim.x + threadIdx.x; i < n_k; i += SCATTER_BLOCKS_PER_LIST * blockDim.x) apply(list[i], true);
+    {   // four events per trip: their loads, then their site-bitmap loads, are in flight together (the loop is a chain of dependent loads)
+        constexpr uint32_t U = 4;
+        const uint32_t stride = SCATTER_BLOCKS_PER_LIST * blockDim.x;
+        uint32_t i = bx * blockDim.x + threadIdx.x;
+        for (; i + (U - 1u) * stride < n_k; i += U * stride) {
+            Pair32 e[U]; unsigned long long w[U];
+#pragma unroll
+            for (uint32_t u = 0; u < U; ++u) e[u] = list[i + u * stride];
+#pragma unroll
+            for (uint32_t u = 0; u < U; ++u) w[u] = a.site_bits[e[u].x >> 6];
+#pragma unroll
+            for (uint32_t u = 0; u < U; ++u) {
+                const unsigned long long bit = 1ull << (e[u].x & 63u);
+                if (!(w[u] & bit)) continue;
+                const uint32_t s = a.site_rank[e[u].x >> 6] + (uint32_t)__popcll(w[u] & (bit - 1ull));
+                add_u16(&a.out[(uint64_t)s * a.n_samples + (e[u].y >> 18)].n[(e[u].y >> 16) & 3u], e[u].y & 0xffffu);
+            }
+        }
+        for (; i < n_k; i += stride) apply(list[i], true);
+    }
     const uint32_t n_overflow = min(a.counters[1], a.cap_overflow);
     for (uint32_t i = (k * SCATTER_BLOCKS_PER_LIST + bx) * blockDim.x + threadIdx.x; i < n_overflow; i += SCATTER_BLOCKS_PER_LIST * EV_LISTS * blockDim.x)
         apply(a.overflow[i], false);
@@ -964,6 +1045,14 @@ __device__ __forceinline__ void scatter_events_block(const TailArgs &a, const ui
 //   >= 255 coverages of the wide kernel from the overflow list.
 __global__ __launch_bounds__(256) void msnv_gather_scatter(TailArgs a) {
     constexpr uint32_t n_scatter = SCATTER_BLOCKS_PER_LIST * EV_LISTS;     // dispatched first: the longer-running half
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // counters[0] for the host: the number of allele events, or -- when a sub-list overflowed -- the total capacity
+        // that would have held the fullest one (the host grows the list to that and runs the pass again)
+        unsigned long long total = 0; uint32_t fullest = 0;
+        for (uint32_t k = 0; k < EV_LISTS; ++k) { const uint32_t c = a.counters[16u + k * EV_CNT_STRIDE]; total += c; fullest = max(fullest, c); }
+        if (fullest > a.cap_list) total = (unsigned long long)fullest * EV_LISTS;
+        a.counters[0] = (uint32_t)min(total, 0xffffffffull);
+    }
     if (blockIdx.x < n_scatter) scatter_events_block(a, blockIdx.x % SCATTER_BLOCKS_PER_LIST, blockIdx.x / SCATTER_BLOCKS_PER_LIST);
     else gather_cov_block(a, blockIdx.x - n_scatter);
 }
@@ -979,14 +1068,6 @@ __global__ __launch_bounds__(256) void msnv_decide_sites(const SiteRec *sites, u
                                                          uint32_t n_samples, int min_snvs, double min_frac, uint8_t *site_flags, uint32_t cap_list) {
     __shared__ uint32_t s_pop, s_ind;
     if (threadIdx.x == 0) { s_pop = 0; s_ind = 0; }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        // counters[0] for the host: the number of allele events, or -- when a sub-list overflowed -- the total capacity
-        // that would have held the fullest one (the host grows the list to that and runs the pass again)
-        unsigned long long total = 0; uint32_t fullest = 0;
-        for (uint32_t k = 0; k < EV_LISTS; ++k) { const uint32_t c = counters[16u + k * EV_CNT_STRIDE]; total += c; fullest = max(fullest, c); }
-        if (fullest > cap_list) total = (unsigned long long)fullest * EV_LISTS;
-        counters[0] = (uint32_t)min(total, 0xffffffffull);
-    }
     __syncthreads();
     const uint32_t n_sites = counters[2];
     const int lane = threadIdx.x & 63;
@@ -1037,19 +1118,29 @@ __device__ __forceinline__ int wave_reduce_add(int x) {
     return __builtin_amdgcn_readlane(x, 63);
 }
 
-__global__ __launch_bounds__(C_NT) void msnv_coverage_tiles(const Pair32 *iv, const uint64_t *s_cov_base, const TilePair *pairs,
+__global__ __launch_bounds__(C_NT) void msnv_coverage_tiles(const Pair32 *iv, const TilePair *pairs,
                                                             const WorkItem *work, const uint32_t *tile_len, const uint32_t *tile_contig,
                                                             unsigned long long *acc, uint32_t n_contigs, int max_cov, uint32_t n_samples, uint32_t n_copies) {
     // One barrier per (tile, sample) pair: the difference array, the quarter-boundary carries and the workgroup accumulators
     // are double-buffered, so pair k + 1 scatters while slower wavefronts still scan pair k, and the accumulators of pair k
     // are flushed behind the barrier of pair k + 1.  Wavefront w scans positions [512 w, 512 w + 512) on its own: the depth
     // at its left edge is the number of intervals that cover position 512 w - 1, counted while they are scattered.
+    // The kernel was bound by its chain of dependent loads per pair (pair descriptor -> sample base -> intervals, ~3.6 us per
+    // pair whatever it holds): the descriptors now carry the absolute interval offset and are prefetched two pairs ahead, the
+    // first 256 intervals of the next pair one pair ahead, both issued right behind the barrier so that they fly under the scan.
     __shared__ int s_d[2][TILE + 4];
     __shared__ int s_carry[2][C_NT / 64 + 1];
     __shared__ int s_acc[2][COV_BINS + 2];
     const WorkItem w = work[blockIdx.x];
     const uint32_t t0 = w.tile * TILE, tl = tile_len[w.tile], contig = tile_contig[w.tile];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    auto load_pair = [&](const uint32_t k) -> TilePair { return k < w.pair_hi ? pairs[k] : TilePair{0, 0, 0, 0, 0, 0, 0, 0}; };
+    auto base_of = [](const TilePair &p) -> uint64_t { return (uint64_t)p.nblk << 32 | p.blk_lo; };      // absolute index of the sample's first interval
+    auto load_first = [&](const TilePair &p) -> Pair32 {
+        return (p.read_lo + (uint32_t)tid < p.read_hi) ? iv[base_of(p) + p.read_lo + (uint32_t)tid] : Pair32{0u, 0u};   // {0, 0} touches nothing
+    };
+    TilePair pr = load_pair(w.pair_lo), pr1 = load_pair(w.pair_lo + 1u);
+    Pair32 x0 = load_first(pr);
     for (int i = tid; i < 2 * (int)(TILE + 4); i += C_NT) (&s_d[0][0])[i] = 0;
     if (tid < 2 * (COV_BINS + 2)) (&s_acc[0][0])[tid] = 0;
     if (tid < 2 * (C_NT / 64 + 1)) (&s_carry[0][0])[tid] = 0;
@@ -1063,17 +1154,27 @@ __global__ __launch_bounds__(C_NT) void msnv_coverage_tiles(const Pair32 *iv, co
     uint32_t prev_sample = 0;
     for (uint32_t k = w.pair_lo; k < w.pair_hi; ++k) {
         const uint32_t b = k & 1u;
-        const TilePair pr = pairs[k];
-        const Pair32 *v = iv + s_cov_base[pr.sample];
-        for (uint32_t i = pr.read_lo + (uint32_t)tid; i < pr.read_hi; i += C_NT) {
-            const Pair32 x = v[i];
-            if (x.y <= t0 || x.x >= t0 + TILE) continue;
+        auto scatter = [&](const Pair32 x) {
+            if (x.x > x.y) {
+                // qaCompute's `--entireChr[chrSize-1]` without a matching `++` inside the scanned range: an M op whose cursor is
+                // at or beyond the contig end (qaCompute.cpp:542-549; the host stores it as {end, end - 1})
+                if (x.y >= t0 && x.y < t0 + TILE) atomicAdd(&s_d[b][x.y - t0], -1);
+                return;
+            }
+            if (x.y <= t0 || x.x >= t0 + TILE) return;
             const uint32_t s = x.x > t0 ? x.x - t0 : 0u, e = min(x.y - t0, TILE);   // intervals that started in an earlier tile enter at 0
             atomicAdd(&s_d[b][s], 1);
             if (e < TILE) atomicAdd(&s_d[b][e], -1);
             for (uint32_t q = (s >> 9) + 1u; q <= min(e >> 9, 3u); ++q) atomicAdd(&s_carry[b][q], 1);
+        };
+        scatter(x0);
+        if (pr.read_hi - pr.read_lo > (uint32_t)C_NT) {
+            const Pair32 *v = iv + base_of(pr);
+            for (uint32_t i = pr.read_lo + (uint32_t)C_NT + (uint32_t)tid; i < pr.read_hi; i += C_NT) scatter(v[i]);
         }
         __syncthreads();
+        const TilePair pr2 = load_pair(k + 2u);                // in flight under the scan
+        x0 = load_first(pr1);
         if (k > w.pair_lo && tid <= max_cov + 1) flush(b ^ 1u, prev_sample);
         prev_sample = pr.sample;
         int4 d0 = *reinterpret_cast<int4 *>(&s_d[b][C_PPT * tid]);
@@ -1091,12 +1192,13 @@ __global__ __launch_bounds__(C_NT) void msnv_coverage_tiles(const Pair32 *iv, co
         for (int j = 0; j < C_PPT; ++j) {
             if ((uint32_t)(C_PPT * tid + j) < tl) {
                 csum += cv[j];
-                hp += 1ull << (4 * min(cv[j], max_cov));
+                // -1 at the last position of a contig (see scatter): the reference then increments coverageHist[-1], out of
+                // bounds -- the position lands in no bin, the sum takes the -1 (and wraps, unsigned, exactly as covSum does)
+                if (cv[j] >= 0) hp += 1ull << (4 * min(cv[j], max_cov));
             }
         }
         // reduce inside the workgroup first (wave DPP reduction, then LDS), so that one pair costs 1 + max_cov + 1 global
-        // atomics instead of that many per wavefront (the accumulators are 64-bit atomics at the memory side: they, not
-        // the arithmetic, bounded this kernel)
+        // atomics instead of that many per wavefront (the accumulators are 64-bit atomics at the memory side)
         int *sa = s_acc[b];
         const int ws = wave_reduce_add(csum);
         if (lane == 0 && ws) atomicAdd(&sa[0], ws);
@@ -1113,6 +1215,7 @@ __global__ __launch_bounds__(C_NT) void msnv_coverage_tiles(const Pair32 *iv, co
                 }
             }
         }
+        pr = pr1; pr1 = pr2;
     }
     __syncthreads();
     if (w.pair_hi > w.pair_lo && tid <= max_cov + 1) flush((w.pair_hi - 1u) & 1u, prev_sample);
@@ -1150,7 +1253,7 @@ void dev_stream_destroy(void *stream) { if (stream) (void)hipStreamDestroy((hipS
 
 void dev_free_all(DeviceCols &d) {
     void *ptrs[] = {d.hdr, d.hdr8, d.blk, d.seq, d.qual, d.s_read_base, d.s_seq_base, d.ref4, d.ref_lc, d.pairs,
-                    d.tile_pair_start, d.work, d.chunks, d.tile_vbeg, d.tile_vend, d.tot, d.part, d.tile_slot_start, d.tile_slot_u16, d.tile_slot_wide, d.slot_off, d.spill, d.events, d.overflow, d.counters,
+                    d.tile_pair_start, d.work, d.chunks, d.tile_vbeg, d.tile_vend, d.tot, d.part, d.tile_slot_start, d.tile_slot_u16, d.tile_slot_wide, d.slot_off, d.spill, d.events, d.overflow, d.counters, d.ind4,
                     d.sites, d.tile_site_base, d.tile_site_cnt, d.out, d.cov_col, d.site_flags,
                     d.cov_iv, d.s_cov_base, d.cov_pairs, d.cov_work, d.tile_len, d.tile_contig_dev, d.cov_acc};
     for (void *p : ptrs) dev_free(p);
@@ -1159,7 +1262,7 @@ void dev_free_all(DeviceCols &d) {
     for (void *e : d.timing_events) if (e) (void)hipEventDestroy((hipEvent_t)e);
     for (void *e : d.event_pool) (void)hipEventDestroy((hipEvent_t)e);
     if (d.pinned_cnt) (void)hipHostFree(d.pinned_cnt);
-    void *alts[] = {d.alt.tot, d.alt.part, d.alt.spill, d.alt.events, d.alt.overflow, d.alt.counters, d.alt.sites, d.alt.tile_site_base,
+    void *alts[] = {d.alt.tot, d.alt.part, d.alt.spill, d.alt.events, d.alt.overflow, d.alt.counters, d.alt.ind4, d.alt.sites, d.alt.tile_site_base,
                     d.alt.tile_site_cnt, d.alt.out, d.alt.cov_col, d.alt.site_flags, d.alt.site_bits, d.site_bits, d.alt.site_rank, d.site_rank, d.active_tiles};
     for (void *p : alts) dev_free(p);
     if (d.stream2) (void)hipStreamDestroy((hipStream_t)d.stream2);
@@ -1185,8 +1288,10 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
                         hipEvent_t ev3, hipEvent_t ev4, uint32_t *host_cnt, hipEvent_t wait_before_pileup = nullptr) {
     const uint64_t npos = (uint64_t)d.n_tiles * TILE;
     if (ev_begin) HIP_TRY(hipEventRecord(ev_begin, st));
-    // d.tot needs no memset: it is zero after finalize and msnv_gate_sites zeroes what a pass has written
-    HIP_TRY(hipMemsetAsync(d.counters, 0, (CNT_WORDS + npos / 32 + 1) * sizeof(uint32_t), st));   // counters + individual-candidate bits (one allocation)
+    // nothing to clear: d.tot and the individual-rule bits are zero after finalize and msnv_gate_sites zeroes what a pass has
+    // written; the counters live in two blocks that consecutive passes alternate between (the gate kernel zeroes the other one)
+    uint32_t *const counters = d.counters + d.cnt_parity * CNT_WORDS, *const counters_next = d.counters + (d.cnt_parity ^ 1u) * CNT_WORDS;
+    d.cnt_parity ^= 1u;
     if (wait_before_pileup) HIP_TRY(hipStreamWaitEvent(st, wait_before_pileup, 0));   // the previous pass' pileup kernel (other stream)
     HIP_TRY(hipEventRecord(ev_pile0, st));
     if (d.n_work) {
@@ -1195,8 +1300,8 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
         a.s_read_base = d.s_read_base; a.s_seq_base = d.s_seq_base;
         a.ref4 = d.ref4; a.pairs = d.pairs; a.work = d.work; a.chunks = d.chunks; a.tot = d.tot; a.part = d.part; a.npos = npos; a.spill = d.spill;
         a.events = d.events; a.cap_events = d.cap_events / EV_LISTS; a.ev_count = nullptr; a.overflow = d.overflow; a.cap_overflow = d.cap_overflow;
-        a.counters = d.counters; a.min_baseq = (uint32_t)std::max(0, p.min_baseq);
-        a.ind_bits = d.ind_bits; a.min_snvs = (uint32_t)std::max(0, p.calling_threshold);
+        a.counters = counters; a.min_baseq = (uint32_t)std::max(0, p.min_baseq);
+        a.ind4 = d.ind4; a.unc_bits = d.unc_bits; a.min_snvs = (uint32_t)std::max(0, p.calling_threshold);
         const uint32_t n_narrow = d.n_work_narrow;
         // narrow work items (byte bins) and wide ones (16-bit bins) touch disjoint (tile, sample) pairs
         if (n_narrow && d.dense) hipLaunchKernelGGL(msnv_pileup_tiles_dense, dim3(n_narrow), dim3(N_NT), 0, st, a);
@@ -1210,12 +1315,18 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
     }
     HIP_TRY(hipEventRecord(ev_pile1, st));
     const uint32_t cap_out = (uint32_t)std::min<uint64_t>(d.cap_out_sites, 0xffffffffull);
+    const bool decide_in_gate = !d.any_split;          // else a sample's pairs must be summed first: msnv_decide_sites behind the scatter
     if (d.n_active_tiles) {
-        hipLaunchKernelGGL(msnv_gate_sites, dim3(d.n_active_tiles), dim3(GATE_NT), 0, st, d.tot, d.part, d.slot_off, d.tile_slot_start, d.tile_slot_u16, d.tile_slot_wide, npos, d.tile_vbeg, d.tile_vend,
-                           p.min_coverage, p.calling_threshold, p.min_fraction, d.ind_bits, d.site_bits, d.site_rank, d.sites, d.cap_sites, d.counters, d.tile_site_base, d.tile_site_cnt, d.active_tiles,
-                           d.out, d.cov_col, d.n_samples, cap_out);
+        GateArgs g;
+        g.tot = d.tot; g.part = d.part; g.slot_off = d.slot_off; g.tile_slot_start = d.tile_slot_start; g.tile_slot_u16 = d.tile_slot_u16; g.tile_slot_wide = d.tile_slot_wide;
+        g.npos = npos; g.tile_vbeg = d.tile_vbeg; g.tile_vend = d.tile_vend; g.min_cov = p.min_coverage; g.min_snvs = p.calling_threshold; g.min_frac = p.min_fraction;
+        g.ind4 = d.ind4; g.unc_bits = d.unc_bits; g.ref4 = d.ref4; g.ref_lc = d.ref_lc;
+        g.site_bits = d.site_bits; g.site_rank = d.site_rank; g.sites = d.sites; g.cap_sites = d.cap_sites; g.counters = counters; g.counters_next = counters_next;
+        g.tile_site_base = d.tile_site_base; g.tile_site_cnt = d.tile_site_cnt; g.active_tiles = d.active_tiles;
+        g.out = d.out; g.cov_col = d.cov_col; g.site_flags = d.site_flags; g.n_samples = d.n_samples; g.cap_out = cap_out; g.decide_here = decide_in_gate ? 1u : 0u;
+        hipLaunchKernelGGL(msnv_gate_sites, dim3(d.n_active_tiles), dim3(GATE_NT), 0, st, g);
         HIP_TRY(hipGetLastError());
-    }
+    } else HIP_TRY(hipMemsetAsync(counters_next, 0, CNT_WORDS * sizeof(uint32_t), st));   // nobody else would
     if (ev3) HIP_TRY(hipEventRecord(ev3, st));
     // the tail runs on device-side counts: no host round trip inside a pass
     if (d.n_active_tiles) {
@@ -1223,16 +1334,18 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
         ta.sites = d.sites; ta.tile_site_base = d.tile_site_base; ta.tile_site_cnt = d.tile_site_cnt; ta.tile_pair_start = d.tile_pair_start;
         ta.pairs = d.pairs; ta.spill = d.spill; ta.out = d.out; ta.cov_col = d.cov_col; ta.n_samples = d.n_samples; ta.cap_out = cap_out; ta.active_tiles = d.active_tiles;
         ta.n_gather_blocks = d.n_active_tiles * GATHER_SPLIT;
-        ta.events = d.events; ta.overflow = d.overflow; ta.counters = d.counters; ta.cap_list = d.cap_events / EV_LISTS; ta.cap_overflow = d.cap_overflow;
+        ta.events = d.events; ta.overflow = d.overflow; ta.counters = counters; ta.cap_list = d.cap_events / EV_LISTS; ta.cap_overflow = d.cap_overflow;
         ta.site_bits = d.site_bits; ta.site_rank = d.site_rank;
         hipLaunchKernelGGL(msnv_gather_scatter, dim3(ta.n_gather_blocks + SCATTER_BLOCKS_PER_LIST * EV_LISTS), dim3(256), 0, st, ta);
         HIP_TRY(hipGetLastError());
     }
     if (ev4) HIP_TRY(hipEventRecord(ev4, st));
-    hipLaunchKernelGGL(msnv_decide_sites, dim3(512), dim3(256), 0, st, d.sites, d.counters, d.cap_sites, cap_out, d.ref4, d.ref_lc,
-                       d.out, d.n_samples, p.calling_threshold, p.min_fraction, d.site_flags, d.cap_events / EV_LISTS);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(host_cnt, d.counters, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    if (!decide_in_gate && d.n_active_tiles) {
+        hipLaunchKernelGGL(msnv_decide_sites, dim3(512), dim3(256), 0, st, d.sites, counters, d.cap_sites, cap_out, d.ref4, d.ref_lc,
+                           d.out, d.n_samples, p.calling_threshold, p.min_fraction, d.site_flags, d.cap_events / EV_LISTS);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipMemcpyAsync(host_cnt, counters, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     return MSNV_OK;
 }
 
@@ -1284,7 +1397,7 @@ static int ensure_alt(DeviceCols &d) {
     DeviceCols::AltBufs &a = d.alt;
     const uint64_t npos = (uint64_t)d.n_tiles * TILE;
     if (a.tot && a.cap_events == d.cap_events && a.cap_overflow == d.cap_overflow && a.cap_sites == d.cap_sites && a.cap_out_sites == d.cap_out_sites) return MSNV_OK;
-    void *old[] = {a.tot, a.part, a.spill, a.events, a.overflow, a.counters, a.sites, a.tile_site_base, a.tile_site_cnt, a.out, a.cov_col, a.site_flags, a.site_bits, a.site_rank};
+    void *old[] = {a.tot, a.part, a.spill, a.events, a.overflow, a.counters, a.ind4, a.sites, a.tile_site_base, a.tile_site_cnt, a.out, a.cov_col, a.site_flags, a.site_bits, a.site_rank};
     for (void *p : old) dev_free(p);
     a = DeviceCols::AltBufs{};
     if (int rc = dev_alloc((void **)&a.tot, std::max<uint64_t>(1, 4 * npos) * sizeof(uint32_t), &d.device_bytes)) return rc;
@@ -1294,8 +1407,11 @@ static int ensure_alt(DeviceCols &d) {
     if (int rc = dev_alloc((void **)&a.events, (uint64_t)d.cap_events * sizeof(Pair32), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.overflow, (uint64_t)d.cap_overflow * sizeof(Pair32), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.sites, (uint64_t)d.cap_sites * sizeof(SiteRec), &d.device_bytes)) return rc;
-    if (int rc = dev_alloc((void **)&a.counters, (CNT_WORDS + npos / 32 + 1) * sizeof(uint32_t), &d.device_bytes)) return rc;
-    a.ind_bits = a.counters + CNT_WORDS;
+    if (int rc = dev_alloc((void **)&a.counters, 2 * CNT_WORDS * sizeof(uint32_t), &d.device_bytes)) return rc;
+    if (int rc = dev_memset(a.counters, 0, 2 * CNT_WORDS * sizeof(uint32_t))) return rc;
+    if (int rc = dev_alloc((void **)&a.ind4, (npos / 8 + npos / 32 + 2) * sizeof(uint32_t), &d.device_bytes)) return rc;
+    if (int rc = dev_memset(a.ind4, 0, (npos / 8 + npos / 32 + 2) * sizeof(uint32_t))) return rc;
+    a.unc_bits = a.ind4 + npos / 8 + 1; a.cnt_parity = 0;
     if (int rc = dev_alloc((void **)&a.site_bits, (npos / 64 + 1) * sizeof(unsigned long long), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.site_rank, (npos / 64 + 1) * sizeof(uint32_t), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.tile_site_base, ((uint64_t)d.n_tiles + 1) * sizeof(uint32_t), &d.device_bytes)) return rc;
@@ -1313,7 +1429,7 @@ static void swap_sets(DeviceCols &d) {
     std::swap(d.tot, a.tot); std::swap(d.part, a.part); std::swap(d.spill, a.spill); std::swap(d.events, a.events);
     std::swap(d.overflow, a.overflow); std::swap(d.counters, a.counters); std::swap(d.sites, a.sites);
     std::swap(d.tile_site_base, a.tile_site_base); std::swap(d.tile_site_cnt, a.tile_site_cnt); std::swap(d.out, a.out); std::swap(d.cov_col, a.cov_col);
-    std::swap(d.site_flags, a.site_flags); std::swap(d.ind_bits, a.ind_bits); std::swap(d.site_bits, a.site_bits); std::swap(d.site_rank, a.site_rank);
+    std::swap(d.site_flags, a.site_flags); std::swap(d.ind4, a.ind4); std::swap(d.unc_bits, a.unc_bits); std::swap(d.cnt_parity, a.cnt_parity); std::swap(d.site_bits, a.site_bits); std::swap(d.site_rank, a.site_rank);
 }
 
 // n passes, ONE host synchronisation at the end; with `overlap` they are in flight on two streams (a queue of shards / repeated passes keeps the
@@ -1393,7 +1509,7 @@ int dev_run_coverage(DeviceCols &d, int max_cov, void *stream_, msnv_run_stats *
     HIP_TRY(hipEventRecord(e0, st));
     HIP_TRY(hipMemsetAsync(d.cov_acc, 0, (uint64_t)d.cov_copies * d.n_samples * d.n_contigs * (1 + COV_BINS) * sizeof(unsigned long long), st));
     if (d.n_cov_work) {
-        hipLaunchKernelGGL(msnv_coverage_tiles, dim3(d.n_cov_work), dim3(C_NT), 0, st, d.cov_iv, d.s_cov_base, d.cov_pairs, d.cov_work,
+        hipLaunchKernelGGL(msnv_coverage_tiles, dim3(d.n_cov_work), dim3(C_NT), 0, st, d.cov_iv, d.cov_pairs, d.cov_work,
                            d.tile_len, d.tile_contig_dev, d.cov_acc, d.n_contigs, max_cov, d.n_samples, d.cov_copies);
         HIP_TRY(hipGetLastError());
     }

@@ -517,11 +517,23 @@ int pack_sample(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, Sa
             for (; k < r.n_cigar; ++k) {
                 const uint32_t c = ld_u32(r.cigar + 4 * k), t = c & 15u, l = c >> 4;
                 if (t == C_M && ds.sel[(size_t)r.tid]) {
-                    // `++entireChr[pp]` with pp >= chrSize writes past the scanned range and the matching
-                    // `--entireChr[chrSize-1]` drives the coverage negative (qaCompute.cpp:542-549): undefined there
-                    if (pp >= ds.lengths[(size_t)r.tid])
-                        return fail(MSNV_EDOMAIN, "read at %s:%d aligns at or beyond the contig end (qaCompute: undefined behaviour)", ds.names[(size_t)r.tid].c_str(), r.pos + 1);
-                    sc.cov_tid.push_back(r.tid); sc.cov_beg.push_back((int32_t)pp); sc.cov_end.push_back((int32_t)(pp + l));
+                    // qaCompute.cpp:542-549: `++entireChr[pp]`, then `--entireChr[min(pp + l, chrSize - 1)]`.  With pp >= chrSize
+                    // (a read whose cursor -- pos + 1, advanced by EVERY earlier op -- reaches the contig end; pp == chrSize is still
+                    // inside the chrSize + 1 slots, beyond that the reference writes out of bounds) only the decrement at
+                    // chrSize - 1 lands in the scanned range, and that position can never be covered (every read that reaches it is
+                    // clamped onto it), so its coverage goes to -1 and the reference increments coverageHist[-1]: undefined there.
+                    // One such read must not take a whole metaSNV run down: the library warns once per sample and computes what
+                    // the reference's arithmetic says short of the out-of-bounds write -- covSum takes the -1, the position lands in
+                    // no histogram bin.  Stored as the interval {L, L - 1} (begin > end) = "-1 at L - 1".
+                    const int64_t L = ds.lengths[(size_t)r.tid];
+                    if (pp >= L) {
+                        if (!sc.warned_beyond_end) {
+                            sc.warned_beyond_end = true;
+                            fprintf(stderr, "msnv: warning: read at %s:%d reaches the contig end in qaCompute's index space (undefined behaviour in the reference: coverageHist[-1]); "
+                                            "the last position of the contig is left out of the coverage histogram\n", ds.names[(size_t)r.tid].c_str(), r.pos + 1);
+                        }
+                        if (L >= 1) { sc.cov_tid.push_back(r.tid); sc.cov_beg.push_back((int32_t)L); sc.cov_end.push_back((int32_t)(L - 1)); }
+                    } else { sc.cov_tid.push_back(r.tid); sc.cov_beg.push_back((int32_t)pp); sc.cov_end.push_back((int32_t)(pp + l)); }
                 }
                 pp += l;
             }
@@ -658,7 +670,7 @@ int finalize_dataset(msnv_dataset &ds) {
     {
         for (size_t i = 0; i < sc.hdr.size(); ++i) maxend[(size_t)sc.tid[i]] = std::max<int64_t>(maxend[(size_t)sc.tid[i]], sc.end[i]);
         for (size_t i = 0; i < sc.cov_tid.size(); ++i)
-            if (ds.sel[(size_t)sc.cov_tid[i]]) maxend[(size_t)sc.cov_tid[i]] = std::max<int64_t>(maxend[(size_t)sc.cov_tid[i]], (int64_t)sc.cov_beg[i] + 1);
+            if (ds.sel[(size_t)sc.cov_tid[i]]) maxend[(size_t)sc.cov_tid[i]] = std::max<int64_t>(maxend[(size_t)sc.cov_tid[i]], std::min<int64_t>((int64_t)sc.cov_beg[i] + 1, ds.lengths[(size_t)sc.cov_tid[i]]));
     }
     ds.tile_base.assign(NC, UINT32_MAX);
     ds.tile_contig.clear();
@@ -966,13 +978,15 @@ int finalize_dataset(msnv_dataset &ds) {
                 const size_t c = (size_t)sc.cov_tid[i];
                 const int64_t L = ds.lengths[c];
                 const int64_t b = sc.cov_beg[i];
-                const int64_t e = sc.cov_end[i] >= L ? L - 1 : sc.cov_end[i];       // qaCompute.cpp:544-549
-                if (b >= e) continue;
+                const bool minus_one = b > sc.cov_end[i];                          // {L, L - 1}: "-1 at L - 1" (pack_sample)
+                const int64_t e = minus_one ? sc.cov_end[i] : (sc.cov_end[i] >= L ? L - 1 : sc.cov_end[i]);       // qaCompute.cpp:544-549
+                if (!minus_one && b >= e) continue;
                 const uint64_t g0 = (uint64_t)ds.tile_base[c] * TILE;
                 const uint32_t idx = n_here++;
                 iv.push_back(Pair32{(uint32_t)(g0 + (uint64_t)b), (uint32_t)(g0 + (uint64_t)e)});
                 std::vector<CP> &pv = per[s];
-                for (uint32_t t = (uint32_t)((g0 + b) / TILE); t <= (uint32_t)((g0 + e - 1) / TILE); ++t) {
+                const uint32_t t_first = (uint32_t)((g0 + (uint64_t)(minus_one ? e : b)) / TILE), t_last = minus_one ? t_first : (uint32_t)((g0 + e - 1) / TILE);
+                for (uint32_t t = t_first; t <= t_last; ++t) {
                     size_t k = pv.size();
                     while (k > 0 && pv[k - 1].tile > t) --k;
                     if (k > 0 && pv[k - 1].tile == t) pv[k - 1].hi = idx + 1;
@@ -987,7 +1001,8 @@ int finalize_dataset(msnv_dataset &ds) {
         std::vector<TilePair> cpairs(cps[nt]);
         {
             std::vector<uint32_t> fill(cps.begin(), cps.end() - 1);
-            for (size_t s = 0; s < S; ++s) for (const CP &p : per[s]) cpairs[fill[p.tile]++] = TilePair{p.sample, p.lo, p.hi, 0, 0, 0, 0, 0};
+            // blk_lo / nblk: absolute index of the sample's first interval (the kernel needs no per-sample base lookup)
+            for (size_t s = 0; s < S; ++s) for (const CP &p : per[s]) cpairs[fill[p.tile]++] = TilePair{p.sample, p.lo, p.hi, 0, (uint32_t)cvbase[s], (uint32_t)(cvbase[s] >> 32), 0, 0};
         }
         std::vector<WorkItem> cwork;
         const uint64_t cov_item_intervals = [] { const char *e = getenv("MSNV_COV_ITEM"); const long long v = e ? atoll(e) : 1024; return (uint64_t)(v > 0 ? v : 1024); }();   // intervals per coverage work item: 4096 -> 0.173 ms, 2048 -> 0.149, 1024 -> 0.143, 512 -> 0.143, 256 -> 0.151 (benchmark shape)
@@ -1030,9 +1045,14 @@ int finalize_dataset(msnv_dataset &ds) {
     if (int rc = dev_alloc((void **)&d->events, (uint64_t)d->cap_events * sizeof(Pair32), &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->overflow, (uint64_t)d->cap_overflow * sizeof(Pair32), &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->sites, (uint64_t)d->cap_sites * sizeof(SiteRec), &d->device_bytes)) return rc;
-    // counters and the individual-candidate bits share one allocation: one memset per pass clears both
-    if (int rc = dev_alloc((void **)&d->counters, (CNT_WORDS + npos / 32 + 1) * sizeof(uint32_t), &d->device_bytes)) return rc;
-    d->ind_bits = d->counters + CNT_WORDS;
+    // no memset per pass: the counter blocks alternate (the gate kernel zeroes the next one) and the gate kernel leaves the
+    // individual-rule bits it consumes zero, like the allele totals
+    if (int rc = dev_alloc((void **)&d->counters, 2 * CNT_WORDS * sizeof(uint32_t), &d->device_bytes)) return rc;
+    if (int rc = dev_memset(d->counters, 0, 2 * CNT_WORDS * sizeof(uint32_t))) return rc;
+    if (int rc = dev_alloc((void **)&d->ind4, (npos / 8 + npos / 32 + 2) * sizeof(uint32_t), &d->device_bytes)) return rc;
+    if (int rc = dev_memset(d->ind4, 0, (npos / 8 + npos / 32 + 2) * sizeof(uint32_t))) return rc;
+    d->unc_bits = d->ind4 + npos / 8 + 1;
+    for (const TilePair &tp : pairs) if (tp.pad) { d->any_split = true; break; }
     if (int rc = dev_alloc((void **)&d->site_bits, (npos / 64 + 1) * sizeof(unsigned long long), &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->site_rank, (npos / 64 + 1) * sizeof(uint32_t), &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->tile_site_base, (nt + 1) * sizeof(uint32_t), &d->device_bytes)) return rc;

@@ -33,7 +33,9 @@ static void compute_print_cov(FILE *out, FILE *detail, int max_cov, int *data, c
         data[i] = covVal;
         covSum += (uint64_t)(int64_t)covVal;
         if (covVal > max_cov) { ++coverageHist[max_cov]; ++local[max_cov]; }
-        else                  { ++coverageHist[covVal];  ++local[covVal]; }
+        else if (covVal >= 0) { ++coverageHist[covVal];  ++local[covVal]; }
+        /* covVal == -1 (last position, below a read whose cursor reached the contig end): the reference increments
+           coverageHist[-1] and localCoverageHist[-1], out of bounds -- undefined; restated as "lands in no bin" */
     }
     fprintf(detail, "%s\t%d\t", name, (int)chrSize);                    /* :192-201 */
     for (k = 1; k <= max_cov; ++k) {
@@ -111,8 +113,10 @@ int orc_qacompute(const orc_ref *head, const orc_sample *sample, int max_cov, in
                         if ((op & 15) != 0) {
                             pp = pp + (op >> 4);
                         } else {
-                            if (pp >= chrSize) { orc_set_error("read aligns at or beyond the contig end (reference: out-of-bounds write / negative coverage)"); free(entireChr); free(coverageHist); fclose(out); fclose(detail); return ORC_ERR_DOMAIN; }
-                            ++entireChr[pp];
+                            /* the array has chrSize + 1 slots (:490): pp == chrSize is in bounds and lands outside the scanned range;
+                               pp > chrSize writes out of bounds in the reference: that increment is left out here (what the
+                               heap's slack makes of it in practice), the decrement below is the visible effect either way */
+                            if (pp <= chrSize) ++entireChr[pp];
                             pp = pp + (op >> 4);
                             if (pp >= chrSize) --entireChr[chrSize - 1];
                             else --entireChr[pp];

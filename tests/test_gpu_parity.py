@@ -531,12 +531,21 @@ def test_coverage_cigar_quirks_and_filters(tmp_path):
             assert got == want
 
 
-def test_coverage_domain_errors_are_reported():
-    ctx = core.Context(0)
-    ds = core.Dataset(ctx, ["c1"], [100], None)
-    with pytest.raises(core._lib.MsnvError) as e:
-        ds.add_sample_records(bt.records(bt.make_record(0, 99, "5M", "ACGTA")))      # index 100 >= length
-    assert e.value.code == core._lib.EDOMAIN
+def test_coverage_reads_at_the_contig_end_do_not_fail_the_run(tmp_path):
+    """qaCompute.cpp:542-549: an M op whose cursor (pos + 1, advanced by EVERY earlier op) is at or beyond the contig length only
+    decrements the last position, which no read can cover -- its coverage becomes -1 and the reference increments
+    coverageHist[-1] (undefined).  One such read must not fail a whole metaSNV run: the library warns and computes the
+    reference's arithmetic short of the out-of-bounds write (covSum takes the -1, the position lands in no bin), and so does
+    the oracle."""
+    L = 100
+    ref = "ACGT" * 25
+    s = bt.records(*[bt.make_record(0, 60, "40M", ref[60:100], name="c%d" % i) for i in range(3)],
+                   bt.make_record(0, 90, "5M8I2M", ref[90:95] + "G" * 8 + "AC", name="t2"),      # second M op at cursor 104 > L
+                   bt.make_record(0, 97, "2M", "CG", name="t0"),
+                   bt.make_record(0, 99, "1M4S", "ACGTA", name="t1"))                              # cursor == L
+    res, st = _coverage_both(["c1", "c2"], [L, 50], [s], tmp_path)
+    assert res[0][0] == res[0][1]
+    assert res[0][0][1].startswith("c1\t100\t38\t")           # indices 61..98 covered, index 99 (coverage -2) in no bin
 
 
 def _write_inputs(tmp_path, syn, samples):
