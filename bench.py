@@ -25,6 +25,37 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
 
 
+# Synthetic workloads.  testdata: 160 samples x 3 refGenomes x 300 kb, ~10x, 10 % of the (sample, species) pairs
+# absent.  config3 (BASELINE configs[2]): 100 species x (1-50 contigs, 3 Mbp), 160 samples, each carries 10 random species at
+# LogNormal(ln 10, 0.7)x.  config4shard (one GPU's share of BASELINE configs[3]): 1500 species x ~2.07 Mbp (3.1 G positions), 500 samples,
+# each carries 20 of the 12 000 species = 2.5 of this shard's, at 5x.
+WORKLOADS = {
+    "testdata": dict(n_species=3, contig_len=300000, n_samples=160, mean_cov=10.0),
+    "config3": dict(n_species=100, contig_len=3000000, n_samples=160, mean_cov=10.0, sigma_cov=0.7, contigs_per_species_max=50, species_per_sample=10),
+    "config4shard": dict(n_species=1500, contig_len=2070000, n_samples=500, mean_cov=5.0, sigma_cov=0.3, contigs_per_species_max=20, species_per_sample=2.5),
+}
+
+
+def workload_params(a, rank=0):
+    kw = dict(WORKLOADS[a.workload])
+    label = {"testdata": "testdata shape (BASELINE configs[1])", "config3": "ProGenomes2-subset shape (BASELINE configs[2])",
+             "config4shard": "one GPU's contig shard of BASELINE configs[3]"}[a.workload]
+    if a.workload != "testdata":
+        scale = a.scale if a.scale is not None else 0.25
+        kw["n_species"] = max(2, int(round(kw["n_species"] * scale)))
+        kw["species_per_sample"] = max(1, int(round(kw["species_per_sample"] * scale)))     # the same share of the species per sample
+        label += " at %g of its species" % scale
+    for arg, key in (("samples", "n_samples"), ("contig_len", "contig_len"), ("species", "n_species"), ("mean_cov", "mean_cov")):
+        if getattr(a, arg) is not None:
+            kw[key] = getattr(a, arg)
+    kw["seed"] = 1 + rank
+    if a.read_len != 100:
+        kw["read_len"] = a.read_len
+    if a.error_rate is not None:
+        kw["error_rate"] = a.error_rate
+    return kw, label
+
+
 def measured_traffic(samples, species, contig_len, mean_cov):
     """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/
     (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 read correction applied).
@@ -43,10 +74,14 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--samples", type=int, default=160)
-    ap.add_argument("--contig-len", type=int, default=300000)
-    ap.add_argument("--species", type=int, default=3)
-    ap.add_argument("--mean-cov", type=float, default=10.0)
+    ap.add_argument("--workload", default="testdata", choices=sorted(WORKLOADS),
+                    help="testdata = BASELINE configs[1] (the metric's configuration, default); config3 / config4shard = the SURVEY.md 8d shapes of "
+                         "BASELINE configs[2] / the per-GPU shard of configs[3], scaled by --scale")
+    ap.add_argument("--scale", type=float, default=None, help="fraction of the named workload's species (config3 / config4shard; default 0.25: the full shapes need ~100 GB of host staging)")
+    ap.add_argument("--samples", type=int, default=None)
+    ap.add_argument("--contig-len", type=int, default=None)
+    ap.add_argument("--species", type=int, default=None)
+    ap.add_argument("--mean-cov", type=float, default=None)
     ap.add_argument("--read-len", type=int, default=100, help="synthetic read length (BASELINE: 100)")
     ap.add_argument("--error-rate", type=float, default=None, help="synthetic sequencing error rate (BASELINE: 0.001)")
     ap.add_argument("--cpu-samples", type=int, default=64, help="samples of the workload the CPU oracle is timed on")
@@ -65,13 +100,19 @@ def cpu_baseline(sp_kwargs, n_cpu_samples):
     from metasnv_amd import core
     sp = core.synth_params(**sp_kwargs)
     syn = core.Synth(sp)
-    samples = [syn.sample_records(i) for i in range(n_cpu_samples)]
+    samples, nbytes = [], 0
+    for i in range(n_cpu_samples):                     # bounded sample: ~10-30 s of single-threaded CPU work
+        samples.append(syn.sample_records(i))
+        nbytes += samples[-1].size
+        if nbytes > 1.3e9:
+            break
+    n_cpu_samples = len(samples)
     t0 = time.perf_counter()
     pop, ind, n_lines, n_bases = orc.call(syn.names, syn.lengths, syn.seqs, samples)
     dt = time.perf_counter() - t0
     return {"value": n_bases / dt / 1e9, "unit": "Gbases/s", "cores": 1, "kind": "port",
             "sample": "first %d of %d samples, all %d contigs: %d pileup bases in %.1f s (mpileup+snpCall restatement, 1 thread)"
-                      % (n_cpu_samples, sp.n_samples, sp.n_species, n_bases, dt),
+                      % (n_cpu_samples, sp.n_samples, len(syn.names), n_bases, dt),
             "called_lines": pop.count("\n")}
 
 
@@ -143,17 +184,13 @@ def main():
         raise SystemExit("bench.py: no HIP device visible; the pileup path has no CPU fallback")
 
     # ---- build this rank's shard: same shape on every rank, different seed (weak scaling)
-    sp_kwargs = dict(n_species=a.species, contig_len=a.contig_len, n_samples=a.samples, mean_cov=a.mean_cov, seed=1 + rank)
-    if a.read_len != 100:
-        sp_kwargs["read_len"] = a.read_len
-    if a.error_rate is not None:
-        sp_kwargs["error_rate"] = a.error_rate
+    sp_kwargs, wl_label = workload_params(a, rank)
     sp = core.synth_params(**sp_kwargs)
     syn = core.Synth(sp)
     ctx = core.Context(local)
     ds = core.Dataset(ctx, syn.names, syn.lengths, syn.seqs)
     t0 = time.perf_counter()
-    ds.add_synth_samples(sp, 0, a.samples, a.host_threads)
+    ds.add_synth_samples(sp, 0, sp.n_samples, a.host_threads)
     t_pack = time.perf_counter() - t0
     t0 = time.perf_counter()
     info = ds.finalize()
@@ -249,13 +286,13 @@ def main():
             "ms_per_step": dt_max / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "testdata shape: %d synthetic BAM-record streams x %d refGenomes x %d bp, ~%gx, single-end %d bp (BASELINE configs[1])"
-                                   % (a.samples, a.species, a.contig_len, a.mean_cov, a.read_len),
-                       "samples": a.samples, "positions_per_gpu": info["n_positions"], "pileup_bases_per_gpu": bases,
+            "config": {"workload": "%s: %d synthetic BAM-record streams x %d species (%d contigs, %d bp per species), ~%gx, single-end %d bp"
+                                   % (wl_label, sp.n_samples, sp.n_species, len(syn.names), sp.contig_len, sp.mean_cov, sp.read_len),
+                       "samples": sp.n_samples, "pairs_per_gpu": info["n_pairs"], "work_items_per_gpu": info["n_work"], "positions_per_gpu": info["n_positions"], "pileup_bases_per_gpu": bases,
                        "reads_per_gpu": info["n_reads"], "parallelism": "contig shards x%d, no data-path collective" % world,
                        "called_SNPs_lines_per_rank": called},
-            "roofline": {"bound": "hbm", "kernel": "msnv_pileup_tiles_narrow32", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(a.samples, a.species, a.contig_len, a.mean_cov) if world == 1 else None,
+            "roofline": {"bound": "hbm", "kernel": "msnv_pileup_tiles_narrow32" if a.workload == "testdata" else "msnv_pileup_tiles_* (narrow32 + merged [+ wide] between one pair of HIP events)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(sp.n_samples, sp.n_species, sp.contig_len, sp.mean_cov) if (world == 1 and a.workload == "testdata") else None,
                          "algorithmic_bytes_per_launch": alg, "kernel_ms_avg": k_ms,
                          "rank": slowest, "achieved_per_rank": per_rank_gbs,
                          "bytes_per_pileup_base": alg / max(1, bases),
@@ -272,7 +309,7 @@ def main():
         if ann_extra:
             line["annotation"] = ann_extra
         if not a.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(sp_kwargs, min(a.cpu_samples, a.samples))
+            line["cpu_baseline"] = cpu_baseline(sp_kwargs, min(a.cpu_samples, sp.n_samples))
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

@@ -382,9 +382,14 @@ typedef struct {
     uint64_t seed;
     double   frac_paired;        /* 0 (default, the BASELINE testdata shape is single-end): fraction of read starts that
                                     become a proper pair whose mates mostly overlap on the reference               */
+    int32_t  contigs_per_species_max;   /* 0 / 1: one contig per species.  > 1 (BASELINE configs[2] / [3]): a species has
+                                    1 .. max contigs `refGenome<k>clus.c<j>` that share contig_len bases           */
+    int32_t  species_per_sample; /* 0: presence by frac_absent.  > 0: every sample carries exactly that many random species */
 } msnv_synth_params;
 
 void msnv_synth_params_default(msnv_synth_params *p);
+/* Number of contigs the parameters describe (= n_species unless contigs_per_species_max > 1). */
+int  msnv_synth_contig_count(const msnv_synth_params *p);
 /* Reference sequences: caller frees each seqs[i] and the arrays with msnv_free. */
 int  msnv_synth_reference(const msnv_synth_params *p, char ***names, int64_t **lengths, char ***seqs);
 /* One sample's raw BAM record stream (coordinate sorted). */

@@ -92,7 +92,8 @@ class SynthParams(C.Structure):
                 ("mean_cov", C.c_double), ("sigma_cov", C.c_double), ("frac_absent", C.c_double),
                 ("snv_density", C.c_double), ("error_rate", C.c_double), ("frac_lowq", C.c_double),
                 ("frac_indel_reads", C.c_double), ("frac_clip_reads", C.c_double), ("frac_flagged", C.c_double),
-                ("lowercase_ref", C.c_int32), ("seed", C.c_uint64), ("frac_paired", C.c_double)]
+                ("lowercase_ref", C.c_int32), ("seed", C.c_uint64), ("frac_paired", C.c_double),
+                ("contigs_per_species_max", C.c_int32), ("species_per_sample", C.c_int32)]
 
 
 # every symbol include/msnv.h declares: (name, restype, argtypes)
@@ -148,6 +149,7 @@ SYMBOLS = [
     ("msnv_bam_data_free", None, [P(BamData)]),
     ("msnv_bam_write", C.c_int, [C.c_char_p, C.c_char_p, C.c_int32, P(C.c_char_p), P(C.c_int64), _vp, C.c_uint64, C.c_int32]),
     ("msnv_synth_params_default", None, [P(SynthParams)]),
+    ("msnv_synth_contig_count", C.c_int, [P(SynthParams)]),
     ("msnv_synth_reference", C.c_int, [P(SynthParams), P(P(C.c_char_p)), P(P(C.c_int64)), P(P(C.c_char_p))]),
     ("msnv_synth_sample", C.c_int, [P(SynthParams), C.c_int32, P(C.c_char_p), P(P(C.c_uint8)), P(C.c_uint64)]),
     ("msnv_dataset_add_synth_samples", C.c_int, [_vp, P(SynthParams), C.c_int32, C.c_int32, C.c_int32]),

@@ -321,7 +321,7 @@ class Synth:
         lengths = C.POINTER(C.c_int64)()
         seqs = C.POINTER(C.c_char_p)()
         check(lib.msnv_synth_reference(C.byref(params), C.byref(names), C.byref(lengths), C.byref(seqs)))
-        n = params.n_species
+        n = lib.msnv_synth_contig_count(C.byref(params))
         self.names = [names[i].decode() for i in range(n)]
         self.lengths = [int(lengths[i]) for i in range(n)]
         self.seqs = [seqs[i] for i in range(n)]          # bytes copies

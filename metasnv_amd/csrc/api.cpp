@@ -219,7 +219,7 @@ extern "C" int msnv_dataset_add_synth_samples(msnv_dataset *ds, const msnv_synth
     clear_error();
     if (!ds || !p || count < 0) return fail(MSNV_EINVAL, "msnv_dataset_add_synth_samples: bad argument");
     if (ds->finalized) return fail(MSNV_EINVAL, "dataset is already finalized");
-    if ((size_t)p->n_species != ds->names.size()) return fail(MSNV_EINVAL, "synthetic parameters describe %d contigs, dataset has %zu", p->n_species, ds->names.size());
+    if ((size_t)msnv_synth_contig_count(p) != ds->names.size()) return fail(MSNV_EINVAL, "synthetic parameters describe %d contigs, dataset has %zu", msnv_synth_contig_count(p), ds->names.size());
     int nthreads = host_threads > 0 ? host_threads : (int)std::max(1u, std::thread::hardware_concurrency());
     nthreads = std::min(nthreads, std::max(1, (int)count));
     const std::vector<std::string> contigs = synth_contigs(*p);

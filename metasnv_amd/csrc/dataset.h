@@ -47,6 +47,8 @@ struct TilePair { uint32_t sample, read_lo, read_hi, max_depth, blk_lo, nblk, se
 struct WorkItem { uint32_t tile, pair_lo, pair_hi, chunk_lo, chunk_hi, slot, part_lo, part_hi; };   // slot: row of the coverage partials (tile-major); part_lo/hi: byte offset of the row
 // One chunk = up to CHUNK_READS consecutive reads of one (tile, sample) pair, with everything the
 // kernel needs to start loading (no dependent scalar loads on the critical path).
+constexpr uint32_t MERGE_MAX_PAIRS = 256;    // pairs per merged group of shallow (sample, tile) pairs (pack.cpp; kernels.hip: msnv_pileup_tiles_merged)
+constexpr uint32_t MERGE_MAX_DEPTH = 240;    // their depth bounds add up to at most this (byte bins)
 constexpr uint32_t CHUNK_READS = 128;
 constexpr uint32_t MAX_CHUNKS_PER_ITEM = 32;
 struct ChunkDesc { uint64_t hdr_base, seq_base; uint32_t sample, pair, nrd_flags, pad; };   // nrd | last_chunk << 16

@@ -43,6 +43,9 @@ struct DeviceCols {
     // ---- inputs (uploaded once by finalize)
     ReadHdr  *hdr = nullptr;         // 16-byte piece headers (wide kernel)
     PieceHdr *hdr8 = nullptr;        // 8-byte tile-local piece headers (narrow32 kernel, MSNV_LAYOUT=pieces)
+    PieceHdr *hdr8m = nullptr;       // headers of the merged groups of shallow pairs, group by group: pair index in bits 19+, ABSOLUTE seq offset / 8
+    uint32_t *tile_pair_merged = nullptr;   // per tile: first merged pair (they sit behind the tile's other pairs)
+    uint32_t  n_work_merged = 0;     // work[n_work_narrow .. + n_work_merged) = merged items
     uint32_t *blk = nullptr;         // dense layout: one descriptor per 32-base block (dense kernel)
     bool      dense = true;
     uint8_t  *seq = nullptr;

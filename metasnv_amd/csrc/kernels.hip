@@ -337,7 +337,8 @@ struct NarrowLds {
     Pair32   ev[N_EVCAP];
     ChunkDesc desc[MAX_CHUNKS_PER_ITEM];
     uint32_t carry[N_NT / 64 + 1];             // depth at the left edge of each wavefront's quarter of the tile ([4]: scratch for pieces that end at the tile end)
-    uint32_t evn, ev_base;
+    uint32_t gsample[MERGE_MAX_PAIRS];         // merged groups: sample of every pair of the group (piece headers carry the pair's index)
+    uint32_t evn, ev_base, flush_flag;
 };
 
 // Per-sample pass of the narrow kernel: prefix sum of start/end -> depth, minus the not-counted bases;
@@ -347,7 +348,12 @@ struct NarrowLds {
 // cover position 512 w - 1, counted while they were classified), so the prefix sum never leaves the wavefront; allele
 // events are placed per wavefront too (one LDS reservation in the staging buffer, or -- staging full, noisy reads --
 // one reservation in the event list; the lanes write at their prefix-sum offsets).
-template <typename LDS, int EXC_PAD>
+// MERGED: the bins hold a GROUP of shallow (sample, tile) pairs (pack.cpp: merged groups).  Their pieces went into the same
+// bins, every mismatching base was sent out as an event of its own while it was classified, and nobody needs the per-sample
+// coverage bytes (the gather recomputes the few cells at called positions from the pieces), so the pass only adds the group to
+// the running totals and the allele totals, marks positions where one sample MIGHT hold >= min_snvs reads of an allele (the
+// calling rule then reads the summed per-sample records), and leaves every bin zero.
+template <typename LDS, int EXC_PAD, bool MERGED = false>
 __device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_t (&tc)[N_PPT / 2], const uint32_t t0,
                                             const int tid, const int lane, const int wave, const uint32_t sample, const uint32_t k,
                                             const uint32_t split) {
@@ -371,7 +377,7 @@ __device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_
     const uint32_t c0 = v0 - ex.x, c1 = v1 - ex.y;
     tc[0] += c0 & 0x00ff00ffu; tc[1] += (c0 >> 8) & 0x00ff00ffu;   // running totals, two u16 per register: positions (0,2) (1,3) (4,6) (5,7)
     tc[2] += c1 & 0x00ff00ffu; tc[3] += (c1 >> 8) & 0x00ff00ffu;
-    *reinterpret_cast<uint2 *>(a.spill + (uint64_t)k * TILE + N_PPT * tid) = make_uint2(c0, c1);
+    if (!MERGED) *reinterpret_cast<uint2 *>(a.spill + (uint64_t)k * TILE + N_PPT * tid) = make_uint2(c0, c1);
     // ---- allele events.  The allele bins are only looked at here, and word by word again when events are written: the
     // registers of the next chunk's column loads are live across this pass.
     uint32_t pm = 0, myev;                                   // positions of mine with a mismatching allele; (position, allele) events
@@ -384,6 +390,24 @@ __device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_
         myev = count_nz_bytes(a0, a1);
     }
     if (!__any(pm != 0u)) return;                            // no mismatching allele in this wavefront's 512 positions
+    if (MERGED) {
+        while (pm) {
+            const uint32_t j = (uint32_t)__builtin_ctz(pm);
+            pm &= pm - 1u;
+            const uint32_t word = L.al[N_PPT * tid + j];
+            L.al[N_PPT * tid + j] = 0u;
+            const uint32_t gpos = t0 + N_PPT * tid + j;
+#pragma unroll
+            for (uint32_t x = 0; x < 4; ++x) {
+                const uint32_t n = (word >> (8u * x)) & 0xffu;
+                if (n) {
+                    atomicAdd(&a.tot[(uint64_t)x * a.npos + gpos], n);
+                    if (n >= a.min_snvs) atomicOr(&a.unc_bits[gpos >> 5], 1u << (gpos & 31u));
+                }
+            }
+        }
+        return;
+    }
     const uint32_t ei = (uint32_t)wave_inclusive_scan((int)myev);   // exclusive prefix of the lanes' event counts = their slots
     uint32_t res = 0;
     if (lane == 63) {
@@ -457,8 +481,9 @@ constexpr int N32_GROUPS = N_NT / N32_LANES;   // 64 pieces per round
 constexpr int N32_ROUNDS = N_HCAP / N32_GROUPS;   // 2
 static_assert(N32_LANES * 32 == SEG_MAX && N32_ROUNDS == 2, "narrow32 is written for 128-base pieces, 128-piece chunks");
 
-__device__ __forceinline__ void narrow_classify32(NarrowLds &L, const uint4 qa, const uint4 qb, const uint4 sq, const uint32_t P0,
-                                                  const int vhi, const uint32_t kq) {
+template <bool MERGED>
+__device__ __forceinline__ void narrow_classify32(NarrowLds &L, const PileupArgs &a, const uint4 qa, const uint4 qb, const uint4 sq, const uint32_t P0,
+                                                  const int vhi, const uint32_t kq, const uint32_t t0, const uint32_t pidx) {
     const uint32_t wi = P0 >> 3, sh = (P0 & 7u) * 4u;
     const uint32_t w0 = L.ref[wi], w1 = L.ref[wi + 1], w2 = L.ref[wi + 2], w3 = L.ref[wi + 3], w4 = L.ref[wi + 4];
     const uint32_t vmask = (vhi >= 32) ? 0xffffffffu : ((1u << vhi) - 1u);
@@ -491,12 +516,17 @@ __device__ __forceinline__ void narrow_classify32(NarrowLds &L, const uint4 qa, 
         const uint32_t word = (k == 0u) ? sw[0] : (k == 1u) ? sw[1] : (k == 2u) ? sw[2] : sw[3];
         const uint32_t code = (word >> (4u * jn)) & 0xfu;
         const uint32_t p = P0 + j;
-        if ((code & (code - 1u)) == 0u) atomicAdd(&L.al[p], 1u << (8u * (uint32_t)__builtin_ctz(code)));
-        else atomicAdd(&L.exc[p >> 3], 1ull << (8u * (p & 7u)));
+        if ((code & (code - 1u)) == 0u) {
+            const uint32_t x = (uint32_t)__builtin_ctz(code);
+            atomicAdd(&L.al[p], 1u << (8u * x));
+            // merged group: the bins mix samples, so the per-sample allele count leaves as one event per mismatching base
+            if (MERGED) stage_allele_event<NarrowLds, N_EVCAP>(L, a, Pair32{t0 + p, L.gsample[pidx] << 18 | x << 16 | 1u});
+        } else atomicAdd(&L.exc[p >> 3], 1ull << (8u * (p & 7u)));
     }
 }
 
-__global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32(PileupArgs a) {
+template <bool MERGED>
+__device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a) {
     ev_list(a);
     __shared__ NarrowLds L;
     const WorkItem w = a.work[blockIdx.x];
@@ -512,7 +542,7 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32(PileupArgs a)
     for (int i = tid; i < (int)(TILE / 8 + 4); i += N_NT) L.exc[i] = 0;
     L.spread[tid] = ((unsigned long long)((((uint32_t)tid >> 4) * 0x00204081u) & 0x01010101u) << 32) | (((uint32_t)tid & 0xfu) * 0x00204081u & 0x01010101u);
     for (int i = tid; i < (int)TILE; i += N_NT) L.al[i] = 0;
-    if (tid == 0) L.evn = 0;
+    if (tid == 0) { L.evn = 0; L.flush_flag = 0; }
     if (tid < N_NT / 64 + 1) L.carry[tid] = 0;
     uint32_t tc[N_PPT / 2] = {0u, 0u, 0u, 0u};                  // coverage totals of my 8 positions over the item's samples (u16 pairs)
 
@@ -535,7 +565,14 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32(PileupArgs a)
     uint2 hreg = load_hdr(0);
     if (tid < N_HCAP) L.hdr[0][tid] = hreg;
     hreg = load_hdr(1);
-    uint4 qa[N32_ROUNDS], qb[N32_ROUNDS], sq[N32_ROUNDS]; uint32_t P0[N32_ROUNDS]; int vh[N32_ROUNDS];
+    uint4 qa[N32_ROUNDS], qb[N32_ROUNDS], sq[N32_ROUNDS]; uint32_t P0[N32_ROUNDS], pidx[N32_ROUNDS]; int vh[N32_ROUNDS];
+    // merged groups: the samples of the group's pairs (the headers of the group's pieces carry the pair's index)
+    auto load_group = [&](const uint32_t c) {
+        if (!MERGED) return;
+        const ChunkDesc g = L.desc[c % MAX_CHUNKS_PER_ITEM];
+        if ((uint32_t)tid < g.pad) L.gsample[tid] = a.pairs[g.pair + (uint32_t)tid].sample;
+    };
+    if (nch) load_group(0u);
     auto issue_loads = [&](const uint32_t c) {
         const uint64_t sbase = L.desc[c % MAX_CHUNKS_PER_ITEM].seq_base;
         const uint8_t *seq = a.seq + sbase;
@@ -543,7 +580,8 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32(PileupArgs a)
 #pragma unroll
         for (int i = 0; i < N32_ROUNDS; ++i) {
             const uint2 h = L.hdr[c & 1u][grp + i * N32_GROUPS];     // all zero for empty slots
-            const uint32_t len = h.x >> 11;
+            const uint32_t len = (h.x >> 11) & 0xffu;                // (bits 19+: index of the piece's pair inside a merged group)
+            pidx[i] = h.x >> 19;
             const uint32_t s = h.x & (TILE - 1u);
             const uint64_t so = (uint64_t)h.y << 3;                  // seq byte offset of the piece inside the sample
             vh[i] = min(max((int)len - b0, 0), 32);
@@ -566,10 +604,16 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32(PileupArgs a)
         const bool last_chunk = (cd.nrd_flags >> 16) != 0u;
         if (prev_last) __syncthreads();                              // (A): the pass of the previous pair left every bin zero
         desc_refill(L.desc, a.chunks + w.chunk_lo, c, nch, tid);
-        if (L.evn >= (uint32_t)(N_EVCAP / 2)) flush_events<NarrowLds, N_NT, N_EVCAP>(L, a, tid);
+        // (merged groups stage events while they classify, so the fill level moves while the wavefronts pass this point: thread 0
+        // samples it ahead of barrier (B) and everybody acts on that one value a chunk later; what does not fit meanwhile goes
+        // straight to the list)
+        if (MERGED ? (L.flush_flag != 0u) : (L.evn >= (uint32_t)(N_EVCAP / 2))) {
+            flush_events<NarrowLds, N_NT, N_EVCAP>(L, a, tid);
+            if (MERGED && tid == 0) L.flush_flag = 0u;
+        }
         if (tid < N_HCAP) {
             const uint32_t hx = L.hdr[c & 1u][tid].x;
-            const uint32_t s = hx & (TILE - 1u), sb = s + (hx >> 11);
+            const uint32_t s = hx & (TILE - 1u), sb = s + ((hx >> 11) & 0xffu);
             if (sb != s) {                                           // coverage difference array: +1 at the start, -1 behind the end
                 atomicAdd(&L.start[s >> 2], 1u << (8u * (s & 3u)));
                 atomicAdd(&L.end[sb >> 2], 1u << (8u * (sb & 3u)));
@@ -579,19 +623,29 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32(PileupArgs a)
         }
 #pragma unroll
         for (int i = 0; i < N32_ROUNDS; ++i)
-            if (__any(vh[i] > 0)) narrow_classify32(L, qa[i], qb[i], sq[i], P0[i], vh[i], kq);
+            if (__any(vh[i] > 0)) narrow_classify32<MERGED>(L, a, qa[i], qb[i], sq[i], P0[i], vh[i], kq, t0, pidx[i]);
 
         if (tid < N_HCAP) L.hdr[(c + 1u) & 1u][tid] = hreg;          // headers of chunk c + 1 (zeros behind the last chunk)
         hreg = load_hdr(c + 2u);
+        if (MERGED && tid == 0 && L.evn >= (uint32_t)(N_EVCAP / 2)) L.flush_flag = 1u;
         __syncthreads();                                            // (B): this chunk is in the bins; the next chunk's headers are visible
         if (c + 1u < nch) issue_loads(c + 1u);                       // in flight under the per-sample pass
-        if (last_chunk) narrow_pass<NarrowLds, 0>(L, a, tc, t0, tid, lane, wave, cd.sample, cd.pair, cd.pad);
+        if (last_chunk) {
+            if (c + 1u < nch) load_group(c + 1u);                    // visible behind barrier (A) of the next chunk; this group is classified
+            narrow_pass<NarrowLds, 0, MERGED>(L, a, tc, t0, tid, lane, wave, cd.sample, cd.pair, cd.pad);
+        }
         prev_last = last_chunk;
     }
     __syncthreads();
     flush_events<NarrowLds, N_NT, N_EVCAP>(L, a, tid);
     store_part_row(a.part, w, tc, tid);
 }
+
+__global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32(PileupArgs a) { pileup_tiles_narrow32_body<false>(a); }
+// The same kernel over MERGED groups of shallow (sample, tile) pairs: a chunk holds pieces of several samples, one pass per
+// group instead of one per pair, no per-sample coverage spill (narrow_pass, narrow_classify32).  A pair of ~20 pieces costs
+// a chunk iteration and a pass over all 2048 positions whatever it holds (1600 samples at 1x ran at 24 % of the roofline).
+__global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_merged(PileupArgs a) { pileup_tiles_narrow32_body<true>(a); }
 
 // ------------------------------------------------------------------------------------------
 // msnv_pileup_tiles_dense: the narrow algorithm over the DENSE layout (dataset.h: BLK_*, pack.cpp: relayout_dense).
@@ -976,7 +1030,10 @@ __device__ __forceinline__ void add_u16(uint16_t *field, uint32_t v) {
 constexpr uint32_t GATHER_SPLIT = 4;
 constexpr uint32_t SCATTER_BLOCKS_PER_LIST = 32;
 struct TailArgs {
-    const SiteRec *sites; const uint32_t *tile_site_base, *tile_site_cnt, *tile_pair_start; const TilePair *pairs; const uint8_t *spill;
+    const SiteRec *sites; const uint32_t *tile_site_base, *tile_site_cnt, *tile_pair_start, *tile_pair_merged; const TilePair *pairs; const uint8_t *spill;
+    // merged groups of shallow pairs: their per-sample coverage at the called positions is recomputed from the pieces
+    const WorkItem *work_merged; const ChunkDesc *chunks; const PieceHdr *hdr8m; const uint8_t *seq, *qual; const uint32_t *ref4;
+    uint32_t n_merged_blocks, min_baseq;
     msnv_site_sample *out; uint16_t *cov_col; uint32_t n_samples, cap_out; const uint32_t *active_tiles; uint32_t n_gather_blocks;
     const Pair32 *events, *overflow; uint32_t *counters; uint32_t cap_list, cap_overflow;
     const unsigned long long *site_bits; const uint32_t *site_rank;
@@ -988,7 +1045,8 @@ __device__ __forceinline__ void gather_cov_block(const TailArgs &a, const uint32
     if (n <= part) return;
     const uint32_t base = a.tile_site_base[tile];
     if (base + n > a.cap_out) return;                   // the host sees the site count and retries with a larger buffer
-    const uint32_t ps = a.tile_pair_start[tile], np = a.tile_pair_start[tile + 1] - ps;
+    const uint32_t ps = a.tile_pair_start[tile], np = a.tile_pair_merged[tile] - ps;      // the merged pairs (behind the others) spill nothing
+    if (np == 0u) return;
     const uint32_t t0 = tile * TILE;
     const uint32_t mine = (n - part + GATHER_SPLIT - 1) / GATHER_SPLIT;
     const uint64_t work = (uint64_t)mine * np;
@@ -1039,6 +1097,77 @@ __device__ __forceinline__ void scatter_events_block(const TailArgs &a, const ui
         apply(a.overflow[i], false);
 }
 
+// Per-sample coverage of the called positions for the pairs of MERGED groups (no spill row exists for them): one workgroup
+// per merged work item walks the item's groups; the pieces of a group are checked against the tile's site bitmap, and every
+// counted base at a called position -- quality at or above the cutoff and either a match or one of A, C, G, T: the bases the
+// pileup kernel did not put into its exception bins -- adds one to the group's LDS table [site][pair of the group], which
+// is then written out with plain stores (every (site, sample) cell belongs to exactly one group).
+constexpr uint32_t GM_CELLS = 8192;           // u16 cells of the LDS table; a tile with more sites x pairs is done in batches of sites
+__device__ __forceinline__ void gather_merged_block(const TailArgs &a, const uint32_t bid) {
+    __shared__ unsigned long long s_bits[TILE / 64];
+    __shared__ uint32_t s_rank[TILE / 64];
+    __shared__ uint32_t s_cov[GM_CELLS / 2];
+    __shared__ uint32_t s_gsample[MERGE_MAX_PAIRS];
+    const WorkItem w = a.work_merged[bid];
+    const uint32_t tile = w.tile, n = a.tile_site_cnt[tile];
+    if (n == 0u) return;
+    const uint32_t base = a.tile_site_base[tile];
+    if (base + n > a.cap_out) return;                   // the host sees the site count and retries with a larger buffer
+    const uint32_t t0 = tile * TILE;
+    const uint32_t tid = threadIdx.x;
+    if (tid < TILE / 64) { s_bits[tid] = a.site_bits[(t0 >> 6) + tid]; s_rank[tid] = a.site_rank[(t0 >> 6) + tid] - base; }
+    const uint32_t kq = min(a.min_baseq, 128u);
+    uint32_t c = w.chunk_lo;
+    while (c < w.chunk_hi) {
+        // one group = the chunks up to and including the one flagged "last"
+        const ChunkDesc g = a.chunks[c];
+        uint32_t n_pieces = 0, ce = c;
+        for (;;) { const uint32_t f = a.chunks[ce].nrd_flags; n_pieces += f & 0xffffu; ++ce; if ((f >> 16) || ce >= w.chunk_hi) break; }
+        const uint32_t m = g.pad;                         // pairs of the group
+        const uint32_t batch = max(1u, GM_CELLS / m);     // sites per round
+        __syncthreads();                                  // the previous group's table and sample list are no longer read
+        if (tid < m) s_gsample[tid] = a.pairs[g.pair + tid].sample;
+        for (uint32_t j0 = 0; j0 < n; j0 += batch) {
+            const uint32_t nj = min(batch, n - j0);
+            for (uint32_t i = tid; i < (nj * m + 1u) / 2u; i += blockDim.x) s_cov[i] = 0u;
+            __syncthreads();
+            for (uint32_t pi = tid; pi < n_pieces; pi += blockDim.x) {
+                const PieceHdr h = a.hdr8m[g.hdr_base + pi];
+                const uint32_t s = h.w0 & (TILE - 1u), len = (h.w0 >> 11) & 0xffu, pidx = h.w0 >> 19;
+                const uint64_t so = (uint64_t)h.seqoff8 << 3;
+                for (uint32_t wd = s >> 6; wd <= (s + len - 1u) >> 6 && wd < TILE / 64; ++wd) {
+                    unsigned long long bits = s_bits[wd];
+                    if (wd == (s >> 6)) bits &= ~0ull << (s & 63u);
+                    if (wd == ((s + len - 1u) >> 6)) bits &= ~0ull >> (63u - ((s + len - 1u) & 63u));
+                    while (bits) {
+                        const uint32_t b = (uint32_t)__builtin_ctzll(bits);
+                        const unsigned long long low = bits & (0ull - bits);
+                        bits ^= low;
+                        const uint32_t j = s_rank[wd] + (uint32_t)__popcll(s_bits[wd] & (low - 1ull));   // site index inside the tile
+                        if (j < j0 || j >= j0 + nj) continue;
+                        const uint32_t q = (wd << 6) + b, o = q - s;
+                        const uint32_t qv = a.qual[2ull * so + o];
+                        const uint32_t code = (a.seq[so + (o >> 1)] >> (4u * (o & 1u))) & 0xfu;
+                        const uint32_t gp = t0 + q;
+                        const uint32_t rc = (a.ref4[gp >> 3] >> (4u * (gp & 7u))) & 0xfu;
+                        if (qv >= kq && (code == rc || (code != 0u && (code & (code - 1u)) == 0u))) {
+                            const uint32_t cell = (j - j0) * m + pidx;
+                            atomicAdd(&s_cov[cell >> 1], 1u << (16u * (cell & 1u)));
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            for (uint32_t i = tid; i < nj * m; i += blockDim.x) {
+                const uint32_t v = (s_cov[i >> 1] >> (16u * (i & 1u))) & 0xffffu;
+                if (v) a.cov_col[(uint64_t)(base + j0 + i / m) * a.n_samples + s_gsample[i % m]] = (uint16_t)v;
+            }
+            __syncthreads();
+        }
+        c = ce;
+    }
+}
+
 // msnv_gather_scatter: one launch, two independent halves working on the zeroed (msnv_gate_sites) per-sample records.
 //   blocks [0, n_gather_blocks): per-sample coverage of every surviving site, from the spilled bytes;
 //   the other SCATTER_BLOCKS_PER_LIST x EV_LISTS blocks: per-sample allele counts from the event sub-lists (sparse) and the
@@ -1054,7 +1183,8 @@ __global__ __launch_bounds__(256) void msnv_gather_scatter(TailArgs a) {
         a.counters[0] = (uint32_t)min(total, 0xffffffffull);
     }
     if (blockIdx.x < n_scatter) scatter_events_block(a, blockIdx.x % SCATTER_BLOCKS_PER_LIST, blockIdx.x / SCATTER_BLOCKS_PER_LIST);
-    else gather_cov_block(a, blockIdx.x - n_scatter);
+    else if (blockIdx.x < n_scatter + a.n_merged_blocks) gather_merged_block(a, blockIdx.x - n_scatter);
+    else gather_cov_block(a, blockIdx.x - n_scatter - a.n_merged_blocks);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1252,7 +1382,7 @@ int dev_stream_create(void **stream) { hipStream_t s; HIP_TRY(hipStreamCreateWit
 void dev_stream_destroy(void *stream) { if (stream) (void)hipStreamDestroy((hipStream_t)stream); }
 
 void dev_free_all(DeviceCols &d) {
-    void *ptrs[] = {d.hdr, d.hdr8, d.blk, d.seq, d.qual, d.s_read_base, d.s_seq_base, d.ref4, d.ref_lc, d.pairs,
+    void *ptrs[] = {d.hdr, d.hdr8, d.hdr8m, d.tile_pair_merged, d.blk, d.seq, d.qual, d.s_read_base, d.s_seq_base, d.ref4, d.ref_lc, d.pairs,
                     d.tile_pair_start, d.work, d.chunks, d.tile_vbeg, d.tile_vend, d.tot, d.part, d.tile_slot_start, d.tile_slot_u16, d.tile_slot_wide, d.slot_off, d.spill, d.events, d.overflow, d.counters, d.ind4,
                     d.sites, d.tile_site_base, d.tile_site_cnt, d.out, d.cov_col, d.site_flags,
                     d.cov_iv, d.s_cov_base, d.cov_pairs, d.cov_work, d.tile_len, d.tile_contig_dev, d.cov_acc};
@@ -1302,20 +1432,25 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
         a.events = d.events; a.cap_events = d.cap_events / EV_LISTS; a.ev_count = nullptr; a.overflow = d.overflow; a.cap_overflow = d.cap_overflow;
         a.counters = counters; a.min_baseq = (uint32_t)std::max(0, p.min_baseq);
         a.ind4 = d.ind4; a.unc_bits = d.unc_bits; a.min_snvs = (uint32_t)std::max(0, p.calling_threshold);
-        const uint32_t n_narrow = d.n_work_narrow;
-        // narrow work items (byte bins) and wide ones (16-bit bins) touch disjoint (tile, sample) pairs
+        const uint32_t n_narrow = d.n_work_narrow, n_merged = d.n_work_merged;
+        // narrow work items (byte bins), merged groups of shallow pairs and wide items (16-bit bins) touch disjoint (tile, sample) pairs
         if (n_narrow && d.dense) hipLaunchKernelGGL(msnv_pileup_tiles_dense, dim3(n_narrow), dim3(N_NT), 0, st, a);
         else if (n_narrow) hipLaunchKernelGGL(msnv_pileup_tiles_narrow32, dim3(n_narrow), dim3(N_NT), 0, st, a);
-        if (d.n_work > n_narrow) {
+        if (n_merged) {
             PileupArgs b = a;
-            b.work = d.work + n_narrow;
-            hipLaunchKernelGGL(msnv_pileup_tiles_wide, dim3(d.n_work - n_narrow), dim3(W_NT), 0, st, b);
+            b.work = d.work + n_narrow; b.hdr8 = d.hdr8m;
+            hipLaunchKernelGGL(msnv_pileup_tiles_merged, dim3(n_merged), dim3(N_NT), 0, st, b);
+        }
+        if (d.n_work > n_narrow + n_merged) {
+            PileupArgs b = a;
+            b.work = d.work + n_narrow + n_merged;
+            hipLaunchKernelGGL(msnv_pileup_tiles_wide, dim3(d.n_work - n_narrow - n_merged), dim3(W_NT), 0, st, b);
         }
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(ev_pile1, st));
     const uint32_t cap_out = (uint32_t)std::min<uint64_t>(d.cap_out_sites, 0xffffffffull);
-    const bool decide_in_gate = !d.any_split;          // else a sample's pairs must be summed first: msnv_decide_sites behind the scatter
+    const bool decide_in_gate = !d.any_split && !d.n_work_merged;   // else per-sample sums come first: msnv_decide_sites behind the scatter
     if (d.n_active_tiles) {
         GateArgs g;
         g.tot = d.tot; g.part = d.part; g.slot_off = d.slot_off; g.tile_slot_start = d.tile_slot_start; g.tile_slot_u16 = d.tile_slot_u16; g.tile_slot_wide = d.tile_slot_wide;
@@ -1334,9 +1469,11 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
         ta.sites = d.sites; ta.tile_site_base = d.tile_site_base; ta.tile_site_cnt = d.tile_site_cnt; ta.tile_pair_start = d.tile_pair_start;
         ta.pairs = d.pairs; ta.spill = d.spill; ta.out = d.out; ta.cov_col = d.cov_col; ta.n_samples = d.n_samples; ta.cap_out = cap_out; ta.active_tiles = d.active_tiles;
         ta.n_gather_blocks = d.n_active_tiles * GATHER_SPLIT;
+        ta.tile_pair_merged = d.tile_pair_merged; ta.work_merged = d.work + d.n_work_narrow; ta.chunks = d.chunks; ta.hdr8m = d.hdr8m;
+        ta.seq = d.seq; ta.qual = d.qual; ta.ref4 = d.ref4; ta.n_merged_blocks = d.n_work_merged; ta.min_baseq = (uint32_t)std::max(0, p.min_baseq);
         ta.events = d.events; ta.overflow = d.overflow; ta.counters = counters; ta.cap_list = d.cap_events / EV_LISTS; ta.cap_overflow = d.cap_overflow;
         ta.site_bits = d.site_bits; ta.site_rank = d.site_rank;
-        hipLaunchKernelGGL(msnv_gather_scatter, dim3(ta.n_gather_blocks + SCATTER_BLOCKS_PER_LIST * EV_LISTS), dim3(256), 0, st, ta);
+        hipLaunchKernelGGL(msnv_gather_scatter, dim3(ta.n_gather_blocks + ta.n_merged_blocks + SCATTER_BLOCKS_PER_LIST * EV_LISTS), dim3(256), 0, st, ta);
         HIP_TRY(hipGetLastError());
     }
     if (ev4) HIP_TRY(hipEventRecord(ev4, st));

@@ -801,12 +801,32 @@ int finalize_dataset(msnv_dataset &ds) {
                 }
                 pairs[fill[p.tile]++] = tp;
             }
-        // inside a tile: narrow pairs (every per-position count fits a byte) first, then wide ones
-        for (uint64_t t = 0; t < nt; ++t)
-            std::stable_partition(pairs.begin() + tps[t], pairs.begin() + tps[t + 1], [](const TilePair &p) { return p.max_depth < NARROW_MAX_DEPTH; });
+        // inside a tile: narrow pairs (every per-position count fits a byte) first, then wide ones, then the SHALLOW pairs that
+        // are merged into groups (msnv_pileup_tiles_merged): pad = 2.  A pair of ~20 pieces costs the narrow kernel a chunk
+        // iteration and a pass over all 2048 positions whatever it holds, so cohorts of many shallow samples (1600 x 1x ran at
+        // 24 % of the roofline) and contigs much shorter than a tile put several pairs into the same bins.
+        // MSNV_SHALLOW_PIECES: number of pieces up to which a pair counts as shallow (default 48 = 3/8 of a chunk; 0 = never
+        // merge); its depth bound must leave room for at least three pairs in a group, and a tile needs two such pairs.
+        const uint32_t shallow_pieces = [] { const char *e = getenv("MSNV_SHALLOW_PIECES"); const int v = e ? atoi(e) : 48; return (uint32_t)std::max(0, v); }();   // read per dataset (tests switch it)
+        const bool can_merge = !dense && shallow_pieces > 0 && sbase[S] < (32ull << 30);   // merged headers hold absolute seq offsets / 8 in 32 bits
+        auto is_shallow = [&](const TilePair &p) { return p.read_hi - p.read_lo <= shallow_pieces && p.max_depth <= MERGE_MAX_DEPTH / 3 && !p.pad; };
+        for (uint64_t t = 0; t < nt; ++t) {
+            auto b = pairs.begin() + tps[t], e = pairs.begin() + tps[t + 1];
+            uint32_t n_shallow = 0;
+            if (can_merge) for (auto it = b; it != e; ++it) if (is_shallow(*it)) ++n_shallow;
+            if (n_shallow >= 2) for (auto it = b; it != e; ++it) if (is_shallow(*it)) it->pad = 2;
+            std::stable_sort(b, e, [](const TilePair &x, const TilePair &y) {
+                auto cls = [](const TilePair &p) { return p.pad == 2 ? 2 : p.max_depth < NARROW_MAX_DEPTH ? 0 : 1; };
+                return cls(x) < cls(y);
+            });
+        }
     }
+    std::vector<uint32_t> tpm(nt + 1, 0);                           // per tile: first merged pair
+    for (uint64_t t = 0; t < nt; ++t) { uint32_t k = tps[t]; while (k < tps[t + 1] && pairs[k].pad != 2) ++k; tpm[t] = k; }
     // ---- work list: split each tile's pairs so that work items carry similar read counts
     std::vector<WorkItem> work;
+    struct MergedGroup { uint32_t pair_lo, pair_hi; };
+    std::vector<MergedGroup> groups;                                // in work-item order
     {
         uint64_t total_reads_in_pairs = 0;
         for (const TilePair &p : pairs) total_reads_in_pairs += p.read_hi - p.read_lo;
@@ -820,7 +840,7 @@ int finalize_dataset(msnv_dataset &ds) {
         // (0.595 -> 0.612 ms) -- neighbouring items of a tile share the reference and the allele-total lines in L2.
         uint64_t target = 1000;
         if (const char *e = getenv("MSNV_ITEM_PIECES")) target = std::max<uint64_t>(64, (uint64_t)atoll(e));
-        std::vector<WorkItem> wide;
+        std::vector<WorkItem> wide, merged;
         auto chunks_of = [&](const TilePair &q) -> uint64_t {
             const bool nar = q.max_depth < NARROW_MAX_DEPTH;
             if (dense && nar) return (q.nblk + DENSE_CHUNK_BLOCKS - 1) / DENSE_CHUNK_BLOCKS;
@@ -844,12 +864,29 @@ int finalize_dataset(msnv_dataset &ds) {
                 const double left = (double)(total_reads_in_pairs - seen) / wave_pieces;
                 target = left < u3 ? std::max<uint64_t>(64, base_target / 8) : left < u2 ? std::max<uint64_t>(64, base_target / 4) : left < u1 ? std::max<uint64_t>(64, base_target / 2) : base_target;
             }
-            for (uint32_t k = tps[t]; k < tps[t + 1]; ++k) {
+            // merged groups: consecutive shallow pairs whose depth bounds add up to <= MERGE_MAX_DEPTH; an item = whole groups
+            {
+                uint32_t g_lo = tpm[t], i_lo = tpm[t];
+                uint64_t g_depth = 0, i_pieces = 0, i_chunks = 0, g_pieces = 0;
+                for (uint32_t k = tpm[t]; k < tps[t + 1]; ++k) {
+                    const uint32_t nr = pairs[k].read_hi - pairs[k].read_lo;
+                    seen += nr;
+                    if (k > g_lo && (g_depth + pairs[k].max_depth > MERGE_MAX_DEPTH || k - g_lo >= MERGE_MAX_PAIRS)) {   // close the group
+                        groups.push_back(MergedGroup{g_lo, k});
+                        i_pieces += g_pieces; i_chunks += (g_pieces + CHUNK_READS - 1) / CHUNK_READS;
+                        g_lo = k; g_depth = 0; g_pieces = 0;
+                        if (i_pieces >= target || i_chunks >= MAX_CHUNKS_PER_ITEM / 2) { merged.push_back(WorkItem{(uint32_t)t, i_lo, k, 0, 0, 0, 0, 0}); i_lo = k; i_pieces = 0; i_chunks = 0; }
+                    }
+                    g_depth += pairs[k].max_depth; g_pieces += nr;
+                }
+                if (tps[t + 1] > g_lo) { groups.push_back(MergedGroup{g_lo, tps[t + 1]}); merged.push_back(WorkItem{(uint32_t)t, i_lo, tps[t + 1], 0, 0, 0, 0, 0}); }
+            }
+            for (uint32_t k = tps[t]; k < tpm[t]; ++k) {
                 const uint32_t nr = pairs[k].read_hi - pairs[k].read_lo;
                 seen += nr;
                 acc += nr; nch += chunks_of(pairs[k]);
                 const bool narrow = pairs[k].max_depth < NARROW_MAX_DEPTH;
-                const bool boundary = k + 1 == tps[t + 1] || (narrow != (pairs[k + 1].max_depth < NARROW_MAX_DEPTH));
+                const bool boundary = k + 1 == tpm[t] || (narrow != (pairs[k + 1].max_depth < NARROW_MAX_DEPTH));
                 const uint64_t next_ch = boundary ? 0 : chunks_of(pairs[k + 1]);
                 if (acc >= target || boundary || nch + next_ch > MAX_CHUNKS_PER_ITEM) {
                     (narrow ? work : wide).push_back(WorkItem{(uint32_t)t, lo, k + 1, 0, 0, 0, 0, 0}); lo = k + 1; acc = 0; nch = 0;
@@ -857,6 +894,8 @@ int finalize_dataset(msnv_dataset &ds) {
             }
         }
         d->n_work_narrow = (uint32_t)work.size();
+        d->n_work_merged = (uint32_t)merged.size();
+        work.insert(work.end(), merged.begin(), merged.end());
         work.insert(work.end(), wide.begin(), wide.end());
     }
     // ---- coverage partials: one row of TILE counters per work item, rows of a tile contiguous (the gate kernel sums them):
@@ -868,7 +907,7 @@ int finalize_dataset(msnv_dataset &ds) {
         for (uint64_t t = 0; t < nt; ++t) tss[t + 1] += tss[t];
         std::vector<uint8_t> cls(work.size(), 0);
         for (size_t i = 0; i < work.size(); ++i) {
-            if (i >= d->n_work_narrow) { cls[i] = 2; continue; }
+            if (i >= d->n_work_narrow + d->n_work_merged) { cls[i] = 2; continue; }
             uint64_t bound = 0;
             for (uint32_t k = work[i].pair_lo; k < work[i].pair_hi; ++k) bound += pairs[k].max_depth;
             cls[i] = bound < 256 ? 0 : 1;
@@ -923,6 +962,35 @@ int finalize_dataset(msnv_dataset &ds) {
             }
         }
         w.chunk_hi = (uint32_t)chunks.size();
+    }
+    // ---- merged groups: their piece headers, group by group, and chunks that run across the group's pairs
+    {
+        std::vector<PieceHdr> hm;
+        size_t gi = 0;
+        for (uint32_t wi = d->n_work_narrow; wi < d->n_work_narrow + d->n_work_merged; ++wi) {
+            WorkItem &w = work[wi];
+            w.chunk_lo = (uint32_t)chunks.size();
+            for (; gi < groups.size() && groups[gi].pair_lo >= w.pair_lo && groups[gi].pair_hi <= w.pair_hi; ++gi) {
+                const MergedGroup &g = groups[gi];
+                const uint64_t h0 = hm.size();
+                for (uint32_t k = g.pair_lo; k < g.pair_hi; ++k) {
+                    const TilePair &p = pairs[k];
+                    const SampleCols &sc = ds.samples[p.sample];
+                    for (uint32_t r = p.read_lo; r < p.read_hi; ++r)
+                        hm.push_back(PieceHdr{(sc.hdr[r].gpos % TILE) | sc.hdr[r].cig << 11 | (k - g.pair_lo) << 19, (uint32_t)((sbase[p.sample] + sc.hdr[r].seqoff) >> 3)});
+                }
+                const uint64_t n_h = hm.size() - h0;
+                for (uint64_t r = 0; r < n_h; r += CHUNK_READS) {
+                    const uint32_t n = (uint32_t)std::min<uint64_t>(CHUNK_READS, n_h - r);
+                    chunks.push_back(ChunkDesc{h0 + r, 0, pairs[g.pair_lo].sample, g.pair_lo, n | (r + n >= n_h ? 1u << 16 : 0u), g.pair_hi - g.pair_lo});
+                }
+            }
+            w.chunk_hi = (uint32_t)chunks.size();
+        }
+        if (gi != groups.size()) return fail(MSNV_EINVAL, "internal: merged groups and work items disagree");
+        ds.info.bytes_headers += hm.size() * sizeof(PieceHdr);
+        if (int rc = upload_vec(&d->hdr8m, hm, &d->device_bytes, 1)) return rc;
+        if (int rc = upload_vec(&d->tile_pair_merged, tpm, &d->device_bytes)) return rc;
     }
     if (int rc = upload_vec(&d->chunks, chunks, &d->device_bytes, 1)) return rc;
     d->n_pairs = (uint32_t)pairs.size(); d->n_work = (uint32_t)work.size();
@@ -1052,7 +1120,7 @@ int finalize_dataset(msnv_dataset &ds) {
     if (int rc = dev_alloc((void **)&d->ind4, (npos / 8 + npos / 32 + 2) * sizeof(uint32_t), &d->device_bytes)) return rc;
     if (int rc = dev_memset(d->ind4, 0, (npos / 8 + npos / 32 + 2) * sizeof(uint32_t))) return rc;
     d->unc_bits = d->ind4 + npos / 8 + 1;
-    for (const TilePair &tp : pairs) if (tp.pad) { d->any_split = true; break; }
+    for (const TilePair &tp : pairs) if (tp.pad == 1) { d->any_split = true; break; }
     if (int rc = dev_alloc((void **)&d->site_bits, (npos / 64 + 1) * sizeof(unsigned long long), &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->site_rank, (npos / 64 + 1) * sizeof(uint32_t), &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->tile_site_base, (nt + 1) * sizeof(uint32_t), &d->device_bytes)) return rc;

@@ -41,7 +41,37 @@ struct Rng {   // xoshiro256** seeded by splitmix64
 
 static const char kBases[4] = {'A', 'C', 'G', 'T'};
 
-static std::string synth_contig(const msnv_synth_params &p, int k) {
+// Contig table.  Default (contigs_per_species_max <= 1): n_species contigs of contig_len bases, one per species.  Otherwise
+// (BASELINE configs[2] / [3] shapes) species k has 1 .. contigs_per_species_max contigs named
+// refGenome<k>clus.c<j> whose lengths add up to contig_len (the SPECIES length): random cuts, every contig at least 200 bases.
+struct SynthContig { int species; int64_t len; int idx_in_species; };
+static std::vector<SynthContig> synth_contig_table(const msnv_synth_params &p) {
+    std::vector<SynthContig> v;
+    if (p.contigs_per_species_max <= 1) {
+        for (int k = 0; k < p.n_species; ++k) v.push_back(SynthContig{k, p.contig_len, 0});
+        return v;
+    }
+    Rng r(p.seed * 7349ull + 99991);
+    for (int k = 0; k < p.n_species; ++k) {
+        int n = 1 + (int)r.below((uint32_t)p.contigs_per_species_max);
+        n = (int)std::max<int64_t>(1, std::min<int64_t>(n, p.contig_len / 400));
+        std::vector<int64_t> cuts;
+        for (int j = 0; j + 1 < n; ++j) cuts.push_back(200 + (int64_t)(r.uni() * (double)(p.contig_len - 400)));
+        cuts.push_back(0); cuts.push_back(p.contig_len);
+        std::sort(cuts.begin(), cuts.end());
+        int j = 0;
+        for (size_t c = 0; c + 1 < cuts.size(); ++c) {
+            const int64_t len = cuts[c + 1] - cuts[c];
+            if (len < 200 && c + 2 < cuts.size()) { cuts[c + 1] = cuts[c]; continue; }      // merge slivers into the next contig
+            if (len > 0) v.push_back(SynthContig{k, len, j++});
+        }
+    }
+    return v;
+}
+
+static std::string synth_contig(const msnv_synth_params &p0, int k, int64_t len) {
+    msnv_synth_params p = p0;
+    p.contig_len = len;
     Rng r(p.seed * 1000003ull + 1001 + (uint64_t)k);
     std::string s((size_t)p.contig_len, 'A');
     for (int64_t i = 0; i < p.contig_len; ++i) s[(size_t)i] = kBases[r.next() >> 62];
@@ -60,11 +90,11 @@ static std::string synth_contig(const msnv_synth_params &p, int k) {
 
 // SNV sites of species k: alt base and the subspecies that carries it
 struct SnvSite { int64_t pos; uint8_t alt; uint8_t carrier; };
-static std::vector<SnvSite> synth_sites(const msnv_synth_params &p, int k, const char *seq) {
+static std::vector<SnvSite> synth_sites(const msnv_synth_params &p, int k, int species, int64_t len, const char *seq) {
     Rng r(p.seed * 7919ull + 31337 + (uint64_t)k);
     std::vector<SnvSite> v;
-    int nsub = k % 3 + 1;
-    for (int64_t i = 0; i < p.contig_len; ++i) {
+    int nsub = species % 3 + 1;
+    for (int64_t i = 0; i < len; ++i) {
         if (r.uni() < p.snv_density) {
             uint8_t ref = nt16_of_char((unsigned char)seq[i]);
             uint8_t alt;
@@ -95,16 +125,32 @@ void synth_sample_records(const msnv_synth_params &p, int sample, const std::vec
     uint64_t serial = 0;
     std::vector<uint8_t> codes, quals;
     std::vector<uint32_t> cigar;
-    for (int k = 0; k < p.n_species; ++k) {
+    const std::vector<SynthContig> table = synth_contig_table(p);
+    // species_per_sample > 0 (configs[2] / [3]): this sample carries exactly that many random species, the others are absent
+    std::vector<uint8_t> carried;
+    if (p.species_per_sample > 0) {
+        carried.assign((size_t)p.n_species, 0);
+        Rng rs(p.seed * 104729ull + 777 + (uint64_t)sample);
+        int want = std::min(p.species_per_sample, p.n_species), have = 0;
+        while (have < want) { const uint32_t k = rs.below((uint32_t)p.n_species); if (!carried[k]) { carried[k] = 1; ++have; } }
+    }
+    int cur_species = -1, nsub = 1, my_sub = 0;
+    double cov = 0.0;
+    for (int k = 0; k < (int)table.size(); ++k) {
         const std::string &seq = contigs[(size_t)k];
         const int64_t L = (int64_t)seq.size();
-        int nsub = k % 3 + 1;
-        int my_sub = (int)r.below((uint32_t)nsub);
-        double cov = 0.0;
-        if (r.uni() >= p.frac_absent) cov = std::exp(std::log(p.mean_cov) + p.sigma_cov * r.normal());
+        if (table[(size_t)k].species != cur_species) {           // per species: subspecies of this sample and its coverage
+            cur_species = table[(size_t)k].species;
+            nsub = cur_species % 3 + 1;
+            my_sub = (int)r.below((uint32_t)nsub);
+            cov = 0.0;
+            if (p.species_per_sample > 0) { if (carried[(size_t)cur_species]) cov = std::exp(std::log(p.mean_cov) + p.sigma_cov * r.normal()); }
+            else if (r.uni() >= p.frac_absent) cov = std::exp(std::log(p.mean_cov) + p.sigma_cov * r.normal());
+        }
         int64_t n_reads = (int64_t)(cov * (double)L / p.read_len);
         if (L < p.read_len + 8) n_reads = 0;
-        std::vector<SnvSite> sites = synth_sites(p, k, seq.data());
+        if (n_reads == 0 && p.species_per_sample > 0) continue;    // sparse cohorts: nothing to draw for an absent species
+        std::vector<SnvSite> sites = synth_sites(p, k, cur_species, L, seq.data());
         std::vector<uint8_t> site_alt((size_t)L, 0), site_car((size_t)L, 0);
         for (const SnvSite &s : sites) { site_alt[(size_t)s.pos] = s.alt; site_car[(size_t)s.pos] = (uint8_t)(s.carrier + 1); }
         if (p.frac_paired > 0) n_reads = (int64_t)((double)n_reads / (1.0 + p.frac_paired));     // a fragment yields two reads
@@ -206,9 +252,11 @@ void synth_sample_records(const msnv_synth_params &p, int sample, const std::vec
 
 std::vector<std::string> synth_contigs(const msnv_synth_params &p) {
     std::vector<std::string> v;
-    for (int k = 0; k < p.n_species; ++k) v.push_back(synth_contig(p, k));
+    const std::vector<SynthContig> table = synth_contig_table(p);
+    for (size_t k = 0; k < table.size(); ++k) v.push_back(synth_contig(p, (int)k, table[k].len));
     return v;
 }
+int synth_contig_count(const msnv_synth_params &p) { return (int)synth_contig_table(p).size(); }
 
 }  // namespace msnv
 
@@ -220,20 +268,25 @@ extern "C" void msnv_synth_params_default(msnv_synth_params *p) {
     p->error_rate = 0.001; p->frac_lowq = 0.10; p->frac_indel_reads = 0.035; p->frac_clip_reads = 0.025;
     p->frac_flagged = 0.01; p->lowercase_ref = 0; p->seed = 1;
     p->frac_paired = 0.0;
+    p->contigs_per_species_max = 0; p->species_per_sample = 0;
 }
+
+extern "C" int msnv_synth_contig_count(const msnv_synth_params *p) { return p ? msnv::synth_contig_count(*p) : 0; }
 
 extern "C" int msnv_synth_reference(const msnv_synth_params *p, char ***names, int64_t **lengths, char ***seqs) {
     clear_error();
     if (!p || !names || !lengths || !seqs) return fail(MSNV_EINVAL, "msnv_synth_reference: NULL argument");
-    int n = p->n_species;
+    const std::vector<SynthContig> table = synth_contig_table(*p);
+    int n = (int)table.size();
     *names = (char **)calloc((size_t)n + 1, sizeof(char *));
     *seqs = (char **)calloc((size_t)n + 1, sizeof(char *));
     *lengths = (int64_t *)calloc((size_t)n + 1, sizeof(int64_t));
     for (int k = 0; k < n; ++k) {
         char nm[64];
-        snprintf(nm, sizeof nm, "refGenome%dclus", k + 1);
+        if (p->contigs_per_species_max <= 1) snprintf(nm, sizeof nm, "refGenome%dclus", k + 1);
+        else snprintf(nm, sizeof nm, "refGenome%dclus.c%d", table[(size_t)k].species + 1, table[(size_t)k].idx_in_species + 1);   // species = name up to the first '.'
         (*names)[k] = strdup(nm);
-        std::string s = synth_contig(*p, k);
+        std::string s = synth_contig(*p, k, table[(size_t)k].len);
         (*seqs)[k] = strdup(s.c_str());
         (*lengths)[k] = (int64_t)s.size();
     }
@@ -245,7 +298,8 @@ extern "C" int msnv_synth_sample(const msnv_synth_params *p, int32_t sample_idx,
     clear_error();
     if (!p || !seqs || !records || !n_bytes) return fail(MSNV_EINVAL, "msnv_synth_sample: NULL argument");
     std::vector<std::string> contigs;
-    for (int k = 0; k < p->n_species; ++k) contigs.emplace_back(seqs[k]);
+    const int n_contigs = synth_contig_count(*p);
+    for (int k = 0; k < n_contigs; ++k) contigs.emplace_back(seqs[k]);
     std::vector<uint8_t> out;
     synth_sample_records(*p, sample_idx, contigs, out);
     *records = (uint8_t *)malloc(out.size() + 1);

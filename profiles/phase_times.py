@@ -2,7 +2,7 @@ import sys, os
 os.environ["MSNV_PHASE_TIMES"] = "1"
 sys.path.insert(0, os.getcwd())
 from metasnv_amd import core
-sp = core.synth_params(n_species=3, contig_len=300000, n_samples=int(os.environ.get("NS", "160")), mean_cov=10.0, seed=1,
+sp = core.synth_params(n_species=3, contig_len=300000, n_samples=int(os.environ.get("NS", "160")), mean_cov=float(os.environ.get("COV", "10")), seed=1,
                        **({"error_rate": float(os.environ["ERR"])} if "ERR" in os.environ else {}))
 syn = core.Synth(sp); ctx = core.Context(0)
 ds = core.Dataset(ctx, syn.names, syn.lengths, syn.seqs)

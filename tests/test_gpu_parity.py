@@ -292,6 +292,28 @@ def test_shallow_cohort_and_contigs_shorter_than_a_tile(layout, monkeypatch):
     assert prod[2]["n_pairs"] > 2000 and prod[0].count("\n") > 100
 
 
+@pytest.mark.parametrize("shallow_pieces", ["0", "48", "400"])
+def test_merged_groups_of_shallow_pairs(shallow_pieces, monkeypatch):
+    """Cohort of many shallow samples: the (sample, tile) pairs whose depth bound is at most MSNV_SHALLOW_MAX are merged into
+    groups that share one set of LDS bins and one pass (msnv_pileup_tiles_merged); their per-sample allele counts travel as one
+    event per mismatching base and their per-sample coverage at the called positions is recomputed from the pieces.  Same bytes
+    as the oracle with merging off (0), with the default bound (48 pieces: the ~1x samples merge, the deeper ones do not) and with
+    every pair of the cohort merged (400), population and individual calls (threshold 2 is reached inside single samples)."""
+    monkeypatch.setenv("MSNV_SHALLOW_PIECES", shallow_pieces)
+    monkeypatch.setenv("MSNV_LAYOUT", "pieces")
+    sp = core.synth_params(n_species=3, contig_len=7000, n_samples=150, mean_cov=1.5, sigma_cov=1.0, snv_density=0.04, error_rate=0.01,
+                           frac_absent=0.15, lowercase_ref=1, seed=1700)
+    syn = core.Synth(sp)
+    samples = [syn.sample_records(i) for i in range(sp.n_samples)]
+    for kw in (dict(min_coverage=3, calling_threshold=2), dict(min_coverage=4, calling_threshold=4, min_fraction=0.2)):
+        p = core.default_params(**kw)
+        prod = run_product(syn.names, syn.lengths, syn.seqs, samples, params=p)
+        orac = run_oracle(syn.names, syn.lengths, syn.seqs, samples, params=p)
+        _assert_same(prod, orac)
+        assert prod[2]["n_pileup_bases"] == orac[3]
+    assert prod[0].count("\n") + prod[1].count("\n") > 50
+
+
 def test_event_list_grows_when_a_sub_list_overflows(monkeypatch):
     """The allele-event list is 32 sub-lists with their own counters; a pass that overflows one reports the capacity the
     fullest asked for, the host grows the list and runs the pass again (msnv_pileup_run) -- same records, same event count."""
