@@ -31,8 +31,8 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s
 # each carries 20 of the 12 000 species = 2.5 of this shard's, at 5x.
 WORKLOADS = {
     "testdata": dict(n_species=3, contig_len=300000, n_samples=160, mean_cov=10.0),
-    "config3": dict(n_species=100, contig_len=3000000, n_samples=160, mean_cov=10.0, sigma_cov=0.7, contigs_per_species_max=50, species_per_sample=10),
-    "config4shard": dict(n_species=1500, contig_len=2070000, n_samples=500, mean_cov=5.0, sigma_cov=0.3, contigs_per_species_max=20, species_per_sample=2.5),
+    "config3": dict(n_species=100, contig_len=3000000, n_samples=160, mean_cov=10.0, sigma_cov=0.7, contigs_per_species_max=50, species_per_sample=10, frac_absent=0.0),
+    "config4shard": dict(n_species=1500, contig_len=2070000, n_samples=500, mean_cov=5.0, sigma_cov=0.3, contigs_per_species_max=20, species_per_sample=2.5, frac_absent=0.0),
 }
 
 
@@ -43,7 +43,9 @@ def workload_params(a, rank=0):
     if a.workload != "testdata":
         scale = a.scale if a.scale is not None else 0.25
         kw["n_species"] = max(2, int(round(kw["n_species"] * scale)))
-        kw["species_per_sample"] = max(1, int(round(kw["species_per_sample"] * scale)))     # the same share of the species per sample
+        want = kw["species_per_sample"] * scale                 # the same share of the species per sample, as an expectation:
+        kw["species_per_sample"] = max(1, int(-(-want // 1)))    # draw ceil(want) species and keep each with probability want / ceil(want)
+        kw["frac_absent"] = 1.0 - want / kw["species_per_sample"]
         label += " at %g of its species" % scale
     for arg, key in (("samples", "n_samples"), ("contig_len", "contig_len"), ("species", "n_species"), ("mean_cov", "mean_cov")):
         if getattr(a, arg) is not None:

@@ -384,7 +384,8 @@ typedef struct {
                                     become a proper pair whose mates mostly overlap on the reference               */
     int32_t  contigs_per_species_max;   /* 0 / 1: one contig per species.  > 1 (BASELINE configs[2] / [3]): a species has
                                     1 .. max contigs `refGenome<k>clus.c<j>` that share contig_len bases           */
-    int32_t  species_per_sample; /* 0: presence by frac_absent.  > 0: every sample carries exactly that many random species */
+    int32_t  species_per_sample; /* 0: presence by frac_absent.  > 0: every sample draws that many random species and keeps
+                                    each of them with probability 1 - frac_absent (fractional species counts of scaled shards) */
 } msnv_synth_params;
 
 void msnv_synth_params_default(msnv_synth_params *p);

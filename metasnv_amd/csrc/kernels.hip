@@ -337,8 +337,7 @@ struct NarrowLds {
     Pair32   ev[N_EVCAP];
     ChunkDesc desc[MAX_CHUNKS_PER_ITEM];
     uint32_t carry[N_NT / 64 + 1];             // depth at the left edge of each wavefront's quarter of the tile ([4]: scratch for pieces that end at the tile end)
-    uint32_t gsample[MERGE_MAX_PAIRS];         // merged groups: sample of every pair of the group (piece headers carry the pair's index)
-    uint32_t evn, ev_base, flush_flag;
+    uint32_t evn, ev_base;
 };
 
 // Per-sample pass of the narrow kernel: prefix sum of start/end -> depth, minus the not-counted bases;
@@ -349,8 +348,8 @@ struct NarrowLds {
 // events are placed per wavefront too (one LDS reservation in the staging buffer, or -- staging full, noisy reads --
 // one reservation in the event list; the lanes write at their prefix-sum offsets).
 // MERGED: the bins hold a GROUP of shallow (sample, tile) pairs (pack.cpp: merged groups).  Their pieces went into the same
-// bins, every mismatching base was sent out as an event of its own while it was classified, and nobody needs the per-sample
-// coverage bytes (the gather recomputes the few cells at called positions from the pieces), so the pass only adds the group to
+// bins and nobody needs their per-sample bytes or allele events: the gather recomputes the few per-sample cells at called
+// positions -- coverage and allele counts -- from the pieces themselves (gather_merged_block), so the pass only adds the group to
 // the running totals and the allele totals, marks positions where one sample MIGHT hold >= min_snvs reads of an allele (the
 // calling rule then reads the summed per-sample records), and leaves every bin zero.
 template <typename LDS, int EXC_PAD, bool MERGED = false>
@@ -481,9 +480,8 @@ constexpr int N32_GROUPS = N_NT / N32_LANES;   // 64 pieces per round
 constexpr int N32_ROUNDS = N_HCAP / N32_GROUPS;   // 2
 static_assert(N32_LANES * 32 == SEG_MAX && N32_ROUNDS == 2, "narrow32 is written for 128-base pieces, 128-piece chunks");
 
-template <bool MERGED>
-__device__ __forceinline__ void narrow_classify32(NarrowLds &L, const PileupArgs &a, const uint4 qa, const uint4 qb, const uint4 sq, const uint32_t P0,
-                                                  const int vhi, const uint32_t kq, const uint32_t t0, const uint32_t pidx) {
+__device__ __forceinline__ void narrow_classify32(NarrowLds &L, const uint4 qa, const uint4 qb, const uint4 sq, const uint32_t P0,
+                                                  const int vhi, const uint32_t kq) {
     const uint32_t wi = P0 >> 3, sh = (P0 & 7u) * 4u;
     const uint32_t w0 = L.ref[wi], w1 = L.ref[wi + 1], w2 = L.ref[wi + 2], w3 = L.ref[wi + 3], w4 = L.ref[wi + 4];
     const uint32_t vmask = (vhi >= 32) ? 0xffffffffu : ((1u << vhi) - 1u);
@@ -519,8 +517,6 @@ __device__ __forceinline__ void narrow_classify32(NarrowLds &L, const PileupArgs
         if ((code & (code - 1u)) == 0u) {
             const uint32_t x = (uint32_t)__builtin_ctz(code);
             atomicAdd(&L.al[p], 1u << (8u * x));
-            // merged group: the bins mix samples, so the per-sample allele count leaves as one event per mismatching base
-            if (MERGED) stage_allele_event<NarrowLds, N_EVCAP>(L, a, Pair32{t0 + p, L.gsample[pidx] << 18 | x << 16 | 1u});
         } else atomicAdd(&L.exc[p >> 3], 1ull << (8u * (p & 7u)));
     }
 }
@@ -542,7 +538,7 @@ __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a) {
     for (int i = tid; i < (int)(TILE / 8 + 4); i += N_NT) L.exc[i] = 0;
     L.spread[tid] = ((unsigned long long)((((uint32_t)tid >> 4) * 0x00204081u) & 0x01010101u) << 32) | (((uint32_t)tid & 0xfu) * 0x00204081u & 0x01010101u);
     for (int i = tid; i < (int)TILE; i += N_NT) L.al[i] = 0;
-    if (tid == 0) { L.evn = 0; L.flush_flag = 0; }
+    if (tid == 0) L.evn = 0;
     if (tid < N_NT / 64 + 1) L.carry[tid] = 0;
     uint32_t tc[N_PPT / 2] = {0u, 0u, 0u, 0u};                  // coverage totals of my 8 positions over the item's samples (u16 pairs)
 
@@ -565,14 +561,7 @@ __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a) {
     uint2 hreg = load_hdr(0);
     if (tid < N_HCAP) L.hdr[0][tid] = hreg;
     hreg = load_hdr(1);
-    uint4 qa[N32_ROUNDS], qb[N32_ROUNDS], sq[N32_ROUNDS]; uint32_t P0[N32_ROUNDS], pidx[N32_ROUNDS]; int vh[N32_ROUNDS];
-    // merged groups: the samples of the group's pairs (the headers of the group's pieces carry the pair's index)
-    auto load_group = [&](const uint32_t c) {
-        if (!MERGED) return;
-        const ChunkDesc g = L.desc[c % MAX_CHUNKS_PER_ITEM];
-        if ((uint32_t)tid < g.pad) L.gsample[tid] = a.pairs[g.pair + (uint32_t)tid].sample;
-    };
-    if (nch) load_group(0u);
+    uint4 qa[N32_ROUNDS], qb[N32_ROUNDS], sq[N32_ROUNDS]; uint32_t P0[N32_ROUNDS]; int vh[N32_ROUNDS];
     auto issue_loads = [&](const uint32_t c) {
         const uint64_t sbase = L.desc[c % MAX_CHUNKS_PER_ITEM].seq_base;
         const uint8_t *seq = a.seq + sbase;
@@ -580,8 +569,7 @@ __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a) {
 #pragma unroll
         for (int i = 0; i < N32_ROUNDS; ++i) {
             const uint2 h = L.hdr[c & 1u][grp + i * N32_GROUPS];     // all zero for empty slots
-            const uint32_t len = (h.x >> 11) & 0xffu;                // (bits 19+: index of the piece's pair inside a merged group)
-            pidx[i] = h.x >> 19;
+            const uint32_t len = (h.x >> 11) & 0xffu;                // (bits 19+: index of the piece's pair inside a merged group, for the gather)
             const uint32_t s = h.x & (TILE - 1u);
             const uint64_t so = (uint64_t)h.y << 3;                  // seq byte offset of the piece inside the sample
             vh[i] = min(max((int)len - b0, 0), 32);
@@ -604,13 +592,7 @@ __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a) {
         const bool last_chunk = (cd.nrd_flags >> 16) != 0u;
         if (prev_last) __syncthreads();                              // (A): the pass of the previous pair left every bin zero
         desc_refill(L.desc, a.chunks + w.chunk_lo, c, nch, tid);
-        // (merged groups stage events while they classify, so the fill level moves while the wavefronts pass this point: thread 0
-        // samples it ahead of barrier (B) and everybody acts on that one value a chunk later; what does not fit meanwhile goes
-        // straight to the list)
-        if (MERGED ? (L.flush_flag != 0u) : (L.evn >= (uint32_t)(N_EVCAP / 2))) {
-            flush_events<NarrowLds, N_NT, N_EVCAP>(L, a, tid);
-            if (MERGED && tid == 0) L.flush_flag = 0u;
-        }
+        if (!MERGED && L.evn >= (uint32_t)(N_EVCAP / 2)) flush_events<NarrowLds, N_NT, N_EVCAP>(L, a, tid);
         if (tid < N_HCAP) {
             const uint32_t hx = L.hdr[c & 1u][tid].x;
             const uint32_t s = hx & (TILE - 1u), sb = s + ((hx >> 11) & 0xffu);
@@ -623,27 +605,23 @@ __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < N32_ROUNDS; ++i)
-            if (__any(vh[i] > 0)) narrow_classify32<MERGED>(L, a, qa[i], qb[i], sq[i], P0[i], vh[i], kq, t0, pidx[i]);
+            if (__any(vh[i] > 0)) narrow_classify32(L, qa[i], qb[i], sq[i], P0[i], vh[i], kq);
 
         if (tid < N_HCAP) L.hdr[(c + 1u) & 1u][tid] = hreg;          // headers of chunk c + 1 (zeros behind the last chunk)
         hreg = load_hdr(c + 2u);
-        if (MERGED && tid == 0 && L.evn >= (uint32_t)(N_EVCAP / 2)) L.flush_flag = 1u;
         __syncthreads();                                            // (B): this chunk is in the bins; the next chunk's headers are visible
         if (c + 1u < nch) issue_loads(c + 1u);                       // in flight under the per-sample pass
-        if (last_chunk) {
-            if (c + 1u < nch) load_group(c + 1u);                    // visible behind barrier (A) of the next chunk; this group is classified
-            narrow_pass<NarrowLds, 0, MERGED>(L, a, tc, t0, tid, lane, wave, cd.sample, cd.pair, cd.pad);
-        }
+        if (last_chunk) narrow_pass<NarrowLds, 0, MERGED>(L, a, tc, t0, tid, lane, wave, cd.sample, cd.pair, cd.pad);
         prev_last = last_chunk;
     }
     __syncthreads();
-    flush_events<NarrowLds, N_NT, N_EVCAP>(L, a, tid);
+    if (!MERGED) flush_events<NarrowLds, N_NT, N_EVCAP>(L, a, tid);
     store_part_row(a.part, w, tc, tid);
 }
 
 __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32(PileupArgs a) { pileup_tiles_narrow32_body<false>(a); }
 // The same kernel over MERGED groups of shallow (sample, tile) pairs: a chunk holds pieces of several samples, one pass per
-// group instead of one per pair, no per-sample coverage spill (narrow_pass, narrow_classify32).  A pair of ~20 pieces costs
+// group instead of one per pair, no per-sample coverage spill and no allele events (narrow_pass).  A pair of ~20 pieces costs
 // a chunk iteration and a pass over all 2048 positions whatever it holds (1600 samples at 1x ran at 24 % of the roofline).
 __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_merged(PileupArgs a) { pileup_tiles_narrow32_body<true>(a); }
 
@@ -1102,11 +1080,12 @@ __device__ __forceinline__ void scatter_events_block(const TailArgs &a, const ui
 // counted base at a called position -- quality at or above the cutoff and either a match or one of A, C, G, T: the bases the
 // pileup kernel did not put into its exception bins -- adds one to the group's LDS table [site][pair of the group], which
 // is then written out with plain stores (every (site, sample) cell belongs to exactly one group).
-constexpr uint32_t GM_CELLS = 8192;           // u16 cells of the LDS table; a tile with more sites x pairs is done in batches of sites
+constexpr uint32_t GM_CELLS = 4096;           // cells of the LDS tables (6 B each); a tile with more sites x pairs is done in batches of sites
 __device__ __forceinline__ void gather_merged_block(const TailArgs &a, const uint32_t bid) {
     __shared__ unsigned long long s_bits[TILE / 64];
     __shared__ uint32_t s_rank[TILE / 64];
-    __shared__ uint32_t s_cov[GM_CELLS / 2];
+    __shared__ uint32_t s_cov[GM_CELLS / 2];            // u16 per (site, pair): counted bases
+    __shared__ uint32_t s_al[GM_CELLS];                 // 4 x u8 per (site, pair): mismatching A, C, G, T (a shallow pair is < 81 deep)
     __shared__ uint32_t s_gsample[MERGE_MAX_PAIRS];
     const WorkItem w = a.work_merged[bid];
     const uint32_t tile = w.tile, n = a.tile_site_cnt[tile];
@@ -1130,6 +1109,7 @@ __device__ __forceinline__ void gather_merged_block(const TailArgs &a, const uin
         for (uint32_t j0 = 0; j0 < n; j0 += batch) {
             const uint32_t nj = min(batch, n - j0);
             for (uint32_t i = tid; i < (nj * m + 1u) / 2u; i += blockDim.x) s_cov[i] = 0u;
+            for (uint32_t i = tid; i < nj * m; i += blockDim.x) s_al[i] = 0u;
             __syncthreads();
             for (uint32_t pi = tid; pi < n_pieces; pi += blockDim.x) {
                 const PieceHdr h = a.hdr8m[g.hdr_base + pi];
@@ -1153,6 +1133,7 @@ __device__ __forceinline__ void gather_merged_block(const TailArgs &a, const uin
                         if (qv >= kq && (code == rc || (code != 0u && (code & (code - 1u)) == 0u))) {
                             const uint32_t cell = (j - j0) * m + pidx;
                             atomicAdd(&s_cov[cell >> 1], 1u << (16u * (cell & 1u)));
+                            if (code != rc) atomicAdd(&s_al[cell], 1u << (8u * (uint32_t)__builtin_ctz(code)));
                         }
                     }
                 }
@@ -1160,7 +1141,13 @@ __device__ __forceinline__ void gather_merged_block(const TailArgs &a, const uin
             __syncthreads();
             for (uint32_t i = tid; i < nj * m; i += blockDim.x) {
                 const uint32_t v = (s_cov[i >> 1] >> (16u * (i & 1u))) & 0xffffu;
-                if (v) a.cov_col[(uint64_t)(base + j0 + i / m) * a.n_samples + s_gsample[i % m]] = (uint16_t)v;
+                const uint64_t cell = (uint64_t)(base + j0 + i / m) * a.n_samples + s_gsample[i % m];
+                if (v) a.cov_col[cell] = (uint16_t)v;
+                const uint32_t al = s_al[i];
+                if (al) {
+#pragma unroll
+                    for (uint32_t x = 0; x < 4; ++x) if ((al >> (8u * x)) & 0xffu) a.out[cell].n[x] = (uint16_t)((al >> (8u * x)) & 0xffu);
+                }
             }
             __syncthreads();
         }
@@ -1241,7 +1228,7 @@ __global__ __launch_bounds__(256) void msnv_decide_sites(const SiteRec *sites, u
 // Algorithmic HBM bytes: 8 B per M interval.
 // ------------------------------------------------------------------------------------------
 constexpr int C_NT = 256;
-constexpr int C_PPT = TILE / C_NT;             // 8
+static_assert(C_NT / 64 * COV_PW == COV_ITEM_PAIRS, "coverage work items are sized for COV_PW pairs per wavefront");
 
 __device__ __forceinline__ int wave_reduce_add(int x) {
     x = wave_inclusive_scan(x);
@@ -1251,104 +1238,121 @@ __device__ __forceinline__ int wave_reduce_add(int x) {
 __global__ __launch_bounds__(C_NT) void msnv_coverage_tiles(const Pair32 *iv, const TilePair *pairs,
                                                             const WorkItem *work, const uint32_t *tile_len, const uint32_t *tile_contig,
                                                             unsigned long long *acc, uint32_t n_contigs, int max_cov, uint32_t n_samples, uint32_t n_copies) {
-    // One barrier per (tile, sample) pair: the difference array, the quarter-boundary carries and the workgroup accumulators
-    // are double-buffered, so pair k + 1 scatters while slower wavefronts still scan pair k, and the accumulators of pair k
-    // are flushed behind the barrier of pair k + 1.  Wavefront w scans positions [512 w, 512 w + 512) on its own: the depth
-    // at its left edge is the number of intervals that cover position 512 w - 1, counted while they are scattered.
-    // The kernel was bound by its chain of dependent loads per pair (pair descriptor -> sample base -> intervals, ~3.6 us per
-    // pair whatever it holds): the descriptors now carry the absolute interval offset and are prefetched two pairs ahead, the
-    // first 256 intervals of the next pair one pair ahead, both issued right behind the barrier so that they fly under the scan.
-    __shared__ int s_d[2][TILE + 4];
-    __shared__ int s_carry[2][C_NT / 64 + 1];
-    __shared__ int s_acc[2][COV_BINS + 2];
+    // One WAVEFRONT per (tile, sample) pair, no workgroup barrier at all, and the work follows the BREAKPOINTS of the coverage
+    // instead of the positions: an interval adds +1 / -1 to a difference array in LDS (16-bit halves of 32-bit words) and sets the
+    // bit of either end in a 2048-bit mask; lane l owns positions [32 l, 32 l + 32) = one mask word, sums the differences at its
+    // set bits (one wave scan gives every lane the depth at its left edge) and then walks its ~3 runs of constant depth:
+    // covSum += depth x length, hist[min(depth, max_cov)] += length.  The previous form (one workgroup per pair, every position
+    // visited, a prefix sum and five wave reductions per wavefront) spent ~800 vector instructions per pair; this one ~250.
+    __shared__ int s_d[C_NT / 64][TILE / 2];               // two positions per word: low half = even position
+    __shared__ uint32_t s_mask[C_NT / 64][TILE / 32];
     const WorkItem w = work[blockIdx.x];
     const uint32_t t0 = w.tile * TILE, tl = tile_len[w.tile], contig = tile_contig[w.tile];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    auto load_pair = [&](const uint32_t k) -> TilePair { return k < w.pair_hi ? pairs[k] : TilePair{0, 0, 0, 0, 0, 0, 0, 0}; };
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int *const d = s_d[wave];
+    uint32_t *const mask = s_mask[wave];
+    static_assert(TILE / 32 == 64, "one mask word per lane");
     auto base_of = [](const TilePair &p) -> uint64_t { return (uint64_t)p.nblk << 32 | p.blk_lo; };      // absolute index of the sample's first interval
-    auto load_first = [&](const TilePair &p) -> Pair32 {
-        return (p.read_lo + (uint32_t)tid < p.read_hi) ? iv[base_of(p) + p.read_lo + (uint32_t)tid] : Pair32{0u, 0u};   // {0, 0} touches nothing
+    auto half_at = [&](const uint32_t p) -> int {          // difference at position p: the halves borrow from each other while they are added up
+        const int wd = d[p >> 1], lo = (int)(short)(wd & 0xffff);
+        return (p & 1u) ? (wd - lo) >> 16 : lo;
     };
-    TilePair pr = load_pair(w.pair_lo), pr1 = load_pair(w.pair_lo + 1u);
-    Pair32 x0 = load_first(pr);
-    for (int i = tid; i < 2 * (int)(TILE + 4); i += C_NT) (&s_d[0][0])[i] = 0;
-    if (tid < 2 * (COV_BINS + 2)) (&s_acc[0][0])[tid] = 0;
-    if (tid < 2 * (C_NT / 64 + 1)) (&s_carry[0][0])[tid] = 0;
-    __syncthreads();
-    auto flush = [&](const uint32_t b, const uint32_t sample) {   // threads 0 .. max_cov + 1: covSum and the histogram bins
-        const int v = s_acc[b][tid];
-        s_acc[b][tid] = 0;
-        unsigned long long *dst = acc + (((uint64_t)(w.tile % n_copies) * n_samples + sample) * n_contigs + contig) * (1 + COV_BINS);
-        if (v) atomicAdd(&dst[tid], (unsigned long long)(long long)v);
-    };
-    uint32_t prev_sample = 0;
-    for (uint32_t k = w.pair_lo; k < w.pair_hi; ++k) {
-        const uint32_t b = k & 1u;
+    const uint32_t lim = (uint32_t)min(max((int)tl - 32 * lane, 0), 32);      // scanned positions among my 32 (i < contig length)
+    // A work item holds at most C_NT / 64 * COV_PW pairs (pack.cpp) and every wavefront owns COV_PW consecutive ones: ALL their
+    // descriptors, then the first 128 intervals of ALL of them, are loaded up front -- two round trips to memory per work item
+    // whatever it holds (the kernel was bound by one dependent descriptor -> intervals chain per pair, not by its arithmetic)
+    TilePair prs[COV_PW];
+    Pair32 xs[COV_PW][2];
+#pragma unroll
+    for (int j = 0; j < COV_PW; ++j) {
+        const uint32_t kk = w.pair_lo + (uint32_t)(wave * COV_PW + j);
+        prs[j] = kk < w.pair_hi ? pairs[kk] : TilePair{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int j = 0; j < COV_PW; ++j) {
+        const uint32_t n = prs[j].read_hi - prs[j].read_lo;
+        const Pair32 *v = iv + base_of(prs[j]) + prs[j].read_lo;
+        xs[j][0] = (uint32_t)lane < n ? v[lane] : Pair32{0u, 0u};            // {0, 0} touches nothing
+        xs[j][1] = (uint32_t)lane + 64u < n ? v[lane + 64] : Pair32{0u, 0u};
+    }
+    for (int i = lane; i < (int)(TILE / 2); i += 64) d[i] = 0;               // (under the loads)
+    mask[lane] = 0u;
+#pragma unroll
+    for (int j = 0; j < COV_PW; ++j) {
+        const TilePair pr = prs[j];
+        if (w.pair_lo + (uint32_t)(wave * COV_PW + j) >= w.pair_hi) break;
         auto scatter = [&](const Pair32 x) {
             if (x.x > x.y) {
                 // qaCompute's `--entireChr[chrSize-1]` without a matching `++` inside the scanned range: an M op whose cursor is
                 // at or beyond the contig end (qaCompute.cpp:542-549; the host stores it as {end, end - 1})
-                if (x.y >= t0 && x.y < t0 + TILE) atomicAdd(&s_d[b][x.y - t0], -1);
+                if (x.y >= t0 && x.y < t0 + TILE) {
+                    const uint32_t e = x.y - t0;
+                    atomicAdd(&d[e >> 1], (e & 1u) ? -65536 : -1);
+                    atomicOr(&mask[e >> 5], 1u << (e & 31u));
+                }
                 return;
             }
             if (x.y <= t0 || x.x >= t0 + TILE) return;
             const uint32_t s = x.x > t0 ? x.x - t0 : 0u, e = min(x.y - t0, TILE);   // intervals that started in an earlier tile enter at 0
-            atomicAdd(&s_d[b][s], 1);
-            if (e < TILE) atomicAdd(&s_d[b][e], -1);
-            for (uint32_t q = (s >> 9) + 1u; q <= min(e >> 9, 3u); ++q) atomicAdd(&s_carry[b][q], 1);
+            atomicAdd(&d[s >> 1], (s & 1u) ? 65536 : 1);
+            atomicOr(&mask[s >> 5], 1u << (s & 31u));
+            if (e < TILE) {
+                atomicAdd(&d[e >> 1], (e & 1u) ? -65536 : -1);
+                atomicOr(&mask[e >> 5], 1u << (e & 31u));
+            }
         };
-        scatter(x0);
-        if (pr.read_hi - pr.read_lo > (uint32_t)C_NT) {
+        scatter(xs[j][0]);
+        scatter(xs[j][1]);
+        if (pr.read_hi - pr.read_lo > 128u) {
             const Pair32 *v = iv + base_of(pr);
-            for (uint32_t i = pr.read_lo + (uint32_t)C_NT + (uint32_t)tid; i < pr.read_hi; i += C_NT) scatter(v[i]);
+            for (uint32_t i = pr.read_lo + 128u + (uint32_t)lane; i < pr.read_hi; i += 64) scatter(v[i]);
         }
-        __syncthreads();
-        const TilePair pr2 = load_pair(k + 2u);                // in flight under the scan
-        x0 = load_first(pr1);
-        if (k > w.pair_lo && tid <= max_cov + 1) flush(b ^ 1u, prev_sample);
-        prev_sample = pr.sample;
-        int4 d0 = *reinterpret_cast<int4 *>(&s_d[b][C_PPT * tid]);
-        int4 d1 = *reinterpret_cast<int4 *>(&s_d[b][C_PPT * tid + 4]);
-        int off = s_carry[b][wave];
-        *reinterpret_cast<int4 *>(&s_d[b][C_PPT * tid]) = make_int4(0, 0, 0, 0);
-        *reinterpret_cast<int4 *>(&s_d[b][C_PPT * tid + 4]) = make_int4(0, 0, 0, 0);
-        if (lane == 0) s_carry[b][wave] = 0;
-        d0.y += d0.x; d0.z += d0.y; d0.w += d0.z; d1.x += d0.w; d1.y += d1.x; d1.z += d1.y; d1.w += d1.z;
-        off += wave_inclusive_scan(d1.w) - d1.w;
-        const int cv[C_PPT] = {off + d0.x, off + d0.y, off + d0.z, off + d0.w, off + d1.x, off + d1.y, off + d1.z, off + d1.w};
-        unsigned long long hp = 0;          // 16 bins x 4 bits (at most 8 positions per thread)
+        // the LDS executes one wavefront's instructions in order: the atomics above are done before the reads below are served
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const uint32_t m = mask[lane];
+        mask[lane] = 0u;
+        int delta = 0;
+        for (uint32_t mm = m; mm; mm &= mm - 1u) delta += half_at(32u * (uint32_t)lane + (uint32_t)__builtin_ctz(mm));
+        int cur = wave_inclusive_scan(delta) - delta;      // depth at my left edge
+        // runs of constant depth inside my 32 positions
+        unsigned long long ha = 0, hb = 0;                 // bins 0-7 / 8-15, one byte each (a lane adds at most 32)
         int csum = 0;
-#pragma unroll
-        for (int j = 0; j < C_PPT; ++j) {
-            if ((uint32_t)(C_PPT * tid + j) < tl) {
-                csum += cv[j];
-                // -1 at the last position of a contig (see scatter): the reference then increments coverageHist[-1], out of
-                // bounds -- the position lands in no bin, the sum takes the -1 (and wraps, unsigned, exactly as covSum does)
-                if (cv[j] >= 0) hp += 1ull << (4 * min(cv[j], max_cov));
-            }
+        uint32_t prev = 0;
+        auto account = [&](const int depth, const uint32_t from, const uint32_t to) {
+            const uint32_t len = min(to, lim) - min(from, lim);
+            if (!len) return;
+            csum += depth * (int)len;
+            // -1 at the last position of a contig (see above): the reference then increments coverageHist[-1], out of bounds --
+            // the position lands in no bin, the sum takes the -1 (and wraps, unsigned, exactly as covSum does)
+            if (depth < 0) return;
+            const uint32_t bin = (uint32_t)min(depth, max_cov);
+            const unsigned long long add = (unsigned long long)len << (8u * (bin & 7u));
+            if (bin < 8u) ha += add; else hb += add;
+        };
+        for (uint32_t mm = m; mm; mm &= mm - 1u) {
+            const uint32_t bpos = (uint32_t)__builtin_ctz(mm);
+            account(cur, prev, bpos);
+            cur += half_at(32u * (uint32_t)lane + bpos);
+            prev = bpos;
         }
-        // reduce inside the workgroup first (wave DPP reduction, then LDS), so that one pair costs 1 + max_cov + 1 global
-        // atomics instead of that many per wavefront (the accumulators are 64-bit atomics at the memory side)
-        int *sa = s_acc[b];
+        account(cur, prev, 32u);
+        for (uint32_t mm = m; mm; mm &= mm - 1u) d[(32u * (uint32_t)lane + (uint32_t)__builtin_ctz(mm)) >> 1] = 0;   // my words only: positions 32 l .. 32 l + 31
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // reduce over the wavefront: covSum, and two bins per register in 16-bit fields (a wavefront adds at most 2048 per bin)
         const int ws = wave_reduce_add(csum);
-        if (lane == 0 && ws) atomicAdd(&sa[0], ws);
-        // histogram: three bins per register in 10-bit fields (a wavefront adds at most 64 x 8 = 512 per bin), so the
-        // max_cov + 1 bins cost a third of the wave reductions
-        for (int q = 0; 3 * q <= max_cov; ++q) {
-            const uint32_t x = (uint32_t)(hp >> (12 * q)) & 0xfffu;
-            const uint32_t wq = (uint32_t)wave_reduce_add((int)((x & 0xfu) | (x & 0xf0u) << 6 | (x & 0xf00u) << 12));
-            if (lane == 0 && wq) {
-#pragma unroll
-                for (int f = 0; f < 3; ++f) {
-                    const int wb = (int)((wq >> (10 * f)) & 0x3ffu);
-                    if (wb) atomicAdd(&sa[1 + 3 * q + f], wb);      // bins beyond max_cov are empty
-                }
-            }
+        int val = ws;                                       // lane 0: covSum; lane 1 + b: bin b
+        for (int q = 0; 2 * q <= max_cov; ++q) {
+            const unsigned long long src = q < 4 ? ha >> (16 * q) : hb >> (16 * (q - 4));
+            const uint32_t two = (uint32_t)(src & 0xffull) | (uint32_t)((src >> 8) & 0xffull) << 16;
+            const uint32_t wq = (uint32_t)wave_reduce_add((int)two);
+            if (lane == 1 + 2 * q) val = (int)(wq & 0xffffu);
+            if (lane == 2 + 2 * q) val = (int)(wq >> 16);
         }
-        pr = pr1; pr1 = pr2;
+        if (lane <= max_cov + 1 && val) {
+            unsigned long long *dst = acc + (((uint64_t)(w.tile % n_copies) * n_samples + pr.sample) * n_contigs + contig) * (1 + COV_BINS);
+            atomicAdd(&dst[lane], (unsigned long long)(long long)val);
+        }
     }
-    __syncthreads();
-    if (w.pair_hi > w.pair_lo && tid <= max_cov + 1) flush((w.pair_hi - 1u) & 1u, prev_sample);
 }
 
 // ------------------------------------------------------------------------------------------ host side

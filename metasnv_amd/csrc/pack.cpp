@@ -1073,12 +1073,14 @@ int finalize_dataset(msnv_dataset &ds) {
             for (size_t s = 0; s < S; ++s) for (const CP &p : per[s]) cpairs[fill[p.tile]++] = TilePair{p.sample, p.lo, p.hi, 0, (uint32_t)cvbase[s], (uint32_t)(cvbase[s] >> 32), 0, 0};
         }
         std::vector<WorkItem> cwork;
-        const uint64_t cov_item_intervals = [] { const char *e = getenv("MSNV_COV_ITEM"); const long long v = e ? atoll(e) : 1024; return (uint64_t)(v > 0 ? v : 1024); }();   // intervals per coverage work item: 4096 -> 0.173 ms, 2048 -> 0.149, 1024 -> 0.143, 512 -> 0.143, 256 -> 0.151 (benchmark shape)
+        // a coverage work item = COV_ITEM_PAIRS consecutive pairs of a tile: every wavefront of msnv_coverage_tiles owns COV_PW of
+        // them and loads their descriptors and intervals up front (fewer when one pair alone is deep: MSNV_COV_ITEM intervals)
+        const uint64_t cov_item_intervals = [] { const char *e = getenv("MSNV_COV_ITEM"); const long long v = e ? atoll(e) : 16384; return (uint64_t)(v > 0 ? v : 16384); }();
         for (uint64_t t = 0; t < nt; ++t) {
             uint32_t lo = cps[t]; uint64_t acc = 0;
             for (uint32_t k = cps[t]; k < cps[t + 1]; ++k) {
                 acc += cpairs[k].read_hi - cpairs[k].read_lo;
-                if (acc >= cov_item_intervals || k + 1 == cps[t + 1]) { cwork.push_back(WorkItem{(uint32_t)t, lo, k + 1, 0, 0, 0, 0, 0}); lo = k + 1; acc = 0; }
+                if (acc >= cov_item_intervals || k + 1 - lo >= COV_ITEM_PAIRS || k + 1 == cps[t + 1]) { cwork.push_back(WorkItem{(uint32_t)t, lo, k + 1, 0, 0, 0, 0, 0}); lo = k + 1; acc = 0; }
             }
         }
         std::vector<uint32_t> tlen(nt + 1, 0), tcont(nt + 1, 0);

@@ -144,7 +144,7 @@ void synth_sample_records(const msnv_synth_params &p, int sample, const std::vec
             nsub = cur_species % 3 + 1;
             my_sub = (int)r.below((uint32_t)nsub);
             cov = 0.0;
-            if (p.species_per_sample > 0) { if (carried[(size_t)cur_species]) cov = std::exp(std::log(p.mean_cov) + p.sigma_cov * r.normal()); }
+            if (p.species_per_sample > 0) { if (carried[(size_t)cur_species] && r.uni() >= p.frac_absent) cov = std::exp(std::log(p.mean_cov) + p.sigma_cov * r.normal()); }
             else if (r.uni() >= p.frac_absent) cov = std::exp(std::log(p.mean_cov) + p.sigma_cov * r.normal());
         }
         int64_t n_reads = (int64_t)(cov * (double)L / p.read_len);
