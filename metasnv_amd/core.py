@@ -321,7 +321,10 @@ class Synth:
         lengths = C.POINTER(C.c_int64)()
         seqs = C.POINTER(C.c_char_p)()
         check(lib.msnv_synth_reference(C.byref(params), C.byref(names), C.byref(lengths), C.byref(seqs)))
-        n = lib.msnv_synth_contig_count(C.byref(params))
+        try:
+            n = lib.msnv_synth_contig_count(C.byref(params))
+        except AttributeError:                            # an older build under MSNV_LIBRARY (profiles/ab.sh): one contig per species
+            n = params.n_species
         self.names = [names[i].decode() for i in range(n)]
         self.lengths = [int(lengths[i]) for i in range(n)]
         self.seqs = [seqs[i] for i in range(n)]          # bytes copies

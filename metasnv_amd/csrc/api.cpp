@@ -302,7 +302,12 @@ extern "C" int msnv_pileup_run(msnv_dataset *ds, msnv_run_stats *stats) {
         };
         if (int r2 = grow((void **)&d.events, d.cap_events, c.n_events, sizeof(Pair32))) return r2;
         if (int r2 = grow((void **)&d.overflow, d.cap_overflow, c.n_overflow, sizeof(Pair32))) return r2;
+        const uint32_t old_cap_sites = d.cap_sites;
         if (int r2 = grow((void **)&d.sites, d.cap_sites, c.n_sites, sizeof(SiteRec))) return r2;
+        if (d.cap_sites != old_cap_sites) {                 // the list of sites msnv_decide_sites looks at is sized like the sites
+            dev_free(d.unc_sites); d.unc_sites = nullptr;
+            if (int r2 = dev_alloc((void **)&d.unc_sites, (uint64_t)d.cap_sites * sizeof(uint32_t), &d.device_bytes)) return r2;
+        }
         clear_error();
         rc = dev_run_pipeline(d, ds->params, ds->ctx->stream, &st, &c);
     }
@@ -330,10 +335,14 @@ static int fetch_results(msnv_dataset *ds) {
     if (int r2 = dev_download(flags.data(), d.site_flags, n)) return r2;
     if (int r2 = dev_download(tbase.data(), d.tile_site_base, (uint64_t)ds->n_tiles * 4)) return r2;
     if (int r2 = dev_download(tcnt.data(), d.tile_site_cnt, (uint64_t)ds->n_tiles * 4)) return r2;
-    std::vector<msnv_site_sample> raw((size_t)n * d.n_samples);
+    // per-sample cells are stored per (site, slot of the tile) on the device (kernels.hip: CellMap); expanded to all samples here
+    std::vector<unsigned long long> tcell(ds->n_tiles + 1);
+    if (int r2 = dev_download(tcell.data(), d.tile_cell_base, (uint64_t)ds->n_tiles * sizeof(unsigned long long))) return r2;
+    const uint64_t n_cells = d.last_cells;
+    std::vector<msnv_site_sample> raw((size_t)n_cells);
     if (int r2 = dev_download(raw.data(), d.out, raw.size() * sizeof(msnv_site_sample))) return r2;
     {   // the per-sample coverage is a column of its own on the device (device.h): merged into the records here
-        std::vector<uint16_t> cov((size_t)n * d.n_samples);
+        std::vector<uint16_t> cov((size_t)n_cells);
         if (int r2 = dev_download(cov.data(), d.cov_col, cov.size() * sizeof(uint16_t))) return r2;
         for (size_t i = 0; i < raw.size(); ++i) raw[i].cov = cov[i];
     }
@@ -341,6 +350,7 @@ static int fetch_results(msnv_dataset *ds) {
     ds->sites.clear(); ds->site_samples.clear(); ds->site_dev_index.clear();
     ds->sites.reserve(n);
     for (uint32_t t = 0; t < ds->n_tiles; ++t) {
+        const uint64_t slot0 = ds->tile_slot_base[t], n_slots = ds->tile_slot_base[t + 1] - slot0;
         for (uint32_t j = 0; j < tcnt[t]; ++j) {
             const uint32_t i = tbase[t] + j;
             if (!flags[i]) continue;               // passed the gates but neither rule fired
@@ -354,7 +364,11 @@ static int fetch_results(msnv_dataset *ds) {
             s.dropped = (ds->params.drop_first_line && s.tid == ds->first_tid && s.pos == ds->first_pos) ? 1 : 0;
             ds->sites.push_back(s);
             ds->site_dev_index.push_back(i);
-            ds->site_samples.insert(ds->site_samples.end(), raw.begin() + (size_t)i * d.n_samples, raw.begin() + (size_t)(i + 1) * d.n_samples);
+            const size_t row = ds->site_samples.size();
+            ds->site_samples.resize(row + d.n_samples, msnv_site_sample{});
+            const uint64_t cell0 = tcell[t] + (uint64_t)j * n_slots;
+            if (cell0 + n_slots > n_cells) return fail(MSNV_EHIP, "internal: the device reported %llu cells but tile %u needs cell %llu", (unsigned long long)n_cells, t, (unsigned long long)(cell0 + n_slots));
+            for (uint64_t c = 0; c < n_slots; ++c) ds->site_samples[row + ds->slot_sample[(size_t)(slot0 + c)]] = raw[(size_t)(cell0 + c)];
         }
     }
     ds->results_fetched = true;

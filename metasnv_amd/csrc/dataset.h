@@ -105,6 +105,8 @@ struct msnv_dataset {
     // layout
     std::vector<uint32_t> tile_base;       // per contig (selected only; others = UINT32_MAX)
     std::vector<uint32_t> tile_contig;     // per tile
+    std::vector<uint64_t> tile_slot_base;  // per tile: first entry of slot_sample (n_tiles + 1)
+    std::vector<uint32_t> slot_sample;     // sample of every (tile, slot): the device stores per-sample cells per slot (kernels.hip: CellMap)
     uint32_t n_tiles = 0;
     // first pileup line of the invocation (call_vC.cpp:423)
     int32_t first_tid = -1; int64_t first_pos = -1;

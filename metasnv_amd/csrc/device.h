@@ -78,14 +78,22 @@ struct DeviceCols {
     uint32_t  cnt_parity = 0;        // block the NEXT pass uses
     uint32_t *ind4 = nullptr;        // 4 bits per position: some sample holds >= calling_threshold reads of mismatching A / C / G / T
     uint32_t *unc_bits = nullptr;    // 1 bit per position: a sample split into several pairs holds a mismatching allele (follows ind4 in its allocation)
+    uint32_t *tile_dirty = nullptr;  // per work item (by the slot of its coverage row), 1 bit per 64 positions of the tile: the item added to the allele totals there
+                                     // (set by the pileup kernels, consumed and cleared by the gate)
+    uint32_t *unc_sites = nullptr;   // [cap_sites]: sites whose call depends on a split / merged sample's summed counts (msnv_decide_sites)
+    struct GateTileH { uint32_t tile, slot_lo, slot_16, slot_w, slot_hi, vbeg, vend, n_slots; uint64_t row0; uint64_t pad_; } *gate_tiles = nullptr;   // per active tile (kernels.hip: GateTile)
+    uint32_t  gather_split = 4;      // workgroups per tile in the spill gather (fewer for sparse cohorts: a pair or two per tile)
     bool      any_split = false;     // some (sample, tile) run was dealt into several pairs: the calling rule then needs the summed per-sample records
     unsigned long long *site_bits = nullptr;   // 1 bit per position: is a site (written by the gate kernel for every tile)
     uint32_t *site_rank = nullptr;   // per 64 positions: index of their first site (tiles with sites only)
     uint32_t  cap_events = 0, cap_overflow = 0, cap_sites = 0;
     SiteRec  *sites = nullptr;
     uint32_t *tile_site_base = nullptr, *tile_site_cnt = nullptr;
-    msnv_site_sample *out = nullptr; // [cap_out_sites][n_samples]: allele counts per sample; the .cov field is filled in when the host fetches
-    uint16_t *cov_col = nullptr;     // [cap_out_sites][n_samples]: per-sample coverage, a column of its own on the device (two-byte stores
+    uint32_t *tile_nslots = nullptr; // per tile: samples that have reads in it = cells per site of that tile (kernels.hip: CellMap)
+    unsigned long long *tile_cell_base = nullptr;   // per tile and pass: first cell of its sites' rows (gate kernel)
+    uint64_t  cap_cells = 0, last_cells = 0;
+    msnv_site_sample *out = nullptr; // [cap_cells]: allele counts per (site, slot); the .cov field is filled in when the host fetches
+    uint16_t *cov_col = nullptr;     // [cap_cells]: per-sample coverage, a column of its own on the device (two-byte stores
                                      // into 10-byte records are partial-line writes: gather/scatter launch 41 -> 37 us)
     uint8_t  *site_flags = nullptr;  // pop_mask | ind_mask << 4
     uint64_t  cap_out_sites = 0, last_sites = 0;
@@ -107,9 +115,9 @@ struct DeviceCols {
     // that the small tail kernels of pass i overlap with the pileup kernel of pass i+1 (allocated on first use)
     struct AltBufs {
         uint32_t *tot = nullptr; uint8_t *part = nullptr; uint8_t *spill = nullptr; Pair32 *events = nullptr, *overflow = nullptr;
-        uint32_t *counters = nullptr; SiteRec *sites = nullptr; uint32_t *tile_site_base = nullptr, *tile_site_cnt = nullptr;
-        msnv_site_sample *out = nullptr; uint16_t *cov_col = nullptr; uint8_t *site_flags = nullptr; uint32_t *ind4 = nullptr, *unc_bits = nullptr; unsigned long long *site_bits = nullptr; uint32_t *site_rank = nullptr;
-        uint32_t cap_events = 0, cap_overflow = 0, cap_sites = 0, cnt_parity = 0; uint64_t cap_out_sites = 0;
+        uint32_t *counters = nullptr; SiteRec *sites = nullptr; uint32_t *tile_site_base = nullptr, *tile_site_cnt = nullptr; unsigned long long *tile_cell_base = nullptr;
+        msnv_site_sample *out = nullptr; uint16_t *cov_col = nullptr; uint8_t *site_flags = nullptr; uint32_t *ind4 = nullptr, *unc_bits = nullptr, *tile_dirty = nullptr, *unc_sites = nullptr; unsigned long long *site_bits = nullptr; uint32_t *site_rank = nullptr;
+        uint32_t cap_events = 0, cap_overflow = 0, cap_sites = 0, cnt_parity = 0; uint64_t cap_out_sites = 0, cap_cells = 0;
     } alt;
     void     *stream2 = nullptr;
     std::vector<void *> event_pool;          // hipEvent_t of msnv_pileup_run_many
@@ -122,9 +130,16 @@ struct DeviceCols {
 // (work item i appends to sub-list i % EV_LISTS): returning atomics on ONE address serialise device-wide, and reads with
 // several per cent of mismatches append often enough for that to dominate the pileup kernel.
 constexpr uint32_t EV_LISTS = 32, EV_CNT_STRIDE = 16;
-constexpr uint32_t CNT_WORDS = 16 + EV_LISTS * EV_CNT_STRIDE;   // counters[0..15], then the sub-list counters; ind_bits follow
+// counters[0..15] (what the host reads back: [0] events [1] overflow [2] sites [4] pop lines [5] indiv lines [6..7] cells), the
+// event sub-list counters, then the counters every gate workgroup adds to -- each on a 64-byte line of its own: with a sparse
+// cohort 10^5 workgroups add to them, and atomics on one line serialise at the memory side (BASELINE configs[3] shard: the gate
+// kernel went from 2.0 to 2.9 ms when two more counters shared the line of the site counter)
+constexpr uint32_t CNT_CELLS = 16 + EV_LISTS * EV_CNT_STRIDE;   // 64-bit: cells of the per-sample records
+constexpr uint32_t CNT_TALLY = CNT_CELLS + 16;                  // 64-bit: population lines | individual lines << 32 (gate kernel's share)
+constexpr uint32_t CNT_UNC = CNT_TALLY + 16;                    // sites left to msnv_decide_sites
+constexpr uint32_t CNT_WORDS = CNT_UNC + 16;
 
-struct RunCounts { uint32_t n_events, n_overflow, n_sites, err; };
+struct RunCounts { uint32_t n_events, n_overflow, n_sites, err; uint64_t n_cells; };
 
 int  dev_set_device(int device);
 uint32_t dev_resident_workgroups(uint32_t per_cu);   // compute units of the current device x per_cu (256 CUs when the query fails)

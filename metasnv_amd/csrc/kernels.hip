@@ -52,6 +52,7 @@ struct PileupArgs {
     uint32_t        min_baseq;
     uint32_t       *ind4;         // 4 bits per position (A, C, G, T): some sample holds >= min_snvs reads of that mismatching allele
     uint32_t       *unc_bits;     // 1 bit per position: a sample that was split into several pairs holds the allele (it may reach the threshold only in sum)
+    uint32_t       *slot_dirty;   // per work item (by the slot of its coverage row), 1 bit per 64 positions: the item added to the allele totals there
     uint32_t        min_snvs;
 };
 
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(W_NT) void msnv_pileup_tiles_wide(PileupArgs a) {
     while (k < w.pair_hi) {
         const uint32_t nrd = min((uint32_t)W_HCAP, pr.read_hi - rbeg);
         const bool last_chunk = rbeg + nrd >= pr.read_hi;
-        const uint32_t sample = pr.sample;
+        const uint32_t sample = pr.pad >> 8;                       // the sample's SLOT in the tile (what events and overflow entries carry)
         if (tid < W_HCAP) L.hdr[buf][tid] = hreg;                   // slots beyond nrd hold meta = 0
         uint32_t nk = k, nrbeg = rbeg + nrd;
         TilePair npr = pr;
@@ -289,13 +290,15 @@ __global__ __launch_bounds__(W_NT) void msnv_pileup_tiles_wide(PileupArgs a) {
     flush_events<WideLds, W_NT, W_EVCAP>(L, a, tid);
 
     *reinterpret_cast<uint4 *>(a.part + ((uint64_t)w.part_hi << 32 | w.part_lo) + 4u * W_PPT * tid) = make_uint4(tc[0], tc[1], tc[2], tc[3]);   // u32 row
+    bool any_allele = false;
 #pragma unroll
     for (int j = 0; j < W_PPT; ++j) {
         const uint64_t g = (uint64_t)t0 + W_PPT * tid + j;
 #pragma unroll
         for (int x = 0; x < 4; ++x)
-            if (tn[j][x]) atomicAdd(&a.tot[(uint64_t)x * a.npos + g], tn[j][x]);
+            if (tn[j][x]) { atomicAdd(&a.tot[(uint64_t)x * a.npos + g], tn[j][x]); any_allele = true; }
     }
+    if (any_allele) atomicOr(&a.slot_dirty[w.slot], 1u << ((W_PPT * (uint32_t)tid) >> 6));      // (gate kernel: blocks whose allele totals are not all zero; one word per item)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -353,7 +356,7 @@ struct NarrowLds {
 // the running totals and the allele totals, marks positions where one sample MIGHT hold >= min_snvs reads of an allele (the
 // calling rule then reads the summed per-sample records), and leaves every bin zero.
 template <typename LDS, int EXC_PAD, bool MERGED = false>
-__device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_t (&tc)[N_PPT / 2], const uint32_t t0,
+__device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_t (&tc)[N_PPT / 2], bool &dirty, const uint32_t t0,
                                             const int tid, const int lane, const int wave, const uint32_t sample, const uint32_t k,
                                             const uint32_t split) {
     const uint2 st = *reinterpret_cast<uint2 *>(&L.start[2 * tid]);
@@ -389,6 +392,7 @@ __device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_
         myev = count_nz_bytes(a0, a1);
     }
     if (!__any(pm != 0u)) return;                            // no mismatching allele in this wavefront's 512 positions
+    dirty |= pm != 0u;                                       // my 8 positions lie in one 64-position block (store_part_row tells the gate kernel)
     if (MERGED) {
         while (pm) {
             const uint32_t j = (uint32_t)__builtin_ctz(pm);
@@ -453,6 +457,17 @@ __device__ __forceinline__ void store_part_row(uint8_t *part, const WorkItem &w,
         *reinterpret_cast<uint4 *>(row + 2u * N_PPT * tid) =
             make_uint4((tc[0] & 0xffffu) | tc[1] << 16, tc[0] >> 16 | (tc[1] & 0xffff0000u), (tc[2] & 0xffffu) | tc[3] << 16, tc[2] >> 16 | (tc[3] & 0xffff0000u));
     }
+}
+
+// 64-position blocks of the tile in which this item added to the allele totals: one word per work item, next to its coverage
+// partial row in spirit (indexed by the row's slot); the gate kernel ORs the words of the tile's items and does not even read
+// the totals of the other blocks.  Eight consecutive threads share a block, so a wavefront's ballot folds to 8 bits.
+__device__ __forceinline__ void store_item_dirty(uint32_t *slot_dirty, const WorkItem &w, const bool dirty, const int tid) {
+    const unsigned long long b = __ballot(dirty);
+    uint32_t byte = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) byte |= ((b >> (8 * i)) & 0xffull) ? 1u << i : 0u;
+    if ((tid & 63) == 0 && byte) atomicOr(&slot_dirty[w.slot], byte << (8 * (tid >> 6)));      // four wavefronts, one word of THIS item: no contention
 }
 
 // Ring refill of the chunk descriptors, called by every thread right after barrier (A) of chunk c: every
@@ -541,6 +556,7 @@ __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a) {
     if (tid == 0) L.evn = 0;
     if (tid < N_NT / 64 + 1) L.carry[tid] = 0;
     uint32_t tc[N_PPT / 2] = {0u, 0u, 0u, 0u};                  // coverage totals of my 8 positions over the item's samples (u16 pairs)
+    bool dirty = false;                                         // some pass of this item added to the allele totals of my 8 positions
 
     const uint32_t nch = w.chunk_hi - w.chunk_lo;
     // the chunk descriptors go through a ring of MAX_CHUNKS_PER_ITEM LDS slots: one deep (sample, tile) pair alone can
@@ -611,12 +627,13 @@ __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a) {
         hreg = load_hdr(c + 2u);
         __syncthreads();                                            // (B): this chunk is in the bins; the next chunk's headers are visible
         if (c + 1u < nch) issue_loads(c + 1u);                       // in flight under the per-sample pass
-        if (last_chunk) narrow_pass<NarrowLds, 0, MERGED>(L, a, tc, t0, tid, lane, wave, cd.sample, cd.pair, cd.pad);
+        if (last_chunk) narrow_pass<NarrowLds, 0, MERGED>(L, a, tc, dirty, t0, tid, lane, wave, cd.sample, cd.pair, cd.pad);
         prev_last = last_chunk;
     }
     __syncthreads();
     if (!MERGED) flush_events<NarrowLds, N_NT, N_EVCAP>(L, a, tid);
     store_part_row(a.part, w, tc, tid);
+    store_item_dirty(a.slot_dirty, w, dirty, tid);
 }
 
 __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32(PileupArgs a) { pileup_tiles_narrow32_body<false>(a); }
@@ -711,6 +728,7 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_dense(PileupArgs a) {
     if (tid == 0) L.evn = 0;
     if (tid < N_NT / 64 + 1) L.carry[tid] = 0;
     uint32_t tc[N_PPT / 2] = {0u, 0u, 0u, 0u};                  // coverage totals of my 8 positions over the item's samples (u16 pairs)
+    bool dirty = false;                                         // some pass of this item added to the allele totals of my 8 positions
 
     const uint32_t nch = w.chunk_hi - w.chunk_lo;
     // the chunk descriptors go through a ring of MAX_CHUNKS_PER_ITEM LDS slots: one deep (sample, tile) pair alone can
@@ -778,12 +796,13 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_dense(PileupArgs a) {
         }
         if (last_chunk) {
             __syncthreads();                                        // (B)
-            narrow_pass<DenseLds, D_PAD>(L, a, tc, t0, tid, lane, wave, cd.sample, cd.pair, cd.pad);
+            narrow_pass<DenseLds, D_PAD>(L, a, tc, dirty, t0, tid, lane, wave, cd.sample, cd.pair, cd.pad);
         }
     }
     __syncthreads();
     flush_events<DenseLds, N_NT, N_EVCAP>(L, a, tid);
     store_part_row(a.part, w, tc, tid);
+    store_item_dirty(a.slot_dirty, w, dirty, tid);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -799,6 +818,18 @@ constexpr int GATE_NT = 256;
 constexpr int GATE_PPT = TILE / GATE_NT;       // 8 consecutive positions per thread: one 8 / 16 / 32-byte load per row and thread
 static_assert(GATE_PPT == 8, "the gate kernel is written for 8 positions per thread (one site_bits word per 8 lanes)");
 
+// Per-sample records of the called positions are stored per TILE SLOT, not per sample: a tile's sites own rows of
+// tile_nslots[tile] cells -- one per sample that has reads in the tile (pack.cpp numbers them; the pairs of a split sample share
+// one) -- so a sparse cohort (BASELINE configs[3]: 500 samples, a species carried by a handful) does not pay 500 cells per
+// site.  The host expands to all samples when it fetches.  Cell of (site, slot): tile_cell_base[tile] + (site - first site of
+// the tile) * slots + slot; the gate kernel reserves a tile's cells with one 64-bit atomic (counters[6..7]).
+struct CellMap { const uint32_t *tile_site_base; const unsigned long long *tile_cell_base; const uint32_t *tile_nslots; unsigned long long cap_cells; };
+__device__ __forceinline__ uint64_t cell_of(const CellMap &m, const uint32_t tile, const uint32_t site, const uint32_t slot) {
+    return m.tile_cell_base[tile] + (uint64_t)(site - m.tile_site_base[tile]) * m.tile_nslots[tile] + slot;
+}
+
+struct GateTile { uint32_t tile, slot_lo, slot_16, slot_w, slot_hi, vbeg, vend, n_slots; uint64_t row0; uint64_t pad_; };   // 48 B (pack.cpp)
+
 struct GateArgs {
     uint32_t *tot; const uint8_t *part; const uint64_t *slot_off; const uint32_t *tile_slot_start, *tile_slot_u16, *tile_slot_wide; uint64_t npos;
     const uint32_t *tile_vbeg, *tile_vend; int min_cov, min_snvs; double min_frac;
@@ -806,41 +837,51 @@ struct GateArgs {
     const uint32_t *ref4, *ref_lc;
     unsigned long long *site_bits; uint32_t *site_rank; SiteRec *sites; uint32_t cap_sites; uint32_t *counters, *counters_next;
     uint32_t *tile_site_base, *tile_site_cnt; const uint32_t *active_tiles;
-    msnv_site_sample *out; uint16_t *cov_col; uint8_t *site_flags; uint32_t n_samples, cap_out;
+    msnv_site_sample *out; uint16_t *cov_col; uint8_t *site_flags; uint32_t cap_out;
+    const uint32_t *tile_nslots; unsigned long long *tile_cell_base; unsigned long long cap_cells;
+    const GateTile *gate_tiles; uint32_t *tile_dirty; uint32_t *unc_sites;
     uint32_t decide_here;                      // 1: no sample is split into several pairs, so the calling rule is applied right here
 };
 
 __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
-    uint32_t *const tot = a.tot; const uint8_t *const part = a.part; const uint64_t *const slot_off = a.slot_off;
-    const uint32_t *const tile_slot_start = a.tile_slot_start, *const tile_slot_u16 = a.tile_slot_u16, *const tile_slot_wide = a.tile_slot_wide;
-    const uint64_t npos = a.npos; const uint32_t *const tile_vbeg = a.tile_vbeg, *const tile_vend = a.tile_vend;
+    uint32_t *const tot = a.tot; const uint8_t *const part = a.part;
+    const uint64_t npos = a.npos;
     const int min_cov = a.min_cov, min_snvs = a.min_snvs; const double min_frac = a.min_frac;
     unsigned long long *const site_bits = a.site_bits; uint32_t *const site_rank = a.site_rank; SiteRec *const sites = a.sites;
     const uint32_t cap_sites = a.cap_sites; uint32_t *const counters = a.counters; uint32_t *const tile_site_base = a.tile_site_base, *const tile_site_cnt = a.tile_site_cnt;
-    const uint32_t *const active_tiles = a.active_tiles; msnv_site_sample *const out = a.out; uint16_t *const cov_col = a.cov_col;
-    const uint32_t n_samples = a.n_samples, cap_out = a.cap_out;
+    msnv_site_sample *const out = a.out; uint16_t *const cov_col = a.cov_col;
+    const uint32_t cap_out = a.cap_out;
     __shared__ uint32_t s_pop, s_ind;
+    __shared__ unsigned long long s_cell;
     if (threadIdx.x == 0) { s_pop = 0; s_ind = 0; }
     // the counter block of the NEXT pass (the passes of a dataset alternate between two blocks: no memset between passes)
     if (blockIdx.x == 0) for (uint32_t i = threadIdx.x; i < CNT_WORDS; i += GATE_NT) a.counters_next[i] = 0u;
     __shared__ uint32_t s_wave[GATE_NT / 64];
     __shared__ uint32_t s_base;
-    const uint32_t tile = active_tiles[blockIdx.x];           // tiles that hold work items; the others have no coverage
+    // everything the workgroup needs to know about its tile in ONE load (the kernel is a chain of dependent loads; with a sparse
+    // cohort -- BASELINE configs[3]: a pair or two per tile -- the chain is all there is)
+    const GateTile gt = a.gate_tiles[blockIdx.x];              // tiles that hold work items; the others have no coverage
+    const uint32_t tile = gt.tile;
     const uint32_t t0 = tile * TILE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t vb = tile_vbeg[tile], ve = tile_vend[tile];
+    const uint32_t vb = gt.vbeg, ve = gt.vend;
     const uint32_t p0 = (uint32_t)GATE_PPT * (uint32_t)tid;    // my positions: p0 .. p0 + 7
     const uint64_t g0 = (uint64_t)t0 + p0;
 
-    const uint32_t slot_lo = tile_slot_start[tile], slot_hi = tile_slot_start[tile + 1];
-    const uint32_t slot_16 = tile_slot_u16[tile], slot_w = tile_slot_wide[tile];
+    const uint32_t slot_lo = gt.slot_lo, slot_hi = gt.slot_hi;
+    const uint32_t slot_16 = gt.slot_16, slot_w = gt.slot_w;
+    // 64-position blocks of the tile in which some pass added to the allele totals (narrow_pass / wide kernel): the other blocks'
+    // totals and individual-rule bits are zero and are not even read (16.6 B per position against ~8 B of reads at 5x)
+    uint32_t dirty = 0;
+    for (uint32_t sl = slot_lo; sl < slot_hi; ++sl) dirty |= a.tile_dirty[sl];      // (uniform addresses, independent loads)
+    const bool my_dirty = (dirty >> (p0 >> 6)) & 1u;
     uint32_t covs[GATE_PPT];
 #pragma unroll
     for (int j = 0; j < GATE_PPT; ++j) covs[j] = 0;
     // coverage = sum of the tile's work-item partials.  The rows of a tile are contiguous (u8 rows, then u16 rows, then the
     // u32 rows of wide items), so the addresses need no per-row lookup and the loads of several rows are in flight together.
     if (slot_16 > slot_lo) {
-        const uint8_t *p8 = part + slot_off[slot_lo] + p0;
+        const uint8_t *p8 = part + gt.row0 + p0;
         const uint32_t n8 = slot_16 - slot_lo;
         // u8 rows are summed two positions per register (u16 halves: positions (0,2) (1,3) (4,6) (5,7)); widened every 255 rows
         for (uint32_t r0 = 0; r0 < n8; r0 += 255u) {
@@ -869,7 +910,7 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
         }
     }
     if (slot_w > slot_16) {
-        const uint8_t *p16 = part + slot_off[slot_16] + 2u * p0;
+        const uint8_t *p16 = part + gt.row0 + (uint64_t)(slot_16 - slot_lo) * TILE + 2u * p0;
         const uint32_t n16 = slot_w - slot_16;
 #pragma unroll 2
         for (uint32_t s = 0; s < n16; ++s) {
@@ -879,7 +920,7 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
         }
     }
     if (slot_hi > slot_w) {
-        const uint8_t *p32 = part + slot_off[slot_w] + 4u * p0;
+        const uint8_t *p32 = part + gt.row0 + (uint64_t)(slot_16 - slot_lo) * TILE + (uint64_t)(slot_w - slot_16) * 2u * TILE + 4u * p0;
         const uint32_t n32 = slot_hi - slot_w;
         for (uint32_t s = 0; s < n32; ++s) {
             const uint4 v0 = *reinterpret_cast<const uint4 *>(p32 + (uint64_t)s * 4u * TILE);
@@ -893,21 +934,24 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
     uint32_t nal[4][GATE_PPT];
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
+#pragma unroll
+        for (int j = 0; j < GATE_PPT; ++j) nal[x][j] = 0u;
+        if (!my_dirty) continue;
         uint32_t *tp = tot + (uint64_t)x * npos + g0;
-        const uint4 a = *reinterpret_cast<const uint4 *>(tp), b = *reinterpret_cast<const uint4 *>(tp + 4);
-        nal[x][0] = a.x; nal[x][1] = a.y; nal[x][2] = a.z; nal[x][3] = a.w; nal[x][4] = b.x; nal[x][5] = b.y; nal[x][6] = b.z; nal[x][7] = b.w;
-        if (a.x | a.y | a.z | a.w) *reinterpret_cast<uint4 *>(tp) = make_uint4(0u, 0u, 0u, 0u);
-        if (b.x | b.y | b.z | b.w) *reinterpret_cast<uint4 *>(tp + 4) = make_uint4(0u, 0u, 0u, 0u);
+        const uint4 va = *reinterpret_cast<const uint4 *>(tp), vb4 = *reinterpret_cast<const uint4 *>(tp + 4);
+        nal[x][0] = va.x; nal[x][1] = va.y; nal[x][2] = va.z; nal[x][3] = va.w; nal[x][4] = vb4.x; nal[x][5] = vb4.y; nal[x][6] = vb4.z; nal[x][7] = vb4.w;
+        if (va.x | va.y | va.z | va.w) *reinterpret_cast<uint4 *>(tp) = make_uint4(0u, 0u, 0u, 0u);
+        if (vb4.x | vb4.y | vb4.z | vb4.w) *reinterpret_cast<uint4 *>(tp + 4) = make_uint4(0u, 0u, 0u, 0u);
     }
     // individual-rule bits of my 8 positions (4 per position) and the "split sample" marks; consumed here and here only, so they
     // are left zero for the next pass like the allele totals
-    const uint32_t ind4w = a.ind4[g0 >> 3];
+    const uint32_t ind4w = my_dirty ? a.ind4[g0 >> 3] : 0u;
     if (ind4w) a.ind4[g0 >> 3] = 0u;
-    const uint32_t uncb = reinterpret_cast<const uint8_t *>(a.unc_bits)[g0 >> 3];
+    const uint32_t uncb = my_dirty ? reinterpret_cast<const uint8_t *>(a.unc_bits)[g0 >> 3] : 0u;
     if (uncb) reinterpret_cast<uint8_t *>(a.unc_bits)[g0 >> 3] = 0;
     const uint32_t refw = a.ref4[g0 >> 3];                                  // nt16 codes of my 8 positions
     const uint32_t lcb = reinterpret_cast<const uint8_t *>(a.ref_lc)[g0 >> 3];   // FASTA character is a lower-case a / c / g / t
-    uint32_t okm = 0, flw[2] = {0u, 0u};                                    // site mask; pop | ind << 4 of my 8 positions, one byte each
+    uint32_t okm = 0, uncm = 0, flw[2] = {0u, 0u};                          // site mask; "ask the per-sample records" mask; pop | ind << 4 of my 8 positions
 #pragma unroll
     for (int j = 0; j < GATE_PPT; ++j) {
         const uint32_t p = p0 + (uint32_t)j, cov = covs[j];
@@ -928,6 +972,7 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
                 ok |= is_pop || is_ind || unc;
                 if (lc && rc == (1u << x)) continue;                       // skip-same-base, case-sensitive (call_vC.cpp:580)
                 if (is_pop) pop |= 1u << x; else if (is_ind) ind |= 1u << x;
+                else if (unc) uncm |= 1u << j;                             // a split / merged sample may hold >= t reads in sum: msnv_decide_sites
             }
             okm |= (ok ? 1u : 0u) << j;
             flw[j >> 2] |= (pop | ind << 4) << (8 * (j & 3));
@@ -939,6 +984,7 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
         w |= __shfl_xor(w, 1); w |= __shfl_xor(w, 2); w |= __shfl_xor(w, 4);
         if ((lane & 7) == 0) site_bits[g0 >> 6] = w;
     }
+    uint32_t okm_certain;
     const uint32_t mycnt = (uint32_t)__popc(okm);
     const uint32_t incl = (uint32_t)wave_inclusive_scan((int)mycnt);
     if (lane == 63) s_wave[wave] = incl;
@@ -949,33 +995,38 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
         if (wv < wave) mybase += s_wave[wv];
         total += s_wave[wv];
     }
+    const uint32_t n_slots = gt.n_slots;
     if (tid == 0) {
+        if (dirty) for (uint32_t sl = slot_lo; sl < slot_hi; ++sl) a.tile_dirty[sl] = 0u;     // (every thread read them before the barrier above)
         uint32_t base = total ? atomicAdd(&counters[2], total) : 0u;
         s_base = base;
         tile_site_base[tile] = base;
         tile_site_cnt[tile] = total;
+        const unsigned long long cb = total ? atomicAdd(reinterpret_cast<unsigned long long *>(&counters[CNT_CELLS]), (unsigned long long)total * n_slots) : 0ull;
+        s_cell = cb;
+        a.tile_cell_base[tile] = cb;
     }
-    if (a.decide_here && okm) {                                           // output-line tallies (before the first-line drop)
+    // output-line tallies (before the first-line drop); the sites of the "ask" mask are tallied by msnv_decide_sites
+    okm_certain = okm & ~uncm;
+    if (okm_certain) {
         uint32_t np = 0, ni = 0;
 #pragma unroll
-        for (int j = 0; j < GATE_PPT; ++j) { const uint32_t f = (flw[j >> 2] >> (8 * (j & 3))) & 0xffu; np += (f & 15u) ? 1u : 0u; ni += (f >> 4) ? 1u : 0u; }
+        for (int j = 0; j < GATE_PPT; ++j) { const uint32_t f = ((okm_certain >> j) & 1u) ? (flw[j >> 2] >> (8 * (j & 3))) & 0xffu : 0u; np += (f & 15u) ? 1u : 0u; ni += (f >> 4) ? 1u : 0u; }
         if (np) atomicAdd(&s_pop, np);
         if (ni) atomicAdd(&s_ind, ni);
     }
     __syncthreads();
     if (total == 0) return;
-    if (tid == 0 && a.decide_here) {
-        if (s_pop) atomicAdd(&counters[4], s_pop);
-        if (s_ind) atomicAdd(&counters[5], s_ind);
-    }
+    if (tid == 0 && (s_pop | s_ind)) atomicAdd(reinterpret_cast<unsigned long long *>(&counters[CNT_TALLY]), (unsigned long long)s_pop | (unsigned long long)s_ind << 32);
     const uint32_t base = s_base;
-    if ((uint64_t)base + total <= cap_out) {                         // else: the host sees the site count and runs again with a larger buffer
-        // the per-sample records of this tile's sites start out zero: gather and scatter (one launch, side by side) only add to them
-        uint16_t *rows = reinterpret_cast<uint16_t *>(out + (uint64_t)base * n_samples);
-        const uint64_t nhw = (uint64_t)total * n_samples * (sizeof(msnv_site_sample) / 2);
+    if ((uint64_t)base + total <= cap_out && s_cell + (unsigned long long)total * n_slots <= a.cap_cells) {   // else: the host sees the counts and runs again with larger buffers
+        // the per-sample cells of this tile's sites start out zero: gather and scatter (one launch, side by side) only add to them
+        const uint64_t n_cells = (uint64_t)total * n_slots;
+        uint16_t *rows = reinterpret_cast<uint16_t *>(out + s_cell);
+        const uint64_t nhw = n_cells * (sizeof(msnv_site_sample) / 2);
         for (uint64_t i = (uint64_t)tid; i < nhw; i += GATE_NT) rows[i] = 0;
-        uint16_t *crow = cov_col + (uint64_t)base * n_samples;      // samples without reads in this tile keep coverage 0
-        for (uint64_t i = (uint64_t)tid; i < (uint64_t)total * n_samples; i += GATE_NT) crow[i] = 0;
+        uint16_t *crow = cov_col + s_cell;                          // samples without reads at a position keep coverage 0
+        for (uint64_t i = (uint64_t)tid; i < n_cells; i += GATE_NT) crow[i] = 0;
     }
     // index of the first site of every 64 positions: an event finds its site as rank + popcount of the lower bits
     if ((lane & 7) == 0) site_rank[g0 >> 6] = base + mybase;
@@ -988,7 +1039,11 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
                 s.gpos = (uint32_t)(g0 + (uint32_t)j); s.cov = covs[j];
                 s.n[0] = nal[0][j]; s.n[1] = nal[1][j]; s.n[2] = nal[2][j]; s.n[3] = nal[3][j];
                 sites[idx] = s;
-                if (a.decide_here && idx < cap_out) a.site_flags[idx] = (uint8_t)((flw[j >> 2] >> (8 * (j & 3))) & 0xffu);
+                if (idx < cap_out) a.site_flags[idx] = (uint8_t)((flw[j >> 2] >> (8 * (j & 3))) & 0xffu);
+                if ((uncm >> j) & 1u) {                                 // decided from the per-sample records behind the scatter
+                    const uint32_t u = atomicAdd(&counters[CNT_UNC], 1u);
+                    if (u < cap_sites) a.unc_sites[u] = idx;
+                }
             }
             ++idx;
         }
@@ -1005,24 +1060,28 @@ __device__ __forceinline__ void add_u16(uint16_t *field, uint32_t v) {
 
 // tail of a pass: per-sample coverages (gather half) and allele counts (scatter half) of the surviving sites.
 // ------------------------------------------------------------------------------------------
-constexpr uint32_t GATHER_SPLIT = 4;
 constexpr uint32_t SCATTER_BLOCKS_PER_LIST = 32;
 struct TailArgs {
     const SiteRec *sites; const uint32_t *tile_site_base, *tile_site_cnt, *tile_pair_start, *tile_pair_merged; const TilePair *pairs; const uint8_t *spill;
     // merged groups of shallow pairs: their per-sample coverage at the called positions is recomputed from the pieces
     const WorkItem *work_merged; const ChunkDesc *chunks; const PieceHdr *hdr8m; const uint8_t *seq, *qual; const uint32_t *ref4;
     uint32_t n_merged_blocks, min_baseq;
-    msnv_site_sample *out; uint16_t *cov_col; uint32_t n_samples, cap_out; const uint32_t *active_tiles; uint32_t n_gather_blocks;
+    msnv_site_sample *out; uint16_t *cov_col; uint32_t cap_out; const uint32_t *active_tiles; uint32_t n_gather_blocks;
+    CellMap cells; uint32_t gather_split;
     const Pair32 *events, *overflow; uint32_t *counters; uint32_t cap_list, cap_overflow;
     const unsigned long long *site_bits; const uint32_t *site_rank;
 };
 
 __device__ __forceinline__ void gather_cov_block(const TailArgs &a, const uint32_t bid) {
+    const uint32_t GATHER_SPLIT = a.gather_split;
     const uint32_t tile = a.active_tiles[bid / GATHER_SPLIT], part = bid % GATHER_SPLIT;   // a tile's sites are dealt to GATHER_SPLIT workgroups
     const uint32_t n = a.tile_site_cnt[tile];
     if (n <= part) return;
     const uint32_t base = a.tile_site_base[tile];
     if (base + n > a.cap_out) return;                   // the host sees the site count and retries with a larger buffer
+    const uint32_t n_slots = a.cells.tile_nslots[tile];
+    const unsigned long long cell0 = a.cells.tile_cell_base[tile];
+    if (cell0 + (unsigned long long)n * n_slots > a.cells.cap_cells) return;
     const uint32_t ps = a.tile_pair_start[tile], np = a.tile_pair_merged[tile] - ps;      // the merged pairs (behind the others) spill nothing
     if (np == 0u) return;
     const uint32_t t0 = tile * TILE;
@@ -1033,20 +1092,21 @@ __device__ __forceinline__ void gather_cov_block(const TailArgs &a, const uint32
         const uint32_t off = a.sites[base + j].gpos - t0;
         const uint32_t cov = a.spill[(uint64_t)(ps + kk) * TILE + off];
         const TilePair pr = a.pairs[ps + kk];
-        uint16_t *dst = &a.cov_col[(uint64_t)(base + j) * a.n_samples + pr.sample];
-        if (pr.pad) add_u16(dst, cov);                      // one of several pairs of this sample: the groups add up
+        uint16_t *dst = &a.cov_col[cell0 + (uint64_t)j * n_slots + (pr.pad >> 8)];       // pad: kind | slot << 8
+        if (pr.pad & 0xffu) add_u16(dst, cov);              // one of several pairs of this sample: the groups add up
         else if (cov != 255u) *dst = (uint16_t)cov;         // 255 (wide kernel only): the overflow list holds the value, the scatter half writes it
     }
 }
 
 __device__ __forceinline__ void scatter_events_block(const TailArgs &a, const uint32_t bx, const uint32_t k) {
-    if (a.counters[2] > a.cap_out) return;
+    if (a.counters[2] > a.cap_out || *reinterpret_cast<const unsigned long long *>(&a.counters[CNT_CELLS]) > a.cells.cap_cells) return;
     auto apply = [&](const Pair32 e, const bool allele) {
         const unsigned long long w = a.site_bits[e.x >> 6], bit = 1ull << (e.x & 63u);
         if (!(w & bit)) return;                    // most events are sequencing errors at positions that are not sites
         const uint32_t s = a.site_rank[e.x >> 6] + (uint32_t)__popcll(w & (bit - 1ull));
-        if (allele) add_u16(&a.out[(uint64_t)s * a.n_samples + (e.y >> 18)].n[(e.y >> 16) & 3u], e.y & 0xffffu);   // one event per (site, pair, allele)
-        else a.cov_col[(uint64_t)s * a.n_samples + (e.y >> 16)] = (uint16_t)(e.y & 0xffffu);
+        // events carry the SLOT of their sample in the tile (pack.cpp)
+        if (allele) add_u16(&a.out[cell_of(a.cells, e.x / TILE, s, e.y >> 18)].n[(e.y >> 16) & 3u], e.y & 0xffffu);   // one event per (site, pair, allele)
+        else a.cov_col[cell_of(a.cells, e.x / TILE, s, e.y >> 16)] = (uint16_t)(e.y & 0xffffu);
     };
     const uint32_t n_k = min(a.counters[16u + k * EV_CNT_STRIDE], a.cap_list);
     const Pair32 *list = a.events + (uint64_t)k * a.cap_list;
@@ -1065,7 +1125,7 @@ __device__ __forceinline__ void scatter_events_block(const TailArgs &a, const ui
                 const unsigned long long bit = 1ull << (e[u].x & 63u);
                 if (!(w[u] & bit)) continue;
                 const uint32_t s = a.site_rank[e[u].x >> 6] + (uint32_t)__popcll(w[u] & (bit - 1ull));
-                add_u16(&a.out[(uint64_t)s * a.n_samples + (e[u].y >> 18)].n[(e[u].y >> 16) & 3u], e[u].y & 0xffffu);
+                add_u16(&a.out[cell_of(a.cells, e[u].x / TILE, s, e[u].y >> 18)].n[(e[u].y >> 16) & 3u], e[u].y & 0xffffu);
             }
         }
         for (; i < n_k; i += stride) apply(list[i], true);
@@ -1092,6 +1152,9 @@ __device__ __forceinline__ void gather_merged_block(const TailArgs &a, const uin
     if (n == 0u) return;
     const uint32_t base = a.tile_site_base[tile];
     if (base + n > a.cap_out) return;                   // the host sees the site count and retries with a larger buffer
+    const uint32_t n_slots = a.cells.tile_nslots[tile];
+    const unsigned long long cell0 = a.cells.tile_cell_base[tile];
+    if (cell0 + (unsigned long long)n * n_slots > a.cells.cap_cells) return;
     const uint32_t t0 = tile * TILE;
     const uint32_t tid = threadIdx.x;
     if (tid < TILE / 64) { s_bits[tid] = a.site_bits[(t0 >> 6) + tid]; s_rank[tid] = a.site_rank[(t0 >> 6) + tid] - base; }
@@ -1105,7 +1168,7 @@ __device__ __forceinline__ void gather_merged_block(const TailArgs &a, const uin
         const uint32_t m = g.pad;                         // pairs of the group
         const uint32_t batch = max(1u, GM_CELLS / m);     // sites per round
         __syncthreads();                                  // the previous group's table and sample list are no longer read
-        if (tid < m) s_gsample[tid] = a.pairs[g.pair + tid].sample;
+        if (tid < m) s_gsample[tid] = a.pairs[g.pair + tid].pad >> 8;      // the pair's slot in the tile
         for (uint32_t j0 = 0; j0 < n; j0 += batch) {
             const uint32_t nj = min(batch, n - j0);
             for (uint32_t i = tid; i < (nj * m + 1u) / 2u; i += blockDim.x) s_cov[i] = 0u;
@@ -1141,7 +1204,7 @@ __device__ __forceinline__ void gather_merged_block(const TailArgs &a, const uin
             __syncthreads();
             for (uint32_t i = tid; i < nj * m; i += blockDim.x) {
                 const uint32_t v = (s_cov[i >> 1] >> (16u * (i & 1u))) & 0xffffu;
-                const uint64_t cell = (uint64_t)(base + j0 + i / m) * a.n_samples + s_gsample[i % m];
+                const uint64_t cell = cell0 + (uint64_t)(j0 + i / m) * n_slots + s_gsample[i % m];
                 if (v) a.cov_col[cell] = (uint16_t)v;
                 const uint32_t al = s_al[i];
                 if (al) {
@@ -1168,6 +1231,11 @@ __global__ __launch_bounds__(256) void msnv_gather_scatter(TailArgs a) {
         for (uint32_t k = 0; k < EV_LISTS; ++k) { const uint32_t c = a.counters[16u + k * EV_CNT_STRIDE]; total += c; fullest = max(fullest, c); }
         if (fullest > a.cap_list) total = (unsigned long long)fullest * EV_LISTS;
         a.counters[0] = (uint32_t)min(total, 0xffffffffull);
+        // the gate kernel's spread counters, where the host reads them (msnv_decide_sites adds its own lines to [4], [5] afterwards)
+        const unsigned long long cells = *reinterpret_cast<const unsigned long long *>(&a.counters[CNT_CELLS]);
+        const unsigned long long tally = *reinterpret_cast<const unsigned long long *>(&a.counters[CNT_TALLY]);
+        a.counters[6] = (uint32_t)cells; a.counters[7] = (uint32_t)(cells >> 32);
+        a.counters[4] = (uint32_t)tally; a.counters[5] = (uint32_t)(tally >> 32);
     }
     if (blockIdx.x < n_scatter) scatter_events_block(a, blockIdx.x % SCATTER_BLOCKS_PER_LIST, blockIdx.x / SCATTER_BLOCKS_PER_LIST);
     else if (blockIdx.x < n_scatter + a.n_merged_blocks) gather_merged_block(a, blockIdx.x - n_scatter);
@@ -1180,16 +1248,20 @@ __global__ __launch_bounds__(256) void msnv_gather_scatter(TailArgs a) {
 //   population  iff n_x >= t and (double)n_x >= cov * min_fraction          (:588)
 //   individual  iff not population and some sample has x_s >= t              (:593-600)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void msnv_decide_sites(const SiteRec *sites, uint32_t *counters, uint32_t cap_sites, uint32_t cap_out,
+__global__ __launch_bounds__(256) void msnv_decide_sites(const SiteRec *sites, const uint32_t *unc_sites, uint32_t *counters, uint32_t cap_sites, uint32_t cap_out,
                                                          const uint32_t *ref4, const uint32_t *ref_lc, const msnv_site_sample *out,
-                                                         uint32_t n_samples, int min_snvs, double min_frac, uint8_t *site_flags, uint32_t cap_list) {
+                                                         const CellMap cells, int min_snvs, double min_frac, uint8_t *site_flags) {
+    // Only the sites the gate kernel could not decide: some allele x has n_x >= t, is no population call, no single pair holds
+    // >= t reads of it, but a sample that is split into several pairs / sits in a merged group holds some -- the individual rule
+    // then asks the summed per-sample records.  One wavefront per site.
     __shared__ uint32_t s_pop, s_ind;
     if (threadIdx.x == 0) { s_pop = 0; s_ind = 0; }
     __syncthreads();
-    const uint32_t n_sites = counters[2];
+    const uint32_t n_unc = min(counters[CNT_UNC], cap_sites), n_sites = counters[2];
     const int lane = threadIdx.x & 63;
-    if (n_sites <= cap_sites && n_sites <= cap_out) {
-        for (uint32_t site = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); site < n_sites; site += gridDim.x * (blockDim.x >> 6)) {
+    if (n_sites <= cap_sites && n_sites <= cap_out && *reinterpret_cast<const unsigned long long *>(&counters[CNT_CELLS]) <= cells.cap_cells) {
+        for (uint32_t u = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); u < n_unc; u += gridDim.x * (blockDim.x >> 6)) {
+            const uint32_t site = unc_sites[u];
             const SiteRec s = sites[site];
             const uint32_t rc = (ref4[s.gpos >> 3] >> (4 * (s.gpos & 7))) & 0xfu;
             const bool lc = (ref_lc[s.gpos >> 5] >> (s.gpos & 31)) & 1u;
@@ -1200,8 +1272,10 @@ __global__ __launch_bounds__(256) void msnv_decide_sites(const SiteRec *sites, u
                 if ((int)nx < min_snvs) continue;           // neither rule can fire
                 if ((double)nx >= (double)(int)s.cov * min_frac) { pop |= 1u << x; continue; }
                 bool any = false;
-                for (uint32_t i = lane; i < n_samples; i += 64)
-                    any |= (int)out[(uint64_t)site * n_samples + i].n[x] >= min_snvs;
+                const uint32_t tile = s.gpos / TILE, n_slots = cells.tile_nslots[tile];
+                const uint64_t row = cell_of(cells, tile, site, 0u);
+                for (uint32_t i = lane; i < n_slots; i += 64)
+                    any |= (int)out[row + i].n[x] >= min_snvs;
                 if (__any(any)) ind |= 1u << x;
             }
             if (lane == 0) {
@@ -1387,8 +1461,8 @@ void dev_stream_destroy(void *stream) { if (stream) (void)hipStreamDestroy((hipS
 
 void dev_free_all(DeviceCols &d) {
     void *ptrs[] = {d.hdr, d.hdr8, d.hdr8m, d.tile_pair_merged, d.blk, d.seq, d.qual, d.s_read_base, d.s_seq_base, d.ref4, d.ref_lc, d.pairs,
-                    d.tile_pair_start, d.work, d.chunks, d.tile_vbeg, d.tile_vend, d.tot, d.part, d.tile_slot_start, d.tile_slot_u16, d.tile_slot_wide, d.slot_off, d.spill, d.events, d.overflow, d.counters, d.ind4,
-                    d.sites, d.tile_site_base, d.tile_site_cnt, d.out, d.cov_col, d.site_flags,
+                    d.tile_pair_start, d.work, d.chunks, d.tile_vbeg, d.tile_vend, d.tot, d.part, d.tile_slot_start, d.tile_slot_u16, d.tile_slot_wide, d.slot_off, d.spill, d.events, d.overflow, d.counters, d.ind4, d.tile_dirty, d.unc_sites, d.gate_tiles,
+                    d.sites, d.tile_site_base, d.tile_site_cnt, d.tile_cell_base, d.tile_nslots, d.out, d.cov_col, d.site_flags,
                     d.cov_iv, d.s_cov_base, d.cov_pairs, d.cov_work, d.tile_len, d.tile_contig_dev, d.cov_acc};
     for (void *p : ptrs) dev_free(p);
     void *aptrs[] = {d.ann.seg_beg, d.ann.seg_end, d.ann.seg_gene, d.ann.genes, d.ann.contigs, d.ann.codons, d.ann.out, d.ann.err};
@@ -1396,22 +1470,28 @@ void dev_free_all(DeviceCols &d) {
     for (void *e : d.timing_events) if (e) (void)hipEventDestroy((hipEvent_t)e);
     for (void *e : d.event_pool) (void)hipEventDestroy((hipEvent_t)e);
     if (d.pinned_cnt) (void)hipHostFree(d.pinned_cnt);
-    void *alts[] = {d.alt.tot, d.alt.part, d.alt.spill, d.alt.events, d.alt.overflow, d.alt.counters, d.alt.ind4, d.alt.sites, d.alt.tile_site_base,
-                    d.alt.tile_site_cnt, d.alt.out, d.alt.cov_col, d.alt.site_flags, d.alt.site_bits, d.site_bits, d.alt.site_rank, d.site_rank, d.active_tiles};
+    void *alts[] = {d.alt.tot, d.alt.part, d.alt.spill, d.alt.events, d.alt.overflow, d.alt.counters, d.alt.ind4, d.alt.tile_dirty, d.alt.unc_sites, d.alt.sites, d.alt.tile_site_base,
+                    d.alt.tile_site_cnt, d.alt.tile_cell_base, d.alt.out, d.alt.cov_col, d.alt.site_flags, d.alt.site_bits, d.site_bits, d.alt.site_rank, d.site_rank, d.active_tiles};
     for (void *p : alts) dev_free(p);
     if (d.stream2) (void)hipStreamDestroy((hipStream_t)d.stream2);
     d = DeviceCols{};
 }
 
-static int ensure_out(DeviceCols &d, uint64_t n_sites) {
-    if (n_sites <= d.cap_out_sites) return MSNV_OK;
-    dev_free(d.out); dev_free(d.cov_col); dev_free(d.site_flags);
-    d.out = nullptr; d.cov_col = nullptr; d.site_flags = nullptr;
-    uint64_t cap = std::max<uint64_t>(n_sites + n_sites / 4, 1024);
-    if (int rc = dev_alloc((void **)&d.out, cap * d.n_samples * sizeof(msnv_site_sample), &d.device_bytes)) return rc;
-    if (int rc = dev_alloc((void **)&d.cov_col, cap * d.n_samples * sizeof(uint16_t) + 16, &d.device_bytes)) return rc;
-    if (int rc = dev_alloc((void **)&d.site_flags, cap, &d.device_bytes)) return rc;
-    d.cap_out_sites = cap;
+static int ensure_out(DeviceCols &d, uint64_t n_sites, uint64_t n_cells) {
+    if (n_sites > d.cap_out_sites) {
+        dev_free(d.site_flags); d.site_flags = nullptr;
+        const uint64_t cap = std::max<uint64_t>(n_sites + n_sites / 4, 1024);
+        if (int rc = dev_alloc((void **)&d.site_flags, cap, &d.device_bytes)) return rc;
+        d.cap_out_sites = cap;
+    }
+    if (n_cells > d.cap_cells) {
+        dev_free(d.out); dev_free(d.cov_col);
+        d.out = nullptr; d.cov_col = nullptr;
+        const uint64_t cap = std::max<uint64_t>(n_cells + n_cells / 4, 1u << 16);
+        if (int rc = dev_alloc((void **)&d.out, cap * sizeof(msnv_site_sample), &d.device_bytes)) return rc;
+        if (int rc = dev_alloc((void **)&d.cov_col, cap * sizeof(uint16_t) + 16, &d.device_bytes)) return rc;
+        d.cap_cells = cap;
+    }
     return MSNV_OK;
 }
 
@@ -1435,7 +1515,7 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
         a.ref4 = d.ref4; a.pairs = d.pairs; a.work = d.work; a.chunks = d.chunks; a.tot = d.tot; a.part = d.part; a.npos = npos; a.spill = d.spill;
         a.events = d.events; a.cap_events = d.cap_events / EV_LISTS; a.ev_count = nullptr; a.overflow = d.overflow; a.cap_overflow = d.cap_overflow;
         a.counters = counters; a.min_baseq = (uint32_t)std::max(0, p.min_baseq);
-        a.ind4 = d.ind4; a.unc_bits = d.unc_bits; a.min_snvs = (uint32_t)std::max(0, p.calling_threshold);
+        a.ind4 = d.ind4; a.unc_bits = d.unc_bits; a.slot_dirty = d.tile_dirty; a.min_snvs = (uint32_t)std::max(0, p.calling_threshold);
         const uint32_t n_narrow = d.n_work_narrow, n_merged = d.n_work_merged;
         // narrow work items (byte bins), merged groups of shallow pairs and wide items (16-bit bins) touch disjoint (tile, sample) pairs
         if (n_narrow && d.dense) hipLaunchKernelGGL(msnv_pileup_tiles_dense, dim3(n_narrow), dim3(N_NT), 0, st, a);
@@ -1454,7 +1534,8 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
     }
     HIP_TRY(hipEventRecord(ev_pile1, st));
     const uint32_t cap_out = (uint32_t)std::min<uint64_t>(d.cap_out_sites, 0xffffffffull);
-    const bool decide_in_gate = !d.any_split && !d.n_work_merged;   // else per-sample sums come first: msnv_decide_sites behind the scatter
+    const bool need_decide = d.any_split || d.n_work_merged;        // some sample's reads sit in several pairs / a merged group: sites whose call
+                                                                    // depends on its summed counts are decided behind the scatter (msnv_decide_sites)
     if (d.n_active_tiles) {
         GateArgs g;
         g.tot = d.tot; g.part = d.part; g.slot_off = d.slot_off; g.tile_slot_start = d.tile_slot_start; g.tile_slot_u16 = d.tile_slot_u16; g.tile_slot_wide = d.tile_slot_wide;
@@ -1462,7 +1543,10 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
         g.ind4 = d.ind4; g.unc_bits = d.unc_bits; g.ref4 = d.ref4; g.ref_lc = d.ref_lc;
         g.site_bits = d.site_bits; g.site_rank = d.site_rank; g.sites = d.sites; g.cap_sites = d.cap_sites; g.counters = counters; g.counters_next = counters_next;
         g.tile_site_base = d.tile_site_base; g.tile_site_cnt = d.tile_site_cnt; g.active_tiles = d.active_tiles;
-        g.out = d.out; g.cov_col = d.cov_col; g.site_flags = d.site_flags; g.n_samples = d.n_samples; g.cap_out = cap_out; g.decide_here = decide_in_gate ? 1u : 0u;
+        g.out = d.out; g.cov_col = d.cov_col; g.site_flags = d.site_flags; g.cap_out = cap_out; g.decide_here = 1u;
+        g.gate_tiles = reinterpret_cast<const GateTile *>(d.gate_tiles); g.tile_dirty = d.tile_dirty; g.unc_sites = d.unc_sites;
+        static_assert(sizeof(GateTile) == sizeof(DeviceCols::GateTileH) && sizeof(GateTile) == 48, "gate tile descriptor");
+        g.tile_nslots = d.tile_nslots; g.tile_cell_base = d.tile_cell_base; g.cap_cells = d.cap_cells;
         hipLaunchKernelGGL(msnv_gate_sites, dim3(d.n_active_tiles), dim3(GATE_NT), 0, st, g);
         HIP_TRY(hipGetLastError());
     } else HIP_TRY(hipMemsetAsync(counters_next, 0, CNT_WORDS * sizeof(uint32_t), st));   // nobody else would
@@ -1471,8 +1555,10 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
     if (d.n_active_tiles) {
         TailArgs ta;
         ta.sites = d.sites; ta.tile_site_base = d.tile_site_base; ta.tile_site_cnt = d.tile_site_cnt; ta.tile_pair_start = d.tile_pair_start;
-        ta.pairs = d.pairs; ta.spill = d.spill; ta.out = d.out; ta.cov_col = d.cov_col; ta.n_samples = d.n_samples; ta.cap_out = cap_out; ta.active_tiles = d.active_tiles;
-        ta.n_gather_blocks = d.n_active_tiles * GATHER_SPLIT;
+        ta.pairs = d.pairs; ta.spill = d.spill; ta.out = d.out; ta.cov_col = d.cov_col; ta.cap_out = cap_out; ta.active_tiles = d.active_tiles;
+        ta.cells = CellMap{d.tile_site_base, d.tile_cell_base, d.tile_nslots, d.cap_cells};
+        ta.gather_split = d.gather_split;
+        ta.n_gather_blocks = d.n_active_tiles * d.gather_split;
         ta.tile_pair_merged = d.tile_pair_merged; ta.work_merged = d.work + d.n_work_narrow; ta.chunks = d.chunks; ta.hdr8m = d.hdr8m;
         ta.seq = d.seq; ta.qual = d.qual; ta.ref4 = d.ref4; ta.n_merged_blocks = d.n_work_merged; ta.min_baseq = (uint32_t)std::max(0, p.min_baseq);
         ta.events = d.events; ta.overflow = d.overflow; ta.counters = counters; ta.cap_list = d.cap_events / EV_LISTS; ta.cap_overflow = d.cap_overflow;
@@ -1481,9 +1567,9 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
         HIP_TRY(hipGetLastError());
     }
     if (ev4) HIP_TRY(hipEventRecord(ev4, st));
-    if (!decide_in_gate && d.n_active_tiles) {
-        hipLaunchKernelGGL(msnv_decide_sites, dim3(512), dim3(256), 0, st, d.sites, counters, d.cap_sites, cap_out, d.ref4, d.ref_lc,
-                           d.out, d.n_samples, p.calling_threshold, p.min_fraction, d.site_flags, d.cap_events / EV_LISTS);
+    if (need_decide && d.n_active_tiles) {
+        hipLaunchKernelGGL(msnv_decide_sites, dim3(256), dim3(256), 0, st, d.sites, d.unc_sites, counters, d.cap_sites, cap_out, d.ref4, d.ref_lc,
+                           d.out, CellMap{d.tile_site_base, d.tile_cell_base, d.tile_nslots, d.cap_cells}, p.calling_threshold, p.min_fraction, d.site_flags);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipMemcpyAsync(host_cnt, counters, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -1491,13 +1577,13 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
 }
 
 static int check_counts(DeviceCols &d, const uint32_t *cnt, RunCounts *counts) {
-    RunCounts c{cnt[0], cnt[1], cnt[2], cnt[3]};
-    d.last_sites = c.n_sites;
+    RunCounts c{cnt[0], cnt[1], cnt[2], cnt[3], (uint64_t)cnt[6] | (uint64_t)cnt[7] << 32};
+    d.last_sites = c.n_sites; d.last_cells = c.n_cells;
     if (counts) *counts = c;
-    if (c.n_events > d.cap_events / EV_LISTS * EV_LISTS || c.n_overflow > d.cap_overflow || c.n_sites > d.cap_sites || c.n_sites > d.cap_out_sites)
-        return fail_quiet(MSNV_ECAPACITY, "device buffer too small: events %u/%u overflow %u/%u sites %u/%u out %u/%llu",
+    if (c.n_events > d.cap_events / EV_LISTS * EV_LISTS || c.n_overflow > d.cap_overflow || c.n_sites > d.cap_sites || c.n_sites > d.cap_out_sites || c.n_cells > d.cap_cells)
+        return fail_quiet(MSNV_ECAPACITY, "device buffer too small: events %u/%u overflow %u/%u sites %u/%u out %u/%llu cells %llu/%llu",
                           c.n_events, d.cap_events, c.n_overflow, d.cap_overflow, c.n_sites, d.cap_sites, c.n_sites,
-                          (unsigned long long)d.cap_out_sites);
+                          (unsigned long long)d.cap_out_sites, (unsigned long long)c.n_cells, (unsigned long long)d.cap_cells);
     return MSNV_OK;
 }
 
@@ -1511,7 +1597,7 @@ int dev_run_pipeline(DeviceCols &d, const msnv_params &p, void *stream_, msnv_ru
     // every event record costs ~6 us of stream time (the next kernel waits for the marker): the per-phase split of
     // the tail is only recorded on request (MSNV_PHASE_TIMES=1, profiles/phase_times.py)
     static const bool phase_times = [] { const char *e = getenv("MSNV_PHASE_TIMES"); return e && e[0] == '1'; }();
-    if (int rc = ensure_out(d, std::max<uint64_t>(d.last_sites + d.last_sites / 2, 4096))) return rc;
+    if (int rc = ensure_out(d, std::max<uint64_t>(d.last_sites + d.last_sites / 2, 4096), std::max<uint64_t>(d.last_cells + d.last_cells / 2, 1u << 18))) return rc;
     uint32_t cnt[8] = {0};
     if (int rc = enqueue_pass(d, p, st, ev[0], ev[1], ev[2], phase_times ? ev[3] : nullptr, phase_times ? ev[4] : nullptr, cnt)) return rc;
     HIP_TRY(hipEventRecord(ev[5], st));
@@ -1537,8 +1623,8 @@ int dev_run_pipeline(DeviceCols &d, const msnv_params &p, void *stream_, msnv_ru
 static int ensure_alt(DeviceCols &d) {
     DeviceCols::AltBufs &a = d.alt;
     const uint64_t npos = (uint64_t)d.n_tiles * TILE;
-    if (a.tot && a.cap_events == d.cap_events && a.cap_overflow == d.cap_overflow && a.cap_sites == d.cap_sites && a.cap_out_sites == d.cap_out_sites) return MSNV_OK;
-    void *old[] = {a.tot, a.part, a.spill, a.events, a.overflow, a.counters, a.ind4, a.sites, a.tile_site_base, a.tile_site_cnt, a.out, a.cov_col, a.site_flags, a.site_bits, a.site_rank};
+    if (a.tot && a.cap_events == d.cap_events && a.cap_overflow == d.cap_overflow && a.cap_sites == d.cap_sites && a.cap_out_sites == d.cap_out_sites && a.cap_cells == d.cap_cells) return MSNV_OK;
+    void *old[] = {a.tot, a.part, a.spill, a.events, a.overflow, a.counters, a.ind4, a.tile_dirty, a.unc_sites, a.sites, a.tile_site_base, a.tile_site_cnt, a.tile_cell_base, a.out, a.cov_col, a.site_flags, a.site_bits, a.site_rank};
     for (void *p : old) dev_free(p);
     a = DeviceCols::AltBufs{};
     if (int rc = dev_alloc((void **)&a.tot, std::max<uint64_t>(1, 4 * npos) * sizeof(uint32_t), &d.device_bytes)) return rc;
@@ -1548,6 +1634,9 @@ static int ensure_alt(DeviceCols &d) {
     if (int rc = dev_alloc((void **)&a.events, (uint64_t)d.cap_events * sizeof(Pair32), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.overflow, (uint64_t)d.cap_overflow * sizeof(Pair32), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.sites, (uint64_t)d.cap_sites * sizeof(SiteRec), &d.device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&a.unc_sites, (uint64_t)d.cap_sites * sizeof(uint32_t), &d.device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&a.tile_dirty, ((uint64_t)d.n_work + 1) * sizeof(uint32_t), &d.device_bytes)) return rc;
+    if (int rc = dev_memset(a.tile_dirty, 0, ((uint64_t)d.n_work + 1) * sizeof(uint32_t))) return rc;
     if (int rc = dev_alloc((void **)&a.counters, 2 * CNT_WORDS * sizeof(uint32_t), &d.device_bytes)) return rc;
     if (int rc = dev_memset(a.counters, 0, 2 * CNT_WORDS * sizeof(uint32_t))) return rc;
     if (int rc = dev_alloc((void **)&a.ind4, (npos / 8 + npos / 32 + 2) * sizeof(uint32_t), &d.device_bytes)) return rc;
@@ -1559,18 +1648,20 @@ static int ensure_alt(DeviceCols &d) {
     if (int rc = dev_alloc((void **)&a.tile_site_cnt, ((uint64_t)d.n_tiles + 1) * sizeof(uint32_t), &d.device_bytes)) return rc;
     if (int rc = dev_memset(a.tile_site_cnt, 0, ((uint64_t)d.n_tiles + 1) * sizeof(uint32_t))) return rc;
     if (int rc = dev_memset(a.tile_site_base, 0, ((uint64_t)d.n_tiles + 1) * sizeof(uint32_t))) return rc;
-    if (int rc = dev_alloc((void **)&a.out, d.cap_out_sites * d.n_samples * sizeof(msnv_site_sample), &d.device_bytes)) return rc;
-    if (int rc = dev_alloc((void **)&a.cov_col, d.cap_out_sites * d.n_samples * sizeof(uint16_t) + 16, &d.device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&a.tile_cell_base, ((uint64_t)d.n_tiles + 1) * sizeof(unsigned long long), &d.device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&a.out, d.cap_cells * sizeof(msnv_site_sample), &d.device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&a.cov_col, d.cap_cells * sizeof(uint16_t) + 16, &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.site_flags, d.cap_out_sites, &d.device_bytes)) return rc;
-    a.cap_events = d.cap_events; a.cap_overflow = d.cap_overflow; a.cap_sites = d.cap_sites; a.cap_out_sites = d.cap_out_sites;
+    a.cap_events = d.cap_events; a.cap_overflow = d.cap_overflow; a.cap_sites = d.cap_sites; a.cap_out_sites = d.cap_out_sites; a.cap_cells = d.cap_cells;
     return MSNV_OK;
 }
 static void swap_sets(DeviceCols &d) {
     DeviceCols::AltBufs &a = d.alt;
     std::swap(d.tot, a.tot); std::swap(d.part, a.part); std::swap(d.spill, a.spill); std::swap(d.events, a.events);
     std::swap(d.overflow, a.overflow); std::swap(d.counters, a.counters); std::swap(d.sites, a.sites);
-    std::swap(d.tile_site_base, a.tile_site_base); std::swap(d.tile_site_cnt, a.tile_site_cnt); std::swap(d.out, a.out); std::swap(d.cov_col, a.cov_col);
-    std::swap(d.site_flags, a.site_flags); std::swap(d.ind4, a.ind4); std::swap(d.unc_bits, a.unc_bits); std::swap(d.cnt_parity, a.cnt_parity); std::swap(d.site_bits, a.site_bits); std::swap(d.site_rank, a.site_rank);
+    std::swap(d.tile_site_base, a.tile_site_base); std::swap(d.tile_site_cnt, a.tile_site_cnt); std::swap(d.tile_cell_base, a.tile_cell_base); std::swap(d.out, a.out); std::swap(d.cov_col, a.cov_col);
+    std::swap(d.site_flags, a.site_flags); std::swap(d.ind4, a.ind4); std::swap(d.unc_bits, a.unc_bits); std::swap(d.cnt_parity, a.cnt_parity);
+    std::swap(d.tile_dirty, a.tile_dirty); std::swap(d.unc_sites, a.unc_sites); std::swap(d.site_bits, a.site_bits); std::swap(d.site_rank, a.site_rank);
 }
 
 // n passes, ONE host synchronisation at the end; with `overlap` they are in flight on two streams (a queue of shards / repeated passes keeps the
@@ -1585,7 +1676,7 @@ static void swap_sets(DeviceCols &d) {
 int dev_run_pipeline_many(DeviceCols &d, const msnv_params &p, void *stream_, int n, bool overlap, msnv_run_stats *stats, RunCounts *counts) {
     if (n <= 0) return MSNV_OK;
     hipStream_t s0 = (hipStream_t)stream_, s1 = s0;
-    if (int rc = ensure_out(d, std::max<uint64_t>(d.last_sites + d.last_sites / 2, 4096))) return rc;
+    if (int rc = ensure_out(d, std::max<uint64_t>(d.last_sites + d.last_sites / 2, 4096), std::max<uint64_t>(d.last_cells + d.last_cells / 2, 1u << 18))) return rc;
     if (overlap && n > 1) {
         if (!d.stream2) { hipStream_t s; HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); d.stream2 = s; }
         s1 = (hipStream_t)d.stream2;

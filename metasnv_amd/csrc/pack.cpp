@@ -712,6 +712,7 @@ int finalize_dataset(msnv_dataset &ds) {
         ds.info.bytes_ref = npos / 2;
     }
     // ---- callable range per tile (BED -l regions; without BED every covered position)
+    std::vector<uint32_t> vb_host, ve_host;
     {
         std::vector<uint32_t> vb(nt + 1, 0), ve(nt + 1, 0);
         for (uint64_t t = 0; t < nt; ++t) {
@@ -724,6 +725,7 @@ int finalize_dataset(msnv_dataset &ds) {
         }
         if (int rc = upload_vec(&d->tile_vbeg, vb, &d->device_bytes)) return rc;
         if (int rc = upload_vec(&d->tile_vend, ve, &d->device_bytes)) return rc;
+        vb_host = vb; ve_host = ve;
     }
 
     // ---- per sample: gpos, tile overlap index; concatenate columns
@@ -823,6 +825,28 @@ int finalize_dataset(msnv_dataset &ds) {
     }
     std::vector<uint32_t> tpm(nt + 1, 0);                           // per tile: first merged pair
     for (uint64_t t = 0; t < nt; ++t) { uint32_t k = tps[t]; while (k < tps[t + 1] && pairs[k].pad != 2) ++k; tpm[t] = k; }
+    // ---- slots: the samples that have reads in a tile are numbered 0 .. n - 1 (the pairs of a split sample, consecutive, share
+    // one); the per-sample cells of the tile's called positions are stored per slot (kernels.hip: CellMap) and the host expands
+    // to all samples when it fetches.  From here on TilePair::pad = kind (0 narrow or wide, 1 split, 2 merged) | slot << 8.
+    ds.tile_slot_base.assign(nt + 1, 0);
+    ds.slot_sample.clear();
+    {
+        std::vector<uint32_t> nslots(nt + 1, 0);
+        for (uint64_t t = 0; t < nt; ++t) {
+            ds.tile_slot_base[t] = (uint64_t)ds.slot_sample.size();
+            uint32_t n = 0;
+            for (uint32_t k = tps[t]; k < tps[t + 1]; ++k) {
+                const bool same = k > tps[t] && pairs[k].pad == 1 && (pairs[k - 1].pad & 0xffu) == 1 && pairs[k].sample == pairs[k - 1].sample;
+                if (!same) { ds.slot_sample.push_back(pairs[k].sample); ++n; }
+                pairs[k].pad |= (n - 1u) << 8;
+            }
+            nslots[t] = n;
+        }
+        ds.tile_slot_base[nt] = (uint64_t)ds.slot_sample.size();
+        if (int rc = upload_vec(&d->tile_nslots, nslots, &d->device_bytes)) return rc;
+        if (int rc = dev_alloc((void **)&d->tile_cell_base, (nt + 1) * sizeof(unsigned long long), &d->device_bytes)) return rc;
+        if (int rc = dev_memset(d->tile_cell_base, 0, (nt + 1) * sizeof(unsigned long long))) return rc;
+    }
     // ---- work list: split each tile's pairs so that work items carry similar read counts
     std::vector<WorkItem> work;
     struct MergedGroup { uint32_t pair_lo, pair_hi; };
@@ -940,6 +964,14 @@ int finalize_dataset(msnv_dataset &ds) {
         if (int rc = upload_vec(&d->tile_slot_wide, twide, &d->device_bytes)) return rc;
         if (int rc = upload_vec(&d->slot_off, off, &d->device_bytes)) return rc;
         if (int rc = dev_alloc((void **)&d->part, d->part_bytes, &d->device_bytes)) return rc;
+        // one descriptor per active tile for the gate kernel: everything it looks up about its tile in one load
+        std::vector<uint32_t> nslots_host(nt + 1, 0);
+        for (uint64_t t = 0; t < nt; ++t) nslots_host[t] = (uint32_t)(ds.tile_slot_base[t + 1] - ds.tile_slot_base[t]);
+        std::vector<DeviceCols::GateTileH> gts;
+        gts.reserve(active.size());
+        for (uint32_t t : active) gts.push_back(DeviceCols::GateTileH{t, tss[t], t16[t], twide[t], tss[t + 1], vb_host[t], ve_host[t], nslots_host[t], off[tss[t]], 0});
+        if (int rc = upload_vec(&d->gate_tiles, gts, &d->device_bytes, 1)) return rc;
+        d->gather_split = (uint32_t)std::min<uint64_t>(4, std::max<uint64_t>(1, (active.empty() ? 0 : pairs.size() / active.size()) / 40));
     }
     // ---- chunk descriptors of the narrow work items
     std::vector<ChunkDesc> chunks;
@@ -951,14 +983,14 @@ int finalize_dataset(msnv_dataset &ds) {
             if (dense) {        // chunk = up to DENSE_CHUNK_BLOCKS blocks of the pair's stream: {first block, seq byte offset of that block}
                 for (uint32_t b = 0; b < p.nblk; b += DENSE_CHUNK_BLOCKS) {
                     const uint32_t n = std::min<uint32_t>(DENSE_CHUNK_BLOCKS, p.nblk - b);
-                    chunks.push_back(ChunkDesc{bbase[p.sample] + p.blk_lo + b, sbase[p.sample] + p.seq0 + 16ull * b, p.sample, k,
-                                               n | (b + n >= p.nblk ? 1u << 16 : 0u), p.pad});
+                    chunks.push_back(ChunkDesc{bbase[p.sample] + p.blk_lo + b, sbase[p.sample] + p.seq0 + 16ull * b, p.pad >> 8, k,
+                                               n | (b + n >= p.nblk ? 1u << 16 : 0u), p.pad & 0xffu});      // "sample" = the sample's slot in the tile
                 }
                 continue;
             }
             for (uint32_t r = p.read_lo; r < p.read_hi; r += CHUNK_READS) {
                 const uint32_t n = std::min<uint32_t>(CHUNK_READS, p.read_hi - r);
-                chunks.push_back(ChunkDesc{rbase[p.sample] + r, sbase[p.sample], p.sample, k, n | (r + n >= p.read_hi ? 1u << 16 : 0u), p.pad});
+                chunks.push_back(ChunkDesc{rbase[p.sample] + r, sbase[p.sample], p.pad >> 8, k, n | (r + n >= p.read_hi ? 1u << 16 : 0u), p.pad & 0xffu});
             }
         }
         w.chunk_hi = (uint32_t)chunks.size();
@@ -1115,6 +1147,9 @@ int finalize_dataset(msnv_dataset &ds) {
     if (int rc = dev_alloc((void **)&d->events, (uint64_t)d->cap_events * sizeof(Pair32), &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->overflow, (uint64_t)d->cap_overflow * sizeof(Pair32), &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->sites, (uint64_t)d->cap_sites * sizeof(SiteRec), &d->device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&d->unc_sites, (uint64_t)d->cap_sites * sizeof(uint32_t), &d->device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&d->tile_dirty, ((uint64_t)work.size() + 1) * sizeof(uint32_t), &d->device_bytes)) return rc;    // one word per work item (by slot)
+    if (int rc = dev_memset(d->tile_dirty, 0, ((uint64_t)work.size() + 1) * sizeof(uint32_t))) return rc;
     // no memset per pass: the counter blocks alternate (the gate kernel zeroes the next one) and the gate kernel leaves the
     // individual-rule bits it consumes zero, like the allele totals
     if (int rc = dev_alloc((void **)&d->counters, 2 * CNT_WORDS * sizeof(uint32_t), &d->device_bytes)) return rc;
@@ -1122,7 +1157,7 @@ int finalize_dataset(msnv_dataset &ds) {
     if (int rc = dev_alloc((void **)&d->ind4, (npos / 8 + npos / 32 + 2) * sizeof(uint32_t), &d->device_bytes)) return rc;
     if (int rc = dev_memset(d->ind4, 0, (npos / 8 + npos / 32 + 2) * sizeof(uint32_t))) return rc;
     d->unc_bits = d->ind4 + npos / 8 + 1;
-    for (const TilePair &tp : pairs) if (tp.pad == 1) { d->any_split = true; break; }
+    for (const TilePair &tp : pairs) if ((tp.pad & 0xffu) == 1) { d->any_split = true; break; }
     if (int rc = dev_alloc((void **)&d->site_bits, (npos / 64 + 1) * sizeof(unsigned long long), &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->site_rank, (npos / 64 + 1) * sizeof(uint32_t), &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->tile_site_base, (nt + 1) * sizeof(uint32_t), &d->device_bytes)) return rc;
