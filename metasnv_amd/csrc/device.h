@@ -11,6 +11,8 @@
 namespace msnv {
 
 struct Pair32 { uint32_t x, y; };
+struct MergedGroupDev { uint64_t hdr_base; uint32_t tile, pair_lo, n_pairs, n_pieces; };   // one merged group of shallow pairs (gather_merged_block): its
+                                                                                        // headers in hdr8m, its pairs
 
 // ---- gene / codon annotation tables (ann_tables.cpp builds them, msnv_annotate_sites reads them)
 constexpr uint8_t ANN_GENE_MINUS = 1, ANN_GENE_LINEAR = 2;       // strand '-', start < end (call_vC.cpp:609)
@@ -46,6 +48,7 @@ struct DeviceCols {
     PieceHdr *hdr8m = nullptr;       // headers of the merged groups of shallow pairs, group by group: pair index in bits 19+, ABSOLUTE seq offset / 8
     uint32_t *tile_pair_merged = nullptr;   // per tile: first merged pair (they sit behind the tile's other pairs)
     uint32_t  n_work_merged = 0;     // work[n_work_narrow .. + n_work_merged) = merged items
+    MergedGroupDev *merged_groups = nullptr; uint32_t n_merged_groups = 0;   // every merged group, for the gather
     uint32_t *blk = nullptr;         // dense layout: one descriptor per 32-base block (dense kernel)
     bool      dense = true;
     uint8_t  *seq = nullptr;
@@ -82,6 +85,8 @@ struct DeviceCols {
                                      // (set by the pileup kernels, consumed and cleared by the gate)
     uint32_t *unc_sites = nullptr;   // [cap_sites]: sites whose call depends on a split / merged sample's summed counts (msnv_decide_sites)
     struct GateTileH { uint32_t tile, slot_lo, slot_16, slot_w, slot_hi, vbeg, vend, n_slots; uint64_t row0; uint64_t pad_; } *gate_tiles = nullptr;   // per active tile (kernels.hip: GateTile)
+    unsigned long long *site_row = nullptr;   // per 64 positions: first cell of the first site in them (gate kernel; what an event finds its cell with)
+    bool      use_dirty = false;     // sparse cohort (few work items per tile): the gate kernel consults tile_dirty before it reads the allele totals
     uint32_t  gather_split = 4;      // workgroups per tile in the spill gather (fewer for sparse cohorts: a pair or two per tile)
     bool      any_split = false;     // some (sample, tile) run was dealt into several pairs: the calling rule then needs the summed per-sample records
     unsigned long long *site_bits = nullptr;   // 1 bit per position: is a site (written by the gate kernel for every tile)
@@ -96,6 +101,7 @@ struct DeviceCols {
     uint16_t *cov_col = nullptr;     // [cap_cells]: per-sample coverage, a column of its own on the device (two-byte stores
                                      // into 10-byte records are partial-line writes: gather/scatter launch 41 -> 37 us)
     uint8_t  *site_flags = nullptr;  // pop_mask | ind_mask << 4
+    uint8_t  *site_elig = nullptr;   // alleles still open to the individual rule when the gate kernel has decided what it can (merged gather)
     uint64_t  cap_out_sites = 0, last_sites = 0;
     // ---- genome coverage (qaCompute path)
     Pair32   *cov_iv = nullptr;          // {gbeg, gend}: +1 at gbeg, -1 at gend (index space of qaCompute.cpp:530-552)
@@ -116,7 +122,7 @@ struct DeviceCols {
     struct AltBufs {
         uint32_t *tot = nullptr; uint8_t *part = nullptr; uint8_t *spill = nullptr; Pair32 *events = nullptr, *overflow = nullptr;
         uint32_t *counters = nullptr; SiteRec *sites = nullptr; uint32_t *tile_site_base = nullptr, *tile_site_cnt = nullptr; unsigned long long *tile_cell_base = nullptr;
-        msnv_site_sample *out = nullptr; uint16_t *cov_col = nullptr; uint8_t *site_flags = nullptr; uint32_t *ind4 = nullptr, *unc_bits = nullptr, *tile_dirty = nullptr, *unc_sites = nullptr; unsigned long long *site_bits = nullptr; uint32_t *site_rank = nullptr;
+        msnv_site_sample *out = nullptr; uint16_t *cov_col = nullptr; uint8_t *site_flags = nullptr, *site_elig = nullptr; uint32_t *ind4 = nullptr, *unc_bits = nullptr, *tile_dirty = nullptr, *unc_sites = nullptr; unsigned long long *site_row = nullptr; unsigned long long *site_bits = nullptr; uint32_t *site_rank = nullptr;
         uint32_t cap_events = 0, cap_overflow = 0, cap_sites = 0, cnt_parity = 0; uint64_t cap_out_sites = 0, cap_cells = 0;
     } alt;
     void     *stream2 = nullptr;

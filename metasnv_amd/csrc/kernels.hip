@@ -34,6 +34,8 @@ struct PileupArgs {
     const ReadHdr  *hdr;          // one 16-byte header per M/=/X segment piece: {gpos, seqoff, length, meta}
     const uint32_t *blk;          // dense layout: one descriptor per 32-base block
     const PieceHdr *hdr8;         // the same pieces, tile-local 8-byte form: {start | length << 11, seqoff / 8}
+    const PieceHdr *hdr8m;        // headers of the merged groups (pair index in bits 19+, absolute seq offset / 8)
+    uint32_t        n_narrow;     // narrow32 launch: work items [0, n_narrow) are ordinary, the rest hold merged groups
     const uint8_t  *seq;
     const uint8_t  *qual;
     const uint64_t *s_read_base, *s_seq_base;
@@ -537,9 +539,8 @@ __device__ __forceinline__ void narrow_classify32(NarrowLds &L, const uint4 qa, 
 }
 
 template <bool MERGED>
-__device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a) {
+__device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a, NarrowLds &L) {
     ev_list(a);
-    __shared__ NarrowLds L;
     const WorkItem w = a.work[blockIdx.x];
     const uint32_t t0 = w.tile * TILE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -636,11 +637,16 @@ __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a) {
     store_item_dirty(a.slot_dirty, w, dirty, tid);
 }
 
-__global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32(PileupArgs a) { pileup_tiles_narrow32_body<false>(a); }
-// The same kernel over MERGED groups of shallow (sample, tile) pairs: a chunk holds pieces of several samples, one pass per
-// group instead of one per pair, no per-sample coverage spill and no allele events (narrow_pass).  A pair of ~20 pieces costs
-// a chunk iteration and a pass over all 2048 positions whatever it holds (1600 samples at 1x ran at 24 % of the roofline).
-__global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_merged(PileupArgs a) { pileup_tiles_narrow32_body<true>(a); }
+// Work items [0, n_narrow) are ordinary ones; the items behind them hold MERGED groups of shallow (sample, tile) pairs: a chunk
+// holds pieces of several samples, one pass per group instead of one per pair, no per-sample coverage spill and no allele
+// events (narrow_pass).  A pair of ~20 pieces costs a chunk iteration and a pass over all 2048 positions whatever it holds
+// (1600 samples at 1x ran at 24 % of the roofline).  One launch for both kinds: a handful of merged items (the partial last
+// tile of every contig) would otherwise run as a launch of its own with the chip idle around it (17.8 us on the benchmark shape).
+__global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32(PileupArgs a) {
+    __shared__ NarrowLds L;                                     // ONE instance for both kinds of work item (7 workgroups per CU)
+    if (blockIdx.x < a.n_narrow) pileup_tiles_narrow32_body<false>(a, L);
+    else { a.hdr8 = a.hdr8m; pileup_tiles_narrow32_body<true>(a, L); }
+}
 
 // ------------------------------------------------------------------------------------------
 // msnv_pileup_tiles_dense: the narrow algorithm over the DENSE layout (dataset.h: BLK_*, pack.cpp: relayout_dense).
@@ -823,7 +829,8 @@ static_assert(GATE_PPT == 8, "the gate kernel is written for 8 positions per thr
 // one) -- so a sparse cohort (BASELINE configs[3]: 500 samples, a species carried by a handful) does not pay 500 cells per
 // site.  The host expands to all samples when it fetches.  Cell of (site, slot): tile_cell_base[tile] + (site - first site of
 // the tile) * slots + slot; the gate kernel reserves a tile's cells with one 64-bit atomic (counters[6..7]).
-struct CellMap { const uint32_t *tile_site_base; const unsigned long long *tile_cell_base; const uint32_t *tile_nslots; unsigned long long cap_cells; };
+struct CellMap { const uint32_t *tile_site_base; const unsigned long long *tile_cell_base; const uint32_t *tile_nslots; unsigned long long cap_cells;
+                 const unsigned long long *block_row; };     // per 64 positions: first cell of the first site in them (gate kernel)
 __device__ __forceinline__ uint64_t cell_of(const CellMap &m, const uint32_t tile, const uint32_t site, const uint32_t slot) {
     return m.tile_cell_base[tile] + (uint64_t)(site - m.tile_site_base[tile]) * m.tile_nslots[tile] + slot;
 }
@@ -839,7 +846,8 @@ struct GateArgs {
     uint32_t *tile_site_base, *tile_site_cnt; const uint32_t *active_tiles;
     msnv_site_sample *out; uint16_t *cov_col; uint8_t *site_flags; uint32_t cap_out;
     const uint32_t *tile_nslots; unsigned long long *tile_cell_base; unsigned long long cap_cells;
-    const GateTile *gate_tiles; uint32_t *tile_dirty; uint32_t *unc_sites;
+    const GateTile *gate_tiles; uint32_t *tile_dirty; uint32_t *unc_sites; uint32_t use_dirty; unsigned long long *block_row;
+    uint8_t *site_elig; uint32_t any_split;
     uint32_t decide_here;                      // 1: no sample is split into several pairs, so the calling rule is applied right here
 };
 
@@ -872,9 +880,11 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
     const uint32_t slot_16 = gt.slot_16, slot_w = gt.slot_w;
     // 64-position blocks of the tile in which some pass added to the allele totals (narrow_pass / wide kernel): the other blocks'
     // totals and individual-rule bits are zero and are not even read (16.6 B per position against ~8 B of reads at 5x)
+    // (only consulted for sparse cohorts, use_dirty: with many work items per tile every block is dirty anyway and the totals'
+    // loads would wait for the words for nothing)
     uint32_t dirty = 0;
-    for (uint32_t sl = slot_lo; sl < slot_hi; ++sl) dirty |= a.tile_dirty[sl];      // (uniform addresses, independent loads)
-    const bool my_dirty = (dirty >> (p0 >> 6)) & 1u;
+    if (a.use_dirty) for (uint32_t sl = slot_lo; sl < slot_hi; ++sl) dirty |= a.tile_dirty[sl];      // (uniform addresses, independent loads)
+    const bool my_dirty = !a.use_dirty || ((dirty >> (p0 >> 6)) & 1u);
     uint32_t covs[GATE_PPT];
 #pragma unroll
     for (int j = 0; j < GATE_PPT; ++j) covs[j] = 0;
@@ -951,7 +961,8 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
     if (uncb) reinterpret_cast<uint8_t *>(a.unc_bits)[g0 >> 3] = 0;
     const uint32_t refw = a.ref4[g0 >> 3];                                  // nt16 codes of my 8 positions
     const uint32_t lcb = reinterpret_cast<const uint8_t *>(a.ref_lc)[g0 >> 3];   // FASTA character is a lower-case a / c / g / t
-    uint32_t okm = 0, uncm = 0, flw[2] = {0u, 0u};                          // site mask; "ask the per-sample records" mask; pop | ind << 4 of my 8 positions
+    uint32_t okm = 0, uncm = 0, flw[2] = {0u, 0u}, elig[2] = {0u, 0u};      // site mask; "ask the per-sample records" mask; pop | ind << 4 and the alleles
+                                                                            // still open to the individual rule, one byte per position
 #pragma unroll
     for (int j = 0; j < GATE_PPT; ++j) {
         const uint32_t p = p0 + (uint32_t)j, cov = covs[j];
@@ -972,7 +983,7 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
                 ok |= is_pop || is_ind || unc;
                 if (lc && rc == (1u << x)) continue;                       // skip-same-base, case-sensitive (call_vC.cpp:580)
                 if (is_pop) pop |= 1u << x; else if (is_ind) ind |= 1u << x;
-                else if (unc) uncm |= 1u << j;                             // a split / merged sample may hold >= t reads in sum: msnv_decide_sites
+                else if (unc) { uncm |= 1u << j; elig[j >> 2] |= (1u << x) << (8 * (j & 3)); }   // a split / merged sample may hold >= t reads in sum
             }
             okm |= (ok ? 1u : 0u) << j;
             flw[j >> 2] |= (pop | ind << 4) << (8 * (j & 3));
@@ -1007,7 +1018,9 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
         a.tile_cell_base[tile] = cb;
     }
     // output-line tallies (before the first-line drop); the sites of the "ask" mask are tallied by msnv_decide_sites
-    okm_certain = okm & ~uncm;
+    // (a split sample: msnv_decide_sites re-decides and tallies those sites; merged groups only: the merged gather adds the
+    // individual calls it finds, so everything decided here is tallied here)
+    okm_certain = a.any_split ? okm & ~uncm : okm;
     if (okm_certain) {
         uint32_t np = 0, ni = 0;
 #pragma unroll
@@ -1029,7 +1042,10 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
         for (uint64_t i = (uint64_t)tid; i < n_cells; i += GATE_NT) crow[i] = 0;
     }
     // index of the first site of every 64 positions: an event finds its site as rank + popcount of the lower bits
-    if ((lane & 7) == 0) site_rank[g0 >> 6] = base + mybase;
+    if ((lane & 7) == 0) {
+        site_rank[g0 >> 6] = base + mybase;
+        a.block_row[g0 >> 6] = s_cell + (unsigned long long)mybase * n_slots;     // first cell of the block's first site: what an event needs
+    }
     uint32_t idx = base + mybase;
 #pragma unroll
     for (int j = 0; j < GATE_PPT; ++j) {
@@ -1040,7 +1056,8 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
                 s.n[0] = nal[0][j]; s.n[1] = nal[1][j]; s.n[2] = nal[2][j]; s.n[3] = nal[3][j];
                 sites[idx] = s;
                 if (idx < cap_out) a.site_flags[idx] = (uint8_t)((flw[j >> 2] >> (8 * (j & 3))) & 0xffu);
-                if ((uncm >> j) & 1u) {                                 // decided from the per-sample records behind the scatter
+                if (idx < cap_out) a.site_elig[idx] = (uint8_t)((elig[j >> 2] >> (8 * (j & 3))) & 0xffu);
+                if (a.any_split && ((uncm >> j) & 1u)) {                // decided from the per-sample records behind the scatter
                     const uint32_t u = atomicAdd(&counters[CNT_UNC], 1u);
                     if (u < cap_sites) a.unc_sites[u] = idx;
                 }
@@ -1064,8 +1081,10 @@ constexpr uint32_t SCATTER_BLOCKS_PER_LIST = 32;
 struct TailArgs {
     const SiteRec *sites; const uint32_t *tile_site_base, *tile_site_cnt, *tile_pair_start, *tile_pair_merged; const TilePair *pairs; const uint8_t *spill;
     // merged groups of shallow pairs: their per-sample coverage at the called positions is recomputed from the pieces
-    const WorkItem *work_merged; const ChunkDesc *chunks; const PieceHdr *hdr8m; const uint8_t *seq, *qual; const uint32_t *ref4;
+    const MergedGroupDev *merged_groups; const ChunkDesc *chunks; const PieceHdr *hdr8m; const uint8_t *seq, *qual; const uint32_t *ref4;
     uint32_t n_merged_blocks, min_baseq;
+    // individual rule inside the merged gather (a sample's reads at a site all sit in ONE group): unless a split sample needs msnv_decide_sites anyway
+    uint8_t *site_flags; const uint8_t *site_elig; uint32_t ind_in_gather, min_snvs;
     msnv_site_sample *out; uint16_t *cov_col; uint32_t cap_out; const uint32_t *active_tiles; uint32_t n_gather_blocks;
     CellMap cells; uint32_t gather_split;
     const Pair32 *events, *overflow; uint32_t *counters; uint32_t cap_list, cap_overflow;
@@ -1100,32 +1119,36 @@ __device__ __forceinline__ void gather_cov_block(const TailArgs &a, const uint32
 
 __device__ __forceinline__ void scatter_events_block(const TailArgs &a, const uint32_t bx, const uint32_t k) {
     if (a.counters[2] > a.cap_out || *reinterpret_cast<const unsigned long long *>(&a.counters[CNT_CELLS]) > a.cells.cap_cells) return;
+    // an event finds its cell from three INDEPENDENT lookups by position -- site bitmap word, first cell of the 64-position
+    // block's first site, slots of the tile -- so the loop is two levels of dependent loads deep (event -> tables -> atomic)
     auto apply = [&](const Pair32 e, const bool allele) {
         const unsigned long long w = a.site_bits[e.x >> 6], bit = 1ull << (e.x & 63u);
+        const unsigned long long row0 = a.cells.block_row[e.x >> 6];
+        const uint32_t ns = a.cells.tile_nslots[e.x / TILE];
         if (!(w & bit)) return;                    // most events are sequencing errors at positions that are not sites
-        const uint32_t s = a.site_rank[e.x >> 6] + (uint32_t)__popcll(w & (bit - 1ull));
+        const unsigned long long row = row0 + (unsigned long long)__popcll(w & (bit - 1ull)) * ns;
         // events carry the SLOT of their sample in the tile (pack.cpp)
-        if (allele) add_u16(&a.out[cell_of(a.cells, e.x / TILE, s, e.y >> 18)].n[(e.y >> 16) & 3u], e.y & 0xffffu);   // one event per (site, pair, allele)
-        else a.cov_col[cell_of(a.cells, e.x / TILE, s, e.y >> 16)] = (uint16_t)(e.y & 0xffffu);
+        if (allele) add_u16(&a.out[row + (e.y >> 18)].n[(e.y >> 16) & 3u], e.y & 0xffffu);   // one event per (site, pair, allele)
+        else a.cov_col[row + (e.y >> 16)] = (uint16_t)(e.y & 0xffffu);
     };
     const uint32_t n_k = min(a.counters[16u + k * EV_CNT_STRIDE], a.cap_list);
     const Pair32 *list = a.events + (uint64_t)k * a.cap_list;
-    {   // four events per trip: their loads, then their site-bitmap loads, are in flight together (the loop is a chain of dependent loads)
+    {   // four events per trip: their loads, then their table loads, are in flight together
         constexpr uint32_t U = 4;
         const uint32_t stride = SCATTER_BLOCKS_PER_LIST * blockDim.x;
         uint32_t i = bx * blockDim.x + threadIdx.x;
         for (; i + (U - 1u) * stride < n_k; i += U * stride) {
-            Pair32 e[U]; unsigned long long w[U];
+            Pair32 e[U]; unsigned long long w[U], row0[U]; uint32_t ns[U];
 #pragma unroll
             for (uint32_t u = 0; u < U; ++u) e[u] = list[i + u * stride];
 #pragma unroll
-            for (uint32_t u = 0; u < U; ++u) w[u] = a.site_bits[e[u].x >> 6];
+            for (uint32_t u = 0; u < U; ++u) { w[u] = a.site_bits[e[u].x >> 6]; row0[u] = a.cells.block_row[e[u].x >> 6]; ns[u] = a.cells.tile_nslots[e[u].x / TILE]; }
 #pragma unroll
             for (uint32_t u = 0; u < U; ++u) {
                 const unsigned long long bit = 1ull << (e[u].x & 63u);
                 if (!(w[u] & bit)) continue;
-                const uint32_t s = a.site_rank[e[u].x >> 6] + (uint32_t)__popcll(w[u] & (bit - 1ull));
-                add_u16(&a.out[cell_of(a.cells, e[u].x / TILE, s, e[u].y >> 18)].n[(e[u].y >> 16) & 3u], e[u].y & 0xffffu);
+                const unsigned long long row = row0[u] + (unsigned long long)__popcll(w[u] & (bit - 1ull)) * ns[u];
+                add_u16(&a.out[row + (e[u].y >> 18)].n[(e[u].y >> 16) & 3u], e[u].y & 0xffffu);
             }
         }
         for (; i < n_k; i += stride) apply(list[i], true);
@@ -1140,14 +1163,14 @@ __device__ __forceinline__ void scatter_events_block(const TailArgs &a, const ui
 // counted base at a called position -- quality at or above the cutoff and either a match or one of A, C, G, T: the bases the
 // pileup kernel did not put into its exception bins -- adds one to the group's LDS table [site][pair of the group], which
 // is then written out with plain stores (every (site, sample) cell belongs to exactly one group).
-constexpr uint32_t GM_CELLS = 4096;           // cells of the LDS tables (6 B each); a tile with more sites x pairs is done in batches of sites
+constexpr uint32_t GM_CELLS = 2048;           // cells of the LDS tables (6 B each); a tile with more sites x pairs is done in batches of sites
 __device__ __forceinline__ void gather_merged_block(const TailArgs &a, const uint32_t bid) {
     __shared__ unsigned long long s_bits[TILE / 64];
     __shared__ uint32_t s_rank[TILE / 64];
     __shared__ uint32_t s_cov[GM_CELLS / 2];            // u16 per (site, pair): counted bases
     __shared__ uint32_t s_al[GM_CELLS];                 // 4 x u8 per (site, pair): mismatching A, C, G, T (a shallow pair is < 81 deep)
     __shared__ uint32_t s_gsample[MERGE_MAX_PAIRS];
-    const WorkItem w = a.work_merged[bid];
+    const MergedGroupDev w = a.merged_groups[bid];      // ONE group per workgroup (a work item's groups in a row made this block the launch's long pole)
     const uint32_t tile = w.tile, n = a.tile_site_cnt[tile];
     if (n == 0u) return;
     const uint32_t base = a.tile_site_base[tile];
@@ -1159,15 +1182,13 @@ __device__ __forceinline__ void gather_merged_block(const TailArgs &a, const uin
     const uint32_t tid = threadIdx.x;
     if (tid < TILE / 64) { s_bits[tid] = a.site_bits[(t0 >> 6) + tid]; s_rank[tid] = a.site_rank[(t0 >> 6) + tid] - base; }
     const uint32_t kq = min(a.min_baseq, 128u);
-    uint32_t c = w.chunk_lo;
-    while (c < w.chunk_hi) {
-        // one group = the chunks up to and including the one flagged "last"
-        const ChunkDesc g = a.chunks[c];
-        uint32_t n_pieces = 0, ce = c;
-        for (;;) { const uint32_t f = a.chunks[ce].nrd_flags; n_pieces += f & 0xffffu; ++ce; if ((f >> 16) || ce >= w.chunk_hi) break; }
+    {
+        // the group's extent comes with its descriptor: every table the block needs is one load away from it (a chain of ten
+        // dependent loads -- chunk descriptors walked one by one -- made this block the long pole of the launch)
+        struct { uint64_t hdr_base; uint32_t pair, pad; } g{w.hdr_base, w.pair_lo, w.n_pairs};
+        const uint32_t n_pieces = w.n_pieces;
         const uint32_t m = g.pad;                         // pairs of the group
         const uint32_t batch = max(1u, GM_CELLS / m);     // sites per round
-        __syncthreads();                                  // the previous group's table and sample list are no longer read
         if (tid < m) s_gsample[tid] = a.pairs[g.pair + tid].pad >> 8;      // the pair's slot in the tile
         for (uint32_t j0 = 0; j0 < n; j0 += batch) {
             const uint32_t nj = min(batch, n - j0);
@@ -1208,13 +1229,29 @@ __device__ __forceinline__ void gather_merged_block(const TailArgs &a, const uin
                 if (v) a.cov_col[cell] = (uint16_t)v;
                 const uint32_t al = s_al[i];
                 if (al) {
+                    uint32_t ind = 0;
 #pragma unroll
-                    for (uint32_t x = 0; x < 4; ++x) if ((al >> (8u * x)) & 0xffu) a.out[cell].n[x] = (uint16_t)((al >> (8u * x)) & 0xffu);
+                    for (uint32_t x = 0; x < 4; ++x) {
+                        const uint32_t cnt = (al >> (8u * x)) & 0xffu;
+                        if (cnt) a.out[cell].n[x] = (uint16_t)cnt;
+                        if (cnt >= a.min_snvs) ind |= 1u << x;
+                    }
+                    // call_vC.cpp:593-600: this sample holds >= t reads of an allele the gate kernel left open -> individual call
+                    if (ind && a.ind_in_gather) {
+                        const uint32_t site = base + j0 + i / m;
+                        ind &= a.site_elig[site];
+                        if (ind) {
+                            uint32_t *wordp = reinterpret_cast<uint32_t *>(a.site_flags + (site & ~3u));
+                            const uint32_t sh = 8u * (site & 3u);
+                            const uint32_t old = atomicOr(wordp, (ind << 4) << sh);
+                            if ((((old >> sh) & 0xffu) >> 4) == 0u)          // the site's first individual call: one more indiv_called line
+                                atomicAdd(reinterpret_cast<unsigned long long *>(&a.counters[CNT_TALLY]), 1ull << 32);
+                        }
+                    }
                 }
             }
             __syncthreads();
         }
-        c = ce;
     }
 }
 
@@ -1222,23 +1259,28 @@ __device__ __forceinline__ void gather_merged_block(const TailArgs &a, const uin
 //   blocks [0, n_gather_blocks): per-sample coverage of every surviving site, from the spilled bytes;
 //   the other SCATTER_BLOCKS_PER_LIST x EV_LISTS blocks: per-sample allele counts from the event sub-lists (sparse) and the
 //   >= 255 coverages of the wide kernel from the overflow list.
+// HAS_MERGED = false: no merged groups in the dataset -- the instantiation without the merged gather's LDS tables (with them
+// every workgroup of the launch allocates 14 KB it never touches: 33.8 -> 43 us on the benchmark shape)
+template <bool HAS_MERGED>
 __global__ __launch_bounds__(256) void msnv_gather_scatter(TailArgs a) {
     constexpr uint32_t n_scatter = SCATTER_BLOCKS_PER_LIST * EV_LISTS;     // dispatched first: the longer-running half
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (blockIdx.x == gridDim.x - 1u) {
+        // (one workgroup of its own at the END of the grid: in front of a scatter block -- the long pole of this launch -- the 32
+        // counter loads delayed the whole kernel by ~10 us)
         // counters[0] for the host: the number of allele events, or -- when a sub-list overflowed -- the total capacity
         // that would have held the fullest one (the host grows the list to that and runs the pass again)
-        unsigned long long total = 0; uint32_t fullest = 0;
-        for (uint32_t k = 0; k < EV_LISTS; ++k) { const uint32_t c = a.counters[16u + k * EV_CNT_STRIDE]; total += c; fullest = max(fullest, c); }
-        if (fullest > a.cap_list) total = (unsigned long long)fullest * EV_LISTS;
-        a.counters[0] = (uint32_t)min(total, 0xffffffffull);
-        // the gate kernel's spread counters, where the host reads them (msnv_decide_sites adds its own lines to [4], [5] afterwards)
-        const unsigned long long cells = *reinterpret_cast<const unsigned long long *>(&a.counters[CNT_CELLS]);
-        const unsigned long long tally = *reinterpret_cast<const unsigned long long *>(&a.counters[CNT_TALLY]);
-        a.counters[6] = (uint32_t)cells; a.counters[7] = (uint32_t)(cells >> 32);
-        a.counters[4] = (uint32_t)tally; a.counters[5] = (uint32_t)(tally >> 32);
+        if (threadIdx.x < 64) {
+            const uint32_t c = threadIdx.x < EV_LISTS ? a.counters[16u + threadIdx.x * EV_CNT_STRIDE] : 0u;
+            unsigned long long total = c; uint32_t fullest = c;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) { total += __shfl_xor(total, o); fullest = max(fullest, (uint32_t)__shfl_xor((int)fullest, o)); }
+            if (fullest > a.cap_list) total = (unsigned long long)fullest * EV_LISTS;
+            if (threadIdx.x == 0) a.counters[0] = (uint32_t)min(total, 0xffffffffull);
+        }
+        return;
     }
     if (blockIdx.x < n_scatter) scatter_events_block(a, blockIdx.x % SCATTER_BLOCKS_PER_LIST, blockIdx.x / SCATTER_BLOCKS_PER_LIST);
-    else if (blockIdx.x < n_scatter + a.n_merged_blocks) gather_merged_block(a, blockIdx.x - n_scatter);
+    else if (HAS_MERGED && blockIdx.x < n_scatter + a.n_merged_blocks) gather_merged_block(a, blockIdx.x - n_scatter);
     else gather_cov_block(a, blockIdx.x - n_scatter - a.n_merged_blocks);
 }
 
@@ -1460,9 +1502,9 @@ int dev_stream_create(void **stream) { hipStream_t s; HIP_TRY(hipStreamCreateWit
 void dev_stream_destroy(void *stream) { if (stream) (void)hipStreamDestroy((hipStream_t)stream); }
 
 void dev_free_all(DeviceCols &d) {
-    void *ptrs[] = {d.hdr, d.hdr8, d.hdr8m, d.tile_pair_merged, d.blk, d.seq, d.qual, d.s_read_base, d.s_seq_base, d.ref4, d.ref_lc, d.pairs,
-                    d.tile_pair_start, d.work, d.chunks, d.tile_vbeg, d.tile_vend, d.tot, d.part, d.tile_slot_start, d.tile_slot_u16, d.tile_slot_wide, d.slot_off, d.spill, d.events, d.overflow, d.counters, d.ind4, d.tile_dirty, d.unc_sites, d.gate_tiles,
-                    d.sites, d.tile_site_base, d.tile_site_cnt, d.tile_cell_base, d.tile_nslots, d.out, d.cov_col, d.site_flags,
+    void *ptrs[] = {d.hdr, d.hdr8, d.hdr8m, d.merged_groups, d.tile_pair_merged, d.blk, d.seq, d.qual, d.s_read_base, d.s_seq_base, d.ref4, d.ref_lc, d.pairs,
+                    d.tile_pair_start, d.work, d.chunks, d.tile_vbeg, d.tile_vend, d.tot, d.part, d.tile_slot_start, d.tile_slot_u16, d.tile_slot_wide, d.slot_off, d.spill, d.events, d.overflow, d.counters, d.ind4, d.tile_dirty, d.unc_sites, d.site_row, d.gate_tiles,
+                    d.sites, d.tile_site_base, d.tile_site_cnt, d.tile_cell_base, d.tile_nslots, d.out, d.cov_col, d.site_flags, d.site_elig,
                     d.cov_iv, d.s_cov_base, d.cov_pairs, d.cov_work, d.tile_len, d.tile_contig_dev, d.cov_acc};
     for (void *p : ptrs) dev_free(p);
     void *aptrs[] = {d.ann.seg_beg, d.ann.seg_end, d.ann.seg_gene, d.ann.genes, d.ann.contigs, d.ann.codons, d.ann.out, d.ann.err};
@@ -1470,8 +1512,8 @@ void dev_free_all(DeviceCols &d) {
     for (void *e : d.timing_events) if (e) (void)hipEventDestroy((hipEvent_t)e);
     for (void *e : d.event_pool) (void)hipEventDestroy((hipEvent_t)e);
     if (d.pinned_cnt) (void)hipHostFree(d.pinned_cnt);
-    void *alts[] = {d.alt.tot, d.alt.part, d.alt.spill, d.alt.events, d.alt.overflow, d.alt.counters, d.alt.ind4, d.alt.tile_dirty, d.alt.unc_sites, d.alt.sites, d.alt.tile_site_base,
-                    d.alt.tile_site_cnt, d.alt.tile_cell_base, d.alt.out, d.alt.cov_col, d.alt.site_flags, d.alt.site_bits, d.site_bits, d.alt.site_rank, d.site_rank, d.active_tiles};
+    void *alts[] = {d.alt.tot, d.alt.part, d.alt.spill, d.alt.events, d.alt.overflow, d.alt.counters, d.alt.ind4, d.alt.tile_dirty, d.alt.unc_sites, d.alt.site_row, d.alt.sites, d.alt.tile_site_base,
+                    d.alt.tile_site_cnt, d.alt.tile_cell_base, d.alt.out, d.alt.cov_col, d.alt.site_flags, d.alt.site_elig, d.alt.site_bits, d.site_bits, d.alt.site_rank, d.site_rank, d.active_tiles};
     for (void *p : alts) dev_free(p);
     if (d.stream2) (void)hipStreamDestroy((hipStream_t)d.stream2);
     d = DeviceCols{};
@@ -1480,8 +1522,10 @@ void dev_free_all(DeviceCols &d) {
 static int ensure_out(DeviceCols &d, uint64_t n_sites, uint64_t n_cells) {
     if (n_sites > d.cap_out_sites) {
         dev_free(d.site_flags); d.site_flags = nullptr;
+        dev_free(d.site_elig); d.site_elig = nullptr;
         const uint64_t cap = std::max<uint64_t>(n_sites + n_sites / 4, 1024);
-        if (int rc = dev_alloc((void **)&d.site_flags, cap, &d.device_bytes)) return rc;
+        if (int rc = dev_alloc((void **)&d.site_flags, cap + 4, &d.device_bytes)) return rc;      // (+4: 32-bit atomics on the byte's aligned word)
+        if (int rc = dev_alloc((void **)&d.site_elig, cap + 4, &d.device_bytes)) return rc;
         d.cap_out_sites = cap;
     }
     if (n_cells > d.cap_cells) {
@@ -1495,7 +1539,7 @@ static int ensure_out(DeviceCols &d, uint64_t n_sites, uint64_t n_cells) {
     return MSNV_OK;
 }
 
-// Enqueues one pass (memsets + kernels + readback of the counters into host_cnt[8]) without waiting for it.
+// Enqueues one pass (kernels + readback of the pass' counter block into host_cnt[CNT_WORDS]) without waiting for it.
 // ev_begin / ev_pile0 / ev_pile1 are recorded before the pass, before and after the pileup kernel(s); ev3 / ev4 (optional)
 // split the tail.  Buffers must have been sized by ensure_out before.
 static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hipEvent_t ev_begin, hipEvent_t ev_pile0, hipEvent_t ev_pile1,
@@ -1518,13 +1562,9 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
         a.ind4 = d.ind4; a.unc_bits = d.unc_bits; a.slot_dirty = d.tile_dirty; a.min_snvs = (uint32_t)std::max(0, p.calling_threshold);
         const uint32_t n_narrow = d.n_work_narrow, n_merged = d.n_work_merged;
         // narrow work items (byte bins), merged groups of shallow pairs and wide items (16-bit bins) touch disjoint (tile, sample) pairs
-        if (n_narrow && d.dense) hipLaunchKernelGGL(msnv_pileup_tiles_dense, dim3(n_narrow), dim3(N_NT), 0, st, a);
-        else if (n_narrow) hipLaunchKernelGGL(msnv_pileup_tiles_narrow32, dim3(n_narrow), dim3(N_NT), 0, st, a);
-        if (n_merged) {
-            PileupArgs b = a;
-            b.work = d.work + n_narrow; b.hdr8 = d.hdr8m;
-            hipLaunchKernelGGL(msnv_pileup_tiles_merged, dim3(n_merged), dim3(N_NT), 0, st, b);
-        }
+        a.hdr8m = d.hdr8m; a.n_narrow = n_narrow;
+        if (n_narrow && d.dense) hipLaunchKernelGGL(msnv_pileup_tiles_dense, dim3(n_narrow), dim3(N_NT), 0, st, a);      // (the dense layout never merges)
+        else if (n_narrow + n_merged) hipLaunchKernelGGL(msnv_pileup_tiles_narrow32, dim3(n_narrow + n_merged), dim3(N_NT), 0, st, a);
         if (d.n_work > n_narrow + n_merged) {
             PileupArgs b = a;
             b.work = d.work + n_narrow + n_merged;
@@ -1534,8 +1574,9 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
     }
     HIP_TRY(hipEventRecord(ev_pile1, st));
     const uint32_t cap_out = (uint32_t)std::min<uint64_t>(d.cap_out_sites, 0xffffffffull);
-    const bool need_decide = d.any_split || d.n_work_merged;        // some sample's reads sit in several pairs / a merged group: sites whose call
-                                                                    // depends on its summed counts are decided behind the scatter (msnv_decide_sites)
+    const bool need_decide = d.any_split;                           // some sample's reads sit in several pairs of a tile: sites whose call depends
+                                                                    // on its summed counts are decided behind the scatter (msnv_decide_sites);
+                                                                    // merged groups alone are handled inside the merged gather
     if (d.n_active_tiles) {
         GateArgs g;
         g.tot = d.tot; g.part = d.part; g.slot_off = d.slot_off; g.tile_slot_start = d.tile_slot_start; g.tile_slot_u16 = d.tile_slot_u16; g.tile_slot_wide = d.tile_slot_wide;
@@ -1545,6 +1586,7 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
         g.tile_site_base = d.tile_site_base; g.tile_site_cnt = d.tile_site_cnt; g.active_tiles = d.active_tiles;
         g.out = d.out; g.cov_col = d.cov_col; g.site_flags = d.site_flags; g.cap_out = cap_out; g.decide_here = 1u;
         g.gate_tiles = reinterpret_cast<const GateTile *>(d.gate_tiles); g.tile_dirty = d.tile_dirty; g.unc_sites = d.unc_sites;
+        g.use_dirty = d.use_dirty ? 1u : 0u; g.block_row = d.site_row; g.site_elig = d.site_elig; g.any_split = d.any_split ? 1u : 0u;
         static_assert(sizeof(GateTile) == sizeof(DeviceCols::GateTileH) && sizeof(GateTile) == 48, "gate tile descriptor");
         g.tile_nslots = d.tile_nslots; g.tile_cell_base = d.tile_cell_base; g.cap_cells = d.cap_cells;
         hipLaunchKernelGGL(msnv_gate_sites, dim3(d.n_active_tiles), dim3(GATE_NT), 0, st, g);
@@ -1556,28 +1598,31 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
         TailArgs ta;
         ta.sites = d.sites; ta.tile_site_base = d.tile_site_base; ta.tile_site_cnt = d.tile_site_cnt; ta.tile_pair_start = d.tile_pair_start;
         ta.pairs = d.pairs; ta.spill = d.spill; ta.out = d.out; ta.cov_col = d.cov_col; ta.cap_out = cap_out; ta.active_tiles = d.active_tiles;
-        ta.cells = CellMap{d.tile_site_base, d.tile_cell_base, d.tile_nslots, d.cap_cells};
+        ta.cells = CellMap{d.tile_site_base, d.tile_cell_base, d.tile_nslots, d.cap_cells, d.site_row};
         ta.gather_split = d.gather_split;
         ta.n_gather_blocks = d.n_active_tiles * d.gather_split;
-        ta.tile_pair_merged = d.tile_pair_merged; ta.work_merged = d.work + d.n_work_narrow; ta.chunks = d.chunks; ta.hdr8m = d.hdr8m;
-        ta.seq = d.seq; ta.qual = d.qual; ta.ref4 = d.ref4; ta.n_merged_blocks = d.n_work_merged; ta.min_baseq = (uint32_t)std::max(0, p.min_baseq);
+        ta.tile_pair_merged = d.tile_pair_merged; ta.merged_groups = d.merged_groups; ta.chunks = d.chunks; ta.hdr8m = d.hdr8m;
+        ta.seq = d.seq; ta.qual = d.qual; ta.ref4 = d.ref4; ta.n_merged_blocks = d.n_merged_groups; ta.min_baseq = (uint32_t)std::max(0, p.min_baseq);
+        ta.site_flags = d.site_flags; ta.site_elig = d.site_elig; ta.ind_in_gather = d.any_split ? 0u : 1u; ta.min_snvs = (uint32_t)std::max(1, p.calling_threshold);
         ta.events = d.events; ta.overflow = d.overflow; ta.counters = counters; ta.cap_list = d.cap_events / EV_LISTS; ta.cap_overflow = d.cap_overflow;
         ta.site_bits = d.site_bits; ta.site_rank = d.site_rank;
-        hipLaunchKernelGGL(msnv_gather_scatter, dim3(ta.n_gather_blocks + ta.n_merged_blocks + SCATTER_BLOCKS_PER_LIST * EV_LISTS), dim3(256), 0, st, ta);
+        const dim3 grid(ta.n_gather_blocks + ta.n_merged_blocks + SCATTER_BLOCKS_PER_LIST * EV_LISTS + 1u);      // + 1: the event total
+        if (ta.n_merged_blocks) hipLaunchKernelGGL(msnv_gather_scatter<true>, grid, dim3(256), 0, st, ta);
+        else hipLaunchKernelGGL(msnv_gather_scatter<false>, grid, dim3(256), 0, st, ta);
         HIP_TRY(hipGetLastError());
     }
     if (ev4) HIP_TRY(hipEventRecord(ev4, st));
     if (need_decide && d.n_active_tiles) {
         hipLaunchKernelGGL(msnv_decide_sites, dim3(256), dim3(256), 0, st, d.sites, d.unc_sites, counters, d.cap_sites, cap_out, d.ref4, d.ref_lc,
-                           d.out, CellMap{d.tile_site_base, d.tile_cell_base, d.tile_nslots, d.cap_cells}, p.calling_threshold, p.min_fraction, d.site_flags);
+                           d.out, CellMap{d.tile_site_base, d.tile_cell_base, d.tile_nslots, d.cap_cells, d.site_row}, p.calling_threshold, p.min_fraction, d.site_flags);
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipMemcpyAsync(host_cnt, counters, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(host_cnt, counters, CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     return MSNV_OK;
 }
 
 static int check_counts(DeviceCols &d, const uint32_t *cnt, RunCounts *counts) {
-    RunCounts c{cnt[0], cnt[1], cnt[2], cnt[3], (uint64_t)cnt[6] | (uint64_t)cnt[7] << 32};
+    RunCounts c{cnt[0], cnt[1], cnt[2], cnt[3], (uint64_t)cnt[CNT_CELLS] | (uint64_t)cnt[CNT_CELLS + 1] << 32};
     d.last_sites = c.n_sites; d.last_cells = c.n_cells;
     if (counts) *counts = c;
     if (c.n_events > d.cap_events / EV_LISTS * EV_LISTS || c.n_overflow > d.cap_overflow || c.n_sites > d.cap_sites || c.n_sites > d.cap_out_sites || c.n_cells > d.cap_cells)
@@ -1598,7 +1643,7 @@ int dev_run_pipeline(DeviceCols &d, const msnv_params &p, void *stream_, msnv_ru
     // the tail is only recorded on request (MSNV_PHASE_TIMES=1, profiles/phase_times.py)
     static const bool phase_times = [] { const char *e = getenv("MSNV_PHASE_TIMES"); return e && e[0] == '1'; }();
     if (int rc = ensure_out(d, std::max<uint64_t>(d.last_sites + d.last_sites / 2, 4096), std::max<uint64_t>(d.last_cells + d.last_cells / 2, 1u << 18))) return rc;
-    uint32_t cnt[8] = {0};
+    uint32_t cnt[CNT_WORDS] = {0};
     if (int rc = enqueue_pass(d, p, st, ev[0], ev[1], ev[2], phase_times ? ev[3] : nullptr, phase_times ? ev[4] : nullptr, cnt)) return rc;
     HIP_TRY(hipEventRecord(ev[5], st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -1613,7 +1658,7 @@ int dev_run_pipeline(DeviceCols &d, const msnv_params &p, void *stream_, msnv_ru
             HIP_TRY(hipEventElapsedTime(&ms, ev[4], ev[5])); stats->ms_decide = ms;
         }
         stats->n_sites = cnt[2]; stats->n_events = cnt[0]; stats->n_overflow = cnt[1];
-        stats->n_called_pop = cnt[4]; stats->n_called_indiv = cnt[5];
+        stats->n_called_pop = cnt[4] + cnt[CNT_TALLY]; stats->n_called_indiv = cnt[5] + cnt[CNT_TALLY + 1];    // msnv_decide_sites' lines + the gate kernel's (and the merged gather's)
         stats->algorithmic_bytes = d.algorithmic_bytes;
     }
     return MSNV_OK;
@@ -1624,7 +1669,7 @@ static int ensure_alt(DeviceCols &d) {
     DeviceCols::AltBufs &a = d.alt;
     const uint64_t npos = (uint64_t)d.n_tiles * TILE;
     if (a.tot && a.cap_events == d.cap_events && a.cap_overflow == d.cap_overflow && a.cap_sites == d.cap_sites && a.cap_out_sites == d.cap_out_sites && a.cap_cells == d.cap_cells) return MSNV_OK;
-    void *old[] = {a.tot, a.part, a.spill, a.events, a.overflow, a.counters, a.ind4, a.tile_dirty, a.unc_sites, a.sites, a.tile_site_base, a.tile_site_cnt, a.tile_cell_base, a.out, a.cov_col, a.site_flags, a.site_bits, a.site_rank};
+    void *old[] = {a.tot, a.part, a.spill, a.events, a.overflow, a.counters, a.ind4, a.tile_dirty, a.unc_sites, a.site_row, a.sites, a.tile_site_base, a.tile_site_cnt, a.tile_cell_base, a.out, a.cov_col, a.site_flags, a.site_elig, a.site_bits, a.site_rank};
     for (void *p : old) dev_free(p);
     a = DeviceCols::AltBufs{};
     if (int rc = dev_alloc((void **)&a.tot, std::max<uint64_t>(1, 4 * npos) * sizeof(uint32_t), &d.device_bytes)) return rc;
@@ -1635,6 +1680,7 @@ static int ensure_alt(DeviceCols &d) {
     if (int rc = dev_alloc((void **)&a.overflow, (uint64_t)d.cap_overflow * sizeof(Pair32), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.sites, (uint64_t)d.cap_sites * sizeof(SiteRec), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.unc_sites, (uint64_t)d.cap_sites * sizeof(uint32_t), &d.device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&a.site_row, (npos / 64 + 1) * sizeof(unsigned long long), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.tile_dirty, ((uint64_t)d.n_work + 1) * sizeof(uint32_t), &d.device_bytes)) return rc;
     if (int rc = dev_memset(a.tile_dirty, 0, ((uint64_t)d.n_work + 1) * sizeof(uint32_t))) return rc;
     if (int rc = dev_alloc((void **)&a.counters, 2 * CNT_WORDS * sizeof(uint32_t), &d.device_bytes)) return rc;
@@ -1651,7 +1697,8 @@ static int ensure_alt(DeviceCols &d) {
     if (int rc = dev_alloc((void **)&a.tile_cell_base, ((uint64_t)d.n_tiles + 1) * sizeof(unsigned long long), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.out, d.cap_cells * sizeof(msnv_site_sample), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.cov_col, d.cap_cells * sizeof(uint16_t) + 16, &d.device_bytes)) return rc;
-    if (int rc = dev_alloc((void **)&a.site_flags, d.cap_out_sites, &d.device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&a.site_flags, d.cap_out_sites + 4, &d.device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&a.site_elig, d.cap_out_sites + 4, &d.device_bytes)) return rc;
     a.cap_events = d.cap_events; a.cap_overflow = d.cap_overflow; a.cap_sites = d.cap_sites; a.cap_out_sites = d.cap_out_sites; a.cap_cells = d.cap_cells;
     return MSNV_OK;
 }
@@ -1660,8 +1707,8 @@ static void swap_sets(DeviceCols &d) {
     std::swap(d.tot, a.tot); std::swap(d.part, a.part); std::swap(d.spill, a.spill); std::swap(d.events, a.events);
     std::swap(d.overflow, a.overflow); std::swap(d.counters, a.counters); std::swap(d.sites, a.sites);
     std::swap(d.tile_site_base, a.tile_site_base); std::swap(d.tile_site_cnt, a.tile_site_cnt); std::swap(d.tile_cell_base, a.tile_cell_base); std::swap(d.out, a.out); std::swap(d.cov_col, a.cov_col);
-    std::swap(d.site_flags, a.site_flags); std::swap(d.ind4, a.ind4); std::swap(d.unc_bits, a.unc_bits); std::swap(d.cnt_parity, a.cnt_parity);
-    std::swap(d.tile_dirty, a.tile_dirty); std::swap(d.unc_sites, a.unc_sites); std::swap(d.site_bits, a.site_bits); std::swap(d.site_rank, a.site_rank);
+    std::swap(d.site_flags, a.site_flags); std::swap(d.site_elig, a.site_elig); std::swap(d.ind4, a.ind4); std::swap(d.unc_bits, a.unc_bits); std::swap(d.cnt_parity, a.cnt_parity);
+    std::swap(d.tile_dirty, a.tile_dirty); std::swap(d.unc_sites, a.unc_sites); std::swap(d.site_row, a.site_row); std::swap(d.site_bits, a.site_bits); std::swap(d.site_rank, a.site_rank);
 }
 
 // n passes, ONE host synchronisation at the end; with `overlap` they are in flight on two streams (a queue of shards / repeated passes keeps the
@@ -1691,7 +1738,7 @@ int dev_run_pipeline_many(DeviceCols &d, const msnv_params &p, void *stream_, in
     if (d.pinned_cnt_cap < (size_t)n) {
         if (d.pinned_cnt) (void)hipHostFree(d.pinned_cnt);
         d.pinned_cnt = nullptr; d.pinned_cnt_cap = 0;
-        if (hipHostMalloc((void **)&d.pinned_cnt, (size_t)n * 8 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return fail(MSNV_ENOMEM, "pinned host memory for %d counter blocks", n);
+        if (hipHostMalloc((void **)&d.pinned_cnt, (size_t)n * CNT_WORDS * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return fail(MSNV_ENOMEM, "pinned host memory for %d counter blocks", n);
         d.pinned_cnt_cap = (size_t)n;
     }
     uint32_t *cnt = d.pinned_cnt;
@@ -1703,7 +1750,7 @@ int dev_run_pipeline_many(DeviceCols &d, const msnv_params &p, void *stream_, in
         if (two && (i & 1) != (swapped ? 1 : 0)) { swap_sets(d); swapped = !swapped; }
         // the pileup kernel of pass i starts after the one of pass i-1 (other stream) has finished; its memsets do not wait
         // (only the first pass records a begin event: every event record costs stream time)
-        rc = enqueue_pass(d, p, st, i == 0 ? ev[0] : nullptr, ev[4 * i + 1], ev[4 * i + 2], nullptr, nullptr, cnt + 8 * i, (two && i > 0) ? ev[4 * (i - 1) + 2] : nullptr);
+        rc = enqueue_pass(d, p, st, i == 0 ? ev[0] : nullptr, ev[4 * i + 1], ev[4 * i + 2], nullptr, nullptr, cnt + (size_t)CNT_WORDS * i, (two && i > 0) ? ev[4 * (i - 1) + 2] : nullptr);
     }
     if (!rc && he == hipSuccess) he = hipEventRecord(ev[4 * n], s0);
     if (!rc && he == hipSuccess) he = hipEventRecord(ev[4 * n + 1], s1);
@@ -1718,15 +1765,15 @@ int dev_run_pipeline_many(DeviceCols &d, const msnv_params &p, void *stream_, in
         if (two && hipEventElapsedTime(&t1, ev[0], ev[4 * n + 1]) == hipSuccess) total = std::max(total, t1);
     }
     for (int i = 0; i < n && !rc; ++i) {
-        rc = check_counts(d, cnt + 8 * i, counts);
+        rc = check_counts(d, cnt + (size_t)CNT_WORDS * i, counts);
         if (rc || !stats) continue;
         float ms = 0;
         msnv_run_stats &s = stats[i];
         s = msnv_run_stats{};
         s.ms_total = total / (float)n;
         if (hipEventElapsedTime(&ms, ev[4 * i + 1], ev[4 * i + 2]) == hipSuccess) s.ms_pileup = ms;
-        const uint32_t *c = cnt + 8 * i;
-        s.n_sites = c[2]; s.n_events = c[0]; s.n_overflow = c[1]; s.n_called_pop = c[4]; s.n_called_indiv = c[5];
+        const uint32_t *c = cnt + (size_t)CNT_WORDS * i;
+        s.n_sites = c[2]; s.n_events = c[0]; s.n_overflow = c[1]; s.n_called_pop = c[4] + c[CNT_TALLY]; s.n_called_indiv = c[5] + c[CNT_TALLY + 1];
         s.algorithmic_bytes = d.algorithmic_bytes;
     }
     cleanup();

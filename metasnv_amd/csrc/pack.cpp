@@ -812,11 +812,22 @@ int finalize_dataset(msnv_dataset &ds) {
         const uint32_t shallow_pieces = [] { const char *e = getenv("MSNV_SHALLOW_PIECES"); const int v = e ? atoi(e) : 48; return (uint32_t)std::max(0, v); }();   // read per dataset (tests switch it)
         const bool can_merge = !dense && shallow_pieces > 0 && sbase[S] < (32ull << 30);   // merged headers hold absolute seq offsets / 8 in 32 bits
         auto is_shallow = [&](const TilePair &p) { return p.read_hi - p.read_lo <= shallow_pieces && p.max_depth <= MERGE_MAX_DEPTH / 3 && !p.pad; };
+        // ... and only when the shallow pairs are a real share of the dataset (>= 3 % of its pieces): a few of them -- the
+        // partial last tile of every contig of the benchmark shape -- are not worth the second code path in the tail
+        std::vector<uint8_t> merge_tile(nt, 0);
+        if (can_merge) {
+            uint64_t shallow_pieces_total = 0, all_pieces = 0;
+            for (uint64_t t = 0; t < nt; ++t) {
+                uint32_t n_shallow = 0; uint64_t np = 0;
+                for (uint32_t k = tps[t]; k < tps[t + 1]; ++k) { all_pieces += pairs[k].read_hi - pairs[k].read_lo; if (is_shallow(pairs[k])) { ++n_shallow; np += pairs[k].read_hi - pairs[k].read_lo; } }
+                if (n_shallow >= 2) { merge_tile[t] = 1; shallow_pieces_total += np; }
+            }
+            const bool force = [] { const char *e = getenv("MSNV_MERGE_ALWAYS"); return e && e[0] == '1'; }();   // (tests)
+            if (!force && shallow_pieces_total * 100 < all_pieces * 3) std::fill(merge_tile.begin(), merge_tile.end(), 0);
+        }
         for (uint64_t t = 0; t < nt; ++t) {
             auto b = pairs.begin() + tps[t], e = pairs.begin() + tps[t + 1];
-            uint32_t n_shallow = 0;
-            if (can_merge) for (auto it = b; it != e; ++it) if (is_shallow(*it)) ++n_shallow;
-            if (n_shallow >= 2) for (auto it = b; it != e; ++it) if (is_shallow(*it)) it->pad = 2;
+            if (merge_tile[t]) for (auto it = b; it != e; ++it) if (is_shallow(*it)) it->pad = 2;
             std::stable_sort(b, e, [](const TilePair &x, const TilePair &y) {
                 auto cls = [](const TilePair &p) { return p.pad == 2 ? 2 : p.max_depth < NARROW_MAX_DEPTH ? 0 : 1; };
                 return cls(x) < cls(y);
@@ -971,7 +982,8 @@ int finalize_dataset(msnv_dataset &ds) {
         gts.reserve(active.size());
         for (uint32_t t : active) gts.push_back(DeviceCols::GateTileH{t, tss[t], t16[t], twide[t], tss[t + 1], vb_host[t], ve_host[t], nslots_host[t], off[tss[t]], 0});
         if (int rc = upload_vec(&d->gate_tiles, gts, &d->device_bytes, 1)) return rc;
-        d->gather_split = (uint32_t)std::min<uint64_t>(4, std::max<uint64_t>(1, (active.empty() ? 0 : pairs.size() / active.size()) / 40));
+        d->gather_split = (uint32_t)std::min<uint64_t>(4, std::max<uint64_t>(1, (active.empty() ? 0 : pairs.size() / active.size()) / 32));
+        d->use_dirty = !active.empty() && work.size() < 4 * active.size();       // a sparse cohort: fewer than four work items per tile
     }
     // ---- chunk descriptors of the narrow work items
     std::vector<ChunkDesc> chunks;
@@ -998,6 +1010,7 @@ int finalize_dataset(msnv_dataset &ds) {
     // ---- merged groups: their piece headers, group by group, and chunks that run across the group's pairs
     {
         std::vector<PieceHdr> hm;
+        std::vector<MergedGroupDev> mgroups;
         size_t gi = 0;
         for (uint32_t wi = d->n_work_narrow; wi < d->n_work_narrow + d->n_work_merged; ++wi) {
             WorkItem &w = work[wi];
@@ -1012,6 +1025,7 @@ int finalize_dataset(msnv_dataset &ds) {
                         hm.push_back(PieceHdr{(sc.hdr[r].gpos % TILE) | sc.hdr[r].cig << 11 | (k - g.pair_lo) << 19, (uint32_t)((sbase[p.sample] + sc.hdr[r].seqoff) >> 3)});
                 }
                 const uint64_t n_h = hm.size() - h0;
+                mgroups.push_back(MergedGroupDev{h0, w.tile, g.pair_lo, g.pair_hi - g.pair_lo, (uint32_t)n_h});
                 for (uint64_t r = 0; r < n_h; r += CHUNK_READS) {
                     const uint32_t n = (uint32_t)std::min<uint64_t>(CHUNK_READS, n_h - r);
                     chunks.push_back(ChunkDesc{h0 + r, 0, pairs[g.pair_lo].sample, g.pair_lo, n | (r + n >= n_h ? 1u << 16 : 0u), g.pair_hi - g.pair_lo});
@@ -1022,6 +1036,8 @@ int finalize_dataset(msnv_dataset &ds) {
         if (gi != groups.size()) return fail(MSNV_EINVAL, "internal: merged groups and work items disagree");
         ds.info.bytes_headers += hm.size() * sizeof(PieceHdr);
         if (int rc = upload_vec(&d->hdr8m, hm, &d->device_bytes, 1)) return rc;
+        d->n_merged_groups = (uint32_t)mgroups.size();
+        if (int rc = upload_vec(&d->merged_groups, mgroups, &d->device_bytes, 1)) return rc;
         if (int rc = upload_vec(&d->tile_pair_merged, tpm, &d->device_bytes)) return rc;
     }
     if (int rc = upload_vec(&d->chunks, chunks, &d->device_bytes, 1)) return rc;
@@ -1148,6 +1164,7 @@ int finalize_dataset(msnv_dataset &ds) {
     if (int rc = dev_alloc((void **)&d->overflow, (uint64_t)d->cap_overflow * sizeof(Pair32), &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->sites, (uint64_t)d->cap_sites * sizeof(SiteRec), &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->unc_sites, (uint64_t)d->cap_sites * sizeof(uint32_t), &d->device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&d->site_row, (npos / 64 + 1) * sizeof(unsigned long long), &d->device_bytes)) return rc;   // per 64 positions (kernels.hip: CellMap::block_row)
     if (int rc = dev_alloc((void **)&d->tile_dirty, ((uint64_t)work.size() + 1) * sizeof(uint32_t), &d->device_bytes)) return rc;    // one word per work item (by slot)
     if (int rc = dev_memset(d->tile_dirty, 0, ((uint64_t)work.size() + 1) * sizeof(uint32_t))) return rc;
     // no memset per pass: the counter blocks alternate (the gate kernel zeroes the next one) and the gate kernel leaves the
