@@ -342,6 +342,9 @@ int  msnv_results_fetch(msnv_dataset *ds, msnv_site *sites, msnv_site_sample *sa
  * Host I/O helpers used by the Python CLI and the tests (BGZF/BAM on zlib: htslib is not
  * available in the build image).
  * ------------------------------------------------------------------------------------ */
+/* Host-stage counters since the library was loaded: BGZF blocks that the library's own DEFLATE decoder (csrc/inflate.cpp)
+ * handed to zlib (0 for well-formed files; tests). */
+int  msnv_host_stats(uint64_t *zlib_fallbacks);
 /* `samtools view -H` replacement for bed_header (metaSNV.py:81-94): writes SN\t1\tLN lines. */
 int  msnv_bam_write_bed_header(const char *bam_path, const char *out_path);
 /* Reads a whole BAM: header text, contigs and the raw record stream.  Free with msnv_free. */

@@ -4,6 +4,7 @@
 #include <atomic>
 #include <climits>
 #include <cstring>
+#include <stdexcept>
 #include <thread>
 
 #include "device.h"
@@ -155,7 +156,9 @@ extern "C" int msnv_dataset_add_sample_records(msnv_dataset *ds, const uint8_t *
     if (!ds || (n_bytes && !records)) return fail(MSNV_EINVAL, "msnv_dataset_add_sample_records: NULL argument");
     if (ds->finalized) return fail(MSNV_EINVAL, "dataset is already finalized");
     ds->samples.emplace_back();
-    int rc = pack_sample(*ds, records, n_bytes, ds->samples.back());
+    int rc;
+    try { rc = pack_sample(*ds, records, n_bytes, ds->samples.back()); }
+    catch (const std::exception &e) { rc = fail(MSNV_ENOMEM, "packing a sample failed: %s", e.what()); }      // nothing is thrown across the C ABI
     if (rc) ds->samples.pop_back();
     return rc;
 }
@@ -197,10 +200,13 @@ extern "C" int msnv_dataset_add_sample_bams(msnv_dataset *ds, const char *const 
         for (;;) {
             int i = next.fetch_add(1);
             if (i >= n || err.load()) break;
-            BamHeader h; std::vector<uint8_t> rec;
-            int rc = bam_read(bam_paths[i], h, rec, 1);
-            if (!rc) rc = check_header(*ds, h, bam_paths[i]);
-            if (!rc) rc = pack_sample(*ds, rec.data(), rec.size(), ds->samples[first + (size_t)i]);
+            int rc;
+            try {                                              // an exception in a worker thread would be std::terminate
+                BamHeader h; std::vector<uint8_t> rec;
+                rc = bam_read(bam_paths[i], h, rec, 1);
+                if (!rc) rc = check_header(*ds, h, bam_paths[i]);
+                if (!rc) rc = pack_sample(*ds, rec.data(), rec.size(), ds->samples[first + (size_t)i]);
+            } catch (const std::exception &e) { rc = fail(MSNV_ENOMEM, "%s: %s", bam_paths[i], e.what()); }
             if (rc) { msgs[(size_t)i] = msnv_last_error(); err.store(rc); }
         }
     };
@@ -232,8 +238,11 @@ extern "C" int msnv_dataset_add_synth_samples(msnv_dataset *ds, const msnv_synth
         for (;;) {
             int i = next.fetch_add(1);
             if (i >= count || err.load()) break;
-            synth_sample_records(*p, first + i, contigs, rec);
-            int rc = pack_sample(*ds, rec.data(), rec.size(), ds->samples[base + (size_t)i]);
+            int rc;
+            try {
+                synth_sample_records(*p, first + i, contigs, rec);
+                rc = pack_sample(*ds, rec.data(), rec.size(), ds->samples[base + (size_t)i]);
+            } catch (const std::exception &) { rc = MSNV_ENOMEM; }
             if (rc) { err.store(rc); }
         }
     };
@@ -250,7 +259,8 @@ extern "C" int msnv_dataset_finalize(msnv_dataset *ds) {
     if (ds->finalized) return fail(MSNV_EINVAL, "dataset is already finalized");
     if (!ds->ctx) return fail(MSNV_ENODEV, "this dataset was created without a device context: only the host-stage entry points work on it (no CPU fallback)");
     if (int rc = dev_set_device(ds->ctx->device)) return rc;
-    return finalize_dataset(*ds);
+    try { return finalize_dataset(*ds); }
+    catch (const std::exception &e) { return fail(MSNV_ENOMEM, "building the device dataset failed: %s", e.what()); }
 }
 
 extern "C" int msnv_dataset_info_get(const msnv_dataset *ds, msnv_dataset_info *out) {

@@ -10,7 +10,9 @@
 
 #include <atomic>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
+#include <stdexcept>
 #include <thread>
 
 namespace msnv {
@@ -38,6 +40,8 @@ void clear_error() { t_err[0] = 0; }
 }  // namespace msnv
 
 extern "C" const char *msnv_last_error(void) { return msnv::t_err; }
+namespace msnv { uint64_t inflate_zlib_fallbacks(); }
+extern "C" int msnv_host_stats(uint64_t *zlib_fallbacks) { if (zlib_fallbacks) *zlib_fallbacks = msnv::inflate_zlib_fallbacks(); return MSNV_OK; }
 
 namespace msnv {
 
@@ -48,9 +52,11 @@ static int read_file(const char *path, std::vector<uint8_t> &buf) {
     long n = ftell(f);
     fseek(f, 0, SEEK_SET);
     if (n < 0) { fclose(f); return fail(MSNV_EIO, "cannot stat %s", path); }
-    buf.resize((size_t)n);
+    try { buf.resize((size_t)n + 16); } catch (const std::exception &) { fclose(f); return fail(MSNV_ENOMEM, "out of memory reading %s (%ld bytes)", path, n); }
     if (n && fread(buf.data(), 1, (size_t)n, f) != (size_t)n) { fclose(f); return fail(MSNV_EIO, "short read on %s", path); }
     fclose(f);
+    memset(buf.data() + n, 0, 16);       // the inflate fast path loads 8 bytes at a time
+    buf.resize((size_t)n);               // (capacity keeps the padding readable)
     return MSNV_OK;
 }
 
@@ -66,17 +72,20 @@ static int bgzf_index(const std::vector<uint8_t> &in, const char *path, std::vec
         const uint8_t *p = in.data() + off;
         if (p[0] != 31 || p[1] != 139 || p[2] != 8 || !(p[3] & 4)) return fail(MSNV_EFORMAT, "%s: not a BGZF file", path);
         uint32_t xlen = p[10] | p[11] << 8;
+        if (12ull + xlen > in.size() - off) return fail(MSNV_EFORMAT, "%s: truncated BGZF extra field", path);      // nothing of the file is trusted
         uint32_t bsize = 0;
         bool found = false;
         uint32_t x = 0;
         while (x + 4 <= xlen) {
             const uint8_t *e = p + 12 + x;
             uint32_t slen = e[2] | e[3] << 8;
+            if (x + 4 + slen > xlen) break;
             if (e[0] == 'B' && e[1] == 'C' && slen == 2) { bsize = (e[4] | e[5] << 8) + 1u; found = true; }
             x += 4 + slen;
         }
         if (!found || off + bsize > in.size() || bsize < 12 + xlen + 8) return fail(MSNV_EFORMAT, "%s: bad BGZF block", path);
         uint32_t isize = ld_u32(p + bsize - 4);
+        if (isize > 65536u) return fail(MSNV_EFORMAT, "%s: BGZF block claims %u uncompressed bytes (the format allows 65536)", path, isize);
         BlockRef b{off + 12 + xlen, bsize - 12 - xlen - 8, isize, total_out};
         blocks.push_back(b);
         total_out += isize;
@@ -85,8 +94,18 @@ static int bgzf_index(const std::vector<uint8_t> &in, const char *path, std::vec
     return MSNV_OK;
 }
 
+bool inflate_raw(const uint8_t *src, uint32_t n_in, uint8_t *dst, uint32_t n_out);          // inflate.cpp
+bool inflate_raw_bmi2(const uint8_t *src, uint32_t n_in, uint8_t *dst, uint32_t n_out);     // the same, compiled with -mbmi2
+static std::atomic<uint64_t> g_zlib_fallbacks{0};
+uint64_t inflate_zlib_fallbacks() { return g_zlib_fallbacks.load(); }
+
 static bool inflate_block(const uint8_t *src, uint32_t n_in, uint8_t *dst, uint32_t n_out) {
     if (n_out == 0) return true;
+    static const bool use_zlib = [] { const char *e = getenv("MSNV_INFLATE"); return e && e[0] == 'z'; }();     // MSNV_INFLATE=zlib: A/B of the two decoders
+    static const bool bmi2 = __builtin_cpu_supports("bmi2") != 0;
+    if (!use_zlib && (bmi2 ? inflate_raw_bmi2(src, n_in, dst, n_out) : inflate_raw(src, n_in, dst, n_out))) return true;
+    // zlib decides about anything the fast decoder refuses (a malformed block fails here too); counted: a well-formed file never gets here
+    if (!use_zlib) g_zlib_fallbacks.fetch_add(1);
     z_stream zs;
     memset(&zs, 0, sizeof zs);
     if (inflateInit2(&zs, -15) != Z_OK) return false;
@@ -103,7 +122,7 @@ int bgzf_read_all(const char *path, std::vector<uint8_t> &out, int threads) {
     std::vector<BlockRef> blocks;
     uint64_t total = 0;
     if (int rc = bgzf_index(in, path, blocks, total)) return rc;
-    out.resize(total);
+    try { out.resize(total); } catch (const std::exception &) { return fail(MSNV_ENOMEM, "%s: out of memory for %llu inflated bytes", path, (unsigned long long)total); }
     std::atomic<size_t> next{0};
     std::atomic<bool> bad{false};
     auto worker = [&]() {
@@ -187,7 +206,10 @@ int bam_read(const char *path, BamHeader &hdr, std::vector<uint8_t> &records, in
     if (int rc = bgzf_read_all(path, u, threads)) return rc;
     uint64_t off = 0;
     if (int rc = bam_parse_header(u, path, hdr, off)) return rc;
-    records.assign(u.begin() + (ptrdiff_t)off, u.end());
+    // the records follow the header in the same buffer: shift them down instead of copying them into a second one
+    if (off) memmove(u.data(), u.data() + off, u.size() - off);
+    u.resize(u.size() - off);
+    records.swap(u);
     return MSNV_OK;
 }
 

@@ -20,6 +20,8 @@ SHAPES = [
     ("few_deep_16x100", dict(n_samples=16, mean_cov=100.0)),
     ("many_shallow_1600x1", dict(n_samples=1600, mean_cov=1.0)),
     ("one_sample_1600x", dict(n_samples=1, mean_cov=1600.0, sigma_cov=0.0, frac_absent=0.0)),
+    ("sparse_500x5x_20ofN", dict(n_species=150, contig_len=2070000, n_samples=500, mean_cov=5.0, sigma_cov=0.3, contigs_per_species_max=20, species_per_sample=1, frac_absent=0.75)),
+    ("config3_quarter", dict(n_species=25, contig_len=3000000, n_samples=160, mean_cov=10.0, sigma_cov=0.7, contigs_per_species_max=50, species_per_sample=3, frac_absent=0.1667)),
 ]
 only = sys.argv[1:]
 ctx = core.Context(0)
