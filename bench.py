@@ -240,7 +240,12 @@ def main():
         ms = []
         for _ in range(5):
             ms.append(ds.coverage_run()["ms_coverage"])
-        cov_extra = {"kernel_ms": sum(ms[1:]) / len(ms[1:]), "bytes_per_M_interval": 8, "intervals": info["n_reads_pileup"]}
+        cov_ms = sum(ms[1:]) / len(ms[1:])
+        cov_extra = {"kernel_ms": cov_ms, "bytes_per_M_interval": 8, "intervals": info["n_reads_pileup"],
+                     "roofline": {"bound": "hbm", "achieved": 8.0 * info["n_reads_pileup"] / (cov_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": 8.0 * info["n_reads_pileup"] / (cov_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "limited_by": "vector-instruction issue, not HBM: ~900 wave-instructions per (tile, sample) pair whatever its ~100 intervals "
+                                                "hold (profiles/r02cov_pmc.json: SQ_INSTS_VALU 65.8 M per launch, FETCH_SIZE x2 = 143 MB)"}}
 
     ann_extra = None
     if not a.no_annotation and rank == 0:
@@ -256,6 +261,27 @@ def main():
             ms = [ds.annotate(an, fa)[1] for _ in range(5)]
             ann_extra = {"genes": n_genes, "sites": int(len(recs)), "sites_in_gene": int((recs["gene"] >= 0).sum()),
                          "kernel_ms": sum(ms) / len(ms), "first_call_s_incl_parse_upload": t_first}
+
+    dist_extra = None
+    if not a.no_annotation and rank == 0 and a.workload == "testdata":
+        # metaSNV_DistDiv.py --dist on the device, on a table of the size this workload's calls give
+        # (samples x called positions; random frequencies, 10 % of the cells uninformative), outside the timed region
+        import random
+        import tempfile
+        import ctypes as C
+        from metasnv_amd import _lib
+        rnd = random.Random(11)
+        n_pos = 6000
+        with tempfile.TemporaryDirectory() as td:
+            fp = os.path.join(td, "sp.filtered.freq")
+            with open(fp, "w") as f:
+                f.write("\t" + "\t".join("s%d.bam" % i for i in range(sp.n_samples)) + "\n")
+                for k in range(n_pos):
+                    f.write("c:-:%d:A>T:.\t%s\n" % (k + 1, "\t".join("-1" if rnd.random() < 0.1 else repr(rnd.randint(0, 40) / 40) for _ in range(sp.n_samples))))
+            ns, npos, ms = C.c_int32(), C.c_uint64(), C.c_double()
+            _lib.check(_lib.lib.msnv_dist_file(ctx._h, fp.encode(), (fp + ".mann").encode(), (fp + ".allele").encode(), 0.6, C.byref(ns), C.byref(npos), C.byref(ms)))
+            dist_extra = {"samples": ns.value, "positions": int(npos.value), "pairs": ns.value * (ns.value + 1) // 2, "kernel_ms": ms.value,
+                          "table_bytes_read_per_pair": 16 * int(npos.value)}
 
     bases = info["n_pileup_bases"]
     k_ms = sum(ms_pileup) / len(ms_pileup)
@@ -310,6 +336,8 @@ def main():
             line["coverage_pass"] = cov_extra
         if ann_extra:
             line["annotation"] = ann_extra
+        if dist_extra:
+            line["distances"] = dist_extra
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(sp_kwargs, min(a.cpu_samples, sp.n_samples))
         print(json.dumps(line))

@@ -145,6 +145,14 @@ int msnv_format_float(double x, char *buf, int32_t cap);
 int msnv_filter_files(msnv_ctx *ctx, const char *const *snp_paths, int32_t n_paths, int32_t n_samples,
                       const msnv_filter_species *species, int32_t n_species, double min_cov_c, double min_prop_p,
                       const char *out_dir, uint64_t *n_positions_kept, double *ms_kernel);
+/* The same filter fed from the records of the dataset's last msnv_pileup_run instead of the text of called_SNPs /
+ * indiv_called (no S-wide lines are written, read back and split): which = 0 the population calls (what called_SNPs
+ * holds), 1 the individual calls (indiv_called, metaSNV_Filtering.py --ind).  ann_path / fasta_path as for msnv_write_calls
+ * (gene column and codon tags of the row ids), or NULL.  Writes the same bytes as msnv_filter_files on the written files. */
+struct msnv_dataset;
+int msnv_filter_resident(struct msnv_dataset *ds, int32_t which, const msnv_filter_species *species, int32_t n_species,
+                         double min_cov_c, double min_prop_p, const char *out_dir, const char *ann_path, const char *fasta_path,
+                         uint64_t *n_positions_kept, double *ms_kernel);
 
 /* metaSNV_DistDiv.py --dist (computeDist, metaSNV_DistDiv.py:105-124): pairwise sample
  * distances of one species' *.filtered.freq table on the device, bit-exact with pandas (NaN-skipping mean whose sum is

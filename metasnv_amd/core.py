@@ -210,6 +210,22 @@ class Dataset:
         check(lib.msnv_dataset_first_line(self._h, C.byref(t), C.byref(p)))
         return t.value, p.value
 
+    def filter_resident(self, species, out_dir, min_cov_c=5.0, min_prop_p=0.5, ind=False, ann_path=None, fasta_path=None):
+        """metaSNV_Filtering.py filter_two straight from the records of the last run (no called_SNPs text round trip).
+        species: list of (taxid, [sample indices of interest], [their names]).  Returns (positions kept, kernel ms)."""
+        from ._lib import FilterSpecies
+        keep = []
+        arr = (FilterSpecies * len(species))()
+        for i, (name, idx, names) in enumerate(species):
+            ia = (C.c_int32 * len(idx))(*idx)
+            na = _cstr_array(names)
+            keep += [ia, na]
+            arr[i] = FilterSpecies(name.encode(), len(idx), ia, na)
+        n, ms = C.c_uint64(), C.c_double()
+        check(lib.msnv_filter_resident(self._h, 1 if ind else 0, arr, len(species), float(min_cov_c), float(min_prop_p), out_dir.encode(),
+                                       ann_path.encode() if ann_path else None, fasta_path.encode() if fasta_path else None, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
     def first_lines(self):
         """Per contig: first pileup line without -l / under metaSNV's `name 1 LEN` split BED (-1 = none); int32 arrays."""
         n = len(self.names)

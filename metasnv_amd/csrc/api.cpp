@@ -180,10 +180,10 @@ static int check_header(const msnv_dataset &ds, const BamHeader &h, const char *
 extern "C" int msnv_dataset_add_sample_bam(msnv_dataset *ds, const char *bam_path) {
     clear_error();
     if (!ds || !bam_path) return fail(MSNV_EINVAL, "msnv_dataset_add_sample_bam: NULL argument");
-    BamHeader h; std::vector<uint8_t> rec;
-    if (int rc = bam_read(bam_path, h, rec, 4)) return rc;
+    BamHeader h; ByteBuf buf; uint64_t rec_off = 0;
+    if (int rc = bam_read(bam_path, h, buf, rec_off, 4)) return rc;
     if (int rc = check_header(*ds, h, bam_path)) return rc;
-    return msnv_dataset_add_sample_records(ds, rec.data(), rec.size());
+    return msnv_dataset_add_sample_records(ds, buf.data() + rec_off, buf.size() - rec_off);
 }
 
 extern "C" int msnv_dataset_add_sample_bams(msnv_dataset *ds, const char *const *bam_paths, int32_t n, int32_t host_threads) {
@@ -202,10 +202,10 @@ extern "C" int msnv_dataset_add_sample_bams(msnv_dataset *ds, const char *const 
             if (i >= n || err.load()) break;
             int rc;
             try {                                              // an exception in a worker thread would be std::terminate
-                BamHeader h; std::vector<uint8_t> rec;
-                rc = bam_read(bam_paths[i], h, rec, 1);
+                BamHeader h; ByteBuf buf; uint64_t rec_off = 0;
+                rc = bam_read(bam_paths[i], h, buf, rec_off, 1);
                 if (!rc) rc = check_header(*ds, h, bam_paths[i]);
-                if (!rc) rc = pack_sample(*ds, rec.data(), rec.size(), ds->samples[first + (size_t)i]);
+                if (!rc) rc = pack_sample(*ds, buf.data() + rec_off, buf.size() - rec_off, ds->samples[first + (size_t)i]);
             } catch (const std::exception &e) { rc = fail(MSNV_ENOMEM, "%s: %s", bam_paths[i], e.what()); }
             if (rc) { msgs[(size_t)i] = msnv_last_error(); err.store(rc); }
         }
@@ -601,6 +601,7 @@ int filter_files(msnv_ctx *ctx, const char *const *paths, int n_paths, uint32_t 
                  double min_cov, double min_prop, const char *out_dir, uint64_t *n_lines_kept, double *ms_kernel);
 }
 namespace msnv { void py_repr(double x, std::string &out); }
+static int make_filter_species(const msnv_filter_species *species, int32_t n_species, int32_t n_samples, FilterSpecies &sp, const char *who);
 extern "C" int msnv_format_float(double x, char *buf, int32_t cap) {
     std::string s;
     py_repr(x, s);
@@ -617,24 +618,56 @@ extern "C" int msnv_filter_files(msnv_ctx *ctx, const char *const *snp_paths, in
         return fail(MSNV_EINVAL, "msnv_filter_files: bad argument");
     if (int rc = dev_set_device(ctx->device)) return rc;
     FilterSpecies sp;
+    if (int rc = make_filter_species(species, n_species, n_samples, sp, "msnv_filter_files")) return rc;
+    if (ms_kernel) *ms_kernel = 0;
+    if (n_positions_kept) *n_positions_kept = 0;
+    if (!n_species) return MSNV_OK;
+    return filter_files(ctx, snp_paths, n_paths, (uint32_t)n_samples, sp, min_cov_c, min_prop_p, out_dir, n_positions_kept, ms_kernel);
+}
+
+namespace msnv {
+int filter_resident(msnv_dataset &ds, int which, const FilterSpecies &sp, double min_cov, double min_prop, const char *out_dir,
+                    const msnv_site_ann *ann, const std::vector<std::string> *gene_names, uint64_t *n_lines_kept, double *ms_kernel);
+}
+static int make_filter_species(const msnv_filter_species *species, int32_t n_species, int32_t n_samples, FilterSpecies &sp, const char *who) {
     sp.soi_off.push_back(0);
     for (int i = 0; i < n_species; ++i) {
         const msnv_filter_species &s = species[i];
         if (!s.species || s.n_soi <= 0 || !s.soi || !s.soi_names)
-            return fail(MSNV_EINVAL, "msnv_filter_files: species %d has no samples of interest (the reference divides by their number)", i);
+            return fail(MSNV_EINVAL, "%s: species %d has no samples of interest (the reference divides by their number)", who, i);
         sp.name.emplace_back(s.species);
         sp.soi_names.emplace_back();
         for (int k = 0; k < s.n_soi; ++k) {
-            if (s.soi[k] < 0 || s.soi[k] >= n_samples) return fail(MSNV_EINVAL, "msnv_filter_files: sample index %d out of range", s.soi[k]);
+            if (s.soi[k] < 0 || s.soi[k] >= n_samples) return fail(MSNV_EINVAL, "%s: sample index %d out of range", who, s.soi[k]);
             sp.soi_idx.push_back((uint32_t)s.soi[k]);
             sp.soi_names.back().emplace_back(s.soi_names[k]);
         }
         sp.soi_off.push_back((uint32_t)sp.soi_idx.size());
     }
+    return MSNV_OK;
+}
+
+extern "C" int msnv_filter_resident(msnv_dataset *ds, int32_t which, const msnv_filter_species *species, int32_t n_species,
+                                    double min_cov_c, double min_prop_p, const char *out_dir, const char *ann_path, const char *fasta_path,
+                                    uint64_t *n_positions_kept, double *ms_kernel) {
+    clear_error();
+    if (!ds || n_species < 0 || (n_species && !species) || !out_dir || (which != 0 && which != 1)) return fail(MSNV_EINVAL, "msnv_filter_resident: bad argument");
+    if (!ds->have_results) return fail(MSNV_EINVAL, "no results: call msnv_pileup_run first");
+    if (int rc = dev_set_device(ds->ctx->device)) return rc;
     if (ms_kernel) *ms_kernel = 0;
     if (n_positions_kept) *n_positions_kept = 0;
     if (!n_species) return MSNV_OK;
-    return filter_files(ctx, snp_paths, n_paths, (uint32_t)n_samples, sp, min_cov_c, min_prop_p, out_dir, n_positions_kept, ms_kernel);
+    FilterSpecies sp;
+    if (int rc = make_filter_species(species, n_species, (int32_t)ds->samples.size(), sp, "msnv_filter_resident")) return rc;
+    if (int rc = fetch_results(ds)) return rc;
+    std::vector<msnv_site_ann> ann;
+    const bool annotated = ann_path && fasta_path;
+    if (annotated) {
+        if (int rc = annotate_sites(ds, ann_path, fasta_path, nullptr)) return rc;
+        if (int rc = fetch_ann(ds, ann)) return rc;
+    }
+    return filter_resident(*ds, which, sp, min_cov_c, min_prop_p, out_dir, annotated ? ann.data() : nullptr,
+                           annotated ? &ds->dev->ann.gene_names : nullptr, n_positions_kept, ms_kernel);
 }
 
 // ------------------------------------------------------------------------------ --dist (section 8 f3)

@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <vector>
 
 #include "msnv_internal.h"
 
@@ -29,51 +30,78 @@ __device__ __forceinline__ double absdiff0(const double *__restrict__ x, const d
     return (a != a || b != b) ? 0.0 : fabs(a - b);            // NaN -> 0 (pandas nanops: fill_value 0)
 }
 
-__device__ double pairwise_sum(const double *__restrict__ x, const double *__restrict__ y, long lo, long n) {
-    if (n < 8) {
-        double res = 0.0;
-        for (long i = 0; i < n; ++i) res += absdiff0(x, y, lo + i);
-        return res;
-    }
-    if (n <= 128) {
-        double r[8];
-        for (int j = 0; j < 8; ++j) r[j] = absdiff0(x, y, lo + j);
-        long i = 8;
-        for (; i < n - (n % 8); i += 8)
-            for (int j = 0; j < 8; ++j) r[j] += absdiff0(x, y, lo + i + j);
-        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-        for (; i < n; ++i) res += absdiff0(x, y, lo + i);
-        return res;
-    }
-    long n2 = n / 2;
-    n2 -= n2 % 8;
-    return pairwise_sum(x, y, lo, n2) + pairwise_sum(x, y, lo + n2, n - n2);
-}
+// numpy's pairwise summation as data: the leaves (blocks of <= 128 elements, in array order) and the order in which their sums
+// are combined (a postfix program: 0 = take the next leaf, 1 = add the two on top) -- the same for every pair of samples,
+// built once on the host from n_pos.  ONE WAVEFRONT per pair of samples: eight lanes share a leaf, lane j accumulating the
+// elements j, 8 + j, 16 + j ... exactly like numpy's r[j], so every load instruction of the wavefront reads whole 64-byte lines
+// (the first form had one thread per pair walking two rows: lane stride n_pos x 8 bytes, nothing coalesced, device recursion).
+struct DistLeaf { long lo; int n; int pad; };
+constexpr int DIST_MAX_LEAVES_LDS = 2048;                     // leaf sums kept in LDS (n_pos <= 262144); beyond that in global scratch
 
-// xt: [n_samples][n_pos] (sample-major), NaN = not informative
-__global__ void msnv_dist_pairs(const double *__restrict__ xt, int n_samples, long n_pos, double threshold,
-                                double *__restrict__ mann, double *__restrict__ allele) {
-    const long pair = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long n_pairs = (long)n_samples * (n_samples + 1) / 2;
-    if (pair >= n_pairs) return;
+__global__ __launch_bounds__(64) void msnv_dist_pairs(const double *__restrict__ xt, int n_samples, long n_pos, double threshold,
+                                                      const DistLeaf *__restrict__ leaves, int n_leaves, const unsigned char *__restrict__ prog, int n_prog,
+                                                      double *__restrict__ scratch, double *__restrict__ mann, double *__restrict__ allele) {
+    __shared__ double s_leaf[DIST_MAX_LEAVES_LDS];
+    __shared__ double s_stack[64];
+    const long pair = blockIdx.x;
     // unrank (i <= j) from the row-major upper triangle
     long i = 0, rem = pair;
     while (rem >= n_samples - i) { rem -= n_samples - i; ++i; }
     const long j = i + rem;
     const double *x = xt + i * n_pos, *y = xt + j * n_pos;
-    const double sum = 0.0 + pairwise_sum(x, y, 0, n_pos);
+    const int lane = threadIdx.x, sub = lane & 7, grp = lane >> 3;
+    double *leaf_sum = n_leaves <= DIST_MAX_LEAVES_LDS ? s_leaf : scratch + (long)pair * n_leaves;
     long count = 0, above = 0;
-    for (long k = 0; k < n_pos; ++k) {
-        const double a = x[k], b = y[k];
-        const bool ok = !(a != a || b != b);
-        count += ok ? 1 : 0;
-        above += (ok && fabs(a - b) > threshold) ? 1 : 0;
+    for (int l = grp; l < n_leaves; l += 8) {
+        const DistLeaf lf = leaves[l];
+        double res;
+        if (lf.n < 8) {                                          // only a table shorter than 8 positions: plain left-to-right sum
+            res = 0.0;
+            for (int k = 0; k < lf.n; ++k) res += absdiff0(x, y, lf.lo + k);
+        } else {
+            const int n8 = lf.n - (lf.n % 8);
+            double r = absdiff0(x, y, lf.lo + sub);              // r[sub]
+            for (int k = 8; k < n8; k += 8) r += absdiff0(x, y, lf.lo + k + sub);
+            // ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)): the partner's value is added in the same order in every lane
+            const double a1 = r + __shfl_xor(r, 1);              // lanes 0,1 hold r0 + r1 (lane 1 computes r1 + r0: the same double)
+            const double a2 = a1 + __shfl_xor(a1, 2);
+            res = a2 + __shfl_xor(a2, 4);
+            for (int k = n8; k < lf.n; ++k) res += absdiff0(x, y, lf.lo + k);
+        }
+        if (sub == 0) leaf_sum[l] = res;
+        // counts (order does not matter): every lane looks at its own elements
+        for (int k = sub; k < lf.n; k += 8) {
+            const double a = x[lf.lo + k], b = y[lf.lo + k];
+            const bool ok = !(a != a || b != b);
+            count += ok ? 1 : 0;
+            above += (ok && fabs(a - b) > threshold) ? 1 : 0;
+        }
     }
-    const double nanv = nan("");
-    const double m = count > 0 ? sum / (double)count : nanv;
-    const double al = n_pos > 0 ? (double)above / (double)n_pos : nanv;
-    mann[i * n_samples + j] = m; mann[j * n_samples + i] = m;
-    allele[i * n_samples + j] = al; allele[j * n_samples + i] = al;
+    for (int o = 32; o >= 1; o >>= 1) { count += __shfl_xor(count, o); above += __shfl_xor(above, o); }
+    __syncthreads();
+    if (lane == 0) {
+        int sp = 0, next = 0;
+        for (int k = 0; k < n_prog; ++k) {
+            if (prog[k] == 0) s_stack[sp++] = leaf_sum[next++];
+            else { --sp; s_stack[sp - 1] = s_stack[sp - 1] + s_stack[sp]; }
+        }
+        const double sum = 0.0 + (n_leaves ? s_stack[0] : 0.0);
+        const double nanv = nan("");
+        const double m = count > 0 ? sum / (double)count : nanv;
+        const double al = n_pos > 0 ? (double)above / (double)n_pos : nanv;
+        mann[i * n_samples + j] = m; mann[j * n_samples + i] = m;
+        allele[i * n_samples + j] = al; allele[j * n_samples + i] = al;
+    }
+}
+
+// the leaves and the combination order of numpy's pairwise sum over n elements (numpy/core/src/umath/loops_utils.h pairwise_sum)
+static void pairwise_plan(long lo, long n, std::vector<DistLeaf> &leaves, std::vector<unsigned char> &prog) {
+    if (n <= 128) { leaves.push_back(DistLeaf{lo, (int)n, 0}); prog.push_back(0); return; }
+    long n2 = n / 2;
+    n2 -= n2 % 8;
+    pairwise_plan(lo, n2, leaves, prog);
+    pairwise_plan(lo + n2, n - n2, leaves, prog);
+    prog.push_back(1);
 }
 
 int dev_dist(const double *xt_host, int n_samples, long n_pos, double threshold, void *stream_, double *mann, double *allele, double *ms_kernel) {
@@ -85,13 +113,21 @@ int dev_dist(const double *xt_host, int n_samples, long n_pos, double threshold,
     HIP_TRY(hipMalloc(&d_m.p, std::max<size_t>(mb, 16)));
     HIP_TRY(hipMalloc(&d_a.p, std::max<size_t>(mb, 16)));
     if (n_pos > 0) HIP_TRY(hipMemcpyAsync(d_x.p, xt_host, (size_t)n_samples * n_pos * sizeof(double), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipDeviceSetLimit(hipLimitStackSize, 8192));     // pairwise_sum recurses log2(n / 128) deep
+    std::vector<DistLeaf> leaves; std::vector<unsigned char> prog;
+    if (n_pos > 0) pairwise_plan(0, n_pos, leaves, prog);
+    const long n_pairs = (long)n_samples * (n_samples + 1) / 2;
+    Buf d_l, d_p, d_s;
+    HIP_TRY(hipMalloc(&d_l.p, std::max<size_t>(leaves.size() * sizeof(DistLeaf), 16)));
+    HIP_TRY(hipMalloc(&d_p.p, std::max<size_t>(prog.size(), 16)));
+    if (!leaves.empty()) HIP_TRY(hipMemcpyAsync(d_l.p, leaves.data(), leaves.size() * sizeof(DistLeaf), hipMemcpyHostToDevice, st));
+    if (!prog.empty()) HIP_TRY(hipMemcpyAsync(d_p.p, prog.data(), prog.size(), hipMemcpyHostToDevice, st));
+    if ((int)leaves.size() > DIST_MAX_LEAVES_LDS) HIP_TRY(hipMalloc(&d_s.p, (size_t)n_pairs * leaves.size() * sizeof(double)));
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
-    const long n_pairs = (long)n_samples * (n_samples + 1) / 2;
     hipError_t he = hipEventRecord(e0, st);
     if (he == hipSuccess && n_pairs) {
-        hipLaunchKernelGGL(msnv_dist_pairs, dim3((unsigned)((n_pairs + 63) / 64)), dim3(64), 0, st, (const double *)d_x.p, n_samples, n_pos, threshold,
+        hipLaunchKernelGGL(msnv_dist_pairs, dim3((unsigned)n_pairs), dim3(64), 0, st, (const double *)d_x.p, n_samples, n_pos, threshold,
+                           (const DistLeaf *)d_l.p, (int)leaves.size(), (const unsigned char *)d_p.p, (int)prog.size(), (double *)d_s.p,
                            (double *)d_m.p, (double *)d_a.p);
         he = hipGetLastError();
     }

@@ -14,6 +14,8 @@
 #include "dataset.h"
 #include "filter.h"
 
+struct msnv_ctx;
+
 namespace msnv {
 
 // repr(float) of CPython >= 3.1 for a finite double: shortest digits that round-trip (std::to_chars), laid out by
@@ -89,21 +91,24 @@ bool parse_bar_ints(const char *s, const char *e, std::vector<uint32_t> &out, si
 
 }  // namespace
 
-int filter_files(msnv_ctx *ctx, const char *const *paths, int n_paths, uint32_t n_samples, const FilterSpecies &sp,
-                 double min_cov, double min_prop, const char *out_dir, uint64_t *n_lines_kept, double *ms_kernel) {
-    std::map<std::string, uint32_t> sp_index;
-    for (size_t i = 0; i < sp.name.size(); ++i) sp_index[sp.name[i]] = (uint32_t)i;
-    std::vector<FILE *> outs(sp.name.size(), nullptr);
-    auto close_all = [&]() { for (FILE *f : outs) if (f) fclose(f); };
+namespace {
+// Batches lines of species of interest, runs the device kernel and prints `<species>.filtered.freq` (shared by the path that
+// parses called_SNPs text and the one that reads the resident records).
+struct FilterWriter {
+    msnv_ctx *ctx; const FilterSpecies &sp; double min_cov, min_prop; const char *out_dir; double *ms_kernel;
+    std::vector<FILE *> outs;
     FilterBatch b;
-    b.n_samples = n_samples;
     std::vector<double> freq;
     std::vector<uint8_t> pass;
     std::string text;
     uint64_t kept = 0;
-    const size_t BATCH_CELLS = (size_t)32 << 20;                       // 128 MB of u32 per array before a flush
-
-    auto flush = [&]() -> int {
+    static constexpr size_t BATCH_CELLS = (size_t)32 << 20;           // 128 MB of u32 per array before a flush
+    FilterWriter(msnv_ctx *c, const FilterSpecies &s, uint32_t n_samples, double mc, double mp, const char *od, double *ms)
+        : ctx(c), sp(s), min_cov(mc), min_prop(mp), out_dir(od), ms_kernel(ms), outs(s.name.size(), nullptr) { b.n_samples = n_samples; }
+    ~FilterWriter() { close_all(); }
+    void close_all() { for (FILE *&f : outs) if (f) { fclose(f); f = nullptr; } }
+    bool full() const { return b.cnt.size() >= BATCH_CELLS || b.n_out >= BATCH_CELLS / 2; }
+    int flush() {
         if (b.row_line.empty()) { b.clear(); return MSNV_OK; }
         if (int rc = dev_filter_batch(b, sp, min_cov, min_prop, ctx->stream, freq, pass, ms_kernel)) return rc;
         for (size_t r = 0; r < b.row_line.size(); ++r) {
@@ -132,7 +137,18 @@ int filter_files(msnv_ctx *ctx, const char *const *paths, int n_paths, uint32_t 
         }
         b.clear();
         return MSNV_OK;
-    };
+    }
+};
+}  // namespace
+
+int filter_files(msnv_ctx *ctx, const char *const *paths, int n_paths, uint32_t n_samples, const FilterSpecies &sp,
+                 double min_cov, double min_prop, const char *out_dir, uint64_t *n_lines_kept, double *ms_kernel) {
+    std::map<std::string, uint32_t> sp_index;
+    for (size_t i = 0; i < sp.name.size(); ++i) sp_index[sp.name[i]] = (uint32_t)i;
+    FilterWriter W(ctx, sp, n_samples, min_cov, min_prop, out_dir, ms_kernel);
+    FilterBatch &b = W.b;
+    auto close_all = [&]() { W.close_all(); };
+    auto flush = [&]() -> int { return W.flush(); };
 
     std::vector<char> linebuf;
     for (int pi = 0; pi < n_paths; ++pi) {
@@ -179,7 +195,7 @@ int filter_files(msnv_ctx *ctx, const char *const *paths, int n_paths, uint32_t 
                 if (!comma) break;
                 s = comma + 1;
             }
-            if (b.cnt.size() >= BATCH_CELLS || b.n_out >= BATCH_CELLS / 2) {
+            if (W.full()) {
                 if (int rc = flush()) { free(line); fclose(in); close_all(); return rc; }
             }
         }
@@ -188,7 +204,78 @@ int filter_files(msnv_ctx *ctx, const char *const *paths, int n_paths, uint32_t 
     }
     int rc = flush();
     close_all();
-    if (n_lines_kept) *n_lines_kept = kept;
+    if (n_lines_kept) *n_lines_kept = W.kept;
+    return rc;
+}
+
+// filter_two straight from the records of the last pass ("avoids re-parsing called_SNPs text"):
+// the same batches, kernel and printer as filter_files, fed from ds.sites / ds.site_samples and the device annotation records
+// instead of S-wide text lines.  which = 0: the lines of called_SNPs (population calls), 1: those of indiv_called.
+int filter_resident(msnv_dataset &ds, int which, const FilterSpecies &sp, double min_cov, double min_prop, const char *out_dir,
+                    const msnv_site_ann *ann, const std::vector<std::string> *gene_names, uint64_t *n_lines_kept, double *ms_kernel) {
+    std::map<std::string, uint32_t> sp_index;
+    for (size_t i = 0; i < sp.name.size(); ++i) sp_index[sp.name[i]] = (uint32_t)i;
+    const size_t S = ds.samples.size();
+    FilterWriter W(ds.ctx, sp, (uint32_t)S, min_cov, min_prop, out_dir, ms_kernel);
+    FilterBatch &b = W.b;
+    static const int order[4] = {0, 1, 3, 2};               // alleles are emitted a, c, t, g (call_vC.cpp:561)
+    static const char letter[4] = {'A', 'C', 'G', 'T'};
+    std::vector<int32_t> contig_species(ds.names.size(), -1);
+    for (size_t c = 0; c < ds.names.size(); ++c) {
+        const std::string &nm = ds.names[c];
+        auto it = sp_index.find(nm.substr(0, nm.find('.')));
+        if (it != sp_index.end()) contig_species[c] = (int32_t)it->second;
+    }
+    std::string id, tag;
+    for (size_t i = 0; i < ds.sites.size(); ++i) {
+        const msnv_site &s = ds.sites[i];
+        if (s.dropped) continue;                              // call_vC.cpp:423: the line never reaches the files
+        const int32_t spi = contig_species[(size_t)s.tid];
+        if (spi < 0) continue;                                // species filter (metaSNV_Filtering.py:175)
+        const uint32_t mask = which ? s.ind_mask : s.pop_mask;
+        if (!mask) continue;                                  // no line of this kind for the position
+        const msnv_site_sample *ss = &ds.site_samples[i * S];
+        const msnv_site_ann *an = ann ? &ann[i] : nullptr;
+        const bool in_gene = an && an->gene >= 0;
+        id.assign(ds.names[(size_t)s.tid]); id.push_back(':');
+        id += (in_gene && gene_names && (size_t)an->gene < gene_names->size()) ? (*gene_names)[(size_t)an->gene] : std::string("-");
+        id.push_back(':'); id += std::to_string(s.pos + 1); id.push_back(':'); id.push_back((char)s.refchar);
+        const uint32_t li = (uint32_t)b.line_species.size();
+        const uint32_t n_soi = sp.soi_off[(size_t)spi + 1] - sp.soi_off[(size_t)spi];
+        uint32_t n_rows = 0;
+        for (int oi = 0; oi < 4; ++oi) {
+            const int x = order[oi];
+            if (!((mask >> x) & 1u)) continue;
+            tag.assign(".");
+            if (in_gene) {
+                const uint8_t *c = an->codon[x];
+                if (!(c[0] & MSNV_ANN_VALID)) return fail(MSNV_EDOMAIN, "no codon for %s:%d", ds.names[(size_t)s.tid].c_str(), s.pos + 1);
+                if (c[0] & MSNV_ANN_CIRCULAR) continue;       // the allele vanishes from the line (call_vC.cpp:614-617)
+                tag.assign(1, (c[0] & MSNV_ANN_SYNONYMOUS) ? 'S' : 'N');
+                tag.push_back('[');
+                tag.append(reinterpret_cast<const char *>(c + 2), (size_t)(c[1] & 15));
+                tag.push_back('-');
+                tag.append(reinterpret_cast<const char *>(c + 5), (size_t)(c[1] >> 4));
+                tag.push_back(']');
+            }
+            if (n_rows == 0) { for (size_t k = 0; k < S; ++k) b.cov.push_back(ss[k].cov); b.line_species.push_back((uint32_t)spi); }
+            for (size_t k = 0; k < S; ++k) b.cnt.push_back(ss[k].n[x]);
+            std::string rid = id;
+            rid.push_back('>'); rid.push_back(letter[x]); rid.push_back(':'); rid += tag;
+            b.row_id.push_back(std::move(rid));
+            b.row_line.push_back(li);
+            b.row_out.push_back(b.n_out);
+            b.n_out += n_soi;
+            ++n_rows;
+        }
+        // a population line whose alleles all vanished is written with an empty allele field by the reference, which its own
+        // Filtering script cannot split (fewer than 6 fields): the same error as the file path gives
+        if (n_rows == 0 && which == 0) return fail(MSNV_EFORMAT, "%s:%d: the called_SNPs line has no allele left (circular gene): fewer than 6 fields", ds.names[(size_t)s.tid].c_str(), s.pos + 1);
+        if (W.full()) if (int rc = W.flush()) return rc;
+    }
+    int rc = W.flush();
+    W.close_all();
+    if (n_lines_kept) *n_lines_kept = W.kept;
     return rc;
 }
 

@@ -45,18 +45,24 @@ extern "C" int msnv_host_stats(uint64_t *zlib_fallbacks) { if (zlib_fallbacks) *
 
 namespace msnv {
 
-static int read_file(const char *path, std::vector<uint8_t> &buf) {
+static int read_file(const char *path, ByteBuf &buf, size_t &n_out) {
     FILE *f = fopen(path, "rb");
     if (!f) return fail(MSNV_EIO, "cannot open %s", path);
     fseek(f, 0, SEEK_END);
     long n = ftell(f);
     fseek(f, 0, SEEK_SET);
     if (n < 0) { fclose(f); return fail(MSNV_EIO, "cannot stat %s", path); }
-    try { buf.resize((size_t)n + 16); } catch (const std::exception &) { fclose(f); return fail(MSNV_ENOMEM, "out of memory reading %s (%ld bytes)", path, n); }
+    if (!buf.alloc((size_t)n + 16)) { fclose(f); return fail(MSNV_ENOMEM, "out of memory reading %s (%ld bytes)", path, n); }
     if (n && fread(buf.data(), 1, (size_t)n, f) != (size_t)n) { fclose(f); return fail(MSNV_EIO, "short read on %s", path); }
     fclose(f);
     memset(buf.data() + n, 0, 16);       // the inflate fast path loads 8 bytes at a time
-    buf.resize((size_t)n);               // (capacity keeps the padding readable)
+    n_out = (size_t)n;
+    return MSNV_OK;
+}
+static int read_file(const char *path, std::vector<uint8_t> &buf) {      // small files (FASTA / BED / annotation readers)
+    ByteBuf b; size_t n = 0;
+    if (int rc = read_file(path, b, n)) return rc;
+    try { buf.assign(b.data(), b.data() + n); } catch (const std::exception &) { return fail(MSNV_ENOMEM, "out of memory reading %s", path); }
     return MSNV_OK;
 }
 
@@ -64,7 +70,8 @@ static int read_file(const char *path, std::vector<uint8_t> &buf) {
 // A BGZF block is a gzip member with an extra field "BC" holding BSIZE-1 (SAMv1 4.1).
 struct BlockRef { uint64_t in_off; uint32_t in_size; uint32_t out_size; uint64_t out_off; };
 
-static int bgzf_index(const std::vector<uint8_t> &in, const char *path, std::vector<BlockRef> &blocks, uint64_t &total_out) {
+struct ConstBytes { const uint8_t *p; size_t n; const uint8_t *data() const { return p; } size_t size() const { return n; } };
+static int bgzf_index(const ConstBytes in, const char *path, std::vector<BlockRef> &blocks, uint64_t &total_out) {
     uint64_t off = 0;
     total_out = 0;
     while (off < in.size()) {
@@ -116,13 +123,14 @@ static bool inflate_block(const uint8_t *src, uint32_t n_in, uint8_t *dst, uint3
     return rc == Z_STREAM_END && zs.avail_out == 0;
 }
 
-int bgzf_read_all(const char *path, std::vector<uint8_t> &out, int threads) {
-    std::vector<uint8_t> in;
-    if (int rc = read_file(path, in)) return rc;
+int bgzf_read_all(const char *path, ByteBuf &out, int threads) {
+    ByteBuf inb; size_t n_in = 0;
+    if (int rc = read_file(path, inb, n_in)) return rc;
+    const ConstBytes in{inb.data(), n_in};
     std::vector<BlockRef> blocks;
     uint64_t total = 0;
     if (int rc = bgzf_index(in, path, blocks, total)) return rc;
-    try { out.resize(total); } catch (const std::exception &) { return fail(MSNV_ENOMEM, "%s: out of memory for %llu inflated bytes", path, (unsigned long long)total); }
+    if (!out.alloc(total)) return fail(MSNV_ENOMEM, "%s: out of memory for %llu inflated bytes", path, (unsigned long long)total);
     std::atomic<size_t> next{0};
     std::atomic<bool> bad{false};
     auto worker = [&]() {
@@ -177,7 +185,8 @@ int bgzf_write_all(const char *path, const uint8_t *data, uint64_t n, int level)
 }
 
 // ------------------------------------------------------------------------------ BAM
-static int bam_parse_header(const std::vector<uint8_t> &u, const char *path, BamHeader &hdr, uint64_t &rec_off) {
+template <typename Bytes>
+static int bam_parse_header(const Bytes &u, const char *path, BamHeader &hdr, uint64_t &rec_off) {
     if (u.size() < 12 || memcmp(u.data(), "BAM\1", 4) != 0) return fail(MSNV_EFORMAT, "%s: not a BAM file", path);
     uint32_t l_text = ld_u32(u.data() + 4);
     if (8ull + l_text + 4 > u.size()) return fail(MSNV_EFORMAT, "%s: truncated BAM header", path);
@@ -201,22 +210,16 @@ static int bam_parse_header(const std::vector<uint8_t> &u, const char *path, Bam
     return MSNV_OK;
 }
 
-int bam_read(const char *path, BamHeader &hdr, std::vector<uint8_t> &records, int threads) {
-    std::vector<uint8_t> u;
-    if (int rc = bgzf_read_all(path, u, threads)) return rc;
-    uint64_t off = 0;
-    if (int rc = bam_parse_header(u, path, hdr, off)) return rc;
-    // the records follow the header in the same buffer: shift them down instead of copying them into a second one
-    if (off) memmove(u.data(), u.data() + off, u.size() - off);
-    u.resize(u.size() - off);
-    records.swap(u);
-    return MSNV_OK;
+int bam_read(const char *path, BamHeader &hdr, ByteBuf &buf, uint64_t &rec_off, int threads) {
+    if (int rc = bgzf_read_all(path, buf, threads)) return rc;
+    return bam_parse_header(buf, path, hdr, rec_off);
 }
 
 int bam_read_header(const char *path, BamHeader &hdr) {
     // headers are small; inflate leading blocks until the contig table is complete
-    std::vector<uint8_t> in;
-    if (int rc = read_file(path, in)) return rc;
+    ByteBuf inb; size_t n_in = 0;
+    if (int rc = read_file(path, inb, n_in)) return rc;
+    const ConstBytes in{inb.data(), n_in};
     std::vector<BlockRef> blocks;
     uint64_t total = 0;
     if (int rc = bgzf_index(in, path, blocks, total)) return rc;
@@ -387,8 +390,9 @@ extern "C" int msnv_bam_read(const char *bam_path, msnv_bam_data *out) {
     if (!bam_path || !out) return fail(MSNV_EINVAL, "msnv_bam_read: NULL argument");
     memset(out, 0, sizeof *out);
     BamHeader h;
-    std::vector<uint8_t> rec;
-    if (int rc = bam_read(bam_path, h, rec, 1)) return rc;
+    ByteBuf buf; uint64_t rec_off = 0;
+    if (int rc = bam_read(bam_path, h, buf, rec_off, 1)) return rc;
+    struct { const uint8_t *p; size_t n; const uint8_t *data() const { return p; } size_t size() const { return n; } } rec{buf.data() + rec_off, buf.size() - (size_t)rec_off};
     out->n_contigs = (int32_t)h.names.size();
     out->names = (char **)calloc(h.names.size() + 1, sizeof(char *));
     out->lengths = (int64_t *)calloc(h.names.size() + 1, sizeof(int64_t));

@@ -3,6 +3,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -23,12 +24,26 @@ struct BamHeader {
     std::vector<int64_t>     lengths;
 };
 
+// Uninitialised byte buffer (a std::vector would zero hundreds of megabytes that the inflate overwrites right away).
+struct ByteBuf {
+    uint8_t *p = nullptr; size_t n = 0;
+    ByteBuf() = default;
+    ByteBuf(const ByteBuf &) = delete;
+    ByteBuf &operator=(const ByteBuf &) = delete;
+    ~ByteBuf() { free(p); }
+    bool alloc(size_t m) { free(p); p = (uint8_t *)malloc(m ? m : 1); n = p ? m : 0; return p != nullptr; }
+    uint8_t *data() { return p; }
+    const uint8_t *data() const { return p; }
+    size_t size() const { return n; }
+};
+
 // Whole-file BGZF inflate (blocks are independent; `threads` > 1 inflates them in parallel).
-int bgzf_read_all(const char *path, std::vector<uint8_t> &out, int threads);
+int bgzf_read_all(const char *path, ByteBuf &out, int threads);
 int bgzf_write_all(const char *path, const uint8_t *data, uint64_t n, int level);
 
 // BAM = BGZF(magic, header text, contig table, records...)
-int bam_read(const char *path, BamHeader &hdr, std::vector<uint8_t> &records, int threads);
+// The records start at buf.data() + rec_off (the header sits in front of them in the same buffer: no second copy).
+int bam_read(const char *path, BamHeader &hdr, ByteBuf &buf, uint64_t &rec_off, int threads);
 int bam_read_header(const char *path, BamHeader &hdr);
 int bam_write(const char *path, const BamHeader &hdr, const uint8_t *records, uint64_t n, int level);
 

@@ -688,6 +688,45 @@ def test_filtering_of_pipeline_output_matches_python_restatement(tmp_path):
                 assert not os.path.exists(path)
 
 
+def test_filter_from_resident_records_equals_the_file_path(tmp_path):
+    """filter_two fed from the records of the last pass (msnv_filter_resident) writes the same
+    <species>.filtered.freq bytes as the path that parses the called_SNPs / indiv_called text the same dataset wrote
+    (msnv_filter_files, itself pinned by the reference script's outputs), population and --ind, with codon annotation."""
+    from metasnv_amd import filtering
+    sp = core.synth_params(n_species=6, contig_len=5000, n_samples=9, mean_cov=9.0, sigma_cov=0.8, snv_density=0.04, frac_absent=0.2,
+                           contigs_per_species_max=3, seed=808)
+    syn = core.Synth(sp)
+    fa, ann = str(tmp_path / "ref.fa"), str(tmp_path / "ann.tsv")
+    syn.write_fasta(fa)
+    rows = []
+    for i, (n, L) in enumerate(zip(syn.names, syn.lengths)):
+        if L > 900:
+            rows.append(("g%da" % i, n, 10, min(L - 20, 700), "+-"[i % 2]))
+    _write_ann(ann, rows)
+    ctx = core.Context(0)
+    ds = core.Dataset(ctx, syn.names, syn.lengths, syn.seqs, core.default_params(min_coverage=3, calling_threshold=2))
+    for i in range(sp.n_samples):
+        ds.add_sample_records(syn.sample_records(i))
+    ds.finalize(); ds.run()
+    called, indiv = str(tmp_path / "called_SNPs"), str(tmp_path / "indiv_called")
+    ds.write_calls(called, indiv, ann, fa)
+    names = ["s%d.bam" % i for i in range(sp.n_samples)]
+    open(tmp_path / "all_samples", "w").write("\n".join(names) + "\n")
+    species = sorted({n.split(".")[0] for n in syn.names})
+    soi = {s: [names[k] for k in range(sp.n_samples) if (k + j) % 4 != 0] for j, s in enumerate(species)}
+    for ind, src in ((False, called), (True, indiv)):
+        d_file, d_res = str(tmp_path / ("file%d" % ind)), str(tmp_path / ("res%d" % ind))
+        os.makedirs(d_file); os.makedirs(d_res)
+        filtering.filter_two_all(ctx, str(tmp_path / "all_samples"), [src], d_file, soi, 3.0, 0.4)
+        n_kept, ms = ds.filter_resident([(s, [names.index(x) for x in soi[s]], soi[s]) for s in species], d_res, 3.0, 0.4, ind=ind, ann_path=ann, fasta_path=fa)
+        got, want = sorted(os.listdir(d_res)), sorted(os.listdir(d_file))
+        assert got == want and (ind or len(want) >= 3)
+        for f in want:
+            assert open(os.path.join(d_res, f)).read() == open(os.path.join(d_file, f)).read(), (ind, f)
+        assert n_kept > 0 or ind
+    ds.close(); ctx.close()
+
+
 def test_two_rank_sharded_call_with_annotation(tmp_path):
     """The N-rank product path (contig mask per rank, kernels on the GPU, gather of site + annotation records, rank 0
     writes the files) rehearsed with two ranks sharing this GPU (tables over gloo): output equals the oracle's
