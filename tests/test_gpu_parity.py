@@ -993,6 +993,91 @@ def test_full_testdata_shape_properties():
     ctx.close()
 
 
+@pytest.mark.parametrize("shape", ["config3", "config4shard"])
+def test_config3_and_config4_shapes_against_the_oracle_at_reduced_size(shape, tmp_path):
+    """The SURVEY.md section 8d generators of BASELINE configs[2] (species of 1-50 contigs, every sample carries a few random
+    species) and of one GPU's shard of configs[3] (500-sample cohort shape: many samples, a species carried by a handful of
+    them at ~5x -- per-tile slots, sparse tiles, merged groups at the contig ends) at a size the oracle finishes in seconds:
+    called_SNPs / indiv_called and the coverage files byte for byte, from ONE resident dataset (fused coverage + calls)."""
+    if shape == "config3":
+        kw = dict(n_species=12, contig_len=24000, n_samples=24, mean_cov=10.0, sigma_cov=0.7, contigs_per_species_max=10, species_per_sample=3, snv_density=0.02, seed=2003)
+    else:
+        kw = dict(n_species=40, contig_len=9000, n_samples=60, mean_cov=5.0, sigma_cov=0.3, contigs_per_species_max=5, species_per_sample=3, frac_absent=0.5, snv_density=0.02, seed=2004)
+    sp = core.synth_params(**kw)
+    syn = core.Synth(sp)
+    samples = [syn.sample_records(i) for i in range(sp.n_samples)]
+    assert len(syn.names) > sp.n_species and len({n.split(".")[0] for n in syn.names}) == sp.n_species
+    ctx = core.Context(0)
+    ds = core.Dataset(ctx, syn.names, syn.lengths, syn.seqs)
+    for s in samples:
+        ds.add_sample_records(s)
+    info = ds.finalize()
+    st_p, st_c = ds.fused_run()
+    pp, ip = str(tmp_path / "called"), str(tmp_path / "indiv")
+    ds.write_calls(pp, ip)
+    orac = run_oracle(syn.names, syn.lengths, syn.seqs, samples)
+    _assert_same((open(pp).read(), open(ip).read()), orac)
+    assert info["n_pileup_bases"] == orac[3] and orac[0].count("\n") + orac[1].count("\n") > 30
+    n_cov = 0
+    for i, s in enumerate(samples):
+        if s.size == 0:
+            continue
+        cp, dp = str(tmp_path / "c.cov"), str(tmp_path / "c.detail")
+        ds.write_coverage(i, cp, dp)
+        want = orc.qacompute(syn.names, syn.lengths, s)
+        assert open(cp).read() == want[0] and open(dp).read() == want[1]
+        n_cov += 1
+    assert n_cov >= sp.n_samples // 2
+    ds.close(); ctx.close()
+
+
+def test_config4_shard_shape_properties_at_scale():
+    """One GPU's shard of BASELINE configs[3] at 2 % of its species (30 species x ~2 Mbp = 62 M positions, 500 samples, 5x, every
+    species carried by a handful of samples): too big for the oracle, checked through size-independent properties --
+    conservation of the per-sample columns, (contig, position) order, idempotence of a second pass, and independence of a
+    sample's columns from the other samples."""
+    kw = dict(n_species=30, contig_len=2070000, n_samples=500, mean_cov=5.0, sigma_cov=0.3, contigs_per_species_max=20, species_per_sample=1, frac_absent=0.95, seed=77)
+    sp = core.synth_params(**kw)
+    syn = core.Synth(sp)
+    ctx = core.Context(0)
+
+    def run(sample_ids):
+        ds = core.Dataset(ctx, syn.names, syn.lengths, syn.seqs)
+        for i in sample_ids:
+            ds.add_synth_samples(sp, i, 1, 0)
+        info = ds.finalize()
+        st = ds.run()
+        sites, samples = ds.results()
+        ds.run()
+        s2, m2 = ds.results()
+        assert s2.tobytes() == sites.tobytes() and m2.tobytes() == samples.tobytes()
+        ds.close()
+        return info, st, sites, samples
+
+    ids = list(range(sp.n_samples))
+    info, st, sites, samples = run(ids)
+    assert info["n_positions"] > 5e7 and info["n_pileup_bases"] > 1e8 and len(sites) > 1000
+    assert (samples["cov"].astype(np.int64).sum(axis=1) == sites["cov"]).all()
+    for x in range(4):
+        called = ((sites["pop_mask"] | sites["ind_mask"]) >> x) & 1 == 1
+        assert (samples["n"][:, :, x].astype(np.int64).sum(axis=1)[called] == sites["n"][called, x]).all()
+    key = sites["tid"].astype(np.int64) << 32 | sites["pos"]
+    assert (np.diff(key) > 0).all()
+    # the samples that carry anything, alone: their columns do not change
+    carriers = [i for i in ids if samples["cov"][:, i].any()][:40]
+    _, _, s_sub, m_sub = run(carriers)
+    pos_full = {(int(t), int(p)): i for i, (t, p) in enumerate(zip(sites["tid"], sites["pos"]))}
+    hits = 0
+    for j, (t, p) in enumerate(zip(s_sub["tid"], s_sub["pos"])):
+        i = pos_full.get((int(t), int(p)))
+        if i is None:
+            continue
+        hits += 1
+        assert (m_sub["cov"][j] == samples["cov"][i, carriers]).all()
+    assert hits > 100
+    ctx.close()
+
+
 def test_randomised_parity_sweep(monkeypatch):
     """A slice of the randomised sweep (tests/fuzz_parity.py: generator and caller parameters, read lengths 20-400, coverages
     0.5-300x, both data layouts, BED splits, fused coverage, device annotation, batched / overlapped passes).  The full
