@@ -44,7 +44,6 @@ constexpr int DENSE_CHUNK_BLOCKS = 512;   // blocks per chunk descriptor (two ro
 
 struct TilePair { uint32_t sample, read_lo, read_hi, max_depth, blk_lo, nblk, seq0, pad; };    // reads of `sample` that may overlap the tile;
                                                                         // max_depth = upper bound of the per-position depth
-struct WorkItem { uint32_t tile, pair_lo, pair_hi, chunk_lo, chunk_hi, slot, part_lo, part_hi; };   // slot: row of the coverage partials (tile-major); part_lo/hi: byte offset of the row
 // One chunk = up to CHUNK_READS consecutive reads of one (tile, sample) pair, with everything the
 // kernel needs to start loading (no dependent scalar loads on the critical path).
 constexpr uint32_t MERGE_MAX_PAIRS = 256;    // pairs per merged group of shallow (sample, tile) pairs (pack.cpp; kernels.hip: msnv_pileup_tiles_merged)
@@ -54,6 +53,10 @@ constexpr uint32_t COV_ITEM_PAIRS = 16;      // pairs per coverage work item (4 
 constexpr uint32_t CHUNK_READS = 128;
 constexpr uint32_t MAX_CHUNKS_PER_ITEM = 32;
 struct ChunkDesc { uint64_t hdr_base, seq_base; uint32_t sample, pair, nrd_flags, pad; };   // nrd | last_chunk << 16
+// first: the item's first chunk descriptor, so that a workgroup can fetch its first headers without waiting for the
+// descriptor stream (one dependent load less at start-up: what a sparse cohort's one-chunk work items are made of)
+struct WorkItem { uint32_t tile, pair_lo, pair_hi, chunk_lo, chunk_hi, slot, part_lo, part_hi; ChunkDesc first; };   // slot: row of the coverage partials (tile-major); part_lo/hi: byte offset of the row
+static_assert(sizeof(WorkItem) == 64, "work items are loaded as four 16-byte words");
 
 struct SiteRec { uint32_t gpos, cov, n[4]; };                          // gate kernel output (24 B)
 

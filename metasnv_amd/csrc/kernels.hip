@@ -562,6 +562,9 @@ __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a, NarrowL
     const uint32_t nch = w.chunk_hi - w.chunk_lo;
     // the chunk descriptors go through a ring of MAX_CHUNKS_PER_ITEM LDS slots: one deep (sample, tile) pair alone can
     // hold more chunks than that, so half of the ring is refilled every MAX_CHUNKS_PER_ITEM / 2 chunks (desc_refill)
+    // the headers of chunk 0 do not wait for the descriptor stream: their descriptor came with the work item
+    uint2 hreg0 = make_uint2(0, 0);
+    if (nch && tid < N_HCAP && (uint32_t)tid < (w.first.nrd_flags & 0xffffu)) hreg0 = *reinterpret_cast<const uint2 *>(a.hdr8 + w.first.hdr_base + tid);
     for (uint32_t i = tid; i < min(nch, (uint32_t)MAX_CHUNKS_PER_ITEM) * 2; i += N_NT)
         reinterpret_cast<uint4 *>(L.desc)[i] = reinterpret_cast<const uint4 *>(a.chunks + w.chunk_lo)[i];
     __syncthreads();
@@ -575,9 +578,8 @@ __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a, NarrowL
             h = *reinterpret_cast<const uint2 *>(a.hdr8 + L.desc[c % MAX_CHUNKS_PER_ITEM].hdr_base + tid);
         return h;
     };
-    uint2 hreg = load_hdr(0);
-    if (tid < N_HCAP) L.hdr[0][tid] = hreg;
-    hreg = load_hdr(1);
+    if (tid < N_HCAP) L.hdr[0][tid] = hreg0;                      // chunk 0: fetched through the descriptor that came with the work item
+    uint2 hreg = load_hdr(1);
     uint4 qa[N32_ROUNDS], qb[N32_ROUNDS], sq[N32_ROUNDS]; uint32_t P0[N32_ROUNDS]; int vh[N32_ROUNDS];
     auto issue_loads = [&](const uint32_t c) {
         const uint64_t sbase = L.desc[c % MAX_CHUNKS_PER_ITEM].seq_base;

@@ -910,11 +910,11 @@ int finalize_dataset(msnv_dataset &ds) {
                         groups.push_back(MergedGroup{g_lo, k});
                         i_pieces += g_pieces; i_chunks += (g_pieces + CHUNK_READS - 1) / CHUNK_READS;
                         g_lo = k; g_depth = 0; g_pieces = 0;
-                        if (i_pieces >= target || i_chunks >= MAX_CHUNKS_PER_ITEM / 2) { merged.push_back(WorkItem{(uint32_t)t, i_lo, k, 0, 0, 0, 0, 0}); i_lo = k; i_pieces = 0; i_chunks = 0; }
+                        if (i_pieces >= target || i_chunks >= MAX_CHUNKS_PER_ITEM / 2) { merged.push_back(WorkItem{(uint32_t)t, i_lo, k, 0, 0, 0, 0, 0, ChunkDesc{}}); i_lo = k; i_pieces = 0; i_chunks = 0; }
                     }
                     g_depth += pairs[k].max_depth; g_pieces += nr;
                 }
-                if (tps[t + 1] > g_lo) { groups.push_back(MergedGroup{g_lo, tps[t + 1]}); merged.push_back(WorkItem{(uint32_t)t, i_lo, tps[t + 1], 0, 0, 0, 0, 0}); }
+                if (tps[t + 1] > g_lo) { groups.push_back(MergedGroup{g_lo, tps[t + 1]}); merged.push_back(WorkItem{(uint32_t)t, i_lo, tps[t + 1], 0, 0, 0, 0, 0, ChunkDesc{}}); }
             }
             for (uint32_t k = tps[t]; k < tpm[t]; ++k) {
                 const uint32_t nr = pairs[k].read_hi - pairs[k].read_lo;
@@ -924,7 +924,7 @@ int finalize_dataset(msnv_dataset &ds) {
                 const bool boundary = k + 1 == tpm[t] || (narrow != (pairs[k + 1].max_depth < NARROW_MAX_DEPTH));
                 const uint64_t next_ch = boundary ? 0 : chunks_of(pairs[k + 1]);
                 if (acc >= target || boundary || nch + next_ch > MAX_CHUNKS_PER_ITEM) {
-                    (narrow ? work : wide).push_back(WorkItem{(uint32_t)t, lo, k + 1, 0, 0, 0, 0, 0}); lo = k + 1; acc = 0; nch = 0;
+                    (narrow ? work : wide).push_back(WorkItem{(uint32_t)t, lo, k + 1, 0, 0, 0, 0, 0, ChunkDesc{}}); lo = k + 1; acc = 0; nch = 0;
                 }
             }
         }
@@ -1040,6 +1040,8 @@ int finalize_dataset(msnv_dataset &ds) {
         if (int rc = upload_vec(&d->merged_groups, mgroups, &d->device_bytes, 1)) return rc;
         if (int rc = upload_vec(&d->tile_pair_merged, tpm, &d->device_bytes)) return rc;
     }
+    for (size_t wi = 0; wi < (size_t)d->n_work_narrow + d->n_work_merged; ++wi)
+        if (work[wi].chunk_hi > work[wi].chunk_lo) work[wi].first = chunks[work[wi].chunk_lo];
     if (int rc = upload_vec(&d->chunks, chunks, &d->device_bytes, 1)) return rc;
     d->n_pairs = (uint32_t)pairs.size(); d->n_work = (uint32_t)work.size();
     if (int rc = upload_vec(&d->pairs, pairs, &d->device_bytes)) return rc;
@@ -1128,7 +1130,7 @@ int finalize_dataset(msnv_dataset &ds) {
             uint32_t lo = cps[t]; uint64_t acc = 0;
             for (uint32_t k = cps[t]; k < cps[t + 1]; ++k) {
                 acc += cpairs[k].read_hi - cpairs[k].read_lo;
-                if (acc >= cov_item_intervals || k + 1 - lo >= COV_ITEM_PAIRS || k + 1 == cps[t + 1]) { cwork.push_back(WorkItem{(uint32_t)t, lo, k + 1, 0, 0, 0, 0, 0}); lo = k + 1; acc = 0; }
+                if (acc >= cov_item_intervals || k + 1 - lo >= COV_ITEM_PAIRS || k + 1 == cps[t + 1]) { cwork.push_back(WorkItem{(uint32_t)t, lo, k + 1, 0, 0, 0, 0, 0, ChunkDesc{}}); lo = k + 1; acc = 0; }
             }
         }
         std::vector<uint32_t> tlen(nt + 1, 0), tcont(nt + 1, 0);
