@@ -84,7 +84,7 @@ struct DeviceCols {
     uint32_t *tile_dirty = nullptr;  // per work item (by the slot of its coverage row), 1 bit per 64 positions of the tile: the item added to the allele totals there
                                      // (set by the pileup kernels, consumed and cleared by the gate)
     uint32_t *unc_sites = nullptr;   // [cap_sites]: sites whose call depends on a split / merged sample's summed counts (msnv_decide_sites)
-    struct GateTileH { uint32_t tile, slot_lo, slot_16, slot_w, slot_hi, vbeg, vend, n_slots; uint64_t row0; uint64_t pad_; } *gate_tiles = nullptr;   // per active tile (kernels.hip: GateTile)
+    struct GateTileH { uint32_t tile, slot_lo, slot_16, slot_w, slot_hi, vbeg, vend, n_slots; uint64_t row0; uint32_t tot_mode, pad_; } *gate_tiles = nullptr;   // per active tile (kernels.hip: GateTile)
     unsigned long long *site_row = nullptr;   // per 64 positions: first cell of the first site in them (gate kernel; what an event finds its cell with)
     bool      use_dirty = false;     // sparse cohort (few work items per tile): the gate kernel consults tile_dirty before it reads the allele totals
     uint32_t  gather_split = 4;      // workgroups per tile in the spill gather (fewer for sparse cohorts: a pair or two per tile)

@@ -43,7 +43,7 @@ struct PileupArgs {
     const TilePair *pairs;
     const WorkItem *work;
     const ChunkDesc *chunks;
-    uint32_t       *tot;          // [4][npos]: A, C, G, T mismatch totals over all samples (atomics, sparse)
+    uint32_t       *tot;          // 4 words per position, laid out per tile (tot_add): A, C, G, T mismatch totals over all samples (atomics, sparse)
     uint8_t        *part;         // coverage summed over the item's samples, one row per work item (plain stores)
     uint64_t        npos;
     uint8_t        *spill;
@@ -104,6 +104,34 @@ __device__ __forceinline__ int wave_inclusive_scan(int x) {      // LLVM's DPP s
     x = dpp_add<0x142, 0xa>(x);   // row_bcast:15 -> rows 1 and 3
     x = dpp_add<0x143, 0xc>(x);   // row_bcast:31 -> rows 2 and 3
     return x;
+}
+
+// Allele totals of a tile: 4 x TILE words, position-major, as narrow as the tile's summed depth bound allows (pack.cpp sets the
+// mode per tile; bits 1-2 of WorkItem::part_lo, GateTile::tot_mode): 0 = the four counts in the bytes of one word per position
+// (ONE atomic adds a pair's byte bin as it is), 1 = A | C << 16 and G | T << 16 in two words, 2 = four words.  No field can carry
+// into its neighbour: every total is at most the bound.
+__device__ __forceinline__ uint32_t tot_mode_of(const WorkItem &w) { return (w.part_lo >> 1) & 3u; }
+__device__ __forceinline__ void tot_add(uint32_t *tot, const uint32_t mode, const uint32_t t0, const uint32_t p, const uint32_t n0, const uint32_t n1,
+                                        const uint32_t n2, const uint32_t n3) {
+    uint32_t *base = tot + 4ull * t0;
+    if (mode == 0u) atomicAdd(base + p, n0 | n1 << 8 | n2 << 16 | n3 << 24);
+    else if (mode == 1u) {
+        if (n0 | n1) atomicAdd(base + 2u * p, n0 | n1 << 16);
+        if (n2 | n3) atomicAdd(base + 2u * p + 1u, n2 | n3 << 16);
+    } else {
+        if (n0) atomicAdd(base + 4u * p, n0);
+        if (n1) atomicAdd(base + 4u * p + 1u, n1);
+        if (n2) atomicAdd(base + 4u * p + 2u, n2);
+        if (n3) atomicAdd(base + 4u * p + 3u, n3);
+    }
+}
+// one allele of one position (the narrow kernels: mismatches are rare and mostly one allele per position); the mode is uniform, so
+// the index and shift arithmetic is scalar
+__device__ __forceinline__ void tot_add_one(uint32_t *tile_tot, const uint32_t mode, const uint32_t p, const uint32_t x, const uint32_t n) {
+    const uint32_t shpack = mode == 0u ? 0x18100800u : mode == 1u ? 0x10001000u : 0u;     // shifts of x = 0..3, one byte each
+    // (uniform base + 32-bit byte offset: the address needs no 64-bit register pair -- the kernel sits at the 72-register step)
+    const uint32_t byte_off = ((p << mode) + (x >> (2u - mode))) * 4u;
+    atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(tile_tot) + byte_off), n << ((shpack >> (8u * x)) & 0xffu));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -291,14 +319,14 @@ __global__ __launch_bounds__(W_NT) void msnv_pileup_tiles_wide(PileupArgs a) {
     __syncthreads();
     flush_events<WideLds, W_NT, W_EVCAP>(L, a, tid);
 
-    *reinterpret_cast<uint4 *>(a.part + ((uint64_t)w.part_hi << 32 | w.part_lo) + 4u * W_PPT * tid) = make_uint4(tc[0], tc[1], tc[2], tc[3]);   // u32 row
+    *reinterpret_cast<uint4 *>(a.part + ((uint64_t)w.part_hi << 32 | (w.part_lo & ~7u)) + 4u * W_PPT * tid) = make_uint4(tc[0], tc[1], tc[2], tc[3]);   // u32 row
     bool any_allele = false;
 #pragma unroll
     for (int j = 0; j < W_PPT; ++j) {
-        const uint64_t g = (uint64_t)t0 + W_PPT * tid + j;
-#pragma unroll
-        for (int x = 0; x < 4; ++x)
-            if (tn[j][x]) { atomicAdd(&a.tot[(uint64_t)x * a.npos + g], tn[j][x]); any_allele = true; }
+        if (tn[j][0] | tn[j][1] | tn[j][2] | tn[j][3]) {
+            tot_add(a.tot, tot_mode_of(w), t0, W_PPT * tid + j, tn[j][0], tn[j][1], tn[j][2], tn[j][3]);
+            any_allele = true;
+        }
     }
     if (any_allele) atomicOr(&a.slot_dirty[w.slot], 1u << ((W_PPT * (uint32_t)tid) >> 6));      // (gate kernel: blocks whose allele totals are not all zero; one word per item)
 }
@@ -360,7 +388,7 @@ struct NarrowLds {
 template <typename LDS, int EXC_PAD, bool MERGED = false>
 __device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_t (&tc)[N_PPT / 2], bool &dirty, const uint32_t t0,
                                             const int tid, const int lane, const int wave, const uint32_t sample, const uint32_t k,
-                                            const uint32_t split) {
+                                            const uint32_t split, const uint32_t tmode) {
     const uint2 st = *reinterpret_cast<uint2 *>(&L.start[2 * tid]);
     const uint2 en = *reinterpret_cast<uint2 *>(&L.end[2 * tid]);
     const uint2 ex = *reinterpret_cast<uint2 *>(&L.exc[EXC_PAD + tid]);
@@ -406,7 +434,7 @@ __device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_
             for (uint32_t x = 0; x < 4; ++x) {
                 const uint32_t n = (word >> (8u * x)) & 0xffu;
                 if (n) {
-                    atomicAdd(&a.tot[(uint64_t)x * a.npos + gpos], n);
+                    tot_add_one(a.tot + 4ull * t0, tmode, N_PPT * tid + j, x, n);
                     if (n >= a.min_snvs) atomicOr(&a.unc_bits[gpos >> 5], 1u << (gpos & 31u));
                 }
             }
@@ -433,7 +461,7 @@ __device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_
         for (uint32_t x = 0; x < 4; ++x) {
             const uint32_t n = (word >> (8u * x)) & 0xffu;
             if (n) {
-                atomicAdd(&a.tot[(uint64_t)x * a.npos + gpos], n);
+                tot_add_one(a.tot + 4ull * t0, tmode, N_PPT * tid + j, x, n);
                 // the individual rule's "some sample holds >= t reads of x"; a sample that was split into several pairs may reach
                 // the threshold only in sum: those positions are marked and decided from the per-sample records (msnv_decide_sites)
                 if (n >= a.min_snvs) atomicOr(&a.ind4[gpos >> 3], 1u << (4u * (gpos & 7u) + x));
@@ -450,7 +478,7 @@ __device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_
 // This item's coverage partial: 8 positions per thread, u8 when the host bounded the item's summed depth below 256 (bit 0 of
 // part_lo), else u16 (an item holds <= 32 pairs of depth < 255).  tc: u16 pairs for positions (0,2) (1,3) (4,6) (5,7).
 __device__ __forceinline__ void store_part_row(uint8_t *part, const WorkItem &w, const uint32_t (&tc)[N_PPT / 2], const int tid) {
-    uint8_t *row = part + ((uint64_t)w.part_hi << 32 | (w.part_lo & ~1u));
+    uint8_t *row = part + ((uint64_t)w.part_hi << 32 | (w.part_lo & ~7u));
     if (w.part_lo & 1u) {
         const uint32_t lo = (tc[0] & 0xffu) | (tc[1] & 0xffu) << 8 | (tc[0] >> 16 & 0xffu) << 16 | (tc[1] >> 16) << 24;
         const uint32_t hi = (tc[2] & 0xffu) | (tc[3] & 0xffu) << 8 | (tc[2] >> 16 & 0xffu) << 16 | (tc[3] >> 16) << 24;
@@ -630,7 +658,7 @@ __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a, NarrowL
         hreg = load_hdr(c + 2u);
         __syncthreads();                                            // (B): this chunk is in the bins; the next chunk's headers are visible
         if (c + 1u < nch) issue_loads(c + 1u);                       // in flight under the per-sample pass
-        if (last_chunk) narrow_pass<NarrowLds, 0, MERGED>(L, a, tc, dirty, t0, tid, lane, wave, cd.sample, cd.pair, cd.pad);
+        if (last_chunk) narrow_pass<NarrowLds, 0, MERGED>(L, a, tc, dirty, t0, tid, lane, wave, cd.sample, cd.pair, cd.pad, tot_mode_of(w));
         prev_last = last_chunk;
     }
     __syncthreads();
@@ -804,7 +832,7 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_dense(PileupArgs a) {
         }
         if (last_chunk) {
             __syncthreads();                                        // (B)
-            narrow_pass<DenseLds, D_PAD>(L, a, tc, dirty, t0, tid, lane, wave, cd.sample, cd.pair, cd.pad);
+            narrow_pass<DenseLds, D_PAD>(L, a, tc, dirty, t0, tid, lane, wave, cd.sample, cd.pair, cd.pad, tot_mode_of(w));
         }
     }
     __syncthreads();
@@ -837,7 +865,7 @@ __device__ __forceinline__ uint64_t cell_of(const CellMap &m, const uint32_t til
     return m.tile_cell_base[tile] + (uint64_t)(site - m.tile_site_base[tile]) * m.tile_nslots[tile] + slot;
 }
 
-struct GateTile { uint32_t tile, slot_lo, slot_16, slot_w, slot_hi, vbeg, vend, n_slots; uint64_t row0; uint64_t pad_; };   // 48 B (pack.cpp)
+struct GateTile { uint32_t tile, slot_lo, slot_16, slot_w, slot_hi, vbeg, vend, n_slots; uint64_t row0; uint32_t tot_mode, pad_; };   // 48 B (pack.cpp)
 
 struct GateArgs {
     uint32_t *tot; const uint8_t *part; const uint64_t *slot_off; const uint32_t *tile_slot_start, *tile_slot_u16, *tile_slot_wide; uint64_t npos;
@@ -850,223 +878,346 @@ struct GateArgs {
     const uint32_t *tile_nslots; unsigned long long *tile_cell_base; unsigned long long cap_cells;
     const GateTile *gate_tiles; uint32_t *tile_dirty; uint32_t *unc_sites; uint32_t use_dirty; unsigned long long *block_row;
     uint8_t *site_elig; uint32_t any_split;
-    uint32_t decide_here;                      // 1: no sample is split into several pairs, so the calling rule is applied right here
+    uint32_t n_active, tiles_per_wg;           // active tiles; consecutive ones per workgroup (<= GATE_MAX_TILES)
 };
 
-__global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
-    uint32_t *const tot = a.tot; const uint8_t *const part = a.part;
-    const uint64_t npos = a.npos;
-    const int min_cov = a.min_cov, min_snvs = a.min_snvs; const double min_frac = a.min_frac;
-    unsigned long long *const site_bits = a.site_bits; uint32_t *const site_rank = a.site_rank; SiteRec *const sites = a.sites;
-    const uint32_t cap_sites = a.cap_sites; uint32_t *const counters = a.counters; uint32_t *const tile_site_base = a.tile_site_base, *const tile_site_cnt = a.tile_site_cnt;
-    msnv_site_sample *const out = a.out; uint16_t *const cov_col = a.cov_col;
-    const uint32_t cap_out = a.cap_out;
-    __shared__ uint32_t s_pop, s_ind;
-    __shared__ unsigned long long s_cell;
-    if (threadIdx.x == 0) { s_pop = 0; s_ind = 0; }
-    // the counter block of the NEXT pass (the passes of a dataset alternate between two blocks: no memset between passes)
-    if (blockIdx.x == 0) for (uint32_t i = threadIdx.x; i < CNT_WORDS; i += GATE_NT) a.counters_next[i] = 0u;
-    __shared__ uint32_t s_wave[GATE_NT / 64];
-    __shared__ uint32_t s_base;
-    // everything the workgroup needs to know about its tile in ONE load (the kernel is a chain of dependent loads; with a sparse
-    // cohort -- BASELINE configs[3]: a pair or two per tile -- the chain is all there is)
-    const GateTile gt = a.gate_tiles[blockIdx.x];              // tiles that hold work items; the others have no coverage
-    const uint32_t tile = gt.tile;
-    const uint32_t t0 = tile * TILE;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t vb = gt.vbeg, ve = gt.vend;
-    const uint32_t p0 = (uint32_t)GATE_PPT * (uint32_t)tid;    // my positions: p0 .. p0 + 7
-    const uint64_t g0 = (uint64_t)t0 + p0;
+// Site slots and per-sample cells are handed out with returning atomics on two device-wide counters, and same-address atomics are
+// served one after the other (~6 ns each, measured: doubling them doubled the kernel).  With one tile per workgroup that is all a
+// sparse cohort's launch waits for (BASELINE configs[3] shard: 80 k active tiles of a pair or two, 1.05 ms against 0.6 ms of
+// pileup), so a workgroup takes tiles_per_wg consecutive active tiles, stages their few sites in LDS and reserves once for all of
+// them; a tile with more sites than the stage holds is written straight from the registers as before.
+constexpr uint32_t GATE_STAGE = 384;           // staged sites per reservation
+constexpr uint32_t GATE_MAX_TILES = 8;         // tiles per workgroup (GATE_MAX_TILES x 32 blocks of 64 positions <= GATE_NT)
+struct GateStageTile { uint32_t tile, site_rel, total, n_slots; unsigned long long cell_rel; };
+struct GateLds {
+    SiteRec  rec[GATE_STAGE];
+    uint16_t fl[GATE_STAGE];                   // site_flags | site_elig << 8
+    uint8_t  unc[GATE_STAGE];
+    uint32_t blk_rel[GATE_MAX_TILES][TILE / 64];
+    GateStageTile tiles[GATE_MAX_TILES];
+    uint32_t wave[GATE_NT / 64];
+    uint32_t pop, ind, base;
+    unsigned long long cell;
+};
 
-    const uint32_t slot_lo = gt.slot_lo, slot_hi = gt.slot_hi;
-    const uint32_t slot_16 = gt.slot_16, slot_w = gt.slot_w;
-    // 64-position blocks of the tile in which some pass added to the allele totals (narrow_pass / wide kernel): the other blocks'
-    // totals and individual-rule bits are zero and are not even read (16.6 B per position against ~8 B of reads at 5x)
-    // (only consulted for sparse cohorts, use_dirty: with many work items per tile every block is dirty anyway and the totals'
-    // loads would wait for the words for nothing)
-    uint32_t dirty = 0;
-    if (a.use_dirty) for (uint32_t sl = slot_lo; sl < slot_hi; ++sl) dirty |= a.tile_dirty[sl];      // (uniform addresses, independent loads)
-    const bool my_dirty = !a.use_dirty || ((dirty >> (p0 >> 6)) & 1u);
-    uint32_t covs[GATE_PPT];
-#pragma unroll
-    for (int j = 0; j < GATE_PPT; ++j) covs[j] = 0;
-    // coverage = sum of the tile's work-item partials.  The rows of a tile are contiguous (u8 rows, then u16 rows, then the
-    // u32 rows of wide items), so the addresses need no per-row lookup and the loads of several rows are in flight together.
-    if (slot_16 > slot_lo) {
-        const uint8_t *p8 = part + gt.row0 + p0;
-        const uint32_t n8 = slot_16 - slot_lo;
-        // u8 rows are summed two positions per register (u16 halves: positions (0,2) (1,3) (4,6) (5,7)); widened every 255 rows
-        for (uint32_t r0 = 0; r0 < n8; r0 += 255u) {
-            uint32_t h[4] = {0u, 0u, 0u, 0u};
-            const uint32_t r1 = min(n8, r0 + 255u);
-            // the kernel is latency-bound (under two workgroups per CU): 16 row loads in flight per thread
-            uint32_t s = r0;
-            for (; s + 16u <= r1; s += 16u) {
-                uint2 v[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const uint2 *>(p8 + (uint64_t)(s + (uint32_t)u) * TILE);
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    h[0] += v[u].x & 0x00ff00ffu; h[1] += (v[u].x >> 8) & 0x00ff00ffu;
-                    h[2] += v[u].y & 0x00ff00ffu; h[3] += (v[u].y >> 8) & 0x00ff00ffu;
-                }
-            }
-#pragma unroll 4
-            for (; s < r1; ++s) {
-                const uint2 v = *reinterpret_cast<const uint2 *>(p8 + (uint64_t)s * TILE);
-                h[0] += v.x & 0x00ff00ffu; h[1] += (v.x >> 8) & 0x00ff00ffu;
-                h[2] += v.y & 0x00ff00ffu; h[3] += (v.y >> 8) & 0x00ff00ffu;
-            }
-            covs[0] += h[0] & 0xffffu; covs[2] += h[0] >> 16; covs[1] += h[1] & 0xffffu; covs[3] += h[1] >> 16;
-            covs[4] += h[2] & 0xffffu; covs[6] += h[2] >> 16; covs[5] += h[3] & 0xffffu; covs[7] += h[3] >> 16;
-        }
-    }
-    if (slot_w > slot_16) {
-        const uint8_t *p16 = part + gt.row0 + (uint64_t)(slot_16 - slot_lo) * TILE + 2u * p0;
-        const uint32_t n16 = slot_w - slot_16;
-#pragma unroll 2
-        for (uint32_t s = 0; s < n16; ++s) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(p16 + (uint64_t)s * 2u * TILE);
-            covs[0] += v.x & 0xffffu; covs[1] += v.x >> 16; covs[2] += v.y & 0xffffu; covs[3] += v.y >> 16;
-            covs[4] += v.z & 0xffffu; covs[5] += v.z >> 16; covs[6] += v.w & 0xffffu; covs[7] += v.w >> 16;
-        }
-    }
-    if (slot_hi > slot_w) {
-        const uint8_t *p32 = part + gt.row0 + (uint64_t)(slot_16 - slot_lo) * TILE + (uint64_t)(slot_w - slot_16) * 2u * TILE + 4u * p0;
-        const uint32_t n32 = slot_hi - slot_w;
-        for (uint32_t s = 0; s < n32; ++s) {
-            const uint4 v0 = *reinterpret_cast<const uint4 *>(p32 + (uint64_t)s * 4u * TILE);
-            const uint4 v1 = *reinterpret_cast<const uint4 *>(p32 + (uint64_t)s * 4u * TILE + 16);
-            covs[0] += v0.x; covs[1] += v0.y; covs[2] += v0.z; covs[3] += v0.w;
-            covs[4] += v1.x; covs[5] += v1.y; covs[6] += v1.z; covs[7] += v1.w;
-        }
-    }
-    // allele totals of my positions: 4 x (8 x u32); consumed here and here only, so they are left zero for the next pass
-    // (no 16 B/position memset per pass, which is what a large sparse reference would mostly pay for)
-    uint32_t nal[4][GATE_PPT];
-#pragma unroll
-    for (int x = 0; x < 4; ++x) {
-#pragma unroll
-        for (int j = 0; j < GATE_PPT; ++j) nal[x][j] = 0u;
-        if (!my_dirty) continue;
-        uint32_t *tp = tot + (uint64_t)x * npos + g0;
-        const uint4 va = *reinterpret_cast<const uint4 *>(tp), vb4 = *reinterpret_cast<const uint4 *>(tp + 4);
-        nal[x][0] = va.x; nal[x][1] = va.y; nal[x][2] = va.z; nal[x][3] = va.w; nal[x][4] = vb4.x; nal[x][5] = vb4.y; nal[x][6] = vb4.z; nal[x][7] = vb4.w;
-        if (va.x | va.y | va.z | va.w) *reinterpret_cast<uint4 *>(tp) = make_uint4(0u, 0u, 0u, 0u);
-        if (vb4.x | vb4.y | vb4.z | vb4.w) *reinterpret_cast<uint4 *>(tp + 4) = make_uint4(0u, 0u, 0u, 0u);
-    }
-    // individual-rule bits of my 8 positions (4 per position) and the "split sample" marks; consumed here and here only, so they
-    // are left zero for the next pass like the allele totals
-    const uint32_t ind4w = my_dirty ? a.ind4[g0 >> 3] : 0u;
-    if (ind4w) a.ind4[g0 >> 3] = 0u;
-    const uint32_t uncb = my_dirty ? reinterpret_cast<const uint8_t *>(a.unc_bits)[g0 >> 3] : 0u;
-    if (uncb) reinterpret_cast<uint8_t *>(a.unc_bits)[g0 >> 3] = 0;
-    const uint32_t refw = a.ref4[g0 >> 3];                                  // nt16 codes of my 8 positions
-    const uint32_t lcb = reinterpret_cast<const uint8_t *>(a.ref_lc)[g0 >> 3];   // FASTA character is a lower-case a / c / g / t
-    uint32_t okm = 0, uncm = 0, flw[2] = {0u, 0u}, elig[2] = {0u, 0u};      // site mask; "ask the per-sample records" mask; pop | ind << 4 and the alleles
-                                                                            // still open to the individual rule, one byte per position
-#pragma unroll
-    for (int j = 0; j < GATE_PPT; ++j) {
-        const uint32_t p = p0 + (uint32_t)j, cov = covs[j];
-        // mismatching bases are counted bases: no coverage, no allele totals (a stale total can not exist: they are zeroed above)
-        if (cov != 0u && p >= vb && p < ve && (int)cov >= min_cov &&
-            (int)(nal[0][j] + nal[1][j] + nal[2][j] + nal[3][j]) >= min_snvs) {                          // call_vC.cpp:547,550
-            const uint32_t indx = (ind4w >> (4 * j)) & 15u;
-            const bool unc = (uncb >> j) & 1u;
-            const double lim = (double)(int)cov * min_frac;                // call_vC.cpp:588
-            const uint32_t rc = (refw >> (4 * j)) & 15u;
-            const bool lc = (lcb >> j) & 1u;
-            bool ok = false;
-            uint32_t pop = 0, ind = 0;
-#pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                if ((int)nal[x][j] < min_snvs) continue;                   // neither rule can fire (call_vC.cpp:588,593-600)
-                const bool is_pop = (double)nal[x][j] >= lim, is_ind = (indx >> x) & 1u;
-                ok |= is_pop || is_ind || unc;
-                if (lc && rc == (1u << x)) continue;                       // skip-same-base, case-sensitive (call_vC.cpp:580)
-                if (is_pop) pop |= 1u << x; else if (is_ind) ind |= 1u << x;
-                else if (unc) { uncm |= 1u << j; elig[j >> 2] |= (1u << x) << (8 * (j & 3)); }   // a split / merged sample may hold >= t reads in sum
-            }
-            okm |= (ok ? 1u : 0u) << j;
-            flw[j >> 2] |= (pop | ind << 4) << (8 * (j & 3));
-        }
-    }
-    // 1 bit per position: is a site (the scatter half of msnv_gather_scatter filters on it).  One 64-bit word = 8 lanes.
-    {
-        unsigned long long w = (unsigned long long)okm << (8u * ((uint32_t)lane & 7u));
-        w |= __shfl_xor(w, 1); w |= __shfl_xor(w, 2); w |= __shfl_xor(w, 4);
-        if ((lane & 7) == 0) site_bits[g0 >> 6] = w;
-    }
-    uint32_t okm_certain;
-    const uint32_t mycnt = (uint32_t)__popc(okm);
-    const uint32_t incl = (uint32_t)wave_inclusive_scan((int)mycnt);
-    if (lane == 63) s_wave[wave] = incl;
-    __syncthreads();
-    uint32_t total = 0, mybase = incl - mycnt;                 // exclusive prefix in position order
-#pragma unroll
-    for (int wv = 0; wv < GATE_NT / 64; ++wv) {
-        if (wv < wave) mybase += s_wave[wv];
-        total += s_wave[wv];
-    }
-    const uint32_t n_slots = gt.n_slots;
+// reserve for the staged tiles and write everything that needed the bases; called by all threads, staged data complete (barrier inside)
+__device__ __forceinline__ void gate_flush(GateLds &L, const GateArgs &a, const uint32_t n_tiles, const uint32_t n_sites, const unsigned long long n_cells, const int tid) {
+    if (n_tiles == 0u) return;                                   // (uniform)
     if (tid == 0) {
-        if (dirty) for (uint32_t sl = slot_lo; sl < slot_hi; ++sl) a.tile_dirty[sl] = 0u;     // (every thread read them before the barrier above)
-        uint32_t base = total ? atomicAdd(&counters[2], total) : 0u;
-        s_base = base;
-        tile_site_base[tile] = base;
-        tile_site_cnt[tile] = total;
-        const unsigned long long cb = total ? atomicAdd(reinterpret_cast<unsigned long long *>(&counters[CNT_CELLS]), (unsigned long long)total * n_slots) : 0ull;
-        s_cell = cb;
-        a.tile_cell_base[tile] = cb;
-    }
-    // output-line tallies (before the first-line drop); the sites of the "ask" mask are tallied by msnv_decide_sites
-    // (a split sample: msnv_decide_sites re-decides and tallies those sites; merged groups only: the merged gather adds the
-    // individual calls it finds, so everything decided here is tallied here)
-    okm_certain = a.any_split ? okm & ~uncm : okm;
-    if (okm_certain) {
-        uint32_t np = 0, ni = 0;
-#pragma unroll
-        for (int j = 0; j < GATE_PPT; ++j) { const uint32_t f = ((okm_certain >> j) & 1u) ? (flw[j >> 2] >> (8 * (j & 3))) & 0xffu : 0u; np += (f & 15u) ? 1u : 0u; ni += (f >> 4) ? 1u : 0u; }
-        if (np) atomicAdd(&s_pop, np);
-        if (ni) atomicAdd(&s_ind, ni);
+        L.base = atomicAdd(&a.counters[2], n_sites);
+        L.cell = atomicAdd(reinterpret_cast<unsigned long long *>(&a.counters[CNT_CELLS]), n_cells);
     }
     __syncthreads();
-    if (total == 0) return;
-    if (tid == 0 && (s_pop | s_ind)) atomicAdd(reinterpret_cast<unsigned long long *>(&counters[CNT_TALLY]), (unsigned long long)s_pop | (unsigned long long)s_ind << 32);
-    const uint32_t base = s_base;
-    if ((uint64_t)base + total <= cap_out && s_cell + (unsigned long long)total * n_slots <= a.cap_cells) {   // else: the host sees the counts and runs again with larger buffers
-        // the per-sample cells of this tile's sites start out zero: gather and scatter (one launch, side by side) only add to them
-        const uint64_t n_cells = (uint64_t)total * n_slots;
-        uint16_t *rows = reinterpret_cast<uint16_t *>(out + s_cell);
+    const uint32_t base = L.base; const unsigned long long cb = L.cell;
+    if ((uint32_t)tid < n_tiles) {
+        const GateStageTile t = L.tiles[tid];
+        a.tile_site_base[t.tile] = base + t.site_rel; a.tile_site_cnt[t.tile] = t.total; a.tile_cell_base[t.tile] = cb + t.cell_rel;
+    }
+    if ((unsigned long long)base + n_sites <= a.cap_out && cb + n_cells <= a.cap_cells) {   // else: the host sees the counts and runs again with larger buffers
+        // the per-sample cells of these sites start out zero: gather and scatter (one launch, side by side) only add to them
+        uint16_t *rows = reinterpret_cast<uint16_t *>(a.out + cb);
         const uint64_t nhw = n_cells * (sizeof(msnv_site_sample) / 2);
         for (uint64_t i = (uint64_t)tid; i < nhw; i += GATE_NT) rows[i] = 0;
-        uint16_t *crow = cov_col + s_cell;                          // samples without reads at a position keep coverage 0
+        uint16_t *crow = a.cov_col + cb;                          // samples without reads at a position keep coverage 0
         for (uint64_t i = (uint64_t)tid; i < n_cells; i += GATE_NT) crow[i] = 0;
     }
     // index of the first site of every 64 positions: an event finds its site as rank + popcount of the lower bits
-    if ((lane & 7) == 0) {
-        site_rank[g0 >> 6] = base + mybase;
-        a.block_row[g0 >> 6] = s_cell + (unsigned long long)mybase * n_slots;     // first cell of the block's first site: what an event needs
+    if ((uint32_t)tid < n_tiles * (TILE / 64)) {
+        const uint32_t k = (uint32_t)tid / (TILE / 64), blk = (uint32_t)tid % (TILE / 64);
+        const GateStageTile t = L.tiles[k];
+        const uint32_t rel = L.blk_rel[k][blk];
+        a.site_rank[(uint64_t)t.tile * (TILE / 64) + blk] = base + rel;
+        a.block_row[(uint64_t)t.tile * (TILE / 64) + blk] = cb + t.cell_rel + (unsigned long long)(rel - t.site_rel) * t.n_slots;   // first cell of the block's first site
     }
-    uint32_t idx = base + mybase;
-#pragma unroll
-    for (int j = 0; j < GATE_PPT; ++j) {
-        if (okm & (1u << j)) {
-            if (idx < cap_sites) {
-                SiteRec s;
-                s.gpos = (uint32_t)(g0 + (uint32_t)j); s.cov = covs[j];
-                s.n[0] = nal[0][j]; s.n[1] = nal[1][j]; s.n[2] = nal[2][j]; s.n[3] = nal[3][j];
-                sites[idx] = s;
-                if (idx < cap_out) a.site_flags[idx] = (uint8_t)((flw[j >> 2] >> (8 * (j & 3))) & 0xffu);
-                if (idx < cap_out) a.site_elig[idx] = (uint8_t)((elig[j >> 2] >> (8 * (j & 3))) & 0xffu);
-                if (a.any_split && ((uncm >> j) & 1u)) {                // decided from the per-sample records behind the scatter
-                    const uint32_t u = atomicAdd(&counters[CNT_UNC], 1u);
-                    if (u < cap_sites) a.unc_sites[u] = idx;
-                }
-            }
-            ++idx;
+    for (uint32_t i = (uint32_t)tid; i < n_sites; i += GATE_NT) {
+        const uint32_t idx = base + i;
+        if (idx >= a.cap_sites) continue;
+        a.sites[idx] = L.rec[i];
+        if (idx < a.cap_out) { a.site_flags[idx] = (uint8_t)(L.fl[i] & 0xffu); a.site_elig[idx] = (uint8_t)(L.fl[i] >> 8); }
+        if (L.unc[i]) {                                             // decided from the per-sample records behind the scatter
+            const uint32_t u = atomicAdd(&a.counters[CNT_UNC], 1u);
+            if (u < a.cap_sites) a.unc_sites[u] = idx;
         }
     }
+    __syncthreads();                                                // the stage is free again
+}
+
+// MULTI = false: one tile per workgroup, the loop below runs once and the compiler sees it (80 registers, 6 workgroups per CU: the
+// benchmark shape); true: the loop is a loop (loop-invariant addresses and constants pile up: 126 registers, 4 workgroups per CU).
+template <bool MULTI>
+__global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
+    uint32_t *const tot = a.tot; const uint8_t *const part = a.part;
+    const int min_cov = a.min_cov, min_snvs = a.min_snvs; const double min_frac = a.min_frac;
+    unsigned long long *const site_bits = a.site_bits; SiteRec *const sites = a.sites;
+    const uint32_t cap_sites = a.cap_sites; uint32_t *const counters = a.counters;
+    msnv_site_sample *const out = a.out; uint16_t *const cov_col = a.cov_col;
+    const uint32_t cap_out = a.cap_out;
+    __shared__ GateLds L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t p0 = (uint32_t)GATE_PPT * (uint32_t)tid;    // my positions of every tile: p0 .. p0 + 7
+    if (tid == 0) { L.pop = 0; L.ind = 0; }
+    // the counter block of the NEXT pass (the passes of a dataset alternate between two blocks: no memset between passes)
+    if (blockIdx.x == 0) for (uint32_t i = threadIdx.x; i < CNT_WORDS; i += GATE_NT) a.counters_next[i] = 0u;
+    const uint32_t ti_lo = MULTI ? blockIdx.x * a.tiles_per_wg : blockIdx.x, ti_hi = MULTI ? min(a.n_active, ti_lo + a.tiles_per_wg) : ti_lo + 1u;
+    uint32_t st_tiles = 0, st_sites = 0; unsigned long long st_cells = 0;      // staged so far (uniform)
+    // everything the workgroup needs to know about a tile in ONE load (the kernel is a chain of dependent loads; with a sparse
+    // cohort -- BASELINE configs[3]: a pair or two per tile -- the chain is all there is); the next tile's is fetched a tile ahead
+    GateTile gt_next = a.gate_tiles[ti_lo];                     // tiles that hold work items; the others have no coverage
+    for (uint32_t ti = ti_lo; ti < ti_hi; ++ti) {
+        const GateTile gt = gt_next;
+        if (ti + 1 < ti_hi) gt_next = a.gate_tiles[ti + 1];
+        const uint32_t tile = gt.tile;
+        const uint32_t t0 = tile * TILE;
+        const uint32_t vb = gt.vbeg, ve = gt.vend;
+        const uint64_t g0 = (uint64_t)t0 + p0;
+
+        const uint32_t slot_lo = gt.slot_lo, slot_hi = gt.slot_hi;
+        const uint32_t slot_16 = gt.slot_16, slot_w = gt.slot_w;
+        // 64-position blocks of the tile in which some pass added to the allele totals (narrow_pass / wide kernel): the other blocks'
+        // totals and individual-rule bits are zero and are not even read (16.6 B per position against ~8 B of reads at 5x)
+        // (only consulted for sparse cohorts, use_dirty: with many work items per tile every block is dirty anyway and the totals'
+        // loads would wait for the words for nothing)
+        uint32_t dirty = 0;
+        if (a.use_dirty) for (uint32_t sl = slot_lo; sl < slot_hi; ++sl) dirty |= a.tile_dirty[sl];      // (uniform addresses, independent loads)
+        const bool my_dirty = !a.use_dirty || ((dirty >> (p0 >> 6)) & 1u);
+        uint32_t covs[GATE_PPT];
+    #pragma unroll
+        for (int j = 0; j < GATE_PPT; ++j) covs[j] = 0;
+        // coverage = sum of the tile's work-item partials.  The rows of a tile are contiguous (u8 rows, then u16 rows, then the
+        // u32 rows of wide items), so the addresses need no per-row lookup and the loads of several rows are in flight together.
+        if (slot_16 > slot_lo) {
+            const uint8_t *p8 = part + gt.row0 + p0;
+            const uint32_t n8 = slot_16 - slot_lo;
+            // u8 rows are summed two positions per register (u16 halves: positions (0,2) (1,3) (4,6) (5,7)); widened every 255 rows
+            for (uint32_t r0 = 0; r0 < n8; r0 += 255u) {
+                uint32_t h[4] = {0u, 0u, 0u, 0u};
+                const uint32_t r1 = min(n8, r0 + 255u);
+                // the kernel is latency-bound (under two workgroups per CU): 16 row loads in flight per thread
+                uint32_t s = r0;
+                for (; s + 16u <= r1; s += 16u) {
+                    uint2 v[16];
+    #pragma unroll
+                    for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const uint2 *>(p8 + (uint64_t)(s + (uint32_t)u) * TILE);
+    #pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        h[0] += v[u].x & 0x00ff00ffu; h[1] += (v[u].x >> 8) & 0x00ff00ffu;
+                        h[2] += v[u].y & 0x00ff00ffu; h[3] += (v[u].y >> 8) & 0x00ff00ffu;
+                    }
+                }
+    #pragma unroll 4
+                for (; s < r1; ++s) {
+                    const uint2 v = *reinterpret_cast<const uint2 *>(p8 + (uint64_t)s * TILE);
+                    h[0] += v.x & 0x00ff00ffu; h[1] += (v.x >> 8) & 0x00ff00ffu;
+                    h[2] += v.y & 0x00ff00ffu; h[3] += (v.y >> 8) & 0x00ff00ffu;
+                }
+                covs[0] += h[0] & 0xffffu; covs[2] += h[0] >> 16; covs[1] += h[1] & 0xffffu; covs[3] += h[1] >> 16;
+                covs[4] += h[2] & 0xffffu; covs[6] += h[2] >> 16; covs[5] += h[3] & 0xffffu; covs[7] += h[3] >> 16;
+            }
+        }
+        if (slot_w > slot_16) {
+            const uint8_t *p16 = part + gt.row0 + (uint64_t)(slot_16 - slot_lo) * TILE + 2u * p0;
+            const uint32_t n16 = slot_w - slot_16;
+    #pragma unroll 2
+            for (uint32_t s = 0; s < n16; ++s) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(p16 + (uint64_t)s * 2u * TILE);
+                covs[0] += v.x & 0xffffu; covs[1] += v.x >> 16; covs[2] += v.y & 0xffffu; covs[3] += v.y >> 16;
+                covs[4] += v.z & 0xffffu; covs[5] += v.z >> 16; covs[6] += v.w & 0xffffu; covs[7] += v.w >> 16;
+            }
+        }
+        if (slot_hi > slot_w) {
+            const uint8_t *p32 = part + gt.row0 + (uint64_t)(slot_16 - slot_lo) * TILE + (uint64_t)(slot_w - slot_16) * 2u * TILE + 4u * p0;
+            const uint32_t n32 = slot_hi - slot_w;
+            for (uint32_t s = 0; s < n32; ++s) {
+                const uint4 v0 = *reinterpret_cast<const uint4 *>(p32 + (uint64_t)s * 4u * TILE);
+                const uint4 v1 = *reinterpret_cast<const uint4 *>(p32 + (uint64_t)s * 4u * TILE + 16);
+                covs[0] += v0.x; covs[1] += v0.y; covs[2] += v0.z; covs[3] += v0.w;
+                covs[4] += v1.x; covs[5] += v1.y; covs[6] += v1.z; covs[7] += v1.w;
+            }
+        }
+        // allele totals of my positions: 4 x (8 x u32); consumed here and here only, so they are left zero for the next pass
+        // (no 16 B/position memset per pass, which is what a large sparse reference would mostly pay for)
+        // (the tile's mode -- tot_add -- says how wide they are: 4, 8 or 16 bytes per position)
+        uint32_t nal[4][GATE_PPT];
+    #pragma unroll
+        for (int x = 0; x < 4; ++x)
+    #pragma unroll
+            for (int j = 0; j < GATE_PPT; ++j) nal[x][j] = 0u;
+        if (my_dirty) {
+            uint32_t *tb = tot + 4ull * t0;
+            const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+            if (gt.tot_mode == 0u) {
+                uint4 *tp = reinterpret_cast<uint4 *>(tb + p0);
+                const uint4 v[2] = {tp[0], tp[1]};
+    #pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t wd[4] = {v[h].x, v[h].y, v[h].z, v[h].w};
+    #pragma unroll
+                    for (int j = 0; j < 4; ++j)
+    #pragma unroll
+                        for (int x = 0; x < 4; ++x) nal[x][4 * h + j] = (wd[j] >> (8 * x)) & 0xffu;
+                    if (v[h].x | v[h].y | v[h].z | v[h].w) tp[h] = z4;
+                }
+            } else if (gt.tot_mode == 1u) {
+                uint4 *tp = reinterpret_cast<uint4 *>(tb + 2u * p0);
+                const uint4 v[4] = {tp[0], tp[1], tp[2], tp[3]};
+    #pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    nal[0][2 * h] = v[h].x & 0xffffu; nal[1][2 * h] = v[h].x >> 16; nal[2][2 * h] = v[h].y & 0xffffu; nal[3][2 * h] = v[h].y >> 16;
+                    nal[0][2 * h + 1] = v[h].z & 0xffffu; nal[1][2 * h + 1] = v[h].z >> 16; nal[2][2 * h + 1] = v[h].w & 0xffffu; nal[3][2 * h + 1] = v[h].w >> 16;
+                    if (v[h].x | v[h].y | v[h].z | v[h].w) tp[h] = z4;
+                }
+            } else {
+                uint4 *tp = reinterpret_cast<uint4 *>(tb + 4u * p0);
+    #pragma unroll
+                for (int j = 0; j < GATE_PPT; ++j) {
+                    const uint4 v = tp[j];
+                    nal[0][j] = v.x; nal[1][j] = v.y; nal[2][j] = v.z; nal[3][j] = v.w;
+                    if (v.x | v.y | v.z | v.w) tp[j] = z4;
+                }
+            }
+        }
+        // individual-rule bits of my 8 positions (4 per position) and the "split sample" marks; consumed here and here only, so they
+        // are left zero for the next pass like the allele totals
+        const uint32_t ind4w = my_dirty ? a.ind4[g0 >> 3] : 0u;
+        if (ind4w) a.ind4[g0 >> 3] = 0u;
+        const uint32_t uncb = my_dirty ? reinterpret_cast<const uint8_t *>(a.unc_bits)[g0 >> 3] : 0u;
+        if (uncb) reinterpret_cast<uint8_t *>(a.unc_bits)[g0 >> 3] = 0;
+        const uint32_t refw = a.ref4[g0 >> 3];                                  // nt16 codes of my 8 positions
+        const uint32_t lcb = reinterpret_cast<const uint8_t *>(a.ref_lc)[g0 >> 3];   // FASTA character is a lower-case a / c / g / t
+        uint32_t okm = 0, uncm = 0, flw[2] = {0u, 0u}, elig[2] = {0u, 0u};      // site mask; "ask the per-sample records" mask; pop | ind << 4 and the alleles
+                                                                                // still open to the individual rule, one byte per position
+    #pragma unroll
+        for (int j = 0; j < GATE_PPT; ++j) {
+            const uint32_t p = p0 + (uint32_t)j, cov = covs[j];
+            // mismatching bases are counted bases: no coverage, no allele totals (a stale total can not exist: they are zeroed above)
+            if (cov != 0u && p >= vb && p < ve && (int)cov >= min_cov &&
+                (int)(nal[0][j] + nal[1][j] + nal[2][j] + nal[3][j]) >= min_snvs) {                          // call_vC.cpp:547,550
+                const uint32_t indx = (ind4w >> (4 * j)) & 15u;
+                const bool unc = (uncb >> j) & 1u;
+                const double lim = (double)(int)cov * min_frac;                // call_vC.cpp:588
+                const uint32_t rc = (refw >> (4 * j)) & 15u;
+                const bool lc = (lcb >> j) & 1u;
+                bool ok = false;
+                uint32_t pop = 0, ind = 0;
+    #pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    if ((int)nal[x][j] < min_snvs) continue;                   // neither rule can fire (call_vC.cpp:588,593-600)
+                    const bool is_pop = (double)nal[x][j] >= lim, is_ind = (indx >> x) & 1u;
+                    ok |= is_pop || is_ind || unc;
+                    if (lc && rc == (1u << x)) continue;                       // skip-same-base, case-sensitive (call_vC.cpp:580)
+                    if (is_pop) pop |= 1u << x; else if (is_ind) ind |= 1u << x;
+                    else if (unc) { uncm |= 1u << j; elig[j >> 2] |= (1u << x) << (8 * (j & 3)); }   // a split / merged sample may hold >= t reads in sum
+                }
+                okm |= (ok ? 1u : 0u) << j;
+                flw[j >> 2] |= (pop | ind << 4) << (8 * (j & 3));
+            }
+        }
+        // 1 bit per position: is a site (the scatter half of msnv_gather_scatter filters on it).  One 64-bit word = 8 lanes.
+        {
+            unsigned long long w = (unsigned long long)okm << (8u * ((uint32_t)lane & 7u));
+            w |= __shfl_xor(w, 1); w |= __shfl_xor(w, 2); w |= __shfl_xor(w, 4);
+            if ((lane & 7) == 0) site_bits[g0 >> 6] = w;
+        }
+        const uint32_t mycnt = (uint32_t)__popc(okm);
+        const uint32_t incl = (uint32_t)wave_inclusive_scan((int)mycnt);
+        if (lane == 63) L.wave[wave] = incl;
+        __syncthreads();
+        uint32_t total = 0, mybase = incl - mycnt;                 // exclusive prefix in position order
+#pragma unroll
+        for (int wv = 0; wv < GATE_NT / 64; ++wv) {
+            if (wv < wave) mybase += L.wave[wv];
+            total += L.wave[wv];
+        }
+        const uint32_t n_slots = gt.n_slots;
+        if (tid == 0 && dirty) for (uint32_t sl = slot_lo; sl < slot_hi; ++sl) a.tile_dirty[sl] = 0u;     // (every thread read them before the barrier above)
+        // output-line tallies (before the first-line drop); the sites of the "ask" mask are tallied by msnv_decide_sites
+        // (a split sample: msnv_decide_sites re-decides and tallies those sites; merged groups only: the merged gather adds the
+        // individual calls it finds, so everything decided here is tallied here)
+        const uint32_t okm_certain = a.any_split ? okm & ~uncm : okm;
+        if (okm_certain) {
+            uint32_t np = 0, ni = 0;
+#pragma unroll
+            for (int j = 0; j < GATE_PPT; ++j) { const uint32_t f = ((okm_certain >> j) & 1u) ? (flw[j >> 2] >> (8 * (j & 3))) & 0xffu : 0u; np += (f & 15u) ? 1u : 0u; ni += (f >> 4) ? 1u : 0u; }
+            if (np) atomicAdd(&L.pop, np);
+            if (ni) atomicAdd(&L.ind, ni);
+        }
+        if (total == 0u) {                                          // (uniform)
+            if (tid == 0) { a.tile_site_base[tile] = 0u; a.tile_site_cnt[tile] = 0u; a.tile_cell_base[tile] = 0ull; }
+            __syncthreads();                                        // L.wave is written again by the next tile
+            continue;
+        }
+        if (st_sites + total > GATE_STAGE || st_tiles == GATE_MAX_TILES) {     // (uniform) no room: hand out what is staged
+            gate_flush(L, a, st_tiles, st_sites, st_cells, tid);
+            st_tiles = 0; st_sites = 0; st_cells = 0;
+        }
+        if (total <= GATE_STAGE) {
+            if (tid == 0) L.tiles[st_tiles] = GateStageTile{tile, st_sites, total, n_slots, st_cells};
+            if ((lane & 7) == 0) L.blk_rel[st_tiles][p0 >> 6] = st_sites + mybase;
+            uint32_t i = st_sites + mybase;
+#pragma unroll
+            for (int j = 0; j < GATE_PPT; ++j) {
+                if (okm & (1u << j)) {
+                    SiteRec s;
+                    s.gpos = (uint32_t)(g0 + (uint32_t)j); s.cov = covs[j];
+                    s.n[0] = nal[0][j]; s.n[1] = nal[1][j]; s.n[2] = nal[2][j]; s.n[3] = nal[3][j];
+                    L.rec[i] = s;
+                    L.fl[i] = (uint16_t)(((flw[j >> 2] >> (8 * (j & 3))) & 0xffu) | ((elig[j >> 2] >> (8 * (j & 3))) & 0xffu) << 8);
+                    L.unc[i] = (uint8_t)((a.any_split && ((uncm >> j) & 1u)) ? 1u : 0u);
+                    ++i;
+                }
+            }
+            ++st_tiles; st_sites += total; st_cells += (unsigned long long)total * n_slots;
+            __syncthreads();                                        // L.wave is written again by the next tile
+            continue;
+        }
+        // ---- a tile with more sites than the stage holds: its own reservation, written from the registers
+        if (tid == 0) {
+            const uint32_t base = atomicAdd(&counters[2], total);
+            L.base = base;
+            a.tile_site_base[tile] = base;
+            a.tile_site_cnt[tile] = total;
+            const unsigned long long cb = atomicAdd(reinterpret_cast<unsigned long long *>(&counters[CNT_CELLS]), (unsigned long long)total * n_slots);
+            L.cell = cb;
+            a.tile_cell_base[tile] = cb;
+        }
+        __syncthreads();
+        const uint32_t base = L.base; const unsigned long long s_cell = L.cell;
+        if ((uint64_t)base + total <= cap_out && s_cell + (unsigned long long)total * n_slots <= a.cap_cells) {
+            const uint64_t n_cells = (uint64_t)total * n_slots;
+            uint16_t *rows = reinterpret_cast<uint16_t *>(out + s_cell);
+            const uint64_t nhw = n_cells * (sizeof(msnv_site_sample) / 2);
+            for (uint64_t i = (uint64_t)tid; i < nhw; i += GATE_NT) rows[i] = 0;
+            uint16_t *crow = cov_col + s_cell;
+            for (uint64_t i = (uint64_t)tid; i < n_cells; i += GATE_NT) crow[i] = 0;
+        }
+        if ((lane & 7) == 0) {
+            a.site_rank[g0 >> 6] = base + mybase;
+            a.block_row[g0 >> 6] = s_cell + (unsigned long long)mybase * n_slots;
+        }
+        uint32_t idx = base + mybase;
+#pragma unroll
+        for (int j = 0; j < GATE_PPT; ++j) {
+            if (okm & (1u << j)) {
+                if (idx < cap_sites) {
+                    SiteRec s;
+                    s.gpos = (uint32_t)(g0 + (uint32_t)j); s.cov = covs[j];
+                    s.n[0] = nal[0][j]; s.n[1] = nal[1][j]; s.n[2] = nal[2][j]; s.n[3] = nal[3][j];
+                    sites[idx] = s;
+                    if (idx < cap_out) a.site_flags[idx] = (uint8_t)((flw[j >> 2] >> (8 * (j & 3))) & 0xffu);
+                    if (idx < cap_out) a.site_elig[idx] = (uint8_t)((elig[j >> 2] >> (8 * (j & 3))) & 0xffu);
+                    if (a.any_split && ((uncm >> j) & 1u)) {
+                        const uint32_t u = atomicAdd(&counters[CNT_UNC], 1u);
+                        if (u < cap_sites) a.unc_sites[u] = idx;
+                    }
+                }
+                ++idx;
+            }
+        }
+        __syncthreads();                                            // L.wave, L.base and L.cell are written again
+    }
+    gate_flush(L, a, st_tiles, st_sites, st_cells, tid);
+    __syncthreads();
+    if (tid == 0 && (L.pop | L.ind)) atomicAdd(reinterpret_cast<unsigned long long *>(&counters[CNT_TALLY]), (unsigned long long)L.pop | (unsigned long long)L.ind << 32);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1586,12 +1737,18 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
         g.ind4 = d.ind4; g.unc_bits = d.unc_bits; g.ref4 = d.ref4; g.ref_lc = d.ref_lc;
         g.site_bits = d.site_bits; g.site_rank = d.site_rank; g.sites = d.sites; g.cap_sites = d.cap_sites; g.counters = counters; g.counters_next = counters_next;
         g.tile_site_base = d.tile_site_base; g.tile_site_cnt = d.tile_site_cnt; g.active_tiles = d.active_tiles;
-        g.out = d.out; g.cov_col = d.cov_col; g.site_flags = d.site_flags; g.cap_out = cap_out; g.decide_here = 1u;
+        g.out = d.out; g.cov_col = d.cov_col; g.site_flags = d.site_flags; g.cap_out = cap_out;
         g.gate_tiles = reinterpret_cast<const GateTile *>(d.gate_tiles); g.tile_dirty = d.tile_dirty; g.unc_sites = d.unc_sites;
         g.use_dirty = d.use_dirty ? 1u : 0u; g.block_row = d.site_row; g.site_elig = d.site_elig; g.any_split = d.any_split ? 1u : 0u;
         static_assert(sizeof(GateTile) == sizeof(DeviceCols::GateTileH) && sizeof(GateTile) == 48, "gate tile descriptor");
         g.tile_nslots = d.tile_nslots; g.tile_cell_base = d.tile_cell_base; g.cap_cells = d.cap_cells;
-        hipLaunchKernelGGL(msnv_gate_sites, dim3(d.n_active_tiles), dim3(GATE_NT), 0, st, g);
+        // several tiles per workgroup once the tiles outnumber what the device holds at a time several times over (one reservation of
+        // site slots per workgroup: msnv_gate_sites); MSNV_GATE_TILES overrides (tests run every size)
+        g.n_active = d.n_active_tiles;
+        g.tiles_per_wg = d.n_active_tiles >= 32768u ? 8u : d.n_active_tiles >= 8192u ? 4u : 1u;
+        if (const char *e = getenv("MSNV_GATE_TILES")) g.tiles_per_wg = (uint32_t)std::min<int>((int)GATE_MAX_TILES, std::max(1, atoi(e)));
+        if (g.tiles_per_wg == 1u) hipLaunchKernelGGL(msnv_gate_sites<false>, dim3(d.n_active_tiles), dim3(GATE_NT), 0, st, g);
+        else hipLaunchKernelGGL(msnv_gate_sites<true>, dim3((d.n_active_tiles + g.tiles_per_wg - 1) / g.tiles_per_wg), dim3(GATE_NT), 0, st, g);
         HIP_TRY(hipGetLastError());
     } else HIP_TRY(hipMemsetAsync(counters_next, 0, CNT_WORDS * sizeof(uint32_t), st));   // nobody else would
     if (ev3) HIP_TRY(hipEventRecord(ev3, st));

@@ -935,18 +935,25 @@ int finalize_dataset(msnv_dataset &ds) {
     }
     // ---- coverage partials: one row of TILE counters per work item, rows of a tile contiguous (the gate kernel sums them):
     // u8 rows first (narrow items whose pairs' depth bounds add up to < 256: most of them at ~10x), then u16 rows (the other
-    // narrow items: <= 32 pairs x 254), then the u32 rows of wide items.  Bit 0 of part_lo marks a u8 row.
+    // narrow items: <= 32 pairs x 254), then the u32 rows of wide items.  Bit 0 of part_lo marks a u8 row, bits 1-2 hold the tile's allele-total mode.
     {
         std::vector<uint32_t> tss(nt + 1, 0), t16(nt + 1, 0), twide(nt + 1, 0);
         for (const WorkItem &w : work) ++tss[w.tile + 1];
         for (uint64_t t = 0; t < nt; ++t) tss[t + 1] += tss[t];
         std::vector<uint8_t> cls(work.size(), 0);
+        // Allele totals (kernels.hip: tot_add / msnv_gate_sites): a tile's 4 x TILE words hold its mismatch totals position by
+        // position, as narrow as the tile's summed depth bound allows -- 4 bytes (A, C, G, T) in ONE word per position when the
+        // bound is below 256 (a sparse cohort: the gate kernel then reads 4 B per position instead of 16), 2 x u16 in two words
+        // below 65536 (the benchmark shape), else four words.  MSNV_TOT_MODE=0..2 sets the narrowest mode allowed (tests).
+        std::vector<uint64_t> tile_bound(nt, 0);
         for (size_t i = 0; i < work.size(); ++i) {
-            if (i >= d->n_work_narrow + d->n_work_merged) { cls[i] = 2; continue; }
             uint64_t bound = 0;
             for (uint32_t k = work[i].pair_lo; k < work[i].pair_hi; ++k) bound += pairs[k].max_depth;
-            cls[i] = bound < 256 ? 0 : 1;
+            tile_bound[work[i].tile] += bound;
+            cls[i] = i >= d->n_work_narrow + d->n_work_merged ? 2 : bound < 256 ? 0 : 1;
         }
+        const uint32_t min_tot_mode = [] { const char *e = getenv("MSNV_TOT_MODE"); return e ? (uint32_t)std::min(2, std::max(0, atoi(e))) : 0u; }();
+        auto tot_mode = [&](uint64_t t) { return std::max<uint32_t>(min_tot_mode, tile_bound[t] < 256 ? 0u : tile_bound[t] < 65536 ? 1u : 2u); };
         std::vector<uint32_t> fill(tss.begin(), tss.end() - 1);
         std::vector<uint8_t> slot_cls(work.size(), 0);
         for (int c = 0; c < 3; ++c)
@@ -956,7 +963,7 @@ int finalize_dataset(msnv_dataset &ds) {
         for (size_t s = 0; s < work.size(); ++s) off[s + 1] = off[s] + ((uint64_t)TILE << slot_cls[s]);
         for (size_t i = 0; i < work.size(); ++i) {
             WorkItem &w = work[i];
-            w.part_lo = (uint32_t)off[w.slot] | (cls[i] == 0 ? 1u : 0u); w.part_hi = (uint32_t)(off[w.slot] >> 32);
+            w.part_lo = (uint32_t)off[w.slot] | (cls[i] == 0 ? 1u : 0u) | tot_mode(w.tile) << 1; w.part_hi = (uint32_t)(off[w.slot] >> 32);
         }
         for (uint64_t t = 0; t < nt; ++t) {                    // first u16 row and first u32 row of every tile
             uint32_t s = tss[t];
@@ -980,7 +987,7 @@ int finalize_dataset(msnv_dataset &ds) {
         for (uint64_t t = 0; t < nt; ++t) nslots_host[t] = (uint32_t)(ds.tile_slot_base[t + 1] - ds.tile_slot_base[t]);
         std::vector<DeviceCols::GateTileH> gts;
         gts.reserve(active.size());
-        for (uint32_t t : active) gts.push_back(DeviceCols::GateTileH{t, tss[t], t16[t], twide[t], tss[t + 1], vb_host[t], ve_host[t], nslots_host[t], off[tss[t]], 0});
+        for (uint32_t t : active) gts.push_back(DeviceCols::GateTileH{t, tss[t], t16[t], twide[t], tss[t + 1], vb_host[t], ve_host[t], nslots_host[t], off[tss[t]], tot_mode(t), 0});
         if (int rc = upload_vec(&d->gate_tiles, gts, &d->device_bytes, 1)) return rc;
         d->gather_split = (uint32_t)std::min<uint64_t>(4, std::max<uint64_t>(1, (active.empty() ? 0 : pairs.size() / active.size()) / 32));
         d->use_dirty = !active.empty() && work.size() < 4 * active.size();       // a sparse cohort: fewer than four work items per tile

@@ -2,6 +2,7 @@
 
 Integer counting => the bar is byte-identical called_SNPs / indiv_called."""
 import os
+import tempfile
 
 import numpy as np
 import pytest
@@ -312,6 +313,62 @@ def test_merged_groups_of_shallow_pairs(shallow_pieces, monkeypatch):
         _assert_same(prod, orac)
         assert prod[2]["n_pileup_bases"] == orac[3]
     assert prod[0].count("\n") + prod[1].count("\n") > 50
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gate_tiles", ["1", "3", "8"])
+def test_gate_kernel_with_several_tiles_per_workgroup(gate_tiles, monkeypatch):
+    """msnv_gate_sites hands out site slots and per-sample cells with one reservation per workgroup; with many active tiles a
+    workgroup takes several consecutive tiles and stages their sites in LDS (MSNV_GATE_TILES sets how many).  Same bytes as the
+    oracle when (a) most tiles hold a handful of sites, some none (staged, several tiles per reservation), (b) SNVs are so dense
+    that tiles hold more sites than the stage (flushed early; tiles above 384 sites written directly), (c) a deep sample is split
+    into several pairs of a tile and shallow ones are merged (positions decided behind the scatter go through the stage too)."""
+    monkeypatch.setenv("MSNV_GATE_TILES", gate_tiles)
+    cases = [
+        (dict(n_species=14, contig_len=4500, n_samples=10, mean_cov=6.0, sigma_cov=1.0, snv_density=0.004, error_rate=0.004, frac_absent=0.5,
+              lowercase_ref=1, seed=515), dict()),
+        (dict(n_species=3, contig_len=6500, n_samples=6, mean_cov=12.0, sigma_cov=0.3, snv_density=0.30, error_rate=0.01, frac_absent=0.0,
+              seed=516), dict(min_coverage=2, calling_threshold=2)),
+        (dict(n_species=4, contig_len=5000, n_samples=40, mean_cov=2.0, sigma_cov=2.2, snv_density=0.03, error_rate=0.01, frac_absent=0.2,
+              read_len=60, lowercase_ref=1, seed=517), dict(min_coverage=3, calling_threshold=3)),
+    ]
+    n_lines = []
+    for sk, pk in cases:
+        syn, samples = synth_case(**sk)
+        p = core.default_params(**pk)
+        prod = run_product(syn.names, syn.lengths, syn.seqs, samples, params=p)
+        orac = run_oracle(syn.names, syn.lengths, syn.seqs, samples, params=p)
+        _assert_same(prod, orac)
+        n_lines.append(prod[0].count("\n") + prod[1].count("\n"))
+    assert n_lines[0] > 10 and n_lines[1] > 3 * 400 and n_lines[2] > 10, n_lines
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["pieces", "dense"])
+@pytest.mark.parametrize("tot_mode", ["0", "1", "2"])
+def test_allele_total_modes(tot_mode, layout, monkeypatch):
+    """The allele totals of a tile are as narrow as its summed depth bound allows (pack.cpp: 4 bytes in one word per position,
+    2 x u16 in two words, or four words; kernels.hip tot_add / msnv_gate_sites).  An uneven cohort has tiles of the first two
+    kinds (a few shallow samples here, a deep one there, one sample deep enough for the wide kernel); MSNV_TOT_MODE raises the
+    narrowest mode allowed so that every width runs on every tile.  Same bytes as the oracle each time, two passes per dataset
+    (the gate kernel leaves the totals zero for the next pass in every mode)."""
+    monkeypatch.setenv("MSNV_TOT_MODE", tot_mode)
+    monkeypatch.setenv("MSNV_LAYOUT", layout)
+    sp = core.synth_params(n_species=6, contig_len=5000, n_samples=14, mean_cov=9.0, sigma_cov=1.6, snv_density=0.03, error_rate=0.01,
+                           frac_absent=0.4, lowercase_ref=1, seed=4242)
+    syn = core.Synth(sp)
+    samples = [syn.sample_records(i) for i in range(sp.n_samples)]
+    for kw in (dict(min_coverage=3, calling_threshold=2), dict()):
+        p = core.default_params(**kw)
+        pop, ind, info, st, ds, ctx = run_product(syn.names, syn.lengths, syn.seqs, samples, params=p, return_ds=True)
+        orac = run_oracle(syn.names, syn.lengths, syn.seqs, samples, params=p)
+        _assert_same((pop, ind, info, st), orac)
+        st2 = ds.run()                                              # second pass over the resident dataset
+        with tempfile.TemporaryDirectory() as td:
+            ds.write_calls(os.path.join(td, "p"), os.path.join(td, "i"), None, None)
+            assert open(os.path.join(td, "p")).read() == pop and open(os.path.join(td, "i")).read() == ind
+        ds.close(); ctx.close()
+    assert pop.count("\n") + ind.count("\n") > 20
 
 
 def test_event_list_grows_when_a_sub_list_overflows(monkeypatch):
