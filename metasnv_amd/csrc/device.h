@@ -86,6 +86,7 @@ struct DeviceCols {
     uint32_t *unc_sites = nullptr;   // [cap_sites]: sites whose call depends on a split / merged sample's summed counts (msnv_decide_sites)
     struct GateTileH { uint32_t tile, slot_lo, slot_16, slot_w, slot_hi, vbeg, vend, n_slots; uint64_t row0; uint32_t tot_mode, pad_; } *gate_tiles = nullptr;   // per active tile (kernels.hip: GateTile)
     unsigned long long *site_row = nullptr;   // per 64 positions: first cell of the first site in them (gate kernel; what an event finds its cell with)
+    bool      wide_tot = false;      // some tile's allele totals need 32 bits per allele (tot_add mode 2): the gate kernel's wide instantiation
     bool      use_dirty = false;     // sparse cohort (few work items per tile): the gate kernel consults tile_dirty before it reads the allele totals
     uint32_t  gather_split = 4;      // workgroups per tile in the spill gather (fewer for sparse cohorts: a pair or two per tile)
     bool      any_split = false;     // some (sample, tile) run was dealt into several pairs: the calling rule then needs the summed per-sample records

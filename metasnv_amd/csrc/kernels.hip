@@ -328,7 +328,7 @@ __global__ __launch_bounds__(W_NT) void msnv_pileup_tiles_wide(PileupArgs a) {
             any_allele = true;
         }
     }
-    if (any_allele) atomicOr(&a.slot_dirty[w.slot], 1u << ((W_PPT * (uint32_t)tid) >> 6));      // (gate kernel: blocks whose allele totals are not all zero; one word per item)
+    if (any_allele && tot_mode_of(w) != 0u) atomicOr(&a.slot_dirty[w.slot], 1u << ((W_PPT * (uint32_t)tid) >> 6));      // (gate kernel: blocks whose allele totals are not all zero; one word per item)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -493,6 +493,7 @@ __device__ __forceinline__ void store_part_row(uint8_t *part, const WorkItem &w,
 // partial row in spirit (indexed by the row's slot); the gate kernel ORs the words of the tile's items and does not even read
 // the totals of the other blocks.  Eight consecutive threads share a block, so a wavefront's ballot folds to 8 bits.
 __device__ __forceinline__ void store_item_dirty(uint32_t *slot_dirty, const WorkItem &w, const bool dirty, const int tid) {
+    if (tot_mode_of(w) == 0u) return;                           // the gate kernel reads such a tile's totals whatever they hold
     const unsigned long long b = __ballot(dirty);
     uint32_t byte = 0;
 #pragma unroll
@@ -944,8 +945,10 @@ __device__ __forceinline__ void gate_flush(GateLds &L, const GateArgs &a, const 
 
 // MULTI = false: one tile per workgroup, the loop below runs once and the compiler sees it (80 registers, 6 workgroups per CU: the
 // benchmark shape); true: the loop is a loop (loop-invariant addresses and constants pile up: 126 registers, 4 workgroups per CU).
-template <bool MULTI>
+template <bool MULTI, bool WIDE_TOT>
 __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
+    constexpr int NN = WIDE_TOT ? 4 * GATE_PPT : 2 * GATE_PPT;
+    constexpr int ROWS = MULTI ? 8 : 16;                        // partial rows in flight per thread (a sparse cohort's tile has a row or two)
     uint32_t *const tot = a.tot; const uint8_t *const part = a.part;
     const int min_cov = a.min_cov, min_snvs = a.min_snvs; const double min_frac = a.min_frac;
     unsigned long long *const site_bits = a.site_bits; SiteRec *const sites = a.sites;
@@ -977,9 +980,24 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
         // totals and individual-rule bits are zero and are not even read (16.6 B per position against ~8 B of reads at 5x)
         // (only consulted for sparse cohorts, use_dirty: with many work items per tile every block is dirty anyway and the totals'
         // loads would wait for the words for nothing)
+        // (nor for a tile whose totals are one word per position -- tot_add mode 0, what a sparse cohort's tiles are: 4 B per
+        // position are not worth a round trip, and the pileup kernels do not mark such tiles: store_item_dirty)
+        const bool consult = a.use_dirty && gt.tot_mode != 0u;
         uint32_t dirty = 0;
-        if (a.use_dirty) for (uint32_t sl = slot_lo; sl < slot_hi; ++sl) dirty |= a.tile_dirty[sl];      // (uniform addresses, independent loads)
-        const bool my_dirty = !a.use_dirty || ((dirty >> (p0 >> 6)) & 1u);
+        if (consult) for (uint32_t sl = slot_lo; sl < slot_hi; ++sl) dirty |= a.tile_dirty[sl];      // (uniform addresses, independent loads)
+        const bool my_dirty = !consult || ((dirty >> (p0 >> 6)) & 1u);
+        // Everything else a thread reads about its 8 positions is requested here, ahead of the partial rows: the tile costs ONE round
+        // trip to memory (the kernel is latency-bound: its time goes with 1 / resident workgroups).
+        uint32_t *const tb = tot + 4ull * t0;
+        const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+        uint4 e0 = z4, e1 = z4;                                    // mode 0: the allele totals of my positions
+        if (gt.tot_mode == 0u) { e0 = reinterpret_cast<const uint4 *>(tb + p0)[0]; e1 = reinterpret_cast<const uint4 *>(tb + p0)[1]; }
+        // individual-rule bits of my 8 positions (4 per position) and the "split sample" marks; consumed here and here only, so they
+        // are left zero for the next pass like the allele totals
+        const uint32_t ind4w = my_dirty ? a.ind4[g0 >> 3] : 0u;
+        const uint32_t uncb = my_dirty ? reinterpret_cast<const uint8_t *>(a.unc_bits)[g0 >> 3] : 0u;
+        const uint32_t refw = a.ref4[g0 >> 3];                                  // nt16 codes of my 8 positions
+        const uint32_t lcb = reinterpret_cast<const uint8_t *>(a.ref_lc)[g0 >> 3];   // FASTA character is a lower-case a / c / g / t
         uint32_t covs[GATE_PPT];
     #pragma unroll
         for (int j = 0; j < GATE_PPT; ++j) covs[j] = 0;
@@ -994,12 +1012,12 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
                 const uint32_t r1 = min(n8, r0 + 255u);
                 // the kernel is latency-bound (under two workgroups per CU): 16 row loads in flight per thread
                 uint32_t s = r0;
-                for (; s + 16u <= r1; s += 16u) {
-                    uint2 v[16];
+                for (; s + (uint32_t)ROWS <= r1; s += (uint32_t)ROWS) {
+                    uint2 v[ROWS];
     #pragma unroll
-                    for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const uint2 *>(p8 + (uint64_t)(s + (uint32_t)u) * TILE);
+                    for (int u = 0; u < ROWS; ++u) v[u] = *reinterpret_cast<const uint2 *>(p8 + (uint64_t)(s + (uint32_t)u) * TILE);
     #pragma unroll
-                    for (int u = 0; u < 16; ++u) {
+                    for (int u = 0; u < ROWS; ++u) {
                         h[0] += v[u].x & 0x00ff00ffu; h[1] += (v[u].x >> 8) & 0x00ff00ffu;
                         h[2] += v[u].y & 0x00ff00ffu; h[3] += (v[u].y >> 8) & 0x00ff00ffu;
                     }
@@ -1034,56 +1052,51 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
                 covs[4] += v1.x; covs[5] += v1.y; covs[6] += v1.z; covs[7] += v1.w;
             }
         }
-        // allele totals of my positions: 4 x (8 x u32); consumed here and here only, so they are left zero for the next pass
-        // (no 16 B/position memset per pass, which is what a large sparse reference would mostly pay for)
-        // (the tile's mode -- tot_add -- says how wide they are: 4, 8 or 16 bytes per position)
-        uint32_t nal[4][GATE_PPT];
+        // allele totals of my positions; consumed here and here only, so they are left zero for the next pass (no 16 B/position
+        // memset per pass, which is what a large sparse reference would mostly pay for).  The tile's mode -- tot_add -- says how wide
+        // they are in memory: 4, 8 or 16 bytes per position; in registers two u16 per word (A | C << 16, G | T << 16) unless some
+        // tile of the dataset needs all 32 bits (WIDE_TOT: 32 registers instead of 16).
+        uint32_t nn[NN];
     #pragma unroll
-        for (int x = 0; x < 4; ++x)
-    #pragma unroll
-            for (int j = 0; j < GATE_PPT; ++j) nal[x][j] = 0u;
+        for (int k = 0; k < NN; ++k) nn[k] = 0u;
         if (my_dirty) {
-            uint32_t *tb = tot + 4ull * t0;
-            const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
             if (gt.tot_mode == 0u) {
                 uint4 *tp = reinterpret_cast<uint4 *>(tb + p0);
-                const uint4 v[2] = {tp[0], tp[1]};
+                const uint32_t wd[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
     #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const uint32_t wd[4] = {v[h].x, v[h].y, v[h].z, v[h].w};
-    #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-    #pragma unroll
-                        for (int x = 0; x < 4; ++x) nal[x][4 * h + j] = (wd[j] >> (8 * x)) & 0xffu;
-                    if (v[h].x | v[h].y | v[h].z | v[h].w) tp[h] = z4;
+                for (int k = 0; k < 8; ++k) {
+                    if (WIDE_TOT) { nn[4 * k] = wd[k] & 0xffu; nn[4 * k + 1] = (wd[k] >> 8) & 0xffu; nn[4 * k + 2] = (wd[k] >> 16) & 0xffu; nn[4 * k + 3] = wd[k] >> 24; }
+                    else { nn[2 * k] = (wd[k] & 0xffu) | (wd[k] & 0xff00u) << 8; nn[2 * k + 1] = ((wd[k] >> 16) & 0xffu) | (wd[k] >> 24) << 16; }
                 }
+                if (e0.x | e0.y | e0.z | e0.w) tp[0] = z4;
+                if (e1.x | e1.y | e1.z | e1.w) tp[1] = z4;
             } else if (gt.tot_mode == 1u) {
                 uint4 *tp = reinterpret_cast<uint4 *>(tb + 2u * p0);
                 const uint4 v[4] = {tp[0], tp[1], tp[2], tp[3]};
     #pragma unroll
                 for (int h = 0; h < 4; ++h) {
-                    nal[0][2 * h] = v[h].x & 0xffffu; nal[1][2 * h] = v[h].x >> 16; nal[2][2 * h] = v[h].y & 0xffffu; nal[3][2 * h] = v[h].y >> 16;
-                    nal[0][2 * h + 1] = v[h].z & 0xffffu; nal[1][2 * h + 1] = v[h].z >> 16; nal[2][2 * h + 1] = v[h].w & 0xffffu; nal[3][2 * h + 1] = v[h].w >> 16;
+                    const uint32_t wd[4] = {v[h].x, v[h].y, v[h].z, v[h].w};
+    #pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (WIDE_TOT) { nn[8 * h + 2 * k] = wd[k] & 0xffffu; nn[8 * h + 2 * k + 1] = wd[k] >> 16; }
+                        else nn[4 * h + k] = wd[k];
+                    }
                     if (v[h].x | v[h].y | v[h].z | v[h].w) tp[h] = z4;
                 }
-            } else {
+            } else if (WIDE_TOT) {
                 uint4 *tp = reinterpret_cast<uint4 *>(tb + 4u * p0);
     #pragma unroll
-                for (int j = 0; j < GATE_PPT; ++j) {
-                    const uint4 v = tp[j];
-                    nal[0][j] = v.x; nal[1][j] = v.y; nal[2][j] = v.z; nal[3][j] = v.w;
-                    if (v.x | v.y | v.z | v.w) tp[j] = z4;
+                for (int k = 0; k < GATE_PPT; ++k) {
+                    const uint4 v = tp[k];
+                    nn[4 * k] = v.x; nn[4 * k + 1] = v.y; nn[4 * k + 2] = v.z; nn[4 * k + 3] = v.w;
+                    if (v.x | v.y | v.z | v.w) tp[k] = z4;
                 }
             }
         }
-        // individual-rule bits of my 8 positions (4 per position) and the "split sample" marks; consumed here and here only, so they
-        // are left zero for the next pass like the allele totals
-        const uint32_t ind4w = my_dirty ? a.ind4[g0 >> 3] : 0u;
+        // mismatching A / C / G / T reads at my position j
+        auto n_of = [&](const int j, const int x) -> uint32_t { return WIDE_TOT ? nn[4 * j + x] : (nn[2 * j + (x >> 1)] >> (16 * (x & 1))) & 0xffffu; };
         if (ind4w) a.ind4[g0 >> 3] = 0u;
-        const uint32_t uncb = my_dirty ? reinterpret_cast<const uint8_t *>(a.unc_bits)[g0 >> 3] : 0u;
         if (uncb) reinterpret_cast<uint8_t *>(a.unc_bits)[g0 >> 3] = 0;
-        const uint32_t refw = a.ref4[g0 >> 3];                                  // nt16 codes of my 8 positions
-        const uint32_t lcb = reinterpret_cast<const uint8_t *>(a.ref_lc)[g0 >> 3];   // FASTA character is a lower-case a / c / g / t
         uint32_t okm = 0, uncm = 0, flw[2] = {0u, 0u}, elig[2] = {0u, 0u};      // site mask; "ask the per-sample records" mask; pop | ind << 4 and the alleles
                                                                                 // still open to the individual rule, one byte per position
     #pragma unroll
@@ -1091,7 +1104,7 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
             const uint32_t p = p0 + (uint32_t)j, cov = covs[j];
             // mismatching bases are counted bases: no coverage, no allele totals (a stale total can not exist: they are zeroed above)
             if (cov != 0u && p >= vb && p < ve && (int)cov >= min_cov &&
-                (int)(nal[0][j] + nal[1][j] + nal[2][j] + nal[3][j]) >= min_snvs) {                          // call_vC.cpp:547,550
+                (int)(n_of(j, 0) + n_of(j, 1) + n_of(j, 2) + n_of(j, 3)) >= min_snvs) {                          // call_vC.cpp:547,550
                 const uint32_t indx = (ind4w >> (4 * j)) & 15u;
                 const bool unc = (uncb >> j) & 1u;
                 const double lim = (double)(int)cov * min_frac;                // call_vC.cpp:588
@@ -1101,8 +1114,8 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
                 uint32_t pop = 0, ind = 0;
     #pragma unroll
                 for (int x = 0; x < 4; ++x) {
-                    if ((int)nal[x][j] < min_snvs) continue;                   // neither rule can fire (call_vC.cpp:588,593-600)
-                    const bool is_pop = (double)nal[x][j] >= lim, is_ind = (indx >> x) & 1u;
+                    if ((int)n_of(j, x) < min_snvs) continue;                   // neither rule can fire (call_vC.cpp:588,593-600)
+                    const bool is_pop = (double)n_of(j, x) >= lim, is_ind = (indx >> x) & 1u;
                     ok |= is_pop || is_ind || unc;
                     if (lc && rc == (1u << x)) continue;                       // skip-same-base, case-sensitive (call_vC.cpp:580)
                     if (is_pop) pop |= 1u << x; else if (is_ind) ind |= 1u << x;
@@ -1159,7 +1172,7 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
                 if (okm & (1u << j)) {
                     SiteRec s;
                     s.gpos = (uint32_t)(g0 + (uint32_t)j); s.cov = covs[j];
-                    s.n[0] = nal[0][j]; s.n[1] = nal[1][j]; s.n[2] = nal[2][j]; s.n[3] = nal[3][j];
+                    s.n[0] = n_of(j, 0); s.n[1] = n_of(j, 1); s.n[2] = n_of(j, 2); s.n[3] = n_of(j, 3);
                     L.rec[i] = s;
                     L.fl[i] = (uint16_t)(((flw[j >> 2] >> (8 * (j & 3))) & 0xffu) | ((elig[j >> 2] >> (8 * (j & 3))) & 0xffu) << 8);
                     L.unc[i] = (uint8_t)((a.any_split && ((uncm >> j) & 1u)) ? 1u : 0u);
@@ -1201,7 +1214,7 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
                 if (idx < cap_sites) {
                     SiteRec s;
                     s.gpos = (uint32_t)(g0 + (uint32_t)j); s.cov = covs[j];
-                    s.n[0] = nal[0][j]; s.n[1] = nal[1][j]; s.n[2] = nal[2][j]; s.n[3] = nal[3][j];
+                    s.n[0] = n_of(j, 0); s.n[1] = n_of(j, 1); s.n[2] = n_of(j, 2); s.n[3] = n_of(j, 3);
                     sites[idx] = s;
                     if (idx < cap_out) a.site_flags[idx] = (uint8_t)((flw[j >> 2] >> (8 * (j & 3))) & 0xffu);
                     if (idx < cap_out) a.site_elig[idx] = (uint8_t)((elig[j >> 2] >> (8 * (j & 3))) & 0xffu);
@@ -1747,8 +1760,14 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
         g.n_active = d.n_active_tiles;
         g.tiles_per_wg = d.n_active_tiles >= 32768u ? 8u : d.n_active_tiles >= 8192u ? 4u : 1u;
         if (const char *e = getenv("MSNV_GATE_TILES")) g.tiles_per_wg = (uint32_t)std::min<int>((int)GATE_MAX_TILES, std::max(1, atoi(e)));
-        if (g.tiles_per_wg == 1u) hipLaunchKernelGGL(msnv_gate_sites<false>, dim3(d.n_active_tiles), dim3(GATE_NT), 0, st, g);
-        else hipLaunchKernelGGL(msnv_gate_sites<true>, dim3((d.n_active_tiles + g.tiles_per_wg - 1) / g.tiles_per_wg), dim3(GATE_NT), 0, st, g);
+        const dim3 grid((d.n_active_tiles + g.tiles_per_wg - 1) / g.tiles_per_wg);
+        if (g.tiles_per_wg == 1u) {
+            if (d.wide_tot) hipLaunchKernelGGL((msnv_gate_sites<false, true>), grid, dim3(GATE_NT), 0, st, g);
+            else hipLaunchKernelGGL((msnv_gate_sites<false, false>), grid, dim3(GATE_NT), 0, st, g);
+        } else {
+            if (d.wide_tot) hipLaunchKernelGGL((msnv_gate_sites<true, true>), grid, dim3(GATE_NT), 0, st, g);
+            else hipLaunchKernelGGL((msnv_gate_sites<true, false>), grid, dim3(GATE_NT), 0, st, g);
+        }
         HIP_TRY(hipGetLastError());
     } else HIP_TRY(hipMemsetAsync(counters_next, 0, CNT_WORDS * sizeof(uint32_t), st));   // nobody else would
     if (ev3) HIP_TRY(hipEventRecord(ev3, st));

@@ -990,6 +990,8 @@ int finalize_dataset(msnv_dataset &ds) {
         for (uint32_t t : active) gts.push_back(DeviceCols::GateTileH{t, tss[t], t16[t], twide[t], tss[t + 1], vb_host[t], ve_host[t], nslots_host[t], off[tss[t]], tot_mode(t), 0});
         if (int rc = upload_vec(&d->gate_tiles, gts, &d->device_bytes, 1)) return rc;
         d->gather_split = (uint32_t)std::min<uint64_t>(4, std::max<uint64_t>(1, (active.empty() ? 0 : pairs.size() / active.size()) / 32));
+        d->wide_tot = false;
+        for (uint32_t t : active) if (tot_mode(t) == 2u) d->wide_tot = true;
         d->use_dirty = !active.empty() && work.size() < 4 * active.size();       // a sparse cohort: fewer than four work items per tile
     }
     // ---- chunk descriptors of the narrow work items
