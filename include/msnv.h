@@ -123,6 +123,30 @@ typedef struct {
 
 int msnv_call(msnv_ctx *ctx, const msnv_call_args *args);
 
+/* msnv_call_from_mpileup  <-  snpCall -f ref_fasta [-g ann_path] -i out_indiv_path -c -t [-p] < mpileup.txt > out_called_path
+ * (call_vC.cpp:346-410 options, :423-668 main loop): snpCall on its own input, the TEXT `samtools mpileup -f REF -B -b LIST`
+ * writes -- the reference's literal process boundary, for pipelines that already hold pileup text and for
+ * A/B runs against real samtools output.  The text is parsed and called on the device (csrc/textcall.hip): first line = sample
+ * count, never processed (:423-431); toksplit's 10 000-character tokens (:92-111); ^x / +n / -n / * $ N n (:503-535); gates and
+ * calling rule (:545-601); gene / codon annotation with both ann_path and ref_fasta (:448).
+ *   text / text_bytes: the pileup text in memory; or text = NULL and mpileup_path names a file ("-" or NULL: stdin).
+ *   out_indiv_path may be NULL (individual SNVs are then dropped, :653-660).  Of params only min_coverage, calling_threshold and
+ *   min_fraction apply (the mpileup options were spent by whoever wrote the text).
+ *   stats (may be NULL): [0] lines read, [1] samples, [2] called_SNPs lines, [3] indiv_called lines, [4] kernel microseconds,
+ *   [5] text bytes parsed on the device, [6] base-string characters parsed, [7] reserved.
+ * Input the reference crashes on (a pileup symbol outside its ten keys, e.g. '>' '<' from CIGAR N or an IUPAC letter; more samples
+ * in a line than in the first) is MSNV_EDOMAIN and nothing is written. */
+typedef struct {
+    const char *text; uint64_t text_bytes;
+    const char *mpileup_path;
+    const char *ref_fasta;        /* may be NULL without ann_path */
+    const char *ann_path;         /* may be NULL                  */
+    const char *out_called_path;
+    const char *out_indiv_path;   /* may be NULL                  */
+    msnv_params params;
+} msnv_mpileup_args;
+int msnv_call_from_mpileup(msnv_ctx *ctx, const msnv_mpileup_args *args, uint64_t stats[8]);
+
 /* ------------------------------------------------------------------------------------
  * Next row of the path: metaSNV_Filtering.py filter_two
  * (metaSNV_Filtering.py:156-242) -- position filter and allele frequencies of the called

@@ -39,6 +39,11 @@ class CallArgs(C.Structure):
                 ("n_contig_rank_mask", C.c_int32), ("host_threads", C.c_int32), ("params", Params)]
 
 
+class MpileupArgs(C.Structure):
+    _fields_ = [("text", C.c_char_p), ("text_bytes", C.c_uint64), ("mpileup_path", C.c_char_p), ("ref_fasta", C.c_char_p),
+                ("ann_path", C.c_char_p), ("out_called_path", C.c_char_p), ("out_indiv_path", C.c_char_p), ("params", Params)]
+
+
 class RefDesc(C.Structure):
     _fields_ = [("n_contigs", C.c_int32), ("names", C.POINTER(C.c_char_p)), ("lengths", C.POINTER(C.c_int64)),
                 ("seqs", C.POINTER(C.c_char_p)), ("seq_lens", C.POINTER(C.c_int64))]
@@ -108,6 +113,7 @@ SYMBOLS = [
     ("msnv_params_default", None, [P(Params)]),
     ("msnv_coverage", C.c_int, [_vp, P(CovArgs)]),
     ("msnv_call", C.c_int, [_vp, P(CallArgs)]),
+    ("msnv_call_from_mpileup", C.c_int, [_vp, P(MpileupArgs), P(C.c_uint64)]),
     ("msnv_dataset_create", C.c_int, [_vp, P(RefDesc), P(Params), P(_vp)]),
     ("msnv_dataset_create_from_files", C.c_int, [_vp, C.c_char_p, C.c_char_p, P(Params), P(_vp)]),
     ("msnv_dataset_destroy", None, [_vp]),

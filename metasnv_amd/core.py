@@ -306,6 +306,26 @@ def read_bam(path, records=True):
         lib.msnv_bam_data_free(C.byref(d))
 
 
+def call_from_mpileup(ctx, called_path, indiv_path=None, text=None, mpileup_path=None, fasta=None, ann=None, params=None):
+    """snpCall on mpileup TEXT (msnv_call_from_mpileup: `snpCall -f fasta [-g ann] -i indiv_path ... < text > called_path`),
+    parsed and called on the device.  Returns the stats of include/msnv.h as a dict."""
+    a = _lib.MpileupArgs()
+    if text is not None:
+        raw = text if isinstance(text, (bytes, bytearray)) else text.encode("latin-1")
+        a.text = C.c_char_p(bytes(raw)); a.text_bytes = len(raw)
+    elif mpileup_path is not None:
+        a.mpileup_path = mpileup_path.encode()
+    a.ref_fasta = fasta.encode() if fasta else None
+    a.ann_path = ann.encode() if ann else None
+    a.out_called_path = called_path.encode()
+    a.out_indiv_path = indiv_path.encode() if indiv_path else None
+    a.params = params or default_params()
+    st = (C.c_uint64 * 8)()
+    check(lib.msnv_call_from_mpileup(ctx._h, C.byref(a), st))
+    return {"lines": int(st[0]), "samples": int(st[1]), "called_lines": int(st[2]), "indiv_lines": int(st[3]), "kernel_ms": st[4] / 1000.0,
+            "text_bytes": int(st[5]), "base_chars": int(st[6])}
+
+
 def write_bam(path, names, lengths, records, header_text=None, level=1):
     rec = np.ascontiguousarray(records, dtype=np.uint8)
     n = len(names)

@@ -527,6 +527,33 @@ extern "C" int msnv_write_calls_records(const msnv_ref_desc *ref, int32_t n_samp
     return write_calls_text(tmp, called_path, indiv_path, ann, &gene_names);
 }
 
+namespace msnv {
+int text_call(msnv_ctx *ctx, const char *text, uint64_t n_text, const msnv_params &p, const char *ref_fasta, const char *ann_path,
+              const char *called_path, const char *indiv_path, uint64_t stats[8]);
+}
+
+extern "C" int msnv_call_from_mpileup(msnv_ctx *ctx, const msnv_mpileup_args *a, uint64_t stats[8]) {
+    clear_error();
+    if (!ctx || !a || !a->out_called_path) return fail(MSNV_EINVAL, "msnv_call_from_mpileup: NULL argument");
+    if (a->params.min_coverage < 0 || a->params.calling_threshold < 0 || !(a->params.min_fraction >= 0.0)) return fail(MSNV_EINVAL, "negative cutoff in msnv_params");
+    if (a->ann_path && !a->ref_fasta) return fail(MSNV_EINVAL, "annotation needs both the gene table and the FASTA (call_vC.cpp:448)");
+    try {
+        if (a->text) return text_call(ctx, a->text, a->text_bytes, a->params, a->ref_fasta, a->ann_path, a->out_called_path, a->out_indiv_path, stats);
+        // the whole text in memory (a pileup of the benchmark shape is ~3.6 GB; the reference streams it line by line)
+        const bool from_stdin = !a->mpileup_path || !strcmp(a->mpileup_path, "-");
+        FILE *f = from_stdin ? stdin : fopen(a->mpileup_path, "rb");
+        if (!f) return fail(MSNV_EIO, "cannot open %s", a->mpileup_path);
+        std::string buf;
+        std::vector<char> block(16u << 20);
+        size_t n;
+        while ((n = fread(block.data(), 1, block.size(), f)) > 0) buf.append(block.data(), n);
+        const bool bad = ferror(f) != 0;
+        if (!from_stdin) fclose(f);
+        if (bad) return fail(MSNV_EIO, "read error on %s", from_stdin ? "stdin" : a->mpileup_path);
+        return text_call(ctx, buf.data(), buf.size(), a->params, a->ref_fasta, a->ann_path, a->out_called_path, a->out_indiv_path, stats);
+    } catch (const std::exception &e) { return fail(MSNV_ENOMEM, "msnv_call_from_mpileup: %s", e.what()); }
+}
+
 extern "C" int msnv_coverage_run(msnv_dataset *ds, msnv_run_stats *stats) {
     clear_error();
     if (!ds || !ds->finalized) return fail(MSNV_EINVAL, "msnv_coverage_run: dataset is not finalized");

@@ -2,6 +2,8 @@
 //   samtools mpileup -f REF [-l SPLIT] -B -b LIST | snpCall -f REF [-g ANN] -i INDIV -c C -t T [-p P] > CALLED
 // One process, same options (mpileup's -f/-l/-b, snpCall's -f/-g/-i/-c/-t/-p, call_vC.cpp:346-410), population
 // lines on stdout like snpCall.  The mpileup text never exists: BAMs are decoded on the host and counted on the GPU.
+// Without -b it IS snpCall: the same argv, mpileup text on stdin (msnv_call_from_mpileup, parsed and called on the GPU):
+//   samtools mpileup -f REF -B -b LIST | msnv_snpcall -f REF [-g ANN] -i INDIV -c C -t T > CALLED
 // Exit status: 0 ok, > 0 failure (the driver treats v > 0 as fatal, metaSNV.py:212-221).
 #include <cstdio>
 #include <cstdlib>
@@ -13,7 +15,8 @@
 #include "../../../include/msnv.h"
 
 static void usage() {
-    fprintf(stderr, "Usage: msnv_snpcall -f REF.fa -b BAM_LIST [-l SPLIT.bed] [-g ANNOTATION] [-i INDIV_OUT]\n"
+    fprintf(stderr, "Usage: msnv_snpcall [-f REF.fa] [-g ANNOTATION] [-i INDIV_OUT] [-c 4] [-t 4] [-p 0.01] < mpileup > called_SNPs     (snpCall)\n"
+                    "       msnv_snpcall -f REF.fa -b BAM_LIST [-l SPLIT.bed] [-g ANNOTATION] [-i INDIV_OUT]\n"
                     "                    [-c MIN_COVERAGE=4] [-t MIN_SNV_READS=4] [-p MIN_FRACTION=0.01] [-@ HOST_THREADS] > called_SNPs\n");
 }
 
@@ -37,7 +40,24 @@ int main(int argc, char **argv) {
         default: usage(); return 1;                      // snpCall -h prints the usage and fails (:381-384)
         }
     }
-    if (ref.empty() || list.empty() || optind != argc) { usage(); return 1; }
+    if (optind != argc || argc == 1) { usage(); return 1; }      // (no option at all: the usage text, not a silent wait on stdin)
+    if (list.empty()) {                                  // snpCall's own interface: text on stdin; -f is only needed with -g (call_vC.cpp:448)
+        if (!bed.empty()) { fprintf(stderr, "msnv_snpcall: -l selects regions of BAM files (-b); the text on stdin is what it is\n"); return 1; }
+        msnv_ctx *ctx = nullptr;
+        if (msnv_ctx_create(0, &ctx)) { fprintf(stderr, "msnv_snpcall: %s\n", msnv_last_error()); return 1; }
+        msnv_mpileup_args m{};
+        m.mpileup_path = "-";
+        m.ref_fasta = ref.empty() ? nullptr : ref.c_str();
+        m.ann_path = ann.empty() ? nullptr : ann.c_str();
+        m.out_called_path = "/dev/stdout";
+        m.out_indiv_path = indiv.empty() ? nullptr : indiv.c_str();
+        m.params = p;
+        const int rc = msnv_call_from_mpileup(ctx, &m, nullptr);
+        if (rc) fprintf(stderr, "msnv_snpcall: %s\n", msnv_last_error());
+        msnv_ctx_destroy(ctx);
+        return rc;
+    }
+    if (ref.empty()) { usage(); return 1; }
     std::vector<std::string> bams;
     {
         std::ifstream in(list);
