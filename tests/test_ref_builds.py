@@ -140,3 +140,27 @@ def test_product_equals_the_real_pipe(tmp_path):
     cli.main([proj, lst, fa])
     assert open(os.path.join(proj, "snpCaller", "called_SNPs")).read() == want[0]
     assert open(os.path.join(proj, "snpCaller", "indiv_called")).read() == want[1]
+
+
+@pytest.mark.gpu
+@need_samtools
+def test_real_mpileup_text_through_the_text_entry(tmp_path):
+    """Real `samtools mpileup` text into msnv_call_from_mpileup (snpCall's own boundary): the same bytes as the product's BAM path
+    on the same files, and -- when the reference snpCall could be built -- as the reference's on the same text."""
+    from metasnv_amd import core, cli
+    syn, samples = synth_case(n_species=3, contig_len=6000, n_samples=8, mean_cov=12.0, snv_density=0.03, frac_paired=0.5, seed=1001)
+    fa, paths, lst = _write_project(tmp_path, syn, samples)
+    mp = subprocess.run([SAMTOOLS, "mpileup", "-f", fa, "-B", "-b", lst], capture_output=True, timeout=900)
+    assert mp.returncode == 0
+    ctx = core.Context(0)
+    pp, ip = str(tmp_path / "t.called"), str(tmp_path / "t.indiv")
+    core.call_from_mpileup(ctx, pp, ip, text=mp.stdout)
+    ctx.close()
+    proj = str(tmp_path / "proj")
+    cli.main([proj, lst, fa])
+    assert open(pp).read() == open(os.path.join(proj, "snpCaller", "called_SNPs")).read()
+    assert open(ip).read() == open(os.path.join(proj, "snpCaller", "indiv_called")).read()
+    if os.path.exists(REF_SNPCALL):
+        want = _ref_snpcall(mp.stdout.decode(), tmp_path, fasta=fa)
+        assert (open(pp).read(), open(ip).read()) == (want[0], want[1])
+
