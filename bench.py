@@ -112,10 +112,48 @@ def cpu_baseline(sp_kwargs, n_cpu_samples):
     t0 = time.perf_counter()
     pop, ind, n_lines, n_bases = orc.call(syn.names, syn.lengths, syn.seqs, samples)
     dt = time.perf_counter() - t0
-    return {"value": n_bases / dt / 1e9, "unit": "Gbases/s", "cores": 1, "kind": "port",
-            "sample": "first %d of %d samples, all %d contigs: %d pileup bases in %.1f s (mpileup+snpCall restatement, 1 thread)"
-                      % (n_cpu_samples, sp.n_samples, len(syn.names), n_bases, dt),
-            "called_lines": pop.count("\n")}
+    out = {"value": n_bases / dt / 1e9, "unit": "Gbases/s", "cores": 1, "kind": "port",
+           "sample": "first %d of %d samples, all %d contigs: %d pileup bases in %.1f s (mpileup+snpCall restatement, 1 thread)"
+                     % (n_cpu_samples, sp.n_samples, len(syn.names), n_bases, dt),
+           "called_lines": pop.count("\n")}
+    try:
+        out["snpcall_alone"] = snpcall_alone(syn, samples[:32])
+    except Exception as e:                             # the extra must never cost the bench line
+        out["snpcall_alone"] = {"error": repr(e)}
+    return out
+
+
+def snpcall_alone(syn, samples, n_pos=100000):
+    """snpCall ALONE on mpileup text -- the stage BASELINE.md section 2's figure is about: the oracle's restatement of call_vC.cpp on
+    text rendered from a bounded slice (<= 32 samples, the first n_pos positions of contig 0), one thread, as a process reading
+    stdin like the reference; beside it the product's text entry (msnv_call_from_mpileup: the text parsed and called on the
+    device) on the same bytes, and whether the two outputs are identical."""
+    import tempfile
+    import orc
+    from metasnv_amd import core
+    bed = [(0, 0, min(syn.lengths[0], n_pos))]
+    text = orc.mpileup_text(syn.names, syn.lengths, syn.seqs, samples, bed=bed)
+    n_bases = orc.call(syn.names, syn.lengths, syn.seqs, samples, bed=bed)[3]
+    t0 = time.perf_counter()
+    rc, pop, ind, err = orc.snpcall_text(text)
+    dt = time.perf_counter() - t0
+    ctx = core.Context(0)
+    try:
+        with tempfile.TemporaryDirectory() as td:
+            pp, ip = os.path.join(td, "c"), os.path.join(td, "i")
+            core.call_from_mpileup(ctx, pp, ip, text=text)                          # warm-up (allocations, clocks)
+            t0 = time.perf_counter()
+            st = core.call_from_mpileup(ctx, pp, ip, text=text)
+            wall = time.perf_counter() - t0
+            same = rc == 0 and open(pp).read() == pop and open(ip).read() == ind
+    finally:
+        ctx.close()
+    return {"sample": "%d samples x %d positions of contig 0: %.1f MB of mpileup text, %d pileup bases" % (len(samples), bed[0][2], len(text) / 1e6, n_bases),
+            "cpu": {"value": n_bases / dt / 1e9, "unit": "Gbases/s", "cores": 1, "kind": "port", "text_MB_per_s": len(text) / dt / 1e6, "seconds": dt},
+            "device": {"kernel_ms": st["kernel_ms"], "text_GB_per_s_kernel": st["text_bytes"] / max(st["kernel_ms"], 1e-9) / 1e6,
+                       "Gbases_per_s_kernel": n_bases / max(st["kernel_ms"], 1e-9) / 1e6, "wall_s_with_transfer_and_output": wall,
+                       "Gbases_per_s_wall": n_bases / wall / 1e9},
+            "identical_output": bool(same)}
 
 
 def synth_annotation(syn, path, seed=7):
