@@ -156,7 +156,9 @@ int write_calls_text(msnv_dataset &ds, const char *called_path, const char *indi
         head += cname; head.push_back('\t');
         head += (in_gene && gene_names && (size_t)an->gene < gene_names->size()) ? (*gene_names)[(size_t)an->gene] : std::string("-");
         head.push_back('\t');
-        put_u32(head, (uint32_t)s.pos + 1); head.push_back('\t'); head.push_back((char)s.refchar); head.push_back('\t');
+        if (s.pos < -1) { head.push_back('-'); put_u32(head, (uint32_t)(-((int64_t)s.pos + 1))); }     // (text entry only: snpCall prints atol(field) as it is, call_vC.cpp:499,645)
+        else put_u32(head, (uint32_t)(s.pos + 1));
+        head.push_back('\t'); head.push_back((char)s.refchar); head.push_back('\t');
         for (size_t k = 0; k < S; ++k) { if (k) head.push_back('|'); put_u32(head, ss[k].cov); }
         head.push_back('\t');
         if (write) {

@@ -94,6 +94,7 @@ def test_tokeniser_and_base_string_quirks(tmp_path):
         "  c2\t 12\t T\t4\tGGGG\tIIII\t4\tgggg\tIIII\t1\t+\tI\n",          # blanks in front of name, position and reference character; a lone '+'
         "c2\t13x\tAC\t8\tT-0T+T^\tI\t4\t-TTTT\tI\t4\t+9\tI\n",             # atol("13x") = 13; refchar = first character; -0, +<no digits>, '^' last
         "c2\t\t\t4\tTTTT\tI\t4\tTTTT\tI\t1\t.\tI\n",                       # empty position (atol -> 0 -> "0") and empty reference character (NUL)
+        "c2\t-3\tG\t4\tTTTT\tI\t4\tTTTT\tI\t1\t.\tI\n",                     # a negative position is printed as atol read it
     ]
     text = first + "".join(lines)
     pop, ind, st = same_as_oracle(text, tmp_path)
