@@ -65,6 +65,9 @@ extern "C" int msnv_dataset_create(msnv_ctx *ctx, const msnv_ref_desc *ref, cons
     if (P.cov_max < 1 || P.cov_max >= COV_BINS) return fail(MSNV_EINVAL, "cov_max (qaCompute -c) must be in [1, %d], got %d", COV_BINS - 1, P.cov_max);
     if (P.min_coverage < 0 || P.calling_threshold < 0 || P.min_baseq < 0 || P.min_mapq < 0 || P.cov_min_mapq < 0 || P.token_limit < 0 || !(P.min_fraction >= 0.0))
         return fail(MSNV_EINVAL, "negative cutoff in msnv_params");
+    // snpCall -t 0: every allele of every position that passes the gates becomes an individual call (getSum >= 0 holds for every sample,
+    // call_vC.cpp:593-600) -- gigabytes of zero entries the device path has no representation for (its per-sample evidence is sparse)
+    if (P.calling_threshold < 1) return fail(MSNV_EDOMAIN, "calling_threshold (snpCall -t) must be at least 1 (with 0 the reference prints every allele of every covered position)");
     msnv_dataset *ds = new msnv_dataset();
     ds->ctx = ctx;
     ds->params = P;
@@ -302,7 +305,7 @@ extern "C" int msnv_pileup_run(msnv_dataset *ds, msnv_run_stats *stats) {
     msnv_run_stats st{};
     RunCounts c{};
     int rc = dev_run_pipeline(d, ds->params, ds->ctx->stream, &st, &c);
-    for (int attempt = 0; rc == MSNV_ECAPACITY && attempt < 2; ++attempt) {
+    for (int attempt = 0; rc == MSNV_ECAPACITY && attempt < 3; ++attempt) {      // (sparse buffers; whole-tile items sent back to the unfused path)
         // grow the sparse buffers to what the failed pass asked for and run again
         auto grow = [&](void **p, uint32_t &cap, uint32_t need, size_t elem) -> int {
             if (need <= cap) return MSNV_OK;

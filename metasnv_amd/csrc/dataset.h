@@ -46,6 +46,14 @@ struct TilePair { uint32_t sample, read_lo, read_hi, max_depth, blk_lo, nblk, se
                                                                         // max_depth = upper bound of the per-position depth
 // One chunk = up to CHUNK_READS consecutive reads of one (tile, sample) pair, with everything the
 // kernel needs to start loading (no dependent scalar loads on the critical path).
+// Whole-tile work items (sparse cohorts, pack.cpp): ONE merged group holds every pair of the tile, so the workgroup that piles it up
+// has the tile's coverage and allele totals in its LDS bins and applies snpCall's gates and calling rule itself (kernels.hip:
+// fused_tile_gate); what the gate kernel then reads of such a tile is this record list instead of ~19 KB of per-position state.
+constexpr uint32_t STAGE_CAP = 24;           // candidate positions of one tile kept here; a tile with more sends the dataset back to the unfused path
+struct StageRec { uint32_t pos_flags, cov, nword, pad; };      // position in the tile | "ask the per-sample records" << 11 | (pop | ind << 4) << 16 | eligible alleles << 24;
+                                                               // coverage; mismatching A, C, G, T totals, one byte each (< 256: the group's depth bound)
+struct TileStage { uint32_t count, pad[3]; StageRec rec[STAGE_CAP]; };
+constexpr uint32_t WORK_FUSED = 8u;          // WorkItem::part_lo bit: whole-tile item (bit 0: u8 partial row, bits 1-2: allele-total mode)
 constexpr uint32_t MERGE_MAX_PAIRS = 256;    // pairs per merged group of shallow (sample, tile) pairs (pack.cpp; kernels.hip: msnv_pileup_tiles_merged)
 constexpr uint32_t MERGE_MAX_DEPTH = 240;    // their depth bounds add up to at most this (byte bins)
 constexpr int COV_PW = 4;                    // (tile, sample) pairs per wavefront of msnv_coverage_tiles

@@ -84,8 +84,15 @@ struct DeviceCols {
     uint32_t *tile_dirty = nullptr;  // per work item (by the slot of its coverage row), 1 bit per 64 positions of the tile: the item added to the allele totals there
                                      // (set by the pileup kernels, consumed and cleared by the gate)
     uint32_t *unc_sites = nullptr;   // [cap_sites]: sites whose call depends on a split / merged sample's summed counts (msnv_decide_sites)
-    struct GateTileH { uint32_t tile, slot_lo, slot_16, slot_w, slot_hi, vbeg, vend, n_slots; uint64_t row0; uint32_t tot_mode, pad_; } *gate_tiles = nullptr;   // per active tile (kernels.hip: GateTile)
+    struct GateTileH { uint32_t tile, slot_lo, slot_16, slot_w, slot_hi, vbeg, vend, n_slots; uint64_t row0; uint32_t tot_mode, staged; } *gate_tiles = nullptr;   // per active tile (kernels.hip: GateTile)
     unsigned long long *site_row = nullptr;   // per 64 positions: first cell of the first site in them (gate kernel; what an event finds its cell with)
+    GateTileH *gate_tiles_dense = nullptr, *gate_tiles_staged = nullptr;   // gate_tiles without / only the tiles of whole-tile work items (staged: row0 = index of the record list)
+    TileStage *tile_stage = nullptr;   // per active tile (index of its GateTile): candidate records of whole-tile work items
+    uint32_t *tile_stage_idx = nullptr;   // per tile: that index
+    uint32_t  n_groups_solo = 0;     // the last n_groups_solo merged groups are whole-tile groups of ONE pair (no gather needed when the pass is fused)
+    uint32_t  n_work_fused = 0;      // the last n_work_fused merged work items are whole-tile items
+    uint32_t  n_fused_tiles = 0;     // tiles handled by whole-tile work items
+    bool      fuse_disabled = false; // a pass found a tile with more than STAGE_CAP candidates: the dataset runs unfused from then on
     bool      wide_tot = false;      // some tile's allele totals need 32 bits per allele (tot_add mode 2): the gate kernel's wide instantiation
     bool      use_dirty = false;     // sparse cohort (few work items per tile): the gate kernel consults tile_dirty before it reads the allele totals
     uint32_t  gather_split = 4;      // workgroups per tile in the spill gather (fewer for sparse cohorts: a pair or two per tile)
@@ -122,6 +129,7 @@ struct DeviceCols {
     // that the small tail kernels of pass i overlap with the pileup kernel of pass i+1 (allocated on first use)
     struct AltBufs {
         uint32_t *tot = nullptr; uint8_t *part = nullptr; uint8_t *spill = nullptr; Pair32 *events = nullptr, *overflow = nullptr;
+        TileStage *tile_stage = nullptr;
         uint32_t *counters = nullptr; SiteRec *sites = nullptr; uint32_t *tile_site_base = nullptr, *tile_site_cnt = nullptr; unsigned long long *tile_cell_base = nullptr;
         msnv_site_sample *out = nullptr; uint16_t *cov_col = nullptr; uint8_t *site_flags = nullptr, *site_elig = nullptr; uint32_t *ind4 = nullptr, *unc_bits = nullptr, *tile_dirty = nullptr, *unc_sites = nullptr; unsigned long long *site_row = nullptr; unsigned long long *site_bits = nullptr; uint32_t *site_rank = nullptr;
         uint32_t cap_events = 0, cap_overflow = 0, cap_sites = 0, cnt_parity = 0; uint64_t cap_out_sites = 0, cap_cells = 0;
@@ -144,6 +152,7 @@ constexpr uint32_t EV_LISTS = 32, EV_CNT_STRIDE = 16;
 constexpr uint32_t CNT_CELLS = 16 + EV_LISTS * EV_CNT_STRIDE;   // 64-bit: cells of the per-sample records
 constexpr uint32_t CNT_TALLY = CNT_CELLS + 16;                  // 64-bit: population lines | individual lines << 32 (gate kernel's share)
 constexpr uint32_t CNT_UNC = CNT_TALLY + 16;                    // sites left to msnv_decide_sites
+constexpr uint32_t CNT_STAGE = CNT_UNC + 8;                   // a whole-tile work item found more than STAGE_CAP candidate positions
 constexpr uint32_t CNT_WORDS = CNT_UNC + 16;
 
 struct RunCounts { uint32_t n_events, n_overflow, n_sites, err; uint64_t n_cells; };

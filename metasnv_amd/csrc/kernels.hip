@@ -56,6 +56,11 @@ struct PileupArgs {
     uint32_t       *unc_bits;     // 1 bit per position: a sample that was split into several pairs holds the allele (it may reach the threshold only in sum)
     uint32_t       *slot_dirty;   // per work item (by the slot of its coverage row), 1 bit per 64 positions: the item added to the allele totals there
     uint32_t        min_snvs;
+    // whole-tile work items (dataset.h: WORK_FUSED): the gates and the calling rule are applied by the workgroup that piled the tile up
+    uint32_t        n_fused_lo;   // work items from here on are whole-tile items AND the pass uses their record lists (else = the item count)
+    int             min_cov; double min_frac;
+    const uint32_t *ref_lc, *tile_vbeg, *tile_vend, *tile_stage_idx;
+    TileStage      *tile_stage;
 };
 
 // allele index (A,C,G,T -> 0..3) of a one-hot nt16 code, 4 for anything else
@@ -319,7 +324,7 @@ __global__ __launch_bounds__(W_NT) void msnv_pileup_tiles_wide(PileupArgs a) {
     __syncthreads();
     flush_events<WideLds, W_NT, W_EVCAP>(L, a, tid);
 
-    *reinterpret_cast<uint4 *>(a.part + ((uint64_t)w.part_hi << 32 | (w.part_lo & ~7u)) + 4u * W_PPT * tid) = make_uint4(tc[0], tc[1], tc[2], tc[3]);   // u32 row
+    *reinterpret_cast<uint4 *>(a.part + ((uint64_t)w.part_hi << 32 | (w.part_lo & ~15u)) + 4u * W_PPT * tid) = make_uint4(tc[0], tc[1], tc[2], tc[3]);   // u32 row
     bool any_allele = false;
 #pragma unroll
     for (int j = 0; j < W_PPT; ++j) {
@@ -385,7 +390,7 @@ struct NarrowLds {
 // positions -- coverage and allele counts -- from the pieces themselves (gather_merged_block), so the pass only adds the group to
 // the running totals and the allele totals, marks positions where one sample MIGHT hold >= min_snvs reads of an allele (the
 // calling rule then reads the summed per-sample records), and leaves every bin zero.
-template <typename LDS, int EXC_PAD, bool MERGED = false>
+template <typename LDS, int EXC_PAD, bool MERGED = false, bool FUSED = false>
 __device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_t (&tc)[N_PPT / 2], bool &dirty, const uint32_t t0,
                                             const int tid, const int lane, const int wave, const uint32_t sample, const uint32_t k,
                                             const uint32_t split, const uint32_t tmode) {
@@ -410,6 +415,10 @@ __device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_
     tc[0] += c0 & 0x00ff00ffu; tc[1] += (c0 >> 8) & 0x00ff00ffu;   // running totals, two u16 per register: positions (0,2) (1,3) (4,6) (5,7)
     tc[2] += c1 & 0x00ff00ffu; tc[3] += (c1 >> 8) & 0x00ff00ffu;
     if (!MERGED) *reinterpret_cast<uint2 *>(a.spill + (uint64_t)k * TILE + N_PPT * tid) = make_uint2(c0, c1);
+    if (MERGED && FUSED) {                                      // whole-tile item: this group is the tile.  Its coverage bytes wait in the (zeroed) start bins,
+        *reinterpret_cast<uint2 *>(&L.start[2 * tid]) = make_uint2(c0, c1);      // its allele totals stay in L.al, for fused_tile_gate behind the last barrier
+        return;
+    }
     // ---- allele events.  The allele bins are only looked at here, and word by word again when events are written: the
     // registers of the next chunk's column loads are live across this pass.
     uint32_t pm = 0, myev;                                   // positions of mine with a mismatching allele; (position, allele) events
@@ -478,7 +487,7 @@ __device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_
 // This item's coverage partial: 8 positions per thread, u8 when the host bounded the item's summed depth below 256 (bit 0 of
 // part_lo), else u16 (an item holds <= 32 pairs of depth < 255).  tc: u16 pairs for positions (0,2) (1,3) (4,6) (5,7).
 __device__ __forceinline__ void store_part_row(uint8_t *part, const WorkItem &w, const uint32_t (&tc)[N_PPT / 2], const int tid) {
-    uint8_t *row = part + ((uint64_t)w.part_hi << 32 | (w.part_lo & ~7u));
+    uint8_t *row = part + ((uint64_t)w.part_hi << 32 | (w.part_lo & ~15u));
     if (w.part_lo & 1u) {
         const uint32_t lo = (tc[0] & 0xffu) | (tc[1] & 0xffu) << 8 | (tc[0] >> 16 & 0xffu) << 16 | (tc[1] >> 16) << 24;
         const uint32_t hi = (tc[2] & 0xffu) | (tc[3] & 0xffu) << 8 | (tc[2] >> 16 & 0xffu) << 16 | (tc[3] >> 16) << 24;
@@ -567,7 +576,59 @@ __device__ __forceinline__ void narrow_classify32(NarrowLds &L, const uint4 qa, 
     }
 }
 
-template <bool MERGED>
+// Whole-tile work item (dataset.h): the single merged group of the item held every pair of the tile, so behind the last barrier the
+// start bins hold the tile's coverage bytes and L.al its mismatching A / C / G / T totals (narrow_pass).  snpCall's gates
+// (call_vC.cpp:545-552) and calling rule (:577-601) exactly as msnv_gate_sites applies them to a tile of merged pairs -- no pair
+// can be credited with the individual rule here, every allele with >= t reads that is not a population call is left to the merged
+// gather ("ask" + eligible alleles) -- and the candidates go to the tile's record list: the gate kernel reads that list instead of
+// the tile's per-position state (4 B totals + partial row + rule bits + reference: ~19 KB a tile, as much as the reads themselves
+// in a sparse cohort).
+struct FusedGateArgs { TileStage *st; const uint32_t *ref_lc; uint32_t *counters; uint32_t vb, ve, min_snvs; int min_cov; double min_frac; uint32_t solo; };
+__device__ __attribute__((noinline)) void fused_tile_gate(NarrowLds &L, const FusedGateArgs a, const uint32_t t0, const bool any, const int tid) {
+    // (not inlined: the hot loop of the kernel sits exactly at the 72-register step of 7 workgroups per CU)
+    TileStage *const st = a.st;
+    // (L.evn counts the candidates: merged items stage no events)
+    if (any) {
+        const uint2 cv = *reinterpret_cast<uint2 *>(&L.start[2 * tid]);
+        const uint4 a0 = *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid]);
+        const uint4 a1 = *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid + 4]);
+        const uint32_t alw[N_PPT] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        const uint32_t refw = L.ref[tid];                                        // nt16 codes of my 8 positions
+        const uint32_t lcb = reinterpret_cast<const uint8_t *>(a.ref_lc)[(t0 >> 3) + (uint32_t)tid];
+        const uint32_t vb = a.vb, ve = a.ve;
+#pragma unroll
+        for (int j = 0; j < N_PPT; ++j) {
+            const uint32_t cov = ((j < 4 ? cv.x : cv.y) >> (8 * (j & 3))) & 0xffu, word = alw[j], p = (uint32_t)(N_PPT * tid + j);
+            const uint32_t n[4] = {word & 0xffu, (word >> 8) & 0xffu, (word >> 16) & 0xffu, word >> 24};
+            if (cov == 0u || p < vb || p >= ve || (int)cov < a.min_cov || (int)(n[0] + n[1] + n[2] + n[3]) < (int)a.min_snvs) continue;
+            const double lim = (double)(int)cov * a.min_frac;                     // call_vC.cpp:588
+            const uint32_t rc = (refw >> (4 * j)) & 15u;
+            const bool lc = (lcb >> j) & 1u;
+            bool ok = false;
+            uint32_t pop = 0, ind = 0, elig = 0;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                if ((int)n[x] < (int)a.min_snvs) continue;
+                const bool is_pop = (double)n[x] >= lim;
+                ok = true;                                                        // population call, or some sample may hold >= t reads: the gather decides
+                if (lc && rc == (1u << x)) continue;                              // skip-same-base, case-sensitive (call_vC.cpp:580)
+                if (is_pop) pop |= 1u << x;
+                else if (a.solo) ind |= 1u << x;                                  // the tile's only sample holds them all: the individual rule, decided (call_vC.cpp:593-600)
+                else elig |= 1u << x;
+            }
+            if (!ok) continue;
+            const uint32_t slot = atomicAdd(&L.evn, 1u);
+            if (slot < STAGE_CAP) st->rec[slot] = StageRec{p | (elig ? 1u << 11 : 0u) | (pop | ind << 4) << 16 | elig << 24, cov, word, 0u};
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        st->count = L.evn;
+        if (L.evn > STAGE_CAP) atomicOr(&a.counters[CNT_STAGE], 1u);             // the host runs the pass again, unfused
+    }
+}
+
+template <bool MERGED, bool FUSED = false>
 __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a, NarrowLds &L) {
     ev_list(a);
     const WorkItem w = a.work[blockIdx.x];
@@ -589,6 +650,7 @@ __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a, NarrowL
     bool dirty = false;                                         // some pass of this item added to the allele totals of my 8 positions
 
     const uint32_t nch = w.chunk_hi - w.chunk_lo;
+    constexpr bool fused = MERGED && FUSED;                       // (a compile-time fact: a run-time flag here costs the kernel its 72-register step)
     // the chunk descriptors go through a ring of MAX_CHUNKS_PER_ITEM LDS slots: one deep (sample, tile) pair alone can
     // hold more chunks than that, so half of the ring is refilled every MAX_CHUNKS_PER_ITEM / 2 chunks (desc_refill)
     // the headers of chunk 0 do not wait for the descriptor stream: their descriptor came with the work item
@@ -659,10 +721,15 @@ __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a, NarrowL
         hreg = load_hdr(c + 2u);
         __syncthreads();                                            // (B): this chunk is in the bins; the next chunk's headers are visible
         if (c + 1u < nch) issue_loads(c + 1u);                       // in flight under the per-sample pass
-        if (last_chunk) narrow_pass<NarrowLds, 0, MERGED>(L, a, tc, dirty, t0, tid, lane, wave, cd.sample, cd.pair, cd.pad, tot_mode_of(w));
+        if (last_chunk) narrow_pass<NarrowLds, 0, MERGED, fused>(L, a, tc, dirty, t0, tid, lane, wave, cd.sample, cd.pair, cd.pad, tot_mode_of(w));
         prev_last = last_chunk;
     }
     __syncthreads();
+    if (MERGED && fused) {
+        const FusedGateArgs fa{a.tile_stage + a.tile_stage_idx[w.tile], a.ref_lc, a.counters, a.tile_vbeg[w.tile], a.tile_vend[w.tile], a.min_snvs, a.min_cov, a.min_frac, w.pair_hi - w.pair_lo == 1u ? 1u : 0u};
+        fused_tile_gate(L, fa, t0, nch != 0u, tid);
+        return;
+    }
     if (!MERGED) flush_events<NarrowLds, N_NT, N_EVCAP>(L, a, tid);
     store_part_row(a.part, w, tc, tid);
     store_item_dirty(a.slot_dirty, w, dirty, tid);
@@ -676,7 +743,8 @@ __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a, NarrowL
 __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32(PileupArgs a) {
     __shared__ NarrowLds L;                                     // ONE instance for both kinds of work item (7 workgroups per CU)
     if (blockIdx.x < a.n_narrow) pileup_tiles_narrow32_body<false>(a, L);
-    else { a.hdr8 = a.hdr8m; pileup_tiles_narrow32_body<true>(a, L); }
+    else if (blockIdx.x < a.n_fused_lo) { a.hdr8 = a.hdr8m; pileup_tiles_narrow32_body<true>(a, L); }
+    else { a.hdr8 = a.hdr8m; pileup_tiles_narrow32_body<true, true>(a, L); }      // whole-tile items (the last ones; none when the pass runs unfused)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -866,7 +934,7 @@ __device__ __forceinline__ uint64_t cell_of(const CellMap &m, const uint32_t til
     return m.tile_cell_base[tile] + (uint64_t)(site - m.tile_site_base[tile]) * m.tile_nslots[tile] + slot;
 }
 
-struct GateTile { uint32_t tile, slot_lo, slot_16, slot_w, slot_hi, vbeg, vend, n_slots; uint64_t row0; uint32_t tot_mode, pad_; };   // 48 B (pack.cpp)
+struct GateTile { uint32_t tile, slot_lo, slot_16, slot_w, slot_hi, vbeg, vend, n_slots; uint64_t row0; uint32_t tot_mode, staged; };   // 48 B (pack.cpp); staged: a whole-tile work item leaves the tile's candidates in a record list
 
 struct GateArgs {
     uint32_t *tot; const uint8_t *part; const uint64_t *slot_off; const uint32_t *tile_slot_start, *tile_slot_u16, *tile_slot_wide; uint64_t npos;
@@ -880,6 +948,8 @@ struct GateArgs {
     const GateTile *gate_tiles; uint32_t *tile_dirty; uint32_t *unc_sites; uint32_t use_dirty; unsigned long long *block_row;
     uint8_t *site_elig; uint32_t any_split;
     uint32_t n_active, tiles_per_wg;           // active tiles; consecutive ones per workgroup (<= GATE_MAX_TILES)
+    const TileStage *tile_stage;               // record lists of the whole-tile work items (msnv_gate_staged)
+    uint32_t zero_next;                        // this launch zeroes the counter block of the next pass (one of the two gate kernels does)
 };
 
 // Site slots and per-sample cells are handed out with returning atomics on two device-wide counters, and same-address atomics are
@@ -960,7 +1030,7 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
     const uint32_t p0 = (uint32_t)GATE_PPT * (uint32_t)tid;    // my positions of every tile: p0 .. p0 + 7
     if (tid == 0) { L.pop = 0; L.ind = 0; }
     // the counter block of the NEXT pass (the passes of a dataset alternate between two blocks: no memset between passes)
-    if (blockIdx.x == 0) for (uint32_t i = threadIdx.x; i < CNT_WORDS; i += GATE_NT) a.counters_next[i] = 0u;
+    if (blockIdx.x == 0 && a.zero_next) for (uint32_t i = threadIdx.x; i < CNT_WORDS; i += GATE_NT) a.counters_next[i] = 0u;
     const uint32_t ti_lo = MULTI ? blockIdx.x * a.tiles_per_wg : blockIdx.x, ti_hi = MULTI ? min(a.n_active, ti_lo + a.tiles_per_wg) : ti_lo + 1u;
     uint32_t st_tiles = 0, st_sites = 0; unsigned long long st_cells = 0;      // staged so far (uniform)
     // everything the workgroup needs to know about a tile in ONE load (the kernel is a chain of dependent loads; with a sparse
@@ -1231,6 +1301,115 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
     gate_flush(L, a, st_tiles, st_sites, st_cells, tid);
     __syncthreads();
     if (tid == 0 && (L.pop | L.ind)) atomicAdd(reinterpret_cast<unsigned long long *>(&counters[CNT_TALLY]), (unsigned long long)L.pop | (unsigned long long)L.ind << 32);
+}
+
+// ------------------------------------------------------------------------------------------
+// msnv_gate_staged: the gate kernel's part for tiles piled up by whole-tile work items (fused_tile_gate): their candidates arrive as
+// records with the decision taken, so what is left is the bookkeeping msnv_gate_sites does behind its decision -- site slots and
+// cells, site bitmap, per-block ranks, site records -- and none of it needs a workgroup: ONE WAVEFRONT takes GS_TILES consecutive
+// tiles, reads their record counts (known before anything is computed: one reservation for all of them, no same-address atomic
+// per tile), then walks the tiles: lane q holds record q, its rank among the tile's records is its site; lanes 0-31 build the
+// 32 bitmap words and the per-block site ranks from the same loop over the records.  A tile with ONE pair gets its per-sample
+// cell written right here (the cell is the tile's totals), so the merged gather is not launched for it.
+// (the same tiles through msnv_gate_sites, reading records instead of per-position state: 0.38 ms for 85 k tiles -- three
+// workgroup barriers and a 127-register kernel per handful of records)
+// ------------------------------------------------------------------------------------------
+constexpr int GS_TILES = 16;                   // tiles per wavefront; a workgroup of four wavefronts reserves ONCE for its 64 tiles
+__global__ __launch_bounds__(256) void msnv_gate_staged(const GateArgs a, const GateTile *__restrict__ tiles, const uint32_t n_tiles) {
+    __shared__ uint32_t s_sites[4]; __shared__ unsigned long long s_cells[4];
+    __shared__ uint32_t s_base, s_np, s_ni; __shared__ unsigned long long s_cb;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t w0 = (blockIdx.x * 4u + (uint32_t)wave) * (uint32_t)GS_TILES;
+    if (blockIdx.x == 0 && a.zero_next) for (uint32_t i = threadIdx.x; i < CNT_WORDS; i += 256) a.counters_next[i] = 0u;
+    if (threadIdx.x == 0) { s_np = 0; s_ni = 0; }
+    const uint32_t n_here = w0 < n_tiles ? min((uint32_t)GS_TILES, n_tiles - w0) : 0u;
+    // lanes 0 .. n_here - 1: one tile each
+    GateTile gt{};
+    uint32_t cnt = 0;
+    if ((uint32_t)lane < n_here) { gt = tiles[w0 + (uint32_t)lane]; cnt = min(a.tile_stage[gt.row0].count, STAGE_CAP); }
+    const unsigned long long cells = (unsigned long long)cnt * gt.n_slots;
+    uint32_t site_rel = cnt; unsigned long long cell_rel = cells;
+#pragma unroll
+    for (int o = 1; o < GS_TILES; o <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)site_rel, o); const unsigned long long u = (unsigned long long)__shfl_up((long long)cell_rel, o);
+        if (lane >= o) { site_rel += t; cell_rel += u; }
+    }
+    const uint32_t tot_sites = (uint32_t)__shfl((int)site_rel, GS_TILES - 1); const unsigned long long tot_cells = (unsigned long long)__shfl((long long)cell_rel, GS_TILES - 1);      // (lanes behind n_here hold zeros: the prefix stays)
+    site_rel -= cnt; cell_rel -= cells;                               // exclusive
+    // one reservation per workgroup: same-address returning atomics are served one after the other (~6 ns each: one per wavefront of
+    // 8 tiles was 140 us of this kernel's 290)
+    if (lane == 0) { s_sites[wave] = tot_sites; s_cells[wave] = tot_cells; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t ts = s_sites[0] + s_sites[1] + s_sites[2] + s_sites[3];
+        const unsigned long long tc = s_cells[0] + s_cells[1] + s_cells[2] + s_cells[3];
+        s_base = ts ? atomicAdd(&a.counters[2], ts) : 0u;
+        s_cb = ts ? atomicAdd(reinterpret_cast<unsigned long long *>(&a.counters[CNT_CELLS]), tc) : 0ull;
+    }
+    __syncthreads();
+    uint32_t base = s_base; unsigned long long cb = s_cb;
+    uint32_t wg_sites = 0; unsigned long long wg_cells = 0;
+    for (int k = 0; k < 4; ++k) { if (k < wave) { base += s_sites[k]; cb += s_cells[k]; } wg_sites += s_sites[k]; wg_cells += s_cells[k]; }
+    if ((uint32_t)lane < n_here) { a.tile_site_base[gt.tile] = cnt ? base + site_rel : 0u; a.tile_site_cnt[gt.tile] = cnt; a.tile_cell_base[gt.tile] = cnt ? cb + cell_rel : 0ull; }
+    const bool fits = (unsigned long long)s_base + wg_sites <= a.cap_out && s_cb + wg_cells <= a.cap_cells;   // else: the host sees the counts and runs again with larger buffers
+    uint32_t np = 0, ni = 0;
+    for (uint32_t t = 0; t < n_here; ++t) {
+        const uint32_t tile = (uint32_t)__shfl((int)gt.tile, (int)t), n = (uint32_t)__shfl((int)cnt, (int)t), n_slots = (uint32_t)__shfl((int)gt.n_slots, (int)t);
+        const uint32_t kind = (uint32_t)__shfl((int)gt.staged, (int)t), srel = (uint32_t)__shfl((int)site_rel, (int)t);
+        const unsigned long long crel = (unsigned long long)__shfl((long long)cell_rel, (int)t), sidx = (unsigned long long)__shfl((long long)gt.row0, (int)t);
+        StageRec r{0xffffffffu, 0u, 0u, 0u};
+        if ((uint32_t)lane < n) r = a.tile_stage[sidx].rec[lane];
+        const uint32_t pos = r.pos_flags & (TILE - 1u);
+        uint32_t rank = 0, before = 0; unsigned long long word = 0;      // my record's rank; (lanes 0-31) records in front of my 64 positions, my bitmap word
+        for (uint32_t q = 0; q < n; ++q) {
+            const uint32_t pq = (uint32_t)__shfl((int)pos, (int)q);
+            rank += pq < pos ? 1u : 0u;
+            before += pq < 64u * (uint32_t)lane ? 1u : 0u;
+            if ((pq >> 6) == (uint32_t)lane) word |= 1ull << (pq & 63u);
+        }
+        if (lane < (int)(TILE / 64)) {
+            a.site_bits[(uint64_t)tile * (TILE / 64) + lane] = word;
+            if (n) {
+                a.site_rank[(uint64_t)tile * (TILE / 64) + lane] = base + srel + before;
+                a.block_row[(uint64_t)tile * (TILE / 64) + lane] = cb + crel + (unsigned long long)before * n_slots;
+            }
+        }
+        if ((uint32_t)lane < n) {
+            const uint32_t fl = (r.pos_flags >> 16) & 0xffu, el = r.pos_flags >> 24;
+            const bool ask = (r.pos_flags >> 11) & 1u;
+            if (!(a.any_split && ask)) { np += (fl & 15u) ? 1u : 0u; ni += (fl >> 4) ? 1u : 0u; }      // (those sites are tallied by msnv_decide_sites)
+            const uint32_t idx = base + srel + rank;
+            if (idx < a.cap_sites) {
+                SiteRec sr;
+                sr.gpos = tile * TILE + pos; sr.cov = r.cov;
+                sr.n[0] = r.nword & 0xffu; sr.n[1] = (r.nword >> 8) & 0xffu; sr.n[2] = (r.nword >> 16) & 0xffu; sr.n[3] = r.nword >> 24;
+                a.sites[idx] = sr;
+                if (idx < a.cap_out) { a.site_flags[idx] = (uint8_t)fl; a.site_elig[idx] = (uint8_t)el; }
+                if (a.any_split && ask) {
+                    const uint32_t u = atomicAdd(&a.counters[CNT_UNC], 1u);
+                    if (u < a.cap_sites) a.unc_sites[u] = idx;
+                }
+                if (kind == 2u && fits) {                              // the tile's only pair: its cell is the tile's totals
+                    msnv_site_sample c;
+                    c.cov = 0; c.n[0] = (uint16_t)sr.n[0]; c.n[1] = (uint16_t)sr.n[1]; c.n[2] = (uint16_t)sr.n[2]; c.n[3] = (uint16_t)sr.n[3];
+                    a.out[cb + crel + rank] = c;
+                    a.cov_col[cb + crel + rank] = (uint16_t)r.cov;
+                }
+            }
+        }
+        if (kind != 2u && fits && n) {                                  // the per-sample cells of these sites start out zero (gather / scatter only add to them)
+            const unsigned long long n_cells = (unsigned long long)n * n_slots;
+            uint16_t *rows = reinterpret_cast<uint16_t *>(a.out + cb + crel);
+            for (unsigned long long i = (unsigned long long)lane; i < n_cells * (sizeof(msnv_site_sample) / 2); i += 64) rows[i] = 0;
+            uint16_t *crow = a.cov_col + cb + crel;
+            for (unsigned long long i = (unsigned long long)lane; i < n_cells; i += 64) crow[i] = 0;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { np += (uint32_t)__shfl_xor((int)np, o); ni += (uint32_t)__shfl_xor((int)ni, o); }
+    if (lane == 0 && (np | ni)) { atomicAdd(&s_np, np); atomicAdd(&s_ni, ni); }
+    __syncthreads();
+    if (threadIdx.x == 0 && (s_np | s_ni)) atomicAdd(reinterpret_cast<unsigned long long *>(&a.counters[CNT_TALLY]), (unsigned long long)s_np | (unsigned long long)s_ni << 32);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1671,7 +1850,7 @@ void dev_free_all(DeviceCols &d) {
     void *ptrs[] = {d.hdr, d.hdr8, d.hdr8m, d.merged_groups, d.tile_pair_merged, d.blk, d.seq, d.qual, d.s_read_base, d.s_seq_base, d.ref4, d.ref_lc, d.pairs,
                     d.tile_pair_start, d.work, d.chunks, d.tile_vbeg, d.tile_vend, d.tot, d.part, d.tile_slot_start, d.tile_slot_u16, d.tile_slot_wide, d.slot_off, d.spill, d.events, d.overflow, d.counters, d.ind4, d.tile_dirty, d.unc_sites, d.site_row, d.gate_tiles,
                     d.sites, d.tile_site_base, d.tile_site_cnt, d.tile_cell_base, d.tile_nslots, d.out, d.cov_col, d.site_flags, d.site_elig,
-                    d.cov_iv, d.s_cov_base, d.cov_pairs, d.cov_work, d.tile_len, d.tile_contig_dev, d.cov_acc};
+                    d.cov_iv, d.s_cov_base, d.cov_pairs, d.cov_work, d.tile_len, d.tile_contig_dev, d.cov_acc, d.tile_stage, d.tile_stage_idx, d.alt.tile_stage, d.gate_tiles_dense, d.gate_tiles_staged};
     for (void *p : ptrs) dev_free(p);
     void *aptrs[] = {d.ann.seg_beg, d.ann.seg_end, d.ann.seg_gene, d.ann.genes, d.ann.contigs, d.ann.codons, d.ann.out, d.ann.err};
     for (void *p : aptrs) dev_free(p);
@@ -1717,6 +1896,9 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
     uint32_t *const counters = d.counters + d.cnt_parity * CNT_WORDS, *const counters_next = d.counters + (d.cnt_parity ^ 1u) * CNT_WORDS;
     d.cnt_parity ^= 1u;
     if (wait_before_pileup) HIP_TRY(hipStreamWaitEvent(st, wait_before_pileup, 0));   // the previous pass' pileup kernel (other stream)
+    // whole-tile work items apply the gates themselves (fused_tile_gate) unless a pass found a tile with too many candidates (check_counts);
+    // with a calling threshold below 1 every covered position is a candidate and the unfused path is the one that is defined for it
+    const uint32_t use_stage = (d.n_fused_tiles && !d.fuse_disabled && p.calling_threshold >= 1) ? 1u : 0u;
     HIP_TRY(hipEventRecord(ev_pile0, st));
     if (d.n_work) {
         PileupArgs a;
@@ -1726,6 +1908,8 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
         a.events = d.events; a.cap_events = d.cap_events / EV_LISTS; a.ev_count = nullptr; a.overflow = d.overflow; a.cap_overflow = d.cap_overflow;
         a.counters = counters; a.min_baseq = (uint32_t)std::max(0, p.min_baseq);
         a.ind4 = d.ind4; a.unc_bits = d.unc_bits; a.slot_dirty = d.tile_dirty; a.min_snvs = (uint32_t)std::max(0, p.calling_threshold);
+        a.n_fused_lo = d.n_work_narrow + d.n_work_merged - (use_stage ? d.n_work_fused : 0u); a.min_cov = p.min_coverage; a.min_frac = p.min_fraction; a.ref_lc = d.ref_lc; a.tile_vbeg = d.tile_vbeg; a.tile_vend = d.tile_vend;
+        a.tile_stage = d.tile_stage; a.tile_stage_idx = d.tile_stage_idx;
         const uint32_t n_narrow = d.n_work_narrow, n_merged = d.n_work_merged;
         // narrow work items (byte bins), merged groups of shallow pairs and wide items (16-bit bins) touch disjoint (tile, sample) pairs
         a.hdr8m = d.hdr8m; a.n_narrow = n_narrow;
@@ -1757,17 +1941,26 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
         g.tile_nslots = d.tile_nslots; g.tile_cell_base = d.tile_cell_base; g.cap_cells = d.cap_cells;
         // several tiles per workgroup once the tiles outnumber what the device holds at a time several times over (one reservation of
         // site slots per workgroup: msnv_gate_sites); MSNV_GATE_TILES overrides (tests run every size)
-        g.n_active = d.n_active_tiles;
-        g.tiles_per_wg = d.n_active_tiles >= 32768u ? 8u : d.n_active_tiles >= 8192u ? 4u : 1u;
-        if (const char *e = getenv("MSNV_GATE_TILES")) g.tiles_per_wg = (uint32_t)std::min<int>((int)GATE_MAX_TILES, std::max(1, atoi(e)));
-        const dim3 grid((d.n_active_tiles + g.tiles_per_wg - 1) / g.tiles_per_wg);
-        if (g.tiles_per_wg == 1u) {
-            if (d.wide_tot) hipLaunchKernelGGL((msnv_gate_sites<false, true>), grid, dim3(GATE_NT), 0, st, g);
-            else hipLaunchKernelGGL((msnv_gate_sites<false, false>), grid, dim3(GATE_NT), 0, st, g);
-        } else {
-            if (d.wide_tot) hipLaunchKernelGGL((msnv_gate_sites<true, true>), grid, dim3(GATE_NT), 0, st, g);
-            else hipLaunchKernelGGL((msnv_gate_sites<true, false>), grid, dim3(GATE_NT), 0, st, g);
+        g.tile_stage = d.tile_stage; g.tiles_per_wg = 1u;
+        // whole-tile work items left record lists: their tiles go through msnv_gate_staged, the others through msnv_gate_sites
+        const uint32_t n_staged = use_stage ? d.n_fused_tiles : 0u, n_dense = d.n_active_tiles - n_staged;
+        if (use_stage) g.gate_tiles = reinterpret_cast<const GateTile *>(d.gate_tiles_dense);
+        g.n_active = n_dense;
+        g.zero_next = 1u;
+        if (n_dense) {
+            g.tiles_per_wg = n_dense >= 32768u ? 8u : n_dense >= 8192u ? 4u : 1u;
+            if (const char *e = getenv("MSNV_GATE_TILES")) g.tiles_per_wg = (uint32_t)std::min<int>((int)GATE_MAX_TILES, std::max(1, atoi(e)));
+            const dim3 grid((n_dense + g.tiles_per_wg - 1) / g.tiles_per_wg);
+            if (g.tiles_per_wg == 1u) {
+                if (d.wide_tot) hipLaunchKernelGGL((msnv_gate_sites<false, true>), grid, dim3(GATE_NT), 0, st, g);
+                else hipLaunchKernelGGL((msnv_gate_sites<false, false>), grid, dim3(GATE_NT), 0, st, g);
+            } else {
+                if (d.wide_tot) hipLaunchKernelGGL((msnv_gate_sites<true, true>), grid, dim3(GATE_NT), 0, st, g);
+                else hipLaunchKernelGGL((msnv_gate_sites<true, false>), grid, dim3(GATE_NT), 0, st, g);
+            }
+            g.zero_next = 0u;
         }
+        if (n_staged) hipLaunchKernelGGL(msnv_gate_staged, dim3((n_staged + 4 * GS_TILES - 1) / (4 * GS_TILES)), dim3(256), 0, st, g, reinterpret_cast<const GateTile *>(d.gate_tiles_staged), n_staged);
         HIP_TRY(hipGetLastError());
     } else HIP_TRY(hipMemsetAsync(counters_next, 0, CNT_WORDS * sizeof(uint32_t), st));   // nobody else would
     if (ev3) HIP_TRY(hipEventRecord(ev3, st));
@@ -1780,7 +1973,7 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
         ta.gather_split = d.gather_split;
         ta.n_gather_blocks = d.n_active_tiles * d.gather_split;
         ta.tile_pair_merged = d.tile_pair_merged; ta.merged_groups = d.merged_groups; ta.chunks = d.chunks; ta.hdr8m = d.hdr8m;
-        ta.seq = d.seq; ta.qual = d.qual; ta.ref4 = d.ref4; ta.n_merged_blocks = d.n_merged_groups; ta.min_baseq = (uint32_t)std::max(0, p.min_baseq);
+        ta.seq = d.seq; ta.qual = d.qual; ta.ref4 = d.ref4; ta.n_merged_blocks = d.n_merged_groups - (use_stage ? d.n_groups_solo : 0u); ta.min_baseq = (uint32_t)std::max(0, p.min_baseq);
         ta.site_flags = d.site_flags; ta.site_elig = d.site_elig; ta.ind_in_gather = d.any_split ? 0u : 1u; ta.min_snvs = (uint32_t)std::max(1, p.calling_threshold);
         ta.events = d.events; ta.overflow = d.overflow; ta.counters = counters; ta.cap_list = d.cap_events / EV_LISTS; ta.cap_overflow = d.cap_overflow;
         ta.site_bits = d.site_bits; ta.site_rank = d.site_rank;
@@ -1803,6 +1996,10 @@ static int check_counts(DeviceCols &d, const uint32_t *cnt, RunCounts *counts) {
     RunCounts c{cnt[0], cnt[1], cnt[2], cnt[3], (uint64_t)cnt[CNT_CELLS] | (uint64_t)cnt[CNT_CELLS + 1] << 32};
     d.last_sites = c.n_sites; d.last_cells = c.n_cells;
     if (counts) *counts = c;
+    if (cnt[CNT_STAGE]) {                                      // a tile with more candidates than a record list holds: the pass is run again, unfused
+        d.fuse_disabled = true;
+        return fail_quiet(MSNV_ECAPACITY, "a whole-tile work item found more than %u candidate positions", STAGE_CAP);
+    }
     if (c.n_events > d.cap_events / EV_LISTS * EV_LISTS || c.n_overflow > d.cap_overflow || c.n_sites > d.cap_sites || c.n_sites > d.cap_out_sites || c.n_cells > d.cap_cells)
         return fail_quiet(MSNV_ECAPACITY, "device buffer too small: events %u/%u overflow %u/%u sites %u/%u out %u/%llu cells %llu/%llu",
                           c.n_events, d.cap_events, c.n_overflow, d.cap_overflow, c.n_sites, d.cap_sites, c.n_sites,
@@ -1847,7 +2044,7 @@ static int ensure_alt(DeviceCols &d) {
     DeviceCols::AltBufs &a = d.alt;
     const uint64_t npos = (uint64_t)d.n_tiles * TILE;
     if (a.tot && a.cap_events == d.cap_events && a.cap_overflow == d.cap_overflow && a.cap_sites == d.cap_sites && a.cap_out_sites == d.cap_out_sites && a.cap_cells == d.cap_cells) return MSNV_OK;
-    void *old[] = {a.tot, a.part, a.spill, a.events, a.overflow, a.counters, a.ind4, a.tile_dirty, a.unc_sites, a.site_row, a.sites, a.tile_site_base, a.tile_site_cnt, a.tile_cell_base, a.out, a.cov_col, a.site_flags, a.site_elig, a.site_bits, a.site_rank};
+    void *old[] = {a.tot, a.part, a.spill, a.events, a.overflow, a.counters, a.ind4, a.tile_dirty, a.unc_sites, a.site_row, a.sites, a.tile_site_base, a.tile_site_cnt, a.tile_cell_base, a.out, a.cov_col, a.site_flags, a.site_elig, a.site_bits, a.site_rank, a.tile_stage};
     for (void *p : old) dev_free(p);
     a = DeviceCols::AltBufs{};
     if (int rc = dev_alloc((void **)&a.tot, std::max<uint64_t>(1, 4 * npos) * sizeof(uint32_t), &d.device_bytes)) return rc;
@@ -1877,6 +2074,10 @@ static int ensure_alt(DeviceCols &d) {
     if (int rc = dev_alloc((void **)&a.cov_col, d.cap_cells * sizeof(uint16_t) + 16, &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.site_flags, d.cap_out_sites + 4, &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.site_elig, d.cap_out_sites + 4, &d.device_bytes)) return rc;
+    if (d.n_fused_tiles && !a.tile_stage) {
+        if (int rc = dev_alloc((void **)&a.tile_stage, (uint64_t)d.n_active_tiles * sizeof(TileStage), &d.device_bytes)) return rc;
+        if (int rc = dev_memset(a.tile_stage, 0, (uint64_t)d.n_active_tiles * sizeof(TileStage))) return rc;
+    }
     a.cap_events = d.cap_events; a.cap_overflow = d.cap_overflow; a.cap_sites = d.cap_sites; a.cap_out_sites = d.cap_out_sites; a.cap_cells = d.cap_cells;
     return MSNV_OK;
 }
@@ -1886,6 +2087,7 @@ static void swap_sets(DeviceCols &d) {
     std::swap(d.overflow, a.overflow); std::swap(d.counters, a.counters); std::swap(d.sites, a.sites);
     std::swap(d.tile_site_base, a.tile_site_base); std::swap(d.tile_site_cnt, a.tile_site_cnt); std::swap(d.tile_cell_base, a.tile_cell_base); std::swap(d.out, a.out); std::swap(d.cov_col, a.cov_col);
     std::swap(d.site_flags, a.site_flags); std::swap(d.site_elig, a.site_elig); std::swap(d.ind4, a.ind4); std::swap(d.unc_bits, a.unc_bits); std::swap(d.cnt_parity, a.cnt_parity);
+    if (a.tile_stage) std::swap(d.tile_stage, a.tile_stage);
     std::swap(d.tile_dirty, a.tile_dirty); std::swap(d.unc_sites, a.unc_sites); std::swap(d.site_row, a.site_row); std::swap(d.site_bits, a.site_bits); std::swap(d.site_rank, a.site_rank);
 }
 

@@ -787,6 +787,7 @@ int finalize_dataset(msnv_dataset &ds) {
         }
     }
     // ---- CSR of pairs by tile (sample order inside a tile)
+    std::vector<uint8_t> fuse_tile(nt, 0);                          // tiles piled up by ONE whole-tile work item (see below)
     std::vector<uint32_t> tps(nt + 1, 0);
     for (size_t s = 0; s < S; ++s) for (const PairTmp &p : per_sample[s]) tps[p.tile + 1]++;
     for (uint64_t t = 0; t < nt; ++t) tps[t + 1] += tps[t];
@@ -815,6 +816,25 @@ int finalize_dataset(msnv_dataset &ds) {
         // ... and only when the shallow pairs are a real share of the dataset (>= 3 % of its pieces): a few of them -- the
         // partial last tile of every contig of the benchmark shape -- are not worth the second code path in the tail
         std::vector<uint8_t> merge_tile(nt, 0);
+        // Whole-tile work items: in a SPARSE cohort (a pair or two per tile: BASELINE configs[3]) a tile whose pairs fit ONE merged group
+        // is piled up by one workgroup, which then holds the tile's totals and applies the gates itself (kernels.hip: fused_tile_gate).
+        // MSNV_FUSE=0 switches it off, MSNV_FUSE_PIECES sets the pieces a pair may hold (default 256), MSNV_FUSE=1 forces it on
+        // whatever the cohort looks like (tests).
+        {
+            uint64_t tiles_with_pairs = 0;
+            for (uint64_t t = 0; t < nt; ++t) tiles_with_pairs += tps[t + 1] > tps[t];
+            const char *fe = getenv("MSNV_FUSE");
+            const bool sparse = tiles_with_pairs && pairs.size() < 4 * tiles_with_pairs;
+            const bool fuse_on = can_merge && !(fe && fe[0] == '0') && (sparse || (fe && fe[0] == '1'));
+            const uint32_t fuse_pieces = [] { const char *e = getenv("MSNV_FUSE_PIECES"); return (uint32_t)std::max(1, e ? atoi(e) : 256); }();
+            if (fuse_on) for (uint64_t t = 0; t < nt; ++t) {
+                const uint32_t n = tps[t + 1] - tps[t];
+                if (n == 0 || n > MERGE_MAX_PAIRS) continue;
+                uint64_t depth = 0; bool ok = true;
+                for (uint32_t k = tps[t]; k < tps[t + 1] && ok; ++k) { depth += pairs[k].max_depth; ok = !pairs[k].pad && pairs[k].read_hi - pairs[k].read_lo <= fuse_pieces; }
+                if (ok && depth <= MERGE_MAX_DEPTH) fuse_tile[t] = 1;
+            }
+        }
         if (can_merge) {
             uint64_t shallow_pieces_total = 0, all_pieces = 0;
             for (uint64_t t = 0; t < nt; ++t) {
@@ -827,7 +847,8 @@ int finalize_dataset(msnv_dataset &ds) {
         }
         for (uint64_t t = 0; t < nt; ++t) {
             auto b = pairs.begin() + tps[t], e = pairs.begin() + tps[t + 1];
-            if (merge_tile[t]) for (auto it = b; it != e; ++it) if (is_shallow(*it)) it->pad = 2;
+            if (fuse_tile[t]) for (auto it = b; it != e; ++it) it->pad = 2;
+            else if (merge_tile[t]) for (auto it = b; it != e; ++it) if (is_shallow(*it)) it->pad = 2;
             std::stable_sort(b, e, [](const TilePair &x, const TilePair &y) {
                 auto cls = [](const TilePair &p) { return p.pad == 2 ? 2 : p.max_depth < NARROW_MAX_DEPTH ? 0 : 1; };
                 return cls(x) < cls(y);
@@ -860,7 +881,7 @@ int finalize_dataset(msnv_dataset &ds) {
     }
     // ---- work list: split each tile's pairs so that work items carry similar read counts
     std::vector<WorkItem> work;
-    struct MergedGroup { uint32_t pair_lo, pair_hi; };
+    struct MergedGroup { uint32_t pair_lo, pair_hi, tile; };
     std::vector<MergedGroup> groups;                                // in work-item order
     {
         uint64_t total_reads_in_pairs = 0;
@@ -907,14 +928,14 @@ int finalize_dataset(msnv_dataset &ds) {
                     const uint32_t nr = pairs[k].read_hi - pairs[k].read_lo;
                     seen += nr;
                     if (k > g_lo && (g_depth + pairs[k].max_depth > MERGE_MAX_DEPTH || k - g_lo >= MERGE_MAX_PAIRS)) {   // close the group
-                        groups.push_back(MergedGroup{g_lo, k});
+                        groups.push_back(MergedGroup{g_lo, k, (uint32_t)t});
                         i_pieces += g_pieces; i_chunks += (g_pieces + CHUNK_READS - 1) / CHUNK_READS;
                         g_lo = k; g_depth = 0; g_pieces = 0;
                         if (i_pieces >= target || i_chunks >= MAX_CHUNKS_PER_ITEM / 2) { merged.push_back(WorkItem{(uint32_t)t, i_lo, k, 0, 0, 0, 0, 0, ChunkDesc{}}); i_lo = k; i_pieces = 0; i_chunks = 0; }
                     }
                     g_depth += pairs[k].max_depth; g_pieces += nr;
                 }
-                if (tps[t + 1] > g_lo) { groups.push_back(MergedGroup{g_lo, tps[t + 1]}); merged.push_back(WorkItem{(uint32_t)t, i_lo, tps[t + 1], 0, 0, 0, 0, 0, ChunkDesc{}}); }
+                if (tps[t + 1] > g_lo) { groups.push_back(MergedGroup{g_lo, tps[t + 1], (uint32_t)t}); merged.push_back(WorkItem{(uint32_t)t, i_lo, tps[t + 1], 0, 0, 0, 0, 0, ChunkDesc{}}); }
             }
             for (uint32_t k = tps[t]; k < tpm[t]; ++k) {
                 const uint32_t nr = pairs[k].read_hi - pairs[k].read_lo;
@@ -928,8 +949,18 @@ int finalize_dataset(msnv_dataset &ds) {
                 }
             }
         }
+        // whole-tile items behind the other merged items: the pileup kernel picks its code by the range a work item is in
+        // (and among them the tiles with ONE pair last: their per-sample cells are the tile's totals, written by the gate kernel -- the
+        // merged gather skips their groups, the last n_groups_solo of its list)
+        for (uint64_t t = 0; t < nt; ++t) if (fuse_tile[t] && tps[t + 1] - tps[t] == 1) fuse_tile[t] = 2;
+        std::stable_sort(merged.begin(), merged.end(), [&](const WorkItem &x, const WorkItem &y) { return fuse_tile[x.tile] < fuse_tile[y.tile]; });
+        std::stable_sort(groups.begin(), groups.end(), [&](const MergedGroup &x, const MergedGroup &y) { return fuse_tile[x.tile] < fuse_tile[y.tile]; });
+        d->n_groups_solo = 0;
+        for (const MergedGroup &g : groups) d->n_groups_solo += fuse_tile[g.tile] == 2;
         d->n_work_narrow = (uint32_t)work.size();
         d->n_work_merged = (uint32_t)merged.size();
+        d->n_work_fused = 0;
+        for (const WorkItem &w : merged) d->n_work_fused += fuse_tile[w.tile] != 0;
         work.insert(work.end(), merged.begin(), merged.end());
         work.insert(work.end(), wide.begin(), wide.end());
     }
@@ -963,7 +994,7 @@ int finalize_dataset(msnv_dataset &ds) {
         for (size_t s = 0; s < work.size(); ++s) off[s + 1] = off[s] + ((uint64_t)TILE << slot_cls[s]);
         for (size_t i = 0; i < work.size(); ++i) {
             WorkItem &w = work[i];
-            w.part_lo = (uint32_t)off[w.slot] | (cls[i] == 0 ? 1u : 0u) | tot_mode(w.tile) << 1; w.part_hi = (uint32_t)(off[w.slot] >> 32);
+            w.part_lo = (uint32_t)off[w.slot] | (cls[i] == 0 ? 1u : 0u) | tot_mode(w.tile) << 1 | (fuse_tile[w.tile] ? WORK_FUSED : 0u); w.part_hi = (uint32_t)(off[w.slot] >> 32);
         }
         for (uint64_t t = 0; t < nt; ++t) {                    // first u16 row and first u32 row of every tile
             uint32_t s = tss[t];
@@ -987,9 +1018,29 @@ int finalize_dataset(msnv_dataset &ds) {
         for (uint64_t t = 0; t < nt; ++t) nslots_host[t] = (uint32_t)(ds.tile_slot_base[t + 1] - ds.tile_slot_base[t]);
         std::vector<DeviceCols::GateTileH> gts;
         gts.reserve(active.size());
-        for (uint32_t t : active) gts.push_back(DeviceCols::GateTileH{t, tss[t], t16[t], twide[t], tss[t + 1], vb_host[t], ve_host[t], nslots_host[t], off[tss[t]], tot_mode(t), 0});
+        for (uint32_t t : active) gts.push_back(DeviceCols::GateTileH{t, tss[t], t16[t], twide[t], tss[t + 1], vb_host[t], ve_host[t], nslots_host[t], off[tss[t]], tot_mode(t), (uint32_t)fuse_tile[t]});
         if (int rc = upload_vec(&d->gate_tiles, gts, &d->device_bytes, 1)) return rc;
         d->gather_split = (uint32_t)std::min<uint64_t>(4, std::max<uint64_t>(1, (active.empty() ? 0 : pairs.size() / active.size()) / 32));
+        {   // whole-tile work items write their candidate records per active tile
+            std::vector<uint32_t> stage_idx(nt + 1, 0xffffffffu);
+            uint32_t n_fused = 0;
+            for (size_t i = 0; i < active.size(); ++i) { stage_idx[active[i]] = (uint32_t)i; n_fused += fuse_tile[active[i]] != 0; }
+            d->n_fused_tiles = n_fused;
+            if (n_fused) {
+                std::vector<DeviceCols::GateTileH> dense_l, staged_l;
+                for (size_t i = 0; i < gts.size(); ++i) {
+                    if (!gts[i].staged) { dense_l.push_back(gts[i]); continue; }
+                    DeviceCols::GateTileH g = gts[i];
+                    g.row0 = (uint64_t)i;                              // (a whole-tile item writes no partial row: the field carries the index of its record list)
+                    staged_l.push_back(g);
+                }
+                if (int rc = upload_vec(&d->gate_tiles_dense, dense_l, &d->device_bytes, 1)) return rc;
+                if (int rc = upload_vec(&d->gate_tiles_staged, staged_l, &d->device_bytes, 1)) return rc;
+                if (int rc = upload_vec(&d->tile_stage_idx, stage_idx, &d->device_bytes)) return rc;
+                if (int rc = dev_alloc((void **)&d->tile_stage, (uint64_t)active.size() * sizeof(TileStage), &d->device_bytes)) return rc;
+                if (int rc = dev_memset(d->tile_stage, 0, (uint64_t)active.size() * sizeof(TileStage))) return rc;
+            }
+        }
         d->wide_tot = false;
         for (uint32_t t : active) if (tot_mode(t) == 2u) d->wide_tot = true;
         d->use_dirty = !active.empty() && work.size() < 4 * active.size();       // a sparse cohort: fewer than four work items per tile

@@ -85,3 +85,6 @@ def test_parameters_are_validated_when_a_dataset_is_created():
             core.Dataset(None, ["c"], [10], None, core.default_params(**bad))
         assert e.value.code == _lib.EINVAL, bad
     core.Dataset(None, ["c"], [10], None, core.default_params(max_depth=65535, cov_max=15)).close()
+    with pytest.raises(_lib.MsnvError) as e:                       # snpCall -t 0 prints every allele of every covered position: not supported
+        core.Dataset(None, ["c"], [10], None, core.default_params(calling_threshold=0))
+    assert e.value.code == _lib.EDOMAIN

@@ -316,6 +316,46 @@ def test_merged_groups_of_shallow_pairs(shallow_pieces, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fuse", ["1", "0"])
+def test_whole_tile_work_items(fuse, monkeypatch):
+    """Sparse cohorts: a tile whose pairs fit one merged group is piled up by ONE workgroup, which applies the gates and the calling
+    rule itself and leaves a record list for the gate kernel (kernels.hip: fused_tile_gate; pack.cpp: fuse_tile).  MSNV_FUSE=1 forces
+    the path on cohorts of any shape, 0 switches it off.  Same bytes as the oracle for (a) a sparse cohort with a lower-case
+    reference and a BED split, several thresholds; (b) SNVs so dense that tiles hold more candidates than a record list (the pass is
+    run again, unfused, and the dataset stays unfused); (c) a cohort where some tiles are fused and others hold deep / split pairs."""
+    monkeypatch.setenv("MSNV_FUSE", fuse)
+    monkeypatch.setenv("MSNV_LAYOUT", "pieces")
+    syn, samples = synth_case(n_species=9, contig_len=5000, n_samples=40, mean_cov=4.0, sigma_cov=0.6, snv_density=0.004, error_rate=0.004,
+                              frac_absent=0.85, lowercase_ref=1, seed=6100)
+    for kw in (dict(), dict(min_coverage=1, calling_threshold=1), dict(min_coverage=3, calling_threshold=2, min_fraction=0.4), dict(calling_threshold=1, min_coverage=2, min_fraction=0.0)):
+        p = core.default_params(**kw)
+        pop, ind, info, st, ds, ctx = run_product(syn.names, syn.lengths, syn.seqs, samples, params=p, return_ds=True)
+        orac = run_oracle(syn.names, syn.lengths, syn.seqs, samples, params=p)
+        _assert_same((pop, ind, info, st), orac)
+        ds.run()                                                    # a second pass over the resident dataset
+        with tempfile.TemporaryDirectory() as td:
+            ds.write_calls(os.path.join(td, "p"), os.path.join(td, "i"), None, None)
+            assert open(os.path.join(td, "p")).read() == pop and open(os.path.join(td, "i")).read() == ind
+        ds.close(); ctx.close()
+    bed = [(t, 1, syn.lengths[t]) for t in (1, 4, 7)]
+    prod = run_product(syn.names, syn.lengths, syn.seqs, samples, bed=bed)
+    orac = run_oracle(syn.names, syn.lengths, syn.seqs, samples, bed=bed)
+    _assert_same(prod, orac)
+    # (b) more candidates per tile than a record list holds
+    syn2, samples2 = synth_case(n_species=3, contig_len=4500, n_samples=5, mean_cov=6.0, sigma_cov=0.3, snv_density=0.2, error_rate=0.02, frac_absent=0.3, seed=6101)
+    p = core.default_params(min_coverage=2, calling_threshold=2)
+    prod = run_product(syn2.names, syn2.lengths, syn2.seqs, samples2, params=p)
+    orac = run_oracle(syn2.names, syn2.lengths, syn2.seqs, samples2, params=p)
+    _assert_same(prod, orac)
+    assert prod[0].count("\n") > 100
+    # (c) fused tiles next to tiles with a deep sample
+    syn3, samples3 = synth_case(n_species=6, contig_len=4200, n_samples=12, mean_cov=5.0, sigma_cov=2.0, snv_density=0.01, frac_absent=0.5, read_len=50, seed=6102)
+    prod = run_product(syn3.names, syn3.lengths, syn3.seqs, samples3)
+    orac = run_oracle(syn3.names, syn3.lengths, syn3.seqs, samples3)
+    _assert_same(prod, orac)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("gate_tiles", ["1", "3", "8"])
 def test_gate_kernel_with_several_tiles_per_workgroup(gate_tiles, monkeypatch):
     """msnv_gate_sites hands out site slots and per-sample cells with one reservation per workgroup; with many active tiles a
