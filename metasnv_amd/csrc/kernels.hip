@@ -1984,7 +1984,10 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
     }
     if (ev4) HIP_TRY(hipEventRecord(ev4, st));
     if (need_decide && d.n_active_tiles) {
-        hipLaunchKernelGGL(msnv_decide_sites, dim3(256), dim3(256), 0, st, d.sites, d.unc_sites, counters, d.cap_sites, cap_out, d.ref4, d.ref_lc,
+        // (one wavefront per listed site, grid-stride: a launch that fills the chip -- with 256 workgroups half a million listed sites
+        // of a deep, uneven cohort took 1.6 ms)
+        static const uint32_t decide_grid = dev_resident_workgroups(8);          // (queried once: the device properties call is slow)
+        hipLaunchKernelGGL(msnv_decide_sites, dim3(decide_grid), dim3(256), 0, st, d.sites, d.unc_sites, counters, d.cap_sites, cap_out, d.ref4, d.ref_lc,
                            d.out, CellMap{d.tile_site_base, d.tile_cell_base, d.tile_nslots, d.cap_cells, d.site_row}, p.calling_threshold, p.min_fraction, d.site_flags);
         HIP_TRY(hipGetLastError());
     }
