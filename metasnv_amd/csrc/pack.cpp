@@ -1021,6 +1021,7 @@ int finalize_dataset(msnv_dataset &ds) {
         for (uint32_t t : active) gts.push_back(DeviceCols::GateTileH{t, tss[t], t16[t], twide[t], tss[t + 1], vb_host[t], ve_host[t], nslots_host[t], off[tss[t]], tot_mode(t), (uint32_t)fuse_tile[t]});
         if (int rc = upload_vec(&d->gate_tiles, gts, &d->device_bytes, 1)) return rc;
         d->gather_split = (uint32_t)std::min<uint64_t>(4, std::max<uint64_t>(1, (active.empty() ? 0 : pairs.size() / active.size()) / 32));
+        if (const char *e = getenv("MSNV_GATHER_SPLIT")) d->gather_split = (uint32_t)std::max(1, atoi(e));      // (tuning experiments)
         {   // whole-tile work items write their candidate records per active tile
             std::vector<uint32_t> stage_idx(nt + 1, 0xffffffffu);
             uint32_t n_fused = 0;
