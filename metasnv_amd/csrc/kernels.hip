@@ -1516,16 +1516,19 @@ __device__ __forceinline__ void gather_merged_block(const TailArgs &a, const uin
     __shared__ uint32_t s_al[GM_CELLS];                 // 4 x u8 per (site, pair): mismatching A, C, G, T (a shallow pair is < 81 deep)
     __shared__ uint32_t s_gsample[MERGE_MAX_PAIRS];
     const MergedGroupDev w = a.merged_groups[bid];      // ONE group per workgroup (a work item's groups in a row made this block the launch's long pole)
-    const uint32_t tile = w.tile, n = a.tile_site_cnt[tile];
-    if (n == 0u) return;
-    const uint32_t base = a.tile_site_base[tile];
-    if (base + n > a.cap_out) return;                   // the host sees the site count and retries with a larger buffer
-    const uint32_t n_slots = a.cells.tile_nslots[tile];
+    // everything that hangs on the descriptor alone is requested together -- the tile's site tables, its bitmap and ranks, the first
+    // round of piece headers: the block is a chain of dependent loads (one group of a sparse cohort is ~250 pieces), not arithmetic
+    const uint32_t tile = w.tile, t0 = tile * TILE, tid = threadIdx.x;
+    const uint32_t n = a.tile_site_cnt[tile], base = a.tile_site_base[tile], n_slots = a.cells.tile_nslots[tile];
     const unsigned long long cell0 = a.cells.tile_cell_base[tile];
+    unsigned long long my_bits = 0; uint32_t my_rank = 0;
+    if (tid < TILE / 64) { my_bits = a.site_bits[(t0 >> 6) + tid]; my_rank = a.site_rank[(t0 >> 6) + tid]; }
+    PieceHdr h_first{0u, 0u};
+    if (tid < w.n_pieces) h_first = a.hdr8m[w.hdr_base + tid];
+    if (n == 0u) return;
+    if (base + n > a.cap_out) return;                   // the host sees the site count and retries with a larger buffer
     if (cell0 + (unsigned long long)n * n_slots > a.cells.cap_cells) return;
-    const uint32_t t0 = tile * TILE;
-    const uint32_t tid = threadIdx.x;
-    if (tid < TILE / 64) { s_bits[tid] = a.site_bits[(t0 >> 6) + tid]; s_rank[tid] = a.site_rank[(t0 >> 6) + tid] - base; }
+    if (tid < TILE / 64) { s_bits[tid] = my_bits; s_rank[tid] = my_rank - base; }
     const uint32_t kq = min(a.min_baseq, 128u);
     {
         // the group's extent comes with its descriptor: every table the block needs is one load away from it (a chain of ten
@@ -1541,7 +1544,7 @@ __device__ __forceinline__ void gather_merged_block(const TailArgs &a, const uin
             for (uint32_t i = tid; i < nj * m; i += blockDim.x) s_al[i] = 0u;
             __syncthreads();
             for (uint32_t pi = tid; pi < n_pieces; pi += blockDim.x) {
-                const PieceHdr h = a.hdr8m[g.hdr_base + pi];
+                const PieceHdr h = pi == tid ? h_first : a.hdr8m[g.hdr_base + pi];
                 const uint32_t s = h.w0 & (TILE - 1u), len = (h.w0 >> 11) & 0xffu, pidx = h.w0 >> 19;
                 const uint64_t so = (uint64_t)h.seqoff8 << 3;
                 for (uint32_t wd = s >> 6; wd <= (s + len - 1u) >> 6 && wd < TILE / 64; ++wd) {
