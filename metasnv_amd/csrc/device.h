@@ -87,6 +87,7 @@ struct DeviceCols {
     struct GateTileH { uint32_t tile, slot_lo, slot_16, slot_w, slot_hi, vbeg, vend, n_slots; uint64_t row0; uint32_t tot_mode, staged; } *gate_tiles = nullptr;   // per active tile (kernels.hip: GateTile)
     unsigned long long *site_row = nullptr;   // per 64 positions: first cell of the first site in them (gate kernel; what an event finds its cell with)
     GateTileH *gate_tiles_dense = nullptr, *gate_tiles_staged = nullptr;   // gate_tiles without / only the tiles of whole-tile work items (staged: row0 = index of the record list)
+    uint32_t *gather_tiles = nullptr; uint32_t n_gather_tiles = 0;   // active tiles that hold pairs outside merged groups (spill gather)
     TileStage *tile_stage = nullptr;   // per active tile (index of its GateTile): candidate records of whole-tile work items
     uint32_t *tile_stage_idx = nullptr;   // per tile: that index
     uint32_t  n_groups_solo = 0;     // the last n_groups_solo merged groups are whole-tile groups of ONE pair (no gather needed when the pass is fused)

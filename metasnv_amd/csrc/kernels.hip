@@ -1853,7 +1853,7 @@ void dev_free_all(DeviceCols &d) {
     void *ptrs[] = {d.hdr, d.hdr8, d.hdr8m, d.merged_groups, d.tile_pair_merged, d.blk, d.seq, d.qual, d.s_read_base, d.s_seq_base, d.ref4, d.ref_lc, d.pairs,
                     d.tile_pair_start, d.work, d.chunks, d.tile_vbeg, d.tile_vend, d.tot, d.part, d.tile_slot_start, d.tile_slot_u16, d.tile_slot_wide, d.slot_off, d.spill, d.events, d.overflow, d.counters, d.ind4, d.tile_dirty, d.unc_sites, d.site_row, d.gate_tiles,
                     d.sites, d.tile_site_base, d.tile_site_cnt, d.tile_cell_base, d.tile_nslots, d.out, d.cov_col, d.site_flags, d.site_elig,
-                    d.cov_iv, d.s_cov_base, d.cov_pairs, d.cov_work, d.tile_len, d.tile_contig_dev, d.cov_acc, d.tile_stage, d.tile_stage_idx, d.alt.tile_stage, d.gate_tiles_dense, d.gate_tiles_staged};
+                    d.cov_iv, d.s_cov_base, d.cov_pairs, d.cov_work, d.tile_len, d.tile_contig_dev, d.cov_acc, d.tile_stage, d.tile_stage_idx, d.alt.tile_stage, d.gate_tiles_dense, d.gate_tiles_staged, d.gather_tiles};
     for (void *p : ptrs) dev_free(p);
     void *aptrs[] = {d.ann.seg_beg, d.ann.seg_end, d.ann.seg_gene, d.ann.genes, d.ann.contigs, d.ann.codons, d.ann.out, d.ann.err};
     for (void *p : aptrs) dev_free(p);
@@ -1971,10 +1971,10 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
     if (d.n_active_tiles) {
         TailArgs ta;
         ta.sites = d.sites; ta.tile_site_base = d.tile_site_base; ta.tile_site_cnt = d.tile_site_cnt; ta.tile_pair_start = d.tile_pair_start;
-        ta.pairs = d.pairs; ta.spill = d.spill; ta.out = d.out; ta.cov_col = d.cov_col; ta.cap_out = cap_out; ta.active_tiles = d.active_tiles;
+        ta.pairs = d.pairs; ta.spill = d.spill; ta.out = d.out; ta.cov_col = d.cov_col; ta.cap_out = cap_out; ta.active_tiles = d.gather_tiles;
         ta.cells = CellMap{d.tile_site_base, d.tile_cell_base, d.tile_nslots, d.cap_cells, d.site_row};
         ta.gather_split = d.gather_split;
-        ta.n_gather_blocks = d.n_active_tiles * d.gather_split;
+        ta.n_gather_blocks = d.n_gather_tiles * d.gather_split;
         ta.tile_pair_merged = d.tile_pair_merged; ta.merged_groups = d.merged_groups; ta.chunks = d.chunks; ta.hdr8m = d.hdr8m;
         ta.seq = d.seq; ta.qual = d.qual; ta.ref4 = d.ref4; ta.n_merged_blocks = d.n_merged_groups - (use_stage ? d.n_groups_solo : 0u); ta.min_baseq = (uint32_t)std::max(0, p.min_baseq);
         ta.site_flags = d.site_flags; ta.site_elig = d.site_elig; ta.ind_in_gather = d.any_split ? 0u : 1u; ta.min_snvs = (uint32_t)std::max(1, p.calling_threshold);

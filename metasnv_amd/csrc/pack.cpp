@@ -1007,6 +1007,14 @@ int finalize_dataset(msnv_dataset &ds) {
         for (uint64_t t = 0; t < nt; ++t) if (tss[t + 1] > tss[t]) active.push_back((uint32_t)t);
         d->n_active_tiles = (uint32_t)active.size();
         if (int rc = upload_vec(&d->active_tiles, active, &d->device_bytes, 1)) return rc;
+        // the spill gather only has something to do in tiles that hold pairs outside merged groups (the others -- every tile of a sparse
+        // cohort -- would each cost a workgroup that looks its tile up and leaves)
+        {
+            std::vector<uint32_t> gather_tiles;
+            for (uint32_t t : active) if (tpm[t] > tps[t]) gather_tiles.push_back(t);
+            d->n_gather_tiles = (uint32_t)gather_tiles.size();
+            if (int rc = upload_vec(&d->gather_tiles, gather_tiles, &d->device_bytes, 1)) return rc;
+        }
         d->part_bytes = std::max<uint64_t>(16, off[work.size()]);
         if (int rc = upload_vec(&d->tile_slot_start, tss, &d->device_bytes)) return rc;
         if (int rc = upload_vec(&d->tile_slot_u16, t16, &d->device_bytes)) return rc;
