@@ -911,6 +911,33 @@ def test_launcher_metasnv_py_under_two_ranks_matches_the_oracle(tmp_path, extra)
     assert sum(x["dataset"]["n_positions"] for x in m) == sum(syn.lengths)
 
 
+def test_launcher_under_two_ranks_on_a_sparse_cohort(tmp_path):
+    """The same launcher on a SPARSE cohort (30 samples, each species carried by a few: the configs[3] shape in small): the ranks'
+    datasets run on whole-tile work items (the workgroup that piles a tile up applies the gates; kernels.hip: fused_tile_gate,
+    msnv_gate_staged), with --n_splits 2 so that every split's own first line is dropped.  Same bytes as the oracle."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    syn, samples = synth_case(n_species=8, contig_len=4300, n_samples=36, mean_cov=5.0, sigma_cov=0.4, snv_density=0.02, frac_absent=0.85, lowercase_ref=1, seed=93)
+    samples = [s for s in samples if s.size]                      # (a BAM without mapped reads is undefined in qaCompute: MSNV_EDOMAIN)
+    assert len(samples) > 20
+    fa, paths, lst = _write_inputs(tmp_path, syn, samples)
+    proj = str(tmp_path / "proj")
+    r = _torchrun(2, [os.path.join(root, "metaSNV.py"), proj, lst, fa, "--n_splits", "2", "--min_pos_cov", "2", "--min_pos_snvs", "2"], env=dict(MSNV_DIST_BACKEND="gloo"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    p = core.default_params(min_coverage=2, calling_threshold=2)
+    total = 0
+    for sp in sorted(os.listdir(os.path.join(proj, "bestsplits"))):
+        bed = [(syn.names.index(l.split()[0]), int(l.split()[1]), int(l.split()[2])) for l in open(os.path.join(proj, "bestsplits", sp))]
+        o = run_oracle(syn.names, syn.lengths, syn.seqs, samples, bed=bed, params=p)
+        assert open(os.path.join(proj, "snpCaller", "called_SNPs." + sp)).read() == o[0], sp
+        assert open(os.path.join(proj, "snpCaller", "indiv_called." + sp)).read() == o[1], sp
+        total += o[0].count("\n") + o[1].count("\n")
+    assert total > 30
+    for i, pth in enumerate(paths):
+        want = orc.qacompute(syn.names, syn.lengths, samples[i])
+        base = os.path.join(proj, "cov", os.path.basename(pth) + ".cov")
+        assert open(base).read() == want[0] and open(base + ".detail").read() == want[1]
+
+
 def test_bench_gpus_2_starts_two_ranks_by_itself():
     """`python bench.py --gpus 2` outside torchrun spawns the two rank processes itself (before any GPU call) and the
     rank-0 line reports n_gpus 2, both ranks' line counts and the slowest rank's roofline (gloo rehearsal: one GPU)."""
