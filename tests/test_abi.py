@@ -88,3 +88,21 @@ def test_parameters_are_validated_when_a_dataset_is_created():
     with pytest.raises(_lib.MsnvError) as e:                       # snpCall -t 0 prints every allele of every covered position: not supported
         core.Dataset(None, ["c"], [10], None, core.default_params(calling_threshold=0))
     assert e.value.code == _lib.EDOMAIN
+
+
+def test_integration_md_stub_structs_match_the_bindings():
+    """The ctypes stub INTEGRATION.md shows a maintainer declares the same struct layouts as the library's own bindings."""
+    import ctypes as C
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    ns = {"C": C}
+    classes = re.findall(r"^class (_\w+)\(C\.Structure\):[^\n]*\n((?:    .*\n)+)", text, re.M)
+    assert {c for c, _ in classes} >= {"_Params", "_CovArgs", "_CallArgs", "_MpileupArgs"}
+    for name, body in classes:
+        exec("class %s(C.Structure):\n%s" % (name, body), ns)
+    from metasnv_amd import _lib
+    for stub, real in (("_Params", _lib.Params), ("_CovArgs", _lib.CovArgs), ("_CallArgs", _lib.CallArgs), ("_MpileupArgs", _lib.MpileupArgs)):
+        assert C.sizeof(ns[stub]) == C.sizeof(real), stub
+        assert [f[0] for f in ns[stub]._fields_] == [f[0] for f in real._fields_], stub
+
