@@ -377,6 +377,10 @@ int  msnv_results_fetch(msnv_dataset *ds, msnv_site *sites, msnv_site_sample *sa
 /* Host-stage counters since the library was loaded: BGZF blocks that the library's own DEFLATE decoder (csrc/inflate.cpp)
  * handed to zlib (0 for well-formed files; tests). */
 int  msnv_host_stats(uint64_t *zlib_fallbacks);
+/* Test / measurement hook of the device BGZF inflate (csrc/inflate_k.hip): the inflated bytes of one BGZF
+ * file, through the device (on_device != 0, needs ctx) or the host decoder.  *out is released with msnv_free.  counters (may be
+ * NULL): [0] blocks, [1] blocks the device refused and the host inflated, [2] kernel microseconds, [3] inflated bytes. */
+int  msnv_bgzf_inflate(msnv_ctx *ctx, const char *path, int32_t on_device, uint8_t **out, uint64_t *n_out, uint64_t counters[4]);
 /* `samtools view -H` replacement for bed_header (metaSNV.py:81-94): writes SN\t1\tLN lines. */
 int  msnv_bam_write_bed_header(const char *bam_path, const char *out_path);
 /* Reads a whole BAM: header text, contigs and the raw record stream.  Free with msnv_free. */

@@ -326,6 +326,19 @@ def call_from_mpileup(ctx, called_path, indiv_path=None, text=None, mpileup_path
             "text_bytes": int(st[5]), "base_chars": int(st[6])}
 
 
+def bgzf_inflate(path, ctx=None):
+    """Inflated bytes of a BGZF file through the device (ctx given) or the host decoder; returns (bytes as a numpy array, counters)."""
+    out = C.POINTER(C.c_uint8)()
+    n = C.c_uint64()
+    cnt = (C.c_uint64 * 4)()
+    check(lib.msnv_bgzf_inflate(ctx._h if ctx is not None else None, path.encode(), 1 if ctx is not None else 0, C.byref(out), C.byref(n), cnt))
+    try:
+        data = np.ctypeslib.as_array(out, shape=(n.value,)).copy() if n.value else np.zeros(0, np.uint8)
+    finally:
+        lib.msnv_free(out)
+    return data, {"blocks": int(cnt[0]), "host_blocks": int(cnt[1]), "kernel_ms": cnt[2] / 1000.0, "bytes": int(cnt[3])}
+
+
 def write_bam(path, names, lengths, records, header_text=None, level=1):
     rec = np.ascontiguousarray(records, dtype=np.uint8)
     n = len(names)

@@ -48,8 +48,10 @@ extern "C" int msnv_ctx_create(int device_id, msnv_ctx **out) {
     return MSNV_OK;
 }
 
+namespace msnv { void dev_inflate_release(msnv_ctx *ctx); }
 extern "C" void msnv_ctx_destroy(msnv_ctx *ctx) {
     if (!ctx) return;
+    dev_inflate_release(ctx);
     dev_stream_destroy(ctx->stream);
     delete ctx;
 }
@@ -189,6 +191,130 @@ extern "C" int msnv_dataset_add_sample_bam(msnv_dataset *ds, const char *bam_pat
     return msnv_dataset_add_sample_records(ds, buf.data() + rec_off, buf.size() - rec_off);
 }
 
+namespace msnv {
+struct InfBlock { unsigned long long in_off, out_off; uint32_t in_size, out_size; };
+int dev_inflate_staging(msnv_ctx *ctx, uint64_t in_bytes, uint64_t out_bytes, uint8_t **in, uint8_t **out);
+void dev_inflate_release(msnv_ctx *ctx);
+int dev_inflate(msnv_ctx *ctx, uint64_t comp_bytes, const std::vector<InfBlock> &blocks, uint64_t out_bytes, std::vector<uint32_t> &status, double *ms_kernel);
+}
+
+// BGZF files inflated on the device (inflate_k.hip).  The files of a batch are read by `threads` host threads straight into the
+// context's pinned staging buffer (no copy of the compressed bytes), their blocks are indexed there, the device inflates all blocks of
+// the batch into the pinned output buffer, and `consume(f0, f1, out, ext)` parses files [f0, f1) in place (no copy of the inflated
+// bytes either; the buffer is reused by the next batch).  Blocks the device refuses are inflated by the host decoder, which words
+// the error of a malformed file.  ext[k]: offset and size of file f0 + k in `out`.
+// counters (optional): [0] blocks, [1] blocks inflated on the host after all, [2] kernel microseconds, [3] inflated bytes.
+struct InflatedExt { uint64_t off, size; };
+template <typename Consume>
+static int bgzf_read_files_device(msnv_ctx *ctx, const char *const *paths, int n, int threads, Consume consume, uint64_t counters[4]) {
+    if (int rc = dev_set_device(ctx->device)) return rc;
+    std::vector<uint64_t> fsize((size_t)n, 0);
+    for (int i = 0; i < n; ++i) {
+        FILE *f = fopen(paths[i], "rb");
+        if (!f) return fail(MSNV_EIO, "cannot open %s", paths[i]);
+        fseek(f, 0, SEEK_END);
+        const long sz = ftell(f);
+        fclose(f);
+        if (sz < 0) return fail(MSNV_EIO, "cannot stat %s", paths[i]);
+        fsize[(size_t)i] = (uint64_t)sz;
+    }
+    double ms = 0;
+    uint64_t n_blocks = 0, n_host = 0, n_bytes = 0;
+    const uint64_t batch_in = 1024ull << 20;                       // compressed bytes per batch (~2.5 GB inflated)
+    for (int f0 = 0; f0 < n;) {
+        int f1 = f0; uint64_t ib = 0;
+        std::vector<uint64_t> in_off;
+        while (f1 < n && (f1 == f0 || ib + fsize[(size_t)f1] <= batch_in)) { in_off.push_back(ib); ib += (fsize[(size_t)f1] + 31) & ~15ull; ++f1; }   // 16 bytes of slack behind every file
+        uint8_t *in_stage = nullptr, *out = nullptr;
+        if (int rc = dev_inflate_staging(ctx, ib, 0, &in_stage, &out)) return rc;
+        const int nf = f1 - f0;
+        std::vector<std::vector<BgzfBlock>> blocks((size_t)nf);
+        std::vector<uint64_t> total((size_t)nf, 0);
+        std::atomic<int> next{0}, err{0};
+        std::vector<std::string> msgs((size_t)nf);
+        auto loader = [&]() {
+            for (;;) {
+                const int k = next.fetch_add(1);
+                if (k >= nf || err.load()) break;
+                const char *path = paths[f0 + k];
+                int rc = MSNV_OK;
+                try {
+                    uint8_t *dst = in_stage + in_off[(size_t)k];
+                    const uint64_t sz = fsize[(size_t)(f0 + k)];
+                    FILE *f = fopen(path, "rb");
+                    if (!f) rc = fail(MSNV_EIO, "cannot open %s", path);
+                    else {
+                        if (sz && fread(dst, 1, sz, f) != sz) rc = fail(MSNV_EIO, "short read on %s", path);
+                        fclose(f);
+                    }
+                    if (!rc) { memset(dst + sz, 0, 16); rc = bgzf_index_bytes(dst, sz, path, blocks[(size_t)k], total[(size_t)k]); }
+                } catch (const std::exception &e) { rc = fail(MSNV_ENOMEM, "%s: %s", path, e.what()); }
+                if (rc) { msgs[(size_t)k] = msnv_last_error(); err.store(rc); }
+            }
+        };
+        {
+            std::vector<std::thread> th;
+            for (int t = 0; t < std::max(1, std::min(threads, nf)); ++t) th.emplace_back(loader);
+            for (auto &t : th) t.join();
+        }
+        if (err.load()) { for (const std::string &m : msgs) if (!m.empty()) return fail(err.load(), "%s", m.c_str()); return fail(err.load(), "BGZF read failed"); }
+        uint64_t ob = 0;
+        std::vector<InfBlock> list;
+        std::vector<int> origin;                                     // file (of the batch) of every entry
+        std::vector<InflatedExt> ext((size_t)nf);
+        for (int k = 0; k < nf; ++k) {
+            ext[(size_t)k] = InflatedExt{ob, total[(size_t)k]};
+            for (const BgzfBlock &bl : blocks[(size_t)k]) {
+                if (bl.out_size == 0) continue;
+                list.push_back(InfBlock{in_off[(size_t)k] + bl.in_off, ob + bl.out_off, bl.in_size, bl.out_size});
+                origin.push_back(k);
+            }
+            ob += (total[(size_t)k] + 15) & ~15ull;
+            n_bytes += total[(size_t)k];
+        }
+        if (int rc = dev_inflate_staging(ctx, ib, ob, &in_stage, &out)) return rc;       // (the input staging does not move: it only grows when ib does)
+        std::vector<uint32_t> status;
+        if (int rc = dev_inflate(ctx, ib, list, ob, status, &ms)) return rc;
+        for (size_t e = 0; e < list.size(); ++e) {
+            if (!status[e]) continue;
+            ++n_host;
+            if (!bgzf_inflate_block_host(in_stage + list[e].in_off, list[e].in_size, out + list[e].out_off, list[e].out_size))
+                return fail(MSNV_EFORMAT, "%s: BGZF inflate failed", paths[f0 + origin[e]]);
+        }
+        n_blocks += list.size();
+        if (int rc = consume(f0, f1, (const uint8_t *)out, ext)) return rc;
+        f0 = f1;
+    }
+    if (counters) { counters[0] = n_blocks; counters[1] = n_host; counters[2] = (uint64_t)(ms * 1000.0); counters[3] = n_bytes; }
+    return MSNV_OK;
+}
+
+// Test / measurement hook: the inflated bytes of one BGZF file, through the device (on_device != 0; needs ctx) or the host decoder.
+extern "C" int msnv_bgzf_inflate(msnv_ctx *ctx, const char *path, int32_t on_device, uint8_t **out, uint64_t *n_out, uint64_t counters[4]) {
+    clear_error();
+    if (!path || !out || !n_out) return fail(MSNV_EINVAL, "msnv_bgzf_inflate: NULL argument");
+    *out = nullptr; *n_out = 0;
+    try {
+        ByteBuf buf;
+        if (on_device) {
+            if (!ctx) return fail(MSNV_ENODEV, "msnv_bgzf_inflate: the device path needs a context");
+            const char *p[1] = {path};
+            auto take = [&](int, int, const uint8_t *data, const std::vector<InflatedExt> &ext) -> int {
+                if (!buf.alloc((size_t)ext[0].size)) return fail(MSNV_ENOMEM, "%s: out of memory for %llu inflated bytes", path, (unsigned long long)ext[0].size);
+                memcpy(buf.data(), data + ext[0].off, (size_t)ext[0].size);
+                return MSNV_OK;
+            };
+            if (int rc = bgzf_read_files_device(ctx, p, 1, 1, take, counters)) return rc;
+        } else {
+            if (int rc = bgzf_read_all(path, buf, 1)) return rc;
+            if (counters) for (int i = 0; i < 4; ++i) counters[i] = 0;
+        }
+        *out = buf.p; *n_out = buf.n;
+        buf.p = nullptr; buf.n = 0;                              // released by msnv_free
+        return MSNV_OK;
+    } catch (const std::exception &e) { return fail(MSNV_ENOMEM, "msnv_bgzf_inflate: %s", e.what()); }
+}
+
 extern "C" int msnv_dataset_add_sample_bams(msnv_dataset *ds, const char *const *bam_paths, int32_t n, int32_t host_threads) {
     clear_error();
     if (!ds || (n && !bam_paths)) return fail(MSNV_EINVAL, "msnv_dataset_add_sample_bams: NULL argument");
@@ -199,6 +325,45 @@ extern "C" int msnv_dataset_add_sample_bams(msnv_dataset *ds, const char *const 
     ds->samples.resize(first + (size_t)n);
     std::atomic<int> next{0}, err{0};
     std::vector<std::string> msgs((size_t)n);
+    // MSNV_INFLATE=device: the BGZF blocks of the files are inflated on the device (inflate_k.hip: a wavefront per block, thousands of
+    // blocks at a time), batch by batch; the host threads read the files in front of it and parse / pack the batch's bytes in place
+    const bool on_device = ds->ctx && [] { const char *e = getenv("MSNV_INFLATE"); return e && e[0] == 'd'; }();
+    auto pack_one = [&](int i, const uint8_t *data, uint64_t size, BamHeader &h, uint64_t rec_off) -> int {
+        if (int rc = check_header(*ds, h, bam_paths[i])) return rc;
+        return pack_sample(*ds, data + rec_off, size - rec_off, ds->samples[first + (size_t)i]);
+    };
+    if (on_device) {
+        auto consume = [&](int f0, int f1, const uint8_t *out, const std::vector<InflatedExt> &ext) -> int {
+            std::atomic<int> nxt{f0};
+            auto w = [&]() {
+                for (;;) {
+                    const int i = nxt.fetch_add(1);
+                    if (i >= f1 || err.load()) break;
+                    int rc;
+                    try {
+                        BamHeader h; uint64_t rec_off = 0;
+                        const uint8_t *data = out + ext[(size_t)(i - f0)].off; const uint64_t size = ext[(size_t)(i - f0)].size;
+                        rc = bam_parse_header_bytes(data, size, bam_paths[i], h, rec_off);
+                        if (!rc) rc = pack_one(i, data, size, h, rec_off);
+                    } catch (const std::exception &e) { rc = fail(MSNV_ENOMEM, "%s: %s", bam_paths[i], e.what()); }
+                    if (rc) { msgs[(size_t)i] = msnv_last_error(); err.store(rc); }
+                }
+            };
+            std::vector<std::thread> th;
+            for (int t = 0; t < std::max(1, std::min(nthreads, f1 - f0)); ++t) th.emplace_back(w);
+            for (auto &t : th) t.join();
+            return err.load();
+        };
+        int rc;
+        try { uint64_t cnt[4]; rc = bgzf_read_files_device(ds->ctx, bam_paths, n, nthreads, consume, cnt); }
+        catch (const std::exception &e) { rc = fail(MSNV_ENOMEM, "device inflate: %s", e.what()); }
+        if (rc) {
+            ds->samples.resize(first);
+            for (const std::string &m : msgs) if (!m.empty()) return fail(rc, "%s", m.c_str());
+            return rc;
+        }
+        return MSNV_OK;
+    }
     auto worker = [&]() {
         for (;;) {
             int i = next.fetch_add(1);
@@ -207,8 +372,7 @@ extern "C" int msnv_dataset_add_sample_bams(msnv_dataset *ds, const char *const 
             try {                                              // an exception in a worker thread would be std::terminate
                 BamHeader h; ByteBuf buf; uint64_t rec_off = 0;
                 rc = bam_read(bam_paths[i], h, buf, rec_off, 1);
-                if (!rc) rc = check_header(*ds, h, bam_paths[i]);
-                if (!rc) rc = pack_sample(*ds, buf.data() + rec_off, buf.size() - rec_off, ds->samples[first + (size_t)i]);
+                if (!rc) rc = pack_one(i, buf.data(), buf.size(), h, rec_off);
             } catch (const std::exception &e) { rc = fail(MSNV_ENOMEM, "%s: %s", bam_paths[i], e.what()); }
             if (rc) { msgs[(size_t)i] = msnv_last_error(); err.store(rc); }
         }

@@ -96,6 +96,10 @@ struct DeviceCols;   // kernels.hip
 struct msnv_ctx {
     int device = 0;
     void *stream = nullptr;   // hipStream_t
+    // device BGZF inflate (inflate_k.hip): pinned host staging and device buffers, grown on demand and kept for the life of the context
+    // (pinning memory costs ~0.25 s per GB: paid once, not per batch of BAMs)
+    void *pin_in = nullptr, *pin_out = nullptr, *dev_in = nullptr, *dev_out = nullptr;
+    uint64_t pin_in_cap = 0, pin_out_cap = 0, dev_in_cap = 0, dev_out_cap = 0;
 };
 
 struct msnv_dataset {

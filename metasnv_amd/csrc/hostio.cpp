@@ -68,7 +68,7 @@ static int read_file(const char *path, std::vector<uint8_t> &buf) {      // smal
 
 // ------------------------------------------------------------------------------ BGZF
 // A BGZF block is a gzip member with an extra field "BC" holding BSIZE-1 (SAMv1 4.1).
-struct BlockRef { uint64_t in_off; uint32_t in_size; uint32_t out_size; uint64_t out_off; };
+using BlockRef = BgzfBlock;                  // msnv_internal.h: {in_off, in_size, out_size, out_off}
 
 struct ConstBytes { const uint8_t *p; size_t n; const uint8_t *data() const { return p; } size_t size() const { return n; } };
 static int bgzf_index(const ConstBytes in, const char *path, std::vector<BlockRef> &blocks, uint64_t &total_out) {
@@ -121,6 +121,18 @@ static bool inflate_block(const uint8_t *src, uint32_t n_in, uint8_t *dst, uint3
     int rc = inflate(&zs, Z_FINISH);
     inflateEnd(&zs);
     return rc == Z_STREAM_END && zs.avail_out == 0;
+}
+
+// The two halves of bgzf_read_all for callers that inflate elsewhere (the device: api.cpp / inflate_k.hip)
+int bgzf_load(const char *path, ByteBuf &comp, size_t &n_in, std::vector<BgzfBlock> &blocks, uint64_t &total_out) {
+    if (int rc = read_file(path, comp, n_in)) return rc;
+    blocks.clear();
+    return bgzf_index(ConstBytes{comp.data(), n_in}, path, blocks, total_out);
+}
+bool bgzf_inflate_block_host(const uint8_t *src, uint32_t n_in, uint8_t *dst, uint32_t n_out) { return inflate_block(src, n_in, dst, n_out); }
+int bgzf_index_bytes(const uint8_t *data, size_t n, const char *path, std::vector<BgzfBlock> &blocks, uint64_t &total_out) {
+    blocks.clear();
+    return bgzf_index(ConstBytes{data, n}, path, blocks, total_out);
 }
 
 int bgzf_read_all(const char *path, ByteBuf &out, int threads) {
@@ -208,6 +220,10 @@ static int bam_parse_header(const Bytes &u, const char *path, BamHeader &hdr, ui
     }
     rec_off = off;
     return MSNV_OK;
+}
+
+int bam_parse_header_bytes(const uint8_t *data, size_t n, const char *path, BamHeader &hdr, uint64_t &rec_off) {
+    return bam_parse_header(ConstBytes{data, n}, path, hdr, rec_off);
 }
 
 int bam_read(const char *path, BamHeader &hdr, ByteBuf &buf, uint64_t &rec_off, int threads) {

@@ -30,6 +30,8 @@ struct ByteBuf {
     ByteBuf() = default;
     ByteBuf(const ByteBuf &) = delete;
     ByteBuf &operator=(const ByteBuf &) = delete;
+    ByteBuf(ByteBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    ByteBuf &operator=(ByteBuf &&o) noexcept { if (this != &o) { free(p); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
     ~ByteBuf() { free(p); }
     bool alloc(size_t m) { free(p); p = (uint8_t *)malloc(m ? m : 1); n = p ? m : 0; return p != nullptr; }
     uint8_t *data() { return p; }
@@ -39,6 +41,13 @@ struct ByteBuf {
 
 // Whole-file BGZF inflate (blocks are independent; `threads` > 1 inflates them in parallel).
 int bgzf_read_all(const char *path, ByteBuf &out, int threads);
+// ... in two steps, for the device inflate (inflate_k.hip): the file's bytes + its blocks (offsets of the raw DEFLATE payloads), and
+// the host decoder for one block (own decoder, zlib behind it)
+struct BgzfBlock { uint64_t in_off; uint32_t in_size; uint32_t out_size; uint64_t out_off; };
+int bgzf_load(const char *path, ByteBuf &comp, size_t &n_in, std::vector<BgzfBlock> &blocks, uint64_t &total_out);
+bool bgzf_inflate_block_host(const uint8_t *src, uint32_t n_in, uint8_t *dst, uint32_t n_out);
+int bgzf_index_bytes(const uint8_t *data, size_t n, const char *path, std::vector<BgzfBlock> &blocks, uint64_t &total_out);   // `data` needs 16 readable bytes behind n
+int bam_parse_header_bytes(const uint8_t *data, size_t n, const char *path, BamHeader &hdr, uint64_t &rec_off);
 int bgzf_write_all(const char *path, const uint8_t *data, uint64_t n, int level);
 
 // BAM = BGZF(magic, header text, contig table, records...)
