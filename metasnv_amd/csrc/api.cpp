@@ -327,7 +327,18 @@ extern "C" int msnv_dataset_add_sample_bams(msnv_dataset *ds, const char *const 
     std::vector<std::string> msgs((size_t)n);
     // MSNV_INFLATE=device: the BGZF blocks of the files are inflated on the device (inflate_k.hip: a wavefront per block, thousands of
     // blocks at a time), batch by batch; the host threads read the files in front of it and parse / pack the batch's bytes in place
-    const bool on_device = ds->ctx && [] { const char *e = getenv("MSNV_INFLATE"); return e && e[0] == 'd'; }();
+    // (default: on for calls that bring at least 64 MB of BAM -- below that the host decoder is done before the staging is set up;
+    // MSNV_INFLATE=host | zlib keeps everything on the host, MSNV_INFLATE=device forces the device whatever the size)
+    bool on_device = false;
+    if (ds->ctx) {
+        const char *e = getenv("MSNV_INFLATE");
+        if (e && e[0] == 'd') on_device = true;
+        else if (!e) {
+            uint64_t bytes = 0;
+            for (int i = 0; i < n && bytes < (64ull << 20); ++i) { FILE *f = fopen(bam_paths[i], "rb"); if (f) { fseek(f, 0, SEEK_END); const long z = ftell(f); fclose(f); if (z > 0) bytes += (uint64_t)z; } }
+            on_device = bytes >= (64ull << 20);
+        }
+    }
     auto pack_one = [&](int i, const uint8_t *data, uint64_t size, BamHeader &h, uint64_t rec_off) -> int {
         if (int rc = check_header(*ds, h, bam_paths[i])) return rc;
         return pack_sample(*ds, data + rec_off, size - rec_off, ds->samples[first + (size_t)i]);

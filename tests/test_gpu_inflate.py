@@ -50,3 +50,30 @@ def test_blocks_the_device_refuses_go_to_the_host_decoder(tmp_path):
             core.bgzf_inflate(bad, c)
         assert e.value.code == _lib.EFORMAT
     ctx.close()
+
+
+@pytest.mark.parametrize("mode", ["device", "host"])
+def test_file_entry_point_with_either_inflate(mode, tmp_path, monkeypatch):
+    """msnv_dataset_add_sample_bams with the blocks inflated on the device (the default from 64 MB of BAM on) and on the host: the same
+    dataset -- sizes, called positions, bytes of called_SNPs."""
+    monkeypatch.setenv("MSNV_INFLATE", mode)
+    sp = core.synth_params(n_species=2, contig_len=30000, n_samples=6, mean_cov=12.0, frac_paired=0.4, snv_density=0.02, seed=11)
+    syn = core.Synth(sp)
+    fa = str(tmp_path / "ref.fa"); syn.write_fasta(fa)
+    paths = []
+    for i in range(sp.n_samples):
+        p = str(tmp_path / ("s%d.bam" % i))
+        core.write_bam(p, syn.names, syn.lengths, syn.sample_records(i), level=[1, 6, 0, 9, 4, 2][i]); paths.append(p)
+    ctx = core.Context(0)
+    ds = core.Dataset.from_files(ctx, paths[0], fa)
+    ds.add_sample_bams(paths, 3)
+    info = ds.finalize(); st = ds.run()
+    ds.write_calls(str(tmp_path / "c"), str(tmp_path / "i"), None, None)
+    got = open(tmp_path / "c").read()
+    ds.close(); ctx.close()
+    import orc
+    from parity import run_oracle
+    samples = [syn.sample_records(i) for i in range(sp.n_samples)]
+    want = run_oracle(syn.names, syn.lengths, syn.seqs, samples)
+    assert got == want[0] and got.count("\n") > 10 and info["n_pileup_bases"] == want[3]
+
