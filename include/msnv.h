@@ -377,6 +377,11 @@ int  msnv_results_fetch(msnv_dataset *ds, msnv_site *sites, msnv_site_sample *sa
 /* Host-stage counters since the library was loaded: BGZF blocks that the library's own DEFLATE decoder (csrc/inflate.cpp)
  * handed to zlib (0 for well-formed files; tests). */
 int  msnv_host_stats(uint64_t *zlib_fallbacks);
+/* The alignment-record streams of several BAM files in one call (the N-rank driver reads a round of files and deals their records to
+ * the ranks that own the contigs: msnv_records_partition): through the device BGZF inflate when ctx is given and the files bring
+ * >= 64 MB (MSNV_INFLATE overrides), else one host thread per file.  records[i], n_bytes[i]: the records behind the header of
+ * bam_paths[i]; every records[i] is released with msnv_free.  Replaces the read loop `sam_read1` of qaCompute.cpp:441 / samtools. */
+int  msnv_bam_records_many(msnv_ctx *ctx, const char *const *bam_paths, int32_t n, int32_t host_threads, uint8_t **records, uint64_t *n_bytes);
 /* Test / measurement hook of the device BGZF inflate (csrc/inflate_k.hip): the inflated bytes of one BGZF
  * file, through the device (on_device != 0, needs ctx) or the host decoder.  *out is released with msnv_free.  counters (may be
  * NULL): [0] blocks, [1] blocks the device refused and the host inflated, [2] kernel microseconds, [3] inflated bytes. */

@@ -114,6 +114,7 @@ SYMBOLS = [
     ("msnv_coverage", C.c_int, [_vp, P(CovArgs)]),
     ("msnv_call", C.c_int, [_vp, P(CallArgs)]),
     ("msnv_call_from_mpileup", C.c_int, [_vp, P(MpileupArgs), P(C.c_uint64)]),
+    ("msnv_bam_records_many", C.c_int, [_vp, P(C.c_char_p), C.c_int32, C.c_int32, P(P(C.c_uint8)), P(C.c_uint64)]),
     ("msnv_bgzf_inflate", C.c_int, [_vp, C.c_char_p, C.c_int32, P(P(C.c_uint8)), P(C.c_uint64), P(C.c_uint64)]),
     ("msnv_dataset_create", C.c_int, [_vp, P(RefDesc), P(Params), P(_vp)]),
     ("msnv_dataset_create_from_files", C.c_int, [_vp, C.c_char_p, C.c_char_p, P(Params), P(_vp)]),

@@ -326,6 +326,25 @@ def call_from_mpileup(ctx, called_path, indiv_path=None, text=None, mpileup_path
             "text_bytes": int(st[5]), "base_chars": int(st[6])}
 
 
+def read_bam_records(paths, ctx=None, threads=0):
+    """Record streams (uint8 arrays) of several BAM files in one call: BGZF blocks inflated on the device when ctx is given and the
+    files are large enough (msnv_bam_records_many), else one host thread per file."""
+    n = len(paths)
+    if n == 0:
+        return []
+    recs = (C.POINTER(C.c_uint8) * n)()
+    sizes = (C.c_uint64 * n)()
+    check(lib.msnv_bam_records_many(ctx._h if ctx is not None else None, _cstr_array(paths), n, threads, recs, sizes))
+    out = []
+    try:
+        for i in range(n):
+            out.append(np.ctypeslib.as_array(recs[i], shape=(sizes[i],)).copy() if sizes[i] else np.zeros(0, np.uint8))
+    finally:
+        for i in range(n):
+            lib.msnv_free(recs[i])
+    return out
+
+
 def bgzf_inflate(path, ctx=None):
     """Inflated bytes of a BGZF file through the device (ctx given) or the host decoder; returns (bytes as a numpy array, counters)."""
     out = C.POINTER(C.c_uint8)()

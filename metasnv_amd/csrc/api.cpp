@@ -315,6 +315,74 @@ extern "C" int msnv_bgzf_inflate(msnv_ctx *ctx, const char *path, int32_t on_dev
     } catch (const std::exception &e) { return fail(MSNV_ENOMEM, "msnv_bgzf_inflate: %s", e.what()); }
 }
 
+// The record streams of several BAM files (the N-rank driver deals them to the ranks that own their contigs): through the device
+// inflate when a context is given and the files are large enough (the rule of msnv_dataset_add_sample_bams), else one host thread
+// per file.  records[i] (released with msnv_free) holds n_bytes[i] bytes: the alignment records behind the header of bam_paths[i].
+extern "C" int msnv_bam_records_many(msnv_ctx *ctx, const char *const *bam_paths, int32_t n, int32_t host_threads, uint8_t **records, uint64_t *n_bytes) {
+    clear_error();
+    if (n < 0 || (n && (!bam_paths || !records || !n_bytes))) return fail(MSNV_EINVAL, "msnv_bam_records_many: bad argument");
+    for (int i = 0; i < n; ++i) { records[i] = nullptr; n_bytes[i] = 0; }
+    int nthreads = host_threads > 0 ? host_threads : (int)std::max(1u, std::thread::hardware_concurrency());
+    nthreads = std::min(nthreads, std::max(1, (int)n));
+    bool on_device = false;
+    if (ctx) {
+        const char *e = getenv("MSNV_INFLATE");
+        if (e && e[0] == 'd') on_device = true;
+        else if (!e) {
+            uint64_t bytes = 0;
+            for (int i = 0; i < n && bytes < (64ull << 20); ++i) { FILE *f = fopen(bam_paths[i], "rb"); if (f) { fseek(f, 0, SEEK_END); const long z = ftell(f); fclose(f); if (z > 0) bytes += (uint64_t)z; } }
+            on_device = bytes >= (64ull << 20);
+        }
+    }
+    std::atomic<int> err{0};
+    std::vector<std::string> msgs((size_t)std::max(n, 0));
+    auto keep = [&](int i, const uint8_t *data, uint64_t size) -> int {      // header parsed, records copied out
+        BamHeader h; uint64_t rec_off = 0;
+        if (int rc = bam_parse_header_bytes(data, size, bam_paths[i], h, rec_off)) return rc;
+        const uint64_t nb = size - rec_off;
+        uint8_t *p = (uint8_t *)malloc(nb ? nb : 1);
+        if (!p) return fail(MSNV_ENOMEM, "%s: out of memory for %llu record bytes", bam_paths[i], (unsigned long long)nb);
+        memcpy(p, data + rec_off, nb);
+        records[i] = p; n_bytes[i] = nb;
+        return MSNV_OK;
+    };
+    auto run_threads = [&](int lo, int hi, auto body) {
+        std::atomic<int> nxt{lo};
+        auto w = [&]() {
+            for (;;) {
+                const int i = nxt.fetch_add(1);
+                if (i >= hi || err.load()) break;
+                int rc;
+                try { rc = body(i); } catch (const std::exception &e) { rc = fail(MSNV_ENOMEM, "%s: %s", bam_paths[i], e.what()); }
+                if (rc) { msgs[(size_t)i] = msnv_last_error(); err.store(rc); }
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 0; t < std::max(1, std::min(nthreads, hi - lo)); ++t) th.emplace_back(w);
+        for (auto &t : th) t.join();
+    };
+    int rc = MSNV_OK;
+    try {
+        if (on_device) {
+            auto consume = [&](int f0, int f1, const uint8_t *out, const std::vector<InflatedExt> &ext) -> int {
+                run_threads(f0, f1, [&](int i) { return keep(i, out + ext[(size_t)(i - f0)].off, ext[(size_t)(i - f0)].size); });
+                return err.load();
+            };
+            uint64_t cnt[4];
+            rc = bgzf_read_files_device(ctx, bam_paths, n, nthreads, consume, cnt);
+        } else {
+            run_threads(0, n, [&](int i) { ByteBuf buf; if (int r = bgzf_read_all(bam_paths[i], buf, 1)) return r; return keep(i, buf.data(), buf.size()); });
+            rc = err.load();
+        }
+    } catch (const std::exception &e) { rc = fail(MSNV_ENOMEM, "msnv_bam_records_many: %s", e.what()); }
+    if (rc) {
+        for (int i = 0; i < n; ++i) { free(records[i]); records[i] = nullptr; n_bytes[i] = 0; }
+        for (const std::string &m : msgs) if (!m.empty()) return fail(rc, "%s", m.c_str());
+        return rc;
+    }
+    return MSNV_OK;
+}
+
 extern "C" int msnv_dataset_add_sample_bams(msnv_dataset *ds, const char *const *bam_paths, int32_t n, int32_t host_threads) {
     clear_error();
     if (!ds || (n && !bam_paths)) return fail(MSNV_EINVAL, "msnv_dataset_add_sample_bams: NULL argument");

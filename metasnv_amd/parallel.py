@@ -169,15 +169,18 @@ def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=Non
         if metrics is not None:
             metrics["inflated_record_bytes"] = None
         return np.stack([ds.sample_stats(i) for i in range(n)]) if n else np.zeros((0, len(core.STATS_FIELDS)), np.uint32)
-    if read_records is None:
-        read_records = lambda path: core.read_bam(path)["records"]
+    read_many = None
+    if read_records is None:                             # the library reads a round's files in one call (device inflate when they are large)
+        read_many = lambda paths: core.read_bam_records(paths, ctx=getattr(ds, "ctx", None), threads=max(1, len(paths)))
     stats = np.zeros((n, len(core.STATS_FIELDS)), dtype=np.uint32)
     inflated = 0
     for base, plan in deal_samples(n, batch):
         mine = [i for i, r in plan if r == _rank]
         # decode my samples of this round and deal every one of them to the owners
         per_dest = [[] for _ in range(_world)]          # per destination rank: (sample, bytes) in sample order
-        if len(mine) > 1:                                # the library releases the GIL: one decode thread per BAM of the round
+        if read_many is not None:
+            decoded = read_many([bam_paths[i] for i in mine])
+        elif len(mine) > 1:                              # the library releases the GIL: one decode thread per BAM of the round
             from concurrent.futures import ThreadPoolExecutor
             with ThreadPoolExecutor(max_workers=len(mine)) as ex:
                 decoded = list(ex.map(read_records, [bam_paths[i] for i in mine]))
