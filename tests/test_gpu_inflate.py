@@ -77,3 +77,72 @@ def test_file_entry_point_with_either_inflate(mode, tmp_path, monkeypatch):
     want = run_oracle(syn.names, syn.lengths, syn.seqs, samples)
     assert got == want[0] and got.count("\n") > 10 and info["n_pileup_bases"] == want[3]
 
+
+
+def _bgzf(blocks_payload):
+    """A BGZF file from (raw deflate payload, uncompressed bytes) pairs, plus the EOF block."""
+    import struct, zlib
+    out = bytearray()
+    for comp, data in blocks_payload:
+        bsize = 18 + len(comp) + 8
+        out += bytes([31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0]) + struct.pack("<H", bsize - 1)
+        out += comp + struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data))
+    out += bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    return bytes(out)
+
+
+def test_device_inflate_on_crafted_streams_of_every_kind(tmp_path):
+    """Raw DEFLATE streams of every block type and strategy zlib can write (stored, fixed, dynamic; RLE, Huffman-only, filtered;
+    levels 0-9; distance-1 runs, long matches, incompressible bytes, sizes 0 .. 65280) wrapped as BGZF: the device returns the host
+    decoder's bytes.  Corrupted copies: whatever the host decoder says (error, or some bytes) the device path says too."""
+    import random
+    import zlib
+    rnd = random.Random(5)
+
+    def data_of(kind, n):
+        if kind == 0: return bytes(rnd.getrandbits(8) for _ in range(n))
+        if kind == 1: return bytes(rnd.choice(b"ACGT") for _ in range(n))
+        if kind == 2:
+            v = bytearray(rnd.getrandbits(8) for _ in range(min(n, 300)))
+            while len(v) < n: v.append(v[len(v) - 1 - rnd.randrange(min(len(v), 300))])
+            return bytes(v[:n])
+        if kind == 3: return b"x" * n
+        return bytes(30 + rnd.randrange(11) for _ in range(n))
+
+    ctx = core.Context(0)
+    strategies = [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED]
+    blocks = []
+    for r in range(160):
+        n = r if r < 6 else rnd.choice([17, 300, 4000, 30000, 65280])
+        d = data_of(r % 5, n)
+        c = zlib.compressobj(rnd.randrange(10), zlib.DEFLATED, -15, 8, strategies[(r // 5) % 5])
+        blocks.append((c.compress(d) + c.flush(), d))
+    p = str(tmp_path / "crafted.gz")
+    open(p, "wb").write(_bgzf(blocks))
+    want = b"".join(d for _, d in blocks)
+    host, _ = core.bgzf_inflate(p)
+    dev, cnt = core.bgzf_inflate(p, ctx)
+    assert host.tobytes() == want and dev.tobytes() == want and cnt["host_blocks"] == 0
+    # corrupted payloads, one block per file
+    n_err = n_same = 0
+    for trial in range(60):
+        comp, d = blocks[6 + rnd.randrange(len(blocks) - 6)]
+        if len(comp) < 4:
+            continue
+        bad = bytearray(comp)
+        for _ in range(rnd.randrange(1, 4)):
+            bad[rnd.randrange(len(bad))] ^= 1 << rnd.randrange(8)
+        q = str(tmp_path / ("bad%d.gz" % trial))
+        open(q, "wb").write(_bgzf([(bytes(bad), d)]))
+        res = []
+        for c in (None, ctx):
+            try:
+                res.append(core.bgzf_inflate(q, c)[0].tobytes())
+            except _lib.MsnvError as e:
+                assert e.code == _lib.EFORMAT
+                res.append(None)
+        assert res[0] == res[1], trial
+        n_err += res[0] is None
+        n_same += res[0] is not None
+    assert n_err > 10
+    ctx.close()
