@@ -315,6 +315,25 @@ extern "C" int msnv_bgzf_inflate(msnv_ctx *ctx, const char *path, int32_t on_dev
     } catch (const std::exception &e) { return fail(MSNV_ENOMEM, "msnv_bgzf_inflate: %s", e.what()); }
 }
 
+// Where the BGZF blocks of a call's files are inflated.  Default: on the device for calls that bring at least 64 MB of BAM and have a
+// context -- below that the host decoder is done before the staging is set up; MSNV_INFLATE=host | zlib keeps everything on the host,
+// MSNV_INFLATE=device forces the device whatever the size.
+static bool want_device_inflate(msnv_ctx *ctx, const char *const *paths, int n) {
+    if (!ctx) return false;
+    const char *e = getenv("MSNV_INFLATE");
+    if (e) return e[0] == 'd';
+    uint64_t bytes = 0;
+    for (int i = 0; i < n && bytes < (64ull << 20); ++i) {
+        FILE *f = fopen(paths[i], "rb");
+        if (!f) continue;
+        fseek(f, 0, SEEK_END);
+        const long z = ftell(f);
+        fclose(f);
+        if (z > 0) bytes += (uint64_t)z;
+    }
+    return bytes >= (64ull << 20);
+}
+
 // The record streams of several BAM files (the N-rank driver deals them to the ranks that own their contigs): through the device
 // inflate when a context is given and the files are large enough (the rule of msnv_dataset_add_sample_bams), else one host thread
 // per file.  records[i] (released with msnv_free) holds n_bytes[i] bytes: the alignment records behind the header of bam_paths[i].
@@ -324,16 +343,7 @@ extern "C" int msnv_bam_records_many(msnv_ctx *ctx, const char *const *bam_paths
     for (int i = 0; i < n; ++i) { records[i] = nullptr; n_bytes[i] = 0; }
     int nthreads = host_threads > 0 ? host_threads : (int)std::max(1u, std::thread::hardware_concurrency());
     nthreads = std::min(nthreads, std::max(1, (int)n));
-    bool on_device = false;
-    if (ctx) {
-        const char *e = getenv("MSNV_INFLATE");
-        if (e && e[0] == 'd') on_device = true;
-        else if (!e) {
-            uint64_t bytes = 0;
-            for (int i = 0; i < n && bytes < (64ull << 20); ++i) { FILE *f = fopen(bam_paths[i], "rb"); if (f) { fseek(f, 0, SEEK_END); const long z = ftell(f); fclose(f); if (z > 0) bytes += (uint64_t)z; } }
-            on_device = bytes >= (64ull << 20);
-        }
-    }
+    const bool on_device = want_device_inflate(ctx, bam_paths, n);
     std::atomic<int> err{0};
     std::vector<std::string> msgs((size_t)std::max(n, 0));
     auto keep = [&](int i, const uint8_t *data, uint64_t size) -> int {      // header parsed, records copied out
@@ -395,18 +405,7 @@ extern "C" int msnv_dataset_add_sample_bams(msnv_dataset *ds, const char *const 
     std::vector<std::string> msgs((size_t)n);
     // MSNV_INFLATE=device: the BGZF blocks of the files are inflated on the device (inflate_k.hip: a wavefront per block, thousands of
     // blocks at a time), batch by batch; the host threads read the files in front of it and parse / pack the batch's bytes in place
-    // (default: on for calls that bring at least 64 MB of BAM -- below that the host decoder is done before the staging is set up;
-    // MSNV_INFLATE=host | zlib keeps everything on the host, MSNV_INFLATE=device forces the device whatever the size)
-    bool on_device = false;
-    if (ds->ctx) {
-        const char *e = getenv("MSNV_INFLATE");
-        if (e && e[0] == 'd') on_device = true;
-        else if (!e) {
-            uint64_t bytes = 0;
-            for (int i = 0; i < n && bytes < (64ull << 20); ++i) { FILE *f = fopen(bam_paths[i], "rb"); if (f) { fseek(f, 0, SEEK_END); const long z = ftell(f); fclose(f); if (z > 0) bytes += (uint64_t)z; } }
-            on_device = bytes >= (64ull << 20);
-        }
-    }
+    const bool on_device = want_device_inflate(ds->ctx, bam_paths, n);
     auto pack_one = [&](int i, const uint8_t *data, uint64_t size, BamHeader &h, uint64_t rec_off) -> int {
         if (int rc = check_header(*ds, h, bam_paths[i])) return rc;
         return pack_sample(*ds, data + rec_off, size - rec_off, ds->samples[first + (size_t)i]);
