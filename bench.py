@@ -321,6 +321,41 @@ def main():
             dist_extra = {"samples": ns.value, "positions": int(npos.value), "pairs": ns.value * (ns.value + 1) // 2, "kernel_ms": ms.value,
                           "table_bytes_read_per_pair": 16 * int(npos.value)}
 
+    decode_extra = None
+    if not a.no_annotation and rank == 0 and world == 1 and a.workload == "testdata":
+        # the host stage in front of the kernels -- 16 of the workload's samples written as BAM files and
+        # read back through msnv_dataset_add_sample_bams (read + BGZF inflate + parse + pack) with 8 host threads, the blocks inflated
+        # by the host decoder and on the device (csrc/inflate_k.hip); outside the timed region
+        import tempfile
+        try:
+            with tempfile.TemporaryDirectory() as td:
+                fa = os.path.join(td, "ref.fa")
+                syn.write_fasta(fa)
+                paths = []
+                for i in range(min(16, sp.n_samples)):
+                    pth = os.path.join(td, "s%03d.bam" % i)
+                    core.write_bam(pth, syn.names, syn.lengths, syn.sample_records(i))
+                    paths.append(pth)
+                decode_extra = {"files": len(paths), "bam_bytes": sum(os.path.getsize(x) for x in paths), "host_threads": 8}
+                keep = os.environ.get("MSNV_INFLATE")
+                for mode in ("device", "host", "device"):              # (the first device round pins the staging buffers)
+                    os.environ["MSNV_INFLATE"] = mode
+                    d2 = core.Dataset.from_files(ctx, paths[0], fa)
+                    t0h = time.perf_counter()
+                    d2.add_sample_bams(paths, 8)
+                    dth = time.perf_counter() - t0h
+                    nb = d2.finalize()["n_pileup_bases"]
+                    d2.close()
+                    decode_extra["%s_inflate" % mode] = {"seconds": dth, "Gbases_per_s": nb / dth / 1e9}
+                if keep is None:
+                    os.environ.pop("MSNV_INFLATE", None)
+                else:
+                    os.environ["MSNV_INFLATE"] = keep
+                _, cnt = core.bgzf_inflate(paths[0], ctx)
+                decode_extra["inflate_kernel"] = {"blocks": cnt["blocks"], "ms": cnt["kernel_ms"], "inflated_bytes": cnt["bytes"]}
+        except Exception as e:                             # the extra must never cost the bench line
+            decode_extra = {"error": repr(e)}
+
     bases = info["n_pileup_bases"]
     k_ms = sum(ms_pileup) / len(ms_pileup)
     alg = st["algorithmic_bytes"]
@@ -376,6 +411,8 @@ def main():
             line["annotation"] = ann_extra
         if dist_extra:
             line["distances"] = dist_extra
+        if decode_extra:
+            line["host_decode"] = decode_extra
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(sp_kwargs, min(a.cpu_samples, sp.n_samples))
         print(json.dumps(line))
