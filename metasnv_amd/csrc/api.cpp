@@ -275,6 +275,15 @@ static int bgzf_read_files_device(msnv_ctx *ctx, const char *const *paths, int n
         if (int rc = dev_inflate_staging(ctx, ib, ob, &in_stage, &out)) return rc;       // (the input staging does not move: it only grows when ib does)
         std::vector<uint32_t> status;
         if (int rc = dev_inflate(ctx, ib, list, ob, status, &ms)) return rc;
+        // Spot check: every 64th block's output against the CRC-32 of its BGZF trailer (the device decoder is young; a block that does not
+        // check is handed to the host decoder like one the device refused).  MSNV_INFLATE_CHECK=n: every n-th block (1 = all, 0 = none).
+        static const uint32_t check_every = [] { const char *e = getenv("MSNV_INFLATE_CHECK"); return e ? (uint32_t)std::max(0, atoi(e)) : 64u; }();
+        if (check_every) for (size_t e = (size_t)(f0 % (int)check_every); e < list.size(); e += check_every) {
+            if (status[e]) continue;
+            const uint8_t *trailer = in_stage + list[e].in_off + list[e].in_size;
+            const uint32_t want = (uint32_t)trailer[0] | (uint32_t)trailer[1] << 8 | (uint32_t)trailer[2] << 16 | (uint32_t)trailer[3] << 24;
+            if (bgzf_crc32(out + list[e].out_off, list[e].out_size) != want) status[e] = 2u;
+        }
         for (size_t e = 0; e < list.size(); ++e) {
             if (!status[e]) continue;
             ++n_host;

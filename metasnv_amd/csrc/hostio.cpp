@@ -130,6 +130,7 @@ int bgzf_load(const char *path, ByteBuf &comp, size_t &n_in, std::vector<BgzfBlo
     return bgzf_index(ConstBytes{comp.data(), n_in}, path, blocks, total_out);
 }
 bool bgzf_inflate_block_host(const uint8_t *src, uint32_t n_in, uint8_t *dst, uint32_t n_out) { return inflate_block(src, n_in, dst, n_out); }
+uint32_t bgzf_crc32(const uint8_t *data, uint32_t n) { return (uint32_t)crc32(crc32(0L, Z_NULL, 0), data, n); }
 int bgzf_index_bytes(const uint8_t *data, size_t n, const char *path, std::vector<BgzfBlock> &blocks, uint64_t &total_out) {
     blocks.clear();
     return bgzf_index(ConstBytes{data, n}, path, blocks, total_out);

@@ -46,6 +46,7 @@ int bgzf_read_all(const char *path, ByteBuf &out, int threads);
 struct BgzfBlock { uint64_t in_off; uint32_t in_size; uint32_t out_size; uint64_t out_off; };
 int bgzf_load(const char *path, ByteBuf &comp, size_t &n_in, std::vector<BgzfBlock> &blocks, uint64_t &total_out);
 bool bgzf_inflate_block_host(const uint8_t *src, uint32_t n_in, uint8_t *dst, uint32_t n_out);
+uint32_t bgzf_crc32(const uint8_t *data, uint32_t n);           // CRC-32 as in the BGZF trailer
 int bgzf_index_bytes(const uint8_t *data, size_t n, const char *path, std::vector<BgzfBlock> &blocks, uint64_t &total_out);   // `data` needs 16 readable bytes behind n
 int bam_parse_header_bytes(const uint8_t *data, size_t n, const char *path, BamHeader &hdr, uint64_t &rec_off);
 int bgzf_write_all(const char *path, const uint8_t *data, uint64_t n, int level);
