@@ -277,7 +277,7 @@ static int bgzf_read_files_device(msnv_ctx *ctx, const char *const *paths, int n
         if (int rc = dev_inflate(ctx, ib, list, ob, status, &ms)) return rc;
         // Spot check: every 64th block's output against the CRC-32 of its BGZF trailer (the device decoder is young; a block that does not
         // check is handed to the host decoder like one the device refused).  MSNV_INFLATE_CHECK=n: every n-th block (1 = all, 0 = none).
-        static const uint32_t check_every = [] { const char *e = getenv("MSNV_INFLATE_CHECK"); return e ? (uint32_t)std::max(0, atoi(e)) : 64u; }();
+        const uint32_t check_every = [] { const char *e = getenv("MSNV_INFLATE_CHECK"); return e ? (uint32_t)std::max(0, atoi(e)) : 64u; }();   // (per call: tests switch it)
         if (check_every) for (size_t e = (size_t)(f0 % (int)check_every); e < list.size(); e += check_every) {
             if (status[e]) continue;
             const uint8_t *trailer = in_stage + list[e].in_off + list[e].in_size;

@@ -21,7 +21,8 @@ def _bam(tmp_path, level, seed, **kw):
 
 
 @pytest.mark.parametrize("level", [0, 1, 4, 6, 9])
-def test_device_inflate_equals_host_inflate(level, tmp_path):
+def test_device_inflate_equals_host_inflate(level, tmp_path, monkeypatch):
+    monkeypatch.setenv("MSNV_INFLATE_CHECK", "1")          # every block against the CRC-32 of its trailer (default: every 64th)
     ctx = core.Context(0)
     for seed in (1, 2):
         p = _bam(tmp_path, level, seed)
