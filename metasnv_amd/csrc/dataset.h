@@ -57,7 +57,7 @@ constexpr uint32_t WORK_FUSED = 8u;          // WorkItem::part_lo bit: whole-til
 constexpr uint32_t MERGE_MAX_PAIRS = 256;    // pairs per merged group of shallow (sample, tile) pairs (pack.cpp; kernels.hip: msnv_pileup_tiles_merged)
 constexpr uint32_t MERGE_MAX_DEPTH = 240;    // their depth bounds add up to at most this (byte bins)
 constexpr int COV_PW = 4;                    // (tile, sample) pairs per wavefront of msnv_coverage_tiles
-constexpr uint32_t COV_ITEM_PAIRS = 16;      // pairs per coverage work item (4 wavefronts x COV_PW)
+constexpr uint32_t COV_ITEM_PAIRS = 4;       // pairs per coverage work item (one wavefront x COV_PW)
 constexpr uint32_t CHUNK_READS = 128;
 constexpr uint32_t MAX_CHUNKS_PER_ITEM = 32;
 struct ChunkDesc { uint64_t hdr_base, seq_base; uint32_t sample, pair, nrd_flags, pad; };   // nrd | last_chunk << 16

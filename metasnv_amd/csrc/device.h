@@ -121,7 +121,7 @@ struct DeviceCols {
     uint32_t *tile_contig_dev = nullptr;
     unsigned long long *cov_acc = nullptr;   // [copy][sample][contig][1 + COV_BINS]: covSum, hist[0..]; tile t adds to copy t % cov_copies
     uint32_t  cov_copies = 1;                // (the tiles of a long contig would otherwise queue up on one 64-byte line); summed on the host
-    uint32_t  n_cov_pairs = 0, n_cov_work = 0, n_contigs = 0;
+    uint32_t  n_cov_pairs = 0, n_cov_work = 0, n_cov_work_wide = 0, n_contigs = 0;   // (the last n_cov_work_wide items hold a pair of > 32 767 intervals)
     uint64_t  n_cov_iv = 0;
     uint64_t  device_bytes = 0;
     uint64_t  algorithmic_bytes = 0;

@@ -1686,135 +1686,177 @@ __global__ __launch_bounds__(256) void msnv_decide_sites(const SiteRec *sites, c
 // msnv_coverage_tiles: qaCompute's per-contig coverage arithmetic (qaCompute.cpp:530-552 scatter,
 // :142-165 prefix sum + histogram) for every sample, tile by tile.
 //   per (tile, sample): +1/-1 of every M interval into an LDS difference array (intervals that
-//   started in an earlier tile enter at index 0), DPP prefix sum, then for every scanned index
-//   (i < contig length) covSum += cov and hist[min(cov, max_cov)]++, reduced per wave and added
+//   started in an earlier tile enter at index 0), then per RUN of constant depth (i < contig length)
+//   covSum += depth x length and hist[min(depth, max_cov)] += length, reduced per wavefront and added
 //   to the (sample, contig) accumulators with 64-bit atomics.
-// Algorithmic HBM bytes: 8 B per M interval.
+// Algorithmic HBM bytes: 8 B per M interval.  The kernel is bound by vector-instruction issue
+// (DESIGN.md section 4 "Coverage kernel"), so its form follows the instruction count per pair.
 // ------------------------------------------------------------------------------------------
-constexpr int C_NT = 256;
+constexpr int C_NT = 64;                     // one wavefront per workgroup: nothing is shared, and the chip's wave slots refill one by one (workgroups of four: -9 %)
 static_assert(C_NT / 64 * COV_PW == COV_ITEM_PAIRS, "coverage work items are sized for COV_PW pairs per wavefront");
 
 __device__ __forceinline__ int wave_reduce_add(int x) {
     x = wave_inclusive_scan(x);
     return __builtin_amdgcn_readlane(x, 63);
 }
+// sum over the 16 lanes of a row, left in all of them (xor 1, xor 2, mirror of 8, mirror of 16)
+__device__ __forceinline__ uint32_t row_sum16(uint32_t x) {
+    x = (uint32_t)dpp_add<0xB1, 0xf>((int)x);    // quad_perm [1, 0, 3, 2]
+    x = (uint32_t)dpp_add<0x4E, 0xf>((int)x);    // quad_perm [2, 3, 0, 1]
+    x = (uint32_t)dpp_add<0x141, 0xf>((int)x);   // row_half_mirror
+    x = (uint32_t)dpp_add<0x140, 0xf>((int)x);   // row_mirror
+    return x;
+}
 
+// WIDE = false: the difference array holds two positions per word (16-bit halves biased by 0x8000, so that a half never borrows
+// from or carries into its neighbour) -- good for pairs of at most 32 767 intervals, which pack.cpp guarantees for the work items it hands
+// to this variant; WIDE = true: one word per position, any number of intervals (a pile-up of tens of thousands of reads with one
+// start: a handful of work items at most).
+template <bool WIDE>
 __global__ __launch_bounds__(C_NT) void msnv_coverage_tiles(const Pair32 *iv, const TilePair *pairs,
                                                             const WorkItem *work, const uint32_t *tile_len, const uint32_t *tile_contig,
                                                             unsigned long long *acc, uint32_t n_contigs, int max_cov, uint32_t n_samples, uint32_t n_copies) {
     // One WAVEFRONT per (tile, sample) pair, no workgroup barrier at all, and the work follows the BREAKPOINTS of the coverage
-    // instead of the positions: an interval adds +1 / -1 to a difference array in LDS (16-bit halves of 32-bit words) and sets the
-    // bit of either end in a 2048-bit mask; lane l owns positions [32 l, 32 l + 32) = one mask word, sums the differences at its
-    // set bits (one wave scan gives every lane the depth at its left edge) and then walks its ~3 runs of constant depth:
-    // covSum += depth x length, hist[min(depth, max_cov)] += length.  The previous form (one workgroup per pair, every position
-    // visited, a prefix sum and five wave reductions per wavefront) spent ~800 vector instructions per pair; this one ~250.
-    __shared__ int s_d[C_NT / 64][TILE / 2];               // two positions per word: low half = even position
+    // instead of the positions: an interval adds +1 / -1 to the difference array in LDS and sets the bit of either end in a
+    // 2048-bit mask; lane l owns positions [32 l, 32 l + 32) = one mask word and the 64 (128) bytes of differences behind it.  It
+    // sums ALL its differences with four (eight) 16-byte reads -- one wave scan then gives every lane the depth at its left edge --,
+    // walks its ~7 breakpoints (runs of constant depth: covSum += depth x length, hist[min(depth, max_cov)] += length in byte
+    // fields of two registers) and clears its words with four (eight) 16-byte writes.  The wavefront's histogram is reduced by
+    // halving: two lane-swap steps fold the four byte-field registers into ONE whose rows of 16 lanes hold four bins each, then
+    // four row steps on 16-bit fields.  ~445 vector instructions per pair at ~215 intervals (the first wavefront-per-pair form:
+    // ~915 -- three divergent loops over the breakpoints and nine wave scans; the workgroup-per-pair form before it: ~3200).
+    constexpr int WPL = WIDE ? 32 : 16;                      // LDS words per lane ...
+    constexpr int LSTRIDE = WPL + 4;                         // ... 16 bytes apart from the next lane's: the 16-byte reads and writes of the 64 lanes then spread over all banks (back to back they met 4 to a bank)
+    constexpr uint32_t EMPTY = WIDE ? 0u : 0x80008000u;      // both halves biased: neither ever borrows from or carries into its neighbour, and a half reads as difference + 0x8000
+    __shared__ __attribute__((aligned(16))) uint32_t s_d[C_NT / 64][64 * LSTRIDE];
     __shared__ uint32_t s_mask[C_NT / 64][TILE / 32];
     const WorkItem w = work[blockIdx.x];
     const uint32_t t0 = w.tile * TILE, tl = tile_len[w.tile], contig = tile_contig[w.tile];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int *const d = s_d[wave];
+    uint32_t *const d = s_d[wave];
     uint32_t *const mask = s_mask[wave];
     static_assert(TILE / 32 == 64, "one mask word per lane");
     auto base_of = [](const TilePair &p) -> uint64_t { return (uint64_t)p.nblk << 32 | p.blk_lo; };      // absolute index of the sample's first interval
-    auto half_at = [&](const uint32_t p) -> int {          // difference at position p: the halves borrow from each other while they are added up
-        const int wd = d[p >> 1], lo = (int)(short)(wd & 0xffff);
-        return (p & 1u) ? (wd - lo) >> 16 : lo;
+    uint4 *const mine = reinterpret_cast<uint4 *>(d + LSTRIDE * lane);
+    auto diff_at = [&](const uint32_t bpos) -> int {         // difference at my position bpos
+        if constexpr (WIDE) return (int)d[LSTRIDE * lane + (int)bpos];
+        else {
+            return (int)reinterpret_cast<const uint16_t *>(d + LSTRIDE * lane)[bpos] - 0x8000;
+        }
     };
     const uint32_t lim = (uint32_t)min(max((int)tl - 32 * lane, 0), 32);      // scanned positions among my 32 (i < contig length)
-    // A work item holds at most C_NT / 64 * COV_PW pairs (pack.cpp) and every wavefront owns COV_PW consecutive ones: ALL their
-    // descriptors, then the first 128 intervals of ALL of them, are loaded up front -- two round trips to memory per work item
-    // whatever it holds (the kernel was bound by one dependent descriptor -> intervals chain per pair, not by its arithmetic)
+    const uint32_t lim_mask = lim >= 32u ? 0xffffffffu : (1u << lim) - 1u;
+    // A work item holds at most COV_PW pairs (pack.cpp): ALL their
+    // descriptors are loaded up front, and the first 256 intervals of a pair while the pair before it is worked on (the kernel
+    // waited on one dependent descriptor -> intervals chain per pair, and then on the intervals beyond the first 128)
+    constexpr int PRE = 4;                                   // rounds of 64 intervals loaded ahead
     TilePair prs[COV_PW];
-    Pair32 xs[COV_PW][2];
+    Pair32 xs[COV_PW][PRE];
 #pragma unroll
     for (int j = 0; j < COV_PW; ++j) {
         const uint32_t kk = w.pair_lo + (uint32_t)(wave * COV_PW + j);
         prs[j] = kk < w.pair_hi ? pairs[kk] : TilePair{0, 0, 0, 0, 0, 0, 0, 0};
     }
-#pragma unroll
-    for (int j = 0; j < COV_PW; ++j) {
+    auto load_ahead = [&](const int j) {
         const uint32_t n = prs[j].read_hi - prs[j].read_lo;
         const Pair32 *v = iv + base_of(prs[j]) + prs[j].read_lo;
-        xs[j][0] = (uint32_t)lane < n ? v[lane] : Pair32{0u, 0u};            // {0, 0} touches nothing
-        xs[j][1] = (uint32_t)lane + 64u < n ? v[lane + 64] : Pair32{0u, 0u};
-    }
-    for (int i = lane; i < (int)(TILE / 2); i += 64) d[i] = 0;               // (under the loads)
+#pragma unroll
+        for (int r = 0; r < PRE; ++r) xs[j][r] = (uint32_t)(lane + 64 * r) < n ? v[lane + 64 * r] : Pair32{0u, 0u};   // {0, 0} touches nothing
+    };
+    load_ahead(0);
+    const uint4 empty4 = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
+#pragma unroll
+    for (int i = 0; i < WPL / 4; ++i) mine[i] = empty4;                      // (under the loads)
     mask[lane] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
     for (int j = 0; j < COV_PW; ++j) {
         const TilePair pr = prs[j];
         if (w.pair_lo + (uint32_t)(wave * COV_PW + j) >= w.pair_hi) break;
-        auto scatter = [&](const Pair32 x) {
-            if (x.x > x.y) {
-                // qaCompute's `--entireChr[chrSize-1]` without a matching `++` inside the scanned range: an M op whose cursor is
-                // at or beyond the contig end (qaCompute.cpp:542-549; the host stores it as {end, end - 1})
-                if (x.y >= t0 && x.y < t0 + TILE) {
-                    const uint32_t e = x.y - t0;
-                    atomicAdd(&d[e >> 1], (e & 1u) ? -65536 : -1);
-                    atomicOr(&mask[e >> 5], 1u << (e & 31u));
-                }
-                return;
-            }
-            if (x.y <= t0 || x.x >= t0 + TILE) return;
-            const uint32_t s = x.x > t0 ? x.x - t0 : 0u, e = min(x.y - t0, TILE);   // intervals that started in an earlier tile enter at 0
-            atomicAdd(&d[s >> 1], (s & 1u) ? 65536 : 1);
-            atomicOr(&mask[s >> 5], 1u << (s & 31u));
-            if (e < TILE) {
-                atomicAdd(&d[e >> 1], (e & 1u) ? -65536 : -1);
-                atomicOr(&mask[e >> 5], 1u << (e & 31u));
-            }
+        if (j + 1 < COV_PW) load_ahead(j + 1);
+        auto add_at = [&](const uint32_t p, const bool up) {
+            uint32_t *const word = d + 4u * (p >> 5) + (WIDE ? p : p >> 1);         // (lane p >> 5, LSTRIDE words each)
+            const uint32_t one = WIDE ? 1u : 1u << ((p & 1u) << 4);
+            if (up) atomicAdd(word, one); else atomicSub(word, one);
+            atomicOr(&mask[p >> 5], 1u << (p & 31u));
         };
-        scatter(xs[j][0]);
-        scatter(xs[j][1]);
-        if (pr.read_hi - pr.read_lo > 128u) {
+        auto scatter = [&](const Pair32 x) {
+            // one form for every case: an interval that started in an earlier tile enters at 0; an end left of the tile wraps
+            // (unsigned) and leaves it on the right like one beyond it; {end, end - 1} -- qaCompute's `--entireChr[chrSize-1]`
+            // without a matching `++` inside the scanned range, an M op whose cursor is at or beyond the contig end
+            // (qaCompute.cpp:542-549; pack.cpp stores it that way) -- has no start and its -1 at x.y; the {0, 0} of an idle lane
+            // touches nothing (in the tile at 0: +1 and -1 on position 0)
+            const uint32_t m = max(x.x, t0), e = x.y - t0;
+            if (x.y >= m && m - t0 < TILE) add_at(m - t0, true);
+            if (e < TILE) add_at(e, false);
+        };
+#pragma unroll
+        for (int r = 0; r < PRE; ++r) scatter(xs[j][r]);
+        if (pr.read_hi - pr.read_lo > 64u * PRE) {
             const Pair32 *v = iv + base_of(pr);
-            for (uint32_t i = pr.read_lo + 128u + (uint32_t)lane; i < pr.read_hi; i += 64) scatter(v[i]);
+            for (uint32_t i = pr.read_lo + 64u * PRE + (uint32_t)lane; i < pr.read_hi; i += 64) scatter(v[i]);
         }
         // the LDS executes one wavefront's instructions in order: the atomics above are done before the reads below are served
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        const uint32_t m = mask[lane];
+        const uint32_t m = mask[lane] & lim_mask;           // breakpoints behind the contig end are not scanned
         mask[lane] = 0u;
-        int delta = 0;
-        for (uint32_t mm = m; mm; mm &= mm - 1u) delta += half_at(32u * (uint32_t)lane + (uint32_t)__builtin_ctz(mm));
+        uint32_t sum = 0;
+#pragma unroll
+        for (int i = 0; i < WPL / 4; ++i) { const uint4 q = mine[i]; sum += q.x + q.y + q.z + q.w; }
+        int delta;
+        if constexpr (WIDE) delta = (int)sum;
+        else {
+            // sum = 65536 H + L + 16 x 0x8000 (+ 16 x 0x8000 x 65536 = 0 mod 2^32) with L, H = my even / odd positions'
+            // differences, each within +-32 767
+            const uint32_t s2 = sum - 16u * 0x8000u;
+            const int L = (int)(short)(s2 & 0xffffu);
+            delta = L + (((int)s2 - L) >> 16);
+        }
         int cur = wave_inclusive_scan(delta) - delta;      // depth at my left edge
-        // runs of constant depth inside my 32 positions
+        // runs of constant depth inside my scanned positions
         unsigned long long ha = 0, hb = 0;                 // bins 0-7 / 8-15, one byte each (a lane adds at most 32)
         int csum = 0;
         uint32_t prev = 0;
-        auto account = [&](const int depth, const uint32_t from, const uint32_t to) {
-            const uint32_t len = min(to, lim) - min(from, lim);
-            if (!len) return;
+        auto account = [&](const int depth, const uint32_t len) {
             csum += depth * (int)len;
             // -1 at the last position of a contig (see above): the reference then increments coverageHist[-1], out of bounds --
             // the position lands in no bin, the sum takes the -1 (and wraps, unsigned, exactly as covSum does)
-            if (depth < 0) return;
-            const uint32_t bin = (uint32_t)min(depth, max_cov);
-            const unsigned long long add = (unsigned long long)len << (8u * (bin & 7u));
-            if (bin < 8u) ha += add; else hb += add;
+            const uint32_t bin = (uint32_t)min(depth, max_cov), sh = (8u * bin) & 63u;
+            const uint32_t counted = depth < 0 ? 0u : len, la = bin < 8u ? counted : 0u;
+            ha += (unsigned long long)la << sh;
+            hb += (unsigned long long)(counted - la) << sh;
         };
         for (uint32_t mm = m; mm; mm &= mm - 1u) {
             const uint32_t bpos = (uint32_t)__builtin_ctz(mm);
-            account(cur, prev, bpos);
-            cur += half_at(32u * (uint32_t)lane + bpos);
+            account(cur, bpos - prev);
+            cur += diff_at(bpos);
             prev = bpos;
         }
-        account(cur, prev, 32u);
-        for (uint32_t mm = m; mm; mm &= mm - 1u) d[(32u * (uint32_t)lane + (uint32_t)__builtin_ctz(mm)) >> 1] = 0;   // my words only: positions 32 l .. 32 l + 31
+        account(cur, lim - prev);
+#pragma unroll
+        for (int i = 0; i < WPL / 4; ++i) mine[i] = empty4;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        // reduce over the wavefront: covSum, and two bins per register in 16-bit fields (a wavefront adds at most 2048 per bin)
+        // reduce over the wavefront.  Histogram: G[g] = bins 4 g .. 4 g + 3 in bytes; lanes l and l + 32 meet in the first swap
+        // (G0 | G1 in the two halves of one register), rows r and r + 1 in the second: one register whose rows hold G0, G2, G1, G3
+        // summed over 4 lanes (bytes <= 128); then 16-bit fields and the four steps inside a row (a wavefront adds <= 2048 per bin)
         const int ws = wave_reduce_add(csum);
-        int val = ws;                                       // lane 0: covSum; lane 1 + b: bin b
-        for (int q = 0; 2 * q <= max_cov; ++q) {
-            const unsigned long long src = q < 4 ? ha >> (16 * q) : hb >> (16 * (q - 4));
-            const uint32_t two = (uint32_t)(src & 0xffull) | (uint32_t)((src >> 8) & 0xffull) << 16;
-            const uint32_t wq = (uint32_t)wave_reduce_add((int)two);
-            if (lane == 1 + 2 * q) val = (int)(wq & 0xffffu);
-            if (lane == 2 + 2 * q) val = (int)(wq >> 16);
-        }
-        if (lane <= max_cov + 1 && val) {
+        const auto a01 = __builtin_amdgcn_permlane32_swap((uint32_t)ha, (uint32_t)(ha >> 32), false, false);
+        const auto a23 = __builtin_amdgcn_permlane32_swap((uint32_t)hb, (uint32_t)(hb >> 32), false, false);
+        const auto c = __builtin_amdgcn_permlane16_swap(a01[0] + a01[1], a23[0] + a23[1], false, false);
+        const uint32_t c4 = c[0] + c[1];
+        const uint32_t u0 = row_sum16(__builtin_amdgcn_perm(c4, c4, 0x0c010c00u));     // bins 4 g, 4 g + 1
+        const uint32_t u1 = row_sum16(__builtin_amdgcn_perm(c4, c4, 0x0c030c02u));     // bins 4 g + 2, 4 g + 3
+        // lanes 0-3 of row r hold the bins of group g = {0, 2, 1, 3}[r]; lane 4 adds covSum
+        const uint32_t k = (uint32_t)lane & 15u, r = (uint32_t)lane >> 4;
+        const uint32_t g = ((r & 1u) << 1) | (r >> 1);
+        const uint32_t two = (k & 2u) ? u1 : u0;
+        const uint32_t bin = 4u * g + k;
+        int val = (int)((k & 1u) ? two >> 16 : two & 0xffffu);
+        uint32_t idx = 1u + bin;
+        if (lane == 4) { val = ws; idx = 0u; }
+        if ((k < 4u || lane == 4) && val && idx <= (uint32_t)max_cov + 1u) {
             unsigned long long *dst = acc + (((uint64_t)(w.tile % n_copies) * n_samples + pr.sample) * n_contigs + contig) * (1 + COV_BINS);
-            atomicAdd(&dst[lane], (unsigned long long)(long long)val);
+            atomicAdd(&dst[idx], (unsigned long long)(long long)val);
         }
     }
 }
@@ -2174,8 +2216,12 @@ int dev_run_coverage(DeviceCols &d, int max_cov, void *stream_, msnv_run_stats *
     HIP_TRY(hipEventRecord(e0, st));
     HIP_TRY(hipMemsetAsync(d.cov_acc, 0, (uint64_t)d.cov_copies * d.n_samples * d.n_contigs * (1 + COV_BINS) * sizeof(unsigned long long), st));
     if (d.n_cov_work) {
-        hipLaunchKernelGGL(msnv_coverage_tiles, dim3(d.n_cov_work), dim3(C_NT), 0, st, d.cov_iv, d.cov_pairs, d.cov_work,
-                           d.tile_len, d.tile_contig_dev, d.cov_acc, d.n_contigs, max_cov, d.n_samples, d.cov_copies);
+        // work items that hold a pair of more than 32 767 intervals are the last n_cov_work_wide of the list (pack.cpp)
+        const uint32_t n_narrow = d.n_cov_work - d.n_cov_work_wide;
+        if (n_narrow) hipLaunchKernelGGL(msnv_coverage_tiles<false>, dim3(n_narrow), dim3(C_NT), 0, st, d.cov_iv, d.cov_pairs, d.cov_work,
+                                         d.tile_len, d.tile_contig_dev, d.cov_acc, d.n_contigs, max_cov, d.n_samples, d.cov_copies);
+        if (d.n_cov_work_wide) hipLaunchKernelGGL(msnv_coverage_tiles<true>, dim3(d.n_cov_work_wide), dim3(C_NT), 0, st, d.cov_iv, d.cov_pairs, d.cov_work + n_narrow,
+                                                  d.tile_len, d.tile_contig_dev, d.cov_acc, d.n_contigs, max_cov, d.n_samples, d.cov_copies);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(e1, st));

@@ -1192,8 +1192,9 @@ int finalize_dataset(msnv_dataset &ds) {
             for (size_t s = 0; s < S; ++s) for (const CP &p : per[s]) cpairs[fill[p.tile]++] = TilePair{p.sample, p.lo, p.hi, 0, (uint32_t)cvbase[s], (uint32_t)(cvbase[s] >> 32), 0, 0};
         }
         std::vector<WorkItem> cwork;
-        // a coverage work item = COV_ITEM_PAIRS consecutive pairs of a tile: every wavefront of msnv_coverage_tiles owns COV_PW of
-        // them and loads their descriptors and intervals up front (fewer when one pair alone is deep: MSNV_COV_ITEM intervals)
+        // a coverage work item = COV_ITEM_PAIRS consecutive pairs of a tile = one wavefront of msnv_coverage_tiles, which loads their
+        // descriptors up front and a pair's intervals while it works on the pair before (fewer when one pair alone is deep:
+        // MSNV_COV_ITEM intervals)
         const uint64_t cov_item_intervals = [] { const char *e = getenv("MSNV_COV_ITEM"); const long long v = e ? atoll(e) : 16384; return (uint64_t)(v > 0 ? v : 16384); }();
         for (uint64_t t = 0; t < nt; ++t) {
             uint32_t lo = cps[t]; uint64_t acc = 0;
@@ -1202,6 +1203,13 @@ int finalize_dataset(msnv_dataset &ds) {
                 if (acc >= cov_item_intervals || k + 1 - lo >= COV_ITEM_PAIRS || k + 1 == cps[t + 1]) { cwork.push_back(WorkItem{(uint32_t)t, lo, k + 1, 0, 0, 0, 0, 0, ChunkDesc{}}); lo = k + 1; acc = 0; }
             }
         }
+        // the items with a pair of more than 32 767 intervals go last: msnv_coverage_tiles<true> (one word per position) runs them,
+        // the 16-bit difference array of the usual variant holds +-32 767 per position and per 16 positions of one parity
+        // (MSNV_COV_NARROW_MAX is read per dataset: tests lower it to run the other variant)
+        const uint32_t cov_narrow_max = [] { const char *e = getenv("MSNV_COV_NARROW_MAX"); const long long v = e ? atoll(e) : 32767; return (uint32_t)std::min<long long>(32767, std::max<long long>(1, v)); }();
+        auto cov_wide = [&](const WorkItem &w) { for (uint32_t k = w.pair_lo; k < w.pair_hi; ++k) if (cpairs[k].read_hi - cpairs[k].read_lo > cov_narrow_max) return true; return false; };
+        const auto first_wide = std::stable_partition(cwork.begin(), cwork.end(), [&](const WorkItem &w) { return !cov_wide(w); });
+        d->n_cov_work_wide = (uint32_t)(cwork.end() - first_wide);
         std::vector<uint32_t> tlen(nt + 1, 0), tcont(nt + 1, 0);
         for (uint64_t t = 0; t < nt; ++t) {
             const size_t c = ds.tile_contig[t];

@@ -667,6 +667,30 @@ def test_coverage_reads_at_the_contig_end_do_not_fail_the_run(tmp_path):
     assert res[0][0][1].startswith("c1\t100\t38\t")           # indices 61..98 covered, index 99 (coverage -2) in no bin
 
 
+def test_coverage_kernel_variants_and_a_pile_of_reads_with_one_start(tmp_path, monkeypatch):
+    """msnv_coverage_tiles keeps two positions per LDS word (16-bit differences) for pairs of at most 32 767 intervals and one
+    word per position beyond: (a) both variants on the same ordinary data, (b) 40 000 reads that start on one position (the
+    16-bit form would wrap) next to ordinary samples."""
+    syn, samples = synth_case(n_species=2, contig_len=5000, n_samples=4, mean_cov=8.0, seed=23)
+    samples = [s for s in samples if s.size]
+    want, _ = _coverage_both(syn.names, syn.lengths, samples, tmp_path)
+    monkeypatch.setenv("MSNV_COV_NARROW_MAX", "1")                   # every work item goes to the one-word-per-position variant
+    got, _ = _coverage_both(syn.names, syn.lengths, samples, tmp_path)
+    monkeypatch.delenv("MSNV_COV_NARROW_MAX")
+    for (g, w) in zip(got, want):
+        assert g[0] == g[1] and g[0] == w[0]
+    L = 5000
+    ref = "ACGT" * (L // 4)
+    pile = [bt.make_record(0, 2100, "60M", ref[2100:2160], name="p%d" % i) for i in range(40000)]
+    rest = [bt.make_record(0, 2090 + 7 * k, "50M", ref[2090 + 7 * k:2140 + 7 * k], name="r%d" % k) for k in range(40)]
+    order = sorted(pile + rest, key=lambda r: int.from_bytes(r[8:12], "little", signed=True))
+    s1 = bt.records(*order)
+    s2 = bt.records(*[bt.make_record(0, 13 * k, "70M", ref[13 * k:13 * k + 70], name="q%d" % k) for k in range(300)])
+    res, _ = _coverage_both(["c1"], [L], [s1, s2], tmp_path)
+    for (g, w) in res:
+        assert g == w
+
+
 def _write_inputs(tmp_path, syn, samples):
     fa = str(tmp_path / "ref.fa")
     syn.write_fasta(fa)
