@@ -63,7 +63,7 @@ def measured_traffic(samples, species, contig_len, mean_cov):
     (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 read correction applied).
     Only valid for the workload it was collected on; anything else reports null."""
     try:
-        p = json.load(open(os.path.join(ROOT, "profiles", "r02c_pmc.json")))
+        p = json.load(open(os.path.join(ROOT, "profiles", "r02d_pmc.json")))
         if (samples, species, contig_len, mean_cov) == (160, 3, 300000, 10.0):
             return p["hbm_traffic"]["total_bytes_per_launch"]
     except Exception:
