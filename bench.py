@@ -282,9 +282,9 @@ def main():
         cov_extra = {"kernel_ms": cov_ms, "bytes_per_M_interval": 8, "intervals": info["n_reads_pileup"],
                      "roofline": {"bound": "hbm", "achieved": 8.0 * info["n_reads_pileup"] / (cov_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": 8.0 * info["n_reads_pileup"] / (cov_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                  "limited_by": "vector-instruction issue and LDS, not HBM: ~435 vector wave-instructions and ~37 LDS instructions per (tile, "
-                                                "sample) pair of ~215 intervals (profiles/r02cov4_pmc.json: SQ_INSTS_VALU 31.4 M per launch = 59 % of the issue "
-                                                "slots of the kernel's 78 us, LDS busy 37 % of it; FETCH_SIZE x2 = 143 MB)"}}
+                                  "limited_by": "vector-instruction issue, not HBM: ~450 vector wave-instructions per (tile, sample) pair of ~215 intervals "
+                                                "(profiles/r02cov5_pmc.json: SQ_INSTS_VALU 32.6 M per launch = 74 % of the issue slots of the kernel's 68.5 us, "
+                                                "LDS busy 35 % of it; FETCH_SIZE x2 = 143 MB)"}}
 
     ann_extra = None
     if not a.no_annotation and rank == 0:

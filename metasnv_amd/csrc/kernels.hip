@@ -1715,7 +1715,8 @@ __device__ __forceinline__ uint32_t row_sum16(uint32_t x) {
 template <bool WIDE>
 __global__ __launch_bounds__(C_NT) void msnv_coverage_tiles(const Pair32 *iv, const TilePair *pairs,
                                                             const WorkItem *work, const uint32_t *tile_len, const uint32_t *tile_contig,
-                                                            unsigned long long *acc, uint32_t n_contigs, int max_cov, uint32_t n_samples, uint32_t n_copies) {
+                                                            unsigned long long *acc, uint32_t n_contigs, int max_cov, uint32_t n_samples, uint32_t n_copies,
+                                                            const uint64_t n_iv) {
     // One WAVEFRONT per (tile, sample) pair, no workgroup barrier at all, and the work follows the BREAKPOINTS of the coverage
     // instead of the positions: an interval adds +1 / -1 to the difference array in LDS and sets the bit of either end in a
     // 2048-bit mask; lane l owns positions [32 l, 32 l + 32) = one mask word and the 64 (128) bytes of differences behind it.  It
@@ -1746,22 +1747,31 @@ __global__ __launch_bounds__(C_NT) void msnv_coverage_tiles(const Pair32 *iv, co
     };
     const uint32_t lim = (uint32_t)min(max((int)tl - 32 * lane, 0), 32);      // scanned positions among my 32 (i < contig length)
     const uint32_t lim_mask = lim >= 32u ? 0xffffffffu : (1u << lim) - 1u;
-    // A work item holds at most COV_PW pairs (pack.cpp): ALL their
-    // descriptors are loaded up front, and the first 256 intervals of a pair while the pair before it is worked on (the kernel
-    // waited on one dependent descriptor -> intervals chain per pair, and then on the intervals beyond the first 128)
-    constexpr int PRE = 4;                                   // rounds of 64 intervals loaded ahead
+    // A work item holds at most COV_PW pairs (pack.cpp): ALL their descriptors are loaded up front, and the first 256 intervals of
+    // a pair while the pair before it is worked on (the kernel waited on one dependent descriptor -> intervals chain per pair, and
+    // then on the intervals beyond the first 128).  A lane takes FOUR CONSECUTIVE intervals (two 16-byte loads): the 64 lanes of one
+    // scatter step are then four intervals apart in the sorted list and seldom meet on an LDS word (64 consecutive intervals at 10x
+    // lie within ~600 positions = 19 mask words)
     TilePair prs[COV_PW];
-    Pair32 xs[COV_PW][PRE];
+    uint4 xa[COV_PW], xb[COV_PW];
 #pragma unroll
     for (int j = 0; j < COV_PW; ++j) {
         const uint32_t kk = w.pair_lo + (uint32_t)(wave * COV_PW + j);
         prs[j] = kk < w.pair_hi ? pairs[kk] : TilePair{0, 0, 0, 0, 0, 0, 0, 0};
     }
+    auto load4 = [&](const Pair32 *v, const uint32_t first, const uint32_t n, uint4 &a, uint4 &b) {
+        // lanes without an interval load the {0, 0} entries behind the last one (pack.cpp; they touch nothing): a load under a lane
+        // condition gets its own wait right behind it, and the round trips then run one after the other instead of under the work
+        // on the pair before.  The entries past a pair's last interval are somebody else's: scatter4 leaves them alone
+        const Pair32 *p = first < n ? v + first : iv + n_iv;
+        __builtin_memcpy(&a, p, 16);
+        __builtin_memcpy(&b, p + 2, 16);
+    };
+    // (a pair of at most 64 intervals -- a cohort of many shallow samples -- takes ONE per lane: one scatter step instead of four
+    // with a handful of lanes each)
     auto load_ahead = [&](const int j) {
         const uint32_t n = prs[j].read_hi - prs[j].read_lo;
-        const Pair32 *v = iv + base_of(prs[j]) + prs[j].read_lo;
-#pragma unroll
-        for (int r = 0; r < PRE; ++r) xs[j][r] = (uint32_t)(lane + 64 * r) < n ? v[lane + 64 * r] : Pair32{0u, 0u};   // {0, 0} touches nothing
+        load4(iv + base_of(prs[j]) + prs[j].read_lo, n <= 64u ? (uint32_t)lane : 4u * (uint32_t)lane, n, xa[j], xb[j]);
     };
     load_ahead(0);
     const uint4 empty4 = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
@@ -1790,11 +1800,22 @@ __global__ __launch_bounds__(C_NT) void msnv_coverage_tiles(const Pair32 *iv, co
             if (x.y >= m && m - t0 < TILE) add_at(m - t0, true);
             if (e < TILE) add_at(e, false);
         };
-#pragma unroll
-        for (int r = 0; r < PRE; ++r) scatter(xs[j][r]);
-        if (pr.read_hi - pr.read_lo > 64u * PRE) {
-            const Pair32 *v = iv + base_of(pr);
-            for (uint32_t i = pr.read_lo + 64u * PRE + (uint32_t)lane; i < pr.read_hi; i += 64) scatter(v[i]);
+        const uint32_t n_iv_pair = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pr.read_hi - pr.read_lo));
+        auto scatter4 = [&](const uint4 a, const uint4 b, const uint32_t first) {
+            scatter(Pair32{a.x, a.y});                       // (mine, or {0, 0})
+            if (first + 1u < n_iv_pair) scatter(Pair32{a.z, a.w});
+            if (first + 2u < n_iv_pair) scatter(Pair32{b.x, b.y});
+            if (first + 3u < n_iv_pair) scatter(Pair32{b.z, b.w});
+        };
+        if (n_iv_pair <= 64u) scatter(Pair32{xa[j].x, xa[j].y});
+        else scatter4(xa[j], xb[j], 4u * (uint32_t)lane);
+        if (n_iv_pair > 256u) {                              // a deep pair: 256 intervals per step
+            const Pair32 *v = iv + base_of(pr) + pr.read_lo;
+            for (uint32_t first = 256u + 4u * (uint32_t)lane; first < n_iv_pair + 4u * (uint32_t)lane; first += 256u) {
+                uint4 ya, yb;
+                load4(v, first, n_iv_pair, ya, yb);
+                scatter4(ya, yb, first);
+            }
         }
         // the LDS executes one wavefront's instructions in order: the atomics above are done before the reads below are served
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -2219,9 +2240,9 @@ int dev_run_coverage(DeviceCols &d, int max_cov, void *stream_, msnv_run_stats *
         // work items that hold a pair of more than 32 767 intervals are the last n_cov_work_wide of the list (pack.cpp)
         const uint32_t n_narrow = d.n_cov_work - d.n_cov_work_wide;
         if (n_narrow) hipLaunchKernelGGL(msnv_coverage_tiles<false>, dim3(n_narrow), dim3(C_NT), 0, st, d.cov_iv, d.cov_pairs, d.cov_work,
-                                         d.tile_len, d.tile_contig_dev, d.cov_acc, d.n_contigs, max_cov, d.n_samples, d.cov_copies);
+                                         d.tile_len, d.tile_contig_dev, d.cov_acc, d.n_contigs, max_cov, d.n_samples, d.cov_copies, d.n_cov_iv);
         if (d.n_cov_work_wide) hipLaunchKernelGGL(msnv_coverage_tiles<true>, dim3(d.n_cov_work_wide), dim3(C_NT), 0, st, d.cov_iv, d.cov_pairs, d.cov_work + n_narrow,
-                                                  d.tile_len, d.tile_contig_dev, d.cov_acc, d.n_contigs, max_cov, d.n_samples, d.cov_copies);
+                                                  d.tile_len, d.tile_contig_dev, d.cov_acc, d.n_contigs, max_cov, d.n_samples, d.cov_copies, d.n_cov_iv);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(e1, st));

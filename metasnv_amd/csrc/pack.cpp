@@ -1217,7 +1217,9 @@ int finalize_dataset(msnv_dataset &ds) {
             tlen[t] = (uint32_t)std::min<int64_t>(std::max<int64_t>(ds.lengths[c] - t0, 0), TILE);
             tcont[t] = (uint32_t)c;
         }
-        d->n_cov_iv = iv.size(); d->n_cov_pairs = (uint32_t)cpairs.size(); d->n_cov_work = (uint32_t)cwork.size(); d->n_contigs = (uint32_t)NC;
+        d->n_cov_iv = iv.size();
+        for (int k = 0; k < 4; ++k) iv.push_back(Pair32{0u, 0u});     // behind the last interval: what the idle lanes of msnv_coverage_tiles load, four at a time (they touch nothing)
+        d->n_cov_pairs = (uint32_t)cpairs.size(); d->n_cov_work = (uint32_t)cwork.size(); d->n_contigs = (uint32_t)NC;
         if (int rc = upload_vec(&d->cov_iv, iv, &d->device_bytes, 1)) return rc;
         if (int rc = upload_vec(&d->s_cov_base, cvbase, &d->device_bytes)) return rc;
         if (int rc = upload_vec(&d->cov_pairs, cpairs, &d->device_bytes, 1)) return rc;
