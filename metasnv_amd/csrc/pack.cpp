@@ -37,8 +37,9 @@ static bool layout_dense(uint64_t n_pieces, uint64_t n_bases) {
 // kernels, and the kernels slow down well before that (8 samples at ~100x: 0.531 ms unsplit, 0.336 ms when runs deeper than
 // 192 are dealt into groups of <= 128; at ~400x 2.68 ms with groups of 240, 1.66 ms with groups of 128).  Instead of a second kernel with wider bins, the run is dealt into groups of pieces that each stay below the
 // limit (round robin in start order, verified with an exact sweep, more groups if needed); every group becomes its own
-// (sample, tile) pair and the per-sample results are summed on the device (gather / scatter accumulate).  Pieces of a
-// group are made contiguous.  MSNV_DEEP=wide keeps such runs whole for msnv_pileup_tiles_wide instead.
+// (sample, tile) pair and the per-sample results are summed on the device (gather / scatter accumulate).  The pieces of a
+// group are made contiguous -- headers AND bases / qualities (MSNV_DEEP_RELOCATE=0 leaves the columns in read order: every group's
+// workgroups then fetch almost every cache line of the run).  MSNV_DEEP=wide keeps such runs whole for msnv_pileup_tiles_wide instead.
 static bool deep_runs_split() {
     const char *e = getenv("MSNV_DEEP");                     // read per dataset (tests switch it)
     return !(e && e[0] == 'w');
@@ -50,6 +51,7 @@ static void split_deep_runs(SampleCols &sc) {
     struct Ev { uint32_t pos; int32_t delta; uint32_t g; };
     std::vector<Ev> ev;
     std::vector<uint32_t> cur, mx, order;
+    bool any_split = false;
     size_t i = 0;
     while (i < n) {
         size_t j = i;
@@ -89,9 +91,27 @@ static void split_deep_runs(SampleCols &sc) {
                     sc.grp[i + k] = (uint16_t)(1 + order[k] % G);
                     sc.depth[i + k] = (uint16_t)gmax[order[k] % G];
                 }
+                any_split = true;
             }
         }
         i = j;
+    }
+    // The bases and qualities follow their headers: a group's pieces were every G-th piece of the run in memory, so the workgroups
+    // of the G groups -- at G different times -- each fetched (almost) every cache line of the run (one sample at 1600x: 6.2 GB of
+    // HBM reads per pass for 2.2 GB of columns).  Same blocks (8 bytes of bases + 16 of qualities per 16 bases of a piece), new order.
+    if (any_split && !(getenv("MSNV_DEEP_RELOCATE") && getenv("MSNV_DEEP_RELOCATE")[0] == '0')) {
+        std::vector<uint8_t> nseq(sc.seq.size(), 0xff), nqual(sc.qual.size(), 0);
+        size_t so = 0;
+        for (size_t k = 0; k < n; ++k) {
+            const size_t blk = (size_t)((sc.hdr[k].cig + 15u) / 16u) * 8u;
+            if (so + blk > nseq.size() || 2 * (so + blk) > nqual.size()) return;       // (cannot happen: the blocks are a permutation; keep the old layout rather than write past the end)
+            memcpy(nseq.data() + so, sc.seq.data() + sc.hdr[k].seqoff, blk);
+            memcpy(nqual.data() + 2 * so, sc.qual.data() + 2 * (size_t)sc.hdr[k].seqoff, 2 * blk);
+            so += blk;
+        }
+        so = 0;
+        for (size_t k = 0; k < n; ++k) { sc.hdr[k].seqoff = (uint32_t)so; so += (size_t)((sc.hdr[k].cig + 15u) / 16u) * 8u; }
+        sc.seq.swap(nseq); sc.qual.swap(nqual);
     }
 }
 
