@@ -1436,6 +1436,8 @@ struct TailArgs {
     const unsigned long long *site_bits; const uint32_t *site_rank;
 };
 
+constexpr uint32_t GD_MIN_SITES = 32;          // sites of a tile per gather workgroup from which the cells go through LDS (gather_cov_block)
+constexpr uint32_t GD_ROW = 68;                // bytes per LDS row of 64 pairs (17 words: a wavefront's column writes hit 64 banks)
 __device__ __forceinline__ void gather_cov_block(const TailArgs &a, const uint32_t bid) {
     const uint32_t GATHER_SPLIT = a.gather_split;
     const uint32_t tile = a.active_tiles[bid / GATHER_SPLIT], part = bid % GATHER_SPLIT;   // a tile's sites are dealt to GATHER_SPLIT workgroups
@@ -1450,6 +1452,48 @@ __device__ __forceinline__ void gather_cov_block(const TailArgs &a, const uint32
     if (np == 0u) return;
     const uint32_t t0 = tile * TILE;
     const uint32_t mine = (n - part + GATHER_SPLIT - 1) / GATHER_SPLIT;
+    const uint32_t share = (n + GATHER_SPLIT - 1) / GATHER_SPLIT;          // (the same for every workgroup of the tile: they all take the same path)
+    if (share >= GD_MIN_SITES) {
+        // MANY sites in the tile (deep or divergent data: every other position of a cohort with LogNormal sigma = 2 abundances is a
+        // site).  One cell per thread in (site, pair) order reads one byte of a different spill row per lane -- a cache line per cell,
+        // 10.7 GB for 84 M cells, and the next site's bytes of the same lines come after the lines are gone -- so the block moves
+        // 64 sites x 64 pairs at a time through LDS: a wavefront READS one pair's bytes at 64 of its sites (a line or a few) and WRITES
+        // one site's cells of 64 pairs (consecutive slots).  A workgroup takes a CONTIGUOUS range of the tile's sites here (every
+        // GATHER_SPLIT-th one, as below, spreads each 128-byte line of the cell rows over workgroups on different XCDs).
+        const uint32_t j_lo = min(n, part * share), dense_n = min(n, j_lo + share) - j_lo;
+        __shared__ uint8_t s_t[64][GD_ROW];
+        __shared__ uint32_t s_off[64], s_pad[64];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (uint32_t jj0 = 0; jj0 < dense_n; jj0 += 64) {
+            const uint32_t nS = min(64u, dense_n - jj0);
+            __syncthreads();                                        // (the rows of the previous group have been written out)
+            if (threadIdx.x < 64) s_off[threadIdx.x] = a.sites[base + j_lo + jj0 + min(threadIdx.x, nS - 1u)].gpos - t0;   // (idle lanes: a valid position, their row is not written out)
+            for (uint32_t kk0 = 0; kk0 < np; kk0 += 64) {
+                const uint32_t nP = min(64u, np - kk0);
+                __syncthreads();                                    // s_off is visible; the previous 64 pairs have been written out
+                if (threadIdx.x < nP) s_pad[threadIdx.x] = a.pairs[ps + kk0 + threadIdx.x].pad;
+                const uint32_t off = s_off[lane];
+                for (uint32_t kl = (uint32_t)wave; kl < nP; kl += 16) {      // four loads in flight per lane
+                    uint8_t v[4];
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u) v[u] = a.spill[(uint64_t)(ps + kk0 + min(kl + 4u * u, nP - 1u)) * TILE + off];
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u) if (kl + 4u * u < nP) s_t[lane][kl + 4u * u] = v[u];
+                }
+                __syncthreads();
+                if ((uint32_t)lane < nP) {
+                    const uint32_t pad = s_pad[lane];
+                    for (uint32_t sl = (uint32_t)wave; sl < nS; sl += 4) {
+                        const uint32_t cov = s_t[sl][lane];
+                        uint16_t *dst = &a.cov_col[cell0 + (uint64_t)(j_lo + jj0 + sl) * n_slots + (pad >> 8)];
+                        if (pad & 0xffu) add_u16(dst, cov);
+                        else if (cov != 255u) *dst = (uint16_t)cov;
+                    }
+                }
+            }
+        }
+        return;
+    }
     const uint64_t work = (uint64_t)mine * np;
     for (uint64_t i = threadIdx.x; i < work; i += blockDim.x) {
         const uint32_t j = part + (uint32_t)(i / np) * GATHER_SPLIT, kk = (uint32_t)(i % np);
