@@ -8,9 +8,15 @@ refGenomes), with the packed read columns already resident
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Multi-GPU: contigs shard across ranks with no data-path collective; every
-rank holds its own testdata-shaped shard (weak scaling) and only the small result tables are
-gathered over RCCL after the timed region.
+Multi-GPU: contigs shard across ranks with no data-path collective.
+  --mode weak   (default for the testdata workload = the headline line): every rank holds its own testdata-shaped shard --
+                three species cannot be dealt to eight ranks -- and only a small table is gathered after the timed region.
+  --mode strong (default for config3 / config4shard): ONE fixed multi-species cohort through the product's N-rank path
+                (metasnv_amd/parallel.py: resident_project_run) -- record streams "decoded" by one rank each, contig owners by
+                species LPT on length x coverage from the first round, all-to-all of the records over RCCL, one dataset per rank,
+                K timed passes, then the gather of coverage rows and cell-form site records to rank 0 -- with per-rank bases,
+                imbalance, exchange / gather seconds and bytes beside the kernel line.  With N > 1 the weak line also carries a
+                small strong-scaling block (--no-strong-extra skips it).
 """
 import argparse
 import json
@@ -58,17 +64,23 @@ def workload_params(a, rank=0):
     return kw, label
 
 
+TRAFFIC_PROFILES = ["r03_pmc.json", "r02d_pmc.json"]       # newest first; written by profiles/collect.sh + summarize.py
+
+
 def measured_traffic(samples, species, contig_len, mean_cov):
     """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/
-    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 read correction applied).
-    Only valid for the workload it was collected on; anything else reports null."""
-    try:
-        p = json.load(open(os.path.join(ROOT, "profiles", "r02d_pmc.json")))
-        if (samples, species, contig_len, mean_cov) == (160, 3, 300000, 10.0):
-            return p["hbm_traffic"]["total_bytes_per_launch"]
-    except Exception:
-        pass
-    return None
+    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 read correction applied) and the file they come from.
+    Only valid for the workload it was collected on; anything else reports null.  The counters cannot be collected inside
+    this process (rocprofv3 wraps the command), so the figure is the one of the committed profile of THIS kernel build."""
+    if (samples, species, contig_len, mean_cov) != (160, 3, 300000, 10.0):
+        return None, None
+    for name in TRAFFIC_PROFILES:
+        try:
+            p = json.load(open(os.path.join(ROOT, "profiles", name)))
+            return p["hbm_traffic"]["total_bytes_per_launch"], "profiles/" + name
+        except Exception:
+            continue
+    return None, None
 
 
 def parse():
@@ -79,6 +91,10 @@ def parse():
     ap.add_argument("--workload", default="testdata", choices=sorted(WORKLOADS),
                     help="testdata = BASELINE configs[1] (the metric's configuration, default); config3 / config4shard = the SURVEY.md 8d shapes of "
                          "BASELINE configs[2] / the per-GPU shard of configs[3], scaled by --scale")
+    ap.add_argument("--mode", default=None, choices=["weak", "strong"], help="weak: one shard per rank (default for testdata); strong: one fixed cohort sharded over the ranks "
+                                                                             "through the product's N-rank path (default for config3 / config4shard)")
+    ap.add_argument("--no-strong-extra", action="store_true", help="N > 1, weak mode: skip the small strong-scaling block behind the timed region")
+    ap.add_argument("--strong-extra-shape", default="32,300000", help="species,contig_len of the strong-scaling block's cohort (tests shrink it)")
     ap.add_argument("--scale", type=float, default=None, help="fraction of the named workload's species (config3 / config4shard; default 0.25: the full shapes need ~100 GB of host staging)")
     ap.add_argument("--samples", type=int, default=None)
     ap.add_argument("--contig-len", type=int, default=None)
@@ -113,6 +129,8 @@ def cpu_baseline(sp_kwargs, n_cpu_samples):
     pop, ind, n_lines, n_bases = orc.call(syn.names, syn.lengths, syn.seqs, samples)
     dt = time.perf_counter() - t0
     out = {"value": n_bases / dt / 1e9, "unit": "Gbases/s", "cores": 1, "kind": "port",
+           "what": "port (oracle): the repository's plain-C restatement of samtools mpileup + snpCall (oracle/), NOT the reference binaries -- "
+                   "boost / htslib / samtools are absent from the image, so call_vC.cpp and samtools cannot be built or run here",
            "sample": "first %d of %d samples, all %d contigs: %d pileup bases in %.1f s (mpileup+snpCall restatement, 1 thread)"
                      % (n_cpu_samples, sp.n_samples, len(syn.names), n_bases, dt),
            "called_lines": pop.count("\n")}
@@ -195,6 +213,91 @@ def launcher_command(n, argv, port=None):
             "--master-port", str(port or _free_port()), os.path.abspath(__file__)] + list(argv)
 
 
+def strong_run(a, rank, world, local, dist, brief=False):
+    """ONE fixed cohort through the product's N-rank path (parallel.resident_project_run, the function metaSNV.py runs under
+    torchrun; reference: the split pool, metaSNV.py:196-215 + createOptimumSplit.py:46-62): every rank generates ("decodes") 1/N of
+    the samples' record streams, the contig owners come from the first round's length x coverage, the records travel in an
+    all-to-all per round, every rank packs and uploads its contigs' share and runs K timed passes (barrier + sync on both sides, max
+    over ranks), then the coverage rows and the cell-form site records are gathered to rank 0.  Returns the JSON line (rank 0)."""
+    import numpy as np
+    from metasnv_amd import core, parallel
+    sp_kwargs, wl_label = workload_params(a, 0)            # the same cohort on every rank
+    sp = core.synth_params(**sp_kwargs)
+    syn = core.Synth(sp)
+    ctx = core.Context(local)
+    params = core.default_params()
+    timing = {}
+
+    def barrier():
+        parallel.barrier()
+
+    def run_passes(ds):
+        st = ds.run()                                       # sizes the sparse buffers
+        for _ in range(a.warmup):
+            st = ds.run()
+        barrier()
+        t0 = time.perf_counter()
+        sts = ds.run_many(a.steps) if not a.sync_each_step else [ds.run() for _ in range(a.steps)]
+        barrier()
+        timing["dt"] = time.perf_counter() - t0
+        timing["k_ms"] = sum(x["ms_pileup"] for x in sts) / len(sts)
+        timing["alg"] = sts[-1]["algorithmic_bytes"]
+        timing["called"] = sts[-1]["n_called_pop"]
+        timing["total_ms"] = sum(x["ms_total"] for x in sts) / len(sts)
+        return sts[-1]
+
+    threads = a.host_threads or max(1, min(32, (os.cpu_count() or 8) // max(1, world)))
+    t_all = time.perf_counter()
+    res = parallel.resident_project_run(ctx, None, None, [str(i) for i in range(sp.n_samples)], params, batch=threads, want_coverage=True,
+                                        make_dataset=lambda: core.Dataset(ctx, syn.names, syn.lengths, syn.seqs, params),
+                                        read_records=lambda p: syn.sample_records(int(p)), run_passes=run_passes)
+    t_all = time.perf_counter() - t_all
+    m = res["metrics"]
+    info = m["dataset"]
+    mine = np.array([timing["dt"], float(info["n_pileup_bases"]), timing["k_ms"], float(timing["alg"]), float(timing["called"]), float(m["sites_local"]),
+                     float(m["cells_local"]), m["feed_s"], m["finalize_s"], m.get("gather_coverage_s", 0.0), m["gather_sites_s"], float(info["n_positions"]),
+                     float(m.get("inflated_record_bytes") or 0), float(info["device_bytes"]), timing["total_ms"], m["coverage"]["ms_coverage"]], dtype=np.float64)
+    allr = parallel.gather_fixed(mine)
+    ctx.close()
+    if rank != 0:
+        return None
+    dt_max = max(float(r[0]) for r in allr)
+    bases = [float(r[1]) for r in allr]
+    gbs = [float(r[3]) / (float(r[2]) * 1e-3) / 1e9 if r[2] > 0 else 0.0 for r in allr]
+    # a rank's share of the timed region is its kernel time: the slowest rank is the one with the most bases (imbalance = max / mean)
+    slow = max(range(world), key=lambda r: float(allr[r][2]))
+    n_sites = int(len(res["sites"]))
+    dense_bytes = n_sites * sp.n_samples * 10
+    line = {
+        "metric": "pileup Gbases/s across all samples",
+        "value": sum(bases) * a.steps / dt_max / 1e9, "unit": "Gbases/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt_max / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "%s: ONE cohort of %d synthetic BAM-record streams x %d species (%d contigs, %d bp per species), ~%gx, single-end %d bp, sharded over %d rank(s)"
+                               % (wl_label, sp.n_samples, sp.n_species, len(syn.names), sp.contig_len, sp.mean_cov, sp.read_len, world),
+                   "samples": sp.n_samples, "parallelism": "species LPT (length x first-round coverage) over %d rank(s); all-to-all of records before, gather to rank 0 after; no data-path collective" % world,
+                   "pileup_bases_total": int(sum(bases)), "pileup_bases_per_rank": [int(b) for b in bases],
+                   "positions_per_rank": [int(r[11]) for r in allr], "called_SNPs_lines_per_rank": [int(r[4]) for r in allr]},
+        "imbalance_max_over_mean": max(bases) / (sum(bases) / world) if sum(bases) else None,
+        "roofline": {"bound": "hbm", "kernel": "msnv_pileup_tiles_* (narrow32 + merged [+ wide] between one pair of HIP events)", "achieved": gbs[slow], "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": gbs[slow] / HBM_PEAK_GBS, "traffic": None, "traffic_source": None, "rank": slow, "achieved_per_rank": gbs,
+                     "kernel_ms_avg": float(allr[slow][2]), "algorithmic_bytes_per_launch": int(allr[slow][3]),
+                     "algorithmic_definition": "SURVEY.md 8d: per pileup read 16 B header + 4 B per CIGAR op + 0.5 B/base + 1 B/base quality"},
+        "kernel_ms": {"pileup_per_rank": [float(r[2]) for r in allr], "pipeline_total_per_rank": [float(r[14]) for r in allr], "coverage_per_rank": [float(r[15]) for r in allr]},
+        "exchange": {"backend": parallel.backend() or "none (one process)", "feed_s_per_rank": [float(r[7]) for r in allr],
+                     "what": "generate 1/N of the samples, count first-round bases, partition by owner, all_to_all per round of %d samples x %d ranks, pack" % (threads, world),
+                     "record_bytes_decoded_per_rank": [int(r[12]) for r in allr], "finalize_upload_s_per_rank": [float(r[8]) for r in allr]},
+        "gather": {"to": "rank 0", "sites_total": n_sites, "cells_total": int(len(res["cells"])), "bytes_received_by_rank0": int(m["gather_bytes_received"]),
+                   "dense_form_would_be_bytes": dense_bytes, "seconds_sites_per_rank": [float(r[10]) for r in allr], "seconds_coverage_per_rank": [float(r[9]) for r in allr],
+                   "sites_per_rank": [int(r[5]) for r in allr], "cells_per_rank": [int(r[6]) for r in allr]},
+        "host": {"wall_s_whole_run": t_all, "device_bytes_per_rank": [int(r[13]) for r in allr], "host_threads_per_rank": threads},
+    }
+    if brief:
+        for k in ("metric", "unit", "higher_is_better", "vs_baseline", "dtype", "data"):
+            line.pop(k)
+    return line
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -206,22 +309,25 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world and rank == 0:
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d; the launcher's world size is what runs\n" % (a.gpus, world))
-    dist = None
+    # the process group is the product's own (metasnv_amd/parallel.py: nccl = RCCL; gloo = rehearsal, ranks may share a GPU)
+    os.environ["MSNV_DIST_BACKEND"] = a.dist_backend
+    from metasnv_amd import parallel
+    rank, world, local = parallel.init_from_env()
+    dist = parallel._dist
     if world > 1:
         import torch
-        import torch.distributed as dist_
-        if a.dist_backend == "nccl":
-            torch.cuda.set_device(local)
-            dist_.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
-        else:                                   # rehearsal: ranks may share a GPU, the 4-number table travels over gloo
-            local = local % max(1, torch.cuda.device_count())
-            torch.cuda.set_device(local)
-            dist_.init_process_group(backend=a.dist_backend)
-        dist = dist_
+        torch.cuda.set_device(local)
 
     from metasnv_amd import core
     if core.device_count() < 1:
         raise SystemExit("bench.py: no HIP device visible; the pileup path has no CPU fallback")
+    mode = a.mode or ("weak" if a.workload == "testdata" else "strong")
+    if mode == "strong":
+        line = strong_run(a, rank, world, local, dist)
+        if rank == 0:
+            print(json.dumps(line))
+        parallel.finalize()
+        return
 
     # ---- build this rank's shard: same shape on every rank, different seed (weak scaling)
     sp_kwargs, wl_label = workload_params(a, rank)
@@ -380,6 +486,7 @@ def main():
 
     if rank == 0:
         achieved = alg / (k_ms * 1e-3) / 1e9
+        traffic, traffic_src = measured_traffic(sp.n_samples, sp.n_species, sp.contig_len, sp.mean_cov) if (world == 1 and a.workload == "testdata") else (None, None)
         line = {
             "metric": "pileup Gbases/s across all samples",
             "value": total_bases * a.steps / dt_max / 1e9,
@@ -394,7 +501,7 @@ def main():
                        "reads_per_gpu": info["n_reads"], "parallelism": "contig shards x%d, no data-path collective" % world,
                        "called_SNPs_lines_per_rank": called},
             "roofline": {"bound": "hbm", "kernel": "msnv_pileup_tiles_narrow32" if a.workload == "testdata" else "msnv_pileup_tiles_* (narrow32 + merged [+ wide] between one pair of HIP events)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(sp.n_samples, sp.n_species, sp.contig_len, sp.mean_cov) if (world == 1 and a.workload == "testdata") else None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg, "kernel_ms_avg": k_ms,
                          "rank": slowest, "achieved_per_rank": per_rank_gbs,
                          "bytes_per_pileup_base": alg / max(1, bases),
@@ -416,9 +523,25 @@ def main():
             line["host_decode"] = decode_extra
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(sp_kwargs, min(a.cpu_samples, sp.n_samples))
+    strong = None
+    if world > 1 and not a.no_strong_extra:
+        # the product's N-rank path on ONE fixed cohort (32 species x 300 kb, 160 samples carrying six each): what the weak line above
+        # cannot show -- LPT imbalance, the all-to-all of the records, the gather to rank 0
+        ds.close()
+        import copy
+        b = copy.copy(a)
+        xs, xl = (int(x) for x in a.strong_extra_shape.split(","))
+        b.workload, b.scale, b.species, b.contig_len, b.mean_cov = "config3", 0.32, xs, xl, None
+        b.steps, b.warmup = max(3, min(a.steps, 10)), 1
+        try:
+            strong = strong_run(b, rank, world, local, dist, brief=True)
+        except Exception as e:                             # the extra must never cost the bench line
+            strong = {"error": repr(e)}
+    if rank == 0:
+        if strong is not None:
+            line["strong_scaling"] = strong
         print(json.dumps(line))
-    if dist is not None:
-        dist.destroy_process_group()
+    parallel.finalize()
 
 
 if __name__ == "__main__":

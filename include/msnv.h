@@ -236,6 +236,9 @@ int  msnv_dataset_set_contig_mask(msnv_dataset *ds, const uint8_t *mask, int32_t
  * uncompressed BAM alignment records (each starting with its int32 block_size), i.e. what
  * sam_read1() yields (qaCompute.cpp:441). */
 int  msnv_dataset_add_sample_records(msnv_dataset *ds, const uint8_t *records, uint64_t n_bytes);
+/* n record streams appended as n samples, in order, packed by a pool of host_threads threads (0 = all cores): what the N-rank
+ * driver does with the streams of one exchange round (metasnv_amd/parallel.py: feed_sharded). */
+int  msnv_dataset_add_sample_records_many(msnv_dataset *ds, const uint8_t *const *records, const uint64_t *n_bytes, int32_t n, int32_t host_threads);
 int  msnv_dataset_add_sample_bam(msnv_dataset *ds, const char *bam_path);
 /* Decode many BAMs with a host thread pool, preserving order. */
 int  msnv_dataset_add_sample_bams(msnv_dataset *ds, const char *const *bam_paths, int32_t n, int32_t host_threads);
@@ -336,6 +339,10 @@ typedef struct { uint32_t total_reads, unmapped, zero_quality, proper_pairs, dup
  * part_bytes[n_parts] their sizes; stats (may be NULL) the sample's qaCompute statistics over ALL records. */
 int  msnv_records_partition(const uint8_t *records, uint64_t n_bytes, const int32_t *contig_owner, int32_t n_contigs,
                             int32_t n_parts, int32_t cov_min_mapq, uint8_t *out, uint64_t *part_bytes, msnv_sample_stats *stats);
+/* Adds the aligned (M/=/X) bases of every mapped record of a raw record stream to bases[tid] (n_contigs entries, not cleared):
+ * the weight of the reference's split rule, genome length x coverage = aligned bases (src/createOptimumSplit.py:46-50), which
+ * the N-rank driver takes from its first round of decoded BAMs before it fixes the contig owners. */
+int  msnv_records_contig_bases(const uint8_t *records, uint64_t n_bytes, int32_t n_contigs, uint64_t *bases);
 /* Statistics of sample `sample_idx` as counted while it was packed (only over the records this dataset was given). */
 int  msnv_dataset_sample_stats(const msnv_dataset *ds, int32_t sample_idx, msnv_sample_stats *out);
 /* Accumulators of the last msnv_coverage_run: acc[n_samples][n_contigs][MSNV_COV_WORDS], zeros for contigs outside the shard. */
@@ -369,6 +376,20 @@ int  msnv_results_fetch_ann(msnv_dataset *ds, msnv_site_ann *ann, uint64_t capac
 int  msnv_results_count(const msnv_dataset *ds, uint64_t *n_sites);
 /* sites[n_sites], samples[n_sites * n_samples], both in (tid, pos) order. */
 int  msnv_results_fetch(msnv_dataset *ds, msnv_site *sites, msnv_site_sample *samples, uint64_t capacity);
+/* The same records with the per-sample part as ROWS OF CELLS (CSR) instead of n_samples entries per site: site i owns
+ * cells [row_off[i], row_off[i + 1]) (row_off has n_sites + 1 entries), cell c belongs to sample cell_sample[c] (ascending
+ * inside a row) and samples without a cell hold zeros.  This is what the device keeps (a cell per sample that has reads in the
+ * site's tile) and what the ranks ship to rank 0: a 500-sample cohort whose species are each carried by a handful of samples
+ * (BASELINE configs[3]) costs a handful of cells per site, where the dense form costs 5 KB.  The reference's counterpart is
+ * the `c1|c2|...|cS` text of every called line (call_vC.cpp:316-325,635), S numbers whatever they are. */
+int  msnv_results_cells_count(const msnv_dataset *ds, uint64_t *n_sites, uint64_t *n_cells);
+int  msnv_results_fetch_cells(msnv_dataset *ds, msnv_site *sites, uint64_t *row_off, uint32_t *cell_sample, msnv_site_sample *cells,
+                              uint64_t cap_sites, uint64_t cap_cells);
+/* msnv_write_calls_records for records in the cell form (same text, byte for byte). */
+int  msnv_write_calls_cells(const msnv_ref_desc *ref, int32_t n_samples, const msnv_site *sites, const uint64_t *row_off,
+                            const uint32_t *cell_sample, const msnv_site_sample *cells, uint64_t n_sites,
+                            const char *called_path, const char *indiv_path,
+                            const char *ann_path, const char *fasta_path, const msnv_site_ann *ann);
 
 /* ------------------------------------------------------------------------------------
  * Host I/O helpers used by the Python CLI and the tests (BGZF/BAM on zlib: htslib is not

@@ -123,6 +123,7 @@ SYMBOLS = [
     ("msnv_dataset_set_bed_file", C.c_int, [_vp, C.c_char_p]),
     ("msnv_dataset_set_contig_mask", C.c_int, [_vp, P(C.c_uint8), C.c_int32]),
     ("msnv_dataset_add_sample_records", C.c_int, [_vp, _vp, C.c_uint64]),
+    ("msnv_dataset_add_sample_records_many", C.c_int, [_vp, P(_vp), P(C.c_uint64), C.c_int32, C.c_int32]),
     ("msnv_dataset_add_sample_bam", C.c_int, [_vp, C.c_char_p]),
     ("msnv_dataset_add_sample_bams", C.c_int, [_vp, P(C.c_char_p), C.c_int32, C.c_int32]),
     ("msnv_dataset_pileup_qualities", C.c_int, [_vp, _vp, C.c_uint64, _vp]),
@@ -145,6 +146,11 @@ SYMBOLS = [
     ("msnv_results_fetch_ann", C.c_int, [_vp, P(SiteAnn), C.c_uint64]),
     ("msnv_results_count", C.c_int, [_vp, P(C.c_uint64)]),
     ("msnv_results_fetch", C.c_int, [_vp, P(Site), P(SiteSample), C.c_uint64]),
+    ("msnv_results_cells_count", C.c_int, [_vp, P(C.c_uint64), P(C.c_uint64)]),
+    ("msnv_results_fetch_cells", C.c_int, [_vp, P(Site), P(C.c_uint64), P(C.c_uint32), P(SiteSample), C.c_uint64, C.c_uint64]),
+    ("msnv_write_calls_cells", C.c_int, [P(RefDesc), C.c_int32, P(Site), P(C.c_uint64), P(C.c_uint32), P(SiteSample), C.c_uint64, C.c_char_p, C.c_char_p,
+                                        C.c_char_p, C.c_char_p, P(SiteAnn)]),
+    ("msnv_records_contig_bases", C.c_int, [_vp, C.c_uint64, C.c_int32, P(C.c_uint64)]),
     ("msnv_parse_float", C.c_int, [C.c_char_p, P(C.c_double)]),
     ("msnv_dist_file", C.c_int, [_vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_double, P(C.c_int32), P(C.c_uint64), P(C.c_double)]),
     ("msnv_genotyping_subset", C.c_int, [P(C.c_char_p), C.c_int32, P(C.c_char_p), C.c_int32, C.c_char_p, P(C.c_uint64), P(C.c_uint64)]),
@@ -173,7 +179,7 @@ def _load():
         raise ImportError(
             "metasnv_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("MSNV_DIST_FORCE") == "1":
         # multi-rank runs exchange tables through torch.distributed: torch ships its own libamdhip64, and two HIP
         # runtimes in one process do not both see the GPU.  Importing torch first makes libmsnv.so bind to the
         # runtime torch already loaded (same SONAME).

@@ -141,9 +141,18 @@ def resident_run(args, ctx, rank, world):
             shutil.copy(args.all_samples, args.project_dir + '/all_samples')
         parallel.barrier()
 
+    # contig -> rank by the reference's split rule, genome length x summed coverage (createOptimumSplit.py:46-62): with --use_prev_cov
+    # the previous run's all_cov.tab has the coverages, as the reference's split planner reads them; else the ranks take them from
+    # their first round of decoded BAMs (parallel.feed_sharded)
+    species_weight = None
+    if args.use_prev_cov and world > 1:
+        tab = "{}/{}.all_cov.tab".format(args.project_dir, os.path.basename(args.project_dir))
+        if os.path.isfile(tab):
+            species_weight = tables.species_coverage(tab)
     try:
         res = parallel.resident_project_run(ctx, bams[0], args.ref_db, bams, params, batch=max(1, args.threads),
-                                            want_coverage=not args.use_prev_cov, ann_path=args.db_ann or None, after_coverage=between_passes)
+                                            want_coverage=not args.use_prev_cov, ann_path=args.db_ann or None, after_coverage=between_passes,
+                                            species_weight=species_weight)
     except core._lib.MsnvError as e:
         sys.stderr.write(str(e) + "\n")
         sys.stderr.write("SNV calling failed")
@@ -154,13 +163,13 @@ def resident_run(args, ctx, rank, world):
     try:
         if args.n_splits > 1:
             for split in sorted(glob.glob('{}/bestsplits/best_split_*'.format(args.project_dir))):
-                sites, samples, ann = parallel.split_view(res, read_split_file(split))
+                sites, row_off, cell_sample, cells, ann = parallel.split_view(res, read_split_file(split))
                 sfx = '.' + os.path.basename(split)
-                core.write_calls_records(res["names"], res["n_samples"], sites, samples, os.path.join(snp_dir, "called_SNPs" + sfx),
-                                         os.path.join(snp_dir, "indiv_called" + sfx), args.db_ann or None, args.ref_db, ann)
+                core.write_calls_cells(res["names"], res["n_samples"], sites, row_off, cell_sample, cells, os.path.join(snp_dir, "called_SNPs" + sfx),
+                                       os.path.join(snp_dir, "indiv_called" + sfx), args.db_ann or None, args.ref_db, ann)
         else:
-            core.write_calls_records(res["names"], res["n_samples"], res["sites"], res["samples"], os.path.join(snp_dir, "called_SNPs"),
-                                     os.path.join(snp_dir, "indiv_called"), args.db_ann or None, args.ref_db, res["ann"])
+            core.write_calls_cells(res["names"], res["n_samples"], res["sites"], res["row_off"], res["cell_sample"], res["cells"],
+                                   os.path.join(snp_dir, "called_SNPs"), os.path.join(snp_dir, "indiv_called"), args.db_ann or None, args.ref_db, res["ann"])
     except (core._lib.MsnvError, ValueError) as e:
         sys.stderr.write(str(e) + "\n")
         sys.stderr.write("SNV calling failed")

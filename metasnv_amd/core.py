@@ -120,6 +120,17 @@ class Dataset:
         check(lib.msnv_dataset_add_sample_records(self._h, ptr, n))
         self.n_samples += 1
 
+    def add_samples_records(self, streams, host_threads=0):
+        """Several record streams (numpy uint8 arrays) as consecutive samples, packed by a pool of host threads."""
+        bufs = [np.ascontiguousarray(r, dtype=np.uint8) for r in streams]
+        n = len(bufs)
+        if n == 0:
+            return
+        ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+        sizes = (C.c_uint64 * n)(*[b.size for b in bufs])
+        check(lib.msnv_dataset_add_sample_records_many(self._h, ptrs, sizes, n, host_threads))
+        self.n_samples += n
+
     def pileup_qualities(self, records):
         """The record stream with the base qualities as the pileup engine sees them (overlap tweak, token limit)."""
         rec = np.ascontiguousarray(records, dtype=np.uint8)
@@ -195,6 +206,20 @@ class Dataset:
                                      samples.ctypes.data_as(C.POINTER(SiteSample)), n.value))
         return sites, samples
 
+    def results_cells(self):
+        """The records of the last run with the per-sample part as rows of cells (msnv_results_fetch_cells):
+        (sites, row_off[n_sites + 1], cell_sample, cells) -- site i owns cells row_off[i]:row_off[i + 1], samples without a
+        cell hold zeros."""
+        ns, nc = C.c_uint64(), C.c_uint64()
+        check(lib.msnv_results_cells_count(self._h, C.byref(ns), C.byref(nc)))
+        sites = np.zeros(ns.value, dtype=SITE_DTYPE)
+        row_off = np.zeros(ns.value + 1, dtype=np.uint64)
+        cell_sample = np.zeros(nc.value, dtype=np.uint32)
+        cells = np.zeros(nc.value, dtype=SAMPLE_DTYPE)
+        check(lib.msnv_results_fetch_cells(self._h, sites.ctypes.data_as(C.POINTER(Site)), row_off.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                           cell_sample.ctypes.data_as(C.POINTER(C.c_uint32)), cells.ctypes.data_as(C.POINTER(SiteSample)), ns.value, nc.value))
+        return sites, row_off, cell_sample, cells
+
     def annotate(self, ann_path, fasta_path):
         """Gene / codon annotation of the last run's sites on the device; returns (records, kernel ms)."""
         ms = C.c_double()
@@ -263,6 +288,50 @@ def write_calls_records(names, n_samples, sites, samples, called_path, indiv_pat
                                        indiv_path.encode() if indiv_path else None, ann_path.encode() if ann_path else None,
                                        fasta_path.encode() if fasta_path else None,
                                        np.ascontiguousarray(ann, dtype=ANN_DTYPE).ctypes.data_as(C.POINTER(SiteAnn)) if ann is not None else None))
+
+
+def write_calls_cells(names, n_samples, sites, row_off, cell_sample, cells, called_path, indiv_path=None, ann_path=None, fasta_path=None, ann=None):
+    """write_calls_records for records in the cell form (Dataset.results_cells / parallel.gather_sites_root)."""
+    n = len(names)
+    rd = RefDesc(n, _cstr_array(names), (C.c_int64 * n)(*([0] * n)), None, None)
+    sites = np.ascontiguousarray(sites, dtype=SITE_DTYPE)
+    row_off = np.ascontiguousarray(row_off, dtype=np.uint64)
+    cell_sample = np.ascontiguousarray(cell_sample, dtype=np.uint32)
+    cells = np.ascontiguousarray(cells, dtype=SAMPLE_DTYPE)
+    assert row_off.size == len(sites) + 1
+    check(lib.msnv_write_calls_cells(C.byref(rd), n_samples, sites.ctypes.data_as(C.POINTER(Site)), row_off.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                     cell_sample.ctypes.data_as(C.POINTER(C.c_uint32)), cells.ctypes.data_as(C.POINTER(SiteSample)), len(sites),
+                                     called_path.encode(), indiv_path.encode() if indiv_path else None, ann_path.encode() if ann_path else None,
+                                     fasta_path.encode() if fasta_path else None,
+                                     np.ascontiguousarray(ann, dtype=ANN_DTYPE).ctypes.data_as(C.POINTER(SiteAnn)) if ann is not None else None))
+
+
+def cells_to_dense(n_samples, row_off, cell_sample, cells):
+    """[sites][n_samples] array of SAMPLE_DTYPE from the cell form (tests, small results)."""
+    n = len(row_off) - 1
+    out = np.zeros((n, max(1, n_samples)), dtype=SAMPLE_DTYPE)
+    site_of = np.repeat(np.arange(n), np.diff(row_off.astype(np.int64)))
+    out[site_of, cell_sample] = cells
+    return out
+
+
+def dense_to_cells(samples):
+    """(row_off, cell_sample, cells) of a dense [sites][n_samples] SAMPLE_DTYPE array: the entries that hold anything."""
+    samples = np.asarray(samples)
+    if samples.size == 0:
+        return np.zeros(len(samples) + 1, np.uint64), np.zeros(0, np.uint32), np.zeros(0, SAMPLE_DTYPE)
+    nz = (samples["cov"] != 0) | (samples["n"] != 0).any(axis=-1)
+    site, smp = np.nonzero(nz)
+    row_off = np.concatenate([[0], np.cumsum(nz.sum(axis=1))]).astype(np.uint64)
+    return row_off, smp.astype(np.uint32), np.ascontiguousarray(samples[site, smp])
+
+
+def contig_bases(records, n_contigs, into=None):
+    """Aligned bases per contig of a raw record stream (msnv_records_contig_bases), added to `into` (uint64[n_contigs])."""
+    rec = np.ascontiguousarray(records, dtype=np.uint8)
+    out = into if into is not None else np.zeros(n_contigs, dtype=np.uint64)
+    check(lib.msnv_records_contig_bases(rec.ctypes.data, rec.size, n_contigs, out.ctypes.data_as(C.POINTER(C.c_uint64))))
+    return out
 
 
 def write_coverage_records(names, lengths, max_cov, stats, acc, cov_path, detail_path):

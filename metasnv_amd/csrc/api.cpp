@@ -168,6 +168,38 @@ extern "C" int msnv_dataset_add_sample_records(msnv_dataset *ds, const uint8_t *
     return rc;
 }
 
+extern "C" int msnv_dataset_add_sample_records_many(msnv_dataset *ds, const uint8_t *const *records, const uint64_t *n_bytes, int32_t n, int32_t host_threads) {
+    clear_error();
+    if (!ds || n < 0 || (n && (!records || !n_bytes))) return fail(MSNV_EINVAL, "msnv_dataset_add_sample_records_many: bad argument");
+    if (ds->finalized) return fail(MSNV_EINVAL, "dataset is already finalized");
+    for (int i = 0; i < n; ++i) if (n_bytes[i] && !records[i]) return fail(MSNV_EINVAL, "msnv_dataset_add_sample_records_many: stream %d is NULL", i);
+    int nthreads = host_threads > 0 ? host_threads : (int)std::max(1u, std::thread::hardware_concurrency());
+    nthreads = std::min(nthreads, std::max(1, (int)n));
+    const size_t first = ds->samples.size();
+    ds->samples.resize(first + (size_t)n);
+    std::atomic<int> next{0}, err{0};
+    std::vector<std::string> msgs((size_t)n);
+    auto worker = [&]() {
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= n || err.load()) break;
+            int rc;
+            try { rc = pack_sample(*ds, records[i], n_bytes[i], ds->samples[first + (size_t)i]); }
+            catch (const std::exception &e) { rc = fail(MSNV_ENOMEM, "packing sample %d failed: %s", i, e.what()); }
+            if (rc) { msgs[(size_t)i] = msnv_last_error(); err.store(rc); }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t) th.emplace_back(worker);
+    for (auto &t : th) t.join();
+    if (err.load()) {
+        ds->samples.resize(first);
+        for (const std::string &m : msgs) if (!m.empty()) return fail(err.load(), "%s", m.c_str());
+        return fail(err.load(), "packing failed");
+    }
+    return MSNV_OK;
+}
+
 extern "C" int msnv_dataset_pileup_qualities(const msnv_dataset *ds, const uint8_t *records, uint64_t n_bytes, uint8_t *out) {
     clear_error();
     if (!ds || (n_bytes && (!records || !out))) return fail(MSNV_EINVAL, "msnv_dataset_pileup_qualities: NULL argument");
@@ -612,7 +644,9 @@ static int fetch_results(msnv_dataset *ds) {
     }
 
     ds->sites.clear(); ds->site_samples.clear(); ds->site_dev_index.clear();
+    ds->site_row.clear(); ds->site_cell_sample.clear(); ds->site_cells.clear();
     ds->sites.reserve(n);
+    ds->site_row.push_back(0);
     for (uint32_t t = 0; t < ds->n_tiles; ++t) {
         const uint64_t slot0 = ds->tile_slot_base[t], n_slots = ds->tile_slot_base[t + 1] - slot0;
         for (uint32_t j = 0; j < tcnt[t]; ++j) {
@@ -628,11 +662,27 @@ static int fetch_results(msnv_dataset *ds) {
             s.dropped = (ds->params.drop_first_line && s.tid == ds->first_tid && s.pos == ds->first_pos) ? 1 : 0;
             ds->sites.push_back(s);
             ds->site_dev_index.push_back(i);
-            const size_t row = ds->site_samples.size();
-            ds->site_samples.resize(row + d.n_samples, msnv_site_sample{});
             const uint64_t cell0 = tcell[t] + (uint64_t)j * n_slots;
             if (cell0 + n_slots > n_cells) return fail(MSNV_EHIP, "internal: the device reported %llu cells but tile %u needs cell %llu", (unsigned long long)n_cells, t, (unsigned long long)(cell0 + n_slots));
-            for (uint64_t c = 0; c < n_slots; ++c) ds->site_samples[row + ds->slot_sample[(size_t)(slot0 + c)]] = raw[(size_t)(cell0 + c)];
+            // the site's row of cells: the tile's slots in SAMPLE order (pack.cpp sorts a tile's pairs by kind, so the slots are not),
+            // without the samples that hold nothing at this position
+            const size_t c_lo = ds->site_cells.size();
+            for (uint64_t c = 0; c < n_slots; ++c) {
+                const msnv_site_sample &v = raw[(size_t)(cell0 + c)];
+                if (!(v.cov | v.n[0] | v.n[1] | v.n[2] | v.n[3])) continue;
+                ds->site_cell_sample.push_back(ds->slot_sample[(size_t)(slot0 + c)]);
+                ds->site_cells.push_back(v);
+            }
+            const size_t n_c = ds->site_cells.size() - c_lo;
+            bool sorted = true;
+            for (size_t k = 1; k < n_c && sorted; ++k) sorted = ds->site_cell_sample[c_lo + k - 1] < ds->site_cell_sample[c_lo + k];
+            if (!sorted) {
+                std::vector<std::pair<uint32_t, msnv_site_sample>> tmp(n_c);
+                for (size_t k = 0; k < n_c; ++k) tmp[k] = {ds->site_cell_sample[c_lo + k], ds->site_cells[c_lo + k]};
+                std::sort(tmp.begin(), tmp.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
+                for (size_t k = 0; k < n_c; ++k) { ds->site_cell_sample[c_lo + k] = tmp[k].first; ds->site_cells[c_lo + k] = tmp[k].second; }
+            }
+            ds->site_row.push_back((uint64_t)ds->site_cells.size());
         }
     }
     ds->results_fetched = true;
@@ -655,7 +705,37 @@ extern "C" int msnv_results_fetch(msnv_dataset *ds, msnv_site *sites, msnv_site_
     if (int rc = fetch_results(ds)) return rc;
     if (capacity < ds->sites.size()) return fail(MSNV_ECAPACITY, "capacity %llu < %zu sites", (unsigned long long)capacity, ds->sites.size());
     memcpy(sites, ds->sites.data(), ds->sites.size() * sizeof(msnv_site));
-    memcpy(samples, ds->site_samples.data(), ds->site_samples.size() * sizeof(msnv_site_sample));
+    const size_t S = ds->samples.size();
+    memset(samples, 0, ds->sites.size() * S * sizeof(msnv_site_sample));
+    for (size_t i = 0; i < ds->sites.size(); ++i)
+        for (uint64_t c = ds->site_row[i]; c < ds->site_row[i + 1]; ++c) samples[i * S + ds->site_cell_sample[(size_t)c]] = ds->site_cells[(size_t)c];
+    return MSNV_OK;
+}
+
+extern "C" int msnv_results_cells_count(const msnv_dataset *ds, uint64_t *n_sites, uint64_t *n_cells) {
+    clear_error();
+    if (!ds || !n_sites || !n_cells) return fail(MSNV_EINVAL, "msnv_results_cells_count: NULL argument");
+    if (!ds->have_results) return fail(MSNV_EINVAL, "no results: call msnv_pileup_run first");
+    if (int rc = fetch_results(const_cast<msnv_dataset *>(ds))) return rc;
+    *n_sites = ds->sites.size(); *n_cells = ds->site_cells.size();
+    return MSNV_OK;
+}
+
+extern "C" int msnv_results_fetch_cells(msnv_dataset *ds, msnv_site *sites, uint64_t *row_off, uint32_t *cell_sample, msnv_site_sample *cells,
+                                        uint64_t cap_sites, uint64_t cap_cells) {
+    clear_error();
+    if (!ds || !row_off) return fail(MSNV_EINVAL, "msnv_results_fetch_cells: NULL argument");
+    if (!ds->have_results) return fail(MSNV_EINVAL, "no results: call msnv_pileup_run first");
+    if (int rc = fetch_results(ds)) return rc;
+    if (cap_sites < ds->sites.size() || cap_cells < ds->site_cells.size())
+        return fail(MSNV_ECAPACITY, "capacity %llu sites / %llu cells < %zu / %zu", (unsigned long long)cap_sites, (unsigned long long)cap_cells, ds->sites.size(), ds->site_cells.size());
+    if ((ds->sites.size() && !sites) || (ds->site_cells.size() && (!cell_sample || !cells))) return fail(MSNV_EINVAL, "msnv_results_fetch_cells: NULL argument");
+    if (!ds->sites.empty()) memcpy(sites, ds->sites.data(), ds->sites.size() * sizeof(msnv_site));
+    memcpy(row_off, ds->site_row.data(), ds->site_row.size() * sizeof(uint64_t));
+    if (!ds->site_cells.empty()) {
+        memcpy(cell_sample, ds->site_cell_sample.data(), ds->site_cell_sample.size() * sizeof(uint32_t));
+        memcpy(cells, ds->site_cells.data(), ds->site_cells.size() * sizeof(msnv_site_sample));
+    }
     return MSNV_OK;
 }
 
@@ -756,21 +836,12 @@ extern "C" int msnv_dataset_first_lines(const msnv_dataset *ds, int32_t *first_a
     return MSNV_OK;
 }
 
-extern "C" int msnv_write_calls_records(const msnv_ref_desc *ref, int32_t n_samples, const msnv_site *sites,
-                                        const msnv_site_sample *samples, uint64_t n_sites,
-                                        const char *called_path, const char *indiv_path,
-                                        const char *ann_path, const char *fasta_path, const msnv_site_ann *ann) {
-    clear_error();
-    if (!ref || !called_path || n_samples < 0 || (n_sites && (!sites || !samples))) return fail(MSNV_EINVAL, "msnv_write_calls_records: bad argument");
-    const bool annotated = ann_path && fasta_path;
-    if (annotated && n_sites && !ann) return fail(MSNV_EINVAL, "msnv_write_calls_records: annotation records are required with ann_path (the annotation is computed on the device)");
-    msnv_dataset tmp;                       // formatter state only: names, sample count, records
-    for (int i = 0; i < ref->n_contigs; ++i) tmp.names.emplace_back(ref->names[i]);
-    tmp.samples.resize((size_t)n_samples);
-    tmp.sites.assign(sites, sites + n_sites);
-    tmp.site_samples.assign(samples, samples + n_sites * (uint64_t)n_samples);
+// formatter over records that did not come from a local run: `tmp` holds names, sample count and the records in either form
+static int write_gathered(msnv_dataset &tmp, const msnv_ref_desc *ref, uint64_t n_sites, const char *called_path, const char *indiv_path,
+                          const char *ann_path, const char *fasta_path, const msnv_site_ann *ann) {
     for (uint64_t i = 0; i < n_sites; ++i)
-        if (sites[i].tid < 0 || sites[i].tid >= ref->n_contigs) return fail(MSNV_EINVAL, "record %llu names contig %d", (unsigned long long)i, sites[i].tid);
+        if (tmp.sites[i].tid < 0 || tmp.sites[i].tid >= ref->n_contigs) return fail(MSNV_EINVAL, "record %llu names contig %d", (unsigned long long)i, tmp.sites[i].tid);
+    const bool annotated = ann_path && fasta_path;
     if (!annotated) return write_calls_text(tmp, called_path, indiv_path, nullptr, nullptr);
     Annotation an;                          // gene names only; the codon work was done on the ranks' devices
     if (int rc = load_annotation(ann_path, nullptr, an)) return rc;
@@ -779,6 +850,42 @@ extern "C" int msnv_write_calls_records(const msnv_ref_desc *ref, int32_t n_samp
     for (uint64_t i = 0; i < n_sites; ++i)
         if (ann[i].gene >= (int32_t)gene_names.size()) return fail(MSNV_EINVAL, "annotation record %llu names gene %d of %zu", (unsigned long long)i, ann[i].gene, gene_names.size());
     return write_calls_text(tmp, called_path, indiv_path, ann, &gene_names);
+}
+
+extern "C" int msnv_write_calls_records(const msnv_ref_desc *ref, int32_t n_samples, const msnv_site *sites,
+                                        const msnv_site_sample *samples, uint64_t n_sites,
+                                        const char *called_path, const char *indiv_path,
+                                        const char *ann_path, const char *fasta_path, const msnv_site_ann *ann) {
+    clear_error();
+    if (!ref || !called_path || n_samples < 0 || (n_sites && (!sites || !samples))) return fail(MSNV_EINVAL, "msnv_write_calls_records: bad argument");
+    if (ann_path && fasta_path && n_sites && !ann) return fail(MSNV_EINVAL, "msnv_write_calls_records: annotation records are required with ann_path (the annotation is computed on the device)");
+    msnv_dataset tmp;                       // formatter state only: names, sample count, records
+    for (int i = 0; i < ref->n_contigs; ++i) tmp.names.emplace_back(ref->names[i]);
+    tmp.samples.resize((size_t)n_samples);
+    tmp.sites.assign(sites, sites + n_sites);
+    tmp.site_samples.assign(samples, samples + n_sites * (uint64_t)n_samples);
+    return write_gathered(tmp, ref, n_sites, called_path, indiv_path, ann_path, fasta_path, ann);
+}
+
+extern "C" int msnv_write_calls_cells(const msnv_ref_desc *ref, int32_t n_samples, const msnv_site *sites, const uint64_t *row_off,
+                                      const uint32_t *cell_sample, const msnv_site_sample *cells, uint64_t n_sites,
+                                      const char *called_path, const char *indiv_path,
+                                      const char *ann_path, const char *fasta_path, const msnv_site_ann *ann) {
+    clear_error();
+    if (!ref || !called_path || n_samples < 0 || !row_off || (n_sites && !sites)) return fail(MSNV_EINVAL, "msnv_write_calls_cells: bad argument");
+    if (ann_path && fasta_path && n_sites && !ann) return fail(MSNV_EINVAL, "msnv_write_calls_cells: annotation records are required with ann_path (the annotation is computed on the device)");
+    const uint64_t n_cells = row_off[n_sites];
+    if (row_off[0] != 0 || (n_cells && (!cell_sample || !cells))) return fail(MSNV_EINVAL, "msnv_write_calls_cells: bad row offsets");
+    for (uint64_t i = 0; i < n_sites; ++i) if (row_off[i + 1] < row_off[i]) return fail(MSNV_EINVAL, "msnv_write_calls_cells: row offsets of record %llu decrease", (unsigned long long)i);
+    for (uint64_t c = 0; c < n_cells; ++c) if (cell_sample[c] >= (uint32_t)n_samples) return fail(MSNV_EINVAL, "msnv_write_calls_cells: cell %llu names sample %u of %d", (unsigned long long)c, cell_sample[c], n_samples);
+    msnv_dataset tmp;
+    for (int i = 0; i < ref->n_contigs; ++i) tmp.names.emplace_back(ref->names[i]);
+    tmp.samples.resize((size_t)n_samples);
+    tmp.sites.assign(sites, sites + n_sites);
+    tmp.site_row.assign(row_off, row_off + n_sites + 1);
+    tmp.site_cell_sample.assign(cell_sample, cell_sample + n_cells);
+    tmp.site_cells.assign(cells, cells + n_cells);
+    return write_gathered(tmp, ref, n_sites, called_path, indiv_path, ann_path, fasta_path, ann);
 }
 
 namespace msnv {
@@ -846,6 +953,23 @@ extern "C" int msnv_records_partition(const uint8_t *records, uint64_t n_bytes, 
     const int rc = records_partition(records, n_bytes, contig_owner, n_contigs, n_parts, cov_min_mapq, out, part_bytes, st);
     if (!rc && stats) *stats = st;
     return rc;
+}
+
+extern "C" int msnv_records_contig_bases(const uint8_t *records, uint64_t n_bytes, int32_t n_contigs, uint64_t *bases) {
+    clear_error();
+    if ((n_bytes && !records) || n_contigs < 0 || (n_contigs && !bases)) return fail(MSNV_EINVAL, "msnv_records_contig_bases: bad argument");
+    uint64_t off = 0;
+    while (off < n_bytes) {
+        RecView r;
+        if (!rec_parse(records + off, n_bytes - off, r)) return fail(MSNV_EFORMAT, "malformed BAM record at byte %llu", (unsigned long long)off);
+        off += r.size;
+        if ((r.flag & BAM_FUNMAP) || r.tid < 0) continue;
+        if (r.tid >= n_contigs) return fail(MSNV_EFORMAT, "record refers to contig %d but the header has %d", r.tid, n_contigs);
+        uint64_t m = 0;
+        for (int k = 0; k < r.n_cigar; ++k) { const uint32_t c = ld_u32(r.cigar + 4 * k), t = c & 15u; if (t == C_M || t == C_EQ || t == C_X) m += c >> 4; }
+        bases[r.tid] += m;
+    }
+    return MSNV_OK;
 }
 
 extern "C" int msnv_dataset_sample_stats(const msnv_dataset *ds, int32_t sample_idx, msnv_sample_stats *out) {

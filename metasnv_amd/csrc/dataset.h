@@ -92,6 +92,16 @@ struct SampleCols {
 struct DeviceCols;   // kernels.hip
 
 }  // namespace msnv
+struct msnv_dataset;
+namespace msnv {
+// The per-sample records of fetched site i, one entry per sample: a pointer into the dense form when the dataset holds it, else the
+// site's cells expanded into `scratch` (S entries, all zero between calls: the entries a call touches are zeroed again by the next).
+struct SiteRowView {
+    std::vector<msnv_site_sample> scratch;
+    std::vector<uint32_t> touched;
+    const msnv_site_sample *row(const msnv_dataset &ds, size_t i, size_t S);
+};
+}  // namespace msnv
 
 struct msnv_ctx {
     int device = 0;
@@ -132,9 +142,28 @@ struct msnv_dataset {
     uint32_t last_counts_sites = 0;
     msnv_run_stats last_stats{};
     std::vector<msnv_site> sites;
-    std::vector<msnv_site_sample> site_samples;
+    std::vector<msnv_site_sample> site_samples;   // dense [sites][samples] form: only datasets that were handed dense records hold it (msnv_write_calls_records, text entry)
+    // per-sample records of the fetched sites as ROWS OF CELLS (CSR): site i owns cells [site_row[i], site_row[i + 1]), a cell = one sample
+    // that has counted bases or alleles at the site.  What the device stores per tile slot (kernels.hip: CellMap) stays compact on the
+    // host: a 500-sample cohort in which a species is carried by a handful of samples costs a handful of cells per site, not 500.
+    std::vector<uint64_t> site_row;
+    std::vector<uint32_t> site_cell_sample;
+    std::vector<msnv_site_sample> site_cells;
     std::vector<uint32_t> site_dev_index;      // host record -> device site record
     bool ann_valid = false;                    // the device holds annotation records of the last run
     bool have_coverage = false;
     std::vector<unsigned long long> cov_acc;   // [sample][contig][1 + COV_BINS]
 };
+
+inline const msnv_site_sample *msnv::SiteRowView::row(const msnv_dataset &ds, size_t i, size_t S) {
+    if (ds.site_row.empty()) return &ds.site_samples[i * S];
+    if (scratch.size() != S) { scratch.assign(S, msnv_site_sample{}); touched.clear(); }
+    for (uint32_t k : touched) scratch[k] = msnv_site_sample{};
+    touched.clear();
+    for (uint64_t c = ds.site_row[i]; c < ds.site_row[i + 1]; ++c) {
+        const uint32_t k = ds.site_cell_sample[(size_t)c];
+        scratch[k] = ds.site_cells[(size_t)c];
+        touched.push_back(k);
+    }
+    return scratch.data();
+}

@@ -227,6 +227,7 @@ int filter_resident(msnv_dataset &ds, int which, const FilterSpecies &sp, double
         if (it != sp_index.end()) contig_species[c] = (int32_t)it->second;
     }
     std::string id, tag;
+    SiteRowView rows;
     for (size_t i = 0; i < ds.sites.size(); ++i) {
         const msnv_site &s = ds.sites[i];
         if (s.dropped) continue;                              // call_vC.cpp:423: the line never reaches the files
@@ -234,7 +235,7 @@ int filter_resident(msnv_dataset &ds, int which, const FilterSpecies &sp, double
         if (spi < 0) continue;                                // species filter (metaSNV_Filtering.py:175)
         const uint32_t mask = which ? s.ind_mask : s.pop_mask;
         if (!mask) continue;                                  // no line of this kind for the position
-        const msnv_site_sample *ss = &ds.site_samples[i * S];
+        const msnv_site_sample *ss = rows.row(ds, i, S);
         const msnv_site_ann *an = ann ? &ann[i] : nullptr;
         const bool in_gene = an && an->gene >= 0;
         id.assign(ds.names[(size_t)s.tid]); id.push_back(':');

@@ -113,11 +113,12 @@ int write_calls_text(msnv_dataset &ds, const char *called_path, const char *indi
     static const int order[4] = {0, 1, 3, 2};               // alleles are emitted a, c, t, g (:561)
     static const char letter[4] = {'A', 'C', 'G', 'T'};
     std::string pop, ind, head, entry;
+    SiteRowView rows;
 
     for (size_t i = 0; i < ds.sites.size(); ++i) {
         const msnv_site &s = ds.sites[i];
         if (s.dropped) continue;                              // call_vC.cpp:423
-        const msnv_site_sample *ss = &ds.site_samples[i * S];
+        const msnv_site_sample *ss = rows.row(ds, i, S);
         const std::string &cname = ds.names[(size_t)s.tid];
         const msnv_site_ann *an = ann ? &ann[i] : nullptr;
         const bool in_gene = an && an->gene >= 0;

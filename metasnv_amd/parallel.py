@@ -6,10 +6,14 @@ already bins whole species for its process pool (src/createOptimumSplit.py:46-62
 sees all samples but only its contigs' reads.  The kernels need no collective.  Two exchanges frame them:
   * before: the BAMs are dealt to the ranks for DECODING (every file is inflated once in the whole job; the
     reference's split processes each inflate every BAM, metaSNV.py:196-215) and the decoded records travel to
-    the rank that owns their contig -- one all_to_all of byte streams per batch of BAMs (exchange_records);
-  * after: the GATHER of small result tables to rank 0:
-      - coverage accumulators: fixed size per (sample, contig) -> all_gather of equal tensors, summed;
-      - called-site records: variable length -> all_gather of the counts, then a padded all_gather.
+    the rank that owns their contig -- one all_to_all of byte streams per batch of BAMs (exchange_records).
+    The contig owners are fixed by the reference's rule, whole species heaviest-first by genome length x
+    coverage (createOptimumSplit.py:46-62), with the coverage taken from the first round of decoded BAMs;
+  * after: the GATHER of the result tables TO RANK 0, compressed (gather_to_root: one all_to_all in which only
+    rank 0 receives, exact sizes, no padding):
+      - called-site records in the cell form (a cell per sample that holds something at the site, not
+        n_samples entries per site: core.Dataset.results_cells);
+      - coverage accumulators: the non-zero (sample, contig) rows only.
 """
 import os
 import sys
@@ -20,13 +24,15 @@ _dist = None
 _rank, _world, _local = 0, 1, 0
 
 
-def init_from_env():
-    """Reads RANK / WORLD_SIZE / LOCAL_RANK (torchrun); a no-op for a single process."""
+def init_from_env(force=False):
+    """Reads RANK / WORLD_SIZE / LOCAL_RANK (torchrun); a no-op for a single process unless `force` (or MSNV_DIST_FORCE=1):
+    a process group of ONE rank, which is how the RCCL code paths run on a box with a single GPU (tests/test_gpu_nccl.py)."""
     global _dist, _rank, _world, _local
     _rank = int(os.environ.get("RANK", "0"))
     _world = int(os.environ.get("WORLD_SIZE", "1"))
     _local = int(os.environ.get("LOCAL_RANK", "0"))
-    if _world > 1 and _dist is None:
+    force = force or os.environ.get("MSNV_DIST_FORCE") == "1"
+    if (_world > 1 or force) and _dist is None:
         import torch
         import torch.distributed as dist
         if torch.cuda.is_available() and os.environ.get("MSNV_DIST_BACKEND", "nccl") == "nccl":
@@ -48,6 +54,10 @@ def rank():
 
 def world():
     return _world
+
+
+def backend():
+    return _dist.get_backend() if _dist is not None else None
 
 
 def barrier():
@@ -76,25 +86,41 @@ def _device():
     return torch.device("cuda", _local) if (_dist is not None and _dist.get_backend() == "nccl") else torch.device("cpu")
 
 
+class RankError(RuntimeError):
+    """Another rank failed in a step every rank takes part in (its own exception names the cause on that rank)."""
+
+
 # ------------------------------------------------------------------------------------ sharding policy
-def shard_contigs(names, lengths, n_ranks, species_weight=None):
+def shard_contigs(names, lengths, n_ranks, species_weight=None, contig_bases=None):
     """contig -> rank by the reference's own rule: whole species (name up to the first '.') are
     assigned heaviest-first to the lightest rank (createOptimumSplit.py:46-62).  The weight of a
-    species is genome length x summed coverage when known (species_weight), else its length.
-    Returns a list of rank ids, one per contig."""
+    species is genome length x summed coverage (`read = genomeLen[k]*coverage[k]`, :46-50):
+      species_weight {species: summed coverage}  -- the all_cov.tab column sums, as the reference has them; or
+      contig_bases   [aligned bases per contig]  -- length x coverage IS the aligned bases; counted on a SUBSET of the samples
+                     (the first decode round), so a species none of them carries still gets 5 % of the mean coverage;
+    else its length.  Returns a list of rank ids, one per contig."""
     from .tables import species_of, lpt_assign
-    length = {}
-    for n, l in zip(names, lengths):
-        length[species_of(n)] = length.get(species_of(n), 0) + int(l)
-    weighted = [((species_weight or {}).get(sp, 1.0) * l if species_weight else l, sp) for sp, l in length.items()]
+    length, bases = {}, {}
+    for i, (n, l) in enumerate(zip(names, lengths)):
+        sp = species_of(n)
+        length[sp] = length.get(sp, 0) + int(l)
+        if contig_bases is not None:
+            bases[sp] = bases.get(sp, 0) + int(contig_bases[i])
+    if contig_bases is not None:
+        prior = 0.05 * sum(bases.values()) / max(1, sum(length.values()))
+        weighted = [(bases[sp] + prior * l, sp) for sp, l in length.items()]
+    elif species_weight:
+        weighted = [(species_weight.get(sp, 0.0) * l, sp) for sp, l in length.items()]
+    else:
+        weighted = [(l, sp) for sp, l in length.items()]
     bins = lpt_assign(weighted, n_ranks)
     owner = {sp: r for r, sps in enumerate(bins) for sp in sps}
     return [owner[species_of(n)] for n in names]
 
 
-# ------------------------------------------------------------------------------------ gathers
+# ------------------------------------------------------------------------------------ collectives
 def gather_fixed(array):
-    """all_gather of equally shaped numpy arrays; returns the list (every rank gets it)."""
+    """all_gather of equally shaped numpy arrays; returns the list (every rank gets it).  For SMALL tables only."""
     if _dist is None:
         return [np.asarray(array)]
     import torch
@@ -106,7 +132,7 @@ def gather_fixed(array):
 
 
 def gather_bytes(blob):
-    """Variable-length gather: counts first, then one padded all_gather.  blob: 1-D uint8 array."""
+    """Variable-length gather to EVERY rank: counts first, then one padded all_gather.  blob: 1-D uint8 array."""
     blob = np.ascontiguousarray(blob, dtype=np.uint8).reshape(-1)
     if _dist is None:
         return [blob]
@@ -125,28 +151,52 @@ def gather_bytes(blob):
     return [o[:c].cpu().numpy() for o, c in zip(out, counts)]
 
 
-def exchange_records(parts):
+def exchange_records(parts, status=0):
     """All-to-all of byte streams: parts[q] (1-D uint8 array) goes to rank q; returns the list of the arrays this rank
-    received, indexed by sender.  Sizes travel first (one all_to_all of `world` int64), then the bytes."""
+    received, indexed by sender.  {size, status} pairs travel first (one all_to_all of world x 2 int64), then the bytes.
+    `status` != 0 says "this rank failed in the step that made the parts": every rank then raises RankError before the
+    byte exchange instead of waiting in it for a rank that is gone."""
     if _dist is None:
+        if status:
+            raise RankError("rank 0 reported error %d" % status)
         return [np.ascontiguousarray(parts[0], dtype=np.uint8)]
     import torch
     dev = _device()
     sizes = [int(np.asarray(p).size) for p in parts]
-    ts = torch.tensor(sizes, dtype=torch.int64, device=dev)
-    tr = torch.zeros(_world, dtype=torch.int64, device=dev)
+    ts = torch.tensor([[s, int(status)] for s in sizes], dtype=torch.int64, device=dev).reshape(-1)
+    tr = torch.zeros(2 * _world, dtype=torch.int64, device=dev)
     _dist.all_to_all_single(tr, ts)
-    rsizes = [int(x) for x in tr.cpu().tolist()]
+    got = tr.cpu().tolist()
+    rsizes, rstatus = got[0::2], got[1::2]
+    bad = [(r, int(c)) for r, c in enumerate(rstatus) if c]
+    if bad:
+        raise RankError("rank %d reported error %d while the records were decoded" % bad[0])
     send = np.concatenate([np.ascontiguousarray(p, dtype=np.uint8).reshape(-1) for p in parts]) if sum(sizes) else np.zeros(0, np.uint8)
     tsend = torch.from_numpy(send).to(dev)
     trecv = torch.empty(sum(rsizes), dtype=torch.uint8, device=dev)
-    _dist.all_to_all_single(trecv, tsend, output_split_sizes=rsizes, input_split_sizes=sizes)
+    _dist.all_to_all_single(trecv, tsend, output_split_sizes=[int(x) for x in rsizes], input_split_sizes=sizes)
     got = trecv.cpu().numpy()
     out, o = [], 0
     for n in rsizes:
         out.append(got[o:o + n])
         o += n
     return out
+
+
+def gather_to_root(blob, stats=None):
+    """Variable-length gather to RANK 0 ONLY: the all-to-all of exchange_records in which every rank sends its bytes to
+    rank 0 and nothing to the others (exact sizes, no padding, nothing lands on a rank that does not write).  Returns the list
+    of arrays indexed by sender on rank 0, None elsewhere.  stats (dict): bytes_received accumulates what rank 0 took in."""
+    blob = np.ascontiguousarray(blob, dtype=np.uint8).reshape(-1)
+    if _dist is None:
+        if stats is not None:
+            stats["bytes_received"] = stats.get("bytes_received", 0) + int(blob.size)
+        return [blob]
+    empty = np.zeros(0, np.uint8)
+    got = exchange_records([blob if q == 0 else empty for q in range(_world)])
+    if stats is not None and _rank == 0:
+        stats["bytes_received"] = stats.get("bytes_received", 0) + int(sum(g.size for g in got))
+    return got if _rank == 0 else None
 
 
 def deal_samples(n_samples, batch):
@@ -157,14 +207,21 @@ def deal_samples(n_samples, batch):
         yield base, [(i, (i - base) // batch) for i in range(base, min(n_samples, base + step))]
 
 
-def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=None, metrics=None):
+def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=None, metrics=None, plan=None, pack_threads=0):
     """Decode-sharded input of one dataset per rank: every BAM is read and inflated by ONE rank, its records are dealt by
     contig owner (core.partition_records) and exchanged, and every rank appends all samples in all_samples order holding
     only its contigs' records.  Returns stats[n_samples][6] (qaCompute's per-BAM statistics, counted by the decoder and
-    all-gathered).  read_records(path) -> uint8 array replaces the BAM reader in tests."""
+    all-gathered).  read_records(path) -> uint8 array replaces the BAM reader in tests.
+
+    owner = None: the contig owners are fixed HERE, after the first round has been decoded and before anything is dealt --
+    plan = (names, lengths); the ranks add up the aligned bases per contig of their first-round samples (= genome length x
+    coverage, the reference's split weight, createOptimumSplit.py:46-50), shard_contigs assigns the species, the dataset gets
+    its contig mask and metrics["owner"] the assignment."""
     from . import core
     n = len(bam_paths)
-    if _world == 1 and read_records is None:             # nothing to exchange: decode + pack inside the library's thread pool
+    if _dist is None and read_records is None:           # nothing to exchange: decode + pack inside the library's thread pool
+        if owner is None and metrics is not None:
+            metrics["owner"] = [0] * len(plan[0])
         ds.add_sample_bams(bam_paths, batch)
         if metrics is not None:
             metrics["inflated_record_bytes"] = None
@@ -174,118 +231,253 @@ def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=Non
         read_many = lambda paths: core.read_bam_records(paths, ctx=getattr(ds, "ctx", None), threads=max(1, len(paths)))
     stats = np.zeros((n, len(core.STATS_FIELDS)), dtype=np.uint32)
     inflated = 0
-    for base, plan in deal_samples(n, batch):
-        mine = [i for i, r in plan if r == _rank]
-        # decode my samples of this round and deal every one of them to the owners
-        per_dest = [[] for _ in range(_world)]          # per destination rank: (sample, bytes) in sample order
-        if read_many is not None:
-            decoded = read_many([bam_paths[i] for i in mine])
-        elif len(mine) > 1:                              # the library releases the GIL: one decode thread per BAM of the round
-            from concurrent.futures import ThreadPoolExecutor
-            with ThreadPoolExecutor(max_workers=len(mine)) as ex:
-                decoded = list(ex.map(read_records, [bam_paths[i] for i in mine]))
-        else:
-            decoded = [read_records(bam_paths[i]) for i in mine]
-        for i, rec in zip(mine, decoded):
-            inflated += int(rec.size)
-            parts, st = core.partition_records(rec, owner, _world, cov_min_mapq)
-            stats[i] = st
-            for q in range(_world):
-                per_dest[q].append(parts[q])
+    for base, plan_round in deal_samples(n, batch):
+        mine = [i for i, r in plan_round if r == _rank]
+        # decode my samples of this round; a failure here is carried to every rank by the exchange (status word)
+        failure, decoded = None, []
+        try:
+            if read_many is not None:
+                decoded = read_many([bam_paths[i] for i in mine])
+            elif len(mine) > 1:                              # the library releases the GIL: one decode thread per BAM of the round
+                from concurrent.futures import ThreadPoolExecutor
+                with ThreadPoolExecutor(max_workers=len(mine)) as ex:
+                    decoded = list(ex.map(read_records, [bam_paths[i] for i in mine]))
+            else:
+                decoded = [read_records(bam_paths[i]) for i in mine]
+        except Exception as e:                               # noqa: BLE001 -- re-raised below, after the other ranks have been told
+            failure, decoded = e, []
+        if owner is None:
+            # first round: genome length x coverage per species from what the ranks have just decoded
+            names, lengths = plan
+            local = np.zeros(len(names), dtype=np.uint64)
+            if failure is None:
+                try:
+                    for rec in decoded:
+                        core.contig_bases(rec, len(names), into=local)
+                except Exception as e:                       # noqa: BLE001
+                    failure, decoded = e, []
+            total = sum(a.astype(np.uint64) for a in gather_fixed(local))
+            owner = shard_contigs(names, lengths, _world, contig_bases=total)
+            if _world > 1 and hasattr(ds, "set_contig_mask"):
+                ds.set_contig_mask([o == _rank for o in owner])
+            if metrics is not None:
+                metrics["owner"] = list(owner)
+                metrics["first_round_bases"] = int(total.sum())
+        per_dest = [[] for _ in range(_world)]              # per destination rank: (sample, bytes) in sample order
+        if failure is None:
+            try:
+                for i, rec in zip(mine, decoded):
+                    inflated += int(rec.size)
+                    parts, st = core.partition_records(rec, owner, _world, cov_min_mapq)
+                    stats[i] = st
+                    for q in range(_world):
+                        per_dest[q].append(parts[q])
+            except Exception as e:                           # noqa: BLE001
+                failure, per_dest = e, [[] for _ in range(_world)]
         # one exchange per round: [sizes of my samples' parts | bytes], per destination
         send = []
         for q in range(_world):
             hdr = np.array([p.size for p in per_dest[q]], dtype=np.int64).view(np.uint8)
             send.append(np.concatenate([hdr] + per_dest[q]) if per_dest[q] else np.zeros(0, np.uint8))
-        got = exchange_records(send)
+        try:
+            got = exchange_records(send, status=0 if failure is None else int(getattr(failure, "code", 0)) or 99)
+        except RankError:
+            if failure is not None:
+                raise failure
+            raise
         # unpack in sample order: sender r holds samples base + r * batch ...
-        for i, r in plan:
+        n_from = [0] * _world
+        for _, r in plan_round:
+            n_from[r] += 1
+        sizes_of = [got[r][:8 * n_from[r]].view(np.int64) for r in range(_world)]
+        starts = [8 * n_from[r] + np.concatenate([[0], np.cumsum(sizes_of[r])]).astype(np.int64) for r in range(_world)]
+        streams = []
+        for i, r in plan_round:
             k = i - base - r * batch                     # index among the sender's samples of this round
-            blob = got[r]
-            n_from = len([1 for j, rr in plan if rr == r])
-            sizes = blob[:8 * n_from].view(np.int64)
-            o = 8 * n_from + int(sizes[:k].sum())
-            ds.add_sample_records(blob[o:o + int(sizes[k])])
+            o = int(starts[r][k])
+            streams.append(got[r][o:o + int(sizes_of[r][k])])
+        if hasattr(ds, "add_samples_records"):           # the round's samples are packed side by side by the library's host threads
+            ds.add_samples_records(streams, pack_threads)
+        else:
+            for s in streams:
+                ds.add_sample_records(s)
     allstats = gather_fixed(stats)
     stats = np.maximum.reduce(allstats) if len(allstats) > 1 else stats      # every row is non-zero on exactly one rank
     if metrics is not None:
         metrics["inflated_record_bytes"] = inflated
+        if "owner" not in metrics and owner is not None:
+            metrics["owner"] = list(owner)
     return stats
 
 
-def gather_sites(sites, samples, first_line, ann=None):
-    """Gathers the called-site records of every rank and merges them in (tid, pos) order.
-    first_line: this rank's (tid, pos) of the first pileup line, tid = -1 if none.  Only the globally
-    first line is the one the reference drops (call_vC.cpp:423), so the `dropped` mark of every other
-    rank-local first line is cleared.  Every rank returns the merged arrays; with `ann` (the device
-    annotation records of this rank's sites) the merged annotation records are appended to the tuple."""
-    from .core import SITE_DTYPE, SAMPLE_DTYPE
-    n_samples = samples.shape[1] if samples.ndim == 2 and samples.shape[0] else 0
-    parts_s = gather_bytes(np.ascontiguousarray(sites).view(np.uint8))
-    parts_m = gather_bytes(np.ascontiguousarray(samples).view(np.uint8))
-    firsts = gather_fixed(np.array([first_line[0], first_line[1], n_samples], dtype=np.int64))
-    ns = max(int(f[2]) for f in firsts)
-    all_sites = np.concatenate([p.view(SITE_DTYPE) for p in parts_s]) if parts_s else np.zeros(0, SITE_DTYPE)
-    all_samples = np.concatenate([p.view(SAMPLE_DTYPE).reshape(-1, ns) if p.size else np.zeros((0, ns), SAMPLE_DTYPE) for p in parts_m])
+# ------------------------------------------------------------------------------------ gather of the result tables
+def _merge_cells(parts, want_ann):
+    """parts: per rank (sites, counts, cell_sample, cells, ann or None), each in (tid, pos) order -> merged in (tid, pos) order."""
+    from .core import SITE_DTYPE, SAMPLE_DTYPE, ANN_DTYPE
+    sites = np.concatenate([p[0] for p in parts]) if parts else np.zeros(0, SITE_DTYPE)
+    counts = np.concatenate([p[1] for p in parts]).astype(np.int64) if parts else np.zeros(0, np.int64)
+    cell_sample = np.concatenate([p[2] for p in parts]) if parts else np.zeros(0, np.uint32)
+    cells = np.concatenate([p[3] for p in parts]) if parts else np.zeros(0, SAMPLE_DTYPE)
+    order = np.lexsort((sites["pos"], sites["tid"]))
+    old_off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    new_counts = counts[order]
+    new_off = np.concatenate([[0], np.cumsum(new_counts)]).astype(np.int64)
+    # cell j of new row i comes from old cell old_off[order[i]] + j
+    idx = np.repeat(old_off[order] - new_off[:-1], new_counts) + np.arange(int(new_off[-1]), dtype=np.int64)
+    ann = None
+    if want_ann:
+        ann = np.concatenate([p[4] for p in parts])[order] if parts else np.zeros(0, ANN_DTYPE)
+    return sites[order].copy(), new_off.astype(np.uint64), cell_sample[idx], cells[idx], ann
+
+
+def gather_sites_root(sites, row_off, cell_sample, cells, first_line, ann=None, stats=None):
+    """The called-site records of every rank, in the cell form, gathered TO RANK 0 and merged in (tid, pos) order.
+    first_line: this rank's (tid, pos) of the first pileup line, tid = -1 if none.  Only the globally first line is the one
+    the reference drops (call_vC.cpp:423), so the `dropped` mark of every other rank-local first line is cleared.
+    Rank 0 returns (sites, row_off, cell_sample, cells, ann or None, gfirst); the other ranks (None, ..., gfirst).
+    What travels per site: 32 B + 4 B (cell count) [+ 36 B annotation] + 14 B per non-empty (site, sample) cell."""
+    from .core import SITE_DTYPE, SAMPLE_DTYPE, ANN_DTYPE
+    sites = np.ascontiguousarray(sites, dtype=SITE_DTYPE)
+    counts = np.diff(np.asarray(row_off).astype(np.int64)).astype(np.uint32)
+    head = np.array([len(sites), int(np.asarray(row_off)[-1]) if len(row_off) else 0, 1 if ann is not None else 0], dtype=np.int64)
+    pieces = [head.view(np.uint8), sites.view(np.uint8).reshape(-1), counts.view(np.uint8),
+              np.ascontiguousarray(cell_sample, dtype=np.uint32).view(np.uint8), np.ascontiguousarray(cells, dtype=SAMPLE_DTYPE).view(np.uint8).reshape(-1)]
+    if ann is not None:
+        pieces.append(np.ascontiguousarray(ann, dtype=ANN_DTYPE).view(np.uint8).reshape(-1))
+    firsts = gather_fixed(np.array([first_line[0], first_line[1]], dtype=np.int64))
     cand = [(int(f[0]), int(f[1])) for f in firsts if f[0] >= 0]
     gfirst = min(cand) if cand else (-1, -1)
-    all_sites = all_sites.copy()
-    for i in np.nonzero(all_sites["dropped"])[0]:
-        if (int(all_sites["tid"][i]), int(all_sites["pos"][i])) != gfirst:
-            all_sites["dropped"][i] = 0
-    order = np.lexsort((all_sites["pos"], all_sites["tid"]))
-    if ann is None:
-        return all_sites[order], all_samples[order], gfirst
-    from .core import ANN_DTYPE
-    parts_a = gather_bytes(np.ascontiguousarray(ann, dtype=ANN_DTYPE).view(np.uint8))
-    all_ann = np.concatenate([p.view(ANN_DTYPE) for p in parts_a]) if parts_a else np.zeros(0, ANN_DTYPE)
-    return all_sites[order], all_samples[order], gfirst, all_ann[order]
+    got = gather_to_root(np.concatenate(pieces), stats)
+    if got is None:
+        return None, None, None, None, None, gfirst
+    parts = []
+    for b in got:
+        ns, nc, has_ann = (int(x) for x in b[:24].view(np.int64))
+        o = 24
+        s = b[o:o + ns * SITE_DTYPE.itemsize].view(SITE_DTYPE); o += ns * SITE_DTYPE.itemsize
+        c = b[o:o + 4 * ns].view(np.uint32); o += 4 * ns
+        cs = b[o:o + 4 * nc].view(np.uint32); o += 4 * nc
+        ce = b[o:o + nc * SAMPLE_DTYPE.itemsize].view(SAMPLE_DTYPE); o += nc * SAMPLE_DTYPE.itemsize
+        a = b[o:o + ns * ANN_DTYPE.itemsize].view(ANN_DTYPE) if has_ann else None
+        parts.append((s, c, cs, ce, a))
+    m_sites, m_off, m_cs, m_cells, m_ann = _merge_cells(parts, ann is not None)
+    for i in np.nonzero(m_sites["dropped"])[0]:
+        if (int(m_sites["tid"][i]), int(m_sites["pos"][i])) != gfirst:
+            m_sites["dropped"][i] = 0
+    return m_sites, m_off, m_cs, m_cells, m_ann, gfirst
+
+
+class SparseAcc:
+    """Coverage accumulators [n_samples][n_contigs][COV_WORDS] held as their non-zero (sample, contig) rows; acc[i] is sample
+    i's dense [n_contigs][COV_WORDS] table (what core.write_coverage_records takes)."""
+
+    def __init__(self, n_samples, n_contigs, sample, contig, rows):
+        from .core import COV_WORDS
+        order = np.lexsort((contig, sample))
+        self.n_samples, self.n_contigs, self.words = n_samples, n_contigs, COV_WORDS
+        self.sample, self.contig, self.rows = sample[order], contig[order], rows[order]
+        self.start = np.searchsorted(self.sample, np.arange(n_samples + 1))
+
+    def __len__(self):
+        return self.n_samples
+
+    def __getitem__(self, i):
+        out = np.zeros((self.n_contigs, self.words), dtype=np.uint64)
+        lo, hi = int(self.start[i]), int(self.start[i + 1])
+        np.add.at(out, self.contig[lo:hi], self.rows[lo:hi])          # (a contig is owned by one rank: one row per (sample, contig))
+        return out
+
+    def dense(self):
+        return np.stack([self[i] for i in range(self.n_samples)]) if self.n_samples else np.zeros((0, self.n_contigs, self.words), np.uint64)
+
+
+def gather_coverage_root(acc, stats=None):
+    """acc[n_samples][n_contigs][COV_WORDS] of this rank (zeros outside its contigs) -> SparseAcc of the whole job on rank 0
+    (None elsewhere): only the non-zero (sample, contig) rows travel -- 8 B of index + 136 B each."""
+    acc = np.ascontiguousarray(acc, dtype=np.uint64)
+    S, NC, W = acc.shape
+    nz_s, nz_c = np.nonzero(acc.any(axis=2))
+    rows = acc[nz_s, nz_c]
+    blob = np.concatenate([np.array([len(nz_s)], dtype=np.int64).view(np.uint8), nz_s.astype(np.uint32).view(np.uint8),
+                           nz_c.astype(np.uint32).view(np.uint8), np.ascontiguousarray(rows).view(np.uint8).reshape(-1)])
+    got = gather_to_root(blob, stats)
+    if got is None:
+        return None
+    ss, cc, rr = [], [], []
+    for b in got:
+        n = int(b[:8].view(np.int64)[0])
+        o = 8
+        ss.append(b[o:o + 4 * n].view(np.uint32)); o += 4 * n
+        cc.append(b[o:o + 4 * n].view(np.uint32)); o += 4 * n
+        rr.append(b[o:o + 8 * W * n].view(np.uint64).reshape(n, W))
+    return SparseAcc(S, NC, np.concatenate(ss).astype(np.int64), np.concatenate(cc).astype(np.int64), np.concatenate(rr))
 
 
 def resident_project_run(ctx, first_bam, fasta_path, bam_paths, params, batch=1, want_coverage=True, ann_path=None,
-                         after_coverage=None, species_weight=None):
+                         after_coverage=None, species_weight=None, make_dataset=None, read_records=None, run_passes=None):
     """ONE resident dataset per rank for a whole metaSNV.py run, whatever the number of ranks and splits (the reference forks
     one qaCompute process per BAM, metaSNV.py:55-78, and one `mpileup | snpCall` process per split, :196-221, each of which
-    inflates every BAM again): contigs are sharded over the ranks by species (LPT), the BAMs are dealt to the ranks for
-    decoding and their records exchanged (feed_sharded), every rank runs coverage and then calling [+ annotation] over its
-    contigs, and every rank receives the summed coverage accumulators and the merged site records (rank 0 writes the files).
+    inflates every BAM again): contigs are sharded over the ranks by species (LPT on length x coverage), the BAMs are dealt to
+    the ranks for decoding and their records exchanged (feed_sharded), every rank runs coverage and then calling [+ annotation]
+    over its contigs, and RANK 0 receives the coverage rows and the merged site records (it writes the files).
+
+    species_weight {species: summed coverage} fixes the owners up front (a previous run's all_cov.tab, --use_prev_cov); without
+    it they are fixed after the first decode round (feed_sharded).  make_dataset() / read_records(path) replace the BAM-file
+    dataset and reader (bench.py's strong-scaling mode feeds synthetic record streams through this very function);
+    run_passes(ds) -> stats replaces the single ds.run() (bench.py times K passes there).
 
     after_coverage(result) is called on every rank between the two passes -- the driver writes cov/, the tables and the
     split plan there -- and must contain its own barriers.  Returns a dict:
-      names, lengths, n_samples, stats[n_samples][6], acc[n_samples][n_contigs][17] (None without coverage),
-      sites / samples / ann (merged, (tid, pos) order, `dropped` marks the global first line), first_any / first_from1
-      (per contig, see core.Dataset.first_lines), metrics."""
+      names, lengths, n_samples, stats[n_samples][6], acc (SparseAcc on rank 0, None elsewhere / without coverage),
+      sites / row_off / cell_sample / cells / ann (merged, (tid, pos) order, `dropped` marks the global first line; rank 0 only),
+      first_any / first_from1 (per contig, see core.Dataset.first_lines), metrics."""
+    import time
     from . import core
-    ds = core.Dataset.from_files(ctx, first_bam, fasta_path, params)
+    ds = make_dataset() if make_dataset else core.Dataset.from_files(ctx, first_bam, fasta_path, params)
     names, lengths = ds.names, ds.lengths
-    owner = shard_contigs(names, lengths, _world, species_weight)
-    if _world > 1:
-        ds.set_contig_mask([o == _rank for o in owner])
-    metrics = {"rank": _rank, "world": _world, "contigs": int(sum(1 for o in owner if o == _rank))}
+    owner = None
+    if species_weight is not None or _dist is None:
+        owner = shard_contigs(names, lengths, _world, species_weight)
+        if _world > 1:
+            ds.set_contig_mask([o == _rank for o in owner])
+    metrics = {"rank": _rank, "world": _world}
     res = {"names": names, "lengths": lengths, "n_samples": len(bam_paths), "metrics": metrics, "acc": None}
     try:
-        res["stats"] = feed_sharded(ds, bam_paths, owner, params.cov_min_mapq, batch, metrics=metrics)
+        t0 = time.perf_counter()
+        res["stats"] = feed_sharded(ds, bam_paths, owner, params.cov_min_mapq, batch, read_records=read_records, metrics=metrics, plan=(names, lengths))
+        owner = metrics.pop("owner", owner)
+        res["owner"] = owner
+        metrics["contigs"] = int(sum(1 for o in owner if o == _rank))
+        metrics["feed_s"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
         metrics["dataset"] = ds.finalize()
+        metrics["finalize_s"] = time.perf_counter() - t0
+        gstats = {}
         if want_coverage:
             metrics["coverage"] = ds.coverage_run()
-            # every rank holds zeros outside its contigs, so the sum over ranks is the whole table
-            res["acc"] = sum(a.astype(np.uint64) for a in gather_fixed(ds.coverage_accumulators()))
+            t0 = time.perf_counter()
+            res["acc"] = gather_coverage_root(ds.coverage_accumulators(), gstats)
+            metrics["gather_coverage_s"] = time.perf_counter() - t0
         if after_coverage:
             after_coverage(res)
-        metrics["pileup"] = ds.run()
-        sites, samples = ds.results()
+        metrics["pileup"] = run_passes(ds) if run_passes else ds.run()
+        t0 = time.perf_counter()
+        sites, row_off, cell_sample, cells = ds.results_cells()
+        ann = None
         if ann_path and fasta_path:
             ann, _ = ds.annotate(ann_path, fasta_path)
-            res["sites"], res["samples"], res["gfirst"], res["ann"] = gather_sites(sites, samples, ds.first_line(), ann)
-        else:
-            res["sites"], res["samples"], res["gfirst"] = gather_sites(sites, samples, ds.first_line())
-            res["ann"] = None
+        metrics["sites_local"] = int(len(sites)); metrics["cells_local"] = int(len(cells))
+        res["sites"], res["row_off"], res["cell_sample"], res["cells"], res["ann"], res["gfirst"] = \
+            gather_sites_root(sites, row_off, cell_sample, cells, ds.first_line(), ann, gstats)
+        metrics["gather_sites_s"] = time.perf_counter() - t0
+        metrics["gather_bytes_received"] = gstats.get("bytes_received", 0)
         fa, f1 = ds.first_lines()                      # -1 outside this rank's contigs: the owner's value is the maximum
         res["first_any"] = np.maximum.reduce(gather_fixed(fa))
         res["first_from1"] = np.maximum.reduce(gather_fixed(f1))
-        # per-rank inflated bytes for the report (SURVEY.md section 8 f2: the host stage shards with the ranks)
-        infl = gather_fixed(np.array([metrics.get("inflated_record_bytes") or 0], dtype=np.int64))
+        # per-rank inflated bytes and pileup bases for the report (SURVEY.md section 8 f2: the host stage shards with the ranks)
+        infl = gather_fixed(np.array([metrics.get("inflated_record_bytes") or 0, metrics["dataset"]["n_pileup_bases"]], dtype=np.int64))
         metrics["inflated_record_bytes_per_rank"] = [int(x[0]) for x in infl]
+        metrics["pileup_bases_per_rank"] = [int(x[1]) for x in infl]
     finally:
         ds.close()
     return res
@@ -295,22 +487,27 @@ def split_view(res, split_contigs):
     """The records of one best_split_K invocation (`samtools mpileup -l best_split_K ... | snpCall`, metaSNV.py:160-176) cut
     out of a whole-run result: sites on the split's contigs at 0-based positions >= 1 (the split file's lines are
     `name 1 LEN`, parsed as BED [1, LEN): metaSNV.py:92), with the split's OWN first pileup line marked as dropped
-    (call_vC.cpp:423; lines come in BAM-header order whatever the order of the split file)."""
+    (call_vC.cpp:423; lines come in BAM-header order whatever the order of the split file).
+    Returns (sites, row_off, cell_sample, cells, ann)."""
     tid_of = {n: i for i, n in enumerate(res["names"])}
     tids = sorted(tid_of[n] for n in split_contigs if n in tid_of)          # samtools ignores names that are not in the header
-    sites, samples, ann = res["sites"], res["samples"], res["ann"]
+    sites, ann = res["sites"], res["ann"]
     keep = np.isin(sites["tid"], np.array(tids, dtype=np.int64)) & (sites["pos"] >= 1)
     s = sites[keep].copy()
     first = next(((t, int(res["first_from1"][t])) for t in tids if res["first_from1"][t] >= 0), (-1, -1))
     s["dropped"] = ((s["tid"] == first[0]) & (s["pos"] == first[1])).astype(np.uint8)
-    return s, samples[keep], (ann[keep] if ann is not None else None)
+    counts = np.diff(res["row_off"].astype(np.int64))
+    cell_keep = np.repeat(keep, counts)
+    row_off = np.concatenate([[0], np.cumsum(counts[keep])]).astype(np.uint64)
+    return s, row_off, res["cell_sample"][cell_keep], res["cells"][cell_keep], (ann[keep] if ann is not None else None)
 
 
 def sharded_call(ctx, names, lengths, seqs, add_samples, params=None, species_weight=None,
                  called_path=None, indiv_path=None, ann_path=None, fasta_path=None):
     """One SNV-calling pass over all contigs on all ranks: every rank packs only its shard's
     reads (contig mask), runs the kernels, and rank 0 receives the records and writes the files.
-    add_samples(dataset) must append every sample in all_samples order."""
+    add_samples(dataset) must append every sample in all_samples order.  Returns (sites, dense per-sample records, info, stats)
+    on rank 0 and (None, None, info, stats) elsewhere."""
     from . import core
     owner = shard_contigs(names, lengths, _world, species_weight)
     ds = core.Dataset(ctx, names, lengths, seqs, params)
@@ -318,14 +515,15 @@ def sharded_call(ctx, names, lengths, seqs, add_samples, params=None, species_we
     add_samples(ds)
     info = ds.finalize()
     stats = ds.run()
-    sites, samples = ds.results()
-    merged_ann = None
+    sites, row_off, cell_sample, cells = ds.results_cells()
+    ann = None
     if ann_path and fasta_path:                      # codon annotation runs on every rank's device, records are gathered
         ann, _ = ds.annotate(ann_path, fasta_path)
-        merged_sites, merged_samples, gfirst, merged_ann = gather_sites(sites, samples, ds.first_line(), ann)
-    else:
-        merged_sites, merged_samples, gfirst = gather_sites(sites, samples, ds.first_line())
-    if _rank == 0 and called_path:
-        core.write_calls_records(names, ds.n_samples, merged_sites, merged_samples, called_path, indiv_path, ann_path, fasta_path, merged_ann)
+    m_sites, m_off, m_cs, m_cells, m_ann, gfirst = gather_sites_root(sites, row_off, cell_sample, cells, ds.first_line(), ann)
+    dense = None
+    if _rank == 0:
+        if called_path:
+            core.write_calls_cells(names, ds.n_samples, m_sites, m_off, m_cs, m_cells, called_path, indiv_path, ann_path, fasta_path, m_ann)
+        dense = core.cells_to_dense(ds.n_samples, m_off, m_cs, m_cells)
     ds.close()
-    return merged_sites, merged_samples, info, stats
+    return m_sites, dense, info, stats

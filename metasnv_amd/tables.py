@@ -66,6 +66,20 @@ def collapse_tables(project_dir):
     dump(perc, 'Percentage_1x', os.path.join(project_dir, name + '.all_perc.tab'))
 
 
+def species_coverage(all_cov_tab):
+    """{species: coverage summed over the samples} of an all_cov.tab (createOptimumSplit.py:25-40)."""
+    cov = {}
+    with open(all_cov_tab) as f:
+        f.readline(); f.readline()
+        for line in f:
+            cells = line.rstrip().split('\t')
+            s = 0.0
+            for c in cells[1:]:
+                s += float(c)
+            cov[cells[0]] = s
+    return cov
+
+
 def species_weights(all_cov_tab, bed_header):
     """weight = genome length x summed coverage over samples (createOptimumSplit.py:18-44)."""
     length, contigs = {}, {}

@@ -1,5 +1,5 @@
 """Worker of the world_size-2 gloo test: each rank holds the called-site records of its contig shard,
-the records are gathered (counts first, then a padded all_gather) and rank 0 formats them."""
+the records are gathered to rank 0 in the cell form (parallel.gather_sites_root) and rank 0 formats them."""
 import os
 import sys
 
@@ -26,12 +26,33 @@ def main():
     local_sites = sites[keep].copy()
     if keep.any() and owner[first[0]] != rank:
         local_sites["dropped"][0] = 1                                                  # rank-local first line: must be un-dropped by the merge
-    merged_sites, merged_samples, gfirst = parallel.gather_sites(local_sites, samples[keep], mine_first)
+    row_off, cell_sample, cells = core.dense_to_cells(samples[keep])
+    gst = {}
+    m_sites, m_off, m_cs, m_cells, m_ann, gfirst = parallel.gather_sites_root(local_sites, row_off, cell_sample, cells, mine_first, stats=gst)
     cov = parallel.gather_fixed(np.full((3, 4), rank, dtype=np.uint64))
     assert [int(c[0, 0]) for c in cov] == list(range(world))
+    # coverage rows: rank r holds non-zero rows for the contigs it owns only
+    acc = np.zeros((2, len(names), core.COV_WORDS), dtype=np.uint64)
+    for t, o in enumerate(owner):
+        if o == rank:
+            acc[1, t, :] = (1 << 40) + t
+    sp = parallel.gather_coverage_root(acc, gst)
     if rank == 0:
-        core.write_calls_records(names, S, merged_sites, merged_samples, os.path.join(work, "out_pop"), os.path.join(work, "out_ind"))
-        open(os.path.join(work, "gfirst"), "w").write("%d %d %d" % (gfirst[0], gfirst[1], int(merged_sites["dropped"].sum())))
+        assert m_ann is None
+        core.write_calls_cells(names, S, m_sites, m_off, m_cs, m_cells, os.path.join(work, "out_pop"), os.path.join(work, "out_ind"))
+        # the dense form of the same records goes through the dense formatter to the same bytes
+        core.write_calls_records(names, S, m_sites, core.cells_to_dense(S, m_off, m_cs, m_cells), os.path.join(work, "out_pop_dense"), os.path.join(work, "out_ind_dense"))
+        assert open(os.path.join(work, "out_pop")).read() == open(os.path.join(work, "out_pop_dense")).read()
+        assert open(os.path.join(work, "out_ind")).read() == open(os.path.join(work, "out_ind_dense")).read()
+        open(os.path.join(work, "gfirst"), "w").write("%d %d %d" % (gfirst[0], gfirst[1], int(m_sites["dropped"].sum())))
+        want = np.zeros_like(acc)
+        for t in range(len(names)):
+            want[1, t, :] = (1 << 40) + t
+        assert (sp.dense() == want).all() and (sp[0] == 0).all()
+        # what rank 0 took in is the cells, not sites x samples
+        open(os.path.join(work, "gather_bytes"), "w").write("%d %d %d" % (gst["bytes_received"], len(m_sites), S))
+    else:
+        assert m_sites is None and sp is None
     parallel.barrier()
     parallel.finalize()
 

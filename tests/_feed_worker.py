@@ -29,13 +29,22 @@ def main():
     owner = parallel.shard_contigs(names, syn.lengths, world)
     decoded = []
 
+    fail_at = int(sys.argv[3]) if len(sys.argv) > 3 else -1
+
     def read_records(path):
+        if int(path) == fail_at:
+            raise core._lib.MsnvError(3, "sample %s: malformed BAM (test)" % path)
         decoded.append(int(path))
         return syn.sample_records(int(path))
 
     rec = Recorder()
     metrics = {}
-    stats = parallel.feed_sharded(rec, [str(i) for i in range(sp.n_samples)], owner, 1, batch, read_records=read_records, metrics=metrics)
+    try:
+        stats = parallel.feed_sharded(rec, [str(i) for i in range(sp.n_samples)], owner, 1, batch, read_records=read_records, metrics=metrics)
+    except (core._lib.MsnvError, parallel.RankError) as e:
+        # the rank that failed raises its own error, the others learn of it in the exchange: nobody waits in a collective
+        open(os.path.join(work, "error%d" % rank), "w").write("%s: %s" % (type(e).__name__, e))
+        parallel.abort(3)
     np.save(os.path.join(work, "stats%d.npy" % rank), stats)
     np.save(os.path.join(work, "decoded%d.npy" % rank), np.array(decoded, dtype=np.int64))
     np.save(os.path.join(work, "owner.npy"), np.array(owner, dtype=np.int32))

@@ -971,7 +971,7 @@ def test_bench_gpus_2_starts_two_ranks_by_itself():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "3", "--warmup", "1",
-                        "--samples", "24", "--contig-len", "60000", "--no-cpu-baseline", "--no-annotation", "--no-overlap-extra"],
+                        "--samples", "24", "--contig-len", "60000", "--no-cpu-baseline", "--no-annotation", "--no-overlap-extra", "--no-strong-extra"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])

@@ -40,6 +40,36 @@ def test_formatter_roundtrip_single_process(tmp_path):
     assert open(tmp_path / "i").read() == ind
 
 
+def test_cell_form_of_a_sparse_cohort_is_an_order_of_magnitude_smaller_than_the_dense_one(tmp_path):
+    """BASELINE configs[3] in small: 500 samples, every called position carried by three of them.  What a rank ships to rank 0
+    (gather_sites_root) is 32 + 4 B per site + 14 B per cell; the dense [sites][samples] records of round 2 were 5 KB per site.
+    Same text from either form."""
+    from metasnv_amd import parallel
+    S, n = 500, 400
+    rng = np.random.default_rng(3)
+    sites = np.zeros(n, dtype=core.SITE_DTYPE)
+    sites["tid"] = np.sort(rng.integers(0, 3, n)); sites["pos"] = np.arange(n) * 7; sites["cov"] = 30; sites["n"][:, 3] = 12
+    sites["pop_mask"] = 8; sites["refchar"] = ord("A"); sites["dropped"][0] = 1
+    dense = np.zeros((n, S), dtype=core.SAMPLE_DTYPE)
+    for i in range(n):
+        for k in rng.choice(S, 3, replace=False):
+            dense[i, k]["cov"] = 10; dense[i, k]["n"][3] = 4
+    row_off, cs, cells = core.dense_to_cells(dense)
+    assert len(cells) == 3 * n and (core.cells_to_dense(S, row_off, cs, cells) == dense).all()
+    st = {}
+    m = parallel.gather_sites_root(sites, row_off, cs, cells, (0, 0), stats=st)
+    assert st["bytes_received"] * 10 < dense.nbytes + sites.nbytes and (m[0]["pos"] == sites["pos"]).all()
+    names = ["a.1", "b.1", "c.1"]
+    core.write_calls_cells(names, S, m[0], m[1], m[2], m[3], str(tmp_path / "p1"), str(tmp_path / "i1"))
+    core.write_calls_records(names, S, sites, dense, str(tmp_path / "p2"), str(tmp_path / "i2"))
+    assert open(tmp_path / "p1").read() == open(tmp_path / "p2").read() and open(tmp_path / "p1").read().count("\n") == n - 1   # (0, 0) is the dropped first line
+    # a split is cut out of the cell form without expanding it
+    res = {"names": names, "sites": m[0], "row_off": m[1], "cell_sample": m[2], "cells": m[3], "ann": None, "first_from1": np.array([7, 0, 0])}
+    s2, r2, c2, e2, _ = parallel.split_view(res, ["b.1"])
+    keep = (sites["tid"] == 1) & (sites["pos"] >= 1)
+    assert len(s2) == keep.sum() and len(e2) == 3 * keep.sum() and (core.cells_to_dense(S, r2, c2, e2) == dense[keep]).all()
+
+
 def test_two_rank_gather_reproduces_the_full_output(tmp_path):
     names, lengths, pop, ind = _oracle_case()
     work = str(tmp_path)
@@ -102,6 +132,49 @@ def test_two_rank_decode_sharding_deals_every_record_to_its_owner(tmp_path, batc
             assert (np.load(os.path.join(work, "stats%d.npy" % k))[i] == st).all()
         assert st[0] == len(recs)
     assert nbytes[0] + nbytes[1] == total and max(nbytes) <= 0.75 * total
+
+
+def test_two_rank_decode_failure_reaches_every_rank(tmp_path):
+    """A rank whose decode fails (bad BAM) must not leave the others waiting in the all-to-all: the status word that travels
+    with the sizes makes every rank raise in the same round."""
+    work = str(tmp_path)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_feed_worker.py"), work, "1", "3"]
+    r = subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    assert r.returncode != 0
+    e = [open(os.path.join(work, "error%d" % k)).read() for k in (0, 1)]          # sample 3 is decoded by rank 1 (batch 1, round 2)
+    assert e[1].startswith("MsnvError") and "malformed BAM (test)" in e[1]
+    assert e[0].startswith("RankError") and "rank 1 reported error 3" in e[0]
+
+
+def test_two_rank_owners_follow_length_times_coverage(tmp_path):
+    """createOptimumSplit.py:46-62: species are dealt heaviest-first by genome length x coverage.  One species five times as deep
+    as five others of the same length: by length alone the ranks would hold 70 % and 30 % of the bases; with the coverage of the
+    first decode round (parallel.feed_sharded, owner=None) the heavy species gets a rank of its own and the ranks end within 20 %."""
+    work = str(tmp_path)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_lpt_worker.py"), work]
+    r = subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+    o0, o1 = np.load(os.path.join(work, "owner0.npy")), np.load(os.path.join(work, "owner1.npy"))
+    assert (o0 == o1).all() and sorted(np.bincount(o0).tolist()) == [1, 5] and np.bincount(o0)[o0[0]] == 1
+    b = [int(np.load(os.path.join(work, "bases%d.npy" % k)).sum()) for k in (0, 1)]
+    assert min(b) > 0 and max(b) / (sum(b) / 2.0) < 1.2, b
+    # by length alone: three species each, 70 / 30
+    from metasnv_amd import parallel
+    by_len = parallel.shard_contigs(["sp%d.x.c1" % k for k in range(6)], [20000] * 6, 2)
+    assert sorted(np.bincount(by_len).tolist()) == [3, 3]
+
+
+def test_shard_contigs_weights():
+    from metasnv_amd import parallel
+    names, lengths = ["a.1", "a.2", "b.1", "c.1"], [100, 100, 150, 50]
+    assert parallel.shard_contigs(names, lengths, 2) == [0, 0, 1, 1]                     # by length: a (200) | b (150) + c (50)
+    # all_cov.tab sums (the reference's own weights): c is 10x deeper than the others -> c (500) | a (200) + b (150)
+    assert parallel.shard_contigs(names, lengths, 2, species_weight={"a": 1.0, "b": 1.0, "c": 10.0}) == [1, 1, 1, 0]
+    # aligned bases per contig; a species nobody has seen yet still weighs something
+    own = parallel.shard_contigs(names, lengths, 2, contig_bases=[1000, 1000, 0, 5000])
+    assert own[3] != own[0] and own[0] == own[1]
 
 
 def test_partition_counts_qacompute_statistics_and_drops_unmapped():
