@@ -174,6 +174,49 @@ def snpcall_alone(syn, samples, n_pos=100000):
             "identical_output": bool(same)}
 
 
+def end_to_end(sp, syn, n_bases, host_threads, cpu_rate_gbases=None):
+    """BAM files -> project directory through the LAUNCHER with the reference's argv (metaSNV.py DIR all_samples REF --threads T; the
+    driver this replaces: /root/reference/metaSNV.py:224-292): every sample of the workload written as a BAM file, one process run,
+    wall seconds and what they are made of (the library's host-stage timers + the driver's own)."""
+    import subprocess
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    from metasnv_amd import core
+    with tempfile.TemporaryDirectory() as td:
+        fa = os.path.join(td, "ref.fa")
+        syn.write_fasta(fa)
+        paths = [os.path.join(td, "s%04d.insilicoRefs.unique.sorted.bam" % i) for i in range(sp.n_samples)]
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 8)) as ex:
+            list(ex.map(lambda i: core.write_bam(paths[i], syn.names, syn.lengths, syn.sample_records(i)), range(sp.n_samples)))
+        t_write = time.perf_counter() - t0
+        lst, met, proj = os.path.join(td, "all_samples"), os.path.join(td, "metrics.jsonl"), os.path.join(td, "proj")
+        open(lst, "w").write("\n".join(paths) + "\n")
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        env["MSNV_METRICS"] = met
+        t0 = time.perf_counter()
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "metaSNV.py"), proj, lst, fa, "--threads", str(host_threads), "--n_splits", "1"],
+                           env=env, capture_output=True, text=True, timeout=1800)
+        wall = time.perf_counter() - t0
+        if r.returncode != 0:
+            return {"error": (r.stdout[-500:] + r.stderr[-1500:])}
+        m = json.loads(open(met).read().strip().splitlines()[-1])
+        ht, cw = m.get("host_timers", {}), m.get("cli_wall", {})
+        called = sum(1 for _ in open(os.path.join(proj, "snpCaller", "called_SNPs")))
+        out = {"bams": sp.n_samples, "bam_bytes": sum(os.path.getsize(x) for x in paths), "write_bams_s_not_counted": t_write, "host_threads": host_threads,
+               "argv": "metaSNV.py DIR all_samples REF --threads %d --n_splits 1" % host_threads,
+               "wall_s": wall, "Gbases_per_s": n_bases / wall / 1e9, "called_SNPs_lines": called,
+               "split_wall_s": {"python_start_and_imports": max(0.0, wall - cw.get("total_s", 0.0)),
+                                "decode_and_pack": ht.get("add_bams_wall_s"), "finalize_index_and_upload": ht.get("finalize_upload_wall_s"),
+                                "kernels_coverage_ms": m["coverage"]["ms_coverage"] if "coverage" in m else None, "kernels_pileup_pass_ms": m["pileup"]["ms_total"],
+                                "coverage_files": cw.get("coverage_files_s"), "tables_and_splits": cw.get("tables_and_splits_s"), "calls_text": cw.get("calls_text_s")},
+               "thread_seconds": {"file_read": ht.get("read_s"), "inflate_host_and_crc": ht.get("inflate_host_s"), "parse_and_pack": ht.get("pack_s")},
+               "device_inflate_wall_s": ht.get("inflate_device_wall_s")}
+        if cpu_rate_gbases:
+            out["cpu_baseline_extrapolated_s"] = {"seconds": n_bases / (cpu_rate_gbases * 1e9), "what": "the oracle's mpileup + snpCall restatement, 1 thread, at its measured rate on all %d samples (qaCompute not included)" % sp.n_samples}
+        return out
+
+
 def synth_annotation(syn, path, seed=7):
     """SURVEY.md section 8d annotation shape: CDS of 300-3000 bp (90 % a multiple of 3), 50 % on the '-' strand,
     ~85 % coding density, 5 % of the genes overlapping their predecessor."""
@@ -523,8 +566,14 @@ def main():
             line["host_decode"] = decode_extra
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(sp_kwargs, min(a.cpu_samples, sp.n_samples))
+        if not a.no_annotation and world == 1 and a.workload == "testdata":
+            try:
+                ds.close(); ctx.close()                       # the launcher below is a process of its own with its own context
+                line["end_to_end"] = end_to_end(sp, syn, bases, a.host_threads or min(32, os.cpu_count() or 8), line.get("cpu_baseline", {}).get("value"))
+            except Exception as e:                             # the extra must never cost the bench line
+                line["end_to_end"] = {"error": repr(e)}
     strong = None
-    if world > 1 and not a.no_strong_extra:
+    if world > 1 and not a.no_strong_extra and mode == "weak":
         # the product's N-rank path on ONE fixed cohort (32 species x 300 kb, 160 samples carrying six each): what the weak line above
         # cannot show -- LPT imbalance, the all-to-all of the records, the gather to rank 0
         ds.close()

@@ -398,6 +398,12 @@ int  msnv_write_calls_cells(const msnv_ref_desc *ref, int32_t n_samples, const m
 /* Host-stage counters since the library was loaded: BGZF blocks that the library's own DEFLATE decoder (csrc/inflate.cpp)
  * handed to zlib (0 for well-formed files; tests). */
 int  msnv_host_stats(uint64_t *zlib_fallbacks);
+/* Host-stage timers, cumulative seconds since the library was loaded or the last reset: [0] file reads, [1] host inflate + CRC checks,
+ * [2] device inflate (wall: H2D, kernel, D2H), [3] parse + pack, [4] msnv_dataset_finalize (index build + upload, wall),
+ * [5] text formatting of called_SNPs / indiv_called (wall), [6] msnv_dataset_add_sample_bams (wall).  [0], [1] and [3] are summed over
+ * the host threads that did the work.  What the end-to-end block of bench.py splits a metaSNV.py run into; the reference's
+ * counterpart is the wall time of its process pool (metaSNV.py:55-78,196-221). */
+int  msnv_host_timers(double *seconds, int32_t n, int32_t reset);
 /* The alignment-record streams of several BAM files in one call (the N-rank driver reads a round of files and deals their records to
  * the ranks that own the contigs: msnv_records_partition): through the device BGZF inflate when ctx is given and the files bring
  * >= 64 MB (MSNV_INFLATE overrides), else one host thread per file.  records[i], n_bytes[i]: the records behind the header of

@@ -159,6 +159,7 @@ SYMBOLS = [
     ("msnv_filter_files", C.c_int, [_vp, P(C.c_char_p), C.c_int32, C.c_int32, P(FilterSpecies), C.c_int32, C.c_double, C.c_double,
                                    C.c_char_p, P(C.c_uint64), P(C.c_double)]),
     ("msnv_host_stats", C.c_int, [P(C.c_uint64)]),
+    ("msnv_host_timers", C.c_int, [P(C.c_double), C.c_int32, C.c_int32]),
     ("msnv_filter_resident", C.c_int, [_vp, C.c_int32, P(FilterSpecies), C.c_int32, C.c_double, C.c_double, C.c_char_p, C.c_char_p, C.c_char_p,
                                       P(C.c_uint64), P(C.c_double)]),
     ("msnv_bam_write_bed_header", C.c_int, [C.c_char_p, C.c_char_p]),

@@ -121,7 +121,10 @@ def resident_run(args, ctx, rank, world):
     from ONE resident dataset per rank: every BAM is inflated, packed and uploaded once in the whole job -- by one rank --
     whatever --threads / --n_splits / the number of ranks are (the reference decodes every BAM 1 + n_splits times).
     Same files in the same places; rank 0 writes them."""
+    import time
     from . import core, parallel
+    t_start = time.perf_counter()
+    wall = {"coverage_files_s": 0.0, "tables_and_splits_s": 0.0, "calls_text_s": 0.0}
     bams = read_sample_list(args.all_samples)
     cov_dir, snp_dir = os.path.join(args.project_dir, 'cov'), os.path.join(args.project_dir, 'snpCaller')
     params = core.default_params(min_coverage=args.min_pos_cov, calling_threshold=args.min_pos_snvs, cov_max=10, cov_min_mapq=1)
@@ -129,16 +132,20 @@ def resident_run(args, ctx, rank, world):
     def between_passes(res):
         if rank == 0:
             mkdir_p(cov_dir); mkdir_p(snp_dir)
+            t0 = time.perf_counter()
             if not args.use_prev_cov:
                 for i, b in enumerate(bams):
                     out = os.path.join(cov_dir, os.path.basename(b) + '.cov')
                     core.write_coverage_records(res["names"], res["lengths"], params.cov_max, res["stats"][i], res["acc"][i], out, out + '.detail')
                     print("Printing details in {}!".format(out + '.detail'))      # qaCompute.cpp:387
+                wall["coverage_files_s"] = time.perf_counter() - t0
+                t0 = time.perf_counter()
                 compute_summary(args)
             get_header(args)
             if args.n_splits > 1:
                 split_opt(args)
             shutil.copy(args.all_samples, args.project_dir + '/all_samples')
+            wall["tables_and_splits_s"] = time.perf_counter() - t0
         parallel.barrier()
 
     # contig -> rank by the reference's split rule, genome length x summed coverage (createOptimumSplit.py:46-62): with --use_prev_cov
@@ -157,9 +164,15 @@ def resident_run(args, ctx, rank, world):
         sys.stderr.write(str(e) + "\n")
         sys.stderr.write("SNV calling failed")
         parallel.abort(1)
-    _write_metrics(res["metrics"])
+    def finish():
+        res["metrics"]["host_timers"] = core.host_timers()
+        res["metrics"]["cli_wall"] = dict(wall, total_s=time.perf_counter() - t_start)
+        _write_metrics(res["metrics"])
+
     if rank != 0:
+        finish()
         return
+    t0 = time.perf_counter()
     try:
         if args.n_splits > 1:
             for split in sorted(glob.glob('{}/bestsplits/best_split_*'.format(args.project_dir))):
@@ -174,6 +187,8 @@ def resident_run(args, ctx, rank, world):
         sys.stderr.write(str(e) + "\n")
         sys.stderr.write("SNV calling failed")
         parallel.abort(1)
+    wall["calls_text_s"] = time.perf_counter() - t0
+    finish()
 
 
 def build_parser():                                             # metaSNV.py:225-247

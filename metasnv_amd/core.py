@@ -395,6 +395,16 @@ def call_from_mpileup(ctx, called_path, indiv_path=None, text=None, mpileup_path
             "text_bytes": int(st[5]), "base_chars": int(st[6])}
 
 
+HOST_TIMERS = ["read_s", "inflate_host_s", "inflate_device_wall_s", "pack_s", "finalize_upload_wall_s", "format_wall_s", "add_bams_wall_s"]
+
+
+def host_timers(reset=False):
+    """Cumulative host-stage seconds (msnv_host_timers): thread-seconds for read / host inflate / pack, wall for the others."""
+    a = (C.c_double * len(HOST_TIMERS))()
+    check(lib.msnv_host_timers(a, len(HOST_TIMERS), 1 if reset else 0))
+    return dict(zip(HOST_TIMERS, [float(x) for x in a]))
+
+
 def read_bam_records(paths, ctx=None, threads=0):
     """Record streams (uint8 arrays) of several BAM files in one call: BGZF blocks inflated on the device when ctx is given and the
     files are large enough (msnv_bam_records_many), else one host thread per file."""

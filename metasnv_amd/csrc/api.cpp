@@ -271,6 +271,7 @@ static int bgzf_read_files_device(msnv_ctx *ctx, const char *const *paths, int n
                 const char *path = paths[f0 + k];
                 int rc = MSNV_OK;
                 try {
+                    HostTimerScope ts(HT_READ);
                     uint8_t *dst = in_stage + in_off[(size_t)k];
                     const uint64_t sz = fsize[(size_t)(f0 + k)];
                     FILE *f = fopen(path, "rb");
@@ -306,15 +307,29 @@ static int bgzf_read_files_device(msnv_ctx *ctx, const char *const *paths, int n
         }
         if (int rc = dev_inflate_staging(ctx, ib, ob, &in_stage, &out)) return rc;       // (the input staging does not move: it only grows when ib does)
         std::vector<uint32_t> status;
-        if (int rc = dev_inflate(ctx, ib, list, ob, status, &ms)) return rc;
-        // Spot check: every 64th block's output against the CRC-32 of its BGZF trailer (the device decoder is young; a block that does not
-        // check is handed to the host decoder like one the device refused).  MSNV_INFLATE_CHECK=n: every n-th block (1 = all, 0 = none).
-        const uint32_t check_every = [] { const char *e = getenv("MSNV_INFLATE_CHECK"); return e ? (uint32_t)std::max(0, atoi(e)) : 64u; }();   // (per call: tests switch it)
-        if (check_every) for (size_t e = (size_t)(f0 % (int)check_every); e < list.size(); e += check_every) {
-            if (status[e]) continue;
-            const uint8_t *trailer = in_stage + list[e].in_off + list[e].in_size;
-            const uint32_t want = (uint32_t)trailer[0] | (uint32_t)trailer[1] << 8 | (uint32_t)trailer[2] << 16 | (uint32_t)trailer[3] << 24;
-            if (bgzf_crc32(out + list[e].out_off, list[e].out_size) != want) status[e] = 2u;
+        { HostTimerScope ts(HT_INFLATE_DEVICE_WALL); if (int rc = dev_inflate(ctx, ib, list, ob, status, &ms)) return rc; }
+        // Every block's output is checked against the CRC-32 of its BGZF trailer, as htslib does for the reference's tools (a block that
+        // does not check is handed to the host decoder like one the device refused); the host threads share the blocks.
+        // MSNV_INFLATE_CHECK=n: every n-th block only (0 = none: benchmarks).
+        const uint32_t check_every = [] { const char *e = getenv("MSNV_INFLATE_CHECK"); return e ? (uint32_t)std::max(0, atoi(e)) : 1u; }();   // (per call: tests switch it)
+        if (check_every) {
+            std::atomic<size_t> nxt{0};
+            auto checker = [&]() {
+                HostTimerScope ts(HT_INFLATE_HOST);
+                for (;;) {
+                    const size_t e0 = nxt.fetch_add(64);
+                    if (e0 >= list.size()) break;
+                    for (size_t e = e0; e < std::min(list.size(), e0 + 64); ++e) {
+                        if (status[e] || (e + (size_t)f0) % check_every) continue;
+                        const uint8_t *trailer = in_stage + list[e].in_off + list[e].in_size;
+                        const uint32_t want = (uint32_t)trailer[0] | (uint32_t)trailer[1] << 8 | (uint32_t)trailer[2] << 16 | (uint32_t)trailer[3] << 24;
+                        if (bgzf_crc32(out + list[e].out_off, list[e].out_size) != want) status[e] = 2u;
+                    }
+                }
+            };
+            std::vector<std::thread> th;
+            for (int t = 0; t < std::max(1, std::min<int>(threads, (int)(list.size() / 64) + 1)); ++t) th.emplace_back(checker);
+            for (auto &t : th) t.join();
         }
         for (size_t e = 0; e < list.size(); ++e) {
             if (!status[e]) continue;
@@ -436,6 +451,7 @@ extern "C" int msnv_bam_records_many(msnv_ctx *ctx, const char *const *bam_paths
 
 extern "C" int msnv_dataset_add_sample_bams(msnv_dataset *ds, const char *const *bam_paths, int32_t n, int32_t host_threads) {
     clear_error();
+    HostTimerScope ts_all(HT_ADD_WALL);
     if (!ds || (n && !bam_paths)) return fail(MSNV_EINVAL, "msnv_dataset_add_sample_bams: NULL argument");
     if (ds->finalized) return fail(MSNV_EINVAL, "dataset is already finalized");
     int nthreads = host_threads > 0 ? host_threads : (int)std::max(1u, std::thread::hardware_concurrency());
@@ -545,6 +561,7 @@ extern "C" int msnv_dataset_finalize(msnv_dataset *ds) {
     if (ds->finalized) return fail(MSNV_EINVAL, "dataset is already finalized");
     if (!ds->ctx) return fail(MSNV_ENODEV, "this dataset was created without a device context: only the host-stage entry points work on it (no CPU fallback)");
     if (int rc = dev_set_device(ds->ctx->device)) return rc;
+    HostTimerScope ts(HT_UPLOAD_WALL);
     try { return finalize_dataset(*ds); }
     catch (const std::exception &e) { return fail(MSNV_ENOMEM, "building the device dataset failed: %s", e.what()); }
 }

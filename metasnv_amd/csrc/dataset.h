@@ -26,11 +26,21 @@ constexpr uint32_t TILE = 2048;          // reference positions per tile (LDS bi
 // meta: bits 0-15 n_cigar | 16-23 mapq | 24 pileup_ok | 25 cov_ok | 26 fast
 constexpr uint32_t META_PILEUP_OK = 1u << 24;
 constexpr uint32_t META_COV_OK    = 1u << 25;
+// Piece alignment in the seq column (the quality column is aligned to twice that): 2 bytes = 4 bases, so a 100-base piece carries no
+// padding at all (8-byte starts: 6 + 12 B per piece = 0.27 GB of the benchmark launch's 3.04 GB).  The wide loads are then not
+// naturally aligned; same-box A/B, pileup kernel (profiles/r03b_ab.txt): 8 B 0.573 ms, 4 B 0.548, 2 B 0.547.
+// MSNV_SEQ_ALIGN_LOG2 (build-time, profiles/build_variant.sh) sets 4- or 8-byte piece starts.
+#ifndef MSNV_SEQ_ALIGN_LOG2
+#define MSNV_SEQ_ALIGN_LOG2 1
+#endif
+constexpr uint32_t SEQ_ALIGN_LOG2 = MSNV_SEQ_ALIGN_LOG2;
+constexpr uint32_t SEQ_ALIGN = 1u << SEQ_ALIGN_LOG2;
+static_assert(SEQ_ALIGN_LOG2 >= 1 && SEQ_ALIGN_LOG2 <= 3, "piece starts on 2, 4 or 8 bytes of the seq column");
 constexpr uint32_t SEG_MAX = 128;            // bases per segment piece = 8 lanes x 16 bases
 constexpr uint32_t NARROW_MAX_DEPTH = 255;   // (tile, sample) pairs below this depth use byte-wide LDS bins
 
 struct ReadHdr { uint32_t gpos, seqoff, cig, meta; };
-struct PieceHdr { uint32_t w0, seqoff8; };
+struct PieceHdr { uint32_t w0, seqoff8; };      // seqoff8: seq byte offset / SEQ_ALIGN
 // Dense layout: the pieces of one (sample, tile) pair are packed back to back (each starts on an even base) into a
 // stream of 32-base blocks; a block holds the tail / middle of one piece (segment A, bits [0, nA)) and at most the
 // head of the next one (segment B, bits [sB, 32), sB = nA rounded up to even, always running to the block end).

@@ -104,6 +104,7 @@ inline void put_u32(std::string &o, uint32_t v) {
 // index to the annotation's gene name column.
 int write_calls_text(msnv_dataset &ds, const char *called_path, const char *indiv_path,
                      const msnv_site_ann *ann, const std::vector<std::string> *gene_names) {
+    HostTimerScope ts(HT_FORMAT_WALL);
     FILE *fp = fopen(called_path, "wt");
     if (!fp) return fail(MSNV_EIO, "Cannot open %s", called_path);
     FILE *fi = indiv_path ? fopen(indiv_path, "wt") : nullptr;

@@ -9,6 +9,7 @@
 #include <zlib.h>
 
 #include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstdlib>
 #include <cstring>
@@ -42,6 +43,19 @@ void clear_error() { t_err[0] = 0; }
 extern "C" const char *msnv_last_error(void) { return msnv::t_err; }
 namespace msnv { uint64_t inflate_zlib_fallbacks(); }
 extern "C" int msnv_host_stats(uint64_t *zlib_fallbacks) { if (zlib_fallbacks) *zlib_fallbacks = msnv::inflate_zlib_fallbacks(); return MSNV_OK; }
+
+namespace msnv {
+static std::atomic<uint64_t> g_timer_us[HT_N];
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+void host_timer_add(int which, double seconds) { if (which >= 0 && which < HT_N && seconds > 0) g_timer_us[which].fetch_add((uint64_t)(seconds * 1e6)); }
+HostTimerScope::HostTimerScope(int w) : which(w), t0(now_s()) {}
+HostTimerScope::~HostTimerScope() { host_timer_add(which, now_s() - t0); }
+}  // namespace msnv
+extern "C" int msnv_host_timers(double *seconds, int32_t n, int32_t reset) {
+    for (int i = 0; i < n && seconds; ++i) seconds[i] = i < msnv::HT_N ? (double)msnv::g_timer_us[i].load() * 1e-6 : 0.0;
+    if (reset) for (int i = 0; i < msnv::HT_N; ++i) msnv::g_timer_us[i].store(0);
+    return MSNV_OK;
+}
 
 namespace msnv {
 
@@ -138,7 +152,7 @@ int bgzf_index_bytes(const uint8_t *data, size_t n, const char *path, std::vecto
 
 int bgzf_read_all(const char *path, ByteBuf &out, int threads) {
     ByteBuf inb; size_t n_in = 0;
-    if (int rc = read_file(path, inb, n_in)) return rc;
+    { HostTimerScope ts(HT_READ); if (int rc = read_file(path, inb, n_in)) return rc; }
     const ConstBytes in{inb.data(), n_in};
     std::vector<BlockRef> blocks;
     uint64_t total = 0;
@@ -146,14 +160,21 @@ int bgzf_read_all(const char *path, ByteBuf &out, int threads) {
     if (!out.alloc(total)) return fail(MSNV_ENOMEM, "%s: out of memory for %llu inflated bytes", path, (unsigned long long)total);
     std::atomic<size_t> next{0};
     std::atomic<bool> bad{false};
+    // every block's output is checked against the CRC-32 of its BGZF trailer, as htslib does (MSNV_INFLATE_CHECK=0 skips it: benchmarks)
+    const bool check_crc = [] { const char *e = getenv("MSNV_INFLATE_CHECK"); return !(e && e[0] == '0' && e[1] == 0); }();
     auto worker = [&]() {
+        HostTimerScope ts(HT_INFLATE_HOST);
         for (;;) {
             size_t i = next.fetch_add(16);
             if (i >= blocks.size()) break;
             size_t e = std::min(blocks.size(), i + 16);
             for (; i < e; ++i) {
                 const BlockRef &b = blocks[i];
-                if (!inflate_block(in.data() + b.in_off, b.in_size, out.data() + b.out_off, b.out_size)) bad = true;
+                if (!inflate_block(in.data() + b.in_off, b.in_size, out.data() + b.out_off, b.out_size)) { bad = true; continue; }
+                if (check_crc && b.out_size) {
+                    const uint8_t *t = in.data() + b.in_off + b.in_size;
+                    if (bgzf_crc32(out.data() + b.out_off, b.out_size) != ld_u32(t)) bad = true;
+                }
             }
         }
     };
@@ -163,7 +184,7 @@ int bgzf_read_all(const char *path, ByteBuf &out, int threads) {
         for (int t = 0; t < threads; ++t) th.emplace_back(worker);
         for (auto &t : th) t.join();
     }
-    if (bad) return fail(MSNV_EFORMAT, "%s: BGZF inflate failed", path);
+    if (bad) return fail(MSNV_EFORMAT, "%s: BGZF inflate failed (malformed DEFLATE stream or CRC-32 mismatch)", path);
     return MSNV_OK;
 }
 

@@ -376,6 +376,7 @@ struct NarrowLds {
     ChunkDesc desc[MAX_CHUNKS_PER_ITEM];
     uint32_t carry[N_NT / 64 + 1];             // depth at the left edge of each wavefront's quarter of the tile ([4]: scratch for pieces that end at the tile end)
     uint32_t evn, ev_base;
+    uint32_t emask[SEQ_ALIGN_LOG2 < 3 ? 33 : 1];   // pieces closer than 16 bases apart: mismatch flags of a lane's first n bases (narrow_classify32's flag order)
 };
 
 // Per-sample pass of the narrow kernel: prefix sum of start/end -> depth, minus the not-counted bases;
@@ -561,6 +562,8 @@ __device__ __forceinline__ void narrow_classify32(NarrowLds &L, const uint4 qa, 
     }
     // mismatch flags of the four words in ONE register: bit 4 j + k <-> base 8 k + j (flag bits 4 j + 3 shifted down by 3 - k)
     uint32_t E = (e[0] >> 3) | (e[1] >> 2) | (e[2] >> 1) | e[3];
+    // (pieces that start on 2 or 4 bytes: what follows the lane's last base inside its 16 is the next piece, not reference-filled padding)
+    if constexpr (SEQ_ALIGN_LOG2 < 3) E &= L.emask[min(max(vhi, 0), 32)];
     while (E) {                                                      // mismatches (rare)
         const uint32_t b = (uint32_t)__builtin_ctz(E);
         E &= E - 1u;
@@ -646,6 +649,13 @@ __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a, NarrowL
     for (int i = tid; i < (int)TILE; i += N_NT) L.al[i] = 0;
     if (tid == 0) L.evn = 0;
     if (tid < N_NT / 64 + 1) L.carry[tid] = 0;
+    if constexpr (SEQ_ALIGN_LOG2 < 3) {
+        if (tid < 33) {                                         // flag bit 4 j + k <-> base 8 k + j: the flags of bases 0 .. tid - 1
+            uint32_t m = 0;
+            for (uint32_t b = 0; b < (uint32_t)tid; ++b) m |= 1u << (4u * (b & 7u) + (b >> 3));
+            L.emask[tid] = m;
+        }
+    }
     uint32_t tc[N_PPT / 2] = {0u, 0u, 0u, 0u};                  // coverage totals of my 8 positions over the item's samples (u16 pairs)
     bool dirty = false;                                         // some pass of this item added to the allele totals of my 8 positions
 
@@ -679,9 +689,10 @@ __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a, NarrowL
 #pragma unroll
         for (int i = 0; i < N32_ROUNDS; ++i) {
             const uint2 h = L.hdr[c & 1u][grp + i * N32_GROUPS];     // all zero for empty slots
-            const uint32_t len = (h.x >> 11) & 0xffu;                // (bits 19+: index of the piece's pair inside a merged group, for the gather)
+            const uint32_t len = (h.x >> 11) & 0xffu;                // (bits 19-26: index of the piece's pair inside a merged group, for the gather)
             const uint32_t s = h.x & (TILE - 1u);
-            const uint64_t so = (uint64_t)h.y << 3;                  // seq byte offset of the piece inside the sample
+            // seq byte offset of the piece inside the sample; a merged group's pieces come from all over the column: their ABSOLUTE offset / SEQ_ALIGN is 37 bits wide (bits 27+ of the first word)
+            const uint64_t so = (MERGED ? ((uint64_t)(h.x >> 27) << 32 | h.y) : (uint64_t)h.y) << SEQ_ALIGN_LOG2;
             vh[i] = min(max((int)len - b0, 0), 32);
             qa[i] = any_uint4(); qb[i] = any_uint4(); sq[i] = any_uint4();   // never observed: vh masks every use
             if (vh[i] > 0) {                                         // lanes past the end of the piece load nothing
@@ -1589,8 +1600,8 @@ __device__ __forceinline__ void gather_merged_block(const TailArgs &a, const uin
             __syncthreads();
             for (uint32_t pi = tid; pi < n_pieces; pi += blockDim.x) {
                 const PieceHdr h = pi == tid ? h_first : a.hdr8m[g.hdr_base + pi];
-                const uint32_t s = h.w0 & (TILE - 1u), len = (h.w0 >> 11) & 0xffu, pidx = h.w0 >> 19;
-                const uint64_t so = (uint64_t)h.seqoff8 << 3;
+                const uint32_t s = h.w0 & (TILE - 1u), len = (h.w0 >> 11) & 0xffu, pidx = (h.w0 >> 19) & 0xffu;
+                const uint64_t so = ((uint64_t)(h.w0 >> 27) << 32 | h.seqoff8) << SEQ_ALIGN_LOG2;
                 for (uint32_t wd = s >> 6; wd <= (s + len - 1u) >> 6 && wd < TILE / 64; ++wd) {
                     unsigned long long bits = s_bits[wd];
                     if (wd == (s >> 6)) bits &= ~0ull << (s & 63u);

@@ -17,6 +17,17 @@ int  fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 int  fail_quiet(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));   // sets the message, prints nothing
 void clear_error();
 
+// ---------------------------------------------------------------------------------- host-stage timers (msnv.h: msnv_host_timers)
+// Cumulative microseconds since the library was loaded (or the last reset), summed over the host threads that did the work:
+// what the wall time of BAM files -> resident dataset is made of.
+enum HostTimer { HT_READ = 0, HT_INFLATE_HOST, HT_INFLATE_DEVICE_WALL, HT_PACK, HT_UPLOAD_WALL, HT_FORMAT_WALL, HT_ADD_WALL, HT_N };
+void host_timer_add(int which, double seconds);
+struct HostTimerScope {
+    int which; double t0;
+    explicit HostTimerScope(int w);
+    ~HostTimerScope();
+};
+
 // ---------------------------------------------------------------------------------- host IO
 struct BamHeader {
     std::string              text;

@@ -20,7 +20,7 @@ namespace msnv {
 // Piece alignment in the seq column (bytes; the qual column is twice that).  Measured on one box, pileup kernel:
 // 16 -> 0.725 ms, 8 -> 0.665, 4 -> 0.664, 2 -> 0.651, 1 -> 0.672: padding is HBM traffic, misalignment costs the
 // vector-memory path about as much as it saves below 8.  The compact headers store seq offsets in 8-byte units.
-constexpr uint32_t seq_align = 8;
+constexpr uint32_t seq_align = SEQ_ALIGN;
 
 // Layout of the narrow path: padded per-piece columns (msnv_pileup_tiles_narrow32) or the dense block stream
 // (msnv_pileup_tiles_dense: no alignment padding, every lane owns 32 real bases, but up to two segments per block).
@@ -509,6 +509,7 @@ int pileup_qualities(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_byte
 
 // Packs one sample.  `ds` supplies contig selection, BED and parameters.
 int pack_sample(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, SampleCols &sc) {
+    HostTimerScope ts(HT_PACK);
     const int n_contigs = (int)ds.names.size();
     std::vector<KeptRead> kept;
     std::vector<uint8_t> patched;                 // copy of the record stream with edited qualities (empty: nothing was edited)
@@ -780,7 +781,6 @@ int finalize_dataset(msnv_dataset &ds) {
             const uint64_t gs = (uint64_t)ds.tile_base[c] * TILE + sc.hdr[i].gpos;
             sc.hdr[i].gpos = (uint32_t)gs;
             const uint32_t t = (uint32_t)(gs / TILE);
-            static_assert(seq_align == 8, "msnv_pileup_tiles_narrow32 masks mismatch flags per 16 bases = one 8-byte alignment unit");
             if (!dense) {
                 // The alignment padding behind a piece (up to the next 16 bases) reads as the reference the kernel compares
                 // it with (N beyond the tile): msnv_pileup_tiles_narrow32 then masks mismatch flags per 16 bases, not per base.
@@ -831,7 +831,7 @@ int finalize_dataset(msnv_dataset &ds) {
         // MSNV_SHALLOW_PIECES: number of pieces up to which a pair counts as shallow (default 48 = 3/8 of a chunk; 0 = never
         // merge); its depth bound must leave room for at least three pairs in a group, and a tile needs two such pairs.
         const uint32_t shallow_pieces = [] { const char *e = getenv("MSNV_SHALLOW_PIECES"); const int v = e ? atoi(e) : 48; return (uint32_t)std::max(0, v); }();   // read per dataset (tests switch it)
-        const bool can_merge = !dense && shallow_pieces > 0 && sbase[S] < (32ull << 30);   // merged headers hold absolute seq offsets / 8 in 32 bits
+        const bool can_merge = !dense && shallow_pieces > 0 && sbase[S] < ((uint64_t)SEQ_ALIGN << 37);   // merged headers hold absolute seq offsets / SEQ_ALIGN in 37 bits
         auto is_shallow = [&](const TilePair &p) { return p.read_hi - p.read_lo <= shallow_pieces && p.max_depth <= MERGE_MAX_DEPTH / 3 && !p.pad; };
         // ... and only when the shallow pairs are a real share of the dataset (>= 3 % of its pieces): a few of them -- the
         // partial last tile of every contig of the benchmark shape -- are not worth the second code path in the tail
@@ -1110,8 +1110,10 @@ int finalize_dataset(msnv_dataset &ds) {
                 for (uint32_t k = g.pair_lo; k < g.pair_hi; ++k) {
                     const TilePair &p = pairs[k];
                     const SampleCols &sc = ds.samples[p.sample];
-                    for (uint32_t r = p.read_lo; r < p.read_hi; ++r)
-                        hm.push_back(PieceHdr{(sc.hdr[r].gpos % TILE) | sc.hdr[r].cig << 11 | (k - g.pair_lo) << 19, (uint32_t)((sbase[p.sample] + sc.hdr[r].seqoff) >> 3)});
+                    for (uint32_t r = p.read_lo; r < p.read_hi; ++r) {
+                        const uint64_t so = (sbase[p.sample] + sc.hdr[r].seqoff) >> SEQ_ALIGN_LOG2;          // 37 bits: bits 32-36 ride in bits 27-31 of the first word
+                        hm.push_back(PieceHdr{(sc.hdr[r].gpos % TILE) | sc.hdr[r].cig << 11 | (k - g.pair_lo) << 19 | (uint32_t)(so >> 32) << 27, (uint32_t)so});
+                    }
                 }
                 const uint64_t n_h = hm.size() - h0;
                 mgroups.push_back(MergedGroupDev{h0, w.tile, g.pair_lo, g.pair_hi - g.pair_lo, (uint32_t)n_h});
@@ -1156,7 +1158,7 @@ int finalize_dataset(msnv_dataset &ds) {
             std::vector<uint32_t>().swap(sc.blk);
         } else {   // compact tile-local headers of the narrow kernel: {start in tile | length << 11, seq offset / 8}
             std::vector<PieceHdr> h8(sc.hdr.size());
-            for (size_t i = 0; i < sc.hdr.size(); ++i) h8[i] = PieceHdr{(sc.hdr[i].gpos % TILE) | sc.hdr[i].cig << 11, sc.hdr[i].seqoff >> 3};
+            for (size_t i = 0; i < sc.hdr.size(); ++i) h8[i] = PieceHdr{(sc.hdr[i].gpos % TILE) | sc.hdr[i].cig << 11, sc.hdr[i].seqoff >> SEQ_ALIGN_LOG2};
             if (int rc = dev_upload(d->hdr8 + rbase[s], h8.data(), h8.size() * sizeof(PieceHdr))) return rc;
         }
         if (int rc = dev_upload(d->seq + sbase[s], sc.seq.data(), sc.seq.size())) return rc;

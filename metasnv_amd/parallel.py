@@ -231,6 +231,7 @@ def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=Non
         read_many = lambda paths: core.read_bam_records(paths, ctx=getattr(ds, "ctx", None), threads=max(1, len(paths)))
     stats = np.zeros((n, len(core.STATS_FIELDS)), dtype=np.uint32)
     inflated = 0
+    batch = max(1, min(batch, -(-n // _world)))          # fewer samples than world x batch: every rank still decodes its share
     for base, plan_round in deal_samples(n, batch):
         mine = [i for i, r in plan_round if r == _rank]
         # decode my samples of this round; a failure here is carried to every rank by the exchange (status word)

@@ -27,3 +27,17 @@ def _build_oracle():
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """One block in every pytest log (the -q one the driver keeps as pytest.log too): which of the reference's own tools and
+    libraries this box has -- what pins the oracle (tests/test_ref_builds.py) or leaves it "parity unpinned"."""
+    try:
+        import reftools
+        r = reftools.report()
+    except Exception as e:                                   # never cost a test run
+        r = {"error": repr(e)}
+    terminalreporter.write_line("")
+    terminalreporter.write_line("reference tools on this box (tests/reftools.py): " + ", ".join("%s=%s" % (k, v) for k, v in r.items()))
+    pinned = [k for k in ("samtools", "oracle_ref_snpCall", "oracle_ref_qaCompute") if r.get(k)]
+    terminalreporter.write_line("oracle pinned against: " + (", ".join(pinned) if pinned else "nothing here -- the tests of tests/test_ref_builds.py skip (parity unpinned)"))

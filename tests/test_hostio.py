@@ -77,3 +77,30 @@ def test_synth_is_deterministic_and_sorted():
     assert keys == sorted(keys) and len(keys) > 50
     for r in bt.iter_records(r0):
         assert sum(n for n, op in r["cigar"] if op in (0, 1, 4, 7, 8)) == len(r["seq"])
+
+
+def test_bgzf_crc_of_every_block_is_checked(tmp_path):
+    """htslib verifies the CRC-32 of every BGZF block it inflates (what both reference tools read their BAMs through); so does the
+    host decoder: a block whose trailer CRC does not match its inflated bytes fails the read, MSNV_INFLATE_CHECK=0 opts out."""
+    import os
+    import struct
+    from bamtools import make_record, records
+    from metasnv_amd._lib import MsnvError
+    p = str(tmp_path / "a.bam")
+    core.write_bam(p, ["c1"], [5000], records(*[make_record(0, 10 * i, "50M", "ACGT" * 12 + "AC") for i in range(400)]))
+    assert core.read_bam(p)["records"].size > 0
+    raw = bytearray(open(p, "rb").read())
+    bsize = struct.unpack_from("<H", raw, 16)[0] + 1           # first block: header ... payload, CRC32, ISIZE
+    raw[bsize - 8] ^= 0x5a                                      # a bit of the stored CRC
+    bad = str(tmp_path / "bad.bam")
+    open(bad, "wb").write(bytes(raw))
+    try:
+        core.read_bam(bad)
+        raise AssertionError("a CRC mismatch must fail the read")
+    except MsnvError as e:
+        assert e.code == 3 and "CRC" in str(e)
+    os.environ["MSNV_INFLATE_CHECK"] = "0"
+    try:
+        assert core.read_bam(bad)["records"].size > 0
+    finally:
+        del os.environ["MSNV_INFLATE_CHECK"]

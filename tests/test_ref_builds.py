@@ -20,7 +20,8 @@ from parity import synth_case
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_SNPCALL = os.path.join(ROOT, "oracle", "_ref", "snpCall")
 REF_QACOMPUTE = os.path.join(ROOT, "oracle", "_ref", "qaCompute")
-SAMTOOLS = os.environ.get("MSNV_SAMTOOLS") or shutil.which("samtools")
+import reftools
+SAMTOOLS = reftools.find_samtools()
 
 need_snpcall = pytest.mark.skipif(not os.path.exists(REF_SNPCALL), reason="oracle/_ref/snpCall not built (needs real boost: make -C oracle ref BOOST_ROOT=...)")
 need_qacompute = pytest.mark.skipif(not os.path.exists(REF_QACOMPUTE), reason="oracle/_ref/qaCompute not built (needs htslib: make -C oracle ref)")
