@@ -195,16 +195,17 @@ def end_to_end(sp, syn, n_bases, host_threads, cpu_rate_gbases=None):
         env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
         env["MSNV_METRICS"] = met
         t0 = time.perf_counter()
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "metaSNV.py"), proj, lst, fa, "--threads", str(host_threads), "--n_splits", "1"],
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "metaSNV.py"), proj, lst, fa, "--threads", str(host_threads)],
                            env=env, capture_output=True, text=True, timeout=1800)
         wall = time.perf_counter() - t0
         if r.returncode != 0:
             return {"error": (r.stdout[-500:] + r.stderr[-1500:])}
         m = json.loads(open(met).read().strip().splitlines()[-1])
         ht, cw = m.get("host_timers", {}), m.get("cli_wall", {})
-        called = sum(1 for _ in open(os.path.join(proj, "snpCaller", "called_SNPs")))
+        import glob
+        called = sum(sum(1 for _ in open(f)) for f in glob.glob(os.path.join(proj, "snpCaller", "called_SNPs*")))   # (--threads T makes T splits: metaSNV.py:275-276)
         out = {"bams": sp.n_samples, "bam_bytes": sum(os.path.getsize(x) for x in paths), "write_bams_s_not_counted": t_write, "host_threads": host_threads,
-               "argv": "metaSNV.py DIR all_samples REF --threads %d --n_splits 1" % host_threads,
+               "argv": "metaSNV.py DIR all_samples REF --threads %d (= %d best_split outputs, metaSNV.py:275-276)" % (host_threads, host_threads),
                "wall_s": wall, "Gbases_per_s": n_bases / wall / 1e9, "called_SNPs_lines": called,
                "split_wall_s": {"python_start_and_imports": max(0.0, wall - cw.get("total_s", 0.0)),
                                 "decode_and_pack": ht.get("add_bams_wall_s"), "finalize_index_and_upload": ht.get("finalize_upload_wall_s"),

@@ -227,6 +227,7 @@ namespace msnv {
 struct InfBlock { unsigned long long in_off, out_off; uint32_t in_size, out_size; };
 int dev_inflate_staging(msnv_ctx *ctx, uint64_t in_bytes, uint64_t out_bytes, uint8_t **in, uint8_t **out);
 void dev_inflate_release(msnv_ctx *ctx);
+void dev_inflate_release_device(msnv_ctx *ctx);
 int dev_inflate(msnv_ctx *ctx, uint64_t comp_bytes, const std::vector<InfBlock> &blocks, uint64_t out_bytes, std::vector<uint32_t> &status, double *ms_kernel);
 }
 
@@ -258,7 +259,18 @@ static int bgzf_read_files_device(msnv_ctx *ctx, const char *const *paths, int n
         std::vector<uint64_t> in_off;
         while (f1 < n && (f1 == f0 || ib + fsize[(size_t)f1] <= batch_in)) { in_off.push_back(ib); ib += (fsize[(size_t)f1] + 31) & ~15ull; ++f1; }   // 16 bytes of slack behind every file
         uint8_t *in_stage = nullptr, *out = nullptr;
-        if (int rc = dev_inflate_staging(ctx, ib, 0, &in_stage, &out)) return rc;
+        // A batch whose staging cannot be had (pinned host memory or HBM: MSNV_ENOMEM) or whose launch fails is inflated by the host
+        // decoder instead -- the call must not fail where the host path would have worked (a multi-GB BAM sizes the staging to itself)
+        bool host_batch = false;
+        ByteBuf host_in, host_out;
+        if (int rc = dev_inflate_staging(ctx, ib, 0, &in_stage, &out)) {
+            if (rc != MSNV_ENOMEM) return rc;
+            fprintf(stderr, "libmsnv: no staging for the device inflate (%s); this batch is inflated on the host\n", msnv_last_error());
+            clear_error();
+            host_batch = true;
+            if (!host_in.alloc(ib + 64)) return fail(MSNV_ENOMEM, "out of memory for %llu compressed bytes", (unsigned long long)ib);
+            in_stage = host_in.data();
+        }
         const int nf = f1 - f0;
         std::vector<std::vector<BgzfBlock>> blocks((size_t)nf);
         std::vector<uint64_t> total((size_t)nf, 0);
@@ -305,9 +317,30 @@ static int bgzf_read_files_device(msnv_ctx *ctx, const char *const *paths, int n
             ob += (total[(size_t)k] + 15) & ~15ull;
             n_bytes += total[(size_t)k];
         }
-        if (int rc = dev_inflate_staging(ctx, ib, ob, &in_stage, &out)) return rc;       // (the input staging does not move: it only grows when ib does)
+        if (!host_batch) {
+            uint8_t *same_in = nullptr;
+            if (int rc = dev_inflate_staging(ctx, ib, ob, &same_in, &out)) {      // (the input staging does not move: it only grows when ib does)
+                if (rc != MSNV_ENOMEM) return rc;
+                fprintf(stderr, "libmsnv: no staging for the device inflate (%s); this batch is inflated on the host\n", msnv_last_error());
+                clear_error();
+                host_batch = true;
+            }
+        }
+        if (host_batch) {
+            if (!host_out.alloc(ob + 64)) return fail(MSNV_ENOMEM, "out of memory for %llu inflated bytes", (unsigned long long)ob);
+            out = host_out.data();
+        }
         std::vector<uint32_t> status;
-        { HostTimerScope ts(HT_INFLATE_DEVICE_WALL); if (int rc = dev_inflate(ctx, ib, list, ob, status, &ms)) return rc; }
+        if (!host_batch) {
+            HostTimerScope ts(HT_INFLATE_DEVICE_WALL);
+            if (int rc = dev_inflate(ctx, ib, list, ob, status, &ms)) {
+                if (rc != MSNV_ENOMEM && rc != MSNV_EHIP) return rc;
+                fprintf(stderr, "libmsnv: the device inflate failed (%s); this batch is inflated on the host\n", msnv_last_error());
+                clear_error();
+                host_batch = true;
+            }
+        }
+        if (host_batch) status.assign(list.size(), 1u);
         // Every block's output is checked against the CRC-32 of its BGZF trailer, as htslib does for the reference's tools (a block that
         // does not check is handed to the host decoder like one the device refused); the host threads share the blocks.
         // MSNV_INFLATE_CHECK=n: every n-th block only (0 = none: benchmarks).
@@ -331,17 +364,44 @@ static int bgzf_read_files_device(msnv_ctx *ctx, const char *const *paths, int n
             for (int t = 0; t < std::max(1, std::min<int>(threads, (int)(list.size() / 64) + 1)); ++t) th.emplace_back(checker);
             for (auto &t : th) t.join();
         }
-        for (size_t e = 0; e < list.size(); ++e) {
-            if (!status[e]) continue;
-            ++n_host;
-            if (!bgzf_inflate_block_host(in_stage + list[e].in_off, list[e].in_size, out + list[e].out_off, list[e].out_size))
-                return fail(MSNV_EFORMAT, "%s: BGZF inflate failed", paths[f0 + origin[e]]);
+        {   // blocks the device refused (or all of them, for a host batch): the host decoder, shared by the host threads
+            std::atomic<size_t> nxt{0};
+            std::atomic<int> bad{-1};
+            std::atomic<uint64_t> done{0};
+            auto redo = [&]() {
+                HostTimerScope ts(HT_INFLATE_HOST);
+                for (;;) {
+                    const size_t e0 = nxt.fetch_add(16);
+                    if (e0 >= list.size() || bad.load() >= 0) break;
+                    for (size_t e = e0; e < std::min(list.size(), e0 + 16); ++e) {
+                        if (!status[e]) continue;
+                        done.fetch_add(1);
+                        bool ok = bgzf_inflate_block_host(in_stage + list[e].in_off, list[e].in_size, out + list[e].out_off, list[e].out_size);
+                        if (ok && check_every) {                     // the host decoder's bytes answer to the same trailer
+                            const uint8_t *trailer = in_stage + list[e].in_off + list[e].in_size;
+                            const uint32_t want = (uint32_t)trailer[0] | (uint32_t)trailer[1] << 8 | (uint32_t)trailer[2] << 16 | (uint32_t)trailer[3] << 24;
+                            ok = bgzf_crc32(out + list[e].out_off, list[e].out_size) == want;
+                        }
+                        if (!ok) { int expect = -1; bad.compare_exchange_strong(expect, origin[e]); }
+                    }
+                }
+            };
+            bool any = host_batch;
+            for (size_t e = 0; e < list.size() && !any; ++e) any = status[e] != 0u;
+            if (any) {
+                std::vector<std::thread> th;
+                for (int t = 0; t < std::max(1, host_batch ? threads : std::min(threads, 4)); ++t) th.emplace_back(redo);
+                for (auto &t : th) t.join();
+            }
+            n_host += done.load();
+            if (bad.load() >= 0) return fail(MSNV_EFORMAT, "%s: BGZF inflate failed (malformed DEFLATE stream or CRC-32 mismatch)", paths[f0 + bad.load()]);
         }
         n_blocks += list.size();
         if (int rc = consume(f0, f1, (const uint8_t *)out, ext)) return rc;
         f0 = f1;
     }
     if (counters) { counters[0] = n_blocks; counters[1] = n_host; counters[2] = (uint64_t)(ms * 1000.0); counters[3] = n_bytes; }
+    dev_inflate_release_device(ctx);                                // the batch buffers in HBM go back before the dataset is uploaded (the pinned half stays)
     return MSNV_OK;
 }
 
@@ -371,23 +431,31 @@ extern "C" int msnv_bgzf_inflate(msnv_ctx *ctx, const char *path, int32_t on_dev
     } catch (const std::exception &e) { return fail(MSNV_ENOMEM, "msnv_bgzf_inflate: %s", e.what()); }
 }
 
-// Where the BGZF blocks of a call's files are inflated.  Default: on the device for calls that bring at least 64 MB of BAM and have a
-// context -- below that the host decoder is done before the staging is set up; MSNV_INFLATE=host | zlib keeps everything on the host,
-// MSNV_INFLATE=device forces the device whatever the size.
-static bool want_device_inflate(msnv_ctx *ctx, const char *const *paths, int n) {
+// Where the BGZF blocks of a call's files are inflated: on the device when that is the faster way for THIS call.  The device path
+// needs pinned staging for a batch (up to 1 GB compressed + its inflated bytes), and pinning costs ~0.25 s per GB the first time a
+// context does it -- more than 32 host threads need for the whole job of the benchmark shape (160 BAMs, 1.35 GB: device path cold
+// 1.5 s, host decoder 0.4 s; profiles/r03d end-to-end).  So: device when the estimated host time (compressed bytes / threads x
+// ~90 MB/s per thread) exceeds the estimated device time (staging still to pin + both transfers at ~25 GB/s + a launch).
+// MSNV_INFLATE=host | zlib keeps everything on the host, MSNV_INFLATE=device forces the device whatever the size.
+static bool want_device_inflate(msnv_ctx *ctx, const char *const *paths, int n, int threads) {
     if (!ctx) return false;
     const char *e = getenv("MSNV_INFLATE");
     if (e) return e[0] == 'd';
-    uint64_t bytes = 0;
-    for (int i = 0; i < n && bytes < (64ull << 20); ++i) {
+    uint64_t bytes = 0, largest = 0;
+    for (int i = 0; i < n; ++i) {
         FILE *f = fopen(paths[i], "rb");
         if (!f) continue;
         fseek(f, 0, SEEK_END);
         const long z = ftell(f);
         fclose(f);
-        if (z > 0) bytes += (uint64_t)z;
+        if (z > 0) { bytes += (uint64_t)z; largest = std::max<uint64_t>(largest, (uint64_t)z); }
     }
-    return bytes >= (64ull << 20);
+    if (bytes < (64ull << 20)) return false;                       // the host decoder is done before the staging is set up
+    const double batch_in = (double)std::max<uint64_t>(std::min<uint64_t>(bytes, 1024ull << 20), largest), batch_out = 3.6 * batch_in;
+    const double to_pin = std::max(0.0, batch_in - (double)ctx->pin_in_cap) + std::max(0.0, batch_out - (double)ctx->pin_out_cap);
+    const double est_dev = to_pin * 0.25e-9 + (double)bytes * (1.0 + 3.6) / 25e9 + 0.02;
+    const double est_host = (double)bytes / ((double)std::max(1, threads) * 90e6);
+    return est_dev < est_host;
 }
 
 // The record streams of several BAM files (the N-rank driver deals them to the ranks that own their contigs): through the device
@@ -399,7 +467,7 @@ extern "C" int msnv_bam_records_many(msnv_ctx *ctx, const char *const *bam_paths
     for (int i = 0; i < n; ++i) { records[i] = nullptr; n_bytes[i] = 0; }
     int nthreads = host_threads > 0 ? host_threads : (int)std::max(1u, std::thread::hardware_concurrency());
     nthreads = std::min(nthreads, std::max(1, (int)n));
-    const bool on_device = want_device_inflate(ctx, bam_paths, n);
+    const bool on_device = want_device_inflate(ctx, bam_paths, n, nthreads);
     std::atomic<int> err{0};
     std::vector<std::string> msgs((size_t)std::max(n, 0));
     auto keep = [&](int i, const uint8_t *data, uint64_t size) -> int {      // header parsed, records copied out
@@ -462,7 +530,7 @@ extern "C" int msnv_dataset_add_sample_bams(msnv_dataset *ds, const char *const 
     std::vector<std::string> msgs((size_t)n);
     // MSNV_INFLATE=device: the BGZF blocks of the files are inflated on the device (inflate_k.hip: a wavefront per block, thousands of
     // blocks at a time), batch by batch; the host threads read the files in front of it and parse / pack the batch's bytes in place
-    const bool on_device = want_device_inflate(ds->ctx, bam_paths, n);
+    bool on_device = want_device_inflate(ds->ctx, bam_paths, n, nthreads);
     auto pack_one = [&](int i, const uint8_t *data, uint64_t size, BamHeader &h, uint64_t rec_off) -> int {
         if (int rc = check_header(*ds, h, bam_paths[i])) return rc;
         return pack_sample(*ds, data + rec_off, size - rec_off, ds->samples[first + (size_t)i]);
@@ -679,7 +747,7 @@ static int fetch_results(msnv_dataset *ds) {
             s.dropped = (ds->params.drop_first_line && s.tid == ds->first_tid && s.pos == ds->first_pos) ? 1 : 0;
             ds->sites.push_back(s);
             ds->site_dev_index.push_back(i);
-            const uint64_t cell0 = tcell[t] + (uint64_t)j * n_slots;
+            const uint64_t cell0 = tcell[t] + (uint64_t)j * ds->tile_slot_stride[t];
             if (cell0 + n_slots > n_cells) return fail(MSNV_EHIP, "internal: the device reported %llu cells but tile %u needs cell %llu", (unsigned long long)n_cells, t, (unsigned long long)(cell0 + n_slots));
             // the site's row of cells: the tile's slots in SAMPLE order (pack.cpp sorts a tile's pairs by kind, so the slots are not),
             // without the samples that hold nothing at this position

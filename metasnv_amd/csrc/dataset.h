@@ -141,6 +141,7 @@ struct msnv_dataset {
     std::vector<uint32_t> tile_base;       // per contig (selected only; others = UINT32_MAX)
     std::vector<uint32_t> tile_contig;     // per tile
     std::vector<uint64_t> tile_slot_base;  // per tile: first entry of slot_sample (n_tiles + 1)
+    std::vector<uint32_t> tile_slot_stride; // per tile: cells per site row on the device (>= its slots: rows of big tiles are padded to multiples of 8 cells)
     std::vector<uint32_t> slot_sample;     // sample of every (tile, slot): the device stores per-sample cells per slot (kernels.hip: CellMap)
     uint32_t n_tiles = 0;
     // first pileup line of the invocation (call_vC.cpp:423)

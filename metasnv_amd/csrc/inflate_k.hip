@@ -320,6 +320,7 @@ __global__ __launch_bounds__(64) void msnv_inflate_blocks(const uint8_t *__restr
 
 // Pinned staging of a context, grown on demand: *in holds `in_bytes` compressed bytes (the caller fills it), *out receives the output.
 int dev_inflate_staging(msnv_ctx *ctx, uint64_t in_bytes, uint64_t out_bytes, uint8_t **in, uint8_t **out) {
+    if (const char *e = getenv("MSNV_TEST_NO_STAGING")) if (e[0] == '1') return fail_quiet(MSNV_ENOMEM, "staging refused (MSNV_TEST_NO_STAGING=1)");   // tests: the host takes the batch
     auto grow = [](void **p, uint64_t *cap, uint64_t need, bool host) -> int {
         if (need <= *cap) return MSNV_OK;
         if (*p) { if (host) (void)hipHostFree(*p); else (void)hipFree(*p); *p = nullptr; *cap = 0; }
@@ -335,6 +336,14 @@ int dev_inflate_staging(msnv_ctx *ctx, uint64_t in_bytes, uint64_t out_bytes, ui
     if (int rc = grow(&ctx->dev_out, &ctx->dev_out_cap, out_bytes + 64, false)) return rc;
     *in = (uint8_t *)ctx->pin_in; *out = (uint8_t *)ctx->pin_out;
     return MSNV_OK;
+}
+// The DEVICE half of the staging only (what a finished msnv_dataset_add_sample_bams / msnv_bam_records_many call gives back before the
+// dataset is uploaded: compressed + inflated bytes of a batch would otherwise sit in HBM next to the columns); the pinned half stays.
+void dev_inflate_release_device(msnv_ctx *ctx) {
+    if (ctx->dev_in) (void)hipFree(ctx->dev_in);
+    if (ctx->dev_out) (void)hipFree(ctx->dev_out);
+    ctx->dev_in = ctx->dev_out = nullptr;
+    ctx->dev_in_cap = ctx->dev_out_cap = 0;
 }
 void dev_inflate_release(msnv_ctx *ctx) {
     if (ctx->pin_in) (void)hipHostFree(ctx->pin_in);

@@ -945,6 +945,20 @@ __device__ __forceinline__ uint64_t cell_of(const CellMap &m, const uint32_t til
     return m.tile_cell_base[tile] + (uint64_t)(site - m.tile_site_base[tile]) * m.tile_nslots[tile] + slot;
 }
 
+// Zeroes n bytes at p (2-byte aligned, n even) with the NT threads of the caller: halfword stores up to the first 16-byte boundary
+// and behind the last, 16-byte stores in between (two-byte stores cost a wavefront ~540 cycles each: DESIGN.md "tail").
+template <int NT>
+__device__ __forceinline__ void zero_span(uint8_t *p, const uint64_t n, const uint32_t tid) {
+    const uint64_t head = min(n, (uint64_t)((16u - (uint32_t)(reinterpret_cast<uintptr_t>(p) & 15u)) & 15u));
+    if ((uint64_t)2u * tid < head) *reinterpret_cast<uint16_t *>(p + 2u * tid) = 0;                     // (head <= 14 bytes)
+    uint8_t *q = p + head;
+    const uint64_t body = (n - head) >> 4;
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (uint64_t i = tid; i < body; i += NT) reinterpret_cast<uint4 *>(q)[i] = z;
+    const uint64_t tail0 = head + (body << 4);
+    if (tail0 + 2u * tid < n) *reinterpret_cast<uint16_t *>(p + tail0 + 2u * tid) = 0;                   // (tail <= 14 bytes)
+}
+
 struct GateTile { uint32_t tile, slot_lo, slot_16, slot_w, slot_hi, vbeg, vend, n_slots; uint64_t row0; uint32_t tot_mode, staged; };   // 48 B (pack.cpp); staged: a whole-tile work item leaves the tile's candidates in a record list
 
 struct GateArgs {
@@ -987,7 +1001,7 @@ __device__ __forceinline__ void gate_flush(GateLds &L, const GateArgs &a, const 
     if (n_tiles == 0u) return;                                   // (uniform)
     if (tid == 0) {
         L.base = atomicAdd(&a.counters[2], n_sites);
-        L.cell = atomicAdd(reinterpret_cast<unsigned long long *>(&a.counters[CNT_CELLS]), n_cells);
+        L.cell = atomicAdd(reinterpret_cast<unsigned long long *>(&a.counters[CNT_CELLS]), (n_cells + 7ull) & ~7ull);   // (the counter stays a multiple of 8: gather_cov_wide)
     }
     __syncthreads();
     const uint32_t base = L.base; const unsigned long long cb = L.cell;
@@ -997,11 +1011,8 @@ __device__ __forceinline__ void gate_flush(GateLds &L, const GateArgs &a, const 
     }
     if ((unsigned long long)base + n_sites <= a.cap_out && cb + n_cells <= a.cap_cells) {   // else: the host sees the counts and runs again with larger buffers
         // the per-sample cells of these sites start out zero: gather and scatter (one launch, side by side) only add to them
-        uint16_t *rows = reinterpret_cast<uint16_t *>(a.out + cb);
-        const uint64_t nhw = n_cells * (sizeof(msnv_site_sample) / 2);
-        for (uint64_t i = (uint64_t)tid; i < nhw; i += GATE_NT) rows[i] = 0;
-        uint16_t *crow = a.cov_col + cb;                          // samples without reads at a position keep coverage 0
-        for (uint64_t i = (uint64_t)tid; i < n_cells; i += GATE_NT) crow[i] = 0;
+        zero_span<GATE_NT>(reinterpret_cast<uint8_t *>(a.out + cb), n_cells * sizeof(msnv_site_sample), (uint32_t)tid);
+        zero_span<GATE_NT>(reinterpret_cast<uint8_t *>(a.cov_col + cb), n_cells * sizeof(uint16_t), (uint32_t)tid);      // samples without reads at a position keep coverage 0
     }
     // index of the first site of every 64 positions: an event finds its site as rank + popcount of the lower bits
     if ((uint32_t)tid < n_tiles * (TILE / 64)) {
@@ -1245,6 +1256,7 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
             st_tiles = 0; st_sites = 0; st_cells = 0;
         }
         if (total <= GATE_STAGE) {
+            if ((n_slots & 7u) == 0u) st_cells = (st_cells + 7ull) & ~7ull;      // a tile whose rows are multiples of 16 bytes starts on 16 bytes (gather_cov_wide)
             if (tid == 0) L.tiles[st_tiles] = GateStageTile{tile, st_sites, total, n_slots, st_cells};
             if ((lane & 7) == 0) L.blk_rel[st_tiles][p0 >> 6] = st_sites + mybase;
             uint32_t i = st_sites + mybase;
@@ -1270,7 +1282,7 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
             L.base = base;
             a.tile_site_base[tile] = base;
             a.tile_site_cnt[tile] = total;
-            const unsigned long long cb = atomicAdd(reinterpret_cast<unsigned long long *>(&counters[CNT_CELLS]), (unsigned long long)total * n_slots);
+            const unsigned long long cb = atomicAdd(reinterpret_cast<unsigned long long *>(&counters[CNT_CELLS]), ((unsigned long long)total * n_slots + 7ull) & ~7ull);
             L.cell = cb;
             a.tile_cell_base[tile] = cb;
         }
@@ -1278,11 +1290,8 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
         const uint32_t base = L.base; const unsigned long long s_cell = L.cell;
         if ((uint64_t)base + total <= cap_out && s_cell + (unsigned long long)total * n_slots <= a.cap_cells) {
             const uint64_t n_cells = (uint64_t)total * n_slots;
-            uint16_t *rows = reinterpret_cast<uint16_t *>(out + s_cell);
-            const uint64_t nhw = n_cells * (sizeof(msnv_site_sample) / 2);
-            for (uint64_t i = (uint64_t)tid; i < nhw; i += GATE_NT) rows[i] = 0;
-            uint16_t *crow = cov_col + s_cell;
-            for (uint64_t i = (uint64_t)tid; i < n_cells; i += GATE_NT) crow[i] = 0;
+            zero_span<GATE_NT>(reinterpret_cast<uint8_t *>(out + s_cell), n_cells * sizeof(msnv_site_sample), (uint32_t)tid);
+            zero_span<GATE_NT>(reinterpret_cast<uint8_t *>(cov_col + s_cell), n_cells * sizeof(uint16_t), (uint32_t)tid);
         }
         if ((lane & 7) == 0) {
             a.site_rank[g0 >> 6] = base + mybase;
@@ -1355,7 +1364,7 @@ __global__ __launch_bounds__(256) void msnv_gate_staged(const GateArgs a, const 
         const uint32_t ts = s_sites[0] + s_sites[1] + s_sites[2] + s_sites[3];
         const unsigned long long tc = s_cells[0] + s_cells[1] + s_cells[2] + s_cells[3];
         s_base = ts ? atomicAdd(&a.counters[2], ts) : 0u;
-        s_cb = ts ? atomicAdd(reinterpret_cast<unsigned long long *>(&a.counters[CNT_CELLS]), tc) : 0ull;
+        s_cb = ts ? atomicAdd(reinterpret_cast<unsigned long long *>(&a.counters[CNT_CELLS]), (tc + 7ull) & ~7ull) : 0ull;
     }
     __syncthreads();
     uint32_t base = s_base; unsigned long long cb = s_cb;
@@ -1410,10 +1419,8 @@ __global__ __launch_bounds__(256) void msnv_gate_staged(const GateArgs a, const 
         }
         if (kind != 2u && fits && n) {                                  // the per-sample cells of these sites start out zero (gather / scatter only add to them)
             const unsigned long long n_cells = (unsigned long long)n * n_slots;
-            uint16_t *rows = reinterpret_cast<uint16_t *>(a.out + cb + crel);
-            for (unsigned long long i = (unsigned long long)lane; i < n_cells * (sizeof(msnv_site_sample) / 2); i += 64) rows[i] = 0;
-            uint16_t *crow = a.cov_col + cb + crel;
-            for (unsigned long long i = (unsigned long long)lane; i < n_cells; i += 64) crow[i] = 0;
+            zero_span<64>(reinterpret_cast<uint8_t *>(a.out + cb + crel), n_cells * sizeof(msnv_site_sample), (uint32_t)lane);
+            zero_span<64>(reinterpret_cast<uint8_t *>(a.cov_col + cb + crel), n_cells * sizeof(uint16_t), (uint32_t)lane);
         }
     }
 #pragma unroll
@@ -1443,15 +1450,70 @@ struct TailArgs {
     uint8_t *site_flags; const uint8_t *site_elig; uint32_t ind_in_gather, min_snvs;
     msnv_site_sample *out; uint16_t *cov_col; uint32_t cap_out; const uint32_t *active_tiles; uint32_t n_gather_blocks;
     CellMap cells; uint32_t gather_split;
+    uint32_t has_wide;                          // some work item runs the wide kernel (coverage bytes of 255 stand for an overflow-list entry the scatter half writes)
     const Pair32 *events, *overflow; uint32_t *counters; uint32_t cap_list, cap_overflow;
     const unsigned long long *site_bits; const uint32_t *site_rank;
 };
 
 constexpr uint32_t GD_MIN_SITES = 32;          // sites of a tile per gather workgroup from which the cells go through LDS (gather_cov_block)
 constexpr uint32_t GD_ROW = 68;                // bytes per LDS row of 64 pairs (17 words: a wavefront's column writes hit 64 banks)
+constexpr uint32_t GW_ROW = 34;                // words per LDS row of 64 slots (u16 each) + 2: 8-byte aligned rows, a wavefront's column updates meet two to a bank
+
+// Dense gather with 16-BYTE STORES (round 3).  The two-byte cell stores of the form below cost a wavefront ~540 cycles each and were all
+// the many-site gather waited for (stores off: 1.90 -> 0.38 ms on the sigma = 2 cohort).  Here a block of 64 sites x 64 SLOTS is
+// assembled in LDS -- a wavefront reads one pair's bytes at the 64 sites into the pair's slot column -- and written out as rows of
+// cells, eight cells (16 bytes) per lane.  That needs rows that start on 16 bytes: the tile's cell stride is a multiple of 8
+// (pack.cpp pads tiles of >= 16 slots) and so is its first cell (the gate kernels reserve in multiples of 8).  Only for tiles without a
+// split sample (pack.cpp marks the others: slot = pair index here, and no cell needs a sum).  Slots of merged pairs (behind the
+// others) belong to gather_merged_block: the group of eight that straddles their first slot is written cell by cell.
+__device__ __forceinline__ void gather_cov_wide(const TailArgs &a, uint32_t *s_acc, uint32_t *s_off, const uint32_t t0, const uint32_t base, const uint32_t stride,
+                                                const unsigned long long cell0, const uint32_t ps, const uint32_t np, const bool tile_has_merged, const uint32_t j_lo, const uint32_t dense_n) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t nblk = (np + 63u) >> 6;
+    // cells of the last group of eight that this path may write as a whole: everything when no merged pair follows, else up to the first merged slot
+    const uint32_t wide_end = tile_has_merged ? (np & ~7u) : stride;
+    for (uint32_t jj0 = 0; jj0 < dense_n; jj0 += 64u) {
+        const uint32_t nS = min(64u, dense_n - jj0);
+        __syncthreads();                                            // (the block before has been written out)
+        if (tid < 64u) s_off[tid] = a.sites[base + j_lo + jj0 + min(tid, nS - 1u)].gpos - t0;   // (idle lanes: a valid position; their rows are not written out)
+        for (uint32_t b = 0; b < nblk; ++b) {
+            __syncthreads();                                        // s_off is visible; the previous 64 slots have been written out
+            const uint32_t kA = 64u * b, kB = min(np, kA + 64u);
+            const uint32_t off = s_off[lane];
+            for (uint32_t kl = kA + wave; kl < kB; kl += 16u) {      // four loads in flight per lane
+                uint8_t v[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) v[u] = a.spill[(uint64_t)(ps + min(kl + 4u * u, kB - 1u)) * TILE + off];
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u)
+                    if (kl + 4u * u < kB) reinterpret_cast<uint16_t *>(s_acc + lane * GW_ROW)[kl + 4u * u - kA] = (uint16_t)v[u];
+            }
+            __syncthreads();
+            for (uint32_t idx = tid; idx < nS * 8u; idx += 256u) {
+                const uint32_t row = idx >> 3, seg = idx & 7u, c0 = kA + 8u * seg;
+                if (c0 >= np) continue;                                  // (slots of merged pairs, padding behind the last slot: zeroed by the gate kernel)
+                const uint32_t nc = min(8u, np - c0);                    // (columns beyond the block's pairs hold stale halfwords: masked here)
+                uint2 lo = *reinterpret_cast<const uint2 *>(&s_acc[row * GW_ROW + 4u * seg]);
+                uint2 hi = *reinterpret_cast<const uint2 *>(&s_acc[row * GW_ROW + 4u * seg + 2u]);
+                uint32_t w[4] = {lo.x, lo.y, hi.x, hi.y};
+                uint16_t *dst = a.cov_col + cell0 + (uint64_t)(j_lo + jj0 + row) * stride + c0;
+                if (c0 + 8u <= wide_end) {
+#pragma unroll
+                    for (uint32_t q = 0; q < 4u; ++q) w[q] = 2u * q + 1u < nc ? w[q] : 2u * q < nc ? w[q] & 0xffffu : 0u;
+                    *reinterpret_cast<uint4 *>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+                } else {
+                    for (uint32_t q = 0; q < nc; ++q) dst[q] = (uint16_t)(w[q >> 1] >> (16u * (q & 1u)));
+                }
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ void gather_cov_block(const TailArgs &a, const uint32_t bid) {
     const uint32_t GATHER_SPLIT = a.gather_split;
-    const uint32_t tile = a.active_tiles[bid / GATHER_SPLIT], part = bid % GATHER_SPLIT;   // a tile's sites are dealt to GATHER_SPLIT workgroups
+    const uint32_t tile_word = a.active_tiles[bid / GATHER_SPLIT], part = bid % GATHER_SPLIT;   // a tile's sites are dealt to GATHER_SPLIT workgroups
+    const uint32_t tile = tile_word & 0x7fffffffu;
+    const bool tile_split = (tile_word >> 31) != 0u;                // some sample of the tile was split into several pairs (pack.cpp: gather_tiles)
     const uint32_t n = a.tile_site_cnt[tile];
     if (n <= part) return;
     const uint32_t base = a.tile_site_base[tile];
@@ -1472,8 +1534,13 @@ __device__ __forceinline__ void gather_cov_block(const TailArgs &a, const uint32
         // one site's cells of 64 pairs (consecutive slots).  A workgroup takes a CONTIGUOUS range of the tile's sites here (every
         // GATHER_SPLIT-th one, as below, spreads each 128-byte line of the cell rows over workgroups on different XCDs).
         const uint32_t j_lo = min(n, part * share), dense_n = min(n, j_lo + share) - j_lo;
-        __shared__ uint8_t s_t[64][GD_ROW];
+        __shared__ __attribute__((aligned(8))) uint32_t s_lds[64 * GW_ROW];      // one block for both forms of the dense gather
         __shared__ uint32_t s_off[64], s_pad[64];
+        if ((n_slots & 7u) == 0u && (cell0 & 7ull) == 0ull && !tile_split && !a.has_wide) {      // (uniform)
+            gather_cov_wide(a, s_lds, s_off, t0, base, n_slots, cell0, ps, np, a.tile_pair_merged[tile] < a.tile_pair_start[tile + 1u], j_lo, dense_n);
+            return;
+        }
+        uint8_t (*s_t)[GD_ROW] = reinterpret_cast<uint8_t (*)[GD_ROW]>(s_lds);
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         for (uint32_t jj0 = 0; jj0 < dense_n; jj0 += 64) {
             const uint32_t nS = min(64u, dense_n - jj0);
@@ -2092,6 +2159,7 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
         ta.pairs = d.pairs; ta.spill = d.spill; ta.out = d.out; ta.cov_col = d.cov_col; ta.cap_out = cap_out; ta.active_tiles = d.gather_tiles;
         ta.cells = CellMap{d.tile_site_base, d.tile_cell_base, d.tile_nslots, d.cap_cells, d.site_row};
         ta.gather_split = d.gather_split;
+        ta.has_wide = d.n_work > d.n_work_narrow + d.n_work_merged ? 1u : 0u;
         ta.n_gather_blocks = d.n_gather_tiles * d.gather_split;
         ta.tile_pair_merged = d.tile_pair_merged; ta.merged_groups = d.merged_groups; ta.chunks = d.chunks; ta.hdr8m = d.hdr8m;
         ta.seq = d.seq; ta.qual = d.qual; ta.ref4 = d.ref4; ta.n_merged_blocks = d.n_merged_groups - (use_stage ? d.n_groups_solo : 0u); ta.min_baseq = (uint32_t)std::max(0, p.min_baseq);

@@ -892,8 +892,11 @@ int finalize_dataset(msnv_dataset &ds) {
                 if (!same) { ds.slot_sample.push_back(pairs[k].sample); ++n; }
                 pairs[k].pad |= (n - 1u) << 8;
             }
-            nslots[t] = n;
+            // the device's row stride: tiles of >= 16 slots get rows that are multiples of 16 bytes (8 coverage cells), so that the
+            // many-site gather can write them with 16-byte stores (kernels.hip: gather_cov_wide); the padding cells stay zero
+            nslots[t] = n >= 16u ? (n + 7u) & ~7u : n;
         }
+        ds.tile_slot_stride = nslots;
         ds.tile_slot_base[nt] = (uint64_t)ds.slot_sample.size();
         if (int rc = upload_vec(&d->tile_nslots, nslots, &d->device_bytes)) return rc;
         if (int rc = dev_alloc((void **)&d->tile_cell_base, (nt + 1) * sizeof(unsigned long long), &d->device_bytes)) return rc;
@@ -1031,7 +1034,11 @@ int finalize_dataset(msnv_dataset &ds) {
         // cohort -- would each cost a workgroup that looks its tile up and leaves)
         {
             std::vector<uint32_t> gather_tiles;
-            for (uint32_t t : active) if (tpm[t] > tps[t]) gather_tiles.push_back(t);
+            for (uint32_t t : active) if (tpm[t] > tps[t]) {
+                bool split = false;                                   // bit 31: a sample of the tile was split into several pairs (their cells are sums)
+                for (uint32_t k = tps[t]; k < tpm[t] && !split; ++k) split = (pairs[k].pad & 0xffu) == 1u;
+                gather_tiles.push_back(t | (split ? 0x80000000u : 0u));
+            }
             d->n_gather_tiles = (uint32_t)gather_tiles.size();
             if (int rc = upload_vec(&d->gather_tiles, gather_tiles, &d->device_bytes, 1)) return rc;
         }
@@ -1043,7 +1050,7 @@ int finalize_dataset(msnv_dataset &ds) {
         if (int rc = dev_alloc((void **)&d->part, d->part_bytes, &d->device_bytes)) return rc;
         // one descriptor per active tile for the gate kernel: everything it looks up about its tile in one load
         std::vector<uint32_t> nslots_host(nt + 1, 0);
-        for (uint64_t t = 0; t < nt; ++t) nslots_host[t] = (uint32_t)(ds.tile_slot_base[t + 1] - ds.tile_slot_base[t]);
+        for (uint64_t t = 0; t < nt; ++t) nslots_host[t] = ds.tile_slot_stride[t];
         std::vector<DeviceCols::GateTileH> gts;
         gts.reserve(active.size());
         for (uint32_t t : active) gts.push_back(DeviceCols::GateTileH{t, tss[t], t16[t], twide[t], tss[t + 1], vb_host[t], ve_host[t], nslots_host[t], off[tss[t]], tot_mode(t), (uint32_t)fuse_tile[t]});

@@ -1,0 +1,108 @@
+"""BASELINE configs[2] at FULL size on one GPU: 100 species x 3 Mbp (1-50 contigs each) x 160 samples, every sample carrying ten
+species at LogNormal(ln 10, 0.7)x -- 5.8e10 pileup bases, 300 M reference positions, ~140 GB resident in HBM.  The oracle cannot
+follow to this size (it runs 0.05 Gbases/s), so the test checks size-independent properties of what the device returns:
+idempotence of a pass, the calling rule re-derived from the returned counts for EVERY site (call_vC.cpp:545-552,577-601), the
+per-sample cells adding up to the site totals (a checksum of checksums over all samples), and qaCompute's histogram covering every
+scanned position once (qaCompute.cpp:142-165).  The reduced-size shape is checked against the oracle byte for byte in
+test_gpu_parity.py::test_config3_shape_fused_coverage_and_calls.  Needs a box with >= 400 GB of RAM and >= 200 GB of free HBM
+(skipped elsewhere); MSNV_SKIP_FULL_CONFIG3=1 skips it."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from metasnv_amd import core
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _ram_gb():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    return 0.0
+
+
+@pytest.mark.skipif(os.environ.get("MSNV_SKIP_FULL_CONFIG3") == "1", reason="MSNV_SKIP_FULL_CONFIG3=1")
+@pytest.mark.skipif(_ram_gb() < 400, reason="needs >= 400 GB of host memory for staging")
+def test_full_size_config3_properties():
+    sys.path.insert(0, ROOT)
+    import bench
+    scale = float(os.environ.get("MSNV_FULL_CONFIG3_SCALE", "1.0"))
+    a = argparse.Namespace(workload="config3", scale=scale, samples=None, contig_len=None, species=None, mean_cov=None, read_len=100, error_rate=None)
+    kw, label = bench.workload_params(a)
+    sp = core.synth_params(**kw)
+    syn = core.Synth(sp)
+    ctx = core.Context(0)
+    ds = core.Dataset(ctx, syn.names, syn.lengths, syn.seqs)
+    ds.add_synth_samples(sp, 0, sp.n_samples, 0)
+    info = ds.finalize()
+    if scale == 1.0:
+        assert info["n_pileup_bases"] > 4.8e10 and info["n_positions"] == 300000000 and info["n_samples"] == 160
+    p = ds.params
+    t, c_min, frac = p.calling_threshold, p.min_coverage, p.min_fraction
+
+    # ---- idempotence: a pass leaves the dataset as it found it
+    st1 = ds.run()
+    st2 = ds.run()
+    for k in ("n_sites", "n_called_pop", "n_called_indiv", "n_events", "n_overflow"):
+        assert st1[k] == st2[k], k
+    sites, row_off, cell_sample, cells = ds.results_cells()
+    n = len(sites)
+    assert n > 1000 * scale and row_off[-1] == len(cells)
+    # (tid, pos) order, every site once
+    key = sites["tid"].astype(np.int64) << 32 | sites["pos"].astype(np.int64)
+    assert (np.diff(key) > 0).all()
+    lens = np.asarray(syn.lengths, dtype=np.int64)
+    assert (sites["pos"] >= 0).all() and (sites["pos"] < lens[sites["tid"]]).all()
+
+    # ---- checksum of checksums: the per-sample cells add up to the site totals
+    site_of = np.repeat(np.arange(n), np.diff(row_off.astype(np.int64)))
+    cov_sum = np.bincount(site_of, weights=cells["cov"].astype(np.float64), minlength=n)
+    assert (cov_sum == sites["cov"]).all()
+    for x in range(4):
+        nx_sum = np.bincount(site_of, weights=cells["n"][:, x].astype(np.float64), minlength=n)
+        assert (nx_sum == sites["n"][:, x]).all(), x
+    assert (cell_sample < sp.n_samples).all()
+
+    # ---- the gates and the calling rule, re-derived from the returned counts for every site (call_vC.cpp:545-552,577-601)
+    cov = sites["cov"].astype(np.int64)
+    nn = sites["n"].astype(np.int64)
+    assert (cov >= c_min).all() and (nn.sum(axis=1) >= t).all()
+    ref_lower = np.isin(sites["refchar"], np.frombuffer(b"acgt", dtype=np.uint8))
+    assert not ref_lower.any()                               # (the synthetic reference is upper-case: nothing is skipped as "same base")
+    lim = cov.astype(np.float64) * frac
+    pop_expect = np.zeros(n, dtype=np.uint8)
+    ind_expect = np.zeros(n, dtype=np.uint8)
+    for x in range(4):
+        is_pop = (nn[:, x] >= t) & (nn[:, x].astype(np.float64) >= lim)
+        some = np.zeros(n, dtype=bool)
+        hit = cells["n"][:, x] >= t
+        some[site_of[hit]] = True
+        pop_expect |= (is_pop.astype(np.uint8) << x)
+        ind_expect |= ((~is_pop & (nn[:, x] >= t) & some).astype(np.uint8) << x)
+    assert (sites["pop_mask"] == pop_expect).all()
+    assert (sites["ind_mask"] == ind_expect).all()
+    assert ((sites["pop_mask"] | sites["ind_mask"]) != 0).all()
+    assert st1["n_called_pop"] == int((sites["pop_mask"] != 0).sum()) and st1["n_called_indiv"] == int((sites["ind_mask"] != 0).sum())
+
+    # ---- qaCompute: every scanned position of a covered (sample, contig) lands in exactly one histogram bin; covSum = sum of depth x run
+    cst = ds.coverage_run()
+    acc = ds.coverage_accumulators()
+    rows = acc.any(axis=2)
+    tot = acc[:, :, 1:].sum(axis=2)
+    # every scanned position of a tile the sample has reads in lands in exactly one bin (the tiles it has none in are zero-depth
+    # positions the host adds when it prints): never more than the contig holds, and the depth-weighted bins never exceed covSum
+    assert (tot <= np.broadcast_to(lens.astype(np.uint64), tot.shape)).all() and (tot[rows] > 0).all()
+    depth_sum_from_bins_lower_bound = (acc[:, :, 1:12] * np.arange(11, dtype=np.uint64)).sum(axis=2)     # bins are min(depth, 10): covSum is at least that
+    assert (acc[:, :, 0] >= depth_sum_from_bins_lower_bound)[rows].all()
+    # covSum over everything = the aligned bases of qaCompute's reads: the same order of magnitude as the pileup's (filters differ by flags only)
+    assert 0.9 * info["n_pileup_bases"] < float(acc[:, :, 0].sum()) < 1.2 * info["n_pileup_bases"]
+    assert rows.sum() > sp.n_samples and cst["ms_coverage"] > 0
+    ds.close(); ctx.close()

@@ -22,7 +22,7 @@ def _bam(tmp_path, level, seed, **kw):
 
 @pytest.mark.parametrize("level", [0, 1, 4, 6, 9])
 def test_device_inflate_equals_host_inflate(level, tmp_path, monkeypatch):
-    monkeypatch.setenv("MSNV_INFLATE_CHECK", "1")          # every block against the CRC-32 of its trailer (default: every 64th)
+    monkeypatch.setenv("MSNV_INFLATE_CHECK", "1")          # every block against the CRC-32 of its trailer (the default since round 3)
     ctx = core.Context(0)
     for seed in (1, 2):
         p = _bam(tmp_path, level, seed)
@@ -53,11 +53,14 @@ def test_blocks_the_device_refuses_go_to_the_host_decoder(tmp_path):
     ctx.close()
 
 
-@pytest.mark.parametrize("mode", ["device", "host"])
+@pytest.mark.parametrize("mode", ["device", "host", "device-without-staging"])
 def test_file_entry_point_with_either_inflate(mode, tmp_path, monkeypatch):
-    """msnv_dataset_add_sample_bams with the blocks inflated on the device (the default from 64 MB of BAM on) and on the host: the same
-    dataset -- sizes, called positions, bytes of called_SNPs."""
-    monkeypatch.setenv("MSNV_INFLATE", mode)
+    """msnv_dataset_add_sample_bams with the blocks inflated on the device (picked when it is the faster way for the call) and on the
+    host: the same dataset -- sizes, called positions, bytes of called_SNPs.  "device-without-staging": the staging allocation fails
+    (MSNV_ENOMEM: a multi-GB BAM on a full device) and the batch is inflated by the host decoder instead of failing the call."""
+    monkeypatch.setenv("MSNV_INFLATE", mode.split("-")[0])
+    if mode == "device-without-staging":
+        monkeypatch.setenv("MSNV_TEST_NO_STAGING", "1")
     sp = core.synth_params(n_species=2, contig_len=30000, n_samples=6, mean_cov=12.0, frac_paired=0.4, snv_density=0.02, seed=11)
     syn = core.Synth(sp)
     fa = str(tmp_path / "ref.fa"); syn.write_fasta(fa)

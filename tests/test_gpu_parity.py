@@ -277,6 +277,26 @@ def test_noisy_reads_reserve_their_event_ranges_per_pass(layout, monkeypatch):
     assert prod[0].count("\n") > 200
 
 
+@pytest.mark.parametrize("n_samples,mean_cov,sigma,gather_split", [(21, 12.0, 0.4, None), (70, 6.0, 1.2, "1"), (33, 9.0, 0.3, "4"), (16, 14.0, 0.2, None)])
+def test_many_sites_per_tile_cells_written_with_wide_stores(n_samples, mean_cov, sigma, gather_split, monkeypatch):
+    """Several per cent of mismatches and low thresholds: most positions of a tile are called, so the coverage gather takes its
+    dense form, and with >= 16 samples in a tile (rows padded to multiples of 8 cells, first cell a multiple of 8) the one that
+    assembles 64 sites x 64 slots in LDS and writes 16 bytes per lane (kernels.hip: gather_cov_wide): slot counts that are and are
+    not multiples of 8 / 64, one and several workgroups per tile, tiles whose shallow pairs are merged (their slots are left to the
+    merged gather), samples absent from a contig.  Same bytes as the oracle."""
+    if gather_split:
+        monkeypatch.setenv("MSNV_GATHER_SPLIT", gather_split)
+    monkeypatch.setenv("MSNV_MERGE_ALWAYS", "1")
+    syn, samples = synth_case(n_species=3, contig_len=5200, n_samples=n_samples, mean_cov=mean_cov, sigma_cov=sigma, snv_density=0.05,
+                              error_rate=0.04, frac_absent=0.1, seed=7300 + n_samples)
+    p = core.default_params(min_coverage=2, calling_threshold=2)
+    prod = run_product(syn.names, syn.lengths, syn.seqs, samples, params=p)
+    orac = run_oracle(syn.names, syn.lengths, syn.seqs, samples, params=p)
+    _assert_same(prod, orac)
+    assert prod[2]["n_pileup_bases"] == orac[3]
+    assert prod[0].count("\n") + prod[1].count("\n") > 3 * 2048          # well over 32 sites per gather workgroup in every tile
+
+
 @pytest.mark.parametrize("layout", ["pieces", "dense"])
 def test_shallow_cohort_and_contigs_shorter_than_a_tile(layout, monkeypatch):
     """Many samples at ~1x over contigs of a few hundred bases: every (sample, tile) pair is a single short chunk, so each
