@@ -207,7 +207,7 @@ def end_to_end(sp, syn, n_bases, host_threads, cpu_rate_gbases=None):
         out = {"bams": sp.n_samples, "bam_bytes": sum(os.path.getsize(x) for x in paths), "write_bams_s_not_counted": t_write, "host_threads": host_threads,
                "argv": "metaSNV.py DIR all_samples REF --threads %d (= %d best_split outputs, metaSNV.py:275-276)" % (host_threads, host_threads),
                "wall_s": wall, "Gbases_per_s": n_bases / wall / 1e9, "called_SNPs_lines": called,
-               "split_wall_s": {"python_start_and_imports": max(0.0, wall - cw.get("total_s", 0.0)),
+               "split_wall_s": {"process_start_hip_runtime_and_context": max(0.0, wall - cw.get("total_s", 0.0)),
                                 "decode_and_pack": ht.get("add_bams_wall_s"), "finalize_index_and_upload": ht.get("finalize_upload_wall_s"),
                                 "kernels_coverage_ms": m["coverage"]["ms_coverage"] if "coverage" in m else None, "kernels_pileup_pass_ms": m["pileup"]["ms_total"],
                                 "coverage_files": cw.get("coverage_files_s"), "tables_and_splits": cw.get("tables_and_splits_s"), "calls_text": cw.get("calls_text_s")},

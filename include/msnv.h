@@ -347,6 +347,12 @@ int  msnv_records_contig_bases(const uint8_t *records, uint64_t n_bytes, int32_t
 int  msnv_dataset_sample_stats(const msnv_dataset *ds, int32_t sample_idx, msnv_sample_stats *out);
 /* Accumulators of the last msnv_coverage_run: acc[n_samples][n_contigs][MSNV_COV_WORDS], zeros for contigs outside the shard. */
 int  msnv_coverage_fetch(msnv_dataset *ds, uint64_t *acc, uint64_t capacity_words);
+/* The same accumulators as ROWS: one per (sample, contig) that has reads passing qaCompute's filter on this rank, in (sample, contig)
+ * order -- what the device keeps and what a rank ships to rank 0.  The dense table above is n_samples x n_contigs x 136 bytes whatever
+ * it holds (500 BAMs over a database of a million contigs: 68 GB); qaCompute itself prints a row per header contig per BAM
+ * (qaCompute.cpp:226-263 for the ones without reads), which the writers below still do. */
+int  msnv_coverage_rows_count(const msnv_dataset *ds, uint64_t *n_rows);
+int  msnv_coverage_fetch_rows(msnv_dataset *ds, uint32_t *sample, uint32_t *contig, uint64_t *acc, uint64_t capacity_rows);
 /* Writes OUT / OUT.detail of one sample from gathered accumulators acc[n_contigs][MSNV_COV_WORDS] exactly as
  * msnv_write_coverage does (qaCompute.cpp:192-217,226-263,439,623-657). */
 int  msnv_write_coverage_records(const msnv_ref_desc *ref, int32_t max_cov, const msnv_sample_stats *stats, const uint64_t *acc,

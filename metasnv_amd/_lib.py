@@ -141,6 +141,8 @@ SYMBOLS = [
     ("msnv_records_partition", C.c_int, [_vp, C.c_uint64, P(C.c_int32), C.c_int32, C.c_int32, C.c_int32, _vp, P(C.c_uint64), P(SampleStats)]),
     ("msnv_dataset_sample_stats", C.c_int, [_vp, C.c_int32, P(SampleStats)]),
     ("msnv_coverage_fetch", C.c_int, [_vp, P(C.c_uint64), C.c_uint64]),
+    ("msnv_coverage_rows_count", C.c_int, [_vp, P(C.c_uint64)]),
+    ("msnv_coverage_fetch_rows", C.c_int, [_vp, P(C.c_uint32), P(C.c_uint32), P(C.c_uint64), C.c_uint64]),
     ("msnv_write_coverage_records", C.c_int, [P(RefDesc), C.c_int32, P(SampleStats), P(C.c_uint64), C.c_char_p, C.c_char_p]),
     ("msnv_annotate_run", C.c_int, [_vp, C.c_char_p, C.c_char_p, P(C.c_double)]),
     ("msnv_results_fetch_ann", C.c_int, [_vp, P(SiteAnn), C.c_uint64]),

@@ -189,6 +189,17 @@ class Dataset:
         check(lib.msnv_coverage_fetch(self._h, acc.ctypes.data_as(C.POINTER(C.c_uint64)), acc.size))
         return acc
 
+    def coverage_rows(self):
+        """The accumulators of the last coverage run as rows (msnv_coverage_fetch_rows): (sample[n], contig[n], acc[n][COV_WORDS]),
+        one row per (sample, contig) with reads on this rank, in (sample, contig) order."""
+        n = C.c_uint64()
+        check(lib.msnv_coverage_rows_count(self._h, C.byref(n)))
+        smp, ctg = np.zeros(n.value, dtype=np.uint32), np.zeros(n.value, dtype=np.uint32)
+        acc = np.zeros((n.value, COV_WORDS), dtype=np.uint64)
+        check(lib.msnv_coverage_fetch_rows(self._h, smp.ctypes.data_as(C.POINTER(C.c_uint32)), ctg.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                           acc.ctypes.data_as(C.POINTER(C.c_uint64)), n.value))
+        return smp, ctg, acc
+
     def sample_stats(self, sample_idx):
         st = SampleStats()
         check(lib.msnv_dataset_sample_stats(self._h, sample_idx, C.byref(st)))

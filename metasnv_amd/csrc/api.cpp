@@ -721,11 +721,14 @@ static int fetch_results(msnv_dataset *ds) {
     if (int r2 = dev_download(tcell.data(), d.tile_cell_base, (uint64_t)ds->n_tiles * sizeof(unsigned long long))) return r2;
     const uint64_t n_cells = d.last_cells;
     std::vector<msnv_site_sample> raw((size_t)n_cells);
-    if (int r2 = dev_download(raw.data(), d.out, raw.size() * sizeof(msnv_site_sample))) return r2;
-    {   // the per-sample coverage is a column of its own on the device (device.h): merged into the records here
-        std::vector<uint16_t> cov((size_t)n_cells);
-        if (int r2 = dev_download(cov.data(), d.cov_col, cov.size() * sizeof(uint16_t))) return r2;
-        for (size_t i = 0; i < raw.size(); ++i) raw[i].cov = cov[i];
+    {   // five u16 columns on the device (coverage and the four allele counts, device.h): zipped into records here
+        std::vector<uint16_t> col((size_t)n_cells);
+        if (int r2 = dev_download(col.data(), d.cov_col, col.size() * sizeof(uint16_t))) return r2;
+        for (size_t i = 0; i < raw.size(); ++i) raw[i].cov = col[i];
+        for (int x = 0; x < 4; ++x) {
+            if (int r2 = dev_download(col.data(), d.ncol + (uint64_t)x * d.cap_cells, col.size() * sizeof(uint16_t))) return r2;
+            for (size_t i = 0; i < raw.size(); ++i) raw[i].n[x] = col[i];
+        }
     }
 
     ds->sites.clear(); ds->site_samples.clear(); ds->site_dev_index.clear();
@@ -1069,9 +1072,35 @@ extern "C" int msnv_coverage_fetch(msnv_dataset *ds, uint64_t *acc, uint64_t cap
     clear_error();
     if (!ds || !acc) return fail(MSNV_EINVAL, "msnv_coverage_fetch: NULL argument");
     if (!ds->have_coverage) return fail(MSNV_EINVAL, "no coverage results: call msnv_coverage_run first");
-    if (capacity_words < ds->cov_acc.size()) return fail(MSNV_ECAPACITY, "capacity %llu < %zu words", (unsigned long long)capacity_words, ds->cov_acc.size());
+    const uint64_t words = (uint64_t)ds->samples.size() * ds->names.size() * (1 + COV_BINS);
+    if (capacity_words < words) return fail(MSNV_ECAPACITY, "capacity %llu < %llu words", (unsigned long long)capacity_words, (unsigned long long)words);
     static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "accumulators are 64-bit");
-    memcpy(acc, ds->cov_acc.data(), ds->cov_acc.size() * sizeof(uint64_t));
+    memset(acc, 0, words * sizeof(uint64_t));
+    for (size_t r = 0; r < ds->cov_row_sample.size(); ++r)
+        memcpy(acc + ((uint64_t)ds->cov_row_sample[r] * ds->names.size() + ds->cov_row_contig[r]) * (1 + COV_BINS), &ds->cov_acc[r * (1 + COV_BINS)], (1 + COV_BINS) * sizeof(uint64_t));
+    return MSNV_OK;
+}
+
+extern "C" int msnv_coverage_rows_count(const msnv_dataset *ds, uint64_t *n_rows) {
+    clear_error();
+    if (!ds || !n_rows) return fail(MSNV_EINVAL, "msnv_coverage_rows_count: NULL argument");
+    if (!ds->have_coverage) return fail(MSNV_EINVAL, "no coverage results: call msnv_coverage_run first");
+    *n_rows = ds->cov_row_sample.size();
+    return MSNV_OK;
+}
+
+extern "C" int msnv_coverage_fetch_rows(msnv_dataset *ds, uint32_t *sample, uint32_t *contig, uint64_t *acc, uint64_t capacity_rows) {
+    clear_error();
+    if (!ds) return fail(MSNV_EINVAL, "msnv_coverage_fetch_rows: NULL argument");
+    if (!ds->have_coverage) return fail(MSNV_EINVAL, "no coverage results: call msnv_coverage_run first");
+    const size_t n = ds->cov_row_sample.size();
+    if (capacity_rows < n) return fail(MSNV_ECAPACITY, "capacity %llu < %zu rows", (unsigned long long)capacity_rows, n);
+    if (n && (!sample || !contig || !acc)) return fail(MSNV_EINVAL, "msnv_coverage_fetch_rows: NULL argument");
+    if (n) {
+        memcpy(sample, ds->cov_row_sample.data(), n * sizeof(uint32_t));
+        memcpy(contig, ds->cov_row_contig.data(), n * sizeof(uint32_t));
+        memcpy(acc, ds->cov_acc.data(), n * (1 + COV_BINS) * sizeof(uint64_t));
+    }
     return MSNV_OK;
 }
 

@@ -11,7 +11,7 @@ int coverage_run(msnv_dataset &ds, msnv_run_stats *stats) {
     DeviceCols &d = *ds.dev;
     msnv_run_stats st{};
     if (int rc = dev_run_coverage(d, ds.params.cov_max, ds.ctx->stream, &st)) return rc;
-    const size_t n = (size_t)d.n_samples * d.n_contigs * (1 + COV_BINS);
+    const size_t n = (size_t)d.n_cov_rows * (1 + COV_BINS);
     std::vector<unsigned long long> copies((size_t)d.cov_copies * n);
     if (int rc = dev_download(copies.data(), d.cov_acc, copies.size() * sizeof(unsigned long long))) return rc;
     ds.cov_acc.assign(n, 0);                                 // tile t added to copy t % cov_copies (device.h)
@@ -76,9 +76,12 @@ int coverage_write_rows(const std::vector<std::string> &names, const std::vector
 int coverage_write(msnv_dataset &ds, int sample, const char *cov_path, const char *detail_path) {
     if (!ds.have_coverage) return fail(MSNV_EINVAL, "no coverage results: call msnv_coverage_run first");
     if (sample < 0 || (size_t)sample >= ds.samples.size()) return fail(MSNV_EINVAL, "sample index %d out of range", sample);
-    // contigs outside this shard carry zeros (multi-GPU: the ranks' accumulators are summed before rank 0 writes, parallel.py)
-    return coverage_write_rows(ds.names, ds.lengths, ds.params.cov_max, ds.samples[(size_t)sample].st,
-                               &ds.cov_acc[(size_t)sample * ds.names.size() * (1 + COV_BINS)], cov_path, detail_path, sample);
+    // the sample's rows expanded to one per contig; contigs without reads and contigs outside this shard carry zeros (multi-GPU: rank 0
+    // receives every rank's rows before it writes, parallel.py)
+    std::vector<unsigned long long> dense(ds.names.size() * (1 + COV_BINS), 0ull);
+    for (uint64_t r = ds.cov_row_start[(size_t)sample]; r < ds.cov_row_start[(size_t)sample + 1]; ++r)
+        memcpy(&dense[(size_t)ds.cov_row_contig[(size_t)r] * (1 + COV_BINS)], &ds.cov_acc[(size_t)r * (1 + COV_BINS)], (1 + COV_BINS) * sizeof(unsigned long long));
+    return coverage_write_rows(ds.names, ds.lengths, ds.params.cov_max, ds.samples[(size_t)sample].st, dense.data(), cov_path, detail_path, sample);
 }
 
 }  // namespace msnv

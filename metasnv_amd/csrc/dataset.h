@@ -163,7 +163,10 @@ struct msnv_dataset {
     std::vector<uint32_t> site_dev_index;      // host record -> device site record
     bool ann_valid = false;                    // the device holds annotation records of the last run
     bool have_coverage = false;
-    std::vector<unsigned long long> cov_acc;   // [sample][contig][1 + COV_BINS]
+    // coverage accumulators, one row per (sample, contig) that has intervals, in (sample, contig) order
+    std::vector<uint32_t> cov_row_sample, cov_row_contig;
+    std::vector<uint64_t> cov_row_start;       // per sample: its first row (n_samples + 1)
+    std::vector<unsigned long long> cov_acc;   // [row][1 + COV_BINS] of the last coverage run
 };
 
 inline const msnv_site_sample *msnv::SiteRowView::row(const msnv_dataset &ds, size_t i, size_t S) {

@@ -106,9 +106,9 @@ struct DeviceCols {
     uint32_t *tile_nslots = nullptr; // per tile: samples that have reads in it = cells per site of that tile (kernels.hip: CellMap)
     unsigned long long *tile_cell_base = nullptr;   // per tile and pass: first cell of its sites' rows (gate kernel)
     uint64_t  cap_cells = 0, last_cells = 0;
-    msnv_site_sample *out = nullptr; // [cap_cells]: allele counts per (site, slot); the .cov field is filled in when the host fetches
-    uint16_t *cov_col = nullptr;     // [cap_cells]: per-sample coverage, a column of its own on the device (two-byte stores
-                                     // into 10-byte records are partial-line writes: gather/scatter launch 41 -> 37 us)
+    uint16_t *ncol = nullptr;        // [4][cap_cells]: mismatching A, C, G, T counts per (site, slot), one column per allele
+    uint16_t *cov_col = nullptr;     // [cap_cells]: per-sample coverage.  Structure of arrays: a site's row of cells is contiguous in every column,
+                                     // so rows can be zeroed and written 16 bytes at a time; the host zips the five columns into msnv_site_sample records
     uint8_t  *site_flags = nullptr;  // pop_mask | ind_mask << 4
     uint8_t  *site_elig = nullptr;   // alleles still open to the individual rule when the gate kernel has decided what it can (merged gather)
     uint64_t  cap_out_sites = 0, last_sites = 0;
@@ -119,7 +119,8 @@ struct DeviceCols {
     WorkItem *cov_work = nullptr;
     uint32_t *tile_len = nullptr;        // scanned indices of each tile (i < contig length)
     uint32_t *tile_contig_dev = nullptr;
-    unsigned long long *cov_acc = nullptr;   // [copy][sample][contig][1 + COV_BINS]: covSum, hist[0..]; tile t adds to copy t % cov_copies
+    unsigned long long *cov_acc = nullptr;   // [copy][row][1 + COV_BINS]: covSum, hist[0..] of every (sample, contig) that has intervals (rows: dataset.h); tile t adds to copy t % cov_copies
+    uint64_t  n_cov_rows = 0;
     uint32_t  cov_copies = 1;                // (the tiles of a long contig would otherwise queue up on one 64-byte line); summed on the host
     uint32_t  n_cov_pairs = 0, n_cov_work = 0, n_cov_work_wide = 0, n_contigs = 0;   // (the last n_cov_work_wide items hold a pair of > 32 767 intervals)
     uint64_t  n_cov_iv = 0;
@@ -132,7 +133,7 @@ struct DeviceCols {
         uint32_t *tot = nullptr; uint8_t *part = nullptr; uint8_t *spill = nullptr; Pair32 *events = nullptr, *overflow = nullptr;
         TileStage *tile_stage = nullptr;
         uint32_t *counters = nullptr; SiteRec *sites = nullptr; uint32_t *tile_site_base = nullptr, *tile_site_cnt = nullptr; unsigned long long *tile_cell_base = nullptr;
-        msnv_site_sample *out = nullptr; uint16_t *cov_col = nullptr; uint8_t *site_flags = nullptr, *site_elig = nullptr; uint32_t *ind4 = nullptr, *unc_bits = nullptr, *tile_dirty = nullptr, *unc_sites = nullptr; unsigned long long *site_row = nullptr; unsigned long long *site_bits = nullptr; uint32_t *site_rank = nullptr;
+        uint16_t *ncol = nullptr; uint16_t *cov_col = nullptr; uint8_t *site_flags = nullptr, *site_elig = nullptr; uint32_t *ind4 = nullptr, *unc_bits = nullptr, *tile_dirty = nullptr, *unc_sites = nullptr; unsigned long long *site_row = nullptr; unsigned long long *site_bits = nullptr; uint32_t *site_rank = nullptr;
         uint32_t cap_events = 0, cap_overflow = 0, cap_sites = 0, cnt_parity = 0; uint64_t cap_out_sites = 0, cap_cells = 0;
     } alt;
     void     *stream2 = nullptr;

@@ -959,6 +959,15 @@ __device__ __forceinline__ void zero_span(uint8_t *p, const uint64_t n, const ui
     if (tail0 + 2u * tid < n) *reinterpret_cast<uint16_t *>(p + tail0 + 2u * tid) = 0;                   // (tail <= 14 bytes)
 }
 
+// The per-sample cells of newly reserved sites start out zero (gather and scatter only add to them): n cells from `first` on in the five
+// u16 columns -- coverage and the four allele counts (structure of arrays: a site's row of cells is contiguous in every column)
+template <int NT>
+__device__ __forceinline__ void zero_cells(uint16_t *ncol, uint16_t *cov_col, const unsigned long long cap_cells, const unsigned long long first, const unsigned long long n, const uint32_t tid) {
+#pragma unroll
+    for (int x = 0; x < 4; ++x) zero_span<NT>(reinterpret_cast<uint8_t *>(ncol + (uint64_t)x * cap_cells + first), n * sizeof(uint16_t), tid);
+    zero_span<NT>(reinterpret_cast<uint8_t *>(cov_col + first), n * sizeof(uint16_t), tid);      // samples without reads at a position keep coverage 0
+}
+
 struct GateTile { uint32_t tile, slot_lo, slot_16, slot_w, slot_hi, vbeg, vend, n_slots; uint64_t row0; uint32_t tot_mode, staged; };   // 48 B (pack.cpp); staged: a whole-tile work item leaves the tile's candidates in a record list
 
 struct GateArgs {
@@ -968,7 +977,7 @@ struct GateArgs {
     const uint32_t *ref4, *ref_lc;
     unsigned long long *site_bits; uint32_t *site_rank; SiteRec *sites; uint32_t cap_sites; uint32_t *counters, *counters_next;
     uint32_t *tile_site_base, *tile_site_cnt; const uint32_t *active_tiles;
-    msnv_site_sample *out; uint16_t *cov_col; uint8_t *site_flags; uint32_t cap_out;
+    uint16_t *ncol; uint16_t *cov_col; uint8_t *site_flags; uint32_t cap_out;      // ncol: four columns of cap_cells u16 (A, C, G, T counts of every cell), like cov_col
     const uint32_t *tile_nslots; unsigned long long *tile_cell_base; unsigned long long cap_cells;
     const GateTile *gate_tiles; uint32_t *tile_dirty; uint32_t *unc_sites; uint32_t use_dirty; unsigned long long *block_row;
     uint8_t *site_elig; uint32_t any_split;
@@ -1011,8 +1020,7 @@ __device__ __forceinline__ void gate_flush(GateLds &L, const GateArgs &a, const 
     }
     if ((unsigned long long)base + n_sites <= a.cap_out && cb + n_cells <= a.cap_cells) {   // else: the host sees the counts and runs again with larger buffers
         // the per-sample cells of these sites start out zero: gather and scatter (one launch, side by side) only add to them
-        zero_span<GATE_NT>(reinterpret_cast<uint8_t *>(a.out + cb), n_cells * sizeof(msnv_site_sample), (uint32_t)tid);
-        zero_span<GATE_NT>(reinterpret_cast<uint8_t *>(a.cov_col + cb), n_cells * sizeof(uint16_t), (uint32_t)tid);      // samples without reads at a position keep coverage 0
+        zero_cells<GATE_NT>(a.ncol, a.cov_col, a.cap_cells, cb, n_cells, (uint32_t)tid);
     }
     // index of the first site of every 64 positions: an event finds its site as rank + popcount of the lower bits
     if ((uint32_t)tid < n_tiles * (TILE / 64)) {
@@ -1045,7 +1053,7 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
     const int min_cov = a.min_cov, min_snvs = a.min_snvs; const double min_frac = a.min_frac;
     unsigned long long *const site_bits = a.site_bits; SiteRec *const sites = a.sites;
     const uint32_t cap_sites = a.cap_sites; uint32_t *const counters = a.counters;
-    msnv_site_sample *const out = a.out; uint16_t *const cov_col = a.cov_col;
+    uint16_t *const cov_col = a.cov_col;
     const uint32_t cap_out = a.cap_out;
     __shared__ GateLds L;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1290,8 +1298,7 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
         const uint32_t base = L.base; const unsigned long long s_cell = L.cell;
         if ((uint64_t)base + total <= cap_out && s_cell + (unsigned long long)total * n_slots <= a.cap_cells) {
             const uint64_t n_cells = (uint64_t)total * n_slots;
-            zero_span<GATE_NT>(reinterpret_cast<uint8_t *>(out + s_cell), n_cells * sizeof(msnv_site_sample), (uint32_t)tid);
-            zero_span<GATE_NT>(reinterpret_cast<uint8_t *>(cov_col + s_cell), n_cells * sizeof(uint16_t), (uint32_t)tid);
+            zero_cells<GATE_NT>(a.ncol, cov_col, a.cap_cells, s_cell, n_cells, (uint32_t)tid);
         }
         if ((lane & 7) == 0) {
             a.site_rank[g0 >> 6] = base + mybase;
@@ -1410,17 +1417,15 @@ __global__ __launch_bounds__(256) void msnv_gate_staged(const GateArgs a, const 
                     if (u < a.cap_sites) a.unc_sites[u] = idx;
                 }
                 if (kind == 2u && fits) {                              // the tile's only pair: its cell is the tile's totals
-                    msnv_site_sample c;
-                    c.cov = 0; c.n[0] = (uint16_t)sr.n[0]; c.n[1] = (uint16_t)sr.n[1]; c.n[2] = (uint16_t)sr.n[2]; c.n[3] = (uint16_t)sr.n[3];
-                    a.out[cb + crel + rank] = c;
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) a.ncol[(uint64_t)x * a.cap_cells + cb + crel + rank] = (uint16_t)sr.n[x];
                     a.cov_col[cb + crel + rank] = (uint16_t)r.cov;
                 }
             }
         }
         if (kind != 2u && fits && n) {                                  // the per-sample cells of these sites start out zero (gather / scatter only add to them)
             const unsigned long long n_cells = (unsigned long long)n * n_slots;
-            zero_span<64>(reinterpret_cast<uint8_t *>(a.out + cb + crel), n_cells * sizeof(msnv_site_sample), (uint32_t)lane);
-            zero_span<64>(reinterpret_cast<uint8_t *>(a.cov_col + cb + crel), n_cells * sizeof(uint16_t), (uint32_t)lane);
+            zero_cells<64>(a.ncol, a.cov_col, a.cap_cells, cb + crel, n_cells, (uint32_t)lane);
         }
     }
 #pragma unroll
@@ -1448,7 +1453,7 @@ struct TailArgs {
     uint32_t n_merged_blocks, min_baseq;
     // individual rule inside the merged gather (a sample's reads at a site all sit in ONE group): unless a split sample needs msnv_decide_sites anyway
     uint8_t *site_flags; const uint8_t *site_elig; uint32_t ind_in_gather, min_snvs;
-    msnv_site_sample *out; uint16_t *cov_col; uint32_t cap_out; const uint32_t *active_tiles; uint32_t n_gather_blocks;
+    uint16_t *ncol; uint16_t *cov_col; uint32_t cap_out; const uint32_t *active_tiles; uint32_t n_gather_blocks;
     CellMap cells; uint32_t gather_split;
     uint32_t has_wide;                          // some work item runs the wide kernel (coverage bytes of 255 stand for an overflow-list entry the scatter half writes)
     const Pair32 *events, *overflow; uint32_t *counters; uint32_t cap_list, cap_overflow;
@@ -1461,48 +1466,57 @@ constexpr uint32_t GW_ROW = 34;                // words per LDS row of 64 slots 
 
 // Dense gather with 16-BYTE STORES (round 3).  The two-byte cell stores of the form below cost a wavefront ~540 cycles each and were all
 // the many-site gather waited for (stores off: 1.90 -> 0.38 ms on the sigma = 2 cohort).  Here a block of 64 sites x 64 SLOTS is
-// assembled in LDS -- a wavefront reads one pair's bytes at the 64 sites into the pair's slot column -- and written out as rows of
-// cells, eight cells (16 bytes) per lane.  That needs rows that start on 16 bytes: the tile's cell stride is a multiple of 8
-// (pack.cpp pads tiles of >= 16 slots) and so is its first cell (the gate kernels reserve in multiples of 8).  Only for tiles without a
-// split sample (pack.cpp marks the others: slot = pair index here, and no cell needs a sum).  Slots of merged pairs (behind the
-// others) belong to gather_merged_block: the group of eight that straddles their first slot is written cell by cell.
-__device__ __forceinline__ void gather_cov_wide(const TailArgs &a, uint32_t *s_acc, uint32_t *s_off, const uint32_t t0, const uint32_t base, const uint32_t stride,
+// assembled in LDS -- a wavefront reads one pair's bytes at the 64 sites and adds them to the pair's slot column, so the pairs of a
+// split sample sum up right there, no global atomic -- and written out as rows of cells, eight cells (16 bytes) per lane.  That needs
+// rows that start on 16 bytes: the tile's cell stride is a multiple of 8 (pack.cpp pads tiles of >= 16 slots) and so is its first
+// cell (the gate kernels reserve in multiples of 8).  Slots of merged pairs (behind the others) belong to gather_merged_block: the
+// group of eight that straddles their first slot is written cell by cell.
+constexpr uint32_t GW_MAX_BLOCKS = 256;        // 64-slot blocks of a tile (<= 16383 samples)
+__device__ __forceinline__ void gather_cov_wide(const TailArgs &a, uint32_t *s_acc, uint32_t *s_off, uint32_t *s_blk, const uint32_t t0, const uint32_t base, const uint32_t stride,
                                                 const unsigned long long cell0, const uint32_t ps, const uint32_t np, const bool tile_has_merged, const uint32_t j_lo, const uint32_t dense_n) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t nblk = (np + 63u) >> 6;
+    // slots are numbered in pair order (the pairs of a split sample share one): first pair of every block of 64 slots
+    const uint32_t n_real = (a.pairs[ps + np - 1u].pad >> 8) + 1u, nblk = (n_real + 63u) >> 6;
+    for (uint32_t kk = tid; kk < np; kk += 256u) {
+        const uint32_t sl = a.pairs[ps + kk].pad >> 8, prev = kk ? a.pairs[ps + kk - 1u].pad >> 8 : 0xffffffffu;
+        if (kk == 0u || (prev >> 6) != (sl >> 6)) s_blk[sl >> 6] = kk;
+    }
+    if (tid == 0u) s_blk[nblk] = np;
     // cells of the last group of eight that this path may write as a whole: everything when no merged pair follows, else up to the first merged slot
-    const uint32_t wide_end = tile_has_merged ? (np & ~7u) : stride;
+    const uint32_t wide_end = tile_has_merged ? (n_real & ~7u) : stride;
     for (uint32_t jj0 = 0; jj0 < dense_n; jj0 += 64u) {
         const uint32_t nS = min(64u, dense_n - jj0);
-        __syncthreads();                                            // (the block before has been written out)
+        __syncthreads();                                            // (the block before has been written out; s_blk is visible)
         if (tid < 64u) s_off[tid] = a.sites[base + j_lo + jj0 + min(tid, nS - 1u)].gpos - t0;   // (idle lanes: a valid position; their rows are not written out)
         for (uint32_t b = 0; b < nblk; ++b) {
             __syncthreads();                                        // s_off is visible; the previous 64 slots have been written out
-            const uint32_t kA = 64u * b, kB = min(np, kA + 64u);
+            for (uint32_t i = tid; i < 64u * GW_ROW; i += 256u) s_acc[i] = 0u;
+            __syncthreads();
+            const uint32_t kA = s_blk[b], kB = s_blk[b + 1u];
             const uint32_t off = s_off[lane];
             for (uint32_t kl = kA + wave; kl < kB; kl += 16u) {      // four loads in flight per lane
-                uint8_t v[4];
+                uint32_t v[4], c[4];
 #pragma unroll
-                for (uint32_t u = 0; u < 4u; ++u) v[u] = a.spill[(uint64_t)(ps + min(kl + 4u * u, kB - 1u)) * TILE + off];
+                for (uint32_t u = 0; u < 4u; ++u) {
+                    const uint32_t k = ps + min(kl + 4u * u, kB - 1u);
+                    v[u] = a.spill[(uint64_t)k * TILE + off];
+                    c[u] = (a.pairs[k].pad >> 8) - 64u * b;          // (one address for the wavefront)
+                }
 #pragma unroll
                 for (uint32_t u = 0; u < 4u; ++u)
-                    if (kl + 4u * u < kB) reinterpret_cast<uint16_t *>(s_acc + lane * GW_ROW)[kl + 4u * u - kA] = (uint16_t)v[u];
+                    if (kl + 4u * u < kB) atomicAdd(&s_acc[lane * GW_ROW + (c[u] >> 1)], v[u] << (16u * (c[u] & 1u)));
             }
             __syncthreads();
             for (uint32_t idx = tid; idx < nS * 8u; idx += 256u) {
-                const uint32_t row = idx >> 3, seg = idx & 7u, c0 = kA + 8u * seg;
-                if (c0 >= np) continue;                                  // (slots of merged pairs, padding behind the last slot: zeroed by the gate kernel)
-                const uint32_t nc = min(8u, np - c0);                    // (columns beyond the block's pairs hold stale halfwords: masked here)
-                uint2 lo = *reinterpret_cast<const uint2 *>(&s_acc[row * GW_ROW + 4u * seg]);
-                uint2 hi = *reinterpret_cast<const uint2 *>(&s_acc[row * GW_ROW + 4u * seg + 2u]);
-                uint32_t w[4] = {lo.x, lo.y, hi.x, hi.y};
+                const uint32_t row = idx >> 3, seg = idx & 7u, c0 = 64u * b + 8u * seg;
+                if (c0 >= n_real) continue;                              // (slots of merged pairs, padding behind the last slot: zeroed by the gate kernel)
+                const uint2 lo = *reinterpret_cast<const uint2 *>(&s_acc[row * GW_ROW + 4u * seg]);
+                const uint2 hi = *reinterpret_cast<const uint2 *>(&s_acc[row * GW_ROW + 4u * seg + 2u]);
                 uint16_t *dst = a.cov_col + cell0 + (uint64_t)(j_lo + jj0 + row) * stride + c0;
-                if (c0 + 8u <= wide_end) {
-#pragma unroll
-                    for (uint32_t q = 0; q < 4u; ++q) w[q] = 2u * q + 1u < nc ? w[q] : 2u * q < nc ? w[q] & 0xffffu : 0u;
-                    *reinterpret_cast<uint4 *>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
-                } else {
-                    for (uint32_t q = 0; q < nc; ++q) dst[q] = (uint16_t)(w[q >> 1] >> (16u * (q & 1u)));
+                if (c0 + 8u <= wide_end) *reinterpret_cast<uint4 *>(dst) = make_uint4(lo.x, lo.y, hi.x, hi.y);      // (columns behind the last slot are zero)
+                else {
+                    const uint32_t w[4] = {lo.x, lo.y, hi.x, hi.y};
+                    for (uint32_t q = 0; q < 8u && c0 + q < n_real; ++q) dst[q] = (uint16_t)(w[q >> 1] >> (16u * (q & 1u)));
                 }
             }
         }
@@ -1511,9 +1525,7 @@ __device__ __forceinline__ void gather_cov_wide(const TailArgs &a, uint32_t *s_a
 
 __device__ __forceinline__ void gather_cov_block(const TailArgs &a, const uint32_t bid) {
     const uint32_t GATHER_SPLIT = a.gather_split;
-    const uint32_t tile_word = a.active_tiles[bid / GATHER_SPLIT], part = bid % GATHER_SPLIT;   // a tile's sites are dealt to GATHER_SPLIT workgroups
-    const uint32_t tile = tile_word & 0x7fffffffu;
-    const bool tile_split = (tile_word >> 31) != 0u;                // some sample of the tile was split into several pairs (pack.cpp: gather_tiles)
+    const uint32_t tile = a.active_tiles[bid / GATHER_SPLIT], part = bid % GATHER_SPLIT;   // a tile's sites are dealt to GATHER_SPLIT workgroups
     const uint32_t n = a.tile_site_cnt[tile];
     if (n <= part) return;
     const uint32_t base = a.tile_site_base[tile];
@@ -1535,9 +1547,9 @@ __device__ __forceinline__ void gather_cov_block(const TailArgs &a, const uint32
         // GATHER_SPLIT-th one, as below, spreads each 128-byte line of the cell rows over workgroups on different XCDs).
         const uint32_t j_lo = min(n, part * share), dense_n = min(n, j_lo + share) - j_lo;
         __shared__ __attribute__((aligned(8))) uint32_t s_lds[64 * GW_ROW];      // one block for both forms of the dense gather
-        __shared__ uint32_t s_off[64], s_pad[64];
-        if ((n_slots & 7u) == 0u && (cell0 & 7ull) == 0ull && !tile_split && !a.has_wide) {      // (uniform)
-            gather_cov_wide(a, s_lds, s_off, t0, base, n_slots, cell0, ps, np, a.tile_pair_merged[tile] < a.tile_pair_start[tile + 1u], j_lo, dense_n);
+        __shared__ uint32_t s_off[64], s_pad[64], s_blk[GW_MAX_BLOCKS + 2];
+        if ((n_slots & 7u) == 0u && (cell0 & 7ull) == 0ull && !a.has_wide) {      // (uniform)
+            gather_cov_wide(a, s_lds, s_off, s_blk, t0, base, n_slots, cell0, ps, np, a.tile_pair_merged[tile] < a.tile_pair_start[tile + 1u], j_lo, dense_n);
             return;
         }
         uint8_t (*s_t)[GD_ROW] = reinterpret_cast<uint8_t (*)[GD_ROW]>(s_lds);
@@ -1595,7 +1607,7 @@ __device__ __forceinline__ void scatter_events_block(const TailArgs &a, const ui
         if (!(w & bit)) return;                    // most events are sequencing errors at positions that are not sites
         const unsigned long long row = row0 + (unsigned long long)__popcll(w & (bit - 1ull)) * ns;
         // events carry the SLOT of their sample in the tile (pack.cpp)
-        if (allele) add_u16(&a.out[row + (e.y >> 18)].n[(e.y >> 16) & 3u], e.y & 0xffffu);   // one event per (site, pair, allele)
+        if (allele) add_u16(&a.ncol[(uint64_t)((e.y >> 16) & 3u) * a.cells.cap_cells + row + (e.y >> 18)], e.y & 0xffffu);   // one event per (site, pair, allele)
         else a.cov_col[row + (e.y >> 16)] = (uint16_t)(e.y & 0xffffu);
     };
     const uint32_t n_k = min(a.counters[16u + k * EV_CNT_STRIDE], a.cap_list);
@@ -1615,7 +1627,7 @@ __device__ __forceinline__ void scatter_events_block(const TailArgs &a, const ui
                 const unsigned long long bit = 1ull << (e[u].x & 63u);
                 if (!(w[u] & bit)) continue;
                 const unsigned long long row = row0[u] + (unsigned long long)__popcll(w[u] & (bit - 1ull)) * ns[u];
-                add_u16(&a.out[row + (e[u].y >> 18)].n[(e[u].y >> 16) & 3u], e[u].y & 0xffffu);
+                add_u16(&a.ncol[(uint64_t)((e[u].y >> 16) & 3u) * a.cells.cap_cells + row + (e[u].y >> 18)], e[u].y & 0xffffu);
             }
         }
         for (; i < n_k; i += stride) apply(list[i], true);
@@ -1703,7 +1715,7 @@ __device__ __forceinline__ void gather_merged_block(const TailArgs &a, const uin
 #pragma unroll
                     for (uint32_t x = 0; x < 4; ++x) {
                         const uint32_t cnt = (al >> (8u * x)) & 0xffu;
-                        if (cnt) a.out[cell].n[x] = (uint16_t)cnt;
+                        if (cnt) a.ncol[(uint64_t)x * a.cells.cap_cells + cell] = (uint16_t)cnt;
                         if (cnt >= a.min_snvs) ind |= 1u << x;
                     }
                     // call_vC.cpp:593-600: this sample holds >= t reads of an allele the gate kernel left open -> individual call
@@ -1761,7 +1773,7 @@ __global__ __launch_bounds__(256) void msnv_gather_scatter(TailArgs a) {
 //   individual  iff not population and some sample has x_s >= t              (:593-600)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void msnv_decide_sites(const SiteRec *sites, const uint32_t *unc_sites, uint32_t *counters, uint32_t cap_sites, uint32_t cap_out,
-                                                         const uint32_t *ref4, const uint32_t *ref_lc, const msnv_site_sample *out,
+                                                         const uint32_t *ref4, const uint32_t *ref_lc, const uint16_t *ncol,
                                                          const CellMap cells, int min_snvs, double min_frac, uint8_t *site_flags) {
     // Only the sites the gate kernel could not decide: some allele x has n_x >= t, is no population call, no single pair holds
     // >= t reads of it, but a sample that is split into several pairs / sits in a merged group holds some -- the individual rule
@@ -1787,7 +1799,7 @@ __global__ __launch_bounds__(256) void msnv_decide_sites(const SiteRec *sites, c
                 const uint32_t tile = s.gpos / TILE, n_slots = cells.tile_nslots[tile];
                 const uint64_t row = cell_of(cells, tile, site, 0u);
                 for (uint32_t i = lane; i < n_slots; i += 64)
-                    any |= (int)out[row + i].n[x] >= min_snvs;
+                    any |= (int)ncol[(uint64_t)x * cells.cap_cells + row + i] >= min_snvs;
                 if (__any(any)) ind |= 1u << x;
             }
             if (lane == 0) {
@@ -1836,8 +1848,8 @@ __device__ __forceinline__ uint32_t row_sum16(uint32_t x) {
 // start: a handful of work items at most).
 template <bool WIDE>
 __global__ __launch_bounds__(C_NT) void msnv_coverage_tiles(const Pair32 *iv, const TilePair *pairs,
-                                                            const WorkItem *work, const uint32_t *tile_len, const uint32_t *tile_contig,
-                                                            unsigned long long *acc, uint32_t n_contigs, int max_cov, uint32_t n_samples, uint32_t n_copies,
+                                                            const WorkItem *work, const uint32_t *tile_len,
+                                                            unsigned long long *acc, uint32_t n_rows, int max_cov, uint32_t n_copies,
                                                             const uint64_t n_iv) {
     // One WAVEFRONT per (tile, sample) pair, no workgroup barrier at all, and the work follows the BREAKPOINTS of the coverage
     // instead of the positions: an interval adds +1 / -1 to the difference array in LDS and sets the bit of either end in a
@@ -1854,7 +1866,7 @@ __global__ __launch_bounds__(C_NT) void msnv_coverage_tiles(const Pair32 *iv, co
     __shared__ __attribute__((aligned(16))) uint32_t s_d[C_NT / 64][64 * LSTRIDE];
     __shared__ uint32_t s_mask[C_NT / 64][TILE / 32];
     const WorkItem w = work[blockIdx.x];
-    const uint32_t t0 = w.tile * TILE, tl = tile_len[w.tile], contig = tile_contig[w.tile];
+    const uint32_t t0 = w.tile * TILE, tl = tile_len[w.tile];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t *const d = s_d[wave];
     uint32_t *const mask = s_mask[wave];
@@ -1998,7 +2010,9 @@ __global__ __launch_bounds__(C_NT) void msnv_coverage_tiles(const Pair32 *iv, co
         uint32_t idx = 1u + bin;
         if (lane == 4) { val = ws; idx = 0u; }
         if ((k < 4u || lane == 4) && val && idx <= (uint32_t)max_cov + 1u) {
-            unsigned long long *dst = acc + (((uint64_t)(w.tile % n_copies) * n_samples + pr.sample) * n_contigs + contig) * (1 + COV_BINS);
+            // one accumulator row per (sample, contig) that HAS intervals (pack.cpp numbers them; TilePair::max_depth carries the row): a
+            // 500-sample cohort over a million contigs would need 100 GB as a dense [sample][contig] table, and holds a few million rows
+            unsigned long long *dst = acc + ((uint64_t)(w.tile % n_copies) * n_rows + pr.max_depth) * (1 + COV_BINS);
             atomicAdd(&dst[idx], (unsigned long long)(long long)val);
         }
     }
@@ -2037,7 +2051,7 @@ void dev_stream_destroy(void *stream) { if (stream) (void)hipStreamDestroy((hipS
 void dev_free_all(DeviceCols &d) {
     void *ptrs[] = {d.hdr, d.hdr8, d.hdr8m, d.merged_groups, d.tile_pair_merged, d.blk, d.seq, d.qual, d.s_read_base, d.s_seq_base, d.ref4, d.ref_lc, d.pairs,
                     d.tile_pair_start, d.work, d.chunks, d.tile_vbeg, d.tile_vend, d.tot, d.part, d.tile_slot_start, d.tile_slot_u16, d.tile_slot_wide, d.slot_off, d.spill, d.events, d.overflow, d.counters, d.ind4, d.tile_dirty, d.unc_sites, d.site_row, d.gate_tiles,
-                    d.sites, d.tile_site_base, d.tile_site_cnt, d.tile_cell_base, d.tile_nslots, d.out, d.cov_col, d.site_flags, d.site_elig,
+                    d.sites, d.tile_site_base, d.tile_site_cnt, d.tile_cell_base, d.tile_nslots, d.ncol, d.cov_col, d.site_flags, d.site_elig,
                     d.cov_iv, d.s_cov_base, d.cov_pairs, d.cov_work, d.tile_len, d.tile_contig_dev, d.cov_acc, d.tile_stage, d.tile_stage_idx, d.alt.tile_stage, d.gate_tiles_dense, d.gate_tiles_staged, d.gather_tiles};
     for (void *p : ptrs) dev_free(p);
     void *aptrs[] = {d.ann.seg_beg, d.ann.seg_end, d.ann.seg_gene, d.ann.genes, d.ann.contigs, d.ann.codons, d.ann.out, d.ann.err};
@@ -2046,7 +2060,7 @@ void dev_free_all(DeviceCols &d) {
     for (void *e : d.event_pool) (void)hipEventDestroy((hipEvent_t)e);
     if (d.pinned_cnt) (void)hipHostFree(d.pinned_cnt);
     void *alts[] = {d.alt.tot, d.alt.part, d.alt.spill, d.alt.events, d.alt.overflow, d.alt.counters, d.alt.ind4, d.alt.tile_dirty, d.alt.unc_sites, d.alt.site_row, d.alt.sites, d.alt.tile_site_base,
-                    d.alt.tile_site_cnt, d.alt.tile_cell_base, d.alt.out, d.alt.cov_col, d.alt.site_flags, d.alt.site_elig, d.alt.site_bits, d.site_bits, d.alt.site_rank, d.site_rank, d.active_tiles};
+                    d.alt.tile_site_cnt, d.alt.tile_cell_base, d.alt.ncol, d.alt.cov_col, d.alt.site_flags, d.alt.site_elig, d.alt.site_bits, d.site_bits, d.alt.site_rank, d.site_rank, d.active_tiles};
     for (void *p : alts) dev_free(p);
     if (d.stream2) (void)hipStreamDestroy((hipStream_t)d.stream2);
     d = DeviceCols{};
@@ -2062,10 +2076,10 @@ static int ensure_out(DeviceCols &d, uint64_t n_sites, uint64_t n_cells) {
         d.cap_out_sites = cap;
     }
     if (n_cells > d.cap_cells) {
-        dev_free(d.out); dev_free(d.cov_col);
-        d.out = nullptr; d.cov_col = nullptr;
-        const uint64_t cap = std::max<uint64_t>(n_cells + n_cells / 4, 1u << 16);
-        if (int rc = dev_alloc((void **)&d.out, cap * sizeof(msnv_site_sample), &d.device_bytes)) return rc;
+        dev_free(d.ncol); dev_free(d.cov_col);
+        d.ncol = nullptr; d.cov_col = nullptr;
+        const uint64_t cap = (std::max<uint64_t>(n_cells + n_cells / 4, 1u << 16) + 7) & ~7ull;      // (a multiple of 8: every column starts on 16 bytes)
+        if (int rc = dev_alloc((void **)&d.ncol, 4 * cap * sizeof(uint16_t) + 16, &d.device_bytes)) return rc;
         if (int rc = dev_alloc((void **)&d.cov_col, cap * sizeof(uint16_t) + 16, &d.device_bytes)) return rc;
         d.cap_cells = cap;
     }
@@ -2122,7 +2136,7 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
         g.ind4 = d.ind4; g.unc_bits = d.unc_bits; g.ref4 = d.ref4; g.ref_lc = d.ref_lc;
         g.site_bits = d.site_bits; g.site_rank = d.site_rank; g.sites = d.sites; g.cap_sites = d.cap_sites; g.counters = counters; g.counters_next = counters_next;
         g.tile_site_base = d.tile_site_base; g.tile_site_cnt = d.tile_site_cnt; g.active_tiles = d.active_tiles;
-        g.out = d.out; g.cov_col = d.cov_col; g.site_flags = d.site_flags; g.cap_out = cap_out;
+        g.ncol = d.ncol; g.cov_col = d.cov_col; g.site_flags = d.site_flags; g.cap_out = cap_out;
         g.gate_tiles = reinterpret_cast<const GateTile *>(d.gate_tiles); g.tile_dirty = d.tile_dirty; g.unc_sites = d.unc_sites;
         g.use_dirty = d.use_dirty ? 1u : 0u; g.block_row = d.site_row; g.site_elig = d.site_elig; g.any_split = d.any_split ? 1u : 0u;
         static_assert(sizeof(GateTile) == sizeof(DeviceCols::GateTileH) && sizeof(GateTile) == 48, "gate tile descriptor");
@@ -2156,7 +2170,7 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
     if (d.n_active_tiles) {
         TailArgs ta;
         ta.sites = d.sites; ta.tile_site_base = d.tile_site_base; ta.tile_site_cnt = d.tile_site_cnt; ta.tile_pair_start = d.tile_pair_start;
-        ta.pairs = d.pairs; ta.spill = d.spill; ta.out = d.out; ta.cov_col = d.cov_col; ta.cap_out = cap_out; ta.active_tiles = d.gather_tiles;
+        ta.pairs = d.pairs; ta.spill = d.spill; ta.ncol = d.ncol; ta.cov_col = d.cov_col; ta.cap_out = cap_out; ta.active_tiles = d.gather_tiles;
         ta.cells = CellMap{d.tile_site_base, d.tile_cell_base, d.tile_nslots, d.cap_cells, d.site_row};
         ta.gather_split = d.gather_split;
         ta.has_wide = d.n_work > d.n_work_narrow + d.n_work_merged ? 1u : 0u;
@@ -2177,7 +2191,7 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
         // of a deep, uneven cohort took 1.6 ms)
         static const uint32_t decide_grid = dev_resident_workgroups(8);          // (queried once: the device properties call is slow)
         hipLaunchKernelGGL(msnv_decide_sites, dim3(decide_grid), dim3(256), 0, st, d.sites, d.unc_sites, counters, d.cap_sites, cap_out, d.ref4, d.ref_lc,
-                           d.out, CellMap{d.tile_site_base, d.tile_cell_base, d.tile_nslots, d.cap_cells, d.site_row}, p.calling_threshold, p.min_fraction, d.site_flags);
+                           d.ncol, CellMap{d.tile_site_base, d.tile_cell_base, d.tile_nslots, d.cap_cells, d.site_row}, p.calling_threshold, p.min_fraction, d.site_flags);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipMemcpyAsync(host_cnt, counters, CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -2236,7 +2250,7 @@ static int ensure_alt(DeviceCols &d) {
     DeviceCols::AltBufs &a = d.alt;
     const uint64_t npos = (uint64_t)d.n_tiles * TILE;
     if (a.tot && a.cap_events == d.cap_events && a.cap_overflow == d.cap_overflow && a.cap_sites == d.cap_sites && a.cap_out_sites == d.cap_out_sites && a.cap_cells == d.cap_cells) return MSNV_OK;
-    void *old[] = {a.tot, a.part, a.spill, a.events, a.overflow, a.counters, a.ind4, a.tile_dirty, a.unc_sites, a.site_row, a.sites, a.tile_site_base, a.tile_site_cnt, a.tile_cell_base, a.out, a.cov_col, a.site_flags, a.site_elig, a.site_bits, a.site_rank, a.tile_stage};
+    void *old[] = {a.tot, a.part, a.spill, a.events, a.overflow, a.counters, a.ind4, a.tile_dirty, a.unc_sites, a.site_row, a.sites, a.tile_site_base, a.tile_site_cnt, a.tile_cell_base, a.ncol, a.cov_col, a.site_flags, a.site_elig, a.site_bits, a.site_rank, a.tile_stage};
     for (void *p : old) dev_free(p);
     a = DeviceCols::AltBufs{};
     if (int rc = dev_alloc((void **)&a.tot, std::max<uint64_t>(1, 4 * npos) * sizeof(uint32_t), &d.device_bytes)) return rc;
@@ -2262,7 +2276,7 @@ static int ensure_alt(DeviceCols &d) {
     if (int rc = dev_memset(a.tile_site_cnt, 0, ((uint64_t)d.n_tiles + 1) * sizeof(uint32_t))) return rc;
     if (int rc = dev_memset(a.tile_site_base, 0, ((uint64_t)d.n_tiles + 1) * sizeof(uint32_t))) return rc;
     if (int rc = dev_alloc((void **)&a.tile_cell_base, ((uint64_t)d.n_tiles + 1) * sizeof(unsigned long long), &d.device_bytes)) return rc;
-    if (int rc = dev_alloc((void **)&a.out, d.cap_cells * sizeof(msnv_site_sample), &d.device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&a.ncol, 4 * d.cap_cells * sizeof(uint16_t) + 16, &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.cov_col, d.cap_cells * sizeof(uint16_t) + 16, &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.site_flags, d.cap_out_sites + 4, &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.site_elig, d.cap_out_sites + 4, &d.device_bytes)) return rc;
@@ -2277,7 +2291,7 @@ static void swap_sets(DeviceCols &d) {
     DeviceCols::AltBufs &a = d.alt;
     std::swap(d.tot, a.tot); std::swap(d.part, a.part); std::swap(d.spill, a.spill); std::swap(d.events, a.events);
     std::swap(d.overflow, a.overflow); std::swap(d.counters, a.counters); std::swap(d.sites, a.sites);
-    std::swap(d.tile_site_base, a.tile_site_base); std::swap(d.tile_site_cnt, a.tile_site_cnt); std::swap(d.tile_cell_base, a.tile_cell_base); std::swap(d.out, a.out); std::swap(d.cov_col, a.cov_col);
+    std::swap(d.tile_site_base, a.tile_site_base); std::swap(d.tile_site_cnt, a.tile_site_cnt); std::swap(d.tile_cell_base, a.tile_cell_base); std::swap(d.ncol, a.ncol); std::swap(d.cov_col, a.cov_col);
     std::swap(d.site_flags, a.site_flags); std::swap(d.site_elig, a.site_elig); std::swap(d.ind4, a.ind4); std::swap(d.unc_bits, a.unc_bits); std::swap(d.cnt_parity, a.cnt_parity);
     if (a.tile_stage) std::swap(d.tile_stage, a.tile_stage);
     std::swap(d.tile_dirty, a.tile_dirty); std::swap(d.unc_sites, a.unc_sites); std::swap(d.site_row, a.site_row); std::swap(d.site_bits, a.site_bits); std::swap(d.site_rank, a.site_rank);
@@ -2358,14 +2372,14 @@ int dev_run_coverage(DeviceCols &d, int max_cov, void *stream_, msnv_run_stats *
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, st));
-    HIP_TRY(hipMemsetAsync(d.cov_acc, 0, (uint64_t)d.cov_copies * d.n_samples * d.n_contigs * (1 + COV_BINS) * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(d.cov_acc, 0, (uint64_t)d.cov_copies * std::max<uint64_t>(1, d.n_cov_rows) * (1 + COV_BINS) * sizeof(unsigned long long), st));
     if (d.n_cov_work) {
         // work items that hold a pair of more than 32 767 intervals are the last n_cov_work_wide of the list (pack.cpp)
         const uint32_t n_narrow = d.n_cov_work - d.n_cov_work_wide;
         if (n_narrow) hipLaunchKernelGGL(msnv_coverage_tiles<false>, dim3(n_narrow), dim3(C_NT), 0, st, d.cov_iv, d.cov_pairs, d.cov_work,
-                                         d.tile_len, d.tile_contig_dev, d.cov_acc, d.n_contigs, max_cov, d.n_samples, d.cov_copies, d.n_cov_iv);
+                                         d.tile_len, d.cov_acc, (uint32_t)d.n_cov_rows, max_cov, d.cov_copies, d.n_cov_iv);
         if (d.n_cov_work_wide) hipLaunchKernelGGL(msnv_coverage_tiles<true>, dim3(d.n_cov_work_wide), dim3(C_NT), 0, st, d.cov_iv, d.cov_pairs, d.cov_work + n_narrow,
-                                                  d.tile_len, d.tile_contig_dev, d.cov_acc, d.n_contigs, max_cov, d.n_samples, d.cov_copies, d.n_cov_iv);
+                                                  d.tile_len, d.cov_acc, (uint32_t)d.n_cov_rows, max_cov, d.cov_copies, d.n_cov_iv);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(e1, st));

@@ -9,6 +9,7 @@
 #include <climits>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <queue>
 #include <thread>
 #include <unordered_map>
@@ -17,9 +18,9 @@
 
 namespace msnv {
 
-// Piece alignment in the seq column (bytes; the qual column is twice that).  Measured on one box, pileup kernel:
-// 16 -> 0.725 ms, 8 -> 0.665, 4 -> 0.664, 2 -> 0.651, 1 -> 0.672: padding is HBM traffic, misalignment costs the
-// vector-memory path about as much as it saves below 8.  The compact headers store seq offsets in 8-byte units.
+// Piece alignment in the seq column (bytes; the qual column is twice that): dataset.h SEQ_ALIGN, 2 bytes since round 3 (round 1,
+// 16 bases per lane: 16 -> 0.725 ms, 8 -> 0.665, 4 -> 0.664, 2 -> 0.651; round 3, 32 bases per lane: 8 -> 0.573, 4 -> 0.548, 2 -> 0.547).
+// The compact headers store seq offsets in SEQ_ALIGN units.
 constexpr uint32_t seq_align = SEQ_ALIGN;
 
 // Layout of the narrow path: padded per-piece columns (msnv_pileup_tiles_narrow32) or the dense block stream
@@ -98,19 +99,20 @@ static void split_deep_runs(SampleCols &sc) {
     }
     // The bases and qualities follow their headers: a group's pieces were every G-th piece of the run in memory, so the workgroups
     // of the G groups -- at G different times -- each fetched (almost) every cache line of the run (one sample at 1600x: 6.2 GB of
-    // HBM reads per pass for 2.2 GB of columns).  Same blocks (8 bytes of bases + 16 of qualities per 16 bases of a piece), new order.
+    // HBM reads per pass for 2.2 GB of columns).  Same pieces (bases + twice as many quality bytes, alignment padding included), new order.
     if (any_split && !(getenv("MSNV_DEEP_RELOCATE") && getenv("MSNV_DEEP_RELOCATE")[0] == '0')) {
         std::vector<uint8_t> nseq(sc.seq.size(), 0xff), nqual(sc.qual.size(), 0);
         size_t so = 0;
+        auto stored = [](uint32_t bases) { return (size_t)(((bases + 1u) / 2u + seq_align - 1u) & ~(seq_align - 1u)); };      // seq bytes of a piece with its alignment padding (pack_sample)
         for (size_t k = 0; k < n; ++k) {
-            const size_t blk = (size_t)((sc.hdr[k].cig + 15u) / 16u) * 8u;
+            const size_t blk = stored(sc.hdr[k].cig);
             if (so + blk > nseq.size() || 2 * (so + blk) > nqual.size()) return;       // (cannot happen: the blocks are a permutation; keep the old layout rather than write past the end)
             memcpy(nseq.data() + so, sc.seq.data() + sc.hdr[k].seqoff, blk);
             memcpy(nqual.data() + 2 * so, sc.qual.data() + 2 * (size_t)sc.hdr[k].seqoff, 2 * blk);
             so += blk;
         }
         so = 0;
-        for (size_t k = 0; k < n; ++k) { sc.hdr[k].seqoff = (uint32_t)so; so += (size_t)((sc.hdr[k].cig + 15u) / 16u) * 8u; }
+        for (size_t k = 0; k < n; ++k) { sc.hdr[k].seqoff = (uint32_t)so; so += stored(sc.hdr[k].cig); }
         sc.seq.swap(nseq); sc.qual.swap(nqual);
     }
 }
@@ -672,6 +674,18 @@ int pack_sample(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, Sa
     return MSNV_OK;
 }
 
+// Index loops of finalize that run per sample (16 M pieces on the benchmark shape, 6e8 at BASELINE configs[2] scale): dealt to host threads.
+template <typename F>
+static void parallel_for(size_t n, F fn) {
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const size_t nt = std::min<size_t>(std::min<size_t>(n, hw), 64);
+    if (nt <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < nt; ++t) th.emplace_back([&]() { for (;;) { const size_t i = next.fetch_add(1); if (i >= n) break; fn(i); } });
+    for (auto &t : th) t.join();
+}
+
 template <typename T>
 static int upload_vec(T **dst, const std::vector<T> &v, uint64_t *acct, size_t pad_elems = 0) {
     if (int rc = dev_alloc((void **)dst, (v.size() + pad_elems) * sizeof(T), acct)) return rc;
@@ -687,11 +701,24 @@ int finalize_dataset(msnv_dataset &ds) {
     // ---- tile layout: every selected contig owns ceil(max(L, furthest read end) / TILE) tiles
     std::vector<int64_t> maxend(NC, 0);
     for (size_t c = 0; c < NC; ++c) maxend[c] = ds.sel[c] ? ds.lengths[c] : 0;
-    for (const SampleCols &sc : ds.samples)
     {
-        for (size_t i = 0; i < sc.hdr.size(); ++i) maxend[(size_t)sc.tid[i]] = std::max<int64_t>(maxend[(size_t)sc.tid[i]], sc.end[i]);
-        for (size_t i = 0; i < sc.cov_tid.size(); ++i)
-            if (ds.sel[(size_t)sc.cov_tid[i]]) maxend[(size_t)sc.cov_tid[i]] = std::max<int64_t>(maxend[(size_t)sc.cov_tid[i]], std::min<int64_t>((int64_t)sc.cov_beg[i] + 1, ds.lengths[(size_t)sc.cov_tid[i]]));
+        // per sample: the contigs it touches and how far (reads are sorted by contig: runs), merged under a lock
+        std::mutex mu;
+        parallel_for(S, [&](size_t s) {
+            const SampleCols &sc = ds.samples[s];
+            std::vector<std::pair<int32_t, int64_t>> mine;
+            for (size_t i = 0; i < sc.hdr.size(); ++i) {
+                if (mine.empty() || mine.back().first != sc.tid[i]) mine.emplace_back(sc.tid[i], 0);
+                mine.back().second = std::max<int64_t>(mine.back().second, sc.end[i]);
+            }
+            for (size_t i = 0; i < sc.cov_tid.size(); ++i) {
+                if (!ds.sel[(size_t)sc.cov_tid[i]]) continue;
+                if (mine.empty() || mine.back().first != sc.cov_tid[i]) mine.emplace_back(sc.cov_tid[i], 0);
+                mine.back().second = std::max<int64_t>(mine.back().second, std::min<int64_t>((int64_t)sc.cov_beg[i] + 1, ds.lengths[(size_t)sc.cov_tid[i]]));
+            }
+            std::lock_guard<std::mutex> lk(mu);
+            for (const auto &m : mine) maxend[(size_t)m.first] = std::max(maxend[(size_t)m.first], m.second);
+        });
     }
     ds.tile_base.assign(NC, UINT32_MAX);
     ds.tile_contig.clear();
@@ -750,17 +777,18 @@ int finalize_dataset(msnv_dataset &ds) {
     }
 
     // ---- per sample: gpos, tile overlap index; concatenate columns
-    for (SampleCols &sc : ds.samples) split_deep_runs(sc);
+    parallel_for(S, [&](size_t s) { split_deep_runs(ds.samples[s]); });
     uint64_t all_pieces = 0, all_bases = 0;
     for (const SampleCols &sc : ds.samples) { all_pieces += sc.hdr.size(); all_bases += sc.n_pileup_bases; }
     const bool dense = layout_dense(all_pieces, all_bases);
     d->dense = dense;
     if (dense) {
-        for (SampleCols &sc : ds.samples) {
+        parallel_for(S, [&](size_t s) {
+            SampleCols &sc = ds.samples[s];
             relayout_dense(sc);
             for (int i = 0; i < 32; ++i) sc.seq.push_back(0xff);     // tail padding as in pack_sample
             while (sc.qual.size() < 2 * sc.seq.size()) sc.qual.push_back(0);
-        }
+        });
     }
     std::vector<uint64_t> rbase(S + 1, 0), sbase(S + 1, 0), bbase(S + 1, 0);
     for (size_t s = 0; s < S; ++s) {
@@ -772,7 +800,7 @@ int finalize_dataset(msnv_dataset &ds) {
     std::vector<std::vector<PairTmp>> per_sample(S);
     ds.first_tid = -1; ds.first_pos = -1;
     uint64_t tot_reads = 0, tot_pile_reads = 0, tot_bases = 0;
-    for (size_t s = 0; s < S; ++s) {
+    parallel_for(S, [&](size_t s) {
         SampleCols &sc = ds.samples[s];
         std::vector<PairTmp> &pv = per_sample[s];
         // pieces are grouped by tile: one pair per run
@@ -801,6 +829,9 @@ int finalize_dataset(msnv_dataset &ds) {
             for (uint32_t i = p.lo; i < p.hi; ++i) m = std::max<uint32_t>(m, sc.depth[i]);
             p.maxd = m;
         }
+    });
+    for (size_t s = 0; s < S; ++s) {
+        const SampleCols &sc = ds.samples[s];
         tot_reads += sc.hdr.size(); tot_pile_reads += sc.n_pileup_reads; tot_bases += sc.n_pileup_bases;
         if (sc.first_tid >= 0 && (ds.first_tid < 0 || sc.first_tid < ds.first_tid || (sc.first_tid == ds.first_tid && sc.first_beg < ds.first_pos))) {
             ds.first_tid = sc.first_tid; ds.first_pos = sc.first_beg;
@@ -1034,11 +1065,7 @@ int finalize_dataset(msnv_dataset &ds) {
         // cohort -- would each cost a workgroup that looks its tile up and leaves)
         {
             std::vector<uint32_t> gather_tiles;
-            for (uint32_t t : active) if (tpm[t] > tps[t]) {
-                bool split = false;                                   // bit 31: a sample of the tile was split into several pairs (their cells are sums)
-                for (uint32_t k = tps[t]; k < tpm[t] && !split; ++k) split = (pairs[k].pad & 0xffu) == 1u;
-                gather_tiles.push_back(t | (split ? 0x80000000u : 0u));
-            }
+            for (uint32_t t : active) if (tpm[t] > tps[t]) gather_tiles.push_back(t);
             d->n_gather_tiles = (uint32_t)gather_tiles.size();
             if (int rc = upload_vec(&d->gather_tiles, gather_tiles, &d->device_bytes, 1)) return rc;
         }
@@ -1156,28 +1183,49 @@ int finalize_dataset(msnv_dataset &ds) {
     if (int rc = dev_alloc((void **)&d->seq, sbase[S] + 256, &d->device_bytes)) return rc;     // lanes past the end of the last piece read on
     if (int rc = dev_alloc((void **)&d->qual, 2 * sbase[S] + 512, &d->device_bytes)) return rc;
     uint64_t alg = 0;
-    for (size_t s = 0; s < S; ++s) {
-        SampleCols &sc = ds.samples[s];
-        if (int rc = dev_upload(d->hdr + rbase[s], sc.hdr.data(), sc.hdr.size() * sizeof(ReadHdr))) return rc;
-        if (dense) {
-            if (int rc = dev_upload(d->blk + bbase[s], sc.blk.data(), sc.blk.size() * sizeof(uint32_t))) return rc;
-            ds.info.bytes_headers += sc.blk.size() * sizeof(uint32_t);
-            std::vector<uint32_t>().swap(sc.blk);
-        } else {   // compact tile-local headers of the narrow kernel: {start in tile | length << 11, seq offset / 8}
-            std::vector<PieceHdr> h8(sc.hdr.size());
-            for (size_t i = 0; i < sc.hdr.size(); ++i) h8[i] = PieceHdr{(sc.hdr[i].gpos % TILE) | sc.hdr[i].cig << 11, sc.hdr[i].seqoff >> SEQ_ALIGN_LOG2};
-            if (int rc = dev_upload(d->hdr8 + rbase[s], h8.data(), h8.size() * sizeof(PieceHdr))) return rc;
+    {
+        // the samples' columns go up from a few host threads at a time (a pageable copy is staged by the runtime: several in flight keep
+        // the link busy while the compact headers of the next samples are built)
+        std::atomic<int> up_err{0};
+        std::mutex up_mu; std::string up_msg;
+        const int device = ds.ctx ? ds.ctx->device : 0;
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+            (void)dev_set_device(device);
+            for (;;) {
+                const size_t s = next.fetch_add(1);
+                if (s >= S || up_err.load()) break;
+                SampleCols &sc = ds.samples[s];
+                int rc = dev_upload(d->hdr + rbase[s], sc.hdr.data(), sc.hdr.size() * sizeof(ReadHdr));
+                if (!rc && dense) {
+                    rc = dev_upload(d->blk + bbase[s], sc.blk.data(), sc.blk.size() * sizeof(uint32_t));
+                } else if (!rc) {   // compact tile-local headers of the narrow kernel: {start in tile | length << 11, seq offset / SEQ_ALIGN}
+                    std::vector<PieceHdr> h8(sc.hdr.size());
+                    for (size_t i = 0; i < sc.hdr.size(); ++i) h8[i] = PieceHdr{(sc.hdr[i].gpos % TILE) | sc.hdr[i].cig << 11, sc.hdr[i].seqoff >> SEQ_ALIGN_LOG2};
+                    rc = dev_upload(d->hdr8 + rbase[s], h8.data(), h8.size() * sizeof(PieceHdr));
+                }
+                if (!rc) rc = dev_upload(d->seq + sbase[s], sc.seq.data(), sc.seq.size());
+                if (!rc) rc = dev_upload(d->qual + 2 * sbase[s], sc.qual.data(), sc.qual.size());
+                if (rc) { std::lock_guard<std::mutex> lk(up_mu); if (!up_err.load()) { up_msg = msnv_last_error(); up_err.store(rc); } continue; }
+                // release host staging of the bulky columns; headers stay (coverage pass, results mapping)
+                std::vector<uint8_t>().swap(sc.seq);
+                std::vector<uint8_t>().swap(sc.qual);
+                if (dense) std::vector<uint32_t>().swap(sc.blk);
+            }
+        };
+        const size_t n_up = std::min<size_t>(S, std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency())));
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < n_up; ++t) th.emplace_back(worker);
+        for (auto &t : th) t.join();
+        if (up_err.load()) return fail(up_err.load(), "%s", up_msg.c_str());
+        for (size_t s = 0; s < S; ++s) {
+            const SampleCols &sc = ds.samples[s];
+            ds.info.bytes_headers += dense ? (rbase[s + 1] - rbase[s]) * 0 + (bbase[s + 1] - bbase[s]) * sizeof(uint32_t) : sc.hdr.size() * sizeof(PieceHdr);
+            ds.info.bytes_cigar += sc.alg_cigar_bytes;
+            alg += sc.alg_8d_bytes;
+            ds.info.bytes_seq += sc.alg_seq_bytes;
+            ds.info.bytes_qual += sc.alg_qual_bytes;
         }
-        if (int rc = dev_upload(d->seq + sbase[s], sc.seq.data(), sc.seq.size())) return rc;
-        if (int rc = dev_upload(d->qual + 2 * sbase[s], sc.qual.data(), sc.qual.size())) return rc;
-        if (!dense) ds.info.bytes_headers += sc.hdr.size() * sizeof(PieceHdr);
-        ds.info.bytes_cigar += sc.alg_cigar_bytes;
-        alg += sc.alg_8d_bytes;
-        ds.info.bytes_seq += sc.alg_seq_bytes;
-        ds.info.bytes_qual += sc.alg_qual_bytes;
-        // release host staging of the bulky columns; headers stay (coverage pass, results mapping)
-        std::vector<uint8_t>().swap(sc.seq);
-        std::vector<uint8_t>().swap(sc.qual);
     }
     d->algorithmic_bytes = alg;                  // SURVEY.md section 8d figure; the shipped bytes are bytes_headers + bytes_seq + bytes_qual
 
@@ -1218,7 +1266,19 @@ int finalize_dataset(msnv_dataset &ds) {
         {
             std::vector<uint32_t> fill(cps.begin(), cps.end() - 1);
             // blk_lo / nblk: absolute index of the sample's first interval (the kernel needs no per-sample base lookup)
-            for (size_t s = 0; s < S; ++s) for (const CP &p : per[s]) cpairs[fill[p.tile]++] = TilePair{p.sample, p.lo, p.hi, 0, (uint32_t)cvbase[s], (uint32_t)(cvbase[s] >> 32), 0, 0};
+            // max_depth: the accumulator row of the pair's (sample, contig) -- rows exist for the combinations that have intervals only
+            ds.cov_row_sample.clear(); ds.cov_row_contig.clear(); ds.cov_row_start.assign(S + 1, 0);
+            for (size_t s = 0; s < S; ++s) {
+                ds.cov_row_start[s] = ds.cov_row_sample.size();
+                uint32_t last_contig = UINT32_MAX;
+                for (const CP &p : per[s]) {                      // (tile order = contig order)
+                    const uint32_t c = ds.tile_contig[p.tile];
+                    if (c != last_contig) { ds.cov_row_sample.push_back((uint32_t)s); ds.cov_row_contig.push_back(c); last_contig = c; }
+                    if (ds.cov_row_sample.size() > 0xffffffffull) return fail(MSNV_EDOMAIN, "more than 2^32 (sample, contig) pairs with coverage in one shard");
+                    cpairs[fill[p.tile]++] = TilePair{p.sample, p.lo, p.hi, (uint32_t)(ds.cov_row_sample.size() - 1), (uint32_t)cvbase[s], (uint32_t)(cvbase[s] >> 32), 0, 0};
+                }
+            }
+            ds.cov_row_start[S] = ds.cov_row_sample.size();
         }
         std::vector<WorkItem> cwork;
         // a coverage work item = COV_ITEM_PAIRS consecutive pairs of a tile = one wavefront of msnv_coverage_tiles, which loads their
@@ -1256,7 +1316,8 @@ int finalize_dataset(msnv_dataset &ds) {
         if (int rc = upload_vec(&d->tile_len, tlen, &d->device_bytes)) return rc;
         if (int rc = upload_vec(&d->tile_contig_dev, tcont, &d->device_bytes)) return rc;
         // accumulator copies: as many as fit 64 MB, at most 8 (many contigs = few tiles per contig = little contention anyway)
-        const uint64_t acc_bytes = (uint64_t)S * NC * (1 + COV_BINS) * sizeof(unsigned long long);
+        d->n_cov_rows = ds.cov_row_sample.size();
+        const uint64_t acc_bytes = std::max<uint64_t>(1, d->n_cov_rows) * (1 + COV_BINS) * sizeof(unsigned long long);
         d->cov_copies = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(8, (64ull << 20) / std::max<uint64_t>(1, acc_bytes)));
         if (int rc = dev_alloc((void **)&d->cov_acc, d->cov_copies * acc_bytes, &d->device_bytes)) return rc;
     }

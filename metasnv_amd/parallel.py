@@ -392,26 +392,34 @@ class SparseAcc:
         return np.stack([self[i] for i in range(self.n_samples)]) if self.n_samples else np.zeros((0, self.n_contigs, self.words), np.uint64)
 
 
-def gather_coverage_root(acc, stats=None):
-    """acc[n_samples][n_contigs][COV_WORDS] of this rank (zeros outside its contigs) -> SparseAcc of the whole job on rank 0
-    (None elsewhere): only the non-zero (sample, contig) rows travel -- 8 B of index + 136 B each."""
-    acc = np.ascontiguousarray(acc, dtype=np.uint64)
-    S, NC, W = acc.shape
-    nz_s, nz_c = np.nonzero(acc.any(axis=2))
-    rows = acc[nz_s, nz_c]
+def gather_coverage_root(acc, stats=None, rows=None, shape=None):
+    """Coverage accumulators of every rank -> SparseAcc of the whole job on rank 0 (None elsewhere): only the (sample, contig) rows
+    that hold something travel -- 8 B of index + 136 B each.  rows = (sample[n], contig[n], acc[n][COV_WORDS]) with shape =
+    (n_samples, n_contigs) (core.Dataset.coverage_rows: what the device keeps), or acc = the dense [n_samples][n_contigs][COV_WORDS]
+    table of this rank (zeros outside its contigs)."""
+    from .core import COV_WORDS
+    if rows is not None:
+        nz_s, nz_c, rr = (np.asarray(rows[0], dtype=np.uint32), np.asarray(rows[1], dtype=np.uint32), np.ascontiguousarray(rows[2], dtype=np.uint64))
+        S, NC = shape
+        W = COV_WORDS
+    else:
+        acc = np.ascontiguousarray(acc, dtype=np.uint64)
+        S, NC, W = acc.shape
+        nz_s, nz_c = np.nonzero(acc.any(axis=2))
+        rr = acc[nz_s, nz_c]
     blob = np.concatenate([np.array([len(nz_s)], dtype=np.int64).view(np.uint8), nz_s.astype(np.uint32).view(np.uint8),
-                           nz_c.astype(np.uint32).view(np.uint8), np.ascontiguousarray(rows).view(np.uint8).reshape(-1)])
+                           nz_c.astype(np.uint32).view(np.uint8), np.ascontiguousarray(rr).view(np.uint8).reshape(-1)])
     got = gather_to_root(blob, stats)
     if got is None:
         return None
-    ss, cc, rr = [], [], []
+    ss, cc, rws = [], [], []
     for b in got:
         n = int(b[:8].view(np.int64)[0])
         o = 8
         ss.append(b[o:o + 4 * n].view(np.uint32)); o += 4 * n
         cc.append(b[o:o + 4 * n].view(np.uint32)); o += 4 * n
-        rr.append(b[o:o + 8 * W * n].view(np.uint64).reshape(n, W))
-    return SparseAcc(S, NC, np.concatenate(ss).astype(np.int64), np.concatenate(cc).astype(np.int64), np.concatenate(rr))
+        rws.append(b[o:o + 8 * W * n].view(np.uint64).reshape(n, W))
+    return SparseAcc(S, NC, np.concatenate(ss).astype(np.int64), np.concatenate(cc).astype(np.int64), np.concatenate(rws))
 
 
 def resident_project_run(ctx, first_bam, fasta_path, bam_paths, params, batch=1, want_coverage=True, ann_path=None,
@@ -457,7 +465,7 @@ def resident_project_run(ctx, first_bam, fasta_path, bam_paths, params, batch=1,
         if want_coverage:
             metrics["coverage"] = ds.coverage_run()
             t0 = time.perf_counter()
-            res["acc"] = gather_coverage_root(ds.coverage_accumulators(), gstats)
+            res["acc"] = gather_coverage_root(None, gstats, rows=ds.coverage_rows(), shape=(len(bam_paths), len(names)))
             metrics["gather_coverage_s"] = time.perf_counter() - t0
         if after_coverage:
             after_coverage(res)

@@ -1,5 +1,5 @@
 """profiles/phase_times.py -- per-phase times of a pass (MSNV_PHASE_TIMES=1: HIP events between the tail kernels, ~6 us each).
-  NS / COV / ERR: testdata shape with that many samples / mean coverage / error rate;  WORKLOAD=config3|config4shard SCALE=0.1: bench.py's shapes."""
+  NS / COV / ERR / SIGMA: testdata shape with that many samples / mean coverage / error rate / log-normal sigma of the coverages;  WORKLOAD=config3|config4shard SCALE=0.1: bench.py's shapes."""
 import sys, os
 os.environ["MSNV_PHASE_TIMES"] = "1"
 sys.path.insert(0, os.getcwd())
@@ -12,7 +12,7 @@ if "WORKLOAD" in os.environ:
     sp = core.synth_params(**kw)
 else:
     sp = core.synth_params(n_species=3, contig_len=300000, n_samples=int(os.environ.get("NS", "160")), mean_cov=float(os.environ.get("COV", "10")), seed=1,
-                           **({"error_rate": float(os.environ["ERR"])} if "ERR" in os.environ else {}))
+                           **({"error_rate": float(os.environ["ERR"])} if "ERR" in os.environ else {}), **({"sigma_cov": float(os.environ["SIGMA"])} if "SIGMA" in os.environ else {}))
 syn = core.Synth(sp); ctx = core.Context(0)
 ds = core.Dataset(ctx, syn.names, syn.lengths, syn.seqs)
 ds.add_synth_samples(sp, 0, sp.n_samples, 0); info = ds.finalize()
