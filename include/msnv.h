@@ -260,6 +260,9 @@ typedef struct {
     uint64_t bytes_headers, bytes_cigar, bytes_seq, bytes_qual, bytes_ref, bytes_index;
     uint64_t n_tiles, n_pairs, n_work;
     uint64_t device_bytes;                        /* total HBM held by the dataset                 */
+    uint64_t allele_planes;                       /* 1: the per-sample allele counts go through byte planes (noisy reads), 0: through
+                                                     sparse events (clean reads); picked by finalize from the sampled mismatch rate */
+    uint64_t sampled_mismatch_ppm;                /* aligned bases that differ from the reference, per million (every 16th piece)   */
 } msnv_dataset_info;
 
 int  msnv_dataset_info_get(const msnv_dataset *ds, msnv_dataset_info *out);

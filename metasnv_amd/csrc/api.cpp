@@ -24,7 +24,7 @@ void synth_sample_records(const msnv_synth_params &p, int sample, const std::vec
 
 using namespace msnv;
 
-extern "C" int msnv_abi_version(void) { return 2; }
+extern "C" int msnv_abi_version(void) { return 3; }
 
 extern "C" void msnv_params_default(msnv_params *p) {
     if (!p) return;

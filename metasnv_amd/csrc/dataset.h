@@ -91,6 +91,7 @@ struct SampleCols {
     std::vector<uint32_t> run_blk_lo, run_nblk, run_seq0;   // per run, in run order: first block, block count, seq byte offset
     std::vector<int32_t>  cov_tid, cov_beg, cov_end;   // qaCompute M intervals (index space), reads that pass its filter
     uint64_t n_pileup_bases = 0, n_pileup_reads = 0;
+    uint64_t mm_sampled_bases = 0, mm_sampled = 0;   // every 16th piece: aligned bases compared with the reference / how many differ (finalize picks the allele bookkeeping by it)
     uint64_t alg_seq_bytes = 0, alg_qual_bytes = 0;   // shipped bytes without alignment padding
     uint64_t alg_8d_bytes = 0, alg_cigar_bytes = 0;   // SURVEY.md section 8d accounting (per pileup read)
     int32_t  first_tid = -1, first_beg = 0, first_end = 0;   // first pileup_ok read (first-line quirk)

@@ -74,6 +74,8 @@ struct DeviceCols {
     uint64_t  part_bytes = 0;
     uint32_t *tile_slot_start = nullptr;   // n_tiles + 1
     uint8_t  *spill = nullptr;       // [n_pairs][TILE] per-sample coverage, saturating at 255
+    uint8_t  *aspill = nullptr;      // [n_pairs][4][TILE] per-sample mismatching A, C, G, T counts (allele planes: noisy reads, pack.cpp); else NULL
+    bool      allele_planes = false;
     Pair32   *events = nullptr;      // {gpos, sample<<18 | allele<<16 | count}
     Pair32   *overflow = nullptr;    // {gpos, sample<<16 | cov}
     uint32_t *counters = nullptr;    // two blocks of CNT_WORDS ([0] events [1] overflow [2] sites [4] pop lines [5] indiv lines, then the event
@@ -84,7 +86,7 @@ struct DeviceCols {
     uint32_t *tile_dirty = nullptr;  // per work item (by the slot of its coverage row), 1 bit per 64 positions of the tile: the item added to the allele totals there
                                      // (set by the pileup kernels, consumed and cleared by the gate)
     uint32_t *unc_sites = nullptr;   // [cap_sites]: sites whose call depends on a split / merged sample's summed counts (msnv_decide_sites)
-    struct GateTileH { uint32_t tile, slot_lo, slot_16, slot_w, slot_hi, vbeg, vend, n_slots; uint64_t row0; uint32_t tot_mode, staged; } *gate_tiles = nullptr;   // per active tile (kernels.hip: GateTile)
+    struct GateTileH { uint32_t tile, slot_lo, slot_16, slot_w, slot_hi, vbeg, vend, n_slots; uint64_t row0; uint32_t tot_mode, staged, pair_lo, n_plane_pairs, pad0, pad1; } *gate_tiles = nullptr;   // per active tile (kernels.hip: GateTile)
     unsigned long long *site_row = nullptr;   // per 64 positions: first cell of the first site in them (gate kernel; what an event finds its cell with)
     GateTileH *gate_tiles_dense = nullptr, *gate_tiles_staged = nullptr;   // gate_tiles without / only the tiles of whole-tile work items (staged: row0 = index of the record list)
     uint32_t *gather_tiles = nullptr; uint32_t n_gather_tiles = 0;   // active tiles that hold pairs outside merged groups (spill gather)
@@ -130,7 +132,7 @@ struct DeviceCols {
     // second set of per-pass intermediates + second stream: msnv_pileup_run_many alternates passes between the two sets so
     // that the small tail kernels of pass i overlap with the pileup kernel of pass i+1 (allocated on first use)
     struct AltBufs {
-        uint32_t *tot = nullptr; uint8_t *part = nullptr; uint8_t *spill = nullptr; Pair32 *events = nullptr, *overflow = nullptr;
+        uint32_t *tot = nullptr; uint8_t *part = nullptr; uint8_t *spill = nullptr, *aspill = nullptr; Pair32 *events = nullptr, *overflow = nullptr;
         TileStage *tile_stage = nullptr;
         uint32_t *counters = nullptr; SiteRec *sites = nullptr; uint32_t *tile_site_base = nullptr, *tile_site_cnt = nullptr; unsigned long long *tile_cell_base = nullptr;
         uint16_t *ncol = nullptr; uint16_t *cov_col = nullptr; uint8_t *site_flags = nullptr, *site_elig = nullptr; uint32_t *ind4 = nullptr, *unc_bits = nullptr, *tile_dirty = nullptr, *unc_sites = nullptr; unsigned long long *site_row = nullptr; unsigned long long *site_bits = nullptr; uint32_t *site_rank = nullptr;

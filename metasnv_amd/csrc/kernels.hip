@@ -47,6 +47,7 @@ struct PileupArgs {
     uint8_t        *part;         // coverage summed over the item's samples, one row per work item (plain stores)
     uint64_t        npos;
     uint8_t        *spill;
+    uint8_t        *aspill;       // allele planes (noisy reads): [pair][A, C, G, T][TILE] mismatch counts of the pair, instead of events and total atomics
     Pair32         *events;   uint32_t cap_events;   // this work item's sub-list (ev_list) and the capacity of ONE sub-list
     Pair32         *overflow; uint32_t cap_overflow;
     uint32_t       *counters;
@@ -391,7 +392,9 @@ struct NarrowLds {
 // positions -- coverage and allele counts -- from the pieces themselves (gather_merged_block), so the pass only adds the group to
 // the running totals and the allele totals, marks positions where one sample MIGHT hold >= min_snvs reads of an allele (the
 // calling rule then reads the summed per-sample records), and leaves every bin zero.
-template <typename LDS, int EXC_PAD, bool MERGED = false, bool FUSED = false>
+// DA ("dense alleles", pack.cpp: allele planes): the pair's mismatch counts leave as four byte planes -- plain stores next to the coverage
+// bytes -- instead of one total atomic + one event per (position, allele): what a pass costs no longer depends on how noisy the reads are.
+template <typename LDS, int EXC_PAD, bool MERGED = false, bool FUSED = false, bool DA = false>
 __device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_t (&tc)[N_PPT / 2], bool &dirty, const uint32_t t0,
                                             const int tid, const int lane, const int wave, const uint32_t sample, const uint32_t k,
                                             const uint32_t split, const uint32_t tmode) {
@@ -430,6 +433,40 @@ __device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_
 #pragma unroll
         for (int j = 0; j < N_PPT; ++j) pm |= (alw[j] ? 1u : 0u) << j;
         myev = count_nz_bytes(a0, a1);
+        if constexpr (DA && !MERGED) {
+            // byte x of the eight words -> eight bytes of plane x (v_perm_b32: selector bytes 0-3 pick from the second operand, 4-7 from the first)
+            uint8_t *row = a.aspill + (uint64_t)k * (4u * TILE) + N_PPT * tid;
+            uint32_t hit = 0;                                  // some allele of some position holds >= min_snvs reads (rare: SNV positions of this sample)
+            const uint32_t ge = (0x80u - min(a.min_snvs, 127u)) * 0x01010101u;
+#pragma unroll
+            for (uint32_t x = 0; x < 4u; ++x) {
+                const uint32_t s2 = x | (4u + x) << 8 | 0x0c0c0000u;
+                const uint32_t t01 = __builtin_amdgcn_perm(alw[1], alw[0], s2), t23 = __builtin_amdgcn_perm(alw[3], alw[2], s2);
+                const uint32_t t45 = __builtin_amdgcn_perm(alw[5], alw[4], s2), t67 = __builtin_amdgcn_perm(alw[7], alw[6], s2);
+                *reinterpret_cast<uint2 *>(row + x * TILE) = make_uint2(__builtin_amdgcn_perm(t23, t01, 0x05040100u), __builtin_amdgcn_perm(t67, t45, 0x05040100u));
+            }
+#pragma unroll
+            for (int j = 0; j < N_PPT; ++j) hit |= ((((alw[j] & 0x7f7f7f7fu) + ge) | alw[j]) & 0x80808080u) ? 1u << j : 0u;
+            if (pm) {                                          // the bins are left zero for the next sample
+                *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid]) = make_uint4(0u, 0u, 0u, 0u);
+                *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid + 4]) = make_uint4(0u, 0u, 0u, 0u);
+            }
+            dirty |= pm != 0u;
+            uint32_t todo = split ? pm : hit;                  // the individual rule's marks (see below); a split sample may reach the threshold only in sum
+            while (todo) {
+                const uint32_t j = (uint32_t)__builtin_ctz(todo);
+                todo &= todo - 1u;
+                const uint32_t word = (j == 0u ? alw[0] : j == 1u ? alw[1] : j == 2u ? alw[2] : j == 3u ? alw[3] : j == 4u ? alw[4] : j == 5u ? alw[5] : j == 6u ? alw[6] : alw[7]);
+                const uint32_t gpos = t0 + N_PPT * tid + j;
+#pragma unroll
+                for (uint32_t x = 0; x < 4u; ++x) {
+                    const uint32_t n = (word >> (8u * x)) & 0xffu;
+                    if (n >= a.min_snvs) atomicOr(&a.ind4[gpos >> 3], 1u << (4u * (gpos & 7u) + x));
+                    else if (n && split) atomicOr(&a.unc_bits[gpos >> 5], 1u << (gpos & 31u));
+                }
+            }
+            return;
+        }
     }
     if (!__any(pm != 0u)) return;                            // no mismatching allele in this wavefront's 512 positions
     dirty |= pm != 0u;                                       // my 8 positions lie in one 64-position block (store_part_row tells the gate kernel)
@@ -631,7 +668,7 @@ __device__ __attribute__((noinline)) void fused_tile_gate(NarrowLds &L, const Fu
     }
 }
 
-template <bool MERGED, bool FUSED = false>
+template <bool MERGED, bool FUSED = false, bool DA = false>
 __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a, NarrowLds &L) {
     ev_list(a);
     const WorkItem w = a.work[blockIdx.x];
@@ -713,7 +750,7 @@ __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a, NarrowL
         const bool last_chunk = (cd.nrd_flags >> 16) != 0u;
         if (prev_last) __syncthreads();                              // (A): the pass of the previous pair left every bin zero
         desc_refill(L.desc, a.chunks + w.chunk_lo, c, nch, tid);
-        if (!MERGED && L.evn >= (uint32_t)(N_EVCAP / 2)) flush_events<NarrowLds, N_NT, N_EVCAP>(L, a, tid);
+        if (!MERGED && !DA && L.evn >= (uint32_t)(N_EVCAP / 2)) flush_events<NarrowLds, N_NT, N_EVCAP>(L, a, tid);
         if (tid < N_HCAP) {
             const uint32_t hx = L.hdr[c & 1u][tid].x;
             const uint32_t s = hx & (TILE - 1u), sb = s + ((hx >> 11) & 0xffu);
@@ -732,7 +769,7 @@ __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a, NarrowL
         hreg = load_hdr(c + 2u);
         __syncthreads();                                            // (B): this chunk is in the bins; the next chunk's headers are visible
         if (c + 1u < nch) issue_loads(c + 1u);                       // in flight under the per-sample pass
-        if (last_chunk) narrow_pass<NarrowLds, 0, MERGED, fused>(L, a, tc, dirty, t0, tid, lane, wave, cd.sample, cd.pair, cd.pad, tot_mode_of(w));
+        if (last_chunk) narrow_pass<NarrowLds, 0, MERGED, fused, DA>(L, a, tc, dirty, t0, tid, lane, wave, cd.sample, cd.pair, cd.pad, tot_mode_of(w));
         prev_last = last_chunk;
     }
     __syncthreads();
@@ -741,7 +778,7 @@ __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a, NarrowL
         fused_tile_gate(L, fa, t0, nch != 0u, tid);
         return;
     }
-    if (!MERGED) flush_events<NarrowLds, N_NT, N_EVCAP>(L, a, tid);
+    if (!MERGED && !DA) flush_events<NarrowLds, N_NT, N_EVCAP>(L, a, tid);
     store_part_row(a.part, w, tc, tid);
     store_item_dirty(a.slot_dirty, w, dirty, tid);
 }
@@ -756,6 +793,14 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32(PileupArgs a)
     if (blockIdx.x < a.n_narrow) pileup_tiles_narrow32_body<false>(a, L);
     else if (blockIdx.x < a.n_fused_lo) { a.hdr8 = a.hdr8m; pileup_tiles_narrow32_body<true>(a, L); }
     else { a.hdr8 = a.hdr8m; pileup_tiles_narrow32_body<true, true>(a, L); }      // whole-tile items (the last ones; none when the pass runs unfused)
+}
+// The same launch for noisy reads (pack.cpp: allele planes): the ordinary work items write their pairs' allele counts as byte planes;
+// merged groups and whole-tile items keep their own bookkeeping (a group's few per-sample cells are recomputed from the pieces).
+__global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32_planes(PileupArgs a) {
+    __shared__ NarrowLds L;
+    if (blockIdx.x < a.n_narrow) pileup_tiles_narrow32_body<false, false, true>(a, L);
+    else if (blockIdx.x < a.n_fused_lo) { a.hdr8 = a.hdr8m; pileup_tiles_narrow32_body<true>(a, L); }
+    else { a.hdr8 = a.hdr8m; pileup_tiles_narrow32_body<true, true>(a, L); }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -968,7 +1013,7 @@ __device__ __forceinline__ void zero_cells(uint16_t *ncol, uint16_t *cov_col, co
     zero_span<NT>(reinterpret_cast<uint8_t *>(cov_col + first), n * sizeof(uint16_t), tid);      // samples without reads at a position keep coverage 0
 }
 
-struct GateTile { uint32_t tile, slot_lo, slot_16, slot_w, slot_hi, vbeg, vend, n_slots; uint64_t row0; uint32_t tot_mode, staged; };   // 48 B (pack.cpp); staged: a whole-tile work item leaves the tile's candidates in a record list
+struct GateTile { uint32_t tile, slot_lo, slot_16, slot_w, slot_hi, vbeg, vend, n_slots; uint64_t row0; uint32_t tot_mode, staged, pair_lo, n_plane_pairs, pad0, pad1; };   // 64 B (pack.cpp); staged: a whole-tile work item leaves the tile's candidates in a record list; pair_lo / n_plane_pairs: the tile's pairs that write allele planes
 
 struct GateArgs {
     uint32_t *tot; const uint8_t *part; const uint64_t *slot_off; const uint32_t *tile_slot_start, *tile_slot_u16, *tile_slot_wide; uint64_t npos;
@@ -983,6 +1028,7 @@ struct GateArgs {
     uint8_t *site_elig; uint32_t any_split;
     uint32_t n_active, tiles_per_wg;           // active tiles; consecutive ones per workgroup (<= GATE_MAX_TILES)
     const TileStage *tile_stage;               // record lists of the whole-tile work items (msnv_gate_staged)
+    const uint8_t *aspill;                     // allele planes of the pairs (noisy reads: msnv_gate_sites<.., .., true> sums them), else NULL
     uint32_t zero_next;                        // this launch zeroes the counter block of the next pass (one of the two gate kernels does)
 };
 
@@ -1045,7 +1091,7 @@ __device__ __forceinline__ void gate_flush(GateLds &L, const GateArgs &a, const 
 
 // MULTI = false: one tile per workgroup, the loop below runs once and the compiler sees it (80 registers, 6 workgroups per CU: the
 // benchmark shape); true: the loop is a loop (loop-invariant addresses and constants pile up: 126 registers, 4 workgroups per CU).
-template <bool MULTI, bool WIDE_TOT>
+template <bool MULTI, bool WIDE_TOT, bool PLANES = false>
 __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
     constexpr int NN = WIDE_TOT ? 4 * GATE_PPT : 2 * GATE_PPT;
     constexpr int ROWS = MULTI ? 8 : 16;                        // partial rows in flight per thread (a sparse cohort's tile has a row or two)
@@ -1159,7 +1205,7 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
         uint32_t nn[NN];
     #pragma unroll
         for (int k = 0; k < NN; ++k) nn[k] = 0u;
-        if (my_dirty) {
+        if (my_dirty) {                                            // (allele planes: only merged groups add to the totals)
             if (gt.tot_mode == 0u) {
                 uint4 *tp = reinterpret_cast<uint4 *>(tb + p0);
                 const uint32_t wd[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
@@ -1190,6 +1236,47 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
                     const uint4 v = tp[k];
                     nn[4 * k] = v.x; nn[4 * k + 1] = v.y; nn[4 * k + 2] = v.z; nn[4 * k + 3] = v.w;
                     if (v.x | v.y | v.z | v.w) tp[k] = z4;
+                }
+            }
+        }
+        if constexpr (PLANES) {
+            // noisy reads: the pairs of the ordinary work items wrote their allele counts as byte planes (narrow_pass<.., DA>): summed like the
+            // u8 coverage rows, two positions per register, widened every 255 rows; merged groups still came through the totals above
+            const uint32_t npl = gt.n_plane_pairs;
+            if (npl) {
+#pragma unroll 1
+                for (int x = 0; x < 4; ++x) {
+                    const uint8_t *p8 = a.aspill + ((uint64_t)gt.pair_lo * 4u + (uint32_t)x) * TILE + p0;
+                    uint32_t sum[GATE_PPT];
+#pragma unroll
+                    for (int j = 0; j < GATE_PPT; ++j) sum[j] = 0u;
+                    for (uint32_t r0 = 0; r0 < npl; r0 += 255u) {
+                        uint32_t h[4] = {0u, 0u, 0u, 0u};
+                        const uint32_t r1 = min(npl, r0 + 255u);
+                        uint32_t sidx = r0;
+                        for (; sidx + 8u <= r1; sidx += 8u) {
+                            uint2 v[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const uint2 *>(p8 + (uint64_t)(sidx + (uint32_t)u) * (4u * TILE));
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                h[0] += v[u].x & 0x00ff00ffu; h[1] += (v[u].x >> 8) & 0x00ff00ffu;
+                                h[2] += v[u].y & 0x00ff00ffu; h[3] += (v[u].y >> 8) & 0x00ff00ffu;
+                            }
+                        }
+                        for (; sidx < r1; ++sidx) {
+                            const uint2 v = *reinterpret_cast<const uint2 *>(p8 + (uint64_t)sidx * (4u * TILE));
+                            h[0] += v.x & 0x00ff00ffu; h[1] += (v.x >> 8) & 0x00ff00ffu;
+                            h[2] += v.y & 0x00ff00ffu; h[3] += (v.y >> 8) & 0x00ff00ffu;
+                        }
+                        sum[0] += h[0] & 0xffffu; sum[2] += h[0] >> 16; sum[1] += h[1] & 0xffffu; sum[3] += h[1] >> 16;
+                        sum[4] += h[2] & 0xffffu; sum[6] += h[2] >> 16; sum[5] += h[3] & 0xffffu; sum[7] += h[3] >> 16;
+                    }
+#pragma unroll
+                    for (int j = 0; j < GATE_PPT; ++j) {
+                        if (WIDE_TOT) nn[4 * j + x] += sum[j];
+                        else nn[2 * j + (x >> 1)] += sum[j] << (16 * (x & 1));
+                    }
                 }
             }
         }
@@ -1455,6 +1542,7 @@ struct TailArgs {
     uint8_t *site_flags; const uint8_t *site_elig; uint32_t ind_in_gather, min_snvs;
     uint16_t *ncol; uint16_t *cov_col; uint32_t cap_out; const uint32_t *active_tiles; uint32_t n_gather_blocks;
     CellMap cells; uint32_t gather_split;
+    const uint8_t *aspill;                      // allele planes of the pairs (noisy reads), else NULL: gathered into the four allele columns like the coverage bytes
     uint32_t has_wide;                          // some work item runs the wide kernel (coverage bytes of 255 stand for an overflow-list entry the scatter half writes)
     const Pair32 *events, *overflow; uint32_t *counters; uint32_t cap_list, cap_overflow;
     const unsigned long long *site_bits; const uint32_t *site_rank;
@@ -1472,7 +1560,14 @@ constexpr uint32_t GW_ROW = 34;                // words per LDS row of 64 slots 
 // cell (the gate kernels reserve in multiples of 8).  Slots of merged pairs (behind the others) belong to gather_merged_block: the
 // group of eight that straddles their first slot is written cell by cell.
 constexpr uint32_t GW_MAX_BLOCKS = 256;        // 64-slot blocks of a tile (<= 16383 samples)
-__device__ __forceinline__ void gather_cov_wide(const TailArgs &a, uint32_t *s_acc, uint32_t *s_off, uint32_t *s_blk, const uint32_t t0, const uint32_t base, const uint32_t stride,
+// Byte planes a pair leaves behind: plane 0 = its coverage bytes (spill), planes 1-4 = its mismatching A, C, G, T counts (allele planes:
+// noisy reads only); plane p of the tile's pair kk, position off: src[kk * stride + off]; it lands in column col.
+struct PlaneSrc { const uint8_t *src; uint64_t stride; uint16_t *col; };
+__device__ __forceinline__ PlaneSrc plane_of(const TailArgs &a, const uint32_t ps, const uint32_t pl) {
+    if (pl == 0u) return PlaneSrc{a.spill + (uint64_t)ps * TILE, TILE, a.cov_col};
+    return PlaneSrc{a.aspill + ((uint64_t)ps * 4u + (pl - 1u)) * TILE, 4u * TILE, a.ncol + (uint64_t)(pl - 1u) * a.cells.cap_cells};
+}
+__device__ __forceinline__ void gather_cov_wide(const TailArgs &a, const uint32_t n_planes, uint32_t *s_acc, uint32_t *s_off, uint32_t *s_blk, const uint32_t t0, const uint32_t base, const uint32_t stride,
                                                 const unsigned long long cell0, const uint32_t ps, const uint32_t np, const bool tile_has_merged, const uint32_t j_lo, const uint32_t dense_n) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     // slots are numbered in pair order (the pairs of a split sample share one): first pair of every block of 64 slots
@@ -1488,7 +1583,10 @@ __device__ __forceinline__ void gather_cov_wide(const TailArgs &a, uint32_t *s_a
         const uint32_t nS = min(64u, dense_n - jj0);
         __syncthreads();                                            // (the block before has been written out; s_blk is visible)
         if (tid < 64u) s_off[tid] = a.sites[base + j_lo + jj0 + min(tid, nS - 1u)].gpos - t0;   // (idle lanes: a valid position; their rows are not written out)
-        for (uint32_t b = 0; b < nblk; ++b) {
+        for (uint32_t pb = 0; pb < n_planes * nblk; ++pb) {
+            const uint32_t pl = pb / nblk, b = pb % nblk;
+            const PlaneSrc P = plane_of(a, ps, pl);
+            const uint8_t *src = P.src; const uint64_t src_stride = P.stride; uint16_t *col = P.col;
             __syncthreads();                                        // s_off is visible; the previous 64 slots have been written out
             for (uint32_t i = tid; i < 64u * GW_ROW; i += 256u) s_acc[i] = 0u;
             __syncthreads();
@@ -1499,7 +1597,7 @@ __device__ __forceinline__ void gather_cov_wide(const TailArgs &a, uint32_t *s_a
 #pragma unroll
                 for (uint32_t u = 0; u < 4u; ++u) {
                     const uint32_t k = ps + min(kl + 4u * u, kB - 1u);
-                    v[u] = a.spill[(uint64_t)k * TILE + off];
+                    v[u] = src[(uint64_t)(k - ps) * src_stride + off];
                     c[u] = (a.pairs[k].pad >> 8) - 64u * b;          // (one address for the wavefront)
                 }
 #pragma unroll
@@ -1512,7 +1610,7 @@ __device__ __forceinline__ void gather_cov_wide(const TailArgs &a, uint32_t *s_a
                 if (c0 >= n_real) continue;                              // (slots of merged pairs, padding behind the last slot: zeroed by the gate kernel)
                 const uint2 lo = *reinterpret_cast<const uint2 *>(&s_acc[row * GW_ROW + 4u * seg]);
                 const uint2 hi = *reinterpret_cast<const uint2 *>(&s_acc[row * GW_ROW + 4u * seg + 2u]);
-                uint16_t *dst = a.cov_col + cell0 + (uint64_t)(j_lo + jj0 + row) * stride + c0;
+                uint16_t *dst = col + cell0 + (uint64_t)(j_lo + jj0 + row) * stride + c0;
                 if (c0 + 8u <= wide_end) *reinterpret_cast<uint4 *>(dst) = make_uint4(lo.x, lo.y, hi.x, hi.y);      // (columns behind the last slot are zero)
                 else {
                     const uint32_t w[4] = {lo.x, lo.y, hi.x, hi.y};
@@ -1538,6 +1636,7 @@ __device__ __forceinline__ void gather_cov_block(const TailArgs &a, const uint32
     const uint32_t t0 = tile * TILE;
     const uint32_t mine = (n - part + GATHER_SPLIT - 1) / GATHER_SPLIT;
     const uint32_t share = (n + GATHER_SPLIT - 1) / GATHER_SPLIT;          // (the same for every workgroup of the tile: they all take the same path)
+    const uint32_t n_planes = a.aspill ? 5u : 1u;                          // coverage bytes [+ the four allele planes of noisy reads]
     if (share >= GD_MIN_SITES) {
         // MANY sites in the tile (deep or divergent data: every other position of a cohort with LogNormal sigma = 2 abundances is a
         // site).  One cell per thread in (site, pair) order reads one byte of a different spill row per lane -- a cache line per cell,
@@ -1549,7 +1648,7 @@ __device__ __forceinline__ void gather_cov_block(const TailArgs &a, const uint32
         __shared__ __attribute__((aligned(8))) uint32_t s_lds[64 * GW_ROW];      // one block for both forms of the dense gather
         __shared__ uint32_t s_off[64], s_pad[64], s_blk[GW_MAX_BLOCKS + 2];
         if ((n_slots & 7u) == 0u && (cell0 & 7ull) == 0ull && !a.has_wide) {      // (uniform)
-            gather_cov_wide(a, s_lds, s_off, s_blk, t0, base, n_slots, cell0, ps, np, a.tile_pair_merged[tile] < a.tile_pair_start[tile + 1u], j_lo, dense_n);
+            gather_cov_wide(a, n_planes, s_lds, s_off, s_blk, t0, base, n_slots, cell0, ps, np, a.tile_pair_merged[tile] < a.tile_pair_start[tile + 1u], j_lo, dense_n);
             return;
         }
         uint8_t (*s_t)[GD_ROW] = reinterpret_cast<uint8_t (*)[GD_ROW]>(s_lds);
@@ -1558,7 +1657,9 @@ __device__ __forceinline__ void gather_cov_block(const TailArgs &a, const uint32
             const uint32_t nS = min(64u, dense_n - jj0);
             __syncthreads();                                        // (the rows of the previous group have been written out)
             if (threadIdx.x < 64) s_off[threadIdx.x] = a.sites[base + j_lo + jj0 + min(threadIdx.x, nS - 1u)].gpos - t0;   // (idle lanes: a valid position, their row is not written out)
-            for (uint32_t kk0 = 0; kk0 < np; kk0 += 64) {
+            for (uint32_t pk = 0; pk < n_planes * ((np + 63u) / 64u); ++pk) {
+                const uint32_t pl = pk / ((np + 63u) / 64u), kk0 = (pk % ((np + 63u) / 64u)) * 64u;
+                const PlaneSrc P = plane_of(a, ps, pl);
                 const uint32_t nP = min(64u, np - kk0);
                 __syncthreads();                                    // s_off is visible; the previous 64 pairs have been written out
                 if (threadIdx.x < nP) s_pad[threadIdx.x] = a.pairs[ps + kk0 + threadIdx.x].pad;
@@ -1566,7 +1667,7 @@ __device__ __forceinline__ void gather_cov_block(const TailArgs &a, const uint32
                 for (uint32_t kl = (uint32_t)wave; kl < nP; kl += 16) {      // four loads in flight per lane
                     uint8_t v[4];
 #pragma unroll
-                    for (uint32_t u = 0; u < 4; ++u) v[u] = a.spill[(uint64_t)(ps + kk0 + min(kl + 4u * u, nP - 1u)) * TILE + off];
+                    for (uint32_t u = 0; u < 4; ++u) v[u] = P.src[(uint64_t)(kk0 + min(kl + 4u * u, nP - 1u)) * P.stride + off];
 #pragma unroll
                     for (uint32_t u = 0; u < 4; ++u) if (kl + 4u * u < nP) s_t[lane][kl + 4u * u] = v[u];
                 }
@@ -1575,7 +1676,7 @@ __device__ __forceinline__ void gather_cov_block(const TailArgs &a, const uint32
                     const uint32_t pad = s_pad[lane];
                     for (uint32_t sl = (uint32_t)wave; sl < nS; sl += 4) {
                         const uint32_t cov = s_t[sl][lane];
-                        uint16_t *dst = &a.cov_col[cell0 + (uint64_t)(j_lo + jj0 + sl) * n_slots + (pad >> 8)];
+                        uint16_t *dst = &P.col[cell0 + (uint64_t)(j_lo + jj0 + sl) * n_slots + (pad >> 8)];
                         if (pad & 0xffu) add_u16(dst, cov);
                         else if (cov != 255u) *dst = (uint16_t)cov;
                     }
@@ -1588,11 +1689,14 @@ __device__ __forceinline__ void gather_cov_block(const TailArgs &a, const uint32
     for (uint64_t i = threadIdx.x; i < work; i += blockDim.x) {
         const uint32_t j = part + (uint32_t)(i / np) * GATHER_SPLIT, kk = (uint32_t)(i % np);
         const uint32_t off = a.sites[base + j].gpos - t0;
-        const uint32_t cov = a.spill[(uint64_t)(ps + kk) * TILE + off];
-        const TilePair pr = a.pairs[ps + kk];
-        uint16_t *dst = &a.cov_col[cell0 + (uint64_t)j * n_slots + (pr.pad >> 8)];       // pad: kind | slot << 8
-        if (pr.pad & 0xffu) add_u16(dst, cov);              // one of several pairs of this sample: the groups add up
-        else if (cov != 255u) *dst = (uint16_t)cov;         // 255 (wide kernel only): the overflow list holds the value, the scatter half writes it
+        const uint32_t pad = a.pairs[ps + kk].pad;          // kind | slot << 8
+        for (uint32_t pl = 0; pl < n_planes; ++pl) {
+            const PlaneSrc P = plane_of(a, ps, pl);
+            const uint32_t cov = P.src[(uint64_t)kk * P.stride + off];
+            uint16_t *dst = &P.col[cell0 + (uint64_t)j * n_slots + (pad >> 8)];
+            if (pad & 0xffu) add_u16(dst, cov);             // one of several pairs of this sample: the groups add up
+            else if (cov != 255u && cov) *dst = (uint16_t)cov;  // (zero: what the gate kernel left there) 255 (wide kernel only): the overflow list holds the value, the scatter half writes it
+        }
     }
 }
 
@@ -2059,7 +2163,7 @@ void dev_free_all(DeviceCols &d) {
     for (void *e : d.timing_events) if (e) (void)hipEventDestroy((hipEvent_t)e);
     for (void *e : d.event_pool) (void)hipEventDestroy((hipEvent_t)e);
     if (d.pinned_cnt) (void)hipHostFree(d.pinned_cnt);
-    void *alts[] = {d.alt.tot, d.alt.part, d.alt.spill, d.alt.events, d.alt.overflow, d.alt.counters, d.alt.ind4, d.alt.tile_dirty, d.alt.unc_sites, d.alt.site_row, d.alt.sites, d.alt.tile_site_base,
+    void *alts[] = {d.aspill, d.alt.aspill, d.alt.tot, d.alt.part, d.alt.spill, d.alt.events, d.alt.overflow, d.alt.counters, d.alt.ind4, d.alt.tile_dirty, d.alt.unc_sites, d.alt.site_row, d.alt.sites, d.alt.tile_site_base,
                     d.alt.tile_site_cnt, d.alt.tile_cell_base, d.alt.ncol, d.alt.cov_col, d.alt.site_flags, d.alt.site_elig, d.alt.site_bits, d.site_bits, d.alt.site_rank, d.site_rank, d.active_tiles};
     for (void *p : alts) dev_free(p);
     if (d.stream2) (void)hipStreamDestroy((hipStream_t)d.stream2);
@@ -2106,7 +2210,7 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
         PileupArgs a;
         a.hdr = d.hdr; a.hdr8 = d.hdr8; a.blk = d.blk; a.seq = d.seq; a.qual = d.qual;
         a.s_read_base = d.s_read_base; a.s_seq_base = d.s_seq_base;
-        a.ref4 = d.ref4; a.pairs = d.pairs; a.work = d.work; a.chunks = d.chunks; a.tot = d.tot; a.part = d.part; a.npos = npos; a.spill = d.spill;
+        a.ref4 = d.ref4; a.pairs = d.pairs; a.work = d.work; a.chunks = d.chunks; a.tot = d.tot; a.part = d.part; a.npos = npos; a.spill = d.spill; a.aspill = d.aspill;
         a.events = d.events; a.cap_events = d.cap_events / EV_LISTS; a.ev_count = nullptr; a.overflow = d.overflow; a.cap_overflow = d.cap_overflow;
         a.counters = counters; a.min_baseq = (uint32_t)std::max(0, p.min_baseq);
         a.ind4 = d.ind4; a.unc_bits = d.unc_bits; a.slot_dirty = d.tile_dirty; a.min_snvs = (uint32_t)std::max(0, p.calling_threshold);
@@ -2116,6 +2220,7 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
         // narrow work items (byte bins), merged groups of shallow pairs and wide items (16-bit bins) touch disjoint (tile, sample) pairs
         a.hdr8m = d.hdr8m; a.n_narrow = n_narrow;
         if (n_narrow && d.dense) hipLaunchKernelGGL(msnv_pileup_tiles_dense, dim3(n_narrow), dim3(N_NT), 0, st, a);      // (the dense layout never merges)
+        else if (n_narrow + n_merged && d.allele_planes) hipLaunchKernelGGL(msnv_pileup_tiles_narrow32_planes, dim3(n_narrow + n_merged), dim3(N_NT), 0, st, a);
         else if (n_narrow + n_merged) hipLaunchKernelGGL(msnv_pileup_tiles_narrow32, dim3(n_narrow + n_merged), dim3(N_NT), 0, st, a);
         if (d.n_work > n_narrow + n_merged) {
             PileupArgs b = a;
@@ -2139,7 +2244,7 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
         g.ncol = d.ncol; g.cov_col = d.cov_col; g.site_flags = d.site_flags; g.cap_out = cap_out;
         g.gate_tiles = reinterpret_cast<const GateTile *>(d.gate_tiles); g.tile_dirty = d.tile_dirty; g.unc_sites = d.unc_sites;
         g.use_dirty = d.use_dirty ? 1u : 0u; g.block_row = d.site_row; g.site_elig = d.site_elig; g.any_split = d.any_split ? 1u : 0u;
-        static_assert(sizeof(GateTile) == sizeof(DeviceCols::GateTileH) && sizeof(GateTile) == 48, "gate tile descriptor");
+        static_assert(sizeof(GateTile) == sizeof(DeviceCols::GateTileH) && sizeof(GateTile) == 64, "gate tile descriptor");
         g.tile_nslots = d.tile_nslots; g.tile_cell_base = d.tile_cell_base; g.cap_cells = d.cap_cells;
         // several tiles per workgroup once the tiles outnumber what the device holds at a time several times over (one reservation of
         // site slots per workgroup: msnv_gate_sites); MSNV_GATE_TILES overrides (tests run every size)
@@ -2153,7 +2258,16 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
             g.tiles_per_wg = n_dense >= 32768u ? 8u : n_dense >= 8192u ? 4u : 1u;
             if (const char *e = getenv("MSNV_GATE_TILES")) g.tiles_per_wg = (uint32_t)std::min<int>((int)GATE_MAX_TILES, std::max(1, atoi(e)));
             const dim3 grid((n_dense + g.tiles_per_wg - 1) / g.tiles_per_wg);
-            if (g.tiles_per_wg == 1u) {
+            g.aspill = d.aspill;
+            if (d.allele_planes) {
+                if (g.tiles_per_wg == 1u) {
+                    if (d.wide_tot) hipLaunchKernelGGL((msnv_gate_sites<false, true, true>), grid, dim3(GATE_NT), 0, st, g);
+                    else hipLaunchKernelGGL((msnv_gate_sites<false, false, true>), grid, dim3(GATE_NT), 0, st, g);
+                } else {
+                    if (d.wide_tot) hipLaunchKernelGGL((msnv_gate_sites<true, true, true>), grid, dim3(GATE_NT), 0, st, g);
+                    else hipLaunchKernelGGL((msnv_gate_sites<true, false, true>), grid, dim3(GATE_NT), 0, st, g);
+                }
+            } else if (g.tiles_per_wg == 1u) {
                 if (d.wide_tot) hipLaunchKernelGGL((msnv_gate_sites<false, true>), grid, dim3(GATE_NT), 0, st, g);
                 else hipLaunchKernelGGL((msnv_gate_sites<false, false>), grid, dim3(GATE_NT), 0, st, g);
             } else {
@@ -2174,6 +2288,7 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
         ta.cells = CellMap{d.tile_site_base, d.tile_cell_base, d.tile_nslots, d.cap_cells, d.site_row};
         ta.gather_split = d.gather_split;
         ta.has_wide = d.n_work > d.n_work_narrow + d.n_work_merged ? 1u : 0u;
+        ta.aspill = d.allele_planes ? d.aspill : nullptr;
         ta.n_gather_blocks = d.n_gather_tiles * d.gather_split;
         ta.tile_pair_merged = d.tile_pair_merged; ta.merged_groups = d.merged_groups; ta.chunks = d.chunks; ta.hdr8m = d.hdr8m;
         ta.seq = d.seq; ta.qual = d.qual; ta.ref4 = d.ref4; ta.n_merged_blocks = d.n_merged_groups - (use_stage ? d.n_groups_solo : 0u); ta.min_baseq = (uint32_t)std::max(0, p.min_baseq);
@@ -2250,13 +2365,17 @@ static int ensure_alt(DeviceCols &d) {
     DeviceCols::AltBufs &a = d.alt;
     const uint64_t npos = (uint64_t)d.n_tiles * TILE;
     if (a.tot && a.cap_events == d.cap_events && a.cap_overflow == d.cap_overflow && a.cap_sites == d.cap_sites && a.cap_out_sites == d.cap_out_sites && a.cap_cells == d.cap_cells) return MSNV_OK;
-    void *old[] = {a.tot, a.part, a.spill, a.events, a.overflow, a.counters, a.ind4, a.tile_dirty, a.unc_sites, a.site_row, a.sites, a.tile_site_base, a.tile_site_cnt, a.tile_cell_base, a.ncol, a.cov_col, a.site_flags, a.site_elig, a.site_bits, a.site_rank, a.tile_stage};
+    void *old[] = {a.aspill, a.tot, a.part, a.spill, a.events, a.overflow, a.counters, a.ind4, a.tile_dirty, a.unc_sites, a.site_row, a.sites, a.tile_site_base, a.tile_site_cnt, a.tile_cell_base, a.ncol, a.cov_col, a.site_flags, a.site_elig, a.site_bits, a.site_rank, a.tile_stage};
     for (void *p : old) dev_free(p);
     a = DeviceCols::AltBufs{};
     if (int rc = dev_alloc((void **)&a.tot, std::max<uint64_t>(1, 4 * npos) * sizeof(uint32_t), &d.device_bytes)) return rc;
     if (int rc = dev_memset(a.tot, 0, std::max<uint64_t>(1, 4 * npos) * sizeof(uint32_t))) return rc;
     if (int rc = dev_alloc((void **)&a.part, d.part_bytes, &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.spill, std::max<uint64_t>(1, d.n_pairs) * TILE, &d.device_bytes)) return rc;
+    if (d.allele_planes) {
+        if (int rc = dev_alloc((void **)&a.aspill, (uint64_t)d.n_pairs * 4 * TILE, &d.device_bytes)) return rc;
+        if (int rc = dev_memset(a.aspill, 0, (uint64_t)d.n_pairs * 4 * TILE)) return rc;
+    }
     if (int rc = dev_alloc((void **)&a.events, (uint64_t)d.cap_events * sizeof(Pair32), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.overflow, (uint64_t)d.cap_overflow * sizeof(Pair32), &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.sites, (uint64_t)d.cap_sites * sizeof(SiteRec), &d.device_bytes)) return rc;
@@ -2290,6 +2409,7 @@ static int ensure_alt(DeviceCols &d) {
 static void swap_sets(DeviceCols &d) {
     DeviceCols::AltBufs &a = d.alt;
     std::swap(d.tot, a.tot); std::swap(d.part, a.part); std::swap(d.spill, a.spill); std::swap(d.events, a.events);
+    if (a.aspill) std::swap(d.aspill, a.aspill);
     std::swap(d.overflow, a.overflow); std::swap(d.counters, a.counters); std::swap(d.sites, a.sites);
     std::swap(d.tile_site_base, a.tile_site_base); std::swap(d.tile_site_cnt, a.tile_site_cnt); std::swap(d.tile_cell_base, a.tile_cell_base); std::swap(d.ncol, a.ncol); std::swap(d.cov_col, a.cov_col);
     std::swap(d.site_flags, a.site_flags); std::swap(d.site_elig, a.site_elig); std::swap(d.ind4, a.ind4); std::swap(d.unc_bits, a.unc_bits); std::swap(d.cnt_parity, a.cnt_parity);

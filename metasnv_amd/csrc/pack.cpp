@@ -627,6 +627,15 @@ int pack_sample(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, Sa
                             dst[j >> 1] = (uint8_t)((dst[j >> 1] & ~(0xf << sh)) | code << sh);  // low nibble first
                         }
                     }
+                    if (has_ref && (sc.hdr.size() & 15u) == 0u) {      // one piece in 16: how noisy are these reads? (finalize_dataset: dense allele planes)
+                        uint32_t mm = 0;
+                        for (uint32_t j = 0; j < n; ++j) {
+                            const int64_t g = rp + off + j;
+                            if (g < 0 || (size_t)g >= refseq.size()) break;
+                            mm += ((dst[j >> 1] >> (4u * (j & 1u))) & 0xfu) != nt16_of_char((unsigned char)refseq[(size_t)g]);
+                        }
+                        sc.mm_sampled_bases += n; sc.mm_sampled += mm;
+                    }
                     {   // qualities above 127 (0xff = "not stored") pass every cutoff; clamping keeps the comparison
                         const size_t qs = sc.qual.size();
                         sc.qual.resize(qs + n);
@@ -1080,7 +1089,8 @@ int finalize_dataset(msnv_dataset &ds) {
         for (uint64_t t = 0; t < nt; ++t) nslots_host[t] = ds.tile_slot_stride[t];
         std::vector<DeviceCols::GateTileH> gts;
         gts.reserve(active.size());
-        for (uint32_t t : active) gts.push_back(DeviceCols::GateTileH{t, tss[t], t16[t], twide[t], tss[t + 1], vb_host[t], ve_host[t], nslots_host[t], off[tss[t]], tot_mode(t), (uint32_t)fuse_tile[t]});
+        for (uint32_t t : active) gts.push_back(DeviceCols::GateTileH{t, tss[t], t16[t], twide[t], tss[t + 1], vb_host[t], ve_host[t], nslots_host[t], off[tss[t]], tot_mode(t), (uint32_t)fuse_tile[t],
+                                                                      tps[t], tpm[t] - tps[t], 0, 0});
         if (int rc = upload_vec(&d->gate_tiles, gts, &d->device_bytes, 1)) return rc;
         d->gather_split = (uint32_t)std::min<uint64_t>(4, std::max<uint64_t>(1, (active.empty() ? 0 : pairs.size() / active.size()) / 32));
         if (const char *e = getenv("MSNV_GATHER_SPLIT")) d->gather_split = (uint32_t)std::max(1, atoi(e));      // (tuning experiments)
@@ -1326,6 +1336,32 @@ int finalize_dataset(msnv_dataset &ds) {
     if (int rc = dev_alloc((void **)&d->tot, std::max<uint64_t>(1, 4 * npos) * sizeof(uint32_t), &d->device_bytes)) return rc;
     if (int rc = dev_memset(d->tot, 0, std::max<uint64_t>(1, 4 * npos) * sizeof(uint32_t))) return rc;   // the gate kernel keeps it zero between passes
     if (int rc = dev_alloc((void **)&d->spill, std::max<uint64_t>(1, (uint64_t)pairs.size()) * TILE, &d->device_bytes)) return rc;
+    {
+        // Allele bookkeeping of the narrow work items.  Clean reads (the benchmark's 0.1 % errors): a mismatching base is an EVENT -- one
+        // memory-side atomic on the position's totals + 8 bytes in the event list, scattered into the called sites' cells afterwards.
+        // At a few per cent of mismatches (real metagenomic reads against a species representative) every position carries some and the
+        // events are the pass: 37.7 M of them at 3 % = 1.2 ms of atomics in the pileup kernel + 1.5 ms of scatter (profiles/r03e).  Then
+        // the alleles go the way the coverage goes: every (sample, tile) pair writes four byte PLANES (A, C, G, T counts per position,
+        // 8 KB a pair, plain 16-byte stores), the gate kernel sums the planes, the gather transposes them into the cells.  Picked when the
+        // sampled mismatch rate says the events would cost more than the planes (from ~1.8 % at 10x: at 1 % the events still win, whole pass
+        // 0.80 vs 0.85 ms; at 3 % 3.55 vs 2.08 ms, at 10 % 8.5 vs 2.1 ms, profiles/r03g_*); MSNV_ALLELES=planes | events overrides.
+        // Needs byte counts everywhere: not with wide work items (MSNV_DEEP=wide) and not in the dense piece layout's kernel.
+        uint64_t sb = 0, sm = 0;
+        for (const SampleCols &sc : ds.samples) { sb += sc.mm_sampled_bases; sm += sc.mm_sampled; }
+        const double rate = sb ? (double)sm / (double)sb : 0.0;
+        const double est_events = rate * (double)tot_bases;
+        bool planes = est_events * 72.0 > (double)pairs.size() * 4.0 * TILE * 3.5;
+        if (const char *e = getenv("MSNV_ALLELES")) planes = e[0] == 'p';
+        if (dense || d->n_work > d->n_work_narrow + d->n_work_merged || pairs.empty()) planes = false;
+        d->allele_planes = planes;
+        if (planes) {
+            const uint64_t bytes = (uint64_t)pairs.size() * 4 * TILE;
+            if (int rc = dev_alloc((void **)&d->aspill, bytes, &d->device_bytes)) return rc;
+            if (int rc = dev_memset(d->aspill, 0, bytes)) return rc;      // (rows of merged pairs are never written and never read)
+        }
+        ds.info.allele_planes = planes ? 1 : 0;
+        ds.info.sampled_mismatch_ppm = (uint64_t)(rate * 1e6);
+    }
     // sparse buffers: generous first guess, grown on MSNV_ECAPACITY by the caller
     d->cap_events = (uint32_t)std::min<uint64_t>(0x7fffffffull, std::max<uint64_t>(1u << 20, tot_bases / 16));
     if (const char *e = getenv("MSNV_CAP_EVENTS")) d->cap_events = (uint32_t)std::max<long long>(EV_LISTS, atoll(e));   // tests: force the grow-and-rerun path

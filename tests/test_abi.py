@@ -19,7 +19,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert declared == bound, (declared - bound, bound - declared)
     for name in declared:
         assert hasattr(_lib.lib, name)
-    assert _lib.lib.msnv_abi_version() == 2
+    assert _lib.lib.msnv_abi_version() == 3
 
 
 def test_struct_layouts_match_the_header():

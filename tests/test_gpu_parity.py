@@ -267,6 +267,7 @@ def test_noisy_reads_reserve_their_event_ranges_per_pass(layout, monkeypatch):
     depth x error rate) than the 256-entry LDS staging buffer holds, so the pass reserves its range of the event list per
     wave and writes at prefix-sum offsets; passes that fit (shallow samples) keep staging -- both paths in one run."""
     monkeypatch.setenv("MSNV_LAYOUT", layout)
+    monkeypatch.setenv("MSNV_ALLELES", "events")                      # (reads this noisy would be switched to allele planes: this test is about the event path)
     syn, samples = synth_case(n_species=2, contig_len=9000, n_samples=9, mean_cov=25.0, sigma_cov=1.0, snv_density=0.02,
                               error_rate=0.06, frac_absent=0.0, seed=4242)
     prod = run_product(syn.names, syn.lengths, syn.seqs, samples)
@@ -435,6 +436,7 @@ def test_event_list_grows_when_a_sub_list_overflows(monkeypatch):
     """The allele-event list is 32 sub-lists with their own counters; a pass that overflows one reports the capacity the
     fullest asked for, the host grows the list and runs the pass again (msnv_pileup_run) -- same records, same event count."""
     syn, samples = synth_case(n_species=2, contig_len=7000, n_samples=8, mean_cov=14.0, snv_density=0.03, error_rate=0.01, seed=909)
+    monkeypatch.setenv("MSNV_ALLELES", "events")                      # (whatever the mismatch rate says: this test is about the event list)
     ref_run = run_product(syn.names, syn.lengths, syn.seqs, samples)
     monkeypatch.setenv("MSNV_CAP_EVENTS", "1024")                    # 32 events per sub-list: every list overflows
     prod = run_product(syn.names, syn.lengths, syn.seqs, samples)
@@ -1256,6 +1258,35 @@ def test_randomised_parity_sweep(monkeypatch):
         assert fuzz_parity.sweep(70, 2024, verbose=False) == 0
     finally:
         os.environ.pop("MSNV_LAYOUT", None)
+
+
+def test_randomised_parity_sweep_with_allele_planes(monkeypatch):
+    """The same sweep with the allele bookkeeping of noisy reads forced on (MSNV_ALLELES=planes, pack.cpp): every (sample, tile) pair of
+    an ordinary work item writes its mismatching A / C / G / T counts as four byte planes, the gate kernel sums the planes, the gather
+    transposes them into the cells -- no total atomics, no events.  Other seeds than the sweep above."""
+    import fuzz_parity
+    monkeypatch.setenv("MSNV_ALLELES", "planes")
+    monkeypatch.delenv("MSNV_LAYOUT", raising=False)
+    try:
+        assert fuzz_parity.sweep(70, 4711, verbose=False) == 0
+    finally:
+        os.environ.pop("MSNV_LAYOUT", None)
+
+
+@pytest.mark.parametrize("error_rate,expect_planes", [(0.001, 0), (0.04, 1)])
+def test_allele_bookkeeping_follows_the_sampled_mismatch_rate(error_rate, expect_planes):
+    """finalize samples every 16th piece against the reference: clean reads keep the sparse events, a few per cent of mismatches switch
+    the dataset to allele planes (reported in the dataset info).  Same bytes as the oracle either way, with many sites per tile, split
+    samples (one deep sample), merged groups in other tiles and both gather forms."""
+    syn, samples = synth_case(n_species=3, contig_len=5200, n_samples=24, mean_cov=10.0, sigma_cov=1.6, snv_density=0.03, error_rate=error_rate,
+                              frac_absent=0.1, seed=8800 + expect_planes)
+    p = core.default_params(min_coverage=3, calling_threshold=2)
+    prod = run_product(syn.names, syn.lengths, syn.seqs, samples, params=p)
+    orac = run_oracle(syn.names, syn.lengths, syn.seqs, samples, params=p)
+    _assert_same(prod, orac)
+    assert prod[2]["allele_planes"] == expect_planes
+    assert (prod[2]["sampled_mismatch_ppm"] > 20000) == bool(expect_planes)
+    assert prod[3]["n_events"] == 0 if expect_planes else prod[3]["n_events"] > 0
 
 
 def test_filtering_random_tables_against_python_formulas(tmp_path):
