@@ -36,6 +36,15 @@ constexpr uint32_t META_COV_OK    = 1u << 25;
 constexpr uint32_t SEQ_ALIGN_LOG2 = MSNV_SEQ_ALIGN_LOG2;
 constexpr uint32_t SEQ_ALIGN = 1u << SEQ_ALIGN_LOG2;
 static_assert(SEQ_ALIGN_LOG2 >= 1 && SEQ_ALIGN_LOG2 <= 3, "piece starts on 2, 4 or 8 bytes of the seq column");
+// Piece headers of the ordinary narrow work items: 4 bytes -- start in the tile (11 bits) | length (8) | seq offset relative to the
+// CHUNK's first byte in SEQ_ALIGN units (13 bits: a chunk spans < 16 KB of the seq column, pack.cpp closes it early otherwise); the
+// chunk descriptor carries the absolute base (uniform per chunk: scalar registers, the loads take base + 32-bit lane offset).
+// MSNV_HDR4=0 (build-time) keeps the 8-byte form {start | length << 11, offset in the sample / SEQ_ALIGN} for A/B runs.
+#ifndef MSNV_HDR4
+#define MSNV_HDR4 1
+#endif
+constexpr bool HDR4 = MSNV_HDR4 != 0;
+constexpr uint32_t HDR4_OFF_BITS = 13;
 constexpr uint32_t SEG_MAX = 128;            // bases per segment piece = 8 lanes x 16 bases
 constexpr uint32_t NARROW_MAX_DEPTH = 255;   // (tile, sample) pairs below this depth use byte-wide LDS bins
 

@@ -44,7 +44,8 @@ int  dev_annotate(DeviceCols &d, uint32_t n_sites, uint32_t drop_gpos, void *str
 struct DeviceCols {
     // ---- inputs (uploaded once by finalize)
     ReadHdr  *hdr = nullptr;         // 16-byte piece headers (wide kernel)
-    PieceHdr *hdr8 = nullptr;        // 8-byte tile-local piece headers (narrow32 kernel, MSNV_LAYOUT=pieces)
+    PieceHdr *hdr8 = nullptr;        // 8-byte tile-local piece headers (narrow32 kernel, MSNV_LAYOUT=pieces; MSNV_HDR4=0 builds)
+    uint32_t *hdr4 = nullptr;        // 4-byte chunk-relative piece headers (narrow32 kernel, default; dataset.h: HDR4)
     PieceHdr *hdr8m = nullptr;       // headers of the merged groups of shallow pairs, group by group: pair index in bits 19+, ABSOLUTE seq offset / 8
     uint32_t *tile_pair_merged = nullptr;   // per tile: first merged pair (they sit behind the tile's other pairs)
     uint32_t  n_work_merged = 0;     // work[n_work_narrow .. + n_work_merged) = merged items

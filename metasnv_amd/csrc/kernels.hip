@@ -33,7 +33,8 @@ static_assert(LANES_PER_READ * 16 == SEG_MAX, "segment pieces are sized for 8 la
 struct PileupArgs {
     const ReadHdr  *hdr;          // one 16-byte header per M/=/X segment piece: {gpos, seqoff, length, meta}
     const uint32_t *blk;          // dense layout: one descriptor per 32-base block
-    const PieceHdr *hdr8;         // the same pieces, tile-local 8-byte form: {start | length << 11, seqoff / 8}
+    const PieceHdr *hdr8;         // the same pieces, tile-local 8-byte form: {start | length << 11, seqoff / SEQ_ALIGN} (MSNV_HDR4=0 builds)
+    const uint32_t *hdr4;         // ... 4-byte form with chunk-relative offsets (dataset.h: HDR4), what the ordinary narrow work items read
     const PieceHdr *hdr8m;        // headers of the merged groups (pair index in bits 19+, absolute seq offset / 8)
     uint32_t        n_narrow;     // narrow32 launch: work items [0, n_narrow) are ordinary, the rest hold merged groups
     const uint8_t  *seq;
@@ -425,39 +426,33 @@ __device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_
     }
     // ---- allele events.  The allele bins are only looked at here, and word by word again when events are written: the
     // registers of the next chunk's column loads are live across this pass.
-    uint32_t pm = 0, myev;                                   // positions of mine with a mismatching allele; (position, allele) events
-    {
-        const uint4 a0 = *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid]);
-        const uint4 a1 = *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid + 4]);
-        const uint32_t alw[N_PPT] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    if constexpr (DA && !MERGED) {
+        uint8_t *row = a.aspill + (uint64_t)k * (4u * TILE) + N_PPT * tid;
+        const uint32_t ge = (0x80u - min(a.min_snvs, 127u)) * 0x01010101u;
 #pragma unroll
-        for (int j = 0; j < N_PPT; ++j) pm |= (alw[j] ? 1u : 0u) << j;
-        myev = count_nz_bytes(a0, a1);
-        if constexpr (DA && !MERGED) {
-            // byte x of the eight words -> eight bytes of plane x (v_perm_b32: selector bytes 0-3 pick from the second operand, 4-7 from the first)
-            uint8_t *row = a.aspill + (uint64_t)k * (4u * TILE) + N_PPT * tid;
-            uint32_t hit = 0;                                  // some allele of some position holds >= min_snvs reads (rare: SNV positions of this sample)
-            const uint32_t ge = (0x80u - min(a.min_snvs, 127u)) * 0x01010101u;
+        for (uint32_t half = 0; half < 2u; ++half) {
+            const uint4 v = *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid + 4u * half]);
+            const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+            // byte x of the four words -> four bytes of plane x (v_perm_b32: selector bytes 0-3 pick from the second operand, 4-7 from the first)
 #pragma unroll
             for (uint32_t x = 0; x < 4u; ++x) {
                 const uint32_t s2 = x | (4u + x) << 8 | 0x0c0c0000u;
-                const uint32_t t01 = __builtin_amdgcn_perm(alw[1], alw[0], s2), t23 = __builtin_amdgcn_perm(alw[3], alw[2], s2);
-                const uint32_t t45 = __builtin_amdgcn_perm(alw[5], alw[4], s2), t67 = __builtin_amdgcn_perm(alw[7], alw[6], s2);
-                *reinterpret_cast<uint2 *>(row + x * TILE) = make_uint2(__builtin_amdgcn_perm(t23, t01, 0x05040100u), __builtin_amdgcn_perm(t67, t45, 0x05040100u));
+                *reinterpret_cast<uint32_t *>(row + x * TILE + 4u * half) =
+                    __builtin_amdgcn_perm(__builtin_amdgcn_perm(w4[3], w4[2], s2), __builtin_amdgcn_perm(w4[1], w4[0], s2), 0x05040100u);
             }
+            if (!(v.x | v.y | v.z | v.w)) continue;
+            *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid + 4u * half]) = make_uint4(0u, 0u, 0u, 0u);      // the bins are left zero for the next sample
+            dirty = true;
+            // the individual rule's marks (see below): some allele holds >= min_snvs reads (rare: SNV positions of this sample); a split
+            // sample may reach the threshold only in sum: every position it holds an allele at is marked
+            uint32_t todo = 0;
 #pragma unroll
-            for (int j = 0; j < N_PPT; ++j) hit |= ((((alw[j] & 0x7f7f7f7fu) + ge) | alw[j]) & 0x80808080u) ? 1u << j : 0u;
-            if (pm) {                                          // the bins are left zero for the next sample
-                *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid]) = make_uint4(0u, 0u, 0u, 0u);
-                *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid + 4]) = make_uint4(0u, 0u, 0u, 0u);
-            }
-            dirty |= pm != 0u;
-            uint32_t todo = split ? pm : hit;                  // the individual rule's marks (see below); a split sample may reach the threshold only in sum
+            for (uint32_t j = 0; j < 4u; ++j) todo |= (split ? w4[j] != 0u : ((((w4[j] & 0x7f7f7f7fu) + ge) | w4[j]) & 0x80808080u) != 0u) ? 1u << j : 0u;
             while (todo) {
                 const uint32_t j = (uint32_t)__builtin_ctz(todo);
                 todo &= todo - 1u;
-                const uint32_t word = (j == 0u ? alw[0] : j == 1u ? alw[1] : j == 2u ? alw[2] : j == 3u ? alw[3] : j == 4u ? alw[4] : j == 5u ? alw[5] : j == 6u ? alw[6] : alw[7]);
-                const uint32_t gpos = t0 + N_PPT * tid + j;
+                const uint32_t word = j == 0u ? w4[0] : j == 1u ? w4[1] : j == 2u ? w4[2] : w4[3];
+                const uint32_t gpos = t0 + N_PPT * tid + 4u * half + j;
 #pragma unroll
                 for (uint32_t x = 0; x < 4u; ++x) {
                     const uint32_t n = (word >> (8u * x)) & 0xffu;
@@ -465,8 +460,17 @@ __device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_
                     else if (n && split) atomicOr(&a.unc_bits[gpos >> 5], 1u << (gpos & 31u));
                 }
             }
-            return;
         }
+        return;
+    }
+    uint32_t pm = 0, myev;
+    {
+        const uint4 a0 = *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid]);
+        const uint4 a1 = *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid + 4]);
+        const uint32_t alw[N_PPT] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+        for (int j = 0; j < N_PPT; ++j) pm |= (alw[j] ? 1u : 0u) << j;
+        myev = count_nz_bytes(a0, a1);
     }
     if (!__any(pm != 0u)) return;                            // no mismatching allele in this wavefront's 512 positions
     dirty |= pm != 0u;                                       // my 8 positions lie in one 64-position block (store_part_row tells the gate kernel)
@@ -689,7 +693,11 @@ __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a, NarrowL
     if constexpr (SEQ_ALIGN_LOG2 < 3) {
         if (tid < 33) {                                         // flag bit 4 j + k <-> base 8 k + j: the flags of bases 0 .. tid - 1
             uint32_t m = 0;
-            for (uint32_t b = 0; b < (uint32_t)tid; ++b) m |= 1u << (4u * (b & 7u) + (b >> 3));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                       // word k holds bases 8 k .. 8 k + 7: the first c of them
+                const int c = min(max(tid - 8 * k, 0), 8);
+                m |= (c >= 8 ? 0xffffffffu : (1u << (4 * c)) - 1u) & (0x11111111u << k);
+            }
             L.emask[tid] = m;
         }
     }
@@ -701,8 +709,20 @@ __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a, NarrowL
     // the chunk descriptors go through a ring of MAX_CHUNKS_PER_ITEM LDS slots: one deep (sample, tile) pair alone can
     // hold more chunks than that, so half of the ring is refilled every MAX_CHUNKS_PER_ITEM / 2 chunks (desc_refill)
     // the headers of chunk 0 do not wait for the descriptor stream: their descriptor came with the work item
+    constexpr bool H4 = HDR4 && !MERGED;                          // ordinary work items: 4-byte headers, offsets relative to the chunk's base
+    auto fetch_hdr = [&](const uint64_t hdr_base) -> uint2 {
+        if constexpr (H4) return make_uint2(a.hdr4[hdr_base + (uint32_t)tid], 0u);
+        else return *reinterpret_cast<const uint2 *>(a.hdr8 + hdr_base + tid);
+    };
+    // LDS staging of the headers: 4-byte slots for the 4-byte form (half the LDS traffic of the staging)
+    auto put_hdr = [&](const uint32_t buf, const uint2 h) {
+        if constexpr (H4) reinterpret_cast<uint32_t *>(L.hdr[buf])[tid] = h.x; else L.hdr[buf][tid] = h;
+    };
+    auto get_hdr = [&](const uint32_t buf, const uint32_t i) -> uint2 {
+        if constexpr (H4) return make_uint2(reinterpret_cast<const uint32_t *>(L.hdr[buf])[i], 0u); else return L.hdr[buf][i];
+    };
     uint2 hreg0 = make_uint2(0, 0);
-    if (nch && tid < N_HCAP && (uint32_t)tid < (w.first.nrd_flags & 0xffffu)) hreg0 = *reinterpret_cast<const uint2 *>(a.hdr8 + w.first.hdr_base + tid);
+    if (nch && tid < N_HCAP && (uint32_t)tid < (w.first.nrd_flags & 0xffffu)) hreg0 = fetch_hdr(w.first.hdr_base);
     for (uint32_t i = tid; i < min(nch, (uint32_t)MAX_CHUNKS_PER_ITEM) * 2; i += N_NT)
         reinterpret_cast<uint4 *>(L.desc)[i] = reinterpret_cast<const uint4 *>(a.chunks + w.chunk_lo)[i];
     __syncthreads();
@@ -713,30 +733,42 @@ __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a, NarrowL
     auto load_hdr = [&](const uint32_t c) -> uint2 {
         uint2 h = make_uint2(0, 0);                                   // slots beyond nrd hold length 0
         if (c < nch && tid < N_HCAP && (uint32_t)tid < (L.desc[c % MAX_CHUNKS_PER_ITEM].nrd_flags & 0xffffu))
-            h = *reinterpret_cast<const uint2 *>(a.hdr8 + L.desc[c % MAX_CHUNKS_PER_ITEM].hdr_base + tid);
+            h = fetch_hdr(L.desc[c % MAX_CHUNKS_PER_ITEM].hdr_base);
         return h;
     };
-    if (tid < N_HCAP) L.hdr[0][tid] = hreg0;                      // chunk 0: fetched through the descriptor that came with the work item
+    if (tid < N_HCAP) put_hdr(0u, hreg0);                         // chunk 0: fetched through the descriptor that came with the work item
     uint2 hreg = load_hdr(1);
     uint4 qa[N32_ROUNDS], qb[N32_ROUNDS], sq[N32_ROUNDS]; uint32_t P0[N32_ROUNDS]; int vh[N32_ROUNDS];
     auto issue_loads = [&](const uint32_t c) {
-        const uint64_t sbase = L.desc[c % MAX_CHUNKS_PER_ITEM].seq_base;
+        uint64_t sbase = L.desc[c % MAX_CHUNKS_PER_ITEM].seq_base;
+        // (4-byte headers: the chunk's base is the same in every lane -- scalar registers, so that a lane's address is base + 32-bit offset)
+        if constexpr (H4) sbase = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(sbase >> 32)) << 32 | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sbase);
         const uint8_t *seq = a.seq + sbase;
         const uint8_t *qual = a.qual + 2 * sbase;
 #pragma unroll
         for (int i = 0; i < N32_ROUNDS; ++i) {
-            const uint2 h = L.hdr[c & 1u][grp + i * N32_GROUPS];     // all zero for empty slots
+            const uint2 h = get_hdr(c & 1u, (uint32_t)(grp + i * N32_GROUPS));     // all zero for empty slots
             const uint32_t len = (h.x >> 11) & 0xffu;                // (bits 19-26: index of the piece's pair inside a merged group, for the gather)
             const uint32_t s = h.x & (TILE - 1u);
             // seq byte offset of the piece inside the sample; a merged group's pieces come from all over the column: their ABSOLUTE offset / SEQ_ALIGN is 37 bits wide (bits 27+ of the first word)
-            const uint64_t so = (MERGED ? ((uint64_t)(h.x >> 27) << 32 | h.y) : (uint64_t)h.y) << SEQ_ALIGN_LOG2;
             vh[i] = min(max((int)len - b0, 0), 32);
             qa[i] = any_uint4(); qb[i] = any_uint4(); sq[i] = any_uint4();   // never observed: vh masks every use
-            if (vh[i] > 0) {                                         // lanes past the end of the piece load nothing
-                const uint8_t *qp = qual + 2ull * so + (uint32_t)b0;       // pieces start on 16-byte (qual) / 8-byte (seq) boundaries
-                __builtin_memcpy(&qa[i], qp, 16);
-                if (vh[i] > 16) __builtin_memcpy(&qb[i], qp + 16, 16);
-                __builtin_memcpy(&sq[i], seq + so + (uint32_t)(b0 >> 1), 16);
+            if constexpr (H4) {
+                const uint32_t so = (h.x >> 19) << SEQ_ALIGN_LOG2;       // < 16 KB from the chunk's base
+                if (vh[i] > 0) {                                     // lanes past the end of the piece load nothing
+                    const uint32_t qo = 2u * so + (uint32_t)b0, sq_o = so + (uint32_t)(b0 >> 1);
+                    __builtin_memcpy(&qa[i], qual + qo, 16);
+                    if (vh[i] > 16) __builtin_memcpy(&qb[i], qual + qo + 16u, 16);
+                    __builtin_memcpy(&sq[i], seq + sq_o, 16);
+                }
+            } else {
+                const uint64_t so = (MERGED ? ((uint64_t)(h.x >> 27) << 32 | h.y) : (uint64_t)h.y) << SEQ_ALIGN_LOG2;
+                if (vh[i] > 0) {                                     // lanes past the end of the piece load nothing
+                    const uint8_t *qp = qual + 2ull * so + (uint32_t)b0;   // pieces start on 2 x SEQ_ALIGN (qual) / SEQ_ALIGN (seq) bytes
+                    __builtin_memcpy(&qa[i], qp, 16);
+                    if (vh[i] > 16) __builtin_memcpy(&qb[i], qp + 16, 16);
+                    __builtin_memcpy(&sq[i], seq + so + (uint32_t)(b0 >> 1), 16);
+                }
             }
             P0[i] = vh[i] > 0 ? s + (uint32_t)b0 : 0u;
         }
@@ -752,7 +784,7 @@ __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a, NarrowL
         desc_refill(L.desc, a.chunks + w.chunk_lo, c, nch, tid);
         if (!MERGED && !DA && L.evn >= (uint32_t)(N_EVCAP / 2)) flush_events<NarrowLds, N_NT, N_EVCAP>(L, a, tid);
         if (tid < N_HCAP) {
-            const uint32_t hx = L.hdr[c & 1u][tid].x;
+            const uint32_t hx = get_hdr(c & 1u, (uint32_t)tid).x;
             const uint32_t s = hx & (TILE - 1u), sb = s + ((hx >> 11) & 0xffu);
             if (sb != s) {                                           // coverage difference array: +1 at the start, -1 behind the end
                 atomicAdd(&L.start[s >> 2], 1u << (8u * (s & 3u)));
@@ -765,7 +797,7 @@ __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a, NarrowL
         for (int i = 0; i < N32_ROUNDS; ++i)
             if (__any(vh[i] > 0)) narrow_classify32(L, qa[i], qb[i], sq[i], P0[i], vh[i], kq);
 
-        if (tid < N_HCAP) L.hdr[(c + 1u) & 1u][tid] = hreg;          // headers of chunk c + 1 (zeros behind the last chunk)
+        if (tid < N_HCAP) put_hdr((c + 1u) & 1u, hreg);               // headers of chunk c + 1 (zeros behind the last chunk)
         hreg = load_hdr(c + 2u);
         __syncthreads();                                            // (B): this chunk is in the bins; the next chunk's headers are visible
         if (c + 1u < nch) issue_loads(c + 1u);                       // in flight under the per-sample pass
@@ -1008,6 +1040,14 @@ __device__ __forceinline__ void zero_span(uint8_t *p, const uint64_t n, const ui
 // u16 columns -- coverage and the four allele counts (structure of arrays: a site's row of cells is contiguous in every column)
 template <int NT>
 __device__ __forceinline__ void zero_cells(uint16_t *ncol, uint16_t *cov_col, const unsigned long long cap_cells, const unsigned long long first, const unsigned long long n, const uint32_t tid) {
+    if (n <= (unsigned long long)NT) {                              // a handful of cells (a sparse cohort's tile): one store per column and lane, no alignment bookkeeping
+        if (tid < (uint32_t)n) {
+#pragma unroll
+            for (int x = 0; x < 4; ++x) ncol[(uint64_t)x * cap_cells + first + tid] = 0;
+            cov_col[first + tid] = 0;
+        }
+        return;
+    }
 #pragma unroll
     for (int x = 0; x < 4; ++x) zero_span<NT>(reinterpret_cast<uint8_t *>(ncol + (uint64_t)x * cap_cells + first), n * sizeof(uint16_t), tid);
     zero_span<NT>(reinterpret_cast<uint8_t *>(cov_col + first), n * sizeof(uint16_t), tid);      // samples without reads at a position keep coverage 0
@@ -2153,7 +2193,7 @@ int dev_stream_create(void **stream) { hipStream_t s; HIP_TRY(hipStreamCreateWit
 void dev_stream_destroy(void *stream) { if (stream) (void)hipStreamDestroy((hipStream_t)stream); }
 
 void dev_free_all(DeviceCols &d) {
-    void *ptrs[] = {d.hdr, d.hdr8, d.hdr8m, d.merged_groups, d.tile_pair_merged, d.blk, d.seq, d.qual, d.s_read_base, d.s_seq_base, d.ref4, d.ref_lc, d.pairs,
+    void *ptrs[] = {d.hdr, d.hdr8, d.hdr4, d.hdr8m, d.merged_groups, d.tile_pair_merged, d.blk, d.seq, d.qual, d.s_read_base, d.s_seq_base, d.ref4, d.ref_lc, d.pairs,
                     d.tile_pair_start, d.work, d.chunks, d.tile_vbeg, d.tile_vend, d.tot, d.part, d.tile_slot_start, d.tile_slot_u16, d.tile_slot_wide, d.slot_off, d.spill, d.events, d.overflow, d.counters, d.ind4, d.tile_dirty, d.unc_sites, d.site_row, d.gate_tiles,
                     d.sites, d.tile_site_base, d.tile_site_cnt, d.tile_cell_base, d.tile_nslots, d.ncol, d.cov_col, d.site_flags, d.site_elig,
                     d.cov_iv, d.s_cov_base, d.cov_pairs, d.cov_work, d.tile_len, d.tile_contig_dev, d.cov_acc, d.tile_stage, d.tile_stage_idx, d.alt.tile_stage, d.gate_tiles_dense, d.gate_tiles_staged, d.gather_tiles};
@@ -2208,7 +2248,7 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
     HIP_TRY(hipEventRecord(ev_pile0, st));
     if (d.n_work) {
         PileupArgs a;
-        a.hdr = d.hdr; a.hdr8 = d.hdr8; a.blk = d.blk; a.seq = d.seq; a.qual = d.qual;
+        a.hdr = d.hdr; a.hdr8 = d.hdr8; a.hdr4 = d.hdr4; a.blk = d.blk; a.seq = d.seq; a.qual = d.qual;
         a.s_read_base = d.s_read_base; a.s_seq_base = d.s_seq_base;
         a.ref4 = d.ref4; a.pairs = d.pairs; a.work = d.work; a.chunks = d.chunks; a.tot = d.tot; a.part = d.part; a.npos = npos; a.spill = d.spill; a.aspill = d.aspill;
         a.events = d.events; a.cap_events = d.cap_events / EV_LISTS; a.ev_count = nullptr; a.overflow = d.overflow; a.cap_overflow = d.cap_overflow;

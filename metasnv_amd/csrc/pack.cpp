@@ -1120,6 +1120,8 @@ int finalize_dataset(msnv_dataset &ds) {
     }
     // ---- chunk descriptors of the narrow work items
     std::vector<ChunkDesc> chunks;
+    std::vector<std::vector<uint32_t>> hdr4_of(HDR4 && !dense ? S : 0);      // 4-byte piece headers, per sample (chunk-relative offsets: filled with the chunks)
+    for (size_t s = 0; s < hdr4_of.size(); ++s) hdr4_of[s].assign(ds.samples[s].hdr.size(), 0u);
     for (uint32_t wi = 0; wi < d->n_work_narrow; ++wi) {
         WorkItem &w = work[wi];
         w.chunk_lo = (uint32_t)chunks.size();
@@ -1130,6 +1132,29 @@ int finalize_dataset(msnv_dataset &ds) {
                     const uint32_t n = std::min<uint32_t>(DENSE_CHUNK_BLOCKS, p.nblk - b);
                     chunks.push_back(ChunkDesc{bbase[p.sample] + p.blk_lo + b, sbase[p.sample] + p.seq0 + 16ull * b, p.pad >> 8, k,
                                                n | (b + n >= p.nblk ? 1u << 16 : 0u), p.pad & 0xffu});      // "sample" = the sample's slot in the tile
+                }
+                continue;
+            }
+            if (HDR4) {
+                // a chunk = up to CHUNK_READS consecutive pieces whose seq bytes lie within 2^HDR4_OFF_BITS alignment units of the chunk's
+                // lowest offset (always true for pieces in storage order; the pieces a read leaves in the NEXT tile sit a little before
+                // that tile's other pieces); seq_base = the absolute offset of that lowest byte, the headers hold the distance to it
+                const SampleCols &sc = ds.samples[p.sample];
+                std::vector<uint32_t> &h4 = hdr4_of[p.sample];
+                constexpr uint64_t span_max = (uint64_t)SEQ_ALIGN << HDR4_OFF_BITS;
+                uint32_t r = p.read_lo;
+                while (r < p.read_hi) {
+                    uint64_t lo = sc.hdr[r].seqoff, hi = lo;
+                    uint32_t e = r;
+                    while (e < p.read_hi && e - r < CHUNK_READS) {
+                        const uint64_t o = sc.hdr[e].seqoff, nlo = std::min(lo, o), nhi = std::max(hi, o);
+                        if (nhi - nlo >= span_max) break;
+                        lo = nlo; hi = nhi; ++e;
+                    }
+                    for (uint32_t i = r; i < e; ++i)
+                        h4[i] = (sc.hdr[i].gpos % TILE) | sc.hdr[i].cig << 11 | (uint32_t)((sc.hdr[i].seqoff - lo) >> SEQ_ALIGN_LOG2) << 19;
+                    chunks.push_back(ChunkDesc{rbase[p.sample] + r, sbase[p.sample] + lo, p.pad >> 8, k, (e - r) | (e >= p.read_hi ? 1u << 16 : 0u), p.pad & 0xffu});
+                    r = e;
                 }
                 continue;
             }
@@ -1188,7 +1213,8 @@ int finalize_dataset(msnv_dataset &ds) {
     // ---- columns
     d->n_reads = rbase[S]; d->n_seq_bytes = sbase[S];
     if (int rc = dev_alloc((void **)&d->hdr, (rbase[S] + 1) * sizeof(ReadHdr), &d->device_bytes)) return rc;
-    if (!dense) if (int rc = dev_alloc((void **)&d->hdr8, (rbase[S] + 1) * sizeof(PieceHdr), &d->device_bytes)) return rc;
+    if (!dense && !HDR4) if (int rc = dev_alloc((void **)&d->hdr8, (rbase[S] + 1) * sizeof(PieceHdr), &d->device_bytes)) return rc;
+    if (!dense && HDR4) if (int rc = dev_alloc((void **)&d->hdr4, (rbase[S] + 4) * sizeof(uint32_t), &d->device_bytes)) return rc;
     if (dense) if (int rc = dev_alloc((void **)&d->blk, (bbase[S] + 1) * sizeof(uint32_t), &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->seq, sbase[S] + 256, &d->device_bytes)) return rc;     // lanes past the end of the last piece read on
     if (int rc = dev_alloc((void **)&d->qual, 2 * sbase[S] + 512, &d->device_bytes)) return rc;
@@ -1209,6 +1235,9 @@ int finalize_dataset(msnv_dataset &ds) {
                 int rc = dev_upload(d->hdr + rbase[s], sc.hdr.data(), sc.hdr.size() * sizeof(ReadHdr));
                 if (!rc && dense) {
                     rc = dev_upload(d->blk + bbase[s], sc.blk.data(), sc.blk.size() * sizeof(uint32_t));
+                } else if (!rc && HDR4) {
+                    rc = dev_upload(d->hdr4 + rbase[s], hdr4_of[s].data(), hdr4_of[s].size() * sizeof(uint32_t));
+                    std::vector<uint32_t>().swap(hdr4_of[s]);
                 } else if (!rc) {   // compact tile-local headers of the narrow kernel: {start in tile | length << 11, seq offset / SEQ_ALIGN}
                     std::vector<PieceHdr> h8(sc.hdr.size());
                     for (size_t i = 0; i < sc.hdr.size(); ++i) h8[i] = PieceHdr{(sc.hdr[i].gpos % TILE) | sc.hdr[i].cig << 11, sc.hdr[i].seqoff >> SEQ_ALIGN_LOG2};
@@ -1230,7 +1259,7 @@ int finalize_dataset(msnv_dataset &ds) {
         if (up_err.load()) return fail(up_err.load(), "%s", up_msg.c_str());
         for (size_t s = 0; s < S; ++s) {
             const SampleCols &sc = ds.samples[s];
-            ds.info.bytes_headers += dense ? (rbase[s + 1] - rbase[s]) * 0 + (bbase[s + 1] - bbase[s]) * sizeof(uint32_t) : sc.hdr.size() * sizeof(PieceHdr);
+            ds.info.bytes_headers += dense ? (bbase[s + 1] - bbase[s]) * sizeof(uint32_t) : sc.hdr.size() * (HDR4 ? sizeof(uint32_t) : sizeof(PieceHdr));
             ds.info.bytes_cigar += sc.alg_cigar_bytes;
             alg += sc.alg_8d_bytes;
             ds.info.bytes_seq += sc.alg_seq_bytes;

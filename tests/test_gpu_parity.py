@@ -1278,8 +1278,8 @@ def test_allele_bookkeeping_follows_the_sampled_mismatch_rate(error_rate, expect
     """finalize samples every 16th piece against the reference: clean reads keep the sparse events, a few per cent of mismatches switch
     the dataset to allele planes (reported in the dataset info).  Same bytes as the oracle either way, with many sites per tile, split
     samples (one deep sample), merged groups in other tiles and both gather forms."""
-    syn, samples = synth_case(n_species=3, contig_len=5200, n_samples=24, mean_cov=10.0, sigma_cov=1.6, snv_density=0.03, error_rate=error_rate,
-                              frac_absent=0.1, seed=8800 + expect_planes)
+    syn, samples = synth_case(n_species=3, contig_len=5200, n_samples=24, mean_cov=10.0, sigma_cov=1.6, snv_density=0.03 if expect_planes else 0.004,
+                              error_rate=error_rate, frac_absent=0.1, seed=8800 + expect_planes)
     p = core.default_params(min_coverage=3, calling_threshold=2)
     prod = run_product(syn.names, syn.lengths, syn.seqs, samples, params=p)
     orac = run_oracle(syn.names, syn.lengths, syn.seqs, samples, params=p)
