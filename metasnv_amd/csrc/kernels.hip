@@ -587,7 +587,12 @@ __device__ __forceinline__ void narrow_classify32(NarrowLds &L, const uint4 qa, 
 #pragma unroll
     for (int w = 0; w < 5; ++w) {
         const uint32_t byte = (uint32_t)(m >> (8 * w)) & 0xffu;
+#if defined(MSNV_SPREAD_ALU)
+        // bit k of the byte -> byte k: two 24-bit multiplies instead of a table read the atomic has to wait for
+        if (byte) atomicAdd(&L.exc[wi + w], (unsigned long long)(__umul24(byte >> 4, 0x00204081u) & 0x01010101u) << 32 | (__umul24(byte & 0xfu, 0x00204081u) & 0x01010101u));
+#else
         if (byte) atomicAdd(&L.exc[wi + w], L.spread[byte]);
+#endif
     }
     const uint32_t sw[4] = {sq.x, sq.y, sq.z, sq.w};
     const uint32_t rw[4] = {__builtin_amdgcn_alignbit(w1, w0, sh), __builtin_amdgcn_alignbit(w2, w1, sh),

@@ -957,7 +957,10 @@ int finalize_dataset(msnv_dataset &ds) {
         // (at 4x the benchmark size 1000 still beats 2000: 55.5 vs 54.5 % of the roofline, so the size is a constant)
         // Items stay in tile order: dispatching the longest items first (shorter last wave of workgroups) measured 3 % SLOWER
         // (0.595 -> 0.612 ms) -- neighbouring items of a tile share the reference and the allele-total lines in L2.
-        uint64_t target = 1000;
+        // (round 3, after the kernel had lost 9 % of its time: 1000 -> 0.5544 ms kernel / 0.6269 ms pass, 1400 -> 0.5520 / 0.6232,
+        // 2000 -> 0.5510 / 0.6197, 2800 -> 0.5536 / 0.6235 over four alternations, profiles/r03k_ab_items.txt: flat in the kernel, the gate
+        // kernel sums fewer partial rows)
+        uint64_t target = 2000;
         if (const char *e = getenv("MSNV_ITEM_PIECES")) target = std::max<uint64_t>(64, (uint64_t)atoll(e));
         std::vector<WorkItem> wide, merged;
         auto chunks_of = [&](const TilePair &q) -> uint64_t {
