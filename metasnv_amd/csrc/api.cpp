@@ -992,14 +992,30 @@ extern "C" int msnv_call_from_mpileup(msnv_ctx *ctx, const msnv_mpileup_args *a,
         const bool from_stdin = !a->mpileup_path || !strcmp(a->mpileup_path, "-");
         FILE *f = from_stdin ? stdin : fopen(a->mpileup_path, "rb");
         if (!f) return fail(MSNV_EIO, "cannot open %s", a->mpileup_path);
-        std::string buf;
-        std::vector<char> block(16u << 20);
+        // read straight into one buffer that grows with realloc (large blocks are remapped, not copied: no second copy of a
+        // multi-GB pileup at the peak, which a growing std::string makes); a regular file is sized up front
+        size_t cap = 64u << 20, len = 0;
+        if (!from_stdin && fseek(f, 0, SEEK_END) == 0) { const long z = ftell(f); if (z > 0) cap = (size_t)z + 1; fseek(f, 0, SEEK_SET); }
+        char *buf = (char *)malloc(cap);
+        if (!buf) { if (!from_stdin) fclose(f); return fail(MSNV_ENOMEM, "out of memory for the pileup text"); }
         size_t n;
-        while ((n = fread(block.data(), 1, block.size(), f)) > 0) buf.append(block.data(), n);
+        while ((n = fread(buf + len, 1, cap - len, f)) > 0) {
+            len += n;
+            if (len == cap) {
+                char *nb = (char *)realloc(buf, cap + cap / 2);
+                if (!nb) { free(buf); if (!from_stdin) fclose(f); return fail(MSNV_ENOMEM, "out of memory for the pileup text"); }
+                buf = nb; cap += cap / 2;
+            }
+        }
         const bool bad = ferror(f) != 0;
         if (!from_stdin) fclose(f);
-        if (bad) return fail(MSNV_EIO, "read error on %s", from_stdin ? "stdin" : a->mpileup_path);
-        return text_call(ctx, buf.data(), buf.size(), a->params, a->ref_fasta, a->ann_path, a->out_called_path, a->out_indiv_path, stats);
+        if (bad) { free(buf); return fail(MSNV_EIO, "read error on %s", from_stdin ? "stdin" : a->mpileup_path); }
+        buf[len] = 0;                                                  // (len < cap here: the loop grows the buffer when it fills)
+        int rc;
+        try { rc = text_call(ctx, buf, len, a->params, a->ref_fasta, a->ann_path, a->out_called_path, a->out_indiv_path, stats); }
+        catch (...) { free(buf); throw; }
+        free(buf);
+        return rc;
     } catch (const std::exception &e) { return fail(MSNV_ENOMEM, "msnv_call_from_mpileup: %s", e.what()); }
 }
 

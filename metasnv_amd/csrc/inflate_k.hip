@@ -183,7 +183,9 @@ __global__ __launch_bounds__(64) void msnv_inflate_blocks(const uint8_t *__restr
     // one window at a time is handled by reloading
     auto resync = [&]() {
         const uint32_t wi = (a0 + ip) >> 2;
-        if (wi >= win_at + 64u) {
+        // (also backwards: the stored-block path hands unread bytes of the bit buffer back; with today's refill sizes ip never falls
+        // behind the window, but readlane(win, wi - win_at) with a wrapped index would read the wrong dword without any error)
+        if (wi < win_at || wi >= win_at + 64u) {
             win_at = wi & ~63u;
             win = win_at + (uint32_t)lane < n_words ? wsrc[win_at + lane] : 0u;
             win_next = win_at + 64u + (uint32_t)lane < n_words ? wsrc[win_at + 64u + lane] : 0u;

@@ -48,7 +48,7 @@ struct PileupArgs {
     uint8_t        *part;         // coverage summed over the item's samples, one row per work item (plain stores)
     uint64_t        npos;
     uint8_t        *spill;
-    uint8_t        *aspill;       // allele planes (noisy reads): [pair][A, C, G, T][TILE] mismatch counts of the pair, instead of events and total atomics
+    uint8_t        *aspill;       // allele rows (noisy reads): [pair][TILE] words A | C << 8 | G << 16 | T << 24 = the pair's mismatch counts per position, instead of events and total atomics
     Pair32         *events;   uint32_t cap_events;   // this work item's sub-list (ev_list) and the capacity of ONE sub-list
     Pair32         *overflow; uint32_t cap_overflow;
     uint32_t       *counters;
@@ -427,19 +427,13 @@ __device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_
     // ---- allele events.  The allele bins are only looked at here, and word by word again when events are written: the
     // registers of the next chunk's column loads are live across this pass.
     if constexpr (DA && !MERGED) {
-        uint8_t *row = a.aspill + (uint64_t)k * (4u * TILE) + N_PPT * tid;
+        uint32_t *row = reinterpret_cast<uint32_t *>(a.aspill) + (uint64_t)k * TILE + N_PPT * tid;      // the pair's row of allele words: A | C << 8 | G << 16 | T << 24 per position
         const uint32_t ge = (0x80u - min(a.min_snvs, 127u)) * 0x01010101u;
 #pragma unroll
         for (uint32_t half = 0; half < 2u; ++half) {
             const uint4 v = *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid + 4u * half]);
             const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
-            // byte x of the four words -> four bytes of plane x (v_perm_b32: selector bytes 0-3 pick from the second operand, 4-7 from the first)
-#pragma unroll
-            for (uint32_t x = 0; x < 4u; ++x) {
-                const uint32_t s2 = x | (4u + x) << 8 | 0x0c0c0000u;
-                *reinterpret_cast<uint32_t *>(row + x * TILE + 4u * half) =
-                    __builtin_amdgcn_perm(__builtin_amdgcn_perm(w4[3], w4[2], s2), __builtin_amdgcn_perm(w4[1], w4[0], s2), 0x05040100u);
-            }
+            *reinterpret_cast<uint4 *>(row + 4u * half) = v;         // the bins as they are: 16-byte stores, 8 KB per pair
             if (!(v.x | v.y | v.z | v.w)) continue;
             *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid + 4u * half]) = make_uint4(0u, 0u, 0u, 0u);      // the bins are left zero for the next sample
             dirty = true;
@@ -614,8 +608,17 @@ __device__ __forceinline__ void narrow_classify32(NarrowLds &L, const uint4 qa, 
         const uint32_t b = (uint32_t)__builtin_ctz(E);
         E &= E - 1u;
         const uint32_t k = b & 3u, jn = b >> 2, j = jn + 8u * k;
+#if defined(MSNV_MISM_BRANCHY)
         if ((lq >> j) & 1u) continue;                                  // below the BQ cutoff: already in exc
         const uint32_t word = (k == 0u) ? sw[0] : (k == 1u) ? sw[1] : (k == 2u) ? sw[2] : sw[3];
+#else
+        // the word that holds the base, picked with bit-field inserts: as a chain of ?: the compiler made it three nested divergent
+        // branches (exec-mask bookkeeping on the scalar unit for a loop body that runs with a handful of lanes)
+        const uint32_t m1 = 0u - (k & 1u), m2 = 0u - (k >> 1);
+        const uint32_t lo = (sw[1] & m1) | (sw[0] & ~m1), hi = (sw[3] & m1) | (sw[2] & ~m1);
+        const uint32_t word = (hi & m2) | (lo & ~m2);
+        if ((lq >> j) & 1u) continue;                                  // below the BQ cutoff: already in exc
+#endif
         const uint32_t code = (word >> (4u * jn)) & 0xfu;
         const uint32_t p = P0 + j;
         if ((code & (code - 1u)) == 0u) {
@@ -1289,38 +1292,39 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
             // u8 coverage rows, two positions per register, widened every 255 rows; merged groups still came through the totals above
             const uint32_t npl = gt.n_plane_pairs;
             if (npl) {
-#pragma unroll 1
-                for (int x = 0; x < 4; ++x) {
-                    const uint8_t *p8 = a.aspill + ((uint64_t)gt.pair_lo * 4u + (uint32_t)x) * TILE + p0;
-                    uint32_t sum[GATE_PPT];
+                // even bytes (A, G) and odd bytes (C, T) of the words as u16 pairs: ae[j] = A | G << 16, ao[j] = C | T << 16 of my position j
+                const uint32_t *p32 = reinterpret_cast<const uint32_t *>(a.aspill) + (uint64_t)gt.pair_lo * TILE + p0;
+                for (uint32_t r0 = 0; r0 < npl; r0 += 256u) {                 // (a u16 half holds 256 rows of bytes)
+                    uint32_t ae[GATE_PPT], ao[GATE_PPT];
 #pragma unroll
-                    for (int j = 0; j < GATE_PPT; ++j) sum[j] = 0u;
-                    for (uint32_t r0 = 0; r0 < npl; r0 += 255u) {
-                        uint32_t h[4] = {0u, 0u, 0u, 0u};
-                        const uint32_t r1 = min(npl, r0 + 255u);
-                        uint32_t sidx = r0;
-                        for (; sidx + 8u <= r1; sidx += 8u) {
-                            uint2 v[8];
+                    for (int j = 0; j < GATE_PPT; ++j) { ae[j] = 0u; ao[j] = 0u; }
+                    const uint32_t r1 = min(npl, r0 + 256u);
+                    uint32_t sidx = r0;
+                    for (; sidx + 4u <= r1; sidx += 4u) {
+                        uint4 v[4][2];
 #pragma unroll
-                            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const uint2 *>(p8 + (uint64_t)(sidx + (uint32_t)u) * (4u * TILE));
-#pragma unroll
-                            for (int u = 0; u < 8; ++u) {
-                                h[0] += v[u].x & 0x00ff00ffu; h[1] += (v[u].x >> 8) & 0x00ff00ffu;
-                                h[2] += v[u].y & 0x00ff00ffu; h[3] += (v[u].y >> 8) & 0x00ff00ffu;
-                            }
+                        for (int u = 0; u < 4; ++u) {
+                            const uint4 *q = reinterpret_cast<const uint4 *>(p32 + (uint64_t)(sidx + (uint32_t)u) * TILE);
+                            v[u][0] = q[0]; v[u][1] = q[1];
                         }
-                        for (; sidx < r1; ++sidx) {
-                            const uint2 v = *reinterpret_cast<const uint2 *>(p8 + (uint64_t)sidx * (4u * TILE));
-                            h[0] += v.x & 0x00ff00ffu; h[1] += (v.x >> 8) & 0x00ff00ffu;
-                            h[2] += v.y & 0x00ff00ffu; h[3] += (v.y >> 8) & 0x00ff00ffu;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const uint32_t w8[8] = {v[u][0].x, v[u][0].y, v[u][0].z, v[u][0].w, v[u][1].x, v[u][1].y, v[u][1].z, v[u][1].w};
+#pragma unroll
+                            for (int j = 0; j < GATE_PPT; ++j) { ae[j] += w8[j] & 0x00ff00ffu; ao[j] += (w8[j] >> 8) & 0x00ff00ffu; }
                         }
-                        sum[0] += h[0] & 0xffffu; sum[2] += h[0] >> 16; sum[1] += h[1] & 0xffffu; sum[3] += h[1] >> 16;
-                        sum[4] += h[2] & 0xffffu; sum[6] += h[2] >> 16; sum[5] += h[3] & 0xffffu; sum[7] += h[3] >> 16;
+                    }
+                    for (; sidx < r1; ++sidx) {
+                        const uint4 *q = reinterpret_cast<const uint4 *>(p32 + (uint64_t)sidx * TILE);
+                        const uint4 v0 = q[0], v1 = q[1];
+                        const uint32_t w8[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                        for (int j = 0; j < GATE_PPT; ++j) { ae[j] += w8[j] & 0x00ff00ffu; ao[j] += (w8[j] >> 8) & 0x00ff00ffu; }
                     }
 #pragma unroll
                     for (int j = 0; j < GATE_PPT; ++j) {
-                        if (WIDE_TOT) nn[4 * j + x] += sum[j];
-                        else nn[2 * j + (x >> 1)] += sum[j] << (16 * (x & 1));
+                        if (WIDE_TOT) { nn[4 * j] += ae[j] & 0xffffu; nn[4 * j + 1] += ao[j] & 0xffffu; nn[4 * j + 2] += ae[j] >> 16; nn[4 * j + 3] += ao[j] >> 16; }
+                        else { nn[2 * j] += (ae[j] & 0xffffu) | ao[j] << 16; nn[2 * j + 1] += (ae[j] >> 16) | (ao[j] & 0xffff0000u); }
                     }
                 }
             }
@@ -1568,6 +1572,11 @@ __global__ __launch_bounds__(256) void msnv_gate_staged(const GateArgs a, const 
 }
 
 // ------------------------------------------------------------------------------------------
+// First cell of allele column x (A, C, G, T): x * cap_cells without a 64-bit vector multiply (x differs from lane to lane, the
+// capacity is uniform: two selects and an add)
+__device__ __forceinline__ unsigned long long ncol_base(const uint32_t x, const unsigned long long cap_cells) {
+    return ((x & 1u) ? cap_cells : 0ull) + ((x & 2u) ? cap_cells << 1 : 0ull);
+}
 // The u16 fields of the site records are summed with 32-bit atomics on the aligned word that holds them (sums stay below
 // 65536: the depth cap is 8000), so that a sample which was split into several (sample, tile) pairs adds up.
 __device__ __forceinline__ void add_u16(uint16_t *field, uint32_t v) {
@@ -1587,7 +1596,7 @@ struct TailArgs {
     uint8_t *site_flags; const uint8_t *site_elig; uint32_t ind_in_gather, min_snvs;
     uint16_t *ncol; uint16_t *cov_col; uint32_t cap_out; const uint32_t *active_tiles; uint32_t n_gather_blocks;
     CellMap cells; uint32_t gather_split;
-    const uint8_t *aspill;                      // allele planes of the pairs (noisy reads), else NULL: gathered into the four allele columns like the coverage bytes
+    const uint8_t *aspill;                      // allele rows of the pairs (noisy reads: a word per position), else NULL: gathered into the four allele columns like the coverage bytes
     uint32_t has_wide;                          // some work item runs the wide kernel (coverage bytes of 255 stand for an overflow-list entry the scatter half writes)
     const Pair32 *events, *overflow; uint32_t *counters; uint32_t cap_list, cap_overflow;
     const unsigned long long *site_bits; const uint32_t *site_rank;
@@ -1604,15 +1613,9 @@ constexpr uint32_t GW_ROW = 34;                // words per LDS row of 64 slots 
 // rows that start on 16 bytes: the tile's cell stride is a multiple of 8 (pack.cpp pads tiles of >= 16 slots) and so is its first
 // cell (the gate kernels reserve in multiples of 8).  Slots of merged pairs (behind the others) belong to gather_merged_block: the
 // group of eight that straddles their first slot is written cell by cell.
-constexpr uint32_t GW_MAX_BLOCKS = 256;        // 64-slot blocks of a tile (<= 16383 samples)
-// Byte planes a pair leaves behind: plane 0 = its coverage bytes (spill), planes 1-4 = its mismatching A, C, G, T counts (allele planes:
-// noisy reads only); plane p of the tile's pair kk, position off: src[kk * stride + off]; it lands in column col.
-struct PlaneSrc { const uint8_t *src; uint64_t stride; uint16_t *col; };
-__device__ __forceinline__ PlaneSrc plane_of(const TailArgs &a, const uint32_t ps, const uint32_t pl) {
-    if (pl == 0u) return PlaneSrc{a.spill + (uint64_t)ps * TILE, TILE, a.cov_col};
-    return PlaneSrc{a.aspill + ((uint64_t)ps * 4u + (pl - 1u)) * TILE, 4u * TILE, a.ncol + (uint64_t)(pl - 1u) * a.cells.cap_cells};
-}
-__device__ __forceinline__ void gather_cov_wide(const TailArgs &a, const uint32_t n_planes, uint32_t *s_acc, uint32_t *s_off, uint32_t *s_blk, const uint32_t t0, const uint32_t base, const uint32_t stride,
+constexpr uint32_t GW_MAX_BLOCKS = 64;         // 64-slot blocks of a tile this form takes (<= 4096 slots; larger cohorts keep the two-byte form)
+constexpr uint32_t GW_SITES = 64;              // sites per LDS block: 64 x 64 slots x u16 = 8.7 KB (32: the many-site gather 8 % slower, the benchmark shape's tail the same: profiles/r03l_phase_times.txt)
+__device__ __forceinline__ void gather_cov_wide(const TailArgs &a, uint32_t *s_acc, uint32_t *s_off, uint32_t *s_blk, const uint32_t t0, const uint32_t base, const uint32_t stride,
                                                 const unsigned long long cell0, const uint32_t ps, const uint32_t np, const bool tile_has_merged, const uint32_t j_lo, const uint32_t dense_n) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     // slots are numbered in pair order (the pairs of a split sample share one): first pair of every block of 64 slots
@@ -1624,19 +1627,19 @@ __device__ __forceinline__ void gather_cov_wide(const TailArgs &a, const uint32_
     if (tid == 0u) s_blk[nblk] = np;
     // cells of the last group of eight that this path may write as a whole: everything when no merged pair follows, else up to the first merged slot
     const uint32_t wide_end = tile_has_merged ? (n_real & ~7u) : stride;
-    for (uint32_t jj0 = 0; jj0 < dense_n; jj0 += 64u) {
-        const uint32_t nS = min(64u, dense_n - jj0);
+    for (uint32_t jj0 = 0; jj0 < dense_n; jj0 += GW_SITES) {
+        const uint32_t nS = min(GW_SITES, dense_n - jj0);
         __syncthreads();                                            // (the block before has been written out; s_blk is visible)
-        if (tid < 64u) s_off[tid] = a.sites[base + j_lo + jj0 + min(tid, nS - 1u)].gpos - t0;   // (idle lanes: a valid position; their rows are not written out)
-        for (uint32_t pb = 0; pb < n_planes * nblk; ++pb) {
-            const uint32_t pl = pb / nblk, b = pb % nblk;
-            const PlaneSrc P = plane_of(a, ps, pl);
-            const uint8_t *src = P.src; const uint64_t src_stride = P.stride; uint16_t *col = P.col;
+        if (tid < GW_SITES) s_off[tid] = a.sites[base + j_lo + jj0 + min(tid, nS - 1u)].gpos - t0;   // (idle lanes: a valid position; their rows are not written out)
+        for (uint32_t b = 0; b < nblk; ++b) {
+            const uint8_t *src = a.spill + (uint64_t)ps * TILE; const uint64_t src_stride = TILE; uint16_t *col = a.cov_col;
             __syncthreads();                                        // s_off is visible; the previous 64 slots have been written out
-            for (uint32_t i = tid; i < 64u * GW_ROW; i += 256u) s_acc[i] = 0u;
+            for (uint32_t i = tid; i < GW_SITES * GW_ROW; i += 256u) s_acc[i] = 0u;
             __syncthreads();
             const uint32_t kA = s_blk[b], kB = s_blk[b + 1u];
-            const uint32_t off = s_off[lane];
+            const uint32_t site = lane;                              // (GW_SITES == 64: a lane per site, a wavefront per pair)
+            static_assert(GW_SITES == 64, "the fill loop deals one site to every lane of a wavefront");
+            const uint32_t off = s_off[site];
             for (uint32_t kl = kA + wave; kl < kB; kl += 16u) {      // four loads in flight per lane
                 uint32_t v[4], c[4];
 #pragma unroll
@@ -1647,7 +1650,7 @@ __device__ __forceinline__ void gather_cov_wide(const TailArgs &a, const uint32_
                 }
 #pragma unroll
                 for (uint32_t u = 0; u < 4u; ++u)
-                    if (kl + 4u * u < kB) atomicAdd(&s_acc[lane * GW_ROW + (c[u] >> 1)], v[u] << (16u * (c[u] & 1u)));
+                    if (kl + 4u * u < kB) atomicAdd(&s_acc[site * GW_ROW + (c[u] >> 1)], v[u] << (16u * (c[u] & 1u)));
             }
             __syncthreads();
             for (uint32_t idx = tid; idx < nS * 8u; idx += 256u) {
@@ -1666,7 +1669,87 @@ __device__ __forceinline__ void gather_cov_wide(const TailArgs &a, const uint32_
     }
 }
 
-__device__ __forceinline__ void gather_cov_block(const TailArgs &a, const uint32_t bid) {
+// The same for the ALLELE ROWS of noisy reads (pack.cpp: allele planes): a pair's word A | C << 8 | G << 16 | T << 24 at a site goes
+// into four u16 column blocks in LDS -- [site][allele][32 slots], one LDS atomic per allele the word holds (mostly one) -- and every
+// allele column is written as rows of 32 slots, eight cells (16 bytes) per lane.  One load per (site, pair) for all four alleles.
+constexpr uint32_t GA_SLOTS = 32;              // slots per LDS block of the allele gather
+constexpr uint32_t GA_ROW = 4 * GA_SLOTS / 2 + 2;   // words per site: 4 alleles x 32 u16 + 2 (8-byte aligned rows, column updates spread over the banks)
+__device__ __forceinline__ void gather_alleles_wide(const TailArgs &a, uint32_t *s_acc, uint32_t *s_off, uint32_t *s_blk, const uint32_t t0, const uint32_t base, const uint32_t stride,
+                                                    const unsigned long long cell0, const uint32_t ps, const uint32_t np, const bool tile_has_merged, const uint32_t j_lo, const uint32_t dense_n) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t n_real = (a.pairs[ps + np - 1u].pad >> 8) + 1u, nblk = (n_real + GA_SLOTS - 1u) / GA_SLOTS;
+    __syncthreads();                                                // (s_blk is re-used: the coverage gather is done with it)
+    for (uint32_t kk = tid; kk < np; kk += 256u) {
+        const uint32_t sl = a.pairs[ps + kk].pad >> 8, prev = kk ? a.pairs[ps + kk - 1u].pad >> 8 : 0xffffffffu;
+        if (kk == 0u || (prev / GA_SLOTS) != (sl / GA_SLOTS)) s_blk[sl / GA_SLOTS] = kk;
+    }
+    if (tid == 0u) s_blk[nblk] = np;
+    const uint32_t wide_end = tile_has_merged ? (n_real & ~7u) : stride;
+    const uint32_t *rows = reinterpret_cast<const uint32_t *>(a.aspill) + (uint64_t)ps * TILE;
+    for (uint32_t jj0 = 0; jj0 < dense_n; jj0 += 64u) {
+        const uint32_t nS = min(64u, dense_n - jj0);
+        __syncthreads();
+        if (tid < 64u) s_off[tid] = a.sites[base + j_lo + jj0 + min(tid, nS - 1u)].gpos - t0;
+        for (uint32_t b = 0; b < nblk; ++b) {
+            __syncthreads();
+            for (uint32_t i = tid; i < 64u * GA_ROW; i += 256u) s_acc[i] = 0u;
+            __syncthreads();
+            const uint32_t kA = s_blk[b], kB = s_blk[b + 1u];
+            const uint32_t off = s_off[lane];
+            for (uint32_t kl = kA + wave; kl < kB; kl += 16u) {      // four loads in flight per lane
+                uint32_t v[4], c[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) {
+                    const uint32_t k = min(kl + 4u * u, kB - 1u);
+                    v[u] = rows[(uint64_t)k * TILE + off];
+                    c[u] = (a.pairs[ps + k].pad >> 8) - GA_SLOTS * b;
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) {
+                    if (kl + 4u * u >= kB || v[u] == 0u) continue;
+#pragma unroll
+                    for (uint32_t x = 0; x < 4u; ++x) {
+                        const uint32_t n = (v[u] >> (8u * x)) & 0xffu;
+                        if (n) atomicAdd(&s_acc[lane * GA_ROW + x * (GA_SLOTS / 2u) + (c[u] >> 1)], n << (16u * (c[u] & 1u)));
+                    }
+                }
+            }
+            __syncthreads();
+            // a site's block: 4 alleles x 4 segments of eight slots
+            for (uint32_t idx = tid; idx < nS * 16u; idx += 256u) {
+                const uint32_t row = idx >> 4, x = (idx >> 2) & 3u, seg = idx & 3u, c0 = GA_SLOTS * b + 8u * seg;
+                if (c0 >= n_real) continue;
+                const uint2 lo = *reinterpret_cast<const uint2 *>(&s_acc[row * GA_ROW + x * (GA_SLOTS / 2u) + 4u * seg]);
+                const uint2 hi = *reinterpret_cast<const uint2 *>(&s_acc[row * GA_ROW + x * (GA_SLOTS / 2u) + 4u * seg + 2u]);
+                uint16_t *dst = a.ncol + (uint64_t)x * a.cells.cap_cells + cell0 + (uint64_t)(j_lo + jj0 + row) * stride + c0;
+                if (c0 + 8u <= wide_end) *reinterpret_cast<uint4 *>(dst) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                else {
+                    const uint32_t w[4] = {lo.x, lo.y, hi.x, hi.y};
+                    for (uint32_t q = 0; q < 8u && c0 + q < n_real; ++q) dst[q] = (uint16_t)(w[q >> 1] >> (16u * (q & 1u)));
+                }
+            }
+        }
+    }
+}
+
+// One cell at a time (tiles with few sites, or rows that do not start on 16 bytes): the pair's allele word at the site -> its cell in
+// the allele columns.  add: the pair is one of several of a split sample (their counts add up).
+__device__ __forceinline__ void put_allele_word(const TailArgs &a, const uint32_t word, const unsigned long long cell, const bool add) {
+    if (word == 0u) return;                                         // (what the gate kernel left there)
+#pragma unroll
+    for (uint32_t x = 0; x < 4u; ++x) {
+        const uint32_t n = (word >> (8u * x)) & 0xffu;
+        if (!n) continue;
+        uint16_t *dst = a.ncol + (uint64_t)x * a.cells.cap_cells + cell;
+        if (add) add_u16(dst, n); else *dst = (uint16_t)n;
+    }
+}
+
+// LDS of the launch: ONE pool that the block types carve up (a workgroup is one of them): the dense gathers need 64 x GA_ROW words + three
+// small tables, the merged gather 13.7 KB.  Separate __shared__ arrays per block type add up in every workgroup of the launch (31.6 KB:
+// five workgroups per CU where the latency-bound scatter and merged blocks want eight).
+constexpr uint32_t TAIL_POOL_WORDS = 64 * GA_ROW + 64 + 64 + 2 * GW_MAX_BLOCKS + 2;
+__device__ __forceinline__ void gather_cov_block(const TailArgs &a, const uint32_t bid, uint32_t *s_pool) {
     const uint32_t GATHER_SPLIT = a.gather_split;
     const uint32_t tile = a.active_tiles[bid / GATHER_SPLIT], part = bid % GATHER_SPLIT;   // a tile's sites are dealt to GATHER_SPLIT workgroups
     const uint32_t n = a.tile_site_cnt[tile];
@@ -1681,7 +1764,7 @@ __device__ __forceinline__ void gather_cov_block(const TailArgs &a, const uint32
     const uint32_t t0 = tile * TILE;
     const uint32_t mine = (n - part + GATHER_SPLIT - 1) / GATHER_SPLIT;
     const uint32_t share = (n + GATHER_SPLIT - 1) / GATHER_SPLIT;          // (the same for every workgroup of the tile: they all take the same path)
-    const uint32_t n_planes = a.aspill ? 5u : 1u;                          // coverage bytes [+ the four allele planes of noisy reads]
+    const uint32_t *arows = a.aspill ? reinterpret_cast<const uint32_t *>(a.aspill) + (uint64_t)ps * TILE : nullptr;      // allele rows of the tile's pairs (noisy reads)
     if (share >= GD_MIN_SITES) {
         // MANY sites in the tile (deep or divergent data: every other position of a cohort with LogNormal sigma = 2 abundances is a
         // site).  One cell per thread in (site, pair) order reads one byte of a different spill row per lane -- a cache line per cell,
@@ -1690,10 +1773,13 @@ __device__ __forceinline__ void gather_cov_block(const TailArgs &a, const uint32
         // one site's cells of 64 pairs (consecutive slots).  A workgroup takes a CONTIGUOUS range of the tile's sites here (every
         // GATHER_SPLIT-th one, as below, spreads each 128-byte line of the cell rows over workgroups on different XCDs).
         const uint32_t j_lo = min(n, part * share), dense_n = min(n, j_lo + share) - j_lo;
-        __shared__ __attribute__((aligned(8))) uint32_t s_lds[64 * GW_ROW];      // one block for both forms of the dense gather
-        __shared__ uint32_t s_off[64], s_pad[64], s_blk[GW_MAX_BLOCKS + 2];
-        if ((n_slots & 7u) == 0u && (cell0 & 7ull) == 0ull && !a.has_wide) {      // (uniform)
-            gather_cov_wide(a, n_planes, s_lds, s_off, s_blk, t0, base, n_slots, cell0, ps, np, a.tile_pair_merged[tile] < a.tile_pair_start[tile + 1u], j_lo, dense_n);
+        uint32_t *const s_lds = s_pool;                              // one block for every form of the dense gather (coverage: 64 x 34 words; the older form: 64 rows of 68 bytes; alleles: 64 x 66 words)
+        static_assert(GA_ROW >= GW_ROW && GW_SITES == 64 && 64 * GW_ROW * 4 >= 64 * GD_ROW, "the coverage forms live in the allele gather's LDS block");
+        uint32_t *const s_off = s_pool + 64 * GA_ROW, *const s_pad = s_off + 64, *const s_blk = s_pad + 64;      // (s_blk: first pair of every block of 64 slots -- coverage -- or 32 slots -- alleles)
+        if ((n_slots & 7u) == 0u && (cell0 & 7ull) == 0ull && !a.has_wide && n_slots <= 64u * GW_MAX_BLOCKS) {      // (uniform)
+            const bool has_merged = a.tile_pair_merged[tile] < a.tile_pair_start[tile + 1u];
+            gather_cov_wide(a, s_lds, s_off, s_blk, t0, base, n_slots, cell0, ps, np, has_merged, j_lo, dense_n);
+            if (arows) gather_alleles_wide(a, s_lds, s_off, s_blk, t0, base, n_slots, cell0, ps, np, has_merged, j_lo, dense_n);
             return;
         }
         uint8_t (*s_t)[GD_ROW] = reinterpret_cast<uint8_t (*)[GD_ROW]>(s_lds);
@@ -1702,9 +1788,7 @@ __device__ __forceinline__ void gather_cov_block(const TailArgs &a, const uint32
             const uint32_t nS = min(64u, dense_n - jj0);
             __syncthreads();                                        // (the rows of the previous group have been written out)
             if (threadIdx.x < 64) s_off[threadIdx.x] = a.sites[base + j_lo + jj0 + min(threadIdx.x, nS - 1u)].gpos - t0;   // (idle lanes: a valid position, their row is not written out)
-            for (uint32_t pk = 0; pk < n_planes * ((np + 63u) / 64u); ++pk) {
-                const uint32_t pl = pk / ((np + 63u) / 64u), kk0 = (pk % ((np + 63u) / 64u)) * 64u;
-                const PlaneSrc P = plane_of(a, ps, pl);
+            for (uint32_t kk0 = 0; kk0 < np; kk0 += 64u) {
                 const uint32_t nP = min(64u, np - kk0);
                 __syncthreads();                                    // s_off is visible; the previous 64 pairs have been written out
                 if (threadIdx.x < nP) s_pad[threadIdx.x] = a.pairs[ps + kk0 + threadIdx.x].pad;
@@ -1712,7 +1796,7 @@ __device__ __forceinline__ void gather_cov_block(const TailArgs &a, const uint32
                 for (uint32_t kl = (uint32_t)wave; kl < nP; kl += 16) {      // four loads in flight per lane
                     uint8_t v[4];
 #pragma unroll
-                    for (uint32_t u = 0; u < 4; ++u) v[u] = P.src[(uint64_t)(kk0 + min(kl + 4u * u, nP - 1u)) * P.stride + off];
+                    for (uint32_t u = 0; u < 4; ++u) v[u] = a.spill[(uint64_t)(ps + kk0 + min(kl + 4u * u, nP - 1u)) * TILE + off];
 #pragma unroll
                     for (uint32_t u = 0; u < 4; ++u) if (kl + 4u * u < nP) s_t[lane][kl + 4u * u] = v[u];
                 }
@@ -1721,11 +1805,19 @@ __device__ __forceinline__ void gather_cov_block(const TailArgs &a, const uint32
                     const uint32_t pad = s_pad[lane];
                     for (uint32_t sl = (uint32_t)wave; sl < nS; sl += 4) {
                         const uint32_t cov = s_t[sl][lane];
-                        uint16_t *dst = &P.col[cell0 + (uint64_t)(j_lo + jj0 + sl) * n_slots + (pad >> 8)];
+                        uint16_t *dst = &a.cov_col[cell0 + (uint64_t)(j_lo + jj0 + sl) * n_slots + (pad >> 8)];
                         if (pad & 0xffu) add_u16(dst, cov);
                         else if (cov != 255u) *dst = (uint16_t)cov;
                     }
                 }
+            }
+        }
+        if (arows) {                                                  // (rows that do not start on 16 bytes: small tiles; one cell per thread)
+            const uint64_t work = (uint64_t)dense_n * np;
+            for (uint64_t i = threadIdx.x; i < work; i += blockDim.x) {
+                const uint32_t j = j_lo + (uint32_t)(i / np), kk = (uint32_t)(i % np);
+                const uint32_t pad = a.pairs[ps + kk].pad;
+                put_allele_word(a, arows[(uint64_t)kk * TILE + (a.sites[base + j].gpos - t0)], cell0 + (uint64_t)j * n_slots + (pad >> 8), (pad & 0xffu) != 0u);
             }
         }
         return;
@@ -1735,13 +1827,11 @@ __device__ __forceinline__ void gather_cov_block(const TailArgs &a, const uint32
         const uint32_t j = part + (uint32_t)(i / np) * GATHER_SPLIT, kk = (uint32_t)(i % np);
         const uint32_t off = a.sites[base + j].gpos - t0;
         const uint32_t pad = a.pairs[ps + kk].pad;          // kind | slot << 8
-        for (uint32_t pl = 0; pl < n_planes; ++pl) {
-            const PlaneSrc P = plane_of(a, ps, pl);
-            const uint32_t cov = P.src[(uint64_t)kk * P.stride + off];
-            uint16_t *dst = &P.col[cell0 + (uint64_t)j * n_slots + (pad >> 8)];
-            if (pad & 0xffu) add_u16(dst, cov);             // one of several pairs of this sample: the groups add up
-            else if (cov != 255u && cov) *dst = (uint16_t)cov;  // (zero: what the gate kernel left there) 255 (wide kernel only): the overflow list holds the value, the scatter half writes it
-        }
+        const uint32_t cov = a.spill[(uint64_t)(ps + kk) * TILE + off];
+        uint16_t *dst = &a.cov_col[cell0 + (uint64_t)j * n_slots + (pad >> 8)];
+        if (pad & 0xffu) add_u16(dst, cov);                 // one of several pairs of this sample: the groups add up
+        else if (cov != 255u && cov) *dst = (uint16_t)cov;  // (zero: what the gate kernel left there) 255 (wide kernel only): the overflow list holds the value, the scatter half writes it
+        if (arows) put_allele_word(a, arows[(uint64_t)kk * TILE + off], cell0 + (uint64_t)j * n_slots + (pad >> 8), (pad & 0xffu) != 0u);
     }
 }
 
@@ -1756,7 +1846,7 @@ __device__ __forceinline__ void scatter_events_block(const TailArgs &a, const ui
         if (!(w & bit)) return;                    // most events are sequencing errors at positions that are not sites
         const unsigned long long row = row0 + (unsigned long long)__popcll(w & (bit - 1ull)) * ns;
         // events carry the SLOT of their sample in the tile (pack.cpp)
-        if (allele) add_u16(&a.ncol[(uint64_t)((e.y >> 16) & 3u) * a.cells.cap_cells + row + (e.y >> 18)], e.y & 0xffffu);   // one event per (site, pair, allele)
+        if (allele) add_u16(&a.ncol[ncol_base((e.y >> 16) & 3u, a.cells.cap_cells) + row + (e.y >> 18)], e.y & 0xffffu);   // one event per (site, pair, allele)
         else a.cov_col[row + (e.y >> 16)] = (uint16_t)(e.y & 0xffffu);
     };
     const uint32_t n_k = min(a.counters[16u + k * EV_CNT_STRIDE], a.cap_list);
@@ -1776,7 +1866,7 @@ __device__ __forceinline__ void scatter_events_block(const TailArgs &a, const ui
                 const unsigned long long bit = 1ull << (e[u].x & 63u);
                 if (!(w[u] & bit)) continue;
                 const unsigned long long row = row0[u] + (unsigned long long)__popcll(w[u] & (bit - 1ull)) * ns[u];
-                add_u16(&a.ncol[(uint64_t)((e[u].y >> 16) & 3u) * a.cells.cap_cells + row + (e[u].y >> 18)], e[u].y & 0xffffu);
+                add_u16(&a.ncol[ncol_base((e[u].y >> 16) & 3u, a.cells.cap_cells) + row + (e[u].y >> 18)], e[u].y & 0xffffu);
             }
         }
         for (; i < n_k; i += stride) apply(list[i], true);
@@ -1792,12 +1882,13 @@ __device__ __forceinline__ void scatter_events_block(const TailArgs &a, const ui
 // pileup kernel did not put into its exception bins -- adds one to the group's LDS table [site][pair of the group], which
 // is then written out with plain stores (every (site, sample) cell belongs to exactly one group).
 constexpr uint32_t GM_CELLS = 2048;           // cells of the LDS tables (6 B each); a tile with more sites x pairs is done in batches of sites
-__device__ __forceinline__ void gather_merged_block(const TailArgs &a, const uint32_t bid) {
-    __shared__ unsigned long long s_bits[TILE / 64];
-    __shared__ uint32_t s_rank[TILE / 64];
-    __shared__ uint32_t s_cov[GM_CELLS / 2];            // u16 per (site, pair): counted bases
-    __shared__ uint32_t s_al[GM_CELLS];                 // 4 x u8 per (site, pair): mismatching A, C, G, T (a shallow pair is < 81 deep)
-    __shared__ uint32_t s_gsample[MERGE_MAX_PAIRS];
+__device__ __forceinline__ void gather_merged_block(const TailArgs &a, const uint32_t bid, uint32_t *s_pool) {
+    static_assert(2 * (TILE / 64) + TILE / 64 + GM_CELLS / 2 + GM_CELLS + MERGE_MAX_PAIRS <= 64 * (4 * 32 / 2 + 2), "the merged gather's tables fit the launch's LDS pool");
+    unsigned long long *const s_bits = reinterpret_cast<unsigned long long *>(s_pool);      // [TILE / 64]
+    uint32_t *const s_rank = s_pool + 2 * (TILE / 64);                                       // [TILE / 64]
+    uint32_t *const s_cov = s_rank + TILE / 64;         // [GM_CELLS / 2]: u16 per (site, pair): counted bases
+    uint32_t *const s_al = s_cov + GM_CELLS / 2;        // [GM_CELLS]: 4 x u8 per (site, pair): mismatching A, C, G, T (a shallow pair is < 81 deep)
+    uint32_t *const s_gsample = s_al + GM_CELLS;        // [MERGE_MAX_PAIRS]
     const MergedGroupDev w = a.merged_groups[bid];      // ONE group per workgroup (a work item's groups in a row made this block the launch's long pole)
     // everything that hangs on the descriptor alone is requested together -- the tile's site tables, its bitmap and ranks, the first
     // round of piece headers: the block is a chain of dependent loads (one group of a sparse cohort is ~250 pieces), not arithmetic
@@ -1910,9 +2001,10 @@ __global__ __launch_bounds__(256) void msnv_gather_scatter(TailArgs a) {
         }
         return;
     }
+    __shared__ __attribute__((aligned(16))) uint32_t s_pool[TAIL_POOL_WORDS];
     if (blockIdx.x < n_scatter) scatter_events_block(a, blockIdx.x % SCATTER_BLOCKS_PER_LIST, blockIdx.x / SCATTER_BLOCKS_PER_LIST);
-    else if (HAS_MERGED && blockIdx.x < n_scatter + a.n_merged_blocks) gather_merged_block(a, blockIdx.x - n_scatter);
-    else gather_cov_block(a, blockIdx.x - n_scatter - a.n_merged_blocks);
+    else if (HAS_MERGED && blockIdx.x < n_scatter + a.n_merged_blocks) gather_merged_block(a, blockIdx.x - n_scatter, s_pool);
+    else gather_cov_block(a, blockIdx.x - n_scatter - a.n_merged_blocks, s_pool);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -50,7 +50,7 @@ struct TextArgs {
     uint32_t *fstart;                          // [waves][n_samples]: where each sample's base string starts (line-relative)
     msnv_site_sample *scratch;                 // [waves][n_samples]: the line's per-sample counts
     TextRec *rec; msnv_site_sample *rec_samples; uint32_t cap_rec;
-    uint32_t *counters;                        // [0] records, [1] first line with a domain error (min), [2] its kind | byte << 8
+    uint32_t *counters;                        // [0] records, [2..3] (64-bit minimum) first line with a domain error << 32 | its kind | byte << 8
     uint64_t *bases_parsed;
 };
 
@@ -239,10 +239,8 @@ __global__ __launch_bounds__(TC_NT) void msnv_parse_pileup_lines(const TextArgs 
         if (errs || extra) {                                                        // (uniform) a domain error: the earliest line wins
             uint32_t code = extra ? 2u : 0u;
             if (errs) code = (uint32_t)__shfl((int)err, (int)__builtin_ctzll(errs));
-            if (lane == 0) {
-                const uint32_t old = atomicMin(&a.counters[1], li);
-                if (li < old) a.counters[2] = code;                                 // (racy between lines; the host only words the message with it)
-            }
+            // line and code travel in ONE 64-bit minimum: the code the host words its message with is the one of the line it names
+            if (lane == 0) atomicMin(reinterpret_cast<unsigned long long *>(&a.counters[2]), (unsigned long long)li << 32 | code);
         } else if ((int)t_cov >= a.min_cov && (int)(t_n[0] + t_n[1] + t_n[2] + t_n[3]) >= a.min_snvs) {     // gates (call_vC.cpp:545-552)
             // reference character: field 2, tok[0] (call_vC.cpp:502) -- the allele that equals it AS A CHARACTER is skipped (:580)
             uint32_t refc = 0;
@@ -326,7 +324,7 @@ static int run_chunk(msnv_ctx *ctx, const char *text, const std::vector<uint64_t
     HIP_TRY(hipMemcpyAsync(d_text.p, text, n_bytes, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_off.p, off.data(), off.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
     uint32_t init[16] = {0};
-    init[1] = UINT32_MAX;
+    init[2] = UINT32_MAX; init[3] = UINT32_MAX;
     HIP_TRY(hipMemcpyAsync(d_cnt.p, init, sizeof init, hipMemcpyHostToDevice, st));
     TextArgs a;
     a.text = (const uint8_t *)d_text.p; a.line_off = (const uint64_t *)d_off.p; a.n_lines = n_lines; a.n_samples = S;
@@ -357,7 +355,7 @@ static int run_chunk(msnv_ctx *ctx, const char *text, const std::vector<uint64_t
     if (he != hipSuccess) return fail(MSNV_EHIP, "mpileup text kernel: %s", hipGetErrorString(he));
     if (ms_kernel) *ms_kernel += t;
     if (bases) { uint64_t b; memcpy(&b, cnt + 8, 8); *bases += b; }
-    if (cnt[1] != UINT32_MAX) { *err_line = cnt[1]; *err_code = cnt[2]; return MSNV_OK; }
+    if (cnt[3] != UINT32_MAX || cnt[2] != UINT32_MAX) { *err_line = cnt[3]; *err_code = cnt[2]; return MSNV_OK; }
     const uint32_t n = cnt[0];
     if (n > cap_rec) return fail(MSNV_EINVAL, "internal: %u records from %u lines", n, n_lines);
     std::vector<TextRec> r(n);

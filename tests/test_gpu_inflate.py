@@ -121,6 +121,21 @@ def test_device_inflate_on_crafted_streams_of_every_kind(tmp_path):
         d = data_of(r % 5, n)
         c = zlib.compressobj(rnd.randrange(10), zlib.DEFLATED, -15, 8, strategies[(r // 5) % 5])
         blocks.append((c.compress(d) + c.flush(), d))
+    # streams of SEVERAL deflate blocks: Z_SYNC_FLUSH (an empty stored block behind every piece), Z_FULL_FLUSH, stored data cut into
+    # non-final stored blocks of odd sizes -- the stored-block path moves the input position back and forth across the decoder's window
+    for r in range(24):
+        n = rnd.choice([40, 700, 9000, 65280])
+        d = data_of(r % 5, n)
+        c = zlib.compressobj([0, 1, 6, 9][r % 4], zlib.DEFLATED, -15, 8, strategies[r % 5])
+        out, o = b"", 0
+        while o < n:
+            step = rnd.choice([1, 3, 64, 255, 256, 257, 1000, 5000])
+            out += c.compress(d[o:o + step]) + c.flush(rnd.choice([zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH, zlib.Z_NO_FLUSH]))
+            o += step
+            if len(out) > 52000:                                   # (a BGZF block payload must stay below 64 KiB)
+                break
+        d = d[:o]
+        blocks.append((out + c.flush(), d))
     p = str(tmp_path / "crafted.gz")
     open(p, "wb").write(_bgzf(blocks))
     want = b"".join(d for _, d in blocks)
