@@ -422,6 +422,27 @@ def main():
         overlapped = {"ms_per_step": dto / a.steps * 1e3, "pileup_kernel_ms_sharing_the_chip": sum(x["ms_pileup"] for x in so) / len(so),
                       "per_gpu_value": info["n_pileup_bases"] * a.steps / dto / 1e9, "unit": "Gbases/s"}
 
+    def coverage_counters(kernel_ms):
+        """What bounds msnv_coverage_tiles, from the counter passes committed under profiles/ (profiles/cov_prof.sh: rocprofv3 --pmc in
+        separate runs; they cannot be collected inside this process).  Issue-slot share = VALU wave-instructions x 4 cycles / (1024
+        SIMDs x the kernel's cycles at 2.4 GHz)."""
+        for name in ("r03cov_pmc.json", "r02cov5_pmc.json"):
+            try:
+                c = json.load(open(os.path.join(ROOT, "profiles", name)))["counters"]
+                k = [v for kk, v in c.items() if "coverage_tiles" in kk][0]
+                valu = k["SQ_INSTS_VALU"]["avg_per_launch"]
+                out = {"source": "profiles/" + name, "valu_wave_instructions_per_launch": valu,
+                       "valu_issue_share_of_this_run": valu * 4.0 / (1024.0 * kernel_ms * 1e-3 * 2.4e9)}
+                if "SQ_INSTS_LDS" in k:
+                    out["lds_wave_instructions_per_launch"] = k["SQ_INSTS_LDS"]["avg_per_launch"]
+                if "FETCH_SIZE" in k:
+                    out["fetch_bytes_x2_per_launch"] = 2 * 1024.0 * k["FETCH_SIZE"]["avg_per_launch"]
+                out["limited_by"] = "vector-instruction issue" if out["valu_issue_share_of_this_run"] > 0.5 else "latency / occupancy"
+                return out
+            except Exception:
+                continue
+        return None
+
     cov_extra = None
     if rank == 0:
         # the qaCompute half of the path on the same resident columns (msnv_coverage_tiles), outside the timed region
@@ -432,9 +453,7 @@ def main():
         cov_extra = {"kernel_ms": cov_ms, "bytes_per_M_interval": 8, "intervals": info["n_reads_pileup"],
                      "roofline": {"bound": "hbm", "achieved": 8.0 * info["n_reads_pileup"] / (cov_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": 8.0 * info["n_reads_pileup"] / (cov_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                  "limited_by": "vector-instruction issue, not HBM: ~450 vector wave-instructions per (tile, sample) pair of ~215 intervals "
-                                                "(profiles/r02cov5_pmc.json: SQ_INSTS_VALU 32.6 M per launch = 74 % of the issue slots of the kernel's 68.5 us, "
-                                                "LDS busy 35 % of it; FETCH_SIZE x2 = 143 MB)"}}
+                                  "counters": coverage_counters(cov_ms)}}
 
     ann_extra = None
     if not a.no_annotation and rank == 0:

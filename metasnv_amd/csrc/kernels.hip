@@ -1586,7 +1586,7 @@ __device__ __forceinline__ void add_u16(uint16_t *field, uint32_t v) {
 
 // tail of a pass: per-sample coverages (gather half) and allele counts (scatter half) of the surviving sites.
 // ------------------------------------------------------------------------------------------
-constexpr uint32_t SCATTER_BLOCKS_PER_LIST = 32;
+constexpr uint32_t SCATTER_BLOCKS_PER_LIST = 16;   // default (gather || scatter launch on the benchmark shape: 32 -> 50 us, 16 -> 45, 8 -> 48, 4 -> 57; profiles/r03r_tail_tune.txt); TailArgs::scatter_blocks is what a launch uses (MSNV_SCATTER_BLOCKS: tuning experiments)
 struct TailArgs {
     const SiteRec *sites; const uint32_t *tile_site_base, *tile_site_cnt, *tile_pair_start, *tile_pair_merged; const TilePair *pairs; const uint8_t *spill;
     // merged groups of shallow pairs: their per-sample coverage at the called positions is recomputed from the pieces
@@ -1596,6 +1596,8 @@ struct TailArgs {
     uint8_t *site_flags; const uint8_t *site_elig; uint32_t ind_in_gather, min_snvs;
     uint16_t *ncol; uint16_t *cov_col; uint32_t cap_out; const uint32_t *active_tiles; uint32_t n_gather_blocks;
     CellMap cells; uint32_t gather_split;
+    uint32_t scatter_blocks;                    // workgroups per event sub-list
+    uint32_t debug_skip;                        // MSNV_TAIL_SKIP (profiling only, results are wrong): 1 = no scatter blocks, 2 = no gather blocks, 4 = no merged blocks
     const uint8_t *aspill;                      // allele rows of the pairs (noisy reads: a word per position), else NULL: gathered into the four allele columns like the coverage bytes
     uint32_t has_wide;                          // some work item runs the wide kernel (coverage bytes of 255 stand for an overflow-list entry the scatter half writes)
     const Pair32 *events, *overflow; uint32_t *counters; uint32_t cap_list, cap_overflow;
@@ -1853,7 +1855,7 @@ __device__ __forceinline__ void scatter_events_block(const TailArgs &a, const ui
     const Pair32 *list = a.events + (uint64_t)k * a.cap_list;
     {   // four events per trip: their loads, then their table loads, are in flight together
         constexpr uint32_t U = 4;
-        const uint32_t stride = SCATTER_BLOCKS_PER_LIST * blockDim.x;
+        const uint32_t stride = a.scatter_blocks * blockDim.x;
         uint32_t i = bx * blockDim.x + threadIdx.x;
         for (; i + (U - 1u) * stride < n_k; i += U * stride) {
             Pair32 e[U]; unsigned long long w[U], row0[U]; uint32_t ns[U];
@@ -1872,7 +1874,7 @@ __device__ __forceinline__ void scatter_events_block(const TailArgs &a, const ui
         for (; i < n_k; i += stride) apply(list[i], true);
     }
     const uint32_t n_overflow = min(a.counters[1], a.cap_overflow);
-    for (uint32_t i = (k * SCATTER_BLOCKS_PER_LIST + bx) * blockDim.x + threadIdx.x; i < n_overflow; i += SCATTER_BLOCKS_PER_LIST * EV_LISTS * blockDim.x)
+    for (uint32_t i = (k * a.scatter_blocks + bx) * blockDim.x + threadIdx.x; i < n_overflow; i += a.scatter_blocks * EV_LISTS * blockDim.x)
         apply(a.overflow[i], false);
 }
 
@@ -1985,7 +1987,7 @@ __device__ __forceinline__ void gather_merged_block(const TailArgs &a, const uin
 // every workgroup of the launch allocates 14 KB it never touches: 33.8 -> 43 us on the benchmark shape)
 template <bool HAS_MERGED>
 __global__ __launch_bounds__(256) void msnv_gather_scatter(TailArgs a) {
-    constexpr uint32_t n_scatter = SCATTER_BLOCKS_PER_LIST * EV_LISTS;     // dispatched first: the longer-running half
+    const uint32_t n_scatter = a.scatter_blocks * EV_LISTS;     // dispatched first: the longer-running half
     if (blockIdx.x == gridDim.x - 1u) {
         // (one workgroup of its own at the END of the grid: in front of a scatter block -- the long pole of this launch -- the 32
         // counter loads delayed the whole kernel by ~10 us)
@@ -2002,9 +2004,9 @@ __global__ __launch_bounds__(256) void msnv_gather_scatter(TailArgs a) {
         return;
     }
     __shared__ __attribute__((aligned(16))) uint32_t s_pool[TAIL_POOL_WORDS];
-    if (blockIdx.x < n_scatter) scatter_events_block(a, blockIdx.x % SCATTER_BLOCKS_PER_LIST, blockIdx.x / SCATTER_BLOCKS_PER_LIST);
-    else if (HAS_MERGED && blockIdx.x < n_scatter + a.n_merged_blocks) gather_merged_block(a, blockIdx.x - n_scatter, s_pool);
-    else gather_cov_block(a, blockIdx.x - n_scatter - a.n_merged_blocks, s_pool);
+    if (blockIdx.x < n_scatter) { if (!(a.debug_skip & 1u)) scatter_events_block(a, blockIdx.x % a.scatter_blocks, blockIdx.x / a.scatter_blocks); }
+    else if (HAS_MERGED && blockIdx.x < n_scatter + a.n_merged_blocks) { if (!(a.debug_skip & 4u)) gather_merged_block(a, blockIdx.x - n_scatter, s_pool); }
+    else if (!(a.debug_skip & 2u)) gather_cov_block(a, blockIdx.x - n_scatter - a.n_merged_blocks, s_pool);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2426,13 +2428,17 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
         ta.gather_split = d.gather_split;
         ta.has_wide = d.n_work > d.n_work_narrow + d.n_work_merged ? 1u : 0u;
         ta.aspill = d.allele_planes ? d.aspill : nullptr;
+        static const uint32_t tail_skip = [] { const char *e = getenv("MSNV_TAIL_SKIP"); return e ? (uint32_t)atoi(e) : 0u; }();
+        ta.debug_skip = tail_skip;
         ta.n_gather_blocks = d.n_gather_tiles * d.gather_split;
         ta.tile_pair_merged = d.tile_pair_merged; ta.merged_groups = d.merged_groups; ta.chunks = d.chunks; ta.hdr8m = d.hdr8m;
         ta.seq = d.seq; ta.qual = d.qual; ta.ref4 = d.ref4; ta.n_merged_blocks = d.n_merged_groups - (use_stage ? d.n_groups_solo : 0u); ta.min_baseq = (uint32_t)std::max(0, p.min_baseq);
         ta.site_flags = d.site_flags; ta.site_elig = d.site_elig; ta.ind_in_gather = d.any_split ? 0u : 1u; ta.min_snvs = (uint32_t)std::max(1, p.calling_threshold);
         ta.events = d.events; ta.overflow = d.overflow; ta.counters = counters; ta.cap_list = d.cap_events / EV_LISTS; ta.cap_overflow = d.cap_overflow;
         ta.site_bits = d.site_bits; ta.site_rank = d.site_rank;
-        const dim3 grid(ta.n_gather_blocks + ta.n_merged_blocks + SCATTER_BLOCKS_PER_LIST * EV_LISTS + 1u);      // + 1: the event total
+        static const uint32_t scatter_blocks = [] { const char *e = getenv("MSNV_SCATTER_BLOCKS"); return e ? (uint32_t)std::max(1, atoi(e)) : SCATTER_BLOCKS_PER_LIST; }();
+        ta.scatter_blocks = scatter_blocks;
+        const dim3 grid(ta.n_gather_blocks + ta.n_merged_blocks + ta.scatter_blocks * EV_LISTS + 1u);      // + 1: the event total
         if (ta.n_merged_blocks) hipLaunchKernelGGL(msnv_gather_scatter<true>, grid, dim3(256), 0, st, ta);
         else hipLaunchKernelGGL(msnv_gather_scatter<false>, grid, dim3(256), 0, st, ta);
         HIP_TRY(hipGetLastError());
