@@ -224,6 +224,10 @@ int  msnv_dataset_create(msnv_ctx *ctx, const msnv_ref_desc *ref, const msnv_par
 /* Convenience: contigs from the header of `bam_path`, sequences from `fasta_path`. */
 int  msnv_dataset_create_from_files(msnv_ctx *ctx, const char *bam_path, const char *fasta_path,
                                     const msnv_params *params, msnv_dataset **out);
+/* Gives a dataset that was created without a context (ctx = NULL: host-stage entry points only) its device, before msnv_dataset_finalize.
+ * A one-shot driver creates the HIP context (~0.5 s of runtime start-up) on a thread of its own while the BAMs are read, inflated and
+ * packed by the host threads (metasnv_amd/cli.py); the reference's counterpart is process start-up of its tools. */
+int  msnv_dataset_attach_ctx(msnv_dataset *ds, msnv_ctx *ctx);
 void msnv_dataset_destroy(msnv_dataset *ds);
 
 /* Restrict the shard: BED regions (mpileup -l; 0-based half-open, at most one region per

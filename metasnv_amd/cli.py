@@ -232,11 +232,27 @@ def main(argv=None):
     ctx = None
     if not args.print_commands:
         from . import core
-        try:
-            ctx = core.Context(local)
-        except core._lib.MsnvError as e:
-            sys.stderr.write("\nERROR:  {}\n\nSOLUTION: run on a node with an AMD Instinct GPU (there is no CPU fallback)\n\n".format(e))
+        if core.device_count() < 1:                                 # (hipGetDeviceCount: does not bring the runtime up)
+            sys.stderr.write("\nERROR:  no HIP device is available\n\nSOLUTION: run on a node with an AMD Instinct GPU (there is no CPU fallback)\n\n")
             parallel.abort(1)
+        if world == 1 and args.threads >= 8:
+            # one process, many host threads: the BAMs are inflated by the host decoder (csrc/api.cpp: want_device_inflate), so the device
+            # is first needed when the packed columns go up -- the context comes up on a thread of its own meanwhile
+            from concurrent.futures import ThreadPoolExecutor
+            fut = ThreadPoolExecutor(max_workers=1).submit(core.Context, local)
+
+            def ctx():
+                try:
+                    return fut.result()
+                except core._lib.MsnvError as e:
+                    sys.stderr.write("\nERROR:  {}\n\nSOLUTION: run on a node with an AMD Instinct GPU (there is no CPU fallback)\n\n".format(e))
+                    parallel.abort(1)
+        else:
+            try:
+                ctx = core.Context(local)
+            except core._lib.MsnvError as e:
+                sys.stderr.write("\nERROR:  {}\n\nSOLUTION: run on a node with an AMD Instinct GPU (there is no CPU fallback)\n\n".format(e))
+                parallel.abort(1)
 
     if args.print_commands:                                     # metaSNV.py --print-commands: nothing runs
         if rank == 0:

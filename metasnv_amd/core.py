@@ -87,11 +87,16 @@ class Dataset:
         self.params = params or default_params()
         self._h = C.c_void_p()
         self.n_samples = 0
-        check(lib.msnv_dataset_create_from_files(ctx._h, first_bam.encode(), fasta.encode() if fasta else None,
+        check(lib.msnv_dataset_create_from_files(ctx._h if ctx is not None else None, first_bam.encode(), fasta.encode() if fasta else None,
                                                  C.byref(self.params), C.byref(self._h)))
         hdr = read_bam(first_bam, records=False)
         self.names, self.lengths = hdr["names"], hdr["lengths"]
         return self
+
+    def attach_context(self, ctx):
+        """Gives a dataset created with ctx=None its device context (before finalize)."""
+        check(lib.msnv_dataset_attach_ctx(self._h, ctx._h))
+        self.ctx = ctx
 
     def set_bed(self, regions):
         """regions: iterable of (tid, beg, end), 0-based half-open (mpileup -l)."""

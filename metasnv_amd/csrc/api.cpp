@@ -6,6 +6,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <thread>
+#include <unordered_map>
 
 #include "device.h"
 #include "filter.h"
@@ -96,16 +97,27 @@ extern "C" int msnv_dataset_create_from_files(msnv_ctx *ctx, const char *bam_pat
     if (fasta_path) if (int rc = fasta_read(fasta_path, fa)) return rc;
     std::vector<const char *> names, seqs;
     std::vector<int64_t> lens, slens;
+    std::unordered_map<std::string, const FastaSeq *> by_name;          // (a database of a million contigs: no scan per header line; the FIRST record of a name wins, like the scan did)
+    by_name.reserve(fa.size() * 2);
+    for (const FastaSeq &f : fa) by_name.emplace(f.name, &f);
     for (size_t i = 0; i < h.names.size(); ++i) {
         names.push_back(h.names[i].c_str());
         lens.push_back(h.lengths[i]);
-        const FastaSeq *hit = nullptr;
-        for (const FastaSeq &f : fa) if (f.name == h.names[i]) { hit = &f; break; }
+        const auto it = by_name.find(h.names[i]);
+        const FastaSeq *hit = it == by_name.end() ? nullptr : it->second;
         seqs.push_back(hit ? hit->seq.data() : nullptr);
         slens.push_back(hit ? (int64_t)hit->seq.size() : 0);
     }
     msnv_ref_desc rd{(int32_t)names.size(), names.data(), lens.data(), seqs.data(), slens.data()};
     return msnv_dataset_create(ctx, &rd, params, out);
+}
+
+extern "C" int msnv_dataset_attach_ctx(msnv_dataset *ds, msnv_ctx *ctx) {
+    clear_error();
+    if (!ds || !ctx) return fail(MSNV_EINVAL, "msnv_dataset_attach_ctx: NULL argument");
+    if (ds->finalized) return fail(MSNV_EINVAL, "dataset is already finalized");
+    ds->ctx = ctx;
+    return MSNV_OK;
 }
 
 extern "C" void msnv_dataset_destroy(msnv_dataset *ds) {

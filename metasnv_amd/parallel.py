@@ -442,7 +442,10 @@ def resident_project_run(ctx, first_bam, fasta_path, bam_paths, params, batch=1,
       first_any / first_from1 (per contig, see core.Dataset.first_lines), metrics."""
     import time
     from . import core
-    ds = make_dataset() if make_dataset else core.Dataset.from_files(ctx, first_bam, fasta_path, params)
+    # ctx may be a zero-argument callable that returns the context when it is first needed (cli.py creates it on a thread of its own:
+    # the HIP runtime takes ~0.5 s to come up, which a one-process run spends reading and packing BAMs with host threads)
+    lazy_ctx = callable(ctx)
+    ds = make_dataset() if make_dataset else core.Dataset.from_files(None if lazy_ctx else ctx, first_bam, fasta_path, params)
     names, lengths = ds.names, ds.lengths
     owner = None
     if species_weight is not None or _dist is None:
@@ -458,6 +461,10 @@ def resident_project_run(ctx, first_bam, fasta_path, bam_paths, params, batch=1,
         res["owner"] = owner
         metrics["contigs"] = int(sum(1 for o in owner if o == _rank))
         metrics["feed_s"] = time.perf_counter() - t0
+        if lazy_ctx:
+            t0 = time.perf_counter()
+            ds.attach_context(ctx())
+            metrics["wait_for_context_s"] = time.perf_counter() - t0
         t0 = time.perf_counter()
         metrics["dataset"] = ds.finalize()
         metrics["finalize_s"] = time.perf_counter() - t0

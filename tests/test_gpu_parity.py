@@ -1087,6 +1087,16 @@ def test_cli_project_layout_and_contents(tmp_path, capsys):
         assert open(os.path.join(proj3, "snpCaller", "indiv_called." + sp)).read() == o[1]
         total += got.count("\n")
     assert total > 0
+    # ---- eight threads, one split: the launcher brings the HIP context up on a thread of its own while the host threads read and pack
+    # (cli.py: lazy context; msnv_dataset_attach_ctx gives the dataset its device before finalize)
+    proj8 = str(tmp_path / "out8")
+    cli.main([proj8, lst, fa, "--threads", "8", "--n_splits", "8"])
+    got8 = "".join(open(os.path.join(proj8, "snpCaller", f)).read() for f in sorted(os.listdir(os.path.join(proj8, "snpCaller"))) if f.startswith("called_SNPs"))
+    assert got8.count("\n") == total                        # (the same three species, dealt to eight split files: five of them empty)
+    for i, p in enumerate(paths):
+        want = orc.qacompute(syn.names, syn.lengths, samples[i])
+        base = os.path.join(proj8, "cov", os.path.basename(p) + ".cov")
+        assert open(base).read() == want[0] and open(base + ".detail").read() == want[1]
     # an existing project directory is refused exactly like the reference (metaSNV.py:278-280)
     with pytest.raises(SystemExit):
         cli.main([proj, lst, fa])
