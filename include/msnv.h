@@ -267,6 +267,9 @@ typedef struct {
     uint64_t allele_planes;                       /* 1: the per-sample allele counts go through byte planes (noisy reads), 0: through
                                                      sparse events (clean reads); picked by finalize from the sampled mismatch rate */
     uint64_t sampled_mismatch_ppm;                /* aligned bases that differ from the reference, per million (every 16th piece)   */
+    uint64_t n_whole_tile_items;                  /* tiles piled up AND gated by one workgroup (sparse cohorts) */
+    uint64_t n_listed_tiles;                      /* ... of which the last pass sent through the ordinary gate kernel: more candidate
+                                                     positions than a tile's record list holds                                      */
 } msnv_dataset_info;
 
 int  msnv_dataset_info_get(const msnv_dataset *ds, msnv_dataset_info *out);

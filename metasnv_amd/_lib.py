@@ -53,7 +53,7 @@ class DatasetInfo(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "n_samples", "n_contigs", "n_positions", "n_reads", "n_reads_pileup", "n_pileup_bases",
         "bytes_headers", "bytes_cigar", "bytes_seq", "bytes_qual", "bytes_ref", "bytes_index",
-        "n_tiles", "n_pairs", "n_work", "device_bytes", "allele_planes", "sampled_mismatch_ppm")]
+        "n_tiles", "n_pairs", "n_work", "device_bytes", "allele_planes", "sampled_mismatch_ppm", "n_whole_tile_items", "n_listed_tiles")]
 
 
 class RunStats(C.Structure):

@@ -650,6 +650,7 @@ extern "C" int msnv_dataset_info_get(const msnv_dataset *ds, msnv_dataset_info *
     clear_error();
     if (!ds || !out) return fail(MSNV_EINVAL, "msnv_dataset_info_get: NULL argument");
     *out = ds->info;
+    if (ds->dev) { out->n_whole_tile_items = ds->dev->n_fused_tiles; out->n_listed_tiles = ds->dev->last_ovf_tiles; }
     return MSNV_OK;
 }
 

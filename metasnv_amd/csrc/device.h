@@ -96,7 +96,8 @@ struct DeviceCols {
     uint32_t  n_groups_solo = 0;     // the last n_groups_solo merged groups are whole-tile groups of ONE pair (no gather needed when the pass is fused)
     uint32_t  n_work_fused = 0;      // the last n_work_fused merged work items are whole-tile items
     uint32_t  n_fused_tiles = 0;     // tiles handled by whole-tile work items
-    bool      fuse_disabled = false; // a pass found a tile with more than STAGE_CAP candidates: the dataset runs unfused from then on
+    bool      fuse_disabled = false; // the passes of this dataset do not use the record lists (tests, experiments)
+    uint32_t  last_ovf_tiles = 0;    // whole-tile work items of the last pass whose candidates did not fit a record list (their tiles took the unfused route)
     bool      wide_tot = false;      // some tile's allele totals need 32 bits per allele (tot_add mode 2): the gate kernel's wide instantiation
     bool      use_dirty = false;     // sparse cohort (few work items per tile): the gate kernel consults tile_dirty before it reads the allele totals
     uint32_t  gather_split = 4;      // workgroups per tile in the spill gather (fewer for sparse cohorts: a pair or two per tile)

@@ -63,6 +63,7 @@ struct PileupArgs {
     int             min_cov; double min_frac;
     const uint32_t *ref_lc, *tile_vbeg, *tile_vend, *tile_stage_idx;
     TileStage      *tile_stage;
+    uint32_t       *stage_ovf;    // record-list indices of the tiles with more candidates than a list holds (counters[CNT_STAGE] of them): fused_tile_gate
 };
 
 // allele index (A,C,G,T -> 0..3) of a one-hot nt16 code, 4 for anything else
@@ -636,7 +637,9 @@ __device__ __forceinline__ void narrow_classify32(NarrowLds &L, const uint4 qa, 
 // the tile's per-position state (4 B totals + partial row + rule bits + reference: ~19 KB a tile, as much as the reads themselves
 // in a sparse cohort).
 struct FusedGateArgs { TileStage *st; const uint32_t *ref_lc; uint32_t *counters; uint32_t vb, ve, min_snvs; int min_cov; double min_frac; uint32_t solo; };
-__device__ __attribute__((noinline)) void fused_tile_gate(NarrowLds &L, const FusedGateArgs a, const uint32_t t0, const bool any, const int tid) {
+// (two functions, two argument lists of <= 56 bytes: the ABI passes 16 registers of aggregates, a longer list goes through scratch memory -- in every lane of the kernel)
+struct FusedSpillArgs { uint8_t *row; uint32_t *tot, *unc_bits, *item_dirty, *stage_ovf, *counters; uint32_t stage_idx, flags_snvs; };   // part_lo flags | min_snvs << 4; row, item_dirty: the work item's partial row and dirty word
+__device__ __attribute__((noinline)) bool fused_tile_gate(NarrowLds &L, const FusedGateArgs a, const uint32_t t0, const bool any, const int tid) {
     // (not inlined: the hot loop of the kernel sits exactly at the 72-register step of 7 workgroups per CU)
     TileStage *const st = a.st;
     // (L.evn counts the candidates: merged items stage no events)
@@ -674,9 +677,42 @@ __device__ __attribute__((noinline)) void fused_tile_gate(NarrowLds &L, const Fu
         }
     }
     __syncthreads();
-    if (tid == 0) {
-        st->count = L.evn;
-        if (L.evn > STAGE_CAP) atomicOr(&a.counters[CNT_STAGE], 1u);             // the host runs the pass again, unfused
+    const uint32_t n_cand = L.evn;
+    if (tid == 0) st->count = n_cand;                                             // (> STAGE_CAP: msnv_gate_staged leaves the tile alone)
+    return n_cand > STAGE_CAP;                                                    // (uniform) more than the list holds: fused_tile_spill
+}
+
+// More candidates than the list holds (a handful of tiles of a large sparse cohort: a hypervariable stretch, a tile of noisy
+// reads): THIS tile takes the unfused route -- coverage partial row, allele totals and "some sample may hold >= t reads" marks in
+// global memory, exactly what narrow_pass<MERGED> and store_part_row leave behind -- and goes on the list msnv_gate_sites works
+// through behind msnv_gate_staged.  (Until round 3 one such tile sent the whole dataset back to the unfused pass: 2-3 x the tail
+// of BASELINE configs[3] at full scale.)
+__device__ __attribute__((noinline)) void fused_tile_spill(NarrowLds &L, const FusedSpillArgs a, const uint32_t t0, const int tid) {
+    {
+        WorkItem w{};                                                             // (what store_part_row and store_item_dirty look at)
+        w.slot = 0u; w.part_lo = a.flags_snvs & 15u; w.part_hi = 0u;
+        const uint2 cv = *reinterpret_cast<uint2 *>(&L.start[2 * tid]);
+        const uint32_t tc[N_PPT / 2] = {cv.x & 0x00ff00ffu, (cv.x >> 8) & 0x00ff00ffu, cv.y & 0x00ff00ffu, (cv.y >> 8) & 0x00ff00ffu};
+        store_part_row(a.row, w, tc, tid);
+        const uint32_t tmode = tot_mode_of(w);
+        bool dirty = false;
+#pragma unroll 1
+        for (uint32_t j = 0; j < (uint32_t)N_PPT; ++j) {
+            const uint32_t word = L.al[N_PPT * tid + j];
+            if (!word) continue;
+            dirty = true;
+            const uint32_t gpos = t0 + N_PPT * tid + j;
+#pragma unroll
+            for (uint32_t x = 0; x < 4; ++x) {
+                const uint32_t n = (word >> (8u * x)) & 0xffu;
+                if (n) {
+                    tot_add_one(a.tot + 4ull * t0, tmode, N_PPT * tid + j, x, n);
+                    if (n >= (a.flags_snvs >> 4)) atomicOr(&a.unc_bits[gpos >> 5], 1u << (gpos & 31u));
+                }
+            }
+        }
+        store_item_dirty(a.item_dirty, w, dirty, tid);
+        if (tid == 0) a.stage_ovf[atomicAdd(&a.counters[CNT_STAGE], 1u)] = a.stage_idx;
     }
 }
 
@@ -814,8 +850,12 @@ __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a, NarrowL
     }
     __syncthreads();
     if (MERGED && fused) {
-        const FusedGateArgs fa{a.tile_stage + a.tile_stage_idx[w.tile], a.ref_lc, a.counters, a.tile_vbeg[w.tile], a.tile_vend[w.tile], a.min_snvs, a.min_cov, a.min_frac, w.pair_hi - w.pair_lo == 1u ? 1u : 0u};
-        fused_tile_gate(L, fa, t0, nch != 0u, tid);
+        const uint32_t sidx = a.tile_stage_idx[w.tile];
+        const FusedGateArgs fa{a.tile_stage + sidx, a.ref_lc, a.counters, a.tile_vbeg[w.tile], a.tile_vend[w.tile], a.min_snvs, a.min_cov, a.min_frac, w.pair_hi - w.pair_lo == 1u ? 1u : 0u};
+        if (fused_tile_gate(L, fa, t0, nch != 0u, tid)) {
+            const FusedSpillArgs sa{a.part + ((uint64_t)w.part_hi << 32 | (w.part_lo & ~15u)), a.tot, a.unc_bits, a.slot_dirty + w.slot, a.stage_ovf, a.counters, sidx, (w.part_lo & 15u) | a.min_snvs << 4};
+            fused_tile_spill(L, sa, t0, tid);
+        }
         return;
     }
     if (!MERGED && !DA) flush_events<NarrowLds, N_NT, N_EVCAP>(L, a, tid);
@@ -1078,6 +1118,10 @@ struct GateArgs {
     const TileStage *tile_stage;               // record lists of the whole-tile work items (msnv_gate_staged)
     const uint8_t *aspill;                     // allele planes of the pairs (noisy reads: msnv_gate_sites<.., .., true> sums them), else NULL
     uint32_t zero_next;                        // this launch zeroes the counter block of the next pass (one of the two gate kernels does)
+    // the launch behind msnv_gate_staged: tiles whose whole-tile work item found more candidates than its record list holds (fused_tile_gate);
+    // tile_list[i] = index into gate_tiles, counters[CNT_STAGE] of them; the workgroups stride over the list
+    const uint32_t *tile_list;
+    uint32_t solo_cells;                       // the merged gather skips tiles with ONE pair (their cell is the tile's totals): write it here
 };
 
 // Site slots and per-sample cells are handed out with returning atomics on two device-wide counters, and same-address atomics are
@@ -1155,14 +1199,19 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
     if (tid == 0) { L.pop = 0; L.ind = 0; }
     // the counter block of the NEXT pass (the passes of a dataset alternate between two blocks: no memset between passes)
     if (blockIdx.x == 0 && a.zero_next) for (uint32_t i = threadIdx.x; i < CNT_WORDS; i += GATE_NT) a.counters_next[i] = 0u;
-    const uint32_t ti_lo = MULTI ? blockIdx.x * a.tiles_per_wg : blockIdx.x, ti_hi = MULTI ? min(a.n_active, ti_lo + a.tiles_per_wg) : ti_lo + 1u;
+    const bool listed = MULTI && a.tile_list != nullptr;       // (uniform) the tiles of a device-side list, workgroups stride over it
+    const uint32_t ti_step = listed ? gridDim.x : 1u;
+    const uint32_t ti_lo = listed ? blockIdx.x : MULTI ? blockIdx.x * a.tiles_per_wg : blockIdx.x;
+    const uint32_t ti_hi = listed ? min(a.counters[CNT_STAGE], a.n_active) : MULTI ? min(a.n_active, ti_lo + a.tiles_per_wg) : ti_lo + 1u;
+    if (MULTI && ti_lo >= ti_hi) return;                        // (uniform; before any barrier)
+    auto tile_at = [&](const uint32_t ti) -> GateTile { return a.gate_tiles[listed ? a.tile_list[ti] : ti]; };
     uint32_t st_tiles = 0, st_sites = 0; unsigned long long st_cells = 0;      // staged so far (uniform)
     // everything the workgroup needs to know about a tile in ONE load (the kernel is a chain of dependent loads; with a sparse
     // cohort -- BASELINE configs[3]: a pair or two per tile -- the chain is all there is); the next tile's is fetched a tile ahead
-    GateTile gt_next = a.gate_tiles[ti_lo];                     // tiles that hold work items; the others have no coverage
-    for (uint32_t ti = ti_lo; ti < ti_hi; ++ti) {
+    GateTile gt_next = tile_at(ti_lo);                          // tiles that hold work items; the others have no coverage
+    for (uint32_t ti = ti_lo; ti < ti_hi; ti += ti_step) {
         const GateTile gt = gt_next;
-        if (ti + 1 < ti_hi) gt_next = a.gate_tiles[ti + 1];
+        if (ti + ti_step < ti_hi) gt_next = tile_at(ti + ti_step);
         const uint32_t tile = gt.tile;
         const uint32_t t0 = tile * TILE;
         const uint32_t vb = gt.vbeg, ve = gt.vend;
@@ -1170,6 +1219,9 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
 
         const uint32_t slot_lo = gt.slot_lo, slot_hi = gt.slot_hi;
         const uint32_t slot_16 = gt.slot_16, slot_w = gt.slot_w;
+        // a listed tile with ONE (sample, tile) pair: the merged gather is not launched for it (msnv_gate_staged writes such a tile's cells), so the
+        // individual rule is decided here -- the pair holds every read of the tile -- and the cells are written here
+        const bool solo = MULTI && a.solo_cells && gt.staged == 2u;
         // 64-position blocks of the tile in which some pass added to the allele totals (narrow_pass / wide kernel): the other blocks'
         // totals and individual-rule bits are zero and are not even read (16.6 B per position against ~8 B of reads at 5x)
         // (only consulted for sparse cohorts, use_dirty: with many work items per tile every block is dirty anyway and the totals'
@@ -1351,7 +1403,7 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
     #pragma unroll
                 for (int x = 0; x < 4; ++x) {
                     if ((int)n_of(j, x) < min_snvs) continue;                   // neither rule can fire (call_vC.cpp:588,593-600)
-                    const bool is_pop = (double)n_of(j, x) >= lim, is_ind = (indx >> x) & 1u;
+                    const bool is_pop = (double)n_of(j, x) >= lim, is_ind = ((indx >> x) & 1u) || (solo && unc);
                     ok |= is_pop || is_ind || unc;
                     if (lc && rc == (1u << x)) continue;                       // skip-same-base, case-sensitive (call_vC.cpp:580)
                     if (is_pop) pop |= 1u << x; else if (is_ind) ind |= 1u << x;
@@ -1399,7 +1451,7 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
             gate_flush(L, a, st_tiles, st_sites, st_cells, tid);
             st_tiles = 0; st_sites = 0; st_cells = 0;
         }
-        if (total <= GATE_STAGE) {
+        if (total <= GATE_STAGE && !solo) {
             if ((n_slots & 7u) == 0u) st_cells = (st_cells + 7ull) & ~7ull;      // a tile whose rows are multiples of 16 bytes starts on 16 bytes (gather_cov_wide)
             if (tid == 0) L.tiles[st_tiles] = GateStageTile{tile, st_sites, total, n_slots, st_cells};
             if ((lane & 7) == 0) L.blk_rel[st_tiles][p0 >> 6] = st_sites + mybase;
@@ -1432,7 +1484,8 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
         }
         __syncthreads();
         const uint32_t base = L.base; const unsigned long long s_cell = L.cell;
-        if ((uint64_t)base + total <= cap_out && s_cell + (unsigned long long)total * n_slots <= a.cap_cells) {
+        const bool fits = (uint64_t)base + total <= cap_out && s_cell + (unsigned long long)total * n_slots <= a.cap_cells;
+        if (fits && !solo) {
             const uint64_t n_cells = (uint64_t)total * n_slots;
             zero_cells<GATE_NT>(a.ncol, cov_col, a.cap_cells, s_cell, n_cells, (uint32_t)tid);
         }
@@ -1454,6 +1507,12 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
                     if (a.any_split && ((uncm >> j) & 1u)) {
                         const uint32_t u = atomicAdd(&counters[CNT_UNC], 1u);
                         if (u < cap_sites) a.unc_sites[u] = idx;
+                    }
+                    if (solo && fits) {                                // one slot per site: the cell is the tile's totals
+                        const unsigned long long cell = s_cell + (idx - base);
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) a.ncol[(uint64_t)x * a.cap_cells + cell] = (uint16_t)s.n[x];
+                        cov_col[cell] = (uint16_t)s.cov;
                     }
                 }
                 ++idx;
@@ -1489,7 +1548,11 @@ __global__ __launch_bounds__(256) void msnv_gate_staged(const GateArgs a, const 
     // lanes 0 .. n_here - 1: one tile each
     GateTile gt{};
     uint32_t cnt = 0;
-    if ((uint32_t)lane < n_here) { gt = tiles[w0 + (uint32_t)lane]; cnt = min(a.tile_stage[gt.row0].count, STAGE_CAP); }
+    bool mine = (uint32_t)lane < n_here;                              // a tile whose candidates did not fit its list is not mine: fused_tile_gate sent it to msnv_gate_sites
+    if (mine) {
+        gt = tiles[w0 + (uint32_t)lane]; cnt = a.tile_stage[gt.row0].count;
+        if (cnt > STAGE_CAP) { mine = false; cnt = 0u; }
+    }
     const unsigned long long cells = (unsigned long long)cnt * gt.n_slots;
     uint32_t site_rel = cnt; unsigned long long cell_rel = cells;
 #pragma unroll
@@ -1513,10 +1576,12 @@ __global__ __launch_bounds__(256) void msnv_gate_staged(const GateArgs a, const 
     uint32_t base = s_base; unsigned long long cb = s_cb;
     uint32_t wg_sites = 0; unsigned long long wg_cells = 0;
     for (int k = 0; k < 4; ++k) { if (k < wave) { base += s_sites[k]; cb += s_cells[k]; } wg_sites += s_sites[k]; wg_cells += s_cells[k]; }
-    if ((uint32_t)lane < n_here) { a.tile_site_base[gt.tile] = cnt ? base + site_rel : 0u; a.tile_site_cnt[gt.tile] = cnt; a.tile_cell_base[gt.tile] = cnt ? cb + cell_rel : 0ull; }
+    if (mine) { a.tile_site_base[gt.tile] = cnt ? base + site_rel : 0u; a.tile_site_cnt[gt.tile] = cnt; a.tile_cell_base[gt.tile] = cnt ? cb + cell_rel : 0ull; }
     const bool fits = (unsigned long long)s_base + wg_sites <= a.cap_out && s_cb + wg_cells <= a.cap_cells;   // else: the host sees the counts and runs again with larger buffers
     uint32_t np = 0, ni = 0;
+    const unsigned long long mine_mask = __ballot(mine);
     for (uint32_t t = 0; t < n_here; ++t) {
+        if (!((mine_mask >> t) & 1ull)) continue;                       // (uniform)
         const uint32_t tile = (uint32_t)__shfl((int)gt.tile, (int)t), n = (uint32_t)__shfl((int)cnt, (int)t), n_slots = (uint32_t)__shfl((int)gt.n_slots, (int)t);
         const uint32_t kind = (uint32_t)__shfl((int)gt.staged, (int)t), srel = (uint32_t)__shfl((int)site_rel, (int)t);
         const unsigned long long crel = (unsigned long long)__shfl((long long)cell_rel, (int)t), sidx = (unsigned long long)__shfl((long long)gt.row0, (int)t);
@@ -2329,6 +2394,9 @@ static int ensure_out(DeviceCols &d, uint64_t n_sites, uint64_t n_cells) {
     return MSNV_OK;
 }
 
+// (the list lives behind the record lists, in the same allocation: the two sets of intermediates swap it with them)
+static inline uint32_t *stage_ovf_list(const DeviceCols &d) { return d.tile_stage ? reinterpret_cast<uint32_t *>(d.tile_stage + d.n_active_tiles) : nullptr; }
+
 // Enqueues one pass (kernels + readback of the pass' counter block into host_cnt[CNT_WORDS]) without waiting for it.
 // ev_begin / ev_pile0 / ev_pile1 are recorded before the pass, before and after the pileup kernel(s); ev3 / ev4 (optional)
 // split the tail.  Buffers must have been sized by ensure_out before.
@@ -2354,7 +2422,7 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
         a.counters = counters; a.min_baseq = (uint32_t)std::max(0, p.min_baseq);
         a.ind4 = d.ind4; a.unc_bits = d.unc_bits; a.slot_dirty = d.tile_dirty; a.min_snvs = (uint32_t)std::max(0, p.calling_threshold);
         a.n_fused_lo = d.n_work_narrow + d.n_work_merged - (use_stage ? d.n_work_fused : 0u); a.min_cov = p.min_coverage; a.min_frac = p.min_fraction; a.ref_lc = d.ref_lc; a.tile_vbeg = d.tile_vbeg; a.tile_vend = d.tile_vend;
-        a.tile_stage = d.tile_stage; a.tile_stage_idx = d.tile_stage_idx;
+        a.tile_stage = d.tile_stage; a.tile_stage_idx = d.tile_stage_idx; a.stage_ovf = stage_ovf_list(d);
         const uint32_t n_narrow = d.n_work_narrow, n_merged = d.n_work_merged;
         // narrow work items (byte bins), merged groups of shallow pairs and wide items (16-bit bins) touch disjoint (tile, sample) pairs
         a.hdr8m = d.hdr8m; a.n_narrow = n_narrow;
@@ -2392,7 +2460,7 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
         const uint32_t n_staged = use_stage ? d.n_fused_tiles : 0u, n_dense = d.n_active_tiles - n_staged;
         if (use_stage) g.gate_tiles = reinterpret_cast<const GateTile *>(d.gate_tiles_dense);
         g.n_active = n_dense;
-        g.zero_next = 1u;
+        g.zero_next = 1u; g.tile_list = nullptr; g.solo_cells = 0u;
         if (n_dense) {
             g.tiles_per_wg = n_dense >= 32768u ? 8u : n_dense >= 8192u ? 4u : 1u;
             if (const char *e = getenv("MSNV_GATE_TILES")) g.tiles_per_wg = (uint32_t)std::min<int>((int)GATE_MAX_TILES, std::max(1, atoi(e)));
@@ -2415,7 +2483,21 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
             }
             g.zero_next = 0u;
         }
-        if (n_staged) hipLaunchKernelGGL(msnv_gate_staged, dim3((n_staged + 4 * GS_TILES - 1) / (4 * GS_TILES)), dim3(256), 0, st, g, reinterpret_cast<const GateTile *>(d.gate_tiles_staged), n_staged);
+        if (n_staged) {
+            hipLaunchKernelGGL(msnv_gate_staged, dim3((n_staged + 4 * GS_TILES - 1) / (4 * GS_TILES)), dim3(256), 0, st, g, reinterpret_cast<const GateTile *>(d.gate_tiles_staged), n_staged);
+            // the tiles whose candidates did not fit their record list (counted and listed on the device: fused_tile_gate) through the ordinary
+            // gate; the workgroups stride over the list -- as many as the previous pass would have kept busy, a handful when it listed none
+            g.gate_tiles = reinterpret_cast<const GateTile *>(d.gate_tiles); g.tile_list = stage_ovf_list(d); g.n_active = n_staged; g.solo_cells = 1u;
+            g.tiles_per_wg = 1u; g.zero_next = 0u; g.aspill = d.aspill;
+            const dim3 grid(std::min<uint32_t>(n_staged, std::max<uint32_t>(64u, std::min<uint32_t>(4096u, d.last_ovf_tiles))));
+            if (d.allele_planes) {
+                if (d.wide_tot) hipLaunchKernelGGL((msnv_gate_sites<true, true, true>), grid, dim3(GATE_NT), 0, st, g);
+                else hipLaunchKernelGGL((msnv_gate_sites<true, false, true>), grid, dim3(GATE_NT), 0, st, g);
+            } else {
+                if (d.wide_tot) hipLaunchKernelGGL((msnv_gate_sites<true, true>), grid, dim3(GATE_NT), 0, st, g);
+                else hipLaunchKernelGGL((msnv_gate_sites<true, false>), grid, dim3(GATE_NT), 0, st, g);
+            }
+        }
         HIP_TRY(hipGetLastError());
     } else HIP_TRY(hipMemsetAsync(counters_next, 0, CNT_WORDS * sizeof(uint32_t), st));   // nobody else would
     if (ev3) HIP_TRY(hipEventRecord(ev3, st));
@@ -2460,10 +2542,7 @@ static int check_counts(DeviceCols &d, const uint32_t *cnt, RunCounts *counts) {
     RunCounts c{cnt[0], cnt[1], cnt[2], cnt[3], (uint64_t)cnt[CNT_CELLS] | (uint64_t)cnt[CNT_CELLS + 1] << 32};
     d.last_sites = c.n_sites; d.last_cells = c.n_cells;
     if (counts) *counts = c;
-    if (cnt[CNT_STAGE]) {                                      // a tile with more candidates than a record list holds: the pass is run again, unfused
-        d.fuse_disabled = true;
-        return fail_quiet(MSNV_ECAPACITY, "a whole-tile work item found more than %u candidate positions", STAGE_CAP);
-    }
+    d.last_ovf_tiles = cnt[CNT_STAGE];                         // whole-tile work items whose candidates did not fit a record list (their tiles went through msnv_gate_sites)
     if (c.n_events > d.cap_events / EV_LISTS * EV_LISTS || c.n_overflow > d.cap_overflow || c.n_sites > d.cap_sites || c.n_sites > d.cap_out_sites || c.n_cells > d.cap_cells)
         return fail_quiet(MSNV_ECAPACITY, "device buffer too small: events %u/%u overflow %u/%u sites %u/%u out %u/%llu cells %llu/%llu",
                           c.n_events, d.cap_events, c.n_overflow, d.cap_overflow, c.n_sites, d.cap_sites, c.n_sites,
@@ -2543,7 +2622,7 @@ static int ensure_alt(DeviceCols &d) {
     if (int rc = dev_alloc((void **)&a.site_flags, d.cap_out_sites + 4, &d.device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&a.site_elig, d.cap_out_sites + 4, &d.device_bytes)) return rc;
     if (d.n_fused_tiles && !a.tile_stage) {
-        if (int rc = dev_alloc((void **)&a.tile_stage, (uint64_t)d.n_active_tiles * sizeof(TileStage), &d.device_bytes)) return rc;
+        if (int rc = dev_alloc((void **)&a.tile_stage, (uint64_t)d.n_active_tiles * sizeof(TileStage) + (uint64_t)d.n_fused_tiles * sizeof(uint32_t), &d.device_bytes)) return rc;   // (+ the overflow list: stage_ovf_list)
         if (int rc = dev_memset(a.tile_stage, 0, (uint64_t)d.n_active_tiles * sizeof(TileStage))) return rc;
     }
     a.cap_events = d.cap_events; a.cap_overflow = d.cap_overflow; a.cap_sites = d.cap_sites; a.cap_out_sites = d.cap_out_sites; a.cap_cells = d.cap_cells;

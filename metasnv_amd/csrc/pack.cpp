@@ -1113,7 +1113,8 @@ int finalize_dataset(msnv_dataset &ds) {
                 if (int rc = upload_vec(&d->gate_tiles_dense, dense_l, &d->device_bytes, 1)) return rc;
                 if (int rc = upload_vec(&d->gate_tiles_staged, staged_l, &d->device_bytes, 1)) return rc;
                 if (int rc = upload_vec(&d->tile_stage_idx, stage_idx, &d->device_bytes)) return rc;
-                if (int rc = dev_alloc((void **)&d->tile_stage, (uint64_t)active.size() * sizeof(TileStage), &d->device_bytes)) return rc;
+                // (+ one index per whole-tile item behind the lists: the tiles whose candidates do not fit a list -- kernels.hip: stage_ovf_list)
+                if (int rc = dev_alloc((void **)&d->tile_stage, (uint64_t)active.size() * sizeof(TileStage) + (uint64_t)n_fused * sizeof(uint32_t), &d->device_bytes)) return rc;
                 if (int rc = dev_memset(d->tile_stage, 0, (uint64_t)active.size() * sizeof(TileStage))) return rc;
             }
         }

@@ -24,4 +24,4 @@ for _ in range(N):
     for k in ("ms_total", "ms_pileup", "ms_gate", "ms_gather", "ms_decide"):
         acc[k] = acc.get(k, 0) + st[k] / N
 print({k: round(v, 4) for k, v in acc.items()}, {k: st[k] for k in ("n_sites", "n_events", "n_called_pop", "n_called_indiv")},
-      {k: info[k] for k in ("n_pileup_bases", "n_positions", "n_tiles", "n_pairs", "n_work")})
+      {k: info[k] for k in ("n_pileup_bases", "n_positions", "n_tiles", "n_pairs", "n_work")}, {k: ds.info()[k] for k in ("n_whole_tile_items", "n_listed_tiles")})

@@ -342,8 +342,9 @@ def test_whole_tile_work_items(fuse, monkeypatch):
     """Sparse cohorts: a tile whose pairs fit one merged group is piled up by ONE workgroup, which applies the gates and the calling
     rule itself and leaves a record list for the gate kernel (kernels.hip: fused_tile_gate; pack.cpp: fuse_tile).  MSNV_FUSE=1 forces
     the path on cohorts of any shape, 0 switches it off.  Same bytes as the oracle for (a) a sparse cohort with a lower-case
-    reference and a BED split, several thresholds; (b) SNVs so dense that tiles hold more candidates than a record list (the pass is
-    run again, unfused, and the dataset stays unfused); (c) a cohort where some tiles are fused and others hold deep / split pairs."""
+    reference and a BED split, several thresholds; (b) SNVs so dense that tiles hold more candidates than a record list (those tiles
+    go through the ordinary gate kernel: test_whole_tile_items_with_more_candidates_than_a_record_list); (c) a cohort where some tiles
+    are fused and others hold deep / split pairs."""
     monkeypatch.setenv("MSNV_FUSE", fuse)
     monkeypatch.setenv("MSNV_LAYOUT", "pieces")
     syn, samples = synth_case(n_species=9, contig_len=5000, n_samples=40, mean_cov=4.0, sigma_cov=0.6, snv_density=0.004, error_rate=0.004,
@@ -374,6 +375,47 @@ def test_whole_tile_work_items(fuse, monkeypatch):
     prod = run_product(syn3.names, syn3.lengths, syn3.seqs, samples3)
     orac = run_oracle(syn3.names, syn3.lengths, syn3.seqs, samples3)
     _assert_same(prod, orac)
+
+
+@pytest.mark.gpu
+def test_whole_tile_items_with_more_candidates_than_a_record_list(monkeypatch):
+    """A whole-tile work item that finds more than STAGE_CAP (24) candidate positions does not fit its record list: THAT tile leaves
+    the workgroup the unfused way (partial row, allele totals, marks: kernels.hip fused_tile_spill), goes on a device-side list and
+    through msnv_gate_sites behind msnv_gate_staged; the other tiles keep their record lists (until round 3 one such tile sent the
+    whole dataset back to the unfused pass).  Cohorts where (a) some tiles are listed and most are not, (b) tiles with ONE pair are
+    listed (their cells are written by the gate kernel: the merged gather is not launched for them), (c) every tile is listed
+    (threshold 1: every error is a candidate); lower-case reference; repeated and overlapped passes over the resident dataset (the
+    list lives in both sets of intermediates).  Same bytes as the oracle, and the info block says how many tiles were listed."""
+    monkeypatch.setenv("MSNV_FUSE", "1")
+    monkeypatch.setenv("MSNV_LAYOUT", "pieces")
+    cases = [
+        (dict(n_species=12, contig_len=5000, n_samples=16, mean_cov=5.0, sigma_cov=0.5, snv_density=0.012, error_rate=0.004, frac_absent=0.6, lowercase_ref=1, seed=6301),
+         dict(min_coverage=2, calling_threshold=2), "some"),
+        (dict(n_species=10, contig_len=4500, n_samples=3, mean_cov=7.0, sigma_cov=0.4, snv_density=0.03, error_rate=0.004, frac_absent=0.6, lowercase_ref=1, seed=6302),
+         dict(min_coverage=2, calling_threshold=2), "some"),
+        (dict(n_species=5, contig_len=4200, n_samples=8, mean_cov=4.0, sigma_cov=0.5, snv_density=0.01, error_rate=0.02, frac_absent=0.5, seed=6303),
+         dict(min_coverage=1, calling_threshold=1, min_fraction=0.0), "all"),
+    ]
+    for sk, pk, how in cases:
+        syn, samples = synth_case(**sk)
+        p = core.default_params(**pk)
+        pop, ind, info, st, ds, ctx = run_product(syn.names, syn.lengths, syn.seqs, samples, params=p, return_ds=True)
+        orac = run_oracle(syn.names, syn.lengths, syn.seqs, samples, params=p)
+        _assert_same((pop, ind, info, st), orac)
+        i2 = ds.info()
+        assert i2["n_whole_tile_items"] > 0
+        if how == "some":
+            assert 0 < i2["n_listed_tiles"] < i2["n_whole_tile_items"], i2
+        else:
+            assert i2["n_listed_tiles"] > 0.5 * i2["n_whole_tile_items"], i2      # (the short last tile of a contig may hold few)
+        for again in ("run", "many", "overlap"):
+            if again == "run": ds.run()
+            else: ds.run_many(3, overlap=again == "overlap")
+            assert ds.info()["n_listed_tiles"] == i2["n_listed_tiles"]
+            with tempfile.TemporaryDirectory() as td:
+                ds.write_calls(os.path.join(td, "p"), os.path.join(td, "i"), None, None)
+                assert open(os.path.join(td, "p")).read() == pop and open(os.path.join(td, "i")).read() == ind, again
+        ds.close(); ctx.close()
 
 
 @pytest.mark.gpu
