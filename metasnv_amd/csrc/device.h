@@ -97,6 +97,7 @@ struct DeviceCols {
     uint32_t  n_work_fused = 0;      // the last n_work_fused merged work items are whole-tile items
     uint32_t  n_fused_tiles = 0;     // tiles handled by whole-tile work items
     bool      fuse_disabled = false; // the passes of this dataset do not use the record lists (tests, experiments)
+    int       qlow_cutoff = 0;       // the -Q cutoff the one-bit quality column was packed with (pack.cpp: pack_lowq); a pass must ask for the same
     uint32_t  last_ovf_tiles = 0;    // whole-tile work items of the last pass whose candidates did not fit a record list (their tiles took the unfused route)
     bool      wide_tot = false;      // some tile's allele totals need 32 bits per allele (tot_add mode 2): the gate kernel's wide instantiation
     bool      use_dirty = false;     // sparse cohort (few work items per tile): the gate kernel consults tile_dirty before it reads the allele totals

@@ -38,7 +38,7 @@ struct PileupArgs {
     const PieceHdr *hdr8m;        // headers of the merged groups (pair index in bits 19+, absolute seq offset / 8)
     uint32_t        n_narrow;     // narrow32 launch: work items [0, n_narrow) are ordinary, the rest hold merged groups
     const uint8_t  *seq;
-    const uint8_t  *qual;
+    const uint8_t  *qual;         // ONE BIT per base, in the order of the seq column's nibbles: the base's quality is below the -Q cutoff (pack.cpp packs them at upload: the cutoff is a parameter of the dataset)
     const uint64_t *s_read_base, *s_seq_base;
     const uint32_t *ref4;
     const TilePair *pairs;
@@ -90,14 +90,15 @@ __device__ __forceinline__ uint4 any_uint4() {
     asm volatile("" : "=v"(v.x), "=v"(v.y), "=v"(v.z), "=v"(v.w));
     return v;
 }
-// 16 quality bytes (each <= 127, host clamps) -> 16-bit mask of bytes below the cutoff
-// kq = 0x80808080 - min_baseq * 0x01010101: bit 7 of (byte + kq) is set iff byte >= min_baseq
-__device__ __forceinline__ uint32_t lowq_mask(const uint4 qv, const uint32_t kq) {
-    const uint32_t l0 = ~(qv.x + kq) & 0x80808080u, l1 = ~(qv.y + kq) & 0x80808080u;
-    const uint32_t l2 = ~(qv.z + kq) & 0x80808080u, l3 = ~(qv.w + kq) & 0x80808080u;
-    const uint32_t lqa = __builtin_amdgcn_udot4(l1, 0x80402010u, __builtin_amdgcn_udot4(l0, 0x08040201u, 0u, false), false);
-    const uint32_t lqb = __builtin_amdgcn_udot4(l3, 0x80402010u, __builtin_amdgcn_udot4(l2, 0x08040201u, 0u, false), false);
-    return ((lqa >> 7) & 0xffu) | ((lqb << 1) & 0xff00u);
+// Low-quality flags of up to 32 consecutive bases: `bit` = index of the first base's flag in the column (= its nibble index in the seq
+// column).  Pieces start on SEQ_ALIGN bytes of seq = a multiple of 4 bases, so the flags start anywhere in a byte: eight bytes, shifted.
+__device__ __forceinline__ uint2 lowq_fetch(const uint8_t *qlow, const uint64_t bit) {
+    uint2 v;
+    __builtin_memcpy(&v, qlow + (bit >> 3), 8);
+    return v;
+}
+__device__ __forceinline__ uint32_t lowq_bits(const uint2 v, const uint32_t shift) {
+    return (uint32_t)(((unsigned long long)v.y << 32 | v.x) >> shift);
 }
 
 template <int CTRL, int ROW_MASK>
@@ -196,14 +197,13 @@ __device__ __forceinline__ void stage_allele_event(LDS &L, const PileupArgs &a, 
     if (g < a.cap_events) a.events[g] = e;
 }
 
-__device__ __forceinline__ void wide_classify(WideLds &L, const uint4 qv, const uint32_t s0, const uint32_t s1,
-                                              const uint32_t P0, const uint32_t vmask, const uint32_t kq) {
+__device__ __forceinline__ void wide_classify(WideLds &L, const uint32_t lq, const uint32_t s0, const uint32_t s1,
+                                              const uint32_t P0, const uint32_t vmask) {
     const uint32_t pr = P0;
     const uint32_t wi = pr >> 3, sh = (pr & 7u) * 4u;
     const uint32_t w0 = L.ref[wi], w1 = L.ref[wi + 1], w2 = L.ref[wi + 2];
     const uint32_t r0 = __builtin_amdgcn_alignbit(w1, w0, sh), r1 = __builtin_amdgcn_alignbit(w2, w1, sh);
     const uint32_t nm = nibflags_to_bits(nz_nibbles(s0 ^ r0)) | nibflags_to_bits(nz_nibbles(s1 ^ r1)) << 8;
-    const uint32_t lq = lowq_mask(qv, kq);
     uint32_t e = (lq | nm) & vmask;
     while (e) {
         const uint32_t j = (uint32_t)__builtin_ctz(e);
@@ -223,7 +223,6 @@ __global__ __launch_bounds__(W_NT) void msnv_pileup_tiles_wide(PileupArgs a) {
     const uint32_t t0 = w.tile * TILE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lane8 = tid & (LANES_PER_READ - 1), grp = tid / LANES_PER_READ;
-    const uint32_t kq = 0x80808080u - min(a.min_baseq, 128u) * 0x01010101u;
     const int b0 = 16 * lane8;
 
     for (int i = tid; i < (int)(TILE / 8 + 4); i += W_NT)
@@ -259,7 +258,7 @@ __global__ __launch_bounds__(W_NT) void msnv_pileup_tiles_wide(PileupArgs a) {
         __syncthreads();                                            // (A) headers visible, bins clean
 
         const uint8_t *seq = a.seq + a.s_seq_base[sample];
-        const uint8_t *qual = a.qual + 2 * a.s_seq_base[sample];
+        const uint64_t qbit0 = 2ull * a.s_seq_base[sample];      // the sample's first flag in the low-quality column
         for (uint32_t r = (uint32_t)grp; r < nrd; r += W_NT / LANES_PER_READ) {
             const uint4 h = L.hdr[buf][r];
             if (!(h.w & META_PILEUP_OK)) continue;
@@ -267,10 +266,11 @@ __global__ __launch_bounds__(W_NT) void msnv_pileup_tiles_wide(PileupArgs a) {
             if (lane8 == 0) { atomicAdd(&L.span[s], 1); atomicAdd(&L.span[s + len], -1); }
             const int vhi = min(max((int)len - b0, 0), 16);
             if (vhi <= 0) continue;
-            uint4 qv; uint2 sv;
-            __builtin_memcpy(&qv, qual + 2ull * h.y + (uint32_t)b0, 16);
+            uint2 sv;
+            const uint64_t qbit = qbit0 + 2ull * h.y + (uint32_t)b0;
+            const uint2 qv = lowq_fetch(a.qual, qbit);
             __builtin_memcpy(&sv, seq + (uint64_t)h.y + (uint32_t)(b0 >> 1), 8);
-            wide_classify(L, qv, sv.x, sv.y, s + (uint32_t)b0, (1u << vhi) - 1u, kq);
+            wide_classify(L, lowq_bits(qv, (uint32_t)qbit & 7u), sv.x, sv.y, s + (uint32_t)b0, (1u << vhi) - 1u);
         }
 
         if (last_chunk) {
@@ -572,12 +572,11 @@ constexpr int N32_GROUPS = N_NT / N32_LANES;   // 64 pieces per round
 constexpr int N32_ROUNDS = N_HCAP / N32_GROUPS;   // 2
 static_assert(N32_LANES * 32 == SEG_MAX && N32_ROUNDS == 2, "narrow32 is written for 128-base pieces, 128-piece chunks");
 
-__device__ __forceinline__ void narrow_classify32(NarrowLds &L, const uint4 qa, const uint4 qb, const uint4 sq, const uint32_t P0,
-                                                  const int vhi, const uint32_t kq) {
+__device__ __forceinline__ void narrow_classify32(NarrowLds &L, const uint32_t lq_all, const uint4 sq, const uint32_t P0, const int vhi) {
     const uint32_t wi = P0 >> 3, sh = (P0 & 7u) * 4u;
     const uint32_t w0 = L.ref[wi], w1 = L.ref[wi + 1], w2 = L.ref[wi + 2], w3 = L.ref[wi + 3], w4 = L.ref[wi + 4];
     const uint32_t vmask = (vhi >= 32) ? 0xffffffffu : ((1u << vhi) - 1u);
-    const uint32_t lq = (lowq_mask(qa, kq) | lowq_mask(qb, kq) << 16) & vmask;
+    const uint32_t lq = lq_all & vmask;                                       // bases below the BQ cutoff (one bit per base: the low-quality column)
     const unsigned long long m = (unsigned long long)lq << (P0 & 7u);      // <= 39 bits: five groups of 8 byte bins
 #pragma unroll
     for (int w = 0; w < 5; ++w) {
@@ -723,7 +722,6 @@ __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a, NarrowL
     const uint32_t t0 = w.tile * TILE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lane4 = tid & (N32_LANES - 1), grp = tid / N32_LANES;
-    const uint32_t kq = 0x80808080u - min(a.min_baseq, 128u) * 0x01010101u;
     const int b0 = 32 * lane4;
 
     for (int i = tid; i < (int)(TILE / 8 + 4); i += N_NT)
@@ -782,13 +780,15 @@ __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a, NarrowL
     };
     if (tid < N_HCAP) put_hdr(0u, hreg0);                         // chunk 0: fetched through the descriptor that came with the work item
     uint2 hreg = load_hdr(1);
-    uint4 qa[N32_ROUNDS], qb[N32_ROUNDS], sq[N32_ROUNDS]; uint32_t P0[N32_ROUNDS]; int vh[N32_ROUNDS];
+    uint4 sq[N32_ROUNDS]; uint2 ql[N32_ROUNDS]; uint32_t P0[N32_ROUNDS], qsh[N32_ROUNDS]; int vh[N32_ROUNDS];      // ql >> qsh: the lane's 32 low-quality flags
     auto issue_loads = [&](const uint32_t c) {
         uint64_t sbase = L.desc[c % MAX_CHUNKS_PER_ITEM].seq_base;
         // (4-byte headers: the chunk's base is the same in every lane -- scalar registers, so that a lane's address is base + 32-bit offset)
         if constexpr (H4) sbase = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(sbase >> 32)) << 32 | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sbase);
         const uint8_t *seq = a.seq + sbase;
-        const uint8_t *qual = a.qual + 2 * sbase;
+        // low-quality flags: one bit per base, flag of the column's nibble n at bit n (chunk bases are multiples of SEQ_ALIGN bytes = 4 bases)
+        const uint8_t *qlow = a.qual + (sbase >> 2);
+        const uint32_t qrem = 2u * ((uint32_t)sbase & 3u);
 #pragma unroll
         for (int i = 0; i < N32_ROUNDS; ++i) {
             const uint2 h = get_hdr(c & 1u, (uint32_t)(grp + i * N32_GROUPS));     // all zero for empty slots
@@ -796,21 +796,21 @@ __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a, NarrowL
             const uint32_t s = h.x & (TILE - 1u);
             // seq byte offset of the piece inside the sample; a merged group's pieces come from all over the column: their ABSOLUTE offset / SEQ_ALIGN is 37 bits wide (bits 27+ of the first word)
             vh[i] = min(max((int)len - b0, 0), 32);
-            qa[i] = any_uint4(); qb[i] = any_uint4(); sq[i] = any_uint4();   // never observed: vh masks every use
+            sq[i] = any_uint4(); ql[i] = make_uint2(0u, 0u); qsh[i] = 0u;   // (sq never observed: vh masks every use)
             if constexpr (H4) {
                 const uint32_t so = (h.x >> 19) << SEQ_ALIGN_LOG2;       // < 16 KB from the chunk's base
                 if (vh[i] > 0) {                                     // lanes past the end of the piece load nothing
-                    const uint32_t qo = 2u * so + (uint32_t)b0, sq_o = so + (uint32_t)(b0 >> 1);
-                    __builtin_memcpy(&qa[i], qual + qo, 16);
-                    if (vh[i] > 16) __builtin_memcpy(&qb[i], qual + qo + 16u, 16);
+                    const uint32_t qbit = qrem + 2u * so + (uint32_t)b0, sq_o = so + (uint32_t)(b0 >> 1);
+                    __builtin_memcpy(&ql[i], qlow + (qbit >> 3), 8);
+                    qsh[i] = qbit & 7u;
                     __builtin_memcpy(&sq[i], seq + sq_o, 16);
                 }
             } else {
                 const uint64_t so = (MERGED ? ((uint64_t)(h.x >> 27) << 32 | h.y) : (uint64_t)h.y) << SEQ_ALIGN_LOG2;
                 if (vh[i] > 0) {                                     // lanes past the end of the piece load nothing
-                    const uint8_t *qp = qual + 2ull * so + (uint32_t)b0;   // pieces start on 2 x SEQ_ALIGN (qual) / SEQ_ALIGN (seq) bytes
-                    __builtin_memcpy(&qa[i], qp, 16);
-                    if (vh[i] > 16) __builtin_memcpy(&qb[i], qp + 16, 16);
+                    const uint64_t qbit = (uint64_t)qrem + 2ull * so + (uint32_t)b0;
+                    __builtin_memcpy(&ql[i], qlow + (qbit >> 3), 8);
+                    qsh[i] = (uint32_t)qbit & 7u;
                     __builtin_memcpy(&sq[i], seq + so + (uint32_t)(b0 >> 1), 16);
                 }
             }
@@ -839,7 +839,7 @@ __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a, NarrowL
         }
 #pragma unroll
         for (int i = 0; i < N32_ROUNDS; ++i)
-            if (__any(vh[i] > 0)) narrow_classify32(L, qa[i], qb[i], sq[i], P0[i], vh[i], kq);
+            if (__any(vh[i] > 0)) narrow_classify32(L, lowq_bits(ql[i], qsh[i]), sq[i], P0[i], vh[i]);
 
         if (tid < N_HCAP) put_hdr((c + 1u) & 1u, hreg);               // headers of chunk c + 1 (zeros behind the last chunk)
         hreg = load_hdr(c + 2u);
@@ -956,7 +956,6 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_dense(PileupArgs a) {
     const WorkItem w = a.work[blockIdx.x];
     const uint32_t t0 = w.tile * TILE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t kq = 0x80808080u - min(a.min_baseq, 128u) * 0x01010101u;
 
     for (int i = tid; i < (int)(TILE / 8 + D_PAD + 8); i += N_NT) {
         const int r = i - D_PAD;
@@ -1002,15 +1001,14 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_dense(PileupArgs a) {
         if (L.evn >= (uint32_t)(N_EVCAP / 2)) flush_events<DenseLds, N_NT, N_EVCAP>(L, a, tid);
 
         const uint8_t *seq = a.seq + cd.seq_base;
-        const uint8_t *qual = a.qual + 2 * cd.seq_base;
-        uint4 qa[ROUNDS], qb[ROUNDS], sq[ROUNDS];
+        const uint64_t qbit0 = 2ull * cd.seq_base;                  // the chunk's first flag in the low-quality column (one bit per base)
+        uint4 sq[ROUNDS]; uint2 ql[ROUNDS];
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
             const uint32_t b = (uint32_t)(r * N_NT + tid);
-            qa[r] = any_uint4(); qb[r] = any_uint4(); sq[r] = any_uint4();   // never observed: an empty descriptor masks every use
+            sq[r] = any_uint4(); ql[r] = make_uint2(0u, 0u);   // (sq never observed: an empty descriptor masks every use)
             if (b < nblk) {
-                const uint4 *qp = reinterpret_cast<const uint4 *>(qual + 32ull * b);
-                qa[r] = qp[0]; qb[r] = qp[1];
+                ql[r] = lowq_fetch(a.qual, qbit0 + 32ull * b);
                 sq[r] = *reinterpret_cast<const uint4 *>(seq + 16ull * b);
             }
         }
@@ -1031,7 +1029,7 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_dense(PileupArgs a) {
                 atomicAdd(&L.start[s >> 2], 1u << (8u * (s & 3u)));
                 if (d & BLK_END_B) { const uint32_t e = PBv; atomicAdd(&L.end[e >> 2], 1u << (8u * (e & 3u))); }   // s + (32 - sB) = PBv
             }
-            const uint32_t lq = lowq_mask(qa[r], kq) | lowq_mask(qb[r], kq) << 16;
+            const uint32_t lq = lowq_bits(ql[r], (uint32_t)qbit0 & 7u);
             dense_segment(L, sq[r], lq, P0A + 32u, 0, (int)nA);
             if (__any(hasB)) dense_segment(L, sq[r], lq, hasB ? PBv : 32u, hasB ? (int)sB : 32, 32);
         }
@@ -1970,7 +1968,6 @@ __device__ __forceinline__ void gather_merged_block(const TailArgs &a, const uin
     if (base + n > a.cap_out) return;                   // the host sees the site count and retries with a larger buffer
     if (cell0 + (unsigned long long)n * n_slots > a.cells.cap_cells) return;
     if (tid < TILE / 64) { s_bits[tid] = my_bits; s_rank[tid] = my_rank - base; }
-    const uint32_t kq = min(a.min_baseq, 128u);
     {
         // the group's extent comes with its descriptor: every table the block needs is one load away from it (a chain of ten
         // dependent loads -- chunk descriptors walked one by one -- made this block the long pole of the launch)
@@ -1999,11 +1996,12 @@ __device__ __forceinline__ void gather_merged_block(const TailArgs &a, const uin
                         const uint32_t j = s_rank[wd] + (uint32_t)__popcll(s_bits[wd] & (low - 1ull));   // site index inside the tile
                         if (j < j0 || j >= j0 + nj) continue;
                         const uint32_t q = (wd << 6) + b, o = q - s;
-                        const uint32_t qv = a.qual[2ull * so + o];
+                        const uint64_t qbit = 2ull * so + o;                              // the base's flag in the low-quality column
+                        const bool counted_q = !((a.qual[qbit >> 3] >> (qbit & 7u)) & 1u);
                         const uint32_t code = (a.seq[so + (o >> 1)] >> (4u * (o & 1u))) & 0xfu;
                         const uint32_t gp = t0 + q;
                         const uint32_t rc = (a.ref4[gp >> 3] >> (4u * (gp & 7u))) & 0xfu;
-                        if (qv >= kq && (code == rc || (code != 0u && (code & (code - 1u)) == 0u))) {
+                        if (counted_q && (code == rc || (code != 0u && (code & (code - 1u)) == 0u))) {
                             const uint32_t cell = (j - j0) * m + pidx;
                             atomicAdd(&s_cov[cell >> 1], 1u << (16u * (cell & 1u)));
                             if (code != rc) atomicAdd(&s_al[cell], 1u << (8u * (uint32_t)__builtin_ctz(code)));
@@ -2403,6 +2401,7 @@ static inline uint32_t *stage_ovf_list(const DeviceCols &d) { return d.tile_stag
 static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hipEvent_t ev_begin, hipEvent_t ev_pile0, hipEvent_t ev_pile1,
                         hipEvent_t ev3, hipEvent_t ev4, uint32_t *host_cnt, hipEvent_t wait_before_pileup = nullptr) {
     const uint64_t npos = (uint64_t)d.n_tiles * TILE;
+    if (p.min_baseq != d.qlow_cutoff) return fail(MSNV_EINVAL, "the dataset's quality column was packed for -Q %d, the pass asks for -Q %d", d.qlow_cutoff, p.min_baseq);
     if (ev_begin) HIP_TRY(hipEventRecord(ev_begin, st));
     // nothing to clear: d.tot and the individual-rule bits are zero after finalize and msnv_gate_sites zeroes what a pass has
     // written; the counters live in two blocks that consecutive passes alternate between (the gate kernel zeroes the other one)

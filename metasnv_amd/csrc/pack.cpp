@@ -15,6 +15,9 @@
 #include <unordered_map>
 
 #include "device.h"
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 namespace msnv {
 
@@ -22,6 +25,25 @@ namespace msnv {
 // 16 bases per lane: 16 -> 0.725 ms, 8 -> 0.665, 4 -> 0.664, 2 -> 0.651; round 3, 32 bases per lane: 8 -> 0.573, 4 -> 0.548, 2 -> 0.547).
 // The compact headers store seq offsets in SEQ_ALIGN units.
 constexpr uint32_t seq_align = SEQ_ALIGN;
+
+// The device's quality column (kernels.hip: lowq_fetch): bit i = quality byte i of the host staging is below the cutoff.  The staged
+// bytes are clamped to <= 127 (pack_sample), padding bytes are 0 (flagged; the kernels mask what lies beyond a piece).
+static void pack_lowq(const uint8_t *q, size_t n, int cutoff, std::vector<uint8_t> &out) {
+    out.assign((n + 7) / 8, 0);
+    if (cutoff <= 0) return;
+    size_t i = 0;
+#if defined(__SSE2__)
+    const __m128i c = _mm_set1_epi8((char)std::min(cutoff, 127));
+    const bool all = cutoff > 127;
+    for (; i + 16 <= n; i += 16) {
+        const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i *>(q + i));
+        const uint32_t m = all ? 0xffffu : (uint32_t)_mm_movemask_epi8(_mm_cmpgt_epi8(c, v));      // (signed compare: both sides are <= 127)
+        out[i >> 3] = (uint8_t)m; out[(i >> 3) + 1] = (uint8_t)(m >> 8);
+    }
+#endif
+    for (; i < n; ++i) if ((int)q[i] < cutoff) out[i >> 3] |= (uint8_t)(1u << (i & 7));
+}
+
 
 // Layout of the narrow path: padded per-piece columns (msnv_pileup_tiles_narrow32) or the dense block stream
 // (msnv_pileup_tiles_dense: no alignment padding, every lane owns 32 real bases, but up to two segments per block).
@@ -1221,7 +1243,12 @@ int finalize_dataset(msnv_dataset &ds) {
     if (!dense && HDR4) if (int rc = dev_alloc((void **)&d->hdr4, (rbase[S] + 4) * sizeof(uint32_t), &d->device_bytes)) return rc;
     if (dense) if (int rc = dev_alloc((void **)&d->blk, (bbase[S] + 1) * sizeof(uint32_t), &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->seq, sbase[S] + 256, &d->device_bytes)) return rc;     // lanes past the end of the last piece read on
-    if (int rc = dev_alloc((void **)&d->qual, 2 * sbase[S] + 512, &d->device_bytes)) return rc;
+    // the quality column of the device is ONE BIT per base -- "below the -Q cutoff" -- at the index of the base's nibble in the seq column: the
+    // cutoff is a parameter of the dataset (mpileup -Q, metaSNV.py:160-165 never changes it) and nothing else of a quality is ever looked at
+    // behind the overlap tweak and the token limit, which ran on the host (pass 1 above).  1 B -> 1/8 B per base of HBM and of upload.
+    if (int rc = dev_alloc((void **)&d->qual, sbase[S] / 4 + 64, &d->device_bytes)) return rc;
+    if (int rc = dev_memset(d->qual, 0, sbase[S] / 4 + 64)) return rc;
+    d->qlow_cutoff = ds.params.min_baseq;
     uint64_t alg = 0;
     {
         // the samples' columns go up from a few host threads at a time (a pageable copy is staged by the runtime: several in flight keep
@@ -1232,6 +1259,7 @@ int finalize_dataset(msnv_dataset &ds) {
         std::atomic<size_t> next{0};
         auto worker = [&]() {
             (void)dev_set_device(device);
+            std::vector<uint8_t> qbits;
             for (;;) {
                 const size_t s = next.fetch_add(1);
                 if (s >= S || up_err.load()) break;
@@ -1248,7 +1276,10 @@ int finalize_dataset(msnv_dataset &ds) {
                     rc = dev_upload(d->hdr8 + rbase[s], h8.data(), h8.size() * sizeof(PieceHdr));
                 }
                 if (!rc) rc = dev_upload(d->seq + sbase[s], sc.seq.data(), sc.seq.size());
-                if (!rc) rc = dev_upload(d->qual + 2 * sbase[s], sc.qual.data(), sc.qual.size());
+                if (!rc) {
+                    pack_lowq(sc.qual.data(), sc.qual.size(), ds.params.min_baseq, qbits);
+                    rc = dev_upload(d->qual + sbase[s] / 4, qbits.data(), qbits.size());      // (sbase: multiples of 16 bytes of seq = 32 flags)
+                }
                 if (rc) { std::lock_guard<std::mutex> lk(up_mu); if (!up_err.load()) { up_msg = msnv_last_error(); up_err.store(rc); } continue; }
                 // release host staging of the bulky columns; headers stay (coverage pass, results mapping)
                 std::vector<uint8_t>().swap(sc.seq);
