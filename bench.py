@@ -550,6 +550,7 @@ def main():
     if rank == 0:
         achieved = alg / (k_ms * 1e-3) / 1e9
         traffic, traffic_src = measured_traffic(sp.n_samples, sp.n_species, sp.contig_len, sp.mean_cov) if (world == 1 and a.workload == "testdata") else (None, None)
+        resident = info["bytes_headers"] + info["bytes_seq"] + (info["bytes_qual"] + 7) // 8
         line = {
             "metric": "pileup Gbases/s across all samples",
             "value": total_bases * a.steps / dt_max / 1e9,
@@ -569,7 +570,9 @@ def main():
                          "rank": slowest, "achieved_per_rank": per_rank_gbs,
                          "bytes_per_pileup_base": alg / max(1, bases),
                          "algorithmic_definition": "SURVEY.md 8d: per pileup read 16 B header + 4 B per CIGAR op + 0.5 B/base + 1 B/base quality",
-                         "shipped_bytes_per_launch": info["bytes_headers"] + info["bytes_seq"] + info["bytes_qual"]},
+                         # what the kernel has to read of the RESIDENT format: piece headers, 4-bit bases and ONE BIT per base of quality ("below the
+                         # -Q cutoff", packed on the host at upload; the reference's input carries a byte, which is what `achieved` counts)
+                         "resident_bytes_per_launch": resident, "frac_resident": resident / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms else None},
             "positions_per_s": info["n_positions"] * world * a.steps / dt_max,
             "kernel_ms": {"pileup": k_ms, "pipeline_total": sum(ms_total) / len(ms_total)},
             "host": {"pack_s": t_pack, "finalize_upload_s": t_up, "device_bytes": info["device_bytes"]},

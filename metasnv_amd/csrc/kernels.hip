@@ -15,6 +15,9 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "device.h"
@@ -257,8 +260,9 @@ __global__ __launch_bounds__(W_NT) void msnv_pileup_tiles_wide(PileupArgs a) {
             hreg = *reinterpret_cast<const uint4 *>(a.hdr + a.s_read_base[npr.sample] + nrbeg + tid);
         __syncthreads();                                            // (A) headers visible, bins clean
 
-        const uint8_t *seq = a.seq + a.s_seq_base[sample];
-        const uint64_t qbit0 = 2ull * a.s_seq_base[sample];      // the sample's first flag in the low-quality column
+        // (pr.sample, not the slot: a tile that some samples have no reads in numbers its slots without them)
+        const uint8_t *seq = a.seq + a.s_seq_base[pr.sample];
+        const uint64_t qbit0 = 2ull * a.s_seq_base[pr.sample];   // the sample's first flag in the low-quality column
         for (uint32_t r = (uint32_t)grp; r < nrd; r += W_NT / LANES_PER_READ) {
             const uint4 h = L.hdr[buf][r];
             if (!(h.w & META_PILEUP_OK)) continue;
@@ -2340,17 +2344,79 @@ int dev_set_device(int device) {
     return MSNV_OK;
 }
 
+// MSNV_GUARD_ALLOC=1 (debugging; tests/test_gpu_guard.py): every device buffer is mapped through the virtual-memory API so that it ENDS at
+// the end of its mapping, with unmapped address space reserved behind it -- a read or write past the end of a buffer is then a GPU memory
+// fault wherever the allocator would otherwise have put a neighbour (round 3: a rocprofv3 counter pass moved the neighbours and faulted).
+struct GuardedAlloc { void *va; size_t reserved, mapped; hipMemGenericAllocationHandle_t handle; };
+static std::mutex g_guard_mu;
+static std::unordered_map<void *, GuardedAlloc> g_guarded;
+static bool guard_alloc_enabled() { static const bool on = [] { const char *e = getenv("MSNV_GUARD_ALLOC"); return e && e[0] == '1'; }(); return on; }
+
 int dev_alloc(void **p, uint64_t bytes, uint64_t *acct) {
     *p = nullptr;
     if (bytes == 0) bytes = 16;
-    HIP_TRY(hipMalloc(p, bytes));
+    if (guard_alloc_enabled()) {
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
+        size_t gran = 0;
+        HIP_TRY(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum));
+        if (gran == 0) gran = 2u << 20;
+        GuardedAlloc g{};
+        g.mapped = (size_t)((bytes + gran - 1) / gran * gran);
+        g.reserved = g.mapped + gran;                               // one granule behind the buffer stays unmapped
+        HIP_TRY(hipMemAddressReserve(&g.va, g.reserved, gran, nullptr, 0));
+        HIP_TRY(hipMemCreate(&g.handle, g.mapped, &prop, 0));
+        HIP_TRY(hipMemMap(g.va, g.mapped, 0, g.handle, 0));
+        hipMemAccessDesc ad = {};
+        ad.location = prop.location; ad.flags = hipMemAccessFlagsProtReadWrite;
+        HIP_TRY(hipMemSetAccess(g.va, g.mapped, &ad, 1));
+        const size_t used = (size_t)((bytes + 15) & ~(uint64_t)15);  // (the buffers are read with 16-byte loads: keep that alignment)
+        *p = static_cast<char *>(g.va) + (g.mapped - used);
+        if (const char *e = getenv("MSNV_GUARD_FILL")) { HIP_TRY(hipMemset(g.va, atoi(e), g.mapped)); HIP_TRY(hipStreamSynchronize(nullptr)); }      // (fresh mappings are not defined to be zero: 0 or 255 tells a read of unwritten memory)
+        if (getenv("MSNV_GUARD_LOG")) fprintf(stderr, "[guard] %p .. %p (%llu bytes; mapping %p + %zu)\n", *p, static_cast<char *>(*p) + bytes, (unsigned long long)bytes, g.va, g.mapped);
+        std::lock_guard<std::mutex> lk(g_guard_mu);
+        g_guarded[*p] = g;
+    } else {
+        HIP_TRY(hipMalloc(p, bytes));
+    }
     if (acct) *acct += bytes;
     return MSNV_OK;
 }
-void dev_free(void *p) { if (p) (void)hipFree(p); }
-int dev_upload(void *dst, const void *src, uint64_t bytes) { if (bytes) HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return MSNV_OK; }
+void dev_free(void *p) {
+    if (!p) return;
+    if (guard_alloc_enabled()) {
+        GuardedAlloc g{};
+        {
+            std::lock_guard<std::mutex> lk(g_guard_mu);
+            auto it = g_guarded.find(p);
+            if (it == g_guarded.end()) { (void)hipFree(p); return; }
+            g = it->second; g_guarded.erase(it);
+        }
+        (void)hipDeviceSynchronize();                               // (what hipFree does by itself)
+        // the address range stays reserved: a freed buffer's addresses are unmapped for good, so a stale pointer faults too.  (Handing the
+        // range back -- hipMemAddressFree -- and mapping the next buffer over it gave kernels wrong bytes on this runtime, with every
+        // kernel serialised and no stale pointer anywhere: profiles/r03zq notes in MEASURED.md)
+        (void)hipMemUnmap(g.va, g.mapped); (void)hipMemRelease(g.handle);
+        return;
+    }
+    (void)hipFree(p);
+}
+int dev_upload(void *dst, const void *src, uint64_t bytes) {
+    if (!bytes) return MSNV_OK;
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return MSNV_OK;
+}
 int dev_download(void *dst, const void *src, uint64_t bytes) { if (bytes) HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return MSNV_OK; }
-int dev_memset(void *dst, int v, uint64_t bytes) { if (bytes) HIP_TRY(hipMemset(dst, v, bytes)); return MSNV_OK; }
+// hipMemset of device memory is enqueued on the null stream and returns before it has run, and the passes run on a NON-BLOCKING stream
+// that the null stream does not order: without the wait below the first kernels of a pass can meet buffers that are not zero yet (fresh
+// hipMalloc memory happens to be zero, so nothing showed -- until a profiler's counter pass delayed the fill kernels and the first pass
+// faulted on garbage counters, and the guarded allocator's fresh mappings gave wrong counts; tests/test_gpu_guard.py)
+int dev_memset(void *dst, int v, uint64_t bytes) {
+    if (bytes) { HIP_TRY(hipMemset(dst, v, bytes)); HIP_TRY(hipStreamSynchronize(nullptr)); }
+    return MSNV_OK;
+}
 int dev_stream_create(void **stream) { hipStream_t s; HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); *stream = s; return MSNV_OK; }
 void dev_stream_destroy(void *stream) { if (stream) (void)hipStreamDestroy((hipStream_t)stream); }
 

@@ -109,6 +109,20 @@ def test_cigar_ops_tile_boundary_overflow_and_empty_sample(deep, monkeypatch):
     assert "\t521\t" in prod[1] and "\t521\t" not in prod[0]   # 4 of 500 reads (< 1 %): individual, not population
 
 
+def test_wide_kernel_on_tiles_that_some_samples_have_no_reads_in(monkeypatch):
+    """MSNV_DEEP=wide keeps deep (sample, tile) runs whole for msnv_pileup_tiles_wide.  A tile numbers its slots without the samples
+    that have no reads in it, so a pair's slot is not its sample: the kernel took the sample's columns by the SLOT until round 3 and
+    piled up somebody else's bases whenever a sample was absent (found with the guarded allocator, tests/test_gpu_guard.py)."""
+    monkeypatch.setenv("MSNV_DEEP", "wide")
+    for kw in (dict(n_species=2, contig_len=9000, n_samples=6, mean_cov=400.0, sigma_cov=1.2, seed=73),
+               dict(n_species=3, contig_len=5000, n_samples=9, mean_cov=300.0, sigma_cov=0.8, frac_absent=0.4, snv_density=0.02, seed=74)):
+        syn, samples = synth_case(**kw)
+        prod = run_product(syn.names, syn.lengths, syn.seqs, samples)
+        orac = run_oracle(syn.names, syn.lengths, syn.seqs, samples)
+        _assert_same(prod, orac)
+        assert prod[3]["n_overflow"] > 0                  # the >= 255 path of the wide kernel really ran
+
+
 def test_many_samples_more_than_one_wave_of_columns():
     """300 samples (more than 256 columns: every 64-lane sample loop wraps several times), shallow coverage."""
     syn, samples = synth_case(n_species=1, contig_len=2500, n_samples=300, mean_cov=3.0, snv_density=0.05, frac_absent=0.3, seed=300)
