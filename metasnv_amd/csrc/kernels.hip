@@ -364,10 +364,26 @@ __global__ __launch_bounds__(W_NT) void msnv_pileup_tiles_wide(PileupArgs a) {
 //   * the per-sample prefix sum uses DPP row shifts; allele totals go straight to global memory and
 //     allele events are staged in LDS (one returning global atomic per flush).
 // ------------------------------------------------------------------------------------------
+// bit k of a byte of flags -> byte k of a 64-bit word (the increment of eight byte bins): two 24-bit multiplies.  (Until the quality column
+// was one bit per base this came from a 256-entry LDS table -- the same speed while the kernel waited for HBM, 2.5 % slower since:
+// the atomic had to wait for the table read, five times per lane and round; profiles/r03zs_ab_spread.txt)
+__device__ __forceinline__ unsigned long long spread_bits(const uint32_t byte) {
+    return (unsigned long long)(__umul24(byte >> 4, 0x00204081u) & 0x01010101u) << 32 | (__umul24(byte & 0xfu, 0x00204081u) & 0x01010101u);
+}
+
 constexpr int N_NT = 256;
 constexpr int N_PPT = TILE / N_NT;             // 8 positions per thread in the per-sample pass
 constexpr int N_HCAP = CHUNK_READS;
-constexpr int N_EVCAP = 256;
+// EIGHT workgroups per CU since the low-quality spread table left the LDS: 20 464 bytes (224 staged events instead of 256 made the last
+// 256 bytes) and <= 64 registers (the compiler is told: 8 waves per SIMD; it lands on 63 without scratch).  Seven: 0.405 ms, eight:
+// 0.392 ms on the benchmark shape, 0.512 -> 0.480 ms on the sparse shard (profiles/r03zt_ab_occ8.txt)
+#if !defined(MSNV_N_EVCAP)
+#define MSNV_N_EVCAP 224
+#endif
+#if !defined(MSNV_N32_WAVES)
+#define MSNV_N32_WAVES 8
+#endif
+constexpr int N_EVCAP = MSNV_N_EVCAP;
 
 static_assert(N_PPT == 8, "narrow per-sample pass is written for 8 positions per thread");
 
@@ -375,7 +391,6 @@ struct NarrowLds {
     uint32_t start[TILE / 4 + 4];
     uint32_t end[TILE / 4 + 4];
     unsigned long long exc[TILE / 8 + 4];      // byte bins, updated 8 positions at a time with 64-bit LDS atomics
-    unsigned long long spread[256];            // spread[b]: byte k = bit k of b (flag bits -> byte-bin increments)
     uint32_t al[TILE];
     uint32_t ref[TILE / 8 + 4];
     uint2    hdr[2][N_HCAP];
@@ -585,12 +600,7 @@ __device__ __forceinline__ void narrow_classify32(NarrowLds &L, const uint32_t l
 #pragma unroll
     for (int w = 0; w < 5; ++w) {
         const uint32_t byte = (uint32_t)(m >> (8 * w)) & 0xffu;
-#if defined(MSNV_SPREAD_ALU)
-        // bit k of the byte -> byte k: two 24-bit multiplies instead of a table read the atomic has to wait for
-        if (byte) atomicAdd(&L.exc[wi + w], (unsigned long long)(__umul24(byte >> 4, 0x00204081u) & 0x01010101u) << 32 | (__umul24(byte & 0xfu, 0x00204081u) & 0x01010101u));
-#else
-        if (byte) atomicAdd(&L.exc[wi + w], L.spread[byte]);
-#endif
+        if (byte) atomicAdd(&L.exc[wi + w], spread_bits(byte));
     }
     const uint32_t sw[4] = {sq.x, sq.y, sq.z, sq.w};
     const uint32_t rw[4] = {__builtin_amdgcn_alignbit(w1, w0, sh), __builtin_amdgcn_alignbit(w2, w1, sh),
@@ -732,7 +742,6 @@ __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a, NarrowL
         L.ref[i] = (i < (int)(TILE / 8)) ? a.ref4[(t0 >> 3) + i] : 0xffffffffu;
     for (int i = tid; i < (int)(TILE / 4 + 4); i += N_NT) { L.start[i] = 0; L.end[i] = 0; }
     for (int i = tid; i < (int)(TILE / 8 + 4); i += N_NT) L.exc[i] = 0;
-    L.spread[tid] = ((unsigned long long)((((uint32_t)tid >> 4) * 0x00204081u) & 0x01010101u) << 32) | (((uint32_t)tid & 0xfu) * 0x00204081u & 0x01010101u);
     for (int i = tid; i < (int)TILE; i += N_NT) L.al[i] = 0;
     if (tid == 0) L.evn = 0;
     if (tid < N_NT / 64 + 1) L.carry[tid] = 0;
@@ -872,7 +881,7 @@ __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a, NarrowL
 // events (narrow_pass).  A pair of ~20 pieces costs a chunk iteration and a pass over all 2048 positions whatever it holds
 // (1600 samples at 1x ran at 24 % of the roofline).  One launch for both kinds: a handful of merged items (the partial last
 // tile of every contig) would otherwise run as a launch of its own with the chip idle around it (17.8 us on the benchmark shape).
-__global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32(PileupArgs a) {
+__global__ __launch_bounds__(N_NT, MSNV_N32_WAVES) void msnv_pileup_tiles_narrow32(PileupArgs a) {
     __shared__ NarrowLds L;                                     // ONE instance for both kinds of work item (7 workgroups per CU)
     if (blockIdx.x < a.n_narrow) pileup_tiles_narrow32_body<false>(a, L);
     else if (blockIdx.x < a.n_fused_lo) { a.hdr8 = a.hdr8m; pileup_tiles_narrow32_body<true>(a, L); }
@@ -880,7 +889,7 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32(PileupArgs a)
 }
 // The same launch for noisy reads (pack.cpp: allele planes): the ordinary work items write their pairs' allele counts as byte planes;
 // merged groups and whole-tile items keep their own bookkeeping (a group's few per-sample cells are recomputed from the pieces).
-__global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_narrow32_planes(PileupArgs a) {
+__global__ __launch_bounds__(N_NT, MSNV_N32_WAVES) void msnv_pileup_tiles_narrow32_planes(PileupArgs a) {
     __shared__ NarrowLds L;
     if (blockIdx.x < a.n_narrow) pileup_tiles_narrow32_body<false, false, true>(a, L);
     else if (blockIdx.x < a.n_fused_lo) { a.hdr8 = a.hdr8m; pileup_tiles_narrow32_body<true>(a, L); }
@@ -904,7 +913,6 @@ struct DenseLds {
     uint32_t start[TILE / 4 + 4];
     uint32_t end[TILE / 4 + 4];
     unsigned long long exc[TILE / 8 + D_PAD + 8];
-    unsigned long long spread[256];
     uint32_t al[TILE];
     uint32_t ref[TILE / 8 + D_PAD + 8];
     Pair32   ev[N_EVCAP];
@@ -931,7 +939,7 @@ __device__ __forceinline__ void dense_segment(DenseLds &L, const uint4 sq, const
 #pragma unroll
     for (int w = 0; w < 5; ++w) {
         const uint32_t byte = (uint32_t)(m >> (8 * w)) & 0xffu;
-        if (byte) atomicAdd(&L.exc[wi + w], L.spread[byte]);
+        if (byte) atomicAdd(&L.exc[wi + w], spread_bits(byte));
     }
     const uint32_t w0 = L.ref[wi], w1 = L.ref[wi + 1], w2 = L.ref[wi + 2], w3 = L.ref[wi + 3], w4 = L.ref[wi + 4];
     const uint32_t sw[4] = {sq.x, sq.y, sq.z, sq.w};
@@ -967,7 +975,6 @@ __global__ __launch_bounds__(N_NT) void msnv_pileup_tiles_dense(PileupArgs a) {
         L.exc[i] = 0;
     }
     for (int i = tid; i < (int)(TILE / 4 + 4); i += N_NT) { L.start[i] = 0; L.end[i] = 0; }
-    L.spread[tid] = ((unsigned long long)((((uint32_t)tid >> 4) * 0x00204081u) & 0x01010101u) << 32) | (((uint32_t)tid & 0xfu) * 0x00204081u & 0x01010101u);
     for (int i = tid; i < (int)TILE; i += N_NT) L.al[i] = 0;
     if (tid == 0) L.evn = 0;
     if (tid < N_NT / 64 + 1) L.carry[tid] = 0;
