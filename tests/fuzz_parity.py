@@ -59,8 +59,10 @@ def sweep(n_cases, seed, verbose=True):
                     cov_ok &= open(td + "/v").read() == want[0] and open(td + "/d").read() == want[1]
         else:
             ds.run()
-        if rnd.random() < 0.3:
-            ds.run_many(3, overlap=rnd.random() < 0.5)
+        force = os.environ.get("FUZZ_MANY")                      # "overlap" / "many": every case runs a batch of passes that way (hunting races)
+        r1, r2 = rnd.random(), rnd.random()
+        if force or r1 < 0.3:
+            ds.run_many(3, overlap=(force == "overlap") if force else r2 < 0.5)
         ann = fa = None
         with tempfile.TemporaryDirectory() as td:
             if rnd.random() < 0.3:                               # random gene table (overlaps, both strands) -> device annotation
