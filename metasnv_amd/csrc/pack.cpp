@@ -27,21 +27,23 @@ namespace msnv {
 constexpr uint32_t seq_align = SEQ_ALIGN;
 
 // The device's quality column (kernels.hip: lowq_fetch): bit i = quality byte i of the host staging is below the cutoff.  The staged
-// bytes are clamped to <= 127 (pack_sample), padding bytes are 0 (flagged; the kernels mask what lies beyond a piece).
+// bytes are clamped to <= 127 (pack_sample), padding bytes are 0 (flagged unless the cutoff is 0; the kernels mask what lies beyond a piece).
 static void pack_lowq(const uint8_t *q, size_t n, int cutoff, std::vector<uint8_t> &out) {
     out.assign((n + 7) / 8, 0);
-    if (cutoff <= 0) return;
+    // staged bytes are 0 .. 127, or 0x80 for a base behind snpCall's token limit: as SIGNED bytes that one is below every cutoff,
+    // the cutoff 0 (mpileup -Q 0: no quality is too low) included
+    const int c_eff = std::min(std::max(cutoff, -127), 127);
+    const bool all = cutoff > 127;
     size_t i = 0;
 #if defined(__SSE2__)
-    const __m128i c = _mm_set1_epi8((char)std::min(cutoff, 127));
-    const bool all = cutoff > 127;
+    const __m128i c = _mm_set1_epi8((char)c_eff);
     for (; i + 16 <= n; i += 16) {
         const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i *>(q + i));
-        const uint32_t m = all ? 0xffffu : (uint32_t)_mm_movemask_epi8(_mm_cmpgt_epi8(c, v));      // (signed compare: both sides are <= 127)
+        const uint32_t m = all ? 0xffffu : (uint32_t)_mm_movemask_epi8(_mm_cmpgt_epi8(c, v));
         out[i >> 3] = (uint8_t)m; out[(i >> 3) + 1] = (uint8_t)(m >> 8);
     }
 #endif
-    for (; i < n; ++i) if ((int)q[i] < cutoff) out[i >> 3] |= (uint8_t)(1u << (i & 7));
+    for (; i < n; ++i) if (all || (int)(int8_t)q[i] < c_eff) out[i >> 3] |= (uint8_t)(1u << (i & 7));
 }
 
 
@@ -324,8 +326,22 @@ static uint32_t max_element_chars(const RecView &r) {
     return (uint32_t)std::min<uint64_t>(0x7fffffffu, 4 + 11 + std::max(ins, del));
 }
 
+// The mark of a base whose character is cut off.  (It used to be quality 0 -- "the device leaves it out like a base below the cutoff" --
+// which is not below a cutoff of 0: with -Q 0 the cut bases were counted.  metaSNV never runs -Q 0; the fuzz sweep does.)  Qualities of
+// 128 and more pass every cutoff just like 127 (pack_sample clamps them), so the reads the walk below can touch are clamped first and
+// the mark cannot be mistaken for a stored quality.
+constexpr uint8_t QUAL_CUT = 0xfe;
+
 template <typename MutableQual>
 static void apply_token_limit(const msnv_params &P, const uint8_t *rec, uint64_t n_bytes, const std::vector<KeptRead> &kept, MutableQual &mutable_qual) {
+    for (const KeptRead &kr : kept) {
+        if (!kr.pile_ok) continue;
+        RecView r;
+        rec_parse(rec + kr.off, n_bytes - kr.off, r);
+        if (r.l_seq <= 0) continue;
+        uint8_t *q = mutable_qual(r);
+        for (int32_t j = 0; j < r.l_seq; ++j) if (q[j] > 127) q[j] = 127;
+    }
     struct Act { RecView r; int64_t end; uint32_t maxc; int k; int64_t x, y; };
     std::vector<Act> act;                                   // pileup reads alive at the current position, in push (= file) order
     uint64_t bound = 0;
@@ -386,7 +402,7 @@ static void apply_token_limit(const msnv_params &P, const uint8_t *rec, uint64_t
                 const int qv = (q && qpos < r.l_seq) ? q[qpos] : 0;
                 if (qv < P.min_baseq) continue;             // not printed at all
                 const bool head = pos == r.pos, tail = pos == a.end - 1;
-                if (!is_del && off + (head ? 2u : 0u) >= limit && q) q[qpos] = 0;      // the base's own character is cut off
+                if (!is_del && off + (head ? 2u : 0u) >= limit && q) q[qpos] = QUAL_CUT;      // the base's own character is cut off
                 const uint64_t n_indel = (uint64_t)(indel < 0 ? -indel : indel);
                 off += (head ? 2u : 0u) + 1u + (indel ? 1u + decimal_digits((uint32_t)n_indel) + n_indel : 0u) + (tail ? 1u : 0u);
             }
@@ -422,8 +438,9 @@ struct NameHash {
 // pileup is counted (the overlapping-mate tweak, the token limit), on a private copy of the record stream (`patched`,
 // left empty when nothing was edited).  kept: the reads pass 2 packs, in file order.
 static int filter_and_edit(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, msnv_sample_stats &st,
-                           std::vector<KeptRead> &kept, std::vector<uint8_t> &patched) {
+                           std::vector<KeptRead> &kept, std::vector<uint8_t> &patched, bool *cut_marks = nullptr) {
     const msnv_params &P = ds.params;
+    if (cut_marks) *cut_marks = false;
     const int n_contigs = (int)ds.names.size();
     uint64_t off = 0;
     int32_t last_tid = -1, last_pos = -1;
@@ -517,7 +534,7 @@ static int filter_and_edit(const msnv_dataset &ds, const uint8_t *rec, uint64_t 
         if (!pile_ok && !cov_ok) continue;
         kept.push_back(KeptRead{rec_off, endpos, depth_here, pile_ok, cov_ok});
     }
-    if (token_limit_in_reach) apply_token_limit(P, rec, n_bytes, kept, mutable_qual);
+    if (token_limit_in_reach) { apply_token_limit(P, rec, n_bytes, kept, mutable_qual); if (cut_marks) *cut_marks = true; }
     return MSNV_OK;
 }
 
@@ -526,8 +543,17 @@ int pileup_qualities(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_byte
     msnv_sample_stats st{};
     std::vector<KeptRead> kept;
     std::vector<uint8_t> patched;
-    if (int rc = filter_and_edit(ds, rec, n_bytes, st, kept, patched)) return rc;
+    bool cut_marks = false;
+    if (int rc = filter_and_edit(ds, rec, n_bytes, st, kept, patched, &cut_marks)) return rc;
     if (n_bytes) memcpy(out, patched.empty() ? rec : patched.data(), n_bytes);
+    if (cut_marks) {                              // the documented form of a cut base is quality 0 (msnv.h)
+        for (const KeptRead &kr : kept) {
+            RecView r;
+            rec_parse(rec + kr.off, n_bytes - kr.off, r);
+            uint8_t *q = out + (r.qual - rec);
+            for (int32_t j = 0; j < r.l_seq; ++j) if (q[j] == QUAL_CUT) q[j] = 0;
+        }
+    }
     return MSNV_OK;
 }
 
@@ -537,7 +563,8 @@ int pack_sample(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, Sa
     const int n_contigs = (int)ds.names.size();
     std::vector<KeptRead> kept;
     std::vector<uint8_t> patched;                 // copy of the record stream with edited qualities (empty: nothing was edited)
-    if (int rc = filter_and_edit(ds, rec, n_bytes, sc.st, kept, patched)) return rc;
+    bool cut_marks = false;                       // the stream carries QUAL_CUT marks (snpCall's token limit was in reach)
+    if (int rc = filter_and_edit(ds, rec, n_bytes, sc.st, kept, patched, &cut_marks)) return rc;
     const uint8_t *qual_base = patched.empty() ? rec : patched.data();          // qualities as the pileup sees them
 
     for (const KeptRead &kr : kept) {
@@ -663,7 +690,8 @@ int pack_sample(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, Sa
                         sc.qual.resize(qs + n);
                         uint8_t *qd = sc.qual.data() + qs;
                         const uint8_t *qsrc = r_qual + q0;
-                        for (uint32_t j = 0; j < n; ++j) qd[j] = qsrc[j] > 127 ? 127 : qsrc[j];
+                        // (0x80: a base behind the token limit -- below every cutoff, pack_lowq)
+                        for (uint32_t j = 0; j < n; ++j) qd[j] = (cut_marks && qsrc[j] == QUAL_CUT) ? 0x80 : qsrc[j] > 127 ? 127 : qsrc[j];
                     }
                     // every piece starts on an 8-byte (seq) / 16-byte (qual) boundary
                     while (sc.seq.size() & (seq_align - 1u)) sc.seq.push_back(0xff);

@@ -123,6 +123,24 @@ def test_wide_kernel_on_tiles_that_some_samples_have_no_reads_in(monkeypatch):
         assert prod[3]["n_overflow"] > 0                  # the >= 255 path of the wide kernel really ran
 
 
+@pytest.mark.parametrize("deep", ["split", "wide"])
+def test_token_limit_cuts_bases_whatever_the_quality_cutoff(deep, monkeypatch):
+    """snpCall keeps 10 000 characters of a sample's base string (call_vC.cpp:48,92-111): behind a stack of reads that start at one
+    position (`^]` costs two characters per start) the last bases of a 6 600-deep position are cut.  The host marks them; until round 3
+    the mark was "quality 0", which a cutoff of 0 (mpileup -Q 0) does not drop -- 34 bases too many at one position of this cohort
+    (found by the fuzz sweep, profiles/r03zr_fuzz_deep_wide.txt).  -Q 0 and the default -Q 13, both deep modes."""
+    monkeypatch.setenv("MSNV_DEEP", deep)
+    kw = dict(n_species=3, contig_len=1500, n_samples=2, mean_cov=300, read_len=100, sigma_cov=1.0, frac_absent=0.1, snv_density=0.0, error_rate=0.02,
+              frac_lowq=0.5, frac_indel_reads=0.0, frac_clip_reads=0.3, frac_flagged=0.0, lowercase_ref=1, frac_paired=0.5, seed=710363175)
+    syn, samples = synth_case(**kw)
+    for q in (0, 13):
+        p = core.default_params(min_coverage=10, calling_threshold=4, min_fraction=0.0, min_baseq=q, count_orphans=1, ignore_overlaps=1)
+        prod = run_product(syn.names, syn.lengths, syn.seqs, samples, params=p)
+        orac = run_oracle(syn.names, syn.lengths, syn.seqs, samples, params=p)
+        _assert_same(prod, orac)
+        assert "\t1397\t" in prod[0]
+
+
 def test_many_samples_more_than_one_wave_of_columns():
     """300 samples (more than 256 columns: every 64-lane sample loop wraps several times), shallow coverage."""
     syn, samples = synth_case(n_species=1, contig_len=2500, n_samples=300, mean_cov=3.0, snv_density=0.05, frac_absent=0.3, seed=300)
