@@ -508,10 +508,19 @@ __device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_
     }
     const uint32_t ei = (uint32_t)wave_inclusive_scan((int)myev);   // exclusive prefix of the lanes' event counts = their slots
     uint32_t res = 0;
-    if (lane == 63) {
-        const uint32_t old = atomicAdd(&L.evn, ei);
-        if (old + ei <= (uint32_t)N_EVCAP) res = old;                             // staged: flushed behind a later barrier (A)
-        else { atomicSub(&L.evn, ei); res = 0x80000000u | atomicAdd(a.ev_count, ei); }   // straight into the list
+    if (lane == 63 && ei) {
+        // A wavefront's slots in the staging buffer are reserved with compare-and-swap: they are taken or they are not.  (Add first, take
+        // it back when the buffer is full -- the form until round 3 -- lets a second wavefront reserve ABOVE the first one's transient
+        // count; when that is taken back the fill count lies below the second one's slots: its events are never flushed and the slots
+        // that are flushed in their place still hold events of an earlier flush -- a per-sample count doubled at one site in 1 of ~10 000
+        // fuzz cases once the buffer held 224 events instead of 256; profiles/stress_case.py shows it in seconds.)
+        uint32_t cur = atomicAdd(&L.evn, 0u);
+        for (;;) {
+            if (cur + ei > (uint32_t)N_EVCAP) { res = 0x80000000u | atomicAdd(a.ev_count, ei); break; }   // straight into the list
+            const uint32_t seen = atomicCAS(&L.evn, cur, cur + ei);
+            if (seen == cur) { res = cur; break; }                                 // staged: flushed behind a later barrier (A)
+            cur = seen;
+        }
     }
     res = (uint32_t)__builtin_amdgcn_readlane((int)res, 63);
     const bool direct = (res & 0x80000000u) != 0u;
