@@ -1435,8 +1435,10 @@ int finalize_dataset(msnv_dataset &ds) {
         // events are the pass: 37.7 M of them at 3 % = 1.2 ms of atomics in the pileup kernel + 1.5 ms of scatter (profiles/r03e).  Then
         // the alleles go the way the coverage goes: every (sample, tile) pair writes four byte PLANES (A, C, G, T counts per position,
         // 8 KB a pair, plain 16-byte stores), the gate kernel sums the planes, the gather transposes them into the cells.  Picked when the
-        // sampled mismatch rate reaches 1.5 % (at 1 % of errors the events still win, whole pass 0.80 vs 0.85 ms; at 3 % 3.55 vs 2.08 ms,
-        // at 10 % 8.5 vs 2.1 ms, profiles/r03g_*; a cost model in events per pair put the sigma = 2 cohort -- 0.4 % of mismatches, deep
+        // sampled mismatch rate reaches 1.0 % (with byte qualities the break-even was 1.5 %; the kernel that reads one bit of quality per base
+        // no longer hides the events behind HBM time: at 0.6 % of errors -- 0.85 % sampled with the cohort's SNVs -- events 0.603 vs planes
+        // 0.643 ms a pass, at 1 % -- 1.25 % sampled -- 0.773 vs 0.601 ms, profiles/r03zam_crossover.txt; at 3 % 3.55 vs 2.08 ms, at 10 % 8.5 vs
+        // 2.1 ms, profiles/r03g_*; a cost model in events per pair put the sigma = 2 cohort -- 0.4 % of mismatches, deep
         // pairs -- on planes, where the five-plane gather over its 526 k sites cost more than the events: 4.95 vs 4.08 ms);
         // MSNV_ALLELES=planes | events overrides.
         // Needs byte counts everywhere: not with wide work items (MSNV_DEEP=wide) and not in the dense piece layout's kernel.
@@ -1445,7 +1447,7 @@ int finalize_dataset(msnv_dataset &ds) {
         const double rate = sb ? (double)sm / (double)sb : 0.0;
         const double est_events = rate * (double)tot_bases;
         (void)est_events;
-        bool planes = rate >= 0.015;
+        bool planes = rate >= 0.010;
         if (const char *e = getenv("MSNV_ALLELES")) planes = e[0] == 'p';
         if (dense || d->n_work > d->n_work_narrow + d->n_work_merged || pairs.empty()) planes = false;
         d->allele_planes = planes;
