@@ -573,9 +573,9 @@ def main():
                          # what the kernel has to read of the RESIDENT format: piece headers, 4-bit bases and ONE BIT per base of quality ("below the
                          # -Q cutoff", packed on the host at upload; the reference's input carries a byte, which is what `achieved` counts)
                          "resident_bytes_per_launch": resident, "frac_resident": resident / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms else None,
-                         "limited_by": "not HBM any more on this shape (traffic = about half the SURVEY bytes): the kernel's exception paths -- mismatching bases "
-                                       "(-37 % of its time with them ablated), low-quality bases (-13 %), the per-sample pass (-18 %) -- and LDS (38 % of its LDS cycles "
-                                       "are bank conflicts); profiles/r03z_ab_ablations_qbits.txt, profiles/r03_pmc.json"},
+                         "limited_by": "vector-instruction issue, not HBM (traffic = about half the SURVEY bytes): 213 M wavefront instructions per launch x 4 cycles "
+                                       "on 1024 SIMDs = 0.35 ms at 2.4 GHz; by ablation the mismatch machinery is 37 % of the time, the low-quality adds 13 %, the "
+                                       "per-sample pass 18 % (profiles/r03_pmc.json, profiles/r03z_ab_ablations_qbits.txt, DESIGN.md section 8)"},
             "positions_per_s": info["n_positions"] * world * a.steps / dt_max,
             "kernel_ms": {"pileup": k_ms, "pipeline_total": sum(ms_total) / len(ms_total)},
             "host": {"pack_s": t_pack, "finalize_upload_s": t_up, "device_bytes": info["device_bytes"]},
