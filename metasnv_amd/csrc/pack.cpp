@@ -50,12 +50,12 @@ static void pack_lowq(const uint8_t *q, size_t n, int cutoff, std::vector<uint8_
 // Layout of the narrow path: padded per-piece columns (msnv_pileup_tiles_narrow32) or the dense block stream
 // (msnv_pileup_tiles_dense: no alignment padding, every lane owns 32 real bases, but up to two segments per block).
 // Dense wins for short pieces (50-base reads: -18 % kernel time), loses from ~100 bases on (kernels.hip), so the
-// dataset picks it when the mean piece is shorter than 72 bases.  MSNV_LAYOUT=pieces|dense overrides.
+// dataset picks it when the mean piece is shorter than 62 bases.  MSNV_LAYOUT=pieces|dense overrides.
 static bool layout_dense(uint64_t n_pieces, uint64_t n_bases) {
     const char *e = getenv("MSNV_LAYOUT");
     if (e && e[0] == 'p') return false;
     if (e && e[0] == 'd') return true;
-    return n_pieces && n_bases / n_pieces < 72;
+    return n_pieces && n_bases / n_pieces < 62;      // (round 3, one bit of quality per base, eight workgroups per CU: 50-base reads 0.589 vs 0.535 ms, 75-base reads 0.476 vs 0.535 -- break-even near 62; it was 72: profiles/r03zap_layout_by_read_length.txt)
 }
 
 // A (contig, tile) run of one sample whose depth can reach NARROW_MAX_DEPTH does not fit the byte bins of the narrow
