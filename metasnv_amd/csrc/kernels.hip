@@ -630,23 +630,16 @@ __device__ __forceinline__ void narrow_classify32(NarrowLds &L, const uint32_t l
     while (E) {                                                      // mismatches (rare)
         const uint32_t b = (uint32_t)__builtin_ctz(E);
         E &= E - 1u;
-        const uint32_t k = b & 3u, jn = b >> 2, j = jn + 8u * k;
-#if defined(MSNV_MISM_BRANCHY)
+        const uint32_t k = b & 3u, j = (b >> 2) + 8u * k;
+        // the register PAIR that holds the base (one select of 64 bits), then one 64-bit shift: this loop body is what the kernel issues
+        // most, and the kernel is bound by vector-instruction issue (bit-field inserts over the four words: 7 instructions more per
+        // iteration, +1.8 % kernel time; a chain of ?: became three nested divergent branches: profiles/r03zar_ab_pair64.txt)
+        const unsigned long long pair = (k & 2u) ? ((unsigned long long)sw[3] << 32 | sw[2]) : ((unsigned long long)sw[1] << 32 | sw[0]);
         if ((lq >> j) & 1u) continue;                                  // below the BQ cutoff: already in exc
-        const uint32_t word = (k == 0u) ? sw[0] : (k == 1u) ? sw[1] : (k == 2u) ? sw[2] : sw[3];
-#else
-        // the word that holds the base, picked with bit-field inserts: as a chain of ?: the compiler made it three nested divergent
-        // branches (exec-mask bookkeeping on the scalar unit for a loop body that runs with a handful of lanes)
-        const uint32_t m1 = 0u - (k & 1u), m2 = 0u - (k >> 1);
-        const uint32_t lo = (sw[1] & m1) | (sw[0] & ~m1), hi = (sw[3] & m1) | (sw[2] & ~m1);
-        const uint32_t word = (hi & m2) | (lo & ~m2);
-        if ((lq >> j) & 1u) continue;                                  // below the BQ cutoff: already in exc
-#endif
-        const uint32_t code = (word >> (4u * jn)) & 0xfu;
+        const uint32_t code = (uint32_t)(pair >> (((b & 1u) << 5) | (b & 28u))) & 0xfu;
         const uint32_t p = P0 + j;
         if ((code & (code - 1u)) == 0u) {
-            const uint32_t x = (uint32_t)__builtin_ctz(code);
-            atomicAdd(&L.al[p], 1u << (8u * x));
+            atomicAdd(&L.al[p], __umul24(code, 0x00204081u) & 0x01010101u);      // one-hot code, bit x -> 1 << 8 x
         } else atomicAdd(&L.exc[p >> 3], 1ull << (8u * (p & 7u)));
     }
 }
@@ -961,12 +954,12 @@ __device__ __forceinline__ void dense_segment(DenseLds &L, const uint4 sq, const
     while (E) {                                                      // mismatches (rare)
         const uint32_t b = (uint32_t)__builtin_ctz(E);
         E &= E - 1u;
-        const uint32_t k = b & 3u, jn = b >> 2, j = jn + 8u * k;
+        const uint32_t k = b & 3u, j = (b >> 2) + 8u * k;
+        const unsigned long long pair = (k & 2u) ? ((unsigned long long)sw[3] << 32 | sw[2]) : ((unsigned long long)sw[1] << 32 | sw[0]);   // (as in narrow_classify32)
         if ((lq >> j) & 1u) continue;                                  // below the BQ cutoff: already in exc
-        const uint32_t word = (k == 0u) ? sw[0] : (k == 1u) ? sw[1] : (k == 2u) ? sw[2] : sw[3];
-        const uint32_t code = (word >> (4u * jn)) & 0xfu;
+        const uint32_t code = (uint32_t)(pair >> (((b & 1u) << 5) | (b & 28u))) & 0xfu;
         const uint32_t pp = P + j;                                     // padded position of the base
-        if ((code & (code - 1u)) == 0u) atomicAdd(&L.al[pp - 32u], 1u << (8u * (uint32_t)__builtin_ctz(code)));
+        if ((code & (code - 1u)) == 0u) atomicAdd(&L.al[pp - 32u], __umul24(code, 0x00204081u) & 0x01010101u);
         else atomicAdd(&L.exc[pp >> 3], 1ull << (8u * (pp & 7u)));
     }
 }
