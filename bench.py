@@ -64,7 +64,7 @@ def workload_params(a, rank=0):
     return kw, label
 
 
-TRAFFIC_PROFILES = ["r03_pmc.json", "r02d_pmc.json"]       # newest first; written by profiles/collect.sh + summarize.py
+TRAFFIC_PROFILES = ["r03fin_pmc.json", "r03_pmc.json", "r02d_pmc.json"]       # newest first; written by profiles/collect.sh + summarize.py
 
 
 def measured_traffic(samples, species, contig_len, mean_cov):
