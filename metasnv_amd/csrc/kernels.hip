@@ -141,7 +141,7 @@ __device__ __forceinline__ void tot_add(uint32_t *tot, const uint32_t mode, cons
 // the index and shift arithmetic is scalar
 __device__ __forceinline__ void tot_add_one(uint32_t *tile_tot, const uint32_t mode, const uint32_t p, const uint32_t x, const uint32_t n) {
     const uint32_t shpack = mode == 0u ? 0x18100800u : mode == 1u ? 0x10001000u : 0u;     // shifts of x = 0..3, one byte each
-    // (uniform base + 32-bit byte offset: the address needs no 64-bit register pair -- the kernel sits at the 72-register step)
+    // (uniform base + 32-bit byte offset: the address needs no 64-bit register pair -- the kernel sits at a register step: 64 for eight workgroups per CU)
     const uint32_t byte_off = ((p << mode) + (x >> (2u - mode))) * 4u;
     atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(tile_tot) + byte_off), n << ((shpack >> (8u * x)) & 0xffu));
 }
@@ -154,7 +154,7 @@ __device__ __forceinline__ void tot_add_one(uint32_t *tile_tot, const uint32_t m
 //   the span coverage) and mismatching A/C/G/T bases (allele counts).  16-bit bins.
 //   Then one pass over the tile adds the sample to the running totals (registers), spills the
 //   per-sample coverage byte (>= 255 goes to an overflow list) and emits the sparse allele events.
-// Algorithmic HBM bytes: 16 B per segment piece + 0.5 B/base seq + 1 B/base qual.
+// Algorithmic HBM bytes: 16 B per segment piece + 0.5 B/base seq + 1 B/base qual (resident: one bit of quality per base).
 // ------------------------------------------------------------------------------------------
 constexpr int W_NT = 512;
 constexpr int W_PPT = TILE / W_NT;             // 4
@@ -350,17 +350,17 @@ __global__ __launch_bounds__(W_NT) void msnv_pileup_tiles_wide(PileupArgs a) {
 //   start[p] / end[p]  segment pieces that begin at / end before p  (coverage = running sum)
 //   exc[p]             bases not counted (BQ below cutoff, N, other IUPAC)
 //   al[p]              4 bytes: mismatching A, C, G, T
-// ~24 KB of LDS and 256 threads per workgroup -> 6 resident workgroups per CU.
+// 20.4 KB of LDS, 63 registers and 256 threads per workgroup -> EIGHT resident workgroups per CU (round 3; six in round 1, seven in round 2).
 // The hot loop is written to minimise instructions and vector-memory operations per base:
 //   * every header is one segment piece of <= 128 aligned bases inside one tile (the host resolves
 //     the CIGAR and splits at tile boundaries): one code path, no clipping, no branches on data;
 //   * chunk descriptors are staged in LDS, headers are prefetched one chunk ahead, and all data
 //     loads of a 128-piece chunk are issued before the first one is consumed;
-//   * BQ cutoff: 4 bytes per add + and-not (host clamps qualities to <= 127); match = nibble equality
-//     against the LDS-staged reference (host rewrites '=' codes); BQ flags compressed with
-//     v_dot4_u32_u8; mismatch flags stay in the nibble domain (they are rare);
-//   * low-quality bases reach the byte bins 8 positions at a time: a 256-entry LDS table turns 8 flag
-//     bits into 8 bytes for one 64-bit LDS atomic, skipped when zero;
+//   * BQ cutoff: resolved by the host into ONE BIT per base (pack.cpp: pack_lowq; the cutoff is a parameter of the dataset) -- a
+//     lane's 32 flags are one 8-byte load and a shift; match = nibble equality against the LDS-staged reference (host rewrites
+//     '=' codes); mismatch flags stay in the nibble domain (they are rare);
+//   * low-quality bases reach the byte bins 8 positions at a time: 8 flag bits become 8 bytes (two 24-bit multiplies: spread_bits)
+//     for one 64-bit LDS atomic, skipped when zero;
 //   * the per-sample prefix sum uses DPP row shifts; allele totals go straight to global memory and
 //     allele events are staged in LDS (one returning global atomic per flush).
 // ------------------------------------------------------------------------------------------
@@ -592,8 +592,10 @@ __device__ __forceinline__ void desc_refill(ChunkDesc *ring, const ChunkDesc *sr
 // msnv_pileup_tiles_narrow32: FOUR lanes per piece, 32 bases per lane.
 // Perturbation runs on the earlier 16-bases-per-lane kernel showed the vector-memory (TA/L1) path to be
 // the most sensitive resource (+1 sixteen-byte load per round: +15 % time; +25 % VALU: +4 %).  32 bases
-// per lane need 3 wide loads (2 x 16 B quality, 1 x 16 B bases) where two 16-base lanes need 4, and the
+// per lane needed 3 wide loads (2 x 16 B quality, 1 x 16 B bases) where two 16-base lanes need 4, and the
 // header decode / reference alignment / exception spreading are paid once per 32 bases (-9 % time).
+// Round 3: the quality bytes became one bit per base (one 8-byte load) and the kernel, no longer waiting for memory, is bound by
+// vector-instruction issue (205 M wavefront instructions per launch x 4 cycles on 1024 SIMDs: DESIGN.md section 8).
 // ------------------------------------------------------------------------------------------
 constexpr int N32_LANES = 4;
 constexpr int N32_GROUPS = N_NT / N32_LANES;   // 64 pieces per round
@@ -655,7 +657,7 @@ struct FusedGateArgs { TileStage *st; const uint32_t *ref_lc; uint32_t *counters
 // (two functions, two argument lists of <= 56 bytes: the ABI passes 16 registers of aggregates, a longer list goes through scratch memory -- in every lane of the kernel)
 struct FusedSpillArgs { uint8_t *row; uint32_t *tot, *unc_bits, *item_dirty, *stage_ovf, *counters; uint32_t stage_idx, flags_snvs; };   // part_lo flags | min_snvs << 4; row, item_dirty: the work item's partial row and dirty word
 __device__ __attribute__((noinline)) bool fused_tile_gate(NarrowLds &L, const FusedGateArgs a, const uint32_t t0, const bool any, const int tid) {
-    // (not inlined: the hot loop of the kernel sits exactly at the 72-register step of 7 workgroups per CU)
+    // (not inlined: the hot loop of the kernel sits exactly at the register step of its occupancy -- 64 for eight workgroups per CU)
     TileStage *const st = a.st;
     // (L.evn counts the candidates: merged items stage no events)
     if (any) {
@@ -762,7 +764,7 @@ __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a, NarrowL
     bool dirty = false;                                         // some pass of this item added to the allele totals of my 8 positions
 
     const uint32_t nch = w.chunk_hi - w.chunk_lo;
-    constexpr bool fused = MERGED && FUSED;                       // (a compile-time fact: a run-time flag here costs the kernel its 72-register step)
+    constexpr bool fused = MERGED && FUSED;                       // (a compile-time fact: a run-time flag here costs the kernel its register step)
     // the chunk descriptors go through a ring of MAX_CHUNKS_PER_ITEM LDS slots: one deep (sample, tile) pair alone can
     // hold more chunks than that, so half of the ring is refilled every MAX_CHUNKS_PER_ITEM / 2 chunks (desc_refill)
     // the headers of chunk 0 do not wait for the descriptor stream: their descriptor came with the work item
@@ -884,7 +886,7 @@ __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a, NarrowL
 // (1600 samples at 1x ran at 24 % of the roofline).  One launch for both kinds: a handful of merged items (the partial last
 // tile of every contig) would otherwise run as a launch of its own with the chip idle around it (17.8 us on the benchmark shape).
 __global__ __launch_bounds__(N_NT, MSNV_N32_WAVES) void msnv_pileup_tiles_narrow32(PileupArgs a) {
-    __shared__ NarrowLds L;                                     // ONE instance for both kinds of work item (7 workgroups per CU)
+    __shared__ NarrowLds L;                                     // ONE instance for both kinds of work item (8 workgroups per CU)
     if (blockIdx.x < a.n_narrow) pileup_tiles_narrow32_body<false>(a, L);
     else if (blockIdx.x < a.n_fused_lo) { a.hdr8 = a.hdr8m; pileup_tiles_narrow32_body<true>(a, L); }
     else { a.hdr8 = a.hdr8m; pileup_tiles_narrow32_body<true, true>(a, L); }      // whole-tile items (the last ones; none when the pass runs unfused)
