@@ -250,7 +250,9 @@ int  msnv_dataset_add_sample_bams(msnv_dataset *ds, const char *const *bam_paths
 /* Host-stage seam (tests, A/B against `samtools mpileup` text): writes to `out` (n_bytes) the same record stream with the
  * base qualities as the pileup engine sees them -- after the overlapping-mate tweak (unless params.ignore_overlaps) and
  * with the bases behind params.token_limit characters of a sample's base string set to quality 0 -- under this dataset's
- * read filters, BED and contig mask.  Does not add a sample. */
+ * read filters, BED and contig mask.  Does not add a sample.  (With params.min_baseq = 0 a quality of 0 is not below the
+ * cutoff, so this FORM cannot tell a cut base from a counted one; the dataset itself marks cut bases below every cutoff:
+ * pack.cpp QUAL_CUT.) */
 int  msnv_dataset_pileup_qualities(const msnv_dataset *ds, const uint8_t *records, uint64_t n_bytes, uint8_t *out);
 
 /* Builds the tile index and uploads the packed columns to HBM. */
