@@ -144,7 +144,6 @@ int bgzf_load(const char *path, ByteBuf &comp, size_t &n_in, std::vector<BgzfBlo
     return bgzf_index(ConstBytes{comp.data(), n_in}, path, blocks, total_out);
 }
 bool bgzf_inflate_block_host(const uint8_t *src, uint32_t n_in, uint8_t *dst, uint32_t n_out) { return inflate_block(src, n_in, dst, n_out); }
-uint32_t bgzf_crc32(const uint8_t *data, uint32_t n) { return (uint32_t)crc32(crc32(0L, Z_NULL, 0), data, n); }
 int bgzf_index_bytes(const uint8_t *data, size_t n, const char *path, std::vector<BgzfBlock> &blocks, uint64_t &total_out) {
     blocks.clear();
     return bgzf_index(ConstBytes{data, n}, path, blocks, total_out);
@@ -209,7 +208,7 @@ int bgzf_write_all(const char *path, const uint8_t *data, uint64_t n, int level)
         if (rc != Z_STREAM_END) { fclose(f); return fail(MSNV_EIO, "deflate failed"); }
         uint32_t bsize = 18 + clen + 8;
         uint8_t h[18] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, (uint8_t)((bsize - 1) & 0xff), (uint8_t)((bsize - 1) >> 8)};
-        uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), data + off, m);
+        uint32_t crc = bgzf_crc32(data + off, (uint32_t)m);
         uint8_t t[8] = {(uint8_t)crc, (uint8_t)(crc >> 8), (uint8_t)(crc >> 16), (uint8_t)(crc >> 24), (uint8_t)m, (uint8_t)(m >> 8), (uint8_t)(m >> 16), (uint8_t)(m >> 24)};
         if (fwrite(h, 1, 18, f) != 18 || fwrite(comp.data(), 1, clen, f) != clen || fwrite(t, 1, 8, f) != 8) { fclose(f); return fail(MSNV_EIO, "write failed on %s", path); }
         off += m;
