@@ -218,3 +218,21 @@ def test_token_limit_edit_reproduces_the_truncated_counts():
         ds0 = core.Dataset(None, ["c1"], [L], [ref], core.default_params(token_limit=0))
         assert (ds0.pileup_qualities(s) == s).all()
         ds0.close()
+
+
+def test_token_limit_marks_do_not_depend_on_the_quality_cutoff():
+    """The bases behind the token limit are the same whatever -Q is (with -Q 0 no base is too low to be printed, so MORE characters
+    sit in front of the cut, never fewer marks than the count of characters says), and the seam reports them as quality 0 in
+    either case; stored qualities of 128 and more behave like 127 everywhere (they pass every cutoff) and come back clamped from a
+    sample whose strings reach the limit."""
+    ref, s = _stack(3)
+    L = len(ref)
+    cut = {}
+    for q in (0, 13):
+        ds = core.Dataset(None, ["c1"], [L], [ref], core.default_params(min_baseq=q))
+        edited = ds.pileup_qualities(s)
+        ds.close()
+        changed = edited != s
+        assert changed.sum() > 500 and (edited[changed] == 0).all()
+        cut[q] = int(changed.sum())
+    assert cut[0] >= cut[13]                                    # (at -Q 13 the low-quality bases in front of the cut are not printed)
