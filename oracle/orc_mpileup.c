@@ -346,7 +346,7 @@ void orc_mpileup_default_opts(orc_mpileup_opts *o) {
 }
 
 /* statistics of the last orc_mpileup call (test/bench bookkeeping, not reference behaviour) */
-static uint64_t g_n_lines, g_n_bases;
+static __thread uint64_t g_n_lines, g_n_bases;      /* per calling thread: bench.py times the restatement on every host core */
 uint64_t orc_mpileup_last_lines(void) { return g_n_lines; }
 uint64_t orc_mpileup_last_bases(void) { return g_n_bases; }
 

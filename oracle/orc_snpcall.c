@@ -20,7 +20,7 @@
 static int orc_verbose(void) { static int v = -1; if (v < 0) v = getenv("ORC_VERBOSE") != NULL; return v; }
 #define CHAT(...) do { if (orc_verbose()) fprintf(stderr, __VA_ARGS__); } while (0)
 
-static char g_err[512];
+static __thread char g_err[512];
 const char *orc_last_error(void) { return g_err; }
 void orc_set_error(const char *msg) { snprintf(g_err, sizeof g_err, "%s", msg); }
 
