@@ -243,6 +243,15 @@ int  msnv_dataset_add_sample_records(msnv_dataset *ds, const uint8_t *records, u
 /* n record streams appended as n samples, in order, packed by a pool of host_threads threads (0 = all cores): what the N-rank
  * driver does with the streams of one exchange round (metasnv_amd/parallel.py: feed_sharded). */
 int  msnv_dataset_add_sample_records_many(msnv_dataset *ds, const uint8_t *const *records, const uint64_t *n_bytes, int32_t n, int32_t host_threads);
+/* The same for record streams that already lie in the HBM of the dataset's device -- what an all-to-all over RCCL has just received
+ * (metasnv_amd/parallel.py: exchange_records), what the device inflate has written: the records never visit a host core.  The per-read
+ * stage of both reference tools runs as kernels over them (csrc/devpack.hip): record boundaries, the read loop and CIGAR walk of
+ * qaCompute (qaCompute.cpp:441-593) and, for `samtools mpileup` (metaSNV.py:160-165), its read filters, the CIGAR walk to aligned
+ * segments and the -Q test of every base.  The streams are copied; the caller may release them when the call returns.
+ * Every add_sample_* entry point takes this route when the dataset has a device context (MSNV_PACK=host keeps the stage on the
+ * host threads: pack.cpp, the same bytes).  The three sequential edits -- depth cap, overlapping-mate tweak, snpCall's token
+ * limit -- are a host pre-pass over the samples whose records can trigger them. */
+int  msnv_dataset_add_sample_records_device(msnv_dataset *ds, const void *const *dev_records, const uint64_t *n_bytes, int32_t n);
 int  msnv_dataset_add_sample_bam(msnv_dataset *ds, const char *bam_path);
 /* Decode many BAMs with a host thread pool, preserving order. */
 int  msnv_dataset_add_sample_bams(msnv_dataset *ds, const char *const *bam_paths, int32_t n, int32_t host_threads);
@@ -275,6 +284,10 @@ typedef struct {
 } msnv_dataset_info;
 
 int  msnv_dataset_info_get(const msnv_dataset *ds, msnv_dataset_info *out);
+/* Inspection hook: the bytes of one device column / index table of a finalized dataset ("hdr", "hdr4", "hdr8m", "blk", "seq", "qual",
+ * "s_read_base", "s_seq_base", "ref4", "pairs", "work", "chunks", "cov_iv", "cov_pairs", "cov_work").  out = NULL: size query.  The tests
+ * use it to show that the device pack (csrc/devpack.hip) and the host pack (csrc/pack.cpp) build the same dataset byte for byte. */
+int  msnv_dataset_fetch_column(msnv_dataset *ds, const char *name, uint8_t *out, uint64_t capacity, uint64_t *n_bytes);
 
 typedef struct {
     float    ms_total;           /* all kernels of one pass, HIP events on the launch stream */

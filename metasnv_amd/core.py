@@ -136,6 +136,17 @@ class Dataset:
         check(lib.msnv_dataset_add_sample_records_many(self._h, ptrs, sizes, n, host_threads))
         self.n_samples += n
 
+    def add_samples_records_device(self, ptrs, sizes):
+        """Record streams that lie in HBM of this dataset's device (device addresses + byte counts, e.g. slices of a torch tensor
+        an all-to-all has just filled) as consecutive samples: parsed, filtered and packed by kernels (msnv_dataset_add_sample_records_device)."""
+        n = len(ptrs)
+        if n == 0:
+            return
+        pa = (C.c_void_p * n)(*[int(p) for p in ptrs])
+        sa = (C.c_uint64 * n)(*[int(x) for x in sizes])
+        check(lib.msnv_dataset_add_sample_records_device(self._h, pa, sa, n))
+        self.n_samples += n
+
     def pileup_qualities(self, records):
         """The record stream with the base qualities as the pileup engine sees them (overlap tweak, token limit)."""
         rec = np.ascontiguousarray(records, dtype=np.uint8)
@@ -164,6 +175,15 @@ class Dataset:
         i = DatasetInfo()
         check(lib.msnv_dataset_info_get(self._h, C.byref(i)))
         return {k: getattr(i, k) for k, _ in DatasetInfo._fields_}
+
+    def column(self, name):
+        """Bytes of a device column / index table of the finalized dataset (msnv_dataset_fetch_column) as a uint8 array."""
+        n = C.c_uint64()
+        check(lib.msnv_dataset_fetch_column(self._h, name.encode(), None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=np.uint8)
+        if n.value:
+            check(lib.msnv_dataset_fetch_column(self._h, name.encode(), out.ctypes.data, out.size, C.byref(n)))
+        return out
 
     def run(self):
         st = RunStats()
@@ -411,7 +431,7 @@ def call_from_mpileup(ctx, called_path, indiv_path=None, text=None, mpileup_path
             "text_bytes": int(st[5]), "base_chars": int(st[6])}
 
 
-HOST_TIMERS = ["read_s", "inflate_host_s", "inflate_device_wall_s", "pack_s", "finalize_upload_wall_s", "format_wall_s", "add_bams_wall_s"]
+HOST_TIMERS = ["read_s", "inflate_host_s", "inflate_device_wall_s", "pack_s", "finalize_upload_wall_s", "format_wall_s", "add_bams_wall_s", "pack_device_wall_s"]
 
 
 def host_timers(reset=False):

@@ -9,6 +9,7 @@
 #include <unordered_map>
 
 #include "device.h"
+#include "devpack.h"
 #include "filter.h"
 
 namespace msnv {
@@ -122,6 +123,7 @@ extern "C" int msnv_dataset_attach_ctx(msnv_dataset *ds, msnv_ctx *ctx) {
 
 extern "C" void msnv_dataset_destroy(msnv_dataset *ds) {
     if (!ds) return;
+    if (ds->ctx && (ds->dp.ready || !ds->dp.round_bufs.empty())) { (void)dev_set_device(ds->ctx->device); devpack_release(ds->dp); }
     if (ds->dev) { dev_free_all(*ds->dev); delete ds->dev; }
     delete ds;
 }
@@ -168,10 +170,47 @@ extern "C" int msnv_dataset_set_contig_mask(msnv_dataset *ds, const uint8_t *mas
     return MSNV_OK;
 }
 
+// Where the per-read stage runs (record parse, read filters, CIGAR walk, -Q test, piece cutting): on the device (devpack.hip) whenever the
+// dataset has a device context -- MSNV_PACK=host keeps it on the host threads (pack.cpp), the same bytes either way.  A dataset created
+// without a context (host-stage entry points only) packs on the host.
+static bool pack_on_device(const msnv_dataset *ds) {
+    if (!ds->ctx) return false;
+    const char *e = getenv("MSNV_PACK");                 // (per call: tests switch it)
+    return !(e && e[0] == 'h');
+}
+// Appends n streams as n samples through the device pack, in rounds of at most MSNV_PACK_ROUND_MB (default 6144) of record bytes.
+static int add_streams_device(msnv_dataset *ds, const uint8_t *const *records, const uint64_t *n_bytes, int n, bool streams_on_device) {
+    HostTimerScope ts(HT_PACK_DEVICE_WALL);
+    const uint64_t round_bytes = [] { const char *e = getenv("MSNV_PACK_ROUND_MB"); const long long v = e ? atoll(e) : 6144; return (uint64_t)std::max<long long>(1, v) << 20; }();
+    const size_t first = ds->samples.size();
+    ds->samples.resize(first + (size_t)n);
+    int rc = MSNV_OK;
+    try {
+        for (int i0 = 0; i0 < n && !rc;) {
+            int i1 = i0; uint64_t b = 0;
+            while (i1 < n && i1 - i0 < 2048 && (i1 == i0 || b + n_bytes[i1] <= round_bytes)) { b += n_bytes[i1]; ++i1; }
+            rc = devpack_add_round(*ds, first + (size_t)i0, records + i0, n_bytes + i0, i1 - i0, streams_on_device);
+            i0 = i1;
+        }
+    } catch (const std::exception &e) { rc = fail(MSNV_ENOMEM, "packing on the device failed: %s", e.what()); }
+    if (rc) ds->samples.resize(first);
+    return rc;
+}
+
+extern "C" int msnv_dataset_add_sample_records_device(msnv_dataset *ds, const void *const *dev_records, const uint64_t *n_bytes, int32_t n) {
+    clear_error();
+    if (!ds || n < 0 || (n && (!dev_records || !n_bytes))) return fail(MSNV_EINVAL, "msnv_dataset_add_sample_records_device: bad argument");
+    if (ds->finalized) return fail(MSNV_EINVAL, "dataset is already finalized");
+    if (!ds->ctx) return fail(MSNV_ENODEV, "msnv_dataset_add_sample_records_device: the dataset has no device context");
+    for (int i = 0; i < n; ++i) if (n_bytes[i] && !dev_records[i]) return fail(MSNV_EINVAL, "msnv_dataset_add_sample_records_device: stream %d is NULL", i);
+    return add_streams_device(ds, reinterpret_cast<const uint8_t *const *>(dev_records), n_bytes, n, true);
+}
+
 extern "C" int msnv_dataset_add_sample_records(msnv_dataset *ds, const uint8_t *records, uint64_t n_bytes) {
     clear_error();
     if (!ds || (n_bytes && !records)) return fail(MSNV_EINVAL, "msnv_dataset_add_sample_records: NULL argument");
     if (ds->finalized) return fail(MSNV_EINVAL, "dataset is already finalized");
+    if (pack_on_device(ds)) return add_streams_device(ds, &records, &n_bytes, 1, false);
     ds->samples.emplace_back();
     int rc;
     try { rc = pack_sample(*ds, records, n_bytes, ds->samples.back()); }
@@ -185,6 +224,7 @@ extern "C" int msnv_dataset_add_sample_records_many(msnv_dataset *ds, const uint
     if (!ds || n < 0 || (n && (!records || !n_bytes))) return fail(MSNV_EINVAL, "msnv_dataset_add_sample_records_many: bad argument");
     if (ds->finalized) return fail(MSNV_EINVAL, "dataset is already finalized");
     for (int i = 0; i < n; ++i) if (n_bytes[i] && !records[i]) return fail(MSNV_EINVAL, "msnv_dataset_add_sample_records_many: stream %d is NULL", i);
+    if (pack_on_device(ds)) return add_streams_device(ds, records, n_bytes, n, false);
     int nthreads = host_threads > 0 ? host_threads : (int)std::max(1u, std::thread::hardware_concurrency());
     nthreads = std::min(nthreads, std::max(1, (int)n));
     const size_t first = ds->samples.size();
@@ -232,7 +272,7 @@ extern "C" int msnv_dataset_add_sample_bam(msnv_dataset *ds, const char *bam_pat
     BamHeader h; ByteBuf buf; uint64_t rec_off = 0;
     if (int rc = bam_read(bam_path, h, buf, rec_off, 4)) return rc;
     if (int rc = check_header(*ds, h, bam_path)) return rc;
-    return msnv_dataset_add_sample_records(ds, buf.data() + rec_off, buf.size() - rec_off);
+    return msnv_dataset_add_sample_records(ds, buf.data() + rec_off, buf.size() - rec_off);      // (device pack when the dataset has a context)
 }
 
 namespace msnv {
@@ -343,6 +383,7 @@ static int bgzf_read_files_device(msnv_ctx *ctx, const char *const *paths, int n
             out = host_out.data();
         }
         std::vector<uint32_t> status;
+        bool dev_valid = false;
         if (!host_batch) {
             HostTimerScope ts(HT_INFLATE_DEVICE_WALL);
             if (int rc = dev_inflate(ctx, ib, list, ob, status, &ms)) {
@@ -407,9 +448,10 @@ static int bgzf_read_files_device(msnv_ctx *ctx, const char *const *paths, int n
             }
             n_host += done.load();
             if (bad.load() >= 0) return fail(MSNV_EFORMAT, "%s: BGZF inflate failed (malformed DEFLATE stream or CRC-32 mismatch)", paths[f0 + bad.load()]);
+            dev_valid = !host_batch && done.load() == 0;               // every block of the batch as the device wrote it: ctx->dev_out holds the same bytes as `out`
         }
         n_blocks += list.size();
-        if (int rc = consume(f0, f1, (const uint8_t *)out, ext)) return rc;
+        if (int rc = consume(f0, f1, (const uint8_t *)out, ext, dev_valid)) return rc;
         f0 = f1;
     }
     if (counters) { counters[0] = n_blocks; counters[1] = n_host; counters[2] = (uint64_t)(ms * 1000.0); counters[3] = n_bytes; }
@@ -427,7 +469,7 @@ extern "C" int msnv_bgzf_inflate(msnv_ctx *ctx, const char *path, int32_t on_dev
         if (on_device) {
             if (!ctx) return fail(MSNV_ENODEV, "msnv_bgzf_inflate: the device path needs a context");
             const char *p[1] = {path};
-            auto take = [&](int, int, const uint8_t *data, const std::vector<InflatedExt> &ext) -> int {
+            auto take = [&](int, int, const uint8_t *data, const std::vector<InflatedExt> &ext, bool) -> int {
                 if (!buf.alloc((size_t)ext[0].size)) return fail(MSNV_ENOMEM, "%s: out of memory for %llu inflated bytes", path, (unsigned long long)ext[0].size);
                 memcpy(buf.data(), data + ext[0].off, (size_t)ext[0].size);
                 return MSNV_OK;
@@ -510,7 +552,7 @@ extern "C" int msnv_bam_records_many(msnv_ctx *ctx, const char *const *bam_paths
     int rc = MSNV_OK;
     try {
         if (on_device) {
-            auto consume = [&](int f0, int f1, const uint8_t *out, const std::vector<InflatedExt> &ext) -> int {
+            auto consume = [&](int f0, int f1, const uint8_t *out, const std::vector<InflatedExt> &ext, bool) -> int {
                 run_threads(f0, f1, [&](int i) { return keep(i, out + ext[(size_t)(i - f0)].off, ext[(size_t)(i - f0)].size); });
                 return err.load();
             };
@@ -529,6 +571,68 @@ extern "C" int msnv_bam_records_many(msnv_ctx *ctx, const char *const *bam_paths
     return MSNV_OK;
 }
 
+// BAM files -> samples with the per-read stage on the device: the files are read and inflated group by group (host threads, or the device
+// inflate when the rule of want_device_inflate picks it), the record streams of a group go to HBM and are packed there (devpack.hip).
+static int add_bams_device_pack(msnv_dataset *ds, const char *const *bam_paths, int n, int nthreads) {
+    const bool inflate_on_device = want_device_inflate(ds->ctx, bam_paths, n, nthreads);
+    if (inflate_on_device) {
+        // the inflated bytes of a batch are in the context's device buffer (and, for the CRC check and the header parse, in its pinned
+        // twin): the record streams are handed over where they lie in HBM
+        auto consume = [&](int f0, int f1, const uint8_t *out, const std::vector<InflatedExt> &ext, bool dev_valid) -> int {
+            std::vector<const uint8_t *> ptrs; std::vector<uint64_t> sizes;
+            // (a batch with blocks the host decoder had to redo holds them in the pinned buffer only: it goes up from there)
+            const uint8_t *base = dev_valid ? static_cast<const uint8_t *>(ds->ctx->dev_out) : out;
+            for (int i = f0; i < f1; ++i) {
+                BamHeader h; uint64_t rec_off = 0;
+                const uint8_t *data = out + ext[(size_t)(i - f0)].off; const uint64_t size = ext[(size_t)(i - f0)].size;
+                if (int rc = bam_parse_header_bytes(data, size, bam_paths[i], h, rec_off)) return rc;
+                if (int rc = check_header(*ds, h, bam_paths[i])) return rc;
+                ptrs.push_back(base + ext[(size_t)(i - f0)].off + rec_off);
+                sizes.push_back(size - rec_off);
+            }
+            return add_streams_device(ds, ptrs.data(), sizes.data(), f1 - f0, dev_valid);
+        };
+        int rc;
+        try { uint64_t cnt[4]; rc = bgzf_read_files_device(ds->ctx, bam_paths, n, nthreads, consume, cnt); }
+        catch (const std::exception &e) { rc = fail(MSNV_ENOMEM, "device inflate: %s", e.what()); }
+        return rc;
+    }
+    const size_t first = ds->samples.size();
+    const int group = std::max(nthreads, 16);
+    for (int g0 = 0; g0 < n; g0 += group) {
+        const int g1 = std::min(n, g0 + group);
+        std::vector<ByteBuf> bufs((size_t)(g1 - g0));
+        std::vector<uint64_t> rec_off((size_t)(g1 - g0), 0);
+        std::atomic<int> next{g0}, err{0};
+        std::vector<std::string> msgs((size_t)(g1 - g0));
+        auto worker = [&]() {
+            for (;;) {
+                const int i = next.fetch_add(1);
+                if (i >= g1 || err.load()) break;
+                int rc;
+                try {
+                    BamHeader h;
+                    rc = bam_read(bam_paths[i], h, bufs[(size_t)(i - g0)], rec_off[(size_t)(i - g0)], 1);
+                    if (!rc) rc = check_header(*ds, h, bam_paths[i]);
+                } catch (const std::exception &e) { rc = fail(MSNV_ENOMEM, "%s: %s", bam_paths[i], e.what()); }
+                if (rc) { msgs[(size_t)(i - g0)] = msnv_last_error(); err.store(rc); }
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 0; t < std::min(nthreads, g1 - g0); ++t) th.emplace_back(worker);
+        for (auto &t : th) t.join();
+        int rc = err.load();
+        if (rc) { for (const std::string &m : msgs) if (!m.empty()) { fail(rc, "%s", m.c_str()); break; } }
+        if (!rc) {
+            std::vector<const uint8_t *> ptrs; std::vector<uint64_t> sizes;
+            for (int i = g0; i < g1; ++i) { ptrs.push_back(bufs[(size_t)(i - g0)].data() + rec_off[(size_t)(i - g0)]); sizes.push_back(bufs[(size_t)(i - g0)].size() - rec_off[(size_t)(i - g0)]); }
+            rc = add_streams_device(ds, ptrs.data(), sizes.data(), g1 - g0, false);
+        }
+        if (rc) { ds->samples.resize(first); return rc; }
+    }
+    return MSNV_OK;
+}
+
 extern "C" int msnv_dataset_add_sample_bams(msnv_dataset *ds, const char *const *bam_paths, int32_t n, int32_t host_threads) {
     clear_error();
     HostTimerScope ts_all(HT_ADD_WALL);
@@ -536,6 +640,7 @@ extern "C" int msnv_dataset_add_sample_bams(msnv_dataset *ds, const char *const 
     if (ds->finalized) return fail(MSNV_EINVAL, "dataset is already finalized");
     int nthreads = host_threads > 0 ? host_threads : (int)std::max(1u, std::thread::hardware_concurrency());
     nthreads = std::min(nthreads, std::max(1, (int)n));
+    if (pack_on_device(ds)) return add_bams_device_pack(ds, bam_paths, n, nthreads);
     const size_t first = ds->samples.size();
     ds->samples.resize(first + (size_t)n);
     std::atomic<int> next{0}, err{0};
@@ -548,7 +653,7 @@ extern "C" int msnv_dataset_add_sample_bams(msnv_dataset *ds, const char *const 
         return pack_sample(*ds, data + rec_off, size - rec_off, ds->samples[first + (size_t)i]);
     };
     if (on_device) {
-        auto consume = [&](int f0, int f1, const uint8_t *out, const std::vector<InflatedExt> &ext) -> int {
+        auto consume = [&](int f0, int f1, const uint8_t *out, const std::vector<InflatedExt> &ext, bool) -> int {
             std::atomic<int> nxt{f0};
             auto w = [&]() {
                 for (;;) {
@@ -611,6 +716,31 @@ extern "C" int msnv_dataset_add_synth_samples(msnv_dataset *ds, const msnv_synth
     int nthreads = host_threads > 0 ? host_threads : (int)std::max(1u, std::thread::hardware_concurrency());
     nthreads = std::min(nthreads, std::max(1, (int)count));
     const std::vector<std::string> contigs = synth_contigs(*p);
+    if (pack_on_device(ds)) {
+        // record streams are made by the host threads, group by group, and packed in HBM
+        const size_t base0 = ds->samples.size();
+        const int group = std::max(nthreads, 1);
+        for (int g0 = 0; g0 < count; g0 += group) {
+            const int g1 = std::min<int>(count, g0 + group);
+            std::vector<std::vector<uint8_t>> recs((size_t)(g1 - g0));
+            std::atomic<int> nxt{g0}, bad{0};
+            auto w = [&]() {
+                for (;;) {
+                    const int i = nxt.fetch_add(1);
+                    if (i >= g1) break;
+                    try { synth_sample_records(*p, first + i, contigs, recs[(size_t)(i - g0)]); } catch (const std::exception &) { bad.store(1); }
+                }
+            };
+            std::vector<std::thread> th;
+            for (int t = 0; t < std::min(nthreads, g1 - g0); ++t) th.emplace_back(w);
+            for (auto &t : th) t.join();
+            if (bad.load()) { ds->samples.resize(base0); return fail(MSNV_ENOMEM, "making a synthetic sample failed"); }
+            std::vector<const uint8_t *> ptrs; std::vector<uint64_t> sizes;
+            for (auto &r : recs) { ptrs.push_back(r.data()); sizes.push_back(r.size()); }
+            if (int rc = add_streams_device(ds, ptrs.data(), sizes.data(), g1 - g0, false)) { ds->samples.resize(base0); return rc; }
+        }
+        return MSNV_OK;
+    }
     const size_t base = ds->samples.size();
     ds->samples.resize(base + (size_t)count);
     std::atomic<int> next{0}, err{0};
@@ -644,6 +774,40 @@ extern "C" int msnv_dataset_finalize(msnv_dataset *ds) {
     HostTimerScope ts(HT_UPLOAD_WALL);
     try { return finalize_dataset(*ds); }
     catch (const std::exception &e) { return fail(MSNV_ENOMEM, "building the device dataset failed: %s", e.what()); }
+}
+
+// Inspection hook (tests/test_gpu_devpack.py: the device pack and the host pack build the same dataset): the bytes of one device
+// column or index table of a finalized dataset.
+extern "C" int msnv_dataset_fetch_column(msnv_dataset *ds, const char *name, uint8_t *out, uint64_t capacity, uint64_t *n_bytes) {
+    clear_error();
+    if (!ds || !name || !n_bytes) return fail(MSNV_EINVAL, "msnv_dataset_fetch_column: NULL argument");
+    if (!ds->finalized || !ds->dev) return fail(MSNV_EINVAL, "msnv_dataset_fetch_column: dataset is not finalized");
+    if (int rc = dev_set_device(ds->ctx->device)) return rc;
+    const DeviceCols &d = *ds->dev;
+    const std::string k(name);
+    const void *p = nullptr; uint64_t n = 0;
+    const uint64_t S = d.n_samples, nt = d.n_tiles;
+    if (k == "hdr") { p = d.hdr; n = d.n_reads * sizeof(ReadHdr); }
+    else if (k == "hdr4") { p = d.hdr4; n = d.hdr4 ? d.n_reads * 4 : 0; }
+    else if (k == "hdr8m") { p = d.hdr8m; n = d.n_hdr8m * sizeof(PieceHdr); }
+    else if (k == "blk") { p = d.blk; n = d.blk ? d.n_blk * 4 : 0; }
+    else if (k == "seq") { p = d.seq; n = d.n_seq_bytes; }
+    else if (k == "qual") { p = d.qual; n = d.n_seq_bytes / 4; }
+    else if (k == "s_read_base") { p = d.s_read_base; n = (S + 1) * 8; }
+    else if (k == "s_seq_base") { p = d.s_seq_base; n = (S + 1) * 8; }
+    else if (k == "ref4") { p = d.ref4; n = (nt * TILE / 8 + 1) * 4; }
+    else if (k == "pairs") { p = d.pairs; n = (uint64_t)d.n_pairs * sizeof(TilePair); }
+    else if (k == "work") { p = d.work; n = (uint64_t)d.n_work * sizeof(WorkItem); }
+    else if (k == "chunks") { p = d.chunks; n = d.n_chunks * sizeof(ChunkDesc); }
+    else if (k == "cov_iv") { p = d.cov_iv; n = d.n_cov_iv * sizeof(Pair32); }
+    else if (k == "cov_pairs") { p = d.cov_pairs; n = (uint64_t)d.n_cov_pairs * sizeof(TilePair); }
+    else if (k == "cov_work") { p = d.cov_work; n = (uint64_t)d.n_cov_work * sizeof(WorkItem); }
+    else return fail(MSNV_EINVAL, "msnv_dataset_fetch_column: no column named %s", name);
+    *n_bytes = n;
+    if (!out) return MSNV_OK;                                      // size query
+    if (capacity < n) return fail(MSNV_ECAPACITY, "msnv_dataset_fetch_column: %s holds %llu bytes, capacity %llu", name, (unsigned long long)n, (unsigned long long)capacity);
+    if (n && !p) return fail(MSNV_EINVAL, "msnv_dataset_fetch_column: %s is not allocated in this layout", name);
+    return dev_download(out, p, n);
 }
 
 extern "C" int msnv_dataset_info_get(const msnv_dataset *ds, msnv_dataset_info *out) {

@@ -106,10 +106,27 @@ struct SampleCols {
     int32_t  first_tid = -1, first_beg = 0, first_end = 0;   // first pileup_ok read (first-line quirk)
     std::vector<int32_t> first_any, first_from1;             // per contig (empty = no pileup read): first pileup line without -l / with `name 1 LEN`
     bool     warned_beyond_end = false;   // qaCompute cursor beyond a contig end: reported once per sample
+    // packed on the device (devpack.hip): bases and quality FLAGS (one bit per base, as the kernels read them) live in HBM, seq / qual above stay empty
+    bool     on_device = false;
+    uint8_t *d_seq = nullptr, *d_qual = nullptr;      // into a round buffer of msnv_dataset::dp
+    uint64_t d_seq_bytes = 0;                         // bytes of the seq column incl. the 32 tail bytes (what seq.size() is for a host-packed sample)
     msnv_sample_stats st{};          // qaCompute "Other" statistics (qaCompute.cpp:642-654), counted over every record of the BAM
 };
 
 struct DeviceCols;   // kernels.hip
+
+// Dataset-level tables of the device pack, built when the first sample is packed on the device (BED and contig mask are fixed by then).
+struct DevPackTables {
+    void     *contigs = nullptr;      // DpContig[n_contigs]
+    uint32_t *pref4 = nullptr;        // nt16 codes of the FASTA records of the selected contigs, 8 per word, contig c from nibble pref_off[c]
+    uint64_t  pref_words = 0;
+    std::vector<void *> round_bufs;   // packed seq / quality-bit buffers of the rounds (SampleCols::d_seq / d_qual point into them): freed by finalize
+    bool      ready = false;
+    // cumulative device-pack accounting (msnv_host_timers: pack_device_wall_s; msnv_devpack_stats)
+    double    ms_scan = 0, ms_measure = 0, ms_depth = 0, ms_emit = 0, ms_sort = 0, wall_upload_s = 0, wall_download_s = 0, wall_prepass_s = 0;
+    uint64_t  raw_bytes = 0, n_records = 0, n_pieces = 0, n_prepass_samples = 0;
+};
+
 
 }  // namespace msnv
 struct msnv_dataset;
@@ -158,6 +175,7 @@ struct msnv_dataset {
     int32_t first_tid = -1; int64_t first_pos = -1;
     msnv_dataset_info info{};
     msnv::DeviceCols *dev = nullptr;
+    msnv::DevPackTables dp;
     // results of the last run (host copies)
     bool have_results = false, results_fetched = false;
     uint32_t last_counts_sites = 0;

@@ -63,7 +63,7 @@ struct DeviceCols {
     ChunkDesc *chunks = nullptr;
     uint32_t *tile_vbeg = nullptr, *tile_vend = nullptr;   // callable range inside each tile (BED / contig)
     uint32_t  n_tiles = 0, n_pairs = 0, n_work = 0, n_work_narrow = 0, n_samples = 0;   // work[0..n_work_narrow) = narrow items
-    uint64_t  n_reads = 0, n_seq_bytes = 0;
+    uint64_t  n_reads = 0, n_seq_bytes = 0, n_chunks = 0, n_hdr8m = 0, n_blk = 0;
     // ---- intermediates
     uint32_t *tot = nullptr;         // [4][n_tiles*TILE]: mismatching A, C, G, T summed over samples
     uint32_t *active_tiles = nullptr; // tiles that hold work items (gate / gather run over these only)

@@ -1,0 +1,34 @@
+// metasnv_amd/csrc/devpack.h -- the per-read stage on the device (devpack.hip): raw BAM alignment records resident in HBM ->
+// packed read columns (dataset.h).  What the reference's tools do per read before anything is counted -- samtools' read filters
+// (bam_plcmd.c mplp_func [EXT]), its CIGAR walk, the -Q test of every base, qaCompute's read filter and its
+// walk over the M blocks (qaCompute.cpp:441-593, the walk :530-552) -- as kernels over a record stream that never visits a host core.
+// pack.cpp holds the same stage as host code (MSNV_PACK=host); both produce the same bytes (tests/test_gpu_devpack.py).
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+#include "dataset.h"
+
+namespace msnv {
+
+// One round of samples: streams[i] (n_bytes[i] bytes of alignment records, on the host or -- on_device -- in HBM of the dataset's device)
+// become ds.samples[first + i].  The headers, intervals and per-sample summaries come back to the host (finalize_dataset builds the tile
+// index from them); bases and quality bits stay in HBM.
+int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *streams, const uint64_t *n_bytes, int n, bool on_device);
+// A device-packed sample's bases and quality flags as host staging (SampleCols::seq / qual), for the two re-layouts that still run on
+// the host (pack.cpp: relayout_dense, split_deep_runs' relocation).
+int devpack_sample_to_host(SampleCols &sc);
+void devpack_release(DevPackTables &t);
+// finalize: copies of the rounds' columns into the dataset's, and the alignment padding behind every piece set to the reference
+int devpack_copy_columns(const SampleCols &sc, uint8_t *dst_seq, uint8_t *dst_qual_bits, void *stream);
+int devpack_fill_padding(DeviceCols &d, const std::vector<uint8_t> &sample_on_device, void *stream);
+// waits for the copies, releases the round buffers and the tables (no sample can be added after finalize)
+int devpack_finish(msnv_dataset &ds);
+
+// pack.cpp: the three sequential edits of the host stage (depth cap, overlapping-mate tweak, snpCall's token limit) for ONE sample whose
+// records need them (devpack.hip decides that): per record 1 | pile_ok << 1 | cov_ok << 2 | depth << 16, the stream with the edited
+// qualities (empty: nothing was edited), and whether it carries QUAL_CUT marks.
+int host_prepass(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, std::vector<uint32_t> &ovr, std::vector<uint8_t> &patched, bool &cut_marks);
+
+}  // namespace msnv

@@ -1,0 +1,1125 @@
+// metasnv_amd/csrc/devpack.hip -- the per-read stage as device kernels: raw BAM alignment records in HBM -> packed read columns.
+//
+// What it replaces: the read loop of the reference's tools, per record -- flag / MAPQ / duplicate filter and the walk over the CIGAR's M
+// blocks of qaCompute (/root/reference/src/qaTools/qaCompute.cpp:441-593, the walk :530-552), and what `samtools mpileup` (call site
+// /root/reference/metaSNV.py:160-165; bam_plcmd.c mplp_func, sam.c resolve_cigar2 [EXT], restated in SURVEY.md Appendix C) does with a
+// record before its pileup is counted: --ff 0x704, -l overlap, start beyond the reference, -q, orphans, the CIGAR walk to aligned
+// (M/=/X) segments, '=' -> reference base, and the -Q test of every base.  pack.cpp is the same stage on host threads (MSNV_PACK=host);
+// the two produce the same columns byte for byte (tests/test_gpu_devpack.py).
+//
+// Stages of one round of samples (all on the context's stream):
+//   msnv_scan_records     the block_size chain of every stream (one wavefront per stream walks it through LDS windows) -> record offsets
+//   msnv_measure_reads    one thread per record: header, CIGAR geometry, the read filters of both tools, qaCompute's statistics, the
+//                         number of pieces / seq bytes / M intervals the record will emit
+//   (depth)               pileup reads alive at every read start (mpileup -d, and the depth bound of the tile index): sort of
+//                         (contig run, end) keys + a search per read; upper bound of the sample's base-string length (snpCall's token limit)
+//   msnv_emit_headers     one thread per kept record: piece headers {position, seq offset, length}, qaCompute's {+1, -1} intervals
+//   msnv_emit_pieces      16 lanes per piece, 8 bases per lane: nibble swap (BAM stores base 2i in the HIGH nibble), '=' -> reference code,
+//                         "quality below the -Q cutoff" flag per base, mismatch sampling of every 16th piece
+//   (tile order)          stable sort of the headers by (sample, contig, tile): the pieces a read leaves in the NEXT tile move behind
+// The three SEQUENTIAL edits of the host stage -- depth cap, overlapping-mate quality tweak, snpCall's token limit -- stay a host
+// pre-pass (pack.cpp: host_prepass) that runs only for the samples whose records can trigger one of them (decided here, on the device:
+// some read starts above the cap; two or more reads pass htslib's overlap_push precondition; the upper bound of a base string reaches
+// the limit); it hands back the verdict per record and the edited qualities, and the kernels take it from there.
+#include <algorithm>
+#include <chrono>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include "device.h"
+#include "devpack.h"
+
+namespace msnv {
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(MSNV_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+namespace {
+
+struct DpContig { long long len, seq_len, bed_beg, bed_end; unsigned long long pref_off; uint32_t sel, pad; };   // seq_len < 0: no FASTA record
+struct DpParams {
+    int flag_filter, min_mapq, count_orphans, cov_min_mapq, max_depth, token_limit, ignore_overlaps;
+    int c_eff, all_low;            // the -Q cutoff as pack.cpp: pack_lowq applies it: flagged = all_low || quality < c_eff
+    int n_contigs, has_bed;
+};
+// per sample of the round
+struct DpAcc {
+    unsigned long long err;         // min over records of (flat record index << 3 | kind), ~0 = none
+    unsigned long long first_pile;  // min flat index of a read that enters the pileup
+    unsigned long long beyond;      // min flat index of a read whose qaCompute cursor reaches the contig end
+    unsigned long long n_bases, alg8d, alg_cigar, alg_seq, alg_qual, mm_bases, mm;
+    uint32_t total, unmapped, zeroq, proper, dup, any_mapped;
+    uint32_t n_pile_reads, n_ovl, need_host, pad;
+};
+enum : uint32_t { ERR_MALFORMED = 1, ERR_TID = 2, ERR_UNSORTED = 3, ERR_QLEN = 4 };
+enum : uint8_t { RF_PILE = 1, RF_COV = 2, RF_MAPPED = 4 };
+enum : uint32_t { NEED_CAP = 1, NEED_TOKEN = 2 };
+
+__device__ __forceinline__ uint32_t ld16(const uint8_t *p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }
+__device__ __forceinline__ uint32_t ld32(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+__device__ __forceinline__ uint64_t ld64(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+
+// fixed part of an alignment record (SAM spec 4.2): block_size refID pos l_read_name mapq bin n_cigar_op flag l_seq next_refID next_pos tlen
+struct Rec {
+    int32_t tid, pos, l_seq, mtid, mpos, tlen;
+    uint32_t bs, l_name, n_cigar, flag, mapq;
+    const uint8_t *cigar, *seq, *qual;
+    bool ok;
+};
+__device__ __forceinline__ Rec rec_load(const uint8_t *p, uint64_t avail) {
+    Rec r;
+    const uint64_t a = ld64(p), b = ld64(p + 8), c = ld64(p + 16), d = ld64(p + 24);
+    r.bs = (uint32_t)a; r.tid = (int32_t)(a >> 32); r.pos = (int32_t)(uint32_t)b;
+    const uint32_t w = (uint32_t)(b >> 32);
+    r.l_name = w & 0xffu; r.mapq = (w >> 8) & 0xffu;
+    const uint32_t fn = (uint32_t)c;
+    r.n_cigar = fn & 0xffffu; r.flag = fn >> 16; r.l_seq = (int32_t)(c >> 32);
+    r.mtid = (int32_t)(uint32_t)d; r.mpos = (int32_t)(d >> 32); r.tlen = (int32_t)ld32(p + 32);
+    r.cigar = p + 36 + r.l_name;
+    r.seq = r.cigar + 4ull * r.n_cigar;
+    r.qual = r.seq + ((uint64_t)(uint32_t)r.l_seq + 1) / 2;
+    const uint64_t need = 36ull + r.l_name + 4ull * r.n_cigar + ((uint64_t)(uint32_t)r.l_seq + 1) / 2 + (uint64_t)(uint32_t)r.l_seq;
+    r.ok = avail >= 36 && (int32_t)r.bs >= 32 && (uint64_t)r.bs + 4 <= avail && r.l_seq >= 0 && need <= (uint64_t)r.bs + 4;      // hostio.cpp: rec_parse
+    return r;
+}
+__device__ __forceinline__ bool rec_mapped(uint32_t flag, int32_t tid) { return !(flag & 4u) && tid >= 0; }
+
+__device__ __forceinline__ bool cg_ref(uint32_t t) { return t == C_M || t == C_D || t == C_N || t == C_EQ || t == C_X; }
+__device__ __forceinline__ bool cg_query(uint32_t t) { return t == C_M || t == C_I || t == C_S || t == C_EQ || t == C_X; }
+__device__ __forceinline__ bool cg_match(uint32_t t) { return t == C_M || t == C_EQ || t == C_X; }
+// seq bytes of a piece of n bases with its alignment padding (pack.cpp: pack_sample)
+__device__ __host__ __forceinline__ uint32_t stored_bytes(uint32_t n) { return ((n + 1u) / 2u + SEQ_ALIGN - 1u) & ~(SEQ_ALIGN - 1u); }
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    return v;                                                   // lane 0
+}
+__device__ __forceinline__ unsigned long long wave_min(unsigned long long v) {
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long w = __shfl_down(v, o); v = w < v ? w : v; }
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------ record boundaries
+// The records of a BAM are a chain: the next one starts block_size + 4 bytes behind this one (qaCompute.cpp:441 reads them with sam_read1
+// one at a time).  One wavefront per stream stages 16 KB windows of it in LDS (one coalesced sweep) and walks the chain there: ~50 ns a
+// record instead of a dependent HBM access each.  Streams run in parallel.
+constexpr uint32_t SCAN_WIN = 16384;
+__global__ __launch_bounds__(64) void msnv_scan_records(const uint8_t *raw, const unsigned long long *s_beg, const unsigned long long *s_len, const unsigned long long *cap_base,
+                                                        unsigned long long *tmp_off, uint32_t *n_rec, unsigned long long *bad_off) {
+    __shared__ uint4 win[SCAN_WIN / 16 + 1];
+    const uint32_t s = blockIdx.x, lane = threadIdx.x;
+    const uint8_t *base = raw + s_beg[s];                        // 16-byte aligned, 64 readable bytes behind the stream (round buffer)
+    const unsigned long long n = s_len[s];
+    unsigned long long off = 0, wlo = 0, whi = 0, bad = ~0ull;
+    unsigned long long *out = tmp_off + cap_base[s];
+    uint32_t cnt = 0;
+    const uint32_t *w32 = reinterpret_cast<const uint32_t *>(win);
+    while (off < n) {
+        if (n - off < 36) { bad = off; break; }
+        if (off + 4 > whi) {
+            wlo = off & ~15ull;
+            const unsigned long long left = (n - wlo + 15) & ~15ull;
+            const uint32_t want = (uint32_t)(left < SCAN_WIN ? left : SCAN_WIN);
+            __syncthreads();
+            for (uint32_t k = lane; k < want / 16; k += 64) win[k] = *reinterpret_cast<const uint4 *>(base + wlo + 16ull * k);
+            __syncthreads();
+            whi = wlo + want;
+        }
+        const uint32_t o = (uint32_t)(off - wlo);
+        const uint32_t lo = w32[o >> 2], hi = w32[(o >> 2) + 1];
+        const uint32_t bs = __builtin_amdgcn_alignbyte(hi, lo, o & 3u);
+        if ((int32_t)bs < 32 || (unsigned long long)bs + 4 > n - off) { bad = off; break; }
+        if (lane == 0) out[cnt] = off;
+        ++cnt;
+        off += 4ull + bs;
+    }
+    if (lane == 0) { n_rec[s] = cnt; bad_off[s] = bad; }
+}
+
+__global__ void msnv_compact_offsets(const unsigned long long *tmp_off, const unsigned long long *cap_base, const uint32_t *rec_base, const unsigned long long *s_beg,
+                                     unsigned long long *rec_off, uint16_t *rec_sample) {
+    const uint32_t s = blockIdx.y;
+    const uint32_t n = rec_base[s + 1] - rec_base[s];
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        rec_off[rec_base[s] + k] = s_beg[s] + tmp_off[cap_base[s] + k];
+        rec_sample[rec_base[s] + k] = (uint16_t)s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ per-record measure
+// Everything of pack.cpp: filter_and_edit + pack_sample that one record decides by itself.
+__global__ __launch_bounds__(256) void msnv_measure_reads(const uint8_t *raw, const unsigned long long *rec_off, const uint16_t *rec_sample, const uint32_t *rec_base,
+                                                          const unsigned long long *s_end, uint32_t n_rec, const DpContig *ctg, DpParams P, const uint32_t *ovr,
+                                                          uint8_t *r_flags, unsigned long long *r_key, uint32_t *r_end, uint32_t *r_maxc, uint32_t *r_pile,
+                                                          uint32_t *r_npiece, uint32_t *r_seqb, uint32_t *r_niv, DpAcc *acc) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i < n_rec;
+    const uint32_t s = valid ? rec_sample[i] : 0xffffffffu;
+    uint32_t st_total = 0, st_unmapped = 0, st_zeroq = 0, st_proper = 0, st_dup = 0, st_any = 0, n_pile = 0, n_ovl = 0;
+    unsigned long long m_pile = 0, alg8d = 0, alg_cigar = 0, alg_seq = 0, alg_qual = 0;
+    unsigned long long err = ~0ull, first_pile = ~0ull, beyond_at = ~0ull;
+    uint8_t flags = 0; unsigned long long key = 0; uint32_t o_end = 0, o_maxc = 0, o_np = 0, o_sb = 0, o_niv = 0;
+    if (valid) {
+        const uint8_t *p = raw + rec_off[i];
+        const Rec r = rec_load(p, s_end[s] - rec_off[i]);
+        st_total = 1;
+        if (!r.ok) err = (unsigned long long)i << 3 | ERR_MALFORMED;
+        else if (!rec_mapped(r.flag, r.tid)) st_unmapped = 1;                               // qaCompute.cpp:461-473
+        else {
+            st_any = 1;
+            bool cov_ok = false;
+            if ((int)r.mapq >= P.cov_min_mapq) {                                            // qaCompute.cpp:518-526
+                if (r.flag & 2u) st_proper = 1;
+                if (r.flag & 0x400u) st_dup = 1; else cov_ok = true;
+            } else st_zeroq = 1;
+            flags = RF_MAPPED;
+            key = (unsigned long long)(uint32_t)r.tid << 32 | (uint32_t)r.pos;
+            if (r.tid >= P.n_contigs) err = (unsigned long long)i << 3 | ERR_TID;
+            else {
+                // coordinate order: against the mapped record before this one (unmapped ones -- placed mates -- are stepped over)
+                for (uint32_t j = i; j > rec_base[s];) {
+                    --j;
+                    const uint8_t *q = raw + rec_off[j];
+                    const uint64_t a = ld64(q), c = ld64(q + 16);
+                    const int32_t tj = (int32_t)(a >> 32);
+                    if (!rec_mapped((uint32_t)c >> 16, tj)) continue;
+                    const int32_t pj = (int32_t)ld32(q + 8);
+                    if (r.tid < tj || (r.tid == tj && r.pos < pj)) err = (unsigned long long)i << 3 | ERR_UNSORTED;
+                    break;
+                }
+                const DpContig c = ctg[r.tid];
+                if (c.sel) {
+                    // ---- CIGAR geometry, pieces, qaCompute's intervals: one walk
+                    long long rlen = 0, qlen = 0, m_bases = 0, ins = 0, del = 0, rp = r.pos, pp = (long long)r.pos + 1;
+                    bool has_ref_op = false, beyond = false;
+                    uint32_t n_piece = 0, seqb = 0, n_iv = 0;
+                    unsigned long long a_seq = 0;
+                    uint32_t k0 = 0;
+                    if (r.n_cigar > 0) { const uint32_t t = ld32(r.cigar) & 15u; if (t == C_S || t == C_H) k0 = 1; }
+                    for (uint32_t k = 0; k < r.n_cigar; ++k) {
+                        const uint32_t cg = ld32(r.cigar + 4ull * k), t = cg & 15u, l = cg >> 4;
+                        if (cg_ref(t)) { rlen += l; has_ref_op = true; }
+                        if (cg_query(t)) qlen += l;
+                        if (t == C_I) ins += l; else if (t == C_D) del = del > (long long)l ? del : (long long)l;
+                        if (k >= k0) {                                                       // qaCompute.cpp:537-552
+                            if (t == C_M) { if (pp >= c.len) { beyond = true; n_iv += c.len >= 1; } else ++n_iv; }
+                            pp += l;
+                        }
+                        if (cg_match(t)) {
+                            m_bases += l;
+                            for (uint32_t off = 0, n = 0; off < l; off += n) {               // pieces never cross a tile (pack.cpp: pack_sample)
+                                const uint32_t to_tile = TILE - (uint32_t)((rp + off) % TILE);
+                                n = SEG_MAX < l - off ? SEG_MAX : l - off;
+                                n = n < to_tile ? n : to_tile;
+                                ++n_piece; seqb += stored_bytes(n); a_seq += (n + 1u) / 2u;
+                            }
+                            rp += l;
+                        } else if (cg_ref(t)) rp += l;
+                    }
+                    const long long endpos = (long long)r.pos + (rlen ? rlen : 1);           // bam_endpos
+                    // ---- mpileup's read-level filters, in mplp_func's order
+                    bool pile_ok = !(r.flag & (uint32_t)P.flag_filter);
+                    if (pile_ok && P.has_bed) pile_ok = c.bed_beg < endpos && (long long)r.pos < c.bed_end;
+                    if (pile_ok && c.seq_len >= 0 && c.seq_len <= (long long)r.pos) pile_ok = false;
+                    if (pile_ok && (int)r.mapq < P.min_mapq) pile_ok = false;
+                    if (pile_ok && !P.count_orphans && (r.flag & 1u) && !(r.flag & 2u)) pile_ok = false;
+                    if (pile_ok && !has_ref_op) pile_ok = false;
+                    if (pile_ok && r.l_seq > 0 && qlen != (long long)r.l_seq) err = (unsigned long long)i << 3 | ERR_QLEN;
+                    const uint32_t ov = ovr ? ovr[i] : 0u;
+                    if (ov & 1u) pile_ok = (ov >> 1) & 1u;                                   // the host pre-pass has decided (depth cap)
+                    const long long absl = r.tlen < 0 ? -(long long)r.tlen : (long long)r.tlen;
+                    if (pile_ok && !P.ignore_overlaps && !(r.flag & 8u) && (r.flag & 2u) &&   // sam.c overlap_push's precondition
+                        !((r.mtid >= 0 && r.tid != r.mtid) || (absl >= 2ll * r.l_seq && (long long)r.mpos >= endpos))) n_ovl = 1;
+                    const unsigned long long mc = 4ull + 11ull + (unsigned long long)(ins > del ? ins : del);      // pack.cpp: max_element_chars
+                    o_maxc = (uint32_t)(mc < 0x7fffffffull ? mc : 0x7fffffffull);
+                    o_end = (uint32_t)(endpos < 0xffffffffll ? endpos : 0xffffffffll);
+                    if (cov_ok) { flags |= RF_COV; o_niv = n_iv; if (beyond) beyond_at = i; }
+                    if (pile_ok) {
+                        flags |= RF_PILE;
+                        n_pile = 1; first_pile = i;
+                        m_pile = (unsigned long long)m_bases;
+                        alg8d = 16ull + 4ull * r.n_cigar + ((unsigned long long)m_bases + 1) / 2 + (unsigned long long)m_bases;
+                        alg_cigar = 4ull * r.n_cigar;
+                        if (r.l_seq > 0) { o_np = n_piece; o_sb = seqb; alg_seq = a_seq; alg_qual = (unsigned long long)m_bases; }
+                    }
+                }
+            }
+        }
+        r_flags[i] = flags; r_key[i] = key; r_end[i] = o_end; r_maxc[i] = o_maxc; r_pile[i] = (flags & RF_PILE) ? 1u : 0u;
+        r_npiece[i] = o_np; r_seqb[i] = o_sb; r_niv[i] = o_niv;
+    }
+    // ---- per-sample sums: a wavefront's records almost always belong to one sample -> one atomic per counter and wavefront
+    const uint32_t s0 = __shfl(s, 0);
+    const bool uniform = __all(s == s0 || !valid) && s0 != 0xffffffffu;
+    if (uniform) {
+        const uint32_t t0 = wave_sum(st_total), t1 = wave_sum(st_unmapped), t2 = wave_sum(st_zeroq), t3 = wave_sum(st_proper), t4 = wave_sum(st_dup), t5 = wave_sum(st_any),
+                       t6 = wave_sum(n_pile), t7 = wave_sum(n_ovl);
+        const unsigned long long u0 = wave_sum(m_pile), u1 = wave_sum(alg8d), u2 = wave_sum(alg_cigar), u3 = wave_sum(alg_seq), u4 = wave_sum(alg_qual);
+        const unsigned long long e0 = wave_min(err), e1 = wave_min(first_pile), e2 = wave_min(beyond_at);
+        if ((threadIdx.x & 63u) == 0) {
+            DpAcc &a = acc[s0];
+            if (t0) atomicAdd(&a.total, t0);
+            if (t1) atomicAdd(&a.unmapped, t1);
+            if (t2) atomicAdd(&a.zeroq, t2);
+            if (t3) atomicAdd(&a.proper, t3);
+            if (t4) atomicAdd(&a.dup, t4);
+            if (t5) atomicOr(&a.any_mapped, 1u);
+            if (t6) atomicAdd(&a.n_pile_reads, t6);
+            if (t7) atomicAdd(&a.n_ovl, t7);
+            if (u0) atomicAdd(&a.n_bases, u0);
+            if (u1) atomicAdd(&a.alg8d, u1);
+            if (u2) atomicAdd(&a.alg_cigar, u2);
+            if (u3) atomicAdd(&a.alg_seq, u3);
+            if (u4) atomicAdd(&a.alg_qual, u4);
+            if (e0 != ~0ull) atomicMin(&a.err, e0);
+            if (e1 != ~0ull) atomicMin(&a.first_pile, e1);
+            if (e2 != ~0ull) atomicMin(&a.beyond, e2);
+        }
+    } else if (valid) {
+        DpAcc &a = acc[s];
+        atomicAdd(&a.total, st_total);
+        if (st_unmapped) atomicAdd(&a.unmapped, 1u);
+        if (st_zeroq) atomicAdd(&a.zeroq, 1u);
+        if (st_proper) atomicAdd(&a.proper, 1u);
+        if (st_dup) atomicAdd(&a.dup, 1u);
+        if (st_any) atomicOr(&a.any_mapped, 1u);
+        if (n_pile) atomicAdd(&a.n_pile_reads, 1u);
+        if (n_ovl) atomicAdd(&a.n_ovl, 1u);
+        if (m_pile) atomicAdd(&a.n_bases, m_pile);
+        if (alg8d) atomicAdd(&a.alg8d, alg8d);
+        if (alg_cigar) atomicAdd(&a.alg_cigar, alg_cigar);
+        if (alg_seq) atomicAdd(&a.alg_seq, alg_seq);
+        if (alg_qual) atomicAdd(&a.alg_qual, alg_qual);
+        if (err != ~0ull) atomicMin(&a.err, err);
+        if (first_pile != ~0ull) atomicMin(&a.first_pile, first_pile);
+        if (beyond_at != ~0ull) atomicMin(&a.beyond, beyond_at);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ depth at every read start
+// pack.cpp keeps the pileup reads of a sample in a heap by reference end (sam.c bam_plp_push [EXT], sample-local): when a read starts,
+// the ones that ended at or before its start are popped, then it is pushed -- depth = reads alive, itself included; the sum of their
+// longest possible pileup elements bounds the sample's base string there (snpCall's token limit).  Here: reads alive at the start of
+// read r of a (sample, contig) run = reads of the run before r, r itself, minus the reads of the run that end at or before r's start
+// -- all of which started before it (end > start) -- counted by a search in the run's sorted ends.
+__global__ void msnv_pile_list(const uint32_t *r_pile, const uint32_t *rank, uint32_t n_rec, uint32_t *pl) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_rec && r_pile[i]) pl[rank[i]] = i;
+}
+__global__ void msnv_run_flags(const uint32_t *pl, uint32_t n_pile, const uint16_t *rec_sample, const unsigned long long *r_key, uint32_t *rf) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_pile) return;
+    const uint32_t i = pl[r];
+    bool first = r == 0;
+    if (!first) { const uint32_t j = pl[r - 1]; first = rec_sample[i] != rec_sample[j] || (r_key[i] >> 32) != (r_key[j] >> 32); }
+    rf[r] = first ? 1u : 0u;
+}
+__global__ void msnv_depth_keys(const uint32_t *pl, uint32_t n_pile, const uint32_t *rf, const uint32_t *run_incl, const uint32_t *r_end, const uint32_t *r_maxc,
+                                unsigned long long *keys, uint32_t *vals, uint32_t *maxc_rank, uint32_t *run_first, uint32_t *run_f1) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_pile) { if (r == n_pile) maxc_rank[r] = 0; return; }
+    const uint32_t i = pl[r], g = run_incl[r] - 1u;
+    keys[r] = (unsigned long long)g << 32 | r_end[i];
+    vals[r] = r_maxc[i]; maxc_rank[r] = r_maxc[i];
+    if (rf[r]) { run_first[g] = r; run_f1[g] = 0xffffffffu; }
+}
+__global__ void msnv_depth(const uint32_t *pl, uint32_t n_pile, uint32_t n_runs, const uint32_t *run_incl, const uint32_t *run_first, const unsigned long long *skeys,
+                           const unsigned long long *S, const unsigned long long *Pm, const unsigned long long *r_key, const uint32_t *r_end, const uint16_t *rec_sample,
+                           const uint32_t *ovr, DpParams P, uint16_t *r_depth, uint32_t *run_f1, DpAcc *acc) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_pile) return;
+    const uint32_t i = pl[r], g = run_incl[r] - 1u;
+    const uint32_t lo = run_first[g], hi = g + 1 < n_runs ? run_first[g + 1] : n_pile;
+    const unsigned long long target = (unsigned long long)g << 32 | (uint32_t)r_key[i];     // ends <= this read's start
+    uint32_t a = lo, b = hi;
+    while (a < b) { const uint32_t m = a + (b - a) / 2; if (skeys[m] <= target) a = m + 1; else b = m; }
+    const uint32_t gone = a - lo;
+    const uint32_t depth = r - lo + 1u - gone;
+    const unsigned long long chars = (Pm[r + 1] - Pm[lo]) - (S[a] - S[lo]);
+    if (r_end[i] > 1u) atomicMin(&run_f1[g], r);
+    const uint32_t ov = ovr ? ovr[i] : 0u;
+    if (ov & 1u) { r_depth[i] = (uint16_t)(ov >> 16); return; }
+    r_depth[i] = (uint16_t)(depth < 0xffffu ? depth : 0xffffu);
+    uint32_t need = 0;
+    if (P.max_depth > 0 && depth - 1u > (uint32_t)P.max_depth) need |= NEED_CAP;             // live.size() > max_depth before the push
+    if (P.token_limit > 0 && chars >= (unsigned long long)P.token_limit) need |= NEED_TOKEN;
+    if (need) atomicOr(&acc[rec_sample[i]].need_host, need);
+}
+struct DpRun { uint32_t sample; int32_t tid, first_any, first_from1; };
+__global__ void msnv_run_table(const uint32_t *pl, uint32_t n_runs, const uint32_t *run_first, const uint32_t *run_f1, const unsigned long long *r_key,
+                               const uint16_t *rec_sample, DpRun *runs) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_runs) return;
+    const uint32_t i = pl[run_first[g]];
+    DpRun o;
+    o.sample = rec_sample[i]; o.tid = (int32_t)(r_key[i] >> 32); o.first_any = (int32_t)(uint32_t)r_key[i];
+    const uint32_t f = run_f1[g];
+    if (f == 0xffffffffu) o.first_from1 = -1;
+    else { const int32_t p = (int32_t)(uint32_t)r_key[pl[f]]; o.first_from1 = p > 1 ? p : 1; }
+    runs[g] = o;
+}
+
+// ------------------------------------------------------------------------------------------ headers and intervals
+__global__ __launch_bounds__(256) void msnv_emit_headers(const uint8_t *raw, const unsigned long long *rec_off, const uint16_t *rec_sample, uint32_t n_rec, const DpContig *ctg,
+                                                         const uint8_t *r_flags, const uint16_t *r_depth, const uint32_t *pbase, const unsigned long long *sbase,
+                                                         const uint32_t *ibase, const unsigned long long *samp_sbase0,
+                                                         ReadHdr *hdr, int32_t *ptid, int32_t *pend, uint16_t *pdepth, uint32_t *psrc_rec, uint32_t *psrc_q0,
+                                                         int32_t *cov_tid, int32_t *cov_beg, int32_t *cov_end) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rec) return;
+    const uint8_t f = r_flags[i];
+    if (!(f & (RF_PILE | RF_COV))) return;
+    const uint8_t *p = raw + rec_off[i];
+    const Rec r = rec_load(p, ~0ull);
+    const uint32_t s = rec_sample[i];
+    if (f & RF_COV) {                                                                       // qaCompute.cpp:530-552
+        const long long L = ctg[r.tid].len;
+        long long pp = (long long)r.pos + 1;
+        uint32_t k = 0, w = ibase[i];
+        if (r.n_cigar > 0) { const uint32_t t = ld32(r.cigar) & 15u; if (t == C_S || t == C_H) k = 1; }
+        for (; k < r.n_cigar; ++k) {
+            const uint32_t cg = ld32(r.cigar + 4ull * k), t = cg & 15u, l = cg >> 4;
+            if (t == C_M) {
+                if (pp >= L) { if (L >= 1) { cov_tid[w] = r.tid; cov_beg[w] = (int32_t)L; cov_end[w] = (int32_t)(L - 1); ++w; } }
+                else { cov_tid[w] = r.tid; cov_beg[w] = (int32_t)pp; cov_end[w] = (int32_t)(pp + l); ++w; }
+            }
+            pp += l;
+        }
+    }
+    if (!(f & RF_PILE) || r.l_seq == 0) return;
+    uint32_t w = pbase[i];
+    unsigned long long so = sbase[i] - samp_sbase0[s];
+    long long rp = r.pos, q = 0;
+    const uint16_t depth = r_depth[i];
+    for (uint32_t k = 0; k < r.n_cigar; ++k) {
+        const uint32_t cg = ld32(r.cigar + 4ull * k), t = cg & 15u, l = cg >> 4;
+        if (cg_match(t)) {
+            for (uint32_t off = 0, n = 0; off < l; off += n) {
+                const uint32_t to_tile = TILE - (uint32_t)((rp + off) % TILE);
+                n = SEG_MAX < l - off ? SEG_MAX : l - off;
+                n = n < to_tile ? n : to_tile;
+                ReadHdr h;
+                h.gpos = (uint32_t)(rp + off); h.seqoff = (uint32_t)so; h.cig = n; h.meta = META_PILEUP_OK | r.mapq << 16;
+                hdr[w] = h; ptid[w] = r.tid; pend[w] = (int32_t)(rp + off + n); pdepth[w] = depth; psrc_rec[w] = i; psrc_q0[w] = (uint32_t)(q + off);
+                ++w; so += stored_bytes(n);
+            }
+            rp += l; q += l;
+        } else {
+            if (cg_ref(t)) rp += l;
+            if (cg_query(t)) q += l;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ bases and quality flags
+// 16 lanes per piece (SEG_MAX = 128 bases), 8 bases per lane: one 8-byte load of BAM nibbles, one of phred bytes; 4 bytes of the seq
+// column and 8 flags out.  Pieces start on 4 bases, so a lane's 8 flags start on bit 0 or 4 of a byte: whole bytes are stored, the two
+// nibbles a piece shares with its neighbours' bytes are OR-ed in atomically (the flag column is cleared first).
+struct DpSampleDst { uint8_t *seq, *qual; unsigned long long pbase0; uint32_t cut_marks, pad; };
+__device__ __forceinline__ void or_byte(uint8_t *p, uint32_t v) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    atomicOr(reinterpret_cast<uint32_t *>(a & ~(uintptr_t)3), v << (8u * (uint32_t)(a & 3u)));
+}
+__global__ __launch_bounds__(256) void msnv_emit_pieces(const uint8_t *raw, const unsigned long long *rec_off, const uint16_t *rec_sample, const DpContig *ctg, const uint32_t *pref4,
+                                                        DpParams P, uint32_t n_pieces, const ReadHdr *hdr, const int32_t *ptid, const uint32_t *psrc_rec, const uint32_t *psrc_q0,
+                                                        const DpSampleDst *dst, DpAcc *acc) {
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t pc = gt >> 4, sub = gt & 15u, j0 = 8u * sub;
+    const bool piece = pc < n_pieces;
+    ReadHdr h{}; uint32_t s = 0, rec = 0;
+    if (piece) { h = hdr[pc]; rec = psrc_rec[pc]; s = rec_sample[rec]; }
+    const uint32_t n = h.cig, sb = piece ? stored_bytes(n) : 0u;
+    const bool active = j0 < 2u * sb;                                                       // this lane holds stored nibbles of the piece
+    const uint32_t have = n > j0 ? (n - j0 < 8u ? n - j0 : 8u) : 0u;                       // ... of which real bases
+    DpSampleDst d{};
+    if (piece) d = dst[s];
+    // padding: base N, quality byte 0 (pack.cpp: pack_sample, pack_lowq)
+    uint32_t out = 0xffffffffu, bits = (P.c_eff > 0 || P.all_low) ? 0xffu : 0u, mm = 0;
+    bool sampled = false;
+    if (have) {
+        const uint8_t *p = raw + rec_off[rec];
+        const uint32_t l_name = p[12], n_cigar = ld16(p + 16), l_seq = ld32(p + 20);
+        const uint8_t *seq = p + 36 + l_name + 4ull * n_cigar, *qual = seq + ((unsigned long long)l_seq + 1) / 2;
+        const uint32_t q0 = psrc_q0[pc] + j0;
+        // BAM packs base 2i in the HIGH nibble of byte i; the kernels want base j of the piece in nibble j, low first
+        const uint64_t b = ld64(seq + (q0 >> 1));
+        const uint64_t sw = ((b >> 4) & 0x0f0f0f0f0f0f0f0full) | ((b & 0x0f0f0f0f0f0f0f0full) << 4);
+        out = (uint32_t)(sw >> (4u * (q0 & 1u)));
+        if (have < 8u) out |= 0xffffffffu << (4u * have);
+        const DpContig c = ctg[ptid[pc]];
+        const long long g0 = (long long)h.gpos + j0;                                        // contig-relative position of the lane's first base
+        uint32_t rc = 0xffffffffu;                                                          // reference codes of the lane's positions (N where the FASTA has nothing)
+        if (c.seq_len >= 0 && g0 < c.seq_len) {
+            const unsigned long long nb = c.pref_off + (unsigned long long)g0;
+            const uint64_t w = (uint64_t)pref4[nb >> 3] | (uint64_t)pref4[(nb >> 3) + 1] << 32;
+            rc = (uint32_t)(w >> (4u * (uint32_t)(nb & 7u)));
+            const long long left = c.seq_len - g0;
+            if (left < 8) rc |= 0xffffffffu << (4u * (uint32_t)left);
+        }
+        // '=' (code 0) always counts as a match (bam_plcmd.c pileup_seq [EXT]): ship the reference code, N when that is unknown or '=' itself
+        if ((out - 0x11111111u) & ~out & 0x88888888u) {
+            for (uint32_t t = 0; t < have; ++t) if (((out >> (4u * t)) & 0xfu) == 0u) {
+                uint32_t code = (rc >> (4u * t)) & 0xfu;
+                if (code == 0u) code = 15u;
+                out |= code << (4u * t);
+            }
+        }
+        // one piece in 16: how noisy are these reads? (finalize picks the allele bookkeeping by it)
+        if (c.seq_len >= 0 && ((pc - (uint32_t)d.pbase0) & 15u) == 0u) {
+            sampled = true;
+            const long long left = c.seq_len - g0;
+            const uint32_t cmp = left <= 0 ? 0u : (left < (long long)have ? (uint32_t)left : have);
+            uint32_t x = out ^ rc;
+            x = (x | x >> 1 | x >> 2 | x >> 3) & 0x11111111u;
+            if (cmp < 8u) x &= (1u << (4u * cmp)) - 1u;
+            mm = (uint32_t)__builtin_popcount(x);
+        }
+        const uint64_t qb = ld64(qual + q0);
+        uint32_t low = 0;
+        for (uint32_t t = 0; t < 8u; ++t) {
+            const uint32_t qv = (uint32_t)(qb >> (8u * t)) & 0xffu;
+            const bool f = P.all_low || (int)qv < P.c_eff || (d.cut_marks && qv == 0xfeu);   // 0xfe: behind snpCall's token limit (pack.cpp: QUAL_CUT)
+            low |= (f ? 1u : 0u) << t;
+        }
+        bits = have < 8u ? ((bits & (0xffu << have)) | (low & ((1u << have) - 1u))) : low;
+    }
+    const uint32_t prev = __shfl_up(bits, 1);                                               // lane sub - 1 of the same piece (sub > 0)
+    if (active) {
+        // ---- seq column: 4 bytes (2 when the stored piece ends half way)
+        const bool half = 4u * sub + 4u > sb;                                               // this lane holds 4 stored nibbles only
+        uint8_t *sp = d.seq + h.seqoff + 4u * sub;
+        if (!half) __builtin_memcpy(sp, &out, 4);
+        else { const uint16_t o16 = (uint16_t)out; __builtin_memcpy(sp, &o16, 2); }
+        // ---- flag column: bit index = nibble index of the seq column
+        const unsigned long long b0 = 2ull * h.seqoff + j0;
+        uint8_t *qp = d.qual + (b0 >> 3);
+        const uint32_t last = (2u * sb - 1u) >> 3;                                          // last lane of the piece
+        if (!(b0 & 4ull)) {
+            if (!half) *qp = (uint8_t)bits;
+            else or_byte(qp, bits & 0xfu);                                                  // the high nibble is the next piece's
+        } else {
+            if (sub == 0) or_byte(qp, (bits & 0xfu) << 4);                                  // the low nibble is the previous piece's
+            else *qp = (uint8_t)((bits & 0xfu) << 4 | (prev >> 4 & 0xfu));
+            if (sub == last && !half) or_byte(qp + 1, bits >> 4 & 0xfu);
+        }
+    }
+    // mismatch sample: sum over the 16 lanes of a piece, one atomic per sampled piece
+    for (int o = 8; o > 0; o >>= 1) mm += __shfl_down(mm, o, 16);
+    if (sub == 0 && sampled) { atomicAdd(&acc[s].mm_bases, (unsigned long long)n); if (mm) atomicAdd(&acc[s].mm, (unsigned long long)mm); }
+}
+
+// behind the last piece of every sample: 32 bytes of N and their flags (pack.cpp: pack_sample's tail padding)
+__global__ void msnv_emit_tail(const DpSampleDst *dst, const unsigned long long *seq_bytes, uint32_t n_samples, DpParams P) {
+    const uint32_t s = blockIdx.x, t = threadIdx.x;      // 64 threads
+    if (s >= n_samples) return;
+    const unsigned long long nb = seq_bytes[s];          // without the tail
+    if (t < 32) dst[s].seq[nb + t] = 0xff;
+    if (P.c_eff > 0 || P.all_low) {                      // 64 flags from bit 2 * nb (a multiple of 4)
+        const unsigned long long b0 = 2ull * nb;
+        if (t < 16) or_byte(dst[s].qual + ((b0 + 4ull * t) >> 3), ((b0 + 4ull * t) & 4ull) ? 0xf0u : 0x0fu);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ tile order of the headers
+__global__ void msnv_tile_keys(const ReadHdr *hdr, const int32_t *ptid, const uint32_t *psrc_rec, const uint16_t *rec_sample, uint32_t n, uint32_t tid_bits,
+                               unsigned long long *keys, uint32_t *idx, uint32_t *unsorted) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long k = ((unsigned long long)rec_sample[psrc_rec[i]] << tid_bits | (uint32_t)ptid[i]) << 21 | (hdr[i].gpos / TILE);
+    keys[i] = k; idx[i] = i;
+    if (i > 0) {
+        const unsigned long long kp = ((unsigned long long)rec_sample[psrc_rec[i - 1]] << tid_bits | (uint32_t)ptid[i - 1]) << 21 | (hdr[i - 1].gpos / TILE);
+        if (kp > k) *unsorted = 1u;
+    }
+}
+__global__ void msnv_gather_pieces(const uint32_t *idx, uint32_t n, const ReadHdr *hdr, const int32_t *ptid, const int32_t *pend, const uint16_t *pdepth,
+                                   ReadHdr *hdr2, int32_t *ptid2, int32_t *pend2, uint16_t *pdepth2) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t j = idx[i];
+    hdr2[i] = hdr[j]; ptid2[i] = ptid[j]; pend2[i] = pend[j]; pdepth2[i] = pdepth[j];
+}
+
+// ------------------------------------------------------------------------------------------ finalize: padding behind the pieces
+// The alignment padding behind a piece (up to the next 4 bases) reads as the reference the kernel compares it with, N beyond the tile
+// (pack.cpp: finalize_dataset; msnv_pileup_tiles_narrow32 masks mismatch flags per group of bases, not per base).
+__global__ void msnv_fill_padding(const ReadHdr *hdr, const unsigned long long *s_read_base, const unsigned long long *s_seq_base, const uint8_t *s_dev, uint32_t n_samples,
+                                  unsigned long long n_pieces, const uint32_t *ref4, uint8_t *seq) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pieces) return;
+    uint32_t a = 0, b = n_samples;                       // sample of piece i: last s with s_read_base[s] <= i
+    while (b - a > 1) { const uint32_t m = (a + b) / 2; if (s_read_base[m] <= i) a = m; else b = m; }
+    if (!s_dev[a]) return;
+    const ReadHdr h = hdr[i];
+    const uint32_t len = h.cig, stop = (len + 2u * SEQ_ALIGN - 1u) & ~(2u * SEQ_ALIGN - 1u);
+    uint8_t *sp = seq + s_seq_base[a] + h.seqoff;
+    for (uint32_t j = len; j < stop; ++j) {
+        const unsigned long long g = (unsigned long long)h.gpos + j;
+        const uint32_t code = (h.gpos % TILE + j < TILE) ? (ref4[g >> 3] >> (4u * (uint32_t)(g & 7u))) & 0xfu : 0xfu;
+        const uint32_t sh = (j & 1u) * 4u;
+        sp[j >> 1] = (uint8_t)((sp[j >> 1] & ~(0xfu << sh)) | code << sh);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ host side
+struct DevBuf {
+    void *p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { if (p) dev_free(p); }
+    int alloc(uint64_t bytes) { if (p) { dev_free(p); p = nullptr; } return dev_alloc(&p, bytes, nullptr); }
+    template <typename T> T *as() const { return static_cast<T *>(p); }
+    void *release() { void *q = p; p = nullptr; return q; }
+};
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct Timer {          // HIP events around a group of launches
+    hipEvent_t a = nullptr, b = nullptr; hipStream_t st;
+    explicit Timer(hipStream_t s) : st(s) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); }
+    ~Timer() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    void start() { (void)hipEventRecord(a, st); }
+    double stop() { (void)hipEventRecord(b, st); (void)hipEventSynchronize(b); float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms; }
+};
+
+int scan_u32(const uint32_t *in, uint32_t *out, size_t n, hipStream_t st, DevBuf &tmp, size_t &tmp_cap, bool inclusive = false) {
+    size_t need = 0;
+    if (inclusive) HIP_TRY(rocprim::inclusive_scan(nullptr, need, in, out, n, rocprim::plus<uint32_t>(), st));
+    else HIP_TRY(rocprim::exclusive_scan(nullptr, need, in, out, 0u, n, rocprim::plus<uint32_t>(), st));
+    if (need > tmp_cap) { if (int rc = tmp.alloc(need)) return rc; tmp_cap = need; }
+    if (inclusive) HIP_TRY(rocprim::inclusive_scan(tmp.p, need, in, out, n, rocprim::plus<uint32_t>(), st));
+    else HIP_TRY(rocprim::exclusive_scan(tmp.p, need, in, out, 0u, n, rocprim::plus<uint32_t>(), st));
+    return MSNV_OK;
+}
+int scan_u32_u64(const uint32_t *in, unsigned long long *out, size_t n, hipStream_t st, DevBuf &tmp, size_t &tmp_cap) {
+    size_t need = 0;
+    HIP_TRY(rocprim::exclusive_scan(nullptr, need, in, out, 0ull, n, rocprim::plus<unsigned long long>(), st));
+    if (need > tmp_cap) { if (int rc = tmp.alloc(need)) return rc; tmp_cap = need; }
+    HIP_TRY(rocprim::exclusive_scan(tmp.p, need, in, out, 0ull, n, rocprim::plus<unsigned long long>(), st));
+    return MSNV_OK;
+}
+int sort_pairs(unsigned long long *kin, unsigned long long *kout, uint32_t *vin, uint32_t *vout, size_t n, unsigned end_bit, hipStream_t st, DevBuf &tmp, size_t &tmp_cap) {
+    size_t need = 0;
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, kin, kout, vin, vout, n, 0u, end_bit, st));
+    if (need > tmp_cap) { if (int rc = tmp.alloc(need)) return rc; tmp_cap = need; }
+    HIP_TRY(rocprim::radix_sort_pairs(tmp.p, need, kin, kout, vin, vout, n, 0u, end_bit, st));
+    return MSNV_OK;
+}
+unsigned bit_width_u64(unsigned long long v) { unsigned b = 0; while (v) { ++b; v >>= 1; } return b; }
+inline dim3 grid_for(uint64_t n, uint32_t block) { return dim3((unsigned)std::max<uint64_t>(1, (n + block - 1) / block)); }
+
+// contig table + packed FASTA of the selected contigs
+int build_tables(msnv_dataset &ds) {
+    DevPackTables &t = ds.dp;
+    if (t.ready) return MSNV_OK;
+    const size_t NC = ds.names.size();
+    std::vector<DpContig> ct(NC);
+    uint64_t nib = 0;
+    for (size_t c = 0; c < NC; ++c) {
+        DpContig &d = ct[c];
+        d.len = ds.lengths[c]; d.seq_len = ds.has_seq[c] ? (long long)ds.seqs[c].size() : -1;
+        d.bed_beg = ds.bed_beg[c]; d.bed_end = ds.bed_end[c]; d.sel = ds.sel[c]; d.pad = 0; d.pref_off = nib;
+        if (ds.sel[c] && ds.has_seq[c]) nib += (ds.seqs[c].size() + 7) & ~(size_t)7;
+    }
+    t.pref_words = nib / 8 + 2;
+    if (int rc = dev_alloc(&t.contigs, std::max<size_t>(1, NC) * sizeof(DpContig), nullptr)) return rc;
+    if (int rc = dev_upload(t.contigs, ct.data(), NC * sizeof(DpContig))) return rc;
+    if (int rc = dev_alloc((void **)&t.pref4, t.pref_words * sizeof(uint32_t), nullptr)) return rc;
+    // staged in chunks (a shard of a 25 GB database: gigabases)
+    std::vector<uint32_t> stage;
+    const size_t chunk_words = 16u << 20;
+    uint64_t w0 = 0;                                            // first word of the staging buffer
+    stage.reserve(chunk_words + 1024);
+    auto flush = [&]() -> int {
+        if (stage.empty()) return MSNV_OK;
+        if (int rc = dev_upload(t.pref4 + w0, stage.data(), stage.size() * sizeof(uint32_t))) return rc;
+        w0 += stage.size(); stage.clear();
+        return MSNV_OK;
+    };
+    for (size_t c = 0; c < NC; ++c) {
+        if (!ds.sel[c] || !ds.has_seq[c]) continue;
+        const std::string &sq = ds.seqs[c];
+        const size_t nw = (sq.size() + 7) / 8;
+        for (size_t w = 0; w < nw; ++w) {
+            uint32_t v = 0xffffffffu;
+            const size_t lim = std::min<size_t>(8, sq.size() - 8 * w);
+            for (size_t j = 0; j < lim; ++j) v = (v & ~(0xfu << (4 * j))) | (uint32_t)nt16_of_char((unsigned char)sq[8 * w + j]) << (4 * j);
+            stage.push_back(v);
+            if (stage.size() >= chunk_words) if (int rc = flush()) return rc;
+        }
+    }
+    stage.push_back(0xffffffffu); stage.push_back(0xffffffffu);
+    if (int rc = flush()) return rc;
+    t.ready = true;
+    return MSNV_OK;
+}
+
+const char *err_text(uint32_t kind) {
+    switch (kind) {
+        case ERR_MALFORMED: return "malformed BAM record";
+        case ERR_TID: return "record refers to a contig the header does not have";
+        case ERR_UNSORTED: return "BAM is not coordinate sorted";
+        case ERR_QLEN: return "CIGAR and read length disagree";
+        default: return "bad record";
+    }
+}
+
+}  // namespace
+
+void devpack_release(DevPackTables &t) {
+    if (t.contigs) dev_free(t.contigs);
+    if (t.pref4) dev_free(t.pref4);
+    for (void *p : t.round_bufs) dev_free(p);
+    t.round_bufs.clear();
+    t.contigs = nullptr; t.pref4 = nullptr; t.ready = false;
+}
+
+int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *streams, const uint64_t *n_bytes, int n, bool on_device) {
+    if (n <= 0) return MSNV_OK;
+    if (n > 2048) return fail(MSNV_EINVAL, "internal: a device-pack round holds at most 2048 samples");
+    if (!ds.ctx) return fail(MSNV_ENODEV, "the device pack needs a device context");
+    if (int rc = dev_set_device(ds.ctx->device)) return rc;
+    hipStream_t st = (hipStream_t)ds.ctx->stream;
+    if (int rc = build_tables(ds)) return rc;
+    DevPackTables &T = ds.dp;
+    const size_t S = (size_t)n, NC = ds.names.size();
+    const msnv_params &MP = ds.params;
+    DpParams P{};
+    P.flag_filter = MP.flag_filter; P.min_mapq = MP.min_mapq; P.count_orphans = MP.count_orphans; P.cov_min_mapq = MP.cov_min_mapq;
+    P.max_depth = MP.max_depth; P.token_limit = MP.token_limit; P.ignore_overlaps = MP.ignore_overlaps;
+    P.c_eff = std::min(std::max(MP.min_baseq, -127), 127); P.all_low = MP.min_baseq > 127;
+    P.n_contigs = (int)NC; P.has_bed = ds.has_bed ? 1 : 0;
+    Timer tm(st);
+
+    // ---- the round's streams side by side in one buffer: every stream starts on 16 bytes, 64 readable bytes behind the last
+    std::vector<unsigned long long> s_beg(S), s_len(S), s_end(S), cap_base(S + 1, 0);
+    uint64_t raw_bytes = 0;
+    for (size_t s = 0; s < S; ++s) { s_beg[s] = raw_bytes; s_len[s] = n_bytes[s]; s_end[s] = raw_bytes + n_bytes[s]; raw_bytes += (n_bytes[s] + 15 + 16) & ~15ull; cap_base[s + 1] = cap_base[s] + n_bytes[s] / 36 + 1; }
+    DevBuf raw;
+    if (int rc = raw.alloc(raw_bytes + 64)) return rc;
+    {
+        const double t0 = now_s();
+        if (on_device) {
+            for (size_t s = 0; s < S; ++s) if (n_bytes[s]) HIP_TRY(hipMemcpyAsync(raw.as<uint8_t>() + s_beg[s], streams[s], n_bytes[s], hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        } else {
+            // pageable host memory: a few copies in flight keep the link busy (the runtime stages them)
+            std::atomic<size_t> next{0}; std::atomic<int> bad{0};
+            const int device = ds.ctx->device;
+            auto w = [&]() {
+                (void)hipSetDevice(device);
+                for (;;) { const size_t s = next.fetch_add(1); if (s >= S) break; if (n_bytes[s] && hipMemcpy(raw.as<uint8_t>() + s_beg[s], streams[s], n_bytes[s], hipMemcpyHostToDevice) != hipSuccess) bad.store(1); }
+            };
+            std::vector<std::thread> th;
+            for (size_t k = 0; k < std::min<size_t>(S, 6); ++k) th.emplace_back(w);
+            for (auto &x : th) x.join();
+            if (bad.load()) return fail(MSNV_EHIP, "upload of the record streams failed: %s", hipGetErrorString(hipGetLastError()));
+        }
+        T.wall_upload_s += now_s() - t0;
+    }
+    T.raw_bytes += raw_bytes;
+
+    // ---- record boundaries
+    DevBuf d_sbeg, d_slen, d_send, d_capbase, d_tmpoff, d_nrec, d_bad;
+    if (int rc = d_sbeg.alloc(S * 8)) return rc;
+    if (int rc = d_slen.alloc(S * 8)) return rc;
+    if (int rc = d_send.alloc(S * 8)) return rc;
+    if (int rc = d_capbase.alloc((S + 1) * 8)) return rc;
+    if (int rc = d_tmpoff.alloc(cap_base[S] * 8)) return rc;
+    if (int rc = d_nrec.alloc(S * 4)) return rc;
+    if (int rc = d_bad.alloc(S * 8)) return rc;
+    HIP_TRY(hipMemcpyAsync(d_sbeg.p, s_beg.data(), S * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_slen.p, s_len.data(), S * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_send.p, s_end.data(), S * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_capbase.p, cap_base.data(), (S + 1) * 8, hipMemcpyHostToDevice, st));
+    tm.start();
+    hipLaunchKernelGGL(msnv_scan_records, dim3((unsigned)S), dim3(64), 0, st, raw.as<uint8_t>(), d_sbeg.as<unsigned long long>(), d_slen.as<unsigned long long>(),
+                       d_capbase.as<unsigned long long>(), d_tmpoff.as<unsigned long long>(), d_nrec.as<uint32_t>(), d_bad.as<unsigned long long>());
+    HIP_TRY(hipGetLastError());
+    std::vector<uint32_t> n_rec(S);
+    std::vector<unsigned long long> bad_off(S);
+    HIP_TRY(hipMemcpyAsync(n_rec.data(), d_nrec.p, S * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(bad_off.data(), d_bad.p, S * 8, hipMemcpyDeviceToHost, st));
+    T.ms_scan += tm.stop();
+    std::vector<uint32_t> rec_base(S + 1, 0);
+    uint32_t max_nrec = 0;
+    for (size_t s = 0; s < S; ++s) {
+        if ((uint64_t)rec_base[s] + n_rec[s] > 0xfffffff0ull) return fail(MSNV_EDOMAIN, "more than 2^32 records in one round of the device pack");
+        rec_base[s + 1] = rec_base[s] + n_rec[s]; max_nrec = std::max(max_nrec, n_rec[s]);
+    }
+    const uint32_t NR = rec_base[S];
+    T.n_records += NR;
+    DevBuf d_recbase, d_recoff, d_recsample;
+    if (int rc = d_recbase.alloc((S + 1) * 4)) return rc;
+    if (int rc = d_recoff.alloc(((uint64_t)NR + 1) * 8)) return rc;
+    if (int rc = d_recsample.alloc(((uint64_t)NR + 1) * 2)) return rc;
+    HIP_TRY(hipMemcpyAsync(d_recbase.p, rec_base.data(), (S + 1) * 4, hipMemcpyHostToDevice, st));
+    if (NR) {
+        hipLaunchKernelGGL(msnv_compact_offsets, dim3(std::max(1u, std::min(1024u, (max_nrec + 255u) / 256u)), (unsigned)S), dim3(256), 0, st, d_tmpoff.as<unsigned long long>(),
+                           d_capbase.as<unsigned long long>(), d_recbase.as<uint32_t>(), d_sbeg.as<unsigned long long>(), d_recoff.as<unsigned long long>(), d_recsample.as<uint16_t>());
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    if (int rc = d_tmpoff.alloc(16)) return rc;                                  // (the capacity-sized list is gone)
+
+    // ---- measure (+ the host pre-pass for the samples that need one, then once more with its verdicts)
+    DevBuf d_flags, d_key, d_end, d_maxc, d_pile, d_npiece, d_seqb, d_niv, d_acc, d_ovr, d_depth;
+    const uint64_t NRa = (uint64_t)NR + 1;
+    if (int rc = d_flags.alloc(NRa)) return rc;
+    if (int rc = d_key.alloc(NRa * 8)) return rc;
+    if (int rc = d_end.alloc(NRa * 4)) return rc;
+    if (int rc = d_maxc.alloc(NRa * 4)) return rc;
+    if (int rc = d_pile.alloc(NRa * 4)) return rc;
+    if (int rc = d_npiece.alloc(NRa * 4)) return rc;
+    if (int rc = d_seqb.alloc(NRa * 4)) return rc;
+    if (int rc = d_niv.alloc(NRa * 4)) return rc;
+    if (int rc = d_depth.alloc(NRa * 2)) return rc;
+    if (int rc = d_acc.alloc(S * sizeof(DpAcc))) return rc;
+    std::vector<DpAcc> acc(S);
+    std::vector<uint8_t> cut_marks(S, 0);
+    const DpContig *ctg = static_cast<const DpContig *>(T.contigs);
+    DevBuf tmp; size_t tmp_cap = 0;
+    DevBuf d_rank, d_pl, d_rf, d_runincl, d_keys, d_vals, d_skeys, d_svals, d_maxcr, d_runfirst, d_runf1, d_S, d_Pm, d_runs;
+    std::vector<DpRun> runs;
+    uint32_t NP = 0, n_runs = 0;
+    bool have_ovr = false;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (size_t s = 0; s < S; ++s) { DpAcc a{}; a.err = a.first_pile = a.beyond = ~0ull; acc[s] = a; }
+        HIP_TRY(hipMemcpyAsync(d_acc.p, acc.data(), S * sizeof(DpAcc), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemsetAsync(d_depth.p, 0, NRa * 2, st));
+        tm.start();
+        if (NR) {
+            hipLaunchKernelGGL(msnv_measure_reads, grid_for(NR, 256), dim3(256), 0, st, raw.as<uint8_t>(), d_recoff.as<unsigned long long>(), d_recsample.as<uint16_t>(),
+                               d_recbase.as<uint32_t>(), d_send.as<unsigned long long>(), NR, ctg, P, have_ovr ? d_ovr.as<uint32_t>() : nullptr, d_flags.as<uint8_t>(),
+                               d_key.as<unsigned long long>(), d_end.as<uint32_t>(), d_maxc.as<uint32_t>(), d_pile.as<uint32_t>(), d_npiece.as<uint32_t>(), d_seqb.as<uint32_t>(),
+                               d_niv.as<uint32_t>(), d_acc.as<DpAcc>());
+            HIP_TRY(hipGetLastError());
+        }
+        T.ms_measure += tm.stop();
+        // ---- depth at every read start
+        tm.start();
+        if (int rc = d_rank.alloc(NRa * 4)) return rc;
+        HIP_TRY(hipMemsetAsync(d_pile.as<uint32_t>() + NR, 0, 4, st));
+        if (int rc = scan_u32(d_pile.as<uint32_t>(), d_rank.as<uint32_t>(), NRa, st, tmp, tmp_cap)) return rc;      // (entry NR = number of pileup reads)
+        HIP_TRY(hipMemcpyAsync(&NP, d_rank.as<uint32_t>() + NR, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        n_runs = 0;
+        if (NP) {
+            const uint64_t NPa = (uint64_t)NP + 1;
+            if (int rc = d_pl.alloc(NPa * 4)) return rc;
+            if (int rc = d_rf.alloc(NPa * 4)) return rc;
+            if (int rc = d_runincl.alloc(NPa * 4)) return rc;
+            if (int rc = d_keys.alloc(NPa * 8)) return rc;
+            if (int rc = d_vals.alloc(NPa * 4)) return rc;
+            if (int rc = d_skeys.alloc(NPa * 8)) return rc;
+            if (int rc = d_svals.alloc(NPa * 4)) return rc;
+            if (int rc = d_maxcr.alloc(NPa * 4)) return rc;
+            if (int rc = d_S.alloc(NPa * 8)) return rc;
+            if (int rc = d_Pm.alloc(NPa * 8)) return rc;
+            hipLaunchKernelGGL(msnv_pile_list, grid_for(NR, 256), dim3(256), 0, st, d_pile.as<uint32_t>(), d_rank.as<uint32_t>(), NR, d_pl.as<uint32_t>());
+            hipLaunchKernelGGL(msnv_run_flags, grid_for(NP, 256), dim3(256), 0, st, d_pl.as<uint32_t>(), NP, d_recsample.as<uint16_t>(), d_key.as<unsigned long long>(), d_rf.as<uint32_t>());
+            HIP_TRY(hipGetLastError());
+            if (int rc = scan_u32(d_rf.as<uint32_t>(), d_runincl.as<uint32_t>(), NP, st, tmp, tmp_cap, true)) return rc;
+            HIP_TRY(hipMemcpyAsync(&n_runs, d_runincl.as<uint32_t>() + (NP - 1), 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (int rc = d_runfirst.alloc(((uint64_t)n_runs + 1) * 4)) return rc;
+            if (int rc = d_runf1.alloc(((uint64_t)n_runs + 1) * 4)) return rc;
+            if (int rc = d_runs.alloc(((uint64_t)n_runs + 1) * sizeof(DpRun))) return rc;
+            hipLaunchKernelGGL(msnv_depth_keys, grid_for(NPa, 256), dim3(256), 0, st, d_pl.as<uint32_t>(), NP, d_rf.as<uint32_t>(), d_runincl.as<uint32_t>(), d_end.as<uint32_t>(),
+                               d_maxc.as<uint32_t>(), d_keys.as<unsigned long long>(), d_vals.as<uint32_t>(), d_maxcr.as<uint32_t>(), d_runfirst.as<uint32_t>(), d_runf1.as<uint32_t>());
+            HIP_TRY(hipGetLastError());
+            if (int rc = sort_pairs(d_keys.as<unsigned long long>(), d_skeys.as<unsigned long long>(), d_vals.as<uint32_t>(), d_svals.as<uint32_t>(), NP,
+                                    32u + std::max(1u, bit_width_u64(n_runs)), st, tmp, tmp_cap)) return rc;
+            HIP_TRY(hipMemsetAsync(d_svals.as<uint32_t>() + NP, 0, 4, st));
+            if (int rc = scan_u32_u64(d_svals.as<uint32_t>(), d_S.as<unsigned long long>(), NPa, st, tmp, tmp_cap)) return rc;
+            if (int rc = scan_u32_u64(d_maxcr.as<uint32_t>(), d_Pm.as<unsigned long long>(), NPa, st, tmp, tmp_cap)) return rc;
+            hipLaunchKernelGGL(msnv_depth, grid_for(NP, 256), dim3(256), 0, st, d_pl.as<uint32_t>(), NP, n_runs, d_runincl.as<uint32_t>(), d_runfirst.as<uint32_t>(),
+                               d_skeys.as<unsigned long long>(), d_S.as<unsigned long long>(), d_Pm.as<unsigned long long>(), d_key.as<unsigned long long>(), d_end.as<uint32_t>(),
+                               d_recsample.as<uint16_t>(), have_ovr ? d_ovr.as<uint32_t>() : nullptr, P, d_depth.as<uint16_t>(), d_runf1.as<uint32_t>(), d_acc.as<DpAcc>());
+            hipLaunchKernelGGL(msnv_run_table, grid_for(n_runs, 256), dim3(256), 0, st, d_pl.as<uint32_t>(), n_runs, d_runfirst.as<uint32_t>(), d_runf1.as<uint32_t>(),
+                               d_key.as<unsigned long long>(), d_recsample.as<uint16_t>(), d_runs.as<DpRun>());
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipMemcpyAsync(acc.data(), d_acc.p, S * sizeof(DpAcc), hipMemcpyDeviceToHost, st));
+        T.ms_depth += tm.stop();
+        // ---- errors, in record order (what the host stage's sequential walk would have met first)
+        for (size_t s = 0; s < S; ++s) {
+            unsigned long long e = acc[s].err;
+            if (e != ~0ull) {
+                const uint32_t kind = (uint32_t)(e & 7u); const unsigned long long idx = (e >> 3) - rec_base[s];
+                return fail(MSNV_EFORMAT, "%s (sample %zu of the batch, record %llu)", err_text(kind), s, idx);
+            }
+            if (bad_off[s] != ~0ull) return fail(MSNV_EFORMAT, "malformed BAM record at byte %llu", bad_off[s]);
+        }
+        if (pass == 1) break;
+        // ---- which samples need the sequential edits of the host stage?
+        std::vector<size_t> need;
+        for (size_t s = 0; s < S; ++s) if (acc[s].need_host || (!MP.ignore_overlaps && acc[s].n_ovl >= 2)) need.push_back(s);
+        if (need.empty()) break;
+        const double t0 = now_s();
+        T.n_prepass_samples += need.size();
+        std::vector<uint32_t> ovr_all((size_t)NR + 1, 0u);
+        std::vector<std::vector<uint8_t>> host_copy(need.size()), patched(need.size());
+        std::vector<int> rcs(need.size(), 0); std::vector<std::string> msgs(need.size());
+        for (size_t k = 0; k < need.size(); ++k) if (on_device) {
+            host_copy[k].resize(n_bytes[need[k]]);
+            if (n_bytes[need[k]]) HIP_TRY(hipMemcpy(host_copy[k].data(), raw.as<uint8_t>() + s_beg[need[k]], n_bytes[need[k]], hipMemcpyDeviceToHost));
+        }
+        {
+            std::atomic<size_t> next{0};
+            auto w = [&]() {
+                for (;;) {
+                    const size_t k = next.fetch_add(1);
+                    if (k >= need.size()) break;
+                    const size_t s = need[k];
+                    const uint8_t *rec = on_device ? host_copy[k].data() : streams[s];
+                    std::vector<uint32_t> ov; bool cm = false;
+                    int rc;
+                    try { rc = host_prepass(ds, rec, n_bytes[s], ov, patched[k], cm); } catch (const std::exception &e) { rc = fail_quiet(MSNV_ENOMEM, "host pre-pass: %s", e.what()); }
+                    if (!rc && ov.size() != n_rec[s]) rc = fail_quiet(MSNV_EINVAL, "internal: the host pre-pass saw %zu records, the device scan %u", ov.size(), n_rec[s]);
+                    if (rc) { rcs[k] = rc; msgs[k] = msnv_last_error(); continue; }
+                    std::copy(ov.begin(), ov.end(), ovr_all.begin() + rec_base[s]);
+                    cut_marks[s] = cm ? 1 : 0;
+                }
+            };
+            std::vector<std::thread> th;
+            const size_t nt = std::min<size_t>(need.size(), std::max(1u, std::thread::hardware_concurrency()));
+            for (size_t k = 0; k < nt; ++k) th.emplace_back(w);
+            for (auto &x : th) x.join();
+        }
+        for (size_t k = 0; k < need.size(); ++k) if (rcs[k]) return fail(rcs[k], "%s", msgs[k].c_str());
+        for (size_t k = 0; k < need.size(); ++k) if (!patched[k].empty()) HIP_TRY(hipMemcpy(raw.as<uint8_t>() + s_beg[need[k]], patched[k].data(), patched[k].size(), hipMemcpyHostToDevice));
+        if (int rc = d_ovr.alloc(((uint64_t)NR + 1) * 4)) return rc;
+        HIP_TRY(hipMemcpy(d_ovr.p, ovr_all.data(), ((uint64_t)NR + 1) * 4, hipMemcpyHostToDevice));
+        have_ovr = true;
+        T.wall_prepass_s += now_s() - t0;
+    }
+    runs.resize(n_runs);
+    if (n_runs) HIP_TRY(hipMemcpy(runs.data(), d_runs.p, (size_t)n_runs * sizeof(DpRun), hipMemcpyDeviceToHost));
+    // the depth stage's lists are gone before the pieces are laid out
+    for (DevBuf *b : {&d_rank, &d_pl, &d_rf, &d_runincl, &d_keys, &d_vals, &d_skeys, &d_svals, &d_maxcr, &d_runfirst, &d_runf1, &d_S, &d_Pm, &d_runs, &d_ovr, &d_maxc, &d_pile})
+        if (b->p) { dev_free(b->p); b->p = nullptr; }
+
+    // ---- layout: where every record's pieces, seq bytes and intervals go
+    DevBuf d_pbase, d_sbase, d_ibase;
+    if (int rc = d_pbase.alloc(NRa * 4)) return rc;
+    if (int rc = d_sbase.alloc(NRa * 8)) return rc;
+    if (int rc = d_ibase.alloc(NRa * 4)) return rc;
+    tm.start();
+    HIP_TRY(hipMemsetAsync(d_npiece.as<uint32_t>() + NR, 0, 4, st));
+    HIP_TRY(hipMemsetAsync(d_seqb.as<uint32_t>() + NR, 0, 4, st));
+    HIP_TRY(hipMemsetAsync(d_niv.as<uint32_t>() + NR, 0, 4, st));
+    if (int rc = scan_u32(d_npiece.as<uint32_t>(), d_pbase.as<uint32_t>(), NRa, st, tmp, tmp_cap)) return rc;
+    if (int rc = scan_u32_u64(d_seqb.as<uint32_t>(), d_sbase.as<unsigned long long>(), NRa, st, tmp, tmp_cap)) return rc;
+    if (int rc = scan_u32(d_niv.as<uint32_t>(), d_ibase.as<uint32_t>(), NRa, st, tmp, tmp_cap)) return rc;
+    std::vector<uint32_t> sp0(S + 1), si0(S + 1);
+    std::vector<unsigned long long> ss0(S + 1);
+    for (size_t s = 0; s <= S; ++s) {
+        HIP_TRY(hipMemcpyAsync(&sp0[s], d_pbase.as<uint32_t>() + rec_base[s], 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&ss0[s], d_sbase.as<unsigned long long>() + rec_base[s], 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&si0[s], d_ibase.as<uint32_t>() + rec_base[s], 4, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    const uint32_t NPC = sp0[S], NIV = si0[S];
+    T.n_pieces += NPC;
+    // the round's columns: per sample seq (its pieces + 32 tail bytes, start on 16 bytes) and one flag bit per nibble of it
+    std::vector<unsigned long long> seq_off(S + 1, 0), piece_bytes(S);
+    for (size_t s = 0; s < S; ++s) {
+        piece_bytes[s] = ss0[s + 1] - ss0[s];
+        if (piece_bytes[s] > 0xffffff00ull) return fail(MSNV_EDOMAIN, "one sample holds more than 8.5 G aligned bases in this shard: shard the contigs further");
+        seq_off[s + 1] = seq_off[s] + ((piece_bytes[s] + 32 + 15) & ~15ull);
+    }
+    const uint64_t seq_total = seq_off[S], qual_total = seq_total / 4;
+    void *round_buf = nullptr;
+    if (int rc = dev_alloc(&round_buf, seq_total + qual_total + 64, nullptr)) return rc;
+    T.round_bufs.push_back(round_buf);
+    uint8_t *r_seq = static_cast<uint8_t *>(round_buf), *r_qual = r_seq + seq_total;
+    HIP_TRY(hipMemsetAsync(r_qual, 0, qual_total + 64, st));
+    std::vector<DpSampleDst> dsts(S);
+    for (size_t s = 0; s < S; ++s) dsts[s] = DpSampleDst{r_seq + seq_off[s], r_qual + seq_off[s] / 4, sp0[s], cut_marks[s], 0u};
+    DevBuf d_dst, d_ss0, d_pb;
+    if (int rc = d_dst.alloc(S * sizeof(DpSampleDst))) return rc;
+    if (int rc = d_ss0.alloc((S + 1) * 8)) return rc;
+    if (int rc = d_pb.alloc(S * 8)) return rc;
+    HIP_TRY(hipMemcpyAsync(d_dst.p, dsts.data(), S * sizeof(DpSampleDst), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_ss0.p, ss0.data(), (S + 1) * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_pb.p, piece_bytes.data(), S * 8, hipMemcpyHostToDevice, st));
+    DevBuf d_hdr, d_ptid, d_pend, d_pdepth, d_srec, d_sq0, d_ctid, d_cbeg, d_cend;
+    const uint64_t NPCa = (uint64_t)NPC + 1, NIVa = (uint64_t)NIV + 1;
+    if (int rc = d_hdr.alloc(NPCa * sizeof(ReadHdr))) return rc;
+    if (int rc = d_ptid.alloc(NPCa * 4)) return rc;
+    if (int rc = d_pend.alloc(NPCa * 4)) return rc;
+    if (int rc = d_pdepth.alloc(NPCa * 2)) return rc;
+    if (int rc = d_srec.alloc(NPCa * 4)) return rc;
+    if (int rc = d_sq0.alloc(NPCa * 4)) return rc;
+    if (int rc = d_ctid.alloc(NIVa * 4)) return rc;
+    if (int rc = d_cbeg.alloc(NIVa * 4)) return rc;
+    if (int rc = d_cend.alloc(NIVa * 4)) return rc;
+    if (NR) {
+        hipLaunchKernelGGL(msnv_emit_headers, grid_for(NR, 256), dim3(256), 0, st, raw.as<uint8_t>(), d_recoff.as<unsigned long long>(), d_recsample.as<uint16_t>(), NR, ctg,
+                           d_flags.as<uint8_t>(), d_depth.as<uint16_t>(), d_pbase.as<uint32_t>(), d_sbase.as<unsigned long long>(), d_ibase.as<uint32_t>(),
+                           d_ss0.as<unsigned long long>(), d_hdr.as<ReadHdr>(), d_ptid.as<int32_t>(), d_pend.as<int32_t>(), d_pdepth.as<uint16_t>(), d_srec.as<uint32_t>(),
+                           d_sq0.as<uint32_t>(), d_ctid.as<int32_t>(), d_cbeg.as<int32_t>(), d_cend.as<int32_t>());
+        HIP_TRY(hipGetLastError());
+    }
+    if (NPC) {
+        hipLaunchKernelGGL(msnv_emit_pieces, grid_for((uint64_t)NPC * 16, 256), dim3(256), 0, st, raw.as<uint8_t>(), d_recoff.as<unsigned long long>(), d_recsample.as<uint16_t>(), ctg,
+                           T.pref4, P, NPC, d_hdr.as<ReadHdr>(), d_ptid.as<int32_t>(), d_srec.as<uint32_t>(), d_sq0.as<uint32_t>(), d_dst.as<DpSampleDst>(), d_acc.as<DpAcc>());
+        HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(msnv_emit_tail, dim3((unsigned)S), dim3(64), 0, st, d_dst.as<DpSampleDst>(), d_pb.as<unsigned long long>(), (uint32_t)S, P);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(acc.data(), d_acc.p, S * sizeof(DpAcc), hipMemcpyDeviceToHost, st));
+    T.ms_emit += tm.stop();
+
+    // ---- headers in tile order (stable: read order inside a tile)
+    tm.start();
+    DevBuf d_hdr2, d_ptid2, d_pend2, d_pdepth2;
+    bool permuted = false;
+    if (NPC > 1) {
+        DevBuf d_tk, d_tk2, d_ix, d_ix2, d_uns;
+        if (int rc = d_tk.alloc(NPCa * 8)) return rc;
+        if (int rc = d_ix.alloc(NPCa * 4)) return rc;
+        if (int rc = d_uns.alloc(4)) return rc;
+        HIP_TRY(hipMemsetAsync(d_uns.p, 0, 4, st));
+        const unsigned tid_bits = std::max(1u, bit_width_u64(NC ? NC - 1 : 0));
+        hipLaunchKernelGGL(msnv_tile_keys, grid_for(NPC, 256), dim3(256), 0, st, d_hdr.as<ReadHdr>(), d_ptid.as<int32_t>(), d_srec.as<uint32_t>(), d_recsample.as<uint16_t>(), NPC,
+                           tid_bits, d_tk.as<unsigned long long>(), d_ix.as<uint32_t>(), d_uns.as<uint32_t>());
+        HIP_TRY(hipGetLastError());
+        uint32_t uns = 0;
+        HIP_TRY(hipMemcpyAsync(&uns, d_uns.p, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (uns) {
+            if (int rc = d_tk2.alloc(NPCa * 8)) return rc;
+            if (int rc = d_ix2.alloc(NPCa * 4)) return rc;
+            if (int rc = sort_pairs(d_tk.as<unsigned long long>(), d_tk2.as<unsigned long long>(), d_ix.as<uint32_t>(), d_ix2.as<uint32_t>(), NPC,
+                                    21u + tid_bits + std::max(1u, bit_width_u64(S - 1)), st, tmp, tmp_cap)) return rc;
+            if (int rc = d_hdr2.alloc(NPCa * sizeof(ReadHdr))) return rc;
+            if (int rc = d_ptid2.alloc(NPCa * 4)) return rc;
+            if (int rc = d_pend2.alloc(NPCa * 4)) return rc;
+            if (int rc = d_pdepth2.alloc(NPCa * 2)) return rc;
+            hipLaunchKernelGGL(msnv_gather_pieces, grid_for(NPC, 256), dim3(256), 0, st, d_ix2.as<uint32_t>(), NPC, d_hdr.as<ReadHdr>(), d_ptid.as<int32_t>(), d_pend.as<int32_t>(),
+                               d_pdepth.as<uint16_t>(), d_hdr2.as<ReadHdr>(), d_ptid2.as<int32_t>(), d_pend2.as<int32_t>(), d_pdepth2.as<uint16_t>());
+            HIP_TRY(hipGetLastError());
+            permuted = true;
+        }
+    }
+    T.ms_sort += tm.stop();
+
+    // ---- what the host keeps of a sample: headers, intervals, summaries (finalize_dataset builds the tile index from them)
+    const double t_dl = now_s();
+    const ReadHdr *src_hdr = permuted ? d_hdr2.as<ReadHdr>() : d_hdr.as<ReadHdr>();
+    const int32_t *src_tid = permuted ? d_ptid2.as<int32_t>() : d_ptid.as<int32_t>(), *src_end = permuted ? d_pend2.as<int32_t>() : d_pend.as<int32_t>();
+    const uint16_t *src_depth = permuted ? d_pdepth2.as<uint16_t>() : d_pdepth.as<uint16_t>();
+    for (size_t s = 0; s < S; ++s) {
+        SampleCols &sc = ds.samples[first + s];
+        const size_t np = sp0[s + 1] - sp0[s], ni = si0[s + 1] - si0[s];
+        sc.hdr.resize(np); sc.tid.resize(np); sc.end.resize(np); sc.depth.resize(np);
+        sc.cov_tid.resize(ni); sc.cov_beg.resize(ni); sc.cov_end.resize(ni);
+        if (np) {
+            HIP_TRY(hipMemcpyAsync(sc.hdr.data(), src_hdr + sp0[s], np * sizeof(ReadHdr), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(sc.tid.data(), src_tid + sp0[s], np * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(sc.end.data(), src_end + sp0[s], np * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(sc.depth.data(), src_depth + sp0[s], np * 2, hipMemcpyDeviceToHost, st));
+        }
+        if (ni) {
+            HIP_TRY(hipMemcpyAsync(sc.cov_tid.data(), d_ctid.as<int32_t>() + si0[s], ni * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(sc.cov_beg.data(), d_cbeg.as<int32_t>() + si0[s], ni * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(sc.cov_end.data(), d_cend.as<int32_t>() + si0[s], ni * 4, hipMemcpyDeviceToHost, st));
+        }
+        const DpAcc &a = acc[s];
+        sc.on_device = true; sc.d_seq = dsts[s].seq; sc.d_qual = dsts[s].qual; sc.d_seq_bytes = piece_bytes[s] + 32;
+        sc.n_pileup_bases = a.n_bases; sc.n_pileup_reads = a.n_pile_reads;
+        sc.mm_sampled_bases = a.mm_bases; sc.mm_sampled = a.mm;
+        sc.alg_seq_bytes = a.alg_seq; sc.alg_qual_bytes = a.alg_qual; sc.alg_8d_bytes = a.alg8d; sc.alg_cigar_bytes = a.alg_cigar;
+        sc.st = msnv_sample_stats{a.total, a.unmapped, a.zeroq, a.proper, a.dup, a.any_mapped};
+    }
+    // first pileup read of every sample / of every (sample, contig): the first-line quirk of snpCall (call_vC.cpp:423)
+    for (size_t s = 0; s < S; ++s) {
+        SampleCols &sc = ds.samples[first + s];
+        if (acc[s].first_pile != ~0ull) {
+            unsigned long long key = 0; uint32_t e32 = 0;
+            HIP_TRY(hipMemcpyAsync(&key, d_key.as<unsigned long long>() + acc[s].first_pile, 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(&e32, d_end.as<uint32_t>() + acc[s].first_pile, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            const int32_t tid = (int32_t)(key >> 32), pos = (int32_t)(uint32_t)key;
+            int64_t b = pos, e = (int64_t)e32;
+            if (ds.has_bed) { b = std::max(b, ds.bed_beg[(size_t)tid]); e = std::min(e, ds.bed_end[(size_t)tid]); }
+            if (b < e) { sc.first_tid = tid; sc.first_beg = (int32_t)b; sc.first_end = (int32_t)e; }
+        }
+        if (acc[s].beyond != ~0ull) {
+            unsigned long long key = 0;
+            HIP_TRY(hipMemcpyAsync(&key, d_key.as<unsigned long long>() + acc[s].beyond, 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            sc.warned_beyond_end = true;
+            fprintf(stderr, "msnv: warning: read at %s:%d reaches the contig end in qaCompute's index space (undefined behaviour in the reference: coverageHist[-1]); "
+                            "the last position of the contig is left out of the coverage histogram\n", ds.names[(size_t)(int32_t)(key >> 32)].c_str(), (int32_t)(uint32_t)key + 1);
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    for (const DpRun &r : runs) {
+        SampleCols &sc = ds.samples[first + r.sample];
+        if (sc.first_any.empty()) { sc.first_any.assign(NC, -1); sc.first_from1.assign(NC, -1); }
+        sc.first_any[(size_t)r.tid] = r.first_any; sc.first_from1[(size_t)r.tid] = r.first_from1;
+    }
+    T.wall_download_s += now_s() - t_dl;
+    return MSNV_OK;
+}
+
+int devpack_sample_to_host(SampleCols &sc) {
+    if (!sc.on_device) return MSNV_OK;
+    const uint64_t nb = sc.d_seq_bytes;
+    sc.seq.resize(nb);
+    std::vector<uint8_t> bits((2 * nb + 7) / 8);
+    if (nb) HIP_TRY(hipMemcpy(sc.seq.data(), sc.d_seq, nb, hipMemcpyDeviceToHost));
+    if (!bits.empty()) HIP_TRY(hipMemcpy(bits.data(), sc.d_qual, bits.size(), hipMemcpyDeviceToHost));
+    // flags back to staging bytes: 0x80 is below every cutoff, 127 below none that flags a real quality (pack.cpp: pack_lowq)
+    sc.qual.resize(2 * nb);
+    for (uint64_t i = 0; i < 2 * nb; ++i) sc.qual[i] = (bits[i >> 3] >> (i & 7)) & 1u ? 0x80 : 127;
+    sc.on_device = false; sc.d_seq = nullptr; sc.d_qual = nullptr; sc.d_seq_bytes = 0;
+    return MSNV_OK;
+}
+
+int devpack_copy_columns(const SampleCols &sc, uint8_t *dst_seq, uint8_t *dst_qual_bits, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (sc.d_seq_bytes) HIP_TRY(hipMemcpyAsync(dst_seq, sc.d_seq, sc.d_seq_bytes, hipMemcpyDeviceToDevice, st));
+    const uint64_t qb = (2 * sc.d_seq_bytes + 7) / 8;
+    if (qb) HIP_TRY(hipMemcpyAsync(dst_qual_bits, sc.d_qual, qb, hipMemcpyDeviceToDevice, st));
+    return MSNV_OK;
+}
+
+int devpack_finish(msnv_dataset &ds) {
+    if (!ds.dp.ready && ds.dp.round_bufs.empty()) return MSNV_OK;
+    if (ds.ctx) HIP_TRY(hipStreamSynchronize((hipStream_t)ds.ctx->stream));
+    for (SampleCols &sc : ds.samples) { sc.d_seq = nullptr; sc.d_qual = nullptr; }
+    devpack_release(ds.dp);
+    return MSNV_OK;
+}
+
+int devpack_fill_padding(DeviceCols &d, const std::vector<uint8_t> &sample_on_device, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!d.n_reads || sample_on_device.empty()) return MSNV_OK;
+    bool any = false;
+    for (uint8_t v : sample_on_device) any |= v != 0;
+    if (!any) return MSNV_OK;
+    DevBuf flags;
+    if (int rc = flags.alloc(sample_on_device.size())) return rc;
+    HIP_TRY(hipMemcpyAsync(flags.p, sample_on_device.data(), sample_on_device.size(), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(msnv_fill_padding, grid_for(d.n_reads, 256), dim3(256), 0, st, d.hdr, (const unsigned long long *)d.s_read_base, (const unsigned long long *)d.s_seq_base,
+                       flags.as<uint8_t>(), (uint32_t)sample_on_device.size(), (unsigned long long)d.n_reads, d.ref4, d.seq);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    return MSNV_OK;
+}
+
+}  // namespace msnv

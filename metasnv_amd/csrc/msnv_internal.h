@@ -20,7 +20,7 @@ void clear_error();
 // ---------------------------------------------------------------------------------- host-stage timers (msnv.h: msnv_host_timers)
 // Cumulative microseconds since the library was loaded (or the last reset), summed over the host threads that did the work:
 // what the wall time of BAM files -> resident dataset is made of.
-enum HostTimer { HT_READ = 0, HT_INFLATE_HOST, HT_INFLATE_DEVICE_WALL, HT_PACK, HT_UPLOAD_WALL, HT_FORMAT_WALL, HT_ADD_WALL, HT_N };
+enum HostTimer { HT_READ = 0, HT_INFLATE_HOST, HT_INFLATE_DEVICE_WALL, HT_PACK, HT_UPLOAD_WALL, HT_FORMAT_WALL, HT_ADD_WALL, HT_PACK_DEVICE_WALL, HT_N };
 void host_timer_add(int which, double seconds);
 struct HostTimerScope {
     int which; double t0;

@@ -15,6 +15,7 @@
 #include <unordered_map>
 
 #include "device.h"
+#include "devpack.h"
 #if defined(__SSE2__)
 #include <emmintrin.h>
 #endif
@@ -69,10 +70,10 @@ static bool deep_runs_split() {
     const char *e = getenv("MSNV_DEEP");                     // read per dataset (tests switch it)
     return !(e && e[0] == 'w');
 }
-static void split_deep_runs(SampleCols &sc) {
+static int split_deep_runs(SampleCols &sc, int device) {
     const size_t n = sc.hdr.size();
     sc.grp.assign(n, 0);
-    if (!deep_runs_split()) return;
+    if (!deep_runs_split()) return MSNV_OK;
     struct Ev { uint32_t pos; int32_t delta; uint32_t g; };
     std::vector<Ev> ev;
     std::vector<uint32_t> cur, mx, order;
@@ -125,12 +126,16 @@ static void split_deep_runs(SampleCols &sc) {
     // of the G groups -- at G different times -- each fetched (almost) every cache line of the run (one sample at 1600x: 6.2 GB of
     // HBM reads per pass for 2.2 GB of columns).  Same pieces (bases + twice as many quality bytes, alignment padding included), new order.
     if (any_split && !(getenv("MSNV_DEEP_RELOCATE") && getenv("MSNV_DEEP_RELOCATE")[0] == '0')) {
+        if (sc.on_device) {                              // (the relocation still runs on host staging: a device-packed sample comes back for it)
+            if (int rc = dev_set_device(device)) return rc;
+            if (int rc = devpack_sample_to_host(sc)) return rc;
+        }
         std::vector<uint8_t> nseq(sc.seq.size(), 0xff), nqual(sc.qual.size(), 0);
         size_t so = 0;
         auto stored = [](uint32_t bases) { return (size_t)(((bases + 1u) / 2u + seq_align - 1u) & ~(seq_align - 1u)); };      // seq bytes of a piece with its alignment padding (pack_sample)
         for (size_t k = 0; k < n; ++k) {
             const size_t blk = stored(sc.hdr[k].cig);
-            if (so + blk > nseq.size() || 2 * (so + blk) > nqual.size()) return;       // (cannot happen: the blocks are a permutation; keep the old layout rather than write past the end)
+            if (so + blk > nseq.size() || 2 * (so + blk) > nqual.size()) return MSNV_OK;       // (cannot happen: the blocks are a permutation; keep the old layout rather than write past the end)
             memcpy(nseq.data() + so, sc.seq.data() + sc.hdr[k].seqoff, blk);
             memcpy(nqual.data() + 2 * so, sc.qual.data() + 2 * (size_t)sc.hdr[k].seqoff, 2 * blk);
             so += blk;
@@ -139,6 +144,7 @@ static void split_deep_runs(SampleCols &sc) {
         for (size_t k = 0; k < n; ++k) { sc.hdr[k].seqoff = (uint32_t)so; so += stored(sc.hdr[k].cig); }
         sc.seq.swap(nseq); sc.qual.swap(nqual);
     }
+    return MSNV_OK;
 }
 
 // Rewrites seq / qual of one sample into the dense block streams (dataset.h) and fills blk / run_*.
@@ -302,7 +308,7 @@ static void tweak_overlapping_mates(const RecView &a, uint8_t *qa, const RecView
 }
 
 // One filtered read of pass 1, kept for pass 2 (packing).
-struct KeptRead { uint64_t off; int64_t endpos; uint16_t depth_here; bool pile_ok, cov_ok; };
+struct KeptRead { uint64_t off; int64_t endpos; uint16_t depth_here; bool pile_ok, cov_ok; uint32_t idx; };      // idx: ordinal of the record in the stream
 
 // ---------------------------------------------------------------------------------- snpCall's token limit
 // snpCall copies every tab-separated field of a pileup line through a 10000-character token (call_vC.cpp:92-111,481-483):
@@ -438,7 +444,7 @@ struct NameHash {
 // pileup is counted (the overlapping-mate tweak, the token limit), on a private copy of the record stream (`patched`,
 // left empty when nothing was edited).  kept: the reads pass 2 packs, in file order.
 static int filter_and_edit(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, msnv_sample_stats &st,
-                           std::vector<KeptRead> &kept, std::vector<uint8_t> &patched, bool *cut_marks = nullptr) {
+                           std::vector<KeptRead> &kept, std::vector<uint8_t> &patched, bool *cut_marks = nullptr, uint32_t *n_records = nullptr) {
     const msnv_params &P = ds.params;
     if (cut_marks) *cut_marks = false;
     const int n_contigs = (int)ds.names.size();
@@ -461,11 +467,13 @@ static int filter_and_edit(const msnv_dataset &ds, const uint8_t *rec, uint64_t 
     std::unordered_map<NameKey, Waiting, NameHash> waiting;
     size_t waiting_sweep_at = 8192;
 
+    uint32_t rec_idx = 0xffffffffu;
     while (off < n_bytes) {
         RecView r;
         if (!rec_parse(rec + off, n_bytes - off, r)) return fail(MSNV_EFORMAT, "malformed BAM record at byte %llu", (unsigned long long)off);
         const uint64_t rec_off = off;
         off += r.size;
+        ++rec_idx;
         bool cov_ok = false;
         if (!read_stats(r, P.cov_min_mapq, st, cov_ok)) continue;                // unmapped (qaCompute.cpp:461-473)
         if (r.tid >= n_contigs) return fail(MSNV_EFORMAT, "record refers to contig %d but the header has %d", r.tid, n_contigs);
@@ -532,8 +540,9 @@ static int filter_and_edit(const msnv_dataset &ds, const uint8_t *rec, uint64_t 
             }
         }
         if (!pile_ok && !cov_ok) continue;
-        kept.push_back(KeptRead{rec_off, endpos, depth_here, pile_ok, cov_ok});
+        kept.push_back(KeptRead{rec_off, endpos, depth_here, pile_ok, cov_ok, rec_idx});
     }
+    if (n_records) *n_records = rec_idx + 1u;
     if (token_limit_in_reach) { apply_token_limit(P, rec, n_bytes, kept, mutable_qual); if (cut_marks) *cut_marks = true; }
     return MSNV_OK;
 }
@@ -554,6 +563,19 @@ int pileup_qualities(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_byte
             for (int32_t j = 0; j < r.l_seq; ++j) if (q[j] == QUAL_CUT) q[j] = 0;
         }
     }
+    return MSNV_OK;
+}
+
+// The sequential edits for the device pack (devpack.hip): verdict per record + edited qualities.
+int host_prepass(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, std::vector<uint32_t> &ovr, std::vector<uint8_t> &patched, bool &cut_marks) {
+    HostTimerScope ts(HT_PACK);
+    msnv_sample_stats st{};
+    std::vector<KeptRead> kept;
+    uint32_t n_records = 0;
+    cut_marks = false;
+    if (int rc = filter_and_edit(ds, rec, n_bytes, st, kept, patched, &cut_marks, &n_records)) return rc;
+    ovr.assign(n_records, 1u);
+    for (const KeptRead &kr : kept) ovr[kr.idx] = 1u | (kr.pile_ok ? 2u : 0u) | (kr.cov_ok ? 4u : 0u) | (uint32_t)kr.depth_here << 16;
     return MSNV_OK;
 }
 
@@ -836,12 +858,21 @@ int finalize_dataset(msnv_dataset &ds) {
     }
 
     // ---- per sample: gpos, tile overlap index; concatenate columns
-    parallel_for(S, [&](size_t s) { split_deep_runs(ds.samples[s]); });
+    const int device_id = ds.ctx ? ds.ctx->device : 0;
+    {
+        std::atomic<int> split_err{0}; std::mutex split_mu; std::string split_msg;
+        parallel_for(S, [&](size_t s) {
+            if (int rc = split_deep_runs(ds.samples[s], device_id)) { std::lock_guard<std::mutex> lk(split_mu); if (!split_err.load()) { split_msg = msnv_last_error(); split_err.store(rc); } }
+        });
+        if (split_err.load()) return fail(split_err.load(), "%s", split_msg.c_str());
+    }
     uint64_t all_pieces = 0, all_bases = 0;
     for (const SampleCols &sc : ds.samples) { all_pieces += sc.hdr.size(); all_bases += sc.n_pileup_bases; }
     const bool dense = layout_dense(all_pieces, all_bases);
     d->dense = dense;
     if (dense) {
+        // (the dense re-layout still runs on host staging: device-packed samples come back for it)
+        for (size_t s = 0; s < S; ++s) if (ds.samples[s].on_device) { if (int rc = dev_set_device(device_id)) return rc; if (int rc = devpack_sample_to_host(ds.samples[s])) return rc; }
         parallel_for(S, [&](size_t s) {
             SampleCols &sc = ds.samples[s];
             relayout_dense(sc);
@@ -853,7 +884,8 @@ int finalize_dataset(msnv_dataset &ds) {
     for (size_t s = 0; s < S; ++s) {
         bbase[s + 1] = bbase[s] + ds.samples[s].blk.size();
         rbase[s + 1] = rbase[s] + ds.samples[s].hdr.size();
-        sbase[s + 1] = sbase[s] + ((ds.samples[s].seq.size() + 15) & ~(size_t)15);
+        const size_t seq_bytes = ds.samples[s].on_device ? (size_t)ds.samples[s].d_seq_bytes : ds.samples[s].seq.size();
+        sbase[s + 1] = sbase[s] + ((seq_bytes + 15) & ~(size_t)15);
     }
     struct PairTmp { uint32_t tile, sample, lo, hi, maxd, run, grp; };
     std::vector<std::vector<PairTmp>> per_sample(S);
@@ -868,7 +900,7 @@ int finalize_dataset(msnv_dataset &ds) {
             const uint64_t gs = (uint64_t)ds.tile_base[c] * TILE + sc.hdr[i].gpos;
             sc.hdr[i].gpos = (uint32_t)gs;
             const uint32_t t = (uint32_t)(gs / TILE);
-            if (!dense) {
+            if (!dense && !sc.on_device) {                       // (device-packed samples: devpack.hip msnv_fill_padding, once the columns are in place)
                 // The alignment padding behind a piece (up to the next 16 bases) reads as the reference the kernel compares
                 // it with (N beyond the tile): msnv_pileup_tiles_narrow32 then masks mismatch flags per 16 bases, not per base.
                 const uint32_t len = sc.hdr[i].cig, stop = (len + 2u * seq_align - 1u) & ~(2u * seq_align - 1u);
@@ -1249,13 +1281,15 @@ int finalize_dataset(msnv_dataset &ds) {
         }
         if (gi != groups.size()) return fail(MSNV_EINVAL, "internal: merged groups and work items disagree");
         ds.info.bytes_headers += hm.size() * sizeof(PieceHdr);
-        if (int rc = upload_vec(&d->hdr8m, hm, &d->device_bytes, 1)) return rc;
+        d->n_hdr8m = hm.size();
+    if (int rc = upload_vec(&d->hdr8m, hm, &d->device_bytes, 1)) return rc;
         d->n_merged_groups = (uint32_t)mgroups.size();
         if (int rc = upload_vec(&d->merged_groups, mgroups, &d->device_bytes, 1)) return rc;
         if (int rc = upload_vec(&d->tile_pair_merged, tpm, &d->device_bytes)) return rc;
     }
     for (size_t wi = 0; wi < (size_t)d->n_work_narrow + d->n_work_merged; ++wi)
         if (work[wi].chunk_hi > work[wi].chunk_lo) work[wi].first = chunks[work[wi].chunk_lo];
+    d->n_chunks = chunks.size();
     if (int rc = upload_vec(&d->chunks, chunks, &d->device_bytes, 1)) return rc;
     d->n_pairs = (uint32_t)pairs.size(); d->n_work = (uint32_t)work.size();
     if (int rc = upload_vec(&d->pairs, pairs, &d->device_bytes)) return rc;
@@ -1265,12 +1299,13 @@ int finalize_dataset(msnv_dataset &ds) {
     if (int rc = upload_vec(&d->s_seq_base, sbase, &d->device_bytes)) return rc;
 
     // ---- columns
-    d->n_reads = rbase[S]; d->n_seq_bytes = sbase[S];
+    d->n_reads = rbase[S]; d->n_seq_bytes = sbase[S]; d->n_blk = bbase[S];
     if (int rc = dev_alloc((void **)&d->hdr, (rbase[S] + 1) * sizeof(ReadHdr), &d->device_bytes)) return rc;
     if (!dense && !HDR4) if (int rc = dev_alloc((void **)&d->hdr8, (rbase[S] + 1) * sizeof(PieceHdr), &d->device_bytes)) return rc;
     if (!dense && HDR4) if (int rc = dev_alloc((void **)&d->hdr4, (rbase[S] + 4) * sizeof(uint32_t), &d->device_bytes)) return rc;
     if (dense) if (int rc = dev_alloc((void **)&d->blk, (bbase[S] + 1) * sizeof(uint32_t), &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->seq, sbase[S] + 256, &d->device_bytes)) return rc;     // lanes past the end of the last piece read on
+    if (int rc = dev_memset(d->seq, 0xff, sbase[S] + 256)) return rc;                          // (the < 16 bytes between two samples' columns: defined, so that two builds of a dataset can be compared)
     // the quality column of the device is ONE BIT per base -- "below the -Q cutoff" -- at the index of the base's nibble in the seq column: the
     // cutoff is a parameter of the dataset (mpileup -Q, metaSNV.py:160-165 never changes it) and nothing else of a quality is ever looked at
     // behind the overlap tweak and the token limit, which ran on the host (pass 1 above).  1 B -> 1/8 B per base of HBM and of upload.
@@ -1303,10 +1338,13 @@ int finalize_dataset(msnv_dataset &ds) {
                     for (size_t i = 0; i < sc.hdr.size(); ++i) h8[i] = PieceHdr{(sc.hdr[i].gpos % TILE) | sc.hdr[i].cig << 11, sc.hdr[i].seqoff >> SEQ_ALIGN_LOG2};
                     rc = dev_upload(d->hdr8 + rbase[s], h8.data(), h8.size() * sizeof(PieceHdr));
                 }
-                if (!rc) rc = dev_upload(d->seq + sbase[s], sc.seq.data(), sc.seq.size());
-                if (!rc) {
-                    pack_lowq(sc.qual.data(), sc.qual.size(), ds.params.min_baseq, qbits);
-                    rc = dev_upload(d->qual + sbase[s] / 4, qbits.data(), qbits.size());      // (sbase: multiples of 16 bytes of seq = 32 flags)
+                if (!rc && sc.on_device) rc = devpack_copy_columns(sc, d->seq + sbase[s], d->qual + sbase[s] / 4, ds.ctx ? ds.ctx->stream : nullptr);      // packed on the device: HBM to HBM
+                else {
+                    if (!rc) rc = dev_upload(d->seq + sbase[s], sc.seq.data(), sc.seq.size());
+                    if (!rc) {
+                        pack_lowq(sc.qual.data(), sc.qual.size(), ds.params.min_baseq, qbits);
+                        rc = dev_upload(d->qual + sbase[s] / 4, qbits.data(), qbits.size());      // (sbase: multiples of 16 bytes of seq = 32 flags)
+                    }
                 }
                 if (rc) { std::lock_guard<std::mutex> lk(up_mu); if (!up_err.load()) { up_msg = msnv_last_error(); up_err.store(rc); } continue; }
                 // release host staging of the bulky columns; headers stay (coverage pass, results mapping)
@@ -1320,6 +1358,12 @@ int finalize_dataset(msnv_dataset &ds) {
         for (size_t t = 0; t < n_up; ++t) th.emplace_back(worker);
         for (auto &t : th) t.join();
         if (up_err.load()) return fail(up_err.load(), "%s", up_msg.c_str());
+        {   // device-packed samples: the alignment padding behind their pieces, then their round buffers and the pack tables go back
+            std::vector<uint8_t> on_dev(S, 0);
+            for (size_t s = 0; s < S; ++s) on_dev[s] = ds.samples[s].on_device ? 1 : 0;
+            if (!dense) if (int rc = devpack_fill_padding(*d, on_dev, ds.ctx ? ds.ctx->stream : nullptr)) return rc;
+            if (int rc = devpack_finish(ds)) return rc;
+        }
         for (size_t s = 0; s < S; ++s) {
             const SampleCols &sc = ds.samples[s];
             ds.info.bytes_headers += dense ? (bbase[s + 1] - bbase[s]) * sizeof(uint32_t) : sc.hdr.size() * (HDR4 ? sizeof(uint32_t) : sizeof(PieceHdr));

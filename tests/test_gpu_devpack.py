@@ -1,0 +1,192 @@
+"""The per-read stage on the device (csrc/devpack.hip) builds the same dataset as the host stage (csrc/pack.cpp), byte for byte:
+piece headers, 4-bit bases, quality flags, qaCompute intervals, and the whole tile index derived from them -- and the same
+per-sample summaries (statistics, first lines, pileup base counts).  Then both are checked against the oracle's text."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import bamtools as bt
+from metasnv_amd import core
+from parity import run_oracle, synth_case, first_diff
+
+pytestmark = pytest.mark.gpu
+
+COLUMNS = ["hdr", "hdr4", "hdr8m", "blk", "seq", "qual", "s_read_base", "s_seq_base", "ref4", "pairs", "work", "chunks", "cov_iv", "cov_pairs", "cov_work"]
+
+
+class _env:
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kw}
+        for k, v in self.kw.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _build(where, names, lengths, seqs, samples, bed=None, params=None, many=False, device_ptrs=False):
+    with _env(MSNV_PACK=where):
+        ctx = core.Context(0)
+        ds = core.Dataset(ctx, names, lengths, seqs, params)
+        if bed:
+            ds.set_bed(bed)
+        if device_ptrs:
+            # record streams already in HBM (what an all-to-all over RCCL leaves there): plain hipMalloc + hipMemcpy through the
+            # runtime the library itself is linked to -- torch in this process would bring a second HIP runtime
+            hip = C.CDLL("libamdhip64.so")
+            ptrs, sizes = [], []
+            for smp in samples:
+                a = np.ascontiguousarray(smp, dtype=np.uint8)
+                p = C.c_void_p()
+                assert hip.hipMalloc(C.byref(p), C.c_size_t(max(1, a.size))) == 0
+                if a.size:
+                    assert hip.hipMemcpy(p, C.c_void_p(a.ctypes.data), C.c_size_t(a.size), 1) == 0
+                ptrs.append(p.value); sizes.append(a.size)
+            ds.add_samples_records_device(ptrs, sizes)
+            for p in ptrs:
+                hip.hipFree(C.c_void_p(p))
+        elif many:
+            ds.add_samples_records(samples)
+        else:
+            for s in samples:
+                ds.add_sample_records(s)
+        info = ds.finalize()
+    return ctx, ds, info
+
+
+def _same_dataset(names, lengths, seqs, samples, bed=None, params=None, many=False, device_ptrs=False, check_oracle=True):
+    ch, dh, ih = _build("host", names, lengths, seqs, samples, bed, params)
+    cd, dd, idv = _build("device", names, lengths, seqs, samples, bed, params, many=many, device_ptrs=device_ptrs)
+    try:
+        for k in ("n_reads", "n_reads_pileup", "n_pileup_bases", "bytes_headers", "bytes_cigar", "bytes_seq", "bytes_qual", "n_tiles", "n_pairs", "n_work",
+                  "allele_planes", "sampled_mismatch_ppm"):
+            assert ih[k] == idv[k], (k, ih[k], idv[k])
+        for col in COLUMNS:
+            a, b = dh.column(col), dd.column(col)
+            assert a.size == b.size, (col, a.size, b.size)
+            if not np.array_equal(a, b):
+                i = int(np.flatnonzero(a != b)[0])
+                raise AssertionError("column %s differs at byte %d of %d: host %s device %s" % (col, i, a.size, a[max(0, i - 4):i + 12].tolist(), b[max(0, i - 4):i + 12].tolist()))
+        for s in range(len(samples)):
+            assert np.array_equal(dh.sample_stats(s), dd.sample_stats(s)), s
+        assert dh.first_line() == dd.first_line()
+        if not bed:                                               # (the per-contig first lines are defined for a whole-BAM dataset only)
+            fa, fb = dh.first_lines(), dd.first_lines()
+            assert np.array_equal(fa[0], fb[0]) and np.array_equal(fa[1], fb[1])
+        dd.run(); dh.run()
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            out = []
+            for tag, ds in (("h", dh), ("d", dd)):
+                pp, ip = os.path.join(td, "c" + tag), os.path.join(td, "i" + tag)
+                ds.write_calls(pp, ip)
+                out.append((open(pp).read(), open(ip).read()))
+        assert out[0] == out[1]
+        if check_oracle:
+            orac = run_oracle(names, lengths, seqs, samples, bed=bed, params=params)
+            assert out[1][0] == orac[0], first_diff(out[1][0], orac[0])
+            assert out[1][1] == orac[1], first_diff(out[1][1], orac[1])
+        return idv
+    finally:
+        dh.close(); dd.close(); ch.close(); cd.close()
+
+
+def test_synthetic_cohort_same_columns():
+    syn, samples = synth_case(n_species=3, contig_len=9000, n_samples=10, mean_cov=12.0, snv_density=0.02, error_rate=0.004, lowercase_ref=1, seed=21)
+    info = _same_dataset(syn.names, syn.lengths, syn.seqs, samples)
+    assert info["n_pileup_bases"] > 100000
+
+
+def test_many_streams_one_round_and_device_pointers():
+    syn, samples = synth_case(n_species=2, contig_len=7000, n_samples=12, mean_cov=8.0, snv_density=0.02, seed=22)
+    _same_dataset(syn.names, syn.lengths, syn.seqs, samples, many=True)
+    _same_dataset(syn.names, syn.lengths, syn.seqs, samples, device_ptrs=True, check_oracle=False)
+
+
+def test_bed_split_and_thresholds():
+    syn, samples = synth_case(n_species=3, contig_len=5000, n_samples=5, mean_cov=15.0, snv_density=0.03, frac_absent=0.0, seed=23)
+    _same_dataset(syn.names, syn.lengths, syn.seqs, samples, bed=[(0, 1, 5000), (2, 1, 5000)])
+    for kw in (dict(min_baseq=0), dict(min_baseq=35), dict(flag_filter=0, min_mapq=1), dict(count_orphans=1), dict(min_baseq=200)):
+        _same_dataset(syn.names, syn.lengths, syn.seqs, samples, params=core.default_params(**kw), check_oracle=kw.get("min_baseq", 0) < 128)
+
+
+def _edge_reads():
+    ref = ("ACGTTGCAAGGCTTAACCGGTTAACGTAGCTAGCTAGGATCCGATTACAGATTACAGGCATTACGGATCACGATCGACTAGCTAGCATCGACTGACTAGC" * 60)[:5200]
+
+    def sub(i, n, mut=None):
+        s = list(ref[i:i + n])
+        for k, b in (mut or {}).items():
+            s[k] = b
+        return "".join(s)
+    other = lambda c: "A" if c != "A" else "C"
+    s1, s2, s3 = [], [], []
+    for k in range(6):                                            # reads straddling the tile boundary at 2048, and one that spans two boundaries
+        s1.append(bt.make_record(0, 2000 + k, "100M", sub(2000 + k, 100, {50 - k: other(ref[2050])}), name="a%d" % k))
+    s1.append(bt.make_record(0, 2040, "30M2100D40M", sub(2040, 30) + sub(4170, 40), name="span"))
+    s1.append(bt.make_record(0, 4090, "100M", sub(4090, 100), name="late"))
+    # '=' / X ops, soft and hard clips, insertion, deletion, padding, odd starts, odd lengths, '=' in the SEQ field
+    s2.append(bt.make_record(0, 100, "10=5X10=", sub(100, 25, {10: other(ref[110]), 11: other(ref[111])}), name="b0"))
+    s2.append(bt.make_record(0, 100, "5S20M", "NNNNN" + sub(100, 20, {10: other(ref[110])}), name="b1"))
+    s2.append(bt.make_record(0, 100, "3H21M2H", sub(100, 21, {10: other(ref[110])}), name="b2"))
+    s2.append(bt.make_record(0, 100, "8M3I12M", sub(100, 8) + "GGG" + sub(108, 12, {2: other(ref[110])}), name="b3"))
+    s2.append(bt.make_record(0, 100, "8M2D13M", sub(100, 8) + sub(110, 13, {0: other(ref[110])}), name="b4"))
+    s2.append(bt.make_record(0, 100, "8M1P12M", sub(100, 20, {10: other(ref[110])}), name="b5"))
+    s2.append(bt.make_record(0, 101, "1S7M", "T" + "=" * 3 + sub(104, 4), name="eq"))
+    for k in range(5):
+        s2.append(bt.make_record(0, 105, "11M", sub(105, 11), qual=[5] * 11, name="lowq%d" % k))
+    s2.append(bt.make_record(0, 300, "300M", sub(300, 300), name="long"))                     # three pieces
+    s2.append(bt.make_record(0, 5150, "60M", sub(5150, 50) + "ACGTACGTAC", name="overhang"))    # runs past the contig end (5200)
+    # filtered reads: duplicate, secondary, QC fail, MAPQ 0, orphan, unmapped with a position
+    s3.append(bt.make_record(0, 500, "50M", sub(500, 50), flag=0x400, name="dup"))
+    s3.append(bt.make_record(0, 500, "50M", sub(500, 50), flag=0x100, name="sec"))
+    s3.append(bt.make_record(0, 500, "50M", sub(500, 50), flag=0x200, name="qcf"))
+    s3.append(bt.make_record(0, 501, "50M", sub(501, 50), mapq=0, name="mq0"))
+    s3.append(bt.make_record(0, 502, "50M", sub(502, 50), flag=0x1, name="orphan"))
+    s3.append(bt.make_record(0, 503, "*", "", flag=0x4, name="unm"))
+    s3.append(bt.make_record(0, 504, "50M", sub(504, 50, {7: other(ref[511])}), name="plain"))
+    s3.append(bt.make_record(1, 10, "40M", "ACGT" * 10, name="othercontig"))
+    s3.append(bt.make_record(-1, -1, "*", "", flag=0x4, name="unplaced"))
+    return ["edge", "tiny"], [len(ref), 60], [ref, "ACGT" * 15], [bt.records(*s1), bt.records(*s2), bt.records(*s3), bt.records()]
+
+
+def test_edge_case_records_same_columns():
+    names, lengths, seqs, samples = _edge_reads()
+    _same_dataset(names, lengths, seqs, samples, params=core.default_params(min_coverage=1, calling_threshold=1))
+
+
+def test_paired_reads_take_the_host_prepass_and_agree():
+    syn, samples = synth_case(n_species=2, contig_len=6000, n_samples=6, mean_cov=14.0, snv_density=0.02, frac_paired=0.6, seed=24)
+    core.host_timers(reset=True)
+    _same_dataset(syn.names, syn.lengths, syn.seqs, samples)
+
+
+def test_errors_carry_the_host_stage_codes():
+    from metasnv_amd import _lib
+    ref = "ACGT" * 100
+    good = bt.make_record(0, 10, "20M", ref[10:30], name="g")
+    unsorted_stream = bt.records(bt.make_record(0, 50, "20M", ref[50:70], name="x"), good)
+    truncated = bt.records(good)[:-5]
+    ctx = core.Context(0)
+    try:
+        for bad in (unsorted_stream, truncated):
+            for where in ("host", "device"):
+                with _env(MSNV_PACK=where):
+                    ds = core.Dataset(ctx, ["c"], [400], [ref])
+                    with pytest.raises(_lib.MsnvError) as e:
+                        ds.add_sample_records(bad)
+                    assert e.value.code == _lib.EFORMAT, where
+                    ds.close()
+    finally:
+        ctx.close()
