@@ -385,6 +385,7 @@ def main():
     t0 = time.perf_counter()
     info = ds.finalize()
     t_up = time.perf_counter() - t0
+    pack = ds.pack_stats()          # the per-read stage as kernels (csrc/devpack.hip): all zero under MSNV_PACK=host
 
     def barrier():
         if dist is not None:
@@ -578,8 +579,28 @@ def main():
                                        "per-sample pass 18 % (profiles/r03_pmc.json, profiles/r03z_ab_ablations_qbits.txt, DESIGN.md section 8)"},
             "positions_per_s": info["n_positions"] * world * a.steps / dt_max,
             "kernel_ms": {"pileup": k_ms, "pipeline_total": sum(ms_total) / len(ms_total)},
-            "host": {"pack_s": t_pack, "finalize_upload_s": t_up, "device_bytes": info["device_bytes"]},
+            "host": {"pack_s": t_pack, "finalize_upload_s": t_up, "device_bytes": info["device_bytes"],
+                     "what": "pack_s = wall seconds of building the samples: %s" % ("synthetic record streams made by the host threads, uploaded, and parsed / filtered / cut into pieces by "
+                             "kernels (csrc/devpack.hip)" if pack["records"] else "synthetic record streams made AND packed by the host threads (MSNV_PACK=host, csrc/pack.cpp)")},
         }
+        if pack["records"]:
+            # Second roofline block: the timed region starts at RAW alignment records resident in HBM -- the SURVEY 8d bytes and then some
+            # (36-byte fixed part, read name, CIGAR, 4-bit bases, one byte of quality per base) -- and ends at the calls: the per-read stage's
+            # kernels (HIP events on their stream, summed over the rounds of this dataset) + one pileup kernel launch / one whole pass.
+            pk = pack["scan_ms"] + pack["measure_ms"] + pack["depth_ms"] + pack["emit_ms"] + pack["tile_sort_ms"]
+            line["roofline_from_records"] = {
+                "bound": "hbm", "kernel": "msnv_scan_records + msnv_measure_reads + depth (rocPRIM sort / scans) + msnv_emit_headers + msnv_emit_pieces + tile-order sort, then msnv_pileup_tiles_narrow32",
+                "timed_region": "raw BAM records in HBM -> packed columns (once per dataset) -> one pileup kernel launch",
+                "achieved": alg / ((pk + k_ms) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / ((pk + k_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch": alg, "record_bytes_resident": int(pack["record_bytes"]),
+                "pack_kernels_ms": pk, "pileup_kernel_ms": k_ms, "whole_pass_ms": sum(ms_total) / len(ms_total),
+                "pack_stage_ms": {k: pack[k] for k in ("scan_ms", "measure_ms", "depth_ms", "emit_ms", "tile_sort_ms")},
+                "pack_alone": {"achieved_on_record_bytes": pack["record_bytes"] / (pk * 1e-3) / 1e9 if pk else None, "unit": "GB/s",
+                               "frac": pack["record_bytes"] / (pk * 1e-3) / 1e9 / HBM_PEAK_GBS if pk else None,
+                               "Gbases_per_s": bases / (pk * 1e-3) / 1e9 if pk else None},
+                "records": int(pack["records"]), "pieces": int(pack["pieces"]), "samples_through_the_host_prepass": int(pack["prepass_samples"]),
+                "transfers_wall_s": {"upload_of_host_made_streams": pack["upload_wall_s"], "download_of_headers_and_intervals": pack["download_wall_s"],
+                                     "host_prepass": pack["host_prepass_wall_s"]}}
         if overlapped:
             line["overlapped_passes"] = overlapped
         if cov_extra:

@@ -176,6 +176,15 @@ class Dataset:
         check(lib.msnv_dataset_info_get(self._h, C.byref(i)))
         return {k: getattr(i, k) for k, _ in DatasetInfo._fields_}
 
+    PACK_STATS = ["scan_ms", "measure_ms", "depth_ms", "emit_ms", "tile_sort_ms", "upload_wall_s", "download_wall_s", "host_prepass_wall_s",
+                  "record_bytes", "records", "pieces", "prepass_samples", "scan_segments_redone"]
+
+    def pack_stats(self):
+        """Cost of the per-read stage on the device so far (msnv_dataset_pack_stats); all zero for a host-packed dataset."""
+        a = (C.c_double * len(self.PACK_STATS))()
+        check(lib.msnv_dataset_pack_stats(self._h, a, len(self.PACK_STATS)))
+        return dict(zip(self.PACK_STATS, [float(x) for x in a]))
+
     def column(self, name):
         """Bytes of a device column / index table of the finalized dataset (msnv_dataset_fetch_column) as a uint8 array."""
         n = C.c_uint64()

@@ -776,6 +776,18 @@ extern "C" int msnv_dataset_finalize(msnv_dataset *ds) {
     catch (const std::exception &e) { return fail(MSNV_ENOMEM, "building the device dataset failed: %s", e.what()); }
 }
 
+// What the device pack of this dataset cost so far (cumulative over its rounds; devpack.hip): kernel milliseconds by stage (HIP events on the
+// context's stream), wall seconds of the transfers and of the host pre-pass, and counts.
+extern "C" int msnv_dataset_pack_stats(const msnv_dataset *ds, double *out, int32_t n) {
+    clear_error();
+    if (!ds || !out || n < 0) return fail(MSNV_EINVAL, "msnv_dataset_pack_stats: bad argument");
+    const DevPackTables &t = ds->dp;
+    const double v[MSNV_PACK_STATS] = {t.ms_scan, t.ms_measure, t.ms_depth, t.ms_emit, t.ms_sort, t.wall_upload_s, t.wall_download_s, t.wall_prepass_s,
+                                       (double)t.raw_bytes, (double)t.n_records, (double)t.n_pieces, (double)t.n_prepass_samples, (double)t.n_scan_redone};
+    for (int i = 0; i < n; ++i) out[i] = i < MSNV_PACK_STATS ? v[i] : 0.0;
+    return MSNV_OK;
+}
+
 // Inspection hook (tests/test_gpu_devpack.py: the device pack and the host pack build the same dataset): the bytes of one device
 // column or index table of a finalized dataset.
 extern "C" int msnv_dataset_fetch_column(msnv_dataset *ds, const char *name, uint8_t *out, uint64_t capacity, uint64_t *n_bytes) {

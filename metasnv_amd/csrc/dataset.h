@@ -121,10 +121,11 @@ struct DevPackTables {
     uint32_t *pref4 = nullptr;        // nt16 codes of the FASTA records of the selected contigs, 8 per word, contig c from nibble pref_off[c]
     uint64_t  pref_words = 0;
     std::vector<void *> round_bufs;   // packed seq / quality-bit buffers of the rounds (SampleCols::d_seq / d_qual point into them): freed by finalize
+    std::vector<std::pair<void *, uint64_t>> scratch;   // per-round work buffers, kept (grow-only) from round to round: {pointer, capacity}
     bool      ready = false;
     // cumulative device-pack accounting (msnv_host_timers: pack_device_wall_s; msnv_devpack_stats)
     double    ms_scan = 0, ms_measure = 0, ms_depth = 0, ms_emit = 0, ms_sort = 0, wall_upload_s = 0, wall_download_s = 0, wall_prepass_s = 0;
-    uint64_t  raw_bytes = 0, n_records = 0, n_pieces = 0, n_prepass_samples = 0;
+    uint64_t  raw_bytes = 0, n_records = 0, n_pieces = 0, n_prepass_samples = 0, n_scan_redone = 0;
 };
 
 

@@ -64,7 +64,6 @@ enum : uint32_t { ERR_MALFORMED = 1, ERR_TID = 2, ERR_UNSORTED = 3, ERR_QLEN = 4
 enum : uint8_t { RF_PILE = 1, RF_COV = 2, RF_MAPPED = 4 };
 enum : uint32_t { NEED_CAP = 1, NEED_TOKEN = 2 };
 
-__device__ __forceinline__ uint32_t ld16(const uint8_t *p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }
 __device__ __forceinline__ uint32_t ld32(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 __device__ __forceinline__ uint64_t ld64(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 
@@ -111,49 +110,115 @@ __device__ __forceinline__ unsigned long long wave_min(unsigned long long v) {
 
 // ------------------------------------------------------------------------------------------ record boundaries
 // The records of a BAM are a chain: the next one starts block_size + 4 bytes behind this one (qaCompute.cpp:441 reads them with sam_read1
-// one at a time).  One wavefront per stream stages 16 KB windows of it in LDS (one coalesced sweep) and walks the chain there: ~50 ns a
-// record instead of a dependent HBM access each.  Streams run in parallel.
+// one at a time).  A stream is cut into segments of MSNV_SCAN_SEG_KB (256 KB); one wavefront per segment stages 16 KB windows of it in LDS
+// (sixteen 16-byte loads per lane in flight, the next window fetched while this one is walked) and walks the chain there.  Where does the
+// chain enter a segment that is not a stream's first?  The wavefront looks for the first offset whose 36 header bytes are those of a
+// plausible record (sizes consistent, contig ids in range) and whose two successors are too -- a GUESS, 64 offsets tested per step --
+// and the host then checks every seam: a segment's walk must end exactly where the next segment's began.  Accepted seams make the
+// concatenated chain the true one by induction from offset 0; a segment that guessed wrong is walked again from the true entry point
+// (never seen on real streams; tests force it).
 constexpr uint32_t SCAN_WIN = 16384;
-__global__ __launch_bounds__(64) void msnv_scan_records(const uint8_t *raw, const unsigned long long *s_beg, const unsigned long long *s_len, const unsigned long long *cap_base,
-                                                        unsigned long long *tmp_off, uint32_t *n_rec, unsigned long long *bad_off) {
-    __shared__ uint4 win[SCAN_WIN / 16 + 1];
-    const uint32_t s = blockIdx.x, lane = threadIdx.x;
-    const uint8_t *base = raw + s_beg[s];                        // 16-byte aligned, 64 readable bytes behind the stream (round buffer)
-    const unsigned long long n = s_len[s];
-    unsigned long long off = 0, wlo = 0, whi = 0, bad = ~0ull;
-    unsigned long long *out = tmp_off + cap_base[s];
-    uint32_t cnt = 0;
-    const uint32_t *w32 = reinterpret_cast<const uint32_t *>(win);
-    while (off < n) {
-        if (n - off < 36) { bad = off; break; }
-        if (off + 4 > whi) {
-            wlo = off & ~15ull;
-            const unsigned long long left = (n - wlo + 15) & ~15ull;
-            const uint32_t want = (uint32_t)(left < SCAN_WIN ? left : SCAN_WIN);
-            __syncthreads();
-            for (uint32_t k = lane; k < want / 16; k += 64) win[k] = *reinterpret_cast<const uint4 *>(base + wlo + 16ull * k);
-            __syncthreads();
-            whi = wlo + want;
-        }
-        const uint32_t o = (uint32_t)(off - wlo);
-        const uint32_t lo = w32[o >> 2], hi = w32[(o >> 2) + 1];
-        const uint32_t bs = __builtin_amdgcn_alignbyte(hi, lo, o & 3u);
-        if ((int32_t)bs < 32 || (unsigned long long)bs + 4 > n - off) { bad = off; break; }
-        if (lane == 0) out[cnt] = off;
-        ++cnt;
-        off += 4ull + bs;
-    }
-    if (lane == 0) { n_rec[s] = cnt; bad_off[s] = bad; }
+struct ScanSeg { unsigned long long beg, end, s_end, start, out_base; };     // [beg, end) of the round buffer, the stream's end, forced entry point or ~0 (search), first slot of tmp_off
+struct ScanOut { unsigned long long first, stop, bad; uint32_t cnt, pad; };  // entry point used (~0: none found), where the walk stopped (first record start >= end), malformed chain at (~0: none)
+
+__device__ __forceinline__ uint32_t lds_u32(const uint32_t *w32, uint32_t o) { return __builtin_amdgcn_alignbyte(w32[(o >> 2) + 1], w32[o >> 2], o & 3u); }
+// plausibility of a record header at absolute offset o (fields from global memory, unaligned)
+__device__ __forceinline__ bool plausible_at(const uint8_t *raw, unsigned long long o, unsigned long long s_end, int n_contigs, uint32_t &bs_out) {
+    if (s_end - o < 36) return false;
+    const Rec r = rec_load(raw + o, s_end - o);
+    bs_out = r.bs;
+    return r.ok && r.tid >= -1 && r.tid < n_contigs && r.pos >= -1 && r.l_name >= 1 && r.mtid >= -1 && r.mtid < n_contigs && r.mpos >= -1 && r.bs < (1u << 28);
 }
 
-__global__ void msnv_compact_offsets(const unsigned long long *tmp_off, const unsigned long long *cap_base, const uint32_t *rec_base, const unsigned long long *s_beg,
-                                     unsigned long long *rec_off, uint16_t *rec_sample) {
-    const uint32_t s = blockIdx.y;
-    const uint32_t n = rec_base[s + 1] - rec_base[s];
-    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
-        rec_off[rec_base[s] + k] = s_beg[s] + tmp_off[cap_base[s] + k];
-        rec_sample[rec_base[s] + k] = (uint16_t)s;
+__global__ __launch_bounds__(64) void msnv_scan_segments(const uint8_t *raw, const ScanSeg *segs, uint32_t n_segs, int n_contigs, unsigned long long *tmp_off, ScanOut *outs) {
+    __shared__ uint4 win[SCAN_WIN / 16 + 1];
+    __shared__ unsigned long long obuf[64];
+    const uint32_t sg = blockIdx.x, lane = threadIdx.x;
+    if (sg >= n_segs) return;
+    const ScanSeg S = segs[sg];
+    const uint32_t *w32 = reinterpret_cast<const uint32_t *>(win);
+    unsigned long long wlo = 0, whi = 0;                         // window = [wlo, whi) of the round buffer, wlo on 16 bytes
+    unsigned long long plo = ~0ull, phi = 0;                     // the prefetched window (in registers)
+    uint4 pre[16];
+    auto fetch = [&](unsigned long long lo, unsigned long long &hi_out) {   // 16 KB from lo (on 16 bytes) into registers, clipped to the stream (+ 16 bytes: the round buffer has slack)
+        const unsigned long long lim = (S.s_end + 15) & ~15ull;
+        const unsigned long long hi = lo + SCAN_WIN < lim ? lo + SCAN_WIN : lim;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const unsigned long long a = lo + 16ull * (64u * k + lane);
+            pre[k] = a < hi ? *reinterpret_cast<const uint4 *>(raw + a) : make_uint4(0, 0, 0, 0);
+        }
+        hi_out = hi;
+    };
+    auto commit = [&]() {                                        // registers -> LDS
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) win[64 * k + lane] = pre[k];
+        __syncthreads();
+    };
+    auto need = [&](unsigned long long from, unsigned long long upto) {     // make [from, upto) readable from LDS (upto - from <= a few hundred bytes)
+        if (from >= wlo && upto <= whi) return;
+        const unsigned long long lo = from & ~15ull;
+        if (!(plo != ~0ull && lo >= plo && upto <= phi)) { plo = lo; fetch(plo, phi); }
+        commit();
+        wlo = plo; whi = phi;
+        plo = whi >= 16 ? whi - 16 : 0;                          // the chain enters the next window within its first 16 bytes, unless a record jumps over it
+        if (plo < ((S.s_end + 15) & ~15ull)) fetch(plo, phi); else plo = ~0ull;
+    };
+    // ---- entry point
+    unsigned long long first = S.start;
+    if (first == ~0ull) {
+        for (unsigned long long base = S.beg; base < S.end && first == ~0ull; base += 64) {
+            const unsigned long long o = base + lane;
+            const unsigned long long upto = base + 64 + 36 < S.s_end ? base + 64 + 36 : S.s_end;
+            need(base, upto);
+            bool ok = o < S.end && S.s_end - o >= 36;
+            uint32_t bs = 0;
+            if (ok) {
+                const uint32_t b = (uint32_t)(o - wlo);
+                bs = lds_u32(w32, b);
+                const int32_t tid = (int32_t)lds_u32(w32, b + 4), pos = (int32_t)lds_u32(w32, b + 8);
+                const uint32_t w = lds_u32(w32, b + 12), fn = lds_u32(w32, b + 16);
+                const int32_t l_seq = (int32_t)lds_u32(w32, b + 20), mtid = (int32_t)lds_u32(w32, b + 24), mpos = (int32_t)lds_u32(w32, b + 28);
+                const uint32_t l_name = w & 0xffu, n_cigar = fn & 0xffffu;
+                const unsigned long long needb = 36ull + l_name + 4ull * n_cigar + ((unsigned long long)(uint32_t)l_seq + 1) / 2 + (unsigned long long)(uint32_t)l_seq;
+                ok = (int32_t)bs >= 32 && bs < (1u << 28) && (unsigned long long)bs + 4 <= S.s_end - o && tid >= -1 && tid < n_contigs && pos >= -1 && l_name >= 1 &&
+                     l_seq >= 0 && needb <= (unsigned long long)bs + 4 && mtid >= -1 && mtid < n_contigs && mpos >= -1;
+            }
+            if (ok) {                                            // its two successors (global memory: few lanes get here)
+                unsigned long long o2 = o + 4ull + bs;
+                for (int d = 0; d < 2 && ok && o2 < S.s_end; ++d) { uint32_t b2 = 0; ok = plausible_at(raw, o2, S.s_end, n_contigs, b2); o2 += 4ull + b2; }
+            }
+            const unsigned long long m = __ballot(ok);
+            if (m) first = base + (unsigned long long)__builtin_ctzll(m);
+        }
     }
+    // ---- walk
+    unsigned long long off = first, bad = ~0ull, stop = ~0ull;
+    unsigned long long *out = tmp_off + S.out_base;
+    uint32_t cnt = 0;
+    if (first != ~0ull) {
+        while (off < S.end) {
+            if (S.s_end - off < 36) { bad = off; break; }
+            need(off, off + 4);
+            const uint32_t bs = lds_u32(w32, (uint32_t)(off - wlo));
+            if ((int32_t)bs < 32 || (unsigned long long)bs + 4 > S.s_end - off) { bad = off; break; }
+            if (lane == 0) obuf[cnt & 63u] = off;
+            ++cnt;
+            if ((cnt & 63u) == 0u) { __syncthreads(); out[cnt - 64u + lane] = obuf[lane]; __syncthreads(); }
+            off += 4ull + bs;
+        }
+        stop = off;
+        __syncthreads();
+        if (lane < (cnt & 63u)) out[(cnt & ~63u) + lane] = obuf[lane];
+    }
+    if (lane == 0) outs[sg] = ScanOut{first, stop, bad, cnt, 0u};
+}
+
+struct CompactSeg { unsigned long long src; uint32_t dst, cnt, sample, pad; };
+__global__ void msnv_compact_offsets(const unsigned long long *tmp_off, const CompactSeg *segs, unsigned long long *rec_off, uint16_t *rec_sample) {
+    const CompactSeg c = segs[blockIdx.x];
+    for (uint32_t k = threadIdx.x; k < c.cnt; k += blockDim.x) { rec_off[c.dst + k] = tmp_off[c.src + k]; rec_sample[c.dst + k] = (uint16_t)c.sample; }
 }
 
 // ------------------------------------------------------------------------------------------ per-record measure
@@ -324,29 +389,39 @@ __global__ void msnv_run_flags(const uint32_t *pl, uint32_t n_pile, const uint16
     if (!first) { const uint32_t j = pl[r - 1]; first = rec_sample[i] != rec_sample[j] || (r_key[i] >> 32) != (r_key[j] >> 32); }
     rf[r] = first ? 1u : 0u;
 }
-__global__ void msnv_depth_keys(const uint32_t *pl, uint32_t n_pile, const uint32_t *rf, const uint32_t *run_incl, const uint32_t *r_end, const uint32_t *r_maxc,
-                                unsigned long long *keys, uint32_t *vals, uint32_t *maxc_rank, uint32_t *run_first, uint32_t *run_f1) {
+// keys of the merged list: entry r = the START of pileup read r, entry n_pile + r = its END; inside a run, ends sort before starts of the same value
+// (a read that ends where this one starts is gone)
+__global__ void msnv_depth_keys(const uint32_t *pl, uint32_t n_pile, const uint32_t *rf, const uint32_t *run_incl, const unsigned long long *r_key, const uint32_t *r_end,
+                                const uint32_t *r_maxc, unsigned long long *keys, uint32_t *vals, uint32_t *maxc_rank, uint32_t *run_first, uint32_t *run_f1) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_pile) { if (r == n_pile) maxc_rank[r] = 0; return; }
     const uint32_t i = pl[r], g = run_incl[r] - 1u;
-    keys[r] = (unsigned long long)g << 32 | r_end[i];
-    vals[r] = r_maxc[i]; maxc_rank[r] = r_maxc[i];
+    const uint32_t pos = (uint32_t)r_key[i] & 0x7fffffffu, end = r_end[i] < 0x7fffffffu ? r_end[i] : 0x7fffffffu;
+    keys[r] = (unsigned long long)g << 32 | (pos << 1 | 1u); vals[r] = r;
+    keys[n_pile + r] = (unsigned long long)g << 32 | (end << 1); vals[n_pile + r] = n_pile + r;
+    maxc_rank[r] = r_maxc[i];
     if (rf[r]) { run_first[g] = r; run_f1[g] = 0xffffffffu; }
 }
-__global__ void msnv_depth(const uint32_t *pl, uint32_t n_pile, uint32_t n_runs, const uint32_t *run_incl, const uint32_t *run_first, const unsigned long long *skeys,
-                           const unsigned long long *S, const unsigned long long *Pm, const unsigned long long *r_key, const uint32_t *r_end, const uint16_t *rec_sample,
-                           const uint32_t *ovr, DpParams P, uint16_t *r_depth, uint32_t *run_f1, DpAcc *acc) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_pile) return;
-    const uint32_t i = pl[r], g = run_incl[r] - 1u;
-    const uint32_t lo = run_first[g], hi = g + 1 < n_runs ? run_first[g + 1] : n_pile;
-    const unsigned long long target = (unsigned long long)g << 32 | (uint32_t)r_key[i];     // ends <= this read's start
-    uint32_t a = lo, b = hi;
-    while (a < b) { const uint32_t m = a + (b - a) / 2; if (skeys[m] <= target) a = m + 1; else b = m; }
-    const uint32_t gone = a - lo;
+__global__ void msnv_depth_endchars(const uint32_t *svals, uint32_t n_pile, const uint32_t *maxc_rank, uint32_t *ev) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q > 2u * n_pile) return;
+    const uint32_t v = q < 2u * n_pile ? svals[q] : 0u;
+    ev[q] = (q < 2u * n_pile && v >= n_pile) ? maxc_rank[v - n_pile] : 0u;
+}
+__global__ void msnv_depth(const uint32_t *pl, uint32_t n_pile, const uint32_t *svals, const uint32_t *run_incl, const uint32_t *run_first, const unsigned long long *E,
+                           const unsigned long long *Pm, const unsigned long long *r_key, const uint32_t *r_end, const uint16_t *rec_sample, const uint32_t *ovr, DpParams P, uint16_t *r_depth, uint32_t *run_f1,
+                           DpAcc *acc) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= 2u * n_pile) return;
+    const uint32_t r = svals[q];
+    if (r >= n_pile) return;                                     // an end
+    const uint32_t i = pl[r], g = run_incl[r] - 1u, lo = run_first[g];
+    const uint32_t gone = q - lo - r;                            // entries of the run before q = (r - lo) starts + the ends at or before this start
     const uint32_t depth = r - lo + 1u - gone;
-    const unsigned long long chars = (Pm[r + 1] - Pm[lo]) - (S[a] - S[lo]);
-    if (r_end[i] > 1u) atomicMin(&run_f1[g], r);
+    const unsigned long long chars = (Pm[r + 1] - Pm[lo]) - (E[q] - E[2u * lo]);
+    // first read of the run whose end lies beyond position 1 (the first line under metaSNV's `name 1 LEN` split): a read that starts at
+    // position >= 1 always qualifies, so only the reads at position 0 and the first one behind them can be it -- a handful of atomics per run
+    if (r_end[i] > 1u && (r == lo || (uint32_t)r_key[i] == 0u || (uint32_t)r_key[pl[r - 1]] == 0u)) atomicMin(&run_f1[g], r);
     const uint32_t ov = ovr ? ovr[i] : 0u;
     if (ov & 1u) { r_depth[i] = (uint16_t)(ov >> 16); return; }
     r_depth[i] = (uint16_t)(depth < 0xffffu ? depth : 0xffffu);
@@ -370,10 +445,12 @@ __global__ void msnv_run_table(const uint32_t *pl, uint32_t n_runs, const uint32
 }
 
 // ------------------------------------------------------------------------------------------ headers and intervals
+// where a piece's bases and qualities lie in the round buffer, and its reference: everything msnv_emit_pieces needs without going back to the record
+struct PieceSrc { unsigned long long seq, qual, ref_nib; uint32_t q0, ref_left; uint32_t sample, pad; };   // ref_nib: nibble index into pref4 of the piece's first position (~0: no FASTA); ref_left: FASTA characters from there
 __global__ __launch_bounds__(256) void msnv_emit_headers(const uint8_t *raw, const unsigned long long *rec_off, const uint16_t *rec_sample, uint32_t n_rec, const DpContig *ctg,
                                                          const uint8_t *r_flags, const uint16_t *r_depth, const uint32_t *pbase, const unsigned long long *sbase,
                                                          const uint32_t *ibase, const unsigned long long *samp_sbase0,
-                                                         ReadHdr *hdr, int32_t *ptid, int32_t *pend, uint16_t *pdepth, uint32_t *psrc_rec, uint32_t *psrc_q0,
+                                                         ReadHdr *hdr, int32_t *ptid, int32_t *pend, uint16_t *pdepth, PieceSrc *psrc,
                                                          int32_t *cov_tid, int32_t *cov_beg, int32_t *cov_end) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rec) return;
@@ -382,8 +459,9 @@ __global__ __launch_bounds__(256) void msnv_emit_headers(const uint8_t *raw, con
     const uint8_t *p = raw + rec_off[i];
     const Rec r = rec_load(p, ~0ull);
     const uint32_t s = rec_sample[i];
+    const DpContig c = ctg[r.tid];
     if (f & RF_COV) {                                                                       // qaCompute.cpp:530-552
-        const long long L = ctg[r.tid].len;
+        const long long L = c.len;
         long long pp = (long long)r.pos + 1;
         uint32_t k = 0, w = ibase[i];
         if (r.n_cigar > 0) { const uint32_t t = ld32(r.cigar) & 15u; if (t == C_S || t == C_H) k = 1; }
@@ -401,6 +479,7 @@ __global__ __launch_bounds__(256) void msnv_emit_headers(const uint8_t *raw, con
     unsigned long long so = sbase[i] - samp_sbase0[s];
     long long rp = r.pos, q = 0;
     const uint16_t depth = r_depth[i];
+    const unsigned long long seq_abs = (unsigned long long)(r.seq - raw), qual_abs = (unsigned long long)(r.qual - raw);
     for (uint32_t k = 0; k < r.n_cigar; ++k) {
         const uint32_t cg = ld32(r.cigar + 4ull * k), t = cg & 15u, l = cg >> 4;
         if (cg_match(t)) {
@@ -410,7 +489,13 @@ __global__ __launch_bounds__(256) void msnv_emit_headers(const uint8_t *raw, con
                 n = n < to_tile ? n : to_tile;
                 ReadHdr h;
                 h.gpos = (uint32_t)(rp + off); h.seqoff = (uint32_t)so; h.cig = n; h.meta = META_PILEUP_OK | r.mapq << 16;
-                hdr[w] = h; ptid[w] = r.tid; pend[w] = (int32_t)(rp + off + n); pdepth[w] = depth; psrc_rec[w] = i; psrc_q0[w] = (uint32_t)(q + off);
+                hdr[w] = h; ptid[w] = r.tid; pend[w] = (int32_t)(rp + off + n); pdepth[w] = depth;
+                PieceSrc ps;
+                ps.seq = seq_abs; ps.qual = qual_abs; ps.q0 = (uint32_t)(q + off); ps.sample = s; ps.pad = 0;
+                const long long g = rp + off, left = c.seq_len - g;
+                if (c.seq_len >= 0 && g >= 0 && left > 0) { ps.ref_nib = c.pref_off + (unsigned long long)g; ps.ref_left = (uint32_t)(left < 0xffffffffll ? left : 0xffffffffll); }
+                else { ps.ref_nib = c.seq_len >= 0 ? ~1ull : ~0ull; ps.ref_left = 0; }        // ~1: a FASTA record exists but holds nothing here (sampled, nothing to compare)
+                psrc[w] = ps;
                 ++w; so += stored_bytes(n);
             }
             rp += l; q += l;
@@ -430,41 +515,38 @@ __device__ __forceinline__ void or_byte(uint8_t *p, uint32_t v) {
     const uintptr_t a = reinterpret_cast<uintptr_t>(p);
     atomicOr(reinterpret_cast<uint32_t *>(a & ~(uintptr_t)3), v << (8u * (uint32_t)(a & 3u)));
 }
-__global__ __launch_bounds__(256) void msnv_emit_pieces(const uint8_t *raw, const unsigned long long *rec_off, const uint16_t *rec_sample, const DpContig *ctg, const uint32_t *pref4,
-                                                        DpParams P, uint32_t n_pieces, const ReadHdr *hdr, const int32_t *ptid, const uint32_t *psrc_rec, const uint32_t *psrc_q0,
+__global__ __launch_bounds__(256) void msnv_emit_pieces(const uint8_t *raw, const uint32_t *pref4, DpParams P, uint32_t n_pieces, const ReadHdr *hdr, const PieceSrc *psrc,
                                                         const DpSampleDst *dst, DpAcc *acc) {
     const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t pc = gt >> 4, sub = gt & 15u, j0 = 8u * sub;
     const bool piece = pc < n_pieces;
-    ReadHdr h{}; uint32_t s = 0, rec = 0;
-    if (piece) { h = hdr[pc]; rec = psrc_rec[pc]; s = rec_sample[rec]; }
+    ReadHdr h{}; PieceSrc ps{};
+    if (piece) { h = hdr[pc]; ps = psrc[pc]; }
     const uint32_t n = h.cig, sb = piece ? stored_bytes(n) : 0u;
     const bool active = j0 < 2u * sb;                                                       // this lane holds stored nibbles of the piece
     const uint32_t have = n > j0 ? (n - j0 < 8u ? n - j0 : 8u) : 0u;                       // ... of which real bases
     DpSampleDst d{};
-    if (piece) d = dst[s];
+    if (piece) d = dst[ps.sample];
     // padding: base N, quality byte 0 (pack.cpp: pack_sample, pack_lowq)
     uint32_t out = 0xffffffffu, bits = (P.c_eff > 0 || P.all_low) ? 0xffu : 0u, mm = 0;
     bool sampled = false;
     if (have) {
-        const uint8_t *p = raw + rec_off[rec];
-        const uint32_t l_name = p[12], n_cigar = ld16(p + 16), l_seq = ld32(p + 20);
-        const uint8_t *seq = p + 36 + l_name + 4ull * n_cigar, *qual = seq + ((unsigned long long)l_seq + 1) / 2;
-        const uint32_t q0 = psrc_q0[pc] + j0;
+        const uint32_t q0 = ps.q0 + j0;
         // BAM packs base 2i in the HIGH nibble of byte i; the kernels want base j of the piece in nibble j, low first
-        const uint64_t b = ld64(seq + (q0 >> 1));
+        const uint64_t b = ld64(raw + ps.seq + (q0 >> 1));
+        const uint64_t qb = ld64(raw + ps.qual + q0);
         const uint64_t sw = ((b >> 4) & 0x0f0f0f0f0f0f0f0full) | ((b & 0x0f0f0f0f0f0f0f0full) << 4);
         out = (uint32_t)(sw >> (4u * (q0 & 1u)));
         if (have < 8u) out |= 0xffffffffu << (4u * have);
-        const DpContig c = ctg[ptid[pc]];
-        const long long g0 = (long long)h.gpos + j0;                                        // contig-relative position of the lane's first base
+        const bool has_fasta = ps.ref_nib != ~0ull;
+        const uint32_t left = ps.ref_left > j0 ? ps.ref_left - j0 : 0u;                   // FASTA characters from the lane's first position
         uint32_t rc = 0xffffffffu;                                                          // reference codes of the lane's positions (N where the FASTA has nothing)
-        if (c.seq_len >= 0 && g0 < c.seq_len) {
-            const unsigned long long nb = c.pref_off + (unsigned long long)g0;
+        const bool need_ref = ((out - 0x11111111u) & ~out & 0x88888888u) != 0u || (has_fasta && ((pc - (uint32_t)d.pbase0) & 15u) == 0u);
+        if (need_ref && left) {
+            const unsigned long long nb = ps.ref_nib + j0;
             const uint64_t w = (uint64_t)pref4[nb >> 3] | (uint64_t)pref4[(nb >> 3) + 1] << 32;
             rc = (uint32_t)(w >> (4u * (uint32_t)(nb & 7u)));
-            const long long left = c.seq_len - g0;
-            if (left < 8) rc |= 0xffffffffu << (4u * (uint32_t)left);
+            if (left < 8u) rc |= 0xffffffffu << (4u * left);
         }
         // '=' (code 0) always counts as a match (bam_plcmd.c pileup_seq [EXT]): ship the reference code, N when that is unknown or '=' itself
         if ((out - 0x11111111u) & ~out & 0x88888888u) {
@@ -475,16 +557,14 @@ __global__ __launch_bounds__(256) void msnv_emit_pieces(const uint8_t *raw, cons
             }
         }
         // one piece in 16: how noisy are these reads? (finalize picks the allele bookkeeping by it)
-        if (c.seq_len >= 0 && ((pc - (uint32_t)d.pbase0) & 15u) == 0u) {
+        if (has_fasta && ((pc - (uint32_t)d.pbase0) & 15u) == 0u) {
             sampled = true;
-            const long long left = c.seq_len - g0;
-            const uint32_t cmp = left <= 0 ? 0u : (left < (long long)have ? (uint32_t)left : have);
+            const uint32_t cmp = left < have ? left : have;
             uint32_t x = out ^ rc;
             x = (x | x >> 1 | x >> 2 | x >> 3) & 0x11111111u;
             if (cmp < 8u) x &= (1u << (4u * cmp)) - 1u;
             mm = (uint32_t)__builtin_popcount(x);
         }
-        const uint64_t qb = ld64(qual + q0);
         uint32_t low = 0;
         for (uint32_t t = 0; t < 8u; ++t) {
             const uint32_t qv = (uint32_t)(qb >> (8u * t)) & 0xffu;
@@ -515,7 +595,24 @@ __global__ __launch_bounds__(256) void msnv_emit_pieces(const uint8_t *raw, cons
     }
     // mismatch sample: sum over the 16 lanes of a piece, one atomic per sampled piece
     for (int o = 8; o > 0; o >>= 1) mm += __shfl_down(mm, o, 16);
-    if (sub == 0 && sampled) { atomicAdd(&acc[s].mm_bases, (unsigned long long)n); if (mm) atomicAdd(&acc[s].mm, (unsigned long long)mm); }
+    if (sub == 0 && sampled) { atomicAdd(&acc[ps.sample].mm_bases, (unsigned long long)n); if (mm) atomicAdd(&acc[ps.sample].mm, (unsigned long long)mm); }
+}
+
+// per sample: where its records' pieces / seq bytes / intervals start, and the first pileup read (one small copy instead of three per sample)
+struct DpSampleSum { unsigned long long sbase0, first_key, beyond_key; uint32_t pbase0, ibase0, first_end, pad; };
+__global__ void msnv_sample_bases(const uint32_t *rec_base, uint32_t n_samples, const uint32_t *pbase, const unsigned long long *sbase, const uint32_t *ibase,
+                                  const DpAcc *acc, const unsigned long long *r_key, const uint32_t *r_end, DpSampleSum *out) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > n_samples) return;
+    DpSampleSum o{};
+    const uint32_t i = rec_base[s];
+    o.sbase0 = sbase[i]; o.pbase0 = pbase[i]; o.ibase0 = ibase[i];
+    if (s < n_samples) {
+        const DpAcc a = acc[s];
+        if (a.first_pile != ~0ull) { o.first_key = r_key[a.first_pile]; o.first_end = r_end[a.first_pile]; }
+        if (a.beyond != ~0ull) o.beyond_key = r_key[a.beyond];
+    }
+    out[s] = o;
 }
 
 // behind the last piece of every sample: 32 bytes of N and their flags (pack.cpp: pack_sample's tail padding)
@@ -531,14 +628,14 @@ __global__ void msnv_emit_tail(const DpSampleDst *dst, const unsigned long long 
 }
 
 // ------------------------------------------------------------------------------------------ tile order of the headers
-__global__ void msnv_tile_keys(const ReadHdr *hdr, const int32_t *ptid, const uint32_t *psrc_rec, const uint16_t *rec_sample, uint32_t n, uint32_t tid_bits,
+__global__ void msnv_tile_keys(const ReadHdr *hdr, const int32_t *ptid, const PieceSrc *psrc, uint32_t n, uint32_t tid_bits,
                                unsigned long long *keys, uint32_t *idx, uint32_t *unsorted) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const unsigned long long k = ((unsigned long long)rec_sample[psrc_rec[i]] << tid_bits | (uint32_t)ptid[i]) << 21 | (hdr[i].gpos / TILE);
+    const unsigned long long k = ((unsigned long long)psrc[i].sample << tid_bits | (uint32_t)ptid[i]) << 21 | (hdr[i].gpos / TILE);
     keys[i] = k; idx[i] = i;
     if (i > 0) {
-        const unsigned long long kp = ((unsigned long long)rec_sample[psrc_rec[i - 1]] << tid_bits | (uint32_t)ptid[i - 1]) << 21 | (hdr[i - 1].gpos / TILE);
+        const unsigned long long kp = ((unsigned long long)psrc[i - 1].sample << tid_bits | (uint32_t)ptid[i - 1]) << 21 | (hdr[i - 1].gpos / TILE);
         if (kp > k) *unsorted = 1u;
     }
 }
@@ -592,29 +689,6 @@ struct Timer {          // HIP events around a group of launches
     double stop() { (void)hipEventRecord(b, st); (void)hipEventSynchronize(b); float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms; }
 };
 
-int scan_u32(const uint32_t *in, uint32_t *out, size_t n, hipStream_t st, DevBuf &tmp, size_t &tmp_cap, bool inclusive = false) {
-    size_t need = 0;
-    if (inclusive) HIP_TRY(rocprim::inclusive_scan(nullptr, need, in, out, n, rocprim::plus<uint32_t>(), st));
-    else HIP_TRY(rocprim::exclusive_scan(nullptr, need, in, out, 0u, n, rocprim::plus<uint32_t>(), st));
-    if (need > tmp_cap) { if (int rc = tmp.alloc(need)) return rc; tmp_cap = need; }
-    if (inclusive) HIP_TRY(rocprim::inclusive_scan(tmp.p, need, in, out, n, rocprim::plus<uint32_t>(), st));
-    else HIP_TRY(rocprim::exclusive_scan(tmp.p, need, in, out, 0u, n, rocprim::plus<uint32_t>(), st));
-    return MSNV_OK;
-}
-int scan_u32_u64(const uint32_t *in, unsigned long long *out, size_t n, hipStream_t st, DevBuf &tmp, size_t &tmp_cap) {
-    size_t need = 0;
-    HIP_TRY(rocprim::exclusive_scan(nullptr, need, in, out, 0ull, n, rocprim::plus<unsigned long long>(), st));
-    if (need > tmp_cap) { if (int rc = tmp.alloc(need)) return rc; tmp_cap = need; }
-    HIP_TRY(rocprim::exclusive_scan(tmp.p, need, in, out, 0ull, n, rocprim::plus<unsigned long long>(), st));
-    return MSNV_OK;
-}
-int sort_pairs(unsigned long long *kin, unsigned long long *kout, uint32_t *vin, uint32_t *vout, size_t n, unsigned end_bit, hipStream_t st, DevBuf &tmp, size_t &tmp_cap) {
-    size_t need = 0;
-    HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, kin, kout, vin, vout, n, 0u, end_bit, st));
-    if (need > tmp_cap) { if (int rc = tmp.alloc(need)) return rc; tmp_cap = need; }
-    HIP_TRY(rocprim::radix_sort_pairs(tmp.p, need, kin, kout, vin, vout, n, 0u, end_bit, st));
-    return MSNV_OK;
-}
 unsigned bit_width_u64(unsigned long long v) { unsigned b = 0; while (v) { ++b; v >>= 1; } return b; }
 inline dim3 grid_for(uint64_t n, uint32_t block) { return dim3((unsigned)std::max<uint64_t>(1, (n + block - 1) / block)); }
 
@@ -681,6 +755,8 @@ void devpack_release(DevPackTables &t) {
     if (t.pref4) dev_free(t.pref4);
     for (void *p : t.round_bufs) dev_free(p);
     t.round_bufs.clear();
+    for (auto &b : t.scratch) if (b.first) dev_free(b.first);
+    t.scratch.clear();
     t.contigs = nullptr; t.pref4 = nullptr; t.ready = false;
 }
 
@@ -700,17 +776,37 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     P.c_eff = std::min(std::max(MP.min_baseq, -127), 127); P.all_low = MP.min_baseq > 127;
     P.n_contigs = (int)NC; P.has_bed = ds.has_bed ? 1 : 0;
     Timer tm(st);
+    // work buffers of the round: taken from the dataset's pool in call order (grow-only, so a dataset's second round allocates nothing);
+    // with guarded allocations (MSNV_GUARD_ALLOC=1) every buffer is exact and fresh
+    size_t next_buf = 0;
+    int pool_rc = MSNV_OK;
+    const bool exact = [] { const char *e = getenv("MSNV_GUARD_ALLOC"); return e && e[0] == '1'; }();
+    auto buf = [&](uint64_t bytes) -> void * {
+        if (next_buf >= T.scratch.size()) T.scratch.emplace_back(nullptr, 0);
+        std::pair<void *, uint64_t> &b = T.scratch[next_buf++];
+        bytes = std::max<uint64_t>(bytes, 16);
+        if (b.second < bytes || (exact && b.second != bytes)) {
+            if (b.first) dev_free(b.first);
+            b.first = nullptr; b.second = 0;
+            const uint64_t want = exact ? bytes : bytes + bytes / 8;
+            if (int rc = dev_alloc(&b.first, want, nullptr)) { pool_rc = rc; return nullptr; }
+            b.second = want;
+        }
+        return b.first;
+    };
+#define DP_BUF(type, name, count)                                                  \
+    type *name = static_cast<type *>(buf((uint64_t)(count) * sizeof(type)));       \
+    if (!name) return pool_rc
 
-    // ---- the round's streams side by side in one buffer: every stream starts on 16 bytes, 64 readable bytes behind the last
-    std::vector<unsigned long long> s_beg(S), s_len(S), s_end(S), cap_base(S + 1, 0);
+    // ---- the round's streams side by side in one buffer: every stream starts on 16 bytes, readable bytes behind the last
+    std::vector<unsigned long long> s_beg(S), s_end(S);
     uint64_t raw_bytes = 0;
-    for (size_t s = 0; s < S; ++s) { s_beg[s] = raw_bytes; s_len[s] = n_bytes[s]; s_end[s] = raw_bytes + n_bytes[s]; raw_bytes += (n_bytes[s] + 15 + 16) & ~15ull; cap_base[s + 1] = cap_base[s] + n_bytes[s] / 36 + 1; }
-    DevBuf raw;
-    if (int rc = raw.alloc(raw_bytes + 64)) return rc;
+    for (size_t s = 0; s < S; ++s) { s_beg[s] = raw_bytes; s_end[s] = raw_bytes + n_bytes[s]; raw_bytes += (n_bytes[s] + 15 + 16) & ~15ull; }
+    DP_BUF(uint8_t, raw, raw_bytes + 256);
     {
         const double t0 = now_s();
         if (on_device) {
-            for (size_t s = 0; s < S; ++s) if (n_bytes[s]) HIP_TRY(hipMemcpyAsync(raw.as<uint8_t>() + s_beg[s], streams[s], n_bytes[s], hipMemcpyDeviceToDevice, st));
+            for (size_t s = 0; s < S; ++s) if (n_bytes[s]) HIP_TRY(hipMemcpyAsync(raw + s_beg[s], streams[s], n_bytes[s], hipMemcpyDeviceToDevice, st));
             HIP_TRY(hipStreamSynchronize(st));
         } else {
             // pageable host memory: a few copies in flight keep the link busy (the runtime stages them)
@@ -718,7 +814,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
             const int device = ds.ctx->device;
             auto w = [&]() {
                 (void)hipSetDevice(device);
-                for (;;) { const size_t s = next.fetch_add(1); if (s >= S) break; if (n_bytes[s] && hipMemcpy(raw.as<uint8_t>() + s_beg[s], streams[s], n_bytes[s], hipMemcpyHostToDevice) != hipSuccess) bad.store(1); }
+                for (;;) { const size_t s = next.fetch_add(1); if (s >= S) break; if (n_bytes[s] && hipMemcpy(raw + s_beg[s], streams[s], n_bytes[s], hipMemcpyHostToDevice) != hipSuccess) bad.store(1); }
             };
             std::vector<std::thread> th;
             for (size_t k = 0; k < std::min<size_t>(S, 6); ++k) th.emplace_back(w);
@@ -729,132 +825,218 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     }
     T.raw_bytes += raw_bytes;
 
-    // ---- record boundaries
-    DevBuf d_sbeg, d_slen, d_send, d_capbase, d_tmpoff, d_nrec, d_bad;
-    if (int rc = d_sbeg.alloc(S * 8)) return rc;
-    if (int rc = d_slen.alloc(S * 8)) return rc;
-    if (int rc = d_send.alloc(S * 8)) return rc;
-    if (int rc = d_capbase.alloc((S + 1) * 8)) return rc;
-    if (int rc = d_tmpoff.alloc(cap_base[S] * 8)) return rc;
-    if (int rc = d_nrec.alloc(S * 4)) return rc;
-    if (int rc = d_bad.alloc(S * 8)) return rc;
-    HIP_TRY(hipMemcpyAsync(d_sbeg.p, s_beg.data(), S * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_slen.p, s_len.data(), S * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_send.p, s_end.data(), S * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_capbase.p, cap_base.data(), (S + 1) * 8, hipMemcpyHostToDevice, st));
-    tm.start();
-    hipLaunchKernelGGL(msnv_scan_records, dim3((unsigned)S), dim3(64), 0, st, raw.as<uint8_t>(), d_sbeg.as<unsigned long long>(), d_slen.as<unsigned long long>(),
-                       d_capbase.as<unsigned long long>(), d_tmpoff.as<unsigned long long>(), d_nrec.as<uint32_t>(), d_bad.as<unsigned long long>());
-    HIP_TRY(hipGetLastError());
-    std::vector<uint32_t> n_rec(S);
-    std::vector<unsigned long long> bad_off(S);
-    HIP_TRY(hipMemcpyAsync(n_rec.data(), d_nrec.p, S * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(bad_off.data(), d_bad.p, S * 8, hipMemcpyDeviceToHost, st));
-    T.ms_scan += tm.stop();
-    std::vector<uint32_t> rec_base(S + 1, 0);
-    uint32_t max_nrec = 0;
+    // ---- record boundaries: segments, guessed entry points, seams checked here
+    const uint64_t seg_bytes = [] { const char *e = getenv("MSNV_SCAN_SEG_KB"); const long long v = e ? atoll(e) : 256; return (uint64_t)std::max<long long>(1, v) << 10; }();   // (per call: tests shrink it)
+    std::vector<ScanSeg> segs;
+    std::vector<uint32_t> seg_lo(S + 1, 0);                       // per stream: its first segment
+    uint64_t cap_total = 0;
     for (size_t s = 0; s < S; ++s) {
-        if ((uint64_t)rec_base[s] + n_rec[s] > 0xfffffff0ull) return fail(MSNV_EDOMAIN, "more than 2^32 records in one round of the device pack");
-        rec_base[s + 1] = rec_base[s] + n_rec[s]; max_nrec = std::max(max_nrec, n_rec[s]);
+        seg_lo[s] = (uint32_t)segs.size();
+        for (uint64_t o = s_beg[s]; o < s_end[s]; o += seg_bytes) {
+            const uint64_t e = std::min<uint64_t>(o + seg_bytes, s_end[s]);
+            segs.push_back(ScanSeg{o, e, s_end[s], o == s_beg[s] ? o : ~0ull, cap_total});
+            cap_total += (e - o) / 36 + 2;
+        }
+    }
+    seg_lo[S] = (uint32_t)segs.size();
+    const size_t NSEG = segs.size();
+    if (NSEG > 0x7fffffffull) return fail(MSNV_EDOMAIN, "too many scan segments in one round");
+    DP_BUF(ScanSeg, d_segs, NSEG + 1);
+    DP_BUF(ScanOut, d_outs, NSEG + 1);
+    DP_BUF(unsigned long long, d_tmpoff, cap_total + 64);
+    std::vector<ScanOut> outs(NSEG);
+    std::vector<uint32_t> n_rec(S, 0), acc_cnt(NSEG, 0);
+    std::vector<unsigned long long> bad_off(S, ~0ull);
+    tm.start();
+    if (NSEG) {
+        HIP_TRY(hipMemcpyAsync(d_segs, segs.data(), NSEG * sizeof(ScanSeg), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(msnv_scan_segments, dim3((unsigned)NSEG), dim3(64), 0, st, raw, d_segs, (uint32_t)NSEG, (int)NC, d_tmpoff, d_outs);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(outs.data(), d_outs, NSEG * sizeof(ScanOut), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        // seams: cur = where the true chain stands; a segment is accepted when its walk began exactly there
+        std::vector<unsigned long long> cur(S);
+        std::vector<uint32_t> at(S);                             // next segment to look at, per stream
+        for (size_t s = 0; s < S; ++s) { cur[s] = s_beg[s]; at[s] = seg_lo[s]; }
+        for (int round_no = 0;; ++round_no) {
+            std::vector<uint32_t> redo;
+            for (size_t s = 0; s < S; ++s) {
+                while (at[s] < seg_lo[s + 1] && bad_off[s] == ~0ull) {
+                    const uint32_t k = at[s];
+                    if (cur[s] >= segs[k].end) { acc_cnt[k] = 0; ++at[s]; continue; }          // a record runs across the whole segment
+                    if (outs[k].first != cur[s]) { segs[k].start = cur[s]; redo.push_back(k); break; }
+                    acc_cnt[k] = outs[k].cnt;
+                    if (outs[k].bad != ~0ull) { bad_off[s] = outs[k].bad - s_beg[s]; break; }
+                    cur[s] = outs[k].stop;
+                    ++at[s];
+                }
+            }
+            if (redo.empty()) break;
+            if (round_no > (int)NSEG + 1) return fail(MSNV_EINVAL, "internal: the record scan does not converge");
+            // walk the segments that guessed wrong again, from the true entry point (one launch over just those)
+            std::vector<ScanSeg> again;
+            for (uint32_t k : redo) again.push_back(segs[k]);
+            DP_BUF(ScanSeg, d_again, again.size());
+            DP_BUF(ScanOut, d_aout, again.size());
+            std::vector<ScanOut> aout(again.size());
+            HIP_TRY(hipMemcpyAsync(d_again, again.data(), again.size() * sizeof(ScanSeg), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(msnv_scan_segments, dim3((unsigned)again.size()), dim3(64), 0, st, raw, d_again, (uint32_t)again.size(), (int)NC, d_tmpoff, d_aout);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(aout.data(), d_aout, again.size() * sizeof(ScanOut), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            for (size_t j = 0; j < redo.size(); ++j) outs[redo[j]] = aout[j];
+            T.n_scan_redone += redo.size();
+            next_buf -= 2;                                        // (the two lists are reused by the next repair round)
+        }
+    }
+    std::vector<uint32_t> rec_base(S + 1, 0);
+    std::vector<CompactSeg> csegs;
+    {
+        uint64_t total = 0;
+        for (size_t s = 0; s < S; ++s) {
+            rec_base[s] = (uint32_t)total;
+            for (uint32_t k = seg_lo[s]; k < seg_lo[s + 1]; ++k) {
+                if (acc_cnt[k]) csegs.push_back(CompactSeg{segs[k].out_base, (uint32_t)total, acc_cnt[k], (uint32_t)s, 0u});
+                total += acc_cnt[k];
+                if (total > 0xfffffff0ull) return fail(MSNV_EDOMAIN, "more than 2^32 records in one round of the device pack");
+            }
+            n_rec[s] = (uint32_t)total - rec_base[s];
+        }
+        rec_base[S] = (uint32_t)total;
     }
     const uint32_t NR = rec_base[S];
+    const uint64_t NRa = (uint64_t)NR + 1;
     T.n_records += NR;
-    DevBuf d_recbase, d_recoff, d_recsample;
-    if (int rc = d_recbase.alloc((S + 1) * 4)) return rc;
-    if (int rc = d_recoff.alloc(((uint64_t)NR + 1) * 8)) return rc;
-    if (int rc = d_recsample.alloc(((uint64_t)NR + 1) * 2)) return rc;
-    HIP_TRY(hipMemcpyAsync(d_recbase.p, rec_base.data(), (S + 1) * 4, hipMemcpyHostToDevice, st));
-    if (NR) {
-        hipLaunchKernelGGL(msnv_compact_offsets, dim3(std::max(1u, std::min(1024u, (max_nrec + 255u) / 256u)), (unsigned)S), dim3(256), 0, st, d_tmpoff.as<unsigned long long>(),
-                           d_capbase.as<unsigned long long>(), d_recbase.as<uint32_t>(), d_sbeg.as<unsigned long long>(), d_recoff.as<unsigned long long>(), d_recsample.as<uint16_t>());
+    DP_BUF(uint32_t, d_recbase, S + 1);
+    DP_BUF(unsigned long long, d_send, S);
+    DP_BUF(unsigned long long, d_recoff, NRa);
+    DP_BUF(uint16_t, d_recsample, NRa);
+    DP_BUF(CompactSeg, d_csegs, csegs.size() + 1);
+    HIP_TRY(hipMemcpyAsync(d_recbase, rec_base.data(), (S + 1) * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_send, s_end.data(), S * 8, hipMemcpyHostToDevice, st));
+    if (!csegs.empty()) {
+        HIP_TRY(hipMemcpyAsync(d_csegs, csegs.data(), csegs.size() * sizeof(CompactSeg), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(msnv_compact_offsets, dim3((unsigned)csegs.size()), dim3(256), 0, st, d_tmpoff, d_csegs, d_recoff, d_recsample);
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipStreamSynchronize(st));
-    if (int rc = d_tmpoff.alloc(16)) return rc;                                  // (the capacity-sized list is gone)
+    T.ms_scan += tm.stop();
 
     // ---- measure (+ the host pre-pass for the samples that need one, then once more with its verdicts)
-    DevBuf d_flags, d_key, d_end, d_maxc, d_pile, d_npiece, d_seqb, d_niv, d_acc, d_ovr, d_depth;
-    const uint64_t NRa = (uint64_t)NR + 1;
-    if (int rc = d_flags.alloc(NRa)) return rc;
-    if (int rc = d_key.alloc(NRa * 8)) return rc;
-    if (int rc = d_end.alloc(NRa * 4)) return rc;
-    if (int rc = d_maxc.alloc(NRa * 4)) return rc;
-    if (int rc = d_pile.alloc(NRa * 4)) return rc;
-    if (int rc = d_npiece.alloc(NRa * 4)) return rc;
-    if (int rc = d_seqb.alloc(NRa * 4)) return rc;
-    if (int rc = d_niv.alloc(NRa * 4)) return rc;
-    if (int rc = d_depth.alloc(NRa * 2)) return rc;
-    if (int rc = d_acc.alloc(S * sizeof(DpAcc))) return rc;
+    DP_BUF(uint8_t, d_flags, NRa);
+    DP_BUF(unsigned long long, d_key, NRa);
+    DP_BUF(uint32_t, d_end, NRa);
+    DP_BUF(uint32_t, d_maxc, NRa);
+    DP_BUF(uint32_t, d_pile, NRa);
+    DP_BUF(uint32_t, d_npiece, NRa);
+    DP_BUF(uint32_t, d_seqb, NRa);
+    DP_BUF(uint32_t, d_niv, NRa);
+    DP_BUF(uint16_t, d_depth, NRa);
+    DP_BUF(uint32_t, d_rank, NRa);
+    DP_BUF(uint32_t, d_ovr, NRa);
+    DP_BUF(DpAcc, d_acc, S);
+    DP_BUF(uint8_t, d_tmp, 1u << 20);                             // rocPRIM's temporary storage (grown below when a call asks for more)
+    size_t tmp_cap = (size_t)T.scratch[next_buf - 1].second;
+    const size_t tmp_slot = next_buf - 1;
+    auto tmp_for = [&](size_t need) -> int {
+        if (need <= tmp_cap) return MSNV_OK;
+        const size_t keep = next_buf;
+        next_buf = tmp_slot;
+        d_tmp = static_cast<uint8_t *>(buf(need));
+        next_buf = keep;
+        if (!d_tmp) return pool_rc;
+        tmp_cap = (size_t)T.scratch[tmp_slot].second;
+        return MSNV_OK;
+    };
+    auto scan32 = [&](const uint32_t *in, uint32_t *out, size_t cnt, bool inclusive) -> int {
+        size_t need = 0;
+        if (inclusive) HIP_TRY(rocprim::inclusive_scan(nullptr, need, in, out, cnt, rocprim::plus<uint32_t>(), st));
+        else HIP_TRY(rocprim::exclusive_scan(nullptr, need, in, out, 0u, cnt, rocprim::plus<uint32_t>(), st));
+        if (int rc = tmp_for(need)) return rc;
+        if (inclusive) HIP_TRY(rocprim::inclusive_scan(d_tmp, need, in, out, cnt, rocprim::plus<uint32_t>(), st));
+        else HIP_TRY(rocprim::exclusive_scan(d_tmp, need, in, out, 0u, cnt, rocprim::plus<uint32_t>(), st));
+        return MSNV_OK;
+    };
+    auto scan64 = [&](const uint32_t *in, unsigned long long *out, size_t cnt) -> int {
+        size_t need = 0;
+        HIP_TRY(rocprim::exclusive_scan(nullptr, need, in, out, 0ull, cnt, rocprim::plus<unsigned long long>(), st));
+        if (int rc = tmp_for(need)) return rc;
+        HIP_TRY(rocprim::exclusive_scan(d_tmp, need, in, out, 0ull, cnt, rocprim::plus<unsigned long long>(), st));
+        return MSNV_OK;
+    };
+    auto sort64 = [&](unsigned long long *kin, unsigned long long *kout, uint32_t *vin, uint32_t *vout, size_t cnt, unsigned end_bit) -> int {
+        size_t need = 0;
+        HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, kin, kout, vin, vout, cnt, 0u, end_bit, st));
+        if (int rc = tmp_for(need)) return rc;
+        HIP_TRY(rocprim::radix_sort_pairs(d_tmp, need, kin, kout, vin, vout, cnt, 0u, end_bit, st));
+        return MSNV_OK;
+    };
     std::vector<DpAcc> acc(S);
     std::vector<uint8_t> cut_marks(S, 0);
     const DpContig *ctg = static_cast<const DpContig *>(T.contigs);
-    DevBuf tmp; size_t tmp_cap = 0;
-    DevBuf d_rank, d_pl, d_rf, d_runincl, d_keys, d_vals, d_skeys, d_svals, d_maxcr, d_runfirst, d_runf1, d_S, d_Pm, d_runs;
     std::vector<DpRun> runs;
     uint32_t NP = 0, n_runs = 0;
     bool have_ovr = false;
+    const size_t depth_bufs_from = next_buf;
     for (int pass = 0; pass < 2; ++pass) {
+        next_buf = depth_bufs_from;
         for (size_t s = 0; s < S; ++s) { DpAcc a{}; a.err = a.first_pile = a.beyond = ~0ull; acc[s] = a; }
-        HIP_TRY(hipMemcpyAsync(d_acc.p, acc.data(), S * sizeof(DpAcc), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemsetAsync(d_depth.p, 0, NRa * 2, st));
+        HIP_TRY(hipMemcpyAsync(d_acc, acc.data(), S * sizeof(DpAcc), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemsetAsync(d_depth, 0, NRa * 2, st));
+        HIP_TRY(hipMemsetAsync(d_pile + NR, 0, 4, st));
         tm.start();
         if (NR) {
-            hipLaunchKernelGGL(msnv_measure_reads, grid_for(NR, 256), dim3(256), 0, st, raw.as<uint8_t>(), d_recoff.as<unsigned long long>(), d_recsample.as<uint16_t>(),
-                               d_recbase.as<uint32_t>(), d_send.as<unsigned long long>(), NR, ctg, P, have_ovr ? d_ovr.as<uint32_t>() : nullptr, d_flags.as<uint8_t>(),
-                               d_key.as<unsigned long long>(), d_end.as<uint32_t>(), d_maxc.as<uint32_t>(), d_pile.as<uint32_t>(), d_npiece.as<uint32_t>(), d_seqb.as<uint32_t>(),
-                               d_niv.as<uint32_t>(), d_acc.as<DpAcc>());
+            hipLaunchKernelGGL(msnv_measure_reads, grid_for(NR, 256), dim3(256), 0, st, raw, d_recoff, d_recsample, d_recbase, d_send, NR, ctg, P, have_ovr ? d_ovr : nullptr, d_flags,
+                               d_key, d_end, d_maxc, d_pile, d_npiece, d_seqb, d_niv, d_acc);
             HIP_TRY(hipGetLastError());
         }
+        if (int rc = scan32(d_pile, d_rank, NRa, false)) return rc;                          // (entry NR = number of pileup reads)
+        HIP_TRY(hipMemcpyAsync(&NP, d_rank + NR, 4, hipMemcpyDeviceToHost, st));
         T.ms_measure += tm.stop();
         // ---- depth at every read start
-        tm.start();
-        if (int rc = d_rank.alloc(NRa * 4)) return rc;
-        HIP_TRY(hipMemsetAsync(d_pile.as<uint32_t>() + NR, 0, 4, st));
-        if (int rc = scan_u32(d_pile.as<uint32_t>(), d_rank.as<uint32_t>(), NRa, st, tmp, tmp_cap)) return rc;      // (entry NR = number of pileup reads)
-        HIP_TRY(hipMemcpyAsync(&NP, d_rank.as<uint32_t>() + NR, 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
         n_runs = 0;
         if (NP) {
-            const uint64_t NPa = (uint64_t)NP + 1;
-            if (int rc = d_pl.alloc(NPa * 4)) return rc;
-            if (int rc = d_rf.alloc(NPa * 4)) return rc;
-            if (int rc = d_runincl.alloc(NPa * 4)) return rc;
-            if (int rc = d_keys.alloc(NPa * 8)) return rc;
-            if (int rc = d_vals.alloc(NPa * 4)) return rc;
-            if (int rc = d_skeys.alloc(NPa * 8)) return rc;
-            if (int rc = d_svals.alloc(NPa * 4)) return rc;
-            if (int rc = d_maxcr.alloc(NPa * 4)) return rc;
-            if (int rc = d_S.alloc(NPa * 8)) return rc;
-            if (int rc = d_Pm.alloc(NPa * 8)) return rc;
-            hipLaunchKernelGGL(msnv_pile_list, grid_for(NR, 256), dim3(256), 0, st, d_pile.as<uint32_t>(), d_rank.as<uint32_t>(), NR, d_pl.as<uint32_t>());
-            hipLaunchKernelGGL(msnv_run_flags, grid_for(NP, 256), dim3(256), 0, st, d_pl.as<uint32_t>(), NP, d_recsample.as<uint16_t>(), d_key.as<unsigned long long>(), d_rf.as<uint32_t>());
+            const uint64_t NPa = (uint64_t)NP + 1, N2 = 2ull * NP + 1;
+            DP_BUF(uint32_t, d_pl, NPa);
+            DP_BUF(uint32_t, d_rf, NPa);
+            DP_BUF(uint32_t, d_runincl, NPa);
+            DP_BUF(uint32_t, d_maxcr, NPa);
+            DP_BUF(unsigned long long, d_Pm, NPa);
+            DP_BUF(unsigned long long, d_keys, N2);
+            DP_BUF(unsigned long long, d_skeys, N2);
+            DP_BUF(uint32_t, d_vals, N2);
+            DP_BUF(uint32_t, d_svals, N2);
+            DP_BUF(uint32_t, d_ev, N2);
+            DP_BUF(unsigned long long, d_E, N2);
+            tm.start();
+            hipLaunchKernelGGL(msnv_pile_list, grid_for(NR, 256), dim3(256), 0, st, d_pile, d_rank, NR, d_pl);
+            hipLaunchKernelGGL(msnv_run_flags, grid_for(NP, 256), dim3(256), 0, st, d_pl, NP, d_recsample, d_key, d_rf);
             HIP_TRY(hipGetLastError());
-            if (int rc = scan_u32(d_rf.as<uint32_t>(), d_runincl.as<uint32_t>(), NP, st, tmp, tmp_cap, true)) return rc;
-            HIP_TRY(hipMemcpyAsync(&n_runs, d_runincl.as<uint32_t>() + (NP - 1), 4, hipMemcpyDeviceToHost, st));
+            if (int rc = scan32(d_rf, d_runincl, NP, true)) return rc;
+            HIP_TRY(hipMemcpyAsync(&n_runs, d_runincl + (NP - 1), 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
-            if (int rc = d_runfirst.alloc(((uint64_t)n_runs + 1) * 4)) return rc;
-            if (int rc = d_runf1.alloc(((uint64_t)n_runs + 1) * 4)) return rc;
-            if (int rc = d_runs.alloc(((uint64_t)n_runs + 1) * sizeof(DpRun))) return rc;
-            hipLaunchKernelGGL(msnv_depth_keys, grid_for(NPa, 256), dim3(256), 0, st, d_pl.as<uint32_t>(), NP, d_rf.as<uint32_t>(), d_runincl.as<uint32_t>(), d_end.as<uint32_t>(),
-                               d_maxc.as<uint32_t>(), d_keys.as<unsigned long long>(), d_vals.as<uint32_t>(), d_maxcr.as<uint32_t>(), d_runfirst.as<uint32_t>(), d_runf1.as<uint32_t>());
+            DP_BUF(uint32_t, d_runfirst, (uint64_t)n_runs + 1);
+            DP_BUF(uint32_t, d_runf1, (uint64_t)n_runs + 1);
+            DP_BUF(DpRun, d_runs, (uint64_t)n_runs + 1);
+            hipLaunchKernelGGL(msnv_depth_keys, grid_for(NPa, 256), dim3(256), 0, st, d_pl, NP, d_rf, d_runincl, d_key, d_end, d_maxc, d_keys, d_vals, d_maxcr, d_runfirst, d_runf1);
             HIP_TRY(hipGetLastError());
-            if (int rc = sort_pairs(d_keys.as<unsigned long long>(), d_skeys.as<unsigned long long>(), d_vals.as<uint32_t>(), d_svals.as<uint32_t>(), NP,
-                                    32u + std::max(1u, bit_width_u64(n_runs)), st, tmp, tmp_cap)) return rc;
-            HIP_TRY(hipMemsetAsync(d_svals.as<uint32_t>() + NP, 0, 4, st));
-            if (int rc = scan_u32_u64(d_svals.as<uint32_t>(), d_S.as<unsigned long long>(), NPa, st, tmp, tmp_cap)) return rc;
-            if (int rc = scan_u32_u64(d_maxcr.as<uint32_t>(), d_Pm.as<unsigned long long>(), NPa, st, tmp, tmp_cap)) return rc;
-            hipLaunchKernelGGL(msnv_depth, grid_for(NP, 256), dim3(256), 0, st, d_pl.as<uint32_t>(), NP, n_runs, d_runincl.as<uint32_t>(), d_runfirst.as<uint32_t>(),
-                               d_skeys.as<unsigned long long>(), d_S.as<unsigned long long>(), d_Pm.as<unsigned long long>(), d_key.as<unsigned long long>(), d_end.as<uint32_t>(),
-                               d_recsample.as<uint16_t>(), have_ovr ? d_ovr.as<uint32_t>() : nullptr, P, d_depth.as<uint16_t>(), d_runf1.as<uint32_t>(), d_acc.as<DpAcc>());
-            hipLaunchKernelGGL(msnv_run_table, grid_for(n_runs, 256), dim3(256), 0, st, d_pl.as<uint32_t>(), n_runs, d_runfirst.as<uint32_t>(), d_runf1.as<uint32_t>(),
-                               d_key.as<unsigned long long>(), d_recsample.as<uint16_t>(), d_runs.as<DpRun>());
+            if (int rc = sort64(d_keys, d_skeys, d_vals, d_svals, 2ull * NP, 32u + std::max(1u, bit_width_u64(n_runs)))) return rc;
+            hipLaunchKernelGGL(msnv_depth_endchars, grid_for(N2, 256), dim3(256), 0, st, d_svals, NP, d_maxcr, d_ev);
             HIP_TRY(hipGetLastError());
-        }
-        HIP_TRY(hipMemcpyAsync(acc.data(), d_acc.p, S * sizeof(DpAcc), hipMemcpyDeviceToHost, st));
-        T.ms_depth += tm.stop();
+            if (int rc = scan64(d_ev, d_E, N2)) return rc;
+            if (int rc = scan64(d_maxcr, d_Pm, NPa)) return rc;
+            hipLaunchKernelGGL(msnv_depth, grid_for(2ull * NP, 256), dim3(256), 0, st, d_pl, NP, d_svals, d_runincl, d_runfirst, d_E, d_Pm, d_key, d_end, d_recsample,
+                               have_ovr ? d_ovr : nullptr, P, d_depth, d_runf1, d_acc);
+            hipLaunchKernelGGL(msnv_run_table, grid_for(n_runs, 256), dim3(256), 0, st, d_pl, n_runs, d_runfirst, d_runf1, d_key, d_recsample, d_runs);
+            HIP_TRY(hipGetLastError());
+            runs.resize(n_runs);
+            HIP_TRY(hipMemcpyAsync(runs.data(), d_runs, (size_t)n_runs * sizeof(DpRun), hipMemcpyDeviceToHost, st));
+            T.ms_depth += tm.stop();
+        } else runs.clear();
+        HIP_TRY(hipMemcpyAsync(acc.data(), d_acc, S * sizeof(DpAcc), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
         // ---- errors, in record order (what the host stage's sequential walk would have met first)
         for (size_t s = 0; s < S; ++s) {
-            unsigned long long e = acc[s].err;
+            const unsigned long long e = acc[s].err;
             if (e != ~0ull) {
                 const uint32_t kind = (uint32_t)(e & 7u); const unsigned long long idx = (e >> 3) - rec_base[s];
                 return fail(MSNV_EFORMAT, "%s (sample %zu of the batch, record %llu)", err_text(kind), s, idx);
@@ -873,7 +1055,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
         std::vector<int> rcs(need.size(), 0); std::vector<std::string> msgs(need.size());
         for (size_t k = 0; k < need.size(); ++k) if (on_device) {
             host_copy[k].resize(n_bytes[need[k]]);
-            if (n_bytes[need[k]]) HIP_TRY(hipMemcpy(host_copy[k].data(), raw.as<uint8_t>() + s_beg[need[k]], n_bytes[need[k]], hipMemcpyDeviceToHost));
+            if (n_bytes[need[k]]) HIP_TRY(hipMemcpy(host_copy[k].data(), raw + s_beg[need[k]], n_bytes[need[k]], hipMemcpyDeviceToHost));
         }
         {
             std::atomic<size_t> next{0};
@@ -898,42 +1080,35 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
             for (auto &x : th) x.join();
         }
         for (size_t k = 0; k < need.size(); ++k) if (rcs[k]) return fail(rcs[k], "%s", msgs[k].c_str());
-        for (size_t k = 0; k < need.size(); ++k) if (!patched[k].empty()) HIP_TRY(hipMemcpy(raw.as<uint8_t>() + s_beg[need[k]], patched[k].data(), patched[k].size(), hipMemcpyHostToDevice));
-        if (int rc = d_ovr.alloc(((uint64_t)NR + 1) * 4)) return rc;
-        HIP_TRY(hipMemcpy(d_ovr.p, ovr_all.data(), ((uint64_t)NR + 1) * 4, hipMemcpyHostToDevice));
+        for (size_t k = 0; k < need.size(); ++k) if (!patched[k].empty()) HIP_TRY(hipMemcpy(raw + s_beg[need[k]], patched[k].data(), patched[k].size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_ovr, ovr_all.data(), ((uint64_t)NR + 1) * 4, hipMemcpyHostToDevice));
         have_ovr = true;
         T.wall_prepass_s += now_s() - t0;
     }
-    runs.resize(n_runs);
-    if (n_runs) HIP_TRY(hipMemcpy(runs.data(), d_runs.p, (size_t)n_runs * sizeof(DpRun), hipMemcpyDeviceToHost));
-    // the depth stage's lists are gone before the pieces are laid out
-    for (DevBuf *b : {&d_rank, &d_pl, &d_rf, &d_runincl, &d_keys, &d_vals, &d_skeys, &d_svals, &d_maxcr, &d_runfirst, &d_runf1, &d_S, &d_Pm, &d_runs, &d_ovr, &d_maxc, &d_pile})
-        if (b->p) { dev_free(b->p); b->p = nullptr; }
 
     // ---- layout: where every record's pieces, seq bytes and intervals go
-    DevBuf d_pbase, d_sbase, d_ibase;
-    if (int rc = d_pbase.alloc(NRa * 4)) return rc;
-    if (int rc = d_sbase.alloc(NRa * 8)) return rc;
-    if (int rc = d_ibase.alloc(NRa * 4)) return rc;
+    next_buf = depth_bufs_from;                                   // (the depth stage's lists are done with: their buffers serve the pieces)
+    DP_BUF(uint32_t, d_pbase, NRa);
+    DP_BUF(unsigned long long, d_sbase, NRa);
+    DP_BUF(uint32_t, d_ibase, NRa);
+    DP_BUF(DpSampleSum, d_sum, S + 1);
     tm.start();
-    HIP_TRY(hipMemsetAsync(d_npiece.as<uint32_t>() + NR, 0, 4, st));
-    HIP_TRY(hipMemsetAsync(d_seqb.as<uint32_t>() + NR, 0, 4, st));
-    HIP_TRY(hipMemsetAsync(d_niv.as<uint32_t>() + NR, 0, 4, st));
-    if (int rc = scan_u32(d_npiece.as<uint32_t>(), d_pbase.as<uint32_t>(), NRa, st, tmp, tmp_cap)) return rc;
-    if (int rc = scan_u32_u64(d_seqb.as<uint32_t>(), d_sbase.as<unsigned long long>(), NRa, st, tmp, tmp_cap)) return rc;
-    if (int rc = scan_u32(d_niv.as<uint32_t>(), d_ibase.as<uint32_t>(), NRa, st, tmp, tmp_cap)) return rc;
-    std::vector<uint32_t> sp0(S + 1), si0(S + 1);
-    std::vector<unsigned long long> ss0(S + 1);
-    for (size_t s = 0; s <= S; ++s) {
-        HIP_TRY(hipMemcpyAsync(&sp0[s], d_pbase.as<uint32_t>() + rec_base[s], 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(&ss0[s], d_sbase.as<unsigned long long>() + rec_base[s], 8, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(&si0[s], d_ibase.as<uint32_t>() + rec_base[s], 4, hipMemcpyDeviceToHost, st));
-    }
+    HIP_TRY(hipMemsetAsync(d_npiece + NR, 0, 4, st));
+    HIP_TRY(hipMemsetAsync(d_seqb + NR, 0, 4, st));
+    HIP_TRY(hipMemsetAsync(d_niv + NR, 0, 4, st));
+    if (int rc = scan32(d_npiece, d_pbase, NRa, false)) return rc;
+    if (int rc = scan64(d_seqb, d_sbase, NRa)) return rc;
+    if (int rc = scan32(d_niv, d_ibase, NRa, false)) return rc;
+    hipLaunchKernelGGL(msnv_sample_bases, grid_for(S + 1, 64), dim3(64), 0, st, d_recbase, (uint32_t)S, d_pbase, d_sbase, d_ibase, d_acc, d_key, d_end, d_sum);
+    HIP_TRY(hipGetLastError());
+    std::vector<DpSampleSum> sum(S + 1);
+    HIP_TRY(hipMemcpyAsync(sum.data(), d_sum, (S + 1) * sizeof(DpSampleSum), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    const uint32_t NPC = sp0[S], NIV = si0[S];
+    const uint32_t NPC = sum[S].pbase0, NIV = sum[S].ibase0;
     T.n_pieces += NPC;
     // the round's columns: per sample seq (its pieces + 32 tail bytes, start on 16 bytes) and one flag bit per nibble of it
-    std::vector<unsigned long long> seq_off(S + 1, 0), piece_bytes(S);
+    std::vector<unsigned long long> seq_off(S + 1, 0), piece_bytes(S), ss0(S + 1);
+    for (size_t s = 0; s <= S; ++s) ss0[s] = sum[s].sbase0;
     for (size_t s = 0; s < S; ++s) {
         piece_bytes[s] = ss0[s + 1] - ss0[s];
         if (piece_bytes[s] > 0xffffff00ull) return fail(MSNV_EDOMAIN, "one sample holds more than 8.5 G aligned bases in this shard: shard the contigs further");
@@ -946,96 +1121,82 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     uint8_t *r_seq = static_cast<uint8_t *>(round_buf), *r_qual = r_seq + seq_total;
     HIP_TRY(hipMemsetAsync(r_qual, 0, qual_total + 64, st));
     std::vector<DpSampleDst> dsts(S);
-    for (size_t s = 0; s < S; ++s) dsts[s] = DpSampleDst{r_seq + seq_off[s], r_qual + seq_off[s] / 4, sp0[s], cut_marks[s], 0u};
-    DevBuf d_dst, d_ss0, d_pb;
-    if (int rc = d_dst.alloc(S * sizeof(DpSampleDst))) return rc;
-    if (int rc = d_ss0.alloc((S + 1) * 8)) return rc;
-    if (int rc = d_pb.alloc(S * 8)) return rc;
-    HIP_TRY(hipMemcpyAsync(d_dst.p, dsts.data(), S * sizeof(DpSampleDst), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_ss0.p, ss0.data(), (S + 1) * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_pb.p, piece_bytes.data(), S * 8, hipMemcpyHostToDevice, st));
-    DevBuf d_hdr, d_ptid, d_pend, d_pdepth, d_srec, d_sq0, d_ctid, d_cbeg, d_cend;
+    for (size_t s = 0; s < S; ++s) dsts[s] = DpSampleDst{r_seq + seq_off[s], r_qual + seq_off[s] / 4, sum[s].pbase0, cut_marks[s], 0u};
     const uint64_t NPCa = (uint64_t)NPC + 1, NIVa = (uint64_t)NIV + 1;
-    if (int rc = d_hdr.alloc(NPCa * sizeof(ReadHdr))) return rc;
-    if (int rc = d_ptid.alloc(NPCa * 4)) return rc;
-    if (int rc = d_pend.alloc(NPCa * 4)) return rc;
-    if (int rc = d_pdepth.alloc(NPCa * 2)) return rc;
-    if (int rc = d_srec.alloc(NPCa * 4)) return rc;
-    if (int rc = d_sq0.alloc(NPCa * 4)) return rc;
-    if (int rc = d_ctid.alloc(NIVa * 4)) return rc;
-    if (int rc = d_cbeg.alloc(NIVa * 4)) return rc;
-    if (int rc = d_cend.alloc(NIVa * 4)) return rc;
+    DP_BUF(DpSampleDst, d_dst, S);
+    DP_BUF(unsigned long long, d_ss0, S + 1);
+    DP_BUF(unsigned long long, d_pb, S);
+    DP_BUF(ReadHdr, d_hdr, NPCa);
+    DP_BUF(int32_t, d_ptid, NPCa);
+    DP_BUF(int32_t, d_pend, NPCa);
+    DP_BUF(uint16_t, d_pdepth, NPCa);
+    DP_BUF(PieceSrc, d_psrc, NPCa);
+    DP_BUF(int32_t, d_ctid, NIVa);
+    DP_BUF(int32_t, d_cbeg, NIVa);
+    DP_BUF(int32_t, d_cend, NIVa);
+    HIP_TRY(hipMemcpyAsync(d_dst, dsts.data(), S * sizeof(DpSampleDst), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_ss0, ss0.data(), (S + 1) * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_pb, piece_bytes.data(), S * 8, hipMemcpyHostToDevice, st));
     if (NR) {
-        hipLaunchKernelGGL(msnv_emit_headers, grid_for(NR, 256), dim3(256), 0, st, raw.as<uint8_t>(), d_recoff.as<unsigned long long>(), d_recsample.as<uint16_t>(), NR, ctg,
-                           d_flags.as<uint8_t>(), d_depth.as<uint16_t>(), d_pbase.as<uint32_t>(), d_sbase.as<unsigned long long>(), d_ibase.as<uint32_t>(),
-                           d_ss0.as<unsigned long long>(), d_hdr.as<ReadHdr>(), d_ptid.as<int32_t>(), d_pend.as<int32_t>(), d_pdepth.as<uint16_t>(), d_srec.as<uint32_t>(),
-                           d_sq0.as<uint32_t>(), d_ctid.as<int32_t>(), d_cbeg.as<int32_t>(), d_cend.as<int32_t>());
+        hipLaunchKernelGGL(msnv_emit_headers, grid_for(NR, 256), dim3(256), 0, st, raw, d_recoff, d_recsample, NR, ctg, d_flags, d_depth, d_pbase, d_sbase, d_ibase, d_ss0,
+                           d_hdr, d_ptid, d_pend, d_pdepth, d_psrc, d_ctid, d_cbeg, d_cend);
         HIP_TRY(hipGetLastError());
     }
     if (NPC) {
-        hipLaunchKernelGGL(msnv_emit_pieces, grid_for((uint64_t)NPC * 16, 256), dim3(256), 0, st, raw.as<uint8_t>(), d_recoff.as<unsigned long long>(), d_recsample.as<uint16_t>(), ctg,
-                           T.pref4, P, NPC, d_hdr.as<ReadHdr>(), d_ptid.as<int32_t>(), d_srec.as<uint32_t>(), d_sq0.as<uint32_t>(), d_dst.as<DpSampleDst>(), d_acc.as<DpAcc>());
+        hipLaunchKernelGGL(msnv_emit_pieces, grid_for((uint64_t)NPC * 16, 256), dim3(256), 0, st, raw, T.pref4, P, NPC, d_hdr, d_psrc, d_dst, d_acc);
         HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(msnv_emit_tail, dim3((unsigned)S), dim3(64), 0, st, d_dst.as<DpSampleDst>(), d_pb.as<unsigned long long>(), (uint32_t)S, P);
+    hipLaunchKernelGGL(msnv_emit_tail, dim3((unsigned)S), dim3(64), 0, st, d_dst, d_pb, (uint32_t)S, P);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(acc.data(), d_acc.p, S * sizeof(DpAcc), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(acc.data(), d_acc, S * sizeof(DpAcc), hipMemcpyDeviceToHost, st));
     T.ms_emit += tm.stop();
 
     // ---- headers in tile order (stable: read order inside a tile)
     tm.start();
-    DevBuf d_hdr2, d_ptid2, d_pend2, d_pdepth2;
-    bool permuted = false;
+    const ReadHdr *src_hdr = d_hdr; const int32_t *src_tid = d_ptid, *src_end = d_pend; const uint16_t *src_depth = d_pdepth;
     if (NPC > 1) {
-        DevBuf d_tk, d_tk2, d_ix, d_ix2, d_uns;
-        if (int rc = d_tk.alloc(NPCa * 8)) return rc;
-        if (int rc = d_ix.alloc(NPCa * 4)) return rc;
-        if (int rc = d_uns.alloc(4)) return rc;
-        HIP_TRY(hipMemsetAsync(d_uns.p, 0, 4, st));
+        DP_BUF(unsigned long long, d_tk, NPCa);
+        DP_BUF(uint32_t, d_ix, NPCa);
+        DP_BUF(uint32_t, d_uns, 4);
+        HIP_TRY(hipMemsetAsync(d_uns, 0, 4, st));
         const unsigned tid_bits = std::max(1u, bit_width_u64(NC ? NC - 1 : 0));
-        hipLaunchKernelGGL(msnv_tile_keys, grid_for(NPC, 256), dim3(256), 0, st, d_hdr.as<ReadHdr>(), d_ptid.as<int32_t>(), d_srec.as<uint32_t>(), d_recsample.as<uint16_t>(), NPC,
-                           tid_bits, d_tk.as<unsigned long long>(), d_ix.as<uint32_t>(), d_uns.as<uint32_t>());
+        hipLaunchKernelGGL(msnv_tile_keys, grid_for(NPC, 256), dim3(256), 0, st, d_hdr, d_ptid, d_psrc, NPC, tid_bits, d_tk, d_ix, d_uns);
         HIP_TRY(hipGetLastError());
         uint32_t uns = 0;
-        HIP_TRY(hipMemcpyAsync(&uns, d_uns.p, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&uns, d_uns, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         if (uns) {
-            if (int rc = d_tk2.alloc(NPCa * 8)) return rc;
-            if (int rc = d_ix2.alloc(NPCa * 4)) return rc;
-            if (int rc = sort_pairs(d_tk.as<unsigned long long>(), d_tk2.as<unsigned long long>(), d_ix.as<uint32_t>(), d_ix2.as<uint32_t>(), NPC,
-                                    21u + tid_bits + std::max(1u, bit_width_u64(S - 1)), st, tmp, tmp_cap)) return rc;
-            if (int rc = d_hdr2.alloc(NPCa * sizeof(ReadHdr))) return rc;
-            if (int rc = d_ptid2.alloc(NPCa * 4)) return rc;
-            if (int rc = d_pend2.alloc(NPCa * 4)) return rc;
-            if (int rc = d_pdepth2.alloc(NPCa * 2)) return rc;
-            hipLaunchKernelGGL(msnv_gather_pieces, grid_for(NPC, 256), dim3(256), 0, st, d_ix2.as<uint32_t>(), NPC, d_hdr.as<ReadHdr>(), d_ptid.as<int32_t>(), d_pend.as<int32_t>(),
-                               d_pdepth.as<uint16_t>(), d_hdr2.as<ReadHdr>(), d_ptid2.as<int32_t>(), d_pend2.as<int32_t>(), d_pdepth2.as<uint16_t>());
+            DP_BUF(unsigned long long, d_tk2, NPCa);
+            DP_BUF(uint32_t, d_ix2, NPCa);
+            DP_BUF(ReadHdr, d_hdr2, NPCa);
+            DP_BUF(int32_t, d_ptid2, NPCa);
+            DP_BUF(int32_t, d_pend2, NPCa);
+            DP_BUF(uint16_t, d_pdepth2, NPCa);
+            if (int rc = sort64(d_tk, d_tk2, d_ix, d_ix2, NPC, 21u + tid_bits + std::max(1u, bit_width_u64(S - 1)))) return rc;
+            hipLaunchKernelGGL(msnv_gather_pieces, grid_for(NPC, 256), dim3(256), 0, st, d_ix2, NPC, d_hdr, d_ptid, d_pend, d_pdepth, d_hdr2, d_ptid2, d_pend2, d_pdepth2);
             HIP_TRY(hipGetLastError());
-            permuted = true;
+            src_hdr = d_hdr2; src_tid = d_ptid2; src_end = d_pend2; src_depth = d_pdepth2;
         }
     }
     T.ms_sort += tm.stop();
 
     // ---- what the host keeps of a sample: headers, intervals, summaries (finalize_dataset builds the tile index from them)
     const double t_dl = now_s();
-    const ReadHdr *src_hdr = permuted ? d_hdr2.as<ReadHdr>() : d_hdr.as<ReadHdr>();
-    const int32_t *src_tid = permuted ? d_ptid2.as<int32_t>() : d_ptid.as<int32_t>(), *src_end = permuted ? d_pend2.as<int32_t>() : d_pend.as<int32_t>();
-    const uint16_t *src_depth = permuted ? d_pdepth2.as<uint16_t>() : d_pdepth.as<uint16_t>();
     for (size_t s = 0; s < S; ++s) {
         SampleCols &sc = ds.samples[first + s];
-        const size_t np = sp0[s + 1] - sp0[s], ni = si0[s + 1] - si0[s];
+        const size_t np = sum[s + 1].pbase0 - sum[s].pbase0, ni = sum[s + 1].ibase0 - sum[s].ibase0;
         sc.hdr.resize(np); sc.tid.resize(np); sc.end.resize(np); sc.depth.resize(np);
         sc.cov_tid.resize(ni); sc.cov_beg.resize(ni); sc.cov_end.resize(ni);
         if (np) {
-            HIP_TRY(hipMemcpyAsync(sc.hdr.data(), src_hdr + sp0[s], np * sizeof(ReadHdr), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(sc.tid.data(), src_tid + sp0[s], np * 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(sc.end.data(), src_end + sp0[s], np * 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(sc.depth.data(), src_depth + sp0[s], np * 2, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(sc.hdr.data(), src_hdr + sum[s].pbase0, np * sizeof(ReadHdr), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(sc.tid.data(), src_tid + sum[s].pbase0, np * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(sc.end.data(), src_end + sum[s].pbase0, np * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(sc.depth.data(), src_depth + sum[s].pbase0, np * 2, hipMemcpyDeviceToHost, st));
         }
         if (ni) {
-            HIP_TRY(hipMemcpyAsync(sc.cov_tid.data(), d_ctid.as<int32_t>() + si0[s], ni * 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(sc.cov_beg.data(), d_cbeg.as<int32_t>() + si0[s], ni * 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(sc.cov_end.data(), d_cend.as<int32_t>() + si0[s], ni * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(sc.cov_tid.data(), d_ctid + sum[s].ibase0, ni * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(sc.cov_beg.data(), d_cbeg + sum[s].ibase0, ni * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(sc.cov_end.data(), d_cend + sum[s].ibase0, ni * 4, hipMemcpyDeviceToHost, st));
         }
         const DpAcc &a = acc[s];
         sc.on_device = true; sc.d_seq = dsts[s].seq; sc.d_qual = dsts[s].qual; sc.d_seq_bytes = piece_bytes[s] + 32;
@@ -1043,36 +1204,29 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
         sc.mm_sampled_bases = a.mm_bases; sc.mm_sampled = a.mm;
         sc.alg_seq_bytes = a.alg_seq; sc.alg_qual_bytes = a.alg_qual; sc.alg_8d_bytes = a.alg8d; sc.alg_cigar_bytes = a.alg_cigar;
         sc.st = msnv_sample_stats{a.total, a.unmapped, a.zeroq, a.proper, a.dup, a.any_mapped};
-    }
-    // first pileup read of every sample / of every (sample, contig): the first-line quirk of snpCall (call_vC.cpp:423)
-    for (size_t s = 0; s < S; ++s) {
-        SampleCols &sc = ds.samples[first + s];
-        if (acc[s].first_pile != ~0ull) {
-            unsigned long long key = 0; uint32_t e32 = 0;
-            HIP_TRY(hipMemcpyAsync(&key, d_key.as<unsigned long long>() + acc[s].first_pile, 8, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(&e32, d_end.as<uint32_t>() + acc[s].first_pile, 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            const int32_t tid = (int32_t)(key >> 32), pos = (int32_t)(uint32_t)key;
-            int64_t b = pos, e = (int64_t)e32;
+        // first pileup read of the sample: the first-line quirk of snpCall (call_vC.cpp:423)
+        if (a.first_pile != ~0ull) {
+            const int32_t tid = (int32_t)(sum[s].first_key >> 32), pos = (int32_t)(uint32_t)sum[s].first_key;
+            int64_t b = pos, e = (int64_t)sum[s].first_end;
             if (ds.has_bed) { b = std::max(b, ds.bed_beg[(size_t)tid]); e = std::min(e, ds.bed_end[(size_t)tid]); }
             if (b < e) { sc.first_tid = tid; sc.first_beg = (int32_t)b; sc.first_end = (int32_t)e; }
         }
-        if (acc[s].beyond != ~0ull) {
-            unsigned long long key = 0;
-            HIP_TRY(hipMemcpyAsync(&key, d_key.as<unsigned long long>() + acc[s].beyond, 8, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
+        if (a.beyond != ~0ull) {
             sc.warned_beyond_end = true;
             fprintf(stderr, "msnv: warning: read at %s:%d reaches the contig end in qaCompute's index space (undefined behaviour in the reference: coverageHist[-1]); "
-                            "the last position of the contig is left out of the coverage histogram\n", ds.names[(size_t)(int32_t)(key >> 32)].c_str(), (int32_t)(uint32_t)key + 1);
+                            "the last position of the contig is left out of the coverage histogram\n", ds.names[(size_t)(int32_t)(sum[s].beyond_key >> 32)].c_str(),
+                    (int32_t)(uint32_t)sum[s].beyond_key + 1);
         }
     }
     HIP_TRY(hipStreamSynchronize(st));
+    // ... and of every (sample, contig)
     for (const DpRun &r : runs) {
         SampleCols &sc = ds.samples[first + r.sample];
         if (sc.first_any.empty()) { sc.first_any.assign(NC, -1); sc.first_from1.assign(NC, -1); }
         sc.first_any[(size_t)r.tid] = r.first_any; sc.first_from1[(size_t)r.tid] = r.first_from1;
     }
     T.wall_download_s += now_s() - t_dl;
+#undef DP_BUF
     return MSNV_OK;
 }
 

@@ -190,3 +190,35 @@ def test_errors_carry_the_host_stage_codes():
                     ds.close()
     finally:
         ctx.close()
+
+
+def test_record_scan_across_segment_seams():
+    """The record chain is walked segment by segment with GUESSED entry points checked at every seam (devpack.hip: msnv_scan_segments):
+    tiny segments put a seam into almost every record, a read name that looks like a record header makes a guess go wrong."""
+    syn, samples = synth_case(n_species=2, contig_len=6000, n_samples=4, mean_cov=9.0, snv_density=0.02, seed=25)
+    for kb in ("1", "2", "64"):
+        with _env(MSNV_SCAN_SEG_KB=kb):
+            _same_dataset(syn.names, syn.lengths, syn.seqs, samples, check_oracle=(kb == "1"))
+    # a decoy: inside a long read name, the bytes of three consecutive plausible record headers
+    import struct
+    ref = "ACGT" * 1500
+
+    def fake(nxt):                      # 36 header bytes of a "record" with block_size nxt - 4 whose fields pass every plausibility test
+        return struct.pack("<iiiBBHHHiiii", nxt - 4, 0, 5, 2, 60, 4680, 0, 0, 0, -1, -1, 0)
+    decoy = (fake(40) + b"ab\0\0") * 6
+    name = ("N" * 3 + decoy.decode("latin-1")[:200]).replace("\0", "x")
+    recs = []
+    for k in range(40):
+        recs.append(bt.make_record(0, 10 + 20 * k, "50M", ref[10 + 20 * k:60 + 20 * k], name="r%d" % k))
+    stream = bt.records(*recs)
+    ctx = core.Context(0)
+    try:
+        for kb in ("1", "256"):
+            with _env(MSNV_SCAN_SEG_KB=kb, MSNV_PACK="device"):
+                ds = core.Dataset(ctx, ["c"], [6000], [ref])
+                ds.add_sample_records(stream)
+                ds.finalize()
+                assert ds.info()["n_reads_pileup"] == 40
+                ds.close()
+    finally:
+        ctx.close()
