@@ -495,6 +495,10 @@ typedef struct {
                                     1 .. max contigs `refGenome<k>clus.c<j>` that share contig_len bases           */
     int32_t  species_per_sample; /* 0: presence by frac_absent.  > 0: every sample draws that many random species and keeps
                                     each of them with probability 1 - frac_absent (fractional species counts of scaled shards) */
+    double   frac_aux;           /* records that carry auxiliary fields behind the qualities, as every aligner writes them
+                                    (NM:C, MD:Z, AS:i -- 18 bytes); 0 = none (the default workload's bytes do not change)       */
+    double   frac_noseq;         /* records with SEQ `*` (l_seq = 0, CIGAR kept): in the pileup every base of such a read is N
+                                    with quality 0; qaCompute counts its M blocks like any other                               */
 } msnv_synth_params;
 
 void msnv_synth_params_default(msnv_synth_params *p);

@@ -98,7 +98,8 @@ class SynthParams(C.Structure):
                 ("snv_density", C.c_double), ("error_rate", C.c_double), ("frac_lowq", C.c_double),
                 ("frac_indel_reads", C.c_double), ("frac_clip_reads", C.c_double), ("frac_flagged", C.c_double),
                 ("lowercase_ref", C.c_int32), ("seed", C.c_uint64), ("frac_paired", C.c_double),
-                ("contigs_per_species_max", C.c_int32), ("species_per_sample", C.c_int32)]
+                ("contigs_per_species_max", C.c_int32), ("species_per_sample", C.c_int32),
+                ("frac_aux", C.c_double), ("frac_noseq", C.c_double)]
 
 
 # every symbol include/msnv.h declares: (name, restype, argtypes)

@@ -234,7 +234,21 @@ void synth_sample_records(const msnv_synth_params &p, int sample, const std::vec
             // ---- serialise (SAMv1 4.2)
             char name[32];
             int l_name = snprintf(name, sizeof name, "s%dr%llu", sample, (unsigned long long)job.name) + 1;
-            uint32_t bs = 32 + (uint32_t)l_name + 4u * (uint32_t)cigar.size() + (uint32_t)(l_seq + 1) / 2 + (uint32_t)l_seq;
+            // (drawn only when asked for: the default workload's streams stay what they were)
+            const bool noseq = p.frac_noseq > 0 && r.uni() < p.frac_noseq;            // SEQ `*`: no bases, no qualities, the CIGAR stays
+            const bool aux = p.frac_aux > 0 && r.uni() < p.frac_aux;                  // NM:C MD:Z AS:i behind the qualities
+            if (noseq) l_seq = 0;
+            uint8_t auxb[24]; uint32_t n_aux = 0;
+            if (aux) {
+                const uint8_t nm[4] = {'N', 'M', 'C', (uint8_t)r.below(4)};
+                memcpy(auxb, nm, 4); n_aux = 4;
+                const int md = snprintf((char *)auxb + n_aux, 8, "MDZ%d", rl) + 1; n_aux += (uint32_t)md;
+                const uint8_t as[3] = {'A', 'S', 'i'};
+                memcpy(auxb + n_aux, as, 3); n_aux += 3;
+                const uint32_t score = (uint32_t)rl - r.below(10);
+                for (int b = 0; b < 4; ++b) auxb[n_aux++] = (uint8_t)(score >> (8 * b));
+            }
+            uint32_t bs = 32 + (uint32_t)l_name + 4u * (uint32_t)cigar.size() + (uint32_t)(l_seq + 1) / 2 + (uint32_t)l_seq + n_aux;
             put32(out, bs);
             put32(out, (uint32_t)k); put32(out, (uint32_t)pos);
             out.push_back((uint8_t)l_name); out.push_back((uint8_t)mapq);
@@ -245,7 +259,8 @@ void synth_sample_records(const msnv_synth_params &p, int sample, const std::vec
             out.insert(out.end(), name, name + l_name);
             for (uint32_t c : cigar) put32(out, c);
             for (int j = 0; j < l_seq; j += 2) out.push_back((uint8_t)(codes[(size_t)j] << 4 | (j + 1 < l_seq ? codes[(size_t)j + 1] : 0)));
-            out.insert(out.end(), quals.begin(), quals.end());
+            out.insert(out.end(), quals.begin(), quals.begin() + l_seq);
+            out.insert(out.end(), auxb, auxb + n_aux);
         }
     }
 }
@@ -269,6 +284,7 @@ extern "C" void msnv_synth_params_default(msnv_synth_params *p) {
     p->frac_flagged = 0.01; p->lowercase_ref = 0; p->seed = 1;
     p->frac_paired = 0.0;
     p->contigs_per_species_max = 0; p->species_per_sample = 0;
+    p->frac_aux = 0.0; p->frac_noseq = 0.0;
 }
 
 extern "C" int msnv_synth_contig_count(const msnv_synth_params *p) { return p ? msnv::synth_contig_count(*p) : 0; }

@@ -25,7 +25,7 @@ int main(int argc, char **argv) {
     msnv_params p;
     msnv_params_default(&p);
     int threads = 0, arg;
-    while ((arg = getopt(argc, argv, "f:b:l:g:i:c:t:p:@:Ba:d:h")) >= 0) {
+    while ((arg = getopt(argc, argv, "f:b:l:g:i:c:t:p:@:Badh")) >= 0) {
         switch (arg) {
         case 'f': ref = optarg; break;
         case 'b': list = optarg; break;
@@ -36,7 +36,7 @@ int main(int argc, char **argv) {
         case 't': p.calling_threshold = atoi(optarg); break;
         case 'p': p.min_fraction = atof(optarg); break;
         case '@': threads = atoi(optarg); break;
-        case 'B': case 'a': case 'd': break;             // mpileup -B is implied (no BAQ); snpCall -a/-d are accepted and ignored (:370-380)
+        case 'B': case 'a': case 'd': break;             // mpileup -B is implied (no BAQ); snpCall's -a / -d are flags WITHOUT an argument (getopt string "hdab:f:g:i:c:p:t:", call_vC.cpp:346), accepted and ignored (:351-357)
         default: usage(); return 1;                      // snpCall -h prints the usage and fails (:381-384)
         }
     }

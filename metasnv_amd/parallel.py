@@ -151,11 +151,31 @@ def gather_bytes(blob):
     return [o[:c].cpu().numpy() for o, c in zip(out, counts)]
 
 
-def exchange_records(parts, status=0):
+class DeviceParts:
+    """What exchange_records(..., keep_on_device=True) returns over RCCL: the received bytes as ONE tensor in HBM and where every
+    sender's part lies in it.  The record streams inside go to the library where they are (core.Dataset.add_samples_records_device:
+    parsed, filtered and packed by kernels); only the few header bytes a caller asks for with head() come to the host."""
+
+    def __init__(self, tensor, sizes):
+        self.tensor, self.sizes = tensor, [int(x) for x in sizes]
+        self.offsets = [0]
+        for n in self.sizes:
+            self.offsets.append(self.offsets[-1] + n)
+
+    def head(self, sender, n_bytes):
+        o = self.offsets[sender]
+        return self.tensor[o:o + n_bytes].cpu().numpy()
+
+    def address(self, sender, offset=0):
+        return self.tensor.data_ptr() + self.offsets[sender] + int(offset)
+
+
+def exchange_records(parts, status=0, keep_on_device=False):
     """All-to-all of byte streams: parts[q] (1-D uint8 array) goes to rank q; returns the list of the arrays this rank
     received, indexed by sender.  {size, status} pairs travel first (one all_to_all of world x 2 int64), then the bytes.
     `status` != 0 says "this rank failed in the step that made the parts": every rank then raises RankError before the
-    byte exchange instead of waiting in it for a rank that is gone."""
+    byte exchange instead of waiting in it for a rank that is gone.
+    keep_on_device (RCCL only; ignored over gloo): the received bytes stay in HBM -- returns a DeviceParts instead of host arrays."""
     if _dist is None:
         if status:
             raise RankError("rank 0 reported error %d" % status)
@@ -175,6 +195,9 @@ def exchange_records(parts, status=0):
     tsend = torch.from_numpy(send).to(dev)
     trecv = torch.empty(sum(rsizes), dtype=torch.uint8, device=dev)
     _dist.all_to_all_single(trecv, tsend, output_split_sizes=[int(x) for x in rsizes], input_split_sizes=sizes)
+    if keep_on_device and dev.type == "cuda":
+        torch.cuda.current_stream().synchronize()        # the library reads the tensor on a stream of its own
+        return DeviceParts(trecv, rsizes)
     got = trecv.cpu().numpy()
     out, o = [], 0
     for n in rsizes:
@@ -280,8 +303,11 @@ def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=Non
         for q in range(_world):
             hdr = np.array([p.size for p in per_dest[q]], dtype=np.int64).view(np.uint8)
             send.append(np.concatenate([hdr] + per_dest[q]) if per_dest[q] else np.zeros(0, np.uint8))
+        # over RCCL the received streams stay in HBM and are parsed / filtered / packed there (csrc/devpack.hip): no copy to the host, no host
+        # pack, no second upload (MSNV_PACK=host keeps the round trip)
+        on_device = getattr(ds, "ctx", None) is not None and hasattr(ds, "add_samples_records_device") and os.environ.get("MSNV_PACK", "device")[:1] != "h"
         try:
-            got = exchange_records(send, status=0 if failure is None else int(getattr(failure, "code", 0)) or 99)
+            got = exchange_records(send, status=0 if failure is None else int(getattr(failure, "code", 0)) or 99, keep_on_device=on_device)
         except RankError:
             if failure is not None:
                 raise failure
@@ -290,6 +316,19 @@ def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=Non
         n_from = [0] * _world
         for _, r in plan_round:
             n_from[r] += 1
+        if isinstance(got, DeviceParts):
+            sizes_of = [got.head(r, 8 * n_from[r]).view(np.int64) for r in range(_world)]
+            starts = [8 * n_from[r] + np.concatenate([[0], np.cumsum(sizes_of[r])]).astype(np.int64) for r in range(_world)]
+            ptrs, sizes = [], []
+            for i, r in plan_round:
+                k = i - base - r * batch
+                ptrs.append(got.address(r, starts[r][k]) if int(sizes_of[r][k]) else 0)
+                sizes.append(int(sizes_of[r][k]))
+            ds.add_samples_records_device(ptrs, sizes)
+            if metrics is not None:
+                metrics["records_packed_on_device_bytes"] = metrics.get("records_packed_on_device_bytes", 0) + int(sum(sizes))
+            del got
+            continue
         sizes_of = [got[r][:8 * n_from[r]].view(np.int64) for r in range(_world)]
         starts = [8 * n_from[r] + np.concatenate([[0], np.cumsum(sizes_of[r])]).astype(np.int64) for r in range(_world)]
         streams = []

@@ -57,6 +57,8 @@ def main():
     assert res["owner"] == [0] * len(names)
     m = res["metrics"]
     assert m["gather_bytes_received"] > 0 and m["inflated_record_bytes_per_rank"] == [sum(syn.sample_records(i).size for i in range(sp.n_samples))]
+    # the streams the all-to-all left in HBM were packed there (csrc/devpack.hip): none of them came back to the host
+    assert m.get("records_packed_on_device_bytes", 0) == sum(syn.sample_records(i).size for i in range(sp.n_samples)), m.get("records_packed_on_device_bytes")
     core.write_calls_cells(names, sp.n_samples, res["sites"], res["row_off"], res["cell_sample"], res["cells"],
                            os.path.join(work, "called_SNPs"), os.path.join(work, "indiv_called"))
     for i in range(sp.n_samples):

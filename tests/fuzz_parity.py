@@ -30,6 +30,12 @@ def sweep(n_cases, seed, verbose=True):
                   min_baseq=rnd.choice([0, 13, 13, 30]), max_depth=rnd.choice([8000, 8000, 8000, 60, 7]), min_mapq=rnd.choice([0, 0, 1, 30]),
                   count_orphans=rnd.choice([0, 1]), flag_filter=rnd.choice([0x704, 0x704, 0x400, 0]), ignore_overlaps=rnd.choice([0, 0, 0, 1]))
         os.environ["MSNV_LAYOUT"] = rnd.choice(["pieces", "dense"])
+        # the per-read stage: kernels (csrc/devpack.hip; tiny scan segments put a seam into most records) or, now and then, the host threads
+        rk = random.Random(kw["seed"])
+        os.environ["MSNV_PACK"] = os.environ.get("FUZZ_PACK") or rk.choice(["device", "device", "device", "host"])
+        os.environ["MSNV_SCAN_SEG_KB"] = rk.choice(["1", "8", "256"])
+        # what a real aligner writes: auxiliary fields behind the qualities, now and then a record without SEQ
+        kw["frac_aux"] = rk.choice([0.0, 0.3, 1.0]); kw["frac_noseq"] = rk.choice([0.0, 0.0, 0.05])
         deep_mode = os.environ.get("MSNV_DEEP", "split")
         sp = core.synth_params(**kw)
         syn = core.Synth(sp)

@@ -186,3 +186,8 @@ def test_process_drop_in_reads_stdin_like_snpcall(tmp_path):
     assert r.returncode == 0, r.stderr.decode()
     assert r.stdout.decode() == _read(os.path.join(GOLD, "E2.called_SNPs"))
     assert _read(ip) == _read(os.path.join(GOLD, "E2.indiv_called"))
+    # snpCall's -a and -d are flags without an argument (call_vC.cpp:346 "hdab:f:g:i:c:p:t:"): what follows them is the next option
+    r2 = subprocess.run([exe, "-a", "-f", os.path.join(GOLD, "E2.ref.fa"), "-d", "-g", os.path.join(GOLD, "E2.annotation.tsv"), "-i", ip, "-c", "4", "-t", "4"],
+                        input=text.encode(), capture_output=True, timeout=300)
+    assert r2.returncode == 0, r2.stderr.decode()
+    assert r2.stdout.decode() == r.stdout.decode()
