@@ -87,6 +87,13 @@ static_assert(sizeof(WorkItem) == 64, "work items are loaded as four 16-byte wor
 
 struct SiteRec { uint32_t gpos, cov, n[4]; };                          // gate kernel output (24 B)
 
+// What a round of the device pack leaves in HBM besides the columns: its piece headers (tile order, positions still contig-relative) and
+// qaCompute intervals, sample after sample.  finalize builds the tile index from them on the device (devpack.hip: devfin_*); the host sees
+// one DevPair per (sample, contig, tile) run of pieces.
+struct DevRound { void *buf = nullptr; ReadHdr *hdr = nullptr; int32_t *tid = nullptr, *end = nullptr; uint16_t *depth = nullptr;
+                  int32_t *cov_tid = nullptr, *cov_beg = nullptr, *cov_end = nullptr; uint64_t n_pieces = 0, n_iv = 0; size_t first_sample = 0; };
+struct DevPair { int32_t tid; uint32_t tile, lo, hi, maxd; };      // tile: inside the contig; [lo, hi): pieces of the sample; maxd: bound of the per-position depth
+
 // host staging of one sample
 struct SampleCols {
     std::vector<ReadHdr>  hdr;
@@ -110,6 +117,10 @@ struct SampleCols {
     bool     on_device = false;
     uint8_t *d_seq = nullptr, *d_qual = nullptr;      // into a round buffer of msnv_dataset::dp
     uint64_t d_seq_bytes = 0;                         // bytes of the seq column incl. the 32 tail bytes (what seq.size() is for a host-packed sample)
+    bool     dev_index = false;                       // headers and intervals are still in HBM only (DevPackTables::rounds): hdr / tid / end / depth / cov_* above are empty
+    int32_t  dev_round = -1;                          // ... in that round, from these offsets
+    uint64_t dev_piece0 = 0, dev_iv0 = 0, n_dev_pieces = 0, n_dev_iv = 0;
+    std::vector<DevPair> dev_pairs;                   // its (contig, tile) runs of pieces, in order
     msnv_sample_stats st{};          // qaCompute "Other" statistics (qaCompute.cpp:642-654), counted over every record of the BAM
 };
 
@@ -122,6 +133,9 @@ struct DevPackTables {
     uint64_t  pref_words = 0;
     std::vector<void *> round_bufs;   // packed seq / quality-bit buffers of the rounds (SampleCols::d_seq / d_qual point into them): freed by finalize
     std::vector<std::pair<void *, uint64_t>> scratch;   // per-round work buffers, kept (grow-only) from round to round: {pointer, capacity}
+    std::vector<DevRound> rounds;
+    int32_t  *overhang = nullptr;     // per contig: furthest end of a piece beyond the contig's length (0: none), device
+    uint32_t *any_overhang = nullptr; // device flag
     bool      ready = false;
     // cumulative device-pack accounting (msnv_host_timers: pack_device_wall_s; msnv_devpack_stats)
     double    ms_scan = 0, ms_measure = 0, ms_depth = 0, ms_emit = 0, ms_sort = 0, wall_upload_s = 0, wall_download_s = 0, wall_prepass_s = 0;

@@ -19,10 +19,21 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
 // A device-packed sample's bases and quality flags as host staging (SampleCols::seq / qual), for the two re-layouts that still run on
 // the host (pack.cpp: relayout_dense, split_deep_runs' relocation).
 int devpack_sample_to_host(SampleCols &sc);
+int devpack_download_pieces(msnv_dataset &ds);
 void devpack_release(DevPackTables &t);
 // finalize: copies of the rounds' columns into the dataset's, and the alignment padding behind every piece set to the reference
 int devpack_copy_columns(const SampleCols &sc, uint8_t *dst_seq, uint8_t *dst_qual_bits, void *stream);
 int devpack_fill_padding(DeviceCols &d, const std::vector<uint8_t> &sample_on_device, void *stream);
+// finalize on the device (all samples device-packed; devpack.hip "finalize on the device"): the per-piece / per-interval loops of
+// finalize_dataset as kernels over the rounds' headers and intervals
+struct DevMergedSrc { uint32_t pair, in_group; unsigned long long h_base; };   // a pair of a merged group: its index in the group, first slot of its headers in hdr8m
+struct DevCovPair { uint32_t tile, sample, lo, hi; };                            // intervals [lo, hi) of `sample` (kept ones, sample-relative) may touch `tile`
+int devfin_overhang(msnv_dataset &ds, std::vector<int64_t> &maxend);
+int devfin_headers(msnv_dataset &ds, DeviceCols &d, const std::vector<uint64_t> &rbase);
+int devfin_chunk_counts(msnv_dataset &ds, DeviceCols &d, const std::vector<uint32_t> &narrow_pairs, std::vector<uint32_t> &counts);
+int devfin_chunk_fill(msnv_dataset &ds, DeviceCols &d, const std::vector<uint32_t> &narrow_pairs, const std::vector<uint32_t> &chunk_base, uint64_t n_chunks, std::vector<ChunkDesc> &out);
+int devfin_merged_headers(msnv_dataset &ds, DeviceCols &d, const std::vector<DevMergedSrc> &list);
+int devfin_coverage(msnv_dataset &ds, DeviceCols &d, std::vector<uint64_t> &cvbase, std::vector<DevCovPair> &cp);
 // waits for the copies, releases the round buffers and the tables (no sample can be added after finalize)
 int devpack_finish(msnv_dataset &ds);
 

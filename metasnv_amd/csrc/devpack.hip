@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256) void msnv_emit_headers(const uint8_t *raw, con
                                                          const uint8_t *r_flags, const uint16_t *r_depth, const uint32_t *pbase, const unsigned long long *sbase,
                                                          const uint32_t *ibase, const unsigned long long *samp_sbase0,
                                                          ReadHdr *hdr, int32_t *ptid, int32_t *pend, uint16_t *pdepth, PieceSrc *psrc,
-                                                         int32_t *cov_tid, int32_t *cov_beg, int32_t *cov_end) {
+                                                         int32_t *cov_tid, int32_t *cov_beg, int32_t *cov_end, int32_t *overhang, uint32_t *any_overhang) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rec) return;
     const uint8_t f = r_flags[i];
@@ -490,6 +490,7 @@ __global__ __launch_bounds__(256) void msnv_emit_headers(const uint8_t *raw, con
                 ReadHdr h;
                 h.gpos = (uint32_t)(rp + off); h.seqoff = (uint32_t)so; h.cig = n; h.meta = META_PILEUP_OK | r.mapq << 16;
                 hdr[w] = h; ptid[w] = r.tid; pend[w] = (int32_t)(rp + off + n); pdepth[w] = depth;
+                if (rp + off + n > c.len) { atomicMax(&overhang[r.tid], (int32_t)(rp + off + n)); *any_overhang = 1u; }     // a read that runs past its contig: the contig's tiles reach that far (finalize)
                 PieceSrc ps;
                 ps.seq = seq_abs; ps.qual = qual_abs; ps.q0 = (uint32_t)(q + off); ps.sample = s; ps.pad = 0;
                 const long long g = rp + off, left = c.seq_len - g;
@@ -647,6 +648,29 @@ __global__ void msnv_gather_pieces(const uint32_t *idx, uint32_t n, const ReadHd
     hdr2[i] = hdr[j]; ptid2[i] = ptid[j]; pend2[i] = pend[j]; pdepth2[i] = pdepth[j];
 }
 
+// ------------------------------------------------------------------------------------------ (sample, contig, tile) runs of the sorted pieces
+struct DevPairRec { uint32_t sample; int32_t tid; uint32_t tile, start, maxd; };     // start: piece index in the round
+__global__ void msnv_pair_flags(const unsigned long long *keys, uint32_t n, uint32_t *flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+__global__ void msnv_pair_starts(const unsigned long long *keys, const uint32_t *flag, const uint32_t *pid_incl, uint32_t n, uint32_t tid_bits, DevPairRec *recs) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flag[i]) return;
+    const unsigned long long k = keys[i];
+    DevPairRec r;
+    r.tile = (uint32_t)(k & 0x1fffffu); r.tid = (int32_t)((k >> 21) & ((1ull << tid_bits) - 1ull)); r.sample = (uint32_t)(k >> (21u + tid_bits)); r.start = i; r.maxd = 0;
+    recs[pid_incl[i] - 1u] = r;
+}
+__global__ void msnv_pair_maxd(DevPairRec *recs, uint32_t n_pairs, uint32_t n_pieces, const uint16_t *depth) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    const uint32_t lo = recs[p].start, hi = p + 1 < n_pairs ? recs[p + 1].start : n_pieces;
+    uint32_t m = 0;
+    for (uint32_t i = lo; i < hi; ++i) { const uint32_t d = depth[i]; m = d > m ? d : m; }
+    recs[p].maxd = m;
+}
+
 // ------------------------------------------------------------------------------------------ finalize: padding behind the pieces
 // The alignment padding behind a piece (up to the next 4 bases) reads as the reference the kernel compares it with, N beyond the tile
 // (pack.cpp: finalize_dataset; msnv_pileup_tiles_narrow32 masks mismatch flags per group of bases, not per base).
@@ -708,6 +732,9 @@ int build_tables(msnv_dataset &ds) {
     t.pref_words = nib / 8 + 2;
     if (int rc = dev_alloc(&t.contigs, std::max<size_t>(1, NC) * sizeof(DpContig), nullptr)) return rc;
     if (int rc = dev_upload(t.contigs, ct.data(), NC * sizeof(DpContig))) return rc;
+    if (int rc = dev_alloc((void **)&t.overhang, (std::max<size_t>(1, NC) + 1) * sizeof(int32_t), nullptr)) return rc;
+    if (int rc = dev_memset(t.overhang, 0, (std::max<size_t>(1, NC) + 1) * sizeof(int32_t))) return rc;
+    t.any_overhang = reinterpret_cast<uint32_t *>(t.overhang + std::max<size_t>(1, NC));
     if (int rc = dev_alloc((void **)&t.pref4, t.pref_words * sizeof(uint32_t), nullptr)) return rc;
     // staged in chunks (a shard of a 25 GB database: gigabases)
     std::vector<uint32_t> stage;
@@ -753,6 +780,10 @@ const char *err_text(uint32_t kind) {
 void devpack_release(DevPackTables &t) {
     if (t.contigs) dev_free(t.contigs);
     if (t.pref4) dev_free(t.pref4);
+    if (t.overhang) dev_free(t.overhang);
+    t.overhang = nullptr; t.any_overhang = nullptr;
+    for (DevRound &r : t.rounds) if (r.buf) dev_free(r.buf);
+    t.rounds.clear();
     for (void *p : t.round_bufs) dev_free(p);
     t.round_bufs.clear();
     for (auto &b : t.scratch) if (b.first) dev_free(b.first);
@@ -1139,7 +1170,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     HIP_TRY(hipMemcpyAsync(d_pb, piece_bytes.data(), S * 8, hipMemcpyHostToDevice, st));
     if (NR) {
         hipLaunchKernelGGL(msnv_emit_headers, grid_for(NR, 256), dim3(256), 0, st, raw, d_recoff, d_recsample, NR, ctg, d_flags, d_depth, d_pbase, d_sbase, d_ibase, d_ss0,
-                           d_hdr, d_ptid, d_pend, d_pdepth, d_psrc, d_ctid, d_cbeg, d_cend);
+                           d_hdr, d_ptid, d_pend, d_pdepth, d_psrc, d_ctid, d_cbeg, d_cend, T.overhang, T.any_overhang);
         HIP_TRY(hipGetLastError());
     }
     if (NPC) {
@@ -1151,10 +1182,11 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     HIP_TRY(hipMemcpyAsync(acc.data(), d_acc, S * sizeof(DpAcc), hipMemcpyDeviceToHost, st));
     T.ms_emit += tm.stop();
 
-    // ---- headers in tile order (stable: read order inside a tile)
+    // ---- headers in tile order (stable: read order inside a tile), and the (sample, contig, tile) runs of pieces = the pairs of the tile index
     tm.start();
     const ReadHdr *src_hdr = d_hdr; const int32_t *src_tid = d_ptid, *src_end = d_pend; const uint16_t *src_depth = d_pdepth;
-    if (NPC > 1) {
+    std::vector<DevPairRec> prec;
+    if (NPC >= 1) {
         DP_BUF(unsigned long long, d_tk, NPCa);
         DP_BUF(uint32_t, d_ix, NPCa);
         DP_BUF(uint32_t, d_uns, 4);
@@ -1165,41 +1197,71 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
         uint32_t uns = 0;
         HIP_TRY(hipMemcpyAsync(&uns, d_uns, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        const unsigned long long *skeys = d_tk;
+        DP_BUF(unsigned long long, d_tk2, NPCa);
+        DP_BUF(uint32_t, d_ix2, NPCa);
+        DP_BUF(ReadHdr, d_hdr2, NPCa);
+        DP_BUF(int32_t, d_ptid2, NPCa);
+        DP_BUF(int32_t, d_pend2, NPCa);
+        DP_BUF(uint16_t, d_pdepth2, NPCa);
         if (uns) {
-            DP_BUF(unsigned long long, d_tk2, NPCa);
-            DP_BUF(uint32_t, d_ix2, NPCa);
-            DP_BUF(ReadHdr, d_hdr2, NPCa);
-            DP_BUF(int32_t, d_ptid2, NPCa);
-            DP_BUF(int32_t, d_pend2, NPCa);
-            DP_BUF(uint16_t, d_pdepth2, NPCa);
             if (int rc = sort64(d_tk, d_tk2, d_ix, d_ix2, NPC, 21u + tid_bits + std::max(1u, bit_width_u64(S - 1)))) return rc;
             hipLaunchKernelGGL(msnv_gather_pieces, grid_for(NPC, 256), dim3(256), 0, st, d_ix2, NPC, d_hdr, d_ptid, d_pend, d_pdepth, d_hdr2, d_ptid2, d_pend2, d_pdepth2);
             HIP_TRY(hipGetLastError());
-            src_hdr = d_hdr2; src_tid = d_ptid2; src_end = d_pend2; src_depth = d_pdepth2;
+            src_hdr = d_hdr2; src_tid = d_ptid2; src_end = d_pend2; src_depth = d_pdepth2; skeys = d_tk2;
+        }
+        // runs of equal keys (d_ix / d_ix2 are free again: flags and their scan)
+        uint32_t n_pairs = 0;
+        hipLaunchKernelGGL(msnv_pair_flags, grid_for(NPC, 256), dim3(256), 0, st, skeys, NPC, d_ix);
+        HIP_TRY(hipGetLastError());
+        if (int rc = scan32(d_ix, d_ix2, NPC, true)) return rc;
+        HIP_TRY(hipMemcpyAsync(&n_pairs, d_ix2 + (NPC - 1), 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        DP_BUF(DevPairRec, d_prec, (uint64_t)n_pairs + 1);
+        hipLaunchKernelGGL(msnv_pair_starts, grid_for(NPC, 256), dim3(256), 0, st, skeys, d_ix, d_ix2, NPC, tid_bits, d_prec);
+        hipLaunchKernelGGL(msnv_pair_maxd, grid_for(n_pairs, 64), dim3(64), 0, st, d_prec, n_pairs, NPC, src_depth);
+        HIP_TRY(hipGetLastError());
+        prec.resize(n_pairs);
+        HIP_TRY(hipMemcpyAsync(prec.data(), d_prec, (size_t)n_pairs * sizeof(DevPairRec), hipMemcpyDeviceToHost, st));
+    }
+    // ---- what stays in HBM of the round besides the columns: headers (tile order) and intervals, for finalize
+    DevRound keep;
+    {
+        const uint64_t b_hdr = (uint64_t)NPC * sizeof(ReadHdr), b_4 = (((uint64_t)NPC * 4) + 15) & ~15ull, b_2 = (((uint64_t)NPC * 2) + 15) & ~15ull, b_iv = (((uint64_t)NIV * 4) + 15) & ~15ull;
+        if (int rc = dev_alloc(&keep.buf, b_hdr + 2 * b_4 + b_2 + 3 * b_iv + 64, nullptr)) return rc;
+        uint8_t *q = static_cast<uint8_t *>(keep.buf);
+        keep.hdr = reinterpret_cast<ReadHdr *>(q); q += b_hdr;
+        keep.tid = reinterpret_cast<int32_t *>(q); q += b_4;
+        keep.end = reinterpret_cast<int32_t *>(q); q += b_4;
+        keep.depth = reinterpret_cast<uint16_t *>(q); q += b_2;
+        keep.cov_tid = reinterpret_cast<int32_t *>(q); q += b_iv;
+        keep.cov_beg = reinterpret_cast<int32_t *>(q); q += b_iv;
+        keep.cov_end = reinterpret_cast<int32_t *>(q);
+        keep.n_pieces = NPC; keep.n_iv = NIV; keep.first_sample = first;
+        T.rounds.push_back(keep);
+        if (NPC) {
+            HIP_TRY(hipMemcpyAsync(keep.hdr, src_hdr, (size_t)NPC * sizeof(ReadHdr), hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(keep.tid, src_tid, (size_t)NPC * 4, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(keep.end, src_end, (size_t)NPC * 4, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(keep.depth, src_depth, (size_t)NPC * 2, hipMemcpyDeviceToDevice, st));
+        }
+        if (NIV) {
+            HIP_TRY(hipMemcpyAsync(keep.cov_tid, d_ctid, (size_t)NIV * 4, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(keep.cov_beg, d_cbeg, (size_t)NIV * 4, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(keep.cov_end, d_cend, (size_t)NIV * 4, hipMemcpyDeviceToDevice, st));
         }
     }
     T.ms_sort += tm.stop();
 
-    // ---- what the host keeps of a sample: headers, intervals, summaries (finalize_dataset builds the tile index from them)
+    // ---- what the host keeps of a sample: its summaries and its (contig, tile) runs
     const double t_dl = now_s();
+    const int32_t round_no = (int32_t)T.rounds.size() - 1;
     for (size_t s = 0; s < S; ++s) {
         SampleCols &sc = ds.samples[first + s];
-        const size_t np = sum[s + 1].pbase0 - sum[s].pbase0, ni = sum[s + 1].ibase0 - sum[s].ibase0;
-        sc.hdr.resize(np); sc.tid.resize(np); sc.end.resize(np); sc.depth.resize(np);
-        sc.cov_tid.resize(ni); sc.cov_beg.resize(ni); sc.cov_end.resize(ni);
-        if (np) {
-            HIP_TRY(hipMemcpyAsync(sc.hdr.data(), src_hdr + sum[s].pbase0, np * sizeof(ReadHdr), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(sc.tid.data(), src_tid + sum[s].pbase0, np * 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(sc.end.data(), src_end + sum[s].pbase0, np * 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(sc.depth.data(), src_depth + sum[s].pbase0, np * 2, hipMemcpyDeviceToHost, st));
-        }
-        if (ni) {
-            HIP_TRY(hipMemcpyAsync(sc.cov_tid.data(), d_ctid + sum[s].ibase0, ni * 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(sc.cov_beg.data(), d_cbeg + sum[s].ibase0, ni * 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(sc.cov_end.data(), d_cend + sum[s].ibase0, ni * 4, hipMemcpyDeviceToHost, st));
-        }
         const DpAcc &a = acc[s];
         sc.on_device = true; sc.d_seq = dsts[s].seq; sc.d_qual = dsts[s].qual; sc.d_seq_bytes = piece_bytes[s] + 32;
+        sc.dev_index = true; sc.dev_round = round_no; sc.dev_piece0 = sum[s].pbase0; sc.dev_iv0 = sum[s].ibase0;
+        sc.n_dev_pieces = sum[s + 1].pbase0 - sum[s].pbase0; sc.n_dev_iv = sum[s + 1].ibase0 - sum[s].ibase0;
         sc.n_pileup_bases = a.n_bases; sc.n_pileup_reads = a.n_pile_reads;
         sc.mm_sampled_bases = a.mm_bases; sc.mm_sampled = a.mm;
         sc.alg_seq_bytes = a.alg_seq; sc.alg_qual_bytes = a.alg_qual; sc.alg_8d_bytes = a.alg8d; sc.alg_cigar_bytes = a.alg_cigar;
@@ -1219,6 +1281,12 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
         }
     }
     HIP_TRY(hipStreamSynchronize(st));
+    for (size_t p = 0; p < prec.size(); ++p) {
+        const DevPairRec &r = prec[p];
+        SampleCols &sc = ds.samples[first + r.sample];
+        const uint32_t hi = (p + 1 < prec.size() && prec[p + 1].sample == r.sample) ? prec[p + 1].start : (uint32_t)sum[r.sample + 1].pbase0;
+        sc.dev_pairs.push_back(DevPair{r.tid, r.tile, r.start - sum[r.sample].pbase0, hi - sum[r.sample].pbase0, r.maxd});
+    }
     // ... and of every (sample, contig)
     for (const DpRun &r : runs) {
         SampleCols &sc = ds.samples[first + r.sample];
@@ -1227,6 +1295,37 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     }
     T.wall_download_s += now_s() - t_dl;
 #undef DP_BUF
+    return MSNV_OK;
+}
+
+// The headers and intervals of the device-packed samples as host staging (SampleCols::hdr / tid / end / depth / cov_*): what the host
+// form of finalize_dataset works from.  Taken when the dataset needs one of the re-layouts that still run there (dense pieces, deep
+// (sample, tile) runs dealt into groups) or mixes host-packed samples in.
+int devpack_download_pieces(msnv_dataset &ds) {
+    if (!ds.ctx) return MSNV_OK;
+    if (int rc = dev_set_device(ds.ctx->device)) return rc;
+    const double t0 = now_s();
+    for (SampleCols &sc : ds.samples) {
+        if (!sc.dev_index) continue;
+        const DevRound &r = ds.dp.rounds[(size_t)sc.dev_round];
+        const size_t np = (size_t)sc.n_dev_pieces, ni = (size_t)sc.n_dev_iv;
+        sc.hdr.resize(np); sc.tid.resize(np); sc.end.resize(np); sc.depth.resize(np);
+        sc.cov_tid.resize(ni); sc.cov_beg.resize(ni); sc.cov_end.resize(ni);
+        if (np) {
+            HIP_TRY(hipMemcpy(sc.hdr.data(), r.hdr + sc.dev_piece0, np * sizeof(ReadHdr), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(sc.tid.data(), r.tid + sc.dev_piece0, np * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(sc.end.data(), r.end + sc.dev_piece0, np * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(sc.depth.data(), r.depth + sc.dev_piece0, np * 2, hipMemcpyDeviceToHost));
+        }
+        if (ni) {
+            HIP_TRY(hipMemcpy(sc.cov_tid.data(), r.cov_tid + sc.dev_iv0, ni * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(sc.cov_beg.data(), r.cov_beg + sc.dev_iv0, ni * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(sc.cov_end.data(), r.cov_end + sc.dev_iv0, ni * 4, hipMemcpyDeviceToHost));
+        }
+        sc.dev_index = false; sc.dev_pairs.clear(); sc.dev_pairs.shrink_to_fit();
+    }
+    for (DevRound &r : ds.dp.rounds) if (r.buf) { dev_free(r.buf); r.buf = nullptr; }
+    ds.dp.wall_download_s += now_s() - t0;
     return MSNV_OK;
 }
 
@@ -1249,6 +1348,307 @@ int devpack_copy_columns(const SampleCols &sc, uint8_t *dst_seq, uint8_t *dst_qu
     if (sc.d_seq_bytes) HIP_TRY(hipMemcpyAsync(dst_seq, sc.d_seq, sc.d_seq_bytes, hipMemcpyDeviceToDevice, st));
     const uint64_t qb = (2 * sc.d_seq_bytes + 7) / 8;
     if (qb) HIP_TRY(hipMemcpyAsync(dst_qual_bits, sc.d_qual, qb, hipMemcpyDeviceToDevice, st));
+    return MSNV_OK;
+}
+
+// ------------------------------------------------------------------------------------------ finalize on the device
+// The per-piece and per-interval parts of finalize_dataset (pack.cpp) for a dataset whose samples were all packed here: the headers and
+// intervals never leave HBM; the host works on (sample, tile) pairs only.  Every function mirrors the host loop named beside it and
+// produces the same bytes (tests/test_gpu_devpack.py compares every table of the two builds).
+namespace {
+struct Prim {                        // rocPRIM calls with a grow-only temporary buffer
+    hipStream_t st; DevBuf tmp; size_t cap = 0;
+    explicit Prim(hipStream_t s) : st(s) {}
+    int room(size_t need) { if (need > cap) { if (int rc = tmp.alloc(need)) return rc; cap = need; } return MSNV_OK; }
+    int scan32(const uint32_t *in, uint32_t *out, size_t n, bool inclusive) {
+        size_t need = 0;
+        if (inclusive) HIP_TRY(rocprim::inclusive_scan(nullptr, need, in, out, n, rocprim::plus<uint32_t>(), st));
+        else HIP_TRY(rocprim::exclusive_scan(nullptr, need, in, out, 0u, n, rocprim::plus<uint32_t>(), st));
+        if (int rc = room(need)) return rc;
+        if (inclusive) HIP_TRY(rocprim::inclusive_scan(tmp.p, need, in, out, n, rocprim::plus<uint32_t>(), st));
+        else HIP_TRY(rocprim::exclusive_scan(tmp.p, need, in, out, 0u, n, rocprim::plus<uint32_t>(), st));
+        return MSNV_OK;
+    }
+    int scan64(const uint32_t *in, unsigned long long *out, size_t n) {
+        size_t need = 0;
+        HIP_TRY(rocprim::exclusive_scan(nullptr, need, in, out, 0ull, n, rocprim::plus<unsigned long long>(), st));
+        if (int rc = room(need)) return rc;
+        HIP_TRY(rocprim::exclusive_scan(tmp.p, need, in, out, 0ull, n, rocprim::plus<unsigned long long>(), st));
+        return MSNV_OK;
+    }
+    int sort64(unsigned long long *kin, unsigned long long *kout, uint32_t *vin, uint32_t *vout, size_t n, unsigned end_bit) {
+        size_t need = 0;
+        HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, kin, kout, vin, vout, n, 0u, end_bit, st));
+        if (int rc = room(need)) return rc;
+        HIP_TRY(rocprim::radix_sort_pairs(tmp.p, need, kin, kout, vin, vout, n, 0u, end_bit, st));
+        return MSNV_OK;
+    }
+};
+
+__global__ void msnv_fin_headers(const ReadHdr *src, const int32_t *tid, unsigned long long n, const uint32_t *tile_base, ReadHdr *dst) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    ReadHdr h = src[i];
+    h.gpos += tile_base[tid[i]] * TILE;                           // contig-relative -> linear position of the shard
+    dst[i] = h;
+}
+
+// chunks of the narrow work items' pairs (pack.cpp: "chunk descriptors of the narrow work items", HDR4 form): up to CHUNK_READS consecutive
+// pieces whose seq bytes lie within 2^HDR4_OFF_BITS alignment units of the chunk's lowest offset; FILL writes the descriptors and the
+// 4-byte chunk-relative piece headers
+template <bool FILL>
+__global__ void msnv_fin_chunks(const TilePair *pairs, const uint32_t *list, uint32_t n, const ReadHdr *hdr, const unsigned long long *rbase, const unsigned long long *sbase,
+                                uint32_t *counts, const uint32_t *chunk_base, ChunkDesc *chunks, uint32_t *hdr4) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t k = list[j];
+    const TilePair p = pairs[k];
+    const ReadHdr *h = hdr + rbase[p.sample];
+    constexpr unsigned long long span_max = (unsigned long long)SEQ_ALIGN << HDR4_OFF_BITS;
+    uint32_t r = p.read_lo, c = 0;
+    while (r < p.read_hi) {
+        unsigned long long lo = h[r].seqoff, hi = lo;
+        uint32_t e = r;
+        while (e < p.read_hi && e - r < CHUNK_READS) {
+            const unsigned long long o = h[e].seqoff, nlo = lo < o ? lo : o, nhi = hi > o ? hi : o;
+            if (nhi - nlo >= span_max) break;
+            lo = nlo; hi = nhi; ++e;
+        }
+        if (FILL) {
+            for (uint32_t i = r; i < e; ++i) hdr4[rbase[p.sample] + i] = (h[i].gpos % TILE) | h[i].cig << 11 | (uint32_t)((h[i].seqoff - lo) >> SEQ_ALIGN_LOG2) << 19;
+            chunks[chunk_base[j] + c] = ChunkDesc{rbase[p.sample] + r, sbase[p.sample] + lo, p.pad >> 8, k, (e - r) | (e >= p.read_hi ? 1u << 16 : 0u), p.pad & 0xffu};
+        }
+        ++c; r = e;
+    }
+    if (!FILL) counts[j] = c;
+}
+
+__global__ void msnv_fin_merged(const TilePair *pairs, const DevMergedSrc *list, uint32_t n, const ReadHdr *hdr, const unsigned long long *rbase, const unsigned long long *sbase, PieceHdr *hm) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const DevMergedSrc m = list[j];
+    const TilePair p = pairs[m.pair];
+    const ReadHdr *h = hdr + rbase[p.sample];
+    for (uint32_t r = p.read_lo; r < p.read_hi; ++r) {
+        const unsigned long long so = (sbase[p.sample] + h[r].seqoff) >> SEQ_ALIGN_LOG2;     // 37 bits: bits 32-36 ride in bits 27-31 of the first word
+        hm[m.h_base + (r - p.read_lo)] = PieceHdr{(h[r].gpos % TILE) | h[r].cig << 11 | m.in_group << 19 | (uint32_t)(so >> 32) << 27, (uint32_t)so};
+    }
+}
+
+// qaCompute's intervals -> the coverage kernel's inputs (pack.cpp: "genome coverage index")
+__device__ __forceinline__ uint32_t sample_of(const unsigned long long *iv_start, uint32_t n_samples, unsigned long long j) {
+    uint32_t a = 0, b = n_samples;
+    while (b - a > 1) { const uint32_t m = (a + b) / 2; if (iv_start[m] <= j) a = m; else b = m; }
+    return a;
+}
+__global__ void msnv_fin_cov_measure(const int32_t *ctid, const int32_t *cbeg, const int32_t *cend, unsigned long long n, const DpContig *ctg, const uint32_t *tile_base,
+                                     uint32_t *keep, uint32_t *ntile) {
+    const unsigned long long j = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > n) return;
+    if (j == n) { keep[j] = 0; ntile[j] = 0; return; }
+    const int32_t c = ctid[j];
+    const long long L = ctg[c].len, b = cbeg[j];
+    const bool minus_one = b > (long long)cend[j];                                          // {L, L - 1}: "-1 at L - 1" (msnv_emit_headers)
+    const long long e = minus_one ? (long long)cend[j] : ((long long)cend[j] >= L ? L - 1 : (long long)cend[j]);      // qaCompute.cpp:544-549
+    const bool k = minus_one || b < e;
+    uint32_t nt = 0;
+    if (k) {
+        const unsigned long long g0 = (unsigned long long)tile_base[c] * TILE;
+        const uint32_t tf = (uint32_t)((g0 + (unsigned long long)(minus_one ? e : b)) / TILE), tl = minus_one ? tf : (uint32_t)((g0 + (unsigned long long)e - 1) / TILE);
+        nt = tl - tf + 1;
+    }
+    keep[j] = k ? 1u : 0u; ntile[j] = nt;
+}
+__global__ void msnv_fin_cov_emit(const int32_t *ctid, const int32_t *cbeg, const int32_t *cend, unsigned long long n, const DpContig *ctg, const uint32_t *tile_base,
+                                  const unsigned long long *iv_start, uint32_t n_samples, const uint32_t *keep, const uint32_t *kidx, const unsigned long long *ebase,
+                                  Pair32 *iv, unsigned long long *ekey, uint32_t *eval) {
+    const unsigned long long j = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n || !keep[j]) return;
+    const int32_t c = ctid[j];
+    const long long L = ctg[c].len, b = cbeg[j];
+    const bool minus_one = b > (long long)cend[j];
+    const long long e = minus_one ? (long long)cend[j] : ((long long)cend[j] >= L ? L - 1 : (long long)cend[j]);
+    const unsigned long long g0 = (unsigned long long)tile_base[c] * TILE;
+    iv[kidx[j]] = Pair32{(uint32_t)(g0 + (unsigned long long)b), (uint32_t)(g0 + (unsigned long long)e)};
+    const uint32_t s = sample_of(iv_start, n_samples, j);
+    const uint32_t idx = kidx[j] - kidx[iv_start[s]];                                       // index among the sample's kept intervals
+    const uint32_t tf = (uint32_t)((g0 + (unsigned long long)(minus_one ? e : b)) / TILE), tl = minus_one ? tf : (uint32_t)((g0 + (unsigned long long)e - 1) / TILE);
+    unsigned long long w = ebase[j];
+    for (uint32_t t = tf; t <= tl; ++t, ++w) { ekey[w] = (unsigned long long)s << 32 | t; eval[w] = idx; }
+}
+__global__ void msnv_fin_cov_runs(const unsigned long long *skey, const uint32_t *sval, const uint32_t *flag, const uint32_t *rid_incl, unsigned long long n, DevCovPair *out) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = rid_incl[i] - 1u;
+    if (flag[i]) { out[r].tile = (uint32_t)skey[i]; out[r].sample = (uint32_t)(skey[i] >> 32); out[r].lo = sval[i]; }
+    if (i + 1 == n || flag[i + 1]) out[r].hi = sval[i] + 1u;                                  // (stable sort: the run's values ascend)
+}
+__global__ void msnv_gather_u32(const uint32_t *src, const unsigned long long *idx, uint32_t n, uint32_t *out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = src[idx[i]];
+}
+}  // namespace
+
+int devfin_overhang(msnv_dataset &ds, std::vector<int64_t> &maxend) {
+    if (!ds.dp.overhang) return MSNV_OK;
+    uint32_t any = 0;
+    HIP_TRY(hipMemcpy(&any, ds.dp.any_overhang, 4, hipMemcpyDeviceToHost));
+    if (!any) return MSNV_OK;
+    std::vector<int32_t> oh(ds.names.size());
+    HIP_TRY(hipMemcpy(oh.data(), ds.dp.overhang, oh.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t c = 0; c < oh.size(); ++c) if (ds.sel[c]) maxend[c] = std::max<int64_t>(maxend[c], oh[c]);
+    return MSNV_OK;
+}
+
+// d.hdr (allocated, rbase-sized) from the rounds' headers with the positions made linear; needs ds.tile_base
+int devfin_headers(msnv_dataset &ds, DeviceCols &d, const std::vector<uint64_t> &rbase) {
+    hipStream_t st = (hipStream_t)ds.ctx->stream;
+    DevBuf tb;
+    if (int rc = tb.alloc(std::max<size_t>(1, ds.tile_base.size()) * 4)) return rc;
+    HIP_TRY(hipMemcpyAsync(tb.p, ds.tile_base.data(), ds.tile_base.size() * 4, hipMemcpyHostToDevice, st));
+    for (const DevRound &r : ds.dp.rounds) {
+        if (!r.n_pieces) continue;
+        hipLaunchKernelGGL(msnv_fin_headers, grid_for(r.n_pieces, 256), dim3(256), 0, st, r.hdr, r.tid, (unsigned long long)r.n_pieces, tb.as<uint32_t>(), d.hdr + rbase[r.first_sample]);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    return MSNV_OK;
+}
+
+int devfin_chunk_counts(msnv_dataset &ds, DeviceCols &d, const std::vector<uint32_t> &narrow_pairs, std::vector<uint32_t> &counts) {
+    hipStream_t st = (hipStream_t)ds.ctx->stream;
+    const size_t n = narrow_pairs.size();
+    counts.assign(n, 0);
+    if (!n) return MSNV_OK;
+    DevBuf l, c;
+    if (int rc = l.alloc(n * 4)) return rc;
+    if (int rc = c.alloc(n * 4)) return rc;
+    HIP_TRY(hipMemcpyAsync(l.p, narrow_pairs.data(), n * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(msnv_fin_chunks<false>, grid_for(n, 64), dim3(64), 0, st, d.pairs, l.as<uint32_t>(), (uint32_t)n, d.hdr, (const unsigned long long *)d.s_read_base,
+                       (const unsigned long long *)d.s_seq_base, c.as<uint32_t>(), nullptr, nullptr, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(counts.data(), c.p, n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return MSNV_OK;
+}
+
+// chunk descriptors (returned to the host, which appends the merged groups' and uploads the lot) and d.hdr4 (allocated, zeroed)
+int devfin_chunk_fill(msnv_dataset &ds, DeviceCols &d, const std::vector<uint32_t> &narrow_pairs, const std::vector<uint32_t> &chunk_base, uint64_t n_chunks, std::vector<ChunkDesc> &out) {
+    hipStream_t st = (hipStream_t)ds.ctx->stream;
+    const size_t n = narrow_pairs.size();
+    out.resize(n_chunks);
+    if (!n) return MSNV_OK;
+    DevBuf l, b, c;
+    if (int rc = l.alloc(n * 4)) return rc;
+    if (int rc = b.alloc(n * 4)) return rc;
+    if (int rc = c.alloc(std::max<uint64_t>(1, n_chunks) * sizeof(ChunkDesc))) return rc;
+    HIP_TRY(hipMemcpyAsync(l.p, narrow_pairs.data(), n * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(b.p, chunk_base.data(), n * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(msnv_fin_chunks<true>, grid_for(n, 64), dim3(64), 0, st, d.pairs, l.as<uint32_t>(), (uint32_t)n, d.hdr, (const unsigned long long *)d.s_read_base,
+                       (const unsigned long long *)d.s_seq_base, nullptr, b.as<uint32_t>(), c.as<ChunkDesc>(), d.hdr4);
+    HIP_TRY(hipGetLastError());
+    if (n_chunks) HIP_TRY(hipMemcpyAsync(out.data(), c.p, n_chunks * sizeof(ChunkDesc), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return MSNV_OK;
+}
+
+int devfin_merged_headers(msnv_dataset &ds, DeviceCols &d, const std::vector<DevMergedSrc> &list) {
+    hipStream_t st = (hipStream_t)ds.ctx->stream;
+    if (list.empty()) return MSNV_OK;
+    DevBuf l;
+    if (int rc = l.alloc(list.size() * sizeof(DevMergedSrc))) return rc;
+    HIP_TRY(hipMemcpyAsync(l.p, list.data(), list.size() * sizeof(DevMergedSrc), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(msnv_fin_merged, grid_for(list.size(), 64), dim3(64), 0, st, d.pairs, l.as<DevMergedSrc>(), (uint32_t)list.size(), d.hdr, (const unsigned long long *)d.s_read_base,
+                       (const unsigned long long *)d.s_seq_base, d.hdr8m);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    return MSNV_OK;
+}
+
+// d.cov_iv (allocated here: kept intervals + 4 idle entries) and, for the host, the kept intervals before every sample (cvbase) and the
+// (sample, tile) runs of the intervals in (sample, tile) order
+int devfin_coverage(msnv_dataset &ds, DeviceCols &d, std::vector<uint64_t> &cvbase, std::vector<DevCovPair> &cp) {
+    hipStream_t st = (hipStream_t)ds.ctx->stream;
+    const size_t S = ds.samples.size();
+    std::vector<unsigned long long> iv_start(S + 1, 0);
+    for (size_t s = 0; s < S; ++s) iv_start[s + 1] = iv_start[s] + ds.samples[s].n_dev_iv;
+    const unsigned long long N = iv_start[S];
+    cvbase.assign(S + 1, 0); cp.clear();
+    DevBuf ctid, cbeg, cend, keep, ntile, kidx, ebase, tb, ivs;
+    if (int rc = ctid.alloc((N + 1) * 4)) return rc;
+    if (int rc = cbeg.alloc((N + 1) * 4)) return rc;
+    if (int rc = cend.alloc((N + 1) * 4)) return rc;
+    {   // the rounds' intervals side by side (sample order)
+        unsigned long long o = 0;
+        for (const DevRound &r : ds.dp.rounds) {
+            if (r.n_iv) {
+                HIP_TRY(hipMemcpyAsync(ctid.as<int32_t>() + o, r.cov_tid, r.n_iv * 4, hipMemcpyDeviceToDevice, st));
+                HIP_TRY(hipMemcpyAsync(cbeg.as<int32_t>() + o, r.cov_beg, r.n_iv * 4, hipMemcpyDeviceToDevice, st));
+                HIP_TRY(hipMemcpyAsync(cend.as<int32_t>() + o, r.cov_end, r.n_iv * 4, hipMemcpyDeviceToDevice, st));
+            }
+            o += r.n_iv;
+        }
+        if (o != N) return fail(MSNV_EINVAL, "internal: the rounds hold %llu intervals, the samples %llu", o, N);
+    }
+    if (int rc = keep.alloc((N + 1) * 4)) return rc;
+    if (int rc = ntile.alloc((N + 1) * 4)) return rc;
+    if (int rc = kidx.alloc((N + 1) * 4)) return rc;
+    if (int rc = ebase.alloc((N + 1) * 8)) return rc;
+    if (int rc = tb.alloc(std::max<size_t>(1, ds.tile_base.size()) * 4)) return rc;
+    if (int rc = ivs.alloc((S + 1) * 8)) return rc;
+    HIP_TRY(hipMemcpyAsync(tb.p, ds.tile_base.data(), ds.tile_base.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ivs.p, iv_start.data(), (S + 1) * 8, hipMemcpyHostToDevice, st));
+    const DpContig *ctg = static_cast<const DpContig *>(ds.dp.contigs);
+    Prim pr(st);
+    hipLaunchKernelGGL(msnv_fin_cov_measure, grid_for(N + 1, 256), dim3(256), 0, st, ctid.as<int32_t>(), cbeg.as<int32_t>(), cend.as<int32_t>(), N, ctg, tb.as<uint32_t>(),
+                       keep.as<uint32_t>(), ntile.as<uint32_t>());
+    HIP_TRY(hipGetLastError());
+    if (int rc = pr.scan32(keep.as<uint32_t>(), kidx.as<uint32_t>(), N + 1, false)) return rc;
+    if (int rc = pr.scan64(ntile.as<uint32_t>(), ebase.as<unsigned long long>(), N + 1)) return rc;
+    uint32_t n_keep = 0; unsigned long long n_ent = 0;
+    HIP_TRY(hipMemcpyAsync(&n_keep, kidx.as<uint32_t>() + N, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&n_ent, ebase.as<unsigned long long>() + N, 8, hipMemcpyDeviceToHost, st));
+    DevBuf cvb;
+    if (int rc = cvb.alloc((S + 1) * 4)) return rc;
+    hipLaunchKernelGGL(msnv_gather_u32, grid_for(S + 1, 64), dim3(64), 0, st, kidx.as<uint32_t>(), ivs.as<unsigned long long>(), (uint32_t)(S + 1), cvb.as<uint32_t>());
+    HIP_TRY(hipGetLastError());
+    std::vector<uint32_t> cvb_h(S + 1);
+    HIP_TRY(hipMemcpyAsync(cvb_h.data(), cvb.p, (S + 1) * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (size_t s = 0; s <= S; ++s) cvbase[s] = cvb_h[s];
+    d.n_cov_iv = n_keep;
+    if (int rc = dev_alloc((void **)&d.cov_iv, ((uint64_t)n_keep + 4) * sizeof(Pair32), &d.device_bytes)) return rc;
+    HIP_TRY(hipMemsetAsync(d.cov_iv + n_keep, 0, 4 * sizeof(Pair32), st));                  // behind the last interval: what the idle lanes of msnv_coverage_tiles load
+    DevBuf ekey, eval, skey, sval, flag, rid, runs;
+    if (int rc = ekey.alloc((n_ent + 1) * 8)) return rc;
+    if (int rc = eval.alloc((n_ent + 1) * 4)) return rc;
+    if (N) {
+        hipLaunchKernelGGL(msnv_fin_cov_emit, grid_for(N, 256), dim3(256), 0, st, ctid.as<int32_t>(), cbeg.as<int32_t>(), cend.as<int32_t>(), N, ctg, tb.as<uint32_t>(),
+                           ivs.as<unsigned long long>(), (uint32_t)S, keep.as<uint32_t>(), kidx.as<uint32_t>(), ebase.as<unsigned long long>(), d.cov_iv, ekey.as<unsigned long long>(),
+                           eval.as<uint32_t>());
+        HIP_TRY(hipGetLastError());
+    }
+    if (n_ent) {
+        if (n_ent > 0xfffffff0ull) return fail(MSNV_EDOMAIN, "more than 2^32 (interval, tile) entries in one shard");
+        if (int rc = skey.alloc((n_ent + 1) * 8)) return rc;
+        if (int rc = sval.alloc((n_ent + 1) * 4)) return rc;
+        if (int rc = flag.alloc((n_ent + 1) * 4)) return rc;
+        if (int rc = rid.alloc((n_ent + 1) * 4)) return rc;
+        if (int rc = pr.sort64(ekey.as<unsigned long long>(), skey.as<unsigned long long>(), eval.as<uint32_t>(), sval.as<uint32_t>(), n_ent, 32u + std::max(1u, bit_width_u64(S)))) return rc;
+        hipLaunchKernelGGL(msnv_pair_flags, grid_for(n_ent, 256), dim3(256), 0, st, skey.as<unsigned long long>(), (uint32_t)n_ent, flag.as<uint32_t>());
+        HIP_TRY(hipGetLastError());
+        if (int rc = pr.scan32(flag.as<uint32_t>(), rid.as<uint32_t>(), n_ent, true)) return rc;
+        uint32_t n_runs = 0;
+        HIP_TRY(hipMemcpyAsync(&n_runs, rid.as<uint32_t>() + (n_ent - 1), 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (int rc = runs.alloc((uint64_t)n_runs * sizeof(DevCovPair))) return rc;
+        hipLaunchKernelGGL(msnv_fin_cov_runs, grid_for(n_ent, 256), dim3(256), 0, st, skey.as<unsigned long long>(), sval.as<uint32_t>(), flag.as<uint32_t>(), rid.as<uint32_t>(), n_ent,
+                           runs.as<DevCovPair>());
+        HIP_TRY(hipGetLastError());
+        cp.resize(n_runs);
+        HIP_TRY(hipMemcpyAsync(cp.data(), runs.p, (size_t)n_runs * sizeof(DevCovPair), hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
     return MSNV_OK;
 }
 

@@ -70,6 +70,10 @@ static bool deep_runs_split() {
     const char *e = getenv("MSNV_DEEP");                     // read per dataset (tests switch it)
     return !(e && e[0] == 'w');
 }
+static uint32_t deep_split_at() {
+    static const uint32_t v = [] { const char *e = getenv("MSNV_SPLIT_AT"); const int x = e ? atoi(e) : 192; return (uint32_t)std::min<int>((int)NARROW_MAX_DEPTH, std::max(32, x)); }();
+    return v;
+}
 static int split_deep_runs(SampleCols &sc, int device) {
     const size_t n = sc.hdr.size();
     sc.grp.assign(n, 0);
@@ -84,7 +88,7 @@ static int split_deep_runs(SampleCols &sc, int device) {
         while (j < n && sc.tid[j] == sc.tid[i] && sc.hdr[j].gpos / TILE == sc.hdr[i].gpos / TILE) ++j;
         uint32_t bound = 0;
         for (size_t k = i; k < j; ++k) bound = std::max<uint32_t>(bound, sc.depth[k]);
-        static const uint32_t split_at = [] { const char *e = getenv("MSNV_SPLIT_AT"); const int v = e ? atoi(e) : 192; return (uint32_t)std::min<int>((int)NARROW_MAX_DEPTH, std::max(32, v)); }();
+        const uint32_t split_at = deep_split_at();
         if (bound >= split_at) {
             const size_t m = j - i;
             auto sweep = [&](uint32_t G) -> uint32_t {            // largest per-position depth of any group
@@ -778,6 +782,25 @@ int finalize_dataset(msnv_dataset &ds) {
     const size_t NC = ds.names.size();
     if (S == 0) return fail(MSNV_EINVAL, "dataset has no samples");
     if (S >= 16384) return fail(MSNV_EDOMAIN, "more than 16383 samples per dataset are not supported");
+    // Device-packed samples (devpack.hip) keep their piece headers and intervals in HBM.  When every sample is one, the per-piece and
+    // per-interval loops below run there as kernels (`fast`; devfin_* in devpack.hip) and the host works on (sample, tile) pairs only.  The two
+    // re-layouts that still run on host staging -- dense pieces, deep runs dealt into groups -- and mixed datasets take the host loops:
+    // the headers come down first (MSNV_FINALIZE=host forces that; tests compare the two).
+    bool fast = false;
+    {
+        bool any_dev = false, all_dev = true;
+        for (const SampleCols &sc : ds.samples) { any_dev |= sc.dev_index; all_dev &= sc.dev_index; }
+        fast = any_dev && all_dev && HDR4 && deep_runs_split();
+        if (const char *e = getenv("MSNV_FINALIZE")) if (e[0] == 'h') fast = false;
+        if (fast) {
+            uint64_t np = 0, nb = 0;
+            for (const SampleCols &sc : ds.samples) { np += sc.n_dev_pieces; nb += sc.n_pileup_bases; }
+            if (layout_dense(np, nb)) fast = false;
+            const uint32_t split_at = deep_split_at();
+            for (const SampleCols &sc : ds.samples) for (const DevPair &p : sc.dev_pairs) if (p.maxd >= split_at) { fast = false; break; }
+        }
+        if (any_dev && !fast) if (int rc = devpack_download_pieces(ds)) return rc;
+    }
 
     // ---- tile layout: every selected contig owns ceil(max(L, furthest read end) / TILE) tiles
     std::vector<int64_t> maxend(NC, 0);
@@ -801,6 +824,7 @@ int finalize_dataset(msnv_dataset &ds) {
             for (const auto &m : mine) maxend[(size_t)m.first] = std::max(maxend[(size_t)m.first], m.second);
         });
     }
+    if (fast) if (int rc = devfin_overhang(ds, maxend)) return rc;       // (reads that run past their contig: from the device's per-contig maxima)
     ds.tile_base.assign(NC, UINT32_MAX);
     ds.tile_contig.clear();
     uint64_t nt = 0;
@@ -859,7 +883,7 @@ int finalize_dataset(msnv_dataset &ds) {
 
     // ---- per sample: gpos, tile overlap index; concatenate columns
     const int device_id = ds.ctx ? ds.ctx->device : 0;
-    {
+    if (!fast) {
         std::atomic<int> split_err{0}; std::mutex split_mu; std::string split_msg;
         parallel_for(S, [&](size_t s) {
             if (int rc = split_deep_runs(ds.samples[s], device_id)) { std::lock_guard<std::mutex> lk(split_mu); if (!split_err.load()) { split_msg = msnv_last_error(); split_err.store(rc); } }
@@ -867,7 +891,7 @@ int finalize_dataset(msnv_dataset &ds) {
         if (split_err.load()) return fail(split_err.load(), "%s", split_msg.c_str());
     }
     uint64_t all_pieces = 0, all_bases = 0;
-    for (const SampleCols &sc : ds.samples) { all_pieces += sc.hdr.size(); all_bases += sc.n_pileup_bases; }
+    for (const SampleCols &sc : ds.samples) { all_pieces += fast ? (size_t)sc.n_dev_pieces : sc.hdr.size(); all_bases += sc.n_pileup_bases; }
     const bool dense = layout_dense(all_pieces, all_bases);
     d->dense = dense;
     if (dense) {
@@ -883,7 +907,7 @@ int finalize_dataset(msnv_dataset &ds) {
     std::vector<uint64_t> rbase(S + 1, 0), sbase(S + 1, 0), bbase(S + 1, 0);
     for (size_t s = 0; s < S; ++s) {
         bbase[s + 1] = bbase[s] + ds.samples[s].blk.size();
-        rbase[s + 1] = rbase[s] + ds.samples[s].hdr.size();
+        rbase[s + 1] = rbase[s] + (fast ? (size_t)ds.samples[s].n_dev_pieces : ds.samples[s].hdr.size());
         const size_t seq_bytes = ds.samples[s].on_device ? (size_t)ds.samples[s].d_seq_bytes : ds.samples[s].seq.size();
         sbase[s + 1] = sbase[s] + ((seq_bytes + 15) & ~(size_t)15);
     }
@@ -891,7 +915,14 @@ int finalize_dataset(msnv_dataset &ds) {
     std::vector<std::vector<PairTmp>> per_sample(S);
     ds.first_tid = -1; ds.first_pos = -1;
     uint64_t tot_reads = 0, tot_pile_reads = 0, tot_bases = 0;
-    parallel_for(S, [&](size_t s) {
+    if (fast) for (size_t s = 0; s < S; ++s) {                           // the runs of pieces as the device found them (devpack.hip: msnv_pair_starts / msnv_pair_maxd)
+        const SampleCols &sc = ds.samples[s];
+        std::vector<PairTmp> &pv = per_sample[s];
+        pv.reserve(sc.dev_pairs.size());
+        for (const DevPair &p : sc.dev_pairs)
+            pv.push_back(PairTmp{ds.tile_base[(size_t)p.tid] + p.tile, (uint32_t)s, p.lo, p.hi, p.maxd, (uint32_t)pv.size(), 0u});
+    }
+    else parallel_for(S, [&](size_t s) {
         SampleCols &sc = ds.samples[s];
         std::vector<PairTmp> &pv = per_sample[s];
         // pieces are grouped by tile: one pair per run
@@ -923,7 +954,7 @@ int finalize_dataset(msnv_dataset &ds) {
     });
     for (size_t s = 0; s < S; ++s) {
         const SampleCols &sc = ds.samples[s];
-        tot_reads += sc.hdr.size(); tot_pile_reads += sc.n_pileup_reads; tot_bases += sc.n_pileup_bases;
+        tot_reads += fast ? (size_t)sc.n_dev_pieces : sc.hdr.size(); tot_pile_reads += sc.n_pileup_reads; tot_bases += sc.n_pileup_bases;
         if (sc.first_tid >= 0 && (ds.first_tid < 0 || sc.first_tid < ds.first_tid || (sc.first_tid == ds.first_tid && sc.first_beg < ds.first_pos))) {
             ds.first_tid = sc.first_tid; ds.first_pos = sc.first_beg;
         }
@@ -1206,9 +1237,33 @@ int finalize_dataset(msnv_dataset &ds) {
     }
     // ---- chunk descriptors of the narrow work items
     std::vector<ChunkDesc> chunks;
-    std::vector<std::vector<uint32_t>> hdr4_of(HDR4 && !dense ? S : 0);      // 4-byte piece headers, per sample (chunk-relative offsets: filled with the chunks)
+    std::vector<std::vector<uint32_t>> hdr4_of(HDR4 && !dense && !fast ? S : 0);      // 4-byte piece headers, per sample (chunk-relative offsets: filled with the chunks)
     for (size_t s = 0; s < hdr4_of.size(); ++s) hdr4_of[s].assign(ds.samples[s].hdr.size(), 0u);
-    for (uint32_t wi = 0; wi < d->n_work_narrow; ++wi) {
+    if (fast) {
+        // the pieces are in HBM: pairs and the per-sample bases go up first, the 16-byte headers are put together there (positions made
+        // linear), and the chunks of every narrow pair are cut by a kernel that runs the same greedy rule as the loop below
+        d->n_pairs = (uint32_t)pairs.size();
+        if (int rc = upload_vec(&d->pairs, pairs, &d->device_bytes)) return rc;
+        if (int rc = upload_vec(&d->s_read_base, rbase, &d->device_bytes)) return rc;
+        if (int rc = upload_vec(&d->s_seq_base, sbase, &d->device_bytes)) return rc;
+        if (int rc = dev_alloc((void **)&d->hdr, (rbase[S] + 1) * sizeof(ReadHdr), &d->device_bytes)) return rc;
+        if (int rc = dev_alloc((void **)&d->hdr4, (rbase[S] + 4) * sizeof(uint32_t), &d->device_bytes)) return rc;
+        if (int rc = dev_memset(d->hdr4, 0, (rbase[S] + 4) * sizeof(uint32_t))) return rc;
+        if (int rc = devfin_headers(ds, *d, rbase)) return rc;
+        std::vector<uint32_t> narrow_pairs, counts, cbase;
+        for (uint32_t wi = 0; wi < d->n_work_narrow; ++wi) for (uint32_t k = work[wi].pair_lo; k < work[wi].pair_hi; ++k) narrow_pairs.push_back(k);
+        if (int rc = devfin_chunk_counts(ds, *d, narrow_pairs, counts)) return rc;
+        cbase.resize(narrow_pairs.size());
+        uint64_t nch = 0; size_t j = 0;
+        for (uint32_t wi = 0; wi < d->n_work_narrow; ++wi) {
+            work[wi].chunk_lo = (uint32_t)nch;
+            for (uint32_t k = work[wi].pair_lo; k < work[wi].pair_hi; ++k, ++j) { cbase[j] = (uint32_t)nch; nch += counts[j]; }
+            work[wi].chunk_hi = (uint32_t)nch;
+        }
+        if (nch > 0xfffffff0ull) return fail(MSNV_EDOMAIN, "more than 2^32 chunks in one shard");
+        if (int rc = devfin_chunk_fill(ds, *d, narrow_pairs, cbase, nch, chunks)) return rc;
+    }
+    else for (uint32_t wi = 0; wi < d->n_work_narrow; ++wi) {
         WorkItem &w = work[wi];
         w.chunk_lo = (uint32_t)chunks.size();
         for (uint32_t k = w.pair_lo; k < w.pair_hi; ++k) {
@@ -1254,6 +1309,8 @@ int finalize_dataset(msnv_dataset &ds) {
     // ---- merged groups: their piece headers, group by group, and chunks that run across the group's pairs
     {
         std::vector<PieceHdr> hm;
+        std::vector<DevMergedSrc> hm_src;                           // fast: the pairs whose headers a kernel writes
+        uint64_t hm_count = 0;
         std::vector<MergedGroupDev> mgroups;
         size_t gi = 0;
         for (uint32_t wi = d->n_work_narrow; wi < d->n_work_narrow + d->n_work_merged; ++wi) {
@@ -1261,16 +1318,17 @@ int finalize_dataset(msnv_dataset &ds) {
             w.chunk_lo = (uint32_t)chunks.size();
             for (; gi < groups.size() && groups[gi].pair_lo >= w.pair_lo && groups[gi].pair_hi <= w.pair_hi; ++gi) {
                 const MergedGroup &g = groups[gi];
-                const uint64_t h0 = hm.size();
+                const uint64_t h0 = fast ? hm_count : hm.size();
                 for (uint32_t k = g.pair_lo; k < g.pair_hi; ++k) {
                     const TilePair &p = pairs[k];
+                    if (fast) { hm_src.push_back(DevMergedSrc{k, k - g.pair_lo, hm_count}); hm_count += p.read_hi - p.read_lo; continue; }
                     const SampleCols &sc = ds.samples[p.sample];
                     for (uint32_t r = p.read_lo; r < p.read_hi; ++r) {
                         const uint64_t so = (sbase[p.sample] + sc.hdr[r].seqoff) >> SEQ_ALIGN_LOG2;          // 37 bits: bits 32-36 ride in bits 27-31 of the first word
                         hm.push_back(PieceHdr{(sc.hdr[r].gpos % TILE) | sc.hdr[r].cig << 11 | (k - g.pair_lo) << 19 | (uint32_t)(so >> 32) << 27, (uint32_t)so});
                     }
                 }
-                const uint64_t n_h = hm.size() - h0;
+                const uint64_t n_h = (fast ? hm_count : hm.size()) - h0;
                 mgroups.push_back(MergedGroupDev{h0, w.tile, g.pair_lo, g.pair_hi - g.pair_lo, (uint32_t)n_h});
                 for (uint64_t r = 0; r < n_h; r += CHUNK_READS) {
                     const uint32_t n = (uint32_t)std::min<uint64_t>(CHUNK_READS, n_h - r);
@@ -1280,9 +1338,16 @@ int finalize_dataset(msnv_dataset &ds) {
             w.chunk_hi = (uint32_t)chunks.size();
         }
         if (gi != groups.size()) return fail(MSNV_EINVAL, "internal: merged groups and work items disagree");
-        ds.info.bytes_headers += hm.size() * sizeof(PieceHdr);
-        d->n_hdr8m = hm.size();
-    if (int rc = upload_vec(&d->hdr8m, hm, &d->device_bytes, 1)) return rc;
+        if (fast) {
+            ds.info.bytes_headers += hm_count * sizeof(PieceHdr);
+            d->n_hdr8m = hm_count;
+            if (int rc = dev_alloc((void **)&d->hdr8m, (hm_count + 1) * sizeof(PieceHdr), &d->device_bytes)) return rc;
+            if (int rc = devfin_merged_headers(ds, *d, hm_src)) return rc;
+        } else {
+            ds.info.bytes_headers += hm.size() * sizeof(PieceHdr);
+            d->n_hdr8m = hm.size();
+            if (int rc = upload_vec(&d->hdr8m, hm, &d->device_bytes, 1)) return rc;
+        }
         d->n_merged_groups = (uint32_t)mgroups.size();
         if (int rc = upload_vec(&d->merged_groups, mgroups, &d->device_bytes, 1)) return rc;
         if (int rc = upload_vec(&d->tile_pair_merged, tpm, &d->device_bytes)) return rc;
@@ -1292,17 +1357,17 @@ int finalize_dataset(msnv_dataset &ds) {
     d->n_chunks = chunks.size();
     if (int rc = upload_vec(&d->chunks, chunks, &d->device_bytes, 1)) return rc;
     d->n_pairs = (uint32_t)pairs.size(); d->n_work = (uint32_t)work.size();
-    if (int rc = upload_vec(&d->pairs, pairs, &d->device_bytes)) return rc;
+    if (!fast) if (int rc = upload_vec(&d->pairs, pairs, &d->device_bytes)) return rc;
     if (int rc = upload_vec(&d->tile_pair_start, tps, &d->device_bytes)) return rc;
     if (int rc = upload_vec(&d->work, work, &d->device_bytes)) return rc;
-    if (int rc = upload_vec(&d->s_read_base, rbase, &d->device_bytes)) return rc;
-    if (int rc = upload_vec(&d->s_seq_base, sbase, &d->device_bytes)) return rc;
+    if (!fast) if (int rc = upload_vec(&d->s_read_base, rbase, &d->device_bytes)) return rc;
+    if (!fast) if (int rc = upload_vec(&d->s_seq_base, sbase, &d->device_bytes)) return rc;
 
     // ---- columns
     d->n_reads = rbase[S]; d->n_seq_bytes = sbase[S]; d->n_blk = bbase[S];
-    if (int rc = dev_alloc((void **)&d->hdr, (rbase[S] + 1) * sizeof(ReadHdr), &d->device_bytes)) return rc;
+    if (!fast) if (int rc = dev_alloc((void **)&d->hdr, (rbase[S] + 1) * sizeof(ReadHdr), &d->device_bytes)) return rc;
     if (!dense && !HDR4) if (int rc = dev_alloc((void **)&d->hdr8, (rbase[S] + 1) * sizeof(PieceHdr), &d->device_bytes)) return rc;
-    if (!dense && HDR4) if (int rc = dev_alloc((void **)&d->hdr4, (rbase[S] + 4) * sizeof(uint32_t), &d->device_bytes)) return rc;
+    if (!dense && HDR4 && !fast) if (int rc = dev_alloc((void **)&d->hdr4, (rbase[S] + 4) * sizeof(uint32_t), &d->device_bytes)) return rc;
     if (dense) if (int rc = dev_alloc((void **)&d->blk, (bbase[S] + 1) * sizeof(uint32_t), &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->seq, sbase[S] + 256, &d->device_bytes)) return rc;     // lanes past the end of the last piece read on
     if (int rc = dev_memset(d->seq, 0xff, sbase[S] + 256)) return rc;                          // (the < 16 bytes between two samples' columns: defined, so that two builds of a dataset can be compared)
@@ -1327,8 +1392,10 @@ int finalize_dataset(msnv_dataset &ds) {
                 const size_t s = next.fetch_add(1);
                 if (s >= S || up_err.load()) break;
                 SampleCols &sc = ds.samples[s];
-                int rc = dev_upload(d->hdr + rbase[s], sc.hdr.data(), sc.hdr.size() * sizeof(ReadHdr));
-                if (!rc && dense) {
+                int rc = fast ? MSNV_OK : dev_upload(d->hdr + rbase[s], sc.hdr.data(), sc.hdr.size() * sizeof(ReadHdr));
+                if (fast) {
+                    // (headers and 4-byte headers were built in HBM)
+                } else if (!rc && dense) {
                     rc = dev_upload(d->blk + bbase[s], sc.blk.data(), sc.blk.size() * sizeof(uint32_t));
                 } else if (!rc && HDR4) {
                     rc = dev_upload(d->hdr4 + rbase[s], hdr4_of[s].data(), hdr4_of[s].size() * sizeof(uint32_t));
@@ -1362,11 +1429,10 @@ int finalize_dataset(msnv_dataset &ds) {
             std::vector<uint8_t> on_dev(S, 0);
             for (size_t s = 0; s < S; ++s) on_dev[s] = ds.samples[s].on_device ? 1 : 0;
             if (!dense) if (int rc = devpack_fill_padding(*d, on_dev, ds.ctx ? ds.ctx->stream : nullptr)) return rc;
-            if (int rc = devpack_finish(ds)) return rc;
         }
         for (size_t s = 0; s < S; ++s) {
             const SampleCols &sc = ds.samples[s];
-            ds.info.bytes_headers += dense ? (bbase[s + 1] - bbase[s]) * sizeof(uint32_t) : sc.hdr.size() * (HDR4 ? sizeof(uint32_t) : sizeof(PieceHdr));
+            ds.info.bytes_headers += dense ? (bbase[s + 1] - bbase[s]) * sizeof(uint32_t) : (rbase[s + 1] - rbase[s]) * (HDR4 ? sizeof(uint32_t) : sizeof(PieceHdr));
             ds.info.bytes_cigar += sc.alg_cigar_bytes;
             alg += sc.alg_8d_bytes;
             ds.info.bytes_seq += sc.alg_seq_bytes;
@@ -1381,7 +1447,13 @@ int finalize_dataset(msnv_dataset &ds) {
         std::vector<uint64_t> cvbase(S + 1, 0);
         struct CP { uint32_t tile, sample, lo, hi; };
         std::vector<std::vector<CP>> per(S);
-        for (size_t s = 0; s < S; ++s) {
+        if (fast) {
+            // the intervals are in HBM: filtered, made linear and grouped by (sample, tile) there (devpack.hip: devfin_coverage)
+            std::vector<DevCovPair> cp;
+            if (int rc = devfin_coverage(ds, *d, cvbase, cp)) return rc;
+            for (const DevCovPair &c : cp) per[c.sample].push_back(CP{c.tile, c.sample, c.lo, c.hi});
+        }
+        else for (size_t s = 0; s < S; ++s) {
             const SampleCols &sc = ds.samples[s];
             uint32_t n_here = 0;
             for (size_t i = 0; i < sc.cov_tid.size(); ++i) {
@@ -1452,10 +1524,10 @@ int finalize_dataset(msnv_dataset &ds) {
             tlen[t] = (uint32_t)std::min<int64_t>(std::max<int64_t>(ds.lengths[c] - t0, 0), TILE);
             tcont[t] = (uint32_t)c;
         }
-        d->n_cov_iv = iv.size();
+        if (!fast) d->n_cov_iv = iv.size();
         for (int k = 0; k < 4; ++k) iv.push_back(Pair32{0u, 0u});     // behind the last interval: what the idle lanes of msnv_coverage_tiles load, four at a time (they touch nothing)
         d->n_cov_pairs = (uint32_t)cpairs.size(); d->n_cov_work = (uint32_t)cwork.size(); d->n_contigs = (uint32_t)NC;
-        if (int rc = upload_vec(&d->cov_iv, iv, &d->device_bytes, 1)) return rc;
+        if (!fast) if (int rc = upload_vec(&d->cov_iv, iv, &d->device_bytes, 1)) return rc;
         if (int rc = upload_vec(&d->s_cov_base, cvbase, &d->device_bytes)) return rc;
         if (int rc = upload_vec(&d->cov_pairs, cpairs, &d->device_bytes, 1)) return rc;
         if (int rc = upload_vec(&d->cov_work, cwork, &d->device_bytes, 1)) return rc;
@@ -1467,6 +1539,8 @@ int finalize_dataset(msnv_dataset &ds) {
         d->cov_copies = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(8, (64ull << 20) / std::max<uint64_t>(1, acc_bytes)));
         if (int rc = dev_alloc((void **)&d->cov_acc, d->cov_copies * acc_bytes, &d->device_bytes)) return rc;
     }
+
+    if (int rc = devpack_finish(ds)) return rc;                // (device-packed samples: the rounds' buffers and the pack tables go back)
 
     // ---- intermediates
     if (int rc = dev_alloc((void **)&d->tot, std::max<uint64_t>(1, 4 * npos) * sizeof(uint32_t), &d->device_bytes)) return rc;

@@ -36,8 +36,8 @@ class _env:
                 os.environ[k] = v
 
 
-def _build(where, names, lengths, seqs, samples, bed=None, params=None, many=False, device_ptrs=False):
-    with _env(MSNV_PACK=where):
+def _build(where, names, lengths, seqs, samples, bed=None, params=None, many=False, device_ptrs=False, finalize=None):
+    with _env(MSNV_PACK=where, MSNV_FINALIZE=finalize):
         ctx = core.Context(0)
         ds = core.Dataset(ctx, names, lengths, seqs, params)
         if bed:
@@ -66,9 +66,11 @@ def _build(where, names, lengths, seqs, samples, bed=None, params=None, many=Fal
     return ctx, ds, info
 
 
-def _same_dataset(names, lengths, seqs, samples, bed=None, params=None, many=False, device_ptrs=False, check_oracle=True):
+def _same_dataset(names, lengths, seqs, samples, bed=None, params=None, many=False, device_ptrs=False, check_oracle=True, finalize=None):
+    """finalize: None = the tile index of the device-packed dataset is built in HBM where it can be (devfin_*), "host" = its headers come
+    down and the host loops of finalize_dataset build it."""
     ch, dh, ih = _build("host", names, lengths, seqs, samples, bed, params)
-    cd, dd, idv = _build("device", names, lengths, seqs, samples, bed, params, many=many, device_ptrs=device_ptrs)
+    cd, dd, idv = _build("device", names, lengths, seqs, samples, bed, params, many=many, device_ptrs=device_ptrs, finalize=finalize)
     try:
         for k in ("n_reads", "n_reads_pileup", "n_pileup_bases", "bytes_headers", "bytes_cigar", "bytes_seq", "bytes_qual", "n_tiles", "n_pairs", "n_work",
                   "allele_planes", "sampled_mismatch_ppm"):
@@ -107,6 +109,23 @@ def test_synthetic_cohort_same_columns():
     syn, samples = synth_case(n_species=3, contig_len=9000, n_samples=10, mean_cov=12.0, snv_density=0.02, error_rate=0.004, lowercase_ref=1, seed=21)
     info = _same_dataset(syn.names, syn.lengths, syn.seqs, samples)
     assert info["n_pileup_bases"] > 100000
+    _same_dataset(syn.names, syn.lengths, syn.seqs, samples, finalize="host", check_oracle=False)
+
+
+def test_sparse_cohort_and_merged_groups_same_columns():
+    """Whole-tile work items and merged groups of shallow pairs (their headers are written by devfin_merged_headers), many contigs."""
+    syn, samples = synth_case(n_species=12, contig_len=5000, n_samples=24, mean_cov=2.0, sigma_cov=0.3, species_per_sample=3, contigs_per_species_max=3,
+                              snv_density=0.02, seed=26)
+    _same_dataset(syn.names, syn.lengths, syn.seqs, samples, many=True)
+    with _env(MSNV_FUSE="0", MSNV_MERGE_ALWAYS="1"):
+        _same_dataset(syn.names, syn.lengths, syn.seqs, samples, many=True, check_oracle=False)
+
+
+def test_deep_and_dense_datasets_take_the_host_relayouts():
+    syn, samples = synth_case(n_species=1, contig_len=4000, n_samples=3, mean_cov=300.0, snv_density=0.02, seed=27)      # runs deeper than 192: dealt into groups
+    _same_dataset(syn.names, syn.lengths, syn.seqs, samples)
+    syn, samples = synth_case(n_species=2, contig_len=5000, n_samples=4, mean_cov=12.0, read_len=36, snv_density=0.02, seed=28)   # short reads: dense block layout
+    _same_dataset(syn.names, syn.lengths, syn.seqs, samples)
 
 
 def test_many_streams_one_round_and_device_pointers():
