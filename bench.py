@@ -208,11 +208,11 @@ def end_to_end(sp, syn, n_bases, host_threads, cpu_rate_gbases=None):
                "argv": "metaSNV.py DIR all_samples REF --threads %d (= %d best_split outputs, metaSNV.py:275-276)" % (host_threads, host_threads),
                "wall_s": wall, "Gbases_per_s": n_bases / wall / 1e9, "called_SNPs_lines": called,
                "split_wall_s": {"process_start_hip_runtime_and_context": max(0.0, wall - cw.get("total_s", 0.0)),
-                                "decode_and_pack": ht.get("add_bams_wall_s"), "finalize_index_and_upload": ht.get("finalize_upload_wall_s"),
+                                "decode_and_pack": ht.get("add_bams_wall_s"), "pack_on_device_incl_upload_of_records": ht.get("pack_device_wall_s"), "finalize_index_and_upload": ht.get("finalize_upload_wall_s"),
                                 "kernels_coverage_ms": m["coverage"]["ms_coverage"] if "coverage" in m else None, "kernels_pileup_pass_ms": m["pileup"]["ms_total"],
                                 "coverage_files": cw.get("coverage_files_s"), "tables_and_splits": cw.get("tables_and_splits_s"), "calls_text": cw.get("calls_text_s")},
                "thread_seconds": {"file_read": ht.get("read_s"), "inflate_host_and_crc": ht.get("inflate_host_s"), "parse_and_pack": ht.get("pack_s")},
-               "device_inflate_wall_s": ht.get("inflate_device_wall_s")}
+               "device_inflate_wall_s": ht.get("inflate_device_wall_s"), "pack_on_device": m.get("pack_on_device")}
         if cpu_rate_gbases:
             out["cpu_baseline_extrapolated_s"] = {"seconds": n_bases / (cpu_rate_gbases * 1e9), "what": "the oracle's mpileup + snpCall restatement, 1 thread, at its measured rate on all %d samples (qaCompute not included)" % sp.n_samples}
         return out

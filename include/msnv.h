@@ -256,6 +256,10 @@ int  msnv_dataset_add_sample_bam(msnv_dataset *ds, const char *bam_path);
 /* Decode many BAMs with a host thread pool, preserving order. */
 int  msnv_dataset_add_sample_bams(msnv_dataset *ds, const char *const *bam_paths, int32_t n, int32_t host_threads);
 
+/* The files are read, inflated and checked now (host threads), packed by msnv_dataset_finalize: a dataset created without a context
+ * (msnv_dataset_attach_ctx later) still gets the per-read stage as kernels.  No other add_sample_* call may follow. */
+int  msnv_dataset_stage_sample_bams(msnv_dataset *ds, const char *const *bam_paths, int32_t n, int32_t host_threads);
+
 /* Host-stage seam (tests, A/B against `samtools mpileup` text): writes to `out` (n_bytes) the same record stream with the
  * base qualities as the pileup engine sees them -- after the overlapping-mate tweak (unless params.ignore_overlaps) and
  * with the bases behind params.token_limit characters of a sample's base string set to quality 0 -- under this dataset's

@@ -163,6 +163,13 @@ class Dataset:
         check(lib.msnv_dataset_add_sample_bams(self._h, arr, len(paths), host_threads))
         self.n_samples += len(paths)
 
+    def stage_sample_bams(self, paths, host_threads=0):
+        """Reads and inflates the BAMs now, packs them in finalize() (msnv_dataset_stage_sample_bams): on the device when the dataset has
+        its context by then (attach_context)."""
+        arr = _cstr_array(paths)
+        check(lib.msnv_dataset_stage_sample_bams(self._h, arr, len(paths), host_threads))
+        self.n_samples += len(paths)
+
     def add_synth_samples(self, synth_p, first, count, host_threads=0):
         check(lib.msnv_dataset_add_synth_samples(self._h, C.byref(synth_p), first, count, host_threads))
         self.n_samples += count

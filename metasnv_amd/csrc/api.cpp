@@ -210,6 +210,7 @@ extern "C" int msnv_dataset_add_sample_records(msnv_dataset *ds, const uint8_t *
     clear_error();
     if (!ds || (n_bytes && !records)) return fail(MSNV_EINVAL, "msnv_dataset_add_sample_records: NULL argument");
     if (ds->finalized) return fail(MSNV_EINVAL, "dataset is already finalized");
+    if (!ds->staged.empty()) return fail(MSNV_EINVAL, "the dataset holds staged streams (msnv_dataset_stage_sample_bams): they are packed last, by msnv_dataset_finalize");
     if (pack_on_device(ds)) return add_streams_device(ds, &records, &n_bytes, 1, false);
     ds->samples.emplace_back();
     int rc;
@@ -224,6 +225,7 @@ extern "C" int msnv_dataset_add_sample_records_many(msnv_dataset *ds, const uint
     if (!ds || n < 0 || (n && (!records || !n_bytes))) return fail(MSNV_EINVAL, "msnv_dataset_add_sample_records_many: bad argument");
     if (ds->finalized) return fail(MSNV_EINVAL, "dataset is already finalized");
     for (int i = 0; i < n; ++i) if (n_bytes[i] && !records[i]) return fail(MSNV_EINVAL, "msnv_dataset_add_sample_records_many: stream %d is NULL", i);
+    if (!ds->staged.empty()) return fail(MSNV_EINVAL, "the dataset holds staged streams (msnv_dataset_stage_sample_bams): they are packed last, by msnv_dataset_finalize");
     if (pack_on_device(ds)) return add_streams_device(ds, records, n_bytes, n, false);
     int nthreads = host_threads > 0 ? host_threads : (int)std::max(1u, std::thread::hardware_concurrency());
     nthreads = std::min(nthreads, std::max(1, (int)n));
@@ -708,6 +710,45 @@ extern "C" int msnv_dataset_add_sample_bams(msnv_dataset *ds, const char *const 
     return MSNV_OK;
 }
 
+// BAM files read, inflated and header-checked by the host threads, their record streams KEPT as they are: msnv_dataset_finalize packs them,
+// on the device when the dataset has been given its context by then (msnv_dataset_attach_ctx).  For a one-shot driver that brings the HIP
+// runtime up on a thread of its own while the files are read (metasnv_amd/cli.py): the per-read stage then still runs as kernels.
+extern "C" int msnv_dataset_stage_sample_bams(msnv_dataset *ds, const char *const *bam_paths, int32_t n, int32_t host_threads) {
+    clear_error();
+    HostTimerScope ts_all(HT_ADD_WALL);
+    if (!ds || n < 0 || (n && !bam_paths)) return fail(MSNV_EINVAL, "msnv_dataset_stage_sample_bams: bad argument");
+    if (ds->finalized) return fail(MSNV_EINVAL, "dataset is already finalized");
+    if (!ds->samples.empty()) return fail(MSNV_EINVAL, "msnv_dataset_stage_sample_bams: the dataset already holds packed samples (staged streams are packed last)");
+    int nthreads = host_threads > 0 ? host_threads : (int)std::max(1u, std::thread::hardware_concurrency());
+    nthreads = std::min(nthreads, std::max(1, (int)n));
+    const size_t first = ds->staged.size();
+    ds->staged.resize(first + (size_t)n); ds->staged_off.resize(first + (size_t)n, 0);
+    std::atomic<int> next{0}, err{0};
+    std::vector<std::string> msgs((size_t)n);
+    auto worker = [&]() {
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= n || err.load()) break;
+            int rc;
+            try {
+                BamHeader h;
+                rc = bam_read(bam_paths[i], h, ds->staged[first + (size_t)i], ds->staged_off[first + (size_t)i], 1);
+                if (!rc) rc = check_header(*ds, h, bam_paths[i]);
+            } catch (const std::exception &e) { rc = fail(MSNV_ENOMEM, "%s: %s", bam_paths[i], e.what()); }
+            if (rc) { msgs[(size_t)i] = msnv_last_error(); err.store(rc); }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t) th.emplace_back(worker);
+    for (auto &t : th) t.join();
+    if (err.load()) {
+        ds->staged.resize(first); ds->staged_off.resize(first);
+        for (const std::string &m : msgs) if (!m.empty()) return fail(err.load(), "%s", m.c_str());
+        return fail(err.load(), "BAM decode failed");
+    }
+    return MSNV_OK;
+}
+
 extern "C" int msnv_dataset_add_synth_samples(msnv_dataset *ds, const msnv_synth_params *p, int32_t first, int32_t count, int32_t host_threads) {
     clear_error();
     if (!ds || !p || count < 0) return fail(MSNV_EINVAL, "msnv_dataset_add_synth_samples: bad argument");
@@ -771,6 +812,18 @@ extern "C" int msnv_dataset_finalize(msnv_dataset *ds) {
     if (ds->finalized) return fail(MSNV_EINVAL, "dataset is already finalized");
     if (!ds->ctx) return fail(MSNV_ENODEV, "this dataset was created without a device context: only the host-stage entry points work on it (no CPU fallback)");
     if (int rc = dev_set_device(ds->ctx->device)) return rc;
+    if (!ds->staged.empty()) {                                   // streams staged while the device was still coming up: packed now
+        std::vector<const uint8_t *> ptrs; std::vector<uint64_t> sizes;
+        for (size_t i = 0; i < ds->staged.size(); ++i) { ptrs.push_back(ds->staged[i].data() + ds->staged_off[i]); sizes.push_back(ds->staged[i].size() - ds->staged_off[i]); }
+        int rc;
+        if (pack_on_device(ds)) rc = add_streams_device(ds, ptrs.data(), sizes.data(), (int)ptrs.size(), false);
+        else {
+            std::vector<ByteBuf> keep; keep.swap(ds->staged);    // (msnv_dataset_add_sample_records_many refuses a dataset with staged streams)
+            rc = msnv_dataset_add_sample_records_many(ds, ptrs.data(), sizes.data(), (int32_t)ptrs.size(), 0);
+        }
+        ds->staged.clear(); ds->staged_off.clear();
+        if (rc) return rc;
+    }
     HostTimerScope ts(HT_UPLOAD_WALL);
     try { return finalize_dataset(*ds); }
     catch (const std::exception &e) { return fail(MSNV_ENOMEM, "building the device dataset failed: %s", e.what()); }

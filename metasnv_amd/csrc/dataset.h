@@ -191,6 +191,8 @@ struct msnv_dataset {
     msnv_dataset_info info{};
     msnv::DeviceCols *dev = nullptr;
     msnv::DevPackTables dp;
+    // record streams read and inflated before the dataset had its device (msnv_dataset_stage_sample_bams): packed by finalize
+    std::vector<msnv::ByteBuf> staged; std::vector<uint64_t> staged_off;
     // results of the last run (host copies)
     bool have_results = false, results_fetched = false;
     uint32_t last_counts_sites = 0;

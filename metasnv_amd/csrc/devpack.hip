@@ -315,7 +315,8 @@ __global__ __launch_bounds__(256) void msnv_measure_reads(const uint8_t *raw, co
                         m_pile = (unsigned long long)m_bases;
                         alg8d = 16ull + 4ull * r.n_cigar + ((unsigned long long)m_bases + 1) / 2 + (unsigned long long)m_bases;
                         alg_cigar = 4ull * r.n_cigar;
-                        if (r.l_seq > 0) { o_np = n_piece; o_sb = seqb; alg_seq = a_seq; alg_qual = (unsigned long long)m_bases; }
+                        // SEQ '*' (l_seq = 0): N bases of quality 0, shipped only under -Q 0 (pack.cpp: pack_sample)
+                        if (r.l_seq > 0 || (P.c_eff == 0 && !P.all_low)) { o_np = n_piece; o_sb = seqb; alg_seq = a_seq; alg_qual = (unsigned long long)m_bases; }
                     }
                 }
             }
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(256) void msnv_emit_headers(const uint8_t *raw, con
                                                          const uint8_t *r_flags, const uint16_t *r_depth, const uint32_t *pbase, const unsigned long long *sbase,
                                                          const uint32_t *ibase, const unsigned long long *samp_sbase0,
                                                          ReadHdr *hdr, int32_t *ptid, int32_t *pend, uint16_t *pdepth, PieceSrc *psrc,
-                                                         int32_t *cov_tid, int32_t *cov_beg, int32_t *cov_end, int32_t *overhang, uint32_t *any_overhang) {
+                                                         int32_t *cov_tid, int32_t *cov_beg, int32_t *cov_end, int32_t *overhang, uint32_t *any_overhang, uint32_t noseq_counts) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rec) return;
     const uint8_t f = r_flags[i];
@@ -474,7 +475,8 @@ __global__ __launch_bounds__(256) void msnv_emit_headers(const uint8_t *raw, con
             pp += l;
         }
     }
-    if (!(f & RF_PILE) || r.l_seq == 0) return;
+    const bool noseq = r.l_seq == 0;
+    if (!(f & RF_PILE) || (noseq && !noseq_counts)) return;
     uint32_t w = pbase[i];
     unsigned long long so = sbase[i] - samp_sbase0[s];
     long long rp = r.pos, q = 0;
@@ -492,7 +494,7 @@ __global__ __launch_bounds__(256) void msnv_emit_headers(const uint8_t *raw, con
                 hdr[w] = h; ptid[w] = r.tid; pend[w] = (int32_t)(rp + off + n); pdepth[w] = depth;
                 if (rp + off + n > c.len) { atomicMax(&overhang[r.tid], (int32_t)(rp + off + n)); *any_overhang = 1u; }     // a read that runs past its contig: the contig's tiles reach that far (finalize)
                 PieceSrc ps;
-                ps.seq = seq_abs; ps.qual = qual_abs; ps.q0 = (uint32_t)(q + off); ps.sample = s; ps.pad = 0;
+                ps.seq = seq_abs; ps.qual = qual_abs; ps.q0 = noseq ? 0xffffffffu : (uint32_t)(q + off); ps.sample = s; ps.pad = 0;      // q0 = ~0: no SEQ, the bases are N of quality 0
                 const long long g = rp + off, left = c.seq_len - g;
                 if (c.seq_len >= 0 && g >= 0 && left > 0) { ps.ref_nib = c.pref_off + (unsigned long long)g; ps.ref_left = (uint32_t)(left < 0xffffffffll ? left : 0xffffffffll); }
                 else { ps.ref_nib = c.seq_len >= 0 ? ~1ull : ~0ull; ps.ref_left = 0; }        // ~1: a FASTA record exists but holds nothing here (sampled, nothing to compare)
@@ -532,10 +534,11 @@ __global__ __launch_bounds__(256) void msnv_emit_pieces(const uint8_t *raw, cons
     uint32_t out = 0xffffffffu, bits = (P.c_eff > 0 || P.all_low) ? 0xffu : 0u, mm = 0;
     bool sampled = false;
     if (have) {
-        const uint32_t q0 = ps.q0 + j0;
+        const bool noseq = ps.q0 == 0xffffffffu;
+        const uint32_t q0 = noseq ? 0u : ps.q0 + j0;
         // BAM packs base 2i in the HIGH nibble of byte i; the kernels want base j of the piece in nibble j, low first
-        const uint64_t b = ld64(raw + ps.seq + (q0 >> 1));
-        const uint64_t qb = ld64(raw + ps.qual + q0);
+        const uint64_t b = noseq ? ~0ull : ld64(raw + ps.seq + (q0 >> 1));
+        const uint64_t qb = noseq ? 0ull : ld64(raw + ps.qual + q0);
         const uint64_t sw = ((b >> 4) & 0x0f0f0f0f0f0f0f0full) | ((b & 0x0f0f0f0f0f0f0f0full) << 4);
         out = (uint32_t)(sw >> (4u * (q0 & 1u)));
         if (have < 8u) out |= 0xffffffffu << (4u * have);
@@ -1170,7 +1173,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     HIP_TRY(hipMemcpyAsync(d_pb, piece_bytes.data(), S * 8, hipMemcpyHostToDevice, st));
     if (NR) {
         hipLaunchKernelGGL(msnv_emit_headers, grid_for(NR, 256), dim3(256), 0, st, raw, d_recoff, d_recsample, NR, ctg, d_flags, d_depth, d_pbase, d_sbase, d_ibase, d_ss0,
-                           d_hdr, d_ptid, d_pend, d_pdepth, d_psrc, d_ctid, d_cbeg, d_cend, T.overhang, T.any_overhang);
+                           d_hdr, d_ptid, d_pend, d_pdepth, d_psrc, d_ctid, d_cbeg, d_cend, T.overhang, T.any_overhang, (P.c_eff == 0 && !P.all_low) ? 1u : 0u);
         HIP_TRY(hipGetLastError());
     }
     if (NPC) {

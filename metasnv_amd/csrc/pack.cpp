@@ -657,7 +657,10 @@ int pack_sample(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, Sa
         if (sc.first_any.empty()) { sc.first_any.assign((size_t)n_contigs, -1); sc.first_from1.assign((size_t)n_contigs, -1); }
         if (sc.first_any[(size_t)r.tid] < 0) sc.first_any[(size_t)r.tid] = r.pos;
         if (sc.first_from1[(size_t)r.tid] < 0 && endpos > 1) sc.first_from1[(size_t)r.tid] = std::max<int32_t>(r.pos, 1);
-        if (r.l_seq == 0) continue;      // SEQ '*': every base prints as 'N' with quality 0 -> never counted
+        // SEQ '*': every base prints as 'N' with quality 0 (bam_plcmd.c pileup_seq [EXT]) -- below every cutoff but -Q 0, and with -Q 0 an N
+        // over a reference N is a match ('.' / ','): only then the read's pieces are shipped, as N bases of quality 0
+        const bool noseq = r.l_seq == 0;
+        if (noseq && ds.params.min_baseq > 0) continue;
         const std::string &refseq = ds.seqs[(size_t)r.tid];
         const bool has_ref = ds.has_seq[(size_t)r.tid];
         int64_t rp = r.pos; int64_t q = 0;
@@ -682,7 +685,9 @@ int pack_sample(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, Sa
                     const int64_t q0 = q + off;
                     const uint8_t *src = r.seq + (q0 >> 1);
                     bool has_eq = false;
-                    if (!(q0 & 1)) {
+                    if (noseq) {
+                        // (the bytes are N already)
+                    } else if (!(q0 & 1)) {
                         for (uint32_t i = 0; i < n / 2; ++i) { const uint8_t b = src[i]; has_eq |= !(b & 0xf0u) || !(b & 0x0fu); dst[i] = (uint8_t)(b >> 4 | b << 4); }
                         if (n & 1u) { const uint8_t b = (uint8_t)(src[n / 2] >> 4); has_eq |= !b; dst[n / 2] = (uint8_t)(0xf0u | b); }
                     } else {
@@ -717,7 +722,8 @@ int pack_sample(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, Sa
                         uint8_t *qd = sc.qual.data() + qs;
                         const uint8_t *qsrc = r_qual + q0;
                         // (0x80: a base behind the token limit -- below every cutoff, pack_lowq)
-                        for (uint32_t j = 0; j < n; ++j) qd[j] = (cut_marks && qsrc[j] == QUAL_CUT) ? 0x80 : qsrc[j] > 127 ? 127 : qsrc[j];
+                        if (noseq) for (uint32_t j = 0; j < n; ++j) qd[j] = 0;
+                        else for (uint32_t j = 0; j < n; ++j) qd[j] = (cut_marks && qsrc[j] == QUAL_CUT) ? 0x80 : qsrc[j] > 127 ? 127 : qsrc[j];
                     }
                     // every piece starts on an 8-byte (seq) / 16-byte (qual) boundary
                     while (sc.seq.size() & (seq_align - 1u)) sc.seq.push_back(0xff);

@@ -230,6 +230,19 @@ def deal_samples(n_samples, batch):
         yield base, [(i, (i - base) // batch) for i in range(base, min(n_samples, base + step))]
 
 
+def _stageable(paths):
+    """Do the inflated record streams of these files fit the host's memory with room to spare?  (~4x the file bytes; MSNV_STAGE_MAX_MB
+    overrides the default of a quarter of the physical memory.)"""
+    try:
+        total = sum(os.path.getsize(p) for p in paths) * 4
+        limit = int(os.environ.get("MSNV_STAGE_MAX_MB", "0")) << 20
+        if limit <= 0:
+            limit = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") // 4
+        return total <= limit
+    except (OSError, ValueError):
+        return False
+
+
 def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=None, metrics=None, plan=None, pack_threads=0):
     """Decode-sharded input of one dataset per rank: every BAM is read and inflated by ONE rank, its records are dealt by
     contig owner (core.partition_records) and exchanged, and every rank appends all samples in all_samples order holding
@@ -245,9 +258,14 @@ def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=Non
     if _dist is None and read_records is None:           # nothing to exchange: decode + pack inside the library's thread pool
         if owner is None and metrics is not None:
             metrics["owner"] = [0] * len(plan[0])
-        ds.add_sample_bams(bam_paths, batch)
         if metrics is not None:
             metrics["inflated_record_bytes"] = None
+        if getattr(ds, "ctx", None) is None and hasattr(ds, "stage_sample_bams") and os.environ.get("MSNV_PACK", "device")[:1] != "h" and _stageable(bam_paths):
+            # the device is still coming up (cli.py brings the HIP runtime up on a thread of its own): the files are read and inflated now,
+            # their records are packed by kernels once the context is attached (finalize); the statistics exist then
+            ds.stage_sample_bams(bam_paths, batch)
+            return None
+        ds.add_sample_bams(bam_paths, batch)
         return np.stack([ds.sample_stats(i) for i in range(n)]) if n else np.zeros((0, len(core.STATS_FIELDS)), np.uint32)
     read_many = None
     if read_records is None:                             # the library reads a round's files in one call (device inflate when they are large)
@@ -507,6 +525,10 @@ def resident_project_run(ctx, first_bam, fasta_path, bam_paths, params, batch=1,
         t0 = time.perf_counter()
         metrics["dataset"] = ds.finalize()
         metrics["finalize_s"] = time.perf_counter() - t0
+        if res["stats"] is None:                           # staged streams: packed by finalize
+            res["stats"] = np.stack([ds.sample_stats(i) for i in range(len(bam_paths))]) if bam_paths else np.zeros((0, len(core.STATS_FIELDS)), np.uint32)
+        if hasattr(ds, "pack_stats"):
+            metrics["pack_on_device"] = ds.pack_stats()
         gstats = {}
         if want_coverage:
             metrics["coverage"] = ds.coverage_run()

@@ -1196,6 +1196,33 @@ def test_full_testdata_shape_bit_exact(tmp_path):
     assert st["n_called_pop"] == orac[0].count("\n") > 5000
 
 
+def test_full_testdata_shape_with_gene_annotation_bit_exact(tmp_path):
+    """BASELINE configs[4] at its own size: the 160-sample testdata shape with --db_ann -- the SURVEY 8d gene table (CDS of 300-3000 bp,
+    ~85 % coding density, 5 % overlapping their predecessor, half on the '-' strand; bench.synth_annotation) -- called_SNPs and
+    indiv_called with the gene column and the codon tags (call_vC.cpp:567-633) byte-identical to the oracle's."""
+    import bench
+    sp = core.synth_params(seed=1)
+    syn = core.Synth(sp)
+    samples = [syn.sample_records(i) for i in range(sp.n_samples)]
+    fa, an = str(tmp_path / "ref.fa"), str(tmp_path / "ann.tsv")
+    syn.write_fasta(fa)
+    n_genes = bench.synth_annotation(syn, an)
+    ctx = core.Context(0)
+    ds = core.Dataset(ctx, syn.names, syn.lengths, syn.seqs)
+    ds.add_synth_samples(sp, 0, sp.n_samples, 0)
+    ds.finalize()
+    ds.run()
+    pp, ip = str(tmp_path / "called_SNPs"), str(tmp_path / "indiv_called")
+    ds.write_calls(pp, ip, an, fa)
+    ds.close(); ctx.close()
+    orac = run_oracle(syn.names, syn.lengths, syn.seqs, samples, ann=an, fasta=fa)
+    pop, ind = open(pp).read(), open(ip).read()
+    _assert_same((pop, ind), orac)
+    assert n_genes > 300 and pop.count("\n") > 5000
+    assert sum(1 for l in pop.split("\n") if l and l.split("\t")[1] != "-") > 3000        # most called sites lie in a gene
+    assert "S[" in pop and "N[" in pop
+
+
 def test_full_testdata_shape_properties():
     """BASELINE configs[1] at full size (160 samples x 3 x 300 kb, 1.5 G pileup bases): too big for the
     oracle to finish in seconds, so the HIP path is checked through size-independent properties."""
