@@ -307,6 +307,9 @@ static int bgzf_read_files_device(msnv_ctx *ctx, const char *const *paths, int n
     }
     double ms = 0;
     uint64_t n_blocks = 0, n_host = 0, n_bytes = 0;
+    // the batch buffers in HBM go back on EVERY way out (a caller that falls back to the host path after an error must not find up to ~4.6 GB
+    // of staging still attached to the context); the pinned half stays for the next call
+    struct ReleaseDevice { msnv_ctx *c; ~ReleaseDevice() { dev_inflate_release_device(c); } } release_device{ctx};
     const uint64_t batch_in = 1024ull << 20;                       // compressed bytes per batch (~2.5 GB inflated)
     for (int f0 = 0; f0 < n;) {
         int f1 = f0; uint64_t ib = 0;
@@ -360,13 +363,16 @@ static int bgzf_read_files_device(msnv_ctx *ctx, const char *const *paths, int n
         uint64_t ob = 0;
         std::vector<InfBlock> list;
         std::vector<int> origin;                                     // file (of the batch) of every entry
+        std::vector<uint32_t> blk_in_file;                           // ... and its index among the file's blocks (MSNV_INFLATE_CHECK counts per file)
         std::vector<InflatedExt> ext((size_t)nf);
         for (int k = 0; k < nf; ++k) {
             ext[(size_t)k] = InflatedExt{ob, total[(size_t)k]};
+            uint32_t bi = 0;
             for (const BgzfBlock &bl : blocks[(size_t)k]) {
+                const uint32_t this_block = bi++;
                 if (bl.out_size == 0) continue;
                 list.push_back(InfBlock{in_off[(size_t)k] + bl.in_off, ob + bl.out_off, bl.in_size, bl.out_size});
-                origin.push_back(k);
+                origin.push_back(k); blk_in_file.push_back(this_block);
             }
             ob += (total[(size_t)k] + 15) & ~15ull;
             n_bytes += total[(size_t)k];
@@ -399,7 +405,7 @@ static int bgzf_read_files_device(msnv_ctx *ctx, const char *const *paths, int n
         // Every block's output is checked against the CRC-32 of its BGZF trailer, as htslib does for the reference's tools (a block that
         // does not check is handed to the host decoder like one the device refused); the host threads share the blocks.
         // MSNV_INFLATE_CHECK=n: every n-th block only (0 = none: benchmarks).
-        const uint32_t check_every = [] { const char *e = getenv("MSNV_INFLATE_CHECK"); return e ? (uint32_t)std::max(0, atoi(e)) : 1u; }();   // (per call: tests switch it)
+        const uint32_t check_every = inflate_check_every();       // (one reading for both decoders: msnv_internal.h)
         if (check_every) {
             std::atomic<size_t> nxt{0};
             auto checker = [&]() {
@@ -408,7 +414,7 @@ static int bgzf_read_files_device(msnv_ctx *ctx, const char *const *paths, int n
                     const size_t e0 = nxt.fetch_add(64);
                     if (e0 >= list.size()) break;
                     for (size_t e = e0; e < std::min(list.size(), e0 + 64); ++e) {
-                        if (status[e] || (e + (size_t)f0) % check_every) continue;
+                        if (status[e] || blk_in_file[e] % check_every) continue;
                         const uint8_t *trailer = in_stage + list[e].in_off + list[e].in_size;
                         const uint32_t want = (uint32_t)trailer[0] | (uint32_t)trailer[1] << 8 | (uint32_t)trailer[2] << 16 | (uint32_t)trailer[3] << 24;
                         if (bgzf_crc32(out + list[e].out_off, list[e].out_size) != want) status[e] = 2u;
@@ -457,7 +463,6 @@ static int bgzf_read_files_device(msnv_ctx *ctx, const char *const *paths, int n
         f0 = f1;
     }
     if (counters) { counters[0] = n_blocks; counters[1] = n_host; counters[2] = (uint64_t)(ms * 1000.0); counters[3] = n_bytes; }
-    dev_inflate_release_device(ctx);                                // the batch buffers in HBM go back before the dataset is uploaded (the pinned half stays)
     return MSNV_OK;
 }
 

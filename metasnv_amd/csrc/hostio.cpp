@@ -160,7 +160,7 @@ int bgzf_read_all(const char *path, ByteBuf &out, int threads) {
     std::atomic<size_t> next{0};
     std::atomic<bool> bad{false};
     // every block's output is checked against the CRC-32 of its BGZF trailer, as htslib does (MSNV_INFLATE_CHECK=0 skips it: benchmarks)
-    const bool check_crc = [] { const char *e = getenv("MSNV_INFLATE_CHECK"); return !(e && e[0] == '0' && e[1] == 0); }();
+    const uint32_t check_every = inflate_check_every();
     auto worker = [&]() {
         HostTimerScope ts(HT_INFLATE_HOST);
         for (;;) {
@@ -170,7 +170,7 @@ int bgzf_read_all(const char *path, ByteBuf &out, int threads) {
             for (; i < e; ++i) {
                 const BlockRef &b = blocks[i];
                 if (!inflate_block(in.data() + b.in_off, b.in_size, out.data() + b.out_off, b.out_size)) { bad = true; continue; }
-                if (check_crc && b.out_size) {
+                if (check_every && i % check_every == 0 && b.out_size) {
                     const uint8_t *t = in.data() + b.in_off + b.in_size;
                     if (bgzf_crc32(out.data() + b.out_off, b.out_size) != ld_u32(t)) bad = true;
                 }

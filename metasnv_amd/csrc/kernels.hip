@@ -1,8 +1,9 @@
 // metasnv_amd/csrc/kernels.hip -- CDNA4 (gfx950) kernels of the pileup SNV-calling path.
 //
 // What they replace (reference, CPU, text based):
-//   samtools mpileup CIGAR walk + BQ filter  [EXT]            -> msnv_pileup_tiles
-//   snpCall base-string parse + bpCounts      call_vC.cpp:503-535 -> msnv_pileup_tiles
+//   samtools mpileup's per-position counting of the aligned bases that pass -Q  [EXT] -> msnv_pileup_tiles_* (the CIGAR walk to aligned
+//     pieces, the -Q test of every base and the read filters run BEFORE these kernels: devpack.hip on the device, pack.cpp on host threads)
+//   snpCall base-string parse + bpCounts      call_vC.cpp:503-535 -> msnv_pileup_tiles_*
 //   snpCall gates                             call_vC.cpp:545-552 -> msnv_gate_sites
 //   snpCall per-sample strings (counts only)  call_vC.cpp:316-325 -> msnv_gather_scatter
 //   snpCall population / individual rule      call_vC.cpp:577-601 -> msnv_decide_sites

@@ -50,6 +50,10 @@ struct ByteBuf {
     size_t size() const { return n; }
 };
 
+// MSNV_INFLATE_CHECK=n: block i of a file is checked against the CRC-32 of its BGZF trailer when i % n == 0 (default 1: every block, as
+// htslib does; 0: none -- benchmarks).  ONE reading for the host decoder and the device inflate (read per call: tests switch it).
+inline uint32_t inflate_check_every() { const char *e = getenv("MSNV_INFLATE_CHECK"); const int v = e ? atoi(e) : 1; return (uint32_t)(v < 0 ? 0 : v); }
+
 // Whole-file BGZF inflate (blocks are independent; `threads` > 1 inflates them in parallel).
 int bgzf_read_all(const char *path, ByteBuf &out, int threads);
 // ... in two steps, for the device inflate (inflate_k.hip): the file's bytes + its blocks (offsets of the raw DEFLATE payloads), and

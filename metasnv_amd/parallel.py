@@ -151,6 +151,21 @@ def gather_bytes(blob):
     return [o[:c].cpu().numpy() for o, c in zip(out, counts)]
 
 
+def agree(failure, what):
+    """Every rank calls this behind a step any of them may have failed in (an exception object, or None): the ranks exchange their status,
+    the failing rank re-raises its own exception, the others raise RankError naming it -- nobody is left waiting in the next collective."""
+    if _dist is None:
+        if failure is not None:
+            raise failure
+        return
+    codes = gather_fixed(np.array([0 if failure is None else (int(getattr(failure, "code", 0)) or 99)], dtype=np.int64))
+    bad = [(r, int(c[0])) for r, c in enumerate(codes) if int(c[0])]
+    if failure is not None:
+        raise failure
+    if bad:
+        raise RankError("rank %d reported error %d while %s" % (bad[0][0], bad[0][1], what))
+
+
 class DeviceParts:
     """What exchange_records(..., keep_on_device=True) returns over RCCL: the received bytes as ONE tensor in HBM and where every
     sender's part lies in it.  The record streams inside go to the library where they are (core.Dataset.add_samples_records_device:
@@ -273,9 +288,9 @@ def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=Non
     stats = np.zeros((n, len(core.STATS_FIELDS)), dtype=np.uint32)
     inflated = 0
     batch = max(1, min(batch, -(-n // _world)))          # fewer samples than world x batch: every rank still decodes its share
-    for base, plan_round in deal_samples(n, batch):
+    def decode_round(plan_round):
+        """My samples of this round, decoded; a failure here is carried to every rank by the exchange (status word)."""
         mine = [i for i, r in plan_round if r == _rank]
-        # decode my samples of this round; a failure here is carried to every rank by the exchange (status word)
         failure, decoded = None, []
         try:
             if read_many is not None:
@@ -286,25 +301,15 @@ def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=Non
                     decoded = list(ex.map(read_records, [bam_paths[i] for i in mine]))
             else:
                 decoded = [read_records(bam_paths[i]) for i in mine]
-        except Exception as e:                               # noqa: BLE001 -- re-raised below, after the other ranks have been told
+        except Exception as e:                               # noqa: BLE001 -- re-raised by deliver(), after the other ranks have been told
             failure, decoded = e, []
-        if owner is None:
-            # first round: genome length x coverage per species from what the ranks have just decoded
-            names, lengths = plan
-            local = np.zeros(len(names), dtype=np.uint64)
-            if failure is None:
-                try:
-                    for rec in decoded:
-                        core.contig_bases(rec, len(names), into=local)
-                except Exception as e:                       # noqa: BLE001
-                    failure, decoded = e, []
-            total = sum(a.astype(np.uint64) for a in gather_fixed(local))
-            owner = shard_contigs(names, lengths, _world, contig_bases=total)
-            if _world > 1 and hasattr(ds, "set_contig_mask"):
-                ds.set_contig_mask([o == _rank for o in owner])
-            if metrics is not None:
-                metrics["owner"] = list(owner)
-                metrics["first_round_bases"] = int(total.sum())
+        return mine, decoded, failure
+
+    def deliver(base, plan_round, mine, decoded, failure):
+        """Deals the round's records to the contig owners, exchanges them, appends the round's samples to this rank's dataset."""
+        nonlocal inflated
+        if failure is None and pending[0] is not None:      # the previous round's append failed here: this round's status word says so
+            failure, pending[0] = pending[0], None
         per_dest = [[] for _ in range(_world)]              # per destination rank: (sample, bytes) in sample order
         if failure is None:
             try:
@@ -342,11 +347,13 @@ def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=Non
                 k = i - base - r * batch
                 ptrs.append(got.address(r, starts[r][k]) if int(sizes_of[r][k]) else 0)
                 sizes.append(int(sizes_of[r][k]))
-            ds.add_samples_records_device(ptrs, sizes)
+            try:
+                ds.add_samples_records_device(ptrs, sizes)
+            except Exception as e:                           # noqa: BLE001 -- told to the other ranks by the next round's status word / agree()
+                pending[0] = e
             if metrics is not None:
                 metrics["records_packed_on_device_bytes"] = metrics.get("records_packed_on_device_bytes", 0) + int(sum(sizes))
-            del got
-            continue
+            return
         sizes_of = [got[r][:8 * n_from[r]].view(np.int64) for r in range(_world)]
         starts = [8 * n_from[r] + np.concatenate([[0], np.cumsum(sizes_of[r])]).astype(np.int64) for r in range(_world)]
         streams = []
@@ -354,11 +361,63 @@ def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=Non
             k = i - base - r * batch                     # index among the sender's samples of this round
             o = int(starts[r][k])
             streams.append(got[r][o:o + int(sizes_of[r][k])])
-        if hasattr(ds, "add_samples_records"):           # the round's samples are packed side by side by the library's host threads
-            ds.add_samples_records(streams, pack_threads)
-        else:
-            for s in streams:
-                ds.add_sample_records(s)
+        try:
+            if hasattr(ds, "add_samples_records"):       # the round's samples are packed side by side by the library
+                ds.add_samples_records(streams, pack_threads)
+            else:
+                for s in streams:
+                    ds.add_sample_records(s)
+        except Exception as e:                               # noqa: BLE001
+            pending[0] = e
+
+    pending = [None]                                         # a failure of THIS rank while it appended a round (pack: ENOMEM, EDOMAIN ...)
+    rounds = list(deal_samples(n, batch))
+    k = 0
+    if owner is None:
+        # The contig owners are fixed by the reference's rule -- whole species, heaviest first, weight = genome length x coverage = aligned
+        # bases (createOptimumSplit.py:46-62, which runs AFTER qaCompute has seen every BAM) -- from as many rounds as fit the planning
+        # budget: decoded rounds are HELD (MSNV_PLAN_MB of record bytes per rank, default a quarter of the host memory divided by the
+        # ranks) and dealt once the owners are known; whatever follows streams through.  A small cohort is planned on all of its reads.
+        names, lengths = plan
+        local = np.zeros(len(names), dtype=np.uint64)
+        budget = int(os.environ.get("MSNV_PLAN_MB", "0")) << 20
+        if budget <= 0:
+            try:
+                budget = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") // 4 // max(1, _world)
+            except (OSError, ValueError):
+                budget = 1 << 30
+        held, held_bytes = [], 0
+        while k < len(rounds):
+            base, plan_round = rounds[k]
+            mine, decoded, failure = decode_round(plan_round)
+            if failure is None:
+                try:
+                    for rec in decoded:
+                        core.contig_bases(rec, len(names), into=local)
+                except Exception as e:                       # noqa: BLE001
+                    failure, decoded = e, []
+            held.append((base, plan_round, mine, decoded, failure))
+            held_bytes += sum(int(r.size) for r in decoded)
+            k += 1
+            stop = gather_fixed(np.array([1 if (held_bytes > budget or failure is not None) else 0], dtype=np.int64))
+            if any(int(x[0]) for x in stop):
+                break
+        total = sum(a.astype(np.uint64) for a in gather_fixed(local))
+        owner = shard_contigs(names, lengths, _world, contig_bases=total)
+        if _world > 1 and hasattr(ds, "set_contig_mask"):
+            ds.set_contig_mask([o == _rank for o in owner])
+        if metrics is not None:
+            metrics["owner"] = list(owner)
+            metrics["first_round_bases"] = int(total.sum())
+            metrics["plan_rounds"] = len(held)
+            metrics["plan_samples"] = int(sum(len(h[1]) for h in held))
+        while held:
+            deliver(*held.pop(0))
+    while k < len(rounds):
+        base, plan_round = rounds[k]
+        deliver(base, plan_round, *decode_round(plan_round))
+        k += 1
+    agree(pending[0], "the last round of records was appended")
     allstats = gather_fixed(stats)
     stats = np.maximum.reduce(allstats) if len(allstats) > 1 else stats      # every row is non-zero on exactly one rank
     if metrics is not None:
@@ -523,7 +582,12 @@ def resident_project_run(ctx, first_bam, fasta_path, bam_paths, params, batch=1,
             ds.attach_context(ctx())
             metrics["wait_for_context_s"] = time.perf_counter() - t0
         t0 = time.perf_counter()
-        metrics["dataset"] = ds.finalize()
+        err = None
+        try:
+            metrics["dataset"] = ds.finalize()
+        except Exception as e:                               # noqa: BLE001 -- every rank learns of it before the next collective
+            err = e
+        agree(err, "the datasets were finalized")
         metrics["finalize_s"] = time.perf_counter() - t0
         if res["stats"] is None:                           # staged streams: packed by finalize
             res["stats"] = np.stack([ds.sample_stats(i) for i in range(len(bam_paths))]) if bam_paths else np.zeros((0, len(core.STATS_FIELDS)), np.uint32)
@@ -537,7 +601,12 @@ def resident_project_run(ctx, first_bam, fasta_path, bam_paths, params, batch=1,
             metrics["gather_coverage_s"] = time.perf_counter() - t0
         if after_coverage:
             after_coverage(res)
-        metrics["pileup"] = run_passes(ds) if run_passes else ds.run()
+        err = None
+        try:
+            metrics["pileup"] = run_passes(ds) if run_passes else ds.run()
+        except Exception as e:                               # noqa: BLE001
+            err = e
+        agree(err, "the calling pass ran")
         t0 = time.perf_counter()
         sites, row_off, cell_sample, cells = ds.results_cells()
         ann = None

@@ -1058,6 +1058,36 @@ def test_launcher_under_two_ranks_on_a_sparse_cohort(tmp_path):
         assert open(base).read() == want[0] and open(base + ".detail").read() == want[1]
 
 
+def test_launcher_under_eight_ranks_writes_the_one_rank_project(tmp_path):
+    """The N-rank path at the node's real width: metaSNV.py under torchrun with EIGHT ranks (sharing this GPU, tables over gloo) on a
+    sparse cohort of 20 species -- species LPT over eight owners (createOptimumSplit.py:46-62), every BAM decoded by one rank, records
+    exchanged, eight datasets, gather to rank 0 -- writes the same called_SNPs / indiv_called / cov files, byte for byte, as one rank."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    syn, samples = synth_case(n_species=20, contig_len=4100, n_samples=24, mean_cov=6.0, sigma_cov=0.4, snv_density=0.02, species_per_sample=5, lowercase_ref=1, seed=97)
+    samples = [s for s in samples if s.size]
+    fa, paths, lst = _write_inputs(tmp_path, syn, samples)
+    out = {}
+    for n in (1, 8):
+        proj, met = str(tmp_path / ("proj%d" % n)), str(tmp_path / ("metrics%d.jsonl" % n))
+        r = _torchrun(n, [os.path.join(root, "metaSNV.py"), proj, lst, fa, "--min_pos_cov", "2", "--min_pos_snvs", "2"], env=dict(MSNV_DIST_BACKEND="gloo", MSNV_METRICS=met), timeout=1500)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        files = {"called_SNPs": open(os.path.join(proj, "snpCaller", "called_SNPs")).read(), "indiv_called": open(os.path.join(proj, "snpCaller", "indiv_called")).read()}
+        for pth in paths:
+            base = os.path.join(proj, "cov", os.path.basename(pth) + ".cov")
+            files[os.path.basename(base)] = open(base).read()
+            files[os.path.basename(base) + ".detail"] = open(base + ".detail").read()
+        out[n] = (files, [json.loads(l) for l in open(met)])
+    assert out[1][0].keys() == out[8][0].keys()
+    for k in out[1][0]:
+        assert out[1][0][k] == out[8][0][k], k
+    assert out[1][0]["called_SNPs"].count("\n") > 100
+    m8 = out[8][1]
+    assert sorted(x["rank"] for x in m8) == list(range(8)) and all(x["contigs"] >= 1 for x in m8)      # 20 species over 8 owners
+    bases = [x["dataset"]["n_pileup_bases"] for x in m8]
+    assert max(bases) <= 2.0 * sum(bases) / 8                      # LPT on length x first-round coverage
+
+
 def test_bench_gpus_2_starts_two_ranks_by_itself():
     """`python bench.py --gpus 2` outside torchrun spawns the two rank processes itself (before any GPU call) and the
     rank-0 line reports n_gpus 2, both ranks' line counts and the slowest rank's roofline (gloo rehearsal: one GPU)."""
