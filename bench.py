@@ -401,9 +401,11 @@ def main():
     syn = core.Synth(sp)
     ctx = core.Context(local)
     ds = core.Dataset(ctx, syn.names, syn.lengths, syn.seqs)
+    core.host_timers(reset=True)
     t0 = time.perf_counter()
     ds.add_synth_samples(sp, 0, sp.n_samples, a.host_threads)
     t_pack = time.perf_counter() - t0
+    ht_build = core.host_timers()
     t0 = time.perf_counter()
     info = ds.finalize()
     t_up = time.perf_counter() - t0
@@ -603,7 +605,8 @@ def main():
                          "counters": pileup_counters(sp.n_samples, sp.n_species, sp.contig_len, sp.mean_cov, k_ms) if (world == 1 and a.workload == "testdata") else None},
             "positions_per_s": info["n_positions"] * world * a.steps / dt_max,
             "kernel_ms": {"pileup": k_ms, "pipeline_total": sum(ms_total) / len(ms_total)},
-            "host": {"pack_s": t_pack, "finalize_upload_s": t_up, "device_bytes": info["device_bytes"],
+            "host": {"pack_s": t_pack, "synth_generator_wall_s": ht_build.get("synth_wall_s"), "pack_on_device_wall_s_incl_upload": ht_build.get("pack_device_wall_s"),
+                     "finalize_upload_s": t_up, "device_bytes": info["device_bytes"],
                      "what": "pack_s = wall seconds of building the samples: %s" % ("synthetic record streams made by the host threads, uploaded, and parsed / filtered / cut into pieces by "
                              "kernels (csrc/devpack.hip)" if pack["records"] else "synthetic record streams made AND packed by the host threads (MSNV_PACK=host, csrc/pack.cpp)")},
         }

@@ -447,7 +447,7 @@ def call_from_mpileup(ctx, called_path, indiv_path=None, text=None, mpileup_path
             "text_bytes": int(st[5]), "base_chars": int(st[6])}
 
 
-HOST_TIMERS = ["read_s", "inflate_host_s", "inflate_device_wall_s", "pack_s", "finalize_upload_wall_s", "format_wall_s", "add_bams_wall_s", "pack_device_wall_s"]
+HOST_TIMERS = ["read_s", "inflate_host_s", "inflate_device_wall_s", "pack_s", "finalize_upload_wall_s", "format_wall_s", "add_bams_wall_s", "pack_device_wall_s", "synth_wall_s"]
 
 
 def host_timers(reset=False):

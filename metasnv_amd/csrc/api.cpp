@@ -2,6 +2,7 @@
 // pipeline driver, result mapping and the reference-format text writers.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <climits>
 #include <cstring>
 #include <stdexcept>
@@ -770,6 +771,7 @@ extern "C" int msnv_dataset_add_synth_samples(msnv_dataset *ds, const msnv_synth
             const int g1 = std::min<int>(count, g0 + group);
             std::vector<std::vector<uint8_t>> recs((size_t)(g1 - g0));
             std::atomic<int> nxt{g0}, bad{0};
+            const auto t_synth = std::chrono::steady_clock::now();     // (wall seconds of MAKING the group's streams: the generator, not the product)
             auto w = [&]() {
                 for (;;) {
                     const int i = nxt.fetch_add(1);
@@ -781,6 +783,7 @@ extern "C" int msnv_dataset_add_synth_samples(msnv_dataset *ds, const msnv_synth
             for (int t = 0; t < std::min(nthreads, g1 - g0); ++t) th.emplace_back(w);
             for (auto &t : th) t.join();
             if (bad.load()) { ds->samples.resize(base0); return fail(MSNV_ENOMEM, "making a synthetic sample failed"); }
+            host_timer_add(HT_SYNTH_WALL, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_synth).count());
             std::vector<const uint8_t *> ptrs; std::vector<uint64_t> sizes;
             for (auto &r : recs) { ptrs.push_back(r.data()); sizes.push_back(r.size()); }
             if (int rc = add_streams_device(ds, ptrs.data(), sizes.data(), g1 - g0, false)) { ds->samples.resize(base0); return rc; }

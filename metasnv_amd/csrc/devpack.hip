@@ -88,6 +88,35 @@ __device__ __forceinline__ Rec rec_load(const uint8_t *p, uint64_t avail) {
     r.qual = r.seq + ((uint64_t)(uint32_t)r.l_seq + 1) / 2;
     const uint64_t need = 36ull + r.l_name + 4ull * r.n_cigar + ((uint64_t)(uint32_t)r.l_seq + 1) / 2 + (uint64_t)(uint32_t)r.l_seq;
     r.ok = avail >= 36 && (int32_t)r.bs >= 32 && (uint64_t)r.bs + 4 <= avail && r.l_seq >= 0 && need <= (uint64_t)r.bs + 4;      // hostio.cpp: rec_parse
+    // a CIGAR that lives in the CG:B,I field behind a placeholder `<l_seq>S<ref_len>N` (more than 65535 operations; sam.c bam_tag2cigar
+    // [EXT]): the walk below is taken by such records only (hostio.cpp: rec_parse states the conditions)
+    if (r.ok && r.n_cigar > 0 && r.tid >= 0 && r.pos >= 0) {
+        const uint32_t c0 = ld32(r.cigar);
+        if ((c0 & 15u) == C_S && (int32_t)(c0 >> 4) == r.l_seq) {
+            const uint8_t *aux = r.qual + (uint32_t)r.l_seq, *end = p + 4ull + r.bs;
+            while (aux + 3 <= end) {
+                const uint8_t t = aux[2], *v = aux + 3;
+                unsigned long long sz;
+                if (t == 'A' || t == 'c' || t == 'C') sz = 1;
+                else if (t == 's' || t == 'S') sz = 2;
+                else if (t == 'i' || t == 'I' || t == 'f') sz = 4;
+                else if (t == 'd') sz = 8;
+                else if (t == 'Z' || t == 'H') { const uint8_t *q = v; while (q < end && *q) ++q; sz = (unsigned long long)(q - v) + 1; }
+                else if (t == 'B') {
+                    if (v + 5 > end) break;
+                    const unsigned long long es = (v[0] == 'c' || v[0] == 'C') ? 1 : (v[0] == 's' || v[0] == 'S') ? 2 : 4, n = ld32(v + 1);
+                    if (aux[0] == 'C' && aux[1] == 'G') {
+                        if ((v[0] == 'I' || v[0] == 'i') && n >= r.n_cigar && n < (1ull << 29) && v + 5 + 4 * n <= end) { r.cigar = v + 5; r.n_cigar = (uint32_t)n; }
+                        break;
+                    }
+                    sz = 5 + es * n;
+                } else break;
+                if (aux[0] == 'C' && aux[1] == 'G') break;
+                if (v + sz > end) break;
+                aux = v + sz;
+            }
+        }
+    }
     return r;
 }
 __device__ __forceinline__ bool rec_mapped(uint32_t flag, int32_t tid) { return !(flag & 4u) && tid >= 0; }

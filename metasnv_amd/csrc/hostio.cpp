@@ -312,7 +312,7 @@ bool rec_parse(const uint8_t *p, uint64_t avail, RecView &r) {
     r.pos = (int32_t)ld_u32(p + 8);
     uint32_t l_name = p[12];
     r.mapq = p[13];
-    r.n_cigar = (uint16_t)(p[16] | p[17] << 8);
+    r.n_cigar = (int32_t)(p[16] | p[17] << 8);
     r.flag = (uint16_t)(p[18] | p[19] << 8);
     r.l_seq = (int32_t)ld_u32(p + 20);
     if (r.l_seq < 0) return false;
@@ -324,6 +324,37 @@ bool rec_parse(const uint8_t *p, uint64_t avail, RecView &r) {
     r.seq = r.cigar + 4ull * r.n_cigar;
     r.qual = r.seq + ((uint64_t)r.l_seq + 1) / 2;
     r.size = (uint32_t)bs + 4;
+    // A CIGAR of more than 65535 operations travels in the auxiliary field CG:B,I behind a placeholder `<l_seq>S<ref_len>N`; htslib puts it
+    // back when it reads the record (sam.c bam_tag2cigar, called by bam_read1 [EXT]), so samtools mpileup and qaCompute (sam_read1,
+    // qaCompute.cpp:441) both walk the real one.  Same conditions here: mapped, first operation a soft clip of exactly l_seq bases, a CG
+    // field of type B,I / B,i with at least as many operations as the placeholder (devpack.hip: rec_load does the same on the device).
+    if (r.n_cigar > 0 && r.tid >= 0 && r.pos >= 0) {
+        const uint32_t c0 = ld_u32(r.cigar);
+        if ((c0 & 15u) == C_S && (int32_t)(c0 >> 4) == r.l_seq) {
+            const uint8_t *aux = r.qual + r.l_seq, *end = p + r.size;
+            while (aux + 3 <= end) {
+                const uint8_t t = aux[2], *v = aux + 3;
+                uint64_t sz;
+                if (t == 'A' || t == 'c' || t == 'C') sz = 1;
+                else if (t == 's' || t == 'S') sz = 2;
+                else if (t == 'i' || t == 'I' || t == 'f') sz = 4;
+                else if (t == 'd') sz = 8;
+                else if (t == 'Z' || t == 'H') { const uint8_t *q = v; while (q < end && *q) ++q; sz = (uint64_t)(q - v) + 1; }
+                else if (t == 'B') {
+                    if (v + 5 > end) break;
+                    const uint64_t es = (v[0] == 'c' || v[0] == 'C') ? 1 : (v[0] == 's' || v[0] == 'S') ? 2 : 4, n = ld_u32(v + 1);
+                    if (aux[0] == 'C' && aux[1] == 'G') {
+                        if ((v[0] == 'I' || v[0] == 'i') && n >= (uint64_t)r.n_cigar && n < (1ull << 29) && v + 5 + 4 * n <= end) { r.cigar = v + 5; r.n_cigar = (int32_t)n; }
+                        break;
+                    }
+                    sz = 5 + es * n;
+                } else break;
+                if (aux[0] == 'C' && aux[1] == 'G') break;
+                if (v + sz > end) break;
+                aux = v + sz;
+            }
+        }
+    }
     return true;
 }
 

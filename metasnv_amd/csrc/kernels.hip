@@ -612,7 +612,7 @@ __device__ __forceinline__ void narrow_classify32(NarrowLds &L, const uint32_t l
 #pragma unroll
     for (int w = 0; w < 5; ++w) {
         const uint32_t byte = (uint32_t)(m >> (8 * w)) & 0xffu;
-        if (byte) atomicAdd(&L.exc[wi + w], spread_bits(byte));
+        if (byte) atomicAdd(&L.exc[wi + w], spread_bits(byte));      // (one test per lane for the first four words instead of one per word: 0.395 vs 0.387 ms, round 4)
     }
     const uint32_t sw[4] = {sq.x, sq.y, sq.z, sq.w};
     const uint32_t rw[4] = {__builtin_amdgcn_alignbit(w1, w0, sh), __builtin_amdgcn_alignbit(w2, w1, sh),

@@ -20,7 +20,7 @@ void clear_error();
 // ---------------------------------------------------------------------------------- host-stage timers (msnv.h: msnv_host_timers)
 // Cumulative microseconds since the library was loaded (or the last reset), summed over the host threads that did the work:
 // what the wall time of BAM files -> resident dataset is made of.
-enum HostTimer { HT_READ = 0, HT_INFLATE_HOST, HT_INFLATE_DEVICE_WALL, HT_PACK, HT_UPLOAD_WALL, HT_FORMAT_WALL, HT_ADD_WALL, HT_PACK_DEVICE_WALL, HT_N };
+enum HostTimer { HT_READ = 0, HT_INFLATE_HOST, HT_INFLATE_DEVICE_WALL, HT_PACK, HT_UPLOAD_WALL, HT_FORMAT_WALL, HT_ADD_WALL, HT_PACK_DEVICE_WALL, HT_SYNTH_WALL, HT_N };
 void host_timer_add(int which, double seconds);
 struct HostTimerScope {
     int which; double t0;
@@ -99,7 +99,7 @@ enum CigarOp : uint32_t { C_M = 0, C_I = 1, C_D = 2, C_N = 3, C_S = 4, C_H = 5, 
 
 struct RecView {
     int32_t  tid, pos, l_seq;
-    uint16_t flag, n_cigar;
+    uint16_t flag; int32_t n_cigar;      // n_cigar / cigar: the record's, or the CG:B,I field's when the CIGAR lives there (rec_parse)
     uint8_t  mapq;
     const uint8_t *cigar, *seq, *qual;   // unaligned little-endian
     const uint8_t *qname; uint32_t l_name;   // NUL-terminated read name, l_name includes the NUL

@@ -120,4 +120,44 @@ int orc_qacompute(const orc_ref *ref /* names+lengths only */, const orc_sample 
 #ifdef __cplusplus
 }
 #endif
+
+/* A CIGAR of more than 65535 operations does not fit the record's 16-bit count: it travels in the auxiliary field CG:B,I behind a
+ * placeholder CIGAR `<l_seq>S<ref_len>N`, and htslib puts it back when it reads the record (sam.c bam_tag2cigar, called by bam_read1
+ * [EXT]) -- so both `samtools mpileup` and qaCompute (sam_read1, qaCompute.cpp:441) see the real one.  Restated: if the record is
+ * mapped (tid, pos >= 0), has at least one operation, its first operation is a soft clip of exactly l_seq bases, and a CG field of type
+ * B with subtype I or i holds at least as many operations as the placeholder (and fewer than 2^29), *cigar / *n_cigar become the
+ * field's.  aux .. end: the bytes behind the qualities. */
+static inline void orc_resolve_cg(const unsigned char *aux, const unsigned char *end, int tid, int pos, int l_seq, const unsigned char **cigar, unsigned *n_cigar) {
+    const unsigned char *c0 = *cigar;
+    unsigned first;
+    if (*n_cigar == 0 || tid < 0 || pos < 0) return;
+    first = (unsigned)c0[0] | (unsigned)c0[1] << 8 | (unsigned)c0[2] << 16 | (unsigned)c0[3] << 24;
+    if ((first & 15u) != 4u || (int)(first >> 4) != l_seq) return;
+    while (aux + 3 <= end) {                                   /* tag[2] type[1] value */
+        const unsigned char t = aux[2];
+        const unsigned char *v = aux + 3;
+        unsigned long sz;
+        if (t == 'A' || t == 'c' || t == 'C') sz = 1;
+        else if (t == 's' || t == 'S') sz = 2;
+        else if (t == 'i' || t == 'I' || t == 'f') sz = 4;
+        else if (t == 'd') sz = 8;
+        else if (t == 'Z' || t == 'H') { const unsigned char *q = v; while (q < end && *q) ++q; sz = (unsigned long)(q - v) + 1; }
+        else if (t == 'B') {
+            unsigned long es, n;
+            if (v + 5 > end) return;
+            es = (v[0] == 'c' || v[0] == 'C') ? 1 : (v[0] == 's' || v[0] == 'S') ? 2 : 4;
+            n = (unsigned long)v[1] | (unsigned long)v[2] << 8 | (unsigned long)v[3] << 16 | (unsigned long)v[4] << 24;
+            if (aux[0] == 'C' && aux[1] == 'G') {
+                if ((v[0] != 'I' && v[0] != 'i') || n < *n_cigar || n >= (1ul << 29) || v + 5 + 4 * n > end) return;
+                *cigar = v + 5; *n_cigar = (unsigned)n;
+                return;
+            }
+            sz = 5 + es * n;
+        } else return;                                         /* unknown type: the walk cannot go on */
+        if (aux[0] == 'C' && aux[1] == 'G') return;             /* a CG field of another type: no real CIGAR there */
+        if (v + sz > end) return;
+        aux = v + sz;
+    }
+}
+
 #endif

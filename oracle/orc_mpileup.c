@@ -57,7 +57,7 @@ static uint16_t rd_u16(const uint8_t *p) { return (uint16_t)(p[0] | p[1] << 8); 
 /* One alignment record, fields of SAM spec 4.2 */
 typedef struct {
     int32_t tid, pos, l_seq;
-    uint16_t flag, n_cigar;
+    uint16_t flag; uint32_t n_cigar;    /* (the count of the CG field when the CIGAR lives there: orc_resolve_cg) */
     uint8_t mapq;
     const uint8_t *cigar, *seq, *qual;
     const char *qname; int32_t mtid, mpos, isize;
@@ -85,7 +85,8 @@ static int parse_record(const uint8_t *p, uint64_t avail, read_t *r, uint64_t *c
     r->seq = r->cigar + 4 * (size_t)r->n_cigar;
     r->qual = r->seq + ((size_t)r->l_seq + 1) / 2;
     if ((uint64_t)(r->qual + r->l_seq - p) > (uint64_t)bs + 4) return -1;
-    for (k = 0; k < r->n_cigar; ++k) {          /* bam_cigar2rlen */
+    { unsigned nc = r->n_cigar; orc_resolve_cg(r->qual + r->l_seq, p + 4 + (size_t)bs, r->tid, r->pos, r->l_seq, &r->cigar, &nc); r->n_cigar = nc; }   /* bam_read1 -> bam_tag2cigar */
+    for (k = 0; k < (int)r->n_cigar; ++k) {          /* bam_cigar2rlen */
         uint32_t c = cig(r, k); int op = c & 15;
         if (op == CM || op == CD || op == CN || op == CEQ || op == CX) rlen += c >> 4;
     }
@@ -99,7 +100,7 @@ static int parse_record(const uint8_t *p, uint64_t avail, read_t *r, uint64_t *c
 
 static int has_ref_op(const read_t *r) {
     int k;
-    for (k = 0; k < r->n_cigar; ++k) { int op = cig(r, k) & 15; if (op == CM || op == CD || op == CN || op == CEQ || op == CX) return 1; }
+    for (k = 0; k < (int)r->n_cigar; ++k) { int op = cig(r, k) & 15; if (op == CM || op == CD || op == CN || op == CEQ || op == CX) return 1; }
     return 0;
 }
 
@@ -120,7 +121,7 @@ static int iref2iseq_set(const read_t *r, int *kc, int64_t *icig, int64_t *iseq,
     int64_t pos = *iref;
     if (pos < 0) return -1;
     *icig = 0; *iseq = 0; *iref = 0; *kc = 0;
-    while (*kc < r->n_cigar) {
+    while (*kc < (int)r->n_cigar) {
         uint32_t c = cig(r, *kc); int op = c & 15; int64_t n = c >> 4;
         if (op == CS) { (*kc)++; *iseq += n; *icig = 0; continue; }
         if (op == CH || op == CP) { (*kc)++; *icig = 0; continue; }
@@ -144,7 +145,7 @@ static int iref2iseq_set(const read_t *r, int *kc, int64_t *icig, int64_t *iseq,
 }
 /* cigar_iref2iseq_next: the next CMATCH base */
 static int iref2iseq_next(const read_t *r, int *kc, int64_t *icig, int64_t *iseq, int64_t *iref) {
-    while (*kc < r->n_cigar) {
+    while (*kc < (int)r->n_cigar) {
         uint32_t c = cig(r, *kc); int op = c & 15; int64_t n = c >> 4;
         if (op == CM || op == CEQ || op == CX) {
             if (*icig >= n - 1) { *icig = -1; (*kc)++; continue; }
@@ -252,7 +253,7 @@ static int resolve(read_t *r, int64_t pos, elem_t *p) {
     int k;
     if (r->k == -1) {                        /* first ref-consuming op */
         r->x = r->pos; r->y = 0;
-        for (k = 0; k < r->n_cigar; ++k) {
+        for (k = 0; k < (int)r->n_cigar; ++k) {
             uint32_t c = cig(r, k); int op = c & 15;
             if (op == CM || op == CD || op == CN || op == CEQ || op == CX) break;
             else if (op == CI || op == CS) r->y += (int32_t)(c >> 4);
@@ -267,20 +268,20 @@ static int resolve(read_t *r, int64_t pos, elem_t *p) {
         if (refc) r->x += l;
         if (op == CM || op == CI || op == CS || op == CEQ || op == CX) r->y += (int32_t)l;
         r->k++;
-        if (r->k >= r->n_cigar) return 0;
+        if (r->k >= (int)r->n_cigar) return 0;
     }
     {
         uint32_t c = cig(r, r->k); int op = c & 15; int64_t l = c >> 4;
         memset(p, 0, sizeof *p);
         if (op == CM || op == CEQ || op == CX) {
             p->qpos = r->y + (int)(pos - r->x);
-            if (r->x + l - 1 == pos && r->k + 1 < r->n_cigar) {
+            if (r->x + l - 1 == pos && r->k + 1 < (int)r->n_cigar) {
                 uint32_t c2 = cig(r, r->k + 1); int op2 = c2 & 15; int l2 = (int)(c2 >> 4);
                 if (op2 == CD) p->indel = -l2;
                 else if (op2 == CI) p->indel = l2;
-                else if (op2 == CP && r->k + 2 < r->n_cigar) {
+                else if (op2 == CP && r->k + 2 < (int)r->n_cigar) {
                     int l3 = 0;
-                    for (k = r->k + 2; k < r->n_cigar; ++k) {
+                    for (k = r->k + 2; k < (int)r->n_cigar; ++k) {
                         c2 = cig(r, k); op2 = c2 & 15; l2 = (int)(c2 >> 4);
                         if (op2 == CI) l3 += l2;
                         else if (op2 == CD || op2 == CM || op2 == CN || op2 == CEQ || op2 == CX) break;

@@ -72,11 +72,16 @@ int orc_qacompute(const orc_ref *head, const orc_sample *sample, int max_cov, in
 
     while (off < sample->n_bytes) {                                                              /* :441 */
         const uint8_t *p = sample->records + off;
-        int32_t bs, tid, pos; uint32_t l_name; uint16_t n_cigar, flag; uint8_t mapq; const uint8_t *cigar;
+        int32_t bs, tid, pos; uint32_t l_name; unsigned n_cigar; uint16_t flag; uint8_t mapq; const uint8_t *cigar;
         if (sample->n_bytes - off < 36) { orc_set_error("truncated BAM record"); free(entireChr); free(coverageHist); fclose(out); fclose(detail); return ORC_ERR_FORMAT; }
         bs = rd_i32(p); tid = rd_i32(p + 4); pos = rd_i32(p + 8);
         l_name = p[12]; mapq = p[13]; n_cigar = rd_u16(p + 16); flag = rd_u16(p + 18);
         cigar = p + 36 + l_name;
+        {   /* sam_read1 -> bam_read1 puts a CIGAR that lives in the CG field back (orc.h: orc_resolve_cg) */
+            const int32_t l_seq = rd_i32(p + 20);
+            const uint8_t *aux = cigar + 4 * (size_t)n_cigar + ((size_t)(l_seq > 0 ? l_seq : 0) + 1) / 2 + (size_t)(l_seq > 0 ? l_seq : 0);
+            if (bs >= 32 && aux <= p + 4 + (size_t)bs) orc_resolve_cg(aux, p + 4 + (size_t)bs, tid, pos, l_seq, &cigar, &n_cigar);
+        }
         off += (uint64_t)bs + 4;
 
         if (flag & BAM_FUNMAP) {                                                                 /* :461-462 */
@@ -107,7 +112,7 @@ int orc_qacompute(const orc_ref *head, const orc_sample *sample, int max_cov, in
                     /* the reference reads *cigar even when n_cigar == 0 (then sees sequence bytes);
                        the loop below never runs in that case, so the peek has no effect */
                     if (n_cigar > 0 && (((rd_u32(c) & 15) == 4) || ((rd_u32(c) & 15) == 5))) { c += 4; ++k; }
-                    while (k < n_cigar) {
+                    while (k < (int)n_cigar) {
                         uint32_t op = rd_u32(c);
                         ++k;
                         if ((op & 15) != 0) {

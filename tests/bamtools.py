@@ -32,16 +32,36 @@ def reg2bin(beg, end):
     return 0
 
 
-def make_record(tid, pos, cigar, seq, qual=None, flag=0, mapq=60, name="r", mtid=-1, mpos=-1, tlen=0):
-    """One raw BAM alignment record (SAMv1 4.2).  pos is 0-based; qual is a list of ints or None."""
+def aux_fields(nm=None, md=None, score=None):
+    """Auxiliary fields as bwa / ngless write them behind the qualities: NM:C, MD:Z, AS:i."""
+    out = b""
+    if nm is not None:
+        out += b"NMC" + bytes([nm])
+    if md is not None:
+        out += b"MDZ" + md.encode() + b"\0"
+    if score is not None:
+        out += b"ASi" + struct.pack("<i", score)
+    return out
+
+
+def make_record(tid, pos, cigar, seq, qual=None, flag=0, mapq=60, name="r", mtid=-1, mpos=-1, tlen=0, aux=b"", cg_form=False):
+    """One raw BAM alignment record (SAMv1 4.2).  pos is 0-based; qual is a list of ints or None; aux: bytes behind the qualities.
+    cg_form: the CIGAR goes into a CG:B,I field behind the placeholder `<l_seq>S<ref_len>N`, as a writer does for more than 65535
+    operations (SAMv1 4.2.2) -- htslib puts it back on reading, whatever its length."""
     ops = parse_cigar(cigar)
+    if cg_form:
+        real = ops
+        l = 0 if seq in ("*", "") else len(seq)
+        ref_len = sum(n for n, op in real if op in (0, 2, 3, 7, 8))
+        ops = [(l, 4), (ref_len, 3)]
+        aux = aux + b"CGBI" + struct.pack("<I", len(real)) + b"".join(struct.pack("<I", n << 4 | op) for n, op in real)
     l_seq = 0 if seq in ("*", "") else len(seq)
     if qual is None:
         qual = [40] * l_seq
     if isinstance(qual, str):
         qual = [ord(c) - 33 for c in qual]
     assert len(qual) == l_seq
-    rlen = sum(n for n, op in ops if op in (0, 2, 3, 7, 8))
+    rlen = sum(n for n, op in (real if cg_form else ops) if op in (0, 2, 3, 7, 8))
     nm = name.encode() + b"\0"
     seqb = bytearray((l_seq + 1) // 2)
     for i in range(l_seq):
@@ -49,7 +69,7 @@ def make_record(tid, pos, cigar, seq, qual=None, flag=0, mapq=60, name="r", mtid
         seqb[i >> 1] |= code << (4 if i % 2 == 0 else 0)
     body = struct.pack("<iiBBHHHiiii", tid, pos, len(nm), mapq, reg2bin(pos, pos + max(rlen, 1)), len(ops), flag,
                        l_seq, mtid, mpos, tlen)
-    body += nm + b"".join(struct.pack("<I", n << 4 | op) for n, op in ops) + bytes(seqb) + bytes(qual)
+    body += nm + b"".join(struct.pack("<I", n << 4 | op) for n, op in ops) + bytes(seqb) + bytes(qual) + aux
     return struct.pack("<i", len(body)) + body
 
 

@@ -117,3 +117,22 @@ def test_overlapping_mates_first_base_behind_a_gap_of_the_second_mate_is_left_al
     assert got[6] == "c1\t7\tG\t2\t.,\t?5" and got[7:] == ["c1\t8\tT\t1\t.\tS", "c1\t9\tA\t1\t.\tS", "c1\t10\tC\t1\t.$\tS"]
     b = _pair("ACGTGTAC", [30] * 8, "GTACGTAC", [20] * 8, a_pos=0, b_pos=2, a_cig="4M2D4M", b_cig="8M", tlen=10)
     assert _lines(b)[6] == "c1\t7\tG\t1\t.\tS"
+
+
+def test_cigar_in_the_cg_field_reads_like_the_plain_record():
+    """htslib puts a CIGAR that travels in CG:B,I behind the placeholder `<l_seq>S<ref_len>N` back when it reads the record (sam.c
+    bam_tag2cigar [EXT]): mpileup text and qaCompute's files of the two forms are the same; auxiliary fields around it change nothing."""
+    import bamtools as bt
+    import orc
+    ref = ("ACGTTGCAAGGCTTAACCGGTTAACGTAGCTAGCTAGGATCCGATTACAGATTACAGGCATTACG" * 8)[:480]
+    reads = [(10, "20M2D30M", ref[10:30] + ref[32:62]), (12, "5S40M3I10M", "NNNNN" + ref[12:52] + "GGG" + ref[52:62]), (40, "30M1X29M", ref[40:100])]
+    forms = []
+    for cg in (False, True):
+        recs = [bt.make_record(0, pos, cig, seq, name="r%d" % k, aux=bt.aux_fields(nm=1, md="50", score=47), cg_form=cg) for k, (pos, cig, seq) in enumerate(reads)]
+        s = bt.records(*recs)
+        forms.append((orc.mpileup_text(["c"], [len(ref)], [ref], [s]), orc.qacompute(["c"], [len(ref)], s)))
+    assert forms[0] == forms[1]
+    assert forms[0][0].count("\n") > 80
+    # a CG field that holds FEWER operations than the placeholder is not a real CIGAR: the record stays what it says (all clipped, ref-skip)
+    odd = bt.make_record(0, 5, "30S30N", ref[5:35], name="odd", aux=b"CGBI" + __import__("struct").pack("<II", 1, 30 << 4))
+    assert orc.qacompute(["c"], [len(ref)], bt.records(odd))[0] == orc.qacompute(["c"], [len(ref)], bt.records(bt.make_record(0, 5, "30S30N", ref[5:35], name="odd")))[0]
