@@ -16,7 +16,18 @@
 #include <stdexcept>
 #include <thread>
 
+#include <sys/mman.h>
+
 namespace msnv {
+
+void msnv_advise_huge(void *p, size_t bytes) {
+#if defined(MADV_HUGEPAGE)
+    (void)madvise(p, bytes, MADV_HUGEPAGE);
+#else
+    (void)p; (void)bytes;
+#endif
+}
+
 
 // ------------------------------------------------------------------------------ error state
 static thread_local char t_err[1024];

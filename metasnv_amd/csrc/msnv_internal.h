@@ -35,6 +35,8 @@ struct BamHeader {
     std::vector<int64_t>     lengths;
 };
 
+void msnv_advise_huge(void *p, size_t bytes);   // madvise(MADV_HUGEPAGE) where the platform has it (hostio.cpp)
+
 // Uninitialised byte buffer (a std::vector would zero hundreds of megabytes that the inflate overwrites right away).
 struct ByteBuf {
     uint8_t *p = nullptr; size_t n = 0;
@@ -44,7 +46,20 @@ struct ByteBuf {
     ByteBuf(ByteBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
     ByteBuf &operator=(ByteBuf &&o) noexcept { if (this != &o) { free(p); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
     ~ByteBuf() { free(p); }
-    bool alloc(size_t m) { free(p); p = (uint8_t *)malloc(m ? m : 1); n = p ? m : 0; return p != nullptr; }
+    // Large buffers (the inflated bytes of a BAM) ask for transparent huge pages where the system grants them on request (THP "madvise"):
+    // a 22 MB stream is 11 page faults instead of 5 600 when the inflate threads first touch it, and unmapping 3.5 GB of them at the end of
+    // a 160-BAM job takes milliseconds instead of 0.3 s under the address-space lock (where it stalled the device allocations of finalize).
+    bool alloc(size_t m) {
+        free(p); p = nullptr;
+        constexpr size_t huge = 2u << 20;
+        if (m >= 4 * huge) {
+            void *q = nullptr;
+            if (posix_memalign(&q, huge, (m + huge - 1) / huge * huge) == 0) { p = (uint8_t *)q; msnv_advise_huge(p, (m + huge - 1) / huge * huge); }
+        }
+        if (!p) p = (uint8_t *)malloc(m ? m : 1);
+        n = p ? m : 0;
+        return p != nullptr;
+    }
     uint8_t *data() { return p; }
     const uint8_t *data() const { return p; }
     size_t size() const { return n; }
