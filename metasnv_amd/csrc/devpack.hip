@@ -1476,8 +1476,7 @@ __device__ __forceinline__ uint32_t sample_of(const unsigned long long *iv_start
 __global__ void msnv_fin_cov_measure(const int32_t *ctid, const int32_t *cbeg, const int32_t *cend, unsigned long long n, const DpContig *ctg, const uint32_t *tile_base,
                                      uint32_t *keep, uint32_t *ntile) {
     const unsigned long long j = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j > n) return;
-    if (j == n) { keep[j] = 0; ntile[j] = 0; return; }
+    if (j >= n) return;
     const int32_t c = ctid[j];
     const long long L = ctg[c].len, b = cbeg[j];
     const bool minus_one = b > (long long)cend[j];                                          // {L, L - 1}: "-1 at L - 1" (msnv_emit_headers)
@@ -1491,19 +1490,21 @@ __global__ void msnv_fin_cov_measure(const int32_t *ctid, const int32_t *cbeg, c
     }
     keep[j] = k ? 1u : 0u; ntile[j] = nt;
 }
-__global__ void msnv_fin_cov_emit(const int32_t *ctid, const int32_t *cbeg, const int32_t *cend, unsigned long long n, const DpContig *ctg, const uint32_t *tile_base,
-                                  const unsigned long long *iv_start, uint32_t n_samples, const uint32_t *keep, const uint32_t *kidx, const unsigned long long *ebase,
-                                  Pair32 *iv, unsigned long long *ekey, uint32_t *eval) {
+// (the round's arrays are indexed by j, the dataset-wide ones -- kidx, iv_start -- by j0 + j; ntile / ebase come offset to the round)
+__global__ void msnv_fin_cov_emit(const int32_t *ctid, const int32_t *cbeg, const int32_t *cend, unsigned long long n, unsigned long long j0, const DpContig *ctg,
+                                  const uint32_t *tile_base, const unsigned long long *iv_start, uint32_t n_samples, const uint32_t *ntile, const uint32_t *kidx_all,
+                                  const uint32_t *ebase, Pair32 *iv, unsigned long long *ekey, uint32_t *eval) {
     const unsigned long long j = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n || !keep[j]) return;
+    if (j >= n || !ntile[j]) return;
+    const uint32_t *kidx = kidx_all + j0;
     const int32_t c = ctid[j];
     const long long L = ctg[c].len, b = cbeg[j];
     const bool minus_one = b > (long long)cend[j];
     const long long e = minus_one ? (long long)cend[j] : ((long long)cend[j] >= L ? L - 1 : (long long)cend[j]);
     const unsigned long long g0 = (unsigned long long)tile_base[c] * TILE;
     iv[kidx[j]] = Pair32{(uint32_t)(g0 + (unsigned long long)b), (uint32_t)(g0 + (unsigned long long)e)};
-    const uint32_t s = sample_of(iv_start, n_samples, j);
-    const uint32_t idx = kidx[j] - kidx[iv_start[s]];                                       // index among the sample's kept intervals
+    const uint32_t s = sample_of(iv_start, n_samples, j0 + j);
+    const uint32_t idx = kidx[j] - kidx_all[iv_start[s]];                                   // index among the sample's kept intervals
     const uint32_t tf = (uint32_t)((g0 + (unsigned long long)(minus_one ? e : b)) / TILE), tl = minus_one ? tf : (uint32_t)((g0 + (unsigned long long)e - 1) / TILE);
     unsigned long long w = ebase[j];
     for (uint32_t t = tf; t <= tl; ++t, ++w) { ekey[w] = (unsigned long long)s << 32 | t; eval[w] = idx; }
@@ -1598,7 +1599,8 @@ int devfin_merged_headers(msnv_dataset &ds, DeviceCols &d, const std::vector<Dev
 }
 
 // d.cov_iv (allocated here: kept intervals + 4 idle entries) and, for the host, the kept intervals before every sample (cvbase) and the
-// (sample, tile) runs of the intervals in (sample, tile) order
+// (sample, tile) runs of the intervals in (sample, tile) order.  Work memory: 12 B per interval + 24 B per (interval, tile) entry in ONE
+// allocation (hipMalloc / hipFree of a dozen multi-gigabyte buffers was most of this step's second at BASELINE configs[2] scale).
 int devfin_coverage(msnv_dataset &ds, DeviceCols &d, std::vector<uint64_t> &cvbase, std::vector<DevCovPair> &cp) {
     hipStream_t st = (hipStream_t)ds.ctx->stream;
     const size_t S = ds.samples.size();
@@ -1606,79 +1608,95 @@ int devfin_coverage(msnv_dataset &ds, DeviceCols &d, std::vector<uint64_t> &cvba
     for (size_t s = 0; s < S; ++s) iv_start[s + 1] = iv_start[s] + ds.samples[s].n_dev_iv;
     const unsigned long long N = iv_start[S];
     cvbase.assign(S + 1, 0); cp.clear();
-    DevBuf ctid, cbeg, cend, keep, ntile, kidx, ebase, tb, ivs;
-    if (int rc = ctid.alloc((N + 1) * 4)) return rc;
-    if (int rc = cbeg.alloc((N + 1) * 4)) return rc;
-    if (int rc = cend.alloc((N + 1) * 4)) return rc;
-    {   // the rounds' intervals side by side (sample order)
+    if (N > 0xfffffff0ull) return fail(MSNV_EDOMAIN, "more than 2^32 qaCompute intervals in one shard");
+    auto up = [](unsigned long long b) { return (b + 255ull) & ~255ull; };
+    DevBuf small, work;
+    const unsigned long long b_tb = up(std::max<size_t>(1, ds.tile_base.size()) * 4), b_ivs = up((S + 1) * 8), b_cvb = up((S + 1) * 4);
+    if (int rc = small.alloc(b_tb + b_ivs + b_cvb)) return rc;
+    uint32_t *tb = small.as<uint32_t>();
+    unsigned long long *ivs = reinterpret_cast<unsigned long long *>(small.as<uint8_t>() + b_tb);
+    uint32_t *cvb = reinterpret_cast<uint32_t *>(small.as<uint8_t>() + b_tb + b_ivs);
+    HIP_TRY(hipMemcpyAsync(tb, ds.tile_base.data(), ds.tile_base.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ivs, iv_start.data(), (S + 1) * 8, hipMemcpyHostToDevice, st));
+    const unsigned long long b_n = up((N + 1) * 4);
+    if (int rc = work.alloc(3 * b_n)) return rc;
+    uint32_t *keep = work.as<uint32_t>(), *ntile = reinterpret_cast<uint32_t *>(work.as<uint8_t>() + b_n), *kidx = reinterpret_cast<uint32_t *>(work.as<uint8_t>() + 2 * b_n);
+    const DpContig *ctg = static_cast<const DpContig *>(ds.dp.contigs);
+    Prim pr(st);
+    {   // the rounds' intervals where they lie (sample order = round order)
         unsigned long long o = 0;
         for (const DevRound &r : ds.dp.rounds) {
             if (r.n_iv) {
-                HIP_TRY(hipMemcpyAsync(ctid.as<int32_t>() + o, r.cov_tid, r.n_iv * 4, hipMemcpyDeviceToDevice, st));
-                HIP_TRY(hipMemcpyAsync(cbeg.as<int32_t>() + o, r.cov_beg, r.n_iv * 4, hipMemcpyDeviceToDevice, st));
-                HIP_TRY(hipMemcpyAsync(cend.as<int32_t>() + o, r.cov_end, r.n_iv * 4, hipMemcpyDeviceToDevice, st));
+                hipLaunchKernelGGL(msnv_fin_cov_measure, grid_for(r.n_iv, 256), dim3(256), 0, st, r.cov_tid, r.cov_beg, r.cov_end, (unsigned long long)r.n_iv, ctg, tb, keep + o, ntile + o);
+                HIP_TRY(hipGetLastError());
             }
             o += r.n_iv;
         }
         if (o != N) return fail(MSNV_EINVAL, "internal: the rounds hold %llu intervals, the samples %llu", o, N);
+        HIP_TRY(hipMemsetAsync(keep + N, 0, 4, st));
+        HIP_TRY(hipMemsetAsync(ntile + N, 0, 4, st));
     }
-    if (int rc = keep.alloc((N + 1) * 4)) return rc;
-    if (int rc = ntile.alloc((N + 1) * 4)) return rc;
-    if (int rc = kidx.alloc((N + 1) * 4)) return rc;
-    if (int rc = ebase.alloc((N + 1) * 8)) return rc;
-    if (int rc = tb.alloc(std::max<size_t>(1, ds.tile_base.size()) * 4)) return rc;
-    if (int rc = ivs.alloc((S + 1) * 8)) return rc;
-    HIP_TRY(hipMemcpyAsync(tb.p, ds.tile_base.data(), ds.tile_base.size() * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(ivs.p, iv_start.data(), (S + 1) * 8, hipMemcpyHostToDevice, st));
-    const DpContig *ctg = static_cast<const DpContig *>(ds.dp.contigs);
-    Prim pr(st);
-    hipLaunchKernelGGL(msnv_fin_cov_measure, grid_for(N + 1, 256), dim3(256), 0, st, ctid.as<int32_t>(), cbeg.as<int32_t>(), cend.as<int32_t>(), N, ctg, tb.as<uint32_t>(),
-                       keep.as<uint32_t>(), ntile.as<uint32_t>());
-    HIP_TRY(hipGetLastError());
-    if (int rc = pr.scan32(keep.as<uint32_t>(), kidx.as<uint32_t>(), N + 1, false)) return rc;
-    if (int rc = pr.scan64(ntile.as<uint32_t>(), ebase.as<unsigned long long>(), N + 1)) return rc;
-    uint32_t n_keep = 0; unsigned long long n_ent = 0;
-    HIP_TRY(hipMemcpyAsync(&n_keep, kidx.as<uint32_t>() + N, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(&n_ent, ebase.as<unsigned long long>() + N, 8, hipMemcpyDeviceToHost, st));
-    DevBuf cvb;
-    if (int rc = cvb.alloc((S + 1) * 4)) return rc;
-    hipLaunchKernelGGL(msnv_gather_u32, grid_for(S + 1, 64), dim3(64), 0, st, kidx.as<uint32_t>(), ivs.as<unsigned long long>(), (uint32_t)(S + 1), cvb.as<uint32_t>());
+    if (int rc = pr.scan32(keep, kidx, N + 1, false)) return rc;
+    uint32_t n_keep = 0;
+    HIP_TRY(hipMemcpyAsync(&n_keep, kidx + N, 4, hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(msnv_gather_u32, grid_for(S + 1, 64), dim3(64), 0, st, kidx, ivs, (uint32_t)(S + 1), cvb);
     HIP_TRY(hipGetLastError());
     std::vector<uint32_t> cvb_h(S + 1);
-    HIP_TRY(hipMemcpyAsync(cvb_h.data(), cvb.p, (S + 1) * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpyAsync(cvb_h.data(), cvb, (S + 1) * 4, hipMemcpyDeviceToHost, st));
+    // entry slots: exclusive scan of the tile counts, in place of `keep` (no longer needed once kidx exists)
+    unsigned long long n_ent64 = 0;
+    {
+        DevBuf tot;
+        if (int rc = tot.alloc(16)) return rc;
+        // (a 64-bit total first: the 32-bit scan below must not wrap)
+        size_t need = 0;
+        HIP_TRY(rocprim::reduce(nullptr, need, ntile, tot.as<unsigned long long>(), 0ull, (size_t)N, rocprim::plus<unsigned long long>(), st));
+        if (int rc = pr.room(need)) return rc;
+        HIP_TRY(rocprim::reduce(pr.tmp.p, need, ntile, tot.as<unsigned long long>(), 0ull, (size_t)N, rocprim::plus<unsigned long long>(), st));
+        HIP_TRY(hipMemcpyAsync(&n_ent64, tot.p, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    if (n_ent64 > 0xfffffff0ull) return fail(MSNV_EDOMAIN, "more than 2^32 (interval, tile) entries in one shard");
+    const uint32_t n_ent = (uint32_t)n_ent64;
+    uint32_t *ebase = keep;
+    if (int rc = pr.scan32(ntile, ebase, N + 1, false)) return rc;
     for (size_t s = 0; s <= S; ++s) cvbase[s] = cvb_h[s];
     d.n_cov_iv = n_keep;
     if (int rc = dev_alloc((void **)&d.cov_iv, ((uint64_t)n_keep + 4) * sizeof(Pair32), &d.device_bytes)) return rc;
     HIP_TRY(hipMemsetAsync(d.cov_iv + n_keep, 0, 4 * sizeof(Pair32), st));                  // behind the last interval: what the idle lanes of msnv_coverage_tiles load
-    DevBuf ekey, eval, skey, sval, flag, rid, runs;
-    if (int rc = ekey.alloc((n_ent + 1) * 8)) return rc;
-    if (int rc = eval.alloc((n_ent + 1) * 4)) return rc;
-    if (N) {
-        hipLaunchKernelGGL(msnv_fin_cov_emit, grid_for(N, 256), dim3(256), 0, st, ctid.as<int32_t>(), cbeg.as<int32_t>(), cend.as<int32_t>(), N, ctg, tb.as<uint32_t>(),
-                           ivs.as<unsigned long long>(), (uint32_t)S, keep.as<uint32_t>(), kidx.as<uint32_t>(), ebase.as<unsigned long long>(), d.cov_iv, ekey.as<unsigned long long>(),
-                           eval.as<uint32_t>());
-        HIP_TRY(hipGetLastError());
+    DevBuf ent;
+    const unsigned long long b_k = up(((unsigned long long)n_ent + 1) * 8), b_v = up(((unsigned long long)n_ent + 1) * 4);
+    if (int rc = ent.alloc(2 * b_k + 2 * b_v)) return rc;
+    unsigned long long *ekey = ent.as<unsigned long long>(), *skey = reinterpret_cast<unsigned long long *>(ent.as<uint8_t>() + b_k);
+    uint32_t *eval = reinterpret_cast<uint32_t *>(ent.as<uint8_t>() + 2 * b_k), *sval = reinterpret_cast<uint32_t *>(ent.as<uint8_t>() + 2 * b_k + b_v);
+    {
+        unsigned long long o = 0;
+        for (const DevRound &r : ds.dp.rounds) {
+            if (r.n_iv) {
+                hipLaunchKernelGGL(msnv_fin_cov_emit, grid_for(r.n_iv, 256), dim3(256), 0, st, r.cov_tid, r.cov_beg, r.cov_end, (unsigned long long)r.n_iv, o, ctg, tb, ivs, (uint32_t)S,
+                                   ntile + o, kidx, ebase + o, d.cov_iv, ekey, eval);
+                HIP_TRY(hipGetLastError());
+            }
+            o += r.n_iv;
+        }
     }
     if (n_ent) {
-        if (n_ent > 0xfffffff0ull) return fail(MSNV_EDOMAIN, "more than 2^32 (interval, tile) entries in one shard");
-        if (int rc = skey.alloc((n_ent + 1) * 8)) return rc;
-        if (int rc = sval.alloc((n_ent + 1) * 4)) return rc;
-        if (int rc = flag.alloc((n_ent + 1) * 4)) return rc;
-        if (int rc = rid.alloc((n_ent + 1) * 4)) return rc;
-        if (int rc = pr.sort64(ekey.as<unsigned long long>(), skey.as<unsigned long long>(), eval.as<uint32_t>(), sval.as<uint32_t>(), n_ent, 32u + std::max(1u, bit_width_u64(S)))) return rc;
-        hipLaunchKernelGGL(msnv_pair_flags, grid_for(n_ent, 256), dim3(256), 0, st, skey.as<unsigned long long>(), (uint32_t)n_ent, flag.as<uint32_t>());
+        if (int rc = pr.sort64(ekey, skey, eval, sval, n_ent, 32u + std::max(1u, bit_width_u64(S)))) return rc;
+        // runs of equal (sample, tile): flags and their scan in the unsorted arrays' memory (dead behind the sort)
+        uint32_t *flag = eval, *rid = reinterpret_cast<uint32_t *>(ekey);
+        hipLaunchKernelGGL(msnv_pair_flags, grid_for(n_ent, 256), dim3(256), 0, st, skey, n_ent, flag);
         HIP_TRY(hipGetLastError());
-        if (int rc = pr.scan32(flag.as<uint32_t>(), rid.as<uint32_t>(), n_ent, true)) return rc;
+        if (int rc = pr.scan32(flag, rid, n_ent, true)) return rc;
         uint32_t n_runs = 0;
-        HIP_TRY(hipMemcpyAsync(&n_runs, rid.as<uint32_t>() + (n_ent - 1), 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&n_runs, rid + (n_ent - 1), 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        DevBuf runs;
         if (int rc = runs.alloc((uint64_t)n_runs * sizeof(DevCovPair))) return rc;
-        hipLaunchKernelGGL(msnv_fin_cov_runs, grid_for(n_ent, 256), dim3(256), 0, st, skey.as<unsigned long long>(), sval.as<uint32_t>(), flag.as<uint32_t>(), rid.as<uint32_t>(), n_ent,
-                           runs.as<DevCovPair>());
+        hipLaunchKernelGGL(msnv_fin_cov_runs, grid_for(n_ent, 256), dim3(256), 0, st, skey, sval, flag, rid, (unsigned long long)n_ent, runs.as<DevCovPair>());
         HIP_TRY(hipGetLastError());
         cp.resize(n_runs);
         HIP_TRY(hipMemcpyAsync(cp.data(), runs.p, (size_t)n_runs * sizeof(DevCovPair), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
     }
     HIP_TRY(hipStreamSynchronize(st));
     return MSNV_OK;

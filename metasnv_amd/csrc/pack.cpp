@@ -6,6 +6,7 @@
 // (qaCompute.cpp:461-526), both reduced to two bits per read.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <climits>
 #include <cstdlib>
 #include <cstring>
@@ -788,6 +789,15 @@ int finalize_dataset(msnv_dataset &ds) {
     const size_t NC = ds.names.size();
     if (S == 0) return fail(MSNV_EINVAL, "dataset has no samples");
     if (S >= 16384) return fail(MSNV_EDOMAIN, "more than 16383 samples per dataset are not supported");
+    // MSNV_FINALIZE_TRACE=1: wall seconds of every stage to stderr (where a big dataset's finalize goes)
+    const bool trace = [] { const char *e = getenv("MSNV_FINALIZE_TRACE"); return e && e[0] == '1'; }();
+    auto t_lap = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[finalize] %-34s %8.3f s\n", what, std::chrono::duration<double>(now - t_lap).count());
+        t_lap = now;
+    };
     // Device-packed samples (devpack.hip) keep their piece headers and intervals in HBM.  When every sample is one, the per-piece and
     // per-interval loops below run there as kernels (`fast`; devfin_* in devpack.hip) and the host works on (sample, tile) pairs only.  The two
     // re-layouts that still run on host staging -- dense pieces, deep runs dealt into groups -- and mixed datasets take the host loops:
@@ -808,6 +818,7 @@ int finalize_dataset(msnv_dataset &ds) {
         if (any_dev && !fast) if (int rc = devpack_download_pieces(ds)) return rc;
     }
 
+    lap("decide / download");
     // ---- tile layout: every selected contig owns ceil(max(L, furthest read end) / TILE) tiles
     std::vector<int64_t> maxend(NC, 0);
     for (size_t c = 0; c < NC; ++c) maxend[c] = ds.sel[c] ? ds.lengths[c] : 0;
@@ -849,12 +860,17 @@ int finalize_dataset(msnv_dataset &ds) {
     ds.dev = d;
     d->n_tiles = ds.n_tiles; d->n_samples = (uint32_t)S;
 
+    lap("tile layout");
     // ---- reference: nt16 codes (N beyond the contig end, as mpileup prints) + lower-case bits
     std::vector<uint32_t> ref4(npos / 8 + 1, 0xffffffffu);
     {
         std::vector<uint32_t> lc(npos / 32 + 1, 0u);
-        for (size_t c = 0; c < NC; ++c) {
-            if (!ds.sel[c] || !ds.has_seq[c]) continue;
+        // (contigs start on tile boundaries: their words of both tables are disjoint, so the contigs are dealt to the host threads --
+        // a database shard is gigabases of FASTA)
+        std::vector<size_t> with_seq;
+        for (size_t c = 0; c < NC; ++c) if (ds.sel[c] && ds.has_seq[c]) with_seq.push_back(c);
+        parallel_for(with_seq.size(), [&](size_t k) {
+            const size_t c = with_seq[k];
             const std::string &s = ds.seqs[c];
             const uint64_t g0 = (uint64_t)ds.tile_base[c] * TILE;
             const uint64_t lim = std::min<uint64_t>(s.size(), (uint64_t)maxend[c]);
@@ -865,11 +881,12 @@ int finalize_dataset(msnv_dataset &ds) {
                 const char ch = s[i];
                 if (ch == 'a' || ch == 'c' || ch == 'g' || ch == 't') lc[g >> 5] |= 1u << (g & 31);
             }
-        }
+        });
         if (int rc = upload_vec(&d->ref4, ref4, &d->device_bytes)) return rc;
         if (int rc = upload_vec(&d->ref_lc, lc, &d->device_bytes)) return rc;
         ds.info.bytes_ref = npos / 2;
     }
+    lap("reference");
     // ---- callable range per tile (BED -l regions; without BED every covered position)
     std::vector<uint32_t> vb_host, ve_host;
     {
@@ -887,6 +904,7 @@ int finalize_dataset(msnv_dataset &ds) {
         vb_host = vb; ve_host = ve;
     }
 
+    lap("callable ranges");
     // ---- per sample: gpos, tile overlap index; concatenate columns
     const int device_id = ds.ctx ? ds.ctx->device : 0;
     if (!fast) {
@@ -965,6 +983,7 @@ int finalize_dataset(msnv_dataset &ds) {
             ds.first_tid = sc.first_tid; ds.first_pos = sc.first_beg;
         }
     }
+    lap("pairs per sample");
     // ---- CSR of pairs by tile (sample order inside a tile)
     std::vector<uint8_t> fuse_tile(nt, 0);                          // tiles piled up by ONE whole-tile work item (see below)
     std::vector<uint32_t> tps(nt + 1, 0);
@@ -1036,6 +1055,7 @@ int finalize_dataset(msnv_dataset &ds) {
     }
     std::vector<uint32_t> tpm(nt + 1, 0);                           // per tile: first merged pair
     for (uint64_t t = 0; t < nt; ++t) { uint32_t k = tps[t]; while (k < tps[t + 1] && pairs[k].pad != 2) ++k; tpm[t] = k; }
+    lap("pair CSR, merge / fuse classes");
     // ---- slots: the samples that have reads in a tile are numbered 0 .. n - 1 (the pairs of a split sample, consecutive, share
     // one); the per-sample cells of the tile's called positions are stored per slot (kernels.hip: CellMap) and the host expands
     // to all samples when it fetches.  From here on TilePair::pad = kind (0 narrow or wide, 1 split, 2 merged) | slot << 8.
@@ -1061,6 +1081,7 @@ int finalize_dataset(msnv_dataset &ds) {
         if (int rc = dev_alloc((void **)&d->tile_cell_base, (nt + 1) * sizeof(unsigned long long), &d->device_bytes)) return rc;
         if (int rc = dev_memset(d->tile_cell_base, 0, (nt + 1) * sizeof(unsigned long long))) return rc;
     }
+    lap("slots");
     // ---- work list: split each tile's pairs so that work items carry similar read counts
     std::vector<WorkItem> work;
     struct MergedGroup { uint32_t pair_lo, pair_hi, tile; };
@@ -1149,6 +1170,7 @@ int finalize_dataset(msnv_dataset &ds) {
         work.insert(work.end(), merged.begin(), merged.end());
         work.insert(work.end(), wide.begin(), wide.end());
     }
+    lap("work list");
     // ---- coverage partials: one row of TILE counters per work item, rows of a tile contiguous (the gate kernel sums them):
     // u8 rows first (narrow items whose pairs' depth bounds add up to < 256: most of them at ~10x), then u16 rows (the other
     // narrow items: <= 32 pairs x 254), then the u32 rows of wide items.  Bit 0 of part_lo marks a u8 row, bits 1-2 hold the tile's allele-total mode.
@@ -1241,6 +1263,7 @@ int finalize_dataset(msnv_dataset &ds) {
         for (uint32_t t : active) if (tot_mode(t) == 2u) d->wide_tot = true;
         d->use_dirty = !active.empty() && work.size() < 4 * active.size();       // a sparse cohort: fewer than four work items per tile
     }
+    lap("partial rows, gate tiles");
     // ---- chunk descriptors of the narrow work items
     std::vector<ChunkDesc> chunks;
     std::vector<std::vector<uint32_t>> hdr4_of(HDR4 && !dense && !fast ? S : 0);      // 4-byte piece headers, per sample (chunk-relative offsets: filled with the chunks)
@@ -1312,6 +1335,7 @@ int finalize_dataset(msnv_dataset &ds) {
         }
         w.chunk_hi = (uint32_t)chunks.size();
     }
+    lap("chunks + headers");
     // ---- merged groups: their piece headers, group by group, and chunks that run across the group's pairs
     {
         std::vector<PieceHdr> hm;
@@ -1369,6 +1393,7 @@ int finalize_dataset(msnv_dataset &ds) {
     if (!fast) if (int rc = upload_vec(&d->s_read_base, rbase, &d->device_bytes)) return rc;
     if (!fast) if (int rc = upload_vec(&d->s_seq_base, sbase, &d->device_bytes)) return rc;
 
+    lap("merged groups");
     // ---- columns
     d->n_reads = rbase[S]; d->n_seq_bytes = sbase[S]; d->n_blk = bbase[S];
     if (!fast) if (int rc = dev_alloc((void **)&d->hdr, (rbase[S] + 1) * sizeof(ReadHdr), &d->device_bytes)) return rc;
@@ -1447,6 +1472,7 @@ int finalize_dataset(msnv_dataset &ds) {
     }
     d->algorithmic_bytes = alg;                  // SURVEY.md section 8d figure; the shipped bytes are bytes_headers + bytes_seq + bytes_qual
 
+    lap("columns");
     // ---- genome coverage index: intervals of qaCompute's difference array, grouped by tile
     {
         std::vector<Pair32> iv;
@@ -1548,10 +1574,12 @@ int finalize_dataset(msnv_dataset &ds) {
 
     if (int rc = devpack_finish(ds)) return rc;                // (device-packed samples: the rounds' buffers and the pack tables go back)
 
+    lap("coverage index");
     // ---- intermediates
     if (int rc = dev_alloc((void **)&d->tot, std::max<uint64_t>(1, 4 * npos) * sizeof(uint32_t), &d->device_bytes)) return rc;
     if (int rc = dev_memset(d->tot, 0, std::max<uint64_t>(1, 4 * npos) * sizeof(uint32_t))) return rc;   // the gate kernel keeps it zero between passes
     if (int rc = dev_alloc((void **)&d->spill, std::max<uint64_t>(1, (uint64_t)pairs.size()) * TILE, &d->device_bytes)) return rc;
+    double est_events = 0.0;                                        // mismatching bases the sampled rate predicts: what the event list is sized by
     {
         // Allele bookkeeping of the narrow work items.  Clean reads (the benchmark's 0.1 % errors): a mismatching base is an EVENT -- one
         // memory-side atomic on the position's totals + 8 bytes in the event list, scattered into the called sites' cells afterwards.
@@ -1569,8 +1597,7 @@ int finalize_dataset(msnv_dataset &ds) {
         uint64_t sb = 0, sm = 0;
         for (const SampleCols &sc : ds.samples) { sb += sc.mm_sampled_bases; sm += sc.mm_sampled; }
         const double rate = sb ? (double)sm / (double)sb : 0.0;
-        const double est_events = rate * (double)tot_bases;
-        (void)est_events;
+        est_events = rate * (double)tot_bases;
         bool planes = rate >= 0.010;
         if (const char *e = getenv("MSNV_ALLELES")) planes = e[0] == 'p';
         if (dense || d->n_work > d->n_work_narrow + d->n_work_merged || pairs.empty()) planes = false;
@@ -1584,7 +1611,9 @@ int finalize_dataset(msnv_dataset &ds) {
         ds.info.sampled_mismatch_ppm = (uint64_t)(rate * 1e6);
     }
     // sparse buffers: generous first guess, grown on MSNV_ECAPACITY by the caller
-    d->cap_events = (uint32_t)std::min<uint64_t>(0x7fffffffull, std::max<uint64_t>(1u << 20, tot_bases / 16));
+    // (the event list: four times the mismatching bases the sample of every 16th piece predicts, at most one per 16 bases -- the flat
+    // "one per 16 bases" of the earlier rounds was 29 GB of HBM, and 1 s of hipMalloc, for BASELINE configs[2]'s 5.8e10 bases at 0.4 % of mismatches)
+    d->cap_events = (uint32_t)std::min<uint64_t>(0x7fffffffull, std::max<uint64_t>(1u << 20, std::min<uint64_t>(tot_bases / 16, (uint64_t)(4.0 * est_events) + (1u << 20))));
     if (const char *e = getenv("MSNV_CAP_EVENTS")) d->cap_events = (uint32_t)std::max<long long>(EV_LISTS, atoll(e));   // tests: force the grow-and-rerun path
     d->cap_overflow = (uint32_t)std::min<uint64_t>(0x7fffffffull, std::max<uint64_t>(1u << 16, npos / 8));
     d->cap_sites = (uint32_t)std::min<uint64_t>(0x7fffffffull, std::max<uint64_t>(1u << 16, npos / 4));
@@ -1616,6 +1645,7 @@ int finalize_dataset(msnv_dataset &ds) {
     ds.info.n_tiles = nt; ds.info.n_pairs = pairs.size(); ds.info.n_work = work.size();
     ds.info.bytes_index = pairs.size() * sizeof(TilePair) + work.size() * sizeof(WorkItem) + chunks.size() * sizeof(ChunkDesc) + (nt + 1) * 4;
     ds.info.device_bytes = d->device_bytes;
+    lap("intermediates");
     ds.finalized = true;
     return MSNV_OK;
 }
