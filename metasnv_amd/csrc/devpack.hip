@@ -60,6 +60,10 @@ struct DpAcc {
     uint32_t total, unmapped, zeroq, proper, dup, any_mapped;
     uint32_t n_pile_reads, n_ovl, need_host, pad;
 };
+// A sample's accumulators exist ACC_COPIES times (a workgroup adds to copy blockIdx % ACC_COPIES, msnv_acc_fold sums them into copy 0): a round
+// of a few big samples -- BASELINE configs[2]: eight per round -- otherwise sends every wavefront's atomics to the same eight cache lines
+// (the measure kernel ran 3.4 x slower per record there than on the benchmark's 160 samples a round).
+constexpr uint32_t ACC_COPIES = 64;
 enum : uint32_t { ERR_MALFORMED = 1, ERR_TID = 2, ERR_UNSORTED = 3, ERR_QLEN = 4 };
 enum : uint8_t { RF_PILE = 1, RF_COV = 2, RF_MAPPED = 4 };
 enum : uint32_t { NEED_CAP = 1, NEED_TOKEN = 2 };
@@ -126,6 +130,21 @@ __device__ __forceinline__ bool cg_query(uint32_t t) { return t == C_M || t == C
 __device__ __forceinline__ bool cg_match(uint32_t t) { return t == C_M || t == C_EQ || t == C_X; }
 // seq bytes of a piece of n bases with its alignment padding (pack.cpp: pack_sample)
 __device__ __host__ __forceinline__ uint32_t stored_bytes(uint32_t n) { return ((n + 1u) / 2u + SEQ_ALIGN - 1u) & ~(SEQ_ALIGN - 1u); }
+
+__global__ void msnv_acc_fold(DpAcc *acc, uint32_t n_samples) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_samples) return;
+    DpAcc &a = acc[(size_t)s * ACC_COPIES];
+    for (uint32_t c = 1; c < ACC_COPIES; ++c) {
+        DpAcc &b = acc[(size_t)s * ACC_COPIES + c];
+        a.err = a.err < b.err ? a.err : b.err; a.first_pile = a.first_pile < b.first_pile ? a.first_pile : b.first_pile; a.beyond = a.beyond < b.beyond ? a.beyond : b.beyond;
+        a.n_bases += b.n_bases; a.alg8d += b.alg8d; a.alg_cigar += b.alg_cigar; a.alg_seq += b.alg_seq; a.alg_qual += b.alg_qual; a.mm_bases += b.mm_bases; a.mm += b.mm;
+        a.total += b.total; a.unmapped += b.unmapped; a.zeroq += b.zeroq; a.proper += b.proper; a.dup += b.dup; a.any_mapped |= b.any_mapped;
+        a.n_pile_reads += b.n_pile_reads; a.n_ovl += b.n_ovl; a.need_host |= b.need_host;
+        DpAcc z{}; z.err = z.first_pile = z.beyond = ~0ull;
+        b = z;                                                   // (a copy that has been folded in counts nothing twice)
+    }
+}
 
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
@@ -362,7 +381,7 @@ __global__ __launch_bounds__(256) void msnv_measure_reads(const uint8_t *raw, co
         const unsigned long long u0 = wave_sum(m_pile), u1 = wave_sum(alg8d), u2 = wave_sum(alg_cigar), u3 = wave_sum(alg_seq), u4 = wave_sum(alg_qual);
         const unsigned long long e0 = wave_min(err), e1 = wave_min(first_pile), e2 = wave_min(beyond_at);
         if ((threadIdx.x & 63u) == 0) {
-            DpAcc &a = acc[s0];
+            DpAcc &a = acc[(size_t)s0 * ACC_COPIES + (blockIdx.x % ACC_COPIES)];
             if (t0) atomicAdd(&a.total, t0);
             if (t1) atomicAdd(&a.unmapped, t1);
             if (t2) atomicAdd(&a.zeroq, t2);
@@ -381,7 +400,7 @@ __global__ __launch_bounds__(256) void msnv_measure_reads(const uint8_t *raw, co
             if (e2 != ~0ull) atomicMin(&a.beyond, e2);
         }
     } else if (valid) {
-        DpAcc &a = acc[s];
+        DpAcc &a = acc[(size_t)s * ACC_COPIES + (blockIdx.x % ACC_COPIES)];
         atomicAdd(&a.total, st_total);
         if (st_unmapped) atomicAdd(&a.unmapped, 1u);
         if (st_zeroq) atomicAdd(&a.zeroq, 1u);
@@ -458,7 +477,7 @@ __global__ void msnv_depth(const uint32_t *pl, uint32_t n_pile, const uint32_t *
     uint32_t need = 0;
     if (P.max_depth > 0 && depth - 1u > (uint32_t)P.max_depth) need |= NEED_CAP;             // live.size() > max_depth before the push
     if (P.token_limit > 0 && chars >= (unsigned long long)P.token_limit) need |= NEED_TOKEN;
-    if (need) atomicOr(&acc[rec_sample[i]].need_host, need);
+    if (need) atomicOr(&acc[(size_t)rec_sample[i] * ACC_COPIES].need_host, need);
 }
 struct DpRun { uint32_t sample; int32_t tid, first_any, first_from1; };
 __global__ void msnv_run_table(const uint32_t *pl, uint32_t n_runs, const uint32_t *run_first, const uint32_t *run_f1, const unsigned long long *r_key,
@@ -539,96 +558,134 @@ __global__ __launch_bounds__(256) void msnv_emit_headers(const uint8_t *raw, con
 }
 
 // ------------------------------------------------------------------------------------------ bases and quality flags
-// 16 lanes per piece (SEG_MAX = 128 bases), 8 bases per lane: one 8-byte load of BAM nibbles, one of phred bytes; 4 bytes of the seq
-// column and 8 flags out.  Pieces start on 4 bases, so a lane's 8 flags start on bit 0 or 4 of a byte: whole bytes are stored, the two
-// nibbles a piece shares with its neighbours' bytes are OR-ed in atomically (the flag column is cleared first).
+// Pieces start on 4 bases, so a piece's flags start on bit 0 or 4 of a byte: whole bytes are stored, the two nibbles a piece shares with
+// its neighbours' bytes are OR-ed in atomically (the flag column is cleared first).
 struct DpSampleDst { uint8_t *seq, *qual; unsigned long long pbase0; uint32_t cut_marks, pad; };
 __device__ __forceinline__ void or_byte(uint8_t *p, uint32_t v) {
     const uintptr_t a = reinterpret_cast<uintptr_t>(p);
     atomicOr(reinterpret_cast<uint32_t *>(a & ~(uintptr_t)3), v << (8u * (uint32_t)(a & 3u)));
 }
+// FOUR lanes per piece, 32 bases per lane (round 4; the first form took 16 lanes of 8 bases: 6.4 ms on the benchmark shape against 2.x here):
+// three 8-byte loads of BAM nibbles, four of phred bytes; 16 bytes of the seq column and 32 flags out.
+__device__ __forceinline__ uint64_t nib_swap64(uint64_t b) { return ((b >> 4) & 0x0f0f0f0f0f0f0f0full) | ((b & 0x0f0f0f0f0f0f0f0full) << 4); }
+// bit t = byte t of q is a quality below c (1 <= c <= 127; bytes of 128 and more -- "not stored", clamped to 127 by the host stage -- are not)
+__device__ __forceinline__ uint32_t low_flags8(uint64_t q, uint32_t c) {
+    const uint64_t y = (q | 0x8080808080808080ull) - 0x0101010101010101ull * c;            // bit 7 of a byte: (q & 0x7f) >= c; no borrow between bytes
+    const uint64_t lt = ~(q | y) & 0x8080808080808080ull;
+    return (uint32_t)(((lt >> 7) * 0x0102040810204080ull) >> 56);
+}
+__device__ __forceinline__ void store_bytes(uint8_t *p, uint64_t v, uint32_t n) {          // the n low bytes of v (n <= 8), any address
+    if (n >= 8u) { __builtin_memcpy(p, &v, 8); return; }
+    if (n & 4u) { const uint32_t w = (uint32_t)v; __builtin_memcpy(p, &w, 4); p += 4; v >>= 32; }
+    if (n & 2u) { const uint16_t w = (uint16_t)v; __builtin_memcpy(p, &w, 2); p += 2; v >>= 16; }
+    if (n & 1u) *p = (uint8_t)v;
+}
 __global__ __launch_bounds__(256) void msnv_emit_pieces(const uint8_t *raw, const uint32_t *pref4, DpParams P, uint32_t n_pieces, const ReadHdr *hdr, const PieceSrc *psrc,
                                                         const DpSampleDst *dst, DpAcc *acc) {
     const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t pc = gt >> 4, sub = gt & 15u, j0 = 8u * sub;
+    const uint32_t pc = gt >> 2, sub = gt & 3u, j0 = 32u * sub;
     const bool piece = pc < n_pieces;
     ReadHdr h{}; PieceSrc ps{};
     if (piece) { h = hdr[pc]; ps = psrc[pc]; }
     const uint32_t n = h.cig, sb = piece ? stored_bytes(n) : 0u;
-    const bool active = j0 < 2u * sb;                                                       // this lane holds stored nibbles of the piece
-    const uint32_t have = n > j0 ? (n - j0 < 8u ? n - j0 : 8u) : 0u;                       // ... of which real bases
+    const uint32_t st = 2u * sb > j0 ? (2u * sb - j0 < 32u ? 2u * sb - j0 : 32u) : 0u;    // stored nibbles of this lane (a multiple of 4)
+    const uint32_t have = n > j0 ? (n - j0 < 32u ? n - j0 : 32u) : 0u;                     // ... of which real bases
     DpSampleDst d{};
     if (piece) d = dst[ps.sample];
-    // padding: base N, quality byte 0 (pack.cpp: pack_sample, pack_lowq)
-    uint32_t out = 0xffffffffu, bits = (P.c_eff > 0 || P.all_low) ? 0xffu : 0u, mm = 0;
+    const bool pad_low = P.c_eff > 0 || P.all_low;                                          // padding: base N, quality byte 0 (pack.cpp: pack_sample, pack_lowq)
+    uint64_t o0 = ~0ull, o1 = ~0ull;                                                        // the lane's 32 nibbles, low first
+    uint32_t bits = pad_low ? 0xffffffffu : 0u, mm = 0;
     bool sampled = false;
     if (have) {
         const bool noseq = ps.q0 == 0xffffffffu;
         const uint32_t q0 = noseq ? 0u : ps.q0 + j0;
-        // BAM packs base 2i in the HIGH nibble of byte i; the kernels want base j of the piece in nibble j, low first
-        const uint64_t b = noseq ? ~0ull : ld64(raw + ps.seq + (q0 >> 1));
-        const uint64_t qb = noseq ? 0ull : ld64(raw + ps.qual + q0);
-        const uint64_t sw = ((b >> 4) & 0x0f0f0f0f0f0f0f0full) | ((b & 0x0f0f0f0f0f0f0f0full) << 4);
-        out = (uint32_t)(sw >> (4u * (q0 & 1u)));
-        if (have < 8u) out |= 0xffffffffu << (4u * have);
+        if (!noseq) {
+            // BAM packs base 2i in the HIGH nibble of byte i; the kernels want base j of the piece in nibble j, low first
+            const uint8_t *sp = raw + ps.seq + (q0 >> 1);
+            const uint64_t s0 = nib_swap64(ld64(sp)), s1 = nib_swap64(ld64(sp + 8)), s2 = nib_swap64(ld64(sp + 16));
+            if (q0 & 1u) { o0 = s0 >> 4 | s1 << 60; o1 = s1 >> 4 | s2 << 60; } else { o0 = s0; o1 = s1; }
+        }
+        if (have < 16u) { o0 |= ~0ull << (4u * have); o1 = ~0ull; } else if (have < 32u) o1 |= ~0ull << (4u * (have - 16u));
         const bool has_fasta = ps.ref_nib != ~0ull;
         const uint32_t left = ps.ref_left > j0 ? ps.ref_left - j0 : 0u;                   // FASTA characters from the lane's first position
-        uint32_t rc = 0xffffffffu;                                                          // reference codes of the lane's positions (N where the FASTA has nothing)
-        const bool need_ref = ((out - 0x11111111u) & ~out & 0x88888888u) != 0u || (has_fasta && ((pc - (uint32_t)d.pbase0) & 15u) == 0u);
-        if (need_ref && left) {
-            const unsigned long long nb = ps.ref_nib + j0;
-            const uint64_t w = (uint64_t)pref4[nb >> 3] | (uint64_t)pref4[(nb >> 3) + 1] << 32;
-            rc = (uint32_t)(w >> (4u * (uint32_t)(nb & 7u)));
-            if (left < 8u) rc |= 0xffffffffu << (4u * left);
-        }
-        // '=' (code 0) always counts as a match (bam_plcmd.c pileup_seq [EXT]): ship the reference code, N when that is unknown or '=' itself
-        if ((out - 0x11111111u) & ~out & 0x88888888u) {
-            for (uint32_t t = 0; t < have; ++t) if (((out >> (4u * t)) & 0xfu) == 0u) {
-                uint32_t code = (rc >> (4u * t)) & 0xfu;
-                if (code == 0u) code = 15u;
-                out |= code << (4u * t);
+        const bool sample_this = has_fasta && ((pc - (uint32_t)d.pbase0) & 15u) == 0u;     // one piece in 16: how noisy are these reads?
+        const uint64_t z0 = (o0 - 0x1111111111111111ull) & ~o0 & 0x8888888888888888ull, z1 = (o1 - 0x1111111111111111ull) & ~o1 & 0x8888888888888888ull;
+        if ((z0 | z1) || sample_this) {
+            uint64_t r0 = ~0ull, r1 = ~0ull;                                                // reference codes of the lane's positions (N where the FASTA has nothing)
+            if (left) {
+                const unsigned long long nb = ps.ref_nib + j0;
+                const uint32_t *w = pref4 + (nb >> 3);
+                const uint64_t a = (uint64_t)w[0] | (uint64_t)w[1] << 32, b = (uint64_t)w[2] | (uint64_t)w[3] << 32, c = (uint64_t)w[4];
+                const uint32_t sh = 4u * (uint32_t)(nb & 7u);
+                r0 = sh ? (a >> sh | b << (64u - sh)) : a;
+                r1 = sh ? (b >> sh | c << (64u - sh)) : b;
+                if (left < 16u) { r0 |= ~0ull << (4u * left); r1 = ~0ull; } else if (left < 32u) r1 |= ~0ull << (4u * (left - 16u));
+            }
+            // '=' (code 0) always counts as a match (bam_plcmd.c pileup_seq [EXT]): ship the reference code, N when that is unknown or '=' itself
+            if (z0 | z1) {
+                for (uint32_t t = 0; t < have; ++t) {
+                    uint64_t &o = t < 16u ? o0 : o1; const uint64_t r = t < 16u ? r0 : r1; const uint32_t k = 4u * (t & 15u);
+                    if (((o >> k) & 0xfull) == 0ull) { uint64_t code = (r >> k) & 0xfull; if (code == 0ull) code = 15ull; o |= code << k; }
+                }
+            }
+            if (sample_this) {
+                sampled = true;
+                const uint32_t cmp = left < have ? left : have;
+                uint64_t x0 = o0 ^ r0, x1 = o1 ^ r1;
+                x0 = (x0 | x0 >> 1 | x0 >> 2 | x0 >> 3) & 0x1111111111111111ull; x1 = (x1 | x1 >> 1 | x1 >> 2 | x1 >> 3) & 0x1111111111111111ull;
+                if (cmp < 16u) { x0 &= (1ull << (4u * cmp)) - 1ull; x1 = 0ull; } else if (cmp < 32u) x1 &= (1ull << (4u * (cmp - 16u))) - 1ull;
+                mm = (uint32_t)(__builtin_popcountll(x0) + __builtin_popcountll(x1));
             }
         }
-        // one piece in 16: how noisy are these reads? (finalize picks the allele bookkeeping by it)
-        if (has_fasta && ((pc - (uint32_t)d.pbase0) & 15u) == 0u) {
-            sampled = true;
-            const uint32_t cmp = left < have ? left : have;
-            uint32_t x = out ^ rc;
-            x = (x | x >> 1 | x >> 2 | x >> 3) & 0x11111111u;
-            if (cmp < 8u) x &= (1u << (4u * cmp)) - 1u;
-            mm = (uint32_t)__builtin_popcount(x);
-        }
         uint32_t low = 0;
-        for (uint32_t t = 0; t < 8u; ++t) {
-            const uint32_t qv = (uint32_t)(qb >> (8u * t)) & 0xffu;
-            const bool f = P.all_low || (int)qv < P.c_eff || (d.cut_marks && qv == 0xfeu);   // 0xfe: behind snpCall's token limit (pack.cpp: QUAL_CUT)
-            low |= (f ? 1u : 0u) << t;
+        if (P.all_low) low = 0xffffffffu;
+        else if (!noseq && (P.c_eff > 0 || d.cut_marks)) {
+            const uint8_t *qp = raw + ps.qual + q0;
+            const uint64_t qa = ld64(qp), qb = ld64(qp + 8), qc = ld64(qp + 16), qd = ld64(qp + 24);
+            if (P.c_eff > 0) low = low_flags8(qa, (uint32_t)P.c_eff) | low_flags8(qb, (uint32_t)P.c_eff) << 8 | low_flags8(qc, (uint32_t)P.c_eff) << 16 | low_flags8(qd, (uint32_t)P.c_eff) << 24;
+            if (d.cut_marks) {                                                              // 0xfe: behind snpCall's token limit (pack.cpp: QUAL_CUT), below every cutoff
+                const uint64_t q4[4] = {qa, qb, qc, qd};
+                for (uint32_t t = 0; t < 32u; ++t) if (((q4[t >> 3] >> (8u * (t & 7u))) & 0xffull) == 0xfeull) low |= 1u << t;
+            }
         }
-        bits = have < 8u ? ((bits & (0xffu << have)) | (low & ((1u << have) - 1u))) : low;
+        // (no SEQ: quality 0 -- shipped only when the cutoff is 0, where it is not below it)
+        bits = have < 32u ? ((bits & (0xffffffffu << have)) | (low & ((1u << have) - 1u))) : low;
     }
-    const uint32_t prev = __shfl_up(bits, 1);                                               // lane sub - 1 of the same piece (sub > 0)
-    if (active) {
-        // ---- seq column: 4 bytes (2 when the stored piece ends half way)
-        const bool half = 4u * sub + 4u > sb;                                               // this lane holds 4 stored nibbles only
-        uint8_t *sp = d.seq + h.seqoff + 4u * sub;
-        if (!half) __builtin_memcpy(sp, &out, 4);
-        else { const uint16_t o16 = (uint16_t)out; __builtin_memcpy(sp, &o16, 2); }
-        // ---- flag column: bit index = nibble index of the seq column
+    const uint32_t prev_last = __shfl_up(bits >> 28, 1);                                    // the last four flags of lane sub - 1 of the same piece (sub > 0, that lane is full)
+    if (st) {
+        // ---- seq column: st / 2 bytes
+        uint8_t *sp = d.seq + h.seqoff + 16u * sub;
+        const uint32_t nb = st >> 1;
+        store_bytes(sp, o0, nb < 8u ? nb : 8u);
+        if (nb > 8u) store_bytes(sp + 8, o1, nb - 8u);
+        // ---- flag column: bit index = nibble index of the seq column; the piece starts on bit 0 or 4 of a byte
         const unsigned long long b0 = 2ull * h.seqoff + j0;
         uint8_t *qp = d.qual + (b0 >> 3);
-        const uint32_t last = (2u * sb - 1u) >> 3;                                          // last lane of the piece
+        const bool last_lane = sub == ((2u * sb - 1u) >> 5);
+        const uint32_t v = st < 32u ? bits & ((1u << st) - 1u) : bits;
         if (!(b0 & 4ull)) {
-            if (!half) *qp = (uint8_t)bits;
-            else or_byte(qp, bits & 0xfu);                                                  // the high nibble is the next piece's
+            const uint32_t full = st >> 3;                                                  // whole bytes of mine
+            store_bytes(qp, v, full);
+            if (st & 4u) or_byte(qp + full, (v >> (8u * full)) & 0xfu);                     // a trailing nibble: the byte's other half is the next piece's (only the last lane ends on one)
+        } else if (sub == 0) {
+            or_byte(qp, (v & 0xfu) << 4);                                                   // the low nibble of the first byte is the previous piece's
+            const uint32_t rest = st - 4u, full = rest >> 3;
+            store_bytes(qp + 1, v >> 4, full);
+            if ((rest & 4u) && last_lane) or_byte(qp + 1 + full, (v >> (4u + 8u * full)) & 0xfu);      // (else lane 1 writes that byte with my nibble in it)
         } else {
-            if (sub == 0) or_byte(qp, (bits & 0xfu) << 4);                                  // the low nibble is the previous piece's
-            else *qp = (uint8_t)((bits & 0xfu) << 4 | (prev >> 4 & 0xfu));
-            if (sub == last && !half) or_byte(qp + 1, bits >> 4 & 0xfu);
+            const uint64_t w = (uint64_t)v << 4 | (prev_last & 0xfu);                       // the byte I start in, whole: the lane before me left its last nibble there
+            const uint32_t total = st + 4u, full = total >> 3;
+            store_bytes(qp, w, full);
+            if ((total & 4u) && last_lane) or_byte(qp + full, (uint32_t)(w >> (8u * full)) & 0xfu);
         }
     }
-    // mismatch sample: sum over the 16 lanes of a piece, one atomic per sampled piece
-    for (int o = 8; o > 0; o >>= 1) mm += __shfl_down(mm, o, 16);
-    if (sub == 0 && sampled) { atomicAdd(&acc[ps.sample].mm_bases, (unsigned long long)n); if (mm) atomicAdd(&acc[ps.sample].mm, (unsigned long long)mm); }
+    // mismatch sample: sum over the 4 lanes of a piece, one atomic per sampled piece
+    mm += __shfl_down(mm, 2, 4); mm += __shfl_down(mm, 1, 4);
+    if (sub == 0 && sampled) {
+        DpAcc &a = acc[(size_t)ps.sample * ACC_COPIES + (blockIdx.x % ACC_COPIES)];
+        atomicAdd(&a.mm_bases, (unsigned long long)n);
+        if (mm) atomicAdd(&a.mm, (unsigned long long)mm);
+    }
 }
 
 // per sample: where its records' pieces / seq bytes / intervals start, and the first pileup read (one small copy instead of three per sample)
@@ -641,7 +698,7 @@ __global__ void msnv_sample_bases(const uint32_t *rec_base, uint32_t n_samples, 
     const uint32_t i = rec_base[s];
     o.sbase0 = sbase[i]; o.pbase0 = pbase[i]; o.ibase0 = ibase[i];
     if (s < n_samples) {
-        const DpAcc a = acc[s];
+        const DpAcc a = acc[(size_t)s * ACC_COPIES];              // (folded: msnv_acc_fold)
         if (a.first_pile != ~0ull) { o.first_key = r_key[a.first_pile]; o.first_end = r_end[a.first_pile]; }
         if (a.beyond != ~0ull) o.beyond_key = r_key[a.beyond];
     }
@@ -761,7 +818,7 @@ int build_tables(msnv_dataset &ds) {
         d.bed_beg = ds.bed_beg[c]; d.bed_end = ds.bed_end[c]; d.sel = ds.sel[c]; d.pad = 0; d.pref_off = nib;
         if (ds.sel[c] && ds.has_seq[c]) nib += (ds.seqs[c].size() + 7) & ~(size_t)7;
     }
-    t.pref_words = nib / 8 + 2;
+    t.pref_words = nib / 8 + 8;                                  // (msnv_emit_pieces reads five words from a lane's first position)
     if (int rc = dev_alloc(&t.contigs, std::max<size_t>(1, NC) * sizeof(DpContig), nullptr)) return rc;
     if (int rc = dev_upload(t.contigs, ct.data(), NC * sizeof(DpContig))) return rc;
     if (int rc = dev_alloc((void **)&t.overhang, (std::max<size_t>(1, NC) + 1) * sizeof(int32_t), nullptr)) return rc;
@@ -791,7 +848,7 @@ int build_tables(msnv_dataset &ds) {
             if (stage.size() >= chunk_words) if (int rc = flush()) return rc;
         }
     }
-    stage.push_back(0xffffffffu); stage.push_back(0xffffffffu);
+    for (int k = 0; k < 8; ++k) stage.push_back(0xffffffffu);
     if (int rc = flush()) return rc;
     t.ready = true;
     return MSNV_OK;
@@ -996,7 +1053,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     DP_BUF(uint16_t, d_depth, NRa);
     DP_BUF(uint32_t, d_rank, NRa);
     DP_BUF(uint32_t, d_ovr, NRa);
-    DP_BUF(DpAcc, d_acc, S);
+    DP_BUF(DpAcc, d_acc, S * ACC_COPIES);
     DP_BUF(uint8_t, d_tmp, 1u << 20);                             // rocPRIM's temporary storage (grown below when a call asks for more)
     size_t tmp_cap = (size_t)T.scratch[next_buf - 1].second;
     const size_t tmp_slot = next_buf - 1;
@@ -1042,8 +1099,12 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     const size_t depth_bufs_from = next_buf;
     for (int pass = 0; pass < 2; ++pass) {
         next_buf = depth_bufs_from;
-        for (size_t s = 0; s < S; ++s) { DpAcc a{}; a.err = a.first_pile = a.beyond = ~0ull; acc[s] = a; }
-        HIP_TRY(hipMemcpyAsync(d_acc, acc.data(), S * sizeof(DpAcc), hipMemcpyHostToDevice, st));
+        {
+            DpAcc a{}; a.err = a.first_pile = a.beyond = ~0ull;
+            std::vector<DpAcc> init(S * ACC_COPIES, a);
+            HIP_TRY(hipMemcpyAsync(d_acc, init.data(), init.size() * sizeof(DpAcc), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        }
         HIP_TRY(hipMemsetAsync(d_depth, 0, NRa * 2, st));
         HIP_TRY(hipMemsetAsync(d_pile + NR, 0, 4, st));
         tm.start();
@@ -1095,7 +1156,9 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
             HIP_TRY(hipMemcpyAsync(runs.data(), d_runs, (size_t)n_runs * sizeof(DpRun), hipMemcpyDeviceToHost, st));
             T.ms_depth += tm.stop();
         } else runs.clear();
-        HIP_TRY(hipMemcpyAsync(acc.data(), d_acc, S * sizeof(DpAcc), hipMemcpyDeviceToHost, st));
+        hipLaunchKernelGGL(msnv_acc_fold, grid_for(S, 64), dim3(64), 0, st, d_acc, (uint32_t)S);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy2DAsync(acc.data(), sizeof(DpAcc), d_acc, sizeof(DpAcc) * ACC_COPIES, sizeof(DpAcc), S, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         // ---- errors, in record order (what the host stage's sequential walk would have met first)
         for (size_t s = 0; s < S; ++s) {
@@ -1206,12 +1269,13 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
         HIP_TRY(hipGetLastError());
     }
     if (NPC) {
-        hipLaunchKernelGGL(msnv_emit_pieces, grid_for((uint64_t)NPC * 16, 256), dim3(256), 0, st, raw, T.pref4, P, NPC, d_hdr, d_psrc, d_dst, d_acc);
+        hipLaunchKernelGGL(msnv_emit_pieces, grid_for((uint64_t)NPC * 4, 256), dim3(256), 0, st, raw, T.pref4, P, NPC, d_hdr, d_psrc, d_dst, d_acc);
         HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(msnv_emit_tail, dim3((unsigned)S), dim3(64), 0, st, d_dst, d_pb, (uint32_t)S, P);
+    hipLaunchKernelGGL(msnv_acc_fold, grid_for(S, 64), dim3(64), 0, st, d_acc, (uint32_t)S);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(acc.data(), d_acc, S * sizeof(DpAcc), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpy2DAsync(acc.data(), sizeof(DpAcc), d_acc, sizeof(DpAcc) * ACC_COPIES, sizeof(DpAcc), S, hipMemcpyDeviceToHost, st));
     T.ms_emit += tm.stop();
 
     // ---- headers in tile order (stable: read order inside a tile), and the (sample, contig, tile) runs of pieces = the pairs of the tile index
