@@ -65,8 +65,8 @@ struct DpAcc {
 // (the measure kernel ran 3.4 x slower per record there than on the benchmark's 160 samples a round).
 constexpr uint32_t ACC_COPIES = 64;
 enum : uint32_t { ERR_MALFORMED = 1, ERR_TID = 2, ERR_UNSORTED = 3, ERR_QLEN = 4 };
-enum : uint8_t { RF_PILE = 1, RF_COV = 2, RF_MAPPED = 4 };
-enum : uint32_t { NEED_CAP = 1, NEED_TOKEN = 2 };
+enum : uint8_t { RF_PILE = 1, RF_COV = 2, RF_MAPPED = 4, RF_OVL = 8 };      // RF_OVL: passes sam.c overlap_push's precondition (a mate may overlap it)
+enum : uint32_t { NEED_CAP = 1, NEED_TOKEN = 2, NEED_OVL = 4 };      // NEED_OVL: too many alignments of one template wait at once for the device's slots
 
 __device__ __forceinline__ uint32_t ld32(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 __device__ __forceinline__ uint64_t ld64(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void msnv_measure_reads(const uint8_t *raw, co
                     if (ov & 1u) pile_ok = (ov >> 1) & 1u;                                   // the host pre-pass has decided (depth cap)
                     const long long absl = r.tlen < 0 ? -(long long)r.tlen : (long long)r.tlen;
                     if (pile_ok && !P.ignore_overlaps && !(r.flag & 8u) && (r.flag & 2u) &&   // sam.c overlap_push's precondition
-                        !((r.mtid >= 0 && r.tid != r.mtid) || (absl >= 2ll * r.l_seq && (long long)r.mpos >= endpos))) n_ovl = 1;
+                        !((r.mtid >= 0 && r.tid != r.mtid) || (absl >= 2ll * r.l_seq && (long long)r.mpos >= endpos))) { n_ovl = 1; flags |= RF_OVL; }
                     const unsigned long long mc = 4ull + 11ull + (unsigned long long)(ins > del ? ins : del);      // pack.cpp: max_element_chars
                     o_maxc = (uint32_t)(mc < 0x7fffffffull ? mc : 0x7fffffffull);
                     o_end = (uint32_t)(endpos < 0xffffffffll ? endpos : 0xffffffffll);
@@ -491,6 +491,107 @@ __global__ void msnv_run_table(const uint32_t *pl, uint32_t n_runs, const uint32
     if (f == 0xffffffffu) o.first_from1 = -1;
     else { const int32_t p = (int32_t)(uint32_t)r_key[pl[f]]; o.first_from1 = p > 1 ? p : 1; }
     runs[g] = o;
+}
+
+// ------------------------------------------------------------------------------------------ overlapping mates
+// `samtools mpileup` without -x lets htslib's pileup engine edit the qualities of proper-pair mates that overlap on the reference before
+// the -Q cutoff sees them (sam.c overlap_push / tweak_overlap_quality [EXT]; pack.cpp: filter_and_edit restates the engine, read after read,
+// with a hash of waiting mates by read name).  The entries of different names never interact, so the walk is independent per NAME: the
+// candidates of a round are sorted by (sample, hash of the name) -- stable, so file order survives inside a group -- and one thread runs
+// the engine's state machine over each group: a read finds the waiting mate of its name (alive: same contig, end beyond this start), the
+// pair is edited in place in the round buffer and the entry leaves; else the read waits if its mate is still to come.  Groups are two
+// reads almost always; names are compared byte for byte inside a group (hash collisions make a group bigger, never wrong).
+constexpr int OVL_SLOTS = 8;
+__global__ void msnv_ovl_list(const uint8_t *r_flags, const uint32_t *orank, uint32_t n_rec, const uint8_t *raw, const unsigned long long *rec_off, const uint16_t *rec_sample,
+                              const uint8_t *skip_sample, unsigned long long *keys, uint32_t *vals) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rec || !(r_flags[i] & RF_OVL) || skip_sample[rec_sample[i]]) return;
+    const uint8_t *p = raw + rec_off[i];
+    const uint32_t l_name = p[12];
+    unsigned long long h = 1469598103934665603ull;                // FNV-1a over the name
+    for (uint32_t k = 0; k < l_name; ++k) { h ^= p[36 + k]; h *= 1099511628211ull; }
+    const uint32_t w = orank[i];
+    keys[w] = (unsigned long long)rec_sample[i] << 53 | (h >> 11);
+    vals[w] = i;
+}
+__global__ void msnv_ovl_mark(const uint8_t *r_flags, uint32_t n_rec, const uint16_t *rec_sample, const uint8_t *skip_sample, uint32_t *flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n_rec) return;
+    flag[i] = (i < n_rec && (r_flags[i] & RF_OVL) && !skip_sample[rec_sample[i]]) ? 1u : 0u;
+}
+__global__ void msnv_ovl_group_starts(const uint32_t *flag, const uint32_t *gid_incl, uint32_t n, uint32_t *starts) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && flag[i]) starts[gid_incl[i] - 1u] = i;
+}
+// groups of more than OVL_SLOTS members could overflow the waiting slots: their samples take the host pre-pass (decided BEFORE anything is edited)
+__global__ void msnv_ovl_check(const uint32_t *starts, uint32_t n_groups, uint32_t n, const uint32_t *svals, const uint16_t *rec_sample, DpAcc *acc) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups) return;
+    const uint32_t lo = starts[g], hi = g + 1 < n_groups ? starts[g + 1] : n;
+    if (hi - lo > (uint32_t)OVL_SLOTS) atomicOr(&acc[(size_t)rec_sample[svals[lo]] * ACC_COPIES].need_host, NEED_OVL);
+}
+struct MatchCur {                                               // the M/=/X bases of one alignment in reference order (pack.cpp: MatchCursor)
+    const uint8_t *cigar; uint32_t n_cigar, k; long long op_ref, op_q, ref, q;
+    __device__ bool seek(const long long target) {
+        for (; k < n_cigar; ++k) {
+            const uint32_t c = ld32(cigar + 4ull * k), t = c & 15u; const long long l = c >> 4;
+            if (cg_match(t)) {
+                if (target < op_ref + l) { ref = target > op_ref ? target : op_ref; q = op_q + (ref - op_ref); return true; }
+                op_ref += l; op_q += l;
+            } else {
+                if (t == C_D || t == C_N) op_ref += l;
+                if (t == C_I || t == C_S) op_q += l;
+            }
+        }
+        return false;
+    }
+};
+__device__ void tweak_pair(uint8_t *pa, const Rec &a, uint8_t *pb, const Rec &b) {          // pack.cpp: tweak_overlapping_mates (qualities edited in the round buffer)
+    if (a.l_seq == 0 || b.l_seq == 0) return;
+    MatchCur ca{a.cigar, a.n_cigar, 0u, a.pos, 0, -1, -1}, cb{b.cigar, b.n_cigar, 0u, b.pos, 0, -1, -1};
+    uint8_t *qa = pa + (a.qual - (const uint8_t *)pa), *qb = pb + (b.qual - (const uint8_t *)pb);
+    long long t = b.pos;
+    while (ca.seek(t) && cb.seek(ca.ref)) {
+        t = cb.ref + 1;
+        if (ca.ref != cb.ref) continue;
+        if (ca.q >= a.l_seq || cb.q >= b.l_seq) return;
+        const uint32_t ba = (a.seq[ca.q >> 1] >> ((~ca.q & 1) << 2)) & 0xfu, bb = (b.seq[cb.q >> 1] >> ((~cb.q & 1) << 2)) & 0xfu;
+        const uint32_t x = qa[ca.q], y = qb[cb.q];
+        if (ba == bb) { const uint32_t sum = x + y; qa[ca.q] = (uint8_t)(sum > 200u ? 200u : sum); qb[cb.q] = 0; }
+        else if (x >= y) { qa[ca.q] = (uint8_t)(0.8 * (double)x); qb[cb.q] = 0; }
+        else { qb[cb.q] = (uint8_t)(0.8 * (double)y); qa[ca.q] = 0; }
+    }
+}
+__global__ void msnv_ovl_groups(const uint32_t *starts, uint32_t n_groups, uint32_t n, const uint32_t *svals, uint8_t *raw, const unsigned long long *rec_off,
+                                const uint32_t *r_end, const uint16_t *rec_sample, const uint8_t *skip_sample) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups) return;
+    const uint32_t lo = starts[g], hi = g + 1 < n_groups ? starts[g + 1] : n;
+    if (hi - lo < 2u || hi - lo > (uint32_t)OVL_SLOTS) return;    // a lone read waits for nobody who comes; oversized groups went to the host
+    if (skip_sample[rec_sample[svals[lo]]]) return;               // this sample's edits ran in the host pre-pass
+    uint32_t wait[OVL_SLOTS]; int n_wait = 0;
+    for (uint32_t m = lo; m < hi; ++m) {
+        const uint32_t i = svals[m];
+        uint8_t *p = raw + rec_off[i];
+        const Rec r = rec_load(p, ~0ull);
+        int found = -1;
+        for (int w = 0; w < n_wait && found < 0; ++w) {            // the waiting mate of this NAME
+            const uint8_t *q = raw + rec_off[wait[w]];
+            if (q[12] != r.l_name) continue;
+            bool same = true;
+            for (uint32_t k = 0; k < r.l_name && same; ++k) same = q[36 + k] == p[36 + k];
+            if (same) found = w;
+        }
+        if (found >= 0) {
+            const uint32_t j = wait[found];
+            uint8_t *q = raw + rec_off[j];
+            const Rec a = rec_load(q, ~0ull);
+            for (int w = found; w + 1 < n_wait; ++w) wait[w] = wait[w + 1];        // the entry leaves either way (stale: erased; alive: edited and erased)
+            --n_wait;
+            if (a.tid == r.tid && (long long)r_end[j] > (long long)r.pos) { tweak_pair(q, a, p, r); continue; }
+        }
+        if (r.mpos >= r.pos || ((r.flag & 1u) && r.mpos == -1)) { if (n_wait < OVL_SLOTS) wait[n_wait++] = i; }
+    }
 }
 
 // ------------------------------------------------------------------------------------------ headers and intervals
@@ -1009,6 +1110,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
             next_buf -= 2;                                        // (the two lists are reused by the next repair round)
         }
     }
+    T.ms_scan += tm.stop();                                       // (the lists below are allocated outside the timed region)
     std::vector<uint32_t> rec_base(S + 1, 0);
     std::vector<CompactSeg> csegs;
     {
@@ -1032,6 +1134,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     DP_BUF(unsigned long long, d_recoff, NRa);
     DP_BUF(uint16_t, d_recsample, NRa);
     DP_BUF(CompactSeg, d_csegs, csegs.size() + 1);
+    tm.start();
     HIP_TRY(hipMemcpyAsync(d_recbase, rec_base.data(), (S + 1) * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_send, s_end.data(), S * 8, hipMemcpyHostToDevice, st));
     if (!csegs.empty()) {
@@ -1096,6 +1199,9 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     std::vector<DpRun> runs;
     uint32_t NP = 0, n_runs = 0;
     bool have_ovr = false;
+    DevBuf o_flag, o_rank, o_skip, o_keys, o_skeys, o_vals, o_svals, o_starts;      // overlapping mates (paired reads only: not from the pool)
+    uint32_t n_ovl_reads = 0, n_ovl_groups = 0;
+    std::vector<uint8_t> host_sample(S, 0);                       // samples whose sequential edits ran on the host (pre-pass)
     const size_t depth_bufs_from = next_buf;
     for (int pass = 0; pass < 2; ++pass) {
         next_buf = depth_bufs_from;
@@ -1170,9 +1276,53 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
             if (bad_off[s] != ~0ull) return fail(MSNV_EFORMAT, "malformed BAM record at byte %llu", bad_off[s]);
         }
         if (pass == 1) break;
+        // ---- overlapping mates: the candidates grouped by (sample, name); nothing is edited yet (MSNV_OVERLAP=host: the host pre-pass does it)
+        const bool ovl_on_host = [] { const char *e = getenv("MSNV_OVERLAP"); return e && e[0] == 'h'; }();
+        bool any_ovl = false;
+        for (size_t s = 0; s < S; ++s) any_ovl |= !MP.ignore_overlaps && acc[s].n_ovl >= 2;
+        if (any_ovl && !ovl_on_host) {
+            tm.start();
+            if (int rc = o_flag.alloc(NRa * 4)) return rc;
+            if (int rc = o_rank.alloc(NRa * 4)) return rc;
+            if (int rc = o_skip.alloc(S)) return rc;
+            HIP_TRY(hipMemsetAsync(o_skip.p, 0, S, st));
+            hipLaunchKernelGGL(msnv_ovl_mark, grid_for(NRa, 256), dim3(256), 0, st, d_flags, NR, d_recsample, o_skip.as<uint8_t>(), o_flag.as<uint32_t>());
+            HIP_TRY(hipGetLastError());
+            if (int rc = scan32(o_flag.as<uint32_t>(), o_rank.as<uint32_t>(), NRa, false)) return rc;
+            HIP_TRY(hipMemcpyAsync(&n_ovl_reads, o_rank.as<uint32_t>() + NR, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (n_ovl_reads >= 2) {
+                const uint64_t NOa = (uint64_t)n_ovl_reads + 1;
+                if (int rc = o_keys.alloc(NOa * 8)) return rc;
+                if (int rc = o_skeys.alloc(NOa * 8)) return rc;
+                if (int rc = o_vals.alloc(NOa * 4)) return rc;
+                if (int rc = o_svals.alloc(NOa * 4)) return rc;
+                hipLaunchKernelGGL(msnv_ovl_list, grid_for(NR, 256), dim3(256), 0, st, d_flags, o_rank.as<uint32_t>(), NR, raw, d_recoff, d_recsample, o_skip.as<uint8_t>(),
+                                   o_keys.as<unsigned long long>(), o_vals.as<uint32_t>());
+                HIP_TRY(hipGetLastError());
+                if (int rc = sort64(o_keys.as<unsigned long long>(), o_skeys.as<unsigned long long>(), o_vals.as<uint32_t>(), o_svals.as<uint32_t>(), n_ovl_reads, 64u)) return rc;
+                // groups of equal keys: flags and their scan in the unsorted arrays' memory
+                uint32_t *gflag = o_vals.as<uint32_t>(), *gid = reinterpret_cast<uint32_t *>(o_keys.p);
+                hipLaunchKernelGGL(msnv_pair_flags, grid_for(n_ovl_reads, 256), dim3(256), 0, st, o_skeys.as<unsigned long long>(), n_ovl_reads, gflag);
+                HIP_TRY(hipGetLastError());
+                if (int rc = scan32(gflag, gid, n_ovl_reads, true)) return rc;
+                HIP_TRY(hipMemcpyAsync(&n_ovl_groups, gid + (n_ovl_reads - 1), 4, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                if (int rc = o_starts.alloc(((uint64_t)n_ovl_groups + 1) * 4)) return rc;
+                hipLaunchKernelGGL(msnv_ovl_group_starts, grid_for(n_ovl_reads, 256), dim3(256), 0, st, gflag, gid, n_ovl_reads, o_starts.as<uint32_t>());
+                hipLaunchKernelGGL(msnv_ovl_check, grid_for(n_ovl_groups, 256), dim3(256), 0, st, o_starts.as<uint32_t>(), n_ovl_groups, n_ovl_reads, o_svals.as<uint32_t>(), d_recsample, d_acc);
+                HIP_TRY(hipGetLastError());
+                std::vector<DpAcc> again(S);
+                HIP_TRY(hipMemcpy2DAsync(again.data(), sizeof(DpAcc), d_acc, sizeof(DpAcc) * ACC_COPIES, sizeof(DpAcc), S, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                for (size_t s = 0; s < S; ++s) acc[s].need_host = again[s].need_host;
+            }
+            T.ms_depth += tm.stop();
+        }
         // ---- which samples need the sequential edits of the host stage?
         std::vector<size_t> need;
-        for (size_t s = 0; s < S; ++s) if (acc[s].need_host || (!MP.ignore_overlaps && acc[s].n_ovl >= 2)) need.push_back(s);
+        for (size_t s = 0; s < S; ++s) if (acc[s].need_host || (ovl_on_host && !MP.ignore_overlaps && acc[s].n_ovl >= 2)) need.push_back(s);
+        for (size_t s : need) host_sample[s] = 1;
         if (need.empty()) break;
         const double t0 = now_s();
         T.n_prepass_samples += need.size();
@@ -1212,6 +1362,15 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
         T.wall_prepass_s += now_s() - t0;
     }
 
+    // ---- overlapping mates: the qualities of the pairs are edited where they lie (samples that took the host pre-pass had theirs edited there)
+    if (n_ovl_groups) {
+        tm.start();
+        HIP_TRY(hipMemcpyAsync(o_skip.p, host_sample.data(), S, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(msnv_ovl_groups, grid_for(n_ovl_groups, 64), dim3(64), 0, st, o_starts.as<uint32_t>(), n_ovl_groups, n_ovl_reads, o_svals.as<uint32_t>(), raw, d_recoff, d_end,
+                           d_recsample, o_skip.as<uint8_t>());
+        HIP_TRY(hipGetLastError());
+        T.ms_depth += tm.stop();
+    }
     // ---- layout: where every record's pieces, seq bytes and intervals go
     next_buf = depth_bufs_from;                                   // (the depth stage's lists are done with: their buffers serve the pieces)
     DP_BUF(uint32_t, d_pbase, NRa);

@@ -185,10 +185,26 @@ def test_edge_case_records_same_columns():
     _same_dataset(names, lengths, seqs, samples, params=core.default_params(min_coverage=1, calling_threshold=1))
 
 
-def test_paired_reads_take_the_host_prepass_and_agree():
-    syn, samples = synth_case(n_species=2, contig_len=6000, n_samples=6, mean_cov=14.0, snv_density=0.02, frac_paired=0.6, seed=24)
-    core.host_timers(reset=True)
+def test_overlapping_mates_are_edited_on_the_device():
+    """Proper pairs whose mates overlap: htslib's quality tweak (sam.c tweak_overlap_quality [EXT]) runs as a kernel over the candidates grouped
+    by read name (devpack.hip: msnv_ovl_groups) -- no sample takes the host pre-pass -- and the columns equal the host stage's, which walks
+    the reads one by one with a hash of waiting mates (pack.cpp); MSNV_OVERLAP=host sends them through that walk instead."""
+    syn, samples = synth_case(n_species=2, contig_len=6000, n_samples=6, mean_cov=14.0, snv_density=0.02, frac_paired=0.6, frac_indel_reads=0.2, frac_clip_reads=0.1, seed=24)
     _same_dataset(syn.names, syn.lengths, syn.seqs, samples)
+    ctx = core.Context(0)
+    try:
+        for where, want in (("device", 0), ("host", len([s for s in samples if len(s)]))):
+            with _env(MSNV_PACK="device", MSNV_OVERLAP=where):
+                ds = core.Dataset(ctx, syn.names, syn.lengths, syn.seqs)
+                ds.add_samples_records(samples)
+                assert ds.pack_stats()["prepass_samples"] == want, where
+                ds.close()
+    finally:
+        ctx.close()
+    with _env(MSNV_OVERLAP="host"):
+        _same_dataset(syn.names, syn.lengths, syn.seqs, samples, check_oracle=False)
+    # a depth cap in reach sends the sample through the host pre-pass whatever its pairs do
+    _same_dataset(syn.names, syn.lengths, syn.seqs, samples, params=core.default_params(max_depth=9))
 
 
 def test_errors_carry_the_host_stage_codes():
