@@ -92,7 +92,7 @@ struct SiteRec { uint32_t gpos, cov, n[4]; };                          // gate k
 // one DevPair per (sample, contig, tile) run of pieces.
 struct DevRound { void *buf = nullptr; ReadHdr *hdr = nullptr; int32_t *tid = nullptr, *end = nullptr; uint16_t *depth = nullptr;
                   int32_t *cov_tid = nullptr, *cov_beg = nullptr, *cov_end = nullptr; uint64_t n_pieces = 0, n_iv = 0; size_t first_sample = 0; };
-struct DevPair { int32_t tid; uint32_t tile, lo, hi, maxd; };      // tile: inside the contig; [lo, hi): pieces of the sample; maxd: bound of the per-position depth
+struct DevPair { int32_t tid; uint32_t tile, lo, hi, maxd, grp; };      // tile: inside the contig; [lo, hi): pieces of the sample; maxd: bound of the per-position depth; grp: 0, or 1 + group of a deep run dealt into groups
 
 // host staging of one sample
 struct SampleCols {
@@ -139,7 +139,7 @@ struct DevPackTables {
     bool      ready = false;
     // cumulative device-pack accounting (msnv_host_timers: pack_device_wall_s; msnv_devpack_stats)
     double    ms_scan = 0, ms_measure = 0, ms_depth = 0, ms_emit = 0, ms_sort = 0, wall_upload_s = 0, wall_download_s = 0, wall_prepass_s = 0;
-    uint64_t  raw_bytes = 0, n_records = 0, n_pieces = 0, n_prepass_samples = 0, n_scan_redone = 0;
+    uint64_t  raw_bytes = 0, n_records = 0, n_pieces = 0, n_prepass_samples = 0, n_scan_redone = 0, n_deep_runs_split = 0;
 };
 
 

@@ -29,6 +29,10 @@ int devpack_fill_padding(DeviceCols &d, const std::vector<uint8_t> &sample_on_de
 struct DevMergedSrc { uint32_t pair, in_group; unsigned long long h_base; };   // a pair of a merged group: its index in the group, first slot of its headers in hdr8m
 struct DevCovPair { uint32_t tile, sample, lo, hi; };                            // intervals [lo, hi) of `sample` (kept ones, sample-relative) may touch `tile`
 int devfin_overhang(msnv_dataset &ds, std::vector<int64_t> &maxend);
+// deep (sample, tile) runs (pack.cpp: split_deep_runs) on the device: exact depth of every run whose bound reaches split_at, runs that are
+// really that deep dealt round robin into groups of pieces that each stay below the byte bins' limit; the sample's headers are permuted group
+// by group and its columns re-laid in header order.  Updates SampleCols::dev_pairs.  *fallback: a run needs more groups than the kernel holds.
+int devfin_deep_runs(msnv_dataset &ds, uint32_t split_at, uint32_t group_depth, bool *fallback);
 int devfin_headers(msnv_dataset &ds, DeviceCols &d, const std::vector<uint64_t> &rbase);
 int devfin_chunk_counts(msnv_dataset &ds, DeviceCols &d, const std::vector<uint32_t> &narrow_pairs, std::vector<uint32_t> &counts);
 int devfin_chunk_fill(msnv_dataset &ds, DeviceCols &d, const std::vector<uint32_t> &narrow_pairs, const std::vector<uint32_t> &chunk_base, uint64_t n_chunks, std::vector<ChunkDesc> &out);

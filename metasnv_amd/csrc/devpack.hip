@@ -681,6 +681,35 @@ __device__ __forceinline__ void store_bytes(uint8_t *p, uint64_t v, uint32_t n) 
     if (n & 2u) { const uint16_t w = (uint16_t)v; __builtin_memcpy(p, &w, 2); p += 2; v >>= 16; }
     if (n & 1u) *p = (uint8_t)v;
 }
+// One lane's share of a piece into the columns: st stored nibbles (a multiple of 4) of lane `sub` (32 nibbles per lane), their flags in `bits`.
+__device__ __forceinline__ void put_piece_lane(uint8_t *seq_col, uint8_t *qual_col, uint32_t seqoff, uint32_t sub, uint32_t sb, uint32_t st, uint64_t o0, uint64_t o1,
+                                               uint32_t bits, uint32_t prev_last) {
+    // ---- seq column: st / 2 bytes
+    uint8_t *sp = seq_col + seqoff + 16u * sub;
+    const uint32_t nb = st >> 1;
+    store_bytes(sp, o0, nb < 8u ? nb : 8u);
+    if (nb > 8u) store_bytes(sp + 8, o1, nb - 8u);
+    // ---- flag column: bit index = nibble index of the seq column; the piece starts on bit 0 or 4 of a byte
+    const unsigned long long b0 = 2ull * seqoff + 32u * sub;
+    uint8_t *qp = qual_col + (b0 >> 3);
+    const bool last_lane = sub == ((2u * sb - 1u) >> 5);
+    const uint32_t v = st < 32u ? bits & ((1u << st) - 1u) : bits;
+    if (!(b0 & 4ull)) {
+        const uint32_t full = st >> 3;                                                  // whole bytes of mine
+        store_bytes(qp, v, full);
+        if (st & 4u) or_byte(qp + full, (v >> (8u * full)) & 0xfu);                     // a trailing nibble: the byte's other half is the next piece's (only the last lane ends on one)
+    } else if (sub == 0) {
+        or_byte(qp, (v & 0xfu) << 4);                                                   // the low nibble of the first byte is the previous piece's
+        const uint32_t rest = st - 4u, full = rest >> 3;
+        store_bytes(qp + 1, v >> 4, full);
+        if ((rest & 4u) && last_lane) or_byte(qp + 1 + full, (v >> (4u + 8u * full)) & 0xfu);      // (else lane 1 writes that byte with my nibble in it)
+    } else {
+        const uint64_t w = (uint64_t)v << 4 | (prev_last & 0xfu);                       // the byte I start in, whole: the lane before me left its last nibble there
+        const uint32_t total = st + 4u, full = total >> 3;
+        store_bytes(qp, w, full);
+        if ((total & 4u) && last_lane) or_byte(qp + full, (uint32_t)(w >> (8u * full)) & 0xfu);
+    }
+}
 __global__ __launch_bounds__(256) void msnv_emit_pieces(const uint8_t *raw, const uint32_t *pref4, DpParams P, uint32_t n_pieces, const ReadHdr *hdr, const PieceSrc *psrc,
                                                         const DpSampleDst *dst, DpAcc *acc) {
     const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
@@ -753,33 +782,7 @@ __global__ __launch_bounds__(256) void msnv_emit_pieces(const uint8_t *raw, cons
         bits = have < 32u ? ((bits & (0xffffffffu << have)) | (low & ((1u << have) - 1u))) : low;
     }
     const uint32_t prev_last = __shfl_up(bits >> 28, 1);                                    // the last four flags of lane sub - 1 of the same piece (sub > 0, that lane is full)
-    if (st) {
-        // ---- seq column: st / 2 bytes
-        uint8_t *sp = d.seq + h.seqoff + 16u * sub;
-        const uint32_t nb = st >> 1;
-        store_bytes(sp, o0, nb < 8u ? nb : 8u);
-        if (nb > 8u) store_bytes(sp + 8, o1, nb - 8u);
-        // ---- flag column: bit index = nibble index of the seq column; the piece starts on bit 0 or 4 of a byte
-        const unsigned long long b0 = 2ull * h.seqoff + j0;
-        uint8_t *qp = d.qual + (b0 >> 3);
-        const bool last_lane = sub == ((2u * sb - 1u) >> 5);
-        const uint32_t v = st < 32u ? bits & ((1u << st) - 1u) : bits;
-        if (!(b0 & 4ull)) {
-            const uint32_t full = st >> 3;                                                  // whole bytes of mine
-            store_bytes(qp, v, full);
-            if (st & 4u) or_byte(qp + full, (v >> (8u * full)) & 0xfu);                     // a trailing nibble: the byte's other half is the next piece's (only the last lane ends on one)
-        } else if (sub == 0) {
-            or_byte(qp, (v & 0xfu) << 4);                                                   // the low nibble of the first byte is the previous piece's
-            const uint32_t rest = st - 4u, full = rest >> 3;
-            store_bytes(qp + 1, v >> 4, full);
-            if ((rest & 4u) && last_lane) or_byte(qp + 1 + full, (v >> (4u + 8u * full)) & 0xfu);      // (else lane 1 writes that byte with my nibble in it)
-        } else {
-            const uint64_t w = (uint64_t)v << 4 | (prev_last & 0xfu);                       // the byte I start in, whole: the lane before me left its last nibble there
-            const uint32_t total = st + 4u, full = total >> 3;
-            store_bytes(qp, w, full);
-            if ((total & 4u) && last_lane) or_byte(qp + full, (uint32_t)(w >> (8u * full)) & 0xfu);
-        }
-    }
+    if (st) put_piece_lane(d.seq, d.qual, h.seqoff, sub, sb, st, o0, o1, bits, prev_last);
     // mismatch sample: sum over the 4 lanes of a piece, one atomic per sampled piece
     mm += __shfl_down(mm, 2, 4); mm += __shfl_down(mm, 1, 4);
     if (sub == 0 && sampled) {
@@ -1540,7 +1543,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
         const DevPairRec &r = prec[p];
         SampleCols &sc = ds.samples[first + r.sample];
         const uint32_t hi = (p + 1 < prec.size() && prec[p + 1].sample == r.sample) ? prec[p + 1].start : (uint32_t)sum[r.sample + 1].pbase0;
-        sc.dev_pairs.push_back(DevPair{r.tid, r.tile, r.start - sum[r.sample].pbase0, hi - sum[r.sample].pbase0, r.maxd});
+        sc.dev_pairs.push_back(DevPair{r.tid, r.tile, r.start - sum[r.sample].pbase0, hi - sum[r.sample].pbase0, r.maxd, 0u});
     }
     // ... and of every (sample, contig)
     for (const DpRun &r : runs) {
@@ -1922,6 +1925,230 @@ int devfin_coverage(msnv_dataset &ds, DeviceCols &d, std::vector<uint64_t> &cvba
         HIP_TRY(hipStreamSynchronize(st));
     }
     HIP_TRY(hipStreamSynchronize(st));
+    return MSNV_OK;
+}
+
+// ------------------------------------------------------------------------------------------ deep runs (pack.cpp: split_deep_runs)
+namespace {
+__device__ __forceinline__ int wave_inclusive_scan_int(int v) {
+    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(v, o); if ((int)(threadIdx.x & 63u) >= o) v += y; }
+    return v;
+}
+constexpr uint32_t DEEP_G_CAP = 512;                              // groups a run may be dealt into (depth cap 65535 / group depth 128)
+struct DevDeepRun { unsigned long long piece0; uint32_t n, pad; };   // pieces [piece0, piece0 + n) of a ROUND's header array
+struct DevDeepOut { uint32_t G, exact; };                            // G = 1: not split, `exact` is the run's true depth; G > 1: dealt into G groups (their depths in gmax); G = 0: too many groups
+// largest per-position depth of the pieces g, g + G, g + 2G, ... of the run (one workgroup of 256, a difference array of the tile in LDS)
+__device__ uint32_t deep_sweep(const ReadHdr *h, const uint32_t n, const uint32_t G, const uint32_t g, int *diff, int *wsum) {
+    const int tid = threadIdx.x;
+    for (int i = tid; i < (int)TILE + 8; i += 256) diff[i] = 0;
+    __syncthreads();
+    for (uint32_t j = g + G * (uint32_t)tid; j < n; j += G * 256u) {
+        const ReadHdr x = h[j];
+        const uint32_t s0 = x.gpos % TILE;
+        atomicAdd(&diff[s0], 1); atomicAdd(&diff[s0 + x.cig], -1);
+    }
+    __syncthreads();
+    int v[8], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { v[k] = diff[8 * tid + k]; sum += v[k]; }
+    const int incl = wave_inclusive_scan_int(sum);
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    int base = incl - sum;
+    for (int w = 0; w < (tid >> 6); ++w) base += wsum[w];
+    int m = 0, cur = base;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { cur += v[k]; m = cur > m ? cur : m; }
+    for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_down(m, o); m = y > m ? y : m; }
+    __syncthreads();
+    if ((tid & 63) == 0) wsum[4 + (tid >> 6)] = m;
+    __syncthreads();
+    const int r = max(max(wsum[4], wsum[5]), max(wsum[6], wsum[7]));
+    __syncthreads();
+    return (uint32_t)r;
+}
+__global__ __launch_bounds__(256) void msnv_fin_deep_sweep(const ReadHdr *hdr, const DevDeepRun *runs, uint32_t split_at, uint32_t group_depth, DevDeepOut *outs, uint32_t *gmax) {
+    __shared__ int diff[TILE + 8];
+    __shared__ int wsum[8];
+    const DevDeepRun r = runs[blockIdx.x];
+    const ReadHdr *h = hdr + r.piece0;
+    uint32_t *gm = gmax + (size_t)blockIdx.x * DEEP_G_CAP;
+    const uint32_t exact = deep_sweep(h, r.n, 1u, 0u, diff, wsum);
+    if (exact < split_at) { if (threadIdx.x == 0) outs[blockIdx.x] = DevDeepOut{1u, exact}; return; }
+    uint32_t G = exact / group_depth + 1u;
+    for (;; ++G) {
+        if (G > DEEP_G_CAP) { if (threadIdx.x == 0) outs[blockIdx.x] = DevDeepOut{0u, exact}; return; }
+        uint32_t worst = 0;
+        for (uint32_t g = 0; g < G; ++g) { const uint32_t d = deep_sweep(h, r.n, G, g, diff, wsum); if (threadIdx.x == 0) gm[g] = d; worst = d > worst ? d : worst; }
+        if (worst < NARROW_MAX_DEPTH) break;
+    }
+    if (threadIdx.x == 0) outs[blockIdx.x] = DevDeepOut{G, exact};
+}
+// where the piece that ends up at position j of a split run comes from: groups one after the other, a group's pieces in their old order
+struct DevDeepPerm { unsigned long long piece0; uint32_t n, G; };
+__global__ void msnv_fin_deep_perm(const DevDeepPerm *runs, uint32_t *src) {
+    const DevDeepPerm r = runs[blockIdx.x];
+    const uint32_t q = r.n / r.G, rem = r.n % r.G;
+    for (uint32_t k = threadIdx.x; k < r.n; k += blockDim.x) {
+        const uint32_t g = k % r.G, newpos = g * q + (g < rem ? g : rem) + k / r.G;
+        src[r.piece0 + newpos] = (uint32_t)(r.piece0 + k);
+    }
+}
+__global__ void msnv_iota(uint32_t *a, unsigned long long n) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = (uint32_t)i;
+}
+__global__ void msnv_fin_stored(const ReadHdr *hdr, unsigned long long n, uint32_t *out) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= n) out[i] = i < n ? stored_bytes(hdr[i].cig) : 0u;
+}
+// a sample's columns re-laid in header order: 4 lanes per piece, 32 stored nibbles per lane, from the old offsets to the new
+__global__ __launch_bounds__(256) void msnv_fin_relayout(ReadHdr *hdr, unsigned long long n_pieces, const uint32_t *new_off, const uint8_t *old_seq, const uint8_t *old_qual,
+                                                         uint8_t *new_seq, uint8_t *new_qual) {
+    const unsigned long long gt = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long pc = gt >> 2; const uint32_t sub = (uint32_t)gt & 3u;
+    ReadHdr h{}; uint32_t sb = 0, noff = 0;
+    if (pc < n_pieces) { h = hdr[pc]; sb = stored_bytes(h.cig); noff = new_off[pc]; }
+    const uint32_t st = 2u * sb > 32u * sub ? (2u * sb - 32u * sub < 32u ? 2u * sb - 32u * sub : 32u) : 0u;
+    uint64_t o0 = 0, o1 = 0; uint32_t bits = 0;
+    if (st) {
+        const uint8_t *sp = old_seq + h.seqoff + 16u * sub;
+        o0 = ld64(sp); o1 = ld64(sp + 8);
+        const unsigned long long b = 2ull * h.seqoff + 32u * sub;
+        bits = (uint32_t)(ld64(old_qual + (b >> 3)) >> (uint32_t)(b & 7ull));
+    }
+    const uint32_t prev_last = __shfl_up(bits >> 28, 1);
+    if (st) put_piece_lane(new_seq, new_qual, noff, sub, sb, st, o0, o1, bits, prev_last);
+    if (st && sub == 0) hdr[pc].seqoff = noff;                     // (every lane of the piece has read its header by now: the loads sit above the shuffle)
+}
+}  // namespace
+
+int devfin_deep_runs(msnv_dataset &ds, uint32_t split_at, uint32_t group_depth, bool *fallback) {
+    *fallback = false;
+    hipStream_t st = (hipStream_t)ds.ctx->stream;
+    DevPackTables &T = ds.dp;
+    const size_t S = ds.samples.size();
+    // ---- the runs whose bound reaches split_at, round by round
+    struct Ref { size_t sample, pair; };
+    std::vector<std::vector<DevDeepRun>> runs(T.rounds.size());
+    std::vector<std::vector<Ref>> refs(T.rounds.size());
+    for (size_t s = 0; s < S; ++s) {
+        const SampleCols &sc = ds.samples[s];
+        for (size_t k = 0; k < sc.dev_pairs.size(); ++k) if (sc.dev_pairs[k].maxd >= split_at) {
+            runs[(size_t)sc.dev_round].push_back(DevDeepRun{sc.dev_piece0 + sc.dev_pairs[k].lo, sc.dev_pairs[k].hi - sc.dev_pairs[k].lo, 0u});
+            refs[(size_t)sc.dev_round].push_back(Ref{s, k});
+        }
+    }
+    std::vector<uint8_t> split_sample(S, 0);
+    std::vector<std::vector<DevDeepPerm>> perms(T.rounds.size());
+    struct NewPairs { size_t pair; uint32_t G; std::vector<uint32_t> gmax; };
+    std::vector<std::vector<NewPairs>> edits(S);
+    for (size_t r = 0; r < T.rounds.size(); ++r) {
+        const size_t n = runs[r].size();
+        if (!n) continue;
+        DevBuf d_runs, d_outs, d_gmax;
+        if (int rc = d_runs.alloc(n * sizeof(DevDeepRun))) return rc;
+        if (int rc = d_outs.alloc(n * sizeof(DevDeepOut))) return rc;
+        if (int rc = d_gmax.alloc(n * DEEP_G_CAP * 4)) return rc;
+        HIP_TRY(hipMemcpyAsync(d_runs.p, runs[r].data(), n * sizeof(DevDeepRun), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(msnv_fin_deep_sweep, dim3((unsigned)n), dim3(256), 0, st, T.rounds[r].hdr, d_runs.as<DevDeepRun>(), split_at, group_depth, d_outs.as<DevDeepOut>(), d_gmax.as<uint32_t>());
+        HIP_TRY(hipGetLastError());
+        std::vector<DevDeepOut> outs(n);
+        std::vector<uint32_t> gmax(n * DEEP_G_CAP);
+        HIP_TRY(hipMemcpyAsync(outs.data(), d_outs.p, n * sizeof(DevDeepOut), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(gmax.data(), d_gmax.p, n * DEEP_G_CAP * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (size_t i = 0; i < n; ++i) {
+            const Ref ref = refs[r][i];
+            SampleCols &sc = ds.samples[ref.sample];
+            if (outs[i].G == 0u) { *fallback = true; return MSNV_OK; }
+            if (outs[i].G == 1u) { sc.dev_pairs[ref.pair].maxd = outs[i].exact; continue; }      // the start-time bound was pessimistic
+            split_sample[ref.sample] = 1;
+            ++T.n_deep_runs_split;
+            perms[r].push_back(DevDeepPerm{runs[r][i].piece0, runs[r][i].n, outs[i].G});
+            edits[ref.sample].push_back(NewPairs{ref.pair, outs[i].G, std::vector<uint32_t>(gmax.begin() + i * DEEP_G_CAP, gmax.begin() + i * DEEP_G_CAP + outs[i].G)});
+        }
+    }
+    // ---- the pair lists of the samples with split runs: a run of n pieces in G groups becomes G pairs (group g: the pieces g, g + G, ...)
+    for (size_t s = 0; s < S; ++s) {
+        if (edits[s].empty()) continue;
+        SampleCols &sc = ds.samples[s];
+        std::vector<DevPair> np;
+        size_t e = 0;
+        for (size_t k = 0; k < sc.dev_pairs.size(); ++k) {
+            const DevPair p = sc.dev_pairs[k];
+            if (e < edits[s].size() && edits[s][e].pair == k) {
+                const uint32_t n = p.hi - p.lo, G = edits[s][e].G, q = n / G, rem = n % G;
+                uint32_t lo = p.lo;
+                for (uint32_t g = 0; g < G; ++g) { const uint32_t cnt = q + (g < rem ? 1u : 0u); if (cnt) np.push_back(DevPair{p.tid, p.tile, lo, lo + cnt, edits[s][e].gmax[g], 1u + g}); lo += cnt; }
+                ++e;
+            } else np.push_back(p);
+        }
+        sc.dev_pairs.swap(np);
+    }
+    // ---- headers of the split runs group by group, then the columns of their samples in header order
+    for (size_t r = 0; r < T.rounds.size(); ++r) {
+        if (perms[r].empty()) continue;
+        DevRound &R = T.rounds[r];
+        DevBuf d_perm, d_src;
+        if (int rc = d_perm.alloc(perms[r].size() * sizeof(DevDeepPerm))) return rc;
+        if (int rc = d_src.alloc((R.n_pieces + 1) * 4)) return rc;
+        HIP_TRY(hipMemcpyAsync(d_perm.p, perms[r].data(), perms[r].size() * sizeof(DevDeepPerm), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(msnv_iota, grid_for(R.n_pieces, 256), dim3(256), 0, st, d_src.as<uint32_t>(), (unsigned long long)R.n_pieces);
+        hipLaunchKernelGGL(msnv_fin_deep_perm, dim3((unsigned)perms[r].size()), dim3(256), 0, st, d_perm.as<DevDeepPerm>(), d_src.as<uint32_t>());
+        HIP_TRY(hipGetLastError());
+        // the round's headers through the permutation, into a buffer of their own (the intervals stay where they are)
+        const uint64_t b_hdr = R.n_pieces * sizeof(ReadHdr), b_4 = ((R.n_pieces * 4) + 15) & ~15ull, b_2 = ((R.n_pieces * 2) + 15) & ~15ull;
+        void *nb = nullptr;
+        if (int rc = dev_alloc(&nb, b_hdr + 2 * b_4 + b_2 + 64, nullptr)) return rc;
+        uint8_t *q = static_cast<uint8_t *>(nb);
+        ReadHdr *h2 = reinterpret_cast<ReadHdr *>(q); q += b_hdr;
+        int32_t *t2 = reinterpret_cast<int32_t *>(q); q += b_4;
+        int32_t *e2 = reinterpret_cast<int32_t *>(q); q += b_4;
+        uint16_t *d2 = reinterpret_cast<uint16_t *>(q);
+        hipLaunchKernelGGL(msnv_gather_pieces, grid_for(R.n_pieces, 256), dim3(256), 0, st, d_src.as<uint32_t>(), (uint32_t)R.n_pieces, R.hdr, R.tid, R.end, R.depth, h2, t2, e2, d2);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(st));
+        T.round_bufs.push_back(R.buf);                             // (the old buffer still holds the round's intervals; freed with the columns)
+        R.buf = nb; R.hdr = h2; R.tid = t2; R.end = e2; R.depth = d2;
+    }
+    Prim pr(st);
+    for (size_t s = 0; s < S; ++s) {
+        if (!split_sample[s]) continue;
+        SampleCols &sc = ds.samples[s];
+        DevRound &R = T.rounds[(size_t)sc.dev_round];
+        ReadHdr *h = R.hdr + sc.dev_piece0;
+        const unsigned long long n = sc.n_dev_pieces;
+        DevBuf d_st, d_off;
+        if (int rc = d_st.alloc((n + 1) * 4)) return rc;
+        if (int rc = d_off.alloc((n + 1) * 4)) return rc;
+        hipLaunchKernelGGL(msnv_fin_stored, grid_for(n + 1, 256), dim3(256), 0, st, h, n, d_st.as<uint32_t>());
+        HIP_TRY(hipGetLastError());
+        if (int rc = pr.scan32(d_st.as<uint32_t>(), d_off.as<uint32_t>(), n + 1, false)) return rc;
+        const uint64_t seq_bytes = (sc.d_seq_bytes + 15) & ~15ull, qual_bytes = seq_bytes / 4;
+        void *nb = nullptr;
+        if (int rc = dev_alloc(&nb, seq_bytes + qual_bytes + 64, nullptr)) return rc;
+        T.round_bufs.push_back(nb);
+        uint8_t *nseq = static_cast<uint8_t *>(nb), *nqual = nseq + seq_bytes;
+        HIP_TRY(hipMemsetAsync(nseq, 0xff, seq_bytes, st));
+        HIP_TRY(hipMemsetAsync(nqual, 0, qual_bytes + 64, st));
+        hipLaunchKernelGGL(msnv_fin_relayout, grid_for(n * 4, 256), dim3(256), 0, st, h, n, d_off.as<uint32_t>(), sc.d_seq, sc.d_qual, nseq, nqual);
+        HIP_TRY(hipGetLastError());
+        // tail: 32 bytes of N (the memset) and their flags
+        const msnv_params &MP = ds.params;
+        DpParams P{}; P.c_eff = std::min(std::max(MP.min_baseq, -127), 127); P.all_low = MP.min_baseq > 127;
+        const DpSampleDst dst{nseq, nqual, 0ull, 0u, 0u};
+        const unsigned long long piece_bytes = sc.d_seq_bytes - 32;
+        DevBuf d_dst, d_pb;
+        if (int rc = d_dst.alloc(sizeof(DpSampleDst))) return rc;
+        if (int rc = d_pb.alloc(8)) return rc;
+        HIP_TRY(hipMemcpyAsync(d_dst.p, &dst, sizeof dst, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_pb.p, &piece_bytes, 8, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(msnv_emit_tail, dim3(1), dim3(64), 0, st, d_dst.as<DpSampleDst>(), d_pb.as<unsigned long long>(), 1u, P);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(st));
+        sc.d_seq = nseq; sc.d_qual = nqual;
+    }
     return MSNV_OK;
 }
 

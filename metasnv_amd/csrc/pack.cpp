@@ -75,6 +75,10 @@ static uint32_t deep_split_at() {
     static const uint32_t v = [] { const char *e = getenv("MSNV_SPLIT_AT"); const int x = e ? atoi(e) : 192; return (uint32_t)std::min<int>((int)NARROW_MAX_DEPTH, std::max(32, x)); }();
     return v;
 }
+static uint32_t deep_group_depth() {
+    static const uint32_t v = [] { const char *e = getenv("MSNV_GROUP_DEPTH"); const int x = e ? atoi(e) : 128; return (uint32_t)std::min(250, std::max(16, x)); }();
+    return v;
+}
 static int split_deep_runs(SampleCols &sc, int device) {
     const size_t n = sc.hdr.size();
     sc.grp.assign(n, 0);
@@ -108,7 +112,7 @@ static int split_deep_runs(SampleCols &sc, int device) {
             if (exact < split_at) {
                 for (size_t k = i; k < j; ++k) sc.depth[k] = (uint16_t)exact;        // the start-time bound was pessimistic
             } else {
-                static const uint32_t group_depth = [] { const char *e = getenv("MSNV_GROUP_DEPTH"); const int v = e ? atoi(e) : 128; return (uint32_t)std::min(250, std::max(16, v)); }();
+                const uint32_t group_depth = deep_group_depth();
                 uint32_t G = exact / group_depth + 1;
                 while (sweep(G) >= NARROW_MAX_DEPTH) ++G;
                 std::vector<uint32_t> gmax = mx;
@@ -799,9 +803,9 @@ int finalize_dataset(msnv_dataset &ds) {
         t_lap = now;
     };
     // Device-packed samples (devpack.hip) keep their piece headers and intervals in HBM.  When every sample is one, the per-piece and
-    // per-interval loops below run there as kernels (`fast`; devfin_* in devpack.hip) and the host works on (sample, tile) pairs only.  The two
-    // re-layouts that still run on host staging -- dense pieces, deep runs dealt into groups -- and mixed datasets take the host loops:
-    // the headers come down first (MSNV_FINALIZE=host forces that; tests compare the two).
+    // per-interval loops below run there as kernels (`fast`; devfin_* in devpack.hip) and the host works on (sample, tile) pairs only.  The
+    // dense piece re-layout (short reads) still runs on host staging, and so do mixed datasets: the headers come down first
+    // (MSNV_FINALIZE=host forces that; tests compare the two).
     bool fast = false;
     {
         bool any_dev = false, all_dev = true;
@@ -812,8 +816,19 @@ int finalize_dataset(msnv_dataset &ds) {
             uint64_t np = 0, nb = 0;
             for (const SampleCols &sc : ds.samples) { np += sc.n_dev_pieces; nb += sc.n_pileup_bases; }
             if (layout_dense(np, nb)) fast = false;
+            // deep (sample, tile) runs: their exact depth, and -- where a run really is that deep -- its pieces dealt into groups and the sample's
+            // columns re-laid, by kernels (devpack.hip: devfin_deep_runs; MSNV_DEEP_RELOCATE=0, a host-only experiment, takes the host loops)
             const uint32_t split_at = deep_split_at();
-            for (const SampleCols &sc : ds.samples) for (const DevPair &p : sc.dev_pairs) if (p.maxd >= split_at) { fast = false; break; }
+            bool any_deep = false;
+            for (const SampleCols &sc : ds.samples) for (const DevPair &p : sc.dev_pairs) if (p.maxd >= split_at) { any_deep = true; break; }
+            if (fast && any_deep) {
+                if (getenv("MSNV_DEEP_RELOCATE") && getenv("MSNV_DEEP_RELOCATE")[0] == '0') fast = false;
+                else {
+                    bool fallback = false;
+                    if (int rc = devfin_deep_runs(ds, split_at, deep_group_depth(), &fallback)) return rc;
+                    if (fallback) fast = false;
+                }
+            }
         }
         if (any_dev && !fast) if (int rc = devpack_download_pieces(ds)) return rc;
     }
@@ -944,7 +959,7 @@ int finalize_dataset(msnv_dataset &ds) {
         std::vector<PairTmp> &pv = per_sample[s];
         pv.reserve(sc.dev_pairs.size());
         for (const DevPair &p : sc.dev_pairs)
-            pv.push_back(PairTmp{ds.tile_base[(size_t)p.tid] + p.tile, (uint32_t)s, p.lo, p.hi, p.maxd, (uint32_t)pv.size(), 0u});
+            pv.push_back(PairTmp{ds.tile_base[(size_t)p.tid] + p.tile, (uint32_t)s, p.lo, p.hi, p.maxd, (uint32_t)pv.size(), p.grp});
     }
     else parallel_for(S, [&](size_t s) {
         SampleCols &sc = ds.samples[s];

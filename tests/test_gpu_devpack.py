@@ -121,9 +121,22 @@ def test_sparse_cohort_and_merged_groups_same_columns():
         _same_dataset(syn.names, syn.lengths, syn.seqs, samples, many=True, check_oracle=False)
 
 
-def test_deep_and_dense_datasets_take_the_host_relayouts():
-    syn, samples = synth_case(n_species=1, contig_len=4000, n_samples=3, mean_cov=300.0, snv_density=0.02, seed=27)      # runs deeper than 192: dealt into groups
+def test_deep_runs_are_dealt_into_groups_on_the_device_and_dense_layouts_on_the_host():
+    """(sample, tile) runs deeper than the byte bins hold (pack.cpp: split_deep_runs): exact sweep, round-robin groups, header permutation and
+    the re-layout of the sample's columns run as kernels (devpack.hip: devfin_deep_runs) and give the host stage's bytes; the dense block
+    layout of short reads still re-lays on host staging."""
+    syn, samples = synth_case(n_species=1, contig_len=4000, n_samples=3, mean_cov=300.0, sigma_cov=0.3, snv_density=0.02, seed=27)      # runs deeper than 192: dealt into groups
     _same_dataset(syn.names, syn.lengths, syn.seqs, samples)
+    with _env(MSNV_PACK="device"):
+        ctx = core.Context(0)
+        ds = core.Dataset(ctx, syn.names, syn.lengths, syn.seqs)
+        ds.add_samples_records(samples)
+        ds.finalize()
+        assert ds.pack_stats()["deep_runs_split"] >= 2
+        ds.close(); ctx.close()
+    with _env(MSNV_SPLIT_AT="40", MSNV_GROUP_DEPTH="24"):                                                        # (many groups per run; some runs only look deep)
+        syn2, samples2 = synth_case(n_species=2, contig_len=5000, n_samples=4, mean_cov=45.0, sigma_cov=0.6, snv_density=0.02, seed=29)
+        _same_dataset(syn2.names, syn2.lengths, syn2.seqs, samples2)
     syn, samples = synth_case(n_species=2, contig_len=5000, n_samples=4, mean_cov=12.0, read_len=36, snv_density=0.02, seed=28)   # short reads: dense block layout
     _same_dataset(syn.names, syn.lengths, syn.seqs, samples)
 
