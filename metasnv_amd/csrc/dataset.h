@@ -120,6 +120,7 @@ struct SampleCols {
     bool     dev_index = false;                       // headers and intervals are still in HBM only (DevPackTables::rounds): hdr / tid / end / depth / cov_* above are empty
     int32_t  dev_round = -1;                          // ... in that round, from these offsets
     uint64_t dev_piece0 = 0, dev_iv0 = 0, n_dev_pieces = 0, n_dev_iv = 0;
+    uint32_t *d_blk = nullptr; uint64_t n_dev_blk = 0;  // dense layout: its block descriptors in HBM (devpack.hip: devfin_dense)
     std::vector<DevPair> dev_pairs;                   // its (contig, tile) runs of pieces, in order
     msnv_sample_stats st{};          // qaCompute "Other" statistics (qaCompute.cpp:642-654), counted over every record of the BAM
 };
@@ -139,7 +140,7 @@ struct DevPackTables {
     bool      ready = false;
     // cumulative device-pack accounting (msnv_host_timers: pack_device_wall_s; msnv_devpack_stats)
     double    ms_scan = 0, ms_measure = 0, ms_depth = 0, ms_emit = 0, ms_sort = 0, wall_upload_s = 0, wall_download_s = 0, wall_prepass_s = 0;
-    uint64_t  raw_bytes = 0, n_records = 0, n_pieces = 0, n_prepass_samples = 0, n_scan_redone = 0, n_deep_runs_split = 0;
+    uint64_t  raw_bytes = 0, n_records = 0, n_pieces = 0, n_prepass_samples = 0, n_scan_redone = 0, n_deep_runs_split = 0, n_dense_samples = 0;
 };
 
 

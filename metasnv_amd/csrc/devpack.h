@@ -33,6 +33,9 @@ int devfin_overhang(msnv_dataset &ds, std::vector<int64_t> &maxend);
 // really that deep dealt round robin into groups of pieces that each stay below the byte bins' limit; the sample's headers are permuted group
 // by group and its columns re-laid in header order.  Updates SampleCols::dev_pairs.  *fallback: a run needs more groups than the kernel holds.
 int devfin_deep_runs(msnv_dataset &ds, uint32_t split_at, uint32_t group_depth, bool *fallback);
+// pack.cpp: relayout_dense for device-packed samples: every sample's columns as dense block streams, its descriptors (d_blk) and run_* tables
+int devfin_dense(msnv_dataset &ds);
+int devpack_copy_blocks(const SampleCols &sc, uint32_t *dst, void *stream);
 int devfin_headers(msnv_dataset &ds, DeviceCols &d, const std::vector<uint64_t> &rbase);
 int devfin_chunk_counts(msnv_dataset &ds, DeviceCols &d, const std::vector<uint32_t> &narrow_pairs, std::vector<uint32_t> &counts);
 int devfin_chunk_fill(msnv_dataset &ds, DeviceCols &d, const std::vector<uint32_t> &narrow_pairs, const std::vector<uint32_t> &chunk_base, uint64_t n_chunks, std::vector<ChunkDesc> &out);

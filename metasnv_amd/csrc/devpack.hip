@@ -2152,6 +2152,183 @@ int devfin_deep_runs(msnv_dataset &ds, uint32_t split_at, uint32_t group_depth, 
     return MSNV_OK;
 }
 
+// ------------------------------------------------------------------------------------------ dense block streams (short reads)
+// pack.cpp: relayout_dense as kernels.  A run's stream is cut into blocks of 32 bases: a piece starts on an even base, opens a fresh block
+// when the block it would start in already holds a second segment or when it would end inside that block.  One thread walks one run (the
+// rule is sequential inside a run): first to count the run's blocks, then -- block bases known -- to write descriptors and the pieces' new
+// offsets; the bases and flags move with four lanes per piece.
+namespace {
+struct DevDenseRun { unsigned long long piece0; uint32_t n, blk0, seq0, pad; };        // blk0: index into the round's block array; seq0: byte offset of the run in its sample's seq column
+template <bool WRITE>
+__device__ __forceinline__ uint32_t dense_walk(const ReadHdr *h, uint32_t n, uint32_t seq0, uint32_t *blk, uint32_t *new_off) {
+    uint32_t cursor = 0, nblk = 0, lastw = BLK_EMPTY;                                   // lastw: descriptor of block nblk - 1, not yet written
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t len = h[k].cig, P = h[k].gpos % TILE;
+        cursor = (cursor + 1u) & ~1u;
+        uint32_t o = cursor & 31u;
+        if (o != 0u) {                                                                  // (then the block holding `cursor` is block nblk - 1)
+            const bool has_b = ((lastw >> 17) & 0xfffu) != BLK_NO_B;
+            if (has_b || len < 32u - o) { cursor = ((cursor >> 5) + 1u) << 5; o = 0u; }
+        }
+        if (WRITE) new_off[k] = seq0 + (cursor >> 1);
+        uint32_t done = 0;
+        if (o != 0u) {                                                                  // the head of the piece = segment B of the open block
+            lastw = (lastw & ~(0xfffu << 17)) | ((P - o + 32u) << 17);
+            done = 32u - o;
+            if (done == len) lastw |= BLK_END_B;
+        }
+        bool first = o == 0u;
+        while (done < len) {
+            const uint32_t na = len - done < 32u ? len - done : 32u;
+            if (WRITE && nblk) blk[nblk - 1u] = lastw;
+            ++nblk;
+            lastw = BLK_EMPTY | (P + done) | na << 11 | (first ? BLK_START_A : 0u) | (done + na == len ? BLK_END_A : 0u);
+            first = false; done += na;
+        }
+        cursor += len;
+    }
+    if (WRITE && nblk) blk[nblk - 1u] = lastw;
+    return nblk;
+}
+__global__ void msnv_fin_dense_count(const ReadHdr *hdr, const DevDenseRun *runs, uint32_t n_runs, uint32_t *nblk) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_runs) return;
+    nblk[r] = dense_walk<false>(hdr + runs[r].piece0, runs[r].n, 0u, nullptr, nullptr);
+}
+__global__ void msnv_fin_dense_place(const ReadHdr *hdr, const DevDenseRun *runs, uint32_t n_runs, uint32_t *blk, uint32_t *new_off) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_runs) return;
+    const DevDenseRun R = runs[r];
+    dense_walk<true>(hdr + R.piece0, R.n, R.seq0, blk + R.blk0, new_off + R.piece0);
+}
+// bits [b0, b0 + n) of a flag column := the n low bits of v (n <= 32).  The column was filled with `ones` everywhere; whole bytes are stored,
+// the bytes shared with a neighbour get ONE atomic (clear what must be 0, or set what must be 1).
+__device__ __forceinline__ void and_byte(uint8_t *p, uint32_t v) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const uint32_t sh = 8u * (uint32_t)(a & 3u);
+    atomicAnd(reinterpret_cast<uint32_t *>(a & ~(uintptr_t)3), ~(0xffu << sh) | v << sh);
+}
+__device__ __forceinline__ void put_flag_bits(uint8_t *col, unsigned long long b0, uint32_t n, uint32_t v, bool ones) {
+    uint8_t *p = col + (b0 >> 3);
+    const uint32_t sh = (uint32_t)(b0 & 7ull);
+    const uint64_t m = (n < 32u ? (1ull << n) - 1ull : 0xffffffffull) << sh, w = ((uint64_t)v << sh) & m;
+    const uint32_t nbytes = (sh + n + 7u) >> 3;
+    for (uint32_t k = 0; k < nbytes; ++k) {
+        const uint32_t mb = (uint32_t)(m >> (8u * k)) & 0xffu, wb = (uint32_t)(w >> (8u * k)) & 0xffu;
+        if (mb == 0xffu) p[k] = (uint8_t)wb;
+        else if (ones) and_byte(p + k, (~mb | wb) & 0xffu);
+        else if (wb) or_byte(p + k, wb);
+    }
+}
+// the pieces of one sample into its dense columns: 4 lanes per piece, 32 bases per lane, nothing but the real bases moves
+__global__ __launch_bounds__(256) void msnv_fin_dense_copy(ReadHdr *hdr, unsigned long long n_pieces, const uint32_t *new_off, const uint8_t *old_seq, const uint8_t *old_qual,
+                                                           uint8_t *new_seq, uint8_t *new_qual, uint32_t ones) {
+    const unsigned long long gt = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long pc = gt >> 2; const uint32_t sub = (uint32_t)gt & 3u, j0 = 32u * sub;
+    ReadHdr h{}; uint32_t noff = 0;
+    if (pc < n_pieces) { h = hdr[pc]; noff = new_off[pc]; }
+    const uint32_t have = h.cig > j0 ? (h.cig - j0 < 32u ? h.cig - j0 : 32u) : 0u;
+    if (have) {
+        const uint8_t *sp = old_seq + h.seqoff + 16u * sub;
+        uint64_t o0 = ld64(sp), o1 = ld64(sp + 8);
+        if (have & 1u) { if (have < 16u) o0 |= 0xfull << (4u * have); else o1 |= 0xfull << (4u * (have - 16u)); }      // the pad nibble of an odd piece reads as N
+        const uint32_t nb = (have + 1u) >> 1;
+        uint8_t *dp = new_seq + noff + 16u * sub;
+        store_bytes(dp, o0, nb < 8u ? nb : 8u);
+        if (nb > 8u) store_bytes(dp + 8, o1, nb - 8u);
+        const unsigned long long b = 2ull * h.seqoff + j0;
+        const uint32_t bits = (uint32_t)(ld64(old_qual + (b >> 3)) >> (uint32_t)(b & 7ull));
+        put_flag_bits(new_qual, 2ull * noff + j0, have, bits, ones != 0u);
+    }
+    if (have && sub == 0) hdr[pc].seqoff = noff;                   // (the four lanes of a piece sit in one wavefront: all of them have read the header)
+}
+}  // namespace
+
+int devfin_dense(msnv_dataset &ds) {
+    hipStream_t st = (hipStream_t)ds.ctx->stream;
+    DevPackTables &T = ds.dp;
+    const size_t S = ds.samples.size();
+    const msnv_params &MP = ds.params;
+    const bool ones = std::min(std::max(MP.min_baseq, -127), 127) > 0 || MP.min_baseq > 127;      // what a padding byte's flag is (pack.cpp: pack_lowq of a 0 byte)
+    for (size_t r = 0; r < T.rounds.size(); ++r) {
+        DevRound &R = T.rounds[r];
+        std::vector<DevDenseRun> runs;
+        std::vector<size_t> s_of;                                    // samples of this round, in order
+        for (size_t s = 0; s < S; ++s) if (ds.samples[s].dev_index && (size_t)ds.samples[s].dev_round == r) {
+            s_of.push_back(s);
+            for (const DevPair &p : ds.samples[s].dev_pairs) runs.push_back(DevDenseRun{ds.samples[s].dev_piece0 + p.lo, p.hi - p.lo, 0u, 0u, 0u});
+        }
+        if (s_of.empty()) continue;
+        const size_t n = runs.size();
+        std::vector<uint32_t> nblk(n, 0);
+        DevBuf d_runs, d_nblk, d_off;
+        if (n) {
+            if (int rc = d_runs.alloc(n * sizeof(DevDenseRun))) return rc;
+            if (int rc = d_nblk.alloc(n * 4)) return rc;
+            HIP_TRY(hipMemcpyAsync(d_runs.p, runs.data(), n * sizeof(DevDenseRun), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(msnv_fin_dense_count, grid_for(n, 64), dim3(64), 0, st, R.hdr, d_runs.as<DevDenseRun>(), (uint32_t)n, d_nblk.as<uint32_t>());
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(nblk.data(), d_nblk.p, n * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        }
+        // block bases: per sample (run_* as relayout_dense leaves them), and where the sample's blocks and columns sit in the round's buffers
+        std::vector<uint64_t> blk_at(s_of.size() + 1, 0), col_at(s_of.size() + 1, 0);
+        size_t k = 0;
+        for (size_t i = 0; i < s_of.size(); ++i) {
+            SampleCols &sc = ds.samples[s_of[i]];
+            sc.run_blk_lo.clear(); sc.run_nblk.clear(); sc.run_seq0.clear();
+            uint64_t b = 0;
+            for (size_t j = 0; j < sc.dev_pairs.size(); ++j, ++k) {
+                if (b + nblk[k] > 0x07ffffffull) return fail(MSNV_EDOMAIN, "a sample's dense block stream exceeds 2^27 blocks");
+                runs[k].blk0 = (uint32_t)(blk_at[i] + b); runs[k].seq0 = (uint32_t)(16u * b);
+                sc.run_blk_lo.push_back((uint32_t)b); sc.run_nblk.push_back(nblk[k]); sc.run_seq0.push_back((uint32_t)(16u * b));
+                b += nblk[k];
+            }
+            if (blk_at[i] + b > 0xfffffff0ull) return fail(MSNV_EDOMAIN, "more than 2^32 dense blocks in one round");
+            blk_at[i + 1] = blk_at[i] + b;
+            const uint64_t seq_bytes = 16ull * b + 32ull;            // + the tail padding
+            col_at[i + 1] = col_at[i] + ((seq_bytes + seq_bytes / 4 + 64ull + 15ull) & ~15ull);
+        }
+        void *colbuf = nullptr, *blkbuf = nullptr;
+        if (int rc = dev_alloc(&colbuf, col_at.back() + 64, nullptr)) return rc;
+        T.round_bufs.push_back(colbuf);
+        if (int rc = dev_alloc(&blkbuf, (blk_at.back() + 1) * 4, nullptr)) return rc;
+        T.round_bufs.push_back(blkbuf);
+        if (n) {
+            if (int rc = d_off.alloc((R.n_pieces + 1) * 4)) return rc;
+            HIP_TRY(hipMemcpyAsync(d_runs.p, runs.data(), n * sizeof(DevDenseRun), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(msnv_fin_dense_place, grid_for(n, 64), dim3(64), 0, st, R.hdr, d_runs.as<DevDenseRun>(), (uint32_t)n, static_cast<uint32_t *>(blkbuf), d_off.as<uint32_t>());
+            HIP_TRY(hipGetLastError());
+        }
+        for (size_t i = 0; i < s_of.size(); ++i) {
+            SampleCols &sc = ds.samples[s_of[i]];
+            const uint64_t seq_bytes = 16ull * (blk_at[i + 1] - blk_at[i]) + 32ull;
+            uint8_t *nseq = static_cast<uint8_t *>(colbuf) + col_at[i], *nqual = nseq + seq_bytes;
+            HIP_TRY(hipMemsetAsync(nseq, 0xff, seq_bytes, st));
+            HIP_TRY(hipMemsetAsync(nqual, ones ? 0xff : 0, seq_bytes / 4, st));
+            if (sc.n_dev_pieces) {
+                hipLaunchKernelGGL(msnv_fin_dense_copy, grid_for(sc.n_dev_pieces * 4, 256), dim3(256), 0, st, R.hdr + sc.dev_piece0, (unsigned long long)sc.n_dev_pieces,
+                                   d_off.as<uint32_t>() + sc.dev_piece0, sc.d_seq, sc.d_qual, nseq, nqual, ones ? 1u : 0u);
+                HIP_TRY(hipGetLastError());
+            }
+        }
+        HIP_TRY(hipStreamSynchronize(st));
+        for (size_t i = 0; i < s_of.size(); ++i) {
+            SampleCols &sc = ds.samples[s_of[i]];
+            const uint64_t seq_bytes = 16ull * (blk_at[i + 1] - blk_at[i]) + 32ull;
+            sc.d_seq = static_cast<uint8_t *>(colbuf) + col_at[i]; sc.d_qual = sc.d_seq + seq_bytes; sc.d_seq_bytes = seq_bytes;
+            sc.d_blk = static_cast<uint32_t *>(blkbuf) + blk_at[i]; sc.n_dev_blk = blk_at[i + 1] - blk_at[i];
+            ++T.n_dense_samples;
+        }
+    }
+    return MSNV_OK;
+}
+
+int devpack_copy_blocks(const SampleCols &sc, uint32_t *dst, void *stream) {
+    if (sc.n_dev_blk) HIP_TRY(hipMemcpyAsync(dst, sc.d_blk, sc.n_dev_blk * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return MSNV_OK;
+}
+
 int devpack_finish(msnv_dataset &ds) {
     if (!ds.dp.ready && ds.dp.round_bufs.empty()) return MSNV_OK;
     if (ds.ctx) HIP_TRY(hipStreamSynchronize((hipStream_t)ds.ctx->stream));

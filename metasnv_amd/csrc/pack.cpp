@@ -815,7 +815,7 @@ int finalize_dataset(msnv_dataset &ds) {
         if (fast) {
             uint64_t np = 0, nb = 0;
             for (const SampleCols &sc : ds.samples) { np += sc.n_dev_pieces; nb += sc.n_pileup_bases; }
-            if (layout_dense(np, nb)) fast = false;
+            if (layout_dense(np, nb)) if (const char *e = getenv("MSNV_DENSE_RELAYOUT")) if (e[0] == 'h') fast = false;      // (the dense re-layout on host staging: tests compare the two)
             // deep (sample, tile) runs: their exact depth, and -- where a run really is that deep -- its pieces dealt into groups and the sample's
             // columns re-laid, by kernels (devpack.hip: devfin_deep_runs; MSNV_DEEP_RELOCATE=0, a host-only experiment, takes the host loops)
             const uint32_t split_at = deep_split_at();
@@ -933,8 +933,9 @@ int finalize_dataset(msnv_dataset &ds) {
     for (const SampleCols &sc : ds.samples) { all_pieces += fast ? (size_t)sc.n_dev_pieces : sc.hdr.size(); all_bases += sc.n_pileup_bases; }
     const bool dense = layout_dense(all_pieces, all_bases);
     d->dense = dense;
-    if (dense) {
-        // (the dense re-layout still runs on host staging: device-packed samples come back for it)
+    if (dense && fast) {
+        if (int rc = devfin_dense(ds)) return rc;                    // devpack.hip: block streams, descriptors and run tables of every sample, in HBM
+    } else if (dense) {
         for (size_t s = 0; s < S; ++s) if (ds.samples[s].on_device) { if (int rc = dev_set_device(device_id)) return rc; if (int rc = devpack_sample_to_host(ds.samples[s])) return rc; }
         parallel_for(S, [&](size_t s) {
             SampleCols &sc = ds.samples[s];
@@ -945,7 +946,7 @@ int finalize_dataset(msnv_dataset &ds) {
     }
     std::vector<uint64_t> rbase(S + 1, 0), sbase(S + 1, 0), bbase(S + 1, 0);
     for (size_t s = 0; s < S; ++s) {
-        bbase[s + 1] = bbase[s] + ds.samples[s].blk.size();
+        bbase[s + 1] = bbase[s] + (fast ? (size_t)ds.samples[s].n_dev_blk : ds.samples[s].blk.size());
         rbase[s + 1] = rbase[s] + (fast ? (size_t)ds.samples[s].n_dev_pieces : ds.samples[s].hdr.size());
         const size_t seq_bytes = ds.samples[s].on_device ? (size_t)ds.samples[s].d_seq_bytes : ds.samples[s].seq.size();
         sbase[s + 1] = sbase[s] + ((seq_bytes + 15) & ~(size_t)15);
@@ -1291,9 +1292,11 @@ int finalize_dataset(msnv_dataset &ds) {
         if (int rc = upload_vec(&d->s_read_base, rbase, &d->device_bytes)) return rc;
         if (int rc = upload_vec(&d->s_seq_base, sbase, &d->device_bytes)) return rc;
         if (int rc = dev_alloc((void **)&d->hdr, (rbase[S] + 1) * sizeof(ReadHdr), &d->device_bytes)) return rc;
+        if (int rc = devfin_headers(ds, *d, rbase)) return rc;
+    }
+    if (fast && !dense) {
         if (int rc = dev_alloc((void **)&d->hdr4, (rbase[S] + 4) * sizeof(uint32_t), &d->device_bytes)) return rc;
         if (int rc = dev_memset(d->hdr4, 0, (rbase[S] + 4) * sizeof(uint32_t))) return rc;
-        if (int rc = devfin_headers(ds, *d, rbase)) return rc;
         std::vector<uint32_t> narrow_pairs, counts, cbase;
         for (uint32_t wi = 0; wi < d->n_work_narrow; ++wi) for (uint32_t k = work[wi].pair_lo; k < work[wi].pair_hi; ++k) narrow_pairs.push_back(k);
         if (int rc = devfin_chunk_counts(ds, *d, narrow_pairs, counts)) return rc;
@@ -1440,7 +1443,8 @@ int finalize_dataset(msnv_dataset &ds) {
                 SampleCols &sc = ds.samples[s];
                 int rc = fast ? MSNV_OK : dev_upload(d->hdr + rbase[s], sc.hdr.data(), sc.hdr.size() * sizeof(ReadHdr));
                 if (fast) {
-                    // (headers and 4-byte headers were built in HBM)
+                    // (headers and 4-byte headers were built in HBM; so were the block descriptors of the dense layout)
+                    if (dense) rc = devpack_copy_blocks(sc, d->blk + bbase[s], ds.ctx ? ds.ctx->stream : nullptr);
                 } else if (!rc && dense) {
                     rc = dev_upload(d->blk + bbase[s], sc.blk.data(), sc.blk.size() * sizeof(uint32_t));
                 } else if (!rc && HDR4) {

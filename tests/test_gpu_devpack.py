@@ -121,10 +121,10 @@ def test_sparse_cohort_and_merged_groups_same_columns():
         _same_dataset(syn.names, syn.lengths, syn.seqs, samples, many=True, check_oracle=False)
 
 
-def test_deep_runs_are_dealt_into_groups_on_the_device_and_dense_layouts_on_the_host():
+def test_deep_runs_are_dealt_into_groups_and_short_reads_into_block_streams_on_the_device():
     """(sample, tile) runs deeper than the byte bins hold (pack.cpp: split_deep_runs): exact sweep, round-robin groups, header permutation and
-    the re-layout of the sample's columns run as kernels (devpack.hip: devfin_deep_runs) and give the host stage's bytes; the dense block
-    layout of short reads still re-lays on host staging."""
+    the re-layout of the sample's columns run as kernels (devpack.hip: devfin_deep_runs) and give the host stage's bytes; so does the dense
+    block layout of short reads (pack.cpp: relayout_dense; devpack.hip: devfin_dense) -- descriptors, columns and run tables."""
     syn, samples = synth_case(n_species=1, contig_len=4000, n_samples=3, mean_cov=300.0, sigma_cov=0.3, snv_density=0.02, seed=27)      # runs deeper than 192: dealt into groups
     _same_dataset(syn.names, syn.lengths, syn.seqs, samples)
     with _env(MSNV_PACK="device"):
@@ -137,8 +137,23 @@ def test_deep_runs_are_dealt_into_groups_on_the_device_and_dense_layouts_on_the_
     with _env(MSNV_SPLIT_AT="40", MSNV_GROUP_DEPTH="24"):                                                        # (many groups per run; some runs only look deep)
         syn2, samples2 = synth_case(n_species=2, contig_len=5000, n_samples=4, mean_cov=45.0, sigma_cov=0.6, snv_density=0.02, seed=29)
         _same_dataset(syn2.names, syn2.lengths, syn2.seqs, samples2)
-    syn, samples = synth_case(n_species=2, contig_len=5000, n_samples=4, mean_cov=12.0, read_len=36, snv_density=0.02, seed=28)   # short reads: dense block layout
-    _same_dataset(syn.names, syn.lengths, syn.seqs, samples)
+    # short reads: dense block layout (odd and even lengths, indels cut the reads into pieces of every length)
+    for read_len, seed, kw in ((36, 28, {}), (35, 30, dict(min_baseq=0)), (51, 31, dict(min_baseq=30)), (20, 32, {})):
+        syn, samples = synth_case(n_species=2, contig_len=5000, n_samples=4, mean_cov=12.0, read_len=read_len, snv_density=0.02, frac_indel_reads=0.3, seed=seed)
+        _same_dataset(syn.names, syn.lengths, syn.seqs, samples, params=core.default_params(**kw) if kw else None)
+    with _env(MSNV_PACK="device"):
+        ctx = core.Context(0)
+        ds = core.Dataset(ctx, syn.names, syn.lengths, syn.seqs)
+        ds.add_samples_records(samples)
+        ds.finalize()
+        assert ds.pack_stats()["dense_samples"] == len(samples) and ds.column("blk").size > 0
+        ds.close(); ctx.close()
+    with _env(MSNV_SPLIT_AT="40", MSNV_GROUP_DEPTH="24"):                                                        # deep runs of short reads: dealt first, then laid out
+        syn3, samples3 = synth_case(n_species=1, contig_len=4000, n_samples=3, mean_cov=60.0, read_len=40, sigma_cov=0.4, snv_density=0.02, seed=33)
+        _same_dataset(syn3.names, syn3.lengths, syn3.seqs, samples3)
+    with _env(MSNV_LAYOUT="dense"):                                                                              # long reads forced into blocks: pieces of up to four blocks
+        syn4, samples4 = synth_case(n_species=2, contig_len=6000, n_samples=3, mean_cov=15.0, snv_density=0.02, seed=34)
+        _same_dataset(syn4.names, syn4.lengths, syn4.seqs, samples4)
 
 
 def test_many_streams_one_round_and_device_pointers():
