@@ -468,6 +468,8 @@ typedef struct {
     char     *header_text;
 } msnv_bam_data;
 int  msnv_bam_read(const char *bam_path, msnv_bam_data *out);
+/* ... the header alone (records = NULL): only the leading BGZF blocks are inflated (what `samtools view -H` reads, metaSNV.py:88). */
+int  msnv_bam_read_header(const char *bam_path, msnv_bam_data *out);
 void msnv_bam_data_free(msnv_bam_data *d);
 /* Writes a BAM (BGZF) from a header and a raw record stream (synthetic inputs, tests). */
 int  msnv_bam_write(const char *bam_path, const char *header_text, int32_t n_contigs,

@@ -9,3 +9,7 @@ from metasnv_amd.cli import main  # noqa: E402
 
 if __name__ == "__main__":
     main()
+    # every output file is closed by now (cli.py); leaving through the interpreter's teardown would unmap gigabytes of host staging buffer by
+    # buffer and shut the HIP runtime down allocation by allocation -- 0.2 s of a 1.2 s job.  The kernel takes the address space back in one go.
+    sys.stdout.flush(); sys.stderr.flush()
+    os._exit(0)

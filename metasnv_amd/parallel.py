@@ -561,14 +561,16 @@ def resident_project_run(ctx, first_bam, fasta_path, bam_paths, params, batch=1,
     # ctx may be a zero-argument callable that returns the context when it is first needed (cli.py creates it on a thread of its own:
     # the HIP runtime takes ~0.5 s to come up, which a one-process run spends reading and packing BAMs with host threads)
     lazy_ctx = callable(ctx)
+    t_open = time.perf_counter()
     ds = make_dataset() if make_dataset else core.Dataset.from_files(None if lazy_ctx else ctx, first_bam, fasta_path, params)
+    t_open = time.perf_counter() - t_open
     names, lengths = ds.names, ds.lengths
     owner = None
     if species_weight is not None or _dist is None:
         owner = shard_contigs(names, lengths, _world, species_weight)
         if _world > 1:
             ds.set_contig_mask([o == _rank for o in owner])
-    metrics = {"rank": _rank, "world": _world}
+    metrics = {"rank": _rank, "world": _world, "open_dataset_s": t_open}
     res = {"names": names, "lengths": lengths, "n_samples": len(bam_paths), "metrics": metrics, "acc": None}
     try:
         t0 = time.perf_counter()
@@ -595,18 +597,22 @@ def resident_project_run(ctx, first_bam, fasta_path, bam_paths, params, batch=1,
             metrics["pack_on_device"] = ds.pack_stats()
         gstats = {}
         if want_coverage:
+            t0 = time.perf_counter()
             metrics["coverage"] = ds.coverage_run()
+            metrics["coverage_run_s"] = time.perf_counter() - t0
             t0 = time.perf_counter()
             res["acc"] = gather_coverage_root(None, gstats, rows=ds.coverage_rows(), shape=(len(bam_paths), len(names)))
             metrics["gather_coverage_s"] = time.perf_counter() - t0
         if after_coverage:
             after_coverage(res)
         err = None
+        t0 = time.perf_counter()
         try:
             metrics["pileup"] = run_passes(ds) if run_passes else ds.run()
         except Exception as e:                               # noqa: BLE001
             err = e
         agree(err, "the calling pass ran")
+        metrics["calling_pass_s"] = time.perf_counter() - t0
         t0 = time.perf_counter()
         sites, row_off, cell_sample, cells = ds.results_cells()
         ann = None
@@ -625,7 +631,9 @@ def resident_project_run(ctx, first_bam, fasta_path, bam_paths, params, batch=1,
         metrics["inflated_record_bytes_per_rank"] = [int(x[0]) for x in infl]
         metrics["pileup_bases_per_rank"] = [int(x[1]) for x in infl]
     finally:
+        t0 = time.perf_counter()
         ds.close()
+        metrics["close_dataset_s"] = time.perf_counter() - t0
     return res
 
 

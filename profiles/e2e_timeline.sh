@@ -31,7 +31,7 @@ done
 python3 - <<PY
 import json
 m = json.loads(open("$W/m.jsonl").read().strip().splitlines()[-1])
-for k in ("feed_s", "wait_for_context_s", "finalize_s", "gather_coverage_s", "gather_sites_s"):
+for k in ("open_dataset_s", "feed_s", "wait_for_context_s", "finalize_s", "coverage_run_s", "gather_coverage_s", "calling_pass_s", "gather_sites_s", "close_dataset_s"):
     print(k, m.get(k))
-print("cli_wall", m.get("cli_wall")); print("host_timers", m.get("host_timers")); print("pack", m.get("pack_on_device"))
+print("pileup", m.get("pileup")); print("cli_wall", m.get("cli_wall"), "(process_age_at_end_s: seconds since exec when the last output file was closed; the rest of the wall clock above is teardown)"); print("host_timers", m.get("host_timers")); print("pack", m.get("pack_on_device"))
 PY
