@@ -356,7 +356,9 @@ def strong_run(a, rank, world, local, dist, brief=False):
         "gather": {"to": "rank 0", "sites_total": n_sites, "cells_total": int(len(res["cells"])), "bytes_received_by_rank0": int(m["gather_bytes_received"]),
                    "dense_form_would_be_bytes": dense_bytes, "seconds_sites_per_rank": [float(r[10]) for r in allr], "seconds_coverage_per_rank": [float(r[9]) for r in allr],
                    "sites_per_rank": [int(r[5]) for r in allr], "cells_per_rank": [int(r[6]) for r in allr]},
-        "host": {"wall_s_whole_run": t_all, "device_bytes_per_rank": [int(r[13]) for r in allr], "host_threads_per_rank": threads},
+        "host": {"wall_s_whole_run": t_all, "device_bytes_per_rank": [int(r[13]) for r in allr], "host_threads_per_rank": threads,
+                 # rank 0's feed, split: the synthetic generator stands where the BAM decoder stands in a real run; deal + exchange + pack is the product's stage
+                 "feed_decode_s_rank0": m.get("decode_s"), "feed_deal_exchange_pack_s_rank0": m.get("deliver_s"), "pack_on_device_rank0": m.get("pack_on_device")},
     }
     if brief:
         for k in ("metric", "unit", "higher_is_better", "vs_baseline", "dtype", "data"):

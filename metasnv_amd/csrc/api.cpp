@@ -286,6 +286,10 @@ int dev_inflate_staging(msnv_ctx *ctx, uint64_t in_bytes, uint64_t out_bytes, ui
 void dev_inflate_release(msnv_ctx *ctx);
 void dev_inflate_release_device(msnv_ctx *ctx);
 int dev_inflate(msnv_ctx *ctx, uint64_t comp_bytes, const std::vector<InfBlock> &blocks, uint64_t out_bytes, std::vector<uint32_t> &status, double *ms_kernel);
+int dev_inflate_device_buffers(msnv_ctx *ctx, uint64_t in_bytes, uint64_t out_bytes);
+int dev_inflate_resident(msnv_ctx *ctx, const uint8_t *host_in, uint64_t comp_bytes, const std::vector<InfBlock> &blocks, const std::vector<uint32_t> &blk_in_file,
+                         uint32_t check_every, std::vector<uint32_t> &status, double *ms_kernel);
+int dev_inflate_patch(msnv_ctx *ctx, uint64_t out_off, const uint8_t *data, uint32_t n);
 }
 
 // BGZF files inflated on the device (inflate_k.hip).  The files of a batch are read by `threads` host threads straight into the
@@ -295,8 +299,14 @@ int dev_inflate(msnv_ctx *ctx, uint64_t comp_bytes, const std::vector<InfBlock> 
 // the error of a malformed file.  ext[k]: offset and size of file f0 + k in `out`.
 // counters (optional): [0] blocks, [1] blocks inflated on the host after all, [2] kernel microseconds, [3] inflated bytes.
 struct InflatedExt { uint64_t off, size; };
+// RESIDENT form (res != nullptr; the device pack's: add_bams_device_pack): the inflated bytes never leave HBM.  The files are read into
+// pageable memory (no pinning: a context's first gigabyte of pinned staging costs 0.25 s), the batch goes up as it is, every block's CRC-32
+// is checked by a kernel (inflate_k.hip: msnv_crc_blocks), only the status words come back; the BAM headers are read from the leading
+// blocks of every file by the host decoder (res->hdr / res->rec_off, per file of the batch); a block the device refused or that did not
+// check is inflated by the host decoder and patched into the device buffer.  consume() then gets out = nullptr and dev_valid = true.
+struct ResidentBatch { std::vector<BamHeader> hdr; std::vector<uint64_t> rec_off; };
 template <typename Consume>
-static int bgzf_read_files_device(msnv_ctx *ctx, const char *const *paths, int n, int threads, Consume consume, uint64_t counters[4]) {
+static int bgzf_read_files_device(msnv_ctx *ctx, const char *const *paths, int n, int threads, Consume consume, uint64_t counters[4], ResidentBatch *res = nullptr) {
     if (int rc = dev_set_device(ctx->device)) return rc;
     std::vector<uint64_t> fsize((size_t)n, 0);
     for (int i = 0; i < n; ++i) {
@@ -323,7 +333,10 @@ static int bgzf_read_files_device(msnv_ctx *ctx, const char *const *paths, int n
         // decoder instead -- the call must not fail where the host path would have worked (a multi-GB BAM sizes the staging to itself)
         bool host_batch = false;
         ByteBuf host_in, host_out;
-        if (int rc = dev_inflate_staging(ctx, ib, 0, &in_stage, &out)) {
+        if (res) {
+            if (!host_in.alloc(ib + 64)) return fail(MSNV_ENOMEM, "out of memory for %llu compressed bytes", (unsigned long long)ib);
+            in_stage = host_in.data();
+        } else if (int rc = dev_inflate_staging(ctx, ib, 0, &in_stage, &out)) {
             if (rc != MSNV_ENOMEM) return rc;
             fprintf(stderr, "libmsnv: no staging for the device inflate (%s); this batch is inflated on the host\n", msnv_last_error());
             clear_error();
@@ -380,7 +393,32 @@ static int bgzf_read_files_device(msnv_ctx *ctx, const char *const *paths, int n
             ob += (total[(size_t)k] + 15) & ~15ull;
             n_bytes += total[(size_t)k];
         }
-        if (!host_batch) {
+        if (res) {
+            // headers from the leading blocks (host decoder), one file per thread
+            res->hdr.assign((size_t)nf, BamHeader()); res->rec_off.assign((size_t)nf, 0);
+            std::atomic<int> nx{0}, herr{0};
+            std::vector<std::string> hmsg((size_t)nf);
+            auto hw = [&]() {
+                for (;;) {
+                    const int k = nx.fetch_add(1);
+                    if (k >= nf || herr.load()) break;
+                    int rc;
+                    try { rc = bam_header_from_blocks(in_stage + in_off[(size_t)k], blocks[(size_t)k], paths[f0 + k], res->hdr[(size_t)k], res->rec_off[(size_t)k]); }
+                    catch (const std::exception &e) { rc = fail(MSNV_ENOMEM, "%s: %s", paths[f0 + k], e.what()); }
+                    if (rc) { hmsg[(size_t)k] = msnv_last_error(); herr.store(rc); }
+                }
+            };
+            std::vector<std::thread> th;
+            for (int t = 0; t < std::max(1, std::min(threads, nf)); ++t) th.emplace_back(hw);
+            for (auto &t : th) t.join();
+            if (herr.load()) { for (const std::string &m : hmsg) if (!m.empty()) return fail(herr.load(), "%s", m.c_str()); return fail(herr.load(), "BAM header read failed"); }
+            if (int rc = dev_inflate_device_buffers(ctx, ib, ob)) {
+                if (rc != MSNV_ENOMEM) return rc;
+                fprintf(stderr, "libmsnv: no staging for the device inflate (%s); this batch is inflated on the host\n", msnv_last_error());
+                clear_error();
+                host_batch = true;
+            }
+        } else if (!host_batch) {
             uint8_t *same_in = nullptr;
             if (int rc = dev_inflate_staging(ctx, ib, ob, &same_in, &out)) {      // (the input staging does not move: it only grows when ib does)
                 if (rc != MSNV_ENOMEM) return rc;
@@ -395,9 +433,10 @@ static int bgzf_read_files_device(msnv_ctx *ctx, const char *const *paths, int n
         }
         std::vector<uint32_t> status;
         bool dev_valid = false;
+        const uint32_t check_every = inflate_check_every();       // (one reading for both decoders: msnv_internal.h)
         if (!host_batch) {
             HostTimerScope ts(HT_INFLATE_DEVICE_WALL);
-            if (int rc = dev_inflate(ctx, ib, list, ob, status, &ms)) {
+            if (int rc = res ? dev_inflate_resident(ctx, in_stage, ib, list, blk_in_file, check_every, status, &ms) : dev_inflate(ctx, ib, list, ob, status, &ms)) {
                 if (rc != MSNV_ENOMEM && rc != MSNV_EHIP) return rc;
                 fprintf(stderr, "libmsnv: the device inflate failed (%s); this batch is inflated on the host\n", msnv_last_error());
                 clear_error();
@@ -408,8 +447,7 @@ static int bgzf_read_files_device(msnv_ctx *ctx, const char *const *paths, int n
         // Every block's output is checked against the CRC-32 of its BGZF trailer, as htslib does for the reference's tools (a block that
         // does not check is handed to the host decoder like one the device refused); the host threads share the blocks.
         // MSNV_INFLATE_CHECK=n: every n-th block only (0 = none: benchmarks).
-        const uint32_t check_every = inflate_check_every();       // (one reading for both decoders: msnv_internal.h)
-        if (check_every) {
+        if (check_every && !(res && !host_batch)) {                // (resident batches were checked by msnv_crc_blocks)
             std::atomic<size_t> nxt{0};
             auto checker = [&]() {
                 HostTimerScope ts(HT_INFLATE_HOST);
@@ -428,7 +466,27 @@ static int bgzf_read_files_device(msnv_ctx *ctx, const char *const *paths, int n
             for (int t = 0; t < std::max(1, std::min<int>(threads, (int)(list.size() / 64) + 1)); ++t) th.emplace_back(checker);
             for (auto &t : th) t.join();
         }
-        {   // blocks the device refused (or all of them, for a host batch): the host decoder, shared by the host threads
+        if (res && !host_batch) {
+            // resident batch: the few blocks the device refused or that did not check are inflated by the host decoder and patched into HBM
+            std::vector<uint8_t> tmp;
+            uint64_t done = 0;
+            for (size_t e = 0; e < list.size(); ++e) {
+                if (!status[e]) continue;
+                HostTimerScope ts(HT_INFLATE_HOST);
+                ++done;
+                tmp.resize((size_t)list[e].out_size + 64);
+                bool ok = bgzf_inflate_block_host(in_stage + list[e].in_off, list[e].in_size, tmp.data(), list[e].out_size);
+                if (ok && check_every) {
+                    const uint8_t *trailer = in_stage + list[e].in_off + list[e].in_size;
+                    const uint32_t want = (uint32_t)trailer[0] | (uint32_t)trailer[1] << 8 | (uint32_t)trailer[2] << 16 | (uint32_t)trailer[3] << 24;
+                    ok = bgzf_crc32(tmp.data(), list[e].out_size) == want;
+                }
+                if (!ok) return fail(MSNV_EFORMAT, "%s: BGZF inflate failed (malformed DEFLATE stream or CRC-32 mismatch)", paths[f0 + origin[e]]);
+                if (int rc = dev_inflate_patch(ctx, list[e].out_off, tmp.data(), list[e].out_size)) return rc;
+            }
+            n_host += done;
+            dev_valid = true;
+        } else {   // blocks the device refused (or all of them, for a host batch): the host decoder, shared by the host threads
             std::atomic<size_t> nxt{0};
             std::atomic<int> bad{-1};
             std::atomic<uint64_t> done{0};
@@ -501,7 +559,7 @@ extern "C" int msnv_bgzf_inflate(msnv_ctx *ctx, const char *path, int32_t on_dev
 // 1.5 s, host decoder 0.4 s; profiles/r03d end-to-end).  So: device when the estimated host time (compressed bytes / threads x
 // ~90 MB/s per thread) exceeds the estimated device time (staging still to pin + both transfers at ~25 GB/s + a launch).
 // MSNV_INFLATE=host | zlib keeps everything on the host, MSNV_INFLATE=device forces the device whatever the size.
-static bool want_device_inflate(msnv_ctx *ctx, const char *const *paths, int n, int threads) {
+static bool want_device_inflate(msnv_ctx *ctx, const char *const *paths, int n, int threads, bool resident = false) {
     if (!ctx) return false;
     const char *e = getenv("MSNV_INFLATE");
     if (e) return e[0] == 'd';
@@ -517,7 +575,9 @@ static bool want_device_inflate(msnv_ctx *ctx, const char *const *paths, int n, 
     if (bytes < (64ull << 20)) return false;                       // the host decoder is done before the staging is set up
     const double batch_in = (double)std::max<uint64_t>(std::min<uint64_t>(bytes, 1024ull << 20), largest), batch_out = 3.6 * batch_in;
     const double to_pin = std::max(0.0, batch_in - (double)ctx->pin_in_cap) + std::max(0.0, batch_out - (double)ctx->pin_out_cap);
-    const double est_dev = to_pin * 0.25e-9 + (double)bytes * (1.0 + 3.6) / 25e9 + 0.02;
+    // (resident: add_bams_device_pack -- nothing is pinned, the compressed bytes go up from pageable memory at ~40 GB/s, the inflated bytes stay
+    // in HBM and are checked there; the kernel writes ~21 GB/s of output on a 160-BAM job: profiles/r04e_inflate_*)
+    const double est_dev = resident ? (double)bytes / 40e9 + 3.6 * (double)bytes / 21e9 + 0.03 : to_pin * 0.25e-9 + (double)bytes * (1.0 + 3.6) / 25e9 + 0.02;
     const double est_host = (double)bytes / ((double)std::max(1, threads) * 90e6);
     return est_dev < est_host;
 }
@@ -584,26 +644,27 @@ extern "C" int msnv_bam_records_many(msnv_ctx *ctx, const char *const *bam_paths
 // BAM files -> samples with the per-read stage on the device: the files are read and inflated group by group (host threads, or the device
 // inflate when the rule of want_device_inflate picks it), the record streams of a group go to HBM and are packed there (devpack.hip).
 static int add_bams_device_pack(msnv_dataset *ds, const char *const *bam_paths, int n, int nthreads) {
-    const bool inflate_on_device = want_device_inflate(ds->ctx, bam_paths, n, nthreads);
+    const bool inflate_on_device = want_device_inflate(ds->ctx, bam_paths, n, nthreads, true);
     if (inflate_on_device) {
         // the inflated bytes of a batch are in the context's device buffer (and, for the CRC check and the header parse, in its pinned
         // twin): the record streams are handed over where they lie in HBM
+        // (resident form of bgzf_read_files_device: the batch's bytes exist in HBM only, its headers were read from the files' leading blocks)
+        ResidentBatch rb;
         auto consume = [&](int f0, int f1, const uint8_t *out, const std::vector<InflatedExt> &ext, bool dev_valid) -> int {
             std::vector<const uint8_t *> ptrs; std::vector<uint64_t> sizes;
-            // (a batch with blocks the host decoder had to redo holds them in the pinned buffer only: it goes up from there)
+            // (a batch the host decoder had to take -- no room for it in HBM -- is in host memory: it goes up from there)
             const uint8_t *base = dev_valid ? static_cast<const uint8_t *>(ds->ctx->dev_out) : out;
             for (int i = f0; i < f1; ++i) {
-                BamHeader h; uint64_t rec_off = 0;
-                const uint8_t *data = out + ext[(size_t)(i - f0)].off; const uint64_t size = ext[(size_t)(i - f0)].size;
-                if (int rc = bam_parse_header_bytes(data, size, bam_paths[i], h, rec_off)) return rc;
-                if (int rc = check_header(*ds, h, bam_paths[i])) return rc;
+                const uint64_t size = ext[(size_t)(i - f0)].size, rec_off = rb.rec_off[(size_t)(i - f0)];
+                if (int rc = check_header(*ds, rb.hdr[(size_t)(i - f0)], bam_paths[i])) return rc;
+                if (rec_off > size) return fail(MSNV_EFORMAT, "%s: truncated BAM header", bam_paths[i]);
                 ptrs.push_back(base + ext[(size_t)(i - f0)].off + rec_off);
                 sizes.push_back(size - rec_off);
             }
             return add_streams_device(ds, ptrs.data(), sizes.data(), f1 - f0, dev_valid);
         };
         int rc;
-        try { uint64_t cnt[4]; rc = bgzf_read_files_device(ds->ctx, bam_paths, n, nthreads, consume, cnt); }
+        try { uint64_t cnt[4]; rc = bgzf_read_files_device(ds->ctx, bam_paths, n, nthreads, consume, cnt, &rb); }
         catch (const std::exception &e) { rc = fail(MSNV_ENOMEM, "device inflate: %s", e.what()); }
         return rc;
     }

@@ -301,19 +301,14 @@ int bam_read(const char *path, BamHeader &hdr, ByteBuf &buf, uint64_t &rec_off, 
     return bam_parse_header(buf, path, hdr, rec_off);
 }
 
-int bam_read_header(const char *path, BamHeader &hdr) {
-    // headers are small; inflate leading blocks until the contig table is complete
-    ByteBuf inb; size_t n_in = 0;
-    if (int rc = read_file(path, inb, n_in)) return rc;
-    const ConstBytes in{inb.data(), n_in};
-    std::vector<BlockRef> blocks;
-    uint64_t total = 0;
-    if (int rc = bgzf_index(in, path, blocks, total)) return rc;
+// The BAM header of a file whose compressed bytes are in memory (blocks: bgzf_index_bytes): headers are small, the leading blocks are
+// inflated until the contig table is complete.  rec_off = offset of the first alignment record in the inflated stream.
+int bam_header_from_blocks(const uint8_t *file_bytes, const std::vector<BgzfBlock> &blocks, const char *path, BamHeader &hdr, uint64_t &rec_off) {
     std::vector<uint8_t> u;
     for (const BlockRef &b : blocks) {
         size_t old = u.size();
         u.resize(old + b.out_size);
-        if (!inflate_block(in.data() + b.in_off, b.in_size, u.data() + old, b.out_size)) return fail(MSNV_EFORMAT, "%s: BGZF inflate failed", path);
+        if (!inflate_block(file_bytes + b.in_off, b.in_size, u.data() + old, b.out_size)) return fail(MSNV_EFORMAT, "%s: BGZF inflate failed", path);
         // try to parse
         if (u.size() >= 12 && memcmp(u.data(), "BAM\1", 4) == 0) {
             uint32_t l_text = ld_u32(u.data() + 4);
@@ -328,12 +323,22 @@ int bam_read_header(const char *path, BamHeader &hdr) {
                     off += 4ull + l_name + 4;
                     if (off > u.size()) ok = false;
                 }
-                if (ok) { uint64_t ro; return bam_parse_header(u, path, hdr, ro); }
+                if (ok) return bam_parse_header(u, path, hdr, rec_off);
             }
         }
     }
+    return bam_parse_header(u, path, hdr, rec_off);
+}
+
+int bam_read_header(const char *path, BamHeader &hdr) {
+    ByteBuf inb; size_t n_in = 0;
+    if (int rc = read_file(path, inb, n_in)) return rc;
+    const ConstBytes in{inb.data(), n_in};
+    std::vector<BlockRef> blocks;
+    uint64_t total = 0;
+    if (int rc = bgzf_index(in, path, blocks, total)) return rc;
     uint64_t ro;
-    return bam_parse_header(u, path, hdr, ro);
+    return bam_header_from_blocks(inb.data(), blocks, path, hdr, ro);
 }
 
 int bam_write(const char *path, const BamHeader &hdr, const uint8_t *records, uint64_t n, int level) {

@@ -356,6 +356,136 @@ void dev_inflate_release(msnv_ctx *ctx) {
     ctx->pin_in_cap = ctx->pin_out_cap = ctx->dev_in_cap = ctx->dev_out_cap = 0;
 }
 
+// ------------------------------------------------------------------------------------------ CRC-32 of the inflated blocks, on the device
+// htslib checks every BGZF block against the CRC-32 of its trailer (bgzf.c `[EXT]`; the reference's tools read through it); csrc/crc32.cpp
+// does that on host threads over a pinned copy of the output.  When the inflated bytes stay in HBM (the device pack takes them from there)
+// the check runs here: one wavefront per block, lane l runs the table-driven register (four bytes per step, four 256-entry tables in LDS
+// shared by the workgroup's four blocks) over bytes [1024 l, 1024 l + 1024) -- lane 0 from the all-ones register, the others from zero --
+// and moves its register behind the bytes that follow (the register update is linear: a register r followed by n zero bytes is
+// r * x^(8 n) mod P; zlib's crc32_combine is the same identity), the 64 registers are XOR-ed.  ~3 400 vector instructions per block.
+namespace {
+constexpr uint32_t CRC_POLY = 0xEDB88320u;      // reflected CRC-32 (ISO-HDLC), as in the BGZF / gzip trailer
+constexpr uint32_t CRC_SPAN = 1024;             // bytes per lane: 64 lanes cover a block of up to 64 KiB
+// a * b mod P, polynomials in reflected bit order (x^0 = bit 31)
+__host__ __device__ inline uint32_t crc_mulmod(uint32_t a, uint32_t b) {
+    uint32_t p = 0;
+    for (int i = 0; i < 32; ++i) { p ^= (a & 0x80000000u) ? b : 0u; a <<= 1; b = (b >> 1) ^ ((b & 1u) ? CRC_POLY : 0u); }
+    return p;
+}
+__global__ __launch_bounds__(256) void msnv_crc_blocks(const uint8_t *out, const uint8_t *in, const InfBlock *blocks, const uint32_t *blk_in_file, uint32_t n_blocks, uint32_t check_every,
+                                                       const uint32_t *xs /* x^(8 * 1024 k), k < 64 */, const uint32_t *xr /* x^(8 r), r <= 1024 */, uint32_t *status) {
+    __shared__ uint32_t T[4][256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    {   // slicing tables: T[0][i] = register after byte i from zero; T[k][i] = T[k-1][i] moved one byte on
+        uint32_t c = (uint32_t)tid;
+        for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1u) ? CRC_POLY : 0u);
+        T[0][tid] = c;
+        __syncthreads();
+        for (int k = 1; k < 4; ++k) { c = T[0][c & 0xffu] ^ (c >> 8); T[k][tid] = c; }
+        __syncthreads();
+    }
+    const uint32_t bi = blockIdx.x * 4u + (uint32_t)(tid >> 6);
+    if (bi >= n_blocks) return;
+    if (status[bi] != 0u || (check_every > 1u && blk_in_file[bi] % check_every)) return;      // refused by the inflate kernel (the host decoder takes it), or not checked
+    const InfBlock b = blocks[bi];
+    const uint32_t n = b.out_size, L = (n + CRC_SPAN - 1u) / CRC_SPAN;
+    uint32_t r = 0;
+    if ((uint32_t)lane < L) {
+        const uint8_t *p = out + b.out_off + (unsigned long long)CRC_SPAN * (uint32_t)lane;
+        const uint32_t len = min(CRC_SPAN, n - CRC_SPAN * (uint32_t)lane);
+        r = lane == 0 ? 0xffffffffu : 0u;
+        uint32_t i = 0;
+        for (; i + 4u <= len; i += 4u) {
+            uint32_t w; __builtin_memcpy(&w, p + i, 4);
+            r ^= w;
+            r = T[3][r & 0xffu] ^ T[2][(r >> 8) & 0xffu] ^ T[1][(r >> 16) & 0xffu] ^ T[0][r >> 24];
+        }
+        for (; i < len; ++i) r = T[0][(r ^ p[i]) & 0xffu] ^ (r >> 8);
+        if ((uint32_t)lane + 1u < L) {               // bytes behind mine: (L - 2 - lane) whole spans and the last lane's n - 1024 (L - 1)
+            r = crc_mulmod(r, xs[L - 2u - (uint32_t)lane]);
+            r = crc_mulmod(r, xr[n - CRC_SPAN * (L - 1u)]);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) r ^= (uint32_t)__shfl_xor((int)r, o);
+    if (lane == 0) {
+        const uint8_t *t = in + b.in_off + b.in_size;
+        const uint32_t want = (uint32_t)t[0] | (uint32_t)t[1] << 8 | (uint32_t)t[2] << 16 | (uint32_t)t[3] << 24;
+        if ((r ^ 0xffffffffu) != want) status[bi] = 2u;
+    }
+}
+}  // namespace
+
+// The device halves of the staging only (compressed batch in, inflated batch out): the resident path below needs no pinned memory.
+int dev_inflate_device_buffers(msnv_ctx *ctx, uint64_t in_bytes, uint64_t out_bytes) {
+    if (const char *e = getenv("MSNV_TEST_NO_STAGING")) if (e[0] == '1') return fail_quiet(MSNV_ENOMEM, "staging refused (MSNV_TEST_NO_STAGING=1)");
+    auto grow = [](void **p, uint64_t *cap, uint64_t need) -> int {
+        if (need <= *cap) return MSNV_OK;
+        if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
+        const uint64_t want = need + need / 4 + (1u << 20);
+        const hipError_t e = hipMalloc(p, want);
+        if (e != hipSuccess) { *p = nullptr; return fail(MSNV_ENOMEM, "device staging of %llu bytes for the device inflate: %s", (unsigned long long)want, hipGetErrorString(e)); }
+        *cap = want;
+        return MSNV_OK;
+    };
+    if (int rc = grow(&ctx->dev_in, &ctx->dev_in_cap, in_bytes + 64)) return rc;
+    return grow(&ctx->dev_out, &ctx->dev_out_cap, out_bytes + 64);
+}
+
+// A batch inflated AND checked on the device, the output left in ctx->dev_out: `host_in` (pageable) goes up, the blocks are inflated, every
+// checked block's CRC-32 is compared with its trailer (status 2: mismatch); only the status words come back.  blk_in_file: index of every
+// block inside its file (MSNV_INFLATE_CHECK counts per file).
+int dev_inflate_resident(msnv_ctx *ctx, const uint8_t *host_in, uint64_t comp_bytes, const std::vector<InfBlock> &blocks, const std::vector<uint32_t> &blk_in_file,
+                         uint32_t check_every, std::vector<uint32_t> &status, double *ms_kernel) {
+    hipStream_t st = (hipStream_t)ctx->stream;
+    status.assign(blocks.size(), 0u);
+    if (blocks.empty()) return MSNV_OK;
+    struct Buf { void *p = nullptr; ~Buf() { if (p) (void)hipFree(p); } } d_blk, d_st, d_bif, d_x;
+    std::vector<uint32_t> xpow(64 + CRC_SPAN + 1);
+    {   // x^(8 r) for r = 0 .. 1024, then x^(8 * 1024 k) for k = 0 .. 63
+        uint32_t v = 0x80000000u;
+        for (uint32_t r = 0; r <= CRC_SPAN; ++r) { xpow[64 + r] = v; for (int k = 0; k < 8; ++k) v = (v >> 1) ^ ((v & 1u) ? CRC_POLY : 0u); }
+        const uint32_t span = xpow[64 + CRC_SPAN];
+        xpow[0] = 0x80000000u;
+        for (uint32_t k = 1; k < 64; ++k) xpow[k] = crc_mulmod(xpow[k - 1], span);
+    }
+    HIP_TRY(hipMalloc(&d_blk.p, blocks.size() * sizeof(InfBlock)));
+    HIP_TRY(hipMalloc(&d_st.p, blocks.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&d_bif.p, blocks.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&d_x.p, xpow.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpyAsync(ctx->dev_in, host_in, comp_bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_blk.p, blocks.data(), blocks.size() * sizeof(InfBlock), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_bif.p, blk_in_file.data(), blocks.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_x.p, xpow.data(), xpow.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    hipError_t he = hipEventRecord(e0, st);
+    if (he == hipSuccess) {
+        hipLaunchKernelGGL(msnv_inflate_blocks, dim3((unsigned)blocks.size()), dim3(64), 0, st, (const uint8_t *)ctx->dev_in, (const InfBlock *)d_blk.p,
+                           (uint32_t)blocks.size(), (uint8_t *)ctx->dev_out, (uint32_t *)d_st.p);
+        he = hipGetLastError();
+    }
+    if (he == hipSuccess && check_every) {
+        hipLaunchKernelGGL(msnv_crc_blocks, dim3((unsigned)((blocks.size() + 3) / 4)), dim3(256), 0, st, (const uint8_t *)ctx->dev_out, (const uint8_t *)ctx->dev_in, (const InfBlock *)d_blk.p,
+                           (const uint32_t *)d_bif.p, (uint32_t)blocks.size(), check_every, (const uint32_t *)d_x.p, (const uint32_t *)d_x.p + 64, (uint32_t *)d_st.p);
+        he = hipGetLastError();
+    }
+    if (he == hipSuccess) he = hipEventRecord(e1, st);
+    if (he == hipSuccess) he = hipMemcpyAsync(status.data(), d_st.p, blocks.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+    if (he == hipSuccess) he = hipStreamSynchronize(st);
+    float t = 0;
+    if (he == hipSuccess) he = hipEventElapsedTime(&t, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (he != hipSuccess) return fail(MSNV_EHIP, "device inflate: %s", hipGetErrorString(he));
+    if (ms_kernel) *ms_kernel += t;
+    return MSNV_OK;
+}
+// one block the host decoder produced, into the batch's output in HBM (resident path: a block the device refused or that did not check)
+int dev_inflate_patch(msnv_ctx *ctx, uint64_t out_off, const uint8_t *data, uint32_t n) {
+    if (n) HIP_TRY(hipMemcpy(static_cast<uint8_t *>(ctx->dev_out) + out_off, data, n, hipMemcpyHostToDevice));
+    return MSNV_OK;
+}
+
 // Inflates `blocks` (offsets into the context's staging buffers, dev_inflate_staging) on the device; status[i] != 0: block i was refused.
 int dev_inflate(msnv_ctx *ctx, uint64_t comp_bytes, const std::vector<InfBlock> &blocks, uint64_t out_bytes, std::vector<uint32_t> &status, double *ms_kernel) {
     hipStream_t st = (hipStream_t)ctx->stream;

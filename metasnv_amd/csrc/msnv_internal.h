@@ -80,6 +80,7 @@ bool bgzf_inflate_block_host(const uint8_t *src, uint32_t n_in, uint8_t *dst, ui
 uint32_t bgzf_crc32(const uint8_t *data, uint32_t n);           // CRC-32 as in the BGZF trailer
 int bgzf_index_bytes(const uint8_t *data, size_t n, const char *path, std::vector<BgzfBlock> &blocks, uint64_t &total_out);   // `data` needs 16 readable bytes behind n
 int bam_parse_header_bytes(const uint8_t *data, size_t n, const char *path, BamHeader &hdr, uint64_t &rec_off);
+int bam_header_from_blocks(const uint8_t *file_bytes, const std::vector<BgzfBlock> &blocks, const char *path, BamHeader &hdr, uint64_t &rec_off);   // leading blocks inflated on the host
 int bgzf_write_all(const char *path, const uint8_t *data, uint64_t n, int level);
 
 // BAM = BGZF(magic, header text, contig table, records...)

@@ -373,6 +373,25 @@ def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=Non
     pending = [None]                                         # a failure of THIS rank while it appended a round (pack: ENOMEM, EDOMAIN ...)
     rounds = list(deal_samples(n, batch))
     k = 0
+    # where the wall seconds of the feed go (metrics): decoding (read + inflate, or a test's / benchmark's generator) apart from dealing,
+    # exchanging and packing -- a benchmark whose "decoder" is a synthetic generator reports the two separately
+    import time
+    split = {"decode_s": 0.0, "deliver_s": 0.0}
+    _decode_round, _deliver = decode_round, deliver
+
+    def decode_round(plan_round):                            # noqa: F811
+        t0 = time.perf_counter()
+        try:
+            return _decode_round(plan_round)
+        finally:
+            split["decode_s"] += time.perf_counter() - t0
+
+    def deliver(*a):                                         # noqa: F811
+        t0 = time.perf_counter()
+        try:
+            return _deliver(*a)
+        finally:
+            split["deliver_s"] += time.perf_counter() - t0
     if owner is None:
         # The contig owners are fixed by the reference's rule -- whole species, heaviest first, weight = genome length x coverage = aligned
         # bases (createOptimumSplit.py:46-62, which runs AFTER qaCompute has seen every BAM) -- from as many rounds as fit the planning
@@ -417,6 +436,8 @@ def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=Non
         base, plan_round = rounds[k]
         deliver(base, plan_round, *decode_round(plan_round))
         k += 1
+    if metrics is not None:
+        metrics.update(split)
     agree(pending[0], "the last round of records was appended")
     allstats = gather_fixed(stats)
     stats = np.maximum.reduce(allstats) if len(allstats) > 1 else stats      # every row is non-zero on exactly one rank

@@ -165,3 +165,54 @@ def test_device_inflate_on_crafted_streams_of_every_kind(tmp_path):
         n_same += res[0] is not None
     assert n_err > 10
     ctx.close()
+
+
+def test_resident_device_inflate_checks_every_block_in_hbm(tmp_path, monkeypatch):
+    """msnv_dataset_add_sample_bams with the device pack: the inflated bytes stay in HBM, every block's CRC-32 is checked there
+    (inflate_k.hip: msnv_crc_blocks) -- no host inflate at all for good files; a wrong trailer CRC is MSNV_EFORMAT (as the host decoder and
+    htslib have it), a corrupted payload too; MSNV_INFLATE_CHECK=0 lets the wrong trailer through."""
+    monkeypatch.setenv("MSNV_INFLATE", "device"); monkeypatch.setenv("MSNV_PACK", "device")
+    sp = core.synth_params(n_species=2, contig_len=30000, n_samples=4, mean_cov=12.0, frac_paired=0.3, snv_density=0.02, seed=13)
+    syn = core.Synth(sp)
+    fa = str(tmp_path / "ref.fa"); syn.write_fasta(fa)
+    paths = []
+    for i in range(sp.n_samples):
+        p = str(tmp_path / ("s%d.bam" % i))
+        core.write_bam(p, syn.names, syn.lengths, syn.sample_records(i), level=[6, 1, 0, 9][i]); paths.append(p)
+    ctx = core.Context(0)
+    t0 = core.host_timers()
+    ds = core.Dataset.from_files(ctx, paths[0], fa)
+    ds.add_sample_bams(paths, 3)
+    info = ds.finalize(); ds.run()
+    ds.write_calls(str(tmp_path / "c"), str(tmp_path / "i"), None, None)
+    t1 = core.host_timers()
+    assert t1["inflate_host_s"] - t0["inflate_host_s"] == 0.0 and t1["inflate_device_wall_s"] > t0["inflate_device_wall_s"]
+    assert ds.pack_stats()["records"] > 1000 and ds.pack_stats()["upload_wall_s"] < 0.5
+    ds.close()
+    from parity import run_oracle
+    want = run_oracle(syn.names, syn.lengths, syn.seqs, [syn.sample_records(i) for i in range(sp.n_samples)])
+    assert open(tmp_path / "c").read() == want[0] and info["n_pileup_bases"] == want[3]
+    # block 3 of the second file: wrong CRC in the trailer / flipped payload bits
+    raw = bytearray(open(paths[1], "rb").read())
+    off = 0
+    for _ in range(2):
+        off += (raw[off + 16] | raw[off + 17] << 8) + 1
+    bsize = (raw[off + 16] | raw[off + 17] << 8) + 1
+    for kind in ("crc", "payload"):
+        bad = bytearray(raw)
+        if kind == "crc":
+            bad[off + bsize - 8] ^= 0x01
+        else:
+            for k in (40, 41, 90):
+                bad[off + 18 + k] ^= 0x5a
+        badp = str(tmp_path / ("bad_%s.bam" % kind)); open(badp, "wb").write(bad)
+        ds = core.Dataset.from_files(ctx, paths[0], fa)
+        with pytest.raises(_lib.MsnvError) as e:
+            ds.add_sample_bams([paths[0], badp, paths[2]], 3)
+        assert e.value.code == _lib.EFORMAT
+        ds.close()
+    monkeypatch.setenv("MSNV_INFLATE_CHECK", "0")
+    ds = core.Dataset.from_files(ctx, paths[0], fa)
+    ds.add_sample_bams([paths[0], str(tmp_path / "bad_crc.bam"), paths[2]], 3)
+    assert ds.finalize()["n_pileup_bases"] > 0
+    ds.close(); ctx.close()
