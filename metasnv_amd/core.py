@@ -206,6 +206,10 @@ class Dataset:
         check(lib.msnv_pileup_run(self._h, C.byref(st)))
         return {k: getattr(st, k) for k, _ in RunStats._fields_}
 
+    def reserve_passes(self, n):
+        """Creates what a batch of n passes needs besides the passes (events, pinned counters: msnv_pileup_reserve)."""
+        check(lib.msnv_pileup_reserve(self._h, int(n)))
+
     def run_many(self, n, overlap=False):
         """n passes back to back, one host synchronisation; returns the list of per-pass stats.  overlap=True runs
         consecutive passes on two streams (the tail kernels of one pass under the pileup kernel of the next)."""

@@ -974,6 +974,14 @@ extern "C" int msnv_dataset_info_get(const msnv_dataset *ds, msnv_dataset_info *
 }
 
 // ------------------------------------------------------------------------------ pipeline
+namespace msnv { int dev_reserve_passes(DeviceCols &d, int n); }
+extern "C" int msnv_pileup_reserve(msnv_dataset *ds, int32_t n) {
+    clear_error();
+    if (!ds || !ds->finalized || n <= 0) return fail(MSNV_EINVAL, "msnv_pileup_reserve: dataset is not finalized or n <= 0");
+    if (int rc = dev_set_device(ds->ctx->device)) return rc;
+    return dev_reserve_passes(*ds->dev, n);
+}
+
 extern "C" int msnv_pileup_run_many(msnv_dataset *ds, int32_t n, int32_t overlap, msnv_run_stats *stats) {
     clear_error();
     if (!ds || !ds->finalized || n <= 0) return fail(MSNV_EINVAL, "msnv_pileup_run_many: dataset is not finalized or n <= 0");

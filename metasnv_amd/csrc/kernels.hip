@@ -2898,6 +2898,19 @@ static void swap_sets(DeviceCols &d) {
 // the chip with the tail kernels -- which is why bench.py measures the roofline on the non-overlapped form.  stats[i]: pileup-kernel time
 // of pass i from its own event pair (recorded after the cross-stream wait); ms_total = batch time / n.  On return the
 // primary set holds the last pass.
+// events and the pinned counter blocks of a batch of n passes are pooled in the dataset: creating ~4n events and a pinned buffer per call
+// costs about a millisecond of host time before the first pass is even enqueued (msnv_pileup_reserve does it ahead of a timed batch)
+int dev_reserve_passes(DeviceCols &d, int n) {
+    while (d.event_pool.size() < (size_t)4 * n + 2) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); d.event_pool.push_back(e); }
+    if (d.pinned_cnt_cap < (size_t)n) {
+        if (d.pinned_cnt) (void)hipHostFree(d.pinned_cnt);
+        d.pinned_cnt = nullptr; d.pinned_cnt_cap = 0;
+        if (hipHostMalloc((void **)&d.pinned_cnt, (size_t)n * CNT_WORDS * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return fail(MSNV_ENOMEM, "pinned host memory for %d counter blocks", n);
+        d.pinned_cnt_cap = (size_t)n;
+    }
+    return MSNV_OK;
+}
+
 int dev_run_pipeline_many(DeviceCols &d, const msnv_params &p, void *stream_, int n, bool overlap, msnv_run_stats *stats, RunCounts *counts) {
     if (n <= 0) return MSNV_OK;
     hipStream_t s0 = (hipStream_t)stream_, s1 = s0;
@@ -2908,17 +2921,9 @@ int dev_run_pipeline_many(DeviceCols &d, const msnv_params &p, void *stream_, in
         if (int rc = ensure_alt(d)) return rc;
     }
     const bool two = s1 != s0;
-    // events and the pinned counter blocks are pooled in the dataset: creating ~4n events and a pinned buffer per call
-    // costs about a millisecond of host time before the first pass is even enqueued
-    while (d.event_pool.size() < (size_t)4 * n + 2) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); d.event_pool.push_back(e); }
+    if (int rc = dev_reserve_passes(d, n)) return rc;
     hipEvent_t *ev = reinterpret_cast<hipEvent_t *>(d.event_pool.data());
     auto cleanup = [] {};
-    if (d.pinned_cnt_cap < (size_t)n) {
-        if (d.pinned_cnt) (void)hipHostFree(d.pinned_cnt);
-        d.pinned_cnt = nullptr; d.pinned_cnt_cap = 0;
-        if (hipHostMalloc((void **)&d.pinned_cnt, (size_t)n * CNT_WORDS * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return fail(MSNV_ENOMEM, "pinned host memory for %d counter blocks", n);
-        d.pinned_cnt_cap = (size_t)n;
-    }
     uint32_t *cnt = d.pinned_cnt;
     int rc = MSNV_OK;
     hipError_t he = hipSuccess;
