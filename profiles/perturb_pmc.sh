@@ -1,5 +1,6 @@
 #!/bin/bash
-# profiles/perturb_pmc.sh V1 V2 ... -- VALU / SALU / LDS instruction counts of the dominant kernel under MSNV_PERTURB=V (experiment build)
+# profiles/perturb_pmc.sh V1 V2 ... -- VALU / SALU / LDS instruction counts of the dominant kernel under MSNV_PERTURB=V (experiment build of
+# profiles/perturb_build.py, selected with MSNV_LIBRARY)
 export TMPDIR=/tmp
 for V in "$@"; do
   OUT=gpurun_out/pp_$V; mkdir -p $OUT
