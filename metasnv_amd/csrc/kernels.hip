@@ -496,13 +496,11 @@ __device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_
             const uint32_t word = L.al[N_PPT * tid + j];
             L.al[N_PPT * tid + j] = 0u;
             const uint32_t gpos = t0 + N_PPT * tid + j;
-#pragma unroll
-            for (uint32_t x = 0; x < 4; ++x) {
+            for (uint32_t m = nz_bytes(word); m; m &= m - 1u) {      // (the non-zero alleles of the position, usually one: see below)
+                const uint32_t x = (uint32_t)__builtin_ctz(m) >> 3;
                 const uint32_t n = (word >> (8u * x)) & 0xffu;
-                if (n) {
-                    tot_add_one(a.tot + 4ull * t0, tmode, N_PPT * tid + j, x, n);
-                    if (n >= a.min_snvs) atomicOr(&a.unc_bits[gpos >> 5], 1u << (gpos & 31u));
-                }
+                tot_add_one(a.tot + 4ull * t0, tmode, N_PPT * tid + j, x, n);
+                if (n >= a.min_snvs) atomicOr(&a.unc_bits[gpos >> 5], 1u << (gpos & 31u));
             }
         }
         return;
@@ -532,20 +530,20 @@ __device__ __forceinline__ void narrow_pass(LDS &L, const PileupArgs &a, uint32_
         const uint32_t word = L.al[N_PPT * tid + j];
         L.al[N_PPT * tid + j] = 0u;
         const uint32_t gpos = t0 + N_PPT * tid + j;
-#pragma unroll
-        for (uint32_t x = 0; x < 4; ++x) {
+        // (a position with mismatches nearly always holds ONE allele: a walk over the non-zero bytes instead of four unrolled tests, each of
+        // which the wavefront issues in full as soon as one of its lanes holds that allele -- round 4)
+        for (uint32_t m = nz_bytes(word); m; m &= m - 1u) {
+            const uint32_t x = (uint32_t)__builtin_ctz(m) >> 3;
             const uint32_t n = (word >> (8u * x)) & 0xffu;
-            if (n) {
-                tot_add_one(a.tot + 4ull * t0, tmode, N_PPT * tid + j, x, n);
-                // the individual rule's "some sample holds >= t reads of x"; a sample that was split into several pairs may reach
-                // the threshold only in sum: those positions are marked and decided from the per-sample records (msnv_decide_sites)
-                if (n >= a.min_snvs) atomicOr(&a.ind4[gpos >> 3], 1u << (4u * (gpos & 7u) + x));
-                else if (split) atomicOr(&a.unc_bits[gpos >> 5], 1u << (gpos & 31u));
-                const Pair32 e{gpos, sample << 18 | x << 16 | n};
-                if (direct) { if (slot < a.cap_events) a.events[slot] = e; }
-                else L.ev[slot] = e;
-                ++slot;
-            }
+            tot_add_one(a.tot + 4ull * t0, tmode, N_PPT * tid + j, x, n);
+            // the individual rule's "some sample holds >= t reads of x"; a sample that was split into several pairs may reach
+            // the threshold only in sum: those positions are marked and decided from the per-sample records (msnv_decide_sites)
+            if (n >= a.min_snvs) atomicOr(&a.ind4[gpos >> 3], 1u << (4u * (gpos & 7u) + x));
+            else if (split) atomicOr(&a.unc_bits[gpos >> 5], 1u << (gpos & 31u));
+            const Pair32 e{gpos, sample << 18 | x << 16 | n};
+            if (direct) { if (slot < a.cap_events) a.events[slot] = e; }
+            else L.ev[slot] = e;
+            ++slot;
         }
     }
 }
