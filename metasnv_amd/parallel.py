@@ -313,9 +313,17 @@ def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=Non
         per_dest = [[] for _ in range(_world)]              # per destination rank: (sample, bytes) in sample order
         if failure is None:
             try:
-                for i, rec in zip(mine, decoded):
+                # one walk over every sample's records (msnv_records_partition: owner of every record's contig, qaCompute's statistics); the
+                # library releases the GIL, so the round's samples are dealt side by side (one after the other this was 0.3 s per GB and rank)
+                deal = lambda rec: core.partition_records(rec, owner, _world, cov_min_mapq)
+                if len(decoded) > 1:
+                    from concurrent.futures import ThreadPoolExecutor
+                    with ThreadPoolExecutor(max_workers=min(len(decoded), max(1, batch))) as ex:
+                        dealt = list(ex.map(deal, decoded))
+                else:
+                    dealt = [deal(rec) for rec in decoded]
+                for i, rec, (parts, st) in zip(mine, decoded, dealt):
                     inflated += int(rec.size)
-                    parts, st = core.partition_records(rec, owner, _world, cov_min_mapq)
                     stats[i] = st
                     for q in range(_world):
                         per_dest[q].append(parts[q])
