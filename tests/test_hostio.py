@@ -104,3 +104,25 @@ def test_bgzf_crc_of_every_block_is_checked(tmp_path):
         assert core.read_bam(bad)["records"].size > 0
     finally:
         del os.environ["MSNV_INFLATE_CHECK"]
+
+
+def test_header_only_read_inflates_the_leading_blocks_only(tmp_path):
+    """msnv_bam_read_header (what `samtools view -H` reads, metaSNV.py:88): names, lengths and text of msnv_bam_read without the records --
+    also when the header spans several BGZF blocks, and when a LATER block of the file is corrupt (it is never looked at)."""
+    names = ["contig_%05d_with_a_long_name_to_fill_blocks" % i for i in range(4000)]      # ~200 KB of contig table: four blocks
+    lengths = [1000 + i for i in range(4000)]
+    rec = bt.records(*[bt.make_record(7, 10 + i, "50M", "A" * 50, name="r%d" % i) for i in range(3000)])
+    p = str(tmp_path / "big_header.bam")
+    core.write_bam(p, names, lengths, rec)
+    full, hdr = core.read_bam(p), core.read_bam(p, records=False)
+    assert hdr["names"] == names and hdr["lengths"] == lengths and hdr["header_text"] == full["header_text"] and "records" not in hdr
+    raw = bytearray(open(p, "rb").read())
+    off, n = 0, 0
+    while off < len(raw) - 28:                               # the last data block: flip payload bits
+        last = off; off += (raw[off + 16] | raw[off + 17] << 8) + 1; n += 1
+    assert n > 5
+    raw[last + 30] ^= 0xff; raw[last + 31] ^= 0xff
+    bad = str(tmp_path / "bad_tail.bam"); open(bad, "wb").write(raw)
+    assert core.read_bam(bad, records=False)["names"] == names
+    with pytest.raises(core._lib.MsnvError):
+        core.read_bam(bad)
