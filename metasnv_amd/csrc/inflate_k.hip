@@ -325,9 +325,14 @@ int dev_inflate_staging(msnv_ctx *ctx, uint64_t in_bytes, uint64_t out_bytes, ui
     if (const char *e = getenv("MSNV_TEST_NO_STAGING")) if (e[0] == '1') return fail_quiet(MSNV_ENOMEM, "staging refused (MSNV_TEST_NO_STAGING=1)");   // tests: the host takes the batch
     auto grow = [](void **p, uint64_t *cap, uint64_t need, bool host) -> int {
         if (need <= *cap) return MSNV_OK;
-        if (*p) { if (host) (void)hipHostFree(*p); else (void)hipFree(*p); *p = nullptr; *cap = 0; }
+        if (*p) { if (host) (void)hipHostFree(*p); else dev_free(*p); *p = nullptr; *cap = 0; }
         const uint64_t want = need + need / 4 + (1u << 20);
-        const hipError_t e = host ? hipHostMalloc(p, want, hipHostMallocDefault) : hipMalloc(p, want);
+        if (!host) {
+            if (dev_alloc(p, want, nullptr) != MSNV_OK) { *p = nullptr; return fail(MSNV_ENOMEM, "device staging of %llu bytes for the device inflate", (unsigned long long)want); }
+            *cap = want;
+            return MSNV_OK;
+        }
+        const hipError_t e = hipHostMalloc(p, want, hipHostMallocDefault);
         if (e != hipSuccess) { *p = nullptr; return fail(MSNV_ENOMEM, "%s staging of %llu bytes for the device inflate: %s", host ? "pinned host" : "device", (unsigned long long)want, hipGetErrorString(e)); }
         *cap = want;
         return MSNV_OK;
@@ -342,16 +347,16 @@ int dev_inflate_staging(msnv_ctx *ctx, uint64_t in_bytes, uint64_t out_bytes, ui
 // The DEVICE half of the staging only (what a finished msnv_dataset_add_sample_bams / msnv_bam_records_many call gives back before the
 // dataset is uploaded: compressed + inflated bytes of a batch would otherwise sit in HBM next to the columns); the pinned half stays.
 void dev_inflate_release_device(msnv_ctx *ctx) {
-    if (ctx->dev_in) (void)hipFree(ctx->dev_in);
-    if (ctx->dev_out) (void)hipFree(ctx->dev_out);
+    if (ctx->dev_in) dev_free(ctx->dev_in);
+    if (ctx->dev_out) dev_free(ctx->dev_out);
     ctx->dev_in = ctx->dev_out = nullptr;
     ctx->dev_in_cap = ctx->dev_out_cap = 0;
 }
 void dev_inflate_release(msnv_ctx *ctx) {
     if (ctx->pin_in) (void)hipHostFree(ctx->pin_in);
     if (ctx->pin_out) (void)hipHostFree(ctx->pin_out);
-    if (ctx->dev_in) (void)hipFree(ctx->dev_in);
-    if (ctx->dev_out) (void)hipFree(ctx->dev_out);
+    if (ctx->dev_in) dev_free(ctx->dev_in);
+    if (ctx->dev_out) dev_free(ctx->dev_out);
     ctx->pin_in = ctx->pin_out = ctx->dev_in = ctx->dev_out = nullptr;
     ctx->pin_in_cap = ctx->pin_out_cap = ctx->dev_in_cap = ctx->dev_out_cap = 0;
 }
@@ -419,17 +424,18 @@ __global__ __launch_bounds__(256) void msnv_crc_blocks(const uint8_t *out, const
 // The device halves of the staging only (compressed batch in, inflated batch out): the resident path below needs no pinned memory.
 int dev_inflate_device_buffers(msnv_ctx *ctx, uint64_t in_bytes, uint64_t out_bytes) {
     if (const char *e = getenv("MSNV_TEST_NO_STAGING")) if (e[0] == '1') return fail_quiet(MSNV_ENOMEM, "staging refused (MSNV_TEST_NO_STAGING=1)");
-    auto grow = [](void **p, uint64_t *cap, uint64_t need) -> int {
-        if (need <= *cap) return MSNV_OK;
-        if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
-        const uint64_t want = need + need / 4 + (1u << 20);
-        const hipError_t e = hipMalloc(p, want);
-        if (e != hipSuccess) { *p = nullptr; return fail(MSNV_ENOMEM, "device staging of %llu bytes for the device inflate: %s", (unsigned long long)want, hipGetErrorString(e)); }
+    // (through dev_alloc: with MSNV_GUARD_ALLOC=1 the buffers are exact and end at the end of their mapping -- tests/test_gpu_guard.py)
+    const bool exact = [] { const char *e = getenv("MSNV_GUARD_ALLOC"); return e && e[0] == '1'; }();
+    auto grow = [&](void **p, uint64_t *cap, uint64_t need) -> int {
+        if (need <= *cap && !exact) return MSNV_OK;
+        if (*p) { dev_free(*p); *p = nullptr; *cap = 0; }
+        const uint64_t want = exact ? need : need + need / 4 + (1u << 20);
+        if (int rc = dev_alloc(p, want, nullptr)) { *p = nullptr; return rc == MSNV_ENOMEM ? rc : fail(MSNV_ENOMEM, "device staging of %llu bytes for the device inflate", (unsigned long long)want); }
         *cap = want;
         return MSNV_OK;
     };
-    if (int rc = grow(&ctx->dev_in, &ctx->dev_in_cap, in_bytes + 64)) return rc;
-    return grow(&ctx->dev_out, &ctx->dev_out_cap, out_bytes + 64);
+    if (int rc = grow(&ctx->dev_in, &ctx->dev_in_cap, in_bytes + 8)) return rc;       // (+8: the trailer of the last block is read as four bytes behind its payload; files carry 16 bytes of slack anyway)
+    return grow(&ctx->dev_out, &ctx->dev_out_cap, out_bytes + 8);
 }
 
 // A batch inflated AND checked on the device, the output left in ctx->dev_out: `host_in` (pageable) goes up, the blocks are inflated, every

@@ -20,6 +20,10 @@ CASES = {
                          dict(min_coverage=3, calling_threshold=3)),
     "noisy_planes": (dict(n_species=2, contig_len=12000, n_samples=12, mean_cov=12.0, error_rate=0.04, seed=76), dict()),
     "many_sites": (dict(n_species=2, contig_len=8000, n_samples=20, mean_cov=10.0, snv_density=0.3, seed=77), dict(min_coverage=2, calling_threshold=2)),
+    # round 4: overlapping mates, aux tags, SEQ `*` and CG-tag CIGARs through the device pack's kernels (devpack.hip: msnv_ovl_*, rec_load)
+    "paired_aux_records": (dict(n_species=2, contig_len=15000, n_samples=10, mean_cov=14.0, frac_paired=0.6, frac_aux=0.5, frac_noseq=0.05, read_len=90, seed=78), dict()),
+    # ... and BAM FILES through the resident device inflate (inflate_k.hip: msnv_inflate_blocks + msnv_crc_blocks) into the device pack
+    "bam_files_device_inflate": (dict(n_species=2, contig_len=25000, n_samples=6, mean_cov=12.0, frac_paired=0.3, seed=79), dict()),
 }
 
 
@@ -29,7 +33,22 @@ def main():
         sk, pk = CASES[name]
         syn, samples = synth_case(**sk)
         p = core.default_params(**pk)
-        pop, ind, info, st, ds, ctx = run_product(syn.names, syn.lengths, syn.seqs, samples, params=p, return_ds=True)
+        if name == "bam_files_device_inflate":
+            import tempfile
+            os.environ["MSNV_INFLATE"] = "device"
+            with tempfile.TemporaryDirectory() as td:
+                fa = os.path.join(td, "ref.fa"); syn.write_fasta(fa)
+                paths = []
+                for i, rec in enumerate(samples):
+                    paths.append(os.path.join(td, "s%d.bam" % i)); core.write_bam(paths[-1], syn.names, syn.lengths, rec, level=[6, 1, 0, 9, 4, 2][i % 6])
+                ctx = core.Context(0)
+                ds = core.Dataset.from_files(ctx, paths[0], fa, p)
+                ds.add_sample_bams(paths, 3)
+                info = ds.finalize(); st = ds.run()
+                ds.write_calls(os.path.join(td, "c"), os.path.join(td, "i"), None, None)
+                pop, ind = open(os.path.join(td, "c")).read(), open(os.path.join(td, "i")).read()
+        else:
+            pop, ind, info, st, ds, ctx = run_product(syn.names, syn.lengths, syn.seqs, samples, params=p, return_ds=True)
         if os.environ.get("MSNV_GUARD_DEBUG"):
             print("first pass", {k: st[k] for k in ("n_sites", "n_events", "n_overflow", "n_called_pop", "n_called_indiv")}, {k: info[k] for k in ("n_tiles", "n_pairs", "n_work", "allele_planes")}, flush=True)
         ds.run_many(2, overlap=True)

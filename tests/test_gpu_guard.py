@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("deep", ["split", "wide"])
-@pytest.mark.parametrize("case", ["narrow", "short_reads_dense_layout", "deep_wide", "sparse_whole_tile", "merged_and_split", "noisy_planes", "many_sites"])
+@pytest.mark.parametrize("case", ["narrow", "short_reads_dense_layout", "deep_wide", "sparse_whole_tile", "merged_and_split", "noisy_planes", "many_sites", "paired_aux_records", "bam_files_device_inflate"])
 def test_no_access_past_the_end_of_a_device_buffer(case, deep):
     if deep == "wide" and case not in ("deep_wide", "merged_and_split"):
         pytest.skip("no deep runs in this cohort")
