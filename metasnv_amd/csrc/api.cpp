@@ -2,6 +2,7 @@
 // pipeline driver, result mapping and the reference-format text writers.
 #include <algorithm>
 #include <atomic>
+#include <future>
 #include <chrono>
 #include <climits>
 #include <cstring>
@@ -323,18 +324,81 @@ static int bgzf_read_files_device(msnv_ctx *ctx, const char *const *paths, int n
     // the batch buffers in HBM go back on EVERY way out (a caller that falls back to the host path after an error must not find up to ~4.6 GB
     // of staging still attached to the context); the pinned half stays for the next call
     struct ReleaseDevice { msnv_ctx *c; ~ReleaseDevice() { dev_inflate_release_device(c); } } release_device{ctx};
-    const uint64_t batch_in = 1024ull << 20;                       // compressed bytes per batch (~2.5 GB inflated)
+    const uint64_t batch_in = [] { const char *e = getenv("MSNV_INFLATE_BATCH_MB"); const long long v = e ? atoll(e) : 1024; return (uint64_t)std::max<long long>(1, v) << 20; }();   // compressed bytes per batch (~2.5 GB inflated; tests shrink it)
+    // RESIDENT form: a batch's host work -- files read into pageable memory, blocks indexed, BAM headers read from the leading blocks -- is done by
+    // load_batch, and the NEXT batch is loaded (std::async) while the device inflates, checks and packs the current one
+    struct Loaded {
+        int f0 = 0, f1 = 0; uint64_t ib = 0;
+        std::vector<uint64_t> in_off; ByteBuf host_in;
+        std::vector<std::vector<BgzfBlock>> blocks; std::vector<uint64_t> total;
+        std::vector<BamHeader> hdr; std::vector<uint64_t> rec_off;
+        int rc = MSNV_OK; std::string msg;
+    };
+    auto batch_extent = [&](int f0, std::vector<uint64_t> &in_off, uint64_t &ib) -> int {
+        int f1 = f0; ib = 0; in_off.clear();
+        while (f1 < n && (f1 == f0 || ib + fsize[(size_t)f1] <= batch_in)) { in_off.push_back(ib); ib += (fsize[(size_t)f1] + 31) & ~15ull; ++f1; }   // 16 bytes of slack behind every file
+        return f1;
+    };
+    auto load_batch = [&](int f0) -> std::unique_ptr<Loaded> {
+        std::unique_ptr<Loaded> L(new Loaded());
+        L->f0 = f0; L->f1 = batch_extent(f0, L->in_off, L->ib);
+        const int nf = L->f1 - f0;
+        auto failed = [&](int rc) { L->rc = rc; L->msg = msnv_last_error(); return std::move(L); };
+        try {
+            if (!L->host_in.alloc(L->ib + 64)) return failed(fail(MSNV_ENOMEM, "out of memory for %llu compressed bytes", (unsigned long long)L->ib));
+            L->blocks.resize((size_t)nf); L->total.assign((size_t)nf, 0); L->hdr.assign((size_t)nf, BamHeader()); L->rec_off.assign((size_t)nf, 0);
+            std::atomic<int> next{0}, err{0};
+            std::vector<std::string> msgs((size_t)nf);
+            auto w = [&]() {
+                for (;;) {
+                    const int k = next.fetch_add(1);
+                    if (k >= nf || err.load()) break;
+                    const char *path = paths[f0 + k];
+                    int rc = MSNV_OK;
+                    try {
+                        uint8_t *dst = L->host_in.data() + L->in_off[(size_t)k];
+                        const uint64_t sz = fsize[(size_t)(f0 + k)];
+                        {
+                            HostTimerScope ts(HT_READ);
+                            FILE *f = fopen(path, "rb");
+                            if (!f) rc = fail(MSNV_EIO, "cannot open %s", path);
+                            else {
+                                if (sz && fread(dst, 1, sz, f) != sz) rc = fail(MSNV_EIO, "short read on %s", path);
+                                fclose(f);
+                            }
+                        }
+                        if (!rc) { memset(dst + sz, 0, 16); rc = bgzf_index_bytes(dst, sz, path, L->blocks[(size_t)k], L->total[(size_t)k]); }
+                        if (!rc) rc = bam_header_from_blocks(dst, L->blocks[(size_t)k], path, L->hdr[(size_t)k], L->rec_off[(size_t)k]);      // (leading blocks, host decoder)
+                    } catch (const std::exception &e) { rc = fail(MSNV_ENOMEM, "%s: %s", path, e.what()); }
+                    if (rc) { msgs[(size_t)k] = msnv_last_error(); err.store(rc); }
+                }
+            };
+            std::vector<std::thread> th;
+            for (int t = 0; t < std::max(1, std::min(threads, nf)); ++t) th.emplace_back(w);
+            for (auto &t : th) t.join();
+            if (err.load()) { L->rc = err.load(); for (const std::string &m : msgs) if (!m.empty()) { L->msg = m; break; } if (L->msg.empty()) L->msg = "BGZF read failed"; }
+        } catch (const std::exception &e) { L->rc = MSNV_ENOMEM; L->msg = e.what(); }
+        return L;
+    };
+    std::future<std::unique_ptr<Loaded>> ahead;
+    struct WaitAhead { std::future<std::unique_ptr<Loaded>> &f; ~WaitAhead() { if (f.valid()) f.wait(); } } wait_ahead{ahead};      // (the loader reads this frame's variables: never leave it running)
     for (int f0 = 0; f0 < n;) {
         int f1 = f0; uint64_t ib = 0;
         std::vector<uint64_t> in_off;
-        while (f1 < n && (f1 == f0 || ib + fsize[(size_t)f1] <= batch_in)) { in_off.push_back(ib); ib += (fsize[(size_t)f1] + 31) & ~15ull; ++f1; }   // 16 bytes of slack behind every file
+        std::unique_ptr<Loaded> loaded;
+        if (res) {
+            loaded = ahead.valid() ? ahead.get() : load_batch(f0);
+            if (loaded->rc) return fail(loaded->rc, "%s", loaded->msg.c_str());
+            f1 = loaded->f1; ib = loaded->ib; in_off = loaded->in_off;
+            if (f1 < n) ahead = std::async(std::launch::async, load_batch, f1);
+        } else f1 = batch_extent(f0, in_off, ib);
         uint8_t *in_stage = nullptr, *out = nullptr;
         // A batch whose staging cannot be had (pinned host memory or HBM: MSNV_ENOMEM) or whose launch fails is inflated by the host
         // decoder instead -- the call must not fail where the host path would have worked (a multi-GB BAM sizes the staging to itself)
         bool host_batch = false;
         ByteBuf host_in, host_out;
         if (res) {
-            if (!host_in.alloc(ib + 64)) return fail(MSNV_ENOMEM, "out of memory for %llu compressed bytes", (unsigned long long)ib);
+            host_in = std::move(loaded->host_in);
             in_stage = host_in.data();
         } else if (int rc = dev_inflate_staging(ctx, ib, 0, &in_stage, &out)) {
             if (rc != MSNV_ENOMEM) return rc;
@@ -347,6 +411,7 @@ static int bgzf_read_files_device(msnv_ctx *ctx, const char *const *paths, int n
         const int nf = f1 - f0;
         std::vector<std::vector<BgzfBlock>> blocks((size_t)nf);
         std::vector<uint64_t> total((size_t)nf, 0);
+        if (res) { blocks = std::move(loaded->blocks); total = std::move(loaded->total); }
         std::atomic<int> next{0}, err{0};
         std::vector<std::string> msgs((size_t)nf);
         auto loader = [&]() {
@@ -370,7 +435,7 @@ static int bgzf_read_files_device(msnv_ctx *ctx, const char *const *paths, int n
                 if (rc) { msgs[(size_t)k] = msnv_last_error(); err.store(rc); }
             }
         };
-        {
+        if (!res) {
             std::vector<std::thread> th;
             for (int t = 0; t < std::max(1, std::min(threads, nf)); ++t) th.emplace_back(loader);
             for (auto &t : th) t.join();
@@ -394,24 +459,7 @@ static int bgzf_read_files_device(msnv_ctx *ctx, const char *const *paths, int n
             n_bytes += total[(size_t)k];
         }
         if (res) {
-            // headers from the leading blocks (host decoder), one file per thread
-            res->hdr.assign((size_t)nf, BamHeader()); res->rec_off.assign((size_t)nf, 0);
-            std::atomic<int> nx{0}, herr{0};
-            std::vector<std::string> hmsg((size_t)nf);
-            auto hw = [&]() {
-                for (;;) {
-                    const int k = nx.fetch_add(1);
-                    if (k >= nf || herr.load()) break;
-                    int rc;
-                    try { rc = bam_header_from_blocks(in_stage + in_off[(size_t)k], blocks[(size_t)k], paths[f0 + k], res->hdr[(size_t)k], res->rec_off[(size_t)k]); }
-                    catch (const std::exception &e) { rc = fail(MSNV_ENOMEM, "%s: %s", paths[f0 + k], e.what()); }
-                    if (rc) { hmsg[(size_t)k] = msnv_last_error(); herr.store(rc); }
-                }
-            };
-            std::vector<std::thread> th;
-            for (int t = 0; t < std::max(1, std::min(threads, nf)); ++t) th.emplace_back(hw);
-            for (auto &t : th) t.join();
-            if (herr.load()) { for (const std::string &m : hmsg) if (!m.empty()) return fail(herr.load(), "%s", m.c_str()); return fail(herr.load(), "BAM header read failed"); }
+            res->hdr = std::move(loaded->hdr); res->rec_off = std::move(loaded->rec_off);      // (read by load_batch)
             if (int rc = dev_inflate_device_buffers(ctx, ib, ob)) {
                 if (rc != MSNV_ENOMEM) return rc;
                 fprintf(stderr, "libmsnv: no staging for the device inflate (%s); this batch is inflated on the host\n", msnv_last_error());

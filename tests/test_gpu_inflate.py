@@ -172,7 +172,7 @@ def test_resident_device_inflate_checks_every_block_in_hbm(tmp_path, monkeypatch
     (inflate_k.hip: msnv_crc_blocks) -- no host inflate at all for good files; a wrong trailer CRC is MSNV_EFORMAT (as the host decoder and
     htslib have it), a corrupted payload too; MSNV_INFLATE_CHECK=0 lets the wrong trailer through."""
     monkeypatch.setenv("MSNV_INFLATE", "device"); monkeypatch.setenv("MSNV_PACK", "device")
-    sp = core.synth_params(n_species=2, contig_len=30000, n_samples=4, mean_cov=12.0, frac_paired=0.3, snv_density=0.02, seed=13)
+    sp = core.synth_params(n_species=2, contig_len=60000, n_samples=4, mean_cov=16.0, frac_paired=0.3, snv_density=0.02, seed=13)
     syn = core.Synth(sp)
     fa = str(tmp_path / "ref.fa"); syn.write_fasta(fa)
     paths = []
@@ -192,6 +192,16 @@ def test_resident_device_inflate_checks_every_block_in_hbm(tmp_path, monkeypatch
     from parity import run_oracle
     want = run_oracle(syn.names, syn.lengths, syn.seqs, [syn.sample_records(i) for i in range(sp.n_samples)])
     assert open(tmp_path / "c").read() == want[0] and info["n_pileup_bases"] == want[3]
+    # several batches (the next one is read while the device works on the current one): the same dataset
+    monkeypatch.setenv("MSNV_INFLATE_BATCH_MB", "1")
+    assert sum(os.path.getsize(q) for q in paths) > (2 << 20)
+    ds = core.Dataset.from_files(ctx, paths[0], fa)
+    ds.add_sample_bams(paths, 3)
+    info2 = ds.finalize(); ds.run()
+    ds.write_calls(str(tmp_path / "c2"), str(tmp_path / "i2"), None, None)
+    assert open(tmp_path / "c2").read() == want[0] and info2["n_pileup_bases"] == want[3]
+    ds.close()
+    monkeypatch.delenv("MSNV_INFLATE_BATCH_MB")
     # block 3 of the second file: wrong CRC in the trailer / flipped payload bits
     raw = bytearray(open(paths[1], "rb").read())
     off = 0
