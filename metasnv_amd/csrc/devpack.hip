@@ -984,46 +984,44 @@ void devpack_release(DevPackTables &t) {
     t.contigs = nullptr; t.pref4 = nullptr; t.ready = false;
 }
 
-int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *streams, const uint64_t *n_bytes, int n, bool on_device) {
-    if (n <= 0) return MSNV_OK;
-    if (n > 2048) return fail(MSNV_EINVAL, "internal: a device-pack round holds at most 2048 samples");
-    if (!ds.ctx) return fail(MSNV_ENODEV, "the device pack needs a device context");
-    if (int rc = dev_set_device(ds.ctx->device)) return rc;
-    hipStream_t st = (hipStream_t)ds.ctx->stream;
-    if (int rc = build_tables(ds)) return rc;
-    DevPackTables &T = ds.dp;
-    const size_t S = (size_t)n, NC = ds.names.size();
-    const msnv_params &MP = ds.params;
-    DpParams P{};
-    P.flag_filter = MP.flag_filter; P.min_mapq = MP.min_mapq; P.count_orphans = MP.count_orphans; P.cov_min_mapq = MP.cov_min_mapq;
-    P.max_depth = MP.max_depth; P.token_limit = MP.token_limit; P.ignore_overlaps = MP.ignore_overlaps;
-    P.c_eff = std::min(std::max(MP.min_baseq, -127), 127); P.all_low = MP.min_baseq > 127;
-    P.n_contigs = (int)NC; P.has_bed = ds.has_bed ? 1 : 0;
-    Timer tm(st);
-    // work buffers of the round: taken from the dataset's pool in call order (grow-only, so a dataset's second round allocates nothing);
-    // with guarded allocations (MSNV_GUARD_ALLOC=1) every buffer is exact and fresh
-    size_t next_buf = 0;
-    int pool_rc = MSNV_OK;
-    const bool exact = [] { const char *e = getenv("MSNV_GUARD_ALLOC"); return e && e[0] == '1'; }();
-    auto buf = [&](uint64_t bytes) -> void * {
-        if (next_buf >= T.scratch.size()) T.scratch.emplace_back(nullptr, 0);
-        std::pair<void *, uint64_t> &b = T.scratch[next_buf++];
+// Work buffers taken from a grow-only list in call order (a dataset's pool, or a caller's own list).
+struct BufPool {
+    std::vector<std::pair<void *, uint64_t>> &slots;
+    size_t next = 0; int rc = MSNV_OK;
+    bool exact = [] { const char *e = getenv("MSNV_GUARD_ALLOC"); return e && e[0] == '1'; }();
+    void *get(uint64_t bytes) {
+        if (next >= slots.size()) slots.emplace_back(nullptr, 0);
+        std::pair<void *, uint64_t> &b = slots[next++];
         bytes = std::max<uint64_t>(bytes, 16);
         if (b.second < bytes || (exact && b.second != bytes)) {
             if (b.first) dev_free(b.first);
             b.first = nullptr; b.second = 0;
             const uint64_t want = exact ? bytes : bytes + bytes / 8;
-            if (int rc = dev_alloc(&b.first, want, nullptr)) { pool_rc = rc; return nullptr; }
+            if (int r = dev_alloc(&b.first, want, nullptr)) { rc = r; return nullptr; }
             b.second = want;
         }
         return b.first;
-    };
-#define DP_BUF(type, name, count)                                                  \
-    type *name = static_cast<type *>(buf((uint64_t)(count) * sizeof(type)));       \
-    if (!name) return pool_rc
+    }
+};
+#define DP_BUF(type, name, count)                                                      \
+    type *name = static_cast<type *>(pool.get((uint64_t)(count) * sizeof(type)));      \
+    if (!name) return pool.rc
 
+// Record streams (host or device memory) side by side in one device buffer and the offsets of their records: what the device pack
+// (devpack_add_round) and the device dealer (msnv_records_deal_device) start from.
+struct ScanResult {
+    uint8_t *raw = nullptr; uint64_t raw_bytes = 0;
+    std::vector<unsigned long long> s_beg, s_end, bad_off;      // per stream: first / end byte in raw; offset of a malformed record (~0: none)
+    std::vector<uint32_t> rec_base, n_rec;                       // per stream: index of its first record / its record count
+    uint32_t NR = 0;
+    uint32_t *d_recbase = nullptr; unsigned long long *d_send = nullptr, *d_recoff = nullptr; uint16_t *d_recsample = nullptr;
+    double wall_upload_s = 0, ms_scan = 0; uint64_t n_redone = 0;
+};
+static int scan_streams(hipStream_t st, const int device, BufPool &pool, const uint8_t *const *streams, const uint64_t *n_bytes, const size_t S, const bool on_device, const int NC_, ScanResult &R) {
+    const size_t NC = (size_t)NC_;
+    Timer tm(st);
     // ---- the round's streams side by side in one buffer: every stream starts on 16 bytes, readable bytes behind the last
-    std::vector<unsigned long long> s_beg(S), s_end(S);
+    std::vector<unsigned long long> &s_beg = R.s_beg, &s_end = R.s_end; s_beg.assign(S, 0); s_end.assign(S, 0);
     uint64_t raw_bytes = 0;
     for (size_t s = 0; s < S; ++s) { s_beg[s] = raw_bytes; s_end[s] = raw_bytes + n_bytes[s]; raw_bytes += (n_bytes[s] + 15 + 16) & ~15ull; }
     DP_BUF(uint8_t, raw, raw_bytes + 256);
@@ -1035,7 +1033,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
         } else {
             // pageable host memory: a few copies in flight keep the link busy (the runtime stages them)
             std::atomic<size_t> next{0}; std::atomic<int> bad{0};
-            const int device = ds.ctx->device;
+            
             auto w = [&]() {
                 (void)hipSetDevice(device);
                 for (;;) { const size_t s = next.fetch_add(1); if (s >= S) break; if (n_bytes[s] && hipMemcpy(raw + s_beg[s], streams[s], n_bytes[s], hipMemcpyHostToDevice) != hipSuccess) bad.store(1); }
@@ -1045,9 +1043,9 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
             for (auto &x : th) x.join();
             if (bad.load()) return fail(MSNV_EHIP, "upload of the record streams failed: %s", hipGetErrorString(hipGetLastError()));
         }
-        T.wall_upload_s += now_s() - t0;
+        R.wall_upload_s += now_s() - t0;
     }
-    T.raw_bytes += raw_bytes;
+    R.raw = raw; R.raw_bytes = raw_bytes;
 
     // ---- record boundaries: segments, guessed entry points, seams checked here
     const uint64_t seg_bytes = [] { const char *e = getenv("MSNV_SCAN_SEG_KB"); const long long v = e ? atoll(e) : 256; return (uint64_t)std::max<long long>(1, v) << 10; }();   // (per call: tests shrink it)
@@ -1069,8 +1067,8 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     DP_BUF(ScanOut, d_outs, NSEG + 1);
     DP_BUF(unsigned long long, d_tmpoff, cap_total + 64);
     std::vector<ScanOut> outs(NSEG);
-    std::vector<uint32_t> n_rec(S, 0), acc_cnt(NSEG, 0);
-    std::vector<unsigned long long> bad_off(S, ~0ull);
+    std::vector<uint32_t> &n_rec = R.n_rec; n_rec.assign(S, 0); std::vector<uint32_t> acc_cnt(NSEG, 0);
+    std::vector<unsigned long long> &bad_off = R.bad_off; bad_off.assign(S, ~0ull);
     tm.start();
     if (NSEG) {
         HIP_TRY(hipMemcpyAsync(d_segs, segs.data(), NSEG * sizeof(ScanSeg), hipMemcpyHostToDevice, st));
@@ -1109,12 +1107,12 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
             HIP_TRY(hipMemcpyAsync(aout.data(), d_aout, again.size() * sizeof(ScanOut), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             for (size_t j = 0; j < redo.size(); ++j) outs[redo[j]] = aout[j];
-            T.n_scan_redone += redo.size();
-            next_buf -= 2;                                        // (the two lists are reused by the next repair round)
+            R.n_redone += redo.size();
+            pool.next -= 2;                                        // (the two lists are reused by the next repair round)
         }
     }
-    T.ms_scan += tm.stop();                                       // (the lists below are allocated outside the timed region)
-    std::vector<uint32_t> rec_base(S + 1, 0);
+    R.ms_scan += tm.stop();                                       // (the lists below are allocated outside the timed region)
+    std::vector<uint32_t> &rec_base = R.rec_base; rec_base.assign(S + 1, 0);
     std::vector<CompactSeg> csegs;
     {
         uint64_t total = 0;
@@ -1131,7 +1129,6 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     }
     const uint32_t NR = rec_base[S];
     const uint64_t NRa = (uint64_t)NR + 1;
-    T.n_records += NR;
     DP_BUF(uint32_t, d_recbase, S + 1);
     DP_BUF(unsigned long long, d_send, S);
     DP_BUF(unsigned long long, d_recoff, NRa);
@@ -1145,7 +1142,50 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
         hipLaunchKernelGGL(msnv_compact_offsets, dim3((unsigned)csegs.size()), dim3(256), 0, st, d_tmpoff, d_csegs, d_recoff, d_recsample);
         HIP_TRY(hipGetLastError());
     }
-    T.ms_scan += tm.stop();
+    R.ms_scan += tm.stop();
+
+    R.NR = NR;
+    R.d_recbase = d_recbase; R.d_send = d_send; R.d_recoff = d_recoff; R.d_recsample = d_recsample;
+    return MSNV_OK;
+}
+#undef DP_BUF
+
+
+int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *streams, const uint64_t *n_bytes, int n, bool on_device) {
+    if (n <= 0) return MSNV_OK;
+    if (n > 2048) return fail(MSNV_EINVAL, "internal: a device-pack round holds at most 2048 samples");
+    if (!ds.ctx) return fail(MSNV_ENODEV, "the device pack needs a device context");
+    if (int rc = dev_set_device(ds.ctx->device)) return rc;
+    hipStream_t st = (hipStream_t)ds.ctx->stream;
+    if (int rc = build_tables(ds)) return rc;
+    DevPackTables &T = ds.dp;
+    const size_t S = (size_t)n, NC = ds.names.size();
+    const msnv_params &MP = ds.params;
+    DpParams P{};
+    P.flag_filter = MP.flag_filter; P.min_mapq = MP.min_mapq; P.count_orphans = MP.count_orphans; P.cov_min_mapq = MP.cov_min_mapq;
+    P.max_depth = MP.max_depth; P.token_limit = MP.token_limit; P.ignore_overlaps = MP.ignore_overlaps;
+    P.c_eff = std::min(std::max(MP.min_baseq, -127), 127); P.all_low = MP.min_baseq > 127;
+    P.n_contigs = (int)NC; P.has_bed = ds.has_bed ? 1 : 0;
+    Timer tm(st);
+    // work buffers of the round: taken from the dataset's pool in call order (BufPool: grow-only, so a dataset's second round allocates nothing;
+    // with guarded allocations -- MSNV_GUARD_ALLOC=1 -- every buffer is exact and fresh)
+    BufPool pool{T.scratch};
+#define DP_BUF(type, name, count)                                                      \
+    type *name = static_cast<type *>(pool.get((uint64_t)(count) * sizeof(type)));      \
+    if (!name) return pool.rc
+
+    // ---- the round's streams side by side in one buffer, their record boundaries (scan_streams)
+    ScanResult SR;
+    if (int rc = scan_streams(st, ds.ctx->device, pool, streams, n_bytes, S, on_device, (int)NC, SR)) return rc;
+    T.wall_upload_s += SR.wall_upload_s; T.raw_bytes += SR.raw_bytes; T.ms_scan += SR.ms_scan; T.n_scan_redone += SR.n_redone; T.n_records += SR.NR;
+    uint8_t *const raw = SR.raw;
+    const uint64_t raw_bytes = SR.raw_bytes; (void)raw_bytes;
+    const std::vector<unsigned long long> &s_beg = SR.s_beg, &s_end = SR.s_end, &bad_off = SR.bad_off;
+    const std::vector<uint32_t> &rec_base = SR.rec_base, &n_rec = SR.n_rec;
+    const uint32_t NR = SR.NR;
+    const uint64_t NRa = (uint64_t)NR + 1;
+    uint32_t *const d_recbase = SR.d_recbase; unsigned long long *const d_send = SR.d_send, *const d_recoff = SR.d_recoff; uint16_t *const d_recsample = SR.d_recsample;
+    (void)d_send; (void)n_rec; (void)s_beg; (void)s_end;
 
     // ---- measure (+ the host pre-pass for the samples that need one, then once more with its verdicts)
     DP_BUF(uint8_t, d_flags, NRa);
@@ -1161,15 +1201,15 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     DP_BUF(uint32_t, d_ovr, NRa);
     DP_BUF(DpAcc, d_acc, S * ACC_COPIES);
     DP_BUF(uint8_t, d_tmp, 1u << 20);                             // rocPRIM's temporary storage (grown below when a call asks for more)
-    size_t tmp_cap = (size_t)T.scratch[next_buf - 1].second;
-    const size_t tmp_slot = next_buf - 1;
+    size_t tmp_cap = (size_t)T.scratch[pool.next - 1].second;
+    const size_t tmp_slot = pool.next - 1;
     auto tmp_for = [&](size_t need) -> int {
         if (need <= tmp_cap) return MSNV_OK;
-        const size_t keep = next_buf;
-        next_buf = tmp_slot;
-        d_tmp = static_cast<uint8_t *>(buf(need));
-        next_buf = keep;
-        if (!d_tmp) return pool_rc;
+        const size_t keep = pool.next;
+        pool.next = tmp_slot;
+        d_tmp = static_cast<uint8_t *>(pool.get(need));
+        pool.next = keep;
+        if (!d_tmp) return pool.rc;
         tmp_cap = (size_t)T.scratch[tmp_slot].second;
         return MSNV_OK;
     };
@@ -1205,9 +1245,9 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     DevBuf o_flag, o_rank, o_skip, o_keys, o_skeys, o_vals, o_svals, o_starts;      // overlapping mates (paired reads only: not from the pool)
     uint32_t n_ovl_reads = 0, n_ovl_groups = 0;
     std::vector<uint8_t> host_sample(S, 0);                       // samples whose sequential edits ran on the host (pre-pass)
-    const size_t depth_bufs_from = next_buf;
+    const size_t depth_bufs_from = pool.next;
     for (int pass = 0; pass < 2; ++pass) {
-        next_buf = depth_bufs_from;
+        pool.next = depth_bufs_from;
         {
             DpAcc a{}; a.err = a.first_pile = a.beyond = ~0ull;
             std::vector<DpAcc> init(S * ACC_COPIES, a);
@@ -1375,7 +1415,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
         T.ms_depth += tm.stop();
     }
     // ---- layout: where every record's pieces, seq bytes and intervals go
-    next_buf = depth_bufs_from;                                   // (the depth stage's lists are done with: their buffers serve the pieces)
+    pool.next = depth_bufs_from;                                   // (the depth stage's lists are done with: their buffers serve the pieces)
     DP_BUF(uint32_t, d_pbase, NRa);
     DP_BUF(unsigned long long, d_sbase, NRa);
     DP_BUF(uint32_t, d_ibase, NRa);
