@@ -379,6 +379,14 @@ typedef struct { uint32_t total_reads, unmapped, zero_quality, proper_pairs, dup
  * part_bytes[n_parts] their sizes; stats (may be NULL) the sample's qaCompute statistics over ALL records. */
 int  msnv_records_partition(const uint8_t *records, uint64_t n_bytes, const int32_t *contig_owner, int32_t n_contigs,
                             int32_t n_parts, int32_t cov_min_mapq, uint8_t *out, uint64_t *part_bytes, msnv_sample_stats *stats);
+/* msnv_records_partition for n streams at once, ON THE DEVICE (csrc/devpack.hip): the streams (host memory, or device memory when on_device
+ * != 0) are dealt by kernels into `out` -- DEVICE memory of `capacity` bytes, e.g. the send tensor of an all-to-all over RCCL -- destination-
+ * major: part 0 of stream 0, of stream 1, ..., part 1 of stream 0, ..., with `gap` bytes left free in front of every part (the caller's size
+ * table; capacity >= sum of n_bytes + n_parts * gap).  part_bytes[i * n_parts + k] = bytes of stream i in part k; stats[i] = stream i's
+ * qaCompute statistics; contig_bases (may be NULL; n_contigs entries, not cleared) += aligned bases per contig (msnv_records_contig_bases). */
+int  msnv_records_deal_device(msnv_ctx *ctx, const uint8_t *const *streams, const uint64_t *n_bytes, int32_t n, int32_t on_device, const int32_t *contig_owner,
+                              int32_t n_contigs, int32_t n_parts, int32_t cov_min_mapq, uint8_t *out, uint64_t capacity, uint64_t gap, uint64_t *part_bytes,
+                              msnv_sample_stats *stats, uint64_t *contig_bases);
 /* Adds the aligned (M/=/X) bases of every mapped record of a raw record stream to bases[tid] (n_contigs entries, not cleared):
  * the weight of the reference's split rule, genome length x coverage = aligned bases (src/createOptimumSplit.py:46-50), which
  * the N-rank driver takes from its first round of decoded BAMs before it fixes the contig owners. */

@@ -382,6 +382,29 @@ def dense_to_cells(samples):
     return row_off, smp.astype(np.uint32), np.ascontiguousarray(samples[site, smp])
 
 
+def deal_records_device(ctx, streams, contig_owner, n_parts, out_ptr, capacity, gap=0, cov_min_mapq=1, contig_bases=None, on_device=False, sizes=None):
+    """core.partition_records for several streams at once, on the device (msnv_records_deal_device): streams = uint8 arrays (or device addresses
+    with sizes= and on_device=True); out_ptr = DEVICE address of `capacity` bytes that receives the parts destination-major with `gap` free bytes
+    in front of every part.  Returns (part_bytes[n_streams][n_parts] as int64 array, stats[n_streams][6] as uint32 array)."""
+    n = len(streams)
+    owner = np.ascontiguousarray(contig_owner, dtype=np.int32)
+    if on_device:
+        keep, ptrs, nb = None, [int(p) for p in streams], [int(x) for x in sizes]
+    else:
+        keep = [np.ascontiguousarray(r, dtype=np.uint8) for r in streams]
+        ptrs, nb = [b.ctypes.data for b in keep], [b.size for b in keep]
+    pa = (C.c_void_p * max(1, n))(*ptrs)
+    sa = (C.c_uint64 * max(1, n))(*nb)
+    pb = (C.c_uint64 * max(1, n * n_parts))()
+    st = (SampleStats * max(1, n))()
+    cb = contig_bases.ctypes.data_as(C.POINTER(C.c_uint64)) if contig_bases is not None else None
+    check(lib.msnv_records_deal_device(ctx._h, pa, sa, n, 1 if on_device else 0, owner.ctypes.data_as(C.POINTER(C.c_int32)), owner.size, int(n_parts), int(cov_min_mapq),
+                                       C.c_void_p(int(out_ptr)), int(capacity), int(gap), pb, st, cb))
+    parts = np.array(list(pb)[:n * n_parts], dtype=np.int64).reshape(n, n_parts) if n else np.zeros((0, n_parts), np.int64)
+    stats = np.array([[getattr(st[i], k) for k in STATS_FIELDS] for i in range(n)], dtype=np.uint32).reshape(n, len(STATS_FIELDS))
+    return parts, stats
+
+
 def contig_bases(records, n_contigs, into=None):
     """Aligned bases per contig of a raw record stream (msnv_records_contig_bases), added to `into` (uint64[n_contigs])."""
     rec = np.ascontiguousarray(records, dtype=np.uint8)

@@ -1447,6 +1447,17 @@ extern "C" int msnv_records_partition(const uint8_t *records, uint64_t n_bytes, 
     return rc;
 }
 
+extern "C" int msnv_records_deal_device(msnv_ctx *ctx, const uint8_t *const *streams, const uint64_t *n_bytes, int32_t n, int32_t on_device, const int32_t *owner, int32_t n_contigs,
+                                        int32_t n_parts, int32_t cov_min_mapq, uint8_t *out, uint64_t capacity, uint64_t gap, uint64_t *part_bytes, msnv_sample_stats *stats,
+                                        uint64_t *contig_bases) {
+    clear_error();
+    if (!ctx || n < 0 || n_contigs < 0 || (n && (!streams || !n_bytes || !part_bytes || !stats)) || (n_contigs && !owner) || (!out && capacity))
+        return fail(MSNV_EINVAL, "msnv_records_deal_device: bad argument");
+    for (int i = 0; i < n; ++i) if (n_bytes[i] && !streams[i]) return fail(MSNV_EINVAL, "msnv_records_deal_device: stream %d is NULL", i);
+    try { return records_deal_device(ctx, streams, n_bytes, n, on_device != 0, owner, n_contigs, n_parts, cov_min_mapq, out, capacity, gap, part_bytes, stats, contig_bases); }
+    catch (const std::exception &e) { return fail(MSNV_ENOMEM, "msnv_records_deal_device: %s", e.what()); }
+}
+
 extern "C" int msnv_records_contig_bases(const uint8_t *records, uint64_t n_bytes, int32_t n_contigs, uint64_t *bases) {
     clear_error();
     if ((n_bytes && !records) || n_contigs < 0 || (n_contigs && !bases)) return fail(MSNV_EINVAL, "msnv_records_contig_bases: bad argument");

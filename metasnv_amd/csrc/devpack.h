@@ -35,6 +35,9 @@ int devfin_overhang(msnv_dataset &ds, std::vector<int64_t> &maxend);
 int devfin_deep_runs(msnv_dataset &ds, uint32_t split_at, uint32_t group_depth, bool *fallback);
 // pack.cpp: relayout_dense for device-packed samples: every sample's columns as dense block streams, its descriptors (d_blk) and run_* tables
 int devfin_dense(msnv_dataset &ds);
+// msnv_records_deal_device (msnv.h): pack.cpp's records_partition for several streams at once, on the device
+int records_deal_device(msnv_ctx *ctx, const uint8_t *const *streams, const uint64_t *n_bytes, int n, bool on_device, const int32_t *owner, int n_contigs, int n_parts,
+                        int cov_min_mapq, uint8_t *out, uint64_t capacity, uint64_t gap, uint64_t *part_bytes, msnv_sample_stats *stats, uint64_t *contig_bases);
 int devpack_copy_blocks(const SampleCols &sc, uint32_t *dst, void *stream);
 int devfin_headers(msnv_dataset &ds, DeviceCols &d, const std::vector<uint64_t> &rbase);
 int devfin_chunk_counts(msnv_dataset &ds, DeviceCols &d, const std::vector<uint32_t> &narrow_pairs, std::vector<uint32_t> &counts);

@@ -1151,6 +1151,173 @@ static int scan_streams(hipStream_t st, const int device, BufPool &pool, const u
 #undef DP_BUF
 
 
+// ------------------------------------------------------------------------------------------ records dealt to their owners, on the device
+// The N-rank feed (metasnv_amd/parallel.py: feed_sharded): the rank that decoded a BAM sends every mapped record to the rank that owns its
+// contig.  pack.cpp: records_partition does that on a host thread (two walks over the stream + a copy); here the streams go up once, the
+// record scan of the device pack finds the records, one thread per record reads its contig, flag and MAPQ (owner, qaCompute's
+// statistics, optionally the aligned bases per contig that the split planner weighs contigs by), one stable rocPRIM sort by owner and
+// one scan of the sizes give every record its place, and sixteen lanes per record copy it there.  Output: destination-major -- part 0
+// of stream 0, of stream 1, ..., part 1 of stream 0, ... -- with `gap` bytes left free in front of every part (the caller's size table),
+// i.e. exactly the send buffer of the all-to-all; part_bytes[i * n_parts + k] = bytes of stream i in part k.
+namespace {
+constexpr uint32_t DEAL_COPIES = 64;                   // per-stream counters in this many copies (same-address atomics: msnv_measure_reads)
+struct DealAcc { uint32_t total, unmapped, zero_q, proper, dup, any_mapped, bad_tid, bad_owner; };
+__global__ __launch_bounds__(256) void msnv_deal_measure(const uint8_t *raw, const unsigned long long *rec_off, const uint16_t *rec_sample, uint32_t n_rec, const unsigned long long *s_end,
+                                                         const int32_t *owner, int n_contigs, int n_parts, int cov_min_mapq, uint32_t *key, uint32_t *size,
+                                                         DealAcc *acc, unsigned long long *contig_bases) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    int32_t tid = -1; unsigned long long m = 0;
+    if (i < n_rec) {
+        const uint32_t s = rec_sample[i];
+        const Rec r = rec_load(raw + rec_off[i], s_end[s] - rec_off[i]);
+        DealAcc &a = acc[(size_t)s * DEAL_COPIES + (blockIdx.x % DEAL_COPIES)];
+        atomicAdd(&a.total, 1u);
+        uint32_t k = 0xffu;                                    // 0xff: the record goes nowhere (unmapped, or its contig is outside every shard)
+        if ((r.flag & BAM_FUNMAP) || r.tid < 0) atomicAdd(&a.unmapped, 1u);
+        else {
+            a.any_mapped = 1u;
+            if ((int)r.mapq >= cov_min_mapq) {
+                if (r.flag & BAM_FPROPER_PAIR) atomicAdd(&a.proper, 1u);
+                if (r.flag & BAM_FDUP) atomicAdd(&a.dup, 1u);
+            } else atomicAdd(&a.zero_q, 1u);
+            if (r.tid >= n_contigs) a.bad_tid = 1u;
+            else {
+                const int32_t o = owner[r.tid];
+                if (o >= n_parts) a.bad_owner = 1u;
+                else if (o >= 0) k = (uint32_t)o;
+                if (contig_bases) {
+                    tid = r.tid;
+                    for (uint32_t c = 0; c < r.n_cigar; ++c) { const uint32_t w = ld32(r.cigar + 4ull * c); if (cg_match(w & 15u)) m += w >> 4; }
+                }
+            }
+        }
+        key[i] = k;
+        size[i] = k == 0xffu ? 0u : r.bs + 4u;
+    }
+    if (contig_bases) {
+        // records are sorted by contig: a wavefront's lanes nearly always share one -- one atomic per wavefront then
+        const int32_t t0 = __builtin_amdgcn_readfirstlane(tid);
+        if (__all(tid == t0 || tid < 0)) {
+            unsigned long long sum = tid == t0 ? m : 0ull;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+            if ((threadIdx.x & 63) == 0 && t0 >= 0 && sum) atomicAdd(&contig_bases[t0], sum);
+        } else if (tid >= 0 && m) atomicAdd(&contig_bases[tid], m);
+    }
+}
+__global__ void msnv_deal_iota(uint32_t *a, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = i;
+}
+__global__ void msnv_deal_sizes(const uint32_t *order, const uint32_t *size, uint32_t n, uint32_t *out) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) out[j] = size[order[j]];
+}
+// sixteen lanes per record: 16-byte pieces of the record, any alignment on either side; the per-(stream, part) byte counts in DEAL_COPIES copies
+__global__ __launch_bounds__(256) void msnv_deal_copy(const uint8_t *raw, const unsigned long long *rec_off, const uint16_t *rec_sample, const uint32_t *order, const uint32_t *skey,
+                                                      const uint32_t *ssize, const unsigned long long *pos, uint32_t n, uint32_t n_parts, uint32_t n_streams, unsigned long long gap, uint8_t *out,
+                                                      unsigned long long *part_bytes) {
+    const unsigned long long gt = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t j = (uint32_t)(gt >> 4), l = (uint32_t)gt & 15u;
+    if (j >= n) return;
+    const uint32_t k = skey[j];
+    if (k == 0xffu) return;
+    const uint32_t i = order[j], sz = ssize[j];
+    const uint8_t *src = raw + rec_off[i];
+    uint8_t *dst = out + pos[j] + (unsigned long long)(k + 1u) * gap;
+    for (uint32_t o = 16u * l; o + 16u <= sz; o += 256u) { uint4 v; __builtin_memcpy(&v, src + o, 16); __builtin_memcpy(dst + o, &v, 16); }
+    if (l == 0) {
+        for (uint32_t o = sz & ~15u; o < sz; ++o) dst[o] = src[o];
+        atomicAdd(&part_bytes[((size_t)(blockIdx.x % DEAL_COPIES) * n_streams + rec_sample[i]) * n_parts + k], (unsigned long long)sz);
+    }
+}
+}  // namespace
+
+int records_deal_device(msnv_ctx *ctx, const uint8_t *const *streams, const uint64_t *n_bytes, int n, bool on_device, const int32_t *owner, int n_contigs, int n_parts,
+                        int cov_min_mapq, uint8_t *out, uint64_t capacity, uint64_t gap, uint64_t *part_bytes, msnv_sample_stats *stats, uint64_t *contig_bases) {
+    if (n <= 0) return MSNV_OK;
+    if (n > 2048) return fail(MSNV_EINVAL, "msnv_records_deal_device: at most 2048 streams per call");
+    if (n_parts < 1 || n_parts > 254) return fail(MSNV_EINVAL, "msnv_records_deal_device: 1 .. 254 parts");
+    if (int rc = dev_set_device(ctx->device)) return rc;
+    hipStream_t st = (hipStream_t)ctx->stream;
+    const size_t S = (size_t)n;
+    std::vector<std::pair<void *, uint64_t>> slots;                // this call's work buffers
+    struct FreeSlots { std::vector<std::pair<void *, uint64_t>> &v; ~FreeSlots() { for (auto &b : v) if (b.first) dev_free(b.first); } } free_slots{slots};
+    BufPool pool{slots};
+#define DP_BUF(type, name, count)                                                      \
+    type *name = static_cast<type *>(pool.get((uint64_t)(count) * sizeof(type)));      \
+    if (!name) return pool.rc
+    ScanResult SR;
+    if (int rc = scan_streams(st, ctx->device, pool, streams, n_bytes, S, on_device, n_contigs, SR)) return rc;
+    for (size_t s = 0; s < S; ++s) if (SR.bad_off[s] != ~0ull) return fail(MSNV_EFORMAT, "malformed BAM record at byte %llu of stream %zu", (unsigned long long)SR.bad_off[s], s);
+    const uint32_t NR = SR.NR;
+    uint64_t need = (uint64_t)n_parts * gap;
+    for (size_t s = 0; s < S; ++s) need += n_bytes[s];
+    if (capacity < need) return fail(MSNV_ECAPACITY, "msnv_records_deal_device: the output holds %llu bytes, up to %llu are needed", (unsigned long long)capacity, (unsigned long long)need);
+    for (size_t i = 0; i < S * (size_t)n_parts; ++i) part_bytes[i] = 0;
+    for (size_t s = 0; s < S; ++s) stats[s] = msnv_sample_stats{};
+    if (!NR) return MSNV_OK;
+    DP_BUF(int32_t, d_owner, std::max(1, n_contigs));
+    DP_BUF(uint32_t, d_key, (uint64_t)NR + 1);
+    DP_BUF(uint32_t, d_size, (uint64_t)NR + 1);
+    DP_BUF(uint32_t, d_idx, (uint64_t)NR + 1);
+    DP_BUF(uint32_t, d_skey, (uint64_t)NR + 1);
+    DP_BUF(uint32_t, d_order, (uint64_t)NR + 1);
+    DP_BUF(uint32_t, d_ssize, (uint64_t)NR + 1);
+    DP_BUF(unsigned long long, d_pos, (uint64_t)NR + 1);
+    DP_BUF(DealAcc, d_acc, S * DEAL_COPIES);
+    DP_BUF(unsigned long long, d_pb, (uint64_t)DEAL_COPIES * S * (uint64_t)n_parts + 1);
+    DP_BUF(unsigned long long, d_cb, std::max(1, n_contigs));
+    // (per-(stream, part) byte counts: copy c of stream s, part k at ((c * S) + s) * n_parts + k -- indexed below with the same formula)
+    const uint64_t pb_words = (uint64_t)DEAL_COPIES * S * (uint64_t)n_parts;
+    HIP_TRY(hipMemcpyAsync(d_owner, owner, (size_t)n_contigs * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(d_acc, 0, S * DEAL_COPIES * sizeof(DealAcc), st));
+    HIP_TRY(hipMemsetAsync(d_pb, 0, pb_words * 8, st));
+    if (contig_bases) HIP_TRY(hipMemsetAsync(d_cb, 0, (size_t)std::max(1, n_contigs) * 8, st));
+    hipLaunchKernelGGL(msnv_deal_measure, grid_for(NR, 256), dim3(256), 0, st, SR.raw, SR.d_recoff, SR.d_recsample, NR, SR.d_send, d_owner, n_contigs, n_parts, cov_min_mapq,
+                       d_key, d_size, d_acc, contig_bases ? d_cb : nullptr);
+    hipLaunchKernelGGL(msnv_deal_iota, grid_for(NR, 256), dim3(256), 0, st, d_idx, NR);
+    HIP_TRY(hipGetLastError());
+    {   // stable sort by owner (8 bits), then the places: exclusive scan of the sizes in that order
+        size_t tmp = 0;
+        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, d_key, d_skey, d_idx, d_order, (size_t)NR, 0u, 8u, st));
+        DP_BUF(uint8_t, d_tmp, tmp + 16);
+        HIP_TRY(rocprim::radix_sort_pairs(d_tmp, tmp, d_key, d_skey, d_idx, d_order, (size_t)NR, 0u, 8u, st));
+        hipLaunchKernelGGL(msnv_deal_sizes, grid_for(NR, 256), dim3(256), 0, st, d_order, d_size, NR, d_ssize);
+        HIP_TRY(hipGetLastError());
+        size_t tmp2 = 0;
+        HIP_TRY(rocprim::exclusive_scan(nullptr, tmp2, d_ssize, d_pos, 0ull, (size_t)NR, rocprim::plus<unsigned long long>(), st));
+        DP_BUF(uint8_t, d_tmp2, tmp2 + 16);
+        HIP_TRY(rocprim::exclusive_scan(d_tmp2, tmp2, d_ssize, d_pos, 0ull, (size_t)NR, rocprim::plus<unsigned long long>(), st));
+    }
+    hipLaunchKernelGGL(msnv_deal_copy, grid_for((uint64_t)NR * 16, 256), dim3(256), 0, st, SR.raw, SR.d_recoff, SR.d_recsample, d_order, d_skey, d_ssize, d_pos, NR, (uint32_t)n_parts, (uint32_t)S,
+                       (unsigned long long)gap, out, d_pb);
+    HIP_TRY(hipGetLastError());
+    std::vector<DealAcc> acc(S * DEAL_COPIES);
+    std::vector<unsigned long long> pb(pb_words);
+    HIP_TRY(hipMemcpyAsync(acc.data(), d_acc, acc.size() * sizeof(DealAcc), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(pb.data(), d_pb, pb_words * 8, hipMemcpyDeviceToHost, st));
+    std::vector<unsigned long long> cb((size_t)std::max(1, n_contigs), 0);
+    if (contig_bases) HIP_TRY(hipMemcpyAsync(cb.data(), d_cb, cb.size() * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (size_t s = 0; s < S; ++s) {
+        msnv_sample_stats &o = stats[s];
+        bool bad_tid = false, bad_owner = false;
+        for (uint32_t c = 0; c < DEAL_COPIES; ++c) {
+            const DealAcc &a = acc[s * DEAL_COPIES + c];
+            o.total_reads += a.total; o.unmapped += a.unmapped; o.zero_quality += a.zero_q; o.proper_pairs += a.proper; o.duplicates += a.dup; o.any_mapped |= a.any_mapped;
+            bad_tid |= a.bad_tid != 0; bad_owner |= a.bad_owner != 0;
+        }
+        if (bad_tid) return fail(MSNV_EFORMAT, "stream %zu: a record refers to a contig beyond the header's %d", s, n_contigs);
+        if (bad_owner) return fail(MSNV_EINVAL, "stream %zu: a contig is owned by a part beyond %d", s, n_parts);
+    }
+    for (uint32_t c = 0; c < DEAL_COPIES; ++c) for (size_t s = 0; s < S; ++s) for (int k = 0; k < n_parts; ++k)
+        part_bytes[s * (size_t)n_parts + (size_t)k] += pb[((size_t)c * S + s) * (size_t)n_parts + (size_t)k];
+    if (contig_bases) for (int c = 0; c < n_contigs; ++c) contig_bases[c] += cb[(size_t)c];
+    return MSNV_OK;
+#undef DP_BUF
+}
+
 int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *streams, const uint64_t *n_bytes, int n, bool on_device) {
     if (n <= 0) return MSNV_OK;
     if (n > 2048) return fail(MSNV_EINVAL, "internal: a device-pack round holds at most 2048 samples");

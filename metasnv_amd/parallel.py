@@ -419,8 +419,14 @@ def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=Non
             mine, decoded, failure = decode_round(plan_round)
             if failure is None:
                 try:
-                    for rec in decoded:
-                        core.contig_bases(rec, len(names), into=local)
+                    if len(decoded) > 1:                     # (one walk over every record's CIGAR: the round's samples side by side, the library releases the GIL)
+                        from concurrent.futures import ThreadPoolExecutor
+                        with ThreadPoolExecutor(max_workers=min(len(decoded), max(1, batch))) as ex:
+                            for part in ex.map(lambda rec: core.contig_bases(rec, len(names)), decoded):
+                                local += part
+                    else:
+                        for rec in decoded:
+                            core.contig_bases(rec, len(names), into=local)
                 except Exception as e:                       # noqa: BLE001
                     failure, decoded = e, []
             held.append((base, plan_round, mine, decoded, failure))

@@ -307,3 +307,56 @@ def test_aux_fields_and_cigars_in_the_cg_field():
     a = run_oracle(["c"], [len(ref)], [ref], streams[True], params=p)
     b = run_oracle(["c"], [len(ref)], [ref], streams[False], params=p)
     assert a[0] == b[0] and a[1] == b[1] and a[0].count("\n") > 10
+
+
+def test_records_dealt_on_the_device_equal_the_host_partition():
+    """msnv_records_deal_device (the N-rank feed's dealing step as kernels) against msnv_records_partition / msnv_records_contig_bases on host
+    threads: the bytes of every (stream, part), their sizes, qaCompute's statistics and the aligned bases per contig -- paired reads, unmapped
+    records, aux tags, SEQ `*`, contigs owned by nobody, empty streams, one-kilobyte scan segments, a gap in front of every part."""
+    hip = C.CDLL("libamdhip64.so")
+    syn, samples = synth_case(n_species=5, contig_len=6000, n_samples=9, mean_cov=9.0, frac_paired=0.4, frac_aux=0.4, frac_noseq=0.05, frac_absent=0.3, seed=41)
+    unm = bt.records(bt.make_record(-1, -1, "*", "ACGT", name="u1", flag=4), bt.make_record(-1, -1, "*", "ACGTAC", name="u2", flag=4))
+    samples = [np.concatenate([s, np.frombuffer(unm.tobytes(), np.uint8)]) if i % 3 == 0 else s for i, s in enumerate(samples)] + [np.zeros(0, np.uint8)]
+    nc = len(syn.names)
+    ctx = core.Context(0)
+    for n_parts, seg_kb, gap in ((1, None, 0), (3, "1", 72), (8, None, 16)):
+        owner = np.array([(c * 7 + 1) % n_parts if c % 4 != 3 else -1 for c in range(nc)], dtype=np.int32)
+        want_parts, want_stats, want_cb = [], [], np.zeros(nc, np.uint64)
+        for s in samples:
+            parts, st = core.partition_records(s, owner, n_parts)
+            want_parts.append(parts); want_stats.append(st); core.contig_bases(s, nc, into=want_cb)
+        cap = sum(int(s.size) for s in samples) + n_parts * gap
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), C.c_size_t(max(16, cap))) == 0
+        assert hip.hipMemset(p, 0xEE, C.c_size_t(max(16, cap))) == 0
+        cb = np.zeros(nc, np.uint64)
+        with _env(MSNV_SCAN_SEG_KB=seg_kb):
+            pb, stats = core.deal_records_device(ctx, samples, owner, n_parts, p.value, cap, gap=gap, contig_bases=cb)
+        got = np.zeros(max(16, cap), np.uint8)
+        assert hip.hipMemcpy(C.c_void_p(got.ctypes.data), p, C.c_size_t(max(16, cap)), 2) == 0
+        hip.hipFree(p)
+        assert np.array_equal(cb, want_cb) and np.array_equal(stats, np.stack(want_stats))
+        assert np.array_equal(pb, np.array([[q.size for q in parts] for parts in want_parts], dtype=np.int64))
+        o = 0
+        for k in range(n_parts):
+            assert (got[o:o + gap] == 0xEE).all()                   # the caller's gap is left alone
+            o += gap
+            for i in range(len(samples)):
+                w = want_parts[i][k]
+                assert got[o:o + w.size].tobytes() == w.tobytes(), (n_parts, k, i)
+                o += w.size
+        assert (got[o:cap] == 0xEE).all()
+    # a record of a contig the header does not have / an owner beyond the parts: the host partition's error codes
+    bad = bt.records(bt.make_record(nc + 2, 5, "10M", "ACGTACGTAC", name="b"))
+    p = C.c_void_p(); assert hip.hipMalloc(C.byref(p), C.c_size_t(4096)) == 0
+    with pytest.raises(core._lib.MsnvError) as e:
+        core.deal_records_device(ctx, [np.frombuffer(bad.tobytes(), np.uint8)], np.zeros(nc, np.int32), 2, p.value, 4096)
+    assert e.value.code == core._lib.EFORMAT
+    p2 = C.c_void_p(); assert hip.hipMalloc(C.byref(p2), C.c_size_t(int(samples[1].size) + 64)) == 0
+    with pytest.raises(core._lib.MsnvError) as e:
+        core.deal_records_device(ctx, [samples[1]], np.full(nc, 5, np.int32), 2, p2.value, int(samples[1].size) + 64)
+    assert e.value.code == core._lib.EINVAL
+    with pytest.raises(core._lib.MsnvError) as e:                   # an output that cannot hold every record
+        core.deal_records_device(ctx, [samples[1]], np.zeros(nc, np.int32), 2, p.value, 64)
+    assert e.value.code == core._lib.ECAPACITY
+    hip.hipFree(p); hip.hipFree(p2); ctx.close()
