@@ -185,6 +185,13 @@ class DeviceParts:
         return self.tensor.data_ptr() + self.offsets[sender] + int(offset)
 
 
+class DeviceSend:
+    """A send buffer of exchange_records that was put together in HBM: one uint8 tensor holding the parts destination-major, and their sizes."""
+
+    def __init__(self, tensor, sizes):
+        self.tensor, self.sizes = tensor, [int(x) for x in sizes]
+
+
 def exchange_records(parts, status=0, keep_on_device=False):
     """All-to-all of byte streams: parts[q] (1-D uint8 array) goes to rank q; returns the list of the arrays this rank
     received, indexed by sender.  {size, status} pairs travel first (one all_to_all of world x 2 int64), then the bytes.
@@ -197,19 +204,50 @@ def exchange_records(parts, status=0, keep_on_device=False):
         return [np.ascontiguousarray(parts[0], dtype=np.uint8)]
     import torch
     dev = _device()
-    sizes = [int(np.asarray(p).size) for p in parts]
-    ts = torch.tensor([[s, int(status)] for s in sizes], dtype=torch.int64, device=dev).reshape(-1)
-    tr = torch.zeros(2 * _world, dtype=torch.int64, device=dev)
+    on_dev_send = isinstance(parts, DeviceSend)           # the send buffer already lies in HBM, destination-major (core.deal_records_device)
+    sizes = [int(x) for x in parts.sizes] if on_dev_send else [int(np.asarray(p).size) for p in parts]
+    # {size, status, my largest part}: the third word tells every rank how many slices the byte exchange needs (below)
+    ts = torch.tensor([[s, int(status), max(sizes) if sizes else 0] for s in sizes], dtype=torch.int64, device=dev).reshape(-1)
+    tr = torch.zeros(3 * _world, dtype=torch.int64, device=dev)
     _dist.all_to_all_single(tr, ts)
     got = tr.cpu().tolist()
-    rsizes, rstatus = got[0::2], got[1::2]
+    rsizes, rstatus, rmax = got[0::3], got[1::3], got[2::3]
     bad = [(r, int(c)) for r, c in enumerate(rstatus) if c]
     if bad:
         raise RankError("rank %d reported error %d while the records were decoded" % bad[0])
-    send = np.concatenate([np.ascontiguousarray(p, dtype=np.uint8).reshape(-1) for p in parts]) if sum(sizes) else np.zeros(0, np.uint8)
-    tsend = torch.from_numpy(send).to(dev)
+    if on_dev_send:
+        tsend = parts.tensor[:sum(sizes)]
+    else:
+        send = np.concatenate([np.ascontiguousarray(p, dtype=np.uint8).reshape(-1) for p in parts]) if sum(sizes) else np.zeros(0, np.uint8)
+        tsend = torch.from_numpy(send).to(dev)
     trecv = torch.empty(sum(rsizes), dtype=torch.uint8, device=dev)
-    _dist.all_to_all_single(trecv, tsend, output_split_sizes=[int(x) for x in rsizes], input_split_sizes=sizes)
+    # The bytes travel in slices of at most 2^29 / world per part: an all_to_all_single of MORE THAN 2^30 uint8 elements returns wrong bytes
+    # behind the first ~half of the buffer on this stack (RCCL of ROCm 7.2 under torch 2.10, found in round 4 at 1.1 GB per round:
+    # profiles/a2a_check.py) -- and a round of a large cohort is several GB.  Every rank walks the same number of slices (the largest part
+    # anywhere, from the size exchange above).
+    slice_bytes = int(os.environ.get("MSNV_A2A_SLICE_KB", "0")) << 10 or max(1 << 20, (1 << 29) // _world)      # (MSNV_A2A_SLICE_KB: tests)
+    n_slices = max(1, -(-max(rmax + [0]) // slice_bytes))
+    soff = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    roff = np.concatenate([[0], np.cumsum(rsizes)]).astype(np.int64)
+    for j in range(n_slices):
+        lo = j * slice_bytes
+        ins = [min(slice_bytes, max(0, n - lo)) for n in sizes]
+        outs = [min(slice_bytes, max(0, n - lo)) for n in rsizes]
+        if n_slices == 1:
+            _dist.all_to_all_single(trecv, tsend, output_split_sizes=outs, input_split_sizes=ins)
+            break
+        live_in = [q for q in range(_world) if ins[q]]
+        tin = (tsend[int(soff[live_in[0]]) + lo:int(soff[live_in[0]]) + lo + ins[live_in[0]]] if len(live_in) == 1
+               else torch.cat([tsend[int(soff[q]) + lo:int(soff[q]) + lo + ins[q]] for q in live_in]) if live_in else tsend[:0])
+        live_out = [r for r in range(_world) if outs[r]]
+        direct = len(live_out) == 1                          # one sender in this slice: straight into its place
+        tout = trecv[int(roff[live_out[0]]) + lo:int(roff[live_out[0]]) + lo + outs[live_out[0]]] if direct else torch.empty(sum(outs), dtype=torch.uint8, device=dev)
+        _dist.all_to_all_single(tout, tin, output_split_sizes=outs, input_split_sizes=ins)
+        if not direct:
+            o = 0
+            for r in live_out:
+                trecv[int(roff[r]) + lo:int(roff[r]) + lo + outs[r]] = tout[o:o + outs[r]]
+                o += outs[r]
     if keep_on_device and dev.type == "cuda":
         torch.cuda.current_stream().synchronize()        # the library reads the tensor on a stream of its own
         return DeviceParts(trecv, rsizes)
@@ -311,7 +349,34 @@ def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=Non
         if failure is None and pending[0] is not None:      # the previous round's append failed here: this round's status word says so
             failure, pending[0] = pending[0], None
         per_dest = [[] for _ in range(_world)]              # per destination rank: (sample, bytes) in sample order
-        if failure is None:
+        # over RCCL with the device pack, the dealing itself runs on the device (core.deal_records_device: one upload of the round's streams,
+        # kernels put every record where the all-to-all sends it from): no host walk over the records, no host copy of the parts
+        # (MSNV_DEAL=host keeps the host threads)
+        dev_send = None
+        deal_on_device = (failure is None and len(decoded) > 0 and _dist is not None and getattr(ds, "ctx", None) is not None and hasattr(ds, "add_samples_records_device")
+                          and os.environ.get("MSNV_PACK", "device")[:1] != "h" and os.environ.get("MSNV_DEAL", "device")[:1] != "h" and _device().type == "cuda")
+        if deal_on_device:
+            try:
+                import torch
+                gap = 8 * len(mine)
+                cap = int(sum(int(r.size) for r in decoded)) + _world * gap
+                tsend = torch.empty(max(cap, 16), dtype=torch.uint8, device=_device())
+                torch.cuda.current_stream().synchronize()
+                pb, st = core.deal_records_device(ds.ctx, decoded, owner, _world, tsend.data_ptr(), cap, gap=gap, cov_min_mapq=cov_min_mapq)
+                sizes, o = [], 0
+                for q in range(_world):                      # the size table of my samples' parts in front of every part
+                    tsend[o:o + gap] = torch.from_numpy(np.ascontiguousarray(pb[:, q], dtype=np.int64).view(np.uint8).copy()).to(_device())
+                    sizes.append(gap + int(pb[:, q].sum()))
+                    o += sizes[-1]
+                for i, rec, row in zip(mine, decoded, st):
+                    inflated += int(rec.size)
+                    stats[i] = row
+                dev_send = DeviceSend(tsend, sizes)
+                if metrics is not None:
+                    metrics["records_dealt_on_device_bytes"] = metrics.get("records_dealt_on_device_bytes", 0) + int(sum(int(r.size) for r in decoded))
+            except Exception as e:                           # noqa: BLE001
+                failure, dev_send = e, None
+        if failure is None and dev_send is None:
             try:
                 # one walk over every sample's records (msnv_records_partition: owner of every record's contig, qaCompute's statistics); the
                 # library releases the GIL, so the round's samples are dealt side by side (one after the other this was 0.3 s per GB and rank)
@@ -338,7 +403,7 @@ def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=Non
         # pack, no second upload (MSNV_PACK=host keeps the round trip)
         on_device = getattr(ds, "ctx", None) is not None and hasattr(ds, "add_samples_records_device") and os.environ.get("MSNV_PACK", "device")[:1] != "h"
         try:
-            got = exchange_records(send, status=0 if failure is None else int(getattr(failure, "code", 0)) or 99, keep_on_device=on_device)
+            got = exchange_records(dev_send if dev_send is not None else send, status=0 if failure is None else int(getattr(failure, "code", 0)) or 99, keep_on_device=on_device)
         except RankError:
             if failure is not None:
                 raise failure

@@ -64,6 +64,9 @@ def main():
     for i in range(sp.n_samples):
         out = os.path.join(work, "s%d.cov" % i)
         core.write_coverage_records(names, syn.lengths, params.cov_max, res["stats"][i], res["acc"][i], out, out + ".detail")
+    # ... and they were dealt to their owners there too (csrc/devpack.hip: msnv_records_deal_device) -- unless the test asks for the host threads
+    want_dealt = 0 if os.environ.get("MSNV_DEAL", "device")[:1] == "h" else sum(syn.sample_records(i).size for i in range(sp.n_samples))
+    assert m.get("records_dealt_on_device_bytes", 0) == want_dealt, m.get("records_dealt_on_device_bytes")
     open(os.path.join(work, "metrics"), "w").write(repr(m))
     parallel.barrier()
     parallel.finalize()

@@ -25,8 +25,11 @@ def _torchrun_one(script_args, env=None, timeout=900):
     return subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=timeout)
 
 
-def test_collectives_and_product_path_over_rccl(tmp_path):
-    r = _torchrun_one([os.path.join(ROOT, "tests", "_nccl_worker.py"), str(tmp_path)])
+@pytest.mark.parametrize("deal", ["device", "host"])
+def test_collectives_and_product_path_over_rccl(tmp_path, deal):
+    """deal: the records are dealt to their owners by kernels (msnv_records_deal_device, the default over RCCL) or by host threads
+    (msnv_records_partition); the worker asserts which one ran."""
+    r = _torchrun_one([os.path.join(ROOT, "tests", "_nccl_worker.py"), str(tmp_path)], env=dict(MSNV_DEAL=deal))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
     sp = core.synth_params(n_species=5, contig_len=4000, n_samples=6, mean_cov=11.0, snv_density=0.03, frac_absent=0.2, seed=55)
     syn = core.Synth(sp)

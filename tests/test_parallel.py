@@ -100,14 +100,16 @@ def _records(buf):
     return out
 
 
-@pytest.mark.parametrize("batch", [1, 2])
-def test_two_rank_decode_sharding_deals_every_record_to_its_owner(tmp_path, batch):
+@pytest.mark.parametrize("batch,slice_kb", [(1, None), (2, None), (2, "4")])
+def test_two_rank_decode_sharding_deals_every_record_to_its_owner(tmp_path, batch, slice_kb):
     """parallel.feed_sharded over gloo: each sample is read by exactly one rank (per-rank decoded bytes ~ 1/N of the job),
     and after the all-to-all every rank holds, per sample and in order, exactly the records of the contigs it owns."""
     work = str(tmp_path)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_feed_worker.py"), work, str(batch)]
-    r = subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    # slice_kb: the byte exchange in slices of 4 KB (parallel.exchange_records walks a large round in slices: uneven parts, parts that end early)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", **({"MSNV_A2A_SLICE_KB": slice_kb} if slice_kb else {}))
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     assert r.returncode == 0, r.stdout.decode()[-3000:]
     sp = core.synth_params(n_species=5, contig_len=2500, n_samples=7, mean_cov=6.0, frac_absent=0.3, seed=77)
     syn = core.Synth(sp)
