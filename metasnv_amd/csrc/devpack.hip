@@ -1167,23 +1167,23 @@ __global__ __launch_bounds__(256) void msnv_deal_measure(const uint8_t *raw, con
                                                          DealAcc *acc, unsigned long long *contig_bases) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     int32_t tid = -1; unsigned long long m = 0;
+    // what this record adds to its stream's counters: bit 0 a record, 1 unmapped, 2 below the MAPQ cutoff, 3 proper pair, 4 duplicate, 5 mapped,
+    // 6 a contig beyond the header, 7 an owner beyond the parts
+    uint32_t f = 0, s = 0xffffffffu;
     if (i < n_rec) {
-        const uint32_t s = rec_sample[i];
+        s = rec_sample[i];
         const Rec r = rec_load(raw + rec_off[i], s_end[s] - rec_off[i]);
-        DealAcc &a = acc[(size_t)s * DEAL_COPIES + (blockIdx.x % DEAL_COPIES)];
-        atomicAdd(&a.total, 1u);
+        f = 1u;
         uint32_t k = 0xffu;                                    // 0xff: the record goes nowhere (unmapped, or its contig is outside every shard)
-        if ((r.flag & BAM_FUNMAP) || r.tid < 0) atomicAdd(&a.unmapped, 1u);
+        if ((r.flag & BAM_FUNMAP) || r.tid < 0) f |= 2u;
         else {
-            a.any_mapped = 1u;
-            if ((int)r.mapq >= cov_min_mapq) {
-                if (r.flag & BAM_FPROPER_PAIR) atomicAdd(&a.proper, 1u);
-                if (r.flag & BAM_FDUP) atomicAdd(&a.dup, 1u);
-            } else atomicAdd(&a.zero_q, 1u);
-            if (r.tid >= n_contigs) a.bad_tid = 1u;
+            f |= 32u;
+            if ((int)r.mapq >= cov_min_mapq) f |= ((r.flag & BAM_FPROPER_PAIR) ? 8u : 0u) | ((r.flag & BAM_FDUP) ? 16u : 0u);
+            else f |= 4u;
+            if (r.tid >= n_contigs) f |= 64u;
             else {
                 const int32_t o = owner[r.tid];
-                if (o >= n_parts) a.bad_owner = 1u;
+                if (o >= n_parts) f |= 128u;
                 else if (o >= 0) k = (uint32_t)o;
                 if (contig_bases) {
                     tid = r.tid;
@@ -1193,6 +1193,38 @@ __global__ __launch_bounds__(256) void msnv_deal_measure(const uint8_t *raw, con
         }
         key[i] = k;
         size[i] = k == 0xffu ? 0u : r.bs + 4u;
+    }
+    {
+        // a wavefront's records nearly always belong to one stream: its lanes' bits are counted by ballots and one lane adds them (a lane
+        // per record on the same few words was 5 ms of same-address atomics for 16 M records)
+        const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s);
+        if (__all(s == s0 || f == 0u)) {
+            if (s0 != 0xffffffffu) {
+                const unsigned long long b0 = __ballot(f & 1u), b1 = __ballot(f & 2u), b2 = __ballot(f & 4u), b3 = __ballot(f & 8u), b4 = __ballot(f & 16u), b5 = __ballot(f & 32u),
+                                         b6 = __ballot(f & 64u), b7 = __ballot(f & 128u);
+                if ((threadIdx.x & 63) == 0) {
+                    DealAcc &a = acc[(size_t)s0 * DEAL_COPIES + (blockIdx.x % DEAL_COPIES)];
+                    atomicAdd(&a.total, (uint32_t)__popcll(b0));
+                    if (b1) atomicAdd(&a.unmapped, (uint32_t)__popcll(b1));
+                    if (b2) atomicAdd(&a.zero_q, (uint32_t)__popcll(b2));
+                    if (b3) atomicAdd(&a.proper, (uint32_t)__popcll(b3));
+                    if (b4) atomicAdd(&a.dup, (uint32_t)__popcll(b4));
+                    if (b5) a.any_mapped = 1u;
+                    if (b6) a.bad_tid = 1u;
+                    if (b7) a.bad_owner = 1u;
+                }
+            }
+        } else if (f) {
+            DealAcc &a = acc[(size_t)s * DEAL_COPIES + (blockIdx.x % DEAL_COPIES)];
+            atomicAdd(&a.total, 1u);
+            if (f & 2u) atomicAdd(&a.unmapped, 1u);
+            if (f & 4u) atomicAdd(&a.zero_q, 1u);
+            if (f & 8u) atomicAdd(&a.proper, 1u);
+            if (f & 16u) atomicAdd(&a.dup, 1u);
+            if (f & 32u) a.any_mapped = 1u;
+            if (f & 64u) a.bad_tid = 1u;
+            if (f & 128u) a.bad_owner = 1u;
+        }
     }
     if (contig_bases) {
         // records are sorted by contig: a wavefront's lanes nearly always share one -- one atomic per wavefront then
