@@ -384,6 +384,12 @@ int  msnv_records_partition(const uint8_t *records, uint64_t n_bytes, const int3
  * major: part 0 of stream 0, of stream 1, ..., part 1 of stream 0, ..., with `gap` bytes left free in front of every part (the caller's size
  * table; capacity >= sum of n_bytes + n_parts * gap).  part_bytes[i * n_parts + k] = bytes of stream i in part k; stats[i] = stream i's
  * qaCompute statistics; contig_bases (may be NULL; n_contigs entries, not cleared) += aligned bases per contig (msnv_records_contig_bases). */
+/* ... for BAM FILES: their BGZF blocks are inflated and CRC-checked on the device and the record streams dealt from there (no host copy of the
+ * inflated bytes); the headers are checked against the dataset's contigs.  record_bytes[i] = bytes of file i's record stream.  The files of a
+ * call must fit ONE batch of the device inflate (1 GB of BAM; MSNV_EDOMAIN otherwise: the caller takes the host route). */
+int  msnv_dataset_deal_bams_device(msnv_dataset *ds, const char *const *bam_paths, int32_t n, int32_t host_threads, const int32_t *contig_owner, int32_t n_parts,
+                                   int32_t cov_min_mapq, uint8_t *out, uint64_t capacity, uint64_t gap, uint64_t *part_bytes, msnv_sample_stats *stats,
+                                   uint64_t *record_bytes);
 int  msnv_records_deal_device(msnv_ctx *ctx, const uint8_t *const *streams, const uint64_t *n_bytes, int32_t n, int32_t on_device, const int32_t *contig_owner,
                               int32_t n_contigs, int32_t n_parts, int32_t cov_min_mapq, uint8_t *out, uint64_t capacity, uint64_t gap, uint64_t *part_bytes,
                               msnv_sample_stats *stats, uint64_t *contig_bases);

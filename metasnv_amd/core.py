@@ -136,6 +136,22 @@ class Dataset:
         check(lib.msnv_dataset_add_sample_records_many(self._h, ptrs, sizes, n, host_threads))
         self.n_samples += n
 
+    def deal_bams_device(self, paths, contig_owner, n_parts, out_ptr, capacity, gap=0, cov_min_mapq=1, host_threads=0):
+        """BAM files inflated on the device and their records dealt from there into out_ptr (DEVICE memory; msnv_dataset_deal_bams_device).
+        Returns (part_bytes[n][n_parts] int64, stats[n][6] uint32, record_bytes[n] int64)."""
+        n = len(paths)
+        owner = np.ascontiguousarray(contig_owner, dtype=np.int32)
+        if owner.size != len(self.names):
+            raise ValueError("contig_owner has %d entries, the dataset %d contigs" % (owner.size, len(self.names)))
+        pb = (C.c_uint64 * max(1, n * n_parts))()
+        st = (SampleStats * max(1, n))()
+        rb = (C.c_uint64 * max(1, n))()
+        check(lib.msnv_dataset_deal_bams_device(self._h, _cstr_array(paths), n, int(host_threads), owner.ctypes.data_as(C.POINTER(C.c_int32)), int(n_parts), int(cov_min_mapq),
+                                                C.c_void_p(int(out_ptr)), int(capacity), int(gap), pb, st, rb))
+        parts = np.array(list(pb)[:n * n_parts], dtype=np.int64).reshape(n, n_parts) if n else np.zeros((0, n_parts), np.int64)
+        stats = np.array([[getattr(st[i], k) for k in STATS_FIELDS] for i in range(n)], dtype=np.uint32).reshape(n, len(STATS_FIELDS))
+        return parts, stats, np.array(list(rb)[:n], dtype=np.int64)
+
     def add_samples_records_device(self, ptrs, sizes):
         """Record streams that lie in HBM of this dataset's device (device addresses + byte counts, e.g. slices of a torch tensor
         an all-to-all has just filled) as consecutive samples: parsed, filtered and packed by kernels (msnv_dataset_add_sample_records_device)."""

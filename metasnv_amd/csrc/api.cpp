@@ -752,6 +752,51 @@ static int add_bams_device_pack(msnv_dataset *ds, const char *const *bam_paths, 
     return MSNV_OK;
 }
 
+// The N-rank feed's decode + deal step without a host copy of the inflated bytes: the files' BGZF blocks are inflated and checked on the device
+// (resident form of bgzf_read_files_device), the record streams are dealt from where the inflate kernel wrote them (records_deal_device).
+extern "C" int msnv_dataset_deal_bams_device(msnv_dataset *ds, const char *const *bam_paths, int32_t n, int32_t host_threads, const int32_t *contig_owner, int32_t n_parts,
+                                             int32_t cov_min_mapq, uint8_t *out, uint64_t capacity, uint64_t gap, uint64_t *part_bytes, msnv_sample_stats *stats, uint64_t *record_bytes) {
+    clear_error();
+    if (!ds || n < 0 || (n && (!bam_paths || !part_bytes || !stats || !record_bytes)) || !contig_owner) return fail(MSNV_EINVAL, "msnv_dataset_deal_bams_device: bad argument");
+    if (!ds->ctx) return fail(MSNV_ENODEV, "msnv_dataset_deal_bams_device needs a dataset with a device context");
+    if (n == 0) return MSNV_OK;
+    int nthreads = host_threads > 0 ? host_threads : (int)std::max(1u, std::thread::hardware_concurrency());
+    nthreads = std::min(nthreads, std::max(1, (int)n));
+    {   // one batch of the device inflate only: the parts of a call lie destination-major in `out`
+        const uint64_t batch_in = [] { const char *e = getenv("MSNV_INFLATE_BATCH_MB"); const long long v = e ? atoll(e) : 1024; return (uint64_t)std::max<long long>(1, v) << 20; }();
+        uint64_t ib = 0;
+        for (int i = 0; i < n; ++i) {
+            FILE *f = fopen(bam_paths[i], "rb");
+            if (!f) return fail(MSNV_EIO, "cannot open %s", bam_paths[i]);
+            fseek(f, 0, SEEK_END);
+            const long z = ftell(f);
+            fclose(f);
+            if (z < 0) return fail(MSNV_EIO, "cannot stat %s", bam_paths[i]);
+            ib += ((uint64_t)z + 31) & ~15ull;
+        }
+        if (n > 1 && ib > batch_in) return fail_quiet(MSNV_EDOMAIN, "msnv_dataset_deal_bams_device: the files of the call do not fit one batch of the device inflate (%llu bytes)", (unsigned long long)ib);
+    }
+    const int NC = (int)ds->names.size();
+    ResidentBatch rb;
+    int calls = 0;
+    auto consume = [&](int f0, int f1, const uint8_t *host_out, const std::vector<InflatedExt> &ext, bool dev_valid) -> int {
+        if (calls++ || f0 != 0 || f1 != n) return fail(MSNV_EINVAL, "internal: msnv_dataset_deal_bams_device expects one batch");
+        std::vector<const uint8_t *> ptrs; std::vector<uint64_t> sizes;
+        const uint8_t *base = dev_valid ? static_cast<const uint8_t *>(ds->ctx->dev_out) : host_out;      // (a batch the host decoder had to take lies in host memory)
+        for (int i = 0; i < n; ++i) {
+            const uint64_t size = ext[(size_t)i].size, rec_off = rb.rec_off[(size_t)i];
+            if (int rc = check_header(*ds, rb.hdr[(size_t)i], bam_paths[i])) return rc;
+            if (rec_off > size) return fail(MSNV_EFORMAT, "%s: truncated BAM header", bam_paths[i]);
+            ptrs.push_back(base + ext[(size_t)i].off + rec_off);
+            sizes.push_back(size - rec_off);
+            record_bytes[i] = size - rec_off;
+        }
+        return records_deal_device(ds->ctx, ptrs.data(), sizes.data(), n, dev_valid, contig_owner, NC, n_parts, cov_min_mapq, out, capacity, gap, part_bytes, stats, nullptr);
+    };
+    try { uint64_t cnt[4]; return bgzf_read_files_device(ds->ctx, bam_paths, n, nthreads, consume, cnt, &rb); }
+    catch (const std::exception &e) { return fail(MSNV_ENOMEM, "msnv_dataset_deal_bams_device: %s", e.what()); }
+}
+
 extern "C" int msnv_dataset_add_sample_bams(msnv_dataset *ds, const char *const *bam_paths, int32_t n, int32_t host_threads) {
     clear_error();
     HostTimerScope ts_all(HT_ADD_WALL);

@@ -226,3 +226,49 @@ def test_resident_device_inflate_checks_every_block_in_hbm(tmp_path, monkeypatch
     ds.add_sample_bams([paths[0], str(tmp_path / "bad_crc.bam"), paths[2]], 3)
     assert ds.finalize()["n_pileup_bases"] > 0
     ds.close(); ctx.close()
+
+
+def test_bam_files_inflated_and_dealt_on_the_device(tmp_path, monkeypatch):
+    """msnv_dataset_deal_bams_device: the N-rank feed's decode + deal step with nothing of the inflated bytes on the host -- against the host route
+    (msnv_bam_read + msnv_records_partition) file by file: part bytes, sizes, statistics; a BAM of another reference is refused like everywhere."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    sp = core.synth_params(n_species=4, contig_len=20000, n_samples=5, mean_cov=10.0, frac_paired=0.3, frac_absent=0.2, seed=17)
+    syn = core.Synth(sp)
+    fa = str(tmp_path / "ref.fa"); syn.write_fasta(fa)
+    paths = []
+    for i in range(sp.n_samples):
+        p = str(tmp_path / ("s%d.bam" % i)); core.write_bam(p, syn.names, syn.lengths, syn.sample_records(i), level=[6, 0, 9, 1, 4][i]); paths.append(p)
+    ctx = core.Context(0)
+    ds = core.Dataset.from_files(ctx, paths[0], fa)
+    nc, n_parts, gap = len(syn.names), 3, 8 * len(paths)
+    owner = np.array([c % n_parts if c != 2 else -1 for c in range(nc)], dtype=np.int32)
+    want = [core.partition_records(core.read_bam(p)["records"], owner, n_parts) for p in paths]
+    cap = sum(core.read_bam(p)["records"].size for p in paths) + n_parts * gap
+    d = C.c_void_p(); assert hip.hipMalloc(C.byref(d), C.c_size_t(cap + 64)) == 0
+    t0 = core.host_timers()
+    pb, stats, rbytes = ds.deal_bams_device(paths, owner, n_parts, d.value, cap, gap=gap, host_threads=3)
+    t1 = core.host_timers()
+    assert t1["inflate_host_s"] == t0["inflate_host_s"]                       # no block went through the host decoder
+    got = np.zeros(cap, np.uint8); assert hip.hipMemcpy(C.c_void_p(got.ctypes.data), d, C.c_size_t(cap), 2) == 0
+    assert [int(x) for x in rbytes] == [core.read_bam(p)["records"].size for p in paths]
+    assert np.array_equal(stats, np.stack([w[1] for w in want])) and np.array_equal(pb, np.array([[q.size for q in w[0]] for w in want], dtype=np.int64))
+    o = 0
+    for k in range(n_parts):
+        o += gap
+        for i in range(len(paths)):
+            w = want[i][0][k]
+            assert got[o:o + w.size].tobytes() == w.tobytes(), (k, i)
+            o += w.size
+    # a file whose header names other contigs
+    other = str(tmp_path / "other.bam"); core.write_bam(other, ["x1", "x2"], [100, 200], np.zeros(0, np.uint8))
+    with pytest.raises(_lib.MsnvError) as e:
+        ds.deal_bams_device([paths[0], other], owner, n_parts, d.value, cap, gap=gap)
+    assert e.value.code == _lib.EFORMAT
+    # more than one batch of the device inflate: the caller is told to take the host route
+    monkeypatch.setenv("MSNV_INFLATE_BATCH_MB", "1")
+    if sum(os.path.getsize(p) for p in paths) > (1 << 20):
+        with pytest.raises(_lib.MsnvError) as e:
+            ds.deal_bams_device(paths, owner, n_parts, d.value, cap, gap=gap)
+        assert e.value.code == _lib.EDOMAIN
+    hip.hipFree(d); ds.close(); ctx.close()
