@@ -326,11 +326,43 @@ def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=Non
     stats = np.zeros((n, len(core.STATS_FIELDS)), dtype=np.uint32)
     inflated = 0
     batch = max(1, min(batch, -(-n // _world)))          # fewer samples than world x batch: every rank still decodes its share
+    class DealtRound:
+        """A round that left decode_round already dealt on the device: the send tensor with the parts destination-major behind their gaps."""
+        def __init__(self, tensor, part_bytes, stats, record_bytes, gap):
+            self.tensor, self.part_bytes, self.stats, self.record_bytes, self.gap = tensor, part_bytes, stats, record_bytes, gap
+
+    def device_route():
+        return (owner is not None and _dist is not None and getattr(ds, "ctx", None) is not None and hasattr(ds, "deal_bams_device")
+                and os.environ.get("MSNV_PACK", "device")[:1] != "h" and os.environ.get("MSNV_DEAL", "device")[:1] != "h"
+                and os.environ.get("MSNV_INFLATE", "device")[:1] == "d" and _device().type == "cuda")
+
+    def deal_files_on_device(paths):
+        import torch
+        gap = 8 * len(paths)
+        comp = sum(os.path.getsize(p) for p in paths)
+        cap = 8 * comp + (1 << 20) + _world * gap             # (BAM inflates 2.5-4 x; the call answers MSNV_ECAPACITY when this is not enough)
+        tsend = torch.empty(cap, dtype=torch.uint8, device=_device())
+        torch.cuda.current_stream().synchronize()
+        try:
+            pb, st, rb = ds.deal_bams_device(paths, owner, _world, tsend.data_ptr(), cap, gap=gap, cov_min_mapq=cov_min_mapq, host_threads=max(1, len(paths)))
+        except core._lib.MsnvError as e:
+            if e.code in (core._lib.EDOMAIN, core._lib.ECAPACITY):
+                return None
+            raise
+        return DealtRound(tsend, pb, st, rb, gap)
+
     def decode_round(plan_round):
         """My samples of this round, decoded; a failure here is carried to every rank by the exchange (status word)."""
         mine = [i for i, r in plan_round if r == _rank]
         failure, decoded = None, []
         try:
+            if read_many is not None and mine and device_route():
+                # owners known, RCCL, device pack: the round's files are inflated, CRC-checked and dealt ON THE DEVICE (core.Dataset.deal_bams_device:
+                # nothing of the inflated bytes on the host); a round that does not fit one batch of the device inflate, or an output that turns
+                # out too small for its inflated bytes, takes the host route below
+                dealt = deal_files_on_device([bam_paths[i] for i in mine])
+                if dealt is not None:
+                    return mine, dealt, None
             if read_many is not None:
                 decoded = read_many([bam_paths[i] for i in mine])
             elif len(mine) > 1:                              # the library releases the GIL: one decode thread per BAM of the round
@@ -353,7 +385,26 @@ def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=Non
         # kernels put every record where the all-to-all sends it from): no host walk over the records, no host copy of the parts
         # (MSNV_DEAL=host keeps the host threads)
         dev_send = None
-        deal_on_device = (failure is None and len(decoded) > 0 and _dist is not None and getattr(ds, "ctx", None) is not None and hasattr(ds, "add_samples_records_device")
+        if failure is None and isinstance(decoded, DealtRound):
+            try:
+                import torch
+                pb, gap, tsend = decoded.part_bytes, decoded.gap, decoded.tensor
+                sizes, o = [], 0
+                for q in range(_world):
+                    tsend[o:o + gap] = torch.from_numpy(np.ascontiguousarray(pb[:, q], dtype=np.int64).view(np.uint8).copy()).to(_device())
+                    sizes.append(gap + int(pb[:, q].sum()))
+                    o += sizes[-1]
+                for i, row, nb in zip(mine, decoded.stats, decoded.record_bytes):
+                    inflated += int(nb)
+                    stats[i] = row
+                dev_send = DeviceSend(tsend, sizes)
+                if metrics is not None:
+                    metrics["records_dealt_on_device_bytes"] = metrics.get("records_dealt_on_device_bytes", 0) + int(decoded.record_bytes.sum())
+                    metrics["bams_inflated_on_device_bytes"] = metrics.get("bams_inflated_on_device_bytes", 0) + int(decoded.record_bytes.sum())
+            except Exception as e:                           # noqa: BLE001
+                failure, dev_send = e, None
+            decoded = []
+        deal_on_device = (dev_send is None and failure is None and len(decoded) > 0 and _dist is not None and getattr(ds, "ctx", None) is not None and hasattr(ds, "add_samples_records_device")
                           and os.environ.get("MSNV_PACK", "device")[:1] != "h" and os.environ.get("MSNV_DEAL", "device")[:1] != "h" and _device().type == "cuda")
         if deal_on_device:
             try:

@@ -43,8 +43,11 @@ def test_collectives_and_product_path_over_rccl(tmp_path, deal):
         assert open(tmp_path / ("s%d.cov" % i)).read() == want[0] and open(tmp_path / ("s%d.cov.detail" % i)).read() == want[1]
 
 
-def test_launcher_under_one_rccl_rank_matches_the_oracle(tmp_path):
-    """metaSNV.py (reference argv) with the process group FORCED for a single rank (MSNV_DIST_FORCE=1, backend nccl): the BAMs go
+@pytest.mark.parametrize("plan_mb", [None, "1"])
+def test_launcher_under_one_rccl_rank_matches_the_oracle(tmp_path, plan_mb):
+    """plan_mb = "1": the split planner holds one megabyte of decoded records only, so the later rounds STREAM -- their BAMs are inflated,
+    checked and dealt on the device (msnv_dataset_deal_bams_device), nothing of their inflated bytes on the host.
+    metaSNV.py (reference argv) with the process group FORCED for a single rank (MSNV_DIST_FORCE=1, backend nccl): the BAMs go
     through msnv_bam_records_many -> partition -> all_to_all over RCCL -> pack, the coverage rows and the cell-form site records
     through the RCCL gather to rank 0.  Same bytes as the oracle for called_SNPs / indiv_called per split and every cov/ file."""
     syn, samples = synth_case(n_species=6, contig_len=3500, n_samples=8, mean_cov=11.0, snv_density=0.03, frac_absent=0.15, seed=91)
@@ -58,7 +61,7 @@ def test_launcher_under_one_rccl_rank_matches_the_oracle(tmp_path):
     lst = str(tmp_path / "all_samples")
     open(lst, "w").write("\n".join(paths) + "\n")
     proj, met = str(tmp_path / "proj"), str(tmp_path / "metrics.jsonl")
-    r = _torchrun_one([os.path.join(ROOT, "metaSNV.py"), proj, lst, fa, "--n_splits", "2"], env=dict(MSNV_DIST_FORCE="1", MSNV_METRICS=met))
+    r = _torchrun_one([os.path.join(ROOT, "metaSNV.py"), proj, lst, fa, "--n_splits", "2"], env=dict(MSNV_DIST_FORCE="1", MSNV_METRICS=met, **({"MSNV_PLAN_MB": plan_mb} if plan_mb else {})))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-6000:]
     total = 0
     for spf in sorted(os.listdir(os.path.join(proj, "bestsplits"))):
@@ -75,3 +78,6 @@ def test_launcher_under_one_rccl_rank_matches_the_oracle(tmp_path):
     import json
     m = [json.loads(l) for l in open(met)]
     assert len(m) == 1 and m[0]["world"] == 1 and m[0]["gather_bytes_received"] > 0
+    assert m[0].get("records_dealt_on_device_bytes", 0) == sum(int(s.size) for s in samples)       # every record was dealt by kernels ...
+    if plan_mb:
+        assert 0 < m[0].get("bams_inflated_on_device_bytes", 0) < sum(int(s.size) for s in samples)  # ... and the streamed rounds' files never reached the host inflated
