@@ -390,6 +390,11 @@ int  msnv_records_partition(const uint8_t *records, uint64_t n_bytes, const int3
 int  msnv_dataset_deal_bams_device(msnv_dataset *ds, const char *const *bam_paths, int32_t n, int32_t host_threads, const int32_t *contig_owner, int32_t n_parts,
                                    int32_t cov_min_mapq, uint8_t *out, uint64_t capacity, uint64_t gap, uint64_t *part_bytes, msnv_sample_stats *stats,
                                    uint64_t *record_bytes);
+/* ... before the owners are known (the split planner holds decoded rounds): the files' record streams, inflated and checked on the device, are
+ * left in `out` (DEVICE memory) -- stream i at out + rec_off[i], rec_bytes[i] long, 16 readable bytes behind it -- with their statistics and the
+ * aligned bases per contig (contig_bases, n_contigs of the dataset, not cleared); msnv_records_deal_device (on_device != 0) deals them later. */
+int  msnv_dataset_inflate_bams_device(msnv_dataset *ds, const char *const *bam_paths, int32_t n, int32_t host_threads, uint8_t *out, uint64_t capacity,
+                                      uint64_t *rec_off, uint64_t *rec_bytes, msnv_sample_stats *stats, uint64_t *contig_bases);
 int  msnv_records_deal_device(msnv_ctx *ctx, const uint8_t *const *streams, const uint64_t *n_bytes, int32_t n, int32_t on_device, const int32_t *contig_owner,
                               int32_t n_contigs, int32_t n_parts, int32_t cov_min_mapq, uint8_t *out, uint64_t capacity, uint64_t gap, uint64_t *part_bytes,
                               msnv_sample_stats *stats, uint64_t *contig_bases);

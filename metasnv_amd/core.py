@@ -152,6 +152,17 @@ class Dataset:
         stats = np.array([[getattr(st[i], k) for k in STATS_FIELDS] for i in range(n)], dtype=np.uint32).reshape(n, len(STATS_FIELDS))
         return parts, stats, np.array(list(rb)[:n], dtype=np.int64)
 
+    def inflate_bams_device(self, paths, out_ptr, capacity, contig_bases=None, host_threads=0):
+        """BAM files inflated and checked on the device, their record streams left in out_ptr (DEVICE memory; msnv_dataset_inflate_bams_device).
+        Returns (offsets[n], sizes[n] as int64 arrays, stats[n][6] uint32); contig_bases (uint64[n_contigs]) += aligned bases per contig."""
+        n = len(paths)
+        ro = (C.c_uint64 * max(1, n))(); rb = (C.c_uint64 * max(1, n))()
+        st = (SampleStats * max(1, n))()
+        cb = contig_bases.ctypes.data_as(C.POINTER(C.c_uint64)) if contig_bases is not None else None
+        check(lib.msnv_dataset_inflate_bams_device(self._h, _cstr_array(paths), n, int(host_threads), C.c_void_p(int(out_ptr)), int(capacity), ro, rb, st, cb))
+        stats = np.array([[getattr(st[i], k) for k in STATS_FIELDS] for i in range(n)], dtype=np.uint32).reshape(n, len(STATS_FIELDS))
+        return np.array(list(ro)[:n], dtype=np.int64), np.array(list(rb)[:n], dtype=np.int64), stats
+
     def add_samples_records_device(self, ptrs, sizes):
         """Record streams that lie in HBM of this dataset's device (device addresses + byte counts, e.g. slices of a torch tensor
         an all-to-all has just filled) as consecutive samples: parsed, filtered and packed by kernels (msnv_dataset_add_sample_records_device)."""

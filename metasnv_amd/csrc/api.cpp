@@ -797,6 +797,57 @@ extern "C" int msnv_dataset_deal_bams_device(msnv_dataset *ds, const char *const
     catch (const std::exception &e) { return fail(MSNV_ENOMEM, "msnv_dataset_deal_bams_device: %s", e.what()); }
 }
 
+// ... and the step BEFORE the owners are known (the split planner holds decoded rounds): the files' record streams, inflated and checked on the
+// device, are left in the caller's device buffer -- stream i at rec_off[i], rec_bytes[i] long -- with their statistics and the aligned bases per
+// contig the planner weighs contigs by; msnv_records_deal_device deals them from there later.
+extern "C" int msnv_dataset_inflate_bams_device(msnv_dataset *ds, const char *const *bam_paths, int32_t n, int32_t host_threads, uint8_t *out, uint64_t capacity,
+                                                uint64_t *rec_off, uint64_t *rec_bytes, msnv_sample_stats *stats, uint64_t *contig_bases) {
+    clear_error();
+    if (!ds || n < 0 || (n && (!bam_paths || !rec_off || !rec_bytes || !stats || !out))) return fail(MSNV_EINVAL, "msnv_dataset_inflate_bams_device: bad argument");
+    if (!ds->ctx) return fail(MSNV_ENODEV, "msnv_dataset_inflate_bams_device needs a dataset with a device context");
+    if (n == 0) return MSNV_OK;
+    int nthreads = host_threads > 0 ? host_threads : (int)std::max(1u, std::thread::hardware_concurrency());
+    nthreads = std::min(nthreads, std::max(1, (int)n));
+    {
+        const uint64_t batch_in = [] { const char *e = getenv("MSNV_INFLATE_BATCH_MB"); const long long v = e ? atoll(e) : 1024; return (uint64_t)std::max<long long>(1, v) << 20; }();
+        uint64_t ib = 0;
+        for (int i = 0; i < n; ++i) {
+            FILE *f = fopen(bam_paths[i], "rb");
+            if (!f) return fail(MSNV_EIO, "cannot open %s", bam_paths[i]);
+            fseek(f, 0, SEEK_END);
+            const long z = ftell(f);
+            fclose(f);
+            if (z < 0) return fail(MSNV_EIO, "cannot stat %s", bam_paths[i]);
+            ib += ((uint64_t)z + 31) & ~15ull;
+        }
+        if (n > 1 && ib > batch_in) return fail_quiet(MSNV_EDOMAIN, "msnv_dataset_inflate_bams_device: the files of the call do not fit one batch of the device inflate (%llu bytes)", (unsigned long long)ib);
+    }
+    const int NC = (int)ds->names.size();
+    ResidentBatch rb;
+    int calls = 0;
+    auto consume = [&](int f0, int f1, const uint8_t *host_out, const std::vector<InflatedExt> &ext, bool dev_valid) -> int {
+        if (calls++ || f0 != 0 || f1 != n) return fail(MSNV_EINVAL, "internal: msnv_dataset_inflate_bams_device expects one batch");
+        std::vector<const uint8_t *> ptrs; std::vector<uint64_t> sizes;
+        const uint8_t *base = dev_valid ? static_cast<const uint8_t *>(ds->ctx->dev_out) : host_out;
+        uint64_t o = 0;
+        for (int i = 0; i < n; ++i) {
+            const uint64_t size = ext[(size_t)i].size, ro = rb.rec_off[(size_t)i];
+            if (int rc = check_header(*ds, rb.hdr[(size_t)i], bam_paths[i])) return rc;
+            if (ro > size) return fail(MSNV_EFORMAT, "%s: truncated BAM header", bam_paths[i]);
+            rec_off[i] = o; rec_bytes[i] = size - ro;
+            if (o + (size - ro) + 32 > capacity) return fail_quiet(MSNV_ECAPACITY, "msnv_dataset_inflate_bams_device: the output holds %llu bytes, more are needed", (unsigned long long)capacity);
+            if (size - ro) if (int rc = dev_copy_bytes(out + o, base + ext[(size_t)i].off + ro, size - ro, dev_valid, ds->ctx->stream)) return rc;
+            ptrs.push_back(out + o); sizes.push_back(size - ro);
+            o += (size - ro + 31) & ~15ull;                       // (16 readable bytes behind every stream)
+        }
+        std::vector<int32_t> nobody((size_t)std::max(1, NC), -1);
+        std::vector<uint64_t> pb((size_t)n, 0);
+        return records_deal_device(ds->ctx, ptrs.data(), sizes.data(), n, true, nobody.data(), NC, 1, ds->params.cov_min_mapq, nullptr, 0, 0, pb.data(), stats, contig_bases);
+    };
+    try { uint64_t cnt[4]; return bgzf_read_files_device(ds->ctx, bam_paths, n, nthreads, consume, cnt, &rb); }
+    catch (const std::exception &e) { return fail(MSNV_ENOMEM, "msnv_dataset_inflate_bams_device: %s", e.what()); }
+}
+
 extern "C" int msnv_dataset_add_sample_bams(msnv_dataset *ds, const char *const *bam_paths, int32_t n, int32_t host_threads) {
     clear_error();
     HostTimerScope ts_all(HT_ADD_WALL);
@@ -1496,7 +1547,7 @@ extern "C" int msnv_records_deal_device(msnv_ctx *ctx, const uint8_t *const *str
                                         int32_t n_parts, int32_t cov_min_mapq, uint8_t *out, uint64_t capacity, uint64_t gap, uint64_t *part_bytes, msnv_sample_stats *stats,
                                         uint64_t *contig_bases) {
     clear_error();
-    if (!ctx || n < 0 || n_contigs < 0 || (n && (!streams || !n_bytes || !part_bytes || !stats)) || (n_contigs && !owner) || (!out && capacity))
+    if (!ctx || n < 0 || n_contigs < 0 || (n && (!streams || !n_bytes || !part_bytes || !stats)) || (n_contigs && !owner) || (!out && capacity))      // (out = NULL, capacity = 0: measure only)
         return fail(MSNV_EINVAL, "msnv_records_deal_device: bad argument");
     for (int i = 0; i < n; ++i) if (n_bytes[i] && !streams[i]) return fail(MSNV_EINVAL, "msnv_records_deal_device: stream %d is NULL", i);
     try { return records_deal_device(ctx, streams, n_bytes, n, on_device != 0, owner, n_contigs, n_parts, cov_min_mapq, out, capacity, gap, part_bytes, stats, contig_bases); }

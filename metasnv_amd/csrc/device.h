@@ -170,6 +170,7 @@ int  dev_alloc(void **p, uint64_t bytes, uint64_t *acct);
 void dev_free(void *p);
 int  dev_upload(void *dst, const void *src, uint64_t bytes);
 int  dev_download(void *dst, const void *src, uint64_t bytes);
+int  dev_copy_bytes(void *dst_device, const void *src, uint64_t bytes, bool src_on_device, void *stream);      // device <- device or host, on the stream, waited for
 int  dev_memset(void *dst, int v, uint64_t bytes);
 int  dev_stream_create(void **stream);
 void dev_stream_destroy(void *stream);

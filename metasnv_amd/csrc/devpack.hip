@@ -1283,9 +1283,10 @@ int records_deal_device(msnv_ctx *ctx, const uint8_t *const *streams, const uint
     if (int rc = scan_streams(st, ctx->device, pool, streams, n_bytes, S, on_device, n_contigs, SR)) return rc;
     for (size_t s = 0; s < S; ++s) if (SR.bad_off[s] != ~0ull) return fail(MSNV_EFORMAT, "malformed BAM record at byte %llu of stream %zu", (unsigned long long)SR.bad_off[s], s);
     const uint32_t NR = SR.NR;
+    const bool measure_only = out == nullptr;                      // statistics and aligned bases only (the split planner's pass over held streams)
     uint64_t need = (uint64_t)n_parts * gap;
     for (size_t s = 0; s < S; ++s) need += n_bytes[s];
-    if (capacity < need) return fail(MSNV_ECAPACITY, "msnv_records_deal_device: the output holds %llu bytes, up to %llu are needed", (unsigned long long)capacity, (unsigned long long)need);
+    if (!measure_only && capacity < need) return fail(MSNV_ECAPACITY, "msnv_records_deal_device: the output holds %llu bytes, up to %llu are needed", (unsigned long long)capacity, (unsigned long long)need);
     for (size_t i = 0; i < S * (size_t)n_parts; ++i) part_bytes[i] = 0;
     for (size_t s = 0; s < S; ++s) stats[s] = msnv_sample_stats{};
     if (!NR) return MSNV_OK;
@@ -1308,9 +1309,10 @@ int records_deal_device(msnv_ctx *ctx, const uint8_t *const *streams, const uint
     if (contig_bases) HIP_TRY(hipMemsetAsync(d_cb, 0, (size_t)std::max(1, n_contigs) * 8, st));
     hipLaunchKernelGGL(msnv_deal_measure, grid_for(NR, 256), dim3(256), 0, st, SR.raw, SR.d_recoff, SR.d_recsample, NR, SR.d_send, d_owner, n_contigs, n_parts, cov_min_mapq,
                        d_key, d_size, d_acc, contig_bases ? d_cb : nullptr);
-    hipLaunchKernelGGL(msnv_deal_iota, grid_for(NR, 256), dim3(256), 0, st, d_idx, NR);
     HIP_TRY(hipGetLastError());
-    {   // stable sort by owner (8 bits), then the places: exclusive scan of the sizes in that order
+    if (!measure_only) {   // stable sort by owner (8 bits), then the places: exclusive scan of the sizes in that order
+        hipLaunchKernelGGL(msnv_deal_iota, grid_for(NR, 256), dim3(256), 0, st, d_idx, NR);
+        HIP_TRY(hipGetLastError());
         size_t tmp = 0;
         HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, d_key, d_skey, d_idx, d_order, (size_t)NR, 0u, 8u, st));
         DP_BUF(uint8_t, d_tmp, tmp + 16);
@@ -1322,7 +1324,7 @@ int records_deal_device(msnv_ctx *ctx, const uint8_t *const *streams, const uint
         DP_BUF(uint8_t, d_tmp2, tmp2 + 16);
         HIP_TRY(rocprim::exclusive_scan(d_tmp2, tmp2, d_ssize, d_pos, 0ull, (size_t)NR, rocprim::plus<unsigned long long>(), st));
     }
-    hipLaunchKernelGGL(msnv_deal_copy, grid_for((uint64_t)NR * 16, 256), dim3(256), 0, st, SR.raw, SR.d_recoff, SR.d_recsample, d_order, d_skey, d_ssize, d_pos, NR, (uint32_t)n_parts, (uint32_t)S,
+    if (!measure_only) hipLaunchKernelGGL(msnv_deal_copy, grid_for((uint64_t)NR * 16, 256), dim3(256), 0, st, SR.raw, SR.d_recoff, SR.d_recsample, d_order, d_skey, d_ssize, d_pos, NR, (uint32_t)n_parts, (uint32_t)S,
                        (unsigned long long)gap, out, d_pb);
     HIP_TRY(hipGetLastError());
     std::vector<DealAcc> acc(S * DEAL_COPIES);

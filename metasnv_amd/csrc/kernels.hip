@@ -2586,6 +2586,12 @@ int dev_upload(void *dst, const void *src, uint64_t bytes) {
     return MSNV_OK;
 }
 int dev_download(void *dst, const void *src, uint64_t bytes) { if (bytes) HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return MSNV_OK; }
+int dev_copy_bytes(void *dst_device, const void *src, uint64_t bytes, bool src_on_device, void *stream) {
+    if (!bytes) return MSNV_OK;
+    HIP_TRY(hipMemcpyAsync(dst_device, src, bytes, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return MSNV_OK;
+}
 // hipMemset of device memory is enqueued on the null stream and returns before it has run, and the passes run on a NON-BLOCKING stream
 // that the null stream does not order: without the wait below the first kernels of a pass can meet buffers that are not zero yet (fresh
 // hipMalloc memory happens to be zero, so nothing showed -- until a profiler's counter pass delayed the fill kernels and the first pass

@@ -331,8 +331,14 @@ def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=Non
         def __init__(self, tensor, part_bytes, stats, record_bytes, gap):
             self.tensor, self.part_bytes, self.stats, self.record_bytes, self.gap = tensor, part_bytes, stats, record_bytes, gap
 
-    def device_route():
-        return (owner is not None and _dist is not None and getattr(ds, "ctx", None) is not None and hasattr(ds, "deal_bams_device")
+    class HeldOnDevice:
+        """A round decoded BEFORE the owners are known, held in HBM: its record streams in one tensor (inflated there), their statistics and the
+        aligned bases per contig the planner asked for; deliver() deals them from where they lie."""
+        def __init__(self, tensor, offsets, sizes, stats, bases):
+            self.tensor, self.offsets, self.sizes, self.stats, self.bases = tensor, offsets, sizes, stats, bases
+
+    def device_route(need_owner=True):
+        return ((owner is not None or not need_owner) and _dist is not None and getattr(ds, "ctx", None) is not None and hasattr(ds, "deal_bams_device")
                 and os.environ.get("MSNV_PACK", "device")[:1] != "h" and os.environ.get("MSNV_DEAL", "device")[:1] != "h"
                 and os.environ.get("MSNV_INFLATE", "device")[:1] == "d" and _device().type == "cuda")
 
@@ -351,11 +357,34 @@ def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=Non
             raise
         return DealtRound(tsend, pb, st, rb, gap)
 
-    def decode_round(plan_round):
-        """My samples of this round, decoded; a failure here is carried to every rank by the exchange (status word)."""
+    def hold_files_on_device(paths, n_contigs):
+        import torch
+        comp = sum(os.path.getsize(p) for p in paths)
+        cap = 8 * comp + (1 << 20) + 32 * len(paths)
+        t = torch.empty(cap, dtype=torch.uint8, device=_device())
+        torch.cuda.current_stream().synchronize()
+        cb = np.zeros(n_contigs, dtype=np.uint64)
+        try:
+            offs, sizes, st = ds.inflate_bams_device(paths, t.data_ptr(), cap, contig_bases=cb, host_threads=max(1, len(paths)))
+        except core._lib.MsnvError as e:
+            if e.code in (core._lib.EDOMAIN, core._lib.ECAPACITY):
+                return None
+            raise
+        used = int(offs[-1] + sizes[-1]) + 32 if len(offs) else 32
+        held_t = t[:used].clone()                            # (the generous buffer goes back to the allocator's cache: the next round takes it again)
+        del t
+        return HeldOnDevice(held_t, offs, sizes, st, cb)
+
+    def decode_round(plan_round, hold_contigs=0):
+        """My samples of this round, decoded; a failure here is carried to every rank by the exchange (status word).
+        hold_contigs > 0: the split planner's call -- over RCCL the files are inflated on the device and HELD there (HeldOnDevice)."""
         mine = [i for i, r in plan_round if r == _rank]
         failure, decoded = None, []
         try:
+            if hold_contigs and read_many is not None and mine and device_route(need_owner=False):
+                held_dev = hold_files_on_device([bam_paths[i] for i in mine], hold_contigs)
+                if held_dev is not None:
+                    return mine, held_dev, None
             if read_many is not None and mine and device_route():
                 # owners known, RCCL, device pack: the round's files are inflated, CRC-checked and dealt ON THE DEVICE (core.Dataset.deal_bams_device:
                 # nothing of the inflated bytes on the host); a round that does not fit one batch of the device inflate, or an output that turns
@@ -385,6 +414,31 @@ def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=Non
         # kernels put every record where the all-to-all sends it from): no host walk over the records, no host copy of the parts
         # (MSNV_DEAL=host keeps the host threads)
         dev_send = None
+        if failure is None and isinstance(decoded, HeldOnDevice):
+            try:
+                import torch
+                gap = 8 * len(mine)
+                cap = int(decoded.sizes.sum()) + _world * gap
+                tsend = torch.empty(max(cap, 16), dtype=torch.uint8, device=_device())
+                torch.cuda.current_stream().synchronize()
+                base_ptr = decoded.tensor.data_ptr()
+                pb, _st = core.deal_records_device(ds.ctx, [base_ptr + int(o) for o in decoded.offsets], owner, _world, tsend.data_ptr(), cap, gap=gap, cov_min_mapq=cov_min_mapq,
+                                                   on_device=True, sizes=[int(x) for x in decoded.sizes])
+                sizes, o = [], 0
+                for q in range(_world):
+                    tsend[o:o + gap] = torch.from_numpy(np.ascontiguousarray(pb[:, q], dtype=np.int64).view(np.uint8).copy()).to(_device())
+                    sizes.append(gap + int(pb[:, q].sum()))
+                    o += sizes[-1]
+                for i, row, nb in zip(mine, decoded.stats, decoded.sizes):
+                    inflated += int(nb)
+                    stats[i] = row
+                dev_send = DeviceSend(tsend, sizes)
+                if metrics is not None:
+                    metrics["records_dealt_on_device_bytes"] = metrics.get("records_dealt_on_device_bytes", 0) + int(decoded.sizes.sum())
+                    metrics["bams_inflated_on_device_bytes"] = metrics.get("bams_inflated_on_device_bytes", 0) + int(decoded.sizes.sum())
+            except Exception as e:                           # noqa: BLE001
+                failure, dev_send = e, None
+            decoded = []
         if failure is None and isinstance(decoded, DealtRound):
             try:
                 import torch
@@ -503,10 +557,10 @@ def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=Non
     split = {"decode_s": 0.0, "deliver_s": 0.0}
     _decode_round, _deliver = decode_round, deliver
 
-    def decode_round(plan_round):                            # noqa: F811
+    def decode_round(plan_round, hold_contigs=0):            # noqa: F811
         t0 = time.perf_counter()
         try:
-            return _decode_round(plan_round)
+            return _decode_round(plan_round, hold_contigs)
         finally:
             split["decode_s"] += time.perf_counter() - t0
 
@@ -529,11 +583,16 @@ def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=Non
                 budget = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") // 4 // max(1, _world)
             except (OSError, ValueError):
                 budget = 1 << 30
+        if read_many is not None and device_route(need_owner=False):      # rounds held in HBM (hold_files_on_device): a third of what is free there at most
+            import torch
+            budget = min(budget, int(torch.cuda.mem_get_info()[0]) // 3)
         held, held_bytes = [], 0
         while k < len(rounds):
             base, plan_round = rounds[k]
-            mine, decoded, failure = decode_round(plan_round)
-            if failure is None:
+            mine, decoded, failure = decode_round(plan_round, hold_contigs=len(names))
+            if failure is None and isinstance(decoded, HeldOnDevice):
+                local += decoded.bases                          # (counted by the kernel that measured the streams)
+            elif failure is None:
                 try:
                     if len(decoded) > 1:                     # (one walk over every record's CIGAR: the round's samples side by side, the library releases the GIL)
                         from concurrent.futures import ThreadPoolExecutor
@@ -546,7 +605,7 @@ def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=Non
                 except Exception as e:                       # noqa: BLE001
                     failure, decoded = e, []
             held.append((base, plan_round, mine, decoded, failure))
-            held_bytes += sum(int(r.size) for r in decoded)
+            held_bytes += int(decoded.sizes.sum()) if isinstance(decoded, HeldOnDevice) else sum(int(r.size) for r in decoded)
             k += 1
             stop = gather_fixed(np.array([1 if (held_bytes > budget or failure is not None) else 0], dtype=np.int64))
             if any(int(x[0]) for x in stop):
