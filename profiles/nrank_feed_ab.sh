@@ -7,7 +7,7 @@ W=/tmp/e2e_ab
 for setting in "MSNV_INFLATE=device" "MSNV_INFLATE=host" "MSNV_INFLATE=host MSNV_DEAL=host"; do
   for rep in 1 2; do
     rm -rf $W/projn $W/mn.jsonl
-    env $setting MSNV_PLAN_MB=200 MSNV_DIST_FORCE=1 MSNV_METRICS=$W/mn.jsonl python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29581 \
+    env $setting MSNV_PLAN_MB=${PLAN_MB:-200} MSNV_DIST_FORCE=1 MSNV_METRICS=$W/mn.jsonl python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29581 \
         metaSNV.py $W/projn $W/all_samples $W/ref.fa --threads 7 > /dev/null 2>&1
     python3 - "$setting" $W/mn.jsonl <<'PY'
 import json, sys
