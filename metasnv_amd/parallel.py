@@ -404,6 +404,16 @@ def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=Non
             failure, decoded = e, []
         return mine, decoded, failure
 
+    def size_tables(tsend, pb, gap):
+        """The size table of my samples' parts (int64 each) into the gap the dealer left in front of every part; returns the bytes per destination."""
+        import torch
+        sizes, o = [], 0
+        for q in range(_world):
+            tsend[o:o + gap] = torch.from_numpy(np.ascontiguousarray(pb[:, q], dtype=np.int64).view(np.uint8).copy()).to(_device())
+            sizes.append(gap + int(pb[:, q].sum()))
+            o += sizes[-1]
+        return sizes
+
     def deliver(base, plan_round, mine, decoded, failure):
         """Deals the round's records to the contig owners, exchanges them, appends the round's samples to this rank's dataset."""
         nonlocal inflated
@@ -424,11 +434,7 @@ def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=Non
                 base_ptr = decoded.tensor.data_ptr()
                 pb, _st = core.deal_records_device(ds.ctx, [base_ptr + int(o) for o in decoded.offsets], owner, _world, tsend.data_ptr(), cap, gap=gap, cov_min_mapq=cov_min_mapq,
                                                    on_device=True, sizes=[int(x) for x in decoded.sizes])
-                sizes, o = [], 0
-                for q in range(_world):
-                    tsend[o:o + gap] = torch.from_numpy(np.ascontiguousarray(pb[:, q], dtype=np.int64).view(np.uint8).copy()).to(_device())
-                    sizes.append(gap + int(pb[:, q].sum()))
-                    o += sizes[-1]
+                sizes = size_tables(tsend, pb, gap)
                 for i, row, nb in zip(mine, decoded.stats, decoded.sizes):
                     inflated += int(nb)
                     stats[i] = row
@@ -443,11 +449,7 @@ def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=Non
             try:
                 import torch
                 pb, gap, tsend = decoded.part_bytes, decoded.gap, decoded.tensor
-                sizes, o = [], 0
-                for q in range(_world):
-                    tsend[o:o + gap] = torch.from_numpy(np.ascontiguousarray(pb[:, q], dtype=np.int64).view(np.uint8).copy()).to(_device())
-                    sizes.append(gap + int(pb[:, q].sum()))
-                    o += sizes[-1]
+                sizes = size_tables(tsend, pb, gap)
                 for i, row, nb in zip(mine, decoded.stats, decoded.record_bytes):
                     inflated += int(nb)
                     stats[i] = row
@@ -468,11 +470,7 @@ def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=Non
                 tsend = torch.empty(max(cap, 16), dtype=torch.uint8, device=_device())
                 torch.cuda.current_stream().synchronize()
                 pb, st = core.deal_records_device(ds.ctx, decoded, owner, _world, tsend.data_ptr(), cap, gap=gap, cov_min_mapq=cov_min_mapq)
-                sizes, o = [], 0
-                for q in range(_world):                      # the size table of my samples' parts in front of every part
-                    tsend[o:o + gap] = torch.from_numpy(np.ascontiguousarray(pb[:, q], dtype=np.int64).view(np.uint8).copy()).to(_device())
-                    sizes.append(gap + int(pb[:, q].sum()))
-                    o += sizes[-1]
+                sizes = size_tables(tsend, pb, gap)
                 for i, rec, row in zip(mine, decoded, st):
                     inflated += int(rec.size)
                     stats[i] = row
