@@ -31,7 +31,12 @@ void msnv_drop_pages(void *p, size_t bytes) {
 
 void msnv_advise_huge(void *p, size_t bytes) {
 #if defined(MADV_HUGEPAGE)
+    static const int mode = [] { const char *e = getenv("MSNV_HUGE"); return e ? atoi(e) : 1; }();      // 0: small pages; 2: huge pages, populated now (experiments: profiles/stage_threads.py)
+    if (mode == 0) return;
     (void)madvise(p, bytes, MADV_HUGEPAGE);
+#if defined(MADV_POPULATE_WRITE)
+    if (mode == 2) (void)madvise(p, bytes, MADV_POPULATE_WRITE);
+#endif
 #else
     (void)p; (void)bytes;
 #endif
