@@ -233,7 +233,7 @@ extern "C" int msnv_dataset_add_sample_records_many(msnv_dataset *ds, const uint
     for (int i = 0; i < n; ++i) if (n_bytes[i] && !records[i]) return fail(MSNV_EINVAL, "msnv_dataset_add_sample_records_many: stream %d is NULL", i);
     if (!ds->staged.empty()) return fail(MSNV_EINVAL, "the dataset holds staged streams (msnv_dataset_stage_sample_bams): they are packed last, by msnv_dataset_finalize");
     if (pack_on_device(ds)) return add_streams_device(ds, records, n_bytes, n, false);
-    int nthreads = host_threads > 0 ? host_threads : (int)std::max(1u, std::thread::hardware_concurrency());
+    int nthreads = host_threads > 0 ? host_threads : (int)msnv_default_threads();
     nthreads = std::min(nthreads, std::max(1, (int)n));
     const size_t first = ds->samples.size();
     ds->samples.resize(first + (size_t)n);
@@ -639,7 +639,7 @@ extern "C" int msnv_bam_records_many(msnv_ctx *ctx, const char *const *bam_paths
     clear_error();
     if (n < 0 || (n && (!bam_paths || !records || !n_bytes))) return fail(MSNV_EINVAL, "msnv_bam_records_many: bad argument");
     for (int i = 0; i < n; ++i) { records[i] = nullptr; n_bytes[i] = 0; }
-    int nthreads = host_threads > 0 ? host_threads : (int)std::max(1u, std::thread::hardware_concurrency());
+    int nthreads = host_threads > 0 ? host_threads : (int)msnv_default_threads();
     nthreads = std::min(nthreads, std::max(1, (int)n));
     const bool on_device = want_device_inflate(ctx, bam_paths, n, nthreads);
     std::atomic<int> err{0};
@@ -762,7 +762,7 @@ extern "C" int msnv_dataset_deal_bams_device(msnv_dataset *ds, const char *const
     if (!ds || n < 0 || (n && (!bam_paths || !part_bytes || !stats || !record_bytes)) || !contig_owner) return fail(MSNV_EINVAL, "msnv_dataset_deal_bams_device: bad argument");
     if (!ds->ctx) return fail(MSNV_ENODEV, "msnv_dataset_deal_bams_device needs a dataset with a device context");
     if (n == 0) return MSNV_OK;
-    int nthreads = host_threads > 0 ? host_threads : (int)std::max(1u, std::thread::hardware_concurrency());
+    int nthreads = host_threads > 0 ? host_threads : (int)msnv_default_threads();
     nthreads = std::min(nthreads, std::max(1, (int)n));
     {   // one batch of the device inflate only: the parts of a call lie destination-major in `out`
         const uint64_t batch_in = [] { const char *e = getenv("MSNV_INFLATE_BATCH_MB"); const long long v = e ? atoll(e) : 1024; return (uint64_t)std::max<long long>(1, v) << 20; }();
@@ -808,7 +808,7 @@ extern "C" int msnv_dataset_inflate_bams_device(msnv_dataset *ds, const char *co
     if (!ds || n < 0 || (n && (!bam_paths || !rec_off || !rec_bytes || !stats || !out))) return fail(MSNV_EINVAL, "msnv_dataset_inflate_bams_device: bad argument");
     if (!ds->ctx) return fail(MSNV_ENODEV, "msnv_dataset_inflate_bams_device needs a dataset with a device context");
     if (n == 0) return MSNV_OK;
-    int nthreads = host_threads > 0 ? host_threads : (int)std::max(1u, std::thread::hardware_concurrency());
+    int nthreads = host_threads > 0 ? host_threads : (int)msnv_default_threads();
     nthreads = std::min(nthreads, std::max(1, (int)n));
     {
         const uint64_t batch_in = [] { const char *e = getenv("MSNV_INFLATE_BATCH_MB"); const long long v = e ? atoll(e) : 1024; return (uint64_t)std::max<long long>(1, v) << 20; }();
@@ -855,7 +855,7 @@ extern "C" int msnv_dataset_add_sample_bams(msnv_dataset *ds, const char *const 
     HostTimerScope ts_all(HT_ADD_WALL);
     if (!ds || (n && !bam_paths)) return fail(MSNV_EINVAL, "msnv_dataset_add_sample_bams: NULL argument");
     if (ds->finalized) return fail(MSNV_EINVAL, "dataset is already finalized");
-    int nthreads = host_threads > 0 ? host_threads : (int)std::max(1u, std::thread::hardware_concurrency());
+    int nthreads = host_threads > 0 ? host_threads : (int)msnv_default_threads();
     nthreads = std::min(nthreads, std::max(1, (int)n));
     if (pack_on_device(ds)) return add_bams_device_pack(ds, bam_paths, n, nthreads);
     const size_t first = ds->samples.size();
@@ -934,7 +934,7 @@ extern "C" int msnv_dataset_stage_sample_bams(msnv_dataset *ds, const char *cons
     if (!ds || n < 0 || (n && !bam_paths)) return fail(MSNV_EINVAL, "msnv_dataset_stage_sample_bams: bad argument");
     if (ds->finalized) return fail(MSNV_EINVAL, "dataset is already finalized");
     if (!ds->samples.empty()) return fail(MSNV_EINVAL, "msnv_dataset_stage_sample_bams: the dataset already holds packed samples (staged streams are packed last)");
-    int nthreads = host_threads > 0 ? host_threads : (int)std::max(1u, std::thread::hardware_concurrency());
+    int nthreads = host_threads > 0 ? host_threads : (int)msnv_default_threads();
     nthreads = std::min(nthreads, std::max(1, (int)n));
     const size_t first = ds->staged.size();
     ds->staged.resize(first + (size_t)n); ds->staged_off.resize(first + (size_t)n, 0);
@@ -978,7 +978,7 @@ extern "C" int msnv_dataset_add_synth_samples(msnv_dataset *ds, const msnv_synth
     if (!ds || !p || count < 0) return fail(MSNV_EINVAL, "msnv_dataset_add_synth_samples: bad argument");
     if (ds->finalized) return fail(MSNV_EINVAL, "dataset is already finalized");
     if ((size_t)msnv_synth_contig_count(p) != ds->names.size()) return fail(MSNV_EINVAL, "synthetic parameters describe %d contigs, dataset has %zu", msnv_synth_contig_count(p), ds->names.size());
-    int nthreads = host_threads > 0 ? host_threads : (int)std::max(1u, std::thread::hardware_concurrency());
+    int nthreads = host_threads > 0 ? host_threads : (int)msnv_default_threads();
     nthreads = std::min(nthreads, std::max(1, (int)count));
     const std::vector<std::string> contigs = synth_contigs(*p);
     if (pack_on_device(ds)) {
@@ -1049,7 +1049,7 @@ extern "C" int msnv_dataset_finalize(msnv_dataset *ds) {
             if (bufs.empty()) return;
             if (const char *e = getenv("MSNV_STAGE_FREE")) if (e[0] == 's') { bufs.clear(); return; }
             if (const char *e = getenv("MSNV_STAGE_FREE")) if (e[0] == 'n') { static std::vector<ByteBuf> keep; for (ByteBuf &b : bufs) keep.push_back(std::move(b)); return; }
-            const size_t nt = std::min<size_t>(bufs.size(), std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency())));
+            const size_t nt = std::min<size_t>(bufs.size(), std::min<size_t>(16, msnv_default_threads()));
             std::vector<std::vector<ByteBuf>> share(nt);
             for (size_t i = 0; i < bufs.size(); ++i) share[i % nt].push_back(std::move(bufs[i]));
             // (pages first, under the SHARED lock of the address space -- msnv_drop_pages -- so that the threads really work side by side

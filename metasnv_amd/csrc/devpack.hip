@@ -1595,7 +1595,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
                 }
             };
             std::vector<std::thread> th;
-            const size_t nt = std::min<size_t>(need.size(), std::max(1u, std::thread::hardware_concurrency()));
+            const size_t nt = std::min<size_t>(need.size(), msnv_default_threads());
             for (size_t k = 0; k < nt; ++k) th.emplace_back(w);
             for (auto &x : th) x.join();
         }

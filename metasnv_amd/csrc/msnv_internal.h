@@ -38,6 +38,7 @@ struct BamHeader {
 void msnv_advise_huge(void *p, size_t bytes);   // madvise(MADV_HUGEPAGE) where the platform has it (hostio.cpp)
 
 // Uninitialised byte buffer (a std::vector would zero hundreds of megabytes that the inflate overwrites right away).
+unsigned msnv_default_threads();                       // hostio.cpp: hardware threads, capped by the container's CPU quota
 void msnv_drop_pages(void *p, size_t bytes);       // hostio.cpp: the pages of a buffer back to the system ahead of its free (MADV_DONTNEED: shared lock)
 struct ByteBuf {
     uint8_t *p = nullptr; size_t n = 0;

@@ -773,7 +773,7 @@ int pack_sample(const msnv_dataset &ds, const uint8_t *rec, uint64_t n_bytes, Sa
 // Index loops of finalize that run per sample (16 M pieces on the benchmark shape, 6e8 at BASELINE configs[2] scale): dealt to host threads.
 template <typename F>
 static void parallel_for(size_t n, F fn) {
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned hw = msnv_default_threads();
     const size_t nt = std::min<size_t>(std::min<size_t>(n, hw), 64);
     if (nt <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
     std::atomic<size_t> next{0};
@@ -1470,7 +1470,7 @@ int finalize_dataset(msnv_dataset &ds) {
                 if (dense) std::vector<uint32_t>().swap(sc.blk);
             }
         };
-        const size_t n_up = std::min<size_t>(S, std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency())));
+        const size_t n_up = std::min<size_t>(S, std::min<size_t>(8, msnv_default_threads()));
         std::vector<std::thread> th;
         for (size_t t = 0; t < n_up; ++t) th.emplace_back(worker);
         for (auto &t : th) t.join();
