@@ -480,6 +480,8 @@ int  msnv_bam_records_many(msnv_ctx *ctx, const char *const *bam_paths, int32_t 
 int  msnv_bgzf_inflate(msnv_ctx *ctx, const char *path, int32_t on_device, uint8_t **out, uint64_t *n_out, uint64_t counters[4]);
 /* `samtools view -H` replacement for bed_header (metaSNV.py:81-94): writes SN\t1\tLN lines. */
 int  msnv_bam_write_bed_header(const char *bam_path, const char *out_path);
+/* Cores' worth of CPU time this process may use: the hardware threads, or the container's quota (cgroup cpu.max) when that is less. */
+int32_t msnv_host_cores(void);
 /* Reads a whole BAM: header text, contigs and the raw record stream.  Free with msnv_free. */
 typedef struct {
     int32_t   n_contigs;

@@ -138,6 +138,7 @@ SYMBOLS = [
     ("msnv_pileup_run", C.c_int, [_vp, P(RunStats)]),
     ("msnv_pileup_run_many", C.c_int, [_vp, C.c_int32, C.c_int32, P(RunStats)]),
     ("msnv_pileup_reserve", C.c_int, [_vp, C.c_int32]),
+    ("msnv_host_cores", C.c_int32, []),
     ("msnv_dataset_deal_bams_device", C.c_int, [_vp, P(C.c_char_p), C.c_int32, C.c_int32, P(C.c_int32), C.c_int32, C.c_int32, C.c_void_p, C.c_uint64, C.c_uint64,
                                                 P(C.c_uint64), P(SampleStats), P(C.c_uint64)]),
     ("msnv_dataset_inflate_bams_device", C.c_int, [_vp, P(C.c_char_p), C.c_int32, C.c_int32, C.c_void_p, C.c_uint64, P(C.c_uint64), P(C.c_uint64), P(SampleStats), P(C.c_uint64)]),

@@ -251,6 +251,11 @@ def main(argv=None):
             # is first needed when the packed columns go up -- the runtime (counting the devices alone takes 0.1 s) and the context come
             # up on a thread of their own meanwhile; a node without a GPU is reported when that thread is asked for the context
             from concurrent.futures import ThreadPoolExecutor
+            # ... unless the host has few cores for the job (a container's CPU quota counts: 16 cores inflate the benchmark's 160 BAMs in 0.34 s
+            # at best, the device in 0.25 s once its context stands): then the feed waits for the context and inflates on the device
+            # (parallel.feed_sharded: MSNV_ONESHOT=device | host overrides)
+            if "MSNV_ONESHOT" not in os.environ and min(args.threads, core.host_cores()) <= 16:
+                os.environ["MSNV_ONESHOT"] = "device"
 
             def bring_up():
                 return core.Context(local) if core.device_count() >= 1 else None

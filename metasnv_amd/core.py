@@ -24,6 +24,11 @@ def default_params(**kw):
     return p
 
 
+def host_cores():
+    """Cores' worth of CPU time the process may use (msnv_host_cores: hardware threads or the container's cgroup quota)."""
+    return int(lib.msnv_host_cores())
+
+
 def device_count():
     return lib.msnv_device_count()
 

@@ -23,6 +23,7 @@ namespace msnv {
 // Host threads a call may use when the caller names none: the hardware's, capped by the CPU time the container is given (cgroup v2 `cpu.max`,
 // v1 `cpu.cfs_quota_us`): on a 256-thread node that grants 16 cores, 32 threads read + inflate 160 BAMs in 0.29-0.34 s, 128 in 0.37-0.49 s
 // (profiles/stage_threads.py).  Twice the quota: a thread that waits for a page fault or a read leaves its share to another.
+static double g_quota_cores = 0;       // CPU time the container is given, in cores (0: no quota)
 unsigned msnv_default_threads() {
     static const unsigned n = [] {
         unsigned hw = std::max(1u, std::thread::hardware_concurrency());
@@ -37,6 +38,7 @@ unsigned msnv_default_threads() {
             if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &per) != 1) per = 0; fclose(g); }
             if (quota > 0 && per > 0) cores = (double)quota / (double)per;
         }
+        g_quota_cores = cores;
         if (cores >= 1.0) hw = std::min<unsigned>(hw, (unsigned)(2.0 * cores + 0.5));
         return std::max(1u, hw);
     }();
@@ -503,6 +505,12 @@ int bed_read(const char *path, std::vector<BedRegion> &out) {
 
 // ------------------------------------------------------------------------------ C ABI (I/O helpers)
 using namespace msnv;
+
+extern "C" int32_t msnv_host_cores(void) {
+    (void)msnv_default_threads();
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    return (int32_t)(g_quota_cores >= 1.0 ? std::min<double>(hw, g_quota_cores + 0.5) : hw);
+}
 
 extern "C" int msnv_bam_write_bed_header(const char *bam_path, const char *out_path) {
     clear_error();

@@ -296,7 +296,7 @@ def _stageable(paths):
         return False
 
 
-def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=None, metrics=None, plan=None, pack_threads=0):
+def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=None, metrics=None, plan=None, pack_threads=0, ctx_when_ready=None):
     """Decode-sharded input of one dataset per rank: every BAM is read and inflated by ONE rank, its records are dealt by
     contig owner (core.partition_records) and exchanged, and every rank appends all samples in all_samples order holding
     only its contigs' records.  Returns stats[n_samples][6] (qaCompute's per-BAM statistics, counted by the decoder and
@@ -313,6 +313,13 @@ def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=Non
             metrics["owner"] = [0] * len(plan[0])
         if metrics is not None:
             metrics["inflated_record_bytes"] = None
+        if getattr(ds, "ctx", None) is None and callable(ctx_when_ready) and os.environ.get("MSNV_ONESHOT", "")[:1] == "d":
+            # MSNV_ONESHOT=device: wait for the context, then everything on the device (BGZF blocks inflated and checked there, records packed
+            # there) instead of inflating on host threads meanwhile.  On a host that grants the job 16 cores the two are close (one-shot run of
+            # the 160 BAMs: 0.82 vs 0.89 s wall, profiles/e2e_ab.sh); with 32 real cores the host threads finish under the runtime's start-up
+            ds.attach_context(ctx_when_ready())
+            ds.add_sample_bams(bam_paths, batch)
+            return np.stack([ds.sample_stats(i) for i in range(n)]) if n else np.zeros((0, len(core.STATS_FIELDS)), np.uint32)
         if getattr(ds, "ctx", None) is None and hasattr(ds, "stage_sample_bams") and os.environ.get("MSNV_PACK", "device")[:1] != "h" and _stageable(bam_paths):
             # the device is still coming up (cli.py brings the HIP runtime up on a thread of its own): the files are read and inflated now,
             # their records are packed by kernels once the context is attached (finalize); the statistics exist then
@@ -782,12 +789,13 @@ def resident_project_run(ctx, first_bam, fasta_path, bam_paths, params, batch=1,
     res = {"names": names, "lengths": lengths, "n_samples": len(bam_paths), "metrics": metrics, "acc": None}
     try:
         t0 = time.perf_counter()
-        res["stats"] = feed_sharded(ds, bam_paths, owner, params.cov_min_mapq, batch, read_records=read_records, metrics=metrics, plan=(names, lengths))
+        res["stats"] = feed_sharded(ds, bam_paths, owner, params.cov_min_mapq, batch, read_records=read_records, metrics=metrics, plan=(names, lengths),
+                                    ctx_when_ready=ctx if lazy_ctx else None)
         owner = metrics.pop("owner", owner)
         res["owner"] = owner
         metrics["contigs"] = int(sum(1 for o in owner if o == _rank))
         metrics["feed_s"] = time.perf_counter() - t0
-        if lazy_ctx:
+        if lazy_ctx and getattr(ds, "ctx", None) is None:
             t0 = time.perf_counter()
             ds.attach_context(ctx())
             metrics["wait_for_context_s"] = time.perf_counter() - t0

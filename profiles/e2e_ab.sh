@@ -28,7 +28,7 @@ wall = time.perf_counter() - t0
 m = json.loads(open(W + "/m.jsonl").read().strip().splitlines()[-1])
 c = m["cli_wall"]
 print("wall %.3f | start %.2f feed %.3f ctx %.3f finalize %.3f pass %.3f gather %.3f files %.3f | in-process %.3f, ends at %.2f, teardown %.2f" % (
-    wall, c["process_age_at_start_s"], m["feed_s"], m["wait_for_context_s"], m["finalize_s"], m["calling_pass_s"], m["gather_sites_s"],
+    wall, c["process_age_at_start_s"], m["feed_s"], m.get("wait_for_context_s", 0.0), m["finalize_s"], m["calling_pass_s"], m["gather_sites_s"],
     c["coverage_files_s"] + c["tables_and_splits_s"] + c["calls_text_s"], c["total_s"], c["process_age_at_end_s"], wall - c["process_age_at_end_s"]))
 PY
   done
