@@ -170,7 +170,7 @@ def resident_run(args, ctx, rank, world):
     try:
         res = parallel.resident_project_run(ctx, bams[0], args.ref_db, bams, params, batch=max(1, args.threads),
                                             want_coverage=not args.use_prev_cov, ann_path=args.db_ann or None, after_coverage=between_passes,
-                                            species_weight=species_weight)
+                                            species_weight=species_weight, inflate_after_context=getattr(args, "inflate_after_context", False))
     except core._lib.MsnvError as e:
         sys.stderr.write(str(e) + "\n")
         sys.stderr.write("SNV calling failed")
@@ -254,8 +254,8 @@ def main(argv=None):
             # ... unless the host has few cores for the job (a container's CPU quota counts: 16 cores inflate the benchmark's 160 BAMs in 0.34 s
             # at best, the device in 0.25 s once its context stands): then the feed waits for the context and inflates on the device
             # (parallel.feed_sharded: MSNV_ONESHOT=device | host overrides)
-            if "MSNV_ONESHOT" not in os.environ and min(args.threads, core.host_cores()) <= 16:
-                os.environ["MSNV_ONESHOT"] = "device"
+            how = os.environ.get("MSNV_ONESHOT", "")[:1]
+            args.inflate_after_context = how == "d" or (how != "h" and min(args.threads, core.host_cores()) <= 16)
 
             def bring_up():
                 return core.Context(local) if core.device_count() >= 1 else None

@@ -313,8 +313,8 @@ def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=Non
             metrics["owner"] = [0] * len(plan[0])
         if metrics is not None:
             metrics["inflated_record_bytes"] = None
-        if getattr(ds, "ctx", None) is None and callable(ctx_when_ready) and os.environ.get("MSNV_ONESHOT", "")[:1] == "d":
-            # MSNV_ONESHOT=device: wait for the context, then everything on the device (BGZF blocks inflated and checked there, records packed
+        if getattr(ds, "ctx", None) is None and callable(ctx_when_ready):
+            # (cli.py's choice for hosts with few cores; MSNV_ONESHOT=device | host) wait for the context, then everything on the device (BGZF blocks inflated and checked there, records packed
             # there) instead of inflating on host threads meanwhile.  On a host that grants the job 16 cores the two are close (one-shot run of
             # the 160 BAMs: 0.82 vs 0.89 s wall, profiles/e2e_ab.sh); with 32 real cores the host threads finish under the runtime's start-up
             ds.attach_context(ctx_when_ready())
@@ -754,7 +754,7 @@ def gather_coverage_root(acc, stats=None, rows=None, shape=None):
 
 
 def resident_project_run(ctx, first_bam, fasta_path, bam_paths, params, batch=1, want_coverage=True, ann_path=None,
-                         after_coverage=None, species_weight=None, make_dataset=None, read_records=None, run_passes=None):
+                         after_coverage=None, species_weight=None, make_dataset=None, read_records=None, run_passes=None, inflate_after_context=False):
     """ONE resident dataset per rank for a whole metaSNV.py run, whatever the number of ranks and splits (the reference forks
     one qaCompute process per BAM, metaSNV.py:55-78, and one `mpileup | snpCall` process per split, :196-221, each of which
     inflates every BAM again): contigs are sharded over the ranks by species (LPT on length x coverage), the BAMs are dealt to
@@ -790,7 +790,7 @@ def resident_project_run(ctx, first_bam, fasta_path, bam_paths, params, batch=1,
     try:
         t0 = time.perf_counter()
         res["stats"] = feed_sharded(ds, bam_paths, owner, params.cov_min_mapq, batch, read_records=read_records, metrics=metrics, plan=(names, lengths),
-                                    ctx_when_ready=ctx if lazy_ctx else None)
+                                    ctx_when_ready=ctx if (lazy_ctx and inflate_after_context) else None)
         owner = metrics.pop("owner", owner)
         res["owner"] = owner
         metrics["contigs"] = int(sum(1 for o in owner if o == _rank))
