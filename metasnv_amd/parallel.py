@@ -317,6 +317,15 @@ def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=Non
             # (cli.py's choice for hosts with few cores; MSNV_ONESHOT=device | host) wait for the context, then everything on the device (BGZF blocks inflated and checked there, records packed
             # there) instead of inflating on host threads meanwhile.  On a host that grants the job 16 cores the two are close (one-shot run of
             # the 160 BAMs: 0.82 vs 0.89 s wall, profiles/e2e_ab.sh); with 32 real cores the host threads finish under the runtime's start-up
+            for p in bam_paths:                              # (the page cache may fill while the runtime comes up: a hint, not a read)
+                try:
+                    fd = os.open(p, os.O_RDONLY)
+                    try:
+                        os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_WILLNEED)
+                    finally:
+                        os.close(fd)
+                except (OSError, AttributeError):
+                    pass
             ds.attach_context(ctx_when_ready())
             ds.add_sample_bams(bam_paths, batch)
             return np.stack([ds.sample_stats(i) for i in range(n)]) if n else np.zeros((0, len(core.STATS_FIELDS)), np.uint32)
