@@ -60,6 +60,7 @@ namespace msnv { void dev_inflate_release(msnv_ctx *ctx); }
 extern "C" void msnv_ctx_destroy(msnv_ctx *ctx) {
     if (!ctx) return;
     dev_inflate_release(ctx);
+    dev_cache_trim();
     dev_stream_destroy(ctx->stream);
     delete ctx;
 }

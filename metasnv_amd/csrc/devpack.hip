@@ -1992,7 +1992,18 @@ __global__ void msnv_gather_u32(const uint32_t *src, const unsigned long long *i
 int devfin_overhang(msnv_dataset &ds, std::vector<int64_t> &maxend) {
     if (!ds.dp.overhang) return MSNV_OK;
     uint32_t any = 0;
-    HIP_TRY(hipMemcpy(&any, ds.dp.any_overhang, 4, hipMemcpyDeviceToHost));
+    fin_trace("    overhang: enter");
+    if (getenv("MSNV_OVERHANG_ASYNC") && getenv("MSNV_OVERHANG_ASYNC")[0] == '2') {
+        static uint32_t *pin = nullptr; if (!pin) HIP_TRY(hipHostMalloc((void **)&pin, 4096, 0));
+        hipStream_t st = (hipStream_t)ds.ctx->stream;
+        fin_trace("    overhang: pinned ready");
+        HIP_TRY(hipStreamSynchronize(st));
+        fin_trace("    overhang: stream idle");
+        HIP_TRY(hipMemcpyAsync(pin, ds.dp.any_overhang, 4, hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st)); any = pin[0];
+    }
+    else if (getenv("MSNV_OVERHANG_ASYNC")) { hipStream_t st = (hipStream_t)ds.ctx->stream; HIP_TRY(hipMemcpyAsync(&any, ds.dp.any_overhang, 4, hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st)); }
+    else HIP_TRY(hipMemcpy(&any, ds.dp.any_overhang, 4, hipMemcpyDeviceToHost));
+    fin_trace("    overhang: flag down");
     if (!any) return MSNV_OK;
     std::vector<int32_t> oh(ds.names.size());
     HIP_TRY(hipMemcpy(oh.data(), ds.dp.overhang, oh.size() * 4, hipMemcpyDeviceToHost));
@@ -2103,6 +2114,7 @@ int devfin_coverage(msnv_dataset &ds, DeviceCols &d, std::vector<uint64_t> &cvba
         HIP_TRY(hipMemsetAsync(keep + N, 0, 4, st));
         HIP_TRY(hipMemsetAsync(ntile + N, 0, 4, st));
     }
+    fin_trace("    cov: allocs + measure launched");
     if (int rc = pr.scan32(keep, kidx, N + 1, false)) return rc;
     uint32_t n_keep = 0;
     HIP_TRY(hipMemcpyAsync(&n_keep, kidx + N, 4, hipMemcpyDeviceToHost, st));
@@ -2123,6 +2135,7 @@ int devfin_coverage(msnv_dataset &ds, DeviceCols &d, std::vector<uint64_t> &cvba
         HIP_TRY(hipMemcpyAsync(&n_ent64, tot.p, 8, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
+    fin_trace("    cov: scans + reduce (sync)");
     if (n_ent64 > 0xfffffff0ull) return fail(MSNV_EDOMAIN, "more than 2^32 (interval, tile) entries in one shard");
     const uint32_t n_ent = (uint32_t)n_ent64;
     uint32_t *ebase = keep;
@@ -2147,6 +2160,7 @@ int devfin_coverage(msnv_dataset &ds, DeviceCols &d, std::vector<uint64_t> &cvba
             o += r.n_iv;
         }
     }
+    fin_trace("    cov: allocs + emit launched");
     if (n_ent) {
         if (int rc = pr.sort64(ekey, skey, eval, sval, n_ent, 32u + std::max(1u, bit_width_u64(S)))) return rc;
         // runs of equal (sample, tile): flags and their scan in the unsorted arrays' memory (dead behind the sort)
@@ -2164,6 +2178,7 @@ int devfin_coverage(msnv_dataset &ds, DeviceCols &d, std::vector<uint64_t> &cvba
         cp.resize(n_runs);
         HIP_TRY(hipMemcpyAsync(cp.data(), runs.p, (size_t)n_runs * sizeof(DevCovPair), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        fin_trace("    cov: sort + runs (sync)");
     }
     HIP_TRY(hipStreamSynchronize(st));
     return MSNV_OK;

@@ -24,6 +24,16 @@ namespace msnv {
 // v1 `cpu.cfs_quota_us`): on a 256-thread node that grants 16 cores, 32 threads read + inflate 160 BAMs in 0.29-0.34 s, 128 in 0.37-0.49 s
 // (profiles/stage_threads.py).  Twice the quota: a thread that waits for a page fault or a read leaves its share to another.
 static double g_quota_cores = 0;       // CPU time the container is given, in cores (0: no quota)
+static std::chrono::steady_clock::time_point g_fin_trace_t;
+static bool fin_trace_on() { static const bool on = [] { const char *e = getenv("MSNV_FINALIZE_TRACE"); return e && e[0] == '1'; }(); return on; }
+void fin_trace_reset() { if (fin_trace_on()) g_fin_trace_t = std::chrono::steady_clock::now(); }
+void fin_trace(const char *what) {
+    if (!fin_trace_on()) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[finalize] %-44s %9.3f ms\n", what, 1e3 * std::chrono::duration<double>(now - g_fin_trace_t).count());
+    g_fin_trace_t = now;
+}
+
 unsigned msnv_default_threads() {
     static const unsigned n = [] {
         unsigned hw = std::max(1u, std::thread::hardware_concurrency());

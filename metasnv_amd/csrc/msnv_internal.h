@@ -28,6 +28,10 @@ struct HostTimerScope {
     ~HostTimerScope();
 };
 
+// MSNV_FINALIZE_TRACE=1: wall seconds since the previous mark, to stderr (where a dataset's finalize goes; hostio.cpp)
+void fin_trace(const char *what);
+void fin_trace_reset();
+
 // ---------------------------------------------------------------------------------- host IO
 struct BamHeader {
     std::string              text;

@@ -794,14 +794,8 @@ int finalize_dataset(msnv_dataset &ds) {
     if (S == 0) return fail(MSNV_EINVAL, "dataset has no samples");
     if (S >= 16384) return fail(MSNV_EDOMAIN, "more than 16383 samples per dataset are not supported");
     // MSNV_FINALIZE_TRACE=1: wall seconds of every stage to stderr (where a big dataset's finalize goes)
-    const bool trace = [] { const char *e = getenv("MSNV_FINALIZE_TRACE"); return e && e[0] == '1'; }();
-    auto t_lap = std::chrono::steady_clock::now();
-    auto lap = [&](const char *what) {
-        if (!trace) return;
-        const auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "[finalize] %-34s %8.3f s\n", what, std::chrono::duration<double>(now - t_lap).count());
-        t_lap = now;
-    };
+    fin_trace_reset();
+    auto lap = [&](const char *what) { fin_trace(what); };
     // Device-packed samples (devpack.hip) keep their piece headers and intervals in HBM.  When every sample is one, the per-piece and
     // per-interval loops below run there as kernels (`fast`; devfin_* in devpack.hip) and the host works on (sample, tile) pairs only.  The
     // dense piece re-layout (short reads) still runs on host staging, and so do mixed datasets: the headers come down first
@@ -856,7 +850,9 @@ int finalize_dataset(msnv_dataset &ds) {
             for (const auto &m : mine) maxend[(size_t)m.first] = std::max(maxend[(size_t)m.first], m.second);
         });
     }
+    lap("  maxend loops");
     if (fast) if (int rc = devfin_overhang(ds, maxend)) return rc;       // (reads that run past their contig: from the device's per-contig maxima)
+    lap("  devfin_overhang");
     ds.tile_base.assign(NC, UINT32_MAX);
     ds.tile_contig.clear();
     uint64_t nt = 0;
@@ -871,6 +867,7 @@ int finalize_dataset(msnv_dataset &ds) {
     ds.n_tiles = (uint32_t)nt;
     const uint64_t npos = nt * TILE;
 
+    lap("  tile tables");
     DeviceCols *d = new DeviceCols();
     ds.dev = d;
     d->n_tiles = ds.n_tiles; d->n_samples = (uint32_t)S;
@@ -1292,14 +1289,18 @@ int finalize_dataset(msnv_dataset &ds) {
         if (int rc = upload_vec(&d->s_read_base, rbase, &d->device_bytes)) return rc;
         if (int rc = upload_vec(&d->s_seq_base, sbase, &d->device_bytes)) return rc;
         if (int rc = dev_alloc((void **)&d->hdr, (rbase[S] + 1) * sizeof(ReadHdr), &d->device_bytes)) return rc;
+        lap("  pairs / bases up, hdr alloc");
         if (int rc = devfin_headers(ds, *d, rbase)) return rc;
+        lap("  devfin_headers");
     }
     if (fast && !dense) {
         if (int rc = dev_alloc((void **)&d->hdr4, (rbase[S] + 4) * sizeof(uint32_t), &d->device_bytes)) return rc;
         if (int rc = dev_memset(d->hdr4, 0, (rbase[S] + 4) * sizeof(uint32_t))) return rc;
         std::vector<uint32_t> narrow_pairs, counts, cbase;
         for (uint32_t wi = 0; wi < d->n_work_narrow; ++wi) for (uint32_t k = work[wi].pair_lo; k < work[wi].pair_hi; ++k) narrow_pairs.push_back(k);
+        lap("  hdr4 alloc + narrow list");
         if (int rc = devfin_chunk_counts(ds, *d, narrow_pairs, counts)) return rc;
+        lap("  devfin_chunk_counts");
         cbase.resize(narrow_pairs.size());
         uint64_t nch = 0; size_t j = 0;
         for (uint32_t wi = 0; wi < d->n_work_narrow; ++wi) {
@@ -1427,6 +1428,7 @@ int finalize_dataset(msnv_dataset &ds) {
     if (int rc = dev_memset(d->qual, 0, sbase[S] / 4 + 64)) return rc;
     d->qlow_cutoff = ds.params.min_baseq;
     uint64_t alg = 0;
+    lap("  column allocs + memsets");
     {
         // the samples' columns go up from a few host threads at a time (a pageable copy is staged by the runtime: several in flight keep
         // the link busy while the compact headers of the next samples are built)
@@ -1475,6 +1477,7 @@ int finalize_dataset(msnv_dataset &ds) {
         for (size_t t = 0; t < n_up; ++t) th.emplace_back(worker);
         for (auto &t : th) t.join();
         if (up_err.load()) return fail(up_err.load(), "%s", up_msg.c_str());
+        lap("  column copies");
         {   // device-packed samples: the alignment padding behind their pieces, then their round buffers and the pack tables go back
             std::vector<uint8_t> on_dev(S, 0);
             for (size_t s = 0; s < S; ++s) on_dev[s] = ds.samples[s].on_device ? 1 : 0;
@@ -1502,6 +1505,7 @@ int finalize_dataset(msnv_dataset &ds) {
             // the intervals are in HBM: filtered, made linear and grouped by (sample, tile) there (devpack.hip: devfin_coverage)
             std::vector<DevCovPair> cp;
             if (int rc = devfin_coverage(ds, *d, cvbase, cp)) return rc;
+            lap("  devfin_coverage");
             for (const DevCovPair &c : cp) per[c.sample].push_back(CP{c.tile, c.sample, c.lo, c.hi});
         }
         else for (size_t s = 0; s < S; ++s) {
@@ -1591,6 +1595,7 @@ int finalize_dataset(msnv_dataset &ds) {
         if (int rc = dev_alloc((void **)&d->cov_acc, d->cov_copies * acc_bytes, &d->device_bytes)) return rc;
     }
 
+    lap("  coverage tables");
     if (int rc = devpack_finish(ds)) return rc;                // (device-packed samples: the rounds' buffers and the pack tables go back)
 
     lap("coverage index");
