@@ -91,7 +91,11 @@ struct SiteRec { uint32_t gpos, cov, n[4]; };                          // gate k
 // qaCompute intervals, sample after sample.  finalize builds the tile index from them on the device (devpack.hip: devfin_*); the host sees
 // one DevPair per (sample, contig, tile) run of pieces.
 struct DevRound { void *buf = nullptr; ReadHdr *hdr = nullptr; int32_t *tid = nullptr, *end = nullptr; uint16_t *depth = nullptr;
-                  int32_t *cov_tid = nullptr, *cov_beg = nullptr, *cov_end = nullptr; uint64_t n_pieces = 0, n_iv = 0; size_t first_sample = 0; };
+                  int32_t *cov_tid = nullptr, *cov_beg = nullptr, *cov_end = nullptr; uint64_t n_pieces = 0, n_iv = 0; size_t first_sample = 0;
+                  // the round's columns as devpack_add_round laid them out: sample after sample exactly as finalize lays the dataset's (every
+                  // sample's share rounded up to 16 bytes), seq_total bytes of bases, COL_PAD bytes of N, then seq_total / 4 (+ 64) bytes of flags
+                  void *col_buf = nullptr; uint8_t *col_seq = nullptr, *col_qual = nullptr; uint64_t seq_total = 0; size_t n_samples = 0; };
+constexpr uint64_t COL_PAD = 256;          // readable bytes of N behind a seq column (lanes past the last piece read on)
 struct DevPair { int32_t tid; uint32_t tile, lo, hi, maxd, grp; };      // tile: inside the contig; [lo, hi): pieces of the sample; maxd: bound of the per-position depth; grp: 0, or 1 + group of a deep run dealt into groups
 
 // host staging of one sample
@@ -138,6 +142,7 @@ struct DevPackTables {
     int32_t  *overhang = nullptr;     // per contig: furthest end of a piece beyond the contig's length (0: none), device
     uint32_t *any_overhang = nullptr; // device flag
     bool      ready = false;
+    void     *fin_list = nullptr, *fin_cbase = nullptr;   // finalize on the device: the narrow pairs' list and their chunk counts / scan, between devfin_chunk_counts and devfin_chunk_fill
     // cumulative device-pack accounting (msnv_host_timers: pack_device_wall_s; msnv_devpack_stats)
     double    ms_scan = 0, ms_measure = 0, ms_depth = 0, ms_emit = 0, ms_sort = 0, wall_upload_s = 0, wall_download_s = 0, wall_prepass_s = 0;
     uint64_t  raw_bytes = 0, n_records = 0, n_pieces = 0, n_prepass_samples = 0, n_scan_redone = 0, n_deep_runs_split = 0, n_dense_samples = 0;

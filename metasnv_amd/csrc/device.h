@@ -131,6 +131,9 @@ struct DeviceCols {
     uint64_t  n_cov_iv = 0;
     uint64_t  device_bytes = 0;
     uint64_t  algorithmic_bytes = 0;
+    // allocations that hold SEVERAL of the tables above (the index arena of finalize, an adopted round buffer of the device pack): pointers
+    // into one of them are not freed by themselves (dev_free_all)
+    std::vector<std::pair<void *, uint64_t>> blocks;
     AnnDev    ann;
     // second set of per-pass intermediates + second stream: msnv_pileup_run_many alternates passes between the two sets so
     // that the small tail kernels of pass i overlap with the pileup kernel of pass i+1 (allocated on first use)

@@ -23,6 +23,7 @@ int devpack_download_pieces(msnv_dataset &ds);
 void devpack_release(DevPackTables &t);
 // finalize: copies of the rounds' columns into the dataset's, and the alignment padding behind every piece set to the reference
 int devpack_copy_columns(const SampleCols &sc, uint8_t *dst_seq, uint8_t *dst_qual_bits, void *stream);
+int devpack_place_columns(msnv_dataset &ds, DeviceCols &d, const std::vector<uint64_t> &sbase);      // fast finalize, piece layout: adopt one round's buffer / copy round by round
 int devpack_fill_padding(DeviceCols &d, const std::vector<uint8_t> &sample_on_device, void *stream);
 // finalize on the device (all samples device-packed; devpack.hip "finalize on the device"): the per-piece / per-interval loops of
 // finalize_dataset as kernels over the rounds' headers and intervals
@@ -40,8 +41,9 @@ int records_deal_device(msnv_ctx *ctx, const uint8_t *const *streams, const uint
                         int cov_min_mapq, uint8_t *out, uint64_t capacity, uint64_t gap, uint64_t *part_bytes, msnv_sample_stats *stats, uint64_t *contig_bases);
 int devpack_copy_blocks(const SampleCols &sc, uint32_t *dst, void *stream);
 int devfin_headers(msnv_dataset &ds, DeviceCols &d, const std::vector<uint64_t> &rbase);
-int devfin_chunk_counts(msnv_dataset &ds, DeviceCols &d, const std::vector<uint32_t> &narrow_pairs, std::vector<uint32_t> &counts);
-int devfin_chunk_fill(msnv_dataset &ds, DeviceCols &d, const std::vector<uint32_t> &narrow_pairs, const std::vector<uint32_t> &chunk_base, uint64_t n_chunks, std::vector<ChunkDesc> &out);
+int devfin_chunk_counts(msnv_dataset &ds, DeviceCols &d, const std::vector<uint32_t> &narrow_pairs, std::vector<uint32_t> &cbase);   // cbase: first chunk of every listed pair, total behind them
+int devfin_chunk_fill(msnv_dataset &ds, DeviceCols &d, size_t n_pairs_listed);                       // d.chunks[0 .. total), d.hdr4
+int devfin_work_first(msnv_dataset &ds, DeviceCols &d, uint32_t n_items);                            // WorkItem::first of the narrow and merged items, from d.chunks
 int devfin_merged_headers(msnv_dataset &ds, DeviceCols &d, const std::vector<DevMergedSrc> &list);
 int devfin_coverage(msnv_dataset &ds, DeviceCols &d, std::vector<uint64_t> &cvbase, std::vector<DevCovPair> &cp);
 // waits for the copies, releases the round buffers and the tables (no sample can be added after finalize)

@@ -814,7 +814,7 @@ __global__ void msnv_emit_tail(const DpSampleDst *dst, const unsigned long long 
     const uint32_t s = blockIdx.x, t = threadIdx.x;      // 64 threads
     if (s >= n_samples) return;
     const unsigned long long nb = seq_bytes[s];          // without the tail
-    if (t < 32) dst[s].seq[nb + t] = 0xff;
+    if (t < 32 + (uint32_t)((16u - ((nb + 32u) & 15u)) & 15u)) dst[s].seq[nb + t] = 0xff;      // ... and on to the next 16-byte boundary, where the next sample's column starts
     if (P.c_eff > 0 || P.all_low) {                      // 64 flags from bit 2 * nb (a multiple of 4)
         const unsigned long long b0 = 2ull * nb;
         if (t < 16) or_byte(dst[s].qual + ((b0 + 4ull * t) >> 3), ((b0 + 4ull * t) & 4ull) ? 0xf0u : 0x0fu);
@@ -977,11 +977,14 @@ void devpack_release(DevPackTables &t) {
     t.overhang = nullptr; t.any_overhang = nullptr;
     for (DevRound &r : t.rounds) if (r.buf) dev_free(r.buf);
     t.rounds.clear();
-    for (void *p : t.round_bufs) dev_free(p);
+    for (void *p : t.round_bufs) if (p) dev_free(p);
     t.round_bufs.clear();
     for (auto &b : t.scratch) if (b.first) dev_free(b.first);
     t.scratch.clear();
     t.contigs = nullptr; t.pref4 = nullptr; t.ready = false;
+    if (t.fin_list) dev_free(t.fin_list);
+    if (t.fin_cbase) dev_free(t.fin_cbase);
+    t.fin_list = nullptr; t.fin_cbase = nullptr;
 }
 
 // Work buffers taken from a grow-only list in call order (a dataset's pool, or a caller's own list).
@@ -1645,9 +1648,10 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     }
     const uint64_t seq_total = seq_off[S], qual_total = seq_total / 4;
     void *round_buf = nullptr;
-    if (int rc = dev_alloc(&round_buf, seq_total + qual_total + 64, nullptr)) return rc;
+    if (int rc = dev_alloc(&round_buf, seq_total + COL_PAD + qual_total + 64, nullptr)) return rc;
     T.round_bufs.push_back(round_buf);
-    uint8_t *r_seq = static_cast<uint8_t *>(round_buf), *r_qual = r_seq + seq_total;
+    uint8_t *r_seq = static_cast<uint8_t *>(round_buf), *r_qual = r_seq + seq_total + COL_PAD;
+    HIP_TRY(hipMemsetAsync(r_seq + seq_total, 0xff, COL_PAD, st));
     HIP_TRY(hipMemsetAsync(r_qual, 0, qual_total + 64, st));
     std::vector<DpSampleDst> dsts(S);
     for (size_t s = 0; s < S; ++s) dsts[s] = DpSampleDst{r_seq + seq_off[s], r_qual + seq_off[s] / 4, sum[s].pbase0, cut_marks[s], 0u};
@@ -1737,6 +1741,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
         keep.cov_beg = reinterpret_cast<int32_t *>(q); q += b_iv;
         keep.cov_end = reinterpret_cast<int32_t *>(q);
         keep.n_pieces = NPC; keep.n_iv = NIV; keep.first_sample = first;
+        keep.col_buf = round_buf; keep.col_seq = r_seq; keep.col_qual = r_qual; keep.seq_total = seq_total; keep.n_samples = S;
         T.rounds.push_back(keep);
         if (NPC) {
             HIP_TRY(hipMemcpyAsync(keep.hdr, src_hdr, (size_t)NPC * sizeof(ReadHdr), hipMemcpyDeviceToDevice, st));
@@ -1894,11 +1899,21 @@ __global__ void msnv_fin_headers(const ReadHdr *src, const int32_t *tid, unsigne
 
 // chunks of the narrow work items' pairs (pack.cpp: "chunk descriptors of the narrow work items", HDR4 form): up to CHUNK_READS consecutive
 // pieces whose seq bytes lie within 2^HDR4_OFF_BITS alignment units of the chunk's lowest offset; FILL writes the descriptors and the
-// 4-byte chunk-relative piece headers
+// 4-byte chunk-relative piece headers.  One WAVEFRONT per pair: 64 pieces a step, the greedy rule's running minimum / maximum as prefix
+// scans over the lanes, the first piece that would stretch the chunk too far found by a ballot (a thread per pair walking ~250 headers
+// one after the other was 1.1 ms of finalize on the benchmark shape).
+__device__ __forceinline__ unsigned long long wave_prefix_min(unsigned long long v) {
+    for (int o = 1; o < 64; o <<= 1) { const unsigned long long y = __shfl_up(v, o); if ((int)(threadIdx.x & 63u) >= o) v = y < v ? y : v; }
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_prefix_max(unsigned long long v) {
+    for (int o = 1; o < 64; o <<= 1) { const unsigned long long y = __shfl_up(v, o); if ((int)(threadIdx.x & 63u) >= o) v = y > v ? y : v; }
+    return v;
+}
 template <bool FILL>
-__global__ void msnv_fin_chunks(const TilePair *pairs, const uint32_t *list, uint32_t n, const ReadHdr *hdr, const unsigned long long *rbase, const unsigned long long *sbase,
-                                uint32_t *counts, const uint32_t *chunk_base, ChunkDesc *chunks, uint32_t *hdr4) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void msnv_fin_chunks(const TilePair *pairs, const uint32_t *list, uint32_t n, const ReadHdr *hdr, const unsigned long long *rbase, const unsigned long long *sbase,
+                                                       uint32_t *counts, const uint32_t *chunk_base, ChunkDesc *chunks, uint32_t *hdr4) {
+    const uint32_t j = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
     if (j >= n) return;
     const uint32_t k = list[j];
     const TilePair p = pairs[k];
@@ -1906,20 +1921,42 @@ __global__ void msnv_fin_chunks(const TilePair *pairs, const uint32_t *list, uin
     constexpr unsigned long long span_max = (unsigned long long)SEQ_ALIGN << HDR4_OFF_BITS;
     uint32_t r = p.read_lo, c = 0;
     while (r < p.read_hi) {
-        unsigned long long lo = h[r].seqoff, hi = lo;
+        // the chunk that starts at r: pieces r .. e - 1
+        unsigned long long lo = ~0ull, hi = 0;                    // of the pieces taken so far (wave-uniform)
         uint32_t e = r;
-        while (e < p.read_hi && e - r < CHUNK_READS) {
-            const unsigned long long o = h[e].seqoff, nlo = lo < o ? lo : o, nhi = hi > o ? hi : o;
-            if (nhi - nlo >= span_max) break;
-            lo = nlo; hi = nhi; ++e;
+        ReadHdr mine[CHUNK_READS / 64];
+#pragma unroll
+        for (uint32_t step = 0; step < CHUNK_READS / 64; ++step) {
+            const uint32_t i = r + 64u * step + lane;
+            const bool have = i < p.read_hi;
+            if (have) mine[step] = h[i];
+            if (e != r + 64u * step) continue;                     // (the chunk was closed inside an earlier step; wave-uniform)
+            const unsigned long long o = have ? (unsigned long long)mine[step].seqoff : 0ull;
+            unsigned long long pmin = wave_prefix_min(have ? o : ~0ull), pmax = wave_prefix_max(have ? o : 0ull);
+            pmin = pmin < lo ? pmin : lo; pmax = pmax > hi ? pmax : hi;
+            const unsigned long long stop = __ballot(!have || pmax - pmin >= span_max);      // first lane that does not join
+            const uint32_t take = stop ? (uint32_t)__builtin_ctzll(stop) : 64u;
+            if (take) { lo = __shfl(pmin, (int)take - 1); hi = __shfl(pmax, (int)take - 1); }
+            e += take;
         }
+        if (e == r) e = r + 1;                                     // (a single piece always fits: its span is 0 -- never taken, kept against a stuck loop)
         if (FILL) {
-            for (uint32_t i = r; i < e; ++i) hdr4[rbase[p.sample] + i] = (h[i].gpos % TILE) | h[i].cig << 11 | (uint32_t)((h[i].seqoff - lo) >> SEQ_ALIGN_LOG2) << 19;
-            chunks[chunk_base[j] + c] = ChunkDesc{rbase[p.sample] + r, sbase[p.sample] + lo, p.pad >> 8, k, (e - r) | (e >= p.read_hi ? 1u << 16 : 0u), p.pad & 0xffu};
+#pragma unroll
+            for (uint32_t step = 0; step < CHUNK_READS / 64; ++step) {
+                const uint32_t i = r + 64u * step + lane;
+                if (i < e) hdr4[rbase[p.sample] + i] = (mine[step].gpos % TILE) | mine[step].cig << 11 | (uint32_t)((mine[step].seqoff - lo) >> SEQ_ALIGN_LOG2) << 19;
+            }
+            if (lane == 0) chunks[chunk_base[j] + c] = ChunkDesc{rbase[p.sample] + r, sbase[p.sample] + lo, p.pad >> 8, k, (e - r) | (e >= p.read_hi ? 1u << 16 : 0u), p.pad & 0xffu};
         }
         ++c; r = e;
     }
-    if (!FILL) counts[j] = c;
+    if (!FILL && lane == 0) counts[j] = c;
+}
+// every narrow / merged work item's first chunk descriptor, copied into the item (kernels.hip: a workgroup starts loading without the descriptor stream)
+__global__ void msnv_fin_work_first(WorkItem *work, uint32_t n, const ChunkDesc *chunks) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (work[i].chunk_hi > work[i].chunk_lo) work[i].first = chunks[work[i].chunk_lo];
 }
 
 __global__ void msnv_fin_merged(const TilePair *pairs, const DevMergedSrc *list, uint32_t n, const ReadHdr *hdr, const unsigned long long *rbase, const unsigned long long *sbase, PieceHdr *hm) {
@@ -1983,6 +2020,46 @@ __global__ void msnv_fin_cov_runs(const unsigned long long *skey, const uint32_t
     if (flag[i]) { out[r].tile = (uint32_t)skey[i]; out[r].sample = (uint32_t)(skey[i] >> 32); out[r].lo = sval[i]; }
     if (i + 1 == n || flag[i + 1]) out[r].hi = sval[i] + 1u;                                  // (stable sort: the run's values ascend)
 }
+// The (sample, tile) runs without a sort: the intervals of a sample come in nearly ascending order, so a run is the RANGE [first, last + 1)
+// of the kept intervals that touch the tile -- a minimum and a maximum per (sample, tile), kept in a dense [sample][tile] table when that
+// table is small beside the interval list (else the sort of (sample, tile, index) entries above).  Consecutive lanes hold consecutive
+// intervals, nearly always of one (sample, tile): the first lane of such a stretch carries its minimum, the last its maximum -- two atomics
+// per stretch instead of two per interval; an interval that touches several tiles adds to the other tiles' entries by itself.
+__global__ __launch_bounds__(256) void msnv_fin_cov_emit_dense(const int32_t *ctid, const int32_t *cbeg, const int32_t *cend, unsigned long long n, unsigned long long j0, const DpContig *ctg,
+                                                               const uint32_t *tile_base, const unsigned long long *iv_start, uint32_t n_samples, const uint32_t *keep_all, const uint32_t *kidx_all,
+                                                               uint32_t n_tiles, Pair32 *iv, uint32_t *lo, uint32_t *hi) {
+    const unsigned long long j = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long key = ~0ull; uint32_t idx = 0, tf = 0, tl = 0, s = 0;
+    if (j < n && keep_all[j0 + j]) {
+        const uint32_t *kidx = kidx_all + j0;
+        const int32_t c = ctid[j];
+        const long long L = ctg[c].len, b = cbeg[j];
+        const bool minus_one = b > (long long)cend[j];
+        const long long e = minus_one ? (long long)cend[j] : ((long long)cend[j] >= L ? L - 1 : (long long)cend[j]);
+        const unsigned long long g0 = (unsigned long long)tile_base[c] * TILE;
+        iv[kidx[j]] = Pair32{(uint32_t)(g0 + (unsigned long long)b), (uint32_t)(g0 + (unsigned long long)e)};
+        s = sample_of(iv_start, n_samples, j0 + j);
+        idx = kidx[j] - kidx_all[iv_start[s]];
+        tf = (uint32_t)((g0 + (unsigned long long)(minus_one ? e : b)) / TILE); tl = minus_one ? tf : (uint32_t)((g0 + (unsigned long long)e - 1) / TILE);
+        key = (unsigned long long)s * n_tiles + tf;
+    }
+    const unsigned long long kp = __shfl_up(key, 1), kn = __shfl_down(key, 1);
+    const uint32_t lane = threadIdx.x & 63u;
+    if (key != ~0ull) {
+        if (lane == 0 || kp != key) atomicMin(&lo[key], idx);
+        if (lane == 63 || kn != key) atomicMax(&hi[key], idx + 1u);
+        for (uint32_t t = tf + 1; t <= tl; ++t) { atomicMin(&lo[(unsigned long long)s * n_tiles + t], idx); atomicMax(&hi[(unsigned long long)s * n_tiles + t], idx + 1u); }
+    }
+}
+__global__ void msnv_fin_cov_dense_flags(const uint32_t *hi, unsigned long long n, uint32_t *flag) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= n) flag[i] = (i < n && hi[i]) ? 1u : 0u;
+}
+__global__ void msnv_fin_cov_dense_runs(const uint32_t *lo, const uint32_t *hi, const uint32_t *rid_excl, unsigned long long n, uint32_t n_tiles, DevCovPair *out) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !hi[i]) return;
+    out[rid_excl[i]] = DevCovPair{(uint32_t)(i % n_tiles), (uint32_t)(i / n_tiles), lo[i], hi[i]};
+}
 __global__ void msnv_gather_u32(const uint32_t *src, const unsigned long long *idx, uint32_t n, uint32_t *out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = src[idx[i]];
@@ -2026,40 +2103,45 @@ int devfin_headers(msnv_dataset &ds, DeviceCols &d, const std::vector<uint64_t> 
     return MSNV_OK;
 }
 
-int devfin_chunk_counts(msnv_dataset &ds, DeviceCols &d, const std::vector<uint32_t> &narrow_pairs, std::vector<uint32_t> &counts) {
+// The narrow pairs' chunks in two steps with ONE wait between them: counts (+ their exclusive scan, on the device) -> the host learns every
+// pair's first chunk and the total, and allocates the descriptors; then the fill, straight into d.chunks and d.hdr4.  The list and the scan
+// stay in HBM between the two calls (DevPackTables::fin_list / fin_cbase).
+int devfin_chunk_counts(msnv_dataset &ds, DeviceCols &d, const std::vector<uint32_t> &narrow_pairs, std::vector<uint32_t> &cbase) {
     hipStream_t st = (hipStream_t)ds.ctx->stream;
     const size_t n = narrow_pairs.size();
-    counts.assign(n, 0);
+    cbase.assign(n + 1, 0);
     if (!n) return MSNV_OK;
-    DevBuf l, c;
-    if (int rc = l.alloc(n * 4)) return rc;
-    if (int rc = c.alloc(n * 4)) return rc;
-    HIP_TRY(hipMemcpyAsync(l.p, narrow_pairs.data(), n * 4, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(msnv_fin_chunks<false>, grid_for(n, 64), dim3(64), 0, st, d.pairs, l.as<uint32_t>(), (uint32_t)n, d.hdr, (const unsigned long long *)d.s_read_base,
-                       (const unsigned long long *)d.s_seq_base, c.as<uint32_t>(), nullptr, nullptr, nullptr);
+    DevPackTables &T = ds.dp;
+    if (int rc = dev_alloc(&T.fin_list, n * 4, nullptr)) return rc;
+    if (int rc = dev_alloc(&T.fin_cbase, (n + 1) * 8, nullptr)) return rc;      // counts (n + 1 words) and their scan behind them
+    uint32_t *cnt = static_cast<uint32_t *>(T.fin_cbase), *scan = cnt + (n + 1);
+    HIP_TRY(hipMemcpyAsync(T.fin_list, narrow_pairs.data(), n * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(cnt + n, 0, 4, st));
+    hipLaunchKernelGGL(msnv_fin_chunks<false>, grid_for(n * 64, 256), dim3(256), 0, st, d.pairs, static_cast<const uint32_t *>(T.fin_list), (uint32_t)n, d.hdr, (const unsigned long long *)d.s_read_base,
+                       (const unsigned long long *)d.s_seq_base, cnt, nullptr, nullptr, nullptr);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(counts.data(), c.p, n * 4, hipMemcpyDeviceToHost, st));
+    Prim pr(st);
+    if (int rc = pr.scan32(cnt, scan, n + 1, false)) return rc;
+    HIP_TRY(hipMemcpyAsync(cbase.data(), scan, (n + 1) * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return MSNV_OK;
 }
 
-// chunk descriptors (returned to the host, which appends the merged groups' and uploads the lot) and d.hdr4 (allocated, zeroed)
-int devfin_chunk_fill(msnv_dataset &ds, DeviceCols &d, const std::vector<uint32_t> &narrow_pairs, const std::vector<uint32_t> &chunk_base, uint64_t n_chunks, std::vector<ChunkDesc> &out) {
+// d.chunks[0 .. n_narrow) and d.hdr4 (both allocated by the caller) from the kept list and scan
+int devfin_chunk_fill(msnv_dataset &ds, DeviceCols &d, size_t n_pairs_listed) {
     hipStream_t st = (hipStream_t)ds.ctx->stream;
-    const size_t n = narrow_pairs.size();
-    out.resize(n_chunks);
-    if (!n) return MSNV_OK;
-    DevBuf l, b, c;
-    if (int rc = l.alloc(n * 4)) return rc;
-    if (int rc = b.alloc(n * 4)) return rc;
-    if (int rc = c.alloc(std::max<uint64_t>(1, n_chunks) * sizeof(ChunkDesc))) return rc;
-    HIP_TRY(hipMemcpyAsync(l.p, narrow_pairs.data(), n * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(b.p, chunk_base.data(), n * 4, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(msnv_fin_chunks<true>, grid_for(n, 64), dim3(64), 0, st, d.pairs, l.as<uint32_t>(), (uint32_t)n, d.hdr, (const unsigned long long *)d.s_read_base,
-                       (const unsigned long long *)d.s_seq_base, nullptr, b.as<uint32_t>(), c.as<ChunkDesc>(), d.hdr4);
-    HIP_TRY(hipGetLastError());
-    if (n_chunks) HIP_TRY(hipMemcpyAsync(out.data(), c.p, n_chunks * sizeof(ChunkDesc), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    DevPackTables &T = ds.dp;
+    if (n_pairs_listed) {
+        const uint32_t *scan = static_cast<const uint32_t *>(T.fin_cbase) + (n_pairs_listed + 1);
+        hipLaunchKernelGGL(msnv_fin_chunks<true>, grid_for(n_pairs_listed * 64, 256), dim3(256), 0, st, d.pairs, static_cast<const uint32_t *>(T.fin_list), (uint32_t)n_pairs_listed, d.hdr,
+                           (const unsigned long long *)d.s_read_base, (const unsigned long long *)d.s_seq_base, nullptr, scan, d.chunks, d.hdr4);
+        HIP_TRY(hipGetLastError());
+    }
+    return MSNV_OK;
+}
+int devfin_work_first(msnv_dataset &ds, DeviceCols &d, uint32_t n_items) {
+    hipStream_t st = (hipStream_t)ds.ctx->stream;
+    if (n_items) { hipLaunchKernelGGL(msnv_fin_work_first, grid_for(n_items, 256), dim3(256), 0, st, d.work, n_items, d.chunks); HIP_TRY(hipGetLastError()); }
     return MSNV_OK;
 }
 
@@ -2122,6 +2204,48 @@ int devfin_coverage(msnv_dataset &ds, DeviceCols &d, std::vector<uint64_t> &cvba
     HIP_TRY(hipGetLastError());
     std::vector<uint32_t> cvb_h(S + 1);
     HIP_TRY(hipMemcpyAsync(cvb_h.data(), cvb, (S + 1) * 4, hipMemcpyDeviceToHost, st));
+    // ---- the (sample, tile) runs: a dense table of minima / maxima when it is small beside the interval list (MSNV_COV_INDEX=sort|dense forces one)
+    const unsigned long long n_tab = (unsigned long long)S * ds.n_tiles;
+    bool dense_tab = n_tab <= std::max<unsigned long long>(8ull * N, 1ull << 22) && n_tab < 0xfffffff0ull;
+    if (const char *e = getenv("MSNV_COV_INDEX")) dense_tab = e[0] == 'd' ? n_tab < 0xfffffff0ull : e[0] == 's' ? false : dense_tab;
+    if (dense_tab) {
+        d.n_cov_iv = 0;
+        if (int rc = dev_alloc((void **)&d.cov_iv, ((uint64_t)N + 4) * sizeof(Pair32), &d.device_bytes)) return rc;      // (N >= the kept ones: no wait for their count)
+        DevBuf tab;
+        const unsigned long long b_t = up((n_tab + 1) * 4);
+        if (int rc = tab.alloc(4 * b_t)) return rc;
+        uint32_t *lo = tab.as<uint32_t>(), *hi = reinterpret_cast<uint32_t *>(tab.as<uint8_t>() + b_t), *flag = reinterpret_cast<uint32_t *>(tab.as<uint8_t>() + 2 * b_t),
+                 *rid = reinterpret_cast<uint32_t *>(tab.as<uint8_t>() + 3 * b_t);
+        HIP_TRY(hipMemsetAsync(lo, 0xff, b_t, st));
+        HIP_TRY(hipMemsetAsync(hi, 0, b_t, st));
+        unsigned long long o = 0;
+        for (const DevRound &r : ds.dp.rounds) {
+            if (r.n_iv) {
+                hipLaunchKernelGGL(msnv_fin_cov_emit_dense, grid_for(r.n_iv, 256), dim3(256), 0, st, r.cov_tid, r.cov_beg, r.cov_end, (unsigned long long)r.n_iv, o, ctg, tb, ivs, (uint32_t)S,
+                                   keep, kidx, ds.n_tiles, d.cov_iv, lo, hi);
+                HIP_TRY(hipGetLastError());
+            }
+            o += r.n_iv;
+        }
+        hipLaunchKernelGGL(msnv_fin_cov_dense_flags, grid_for(n_tab + 1, 256), dim3(256), 0, st, hi, n_tab, flag);
+        HIP_TRY(hipGetLastError());
+        if (int rc = pr.scan32(flag, rid, n_tab + 1, false)) return rc;
+        uint32_t n_runs = 0;
+        HIP_TRY(hipMemcpyAsync(&n_runs, rid + n_tab, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));                               // (n_keep and the per-sample bases arrive with it)
+        for (size_t s = 0; s <= S; ++s) cvbase[s] = cvb_h[s];
+        d.n_cov_iv = n_keep;
+        HIP_TRY(hipMemsetAsync(d.cov_iv + n_keep, 0, 4 * sizeof(Pair32), st));              // behind the last interval: what the idle lanes of msnv_coverage_tiles load
+        DevBuf runs;
+        if (int rc = runs.alloc(std::max<uint64_t>(1, n_runs) * sizeof(DevCovPair))) return rc;
+        hipLaunchKernelGGL(msnv_fin_cov_dense_runs, grid_for(n_tab, 256), dim3(256), 0, st, lo, hi, rid, n_tab, ds.n_tiles, runs.as<DevCovPair>());
+        HIP_TRY(hipGetLastError());
+        cp.resize(n_runs);
+        if (n_runs) HIP_TRY(hipMemcpyAsync(cp.data(), runs.p, (size_t)n_runs * sizeof(DevCovPair), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        fin_trace("    cov: dense table, runs (sync)");
+        return MSNV_OK;
+    }
     // entry slots: exclusive scan of the tile counts, in place of `keep` (no longer needed once kidx exists)
     unsigned long long n_ent64 = 0;
     {
@@ -2575,6 +2699,56 @@ int devfin_dense(msnv_dataset &ds) {
             sc.d_seq = static_cast<uint8_t *>(colbuf) + col_at[i]; sc.d_qual = sc.d_seq + seq_bytes; sc.d_seq_bytes = seq_bytes;
             sc.d_blk = static_cast<uint32_t *>(blkbuf) + blk_at[i]; sc.n_dev_blk = blk_at[i + 1] - blk_at[i];
             ++T.n_dense_samples;
+        }
+    }
+    return MSNV_OK;
+}
+
+// The columns of a dataset whose samples were all packed here (piece layout, not the dense one): a round's buffer already IS the
+// dataset's layout for its samples, so one round's buffer is adopted as it stands (no copy at all) and several rounds' are copied
+// round by round; a sample whose columns were re-laid behind the pack (deep runs dealt into groups) is copied by itself.
+int devpack_place_columns(msnv_dataset &ds, DeviceCols &d, const std::vector<uint64_t> &sbase) {
+    hipStream_t st = (hipStream_t)ds.ctx->stream;
+    DevPackTables &T = ds.dp;
+    const size_t S = ds.samples.size();
+    auto in_place = [&](const DevRound &R) {
+        for (size_t k = 0; k < R.n_samples; ++k) {
+            const SampleCols &sc = ds.samples[R.first_sample + k];
+            if (sc.d_seq != R.col_seq + (sbase[R.first_sample + k] - sbase[R.first_sample]) || sc.d_qual != R.col_qual + (sbase[R.first_sample + k] - sbase[R.first_sample]) / 4) return false;
+        }
+        return sbase[R.first_sample + R.n_samples] - sbase[R.first_sample] == R.seq_total;
+    };
+    const bool guard = [] { const char *e = getenv("MSNV_GUARD_ALLOC"); return e && e[0] == '1'; }();      // (guarded buffers end at the end of their mapping: no adoption of a buffer that holds two columns)
+    if (T.rounds.size() == 1 && T.rounds[0].first_sample == 0 && T.rounds[0].n_samples == S && in_place(T.rounds[0]) && !guard && !getenv("MSNV_NO_ADOPT")) {
+        DevRound &R = T.rounds[0];
+        d.seq = R.col_seq; d.qual = R.col_qual;
+        d.blocks.emplace_back(R.col_buf, R.seq_total + COL_PAD + R.seq_total / 4 + 64);
+        d.device_bytes += R.seq_total + COL_PAD + R.seq_total / 4 + 64;
+        for (void *&p : T.round_bufs) if (p == R.col_buf) p = nullptr;
+        R.col_buf = nullptr;
+        return MSNV_OK;
+    }
+    if (int rc = dev_alloc((void **)&d.seq, sbase[S] + COL_PAD, &d.device_bytes)) return rc;
+    if (int rc = dev_alloc((void **)&d.qual, sbase[S] / 4 + 64, &d.device_bytes)) return rc;
+    HIP_TRY(hipMemsetAsync(d.seq + sbase[S], 0xff, COL_PAD, st));
+    HIP_TRY(hipMemsetAsync(d.qual + sbase[S] / 4, 0, 64, st));
+    for (const DevRound &R : T.rounds) {
+        if (!R.n_samples) continue;
+        const uint64_t o = sbase[R.first_sample];
+        if (in_place(R)) {
+            if (R.seq_total) {
+                HIP_TRY(hipMemcpyAsync(d.seq + o, R.col_seq, R.seq_total, hipMemcpyDeviceToDevice, st));
+                HIP_TRY(hipMemcpyAsync(d.qual + o / 4, R.col_qual, R.seq_total / 4, hipMemcpyDeviceToDevice, st));
+            }
+            continue;
+        }
+        for (size_t k = 0; k < R.n_samples; ++k) {
+            const size_t s = R.first_sample + k;
+            const SampleCols &sc = ds.samples[s];
+            const uint64_t share = sbase[s + 1] - sbase[s];
+            HIP_TRY(hipMemsetAsync(d.seq + sbase[s], 0xff, share, st));
+            HIP_TRY(hipMemsetAsync(d.qual + sbase[s] / 4, 0, share / 4, st));
+            if (int rc = devpack_copy_columns(sc, d.seq + sbase[s], d.qual + sbase[s] / 4, st)) return rc;
         }
     }
     return MSNV_OK;

@@ -2688,7 +2688,8 @@ void dev_free_all(DeviceCols &d) {
                     d.tile_pair_start, d.work, d.chunks, d.tile_vbeg, d.tile_vend, d.tot, d.part, d.tile_slot_start, d.tile_slot_u16, d.tile_slot_wide, d.slot_off, d.spill, d.events, d.overflow, d.counters, d.ind4, d.tile_dirty, d.unc_sites, d.site_row, d.gate_tiles,
                     d.sites, d.tile_site_base, d.tile_site_cnt, d.tile_cell_base, d.tile_nslots, d.ncol, d.cov_col, d.site_flags, d.site_elig,
                     d.cov_iv, d.s_cov_base, d.cov_pairs, d.cov_work, d.tile_len, d.tile_contig_dev, d.cov_acc, d.tile_stage, d.tile_stage_idx, d.alt.tile_stage, d.gate_tiles_dense, d.gate_tiles_staged, d.gather_tiles};
-    for (void *p : ptrs) dev_free(p);
+    auto in_block = [&](void *p) { for (const auto &b : d.blocks) if ((char *)p >= (char *)b.first && (char *)p < (char *)b.first + b.second) return true; return false; };
+    for (void *p : ptrs) if (p && !in_block(p)) dev_free(p);
     void *aptrs[] = {d.ann.seg_beg, d.ann.seg_end, d.ann.seg_gene, d.ann.genes, d.ann.contigs, d.ann.codons, d.ann.out, d.ann.err};
     for (void *p : aptrs) dev_free(p);
     for (void *e : d.timing_events) if (e) (void)hipEventDestroy((hipEvent_t)e);
@@ -2696,7 +2697,8 @@ void dev_free_all(DeviceCols &d) {
     if (d.pinned_cnt) (void)hipHostFree(d.pinned_cnt);
     void *alts[] = {d.aspill, d.alt.aspill, d.alt.tot, d.alt.part, d.alt.spill, d.alt.events, d.alt.overflow, d.alt.counters, d.alt.ind4, d.alt.tile_dirty, d.alt.unc_sites, d.alt.site_row, d.alt.sites, d.alt.tile_site_base,
                     d.alt.tile_site_cnt, d.alt.tile_cell_base, d.alt.ncol, d.alt.cov_col, d.alt.site_flags, d.alt.site_elig, d.alt.site_bits, d.site_bits, d.alt.site_rank, d.site_rank, d.active_tiles};
-    for (void *p : alts) dev_free(p);
+    for (void *p : alts) if (p && !in_block(p)) dev_free(p);
+    for (const auto &b : d.blocks) dev_free(b.first);
     if (d.stream2) (void)hipStreamDestroy((hipStream_t)d.stream2);
     d = DeviceCols{};
 }

@@ -831,7 +831,7 @@ int finalize_dataset(msnv_dataset &ds) {
     // ---- tile layout: every selected contig owns ceil(max(L, furthest read end) / TILE) tiles
     std::vector<int64_t> maxend(NC, 0);
     for (size_t c = 0; c < NC; ++c) maxend[c] = ds.sel[c] ? ds.lengths[c] : 0;
-    {
+    if (!fast) {       // (fast: the pieces are in HBM -- devfin_overhang below; qaCompute's intervals never reach beyond a contig's length)
         // per sample: the contigs it touches and how far (reads are sorted by contig: runs), merged under a lock
         std::mutex mu;
         parallel_for(S, [&](size_t s) {
@@ -1278,7 +1278,8 @@ int finalize_dataset(msnv_dataset &ds) {
     }
     lap("partial rows, gate tiles");
     // ---- chunk descriptors of the narrow work items
-    std::vector<ChunkDesc> chunks;
+    std::vector<ChunkDesc> chunks;                                  // fast: the merged groups' only -- the narrow items' are cut in HBM (n_chunks_dev of them, in front)
+    uint64_t n_chunks_dev = 0; size_t n_pairs_listed = 0;
     std::vector<std::vector<uint32_t>> hdr4_of(HDR4 && !dense && !fast ? S : 0);      // 4-byte piece headers, per sample (chunk-relative offsets: filled with the chunks)
     for (size_t s = 0; s < hdr4_of.size(); ++s) hdr4_of[s].assign(ds.samples[s].hdr.size(), 0u);
     if (fast) {
@@ -1296,20 +1297,21 @@ int finalize_dataset(msnv_dataset &ds) {
     if (fast && !dense) {
         if (int rc = dev_alloc((void **)&d->hdr4, (rbase[S] + 4) * sizeof(uint32_t), &d->device_bytes)) return rc;
         if (int rc = dev_memset(d->hdr4, 0, (rbase[S] + 4) * sizeof(uint32_t))) return rc;
-        std::vector<uint32_t> narrow_pairs, counts, cbase;
+        if (rbase[S] > 0xfffffff0ull) return fail(MSNV_EDOMAIN, "more than 2^32 pieces in one shard: shard the contigs further");      // (chunks <= pieces: the 32-bit scan of their counts cannot wrap)
+        std::vector<uint32_t> narrow_pairs, cbase;
         for (uint32_t wi = 0; wi < d->n_work_narrow; ++wi) for (uint32_t k = work[wi].pair_lo; k < work[wi].pair_hi; ++k) narrow_pairs.push_back(k);
         lap("  hdr4 alloc + narrow list");
-        if (int rc = devfin_chunk_counts(ds, *d, narrow_pairs, counts)) return rc;
+        if (int rc = devfin_chunk_counts(ds, *d, narrow_pairs, cbase)) return rc;
         lap("  devfin_chunk_counts");
-        cbase.resize(narrow_pairs.size());
-        uint64_t nch = 0; size_t j = 0;
+        size_t j = 0;
         for (uint32_t wi = 0; wi < d->n_work_narrow; ++wi) {
-            work[wi].chunk_lo = (uint32_t)nch;
-            for (uint32_t k = work[wi].pair_lo; k < work[wi].pair_hi; ++k, ++j) { cbase[j] = (uint32_t)nch; nch += counts[j]; }
-            work[wi].chunk_hi = (uint32_t)nch;
+            work[wi].chunk_lo = cbase[j];
+            j += work[wi].pair_hi - work[wi].pair_lo;
+            work[wi].chunk_hi = cbase[j];
         }
-        if (nch > 0xfffffff0ull) return fail(MSNV_EDOMAIN, "more than 2^32 chunks in one shard");
-        if (int rc = devfin_chunk_fill(ds, *d, narrow_pairs, cbase, nch, chunks)) return rc;
+        n_chunks_dev = cbase[narrow_pairs.size()];
+        n_pairs_listed = narrow_pairs.size();
+        if (n_chunks_dev > 0xfffffff0ull) return fail(MSNV_EDOMAIN, "more than 2^32 chunks in one shard");
     }
     else for (uint32_t wi = 0; wi < d->n_work_narrow; ++wi) {
         WorkItem &w = work[wi];
@@ -1364,7 +1366,7 @@ int finalize_dataset(msnv_dataset &ds) {
         size_t gi = 0;
         for (uint32_t wi = d->n_work_narrow; wi < d->n_work_narrow + d->n_work_merged; ++wi) {
             WorkItem &w = work[wi];
-            w.chunk_lo = (uint32_t)chunks.size();
+            w.chunk_lo = (uint32_t)(n_chunks_dev + chunks.size());
             for (; gi < groups.size() && groups[gi].pair_lo >= w.pair_lo && groups[gi].pair_hi <= w.pair_hi; ++gi) {
                 const MergedGroup &g = groups[gi];
                 const uint64_t h0 = fast ? hm_count : hm.size();
@@ -1384,7 +1386,7 @@ int finalize_dataset(msnv_dataset &ds) {
                     chunks.push_back(ChunkDesc{h0 + r, 0, pairs[g.pair_lo].sample, g.pair_lo, n | (r + n >= n_h ? 1u << 16 : 0u), g.pair_hi - g.pair_lo});
                 }
             }
-            w.chunk_hi = (uint32_t)chunks.size();
+            w.chunk_hi = (uint32_t)(n_chunks_dev + chunks.size());
         }
         if (gi != groups.size()) return fail(MSNV_EINVAL, "internal: merged groups and work items disagree");
         if (fast) {
@@ -1401,14 +1403,17 @@ int finalize_dataset(msnv_dataset &ds) {
         if (int rc = upload_vec(&d->merged_groups, mgroups, &d->device_bytes, 1)) return rc;
         if (int rc = upload_vec(&d->tile_pair_merged, tpm, &d->device_bytes)) return rc;
     }
-    for (size_t wi = 0; wi < (size_t)d->n_work_narrow + d->n_work_merged; ++wi)
+    if (!fast) for (size_t wi = 0; wi < (size_t)d->n_work_narrow + d->n_work_merged; ++wi)
         if (work[wi].chunk_hi > work[wi].chunk_lo) work[wi].first = chunks[work[wi].chunk_lo];
-    d->n_chunks = chunks.size();
-    if (int rc = upload_vec(&d->chunks, chunks, &d->device_bytes, 1)) return rc;
+    d->n_chunks = n_chunks_dev + chunks.size();
+    if (int rc = dev_alloc((void **)&d->chunks, (d->n_chunks + 1) * sizeof(ChunkDesc), &d->device_bytes)) return rc;
+    if (int rc = dev_upload(d->chunks + n_chunks_dev, chunks.data(), chunks.size() * sizeof(ChunkDesc))) return rc;
+    if (fast && !dense) if (int rc = devfin_chunk_fill(ds, *d, n_pairs_listed)) return rc;
     d->n_pairs = (uint32_t)pairs.size(); d->n_work = (uint32_t)work.size();
     if (!fast) if (int rc = upload_vec(&d->pairs, pairs, &d->device_bytes)) return rc;
     if (int rc = upload_vec(&d->tile_pair_start, tps, &d->device_bytes)) return rc;
     if (int rc = upload_vec(&d->work, work, &d->device_bytes)) return rc;
+    if (fast) if (int rc = devfin_work_first(ds, *d, d->n_work_narrow + d->n_work_merged)) return rc;
     if (!fast) if (int rc = upload_vec(&d->s_read_base, rbase, &d->device_bytes)) return rc;
     if (!fast) if (int rc = upload_vec(&d->s_seq_base, sbase, &d->device_bytes)) return rc;
 
@@ -1419,6 +1424,9 @@ int finalize_dataset(msnv_dataset &ds) {
     if (!dense && !HDR4) if (int rc = dev_alloc((void **)&d->hdr8, (rbase[S] + 1) * sizeof(PieceHdr), &d->device_bytes)) return rc;
     if (!dense && HDR4 && !fast) if (int rc = dev_alloc((void **)&d->hdr4, (rbase[S] + 4) * sizeof(uint32_t), &d->device_bytes)) return rc;
     if (dense) if (int rc = dev_alloc((void **)&d->blk, (bbase[S] + 1) * sizeof(uint32_t), &d->device_bytes)) return rc;
+    const bool cols_on_device = fast && !dense;                    // every sample's columns are in the rounds' buffers, already in this layout (devpack_place_columns)
+    if (cols_on_device) { if (int rc = devpack_place_columns(ds, *d, sbase)) return rc; }
+    else {
     if (int rc = dev_alloc((void **)&d->seq, sbase[S] + 256, &d->device_bytes)) return rc;     // lanes past the end of the last piece read on
     if (int rc = dev_memset(d->seq, 0xff, sbase[S] + 256)) return rc;                          // (the < 16 bytes between two samples' columns: defined, so that two builds of a dataset can be compared)
     // the quality column of the device is ONE BIT per base -- "below the -Q cutoff" -- at the index of the base's nibble in the seq column: the
@@ -1426,6 +1434,7 @@ int finalize_dataset(msnv_dataset &ds) {
     // behind the overlap tweak and the token limit, which ran on the host (pass 1 above).  1 B -> 1/8 B per base of HBM and of upload.
     if (int rc = dev_alloc((void **)&d->qual, sbase[S] / 4 + 64, &d->device_bytes)) return rc;
     if (int rc = dev_memset(d->qual, 0, sbase[S] / 4 + 64)) return rc;
+    }
     d->qlow_cutoff = ds.params.min_baseq;
     uint64_t alg = 0;
     lap("  column allocs + memsets");
@@ -1457,7 +1466,8 @@ int finalize_dataset(msnv_dataset &ds) {
                     for (size_t i = 0; i < sc.hdr.size(); ++i) h8[i] = PieceHdr{(sc.hdr[i].gpos % TILE) | sc.hdr[i].cig << 11, sc.hdr[i].seqoff >> SEQ_ALIGN_LOG2};
                     rc = dev_upload(d->hdr8 + rbase[s], h8.data(), h8.size() * sizeof(PieceHdr));
                 }
-                if (!rc && sc.on_device) rc = devpack_copy_columns(sc, d->seq + sbase[s], d->qual + sbase[s] / 4, ds.ctx ? ds.ctx->stream : nullptr);      // packed on the device: HBM to HBM
+                if (cols_on_device) {}                                     // (placed above, round by round)
+                else if (!rc && sc.on_device) rc = devpack_copy_columns(sc, d->seq + sbase[s], d->qual + sbase[s] / 4, ds.ctx ? ds.ctx->stream : nullptr);      // packed on the device: HBM to HBM
                 else {
                     if (!rc) rc = dev_upload(d->seq + sbase[s], sc.seq.data(), sc.seq.size());
                     if (!rc) {
@@ -1474,7 +1484,8 @@ int finalize_dataset(msnv_dataset &ds) {
         };
         const size_t n_up = std::min<size_t>(S, std::min<size_t>(8, msnv_default_threads()));
         std::vector<std::thread> th;
-        for (size_t t = 0; t < n_up; ++t) th.emplace_back(worker);
+        if (cols_on_device) worker();                                  // (nothing to upload: no threads)
+        else for (size_t t = 0; t < n_up; ++t) th.emplace_back(worker);
         for (auto &t : th) t.join();
         if (up_err.load()) return fail(up_err.load(), "%s", up_msg.c_str());
         lap("  column copies");
@@ -1667,7 +1678,7 @@ int finalize_dataset(msnv_dataset &ds) {
     for (size_t c = 0; c < NC; ++c) if (ds.sel[c]) { ds.info.n_contigs++; ds.info.n_positions += (uint64_t)ds.lengths[c]; }
     ds.info.n_reads = tot_reads; ds.info.n_reads_pileup = tot_pile_reads; ds.info.n_pileup_bases = tot_bases;
     ds.info.n_tiles = nt; ds.info.n_pairs = pairs.size(); ds.info.n_work = work.size();
-    ds.info.bytes_index = pairs.size() * sizeof(TilePair) + work.size() * sizeof(WorkItem) + chunks.size() * sizeof(ChunkDesc) + (nt + 1) * 4;
+    ds.info.bytes_index = pairs.size() * sizeof(TilePair) + work.size() * sizeof(WorkItem) + d->n_chunks * sizeof(ChunkDesc) + (nt + 1) * 4;
     ds.info.device_bytes = d->device_bytes;
     lap("intermediates");
     ds.finalized = true;
