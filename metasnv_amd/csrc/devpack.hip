@@ -270,18 +270,25 @@ __global__ void msnv_compact_offsets(const unsigned long long *tmp_off, const Co
 }
 
 // ------------------------------------------------------------------------------------------ per-record measure
+// What a record adds to the running sums every later stage places things by: ONE exclusive scan of these over the round's records gives a
+// record its rank among the pileup reads, its first piece, its first interval, the pieces earlier reads leave in the tile behind their
+// own (tile order, below) and its first byte of the seq column.
+struct RecCnt { uint32_t pile, npiece, niv, spill; unsigned long long seqb; };
+struct RecCntSum { __device__ __host__ RecCnt operator()(const RecCnt &a, const RecCnt &b) const { return RecCnt{a.pile + b.pile, a.npiece + b.npiece, a.niv + b.niv, a.spill + b.spill, a.seqb + b.seqb}; } };
+enum : uint32_t { MISC_SORT = 0, MISC_WORDS = 4 };                  // words of the round's flag block: [MISC_SORT] the pieces need the general tile-order sort
 // Everything of pack.cpp: filter_and_edit + pack_sample that one record decides by itself.
 __global__ __launch_bounds__(256) void msnv_measure_reads(const uint8_t *raw, const unsigned long long *rec_off, const uint16_t *rec_sample, const uint32_t *rec_base,
                                                           const unsigned long long *s_end, uint32_t n_rec, const DpContig *ctg, DpParams P, const uint32_t *ovr,
-                                                          uint8_t *r_flags, unsigned long long *r_key, uint32_t *r_end, uint32_t *r_maxc, uint32_t *r_pile,
-                                                          uint32_t *r_npiece, uint32_t *r_seqb, uint32_t *r_niv, DpAcc *acc) {
+                                                          uint8_t *r_flags, unsigned long long *r_key, uint32_t *r_end, uint32_t *r_maxc, RecCnt *r_cnt, uint32_t *r_ftile,
+                                                          DpAcc *acc, uint32_t *misc) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = i < n_rec;
     const uint32_t s = valid ? rec_sample[i] : 0xffffffffu;
     uint32_t st_total = 0, st_unmapped = 0, st_zeroq = 0, st_proper = 0, st_dup = 0, st_any = 0, n_pile = 0, n_ovl = 0;
     unsigned long long m_pile = 0, alg8d = 0, alg_cigar = 0, alg_seq = 0, alg_qual = 0;
     unsigned long long err = ~0ull, first_pile = ~0ull, beyond_at = ~0ull;
-    uint8_t flags = 0; unsigned long long key = 0; uint32_t o_end = 0, o_maxc = 0, o_np = 0, o_sb = 0, o_niv = 0;
+    uint8_t flags = 0; unsigned long long key = 0; uint32_t o_end = 0, o_maxc = 0, o_np = 0, o_sb = 0, o_niv = 0, o_ftile = 0, o_spill = 0;
+    bool need_sort = false;
     if (valid) {
         const uint8_t *p = raw + rec_off[i];
         const Rec r = rec_load(p, s_end[s] - rec_off[i]);
@@ -315,7 +322,7 @@ __global__ __launch_bounds__(256) void msnv_measure_reads(const uint8_t *raw, co
                     // ---- CIGAR geometry, pieces, qaCompute's intervals: one walk
                     long long rlen = 0, qlen = 0, m_bases = 0, ins = 0, del = 0, rp = r.pos, pp = (long long)r.pos + 1;
                     bool has_ref_op = false, beyond = false;
-                    uint32_t n_piece = 0, seqb = 0, n_iv = 0;
+                    uint32_t n_piece = 0, seqb = 0, n_iv = 0, ftile = 0, ltile = 0, n_spill = 0;
                     unsigned long long a_seq = 0;
                     uint32_t k0 = 0;
                     if (r.n_cigar > 0) { const uint32_t t = ld32(r.cigar) & 15u; if (t == C_S || t == C_H) k0 = 1; }
@@ -334,6 +341,10 @@ __global__ __launch_bounds__(256) void msnv_measure_reads(const uint8_t *raw, co
                                 const uint32_t to_tile = TILE - (uint32_t)((rp + off) % TILE);
                                 n = SEG_MAX < l - off ? SEG_MAX : l - off;
                                 n = n < to_tile ? n : to_tile;
+                                const uint32_t tl = (uint32_t)((rp + off) / TILE);
+                                if (!n_piece) ftile = tl;
+                                if (tl != ftile) ++n_spill;
+                                ltile = tl;
                                 ++n_piece; seqb += stored_bytes(n); a_seq += (n + 1u) / 2u;
                             }
                             rp += l;
@@ -365,13 +376,19 @@ __global__ __launch_bounds__(256) void msnv_measure_reads(const uint8_t *raw, co
                         alg_cigar = 4ull * r.n_cigar;
                         // SEQ '*' (l_seq = 0): N bases of quality 0, shipped only under -Q 0 (pack.cpp: pack_sample)
                         if (r.l_seq > 0 || (P.c_eff == 0 && !P.all_low)) { o_np = n_piece; o_sb = seqb; alg_seq = a_seq; alg_qual = (unsigned long long)m_bases; }
+                        o_ftile = ftile; o_spill = o_np ? n_spill : 0u;
+                        // tile order by counting (msnv_emit_headers) needs every pileup read to leave pieces in its first tile and at most the
+                        // one behind it; a read that reaches further (a reference skip, a read of thousands of bases) or ships no piece at all
+                        // sends the round through the general sort
+                        if (!o_np || ltile > ftile + 1u) need_sort = true;
                     }
                 }
             }
         }
-        r_flags[i] = flags; r_key[i] = key; r_end[i] = o_end; r_maxc[i] = o_maxc; r_pile[i] = (flags & RF_PILE) ? 1u : 0u;
-        r_npiece[i] = o_np; r_seqb[i] = o_sb; r_niv[i] = o_niv;
+        r_flags[i] = flags; r_key[i] = key; r_end[i] = o_end; r_maxc[i] = o_maxc; r_ftile[i] = o_ftile;
+        r_cnt[i] = RecCnt{(flags & RF_PILE) ? 1u : 0u, o_np, o_niv, o_spill, (unsigned long long)o_sb};
     }
+    if (__any(need_sort) && (threadIdx.x & 63u) == 0) atomicOr(&misc[MISC_SORT], 1u);
     // ---- per-sample sums: a wavefront's records almost always belong to one sample -> one atomic per counter and wavefront
     const uint32_t s0 = __shfl(s, 0);
     const bool uniform = __all(s == s0 || !valid) && s0 != 0xffffffffu;
@@ -423,74 +440,118 @@ __global__ __launch_bounds__(256) void msnv_measure_reads(const uint8_t *raw, co
 // ------------------------------------------------------------------------------------------ depth at every read start
 // pack.cpp keeps the pileup reads of a sample in a heap by reference end (sam.c bam_plp_push [EXT], sample-local): when a read starts,
 // the ones that ended at or before its start are popped, then it is pushed -- depth = reads alive, itself included; the sum of their
-// longest possible pileup elements bounds the sample's base string there (snpCall's token limit).  Here: reads alive at the start of
-// read r of a (sample, contig) run = reads of the run before r, r itself, minus the reads of the run that end at or before r's start
-// -- all of which started before it (end > start) -- counted by a search in the run's sorted ends.
-__global__ void msnv_pile_list(const uint32_t *r_pile, const uint32_t *rank, uint32_t n_rec, uint32_t *pl) {
+// longest possible pileup elements bounds the sample's base string there (snpCall's token limit).  Here, without a sort (round 5; rounds
+// 1-4 merged the starts and the ends of a round with a radix sort of 2 N keys): the pileup reads of the round are listed in file order
+// (msnv_pile_gather), an inclusive scan carries along the run -- (sample, contig) -- the LARGEST end seen so far, which never decreases
+// inside a run: every read before the first one whose running maximum lies beyond this read's start has ended, so the reads alive at the
+// start of read r are r itself and those of the WINDOW [w, r) that end beyond it -- found by a galloping search from r backwards and one
+// pass over the window (about `depth` reads, the neighbours' cache lines).  The same scan numbers the runs and the (run, first tile)
+// groups of reads that the tile order of the pieces is built from.
+struct PScan { unsigned long long key; uint32_t endmax, runs, grps, pad; };     // key: sample << 32 | contig
+struct PScanOp {
+    __device__ __host__ PScan operator()(const PScan &a, const PScan &b) const {
+        return PScan{b.key, (a.key == b.key && a.endmax > b.endmax) ? a.endmax : b.endmax, a.runs + b.runs, a.grps + b.grps, 0u};
+    }
+};
+struct PScanIn {                                                   // element r of the scan's input, made from the gathered columns
+    const unsigned long long *key; const uint32_t *end, *ftile;
+    __device__ PScan operator()(uint32_t r) const {
+        const unsigned long long k = key[r];
+        const bool run = r == 0 || key[r - 1] != k;
+        return PScan{k, end[r], run ? 1u : 0u, (run || ftile[r - 1] != ftile[r]) ? 1u : 0u, 0u};
+    }
+};
+__global__ void msnv_pile_gather(const RecCnt *r_cnt, const RecCnt *pre, uint32_t n_rec, const uint16_t *rec_sample, const unsigned long long *r_key, const uint32_t *r_end, const uint32_t *r_maxc,
+                                 const uint32_t *r_ftile, unsigned long long *p_key, uint32_t *p_pos, uint32_t *p_end, uint32_t *p_maxc, uint32_t *p_ftile, uint32_t *p_rec) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_rec && r_pile[i]) pl[rank[i]] = i;
+    if (i >= n_rec || !r_cnt[i].pile) return;
+    const uint32_t r = pre[i].pile;
+    const unsigned long long k = r_key[i];
+    p_key[r] = (unsigned long long)rec_sample[i] << 32 | (k >> 32); p_pos[r] = (uint32_t)k & 0x7fffffffu;
+    p_end[r] = r_end[i] < 0x7fffffffu ? r_end[i] : 0x7fffffffu; p_maxc[r] = r_maxc[i]; p_ftile[r] = r_ftile[i]; p_rec[r] = i;
 }
-__global__ void msnv_run_flags(const uint32_t *pl, uint32_t n_pile, const uint16_t *rec_sample, const unsigned long long *r_key, uint32_t *rf) {
+// per group of reads (run, first tile): depth bounds of the pieces it leaves in its own tile / in the tile behind
+__global__ __launch_bounds__(256) void msnv_depth(const PScan *ps, uint32_t n_pile, const unsigned long long *p_key, const uint32_t *p_pos, const uint32_t *p_end, const uint32_t *p_maxc,
+                                                  const uint32_t *p_ftile, const uint32_t *p_rec, const RecCnt *r_cnt, const uint32_t *ovr, DpParams P, uint16_t *r_depth,
+                                                  uint32_t *run_first, uint32_t *run_f1, uint32_t *grp_first, uint32_t *grp_md, DpAcc *acc, uint32_t *misc) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_pile) return;
-    const uint32_t i = pl[r];
-    bool first = r == 0;
-    if (!first) { const uint32_t j = pl[r - 1]; first = rec_sample[i] != rec_sample[j] || (r_key[i] >> 32) != (r_key[j] >> 32); }
-    rf[r] = first ? 1u : 0u;
-}
-// keys of the merged list: entry r = the START of pileup read r, entry n_pile + r = its END; inside a run, ends sort before starts of the same value
-// (a read that ends where this one starts is gone)
-__global__ void msnv_depth_keys(const uint32_t *pl, uint32_t n_pile, const uint32_t *rf, const uint32_t *run_incl, const unsigned long long *r_key, const uint32_t *r_end,
-                                const uint32_t *r_maxc, unsigned long long *keys, uint32_t *vals, uint32_t *maxc_rank, uint32_t *run_first, uint32_t *run_f1) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_pile) { if (r == n_pile) maxc_rank[r] = 0; return; }
-    const uint32_t i = pl[r], g = run_incl[r] - 1u;
-    const uint32_t pos = (uint32_t)r_key[i] & 0x7fffffffu, end = r_end[i] < 0x7fffffffu ? r_end[i] : 0x7fffffffu;
-    keys[r] = (unsigned long long)g << 32 | (pos << 1 | 1u); vals[r] = r;
-    keys[n_pile + r] = (unsigned long long)g << 32 | (end << 1); vals[n_pile + r] = n_pile + r;
-    maxc_rank[r] = r_maxc[i];
-    if (rf[r]) { run_first[g] = r; run_f1[g] = 0xffffffffu; }
-}
-__global__ void msnv_depth_endchars(const uint32_t *svals, uint32_t n_pile, const uint32_t *maxc_rank, uint32_t *ev) {
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q > 2u * n_pile) return;
-    const uint32_t v = q < 2u * n_pile ? svals[q] : 0u;
-    ev[q] = (q < 2u * n_pile && v >= n_pile) ? maxc_rank[v - n_pile] : 0u;
-}
-__global__ void msnv_depth(const uint32_t *pl, uint32_t n_pile, const uint32_t *svals, const uint32_t *run_incl, const uint32_t *run_first, const unsigned long long *E,
-                           const unsigned long long *Pm, const unsigned long long *r_key, const uint32_t *r_end, const uint16_t *rec_sample, const uint32_t *ovr, DpParams P, uint16_t *r_depth, uint32_t *run_f1,
-                           DpAcc *acc) {
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= 2u * n_pile) return;
-    const uint32_t r = svals[q];
-    if (r >= n_pile) return;                                     // an end
-    const uint32_t i = pl[r], g = run_incl[r] - 1u, lo = run_first[g];
-    const uint32_t gone = q - lo - r;                            // entries of the run before q = (r - lo) starts + the ends at or before this start
-    const uint32_t depth = r - lo + 1u - gone;
-    const unsigned long long chars = (Pm[r + 1] - Pm[lo]) - (E[q] - E[2u * lo]);
-    // first read of the run whose end lies beyond position 1 (the first line under metaSNV's `name 1 LEN` split): a read that starts at
-    // position >= 1 always qualifies, so only the reads at position 0 and the first one behind them can be it -- a handful of atomics per run
-    if (r_end[i] > 1u && (r == lo || (uint32_t)r_key[i] == 0u || (uint32_t)r_key[pl[r - 1]] == 0u)) atomicMin(&run_f1[g], r);
-    const uint32_t ov = ovr ? ovr[i] : 0u;
-    if (ov & 1u) { r_depth[i] = (uint16_t)(ov >> 16); return; }
-    r_depth[i] = (uint16_t)(depth < 0xffffu ? depth : 0xffffu);
-    uint32_t need = 0;
-    if (P.max_depth > 0 && depth - 1u > (uint32_t)P.max_depth) need |= NEED_CAP;             // live.size() > max_depth before the push
-    if (P.token_limit > 0 && chars >= (unsigned long long)P.token_limit) need |= NEED_TOKEN;
-    if (need) atomicOr(&acc[(size_t)rec_sample[i] * ACC_COPIES].need_host, need);
+    const bool valid = r < n_pile;
+    uint32_t gi = 0xffffffffu, depth = 0, spill = 0;
+    if (valid) {
+        const unsigned long long key = p_key[r];
+        const uint32_t p = p_pos[r], i = p_rec[r];
+        const PScan me = ps[r];
+        const uint32_t g = me.runs - 1u;
+        gi = me.grps - 1u;
+        const bool run_start = r == 0 || p_key[r - 1] != key;
+        if (run_start) { run_first[g] = r; }
+        if (run_start || p_ftile[r - 1] != p_ftile[r]) grp_first[gi] = i;
+        if (!run_start && p_ftile[r - 1] > p_ftile[r]) atomicOr(&misc[MISC_SORT], 1u);      // (a read whose first aligned base lies in an earlier tile than its predecessor's: leading deletions)
+        // ---- the window: first read of the run before r whose running maximum of ends lies beyond p
+        uint32_t w = r;
+        if (!run_start) {
+            auto beyond = [&](uint32_t j) { const PScan x = ps[j]; return x.key == key && x.endmax > p; };
+            if (beyond(r - 1)) {
+                uint32_t hi = r - 1, step = 1;                     // beyond(hi) holds
+                uint32_t lo = 0; bool found_lo = false;            // a j below hi where it does not
+                while (hi >= step) { const uint32_t j = hi - step; if (beyond(j)) { hi = j; step <<= 1; } else { lo = j; found_lo = true; break; } }
+                if (!found_lo) { if (hi > 0 && beyond(0)) hi = 0; else if (hi > 0) { lo = 0; found_lo = true; } }
+                if (found_lo) while (hi - lo > 1) { const uint32_t m = lo + (hi - lo) / 2; if (beyond(m)) hi = m; else lo = m; }
+                w = hi;
+            }
+        }
+        unsigned long long chars = p_maxc[r];
+        depth = 1;
+        for (uint32_t j = w; j < r; ++j) if (p_end[j] > p) { ++depth; chars += p_maxc[j]; }
+        // first read of the run whose end lies beyond position 1 (the first line under metaSNV's `name 1 LEN` split): a read that starts at
+        // position >= 1 always qualifies, so only the reads at position 0 and the first one behind them can be it -- a handful of atomics per run
+        if (p_end[r] > 1u && (run_start || p == 0u || p_pos[r - 1] == 0u)) atomicMin(&run_f1[g], r);
+        spill = r_cnt[i].spill;
+        const uint32_t ov = ovr ? ovr[i] : 0u;
+        if (ov & 1u) { depth = ov >> 16; r_depth[i] = (uint16_t)depth; }
+        else {
+            r_depth[i] = (uint16_t)(depth < 0xffffu ? depth : 0xffffu);
+            uint32_t need = 0;
+            if (P.max_depth > 0 && depth - 1u > (uint32_t)P.max_depth) need |= NEED_CAP;         // live.size() > max_depth before the push
+            if (P.token_limit > 0 && chars >= (unsigned long long)P.token_limit) need |= NEED_TOKEN;
+            if (need) atomicOr(&acc[(size_t)(key >> 32) * ACC_COPIES].need_host, need);
+            depth = depth < 0xffffu ? depth : 0xffffu;
+        }
+    }
+    // depth bounds per group: [2 gi] over all its reads (every read has a piece in its first tile), [2 gi + 1] over the reads that leave
+    // pieces in the tile behind.  A wavefront's reads nearly always share one group: one atomic per wavefront and bound then.
+    const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)gi);
+    if (__all(gi == g0 || !valid)) {
+        uint32_t a = valid ? depth : 0u, b = (valid && spill) ? depth : 0u;
+        for (int o = 32; o > 0; o >>= 1) { const uint32_t x = __shfl_xor(a, o), y = __shfl_xor(b, o); a = x > a ? x : a; b = y > b ? y : b; }
+        if ((threadIdx.x & 63u) == 0 && g0 != 0xffffffffu) { atomicMax(&grp_md[2u * g0], a); if (b) atomicMax(&grp_md[2u * g0 + 1u], b); }
+    } else if (valid) { atomicMax(&grp_md[2u * gi], depth); if (spill) atomicMax(&grp_md[2u * gi + 1u], depth); }
 }
 struct DpRun { uint32_t sample; int32_t tid, first_any, first_from1; };
-__global__ void msnv_run_table(const uint32_t *pl, uint32_t n_runs, const uint32_t *run_first, const uint32_t *run_f1, const unsigned long long *r_key,
-                               const uint16_t *rec_sample, DpRun *runs) {
+__global__ void msnv_run_table(uint32_t n_runs, const uint32_t *run_first, const uint32_t *run_f1, const unsigned long long *p_key, const uint32_t *p_pos, DpRun *runs) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_runs) return;
-    const uint32_t i = pl[run_first[g]];
+    const uint32_t r = run_first[g];
     DpRun o;
-    o.sample = rec_sample[i]; o.tid = (int32_t)(r_key[i] >> 32); o.first_any = (int32_t)(uint32_t)r_key[i];
+    o.sample = (uint32_t)(p_key[r] >> 32); o.tid = (int32_t)(uint32_t)p_key[r]; o.first_any = (int32_t)p_pos[r];
     const uint32_t f = run_f1[g];
     if (f == 0xffffffffu) o.first_from1 = -1;
-    else { const int32_t p = (int32_t)(uint32_t)r_key[pl[f]]; o.first_from1 = p > 1 ? p : 1; }
+    else { const int32_t q = (int32_t)p_pos[f]; o.first_from1 = q > 1 ? q : 1; }
     runs[g] = o;
+}
+// The (run, first tile) groups, for the host: where a group's pieces lie in tile order -- [a, b) the pieces in its own tile, [b, end) the
+// ones its reads leave in the tile behind -- and the depth bounds of the two parts.
+struct DevGroupRec { uint32_t sample; int32_t tid; uint32_t tile, a, b, end, md_own, md_next; };
+__global__ void msnv_group_table(uint32_t n_groups, const uint32_t *grp_first, const RecCnt *pre, const uint16_t *rec_sample, const unsigned long long *r_key, const uint32_t *r_ftile,
+                                 const uint32_t *grp_md, DevGroupRec *out) {
+    const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= n_groups) return;
+    const uint32_t f = grp_first[gi], e = grp_first[gi + 1];      // records (entry n_groups: the round's record count)
+    const RecCnt pf = pre[f], pe = pre[e];
+    DevGroupRec o;
+    o.sample = rec_sample[f]; o.tid = (int32_t)(r_key[f] >> 32); o.tile = r_ftile[f];
+    o.a = pf.npiece; o.b = pe.npiece - (pe.spill - pf.spill); o.end = pe.npiece; o.md_own = grp_md[2u * gi]; o.md_next = grp_md[2u * gi + 1u];
+    out[gi] = o;
 }
 
 // ------------------------------------------------------------------------------------------ overlapping mates
@@ -596,10 +657,18 @@ __global__ void msnv_ovl_groups(const uint32_t *starts, uint32_t n_groups, uint3
 
 // ------------------------------------------------------------------------------------------ headers and intervals
 // where a piece's bases and qualities lie in the round buffer, and its reference: everything msnv_emit_pieces needs without going back to the record
-struct PieceSrc { unsigned long long seq, qual, ref_nib; uint32_t q0, ref_left; uint32_t sample, pad; };   // ref_nib: nibble index into pref4 of the piece's first position (~0: no FASTA); ref_left: FASTA characters from there
+struct PieceSrc { unsigned long long seq, qual, ref_nib; uint32_t q0, ref_left; uint32_t sample_len, seqoff; };   // ref_nib: nibble index into pref4 of the piece's first position (~0: no FASTA); ref_left: FASTA characters from there; sample_len: sample | bases << 16
+// Tile order without a sort.  The headers of a sample must end up grouped by (contig, tile), read order inside a tile (pack.cpp's stable
+// sort); in file order only the pieces a read leaves in the tile BEHIND its first one are out of place.  Reads sorted by start whose
+// pieces lie in their first tile and at most the next one (msnv_measure_reads checks it; else `in_order`: file order here, rocPRIM sort
+// afterwards) fall into groups of consecutive reads with the same first tile, and the sorted order is, group after group: the group's
+// pieces in its own tile, then the ones it leaves in the next tile (which thereby precede the next group's own pieces -- same tile -- in
+// read order).  With pre.npiece / pre.spill = pieces / next-tile pieces of all earlier reads and f, e = first read of this / the next group:
+//   a piece in the read's first tile goes to  pre[i].npiece - (pre[i].spill - pre[f].spill) + its index among the read's such pieces,
+//   a piece in the tile behind goes to        pre[e].npiece - pre[e].spill + pre[i].spill  + its index among those.
 __global__ __launch_bounds__(256) void msnv_emit_headers(const uint8_t *raw, const unsigned long long *rec_off, const uint16_t *rec_sample, uint32_t n_rec, const DpContig *ctg,
-                                                         const uint8_t *r_flags, const uint16_t *r_depth, const uint32_t *pbase, const unsigned long long *sbase,
-                                                         const uint32_t *ibase, const unsigned long long *samp_sbase0,
+                                                         const uint8_t *r_flags, const uint16_t *r_depth, const RecCnt *pre, const unsigned long long *samp_sbase0,
+                                                         const PScan *ps, const uint32_t *grp_first, uint32_t in_order,
                                                          ReadHdr *hdr, int32_t *ptid, int32_t *pend, uint16_t *pdepth, PieceSrc *psrc,
                                                          int32_t *cov_tid, int32_t *cov_beg, int32_t *cov_end, int32_t *overhang, uint32_t *any_overhang, uint32_t noseq_counts) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -610,10 +679,11 @@ __global__ __launch_bounds__(256) void msnv_emit_headers(const uint8_t *raw, con
     const Rec r = rec_load(p, ~0ull);
     const uint32_t s = rec_sample[i];
     const DpContig c = ctg[r.tid];
+    const RecCnt me = pre[i];
     if (f & RF_COV) {                                                                       // qaCompute.cpp:530-552
         const long long L = c.len;
         long long pp = (long long)r.pos + 1;
-        uint32_t k = 0, w = ibase[i];
+        uint32_t k = 0, w = me.niv;
         if (r.n_cigar > 0) { const uint32_t t = ld32(r.cigar) & 15u; if (t == C_S || t == C_H) k = 1; }
         for (; k < r.n_cigar; ++k) {
             const uint32_t cg = ld32(r.cigar + 4ull * k), t = cg & 15u, l = cg >> 4;
@@ -626,8 +696,17 @@ __global__ __launch_bounds__(256) void msnv_emit_headers(const uint8_t *raw, con
     }
     const bool noseq = r.l_seq == 0;
     if (!(f & RF_PILE) || (noseq && !noseq_counts)) return;
-    uint32_t w = pbase[i];
-    unsigned long long so = sbase[i] - samp_sbase0[s];
+    uint32_t w = me.npiece;                                                                   // file order: where the piece's source record goes (and, in_order, its header)
+    uint32_t d_own = w, d_next = w;                                                           // tile order: next header slot in the read's first tile / the tile behind
+    uint32_t ftile = 0; bool have_ftile = false;
+    if (!in_order) {
+        const uint32_t gi = ps[me.pile].grps - 1u;
+        const uint32_t fr = grp_first[gi], er = grp_first[gi + 1u];
+        const RecCnt pf = pre[fr], pe = pre[er];
+        d_own = me.npiece - (me.spill - pf.spill);
+        d_next = pe.npiece - pe.spill + me.spill;
+    }
+    unsigned long long so = me.seqb - samp_sbase0[s];
     long long rp = r.pos, q = 0;
     const uint16_t depth = r_depth[i];
     const unsigned long long seq_abs = (unsigned long long)(r.seq - raw), qual_abs = (unsigned long long)(r.qual - raw);
@@ -638,16 +717,19 @@ __global__ __launch_bounds__(256) void msnv_emit_headers(const uint8_t *raw, con
                 const uint32_t to_tile = TILE - (uint32_t)((rp + off) % TILE);
                 n = SEG_MAX < l - off ? SEG_MAX : l - off;
                 n = n < to_tile ? n : to_tile;
+                const uint32_t tl = (uint32_t)((rp + off) / TILE);
+                if (!have_ftile) { ftile = tl; have_ftile = true; }
+                const uint32_t dst = in_order ? w : (tl == ftile ? d_own++ : d_next++);
                 ReadHdr h;
                 h.gpos = (uint32_t)(rp + off); h.seqoff = (uint32_t)so; h.cig = n; h.meta = META_PILEUP_OK | r.mapq << 16;
-                hdr[w] = h; ptid[w] = r.tid; pend[w] = (int32_t)(rp + off + n); pdepth[w] = depth;
+                hdr[dst] = h; ptid[dst] = r.tid; pend[dst] = (int32_t)(rp + off + n); pdepth[dst] = depth;
                 if (rp + off + n > c.len) { atomicMax(&overhang[r.tid], (int32_t)(rp + off + n)); *any_overhang = 1u; }     // a read that runs past its contig: the contig's tiles reach that far (finalize)
-                PieceSrc ps;
-                ps.seq = seq_abs; ps.qual = qual_abs; ps.q0 = noseq ? 0xffffffffu : (uint32_t)(q + off); ps.sample = s; ps.pad = 0;      // q0 = ~0: no SEQ, the bases are N of quality 0
+                PieceSrc ps1;
+                ps1.seq = seq_abs; ps1.qual = qual_abs; ps1.q0 = noseq ? 0xffffffffu : (uint32_t)(q + off); ps1.sample_len = s | n << 16; ps1.seqoff = (uint32_t)so;      // q0 = ~0: no SEQ, the bases are N of quality 0
                 const long long g = rp + off, left = c.seq_len - g;
-                if (c.seq_len >= 0 && g >= 0 && left > 0) { ps.ref_nib = c.pref_off + (unsigned long long)g; ps.ref_left = (uint32_t)(left < 0xffffffffll ? left : 0xffffffffll); }
-                else { ps.ref_nib = c.seq_len >= 0 ? ~1ull : ~0ull; ps.ref_left = 0; }        // ~1: a FASTA record exists but holds nothing here (sampled, nothing to compare)
-                psrc[w] = ps;
+                if (c.seq_len >= 0 && g >= 0 && left > 0) { ps1.ref_nib = c.pref_off + (unsigned long long)g; ps1.ref_left = (uint32_t)(left < 0xffffffffll ? left : 0xffffffffll); }
+                else { ps1.ref_nib = c.seq_len >= 0 ? ~1ull : ~0ull; ps1.ref_left = 0; }        // ~1: a FASTA record exists but holds nothing here (sampled, nothing to compare)
+                psrc[w] = ps1;
                 ++w; so += stored_bytes(n);
             }
             rp += l; q += l;
@@ -710,18 +792,18 @@ __device__ __forceinline__ void put_piece_lane(uint8_t *seq_col, uint8_t *qual_c
         if ((total & 4u) && last_lane) or_byte(qp + full, (uint32_t)(w >> (8u * full)) & 0xfu);
     }
 }
-__global__ __launch_bounds__(256) void msnv_emit_pieces(const uint8_t *raw, const uint32_t *pref4, DpParams P, uint32_t n_pieces, const ReadHdr *hdr, const PieceSrc *psrc,
+__global__ __launch_bounds__(256) void msnv_emit_pieces(const uint8_t *raw, const uint32_t *pref4, DpParams P, uint32_t n_pieces, const PieceSrc *psrc,
                                                         const DpSampleDst *dst, DpAcc *acc) {
     const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t pc = gt >> 2, sub = gt & 3u, j0 = 32u * sub;
     const bool piece = pc < n_pieces;
-    ReadHdr h{}; PieceSrc ps{};
-    if (piece) { h = hdr[pc]; ps = psrc[pc]; }
-    const uint32_t n = h.cig, sb = piece ? stored_bytes(n) : 0u;
+    PieceSrc ps{};
+    if (piece) ps = psrc[pc];
+    const uint32_t n = ps.sample_len >> 16, sample = ps.sample_len & 0xffffu, sb = piece ? stored_bytes(n) : 0u;
     const uint32_t st = 2u * sb > j0 ? (2u * sb - j0 < 32u ? 2u * sb - j0 : 32u) : 0u;    // stored nibbles of this lane (a multiple of 4)
     const uint32_t have = n > j0 ? (n - j0 < 32u ? n - j0 : 32u) : 0u;                     // ... of which real bases
     DpSampleDst d{};
-    if (piece) d = dst[ps.sample];
+    if (piece) d = dst[sample];
     const bool pad_low = P.c_eff > 0 || P.all_low;                                          // padding: base N, quality byte 0 (pack.cpp: pack_sample, pack_lowq)
     uint64_t o0 = ~0ull, o1 = ~0ull;                                                        // the lane's 32 nibbles, low first
     uint32_t bits = pad_low ? 0xffffffffu : 0u, mm = 0;
@@ -782,11 +864,11 @@ __global__ __launch_bounds__(256) void msnv_emit_pieces(const uint8_t *raw, cons
         bits = have < 32u ? ((bits & (0xffffffffu << have)) | (low & ((1u << have) - 1u))) : low;
     }
     const uint32_t prev_last = __shfl_up(bits >> 28, 1);                                    // the last four flags of lane sub - 1 of the same piece (sub > 0, that lane is full)
-    if (st) put_piece_lane(d.seq, d.qual, h.seqoff, sub, sb, st, o0, o1, bits, prev_last);
+    if (st) put_piece_lane(d.seq, d.qual, ps.seqoff, sub, sb, st, o0, o1, bits, prev_last);
     // mismatch sample: sum over the 4 lanes of a piece, one atomic per sampled piece
     mm += __shfl_down(mm, 2, 4); mm += __shfl_down(mm, 1, 4);
     if (sub == 0 && sampled) {
-        DpAcc &a = acc[(size_t)ps.sample * ACC_COPIES + (blockIdx.x % ACC_COPIES)];
+        DpAcc &a = acc[(size_t)sample * ACC_COPIES + (blockIdx.x % ACC_COPIES)];
         atomicAdd(&a.mm_bases, (unsigned long long)n);
         if (mm) atomicAdd(&a.mm, (unsigned long long)mm);
     }
@@ -794,13 +876,14 @@ __global__ __launch_bounds__(256) void msnv_emit_pieces(const uint8_t *raw, cons
 
 // per sample: where its records' pieces / seq bytes / intervals start, and the first pileup read (one small copy instead of three per sample)
 struct DpSampleSum { unsigned long long sbase0, first_key, beyond_key; uint32_t pbase0, ibase0, first_end, pad; };
-__global__ void msnv_sample_bases(const uint32_t *rec_base, uint32_t n_samples, const uint32_t *pbase, const unsigned long long *sbase, const uint32_t *ibase,
-                                  const DpAcc *acc, const unsigned long long *r_key, const uint32_t *r_end, DpSampleSum *out) {
+__global__ void msnv_sample_bases(const uint32_t *rec_base, uint32_t n_samples, const RecCnt *pre,
+                                  const DpAcc *acc, const unsigned long long *r_key, const uint32_t *r_end, DpSampleSum *out, unsigned long long *sbase0) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s > n_samples) return;
     DpSampleSum o{};
     const uint32_t i = rec_base[s];
-    o.sbase0 = sbase[i]; o.pbase0 = pbase[i]; o.ibase0 = ibase[i];
+    o.sbase0 = pre[i].seqb; o.pbase0 = pre[i].npiece; o.ibase0 = pre[i].niv;
+    sbase0[s] = o.sbase0;
     if (s < n_samples) {
         const DpAcc a = acc[(size_t)s * ACC_COPIES];              // (folded: msnv_acc_fold)
         if (a.first_pile != ~0ull) { o.first_key = r_key[a.first_pile]; o.first_end = r_end[a.first_pile]; }
@@ -826,10 +909,10 @@ __global__ void msnv_tile_keys(const ReadHdr *hdr, const int32_t *ptid, const Pi
                                unsigned long long *keys, uint32_t *idx, uint32_t *unsorted) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const unsigned long long k = ((unsigned long long)psrc[i].sample << tid_bits | (uint32_t)ptid[i]) << 21 | (hdr[i].gpos / TILE);
+    const unsigned long long k = ((unsigned long long)(psrc[i].sample_len & 0xffffu) << tid_bits | (uint32_t)ptid[i]) << 21 | (hdr[i].gpos / TILE);
     keys[i] = k; idx[i] = i;
     if (i > 0) {
-        const unsigned long long kp = ((unsigned long long)psrc[i - 1].sample << tid_bits | (uint32_t)ptid[i - 1]) << 21 | (hdr[i - 1].gpos / TILE);
+        const unsigned long long kp = ((unsigned long long)(psrc[i - 1].sample_len & 0xffffu) << tid_bits | (uint32_t)ptid[i - 1]) << 21 | (hdr[i - 1].gpos / TILE);
         if (kp > k) *unsorted = 1u;
     }
 }
@@ -1396,14 +1479,13 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     DP_BUF(unsigned long long, d_key, NRa);
     DP_BUF(uint32_t, d_end, NRa);
     DP_BUF(uint32_t, d_maxc, NRa);
-    DP_BUF(uint32_t, d_pile, NRa);
-    DP_BUF(uint32_t, d_npiece, NRa);
-    DP_BUF(uint32_t, d_seqb, NRa);
-    DP_BUF(uint32_t, d_niv, NRa);
+    DP_BUF(uint32_t, d_ftile, NRa);
+    DP_BUF(RecCnt, d_cnt, NRa);
+    DP_BUF(RecCnt, d_pre, NRa);                                   // exclusive scan of d_cnt; entry NR = the round's totals
     DP_BUF(uint16_t, d_depth, NRa);
-    DP_BUF(uint32_t, d_rank, NRa);
     DP_BUF(uint32_t, d_ovr, NRa);
     DP_BUF(DpAcc, d_acc, S * ACC_COPIES);
+    DP_BUF(uint32_t, d_misc, MISC_WORDS);
     DP_BUF(uint8_t, d_tmp, 1u << 20);                             // rocPRIM's temporary storage (grown below when a call asks for more)
     size_t tmp_cap = (size_t)T.scratch[pool.next - 1].second;
     const size_t tmp_slot = pool.next - 1;
@@ -1426,13 +1508,6 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
         else HIP_TRY(rocprim::exclusive_scan(d_tmp, need, in, out, 0u, cnt, rocprim::plus<uint32_t>(), st));
         return MSNV_OK;
     };
-    auto scan64 = [&](const uint32_t *in, unsigned long long *out, size_t cnt) -> int {
-        size_t need = 0;
-        HIP_TRY(rocprim::exclusive_scan(nullptr, need, in, out, 0ull, cnt, rocprim::plus<unsigned long long>(), st));
-        if (int rc = tmp_for(need)) return rc;
-        HIP_TRY(rocprim::exclusive_scan(d_tmp, need, in, out, 0ull, cnt, rocprim::plus<unsigned long long>(), st));
-        return MSNV_OK;
-    };
     auto sort64 = [&](unsigned long long *kin, unsigned long long *kout, uint32_t *vin, uint32_t *vout, size_t cnt, unsigned end_bit) -> int {
         size_t need = 0;
         HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, kin, kout, vin, vout, cnt, 0u, end_bit, st));
@@ -1444,11 +1519,14 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     std::vector<uint8_t> cut_marks(S, 0);
     const DpContig *ctg = static_cast<const DpContig *>(T.contigs);
     std::vector<DpRun> runs;
-    uint32_t NP = 0, n_runs = 0;
+    std::vector<DevGroupRec> groups;
+    RecCnt tot{};                                                 // the round's totals (d_pre[NR])
+    uint32_t NP = 0, n_runs = 0, n_groups = 0, need_sort = 0;
     bool have_ovr = false;
     DevBuf o_flag, o_rank, o_skip, o_keys, o_skeys, o_vals, o_svals, o_starts;      // overlapping mates (paired reads only: not from the pool)
     uint32_t n_ovl_reads = 0, n_ovl_groups = 0;
     std::vector<uint8_t> host_sample(S, 0);                       // samples whose sequential edits ran on the host (pre-pass)
+    PScan *d_ps = nullptr; uint32_t *d_grpfirst = nullptr;
     const size_t depth_bufs_from = pool.next;
     for (int pass = 0; pass < 2; ++pass) {
         pool.next = depth_bufs_from;
@@ -1459,59 +1537,74 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
             HIP_TRY(hipStreamSynchronize(st));
         }
         HIP_TRY(hipMemsetAsync(d_depth, 0, NRa * 2, st));
-        HIP_TRY(hipMemsetAsync(d_pile + NR, 0, 4, st));
+        HIP_TRY(hipMemsetAsync(d_cnt + NR, 0, sizeof(RecCnt), st));
+        HIP_TRY(hipMemsetAsync(d_misc, 0, MISC_WORDS * 4, st));
         tm.start();
         if (NR) {
             hipLaunchKernelGGL(msnv_measure_reads, grid_for(NR, 256), dim3(256), 0, st, raw, d_recoff, d_recsample, d_recbase, d_send, NR, ctg, P, have_ovr ? d_ovr : nullptr, d_flags,
-                               d_key, d_end, d_maxc, d_pile, d_npiece, d_seqb, d_niv, d_acc);
+                               d_key, d_end, d_maxc, d_cnt, d_ftile, d_acc, d_misc);
             HIP_TRY(hipGetLastError());
         }
-        if (int rc = scan32(d_pile, d_rank, NRa, false)) return rc;                          // (entry NR = number of pileup reads)
-        HIP_TRY(hipMemcpyAsync(&NP, d_rank + NR, 4, hipMemcpyDeviceToHost, st));
+        {   // every record's rank among the pileup reads, first piece, first interval, next-tile pieces before it, first seq byte: one scan
+            size_t need = 0;
+            HIP_TRY(rocprim::exclusive_scan(nullptr, need, d_cnt, d_pre, RecCnt{}, (size_t)NRa, RecCntSum(), st));
+            if (int rc = tmp_for(need)) return rc;
+            HIP_TRY(rocprim::exclusive_scan(d_tmp, need, d_cnt, d_pre, RecCnt{}, (size_t)NRa, RecCntSum(), st));
+        }
+        HIP_TRY(hipMemcpyAsync(&tot, d_pre + NR, sizeof(RecCnt), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        NP = tot.pile;
         T.ms_measure += tm.stop();
-        // ---- depth at every read start
-        n_runs = 0;
+        // ---- depth at every read start; the runs and the (run, first tile) groups of reads
+        n_runs = 0; n_groups = 0;
         if (NP) {
-            const uint64_t NPa = (uint64_t)NP + 1, N2 = 2ull * NP + 1;
-            DP_BUF(uint32_t, d_pl, NPa);
-            DP_BUF(uint32_t, d_rf, NPa);
-            DP_BUF(uint32_t, d_runincl, NPa);
-            DP_BUF(uint32_t, d_maxcr, NPa);
-            DP_BUF(unsigned long long, d_Pm, NPa);
-            DP_BUF(unsigned long long, d_keys, N2);
-            DP_BUF(unsigned long long, d_skeys, N2);
-            DP_BUF(uint32_t, d_vals, N2);
-            DP_BUF(uint32_t, d_svals, N2);
-            DP_BUF(uint32_t, d_ev, N2);
-            DP_BUF(unsigned long long, d_E, N2);
+            const uint64_t NPa = (uint64_t)NP + 1;
+            DP_BUF(unsigned long long, d_pkey, NPa);
+            DP_BUF(uint32_t, d_ppos, NPa);
+            DP_BUF(uint32_t, d_pend, NPa);
+            DP_BUF(uint32_t, d_pmaxc, NPa);
+            DP_BUF(uint32_t, d_pftile, NPa);
+            DP_BUF(uint32_t, d_prec, NPa);
+            DP_BUF(PScan, d_ps_, NPa);
+            d_ps = d_ps_;
             tm.start();
-            hipLaunchKernelGGL(msnv_pile_list, grid_for(NR, 256), dim3(256), 0, st, d_pile, d_rank, NR, d_pl);
-            hipLaunchKernelGGL(msnv_run_flags, grid_for(NP, 256), dim3(256), 0, st, d_pl, NP, d_recsample, d_key, d_rf);
+            hipLaunchKernelGGL(msnv_pile_gather, grid_for(NR, 256), dim3(256), 0, st, d_cnt, d_pre, NR, d_recsample, d_key, d_end, d_maxc, d_ftile, d_pkey, d_ppos, d_pend, d_pmaxc, d_pftile, d_prec);
             HIP_TRY(hipGetLastError());
-            if (int rc = scan32(d_rf, d_runincl, NP, true)) return rc;
-            HIP_TRY(hipMemcpyAsync(&n_runs, d_runincl + (NP - 1), 4, hipMemcpyDeviceToHost, st));
+            {
+                auto in = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), PScanIn{d_pkey, d_pend, d_pftile});
+                size_t need = 0;
+                HIP_TRY(rocprim::inclusive_scan(nullptr, need, in, d_ps, (size_t)NP, PScanOp(), st));
+                if (int rc = tmp_for(need)) return rc;
+                HIP_TRY(rocprim::inclusive_scan(d_tmp, need, in, d_ps, (size_t)NP, PScanOp(), st));
+            }
+            PScan last{};
+            HIP_TRY(hipMemcpyAsync(&last, d_ps + (NP - 1), sizeof(PScan), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
+            n_runs = last.runs; n_groups = last.grps;
             DP_BUF(uint32_t, d_runfirst, (uint64_t)n_runs + 1);
             DP_BUF(uint32_t, d_runf1, (uint64_t)n_runs + 1);
             DP_BUF(DpRun, d_runs, (uint64_t)n_runs + 1);
-            hipLaunchKernelGGL(msnv_depth_keys, grid_for(NPa, 256), dim3(256), 0, st, d_pl, NP, d_rf, d_runincl, d_key, d_end, d_maxc, d_keys, d_vals, d_maxcr, d_runfirst, d_runf1);
+            DP_BUF(uint32_t, d_grpfirst_, (uint64_t)n_groups + 2);
+            DP_BUF(uint32_t, d_grpmd, 2 * ((uint64_t)n_groups + 1));
+            DP_BUF(DevGroupRec, d_groups, (uint64_t)n_groups + 1);
+            d_grpfirst = d_grpfirst_;
+            HIP_TRY(hipMemsetAsync(d_runf1, 0xff, ((uint64_t)n_runs + 1) * 4, st));
+            HIP_TRY(hipMemsetAsync(d_grpmd, 0, 2 * ((uint64_t)n_groups + 1) * 4, st));
+            HIP_TRY(hipMemcpyAsync(d_grpfirst + n_groups, &NR, 4, hipMemcpyHostToDevice, st));      // behind the last group: the round's record count (pre[NR] = totals)
+            hipLaunchKernelGGL(msnv_depth, grid_for(NP, 256), dim3(256), 0, st, d_ps, NP, d_pkey, d_ppos, d_pend, d_pmaxc, d_pftile, d_prec, d_cnt, have_ovr ? d_ovr : nullptr, P, d_depth,
+                               d_runfirst, d_runf1, d_grpfirst, d_grpmd, d_acc, d_misc);
+            hipLaunchKernelGGL(msnv_run_table, grid_for(n_runs, 256), dim3(256), 0, st, n_runs, d_runfirst, d_runf1, d_pkey, d_ppos, d_runs);
+            hipLaunchKernelGGL(msnv_group_table, grid_for(n_groups, 256), dim3(256), 0, st, n_groups, d_grpfirst, d_pre, d_recsample, d_key, d_ftile, d_grpmd, d_groups);
             HIP_TRY(hipGetLastError());
-            if (int rc = sort64(d_keys, d_skeys, d_vals, d_svals, 2ull * NP, 32u + std::max(1u, bit_width_u64(n_runs)))) return rc;
-            hipLaunchKernelGGL(msnv_depth_endchars, grid_for(N2, 256), dim3(256), 0, st, d_svals, NP, d_maxcr, d_ev);
-            HIP_TRY(hipGetLastError());
-            if (int rc = scan64(d_ev, d_E, N2)) return rc;
-            if (int rc = scan64(d_maxcr, d_Pm, NPa)) return rc;
-            hipLaunchKernelGGL(msnv_depth, grid_for(2ull * NP, 256), dim3(256), 0, st, d_pl, NP, d_svals, d_runincl, d_runfirst, d_E, d_Pm, d_key, d_end, d_recsample,
-                               have_ovr ? d_ovr : nullptr, P, d_depth, d_runf1, d_acc);
-            hipLaunchKernelGGL(msnv_run_table, grid_for(n_runs, 256), dim3(256), 0, st, d_pl, n_runs, d_runfirst, d_runf1, d_key, d_recsample, d_runs);
-            HIP_TRY(hipGetLastError());
-            runs.resize(n_runs);
+            runs.resize(n_runs); groups.resize(n_groups);
             HIP_TRY(hipMemcpyAsync(runs.data(), d_runs, (size_t)n_runs * sizeof(DpRun), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(groups.data(), d_groups, (size_t)n_groups * sizeof(DevGroupRec), hipMemcpyDeviceToHost, st));
             T.ms_depth += tm.stop();
-        } else runs.clear();
+        } else { runs.clear(); groups.clear(); }
         hipLaunchKernelGGL(msnv_acc_fold, grid_for(S, 64), dim3(64), 0, st, d_acc, (uint32_t)S);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpy2DAsync(acc.data(), sizeof(DpAcc), d_acc, sizeof(DpAcc) * ACC_COPIES, sizeof(DpAcc), S, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&need_sort, d_misc + MISC_SORT, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         // ---- errors, in record order (what the host stage's sequential walk would have met first)
         for (size_t s = 0; s < S; ++s) {
@@ -1618,25 +1711,17 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
         HIP_TRY(hipGetLastError());
         T.ms_depth += tm.stop();
     }
-    // ---- layout: where every record's pieces, seq bytes and intervals go
-    pool.next = depth_bufs_from;                                   // (the depth stage's lists are done with: their buffers serve the pieces)
-    DP_BUF(uint32_t, d_pbase, NRa);
-    DP_BUF(unsigned long long, d_sbase, NRa);
-    DP_BUF(uint32_t, d_ibase, NRa);
+    // ---- layout: where every sample's pieces, seq bytes and intervals start (the per-record places are d_pre)
+    const bool in_order = need_sort != 0 || [] { const char *e = getenv("MSNV_TILE_ORDER"); return e && e[0] == 's'; }();      // the general route: file order, then the sort (MSNV_TILE_ORDER=sort: tests)
     DP_BUF(DpSampleSum, d_sum, S + 1);
+    DP_BUF(unsigned long long, d_ss0, S + 1);
     tm.start();
-    HIP_TRY(hipMemsetAsync(d_npiece + NR, 0, 4, st));
-    HIP_TRY(hipMemsetAsync(d_seqb + NR, 0, 4, st));
-    HIP_TRY(hipMemsetAsync(d_niv + NR, 0, 4, st));
-    if (int rc = scan32(d_npiece, d_pbase, NRa, false)) return rc;
-    if (int rc = scan64(d_seqb, d_sbase, NRa)) return rc;
-    if (int rc = scan32(d_niv, d_ibase, NRa, false)) return rc;
-    hipLaunchKernelGGL(msnv_sample_bases, grid_for(S + 1, 64), dim3(64), 0, st, d_recbase, (uint32_t)S, d_pbase, d_sbase, d_ibase, d_acc, d_key, d_end, d_sum);
+    hipLaunchKernelGGL(msnv_sample_bases, grid_for(S + 1, 64), dim3(64), 0, st, d_recbase, (uint32_t)S, d_pre, d_acc, d_key, d_end, d_sum, d_ss0);
     HIP_TRY(hipGetLastError());
     std::vector<DpSampleSum> sum(S + 1);
     HIP_TRY(hipMemcpyAsync(sum.data(), d_sum, (S + 1) * sizeof(DpSampleSum), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    const uint32_t NPC = sum[S].pbase0, NIV = sum[S].ibase0;
+    const uint32_t NPC = tot.npiece, NIV = tot.niv;
     T.n_pieces += NPC;
     // the round's columns: per sample seq (its pieces + 32 tail bytes, start on 16 bytes) and one flag bit per nibble of it
     std::vector<unsigned long long> seq_off(S + 1, 0), piece_bytes(S), ss0(S + 1);
@@ -1656,78 +1741,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     std::vector<DpSampleDst> dsts(S);
     for (size_t s = 0; s < S; ++s) dsts[s] = DpSampleDst{r_seq + seq_off[s], r_qual + seq_off[s] / 4, sum[s].pbase0, cut_marks[s], 0u};
     const uint64_t NPCa = (uint64_t)NPC + 1, NIVa = (uint64_t)NIV + 1;
-    DP_BUF(DpSampleDst, d_dst, S);
-    DP_BUF(unsigned long long, d_ss0, S + 1);
-    DP_BUF(unsigned long long, d_pb, S);
-    DP_BUF(ReadHdr, d_hdr, NPCa);
-    DP_BUF(int32_t, d_ptid, NPCa);
-    DP_BUF(int32_t, d_pend, NPCa);
-    DP_BUF(uint16_t, d_pdepth, NPCa);
-    DP_BUF(PieceSrc, d_psrc, NPCa);
-    DP_BUF(int32_t, d_ctid, NIVa);
-    DP_BUF(int32_t, d_cbeg, NIVa);
-    DP_BUF(int32_t, d_cend, NIVa);
-    HIP_TRY(hipMemcpyAsync(d_dst, dsts.data(), S * sizeof(DpSampleDst), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_ss0, ss0.data(), (S + 1) * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_pb, piece_bytes.data(), S * 8, hipMemcpyHostToDevice, st));
-    if (NR) {
-        hipLaunchKernelGGL(msnv_emit_headers, grid_for(NR, 256), dim3(256), 0, st, raw, d_recoff, d_recsample, NR, ctg, d_flags, d_depth, d_pbase, d_sbase, d_ibase, d_ss0,
-                           d_hdr, d_ptid, d_pend, d_pdepth, d_psrc, d_ctid, d_cbeg, d_cend, T.overhang, T.any_overhang, (P.c_eff == 0 && !P.all_low) ? 1u : 0u);
-        HIP_TRY(hipGetLastError());
-    }
-    if (NPC) {
-        hipLaunchKernelGGL(msnv_emit_pieces, grid_for((uint64_t)NPC * 4, 256), dim3(256), 0, st, raw, T.pref4, P, NPC, d_hdr, d_psrc, d_dst, d_acc);
-        HIP_TRY(hipGetLastError());
-    }
-    hipLaunchKernelGGL(msnv_emit_tail, dim3((unsigned)S), dim3(64), 0, st, d_dst, d_pb, (uint32_t)S, P);
-    hipLaunchKernelGGL(msnv_acc_fold, grid_for(S, 64), dim3(64), 0, st, d_acc, (uint32_t)S);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy2DAsync(acc.data(), sizeof(DpAcc), d_acc, sizeof(DpAcc) * ACC_COPIES, sizeof(DpAcc), S, hipMemcpyDeviceToHost, st));
-    T.ms_emit += tm.stop();
-
-    // ---- headers in tile order (stable: read order inside a tile), and the (sample, contig, tile) runs of pieces = the pairs of the tile index
-    tm.start();
-    const ReadHdr *src_hdr = d_hdr; const int32_t *src_tid = d_ptid, *src_end = d_pend; const uint16_t *src_depth = d_pdepth;
-    std::vector<DevPairRec> prec;
-    if (NPC >= 1) {
-        DP_BUF(unsigned long long, d_tk, NPCa);
-        DP_BUF(uint32_t, d_ix, NPCa);
-        DP_BUF(uint32_t, d_uns, 4);
-        HIP_TRY(hipMemsetAsync(d_uns, 0, 4, st));
-        const unsigned tid_bits = std::max(1u, bit_width_u64(NC ? NC - 1 : 0));
-        hipLaunchKernelGGL(msnv_tile_keys, grid_for(NPC, 256), dim3(256), 0, st, d_hdr, d_ptid, d_psrc, NPC, tid_bits, d_tk, d_ix, d_uns);
-        HIP_TRY(hipGetLastError());
-        uint32_t uns = 0;
-        HIP_TRY(hipMemcpyAsync(&uns, d_uns, 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        const unsigned long long *skeys = d_tk;
-        DP_BUF(unsigned long long, d_tk2, NPCa);
-        DP_BUF(uint32_t, d_ix2, NPCa);
-        DP_BUF(ReadHdr, d_hdr2, NPCa);
-        DP_BUF(int32_t, d_ptid2, NPCa);
-        DP_BUF(int32_t, d_pend2, NPCa);
-        DP_BUF(uint16_t, d_pdepth2, NPCa);
-        if (uns) {
-            if (int rc = sort64(d_tk, d_tk2, d_ix, d_ix2, NPC, 21u + tid_bits + std::max(1u, bit_width_u64(S - 1)))) return rc;
-            hipLaunchKernelGGL(msnv_gather_pieces, grid_for(NPC, 256), dim3(256), 0, st, d_ix2, NPC, d_hdr, d_ptid, d_pend, d_pdepth, d_hdr2, d_ptid2, d_pend2, d_pdepth2);
-            HIP_TRY(hipGetLastError());
-            src_hdr = d_hdr2; src_tid = d_ptid2; src_end = d_pend2; src_depth = d_pdepth2; skeys = d_tk2;
-        }
-        // runs of equal keys (d_ix / d_ix2 are free again: flags and their scan)
-        uint32_t n_pairs = 0;
-        hipLaunchKernelGGL(msnv_pair_flags, grid_for(NPC, 256), dim3(256), 0, st, skeys, NPC, d_ix);
-        HIP_TRY(hipGetLastError());
-        if (int rc = scan32(d_ix, d_ix2, NPC, true)) return rc;
-        HIP_TRY(hipMemcpyAsync(&n_pairs, d_ix2 + (NPC - 1), 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        DP_BUF(DevPairRec, d_prec, (uint64_t)n_pairs + 1);
-        hipLaunchKernelGGL(msnv_pair_starts, grid_for(NPC, 256), dim3(256), 0, st, skeys, d_ix, d_ix2, NPC, tid_bits, d_prec);
-        hipLaunchKernelGGL(msnv_pair_maxd, grid_for(n_pairs, 64), dim3(64), 0, st, d_prec, n_pairs, NPC, src_depth);
-        HIP_TRY(hipGetLastError());
-        prec.resize(n_pairs);
-        HIP_TRY(hipMemcpyAsync(prec.data(), d_prec, (size_t)n_pairs * sizeof(DevPairRec), hipMemcpyDeviceToHost, st));
-    }
-    // ---- what stays in HBM of the round besides the columns: headers (tile order) and intervals, for finalize
+    // what stays in HBM of the round besides the columns: headers (tile order) and intervals, for finalize -- written where they stay
     DevRound keep;
     {
         const uint64_t b_hdr = (uint64_t)NPC * sizeof(ReadHdr), b_4 = (((uint64_t)NPC * 4) + 15) & ~15ull, b_2 = (((uint64_t)NPC * 2) + 15) & ~15ull, b_iv = (((uint64_t)NIV * 4) + 15) & ~15ull;
@@ -1743,16 +1757,87 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
         keep.n_pieces = NPC; keep.n_iv = NIV; keep.first_sample = first;
         keep.col_buf = round_buf; keep.col_seq = r_seq; keep.col_qual = r_qual; keep.seq_total = seq_total; keep.n_samples = S;
         T.rounds.push_back(keep);
-        if (NPC) {
-            HIP_TRY(hipMemcpyAsync(keep.hdr, src_hdr, (size_t)NPC * sizeof(ReadHdr), hipMemcpyDeviceToDevice, st));
-            HIP_TRY(hipMemcpyAsync(keep.tid, src_tid, (size_t)NPC * 4, hipMemcpyDeviceToDevice, st));
-            HIP_TRY(hipMemcpyAsync(keep.end, src_end, (size_t)NPC * 4, hipMemcpyDeviceToDevice, st));
-            HIP_TRY(hipMemcpyAsync(keep.depth, src_depth, (size_t)NPC * 2, hipMemcpyDeviceToDevice, st));
+    }
+    DP_BUF(DpSampleDst, d_dst, S);
+    DP_BUF(unsigned long long, d_pb, S);
+    DP_BUF(PieceSrc, d_psrc, NPCa);
+    // (the general route keeps the headers in file order first: work buffers, sorted into `keep` below)
+    ReadHdr *w_hdr = keep.hdr; int32_t *w_tid = keep.tid, *w_end = keep.end; uint16_t *w_depth = keep.depth;
+    if (in_order) {
+        DP_BUF(ReadHdr, d_hdr, NPCa);
+        DP_BUF(int32_t, d_ptid, NPCa);
+        DP_BUF(int32_t, d_pend, NPCa);
+        DP_BUF(uint16_t, d_pdepth, NPCa);
+        w_hdr = d_hdr; w_tid = d_ptid; w_end = d_pend; w_depth = d_pdepth;
+    }
+    HIP_TRY(hipMemcpyAsync(d_dst, dsts.data(), S * sizeof(DpSampleDst), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_pb, piece_bytes.data(), S * 8, hipMemcpyHostToDevice, st));
+    if (NR) {
+        hipLaunchKernelGGL(msnv_emit_headers, grid_for(NR, 256), dim3(256), 0, st, raw, d_recoff, d_recsample, NR, ctg, d_flags, d_depth, d_pre, d_ss0, d_ps, d_grpfirst, in_order ? 1u : 0u,
+                           w_hdr, w_tid, w_end, w_depth, d_psrc, keep.cov_tid, keep.cov_beg, keep.cov_end, T.overhang, T.any_overhang, (P.c_eff == 0 && !P.all_low) ? 1u : 0u);
+        HIP_TRY(hipGetLastError());
+    }
+    if (NPC) {
+        hipLaunchKernelGGL(msnv_emit_pieces, grid_for((uint64_t)NPC * 4, 256), dim3(256), 0, st, raw, T.pref4, P, NPC, d_psrc, d_dst, d_acc);
+        HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(msnv_emit_tail, dim3((unsigned)S), dim3(64), 0, st, d_dst, d_pb, (uint32_t)S, P);
+    hipLaunchKernelGGL(msnv_acc_fold, grid_for(S, 64), dim3(64), 0, st, d_acc, (uint32_t)S);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy2DAsync(acc.data(), sizeof(DpAcc), d_acc, sizeof(DpAcc) * ACC_COPIES, sizeof(DpAcc), S, hipMemcpyDeviceToHost, st));
+    T.ms_emit += tm.stop();
+
+    // ---- the (sample, contig, tile) runs of pieces = the pairs of the tile index
+    tm.start();
+    std::vector<DevPairRec> prec;
+    if (NPC >= 1 && in_order) {
+        // the general route: stable sort of the headers by (sample, contig, tile), runs of equal keys
+        DP_BUF(unsigned long long, d_tk, NPCa);
+        DP_BUF(uint32_t, d_ix, NPCa);
+        DP_BUF(uint32_t, d_uns, 4);
+        HIP_TRY(hipMemsetAsync(d_uns, 0, 4, st));
+        const unsigned tid_bits = std::max(1u, bit_width_u64(NC ? NC - 1 : 0));
+        hipLaunchKernelGGL(msnv_tile_keys, grid_for(NPC, 256), dim3(256), 0, st, w_hdr, w_tid, d_psrc, NPC, tid_bits, d_tk, d_ix, d_uns);
+        HIP_TRY(hipGetLastError());
+        uint32_t uns = 0;
+        HIP_TRY(hipMemcpyAsync(&uns, d_uns, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        const unsigned long long *skeys = d_tk;
+        DP_BUF(unsigned long long, d_tk2, NPCa);
+        DP_BUF(uint32_t, d_ix2, NPCa);
+        if (uns) {
+            if (int rc = sort64(d_tk, d_tk2, d_ix, d_ix2, NPC, 21u + tid_bits + std::max(1u, bit_width_u64(S - 1)))) return rc;
+            hipLaunchKernelGGL(msnv_gather_pieces, grid_for(NPC, 256), dim3(256), 0, st, d_ix2, NPC, w_hdr, w_tid, w_end, w_depth, keep.hdr, keep.tid, keep.end, keep.depth);
+            HIP_TRY(hipGetLastError());
+            skeys = d_tk2;
+        } else {
+            HIP_TRY(hipMemcpyAsync(keep.hdr, w_hdr, (size_t)NPC * sizeof(ReadHdr), hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(keep.tid, w_tid, (size_t)NPC * 4, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(keep.end, w_end, (size_t)NPC * 4, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(keep.depth, w_depth, (size_t)NPC * 2, hipMemcpyDeviceToDevice, st));
         }
-        if (NIV) {
-            HIP_TRY(hipMemcpyAsync(keep.cov_tid, d_ctid, (size_t)NIV * 4, hipMemcpyDeviceToDevice, st));
-            HIP_TRY(hipMemcpyAsync(keep.cov_beg, d_cbeg, (size_t)NIV * 4, hipMemcpyDeviceToDevice, st));
-            HIP_TRY(hipMemcpyAsync(keep.cov_end, d_cend, (size_t)NIV * 4, hipMemcpyDeviceToDevice, st));
+        // runs of equal keys (d_ix / d_ix2 are free again: flags and their scan)
+        uint32_t n_pairs = 0;
+        hipLaunchKernelGGL(msnv_pair_flags, grid_for(NPC, 256), dim3(256), 0, st, skeys, NPC, d_ix);
+        HIP_TRY(hipGetLastError());
+        if (int rc = scan32(d_ix, d_ix2, NPC, true)) return rc;
+        HIP_TRY(hipMemcpyAsync(&n_pairs, d_ix2 + (NPC - 1), 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        DP_BUF(DevPairRec, d_prec, (uint64_t)n_pairs + 1);
+        hipLaunchKernelGGL(msnv_pair_starts, grid_for(NPC, 256), dim3(256), 0, st, skeys, d_ix, d_ix2, NPC, tid_bits, d_prec);
+        hipLaunchKernelGGL(msnv_pair_maxd, grid_for(n_pairs, 64), dim3(64), 0, st, d_prec, n_pairs, NPC, keep.depth);
+        HIP_TRY(hipGetLastError());
+        prec.resize(n_pairs);
+        HIP_TRY(hipMemcpyAsync(prec.data(), d_prec, (size_t)n_pairs * sizeof(DevPairRec), hipMemcpyDeviceToHost, st));
+    } else if (NPC >= 1) {
+        // tile order by counting: a group's pieces in its own tile join the ones the group before leaves there (same contig, the tile before)
+        prec.reserve(groups.size() + groups.size() / 8);
+        for (size_t g = 0; g < groups.size(); ++g) {
+            const DevGroupRec &G = groups[g];
+            const bool prev_adj = g > 0 && groups[g - 1].sample == G.sample && groups[g - 1].tid == G.tid && groups[g - 1].tile + 1u == G.tile;
+            const bool next_adj = g + 1 < groups.size() && groups[g + 1].sample == G.sample && groups[g + 1].tid == G.tid && groups[g + 1].tile == G.tile + 1u;
+            prec.push_back(DevPairRec{G.sample, G.tid, G.tile, prev_adj ? groups[g - 1].b : G.a, std::max(G.md_own, prev_adj ? groups[g - 1].md_next : 0u)});
+            if (!next_adj && G.end > G.b) prec.push_back(DevPairRec{G.sample, G.tid, G.tile + 1u, G.b, G.md_next});
         }
     }
     T.ms_sort += tm.stop();
