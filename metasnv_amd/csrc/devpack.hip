@@ -131,19 +131,22 @@ __device__ __forceinline__ bool cg_match(uint32_t t) { return t == C_M || t == C
 // seq bytes of a piece of n bases with its alignment padding (pack.cpp: pack_sample)
 __device__ __host__ __forceinline__ uint32_t stored_bytes(uint32_t n) { return ((n + 1u) / 2u + SEQ_ALIGN - 1u) & ~(SEQ_ALIGN - 1u); }
 
-__global__ void msnv_acc_fold(DpAcc *acc, uint32_t n_samples) {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(64) void msnv_acc_fold(DpAcc *acc, uint32_t n_samples) {       // one wavefront per sample, one lane per copy (ACC_COPIES = 64)
+    const uint32_t s = blockIdx.x, c = threadIdx.x;
     if (s >= n_samples) return;
-    DpAcc &a = acc[(size_t)s * ACC_COPIES];
-    for (uint32_t c = 1; c < ACC_COPIES; ++c) {
-        DpAcc &b = acc[(size_t)s * ACC_COPIES + c];
-        a.err = a.err < b.err ? a.err : b.err; a.first_pile = a.first_pile < b.first_pile ? a.first_pile : b.first_pile; a.beyond = a.beyond < b.beyond ? a.beyond : b.beyond;
-        a.n_bases += b.n_bases; a.alg8d += b.alg8d; a.alg_cigar += b.alg_cigar; a.alg_seq += b.alg_seq; a.alg_qual += b.alg_qual; a.mm_bases += b.mm_bases; a.mm += b.mm;
-        a.total += b.total; a.unmapped += b.unmapped; a.zeroq += b.zeroq; a.proper += b.proper; a.dup += b.dup; a.any_mapped |= b.any_mapped;
-        a.n_pile_reads += b.n_pile_reads; a.n_ovl += b.n_ovl; a.need_host |= b.need_host;
-        DpAcc z{}; z.err = z.first_pile = z.beyond = ~0ull;
-        b = z;                                                   // (a copy that has been folded in counts nothing twice)
-    }
+    DpAcc &b = acc[(size_t)s * ACC_COPIES + c];
+    DpAcc v = b;
+    auto mn = [](unsigned long long x) { for (int o = 32; o > 0; o >>= 1) { const unsigned long long y = __shfl_xor(x, o); x = y < x ? y : x; } return x; };
+    auto su = [](unsigned long long x) { for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o); return x; };
+    auto s32 = [](uint32_t x) { for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o); return x; };
+    auto o32 = [](uint32_t x) { for (int o = 32; o > 0; o >>= 1) x |= __shfl_xor(x, o); return x; };
+    DpAcc t;
+    t.err = mn(v.err); t.first_pile = mn(v.first_pile); t.beyond = mn(v.beyond);
+    t.n_bases = su(v.n_bases); t.alg8d = su(v.alg8d); t.alg_cigar = su(v.alg_cigar); t.alg_seq = su(v.alg_seq); t.alg_qual = su(v.alg_qual); t.mm_bases = su(v.mm_bases); t.mm = su(v.mm);
+    t.total = s32(v.total); t.unmapped = s32(v.unmapped); t.zeroq = s32(v.zeroq); t.proper = s32(v.proper); t.dup = s32(v.dup); t.any_mapped = o32(v.any_mapped);
+    t.n_pile_reads = s32(v.n_pile_reads); t.n_ovl = s32(v.n_ovl); t.need_host = o32(v.need_host); t.pad = 0;
+    DpAcc z{}; z.err = z.first_pile = z.beyond = ~0ull;
+    b = c == 0 ? t : z;                                          // (a copy that has been folded in counts nothing twice)
 }
 
 template <typename T>
@@ -275,12 +278,34 @@ __global__ void msnv_compact_offsets(const unsigned long long *tmp_off, const Co
 // own (tile order, below) and its first byte of the seq column.
 struct RecCnt { uint32_t pile, npiece, niv, spill; unsigned long long seqb; };
 struct RecCntSum { __device__ __host__ RecCnt operator()(const RecCnt &a, const RecCnt &b) const { return RecCnt{a.pile + b.pile, a.npiece + b.npiece, a.niv + b.niv, a.spill + b.spill, a.seqb + b.seqb}; } };
-enum : uint32_t { MISC_SORT = 0, MISC_WORDS = 4 };                  // words of the round's flag block: [MISC_SORT] the pieces need the general tile-order sort
+enum : uint32_t { MISC_SORT = 0, MISC_SPAN = 1, MISC_NOUT = 2, MISC_WORDS = 4 };   // words of the round's flag block: [MISC_SORT] the pieces need the general tile-order sort;
+                                                                   // [MISC_SPAN] longest reference span of an ordinary pileup read; [MISC_NOUT] reads listed as outliers (msnv_depth)
+// The records of a round in blocks of PB = one wavefront: the kernels that go over the records hold a block per wavefront, a block's sums
+// (blk_cnt) are written by the measure kernel, ONE small scan over the blocks gives every block its base (blk_pre), and a record's own
+// place is that base plus the sums of the records before it in its block -- recomputed by whoever needs it, from the 24 bytes per record
+// the measure kernel left (a rocPRIM scan of those structs over all 15 M records of the benchmark shape cost 1 ms of the pack).
+constexpr uint32_t PB = 64;
+constexpr uint32_t SPAN_OUT = 16384;                                // a pileup read that spans more reference than this is listed by itself (msnv_depth's window stays short); raised when a round holds many such reads
+constexpr uint32_t CAP_OUT = 4096;                                  // ... at most this many per round
+__device__ __forceinline__ RecCnt wave_sum_cnt(RecCnt v) {
+    for (int o = 32; o > 0; o >>= 1) { v.pile += __shfl_xor(v.pile, o); v.npiece += __shfl_xor(v.npiece, o); v.niv += __shfl_xor(v.niv, o); v.spill += __shfl_xor(v.spill, o); v.seqb += __shfl_xor(v.seqb, o); }
+    return v;
+}
+__device__ __forceinline__ RecCnt wave_excl_cnt(const RecCnt c) {           // sums of the lanes before this one
+    RecCnt v = c;
+    const int lane = (int)(threadIdx.x & 63u);
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t a = __shfl_up(v.pile, o), b = __shfl_up(v.npiece, o), d = __shfl_up(v.niv, o), e = __shfl_up(v.spill, o); const unsigned long long f = __shfl_up(v.seqb, o);
+        if (lane >= o) { v.pile += a; v.npiece += b; v.niv += d; v.spill += e; v.seqb += f; }
+    }
+    return RecCnt{v.pile - c.pile, v.npiece - c.npiece, v.niv - c.niv, v.spill - c.spill, v.seqb - c.seqb};
+}
+__device__ __forceinline__ RecCnt cnt_add(const RecCnt &a, const RecCnt &b) { return RecCnt{a.pile + b.pile, a.npiece + b.npiece, a.niv + b.niv, a.spill + b.spill, a.seqb + b.seqb}; }
 // Everything of pack.cpp: filter_and_edit + pack_sample that one record decides by itself.
 __global__ __launch_bounds__(256) void msnv_measure_reads(const uint8_t *raw, const unsigned long long *rec_off, const uint16_t *rec_sample, const uint32_t *rec_base,
                                                           const unsigned long long *s_end, uint32_t n_rec, const DpContig *ctg, DpParams P, const uint32_t *ovr,
                                                           uint8_t *r_flags, unsigned long long *r_key, uint32_t *r_end, uint32_t *r_maxc, RecCnt *r_cnt, uint32_t *r_ftile,
-                                                          DpAcc *acc, uint32_t *misc) {
+                                                          RecCnt *blk_cnt, DpAcc *acc, uint32_t *misc, uint32_t *outliers, uint32_t span_out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = i < n_rec;
     const uint32_t s = valid ? rec_sample[i] : 0xffffffffu;
@@ -386,7 +411,17 @@ __global__ __launch_bounds__(256) void msnv_measure_reads(const uint8_t *raw, co
             }
         }
         r_flags[i] = flags; r_key[i] = key; r_end[i] = o_end; r_maxc[i] = o_maxc; r_ftile[i] = o_ftile;
-        r_cnt[i] = RecCnt{(flags & RF_PILE) ? 1u : 0u, o_np, o_niv, o_spill, (unsigned long long)o_sb};
+    }
+    {
+        const RecCnt mine = valid ? RecCnt{(flags & RF_PILE) ? 1u : 0u, o_np, o_niv, o_spill, (unsigned long long)o_sb} : RecCnt{};
+        if (valid) r_cnt[i] = mine;
+        const RecCnt tot = wave_sum_cnt(mine);
+        if ((threadIdx.x & 63u) == 0) blk_cnt[i / PB] = tot;                  // (i is a multiple of PB in lane 0: 256 threads = 4 blocks)
+        // reference span of the pileup reads: the depth kernel's window reaches that far back; a read far beyond the others' is listed by itself
+        uint32_t span = (flags & RF_PILE) ? o_end - ((uint32_t)key & 0x7fffffffu) : 0u;
+        if (span > span_out) { const uint32_t k = atomicAdd(&misc[MISC_NOUT], 1u); if (k < CAP_OUT) outliers[k] = i; span = 0; }
+        for (int o = 32; o > 0; o >>= 1) { const uint32_t x = __shfl_xor(span, o); span = x > span ? x : span; }
+        if ((threadIdx.x & 63u) == 0 && span > *(volatile uint32_t *)&misc[MISC_SPAN]) atomicMax(&misc[MISC_SPAN], span);      // (a plain look first: every wavefront's atomic on one word was 2 ms)
     }
     if (__any(need_sort) && (threadIdx.x & 63u) == 0) atomicOr(&misc[MISC_SORT], 1u);
     // ---- per-sample sums: a wavefront's records almost always belong to one sample -> one atomic per counter and wavefront
@@ -442,70 +477,82 @@ __global__ __launch_bounds__(256) void msnv_measure_reads(const uint8_t *raw, co
 // the ones that ended at or before its start are popped, then it is pushed -- depth = reads alive, itself included; the sum of their
 // longest possible pileup elements bounds the sample's base string there (snpCall's token limit).  Here, without a sort (round 5; rounds
 // 1-4 merged the starts and the ends of a round with a radix sort of 2 N keys): the pileup reads of the round are listed in file order
-// (msnv_pile_gather), an inclusive scan carries along the run -- (sample, contig) -- the LARGEST end seen so far, which never decreases
-// inside a run: every read before the first one whose running maximum lies beyond this read's start has ended, so the reads alive at the
-// start of read r are r itself and those of the WINDOW [w, r) that end beyond it -- found by a galloping search from r backwards and one
-// pass over the window (about `depth` reads, the neighbours' cache lines).  The same scan numbers the runs and the (run, first tile)
-// groups of reads that the tile order of the pieces is built from.
-struct PScan { unsigned long long key; uint32_t endmax, runs, grps, pad; };     // key: sample << 32 | contig
-struct PScanOp {
-    __device__ __host__ PScan operator()(const PScan &a, const PScan &b) const {
-        return PScan{b.key, (a.key == b.key && a.endmax > b.endmax) ? a.endmax : b.endmax, a.runs + b.runs, a.grps + b.grps, 0u};
+// (msnv_pile_gather).  A read that is alive at the start p of read r began after p - W, W = the longest reference span of a read of the
+// round: the reads alive at r are r itself and those of the WINDOW of reads of its run -- (sample, contig) -- that start in (p - W, p],
+// before r, and end beyond p: a search back along the sorted starts and one pass over about `depth` neighbours' cache lines.  Reads that
+// span more than SPAN_OUT positions (a reference skip; none in a metaSNV run) do not widen the window: they are few, listed by
+// themselves (msnv_measure_reads) and looked at by every read.  The same pass numbers the runs and the (run, first tile) groups of reads
+// that the tile order of the pieces is built from (inclusive scan of two flags, packed into one 64-bit sum).
+struct RunGrpIn {                                                  // element r of that scan's input: run start << 32 | group start
+    const uint4 *rd; const uint32_t *ftile;                        // rd: {start, end, contig, sample | longest pileup element << 12} of pileup read r
+    __device__ unsigned long long operator()(uint32_t r) const {
+        bool run = r == 0;
+        if (!run) { const uint4 a = rd[r - 1], b = rd[r]; run = a.z != b.z || ((a.w ^ b.w) & 0xfffu) != 0u; }
+        return (unsigned long long)(run ? 1u : 0u) << 32 | ((run || ftile[r - 1] != ftile[r]) ? 1u : 0u);
     }
 };
-struct PScanIn {                                                   // element r of the scan's input, made from the gathered columns
-    const unsigned long long *key; const uint32_t *end, *ftile;
-    __device__ PScan operator()(uint32_t r) const {
-        const unsigned long long k = key[r];
-        const bool run = r == 0 || key[r - 1] != k;
-        return PScan{k, end[r], run ? 1u : 0u, (run || ftile[r - 1] != ftile[r]) ? 1u : 0u, 0u};
-    }
-};
-__global__ void msnv_pile_gather(const RecCnt *r_cnt, const RecCnt *pre, uint32_t n_rec, const uint16_t *rec_sample, const unsigned long long *r_key, const uint32_t *r_end, const uint32_t *r_maxc,
-                                 const uint32_t *r_ftile, unsigned long long *p_key, uint32_t *p_pos, uint32_t *p_end, uint32_t *p_maxc, uint32_t *p_ftile, uint32_t *p_rec) {
+__global__ __launch_bounds__(256) void msnv_pile_gather(const RecCnt *r_cnt, const RecCnt *blk_pre, uint32_t n_rec, const uint16_t *rec_sample, const unsigned long long *r_key, const uint32_t *r_end,
+                                                        const uint32_t *r_maxc, const uint32_t *r_ftile, uint32_t span_out, uint4 *p_rd, uint32_t *p_ftile, uint32_t *p_rec) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_rec || !r_cnt[i].pile) return;
-    const uint32_t r = pre[i].pile;
+    const bool pile = i < n_rec && r_cnt[i].pile;
+    const unsigned long long m = __ballot(pile);
+    if (!pile) return;
+    const uint32_t r = blk_pre[i / PB].pile + (uint32_t)__builtin_popcountll(m & ((1ull << (threadIdx.x & 63u)) - 1ull));
     const unsigned long long k = r_key[i];
-    p_key[r] = (unsigned long long)rec_sample[i] << 32 | (k >> 32); p_pos[r] = (uint32_t)k & 0x7fffffffu;
-    p_end[r] = r_end[i] < 0x7fffffffu ? r_end[i] : 0x7fffffffu; p_maxc[r] = r_maxc[i]; p_ftile[r] = r_ftile[i]; p_rec[r] = i;
+    const uint32_t pos = (uint32_t)k & 0x7fffffffu, e = r_end[i] < 0x7fffffffu ? r_end[i] : 0x7fffffffu;
+    // (an outlier never counts in the window: it is counted from its list; the element length saturates at 2^20 - 1, far beyond any token
+    // limit: a sum that holds a saturated term sends the sample to the host pre-pass, which counts exactly)
+    const uint32_t mc = r_maxc[i] < 0xfffffu ? r_maxc[i] : 0xfffffu;
+    p_rd[r] = make_uint4(pos, e - pos > span_out ? 0u : e, (uint32_t)(k >> 32), (uint32_t)rec_sample[i] | mc << 12);
+    p_ftile[r] = r_ftile[i]; p_rec[r] = i;
 }
-// per group of reads (run, first tile): depth bounds of the pieces it leaves in its own tile / in the tile behind
-__global__ __launch_bounds__(256) void msnv_depth(const PScan *ps, uint32_t n_pile, const unsigned long long *p_key, const uint32_t *p_pos, const uint32_t *p_end, const uint32_t *p_maxc,
-                                                  const uint32_t *p_ftile, const uint32_t *p_rec, const RecCnt *r_cnt, const uint32_t *ovr, DpParams P, uint16_t *r_depth,
-                                                  uint32_t *run_first, uint32_t *run_f1, uint32_t *grp_first, uint32_t *grp_md, DpAcc *acc, uint32_t *misc) {
+__global__ __launch_bounds__(256) void msnv_depth(const unsigned long long *rg, uint32_t n_pile, const uint4 *p_rd,
+                                                  const uint32_t *p_ftile, const uint32_t *p_rec, const RecCnt *r_cnt, const uint32_t *ovr, DpParams P, uint32_t window, const uint32_t *outliers,
+                                                  uint32_t n_out, const uint16_t *rec_sample, const unsigned long long *r_key, const uint32_t *r_end, const uint32_t *r_maxc,
+                                                  uint16_t *r_depth, uint32_t *run_first, uint32_t *run_f1, uint32_t *grp_first, uint32_t *grp_md, DpAcc *acc, uint32_t *misc) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = r < n_pile;
     uint32_t gi = 0xffffffffu, depth = 0, spill = 0;
     if (valid) {
-        const unsigned long long key = p_key[r];
-        const uint32_t p = p_pos[r], i = p_rec[r];
-        const PScan me = ps[r];
-        const uint32_t g = me.runs - 1u;
-        gi = me.grps - 1u;
-        const bool run_start = r == 0 || p_key[r - 1] != key;
-        if (run_start) { run_first[g] = r; }
-        if (run_start || p_ftile[r - 1] != p_ftile[r]) grp_first[gi] = i;
-        if (!run_start && p_ftile[r - 1] > p_ftile[r]) atomicOr(&misc[MISC_SORT], 1u);      // (a read whose first aligned base lies in an earlier tile than its predecessor's: leading deletions)
-        // ---- the window: first read of the run before r whose running maximum of ends lies beyond p
-        uint32_t w = r;
-        if (!run_start) {
-            auto beyond = [&](uint32_t j) { const PScan x = ps[j]; return x.key == key && x.endmax > p; };
-            if (beyond(r - 1)) {
-                uint32_t hi = r - 1, step = 1;                     // beyond(hi) holds
-                uint32_t lo = 0; bool found_lo = false;            // a j below hi where it does not
-                while (hi >= step) { const uint32_t j = hi - step; if (beyond(j)) { hi = j; step <<= 1; } else { lo = j; found_lo = true; break; } }
-                if (!found_lo) { if (hi > 0 && beyond(0)) hi = 0; else if (hi > 0) { lo = 0; found_lo = true; } }
-                if (found_lo) while (hi - lo > 1) { const uint32_t m = lo + (hi - lo) / 2; if (beyond(m)) hi = m; else lo = m; }
-                w = hi;
-            }
-        }
-        unsigned long long chars = p_maxc[r];
+        const uint4 me4 = p_rd[r];
+        const uint32_t p = me4.x, i = p_rec[r];
+        const unsigned long long me = rg[r];
+        const uint32_t g = (uint32_t)(me >> 32) - 1u;
+        gi = (uint32_t)me - 1u;
+        uint4 prev = make_uint4(0, 0, 0xffffffffu, 0xffffffffu);
+        if (r > 0) prev = p_rd[r - 1];
+        const uint32_t my_sample = me4.w & 0xfffu;
+        const bool run_start = r == 0 || prev.z != me4.z || (prev.w & 0xfffu) != my_sample;
+        const uint32_t ft = p_ftile[r], ftp = run_start ? 0u : p_ftile[r - 1];
+        if (run_start) run_first[g] = r;
+        if (run_start || ftp != ft) grp_first[gi] = i;
+        if (!run_start && ftp > ft) atomicOr(&misc[MISC_SORT], 1u);                         // (a read whose first aligned base lies in an earlier tile than its predecessor's: leading deletions)
+        // ---- the window: back along the reads of the run while they start beyond p - window; four reads a step (the neighbours' cache lines)
+        unsigned long long chars = me4.w >> 12;
         depth = 1;
-        for (uint32_t j = w; j < r; ++j) if (p_end[j] > p) { ++depth; chars += p_maxc[j]; }
+        const unsigned long long pw = p;                                                    // a read is inside while start + window > p
+        for (uint32_t j = r; j > 0;) {
+            const uint32_t n4 = j < 4u ? j : 4u;
+            uint4 x[4];
+#pragma unroll
+            for (uint32_t t = 0; t < 4u; ++t) x[t] = t < n4 ? p_rd[j - 1u - t] : make_uint4(0, 0, 0xffffffffu, 0xffffffffu);
+            bool out = false;
+#pragma unroll
+            for (uint32_t t = 0; t < 4u; ++t) {
+                if (out) break;
+                if (x[t].z != me4.z || (x[t].w & 0xfffu) != my_sample || (unsigned long long)x[t].x + window <= pw) { out = true; break; }
+                if (x[t].y > p) { ++depth; chars += x[t].w >> 12; }
+            }
+            if (out) break;
+            j -= n4;
+        }
+        for (uint32_t k = 0; k < n_out; ++k) {                                              // the round's far-reaching reads: alive here when of this run, before r, ending beyond p
+            const uint32_t o = outliers[k];
+            if (o < i && rec_sample[o] == my_sample && (uint32_t)(r_key[o] >> 32) == me4.z && r_end[o] > p) { ++depth; chars += r_maxc[o]; }
+        }
         // first read of the run whose end lies beyond position 1 (the first line under metaSNV's `name 1 LEN` split): a read that starts at
         // position >= 1 always qualifies, so only the reads at position 0 and the first one behind them can be it -- a handful of atomics per run
-        if (p_end[r] > 1u && (run_start || p == 0u || p_pos[r - 1] == 0u)) atomicMin(&run_f1[g], r);
+        if (r_end[i] > 1u && (run_start || p == 0u || prev.x == 0u)) atomicMin(&run_f1[g], r);
         spill = r_cnt[i].spill;
         const uint32_t ov = ovr ? ovr[i] : 0u;
         if (ov & 1u) { depth = ov >> 16; r_depth[i] = (uint16_t)depth; }
@@ -514,7 +561,7 @@ __global__ __launch_bounds__(256) void msnv_depth(const PScan *ps, uint32_t n_pi
             uint32_t need = 0;
             if (P.max_depth > 0 && depth - 1u > (uint32_t)P.max_depth) need |= NEED_CAP;         // live.size() > max_depth before the push
             if (P.token_limit > 0 && chars >= (unsigned long long)P.token_limit) need |= NEED_TOKEN;
-            if (need) atomicOr(&acc[(size_t)(key >> 32) * ACC_COPIES].need_host, need);
+            if (need) atomicOr(&acc[(size_t)my_sample * ACC_COPIES].need_host, need);
             depth = depth < 0xffffu ? depth : 0xffffu;
         }
     }
@@ -528,29 +575,38 @@ __global__ __launch_bounds__(256) void msnv_depth(const PScan *ps, uint32_t n_pi
     } else if (valid) { atomicMax(&grp_md[2u * gi], depth); if (spill) atomicMax(&grp_md[2u * gi + 1u], depth); }
 }
 struct DpRun { uint32_t sample; int32_t tid, first_any, first_from1; };
-__global__ void msnv_run_table(uint32_t n_runs, const uint32_t *run_first, const uint32_t *run_f1, const unsigned long long *p_key, const uint32_t *p_pos, DpRun *runs) {
+__global__ void msnv_run_table(uint32_t n_runs, const uint32_t *run_first, const uint32_t *run_f1, const uint4 *p_rd, DpRun *runs) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_runs) return;
     const uint32_t r = run_first[g];
     DpRun o;
-    o.sample = (uint32_t)(p_key[r] >> 32); o.tid = (int32_t)(uint32_t)p_key[r]; o.first_any = (int32_t)p_pos[r];
+    o.sample = p_rd[r].w & 0xfffu; o.tid = (int32_t)p_rd[r].z; o.first_any = (int32_t)p_rd[r].x;
     const uint32_t f = run_f1[g];
     if (f == 0xffffffffu) o.first_from1 = -1;
-    else { const int32_t q = (int32_t)p_pos[f]; o.first_from1 = q > 1 ? q : 1; }
+    else { const int32_t q = (int32_t)p_rd[f].x; o.first_from1 = q > 1 ? q : 1; }
     runs[g] = o;
 }
-// The (run, first tile) groups, for the host: where a group's pieces lie in tile order -- [a, b) the pieces in its own tile, [b, end) the
-// ones its reads leave in the tile behind -- and the depth bounds of the two parts.
+// The (run, first tile) groups: where a group's pieces lie in tile order -- [a, b) the pieces in its own tile, [b, end) the ones its reads
+// leave in the tile behind -- and the depth bounds of the two parts, for the host; {pieces, next-tile pieces} before every group's first read
+// (grp_pre; entry n_groups: the round's totals), for the kernel that places the headers.
 struct DevGroupRec { uint32_t sample; int32_t tid; uint32_t tile, a, b, end, md_own, md_next; };
-__global__ void msnv_group_table(uint32_t n_groups, const uint32_t *grp_first, const RecCnt *pre, const uint16_t *rec_sample, const unsigned long long *r_key, const uint32_t *r_ftile,
+__global__ void msnv_group_pre(uint32_t n_groups, const uint32_t *grp_first, uint32_t n_rec, const RecCnt *blk_pre, const RecCnt *r_cnt, uint2 *grp_pre) {
+    const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi > n_groups) return;
+    const uint32_t f = gi < n_groups ? grp_first[gi] : n_rec;
+    RecCnt v = blk_pre[f / PB];
+    for (uint32_t j = f & ~(PB - 1u); j < f; ++j) { v.npiece += r_cnt[j].npiece; v.spill += r_cnt[j].spill; }
+    grp_pre[gi] = make_uint2(v.npiece, v.spill);
+}
+__global__ void msnv_group_table(uint32_t n_groups, const uint32_t *grp_first, const uint2 *grp_pre, const uint16_t *rec_sample, const unsigned long long *r_key, const uint32_t *r_ftile,
                                  const uint32_t *grp_md, DevGroupRec *out) {
     const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
     if (gi >= n_groups) return;
-    const uint32_t f = grp_first[gi], e = grp_first[gi + 1];      // records (entry n_groups: the round's record count)
-    const RecCnt pf = pre[f], pe = pre[e];
+    const uint32_t f = grp_first[gi];
+    const uint2 pf = grp_pre[gi], pe = grp_pre[gi + 1];
     DevGroupRec o;
     o.sample = rec_sample[f]; o.tid = (int32_t)(r_key[f] >> 32); o.tile = r_ftile[f];
-    o.a = pf.npiece; o.b = pe.npiece - (pe.spill - pf.spill); o.end = pe.npiece; o.md_own = grp_md[2u * gi]; o.md_next = grp_md[2u * gi + 1u];
+    o.a = pf.x; o.b = pe.x - (pe.y - pf.y); o.end = pe.x; o.md_own = grp_md[2u * gi]; o.md_next = grp_md[2u * gi + 1u];
     out[gi] = o;
 }
 
@@ -655,91 +711,6 @@ __global__ void msnv_ovl_groups(const uint32_t *starts, uint32_t n_groups, uint3
     }
 }
 
-// ------------------------------------------------------------------------------------------ headers and intervals
-// where a piece's bases and qualities lie in the round buffer, and its reference: everything msnv_emit_pieces needs without going back to the record
-struct PieceSrc { unsigned long long seq, qual, ref_nib; uint32_t q0, ref_left; uint32_t sample_len, seqoff; };   // ref_nib: nibble index into pref4 of the piece's first position (~0: no FASTA); ref_left: FASTA characters from there; sample_len: sample | bases << 16
-// Tile order without a sort.  The headers of a sample must end up grouped by (contig, tile), read order inside a tile (pack.cpp's stable
-// sort); in file order only the pieces a read leaves in the tile BEHIND its first one are out of place.  Reads sorted by start whose
-// pieces lie in their first tile and at most the next one (msnv_measure_reads checks it; else `in_order`: file order here, rocPRIM sort
-// afterwards) fall into groups of consecutive reads with the same first tile, and the sorted order is, group after group: the group's
-// pieces in its own tile, then the ones it leaves in the next tile (which thereby precede the next group's own pieces -- same tile -- in
-// read order).  With pre.npiece / pre.spill = pieces / next-tile pieces of all earlier reads and f, e = first read of this / the next group:
-//   a piece in the read's first tile goes to  pre[i].npiece - (pre[i].spill - pre[f].spill) + its index among the read's such pieces,
-//   a piece in the tile behind goes to        pre[e].npiece - pre[e].spill + pre[i].spill  + its index among those.
-__global__ __launch_bounds__(256) void msnv_emit_headers(const uint8_t *raw, const unsigned long long *rec_off, const uint16_t *rec_sample, uint32_t n_rec, const DpContig *ctg,
-                                                         const uint8_t *r_flags, const uint16_t *r_depth, const RecCnt *pre, const unsigned long long *samp_sbase0,
-                                                         const PScan *ps, const uint32_t *grp_first, uint32_t in_order,
-                                                         ReadHdr *hdr, int32_t *ptid, int32_t *pend, uint16_t *pdepth, PieceSrc *psrc,
-                                                         int32_t *cov_tid, int32_t *cov_beg, int32_t *cov_end, int32_t *overhang, uint32_t *any_overhang, uint32_t noseq_counts) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_rec) return;
-    const uint8_t f = r_flags[i];
-    if (!(f & (RF_PILE | RF_COV))) return;
-    const uint8_t *p = raw + rec_off[i];
-    const Rec r = rec_load(p, ~0ull);
-    const uint32_t s = rec_sample[i];
-    const DpContig c = ctg[r.tid];
-    const RecCnt me = pre[i];
-    if (f & RF_COV) {                                                                       // qaCompute.cpp:530-552
-        const long long L = c.len;
-        long long pp = (long long)r.pos + 1;
-        uint32_t k = 0, w = me.niv;
-        if (r.n_cigar > 0) { const uint32_t t = ld32(r.cigar) & 15u; if (t == C_S || t == C_H) k = 1; }
-        for (; k < r.n_cigar; ++k) {
-            const uint32_t cg = ld32(r.cigar + 4ull * k), t = cg & 15u, l = cg >> 4;
-            if (t == C_M) {
-                if (pp >= L) { if (L >= 1) { cov_tid[w] = r.tid; cov_beg[w] = (int32_t)L; cov_end[w] = (int32_t)(L - 1); ++w; } }
-                else { cov_tid[w] = r.tid; cov_beg[w] = (int32_t)pp; cov_end[w] = (int32_t)(pp + l); ++w; }
-            }
-            pp += l;
-        }
-    }
-    const bool noseq = r.l_seq == 0;
-    if (!(f & RF_PILE) || (noseq && !noseq_counts)) return;
-    uint32_t w = me.npiece;                                                                   // file order: where the piece's source record goes (and, in_order, its header)
-    uint32_t d_own = w, d_next = w;                                                           // tile order: next header slot in the read's first tile / the tile behind
-    uint32_t ftile = 0; bool have_ftile = false;
-    if (!in_order) {
-        const uint32_t gi = ps[me.pile].grps - 1u;
-        const uint32_t fr = grp_first[gi], er = grp_first[gi + 1u];
-        const RecCnt pf = pre[fr], pe = pre[er];
-        d_own = me.npiece - (me.spill - pf.spill);
-        d_next = pe.npiece - pe.spill + me.spill;
-    }
-    unsigned long long so = me.seqb - samp_sbase0[s];
-    long long rp = r.pos, q = 0;
-    const uint16_t depth = r_depth[i];
-    const unsigned long long seq_abs = (unsigned long long)(r.seq - raw), qual_abs = (unsigned long long)(r.qual - raw);
-    for (uint32_t k = 0; k < r.n_cigar; ++k) {
-        const uint32_t cg = ld32(r.cigar + 4ull * k), t = cg & 15u, l = cg >> 4;
-        if (cg_match(t)) {
-            for (uint32_t off = 0, n = 0; off < l; off += n) {
-                const uint32_t to_tile = TILE - (uint32_t)((rp + off) % TILE);
-                n = SEG_MAX < l - off ? SEG_MAX : l - off;
-                n = n < to_tile ? n : to_tile;
-                const uint32_t tl = (uint32_t)((rp + off) / TILE);
-                if (!have_ftile) { ftile = tl; have_ftile = true; }
-                const uint32_t dst = in_order ? w : (tl == ftile ? d_own++ : d_next++);
-                ReadHdr h;
-                h.gpos = (uint32_t)(rp + off); h.seqoff = (uint32_t)so; h.cig = n; h.meta = META_PILEUP_OK | r.mapq << 16;
-                hdr[dst] = h; ptid[dst] = r.tid; pend[dst] = (int32_t)(rp + off + n); pdepth[dst] = depth;
-                if (rp + off + n > c.len) { atomicMax(&overhang[r.tid], (int32_t)(rp + off + n)); *any_overhang = 1u; }     // a read that runs past its contig: the contig's tiles reach that far (finalize)
-                PieceSrc ps1;
-                ps1.seq = seq_abs; ps1.qual = qual_abs; ps1.q0 = noseq ? 0xffffffffu : (uint32_t)(q + off); ps1.sample_len = s | n << 16; ps1.seqoff = (uint32_t)so;      // q0 = ~0: no SEQ, the bases are N of quality 0
-                const long long g = rp + off, left = c.seq_len - g;
-                if (c.seq_len >= 0 && g >= 0 && left > 0) { ps1.ref_nib = c.pref_off + (unsigned long long)g; ps1.ref_left = (uint32_t)(left < 0xffffffffll ? left : 0xffffffffll); }
-                else { ps1.ref_nib = c.seq_len >= 0 ? ~1ull : ~0ull; ps1.ref_left = 0; }        // ~1: a FASTA record exists but holds nothing here (sampled, nothing to compare)
-                psrc[w] = ps1;
-                ++w; so += stored_bytes(n);
-            }
-            rp += l; q += l;
-        } else {
-            if (cg_ref(t)) rp += l;
-            if (cg_query(t)) q += l;
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------ bases and quality flags
 // Pieces start on 4 bases, so a piece's flags start on bit 0 or 4 of a byte: whole bytes are stored, the two nibbles a piece shares with
 // its neighbours' bytes are OR-ed in atomically (the flag column is cleared first).
@@ -792,97 +763,332 @@ __device__ __forceinline__ void put_piece_lane(uint8_t *seq_col, uint8_t *qual_c
         if ((total & 4u) && last_lane) or_byte(qp + full, (uint32_t)(w >> (8u * full)) & 0xfu);
     }
 }
-__global__ __launch_bounds__(256) void msnv_emit_pieces(const uint8_t *raw, const uint32_t *pref4, DpParams P, uint32_t n_pieces, const PieceSrc *psrc,
-                                                        const DpSampleDst *dst, DpAcc *acc) {
-    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t pc = gt >> 2, sub = gt & 3u, j0 = 32u * sub;
-    const bool piece = pc < n_pieces;
-    PieceSrc ps{};
-    if (piece) ps = psrc[pc];
-    const uint32_t n = ps.sample_len >> 16, sample = ps.sample_len & 0xffffu, sb = piece ? stored_bytes(n) : 0u;
-    const uint32_t st = 2u * sb > j0 ? (2u * sb - j0 < 32u ? 2u * sb - j0 : 32u) : 0u;    // stored nibbles of this lane (a multiple of 4)
-    const uint32_t have = n > j0 ? (n - j0 < 32u ? n - j0 : 32u) : 0u;                     // ... of which real bases
-    DpSampleDst d{};
-    if (piece) d = dst[sample];
-    const bool pad_low = P.c_eff > 0 || P.all_low;                                          // padding: base N, quality byte 0 (pack.cpp: pack_sample, pack_lowq)
-    uint64_t o0 = ~0ull, o1 = ~0ull;                                                        // the lane's 32 nibbles, low first
-    uint32_t bits = pad_low ? 0xffffffffu : 0u, mm = 0;
-    bool sampled = false;
-    if (have) {
-        const bool noseq = ps.q0 == 0xffffffffu;
-        const uint32_t q0 = noseq ? 0u : ps.q0 + j0;
-        if (!noseq) {
-            // BAM packs base 2i in the HIGH nibble of byte i; the kernels want base j of the piece in nibble j, low first
-            const uint8_t *sp = raw + ps.seq + (q0 >> 1);
-            const uint64_t s0 = nib_swap64(ld64(sp)), s1 = nib_swap64(ld64(sp + 8)), s2 = nib_swap64(ld64(sp + 16));
-            if (q0 & 1u) { o0 = s0 >> 4 | s1 << 60; o1 = s1 >> 4 | s2 << 60; } else { o0 = s0; o1 = s1; }
-        }
-        if (have < 16u) { o0 |= ~0ull << (4u * have); o1 = ~0ull; } else if (have < 32u) o1 |= ~0ull << (4u * (have - 16u));
-        const bool has_fasta = ps.ref_nib != ~0ull;
-        const uint32_t left = ps.ref_left > j0 ? ps.ref_left - j0 : 0u;                   // FASTA characters from the lane's first position
-        const bool sample_this = has_fasta && ((pc - (uint32_t)d.pbase0) & 15u) == 0u;     // one piece in 16: how noisy are these reads?
-        const uint64_t z0 = (o0 - 0x1111111111111111ull) & ~o0 & 0x8888888888888888ull, z1 = (o1 - 0x1111111111111111ull) & ~o1 & 0x8888888888888888ull;
-        if ((z0 | z1) || sample_this) {
-            uint64_t r0 = ~0ull, r1 = ~0ull;                                                // reference codes of the lane's positions (N where the FASTA has nothing)
-            if (left) {
-                const unsigned long long nb = ps.ref_nib + j0;
-                const uint32_t *w = pref4 + (nb >> 3);
-                const uint64_t a = (uint64_t)w[0] | (uint64_t)w[1] << 32, b = (uint64_t)w[2] | (uint64_t)w[3] << 32, c = (uint64_t)w[4];
-                const uint32_t sh = 4u * (uint32_t)(nb & 7u);
-                r0 = sh ? (a >> sh | b << (64u - sh)) : a;
-                r1 = sh ? (b >> sh | c << (64u - sh)) : b;
-                if (left < 16u) { r0 |= ~0ull << (4u * left); r1 = ~0ull; } else if (left < 32u) r1 |= ~0ull << (4u * (left - 16u));
-            }
-            // '=' (code 0) always counts as a match (bam_plcmd.c pileup_seq [EXT]): ship the reference code, N when that is unknown or '=' itself
-            if (z0 | z1) {
-                for (uint32_t t = 0; t < have; ++t) {
-                    uint64_t &o = t < 16u ? o0 : o1; const uint64_t r = t < 16u ? r0 : r1; const uint32_t k = 4u * (t & 15u);
-                    if (((o >> k) & 0xfull) == 0ull) { uint64_t code = (r >> k) & 0xfull; if (code == 0ull) code = 15ull; o |= code << k; }
-                }
-            }
-            if (sample_this) {
-                sampled = true;
-                const uint32_t cmp = left < have ? left : have;
-                uint64_t x0 = o0 ^ r0, x1 = o1 ^ r1;
-                x0 = (x0 | x0 >> 1 | x0 >> 2 | x0 >> 3) & 0x1111111111111111ull; x1 = (x1 | x1 >> 1 | x1 >> 2 | x1 >> 3) & 0x1111111111111111ull;
-                if (cmp < 16u) { x0 &= (1ull << (4u * cmp)) - 1ull; x1 = 0ull; } else if (cmp < 32u) x1 &= (1ull << (4u * (cmp - 16u))) - 1ull;
-                mm = (uint32_t)(__builtin_popcountll(x0) + __builtin_popcountll(x1));
-            }
-        }
-        uint32_t low = 0;
-        if (P.all_low) low = 0xffffffffu;
-        else if (!noseq && (P.c_eff > 0 || d.cut_marks)) {
-            const uint8_t *qp = raw + ps.qual + q0;
-            const uint64_t qa = ld64(qp), qb = ld64(qp + 8), qc = ld64(qp + 16), qd = ld64(qp + 24);
-            if (P.c_eff > 0) low = low_flags8(qa, (uint32_t)P.c_eff) | low_flags8(qb, (uint32_t)P.c_eff) << 8 | low_flags8(qc, (uint32_t)P.c_eff) << 16 | low_flags8(qd, (uint32_t)P.c_eff) << 24;
-            if (d.cut_marks) {                                                              // 0xfe: behind snpCall's token limit (pack.cpp: QUAL_CUT), below every cutoff
-                const uint64_t q4[4] = {qa, qb, qc, qd};
-                for (uint32_t t = 0; t < 32u; ++t) if (((q4[t >> 3] >> (8u * (t & 7u))) & 0xffull) == 0xfeull) low |= 1u << t;
-            }
-        }
-        // (no SEQ: quality 0 -- shipped only when the cutoff is 0, where it is not below it)
-        bits = have < 32u ? ((bits & (0xffffffffu << have)) | (low & ((1u << have) - 1u))) : low;
+
+// ------------------------------------------------------------------------------------------ headers, intervals, bases: one block of records per workgroup
+// msnv_emit_block (round 5; rounds 4's msnv_emit_headers + msnv_emit_pieces went to every record twice with a thread's worth of scattered
+// loads each): a workgroup takes a block of PB records -- consecutive in the round buffer --, stages their bytes in LDS with coalesced
+// 16-byte loads (every byte of the records is read from HBM once), then
+//   one thread per record: header and CIGAR from LDS -> qaCompute's intervals (qaCompute.cpp:530-552), the piece headers at their places
+//     in tile order, and a descriptor of every piece in LDS;
+//   four lanes per piece, 32 bases a lane: BAM nibble swap, '=' -> reference code, the -Q flag of every base from the phred bytes, mismatch
+//     sample of every 16th piece -- from LDS, out to the sample's columns.
+// A block whose records do not fit the window (long reads), that cuts more pieces than the list holds, or that holds a record whose
+// CIGAR may live in the CG field takes the direct route: a thread per record does the same from global memory, piece after piece.
+//
+// Tile order without a sort.  The headers of a sample must end up grouped by (contig, tile), read order inside a tile (pack.cpp's stable
+// sort); in file order only the pieces a read leaves in the tile BEHIND its first one are out of place.  Reads sorted by start whose
+// pieces lie in their first tile and at most the next one (msnv_measure_reads checks it; else `in_order`: file order here, rocPRIM sort
+// afterwards) fall into groups of consecutive reads with the same first tile, and the sorted order is, group after group: the group's
+// pieces in its own tile, then the ones it leaves in the next tile (which thereby precede the next group's own pieces -- same tile -- in
+// read order).  With npiece / spill = pieces / next-tile pieces of all earlier reads and f, e = first read of this / the next group:
+//   a piece in the read's first tile goes to  npiece(i) - (spill(i) - spill(f)) + its index among the read's such pieces,
+//   a piece in the tile behind goes to        npiece(e) - spill(e) + spill(i)   + its index among those.
+constexpr uint32_t EW_BYTES = 20480;                              // LDS window of a block's records (320 bytes a record)
+struct LdsSrc {                                                   // unaligned little-endian loads from the LDS window (aligned words + funnel shift: gfx9 has no unaligned ds_read)
+    const uint32_t *w;
+    __device__ __forceinline__ uint32_t ld32(unsigned long long o) const { const uint32_t a = (uint32_t)o; return __builtin_amdgcn_alignbyte(w[(a >> 2) + 1], w[a >> 2], a & 3u); }
+    __device__ __forceinline__ uint64_t ld64(unsigned long long o) const {
+        const uint32_t a = (uint32_t)o, w0 = w[a >> 2], w1 = w[(a >> 2) + 1], w2 = w[(a >> 2) + 2];
+        return (uint64_t)__builtin_amdgcn_alignbyte(w1, w0, a & 3u) | (uint64_t)__builtin_amdgcn_alignbyte(w2, w1, a & 3u) << 32;
     }
-    const uint32_t prev_last = __shfl_up(bits >> 28, 1);                                    // the last four flags of lane sub - 1 of the same piece (sub > 0, that lane is full)
-    if (st) put_piece_lane(d.seq, d.qual, ps.seqoff, sub, sb, st, o0, o1, bits, prev_last);
-    // mismatch sample: sum over the 4 lanes of a piece, one atomic per sampled piece
-    mm += __shfl_down(mm, 2, 4); mm += __shfl_down(mm, 1, 4);
-    if (sub == 0 && sampled) {
-        DpAcc &a = acc[(size_t)sample * ACC_COPIES + (blockIdx.x % ACC_COPIES)];
-        atomicAdd(&a.mm_bases, (unsigned long long)n);
-        if (mm) atomicAdd(&a.mm, (unsigned long long)mm);
+};
+struct GlbSrc {
+    const uint8_t *p;
+    __device__ __forceinline__ uint32_t ld32(unsigned long long o) const { return msnv::ld32(p + o); }
+    __device__ __forceinline__ uint64_t ld64(unsigned long long o) const { return msnv::ld64(p + o); }
+};
+// One lane's 32 bases of a piece: nibbles (low first) in o0 / o1, "quality below -Q" flags in bits, mismatches against the reference in mm
+// when the piece is one of the sampled ones.  j0 = 32 * sub; st / have as in the caller.
+template <class Src>
+__device__ __forceinline__ void piece_lane(const Src &src, unsigned long long seq_o, unsigned long long qual_o, uint32_t q0_piece, uint32_t j0, uint32_t have, unsigned long long ref_nib,
+                                           uint32_t ref_left, const uint32_t *pref4, const DpParams &P, uint32_t cut_marks, bool sample_this, uint64_t &o0, uint64_t &o1, uint32_t &bits, uint32_t &mm) {
+    const bool pad_low = P.c_eff > 0 || P.all_low;                                          // padding: base N, quality byte 0 (pack.cpp: pack_sample, pack_lowq)
+    o0 = ~0ull; o1 = ~0ull; bits = pad_low ? 0xffffffffu : 0u; mm = 0;
+    if (!have) return;
+    const bool noseq = q0_piece == 0xffffffffu;
+    const uint32_t q0 = noseq ? 0u : q0_piece + j0;
+    if (!noseq) {
+        // BAM packs base 2i in the HIGH nibble of byte i; the kernels want base j of the piece in nibble j, low first
+        const unsigned long long sp = seq_o + (q0 >> 1);
+        const uint64_t s0 = nib_swap64(src.ld64(sp)), s1 = nib_swap64(src.ld64(sp + 8)), s2 = nib_swap64(src.ld64(sp + 16));
+        if (q0 & 1u) { o0 = s0 >> 4 | s1 << 60; o1 = s1 >> 4 | s2 << 60; } else { o0 = s0; o1 = s1; }
+    }
+    if (have < 16u) { o0 |= ~0ull << (4u * have); o1 = ~0ull; } else if (have < 32u) o1 |= ~0ull << (4u * (have - 16u));
+    const uint32_t left = ref_left > j0 ? ref_left - j0 : 0u;                               // FASTA characters from the lane's first position
+    const uint64_t z0 = (o0 - 0x1111111111111111ull) & ~o0 & 0x8888888888888888ull, z1 = (o1 - 0x1111111111111111ull) & ~o1 & 0x8888888888888888ull;
+    if ((z0 | z1) || sample_this) {
+        uint64_t r0 = ~0ull, r1 = ~0ull;                                                    // reference codes of the lane's positions (N where the FASTA has nothing)
+        if (left) {
+            const unsigned long long nb = ref_nib + j0;
+            const uint32_t *w = pref4 + (nb >> 3);
+            const uint64_t a = (uint64_t)w[0] | (uint64_t)w[1] << 32, b = (uint64_t)w[2] | (uint64_t)w[3] << 32, c = (uint64_t)w[4];
+            const uint32_t sh = 4u * (uint32_t)(nb & 7u);
+            r0 = sh ? (a >> sh | b << (64u - sh)) : a;
+            r1 = sh ? (b >> sh | c << (64u - sh)) : b;
+            if (left < 16u) { r0 |= ~0ull << (4u * left); r1 = ~0ull; } else if (left < 32u) r1 |= ~0ull << (4u * (left - 16u));
+        }
+        // '=' (code 0) always counts as a match (bam_plcmd.c pileup_seq [EXT]): ship the reference code, N when that is unknown or '=' itself
+        if (z0 | z1) {
+            for (uint32_t t = 0; t < have; ++t) {
+                uint64_t &o = t < 16u ? o0 : o1; const uint64_t r = t < 16u ? r0 : r1; const uint32_t k = 4u * (t & 15u);
+                if (((o >> k) & 0xfull) == 0ull) { uint64_t code = (r >> k) & 0xfull; if (code == 0ull) code = 15ull; o |= code << k; }
+            }
+        }
+        if (sample_this) {
+            const uint32_t cmp = left < have ? left : have;
+            uint64_t x0 = o0 ^ r0, x1 = o1 ^ r1;
+            x0 = (x0 | x0 >> 1 | x0 >> 2 | x0 >> 3) & 0x1111111111111111ull; x1 = (x1 | x1 >> 1 | x1 >> 2 | x1 >> 3) & 0x1111111111111111ull;
+            if (cmp < 16u) { x0 &= (1ull << (4u * cmp)) - 1ull; x1 = 0ull; } else if (cmp < 32u) x1 &= (1ull << (4u * (cmp - 16u))) - 1ull;
+            mm = (uint32_t)(__builtin_popcountll(x0) + __builtin_popcountll(x1));
+        }
+    }
+    uint32_t low = 0;
+    if (P.all_low) low = 0xffffffffu;
+    else if (!noseq && (P.c_eff > 0 || cut_marks)) {
+        const unsigned long long qp = qual_o + q0;
+        const uint64_t qa = src.ld64(qp), qb = src.ld64(qp + 8), qc = src.ld64(qp + 16), qd = src.ld64(qp + 24);
+        if (P.c_eff > 0) low = low_flags8(qa, (uint32_t)P.c_eff) | low_flags8(qb, (uint32_t)P.c_eff) << 8 | low_flags8(qc, (uint32_t)P.c_eff) << 16 | low_flags8(qd, (uint32_t)P.c_eff) << 24;
+        if (cut_marks) {                                                                    // 0xfe: behind snpCall's token limit (pack.cpp: QUAL_CUT), below every cutoff
+            const uint64_t q4[4] = {qa, qb, qc, qd};
+            for (uint32_t t = 0; t < 32u; ++t) if (((q4[t >> 3] >> (8u * (t & 7u))) & 0xffull) == 0xfeull) low |= 1u << t;
+        }
+    }
+    // (no SEQ: quality 0 -- shipped only when the cutoff is 0, where it is not below it)
+    bits = have < 32u ? ((bits & (0xffffffffu << have)) | (low & ((1u << have) - 1u))) : low;
+}
+struct EmitArgs {
+    const uint8_t *raw; const unsigned long long *rec_off; const uint16_t *rec_sample; uint32_t n_rec; const DpContig *ctg; const uint8_t *r_flags; const uint16_t *r_depth;
+    const RecCnt *r_cnt, *blk_pre; const unsigned long long *samp_sbase0, *rg; const uint2 *grp_pre; uint32_t in_order;
+    ReadHdr *hdr; int32_t *ptid, *pend; uint16_t *pdepth; int32_t *cov_tid, *cov_beg, *cov_end, *overhang; uint32_t *any_overhang; uint32_t noseq_counts;
+    const uint32_t *pref4; DpParams P; const DpSampleDst *dst; DpAcc *acc;
+};
+// One record by its four lanes (sub = 0 .. 3): every lane reads the header and walks the CIGAR (LDS: cheap), lane 0 writes the intervals
+// and the piece headers, and lane `sub` moves bases 32 sub .. 32 sub + 31 of every piece (a piece holds at most SEG_MAX = 128 bases).
+// Where a lane's share of a piece goes.  GlbOut: straight into the sample's columns (byte-granular stores, the nibbles shared with a
+// neighbour OR-ed in atomically: put_piece_lane).  LdsOut: OR-ed into a zeroed image of the block's stretch of the columns in LDS -- five
+// words of bases and two of flags per lane, no branches --, which the workgroup then writes out with whole 16-byte stores
+// (msnv_emit_block; the records of a block are consecutive in their sample's columns).
+struct GlbOut {
+    static constexpr bool kLds = false;
+    __device__ __forceinline__ void put(const DpSampleDst &d, uint32_t so, uint32_t sub, uint32_t sb, uint32_t st, uint64_t o0, uint64_t o1, uint32_t bits, uint32_t prev_last) const {
+        if (st) put_piece_lane(d.seq, d.qual, so, sub, sb, st, o0, o1, bits, prev_last);
+    }
+};
+struct LdsOut {
+    static constexpr bool kLds = true;
+    uint32_t *seq_w, *flag_w; uint32_t a16;                      // images of the seq / flag columns from byte a16 of the sample's seq column (a multiple of 16)
+    __device__ __forceinline__ void put(const DpSampleDst &, uint32_t so, uint32_t sub, uint32_t, uint32_t st, uint64_t o0, uint64_t o1, uint32_t bits, uint32_t) const {
+        if (!st) return;
+        // bases: st / 2 bytes from byte L of the image; what lies beyond them in the registers must not reach the neighbour's bytes
+        const uint32_t nb = st >> 1, L = so - a16 + 16u * sub, sh = 8u * (L & 3u);
+        if (nb < 8u) { o0 &= (1ull << (8u * nb)) - 1ull; o1 = 0ull; } else if (nb < 16u) o1 &= (1ull << (8u * (nb - 8u))) - 1ull;
+        const uint64_t l = o0 << sh, h = o1 << sh | (sh ? o0 >> (64u - sh) : 0ull);
+        uint32_t *q = seq_w + (L >> 2);
+        atomicOr(q, (uint32_t)l);
+        atomicOr(q + 1, (uint32_t)(l >> 32));
+        atomicOr(q + 2, (uint32_t)h);
+        atomicOr(q + 3, (uint32_t)(h >> 32));
+        if (sh) atomicOr(q + 4, (uint32_t)(o1 >> (64u - sh)));
+        // flags: bit index = nibble index of the seq column
+        const uint32_t fb = 2u * (so - a16) + 32u * sub, v = st < 32u ? bits & ((1u << st) - 1u) : bits;
+        const uint64_t fv = (uint64_t)v << (fb & 31u);
+        atomicOr(flag_w + (fb >> 5), (uint32_t)fv);
+        atomicOr(flag_w + (fb >> 5) + 1, (uint32_t)(fv >> 32));
+    }
+};
+template <class Src, class Out>
+__device__ __forceinline__ void emit_record(const EmitArgs &A, const Src &src, const Out &out, unsigned long long rec_o, const RecCnt me, uint32_t sub, uint8_t f, uint32_t s, uint16_t depth) {
+    if (!(f & (RF_PILE | RF_COV))) return;
+    const int32_t tid = (int32_t)src.ld32(rec_o + 4), pos = (int32_t)src.ld32(rec_o + 8);
+    const uint32_t w3 = src.ld32(rec_o + 12), fn = src.ld32(rec_o + 16);
+    const int32_t l_seq = (int32_t)src.ld32(rec_o + 20);
+    uint32_t n_cigar = fn & 0xffffu; const uint32_t l_name = w3 & 0xffu, mapq = (w3 >> 8) & 0xffu;
+    unsigned long long cig_o = rec_o + 36 + l_name;
+    const unsigned long long seq_o = cig_o + 4ull * n_cigar, qual_o = seq_o + ((unsigned long long)(uint32_t)l_seq + 1) / 2;
+    if (Src::kGlobal) {                                                                     // (the direct route honours a CIGAR that lives in the CG field: rec_load)
+        const Rec r = rec_load(src.base() + rec_o, ~0ull);
+        cig_o = (unsigned long long)(r.cigar - src.base()); n_cigar = r.n_cigar;
+    }
+    // (everything the record needs from global memory is asked for here, in one go: a workgroup's time is the depth of its load chain)
+    const DpContig c = A.ctg[tid];
+    const DpSampleDst d = A.dst[s];
+    const unsigned long long sbase0 = A.samp_sbase0[s];
+    uint2 pf = make_uint2(0u, 0u), pe = make_uint2(0u, 0u);
+    if ((f & RF_PILE) && !A.in_order) {
+        const uint32_t gi = (uint32_t)A.rg[me.pile] - 1u;
+        pf = A.grp_pre[gi]; pe = A.grp_pre[gi + 1u];
+    }
+    if ((f & RF_COV) && sub == 0) {                                                         // qaCompute.cpp:530-552
+        const long long L = c.len;
+        long long pp = (long long)pos + 1;
+        uint32_t k = 0, w = me.niv;
+        if (n_cigar > 0) { const uint32_t t = src.ld32(cig_o) & 15u; if (t == C_S || t == C_H) k = 1; }
+        for (; k < n_cigar; ++k) {
+            const uint32_t cg = src.ld32(cig_o + 4ull * k), t = cg & 15u, l = cg >> 4;
+            if (t == C_M) {
+                if (pp >= L) { if (L >= 1) { A.cov_tid[w] = tid; A.cov_beg[w] = (int32_t)L; A.cov_end[w] = (int32_t)(L - 1); ++w; } }
+                else { A.cov_tid[w] = tid; A.cov_beg[w] = (int32_t)pp; A.cov_end[w] = (int32_t)(pp + l); ++w; }
+            }
+            pp += l;
+        }
+    }
+    const bool noseq = l_seq == 0;
+    if (!(f & RF_PILE) || (noseq && !A.noseq_counts)) return;
+    uint32_t w = me.npiece;                                                                   // file order
+    uint32_t d_own = w, d_next = w;                                                           // tile order: next header slot in the read's first tile / the tile behind
+    uint32_t ftile = 0; bool have_ftile = false;
+    if (!A.in_order) {
+        d_own = me.npiece - (me.spill - pf.y);
+        d_next = pe.x - pe.y + me.spill;
+    }
+    unsigned long long so = me.seqb - sbase0;
+    long long rp = pos, q = 0;
+    const uint32_t j0 = 32u * sub;
+    for (uint32_t k = 0; k < n_cigar; ++k) {
+        const uint32_t cg = src.ld32(cig_o + 4ull * k), t = cg & 15u, l = cg >> 4;
+        if (cg_match(t)) {
+            for (uint32_t off = 0, n = 0; off < l; off += n) {
+                const uint32_t to_tile = TILE - (uint32_t)((rp + off) % TILE);
+                n = SEG_MAX < l - off ? SEG_MAX : l - off;
+                n = n < to_tile ? n : to_tile;
+                const uint32_t tl = (uint32_t)((rp + off) / TILE);
+                if (!have_ftile) { ftile = tl; have_ftile = true; }
+                const uint32_t dst = A.in_order ? w : (tl == ftile ? d_own++ : d_next++);
+                if (sub == 0) {
+                    ReadHdr h;
+                    h.gpos = (uint32_t)(rp + off); h.seqoff = (uint32_t)so; h.cig = n; h.meta = META_PILEUP_OK | mapq << 16;
+                    A.hdr[dst] = h; A.ptid[dst] = tid; A.pend[dst] = (int32_t)(rp + off + n); A.pdepth[dst] = depth;
+                    if (rp + off + n > c.len) { atomicMax(&A.overhang[tid], (int32_t)(rp + off + n)); *A.any_overhang = 1u; }     // a read that runs past its contig: the contig's tiles reach that far (finalize)
+                }
+                // ---- this lane's 32 bases of the piece
+                unsigned long long ref_nib; uint32_t ref_left;
+                const long long g = rp + off, left = c.seq_len - g;
+                if (c.seq_len >= 0 && g >= 0 && left > 0) { ref_nib = c.pref_off + (unsigned long long)g; ref_left = (uint32_t)(left < 0xffffffffll ? left : 0xffffffffll); }
+                else { ref_nib = c.seq_len >= 0 ? ~1ull : ~0ull; ref_left = 0; }              // ~1: a FASTA record exists but holds nothing here (sampled, nothing to compare)
+                const uint32_t sb = stored_bytes(n);
+                const uint32_t st = 2u * sb > j0 ? (2u * sb - j0 < 32u ? 2u * sb - j0 : 32u) : 0u;    // stored nibbles of this lane (a multiple of 4)
+                const uint32_t have = n > j0 ? (n - j0 < 32u ? n - j0 : 32u) : 0u;                     // ... of which real bases
+                const bool sample_this = ref_nib != ~0ull && ((w - (uint32_t)d.pbase0) & 15u) == 0u;   // one piece in 16: how noisy are these reads?
+                uint64_t o0, o1; uint32_t bits, mm;
+                piece_lane(src, seq_o, qual_o, noseq ? 0xffffffffu : (uint32_t)(q + off), j0, have, ref_nib, ref_left, A.pref4, A.P, d.cut_marks, sample_this && have, o0, o1, bits, mm);      // (no SEQ: the bases are N of quality 0)
+                const uint32_t prev_last = Out::kLds ? 0u : __shfl_up(bits >> 28, 1);           // the last four flags of lane sub - 1 of the same piece (sub > 0, that lane is full)
+                out.put(d, (uint32_t)so, sub, sb, st, o0, o1, bits, prev_last);
+                // mismatch sample: sum over the 4 lanes of a piece, one atomic per sampled piece
+                mm += __shfl_down(mm, 2, 4); mm += __shfl_down(mm, 1, 4);
+                if (sub == 0 && sample_this) {
+                    DpAcc &a = A.acc[(size_t)s * ACC_COPIES + (blockIdx.x % ACC_COPIES)];
+                    atomicAdd(&a.mm_bases, (unsigned long long)n);
+                    if (mm) atomicAdd(&a.mm, (unsigned long long)mm);
+                }
+                ++w; so += sb;
+            }
+            rp += l; q += l;
+        } else {
+            if (cg_ref(t)) rp += l;
+            if (cg_query(t)) q += l;
+        }
+    }
+}
+struct LdsSrcK : LdsSrc { static constexpr bool kGlobal = false; __device__ const uint8_t *base() const { return nullptr; } };
+struct GlbSrcK : GlbSrc { static constexpr bool kGlobal = true; __device__ const uint8_t *base() const { return p; } };
+
+constexpr uint32_t EO_BYTES = 8192;                               // bytes of the seq column a block's image holds (its flags: a quarter of that)
+__global__ __launch_bounds__(256) void msnv_emit_block(const EmitArgs A) {
+    __shared__ uint4 win[EW_BYTES / 16 + 4];                       // (+ 64 bytes: a lane's last loads run past its piece)
+    __shared__ RecCnt s_pre[PB];
+    __shared__ uint4 img_seq[EO_BYTES / 16 + 2];                   // (+ 32 bytes: a lane ORs five words from any byte)
+    __shared__ uint4 img_flag[EO_BYTES / 64 + 2];
+    const uint32_t b = blockIdx.x, tid = threadIdx.x, i0 = b * PB;
+    const uint32_t nrec = A.n_rec - i0 < PB ? A.n_rec - i0 : PB;
+    const unsigned long long lo = A.rec_off[i0] & ~15ull, hi = A.rec_off[i0 + nrec];      // (entry n_rec: the end of the round's records)
+    const bool direct = hi - lo > EW_BYTES;
+    // ---- this lane's record: what it needs of the per-record columns (asked for together with the window)
+    const uint32_t r = tid >> 2, sub = tid & 3u, i = i0 + (r < nrec ? r : 0u);
+    const uint8_t f = A.r_flags[i]; const uint32_t smp = A.rec_sample[i]; const uint16_t depth = A.r_depth[i]; const unsigned long long ro = A.rec_off[i];
+    const uint32_t smp_first = A.rec_sample[i0], smp_last = A.rec_sample[i0 + nrec - 1u];
+    const RecCnt base = A.blk_pre[b], next = A.blk_pre[b + 1];
+    // ---- the block's bytes into LDS
+    if (!direct) {
+        const uint32_t n16 = (uint32_t)((hi - lo + 15) >> 4);
+        uint4 v[EW_BYTES / 16 / 256];
+#pragma unroll
+        for (uint32_t k = 0; k < EW_BYTES / 16 / 256; ++k) { const uint32_t c = tid + 256u * k; v[k] = c < n16 ? *reinterpret_cast<const uint4 *>(A.raw + lo + 16ull * c) : make_uint4(0, 0, 0, 0); }
+#pragma unroll
+        for (uint32_t k = 0; k < EW_BYTES / 16 / 256; ++k) { const uint32_t c = tid + 256u * k; if (c < n16 + 4u) win[c] = v[k]; }
+    }
+    // ---- the image of the block's stretch of its sample's columns: one sample, a stretch the image holds (else every lane stores for itself)
+    const unsigned long long sb0 = A.samp_sbase0[smp_first];
+    const unsigned long long a0 = base.seqb - sb0, b0 = next.seqb - sb0;             // the block's pieces own bytes [a0, b0) of the sample's seq column
+    const uint32_t a16 = (uint32_t)a0 & ~15u;
+    const bool image = !direct && smp_first == smp_last && b0 - a16 <= EO_BYTES && b0 > a0;
+    if (image) {
+        for (uint32_t c = tid; c < EO_BYTES / 16 + 2; c += 256u) img_seq[c] = make_uint4(0, 0, 0, 0);
+        if (tid < EO_BYTES / 64 + 2) img_flag[tid] = make_uint4(0, 0, 0, 0);
+    }
+    // ---- every record's own places: the block's base + the sums of the records before it in the block
+    if (tid < 64) {
+        const RecCnt mine = tid < nrec ? A.r_cnt[i0 + tid] : RecCnt{};
+        s_pre[tid] = cnt_add(base, wave_excl_cnt(mine));
+    }
+    __syncthreads();
+    LdsSrcK lsrc; lsrc.w = reinterpret_cast<const uint32_t *>(win);
+    GlbSrcK gsrc; gsrc.p = A.raw;
+    GlbOut gout;
+    LdsOut lout; lout.seq_w = reinterpret_cast<uint32_t *>(img_seq); lout.flag_w = reinterpret_cast<uint32_t *>(img_flag); lout.a16 = a16;
+    if (r < nrec) {
+        bool from_global = direct;                                  // long reads: the block's records do not fit the window
+        if (!direct) {
+            // a CIGAR that may live in the CG field (placeholder `<l_seq>S...`: hostio.cpp rec_parse) is walked by rec_load, from global memory
+            const unsigned long long o = ro - lo;
+            const uint32_t fn = lsrc.ld32(o + 16), l_name = lsrc.ld32(o + 12) & 0xffu;
+            const int32_t l_seq = (int32_t)lsrc.ld32(o + 20);
+            if ((fn & 0xffffu) > 0) { const uint32_t c0 = lsrc.ld32(o + 36 + l_name); from_global = (c0 & 15u) == C_S && (int32_t)(c0 >> 4) == l_seq; }
+        }
+        if (image) { if (from_global) emit_record(A, gsrc, lout, ro, s_pre[r], sub, f, smp, depth); else emit_record(A, lsrc, lout, ro - lo, s_pre[r], sub, f, smp, depth); }
+        else { if (from_global) emit_record(A, gsrc, gout, ro, s_pre[r], sub, f, smp, depth); else emit_record(A, lsrc, gout, ro - lo, s_pre[r], sub, f, smp, depth); }
+    }
+    if (!image) return;
+    __syncthreads();
+    // ---- the image out: whole 16-byte pieces of the columns where the block owns all of them, its own bytes / half bytes at the two ends
+    const DpSampleDst d = A.dst[smp_first];
+    {
+        const uint32_t n16 = ((uint32_t)b0 - a16 + 15u) >> 4;
+        for (uint32_t c = tid; c < n16; c += 256u) {
+            const uint32_t g0 = a16 + 16u * c;                      // byte of the seq column
+            const uint4 v = img_seq[c];
+            if (g0 >= (uint32_t)a0 && g0 + 16u <= (uint32_t)b0) *reinterpret_cast<uint4 *>(d.seq + g0) = v;
+            else {
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                for (uint32_t k = 0; k < 16u; k += 2u) if (g0 + k >= (uint32_t)a0 && g0 + k < (uint32_t)b0) { const uint16_t h = (uint16_t)(w[k >> 2] >> (8u * (k & 3u))); __builtin_memcpy(d.seq + g0 + k, &h, 2); }      // (pieces start and end on 2 bytes)
+            }
+        }
+        // flags: bits [2 a0, 2 b0) of the flag column = bytes from a16 / 4; a byte at an end may be half a neighbour's
+        const uint32_t fa = 2u * (uint32_t)a0, fbe = 2u * (uint32_t)b0, w_n = (fbe - 2u * a16 + 31u) >> 5;
+        const uint32_t *fw = reinterpret_cast<const uint32_t *>(img_flag);
+        for (uint32_t c = tid; c < w_n; c += 256u) {
+            const uint32_t bit0 = 2u * a16 + 32u * c, v = fw[c];
+            uint8_t *gp = d.qual + (bit0 >> 3);
+            if (bit0 >= fa && bit0 + 32u <= fbe) __builtin_memcpy(gp, &v, 4);
+            else for (uint32_t k = 0; k < 4u; ++k) {
+                const uint32_t lo_b = bit0 + 8u * k, byte = (v >> (8u * k)) & 0xffu;
+                if (lo_b >= fa && lo_b + 8u <= fbe) gp[k] = (uint8_t)byte;
+                else if (lo_b + 8u > fa && lo_b < fbe && byte) or_byte(gp + k, byte);      // half a byte is this block's (the other half is zero in the image)
+            }
+        }
     }
 }
 
 // per sample: where its records' pieces / seq bytes / intervals start, and the first pileup read (one small copy instead of three per sample)
 struct DpSampleSum { unsigned long long sbase0, first_key, beyond_key; uint32_t pbase0, ibase0, first_end, pad; };
-__global__ void msnv_sample_bases(const uint32_t *rec_base, uint32_t n_samples, const RecCnt *pre,
+__global__ void msnv_sample_bases(const uint32_t *rec_base, uint32_t n_samples, const RecCnt *blk_pre, const RecCnt *r_cnt,
                                   const DpAcc *acc, const unsigned long long *r_key, const uint32_t *r_end, DpSampleSum *out, unsigned long long *sbase0) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s > n_samples) return;
     DpSampleSum o{};
     const uint32_t i = rec_base[s];
-    o.sbase0 = pre[i].seqb; o.pbase0 = pre[i].npiece; o.ibase0 = pre[i].niv;
+    RecCnt pre = blk_pre[i / PB];
+    for (uint32_t j = i & ~(PB - 1u); j < i; ++j) pre = cnt_add(pre, r_cnt[j]);
+    o.sbase0 = pre.seqb; o.pbase0 = pre.npiece; o.ibase0 = pre.niv;
     sbase0[s] = o.sbase0;
     if (s < n_samples) {
         const DpAcc a = acc[(size_t)s * ACC_COPIES];              // (folded: msnv_acc_fold)
@@ -905,14 +1111,19 @@ __global__ void msnv_emit_tail(const DpSampleDst *dst, const unsigned long long 
 }
 
 // ------------------------------------------------------------------------------------------ tile order of the headers
-__global__ void msnv_tile_keys(const ReadHdr *hdr, const int32_t *ptid, const PieceSrc *psrc, uint32_t n, uint32_t tid_bits,
+__device__ __forceinline__ uint32_t piece_sample(const DpSampleDst *dst, uint32_t n_samples, uint32_t pc) {      // last sample whose first piece is at or before pc
+    uint32_t a = 0, b = n_samples;
+    while (b - a > 1) { const uint32_t m = (a + b) / 2; if ((uint32_t)dst[m].pbase0 <= pc) a = m; else b = m; }
+    return a;
+}
+__global__ void msnv_tile_keys(const ReadHdr *hdr, const int32_t *ptid, const DpSampleDst *dst, uint32_t n_samples, uint32_t n, uint32_t tid_bits,
                                unsigned long long *keys, uint32_t *idx, uint32_t *unsorted) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const unsigned long long k = ((unsigned long long)(psrc[i].sample_len & 0xffffu) << tid_bits | (uint32_t)ptid[i]) << 21 | (hdr[i].gpos / TILE);
+    const unsigned long long k = ((unsigned long long)piece_sample(dst, n_samples, i) << tid_bits | (uint32_t)ptid[i]) << 21 | (hdr[i].gpos / TILE);
     keys[i] = k; idx[i] = i;
     if (i > 0) {
-        const unsigned long long kp = ((unsigned long long)(psrc[i - 1].sample_len & 0xffffu) << tid_bits | (uint32_t)ptid[i - 1]) << 21 | (hdr[i - 1].gpos / TILE);
+        const unsigned long long kp = ((unsigned long long)piece_sample(dst, n_samples, i - 1) << tid_bits | (uint32_t)ptid[i - 1]) << 21 | (hdr[i - 1].gpos / TILE);
         if (kp > k) *unsorted = 1u;
     }
 }
@@ -1481,7 +1692,10 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     DP_BUF(uint32_t, d_maxc, NRa);
     DP_BUF(uint32_t, d_ftile, NRa);
     DP_BUF(RecCnt, d_cnt, NRa);
-    DP_BUF(RecCnt, d_pre, NRa);                                   // exclusive scan of d_cnt; entry NR = the round's totals
+    const uint64_t NB = ((uint64_t)NR + PB - 1) / PB, NBa = NB + 1;   // blocks of PB records: their sums and bases (entry NB of the bases = the round's totals)
+    DP_BUF(RecCnt, d_blkcnt, NBa);
+    DP_BUF(RecCnt, d_blkpre, NBa);
+    DP_BUF(uint32_t, d_outl, CAP_OUT);
     DP_BUF(uint16_t, d_depth, NRa);
     DP_BUF(uint32_t, d_ovr, NRa);
     DP_BUF(DpAcc, d_acc, S * ACC_COPIES);
@@ -1526,7 +1740,12 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     DevBuf o_flag, o_rank, o_skip, o_keys, o_skeys, o_vals, o_svals, o_starts;      // overlapping mates (paired reads only: not from the pool)
     uint32_t n_ovl_reads = 0, n_ovl_groups = 0;
     std::vector<uint8_t> host_sample(S, 0);                       // samples whose sequential edits ran on the host (pre-pass)
-    PScan *d_ps = nullptr; uint32_t *d_grpfirst = nullptr;
+    unsigned long long *d_rg = nullptr; uint2 *d_grppre = nullptr;
+    uint32_t span_out = SPAN_OUT;
+    {   // behind the last record: the end of the round's records (a block of records reaches from its first record's start to the next block's)
+        const unsigned long long end_all = S ? s_end[S - 1] : 0ull;
+        HIP_TRY(hipMemcpyAsync(d_recoff + NR, &end_all, 8, hipMemcpyHostToDevice, st));
+    }
     const size_t depth_bufs_from = pool.next;
     for (int pass = 0; pass < 2; ++pass) {
         pool.next = depth_bufs_from;
@@ -1537,71 +1756,81 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
             HIP_TRY(hipStreamSynchronize(st));
         }
         HIP_TRY(hipMemsetAsync(d_depth, 0, NRa * 2, st));
-        HIP_TRY(hipMemsetAsync(d_cnt + NR, 0, sizeof(RecCnt), st));
-        HIP_TRY(hipMemsetAsync(d_misc, 0, MISC_WORDS * 4, st));
+        uint32_t misc_h[MISC_WORDS] = {0, 0, 0, 0};
         tm.start();
-        if (NR) {
-            hipLaunchKernelGGL(msnv_measure_reads, grid_for(NR, 256), dim3(256), 0, st, raw, d_recoff, d_recsample, d_recbase, d_send, NR, ctg, P, have_ovr ? d_ovr : nullptr, d_flags,
-                               d_key, d_end, d_maxc, d_cnt, d_ftile, d_acc, d_misc);
-            HIP_TRY(hipGetLastError());
+        for (;;) {
+            HIP_TRY(hipMemsetAsync(d_misc, 0, MISC_WORDS * 4, st));
+            HIP_TRY(hipMemsetAsync(d_blkcnt + NB, 0, sizeof(RecCnt), st));
+            if (NR) {
+                hipLaunchKernelGGL(msnv_measure_reads, grid_for(NR, 256), dim3(256), 0, st, raw, d_recoff, d_recsample, d_recbase, d_send, NR, ctg, P, have_ovr ? d_ovr : nullptr, d_flags,
+                                   d_key, d_end, d_maxc, d_cnt, d_ftile, d_blkcnt, d_acc, d_misc, d_outl, span_out);
+                HIP_TRY(hipGetLastError());
+            }
+            {   // every block's base: rank among the pileup reads, first piece, first interval, next-tile pieces before it, first seq byte
+                size_t need = 0;
+                HIP_TRY(rocprim::exclusive_scan(nullptr, need, d_blkcnt, d_blkpre, RecCnt{}, (size_t)NBa, RecCntSum(), st));
+                if (int rc = tmp_for(need)) return rc;
+                HIP_TRY(rocprim::exclusive_scan(d_tmp, need, d_blkcnt, d_blkpre, RecCnt{}, (size_t)NBa, RecCntSum(), st));
+            }
+            HIP_TRY(hipMemcpyAsync(&tot, d_blkpre + NB, sizeof(RecCnt), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(misc_h, d_misc, MISC_WORDS * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (misc_h[MISC_NOUT] <= CAP_OUT || span_out >= 0x40000000u) break;
+            // more far-reaching reads than the list holds (long reads): they are the ordinary reads of this round -- a wider window, again
+            span_out = span_out < 0x04000000u ? span_out * 16u : 0x7fffffffu;
+            DpAcc a{}; a.err = a.first_pile = a.beyond = ~0ull;
+            std::vector<DpAcc> init(S * ACC_COPIES, a);
+            HIP_TRY(hipMemcpyAsync(d_acc, init.data(), init.size() * sizeof(DpAcc), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));
         }
-        {   // every record's rank among the pileup reads, first piece, first interval, next-tile pieces before it, first seq byte: one scan
-            size_t need = 0;
-            HIP_TRY(rocprim::exclusive_scan(nullptr, need, d_cnt, d_pre, RecCnt{}, (size_t)NRa, RecCntSum(), st));
-            if (int rc = tmp_for(need)) return rc;
-            HIP_TRY(rocprim::exclusive_scan(d_tmp, need, d_cnt, d_pre, RecCnt{}, (size_t)NRa, RecCntSum(), st));
-        }
-        HIP_TRY(hipMemcpyAsync(&tot, d_pre + NR, sizeof(RecCnt), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
         NP = tot.pile;
         T.ms_measure += tm.stop();
         // ---- depth at every read start; the runs and the (run, first tile) groups of reads
         n_runs = 0; n_groups = 0;
         if (NP) {
             const uint64_t NPa = (uint64_t)NP + 1;
-            DP_BUF(unsigned long long, d_pkey, NPa);
-            DP_BUF(uint32_t, d_ppos, NPa);
-            DP_BUF(uint32_t, d_pend, NPa);
-            DP_BUF(uint32_t, d_pmaxc, NPa);
+            DP_BUF(uint4, d_prd, NPa);
             DP_BUF(uint32_t, d_pftile, NPa);
             DP_BUF(uint32_t, d_prec, NPa);
-            DP_BUF(PScan, d_ps_, NPa);
-            d_ps = d_ps_;
+            DP_BUF(unsigned long long, d_rg_, NPa);
+            d_rg = d_rg_;
             tm.start();
-            hipLaunchKernelGGL(msnv_pile_gather, grid_for(NR, 256), dim3(256), 0, st, d_cnt, d_pre, NR, d_recsample, d_key, d_end, d_maxc, d_ftile, d_pkey, d_ppos, d_pend, d_pmaxc, d_pftile, d_prec);
+            hipLaunchKernelGGL(msnv_pile_gather, grid_for(NR, 256), dim3(256), 0, st, d_cnt, d_blkpre, NR, d_recsample, d_key, d_end, d_maxc, d_ftile, span_out, d_prd, d_pftile, d_prec);
             HIP_TRY(hipGetLastError());
             {
-                auto in = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), PScanIn{d_pkey, d_pend, d_pftile});
+                auto in = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), RunGrpIn{d_prd, d_pftile});
                 size_t need = 0;
-                HIP_TRY(rocprim::inclusive_scan(nullptr, need, in, d_ps, (size_t)NP, PScanOp(), st));
+                HIP_TRY(rocprim::inclusive_scan(nullptr, need, in, d_rg, (size_t)NP, rocprim::plus<unsigned long long>(), st));
                 if (int rc = tmp_for(need)) return rc;
-                HIP_TRY(rocprim::inclusive_scan(d_tmp, need, in, d_ps, (size_t)NP, PScanOp(), st));
+                HIP_TRY(rocprim::inclusive_scan(d_tmp, need, in, d_rg, (size_t)NP, rocprim::plus<unsigned long long>(), st));
             }
-            PScan last{};
-            HIP_TRY(hipMemcpyAsync(&last, d_ps + (NP - 1), sizeof(PScan), hipMemcpyDeviceToHost, st));
+            unsigned long long last = 0;
+            HIP_TRY(hipMemcpyAsync(&last, d_rg + (NP - 1), 8, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
-            n_runs = last.runs; n_groups = last.grps;
+            n_runs = (uint32_t)(last >> 32); n_groups = (uint32_t)last;
             DP_BUF(uint32_t, d_runfirst, (uint64_t)n_runs + 1);
             DP_BUF(uint32_t, d_runf1, (uint64_t)n_runs + 1);
             DP_BUF(DpRun, d_runs, (uint64_t)n_runs + 1);
-            DP_BUF(uint32_t, d_grpfirst_, (uint64_t)n_groups + 2);
+            DP_BUF(uint32_t, d_grpfirst, (uint64_t)n_groups + 2);
             DP_BUF(uint32_t, d_grpmd, 2 * ((uint64_t)n_groups + 1));
+            DP_BUF(uint2, d_grppre_, (uint64_t)n_groups + 2);
             DP_BUF(DevGroupRec, d_groups, (uint64_t)n_groups + 1);
-            d_grpfirst = d_grpfirst_;
+            d_grppre = d_grppre_;
             HIP_TRY(hipMemsetAsync(d_runf1, 0xff, ((uint64_t)n_runs + 1) * 4, st));
             HIP_TRY(hipMemsetAsync(d_grpmd, 0, 2 * ((uint64_t)n_groups + 1) * 4, st));
-            HIP_TRY(hipMemcpyAsync(d_grpfirst + n_groups, &NR, 4, hipMemcpyHostToDevice, st));      // behind the last group: the round's record count (pre[NR] = totals)
-            hipLaunchKernelGGL(msnv_depth, grid_for(NP, 256), dim3(256), 0, st, d_ps, NP, d_pkey, d_ppos, d_pend, d_pmaxc, d_pftile, d_prec, d_cnt, have_ovr ? d_ovr : nullptr, P, d_depth,
-                               d_runfirst, d_runf1, d_grpfirst, d_grpmd, d_acc, d_misc);
-            hipLaunchKernelGGL(msnv_run_table, grid_for(n_runs, 256), dim3(256), 0, st, n_runs, d_runfirst, d_runf1, d_pkey, d_ppos, d_runs);
-            hipLaunchKernelGGL(msnv_group_table, grid_for(n_groups, 256), dim3(256), 0, st, n_groups, d_grpfirst, d_pre, d_recsample, d_key, d_ftile, d_grpmd, d_groups);
+            const uint32_t n_out = std::min<uint32_t>(misc_h[MISC_NOUT], CAP_OUT);
+            hipLaunchKernelGGL(msnv_depth, grid_for(NP, 256), dim3(256), 0, st, d_rg, NP, d_prd, d_pftile, d_prec, d_cnt, have_ovr ? d_ovr : nullptr, P, misc_h[MISC_SPAN],
+                               d_outl, n_out, d_recsample, d_key, d_end, d_maxc, d_depth, d_runfirst, d_runf1, d_grpfirst, d_grpmd, d_acc, d_misc);
+            hipLaunchKernelGGL(msnv_run_table, grid_for(n_runs, 256), dim3(256), 0, st, n_runs, d_runfirst, d_runf1, d_prd, d_runs);
+            hipLaunchKernelGGL(msnv_group_pre, grid_for((uint64_t)n_groups + 1, 256), dim3(256), 0, st, n_groups, d_grpfirst, NR, d_blkpre, d_cnt, d_grppre);
+            hipLaunchKernelGGL(msnv_group_table, grid_for(n_groups, 256), dim3(256), 0, st, n_groups, d_grpfirst, d_grppre, d_recsample, d_key, d_ftile, d_grpmd, d_groups);
             HIP_TRY(hipGetLastError());
             runs.resize(n_runs); groups.resize(n_groups);
             HIP_TRY(hipMemcpyAsync(runs.data(), d_runs, (size_t)n_runs * sizeof(DpRun), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipMemcpyAsync(groups.data(), d_groups, (size_t)n_groups * sizeof(DevGroupRec), hipMemcpyDeviceToHost, st));
             T.ms_depth += tm.stop();
         } else { runs.clear(); groups.clear(); }
-        hipLaunchKernelGGL(msnv_acc_fold, grid_for(S, 64), dim3(64), 0, st, d_acc, (uint32_t)S);
+        hipLaunchKernelGGL(msnv_acc_fold, dim3((unsigned)S), dim3(64), 0, st, d_acc, (uint32_t)S);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpy2DAsync(acc.data(), sizeof(DpAcc), d_acc, sizeof(DpAcc) * ACC_COPIES, sizeof(DpAcc), S, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(&need_sort, d_misc + MISC_SORT, 4, hipMemcpyDeviceToHost, st));
@@ -1716,7 +1945,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     DP_BUF(DpSampleSum, d_sum, S + 1);
     DP_BUF(unsigned long long, d_ss0, S + 1);
     tm.start();
-    hipLaunchKernelGGL(msnv_sample_bases, grid_for(S + 1, 64), dim3(64), 0, st, d_recbase, (uint32_t)S, d_pre, d_acc, d_key, d_end, d_sum, d_ss0);
+    hipLaunchKernelGGL(msnv_sample_bases, grid_for(S + 1, 64), dim3(64), 0, st, d_recbase, (uint32_t)S, d_blkpre, d_cnt, d_acc, d_key, d_end, d_sum, d_ss0);
     HIP_TRY(hipGetLastError());
     std::vector<DpSampleSum> sum(S + 1);
     HIP_TRY(hipMemcpyAsync(sum.data(), d_sum, (S + 1) * sizeof(DpSampleSum), hipMemcpyDeviceToHost, st));
@@ -1740,7 +1969,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     HIP_TRY(hipMemsetAsync(r_qual, 0, qual_total + 64, st));
     std::vector<DpSampleDst> dsts(S);
     for (size_t s = 0; s < S; ++s) dsts[s] = DpSampleDst{r_seq + seq_off[s], r_qual + seq_off[s] / 4, sum[s].pbase0, cut_marks[s], 0u};
-    const uint64_t NPCa = (uint64_t)NPC + 1, NIVa = (uint64_t)NIV + 1;
+    const uint64_t NPCa = (uint64_t)NPC + 1;
     // what stays in HBM of the round besides the columns: headers (tile order) and intervals, for finalize -- written where they stay
     DevRound keep;
     {
@@ -1760,7 +1989,6 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     }
     DP_BUF(DpSampleDst, d_dst, S);
     DP_BUF(unsigned long long, d_pb, S);
-    DP_BUF(PieceSrc, d_psrc, NPCa);
     // (the general route keeps the headers in file order first: work buffers, sorted into `keep` below)
     ReadHdr *w_hdr = keep.hdr; int32_t *w_tid = keep.tid, *w_end = keep.end; uint16_t *w_depth = keep.depth;
     if (in_order) {
@@ -1773,16 +2001,17 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     HIP_TRY(hipMemcpyAsync(d_dst, dsts.data(), S * sizeof(DpSampleDst), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_pb, piece_bytes.data(), S * 8, hipMemcpyHostToDevice, st));
     if (NR) {
-        hipLaunchKernelGGL(msnv_emit_headers, grid_for(NR, 256), dim3(256), 0, st, raw, d_recoff, d_recsample, NR, ctg, d_flags, d_depth, d_pre, d_ss0, d_ps, d_grpfirst, in_order ? 1u : 0u,
-                           w_hdr, w_tid, w_end, w_depth, d_psrc, keep.cov_tid, keep.cov_beg, keep.cov_end, T.overhang, T.any_overhang, (P.c_eff == 0 && !P.all_low) ? 1u : 0u);
-        HIP_TRY(hipGetLastError());
-    }
-    if (NPC) {
-        hipLaunchKernelGGL(msnv_emit_pieces, grid_for((uint64_t)NPC * 4, 256), dim3(256), 0, st, raw, T.pref4, P, NPC, d_psrc, d_dst, d_acc);
+        EmitArgs A{};
+        A.raw = raw; A.rec_off = d_recoff; A.rec_sample = d_recsample; A.n_rec = NR; A.ctg = ctg; A.r_flags = d_flags; A.r_depth = d_depth; A.r_cnt = d_cnt; A.blk_pre = d_blkpre;
+        A.samp_sbase0 = d_ss0; A.rg = d_rg; A.grp_pre = d_grppre; A.in_order = in_order ? 1u : 0u;
+        A.hdr = w_hdr; A.ptid = w_tid; A.pend = w_end; A.pdepth = w_depth; A.cov_tid = keep.cov_tid; A.cov_beg = keep.cov_beg; A.cov_end = keep.cov_end;
+        A.overhang = T.overhang; A.any_overhang = T.any_overhang; A.noseq_counts = (P.c_eff == 0 && !P.all_low) ? 1u : 0u;
+        A.pref4 = T.pref4; A.P = P; A.dst = d_dst; A.acc = d_acc;
+        hipLaunchKernelGGL(msnv_emit_block, dim3((unsigned)NB), dim3(256), 0, st, A);
         HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(msnv_emit_tail, dim3((unsigned)S), dim3(64), 0, st, d_dst, d_pb, (uint32_t)S, P);
-    hipLaunchKernelGGL(msnv_acc_fold, grid_for(S, 64), dim3(64), 0, st, d_acc, (uint32_t)S);
+    hipLaunchKernelGGL(msnv_acc_fold, dim3((unsigned)S), dim3(64), 0, st, d_acc, (uint32_t)S);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy2DAsync(acc.data(), sizeof(DpAcc), d_acc, sizeof(DpAcc) * ACC_COPIES, sizeof(DpAcc), S, hipMemcpyDeviceToHost, st));
     T.ms_emit += tm.stop();
@@ -1797,7 +2026,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
         DP_BUF(uint32_t, d_uns, 4);
         HIP_TRY(hipMemsetAsync(d_uns, 0, 4, st));
         const unsigned tid_bits = std::max(1u, bit_width_u64(NC ? NC - 1 : 0));
-        hipLaunchKernelGGL(msnv_tile_keys, grid_for(NPC, 256), dim3(256), 0, st, w_hdr, w_tid, d_psrc, NPC, tid_bits, d_tk, d_ix, d_uns);
+        hipLaunchKernelGGL(msnv_tile_keys, grid_for(NPC, 256), dim3(256), 0, st, w_hdr, w_tid, d_dst, (uint32_t)S, NPC, tid_bits, d_tk, d_ix, d_uns);
         HIP_TRY(hipGetLastError());
         uint32_t uns = 0;
         HIP_TRY(hipMemcpyAsync(&uns, d_uns, 4, hipMemcpyDeviceToHost, st));
