@@ -252,6 +252,14 @@ int  msnv_dataset_add_sample_records_many(msnv_dataset *ds, const uint8_t *const
  * host threads: pack.cpp, the same bytes).  The three sequential edits -- depth cap, overlapping-mate tweak, snpCall's token
  * limit -- are a host pre-pass over the samples whose records can trigger them. */
 int  msnv_dataset_add_sample_records_device(msnv_dataset *ds, const void *const *dev_records, const uint64_t *n_bytes, int32_t n);
+/* ... and WITHOUT the copy (round 5), for streams that lie in ONE device buffer the caller hands over for the duration of the call:
+ * stream i = bytes [offsets[i], offsets[i] + n_bytes[i]) of `dev_buffer` (capacity bytes).  The buffer must start on 16 bytes and hold
+ * at least 256 readable bytes behind the last stream's end (the kernels read whole 16-byte pieces around a record); the streams must not
+ * overlap and must come in ascending order.  The library reads the records where they lie and MAY EDIT base qualities in place (htslib's
+ * overlapping-mate tweak, snpCall's token limit: what the reference tools do to their own copy of a record, sam.c [EXT],
+ * call_vC.cpp:481-483): the buffer's contents are the library's until the call returns.  What the device inflate leaves in HBM goes
+ * this way, and the bench's "records resident in HBM -> calls" region starts here. */
+int  msnv_dataset_add_sample_records_resident(msnv_dataset *ds, void *dev_buffer, uint64_t capacity, const uint64_t *offsets, const uint64_t *n_bytes, int32_t n);
 int  msnv_dataset_add_sample_bam(msnv_dataset *ds, const char *bam_path);
 /* Decode many BAMs with a host thread pool, preserving order. */
 int  msnv_dataset_add_sample_bams(msnv_dataset *ds, const char *const *bam_paths, int32_t n, int32_t host_threads);

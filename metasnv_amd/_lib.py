@@ -128,6 +128,7 @@ SYMBOLS = [
     ("msnv_dataset_add_sample_records_many", C.c_int, [_vp, P(_vp), P(C.c_uint64), C.c_int32, C.c_int32]),
     ("msnv_dataset_stage_sample_bams", C.c_int, [_vp, P(C.c_char_p), C.c_int32, C.c_int32]),
     ("msnv_dataset_add_sample_records_device", C.c_int, [_vp, P(_vp), P(C.c_uint64), C.c_int32]),
+    ("msnv_dataset_add_sample_records_resident", C.c_int, [_vp, _vp, C.c_uint64, P(C.c_uint64), P(C.c_uint64), C.c_int32]),
     ("msnv_dataset_pack_stats", C.c_int, [_vp, P(C.c_double), C.c_int32]),
     ("msnv_dataset_fetch_column", C.c_int, [_vp, C.c_char_p, _vp, C.c_uint64, P(C.c_uint64)]),
     ("msnv_dataset_add_sample_bam", C.c_int, [_vp, C.c_char_p]),

@@ -179,6 +179,17 @@ class Dataset:
         check(lib.msnv_dataset_add_sample_records_device(self._h, pa, sa, n))
         self.n_samples += n
 
+    def add_samples_records_resident(self, dev_buffer, capacity, offsets, sizes):
+        """Record streams inside ONE device buffer (16-byte aligned, 256 readable bytes behind the last stream), read where they lie --
+        no copy; qualities may be edited in place (msnv_dataset_add_sample_records_resident)."""
+        n = len(offsets)
+        if n == 0:
+            return
+        oa = (C.c_uint64 * n)(*[int(x) for x in offsets])
+        sa = (C.c_uint64 * n)(*[int(x) for x in sizes])
+        check(lib.msnv_dataset_add_sample_records_resident(self._h, C.c_void_p(int(dev_buffer)), int(capacity), oa, sa, n))
+        self.n_samples += n
+
     def pileup_qualities(self, records):
         """The record stream with the base qualities as the pileup engine sees them (overlap tweak, token limit)."""
         rec = np.ascontiguousarray(records, dtype=np.uint8)

@@ -186,7 +186,7 @@ static bool pack_on_device(const msnv_dataset *ds) {
     return !(e && e[0] == 'h');
 }
 // Appends n streams as n samples through the device pack, in rounds of at most MSNV_PACK_ROUND_MB (default 6144) of record bytes.
-static int add_streams_device(msnv_dataset *ds, const uint8_t *const *records, const uint64_t *n_bytes, int n, bool streams_on_device) {
+static int add_streams_device(msnv_dataset *ds, const uint8_t *const *records, const uint64_t *n_bytes, int n, bool streams_on_device, const uint8_t *in_place_base = nullptr, uint64_t in_place_capacity = 0) {
     HostTimerScope ts(HT_PACK_DEVICE_WALL);
     const uint64_t round_bytes = [] { const char *e = getenv("MSNV_PACK_ROUND_MB"); const long long v = e ? atoll(e) : 6144; return (uint64_t)std::max<long long>(1, v) << 20; }();
     const size_t first = ds->samples.size();
@@ -196,7 +196,7 @@ static int add_streams_device(msnv_dataset *ds, const uint8_t *const *records, c
         for (int i0 = 0; i0 < n && !rc;) {
             int i1 = i0; uint64_t b = 0;
             while (i1 < n && i1 - i0 < 2048 && (i1 == i0 || b + n_bytes[i1] <= round_bytes)) { b += n_bytes[i1]; ++i1; }
-            rc = devpack_add_round(*ds, first + (size_t)i0, records + i0, n_bytes + i0, i1 - i0, streams_on_device);
+            rc = devpack_add_round(*ds, first + (size_t)i0, records + i0, n_bytes + i0, i1 - i0, streams_on_device, in_place_base, in_place_capacity);
             i0 = i1;
         }
     } catch (const std::exception &e) { rc = fail(MSNV_ENOMEM, "packing on the device failed: %s", e.what()); }
@@ -211,6 +211,24 @@ extern "C" int msnv_dataset_add_sample_records_device(msnv_dataset *ds, const vo
     if (!ds->ctx) return fail(MSNV_ENODEV, "msnv_dataset_add_sample_records_device: the dataset has no device context");
     for (int i = 0; i < n; ++i) if (n_bytes[i] && !dev_records[i]) return fail(MSNV_EINVAL, "msnv_dataset_add_sample_records_device: stream %d is NULL", i);
     return add_streams_device(ds, reinterpret_cast<const uint8_t *const *>(dev_records), n_bytes, n, true);
+}
+
+extern "C" int msnv_dataset_add_sample_records_resident(msnv_dataset *ds, void *dev_buffer, uint64_t capacity, const uint64_t *offsets, const uint64_t *n_bytes, int32_t n) {
+    clear_error();
+    if (!ds || n < 0 || (n && (!dev_buffer || !offsets || !n_bytes))) return fail(MSNV_EINVAL, "msnv_dataset_add_sample_records_resident: bad argument");
+    if (ds->finalized) return fail(MSNV_EINVAL, "dataset is already finalized");
+    if (!ds->ctx) return fail(MSNV_ENODEV, "msnv_dataset_add_sample_records_resident: the dataset has no device context");
+    if (!ds->staged.empty()) return fail(MSNV_EINVAL, "the dataset holds staged streams (msnv_dataset_stage_sample_bams): they are packed last, by msnv_dataset_finalize");
+    if (reinterpret_cast<uintptr_t>(dev_buffer) & 15u) return fail(MSNV_EINVAL, "msnv_dataset_add_sample_records_resident: the buffer must start on 16 bytes");
+    uint64_t prev_end = 0;
+    for (int i = 0; i < n; ++i) {
+        if (offsets[i] < prev_end || offsets[i] + n_bytes[i] < offsets[i] || offsets[i] + n_bytes[i] + 256 > capacity)
+            return fail(MSNV_EINVAL, "msnv_dataset_add_sample_records_resident: stream %d must follow the one before it and leave 256 bytes of the buffer behind it", i);
+        prev_end = offsets[i] + n_bytes[i];
+    }
+    std::vector<const uint8_t *> ptrs((size_t)n);
+    for (int i = 0; i < n; ++i) ptrs[(size_t)i] = static_cast<const uint8_t *>(dev_buffer) + offsets[i];
+    return add_streams_device(ds, ptrs.data(), n_bytes, n, true, static_cast<const uint8_t *>(dev_buffer), capacity);
 }
 
 extern "C" int msnv_dataset_add_sample_records(msnv_dataset *ds, const uint8_t *records, uint64_t n_bytes) {
@@ -487,11 +505,19 @@ static int bgzf_read_files_device(msnv_ctx *ctx, const char *const *paths, int n
         const uint32_t check_every = inflate_check_every();       // (one reading for both decoders: msnv_internal.h)
         if (!host_batch) {
             HostTimerScope ts(HT_INFLATE_DEVICE_WALL);
-            if (int rc = res ? dev_inflate_resident(ctx, in_stage, ib, list, blk_in_file, check_every, status, &ms) : dev_inflate(ctx, ib, list, ob, status, &ms)) {
+            int rc = MSNV_OK;
+            if (res && getenv("MSNV_TEST_RESIDENT_FAIL")) rc = fail_quiet(MSNV_ENOMEM, "resident inflate refused (MSNV_TEST_RESIDENT_FAIL)");      // (tests: the fallback below)
+            else rc = res ? dev_inflate_resident(ctx, in_stage, ib, list, blk_in_file, check_every, status, &ms) : dev_inflate(ctx, ib, list, ob, status, &ms);
+            if (rc) {
                 if (rc != MSNV_ENOMEM && rc != MSNV_EHIP) return rc;
                 fprintf(stderr, "libmsnv: the device inflate failed (%s); this batch is inflated on the host\n", msnv_last_error());
                 clear_error();
                 host_batch = true;
+                // (a resident batch has no host copy of its output yet: the host decoder needs one -- round 4 wrote through a NULL pointer here)
+                if (res) {
+                    if (host_out.size() < ob + 64) { if (!host_out.alloc(ob + 64)) return fail(MSNV_ENOMEM, "out of memory for %llu inflated bytes", (unsigned long long)ob); }
+                    out = host_out.data();
+                }
             }
         }
         if (host_batch) status.assign(list.size(), 1u);
@@ -712,7 +738,14 @@ static int add_bams_device_pack(msnv_dataset *ds, const char *const *bam_paths, 
                 ptrs.push_back(base + ext[(size_t)(i - f0)].off + rec_off);
                 sizes.push_back(size - rec_off);
             }
-            return add_streams_device(ds, ptrs.data(), sizes.data(), f1 - f0, dev_valid);
+            // in HBM: the records are read where the inflate kernel wrote them (no copy into a round buffer) when the batch's buffer leaves
+            // the kernels' read-ahead room behind its last stream
+            bool in_place = dev_valid && !(reinterpret_cast<uintptr_t>(base) & 15u) && !getenv("MSNV_PACK_COPY");
+            for (size_t k = 0; k < ptrs.size() && in_place; ++k) {
+                if (k > 0 && ptrs[k] < ptrs[k - 1] + sizes[k - 1]) in_place = false;
+                if ((uint64_t)(ptrs[k] - base) + sizes[k] + 256 > ds->ctx->dev_out_cap) in_place = false;
+            }
+            return add_streams_device(ds, ptrs.data(), sizes.data(), f1 - f0, dev_valid, in_place ? base : nullptr, in_place ? ds->ctx->dev_out_cap : 0);
         };
         int rc;
         try { uint64_t cnt[4]; rc = bgzf_read_files_device(ds->ctx, bam_paths, n, nthreads, consume, cnt, &rb); }

@@ -15,7 +15,9 @@ namespace msnv {
 // One round of samples: streams[i] (n_bytes[i] bytes of alignment records, on the host or -- on_device -- in HBM of the dataset's device)
 // become ds.samples[first + i].  The headers, intervals and per-sample summaries come back to the host (finalize_dataset builds the tile
 // index from them); bases and quality bits stay in HBM.
-int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *streams, const uint64_t *n_bytes, int n, bool on_device);
+// in_place_base != NULL (streams on the device, all inside [in_place_base, + in_place_capacity), 16-byte aligned base, 256 readable bytes behind
+// the last stream): the records are read where they lie, no copy into a round buffer (qualities may be edited there).
+int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *streams, const uint64_t *n_bytes, int n, bool on_device, const uint8_t *in_place_base = nullptr, uint64_t in_place_capacity = 0);
 // A device-packed sample's bases and quality flags as host staging (SampleCols::seq / qual), for the two re-layouts that still run on
 // the host (pack.cpp: relayout_dense, split_deep_runs' relocation).
 int devpack_sample_to_host(SampleCols &sc);

@@ -1314,14 +1314,23 @@ struct ScanResult {
     uint32_t *d_recbase = nullptr; unsigned long long *d_send = nullptr, *d_recoff = nullptr; uint16_t *d_recsample = nullptr;
     double wall_upload_s = 0, ms_scan = 0; uint64_t n_redone = 0;
 };
-static int scan_streams(hipStream_t st, const int device, BufPool &pool, const uint8_t *const *streams, const uint64_t *n_bytes, const size_t S, const bool on_device, const int NC_, ScanResult &R) {
+static int scan_streams(hipStream_t st, const int device, BufPool &pool, const uint8_t *const *streams, const uint64_t *n_bytes, const size_t S, const bool on_device, const int NC_, ScanResult &R,
+                        const uint8_t *in_place_base = nullptr, uint64_t in_place_capacity = 0) {
     const size_t NC = (size_t)NC_;
     Timer tm(st);
     // ---- the round's streams side by side in one buffer: every stream starts on 16 bytes, readable bytes behind the last
     std::vector<unsigned long long> &s_beg = R.s_beg, &s_end = R.s_end; s_beg.assign(S, 0); s_end.assign(S, 0);
     uint64_t raw_bytes = 0;
+    uint8_t *raw = nullptr;
+    if (in_place_base) {
+        // the streams where they lie: offsets into the caller's buffer (api.cpp has checked order, alignment of the base and the bytes behind the last)
+        for (size_t s = 0; s < S; ++s) { s_beg[s] = (unsigned long long)(streams[s] - in_place_base); s_end[s] = s_beg[s] + n_bytes[s]; }
+        raw = const_cast<uint8_t *>(in_place_base);
+        for (size_t s = 0; s < S; ++s) raw_bytes += n_bytes[s];     // (accounting: the records' bytes)
+    } else {
     for (size_t s = 0; s < S; ++s) { s_beg[s] = raw_bytes; s_end[s] = raw_bytes + n_bytes[s]; raw_bytes += (n_bytes[s] + 15 + 16) & ~15ull; }
-    DP_BUF(uint8_t, raw, raw_bytes + 256);
+    DP_BUF(uint8_t, raw_, raw_bytes + 256);
+    raw = raw_;
     {
         const double t0 = now_s();
         if (on_device) {
@@ -1341,6 +1350,7 @@ static int scan_streams(hipStream_t st, const int device, BufPool &pool, const u
             if (bad.load()) return fail(MSNV_EHIP, "upload of the record streams failed: %s", hipGetErrorString(hipGetLastError()));
         }
         R.wall_upload_s += now_s() - t0;
+    }
     }
     R.raw = raw; R.raw_bytes = raw_bytes;
 
@@ -1649,7 +1659,7 @@ int records_deal_device(msnv_ctx *ctx, const uint8_t *const *streams, const uint
 #undef DP_BUF
 }
 
-int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *streams, const uint64_t *n_bytes, int n, bool on_device) {
+int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *streams, const uint64_t *n_bytes, int n, bool on_device, const uint8_t *in_place_base, uint64_t in_place_capacity) {
     if (n <= 0) return MSNV_OK;
     if (n > 2048) return fail(MSNV_EINVAL, "internal: a device-pack round holds at most 2048 samples");
     if (!ds.ctx) return fail(MSNV_ENODEV, "the device pack needs a device context");
@@ -1674,7 +1684,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
 
     // ---- the round's streams side by side in one buffer, their record boundaries (scan_streams)
     ScanResult SR;
-    if (int rc = scan_streams(st, ds.ctx->device, pool, streams, n_bytes, S, on_device, (int)NC, SR)) return rc;
+    if (int rc = scan_streams(st, ds.ctx->device, pool, streams, n_bytes, S, on_device, (int)NC, SR, in_place_base, in_place_capacity)) return rc;
     T.wall_upload_s += SR.wall_upload_s; T.raw_bytes += SR.raw_bytes; T.ms_scan += SR.ms_scan; T.n_scan_redone += SR.n_redone; T.n_records += SR.NR;
     uint8_t *const raw = SR.raw;
     const uint64_t raw_bytes = SR.raw_bytes; (void)raw_bytes;

@@ -340,7 +340,7 @@ int dev_inflate_staging(msnv_ctx *ctx, uint64_t in_bytes, uint64_t out_bytes, ui
     if (int rc = grow(&ctx->pin_in, &ctx->pin_in_cap, in_bytes + 64, true)) return rc;
     if (int rc = grow(&ctx->pin_out, &ctx->pin_out_cap, out_bytes + 64, true)) return rc;
     if (int rc = grow(&ctx->dev_in, &ctx->dev_in_cap, in_bytes + 64, false)) return rc;
-    if (int rc = grow(&ctx->dev_out, &ctx->dev_out_cap, out_bytes + 64, false)) return rc;
+    if (int rc = grow(&ctx->dev_out, &ctx->dev_out_cap, out_bytes + 512, false)) return rc;      // (+ read-ahead room of the kernels that take the records where they lie: devpack.hip)
     *in = (uint8_t *)ctx->pin_in; *out = (uint8_t *)ctx->pin_out;
     return MSNV_OK;
 }
@@ -435,7 +435,7 @@ int dev_inflate_device_buffers(msnv_ctx *ctx, uint64_t in_bytes, uint64_t out_by
         return MSNV_OK;
     };
     if (int rc = grow(&ctx->dev_in, &ctx->dev_in_cap, in_bytes + 8)) return rc;       // (+8: the trailer of the last block is read as four bytes behind its payload; files carry 16 bytes of slack anyway)
-    return grow(&ctx->dev_out, &ctx->dev_out_cap, out_bytes + 8);
+    return grow(&ctx->dev_out, &ctx->dev_out_cap, out_bytes + 512);      // (+ read-ahead room of the kernels that take the records where they lie: devpack.hip)
 }
 
 // A batch inflated AND checked on the device, the output left in ctx->dev_out: `host_in` (pageable) goes up, the blocks are inflated, every

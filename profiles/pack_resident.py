@@ -28,22 +28,24 @@ def main():
     syn = core.Synth(sp)
     ctx = core.Context(0)
     hip = C.CDLL("libamdhip64.so")
-    ptrs, sizes = [], []
-    for i in range(sp.n_samples):
-        r = syn.sample_records(i)
-        p = C.c_void_p()
-        assert hip.hipMalloc(C.byref(p), C.c_size_t(max(16, r.size + 64))) == 0
+    recs = [syn.sample_records(i) for i in range(sp.n_samples)]
+    offs, sizes, o = [], [], 0
+    for r in recs:
+        offs.append(o); sizes.append(int(r.size)); o += (int(r.size) + 15) & ~15
+    cap = o + 256
+    buf = C.c_void_p()
+    assert hip.hipMalloc(C.byref(buf), C.c_size_t(cap)) == 0
+    for r, off in zip(recs, offs):
         if r.size:
-            assert hip.hipMemcpy(p, C.c_void_p(r.ctypes.data), C.c_size_t(r.size), 1) == 0
-        ptrs.append(p.value); sizes.append(int(r.size))
-        del r
+            assert hip.hipMemcpy(C.c_void_p(buf.value + off), C.c_void_p(r.ctypes.data), C.c_size_t(r.size), 1) == 0
+    del recs
     hip.hipDeviceSynchronize()
     time.sleep(0.5)
     out = {"workload": label, "record_bytes": int(sum(sizes)), "reps": []}
     for rep in range(reps):
         ds = core.Dataset(ctx, syn.names, syn.lengths, syn.seqs)
         t0 = time.perf_counter()
-        ds.add_samples_records_device(ptrs, sizes)
+        ds.add_samples_records_resident(buf.value, cap, offs, sizes)
         t1 = time.perf_counter()
         info = ds.finalize()
         t2 = time.perf_counter()

@@ -116,3 +116,43 @@ def iter_records(buf):
         qual = list(buf[p:p + l_seq])
         yield dict(tid=tid, pos=pos, mapq=mapq, flag=flag, cigar=cig, seq=seq, qual=qual, name=name)
         off += bs + 4
+
+
+def write_bam_py(path, names, lengths, record_bytes, rnd, header_text=None):
+    """A BAM written by PYTHON's zlib, not by the library's writer: BGZF members of varying payload sizes (1 byte .. 65280), each deflated
+    with another strategy / level / memory level (Z_FIXED, Z_RLE, Z_HUFFMAN_ONLY, Z_FILTERED, stored level 0, sync-flushed multi-block
+    payloads), empty members in between, records and even the fixed 4-byte fields cut across members, the EOF marker at the end.  What
+    other BGZF writers (htslib with libdeflate, bgzip -l, samtools -1/-9, Picard's Java Deflater) produce differs from zlib level 6 in
+    exactly these ways: block split points, fixed vs dynamic codes, match-length / literal mixes."""
+    import struct
+    import zlib
+    text = (header_text if header_text is not None else "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % (n, l) for n, l in zip(names, lengths))).encode()
+    body = b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", len(names))
+    for n, l in zip(names, lengths):
+        nb = n.encode() + b"\0"
+        body += struct.pack("<i", len(nb)) + nb + struct.pack("<i", l)
+    body += bytes(record_bytes)
+    strategies = [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED]
+
+    def member(payload):
+        st = rnd.choice(strategies); lvl = rnd.choice([0, 1, 1, 4, 6, 6, 9]); mem = rnd.choice([1, 4, 8, 9])
+        c = zlib.compressobj(lvl, zlib.DEFLATED, -15, mem, st)
+        if len(payload) > 2000 and rnd.random() < 0.3:        # several deflate blocks in one member
+            cut = rnd.randrange(1, len(payload))
+            comp = c.compress(payload[:cut]) + c.flush(rnd.choice([zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH])) + c.compress(payload[cut:]) + c.flush()
+        else:
+            comp = c.compress(payload) + c.flush()
+        if len(comp) + 26 > 65536:                            # incompressible under this strategy: stored
+            c = zlib.compressobj(0, zlib.DEFLATED, -15)
+            comp = c.compress(payload) + c.flush()
+        bsize = len(comp) + 25
+        return (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", bsize) + comp + struct.pack("<II", zlib.crc32(payload) & 0xffffffff, len(payload)))
+    out = bytearray()
+    pos = 0
+    while pos < len(body):
+        n = rnd.choice([1, 3, 17, 300, 4000, 30000, 65280, 65280, 65280])
+        if len(body) - pos < n: n = len(body) - pos
+        out += member(body[pos:pos + n]); pos += n
+        if rnd.random() < 0.05: out += member(b"")              # an empty member in the middle of the file
+    out += member(b"")                                         # the EOF marker (an empty member)
+    open(path, "wb").write(out)

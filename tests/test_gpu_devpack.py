@@ -360,3 +360,44 @@ def test_records_dealt_on_the_device_equal_the_host_partition():
         core.deal_records_device(ctx, [samples[1]], np.zeros(nc, np.int32), 2, p.value, 64)
     assert e.value.code == core._lib.ECAPACITY
     hip.hipFree(p); hip.hipFree(p2); ctx.close()
+
+
+def test_streams_read_in_place_from_one_device_buffer():
+    """msnv_dataset_add_sample_records_resident: the streams lie at odd offsets of ONE padded device buffer and are packed where they lie
+    (no copy into a round buffer) -- the same dataset as the host pack builds; arguments that break the contract are refused."""
+    from metasnv_amd import _lib
+    syn, samples = synth_case(n_species=2, contig_len=7000, n_samples=6, mean_cov=9.0, snv_density=0.02, frac_paired=0.5, seed=33)
+    hip = C.CDLL("libamdhip64.so")
+    offs, sizes, o = [], [], 16
+    for smp in samples:
+        offs.append(o); sizes.append(int(smp.size)); o += int(smp.size) + 37          # (odd gaps: nothing of a stream is aligned)
+    cap = o + 256
+    buf = C.c_void_p()
+    assert hip.hipMalloc(C.byref(buf), C.c_size_t(cap)) == 0
+    for smp, off in zip(samples, offs):
+        a = np.ascontiguousarray(smp, dtype=np.uint8)
+        if a.size:
+            assert hip.hipMemcpy(C.c_void_p(buf.value + off), C.c_void_p(a.ctypes.data), C.c_size_t(a.size), 1) == 0
+    with _env(MSNV_PACK="host"):
+        ch = core.Context(0); dh = core.Dataset(ch, syn.names, syn.lengths, syn.seqs)
+        for smp in samples:
+            dh.add_sample_records(smp)
+        ih = dh.finalize()
+    cd = core.Context(0); dd = core.Dataset(cd, syn.names, syn.lengths, syn.seqs)
+    dd.add_samples_records_resident(buf.value, cap, offs, sizes)
+    idv = dd.finalize()
+    assert dd.pack_stats()["upload_wall_s"] == 0.0
+    for k in ("n_reads", "n_pileup_bases", "n_pairs", "n_work"):
+        assert ih[k] == idv[k], k
+    for col in COLUMNS:
+        assert np.array_equal(dh.column(col), dd.column(col)), col
+    dd.close()
+    d2 = core.Dataset(cd, syn.names, syn.lengths, syn.seqs)
+    with pytest.raises(_lib.MsnvError):
+        d2.add_samples_records_resident(buf.value + 4, cap - 4, offs, sizes)                 # base not on 16 bytes
+    with pytest.raises(_lib.MsnvError):
+        d2.add_samples_records_resident(buf.value, offs[-1] + sizes[-1] + 8, offs, sizes)   # no room behind the last stream
+    with pytest.raises(_lib.MsnvError):
+        d2.add_samples_records_resident(buf.value, cap, list(reversed(offs)), list(reversed(sizes)))   # not ascending
+    d2.close(); dh.close(); ch.close(); cd.close()
+    hip.hipFree(buf)

@@ -272,3 +272,58 @@ def test_bam_files_inflated_and_dealt_on_the_device(tmp_path, monkeypatch):
             ds.deal_bams_device(paths, owner, n_parts, d.value, cap, gap=gap)
         assert e.value.code == _lib.EDOMAIN
     hip.hipFree(d); ds.close(); ctx.close()
+
+
+def test_bam_files_written_by_another_deflate_writer(tmp_path, monkeypatch):
+    """Whole BAM files whose BGZF members come from Python's zlib with every strategy / level / flush mode and odd member sizes
+    (tests/bamtools.py: write_bam_py) -- not from the library's own writer -- through the device inflate + device pack, against the oracle
+    on the plain records; the host inflate reads the same files to the same calls."""
+    import random
+    import bamtools as bt
+    from parity import run_oracle
+    sp = core.synth_params(n_species=2, contig_len=30000, n_samples=5, mean_cov=12.0, frac_paired=0.3, snv_density=0.02, seed=77)
+    syn = core.Synth(sp)
+    fa = str(tmp_path / "ref.fa"); syn.write_fasta(fa)
+    rnd = random.Random(11)
+    paths, recs = [], []
+    for i in range(sp.n_samples):
+        p = str(tmp_path / ("p%d.bam" % i))
+        r = syn.sample_records(i); recs.append(r)
+        bt.write_bam_py(p, syn.names, syn.lengths, r.tobytes(), rnd); paths.append(p)
+    want = run_oracle(syn.names, syn.lengths, syn.seqs, recs)
+    ctx = core.Context(0)
+    for mode in ("device", "host"):
+        monkeypatch.setenv("MSNV_INFLATE", mode)
+        ds = core.Dataset.from_files(ctx, paths[0], fa)
+        ds.add_sample_bams(paths, 3)
+        info = ds.finalize(); ds.run()
+        ds.write_calls(str(tmp_path / ("c_" + mode)), str(tmp_path / ("i_" + mode)), None, None)
+        assert open(tmp_path / ("c_" + mode)).read() == want[0], mode
+        assert open(tmp_path / ("i_" + mode)).read() == want[1], mode
+        assert info["n_pileup_bases"] == want[3]
+        ds.close()
+    ctx.close()
+
+
+def test_resident_inflate_that_fails_falls_back_to_the_host_decoder(tmp_path, monkeypatch):
+    """The resident device inflate refusing a batch (no memory for its buffers, a HIP error) must hand the batch to the host decoder --
+    round 4 wrote the host decoder's output through a NULL pointer there (MSNV_TEST_RESIDENT_FAIL makes the call fail)."""
+    from parity import run_oracle
+    monkeypatch.setenv("MSNV_INFLATE", "device"); monkeypatch.setenv("MSNV_PACK", "device")
+    sp = core.synth_params(n_species=1, contig_len=20000, n_samples=3, mean_cov=10.0, snv_density=0.02, seed=5)
+    syn = core.Synth(sp)
+    fa = str(tmp_path / "ref.fa"); syn.write_fasta(fa)
+    paths = []
+    for i in range(sp.n_samples):
+        p = str(tmp_path / ("s%d.bam" % i)); core.write_bam(p, syn.names, syn.lengths, syn.sample_records(i), level=6); paths.append(p)
+    want = run_oracle(syn.names, syn.lengths, syn.seqs, [syn.sample_records(i) for i in range(sp.n_samples)])
+    ctx = core.Context(0)
+    monkeypatch.setenv("MSNV_TEST_RESIDENT_FAIL", "1")
+    t0 = core.host_timers()
+    ds = core.Dataset.from_files(ctx, paths[0], fa)
+    ds.add_sample_bams(paths, 2)
+    ds.finalize(); ds.run()
+    ds.write_calls(str(tmp_path / "c"), str(tmp_path / "i"), None, None)
+    assert core.host_timers()["inflate_host_s"] > t0["inflate_host_s"]
+    assert open(tmp_path / "c").read() == want[0]
+    ds.close(); ctx.close()
