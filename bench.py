@@ -105,6 +105,59 @@ def pileup_counters(samples, species, contig_len, mean_cov, kernel_ms):
     return None
 
 
+class ResidentRecords:
+    """The workload's raw alignment-record streams in ONE device buffer (16-byte aligned streams, 256 bytes of room behind the last): where
+    the "records resident in HBM -> calls" region starts.  Allocated through torch when this process already runs one (N ranks), else through
+    the HIP runtime the library itself is linked to."""
+
+    def __init__(self, syn, n_samples, device):
+        import ctypes as C
+        import numpy as np
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 8)) as ex:      # (the generator runs in the library, outside the GIL)
+            recs = list(ex.map(syn.sample_records, range(n_samples)))
+        self.offsets, self.sizes, o = [], [], 0
+        for r in recs:
+            self.offsets.append(o); self.sizes.append(int(r.size)); o += (int(r.size) + 15) & ~15
+        self.capacity = o + 256
+        self.bytes = int(sum(self.sizes))
+        if "torch" in sys.modules:
+            import torch
+            host = np.zeros(self.capacity, dtype=np.uint8)
+            for r, off in zip(recs, self.offsets):
+                host[off:off + r.size] = r
+            self._t = torch.from_numpy(host).to("cuda:%d" % device)
+            torch.cuda.synchronize()
+            self.ptr = self._t.data_ptr()
+        else:
+            hip = C.CDLL("libamdhip64.so")
+            assert hip.hipSetDevice(device) == 0
+            buf = C.c_void_p()
+            assert hip.hipMalloc(C.byref(buf), C.c_size_t(self.capacity)) == 0
+            for r, off in zip(recs, self.offsets):
+                if r.size:
+                    assert hip.hipMemcpy(C.c_void_p(buf.value + off), C.c_void_p(r.ctypes.data), C.c_size_t(r.size), 1) == 0
+            hip.hipDeviceSynchronize()
+            self._hip, self._buf, self.ptr = hip, buf, buf.value
+        del recs
+        time.sleep(0.4)     # (freeing host memory the runtime has uploaded from stalls the next GPU operation for milliseconds: let that pass, outside every timed region)
+
+    def build(self, core, ctx, syn):
+        """A fresh dataset from the resident records: wall milliseconds of the per-read stage (kernels), of finalize, and the library's HIP-event split."""
+        ds = core.Dataset(ctx, syn.names, syn.lengths, syn.seqs)
+        t0 = time.perf_counter()
+        ds.add_samples_records_resident(self.ptr, self.capacity, self.offsets, self.sizes)
+        t1 = time.perf_counter()
+        info = ds.finalize()
+        t2 = time.perf_counter()
+        return ds, info, 1e3 * (t1 - t0), 1e3 * (t2 - t1)
+
+    def close(self):
+        if hasattr(self, "_hip"):
+            self._hip.hipFree(self._buf)
+        self._t = None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -127,6 +180,7 @@ def parse():
     ap.add_argument("--cpu-samples", type=int, default=64, help="samples of the workload the CPU oracle is timed on")
     ap.add_argument("--sync-each-step", action="store_true", help="one msnv_pileup_run call (with its host sync) per step instead of one batched call")
     ap.add_argument("--no-overlap-extra", action="store_true", help="skip the extra timed batch with overlapped passes (profiling runs)")
+    ap.add_argument("--build-from-host", action="store_true", help="build the dataset the round-4 way (streams made and uploaded group by group inside the build) instead of from records resident in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-annotation", action="store_true", help="skip the --db_ann codon-annotation kernel (BASELINE configs[4]) after the timed region")
     ap.add_argument("--host-threads", type=int, default=0)
@@ -404,15 +458,34 @@ def main():
     sp = core.synth_params(**sp_kwargs)
     syn = core.Synth(sp)
     ctx = core.Context(local)
-    ds = core.Dataset(ctx, syn.names, syn.lengths, syn.seqs)
     core.host_timers(reset=True)
-    t0 = time.perf_counter()
-    ds.add_synth_samples(sp, 0, sp.n_samples, a.host_threads)
-    t_pack = time.perf_counter() - t0
-    ht_build = core.host_timers()
-    t0 = time.perf_counter()
-    info = ds.finalize()
-    t_up = time.perf_counter() - t0
+    from_records = None
+    if os.environ.get("MSNV_PACK", "d")[0] != "h" and not a.build_from_host and a.workload == "testdata":      # (the larger shapes make their streams group by group: they do not fit host memory at once)
+        # The dataset is built from RAW RECORDS RESIDENT IN HBM (msnv_dataset_add_sample_records_resident): the streams go up first, outside
+        # every timed region; then records -> packed columns -> tile index is timed -- three builds, the last one is kept for the passes.
+        t0 = time.perf_counter()
+        rr = ResidentRecords(syn, sp.n_samples, local)
+        t_synth = time.perf_counter() - t0
+        builds = []
+        ds = None
+        for rep in range(3):
+            if ds is not None:
+                ds.close()
+            ds, info, pack_ms, fin_ms = rr.build(core, ctx, syn)
+            builds.append({"pack_wall_ms": pack_ms, "finalize_wall_ms": fin_ms, "pack_kernel_ms": {k: v for k, v in ds.pack_stats().items() if k.endswith("_ms")}})
+        rr.close()
+        from_records = {"record_bytes": rr.bytes, "builds": builds}
+        t_pack, t_up = builds[-1]["pack_wall_ms"] * 1e-3, builds[-1]["finalize_wall_ms"] * 1e-3
+        ht_build = dict(core.host_timers(), synth_wall_s=t_synth)
+    else:
+        ds = core.Dataset(ctx, syn.names, syn.lengths, syn.seqs)
+        t0 = time.perf_counter()
+        ds.add_synth_samples(sp, 0, sp.n_samples, a.host_threads)
+        t_pack = time.perf_counter() - t0
+        ht_build = core.host_timers()
+        t0 = time.perf_counter()
+        info = ds.finalize()
+        t_up = time.perf_counter() - t0
     pack = ds.pack_stats()          # the per-read stage as kernels (csrc/devpack.hip): all zero under MSNV_PACK=host
 
     def barrier():
@@ -611,29 +684,40 @@ def main():
                          "counters": pileup_counters(sp.n_samples, sp.n_species, sp.contig_len, sp.mean_cov, k_ms) if (world == 1 and a.workload == "testdata") else None},
             "positions_per_s": info["n_positions"] * world * a.steps / dt_max,
             "kernel_ms": {"pileup": k_ms, "pipeline_total": sum(ms_total) / len(ms_total)},
-            "host": {"pack_s": t_pack, "synth_generator_wall_s": ht_build.get("synth_wall_s"), "pack_on_device_wall_s_incl_upload": ht_build.get("pack_device_wall_s"),
+            "host": {"pack_s": t_pack, "synth_generator_wall_s": ht_build.get("synth_wall_s"), "pack_on_device_wall_s": ht_build.get("pack_device_wall_s"),
                      "finalize_upload_s": t_up, "device_bytes": info["device_bytes"],
-                     "what": "pack_s = wall seconds of building the samples: %s" % ("synthetic record streams made by the host threads, uploaded, and parsed / filtered / cut into pieces by "
-                             "kernels (csrc/devpack.hip)" if pack["records"] else "synthetic record streams made AND packed by the host threads (MSNV_PACK=host, csrc/pack.cpp)")},
+                     "what": "pack_s = wall seconds of building the samples: %s" % ("record streams resident in HBM parsed / filtered / cut into pieces by kernels (csrc/devpack.hip); "
+                             "synth_generator_wall_s = making the streams on the host and uploading them, before" if from_records else
+                             "synthetic record streams made by the host threads and packed " + ("by kernels (csrc/devpack.hip)" if pack["records"] else "by the host threads too (MSNV_PACK=host, csrc/pack.cpp)"))},
         }
-        if pack["records"]:
+        # what limits the dominant kernel comes from the counters, not from the roofline it is priced against: the path is integer counting (no
+        # MFMA work), `achieved` / `peak` stay HBM GB/s as the contract defines them, `bound` says which unit the counters show saturated
+        cnt = line["roofline"]["counters"]
+        if cnt and cnt.get("limited_by", "").startswith("vector"):
+            line["roofline"]["bound"] = "valu"
+            line["roofline"]["bound_note"] = ("the counters (%s) put the kernel at %.0f %% of its vector-instruction issue slots: it is VALU-issue bound, not HBM bound; achieved / peak / frac "
+                                              "are still the SURVEY 8d bytes over the kernel's time against the HBM peak" % (cnt["source"], 100.0 * cnt["valu_issue_share_of_this_run"]))
+        if from_records:
             # Second roofline block: the timed region starts at RAW alignment records resident in HBM -- the SURVEY 8d bytes and then some
-            # (36-byte fixed part, read name, CIGAR, 4-bit bases, one byte of quality per base) -- and ends at the calls: the per-read stage's
-            # kernels (HIP events on their stream, summed over the rounds of this dataset) + one pileup kernel launch / one whole pass.
-            pk = pack["scan_ms"] + pack["measure_ms"] + pack["depth_ms"] + pack["emit_ms"] + pack["tile_sort_ms"]
+            # (36-byte fixed part, read name, CIGAR, 4-bit bases, one byte of quality per base) -- and ends at the calls: the per-read stage
+            # (kernels of csrc/devpack.hip; WALL milliseconds of the call, host side included), finalize (the tile index; wall milliseconds,
+            # INSIDE the region since round 5) and one launch of the pileup kernel.  Median of three builds.
+            bl = sorted(from_records["builds"], key=lambda b: b["pack_wall_ms"] + b["finalize_wall_ms"])[1]
+            total_ms = bl["pack_wall_ms"] + bl["finalize_wall_ms"] + k_ms
+            pk = sum(bl["pack_kernel_ms"].values())
             line["roofline_from_records"] = {
-                "bound": "hbm", "kernel": "msnv_scan_records + msnv_measure_reads + depth (rocPRIM sort / scans) + msnv_emit_headers + msnv_emit_pieces + tile-order sort, then msnv_pileup_tiles_narrow32",
-                "timed_region": "raw BAM records in HBM -> packed columns (once per dataset) -> one pileup kernel launch",
-                "achieved": alg / ((pk + k_ms) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / ((pk + k_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "algorithmic_bytes_per_launch": alg, "record_bytes_resident": int(pack["record_bytes"]),
-                "pack_kernels_ms": pk, "pileup_kernel_ms": k_ms, "whole_pass_ms": sum(ms_total) / len(ms_total),
-                "pack_stage_ms": {k: pack[k] for k in ("scan_ms", "measure_ms", "depth_ms", "emit_ms", "tile_sort_ms")},
-                "pack_alone": {"achieved_on_record_bytes": pack["record_bytes"] / (pk * 1e-3) / 1e9 if pk else None, "unit": "GB/s",
-                               "frac": pack["record_bytes"] / (pk * 1e-3) / 1e9 / HBM_PEAK_GBS if pk else None,
-                               "Gbases_per_s": bases / (pk * 1e-3) / 1e9 if pk else None},
+                "bound": "hbm", "kernel": "msnv_scan_sub + msnv_measure_reads + msnv_depth + msnv_emit_block (+ small scans), finalize (msnv_fin_*), then msnv_pileup_tiles_narrow32",
+                "timed_region": "raw BAM records resident in HBM -> per-read stage (wall) -> finalize: tile index (wall) -> one pileup kernel launch",
+                "achieved": alg / (total_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "total_ms": total_ms, "pack_wall_ms": bl["pack_wall_ms"], "finalize_ms": bl["finalize_wall_ms"], "pileup_kernel_ms": k_ms,
+                "algorithmic_bytes_per_launch": alg, "record_bytes_resident": from_records["record_bytes"],
+                "pack_kernels_ms": pk, "pack_stage_ms": bl["pack_kernel_ms"], "whole_pass_ms": sum(ms_total) / len(ms_total),
+                "pack_alone": {"achieved_on_record_bytes": from_records["record_bytes"] / (bl["pack_wall_ms"] * 1e-3) / 1e9, "unit": "GB/s",
+                               "frac": from_records["record_bytes"] / (bl["pack_wall_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "Gbases_per_s": bases / (bl["pack_wall_ms"] * 1e-3) / 1e9},
+                "all_builds": from_records["builds"],
                 "records": int(pack["records"]), "pieces": int(pack["pieces"]), "samples_through_the_host_prepass": int(pack["prepass_samples"]),
-                "transfers_wall_s": {"upload_of_host_made_streams": pack["upload_wall_s"], "download_of_headers_and_intervals": pack["download_wall_s"],
-                                     "host_prepass": pack["host_prepass_wall_s"]}}
+                "record_scans_through_the_careful_kernel": int(pack["scan_segments_redone"])}
         if overlapped:
             line["overlapped_passes"] = overlapped
         if cov_extra:

@@ -266,6 +266,129 @@ __global__ __launch_bounds__(64) void msnv_scan_segments(const uint8_t *raw, con
     if (lane == 0) outs[sg] = ScanOut{first, stop, bad, cnt, 0u};
 }
 
+// ---- the same chain, found by many short walks side by side (round 5).  A stream is cut into SUB-SEGMENTS of a few kilobytes, one LANE
+// each: the lane guesses where the chain enters its bytes -- the first offset whose 36 header bytes are those of a plausible record (sizes
+// consistent, contig ids in range, the read name's terminating NUL where l_read_name says) and whose two successors are too --, walks the
+// ~20 records that start there and leaves their offsets (16-bit, relative to the sub-segment) in its slots.  A second kernel checks every
+// seam on the device -- a sub-segment's walk must have begun exactly where the chain stood after the sub-segments before it (running maximum
+// of the walks' ends) --, a scan of the accepted counts gives every sub-segment its first record, a third kernel writes the offsets out.
+// One wait, for the record count.  A seam that does not hold (a wrong guess: a record longer than a sub-segment with something
+// header-like inside) or a malformed chain sends the round through msnv_scan_segments above, which repairs and reports.
+struct SubStream { unsigned long long beg, end; uint32_t sub0, pad; };        // bytes [beg, end) of the round buffer, first sub-segment
+__device__ __forceinline__ bool hdr_plausible(const uint8_t *raw, unsigned long long o, unsigned long long s_end, int n_contigs, uint32_t &bs_out) {
+    if (s_end - o < 36) return false;
+    const uint64_t a = ld64(raw + o);
+    const uint32_t bs = (uint32_t)a; const int32_t tid = (int32_t)(a >> 32);
+    bs_out = bs;
+    if ((int32_t)bs < 32 || bs >= (1u << 28) || (unsigned long long)bs + 4 > s_end - o || tid < -1 || tid >= n_contigs) return false;
+    const uint64_t b = ld64(raw + o + 8), c = ld64(raw + o + 16), d = ld64(raw + o + 24);
+    const int32_t pos = (int32_t)(uint32_t)b, l_seq = (int32_t)(c >> 32), mtid = (int32_t)(uint32_t)d, mpos = (int32_t)(d >> 32);
+    const uint32_t l_name = (uint32_t)(b >> 32) & 0xffu, n_cigar = (uint32_t)c & 0xffffu;
+    if (pos < -1 || l_name < 1 || l_seq < 0 || mtid < -1 || mtid >= n_contigs || mpos < -1) return false;
+    const unsigned long long need = 36ull + l_name + 4ull * n_cigar + ((unsigned long long)(uint32_t)l_seq + 1) / 2 + (unsigned long long)(uint32_t)l_seq;
+    if (need > (unsigned long long)bs + 4) return false;
+    return raw[o + 36 + l_name - 1] == 0;
+}
+__device__ __forceinline__ uint32_t sub_stream_of(const SubStream *ss, uint32_t n_streams, uint32_t g) {        // last stream whose first sub-segment is at or before g
+    uint32_t a = 0, b = n_streams;
+    while (b - a > 1) { const uint32_t m = (a + b) / 2; if (ss[m].sub0 <= g) a = m; else b = m; }
+    return a;
+}
+__global__ __launch_bounds__(256) void msnv_scan_sub(const uint8_t *raw, const SubStream *ss, uint32_t n_streams, uint32_t n_sub, uint32_t sub_bytes, uint32_t cap, int n_contigs,
+                                                     unsigned long long *first, unsigned long long *stop, uint32_t *cnt, uint16_t *delta, uint32_t *flags) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_sub) return;
+    const SubStream S = ss[sub_stream_of(ss, n_streams, g)];
+    const unsigned long long b = S.beg + (unsigned long long)(g - S.sub0) * sub_bytes, e = b + sub_bytes < S.end ? b + sub_bytes : S.end;
+    unsigned long long f = ~0ull;
+    if (g == S.sub0) f = S.beg;
+    else {
+        // sixteen offsets a step from 32 bytes in registers (a load per offset made the kernel L2-bound: every lane steps through its own
+        // cache lines); block_size and refID of a candidate are looked at first -- almost nothing else passes them
+        const unsigned long long a0 = b & ~15ull;                  // (aligned 16-byte pieces; the buffer is readable 256 bytes past the last stream)
+        uint4 lo4 = *reinterpret_cast<const uint4 *>(raw + a0);
+        for (unsigned long long base16 = a0; base16 < e && f == ~0ull; base16 += 16) {
+            const uint4 hi4 = *reinterpret_cast<const uint4 *>(raw + base16 + 16);
+            const uint32_t w[7] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z};
+#pragma unroll
+            for (uint32_t k = 0; k < 16u; ++k) {
+                const uint32_t bs = __builtin_amdgcn_alignbyte(w[(k >> 2) + 1], w[k >> 2], k & 3u);
+                const int32_t tid = (int32_t)__builtin_amdgcn_alignbyte(w[(k >> 2) + 2], w[(k >> 2) + 1], k & 3u);
+                const unsigned long long o = base16 + k;
+                if ((int32_t)bs < 32 || bs >= (1u << 28) || tid < -1 || tid >= n_contigs || o < b || o >= e || f != ~0ull) continue;
+                uint32_t bs1 = 0;
+                if (!hdr_plausible(raw, o, S.end, n_contigs, bs1)) continue;
+                bool ok = true;
+                unsigned long long o2 = o + 4ull + bs1;
+                for (int d = 0; d < 2 && ok && o2 < S.end; ++d) { uint32_t b2 = 0; ok = hdr_plausible(raw, o2, S.end, n_contigs, b2); o2 += 4ull + b2; }
+                if (ok) f = o;
+            }
+            lo4 = hi4;
+        }
+    }
+    uint32_t n = 0; unsigned long long off = f;
+    bool bad = false;
+    if (f != ~0ull) {
+        uint16_t *dl = delta + (size_t)g * cap;
+        while (off < e) {
+            if (S.end - off < 36) { bad = true; break; }
+            const uint32_t bs = ld32(raw + off);
+            if ((int32_t)bs < 32 || (unsigned long long)bs + 4 > S.end - off) { bad = true; break; }
+            if (n < cap) dl[n] = (uint16_t)(off - b);
+            ++n;
+            off += 4ull + bs;
+        }
+    }
+    first[g] = f; stop[g] = f != ~0ull ? off : 0ull; cnt[g] = n;
+    if (bad || n > cap) atomicOr(flags, 1u);                        // a malformed chain (or an impossible count): the careful kernel reports it
+}
+// seams: cur = where the chain stands in front of sub-segment g = the largest end of a walk before it (the stream's first byte for its first
+// sub-segment: ends of earlier streams lie before it)
+__global__ void msnv_scan_seams(const SubStream *ss, uint32_t n_streams, uint32_t n_sub, uint32_t sub_bytes, const unsigned long long *first, const unsigned long long *stop_max, uint32_t *cnt, uint32_t *flags) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_sub) { if (g == n_sub) cnt[g] = 0; return; }
+    const SubStream S = ss[sub_stream_of(ss, n_streams, g)];
+    if (g == S.sub0) return;                                        // (entered at the stream's first byte)
+    const unsigned long long b = S.beg + (unsigned long long)(g - S.sub0) * sub_bytes, e = b + sub_bytes < S.end ? b + sub_bytes : S.end;
+    unsigned long long cur = stop_max[g - 1];
+    cur = cur > S.beg ? cur : S.beg;
+    if (cur >= e) { if (first[g] != ~0ull) atomicOr(flags, 2u); cnt[g] = 0; }      // a record runs across the whole sub-segment: nothing may start here
+    else if (first[g] != cur) atomicOr(flags, 2u);
+}
+struct U64Max { __device__ __host__ unsigned long long operator()(unsigned long long a, unsigned long long b) const { return a > b ? a : b; } };
+// the offsets out: a wavefront takes 64 consecutive sub-segments, whose records are consecutive in the list, and writes them 64 at a time
+// (every record finds its sub-segment among the wavefront's 64 by bisection over the lanes' first records)
+__global__ __launch_bounds__(256) void msnv_scan_write(const SubStream *ss, uint32_t n_streams, uint32_t n_sub, uint32_t sub_bytes, uint32_t cap, const uint32_t *cnt, const uint32_t *base,
+                                                       const uint16_t *delta, unsigned long long *rec_off, uint16_t *rec_sample, uint32_t *rec_base) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u, g0 = g - lane;
+    if (g0 >= n_sub) return;
+    const bool have = g < n_sub;
+    uint32_t si = 0, w = 0xffffffffu; unsigned long long b = 0;
+    if (have) {
+        si = sub_stream_of(ss, n_streams, g);
+        const SubStream S = ss[si];
+        b = S.beg + (unsigned long long)(g - S.sub0) * sub_bytes;
+        w = base[g];
+        if (g == S.sub0) rec_base[si] = w;
+    }
+    const uint32_t n_here = (n_sub - g0 < 64u ? n_sub - g0 : 64u);
+    const uint32_t j_lo = __shfl(w, 0), j_hi = base[g0 + n_here];   // (base has n_sub + 1 entries)
+    for (uint32_t j0 = j_lo; j0 < j_hi; j0 += 64u) {
+        const uint32_t j = j0 + lane;
+        // last lane t (< n_here) whose first record is at or before j
+        uint32_t lo = 0, hi = n_here;
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {                           // (six halvings of at most 64 lanes; every lane takes every step: the shuffles need all lanes)
+            const uint32_t m = (lo + hi) / 2;
+            const uint32_t bm = __shfl(w, (int)m);
+            if (hi - lo > 1) { if (bm <= j) lo = m; else hi = m; }
+        }
+        const uint32_t wt = __shfl(w, (int)lo), st = __shfl(si, (int)lo);
+        const unsigned long long bt = __shfl(b, (int)lo);
+        if (j < j_hi) { rec_off[j] = bt + delta[(size_t)(g0 + lo) * cap + (j - wt)]; rec_sample[j] = (uint16_t)st; }
+    }
+}
+
 struct CompactSeg { unsigned long long src; uint32_t dst, cnt, sample, pad; };
 __global__ void msnv_compact_offsets(const unsigned long long *tmp_off, const CompactSeg *segs, unsigned long long *rec_off, uint16_t *rec_sample) {
     const CompactSeg c = segs[blockIdx.x];
@@ -1354,6 +1477,73 @@ static int scan_streams(hipStream_t st, const int device, BufPool &pool, const u
     }
     R.raw = raw; R.raw_bytes = raw_bytes;
 
+    // ---- record boundaries, the quick way: sub-segments walked side by side, seams checked on the device (MSNV_SCAN=segments: the careful kernel only)
+    const bool quick = [] { const char *e = getenv("MSNV_SCAN"); return !(e && e[0] == 's'); }();
+    if (quick && S > 0) {
+        const uint32_t sub_bytes = [] { const char *e = getenv("MSNV_SCAN_SUB"); const long long v = e ? atoll(e) : 4096; return (uint32_t)std::min<long long>(32768, std::max<long long>(64, v)); }();   // (per call: tests shrink it)
+        const uint32_t cap = sub_bytes / 36u + 2u;
+        std::vector<SubStream> ss(S);
+        uint64_t n_sub64 = 0;
+        for (size_t s = 0; s < S; ++s) { ss[s] = SubStream{s_beg[s], s_end[s], (uint32_t)n_sub64, 0u}; n_sub64 += std::max<uint64_t>(1, (n_bytes[s] + sub_bytes - 1) / sub_bytes); }
+        if (n_sub64 < 0x7ffffff0ull) {
+            const uint32_t n_sub = (uint32_t)n_sub64;
+            const size_t pool_from = pool.next;
+            DP_BUF(SubStream, d_ss, S);
+            DP_BUF(unsigned long long, d_first, (uint64_t)n_sub + 1);
+            DP_BUF(unsigned long long, d_stop, (uint64_t)n_sub + 1);
+            DP_BUF(unsigned long long, d_stopmax, (uint64_t)n_sub + 1);
+            DP_BUF(uint32_t, d_cnt, (uint64_t)n_sub + 1);
+            DP_BUF(uint32_t, d_base, (uint64_t)n_sub + 1);
+            DP_BUF(uint16_t, d_delta, (uint64_t)n_sub * cap + 8);
+            DP_BUF(uint32_t, d_fl, 4);
+            DP_BUF(uint32_t, d_recbase, S + 1);
+            DP_BUF(unsigned long long, d_send, S);
+            DP_BUF(uint8_t, d_tmp, 1u << 20);
+            size_t tmp_cap = (size_t)pool.slots[pool.next - 1].second;
+            tm.start();
+            HIP_TRY(hipMemcpyAsync(d_ss, ss.data(), S * sizeof(SubStream), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(d_send, s_end.data(), S * 8, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemsetAsync(d_fl, 0, 16, st));
+            hipLaunchKernelGGL(msnv_scan_sub, grid_for(n_sub, 256), dim3(256), 0, st, raw, d_ss, (uint32_t)S, n_sub, sub_bytes, cap, (int)NC, d_first, d_stop, d_cnt, d_delta, d_fl);
+            HIP_TRY(hipGetLastError());
+            size_t need = 0, need2 = 0;
+            HIP_TRY(rocprim::inclusive_scan(nullptr, need, d_stop, d_stopmax, (size_t)n_sub, U64Max(), st));
+            HIP_TRY(rocprim::exclusive_scan(nullptr, need2, d_cnt, d_base, 0u, (size_t)n_sub + 1, rocprim::plus<uint32_t>(), st));
+            need = std::max(need, need2);
+            if (need > tmp_cap) { pool.next -= 1; d_tmp = static_cast<uint8_t *>(pool.get(need)); if (!d_tmp) return pool.rc; }
+            HIP_TRY(rocprim::inclusive_scan(d_tmp, need, d_stop, d_stopmax, (size_t)n_sub, U64Max(), st));
+            hipLaunchKernelGGL(msnv_scan_seams, grid_for((uint64_t)n_sub + 1, 256), dim3(256), 0, st, d_ss, (uint32_t)S, n_sub, sub_bytes, d_first, d_stopmax, d_cnt, d_fl);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(rocprim::exclusive_scan(d_tmp, need, d_cnt, d_base, 0u, (size_t)n_sub + 1, rocprim::plus<uint32_t>(), st));
+            uint32_t fl_tot[2] = {0, 0};
+            HIP_TRY(hipMemcpyAsync(&fl_tot[0], d_fl, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(&fl_tot[1], d_base + n_sub, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (!fl_tot[0]) {
+                // (a 32-bit count that wrapped would show as a total below the sub-segments' sum; 2^32 records need 150 GB of stream in one round -- refused by size)
+                if (raw_bytes / 36 > 0xfffffff0ull) return fail(MSNV_EDOMAIN, "more than 2^32 records in one round of the device pack");
+                const uint32_t NR = fl_tot[1];
+                const uint64_t NRa = (uint64_t)NR + 1;
+                DP_BUF(unsigned long long, d_recoff, NRa);
+                DP_BUF(uint16_t, d_recsample, NRa);
+                hipLaunchKernelGGL(msnv_scan_write, grid_for(n_sub, 256), dim3(256), 0, st, d_ss, (uint32_t)S, n_sub, sub_bytes, cap, d_cnt, d_base, d_delta, d_recoff, d_recsample, d_recbase);
+                HIP_TRY(hipGetLastError());
+                std::vector<uint32_t> &rec_base = R.rec_base; rec_base.assign(S + 1, 0);
+                HIP_TRY(hipMemcpyAsync(d_recbase + S, &NR, 4, hipMemcpyHostToDevice, st));
+                HIP_TRY(hipMemcpyAsync(rec_base.data(), d_recbase, S * 4, hipMemcpyDeviceToHost, st));
+                R.ms_scan += tm.stop();
+                rec_base[S] = NR;
+                R.n_rec.assign(S, 0); R.bad_off.assign(S, ~0ull);
+                for (size_t s = 0; s < S; ++s) R.n_rec[s] = rec_base[s + 1] - rec_base[s];
+                R.NR = NR;
+                R.d_recbase = d_recbase; R.d_send = d_send; R.d_recoff = d_recoff; R.d_recsample = d_recsample;
+                return MSNV_OK;
+            }
+            R.ms_scan += tm.stop();
+            R.n_redone += 1;                                      // (counted: the round went through the careful kernel)
+            pool.next = pool_from;
+        }
+    }
     // ---- record boundaries: segments, guessed entry points, seams checked here
     const uint64_t seg_bytes = [] { const char *e = getenv("MSNV_SCAN_SEG_KB"); const long long v = e ? atoll(e) : 256; return (uint64_t)std::max<long long>(1, v) << 10; }();   // (per call: tests shrink it)
     std::vector<ScanSeg> segs;
@@ -1675,6 +1865,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     P.c_eff = std::min(std::max(MP.min_baseq, -127), 127); P.all_low = MP.min_baseq > 127;
     P.n_contigs = (int)NC; P.has_bed = ds.has_bed ? 1 : 0;
     Timer tm(st);
+    fin_trace_reset();
     // work buffers of the round: taken from the dataset's pool in call order (BufPool: grow-only, so a dataset's second round allocates nothing;
     // with guarded allocations -- MSNV_GUARD_ALLOC=1 -- every buffer is exact and fresh)
     BufPool pool{T.scratch};
@@ -1695,6 +1886,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     uint32_t *const d_recbase = SR.d_recbase; unsigned long long *const d_send = SR.d_send, *const d_recoff = SR.d_recoff; uint16_t *const d_recsample = SR.d_recsample;
     (void)d_send; (void)n_rec; (void)s_beg; (void)s_end;
 
+    fin_trace("  pack: scan done");
     // ---- measure (+ the host pre-pass for the samples that need one, then once more with its verdicts)
     DP_BUF(uint8_t, d_flags, NRa);
     DP_BUF(unsigned long long, d_key, NRa);
@@ -1795,6 +1987,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
         }
         NP = tot.pile;
         T.ms_measure += tm.stop();
+        fin_trace("  pack: measure + block scan (sync)");
         // ---- depth at every read start; the runs and the (run, first tile) groups of reads
         n_runs = 0; n_groups = 0;
         if (NP) {
@@ -1845,6 +2038,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
         HIP_TRY(hipMemcpy2DAsync(acc.data(), sizeof(DpAcc), d_acc, sizeof(DpAcc) * ACC_COPIES, sizeof(DpAcc), S, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(&need_sort, d_misc + MISC_SORT, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        fin_trace("  pack: depth stage (sync)");
         // ---- errors, in record order (what the host stage's sequential walk would have met first)
         for (size_t s = 0; s < S; ++s) {
             const unsigned long long e = acc[s].err;
@@ -1950,6 +2144,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
         HIP_TRY(hipGetLastError());
         T.ms_depth += tm.stop();
     }
+    fin_trace("  pack: checks, overlaps");
     // ---- layout: where every sample's pieces, seq bytes and intervals start (the per-record places are d_pre)
     const bool in_order = need_sort != 0 || [] { const char *e = getenv("MSNV_TILE_ORDER"); return e && e[0] == 's'; }();      // the general route: file order, then the sort (MSNV_TILE_ORDER=sort: tests)
     DP_BUF(DpSampleSum, d_sum, S + 1);
@@ -1980,6 +2175,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     std::vector<DpSampleDst> dsts(S);
     for (size_t s = 0; s < S; ++s) dsts[s] = DpSampleDst{r_seq + seq_off[s], r_qual + seq_off[s] / 4, sum[s].pbase0, cut_marks[s], 0u};
     const uint64_t NPCa = (uint64_t)NPC + 1;
+    fin_trace("  pack: sample bases (sync), round buffer");
     // what stays in HBM of the round besides the columns: headers (tile order) and intervals, for finalize -- written where they stay
     DevRound keep;
     {
@@ -2026,6 +2222,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     HIP_TRY(hipMemcpy2DAsync(acc.data(), sizeof(DpAcc), d_acc, sizeof(DpAcc) * ACC_COPIES, sizeof(DpAcc), S, hipMemcpyDeviceToHost, st));
     T.ms_emit += tm.stop();
 
+    fin_trace("  pack: emit (sync)");
     // ---- the (sample, contig, tile) runs of pieces = the pairs of the tile index
     tm.start();
     std::vector<DevPairRec> prec;
@@ -2081,6 +2278,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     }
     T.ms_sort += tm.stop();
 
+    fin_trace("  pack: pairs");
     // ---- what the host keeps of a sample: its summaries and its (contig, tile) runs
     const double t_dl = now_s();
     const int32_t round_no = (int32_t)T.rounds.size() - 1;
@@ -2122,6 +2320,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
         sc.first_any[(size_t)r.tid] = r.first_any; sc.first_from1[(size_t)r.tid] = r.first_from1;
     }
     T.wall_download_s += now_s() - t_dl;
+    fin_trace("  pack: host tables");
 #undef DP_BUF
     return MSNV_OK;
 }

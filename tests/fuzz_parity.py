@@ -34,6 +34,9 @@ def sweep(n_cases, seed, verbose=True):
         rk = random.Random(kw["seed"])
         os.environ["MSNV_PACK"] = os.environ.get("FUZZ_PACK") or rk.choice(["device", "device", "device", "host"])
         os.environ["MSNV_SCAN_SEG_KB"] = rk.choice(["1", "8", "256"])
+        os.environ["MSNV_SCAN_SUB"] = rk.choice(["64", "200", "4096", "4096"])       # (the quick record scan's sub-segments; a seam that does not hold falls back to the careful kernel)
+        if rk.random() < 0.15: os.environ["MSNV_SCAN"] = "segments"
+        else: os.environ.pop("MSNV_SCAN", None)
         # what a real aligner writes: auxiliary fields behind the qualities, now and then a record without SEQ
         kw["frac_aux"] = rk.choice([0.0, 0.3, 1.0]); kw["frac_noseq"] = rk.choice([0.0, 0.0, 0.05])
         deep_mode = os.environ.get("MSNV_DEEP", "split")

@@ -256,28 +256,32 @@ def test_errors_carry_the_host_stage_codes():
 
 
 def test_record_scan_across_segment_seams():
-    """The record chain is walked segment by segment with GUESSED entry points checked at every seam (devpack.hip: msnv_scan_segments):
-    tiny segments put a seam into almost every record, a read name that looks like a record header makes a guess go wrong."""
+    """The record chain is walked piecewise with GUESSED entry points checked at every seam -- round 5: a lane per sub-segment, seams checked
+    on the device (devpack.hip: msnv_scan_sub / msnv_scan_seams; MSNV_SCAN_SUB bytes); the careful form (msnv_scan_segments, MSNV_SCAN=segments,
+    MSNV_SCAN_SEG_KB) repairs wrong guesses and takes over when a seam of the quick form does not hold.  Tiny pieces put a seam into almost
+    every record (and records longer than a sub-segment next to it); a read name that holds plausible record headers makes guesses go wrong."""
     syn, samples = synth_case(n_species=2, contig_len=6000, n_samples=4, mean_cov=9.0, snv_density=0.02, seed=25)
+    for sub in ("64", "100", "333", "4096"):
+        with _env(MSNV_SCAN_SUB=sub):
+            _same_dataset(syn.names, syn.lengths, syn.seqs, samples, check_oracle=(sub == "100"))
     for kb in ("1", "2", "64"):
-        with _env(MSNV_SCAN_SEG_KB=kb):
+        with _env(MSNV_SCAN_SEG_KB=kb, MSNV_SCAN="segments"):
             _same_dataset(syn.names, syn.lengths, syn.seqs, samples, check_oracle=(kb == "1"))
     # a decoy: inside a long read name, the bytes of three consecutive plausible record headers
     import struct
     ref = "ACGT" * 1500
 
-    def fake(nxt):                      # 36 header bytes of a "record" with block_size nxt - 4 whose fields pass every plausibility test
+    def fake(nxt):                      # 36 header bytes of a "record" with block_size nxt - 4 whose fields pass every plausibility test (name: 2 bytes, NUL-terminated)
         return struct.pack("<iiiBBHHHiiii", nxt - 4, 0, 5, 2, 60, 4680, 0, 0, 0, -1, -1, 0)
-    decoy = (fake(40) + b"ab\0\0") * 6
-    name = ("N" * 3 + decoy.decode("latin-1")[:200]).replace("\0", "x")
+    decoy = (fake(40) + b"a\0\0\0") * 6
     recs = []
     for k in range(40):
-        recs.append(bt.make_record(0, 10 + 20 * k, "50M", ref[10 + 20 * k:60 + 20 * k], name="r%d" % k))
+        recs.append(bt.make_record(0, 10 + 20 * k, "50M", ref[10 + 20 * k:60 + 20 * k], name="r%d" % k, aux=b"ZZZ" + decoy[:200] if k % 3 == 0 else b""))
     stream = bt.records(*recs)
     ctx = core.Context(0)
     try:
-        for kb in ("1", "256"):
-            with _env(MSNV_SCAN_SEG_KB=kb, MSNV_PACK="device"):
+        for env in (dict(MSNV_SCAN_SEG_KB="1", MSNV_SCAN="segments"), dict(MSNV_SCAN_SEG_KB="256", MSNV_SCAN="segments"), dict(MSNV_SCAN_SUB="64"), dict(MSNV_SCAN_SUB="128"), dict(MSNV_SCAN_SUB="4096")):
+            with _env(MSNV_PACK="device", **env):
                 ds = core.Dataset(ctx, ["c"], [6000], [ref])
                 ds.add_sample_records(stream)
                 ds.finalize()
