@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256) void msnv_measure_reads(const uint8_t *raw, co
         const RecCnt mine = valid ? RecCnt{(flags & RF_PILE) ? 1u : 0u, o_np, o_niv, o_spill, (unsigned long long)o_sb} : RecCnt{};
         if (valid) r_cnt[i] = mine;
         const RecCnt tot = wave_sum_cnt(mine);
-        if ((threadIdx.x & 63u) == 0) blk_cnt[i / PB] = tot;                  // (i is a multiple of PB in lane 0: 256 threads = 4 blocks)
+        if ((threadIdx.x & 63u) == 0 && valid) blk_cnt[i / PB] = tot;         // (i is a multiple of PB in lane 0: 256 threads = 4 blocks; the grid's last wavefronts may lie behind the last block)
         // reference span of the pileup reads: the depth kernel's window reaches that far back; a read far beyond the others' is listed by itself
         uint32_t span = (flags & RF_PILE) ? o_end - ((uint32_t)key & 0x7fffffffu) : 0u;
         if (span > span_out) { const uint32_t k = atomicAdd(&misc[MISC_NOUT], 1u); if (k < CAP_OUT) outliers[k] = i; span = 0; }
