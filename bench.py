@@ -8,9 +8,12 @@ refGenomes), with the packed read columns already resident
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Multi-GPU: contigs shard across ranks with no data-path collective.
-  --mode weak   (default for the testdata workload = the headline line): every rank holds its own testdata-shaped shard --
-                three species cannot be dealt to eight ranks -- and only a small table is gathered after the timed region.
+Multi-GPU: contigs shard across ranks with no data-path collective.  With the plain argv and N > 1 the line that is
+printed is the STRONG one -- one cohort (the generator of BASELINE configs[3]'s per-GPU shard, 500 samples) through the product's N-rank
+path, value = cohort bases / the slowest rank's pass, "scaling": "strong" -- and the weak replica line rides along as "weak_replicas"; at
+N = 1 the line is the metric's own configuration (BASELINE configs[1]).
+  --mode weak   every rank holds its own testdata-shaped shard -- three species cannot be dealt to eight ranks -- and only a small table
+                is gathered after the timed region (the line itself at N = 1; forces the weak line as the headline at N > 1).
   --mode strong (default for config3 / config4shard): ONE fixed multi-species cohort through the product's N-rank path
                 (metasnv_amd/parallel.py: resident_project_run) -- record streams "decoded" by one rank each, contig owners by
                 species LPT on length x coverage from the first round, all-to-all of the records over RCCL, one dataset per rank,
@@ -169,7 +172,8 @@ def parse():
     ap.add_argument("--mode", default=None, choices=["weak", "strong"], help="weak: one shard per rank (default for testdata); strong: one fixed cohort sharded over the ranks "
                                                                              "through the product's N-rank path (default for config3 / config4shard)")
     ap.add_argument("--no-strong-extra", action="store_true", help="N > 1, weak mode: skip the small strong-scaling block behind the timed region")
-    ap.add_argument("--strong-extra-shape", default="32,300000", help="species,contig_len of the strong-scaling block's cohort (tests shrink it)")
+    ap.add_argument("--strong-extra-shape", default=None, help="species,contig_len of the N-rank cohort (a config3-shaped one; tests shrink it); default: the generator of BASELINE configs[3]'s per-GPU shard "
+                                                                "(config4shard) at --scale (0.25)")
     ap.add_argument("--scale", type=float, default=None, help="fraction of the named workload's species (config3 / config4shard; default 0.25: the full shapes need ~100 GB of host staging)")
     ap.add_argument("--samples", type=int, default=None)
     ap.add_argument("--contig-len", type=int, default=None)
@@ -737,14 +741,20 @@ def main():
             except Exception as e:                             # the extra must never cost the bench line
                 line["end_to_end"] = {"error": repr(e)}
     strong = None
-    if world > 1 and not a.no_strong_extra and mode == "weak":
+    if (world > 1 or (a.mode is None and a.workload == "testdata")) and not a.no_strong_extra and mode == "weak":
+        # (at N = 1 with the plain argv too: the one-rank point of the cohort the N > 1 lines are about -- the base of the scaling curve)
         # the product's N-rank path on ONE fixed cohort (32 species x 300 kb, 160 samples carrying six each): what the weak line above
         # cannot show -- LPT imbalance, the all-to-all of the records, the gather to rank 0
         ds.close()
         import copy
         b = copy.copy(a)
-        xs, xl = (int(x) for x in a.strong_extra_shape.split(","))
-        b.workload, b.scale, b.species, b.contig_len, b.mean_cov = "config3", 0.32, xs, xl, None
+        if a.strong_extra_shape:
+            xs, xl = (int(x) for x in a.strong_extra_shape.split(","))
+            b.workload, b.scale, b.species, b.contig_len, b.mean_cov = "config3", 0.32, xs, xl, None
+        else:
+            # the cohort every rank count shares: the generator of one GPU's contig shard of BASELINE configs[3] (500 samples, sparse coverage,
+            # 375 species x ~2 Mbp at the default scale), dealt to the N ranks by the product's own path
+            b.workload, b.scale, b.species, b.contig_len, b.mean_cov, b.samples = "config4shard", (a.scale if a.scale is not None else 0.25), None, None, None, None
         b.steps, b.warmup = max(3, min(a.steps, 10)), 1
         # the extra must never cost the bench line: not by raising, and not by one rank waiting in a collective for a rank that is gone --
         # after `limit` seconds every rank leaves, rank 0 with the line it already has
@@ -762,15 +772,27 @@ def main():
         watchdog.daemon = True
         watchdog.start()
         try:
-            strong = strong_run(b, rank, world, local, dist, brief=True)
+            strong = strong_run(b, rank, world, local, dist, brief=False)
         except Exception as e:
             strong = {"error": repr(e)}
         watchdog.cancel()
         if not printed.acquire(blocking=False):                   # the watchdog fired between the run's return and the cancel: it prints and exits
             time.sleep(60)
         if rank == 0:
-            line["strong_scaling"] = strong
-            print(json.dumps(line))
+            if world > 1 and a.mode is None and a.workload == "testdata" and strong and "error" not in strong:
+                # N > 1 with the driver's plain argv: the HEADLINE is the product's N-rank path on ONE cohort (strong scaling: three species
+                # cannot shard eight ways, and N independent replicas of them measure nothing); the replica line rides along
+                head = strong
+                head["weak_replicas"] = {k: line[k] for k in ("value", "unit", "ms_per_step", "scaling", "steps", "warmup") if k in line}
+                head["weak_replicas"]["workload"] = line["config"]["workload"]
+                head["weak_replicas"]["roofline"] = {k: line["roofline"][k] for k in ("bound", "kernel", "achieved", "frac", "kernel_ms_avg", "achieved_per_rank") if k in line["roofline"]}
+                print(json.dumps(head))
+            else:
+                for k in ("metric", "unit", "higher_is_better", "vs_baseline", "dtype", "data"):
+                    if strong and "error" not in strong:
+                        strong.pop(k, None)
+                line["strong_scaling"] = strong
+                print(json.dumps(line))
         parallel.finalize()
         return
     if rank == 0:

@@ -192,6 +192,33 @@ class DeviceSend:
         self.tensor, self.sizes = tensor, [int(x) for x in sizes]
 
 
+_a2a_checked = False
+
+
+def _a2a_selfcheck(dev, slice_bytes):
+    """Once per process, before the first byte exchange over RCCL: an all-to-all of a known pattern with parts of the size the exchange
+    slices its buffers to, checked on the device.  This stack has returned wrong bytes for large exchanges (round 4: an all_to_all_single of
+    more than 2^30 uint8 elements, profiles/a2a_check.py); a collective that does not deliver what was sent must stop the run, loudly."""
+    global _a2a_checked
+    if _a2a_checked or os.environ.get("MSNV_A2A_SELFCHECK", "1") == "0":
+        return
+    _a2a_checked = True
+    import torch
+    n = int(min(slice_bytes, 1 << 26))                       # (64 MB a part at most: the check must not need gigabytes)
+    n -= n % 8
+    base = torch.arange(n // 8, dtype=torch.int64, device=dev)
+    send = [((base * 2654435761 + (_rank * 131 + q) * 40503) & 0x7fffffffffffffff).view(torch.uint8) for q in range(_world)]
+    recv = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(_world)]
+    _dist.all_to_all(recv, send)
+    bad = 0
+    for r in range(_world):
+        want = ((base * 2654435761 + (r * 131 + _rank) * 40503) & 0x7fffffffffffffff).view(torch.uint8)
+        bad += int((recv[r] != want).sum().item())
+    if bad:
+        raise RuntimeError("RCCL all_to_all self-check failed on rank %d: %d of %d bytes differ from what the senders sent (parts of %d bytes) -- "
+                           "the collective of this stack cannot be trusted with the record exchange" % (_rank, bad, n * _world, n))
+
+
 def exchange_records(parts, status=0, keep_on_device=False):
     """All-to-all of byte streams: parts[q] (1-D uint8 array) goes to rank q; returns the list of the arrays this rank
     received, indexed by sender.  {size, status} pairs travel first (one all_to_all of world x 2 int64), then the bytes.
@@ -229,10 +256,19 @@ def exchange_records(parts, status=0, keep_on_device=False):
     n_slices = max(1, -(-max(rmax + [0]) // slice_bytes))
     soff = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     roff = np.concatenate([[0], np.cumsum(rsizes)]).astype(np.int64)
+    lists = dev.type == "cuda" and os.environ.get("MSNV_A2A_FORM", "lists") == "lists"
+    if lists:
+        _a2a_selfcheck(dev, slice_bytes)
     for j in range(n_slices):
         lo = j * slice_bytes
         ins = [min(slice_bytes, max(0, n - lo)) for n in sizes]
         outs = [min(slice_bytes, max(0, n - lo)) for n in rsizes]
+        if lists:
+            # RCCL: every part's slice is sent from and received INTO its place -- views of the two buffers, no staging tensor, no copy back
+            # (round 4 concatenated the slices of several senders and copied the received ones back: an extra pass over HBM per round)
+            _dist.all_to_all([trecv[int(roff[r]) + lo:int(roff[r]) + lo + outs[r]] for r in range(_world)],
+                             [tsend[int(soff[q]) + lo:int(soff[q]) + lo + ins[q]] for q in range(_world)])
+            continue
         if n_slices == 1:
             _dist.all_to_all_single(trecv, tsend, output_split_sizes=outs, input_split_sizes=ins)
             break

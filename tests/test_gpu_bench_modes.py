@@ -55,9 +55,17 @@ def test_one_rank_strong_rate_is_the_weak_rate():
     assert abs(strong["value"] / weak["value"] - 1.0) < 0.25
 
 
-def test_weak_line_of_two_ranks_carries_a_strong_block():
-    line = _bench(["--gpus", "2", "--dist-backend", "gloo", "--steps", "3", "--warmup", "1", "--samples", "24", "--contig-len", "60000", "--no-cpu-baseline", "--no-annotation",
-                   "--no-overlap-extra", "--strong-extra-shape", "8,40000"])
+def test_two_ranks_with_the_plain_argv_print_the_strong_line_and_carry_the_weak_one():
+    """N > 1 without --mode: the headline is the product's N-rank path on one cohort (scaling: strong), the weak replica line rides along;
+    --mode weak keeps the weak line as the headline with the strong block inside."""
+    common = ["--gpus", "2", "--dist-backend", "gloo", "--steps", "3", "--warmup", "1", "--samples", "24", "--contig-len", "60000", "--no-cpu-baseline", "--no-annotation",
+              "--no-overlap-extra", "--strong-extra-shape", "8,40000"]
+    line = _bench(common)
+    assert line["scaling"] == "strong" and line["n_gpus"] == 2 and line["value"] > 0 and line["metric"].startswith("pileup Gbases/s")
+    assert len(line["config"]["pileup_bases_per_rank"]) == 2
+    w = line["weak_replicas"]
+    assert w["scaling"] == "weak" and w["value"] > 0 and w["roofline"]["frac"] > 0
+    line = _bench(common + ["--mode", "weak"])
     assert line["scaling"] == "weak" and line["n_gpus"] == 2
     st = line["strong_scaling"]
     assert "error" not in st, st
