@@ -188,6 +188,8 @@ static bool pack_on_device(const msnv_dataset *ds) {
 // Appends n streams as n samples through the device pack, in rounds of at most MSNV_PACK_ROUND_MB (default 6144) of record bytes.
 static int add_streams_device(msnv_dataset *ds, const uint8_t *const *records, const uint64_t *n_bytes, int n, bool streams_on_device, const uint8_t *in_place_base = nullptr, uint64_t in_place_capacity = 0) {
     HostTimerScope ts(HT_PACK_DEVICE_WALL);
+    fin_trace_reset();
+    struct Mark { ~Mark() { fin_trace("pack: whole call"); } } mark;
     const uint64_t round_bytes = [] { const char *e = getenv("MSNV_PACK_ROUND_MB"); const long long v = e ? atoll(e) : 6144; return (uint64_t)std::max<long long>(1, v) << 20; }();
     const size_t first = ds->samples.size();
     ds->samples.resize(first + (size_t)n);

@@ -136,6 +136,10 @@ struct DevPackTables {
     void     *contigs = nullptr;      // DpContig[n_contigs]
     uint32_t *pref4 = nullptr;        // nt16 codes of the FASTA records of the selected contigs, 8 per word, contig c from nibble pref_off[c]
     uint64_t  pref_words = 0;
+    // ... and on the host, for finalize (the reference is converted ONCE per dataset): the same words, per contig its first word (~0: none),
+    // and one bit per base "FASTA char is a lower-case a/c/g/t" (call_vC.cpp:580), 32 per word, contig c from word h_lc_off[c]
+    std::vector<uint32_t> h_codes, h_lc;
+    std::vector<uint64_t> h_code_off, h_lc_off;
     std::vector<void *> round_bufs;   // packed seq / quality-bit buffers of the rounds (SampleCols::d_seq / d_qual point into them): freed by finalize
     std::vector<std::pair<void *, uint64_t>> scratch;   // per-round work buffers, kept (grow-only) from round to round: {pointer, capacity}
     std::vector<DevRound> rounds;

@@ -149,6 +149,13 @@ __global__ __launch_bounds__(64) void msnv_acc_fold(DpAcc *acc, uint32_t n_sampl
     b = c == 0 ? t : z;                                          // (a copy that has been folded in counts nothing twice)
 }
 
+__global__ void msnv_acc_init(DpAcc *acc, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    DpAcc z{}; z.err = z.first_pile = z.beyond = ~0ull;
+    acc[i] = z;
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
@@ -1339,38 +1346,52 @@ int build_tables(msnv_dataset &ds) {
         d.bed_beg = ds.bed_beg[c]; d.bed_end = ds.bed_end[c]; d.sel = ds.sel[c]; d.pad = 0; d.pref_off = nib;
         if (ds.sel[c] && ds.has_seq[c]) nib += (ds.seqs[c].size() + 7) & ~(size_t)7;
     }
-    t.pref_words = nib / 8 + 8;                                  // (msnv_emit_pieces reads five words from a lane's first position)
+    t.pref_words = nib / 8 + 8;                                  // (msnv_emit_block reads five words from a lane's first position)
+    hipStream_t st = ds.ctx ? (hipStream_t)ds.ctx->stream : nullptr;
     if (int rc = dev_alloc(&t.contigs, std::max<size_t>(1, NC) * sizeof(DpContig), nullptr)) return rc;
-    if (int rc = dev_upload(t.contigs, ct.data(), NC * sizeof(DpContig))) return rc;
     if (int rc = dev_alloc((void **)&t.overhang, (std::max<size_t>(1, NC) + 1) * sizeof(int32_t), nullptr)) return rc;
-    if (int rc = dev_memset(t.overhang, 0, (std::max<size_t>(1, NC) + 1) * sizeof(int32_t))) return rc;
-    t.any_overhang = reinterpret_cast<uint32_t *>(t.overhang + std::max<size_t>(1, NC));
     if (int rc = dev_alloc((void **)&t.pref4, t.pref_words * sizeof(uint32_t), nullptr)) return rc;
-    // staged in chunks (a shard of a 25 GB database: gigabases)
-    std::vector<uint32_t> stage;
-    const size_t chunk_words = 16u << 20;
-    uint64_t w0 = 0;                                            // first word of the staging buffer
-    stage.reserve(chunk_words + 1024);
-    auto flush = [&]() -> int {
-        if (stage.empty()) return MSNV_OK;
-        if (int rc = dev_upload(t.pref4 + w0, stage.data(), stage.size() * sizeof(uint32_t))) return rc;
-        w0 += stage.size(); stage.clear();
-        return MSNV_OK;
-    };
+    HIP_TRY(hipMemcpyAsync(t.contigs, ct.data(), NC * sizeof(DpContig), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(t.overhang, 0, (std::max<size_t>(1, NC) + 1) * sizeof(int32_t), st));
+    t.any_overhang = reinterpret_cast<uint32_t *>(t.overhang + std::max<size_t>(1, NC));
+    // the FASTA characters of the selected contigs -> nt16 codes, 8 per word, and lower-case bits, 32 per word: once per dataset, kept on the
+    // host too (finalize lays them out by tile without going back to the characters); big references are cut into pieces for the host threads
+    static const struct Tab { uint8_t code[256], lc[256]; Tab() { for (int c = 0; c < 256; ++c) { code[c] = nt16_of_char((unsigned char)c); lc[c] = (c == 'a' || c == 'c' || c == 'g' || c == 't') ? 1 : 0; } } } tab;
+    t.h_codes.assign(t.pref_words, 0xffffffffu);
+    t.h_code_off.assign(NC, ~0ull); t.h_lc_off.assign(NC, ~0ull);
+    uint64_t lc_words = 0;
+    struct Job { size_t c; uint64_t w0, w1; };                   // words [w0, w1) of contig c
+    std::vector<Job> jobs;
     for (size_t c = 0; c < NC; ++c) {
         if (!ds.sel[c] || !ds.has_seq[c]) continue;
-        const std::string &sq = ds.seqs[c];
-        const size_t nw = (sq.size() + 7) / 8;
-        for (size_t w = 0; w < nw; ++w) {
-            uint32_t v = 0xffffffffu;
-            const size_t lim = std::min<size_t>(8, sq.size() - 8 * w);
-            for (size_t j = 0; j < lim; ++j) v = (v & ~(0xfu << (4 * j))) | (uint32_t)nt16_of_char((unsigned char)sq[8 * w + j]) << (4 * j);
-            stage.push_back(v);
-            if (stage.size() >= chunk_words) if (int rc = flush()) return rc;
-        }
+        t.h_code_off[c] = ct[c].pref_off / 8; t.h_lc_off[c] = lc_words;
+        const uint64_t nw = (ds.seqs[c].size() + 7) / 8;
+        lc_words += (ds.seqs[c].size() + 31) / 32;
+        for (uint64_t w = 0; w < nw; w += 1u << 16) jobs.push_back(Job{c, w, std::min<uint64_t>(nw, w + (1u << 16))});
     }
-    for (int k = 0; k < 8; ++k) stage.push_back(0xffffffffu);
-    if (int rc = flush()) return rc;
+    t.h_lc.assign(lc_words + 1, 0u);
+    auto run_job = [&](const Job &j) {
+        const std::string &sq = ds.seqs[j.c];
+        uint32_t *cw = t.h_codes.data() + t.h_code_off[j.c];
+        uint32_t *lw = t.h_lc.data() + t.h_lc_off[j.c];
+        for (uint64_t w = j.w0; w < j.w1; ++w) {
+            const size_t i0 = 8 * w, lim = std::min<size_t>(8, sq.size() - i0);
+            uint32_t v = 0xffffffffu, l = 0;
+            for (size_t k = 0; k < lim; ++k) { const unsigned char ch = (unsigned char)sq[i0 + k]; v = (v & ~(0xfu << (4 * k))) | (uint32_t)tab.code[ch] << (4 * k); l |= (uint32_t)tab.lc[ch] << k; }
+            cw[w] = v;
+            if (l) reinterpret_cast<uint8_t *>(lw)[w] = (uint8_t)l;          // (8 bases = one byte of the bit column: no two jobs share a byte)
+        }
+    };
+    if (jobs.size() <= 4) for (const Job &j : jobs) run_job(j);
+    else {
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> th;
+        const size_t nt = std::min<size_t>(std::min<size_t>(jobs.size() / 2, msnv_default_threads()), 32);
+        for (size_t k = 0; k < nt; ++k) th.emplace_back([&]() { for (;;) { const size_t i = next.fetch_add(1); if (i >= jobs.size()) break; run_job(jobs[i]); } });
+        for (auto &x : th) x.join();
+    }
+    HIP_TRY(hipMemcpyAsync(t.pref4, t.h_codes.data(), t.pref_words * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
     t.ready = true;
     return MSNV_OK;
 }
@@ -1399,6 +1420,7 @@ void devpack_release(DevPackTables &t) {
     for (auto &b : t.scratch) if (b.first) dev_free(b.first);
     t.scratch.clear();
     t.contigs = nullptr; t.pref4 = nullptr; t.ready = false;
+    std::vector<uint32_t>().swap(t.h_codes); std::vector<uint32_t>().swap(t.h_lc);
     if (t.fin_list) dev_free(t.fin_list);
     if (t.fin_cbase) dev_free(t.fin_cbase);
     t.fin_list = nullptr; t.fin_cbase = nullptr;
@@ -1855,7 +1877,9 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     if (!ds.ctx) return fail(MSNV_ENODEV, "the device pack needs a device context");
     if (int rc = dev_set_device(ds.ctx->device)) return rc;
     hipStream_t st = (hipStream_t)ds.ctx->stream;
+    fin_trace_reset();
     if (int rc = build_tables(ds)) return rc;
+    fin_trace("  pack: reference tables (first round)");
     DevPackTables &T = ds.dp;
     const size_t S = (size_t)n, NC = ds.names.size();
     const msnv_params &MP = ds.params;
@@ -1865,7 +1889,6 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     P.c_eff = std::min(std::max(MP.min_baseq, -127), 127); P.all_low = MP.min_baseq > 127;
     P.n_contigs = (int)NC; P.has_bed = ds.has_bed ? 1 : 0;
     Timer tm(st);
-    fin_trace_reset();
     // work buffers of the round: taken from the dataset's pool in call order (BufPool: grow-only, so a dataset's second round allocates nothing;
     // with guarded allocations -- MSNV_GUARD_ALLOC=1 -- every buffer is exact and fresh)
     BufPool pool{T.scratch};
@@ -1951,12 +1974,8 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     const size_t depth_bufs_from = pool.next;
     for (int pass = 0; pass < 2; ++pass) {
         pool.next = depth_bufs_from;
-        {
-            DpAcc a{}; a.err = a.first_pile = a.beyond = ~0ull;
-            std::vector<DpAcc> init(S * ACC_COPIES, a);
-            HIP_TRY(hipMemcpyAsync(d_acc, init.data(), init.size() * sizeof(DpAcc), hipMemcpyHostToDevice, st));
-            HIP_TRY(hipStreamSynchronize(st));
-        }
+        hipLaunchKernelGGL(msnv_acc_init, grid_for(S * ACC_COPIES, 256), dim3(256), 0, st, d_acc, (uint32_t)(S * ACC_COPIES));
+        HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemsetAsync(d_depth, 0, NRa * 2, st));
         uint32_t misc_h[MISC_WORDS] = {0, 0, 0, 0};
         tm.start();
@@ -1980,10 +1999,8 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
             if (misc_h[MISC_NOUT] <= CAP_OUT || span_out >= 0x40000000u) break;
             // more far-reaching reads than the list holds (long reads): they are the ordinary reads of this round -- a wider window, again
             span_out = span_out < 0x04000000u ? span_out * 16u : 0x7fffffffu;
-            DpAcc a{}; a.err = a.first_pile = a.beyond = ~0ull;
-            std::vector<DpAcc> init(S * ACC_COPIES, a);
-            HIP_TRY(hipMemcpyAsync(d_acc, init.data(), init.size() * sizeof(DpAcc), hipMemcpyHostToDevice, st));
-            HIP_TRY(hipStreamSynchronize(st));
+            hipLaunchKernelGGL(msnv_acc_init, grid_for(S * ACC_COPIES, 256), dim3(256), 0, st, d_acc, (uint32_t)(S * ACC_COPIES));
+            HIP_TRY(hipGetLastError());
         }
         NP = tot.pile;
         T.ms_measure += tm.stop();
@@ -2307,6 +2324,11 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
         }
     }
     HIP_TRY(hipStreamSynchronize(st));
+    {
+        std::vector<uint32_t> per(S, 0);
+        for (const DevPairRec &r : prec) ++per[r.sample];
+        for (size_t s = 0; s < S; ++s) ds.samples[first + s].dev_pairs.reserve(per[s]);
+    }
     for (size_t p = 0; p < prec.size(); ++p) {
         const DevPairRec &r = prec[p];
         SampleCols &sc = ds.samples[first + r.sample];

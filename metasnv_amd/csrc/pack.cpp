@@ -782,11 +782,42 @@ static void parallel_for(size_t n, F fn) {
     for (auto &t : th) t.join();
 }
 
-template <typename T>
-static int upload_vec(T **dst, const std::vector<T> &v, uint64_t *acct, size_t pad_elems = 0) {
-    if (int rc = dev_alloc((void **)dst, (v.size() + pad_elems) * sizeof(T), acct)) return rc;
-    return dev_upload(*dst, v.data(), v.size() * sizeof(T));
-}
+// The index tables of a dataset go up TOGETHER: finalize_dataset builds some thirty small tables (pairs, work items, tile tables, gate
+// descriptors ...); an allocation and a synchronous copy each was a millisecond of finalize.  add() copies a table into one staging block,
+// commit() makes one allocation and one copy of everything added so far and sets the tables' device pointers (so nothing on the device may
+// use a table between its add() and the next commit()).  The block is owned by DeviceCols::blocks.  With guarded allocations
+// (MSNV_GUARD_ALLOC=1) every table keeps an allocation of its own, so that a read past its end still faults.
+struct TableArena {
+    struct Ent { void **dst; size_t off, bytes; };
+    std::vector<Ent> ents;
+    std::vector<uint8_t> stage;
+    template <typename T>
+    int add(T **dst, const std::vector<T> &v, uint64_t *, size_t pad_elems = 0) {
+        const size_t off = (stage.size() + 255) & ~(size_t)255, bytes = (v.size() + pad_elems) * sizeof(T);
+        stage.resize(off + std::max<size_t>(bytes, 16), 0);
+        if (!v.empty()) memcpy(stage.data() + off, v.data(), v.size() * sizeof(T));
+        ents.push_back(Ent{reinterpret_cast<void **>(dst), off, std::max<size_t>(bytes, 16)});
+        return MSNV_OK;
+    }
+    int commit(DeviceCols &d) {
+        if (ents.empty()) return MSNV_OK;
+        static const bool guard = [] { const char *e = getenv("MSNV_GUARD_ALLOC"); return e && e[0] == '1'; }();
+        if (guard) {
+            for (const Ent &e : ents) {
+                if (int rc = dev_alloc(e.dst, e.bytes, &d.device_bytes)) return rc;
+                if (int rc = dev_upload(*e.dst, stage.data() + e.off, e.bytes)) return rc;
+            }
+        } else {
+            void *block = nullptr;
+            if (int rc = dev_alloc(&block, stage.size() + 256, &d.device_bytes)) return rc;
+            d.blocks.emplace_back(block, stage.size() + 256);
+            if (int rc = dev_upload(block, stage.data(), stage.size())) return rc;
+            for (const Ent &e : ents) *e.dst = static_cast<uint8_t *>(block) + e.off;
+        }
+        ents.clear(); stage.clear();
+        return MSNV_OK;
+    }
+};
 
 int finalize_dataset(msnv_dataset &ds) {
     const size_t S = ds.samples.size();
@@ -870,6 +901,7 @@ int finalize_dataset(msnv_dataset &ds) {
     lap("  tile tables");
     DeviceCols *d = new DeviceCols();
     ds.dev = d;
+    TableArena arena;
     d->n_tiles = ds.n_tiles; d->n_samples = (uint32_t)S;
 
     lap("tile layout");
@@ -881,8 +913,19 @@ int finalize_dataset(msnv_dataset &ds) {
         // a database shard is gigabases of FASTA)
         std::vector<size_t> with_seq;
         for (size_t c = 0; c < NC; ++c) if (ds.sel[c] && ds.has_seq[c]) with_seq.push_back(c);
-        parallel_for(with_seq.size(), [&](size_t k) {
-            const size_t c = with_seq[k];
+        // the device pack has converted the selected contigs once already (devpack.hip: build_tables -- codes 8 per word, lower-case bits 32 per
+        // word, per contig): a contig starts on a tile, so its words go into place as they are
+        const bool converted = ds.dp.ready && !ds.dp.h_codes.empty();
+        std::vector<size_t> by_char;
+        for (size_t c : with_seq) {
+            const uint64_t n = std::min<uint64_t>(ds.seqs[c].size(), (uint64_t)maxend[c]);
+            if (!converted || n != ds.seqs[c].size() || ds.dp.h_code_off[c] == ~0ull) { by_char.push_back(c); continue; }      // (a FASTA record longer than its contig's tiles: character by character)
+            const uint64_t g0 = (uint64_t)ds.tile_base[c] * TILE;
+            memcpy(ref4.data() + g0 / 8, ds.dp.h_codes.data() + ds.dp.h_code_off[c], ((n + 7) / 8) * 4);
+            memcpy(lc.data() + g0 / 32, ds.dp.h_lc.data() + ds.dp.h_lc_off[c], ((n + 31) / 32) * 4);
+        }
+        parallel_for(by_char.size(), [&](size_t k) {
+            const size_t c = by_char[k];
             const std::string &s = ds.seqs[c];
             const uint64_t g0 = (uint64_t)ds.tile_base[c] * TILE;
             const uint64_t lim = std::min<uint64_t>(s.size(), (uint64_t)maxend[c]);
@@ -894,8 +937,8 @@ int finalize_dataset(msnv_dataset &ds) {
                 if (ch == 'a' || ch == 'c' || ch == 'g' || ch == 't') lc[g >> 5] |= 1u << (g & 31);
             }
         });
-        if (int rc = upload_vec(&d->ref4, ref4, &d->device_bytes)) return rc;
-        if (int rc = upload_vec(&d->ref_lc, lc, &d->device_bytes)) return rc;
+        if (int rc = arena.add(&d->ref4, ref4, &d->device_bytes)) return rc;
+        if (int rc = arena.add(&d->ref_lc, lc, &d->device_bytes)) return rc;
         ds.info.bytes_ref = npos / 2;
     }
     lap("reference");
@@ -911,8 +954,8 @@ int finalize_dataset(msnv_dataset &ds) {
             e = std::min<int64_t>(std::max<int64_t>(e - t0, 0), TILE);
             vb[t] = (uint32_t)b; ve[t] = (uint32_t)e;
         }
-        if (int rc = upload_vec(&d->tile_vbeg, vb, &d->device_bytes)) return rc;
-        if (int rc = upload_vec(&d->tile_vend, ve, &d->device_bytes)) return rc;
+        if (int rc = arena.add(&d->tile_vbeg, vb, &d->device_bytes)) return rc;
+        if (int rc = arena.add(&d->tile_vend, ve, &d->device_bytes)) return rc;
         vb_host = vb; ve_host = ve;
     }
 
@@ -1090,7 +1133,7 @@ int finalize_dataset(msnv_dataset &ds) {
         }
         ds.tile_slot_stride = nslots;
         ds.tile_slot_base[nt] = (uint64_t)ds.slot_sample.size();
-        if (int rc = upload_vec(&d->tile_nslots, nslots, &d->device_bytes)) return rc;
+        if (int rc = arena.add(&d->tile_nslots, nslots, &d->device_bytes)) return rc;
         if (int rc = dev_alloc((void **)&d->tile_cell_base, (nt + 1) * sizeof(unsigned long long), &d->device_bytes)) return rc;
         if (int rc = dev_memset(d->tile_cell_base, 0, (nt + 1) * sizeof(unsigned long long))) return rc;
     }
@@ -1226,20 +1269,20 @@ int finalize_dataset(msnv_dataset &ds) {
         std::vector<uint32_t> active;
         for (uint64_t t = 0; t < nt; ++t) if (tss[t + 1] > tss[t]) active.push_back((uint32_t)t);
         d->n_active_tiles = (uint32_t)active.size();
-        if (int rc = upload_vec(&d->active_tiles, active, &d->device_bytes, 1)) return rc;
+        if (int rc = arena.add(&d->active_tiles, active, &d->device_bytes, 1)) return rc;
         // the spill gather only has something to do in tiles that hold pairs outside merged groups (the others -- every tile of a sparse
         // cohort -- would each cost a workgroup that looks its tile up and leaves)
         {
             std::vector<uint32_t> gather_tiles;
             for (uint32_t t : active) if (tpm[t] > tps[t]) gather_tiles.push_back(t);
             d->n_gather_tiles = (uint32_t)gather_tiles.size();
-            if (int rc = upload_vec(&d->gather_tiles, gather_tiles, &d->device_bytes, 1)) return rc;
+            if (int rc = arena.add(&d->gather_tiles, gather_tiles, &d->device_bytes, 1)) return rc;
         }
         d->part_bytes = std::max<uint64_t>(16, off[work.size()]);
-        if (int rc = upload_vec(&d->tile_slot_start, tss, &d->device_bytes)) return rc;
-        if (int rc = upload_vec(&d->tile_slot_u16, t16, &d->device_bytes)) return rc;
-        if (int rc = upload_vec(&d->tile_slot_wide, twide, &d->device_bytes)) return rc;
-        if (int rc = upload_vec(&d->slot_off, off, &d->device_bytes)) return rc;
+        if (int rc = arena.add(&d->tile_slot_start, tss, &d->device_bytes)) return rc;
+        if (int rc = arena.add(&d->tile_slot_u16, t16, &d->device_bytes)) return rc;
+        if (int rc = arena.add(&d->tile_slot_wide, twide, &d->device_bytes)) return rc;
+        if (int rc = arena.add(&d->slot_off, off, &d->device_bytes)) return rc;
         if (int rc = dev_alloc((void **)&d->part, d->part_bytes, &d->device_bytes)) return rc;
         // one descriptor per active tile for the gate kernel: everything it looks up about its tile in one load
         std::vector<uint32_t> nslots_host(nt + 1, 0);
@@ -1248,7 +1291,7 @@ int finalize_dataset(msnv_dataset &ds) {
         gts.reserve(active.size());
         for (uint32_t t : active) gts.push_back(DeviceCols::GateTileH{t, tss[t], t16[t], twide[t], tss[t + 1], vb_host[t], ve_host[t], nslots_host[t], off[tss[t]], tot_mode(t), (uint32_t)fuse_tile[t],
                                                                       tps[t], tpm[t] - tps[t], 0, 0});
-        if (int rc = upload_vec(&d->gate_tiles, gts, &d->device_bytes, 1)) return rc;
+        if (int rc = arena.add(&d->gate_tiles, gts, &d->device_bytes, 1)) return rc;
         d->gather_split = (uint32_t)std::min<uint64_t>(4, std::max<uint64_t>(1, (active.empty() ? 0 : pairs.size() / active.size()) / 32));
         if (const char *e = getenv("MSNV_GATHER_SPLIT")) d->gather_split = (uint32_t)std::max(1, atoi(e));      // (tuning experiments)
         {   // whole-tile work items write their candidate records per active tile
@@ -1264,9 +1307,9 @@ int finalize_dataset(msnv_dataset &ds) {
                     g.row0 = (uint64_t)i;                              // (a whole-tile item writes no partial row: the field carries the index of its record list)
                     staged_l.push_back(g);
                 }
-                if (int rc = upload_vec(&d->gate_tiles_dense, dense_l, &d->device_bytes, 1)) return rc;
-                if (int rc = upload_vec(&d->gate_tiles_staged, staged_l, &d->device_bytes, 1)) return rc;
-                if (int rc = upload_vec(&d->tile_stage_idx, stage_idx, &d->device_bytes)) return rc;
+                if (int rc = arena.add(&d->gate_tiles_dense, dense_l, &d->device_bytes, 1)) return rc;
+                if (int rc = arena.add(&d->gate_tiles_staged, staged_l, &d->device_bytes, 1)) return rc;
+                if (int rc = arena.add(&d->tile_stage_idx, stage_idx, &d->device_bytes)) return rc;
                 // (+ one index per whole-tile item behind the lists: the tiles whose candidates do not fit a list -- kernels.hip: stage_ovf_list)
                 if (int rc = dev_alloc((void **)&d->tile_stage, (uint64_t)active.size() * sizeof(TileStage) + (uint64_t)n_fused * sizeof(uint32_t), &d->device_bytes)) return rc;
                 if (int rc = dev_memset(d->tile_stage, 0, (uint64_t)active.size() * sizeof(TileStage))) return rc;
@@ -1286,10 +1329,11 @@ int finalize_dataset(msnv_dataset &ds) {
         // the pieces are in HBM: pairs and the per-sample bases go up first, the 16-byte headers are put together there (positions made
         // linear), and the chunks of every narrow pair are cut by a kernel that runs the same greedy rule as the loop below
         d->n_pairs = (uint32_t)pairs.size();
-        if (int rc = upload_vec(&d->pairs, pairs, &d->device_bytes)) return rc;
-        if (int rc = upload_vec(&d->s_read_base, rbase, &d->device_bytes)) return rc;
-        if (int rc = upload_vec(&d->s_seq_base, sbase, &d->device_bytes)) return rc;
+        if (int rc = arena.add(&d->pairs, pairs, &d->device_bytes)) return rc;
+        if (int rc = arena.add(&d->s_read_base, rbase, &d->device_bytes)) return rc;
+        if (int rc = arena.add(&d->s_seq_base, sbase, &d->device_bytes)) return rc;
         if (int rc = dev_alloc((void **)&d->hdr, (rbase[S] + 1) * sizeof(ReadHdr), &d->device_bytes)) return rc;
+        if (int rc = arena.commit(*d)) return rc;                  // (everything so far: the kernels below read pairs, bases, reference)
         lap("  pairs / bases up, hdr alloc");
         if (int rc = devfin_headers(ds, *d, rbase)) return rc;
         lap("  devfin_headers");
@@ -1397,11 +1441,11 @@ int finalize_dataset(msnv_dataset &ds) {
         } else {
             ds.info.bytes_headers += hm.size() * sizeof(PieceHdr);
             d->n_hdr8m = hm.size();
-            if (int rc = upload_vec(&d->hdr8m, hm, &d->device_bytes, 1)) return rc;
+            if (int rc = arena.add(&d->hdr8m, hm, &d->device_bytes, 1)) return rc;
         }
         d->n_merged_groups = (uint32_t)mgroups.size();
-        if (int rc = upload_vec(&d->merged_groups, mgroups, &d->device_bytes, 1)) return rc;
-        if (int rc = upload_vec(&d->tile_pair_merged, tpm, &d->device_bytes)) return rc;
+        if (int rc = arena.add(&d->merged_groups, mgroups, &d->device_bytes, 1)) return rc;
+        if (int rc = arena.add(&d->tile_pair_merged, tpm, &d->device_bytes)) return rc;
     }
     if (!fast) for (size_t wi = 0; wi < (size_t)d->n_work_narrow + d->n_work_merged; ++wi)
         if (work[wi].chunk_hi > work[wi].chunk_lo) work[wi].first = chunks[work[wi].chunk_lo];
@@ -1410,12 +1454,13 @@ int finalize_dataset(msnv_dataset &ds) {
     if (int rc = dev_upload(d->chunks + n_chunks_dev, chunks.data(), chunks.size() * sizeof(ChunkDesc))) return rc;
     if (fast && !dense) if (int rc = devfin_chunk_fill(ds, *d, n_pairs_listed)) return rc;
     d->n_pairs = (uint32_t)pairs.size(); d->n_work = (uint32_t)work.size();
-    if (!fast) if (int rc = upload_vec(&d->pairs, pairs, &d->device_bytes)) return rc;
-    if (int rc = upload_vec(&d->tile_pair_start, tps, &d->device_bytes)) return rc;
-    if (int rc = upload_vec(&d->work, work, &d->device_bytes)) return rc;
+    if (!fast) if (int rc = arena.add(&d->pairs, pairs, &d->device_bytes)) return rc;
+    if (int rc = arena.add(&d->tile_pair_start, tps, &d->device_bytes)) return rc;
+    if (int rc = arena.add(&d->work, work, &d->device_bytes)) return rc;
+    if (!fast) if (int rc = arena.add(&d->s_read_base, rbase, &d->device_bytes)) return rc;
+    if (!fast) if (int rc = arena.add(&d->s_seq_base, sbase, &d->device_bytes)) return rc;
+    if (int rc = arena.commit(*d)) return rc;
     if (fast) if (int rc = devfin_work_first(ds, *d, d->n_work_narrow + d->n_work_merged)) return rc;
-    if (!fast) if (int rc = upload_vec(&d->s_read_base, rbase, &d->device_bytes)) return rc;
-    if (!fast) if (int rc = upload_vec(&d->s_seq_base, sbase, &d->device_bytes)) return rc;
 
     lap("merged groups");
     // ---- columns
@@ -1593,12 +1638,13 @@ int finalize_dataset(msnv_dataset &ds) {
         if (!fast) d->n_cov_iv = iv.size();
         for (int k = 0; k < 4; ++k) iv.push_back(Pair32{0u, 0u});     // behind the last interval: what the idle lanes of msnv_coverage_tiles load, four at a time (they touch nothing)
         d->n_cov_pairs = (uint32_t)cpairs.size(); d->n_cov_work = (uint32_t)cwork.size(); d->n_contigs = (uint32_t)NC;
-        if (!fast) if (int rc = upload_vec(&d->cov_iv, iv, &d->device_bytes, 1)) return rc;
-        if (int rc = upload_vec(&d->s_cov_base, cvbase, &d->device_bytes)) return rc;
-        if (int rc = upload_vec(&d->cov_pairs, cpairs, &d->device_bytes, 1)) return rc;
-        if (int rc = upload_vec(&d->cov_work, cwork, &d->device_bytes, 1)) return rc;
-        if (int rc = upload_vec(&d->tile_len, tlen, &d->device_bytes)) return rc;
-        if (int rc = upload_vec(&d->tile_contig_dev, tcont, &d->device_bytes)) return rc;
+        if (!fast) if (int rc = arena.add(&d->cov_iv, iv, &d->device_bytes, 1)) return rc;
+        if (int rc = arena.add(&d->s_cov_base, cvbase, &d->device_bytes)) return rc;
+        if (int rc = arena.add(&d->cov_pairs, cpairs, &d->device_bytes, 1)) return rc;
+        if (int rc = arena.add(&d->cov_work, cwork, &d->device_bytes, 1)) return rc;
+        if (int rc = arena.add(&d->tile_len, tlen, &d->device_bytes)) return rc;
+        if (int rc = arena.add(&d->tile_contig_dev, tcont, &d->device_bytes)) return rc;
+        if (int rc = arena.commit(*d)) return rc;
         // accumulator copies: as many as fit 64 MB, at most 8 (many contigs = few tiles per contig = little contention anyway)
         d->n_cov_rows = ds.cov_row_sample.size();
         const uint64_t acc_bytes = std::max<uint64_t>(1, d->n_cov_rows) * (1 + COV_BINS) * sizeof(unsigned long long);
