@@ -257,8 +257,10 @@ int  msnv_dataset_add_sample_records_device(msnv_dataset *ds, const void *const 
  * at least 256 readable bytes behind the last stream's end (the kernels read whole 16-byte pieces around a record); the streams must not
  * overlap and must come in ascending order.  The library reads the records where they lie and MAY EDIT base qualities in place (htslib's
  * overlapping-mate tweak, snpCall's token limit: what the reference tools do to their own copy of a record, sam.c [EXT],
- * call_vC.cpp:481-483): the buffer's contents are the library's until the call returns.  What the device inflate leaves in HBM goes
- * this way, and the bench's "records resident in HBM -> calls" region starts here. */
+ * call_vC.cpp:481-483).  The last kernels of the call may still be READING the buffer when it returns (the host goes on with the
+ * tile index meanwhile): the buffer is the library's -- valid, not written by anyone else -- until the NEXT call on this dataset that
+ * adds samples, finalizes or destroys it has returned.  What the device inflate leaves in HBM goes this way, and the bench's "records
+ * resident in HBM -> calls" region starts here. */
 int  msnv_dataset_add_sample_records_resident(msnv_dataset *ds, void *dev_buffer, uint64_t capacity, const uint64_t *offsets, const uint64_t *n_bytes, int32_t n);
 int  msnv_dataset_add_sample_bam(msnv_dataset *ds, const char *bam_path);
 /* Decode many BAMs with a host thread pool, preserving order. */

@@ -60,6 +60,7 @@ namespace msnv { void dev_inflate_release(msnv_ctx *ctx); }
 extern "C" void msnv_ctx_destroy(msnv_ctx *ctx) {
     if (!ctx) return;
     dev_inflate_release(ctx);
+    devpack_ctx_release(ctx);
     dev_cache_trim();
     dev_stream_destroy(ctx->stream);
     delete ctx;
@@ -1115,6 +1116,7 @@ extern "C" int msnv_dataset_finalize(msnv_dataset *ds) {
 extern "C" int msnv_dataset_pack_stats(const msnv_dataset *ds, double *out, int32_t n) {
     clear_error();
     if (!ds || !out || n < 0) return fail(MSNV_EINVAL, "msnv_dataset_pack_stats: bad argument");
+    if (devpack_sync_pending(*const_cast<msnv_dataset *>(ds))) clear_error();      // (the last round's kernels: their time belongs to the figures)
     const DevPackTables &t = ds->dp;
     const double v[MSNV_PACK_STATS] = {t.ms_scan, t.ms_measure, t.ms_depth, t.ms_emit, t.ms_sort, t.wall_upload_s, t.wall_download_s, t.wall_prepass_s,
                                        (double)t.raw_bytes, (double)t.n_records, (double)t.n_pieces, (double)t.n_prepass_samples, (double)t.n_scan_redone, (double)t.n_deep_runs_split, (double)t.n_dense_samples};

@@ -146,6 +146,11 @@ struct DevPackTables {
     int32_t  *overhang = nullptr;     // per contig: furthest end of a piece beyond the contig's length (0: none), device
     uint32_t *any_overhang = nullptr; // device flag
     bool      ready = false;
+    // a round whose last kernels (msnv_emit_block: bases and headers out) may still be running when devpack_add_round returns: what is left
+    // to read of it -- the mismatch sample of its samples, the kernels' time -- is taken by devpack_sync_pending, which everything that
+    // needs the round finished calls first (the next round, finalize before it decides the allele bookkeeping, the statistics, release)
+    struct Pending { bool active = false; size_t first = 0, n = 0; void *ev0 = nullptr, *ev1 = nullptr; } pending;
+    bool      any_overhang_h = false; // some read of some round runs past its contig (msnv_measure_reads): finalize fetches `overhang`
     void     *fin_list = nullptr, *fin_cbase = nullptr;   // finalize on the device: the narrow pairs' list and their chunk counts / scan, between devfin_chunk_counts and devfin_chunk_fill
     // cumulative device-pack accounting (msnv_host_timers: pack_device_wall_s; msnv_devpack_stats)
     double    ms_scan = 0, ms_measure = 0, ms_depth = 0, ms_emit = 0, ms_sort = 0, wall_upload_s = 0, wall_download_s = 0, wall_prepass_s = 0;
@@ -172,6 +177,7 @@ struct msnv_ctx {
     // (pinning memory costs ~0.25 s per GB: paid once, not per batch of BAMs)
     void *pin_in = nullptr, *pin_out = nullptr, *dev_in = nullptr, *dev_out = nullptr;
     uint64_t pin_in_cap = 0, pin_out_cap = 0, dev_in_cap = 0, dev_out_cap = 0;
+    void *pin_small = nullptr; uint64_t pin_small_cap = 0;   // pinned words for small results a kernel leaves behind an asynchronous copy (devpack.hip)
 };
 
 struct msnv_dataset {

@@ -17,6 +17,9 @@ namespace msnv {
 // index from them); bases and quality bits stay in HBM.
 // in_place_base != NULL (streams on the device, all inside [in_place_base, + in_place_capacity), 16-byte aligned base, 256 readable bytes behind
 // the last stream): the records are read where they lie, no copy into a round buffer (qualities may be edited there).
+// waits for the round devpack_add_round left running, if any, and takes its last results (dataset.h: DevPackTables::Pending)
+int devpack_sync_pending(msnv_dataset &ds);
+void devpack_ctx_release(msnv_ctx *ctx);                         // the context's pinned words (msnv_ctx_destroy)
 int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *streams, const uint64_t *n_bytes, int n, bool on_device, const uint8_t *in_place_base = nullptr, uint64_t in_place_capacity = 0);
 // A device-packed sample's bases and quality flags as host staging (SampleCols::seq / qual), for the two re-layouts that still run on
 // the host (pack.cpp: relayout_dense, split_deep_runs' relocation).

@@ -408,7 +408,7 @@ __global__ void msnv_compact_offsets(const unsigned long long *tmp_off, const Co
 // own (tile order, below) and its first byte of the seq column.
 struct RecCnt { uint32_t pile, npiece, niv, spill; unsigned long long seqb; };
 struct RecCntSum { __device__ __host__ RecCnt operator()(const RecCnt &a, const RecCnt &b) const { return RecCnt{a.pile + b.pile, a.npiece + b.npiece, a.niv + b.niv, a.spill + b.spill, a.seqb + b.seqb}; } };
-enum : uint32_t { MISC_SORT = 0, MISC_SPAN = 1, MISC_NOUT = 2, MISC_WORDS = 4 };   // words of the round's flag block: [MISC_SORT] the pieces need the general tile-order sort;
+enum : uint32_t { MISC_SORT = 0, MISC_SPAN = 1, MISC_NOUT = 2, MISC_OVERHANG = 3, MISC_WORDS = 4 };   // words of the round's flag block: [MISC_SORT] the pieces need the general tile-order sort;
                                                                    // [MISC_SPAN] longest reference span of an ordinary pileup read; [MISC_NOUT] reads listed as outliers (msnv_depth)
 // The records of a round in blocks of PB = one wavefront: the kernels that go over the records hold a block per wavefront, a block's sums
 // (blk_cnt) are written by the measure kernel, ONE small scan over the blocks gives every block its base (blk_pre), and a record's own
@@ -435,7 +435,7 @@ __device__ __forceinline__ RecCnt cnt_add(const RecCnt &a, const RecCnt &b) { re
 __global__ __launch_bounds__(256) void msnv_measure_reads(const uint8_t *raw, const unsigned long long *rec_off, const uint16_t *rec_sample, const uint32_t *rec_base,
                                                           const unsigned long long *s_end, uint32_t n_rec, const DpContig *ctg, DpParams P, const uint32_t *ovr,
                                                           uint8_t *r_flags, unsigned long long *r_key, uint32_t *r_end, uint32_t *r_maxc, RecCnt *r_cnt, uint32_t *r_ftile,
-                                                          RecCnt *blk_cnt, DpAcc *acc, uint32_t *misc, uint32_t *outliers, uint32_t span_out) {
+                                                          RecCnt *blk_cnt, DpAcc *acc, uint32_t *misc, uint32_t *outliers, uint32_t span_out, int32_t *overhang) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = i < n_rec;
     const uint32_t s = valid ? rec_sample[i] : 0xffffffffu;
@@ -478,6 +478,7 @@ __global__ __launch_bounds__(256) void msnv_measure_reads(const uint8_t *raw, co
                     long long rlen = 0, qlen = 0, m_bases = 0, ins = 0, del = 0, rp = r.pos, pp = (long long)r.pos + 1;
                     bool has_ref_op = false, beyond = false;
                     uint32_t n_piece = 0, seqb = 0, n_iv = 0, ftile = 0, ltile = 0, n_spill = 0;
+                    long long m_end = 0;                                                     // end of the last aligned block
                     unsigned long long a_seq = 0;
                     uint32_t k0 = 0;
                     if (r.n_cigar > 0) { const uint32_t t = ld32(r.cigar) & 15u; if (t == C_S || t == C_H) k0 = 1; }
@@ -502,7 +503,7 @@ __global__ __launch_bounds__(256) void msnv_measure_reads(const uint8_t *raw, co
                                 ltile = tl;
                                 ++n_piece; seqb += stored_bytes(n); a_seq += (n + 1u) / 2u;
                             }
-                            rp += l;
+                            rp += l; m_end = rp;
                         } else if (cg_ref(t)) rp += l;
                     }
                     const long long endpos = (long long)r.pos + (rlen ? rlen : 1);           // bam_endpos
@@ -531,6 +532,8 @@ __global__ __launch_bounds__(256) void msnv_measure_reads(const uint8_t *raw, co
                         alg_cigar = 4ull * r.n_cigar;
                         // SEQ '*' (l_seq = 0): N bases of quality 0, shipped only under -Q 0 (pack.cpp: pack_sample)
                         if (r.l_seq > 0 || (P.c_eff == 0 && !P.all_low)) { o_np = n_piece; o_sb = seqb; alg_seq = a_seq; alg_qual = (unsigned long long)m_bases; }
+                        // a read whose pieces run past its contig: the contig's tiles reach that far (finalize)
+                        if (o_np && m_end > c.len) { atomicMax(&overhang[r.tid], (int32_t)(m_end < 0x7fffffffll ? m_end : 0x7fffffffll)); misc[MISC_OVERHANG] = 1u; }
                         o_ftile = ftile; o_spill = o_np ? n_spill : 0u;
                         // tile order by counting (msnv_emit_headers) needs every pileup read to leave pieces in its first tile and at most the
                         // one behind it; a read that reaches further (a reference skip, a read of thousands of bases) or ships no piece at all
@@ -989,7 +992,7 @@ __device__ __forceinline__ void piece_lane(const Src &src, unsigned long long se
 struct EmitArgs {
     const uint8_t *raw; const unsigned long long *rec_off; const uint16_t *rec_sample; uint32_t n_rec; const DpContig *ctg; const uint8_t *r_flags; const uint16_t *r_depth;
     const RecCnt *r_cnt, *blk_pre; const unsigned long long *samp_sbase0, *rg; const uint2 *grp_pre; uint32_t in_order;
-    ReadHdr *hdr; int32_t *ptid, *pend; uint16_t *pdepth; int32_t *cov_tid, *cov_beg, *cov_end, *overhang; uint32_t *any_overhang; uint32_t noseq_counts;
+    ReadHdr *hdr; int32_t *ptid, *pend; uint16_t *pdepth; int32_t *cov_tid, *cov_beg, *cov_end; uint32_t noseq_counts;
     const uint32_t *pref4; DpParams P; const DpSampleDst *dst; DpAcc *acc;
 };
 // One record by its four lanes (sub = 0 .. 3): every lane reads the header and walks the CIGAR (LDS: cheap), lane 0 writes the intervals
@@ -1088,7 +1091,6 @@ __device__ __forceinline__ void emit_record(const EmitArgs &A, const Src &src, c
                     ReadHdr h;
                     h.gpos = (uint32_t)(rp + off); h.seqoff = (uint32_t)so; h.cig = n; h.meta = META_PILEUP_OK | mapq << 16;
                     A.hdr[dst] = h; A.ptid[dst] = tid; A.pend[dst] = (int32_t)(rp + off + n); A.pdepth[dst] = depth;
-                    if (rp + off + n > c.len) { atomicMax(&A.overhang[tid], (int32_t)(rp + off + n)); *A.any_overhang = 1u; }     // a read that runs past its contig: the contig's tiles reach that far (finalize)
                 }
                 // ---- this lane's 32 bases of the piece
                 unsigned long long ref_nib; uint32_t ref_left;
@@ -1408,7 +1410,27 @@ const char *err_text(uint32_t kind) {
 
 }  // namespace
 
+int devpack_sync_pending(msnv_dataset &ds) {
+    DevPackTables &T = ds.dp;
+    if (!T.pending.active) return MSNV_OK;
+    T.pending.active = false;
+    HIP_TRY(hipEventSynchronize((hipEvent_t)T.pending.ev1));
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, (hipEvent_t)T.pending.ev0, (hipEvent_t)T.pending.ev1) == hipSuccess) T.ms_emit += ms;
+    const DpAcc *a = static_cast<const DpAcc *>(ds.ctx->pin_small);
+    for (size_t s = 0; s < T.pending.n && T.pending.first + s < ds.samples.size(); ++s) {
+        SampleCols &sc = ds.samples[T.pending.first + s];
+        sc.mm_sampled_bases = a[s].mm_bases; sc.mm_sampled = a[s].mm;
+    }
+    return MSNV_OK;
+}
+void devpack_ctx_release(msnv_ctx *ctx) {
+    if (ctx && ctx->pin_small) { (void)hipHostFree(ctx->pin_small); ctx->pin_small = nullptr; ctx->pin_small_cap = 0; }
+}
+
 void devpack_release(DevPackTables &t) {
+    if (t.pending.active) { (void)hipDeviceSynchronize(); t.pending.active = false; }
+    if (t.pending.ev0) { (void)hipEventDestroy((hipEvent_t)t.pending.ev0); (void)hipEventDestroy((hipEvent_t)t.pending.ev1); t.pending.ev0 = t.pending.ev1 = nullptr; }
     if (t.contigs) dev_free(t.contigs);
     if (t.pref4) dev_free(t.pref4);
     if (t.overhang) dev_free(t.overhang);
@@ -1878,6 +1900,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     if (int rc = dev_set_device(ds.ctx->device)) return rc;
     hipStream_t st = (hipStream_t)ds.ctx->stream;
     fin_trace_reset();
+    if (int rc = devpack_sync_pending(ds)) return rc;              // (the round before may still be writing: its work buffers are this round's)
     if (int rc = build_tables(ds)) return rc;
     fin_trace("  pack: reference tables (first round)");
     DevPackTables &T = ds.dp;
@@ -1984,7 +2007,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
             HIP_TRY(hipMemsetAsync(d_blkcnt + NB, 0, sizeof(RecCnt), st));
             if (NR) {
                 hipLaunchKernelGGL(msnv_measure_reads, grid_for(NR, 256), dim3(256), 0, st, raw, d_recoff, d_recsample, d_recbase, d_send, NR, ctg, P, have_ovr ? d_ovr : nullptr, d_flags,
-                                   d_key, d_end, d_maxc, d_cnt, d_ftile, d_blkcnt, d_acc, d_misc, d_outl, span_out);
+                                   d_key, d_end, d_maxc, d_cnt, d_ftile, d_blkcnt, d_acc, d_misc, d_outl, span_out, T.overhang);
                 HIP_TRY(hipGetLastError());
             }
             {   // every block's base: rank among the pileup reads, first piece, first interval, next-tile pieces before it, first seq byte
@@ -1996,6 +2019,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
             HIP_TRY(hipMemcpyAsync(&tot, d_blkpre + NB, sizeof(RecCnt), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipMemcpyAsync(misc_h, d_misc, MISC_WORDS * 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
+            if (misc_h[MISC_OVERHANG]) T.any_overhang_h = true;
             if (misc_h[MISC_NOUT] <= CAP_OUT || span_out >= 0x40000000u) break;
             // more far-reaching reads than the list holds (long reads): they are the ordinary reads of this round -- a wider window, again
             span_out = span_out < 0x04000000u ? span_out * 16u : 0x7fffffffu;
@@ -2223,12 +2247,15 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     }
     HIP_TRY(hipMemcpyAsync(d_dst, dsts.data(), S * sizeof(DpSampleDst), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_pb, piece_bytes.data(), S * 8, hipMemcpyHostToDevice, st));
+    T.ms_emit += tm.stop();                                         // (the layout step; the emit kernels' time arrives with devpack_sync_pending)
+    if (!T.pending.ev0) { hipEvent_t a = nullptr, b = nullptr; HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b)); T.pending.ev0 = a; T.pending.ev1 = b; }
+    HIP_TRY(hipEventRecord((hipEvent_t)T.pending.ev0, st));
     if (NR) {
         EmitArgs A{};
         A.raw = raw; A.rec_off = d_recoff; A.rec_sample = d_recsample; A.n_rec = NR; A.ctg = ctg; A.r_flags = d_flags; A.r_depth = d_depth; A.r_cnt = d_cnt; A.blk_pre = d_blkpre;
         A.samp_sbase0 = d_ss0; A.rg = d_rg; A.grp_pre = d_grppre; A.in_order = in_order ? 1u : 0u;
         A.hdr = w_hdr; A.ptid = w_tid; A.pend = w_end; A.pdepth = w_depth; A.cov_tid = keep.cov_tid; A.cov_beg = keep.cov_beg; A.cov_end = keep.cov_end;
-        A.overhang = T.overhang; A.any_overhang = T.any_overhang; A.noseq_counts = (P.c_eff == 0 && !P.all_low) ? 1u : 0u;
+        A.noseq_counts = (P.c_eff == 0 && !P.all_low) ? 1u : 0u;
         A.pref4 = T.pref4; A.P = P; A.dst = d_dst; A.acc = d_acc;
         hipLaunchKernelGGL(msnv_emit_block, dim3((unsigned)NB), dim3(256), 0, st, A);
         HIP_TRY(hipGetLastError());
@@ -2236,12 +2263,28 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     hipLaunchKernelGGL(msnv_emit_tail, dim3((unsigned)S), dim3(64), 0, st, d_dst, d_pb, (uint32_t)S, P);
     hipLaunchKernelGGL(msnv_acc_fold, dim3((unsigned)S), dim3(64), 0, st, d_acc, (uint32_t)S);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy2DAsync(acc.data(), sizeof(DpAcc), d_acc, sizeof(DpAcc) * ACC_COPIES, sizeof(DpAcc), S, hipMemcpyDeviceToHost, st));
-    T.ms_emit += tm.stop();
+    // The round's last kernels are left RUNNING: nothing the host still has to do for this round -- its (sample, tile) pairs, its tables --
+    // and little of what finalize does first needs the bases or the headers.  What they leave for the host (the mismatch sample of every
+    // sample, their time) comes through pinned memory and is taken by devpack_sync_pending.
+    {
+        msnv_ctx *ctx = ds.ctx;
+        const uint64_t need = std::max<uint64_t>(S * sizeof(DpAcc), 4096);
+        if (ctx->pin_small_cap < need) {
+            if (ctx->pin_small) (void)hipHostFree(ctx->pin_small);
+            ctx->pin_small = nullptr; ctx->pin_small_cap = 0;
+            const uint64_t want = std::max<uint64_t>(need, 2048 * sizeof(DpAcc));
+            HIP_TRY(hipHostMalloc(&ctx->pin_small, want, hipHostMallocDefault));
+            ctx->pin_small_cap = want;
+        }
+        HIP_TRY(hipMemcpy2DAsync(ctx->pin_small, sizeof(DpAcc), d_acc, sizeof(DpAcc) * ACC_COPIES, sizeof(DpAcc), S, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord((hipEvent_t)T.pending.ev1, st));
+        T.pending.active = true; T.pending.first = first; T.pending.n = S;
+    }
+    if (in_order) if (int rc = devpack_sync_pending(ds)) return rc;      // (the general tile-order route below waits for its sort anyway)
 
     fin_trace("  pack: emit (sync)");
     // ---- the (sample, contig, tile) runs of pieces = the pairs of the tile index
-    tm.start();
+    if (in_order) tm.start();
     std::vector<DevPairRec> prec;
     if (NPC >= 1 && in_order) {
         // the general route: stable sort of the headers by (sample, contig, tile), runs of equal keys
@@ -2293,7 +2336,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
             if (!next_adj && G.end > G.b) prec.push_back(DevPairRec{G.sample, G.tid, G.tile + 1u, G.b, G.md_next});
         }
     }
-    T.ms_sort += tm.stop();
+    if (in_order) T.ms_sort += tm.stop();                          // (the counting route is host work on the groups: nothing to wait for)
 
     fin_trace("  pack: pairs");
     // ---- what the host keeps of a sample: its summaries and its (contig, tile) runs
@@ -2323,7 +2366,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
                     (int32_t)(uint32_t)sum[s].beyond_key + 1);
         }
     }
-    HIP_TRY(hipStreamSynchronize(st));
+    if (in_order) HIP_TRY(hipStreamSynchronize(st));               // (the sorted pairs come down asynchronously)
     {
         std::vector<uint32_t> per(S, 0);
         for (const DevPairRec &r : prec) ++per[r.sample];
@@ -2612,21 +2655,7 @@ __global__ void msnv_gather_u32(const uint32_t *src, const unsigned long long *i
 }  // namespace
 
 int devfin_overhang(msnv_dataset &ds, std::vector<int64_t> &maxend) {
-    if (!ds.dp.overhang) return MSNV_OK;
-    uint32_t any = 0;
-    fin_trace("    overhang: enter");
-    if (getenv("MSNV_OVERHANG_ASYNC") && getenv("MSNV_OVERHANG_ASYNC")[0] == '2') {
-        static uint32_t *pin = nullptr; if (!pin) HIP_TRY(hipHostMalloc((void **)&pin, 4096, 0));
-        hipStream_t st = (hipStream_t)ds.ctx->stream;
-        fin_trace("    overhang: pinned ready");
-        HIP_TRY(hipStreamSynchronize(st));
-        fin_trace("    overhang: stream idle");
-        HIP_TRY(hipMemcpyAsync(pin, ds.dp.any_overhang, 4, hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st)); any = pin[0];
-    }
-    else if (getenv("MSNV_OVERHANG_ASYNC")) { hipStream_t st = (hipStream_t)ds.ctx->stream; HIP_TRY(hipMemcpyAsync(&any, ds.dp.any_overhang, 4, hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st)); }
-    else HIP_TRY(hipMemcpy(&any, ds.dp.any_overhang, 4, hipMemcpyDeviceToHost));
-    fin_trace("    overhang: flag down");
-    if (!any) return MSNV_OK;
+    if (!ds.dp.overhang || !ds.dp.any_overhang_h) return MSNV_OK;   // (the measure kernel of every round said whether a read runs past its contig)
     std::vector<int32_t> oh(ds.names.size());
     HIP_TRY(hipMemcpy(oh.data(), ds.dp.overhang, oh.size() * 4, hipMemcpyDeviceToHost));
     for (size_t c = 0; c < oh.size(); ++c) if (ds.sel[c]) maxend[c] = std::max<int64_t>(maxend[c], oh[c]);
@@ -3306,6 +3335,7 @@ int devpack_copy_blocks(const SampleCols &sc, uint32_t *dst, void *stream) {
 
 int devpack_finish(msnv_dataset &ds) {
     if (!ds.dp.ready && ds.dp.round_bufs.empty()) return MSNV_OK;
+    if (int rc = devpack_sync_pending(ds)) return rc;
     if (ds.ctx) HIP_TRY(hipStreamSynchronize((hipStream_t)ds.ctx->stream));
     for (SampleCols &sc : ds.samples) { sc.d_seq = nullptr; sc.d_qual = nullptr; }
     devpack_release(ds.dp);

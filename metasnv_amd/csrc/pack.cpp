@@ -855,7 +855,7 @@ int finalize_dataset(msnv_dataset &ds) {
                 }
             }
         }
-        if (any_dev && !fast) if (int rc = devpack_download_pieces(ds)) return rc;
+        if (any_dev && !fast) { if (int rc = devpack_sync_pending(ds)) return rc; if (int rc = devpack_download_pieces(ds)) return rc; }
     }
 
     lap("decide / download");
@@ -1675,6 +1675,7 @@ int finalize_dataset(msnv_dataset &ds) {
         // pairs -- on planes, where the five-plane gather over its 526 k sites cost more than the events: 4.95 vs 4.08 ms);
         // MSNV_ALLELES=planes | events overrides.
         // Needs byte counts everywhere: not with wide work items (MSNV_DEEP=wide) and not in the dense piece layout's kernel.
+        if (int rc = devpack_sync_pending(ds)) return rc;               // (the last round's mismatch sample: its kernels were left running behind the pack)
         uint64_t sb = 0, sm = 0;
         for (const SampleCols &sc : ds.samples) { sb += sc.mm_sampled_bases; sm += sc.mm_sampled; }
         const double rate = sb ? (double)sm / (double)sb : 0.0;
