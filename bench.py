@@ -67,7 +67,7 @@ def workload_params(a, rank=0):
     return kw, label
 
 
-TRAFFIC_PROFILES = ["r04_pmc.json", "r03fin_pmc.json", "r03_pmc.json", "r02d_pmc.json"]       # newest first; written by profiles/collect.sh + summarize.py
+TRAFFIC_PROFILES = ["r05_pmc.json", "r04_pmc.json", "r03fin_pmc.json", "r03_pmc.json", "r02d_pmc.json"]       # newest first; written by profiles/collect.sh + summarize.py
 
 
 def measured_traffic(samples, species, contig_len, mean_cov):
@@ -616,15 +616,15 @@ def main():
                     paths.append(pth)
                 decode_extra = {"files": len(paths), "bam_bytes": sum(os.path.getsize(x) for x in paths), "host_threads": 8}
                 keep = os.environ.get("MSNV_INFLATE")
-                for mode in ("device", "host", "device"):              # (the first device round pins the staging buffers)
-                    os.environ["MSNV_INFLATE"] = mode
+                for inflate_mode in ("device", "host", "device"):      # (the first device round pins the staging buffers)
+                    os.environ["MSNV_INFLATE"] = inflate_mode
                     d2 = core.Dataset.from_files(ctx, paths[0], fa)
                     t0h = time.perf_counter()
                     d2.add_sample_bams(paths, 8)
                     dth = time.perf_counter() - t0h
                     nb = d2.finalize()["n_pileup_bases"]
                     d2.close()
-                    decode_extra["%s_inflate" % mode] = {"seconds": dth, "Gbases_per_s": nb / dth / 1e9}
+                    decode_extra["%s_inflate" % inflate_mode] = {"seconds": dth, "Gbases_per_s": nb / dth / 1e9}
                 if keep is None:
                     os.environ.pop("MSNV_INFLATE", None)
                 else:

@@ -1443,6 +1443,8 @@ void devpack_release(DevPackTables &t) {
     t.scratch.clear();
     t.contigs = nullptr; t.pref4 = nullptr; t.ready = false;
     std::vector<uint32_t>().swap(t.h_codes); std::vector<uint32_t>().swap(t.h_lc);
+    if (t.fin_tile_base) dev_free(t.fin_tile_base);
+    t.fin_tile_base = nullptr;
     if (t.fin_list) dev_free(t.fin_list);
     if (t.fin_cbase) dev_free(t.fin_cbase);
     t.fin_list = nullptr; t.fin_cbase = nullptr;
@@ -2673,7 +2675,7 @@ int devfin_headers(msnv_dataset &ds, DeviceCols &d, const std::vector<uint64_t> 
         hipLaunchKernelGGL(msnv_fin_headers, grid_for(r.n_pieces, 256), dim3(256), 0, st, r.hdr, r.tid, (unsigned long long)r.n_pieces, tb.as<uint32_t>(), d.hdr + rbase[r.first_sample]);
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipStreamSynchronize(st));
+    ds.dp.fin_tile_base = tb.release();                            // (read by kernels that may still be queued: freed with the pack's tables; no wait here)
     return MSNV_OK;
 }
 

@@ -41,5 +41,26 @@ if dom and "FETCH_SIZE" in pmc[dom[0]] and "WRITE_SIZE" in pmc[dom[0]]:
                           "total_bytes_per_launch": 2 * fe + wr,
                           "note": "FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of a wide coalesced stream "
                                   "(MI355X_MICROARCH.md section HBM), so reads are doubled; separate --pmc passes with --kernel-trace only"}
+# ---- the per-read stage (csrc/devpack.hip): HBM traffic of ONE build of the dataset from resident records = sum over its kernels of
+# (2 x FETCH_SIZE + WRITE_SIZE) per launch x launches per build (the bench builds the dataset three times: launches / 3)
+PACK = ("msnv_scan_sub", "msnv_scan_seams", "msnv_scan_write", "msnv_scan_segments", "msnv_compact_offsets", "msnv_measure_reads", "msnv_pile_gather", "msnv_depth", "msnv_run_table",
+        "msnv_group_pre", "msnv_group_table", "msnv_sample_bases", "msnv_emit_block", "msnv_emit_tail", "msnv_acc_fold", "msnv_acc_init", "rocprim")
+builds = 3.0
+pk = {}
+for k, cs in pmc.items():
+    if not any(x in k for x in PACK) or "FETCH_SIZE" not in cs or "WRITE_SIZE" not in cs:
+        continue
+    name = next((x for x in PACK if x in k), k[:40])
+    if name == "rocprim":
+        name = "rocprim scans"
+    n = cs["FETCH_SIZE"]["launches"] / builds
+    e = pk.setdefault(name, {"fetch_x2_bytes_per_build": 0.0, "write_bytes_per_build": 0.0})
+    e["fetch_x2_bytes_per_build"] += 2 * 1024.0 * cs["FETCH_SIZE"]["avg_per_launch"] * n
+    e["write_bytes_per_build"] += 1024.0 * cs["WRITE_SIZE"]["avg_per_launch"] * n
+if pk:
+    tot = sum(v["fetch_x2_bytes_per_build"] + v["write_bytes_per_build"] for v in pk.values())
+    res["pack_traffic"] = {"kernels": pk, "total_bytes_per_build": tot,
+                           "note": "bench.py builds the dataset three times from records resident in HBM; rocPRIM scans of any other stage (finalize) are included; "
+                                   "compare with roofline_from_records.record_bytes_resident of the bench line"}
 json.dump(res, open(os.path.join(out_dir, tag + "_pmc.json"), "w"), indent=1)
 print(json.dumps(res.get("hbm_traffic", {}), indent=1))
