@@ -7,7 +7,7 @@ import tempfile
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_so = os.path.join(ROOT, "oracle", "liborc.so")
+_so = os.environ.get("ORC_LIBRARY") or os.path.join(ROOT, "oracle", "liborc.so")      # (ORC_LIBRARY: a sanitizer build outside the tree, tests/run_sanitized.sh)
 
 
 class OrcRef(C.Structure):
