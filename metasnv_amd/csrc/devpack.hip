@@ -639,12 +639,19 @@ __global__ __launch_bounds__(256) void msnv_pile_gather(const RecCnt *r_cnt, con
     p_rd[r] = make_uint4(pos, e - pos > span_out ? 0u : e, (uint32_t)(k >> 32), (uint32_t)rec_sample[i] | mc << 12);
     p_ftile[r] = r_ftile[i]; p_rec[r] = i;
 }
+constexpr uint32_t DEPTH_BACK = 768;                               // reads in front of a workgroup's 256 that its LDS window holds (16 KB in all)
 __global__ __launch_bounds__(256) void msnv_depth(const unsigned long long *rg, uint32_t n_pile, const uint4 *p_rd,
                                                   const uint32_t *p_ftile, const uint32_t *p_rec, const RecCnt *r_cnt, const uint32_t *ovr, DpParams P, uint32_t window, const uint32_t *outliers,
                                                   uint32_t n_out, const uint16_t *rec_sample, const unsigned long long *r_key, const uint32_t *r_end, const uint32_t *r_maxc,
                                                   uint16_t *r_depth, uint32_t *run_first, uint32_t *run_f1, uint32_t *grp_first, uint32_t *grp_md, DpAcc *acc, uint32_t *misc) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint4 s_rd[DEPTH_BACK + 256];
+    const uint32_t blk0 = blockIdx.x * blockDim.x, r = blk0 + threadIdx.x;
     const bool valid = r < n_pile;
+    {   // the workgroup's reads and DEPTH_BACK reads in front of them (entry k = read lds_lo + k)
+        const uint32_t lds_lo = blk0 > DEPTH_BACK ? blk0 - DEPTH_BACK : 0u, lds_n = (blk0 + 256u < n_pile ? blk0 + 256u : n_pile) - lds_lo;
+        for (uint32_t k = threadIdx.x; k < lds_n; k += 256u) s_rd[k] = p_rd[lds_lo + k];
+    }
+    __syncthreads();
     uint32_t gi = 0xffffffffu, depth = 0, spill = 0;
     if (valid) {
         const uint4 me4 = p_rd[r];
@@ -660,23 +667,34 @@ __global__ __launch_bounds__(256) void msnv_depth(const unsigned long long *rg, 
         if (run_start) run_first[g] = r;
         if (run_start || ftp != ft) grp_first[gi] = i;
         if (!run_start && ftp > ft) atomicOr(&misc[MISC_SORT], 1u);                         // (a read whose first aligned base lies in an earlier tile than its predecessor's: leading deletions)
-        // ---- the window: back along the reads of the run while they start beyond p - window; four reads a step (the neighbours' cache lines)
+        // ---- the window: back along the reads of the run while they start beyond p - window.  The workgroup's 256 reads and the DEPTH_BACK
+        // reads in front of them are in LDS (one coalesced load each; a chain of dependent global loads per read made this kernel 0.8 ms on
+        // the benchmark shape); a window that reaches further back goes on in global memory, four reads a step
         unsigned long long chars = me4.w >> 12;
         depth = 1;
         const unsigned long long pw = p;                                                    // a read is inside while start + window > p
-        for (uint32_t j = r; j > 0;) {
+        uint32_t j = r;                                                                     // reads [j, r) have been looked at
+        bool out = false;
+        {
+            const uint32_t lds_lo = blk0 > DEPTH_BACK ? blk0 - DEPTH_BACK : 0u;            // first read held in LDS
+            while (j > lds_lo) {
+                const uint4 x = s_rd[j - 1u - lds_lo];
+                if (x.z != me4.z || (x.w & 0xfffu) != my_sample || (unsigned long long)x.x + window <= pw) { out = true; break; }
+                if (x.y > p) { ++depth; chars += x.w >> 12; }
+                --j;
+            }
+        }
+        while (!out && j > 0) {
             const uint32_t n4 = j < 4u ? j : 4u;
             uint4 x[4];
 #pragma unroll
             for (uint32_t t = 0; t < 4u; ++t) x[t] = t < n4 ? p_rd[j - 1u - t] : make_uint4(0, 0, 0xffffffffu, 0xffffffffu);
-            bool out = false;
 #pragma unroll
             for (uint32_t t = 0; t < 4u; ++t) {
                 if (out) break;
                 if (x[t].z != me4.z || (x[t].w & 0xfffu) != my_sample || (unsigned long long)x[t].x + window <= pw) { out = true; break; }
                 if (x[t].y > p) { ++depth; chars += x[t].w >> 12; }
             }
-            if (out) break;
             j -= n4;
         }
         for (uint32_t k = 0; k < n_out; ++k) {                                              // the round's far-reaching reads: alive here when of this run, before r, ending beyond p
