@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256) void msnv_measure_reads(const uint8_t *raw, co
     unsigned long long m_pile = 0, alg8d = 0, alg_cigar = 0, alg_seq = 0, alg_qual = 0;
     unsigned long long err = ~0ull, first_pile = ~0ull, beyond_at = ~0ull;
     uint8_t flags = 0; unsigned long long key = 0; uint32_t o_end = 0, o_maxc = 0, o_np = 0, o_sb = 0, o_niv = 0, o_ftile = 0, o_spill = 0;
-    bool need_sort = false;
+    bool need_sort = false, order_me = false;
     if (valid) {
         const uint8_t *p = raw + rec_off[i];
         const Rec r = rec_load(p, s_end[s] - rec_off[i]);
@@ -461,17 +461,7 @@ __global__ __launch_bounds__(256) void msnv_measure_reads(const uint8_t *raw, co
             key = (unsigned long long)(uint32_t)r.tid << 32 | (uint32_t)r.pos;
             if (r.tid >= P.n_contigs) err = (unsigned long long)i << 3 | ERR_TID;
             else {
-                // coordinate order: against the mapped record before this one (unmapped ones -- placed mates -- are stepped over)
-                for (uint32_t j = i; j > rec_base[s];) {
-                    --j;
-                    const uint8_t *q = raw + rec_off[j];
-                    const uint64_t a = ld64(q), c = ld64(q + 16);
-                    const int32_t tj = (int32_t)(a >> 32);
-                    if (!rec_mapped((uint32_t)c >> 16, tj)) continue;
-                    const int32_t pj = (int32_t)ld32(q + 8);
-                    if (r.tid < tj || (r.tid == tj && r.pos < pj)) err = (unsigned long long)i << 3 | ERR_UNSORTED;
-                    break;
-                }
+                order_me = true;                                                             // (coordinate order: checked below, against the neighbours' keys)
                 const DpContig c = ctg[r.tid];
                 if (c.sel) {
                     // ---- CIGAR geometry, pieces, qaCompute's intervals: one walk
@@ -544,6 +534,36 @@ __global__ __launch_bounds__(256) void msnv_measure_reads(const uint8_t *raw, co
             }
         }
         r_flags[i] = flags; r_key[i] = key; r_end[i] = o_end; r_maxc[i] = o_maxc; r_ftile[i] = o_ftile;
+    }
+    {
+        // coordinate order: against the MAPPED record before this one in its stream (unmapped ones -- placed mates -- are stepped over).  The
+        // one before is nearly always a lane of this wavefront: its key comes by a shuffle; only a lane with no mapped record of its stream
+        // in front of it in the wavefront goes back to the records themselves
+        const unsigned long long mapped_m = __ballot((flags & RF_MAPPED) != 0);
+        const uint32_t lane = threadIdx.x & 63u;
+        const unsigned long long below = mapped_m & ((1ull << lane) - 1ull);
+        const int src = below ? 63 - __builtin_clzll(below) : 0;
+        const unsigned long long pk = __shfl(key, src); const uint32_t ps = __shfl(s, src);
+        if (order_me) {
+            bool have = below != 0ull && ps == s;
+            unsigned long long prev_key = pk;
+            if (!have) {
+                const uint32_t stop = below ? i - (lane - (uint32_t)src) + 1u : i - lane;    // records of this wavefront in front of me were looked at (none mapped, or another stream's)
+                for (uint32_t j = stop < rec_base[s] ? rec_base[s] : stop; j > rec_base[s];) {
+                    --j;
+                    const uint8_t *q = raw + rec_off[j];
+                    const uint64_t a = ld64(q), c = ld64(q + 16);
+                    const int32_t tj = (int32_t)(a >> 32);
+                    if (!rec_mapped((uint32_t)c >> 16, tj)) continue;
+                    prev_key = (unsigned long long)(uint32_t)tj << 32 | ld32(q + 8); have = true;
+                    break;
+                }
+            }
+            if (have) {
+                const int32_t tj = (int32_t)(prev_key >> 32), pj = (int32_t)(uint32_t)prev_key, ti = (int32_t)(key >> 32), pi = (int32_t)(uint32_t)key;
+                if (ti < tj || (ti == tj && pi < pj)) { const unsigned long long e = (unsigned long long)i << 3 | ERR_UNSORTED; err = e < err ? e : err; }
+            }
+        }
     }
     {
         const RecCnt mine = valid ? RecCnt{(flags & RF_PILE) ? 1u : 0u, o_np, o_niv, o_spill, (unsigned long long)o_sb} : RecCnt{};
@@ -1069,22 +1089,11 @@ __device__ __forceinline__ void emit_record(const EmitArgs &A, const Src &src, c
         const uint32_t gi = (uint32_t)A.rg[me.pile] - 1u;
         pf = A.grp_pre[gi]; pe = A.grp_pre[gi + 1u];
     }
-    if ((f & RF_COV) && sub == 0) {                                                         // qaCompute.cpp:530-552
-        const long long L = c.len;
-        long long pp = (long long)pos + 1;
-        uint32_t k = 0, w = me.niv;
-        if (n_cigar > 0) { const uint32_t t = src.ld32(cig_o) & 15u; if (t == C_S || t == C_H) k = 1; }
-        for (; k < n_cigar; ++k) {
-            const uint32_t cg = src.ld32(cig_o + 4ull * k), t = cg & 15u, l = cg >> 4;
-            if (t == C_M) {
-                if (pp >= L) { if (L >= 1) { A.cov_tid[w] = tid; A.cov_beg[w] = (int32_t)L; A.cov_end[w] = (int32_t)(L - 1); ++w; } }
-                else { A.cov_tid[w] = tid; A.cov_beg[w] = (int32_t)pp; A.cov_end[w] = (int32_t)(pp + l); ++w; }
-            }
-            pp += l;
-        }
-    }
+    // ONE walk over the CIGAR for both tools: qaCompute's intervals (lane 0; qaCompute.cpp:530-552: every op behind a leading clip moves the
+    // cursor, an M op adds {+1 at the cursor, -1 behind it}) and mpileup's aligned blocks cut into pieces
     const bool noseq = l_seq == 0;
-    if (!(f & RF_PILE) || (noseq && !A.noseq_counts)) return;
+    const bool cov = (f & RF_COV) && sub == 0, pile = (f & RF_PILE) && !(noseq && !A.noseq_counts);
+    if (!cov && !pile) return;
     uint32_t w = me.npiece;                                                                   // file order
     uint32_t d_own = w, d_next = w;                                                           // tile order: next header slot in the read's first tile / the tile behind
     uint32_t ftile = 0; bool have_ftile = false;
@@ -1092,37 +1101,50 @@ __device__ __forceinline__ void emit_record(const EmitArgs &A, const Src &src, c
         d_own = me.npiece - (me.spill - pf.y);
         d_next = pe.x - pe.y + me.spill;
     }
-    unsigned long long so = me.seqb - sbase0;
-    long long rp = pos, q = 0;
+    uint32_t so = (uint32_t)(me.seqb - sbase0);
+    long long rp = pos; uint32_t q = 0;                                                       // (the tile arithmetic below is msnv_measure_reads' to the letter: the two must cut the same pieces)
     const uint32_t j0 = 32u * sub;
+    const long long L = c.len;
+    long long pp = (long long)pos + 1;
+    uint32_t wiv = me.niv, k0 = 0;
+    if (cov && n_cigar > 0) { const uint32_t t = src.ld32(cig_o) & 15u; if (t == C_S || t == C_H) k0 = 1; }
     for (uint32_t k = 0; k < n_cigar; ++k) {
         const uint32_t cg = src.ld32(cig_o + 4ull * k), t = cg & 15u, l = cg >> 4;
+        if (cov && k >= k0) {
+            if (t == C_M) {
+                if (pp >= L) { if (L >= 1) { A.cov_tid[wiv] = tid; A.cov_beg[wiv] = (int32_t)L; A.cov_end[wiv] = (int32_t)(L - 1); ++wiv; } }
+                else { A.cov_tid[wiv] = tid; A.cov_beg[wiv] = (int32_t)pp; A.cov_end[wiv] = (int32_t)(pp + l); ++wiv; }
+            }
+            pp += l;
+        }
         if (cg_match(t)) {
-            for (uint32_t off = 0, n = 0; off < l; off += n) {
-                const uint32_t to_tile = TILE - (uint32_t)((rp + off) % TILE);
+            if (pile) for (uint32_t off = 0, n = 0; off < l; off += n) {
+                const long long gl = rp + off;
+                const uint32_t g = (uint32_t)gl;
+                const uint32_t to_tile = TILE - (uint32_t)(gl % TILE);
                 n = SEG_MAX < l - off ? SEG_MAX : l - off;
                 n = n < to_tile ? n : to_tile;
-                const uint32_t tl = (uint32_t)((rp + off) / TILE);
+                const uint32_t tl = (uint32_t)(gl / TILE);
                 if (!have_ftile) { ftile = tl; have_ftile = true; }
                 const uint32_t dst = A.in_order ? w : (tl == ftile ? d_own++ : d_next++);
                 if (sub == 0) {
                     ReadHdr h;
-                    h.gpos = (uint32_t)(rp + off); h.seqoff = (uint32_t)so; h.cig = n; h.meta = META_PILEUP_OK | mapq << 16;
-                    A.hdr[dst] = h; A.ptid[dst] = tid; A.pend[dst] = (int32_t)(rp + off + n); A.pdepth[dst] = depth;
+                    h.gpos = g; h.seqoff = so; h.cig = n; h.meta = META_PILEUP_OK | mapq << 16;
+                    A.hdr[dst] = h; A.ptid[dst] = tid; A.pend[dst] = (int32_t)(g + n); A.pdepth[dst] = depth;
                 }
                 // ---- this lane's 32 bases of the piece
                 unsigned long long ref_nib; uint32_t ref_left;
-                const long long g = rp + off, left = c.seq_len - g;
-                if (c.seq_len >= 0 && g >= 0 && left > 0) { ref_nib = c.pref_off + (unsigned long long)g; ref_left = (uint32_t)(left < 0xffffffffll ? left : 0xffffffffll); }
+                const long long left = c.seq_len - gl;
+                if (c.seq_len >= 0 && gl >= 0 && left > 0) { ref_nib = c.pref_off + (unsigned long long)gl; ref_left = (uint32_t)(left < 0xffffffffll ? left : 0xffffffffll); }
                 else { ref_nib = c.seq_len >= 0 ? ~1ull : ~0ull; ref_left = 0; }              // ~1: a FASTA record exists but holds nothing here (sampled, nothing to compare)
                 const uint32_t sb = stored_bytes(n);
                 const uint32_t st = 2u * sb > j0 ? (2u * sb - j0 < 32u ? 2u * sb - j0 : 32u) : 0u;    // stored nibbles of this lane (a multiple of 4)
                 const uint32_t have = n > j0 ? (n - j0 < 32u ? n - j0 : 32u) : 0u;                     // ... of which real bases
                 const bool sample_this = ref_nib != ~0ull && ((w - (uint32_t)d.pbase0) & 15u) == 0u;   // one piece in 16: how noisy are these reads?
                 uint64_t o0, o1; uint32_t bits, mm;
-                piece_lane(src, seq_o, qual_o, noseq ? 0xffffffffu : (uint32_t)(q + off), j0, have, ref_nib, ref_left, A.pref4, A.P, d.cut_marks, sample_this && have, o0, o1, bits, mm);      // (no SEQ: the bases are N of quality 0)
+                piece_lane(src, seq_o, qual_o, noseq ? 0xffffffffu : q + off, j0, have, ref_nib, ref_left, A.pref4, A.P, d.cut_marks, sample_this && have, o0, o1, bits, mm);      // (no SEQ: the bases are N of quality 0)
                 const uint32_t prev_last = Out::kLds ? 0u : __shfl_up(bits >> 28, 1);           // the last four flags of lane sub - 1 of the same piece (sub > 0, that lane is full)
-                out.put(d, (uint32_t)so, sub, sb, st, o0, o1, bits, prev_last);
+                out.put(d, so, sub, sb, st, o0, o1, bits, prev_last);
                 // mismatch sample: sum over the 4 lanes of a piece, one atomic per sampled piece
                 mm += __shfl_down(mm, 2, 4); mm += __shfl_down(mm, 1, 4);
                 if (sub == 0 && sample_this) {
