@@ -50,6 +50,7 @@ int devfin_chunk_counts(msnv_dataset &ds, DeviceCols &d, const std::vector<uint3
 int devfin_chunk_fill(msnv_dataset &ds, DeviceCols &d, size_t n_pairs_listed);                       // d.chunks[0 .. total), d.hdr4
 int devfin_work_first(msnv_dataset &ds, DeviceCols &d, uint32_t n_items);                            // WorkItem::first of the narrow and merged items, from d.chunks
 int devfin_merged_headers(msnv_dataset &ds, DeviceCols &d, const std::vector<DevMergedSrc> &list);
+int devfin_coverage_launch(msnv_dataset &ds, DeviceCols &d);   // needs ds.tile_base / n_tiles; the kernels only (their results: devfin_coverage)
 int devfin_coverage(msnv_dataset &ds, DeviceCols &d, std::vector<uint64_t> &cvbase, std::vector<DevCovPair> &cp);
 // waits for the copies, releases the round buffers and the tables (no sample can be added after finalize)
 int devpack_finish(msnv_dataset &ds);

@@ -1483,6 +1483,9 @@ void devpack_release(DevPackTables &t) {
     t.scratch.clear();
     t.contigs = nullptr; t.pref4 = nullptr; t.ready = false;
     std::vector<uint32_t>().swap(t.h_codes); std::vector<uint32_t>().swap(t.h_lc);
+    if (t.cov_job) { (void)hipDeviceSynchronize(); dev_free(t.cov_job); t.cov_job = nullptr; t.cov_runs = nullptr; }
+    if (t.cov_tmp) { dev_free(t.cov_tmp); t.cov_tmp = nullptr; }
+    t.cov_launched = false;
     if (t.fin_tile_base) dev_free(t.fin_tile_base);
     t.fin_tile_base = nullptr;
     if (t.fin_list) dev_free(t.fin_list);
@@ -2314,7 +2317,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
         if (ctx->pin_small_cap < need) {
             if (ctx->pin_small) (void)hipHostFree(ctx->pin_small);
             ctx->pin_small = nullptr; ctx->pin_small_cap = 0;
-            const uint64_t want = std::max<uint64_t>(need, 2048 * sizeof(DpAcc));
+            const uint64_t want = std::max<uint64_t>(2 * need, 4096 * sizeof(DpAcc));       // (the second half: finalize's small results, devfin_coverage_launch)
             HIP_TRY(hipHostMalloc(&ctx->pin_small, want, hipHostMallocDefault));
             ctx->pin_small_cap = want;
         }
@@ -2494,6 +2497,11 @@ struct Prim {                        // rocPRIM calls with a grow-only temporary
     hipStream_t st; DevBuf tmp; size_t cap = 0;
     explicit Prim(hipStream_t s) : st(s) {}
     int room(size_t need) { if (need > cap) { if (int rc = tmp.alloc(need)) return rc; cap = need; } return MSNV_OK; }
+    int reserve_scan32(size_t n) {          // room for scans of up to n words before the first launch: growing later frees, and a free waits for the device
+        size_t need = 0;
+        HIP_TRY(rocprim::exclusive_scan(nullptr, need, (const uint32_t *)nullptr, (uint32_t *)nullptr, 0u, n, rocprim::plus<uint32_t>(), st));
+        return room(need + 256);
+    }
     int scan32(const uint32_t *in, uint32_t *out, size_t n, bool inclusive) {
         size_t need = 0;
         if (inclusive) HIP_TRY(rocprim::inclusive_scan(nullptr, need, in, out, n, rocprim::plus<uint32_t>(), st));
@@ -2777,6 +2785,84 @@ int devfin_merged_headers(msnv_dataset &ds, DeviceCols &d, const std::vector<Dev
 // d.cov_iv (allocated here: kept intervals + 4 idle entries) and, for the host, the kept intervals before every sample (cvbase) and the
 // (sample, tile) runs of the intervals in (sample, tile) order.  Work memory: 12 B per interval + 24 B per (interval, tile) entry in ONE
 // allocation (hipMalloc / hipFree of a dozen multi-gigabyte buffers was most of this step's second at BASELINE configs[2] scale).
+// The coverage index's kernels ahead of their results (round 5): launched as soon as finalize knows the tile layout -- they queue behind
+// whatever the pack left running --, their small results (kept intervals, per-sample bases, number of runs) land in the context's pinned words,
+// and devfin_coverage below only collects them (the host builds the pair tables of the tile index in between).  Dense table form only; when
+// the table would be large beside the interval list nothing is launched here and devfin_coverage runs the sort form, waiting as it goes.
+static bool cov_dense_form(const msnv_dataset &ds, unsigned long long N) {
+    const unsigned long long n_tab = (unsigned long long)ds.samples.size() * ds.n_tiles;
+    bool dense_tab = n_tab <= std::max<unsigned long long>(8ull * N, 1ull << 22) && n_tab < 0xfffffff0ull;
+    if (const char *e = getenv("MSNV_COV_INDEX")) dense_tab = e[0] == 'd' ? n_tab < 0xfffffff0ull : e[0] == 's' ? false : dense_tab;
+    return dense_tab;
+}
+int devfin_coverage_launch(msnv_dataset &ds, DeviceCols &d) {
+    hipStream_t st = (hipStream_t)ds.ctx->stream;
+    DevPackTables &T = ds.dp;
+    const size_t S = ds.samples.size();
+    std::vector<unsigned long long> iv_start(S + 1, 0);
+    for (size_t s = 0; s < S; ++s) iv_start[s + 1] = iv_start[s] + ds.samples[s].n_dev_iv;
+    const unsigned long long N = iv_start[S];
+    const unsigned long long n_tab = (unsigned long long)S * ds.n_tiles;
+    const uint64_t pin_at = ds.ctx->pin_small_cap / 2, pin_need = (S + 4) * 4;
+    if (N > 0xfffffff0ull || !cov_dense_form(ds, N) || n_tab > (1ull << 24) || !ds.ctx->pin_small || pin_at + pin_need > ds.ctx->pin_small_cap || getenv("MSNV_COV_LATE")) return MSNV_OK;
+    auto up = [](unsigned long long b) { return (b + 255ull) & ~255ull; };
+    const unsigned long long b_tb = up(std::max<size_t>(1, ds.tile_base.size()) * 4), b_ivs = up((S + 1) * 8), b_cvb = up((S + 4) * 4);
+    const unsigned long long b_n = up((N + 1) * 4), b_t = up((n_tab + 1) * 4), b_r = up((n_tab + 1) * sizeof(DevCovPair));
+    void *blk = nullptr;
+    if (int rc = dev_alloc(&blk, b_tb + b_ivs + b_cvb + 3 * b_n + 4 * b_t + b_r, nullptr)) return rc;
+    T.cov_job = blk;
+    uint8_t *q = static_cast<uint8_t *>(blk);
+    uint32_t *tb = reinterpret_cast<uint32_t *>(q); q += b_tb;
+    unsigned long long *ivs = reinterpret_cast<unsigned long long *>(q); q += b_ivs;
+    uint32_t *cvb = reinterpret_cast<uint32_t *>(q); q += b_cvb;          // [0 .. S]: kept intervals before every sample; [S + 1] kept in all; [S + 2] runs
+    uint32_t *keep = reinterpret_cast<uint32_t *>(q); q += b_n;
+    uint32_t *ntile = reinterpret_cast<uint32_t *>(q); q += b_n;
+    uint32_t *kidx = reinterpret_cast<uint32_t *>(q); q += b_n;
+    uint32_t *lo = reinterpret_cast<uint32_t *>(q); q += b_t;
+    uint32_t *hi = reinterpret_cast<uint32_t *>(q); q += b_t;
+    uint32_t *flag = reinterpret_cast<uint32_t *>(q); q += b_t;
+    uint32_t *rid = reinterpret_cast<uint32_t *>(q); q += b_t;
+    DevCovPair *runs = reinterpret_cast<DevCovPair *>(q);
+    T.cov_runs = runs;
+    HIP_TRY(hipMemcpyAsync(tb, ds.tile_base.data(), ds.tile_base.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ivs, iv_start.data(), (S + 1) * 8, hipMemcpyHostToDevice, st));
+    const DpContig *ctg = static_cast<const DpContig *>(T.contigs);
+    Prim pr(st);
+    if (int rc = pr.reserve_scan32(std::max<unsigned long long>(N, n_tab) + 1)) return rc;
+    unsigned long long o = 0;
+    for (const DevRound &r : T.rounds) {
+        if (r.n_iv) { hipLaunchKernelGGL(msnv_fin_cov_measure, grid_for(r.n_iv, 256), dim3(256), 0, st, r.cov_tid, r.cov_beg, r.cov_end, (unsigned long long)r.n_iv, ctg, tb, keep + o, ntile + o); HIP_TRY(hipGetLastError()); }
+        o += r.n_iv;
+    }
+    if (o != N) return fail(MSNV_EINVAL, "internal: the rounds hold %llu intervals, the samples %llu", o, N);
+    HIP_TRY(hipMemsetAsync(keep + N, 0, 4, st));
+    if (int rc = pr.scan32(keep, kidx, N + 1, false)) return rc;
+    hipLaunchKernelGGL(msnv_gather_u32, grid_for(S + 1, 64), dim3(64), 0, st, kidx, ivs, (uint32_t)(S + 1), cvb);
+    HIP_TRY(hipMemcpyAsync(cvb + (S + 1), kidx + N, 4, hipMemcpyDeviceToDevice, st));
+    if (int rc = dev_alloc((void **)&d.cov_iv, ((uint64_t)N + 4) * sizeof(Pair32), &d.device_bytes)) return rc;      // (N >= the kept ones: no wait for their count)
+    HIP_TRY(hipMemsetAsync(lo, 0xff, b_t, st));
+    HIP_TRY(hipMemsetAsync(hi, 0, b_t, st));
+    o = 0;
+    for (const DevRound &r : T.rounds) {
+        if (r.n_iv) {
+            hipLaunchKernelGGL(msnv_fin_cov_emit_dense, grid_for(r.n_iv, 256), dim3(256), 0, st, r.cov_tid, r.cov_beg, r.cov_end, (unsigned long long)r.n_iv, o, ctg, tb, ivs, (uint32_t)S,
+                               keep, kidx, ds.n_tiles, d.cov_iv, lo, hi);
+            HIP_TRY(hipGetLastError());
+        }
+        o += r.n_iv;
+    }
+    hipLaunchKernelGGL(msnv_fin_cov_dense_flags, grid_for(n_tab + 1, 256), dim3(256), 0, st, hi, n_tab, flag);
+    HIP_TRY(hipGetLastError());
+    if (int rc = pr.scan32(flag, rid, n_tab + 1, false)) return rc;
+    HIP_TRY(hipMemcpyAsync(cvb + (S + 2), rid + n_tab, 4, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(msnv_fin_cov_dense_runs, grid_for(n_tab, 256), dim3(256), 0, st, lo, hi, rid, n_tab, ds.n_tiles, runs);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(static_cast<uint8_t *>(ds.ctx->pin_small) + pin_at, cvb, (S + 3) * 4, hipMemcpyDeviceToHost, st));      // (pinned: the copy does not wait on the host)
+    T.cov_tmp = pr.tmp.release();                                  // (rocPRIM's work memory: in use until the kernels above have run)
+    T.cov_launched = true;
+    return MSNV_OK;
+}
+
 int devfin_coverage(msnv_dataset &ds, DeviceCols &d, std::vector<uint64_t> &cvbase, std::vector<DevCovPair> &cp) {
     hipStream_t st = (hipStream_t)ds.ctx->stream;
     const size_t S = ds.samples.size();
@@ -2784,6 +2870,24 @@ int devfin_coverage(msnv_dataset &ds, DeviceCols &d, std::vector<uint64_t> &cvba
     for (size_t s = 0; s < S; ++s) iv_start[s + 1] = iv_start[s] + ds.samples[s].n_dev_iv;
     const unsigned long long N = iv_start[S];
     cvbase.assign(S + 1, 0); cp.clear();
+    if (ds.dp.cov_launched) {
+        // the kernels were launched ahead (devfin_coverage_launch): their results are in the pinned words, the runs in HBM
+        DevPackTables &T = ds.dp;
+        T.cov_launched = false;
+        HIP_TRY(hipStreamSynchronize(st));
+        const uint32_t *pw = reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(ds.ctx->pin_small) + ds.ctx->pin_small_cap / 2);
+        for (size_t s = 0; s <= S; ++s) cvbase[s] = pw[s];
+        const uint32_t n_keep = pw[S + 1], n_runs = pw[S + 2];
+        d.n_cov_iv = n_keep;
+        HIP_TRY(hipMemsetAsync(d.cov_iv + n_keep, 0, 4 * sizeof(Pair32), st));              // behind the last interval: what the idle lanes of msnv_coverage_tiles load
+        cp.resize(n_runs);
+        if (n_runs) HIP_TRY(hipMemcpyAsync(cp.data(), T.cov_runs, (size_t)n_runs * sizeof(DevCovPair), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        dev_free(T.cov_job); T.cov_job = nullptr; T.cov_runs = nullptr;
+        if (T.cov_tmp) { dev_free(T.cov_tmp); T.cov_tmp = nullptr; }
+        fin_trace("    cov: results of the kernels launched ahead");
+        return MSNV_OK;
+    }
     if (N > 0xfffffff0ull) return fail(MSNV_EDOMAIN, "more than 2^32 qaCompute intervals in one shard");
     auto up = [](unsigned long long b) { return (b + 255ull) & ~255ull; };
     DevBuf small, work;
@@ -2822,8 +2926,7 @@ int devfin_coverage(msnv_dataset &ds, DeviceCols &d, std::vector<uint64_t> &cvba
     HIP_TRY(hipMemcpyAsync(cvb_h.data(), cvb, (S + 1) * 4, hipMemcpyDeviceToHost, st));
     // ---- the (sample, tile) runs: a dense table of minima / maxima when it is small beside the interval list (MSNV_COV_INDEX=sort|dense forces one)
     const unsigned long long n_tab = (unsigned long long)S * ds.n_tiles;
-    bool dense_tab = n_tab <= std::max<unsigned long long>(8ull * N, 1ull << 22) && n_tab < 0xfffffff0ull;
-    if (const char *e = getenv("MSNV_COV_INDEX")) dense_tab = e[0] == 'd' ? n_tab < 0xfffffff0ull : e[0] == 's' ? false : dense_tab;
+    const bool dense_tab = cov_dense_form(ds, N);
     if (dense_tab) {
         d.n_cov_iv = 0;
         if (int rc = dev_alloc((void **)&d.cov_iv, ((uint64_t)N + 4) * sizeof(Pair32), &d.device_bytes)) return rc;      // (N >= the kept ones: no wait for their count)

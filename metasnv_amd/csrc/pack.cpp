@@ -904,6 +904,7 @@ int finalize_dataset(msnv_dataset &ds) {
     TableArena arena;
     d->n_tiles = ds.n_tiles; d->n_samples = (uint32_t)S;
 
+    if (fast) if (int rc = devfin_coverage_launch(ds, *d)) return rc;     // (the coverage index's kernels go first: they run while the host builds the pair tables)
     lap("tile layout");
     // ---- reference: nt16 codes (N beyond the contig end, as mpileup prints) + lower-case bits
     std::vector<uint32_t> ref4(npos / 8 + 1, 0xffffffffu);
