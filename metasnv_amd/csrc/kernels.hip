@@ -388,7 +388,7 @@ constexpr int N_EVCAP = MSNV_N_EVCAP;
 
 static_assert(N_PPT == 8, "narrow per-sample pass is written for 8 positions per thread");
 
-struct NarrowLds {
+struct alignas(16) NarrowLds {
     uint32_t start[TILE / 4 + 4];
     uint32_t end[TILE / 4 + 4];
     unsigned long long exc[TILE / 8 + 4];      // byte bins, updated 8 positions at a time with 64-bit LDS atomics
@@ -666,9 +666,18 @@ __device__ __attribute__((noinline)) bool fused_tile_gate(NarrowLds &L, const Fu
         const uint32_t alw[N_PPT] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
         const uint32_t refw = L.ref[tid];                                        // nt16 codes of my 8 positions
         const uint32_t vb = a.vb, ve = a.ve;
+        // A candidate holds an allele with >= t reads ("ok" below): a handful of a sparse tile's 2048 positions.  The lanes without one among
+        // their eight leave here, the others look at a position's four bytes before anything else (round 5: the walk over all eight positions
+        // by every lane was a quarter of the kernel's vector instructions on the configs[3] shard: profiles/r05_sparse_ablation.txt).
+        // (bytes >= t for 1 <= t <= 127: bit 7 of (byte & 0x7f) + (0x80 - t), or bit 7 of the byte itself)
+        const bool filt = a.min_snvs >= 1u && a.min_snvs <= 127u;
+        const uint32_t ge = (0x80u - (filt ? a.min_snvs : 1u)) * 0x01010101u;
+        const uint32_t orw = a0.x | a0.y | a0.z | a0.w | a1.x | a1.y | a1.z | a1.w;      // (>= each of the eight words, byte for byte)
+        if (filt && !((((orw & 0x7f7f7f7fu) + ge) | orw) & 0x80808080u)) goto counted;
 #pragma unroll
         for (int j = 0; j < N_PPT; ++j) {
             const uint32_t cov = ((j < 4 ? cv.x : cv.y) >> (8 * (j & 3))) & 0xffu, word = alw[j], p = (uint32_t)(N_PPT * tid + j);
+            if (filt && !((((word & 0x7f7f7f7fu) + ge) | word) & 0x80808080u)) continue;
             const uint32_t n[4] = {word & 0xffu, (word >> 8) & 0xffu, (word >> 16) & 0xffu, word >> 24};
             if (cov == 0u || p < vb || p >= ve || (int)cov < a.min_cov || (int)(n[0] + n[1] + n[2] + n[3]) < (int)a.min_snvs) continue;
             const double lim = (double)(int)cov * a.min_frac;                     // call_vC.cpp:588
@@ -691,6 +700,7 @@ __device__ __attribute__((noinline)) bool fused_tile_gate(NarrowLds &L, const Fu
             if (slot < STAGE_CAP) st->rec[slot] = StageRec{p | (elig ? 1u << 11 : 0u) | (pop | ind << 4) << 16 | elig << 24, cov, word, 0u};
         }
     }
+counted:
     __syncthreads();
     const uint32_t n_cand = L.evn;
     if (tid == 0) st->count = n_cand;                                             // (> STAGE_CAP: msnv_gate_staged leaves the tile alone)
@@ -742,9 +752,13 @@ __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a, NarrowL
 
     for (int i = tid; i < (int)(TILE / 8 + 4); i += N_NT)
         L.ref[i] = (i < (int)(TILE / 8)) ? a.ref4[(t0 >> 3) + i] : 0xffffffffu;
-    for (int i = tid; i < (int)(TILE / 4 + 4); i += N_NT) { L.start[i] = 0; L.end[i] = 0; }
-    for (int i = tid; i < (int)(TILE / 8 + 4); i += N_NT) L.exc[i] = 0;
-    for (int i = tid; i < (int)TILE; i += N_NT) L.al[i] = 0;
+    {   // the bins -- start, end, exc, al lie in a row -- are zeroed 16 bytes a lane (round 5: sixteen 4 / 8-byte stores a lane were a tenth of a sparse tile's instructions)
+        static_assert(offsetof(NarrowLds, start) == 0 && offsetof(NarrowLds, ref) % 16 == 0 && alignof(NarrowLds) >= 16, "the bins are zeroed as 16-byte words");
+        constexpr int n16 = (int)(offsetof(NarrowLds, ref) / 16);
+        uint4 *z = reinterpret_cast<uint4 *>(&L);
+#pragma unroll
+        for (int i = 0; i < (n16 + N_NT - 1) / N_NT; ++i) if (i * N_NT + tid < n16) z[i * N_NT + tid] = make_uint4(0u, 0u, 0u, 0u);
+    }
     if (tid == 0) L.evn = 0;
     if (tid < N_NT / 64 + 1) L.carry[tid] = 0;
     if constexpr (SEQ_ALIGN_LOG2 < 3) {
@@ -840,6 +854,9 @@ __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a, NarrowL
         }
     };
     __syncthreads();
+#ifdef MSNV_ABL
+    if constexpr (fused) { if (MSNV_ABL == 1) { if (tid == 0) a.tile_stage[g_sidx].count = 0u; return; } }
+#endif
     if (nch) issue_loads(0u);
     bool prev_last = false;                                          // the bins start out zero
 
@@ -861,18 +878,30 @@ __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a, NarrowL
         }
 #pragma unroll
         for (int i = 0; i < N32_ROUNDS; ++i)
+#ifdef MSNV_ABL
+            if (!(fused && MSNV_ABL == 2))
+#endif
             if (__any(vh[i] > 0)) narrow_classify32(L, lowq_bits(ql[i], qsh[i]), sq[i], P0[i], vh[i]);
+#ifdef MSNV_ABL
+        if (fused && MSNV_ABL == 2) { for (int i = 0; i < N32_ROUNDS; ++i) if (vh[i] > 0 && (sq[i].x ^ sq[i].y ^ sq[i].z ^ sq[i].w ^ ql[i].x ^ ql[i].y) == 0x12345u) L.al[P0[i]] = 1u; }
+#endif
 
         if (tid < N_HCAP) put_hdr((c + 1u) & 1u, hreg);               // headers of chunk c + 1 (zeros behind the last chunk)
         hreg = load_hdr(c + 2u);
         __syncthreads();                                            // (B): this chunk is in the bins; the next chunk's headers are visible
         if (c + 1u < nch) issue_loads(c + 1u);                       // in flight under the per-sample pass
+#ifdef MSNV_ABL
+        if (!(fused && MSNV_ABL == 4))
+#endif
         if (last_chunk) narrow_pass<NarrowLds, 0, MERGED, fused, DA>(L, a, tc, dirty, t0, tid, lane, wave, cd.sample, cd.pair, cd.pad, tot_mode_of(w));
         prev_last = last_chunk;
     }
     __syncthreads();
     if (MERGED && fused) {
         const uint32_t sidx = g_sidx;
+#ifdef MSNV_ABL
+        if (MSNV_ABL == 3 || MSNV_ABL == 4) { if (tid == 0) a.tile_stage[sidx].count = 0u; return; }
+#endif
         const FusedGateArgs fa{a.tile_stage + sidx, a.ref_lc, a.counters, g_vb, g_ve, a.min_snvs, a.min_cov, a.min_frac, w.pair_hi - w.pair_lo == 1u ? 1u : 0u};
         if (fused_tile_gate(L, fa, g_lcb, nch != 0u, tid)) {
             const FusedSpillArgs sa{a.part + ((uint64_t)w.part_hi << 32 | (w.part_lo & ~15u)), a.tot, a.unc_bits, a.slot_dirty + w.slot, a.stage_ovf, a.counters, sidx, (w.part_lo & 15u) | a.min_snvs << 4};
@@ -904,168 +933,6 @@ __global__ __launch_bounds__(N_NT, MSNV_N32_WAVES) void msnv_pileup_tiles_narrow
     else if (blockIdx.x < a.n_fused_lo) { a.hdr8 = a.hdr8m; pileup_tiles_narrow32_body<true>(a, L); }
     else { a.hdr8 = a.hdr8m; pileup_tiles_narrow32_body<true, true>(a, L); }
 }
-
-// Whole-tile work items of a SPARSE cohort (BASELINE configs[3]: a pair or two per tile, one chunk per item): an item is a chain of
-// dependent loads -- work item -> piece headers -> bases / flags -> the pass -> the gate -- and eight workgroups per CU cannot hide
-// ~12 us of it per item.  Here ONE workgroup walks `span` CONSECUTIVE items (tiles in order): the next item's descriptor is read while
-// this one starts, its headers and its tile's reference words are fetched behind this item's last chunk, and they are in flight while
-// the pass and the gate of this item run; the bins are initialised once (the pass leaves them zero, the gate's two inputs are cleared
-// behind it).  Same per-item code as pileup_tiles_narrow32_body<true, true>: same record lists, same spill route.
-#if !defined(MSNV_FUSED_WAVES)
-#define MSNV_FUSED_WAVES 7                                        // (what it keeps across an item for the next one costs a few registers more than eight waves per SIMD leave)
-#endif
-__global__ __launch_bounds__(N_NT, MSNV_FUSED_WAVES) void msnv_pileup_tiles_fused(PileupArgs a, const uint32_t item_lo, const uint32_t item_hi, const uint32_t span) {
-    __shared__ NarrowLds L;
-    a.hdr8 = a.hdr8m;
-    const uint32_t first = item_lo + blockIdx.x * span, last = min(first + span, item_hi);
-    if (first >= last) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lane4 = tid & (N32_LANES - 1), grp = tid / N32_LANES;
-    const int b0 = 32 * lane4;
-    for (int i = tid; i < (int)(TILE / 8 + 4); i += N_NT) L.ref[i] = 0xffffffffu;       // (words 0 .. 255 are set per item)
-    for (int i = tid; i < (int)(TILE / 4 + 4); i += N_NT) { L.start[i] = 0; L.end[i] = 0; }
-    for (int i = tid; i < (int)(TILE / 8 + 4); i += N_NT) L.exc[i] = 0;
-    for (int i = tid; i < (int)TILE; i += N_NT) L.al[i] = 0;
-    if (tid == 0) L.evn = 0;
-    if (tid < N_NT / 64 + 1) L.carry[tid] = 0;
-    if constexpr (SEQ_ALIGN_LOG2 < 3) {
-        if (tid < 33) {
-            uint32_t m = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int c = min(max(tid - 8 * k, 0), 8);
-                m |= (c >= 8 ? 0xffffffffu : (1u << (4 * c)) - 1u) & (0x11111111u << k);
-            }
-            L.emask[tid] = m;
-        }
-    }
-    auto fetch_hdr = [&](const uint64_t hdr_base) -> uint2 { return *reinterpret_cast<const uint2 *>(a.hdr8 + hdr_base + tid); };
-    // what the prefetch for the NEXT item needs of its descriptor: six scalars (the whole descriptor is read again, cache-hot, when its turn comes)
-    struct NextItem { uint32_t tile, nch, nrd; uint64_t hdr_base; };
-    auto peek_item = [&](const uint32_t idx) -> NextItem {
-        const WorkItem *p = a.work + idx;
-        NextItem n;
-        n.tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)p->tile);
-        n.nch = (uint32_t)__builtin_amdgcn_readfirstlane((int)(p->chunk_hi - p->chunk_lo));
-        n.nrd = (uint32_t)__builtin_amdgcn_readfirstlane((int)(p->first.nrd_flags & 0xffffu));
-        n.hdr_base = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(p->first.hdr_base >> 32)) << 32 | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)p->first.hdr_base);
-        return n;
-    };
-    uint2 hreg0 = make_uint2(0, 0);
-    uint32_t refreg, lcbreg;
-    {
-        const NextItem n0 = peek_item(first);
-        if (n0.nch && tid < N_HCAP && (uint32_t)tid < n0.nrd) hreg0 = fetch_hdr(n0.hdr_base);
-        refreg = a.ref4[(n0.tile * TILE >> 3) + (uint32_t)tid];                            // N_NT == TILE / 8 words
-        lcbreg = reinterpret_cast<const uint8_t *>(a.ref_lc)[(n0.tile * TILE >> 3) + (uint32_t)tid];
-    }
-    static_assert(N_NT == (int)(TILE / 8), "one reference word per thread");
-
-    for (uint32_t item = first; item < last; ++item) {
-        const WorkItem w = a.work[item];
-        const uint32_t t0 = w.tile * TILE;
-        const uint32_t nch = w.chunk_hi - w.chunk_lo;
-        const bool more = item + 1u < last;
-        const NextItem wn = peek_item(more ? item + 1u : item);                            // in flight under this item's work
-        // (the gate's scalars of THIS tile, asked for now, needed behind the pass)
-        const uint32_t sidx = a.tile_stage_idx[w.tile], g_vb = a.tile_vbeg[w.tile], g_ve = a.tile_vend[w.tile];
-        const uint32_t my_lcb = lcbreg;
-        uint32_t tc[N_PPT / 2] = {0u, 0u, 0u, 0u};
-        bool dirty = false;
-        L.ref[tid] = refreg;
-        if (tid < N_HCAP) L.hdr[0][tid] = hreg0;
-        if (tid < 2) {                                            // chunk 0's descriptor came with the work item (selected by value: indexing the struct would put it in scratch memory)
-            const ChunkDesc &f = w.first;
-            reinterpret_cast<uint4 *>(L.desc)[tid] = tid == 0 ? make_uint4((uint32_t)f.hdr_base, (uint32_t)(f.hdr_base >> 32), (uint32_t)f.seq_base, (uint32_t)(f.seq_base >> 32))
-                                                              : make_uint4(f.sample, f.pair, f.nrd_flags, f.pad);
-        }
-        for (uint32_t i = 2u + tid; i < min(nch, (uint32_t)MAX_CHUNKS_PER_ITEM) * 2; i += N_NT)
-            reinterpret_cast<uint4 *>(L.desc)[i] = reinterpret_cast<const uint4 *>(a.chunks + w.chunk_lo)[i];
-        __syncthreads();
-        auto load_hdr = [&](const uint32_t c) -> uint2 {
-            uint2 h = make_uint2(0, 0);
-            if (c < nch && tid < N_HCAP && (uint32_t)tid < (L.desc[c % MAX_CHUNKS_PER_ITEM].nrd_flags & 0xffffu))
-                h = fetch_hdr(L.desc[c % MAX_CHUNKS_PER_ITEM].hdr_base);
-            return h;
-        };
-        uint2 hreg = load_hdr(1);
-        uint4 sq[N32_ROUNDS]; uint2 ql[N32_ROUNDS]; uint32_t P0[N32_ROUNDS], qsh[N32_ROUNDS]; int vh[N32_ROUNDS];
-        auto issue_loads = [&](const uint32_t c) {
-            const uint64_t sbase = L.desc[c % MAX_CHUNKS_PER_ITEM].seq_base;
-            const uint8_t *seq = a.seq + sbase;
-            const uint8_t *qlow = a.qual + (sbase >> 2);
-            const uint32_t qrem = 2u * ((uint32_t)sbase & 3u);
-#pragma unroll
-            for (int i = 0; i < N32_ROUNDS; ++i) {
-                const uint2 h = L.hdr[c & 1u][grp + i * N32_GROUPS];
-                const uint32_t len = (h.x >> 11) & 0xffu;
-                const uint32_t s = h.x & (TILE - 1u);
-                vh[i] = min(max((int)len - b0, 0), 32);
-                sq[i] = any_uint4(); ql[i] = make_uint2(0u, 0u); qsh[i] = 0u;
-                const uint64_t so = ((uint64_t)(h.x >> 27) << 32 | h.y) << SEQ_ALIGN_LOG2;
-                if (vh[i] > 0) {
-                    const uint64_t qbit = (uint64_t)qrem + 2ull * so + (uint32_t)b0;
-                    __builtin_memcpy(&ql[i], qlow + (qbit >> 3), 8);
-                    qsh[i] = (uint32_t)qbit & 7u;
-                    __builtin_memcpy(&sq[i], seq + so + (uint32_t)(b0 >> 1), 16);
-                }
-                P0[i] = vh[i] > 0 ? s + (uint32_t)b0 : 0u;
-            }
-        };
-        if (nch) issue_loads(0u);
-        bool prev_last = false;
-        for (uint32_t c = 0; c < nch; ++c) {
-            const ChunkDesc cd = L.desc[c % MAX_CHUNKS_PER_ITEM];
-            const bool last_chunk = (cd.nrd_flags >> 16) != 0u;
-            if (prev_last) __syncthreads();
-            desc_refill(L.desc, a.chunks + w.chunk_lo, c, nch, tid);
-            if (tid < N_HCAP) {
-                const uint32_t hx = L.hdr[c & 1u][tid].x;
-                const uint32_t s = hx & (TILE - 1u), sb = s + ((hx >> 11) & 0xffu);
-                if (sb != s) {
-                    atomicAdd(&L.start[s >> 2], 1u << (8u * (s & 3u)));
-                    atomicAdd(&L.end[sb >> 2], 1u << (8u * (sb & 3u)));
-                    if ((s >> 9) != (sb >> 9)) atomicAdd(&L.carry[sb >> 9], 1u);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < N32_ROUNDS; ++i)
-                if (__any(vh[i] > 0)) narrow_classify32(L, lowq_bits(ql[i], qsh[i]), sq[i], P0[i], vh[i]);
-            if (tid < N_HCAP) L.hdr[(c + 1u) & 1u][tid] = hreg;
-            hreg = load_hdr(c + 2u);
-            __syncthreads();
-            if (c + 1u < nch) issue_loads(c + 1u);
-            else if (more) {
-                // behind this item's last chunk: the next item's headers, reference words and lower-case bits, in flight under the pass and the gate
-                hreg0 = make_uint2(0, 0);
-                if (wn.nch && tid < N_HCAP && (uint32_t)tid < wn.nrd) hreg0 = fetch_hdr(wn.hdr_base);
-                refreg = a.ref4[(wn.tile * TILE >> 3) + (uint32_t)tid];
-                lcbreg = reinterpret_cast<const uint8_t *>(a.ref_lc)[(wn.tile * TILE >> 3) + (uint32_t)tid];
-            }
-            if (last_chunk) narrow_pass<NarrowLds, 0, true, true, false>(L, a, tc, dirty, t0, tid, lane, wave, cd.sample, cd.pair, cd.pad, tot_mode_of(w));
-            prev_last = last_chunk;
-        }
-        __syncthreads();
-        const FusedGateArgs fa{a.tile_stage + sidx, a.ref_lc, a.counters, g_vb, g_ve, a.min_snvs, a.min_cov, a.min_frac, w.pair_hi - w.pair_lo == 1u ? 1u : 0u};
-        if (fused_tile_gate(L, fa, my_lcb, nch != 0u, tid)) {
-            const FusedSpillArgs sa{a.part + ((uint64_t)w.part_hi << 32 | (w.part_lo & ~15u)), a.tot, a.unc_bits, a.slot_dirty + w.slot, a.stage_ovf, a.counters, sidx, (w.part_lo & 15u) | a.min_snvs << 4};
-            fused_tile_spill(L, sa, t0, tid);
-        }
-        if (!more) break;
-        if (nch == 0u) {                                          // (an item without chunks prefetched nothing)
-            hreg0 = make_uint2(0, 0);
-            if (wn.nch && tid < N_HCAP && (uint32_t)tid < wn.nrd) hreg0 = fetch_hdr(wn.hdr_base);
-            refreg = a.ref4[(wn.tile * TILE >> 3) + (uint32_t)tid];
-            lcbreg = reinterpret_cast<const uint8_t *>(a.ref_lc)[(wn.tile * TILE >> 3) + (uint32_t)tid];
-        }
-        __syncthreads();                                          // the gate (and the spill) have read the tile's coverage bytes and allele totals
-        *reinterpret_cast<uint2 *>(&L.start[2 * tid]) = make_uint2(0u, 0u);
-        *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid]) = make_uint4(0u, 0u, 0u, 0u);
-        *reinterpret_cast<uint4 *>(&L.al[N_PPT * tid + 4]) = make_uint4(0u, 0u, 0u, 0u);
-        if (tid == 0) L.evn = 0;
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // msnv_pileup_tiles_dense: the narrow algorithm over the DENSE layout (dataset.h: BLK_*, pack.cpp: relayout_dense).
 // The pieces of a (sample, tile) pair form a stream of 32-base blocks without alignment padding; ONE lane owns ONE
@@ -2758,12 +2625,9 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
         a.hdr8m = d.hdr8m; a.n_narrow = n_narrow;
         if (n_narrow && d.dense) hipLaunchKernelGGL(msnv_pileup_tiles_dense, dim3(n_narrow), dim3(N_NT), 0, st, a);      // (the dense layout never merges)
         else {
-            // whole-tile items of a sparse cohort: one workgroup walks `span` consecutive items (msnv_pileup_tiles_fused); MSNV_FUSE_SPAN=1: one item per workgroup, inside the one launch
-            static const uint32_t span = [] { const char *e = getenv("MSNV_FUSE_SPAN"); const int v = e ? atoi(e) : 1; return (uint32_t)std::min(64, std::max(1, v)); }();
-            const uint32_t n_all = n_narrow + n_merged, n_stream = (use_stage && span > 1u) ? n_all - a.n_fused_lo : 0u, n_plain = n_all - n_stream;
-            if (n_plain && d.allele_planes) hipLaunchKernelGGL(msnv_pileup_tiles_narrow32_planes, dim3(n_plain), dim3(N_NT), 0, st, a);
-            else if (n_plain) hipLaunchKernelGGL(msnv_pileup_tiles_narrow32, dim3(n_plain), dim3(N_NT), 0, st, a);
-            if (n_stream) hipLaunchKernelGGL(msnv_pileup_tiles_fused, dim3((n_stream + span - 1u) / span), dim3(N_NT), 0, st, a, a.n_fused_lo, n_all, span);
+            const uint32_t n_all = n_narrow + n_merged;       // (whole-tile items of a sparse cohort are the last items of the same launch)
+            if (n_all && d.allele_planes) hipLaunchKernelGGL(msnv_pileup_tiles_narrow32_planes, dim3(n_all), dim3(N_NT), 0, st, a);
+            else if (n_all) hipLaunchKernelGGL(msnv_pileup_tiles_narrow32, dim3(n_all), dim3(N_NT), 0, st, a);
         }
         if (d.n_work > n_narrow + n_merged) {
             PileupArgs b = a;

@@ -1,7 +1,8 @@
 export TMPDIR=/tmp
-timeout 900 python3 -m pytest tests/test_gpu_devpack.py tests/test_gpu_pack.py -x -q 2>&1 | tail -3
-timeout 900 python3 tests/fuzz_parity.py 400 17 2>&1 | tail -2
-python3 profiles/pack_resident.py testdata 1 4 | python3 -c "
-import json,sys; d=json.load(sys.stdin)
-for r in d['reps']: print({k:r[k] for k in ('pack_wall_ms','finalize_wall_ms','pack_kernel_ms')})"
-MSNV_FINALIZE_TRACE=1 python3 profiles/pack_resident.py testdata 1 2 2>&1 | grep -v '^{' | tail -60
+timeout 1200 python3 -m pytest tests/test_gpu_parity.py -x -q -k "whole_tile or sparse or fused or merged" 2>&1 | tail -2
+for i in 1 2 3; do
+  for V in base new; do
+    if [ $V = base ]; then export MSNV_LIBRARY=$PWD/ab/noplane.so; else unset MSNV_LIBRARY; fi
+    echo $V $(python3 profiles/shape_sweep.py sparse_500x5x_20ofN baseline | cut -c60-110)
+  done
+done
