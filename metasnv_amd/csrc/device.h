@@ -93,6 +93,7 @@ struct DeviceCols {
     uint32_t *gather_tiles = nullptr; uint32_t n_gather_tiles = 0;   // active tiles that hold pairs outside merged groups (spill gather)
     TileStage *tile_stage = nullptr;   // per active tile (index of its GateTile): candidate records of whole-tile work items
     uint32_t *tile_stage_idx = nullptr;   // per tile: that index
+    uint32_t  max_group_pairs = 0;   // most pairs a merged group holds (<= GMW_PAIRS: the merged gather runs a wavefront per group, kernels.hip)
     uint32_t  n_groups_solo = 0;     // the last n_groups_solo merged groups are whole-tile groups of ONE pair (no gather needed when the pass is fused)
     uint32_t  n_work_fused = 0;      // the last n_work_fused merged work items are whole-tile items
     uint32_t  n_fused_tiles = 0;     // tiles handled by whole-tile work items

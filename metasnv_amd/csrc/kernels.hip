@@ -1582,13 +1582,14 @@ __global__ __launch_bounds__(GATE_NT) void msnv_gate_sites(const GateArgs a) {
 // (the same tiles through msnv_gate_sites, reading records instead of per-position state: 0.38 ms for 85 k tiles -- three
 // workgroup barriers and a 127-register kernel per handful of records)
 // ------------------------------------------------------------------------------------------
+constexpr int GS_WAVES = 4;                    // wavefronts per workgroup: ONE reservation of site slots and cells per 64 tiles (sixteen wavefronts, a reservation per 256 tiles: 70 -> 79 us on the configs[3] shard -- the barrier waits for the slowest of sixteen load chains; the 1 400 pairs of same-address returning atomics are 20 us of the 70)
 constexpr int GS_TILES = 16;                   // tiles per wavefront; a workgroup of four wavefronts reserves ONCE for its 64 tiles
-__global__ __launch_bounds__(256) void msnv_gate_staged(const GateArgs a, const GateTile *__restrict__ tiles, const uint32_t n_tiles) {
-    __shared__ uint32_t s_sites[4]; __shared__ unsigned long long s_cells[4];
+__global__ __launch_bounds__(64 * GS_WAVES) void msnv_gate_staged(const GateArgs a, const GateTile *__restrict__ tiles, const uint32_t n_tiles) {
+    __shared__ uint32_t s_sites[GS_WAVES]; __shared__ unsigned long long s_cells[GS_WAVES];
     __shared__ uint32_t s_base, s_np, s_ni; __shared__ unsigned long long s_cb;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t w0 = (blockIdx.x * 4u + (uint32_t)wave) * (uint32_t)GS_TILES;
-    if (blockIdx.x == 0 && a.zero_next) for (uint32_t i = threadIdx.x; i < CNT_WORDS; i += 256) a.counters_next[i] = 0u;
+    const uint32_t w0 = (blockIdx.x * (uint32_t)GS_WAVES + (uint32_t)wave) * (uint32_t)GS_TILES;
+    if (blockIdx.x == 0 && a.zero_next) for (uint32_t i = threadIdx.x; i < CNT_WORDS; i += 64 * GS_WAVES) a.counters_next[i] = 0u;
     if (threadIdx.x == 0) { s_np = 0; s_ni = 0; }
     const uint32_t n_here = w0 < n_tiles ? min((uint32_t)GS_TILES, n_tiles - w0) : 0u;
     // lanes 0 .. n_here - 1: one tile each
@@ -1613,15 +1614,15 @@ __global__ __launch_bounds__(256) void msnv_gate_staged(const GateArgs a, const 
     if (lane == 0) { s_sites[wave] = tot_sites; s_cells[wave] = tot_cells; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t ts = s_sites[0] + s_sites[1] + s_sites[2] + s_sites[3];
-        const unsigned long long tc = s_cells[0] + s_cells[1] + s_cells[2] + s_cells[3];
+        uint32_t ts = 0; unsigned long long tc = 0;
+        for (int k = 0; k < GS_WAVES; ++k) { ts += s_sites[k]; tc += s_cells[k]; }
         s_base = ts ? atomicAdd(&a.counters[2], ts) : 0u;
         s_cb = ts ? atomicAdd(reinterpret_cast<unsigned long long *>(&a.counters[CNT_CELLS]), (tc + 7ull) & ~7ull) : 0ull;
     }
     __syncthreads();
     uint32_t base = s_base; unsigned long long cb = s_cb;
     uint32_t wg_sites = 0; unsigned long long wg_cells = 0;
-    for (int k = 0; k < 4; ++k) { if (k < wave) { base += s_sites[k]; cb += s_cells[k]; } wg_sites += s_sites[k]; wg_cells += s_cells[k]; }
+    for (int k = 0; k < GS_WAVES; ++k) { if (k < wave) { base += s_sites[k]; cb += s_cells[k]; } wg_sites += s_sites[k]; wg_cells += s_cells[k]; }
     if (mine) { a.tile_site_base[gt.tile] = cnt ? base + site_rel : 0u; a.tile_site_cnt[gt.tile] = cnt; a.tile_cell_base[gt.tile] = cnt ? cb + cell_rel : 0ull; }
     const bool fits = (unsigned long long)s_base + wg_sites <= a.cap_out && s_cb + wg_cells <= a.cap_cells;   // else: the host sees the counts and runs again with larger buffers
     uint32_t np = 0, ni = 0;
@@ -1703,6 +1704,7 @@ struct TailArgs {
     // merged groups of shallow pairs: their per-sample coverage at the called positions is recomputed from the pieces
     const MergedGroupDev *merged_groups; const ChunkDesc *chunks; const PieceHdr *hdr8m; const uint8_t *seq, *qual; const uint32_t *ref4;
     uint32_t n_merged_blocks, min_baseq;
+    uint32_t n_merged_run, merged_per_block;    // groups the merged gather runs over; groups per workgroup (gather_merged_block)
     // individual rule inside the merged gather (a sample's reads at a site all sit in ONE group): unless a split sample needs msnv_decide_sites anyway
     uint8_t *site_flags; const uint8_t *site_elig; uint32_t ind_in_gather, min_snvs;
     uint16_t *ncol; uint16_t *cov_col; uint32_t cap_out; const uint32_t *active_tiles; uint32_t n_gather_blocks;
@@ -1994,43 +1996,80 @@ __device__ __forceinline__ void scatter_events_block(const TailArgs &a, const ui
 // counted base at a called position -- quality at or above the cutoff and either a match or one of A, C, G, T: the bases the
 // pileup kernel did not put into its exception bins -- adds one to the group's LDS table [site][pair of the group], which
 // is then written out with plain stores (every (site, sample) cell belongs to exactly one group).
+// MSNV_MERGED_GATHER=block|wave forces a form (tests); default: a wavefront per group whenever every group is small enough
+static bool merged_wave_form(const DeviceCols &d);
 constexpr uint32_t GM_CELLS = 2048;           // cells of the LDS tables (6 B each); a tile with more sites x pairs is done in batches of sites
-__device__ __forceinline__ void gather_merged_block(const TailArgs &a, const uint32_t bid, uint32_t *s_pool) {
-    static_assert(2 * (TILE / 64) + TILE / 64 + GM_CELLS / 2 + GM_CELLS + MERGE_MAX_PAIRS <= 64 * (4 * 32 / 2 + 2), "the merged gather's tables fit the launch's LDS pool");
-    unsigned long long *const s_bits = reinterpret_cast<unsigned long long *>(s_pool);      // [TILE / 64]
-    uint32_t *const s_rank = s_pool + 2 * (TILE / 64);                                       // [TILE / 64]
-    uint32_t *const s_cov = s_rank + TILE / 64;         // [GM_CELLS / 2]: u16 per (site, pair): counted bases
-    uint32_t *const s_al = s_cov + GM_CELLS / 2;        // [GM_CELLS]: 4 x u8 per (site, pair): mismatching A, C, G, T (a shallow pair is < 81 deep)
-    uint32_t *const s_gsample = s_al + GM_CELLS;        // [MERGE_MAX_PAIRS]
-    const MergedGroupDev w = a.merged_groups[bid];      // ONE group per workgroup (a work item's groups in a row made this block the launch's long pole)
+constexpr uint32_t GMW_CELLS = 256, GMW_PAIRS = 16, GMW_GROUPS = 4;     // the one-wavefront form: groups of <= 16 pairs, four of them per workgroup
+constexpr uint32_t GMW_HITS = 240, GM_HITS = 480;       // (piece, site) overlaps listed per round (more: looked up where they are found)
+constexpr uint32_t GMW_WORDS = 2 * (TILE / 64) + TILE / 64 + GMW_CELLS / 2 + GMW_CELLS + GMW_PAIRS + 2 + 2 * GMW_HITS;
+constexpr uint32_t GM_WORDS = 2 * (TILE / 64) + TILE / 64 + GM_CELLS / 2 + GM_CELLS + MERGE_MAX_PAIRS + 2 + 2 * GM_HITS;
+// NT = 256: the workgroup works on the group; NT = 64 (round 5): ONE WAVEFRONT does, four groups per workgroup side by side.  A group of a sparse
+// cohort is ~250 pieces and ~5 sites -- no arithmetic to speak of but a chain of six to eight dependent loads (descriptor -> site tables and
+// headers -> slots -> bases / flags / reference of every hit -> rule bits), and a launch of one group per workgroup kept eight chains per CU
+// in flight where the wavefront slots allow thirty-two: 153 us of the configs[3] shard's 680 us pass (profiles/r05_sparse_ablation.txt).
+template <uint32_t NT, uint32_t CELLS, uint32_t PAIRS, uint32_t HITS>
+__device__ __forceinline__ void gather_merged_group(const TailArgs &a, const MergedGroupDev w, uint32_t *s_tab, const uint32_t tid) {
+    static_assert(GM_WORDS <= TAIL_POOL_WORDS && GMW_GROUPS * GMW_WORDS <= TAIL_POOL_WORDS && GMW_WORDS % 2 == 0, "the merged gather's tables fit the launch's LDS pool");
+    static_assert((2 * (TILE / 64) + TILE / 64 + CELLS / 2 + CELLS + PAIRS + 2) % 2 == 0, "the overlap list starts on 8 bytes");
+    unsigned long long *const s_bits = reinterpret_cast<unsigned long long *>(s_tab);       // [TILE / 64]
+    uint32_t *const s_rank = s_tab + 2 * (TILE / 64);                                        // [TILE / 64]
+    uint32_t *const s_cov = s_rank + TILE / 64;         // [CELLS / 2]: u16 per (site, pair): counted bases
+    uint32_t *const s_al = s_cov + CELLS / 2;           // [CELLS]: 4 x u8 per (site, pair): mismatching A, C, G, T (a shallow pair is < 81 deep)
+    uint32_t *const s_gsample = s_al + CELLS;           // [PAIRS]
+    uint32_t *const s_nhit = s_gsample + PAIRS;         // overlaps listed in this round
+    unsigned long long *const s_hit = reinterpret_cast<unsigned long long *>(s_nhit + 2);      // [HITS]
+    // (one wavefront: its LDS operations are served in order; the fences keep the compiler from moving them across)
+    auto sync = [] {
+        if constexpr (NT == 64) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+        else __syncthreads();
+    };
     // everything that hangs on the descriptor alone is requested together -- the tile's site tables, its bitmap and ranks, the first
-    // round of piece headers: the block is a chain of dependent loads (one group of a sparse cohort is ~250 pieces), not arithmetic
-    const uint32_t tile = w.tile, t0 = tile * TILE, tid = threadIdx.x;
+    // round(s) of piece headers, the pairs' slots: the group is a chain of dependent loads (one group of a sparse cohort is ~250 pieces), not arithmetic
+    const uint32_t tile = w.tile, t0 = tile * TILE;
     const uint32_t n = a.tile_site_cnt[tile], base = a.tile_site_base[tile], n_slots = a.cells.tile_nslots[tile];
     const unsigned long long cell0 = a.cells.tile_cell_base[tile];
     unsigned long long my_bits = 0; uint32_t my_rank = 0;
     if (tid < TILE / 64) { my_bits = a.site_bits[(t0 >> 6) + tid]; my_rank = a.site_rank[(t0 >> 6) + tid]; }
-    PieceHdr h_first{0u, 0u};
-    if (tid < w.n_pieces) h_first = a.hdr8m[w.hdr_base + tid];
+    constexpr uint32_t PF = NT == 64 ? 4u : 1u;         // header rounds asked for up front
+    PieceHdr h_first[PF];
+#pragma unroll
+    for (uint32_t k = 0; k < PF; ++k) { h_first[k] = PieceHdr{0u, 0u}; if (tid + k * NT < w.n_pieces) h_first[k] = a.hdr8m[w.hdr_base + tid + k * NT]; }
+    const uint32_t m = w.n_pairs;                       // pairs of the group
+    uint32_t my_slot = 0;
+    if (tid < m) my_slot = a.pairs[w.pair_lo + tid].pad >> 8;      // the pair's slot in the tile
     if (n == 0u) return;
     if (base + n > a.cap_out) return;                   // the host sees the site count and retries with a larger buffer
     if (cell0 + (unsigned long long)n * n_slots > a.cells.cap_cells) return;
     if (tid < TILE / 64) { s_bits[tid] = my_bits; s_rank[tid] = my_rank - base; }
+    if (tid < m) s_gsample[tid] = my_slot;
+    uint32_t my_tally = 0;                              // individual-call lines this lane adds
+    // one (piece, site) overlap: the base's flag, the base, the reference -> the (site, pair) cell
+    auto count_hit = [&](const unsigned long long rec) {
+        const unsigned long long qbit = rec & ((1ull << 40) - 1ull);
+        const uint32_t gp = t0 + ((uint32_t)(rec >> 40) & (TILE - 1u)), cell = (uint32_t)(rec >> 51);
+        const bool counted_q = !((a.qual[qbit >> 3] >> (qbit & 7u)) & 1u);
+        const uint32_t code = (a.seq[qbit >> 1] >> (4u * (uint32_t)(qbit & 1u))) & 0xfu;       // (the flag's index is the base's index in the column)
+        const uint32_t rc = (a.ref4[gp >> 3] >> (4u * (gp & 7u))) & 0xfu;
+        if (counted_q && (code == rc || (code != 0u && (code & (code - 1u)) == 0u))) {
+            atomicAdd(&s_cov[cell >> 1], 1u << (16u * (cell & 1u)));
+            if (code != rc) atomicAdd(&s_al[cell], 1u << (8u * (uint32_t)__builtin_ctz(code)));
+        }
+    };
     {
-        // the group's extent comes with its descriptor: every table the block needs is one load away from it (a chain of ten
-        // dependent loads -- chunk descriptors walked one by one -- made this block the long pole of the launch)
-        struct { uint64_t hdr_base; uint32_t pair, pad; } g{w.hdr_base, w.pair_lo, w.n_pairs};
         const uint32_t n_pieces = w.n_pieces;
-        const uint32_t m = g.pad;                         // pairs of the group
-        const uint32_t batch = max(1u, GM_CELLS / m);     // sites per round
-        if (tid < m) s_gsample[tid] = a.pairs[g.pair + tid].pad >> 8;      // the pair's slot in the tile
+        const uint32_t batch = max(1u, CELLS / m);        // sites per round
         for (uint32_t j0 = 0; j0 < n; j0 += batch) {
             const uint32_t nj = min(batch, n - j0);
-            for (uint32_t i = tid; i < (nj * m + 1u) / 2u; i += blockDim.x) s_cov[i] = 0u;
-            for (uint32_t i = tid; i < nj * m; i += blockDim.x) s_al[i] = 0u;
-            __syncthreads();
-            for (uint32_t pi = tid; pi < n_pieces; pi += blockDim.x) {
-                const PieceHdr h = pi == tid ? h_first : a.hdr8m[g.hdr_base + pi];
+            if (tid == 0u) *s_nhit = 0u;
+            for (uint32_t i = tid; i < (nj * m + 1u) / 2u; i += NT) s_cov[i] = 0u;
+            for (uint32_t i = tid; i < nj * m; i += NT) s_al[i] = 0u;
+            sync();
+            // phase 1: the lanes list the (piece, site) overlaps; phase 2: one overlap per lane -- the three loads of every overlap of the round are
+            // in flight together (round 5: looked up where they were found, a lane's overlaps were as many memory round trips in a row)
+            for (uint32_t pi = tid, k = 0; pi < n_pieces; pi += NT, ++k) {
+                PieceHdr h;
+                if (PF == 4u) h = k == 0u ? h_first[0] : k == 1u ? h_first[PF > 1 ? 1 : 0] : k == 2u ? h_first[PF > 2 ? 2 : 0] : k == 3u ? h_first[PF > 3 ? 3 : 0] : a.hdr8m[w.hdr_base + pi];
+                else h = k == 0u ? h_first[0] : a.hdr8m[w.hdr_base + pi];
                 const uint32_t s = h.w0 & (TILE - 1u), len = (h.w0 >> 11) & 0xffu, pidx = (h.w0 >> 19) & 0xffu;
                 const uint64_t so = ((uint64_t)(h.w0 >> 27) << 32 | h.seqoff8) << SEQ_ALIGN_LOG2;
                 for (uint32_t wd = s >> 6; wd <= (s + len - 1u) >> 6 && wd < TILE / 64; ++wd) {
@@ -2044,21 +2083,17 @@ __device__ __forceinline__ void gather_merged_block(const TailArgs &a, const uin
                         const uint32_t j = s_rank[wd] + (uint32_t)__popcll(s_bits[wd] & (low - 1ull));   // site index inside the tile
                         if (j < j0 || j >= j0 + nj) continue;
                         const uint32_t q = (wd << 6) + b, o = q - s;
-                        const uint64_t qbit = 2ull * so + o;                              // the base's flag in the low-quality column
-                        const bool counted_q = !((a.qual[qbit >> 3] >> (qbit & 7u)) & 1u);
-                        const uint32_t code = (a.seq[so + (o >> 1)] >> (4u * (o & 1u))) & 0xfu;
-                        const uint32_t gp = t0 + q;
-                        const uint32_t rc = (a.ref4[gp >> 3] >> (4u * (gp & 7u))) & 0xfu;
-                        if (counted_q && (code == rc || (code != 0u && (code & (code - 1u)) == 0u))) {
-                            const uint32_t cell = (j - j0) * m + pidx;
-                            atomicAdd(&s_cov[cell >> 1], 1u << (16u * (cell & 1u)));
-                            if (code != rc) atomicAdd(&s_al[cell], 1u << (8u * (uint32_t)__builtin_ctz(code)));
-                        }
+                        const unsigned long long rec = (2ull * so + o) | (unsigned long long)q << 40 | (unsigned long long)((j - j0) * m + pidx) << 51;      // flag bit (40) | position (11) | cell (<= 11 bits)
+                        const uint32_t slot = atomicAdd(s_nhit, 1u);
+                        if (slot < HITS) s_hit[slot] = rec;
+                        else count_hit(rec);                          // (more overlaps than the list holds: looked up here)
                     }
                 }
             }
-            __syncthreads();
-            for (uint32_t i = tid; i < nj * m; i += blockDim.x) {
+            sync();
+            for (uint32_t i = tid, nh = min(*s_nhit, HITS); i < nh; i += NT) count_hit(s_hit[i]);
+            sync();
+            for (uint32_t i = tid; i < nj * m; i += NT) {
                 const uint32_t v = (s_cov[i >> 1] >> (16u * (i & 1u))) & 0xffffu;
                 const uint64_t cell = cell0 + (uint64_t)(j0 + i / m) * n_slots + s_gsample[i % m];
                 if (v) a.cov_col[cell] = (uint16_t)v;
@@ -2079,15 +2114,30 @@ __device__ __forceinline__ void gather_merged_block(const TailArgs &a, const uin
                             uint32_t *wordp = reinterpret_cast<uint32_t *>(a.site_flags + (site & ~3u));
                             const uint32_t sh = 8u * (site & 3u);
                             const uint32_t old = atomicOr(wordp, (ind << 4) << sh);
-                            if ((((old >> sh) & 0xffu) >> 4) == 0u)          // the site's first individual call: one more indiv_called line
-                                atomicAdd(reinterpret_cast<unsigned long long *>(&a.counters[CNT_TALLY]), 1ull << 32);
+                            if ((((old >> sh) & 0xffu) >> 4) == 0u) ++my_tally;      // the site's first individual call: one more indiv_called line
                         }
                     }
                 }
             }
-            __syncthreads();
+            sync();
         }
     }
+    // one add per wavefront (round 5: one per site -- 125 k adds to ONE word on the configs[3] shard, served one after the other by that
+    // word's L2 channel -- was most of this launch's 150 us)
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) my_tally += (uint32_t)__shfl_xor((int)my_tally, o);
+    if ((tid & 63u) == 0u && my_tally) atomicAdd(reinterpret_cast<unsigned long long *>(&a.counters[CNT_TALLY]), (unsigned long long)my_tally << 32);
+}
+// merged_per_block = 1: ONE group per workgroup (a work item's groups in a row made this block the launch's long pole); GMW_GROUPS when every
+// group of the dataset holds <= GMW_PAIRS pairs (a sparse cohort): a wavefront each
+__device__ __forceinline__ void gather_merged_block(const TailArgs &a, const uint32_t bid, uint32_t *s_pool) {
+    if (a.merged_per_block == 1u) { gather_merged_group<256, GM_CELLS, MERGE_MAX_PAIRS, GM_HITS>(a, a.merged_groups[bid], s_pool, threadIdx.x); return; }
+    const uint32_t gi = bid * GMW_GROUPS + (threadIdx.x >> 6);
+    if (gi < a.n_merged_run) gather_merged_group<64, GMW_CELLS, GMW_PAIRS, GMW_HITS>(a, a.merged_groups[gi], s_pool + (threadIdx.x >> 6) * GMW_WORDS, threadIdx.x & 63u);
+}
+static bool merged_wave_form(const DeviceCols &d) {
+    static const int forced = [] { const char *e = getenv("MSNV_MERGED_GATHER"); return !e ? 0 : e[0] == 'b' ? 1 : e[0] == 'w' ? 2 : 0; }();
+    return d.max_group_pairs <= GMW_PAIRS && forced != 1;
 }
 
 // msnv_gather_scatter: one launch, two independent halves working on the zeroed (msnv_gate_sites) per-sample records.
@@ -2684,7 +2734,7 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
             g.zero_next = 0u;
         }
         if (n_staged) {
-            hipLaunchKernelGGL(msnv_gate_staged, dim3((n_staged + 4 * GS_TILES - 1) / (4 * GS_TILES)), dim3(256), 0, st, g, reinterpret_cast<const GateTile *>(d.gate_tiles_staged), n_staged);
+            hipLaunchKernelGGL(msnv_gate_staged, dim3((n_staged + GS_WAVES * GS_TILES - 1) / (GS_WAVES * GS_TILES)), dim3(64 * GS_WAVES), 0, st, g, reinterpret_cast<const GateTile *>(d.gate_tiles_staged), n_staged);
             // the tiles whose candidates did not fit their record list (counted and listed on the device: fused_tile_gate) through the ordinary
             // gate; the workgroups stride over the list -- as many as the previous pass would have kept busy, a handful when it listed none
             g.gate_tiles = reinterpret_cast<const GateTile *>(d.gate_tiles); g.tile_list = stage_ovf_list(d); g.n_active = n_staged; g.solo_cells = 1u;
@@ -2714,7 +2764,8 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
         ta.debug_skip = tail_skip;
         ta.n_gather_blocks = d.n_gather_tiles * d.gather_split;
         ta.tile_pair_merged = d.tile_pair_merged; ta.merged_groups = d.merged_groups; ta.chunks = d.chunks; ta.hdr8m = d.hdr8m;
-        ta.seq = d.seq; ta.qual = d.qual; ta.ref4 = d.ref4; ta.n_merged_blocks = d.n_merged_groups - (use_stage ? d.n_groups_solo : 0u); ta.min_baseq = (uint32_t)std::max(0, p.min_baseq);
+        ta.seq = d.seq; ta.qual = d.qual; ta.ref4 = d.ref4; ta.n_merged_run = d.n_merged_groups - (use_stage ? d.n_groups_solo : 0u);
+        ta.merged_per_block = merged_wave_form(d) ? GMW_GROUPS : 1u; ta.n_merged_blocks = (ta.n_merged_run + ta.merged_per_block - 1u) / ta.merged_per_block; ta.min_baseq = (uint32_t)std::max(0, p.min_baseq);
         ta.site_flags = d.site_flags; ta.site_elig = d.site_elig; ta.ind_in_gather = d.any_split ? 0u : 1u; ta.min_snvs = (uint32_t)std::max(1, p.calling_threshold);
         ta.events = d.events; ta.overflow = d.overflow; ta.counters = counters; ta.cap_list = d.cap_events / EV_LISTS; ta.cap_overflow = d.cap_overflow;
         ta.site_bits = d.site_bits; ta.site_rank = d.site_rank;

@@ -1445,6 +1445,8 @@ int finalize_dataset(msnv_dataset &ds) {
             if (int rc = arena.add(&d->hdr8m, hm, &d->device_bytes, 1)) return rc;
         }
         d->n_merged_groups = (uint32_t)mgroups.size();
+        d->max_group_pairs = 0;
+        for (const MergedGroupDev &g : mgroups) d->max_group_pairs = std::max(d->max_group_pairs, g.n_pairs);
         if (int rc = arena.add(&d->merged_groups, mgroups, &d->device_bytes, 1)) return rc;
         if (int rc = arena.add(&d->tile_pair_merged, tpm, &d->device_bytes)) return rc;
     }
