@@ -671,12 +671,45 @@ def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=Non
             metrics["plan_samples"] = int(sum(len(h[1]) for h in held))
         while held:
             deliver(*held.pop(0))
+    # The rounds that stream through (round 5): round k + 1 is DECODED WHILE round k is dealt, exchanged and packed -- on a thread of its own
+    # when the decoder stays on the host (a test's / benchmark's read_records, MSNV_INFLATE=host: the library releases the GIL and touches
+    # nothing of the context), and as a read-ahead hint for the files of the next round when it does not: the device route inflates and
+    # deals with the context's own staging buffers and stream, which the pack of round k is using (one context, one thread at a time).
+    def read_ahead(plan_round):
+        if read_records is not None:
+            return
+        for i, r in plan_round:
+            if r != _rank:
+                continue
+            try:
+                fd = os.open(bam_paths[i], os.O_RDONLY)
+                try:
+                    os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_WILLNEED)
+                finally:
+                    os.close(fd)
+            except (OSError, AttributeError):
+                pass
+    host_decoder = read_records is not None or os.environ.get("MSNV_INFLATE", "device")[:1] == "h"
+    overlap = host_decoder and os.environ.get("MSNV_FEED_OVERLAP", "1") != "0" and len(rounds) - k > 1
+    if overlap:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=1) as ahead:
+            nxt = ahead.submit(decode_round, rounds[k][1])
+            while k < len(rounds):
+                base, plan_round = rounds[k]
+                got = nxt.result()
+                nxt = ahead.submit(decode_round, rounds[k + 1][1]) if k + 1 < len(rounds) else None
+                deliver(base, plan_round, *got)
+                k += 1
     while k < len(rounds):
         base, plan_round = rounds[k]
+        if k + 1 < len(rounds):
+            read_ahead(rounds[k + 1][1])
         deliver(base, plan_round, *decode_round(plan_round))
         k += 1
     if metrics is not None:
         metrics.update(split)
+        metrics["decode_overlapped"] = bool(overlap)
     agree(pending[0], "the last round of records was appended")
     allstats = gather_fixed(stats)
     stats = np.maximum.reduce(allstats) if len(allstats) > 1 else stats      # every row is non-zero on exactly one rank

@@ -50,7 +50,7 @@ def main():
     np.save(os.path.join(work, "owner.npy"), np.array(owner, dtype=np.int32))
     for i, s in enumerate(rec.samples):
         s.tofile(os.path.join(work, "r%d_s%d.bin" % (rank, i)))
-    open(os.path.join(work, "n%d" % rank), "w").write("%d %d" % (len(rec.samples), metrics["inflated_record_bytes"]))
+    open(os.path.join(work, "n%d" % rank), "w").write("%d %d %d" % (len(rec.samples), metrics["inflated_record_bytes"], int(metrics["decode_overlapped"])))
     parallel.barrier()
     parallel.finalize()
 

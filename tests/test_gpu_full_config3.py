@@ -32,10 +32,23 @@ def _ram_gb():
 @pytest.mark.skipif(os.environ.get("MSNV_SKIP_FULL_CONFIG3") == "1", reason="MSNV_SKIP_FULL_CONFIG3=1")
 @pytest.mark.skipif(_ram_gb() < 400, reason="needs >= 400 GB of host memory for staging")
 def test_full_size_config3_properties():
+    _full_size_properties("config3", float(os.environ.get("MSNV_FULL_CONFIG3_SCALE", "1.0")))
+
+
+@pytest.mark.skipif(os.environ.get("MSNV_SKIP_FULL_CONFIG3") == "1" or os.environ.get("MSNV_SKIP_FULL_CONFIG4") == "1", reason="MSNV_SKIP_FULL_CONFIG3/4=1")
+@pytest.mark.skipif(_ram_gb() < 150, reason="needs >= 150 GB of host memory for staging")
+def test_full_size_config4_shard_properties():
+    """ONE GPU's whole contig shard of BASELINE configs[3] (round 5): 1500 species x ~2.07 Mbp = 3.1e9 reference
+    positions, 500 samples at 5x, every species carried by a handful of samples -- the sparse-cohort route (whole-tile work items, record
+    lists, msnv_gate_staged, a wavefront per merged group in the gather) at the size the 8-GPU run gives every rank.  Same properties as
+    the configs[2] test above; the 2 % shape is checked against the oracle in test_gpu_parity.py."""
+    _full_size_properties("config4shard", float(os.environ.get("MSNV_FULL_CONFIG4_SCALE", "1.0")))
+
+
+def _full_size_properties(workload, scale):
     sys.path.insert(0, ROOT)
     import bench
-    scale = float(os.environ.get("MSNV_FULL_CONFIG3_SCALE", "1.0"))
-    a = argparse.Namespace(workload="config3", scale=scale, samples=None, contig_len=None, species=None, mean_cov=None, read_len=100, error_rate=None)
+    a = argparse.Namespace(workload=workload, scale=scale, samples=None, contig_len=None, species=None, mean_cov=None, read_len=100, error_rate=None)
     kw, label = bench.workload_params(a)
     sp = core.synth_params(**kw)
     syn = core.Synth(sp)
@@ -43,8 +56,11 @@ def test_full_size_config3_properties():
     ds = core.Dataset(ctx, syn.names, syn.lengths, syn.seqs)
     ds.add_synth_samples(sp, 0, sp.n_samples, 0)
     info = ds.finalize()
-    if scale == 1.0:
+    if scale == 1.0 and workload == "config3":
         assert info["n_pileup_bases"] > 4.8e10 and info["n_positions"] == 300000000 and info["n_samples"] == 160
+    if scale == 1.0 and workload == "config4shard":
+        assert info["n_pileup_bases"] > 1.0e10 and info["n_positions"] > 3.0e9 and info["n_samples"] == 500
+        assert info["n_whole_tile_items"] > 500000                # the sparse route is the one that ran
     p = ds.params
     t, c_min, frac = p.calling_threshold, p.min_coverage, p.min_fraction
 

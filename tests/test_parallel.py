@@ -100,17 +100,22 @@ def _records(buf):
     return out
 
 
-@pytest.mark.parametrize("batch,slice_kb", [(1, None), (2, None), (2, "4")])
+@pytest.mark.parametrize("batch,slice_kb", [(1, None), (2, None), (2, "4"), (1, "serial")])
 def test_two_rank_decode_sharding_deals_every_record_to_its_owner(tmp_path, batch, slice_kb):
     """parallel.feed_sharded over gloo: each sample is read by exactly one rank (per-rank decoded bytes ~ 1/N of the job),
-    and after the all-to-all every rank holds, per sample and in order, exactly the records of the contigs it owns."""
+    and after the all-to-all every rank holds, per sample and in order, exactly the records of the contigs it owns.  Round k + 1 is
+    decoded while round k is exchanged (round 5; "serial": MSNV_FEED_OVERLAP=0, one after the other)."""
+    serial = slice_kb == "serial"
+    slice_kb = None if serial else slice_kb
     work = str(tmp_path)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_feed_worker.py"), work, str(batch)]
     # slice_kb: the byte exchange in slices of 4 KB (parallel.exchange_records walks a large round in slices: uneven parts, parts that end early)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", **({"MSNV_A2A_SLICE_KB": slice_kb} if slice_kb else {}))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", **({"MSNV_A2A_SLICE_KB": slice_kb} if slice_kb else {}), **({"MSNV_FEED_OVERLAP": "0"} if serial else {}))
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     assert r.returncode == 0, r.stdout.decode()[-3000:]
+    for k in (0, 1):                                                             # (several rounds stream through: the decoder ran ahead unless told not to)
+        assert int(open(os.path.join(work, "n%d" % k)).read().split()[2]) == (0 if serial else 1)
     sp = core.synth_params(n_species=5, contig_len=2500, n_samples=7, mean_cov=6.0, frac_absent=0.3, seed=77)
     syn = core.Synth(sp)
     owner = np.load(os.path.join(work, "owner.npy"))
