@@ -373,6 +373,9 @@ def strong_run(a, rank, world, local, dist, brief=False):
         return sts[-1]
 
     threads = a.host_threads or max(1, min(32, (os.cpu_count() or 8) // max(1, world)))
+    # (the "decoder" of this benchmark is the synthetic generator: run ahead of the pack -- what feed_sharded does with a host decoder -- its
+    # threads would sit in the pack stage's event brackets, which this line reports as pack_on_device; MSNV_FEED_OVERLAP=1 to see it overlapped)
+    os.environ.setdefault("MSNV_FEED_OVERLAP", "0")
     t_all = time.perf_counter()
     res = parallel.resident_project_run(ctx, None, None, [str(i) for i in range(sp.n_samples)], params, batch=threads, want_coverage=True,
                                         make_dataset=lambda: core.Dataset(ctx, syn.names, syn.lengths, syn.seqs, params),

@@ -294,7 +294,14 @@ __device__ __forceinline__ bool hdr_plausible(const uint8_t *raw, unsigned long 
     if (pos < -1 || l_name < 1 || l_seq < 0 || mtid < -1 || mtid >= n_contigs || mpos < -1) return false;
     const unsigned long long need = 36ull + l_name + 4ull * n_cigar + ((unsigned long long)(uint32_t)l_seq + 1) / 2 + (unsigned long long)(uint32_t)l_seq;
     if (need > (unsigned long long)bs + 4) return false;
-    return raw[o + 36 + l_name - 1] == 0;
+    // (a GUESS may be as strict as it likes -- a sub-segment without one is walked from the true entry by msnv_scan_fix.  More than 64 KB of
+    // auxiliary fields and a read name that does not begin and end on a printable character are turned down: four bytes in front of a true
+    // header the last qualities of the record before read as a block_size of millions, the true block_size as a contig number -- with the
+    // 2 500 contigs of BASELINE configs[2] that passed every other test ~20 times per stream, a repair pass each)
+    if ((unsigned long long)bs + 4 - need > 65536ull) return false;
+    if (raw[o + 36 + l_name - 1] != 0) return false;
+    if (l_name >= 2) { const uint8_t c0 = raw[o + 36], c1 = raw[o + 36 + l_name - 2]; if (c0 < 33 || c0 > 126 || c1 < 33 || c1 > 126) return false; }
+    return true;
 }
 __device__ __forceinline__ uint32_t sub_stream_of(const SubStream *ss, uint32_t n_streams, uint32_t g) {        // last stream whose first sub-segment is at or before g
     uint32_t a = 0, b = n_streams;
@@ -346,21 +353,57 @@ __global__ __launch_bounds__(256) void msnv_scan_sub(const uint8_t *raw, const S
             off += 4ull + bs;
         }
     }
+    if ((bad || n > cap) && g != S.sub0) { first[g] = ~0ull - 1ull; stop[g] = 0ull; cnt[g] = 0u; return; }      // a walk from a GUESSED entry that breaks: a wrong guess (msnv_scan_repair walks again from the true one)
     first[g] = f; stop[g] = f != ~0ull ? off : 0ull; cnt[g] = n;
-    if (bad || n > cap) atomicOr(flags, 1u);                        // a malformed chain (or an impossible count): the careful kernel reports it
+    if (bad || n > cap) atomicOr(flags, 1u);                        // a malformed chain from the stream's first byte (or an impossible count): the careful kernel reports it
 }
 // seams: cur = where the chain stands in front of sub-segment g = the largest end of a walk before it (the stream's first byte for its first
 // sub-segment: ends of earlier streams lie before it)
-__global__ void msnv_scan_seams(const SubStream *ss, uint32_t n_streams, uint32_t n_sub, uint32_t sub_bytes, const unsigned long long *first, const unsigned long long *stop_max, uint32_t *cnt, uint32_t *flags) {
+// Seams of the quick scan, checked AND repaired (round 5): a sub-segment whose walk did not begin where the chain of the earlier ones stands
+// (stop_max: running maximum of their ends) guessed wrong -- a false header inside a read name or a quality string: one in ~1e7 sub-segments,
+// i.e. several in every round of BASELINE configs[2], where sending the whole round through the careful kernel cost 3 x the scan (85 of 128 ms).
+// Only the FIRST such sub-segment of a stream can be trusted to be wrong (everything in front of it is the true chain; a wrong walk's end --
+// it may lie a whole stream further on -- makes the ones behind it LOOK wrong): msnv_scan_check finds it, msnv_scan_fix walks it again from the
+// true entry, the host scans the ends again and asks once more -- as many passes as the worst stream has wrong guesses (usually none).
+// Flags: 2 = a sub-segment was fixed, 4 = the chain breaks from its TRUE entry (malformed input: the careful kernel words the error).
+__global__ void msnv_scan_check(const SubStream *ss, uint32_t n_streams, uint32_t n_sub, uint32_t sub_bytes, const unsigned long long *first, const unsigned long long *stop_max, uint32_t *cnt, uint32_t *first_bad) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_sub) { if (g == n_sub) cnt[g] = 0; return; }
-    const SubStream S = ss[sub_stream_of(ss, n_streams, g)];
+    const uint32_t si = sub_stream_of(ss, n_streams, g);
+    const SubStream S = ss[si];
     if (g == S.sub0) return;                                        // (entered at the stream's first byte)
     const unsigned long long b = S.beg + (unsigned long long)(g - S.sub0) * sub_bytes, e = b + sub_bytes < S.end ? b + sub_bytes : S.end;
     unsigned long long cur = stop_max[g - 1];
     cur = cur > S.beg ? cur : S.beg;
-    if (cur >= e) { if (first[g] != ~0ull) atomicOr(flags, 2u); cnt[g] = 0; }      // a record runs across the whole sub-segment: nothing may start here
-    else if (first[g] != cur) atomicOr(flags, 2u);
+    const unsigned long long want = cur >= e ? ~0ull : cur;         // cur >= e: a record runs across the whole sub-segment, nothing starts here
+    if (first[g] != want) atomicMin(&first_bad[si], g);
+}
+__global__ void msnv_scan_fix(const uint8_t *raw, const SubStream *ss, uint32_t n_streams, uint32_t sub_bytes, uint32_t cap, unsigned long long *first, unsigned long long *stop,
+                              const unsigned long long *stop_max, uint32_t *cnt, uint16_t *delta, uint32_t *first_bad, uint32_t *flags) {
+    const uint32_t si = blockIdx.x * blockDim.x + threadIdx.x;
+    if (si >= n_streams) return;
+    const uint32_t g = first_bad[si];
+    first_bad[si] = 0xffffffffu;                                    // (for the next pass)
+    if (g == 0xffffffffu) return;
+    const SubStream S = ss[si];
+    const unsigned long long b = S.beg + (unsigned long long)(g - S.sub0) * sub_bytes, e = b + sub_bytes < S.end ? b + sub_bytes : S.end;
+    unsigned long long cur = stop_max[g - 1];
+    cur = cur > S.beg ? cur : S.beg;
+    atomicOr(flags, 2u);
+    if (cur >= e) { first[g] = ~0ull; stop[g] = 0ull; cnt[g] = 0u; return; }
+    uint32_t n = 0; unsigned long long off = cur;
+    bool bad = false;
+    uint16_t *dl = delta + (size_t)g * cap;
+    while (off < e) {
+        if (S.end - off < 36) { bad = true; break; }
+        const uint32_t bs = ld32(raw + off);
+        if ((int32_t)bs < 32 || (unsigned long long)bs + 4 > S.end - off) { bad = true; break; }
+        if (n < cap) dl[n] = (uint16_t)(off - b);
+        ++n;
+        off += 4ull + bs;
+    }
+    if (bad || n > cap) { atomicOr(flags, 4u); return; }
+    first[g] = cur; stop[g] = off; cnt[g] = n;
 }
 struct U64Max { __device__ __host__ unsigned long long operator()(unsigned long long a, unsigned long long b) const { return a > b ? a : b; } };
 // the offsets out: a wavefront takes 64 consecutive sub-segments, whose records are consecutive in the list, and writes them 64 at a time
@@ -1600,14 +1643,26 @@ static int scan_streams(hipStream_t st, const int device, BufPool &pool, const u
             HIP_TRY(rocprim::exclusive_scan(nullptr, need2, d_cnt, d_base, 0u, (size_t)n_sub + 1, rocprim::plus<uint32_t>(), st));
             need = std::max(need, need2);
             if (need > tmp_cap) { pool.next -= 1; d_tmp = static_cast<uint8_t *>(pool.get(need)); if (!d_tmp) return pool.rc; }
-            HIP_TRY(rocprim::inclusive_scan(d_tmp, need, d_stop, d_stopmax, (size_t)n_sub, U64Max(), st));
-            hipLaunchKernelGGL(msnv_scan_seams, grid_for((uint64_t)n_sub + 1, 256), dim3(256), 0, st, d_ss, (uint32_t)S, n_sub, sub_bytes, d_first, d_stopmax, d_cnt, d_fl);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(rocprim::exclusive_scan(d_tmp, need, d_cnt, d_base, 0u, (size_t)n_sub + 1, rocprim::plus<uint32_t>(), st));
             uint32_t fl_tot[2] = {0, 0};
-            HIP_TRY(hipMemcpyAsync(&fl_tot[0], d_fl, 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(&fl_tot[1], d_base + n_sub, 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
+            DP_BUF(uint32_t, d_firstbad, S);
+            HIP_TRY(hipMemsetAsync(d_firstbad, 0xff, S * 4, st));
+            for (int pass = 0;; ++pass) {
+                // seams: checked, every stream's first sub-segment that guessed wrong walked again, until none is left (usually the first look)
+                HIP_TRY(rocprim::inclusive_scan(d_tmp, need, d_stop, d_stopmax, (size_t)n_sub, U64Max(), st));
+                hipLaunchKernelGGL(msnv_scan_check, grid_for((uint64_t)n_sub + 1, 256), dim3(256), 0, st, d_ss, (uint32_t)S, n_sub, sub_bytes, d_first, d_stopmax, d_cnt, d_firstbad);
+                hipLaunchKernelGGL(msnv_scan_fix, grid_for(S, 64), dim3(64), 0, st, raw, d_ss, (uint32_t)S, sub_bytes, cap, d_first, d_stop, d_stopmax, d_cnt, d_delta, d_firstbad, d_fl);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipMemcpyAsync(&fl_tot[0], d_fl, 4, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                if (!(fl_tot[0] & 2u) || (fl_tot[0] & 5u) || pass >= 4096) break;
+                R.n_redone += 1;                                  // (counted: a repair pass)
+                HIP_TRY(hipMemsetAsync(d_fl, 0, 4, st));
+            }
+            if (!fl_tot[0]) {
+                HIP_TRY(rocprim::exclusive_scan(d_tmp, need, d_cnt, d_base, 0u, (size_t)n_sub + 1, rocprim::plus<uint32_t>(), st));
+                HIP_TRY(hipMemcpyAsync(&fl_tot[1], d_base + n_sub, 4, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+            }
             if (!fl_tot[0]) {
                 // (a 32-bit count that wrapped would show as a total below the sub-segments' sum; 2^32 records need 150 GB of stream in one round -- refused by size)
                 if (raw_bytes / 36 > 0xfffffff0ull) return fail(MSNV_EDOMAIN, "more than 2^32 records in one round of the device pack");

@@ -257,8 +257,8 @@ def test_errors_carry_the_host_stage_codes():
 
 def test_record_scan_across_segment_seams():
     """The record chain is walked piecewise with GUESSED entry points checked at every seam -- round 5: a lane per sub-segment, seams checked
-    on the device (devpack.hip: msnv_scan_sub / msnv_scan_seams; MSNV_SCAN_SUB bytes); the careful form (msnv_scan_segments, MSNV_SCAN=segments,
-    MSNV_SCAN_SEG_KB) repairs wrong guesses and takes over when a seam of the quick form does not hold.  Tiny pieces put a seam into almost
+    on the device, wrong guesses walked again there (devpack.hip: msnv_scan_sub / msnv_scan_repair; MSNV_SCAN_SUB bytes); the careful form (msnv_scan_segments, MSNV_SCAN=segments,
+    MSNV_SCAN_SEG_KB) repairs wrong guesses on the host and takes over when the quick form meets a chain that breaks.  Tiny pieces put a seam into almost
     every record (and records longer than a sub-segment next to it); a read name that holds plausible record headers makes guesses go wrong."""
     syn, samples = synth_case(n_species=2, contig_len=6000, n_samples=4, mean_cov=9.0, snv_density=0.02, seed=25)
     for sub in ("64", "100", "333", "4096"):
@@ -286,7 +286,13 @@ def test_record_scan_across_segment_seams():
                 ds.add_sample_records(stream)
                 ds.finalize()
                 assert ds.info()["n_reads_pileup"] == 40
+                if env.get("MSNV_SCAN_SUB") in ("64", "128"):
+                    # the quick form fell for the decoy and walked those sub-segments again from the true entry (msnv_scan_repair), on the device
+                    assert ds.pack_stats()["scan_segments_redone"] >= 1
                 ds.close()
+        for sub in ("64", "128"):                                    # ... and what it builds is the host pack's dataset, byte for byte
+            with _env(MSNV_SCAN_SUB=sub):
+                _same_dataset(["c"], [6000], [ref], [stream])
     finally:
         ctx.close()
 
