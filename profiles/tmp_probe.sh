@@ -1,5 +1,15 @@
 export TMPDIR=/tmp
-timeout 1200 python3 -m pytest tests/test_gpu_devpack.py -x -q 2>&1 | tail -2
-timeout 900 python3 tests/fuzz_parity.py 300 93 2>&1 | tail -1
-timeout -s ABRT 300 python3 -X faulthandler bench.py --workload config3 --scale 0.25 --no-cpu-baseline --no-annotation --steps 3 --warmup 1 2> gpurun_out/c3.err | python3 -c "
-import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['host']['wall_s_whole_run'], d['host']['pack_on_device_rank0'])"
+for V in none nodense; do
+  if [ $V = none ]; then unset MSNV_LIBRARY; else export MSNV_LIBRARY=$PWD/ab/$V.so; fi
+  OUT=gpurun_out/pp_$V; rm -rf $OUT; mkdir -p $OUT
+  timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_LDS --kernel-include-regex "narrow32" -d $OUT -o pmc --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-annotation --no-overlap-extra --no-strong-extra > $OUT.log 2>&1
+  python3 - $OUT $V <<'PY'
+import csv, glob, sys, collections
+acc = collections.defaultdict(list)
+for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "narrow32" in r.get("Kernel_Name", ""): acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+print("variant", sys.argv[2], " ".join("%s=%.4g" % (k, sum(v) / len(v)) for k, v in sorted(acc.items())))
+PY
+done
+bash profiles/ab.sh ab/nodense.so 2 2>/dev/null
