@@ -255,7 +255,20 @@ def main(argv=None):
             # at best, the device in 0.25 s once its context stands): then the feed waits for the context and inflates on the device
             # (parallel.feed_sharded: MSNV_ONESHOT=device | host overrides)
             how = os.environ.get("MSNV_ONESHOT", "")[:1]
-            args.inflate_after_context = how == "d" or (how != "h" and min(args.threads, core.host_cores()) <= 16)
+            # ... and only when the library WILL inflate there (csrc/api.cpp: want_device_inflate -- MSNV_INFLATE=host, or fewer than 64 MB of
+            # BAMs, keeps the host decoder): waiting for the context first and then inflating on the host threads anyway would lose the overlap
+            def device_would_inflate():
+                e = os.environ.get("MSNV_INFLATE", "")[:1]
+                if e:
+                    return e == "d"
+                total = 0
+                for b in read_sample_list(args.all_samples):
+                    try:
+                        total += os.path.getsize(b)
+                    except OSError:
+                        pass
+                return total >= (64 << 20)
+            args.inflate_after_context = how == "d" or (how != "h" and min(args.threads, core.host_cores()) <= 16 and device_would_inflate())
 
             def bring_up():
                 return core.Context(local) if core.device_count() >= 1 else None

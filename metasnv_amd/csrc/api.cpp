@@ -181,6 +181,15 @@ extern "C" int msnv_dataset_set_contig_mask(msnv_dataset *ds, const uint8_t *mas
 // Where the per-read stage runs (record parse, read filters, CIGAR walk, -Q test, piece cutting): on the device (devpack.hip) whenever the
 // dataset has a device context -- MSNV_PACK=host keeps it on the host threads (pack.cpp), the same bytes either way.  A dataset created
 // without a context (host-stage entry points only) packs on the host.
+// What every entry point that appends samples (and finalize) asks first.  staged_ok: msnv_dataset_stage_sample_bams itself and finalize -- behind a
+// staging call no other add_sample_* call may follow (msnv.h): the staged streams are packed last, so the sample order, and with it every
+// per-sample output column, would come out wrong with no error.
+static int check_open(const msnv_dataset *ds, bool staged_ok = false) {
+    if (ds->finalized) return fail(MSNV_EINVAL, "dataset is already finalized");
+    if (ds->poisoned) return fail(MSNV_EINVAL, "an earlier call failed after part of its samples had been packed on the device: the dataset cannot be used further (destroy it)");
+    if (!staged_ok && !ds->staged.empty()) return fail(MSNV_EINVAL, "the dataset holds staged streams (msnv_dataset_stage_sample_bams): they are packed last, by msnv_dataset_finalize");
+    return MSNV_OK;
+}
 static bool pack_on_device(const msnv_dataset *ds) {
     if (!ds->ctx) return false;
     const char *e = getenv("MSNV_PACK");                 // (per call: tests switch it)
@@ -193,6 +202,7 @@ static int add_streams_device(msnv_dataset *ds, const uint8_t *const *records, c
     struct Mark { ~Mark() { fin_trace("pack: whole call"); } } mark;
     const uint64_t round_bytes = [] { const char *e = getenv("MSNV_PACK_ROUND_MB"); const long long v = e ? atoll(e) : 6144; return (uint64_t)std::max<long long>(1, v) << 20; }();
     const size_t first = ds->samples.size();
+    const size_t rounds_at_entry = ds->dp.rounds.size();
     ds->samples.resize(first + (size_t)n);
     int rc = MSNV_OK;
     try {
@@ -203,14 +213,18 @@ static int add_streams_device(msnv_dataset *ds, const uint8_t *const *records, c
             i0 = i1;
         }
     } catch (const std::exception &e) { rc = fail(MSNV_ENOMEM, "packing on the device failed: %s", e.what()); }
-    if (rc) ds->samples.resize(first);
+    if (rc) {
+        ds->samples.resize(first);
+        // rounds of this call that went through left their tables behind (dp.rounds, first_sample): finalize would index with them
+        if (ds->dp.rounds.size() != rounds_at_entry) ds->poisoned = true;
+    }
     return rc;
 }
 
 extern "C" int msnv_dataset_add_sample_records_device(msnv_dataset *ds, const void *const *dev_records, const uint64_t *n_bytes, int32_t n) {
     clear_error();
     if (!ds || n < 0 || (n && (!dev_records || !n_bytes))) return fail(MSNV_EINVAL, "msnv_dataset_add_sample_records_device: bad argument");
-    if (ds->finalized) return fail(MSNV_EINVAL, "dataset is already finalized");
+    if (int rc = check_open(ds)) return rc;
     if (!ds->ctx) return fail(MSNV_ENODEV, "msnv_dataset_add_sample_records_device: the dataset has no device context");
     for (int i = 0; i < n; ++i) if (n_bytes[i] && !dev_records[i]) return fail(MSNV_EINVAL, "msnv_dataset_add_sample_records_device: stream %d is NULL", i);
     return add_streams_device(ds, reinterpret_cast<const uint8_t *const *>(dev_records), n_bytes, n, true);
@@ -219,9 +233,8 @@ extern "C" int msnv_dataset_add_sample_records_device(msnv_dataset *ds, const vo
 extern "C" int msnv_dataset_add_sample_records_resident(msnv_dataset *ds, void *dev_buffer, uint64_t capacity, const uint64_t *offsets, const uint64_t *n_bytes, int32_t n) {
     clear_error();
     if (!ds || n < 0 || (n && (!dev_buffer || !offsets || !n_bytes))) return fail(MSNV_EINVAL, "msnv_dataset_add_sample_records_resident: bad argument");
-    if (ds->finalized) return fail(MSNV_EINVAL, "dataset is already finalized");
+    if (int rc = check_open(ds)) return rc;
     if (!ds->ctx) return fail(MSNV_ENODEV, "msnv_dataset_add_sample_records_resident: the dataset has no device context");
-    if (!ds->staged.empty()) return fail(MSNV_EINVAL, "the dataset holds staged streams (msnv_dataset_stage_sample_bams): they are packed last, by msnv_dataset_finalize");
     if (reinterpret_cast<uintptr_t>(dev_buffer) & 15u) return fail(MSNV_EINVAL, "msnv_dataset_add_sample_records_resident: the buffer must start on 16 bytes");
     uint64_t prev_end = 0;
     for (int i = 0; i < n; ++i) {
@@ -237,8 +250,7 @@ extern "C" int msnv_dataset_add_sample_records_resident(msnv_dataset *ds, void *
 extern "C" int msnv_dataset_add_sample_records(msnv_dataset *ds, const uint8_t *records, uint64_t n_bytes) {
     clear_error();
     if (!ds || (n_bytes && !records)) return fail(MSNV_EINVAL, "msnv_dataset_add_sample_records: NULL argument");
-    if (ds->finalized) return fail(MSNV_EINVAL, "dataset is already finalized");
-    if (!ds->staged.empty()) return fail(MSNV_EINVAL, "the dataset holds staged streams (msnv_dataset_stage_sample_bams): they are packed last, by msnv_dataset_finalize");
+    if (int rc = check_open(ds)) return rc;
     if (pack_on_device(ds)) return add_streams_device(ds, &records, &n_bytes, 1, false);
     ds->samples.emplace_back();
     int rc;
@@ -251,9 +263,8 @@ extern "C" int msnv_dataset_add_sample_records(msnv_dataset *ds, const uint8_t *
 extern "C" int msnv_dataset_add_sample_records_many(msnv_dataset *ds, const uint8_t *const *records, const uint64_t *n_bytes, int32_t n, int32_t host_threads) {
     clear_error();
     if (!ds || n < 0 || (n && (!records || !n_bytes))) return fail(MSNV_EINVAL, "msnv_dataset_add_sample_records_many: bad argument");
-    if (ds->finalized) return fail(MSNV_EINVAL, "dataset is already finalized");
+    if (int rc = check_open(ds)) return rc;
     for (int i = 0; i < n; ++i) if (n_bytes[i] && !records[i]) return fail(MSNV_EINVAL, "msnv_dataset_add_sample_records_many: stream %d is NULL", i);
-    if (!ds->staged.empty()) return fail(MSNV_EINVAL, "the dataset holds staged streams (msnv_dataset_stage_sample_bams): they are packed last, by msnv_dataset_finalize");
     if (pack_on_device(ds)) return add_streams_device(ds, records, n_bytes, n, false);
     int nthreads = host_threads > 0 ? host_threads : (int)msnv_default_threads();
     nthreads = std::min(nthreads, std::max(1, (int)n));
@@ -891,7 +902,7 @@ extern "C" int msnv_dataset_add_sample_bams(msnv_dataset *ds, const char *const 
     clear_error();
     HostTimerScope ts_all(HT_ADD_WALL);
     if (!ds || (n && !bam_paths)) return fail(MSNV_EINVAL, "msnv_dataset_add_sample_bams: NULL argument");
-    if (ds->finalized) return fail(MSNV_EINVAL, "dataset is already finalized");
+    if (int rc = check_open(ds)) return rc;
     int nthreads = host_threads > 0 ? host_threads : (int)msnv_default_threads();
     nthreads = std::min(nthreads, std::max(1, (int)n));
     if (pack_on_device(ds)) return add_bams_device_pack(ds, bam_paths, n, nthreads);
@@ -969,7 +980,7 @@ extern "C" int msnv_dataset_stage_sample_bams(msnv_dataset *ds, const char *cons
     clear_error();
     HostTimerScope ts_all(HT_ADD_WALL);
     if (!ds || n < 0 || (n && !bam_paths)) return fail(MSNV_EINVAL, "msnv_dataset_stage_sample_bams: bad argument");
-    if (ds->finalized) return fail(MSNV_EINVAL, "dataset is already finalized");
+    if (int rc = check_open(ds, true)) return rc;
     if (!ds->samples.empty()) return fail(MSNV_EINVAL, "msnv_dataset_stage_sample_bams: the dataset already holds packed samples (staged streams are packed last)");
     int nthreads = host_threads > 0 ? host_threads : (int)msnv_default_threads();
     nthreads = std::min(nthreads, std::max(1, (int)n));
@@ -1013,7 +1024,7 @@ extern "C" int msnv_dataset_stage_sample_bams(msnv_dataset *ds, const char *cons
 extern "C" int msnv_dataset_add_synth_samples(msnv_dataset *ds, const msnv_synth_params *p, int32_t first, int32_t count, int32_t host_threads) {
     clear_error();
     if (!ds || !p || count < 0) return fail(MSNV_EINVAL, "msnv_dataset_add_synth_samples: bad argument");
-    if (ds->finalized) return fail(MSNV_EINVAL, "dataset is already finalized");
+    if (int rc = check_open(ds)) return rc;
     if ((size_t)msnv_synth_contig_count(p) != ds->names.size()) return fail(MSNV_EINVAL, "synthetic parameters describe %d contigs, dataset has %zu", msnv_synth_contig_count(p), ds->names.size());
     int nthreads = host_threads > 0 ? host_threads : (int)msnv_default_threads();
     nthreads = std::min(nthreads, std::max(1, (int)count));
@@ -1072,7 +1083,7 @@ extern "C" int msnv_dataset_add_synth_samples(msnv_dataset *ds, const msnv_synth
 extern "C" int msnv_dataset_finalize(msnv_dataset *ds) {
     clear_error();
     if (!ds) return fail(MSNV_EINVAL, "msnv_dataset_finalize: NULL dataset");
-    if (ds->finalized) return fail(MSNV_EINVAL, "dataset is already finalized");
+    if (int rc = check_open(ds, true)) return rc;
     if (!ds->ctx) return fail(MSNV_ENODEV, "this dataset was created without a device context: only the host-stage entry points work on it (no CPU fallback)");
     if (int rc = dev_set_device(ds->ctx->device)) return rc;
     // The staged streams go back to the system on threads of their own, and only once the device dataset stands.  Giving gigabytes back

@@ -197,6 +197,7 @@ struct msnv_dataset {
     // samples
     std::vector<msnv::SampleCols> samples;
     bool finalized = false;
+    bool poisoned = false;          // an add_* call failed AFTER rounds of the device pack had been appended (api.cpp: add_streams_device): nothing more is added or finalized
     // layout
     std::vector<uint32_t> tile_base;       // per contig (selected only; others = UINT32_MAX)
     std::vector<uint32_t> tile_contig;     // per tile

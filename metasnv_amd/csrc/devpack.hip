@@ -1816,7 +1816,8 @@ __global__ __launch_bounds__(256) void msnv_deal_measure(const uint8_t *raw, con
         const Rec r = rec_load(raw + rec_off[i], s_end[s] - rec_off[i]);
         f = 1u;
         uint32_t k = 0xffu;                                    // 0xff: the record goes nowhere (unmapped, or its contig is outside every shard)
-        if ((r.flag & BAM_FUNMAP) || r.tid < 0) f |= 2u;
+        if (!r.ok) f |= 256u;                                  // its inner fields do not fit its block_size: not walked, not forwarded (the host partition's MSNV_EFORMAT)
+        else if ((r.flag & BAM_FUNMAP) || r.tid < 0) f |= 2u;
         else {
             f |= 32u;
             if ((int)r.mapq >= cov_min_mapq) f |= ((r.flag & BAM_FPROPER_PAIR) ? 8u : 0u) | ((r.flag & BAM_FDUP) ? 16u : 0u);
@@ -1851,8 +1852,9 @@ __global__ __launch_bounds__(256) void msnv_deal_measure(const uint8_t *raw, con
                     if (b3) atomicAdd(&a.proper, (uint32_t)__popcll(b3));
                     if (b4) atomicAdd(&a.dup, (uint32_t)__popcll(b4));
                     if (b5) a.any_mapped = 1u;
-                    if (b6) a.bad_tid = 1u;
+                    if (b6) atomicOr(&a.bad_tid, 1u);
                     if (b7) a.bad_owner = 1u;
+                    if (__ballot(f & 256u)) atomicOr(&a.bad_tid, 2u);
                 }
             }
         } else if (f) {
@@ -1863,8 +1865,9 @@ __global__ __launch_bounds__(256) void msnv_deal_measure(const uint8_t *raw, con
             if (f & 8u) atomicAdd(&a.proper, 1u);
             if (f & 16u) atomicAdd(&a.dup, 1u);
             if (f & 32u) a.any_mapped = 1u;
-            if (f & 64u) a.bad_tid = 1u;
+            if (f & 64u) atomicOr(&a.bad_tid, 1u);
             if (f & 128u) a.bad_owner = 1u;
+            if (f & 256u) atomicOr(&a.bad_tid, 2u);
         }
     }
     if (contig_bases) {
@@ -1977,12 +1980,13 @@ int records_deal_device(msnv_ctx *ctx, const uint8_t *const *streams, const uint
     HIP_TRY(hipStreamSynchronize(st));
     for (size_t s = 0; s < S; ++s) {
         msnv_sample_stats &o = stats[s];
-        bool bad_tid = false, bad_owner = false;
+        bool bad_tid = false, bad_owner = false, bad_rec = false;
         for (uint32_t c = 0; c < DEAL_COPIES; ++c) {
             const DealAcc &a = acc[s * DEAL_COPIES + c];
             o.total_reads += a.total; o.unmapped += a.unmapped; o.zero_quality += a.zero_q; o.proper_pairs += a.proper; o.duplicates += a.dup; o.any_mapped |= a.any_mapped;
-            bad_tid |= a.bad_tid != 0; bad_owner |= a.bad_owner != 0;
+            bad_tid |= (a.bad_tid & 1u) != 0; bad_rec |= (a.bad_tid & 2u) != 0; bad_owner |= a.bad_owner != 0;
         }
+        if (bad_rec) return fail(MSNV_EFORMAT, "stream %zu: malformed BAM record (its name, CIGAR and bases do not fit its block_size)", s);
         if (bad_tid) return fail(MSNV_EFORMAT, "stream %zu: a record refers to a contig beyond the header's %d", s, n_contigs);
         if (bad_owner) return fail(MSNV_EINVAL, "stream %zu: a contig is owned by a part beyond %d", s, n_parts);
     }

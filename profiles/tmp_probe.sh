@@ -1,15 +1,2 @@
 export TMPDIR=/tmp
-for V in none nodense; do
-  if [ $V = none ]; then unset MSNV_LIBRARY; else export MSNV_LIBRARY=$PWD/ab/$V.so; fi
-  OUT=gpurun_out/pp_$V; rm -rf $OUT; mkdir -p $OUT
-  timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_LDS --kernel-include-regex "narrow32" -d $OUT -o pmc --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-annotation --no-overlap-extra --no-strong-extra > $OUT.log 2>&1
-  python3 - $OUT $V <<'PY'
-import csv, glob, sys, collections
-acc = collections.defaultdict(list)
-for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
-        if "narrow32" in r.get("Kernel_Name", ""): acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-print("variant", sys.argv[2], " ".join("%s=%.4g" % (k, sum(v) / len(v)) for k, v in sorted(acc.items())))
-PY
-done
-bash profiles/ab.sh ab/nodense.so 2 2>/dev/null
+timeout 2400 python3 -m pytest tests -x -q -m gpu 2>&1 | tail -4

@@ -369,6 +369,16 @@ def test_records_dealt_on_the_device_equal_the_host_partition():
     with pytest.raises(core._lib.MsnvError) as e:                   # an output that cannot hold every record
         core.deal_records_device(ctx, [samples[1]], np.zeros(nc, np.int32), 2, p.value, 64)
     assert e.value.code == core._lib.ECAPACITY
+    # a record whose CIGAR cannot fit its block_size (n_cigar_op patched to 65535): refused like the host partition refuses it -- not walked
+    # (256 KB of "CIGAR" behind a 60-byte record), not forwarded
+    broken = bytearray(bt.records(bt.make_record(0, 5, "10M", "ACGTACGTAC", name="b"), bt.make_record(0, 9, "10M", "ACGTACGTAC", name="c")).tobytes())
+    broken[16:18] = b"\xff\xff"
+    with pytest.raises(core._lib.MsnvError) as e:
+        core.deal_records_device(ctx, [np.frombuffer(bytes(broken), np.uint8)], np.zeros(nc, np.int32), 2, p.value, 4096, contig_bases=np.zeros(nc, np.uint64))
+    assert e.value.code == core._lib.EFORMAT and "malformed" in str(e.value)
+    with pytest.raises(core._lib.MsnvError) as e:
+        core.partition_records(np.frombuffer(bytes(broken), np.uint8), np.zeros(nc, np.int32), 2)
+    assert e.value.code == core._lib.EFORMAT
     hip.hipFree(p); hip.hipFree(p2); ctx.close()
 
 

@@ -126,3 +126,20 @@ def test_header_only_read_inflates_the_leading_blocks_only(tmp_path):
     assert core.read_bam(bad, records=False)["names"] == names
     with pytest.raises(core._lib.MsnvError):
         core.read_bam(bad)
+
+
+def test_nothing_is_added_behind_staged_streams(tmp_path):
+    """msnv_dataset_stage_sample_bams reads now and packs in finalize -- LAST: every add_sample_* entry point refuses a dataset that holds
+    staged streams (the sample order, and with it every per-sample output column, would come out wrong with no error)."""
+    p = str(tmp_path / "x.bam")
+    rec = _records()
+    core.write_bam(p, ["c1", "c2"], [20, 30], rec)
+    ds = core.Dataset(None, ["c1", "c2"], [20, 30], ["A" * 20, "C" * 30])           # no context yet (the runtime is still coming up)
+    ds.stage_sample_bams([p])
+    sp = core.synth_params(n_species=2, contig_len=20, n_samples=1, mean_cov=1.0, read_len=10, seed=1)
+    for call in (lambda: ds.add_sample_records(rec), lambda: ds.add_sample_bams([p]), lambda: ds.add_synth_samples(sp, 0, 1, 1)):
+        with pytest.raises(core._lib.MsnvError) as e:
+            call()
+        assert e.value.code == core._lib.EINVAL and "staged" in str(e.value)
+    ds.stage_sample_bams([p])                                                      # (more staging is fine)
+    ds.close()
