@@ -12,8 +12,10 @@ python3 bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 python3 bench.py --workload config4shard --scale 0.1 --no-cpu-baseline --no-annotation > gpurun_out/${TAG}_bench_config4shard_0p1.json 2>/dev/null
 MSNV_FINALIZE_TRACE=1 python3 profiles/pack_resident.py testdata 1 4 > gpurun_out/${TAG}_records_to_calls.json 2> gpurun_out/${TAG}_records_to_calls_trace.txt
 bash profiles/fuzz.sh ${TAG}fin 1500 9191 > /dev/null 2>&1
+bash profiles/fuzz.sh ${TAG}sparse 1500 4242 MSNV_FUSE=1 > /dev/null 2>&1      # every tile a whole-tile work item: record lists, msnv_gate_staged, both forms of the merged gather
+python3 bench.py --workload config4shard --scale 1.0 --no-cpu-baseline --no-annotation --steps 5 --warmup 2 > gpurun_out/${TAG}_bench_config4shard_full.json 2>/dev/null
 python3 bench.py --workload config3 --scale 1.0 --no-cpu-baseline --no-annotation --steps 3 --warmup 1 > gpurun_out/${TAG}_bench_config3_full.json 2>/dev/null
-for f in bench bench_config4shard_0p1 bench_config3_full; do python3 - gpurun_out/${TAG}_$f.json <<'PY'
+for f in bench bench_config4shard_0p1 bench_config4shard_full bench_config3_full; do python3 - gpurun_out/${TAG}_$f.json <<'PY'
 import json, sys
 try:
     d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
@@ -24,4 +26,4 @@ except Exception as e:
     print(sys.argv[1], "FAILED", e)
 PY
 done
-tail -2 gpurun_out/${TAG}fin_fuzz.txt
+tail -2 gpurun_out/${TAG}fin_fuzz.txt gpurun_out/${TAG}sparse_fuzz.txt
