@@ -26,4 +26,4 @@ except Exception as e:
     print(sys.argv[1], "FAILED", e)
 PY
 done
-tail -2 gpurun_out/${TAG}fin_fuzz.txt gpurun_out/${TAG}sparse_fuzz.txt
+tail -n 2 gpurun_out/${TAG}fin_fuzz.txt; tail -n 2 gpurun_out/${TAG}sparse_fuzz.txt
