@@ -1382,7 +1382,7 @@ __global__ void msnv_fill_padding(const ReadHdr *hdr, const unsigned long long *
     if (i >= n_pieces) return;
     uint32_t a = 0, b = n_samples;                       // sample of piece i: last s with s_read_base[s] <= i
     while (b - a > 1) { const uint32_t m = (a + b) / 2; if (s_read_base[m] <= i) a = m; else b = m; }
-    if (!s_dev[a]) return;
+    if (s_dev && !s_dev[a]) return;                      // (nullptr: every sample was packed on the device)
     const ReadHdr h = hdr[i];
     const uint32_t len = h.cig, stop = (len + 2u * SEQ_ALIGN - 1u) & ~(2u * SEQ_ALIGN - 1u);
     uint8_t *sp = seq + s_seq_base[a] + h.seqoff;
@@ -3549,9 +3549,17 @@ int devpack_finish(msnv_dataset &ds) {
 int devpack_fill_padding(DeviceCols &d, const std::vector<uint8_t> &sample_on_device, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     if (!d.n_reads || sample_on_device.empty()) return MSNV_OK;
-    bool any = false;
-    for (uint8_t v : sample_on_device) any |= v != 0;
+    bool any = false, all = true;
+    for (uint8_t v : sample_on_device) { any |= v != 0; all &= v != 0; }
     if (!any) return MSNV_OK;
+    if (all) {
+        // nothing to tell the kernel apart by, nothing to free behind it: it runs beside the host's coverage tables (round 5: the wait for it
+        // was 0.28 ms of finalize); whoever uses the columns next is on this stream
+        hipLaunchKernelGGL(msnv_fill_padding, grid_for(d.n_reads, 256), dim3(256), 0, st, d.hdr, (const unsigned long long *)d.s_read_base, (const unsigned long long *)d.s_seq_base,
+                           (const uint8_t *)nullptr, (uint32_t)sample_on_device.size(), (unsigned long long)d.n_reads, d.ref4, d.seq);
+        HIP_TRY(hipGetLastError());
+        return MSNV_OK;
+    }
     DevBuf flags;
     if (int rc = flags.alloc(sample_on_device.size())) return rc;
     HIP_TRY(hipMemcpyAsync(flags.p, sample_on_device.data(), sample_on_device.size(), hipMemcpyHostToDevice, st));
