@@ -2136,7 +2136,7 @@ __device__ __forceinline__ void gather_merged_block(const TailArgs &a, const uin
     if (gi < a.n_merged_run) gather_merged_group<64, GMW_CELLS, GMW_PAIRS, GMW_HITS>(a, a.merged_groups[gi], s_pool + (threadIdx.x >> 6) * GMW_WORDS, threadIdx.x & 63u);
 }
 static bool merged_wave_form(const DeviceCols &d) {
-    static const int forced = [] { const char *e = getenv("MSNV_MERGED_GATHER"); return !e ? 0 : e[0] == 'b' ? 1 : e[0] == 'w' ? 2 : 0; }();
+    const int forced = [] { const char *e = getenv("MSNV_MERGED_GATHER"); return !e ? 0 : e[0] == 'b' ? 1 : e[0] == 'w' ? 2 : 0; }();      // (per pass: tests switch it)
     return d.max_group_pairs <= GMW_PAIRS && forced != 1;
 }
 
