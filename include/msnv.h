@@ -267,7 +267,11 @@ int  msnv_dataset_add_sample_bam(msnv_dataset *ds, const char *bam_path);
 int  msnv_dataset_add_sample_bams(msnv_dataset *ds, const char *const *bam_paths, int32_t n, int32_t host_threads);
 
 /* The files are read, inflated and checked now (host threads), packed by msnv_dataset_finalize: a dataset created without a context
- * (msnv_dataset_attach_ctx later) still gets the per-read stage as kernels.  No other add_sample_* call may follow. */
+ * (msnv_dataset_attach_ctx later) still gets the per-read stage as kernels.  No other add_sample_* call may follow: every one of them
+ * returns MSNV_EINVAL on a dataset that holds staged streams (more staging is fine).
+ * Failure of any add_sample_* call leaves the dataset as it was before the call -- except when the call had already packed part of its
+ * samples on the device (a later round of the same call failed: out of memory, a malformed record): such a dataset answers MSNV_EINVAL
+ * to every further add_sample_* and to msnv_dataset_finalize and can only be destroyed. */
 int  msnv_dataset_stage_sample_bams(msnv_dataset *ds, const char *const *bam_paths, int32_t n, int32_t host_threads);
 
 /* Host-stage seam (tests, A/B against `samtools mpileup` text): writes to `out` (n_bytes) the same record stream with the

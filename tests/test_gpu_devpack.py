@@ -421,3 +421,33 @@ def test_streams_read_in_place_from_one_device_buffer():
         d2.add_samples_records_resident(buf.value, cap, list(reversed(offs)), list(reversed(sizes)))   # not ascending
     d2.close(); dh.close(); ch.close(); cd.close()
     hip.hipFree(buf)
+
+
+def test_a_call_that_fails_after_a_round_leaves_the_dataset_unusable():
+    """msnv_dataset_add_sample_records_many packs in rounds (MSNV_PACK_ROUND_MB); when a LATER round fails, the rounds that went through have
+    left their tables behind: the samples of the call are taken back, and the dataset answers MSNV_EINVAL to every further add_* and to
+    finalize instead of indexing with stale rounds.  A call that fails in its FIRST round leaves the dataset usable."""
+    syn, samples = synth_case(n_species=1, contig_len=30000, n_samples=3, mean_cov=60.0, seed=5)
+    assert all(s.size > (1 << 20) // 2 for s in samples)            # (more than half a megabyte each: a round of its own below)
+    bad = samples[2].copy()
+    bad[16:18] = 0xff                                               # n_cigar_op of the first record: 65535 operations cannot fit its block_size
+    ctx = core.Context(0)
+    try:
+        with _env(MSNV_PACK="device", MSNV_PACK_ROUND_MB="1"):
+            ds = core.Dataset(ctx, syn.names, syn.lengths, syn.seqs)
+            with pytest.raises(core._lib.MsnvError) as e:
+                ds.add_samples_records([samples[0], samples[1], bad])
+            assert e.value.code == core._lib.EFORMAT
+            for call in (lambda: ds.add_sample_records(samples[0]), lambda: ds.finalize()):
+                with pytest.raises(core._lib.MsnvError) as e:
+                    call()
+                assert e.value.code == core._lib.EINVAL and "cannot be used further" in str(e.value)
+            ds.close()
+            ds = core.Dataset(ctx, syn.names, syn.lengths, syn.seqs)
+            with pytest.raises(core._lib.MsnvError):
+                ds.add_samples_records([bad])                       # (the first round of the call: nothing was left behind)
+            ds.add_samples_records([samples[0], samples[1]])
+            assert ds.finalize()["n_samples"] == 2
+            ds.close()
+    finally:
+        ctx.close()
