@@ -341,8 +341,18 @@ struct InflatedExt { uint64_t off, size; };
 // blocks of every file by the host decoder (res->hdr / res->rec_off, per file of the batch); a block the device refused or that did not
 // check is inflated by the host decoder and patched into the device buffer.  consume() then gets out = nullptr and dev_valid = true.
 struct ResidentBatch { std::vector<BamHeader> hdr; std::vector<uint64_t> rec_off; };
+// MSNV_FEED_TRACE=1: wall milliseconds between the steps of the device feed, on stderr
+static void feed_mark(const char *what) {
+    static const bool on = [] { const char *e = getenv("MSNV_FEED_TRACE"); return e && e[0] == '1'; }();
+    if (!on) return;
+    static double last = 0;
+    const double now = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    fprintf(stderr, "[feed] %-44s %8.3f ms\n", what, last ? (now - last) * 1e3 : 0.0);
+    last = now;
+}
 template <typename Consume>
 static int bgzf_read_files_device(msnv_ctx *ctx, const char *const *paths, int n, int threads, Consume consume, uint64_t counters[4], ResidentBatch *res = nullptr) {
+    feed_mark("enter");
     if (int rc = dev_set_device(ctx->device)) return rc;
     std::vector<uint64_t> fsize((size_t)n, 0);
     for (int i = 0; i < n; ++i) {
@@ -359,7 +369,11 @@ static int bgzf_read_files_device(msnv_ctx *ctx, const char *const *paths, int n
     // the batch buffers in HBM go back on EVERY way out (a caller that falls back to the host path after an error must not find up to ~4.6 GB
     // of staging still attached to the context); the pinned half stays for the next call
     struct ReleaseDevice { msnv_ctx *c; ~ReleaseDevice() { dev_inflate_release_device(c); } } release_device{ctx};
-    const uint64_t batch_in = [] { const char *e = getenv("MSNV_INFLATE_BATCH_MB"); const long long v = e ? atoll(e) : 1024; return (uint64_t)std::max<long long>(1, v) << 20; }();   // compressed bytes per batch (~2.5 GB inflated; tests shrink it)
+    // compressed bytes per batch (tests shrink it).  1 GB (~3.6 GB inflated) where the batch goes through pinned staging; 2 GB for the resident form,
+    // which pins nothing: the benchmark's 160 BAMs (1.35 GB) are then ONE batch -- as two, the second one's files were read (page faults of fresh
+    // buffers) while the first one's 1 GB went up from pageable memory (the runtime pinning it page by page), and the launcher waited 90 ms
+    // for that read behind the first batch (MSNV_FEED_TRACE=1: round 5)
+    const uint64_t batch_in = [&] { const char *e = getenv("MSNV_INFLATE_BATCH_MB"); const long long v = e ? atoll(e) : (res ? 2048 : 1024); return (uint64_t)std::max<long long>(1, v) << 20; }();
     // RESIDENT form: a batch's host work -- files read into pageable memory, blocks indexed, BAM headers read from the leading blocks -- is done by
     // load_batch, and the NEXT batch is loaded (std::async) while the device inflates, checks and packs the current one
     struct Loaded {
@@ -423,6 +437,7 @@ static int bgzf_read_files_device(msnv_ctx *ctx, const char *const *paths, int n
         std::unique_ptr<Loaded> loaded;
         if (res) {
             loaded = ahead.valid() ? ahead.get() : load_batch(f0);
+            feed_mark("batch loaded (files read, blocks indexed)");
             if (loaded->rc) return fail(loaded->rc, "%s", loaded->msg.c_str());
             f1 = loaded->f1; ib = loaded->ib; in_off = loaded->in_off;
             if (f1 < n) ahead = std::async(std::launch::async, load_batch, f1);
@@ -495,7 +510,10 @@ static int bgzf_read_files_device(msnv_ctx *ctx, const char *const *paths, int n
         }
         if (res) {
             res->hdr = std::move(loaded->hdr); res->rec_off = std::move(loaded->rec_off);      // (read by load_batch)
-            if (int rc = dev_inflate_device_buffers(ctx, ib, ob)) {
+            feed_mark("block list");
+            const int rc_buf = dev_inflate_device_buffers(ctx, ib, ob);
+            feed_mark("device buffers");
+            if (int rc = rc_buf) {
                 if (rc != MSNV_ENOMEM) return rc;
                 fprintf(stderr, "libmsnv: no staging for the device inflate (%s); this batch is inflated on the host\n", msnv_last_error());
                 clear_error();
@@ -522,6 +540,7 @@ static int bgzf_read_files_device(msnv_ctx *ctx, const char *const *paths, int n
             int rc = MSNV_OK;
             if (res && getenv("MSNV_TEST_RESIDENT_FAIL")) rc = fail_quiet(MSNV_ENOMEM, "resident inflate refused (MSNV_TEST_RESIDENT_FAIL)");      // (tests: the fallback below)
             else rc = res ? dev_inflate_resident(ctx, in_stage, ib, list, blk_in_file, check_every, status, &ms) : dev_inflate(ctx, ib, list, ob, status, &ms);
+            feed_mark("upload + inflate + check");
             if (rc) {
                 if (rc != MSNV_ENOMEM && rc != MSNV_EHIP) return rc;
                 fprintf(stderr, "libmsnv: the device inflate failed (%s); this batch is inflated on the host\n", msnv_last_error());
@@ -611,7 +630,9 @@ static int bgzf_read_files_device(msnv_ctx *ctx, const char *const *paths, int n
             dev_valid = !host_batch && done.load() == 0;               // every block of the batch as the device wrote it: ctx->dev_out holds the same bytes as `out`
         }
         n_blocks += list.size();
+        feed_mark("blocks settled");
         if (int rc = consume(f0, f1, (const uint8_t *)out, ext, dev_valid)) return rc;
+        feed_mark("batch consumed (statistics, pack)");
         f0 = f1;
     }
     if (counters) { counters[0] = n_blocks; counters[1] = n_host; counters[2] = (uint64_t)(ms * 1000.0); counters[3] = n_bytes; }
