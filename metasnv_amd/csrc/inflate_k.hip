@@ -30,8 +30,12 @@ struct InfBlock { unsigned long long in_off, out_off; uint32_t in_size, out_size
 
 namespace {
 
+#if !defined(MSNV_INFLATE_WAVES)
+#define MSNV_INFLATE_WAVES 5                                   // wavefronts per SIMD the register allocation aims at (86 registers; 6 = 80 registers, two of them spilled: the same 130.6 ms)
+#endif
 constexpr int I_LL_BITS = 9, I_D_BITS = 6;                     // root table bits (zlib's choice: 852 / 592 entries bound the tables)
-constexpr int I_LL_CAP = 1024, I_D_CAP = 640;
+constexpr int I_LL_CAP = 852, I_D_CAP = 592;                    // zlib's ENOUGH_LENS / ENOUGH_DISTS for these root bits: the most entries a valid code needs (round 5: 1024 / 640 -- the
+                                                                // kernel's rate is wavefronts in flight / latency per symbol, and LDS is what bounds the wavefronts: 18 -> 22 per CU)
 constexpr uint32_t IF_LIT = 1u << 12, IF_EOB = 1u << 13, IF_SUB = 1u << 14, IF_BAD = 1u << 15;
 // entry: bits 0-7 code length (bits to drop), 8-11 extra bits, 12-15 flags, 16-31 literal / base value / subtable start
 
@@ -43,8 +47,7 @@ __constant__ uint8_t k_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 
 
 struct InfLds {
     uint32_t ll[I_LL_CAP];
-    uint32_t d[I_D_CAP];
-    uint32_t cl[128];
+    uint32_t d[I_D_CAP];                       // (its first 128 entries are the code-length code's table while a dynamic block's header is read: d is built behind that)
     uint8_t  lens[32 + 320 + 8];               // [0, 19): code-length code; [32, ...): literal/length lengths, then the distance lengths
     uint16_t code[320];                        // bit-reversed canonical code of every symbol
     uint8_t  sub_bits[1 << I_LL_BITS];
@@ -141,7 +144,7 @@ __device__ bool build_table(InfLds &L, uint32_t *tab, const int main_bits, const
 __device__ __forceinline__ uint32_t uni(const uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 // status: 0 = inflated to exactly out_size bytes; 1 = malformed / unsupported (the host decides)
-__global__ __launch_bounds__(64) void msnv_inflate_blocks(const uint8_t *__restrict__ comp, const InfBlock *__restrict__ blocks, const uint32_t n_blocks,
+__global__ __launch_bounds__(64, MSNV_INFLATE_WAVES) void msnv_inflate_blocks(const uint8_t *__restrict__ comp, const InfBlock *__restrict__ blocks, const uint32_t n_blocks,
                                                           uint8_t *__restrict__ out, uint32_t *__restrict__ status) {
     __shared__ InfLds L;
     const int lane = threadIdx.x;
@@ -234,12 +237,12 @@ __global__ __launch_bounds__(64) void msnv_inflate_blocks(const uint8_t *__restr
                     bb >>= 3; bc -= 3;
                 }
                 __syncthreads();
-                if (!ok || !build_table(L, L.cl, 7, 128, L.lens, 19, 2, lane)) { fail_ = true; break; }
+                if (!ok || !build_table(L, L.d, 7, 128, L.lens, 19, 2, lane)) { fail_ = true; break; }
                 // the code lengths themselves: a serial stream again (every lane decodes it, lane 0 stores)
                 int n = 0; uint32_t prev = 0;
                 while (n < hlit + hdist) {
                     refill(14);                                  // (the tail of the stream may hold fewer bits: checked through l > bc below)
-                    const uint32_t e = uni(L.cl[bb & 127u]);
+                    const uint32_t e = uni(L.d[bb & 127u]);
                     if (e & IF_BAD) { ok = false; break; }
                     const int l = (int)(e & 0xffu), sym = (int)(e >> 16);
                     if (l > bc) { ok = false; break; }
