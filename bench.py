@@ -67,7 +67,7 @@ def workload_params(a, rank=0):
     return kw, label
 
 
-TRAFFIC_PROFILES = ["r05_pmc.json", "r04_pmc.json", "r03fin_pmc.json", "r03_pmc.json", "r02d_pmc.json"]       # newest first; written by profiles/collect.sh + summarize.py
+TRAFFIC_PROFILES = ["r06_pmc.json", "r05_pmc.json", "r04_pmc.json", "r03fin_pmc.json", "r03_pmc.json", "r02d_pmc.json"]       # newest first; written by profiles/collect.sh + summarize.py
 
 
 def measured_traffic(samples, species, contig_len, mean_cov):
@@ -215,10 +215,34 @@ def cpu_baseline(sp_kwargs, n_cpu_samples):
                      % (n_cpu_samples, sp.n_samples, len(syn.names), n_bases, dt),
            "called_lines": pop.count("\n")}
     try:
+        out["all_cores"] = cpu_baseline_all_cores(orc, syn, samples, n_bases)
+    except Exception as e:                             # the extra must never cost the bench line
+        out["all_cores"] = {"error": repr(e)}
+    try:
         out["snpcall_alone"] = snpcall_alone(syn, samples[:32])
     except Exception as e:                             # the extra must never cost the bench line
         out["snpcall_alone"] = {"error": repr(e)}
     return out
+
+
+def cpu_baseline_all_cores(orc, syn, samples, n_bases_whole):
+    """the same restatement on ALL host cores, the way the reference itself uses several -- one `samtools mpileup -l
+    SPLIT | snpCall` per split, every split reading every BAM (/root/reference/metaSNV.py:196-215): the contigs are cut into one position range
+    per core, each range is one thread's orc.call with that range as its BED (the C restatement holds no global state; ctypes drops the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+    cores = os.cpu_count() or 1
+    total = sum(syn.lengths)
+    per = max(1, -(-total // cores))
+    beds = []
+    for tid, L in enumerate(syn.lengths):
+        for b in range(0, L, per):
+            beds.append((tid, b, min(L, b + per)))
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        res = list(ex.map(lambda bed: orc.call(syn.names, syn.lengths, syn.seqs, samples, bed=[bed])[3], beds))
+    dt = time.perf_counter() - t0
+    return {"value": sum(res) / dt / 1e9, "unit": "Gbases/s", "cores": cores, "kind": "port", "splits": len(beds), "seconds": dt,
+            "sample": "the same %d samples, %d position ranges (BED splits like metaSNV.py --n_splits), one thread each: %d pileup bases (whole run: %d)" % (len(samples), len(beds), sum(res), n_bases_whole)}
 
 
 def snpcall_alone(syn, samples, n_pos=100000):
@@ -375,9 +399,9 @@ def strong_run(a, rank, world, local, dist, brief=False):
     threads = a.host_threads or max(1, min(32, (os.cpu_count() or 8) // max(1, world)))
     # (the "decoder" of this benchmark is the synthetic generator: run ahead of the pack -- what feed_sharded does with a host decoder -- its
     # threads would sit in the pack stage's event brackets, which this line reports as pack_on_device; MSNV_FEED_OVERLAP=1 to see it overlapped)
-    os.environ.setdefault("MSNV_FEED_OVERLAP", "0")
+    feed_overlap = os.environ.get("MSNV_FEED_OVERLAP", "0") != "0"      # (the environment is read, never written: the choice is an argument of the run and is printed)
     t_all = time.perf_counter()
-    res = parallel.resident_project_run(ctx, None, None, [str(i) for i in range(sp.n_samples)], params, batch=threads, want_coverage=True,
+    res = parallel.resident_project_run(ctx, None, None, [str(i) for i in range(sp.n_samples)], params, batch=threads, want_coverage=True, feed_overlap=feed_overlap,
                                         make_dataset=lambda: core.Dataset(ctx, syn.names, syn.lengths, syn.seqs, params),
                                         read_records=lambda p: syn.sample_records(int(p)), run_passes=run_passes)
     t_all = time.perf_counter() - t_all
@@ -413,7 +437,7 @@ def strong_run(a, rank, world, local, dist, brief=False):
                      "kernel_ms_avg": float(allr[slow][2]), "algorithmic_bytes_per_launch": int(allr[slow][3]),
                      "algorithmic_definition": "SURVEY.md 8d: per pileup read 16 B header + 4 B per CIGAR op + 0.5 B/base + 1 B/base quality"},
         "kernel_ms": {"pileup_per_rank": [float(r[2]) for r in allr], "pipeline_total_per_rank": [float(r[14]) for r in allr], "coverage_per_rank": [float(r[15]) for r in allr]},
-        "exchange": {"backend": parallel.backend() or "none (one process)", "feed_s_per_rank": [float(r[7]) for r in allr],
+        "exchange": {"backend": parallel.backend() or "none (one process)", "feed_s_per_rank": [float(r[7]) for r in allr], "feed_overlap": feed_overlap,
                      "what": "generate 1/N of the samples, count first-round bases, partition by owner, all_to_all per round of %d samples x %d ranks, pack" % (threads, world),
                      "record_bytes_decoded_per_rank": [int(r[12]) for r in allr], "finalize_upload_s_per_rank": [float(r[8]) for r in allr]},
         "gather": {"to": "rank 0", "sites_total": n_sites, "cells_total": int(len(res["cells"])), "bytes_received_by_rank0": int(m["gather_bytes_received"]),
@@ -537,7 +561,7 @@ def main():
         """What bounds msnv_coverage_tiles, from the counter passes committed under profiles/ (profiles/cov_prof.sh: rocprofv3 --pmc in
         separate runs; they cannot be collected inside this process).  Issue-slot share = VALU wave-instructions x 4 cycles / (1024
         SIMDs x the kernel's cycles at 2.4 GHz)."""
-        for name in ("r03cov_pmc.json", "r02cov5_pmc.json"):
+        for name in TRAFFIC_PROFILES[:2] + ["r03cov_pmc.json", "r02cov5_pmc.json"]:      # (the bench command's own counter passes hold msnv_coverage_tiles since round 5)
             try:
                 c = json.load(open(os.path.join(ROOT, "profiles", name)))["counters"]
                 k = [v for kk, v in c.items() if "coverage_tiles" in kk][0]
@@ -677,6 +701,10 @@ def main():
                        "called_SNPs_lines_per_rank": called},
             "roofline": {"bound": "hbm", "kernel": "msnv_pileup_tiles_narrow32" if a.workload == "testdata" else "msnv_pileup_tiles_* (narrow32 + merged [+ wide] between one pair of HIP events)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         # the three figures that say what `frac` does not (filled below / here): the same SURVEY bytes over the WHOLE region from raw records
+                         # resident in HBM to the calls, that region's milliseconds, and the counters' HBM bytes of the dominant kernel over its time
+                         "frac_from_records": None, "total_ms_from_records": None,
+                         "frac_hbm_traffic": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and k_ms) else None,
                          "algorithmic_bytes_per_launch": alg, "kernel_ms_avg": k_ms,
                          "rank": slowest, "achieved_per_rank": per_rank_gbs,
                          "bytes_per_pileup_base": alg / max(1, bases),
@@ -687,7 +715,6 @@ def main():
                          # `achieved` / `frac` price the SURVEY 8d bytes (the reference's input: a byte of quality per base) against the kernel's time, as the
                          # bench contract defines them; what the kernel MOVES is less (one bit of quality per base): frac_hbm_traffic = measured HBM bytes
                          # of the committed counter passes / this run's kernel time / peak, null away from the profiled workload
-                         "frac_hbm_traffic": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and k_ms) else None,
                          "counters": pileup_counters(sp.n_samples, sp.n_species, sp.contig_len, sp.mean_cov, k_ms) if (world == 1 and a.workload == "testdata") else None},
             "positions_per_s": info["n_positions"] * world * a.steps / dt_max,
             "kernel_ms": {"pileup": k_ms, "pipeline_total": sum(ms_total) / len(ms_total)},
@@ -699,6 +726,9 @@ def main():
         }
         # what limits the dominant kernel comes from the counters, not from the roofline it is priced against: the path is integer counting (no
         # MFMA work), `achieved` / `peak` stay HBM GB/s as the contract defines them, `bound` says which unit the counters show saturated
+        if achieved > 6300.0:
+            line["roofline"]["note"] = ("SURVEY bytes per second, not HBM traffic: `achieved` prices the reference's input (1.70 B per pileup base, a byte of quality per base) over the "
+                                        "kernel's time and exceeds what HBM delivers (~6.3 TB/s); the bytes the kernel moves are `traffic` (frac_hbm_traffic)")
         cnt = line["roofline"]["counters"]
         if cnt and cnt.get("limited_by", "").startswith("vector"):
             line["roofline"]["bound"] = "valu"
@@ -725,6 +755,8 @@ def main():
                 "all_builds": from_records["builds"],
                 "records": int(pack["records"]), "pieces": int(pack["pieces"]), "samples_through_the_host_prepass": int(pack["prepass_samples"]),
                 "record_scans_through_the_careful_kernel": int(pack["scan_segments_redone"])}
+            line["roofline"]["frac_from_records"] = line["roofline_from_records"]["frac"]
+            line["roofline"]["total_ms_from_records"] = total_ms
         if overlapped:
             line["overlapped_passes"] = overlapped
         if cov_extra:

@@ -221,6 +221,15 @@ static int add_streams_device(msnv_dataset *ds, const uint8_t *const *records, c
     return rc;
 }
 
+// A call that appends its samples in SEVERAL add_streams_device calls (groups of files, batches of the device inflate, groups of synthetic
+// samples) and fails in a later one: the samples of the calls that went through are dropped with the rest (msnv.h: a failed add_* call adds
+// nothing), and since their rounds' tables stay behind in dp.rounds the dataset is poisoned like in add_streams_device itself.
+static int fail_multi_add(msnv_dataset *ds, size_t first, size_t rounds_at_entry, int rc) {
+    ds->samples.resize(first);
+    if (ds->dp.rounds.size() != rounds_at_entry) ds->poisoned = true;
+    return rc;
+}
+
 extern "C" int msnv_dataset_add_sample_records_device(msnv_dataset *ds, const void *const *dev_records, const uint64_t *n_bytes, int32_t n) {
     clear_error();
     if (!ds || n < 0 || (n && (!dev_records || !n_bytes))) return fail(MSNV_EINVAL, "msnv_dataset_add_sample_records_device: bad argument");
@@ -762,6 +771,7 @@ static int add_bams_device_pack(msnv_dataset *ds, const char *const *bam_paths, 
         // twin): the record streams are handed over where they lie in HBM
         // (resident form of bgzf_read_files_device: the batch's bytes exist in HBM only, its headers were read from the files' leading blocks)
         ResidentBatch rb;
+        const size_t first = ds->samples.size(), rounds_at_entry = ds->dp.rounds.size();
         auto consume = [&](int f0, int f1, const uint8_t *out, const std::vector<InflatedExt> &ext, bool dev_valid) -> int {
             std::vector<const uint8_t *> ptrs; std::vector<uint64_t> sizes;
             // (a batch the host decoder had to take -- no room for it in HBM -- is in host memory: it goes up from there)
@@ -785,9 +795,9 @@ static int add_bams_device_pack(msnv_dataset *ds, const char *const *bam_paths, 
         int rc;
         try { uint64_t cnt[4]; rc = bgzf_read_files_device(ds->ctx, bam_paths, n, nthreads, consume, cnt, &rb); }
         catch (const std::exception &e) { rc = fail(MSNV_ENOMEM, "device inflate: %s", e.what()); }
-        return rc;
+        return rc ? fail_multi_add(ds, first, rounds_at_entry, rc) : MSNV_OK;      // (a later batch failed: the earlier batches' samples go too)
     }
-    const size_t first = ds->samples.size();
+    const size_t first = ds->samples.size(), rounds_at_entry = ds->dp.rounds.size();
     const int group = std::max(nthreads, 16);
     for (int g0 = 0; g0 < n; g0 += group) {
         const int g1 = std::min(n, g0 + group);
@@ -818,7 +828,7 @@ static int add_bams_device_pack(msnv_dataset *ds, const char *const *bam_paths, 
             for (int i = g0; i < g1; ++i) { ptrs.push_back(bufs[(size_t)(i - g0)].data() + rec_off[(size_t)(i - g0)]); sizes.push_back(bufs[(size_t)(i - g0)].size() - rec_off[(size_t)(i - g0)]); }
             rc = add_streams_device(ds, ptrs.data(), sizes.data(), g1 - g0, false);
         }
-        if (rc) { ds->samples.resize(first); return rc; }
+        if (rc) return fail_multi_add(ds, first, rounds_at_entry, rc);
     }
     return MSNV_OK;
 }
@@ -1052,7 +1062,7 @@ extern "C" int msnv_dataset_add_synth_samples(msnv_dataset *ds, const msnv_synth
     const std::vector<std::string> contigs = synth_contigs(*p);
     if (pack_on_device(ds)) {
         // record streams are made by the host threads, group by group, and packed in HBM
-        const size_t base0 = ds->samples.size();
+        const size_t base0 = ds->samples.size(), rounds_at_entry = ds->dp.rounds.size();
         const int group = std::max(nthreads, 1);
         for (int g0 = 0; g0 < count; g0 += group) {
             const int g1 = std::min<int>(count, g0 + group);
@@ -1069,11 +1079,11 @@ extern "C" int msnv_dataset_add_synth_samples(msnv_dataset *ds, const msnv_synth
             std::vector<std::thread> th;
             for (int t = 0; t < std::min(nthreads, g1 - g0); ++t) th.emplace_back(w);
             for (auto &t : th) t.join();
-            if (bad.load()) { ds->samples.resize(base0); return fail(MSNV_ENOMEM, "making a synthetic sample failed"); }
+            if (bad.load()) return fail_multi_add(ds, base0, rounds_at_entry, fail(MSNV_ENOMEM, "making a synthetic sample failed"));
             host_timer_add(HT_SYNTH_WALL, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_synth).count());
             std::vector<const uint8_t *> ptrs; std::vector<uint64_t> sizes;
             for (auto &r : recs) { ptrs.push_back(r.data()); sizes.push_back(r.size()); }
-            if (int rc = add_streams_device(ds, ptrs.data(), sizes.data(), g1 - g0, false)) { ds->samples.resize(base0); return rc; }
+            if (int rc = add_streams_device(ds, ptrs.data(), sizes.data(), g1 - g0, false)) return fail_multi_add(ds, base0, rounds_at_entry, rc);
         }
         return MSNV_OK;
     }

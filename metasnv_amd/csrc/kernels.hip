@@ -854,9 +854,6 @@ __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a, NarrowL
         }
     };
     __syncthreads();
-#ifdef MSNV_ABL
-    if constexpr (fused) { if (MSNV_ABL == 1) { if (tid == 0) a.tile_stage[g_sidx].count = 0u; return; } }
-#endif
     if (nch) issue_loads(0u);
     bool prev_last = false;                                          // the bins start out zero
 
@@ -878,30 +875,18 @@ __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a, NarrowL
         }
 #pragma unroll
         for (int i = 0; i < N32_ROUNDS; ++i)
-#ifdef MSNV_ABL
-            if (!(fused && MSNV_ABL == 2))
-#endif
             if (__any(vh[i] > 0)) narrow_classify32(L, lowq_bits(ql[i], qsh[i]), sq[i], P0[i], vh[i]);
-#ifdef MSNV_ABL
-        if (fused && MSNV_ABL == 2) { for (int i = 0; i < N32_ROUNDS; ++i) if (vh[i] > 0 && (sq[i].x ^ sq[i].y ^ sq[i].z ^ sq[i].w ^ ql[i].x ^ ql[i].y) == 0x12345u) L.al[P0[i]] = 1u; }
-#endif
 
         if (tid < N_HCAP) put_hdr((c + 1u) & 1u, hreg);               // headers of chunk c + 1 (zeros behind the last chunk)
         hreg = load_hdr(c + 2u);
         __syncthreads();                                            // (B): this chunk is in the bins; the next chunk's headers are visible
         if (c + 1u < nch) issue_loads(c + 1u);                       // in flight under the per-sample pass
-#ifdef MSNV_ABL
-        if (!(fused && MSNV_ABL == 4))
-#endif
         if (last_chunk) narrow_pass<NarrowLds, 0, MERGED, fused, DA>(L, a, tc, dirty, t0, tid, lane, wave, cd.sample, cd.pair, cd.pad, tot_mode_of(w));
         prev_last = last_chunk;
     }
     __syncthreads();
     if (MERGED && fused) {
         const uint32_t sidx = g_sidx;
-#ifdef MSNV_ABL
-        if (MSNV_ABL == 3 || MSNV_ABL == 4) { if (tid == 0) a.tile_stage[sidx].count = 0u; return; }
-#endif
         const FusedGateArgs fa{a.tile_stage + sidx, a.ref_lc, a.counters, g_vb, g_ve, a.min_snvs, a.min_cov, a.min_frac, w.pair_hi - w.pair_lo == 1u ? 1u : 0u};
         if (fused_tile_gate(L, fa, g_lcb, nch != 0u, tid)) {
             const FusedSpillArgs sa{a.part + ((uint64_t)w.part_hi << 32 | (w.part_lo & ~15u)), a.tot, a.unc_bits, a.slot_dirty + w.slot, a.stage_ovf, a.counters, sidx, (w.part_lo & 15u) | a.min_snvs << 4};
@@ -2459,13 +2444,17 @@ static std::mutex g_cache_mu;
 static std::vector<CacheBlock> g_cache_free;
 static std::unordered_map<void *, CacheBlock> g_cache_live;
 static uint64_t g_cache_free_bytes = 0;
-static uint64_t cache_cap_bytes() {
-    static const uint64_t cap = [] {
-        if (const char *e = getenv("MSNV_DEV_CACHE_MB")) return (uint64_t)std::max<long long>(0, atoll(e)) << 20;
-        size_t fr = 0, tot = 0;
-        if (hipMemGetInfo(&fr, &tot) != hipSuccess) return (uint64_t)1 << 30;
-        return std::min<uint64_t>((uint64_t)tot / 16, (uint64_t)16 << 30);
-    }();
+static uint64_t cache_cap_bytes(int dev) {                          // per device: the default is a share of THAT device's memory (the caller has made it current)
+    static const long long env_mb = [] { const char *e = getenv("MSNV_DEV_CACHE_MB"); return e ? std::max<long long>(0, atoll(e)) : -1ll; }();
+    if (env_mb >= 0) return (uint64_t)env_mb << 20;
+    static std::mutex mu;
+    static std::unordered_map<int, uint64_t> caps;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = caps.find(dev);
+    if (it != caps.end()) return it->second;
+    size_t fr = 0, tot = 0;
+    const uint64_t cap = hipMemGetInfo(&fr, &tot) != hipSuccess ? (uint64_t)1 << 30 : std::min<uint64_t>((uint64_t)tot / 16, (uint64_t)16 << 30);
+    caps[dev] = cap;
     return cap;
 }
 static uint64_t cache_round(uint64_t bytes) {
@@ -2505,11 +2494,10 @@ int dev_alloc(void **p, uint64_t bytes, uint64_t *acct) {
         if (getenv("MSNV_GUARD_LOG")) fprintf(stderr, "[guard] %p .. %p (%llu bytes; mapping %p + %zu)\n", *p, static_cast<char *>(*p) + bytes, (unsigned long long)bytes, g.va, g.mapped);
         std::lock_guard<std::mutex> lk(g_guard_mu);
         g_guarded[*p] = g;
-    } else if (cache_cap_bytes() == 0) {
-        HIP_TRY(hipMalloc(p, bytes));
     } else {
         int dev = 0;
         HIP_TRY(hipGetDevice(&dev));
+        if (cache_cap_bytes(dev) == 0) { HIP_TRY(hipMalloc(p, bytes)); if (acct) *acct += bytes; return MSNV_OK; }
         const uint64_t want = cache_round(bytes);
         {
             std::lock_guard<std::mutex> lk(g_cache_mu);
@@ -2562,12 +2550,18 @@ void dev_free(void *p) {
         if (it != g_cache_live.end()) { b = it->second; g_cache_live.erase(it); }
     }
     if (!b.p) { (void)hipFree(p); return; }                         // (not one of ours: allocated while the cache was off)
-    (void)hipDeviceSynchronize();                                   // no kernel of the old owner is running when the next owner gets the block
+    // no kernel of the old owner is running when the next owner gets the block: the BLOCK's device is the one to wait for (a dataset or a
+    // context may be destroyed while another device is current)
+    int cur = b.device;
+    (void)hipGetDevice(&cur);
+    if (cur != b.device) (void)hipSetDevice(b.device);
+    (void)hipDeviceSynchronize();
+    const uint64_t cap = cache_cap_bytes(b.device);
+    if (cur != b.device) (void)hipSetDevice(cur);
     std::vector<CacheBlock> evict;
     {
         std::lock_guard<std::mutex> lk(g_cache_mu);
         g_cache_free.push_back(b); g_cache_free_bytes += b.bytes;
-        const uint64_t cap = cache_cap_bytes();
         while (g_cache_free_bytes > cap && !g_cache_free.empty()) {  // over the cap: the largest blocks go first
             size_t big = 0;
             for (size_t i = 1; i < g_cache_free.size(); ++i) if (g_cache_free[i].bytes > g_cache_free[big].bytes) big = i;

@@ -332,7 +332,7 @@ def _stageable(paths):
         return False
 
 
-def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=None, metrics=None, plan=None, pack_threads=0, ctx_when_ready=None):
+def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=None, metrics=None, plan=None, pack_threads=0, ctx_when_ready=None, feed_overlap=None):
     """Decode-sharded input of one dataset per rank: every BAM is read and inflated by ONE rank, its records are dealt by
     contig owner (core.partition_records) and exchanged, and every rank appends all samples in all_samples order holding
     only its contigs' records.  Returns stats[n_samples][6] (qaCompute's per-BAM statistics, counted by the decoder and
@@ -690,7 +690,8 @@ def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=Non
             except (OSError, AttributeError):
                 pass
     host_decoder = read_records is not None or os.environ.get("MSNV_INFLATE", "device")[:1] == "h"
-    overlap = host_decoder and os.environ.get("MSNV_FEED_OVERLAP", "1") != "0" and len(rounds) - k > 1
+    want_overlap = feed_overlap if feed_overlap is not None else os.environ.get("MSNV_FEED_OVERLAP", "1") != "0"      # (an argument of the run; the environment is the default)
+    overlap = host_decoder and want_overlap and len(rounds) - k > 1
     if overlap:
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=1) as ahead:
@@ -832,7 +833,7 @@ def gather_coverage_root(acc, stats=None, rows=None, shape=None):
 
 
 def resident_project_run(ctx, first_bam, fasta_path, bam_paths, params, batch=1, want_coverage=True, ann_path=None,
-                         after_coverage=None, species_weight=None, make_dataset=None, read_records=None, run_passes=None, inflate_after_context=False):
+                         after_coverage=None, species_weight=None, make_dataset=None, read_records=None, run_passes=None, inflate_after_context=False, feed_overlap=None):
     """ONE resident dataset per rank for a whole metaSNV.py run, whatever the number of ranks and splits (the reference forks
     one qaCompute process per BAM, metaSNV.py:55-78, and one `mpileup | snpCall` process per split, :196-221, each of which
     inflates every BAM again): contigs are sharded over the ranks by species (LPT on length x coverage), the BAMs are dealt to
@@ -868,7 +869,7 @@ def resident_project_run(ctx, first_bam, fasta_path, bam_paths, params, batch=1,
     try:
         t0 = time.perf_counter()
         res["stats"] = feed_sharded(ds, bam_paths, owner, params.cov_min_mapq, batch, read_records=read_records, metrics=metrics, plan=(names, lengths),
-                                    ctx_when_ready=ctx if (lazy_ctx and inflate_after_context) else None)
+                                    ctx_when_ready=ctx if (lazy_ctx and inflate_after_context) else None, feed_overlap=feed_overlap)
         owner = metrics.pop("owner", owner)
         res["owner"] = owner
         metrics["contigs"] = int(sum(1 for o in owner if o == _rank))

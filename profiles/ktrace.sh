@@ -4,7 +4,7 @@ TAG=$1; shift
 export TMPDIR=/tmp
 OUT=gpurun_out/kt_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
-rocprofv3 --kernel-trace --stats -d "$OUT" -o t --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-annotation --no-overlap-extra "$@" > "$OUT/log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$OUT" -o t --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-annotation --no-overlap-extra --no-strong-extra "$@" > "$OUT/log" 2>&1
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
 rows = collections.defaultdict(list)

@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 for V in "$@"; do
   OUT=gpurun_out/pp_$V; mkdir -p $OUT
   export MSNV_PERTURB=$V
-  timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_THREAD_CYCLES_VALU --kernel-include-regex "narrow32" -d $OUT -o pmc --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-annotation --no-overlap-extra > $OUT.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_THREAD_CYCLES_VALU --kernel-include-regex "narrow32" -d $OUT -o pmc --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-annotation --no-overlap-extra --no-strong-extra > $OUT.log 2>&1
   python3 - $OUT $V <<'PY'
 import csv, glob, sys, collections
 acc = collections.defaultdict(list)

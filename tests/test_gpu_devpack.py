@@ -451,3 +451,39 @@ def test_a_call_that_fails_after_a_round_leaves_the_dataset_unusable():
             ds.close()
     finally:
         ctx.close()
+
+
+def test_a_bam_group_that_fails_behind_a_packed_group_poisons_the_dataset(tmp_path):
+    """msnv_dataset_add_sample_bams with the host inflate packs the files group by group (max(threads, 16) files a group: one
+    add_streams_device call each).  A corrupt file in the SECOND group: the first group's samples are dropped with the rest -- a failed
+    add_* call adds nothing -- and, their rounds' tables being left behind, the dataset refuses everything further (the
+    poison flag was set inside one add_streams_device call only, and finalize would have indexed with the stale rounds)."""
+    syn, samples = synth_case(n_species=1, contig_len=4000, n_samples=18, mean_cov=6.0, seed=21)
+    paths = []
+    for i, smp in enumerate(samples):
+        p = str(tmp_path / ("s%02d.bam" % i))
+        core.write_bam(p, syn.names, syn.lengths, smp)
+        paths.append(p)
+    fa = str(tmp_path / "ref.fa")
+    syn.write_fasta(fa)
+    bad = samples[17].copy()
+    bad[16:18] = 0xff                                               # n_cigar_op of the first record: cannot fit its block_size
+    core.write_bam(paths[17], syn.names, syn.lengths, bad)
+    ctx = core.Context(0)
+    try:
+        with _env(MSNV_PACK="device", MSNV_INFLATE="host"):
+            ds = core.Dataset.from_files(ctx, paths[0], fa)
+            with pytest.raises(core._lib.MsnvError) as e:
+                ds.add_sample_bams(paths, 4)                        # groups of 16: files 0-15 pack, the group of files 16-17 fails
+            assert e.value.code == core._lib.EFORMAT
+            for call in (lambda: ds.add_sample_bams(paths[:2], 2), lambda: ds.finalize()):
+                with pytest.raises(core._lib.MsnvError) as e:
+                    call()
+                assert e.value.code == core._lib.EINVAL and "cannot be used further" in str(e.value)
+            ds.close()
+            ds = core.Dataset.from_files(ctx, paths[0], fa)         # the same files without the corrupt one: a usable dataset
+            ds.add_sample_bams(paths[:17], 4)
+            assert ds.finalize()["n_samples"] == 17
+            ds.close()
+    finally:
+        ctx.close()
