@@ -131,7 +131,7 @@ extern "C" int msnv_dataset_attach_ctx(msnv_dataset *ds, msnv_ctx *ctx) {
 
 extern "C" void msnv_dataset_destroy(msnv_dataset *ds) {
     if (!ds) return;
-    if (ds->ctx && (ds->dp.ready || !ds->dp.round_bufs.empty())) { (void)dev_set_device(ds->ctx->device); devpack_release(ds->dp); }
+    if (ds->ctx && (ds->dp.ready || !ds->dp.round_bufs.empty())) { (void)dev_set_device(ds->ctx->device); devpack_release(*ds); }
     if (ds->dev) { dev_free_all(*ds->dev); delete ds->dev; }
     delete ds;
 }

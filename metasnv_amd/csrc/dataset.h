@@ -15,6 +15,7 @@
 
 #include <cstdint>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "msnv_internal.h"
@@ -154,6 +155,13 @@ struct DevPackTables {
     void     *cov_job = nullptr, *cov_tmp = nullptr, *cov_runs = nullptr; bool cov_launched = false;   // finalize: the coverage index's kernels launched ahead of their results (devfin_coverage_launch)
     void     *fin_tile_base = nullptr;                     // finalize on the device: the contigs' first tiles (devfin_headers)
     void     *fin_list = nullptr, *fin_cbase = nullptr;   // finalize on the device: the narrow pairs' list and their chunk counts / scan, between devfin_chunk_counts and devfin_chunk_fill
+    std::vector<void *> fin_keep;                          // small device tables of finalize's kernels, which are queued, not waited for: freed with the pack's tables (devpack_finish)
+    uint64_t  fin_chunk_cap = 0; uint32_t fin_chunk_base = 0; bool fin_chunks_async = false;   // the narrow chunks cut without a wait (devfin_chunks_launch): room for them in d.chunks, where they start
+    // pinned words of THIS dataset (taken from its context's pool, given back by devpack_release): first half = what a round's last kernels
+    // leave for the host (DpAcc per sample: devpack_sync_pending), second half = finalize's small results (coverage index, chunk count)
+    void     *pin = nullptr; uint64_t pin_cap = 0;
+    bool      pad_in_emit = false;    // the rounds' emit kernels wrote the alignment nibbles behind the pieces (reference inside the tile, N beyond): msnv_fill_padding has nothing to do
+    std::vector<uint8_t> h_contigs;                        // the contig table as it went up (the copy is not waited for)
     // cumulative device-pack accounting (msnv_host_timers: pack_device_wall_s; msnv_devpack_stats)
     double    ms_scan = 0, ms_measure = 0, ms_depth = 0, ms_emit = 0, ms_sort = 0, wall_upload_s = 0, wall_download_s = 0, wall_prepass_s = 0;
     uint64_t  raw_bytes = 0, n_records = 0, n_pieces = 0, n_prepass_samples = 0, n_scan_redone = 0, n_deep_runs_split = 0, n_dense_samples = 0;
@@ -179,7 +187,9 @@ struct msnv_ctx {
     // (pinning memory costs ~0.25 s per GB: paid once, not per batch of BAMs)
     void *pin_in = nullptr, *pin_out = nullptr, *dev_in = nullptr, *dev_out = nullptr;
     uint64_t pin_in_cap = 0, pin_out_cap = 0, dev_in_cap = 0, dev_out_cap = 0;
-    void *pin_small = nullptr; uint64_t pin_small_cap = 0;   // pinned words for small results a kernel leaves behind an asynchronous copy (devpack.hip)
+    // pinned blocks for the small results kernels leave behind asynchronous copies (devpack.hip): a dataset takes one for its lifetime and
+    // gives it back (two datasets of one context never share a landing area); pinning costs ~0.1 ms, so the blocks are kept
+    std::vector<std::pair<void *, uint64_t>> pin_pool;
 };
 
 struct msnv_dataset {

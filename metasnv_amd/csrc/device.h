@@ -172,11 +172,14 @@ int  dev_set_device(int device);
 uint32_t dev_resident_workgroups(uint32_t per_cu);   // compute units of the current device x per_cu (256 CUs when the query fails)
 int  dev_alloc(void **p, uint64_t bytes, uint64_t *acct);
 void dev_free(void *p);
+void dev_free_batch(const std::vector<void *> &ptrs);
+int dev_memset_async(void *dst, int v, uint64_t bytes, void *stream);
 void dev_cache_trim();                               // cached free blocks back to the runtime (kernels.hip: dev_alloc)
 int  dev_upload(void *dst, const void *src, uint64_t bytes);
 int  dev_download(void *dst, const void *src, uint64_t bytes);
 int  dev_copy_bytes(void *dst_device, const void *src, uint64_t bytes, bool src_on_device, void *stream);      // device <- device or host, on the stream, waited for
 int  dev_memset(void *dst, int v, uint64_t bytes);
+int  dev_stream_wait(void *stream);
 int  dev_stream_create(void **stream);
 void dev_stream_destroy(void *stream);
 

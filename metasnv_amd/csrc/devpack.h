@@ -25,7 +25,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
 // the host (pack.cpp: relayout_dense, split_deep_runs' relocation).
 int devpack_sample_to_host(SampleCols &sc);
 int devpack_download_pieces(msnv_dataset &ds);
-void devpack_release(DevPackTables &t);
+void devpack_release(msnv_dataset &ds);                       // the pack's tables, round buffers, work buffers; the pinned block back to the context
 // finalize: copies of the rounds' columns into the dataset's, and the alignment padding behind every piece set to the reference
 int devpack_copy_columns(const SampleCols &sc, uint8_t *dst_seq, uint8_t *dst_qual_bits, void *stream);
 int devpack_place_columns(msnv_dataset &ds, DeviceCols &d, const std::vector<uint64_t> &sbase);      // fast finalize, piece layout: adopt one round's buffer / copy round by round
@@ -47,7 +47,11 @@ int records_deal_device(msnv_ctx *ctx, const uint8_t *const *streams, const uint
 int devpack_copy_blocks(const SampleCols &sc, uint32_t *dst, void *stream);
 int devfin_headers(msnv_dataset &ds, DeviceCols &d, const std::vector<uint64_t> &rbase);
 int devfin_chunk_counts(msnv_dataset &ds, DeviceCols &d, const std::vector<uint32_t> &narrow_pairs, std::vector<uint32_t> &cbase);   // cbase: first chunk of every listed pair, total behind them
-int devfin_chunk_fill(msnv_dataset &ds, DeviceCols &d, size_t n_pairs_listed);                       // d.chunks[0 .. total), d.hdr4
+int devfin_chunk_fill(msnv_dataset &ds, DeviceCols &d, size_t n_pairs_listed, uint32_t base);        // d.chunks[base .. base + total), d.hdr4
+// the same without a wait (devpack.hip): item_first[wi] = index of narrow work item wi's first pair in the list (n_work_narrow + 1 entries); the chunks
+// go behind the `base` chunks the host wrote, `cap` of them at most; devfin_chunks_result (behind a wait for the stream) says how many there were
+int devfin_chunks_launch(msnv_dataset &ds, DeviceCols &d, const std::vector<uint32_t> &narrow_pairs, const std::vector<uint32_t> &item_first, uint32_t base, uint64_t cap);
+void devfin_chunks_result(const msnv_dataset &ds, uint64_t *n_chunks, bool *overflow);
 int devfin_work_first(msnv_dataset &ds, DeviceCols &d, uint32_t n_items);                            // WorkItem::first of the narrow and merged items, from d.chunks
 int devfin_merged_headers(msnv_dataset &ds, DeviceCols &d, const std::vector<DevMergedSrc> &list);
 int devfin_coverage_launch(msnv_dataset &ds, DeviceCols &d);   // needs ds.tile_base / n_tiles; the kernels only (their results: devfin_coverage)

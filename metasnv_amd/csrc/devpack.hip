@@ -1013,9 +1013,13 @@ struct GlbSrc {
 };
 // One lane's 32 bases of a piece: nibbles (low first) in o0 / o1, "quality below -Q" flags in bits, mismatches against the reference in mm
 // when the piece is one of the sampled ones.  j0 = 32 * sub; st / have as in the caller.
+// pad_in_tile: how many of the (up to three) alignment nibbles behind the piece's last base still lie in the piece's tile: those read as the
+// reference the pileup kernel compares them with (N where the FASTA has nothing), the ones beyond the tile as N -- what finalize's
+// msnv_fill_padding wrote in a pass of its own over every piece (0.25 ms on the benchmark shape) until round 6.
 template <class Src>
 __device__ __forceinline__ void piece_lane(const Src &src, unsigned long long seq_o, unsigned long long qual_o, uint32_t q0_piece, uint32_t j0, uint32_t have, unsigned long long ref_nib,
-                                           uint32_t ref_left, const uint32_t *pref4, const DpParams &P, uint32_t cut_marks, bool sample_this, uint64_t &o0, uint64_t &o1, uint32_t &bits, uint32_t &mm) {
+                                           uint32_t ref_left, const uint32_t *pref4, const DpParams &P, uint32_t cut_marks, bool sample_this, uint32_t pad_in_tile,
+                                           uint64_t &o0, uint64_t &o1, uint32_t &bits, uint32_t &mm) {
     const bool pad_low = P.c_eff > 0 || P.all_low;                                          // padding: base N, quality byte 0 (pack.cpp: pack_sample, pack_lowq)
     o0 = ~0ull; o1 = ~0ull; bits = pad_low ? 0xffffffffu : 0u; mm = 0;
     if (!have) return;
@@ -1030,7 +1034,8 @@ __device__ __forceinline__ void piece_lane(const Src &src, unsigned long long se
     if (have < 16u) { o0 |= ~0ull << (4u * have); o1 = ~0ull; } else if (have < 32u) o1 |= ~0ull << (4u * (have - 16u));
     const uint32_t left = ref_left > j0 ? ref_left - j0 : 0u;                               // FASTA characters from the lane's first position
     const uint64_t z0 = (o0 - 0x1111111111111111ull) & ~o0 & 0x8888888888888888ull, z1 = (o1 - 0x1111111111111111ull) & ~o1 & 0x8888888888888888ull;
-    if ((z0 | z1) || sample_this) {
+    const uint32_t n_pad = (have & 3u) ? (4u - (have & 3u) < pad_in_tile ? 4u - (have & 3u) : pad_in_tile) : 0u;      // (have & 3: this lane holds the piece's last base)
+    if ((z0 | z1) || sample_this || n_pad) {
         uint64_t r0 = ~0ull, r1 = ~0ull;                                                    // reference codes of the lane's positions (N where the FASTA has nothing)
         if (left) {
             const unsigned long long nb = ref_nib + j0;
@@ -1055,6 +1060,10 @@ __device__ __forceinline__ void piece_lane(const Src &src, unsigned long long se
             if (cmp < 16u) { x0 &= (1ull << (4u * cmp)) - 1ull; x1 = 0ull; } else if (cmp < 32u) x1 &= (1ull << (4u * (cmp - 16u))) - 1ull;
             mm = (uint32_t)(__builtin_popcountll(x0) + __builtin_popcountll(x1));
         }
+        if (n_pad) {                                                                        // nibbles have .. have + n_pad - 1 (all in one of the two words: have + n_pad <= a multiple of 4)
+            const uint64_t m = ((1ull << (4u * n_pad)) - 1ull) << (4u * (have & 15u));
+            if (have < 16u) o0 = (o0 & ~m) | (r0 & m); else o1 = (o1 & ~m) | (r1 & m);
+        }
     }
     uint32_t low = 0;
     if (P.all_low) low = 0xffffffffu;
@@ -1075,6 +1084,8 @@ struct EmitArgs {
     const RecCnt *r_cnt, *blk_pre; const unsigned long long *samp_sbase0, *rg; const uint2 *grp_pre; uint32_t in_order;
     ReadHdr *hdr; int32_t *ptid, *pend; uint16_t *pdepth; int32_t *cov_tid, *cov_beg, *cov_end; uint32_t noseq_counts;
     const uint32_t *pref4; DpParams P; const DpSampleDst *dst; DpAcc *acc;
+    uint32_t force_slow;                                           // MSNV_EMIT=slow (tests): every block takes msnv_emit_block_slow
+    uint32_t *slow;                                                // [0] number of listed blocks, [1 ..] the blocks msnv_emit_block left to msnv_emit_block_slow
 };
 // One record by its four lanes (sub = 0 .. 3): every lane reads the header and walks the CIGAR (LDS: cheap), lane 0 writes the intervals
 // and the piece headers, and lane `sub` moves bases 32 sub .. 32 sub + 31 of every piece (a piece holds at most SEG_MAX = 128 bases).
@@ -1185,7 +1196,8 @@ __device__ __forceinline__ void emit_record(const EmitArgs &A, const Src &src, c
                 const uint32_t have = n > j0 ? (n - j0 < 32u ? n - j0 : 32u) : 0u;                     // ... of which real bases
                 const bool sample_this = ref_nib != ~0ull && ((w - (uint32_t)d.pbase0) & 15u) == 0u;   // one piece in 16: how noisy are these reads?
                 uint64_t o0, o1; uint32_t bits, mm;
-                piece_lane(src, seq_o, qual_o, noseq ? 0xffffffffu : q + off, j0, have, ref_nib, ref_left, A.pref4, A.P, d.cut_marks, sample_this && have, o0, o1, bits, mm);      // (no SEQ: the bases are N of quality 0)
+                piece_lane(src, seq_o, qual_o, noseq ? 0xffffffffu : q + off, j0, have, ref_nib, ref_left, A.pref4, A.P, d.cut_marks, sample_this && have, to_tile - n < 3u ? to_tile - n : 3u,
+                           o0, o1, bits, mm);      // (no SEQ: the bases are N of quality 0)
                 const uint32_t prev_last = Out::kLds ? 0u : __shfl_up(bits >> 28, 1);           // the last four flags of lane sub - 1 of the same piece (sub > 0, that lane is full)
                 out.put(d, so, sub, sb, st, o0, o1, bits, prev_last);
                 // mismatch sample: sum over the 4 lanes of a piece, one atomic per sampled piece
@@ -1207,21 +1219,109 @@ __device__ __forceinline__ void emit_record(const EmitArgs &A, const Src &src, c
 struct LdsSrcK : LdsSrc { static constexpr bool kGlobal = false; __device__ const uint8_t *base() const { return nullptr; } };
 struct GlbSrcK : GlbSrc { static constexpr bool kGlobal = true; __device__ const uint8_t *base() const { return p; } };
 
-constexpr uint32_t EO_BYTES = 8192;                               // bytes of the seq column a block's image holds (its flags: a quarter of that)
+constexpr uint32_t EO_BYTES = 6144;                               // bytes of the seq column a block's image holds (its flags: a quarter of that); with the window and the descriptors 31.4 KB: five workgroups per CU
+// Round 6: the block's work in two phases.  A: ONE lane per record (the block's first wavefront) reads the header and walks the CIGAR in LDS,
+// writes qaCompute's intervals and the piece headers to their places and leaves a 32-byte DESCRIPTOR per piece in LDS -- a record's first piece
+// in the record's slot, every further one (an indel, a clip behind aligned bases, a tile boundary: one read in sixteen) in a slot behind the
+// 64.  B: the whole workgroup moves the pieces, four lanes each, slot after slot -- 64 pieces a step, so the handful of further pieces cost one
+// more step of ONE wavefront, where round 5's form (every record's four lanes walking its CIGAR with the piece body inside the loop) made
+// three wavefronts in four run the body twice for one lane's sake (a quarter of the kernel's vector instructions) and walked every CIGAR
+// four times.  Blocks that do not fit this form -- records longer than the window, two samples in one block, a CIGAR in the CG field, more
+// further pieces than slots -- are listed and taken by msnv_emit_block_slow behind this kernel.
+struct PieceDesc { uint32_t seq_o, qual_o, q0, so, ref_lo, ref_hi, ref_left, nf; };     // window offsets of the record's SEQ / QUAL, first base of the piece in the read (~0: no SEQ), byte of the seq
+                                                                                       // column, reference nibble index (64 bit) + FASTA characters from there, n | sampled << 8 | padding nibbles inside the tile << 9
+constexpr uint32_t EQ_CAP = 32;                                   // further pieces a block of the quick form holds
+__device__ __forceinline__ void emit_walk(const EmitArgs &A, const LdsSrcK &src, unsigned long long rec_o, const RecCnt me, uint8_t f, uint16_t depth, const DpSampleDst &d, unsigned long long sbase0,
+                                          PieceDesc *first_slot, PieceDesc *more_slots) {
+    PieceDesc none{}; none.nf = 0u;
+    *first_slot = none;
+    if (!(f & (RF_PILE | RF_COV))) return;
+    const int32_t tid = (int32_t)src.ld32(rec_o + 4), pos = (int32_t)src.ld32(rec_o + 8);
+    const uint32_t w3 = src.ld32(rec_o + 12), fn = src.ld32(rec_o + 16);
+    const int32_t l_seq = (int32_t)src.ld32(rec_o + 20);
+    const uint32_t n_cigar = fn & 0xffffu, l_name = w3 & 0xffu, mapq = (w3 >> 8) & 0xffu;
+    const unsigned long long cig_o = rec_o + 36 + l_name;
+    const unsigned long long seq_o = cig_o + 4ull * n_cigar, qual_o = seq_o + ((unsigned long long)(uint32_t)l_seq + 1) / 2;
+    const DpContig c = A.ctg[tid];
+    uint2 pf = make_uint2(0u, 0u), pe = make_uint2(0u, 0u);
+    if ((f & RF_PILE) && !A.in_order) {
+        const uint32_t gi = (uint32_t)A.rg[me.pile] - 1u;
+        pf = A.grp_pre[gi]; pe = A.grp_pre[gi + 1u];
+    }
+    const bool noseq = l_seq == 0;
+    const bool cov = (f & RF_COV) != 0, pile = (f & RF_PILE) && !(noseq && !A.noseq_counts);
+    if (!cov && !pile) return;
+    uint32_t w = me.npiece;                                                                   // file order
+    uint32_t d_own = w, d_next = w;                                                           // tile order: next header slot in the read's first tile / the tile behind
+    uint32_t ftile = 0; bool have_ftile = false;
+    if (!A.in_order) {
+        d_own = me.npiece - (me.spill - pf.y);
+        d_next = pe.x - pe.y + me.spill;
+    }
+    uint32_t so = (uint32_t)(me.seqb - sbase0);
+    long long rp = pos; uint32_t q = 0;                                                       // (the tile arithmetic below is msnv_measure_reads' to the letter: the two must cut the same pieces)
+    const long long L = c.len;
+    long long pp = (long long)pos + 1;
+    uint32_t wiv = me.niv, k0 = 0, n_out = 0;
+    if (cov && n_cigar > 0) { const uint32_t t = src.ld32(cig_o) & 15u; if (t == C_S || t == C_H) k0 = 1; }
+    for (uint32_t k = 0; k < n_cigar; ++k) {
+        const uint32_t cg = src.ld32(cig_o + 4ull * k), t = cg & 15u, l = cg >> 4;
+        if (cov && k >= k0) {                                                                 // qaCompute.cpp:530-552
+            if (t == C_M) {
+                if (pp >= L) { if (L >= 1) { A.cov_tid[wiv] = tid; A.cov_beg[wiv] = (int32_t)L; A.cov_end[wiv] = (int32_t)(L - 1); ++wiv; } }
+                else { A.cov_tid[wiv] = tid; A.cov_beg[wiv] = (int32_t)pp; A.cov_end[wiv] = (int32_t)(pp + l); ++wiv; }
+            }
+            pp += l;
+        }
+        if (cg_match(t)) {
+            if (pile) for (uint32_t off = 0, n = 0; off < l; off += n) {
+                const long long gl = rp + off;
+                const uint32_t g = (uint32_t)gl;
+                const uint32_t to_tile = TILE - (uint32_t)(gl % TILE);
+                n = SEG_MAX < l - off ? SEG_MAX : l - off;
+                n = n < to_tile ? n : to_tile;
+                const uint32_t tl = (uint32_t)(gl / TILE);
+                if (!have_ftile) { ftile = tl; have_ftile = true; }
+                const uint32_t dst = A.in_order ? w : (tl == ftile ? d_own++ : d_next++);
+                ReadHdr h;
+                h.gpos = g; h.seqoff = so; h.cig = n; h.meta = META_PILEUP_OK | mapq << 16;
+                A.hdr[dst] = h; A.ptid[dst] = tid; A.pend[dst] = (int32_t)(g + n); A.pdepth[dst] = depth;
+                PieceDesc D;
+                D.seq_o = (uint32_t)seq_o; D.qual_o = (uint32_t)qual_o; D.q0 = noseq ? 0xffffffffu : q + off; D.so = so;
+                unsigned long long ref_nib; uint32_t ref_left;
+                const long long left = c.seq_len - gl;
+                if (c.seq_len >= 0 && gl >= 0 && left > 0) { ref_nib = c.pref_off + (unsigned long long)gl; ref_left = (uint32_t)(left < 0xffffffffll ? left : 0xffffffffll); }
+                else { ref_nib = c.seq_len >= 0 ? ~1ull : ~0ull; ref_left = 0; }              // ~1: a FASTA record exists but holds nothing here (sampled, nothing to compare)
+                D.ref_lo = (uint32_t)ref_nib; D.ref_hi = (uint32_t)(ref_nib >> 32); D.ref_left = ref_left;
+                const bool sample_this = ref_nib != ~0ull && ((w - (uint32_t)d.pbase0) & 15u) == 0u;   // one piece in 16: how noisy are these reads?
+                D.nf = n | (sample_this ? 256u : 0u) | (to_tile - n < 3u ? to_tile - n : 3u) << 9;
+                if (n_out == 0) *first_slot = D; else more_slots[n_out - 1u] = D;
+                ++n_out; ++w; so += stored_bytes(n);
+            }
+            rp += l; q += l;
+        } else {
+            if (cg_ref(t)) rp += l;
+            if (cg_query(t)) q += l;
+        }
+    }
+}
 __global__ __launch_bounds__(256) void msnv_emit_block(const EmitArgs A) {
     __shared__ uint4 win[EW_BYTES / 16 + 4];                       // (+ 64 bytes: a lane's last loads run past its piece)
-    __shared__ RecCnt s_pre[PB];
     __shared__ uint4 img_seq[EO_BYTES / 16 + 2];                   // (+ 32 bytes: a lane ORs five words from any byte)
     __shared__ uint4 img_flag[EO_BYTES / 64 + 2];
+    __shared__ PieceDesc s_desc[PB + EQ_CAP];
+    __shared__ unsigned long long s_mm[2];
+    __shared__ uint32_t s_misc[2];                                 // [0] further pieces of the block, [1] "not this kernel's"
     const uint32_t b = blockIdx.x, tid = threadIdx.x, i0 = b * PB;
     const uint32_t nrec = A.n_rec - i0 < PB ? A.n_rec - i0 : PB;
     const unsigned long long lo = A.rec_off[i0] & ~15ull, hi = A.rec_off[i0 + nrec];      // (entry n_rec: the end of the round's records)
     const bool direct = hi - lo > EW_BYTES;
-    // ---- this lane's record: what it needs of the per-record columns (asked for together with the window)
-    const uint32_t r = tid >> 2, sub = tid & 3u, i = i0 + (r < nrec ? r : 0u);
-    const uint8_t f = A.r_flags[i]; const uint32_t smp = A.rec_sample[i]; const uint16_t depth = A.r_depth[i]; const unsigned long long ro = A.rec_off[i];
     const uint32_t smp_first = A.rec_sample[i0], smp_last = A.rec_sample[i0 + nrec - 1u];
     const RecCnt base = A.blk_pre[b], next = A.blk_pre[b + 1];
+    // ---- the first wavefront's lanes: what their record needs of the per-record columns (asked for together with the window)
+    const uint32_t i = i0 + (tid < nrec ? tid : 0u);
+    uint8_t f = 0; uint16_t depth = 0; unsigned long long ro = 0; RecCnt mine{};
+    if (tid < PB) { f = A.r_flags[i]; depth = A.r_depth[i]; ro = A.rec_off[i]; if (tid < nrec) mine = A.r_cnt[i]; }
     // ---- the block's bytes into LDS
     if (!direct) {
         const uint32_t n16 = (uint32_t)((hi - lo + 15) >> 4);
@@ -1231,7 +1331,7 @@ __global__ __launch_bounds__(256) void msnv_emit_block(const EmitArgs A) {
 #pragma unroll
         for (uint32_t k = 0; k < EW_BYTES / 16 / 256; ++k) { const uint32_t c = tid + 256u * k; if (c < n16 + 4u) win[c] = v[k]; }
     }
-    // ---- the image of the block's stretch of its sample's columns: one sample, a stretch the image holds (else every lane stores for itself)
+    // ---- the image of the block's stretch of its sample's columns: one sample, a stretch the image holds
     const unsigned long long sb0 = A.samp_sbase0[smp_first];
     const unsigned long long a0 = base.seqb - sb0, b0 = next.seqb - sb0;             // the block's pieces own bytes [a0, b0) of the sample's seq column
     const uint32_t a16 = (uint32_t)a0 & ~15u;
@@ -1240,32 +1340,66 @@ __global__ __launch_bounds__(256) void msnv_emit_block(const EmitArgs A) {
         for (uint32_t c = tid; c < EO_BYTES / 16 + 2; c += 256u) img_seq[c] = make_uint4(0, 0, 0, 0);
         if (tid < EO_BYTES / 64 + 2) img_flag[tid] = make_uint4(0, 0, 0, 0);
     }
-    // ---- every record's own places: the block's base + the sums of the records before it in the block
-    if (tid < 64) {
-        const RecCnt mine = tid < nrec ? A.r_cnt[i0 + tid] : RecCnt{};
-        s_pre[tid] = cnt_add(base, wave_excl_cnt(mine));
-    }
+    if (tid == 0) { s_mm[0] = 0ull; s_mm[1] = 0ull; }
     __syncthreads();
     LdsSrcK lsrc; lsrc.w = reinterpret_cast<const uint32_t *>(win);
-    GlbSrcK gsrc; gsrc.p = A.raw;
-    GlbOut gout;
-    LdsOut lout; lout.seq_w = reinterpret_cast<uint32_t *>(img_seq); lout.flag_w = reinterpret_cast<uint32_t *>(img_flag); lout.a16 = a16;
-    if (r < nrec) {
-        bool from_global = direct;                                  // long reads: the block's records do not fit the window
-        if (!direct) {
+    const DpSampleDst d = A.dst[smp_first];
+    if (tid < PB) {
+        // ---- phase A (one wavefront): every record's own places = the block's base + the sums of the records before it in the block
+        const RecCnt pre = cnt_add(base, wave_excl_cnt(mine));
+        uint32_t more = mine.npiece ? mine.npiece - 1u : 0u, more_pre = more;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(more_pre, o); if ((int)tid >= o) more_pre += y; }
+        const uint32_t more_all = __shfl(more_pre, 63);
+        more_pre -= more;
+        bool odd = !image || more_all > EQ_CAP || A.force_slow;                   // (no pieces at all: nothing for the image form to do either -- the slow kernel writes the intervals)
+        if (!odd && tid < nrec) {
             // a CIGAR that may live in the CG field (placeholder `<l_seq>S...`: hostio.cpp rec_parse) is walked by rec_load, from global memory
             const unsigned long long o = ro - lo;
             const uint32_t fn = lsrc.ld32(o + 16), l_name = lsrc.ld32(o + 12) & 0xffu;
             const int32_t l_seq = (int32_t)lsrc.ld32(o + 20);
-            if ((fn & 0xffffu) > 0) { const uint32_t c0 = lsrc.ld32(o + 36 + l_name); from_global = (c0 & 15u) == C_S && (int32_t)(c0 >> 4) == l_seq; }
+            if ((fn & 0xffffu) > 0) { const uint32_t c0 = lsrc.ld32(o + 36 + l_name); odd = (c0 & 15u) == C_S && (int32_t)(c0 >> 4) == l_seq; }
         }
-        if (image) { if (from_global) emit_record(A, gsrc, lout, ro, s_pre[r], sub, f, smp, depth); else emit_record(A, lsrc, lout, ro - lo, s_pre[r], sub, f, smp, depth); }
-        else { if (from_global) emit_record(A, gsrc, gout, ro, s_pre[r], sub, f, smp, depth); else emit_record(A, lsrc, gout, ro - lo, s_pre[r], sub, f, smp, depth); }
+        odd = __any(odd);
+        if (tid == 0) {
+            s_misc[0] = more_all; s_misc[1] = odd ? 1u : 0u;
+            if (odd) A.slow[1u + atomicAdd(A.slow, 1u)] = b;
+        }
+        if (!odd) {
+            if (tid < nrec) emit_walk(A, lsrc, ro - lo, pre, f, depth, d, sb0, &s_desc[tid], &s_desc[PB + more_pre]);
+            else { PieceDesc none{}; s_desc[tid] = none; }
+        }
     }
-    if (!image) return;
     __syncthreads();
+    if (s_misc[1]) return;
+    // ---- phase B: four lanes a piece, 32 bases a lane, into the image
+    LdsOut lout; lout.seq_w = reinterpret_cast<uint32_t *>(img_seq); lout.flag_w = reinterpret_cast<uint32_t *>(img_flag); lout.a16 = a16;
+    {
+        const uint32_t n_desc = PB + s_misc[0], sub = tid & 3u, j0 = 32u * sub;
+        for (uint32_t t = tid >> 2; t < n_desc; t += 64u) {
+            const PieceDesc D = s_desc[t];
+            const uint32_t n = D.nf & 0xffu;
+            if (!n) continue;
+            const bool sample_this = (D.nf & 256u) != 0u;
+            const uint32_t sb = stored_bytes(n);
+            const uint32_t st = 2u * sb > j0 ? (2u * sb - j0 < 32u ? 2u * sb - j0 : 32u) : 0u;    // stored nibbles of this lane (a multiple of 4)
+            const uint32_t have = n > j0 ? (n - j0 < 32u ? n - j0 : 32u) : 0u;                     // ... of which real bases
+            uint64_t o0, o1; uint32_t bits, mm;
+            piece_lane(lsrc, D.seq_o, D.qual_o, D.q0, j0, have, (unsigned long long)D.ref_hi << 32 | D.ref_lo, D.ref_left, A.pref4, A.P, d.cut_marks, sample_this && have, (D.nf >> 9) & 3u,
+                       o0, o1, bits, mm);
+            lout.put(d, D.so, sub, sb, st, o0, o1, bits, 0u);
+            if (sample_this) {                                         // mismatch sample: sum over the 4 lanes of a piece, one LDS atomic per sampled piece
+                mm += __shfl_down(mm, 2, 4); mm += __shfl_down(mm, 1, 4);
+                if (sub == 0) { atomicAdd(&s_mm[0], (unsigned long long)n); if (mm) atomicAdd(&s_mm[1], (unsigned long long)mm); }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0 && s_mm[0]) {
+        DpAcc &a = A.acc[(size_t)smp_first * ACC_COPIES + (blockIdx.x % ACC_COPIES)];
+        atomicAdd(&a.mm_bases, s_mm[0]);
+        if (s_mm[1]) atomicAdd(&a.mm, s_mm[1]);
+    }
     // ---- the image out: whole 16-byte pieces of the columns where the block owns all of them, its own bytes / half bytes at the two ends
-    const DpSampleDst d = A.dst[smp_first];
     {
         const uint32_t n16 = ((uint32_t)b0 - a16 + 15u) >> 4;
         for (uint32_t c = tid; c < n16; c += 256u) {
@@ -1290,6 +1424,29 @@ __global__ __launch_bounds__(256) void msnv_emit_block(const EmitArgs A) {
                 else if (lo_b + 8u > fa && lo_b < fbe && byte) or_byte(gp + k, byte);      // half a byte is this block's (the other half is zero in the image)
             }
         }
+    }
+}
+// The blocks the quick form left (listed in A.slow): four lanes per record from global memory, piece after piece, byte-granular stores with
+// the nibbles shared between neighbours OR-ed in atomically -- round 4's route, which takes everything (records longer than the LDS window,
+// blocks that hold two samples, CIGARs in the CG field).
+__global__ __launch_bounds__(256) void msnv_emit_block_slow(const EmitArgs A) {
+    __shared__ RecCnt s_pre[PB];
+    const uint32_t n_list = A.slow[0], tid = threadIdx.x;
+    GlbSrcK gsrc; gsrc.p = A.raw;
+    GlbOut gout;
+    for (uint32_t li = blockIdx.x; li < n_list; li += gridDim.x) {
+        const uint32_t b = A.slow[1u + li], i0 = b * PB;
+        const uint32_t nrec = A.n_rec - i0 < PB ? A.n_rec - i0 : PB;
+        const uint32_t r = tid >> 2, sub = tid & 3u, i = i0 + (r < nrec ? r : 0u);
+        const uint8_t f = A.r_flags[i]; const uint32_t smp = A.rec_sample[i]; const uint16_t depth = A.r_depth[i]; const unsigned long long ro = A.rec_off[i];
+        const RecCnt base = A.blk_pre[b];
+        __syncthreads();                                            // (the list's previous block has read s_pre)
+        if (tid < 64) {
+            const RecCnt mine = tid < nrec ? A.r_cnt[i0 + tid] : RecCnt{};
+            s_pre[tid] = cnt_add(base, wave_excl_cnt(mine));
+        }
+        __syncthreads();
+        if (r < nrec) emit_record(A, gsrc, gout, ro, s_pre[r], sub, f, smp, depth);
     }
 }
 
@@ -1432,12 +1589,13 @@ int build_tables(msnv_dataset &ds) {
         if (ds.sel[c] && ds.has_seq[c]) nib += (ds.seqs[c].size() + 7) & ~(size_t)7;
     }
     t.pref_words = nib / 8 + 8;                                  // (msnv_emit_block reads five words from a lane's first position)
-    hipStream_t st = ds.ctx ? (hipStream_t)ds.ctx->stream : nullptr;
+    // (the copies below are plain blocking ones on the null stream: this function runs on a thread of its own beside the round's record scan
+    // -- devpack_add_round --, whose stream they must not wait for; whoever joins that thread finds the tables in place)
     if (int rc = dev_alloc(&t.contigs, std::max<size_t>(1, NC) * sizeof(DpContig), nullptr)) return rc;
     if (int rc = dev_alloc((void **)&t.overhang, (std::max<size_t>(1, NC) + 1) * sizeof(int32_t), nullptr)) return rc;
     if (int rc = dev_alloc((void **)&t.pref4, t.pref_words * sizeof(uint32_t), nullptr)) return rc;
-    HIP_TRY(hipMemcpyAsync(t.contigs, ct.data(), NC * sizeof(DpContig), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(t.overhang, 0, (std::max<size_t>(1, NC) + 1) * sizeof(int32_t), st));
+    if (NC) HIP_TRY(hipMemcpy(t.contigs, ct.data(), NC * sizeof(DpContig), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(t.overhang, 0, (std::max<size_t>(1, NC) + 1) * sizeof(int32_t)));
     t.any_overhang = reinterpret_cast<uint32_t *>(t.overhang + std::max<size_t>(1, NC));
     // the FASTA characters of the selected contigs -> nt16 codes, 8 per word, and lower-case bits, 32 per word: once per dataset, kept on the
     // host too (finalize lays them out by tile without going back to the characters); big references are cut into pieces for the host threads
@@ -1452,7 +1610,7 @@ int build_tables(msnv_dataset &ds) {
         t.h_code_off[c] = ct[c].pref_off / 8; t.h_lc_off[c] = lc_words;
         const uint64_t nw = (ds.seqs[c].size() + 7) / 8;
         lc_words += (ds.seqs[c].size() + 31) / 32;
-        for (uint64_t w = 0; w < nw; w += 1u << 16) jobs.push_back(Job{c, w, std::min<uint64_t>(nw, w + (1u << 16))});
+        for (uint64_t w = 0; w < nw; w += 1u << 14) jobs.push_back(Job{c, w, std::min<uint64_t>(nw, w + (1u << 14))});
     }
     t.h_lc.assign(lc_words + 1, 0u);
     auto run_job = [&](const Job &j) {
@@ -1467,16 +1625,16 @@ int build_tables(msnv_dataset &ds) {
             if (l) reinterpret_cast<uint8_t *>(lw)[w] = (uint8_t)l;          // (8 bases = one byte of the bit column: no two jobs share a byte)
         }
     };
-    if (jobs.size() <= 4) for (const Job &j : jobs) run_job(j);
+    if (jobs.size() <= 2) for (const Job &j : jobs) run_job(j);
     else {
         std::atomic<size_t> next{0};
         std::vector<std::thread> th;
-        const size_t nt = std::min<size_t>(std::min<size_t>(jobs.size() / 2, msnv_default_threads()), 32);
+        const size_t nt = std::min<size_t>(std::min<size_t>(jobs.size() / 2, msnv_default_threads()), jobs.size() < 64 ? 4 : 32);
         for (size_t k = 0; k < nt; ++k) th.emplace_back([&]() { for (;;) { const size_t i = next.fetch_add(1); if (i >= jobs.size()) break; run_job(jobs[i]); } });
         for (auto &x : th) x.join();
     }
-    HIP_TRY(hipMemcpyAsync(t.pref4, t.h_codes.data(), t.pref_words * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpy(t.pref4, t.h_codes.data(), t.pref_words * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipStreamSynchronize(nullptr));                      // (the memset above)
     t.ready = true;
     return MSNV_OK;
 }
@@ -1493,6 +1651,24 @@ const char *err_text(uint32_t kind) {
 
 }  // namespace
 
+// The dataset's pinned block: at least `half` bytes in each of its two halves.  Taken from the context's pool (a fresh dataset of a context
+// that has built one before pins nothing); grown only while nothing is in flight into it.
+static int pin_ensure(msnv_dataset &ds, uint64_t half) {
+    DevPackTables &T = ds.dp;
+    if (T.pin && T.pin_cap / 2 >= half) return MSNV_OK;
+    if (int rc = devpack_sync_pending(ds)) return rc;
+    msnv_ctx *ctx = ds.ctx;
+    if (T.pin) { ctx->pin_pool.emplace_back(T.pin, T.pin_cap); T.pin = nullptr; T.pin_cap = 0; }
+    const uint64_t want = std::max<uint64_t>(2 * half, 1ull << 20);
+    size_t best = SIZE_MAX;
+    for (size_t i = 0; i < ctx->pin_pool.size(); ++i) if (ctx->pin_pool[i].second >= want && (best == SIZE_MAX || ctx->pin_pool[i].second < ctx->pin_pool[best].second)) best = i;
+    if (best != SIZE_MAX) { T.pin = ctx->pin_pool[best].first; T.pin_cap = ctx->pin_pool[best].second; ctx->pin_pool.erase(ctx->pin_pool.begin() + (ptrdiff_t)best); return MSNV_OK; }
+    HIP_TRY(hipHostMalloc(&T.pin, want, hipHostMallocDefault));
+    T.pin_cap = want;
+    return MSNV_OK;
+}
+static uint32_t *pin_fin_words(const DevPackTables &T) { return reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(T.pin) + T.pin_cap / 2); }
+
 int devpack_sync_pending(msnv_dataset &ds) {
     DevPackTables &T = ds.dp;
     if (!T.pending.active) return MSNV_OK;
@@ -1500,7 +1676,7 @@ int devpack_sync_pending(msnv_dataset &ds) {
     HIP_TRY(hipEventSynchronize((hipEvent_t)T.pending.ev1));
     float ms = 0;
     if (hipEventElapsedTime(&ms, (hipEvent_t)T.pending.ev0, (hipEvent_t)T.pending.ev1) == hipSuccess) T.ms_emit += ms;
-    const DpAcc *a = static_cast<const DpAcc *>(ds.ctx->pin_small);
+    const DpAcc *a = static_cast<const DpAcc *>(T.pin);
     for (size_t s = 0; s < T.pending.n && T.pending.first + s < ds.samples.size(); ++s) {
         SampleCols &sc = ds.samples[T.pending.first + s];
         sc.mm_sampled_bases = a[s].mm_bases; sc.mm_sampled = a[s].mm;
@@ -1508,32 +1684,42 @@ int devpack_sync_pending(msnv_dataset &ds) {
     return MSNV_OK;
 }
 void devpack_ctx_release(msnv_ctx *ctx) {
-    if (ctx && ctx->pin_small) { (void)hipHostFree(ctx->pin_small); ctx->pin_small = nullptr; ctx->pin_small_cap = 0; }
+    if (!ctx) return;
+    for (auto &b : ctx->pin_pool) if (b.first) (void)hipHostFree(b.first);
+    ctx->pin_pool.clear();
 }
 
-void devpack_release(DevPackTables &t) {
+void devpack_release(msnv_dataset &ds) {
+    DevPackTables &t = ds.dp;
     if (t.pending.active) { (void)hipDeviceSynchronize(); t.pending.active = false; }
     if (t.pending.ev0) { (void)hipEventDestroy((hipEvent_t)t.pending.ev0); (void)hipEventDestroy((hipEvent_t)t.pending.ev1); t.pending.ev0 = t.pending.ev1 = nullptr; }
-    if (t.contigs) dev_free(t.contigs);
-    if (t.pref4) dev_free(t.pref4);
-    if (t.overhang) dev_free(t.overhang);
+    if (t.cov_job || !t.fin_keep.empty()) (void)hipDeviceSynchronize();
+    // everything of the pack goes back in ONE batch (one wait for the device instead of one per buffer: dev_free_batch)
+    std::vector<void *> out;
+    auto give = [&](void *p) { if (p) out.push_back(p); };
+    give(t.contigs); give(t.pref4); give(t.overhang);
     t.overhang = nullptr; t.any_overhang = nullptr;
-    for (DevRound &r : t.rounds) if (r.buf) dev_free(r.buf);
+    for (DevRound &r : t.rounds) give(r.buf);
     t.rounds.clear();
-    for (void *p : t.round_bufs) if (p) dev_free(p);
+    for (void *p : t.round_bufs) give(p);
     t.round_bufs.clear();
-    for (auto &b : t.scratch) if (b.first) dev_free(b.first);
+    for (auto &b : t.scratch) give(b.first);
     t.scratch.clear();
     t.contigs = nullptr; t.pref4 = nullptr; t.ready = false;
     std::vector<uint32_t>().swap(t.h_codes); std::vector<uint32_t>().swap(t.h_lc);
-    if (t.cov_job) { (void)hipDeviceSynchronize(); dev_free(t.cov_job); t.cov_job = nullptr; t.cov_runs = nullptr; }
-    if (t.cov_tmp) { dev_free(t.cov_tmp); t.cov_tmp = nullptr; }
+    give(t.cov_job); t.cov_job = nullptr; t.cov_runs = nullptr;
+    give(t.cov_tmp); t.cov_tmp = nullptr;
     t.cov_launched = false;
-    if (t.fin_tile_base) dev_free(t.fin_tile_base);
-    t.fin_tile_base = nullptr;
-    if (t.fin_list) dev_free(t.fin_list);
-    if (t.fin_cbase) dev_free(t.fin_cbase);
+    give(t.fin_tile_base); t.fin_tile_base = nullptr;
+    give(t.fin_list); give(t.fin_cbase);
     t.fin_list = nullptr; t.fin_cbase = nullptr;
+    for (void *p : t.fin_keep) give(p);
+    t.fin_keep.clear();
+    dev_free_batch(out);
+    if (t.pin) {
+        if (ds.ctx) ds.ctx->pin_pool.emplace_back(t.pin, t.pin_cap); else (void)hipHostFree(t.pin);
+        t.pin = nullptr; t.pin_cap = 0;
+    }
 }
 
 // Work buffers taken from a grow-only list in call order (a dataset's pool, or a caller's own list).
@@ -2005,9 +2191,22 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     hipStream_t st = (hipStream_t)ds.ctx->stream;
     fin_trace_reset();
     if (int rc = devpack_sync_pending(ds)) return rc;              // (the round before may still be writing: its work buffers are this round's)
-    if (int rc = build_tables(ds)) return rc;
-    fin_trace("  pack: reference tables (first round)");
     DevPackTables &T = ds.dp;
+    // the dataset's tables (contigs, packed FASTA of the selected ones) are built by the first round, on a thread of its own BESIDE the
+    // record scan, which needs none of them (round 5: 0.4 ms in front of it)
+    struct TablesJob {
+        std::thread th; int rc = MSNV_OK; std::string msg;
+        int join() { if (th.joinable()) th.join(); if (rc) return fail(rc, "%s", msg.c_str()); return MSNV_OK; }
+        ~TablesJob() { if (th.joinable()) th.join(); }
+    } tables;
+    if (!T.ready) {
+        const int device = ds.ctx->device;
+        tables.th = std::thread([&ds, &tables, device]() {
+            (void)hipSetDevice(device);
+            try { tables.rc = build_tables(ds); } catch (const std::exception &e) { tables.rc = fail_quiet(MSNV_ENOMEM, "device pack tables: %s", e.what()); }
+            if (tables.rc) tables.msg = msnv_last_error();
+        });
+    }
     const size_t S = (size_t)n, NC = ds.names.size();
     const msnv_params &MP = ds.params;
     DpParams P{};
@@ -2037,6 +2236,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     (void)d_send; (void)n_rec; (void)s_beg; (void)s_end;
 
     fin_trace("  pack: scan done");
+    if (int rc = tables.join()) return rc;
     // ---- measure (+ the host pre-pass for the samples that need one, then once more with its verdicts)
     DP_BUF(uint8_t, d_flags, NRa);
     DP_BUF(unsigned long long, d_key, NRa);
@@ -2302,6 +2502,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     HIP_TRY(hipStreamSynchronize(st));
     const uint32_t NPC = tot.npiece, NIV = tot.niv;
     T.n_pieces += NPC;
+    T.pad_in_emit = true;                                          // (msnv_emit_block* leave the alignment nibbles behind every piece as finalize wants them)
     // the round's columns: per sample seq (its pieces + 32 tail bytes, start on 16 bytes) and one flag bit per nibble of it
     std::vector<unsigned long long> seq_off(S + 1, 0), piece_bytes(S), ss0(S + 1);
     for (size_t s = 0; s <= S; ++s) ss0[s] = sum[s].sbase0;
@@ -2340,6 +2541,8 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     }
     DP_BUF(DpSampleDst, d_dst, S);
     DP_BUF(unsigned long long, d_pb, S);
+    DP_BUF(uint32_t, d_slow, NB + 2);
+    HIP_TRY(hipMemsetAsync(d_slow, 0, 4, st));
     // (the general route keeps the headers in file order first: work buffers, sorted into `keep` below)
     ReadHdr *w_hdr = keep.hdr; int32_t *w_tid = keep.tid, *w_end = keep.end; uint16_t *w_depth = keep.depth;
     if (in_order) {
@@ -2361,7 +2564,9 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
         A.hdr = w_hdr; A.ptid = w_tid; A.pend = w_end; A.pdepth = w_depth; A.cov_tid = keep.cov_tid; A.cov_beg = keep.cov_beg; A.cov_end = keep.cov_end;
         A.noseq_counts = (P.c_eff == 0 && !P.all_low) ? 1u : 0u;
         A.pref4 = T.pref4; A.P = P; A.dst = d_dst; A.acc = d_acc;
+        A.slow = d_slow; A.force_slow = [] { const char *e = getenv("MSNV_EMIT"); return e && e[0] == 's'; }() ? 1u : 0u;
         hipLaunchKernelGGL(msnv_emit_block, dim3((unsigned)NB), dim3(256), 0, st, A);
+        hipLaunchKernelGGL(msnv_emit_block_slow, dim3((unsigned)std::min<uint64_t>(NB, 2048)), dim3(256), 0, st, A);
         HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(msnv_emit_tail, dim3((unsigned)S), dim3(64), 0, st, d_dst, d_pb, (uint32_t)S, P);
@@ -2371,16 +2576,8 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     // and little of what finalize does first needs the bases or the headers.  What they leave for the host (the mismatch sample of every
     // sample, their time) comes through pinned memory and is taken by devpack_sync_pending.
     {
-        msnv_ctx *ctx = ds.ctx;
-        const uint64_t need = std::max<uint64_t>(S * sizeof(DpAcc), 4096);
-        if (ctx->pin_small_cap < need) {
-            if (ctx->pin_small) (void)hipHostFree(ctx->pin_small);
-            ctx->pin_small = nullptr; ctx->pin_small_cap = 0;
-            const uint64_t want = std::max<uint64_t>(2 * need, 4096 * sizeof(DpAcc));       // (the second half: finalize's small results, devfin_coverage_launch)
-            HIP_TRY(hipHostMalloc(&ctx->pin_small, want, hipHostMallocDefault));
-            ctx->pin_small_cap = want;
-        }
-        HIP_TRY(hipMemcpy2DAsync(ctx->pin_small, sizeof(DpAcc), d_acc, sizeof(DpAcc) * ACC_COPIES, sizeof(DpAcc), S, hipMemcpyDeviceToHost, st));
+        if (int rc = pin_ensure(ds, std::max<uint64_t>(S * sizeof(DpAcc), (ds.samples.size() + 16) * 4))) return rc;
+        HIP_TRY(hipMemcpy2DAsync(T.pin, sizeof(DpAcc), d_acc, sizeof(DpAcc) * ACC_COPIES, sizeof(DpAcc), S, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipEventRecord((hipEvent_t)T.pending.ev1, st));
         T.pending.active = true; T.pending.first = first; T.pending.n = S;
     }
@@ -2608,13 +2805,15 @@ __device__ __forceinline__ unsigned long long wave_prefix_max(unsigned long long
     return v;
 }
 template <bool FILL>
-__global__ __launch_bounds__(256) void msnv_fin_chunks(const TilePair *pairs, const uint32_t *list, uint32_t n, const ReadHdr *hdr, const unsigned long long *rbase, const unsigned long long *sbase,
-                                                       uint32_t *counts, const uint32_t *chunk_base, ChunkDesc *chunks, uint32_t *hdr4) {
+__global__ __launch_bounds__(256) void msnv_fin_chunks(const TilePair *pairs, const uint32_t *list, uint32_t n, const ReadHdr *const *s_hdr, const unsigned long long *rbase, const unsigned long long *sbase,
+                                                       uint32_t *counts, const uint32_t *chunk_base, ChunkDesc *chunks, uint32_t *hdr4, uint32_t chunk_cap) {
     const uint32_t j = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
     if (j >= n) return;
     const uint32_t k = list[j];
     const TilePair p = pairs[k];
-    const ReadHdr *h = hdr + rbase[p.sample];
+    // (the sample's headers where the pack's round left them: positions contig-relative, which is all the same inside a tile -- contigs start
+    // on tile boundaries --, so nothing here waits for the linear copy, msnv_fin_headers)
+    const ReadHdr *h = s_hdr[p.sample];
     constexpr unsigned long long span_max = (unsigned long long)SEQ_ALIGN << HDR4_OFF_BITS;
     uint32_t r = p.read_lo, c = 0;
     while (r < p.read_hi) {
@@ -2643,11 +2842,21 @@ __global__ __launch_bounds__(256) void msnv_fin_chunks(const TilePair *pairs, co
                 const uint32_t i = r + 64u * step + lane;
                 if (i < e) hdr4[rbase[p.sample] + i] = (mine[step].gpos % TILE) | mine[step].cig << 11 | (uint32_t)((mine[step].seqoff - lo) >> SEQ_ALIGN_LOG2) << 19;
             }
-            if (lane == 0) chunks[chunk_base[j] + c] = ChunkDesc{rbase[p.sample] + r, sbase[p.sample] + lo, p.pad >> 8, k, (e - r) | (e >= p.read_hi ? 1u << 16 : 0u), p.pad & 0xffu};
+            if (lane == 0 && chunk_base[j] + c < chunk_cap) chunks[chunk_base[j] + c] = ChunkDesc{rbase[p.sample] + r, sbase[p.sample] + lo, p.pad >> 8, k, (e - r) | (e >= p.read_hi ? 1u << 16 : 0u), p.pad & 0xffu};
         }
         ++c; r = e;
     }
     if (!FILL && lane == 0) counts[j] = c;
+}
+// The narrow work items' chunk ranges from the scanned counts, on the device (round 6: the host used to wait for the scan to write them):
+// item wi owns the listed pairs [item_first[wi], item_first[wi + 1]) and with them the chunks [base + scan[..], base + scan[..]).  The total
+// and "more chunks than there is room for" go to the host through pinned words; it looks at them behind finalize's last wait.
+__global__ void msnv_fin_work_chunks(WorkItem *work, uint32_t n_narrow, const uint32_t *item_first, const uint32_t *scan, uint32_t n_listed, uint32_t base, uint32_t cap, uint32_t *result) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { result[0] = scan[n_listed]; result[1] = scan[n_listed] > cap ? 1u : 0u; }
+    if (i >= n_narrow) return;
+    work[i].chunk_lo = base + scan[item_first[i]];
+    work[i].chunk_hi = base + scan[item_first[i + 1]];
 }
 // every narrow / merged work item's first chunk descriptor, copied into the item (kernels.hip: a workgroup starts loading without the descriptor stream)
 __global__ void msnv_fin_work_first(WorkItem *work, uint32_t n, const ChunkDesc *chunks) {
@@ -2656,12 +2865,12 @@ __global__ void msnv_fin_work_first(WorkItem *work, uint32_t n, const ChunkDesc 
     if (work[i].chunk_hi > work[i].chunk_lo) work[i].first = chunks[work[i].chunk_lo];
 }
 
-__global__ void msnv_fin_merged(const TilePair *pairs, const DevMergedSrc *list, uint32_t n, const ReadHdr *hdr, const unsigned long long *rbase, const unsigned long long *sbase, PieceHdr *hm) {
+__global__ void msnv_fin_merged(const TilePair *pairs, const DevMergedSrc *list, uint32_t n, const ReadHdr *const *s_hdr, const unsigned long long *sbase, PieceHdr *hm) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const DevMergedSrc m = list[j];
     const TilePair p = pairs[m.pair];
-    const ReadHdr *h = hdr + rbase[p.sample];
+    const ReadHdr *h = s_hdr[p.sample];                            // (contig-relative positions: only the tile-relative part is used)
     for (uint32_t r = p.read_lo; r < p.read_hi; ++r) {
         const unsigned long long so = (sbase[p.sample] + h[r].seqoff) >> SEQ_ALIGN_LOG2;     // 37 bits: bits 32-36 ride in bits 27-31 of the first word
         hm[m.h_base + (r - p.read_lo)] = PieceHdr{(h[r].gpos % TILE) | h[r].cig << 11 | m.in_group << 19 | (uint32_t)(so >> 32) << 27, (uint32_t)so};
@@ -2786,7 +2995,80 @@ int devfin_headers(msnv_dataset &ds, DeviceCols &d, const std::vector<uint64_t> 
     return MSNV_OK;
 }
 
-// The narrow pairs' chunks in two steps with ONE wait between them: counts (+ their exclusive scan, on the device) -> the host learns every
+// Every sample's headers where its round left them (device pointers, one per sample): what msnv_fin_chunks / msnv_fin_merged read
+static int sample_hdr_table(msnv_dataset &ds, const ReadHdr *const **out) {
+    DevPackTables &T = ds.dp;
+    const size_t S = ds.samples.size();
+    std::vector<const ReadHdr *> tab(S, nullptr);
+    for (size_t s = 0; s < S; ++s) {
+        const SampleCols &sc = ds.samples[s];
+        if (sc.dev_round >= 0 && (size_t)sc.dev_round < T.rounds.size()) tab[s] = T.rounds[(size_t)sc.dev_round].hdr + sc.dev_piece0;
+    }
+    void *p = nullptr;
+    if (int rc = dev_alloc(&p, std::max<size_t>(1, S) * sizeof(void *), nullptr)) return rc;
+    T.fin_keep.push_back(p);
+    if (S) HIP_TRY(hipMemcpy(p, tab.data(), S * sizeof(void *), hipMemcpyHostToDevice));
+    *out = static_cast<const ReadHdr *const *>(p);
+    return MSNV_OK;
+}
+
+// The narrow pairs' chunks WITHOUT a wait (round 6; round 5 waited for the counts to size the descriptor table and to write the work items'
+// ranges): counts -> scan -> fill -> the work items' ranges, all queued; d.chunks (allocated by the caller) has room for `cap` narrow chunks
+// behind the `base` chunks of the merged groups, which the host wrote.  cap is the host's bound -- per pair ceil(pieces / CHUNK_READS) + 2: a
+// chunk is closed early only where the seq offsets jump by 16 KB, at most once per pair in data the pack laid out --; the true total and an
+// overflow flag arrive through the dataset's pinned words (devfin_chunks_result, behind finalize's last wait): an overflow sends finalize
+// through devfin_chunk_counts / devfin_chunk_fill below, which wait and size exactly (MSNV_CHUNK_CAP forces it: tests).
+int devfin_chunks_launch(msnv_dataset &ds, DeviceCols &d, const std::vector<uint32_t> &narrow_pairs, const std::vector<uint32_t> &item_first, uint32_t base, uint64_t cap) {
+    hipStream_t st = (hipStream_t)ds.ctx->stream;
+    DevPackTables &T = ds.dp;
+    const size_t n = narrow_pairs.size(), n_items = item_first.size() - 1;
+    T.fin_chunks_async = true; T.fin_chunk_cap = cap; T.fin_chunk_base = base;
+    if (int rc = pin_ensure(ds, (ds.samples.size() + 16) * 4)) return rc;
+    uint32_t *res = pin_fin_words(T) + (ds.samples.size() + 4);
+    res[0] = 0; res[1] = 0;
+    if (!n) return MSNV_OK;
+    const ReadHdr *const *s_hdr = nullptr;
+    if (int rc = sample_hdr_table(ds, &s_hdr)) return rc;
+    void *blk = nullptr;
+    const uint64_t b_list = (n * 4 + 255) & ~255ull, b_if = ((n_items + 1) * 4 + 255) & ~255ull, b_cnt = ((n + 1) * 4 + 255) & ~255ull;
+    if (int rc = dev_alloc(&blk, b_list + b_if + 2 * b_cnt + 256, nullptr)) return rc;
+    T.fin_keep.push_back(blk);
+    uint8_t *q = static_cast<uint8_t *>(blk);
+    uint32_t *list = reinterpret_cast<uint32_t *>(q); q += b_list;
+    uint32_t *ifirst = reinterpret_cast<uint32_t *>(q); q += b_if;
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(q); q += b_cnt;
+    uint32_t *scan = reinterpret_cast<uint32_t *>(q); q += b_cnt;
+    uint32_t *dres = reinterpret_cast<uint32_t *>(q);
+    HIP_TRY(hipMemcpy(list, narrow_pairs.data(), n * 4, hipMemcpyHostToDevice));      // (blocking copies on the null stream: the buffers are fresh, nothing to order against)
+    HIP_TRY(hipMemcpy(ifirst, item_first.data(), (n_items + 1) * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemsetAsync(cnt + n, 0, 4, st));
+    hipLaunchKernelGGL(msnv_fin_chunks<false>, grid_for(n * 64, 256), dim3(256), 0, st, d.pairs, list, (uint32_t)n, s_hdr, (const unsigned long long *)d.s_read_base,
+                       (const unsigned long long *)d.s_seq_base, cnt, nullptr, nullptr, nullptr, 0u);
+    HIP_TRY(hipGetLastError());
+    {
+        // (rocPRIM's temporary storage outlives this call: the scan is only queued)
+        size_t need = 0;
+        HIP_TRY(rocprim::exclusive_scan(nullptr, need, cnt, scan, 0u, n + 1, rocprim::plus<uint32_t>(), st));
+        void *tmp = nullptr;
+        if (int rc = dev_alloc(&tmp, need + 256, nullptr)) return rc;
+        T.fin_keep.push_back(tmp);
+        HIP_TRY(rocprim::exclusive_scan(tmp, need, cnt, scan, 0u, n + 1, rocprim::plus<uint32_t>(), st));
+    }
+    hipLaunchKernelGGL(msnv_fin_chunks<true>, grid_for(n * 64, 256), dim3(256), 0, st, d.pairs, list, (uint32_t)n, s_hdr, (const unsigned long long *)d.s_read_base,
+                       (const unsigned long long *)d.s_seq_base, nullptr, scan, d.chunks + base, d.hdr4, (uint32_t)std::min<uint64_t>(cap, 0xffffffffull));
+    hipLaunchKernelGGL(msnv_fin_work_chunks, grid_for(std::max<size_t>(1, n_items), 256), dim3(256), 0, st, d.work, (uint32_t)n_items, ifirst, scan, (uint32_t)n, base,
+                       (uint32_t)std::min<uint64_t>(cap, 0xffffffffull), dres);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(res, dres, 8, hipMemcpyDeviceToHost, st));
+    return MSNV_OK;
+}
+// behind a wait for the stream: the narrow chunks that were cut, and whether they all found room
+void devfin_chunks_result(const msnv_dataset &ds, uint64_t *n_chunks, bool *overflow) {
+    const uint32_t *res = pin_fin_words(ds.dp) + (ds.samples.size() + 4);
+    *n_chunks = res[0]; *overflow = res[1] != 0;
+}
+
+// ... and the form with ONE wait between counts and fill (exact sizes): counts (+ their exclusive scan, on the device) -> the host learns every
 // pair's first chunk and the total, and allocates the descriptors; then the fill, straight into d.chunks and d.hdr4.  The list and the scan
 // stay in HBM between the two calls (DevPackTables::fin_list / fin_cbase).
 int devfin_chunk_counts(msnv_dataset &ds, DeviceCols &d, const std::vector<uint32_t> &narrow_pairs, std::vector<uint32_t> &cbase) {
@@ -2795,13 +3077,17 @@ int devfin_chunk_counts(msnv_dataset &ds, DeviceCols &d, const std::vector<uint3
     cbase.assign(n + 1, 0);
     if (!n) return MSNV_OK;
     DevPackTables &T = ds.dp;
+    const ReadHdr *const *s_hdr = nullptr;
+    if (int rc = sample_hdr_table(ds, &s_hdr)) return rc;
+    if (T.fin_list) { T.fin_keep.push_back(T.fin_list); T.fin_list = nullptr; }
+    if (T.fin_cbase) { T.fin_keep.push_back(T.fin_cbase); T.fin_cbase = nullptr; }
     if (int rc = dev_alloc(&T.fin_list, n * 4, nullptr)) return rc;
     if (int rc = dev_alloc(&T.fin_cbase, (n + 1) * 8, nullptr)) return rc;      // counts (n + 1 words) and their scan behind them
     uint32_t *cnt = static_cast<uint32_t *>(T.fin_cbase), *scan = cnt + (n + 1);
     HIP_TRY(hipMemcpyAsync(T.fin_list, narrow_pairs.data(), n * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(cnt + n, 0, 4, st));
-    hipLaunchKernelGGL(msnv_fin_chunks<false>, grid_for(n * 64, 256), dim3(256), 0, st, d.pairs, static_cast<const uint32_t *>(T.fin_list), (uint32_t)n, d.hdr, (const unsigned long long *)d.s_read_base,
-                       (const unsigned long long *)d.s_seq_base, cnt, nullptr, nullptr, nullptr);
+    hipLaunchKernelGGL(msnv_fin_chunks<false>, grid_for(n * 64, 256), dim3(256), 0, st, d.pairs, static_cast<const uint32_t *>(T.fin_list), (uint32_t)n, s_hdr, (const unsigned long long *)d.s_read_base,
+                       (const unsigned long long *)d.s_seq_base, cnt, nullptr, nullptr, nullptr, 0u);
     HIP_TRY(hipGetLastError());
     Prim pr(st);
     if (int rc = pr.scan32(cnt, scan, n + 1, false)) return rc;
@@ -2810,14 +3096,16 @@ int devfin_chunk_counts(msnv_dataset &ds, DeviceCols &d, const std::vector<uint3
     return MSNV_OK;
 }
 
-// d.chunks[0 .. n_narrow) and d.hdr4 (both allocated by the caller) from the kept list and scan
-int devfin_chunk_fill(msnv_dataset &ds, DeviceCols &d, size_t n_pairs_listed) {
+// d.chunks[base .. base + n_narrow) and d.hdr4 (both allocated by the caller) from the kept list and scan
+int devfin_chunk_fill(msnv_dataset &ds, DeviceCols &d, size_t n_pairs_listed, uint32_t base) {
     hipStream_t st = (hipStream_t)ds.ctx->stream;
     DevPackTables &T = ds.dp;
     if (n_pairs_listed) {
+        const ReadHdr *const *s_hdr = nullptr;
+        if (int rc = sample_hdr_table(ds, &s_hdr)) return rc;
         const uint32_t *scan = static_cast<const uint32_t *>(T.fin_cbase) + (n_pairs_listed + 1);
-        hipLaunchKernelGGL(msnv_fin_chunks<true>, grid_for(n_pairs_listed * 64, 256), dim3(256), 0, st, d.pairs, static_cast<const uint32_t *>(T.fin_list), (uint32_t)n_pairs_listed, d.hdr,
-                           (const unsigned long long *)d.s_read_base, (const unsigned long long *)d.s_seq_base, nullptr, scan, d.chunks, d.hdr4);
+        hipLaunchKernelGGL(msnv_fin_chunks<true>, grid_for(n_pairs_listed * 64, 256), dim3(256), 0, st, d.pairs, static_cast<const uint32_t *>(T.fin_list), (uint32_t)n_pairs_listed, s_hdr,
+                           (const unsigned long long *)d.s_read_base, (const unsigned long long *)d.s_seq_base, nullptr, scan, d.chunks + base, d.hdr4, 0xffffffffu);
         HIP_TRY(hipGetLastError());
     }
     return MSNV_OK;
@@ -2831,13 +3119,15 @@ int devfin_work_first(msnv_dataset &ds, DeviceCols &d, uint32_t n_items) {
 int devfin_merged_headers(msnv_dataset &ds, DeviceCols &d, const std::vector<DevMergedSrc> &list) {
     hipStream_t st = (hipStream_t)ds.ctx->stream;
     if (list.empty()) return MSNV_OK;
-    DevBuf l;
-    if (int rc = l.alloc(list.size() * sizeof(DevMergedSrc))) return rc;
-    HIP_TRY(hipMemcpyAsync(l.p, list.data(), list.size() * sizeof(DevMergedSrc), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(msnv_fin_merged, grid_for(list.size(), 64), dim3(64), 0, st, d.pairs, l.as<DevMergedSrc>(), (uint32_t)list.size(), d.hdr, (const unsigned long long *)d.s_read_base,
+    const ReadHdr *const *s_hdr = nullptr;
+    if (int rc = sample_hdr_table(ds, &s_hdr)) return rc;
+    void *l = nullptr;
+    if (int rc = dev_alloc(&l, list.size() * sizeof(DevMergedSrc), nullptr)) return rc;
+    ds.dp.fin_keep.push_back(l);                                   // (read by a kernel that is only queued: freed with the pack's tables)
+    HIP_TRY(hipMemcpy(l, list.data(), list.size() * sizeof(DevMergedSrc), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(msnv_fin_merged, grid_for(list.size(), 64), dim3(64), 0, st, d.pairs, static_cast<const DevMergedSrc *>(l), (uint32_t)list.size(), s_hdr,
                        (const unsigned long long *)d.s_seq_base, d.hdr8m);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(st));
     return MSNV_OK;
 }
 
@@ -2862,8 +3152,8 @@ int devfin_coverage_launch(msnv_dataset &ds, DeviceCols &d) {
     for (size_t s = 0; s < S; ++s) iv_start[s + 1] = iv_start[s] + ds.samples[s].n_dev_iv;
     const unsigned long long N = iv_start[S];
     const unsigned long long n_tab = (unsigned long long)S * ds.n_tiles;
-    const uint64_t pin_at = ds.ctx->pin_small_cap / 2, pin_need = (S + 4) * 4;
-    if (N > 0xfffffff0ull || !cov_dense_form(ds, N) || n_tab > (1ull << 24) || !ds.ctx->pin_small || pin_at + pin_need > ds.ctx->pin_small_cap || getenv("MSNV_COV_LATE")) return MSNV_OK;
+    if (N > 0xfffffff0ull || !cov_dense_form(ds, N) || n_tab > (1ull << 24) || getenv("MSNV_COV_LATE")) return MSNV_OK;
+    if (int rc = pin_ensure(ds, (S + 16) * 4)) return rc;
     auto up = [](unsigned long long b) { return (b + 255ull) & ~255ull; };
     const unsigned long long b_tb = up(std::max<size_t>(1, ds.tile_base.size()) * 4), b_ivs = up((S + 1) * 8), b_cvb = up((S + 4) * 4);
     const unsigned long long b_n = up((N + 1) * 4), b_t = up((n_tab + 1) * 4), b_r = up((n_tab + 1) * sizeof(DevCovPair));
@@ -2916,7 +3206,7 @@ int devfin_coverage_launch(msnv_dataset &ds, DeviceCols &d) {
     HIP_TRY(hipMemcpyAsync(cvb + (S + 2), rid + n_tab, 4, hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(msnv_fin_cov_dense_runs, grid_for(n_tab, 256), dim3(256), 0, st, lo, hi, rid, n_tab, ds.n_tiles, runs);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(static_cast<uint8_t *>(ds.ctx->pin_small) + pin_at, cvb, (S + 3) * 4, hipMemcpyDeviceToHost, st));      // (pinned: the copy does not wait on the host)
+    HIP_TRY(hipMemcpyAsync(pin_fin_words(T), cvb, (S + 3) * 4, hipMemcpyDeviceToHost, st));      // (pinned: the copy does not wait on the host)
     T.cov_tmp = pr.tmp.release();                                  // (rocPRIM's work memory: in use until the kernels above have run)
     T.cov_launched = true;
     return MSNV_OK;
@@ -2934,7 +3224,7 @@ int devfin_coverage(msnv_dataset &ds, DeviceCols &d, std::vector<uint64_t> &cvba
         DevPackTables &T = ds.dp;
         T.cov_launched = false;
         HIP_TRY(hipStreamSynchronize(st));
-        const uint32_t *pw = reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(ds.ctx->pin_small) + ds.ctx->pin_small_cap / 2);
+        const uint32_t *pw = pin_fin_words(T);
         for (size_t s = 0; s <= S; ++s) cvbase[s] = pw[s];
         const uint32_t n_keep = pw[S + 1], n_runs = pw[S + 2];
         d.n_cov_iv = n_keep;
@@ -3542,7 +3832,7 @@ int devpack_finish(msnv_dataset &ds) {
     if (int rc = devpack_sync_pending(ds)) return rc;
     if (ds.ctx) HIP_TRY(hipStreamSynchronize((hipStream_t)ds.ctx->stream));
     for (SampleCols &sc : ds.samples) { sc.d_seq = nullptr; sc.d_qual = nullptr; }
-    devpack_release(ds.dp);
+    devpack_release(ds);
     return MSNV_OK;
 }
 

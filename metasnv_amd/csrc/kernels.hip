@@ -2571,6 +2571,37 @@ void dev_free(void *p) {
     }
     for (const CacheBlock &e : evict) (void)hipFree(e.p);
 }
+// Many buffers of ONE owner at once (the device pack's tables and work buffers at the end of finalize): one wait for the device, not one per buffer.
+void dev_free_batch(const std::vector<void *> &ptrs) {
+    if (ptrs.empty()) return;
+    if (guard_alloc_enabled()) { for (void *p : ptrs) dev_free(p); return; }
+    (void)hipDeviceSynchronize();                                   // (the owner's device is current: devpack_finish / msnv_dataset_destroy set it)
+    std::vector<CacheBlock> evict; std::vector<void *> foreign;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        for (void *p : ptrs) {
+            if (!p) continue;
+            auto it = g_cache_live.find(p);
+            if (it == g_cache_live.end()) { foreign.push_back(p); continue; }
+            g_cache_free.push_back(it->second); g_cache_free_bytes += it->second.bytes;
+            g_cache_live.erase(it);
+        }
+    }
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t cap = cache_cap_bytes(dev);
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        while (g_cache_free_bytes > cap && !g_cache_free.empty()) {
+            size_t big = 0;
+            for (size_t i = 1; i < g_cache_free.size(); ++i) if (g_cache_free[i].bytes > g_cache_free[big].bytes) big = i;
+            evict.push_back(g_cache_free[big]); g_cache_free_bytes -= g_cache_free[big].bytes;
+            g_cache_free[big] = g_cache_free.back(); g_cache_free.pop_back();
+        }
+    }
+    for (const CacheBlock &e : evict) (void)hipFree(e.p);
+    for (void *p : foreign) (void)hipFree(p);
+}
 int dev_upload(void *dst, const void *src, uint64_t bytes) {
     if (!bytes) return MSNV_OK;
     HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
@@ -2591,6 +2622,12 @@ int dev_memset(void *dst, int v, uint64_t bytes) {
     if (bytes) { HIP_TRY(hipMemset(dst, v, bytes)); HIP_TRY(hipStreamSynchronize(nullptr)); }
     return MSNV_OK;
 }
+// ... or on the stream the buffer's first user runs on: ordered before it, nothing to wait for
+int dev_memset_async(void *dst, int v, uint64_t bytes, void *stream) {
+    if (bytes) HIP_TRY(hipMemsetAsync(dst, v, bytes, (hipStream_t)stream));
+    return MSNV_OK;
+}
+int dev_stream_wait(void *stream) { HIP_TRY(hipStreamSynchronize((hipStream_t)stream)); return MSNV_OK; }
 int dev_stream_create(void **stream) { hipStream_t s; HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); *stream = s; return MSNV_OK; }
 void dev_stream_destroy(void *stream) { if (stream) (void)hipStreamDestroy((hipStream_t)stream); }
 

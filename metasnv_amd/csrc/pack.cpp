@@ -1136,7 +1136,7 @@ int finalize_dataset(msnv_dataset &ds) {
         ds.tile_slot_base[nt] = (uint64_t)ds.slot_sample.size();
         if (int rc = arena.add(&d->tile_nslots, nslots, &d->device_bytes)) return rc;
         if (int rc = dev_alloc((void **)&d->tile_cell_base, (nt + 1) * sizeof(unsigned long long), &d->device_bytes)) return rc;
-        if (int rc = dev_memset(d->tile_cell_base, 0, (nt + 1) * sizeof(unsigned long long))) return rc;
+        if (int rc = dev_memset_async(d->tile_cell_base, 0, (nt + 1) * sizeof(unsigned long long), ds.ctx ? ds.ctx->stream : nullptr)) return rc;
     }
     lap("slots");
     // ---- work list: split each tile's pairs so that work items carry similar read counts
@@ -1313,7 +1313,7 @@ int finalize_dataset(msnv_dataset &ds) {
                 if (int rc = arena.add(&d->tile_stage_idx, stage_idx, &d->device_bytes)) return rc;
                 // (+ one index per whole-tile item behind the lists: the tiles whose candidates do not fit a list -- kernels.hip: stage_ovf_list)
                 if (int rc = dev_alloc((void **)&d->tile_stage, (uint64_t)active.size() * sizeof(TileStage) + (uint64_t)n_fused * sizeof(uint32_t), &d->device_bytes)) return rc;
-                if (int rc = dev_memset(d->tile_stage, 0, (uint64_t)active.size() * sizeof(TileStage))) return rc;
+                if (int rc = dev_memset_async(d->tile_stage, 0, (uint64_t)active.size() * sizeof(TileStage), ds.ctx ? ds.ctx->stream : nullptr)) return rc;
             }
         }
         d->wide_tot = false;
@@ -1321,53 +1321,69 @@ int finalize_dataset(msnv_dataset &ds) {
         d->use_dirty = !active.empty() && work.size() < 4 * active.size();       // a sparse cohort: fewer than four work items per tile
     }
     lap("partial rows, gate tiles");
-    // ---- chunk descriptors of the narrow work items
-    std::vector<ChunkDesc> chunks;                                  // fast: the merged groups' only -- the narrow items' are cut in HBM (n_chunks_dev of them, in front)
-    uint64_t n_chunks_dev = 0; size_t n_pairs_listed = 0;
+    // ---- chunk descriptors.  Layout of d->chunks (round 6): the merged groups' chunks FIRST -- their number is the host's --, the narrow work
+    // items' behind them: on the fast path those are cut in HBM and nobody waits for their count (devfin_chunks_launch).
+    std::vector<ChunkDesc> mchunks, nchunks;                        // merged groups' / narrow items' (host loops only)
+    std::vector<PieceHdr> hm;
+    std::vector<DevMergedSrc> hm_src;                               // fast: the pairs whose headers a kernel writes
+    uint64_t hm_count = 0;
+    std::vector<MergedGroupDev> mgroups;
+    {   // merged groups: their piece headers, group by group, and chunks that run across the group's pairs
+        size_t gi = 0;
+        for (uint32_t wi = d->n_work_narrow; wi < d->n_work_narrow + d->n_work_merged; ++wi) {
+            WorkItem &w = work[wi];
+            w.chunk_lo = (uint32_t)mchunks.size();
+            for (; gi < groups.size() && groups[gi].pair_lo >= w.pair_lo && groups[gi].pair_hi <= w.pair_hi; ++gi) {
+                const MergedGroup &g = groups[gi];
+                const uint64_t h0 = fast ? hm_count : hm.size();
+                for (uint32_t k = g.pair_lo; k < g.pair_hi; ++k) {
+                    const TilePair &p = pairs[k];
+                    if (fast) { hm_src.push_back(DevMergedSrc{k, k - g.pair_lo, hm_count}); hm_count += p.read_hi - p.read_lo; continue; }
+                    const SampleCols &sc = ds.samples[p.sample];
+                    for (uint32_t r = p.read_lo; r < p.read_hi; ++r) {
+                        const uint64_t so = (sbase[p.sample] + sc.hdr[r].seqoff) >> SEQ_ALIGN_LOG2;          // 37 bits: bits 32-36 ride in bits 27-31 of the first word
+                        hm.push_back(PieceHdr{(sc.hdr[r].gpos % TILE) | sc.hdr[r].cig << 11 | (k - g.pair_lo) << 19 | (uint32_t)(so >> 32) << 27, (uint32_t)so});
+                    }
+                }
+                const uint64_t n_h = (fast ? hm_count : hm.size()) - h0;
+                mgroups.push_back(MergedGroupDev{h0, w.tile, g.pair_lo, g.pair_hi - g.pair_lo, (uint32_t)n_h});
+                for (uint64_t r = 0; r < n_h; r += CHUNK_READS) {
+                    const uint32_t n = (uint32_t)std::min<uint64_t>(CHUNK_READS, n_h - r);
+                    mchunks.push_back(ChunkDesc{h0 + r, 0, pairs[g.pair_lo].sample, g.pair_lo, n | (r + n >= n_h ? 1u << 16 : 0u), g.pair_hi - g.pair_lo});
+                }
+            }
+            w.chunk_hi = (uint32_t)mchunks.size();
+        }
+        if (gi != groups.size()) return fail(MSNV_EINVAL, "internal: merged groups and work items disagree");
+    }
+    const uint64_t M = mchunks.size();
+    if (M > 0x7ffffff0ull) return fail(MSNV_EDOMAIN, "more than 2^31 chunks of merged groups in one shard");
     std::vector<std::vector<uint32_t>> hdr4_of(HDR4 && !dense && !fast ? S : 0);      // 4-byte piece headers, per sample (chunk-relative offsets: filled with the chunks)
     for (size_t s = 0; s < hdr4_of.size(); ++s) hdr4_of[s].assign(ds.samples[s].hdr.size(), 0u);
-    if (fast) {
-        // the pieces are in HBM: pairs and the per-sample bases go up first, the 16-byte headers are put together there (positions made
-        // linear), and the chunks of every narrow pair are cut by a kernel that runs the same greedy rule as the loop below
-        d->n_pairs = (uint32_t)pairs.size();
-        if (int rc = arena.add(&d->pairs, pairs, &d->device_bytes)) return rc;
-        if (int rc = arena.add(&d->s_read_base, rbase, &d->device_bytes)) return rc;
-        if (int rc = arena.add(&d->s_seq_base, sbase, &d->device_bytes)) return rc;
-        if (int rc = dev_alloc((void **)&d->hdr, (rbase[S] + 1) * sizeof(ReadHdr), &d->device_bytes)) return rc;
-        if (int rc = arena.commit(*d)) return rc;                  // (everything so far: the kernels below read pairs, bases, reference)
-        lap("  pairs / bases up, hdr alloc");
-        if (int rc = devfin_headers(ds, *d, rbase)) return rc;
-        lap("  devfin_headers");
-    }
-    if (fast && !dense) {
-        if (int rc = dev_alloc((void **)&d->hdr4, (rbase[S] + 4) * sizeof(uint32_t), &d->device_bytes)) return rc;
-        if (int rc = dev_memset(d->hdr4, 0, (rbase[S] + 4) * sizeof(uint32_t))) return rc;
+    std::vector<uint32_t> narrow_pairs, item_first;                 // fast, piece layout: the narrow items' pairs in item order; every item's first entry
+    uint64_t chunk_cap = 0;                                         // ... and the room their chunks get
+    const bool chunks_on_device = fast && !dense;
+    if (chunks_on_device) {
         if (rbase[S] > 0xfffffff0ull) return fail(MSNV_EDOMAIN, "more than 2^32 pieces in one shard: shard the contigs further");      // (chunks <= pieces: the 32-bit scan of their counts cannot wrap)
-        std::vector<uint32_t> narrow_pairs, cbase;
-        for (uint32_t wi = 0; wi < d->n_work_narrow; ++wi) for (uint32_t k = work[wi].pair_lo; k < work[wi].pair_hi; ++k) narrow_pairs.push_back(k);
-        lap("  hdr4 alloc + narrow list");
-        if (int rc = devfin_chunk_counts(ds, *d, narrow_pairs, cbase)) return rc;
-        lap("  devfin_chunk_counts");
-        size_t j = 0;
+        item_first.reserve((size_t)d->n_work_narrow + 1);
         for (uint32_t wi = 0; wi < d->n_work_narrow; ++wi) {
-            work[wi].chunk_lo = cbase[j];
-            j += work[wi].pair_hi - work[wi].pair_lo;
-            work[wi].chunk_hi = cbase[j];
+            item_first.push_back((uint32_t)narrow_pairs.size());
+            for (uint32_t k = work[wi].pair_lo; k < work[wi].pair_hi; ++k) { narrow_pairs.push_back(k); chunk_cap += (pairs[k].read_hi - pairs[k].read_lo + CHUNK_READS - 1) / CHUNK_READS + 2; }
         }
-        n_chunks_dev = cbase[narrow_pairs.size()];
-        n_pairs_listed = narrow_pairs.size();
-        if (n_chunks_dev > 0xfffffff0ull) return fail(MSNV_EDOMAIN, "more than 2^32 chunks in one shard");
+        item_first.push_back((uint32_t)narrow_pairs.size());
+        if (const char *e = getenv("MSNV_CHUNK_CAP")) chunk_cap = (uint64_t)std::max<long long>(0, atoll(e));      // (tests: a table too small on purpose -> the exact, waiting form)
+        if (M + chunk_cap > 0xfffffff0ull) return fail(MSNV_EDOMAIN, "more than 2^32 chunks in one shard");
     }
     else for (uint32_t wi = 0; wi < d->n_work_narrow; ++wi) {
         WorkItem &w = work[wi];
-        w.chunk_lo = (uint32_t)chunks.size();
+        w.chunk_lo = (uint32_t)(M + nchunks.size());
         for (uint32_t k = w.pair_lo; k < w.pair_hi; ++k) {
             const TilePair &p = pairs[k];
             if (dense) {        // chunk = up to DENSE_CHUNK_BLOCKS blocks of the pair's stream: {first block, seq byte offset of that block}
                 for (uint32_t b = 0; b < p.nblk; b += DENSE_CHUNK_BLOCKS) {
                     const uint32_t n = std::min<uint32_t>(DENSE_CHUNK_BLOCKS, p.nblk - b);
-                    chunks.push_back(ChunkDesc{bbase[p.sample] + p.blk_lo + b, sbase[p.sample] + p.seq0 + 16ull * b, p.pad >> 8, k,
-                                               n | (b + n >= p.nblk ? 1u << 16 : 0u), p.pad & 0xffu});      // "sample" = the sample's slot in the tile
+                    nchunks.push_back(ChunkDesc{bbase[p.sample] + p.blk_lo + b, sbase[p.sample] + p.seq0 + 16ull * b, p.pad >> 8, k,
+                                                n | (b + n >= p.nblk ? 1u << 16 : 0u), p.pad & 0xffu});      // "sample" = the sample's slot in the tile
                 }
                 continue;
             }
@@ -1389,81 +1405,64 @@ int finalize_dataset(msnv_dataset &ds) {
                     }
                     for (uint32_t i = r; i < e; ++i)
                         h4[i] = (sc.hdr[i].gpos % TILE) | sc.hdr[i].cig << 11 | (uint32_t)((sc.hdr[i].seqoff - lo) >> SEQ_ALIGN_LOG2) << 19;
-                    chunks.push_back(ChunkDesc{rbase[p.sample] + r, sbase[p.sample] + lo, p.pad >> 8, k, (e - r) | (e >= p.read_hi ? 1u << 16 : 0u), p.pad & 0xffu});
+                    nchunks.push_back(ChunkDesc{rbase[p.sample] + r, sbase[p.sample] + lo, p.pad >> 8, k, (e - r) | (e >= p.read_hi ? 1u << 16 : 0u), p.pad & 0xffu});
                     r = e;
                 }
                 continue;
             }
             for (uint32_t r = p.read_lo; r < p.read_hi; r += CHUNK_READS) {
                 const uint32_t n = std::min<uint32_t>(CHUNK_READS, p.read_hi - r);
-                chunks.push_back(ChunkDesc{rbase[p.sample] + r, sbase[p.sample], p.pad >> 8, k, n | (r + n >= p.read_hi ? 1u << 16 : 0u), p.pad & 0xffu});
+                nchunks.push_back(ChunkDesc{rbase[p.sample] + r, sbase[p.sample], p.pad >> 8, k, n | (r + n >= p.read_hi ? 1u << 16 : 0u), p.pad & 0xffu});
             }
         }
-        w.chunk_hi = (uint32_t)chunks.size();
+        w.chunk_hi = (uint32_t)(M + nchunks.size());
     }
-    lap("chunks + headers");
-    // ---- merged groups: their piece headers, group by group, and chunks that run across the group's pairs
-    {
-        std::vector<PieceHdr> hm;
-        std::vector<DevMergedSrc> hm_src;                           // fast: the pairs whose headers a kernel writes
-        uint64_t hm_count = 0;
-        std::vector<MergedGroupDev> mgroups;
-        size_t gi = 0;
-        for (uint32_t wi = d->n_work_narrow; wi < d->n_work_narrow + d->n_work_merged; ++wi) {
-            WorkItem &w = work[wi];
-            w.chunk_lo = (uint32_t)(n_chunks_dev + chunks.size());
-            for (; gi < groups.size() && groups[gi].pair_lo >= w.pair_lo && groups[gi].pair_hi <= w.pair_hi; ++gi) {
-                const MergedGroup &g = groups[gi];
-                const uint64_t h0 = fast ? hm_count : hm.size();
-                for (uint32_t k = g.pair_lo; k < g.pair_hi; ++k) {
-                    const TilePair &p = pairs[k];
-                    if (fast) { hm_src.push_back(DevMergedSrc{k, k - g.pair_lo, hm_count}); hm_count += p.read_hi - p.read_lo; continue; }
-                    const SampleCols &sc = ds.samples[p.sample];
-                    for (uint32_t r = p.read_lo; r < p.read_hi; ++r) {
-                        const uint64_t so = (sbase[p.sample] + sc.hdr[r].seqoff) >> SEQ_ALIGN_LOG2;          // 37 bits: bits 32-36 ride in bits 27-31 of the first word
-                        hm.push_back(PieceHdr{(sc.hdr[r].gpos % TILE) | sc.hdr[r].cig << 11 | (k - g.pair_lo) << 19 | (uint32_t)(so >> 32) << 27, (uint32_t)so});
-                    }
-                }
-                const uint64_t n_h = (fast ? hm_count : hm.size()) - h0;
-                mgroups.push_back(MergedGroupDev{h0, w.tile, g.pair_lo, g.pair_hi - g.pair_lo, (uint32_t)n_h});
-                for (uint64_t r = 0; r < n_h; r += CHUNK_READS) {
-                    const uint32_t n = (uint32_t)std::min<uint64_t>(CHUNK_READS, n_h - r);
-                    chunks.push_back(ChunkDesc{h0 + r, 0, pairs[g.pair_lo].sample, g.pair_lo, n | (r + n >= n_h ? 1u << 16 : 0u), g.pair_hi - g.pair_lo});
-                }
-            }
-            w.chunk_hi = (uint32_t)(n_chunks_dev + chunks.size());
-        }
-        if (gi != groups.size()) return fail(MSNV_EINVAL, "internal: merged groups and work items disagree");
-        if (fast) {
-            ds.info.bytes_headers += hm_count * sizeof(PieceHdr);
-            d->n_hdr8m = hm_count;
-            if (int rc = dev_alloc((void **)&d->hdr8m, (hm_count + 1) * sizeof(PieceHdr), &d->device_bytes)) return rc;
-            if (int rc = devfin_merged_headers(ds, *d, hm_src)) return rc;
-        } else {
-            ds.info.bytes_headers += hm.size() * sizeof(PieceHdr);
-            d->n_hdr8m = hm.size();
-            if (int rc = arena.add(&d->hdr8m, hm, &d->device_bytes, 1)) return rc;
-        }
-        d->n_merged_groups = (uint32_t)mgroups.size();
-        d->max_group_pairs = 0;
-        for (const MergedGroupDev &g : mgroups) d->max_group_pairs = std::max(d->max_group_pairs, g.n_pairs);
-        if (int rc = arena.add(&d->merged_groups, mgroups, &d->device_bytes, 1)) return rc;
-        if (int rc = arena.add(&d->tile_pair_merged, tpm, &d->device_bytes)) return rc;
-    }
-    if (!fast) for (size_t wi = 0; wi < (size_t)d->n_work_narrow + d->n_work_merged; ++wi)
-        if (work[wi].chunk_hi > work[wi].chunk_lo) work[wi].first = chunks[work[wi].chunk_lo];
-    d->n_chunks = n_chunks_dev + chunks.size();
-    if (int rc = dev_alloc((void **)&d->chunks, (d->n_chunks + 1) * sizeof(ChunkDesc), &d->device_bytes)) return rc;
-    if (int rc = dev_upload(d->chunks + n_chunks_dev, chunks.data(), chunks.size() * sizeof(ChunkDesc))) return rc;
-    if (fast && !dense) if (int rc = devfin_chunk_fill(ds, *d, n_pairs_listed)) return rc;
+    lap("chunks (host part)");
+    if (!chunks_on_device) for (size_t wi = 0; wi < (size_t)d->n_work_narrow + d->n_work_merged; ++wi)
+        if (work[wi].chunk_hi > work[wi].chunk_lo) work[wi].first = work[wi].chunk_lo < M ? mchunks[work[wi].chunk_lo] : nchunks[work[wi].chunk_lo - M];
+    // ---- the index tables up, in one block; then the kernels that finish them are queued (nothing here waits for them)
     d->n_pairs = (uint32_t)pairs.size(); d->n_work = (uint32_t)work.size();
-    if (!fast) if (int rc = arena.add(&d->pairs, pairs, &d->device_bytes)) return rc;
+    d->n_merged_groups = (uint32_t)mgroups.size();
+    d->max_group_pairs = 0;
+    for (const MergedGroupDev &g : mgroups) d->max_group_pairs = std::max(d->max_group_pairs, g.n_pairs);
+    if (int rc = arena.add(&d->pairs, pairs, &d->device_bytes)) return rc;
+    if (int rc = arena.add(&d->s_read_base, rbase, &d->device_bytes)) return rc;
+    if (int rc = arena.add(&d->s_seq_base, sbase, &d->device_bytes)) return rc;
+    if (int rc = arena.add(&d->merged_groups, mgroups, &d->device_bytes, 1)) return rc;
+    if (int rc = arena.add(&d->tile_pair_merged, tpm, &d->device_bytes)) return rc;
     if (int rc = arena.add(&d->tile_pair_start, tps, &d->device_bytes)) return rc;
     if (int rc = arena.add(&d->work, work, &d->device_bytes)) return rc;
-    if (!fast) if (int rc = arena.add(&d->s_read_base, rbase, &d->device_bytes)) return rc;
-    if (!fast) if (int rc = arena.add(&d->s_seq_base, sbase, &d->device_bytes)) return rc;
+    if (fast) {
+        ds.info.bytes_headers += hm_count * sizeof(PieceHdr);
+        d->n_hdr8m = hm_count;
+    } else {
+        ds.info.bytes_headers += hm.size() * sizeof(PieceHdr);
+        d->n_hdr8m = hm.size();
+        if (int rc = arena.add(&d->hdr8m, hm, &d->device_bytes, 1)) return rc;
+    }
     if (int rc = arena.commit(*d)) return rc;
-    if (fast) if (int rc = devfin_work_first(ds, *d, d->n_work_narrow + d->n_work_merged)) return rc;
+    const uint64_t chunk_room = M + (chunks_on_device ? chunk_cap : nchunks.size());
+    d->n_chunks = M + nchunks.size();                               // (fast, piece layout: the narrow chunks are counted behind finalize's last wait)
+    if (int rc = dev_alloc((void **)&d->chunks, (chunk_room + 1) * sizeof(ChunkDesc), &d->device_bytes)) return rc;
+    if (int rc = dev_upload(d->chunks, mchunks.data(), M * sizeof(ChunkDesc))) return rc;
+    if (int rc = dev_upload(d->chunks + M, nchunks.data(), nchunks.size() * sizeof(ChunkDesc))) return rc;
+    lap("  index tables up");
+    if (fast) {
+        if (int rc = dev_alloc((void **)&d->hdr, (rbase[S] + 1) * sizeof(ReadHdr), &d->device_bytes)) return rc;
+        if (int rc = dev_alloc((void **)&d->hdr8m, (hm_count + 1) * sizeof(PieceHdr), &d->device_bytes)) return rc;
+    }
+    if (chunks_on_device) {
+        // the pieces are in HBM: the chunks of every narrow pair are cut there by a kernel that runs the same greedy rule as the loop above,
+        // the work items learn their ranges there too
+        if (int rc = dev_alloc((void **)&d->hdr4, (rbase[S] + 4) * sizeof(uint32_t), &d->device_bytes)) return rc;
+        if (int rc = dev_memset_async(d->hdr4, 0, (rbase[S] + 4) * sizeof(uint32_t), ds.ctx->stream)) return rc;
+        if (int rc = devfin_chunks_launch(ds, *d, narrow_pairs, item_first, (uint32_t)M, chunk_cap)) return rc;
+    }
+    if (fast) {
+        if (int rc = devfin_merged_headers(ds, *d, hm_src)) return rc;
+        if (int rc = devfin_work_first(ds, *d, d->n_work_narrow + d->n_work_merged)) return rc;
+        if (int rc = devfin_headers(ds, *d, rbase)) return rc;     // (the 16-byte headers with linear positions: wide kernel, padding, host mapping -- behind everything the first pass waits for)
+    }
 
     lap("merged groups");
     // ---- columns
@@ -1540,7 +1539,11 @@ int finalize_dataset(msnv_dataset &ds) {
         {   // device-packed samples: the alignment padding behind their pieces, then their round buffers and the pack tables go back
             std::vector<uint8_t> on_dev(S, 0);
             for (size_t s = 0; s < S; ++s) on_dev[s] = ds.samples[s].on_device ? 1 : 0;
-            if (!dense) if (int rc = devpack_fill_padding(*d, on_dev, ds.ctx ? ds.ctx->stream : nullptr)) return rc;
+            // (round 6: the device pack's emit kernels leave the padding in place -- the pass over every piece is only taken when a FASTA record
+            // is longer than its contig, where "the reference" behind the contig's last tile position differs between the two)
+            bool fasta_longer = false;
+            for (size_t c = 0; c < NC; ++c) if (ds.sel[c] && ds.has_seq[c] && (int64_t)ds.seqs[c].size() > maxend[c]) fasta_longer = true;
+            if (!dense && (!ds.dp.pad_in_emit || fasta_longer || getenv("MSNV_FILL_PADDING"))) if (int rc = devpack_fill_padding(*d, on_dev, ds.ctx ? ds.ctx->stream : nullptr)) return rc;
         }
         for (size_t s = 0; s < S; ++s) {
             const SampleCols &sc = ds.samples[s];
@@ -1554,114 +1557,11 @@ int finalize_dataset(msnv_dataset &ds) {
     d->algorithmic_bytes = alg;                  // SURVEY.md section 8d figure; the shipped bytes are bytes_headers + bytes_seq + bytes_qual
 
     lap("columns");
-    // ---- genome coverage index: intervals of qaCompute's difference array, grouped by tile
-    {
-        std::vector<Pair32> iv;
-        std::vector<uint64_t> cvbase(S + 1, 0);
-        struct CP { uint32_t tile, sample, lo, hi; };
-        std::vector<std::vector<CP>> per(S);
-        if (fast) {
-            // the intervals are in HBM: filtered, made linear and grouped by (sample, tile) there (devpack.hip: devfin_coverage)
-            std::vector<DevCovPair> cp;
-            if (int rc = devfin_coverage(ds, *d, cvbase, cp)) return rc;
-            lap("  devfin_coverage");
-            for (const DevCovPair &c : cp) per[c.sample].push_back(CP{c.tile, c.sample, c.lo, c.hi});
-        }
-        else for (size_t s = 0; s < S; ++s) {
-            const SampleCols &sc = ds.samples[s];
-            uint32_t n_here = 0;
-            for (size_t i = 0; i < sc.cov_tid.size(); ++i) {
-                const size_t c = (size_t)sc.cov_tid[i];
-                const int64_t L = ds.lengths[c];
-                const int64_t b = sc.cov_beg[i];
-                const bool minus_one = b > sc.cov_end[i];                          // {L, L - 1}: "-1 at L - 1" (pack_sample)
-                const int64_t e = minus_one ? sc.cov_end[i] : (sc.cov_end[i] >= L ? L - 1 : sc.cov_end[i]);       // qaCompute.cpp:544-549
-                if (!minus_one && b >= e) continue;
-                const uint64_t g0 = (uint64_t)ds.tile_base[c] * TILE;
-                const uint32_t idx = n_here++;
-                iv.push_back(Pair32{(uint32_t)(g0 + (uint64_t)b), (uint32_t)(g0 + (uint64_t)e)});
-                std::vector<CP> &pv = per[s];
-                const uint32_t t_first = (uint32_t)((g0 + (uint64_t)(minus_one ? e : b)) / TILE), t_last = minus_one ? t_first : (uint32_t)((g0 + e - 1) / TILE);
-                for (uint32_t t = t_first; t <= t_last; ++t) {
-                    size_t k = pv.size();
-                    while (k > 0 && pv[k - 1].tile > t) --k;
-                    if (k > 0 && pv[k - 1].tile == t) pv[k - 1].hi = idx + 1;
-                    else pv.insert(pv.begin() + (ptrdiff_t)k, CP{t, (uint32_t)s, idx, idx + 1});
-                }
-            }
-            cvbase[s + 1] = cvbase[s] + n_here;
-        }
-        std::vector<uint32_t> cps(nt + 1, 0);
-        for (size_t s = 0; s < S; ++s) for (const CP &p : per[s]) cps[p.tile + 1]++;
-        for (uint64_t t = 0; t < nt; ++t) cps[t + 1] += cps[t];
-        std::vector<TilePair> cpairs(cps[nt]);
-        {
-            std::vector<uint32_t> fill(cps.begin(), cps.end() - 1);
-            // blk_lo / nblk: absolute index of the sample's first interval (the kernel needs no per-sample base lookup)
-            // max_depth: the accumulator row of the pair's (sample, contig) -- rows exist for the combinations that have intervals only
-            ds.cov_row_sample.clear(); ds.cov_row_contig.clear(); ds.cov_row_start.assign(S + 1, 0);
-            for (size_t s = 0; s < S; ++s) {
-                ds.cov_row_start[s] = ds.cov_row_sample.size();
-                uint32_t last_contig = UINT32_MAX;
-                for (const CP &p : per[s]) {                      // (tile order = contig order)
-                    const uint32_t c = ds.tile_contig[p.tile];
-                    if (c != last_contig) { ds.cov_row_sample.push_back((uint32_t)s); ds.cov_row_contig.push_back(c); last_contig = c; }
-                    if (ds.cov_row_sample.size() > 0xffffffffull) return fail(MSNV_EDOMAIN, "more than 2^32 (sample, contig) pairs with coverage in one shard");
-                    cpairs[fill[p.tile]++] = TilePair{p.sample, p.lo, p.hi, (uint32_t)(ds.cov_row_sample.size() - 1), (uint32_t)cvbase[s], (uint32_t)(cvbase[s] >> 32), 0, 0};
-                }
-            }
-            ds.cov_row_start[S] = ds.cov_row_sample.size();
-        }
-        std::vector<WorkItem> cwork;
-        // a coverage work item = COV_ITEM_PAIRS consecutive pairs of a tile = one wavefront of msnv_coverage_tiles, which loads their
-        // descriptors up front and a pair's intervals while it works on the pair before (fewer when one pair alone is deep:
-        // MSNV_COV_ITEM intervals)
-        const uint64_t cov_item_intervals = [] { const char *e = getenv("MSNV_COV_ITEM"); const long long v = e ? atoll(e) : 16384; return (uint64_t)(v > 0 ? v : 16384); }();
-        for (uint64_t t = 0; t < nt; ++t) {
-            uint32_t lo = cps[t]; uint64_t acc = 0;
-            for (uint32_t k = cps[t]; k < cps[t + 1]; ++k) {
-                acc += cpairs[k].read_hi - cpairs[k].read_lo;
-                if (acc >= cov_item_intervals || k + 1 - lo >= COV_ITEM_PAIRS || k + 1 == cps[t + 1]) { cwork.push_back(WorkItem{(uint32_t)t, lo, k + 1, 0, 0, 0, 0, 0, ChunkDesc{}}); lo = k + 1; acc = 0; }
-            }
-        }
-        // the items with a pair of more than 32 767 intervals go last: msnv_coverage_tiles<true> (one word per position) runs them,
-        // the 16-bit difference array of the usual variant holds +-32 767 per position and per 16 positions of one parity
-        // (MSNV_COV_NARROW_MAX is read per dataset: tests lower it to run the other variant)
-        const uint32_t cov_narrow_max = [] { const char *e = getenv("MSNV_COV_NARROW_MAX"); const long long v = e ? atoll(e) : 32767; return (uint32_t)std::min<long long>(32767, std::max<long long>(1, v)); }();
-        auto cov_wide = [&](const WorkItem &w) { for (uint32_t k = w.pair_lo; k < w.pair_hi; ++k) if (cpairs[k].read_hi - cpairs[k].read_lo > cov_narrow_max) return true; return false; };
-        const auto first_wide = std::stable_partition(cwork.begin(), cwork.end(), [&](const WorkItem &w) { return !cov_wide(w); });
-        d->n_cov_work_wide = (uint32_t)(cwork.end() - first_wide);
-        std::vector<uint32_t> tlen(nt + 1, 0), tcont(nt + 1, 0);
-        for (uint64_t t = 0; t < nt; ++t) {
-            const size_t c = ds.tile_contig[t];
-            const int64_t t0 = (int64_t)(t - ds.tile_base[c]) * TILE;
-            tlen[t] = (uint32_t)std::min<int64_t>(std::max<int64_t>(ds.lengths[c] - t0, 0), TILE);
-            tcont[t] = (uint32_t)c;
-        }
-        if (!fast) d->n_cov_iv = iv.size();
-        for (int k = 0; k < 4; ++k) iv.push_back(Pair32{0u, 0u});     // behind the last interval: what the idle lanes of msnv_coverage_tiles load, four at a time (they touch nothing)
-        d->n_cov_pairs = (uint32_t)cpairs.size(); d->n_cov_work = (uint32_t)cwork.size(); d->n_contigs = (uint32_t)NC;
-        if (!fast) if (int rc = arena.add(&d->cov_iv, iv, &d->device_bytes, 1)) return rc;
-        if (int rc = arena.add(&d->s_cov_base, cvbase, &d->device_bytes)) return rc;
-        if (int rc = arena.add(&d->cov_pairs, cpairs, &d->device_bytes, 1)) return rc;
-        if (int rc = arena.add(&d->cov_work, cwork, &d->device_bytes, 1)) return rc;
-        if (int rc = arena.add(&d->tile_len, tlen, &d->device_bytes)) return rc;
-        if (int rc = arena.add(&d->tile_contig_dev, tcont, &d->device_bytes)) return rc;
-        if (int rc = arena.commit(*d)) return rc;
-        // accumulator copies: as many as fit 64 MB, at most 8 (many contigs = few tiles per contig = little contention anyway)
-        d->n_cov_rows = ds.cov_row_sample.size();
-        const uint64_t acc_bytes = std::max<uint64_t>(1, d->n_cov_rows) * (1 + COV_BINS) * sizeof(unsigned long long);
-        d->cov_copies = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(8, (64ull << 20) / std::max<uint64_t>(1, acc_bytes)));
-        if (int rc = dev_alloc((void **)&d->cov_acc, d->cov_copies * acc_bytes, &d->device_bytes)) return rc;
-    }
-
-    lap("  coverage tables");
-    if (int rc = devpack_finish(ds)) return rc;                // (device-packed samples: the rounds' buffers and the pack tables go back)
-
-    lap("coverage index");
-    // ---- intermediates
+    // ---- intermediates (before the coverage index: their allocations and fills -- queued on the context's stream, in front of the first
+    // pass -- run while the device still works on the index; the coverage index below holds finalize's last wait)
+    void *const fin_stream = ds.ctx ? ds.ctx->stream : nullptr;
     if (int rc = dev_alloc((void **)&d->tot, std::max<uint64_t>(1, 4 * npos) * sizeof(uint32_t), &d->device_bytes)) return rc;
-    if (int rc = dev_memset(d->tot, 0, std::max<uint64_t>(1, 4 * npos) * sizeof(uint32_t))) return rc;   // the gate kernel keeps it zero between passes
+    if (int rc = dev_memset_async(d->tot, 0, std::max<uint64_t>(1, 4 * npos) * sizeof(uint32_t), fin_stream)) return rc;   // the gate kernel keeps it zero between passes
     if (int rc = dev_alloc((void **)&d->spill, std::max<uint64_t>(1, (uint64_t)pairs.size()) * TILE, &d->device_bytes)) return rc;
     double est_events = 0.0;                                        // mismatching bases the sampled rate predicts: what the event list is sized by
     {
@@ -1690,7 +1590,7 @@ int finalize_dataset(msnv_dataset &ds) {
         if (planes) {
             const uint64_t bytes = (uint64_t)pairs.size() * 4 * TILE;
             if (int rc = dev_alloc((void **)&d->aspill, bytes, &d->device_bytes)) return rc;
-            if (int rc = dev_memset(d->aspill, 0, bytes)) return rc;      // (rows of merged pairs are never written and never read)
+            if (int rc = dev_memset_async(d->aspill, 0, bytes, fin_stream)) return rc;      // (rows of merged pairs are never written and never read)
         }
         ds.info.allele_planes = planes ? 1 : 0;
         ds.info.sampled_mismatch_ppm = (uint64_t)(rate * 1e6);
@@ -1708,29 +1608,176 @@ int finalize_dataset(msnv_dataset &ds) {
     if (int rc = dev_alloc((void **)&d->unc_sites, (uint64_t)d->cap_sites * sizeof(uint32_t), &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->site_row, (npos / 64 + 1) * sizeof(unsigned long long), &d->device_bytes)) return rc;   // per 64 positions (kernels.hip: CellMap::block_row)
     if (int rc = dev_alloc((void **)&d->tile_dirty, ((uint64_t)work.size() + 1) * sizeof(uint32_t), &d->device_bytes)) return rc;    // one word per work item (by slot)
-    if (int rc = dev_memset(d->tile_dirty, 0, ((uint64_t)work.size() + 1) * sizeof(uint32_t))) return rc;
+    if (int rc = dev_memset_async(d->tile_dirty, 0, ((uint64_t)work.size() + 1) * sizeof(uint32_t), fin_stream)) return rc;
     // no memset per pass: the counter blocks alternate (the gate kernel zeroes the next one) and the gate kernel leaves the
     // individual-rule bits it consumes zero, like the allele totals
     if (int rc = dev_alloc((void **)&d->counters, 2 * CNT_WORDS * sizeof(uint32_t), &d->device_bytes)) return rc;
-    if (int rc = dev_memset(d->counters, 0, 2 * CNT_WORDS * sizeof(uint32_t))) return rc;
+    if (int rc = dev_memset_async(d->counters, 0, 2 * CNT_WORDS * sizeof(uint32_t), fin_stream)) return rc;
     if (int rc = dev_alloc((void **)&d->ind4, (npos / 8 + npos / 32 + 2) * sizeof(uint32_t), &d->device_bytes)) return rc;
-    if (int rc = dev_memset(d->ind4, 0, (npos / 8 + npos / 32 + 2) * sizeof(uint32_t))) return rc;
+    if (int rc = dev_memset_async(d->ind4, 0, (npos / 8 + npos / 32 + 2) * sizeof(uint32_t), fin_stream)) return rc;
     d->unc_bits = d->ind4 + npos / 8 + 1;
     for (const TilePair &tp : pairs) if ((tp.pad & 0xffu) == 1) { d->any_split = true; break; }
     if (int rc = dev_alloc((void **)&d->site_bits, (npos / 64 + 1) * sizeof(unsigned long long), &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->site_rank, (npos / 64 + 1) * sizeof(uint32_t), &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->tile_site_base, (nt + 1) * sizeof(uint32_t), &d->device_bytes)) return rc;
     if (int rc = dev_alloc((void **)&d->tile_site_cnt, (nt + 1) * sizeof(uint32_t), &d->device_bytes)) return rc;
-    if (int rc = dev_memset(d->tile_site_cnt, 0, (nt + 1) * sizeof(uint32_t))) return rc;
-    if (int rc = dev_memset(d->tile_site_base, 0, (nt + 1) * sizeof(uint32_t))) return rc;
+    if (int rc = dev_memset_async(d->tile_site_cnt, 0, (nt + 1) * sizeof(uint32_t), fin_stream)) return rc;
+    if (int rc = dev_memset_async(d->tile_site_base, 0, (nt + 1) * sizeof(uint32_t), fin_stream)) return rc;
 
     ds.info.n_samples = S; ds.info.n_contigs = 0; ds.info.n_positions = 0;
     for (size_t c = 0; c < NC; ++c) if (ds.sel[c]) { ds.info.n_contigs++; ds.info.n_positions += (uint64_t)ds.lengths[c]; }
     ds.info.n_reads = tot_reads; ds.info.n_reads_pileup = tot_pile_reads; ds.info.n_pileup_bases = tot_bases;
     ds.info.n_tiles = nt; ds.info.n_pairs = pairs.size(); ds.info.n_work = work.size();
+    lap("intermediates");
+
+    // ---- genome coverage index: intervals of qaCompute's difference array, grouped by tile
+    {
+        std::vector<Pair32> iv;
+        std::vector<uint64_t> cvbase(S + 1, 0);
+        struct CP { uint32_t tile, sample, lo, hi; };
+        std::vector<CP> flat;                                        // all samples' (tile, sample) runs, sample after sample, tiles ascending inside a sample
+        if (fast) {
+            // the intervals are in HBM: filtered, made linear and grouped by (sample, tile) there (devpack.hip: devfin_coverage); the runs come
+            // back sample-major with the tiles ascending, which is the order the loops below want
+            std::vector<DevCovPair> cp;
+            if (int rc = devfin_coverage(ds, *d, cvbase, cp)) return rc;
+            lap("  devfin_coverage");
+            flat.resize(cp.size());
+            bool ordered = true;
+            for (size_t i = 0; i < cp.size(); ++i) {
+                flat[i] = CP{cp[i].tile, cp[i].sample, cp[i].lo, cp[i].hi};
+                if (i && (cp[i].sample < cp[i - 1].sample || (cp[i].sample == cp[i - 1].sample && cp[i].tile < cp[i - 1].tile))) ordered = false;
+            }
+            if (!ordered) std::stable_sort(flat.begin(), flat.end(), [](const CP &a, const CP &b) { return a.sample != b.sample ? a.sample < b.sample : a.tile < b.tile; });
+        }
+        else {
+        std::vector<std::vector<CP>> per(S);
+        for (size_t s = 0; s < S; ++s) {
+            const SampleCols &sc = ds.samples[s];
+            uint32_t n_here = 0;
+            for (size_t i = 0; i < sc.cov_tid.size(); ++i) {
+                const size_t c = (size_t)sc.cov_tid[i];
+                const int64_t L = ds.lengths[c];
+                const int64_t b = sc.cov_beg[i];
+                const bool minus_one = b > sc.cov_end[i];                          // {L, L - 1}: "-1 at L - 1" (pack_sample)
+                const int64_t e = minus_one ? sc.cov_end[i] : (sc.cov_end[i] >= L ? L - 1 : sc.cov_end[i]);       // qaCompute.cpp:544-549
+                if (!minus_one && b >= e) continue;
+                const uint64_t g0 = (uint64_t)ds.tile_base[c] * TILE;
+                const uint32_t idx = n_here++;
+                iv.push_back(Pair32{(uint32_t)(g0 + (uint64_t)b), (uint32_t)(g0 + (uint64_t)e)});
+                std::vector<CP> &pv = per[s];
+                const uint32_t t_first = (uint32_t)((g0 + (uint64_t)(minus_one ? e : b)) / TILE), t_last = minus_one ? t_first : (uint32_t)((g0 + e - 1) / TILE);
+                for (uint32_t t = t_first; t <= t_last; ++t) {
+                    size_t k = pv.size();
+                    while (k > 0 && pv[k - 1].tile > t) --k;
+                    if (k > 0 && pv[k - 1].tile == t) pv[k - 1].hi = idx + 1;
+                    else pv.insert(pv.begin() + (ptrdiff_t)k, CP{t, (uint32_t)s, idx, idx + 1});
+                }
+            }
+            cvbase[s + 1] = cvbase[s] + n_here;
+        }
+        for (size_t s = 0; s < S; ++s) flat.insert(flat.end(), per[s].begin(), per[s].end());
+        }
+        // one pass for the tile counts, one for the pairs (sample order inside a tile comes with the order of `flat`) and the accumulator rows
+        std::vector<uint32_t> cps(nt + 1, 0);
+        for (const CP &p : flat) cps[p.tile + 1]++;
+        for (uint64_t t = 0; t < nt; ++t) cps[t + 1] += cps[t];
+        std::vector<TilePair> cpairs(cps[nt]);
+        {
+            std::vector<uint32_t> fill(cps.begin(), cps.end() - 1);
+            // blk_lo / nblk: absolute index of the sample's first interval (the kernel needs no per-sample base lookup)
+            // max_depth: the accumulator row of the pair's (sample, contig) -- rows exist for the combinations that have intervals only
+            ds.cov_row_sample.clear(); ds.cov_row_contig.clear(); ds.cov_row_start.assign(S + 1, 0);
+            size_t i = 0;
+            for (size_t s = 0; s < S; ++s) {
+                ds.cov_row_start[s] = ds.cov_row_sample.size();
+                uint32_t last_contig = UINT32_MAX;
+                for (; i < flat.size() && flat[i].sample == s; ++i) {                     // (tile order = contig order)
+                    const CP &p = flat[i];
+                    const uint32_t c = ds.tile_contig[p.tile];
+                    if (c != last_contig) { ds.cov_row_sample.push_back((uint32_t)s); ds.cov_row_contig.push_back(c); last_contig = c; }
+                    if (ds.cov_row_sample.size() > 0xffffffffull) return fail(MSNV_EDOMAIN, "more than 2^32 (sample, contig) pairs with coverage in one shard");
+                    cpairs[fill[p.tile]++] = TilePair{p.sample, p.lo, p.hi, (uint32_t)(ds.cov_row_sample.size() - 1), (uint32_t)cvbase[s], (uint32_t)(cvbase[s] >> 32), 0, 0};
+                }
+            }
+            ds.cov_row_start[S] = ds.cov_row_sample.size();
+        }
+        lap("    cov tables: pairs by tile, rows");
+        std::vector<WorkItem> cwork;
+        cwork.reserve(cpairs.size() / 2 + nt + 16);
+        // a coverage work item = COV_ITEM_PAIRS consecutive pairs of a tile = one wavefront of msnv_coverage_tiles, which loads their
+        // descriptors up front and a pair's intervals while it works on the pair before (fewer when one pair alone is deep:
+        // MSNV_COV_ITEM intervals)
+        const uint64_t cov_item_intervals = [] { const char *e = getenv("MSNV_COV_ITEM"); const long long v = e ? atoll(e) : 16384; return (uint64_t)(v > 0 ? v : 16384); }();
+        for (uint64_t t = 0; t < nt; ++t) {
+            uint32_t lo = cps[t]; uint64_t acc = 0;
+            for (uint32_t k = cps[t]; k < cps[t + 1]; ++k) {
+                acc += cpairs[k].read_hi - cpairs[k].read_lo;
+                if (acc >= cov_item_intervals || k + 1 - lo >= COV_ITEM_PAIRS || k + 1 == cps[t + 1]) { cwork.push_back(WorkItem{(uint32_t)t, lo, k + 1, 0, 0, 0, 0, 0, ChunkDesc{}}); lo = k + 1; acc = 0; }
+            }
+        }
+        // the items with a pair of more than 32 767 intervals go last: msnv_coverage_tiles<true> (one word per position) runs them,
+        // the 16-bit difference array of the usual variant holds +-32 767 per position and per 16 positions of one parity
+        // (MSNV_COV_NARROW_MAX is read per dataset: tests lower it to run the other variant)
+        const uint32_t cov_narrow_max = [] { const char *e = getenv("MSNV_COV_NARROW_MAX"); const long long v = e ? atoll(e) : 32767; return (uint32_t)std::min<long long>(32767, std::max<long long>(1, v)); }();
+        auto cov_wide = [&](const WorkItem &w) { for (uint32_t k = w.pair_lo; k < w.pair_hi; ++k) if (cpairs[k].read_hi - cpairs[k].read_lo > cov_narrow_max) return true; return false; };
+        bool any_wide = false;
+        for (const TilePair &q : cpairs) if (q.read_hi - q.read_lo > cov_narrow_max) { any_wide = true; break; }
+        d->n_cov_work_wide = 0;
+        if (any_wide) {
+            const auto first_wide = std::stable_partition(cwork.begin(), cwork.end(), [&](const WorkItem &w) { return !cov_wide(w); });
+            d->n_cov_work_wide = (uint32_t)(cwork.end() - first_wide);
+        }
+        lap("    cov tables: work items");
+        std::vector<uint32_t> tlen(nt + 1, 0), tcont(nt + 1, 0);
+        for (uint64_t t = 0; t < nt; ++t) {
+            const size_t c = ds.tile_contig[t];
+            const int64_t t0 = (int64_t)(t - ds.tile_base[c]) * TILE;
+            tlen[t] = (uint32_t)std::min<int64_t>(std::max<int64_t>(ds.lengths[c] - t0, 0), TILE);
+            tcont[t] = (uint32_t)c;
+        }
+        if (!fast) d->n_cov_iv = iv.size();
+        for (int k = 0; k < 4; ++k) iv.push_back(Pair32{0u, 0u});     // behind the last interval: what the idle lanes of msnv_coverage_tiles load, four at a time (they touch nothing)
+        d->n_cov_pairs = (uint32_t)cpairs.size(); d->n_cov_work = (uint32_t)cwork.size(); d->n_contigs = (uint32_t)NC;
+        if (!fast) if (int rc = arena.add(&d->cov_iv, iv, &d->device_bytes, 1)) return rc;
+        if (int rc = arena.add(&d->s_cov_base, cvbase, &d->device_bytes)) return rc;
+        if (int rc = arena.add(&d->cov_pairs, cpairs, &d->device_bytes, 1)) return rc;
+        if (int rc = arena.add(&d->cov_work, cwork, &d->device_bytes, 1)) return rc;
+        if (int rc = arena.add(&d->tile_len, tlen, &d->device_bytes)) return rc;
+        if (int rc = arena.add(&d->tile_contig_dev, tcont, &d->device_bytes)) return rc;
+        lap("    cov tables: staged");
+        if (int rc = arena.commit(*d)) return rc;
+        lap("    cov tables: up");
+        // accumulator copies: as many as fit 64 MB, at most 8 (many contigs = few tiles per contig = little contention anyway)
+        d->n_cov_rows = ds.cov_row_sample.size();
+        const uint64_t acc_bytes = std::max<uint64_t>(1, d->n_cov_rows) * (1 + COV_BINS) * sizeof(unsigned long long);
+        d->cov_copies = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(8, (64ull << 20) / std::max<uint64_t>(1, acc_bytes)));
+        if (int rc = dev_alloc((void **)&d->cov_acc, d->cov_copies * acc_bytes, &d->device_bytes)) return rc;
+    }
+
+    lap("  coverage tables");
+    // ---- behind the last wait: how many chunks the narrow items got (cut in HBM, counted there)
+    if (chunks_on_device) {
+        uint64_t n_narrow = 0; bool overflow = false;
+        devfin_chunks_result(ds, &n_narrow, &overflow);
+        if (overflow) {
+            // (more chunks than the bound gave room for: once more with the exact number, which is known now)
+            dev_free(d->chunks); d->chunks = nullptr;
+            if (M + n_narrow > 0xfffffff0ull) return fail(MSNV_EDOMAIN, "more than 2^32 chunks in one shard");
+            if (int rc = dev_alloc((void **)&d->chunks, (M + n_narrow + 1) * sizeof(ChunkDesc), &d->device_bytes)) return rc;
+            if (int rc = dev_upload(d->chunks, mchunks.data(), M * sizeof(ChunkDesc))) return rc;
+            if (int rc = devfin_chunks_launch(ds, *d, narrow_pairs, item_first, (uint32_t)M, n_narrow)) return rc;
+            if (int rc = devfin_work_first(ds, *d, d->n_work_narrow + d->n_work_merged)) return rc;
+            if (int rc = dev_stream_wait(fin_stream)) return rc;
+            devfin_chunks_result(ds, &n_narrow, &overflow);
+            if (overflow) return fail(MSNV_EINVAL, "internal: the chunk count changed between two cuts of the same pairs");
+        }
+        d->n_chunks = M + n_narrow;
+    }
+    if (int rc = devpack_finish(ds)) return rc;                // (device-packed samples: the rounds' buffers and the pack tables go back)
+    lap("pack tables released");
     ds.info.bytes_index = pairs.size() * sizeof(TilePair) + work.size() * sizeof(WorkItem) + d->n_chunks * sizeof(ChunkDesc) + (nt + 1) * 4;
     ds.info.device_bytes = d->device_bytes;
-    lap("intermediates");
     ds.finalized = true;
     return MSNV_OK;
 }

@@ -487,3 +487,19 @@ def test_a_bam_group_that_fails_behind_a_packed_group_poisons_the_dataset(tmp_pa
             ds.close()
     finally:
         ctx.close()
+
+
+def test_the_emit_kernels_two_routes_write_the_same_columns():
+    """msnv_emit_block (one lane per record cuts the pieces, the workgroup moves them through an LDS image) leaves the blocks that do not fit
+    that form to msnv_emit_block_slow (four lanes per record from global memory); MSNV_EMIT=slow sends every block there.  Both against
+    the host pack, column by column -- with indels, clips and tile crossings (further pieces), reads of 180 bases (blocks beyond the
+    window) and a cohort whose samples are smaller than a block (two samples in one block)."""
+    for kw in (dict(n_species=2, contig_len=9000, n_samples=6, mean_cov=14.0, snv_density=0.02, error_rate=0.01, seed=31),
+               dict(n_species=1, contig_len=7000, n_samples=3, mean_cov=9.0, read_len=180, seed=32),
+               dict(n_species=3, contig_len=2500, n_samples=12, mean_cov=1.5, seed=33)):
+        syn, samples = synth_case(**kw)
+        _same_dataset(syn.names, syn.lengths, syn.seqs, samples, many=True, check_oracle=False)
+        with _env(MSNV_EMIT="slow"):
+            _same_dataset(syn.names, syn.lengths, syn.seqs, samples, many=True, check_oracle=False)
+        with _env(MSNV_FILL_PADDING="1"):
+            _same_dataset(syn.names, syn.lengths, syn.seqs, samples, many=True, check_oracle=False)
