@@ -152,6 +152,7 @@ struct DevPackTables {
     // needs the round finished calls first (the next round, finalize before it decides the allele bookkeeping, the statistics, release)
     struct Pending { bool active = false; size_t first = 0, n = 0; void *ev0 = nullptr, *ev1 = nullptr; } pending;
     bool      any_overhang_h = false; // some read of some round runs past its contig (msnv_measure_reads): finalize fetches `overhang`
+    void     *cov_event = nullptr;   // recorded behind those kernels: what devfin_coverage waits for
     void     *cov_job = nullptr, *cov_tmp = nullptr, *cov_runs = nullptr; bool cov_launched = false;   // finalize: the coverage index's kernels launched ahead of their results (devfin_coverage_launch)
     void     *fin_tile_base = nullptr;                     // finalize on the device: the contigs' first tiles (devfin_headers)
     void     *fin_list = nullptr, *fin_cbase = nullptr;   // finalize on the device: the narrow pairs' list and their chunk counts / scan, between devfin_chunk_counts and devfin_chunk_fill

@@ -1232,7 +1232,7 @@ struct PieceDesc { uint32_t seq_o, qual_o, q0, so, ref_lo, ref_hi, ref_left, nf;
                                                                                        // column, reference nibble index (64 bit) + FASTA characters from there, n | sampled << 8 | padding nibbles inside the tile << 9
 constexpr uint32_t EQ_CAP = 32;                                   // further pieces a block of the quick form holds
 __device__ __forceinline__ void emit_walk(const EmitArgs &A, const LdsSrcK &src, unsigned long long rec_o, const RecCnt me, uint8_t f, uint16_t depth, const DpSampleDst &d, unsigned long long sbase0,
-                                          PieceDesc *first_slot, PieceDesc *more_slots) {
+                                          const DpContig &c, const uint2 pf, const uint2 pe, PieceDesc *first_slot, PieceDesc *more_slots) {
     PieceDesc none{}; none.nf = 0u;
     *first_slot = none;
     if (!(f & (RF_PILE | RF_COV))) return;
@@ -1242,12 +1242,6 @@ __device__ __forceinline__ void emit_walk(const EmitArgs &A, const LdsSrcK &src,
     const uint32_t n_cigar = fn & 0xffffu, l_name = w3 & 0xffu, mapq = (w3 >> 8) & 0xffu;
     const unsigned long long cig_o = rec_o + 36 + l_name;
     const unsigned long long seq_o = cig_o + 4ull * n_cigar, qual_o = seq_o + ((unsigned long long)(uint32_t)l_seq + 1) / 2;
-    const DpContig c = A.ctg[tid];
-    uint2 pf = make_uint2(0u, 0u), pe = make_uint2(0u, 0u);
-    if ((f & RF_PILE) && !A.in_order) {
-        const uint32_t gi = (uint32_t)A.rg[me.pile] - 1u;
-        pf = A.grp_pre[gi]; pe = A.grp_pre[gi + 1u];
-    }
     const bool noseq = l_seq == 0;
     const bool cov = (f & RF_COV) != 0, pile = (f & RF_PILE) && !(noseq && !A.noseq_counts);
     if (!cov && !pile) return;
@@ -1346,7 +1340,17 @@ __global__ __launch_bounds__(256) void msnv_emit_block(const EmitArgs A) {
     const DpSampleDst d = A.dst[smp_first];
     if (tid < PB) {
         // ---- phase A (one wavefront): every record's own places = the block's base + the sums of the records before it in the block
+        // (its group's words and its contig are asked for here, not under the window's loads: the window's way into LDS would wait for
+        // these chains of dependent loads -- measured: 2.24 -> 2.38 ms)
         const RecCnt pre = cnt_add(base, wave_excl_cnt(mine));
+        DpContig ctg_mine{}; uint2 pf = make_uint2(0u, 0u), pe = make_uint2(0u, 0u);
+        if (tid < nrec) {
+            if ((f & RF_PILE) && !A.in_order) {
+                const uint32_t gi = (uint32_t)A.rg[pre.pile] - 1u;
+                pf = A.grp_pre[gi]; pe = A.grp_pre[gi + 1u];
+            }
+            if (f & (RF_PILE | RF_COV)) ctg_mine = A.ctg[(int32_t)lsrc.ld32(ro - lo + 4)];
+        }
         uint32_t more = mine.npiece ? mine.npiece - 1u : 0u, more_pre = more;
         for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(more_pre, o); if ((int)tid >= o) more_pre += y; }
         const uint32_t more_all = __shfl(more_pre, 63);
@@ -1365,7 +1369,7 @@ __global__ __launch_bounds__(256) void msnv_emit_block(const EmitArgs A) {
             if (odd) A.slow[1u + atomicAdd(A.slow, 1u)] = b;
         }
         if (!odd) {
-            if (tid < nrec) emit_walk(A, lsrc, ro - lo, pre, f, depth, d, sb0, &s_desc[tid], &s_desc[PB + more_pre]);
+            if (tid < nrec) emit_walk(A, lsrc, ro - lo, pre, f, depth, d, sb0, ctg_mine, pf, pe, &s_desc[tid], &s_desc[PB + more_pre]);
             else { PieceDesc none{}; s_desc[tid] = none; }
         }
     }
@@ -1693,6 +1697,7 @@ void devpack_release(msnv_dataset &ds) {
     DevPackTables &t = ds.dp;
     if (t.pending.active) { (void)hipDeviceSynchronize(); t.pending.active = false; }
     if (t.pending.ev0) { (void)hipEventDestroy((hipEvent_t)t.pending.ev0); (void)hipEventDestroy((hipEvent_t)t.pending.ev1); t.pending.ev0 = t.pending.ev1 = nullptr; }
+    if (t.cov_event) { (void)hipEventDestroy((hipEvent_t)t.cov_event); t.cov_event = nullptr; }
     if (t.cov_job || !t.fin_keep.empty()) (void)hipDeviceSynchronize();
     // everything of the pack goes back in ONE batch (one wait for the device instead of one per buffer: dev_free_batch)
     std::vector<void *> out;
@@ -3207,6 +3212,10 @@ int devfin_coverage_launch(msnv_dataset &ds, DeviceCols &d) {
     hipLaunchKernelGGL(msnv_fin_cov_dense_runs, grid_for(n_tab, 256), dim3(256), 0, st, lo, hi, rid, n_tab, ds.n_tiles, runs);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(pin_fin_words(T), cvb, (S + 3) * 4, hipMemcpyDeviceToHost, st));      // (pinned: the copy does not wait on the host)
+    // an event behind the index's kernels: devfin_coverage waits for IT, not for the stream -- the chunk and header kernels finalize queues
+    // behind these run while the host builds the coverage pair tables (round 6)
+    if (!T.cov_event) { hipEvent_t e = nullptr; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); T.cov_event = e; }
+    HIP_TRY(hipEventRecord((hipEvent_t)T.cov_event, st));
     T.cov_tmp = pr.tmp.release();                                  // (rocPRIM's work memory: in use until the kernels above have run)
     T.cov_launched = true;
     return MSNV_OK;
@@ -3223,17 +3232,15 @@ int devfin_coverage(msnv_dataset &ds, DeviceCols &d, std::vector<uint64_t> &cvba
         // the kernels were launched ahead (devfin_coverage_launch): their results are in the pinned words, the runs in HBM
         DevPackTables &T = ds.dp;
         T.cov_launched = false;
-        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipEventSynchronize((hipEvent_t)T.cov_event));
         const uint32_t *pw = pin_fin_words(T);
         for (size_t s = 0; s <= S; ++s) cvbase[s] = pw[s];
         const uint32_t n_keep = pw[S + 1], n_runs = pw[S + 2];
         d.n_cov_iv = n_keep;
         HIP_TRY(hipMemsetAsync(d.cov_iv + n_keep, 0, 4 * sizeof(Pair32), st));              // behind the last interval: what the idle lanes of msnv_coverage_tiles load
         cp.resize(n_runs);
-        if (n_runs) HIP_TRY(hipMemcpyAsync(cp.data(), T.cov_runs, (size_t)n_runs * sizeof(DevCovPair), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        dev_free(T.cov_job); T.cov_job = nullptr; T.cov_runs = nullptr;
-        if (T.cov_tmp) { dev_free(T.cov_tmp); T.cov_tmp = nullptr; }
+        if (n_runs) HIP_TRY(hipMemcpy(cp.data(), T.cov_runs, (size_t)n_runs * sizeof(DevCovPair), hipMemcpyDeviceToHost));      // (a blocking copy on the null stream: the context's stream is still busy, and not waited for)
+        // (the job's buffers go back with the pack's tables: a free here would wait for the device)
         fin_trace("    cov: results of the kernels launched ahead");
         return MSNV_OK;
     }
