@@ -150,7 +150,7 @@ struct DevPackTables {
     // a round whose last kernels (msnv_emit_block: bases and headers out) may still be running when devpack_add_round returns: what is left
     // to read of it -- the mismatch sample of its samples, the kernels' time -- is taken by devpack_sync_pending, which everything that
     // needs the round finished calls first (the next round, finalize before it decides the allele bookkeeping, the statistics, release)
-    struct Pending { bool active = false; size_t first = 0, n = 0; void *ev0 = nullptr, *ev1 = nullptr; } pending;
+    struct Pending { bool active = false; size_t first = 0, n = 0; void *ev0 = nullptr, *ev1 = nullptr, *evh = nullptr, *evd = nullptr; bool has_evd = false; } pending;      // evh: behind the small results the host takes while the emit kernels run
     bool      any_overhang_h = false; // some read of some round runs past its contig (msnv_measure_reads): finalize fetches `overhang`
     void     *cov_event = nullptr;   // recorded behind those kernels: what devfin_coverage waits for
     void     *cov_job = nullptr, *cov_tmp = nullptr, *cov_runs = nullptr; bool cov_launched = false;   // finalize: the coverage index's kernels launched ahead of their results (devfin_coverage_launch)
@@ -166,6 +166,7 @@ struct DevPackTables {
     // cumulative device-pack accounting (msnv_host_timers: pack_device_wall_s; msnv_devpack_stats)
     double    ms_scan = 0, ms_measure = 0, ms_depth = 0, ms_emit = 0, ms_sort = 0, wall_upload_s = 0, wall_download_s = 0, wall_prepass_s = 0;
     uint64_t  raw_bytes = 0, n_records = 0, n_pieces = 0, n_prepass_samples = 0, n_scan_redone = 0, n_deep_runs_split = 0, n_dense_samples = 0;
+    uint64_t  n_quick_redone = 0;    // rounds the quick route had launched and the careful route took over (a sample needs the host pre-pass, far-reaching reads)
 };
 
 

@@ -475,6 +475,97 @@ __device__ __forceinline__ RecCnt wave_excl_cnt(const RecCnt c) {           // s
 }
 __device__ __forceinline__ RecCnt cnt_add(const RecCnt &a, const RecCnt &b) { return RecCnt{a.pile + b.pile, a.npiece + b.npiece, a.niv + b.niv, a.spill + b.spill, a.seqb + b.seqb}; }
 // Everything of pack.cpp: filter_and_edit + pack_sample that one record decides by itself.
+struct RecMeasure {
+    uint32_t flags;                // RF_*
+    uint32_t err;                  // 0, or ERR_MALFORMED / ERR_TID / ERR_QLEN
+    uint32_t st;                   // qaCompute's statistics and the round's flags: ST_* bits
+    unsigned long long key;        // contig << 32 | position of a mapped record
+    uint32_t end, maxc, np, sb, niv, ftile, spill;
+    uint32_t m_bases, a_seq, n_cigar;      // of a read that enters the pileup: aligned bases, its seq bytes without padding, CIGAR operations
+    int32_t over_tid, over_end;    // a read whose pieces run past its contig (ST_OVERHANG)
+};
+enum : uint32_t { ST_UNMAPPED = 1, ST_ZEROQ = 2, ST_PROPER = 4, ST_DUP = 8, ST_ANY = 16, ST_OVL = 32, ST_BEYOND = 64, ST_SORT = 128, ST_OVERHANG = 256, ST_ORDER = 512, ST_SHIPS = 1024 };
+// ovr: the host pre-pass's verdict for this record (0: none)
+__device__ __forceinline__ RecMeasure measure_one(const Rec &r, const DpContig *ctg, const DpParams &P, uint32_t ov) {
+    RecMeasure m{};
+    if (!r.ok) { m.err = ERR_MALFORMED; return m; }
+    if (!rec_mapped(r.flag, r.tid)) { m.st = ST_UNMAPPED; return m; }                     // qaCompute.cpp:461-473
+    m.st = ST_ANY;
+    bool cov_ok = false;
+    if ((int)r.mapq >= P.cov_min_mapq) {                                                  // qaCompute.cpp:518-526
+        if (r.flag & 2u) m.st |= ST_PROPER;
+        if (r.flag & 0x400u) m.st |= ST_DUP; else cov_ok = true;
+    } else m.st |= ST_ZEROQ;
+    m.flags = RF_MAPPED;
+    m.key = (unsigned long long)(uint32_t)r.tid << 32 | (uint32_t)r.pos;
+    if (r.tid >= P.n_contigs) { m.err = ERR_TID; return m; }
+    m.st |= ST_ORDER;                                                                     // (coordinate order: checked by the caller, against the neighbours' keys)
+    const DpContig c = ctg[r.tid];
+    if (!c.sel) return m;
+    // ---- CIGAR geometry, pieces, qaCompute's intervals: one walk
+    long long rlen = 0, qlen = 0, m_bases = 0, ins = 0, del = 0, rp = r.pos, pp = (long long)r.pos + 1;
+    bool has_ref_op = false, beyond = false;
+    uint32_t n_piece = 0, seqb = 0, n_iv = 0, ftile = 0, ltile = 0, n_spill = 0;
+    long long m_end = 0;                                                                   // end of the last aligned block
+    unsigned long long a_seq = 0;
+    uint32_t k0 = 0;
+    if (r.n_cigar > 0) { const uint32_t t = ld32(r.cigar) & 15u; if (t == C_S || t == C_H) k0 = 1; }
+    for (uint32_t k = 0; k < r.n_cigar; ++k) {
+        const uint32_t cg = ld32(r.cigar + 4ull * k), t = cg & 15u, l = cg >> 4;
+        if (cg_ref(t)) { rlen += l; has_ref_op = true; }
+        if (cg_query(t)) qlen += l;
+        if (t == C_I) ins += l; else if (t == C_D) del = del > (long long)l ? del : (long long)l;
+        if (k >= k0) {                                                                     // qaCompute.cpp:537-552
+            if (t == C_M) { if (pp >= c.len) { beyond = true; n_iv += c.len >= 1; } else ++n_iv; }
+            pp += l;
+        }
+        if (cg_match(t)) {
+            m_bases += l;
+            for (uint32_t off = 0, n = 0; off < l; off += n) {                             // pieces never cross a tile (pack.cpp: pack_sample)
+                const uint32_t to_tile = TILE - (uint32_t)((rp + off) % TILE);
+                n = SEG_MAX < l - off ? SEG_MAX : l - off;
+                n = n < to_tile ? n : to_tile;
+                const uint32_t tl = (uint32_t)((rp + off) / TILE);
+                if (!n_piece) ftile = tl;
+                if (tl != ftile) ++n_spill;
+                ltile = tl;
+                ++n_piece; seqb += stored_bytes(n); a_seq += (n + 1u) / 2u;
+            }
+            rp += l; m_end = rp;
+        } else if (cg_ref(t)) rp += l;
+    }
+    const long long endpos = (long long)r.pos + (rlen ? rlen : 1);                         // bam_endpos
+    // ---- mpileup's read-level filters, in mplp_func's order
+    bool pile_ok = !(r.flag & (uint32_t)P.flag_filter);
+    if (pile_ok && P.has_bed) pile_ok = c.bed_beg < endpos && (long long)r.pos < c.bed_end;
+    if (pile_ok && c.seq_len >= 0 && c.seq_len <= (long long)r.pos) pile_ok = false;
+    if (pile_ok && (int)r.mapq < P.min_mapq) pile_ok = false;
+    if (pile_ok && !P.count_orphans && (r.flag & 1u) && !(r.flag & 2u)) pile_ok = false;
+    if (pile_ok && !has_ref_op) pile_ok = false;
+    if (pile_ok && r.l_seq > 0 && qlen != (long long)r.l_seq) m.err = ERR_QLEN;
+    if (ov & 1u) pile_ok = (ov >> 1) & 1u;                                                 // the host pre-pass has decided (depth cap)
+    const long long absl = r.tlen < 0 ? -(long long)r.tlen : (long long)r.tlen;
+    if (pile_ok && !P.ignore_overlaps && !(r.flag & 8u) && (r.flag & 2u) &&                 // sam.c overlap_push's precondition
+        !((r.mtid >= 0 && r.tid != r.mtid) || (absl >= 2ll * r.l_seq && (long long)r.mpos >= endpos))) { m.st |= ST_OVL; m.flags |= RF_OVL; }
+    const unsigned long long mc = 4ull + 11ull + (unsigned long long)(ins > del ? ins : del);      // pack.cpp: max_element_chars
+    m.maxc = (uint32_t)(mc < 0x7fffffffull ? mc : 0x7fffffffull);
+    m.end = (uint32_t)(endpos < 0xffffffffll ? endpos : 0xffffffffll);
+    if (cov_ok) { m.flags |= RF_COV; m.niv = n_iv; if (beyond) m.st |= ST_BEYOND; }
+    if (pile_ok) {
+        m.flags |= RF_PILE;
+        m.m_bases = (uint32_t)m_bases; m.n_cigar = r.n_cigar;
+        // SEQ '*' (l_seq = 0): N bases of quality 0, shipped only under -Q 0 (pack.cpp: pack_sample)
+        if (r.l_seq > 0 || (P.c_eff == 0 && !P.all_low)) { m.np = n_piece; m.sb = seqb; m.a_seq = (uint32_t)a_seq; m.st |= ST_SHIPS; }
+        // a read whose pieces run past its contig: the contig's tiles reach that far (finalize)
+        if (m.np && m_end > c.len) { m.st |= ST_OVERHANG; m.over_tid = r.tid; m.over_end = (int32_t)(m_end < 0x7fffffffll ? m_end : 0x7fffffffll); }
+        m.ftile = ftile; m.spill = m.np ? n_spill : 0u;
+        // tile order by counting (msnv_emit_block) needs every pileup read to leave pieces in its first tile and at most the
+        // one behind it; a read that reaches further (a reference skip, a read of thousands of bases) or ships no piece at all
+        // sends the round through the general sort
+        if (!m.np || ltile > ftile + 1u) m.st |= ST_SORT;
+    }
+    return m;
+}
 __global__ __launch_bounds__(256) void msnv_measure_reads(const uint8_t *raw, const unsigned long long *rec_off, const uint16_t *rec_sample, const uint32_t *rec_base,
                                                           const unsigned long long *s_end, uint32_t n_rec, const DpContig *ctg, DpParams P, const uint32_t *ovr,
                                                           uint8_t *r_flags, unsigned long long *r_key, uint32_t *r_end, uint32_t *r_maxc, RecCnt *r_cnt, uint32_t *r_ftile,
@@ -490,91 +581,22 @@ __global__ __launch_bounds__(256) void msnv_measure_reads(const uint8_t *raw, co
     if (valid) {
         const uint8_t *p = raw + rec_off[i];
         const Rec r = rec_load(p, s_end[s] - rec_off[i]);
+        const RecMeasure m = measure_one(r, ctg, P, ovr ? ovr[i] : 0u);
         st_total = 1;
-        if (!r.ok) err = (unsigned long long)i << 3 | ERR_MALFORMED;
-        else if (!rec_mapped(r.flag, r.tid)) st_unmapped = 1;                               // qaCompute.cpp:461-473
-        else {
-            st_any = 1;
-            bool cov_ok = false;
-            if ((int)r.mapq >= P.cov_min_mapq) {                                            // qaCompute.cpp:518-526
-                if (r.flag & 2u) st_proper = 1;
-                if (r.flag & 0x400u) st_dup = 1; else cov_ok = true;
-            } else st_zeroq = 1;
-            flags = RF_MAPPED;
-            key = (unsigned long long)(uint32_t)r.tid << 32 | (uint32_t)r.pos;
-            if (r.tid >= P.n_contigs) err = (unsigned long long)i << 3 | ERR_TID;
-            else {
-                order_me = true;                                                             // (coordinate order: checked below, against the neighbours' keys)
-                const DpContig c = ctg[r.tid];
-                if (c.sel) {
-                    // ---- CIGAR geometry, pieces, qaCompute's intervals: one walk
-                    long long rlen = 0, qlen = 0, m_bases = 0, ins = 0, del = 0, rp = r.pos, pp = (long long)r.pos + 1;
-                    bool has_ref_op = false, beyond = false;
-                    uint32_t n_piece = 0, seqb = 0, n_iv = 0, ftile = 0, ltile = 0, n_spill = 0;
-                    long long m_end = 0;                                                     // end of the last aligned block
-                    unsigned long long a_seq = 0;
-                    uint32_t k0 = 0;
-                    if (r.n_cigar > 0) { const uint32_t t = ld32(r.cigar) & 15u; if (t == C_S || t == C_H) k0 = 1; }
-                    for (uint32_t k = 0; k < r.n_cigar; ++k) {
-                        const uint32_t cg = ld32(r.cigar + 4ull * k), t = cg & 15u, l = cg >> 4;
-                        if (cg_ref(t)) { rlen += l; has_ref_op = true; }
-                        if (cg_query(t)) qlen += l;
-                        if (t == C_I) ins += l; else if (t == C_D) del = del > (long long)l ? del : (long long)l;
-                        if (k >= k0) {                                                       // qaCompute.cpp:537-552
-                            if (t == C_M) { if (pp >= c.len) { beyond = true; n_iv += c.len >= 1; } else ++n_iv; }
-                            pp += l;
-                        }
-                        if (cg_match(t)) {
-                            m_bases += l;
-                            for (uint32_t off = 0, n = 0; off < l; off += n) {               // pieces never cross a tile (pack.cpp: pack_sample)
-                                const uint32_t to_tile = TILE - (uint32_t)((rp + off) % TILE);
-                                n = SEG_MAX < l - off ? SEG_MAX : l - off;
-                                n = n < to_tile ? n : to_tile;
-                                const uint32_t tl = (uint32_t)((rp + off) / TILE);
-                                if (!n_piece) ftile = tl;
-                                if (tl != ftile) ++n_spill;
-                                ltile = tl;
-                                ++n_piece; seqb += stored_bytes(n); a_seq += (n + 1u) / 2u;
-                            }
-                            rp += l; m_end = rp;
-                        } else if (cg_ref(t)) rp += l;
-                    }
-                    const long long endpos = (long long)r.pos + (rlen ? rlen : 1);           // bam_endpos
-                    // ---- mpileup's read-level filters, in mplp_func's order
-                    bool pile_ok = !(r.flag & (uint32_t)P.flag_filter);
-                    if (pile_ok && P.has_bed) pile_ok = c.bed_beg < endpos && (long long)r.pos < c.bed_end;
-                    if (pile_ok && c.seq_len >= 0 && c.seq_len <= (long long)r.pos) pile_ok = false;
-                    if (pile_ok && (int)r.mapq < P.min_mapq) pile_ok = false;
-                    if (pile_ok && !P.count_orphans && (r.flag & 1u) && !(r.flag & 2u)) pile_ok = false;
-                    if (pile_ok && !has_ref_op) pile_ok = false;
-                    if (pile_ok && r.l_seq > 0 && qlen != (long long)r.l_seq) err = (unsigned long long)i << 3 | ERR_QLEN;
-                    const uint32_t ov = ovr ? ovr[i] : 0u;
-                    if (ov & 1u) pile_ok = (ov >> 1) & 1u;                                   // the host pre-pass has decided (depth cap)
-                    const long long absl = r.tlen < 0 ? -(long long)r.tlen : (long long)r.tlen;
-                    if (pile_ok && !P.ignore_overlaps && !(r.flag & 8u) && (r.flag & 2u) &&   // sam.c overlap_push's precondition
-                        !((r.mtid >= 0 && r.tid != r.mtid) || (absl >= 2ll * r.l_seq && (long long)r.mpos >= endpos))) { n_ovl = 1; flags |= RF_OVL; }
-                    const unsigned long long mc = 4ull + 11ull + (unsigned long long)(ins > del ? ins : del);      // pack.cpp: max_element_chars
-                    o_maxc = (uint32_t)(mc < 0x7fffffffull ? mc : 0x7fffffffull);
-                    o_end = (uint32_t)(endpos < 0xffffffffll ? endpos : 0xffffffffll);
-                    if (cov_ok) { flags |= RF_COV; o_niv = n_iv; if (beyond) beyond_at = i; }
-                    if (pile_ok) {
-                        flags |= RF_PILE;
-                        n_pile = 1; first_pile = i;
-                        m_pile = (unsigned long long)m_bases;
-                        alg8d = 16ull + 4ull * r.n_cigar + ((unsigned long long)m_bases + 1) / 2 + (unsigned long long)m_bases;
-                        alg_cigar = 4ull * r.n_cigar;
-                        // SEQ '*' (l_seq = 0): N bases of quality 0, shipped only under -Q 0 (pack.cpp: pack_sample)
-                        if (r.l_seq > 0 || (P.c_eff == 0 && !P.all_low)) { o_np = n_piece; o_sb = seqb; alg_seq = a_seq; alg_qual = (unsigned long long)m_bases; }
-                        // a read whose pieces run past its contig: the contig's tiles reach that far (finalize)
-                        if (o_np && m_end > c.len) { atomicMax(&overhang[r.tid], (int32_t)(m_end < 0x7fffffffll ? m_end : 0x7fffffffll)); misc[MISC_OVERHANG] = 1u; }
-                        o_ftile = ftile; o_spill = o_np ? n_spill : 0u;
-                        // tile order by counting (msnv_emit_headers) needs every pileup read to leave pieces in its first tile and at most the
-                        // one behind it; a read that reaches further (a reference skip, a read of thousands of bases) or ships no piece at all
-                        // sends the round through the general sort
-                        if (!o_np || ltile > ftile + 1u) need_sort = true;
-                    }
-                }
-            }
+        if (m.err) err = (unsigned long long)i << 3 | m.err;
+        st_unmapped = (m.st & ST_UNMAPPED) ? 1u : 0u; st_zeroq = (m.st & ST_ZEROQ) ? 1u : 0u; st_proper = (m.st & ST_PROPER) ? 1u : 0u; st_dup = (m.st & ST_DUP) ? 1u : 0u;
+        st_any = (m.st & ST_ANY) ? 1u : 0u; n_ovl = (m.st & ST_OVL) ? 1u : 0u;
+        flags = (uint8_t)m.flags; key = m.key; order_me = (m.st & ST_ORDER) != 0u;
+        o_end = m.end; o_maxc = m.maxc; o_niv = m.niv; o_ftile = m.ftile; o_spill = m.spill; o_np = m.np; o_sb = m.sb;
+        if (m.st & ST_BEYOND) beyond_at = i;
+        if (m.flags & RF_PILE) {
+            n_pile = 1; first_pile = i;
+            m_pile = m.m_bases;
+            alg8d = 16ull + 4ull * m.n_cigar + ((unsigned long long)m.m_bases + 1) / 2 + (unsigned long long)m.m_bases;
+            alg_cigar = 4ull * m.n_cigar;
+            if (m.st & ST_SHIPS) { alg_seq = m.a_seq; alg_qual = m.m_bases; }
+            if (m.st & ST_OVERHANG) { atomicMax(&overhang[m.over_tid], m.over_end); misc[MISC_OVERHANG] = 1u; }
+            need_sort = (m.st & ST_SORT) != 0u;
         }
         r_flags[i] = flags; r_key[i] = key; r_end[i] = o_end; r_maxc[i] = o_maxc; r_ftile[i] = o_ftile;
     }
@@ -824,6 +846,517 @@ __global__ void msnv_group_table(uint32_t n_groups, const uint32_t *grp_first, c
     out[gi] = o;
 }
 
+struct DpSampleDst { uint8_t *seq, *qual; unsigned long long pbase0; uint32_t cut_marks, pad; };      // where a sample's columns lie in the round's buffer, its first piece
+// ------------------------------------------------------------------------------------------ round 6: scan and measure in ONE walk
+// The quick scan's lane (one per sub-segment of a stream, above) has every record's header line in hand when it reads block_size; the
+// measure kernel then went to the same lines again, one thread per record, for everything else (3.1 GB of sector fetches for the 3.07 GB of
+// the benchmark's records, 0.92 ms + a wait).  Here the walk measures as it goes (measure_one) and leaves per RECORD a 32-byte slot -- key,
+// end, flags, first tile and its places among the sub-segment's records: pieces, intervals, next-tile pieces, seq bytes, rank among the
+// pileup reads, run and group starts before it -- and per SUB-SEGMENT its sums, qaCompute's statistics, the first / last pileup read and
+// mapped record (what the neighbours' boundaries need) and the first error.  Seams are checked and wrong guesses walked again as before;
+// msnv_sub_bounds settles what crosses a boundary (does the sub-segment's first pileup read start a run / a group?  is its first mapped
+// record in order?); ONE scan over the sub-segments' sums gives every sub-segment its bases, and -- its last entry -- the round's totals:
+// records, pileup reads, pieces, intervals, seq bytes, runs, groups.  That is the ONE wait of the stage: everything behind it
+// (msnv_scan_write2: records in record order with GLOBAL places; depth; groups; layout; msnv_emit_block) is launched back to back.
+struct Slot { uint4 a, b; };       // a = {pos, end, tid, maxc << 13 | inner group start << 8 | inner run start << 7 | err << 4 | RF_*}
+                                   // b = {first tile, seq bytes before | pieces before << 16, intervals before | next-tile pieces before << 16,
+                                   //      pileup reads before | inner run starts up to here << 8 | inner group starts up to here << 16}   (all inside the sub-segment)
+struct SubCnt { uint32_t rec, pile, npiece, niv, spill, runs, grps, ovl; unsigned long long seqb; uint32_t sort, odd; };   // what ONE scan carries (48 B); ovl: reads that pass overlap_push's precondition;
+                                                                   // sort: sub-segments that ask for the general tile-order sort; odd: ... that the quick route cannot take (a field of a slot overflows, two overhanging contigs)
+struct SubCntSum { __device__ __host__ SubCnt operator()(const SubCnt &x, const SubCnt &y) const {
+    return SubCnt{x.rec + y.rec, x.pile + y.pile, x.npiece + y.npiece, x.niv + y.niv, x.spill + y.spill, x.runs + y.runs, x.grps + y.grps, x.ovl + y.ovl, x.seqb + y.seqb, x.sort + y.sort, x.odd + y.odd}; } };
+struct SubInfo {
+    uint32_t pile, npiece, niv, spill, seqb;          // sums over the sub-segment's records
+    uint32_t runs, grps;                              // run / group starts among its pileup reads, the FIRST one's not counted (msnv_sub_bounds settles that one)
+    uint32_t fp_slot, fp_tid, fp_ftile, lp_tid, lp_ftile;       // first / last pileup read: slot (~0: none), contig, first tile
+    uint32_t fm_slot; unsigned long long fm_key, lm_key;        // first / last MAPPED record (coordinate order across sub-segments); fm_slot ~0: none
+    uint32_t st_unmapped, st_zeroq, st_proper, st_dup, st_any, st_ovl;
+    uint32_t m_pile, alg8d, alg_cigar, alg_seq, alg_qual;
+    uint32_t err;                                     // slot << 3 | kind of the first error (~0: none)
+    uint32_t beyond_slot;                             // first record whose qaCompute cursor reaches the contig end (~0: none)
+    uint32_t flags;                                   // 1: the pieces need the general tile-order sort; 2: a read runs past its contig (over_*); 4: ... past two different contigs; 8: a place inside the sub-segment does not fit its slot field
+    int32_t over_tid, over_end;
+    uint32_t maxc_big;                                // some pileup read's longest element does not fit the slot's 19 bits
+};
+constexpr uint32_t MAXC_SAT = 0x7ffffu;
+// One sub-segment's records from `entry`: the chain, the slots, the sums.  Returns false when the chain breaks.
+__device__ __forceinline__ bool walk_sub2(const uint8_t *raw, unsigned long long s_end, unsigned long long b, unsigned long long e, unsigned long long entry, uint32_t cap,
+                                          const DpContig *ctg, const DpParams &P, uint16_t *dl, Slot *slots, SubInfo &I, uint32_t &n_out, unsigned long long &off_out) {
+    SubInfo s{};
+    s.fp_slot = s.fm_slot = s.err = s.beyond_slot = 0xffffffffu;
+    uint32_t n = 0; unsigned long long off = entry;
+    bool bad = false;
+    unsigned long long prev_key = 0; bool have_prev = false;                  // last mapped record of this walk
+    uint32_t lp_sample_tid = 0, lp_ft = 0; bool have_lp = false;              // last pileup read of this walk
+    while (off < e) {
+        if (s_end - off < 36) { bad = true; break; }
+        const Rec r = rec_load(raw + off, s_end - off);
+        if ((int32_t)r.bs < 32 || (unsigned long long)r.bs + 4 > s_end - off) { bad = true; break; }
+        if (n < cap) {
+            const RecMeasure m = measure_one(r, ctg, P, 0u);
+            uint32_t err = m.err;
+            if (m.st & ST_ORDER) {                                             // coordinate order inside the walk (across sub-segments: msnv_sub_bounds)
+                if (have_prev) {
+                    const int32_t tj = (int32_t)(prev_key >> 32), pj = (int32_t)(uint32_t)prev_key, ti = (int32_t)(m.key >> 32), pi = (int32_t)(uint32_t)m.key;
+                    if ((ti < tj || (ti == tj && pi < pj)) && !err) err = ERR_UNSORTED;
+                }
+            }
+            if (m.flags & RF_MAPPED) {
+                if (s.fm_slot == 0xffffffffu) { s.fm_slot = n; s.fm_key = m.key; }
+                s.lm_key = m.key; prev_key = m.key; have_prev = true;
+            }
+            uint32_t run_start = 0, grp_start = 0;
+            if (m.flags & RF_PILE) {
+                const uint32_t t = (uint32_t)(m.key >> 32);
+                if (!have_lp) { s.fp_slot = n; s.fp_tid = t; s.fp_ftile = m.ftile; }
+                else {
+                    run_start = t != lp_sample_tid ? 1u : 0u;
+                    grp_start = (run_start || m.ftile != lp_ft) ? 1u : 0u;
+                    if (!run_start && lp_ft > m.ftile) s.flags |= 1u;           // (a read whose first aligned base lies in an earlier tile than its predecessor's: leading deletions)
+                }
+                lp_sample_tid = t; lp_ft = m.ftile; have_lp = true;
+                s.lp_tid = t; s.lp_ftile = m.ftile;
+                s.runs += run_start; s.grps += grp_start;
+            }
+            if (err && s.err == 0xffffffffu) s.err = n << 3 | err;
+            if ((m.st & ST_BEYOND) && s.beyond_slot == 0xffffffffu) s.beyond_slot = n;
+            if (m.st & ST_SORT) s.flags |= 1u;
+            if (m.st & ST_OVERHANG) {
+                if ((s.flags & 2u) && s.over_tid != m.over_tid) s.flags |= 4u;
+                if (!(s.flags & 2u) || m.over_end > s.over_end) { s.over_tid = m.over_tid; s.over_end = m.over_end; }
+                s.flags |= 2u;
+            }
+            const uint32_t mc = m.maxc < MAXC_SAT ? m.maxc : MAXC_SAT;
+            if ((m.flags & RF_PILE) && m.maxc >= MAXC_SAT) s.maxc_big = 1u;
+            Slot q;
+            q.a = make_uint4((uint32_t)m.key, m.end, (uint32_t)(m.key >> 32), mc << 13 | grp_start << 8 | run_start << 7 | (err & 7u) << 4 | (m.flags & 15u));
+            q.b = make_uint4(m.ftile, s.seqb | s.npiece << 16, s.niv | s.spill << 16, s.pile | s.runs << 8 | s.grps << 16);
+            slots[n] = q;
+            dl[n] = (uint16_t)(off - b);
+            // ---- the sub-segment's sums
+            s.st_unmapped += (m.st & ST_UNMAPPED) ? 1u : 0u; s.st_zeroq += (m.st & ST_ZEROQ) ? 1u : 0u; s.st_proper += (m.st & ST_PROPER) ? 1u : 0u;
+            s.st_dup += (m.st & ST_DUP) ? 1u : 0u; s.st_any += (m.st & ST_ANY) ? 1u : 0u; s.st_ovl += (m.st & ST_OVL) ? 1u : 0u;
+            if (m.flags & RF_PILE) {
+                s.pile += 1u; s.m_pile += m.m_bases;
+                s.alg8d += 16u + 4u * m.n_cigar + (m.m_bases + 1u) / 2u + m.m_bases; s.alg_cigar += 4u * m.n_cigar;
+                if (m.st & ST_SHIPS) { s.alg_seq += m.a_seq; s.alg_qual += m.m_bases; }
+            }
+            s.npiece += m.np; s.niv += m.niv; s.spill += m.spill; s.seqb += m.sb;
+            if ((s.npiece | s.niv | s.spill | s.seqb) > 0xffffu || s.pile > 0xffu) s.flags |= 8u;      // (a SEQ-less read with a CIGAR of thousands of bases, sub-segments of many kilobytes: the careful route's)
+        }
+        ++n;
+        off += 4ull + r.bs;
+    }
+    I = s; n_out = n; off_out = off;
+    return !bad;
+}
+__global__ __launch_bounds__(256) void msnv_scan_sub2(const uint8_t *raw, const SubStream *ss, uint32_t n_streams, uint32_t n_sub, uint32_t sub_bytes, uint32_t cap, int n_contigs,
+                                                      const DpContig *ctg, DpParams P, unsigned long long *first, unsigned long long *stop, uint32_t *cnt, uint16_t *delta, Slot *slots, SubInfo *info,
+                                                      uint32_t *flags) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_sub) return;
+    const SubStream S = ss[sub_stream_of(ss, n_streams, g)];
+    const unsigned long long b = S.beg + (unsigned long long)(g - S.sub0) * sub_bytes, e = b + sub_bytes < S.end ? b + sub_bytes : S.end;
+    unsigned long long f = ~0ull;
+    if (g == S.sub0) f = S.beg;
+    else {
+        const unsigned long long a0 = b & ~15ull;                  // (the entry guess of msnv_scan_sub, to the letter)
+        uint4 lo4 = *reinterpret_cast<const uint4 *>(raw + a0);
+        for (unsigned long long base16 = a0; base16 < e && f == ~0ull; base16 += 16) {
+            const uint4 hi4 = *reinterpret_cast<const uint4 *>(raw + base16 + 16);
+            const uint32_t w[7] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z};
+#pragma unroll
+            for (uint32_t k = 0; k < 16u; ++k) {
+                const uint32_t bs = __builtin_amdgcn_alignbyte(w[(k >> 2) + 1], w[k >> 2], k & 3u);
+                const int32_t tid = (int32_t)__builtin_amdgcn_alignbyte(w[(k >> 2) + 2], w[(k >> 2) + 1], k & 3u);
+                const unsigned long long o = base16 + k;
+                if ((int32_t)bs < 32 || bs >= (1u << 28) || tid < -1 || tid >= n_contigs || o < b || o >= e || f != ~0ull) continue;
+                uint32_t bs1 = 0;
+                if (!hdr_plausible(raw, o, S.end, n_contigs, bs1)) continue;
+                bool ok = true;
+                unsigned long long o2 = o + 4ull + bs1;
+                for (int d = 0; d < 2 && ok && o2 < S.end; ++d) { uint32_t b2 = 0; ok = hdr_plausible(raw, o2, S.end, n_contigs, b2); o2 += 4ull + b2; }
+                if (ok) f = o;
+            }
+            lo4 = hi4;
+        }
+    }
+    uint32_t n = 0; unsigned long long off = f;
+    bool ok = true;
+    SubInfo I{};
+    I.fp_slot = I.fm_slot = I.err = I.beyond_slot = 0xffffffffu;
+    if (f != ~0ull) ok = walk_sub2(raw, S.end, b, e, f, cap, ctg, P, delta + (size_t)g * cap, slots + (size_t)g * cap, I, n, off);
+    if ((!ok || n > cap) && g != S.sub0) { first[g] = ~0ull - 1ull; stop[g] = 0ull; cnt[g] = 0u; return; }      // a walk from a GUESSED entry that breaks: a wrong guess (msnv_scan_fix2 walks again from the true one)
+    first[g] = f; stop[g] = f != ~0ull ? off : 0ull; cnt[g] = n;
+    info[g] = I;
+    if (!ok || n > cap) atomicOr(flags, 1u);                        // a malformed chain from the stream's first byte (or more records than slots): the careful route reports / takes it
+}
+__global__ void msnv_scan_fix2(const uint8_t *raw, const SubStream *ss, uint32_t n_streams, uint32_t sub_bytes, uint32_t cap, const DpContig *ctg, DpParams P, unsigned long long *first,
+                               unsigned long long *stop, const unsigned long long *stop_max, uint32_t *cnt, uint16_t *delta, Slot *slots, SubInfo *info, uint32_t *first_bad, uint32_t *flags) {
+    const uint32_t si = blockIdx.x * blockDim.x + threadIdx.x;
+    if (si >= n_streams) return;
+    const uint32_t g = first_bad[si];
+    first_bad[si] = 0xffffffffu;                                    // (for the next pass)
+    if (g == 0xffffffffu) return;
+    const SubStream S = ss[si];
+    const unsigned long long b = S.beg + (unsigned long long)(g - S.sub0) * sub_bytes, e = b + sub_bytes < S.end ? b + sub_bytes : S.end;
+    unsigned long long cur = stop_max[g - 1];
+    cur = cur > S.beg ? cur : S.beg;
+    atomicOr(flags, 2u);
+    SubInfo I{};
+    I.fp_slot = I.fm_slot = I.err = I.beyond_slot = 0xffffffffu;
+    if (cur >= e) { first[g] = ~0ull; stop[g] = 0ull; cnt[g] = 0u; info[g] = I; return; }
+    uint32_t n = 0; unsigned long long off = cur;
+    const bool ok = walk_sub2(raw, S.end, b, e, cur, cap, ctg, P, delta + (size_t)g * cap, slots + (size_t)g * cap, I, n, off);
+    if (!ok || n > cap) { atomicOr(flags, 4u); return; }
+    first[g] = cur; stop[g] = off; cnt[g] = n; info[g] = I;
+}
+// What crosses a sub-segment's front boundary, once every seam holds: does its first pileup read start a run / a group (against the last
+// pileup read of the nearest sub-segment of its stream in front of it that has one)?  is its first mapped record in coordinate order behind
+// the last mapped one in front?  Output: the scan's input.
+__global__ __launch_bounds__(256) void msnv_sub_bounds(const SubStream *ss, uint32_t n_streams, uint32_t n_sub, const uint32_t *cnt, SubInfo *info, SubCnt *out, uint8_t *bflag) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g > n_sub) return;
+    if (g == n_sub) { out[g] = SubCnt{}; return; }
+    const uint32_t n = cnt[g];
+    SubCnt c{};
+    uint32_t bf = 0;
+    if (n) {
+        SubInfo I = info[g];
+        const SubStream S = ss[sub_stream_of(ss, n_streams, g)];
+        if (I.fp_slot != 0xffffffffu) {
+            bool have = false; uint32_t pt = 0, pf = 0;
+            for (uint32_t k = g; k > S.sub0 && !have;) { --k; if (cnt[k] && info[k].fp_slot != 0xffffffffu) { have = true; pt = info[k].lp_tid; pf = info[k].lp_ftile; } }
+            const bool run = !have || pt != I.fp_tid, grp = run || pf != I.fp_ftile;
+            bf = (run ? 1u : 0u) | (grp ? 2u : 0u);
+            if (!run && pf > I.fp_ftile) bf |= 4u;                   // (tile order needs the sort)
+        }
+        if (I.fm_slot != 0xffffffffu) {
+            bool have = false; unsigned long long pk = 0;
+            for (uint32_t k = g; k > S.sub0 && !have;) { --k; if (cnt[k] && info[k].fm_slot != 0xffffffffu) { have = true; pk = info[k].lm_key; } }
+            if (have) {
+                const int32_t tj = (int32_t)(pk >> 32), pj = (int32_t)(uint32_t)pk, ti = (int32_t)(I.fm_key >> 32), pi = (int32_t)(uint32_t)I.fm_key;
+                if (ti < tj || (ti == tj && pi < pj)) { const uint32_t e = I.fm_slot << 3 | ERR_UNSORTED; if (e < I.err) info[g].err = e; }      // (an error AT the slot itself, if any, was there first: it keeps its word)
+            }
+        }
+        c.rec = n; c.pile = I.pile; c.npiece = I.npiece; c.niv = I.niv; c.spill = I.spill; c.seqb = I.seqb;
+        c.runs = I.runs + (bf & 1u); c.grps = I.grps + ((bf >> 1) & 1u);
+        c.ovl = I.st_ovl; c.sort = ((I.flags & 1u) || (bf & 4u)) ? 1u : 0u; c.odd = (I.flags & 12u) ? 1u : 0u;
+    }
+    out[g] = c; bflag[g] = (uint8_t)bf;
+}
+// The records in record order, a wavefront per 64 consecutive sub-segments (msnv_scan_write's walk): offsets, samples, and from the slots +
+// the sub-segments' bases every record's row of the per-record tables.  The lane that holds a sub-segment adds its statistics to its
+// sample's accumulators first (one atomic per counter and wavefront when the 64 sub-segments are one stream's, as nearly always).
+struct RdTables {
+    unsigned long long *rec_off; uint16_t *rec_sample; uint32_t *rec_base;
+    uint4 *rd;                     // {position, end, contig, sample | outlier << 12 | longest pileup element << 13}
+    RecCnt *r_pre;                 // places BEFORE the record (entry n_rec: the round's totals)
+    uint32_t *r_ftile; uint8_t *r_flags; unsigned long long *r_rg;      // r_flags: RF_* | RF_RUN | RF_GRP; r_rg: run << 32 | group of a pileup read (1-based)
+};
+enum : uint8_t { RF_RUN = 16, RF_GRP = 32 };
+__global__ __launch_bounds__(256) void msnv_scan_write2(const SubStream *ss, uint32_t n_streams, uint32_t n_sub, uint32_t sub_bytes, uint32_t cap, const uint32_t *cnt, const SubCnt *base,
+                                                        const uint8_t *bflag, const uint16_t *delta, const Slot *slots, const SubInfo *info, RdTables T, DpAcc *acc, uint32_t *misc,
+                                                        uint32_t *outliers, uint32_t span_out, int32_t *overhang, DpParams P) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u, g0 = g - lane;
+    if (g0 >= n_sub) return;
+    const bool have = g < n_sub;
+    uint32_t si = 0xffffffffu, w = 0xffffffffu; unsigned long long b = 0;
+    SubCnt B{}; uint32_t bf = 0, fp_slot = 0xffffffffu;
+    {
+        // ---- this lane's sub-segment: base, statistics, first error
+        uint32_t t_total = 0, t_unm = 0, t_zq = 0, t_pp = 0, t_dup = 0, t_any = 0, t_pile = 0, t_ovl = 0, need = 0;
+        unsigned long long u_bases = 0, u_8d = 0, u_cig = 0, u_seq = 0, u_qual = 0, e_err = ~0ull, e_first = ~0ull, e_beyond = ~0ull;
+        if (have) {
+            si = sub_stream_of(ss, n_streams, g);
+            const SubStream S = ss[si];
+            b = S.beg + (unsigned long long)(g - S.sub0) * sub_bytes;
+            B = base[g]; w = B.rec; bf = bflag[g];
+            if (g == S.sub0) T.rec_base[si] = w;
+            if (cnt[g]) {
+                const SubInfo I = info[g];
+                fp_slot = I.fp_slot;
+                t_total = cnt[g]; t_unm = I.st_unmapped; t_zq = I.st_zeroq; t_pp = I.st_proper; t_dup = I.st_dup; t_any = I.st_any; t_pile = I.pile; t_ovl = I.st_ovl;
+                u_bases = I.m_pile; u_8d = I.alg8d; u_cig = I.alg_cigar; u_seq = I.alg_seq; u_qual = I.alg_qual;
+                if (I.err != 0xffffffffu) e_err = (unsigned long long)(w + (I.err >> 3)) << 3 | (I.err & 7u);
+                if (I.fp_slot != 0xffffffffu) e_first = w + I.fp_slot;
+                if (I.beyond_slot != 0xffffffffu) e_beyond = w + I.beyond_slot;
+                if ((I.flags & 1u) || (bf & 4u)) atomicOr(&misc[MISC_SORT], 1u);
+                if (I.flags & 2u) { atomicMax(&overhang[I.over_tid], I.over_end); misc[MISC_OVERHANG] = 1u; }
+                if (I.flags & 4u) misc[MISC_OVERHANG] = 2u;             // (two contigs' worth in one sub-segment: the host takes the careful route)
+                if (I.maxc_big && P.token_limit > 0) need |= NEED_TOKEN;      // (an element longer than the slot holds: the host pre-pass counts exactly)
+            }
+        }
+        const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)si);
+        if (__all(si == s0 || !have) && s0 != 0xffffffffu) {
+            const uint32_t a0 = wave_sum(t_total), a1 = wave_sum(t_unm), a2 = wave_sum(t_zq), a3 = wave_sum(t_pp), a4 = wave_sum(t_dup), a5 = wave_sum(t_any), a6 = wave_sum(t_pile), a7 = wave_sum(t_ovl);
+            const unsigned long long v0 = wave_sum(u_bases), v1 = wave_sum(u_8d), v2 = wave_sum(u_cig), v3 = wave_sum(u_seq), v4 = wave_sum(u_qual);
+            const unsigned long long m0 = wave_min(e_err), m1 = wave_min(e_first), m2 = wave_min(e_beyond);
+            uint32_t nd = need; for (int o = 32; o > 0; o >>= 1) nd |= __shfl_down(nd, o);
+            if (lane == 0) {
+                DpAcc &a = acc[(size_t)s0 * ACC_COPIES + ((blockIdx.x * 4u + (threadIdx.x >> 6)) % ACC_COPIES)];
+                if (a0) atomicAdd(&a.total, a0);
+                if (a1) atomicAdd(&a.unmapped, a1);
+                if (a2) atomicAdd(&a.zeroq, a2);
+                if (a3) atomicAdd(&a.proper, a3);
+                if (a4) atomicAdd(&a.dup, a4);
+                if (a5) atomicOr(&a.any_mapped, 1u);
+                if (a6) atomicAdd(&a.n_pile_reads, a6);
+                if (a7) atomicAdd(&a.n_ovl, a7);
+                if (v0) atomicAdd(&a.n_bases, v0);
+                if (v1) atomicAdd(&a.alg8d, v1);
+                if (v2) atomicAdd(&a.alg_cigar, v2);
+                if (v3) atomicAdd(&a.alg_seq, v3);
+                if (v4) atomicAdd(&a.alg_qual, v4);
+                if (m0 != ~0ull) atomicMin(&a.err, m0);
+                if (m1 != ~0ull) atomicMin(&a.first_pile, m1);
+                if (m2 != ~0ull) atomicMin(&a.beyond, m2);
+                if (nd) atomicOr(&acc[(size_t)s0 * ACC_COPIES].need_host, nd);
+            }
+        } else if (have && t_total) {
+            DpAcc &a = acc[(size_t)si * ACC_COPIES + (blockIdx.x % ACC_COPIES)];
+            atomicAdd(&a.total, t_total);
+            if (t_unm) atomicAdd(&a.unmapped, t_unm);
+            if (t_zq) atomicAdd(&a.zeroq, t_zq);
+            if (t_pp) atomicAdd(&a.proper, t_pp);
+            if (t_dup) atomicAdd(&a.dup, t_dup);
+            if (t_any) atomicOr(&a.any_mapped, 1u);
+            if (t_pile) atomicAdd(&a.n_pile_reads, t_pile);
+            if (t_ovl) atomicAdd(&a.n_ovl, t_ovl);
+            if (u_bases) atomicAdd(&a.n_bases, u_bases);
+            if (u_8d) atomicAdd(&a.alg8d, u_8d);
+            if (u_cig) atomicAdd(&a.alg_cigar, u_cig);
+            if (u_seq) atomicAdd(&a.alg_seq, u_seq);
+            if (u_qual) atomicAdd(&a.alg_qual, u_qual);
+            if (e_err != ~0ull) atomicMin(&a.err, e_err);
+            if (e_first != ~0ull) atomicMin(&a.first_pile, e_first);
+            if (e_beyond != ~0ull) atomicMin(&a.beyond, e_beyond);
+            if (need) atomicOr(&acc[(size_t)si * ACC_COPIES].need_host, need);
+        }
+    }
+    // ---- the records of the wavefront's sub-segments, 64 at a time
+    const uint32_t n_here = (n_sub - g0 < 64u ? n_sub - g0 : 64u);
+    const uint32_t j_lo = __shfl(w, 0), j_hi = base[g0 + n_here].rec;   // (base has n_sub + 1 entries)
+    uint32_t span_max = 0;
+    for (uint32_t j0 = j_lo; j0 < j_hi; j0 += 64u) {
+        const uint32_t j = j0 + lane;
+        uint32_t lo = 0, hi = n_here;                              // last lane t (< n_here) whose first record is at or before j
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+            const uint32_t m = (lo + hi) / 2;
+            const uint32_t bm = __shfl(w, (int)m);
+            if (hi - lo > 1) { if (bm <= j) lo = m; else hi = m; }
+        }
+        const uint32_t wt = __shfl(w, (int)lo), st = __shfl(si, (int)lo), bft = __shfl(bf, (int)lo), fpt = __shfl(fp_slot, (int)lo);
+        const unsigned long long bt = __shfl(b, (int)lo);
+        const uint32_t p_pile = __shfl(B.pile, (int)lo), p_np = __shfl(B.npiece, (int)lo), p_niv = __shfl(B.niv, (int)lo), p_sp = __shfl(B.spill, (int)lo), p_runs = __shfl(B.runs, (int)lo), p_grps = __shfl(B.grps, (int)lo);
+        const unsigned long long p_seqb = __shfl(B.seqb, (int)lo);
+        if (j < j_hi) {
+            const uint32_t k = j - wt;
+            const size_t sl = (size_t)(g0 + lo) * cap + k;
+            const Slot q = slots[sl];
+            T.rec_off[j] = bt + delta[sl]; T.rec_sample[j] = (uint16_t)st;
+            uint8_t fl = (uint8_t)(q.a.w & 15u);
+            const uint32_t mc = q.a.w >> 13;
+            uint32_t outl = 0;
+            if (fl & RF_PILE) {
+                const uint32_t span = q.a.y - (q.a.x & 0x7fffffffu);
+                if (span > span_out) { const uint32_t o = atomicAdd(&misc[MISC_NOUT], 1u); if (o < CAP_OUT) outliers[o] = j; outl = 1u; }
+                else span_max = span > span_max ? span : span_max;
+                const bool first_pile = k == fpt;
+                const uint32_t run_s = first_pile ? (bft & 1u) : (q.a.w >> 7) & 1u, grp_s = first_pile ? (bft >> 1) & 1u : (q.a.w >> 8) & 1u;
+                if (run_s) fl |= RF_RUN;
+                if (grp_s) fl |= RF_GRP;
+                // inclusive numbers: the starts before the sub-segment, its first pileup read's (settled at the boundary), the inner ones up to here
+                const uint32_t run_no = p_runs + (bft & 1u) + ((q.b.w >> 8) & 0xffu), grp_no = p_grps + ((bft >> 1) & 1u) + ((q.b.w >> 16) & 0xffu);
+                T.r_rg[j] = (unsigned long long)run_no << 32 | grp_no;
+            }
+            T.rd[j] = make_uint4(q.a.x, q.a.y, q.a.z, (st & 0xfffu) | outl << 12 | mc << 13);
+            RecCnt pre;
+            pre.pile = p_pile + (q.b.w & 0xffu); pre.npiece = p_np + (q.b.y >> 16); pre.niv = p_niv + (q.b.z & 0xffffu); pre.spill = p_sp + (q.b.z >> 16); pre.seqb = p_seqb + (q.b.y & 0xffffu);
+            T.r_pre[j] = pre;
+            T.r_ftile[j] = q.b.x; T.r_flags[j] = fl;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t x = __shfl_xor(span_max, o); span_max = x > span_max ? x : span_max; }
+    if (lane == 0 && span_max > *(volatile uint32_t *)&misc[MISC_SPAN]) atomicMax(&misc[MISC_SPAN], span_max);
+    // (entry n_rec of r_pre / rec_off: the round's totals and end -- written by the host's launch sequence)
+}
+// ---- the careful route's records in the same tables (msnv_measure_reads has measured them one thread a record, the blocks' sums are scanned):
+// places before every record, the rd rows, run / group starts against the pileup read before (flags; their scan numbers them)
+__global__ __launch_bounds__(256) void msnv_tables_from_measure(uint32_t n_rec, const uint16_t *rec_sample, const uint8_t *r_flags_in, const unsigned long long *r_key, const uint32_t *r_end, const uint32_t *r_maxc,
+                                                                const RecCnt *r_cnt, const RecCnt *blk_pre, const uint32_t *r_ftile, uint32_t span_out, DpParams P, RdTables T, unsigned long long *start_flags, DpAcc *acc) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
+    const bool valid = i < n_rec;
+    const RecCnt mine = valid ? r_cnt[i] : RecCnt{};
+    const RecCnt pre = cnt_add(blk_pre[(valid ? i : n_rec - 1u) / PB], wave_excl_cnt(mine));
+    uint8_t fl = valid ? r_flags_in[i] : 0;
+    const uint32_t s = valid ? rec_sample[i] : 0u, ft = valid ? r_ftile[i] : 0u;
+    const unsigned long long key = valid ? r_key[i] : 0ull;
+    const bool pile = (fl & RF_PILE) != 0;
+    // the pileup read before this one: a lane of the wavefront, or -- for the first one of the wavefront -- looked for in the records in front
+    const unsigned long long pm = __ballot(pile), below = pm & ((1ull << lane) - 1ull);
+    const int src = below ? 63 - __builtin_clzll(below) : 0;
+    unsigned long long pk = __shfl(key, src); uint32_t ps = __shfl(s, src), pf = __shfl(ft, src);
+    bool have_prev = below != 0ull;
+    if (pile && !have_prev) {
+        for (uint32_t j = i - lane; j > 0 && !have_prev;) { --j; if (r_flags_in[j] & RF_PILE) { have_prev = true; pk = r_key[j]; ps = rec_sample[j]; pf = r_ftile[j]; } }
+    }
+    unsigned long long sf = 0;
+    if (valid) {
+        uint32_t outl = 0;
+        if (pile) {
+            const bool run = !have_prev || ps != s || (uint32_t)(pk >> 32) != (uint32_t)(key >> 32), grp = run || pf != ft;
+            if (run) fl |= RF_RUN;
+            if (grp) fl |= RF_GRP;
+            sf = (unsigned long long)(run ? 1u : 0u) << 32 | (grp ? 1u : 0u);
+            const uint32_t span = r_end[i] - ((uint32_t)key & 0x7fffffffu);
+            outl = span > span_out ? 1u : 0u;
+            if (r_maxc[i] >= MAXC_SAT && P.token_limit > 0) atomicOr(&acc[(size_t)s * ACC_COPIES].need_host, NEED_TOKEN);
+        }
+        const uint32_t mc = r_maxc[i] < MAXC_SAT ? r_maxc[i] : MAXC_SAT;
+        T.rd[i] = make_uint4((uint32_t)key, r_end[i], (uint32_t)(key >> 32), (s & 0xfffu) | outl << 12 | mc << 13);
+        T.r_pre[i] = pre; T.r_flags[i] = fl; T.r_ftile[i] = ft;
+        start_flags[i] = sf;
+    }
+}
+// ---- depth at every read start, over the RECORDS (round 6: no list of the pileup reads, no scan of their run / group flags -- both come with the
+// records' tables).  A record that is no pileup read is stepped over by its neighbours' walks; everything else is msnv_depth's.
+__global__ __launch_bounds__(256) void msnv_depth2(uint32_t n_rec, const uint4 *rd, const uint8_t *r_flags, const unsigned long long *r_rg, const RecCnt *r_pre, const uint32_t *r_ftile,
+                                                   const uint32_t *ovr, DpParams P, const uint32_t *misc_span, const uint32_t *outliers, const uint32_t *misc_nout,
+                                                   uint16_t *r_depth, uint32_t *run_first, uint32_t *run_f1, uint32_t *grp_first, uint32_t *grp_md, DpAcc *acc) {
+    __shared__ uint4 s_rd[DEPTH_BACK + 256];
+    __shared__ uint8_t s_fl[DEPTH_BACK + 256];
+    const uint32_t blk0 = blockIdx.x * blockDim.x, i = blk0 + threadIdx.x;
+    const uint32_t lds_lo = blk0 > DEPTH_BACK ? blk0 - DEPTH_BACK : 0u, lds_n = (blk0 + 256u < n_rec ? blk0 + 256u : n_rec) - lds_lo;
+    for (uint32_t k = threadIdx.x; k < lds_n; k += 256u) { s_rd[k] = rd[lds_lo + k]; s_fl[k] = r_flags[lds_lo + k]; }
+    __syncthreads();
+    const uint8_t fl = i < n_rec ? s_fl[i - lds_lo] : 0;
+    const bool valid = (fl & RF_PILE) != 0;
+    uint32_t gi = 0xffffffffu, depth = 0, spill = 0;
+    if (valid) {
+        const uint32_t window = *misc_span;
+        uint32_t n_out = *misc_nout; n_out = n_out < CAP_OUT ? n_out : CAP_OUT;
+        const uint4 me4 = s_rd[i - lds_lo];
+        const uint32_t p = me4.x;
+        const unsigned long long me = r_rg[i];
+        const uint32_t g = (uint32_t)(me >> 32) - 1u;
+        gi = (uint32_t)me - 1u;
+        const uint32_t my_sample = me4.w & 0xfffu;
+        const bool run_start = (fl & RF_RUN) != 0;
+        if (run_start) run_first[g] = i;
+        if (fl & RF_GRP) grp_first[gi] = i;
+        unsigned long long chars = me4.w >> 13;
+        depth = 1;
+        const unsigned long long pw = p;                                                    // a read is inside while start + window > p
+        uint32_t j = i;                                                                     // records [j, i) have been looked at
+        bool out = false, seen_prev = false; uint32_t prev_x = 0;
+        while (j > lds_lo) {
+            const uint32_t k = j - 1u - lds_lo;
+            if (!(s_fl[k] & RF_PILE)) { --j; continue; }
+            const uint4 x = s_rd[k];
+            if (!seen_prev) { seen_prev = true; prev_x = x.x; }
+            if (x.z != me4.z || (x.w & 0xfffu) != my_sample || (unsigned long long)x.x + window <= pw) { out = true; break; }
+            if (x.y > p && !(x.w & 0x1000u)) { ++depth; chars += x.w >> 13; }
+            --j;
+        }
+        while (!out && j > 0) {
+            const uint32_t k = j - 1u;
+            if (!(r_flags[k] & RF_PILE)) { --j; continue; }
+            const uint4 x = rd[k];
+            if (!seen_prev) { seen_prev = true; prev_x = x.x; }
+            if (x.z != me4.z || (x.w & 0xfffu) != my_sample || (unsigned long long)x.x + window <= pw) { out = true; break; }
+            if (x.y > p && !(x.w & 0x1000u)) { ++depth; chars += x.w >> 13; }
+            --j;
+        }
+        for (uint32_t k = 0; k < n_out; ++k) {                                              // the round's far-reaching reads: alive here when of this run, before i, ending beyond p
+            const uint32_t o = outliers[k];
+            if (o < i) { const uint4 x = rd[o]; if ((x.w & 0xfffu) == my_sample && x.z == me4.z && x.y > p) { ++depth; chars += x.w >> 13; } }
+        }
+        // first read of the run whose end lies beyond position 1 (the first line under metaSNV's `name 1 LEN` split): a read that starts at
+        // position >= 1 always qualifies, so only the reads at position 0 and the first one behind them can be it -- a handful of atomics per run
+        if (me4.y > 1u && (run_start || p == 0u || (seen_prev && prev_x == 0u))) atomicMin(&run_f1[g], i);
+        spill = r_pre[i + 1u].spill - r_pre[i].spill;
+        const uint32_t ov = ovr ? ovr[i] : 0u;
+        if (ov & 1u) { depth = ov >> 16; r_depth[i] = (uint16_t)depth; }
+        else {
+            r_depth[i] = (uint16_t)(depth < 0xffffu ? depth : 0xffffu);
+            uint32_t need = 0;
+            if (P.max_depth > 0 && depth - 1u > (uint32_t)P.max_depth) need |= NEED_CAP;         // live.size() > max_depth before the push
+            if (P.token_limit > 0 && chars >= (unsigned long long)P.token_limit) need |= NEED_TOKEN;
+            if (need) atomicOr(&acc[(size_t)my_sample * ACC_COPIES].need_host, need);
+            depth = depth < 0xffffu ? depth : 0xffffu;
+        }
+    } else if (i < n_rec) r_depth[i] = 0;
+    // depth bounds per group: [2 gi] over all its reads (every read has a piece in its first tile), [2 gi + 1] over the reads that leave
+    // pieces in the tile behind.  A wavefront's reads nearly always share one group: one atomic per wavefront and bound then.
+    uint32_t g_any = gi;
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t x = __shfl_xor(g_any, o); g_any = x < g_any ? x : g_any; }      // (a group of the wavefront, if it has a pileup read at all)
+    if (g_any != 0xffffffffu) {
+        if (__all(gi == g_any || !valid)) {
+            uint32_t a = valid ? depth : 0u, b = (valid && spill) ? depth : 0u;
+            for (int o = 32; o > 0; o >>= 1) { const uint32_t x = __shfl_xor(a, o), y = __shfl_xor(b, o); a = x > a ? x : a; b = y > b ? y : b; }
+            if ((threadIdx.x & 63u) == 0) { atomicMax(&grp_md[2u * g_any], a); if (b) atomicMax(&grp_md[2u * g_any + 1u], b); }
+        } else if (valid) { atomicMax(&grp_md[2u * gi], depth); if (spill) atomicMax(&grp_md[2u * gi + 1u], depth); }
+    }
+}
+__global__ void msnv_run_table2(uint32_t n_runs, const uint32_t *run_first, const uint32_t *run_f1, const uint4 *rd, DpRun *runs) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_runs) return;
+    const uint4 a = rd[run_first[g]];
+    DpRun o;
+    o.sample = a.w & 0xfffu; o.tid = (int32_t)a.z; o.first_any = (int32_t)a.x;
+    const uint32_t f = run_f1[g];
+    if (f == 0xffffffffu) o.first_from1 = -1;
+    else { const int32_t q = (int32_t)rd[f].x; o.first_from1 = q > 1 ? q : 1; }
+    runs[g] = o;
+}
+__global__ void msnv_group_table2(uint32_t n_groups, uint32_t n_rec, const uint32_t *grp_first, const RecCnt *r_pre, const uint4 *rd, const uint32_t *r_ftile, const uint32_t *grp_md, uint2 *grp_pre, DevGroupRec *out) {
+    const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi > n_groups) return;
+    const uint32_t f = gi < n_groups ? grp_first[gi] : n_rec;
+    const RecCnt pf = r_pre[f];
+    grp_pre[gi] = make_uint2(pf.npiece, pf.spill);
+    if (gi == n_groups) return;
+    const uint32_t e = gi + 1u < n_groups ? grp_first[gi + 1u] : n_rec;
+    const RecCnt pe = r_pre[e];
+    const uint4 a = rd[f];
+    DevGroupRec o;
+    o.sample = a.w & 0xfffu; o.tid = (int32_t)a.z; o.tile = r_ftile[f];
+    o.a = pf.npiece; o.b = pe.npiece - (pe.spill - pf.spill); o.end = pe.npiece; o.md_own = grp_md[2u * gi]; o.md_next = grp_md[2u * gi + 1u];
+    out[gi] = o;
+}
+// per sample: where its records' pieces / seq bytes / intervals start, the first pileup read -- and where its columns lie in the round's buffer
+// (round 6: the layout is the device's; the host sized the buffer by the round's totals and learns the shares with the other small results)
+struct DpSampleSum2 { unsigned long long sbase0, first_key, beyond_key, seq_off; uint32_t pbase0, ibase0, first_end, pad; };
+__global__ void msnv_sample_layout(const uint32_t *rec_base, uint32_t n_samples, const RecCnt *r_pre, const DpAcc *acc, const uint4 *rd, uint8_t *r_seq, uint8_t *r_qual, const uint8_t *cut_marks,
+                                   DpSampleSum2 *out, unsigned long long *sbase0, DpSampleDst *dst, unsigned long long *piece_bytes) {
+    const uint32_t s = threadIdx.x;                                  // ONE workgroup: the shares are a running sum over the samples (<= 2048 of them a round)
+    __shared__ unsigned long long sh[2049];
+    for (uint32_t k = s; k <= n_samples; k += blockDim.x) sh[k] = r_pre[rec_base[k]].seqb;
+    __syncthreads();
+    if (s == 0) {
+        unsigned long long o = 0;
+        for (uint32_t k = 0; k < n_samples; ++k) { const unsigned long long pb = sh[k + 1] - sh[k]; sh[k] = o; o += (pb + 32ull + 15ull) & ~15ull; }
+        sh[n_samples] = o;
+    }
+    __syncthreads();
+    for (uint32_t k = s; k <= n_samples; k += blockDim.x) {
+        const RecCnt pre = r_pre[rec_base[k]];
+        DpSampleSum2 o{};
+        o.sbase0 = pre.seqb; o.pbase0 = pre.npiece; o.ibase0 = pre.niv; o.seq_off = sh[k];
+        sbase0[k] = pre.seqb;
+        if (k < n_samples) {
+            const DpAcc a = acc[(size_t)k * ACC_COPIES];              // (folded: msnv_acc_fold)
+            if (a.first_pile != ~0ull) { const uint4 x = rd[a.first_pile]; o.first_key = (unsigned long long)x.z << 32 | x.x; o.first_end = x.y; }
+            if (a.beyond != ~0ull) { const uint4 x = rd[a.beyond]; o.beyond_key = (unsigned long long)x.z << 32 | x.x; }
+            dst[k] = DpSampleDst{r_seq + sh[k], r_qual + sh[k] / 4, pre.npiece, cut_marks ? cut_marks[k] : 0u, 0u};
+            piece_bytes[k] = r_pre[rec_base[k + 1]].seqb - pre.seqb;
+        }
+        out[k] = o;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ overlapping mates
 // `samtools mpileup` without -x lets htslib's pileup engine edit the qualities of proper-pair mates that overlap on the reference before
 // the -Q cutoff sees them (sam.c overlap_push / tweak_overlap_quality [EXT]; pack.cpp: filter_and_edit restates the engine, read after read,
@@ -894,7 +1427,7 @@ __device__ void tweak_pair(uint8_t *pa, const Rec &a, uint8_t *pb, const Rec &b)
     }
 }
 __global__ void msnv_ovl_groups(const uint32_t *starts, uint32_t n_groups, uint32_t n, const uint32_t *svals, uint8_t *raw, const unsigned long long *rec_off,
-                                const uint32_t *r_end, const uint16_t *rec_sample, const uint8_t *skip_sample) {
+                                const uint4 *rd, const uint16_t *rec_sample, const uint8_t *skip_sample) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_groups) return;
     const uint32_t lo = starts[g], hi = g + 1 < n_groups ? starts[g + 1] : n;
@@ -919,7 +1452,7 @@ __global__ void msnv_ovl_groups(const uint32_t *starts, uint32_t n_groups, uint3
             const Rec a = rec_load(q, ~0ull);
             for (int w = found; w + 1 < n_wait; ++w) wait[w] = wait[w + 1];        // the entry leaves either way (stale: erased; alive: edited and erased)
             --n_wait;
-            if (a.tid == r.tid && (long long)r_end[j] > (long long)r.pos) { tweak_pair(q, a, p, r); continue; }
+            if (a.tid == r.tid && (long long)rd[j].y > (long long)r.pos) { tweak_pair(q, a, p, r); continue; }
         }
         if (r.mpos >= r.pos || ((r.flag & 1u) && r.mpos == -1)) { if (n_wait < OVL_SLOTS) wait[n_wait++] = i; }
     }
@@ -928,7 +1461,6 @@ __global__ void msnv_ovl_groups(const uint32_t *starts, uint32_t n_groups, uint3
 // ------------------------------------------------------------------------------------------ bases and quality flags
 // Pieces start on 4 bases, so a piece's flags start on bit 0 or 4 of a byte: whole bytes are stored, the two nibbles a piece shares with
 // its neighbours' bytes are OR-ed in atomically (the flag column is cleared first).
-struct DpSampleDst { uint8_t *seq, *qual; unsigned long long pbase0; uint32_t cut_marks, pad; };
 __device__ __forceinline__ void or_byte(uint8_t *p, uint32_t v) {
     const uintptr_t a = reinterpret_cast<uintptr_t>(p);
     atomicOr(reinterpret_cast<uint32_t *>(a & ~(uintptr_t)3), v << (8u * (uint32_t)(a & 3u)));
@@ -1081,7 +1613,7 @@ __device__ __forceinline__ void piece_lane(const Src &src, unsigned long long se
 }
 struct EmitArgs {
     const uint8_t *raw; const unsigned long long *rec_off; const uint16_t *rec_sample; uint32_t n_rec; const DpContig *ctg; const uint8_t *r_flags; const uint16_t *r_depth;
-    const RecCnt *r_cnt, *blk_pre; const unsigned long long *samp_sbase0, *rg; const uint2 *grp_pre; uint32_t in_order;
+    const RecCnt *r_pre; const unsigned long long *samp_sbase0, *rg; const uint2 *grp_pre; uint32_t in_order;      // r_pre: places before every record (entry n_rec: totals); rg: run << 32 | group of a pileup RECORD
     ReadHdr *hdr; int32_t *ptid, *pend; uint16_t *pdepth; int32_t *cov_tid, *cov_beg, *cov_end; uint32_t noseq_counts;
     const uint32_t *pref4; DpParams P; const DpSampleDst *dst; DpAcc *acc;
     uint32_t force_slow;                                           // MSNV_EMIT=slow (tests): every block takes msnv_emit_block_slow
@@ -1122,7 +1654,7 @@ struct LdsOut {
     }
 };
 template <class Src, class Out>
-__device__ __forceinline__ void emit_record(const EmitArgs &A, const Src &src, const Out &out, unsigned long long rec_o, const RecCnt me, uint32_t sub, uint8_t f, uint32_t s, uint16_t depth) {
+__device__ __forceinline__ void emit_record(const EmitArgs &A, const Src &src, const Out &out, unsigned long long rec_o, const RecCnt me, uint32_t sub, uint8_t f, uint32_t s, uint16_t depth, uint32_t rec_index) {
     if (!(f & (RF_PILE | RF_COV))) return;
     const int32_t tid = (int32_t)src.ld32(rec_o + 4), pos = (int32_t)src.ld32(rec_o + 8);
     const uint32_t w3 = src.ld32(rec_o + 12), fn = src.ld32(rec_o + 16);
@@ -1140,7 +1672,7 @@ __device__ __forceinline__ void emit_record(const EmitArgs &A, const Src &src, c
     const unsigned long long sbase0 = A.samp_sbase0[s];
     uint2 pf = make_uint2(0u, 0u), pe = make_uint2(0u, 0u);
     if ((f & RF_PILE) && !A.in_order) {
-        const uint32_t gi = (uint32_t)A.rg[me.pile] - 1u;
+        const uint32_t gi = (uint32_t)A.rg[rec_index] - 1u;
         pf = A.grp_pre[gi]; pe = A.grp_pre[gi + 1u];
     }
     // ONE walk over the CIGAR for both tools: qaCompute's intervals (lane 0; qaCompute.cpp:530-552: every op behind a leading clip moves the
@@ -1311,11 +1843,11 @@ __global__ __launch_bounds__(256) void msnv_emit_block(const EmitArgs A) {
     const unsigned long long lo = A.rec_off[i0] & ~15ull, hi = A.rec_off[i0 + nrec];      // (entry n_rec: the end of the round's records)
     const bool direct = hi - lo > EW_BYTES;
     const uint32_t smp_first = A.rec_sample[i0], smp_last = A.rec_sample[i0 + nrec - 1u];
-    const RecCnt base = A.blk_pre[b], next = A.blk_pre[b + 1];
+    const RecCnt base = A.r_pre[i0], next = A.r_pre[i0 + nrec];
     // ---- the first wavefront's lanes: what their record needs of the per-record columns (asked for together with the window)
     const uint32_t i = i0 + (tid < nrec ? tid : 0u);
-    uint8_t f = 0; uint16_t depth = 0; unsigned long long ro = 0; RecCnt mine{};
-    if (tid < PB) { f = A.r_flags[i]; depth = A.r_depth[i]; ro = A.rec_off[i]; if (tid < nrec) mine = A.r_cnt[i]; }
+    uint8_t f = 0; uint16_t depth = 0; unsigned long long ro = 0; RecCnt pre{}; uint32_t my_pieces = 0;
+    if (tid < PB) { f = A.r_flags[i]; depth = A.r_depth[i]; ro = A.rec_off[i]; pre = A.r_pre[i]; if (tid < nrec) my_pieces = A.r_pre[i + 1u].npiece - pre.npiece; }
     // ---- the block's bytes into LDS
     if (!direct) {
         const uint32_t n16 = (uint32_t)((hi - lo + 15) >> 4);
@@ -1339,19 +1871,10 @@ __global__ __launch_bounds__(256) void msnv_emit_block(const EmitArgs A) {
     LdsSrcK lsrc; lsrc.w = reinterpret_cast<const uint32_t *>(win);
     const DpSampleDst d = A.dst[smp_first];
     if (tid < PB) {
-        // ---- phase A (one wavefront): every record's own places = the block's base + the sums of the records before it in the block
+        // ---- phase A (one wavefront)
         // (its group's words and its contig are asked for here, not under the window's loads: the window's way into LDS would wait for
         // these chains of dependent loads -- measured: 2.24 -> 2.38 ms)
-        const RecCnt pre = cnt_add(base, wave_excl_cnt(mine));
-        DpContig ctg_mine{}; uint2 pf = make_uint2(0u, 0u), pe = make_uint2(0u, 0u);
-        if (tid < nrec) {
-            if ((f & RF_PILE) && !A.in_order) {
-                const uint32_t gi = (uint32_t)A.rg[pre.pile] - 1u;
-                pf = A.grp_pre[gi]; pe = A.grp_pre[gi + 1u];
-            }
-            if (f & (RF_PILE | RF_COV)) ctg_mine = A.ctg[(int32_t)lsrc.ld32(ro - lo + 4)];
-        }
-        uint32_t more = mine.npiece ? mine.npiece - 1u : 0u, more_pre = more;
+        uint32_t more = my_pieces ? my_pieces - 1u : 0u, more_pre = more;
         for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(more_pre, o); if ((int)tid >= o) more_pre += y; }
         const uint32_t more_all = __shfl(more_pre, 63);
         more_pre -= more;
@@ -1369,6 +1892,14 @@ __global__ __launch_bounds__(256) void msnv_emit_block(const EmitArgs A) {
             if (odd) A.slow[1u + atomicAdd(A.slow, 1u)] = b;
         }
         if (!odd) {
+            DpContig ctg_mine{}; uint2 pf = make_uint2(0u, 0u), pe = make_uint2(0u, 0u);
+            if (tid < nrec) {
+                if ((f & RF_PILE) && !A.in_order) {
+                    const uint32_t gi = (uint32_t)A.rg[i] - 1u;
+                    pf = A.grp_pre[gi]; pe = A.grp_pre[gi + 1u];
+                }
+                if (f & (RF_PILE | RF_COV)) ctg_mine = A.ctg[(int32_t)lsrc.ld32(ro - lo + 4)];
+            }
             if (tid < nrec) emit_walk(A, lsrc, ro - lo, pre, f, depth, d, sb0, ctg_mine, pf, pe, &s_desc[tid], &s_desc[PB + more_pre]);
             else { PieceDesc none{}; s_desc[tid] = none; }
         }
@@ -1443,14 +1974,10 @@ __global__ __launch_bounds__(256) void msnv_emit_block_slow(const EmitArgs A) {
         const uint32_t nrec = A.n_rec - i0 < PB ? A.n_rec - i0 : PB;
         const uint32_t r = tid >> 2, sub = tid & 3u, i = i0 + (r < nrec ? r : 0u);
         const uint8_t f = A.r_flags[i]; const uint32_t smp = A.rec_sample[i]; const uint16_t depth = A.r_depth[i]; const unsigned long long ro = A.rec_off[i];
-        const RecCnt base = A.blk_pre[b];
         __syncthreads();                                            // (the list's previous block has read s_pre)
-        if (tid < 64) {
-            const RecCnt mine = tid < nrec ? A.r_cnt[i0 + tid] : RecCnt{};
-            s_pre[tid] = cnt_add(base, wave_excl_cnt(mine));
-        }
+        if (tid < 64) s_pre[tid] = A.r_pre[i0 + (tid < nrec ? tid : 0u)];
         __syncthreads();
-        if (r < nrec) emit_record(A, gsrc, gout, ro, s_pre[r], sub, f, smp, depth);
+        if (r < nrec) emit_record(A, gsrc, gout, ro, s_pre[r], sub, f, smp, depth, i);
     }
 }
 
@@ -1579,10 +2106,10 @@ struct Timer {          // HIP events around a group of launches
 unsigned bit_width_u64(unsigned long long v) { unsigned b = 0; while (v) { ++b; v >>= 1; } return b; }
 inline dim3 grid_for(uint64_t n, uint32_t block) { return dim3((unsigned)std::max<uint64_t>(1, (n + block - 1) / block)); }
 
-// contig table + packed FASTA of the selected contigs
-int build_tables(msnv_dataset &ds) {
+// contig table (small: goes up at once, the record scan's walk reads it) ...
+int build_contigs(msnv_dataset &ds) {
     DevPackTables &t = ds.dp;
-    if (t.ready) return MSNV_OK;
+    if (t.contigs) return MSNV_OK;
     const size_t NC = ds.names.size();
     std::vector<DpContig> ct(NC);
     uint64_t nib = 0;
@@ -1593,14 +2120,26 @@ int build_tables(msnv_dataset &ds) {
         if (ds.sel[c] && ds.has_seq[c]) nib += (ds.seqs[c].size() + 7) & ~(size_t)7;
     }
     t.pref_words = nib / 8 + 8;                                  // (msnv_emit_block reads five words from a lane's first position)
-    // (the copies below are plain blocking ones on the null stream: this function runs on a thread of its own beside the round's record scan
-    // -- devpack_add_round --, whose stream they must not wait for; whoever joins that thread finds the tables in place)
     if (int rc = dev_alloc(&t.contigs, std::max<size_t>(1, NC) * sizeof(DpContig), nullptr)) return rc;
     if (int rc = dev_alloc((void **)&t.overhang, (std::max<size_t>(1, NC) + 1) * sizeof(int32_t), nullptr)) return rc;
-    if (int rc = dev_alloc((void **)&t.pref4, t.pref_words * sizeof(uint32_t), nullptr)) return rc;
+    // (plain blocking copies on the null stream: fresh buffers, nothing of the context's stream to order against)
     if (NC) HIP_TRY(hipMemcpy(t.contigs, ct.data(), NC * sizeof(DpContig), hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(t.overhang, 0, (std::max<size_t>(1, NC) + 1) * sizeof(int32_t)));
+    HIP_TRY(hipStreamSynchronize(nullptr));
     t.any_overhang = reinterpret_cast<uint32_t *>(t.overhang + std::max<size_t>(1, NC));
+    return MSNV_OK;
+}
+// ... and the packed FASTA of the selected contigs (the emit kernels read it: built on a thread of its own beside the round's first kernels)
+int build_tables(msnv_dataset &ds) {
+    DevPackTables &t = ds.dp;
+    if (t.ready) return MSNV_OK;
+    const size_t NC = ds.names.size();
+    std::vector<uint64_t> pref_off(NC, 0);
+    {
+        uint64_t nib = 0;
+        for (size_t c = 0; c < NC; ++c) { pref_off[c] = nib; if (ds.sel[c] && ds.has_seq[c]) nib += (ds.seqs[c].size() + 7) & ~(size_t)7; }
+    }
+    if (int rc = dev_alloc((void **)&t.pref4, t.pref_words * sizeof(uint32_t), nullptr)) return rc;
     // the FASTA characters of the selected contigs -> nt16 codes, 8 per word, and lower-case bits, 32 per word: once per dataset, kept on the
     // host too (finalize lays them out by tile without going back to the characters); big references are cut into pieces for the host threads
     static const struct Tab { uint8_t code[256], lc[256]; Tab() { for (int c = 0; c < 256; ++c) { code[c] = nt16_of_char((unsigned char)c); lc[c] = (c == 'a' || c == 'c' || c == 'g' || c == 't') ? 1 : 0; } } } tab;
@@ -1611,7 +2150,7 @@ int build_tables(msnv_dataset &ds) {
     std::vector<Job> jobs;
     for (size_t c = 0; c < NC; ++c) {
         if (!ds.sel[c] || !ds.has_seq[c]) continue;
-        t.h_code_off[c] = ct[c].pref_off / 8; t.h_lc_off[c] = lc_words;
+        t.h_code_off[c] = pref_off[c] / 8; t.h_lc_off[c] = lc_words;
         const uint64_t nw = (ds.seqs[c].size() + 7) / 8;
         lc_words += (ds.seqs[c].size() + 31) / 32;
         for (uint64_t w = 0; w < nw; w += 1u << 14) jobs.push_back(Job{c, w, std::min<uint64_t>(nw, w + (1u << 14))});
@@ -1638,7 +2177,6 @@ int build_tables(msnv_dataset &ds) {
         for (auto &x : th) x.join();
     }
     HIP_TRY(hipMemcpy(t.pref4, t.h_codes.data(), t.pref_words * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipStreamSynchronize(nullptr));                      // (the memset above)
     t.ready = true;
     return MSNV_OK;
 }
@@ -1680,6 +2218,7 @@ int devpack_sync_pending(msnv_dataset &ds) {
     HIP_TRY(hipEventSynchronize((hipEvent_t)T.pending.ev1));
     float ms = 0;
     if (hipEventElapsedTime(&ms, (hipEvent_t)T.pending.ev0, (hipEvent_t)T.pending.ev1) == hipSuccess) T.ms_emit += ms;
+    if (T.pending.has_evd) { T.pending.has_evd = false; if (hipEventElapsedTime(&ms, (hipEvent_t)T.pending.evd, (hipEvent_t)T.pending.ev0) == hipSuccess) T.ms_depth += ms; }      // (the quick route's depth stage: never waited for by itself)
     const DpAcc *a = static_cast<const DpAcc *>(T.pin);
     for (size_t s = 0; s < T.pending.n && T.pending.first + s < ds.samples.size(); ++s) {
         SampleCols &sc = ds.samples[T.pending.first + s];
@@ -1696,7 +2235,10 @@ void devpack_ctx_release(msnv_ctx *ctx) {
 void devpack_release(msnv_dataset &ds) {
     DevPackTables &t = ds.dp;
     if (t.pending.active) { (void)hipDeviceSynchronize(); t.pending.active = false; }
-    if (t.pending.ev0) { (void)hipEventDestroy((hipEvent_t)t.pending.ev0); (void)hipEventDestroy((hipEvent_t)t.pending.ev1); t.pending.ev0 = t.pending.ev1 = nullptr; }
+    if (t.pending.ev0) {
+        (void)hipEventDestroy((hipEvent_t)t.pending.ev0); (void)hipEventDestroy((hipEvent_t)t.pending.ev1); (void)hipEventDestroy((hipEvent_t)t.pending.evh); (void)hipEventDestroy((hipEvent_t)t.pending.evd);
+        t.pending.ev0 = t.pending.ev1 = t.pending.evh = t.pending.evd = nullptr;
+    }
     if (t.cov_event) { (void)hipEventDestroy((hipEvent_t)t.cov_event); t.cov_event = nullptr; }
     if (t.cov_job || !t.fin_keep.empty()) (void)hipDeviceSynchronize();
     // everything of the pack goes back in ONE batch (one wait for the device instead of one per buffer: dev_free_batch)
@@ -1760,14 +2302,17 @@ struct ScanResult {
     uint32_t *d_recbase = nullptr; unsigned long long *d_send = nullptr, *d_recoff = nullptr; uint16_t *d_recsample = nullptr;
     double wall_upload_s = 0, ms_scan = 0; uint64_t n_redone = 0;
 };
+// stage_only: the streams are put in place and nothing is scanned; a later call with the same ScanResult (raw set) scans what is there.
 static int scan_streams(hipStream_t st, const int device, BufPool &pool, const uint8_t *const *streams, const uint64_t *n_bytes, const size_t S, const bool on_device, const int NC_, ScanResult &R,
-                        const uint8_t *in_place_base = nullptr, uint64_t in_place_capacity = 0) {
+                        const uint8_t *in_place_base = nullptr, uint64_t in_place_capacity = 0, bool stage_only = false) {
     const size_t NC = (size_t)NC_;
     Timer tm(st);
     // ---- the round's streams side by side in one buffer: every stream starts on 16 bytes, readable bytes behind the last
-    std::vector<unsigned long long> &s_beg = R.s_beg, &s_end = R.s_end; s_beg.assign(S, 0); s_end.assign(S, 0);
-    uint64_t raw_bytes = 0;
-    uint8_t *raw = nullptr;
+    std::vector<unsigned long long> &s_beg = R.s_beg, &s_end = R.s_end;
+    uint64_t raw_bytes = R.raw_bytes;
+    uint8_t *raw = R.raw;
+    if (!R.raw) {
+    s_beg.assign(S, 0); s_end.assign(S, 0);
     if (in_place_base) {
         // the streams where they lie: offsets into the caller's buffer (api.cpp has checked order, alignment of the base and the bytes behind the last)
         for (size_t s = 0; s < S; ++s) { s_beg[s] = (unsigned long long)(streams[s] - in_place_base); s_end[s] = s_beg[s] + n_bytes[s]; }
@@ -1799,6 +2344,8 @@ static int scan_streams(hipStream_t st, const int device, BufPool &pool, const u
     }
     }
     R.raw = raw; R.raw_bytes = raw_bytes;
+    }
+    if (stage_only) return MSNV_OK;
 
     // ---- record boundaries, the quick way: sub-segments walked side by side, seams checked on the device (MSNV_SCAN=segments: the careful kernel only)
     const bool quick = [] { const char *e = getenv("MSNV_SCAN"); return !(e && e[0] == 's'); }();
@@ -2197,8 +2744,11 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     fin_trace_reset();
     if (int rc = devpack_sync_pending(ds)) return rc;              // (the round before may still be writing: its work buffers are this round's)
     DevPackTables &T = ds.dp;
-    // the dataset's tables (contigs, packed FASTA of the selected ones) are built by the first round, on a thread of its own BESIDE the
-    // record scan, which needs none of them (round 5: 0.4 ms in front of it)
+    fin_trace("  pack: enter");
+    if (int rc = build_contigs(ds)) return rc;
+    fin_trace("  pack: contigs");
+    // the packed FASTA of the selected contigs is built by the first round, on a thread of its own BESIDE the round's first kernels, which
+    // do not read it (round 5: 0.4 ms in front of them); the emit kernels do
     struct TablesJob {
         std::thread th; int rc = MSNV_OK; std::string msg;
         int join() { if (th.joinable()) th.join(); if (rc) return fail(rc, "%s", msg.c_str()); return MSNV_OK; }
@@ -2227,471 +2777,657 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     type *name = static_cast<type *>(pool.get((uint64_t)(count) * sizeof(type)));      \
     if (!name) return pool.rc
 
-    // ---- the round's streams side by side in one buffer, their record boundaries (scan_streams)
+    // ---- the round's streams side by side in one buffer (or where they lie, in HBM)
     ScanResult SR;
-    if (int rc = scan_streams(st, ds.ctx->device, pool, streams, n_bytes, S, on_device, (int)NC, SR, in_place_base, in_place_capacity)) return rc;
-    T.wall_upload_s += SR.wall_upload_s; T.raw_bytes += SR.raw_bytes; T.ms_scan += SR.ms_scan; T.n_scan_redone += SR.n_redone; T.n_records += SR.NR;
+    if (int rc = scan_streams(st, ds.ctx->device, pool, streams, n_bytes, S, on_device, (int)NC, SR, in_place_base, in_place_capacity, true)) return rc;
+    T.wall_upload_s += SR.wall_upload_s; T.raw_bytes += SR.raw_bytes;
+    SR.wall_upload_s = 0;
     uint8_t *const raw = SR.raw;
-    const uint64_t raw_bytes = SR.raw_bytes; (void)raw_bytes;
-    const std::vector<unsigned long long> &s_beg = SR.s_beg, &s_end = SR.s_end, &bad_off = SR.bad_off;
-    const std::vector<uint32_t> &rec_base = SR.rec_base, &n_rec = SR.n_rec;
-    const uint32_t NR = SR.NR;
-    const uint64_t NRa = (uint64_t)NR + 1;
-    uint32_t *const d_recbase = SR.d_recbase; unsigned long long *const d_send = SR.d_send, *const d_recoff = SR.d_recoff; uint16_t *const d_recsample = SR.d_recsample;
-    (void)d_send; (void)n_rec; (void)s_beg; (void)s_end;
-
-    fin_trace("  pack: scan done");
-    if (int rc = tables.join()) return rc;
-    // ---- measure (+ the host pre-pass for the samples that need one, then once more with its verdicts)
-    DP_BUF(uint8_t, d_flags, NRa);
-    DP_BUF(unsigned long long, d_key, NRa);
-    DP_BUF(uint32_t, d_end, NRa);
-    DP_BUF(uint32_t, d_maxc, NRa);
-    DP_BUF(uint32_t, d_ftile, NRa);
-    DP_BUF(RecCnt, d_cnt, NRa);
-    const uint64_t NB = ((uint64_t)NR + PB - 1) / PB, NBa = NB + 1;   // blocks of PB records: their sums and bases (entry NB of the bases = the round's totals)
-    DP_BUF(RecCnt, d_blkcnt, NBa);
-    DP_BUF(RecCnt, d_blkpre, NBa);
-    DP_BUF(uint32_t, d_outl, CAP_OUT);
-    DP_BUF(uint16_t, d_depth, NRa);
-    DP_BUF(uint32_t, d_ovr, NRa);
-    DP_BUF(DpAcc, d_acc, S * ACC_COPIES);
-    DP_BUF(uint32_t, d_misc, MISC_WORDS);
-    DP_BUF(uint8_t, d_tmp, 1u << 20);                             // rocPRIM's temporary storage (grown below when a call asks for more)
-    size_t tmp_cap = (size_t)T.scratch[pool.next - 1].second;
-    const size_t tmp_slot = pool.next - 1;
-    auto tmp_for = [&](size_t need) -> int {
-        if (need <= tmp_cap) return MSNV_OK;
-        const size_t keep = pool.next;
-        pool.next = tmp_slot;
-        d_tmp = static_cast<uint8_t *>(pool.get(need));
-        pool.next = keep;
-        if (!d_tmp) return pool.rc;
-        tmp_cap = (size_t)T.scratch[tmp_slot].second;
-        return MSNV_OK;
-    };
-    auto scan32 = [&](const uint32_t *in, uint32_t *out, size_t cnt, bool inclusive) -> int {
-        size_t need = 0;
-        if (inclusive) HIP_TRY(rocprim::inclusive_scan(nullptr, need, in, out, cnt, rocprim::plus<uint32_t>(), st));
-        else HIP_TRY(rocprim::exclusive_scan(nullptr, need, in, out, 0u, cnt, rocprim::plus<uint32_t>(), st));
-        if (int rc = tmp_for(need)) return rc;
-        if (inclusive) HIP_TRY(rocprim::inclusive_scan(d_tmp, need, in, out, cnt, rocprim::plus<uint32_t>(), st));
-        else HIP_TRY(rocprim::exclusive_scan(d_tmp, need, in, out, 0u, cnt, rocprim::plus<uint32_t>(), st));
-        return MSNV_OK;
-    };
-    auto sort64 = [&](unsigned long long *kin, unsigned long long *kout, uint32_t *vin, uint32_t *vout, size_t cnt, unsigned end_bit) -> int {
-        size_t need = 0;
-        HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, kin, kout, vin, vout, cnt, 0u, end_bit, st));
-        if (int rc = tmp_for(need)) return rc;
-        HIP_TRY(rocprim::radix_sort_pairs(d_tmp, need, kin, kout, vin, vout, cnt, 0u, end_bit, st));
-        return MSNV_OK;
-    };
-    std::vector<DpAcc> acc(S);
-    std::vector<uint8_t> cut_marks(S, 0);
+    const std::vector<unsigned long long> &s_beg = SR.s_beg, &s_end = SR.s_end;
+    fin_trace("  pack: staged");
+    const size_t pool_staged = pool.next;
     const DpContig *ctg = static_cast<const DpContig *>(T.contigs);
+    const unsigned long long end_all = S ? s_end[S - 1] : 0ull;
+
+    // Two routes to the records' tables.  QUICK (round 6): record boundaries and everything a record decides by itself in ONE walk
+    // (msnv_scan_sub2), one wait for the round's totals, then every kernel up to msnv_emit_block launched back to back; what the host
+    // learns late -- an error, a sample that needs the host pre-pass, more far-reaching reads than the list holds -- sends the round through
+    // the CAREFUL route: round 5's stage-by-stage form (msnv_scan_sub / msnv_scan_segments, msnv_measure_reads, waits between the stages),
+    // which also words malformed input and takes the host pre-pass's verdicts.  MSNV_SCAN=segments and MSNV_FRONT=careful force it (tests).
+    const uint32_t sub_bytes = [] { const char *e = getenv("MSNV_SCAN_SUB"); const long long v = e ? atoll(e) : 4096; return (uint32_t)std::min<long long>(32768, std::max<long long>(64, v)); }();   // (per call: tests shrink it)
+    const bool quick_wanted = [] { const char *e = getenv("MSNV_SCAN"); const char *f = getenv("MSNV_FRONT"); return !(e && e[0] == 's') && !(f && f[0] == 'c'); }();
+    uint64_t n_sub64 = 0;
+    std::vector<SubStream> ss(S);
+    for (size_t s = 0; s < S; ++s) { ss[s] = SubStream{s_beg[s], s_end[s], (uint32_t)n_sub64, 0u}; n_sub64 += std::max<uint64_t>(1, (n_bytes[s] + sub_bytes - 1) / sub_bytes); }
+    const uint32_t cap2 = sub_bytes / 48u + 2u;                   // slots per sub-segment (a sub-segment of more, shorter records takes the careful route)
+    int route = (quick_wanted && S > 0 && sub_bytes <= 8192 && n_sub64 < 0x7ffffff0ull && n_sub64 * cap2 < 0xfffffff0ull) ? 0 : 1;
+
+    std::vector<DpAcc> acc(S);
+    std::vector<uint8_t> cut_marks(S, 0), host_sample(S, 0);
     std::vector<DpRun> runs;
     std::vector<DevGroupRec> groups;
-    RecCnt tot{};                                                 // the round's totals (d_pre[NR])
-    uint32_t NP = 0, n_runs = 0, n_groups = 0, need_sort = 0;
-    bool have_ovr = false;
-    DevBuf o_flag, o_rank, o_skip, o_keys, o_skeys, o_vals, o_svals, o_starts;      // overlapping mates (paired reads only: not from the pool)
-    uint32_t n_ovl_reads = 0, n_ovl_groups = 0;
-    std::vector<uint8_t> host_sample(S, 0);                       // samples whose sequential edits ran on the host (pre-pass)
-    unsigned long long *d_rg = nullptr; uint2 *d_grppre = nullptr;
-    uint32_t span_out = SPAN_OUT;
-    {   // behind the last record: the end of the round's records (a block of records reaches from its first record's start to the next block's)
-        const unsigned long long end_all = S ? s_end[S - 1] : 0ull;
-        HIP_TRY(hipMemcpyAsync(d_recoff + NR, &end_all, 8, hipMemcpyHostToDevice, st));
+    std::vector<DpSampleSum2> sum(S + 1);
+    std::vector<unsigned long long> piece_bytes(S);
+    uint32_t NR = 0, NPC = 0, NIV = 0;
+    bool in_order = false;
+    DevRound keep;
+    uint8_t *r_seq = nullptr, *r_qual = nullptr;
+    std::vector<uint32_t> rec_base_h;
+    RecCnt totals_h{};
+    ReadHdr *w_hdr = nullptr; int32_t *w_tid = nullptr, *w_end = nullptr; uint16_t *w_depth = nullptr;
+    DpSampleDst *d_dst = nullptr;
+
+    if (!T.pending.ev0) {
+        hipEvent_t a = nullptr, b = nullptr, c = nullptr, d = nullptr;
+        HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b)); HIP_TRY(hipEventCreate(&c)); HIP_TRY(hipEventCreate(&d));
+        T.pending.ev0 = a; T.pending.ev1 = b; T.pending.evh = c; T.pending.evd = d;
     }
-    const size_t depth_bufs_from = pool.next;
-    for (int pass = 0; pass < 2; ++pass) {
-        pool.next = depth_bufs_from;
+    for (;;) {
+        pool.next = pool_staged;
+        T.pending.has_evd = false;
+        DP_BUF(DpAcc, d_acc, S * ACC_COPIES);
+        DP_BUF(uint32_t, d_misc, MISC_WORDS);
+        DP_BUF(uint32_t, d_outl, CAP_OUT);
+        DP_BUF(uint8_t, d_cut, S);
+        DP_BUF(uint8_t, d_tmp, 1u << 20);                             // rocPRIM's temporary storage (grown below when a call asks for more)
+        size_t tmp_cap = (size_t)T.scratch[pool.next - 1].second;
+        const size_t tmp_slot = pool.next - 1;
+        auto tmp_for = [&](size_t need) -> int {
+            if (need <= tmp_cap) return MSNV_OK;
+            const size_t keep_next = pool.next;
+            pool.next = tmp_slot;
+            d_tmp = static_cast<uint8_t *>(pool.get(need));
+            pool.next = keep_next;
+            if (!d_tmp) return pool.rc;
+            tmp_cap = (size_t)T.scratch[tmp_slot].second;
+            return MSNV_OK;
+        };
+        auto scan32 = [&](const uint32_t *in, uint32_t *out, size_t cnt, bool inclusive) -> int {
+            size_t need = 0;
+            if (inclusive) HIP_TRY(rocprim::inclusive_scan(nullptr, need, in, out, cnt, rocprim::plus<uint32_t>(), st));
+            else HIP_TRY(rocprim::exclusive_scan(nullptr, need, in, out, 0u, cnt, rocprim::plus<uint32_t>(), st));
+            if (int rc = tmp_for(need)) return rc;
+            if (inclusive) HIP_TRY(rocprim::inclusive_scan(d_tmp, need, in, out, cnt, rocprim::plus<uint32_t>(), st));
+            else HIP_TRY(rocprim::exclusive_scan(d_tmp, need, in, out, 0u, cnt, rocprim::plus<uint32_t>(), st));
+            return MSNV_OK;
+        };
+        auto sort64 = [&](unsigned long long *kin, unsigned long long *kout, uint32_t *vin, uint32_t *vout, size_t cnt, unsigned end_bit) -> int {
+            size_t need = 0;
+            HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, kin, kout, vin, vout, cnt, 0u, end_bit, st));
+            if (int rc = tmp_for(need)) return rc;
+            HIP_TRY(rocprim::radix_sort_pairs(d_tmp, need, kin, kout, vin, vout, cnt, 0u, end_bit, st));
+            return MSNV_OK;
+        };
         hipLaunchKernelGGL(msnv_acc_init, grid_for(S * ACC_COPIES, 256), dim3(256), 0, st, d_acc, (uint32_t)(S * ACC_COPIES));
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemsetAsync(d_depth, 0, NRa * 2, st));
+        HIP_TRY(hipMemsetAsync(d_misc, 0, MISC_WORDS * 4, st));
+        uint32_t span_out = SPAN_OUT, n_runs = 0, n_groups = 0, n_ovl_total = 0;
+        uint64_t seqb_total = 0;
+        (void)n_ovl_total;
         uint32_t misc_h[MISC_WORDS] = {0, 0, 0, 0};
-        tm.start();
-        for (;;) {
-            HIP_TRY(hipMemsetAsync(d_misc, 0, MISC_WORDS * 4, st));
-            HIP_TRY(hipMemsetAsync(d_blkcnt + NB, 0, sizeof(RecCnt), st));
-            if (NR) {
-                hipLaunchKernelGGL(msnv_measure_reads, grid_for(NR, 256), dim3(256), 0, st, raw, d_recoff, d_recsample, d_recbase, d_send, NR, ctg, P, have_ovr ? d_ovr : nullptr, d_flags,
-                                   d_key, d_end, d_maxc, d_cnt, d_ftile, d_blkcnt, d_acc, d_misc, d_outl, span_out, T.overhang);
-                HIP_TRY(hipGetLastError());
-            }
-            {   // every block's base: rank among the pileup reads, first piece, first interval, next-tile pieces before it, first seq byte
-                size_t need = 0;
-                HIP_TRY(rocprim::exclusive_scan(nullptr, need, d_blkcnt, d_blkpre, RecCnt{}, (size_t)NBa, RecCntSum(), st));
-                if (int rc = tmp_for(need)) return rc;
-                HIP_TRY(rocprim::exclusive_scan(d_tmp, need, d_blkcnt, d_blkpre, RecCnt{}, (size_t)NBa, RecCntSum(), st));
-            }
-            HIP_TRY(hipMemcpyAsync(&tot, d_blkpre + NB, sizeof(RecCnt), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(misc_h, d_misc, MISC_WORDS * 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            if (misc_h[MISC_OVERHANG]) T.any_overhang_h = true;
-            if (misc_h[MISC_NOUT] <= CAP_OUT || span_out >= 0x40000000u) break;
-            // more far-reaching reads than the list holds (long reads): they are the ordinary reads of this round -- a wider window, again
-            span_out = span_out < 0x04000000u ? span_out * 16u : 0x7fffffffu;
-            hipLaunchKernelGGL(msnv_acc_init, grid_for(S * ACC_COPIES, 256), dim3(256), 0, st, d_acc, (uint32_t)(S * ACC_COPIES));
-            HIP_TRY(hipGetLastError());
-        }
-        NP = tot.pile;
-        T.ms_measure += tm.stop();
-        fin_trace("  pack: measure + block scan (sync)");
-        // ---- depth at every read start; the runs and the (run, first tile) groups of reads
-        n_runs = 0; n_groups = 0;
-        if (NP) {
-            const uint64_t NPa = (uint64_t)NP + 1;
-            DP_BUF(uint4, d_prd, NPa);
-            DP_BUF(uint32_t, d_pftile, NPa);
-            DP_BUF(uint32_t, d_prec, NPa);
-            DP_BUF(unsigned long long, d_rg_, NPa);
-            d_rg = d_rg_;
-            tm.start();
-            hipLaunchKernelGGL(msnv_pile_gather, grid_for(NR, 256), dim3(256), 0, st, d_cnt, d_blkpre, NR, d_recsample, d_key, d_end, d_maxc, d_ftile, span_out, d_prd, d_pftile, d_prec);
-            HIP_TRY(hipGetLastError());
-            {
-                auto in = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), RunGrpIn{d_prd, d_pftile});
-                size_t need = 0;
-                HIP_TRY(rocprim::inclusive_scan(nullptr, need, in, d_rg, (size_t)NP, rocprim::plus<unsigned long long>(), st));
-                if (int rc = tmp_for(need)) return rc;
-                HIP_TRY(rocprim::inclusive_scan(d_tmp, need, in, d_rg, (size_t)NP, rocprim::plus<unsigned long long>(), st));
-            }
-            unsigned long long last = 0;
-            HIP_TRY(hipMemcpyAsync(&last, d_rg + (NP - 1), 8, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            n_runs = (uint32_t)(last >> 32); n_groups = (uint32_t)last;
-            DP_BUF(uint32_t, d_runfirst, (uint64_t)n_runs + 1);
-            DP_BUF(uint32_t, d_runf1, (uint64_t)n_runs + 1);
-            DP_BUF(DpRun, d_runs, (uint64_t)n_runs + 1);
-            DP_BUF(uint32_t, d_grpfirst, (uint64_t)n_groups + 2);
-            DP_BUF(uint32_t, d_grpmd, 2 * ((uint64_t)n_groups + 1));
-            DP_BUF(uint2, d_grppre_, (uint64_t)n_groups + 2);
-            DP_BUF(DevGroupRec, d_groups, (uint64_t)n_groups + 1);
-            d_grppre = d_grppre_;
+        RdTables TB{};
+        uint32_t *d_recbase = nullptr; unsigned long long *d_send = nullptr;
+        uint16_t *d_depth = nullptr; uint32_t *d_ovr = nullptr;
+        bool have_ovr = false;
+        DevBuf o_flag, o_rank, o_skip, o_keys, o_skeys, o_vals, o_svals, o_starts;      // overlapping mates (paired reads only: not from the pool)
+        uint32_t n_ovl_reads = 0, n_ovl_groups = 0;
+        uint32_t *d_runfirst = nullptr, *d_runf1 = nullptr, *d_grpfirst = nullptr, *d_grpmd = nullptr; DpRun *d_runs = nullptr; uint2 *d_grppre = nullptr; DevGroupRec *d_groups = nullptr;
+        std::fill(host_sample.begin(), host_sample.end(), 0); std::fill(cut_marks.begin(), cut_marks.end(), 0);
+
+        // depth at every read start, the run and group tables: launched, not waited for
+        auto launch_depth_stage = [&]() -> int {
             HIP_TRY(hipMemsetAsync(d_runf1, 0xff, ((uint64_t)n_runs + 1) * 4, st));
             HIP_TRY(hipMemsetAsync(d_grpmd, 0, 2 * ((uint64_t)n_groups + 1) * 4, st));
-            const uint32_t n_out = std::min<uint32_t>(misc_h[MISC_NOUT], CAP_OUT);
-            hipLaunchKernelGGL(msnv_depth, grid_for(NP, 256), dim3(256), 0, st, d_rg, NP, d_prd, d_pftile, d_prec, d_cnt, have_ovr ? d_ovr : nullptr, P, misc_h[MISC_SPAN],
-                               d_outl, n_out, d_recsample, d_key, d_end, d_maxc, d_depth, d_runfirst, d_runf1, d_grpfirst, d_grpmd, d_acc, d_misc);
-            hipLaunchKernelGGL(msnv_run_table, grid_for(n_runs, 256), dim3(256), 0, st, n_runs, d_runfirst, d_runf1, d_prd, d_runs);
-            hipLaunchKernelGGL(msnv_group_pre, grid_for((uint64_t)n_groups + 1, 256), dim3(256), 0, st, n_groups, d_grpfirst, NR, d_blkpre, d_cnt, d_grppre);
-            hipLaunchKernelGGL(msnv_group_table, grid_for(n_groups, 256), dim3(256), 0, st, n_groups, d_grpfirst, d_grppre, d_recsample, d_key, d_ftile, d_grpmd, d_groups);
+            if (NR) hipLaunchKernelGGL(msnv_depth2, grid_for(NR, 256), dim3(256), 0, st, NR, TB.rd, TB.r_flags, TB.r_rg, TB.r_pre, TB.r_ftile, have_ovr ? d_ovr : nullptr, P, d_misc + MISC_SPAN, d_outl,
+                                       d_misc + MISC_NOUT, d_depth, d_runfirst, d_runf1, d_grpfirst, d_grpmd, d_acc);
+            if (n_runs) hipLaunchKernelGGL(msnv_run_table2, grid_for(n_runs, 256), dim3(256), 0, st, n_runs, d_runfirst, d_runf1, TB.rd, d_runs);
+            hipLaunchKernelGGL(msnv_group_table2, grid_for((uint64_t)n_groups + 1, 256), dim3(256), 0, st, n_groups, NR, d_grpfirst, TB.r_pre, TB.rd, TB.r_ftile, d_grpmd, d_grppre, d_groups);
+            hipLaunchKernelGGL(msnv_acc_fold, dim3((unsigned)S), dim3(64), 0, st, d_acc, (uint32_t)S);
             HIP_TRY(hipGetLastError());
-            runs.resize(n_runs); groups.resize(n_groups);
-            HIP_TRY(hipMemcpyAsync(runs.data(), d_runs, (size_t)n_runs * sizeof(DpRun), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(groups.data(), d_groups, (size_t)n_groups * sizeof(DevGroupRec), hipMemcpyDeviceToHost, st));
+            return MSNV_OK;
+        };
+        // errors, in record order (what the host stage's sequential walk would have met first)
+        auto check_errors = [&]() -> int {
+            for (size_t s = 0; s < S; ++s) {
+                const unsigned long long e = acc[s].err;
+                if (e != ~0ull) {
+                    const uint32_t kind = (uint32_t)(e & 7u); const unsigned long long idx = (e >> 3) - rec_base_h[s];
+                    return fail(MSNV_EFORMAT, "%s (sample %zu of the batch, record %llu)", err_text(kind), s, idx);
+                }
+                if (!SR.bad_off.empty() && SR.bad_off[s] != ~0ull) return fail(MSNV_EFORMAT, "malformed BAM record at byte %llu", SR.bad_off[s]);
+            }
+            return MSNV_OK;
+        };
+
+        if (route == 0) {
+            // ================================================================ QUICK: one walk, one wait
+            const uint32_t n_sub = (uint32_t)n_sub64;
+            DP_BUF(SubStream, d_ss, S);
+            DP_BUF(unsigned long long, d_first, (uint64_t)n_sub + 1);
+            DP_BUF(unsigned long long, d_stop, (uint64_t)n_sub + 1);
+            DP_BUF(unsigned long long, d_stopmax, (uint64_t)n_sub + 1);
+            DP_BUF(uint32_t, d_cnt, (uint64_t)n_sub + 1);
+            DP_BUF(uint16_t, d_delta, (uint64_t)n_sub * cap2 + 8);
+            DP_BUF(Slot, d_slots, (uint64_t)n_sub * cap2 + 1);
+            DP_BUF(SubInfo, d_info, (uint64_t)n_sub + 1);
+            DP_BUF(SubCnt, d_subcnt, (uint64_t)n_sub + 1);
+            DP_BUF(SubCnt, d_subbase, (uint64_t)n_sub + 1);
+            DP_BUF(uint8_t, d_bflag, (uint64_t)n_sub + 1);
+            DP_BUF(uint32_t, d_fl, 4);
+            DP_BUF(uint32_t, d_firstbad, S);
+            DP_BUF(uint32_t, d_recbase_, S + 1);
+            DP_BUF(unsigned long long, d_send_, S);
+            d_recbase = d_recbase_; d_send = d_send_;
+            fin_trace("  pack: quick buffers");
+            tm.start();
+            HIP_TRY(hipMemcpyAsync(d_ss, ss.data(), S * sizeof(SubStream), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(d_send, s_end.data(), S * 8, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemsetAsync(d_fl, 0, 16, st));
+            HIP_TRY(hipMemsetAsync(d_firstbad, 0xff, S * 4, st));
+            hipLaunchKernelGGL(msnv_scan_sub2, grid_for(n_sub, 256), dim3(256), 0, st, raw, d_ss, (uint32_t)S, n_sub, sub_bytes, cap2, (int)NC, ctg, P, d_first, d_stop, d_cnt, d_delta, d_slots, d_info, d_fl);
+            HIP_TRY(hipGetLastError());
+            size_t need_max = 0, need_sub = 0;
+            HIP_TRY(rocprim::inclusive_scan(nullptr, need_max, d_stop, d_stopmax, (size_t)n_sub, U64Max(), st));
+            HIP_TRY(rocprim::exclusive_scan(nullptr, need_sub, d_subcnt, d_subbase, SubCnt{}, (size_t)n_sub + 1, SubCntSum(), st));
+            if (int rc = tmp_for(std::max(need_max, need_sub))) return rc;
+            uint32_t fl = 0; SubCnt tot{};
+            for (int pass = 0;; ++pass) {
+                // seams checked, every stream's first sub-segment that guessed wrong walked again (until none is left: usually the first look), then
+                // the boundaries, and the scan whose last entry holds the round's totals -- all of it queued, ONE wait
+                HIP_TRY(rocprim::inclusive_scan(d_tmp, need_max, d_stop, d_stopmax, (size_t)n_sub, U64Max(), st));
+                hipLaunchKernelGGL(msnv_scan_check, grid_for((uint64_t)n_sub + 1, 256), dim3(256), 0, st, d_ss, (uint32_t)S, n_sub, sub_bytes, d_first, d_stopmax, d_cnt, d_firstbad);
+                hipLaunchKernelGGL(msnv_scan_fix2, grid_for(S, 64), dim3(64), 0, st, raw, d_ss, (uint32_t)S, sub_bytes, cap2, ctg, P, d_first, d_stop, d_stopmax, d_cnt, d_delta, d_slots, d_info, d_firstbad, d_fl);
+                hipLaunchKernelGGL(msnv_sub_bounds, grid_for((uint64_t)n_sub + 1, 256), dim3(256), 0, st, d_ss, (uint32_t)S, n_sub, d_cnt, d_info, d_subcnt, d_bflag);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(rocprim::exclusive_scan(d_tmp, need_sub, d_subcnt, d_subbase, SubCnt{}, (size_t)n_sub + 1, SubCntSum(), st));
+                HIP_TRY(hipMemcpyAsync(&fl, d_fl, 4, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipMemcpyAsync(&tot, d_subbase + n_sub, sizeof(SubCnt), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                if (!(fl & 2u) || (fl & 5u) || pass >= 4096) break;
+                T.n_scan_redone += 1;                             // (counted: a repair pass)
+                HIP_TRY(hipMemsetAsync(d_fl, 0, 4, st));
+            }
+            T.ms_scan += tm.stop();
+            fin_trace("  pack: scan + measure, totals (wait)");
+            if (fl || tot.odd) { route = 1; T.n_scan_redone += 1; continue; }      // a chain that breaks, a sub-segment the slots cannot hold: the careful route takes (and words) it
+            if (SR.raw_bytes / 36 > 0xfffffff0ull) return fail(MSNV_EDOMAIN, "more than 2^32 records in one round of the device pack");
+            // paired reads: the candidates of the overlapping-mate tweak are grouped, and the samples that need the host pre-pass known, before
+            // anything is emitted -- the careful route does all of that; the quick route takes the rounds without candidates
+            if (!MP.ignore_overlaps && tot.ovl >= 2) { route = 1; continue; }
+            NR = tot.rec; NPC = tot.npiece; NIV = tot.niv; n_runs = tot.runs; n_groups = tot.grps; n_ovl_total = tot.ovl; seqb_total = tot.seqb;
+            in_order = tot.sort != 0 || [] { const char *e = getenv("MSNV_TILE_ORDER"); return e && e[0] == 's'; }();
+            const uint64_t NRa = (uint64_t)NR + 1;
+            DP_BUF(unsigned long long, d_recoff, NRa);
+            DP_BUF(uint16_t, d_recsample, NRa);
+            DP_BUF(uint4, d_rd, NRa);
+            DP_BUF(RecCnt, d_pre, NRa);
+            DP_BUF(uint32_t, d_ftile, NRa);
+            DP_BUF(uint8_t, d_flags, NRa);
+            DP_BUF(unsigned long long, d_rg, NRa);
+            DP_BUF(uint16_t, d_depth_, NRa);
+            d_depth = d_depth_;
+            TB = RdTables{d_recoff, d_recsample, d_recbase, d_rd, d_pre, d_ftile, d_flags, d_rg};
+            HIP_TRY(hipEventRecord((hipEvent_t)T.pending.evd, st)); T.pending.has_evd = true;
+            if (n_sub) hipLaunchKernelGGL(msnv_scan_write2, grid_for(n_sub, 256), dim3(256), 0, st, d_ss, (uint32_t)S, n_sub, sub_bytes, cap2, d_cnt, d_subbase, d_bflag, d_delta, d_slots, d_info, TB, d_acc, d_misc,
+                                          d_outl, span_out, T.overhang, P);
+            HIP_TRY(hipGetLastError());
+            totals_h = RecCnt{tot.pile, tot.npiece, tot.niv, tot.spill, tot.seqb};      // (function scope: the copy below may read it later)
+            HIP_TRY(hipMemcpyAsync(d_pre + NR, &totals_h, sizeof(RecCnt), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(d_recoff + NR, &end_all, 8, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(d_recbase + S, &NR, 4, hipMemcpyHostToDevice, st));
+        } else {
+            // ================================================================ CAREFUL: stage by stage
+            SR.ms_scan = 0; SR.n_redone = 0;
+            if (int rc = scan_streams(st, ds.ctx->device, pool, streams, n_bytes, S, on_device, (int)NC, SR, in_place_base, in_place_capacity)) return rc;
+            T.ms_scan += SR.ms_scan; T.n_scan_redone += SR.n_redone;
+            NR = SR.NR;
+            const uint64_t NRa = (uint64_t)NR + 1;
+            d_recbase = SR.d_recbase; d_send = SR.d_send;
+            fin_trace("  pack: scan done");
+            DP_BUF(uint8_t, d_flags0, NRa);
+            DP_BUF(unsigned long long, d_key, NRa);
+            DP_BUF(uint32_t, d_end, NRa);
+            DP_BUF(uint32_t, d_maxc, NRa);
+            DP_BUF(uint32_t, d_ftile, NRa);
+            DP_BUF(RecCnt, d_cnt, NRa);
+            const uint64_t NB = ((uint64_t)NR + PB - 1) / PB, NBa = NB + 1;   // blocks of PB records: their sums and bases (entry NB of the bases = the round's totals)
+            DP_BUF(RecCnt, d_blkcnt, NBa);
+            DP_BUF(RecCnt, d_blkpre, NBa);
+            DP_BUF(uint16_t, d_depth_, NRa);
+            DP_BUF(uint32_t, d_ovr_, NRa);
+            DP_BUF(uint4, d_rd, NRa);
+            DP_BUF(RecCnt, d_pre, NRa);
+            DP_BUF(uint8_t, d_flags, NRa);
+            DP_BUF(unsigned long long, d_rg, NRa);
+            DP_BUF(unsigned long long, d_sf, NRa);
+            d_depth = d_depth_; d_ovr = d_ovr_;
+            TB = RdTables{SR.d_recoff, SR.d_recsample, d_recbase, d_rd, d_pre, d_ftile, d_flags, d_rg};
+            HIP_TRY(hipMemcpyAsync(SR.d_recoff + NR, &end_all, 8, hipMemcpyHostToDevice, st));
+            const size_t depth_bufs_from = pool.next;
+            RecCnt tot{};
+            for (int pass = 0; pass < 2; ++pass) {
+                pool.next = depth_bufs_from;
+                hipLaunchKernelGGL(msnv_acc_init, grid_for(S * ACC_COPIES, 256), dim3(256), 0, st, d_acc, (uint32_t)(S * ACC_COPIES));
+                HIP_TRY(hipGetLastError());
+                tm.start();
+                for (;;) {
+                    HIP_TRY(hipMemsetAsync(d_misc, 0, MISC_WORDS * 4, st));
+                    HIP_TRY(hipMemsetAsync(d_blkcnt + NB, 0, sizeof(RecCnt), st));
+                    if (NR) {
+                        hipLaunchKernelGGL(msnv_measure_reads, grid_for(NR, 256), dim3(256), 0, st, raw, SR.d_recoff, SR.d_recsample, d_recbase, d_send, NR, ctg, P, have_ovr ? d_ovr : nullptr, d_flags0,
+                                           d_key, d_end, d_maxc, d_cnt, d_ftile, d_blkcnt, d_acc, d_misc, d_outl, span_out, T.overhang);
+                        HIP_TRY(hipGetLastError());
+                    }
+                    {   // every block's base: rank among the pileup reads, first piece, first interval, next-tile pieces before it, first seq byte
+                        size_t need = 0;
+                        HIP_TRY(rocprim::exclusive_scan(nullptr, need, d_blkcnt, d_blkpre, RecCnt{}, (size_t)NBa, RecCntSum(), st));
+                        if (int rc = tmp_for(need)) return rc;
+                        HIP_TRY(rocprim::exclusive_scan(d_tmp, need, d_blkcnt, d_blkpre, RecCnt{}, (size_t)NBa, RecCntSum(), st));
+                    }
+                    HIP_TRY(hipMemcpyAsync(&tot, d_blkpre + NB, sizeof(RecCnt), hipMemcpyDeviceToHost, st));
+                    HIP_TRY(hipMemcpyAsync(misc_h, d_misc, MISC_WORDS * 4, hipMemcpyDeviceToHost, st));
+                    HIP_TRY(hipStreamSynchronize(st));
+                    if (misc_h[MISC_NOUT] <= CAP_OUT || span_out >= 0x40000000u) break;
+                    // more far-reaching reads than the list holds (long reads): they are the ordinary reads of this round -- a wider window, again
+                    span_out = span_out < 0x04000000u ? span_out * 16u : 0x7fffffffu;
+                    hipLaunchKernelGGL(msnv_acc_init, grid_for(S * ACC_COPIES, 256), dim3(256), 0, st, d_acc, (uint32_t)(S * ACC_COPIES));
+                    HIP_TRY(hipGetLastError());
+                }
+                T.ms_measure += tm.stop();
+                fin_trace("  pack: measure + block scan (sync)");
+                NPC = tot.npiece; NIV = tot.niv; seqb_total = tot.seqb;
+                // ---- the records' tables in the quick route's form; run and group numbers by a scan of their start flags
+                tm.start();
+                n_runs = 0; n_groups = 0;
+                if (NR) {
+                    hipLaunchKernelGGL(msnv_tables_from_measure, grid_for(NR, 256), dim3(256), 0, st, NR, SR.d_recsample, d_flags0, d_key, d_end, d_maxc, d_cnt, d_blkpre, d_ftile, span_out, P, TB, d_sf, d_acc);
+                    HIP_TRY(hipGetLastError());
+                    size_t need = 0;
+                    HIP_TRY(rocprim::inclusive_scan(nullptr, need, d_sf, d_rg, (size_t)NR, rocprim::plus<unsigned long long>(), st));
+                    if (int rc = tmp_for(need)) return rc;
+                    HIP_TRY(rocprim::inclusive_scan(d_tmp, need, d_sf, d_rg, (size_t)NR, rocprim::plus<unsigned long long>(), st));
+                    unsigned long long last = 0;
+                    HIP_TRY(hipMemcpyAsync(&last, d_rg + (NR - 1), 8, hipMemcpyDeviceToHost, st));
+                    HIP_TRY(hipStreamSynchronize(st));
+                    n_runs = (uint32_t)(last >> 32); n_groups = (uint32_t)last;
+                }
+                totals_h = tot;
+                HIP_TRY(hipMemcpyAsync(d_pre + NR, &totals_h, sizeof(RecCnt), hipMemcpyHostToDevice, st));
+                DP_BUF(uint32_t, c_runfirst, (uint64_t)n_runs + 1);
+                DP_BUF(uint32_t, c_runf1, (uint64_t)n_runs + 1);
+                DP_BUF(DpRun, c_runs, (uint64_t)n_runs + 1);
+                DP_BUF(uint32_t, c_grpfirst, (uint64_t)n_groups + 2);
+                DP_BUF(uint32_t, c_grpmd, 2 * ((uint64_t)n_groups + 1));
+                DP_BUF(uint2, c_grppre, (uint64_t)n_groups + 2);
+                DP_BUF(DevGroupRec, c_groups, (uint64_t)n_groups + 1);
+                d_runfirst = c_runfirst; d_runf1 = c_runf1; d_runs = c_runs; d_grpfirst = c_grpfirst; d_grpmd = c_grpmd; d_grppre = c_grppre; d_groups = c_groups;
+                if (int rc = launch_depth_stage()) return rc;
+                runs.resize(n_runs); groups.resize(n_groups);
+                HIP_TRY(hipMemcpyAsync(runs.data(), d_runs, (size_t)n_runs * sizeof(DpRun), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipMemcpyAsync(groups.data(), d_groups, (size_t)n_groups * sizeof(DevGroupRec), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipMemcpy2DAsync(acc.data(), sizeof(DpAcc), d_acc, sizeof(DpAcc) * ACC_COPIES, sizeof(DpAcc), S, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipMemcpyAsync(misc_h, d_misc, MISC_WORDS * 4, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                T.ms_depth += tm.stop();
+                fin_trace("  pack: depth stage (sync)");
+                rec_base_h = SR.rec_base;
+                if (int rc = check_errors()) return rc;
+                if (pass == 1) break;
+                // ---- overlapping mates: the candidates grouped by (sample, name); nothing is edited yet (MSNV_OVERLAP=host: the host pre-pass does it)
+                const bool ovl_on_host = [] { const char *e = getenv("MSNV_OVERLAP"); return e && e[0] == 'h'; }();
+                bool any_ovl = false;
+                for (size_t s = 0; s < S; ++s) any_ovl |= !MP.ignore_overlaps && acc[s].n_ovl >= 2;
+                if (any_ovl && !ovl_on_host) {
+                    tm.start();
+                    if (int rc = o_flag.alloc(NRa * 4)) return rc;
+                    if (int rc = o_rank.alloc(NRa * 4)) return rc;
+                    if (int rc = o_skip.alloc(S)) return rc;
+                    HIP_TRY(hipMemsetAsync(o_skip.p, 0, S, st));
+                    hipLaunchKernelGGL(msnv_ovl_mark, grid_for(NRa, 256), dim3(256), 0, st, TB.r_flags, NR, TB.rec_sample, o_skip.as<uint8_t>(), o_flag.as<uint32_t>());
+                    HIP_TRY(hipGetLastError());
+                    if (int rc = scan32(o_flag.as<uint32_t>(), o_rank.as<uint32_t>(), NRa, false)) return rc;
+                    HIP_TRY(hipMemcpyAsync(&n_ovl_reads, o_rank.as<uint32_t>() + NR, 4, hipMemcpyDeviceToHost, st));
+                    HIP_TRY(hipStreamSynchronize(st));
+                    if (n_ovl_reads >= 2) {
+                        const uint64_t NOa = (uint64_t)n_ovl_reads + 1;
+                        if (int rc = o_keys.alloc(NOa * 8)) return rc;
+                        if (int rc = o_skeys.alloc(NOa * 8)) return rc;
+                        if (int rc = o_vals.alloc(NOa * 4)) return rc;
+                        if (int rc = o_svals.alloc(NOa * 4)) return rc;
+                        hipLaunchKernelGGL(msnv_ovl_list, grid_for(NR, 256), dim3(256), 0, st, TB.r_flags, o_rank.as<uint32_t>(), NR, raw, TB.rec_off, TB.rec_sample, o_skip.as<uint8_t>(),
+                                           o_keys.as<unsigned long long>(), o_vals.as<uint32_t>());
+                        HIP_TRY(hipGetLastError());
+                        if (int rc = sort64(o_keys.as<unsigned long long>(), o_skeys.as<unsigned long long>(), o_vals.as<uint32_t>(), o_svals.as<uint32_t>(), n_ovl_reads, 64u)) return rc;
+                        // groups of equal keys: flags and their scan in the unsorted arrays' memory
+                        uint32_t *gflag = o_vals.as<uint32_t>(), *gid = reinterpret_cast<uint32_t *>(o_keys.p);
+                        hipLaunchKernelGGL(msnv_pair_flags, grid_for(n_ovl_reads, 256), dim3(256), 0, st, o_skeys.as<unsigned long long>(), n_ovl_reads, gflag);
+                        HIP_TRY(hipGetLastError());
+                        if (int rc = scan32(gflag, gid, n_ovl_reads, true)) return rc;
+                        HIP_TRY(hipMemcpyAsync(&n_ovl_groups, gid + (n_ovl_reads - 1), 4, hipMemcpyDeviceToHost, st));
+                        HIP_TRY(hipStreamSynchronize(st));
+                        if (int rc = o_starts.alloc(((uint64_t)n_ovl_groups + 1) * 4)) return rc;
+                        hipLaunchKernelGGL(msnv_ovl_group_starts, grid_for(n_ovl_reads, 256), dim3(256), 0, st, gflag, gid, n_ovl_reads, o_starts.as<uint32_t>());
+                        hipLaunchKernelGGL(msnv_ovl_check, grid_for(n_ovl_groups, 256), dim3(256), 0, st, o_starts.as<uint32_t>(), n_ovl_groups, n_ovl_reads, o_svals.as<uint32_t>(), TB.rec_sample, d_acc);
+                        HIP_TRY(hipGetLastError());
+                        std::vector<DpAcc> again(S);
+                        HIP_TRY(hipMemcpy2DAsync(again.data(), sizeof(DpAcc), d_acc, sizeof(DpAcc) * ACC_COPIES, sizeof(DpAcc), S, hipMemcpyDeviceToHost, st));
+                        HIP_TRY(hipStreamSynchronize(st));
+                        for (size_t s = 0; s < S; ++s) acc[s].need_host = again[s].need_host;
+                    }
+                    T.ms_depth += tm.stop();
+                }
+                // ---- which samples need the sequential edits of the host stage?
+                std::vector<size_t> need;
+                for (size_t s = 0; s < S; ++s) if (acc[s].need_host || (ovl_on_host && !MP.ignore_overlaps && acc[s].n_ovl >= 2)) need.push_back(s);
+                for (size_t s : need) host_sample[s] = 1;
+                if (need.empty()) break;
+                const double t0 = now_s();
+                T.n_prepass_samples += need.size();
+                std::vector<uint32_t> ovr_all((size_t)NR + 1, 0u);
+                std::vector<std::vector<uint8_t>> host_copy(need.size()), patched(need.size());
+                std::vector<int> rcs(need.size(), 0); std::vector<std::string> msgs(need.size());
+                for (size_t k = 0; k < need.size(); ++k) if (on_device) {
+                    host_copy[k].resize(n_bytes[need[k]]);
+                    if (n_bytes[need[k]]) HIP_TRY(hipMemcpy(host_copy[k].data(), raw + s_beg[need[k]], n_bytes[need[k]], hipMemcpyDeviceToHost));
+                }
+                {
+                    std::atomic<size_t> next{0};
+                    auto w = [&]() {
+                        for (;;) {
+                            const size_t k = next.fetch_add(1);
+                            if (k >= need.size()) break;
+                            const size_t s = need[k];
+                            const uint8_t *rec = on_device ? host_copy[k].data() : streams[s];
+                            std::vector<uint32_t> ov; bool cm = false;
+                            int rc;
+                            try { rc = host_prepass(ds, rec, n_bytes[s], ov, patched[k], cm); } catch (const std::exception &e) { rc = fail_quiet(MSNV_ENOMEM, "host pre-pass: %s", e.what()); }
+                            if (!rc && ov.size() != SR.n_rec[s]) rc = fail_quiet(MSNV_EINVAL, "internal: the host pre-pass saw %zu records, the device scan %u", ov.size(), SR.n_rec[s]);
+                            if (rc) { rcs[k] = rc; msgs[k] = msnv_last_error(); continue; }
+                            std::copy(ov.begin(), ov.end(), ovr_all.begin() + SR.rec_base[s]);
+                            cut_marks[s] = cm ? 1 : 0;
+                        }
+                    };
+                    std::vector<std::thread> th;
+                    const size_t nt = std::min<size_t>(need.size(), msnv_default_threads());
+                    for (size_t k = 0; k < nt; ++k) th.emplace_back(w);
+                    for (auto &x : th) x.join();
+                }
+                for (size_t k = 0; k < need.size(); ++k) if (rcs[k]) return fail(rcs[k], "%s", msgs[k].c_str());
+                for (size_t k = 0; k < need.size(); ++k) if (!patched[k].empty()) HIP_TRY(hipMemcpy(raw + s_beg[need[k]], patched[k].data(), patched[k].size(), hipMemcpyHostToDevice));
+                HIP_TRY(hipMemcpy(d_ovr, ovr_all.data(), ((uint64_t)NR + 1) * 4, hipMemcpyHostToDevice));
+                have_ovr = true;
+                T.wall_prepass_s += now_s() - t0;
+            }
+            in_order = misc_h[MISC_SORT] != 0 || [] { const char *e = getenv("MSNV_TILE_ORDER"); return e && e[0] == 's'; }();
+        }
+        const uint64_t NB = ((uint64_t)NR + PB - 1) / PB;
+
+        // ================================================================ the quick route's depth stage (queued behind msnv_scan_write2)
+        if (route == 0) {
+            DP_BUF(uint32_t, q_runfirst, (uint64_t)n_runs + 1);
+            DP_BUF(uint32_t, q_runf1, (uint64_t)n_runs + 1);
+            DP_BUF(DpRun, q_runs, (uint64_t)n_runs + 1);
+            DP_BUF(uint32_t, q_grpfirst, (uint64_t)n_groups + 2);
+            DP_BUF(uint32_t, q_grpmd, 2 * ((uint64_t)n_groups + 1));
+            DP_BUF(uint2, q_grppre, (uint64_t)n_groups + 2);
+            DP_BUF(DevGroupRec, q_groups, (uint64_t)n_groups + 1);
+            d_runfirst = q_runfirst; d_runf1 = q_runf1; d_runs = q_runs; d_grpfirst = q_grpfirst; d_grpmd = q_grpmd; d_grppre = q_grppre; d_groups = q_groups;
+            if (int rc = launch_depth_stage()) return rc;
+        }
+
+        // ================================================================ overlapping mates: the qualities of the pairs are edited where they lie
+        if (n_ovl_groups) {
+            tm.start();
+            HIP_TRY(hipMemcpyAsync(o_skip.p, host_sample.data(), S, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(msnv_ovl_groups, grid_for(n_ovl_groups, 64), dim3(64), 0, st, o_starts.as<uint32_t>(), n_ovl_groups, n_ovl_reads, o_svals.as<uint32_t>(), raw, TB.rec_off, TB.rd,
+                               TB.rec_sample, o_skip.as<uint8_t>());
+            HIP_TRY(hipGetLastError());
             T.ms_depth += tm.stop();
-        } else { runs.clear(); groups.clear(); }
+        }
+        if (route == 1) fin_trace("  pack: checks, overlaps");
+
+        // ================================================================ layout + emit (both routes)
+        // The round's columns: per sample its pieces + 32 tail bytes, starting on 16 bytes, and one flag bit per nibble of them.  The samples'
+        // shares are laid out on the device (msnv_sample_layout: the quick route's host does not know them yet); the buffer is sized by the
+        // round's seq bytes + the most the tails and the rounding can add.
+        const uint64_t seq_bound = (seqb_total + (uint64_t)S * 48ull + 15ull) & ~15ull, qual_bound = seq_bound / 4;
+        const uint64_t NPCa = (uint64_t)NPC + 1;
+        struct Held {                                                // the round's lasting buffers, this function's until the round is known to stand
+            void *round_buf = nullptr, *keep_buf = nullptr;
+            ~Held() { if (round_buf) dev_free(round_buf); if (keep_buf) dev_free(keep_buf); }
+        } held;
+        if (int rc = dev_alloc(&held.round_buf, seq_bound + COL_PAD + qual_bound + 64, nullptr)) return rc;
+        r_seq = static_cast<uint8_t *>(held.round_buf); r_qual = r_seq + seq_bound + COL_PAD;
+        {
+            const uint64_t lo = seqb_total & ~15ull;                  // (from the lowest place the columns can end to the flags: N -- the exact end is the device's)
+            HIP_TRY(hipMemsetAsync(r_seq + lo, 0xff, seq_bound + COL_PAD - lo, st));
+            HIP_TRY(hipMemsetAsync(r_qual, 0, qual_bound + 64, st));
+        }
+        keep = DevRound{};
+        {   // what stays in HBM of the round besides the columns: headers (tile order) and intervals, for finalize -- written where they stay
+            const uint64_t b_hdr = (uint64_t)NPC * sizeof(ReadHdr), b_4 = (((uint64_t)NPC * 4) + 15) & ~15ull, b_2 = (((uint64_t)NPC * 2) + 15) & ~15ull, b_iv = (((uint64_t)NIV * 4) + 15) & ~15ull;
+            if (int rc = dev_alloc(&held.keep_buf, b_hdr + 2 * b_4 + b_2 + 3 * b_iv + 64, nullptr)) return rc;
+            uint8_t *q = static_cast<uint8_t *>(held.keep_buf);
+            keep.buf = held.keep_buf;
+            keep.hdr = reinterpret_cast<ReadHdr *>(q); q += b_hdr;
+            keep.tid = reinterpret_cast<int32_t *>(q); q += b_4;
+            keep.end = reinterpret_cast<int32_t *>(q); q += b_4;
+            keep.depth = reinterpret_cast<uint16_t *>(q); q += b_2;
+            keep.cov_tid = reinterpret_cast<int32_t *>(q); q += b_iv;
+            keep.cov_beg = reinterpret_cast<int32_t *>(q); q += b_iv;
+            keep.cov_end = reinterpret_cast<int32_t *>(q);
+            keep.n_pieces = NPC; keep.n_iv = NIV; keep.first_sample = first;
+            keep.col_buf = held.round_buf; keep.col_seq = r_seq; keep.col_qual = r_qual; keep.seq_total = 0; keep.n_samples = S;
+        }
+        DP_BUF(DpSampleSum2, d_sum, S + 1);
+        DP_BUF(unsigned long long, d_ss0, S + 1);
+        DP_BUF(DpSampleDst, d_dst_, S);
+        DP_BUF(unsigned long long, d_pb, S);
+        DP_BUF(uint32_t, d_slow, NB + 2);
+        d_dst = d_dst_;
+        // (the general route keeps the headers in file order first: work buffers, sorted into `keep` below)
+        w_hdr = keep.hdr; w_tid = keep.tid; w_end = keep.end; w_depth = keep.depth;
+        if (in_order) {
+            DP_BUF(ReadHdr, d_hdr, NPCa);
+            DP_BUF(int32_t, d_ptid, NPCa);
+            DP_BUF(int32_t, d_pend, NPCa);
+            DP_BUF(uint16_t, d_pdepth, NPCa);
+            w_hdr = d_hdr; w_tid = d_ptid; w_end = d_pend; w_depth = d_pdepth;
+        }
+        HIP_TRY(hipMemcpyAsync(d_cut, cut_marks.data(), S, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemsetAsync(d_slow, 0, 4, st));
+        hipLaunchKernelGGL(msnv_sample_layout, dim3(1), dim3(256), 0, st, d_recbase, (uint32_t)S, TB.r_pre, d_acc, TB.rd, r_seq, r_qual, d_cut, d_sum, d_ss0, d_dst, d_pb);
+        HIP_TRY(hipGetLastError());
+        // ---- what the host needs of the stages so far, through the dataset's pinned words, with an event behind the copies: the emit kernels
+        // are launched first, THEN the host waits for the event -- and builds its tables beside them
+        const uint64_t b_acc = S * sizeof(DpAcc), b_sum = (S + 1) * sizeof(DpSampleSum2), b_pb = S * 8, b_rb = (S + 1) * 4, b_runs = (uint64_t)n_runs * sizeof(DpRun), b_grp = (uint64_t)n_groups * sizeof(DevGroupRec);
+        auto up8 = [](uint64_t v) { return (v + 15) & ~15ull; };
+        const uint64_t o_acc = up8(((uint64_t)ds.samples.size() + 16) * 4), o_sum = o_acc + up8(b_acc), o_pb = o_sum + up8(b_sum), o_rb = o_pb + up8(b_pb), o_misc = o_rb + up8(b_rb), o_runs = o_misc + 16, o_grp = o_runs + up8(b_runs),
+                       o_end = o_grp + up8(b_grp);
+        if (int rc = pin_ensure(ds, std::max<uint64_t>(o_end, S * sizeof(DpAcc)))) return rc;
+        uint8_t *pinb = static_cast<uint8_t *>(T.pin) + T.pin_cap / 2;
+        if (route == 0) {
+            HIP_TRY(hipMemcpy2DAsync(pinb + o_acc, sizeof(DpAcc), d_acc, sizeof(DpAcc) * ACC_COPIES, sizeof(DpAcc), S, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(pinb + o_rb, d_recbase, b_rb, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(pinb + o_misc, d_misc, MISC_WORDS * 4, hipMemcpyDeviceToHost, st));
+            if (n_runs) HIP_TRY(hipMemcpyAsync(pinb + o_runs, d_runs, b_runs, hipMemcpyDeviceToHost, st));
+            if (n_groups) HIP_TRY(hipMemcpyAsync(pinb + o_grp, d_groups, b_grp, hipMemcpyDeviceToHost, st));
+        }
+        HIP_TRY(hipMemcpyAsync(pinb + o_sum, d_sum, b_sum, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(pinb + o_pb, d_pb, b_pb, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord((hipEvent_t)T.pending.evh, st));
+        if (int rc = tables.join()) return rc;                        // (the packed FASTA: the emit kernels read it)
+        HIP_TRY(hipEventRecord((hipEvent_t)T.pending.ev0, st));
+        if (NR) {
+            EmitArgs A{};
+            A.raw = raw; A.rec_off = TB.rec_off; A.rec_sample = TB.rec_sample; A.n_rec = NR; A.ctg = ctg; A.r_flags = TB.r_flags; A.r_depth = d_depth; A.r_pre = TB.r_pre;
+            A.samp_sbase0 = d_ss0; A.rg = TB.r_rg; A.grp_pre = d_grppre; A.in_order = in_order ? 1u : 0u;
+            A.hdr = w_hdr; A.ptid = w_tid; A.pend = w_end; A.pdepth = w_depth; A.cov_tid = keep.cov_tid; A.cov_beg = keep.cov_beg; A.cov_end = keep.cov_end;
+            A.noseq_counts = (P.c_eff == 0 && !P.all_low) ? 1u : 0u;
+            A.pref4 = T.pref4; A.P = P; A.dst = d_dst; A.acc = d_acc;
+            A.slow = d_slow; A.force_slow = [] { const char *e = getenv("MSNV_EMIT"); return e && e[0] == 's'; }() ? 1u : 0u;
+            static const bool dbg = getenv("MSNV_DEBUG_SYNC") != nullptr;
+            if (dbg) { HIP_TRY(hipStreamSynchronize(st)); fin_trace("  dbg: before emit"); }
+            hipLaunchKernelGGL(msnv_emit_block, dim3((unsigned)NB), dim3(256), 0, st, A);
+            if (dbg) { HIP_TRY(hipStreamSynchronize(st)); fin_trace("  dbg: emit_block"); }
+            hipLaunchKernelGGL(msnv_emit_block_slow, dim3((unsigned)std::min<uint64_t>(NB, 2048)), dim3(256), 0, st, A);
+            if (dbg) { HIP_TRY(hipStreamSynchronize(st)); fin_trace("  dbg: emit_block_slow"); }
+            HIP_TRY(hipGetLastError());
+        }
+        hipLaunchKernelGGL(msnv_emit_tail, dim3((unsigned)S), dim3(64), 0, st, d_dst, d_pb, (uint32_t)S, P);
+        if (getenv("MSNV_DEBUG_SYNC")) { HIP_TRY(hipStreamSynchronize(st)); fin_trace("  dbg: emit_tail"); }
         hipLaunchKernelGGL(msnv_acc_fold, dim3((unsigned)S), dim3(64), 0, st, d_acc, (uint32_t)S);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpy2DAsync(acc.data(), sizeof(DpAcc), d_acc, sizeof(DpAcc) * ACC_COPIES, sizeof(DpAcc), S, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(&need_sort, d_misc + MISC_SORT, 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        fin_trace("  pack: depth stage (sync)");
-        // ---- errors, in record order (what the host stage's sequential walk would have met first)
-        for (size_t s = 0; s < S; ++s) {
-            const unsigned long long e = acc[s].err;
-            if (e != ~0ull) {
-                const uint32_t kind = (uint32_t)(e & 7u); const unsigned long long idx = (e >> 3) - rec_base[s];
-                return fail(MSNV_EFORMAT, "%s (sample %zu of the batch, record %llu)", err_text(kind), s, idx);
-            }
-            if (bad_off[s] != ~0ull) return fail(MSNV_EFORMAT, "malformed BAM record at byte %llu", bad_off[s]);
-        }
-        if (pass == 1) break;
-        // ---- overlapping mates: the candidates grouped by (sample, name); nothing is edited yet (MSNV_OVERLAP=host: the host pre-pass does it)
-        const bool ovl_on_host = [] { const char *e = getenv("MSNV_OVERLAP"); return e && e[0] == 'h'; }();
-        bool any_ovl = false;
-        for (size_t s = 0; s < S; ++s) any_ovl |= !MP.ignore_overlaps && acc[s].n_ovl >= 2;
-        if (any_ovl && !ovl_on_host) {
-            tm.start();
-            if (int rc = o_flag.alloc(NRa * 4)) return rc;
-            if (int rc = o_rank.alloc(NRa * 4)) return rc;
-            if (int rc = o_skip.alloc(S)) return rc;
-            HIP_TRY(hipMemsetAsync(o_skip.p, 0, S, st));
-            hipLaunchKernelGGL(msnv_ovl_mark, grid_for(NRa, 256), dim3(256), 0, st, d_flags, NR, d_recsample, o_skip.as<uint8_t>(), o_flag.as<uint32_t>());
-            HIP_TRY(hipGetLastError());
-            if (int rc = scan32(o_flag.as<uint32_t>(), o_rank.as<uint32_t>(), NRa, false)) return rc;
-            HIP_TRY(hipMemcpyAsync(&n_ovl_reads, o_rank.as<uint32_t>() + NR, 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            if (n_ovl_reads >= 2) {
-                const uint64_t NOa = (uint64_t)n_ovl_reads + 1;
-                if (int rc = o_keys.alloc(NOa * 8)) return rc;
-                if (int rc = o_skeys.alloc(NOa * 8)) return rc;
-                if (int rc = o_vals.alloc(NOa * 4)) return rc;
-                if (int rc = o_svals.alloc(NOa * 4)) return rc;
-                hipLaunchKernelGGL(msnv_ovl_list, grid_for(NR, 256), dim3(256), 0, st, d_flags, o_rank.as<uint32_t>(), NR, raw, d_recoff, d_recsample, o_skip.as<uint8_t>(),
-                                   o_keys.as<unsigned long long>(), o_vals.as<uint32_t>());
-                HIP_TRY(hipGetLastError());
-                if (int rc = sort64(o_keys.as<unsigned long long>(), o_skeys.as<unsigned long long>(), o_vals.as<uint32_t>(), o_svals.as<uint32_t>(), n_ovl_reads, 64u)) return rc;
-                // groups of equal keys: flags and their scan in the unsorted arrays' memory
-                uint32_t *gflag = o_vals.as<uint32_t>(), *gid = reinterpret_cast<uint32_t *>(o_keys.p);
-                hipLaunchKernelGGL(msnv_pair_flags, grid_for(n_ovl_reads, 256), dim3(256), 0, st, o_skeys.as<unsigned long long>(), n_ovl_reads, gflag);
-                HIP_TRY(hipGetLastError());
-                if (int rc = scan32(gflag, gid, n_ovl_reads, true)) return rc;
-                HIP_TRY(hipMemcpyAsync(&n_ovl_groups, gid + (n_ovl_reads - 1), 4, hipMemcpyDeviceToHost, st));
-                HIP_TRY(hipStreamSynchronize(st));
-                if (int rc = o_starts.alloc(((uint64_t)n_ovl_groups + 1) * 4)) return rc;
-                hipLaunchKernelGGL(msnv_ovl_group_starts, grid_for(n_ovl_reads, 256), dim3(256), 0, st, gflag, gid, n_ovl_reads, o_starts.as<uint32_t>());
-                hipLaunchKernelGGL(msnv_ovl_check, grid_for(n_ovl_groups, 256), dim3(256), 0, st, o_starts.as<uint32_t>(), n_ovl_groups, n_ovl_reads, o_svals.as<uint32_t>(), d_recsample, d_acc);
-                HIP_TRY(hipGetLastError());
-                std::vector<DpAcc> again(S);
-                HIP_TRY(hipMemcpy2DAsync(again.data(), sizeof(DpAcc), d_acc, sizeof(DpAcc) * ACC_COPIES, sizeof(DpAcc), S, hipMemcpyDeviceToHost, st));
-                HIP_TRY(hipStreamSynchronize(st));
-                for (size_t s = 0; s < S; ++s) acc[s].need_host = again[s].need_host;
-            }
-            T.ms_depth += tm.stop();
-        }
-        // ---- which samples need the sequential edits of the host stage?
-        std::vector<size_t> need;
-        for (size_t s = 0; s < S; ++s) if (acc[s].need_host || (ovl_on_host && !MP.ignore_overlaps && acc[s].n_ovl >= 2)) need.push_back(s);
-        for (size_t s : need) host_sample[s] = 1;
-        if (need.empty()) break;
-        const double t0 = now_s();
-        T.n_prepass_samples += need.size();
-        std::vector<uint32_t> ovr_all((size_t)NR + 1, 0u);
-        std::vector<std::vector<uint8_t>> host_copy(need.size()), patched(need.size());
-        std::vector<int> rcs(need.size(), 0); std::vector<std::string> msgs(need.size());
-        for (size_t k = 0; k < need.size(); ++k) if (on_device) {
-            host_copy[k].resize(n_bytes[need[k]]);
-            if (n_bytes[need[k]]) HIP_TRY(hipMemcpy(host_copy[k].data(), raw + s_beg[need[k]], n_bytes[need[k]], hipMemcpyDeviceToHost));
-        }
-        {
-            std::atomic<size_t> next{0};
-            auto w = [&]() {
-                for (;;) {
-                    const size_t k = next.fetch_add(1);
-                    if (k >= need.size()) break;
-                    const size_t s = need[k];
-                    const uint8_t *rec = on_device ? host_copy[k].data() : streams[s];
-                    std::vector<uint32_t> ov; bool cm = false;
-                    int rc;
-                    try { rc = host_prepass(ds, rec, n_bytes[s], ov, patched[k], cm); } catch (const std::exception &e) { rc = fail_quiet(MSNV_ENOMEM, "host pre-pass: %s", e.what()); }
-                    if (!rc && ov.size() != n_rec[s]) rc = fail_quiet(MSNV_EINVAL, "internal: the host pre-pass saw %zu records, the device scan %u", ov.size(), n_rec[s]);
-                    if (rc) { rcs[k] = rc; msgs[k] = msnv_last_error(); continue; }
-                    std::copy(ov.begin(), ov.end(), ovr_all.begin() + rec_base[s]);
-                    cut_marks[s] = cm ? 1 : 0;
-                }
-            };
-            std::vector<std::thread> th;
-            const size_t nt = std::min<size_t>(need.size(), msnv_default_threads());
-            for (size_t k = 0; k < nt; ++k) th.emplace_back(w);
-            for (auto &x : th) x.join();
-        }
-        for (size_t k = 0; k < need.size(); ++k) if (rcs[k]) return fail(rcs[k], "%s", msgs[k].c_str());
-        for (size_t k = 0; k < need.size(); ++k) if (!patched[k].empty()) HIP_TRY(hipMemcpy(raw + s_beg[need[k]], patched[k].data(), patched[k].size(), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(d_ovr, ovr_all.data(), ((uint64_t)NR + 1) * 4, hipMemcpyHostToDevice));
-        have_ovr = true;
-        T.wall_prepass_s += now_s() - t0;
-    }
-
-    // ---- overlapping mates: the qualities of the pairs are edited where they lie (samples that took the host pre-pass had theirs edited there)
-    if (n_ovl_groups) {
-        tm.start();
-        HIP_TRY(hipMemcpyAsync(o_skip.p, host_sample.data(), S, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(msnv_ovl_groups, grid_for(n_ovl_groups, 64), dim3(64), 0, st, o_starts.as<uint32_t>(), n_ovl_groups, n_ovl_reads, o_svals.as<uint32_t>(), raw, d_recoff, d_end,
-                           d_recsample, o_skip.as<uint8_t>());
-        HIP_TRY(hipGetLastError());
-        T.ms_depth += tm.stop();
-    }
-    fin_trace("  pack: checks, overlaps");
-    // ---- layout: where every sample's pieces, seq bytes and intervals start (the per-record places are d_pre)
-    const bool in_order = need_sort != 0 || [] { const char *e = getenv("MSNV_TILE_ORDER"); return e && e[0] == 's'; }();      // the general route: file order, then the sort (MSNV_TILE_ORDER=sort: tests)
-    DP_BUF(DpSampleSum, d_sum, S + 1);
-    DP_BUF(unsigned long long, d_ss0, S + 1);
-    tm.start();
-    hipLaunchKernelGGL(msnv_sample_bases, grid_for(S + 1, 64), dim3(64), 0, st, d_recbase, (uint32_t)S, d_blkpre, d_cnt, d_acc, d_key, d_end, d_sum, d_ss0);
-    HIP_TRY(hipGetLastError());
-    std::vector<DpSampleSum> sum(S + 1);
-    HIP_TRY(hipMemcpyAsync(sum.data(), d_sum, (S + 1) * sizeof(DpSampleSum), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    const uint32_t NPC = tot.npiece, NIV = tot.niv;
-    T.n_pieces += NPC;
-    T.pad_in_emit = true;                                          // (msnv_emit_block* leave the alignment nibbles behind every piece as finalize wants them)
-    // the round's columns: per sample seq (its pieces + 32 tail bytes, start on 16 bytes) and one flag bit per nibble of it
-    std::vector<unsigned long long> seq_off(S + 1, 0), piece_bytes(S), ss0(S + 1);
-    for (size_t s = 0; s <= S; ++s) ss0[s] = sum[s].sbase0;
-    for (size_t s = 0; s < S; ++s) {
-        piece_bytes[s] = ss0[s + 1] - ss0[s];
-        if (piece_bytes[s] > 0xffffff00ull) return fail(MSNV_EDOMAIN, "one sample holds more than 8.5 G aligned bases in this shard: shard the contigs further");
-        seq_off[s + 1] = seq_off[s] + ((piece_bytes[s] + 32 + 15) & ~15ull);
-    }
-    const uint64_t seq_total = seq_off[S], qual_total = seq_total / 4;
-    void *round_buf = nullptr;
-    if (int rc = dev_alloc(&round_buf, seq_total + COL_PAD + qual_total + 64, nullptr)) return rc;
-    T.round_bufs.push_back(round_buf);
-    uint8_t *r_seq = static_cast<uint8_t *>(round_buf), *r_qual = r_seq + seq_total + COL_PAD;
-    HIP_TRY(hipMemsetAsync(r_seq + seq_total, 0xff, COL_PAD, st));
-    HIP_TRY(hipMemsetAsync(r_qual, 0, qual_total + 64, st));
-    std::vector<DpSampleDst> dsts(S);
-    for (size_t s = 0; s < S; ++s) dsts[s] = DpSampleDst{r_seq + seq_off[s], r_qual + seq_off[s] / 4, sum[s].pbase0, cut_marks[s], 0u};
-    const uint64_t NPCa = (uint64_t)NPC + 1;
-    fin_trace("  pack: sample bases (sync), round buffer");
-    // what stays in HBM of the round besides the columns: headers (tile order) and intervals, for finalize -- written where they stay
-    DevRound keep;
-    {
-        const uint64_t b_hdr = (uint64_t)NPC * sizeof(ReadHdr), b_4 = (((uint64_t)NPC * 4) + 15) & ~15ull, b_2 = (((uint64_t)NPC * 2) + 15) & ~15ull, b_iv = (((uint64_t)NIV * 4) + 15) & ~15ull;
-        if (int rc = dev_alloc(&keep.buf, b_hdr + 2 * b_4 + b_2 + 3 * b_iv + 64, nullptr)) return rc;
-        uint8_t *q = static_cast<uint8_t *>(keep.buf);
-        keep.hdr = reinterpret_cast<ReadHdr *>(q); q += b_hdr;
-        keep.tid = reinterpret_cast<int32_t *>(q); q += b_4;
-        keep.end = reinterpret_cast<int32_t *>(q); q += b_4;
-        keep.depth = reinterpret_cast<uint16_t *>(q); q += b_2;
-        keep.cov_tid = reinterpret_cast<int32_t *>(q); q += b_iv;
-        keep.cov_beg = reinterpret_cast<int32_t *>(q); q += b_iv;
-        keep.cov_end = reinterpret_cast<int32_t *>(q);
-        keep.n_pieces = NPC; keep.n_iv = NIV; keep.first_sample = first;
-        keep.col_buf = round_buf; keep.col_seq = r_seq; keep.col_qual = r_qual; keep.seq_total = seq_total; keep.n_samples = S;
-        T.rounds.push_back(keep);
-    }
-    DP_BUF(DpSampleDst, d_dst, S);
-    DP_BUF(unsigned long long, d_pb, S);
-    DP_BUF(uint32_t, d_slow, NB + 2);
-    HIP_TRY(hipMemsetAsync(d_slow, 0, 4, st));
-    // (the general route keeps the headers in file order first: work buffers, sorted into `keep` below)
-    ReadHdr *w_hdr = keep.hdr; int32_t *w_tid = keep.tid, *w_end = keep.end; uint16_t *w_depth = keep.depth;
-    if (in_order) {
-        DP_BUF(ReadHdr, d_hdr, NPCa);
-        DP_BUF(int32_t, d_ptid, NPCa);
-        DP_BUF(int32_t, d_pend, NPCa);
-        DP_BUF(uint16_t, d_pdepth, NPCa);
-        w_hdr = d_hdr; w_tid = d_ptid; w_end = d_pend; w_depth = d_pdepth;
-    }
-    HIP_TRY(hipMemcpyAsync(d_dst, dsts.data(), S * sizeof(DpSampleDst), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_pb, piece_bytes.data(), S * 8, hipMemcpyHostToDevice, st));
-    T.ms_emit += tm.stop();                                         // (the layout step; the emit kernels' time arrives with devpack_sync_pending)
-    if (!T.pending.ev0) { hipEvent_t a = nullptr, b = nullptr; HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b)); T.pending.ev0 = a; T.pending.ev1 = b; }
-    HIP_TRY(hipEventRecord((hipEvent_t)T.pending.ev0, st));
-    if (NR) {
-        EmitArgs A{};
-        A.raw = raw; A.rec_off = d_recoff; A.rec_sample = d_recsample; A.n_rec = NR; A.ctg = ctg; A.r_flags = d_flags; A.r_depth = d_depth; A.r_cnt = d_cnt; A.blk_pre = d_blkpre;
-        A.samp_sbase0 = d_ss0; A.rg = d_rg; A.grp_pre = d_grppre; A.in_order = in_order ? 1u : 0u;
-        A.hdr = w_hdr; A.ptid = w_tid; A.pend = w_end; A.pdepth = w_depth; A.cov_tid = keep.cov_tid; A.cov_beg = keep.cov_beg; A.cov_end = keep.cov_end;
-        A.noseq_counts = (P.c_eff == 0 && !P.all_low) ? 1u : 0u;
-        A.pref4 = T.pref4; A.P = P; A.dst = d_dst; A.acc = d_acc;
-        A.slow = d_slow; A.force_slow = [] { const char *e = getenv("MSNV_EMIT"); return e && e[0] == 's'; }() ? 1u : 0u;
-        hipLaunchKernelGGL(msnv_emit_block, dim3((unsigned)NB), dim3(256), 0, st, A);
-        hipLaunchKernelGGL(msnv_emit_block_slow, dim3((unsigned)std::min<uint64_t>(NB, 2048)), dim3(256), 0, st, A);
-        HIP_TRY(hipGetLastError());
-    }
-    hipLaunchKernelGGL(msnv_emit_tail, dim3((unsigned)S), dim3(64), 0, st, d_dst, d_pb, (uint32_t)S, P);
-    hipLaunchKernelGGL(msnv_acc_fold, dim3((unsigned)S), dim3(64), 0, st, d_acc, (uint32_t)S);
-    HIP_TRY(hipGetLastError());
-    // The round's last kernels are left RUNNING: nothing the host still has to do for this round -- its (sample, tile) pairs, its tables --
-    // and little of what finalize does first needs the bases or the headers.  What they leave for the host (the mismatch sample of every
-    // sample, their time) comes through pinned memory and is taken by devpack_sync_pending.
-    {
-        if (int rc = pin_ensure(ds, std::max<uint64_t>(S * sizeof(DpAcc), (ds.samples.size() + 16) * 4))) return rc;
+        // The round's last kernels are left RUNNING: nothing the host still has to do for this round -- its (sample, tile) pairs, its tables --
+        // and little of what finalize does first needs the bases or the headers.  What they leave for the host (the mismatch sample of every
+        // sample, their time) comes through pinned memory and is taken by devpack_sync_pending.
         HIP_TRY(hipMemcpy2DAsync(T.pin, sizeof(DpAcc), d_acc, sizeof(DpAcc) * ACC_COPIES, sizeof(DpAcc), S, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipEventRecord((hipEvent_t)T.pending.ev1, st));
         T.pending.active = true; T.pending.first = first; T.pending.n = S;
-    }
-    if (in_order) if (int rc = devpack_sync_pending(ds)) return rc;      // (the general tile-order route below waits for its sort anyway)
 
-    fin_trace("  pack: emit (sync)");
-    // ---- the (sample, contig, tile) runs of pieces = the pairs of the tile index
-    if (in_order) tm.start();
-    std::vector<DevPairRec> prec;
-    if (NPC >= 1 && in_order) {
-        // the general route: stable sort of the headers by (sample, contig, tile), runs of equal keys
-        DP_BUF(unsigned long long, d_tk, NPCa);
-        DP_BUF(uint32_t, d_ix, NPCa);
-        DP_BUF(uint32_t, d_uns, 4);
-        HIP_TRY(hipMemsetAsync(d_uns, 0, 4, st));
-        const unsigned tid_bits = std::max(1u, bit_width_u64(NC ? NC - 1 : 0));
-        hipLaunchKernelGGL(msnv_tile_keys, grid_for(NPC, 256), dim3(256), 0, st, w_hdr, w_tid, d_dst, (uint32_t)S, NPC, tid_bits, d_tk, d_ix, d_uns);
-        HIP_TRY(hipGetLastError());
-        uint32_t uns = 0;
-        HIP_TRY(hipMemcpyAsync(&uns, d_uns, 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        const unsigned long long *skeys = d_tk;
-        DP_BUF(unsigned long long, d_tk2, NPCa);
-        DP_BUF(uint32_t, d_ix2, NPCa);
-        if (uns) {
-            if (int rc = sort64(d_tk, d_tk2, d_ix, d_ix2, NPC, 21u + tid_bits + std::max(1u, bit_width_u64(S - 1)))) return rc;
-            hipLaunchKernelGGL(msnv_gather_pieces, grid_for(NPC, 256), dim3(256), 0, st, d_ix2, NPC, w_hdr, w_tid, w_end, w_depth, keep.hdr, keep.tid, keep.end, keep.depth);
+        // ---- the host's share: wait for the small results (not for the emit kernels), look at them
+        HIP_TRY(hipEventSynchronize((hipEvent_t)T.pending.evh));
+        fin_trace("  pack: depth stage, layout (wait)");
+        memcpy(sum.data(), pinb + o_sum, b_sum);
+        memcpy(piece_bytes.data(), pinb + o_pb, b_pb);
+        if (route == 0) {
+            memcpy(acc.data(), pinb + o_acc, b_acc);
+            rec_base_h.assign(S + 1, 0); memcpy(rec_base_h.data(), pinb + o_rb, b_rb);
+            memcpy(misc_h, pinb + o_misc, MISC_WORDS * 4);
+            runs.resize(n_runs); groups.resize(n_groups);
+            if (n_runs) memcpy(runs.data(), pinb + o_runs, b_runs);
+            if (n_groups) memcpy(groups.data(), pinb + o_grp, b_grp);
+            // what the quick route could not know when it launched the emit kernels: an error (reported), or something only the careful route
+            // handles -- a sample that needs the host pre-pass (depth cap, token limit), more far-reaching reads than the list holds, two
+            // overhanging contigs in one sub-segment.  The round is taken back (the kernels that still write into its buffers are waited for)
+            bool again = misc_h[MISC_NOUT] > CAP_OUT || misc_h[MISC_OVERHANG] == 2u;
+            for (size_t s = 0; s < S; ++s) again |= acc[s].need_host != 0;
+            int rc_err = check_errors();
+            if (rc_err || again) {
+                T.pending.active = false;
+                HIP_TRY(hipStreamSynchronize(st));
+                if (rc_err) return rc_err;
+                route = 1; T.n_quick_redone += 1;
+                continue;                                              // (`held` gives the buffers back)
+            }
+        }
+        if (misc_h[MISC_OVERHANG]) T.any_overhang_h = true;
+        for (size_t s = 0; s < S; ++s)
+            if (piece_bytes[s] > 0xffffff00ull) { T.pending.active = false; HIP_TRY(hipStreamSynchronize(st)); return fail(MSNV_EDOMAIN, "one sample holds more than 8.5 G aligned bases in this shard: shard the contigs further"); }
+        keep.seq_total = sum[S].seq_off;
+        T.n_pieces += NPC; T.n_records += NR;
+        T.pad_in_emit = true;                                          // (msnv_emit_block* leave the alignment nibbles behind every piece as finalize wants them)
+        T.round_bufs.push_back(held.round_buf); held.round_buf = nullptr;
+        held.keep_buf = nullptr;
+        T.rounds.push_back(keep);
+        if (in_order) if (int rc = devpack_sync_pending(ds)) return rc;      // (the general tile-order route below waits for its sort anyway)
+        fin_trace("  pack: emit launched, results in");
+
+        // ---- the (sample, contig, tile) runs of pieces = the pairs of the tile index
+        if (in_order) tm.start();
+        std::vector<DevPairRec> prec;
+        if (NPC >= 1 && in_order) {
+            // the general route: stable sort of the headers by (sample, contig, tile), runs of equal keys
+            DP_BUF(unsigned long long, d_tk, NPCa);
+            DP_BUF(uint32_t, d_ix, NPCa);
+            DP_BUF(uint32_t, d_uns, 4);
+            HIP_TRY(hipMemsetAsync(d_uns, 0, 4, st));
+            const unsigned tid_bits = std::max(1u, bit_width_u64(NC ? NC - 1 : 0));
+            hipLaunchKernelGGL(msnv_tile_keys, grid_for(NPC, 256), dim3(256), 0, st, w_hdr, w_tid, d_dst, (uint32_t)S, NPC, tid_bits, d_tk, d_ix, d_uns);
             HIP_TRY(hipGetLastError());
-            skeys = d_tk2;
-        } else {
-            HIP_TRY(hipMemcpyAsync(keep.hdr, w_hdr, (size_t)NPC * sizeof(ReadHdr), hipMemcpyDeviceToDevice, st));
-            HIP_TRY(hipMemcpyAsync(keep.tid, w_tid, (size_t)NPC * 4, hipMemcpyDeviceToDevice, st));
-            HIP_TRY(hipMemcpyAsync(keep.end, w_end, (size_t)NPC * 4, hipMemcpyDeviceToDevice, st));
-            HIP_TRY(hipMemcpyAsync(keep.depth, w_depth, (size_t)NPC * 2, hipMemcpyDeviceToDevice, st));
+            uint32_t uns = 0;
+            HIP_TRY(hipMemcpyAsync(&uns, d_uns, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            const unsigned long long *skeys = d_tk;
+            DP_BUF(unsigned long long, d_tk2, NPCa);
+            DP_BUF(uint32_t, d_ix2, NPCa);
+            if (uns) {
+                if (int rc = sort64(d_tk, d_tk2, d_ix, d_ix2, NPC, 21u + tid_bits + std::max(1u, bit_width_u64(S - 1)))) return rc;
+                hipLaunchKernelGGL(msnv_gather_pieces, grid_for(NPC, 256), dim3(256), 0, st, d_ix2, NPC, w_hdr, w_tid, w_end, w_depth, keep.hdr, keep.tid, keep.end, keep.depth);
+                HIP_TRY(hipGetLastError());
+                skeys = d_tk2;
+            } else {
+                HIP_TRY(hipMemcpyAsync(keep.hdr, w_hdr, (size_t)NPC * sizeof(ReadHdr), hipMemcpyDeviceToDevice, st));
+                HIP_TRY(hipMemcpyAsync(keep.tid, w_tid, (size_t)NPC * 4, hipMemcpyDeviceToDevice, st));
+                HIP_TRY(hipMemcpyAsync(keep.end, w_end, (size_t)NPC * 4, hipMemcpyDeviceToDevice, st));
+                HIP_TRY(hipMemcpyAsync(keep.depth, w_depth, (size_t)NPC * 2, hipMemcpyDeviceToDevice, st));
+            }
+            // runs of equal keys (d_ix / d_ix2 are free again: flags and their scan)
+            uint32_t n_pairs = 0;
+            hipLaunchKernelGGL(msnv_pair_flags, grid_for(NPC, 256), dim3(256), 0, st, skeys, NPC, d_ix);
+            HIP_TRY(hipGetLastError());
+            if (int rc = scan32(d_ix, d_ix2, NPC, true)) return rc;
+            HIP_TRY(hipMemcpyAsync(&n_pairs, d_ix2 + (NPC - 1), 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            DP_BUF(DevPairRec, d_prec, (uint64_t)n_pairs + 1);
+            hipLaunchKernelGGL(msnv_pair_starts, grid_for(NPC, 256), dim3(256), 0, st, skeys, d_ix, d_ix2, NPC, tid_bits, d_prec);
+            hipLaunchKernelGGL(msnv_pair_maxd, grid_for(n_pairs, 64), dim3(64), 0, st, d_prec, n_pairs, NPC, keep.depth);
+            HIP_TRY(hipGetLastError());
+            prec.resize(n_pairs);
+            HIP_TRY(hipMemcpyAsync(prec.data(), d_prec, (size_t)n_pairs * sizeof(DevPairRec), hipMemcpyDeviceToHost, st));
+        } else if (NPC >= 1) {
+            // tile order by counting: a group's pieces in its own tile join the ones the group before leaves there (same contig, the tile before)
+            prec.reserve(groups.size() + groups.size() / 8);
+            for (size_t g = 0; g < groups.size(); ++g) {
+                const DevGroupRec &G = groups[g];
+                const bool prev_adj = g > 0 && groups[g - 1].sample == G.sample && groups[g - 1].tid == G.tid && groups[g - 1].tile + 1u == G.tile;
+                const bool next_adj = g + 1 < groups.size() && groups[g + 1].sample == G.sample && groups[g + 1].tid == G.tid && groups[g + 1].tile == G.tile + 1u;
+                prec.push_back(DevPairRec{G.sample, G.tid, G.tile, prev_adj ? groups[g - 1].b : G.a, std::max(G.md_own, prev_adj ? groups[g - 1].md_next : 0u)});
+                if (!next_adj && G.end > G.b) prec.push_back(DevPairRec{G.sample, G.tid, G.tile + 1u, G.b, G.md_next});
+            }
         }
-        // runs of equal keys (d_ix / d_ix2 are free again: flags and their scan)
-        uint32_t n_pairs = 0;
-        hipLaunchKernelGGL(msnv_pair_flags, grid_for(NPC, 256), dim3(256), 0, st, skeys, NPC, d_ix);
-        HIP_TRY(hipGetLastError());
-        if (int rc = scan32(d_ix, d_ix2, NPC, true)) return rc;
-        HIP_TRY(hipMemcpyAsync(&n_pairs, d_ix2 + (NPC - 1), 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        DP_BUF(DevPairRec, d_prec, (uint64_t)n_pairs + 1);
-        hipLaunchKernelGGL(msnv_pair_starts, grid_for(NPC, 256), dim3(256), 0, st, skeys, d_ix, d_ix2, NPC, tid_bits, d_prec);
-        hipLaunchKernelGGL(msnv_pair_maxd, grid_for(n_pairs, 64), dim3(64), 0, st, d_prec, n_pairs, NPC, keep.depth);
-        HIP_TRY(hipGetLastError());
-        prec.resize(n_pairs);
-        HIP_TRY(hipMemcpyAsync(prec.data(), d_prec, (size_t)n_pairs * sizeof(DevPairRec), hipMemcpyDeviceToHost, st));
-    } else if (NPC >= 1) {
-        // tile order by counting: a group's pieces in its own tile join the ones the group before leaves there (same contig, the tile before)
-        prec.reserve(groups.size() + groups.size() / 8);
-        for (size_t g = 0; g < groups.size(); ++g) {
-            const DevGroupRec &G = groups[g];
-            const bool prev_adj = g > 0 && groups[g - 1].sample == G.sample && groups[g - 1].tid == G.tid && groups[g - 1].tile + 1u == G.tile;
-            const bool next_adj = g + 1 < groups.size() && groups[g + 1].sample == G.sample && groups[g + 1].tid == G.tid && groups[g + 1].tile == G.tile + 1u;
-            prec.push_back(DevPairRec{G.sample, G.tid, G.tile, prev_adj ? groups[g - 1].b : G.a, std::max(G.md_own, prev_adj ? groups[g - 1].md_next : 0u)});
-            if (!next_adj && G.end > G.b) prec.push_back(DevPairRec{G.sample, G.tid, G.tile + 1u, G.b, G.md_next});
-        }
-    }
-    if (in_order) T.ms_sort += tm.stop();                          // (the counting route is host work on the groups: nothing to wait for)
+        if (in_order) T.ms_sort += tm.stop();                          // (the counting route is host work on the groups: nothing to wait for)
 
-    fin_trace("  pack: pairs");
-    // ---- what the host keeps of a sample: its summaries and its (contig, tile) runs
-    const double t_dl = now_s();
-    const int32_t round_no = (int32_t)T.rounds.size() - 1;
-    for (size_t s = 0; s < S; ++s) {
-        SampleCols &sc = ds.samples[first + s];
-        const DpAcc &a = acc[s];
-        sc.on_device = true; sc.d_seq = dsts[s].seq; sc.d_qual = dsts[s].qual; sc.d_seq_bytes = piece_bytes[s] + 32;
-        sc.dev_index = true; sc.dev_round = round_no; sc.dev_piece0 = sum[s].pbase0; sc.dev_iv0 = sum[s].ibase0;
-        sc.n_dev_pieces = sum[s + 1].pbase0 - sum[s].pbase0; sc.n_dev_iv = sum[s + 1].ibase0 - sum[s].ibase0;
-        sc.n_pileup_bases = a.n_bases; sc.n_pileup_reads = a.n_pile_reads;
-        sc.mm_sampled_bases = a.mm_bases; sc.mm_sampled = a.mm;
-        sc.alg_seq_bytes = a.alg_seq; sc.alg_qual_bytes = a.alg_qual; sc.alg_8d_bytes = a.alg8d; sc.alg_cigar_bytes = a.alg_cigar;
-        sc.st = msnv_sample_stats{a.total, a.unmapped, a.zeroq, a.proper, a.dup, a.any_mapped};
-        // first pileup read of the sample: the first-line quirk of snpCall (call_vC.cpp:423)
-        if (a.first_pile != ~0ull) {
-            const int32_t tid = (int32_t)(sum[s].first_key >> 32), pos = (int32_t)(uint32_t)sum[s].first_key;
-            int64_t b = pos, e = (int64_t)sum[s].first_end;
-            if (ds.has_bed) { b = std::max(b, ds.bed_beg[(size_t)tid]); e = std::min(e, ds.bed_end[(size_t)tid]); }
-            if (b < e) { sc.first_tid = tid; sc.first_beg = (int32_t)b; sc.first_end = (int32_t)e; }
+        fin_trace("  pack: pairs");
+        // ---- what the host keeps of a sample: its summaries and its (contig, tile) runs
+        const double t_dl = now_s();
+        const int32_t round_no = (int32_t)T.rounds.size() - 1;
+        for (size_t s = 0; s < S; ++s) {
+            SampleCols &sc = ds.samples[first + s];
+            const DpAcc &a = acc[s];
+            sc.on_device = true; sc.d_seq = r_seq + sum[s].seq_off; sc.d_qual = r_qual + sum[s].seq_off / 4; sc.d_seq_bytes = piece_bytes[s] + 32;
+            sc.dev_index = true; sc.dev_round = round_no; sc.dev_piece0 = sum[s].pbase0; sc.dev_iv0 = sum[s].ibase0;
+            sc.n_dev_pieces = sum[s + 1].pbase0 - sum[s].pbase0; sc.n_dev_iv = sum[s + 1].ibase0 - sum[s].ibase0;
+            sc.n_pileup_bases = a.n_bases; sc.n_pileup_reads = a.n_pile_reads;
+            sc.mm_sampled_bases = a.mm_bases; sc.mm_sampled = a.mm;
+            sc.alg_seq_bytes = a.alg_seq; sc.alg_qual_bytes = a.alg_qual; sc.alg_8d_bytes = a.alg8d; sc.alg_cigar_bytes = a.alg_cigar;
+            sc.st = msnv_sample_stats{a.total, a.unmapped, a.zeroq, a.proper, a.dup, a.any_mapped};
+            // first pileup read of the sample: the first-line quirk of snpCall (call_vC.cpp:423)
+            if (a.first_pile != ~0ull) {
+                const int32_t tid = (int32_t)(sum[s].first_key >> 32), pos = (int32_t)(uint32_t)sum[s].first_key;
+                int64_t b = pos, e = (int64_t)sum[s].first_end;
+                if (ds.has_bed) { b = std::max(b, ds.bed_beg[(size_t)tid]); e = std::min(e, ds.bed_end[(size_t)tid]); }
+                if (b < e) { sc.first_tid = tid; sc.first_beg = (int32_t)b; sc.first_end = (int32_t)e; }
+            }
+            if (a.beyond != ~0ull) {
+                sc.warned_beyond_end = true;
+                fprintf(stderr, "msnv: warning: read at %s:%d reaches the contig end in qaCompute's index space (undefined behaviour in the reference: coverageHist[-1]); "
+                                "the last position of the contig is left out of the coverage histogram\n", ds.names[(size_t)(int32_t)(sum[s].beyond_key >> 32)].c_str(),
+                        (int32_t)(uint32_t)sum[s].beyond_key + 1);
+            }
         }
-        if (a.beyond != ~0ull) {
-            sc.warned_beyond_end = true;
-            fprintf(stderr, "msnv: warning: read at %s:%d reaches the contig end in qaCompute's index space (undefined behaviour in the reference: coverageHist[-1]); "
-                            "the last position of the contig is left out of the coverage histogram\n", ds.names[(size_t)(int32_t)(sum[s].beyond_key >> 32)].c_str(),
-                    (int32_t)(uint32_t)sum[s].beyond_key + 1);
+        if (in_order) HIP_TRY(hipStreamSynchronize(st));               // (the sorted pairs come down asynchronously)
+        {
+            std::vector<uint32_t> per(S, 0);
+            for (const DevPairRec &r : prec) ++per[r.sample];
+            for (size_t s = 0; s < S; ++s) ds.samples[first + s].dev_pairs.reserve(per[s]);
         }
+        for (size_t p = 0; p < prec.size(); ++p) {
+            const DevPairRec &r = prec[p];
+            SampleCols &sc = ds.samples[first + r.sample];
+            const uint32_t hi = (p + 1 < prec.size() && prec[p + 1].sample == r.sample) ? prec[p + 1].start : (uint32_t)sum[r.sample + 1].pbase0;
+            sc.dev_pairs.push_back(DevPair{r.tid, r.tile, r.start - sum[r.sample].pbase0, hi - sum[r.sample].pbase0, r.maxd, 0u});
+        }
+        // ... and of every (sample, contig)
+        for (const DpRun &r : runs) {
+            SampleCols &sc = ds.samples[first + r.sample];
+            if (sc.first_any.empty()) { sc.first_any.assign(NC, -1); sc.first_from1.assign(NC, -1); }
+            sc.first_any[(size_t)r.tid] = r.first_any; sc.first_from1[(size_t)r.tid] = r.first_from1;
+        }
+        T.wall_download_s += now_s() - t_dl;
+        fin_trace("  pack: host tables");
+        break;
     }
-    if (in_order) HIP_TRY(hipStreamSynchronize(st));               // (the sorted pairs come down asynchronously)
-    {
-        std::vector<uint32_t> per(S, 0);
-        for (const DevPairRec &r : prec) ++per[r.sample];
-        for (size_t s = 0; s < S; ++s) ds.samples[first + s].dev_pairs.reserve(per[s]);
-    }
-    for (size_t p = 0; p < prec.size(); ++p) {
-        const DevPairRec &r = prec[p];
-        SampleCols &sc = ds.samples[first + r.sample];
-        const uint32_t hi = (p + 1 < prec.size() && prec[p + 1].sample == r.sample) ? prec[p + 1].start : (uint32_t)sum[r.sample + 1].pbase0;
-        sc.dev_pairs.push_back(DevPair{r.tid, r.tile, r.start - sum[r.sample].pbase0, hi - sum[r.sample].pbase0, r.maxd, 0u});
-    }
-    // ... and of every (sample, contig)
-    for (const DpRun &r : runs) {
-        SampleCols &sc = ds.samples[first + r.sample];
-        if (sc.first_any.empty()) { sc.first_any.assign(NC, -1); sc.first_from1.assign(NC, -1); }
-        sc.first_any[(size_t)r.tid] = r.first_any; sc.first_from1[(size_t)r.tid] = r.first_from1;
-    }
-    T.wall_download_s += now_s() - t_dl;
-    fin_trace("  pack: host tables");
 #undef DP_BUF
     return MSNV_OK;
 }

@@ -503,3 +503,17 @@ def test_the_emit_kernels_two_routes_write_the_same_columns():
             _same_dataset(syn.names, syn.lengths, syn.seqs, samples, many=True, check_oracle=False)
         with _env(MSNV_FILL_PADDING="1"):
             _same_dataset(syn.names, syn.lengths, syn.seqs, samples, many=True, check_oracle=False)
+
+
+def test_the_quick_and_the_careful_front_build_the_same_dataset():
+    """Round 6: records' boundaries and everything a record decides by itself come from ONE walk (msnv_scan_sub2, the quick route); the
+    careful route -- msnv_scan_sub / msnv_scan_segments, msnv_measure_reads, a wait between the stages -- takes what the quick one leaves
+    (paired reads, the host pre-pass, malformed input) and MSNV_FRONT=careful sends everything there.  Both against the host pack, column by
+    column; small sub-segments put many seams, run and group boundaries between the lanes of the walk."""
+    for kw in (dict(n_species=3, contig_len=9000, n_samples=8, mean_cov=12.0, snv_density=0.02, error_rate=0.004, seed=41),
+               dict(n_species=6, contig_len=2600, n_samples=20, mean_cov=1.2, species_per_sample=2, seed=42),
+               dict(n_species=1, contig_len=5000, n_samples=2, mean_cov=40.0, read_len=150, seed=43)):
+        syn, samples = synth_case(**kw)
+        for env in (dict(), dict(MSNV_FRONT="careful"), dict(MSNV_SCAN_SUB="256"), dict(MSNV_SCAN_SUB="8192"), dict(MSNV_SCAN="segments")):
+            with _env(**env):
+                _same_dataset(syn.names, syn.lengths, syn.seqs, samples, many=True, check_oracle=False)
