@@ -724,7 +724,7 @@ __global__ __launch_bounds__(256) void msnv_pile_gather(const RecCnt *r_cnt, con
     p_rd[r] = make_uint4(pos, e - pos > span_out ? 0u : e, (uint32_t)(k >> 32), (uint32_t)rec_sample[i] | mc << 12);
     p_ftile[r] = r_ftile[i]; p_rec[r] = i;
 }
-constexpr uint32_t DEPTH_BACK = 768;                               // reads in front of a workgroup's 256 that its LDS window holds (16 KB in all)
+constexpr uint32_t DEPTH_BACK = 256;                               // reads in front of a workgroup's 256 that its LDS window holds (16 KB in all)
 __global__ __launch_bounds__(256) void msnv_depth(const unsigned long long *rg, uint32_t n_pile, const uint4 *p_rd,
                                                   const uint32_t *p_ftile, const uint32_t *p_rec, const RecCnt *r_cnt, const uint32_t *ovr, DpParams P, uint32_t window, const uint32_t *outliers,
                                                   uint32_t n_out, const uint16_t *rec_sample, const unsigned long long *r_key, const uint32_t *r_end, const uint32_t *r_maxc,
