@@ -409,6 +409,11 @@ int  msnv_dataset_deal_bams_device(msnv_dataset *ds, const char *const *bam_path
  * aligned bases per contig (contig_bases, n_contigs of the dataset, not cleared); msnv_records_deal_device (on_device != 0) deals them later. */
 int  msnv_dataset_inflate_bams_device(msnv_dataset *ds, const char *const *bam_paths, int32_t n, int32_t host_threads, uint8_t *out, uint64_t capacity,
                                       uint64_t *rec_off, uint64_t *rec_bytes, msnv_sample_stats *stats, uint64_t *contig_bases);
+/* A second context OF THE SAME DEVICE for the two calls above (NULL: back to the dataset's own): its stream, staging buffers and pinned
+ * words carry the upload, inflate, CRC check and dealing of round k + 1 of the N-rank feed while the dataset's own context packs round k
+ * (one thread per context) -- the reference overlaps its splits as concurrent processes, each of which reads every BAM
+ * (/root/reference/metaSNV.py:196-215); here a round's files are read once, by the feed.  Nothing of the dataset is written through it. */
+int  msnv_dataset_set_feed_ctx(msnv_dataset *ds, msnv_ctx *ctx);
 int  msnv_records_deal_device(msnv_ctx *ctx, const uint8_t *const *streams, const uint64_t *n_bytes, int32_t n, int32_t on_device, const int32_t *contig_owner,
                               int32_t n_contigs, int32_t n_parts, int32_t cov_min_mapq, uint8_t *out, uint64_t capacity, uint64_t gap, uint64_t *part_bytes,
                               msnv_sample_stats *stats, uint64_t *contig_bases);

@@ -12,4 +12,6 @@ if __name__ == "__main__":
     # every output file is closed by now (cli.py); leaving through the interpreter's teardown would unmap gigabytes of host staging buffer by
     # buffer and shut the HIP runtime down allocation by allocation -- 0.2 s of a 1.2 s job.  The kernel takes the address space back in one go.
     sys.stdout.flush(); sys.stderr.flush()
+    if os.environ.get("MSNV_EXIT") == "normal":      # (a profiler that writes its files from an exit handler: profiles/r06_inflate_trace.sh)
+        sys.exit(0)
     os._exit(0)

@@ -120,6 +120,7 @@ SYMBOLS = [
     ("msnv_dataset_create", C.c_int, [_vp, P(RefDesc), P(Params), P(_vp)]),
     ("msnv_dataset_create_from_files", C.c_int, [_vp, C.c_char_p, C.c_char_p, P(Params), P(_vp)]),
     ("msnv_dataset_attach_ctx", C.c_int, [_vp, _vp]),
+    ("msnv_dataset_set_feed_ctx", C.c_int, [_vp, _vp]),
     ("msnv_dataset_destroy", None, [_vp]),
     ("msnv_dataset_set_bed", C.c_int, [_vp, C.c_int32, P(C.c_int32), P(C.c_int64), P(C.c_int64)]),
     ("msnv_dataset_set_bed_file", C.c_int, [_vp, C.c_char_p]),

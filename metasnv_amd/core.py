@@ -103,6 +103,11 @@ class Dataset:
         check(lib.msnv_dataset_attach_ctx(self._h, ctx._h))
         self.ctx = ctx
 
+    def set_feed_context(self, ctx):
+        """A second context of the dataset's device for deal_bams_device / inflate_bams_device (None: back to the dataset's own): the N-rank
+        feed decodes round k + 1 through it on a thread of its own while this dataset's context packs round k."""
+        check(lib.msnv_dataset_set_feed_ctx(self._h, ctx._h if ctx is not None else None))
+
     def set_bed(self, regions):
         """regions: iterable of (tid, beg, end), 0-based half-open (mpileup -l)."""
         regions = list(regions)

@@ -129,6 +129,14 @@ extern "C" int msnv_dataset_attach_ctx(msnv_dataset *ds, msnv_ctx *ctx) {
     return MSNV_OK;
 }
 
+extern "C" int msnv_dataset_set_feed_ctx(msnv_dataset *ds, msnv_ctx *ctx) {
+    clear_error();
+    if (!ds) return fail(MSNV_EINVAL, "msnv_dataset_set_feed_ctx: NULL dataset");
+    if (ctx && ds->ctx && ctx->device != ds->ctx->device) return fail(MSNV_EINVAL, "msnv_dataset_set_feed_ctx: the feed context must be one of the dataset's device (%d), not of device %d", ds->ctx->device, ctx->device);
+    ds->feed_ctx = ctx;
+    return MSNV_OK;
+}
+
 extern "C" void msnv_dataset_destroy(msnv_dataset *ds) {
     if (!ds) return;
     if (ds->ctx && (ds->dp.ready || !ds->dp.round_bufs.empty())) { (void)dev_set_device(ds->ctx->device); devpack_release(*ds); }
@@ -841,6 +849,8 @@ extern "C" int msnv_dataset_deal_bams_device(msnv_dataset *ds, const char *const
     if (!ds || n < 0 || (n && (!bam_paths || !part_bytes || !stats || !record_bytes)) || !contig_owner) return fail(MSNV_EINVAL, "msnv_dataset_deal_bams_device: bad argument");
     if (!ds->ctx) return fail(MSNV_ENODEV, "msnv_dataset_deal_bams_device needs a dataset with a device context");
     if (n == 0) return MSNV_OK;
+    msnv_ctx *const fc = ds->feed_ctx ? ds->feed_ctx : ds->ctx;      // (msnv_dataset_set_feed_ctx: a round ahead of the dataset's own context)
+    if (int rc = dev_set_device(fc->device)) return rc;
     int nthreads = host_threads > 0 ? host_threads : (int)msnv_default_threads();
     nthreads = std::min(nthreads, std::max(1, (int)n));
     {   // one batch of the device inflate only: the parts of a call lie destination-major in `out`
@@ -863,7 +873,7 @@ extern "C" int msnv_dataset_deal_bams_device(msnv_dataset *ds, const char *const
     auto consume = [&](int f0, int f1, const uint8_t *host_out, const std::vector<InflatedExt> &ext, bool dev_valid) -> int {
         if (calls++ || f0 != 0 || f1 != n) return fail(MSNV_EINVAL, "internal: msnv_dataset_deal_bams_device expects one batch");
         std::vector<const uint8_t *> ptrs; std::vector<uint64_t> sizes;
-        const uint8_t *base = dev_valid ? static_cast<const uint8_t *>(ds->ctx->dev_out) : host_out;      // (a batch the host decoder had to take lies in host memory)
+        const uint8_t *base = dev_valid ? static_cast<const uint8_t *>(fc->dev_out) : host_out;      // (a batch the host decoder had to take lies in host memory)
         for (int i = 0; i < n; ++i) {
             const uint64_t size = ext[(size_t)i].size, rec_off = rb.rec_off[(size_t)i];
             if (int rc = check_header(*ds, rb.hdr[(size_t)i], bam_paths[i])) return rc;
@@ -872,9 +882,9 @@ extern "C" int msnv_dataset_deal_bams_device(msnv_dataset *ds, const char *const
             sizes.push_back(size - rec_off);
             record_bytes[i] = size - rec_off;
         }
-        return records_deal_device(ds->ctx, ptrs.data(), sizes.data(), n, dev_valid, contig_owner, NC, n_parts, cov_min_mapq, out, capacity, gap, part_bytes, stats, nullptr);
+        return records_deal_device(fc, ptrs.data(), sizes.data(), n, dev_valid, contig_owner, NC, n_parts, cov_min_mapq, out, capacity, gap, part_bytes, stats, nullptr);
     };
-    try { uint64_t cnt[4]; return bgzf_read_files_device(ds->ctx, bam_paths, n, nthreads, consume, cnt, &rb); }
+    try { uint64_t cnt[4]; return bgzf_read_files_device(fc, bam_paths, n, nthreads, consume, cnt, &rb); }
     catch (const std::exception &e) { return fail(MSNV_ENOMEM, "msnv_dataset_deal_bams_device: %s", e.what()); }
 }
 
@@ -887,6 +897,8 @@ extern "C" int msnv_dataset_inflate_bams_device(msnv_dataset *ds, const char *co
     if (!ds || n < 0 || (n && (!bam_paths || !rec_off || !rec_bytes || !stats || !out))) return fail(MSNV_EINVAL, "msnv_dataset_inflate_bams_device: bad argument");
     if (!ds->ctx) return fail(MSNV_ENODEV, "msnv_dataset_inflate_bams_device needs a dataset with a device context");
     if (n == 0) return MSNV_OK;
+    msnv_ctx *const fc = ds->feed_ctx ? ds->feed_ctx : ds->ctx;
+    if (int rc = dev_set_device(fc->device)) return rc;
     int nthreads = host_threads > 0 ? host_threads : (int)msnv_default_threads();
     nthreads = std::min(nthreads, std::max(1, (int)n));
     {
@@ -909,7 +921,7 @@ extern "C" int msnv_dataset_inflate_bams_device(msnv_dataset *ds, const char *co
     auto consume = [&](int f0, int f1, const uint8_t *host_out, const std::vector<InflatedExt> &ext, bool dev_valid) -> int {
         if (calls++ || f0 != 0 || f1 != n) return fail(MSNV_EINVAL, "internal: msnv_dataset_inflate_bams_device expects one batch");
         std::vector<const uint8_t *> ptrs; std::vector<uint64_t> sizes;
-        const uint8_t *base = dev_valid ? static_cast<const uint8_t *>(ds->ctx->dev_out) : host_out;
+        const uint8_t *base = dev_valid ? static_cast<const uint8_t *>(fc->dev_out) : host_out;
         uint64_t o = 0;
         for (int i = 0; i < n; ++i) {
             const uint64_t size = ext[(size_t)i].size, ro = rb.rec_off[(size_t)i];
@@ -917,15 +929,15 @@ extern "C" int msnv_dataset_inflate_bams_device(msnv_dataset *ds, const char *co
             if (ro > size) return fail(MSNV_EFORMAT, "%s: truncated BAM header", bam_paths[i]);
             rec_off[i] = o; rec_bytes[i] = size - ro;
             if (o + (size - ro) + 32 > capacity) return fail_quiet(MSNV_ECAPACITY, "msnv_dataset_inflate_bams_device: the output holds %llu bytes, more are needed", (unsigned long long)capacity);
-            if (size - ro) if (int rc = dev_copy_bytes(out + o, base + ext[(size_t)i].off + ro, size - ro, dev_valid, ds->ctx->stream)) return rc;
+            if (size - ro) if (int rc = dev_copy_bytes(out + o, base + ext[(size_t)i].off + ro, size - ro, dev_valid, fc->stream)) return rc;
             ptrs.push_back(out + o); sizes.push_back(size - ro);
             o += (size - ro + 31) & ~15ull;                       // (16 readable bytes behind every stream)
         }
         std::vector<int32_t> nobody((size_t)std::max(1, NC), -1);
         std::vector<uint64_t> pb((size_t)n, 0);
-        return records_deal_device(ds->ctx, ptrs.data(), sizes.data(), n, true, nobody.data(), NC, 1, ds->params.cov_min_mapq, nullptr, 0, 0, pb.data(), stats, contig_bases);
+        return records_deal_device(fc, ptrs.data(), sizes.data(), n, true, nobody.data(), NC, 1, ds->params.cov_min_mapq, nullptr, 0, 0, pb.data(), stats, contig_bases);
     };
-    try { uint64_t cnt[4]; return bgzf_read_files_device(ds->ctx, bam_paths, n, nthreads, consume, cnt, &rb); }
+    try { uint64_t cnt[4]; return bgzf_read_files_device(fc, bam_paths, n, nthreads, consume, cnt, &rb); }
     catch (const std::exception &e) { return fail(MSNV_ENOMEM, "msnv_dataset_inflate_bams_device: %s", e.what()); }
 }
 

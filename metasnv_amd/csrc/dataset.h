@@ -196,6 +196,7 @@ struct msnv_ctx {
 
 struct msnv_dataset {
     msnv_ctx *ctx = nullptr;
+    msnv_ctx *feed_ctx = nullptr;     // msnv_dataset_set_feed_ctx: stream and staging of msnv_dataset_deal_bams_device / msnv_dataset_inflate_bams_device (NULL: ctx)
     msnv_params params{};
     // reference
     std::vector<std::string> names;

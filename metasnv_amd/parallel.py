@@ -396,6 +396,7 @@ def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=Non
 
     def deal_files_on_device(paths):
         import torch
+        torch.cuda.set_device(_device())                         # (the round ahead runs on a thread of its own: torch's current device is per thread)
         gap = 8 * len(paths)
         comp = sum(os.path.getsize(p) for p in paths)
         cap = 8 * comp + (1 << 20) + _world * gap             # (BAM inflates 2.5-4 x; the call answers MSNV_ECAPACITY when this is not enough)
@@ -598,6 +599,20 @@ def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=Non
         except Exception as e:                               # noqa: BLE001
             pending[0] = e
 
+    # Files a rank decodes per round: the caller's (= --threads, what host decode threads want) -- but the DEVICE route inflates a round's files
+    # in one launch of one wavefront per BGZF block, and seven files are ~3 000 blocks for 5 000 wavefront slots: as many files as fit three
+    # quarters of a batch of the device inflate (the feed of the benchmark's 160 BAMs: 0.65 s at 7 files a round, 0.43 s at 32; round 6).
+    # Every rank computes the same number from the same list.  MSNV_FEED_BATCH overrides.
+    if os.environ.get("MSNV_FEED_BATCH"):
+        batch = max(1, int(os.environ["MSNV_FEED_BATCH"]))
+    elif read_many is not None and device_route(need_owner=False):
+        try:
+            largest = max(os.path.getsize(p) for p in bam_paths) if bam_paths else 0
+            room = (int(os.environ.get("MSNV_INFLATE_BATCH_MB", "1024")) << 20) * 3 // 4
+            batch = max(batch, min(64, max(1, room // max(1, largest + 32))))
+        except OSError:
+            pass
+    batch = max(1, min(batch, -(-n // _world)))
     pending = [None]                                         # a failure of THIS rank while it appended a round (pack: ENOMEM, EDOMAIN ...)
     rounds = list(deal_samples(n, batch))
     k = 0
@@ -692,6 +707,17 @@ def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=Non
     host_decoder = read_records is not None or os.environ.get("MSNV_INFLATE", "device")[:1] == "h"
     want_overlap = feed_overlap if feed_overlap is not None else os.environ.get("MSNV_FEED_OVERLAP", "1") != "0"      # (an argument of the run; the environment is the default)
     overlap = host_decoder and want_overlap and len(rounds) - k > 1
+    # ... and on the DEVICE route (round 6): the upload, inflate, CRC check and dealing of round k + 1 run on a second context of the device
+    # (core.Dataset.set_feed_context: its own stream, staging buffers and pinned words) from a thread of its own, under the exchange and the
+    # pack of round k on the dataset's context -- the inflate kernel is bound by latency per symbol and leaves most of the chip to the pack
+    feed_ctx = None
+    if not overlap and want_overlap and len(rounds) - k > 1 and read_many is not None and device_route() and hasattr(ds, "set_feed_context"):
+        try:
+            feed_ctx = core.Context(ds.ctx.device)
+            ds.set_feed_context(feed_ctx)
+            overlap = True
+        except Exception:                                        # noqa: BLE001 -- no second context: one round after the other, as before
+            feed_ctx = None
     if overlap:
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=1) as ahead:
@@ -708,9 +734,13 @@ def feed_sharded(ds, bam_paths, owner, cov_min_mapq=1, batch=1, read_records=Non
             read_ahead(rounds[k + 1][1])
         deliver(base, plan_round, *decode_round(plan_round))
         k += 1
+    if feed_ctx is not None:
+        ds.set_feed_context(None)
+        feed_ctx.close()
     if metrics is not None:
         metrics.update(split)
         metrics["decode_overlapped"] = bool(overlap)
+        metrics["decode_on_second_context"] = feed_ctx is not None
     agree(pending[0], "the last round of records was appended")
     allstats = gather_fixed(stats)
     stats = np.maximum.reduce(allstats) if len(allstats) > 1 else stats      # every row is non-zero on exactly one rank
