@@ -80,13 +80,13 @@ struct Rec {
 };
 __device__ __forceinline__ Rec rec_load(const uint8_t *p, uint64_t avail) {
     Rec r;
-    const uint64_t a = ld64(p), b = ld64(p + 8), c = ld64(p + 16), d = ld64(p + 24);
-    r.bs = (uint32_t)a; r.tid = (int32_t)(a >> 32); r.pos = (int32_t)(uint32_t)b;
-    const uint32_t w = (uint32_t)(b >> 32);
+    uint4 h0, h1; __builtin_memcpy(&h0, p, 16); __builtin_memcpy(&h1, p + 16, 16);      // (two 16-byte loads and a word instead of four 8-byte ones and a word: the walks that call this are bound by the NUMBER of memory requests)
+    r.bs = h0.x; r.tid = (int32_t)h0.y; r.pos = (int32_t)h0.z;
+    const uint32_t w = h0.w;
     r.l_name = w & 0xffu; r.mapq = (w >> 8) & 0xffu;
-    const uint32_t fn = (uint32_t)c;
-    r.n_cigar = fn & 0xffffu; r.flag = fn >> 16; r.l_seq = (int32_t)(c >> 32);
-    r.mtid = (int32_t)(uint32_t)d; r.mpos = (int32_t)(d >> 32); r.tlen = (int32_t)ld32(p + 32);
+    const uint32_t fn = h1.x;
+    r.n_cigar = fn & 0xffffu; r.flag = fn >> 16; r.l_seq = (int32_t)h1.y;
+    r.mtid = (int32_t)h1.z; r.mpos = (int32_t)h1.w; r.tlen = (int32_t)ld32(p + 32);
     r.cigar = p + 36 + r.l_name;
     r.seq = r.cigar + 4ull * r.n_cigar;
     r.qual = r.seq + ((uint64_t)(uint32_t)r.l_seq + 1) / 2;
@@ -486,7 +486,8 @@ struct RecMeasure {
 };
 enum : uint32_t { ST_UNMAPPED = 1, ST_ZEROQ = 2, ST_PROPER = 4, ST_DUP = 8, ST_ANY = 16, ST_OVL = 32, ST_BEYOND = 64, ST_SORT = 128, ST_OVERHANG = 256, ST_ORDER = 512, ST_SHIPS = 1024 };
 // ovr: the host pre-pass's verdict for this record (0: none)
-__device__ __forceinline__ RecMeasure measure_one(const Rec &r, const DpContig *ctg, const DpParams &P, uint32_t ov) {
+// ctg_cache / cached_tid (may be NULL): the contig row of the record the caller measured before -- a walk's records mostly share one
+__device__ __forceinline__ RecMeasure measure_one(const Rec &r, const DpContig *ctg, const DpParams &P, uint32_t ov, DpContig *ctg_cache = nullptr, int32_t *cached_tid = nullptr) {
     RecMeasure m{};
     if (!r.ok) { m.err = ERR_MALFORMED; return m; }
     if (!rec_mapped(r.flag, r.tid)) { m.st = ST_UNMAPPED; return m; }                     // qaCompute.cpp:461-473
@@ -500,7 +501,9 @@ __device__ __forceinline__ RecMeasure measure_one(const Rec &r, const DpContig *
     m.key = (unsigned long long)(uint32_t)r.tid << 32 | (uint32_t)r.pos;
     if (r.tid >= P.n_contigs) { m.err = ERR_TID; return m; }
     m.st |= ST_ORDER;                                                                     // (coordinate order: checked by the caller, against the neighbours' keys)
-    const DpContig c = ctg[r.tid];
+    DpContig c;
+    if (ctg_cache) { if (*cached_tid != r.tid) { *ctg_cache = ctg[r.tid]; *cached_tid = r.tid; } c = *ctg_cache; }
+    else c = ctg[r.tid];
     if (!c.sel) return m;
     // ---- CIGAR geometry, pieces, qaCompute's intervals: one walk
     long long rlen = 0, qlen = 0, m_bases = 0, ins = 0, del = 0, rp = r.pos, pp = (long long)r.pos + 1;
@@ -880,8 +883,13 @@ struct SubInfo {
 };
 constexpr uint32_t MAXC_SAT = 0x7ffffu;
 // One sub-segment's records from `entry`: the chain, the slots, the sums.  Returns false when the chain breaks.
+// st: this lane's column of the workgroup's statistics words in LDS (WALK_STATS rows of blockDim.x words: eleven sums a lane would otherwise
+// keep in registers through the walk -- the kernel sits at the register step of its occupancy)
+constexpr uint32_t WALK_STATS = 11;
 __device__ __forceinline__ bool walk_sub2(const uint8_t *raw, unsigned long long s_end, unsigned long long b, unsigned long long e, unsigned long long entry, uint32_t cap,
-                                          const DpContig *ctg, const DpParams &P, uint16_t *dl, Slot *slots, SubInfo &I, uint32_t &n_out, unsigned long long &off_out) {
+                                          const DpContig *ctg, const DpParams &P, uint16_t *dl, Slot *slots, SubInfo &I, uint32_t &n_out, unsigned long long &off_out, uint32_t *st, uint32_t st_stride) {
+    for (uint32_t k = 0; k < WALK_STATS; ++k) st[k * st_stride] = 0u;
+    DpContig c_cache{}; int32_t c_tid = -2;
     SubInfo s{};
     s.fp_slot = s.fm_slot = s.err = s.beyond_slot = 0xffffffffu;
     uint32_t n = 0; unsigned long long off = entry;
@@ -893,7 +901,7 @@ __device__ __forceinline__ bool walk_sub2(const uint8_t *raw, unsigned long long
         const Rec r = rec_load(raw + off, s_end - off);
         if ((int32_t)r.bs < 32 || (unsigned long long)r.bs + 4 > s_end - off) { bad = true; break; }
         if (n < cap) {
-            const RecMeasure m = measure_one(r, ctg, P, 0u);
+            const RecMeasure m = measure_one(r, ctg, P, 0u, &c_cache, &c_tid);
             uint32_t err = m.err;
             if (m.st & ST_ORDER) {                                             // coordinate order inside the walk (across sub-segments: msnv_sub_bounds)
                 if (have_prev) {
@@ -934,12 +942,16 @@ __device__ __forceinline__ bool walk_sub2(const uint8_t *raw, unsigned long long
             slots[n] = q;
             dl[n] = (uint16_t)(off - b);
             // ---- the sub-segment's sums
-            s.st_unmapped += (m.st & ST_UNMAPPED) ? 1u : 0u; s.st_zeroq += (m.st & ST_ZEROQ) ? 1u : 0u; s.st_proper += (m.st & ST_PROPER) ? 1u : 0u;
-            s.st_dup += (m.st & ST_DUP) ? 1u : 0u; s.st_any += (m.st & ST_ANY) ? 1u : 0u; s.st_ovl += (m.st & ST_OVL) ? 1u : 0u;
+            if (m.st & ST_UNMAPPED) st[0] += 1u;
+            if (m.st & ST_ZEROQ) st[1 * st_stride] += 1u;
+            if (m.st & ST_PROPER) st[2 * st_stride] += 1u;
+            if (m.st & ST_DUP) st[3 * st_stride] += 1u;
+            if (m.st & ST_ANY) st[4 * st_stride] += 1u;
+            if (m.st & ST_OVL) st[5 * st_stride] += 1u;
             if (m.flags & RF_PILE) {
-                s.pile += 1u; s.m_pile += m.m_bases;
-                s.alg8d += 16u + 4u * m.n_cigar + (m.m_bases + 1u) / 2u + m.m_bases; s.alg_cigar += 4u * m.n_cigar;
-                if (m.st & ST_SHIPS) { s.alg_seq += m.a_seq; s.alg_qual += m.m_bases; }
+                s.pile += 1u; st[6 * st_stride] += m.m_bases;
+                st[7 * st_stride] += 16u + 4u * m.n_cigar + (m.m_bases + 1u) / 2u + m.m_bases; st[8 * st_stride] += 4u * m.n_cigar;
+                if (m.st & ST_SHIPS) { st[9 * st_stride] += m.a_seq; st[10 * st_stride] += m.m_bases; }
             }
             s.npiece += m.np; s.niv += m.niv; s.spill += m.spill; s.seqb += m.sb;
             if ((s.npiece | s.niv | s.spill | s.seqb) > 0xffffu || s.pile > 0xffu) s.flags |= 8u;      // (a SEQ-less read with a CIGAR of thousands of bases, sub-segments of many kilobytes: the careful route's)
@@ -947,12 +959,15 @@ __device__ __forceinline__ bool walk_sub2(const uint8_t *raw, unsigned long long
         ++n;
         off += 4ull + r.bs;
     }
+    s.st_unmapped = st[0]; s.st_zeroq = st[1 * st_stride]; s.st_proper = st[2 * st_stride]; s.st_dup = st[3 * st_stride]; s.st_any = st[4 * st_stride]; s.st_ovl = st[5 * st_stride];
+    s.m_pile = st[6 * st_stride]; s.alg8d = st[7 * st_stride]; s.alg_cigar = st[8 * st_stride]; s.alg_seq = st[9 * st_stride]; s.alg_qual = st[10 * st_stride];
     I = s; n_out = n; off_out = off;
     return !bad;
 }
 __global__ __launch_bounds__(256) void msnv_scan_sub2(const uint8_t *raw, const SubStream *ss, uint32_t n_streams, uint32_t n_sub, uint32_t sub_bytes, uint32_t cap, int n_contigs,
                                                       const DpContig *ctg, DpParams P, unsigned long long *first, unsigned long long *stop, uint32_t *cnt, uint16_t *delta, Slot *slots, SubInfo *info,
                                                       uint32_t *flags) {
+    __shared__ uint32_t s_stat[WALK_STATS * 256];
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_sub) return;
     const SubStream S = ss[sub_stream_of(ss, n_streams, g)];
@@ -985,7 +1000,7 @@ __global__ __launch_bounds__(256) void msnv_scan_sub2(const uint8_t *raw, const 
     bool ok = true;
     SubInfo I{};
     I.fp_slot = I.fm_slot = I.err = I.beyond_slot = 0xffffffffu;
-    if (f != ~0ull) ok = walk_sub2(raw, S.end, b, e, f, cap, ctg, P, delta + (size_t)g * cap, slots + (size_t)g * cap, I, n, off);
+    if (f != ~0ull) ok = walk_sub2(raw, S.end, b, e, f, cap, ctg, P, delta + (size_t)g * cap, slots + (size_t)g * cap, I, n, off, &s_stat[threadIdx.x], 256u);
     if ((!ok || n > cap) && g != S.sub0) { first[g] = ~0ull - 1ull; stop[g] = 0ull; cnt[g] = 0u; return; }      // a walk from a GUESSED entry that breaks: a wrong guess (msnv_scan_fix2 walks again from the true one)
     first[g] = f; stop[g] = f != ~0ull ? off : 0ull; cnt[g] = n;
     info[g] = I;
@@ -993,6 +1008,7 @@ __global__ __launch_bounds__(256) void msnv_scan_sub2(const uint8_t *raw, const 
 }
 __global__ void msnv_scan_fix2(const uint8_t *raw, const SubStream *ss, uint32_t n_streams, uint32_t sub_bytes, uint32_t cap, const DpContig *ctg, DpParams P, unsigned long long *first,
                                unsigned long long *stop, const unsigned long long *stop_max, uint32_t *cnt, uint16_t *delta, Slot *slots, SubInfo *info, uint32_t *first_bad, uint32_t *flags) {
+    __shared__ uint32_t s_stat[WALK_STATS * 64];
     const uint32_t si = blockIdx.x * blockDim.x + threadIdx.x;
     if (si >= n_streams) return;
     const uint32_t g = first_bad[si];
@@ -1007,7 +1023,7 @@ __global__ void msnv_scan_fix2(const uint8_t *raw, const SubStream *ss, uint32_t
     I.fp_slot = I.fm_slot = I.err = I.beyond_slot = 0xffffffffu;
     if (cur >= e) { first[g] = ~0ull; stop[g] = 0ull; cnt[g] = 0u; info[g] = I; return; }
     uint32_t n = 0; unsigned long long off = cur;
-    const bool ok = walk_sub2(raw, S.end, b, e, cur, cap, ctg, P, delta + (size_t)g * cap, slots + (size_t)g * cap, I, n, off);
+    const bool ok = walk_sub2(raw, S.end, b, e, cur, cap, ctg, P, delta + (size_t)g * cap, slots + (size_t)g * cap, I, n, off, &s_stat[threadIdx.x], 64u);
     if (!ok || n > cap) { atomicOr(flags, 4u); return; }
     first[g] = cur; stop[g] = off; cnt[g] = n; info[g] = I;
 }
@@ -2794,7 +2810,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     // learns late -- an error, a sample that needs the host pre-pass, more far-reaching reads than the list holds -- sends the round through
     // the CAREFUL route: round 5's stage-by-stage form (msnv_scan_sub / msnv_scan_segments, msnv_measure_reads, waits between the stages),
     // which also words malformed input and takes the host pre-pass's verdicts.  MSNV_SCAN=segments and MSNV_FRONT=careful force it (tests).
-    const uint32_t sub_bytes = [] { const char *e = getenv("MSNV_SCAN_SUB"); const long long v = e ? atoll(e) : 4096; return (uint32_t)std::min<long long>(32768, std::max<long long>(64, v)); }();   // (per call: tests shrink it)
+    const uint32_t sub_bytes = [] { const char *e = getenv("MSNV_SCAN_SUB"); const long long v = e ? atoll(e) : 6144; return (uint32_t)std::min<long long>(32768, std::max<long long>(64, v)); }();   // (per call: tests shrink it; 6 KB: 2.36 -> 2.04 ms of scan + measure on the benchmark shape against 4 KB -- fewer entry guesses --, 8 KB the same)
     const bool quick_wanted = [] { const char *e = getenv("MSNV_SCAN"); const char *f = getenv("MSNV_FRONT"); return !(e && e[0] == 's') && !(f && f[0] == 'c'); }();
     uint64_t n_sub64 = 0;
     std::vector<SubStream> ss(S);
