@@ -748,7 +748,7 @@ def main():
             total_ms = bl["pack_wall_ms"] + bl["finalize_wall_ms"] + k_ms
             pk = sum(bl["pack_kernel_ms"].values())
             line["roofline_from_records"] = {
-                "bound": "hbm", "kernel": "msnv_scan_sub + msnv_measure_reads + msnv_depth + msnv_emit_block (+ small scans), finalize (msnv_fin_*), then msnv_pileup_tiles_narrow32",
+                "bound": "hbm", "kernel": "msnv_scan_sub2 (record boundaries + per-record measure in one walk) + msnv_scan_write2 + msnv_depth2 + msnv_emit_block (+ small scans), finalize (msnv_fin_*), then msnv_pileup_tiles_narrow32",
                 "timed_region": "raw BAM records resident in HBM -> per-read stage (wall) -> finalize: tile index (wall) -> one pileup kernel launch",
                 "achieved": alg / (total_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "total_ms": total_ms, "pack_wall_ms": bl["pack_wall_ms"], "finalize_ms": bl["finalize_wall_ms"], "pileup_kernel_ms": k_ms,

@@ -303,12 +303,13 @@ typedef struct {
 
 int  msnv_dataset_info_get(const msnv_dataset *ds, msnv_dataset_info *out);
 /* Cost of the per-read stage on the device for this dataset so far (csrc/devpack.hip), cumulative over its rounds:
- * out[0..4] kernel ms (HIP events on the context's stream) of record scan, per-record measure, depth, emit (headers + bases + flags),
- * tile-order sort; [5..7] wall seconds of uploading host streams, downloading headers / intervals, the host pre-pass (depth cap,
+ * out[0..4] kernel ms (HIP events on the context's stream) of record scan (the quick route, round 6: record boundaries AND the per-record measure,
+ * one walk), per-record measure (careful route only), depth, emit (headers + bases + flags), tile-order sort; [5..7] wall seconds of uploading host streams, downloading headers / intervals, the host pre-pass (depth cap,
  * overlapping mates, token limit); [8] record bytes resident in HBM, [9] records, [10] pieces, [11] samples that took the pre-pass,
  * [12] scan segments whose guessed entry point was wrong and that were walked again, [13] deep (sample, tile) runs dealt into groups by
- * the device form of finalize, [14] samples whose dense block streams (short reads) were laid out by it. */
-#define MSNV_PACK_STATS 15
+ * the device form of finalize, [14] samples whose dense block streams (short reads) were laid out by it, [15] rounds the quick route had
+ * launched and the careful route took over (a sample that needs the host pre-pass, more far-reaching reads than the list holds). */
+#define MSNV_PACK_STATS 16
 int  msnv_dataset_pack_stats(const msnv_dataset *ds, double *out, int32_t n);
 /* Inspection hook: the bytes of one device column / index table of a finalized dataset ("hdr", "hdr4", "hdr8m", "blk", "seq", "qual",
  * "s_read_base", "s_seq_base", "ref4", "pairs", "work", "chunks", "cov_iv", "cov_pairs", "cov_work").  out = NULL: size query.  The tests

@@ -150,7 +150,7 @@ struct DevPackTables {
     // a round whose last kernels (msnv_emit_block: bases and headers out) may still be running when devpack_add_round returns: what is left
     // to read of it -- the mismatch sample of its samples, the kernels' time -- is taken by devpack_sync_pending, which everything that
     // needs the round finished calls first (the next round, finalize before it decides the allele bookkeeping, the statistics, release)
-    struct Pending { bool active = false; size_t first = 0, n = 0; void *ev0 = nullptr, *ev1 = nullptr, *evh = nullptr, *evd = nullptr; bool has_evd = false; } pending;      // evh: behind the small results the host takes while the emit kernels run
+    struct Pending { bool active = false; size_t first = 0, n = 0; void *ev0 = nullptr, *ev1 = nullptr, *evh = nullptr, *evd = nullptr, *evd2 = nullptr, *evw = nullptr; bool has_evd = false; } pending;      // evd / evd2: around the depth stage on the second stream; evw: the records' tables are written      // evh: behind the small results the host takes while the emit kernels run
     bool      any_overhang_h = false; // some read of some round runs past its contig (msnv_measure_reads): finalize fetches `overhang`
     void     *cov_event = nullptr;   // recorded behind those kernels: what devfin_coverage waits for
     void     *cov_job = nullptr, *cov_tmp = nullptr, *cov_runs = nullptr; bool cov_launched = false;   // finalize: the coverage index's kernels launched ahead of their results (devfin_coverage_launch)
@@ -185,6 +185,7 @@ struct SiteRowView {
 struct msnv_ctx {
     int device = 0;
     void *stream = nullptr;   // hipStream_t
+    void *stream2 = nullptr;  // a second stream of the context, created when first needed: the depth stage of a device-pack round beside its emit kernels (devpack.hip)
     // device BGZF inflate (inflate_k.hip): pinned host staging and device buffers, grown on demand and kept for the life of the context
     // (pinning memory costs ~0.25 s per GB: paid once, not per batch of BAMs)
     void *pin_in = nullptr, *pin_out = nullptr, *dev_in = nullptr, *dev_out = nullptr;

@@ -519,7 +519,10 @@ __device__ __forceinline__ RecMeasure measure_one(const Rec &r, const DpContig *
         if (cg_query(t)) qlen += l;
         if (t == C_I) ins += l; else if (t == C_D) del = del > (long long)l ? del : (long long)l;
         if (k >= k0) {                                                                     // qaCompute.cpp:537-552
-            if (t == C_M) { if (pp >= c.len) { beyond = true; n_iv += c.len >= 1; } else ++n_iv; }
+            // (round 6: only the intervals the coverage index KEEPS are counted and written -- qaCompute.cpp:544-549 clips an M block's end to L - 1,
+            // so a block that starts at L - 1, or an empty one, adds and takes away at the same position: finalize used to filter those in a
+            // pass of its own over all intervals, msnv_fin_cov_measure + a scan)
+            if (t == C_M) { if (pp >= c.len) { beyond = true; n_iv += c.len >= 1; } else if (pp < c.len - 1 && l > 0u) ++n_iv; }
             pp += l;
         }
         if (cg_match(t)) {
@@ -1069,6 +1072,7 @@ struct RdTables {
     uint4 *rd;                     // {position, end, contig, sample | outlier << 12 | longest pileup element << 13}
     RecCnt *r_pre;                 // places BEFORE the record (entry n_rec: the round's totals)
     uint32_t *r_ftile; uint8_t *r_flags; unsigned long long *r_rg;      // r_flags: RF_* | RF_RUN | RF_GRP; r_rg: run << 32 | group of a pileup read (1-based)
+    uint32_t *run_first, *grp_first;                                    // (msnv_scan_write2 only; may be NULL) first record of every run / group
 };
 enum : uint8_t { RF_RUN = 16, RF_GRP = 32 };
 __global__ __launch_bounds__(256) void msnv_scan_write2(const SubStream *ss, uint32_t n_streams, uint32_t n_sub, uint32_t sub_bytes, uint32_t cap, const uint32_t *cnt, const SubCnt *base,
@@ -1186,6 +1190,8 @@ __global__ __launch_bounds__(256) void msnv_scan_write2(const SubStream *ss, uin
                 // inclusive numbers: the starts before the sub-segment, its first pileup read's (settled at the boundary), the inner ones up to here
                 const uint32_t run_no = p_runs + (bft & 1u) + ((q.b.w >> 8) & 0xffu), grp_no = p_grps + ((bft >> 1) & 1u) + ((q.b.w >> 16) & 0xffu);
                 T.r_rg[j] = (unsigned long long)run_no << 32 | grp_no;
+                if (run_s && T.run_first) T.run_first[run_no - 1u] = j;
+                if (grp_s && T.grp_first) T.grp_first[grp_no - 1u] = j;
             }
             T.rd[j] = make_uint4(q.a.x, q.a.y, q.a.z, (st & 0xfffu) | outl << 12 | mc << 13);
             RecCnt pre;
@@ -1201,7 +1207,7 @@ __global__ __launch_bounds__(256) void msnv_scan_write2(const SubStream *ss, uin
 // ---- the careful route's records in the same tables (msnv_measure_reads has measured them one thread a record, the blocks' sums are scanned):
 // places before every record, the rd rows, run / group starts against the pileup read before (flags; their scan numbers them)
 __global__ __launch_bounds__(256) void msnv_tables_from_measure(uint32_t n_rec, const uint16_t *rec_sample, const uint8_t *r_flags_in, const unsigned long long *r_key, const uint32_t *r_end, const uint32_t *r_maxc,
-                                                                const RecCnt *r_cnt, const RecCnt *blk_pre, const uint32_t *r_ftile, uint32_t span_out, DpParams P, RdTables T, unsigned long long *start_flags, DpAcc *acc) {
+                                                                const RecCnt *r_cnt, const RecCnt *blk_pre, const uint32_t *r_ftile, uint32_t span_out, DpParams P, RdTables T, unsigned long long *start_flags, DpAcc *acc, uint32_t *misc) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
     const bool valid = i < n_rec;
     const RecCnt mine = valid ? r_cnt[i] : RecCnt{};
@@ -1225,6 +1231,7 @@ __global__ __launch_bounds__(256) void msnv_tables_from_measure(uint32_t n_rec, 
             const bool run = !have_prev || ps != s || (uint32_t)(pk >> 32) != (uint32_t)(key >> 32), grp = run || pf != ft;
             if (run) fl |= RF_RUN;
             if (grp) fl |= RF_GRP;
+            if (!run && pf > ft) atomicOr(&misc[MISC_SORT], 1u);                         // (a read whose first aligned base lies in an earlier tile than its predecessor's: leading deletions)
             sf = (unsigned long long)(run ? 1u : 0u) << 32 | (grp ? 1u : 0u);
             const uint32_t span = r_end[i] - ((uint32_t)key & 0x7fffffffu);
             outl = span > span_out ? 1u : 0u;
@@ -1240,7 +1247,7 @@ __global__ __launch_bounds__(256) void msnv_tables_from_measure(uint32_t n_rec, 
 // records' tables).  A record that is no pileup read is stepped over by its neighbours' walks; everything else is msnv_depth's.
 __global__ __launch_bounds__(256) void msnv_depth2(uint32_t n_rec, const uint4 *rd, const uint8_t *r_flags, const unsigned long long *r_rg, const RecCnt *r_pre, const uint32_t *r_ftile,
                                                    const uint32_t *ovr, DpParams P, const uint32_t *misc_span, const uint32_t *outliers, const uint32_t *misc_nout,
-                                                   uint16_t *r_depth, uint32_t *run_first, uint32_t *run_f1, uint32_t *grp_first, uint32_t *grp_md, DpAcc *acc) {
+                                                   uint16_t *pdepth, const uint2 *grp_pre, uint32_t in_order, uint32_t *run_first, uint32_t *run_f1, uint32_t *grp_first, uint32_t *grp_md, DpAcc *acc) {
     __shared__ uint4 s_rd[DEPTH_BACK + 256];
     __shared__ uint8_t s_fl[DEPTH_BACK + 256];
     const uint32_t blk0 = blockIdx.x * blockDim.x, i = blk0 + threadIdx.x;
@@ -1292,18 +1299,31 @@ __global__ __launch_bounds__(256) void msnv_depth2(uint32_t n_rec, const uint4 *
         // first read of the run whose end lies beyond position 1 (the first line under metaSNV's `name 1 LEN` split): a read that starts at
         // position >= 1 always qualifies, so only the reads at position 0 and the first one behind them can be it -- a handful of atomics per run
         if (me4.y > 1u && (run_start || p == 0u || (seen_prev && prev_x == 0u))) atomicMin(&run_f1[g], i);
-        spill = r_pre[i + 1u].spill - r_pre[i].spill;
+        const RecCnt pa = r_pre[i], pb = r_pre[i + 1u];
+        spill = pb.spill - pa.spill;
         const uint32_t ov = ovr ? ovr[i] : 0u;
-        if (ov & 1u) { depth = ov >> 16; r_depth[i] = (uint16_t)depth; }
+        if (ov & 1u) depth = ov >> 16;
         else {
-            r_depth[i] = (uint16_t)(depth < 0xffffu ? depth : 0xffffu);
             uint32_t need = 0;
             if (P.max_depth > 0 && depth - 1u > (uint32_t)P.max_depth) need |= NEED_CAP;         // live.size() > max_depth before the push
             if (P.token_limit > 0 && chars >= (unsigned long long)P.token_limit) need |= NEED_TOKEN;
             if (need) atomicOr(&acc[(size_t)my_sample * ACC_COPIES].need_host, need);
             depth = depth < 0xffffu ? depth : 0xffffu;
         }
-    } else if (i < n_rec) r_depth[i] = 0;
+        // the depth of every piece of this read, at the piece's header slot (round 6: the emit kernels do not wait for this kernel any more --
+        // the places are the ones msnv_emit_block computes: file order, or the group's own-tile / next-tile stretches of the tile order)
+        const uint32_t np = pb.npiece - pa.npiece;
+        if (np) {
+            const uint16_t dv = (uint16_t)depth;
+            if (in_order) for (uint32_t k = 0; k < np; ++k) pdepth[pa.npiece + k] = dv;
+            else {
+                const uint2 pf = grp_pre[gi], pe = grp_pre[gi + 1u];
+                const uint32_t d_own = pa.npiece - (pa.spill - pf.y), d_next = pe.x - pe.y + pa.spill;
+                for (uint32_t k = 0; k < np - spill; ++k) pdepth[d_own + k] = dv;
+                for (uint32_t k = 0; k < spill; ++k) pdepth[d_next + k] = dv;
+            }
+        }
+    }
     // depth bounds per group: [2 gi] over all its reads (every read has a piece in its first tile), [2 gi + 1] over the reads that leave
     // pieces in the tile behind.  A wavefront's reads nearly always share one group: one atomic per wavefront and bound then.
     uint32_t g_any = gi;
@@ -1327,12 +1347,25 @@ __global__ void msnv_run_table2(uint32_t n_runs, const uint32_t *run_first, cons
     else { const int32_t q = (int32_t)rd[f].x; o.first_from1 = q > 1 ? q : 1; }
     runs[g] = o;
 }
+__global__ void msnv_group_firsts(uint32_t n_rec, const uint8_t *r_flags, const unsigned long long *r_rg, uint32_t *run_first, uint32_t *grp_first) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rec || !(r_flags[i] & RF_PILE)) return;
+    const unsigned long long me = r_rg[i];
+    if (r_flags[i] & RF_RUN) run_first[(uint32_t)(me >> 32) - 1u] = i;
+    if (r_flags[i] & RF_GRP) grp_first[(uint32_t)me - 1u] = i;
+}
+__global__ void msnv_group_pre2(uint32_t n_groups, uint32_t n_rec, const uint32_t *grp_first, const RecCnt *r_pre, uint2 *grp_pre) {
+    const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi > n_groups) return;
+    const RecCnt pf = r_pre[gi < n_groups ? grp_first[gi] : n_rec];
+    grp_pre[gi] = make_uint2(pf.npiece, pf.spill);
+}
 __global__ void msnv_group_table2(uint32_t n_groups, uint32_t n_rec, const uint32_t *grp_first, const RecCnt *r_pre, const uint4 *rd, const uint32_t *r_ftile, const uint32_t *grp_md, uint2 *grp_pre, DevGroupRec *out) {
     const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
     if (gi > n_groups) return;
     const uint32_t f = gi < n_groups ? grp_first[gi] : n_rec;
     const RecCnt pf = r_pre[f];
-    grp_pre[gi] = make_uint2(pf.npiece, pf.spill);
+    if (grp_pre) grp_pre[gi] = make_uint2(pf.npiece, pf.spill);      // (NULL: msnv_group_pre2 has written them)
     if (gi == n_groups) return;
     const uint32_t e = gi + 1u < n_groups ? grp_first[gi + 1u] : n_rec;
     const RecCnt pe = r_pre[e];
@@ -1628,9 +1661,9 @@ __device__ __forceinline__ void piece_lane(const Src &src, unsigned long long se
     bits = have < 32u ? ((bits & (0xffffffffu << have)) | (low & ((1u << have) - 1u))) : low;
 }
 struct EmitArgs {
-    const uint8_t *raw; const unsigned long long *rec_off; const uint16_t *rec_sample; uint32_t n_rec; const DpContig *ctg; const uint8_t *r_flags; const uint16_t *r_depth;
+    const uint8_t *raw; const unsigned long long *rec_off; const uint16_t *rec_sample; uint32_t n_rec; const DpContig *ctg; const uint8_t *r_flags;
     const RecCnt *r_pre; const unsigned long long *samp_sbase0, *rg; const uint2 *grp_pre; uint32_t in_order;      // r_pre: places before every record (entry n_rec: totals); rg: run << 32 | group of a pileup RECORD
-    ReadHdr *hdr; int32_t *ptid, *pend; uint16_t *pdepth; int32_t *cov_tid, *cov_beg, *cov_end; uint32_t noseq_counts;
+    ReadHdr *hdr; int32_t *ptid, *pend; int32_t *cov_tid, *cov_beg, *cov_end; uint32_t noseq_counts;
     const uint32_t *pref4; DpParams P; const DpSampleDst *dst; DpAcc *acc;
     uint32_t force_slow;                                           // MSNV_EMIT=slow (tests): every block takes msnv_emit_block_slow
     uint32_t *slow;                                                // [0] number of listed blocks, [1 ..] the blocks msnv_emit_block left to msnv_emit_block_slow
@@ -1715,7 +1748,7 @@ __device__ __forceinline__ void emit_record(const EmitArgs &A, const Src &src, c
         if (cov && k >= k0) {
             if (t == C_M) {
                 if (pp >= L) { if (L >= 1) { A.cov_tid[wiv] = tid; A.cov_beg[wiv] = (int32_t)L; A.cov_end[wiv] = (int32_t)(L - 1); ++wiv; } }
-                else { A.cov_tid[wiv] = tid; A.cov_beg[wiv] = (int32_t)pp; A.cov_end[wiv] = (int32_t)(pp + l); ++wiv; }
+                else if (pp < L - 1 && l > 0u) { A.cov_tid[wiv] = tid; A.cov_beg[wiv] = (int32_t)pp; A.cov_end[wiv] = (int32_t)(pp + l); ++wiv; }      // (the kept ones only: msnv_measure_reads / measure_one counts the same)
             }
             pp += l;
         }
@@ -1732,7 +1765,7 @@ __device__ __forceinline__ void emit_record(const EmitArgs &A, const Src &src, c
                 if (sub == 0) {
                     ReadHdr h;
                     h.gpos = g; h.seqoff = so; h.cig = n; h.meta = META_PILEUP_OK | mapq << 16;
-                    A.hdr[dst] = h; A.ptid[dst] = tid; A.pend[dst] = (int32_t)(g + n); A.pdepth[dst] = depth;
+                    A.hdr[dst] = h; A.ptid[dst] = tid; A.pend[dst] = (int32_t)(g + n);
                 }
                 // ---- this lane's 32 bases of the piece
                 unsigned long long ref_nib; uint32_t ref_left;
@@ -1811,7 +1844,7 @@ __device__ __forceinline__ void emit_walk(const EmitArgs &A, const LdsSrcK &src,
         if (cov && k >= k0) {                                                                 // qaCompute.cpp:530-552
             if (t == C_M) {
                 if (pp >= L) { if (L >= 1) { A.cov_tid[wiv] = tid; A.cov_beg[wiv] = (int32_t)L; A.cov_end[wiv] = (int32_t)(L - 1); ++wiv; } }
-                else { A.cov_tid[wiv] = tid; A.cov_beg[wiv] = (int32_t)pp; A.cov_end[wiv] = (int32_t)(pp + l); ++wiv; }
+                else if (pp < L - 1 && l > 0u) { A.cov_tid[wiv] = tid; A.cov_beg[wiv] = (int32_t)pp; A.cov_end[wiv] = (int32_t)(pp + l); ++wiv; }      // (the kept ones only: msnv_measure_reads / measure_one counts the same)
             }
             pp += l;
         }
@@ -1827,7 +1860,7 @@ __device__ __forceinline__ void emit_walk(const EmitArgs &A, const LdsSrcK &src,
                 const uint32_t dst = A.in_order ? w : (tl == ftile ? d_own++ : d_next++);
                 ReadHdr h;
                 h.gpos = g; h.seqoff = so; h.cig = n; h.meta = META_PILEUP_OK | mapq << 16;
-                A.hdr[dst] = h; A.ptid[dst] = tid; A.pend[dst] = (int32_t)(g + n); A.pdepth[dst] = depth;
+                A.hdr[dst] = h; A.ptid[dst] = tid; A.pend[dst] = (int32_t)(g + n);      // (the piece's depth: msnv_depth2)
                 PieceDesc D;
                 D.seq_o = (uint32_t)seq_o; D.qual_o = (uint32_t)qual_o; D.q0 = noseq ? 0xffffffffu : q + off; D.so = so;
                 unsigned long long ref_nib; uint32_t ref_left;
@@ -1863,7 +1896,7 @@ __global__ __launch_bounds__(256) void msnv_emit_block(const EmitArgs A) {
     // ---- the first wavefront's lanes: what their record needs of the per-record columns (asked for together with the window)
     const uint32_t i = i0 + (tid < nrec ? tid : 0u);
     uint8_t f = 0; uint16_t depth = 0; unsigned long long ro = 0; RecCnt pre{}; uint32_t my_pieces = 0;
-    if (tid < PB) { f = A.r_flags[i]; depth = A.r_depth[i]; ro = A.rec_off[i]; pre = A.r_pre[i]; if (tid < nrec) my_pieces = A.r_pre[i + 1u].npiece - pre.npiece; }
+    if (tid < PB) { f = A.r_flags[i]; ro = A.rec_off[i]; pre = A.r_pre[i]; if (tid < nrec) my_pieces = A.r_pre[i + 1u].npiece - pre.npiece; }
     // ---- the block's bytes into LDS
     if (!direct) {
         const uint32_t n16 = (uint32_t)((hi - lo + 15) >> 4);
@@ -1989,7 +2022,7 @@ __global__ __launch_bounds__(256) void msnv_emit_block_slow(const EmitArgs A) {
         const uint32_t b = A.slow[1u + li], i0 = b * PB;
         const uint32_t nrec = A.n_rec - i0 < PB ? A.n_rec - i0 : PB;
         const uint32_t r = tid >> 2, sub = tid & 3u, i = i0 + (r < nrec ? r : 0u);
-        const uint8_t f = A.r_flags[i]; const uint32_t smp = A.rec_sample[i]; const uint16_t depth = A.r_depth[i]; const unsigned long long ro = A.rec_off[i];
+        const uint8_t f = A.r_flags[i]; const uint32_t smp = A.rec_sample[i]; const uint16_t depth = 0; const unsigned long long ro = A.rec_off[i];
         __syncthreads();                                            // (the list's previous block has read s_pre)
         if (tid < 64) s_pre[tid] = A.r_pre[i0 + (tid < nrec ? tid : 0u)];
         __syncthreads();
@@ -2234,7 +2267,7 @@ int devpack_sync_pending(msnv_dataset &ds) {
     HIP_TRY(hipEventSynchronize((hipEvent_t)T.pending.ev1));
     float ms = 0;
     if (hipEventElapsedTime(&ms, (hipEvent_t)T.pending.ev0, (hipEvent_t)T.pending.ev1) == hipSuccess) T.ms_emit += ms;
-    if (T.pending.has_evd) { T.pending.has_evd = false; if (hipEventElapsedTime(&ms, (hipEvent_t)T.pending.evd, (hipEvent_t)T.pending.ev0) == hipSuccess) T.ms_depth += ms; }      // (the quick route's depth stage: never waited for by itself)
+    if (T.pending.has_evd) { T.pending.has_evd = false; if (hipEventElapsedTime(&ms, (hipEvent_t)T.pending.evd, (hipEvent_t)T.pending.evd2) == hipSuccess) T.ms_depth += ms; }      // (the quick route's depth stage, on the second stream beside the emit kernels)
     const DpAcc *a = static_cast<const DpAcc *>(T.pin);
     for (size_t s = 0; s < T.pending.n && T.pending.first + s < ds.samples.size(); ++s) {
         SampleCols &sc = ds.samples[T.pending.first + s];
@@ -2253,7 +2286,8 @@ void devpack_release(msnv_dataset &ds) {
     if (t.pending.active) { (void)hipDeviceSynchronize(); t.pending.active = false; }
     if (t.pending.ev0) {
         (void)hipEventDestroy((hipEvent_t)t.pending.ev0); (void)hipEventDestroy((hipEvent_t)t.pending.ev1); (void)hipEventDestroy((hipEvent_t)t.pending.evh); (void)hipEventDestroy((hipEvent_t)t.pending.evd);
-        t.pending.ev0 = t.pending.ev1 = t.pending.evh = t.pending.evd = nullptr;
+        (void)hipEventDestroy((hipEvent_t)t.pending.evd2); (void)hipEventDestroy((hipEvent_t)t.pending.evw);
+        t.pending.ev0 = t.pending.ev1 = t.pending.evh = t.pending.evd = t.pending.evd2 = t.pending.evw = nullptr;
     }
     if (t.cov_event) { (void)hipEventDestroy((hipEvent_t)t.cov_event); t.cov_event = nullptr; }
     if (t.cov_job || !t.fin_keep.empty()) (void)hipDeviceSynchronize();
@@ -2834,9 +2868,9 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
     DpSampleDst *d_dst = nullptr;
 
     if (!T.pending.ev0) {
-        hipEvent_t a = nullptr, b = nullptr, c = nullptr, d = nullptr;
-        HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b)); HIP_TRY(hipEventCreate(&c)); HIP_TRY(hipEventCreate(&d));
-        T.pending.ev0 = a; T.pending.ev1 = b; T.pending.evh = c; T.pending.evd = d;
+        hipEvent_t a = nullptr, b = nullptr, c = nullptr, d = nullptr, e = nullptr, f = nullptr;
+        HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b)); HIP_TRY(hipEventCreate(&c)); HIP_TRY(hipEventCreate(&d)); HIP_TRY(hipEventCreate(&e)); HIP_TRY(hipEventCreate(&f));
+        T.pending.ev0 = a; T.pending.ev1 = b; T.pending.evh = c; T.pending.evd = d; T.pending.evd2 = e; T.pending.evw = f;
     }
     for (;;) {
         pool.next = pool_staged;
@@ -2883,22 +2917,77 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
         uint32_t misc_h[MISC_WORDS] = {0, 0, 0, 0};
         RdTables TB{};
         uint32_t *d_recbase = nullptr; unsigned long long *d_send = nullptr;
-        uint16_t *d_depth = nullptr; uint32_t *d_ovr = nullptr;
+        uint32_t *d_ovr = nullptr;
         bool have_ovr = false;
+        DpSampleSum2 *d_sum = nullptr; unsigned long long *d_ss0 = nullptr, *d_pb = nullptr; uint32_t *d_slow = nullptr;
+        uint64_t seq_bound = 0, qual_bound = 0;
+        struct Held {                                                // the round's lasting buffers, this function's until the round is known to stand
+            void *round_buf = nullptr, *keep_buf = nullptr;
+            void drop() { if (round_buf) dev_free(round_buf); if (keep_buf) dev_free(keep_buf); round_buf = keep_buf = nullptr; }
+            ~Held() { drop(); }
+        } held;
         DevBuf o_flag, o_rank, o_skip, o_keys, o_skeys, o_vals, o_svals, o_starts;      // overlapping mates (paired reads only: not from the pool)
         uint32_t n_ovl_reads = 0, n_ovl_groups = 0;
         uint32_t *d_runfirst = nullptr, *d_runf1 = nullptr, *d_grpfirst = nullptr, *d_grpmd = nullptr; DpRun *d_runs = nullptr; uint2 *d_grppre = nullptr; DevGroupRec *d_groups = nullptr;
         std::fill(host_sample.begin(), host_sample.end(), 0); std::fill(cut_marks.begin(), cut_marks.end(), 0);
 
         // depth at every read start, the run and group tables: launched, not waited for
-        auto launch_depth_stage = [&]() -> int {
-            HIP_TRY(hipMemsetAsync(d_runf1, 0xff, ((uint64_t)n_runs + 1) * 4, st));
-            HIP_TRY(hipMemsetAsync(d_grpmd, 0, 2 * ((uint64_t)n_groups + 1) * 4, st));
-            if (NR) hipLaunchKernelGGL(msnv_depth2, grid_for(NR, 256), dim3(256), 0, st, NR, TB.rd, TB.r_flags, TB.r_rg, TB.r_pre, TB.r_ftile, have_ovr ? d_ovr : nullptr, P, d_misc + MISC_SPAN, d_outl,
-                                       d_misc + MISC_NOUT, d_depth, d_runfirst, d_runf1, d_grpfirst, d_grpmd, d_acc);
-            if (n_runs) hipLaunchKernelGGL(msnv_run_table2, grid_for(n_runs, 256), dim3(256), 0, st, n_runs, d_runfirst, d_runf1, TB.rd, d_runs);
-            hipLaunchKernelGGL(msnv_group_table2, grid_for((uint64_t)n_groups + 1, 256), dim3(256), 0, st, n_groups, NR, d_grpfirst, TB.r_pre, TB.rd, TB.r_ftile, d_grpmd, d_grppre, d_groups);
-            hipLaunchKernelGGL(msnv_acc_fold, dim3((unsigned)S), dim3(64), 0, st, d_acc, (uint32_t)S);
+        // The round's lasting buffers and the layout's small tables, once the round's totals are known (NPC, NIV, seqb_total, in_order).  The
+        // round's columns: per sample its pieces + 32 tail bytes, starting on 16 bytes, and one flag bit per nibble of them; the samples' shares
+        // are laid out on the device (msnv_sample_layout), the buffer is sized by the round's seq bytes + the most the tails and the rounding add.
+        auto alloc_round_buffers = [&]() -> int {
+            held.drop();
+            seq_bound = (seqb_total + (uint64_t)S * 48ull + 15ull) & ~15ull; qual_bound = seq_bound / 4;
+            const uint64_t NPCa = (uint64_t)NPC + 1, NB_ = ((uint64_t)NR + PB - 1) / PB;
+            if (int rc = dev_alloc(&held.round_buf, seq_bound + COL_PAD + qual_bound + 64, nullptr)) return rc;
+            r_seq = static_cast<uint8_t *>(held.round_buf); r_qual = r_seq + seq_bound + COL_PAD;
+            {
+                const uint64_t lo = seqb_total & ~15ull;              // (from the lowest place the columns can end to the flags: N -- the exact end is the device's)
+                HIP_TRY(hipMemsetAsync(r_seq + lo, 0xff, seq_bound + COL_PAD - lo, st));
+                HIP_TRY(hipMemsetAsync(r_qual, 0, qual_bound + 64, st));
+            }
+            keep = DevRound{};
+            {   // what stays in HBM of the round besides the columns: headers (tile order) and intervals, for finalize -- written where they stay
+                const uint64_t b_hdr = (uint64_t)NPC * sizeof(ReadHdr), b_4 = (((uint64_t)NPC * 4) + 15) & ~15ull, b_2 = (((uint64_t)NPC * 2) + 15) & ~15ull, b_iv = (((uint64_t)NIV * 4) + 15) & ~15ull;
+                if (int rc = dev_alloc(&held.keep_buf, b_hdr + 2 * b_4 + b_2 + 3 * b_iv + 64, nullptr)) return rc;
+                uint8_t *q = static_cast<uint8_t *>(held.keep_buf);
+                keep.buf = held.keep_buf;
+                keep.hdr = reinterpret_cast<ReadHdr *>(q); q += b_hdr;
+                keep.tid = reinterpret_cast<int32_t *>(q); q += b_4;
+                keep.end = reinterpret_cast<int32_t *>(q); q += b_4;
+                keep.depth = reinterpret_cast<uint16_t *>(q); q += b_2;
+                keep.cov_tid = reinterpret_cast<int32_t *>(q); q += b_iv;
+                keep.cov_beg = reinterpret_cast<int32_t *>(q); q += b_iv;
+                keep.cov_end = reinterpret_cast<int32_t *>(q);
+                keep.n_pieces = NPC; keep.n_iv = NIV; keep.first_sample = first;
+                keep.col_buf = held.round_buf; keep.col_seq = r_seq; keep.col_qual = r_qual; keep.seq_total = 0; keep.n_samples = S;
+            }
+            DP_BUF(DpSampleSum2, d_sum_, S + 1);
+            DP_BUF(unsigned long long, d_ss0_, S + 1);
+            DP_BUF(DpSampleDst, d_dst_, S);
+            DP_BUF(unsigned long long, d_pb_, S);
+            DP_BUF(uint32_t, d_slow_, NB_ + 2);
+            d_sum = d_sum_; d_ss0 = d_ss0_; d_dst = d_dst_; d_pb = d_pb_; d_slow = d_slow_;
+            // (the general route keeps the headers in file order first: work buffers, sorted into `keep` below)
+            w_hdr = keep.hdr; w_tid = keep.tid; w_end = keep.end; w_depth = keep.depth;
+            if (in_order) {
+                DP_BUF(ReadHdr, d_hdr, NPCa);
+                DP_BUF(int32_t, d_ptid, NPCa);
+                DP_BUF(int32_t, d_pend, NPCa);
+                DP_BUF(uint16_t, d_pdepth, NPCa);
+                w_hdr = d_hdr; w_tid = d_ptid; w_end = d_pend; w_depth = d_pdepth;
+            }
+            return MSNV_OK;
+        };
+        // depth at every read start (written to the pieces' header slots), the run and group tables: launched on `sx`, not waited for.  Needs
+        // the groups' places (msnv_group_pre2) and the round's buffers.
+        auto launch_depth_stage = [&](hipStream_t sx) -> int {
+            HIP_TRY(hipMemsetAsync(d_runf1, 0xff, ((uint64_t)n_runs + 1) * 4, sx));
+            HIP_TRY(hipMemsetAsync(d_grpmd, 0, 2 * ((uint64_t)n_groups + 1) * 4, sx));
+            if (NR) hipLaunchKernelGGL(msnv_depth2, grid_for(NR, 256), dim3(256), 0, sx, NR, TB.rd, TB.r_flags, TB.r_rg, TB.r_pre, TB.r_ftile, have_ovr ? d_ovr : nullptr, P, d_misc + MISC_SPAN, d_outl,
+                                       d_misc + MISC_NOUT, w_depth, d_grppre, in_order ? 1u : 0u, d_runfirst, d_runf1, d_grpfirst, d_grpmd, d_acc);
+            if (n_runs) hipLaunchKernelGGL(msnv_run_table2, grid_for(n_runs, 256), dim3(256), 0, sx, n_runs, d_runfirst, d_runf1, TB.rd, d_runs);
+            hipLaunchKernelGGL(msnv_group_table2, grid_for((uint64_t)n_groups + 1, 256), dim3(256), 0, sx, n_groups, NR, d_grpfirst, TB.r_pre, TB.rd, TB.r_ftile, d_grpmd, (uint2 *)nullptr, d_groups);
             HIP_TRY(hipGetLastError());
             return MSNV_OK;
         };
@@ -2980,10 +3069,16 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
             DP_BUF(uint32_t, d_ftile, NRa);
             DP_BUF(uint8_t, d_flags, NRa);
             DP_BUF(unsigned long long, d_rg, NRa);
-            DP_BUF(uint16_t, d_depth_, NRa);
-            d_depth = d_depth_;
-            TB = RdTables{d_recoff, d_recsample, d_recbase, d_rd, d_pre, d_ftile, d_flags, d_rg};
-            HIP_TRY(hipEventRecord((hipEvent_t)T.pending.evd, st)); T.pending.has_evd = true;
+            DP_BUF(uint32_t, q_runfirst, (uint64_t)n_runs + 1);
+            DP_BUF(uint32_t, q_runf1, (uint64_t)n_runs + 1);
+            DP_BUF(DpRun, q_runs, (uint64_t)n_runs + 1);
+            DP_BUF(uint32_t, q_grpfirst, (uint64_t)n_groups + 2);
+            DP_BUF(uint32_t, q_grpmd, 2 * ((uint64_t)n_groups + 1));
+            DP_BUF(uint2, q_grppre, (uint64_t)n_groups + 2);
+            DP_BUF(DevGroupRec, q_groups, (uint64_t)n_groups + 1);
+            d_runfirst = q_runfirst; d_runf1 = q_runf1; d_runs = q_runs; d_grpfirst = q_grpfirst; d_grpmd = q_grpmd; d_grppre = q_grppre; d_groups = q_groups;
+            if (int rc = alloc_round_buffers()) return rc;
+            TB = RdTables{d_recoff, d_recsample, d_recbase, d_rd, d_pre, d_ftile, d_flags, d_rg, d_runfirst, d_grpfirst};
             if (n_sub) hipLaunchKernelGGL(msnv_scan_write2, grid_for(n_sub, 256), dim3(256), 0, st, d_ss, (uint32_t)S, n_sub, sub_bytes, cap2, d_cnt, d_subbase, d_bflag, d_delta, d_slots, d_info, TB, d_acc, d_misc,
                                           d_outl, span_out, T.overhang, P);
             HIP_TRY(hipGetLastError());
@@ -2991,6 +3086,19 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
             HIP_TRY(hipMemcpyAsync(d_pre + NR, &totals_h, sizeof(RecCnt), hipMemcpyHostToDevice, st));
             HIP_TRY(hipMemcpyAsync(d_recoff + NR, &end_all, 8, hipMemcpyHostToDevice, st));
             HIP_TRY(hipMemcpyAsync(d_recbase + S, &NR, 4, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(msnv_group_pre2, grid_for((uint64_t)n_groups + 1, 256), dim3(256), 0, st, n_groups, NR, d_grpfirst, TB.r_pre, d_grppre);
+            hipLaunchKernelGGL(msnv_acc_fold, dim3((unsigned)S), dim3(64), 0, st, d_acc, (uint32_t)S);
+            HIP_TRY(hipGetLastError());
+            // ---- the depth stage on the context's SECOND stream, beside the layout and the emit kernels on the first (round 6: msnv_depth2
+            // writes the pieces' depths itself, so nothing the emit kernels read comes from it); what the host needs of it goes to the pinned
+            // words behind it, with an event (evd2)
+            if (!ds.ctx->stream2) { if (int rc = dev_stream_create(&ds.ctx->stream2)) return rc; }
+            static const bool depth_on_main = [] { const char *e = getenv("MSNV_DEPTH_STREAM"); return e && e[0] == 'm'; }();      // (A/B: the depth stage in front of the emit kernels, on their stream)
+            hipStream_t st2 = depth_on_main ? st : (hipStream_t)ds.ctx->stream2;
+            HIP_TRY(hipEventRecord((hipEvent_t)T.pending.evw, st));
+            HIP_TRY(hipStreamWaitEvent(st2, (hipEvent_t)T.pending.evw, 0));
+            HIP_TRY(hipEventRecord((hipEvent_t)T.pending.evd, st2)); T.pending.has_evd = true;
+            if (int rc = launch_depth_stage(st2)) return rc;
         } else {
             // ================================================================ CAREFUL: stage by stage
             SR.ms_scan = 0; SR.n_redone = 0;
@@ -3009,15 +3117,14 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
             const uint64_t NB = ((uint64_t)NR + PB - 1) / PB, NBa = NB + 1;   // blocks of PB records: their sums and bases (entry NB of the bases = the round's totals)
             DP_BUF(RecCnt, d_blkcnt, NBa);
             DP_BUF(RecCnt, d_blkpre, NBa);
-            DP_BUF(uint16_t, d_depth_, NRa);
             DP_BUF(uint32_t, d_ovr_, NRa);
             DP_BUF(uint4, d_rd, NRa);
             DP_BUF(RecCnt, d_pre, NRa);
             DP_BUF(uint8_t, d_flags, NRa);
             DP_BUF(unsigned long long, d_rg, NRa);
             DP_BUF(unsigned long long, d_sf, NRa);
-            d_depth = d_depth_; d_ovr = d_ovr_;
-            TB = RdTables{SR.d_recoff, SR.d_recsample, d_recbase, d_rd, d_pre, d_ftile, d_flags, d_rg};
+            d_ovr = d_ovr_;
+            TB = RdTables{SR.d_recoff, SR.d_recsample, d_recbase, d_rd, d_pre, d_ftile, d_flags, d_rg, nullptr, nullptr};
             HIP_TRY(hipMemcpyAsync(SR.d_recoff + NR, &end_all, 8, hipMemcpyHostToDevice, st));
             const size_t depth_bufs_from = pool.next;
             RecCnt tot{};
@@ -3056,7 +3163,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
                 tm.start();
                 n_runs = 0; n_groups = 0;
                 if (NR) {
-                    hipLaunchKernelGGL(msnv_tables_from_measure, grid_for(NR, 256), dim3(256), 0, st, NR, SR.d_recsample, d_flags0, d_key, d_end, d_maxc, d_cnt, d_blkpre, d_ftile, span_out, P, TB, d_sf, d_acc);
+                    hipLaunchKernelGGL(msnv_tables_from_measure, grid_for(NR, 256), dim3(256), 0, st, NR, SR.d_recsample, d_flags0, d_key, d_end, d_maxc, d_cnt, d_blkpre, d_ftile, span_out, P, TB, d_sf, d_acc, d_misc);
                     HIP_TRY(hipGetLastError());
                     size_t need = 0;
                     HIP_TRY(rocprim::inclusive_scan(nullptr, need, d_sf, d_rg, (size_t)NR, rocprim::plus<unsigned long long>(), st));
@@ -3064,9 +3171,11 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
                     HIP_TRY(rocprim::inclusive_scan(d_tmp, need, d_sf, d_rg, (size_t)NR, rocprim::plus<unsigned long long>(), st));
                     unsigned long long last = 0;
                     HIP_TRY(hipMemcpyAsync(&last, d_rg + (NR - 1), 8, hipMemcpyDeviceToHost, st));
+                    HIP_TRY(hipMemcpyAsync(misc_h, d_misc, MISC_WORDS * 4, hipMemcpyDeviceToHost, st));
                     HIP_TRY(hipStreamSynchronize(st));
                     n_runs = (uint32_t)(last >> 32); n_groups = (uint32_t)last;
                 }
+                in_order = misc_h[MISC_SORT] != 0 || [] { const char *e = getenv("MSNV_TILE_ORDER"); return e && e[0] == 's'; }();      // (the tile order's route: the depth kernel writes the pieces' depths at their header slots)
                 totals_h = tot;
                 HIP_TRY(hipMemcpyAsync(d_pre + NR, &totals_h, sizeof(RecCnt), hipMemcpyHostToDevice, st));
                 DP_BUF(uint32_t, c_runfirst, (uint64_t)n_runs + 1);
@@ -3077,7 +3186,14 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
                 DP_BUF(uint2, c_grppre, (uint64_t)n_groups + 2);
                 DP_BUF(DevGroupRec, c_groups, (uint64_t)n_groups + 1);
                 d_runfirst = c_runfirst; d_runf1 = c_runf1; d_runs = c_runs; d_grpfirst = c_grpfirst; d_grpmd = c_grpmd; d_grppre = c_grppre; d_groups = c_groups;
-                if (int rc = launch_depth_stage()) return rc;
+                if (int rc = alloc_round_buffers()) return rc;
+                // (the groups' first records: this route has no table of them yet -- the depth kernel writes it, the places follow, then the depths)
+                hipLaunchKernelGGL(msnv_group_firsts, grid_for(NR, 256), dim3(256), 0, st, NR, TB.r_flags, TB.r_rg, d_runfirst, d_grpfirst);
+                hipLaunchKernelGGL(msnv_group_pre2, grid_for((uint64_t)n_groups + 1, 256), dim3(256), 0, st, n_groups, NR, d_grpfirst, TB.r_pre, d_grppre);
+                HIP_TRY(hipGetLastError());
+                if (int rc = launch_depth_stage(st)) return rc;
+                hipLaunchKernelGGL(msnv_acc_fold, dim3((unsigned)S), dim3(64), 0, st, d_acc, (uint32_t)S);
+                HIP_TRY(hipGetLastError());
                 runs.resize(n_runs); groups.resize(n_groups);
                 HIP_TRY(hipMemcpyAsync(runs.data(), d_runs, (size_t)n_runs * sizeof(DpRun), hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipMemcpyAsync(groups.data(), d_groups, (size_t)n_groups * sizeof(DevGroupRec), hipMemcpyDeviceToHost, st));
@@ -3174,22 +3290,8 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
                 have_ovr = true;
                 T.wall_prepass_s += now_s() - t0;
             }
-            in_order = misc_h[MISC_SORT] != 0 || [] { const char *e = getenv("MSNV_TILE_ORDER"); return e && e[0] == 's'; }();
         }
         const uint64_t NB = ((uint64_t)NR + PB - 1) / PB;
-
-        // ================================================================ the quick route's depth stage (queued behind msnv_scan_write2)
-        if (route == 0) {
-            DP_BUF(uint32_t, q_runfirst, (uint64_t)n_runs + 1);
-            DP_BUF(uint32_t, q_runf1, (uint64_t)n_runs + 1);
-            DP_BUF(DpRun, q_runs, (uint64_t)n_runs + 1);
-            DP_BUF(uint32_t, q_grpfirst, (uint64_t)n_groups + 2);
-            DP_BUF(uint32_t, q_grpmd, 2 * ((uint64_t)n_groups + 1));
-            DP_BUF(uint2, q_grppre, (uint64_t)n_groups + 2);
-            DP_BUF(DevGroupRec, q_groups, (uint64_t)n_groups + 1);
-            d_runfirst = q_runfirst; d_runf1 = q_runf1; d_runs = q_runs; d_grpfirst = q_grpfirst; d_grpmd = q_grpmd; d_grppre = q_grppre; d_groups = q_groups;
-            if (int rc = launch_depth_stage()) return rc;
-        }
 
         // ================================================================ overlapping mates: the qualities of the pairs are edited where they lie
         if (n_ovl_groups) {
@@ -3203,53 +3305,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
         if (route == 1) fin_trace("  pack: checks, overlaps");
 
         // ================================================================ layout + emit (both routes)
-        // The round's columns: per sample its pieces + 32 tail bytes, starting on 16 bytes, and one flag bit per nibble of them.  The samples'
-        // shares are laid out on the device (msnv_sample_layout: the quick route's host does not know them yet); the buffer is sized by the
-        // round's seq bytes + the most the tails and the rounding can add.
-        const uint64_t seq_bound = (seqb_total + (uint64_t)S * 48ull + 15ull) & ~15ull, qual_bound = seq_bound / 4;
         const uint64_t NPCa = (uint64_t)NPC + 1;
-        struct Held {                                                // the round's lasting buffers, this function's until the round is known to stand
-            void *round_buf = nullptr, *keep_buf = nullptr;
-            ~Held() { if (round_buf) dev_free(round_buf); if (keep_buf) dev_free(keep_buf); }
-        } held;
-        if (int rc = dev_alloc(&held.round_buf, seq_bound + COL_PAD + qual_bound + 64, nullptr)) return rc;
-        r_seq = static_cast<uint8_t *>(held.round_buf); r_qual = r_seq + seq_bound + COL_PAD;
-        {
-            const uint64_t lo = seqb_total & ~15ull;                  // (from the lowest place the columns can end to the flags: N -- the exact end is the device's)
-            HIP_TRY(hipMemsetAsync(r_seq + lo, 0xff, seq_bound + COL_PAD - lo, st));
-            HIP_TRY(hipMemsetAsync(r_qual, 0, qual_bound + 64, st));
-        }
-        keep = DevRound{};
-        {   // what stays in HBM of the round besides the columns: headers (tile order) and intervals, for finalize -- written where they stay
-            const uint64_t b_hdr = (uint64_t)NPC * sizeof(ReadHdr), b_4 = (((uint64_t)NPC * 4) + 15) & ~15ull, b_2 = (((uint64_t)NPC * 2) + 15) & ~15ull, b_iv = (((uint64_t)NIV * 4) + 15) & ~15ull;
-            if (int rc = dev_alloc(&held.keep_buf, b_hdr + 2 * b_4 + b_2 + 3 * b_iv + 64, nullptr)) return rc;
-            uint8_t *q = static_cast<uint8_t *>(held.keep_buf);
-            keep.buf = held.keep_buf;
-            keep.hdr = reinterpret_cast<ReadHdr *>(q); q += b_hdr;
-            keep.tid = reinterpret_cast<int32_t *>(q); q += b_4;
-            keep.end = reinterpret_cast<int32_t *>(q); q += b_4;
-            keep.depth = reinterpret_cast<uint16_t *>(q); q += b_2;
-            keep.cov_tid = reinterpret_cast<int32_t *>(q); q += b_iv;
-            keep.cov_beg = reinterpret_cast<int32_t *>(q); q += b_iv;
-            keep.cov_end = reinterpret_cast<int32_t *>(q);
-            keep.n_pieces = NPC; keep.n_iv = NIV; keep.first_sample = first;
-            keep.col_buf = held.round_buf; keep.col_seq = r_seq; keep.col_qual = r_qual; keep.seq_total = 0; keep.n_samples = S;
-        }
-        DP_BUF(DpSampleSum2, d_sum, S + 1);
-        DP_BUF(unsigned long long, d_ss0, S + 1);
-        DP_BUF(DpSampleDst, d_dst_, S);
-        DP_BUF(unsigned long long, d_pb, S);
-        DP_BUF(uint32_t, d_slow, NB + 2);
-        d_dst = d_dst_;
-        // (the general route keeps the headers in file order first: work buffers, sorted into `keep` below)
-        w_hdr = keep.hdr; w_tid = keep.tid; w_end = keep.end; w_depth = keep.depth;
-        if (in_order) {
-            DP_BUF(ReadHdr, d_hdr, NPCa);
-            DP_BUF(int32_t, d_ptid, NPCa);
-            DP_BUF(int32_t, d_pend, NPCa);
-            DP_BUF(uint16_t, d_pdepth, NPCa);
-            w_hdr = d_hdr; w_tid = d_ptid; w_end = d_pend; w_depth = d_pdepth;
-        }
         HIP_TRY(hipMemcpyAsync(d_cut, cut_marks.data(), S, hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemsetAsync(d_slow, 0, 4, st));
         hipLaunchKernelGGL(msnv_sample_layout, dim3(1), dim3(256), 0, st, d_recbase, (uint32_t)S, TB.r_pre, d_acc, TB.rd, r_seq, r_qual, d_cut, d_sum, d_ss0, d_dst, d_pb);
@@ -3263,11 +3319,14 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
         if (int rc = pin_ensure(ds, std::max<uint64_t>(o_end, S * sizeof(DpAcc)))) return rc;
         uint8_t *pinb = static_cast<uint8_t *>(T.pin) + T.pin_cap / 2;
         if (route == 0) {
-            HIP_TRY(hipMemcpy2DAsync(pinb + o_acc, sizeof(DpAcc), d_acc, sizeof(DpAcc) * ACC_COPIES, sizeof(DpAcc), S, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(pinb + o_rb, d_recbase, b_rb, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(pinb + o_misc, d_misc, MISC_WORDS * 4, hipMemcpyDeviceToHost, st));
-            if (n_runs) HIP_TRY(hipMemcpyAsync(pinb + o_runs, d_runs, b_runs, hipMemcpyDeviceToHost, st));
-            if (n_groups) HIP_TRY(hipMemcpyAsync(pinb + o_grp, d_groups, b_grp, hipMemcpyDeviceToHost, st));
+            static const bool depth_on_main = [] { const char *e = getenv("MSNV_DEPTH_STREAM"); return e && e[0] == 'm'; }();
+            hipStream_t st2 = depth_on_main ? st : (hipStream_t)ds.ctx->stream2;          // (behind the depth stage: its stream)
+            HIP_TRY(hipMemcpy2DAsync(pinb + o_acc, sizeof(DpAcc), d_acc, sizeof(DpAcc) * ACC_COPIES, sizeof(DpAcc), S, hipMemcpyDeviceToHost, st2));
+            HIP_TRY(hipMemcpyAsync(pinb + o_rb, d_recbase, b_rb, hipMemcpyDeviceToHost, st2));
+            HIP_TRY(hipMemcpyAsync(pinb + o_misc, d_misc, MISC_WORDS * 4, hipMemcpyDeviceToHost, st2));
+            if (n_runs) HIP_TRY(hipMemcpyAsync(pinb + o_runs, d_runs, b_runs, hipMemcpyDeviceToHost, st2));
+            if (n_groups) HIP_TRY(hipMemcpyAsync(pinb + o_grp, d_groups, b_grp, hipMemcpyDeviceToHost, st2));
+            HIP_TRY(hipEventRecord((hipEvent_t)T.pending.evd2, st2));
         }
         HIP_TRY(hipMemcpyAsync(pinb + o_sum, d_sum, b_sum, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(pinb + o_pb, d_pb, b_pb, hipMemcpyDeviceToHost, st));
@@ -3276,9 +3335,9 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
         HIP_TRY(hipEventRecord((hipEvent_t)T.pending.ev0, st));
         if (NR) {
             EmitArgs A{};
-            A.raw = raw; A.rec_off = TB.rec_off; A.rec_sample = TB.rec_sample; A.n_rec = NR; A.ctg = ctg; A.r_flags = TB.r_flags; A.r_depth = d_depth; A.r_pre = TB.r_pre;
+            A.raw = raw; A.rec_off = TB.rec_off; A.rec_sample = TB.rec_sample; A.n_rec = NR; A.ctg = ctg; A.r_flags = TB.r_flags; A.r_pre = TB.r_pre;
             A.samp_sbase0 = d_ss0; A.rg = TB.r_rg; A.grp_pre = d_grppre; A.in_order = in_order ? 1u : 0u;
-            A.hdr = w_hdr; A.ptid = w_tid; A.pend = w_end; A.pdepth = w_depth; A.cov_tid = keep.cov_tid; A.cov_beg = keep.cov_beg; A.cov_end = keep.cov_end;
+            A.hdr = w_hdr; A.ptid = w_tid; A.pend = w_end; A.cov_tid = keep.cov_tid; A.cov_beg = keep.cov_beg; A.cov_end = keep.cov_end;
             A.noseq_counts = (P.c_eff == 0 && !P.all_low) ? 1u : 0u;
             A.pref4 = T.pref4; A.P = P; A.dst = d_dst; A.acc = d_acc;
             A.slow = d_slow; A.force_slow = [] { const char *e = getenv("MSNV_EMIT"); return e && e[0] == 's'; }() ? 1u : 0u;
@@ -3292,6 +3351,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
         }
         hipLaunchKernelGGL(msnv_emit_tail, dim3((unsigned)S), dim3(64), 0, st, d_dst, d_pb, (uint32_t)S, P);
         if (getenv("MSNV_DEBUG_SYNC")) { HIP_TRY(hipStreamSynchronize(st)); fin_trace("  dbg: emit_tail"); }
+        if (route == 0) HIP_TRY(hipStreamWaitEvent(st, (hipEvent_t)T.pending.evd2, 0));      // (the depth stage's last words into the accumulators: in front of their fold)
         hipLaunchKernelGGL(msnv_acc_fold, dim3((unsigned)S), dim3(64), 0, st, d_acc, (uint32_t)S);
         HIP_TRY(hipGetLastError());
         // The round's last kernels are left RUNNING: nothing the host still has to do for this round -- its (sample, tile) pairs, its tables --
@@ -3303,6 +3363,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
 
         // ---- the host's share: wait for the small results (not for the emit kernels), look at them
         HIP_TRY(hipEventSynchronize((hipEvent_t)T.pending.evh));
+        if (route == 0) HIP_TRY(hipEventSynchronize((hipEvent_t)T.pending.evd2));
         fin_trace("  pack: depth stage, layout (wait)");
         memcpy(sum.data(), pinb + o_sum, b_sum);
         memcpy(piece_bytes.data(), pinb + o_pb, b_pb);
@@ -3334,7 +3395,7 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
         T.n_pieces += NPC; T.n_records += NR;
         T.pad_in_emit = true;                                          // (msnv_emit_block* leave the alignment nibbles behind every piece as finalize wants them)
         T.round_bufs.push_back(held.round_buf); held.round_buf = nullptr;
-        held.keep_buf = nullptr;
+        held.keep_buf = nullptr;                                       // (the dataset's from here on)
         T.rounds.push_back(keep);
         if (in_order) if (int rc = devpack_sync_pending(ds)) return rc;      // (the general tile-order route below waits for its sort anyway)
         fin_trace("  pack: emit launched, results in");
@@ -3693,16 +3754,16 @@ __global__ __launch_bounds__(256) void msnv_fin_cov_emit_dense(const int32_t *ct
                                                                uint32_t n_tiles, Pair32 *iv, uint32_t *lo, uint32_t *hi) {
     const unsigned long long j = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long key = ~0ull; uint32_t idx = 0, tf = 0, tl = 0, s = 0;
-    if (j < n && keep_all[j0 + j]) {
-        const uint32_t *kidx = kidx_all + j0;
+    if (j < n && (!keep_all || keep_all[j0 + j])) {
         const int32_t c = ctid[j];
         const long long L = ctg[c].len, b = cbeg[j];
         const bool minus_one = b > (long long)cend[j];
         const long long e = minus_one ? (long long)cend[j] : ((long long)cend[j] >= L ? L - 1 : (long long)cend[j]);
         const unsigned long long g0 = (unsigned long long)tile_base[c] * TILE;
-        iv[kidx[j]] = Pair32{(uint32_t)(g0 + (unsigned long long)b), (uint32_t)(g0 + (unsigned long long)e)};
+        const uint32_t place = keep_all ? kidx_all[j0 + j] : (uint32_t)(j0 + j);          // (no tables: every interval is kept -- the device pack writes no other since round 6)
+        iv[place] = Pair32{(uint32_t)(g0 + (unsigned long long)b), (uint32_t)(g0 + (unsigned long long)e)};
         s = sample_of(iv_start, n_samples, j0 + j);
-        idx = kidx[j] - kidx_all[iv_start[s]];
+        idx = place - (keep_all ? kidx_all[iv_start[s]] : (uint32_t)iv_start[s]);
         tf = (uint32_t)((g0 + (unsigned long long)(minus_one ? e : b)) / TILE); tl = minus_one ? tf : (uint32_t)((g0 + (unsigned long long)e - 1) / TILE);
         key = (unsigned long long)s * n_tiles + tf;
     }
@@ -3936,15 +3997,12 @@ int devfin_coverage_launch(msnv_dataset &ds, DeviceCols &d) {
     Prim pr(st);
     if (int rc = pr.reserve_scan32(std::max<unsigned long long>(N, n_tab) + 1)) return rc;
     unsigned long long o = 0;
-    for (const DevRound &r : T.rounds) {
-        if (r.n_iv) { hipLaunchKernelGGL(msnv_fin_cov_measure, grid_for(r.n_iv, 256), dim3(256), 0, st, r.cov_tid, r.cov_beg, r.cov_end, (unsigned long long)r.n_iv, ctg, tb, keep + o, ntile + o); HIP_TRY(hipGetLastError()); }
-        o += r.n_iv;
-    }
+    for (const DevRound &r : T.rounds) o += r.n_iv;
     if (o != N) return fail(MSNV_EINVAL, "internal: the rounds hold %llu intervals, the samples %llu", o, N);
-    HIP_TRY(hipMemsetAsync(keep + N, 0, 4, st));
-    if (int rc = pr.scan32(keep, kidx, N + 1, false)) return rc;
-    hipLaunchKernelGGL(msnv_gather_u32, grid_for(S + 1, 64), dim3(64), 0, st, kidx, ivs, (uint32_t)(S + 1), cvb);
-    HIP_TRY(hipMemcpyAsync(cvb + (S + 1), kidx + N, 4, hipMemcpyDeviceToDevice, st));
+    // (every interval of a device-packed round is one the index keeps -- measure_one counts, the emit kernels write, no other: the kept
+    // intervals before every sample are the host's iv_start, and nothing is measured or scanned here any more)
+    (void)keep; (void)ntile; (void)kidx;
+    HIP_TRY(hipMemsetAsync(cvb, 0, (S + 3) * 4, st));
     if (int rc = dev_alloc((void **)&d.cov_iv, ((uint64_t)N + 4) * sizeof(Pair32), &d.device_bytes)) return rc;      // (N >= the kept ones: no wait for their count)
     HIP_TRY(hipMemsetAsync(lo, 0xff, b_t, st));
     HIP_TRY(hipMemsetAsync(hi, 0, b_t, st));
@@ -3952,7 +4010,7 @@ int devfin_coverage_launch(msnv_dataset &ds, DeviceCols &d) {
     for (const DevRound &r : T.rounds) {
         if (r.n_iv) {
             hipLaunchKernelGGL(msnv_fin_cov_emit_dense, grid_for(r.n_iv, 256), dim3(256), 0, st, r.cov_tid, r.cov_beg, r.cov_end, (unsigned long long)r.n_iv, o, ctg, tb, ivs, (uint32_t)S,
-                               keep, kidx, ds.n_tiles, d.cov_iv, lo, hi);
+                               (const uint32_t *)nullptr, (const uint32_t *)nullptr, ds.n_tiles, d.cov_iv, lo, hi);
             HIP_TRY(hipGetLastError());
         }
         o += r.n_iv;
@@ -3986,8 +4044,8 @@ int devfin_coverage(msnv_dataset &ds, DeviceCols &d, std::vector<uint64_t> &cvba
         T.cov_launched = false;
         HIP_TRY(hipEventSynchronize((hipEvent_t)T.cov_event));
         const uint32_t *pw = pin_fin_words(T);
-        for (size_t s = 0; s <= S; ++s) cvbase[s] = pw[s];
-        const uint32_t n_keep = pw[S + 1], n_runs = pw[S + 2];
+        for (size_t s = 0; s <= S; ++s) cvbase[s] = iv_start[s];       // (every interval is a kept one)
+        const uint32_t n_keep = (uint32_t)N, n_runs = pw[S + 2];
         d.n_cov_iv = n_keep;
         HIP_TRY(hipMemsetAsync(d.cov_iv + n_keep, 0, 4 * sizeof(Pair32), st));              // behind the last interval: what the idle lanes of msnv_coverage_tiles load
         cp.resize(n_runs);

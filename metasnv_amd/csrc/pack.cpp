@@ -905,6 +905,141 @@ int finalize_dataset(msnv_dataset &ds) {
     d->n_tiles = ds.n_tiles; d->n_samples = (uint32_t)S;
 
     if (fast) if (int rc = devfin_coverage_launch(ds, *d)) return rc;     // (the coverage index's kernels go first: they run while the host builds the pair tables)
+    // ---- genome coverage index: intervals of qaCompute's difference array, grouped by tile.  The host's share -- pair tables by tile, accumulator
+    // rows, work items (0.5 ms of loops on the benchmark shape) -- needs the index's kernels' results and nothing else of finalize.  On a thread
+    // of its own beside the tile index (MSNV_COV_THREAD=1) it made finalize SLOWER (median of twelve builds 2.9-3.3 ms against 2.3: the thread's
+    // start and wake-up cost more than the loops; profiles/r06_variants.txt): it runs behind the wait for those kernels, on this thread.
+    uint64_t cov_bytes = 0;
+    auto cov_index = [&](TableArena &A, bool in_thread) -> int {
+        std::vector<Pair32> iv;
+        std::vector<uint64_t> cvbase(S + 1, 0);
+        struct CP { uint32_t tile, sample, lo, hi; };
+        std::vector<CP> flat;                                        // all samples' (tile, sample) runs, sample after sample, tiles ascending inside a sample
+        if (fast) {
+            // the intervals are in HBM: filtered, made linear and grouped by (sample, tile) there (devpack.hip: devfin_coverage); the runs come
+            // back sample-major with the tiles ascending, which is the order the loops below want
+            std::vector<DevCovPair> cp;
+            if (int rc = devfin_coverage(ds, *d, cvbase, cp)) return rc;
+            if (!in_thread) lap("  devfin_coverage");
+            flat.resize(cp.size());
+            bool ordered = true;
+            for (size_t i = 0; i < cp.size(); ++i) {
+                flat[i] = CP{cp[i].tile, cp[i].sample, cp[i].lo, cp[i].hi};
+                if (i && (cp[i].sample < cp[i - 1].sample || (cp[i].sample == cp[i - 1].sample && cp[i].tile < cp[i - 1].tile))) ordered = false;
+            }
+            if (!ordered) std::stable_sort(flat.begin(), flat.end(), [](const CP &a, const CP &b) { return a.sample != b.sample ? a.sample < b.sample : a.tile < b.tile; });
+        }
+        else {
+        std::vector<std::vector<CP>> per(S);
+        for (size_t s = 0; s < S; ++s) {
+            const SampleCols &sc = ds.samples[s];
+            uint32_t n_here = 0;
+            for (size_t i = 0; i < sc.cov_tid.size(); ++i) {
+                const size_t c = (size_t)sc.cov_tid[i];
+                const int64_t L = ds.lengths[c];
+                const int64_t b = sc.cov_beg[i];
+                const bool minus_one = b > sc.cov_end[i];                          // {L, L - 1}: "-1 at L - 1" (pack_sample)
+                const int64_t e = minus_one ? sc.cov_end[i] : (sc.cov_end[i] >= L ? L - 1 : sc.cov_end[i]);       // qaCompute.cpp:544-549
+                if (!minus_one && b >= e) continue;
+                const uint64_t g0 = (uint64_t)ds.tile_base[c] * TILE;
+                const uint32_t idx = n_here++;
+                iv.push_back(Pair32{(uint32_t)(g0 + (uint64_t)b), (uint32_t)(g0 + (uint64_t)e)});
+                std::vector<CP> &pv = per[s];
+                const uint32_t t_first = (uint32_t)((g0 + (uint64_t)(minus_one ? e : b)) / TILE), t_last = minus_one ? t_first : (uint32_t)((g0 + e - 1) / TILE);
+                for (uint32_t t = t_first; t <= t_last; ++t) {
+                    size_t k = pv.size();
+                    while (k > 0 && pv[k - 1].tile > t) --k;
+                    if (k > 0 && pv[k - 1].tile == t) pv[k - 1].hi = idx + 1;
+                    else pv.insert(pv.begin() + (ptrdiff_t)k, CP{t, (uint32_t)s, idx, idx + 1});
+                }
+            }
+            cvbase[s + 1] = cvbase[s] + n_here;
+        }
+        for (size_t s = 0; s < S; ++s) flat.insert(flat.end(), per[s].begin(), per[s].end());
+        }
+        // one pass for the tile counts, one for the pairs (sample order inside a tile comes with the order of `flat`) and the accumulator rows
+        std::vector<uint32_t> cps(nt + 1, 0);
+        for (const CP &p : flat) cps[p.tile + 1]++;
+        for (uint64_t t = 0; t < nt; ++t) cps[t + 1] += cps[t];
+        std::vector<TilePair> cpairs(cps[nt]);
+        {
+            std::vector<uint32_t> fill(cps.begin(), cps.end() - 1);
+            // blk_lo / nblk: absolute index of the sample's first interval (the kernel needs no per-sample base lookup)
+            // max_depth: the accumulator row of the pair's (sample, contig) -- rows exist for the combinations that have intervals only
+            ds.cov_row_sample.clear(); ds.cov_row_contig.clear(); ds.cov_row_start.assign(S + 1, 0);
+            size_t i = 0;
+            for (size_t s = 0; s < S; ++s) {
+                ds.cov_row_start[s] = ds.cov_row_sample.size();
+                uint32_t last_contig = UINT32_MAX;
+                for (; i < flat.size() && flat[i].sample == s; ++i) {                     // (tile order = contig order)
+                    const CP &p = flat[i];
+                    const uint32_t c = ds.tile_contig[p.tile];
+                    if (c != last_contig) { ds.cov_row_sample.push_back((uint32_t)s); ds.cov_row_contig.push_back(c); last_contig = c; }
+                    if (ds.cov_row_sample.size() > 0xffffffffull) return fail(MSNV_EDOMAIN, "more than 2^32 (sample, contig) pairs with coverage in one shard");
+                    cpairs[fill[p.tile]++] = TilePair{p.sample, p.lo, p.hi, (uint32_t)(ds.cov_row_sample.size() - 1), (uint32_t)cvbase[s], (uint32_t)(cvbase[s] >> 32), 0, 0};
+                }
+            }
+            ds.cov_row_start[S] = ds.cov_row_sample.size();
+        }
+        if (!in_thread) lap("    cov tables: pairs by tile, rows");
+        std::vector<WorkItem> cwork;
+        cwork.reserve(cpairs.size() / 2 + nt + 16);
+        // a coverage work item = COV_ITEM_PAIRS consecutive pairs of a tile = one wavefront of msnv_coverage_tiles, which loads their
+        // descriptors up front and a pair's intervals while it works on the pair before (fewer when one pair alone is deep:
+        // MSNV_COV_ITEM intervals)
+        const uint64_t cov_item_intervals = [] { const char *e = getenv("MSNV_COV_ITEM"); const long long v = e ? atoll(e) : 16384; return (uint64_t)(v > 0 ? v : 16384); }();
+        for (uint64_t t = 0; t < nt; ++t) {
+            uint32_t lo = cps[t]; uint64_t acc = 0;
+            for (uint32_t k = cps[t]; k < cps[t + 1]; ++k) {
+                acc += cpairs[k].read_hi - cpairs[k].read_lo;
+                if (acc >= cov_item_intervals || k + 1 - lo >= COV_ITEM_PAIRS || k + 1 == cps[t + 1]) { cwork.push_back(WorkItem{(uint32_t)t, lo, k + 1, 0, 0, 0, 0, 0, ChunkDesc{}}); lo = k + 1; acc = 0; }
+            }
+        }
+        // the items with a pair of more than 32 767 intervals go last: msnv_coverage_tiles<true> (one word per position) runs them,
+        // the 16-bit difference array of the usual variant holds +-32 767 per position and per 16 positions of one parity
+        // (MSNV_COV_NARROW_MAX is read per dataset: tests lower it to run the other variant)
+        const uint32_t cov_narrow_max = [] { const char *e = getenv("MSNV_COV_NARROW_MAX"); const long long v = e ? atoll(e) : 32767; return (uint32_t)std::min<long long>(32767, std::max<long long>(1, v)); }();
+        auto cov_wide = [&](const WorkItem &w) { for (uint32_t k = w.pair_lo; k < w.pair_hi; ++k) if (cpairs[k].read_hi - cpairs[k].read_lo > cov_narrow_max) return true; return false; };
+        bool any_wide = false;
+        for (const TilePair &q : cpairs) if (q.read_hi - q.read_lo > cov_narrow_max) { any_wide = true; break; }
+        d->n_cov_work_wide = 0;
+        if (any_wide) {
+            const auto first_wide = std::stable_partition(cwork.begin(), cwork.end(), [&](const WorkItem &w) { return !cov_wide(w); });
+            d->n_cov_work_wide = (uint32_t)(cwork.end() - first_wide);
+        }
+        if (!in_thread) lap("    cov tables: work items");
+        std::vector<uint32_t> tlen(nt + 1, 0), tcont(nt + 1, 0);
+        for (uint64_t t = 0; t < nt; ++t) {
+            const size_t c = ds.tile_contig[t];
+            const int64_t t0 = (int64_t)(t - ds.tile_base[c]) * TILE;
+            tlen[t] = (uint32_t)std::min<int64_t>(std::max<int64_t>(ds.lengths[c] - t0, 0), TILE);
+            tcont[t] = (uint32_t)c;
+        }
+        if (!fast) d->n_cov_iv = iv.size();
+        for (int k = 0; k < 4; ++k) iv.push_back(Pair32{0u, 0u});     // behind the last interval: what the idle lanes of msnv_coverage_tiles load, four at a time (they touch nothing)
+        d->n_cov_pairs = (uint32_t)cpairs.size(); d->n_cov_work = (uint32_t)cwork.size(); d->n_contigs = (uint32_t)NC;
+        if (!fast) if (int rc = A.add(&d->cov_iv, iv, &cov_bytes, 1)) return rc;
+        if (int rc = A.add(&d->s_cov_base, cvbase, &cov_bytes)) return rc;
+        if (int rc = A.add(&d->cov_pairs, cpairs, &cov_bytes, 1)) return rc;
+        if (int rc = A.add(&d->cov_work, cwork, &cov_bytes, 1)) return rc;
+        if (int rc = A.add(&d->tile_len, tlen, &cov_bytes)) return rc;
+        if (int rc = A.add(&d->tile_contig_dev, tcont, &cov_bytes)) return rc;
+        return MSNV_OK;
+    };
+    TableArena cov_arena;
+    struct CovJob {
+        std::thread th; int rc = MSNV_OK; std::string msg;
+        int join() { if (th.joinable()) th.join(); if (rc) return fail(rc, "%s", msg.c_str()); return MSNV_OK; }
+        ~CovJob() { if (th.joinable()) th.join(); }
+    } cov_job;
+    if (fast && ds.dp.cov_launched && getenv("MSNV_COV_THREAD")) {
+        const int device = ds.ctx ? ds.ctx->device : 0;
+        cov_job.th = std::thread([&cov_job, &cov_index, &cov_arena, device]() {
+            (void)dev_set_device(device);
+            try { cov_job.rc = cov_index(cov_arena, true); } catch (const std::exception &e) { cov_job.rc = fail_quiet(MSNV_ENOMEM, "coverage index: %s", e.what()); }
+            if (cov_job.rc) cov_job.msg = msnv_last_error();
+        });
+    }
     lap("tile layout");
     // ---- reference: nt16 codes (N beyond the contig end, as mpileup prints) + lower-case bits
     std::vector<uint32_t> ref4(npos / 8 + 1, 0xffffffffu);
@@ -1104,10 +1239,10 @@ int finalize_dataset(msnv_dataset &ds) {
             auto b = pairs.begin() + tps[t], e = pairs.begin() + tps[t + 1];
             if (fuse_tile[t]) for (auto it = b; it != e; ++it) it->pad = 2;
             else if (merge_tile[t]) for (auto it = b; it != e; ++it) if (is_shallow(*it)) it->pad = 2;
-            std::stable_sort(b, e, [](const TilePair &x, const TilePair &y) {
-                auto cls = [](const TilePair &p) { return p.pad == 2 ? 2 : p.max_depth < NARROW_MAX_DEPTH ? 0 : 1; };
-                return cls(x) < cls(y);
-            });
+            auto cls = [](const TilePair &p) { return p.pad == 2 ? 2 : p.max_depth < NARROW_MAX_DEPTH ? 0 : 1; };
+            bool in_class_order = true;                              // (nearly every tile's pairs are of one class: the sort's temporary buffer per tile was a third of this stage)
+            for (auto it = b; it != e && it + 1 != e; ++it) if (cls(*(it + 1)) < cls(*it)) { in_class_order = false; break; }
+            if (!in_class_order) std::stable_sort(b, e, [&](const TilePair &x, const TilePair &y) { return cls(x) < cls(y); });
         }
     }
     std::vector<uint32_t> tpm(nt + 1, 0);                           // per tile: first merged pair
@@ -1630,131 +1765,19 @@ int finalize_dataset(msnv_dataset &ds) {
     ds.info.n_tiles = nt; ds.info.n_pairs = pairs.size(); ds.info.n_work = work.size();
     lap("intermediates");
 
-    // ---- genome coverage index: intervals of qaCompute's difference array, grouped by tile
-    {
-        std::vector<Pair32> iv;
-        std::vector<uint64_t> cvbase(S + 1, 0);
-        struct CP { uint32_t tile, sample, lo, hi; };
-        std::vector<CP> flat;                                        // all samples' (tile, sample) runs, sample after sample, tiles ascending inside a sample
-        if (fast) {
-            // the intervals are in HBM: filtered, made linear and grouped by (sample, tile) there (devpack.hip: devfin_coverage); the runs come
-            // back sample-major with the tiles ascending, which is the order the loops below want
-            std::vector<DevCovPair> cp;
-            if (int rc = devfin_coverage(ds, *d, cvbase, cp)) return rc;
-            lap("  devfin_coverage");
-            flat.resize(cp.size());
-            bool ordered = true;
-            for (size_t i = 0; i < cp.size(); ++i) {
-                flat[i] = CP{cp[i].tile, cp[i].sample, cp[i].lo, cp[i].hi};
-                if (i && (cp[i].sample < cp[i - 1].sample || (cp[i].sample == cp[i - 1].sample && cp[i].tile < cp[i - 1].tile))) ordered = false;
-            }
-            if (!ordered) std::stable_sort(flat.begin(), flat.end(), [](const CP &a, const CP &b) { return a.sample != b.sample ? a.sample < b.sample : a.tile < b.tile; });
-        }
-        else {
-        std::vector<std::vector<CP>> per(S);
-        for (size_t s = 0; s < S; ++s) {
-            const SampleCols &sc = ds.samples[s];
-            uint32_t n_here = 0;
-            for (size_t i = 0; i < sc.cov_tid.size(); ++i) {
-                const size_t c = (size_t)sc.cov_tid[i];
-                const int64_t L = ds.lengths[c];
-                const int64_t b = sc.cov_beg[i];
-                const bool minus_one = b > sc.cov_end[i];                          // {L, L - 1}: "-1 at L - 1" (pack_sample)
-                const int64_t e = minus_one ? sc.cov_end[i] : (sc.cov_end[i] >= L ? L - 1 : sc.cov_end[i]);       // qaCompute.cpp:544-549
-                if (!minus_one && b >= e) continue;
-                const uint64_t g0 = (uint64_t)ds.tile_base[c] * TILE;
-                const uint32_t idx = n_here++;
-                iv.push_back(Pair32{(uint32_t)(g0 + (uint64_t)b), (uint32_t)(g0 + (uint64_t)e)});
-                std::vector<CP> &pv = per[s];
-                const uint32_t t_first = (uint32_t)((g0 + (uint64_t)(minus_one ? e : b)) / TILE), t_last = minus_one ? t_first : (uint32_t)((g0 + e - 1) / TILE);
-                for (uint32_t t = t_first; t <= t_last; ++t) {
-                    size_t k = pv.size();
-                    while (k > 0 && pv[k - 1].tile > t) --k;
-                    if (k > 0 && pv[k - 1].tile == t) pv[k - 1].hi = idx + 1;
-                    else pv.insert(pv.begin() + (ptrdiff_t)k, CP{t, (uint32_t)s, idx, idx + 1});
-                }
-            }
-            cvbase[s + 1] = cvbase[s] + n_here;
-        }
-        for (size_t s = 0; s < S; ++s) flat.insert(flat.end(), per[s].begin(), per[s].end());
-        }
-        // one pass for the tile counts, one for the pairs (sample order inside a tile comes with the order of `flat`) and the accumulator rows
-        std::vector<uint32_t> cps(nt + 1, 0);
-        for (const CP &p : flat) cps[p.tile + 1]++;
-        for (uint64_t t = 0; t < nt; ++t) cps[t + 1] += cps[t];
-        std::vector<TilePair> cpairs(cps[nt]);
-        {
-            std::vector<uint32_t> fill(cps.begin(), cps.end() - 1);
-            // blk_lo / nblk: absolute index of the sample's first interval (the kernel needs no per-sample base lookup)
-            // max_depth: the accumulator row of the pair's (sample, contig) -- rows exist for the combinations that have intervals only
-            ds.cov_row_sample.clear(); ds.cov_row_contig.clear(); ds.cov_row_start.assign(S + 1, 0);
-            size_t i = 0;
-            for (size_t s = 0; s < S; ++s) {
-                ds.cov_row_start[s] = ds.cov_row_sample.size();
-                uint32_t last_contig = UINT32_MAX;
-                for (; i < flat.size() && flat[i].sample == s; ++i) {                     // (tile order = contig order)
-                    const CP &p = flat[i];
-                    const uint32_t c = ds.tile_contig[p.tile];
-                    if (c != last_contig) { ds.cov_row_sample.push_back((uint32_t)s); ds.cov_row_contig.push_back(c); last_contig = c; }
-                    if (ds.cov_row_sample.size() > 0xffffffffull) return fail(MSNV_EDOMAIN, "more than 2^32 (sample, contig) pairs with coverage in one shard");
-                    cpairs[fill[p.tile]++] = TilePair{p.sample, p.lo, p.hi, (uint32_t)(ds.cov_row_sample.size() - 1), (uint32_t)cvbase[s], (uint32_t)(cvbase[s] >> 32), 0, 0};
-                }
-            }
-            ds.cov_row_start[S] = ds.cov_row_sample.size();
-        }
-        lap("    cov tables: pairs by tile, rows");
-        std::vector<WorkItem> cwork;
-        cwork.reserve(cpairs.size() / 2 + nt + 16);
-        // a coverage work item = COV_ITEM_PAIRS consecutive pairs of a tile = one wavefront of msnv_coverage_tiles, which loads their
-        // descriptors up front and a pair's intervals while it works on the pair before (fewer when one pair alone is deep:
-        // MSNV_COV_ITEM intervals)
-        const uint64_t cov_item_intervals = [] { const char *e = getenv("MSNV_COV_ITEM"); const long long v = e ? atoll(e) : 16384; return (uint64_t)(v > 0 ? v : 16384); }();
-        for (uint64_t t = 0; t < nt; ++t) {
-            uint32_t lo = cps[t]; uint64_t acc = 0;
-            for (uint32_t k = cps[t]; k < cps[t + 1]; ++k) {
-                acc += cpairs[k].read_hi - cpairs[k].read_lo;
-                if (acc >= cov_item_intervals || k + 1 - lo >= COV_ITEM_PAIRS || k + 1 == cps[t + 1]) { cwork.push_back(WorkItem{(uint32_t)t, lo, k + 1, 0, 0, 0, 0, 0, ChunkDesc{}}); lo = k + 1; acc = 0; }
-            }
-        }
-        // the items with a pair of more than 32 767 intervals go last: msnv_coverage_tiles<true> (one word per position) runs them,
-        // the 16-bit difference array of the usual variant holds +-32 767 per position and per 16 positions of one parity
-        // (MSNV_COV_NARROW_MAX is read per dataset: tests lower it to run the other variant)
-        const uint32_t cov_narrow_max = [] { const char *e = getenv("MSNV_COV_NARROW_MAX"); const long long v = e ? atoll(e) : 32767; return (uint32_t)std::min<long long>(32767, std::max<long long>(1, v)); }();
-        auto cov_wide = [&](const WorkItem &w) { for (uint32_t k = w.pair_lo; k < w.pair_hi; ++k) if (cpairs[k].read_hi - cpairs[k].read_lo > cov_narrow_max) return true; return false; };
-        bool any_wide = false;
-        for (const TilePair &q : cpairs) if (q.read_hi - q.read_lo > cov_narrow_max) { any_wide = true; break; }
-        d->n_cov_work_wide = 0;
-        if (any_wide) {
-            const auto first_wide = std::stable_partition(cwork.begin(), cwork.end(), [&](const WorkItem &w) { return !cov_wide(w); });
-            d->n_cov_work_wide = (uint32_t)(cwork.end() - first_wide);
-        }
-        lap("    cov tables: work items");
-        std::vector<uint32_t> tlen(nt + 1, 0), tcont(nt + 1, 0);
-        for (uint64_t t = 0; t < nt; ++t) {
-            const size_t c = ds.tile_contig[t];
-            const int64_t t0 = (int64_t)(t - ds.tile_base[c]) * TILE;
-            tlen[t] = (uint32_t)std::min<int64_t>(std::max<int64_t>(ds.lengths[c] - t0, 0), TILE);
-            tcont[t] = (uint32_t)c;
-        }
-        if (!fast) d->n_cov_iv = iv.size();
-        for (int k = 0; k < 4; ++k) iv.push_back(Pair32{0u, 0u});     // behind the last interval: what the idle lanes of msnv_coverage_tiles load, four at a time (they touch nothing)
-        d->n_cov_pairs = (uint32_t)cpairs.size(); d->n_cov_work = (uint32_t)cwork.size(); d->n_contigs = (uint32_t)NC;
-        if (!fast) if (int rc = arena.add(&d->cov_iv, iv, &d->device_bytes, 1)) return rc;
-        if (int rc = arena.add(&d->s_cov_base, cvbase, &d->device_bytes)) return rc;
-        if (int rc = arena.add(&d->cov_pairs, cpairs, &d->device_bytes, 1)) return rc;
-        if (int rc = arena.add(&d->cov_work, cwork, &d->device_bytes, 1)) return rc;
-        if (int rc = arena.add(&d->tile_len, tlen, &d->device_bytes)) return rc;
-        if (int rc = arena.add(&d->tile_contig_dev, tcont, &d->device_bytes)) return rc;
-        lap("    cov tables: staged");
-        if (int rc = arena.commit(*d)) return rc;
-        lap("    cov tables: up");
-        // accumulator copies: as many as fit 64 MB, at most 8 (many contigs = few tiles per contig = little contention anyway)
+    // ---- the coverage index's tables: joined (device-packed datasets: built beside everything above) or built here
+    if (cov_job.th.joinable()) { if (int rc = cov_job.join()) return rc; }
+    else if (int rc = cov_index(cov_arena, false)) return rc;
+    lap("    cov tables: staged");
+    d->device_bytes += cov_bytes;
+    if (int rc = cov_arena.commit(*d)) return rc;
+    lap("    cov tables: up");
+    {   // accumulator copies: as many as fit 64 MB, at most 8 (many contigs = few tiles per contig = little contention anyway)
         d->n_cov_rows = ds.cov_row_sample.size();
         const uint64_t acc_bytes = std::max<uint64_t>(1, d->n_cov_rows) * (1 + COV_BINS) * sizeof(unsigned long long);
         d->cov_copies = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(8, (64ull << 20) / std::max<uint64_t>(1, acc_bytes)));
         if (int rc = dev_alloc((void **)&d->cov_acc, d->cov_copies * acc_bytes, &d->device_bytes)) return rc;
     }
-
     lap("  coverage tables");
     // ---- behind the last wait: how many chunks the narrow items got (cut in HBM, counted there)
     if (chunks_on_device) {
