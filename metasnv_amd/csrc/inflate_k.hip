@@ -36,8 +36,13 @@ namespace {
 constexpr int I_LL_BITS = 9, I_D_BITS = 6;                     // root table bits (zlib's choice: 852 / 592 entries bound the tables)
 constexpr int I_LL_CAP = 852, I_D_CAP = 592;                    // zlib's ENOUGH_LENS / ENOUGH_DISTS for these root bits: the most entries a valid code needs (round 5: 1024 / 640 -- the
                                                                 // kernel's rate is wavefronts in flight / latency per symbol, and LDS is what bounds the wavefronts: 18 -> 22 per CU)
-constexpr uint32_t IF_LIT = 1u << 12, IF_EOB = 1u << 13, IF_SUB = 1u << 14, IF_BAD = 1u << 15;
-// entry: bits 0-7 code length (bits to drop), 8-11 extra bits, 12-15 flags, 16-31 literal / base value / subtable start
+// Table entries are 16 bits (round 6; 32 until then): the kernel's rate is wavefronts in flight / latency per symbol, and LDS bounded the
+// wavefronts -- 7.4 KB a wavefront = 20 per CU; with 16-bit entries and the base / extra tables beside them 4.7 KB = 32 per CU, the most a CU runs.
+//   literal / length table:  bits 0-2 kind (LL_LIT, LL_LEN, LL_EOB, LL_SUB, LL_BAD)
+//                            LIT / LEN / EOB: bits 3-6 code bits to drop; LIT: bits 8-15 the byte; LEN: bits 8-12 symbol - 257
+//                            SUB: bits 3-5 subtable bits - 1, bits 6-15 first entry of the subtable
+//   distance / code-length table: bits 0-1 kind (D_SYM, D_SUB, D_BAD); SYM: bits 2-5 code bits, bits 8-12 symbol; SUB: bits 2-5 subtable bits - 1, bits 6-15 first entry
+enum : uint32_t { LL_LIT = 0, LL_LEN = 1, LL_EOB = 2, LL_SUB = 3, LL_BAD = 4, D_SYM = 0, D_SUB = 2, D_BAD = 3 };
 
 __constant__ uint16_t k_len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
 __constant__ uint8_t k_len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
@@ -46,30 +51,33 @@ __constant__ uint8_t k_dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 
 __constant__ uint8_t k_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 struct InfLds {
-    uint32_t ll[I_LL_CAP];
-    uint32_t d[I_D_CAP];                       // (its first 128 entries are the code-length code's table while a dynamic block's header is read: d is built behind that)
+    uint16_t ll[I_LL_CAP];
+    uint16_t d[I_D_CAP];                       // (its first 128 entries are the code-length code's table while a dynamic block's header is read: d is built behind that)
+    uint32_t len_be[32], dist_be[32];          // base << 8 | extra bits of every length / distance symbol (from the constant tables, once per wavefront)
     uint8_t  lens[32 + 320 + 8];               // [0, 19): code-length code; [32, ...): literal/length lengths, then the distance lengths
     uint16_t code[320];                        // bit-reversed canonical code of every symbol
     uint8_t  sub_bits[1 << I_LL_BITS];
-    uint32_t count[16], next_code[16];
+    uint32_t count[16];
     uint32_t next_free;
 };
 
 __device__ __forceinline__ uint32_t rev_bits(uint32_t v, int n) { return __brev(v) >> (32 - n); }
 
-__device__ __forceinline__ uint32_t ll_entry(const int s) {
-    if (s < 256) return (uint32_t)s << 16 | IF_LIT;
-    if (s == 256) return IF_EOB;
-    if (s < 286) return (uint32_t)k_len_base[s - 257] << 16 | (uint32_t)k_len_extra[s - 257] << 8;
-    return IF_BAD;
+// entry of symbol s with `nb` code bits (to drop at the table level it sits in)
+__device__ __forceinline__ uint32_t ll_entry(const int s, const uint32_t nb) {
+    if (s < 256) return LL_LIT | nb << 3 | (uint32_t)s << 8;
+    if (s == 256) return LL_EOB | nb << 3;
+    if (s < 286) return LL_LEN | nb << 3 | (uint32_t)(s - 257) << 8;
+    return LL_BAD;
 }
-__device__ __forceinline__ uint32_t d_entry(const int s) { return s < 30 ? (uint32_t)k_dist_base[s] << 16 | (uint32_t)k_dist_extra[s] << 8 : IF_BAD; }
-__device__ __forceinline__ uint32_t cl_entry(const int s) { return (uint32_t)s << 16; }
+__device__ __forceinline__ uint32_t d_entry(const int s, const uint32_t nb) { return s < 30 ? D_SYM | nb << 2 | (uint32_t)s << 8 : D_BAD; }
+__device__ __forceinline__ uint32_t cl_entry(const int s, const uint32_t nb) { return D_SYM | nb << 2 | (uint32_t)s << 8; }
 
 // Canonical Huffman decode table from code lengths (the algorithm of csrc/inflate.cpp build_table, a symbol per lane where the work
 // has width).  kind: 0 literal/length, 1 distance, 2 code lengths.  Returns false for an over-subscribed code or a table that
 // does not fit.  Called by the whole wavefront; barriers inside.
-__device__ bool build_table(InfLds &L, uint32_t *tab, const int main_bits, const int cap, const uint8_t *lens, const int n_sym, const int kind, const int lane) {
+__device__ bool build_table(InfLds &L, uint16_t *tab, const int main_bits, const int cap, const uint8_t *lens, const int n_sym, const int kind, const int lane) {
+    const uint32_t bad = kind == 0 ? LL_BAD : D_BAD;
     if (lane < 16) L.count[lane] = 0;
     __syncthreads();
     for (int s = lane; s < n_sym; s += 64) if (lens[s]) atomicAdd(&L.count[lens[s]], 1u);
@@ -95,7 +103,7 @@ __device__ bool build_table(InfLds &L, uint32_t *tab, const int main_bits, const
         for (int l = 0; l < 16; ++l) nxt[l] = nc[l];
         for (int s = 0; s < n_sym; ++s) { const int l = lens[s]; if (l) L.code[s] = (uint16_t)rev_bits(nxt[l]++, l); }
     }
-    for (int i = lane; i < main_size; i += 64) { tab[i] = IF_BAD | 1u; L.sub_bits[i] = 0; }      // an incomplete code leaves holes
+    for (int i = lane; i < main_size; i += 64) { tab[i] = (uint16_t)bad; L.sub_bits[i] = 0; }      // an incomplete code leaves holes
     __syncthreads();
     // subtables: per root prefix the longest code that starts with it (serial: a few hundred steps)
     if (lane == 0) {
@@ -109,8 +117,8 @@ __device__ bool build_table(InfLds &L, uint32_t *tab, const int main_bits, const
             if (!L.sub_bits[i]) continue;
             const int sz = 1 << L.sub_bits[i];
             if (next_free + sz > cap) { fits = false; break; }
-            tab[i] = (uint32_t)next_free << 16 | (uint32_t)L.sub_bits[i] << 8 | IF_SUB | (uint32_t)main_bits;
-            for (int k = 0; k < sz; ++k) tab[next_free + k] = IF_BAD | 1u;
+            tab[i] = (uint16_t)(kind == 0 ? LL_SUB | (uint32_t)(L.sub_bits[i] - 1) << 3 | (uint32_t)next_free << 6 : D_SUB | (uint32_t)(L.sub_bits[i] - 1) << 2 | (uint32_t)next_free << 6);
+            for (int k = 0; k < sz; ++k) tab[next_free + k] = (uint16_t)bad;
             next_free += sz;
         }
         L.next_free = fits ? (uint32_t)next_free : 0u;
@@ -121,15 +129,15 @@ __device__ bool build_table(InfLds &L, uint32_t *tab, const int main_bits, const
         const int l = lens[s];
         if (!l) continue;
         const uint32_t c = L.code[s];
-        const uint32_t se = kind == 0 ? ll_entry(s) : kind == 1 ? d_entry(s) : cl_entry(s);
         if (l <= main_bits) {
-            const uint32_t e = se | (uint32_t)l;
-            for (uint32_t k = c; k < (uint32_t)main_size; k += 1u << l) tab[k] = e;
+            const uint32_t e = kind == 0 ? ll_entry(s, (uint32_t)l) : kind == 1 ? d_entry(s, (uint32_t)l) : cl_entry(s, (uint32_t)l);
+            for (uint32_t k = c; k < (uint32_t)main_size; k += 1u << l) tab[k] = (uint16_t)e;
         } else {
             const uint32_t link = tab[c & (uint32_t)(main_size - 1)];
-            const int sb = (int)((link >> 8) & 0xfu), start = (int)(link >> 16);
-            const uint32_t e = se | (uint32_t)(l - main_bits);
-            for (uint32_t k = c >> main_bits; k < (1u << sb); k += 1u << (l - main_bits)) tab[start + (int)k] = e;
+            const int sb = (int)(kind == 0 ? ((link >> 3) & 7u) : ((link >> 2) & 15u)) + 1, start = (int)(link >> 6);
+            const uint32_t nb = (uint32_t)(l - main_bits);
+            const uint32_t e = kind == 0 ? ll_entry(s, nb) : kind == 1 ? d_entry(s, nb) : cl_entry(s, nb);
+            for (uint32_t k = c >> main_bits; k < (1u << sb); k += 1u << (l - main_bits)) tab[start + (int)k] = (uint16_t)e;
         }
     }
     __syncthreads();
@@ -150,6 +158,11 @@ __global__ __launch_bounds__(64, MSNV_INFLATE_WAVES) void msnv_inflate_blocks(co
     const int lane = threadIdx.x;
     const uint32_t bi = blockIdx.x;
     if (bi >= n_blocks) return;
+    if (lane < 32) {
+        L.len_be[lane] = lane < 29 ? (uint32_t)k_len_base[lane] << 8 | k_len_extra[lane] : 0u;
+        L.dist_be[lane] = lane < 30 ? (uint32_t)k_dist_base[lane] << 8 | k_dist_extra[lane] : 0u;
+    }
+    __syncthreads();
     InfBlock B = blocks[bi];
     B.in_size = uni(B.in_size); B.out_size = uni(B.out_size);
     const uint8_t *const src = comp + B.in_off;
@@ -242,9 +255,9 @@ __global__ __launch_bounds__(64, MSNV_INFLATE_WAVES) void msnv_inflate_blocks(co
                 int n = 0; uint32_t prev = 0;
                 while (n < hlit + hdist) {
                     refill(14);                                  // (the tail of the stream may hold fewer bits: checked through l > bc below)
-                    const uint32_t e = uni(L.d[bb & 127u]);
-                    if (e & IF_BAD) { ok = false; break; }
-                    const int l = (int)(e & 0xffu), sym = (int)(e >> 16);
+                    const uint32_t e = uni((uint32_t)L.d[bb & 127u]);
+                    if ((e & 3u) != D_SYM) { ok = false; break; }
+                    const int l = (int)((e >> 2) & 15u), sym = (int)(e >> 8);
                     if (l > bc) { ok = false; break; }
                     bb >>= l; bc -= l;
                     if (sym < 16) { if (lane == 0) L.lens[32 + n] = (uint8_t)sym; prev = (uint32_t)sym; ++n; }
@@ -275,33 +288,36 @@ __global__ __launch_bounds__(64, MSNV_INFLATE_WAVES) void msnv_inflate_blocks(co
             bool done = false;
             while (!done) {
                 refill(48);                                      // a literal/length code (<= 15 + 5 bits) and a distance code (<= 15 + 13): 48 bits
-                uint32_t e = uni(L.ll[bb & ((1u << I_LL_BITS) - 1u)]);
+                uint32_t e = uni((uint32_t)L.ll[bb & ((1u << I_LL_BITS) - 1u)]);
                 int used = 0;
-                if (e & IF_SUB) { used = (int)(e & 0xffu); e = uni(L.ll[(e >> 16) + (uint32_t)((bb >> used) & ((1u << ((e >> 8) & 0xfu)) - 1u))]); }
-                if (e & IF_BAD) { fail_ = true; break; }
-                used += (int)(e & 0xffu);
+                if ((e & 7u) == LL_SUB) { used = I_LL_BITS; e = uni((uint32_t)L.ll[(e >> 6) + (uint32_t)((bb >> I_LL_BITS) & ((2u << ((e >> 3) & 7u)) - 1u))]); }
+                const uint32_t kind = e & 7u;
+                if (kind >= LL_SUB) { fail_ = true; break; }          // (a hole of an incomplete code; a link inside a subtable cannot be)
+                used += (int)((e >> 3) & 15u);
                 if (used > bc) { fail_ = true; break; }
                 bb >>= used; bc -= used;
-                if (e & IF_LIT) {
+                if (kind == LL_LIT) {
                     if (op + n_lit >= n_out) { fail_ = true; break; }
-                    if ((uint32_t)lane == n_lit) lit_reg = e >> 16;
+                    if ((uint32_t)lane == n_lit) lit_reg = e >> 8;
                     if (++n_lit == 64u) flush_lits();
                     continue;
                 }
-                if (e & IF_EOB) { done = true; break; }
-                const int xl = (int)((e >> 8) & 0xfu);
+                if (kind == LL_EOB) { done = true; break; }
+                const uint32_t lbe = uni(L.len_be[(e >> 8) & 31u]);
+                const int xl = (int)(lbe & 0xffu);
                 if (xl > bc) { fail_ = true; break; }
-                const uint32_t len = (e >> 16) + (uint32_t)(bb & ((1u << xl) - 1u));
+                const uint32_t len = (lbe >> 8) + (uint32_t)(bb & ((1u << xl) - 1u));
                 bb >>= xl; bc -= xl;
-                uint32_t d = uni(L.d[bb & ((1u << I_D_BITS) - 1u)]);
+                uint32_t d = uni((uint32_t)L.d[bb & ((1u << I_D_BITS) - 1u)]);
                 used = 0;
-                if (d & IF_SUB) { used = (int)(d & 0xffu); d = uni(L.d[(d >> 16) + (uint32_t)((bb >> used) & ((1u << ((d >> 8) & 0xfu)) - 1u))]); }
-                if (d & IF_BAD) { fail_ = true; break; }
-                used += (int)(d & 0xffu);
-                const int xd = (int)((d >> 8) & 0xfu);
+                if ((d & 3u) == D_SUB) { used = I_D_BITS; d = uni((uint32_t)L.d[(d >> 6) + (uint32_t)((bb >> I_D_BITS) & ((2u << ((d >> 2) & 15u)) - 1u))]); }
+                if ((d & 3u) != D_SYM) { fail_ = true; break; }
+                used += (int)((d >> 2) & 15u);
+                const uint32_t dbe = uni(L.dist_be[(d >> 8) & 31u]);
+                const int xd = (int)(dbe & 0xffu);
                 if (used + xd > bc) { fail_ = true; break; }
                 bb >>= used; bc -= used;
-                const uint32_t dist = (d >> 16) + (uint32_t)(bb & ((1u << xd) - 1u));
+                const uint32_t dist = (dbe >> 8) + (uint32_t)(bb & ((1u << xd) - 1u));
                 bb >>= xd; bc -= xd;
                 flush_lits();
                 if (dist > op || len > n_out - op) { fail_ = true; break; }
