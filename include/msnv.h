@@ -308,8 +308,10 @@ int  msnv_dataset_info_get(const msnv_dataset *ds, msnv_dataset_info *out);
  * overlapping mates, token limit); [8] record bytes resident in HBM, [9] records, [10] pieces, [11] samples that took the pre-pass,
  * [12] scan segments whose guessed entry point was wrong and that were walked again, [13] deep (sample, tile) runs dealt into groups by
  * the device form of finalize, [14] samples whose dense block streams (short reads) were laid out by it, [15] rounds the quick route had
- * launched and the careful route took over (a sample that needs the host pre-pass, more far-reaching reads than the list holds). */
-#define MSNV_PACK_STATS 16
+ * launched and the careful route took over (a sample that needs the sequential edits, more far-reaching reads than the list holds), [16] samples
+ * whose depth cap / token limit ran as kernels (round 6; [11] counts the ones the host pre-pass still takes: MSNV_PREPASS=host, a template with
+ * more alignments than the overlap kernel's slots, far-reaching reads). */
+#define MSNV_PACK_STATS 17
 int  msnv_dataset_pack_stats(const msnv_dataset *ds, double *out, int32_t n);
 /* Inspection hook: the bytes of one device column / index table of a finalized dataset ("hdr", "hdr4", "hdr8m", "blk", "seq", "qual",
  * "s_read_base", "s_seq_base", "ref4", "pairs", "work", "chunks", "cov_iv", "cov_pairs", "cov_work").  out = NULL: size query.  The tests

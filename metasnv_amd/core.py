@@ -232,7 +232,7 @@ class Dataset:
         return {k: getattr(i, k) for k, _ in DatasetInfo._fields_}
 
     PACK_STATS = ["scan_ms", "measure_ms", "depth_ms", "emit_ms", "tile_sort_ms", "upload_wall_s", "download_wall_s", "host_prepass_wall_s",
-                  "record_bytes", "records", "pieces", "prepass_samples", "scan_segments_redone", "deep_runs_split", "dense_samples", "quick_rounds_redone"]
+                  "record_bytes", "records", "pieces", "prepass_samples", "scan_segments_redone", "deep_runs_split", "dense_samples", "quick_rounds_redone", "device_edit_samples"]
 
     def pack_stats(self):
         """Cost of the per-read stage on the device so far (msnv_dataset_pack_stats); all zero for a host-packed dataset."""

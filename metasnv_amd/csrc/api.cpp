@@ -1174,7 +1174,7 @@ extern "C" int msnv_dataset_pack_stats(const msnv_dataset *ds, double *out, int3
     if (devpack_sync_pending(*const_cast<msnv_dataset *>(ds))) clear_error();      // (the last round's kernels: their time belongs to the figures)
     const DevPackTables &t = ds->dp;
     const double v[MSNV_PACK_STATS] = {t.ms_scan, t.ms_measure, t.ms_depth, t.ms_emit, t.ms_sort, t.wall_upload_s, t.wall_download_s, t.wall_prepass_s,
-                                       (double)t.raw_bytes, (double)t.n_records, (double)t.n_pieces, (double)t.n_prepass_samples, (double)t.n_scan_redone, (double)t.n_deep_runs_split, (double)t.n_dense_samples, (double)t.n_quick_redone};
+                                       (double)t.raw_bytes, (double)t.n_records, (double)t.n_pieces, (double)t.n_prepass_samples, (double)t.n_scan_redone, (double)t.n_deep_runs_split, (double)t.n_dense_samples, (double)t.n_quick_redone, (double)t.n_device_edit_samples};
     for (int i = 0; i < n; ++i) out[i] = i < MSNV_PACK_STATS ? v[i] : 0.0;
     return MSNV_OK;
 }

@@ -166,6 +166,7 @@ struct DevPackTables {
     // cumulative device-pack accounting (msnv_host_timers: pack_device_wall_s; msnv_devpack_stats)
     double    ms_scan = 0, ms_measure = 0, ms_depth = 0, ms_emit = 0, ms_sort = 0, wall_upload_s = 0, wall_download_s = 0, wall_prepass_s = 0;
     uint64_t  raw_bytes = 0, n_records = 0, n_pieces = 0, n_prepass_samples = 0, n_scan_redone = 0, n_deep_runs_split = 0, n_dense_samples = 0;
+    uint64_t  n_device_edit_samples = 0;     // samples whose depth cap / token limit ran as kernels (msnv_cap_reads, msnv_token_cut) instead of the host pre-pass
     uint64_t  n_quick_redone = 0;    // rounds the quick route had launched and the careful route took over (a sample needs the host pre-pass, far-reaching reads)
 };
 

@@ -66,7 +66,8 @@ struct DpAcc {
 constexpr uint32_t ACC_COPIES = 64;
 enum : uint32_t { ERR_MALFORMED = 1, ERR_TID = 2, ERR_UNSORTED = 3, ERR_QLEN = 4 };
 enum : uint8_t { RF_PILE = 1, RF_COV = 2, RF_MAPPED = 4, RF_OVL = 8 };      // RF_OVL: passes sam.c overlap_push's precondition (a mate may overlap it)
-enum : uint32_t { NEED_CAP = 1, NEED_TOKEN = 2, NEED_OVL = 4 };      // NEED_OVL: too many alignments of one template wait at once for the device's slots
+enum : uint32_t { NEED_CAP = 1, NEED_TOKEN = 2, NEED_OVL = 4, NEED_BIGC = 8 };      // NEED_OVL: too many alignments of one template wait at once for the device's slots; NEED_BIGC (with NEED_TOKEN):
+                                                                                      // an element longer than the records' tables can say -- both are the host pre-pass's
 
 __device__ __forceinline__ uint32_t ld32(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 __device__ __forceinline__ uint64_t ld64(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
@@ -553,7 +554,7 @@ __device__ __forceinline__ RecMeasure measure_one(const Rec &r, const DpContig *
     const long long absl = r.tlen < 0 ? -(long long)r.tlen : (long long)r.tlen;
     if (pile_ok && !P.ignore_overlaps && !(r.flag & 8u) && (r.flag & 2u) &&                 // sam.c overlap_push's precondition
         !((r.mtid >= 0 && r.tid != r.mtid) || (absl >= 2ll * r.l_seq && (long long)r.mpos >= endpos))) { m.st |= ST_OVL; m.flags |= RF_OVL; }
-    const unsigned long long mc = 4ull + 11ull + (unsigned long long)(ins > del ? ins : del);      // pack.cpp: max_element_chars
+    const unsigned long long mc = 4ull + ((ins | del) ? 11ull + (unsigned long long)(ins > del ? ins : del) : 0ull);      // pack.cpp: max_element_chars
     m.maxc = (uint32_t)(mc < 0x7fffffffull ? mc : 0x7fffffffull);
     m.end = (uint32_t)(endpos < 0xffffffffll ? endpos : 0xffffffffll);
     if (cov_ok) { m.flags |= RF_COV; m.niv = n_iv; if (beyond) m.st |= ST_BEYOND; }
@@ -699,159 +700,18 @@ __global__ __launch_bounds__(256) void msnv_measure_reads(const uint8_t *raw, co
 // ------------------------------------------------------------------------------------------ depth at every read start
 // pack.cpp keeps the pileup reads of a sample in a heap by reference end (sam.c bam_plp_push [EXT], sample-local): when a read starts,
 // the ones that ended at or before its start are popped, then it is pushed -- depth = reads alive, itself included; the sum of their
-// longest possible pileup elements bounds the sample's base string there (snpCall's token limit).  Here, without a sort (round 5; rounds
-// 1-4 merged the starts and the ends of a round with a radix sort of 2 N keys): the pileup reads of the round are listed in file order
-// (msnv_pile_gather).  A read that is alive at the start p of read r began after p - W, W = the longest reference span of a read of the
-// round: the reads alive at r are r itself and those of the WINDOW of reads of its run -- (sample, contig) -- that start in (p - W, p],
-// before r, and end beyond p: a search back along the sorted starts and one pass over about `depth` neighbours' cache lines.  Reads that
-// span more than SPAN_OUT positions (a reference skip; none in a metaSNV run) do not widen the window: they are few, listed by
-// themselves (msnv_measure_reads) and looked at by every read.  The same pass numbers the runs and the (run, first tile) groups of reads
-// that the tile order of the pieces is built from (inclusive scan of two flags, packed into one 64-bit sum).
-struct RunGrpIn {                                                  // element r of that scan's input: run start << 32 | group start
-    const uint4 *rd; const uint32_t *ftile;                        // rd: {start, end, contig, sample | longest pileup element << 12} of pileup read r
-    __device__ unsigned long long operator()(uint32_t r) const {
-        bool run = r == 0;
-        if (!run) { const uint4 a = rd[r - 1], b = rd[r]; run = a.z != b.z || ((a.w ^ b.w) & 0xfffu) != 0u; }
-        return (unsigned long long)(run ? 1u : 0u) << 32 | ((run || ftile[r - 1] != ftile[r]) ? 1u : 0u);
-    }
-};
-__global__ __launch_bounds__(256) void msnv_pile_gather(const RecCnt *r_cnt, const RecCnt *blk_pre, uint32_t n_rec, const uint16_t *rec_sample, const unsigned long long *r_key, const uint32_t *r_end,
-                                                        const uint32_t *r_maxc, const uint32_t *r_ftile, uint32_t span_out, uint4 *p_rd, uint32_t *p_ftile, uint32_t *p_rec) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool pile = i < n_rec && r_cnt[i].pile;
-    const unsigned long long m = __ballot(pile);
-    if (!pile) return;
-    const uint32_t r = blk_pre[i / PB].pile + (uint32_t)__builtin_popcountll(m & ((1ull << (threadIdx.x & 63u)) - 1ull));
-    const unsigned long long k = r_key[i];
-    const uint32_t pos = (uint32_t)k & 0x7fffffffu, e = r_end[i] < 0x7fffffffu ? r_end[i] : 0x7fffffffu;
-    // (an outlier never counts in the window: it is counted from its list; the element length saturates at 2^20 - 1, far beyond any token
-    // limit: a sum that holds a saturated term sends the sample to the host pre-pass, which counts exactly)
-    const uint32_t mc = r_maxc[i] < 0xfffffu ? r_maxc[i] : 0xfffffu;
-    p_rd[r] = make_uint4(pos, e - pos > span_out ? 0u : e, (uint32_t)(k >> 32), (uint32_t)rec_sample[i] | mc << 12);
-    p_ftile[r] = r_ftile[i]; p_rec[r] = i;
-}
-constexpr uint32_t DEPTH_BACK = 256;                               // reads in front of a workgroup's 256 that its LDS window holds (16 KB in all)
-__global__ __launch_bounds__(256) void msnv_depth(const unsigned long long *rg, uint32_t n_pile, const uint4 *p_rd,
-                                                  const uint32_t *p_ftile, const uint32_t *p_rec, const RecCnt *r_cnt, const uint32_t *ovr, DpParams P, uint32_t window, const uint32_t *outliers,
-                                                  uint32_t n_out, const uint16_t *rec_sample, const unsigned long long *r_key, const uint32_t *r_end, const uint32_t *r_maxc,
-                                                  uint16_t *r_depth, uint32_t *run_first, uint32_t *run_f1, uint32_t *grp_first, uint32_t *grp_md, DpAcc *acc, uint32_t *misc) {
-    __shared__ uint4 s_rd[DEPTH_BACK + 256];
-    const uint32_t blk0 = blockIdx.x * blockDim.x, r = blk0 + threadIdx.x;
-    const bool valid = r < n_pile;
-    {   // the workgroup's reads and DEPTH_BACK reads in front of them (entry k = read lds_lo + k)
-        const uint32_t lds_lo = blk0 > DEPTH_BACK ? blk0 - DEPTH_BACK : 0u, lds_n = (blk0 + 256u < n_pile ? blk0 + 256u : n_pile) - lds_lo;
-        for (uint32_t k = threadIdx.x; k < lds_n; k += 256u) s_rd[k] = p_rd[lds_lo + k];
-    }
-    __syncthreads();
-    uint32_t gi = 0xffffffffu, depth = 0, spill = 0;
-    if (valid) {
-        const uint4 me4 = p_rd[r];
-        const uint32_t p = me4.x, i = p_rec[r];
-        const unsigned long long me = rg[r];
-        const uint32_t g = (uint32_t)(me >> 32) - 1u;
-        gi = (uint32_t)me - 1u;
-        uint4 prev = make_uint4(0, 0, 0xffffffffu, 0xffffffffu);
-        if (r > 0) prev = p_rd[r - 1];
-        const uint32_t my_sample = me4.w & 0xfffu;
-        const bool run_start = r == 0 || prev.z != me4.z || (prev.w & 0xfffu) != my_sample;
-        const uint32_t ft = p_ftile[r], ftp = run_start ? 0u : p_ftile[r - 1];
-        if (run_start) run_first[g] = r;
-        if (run_start || ftp != ft) grp_first[gi] = i;
-        if (!run_start && ftp > ft) atomicOr(&misc[MISC_SORT], 1u);                         // (a read whose first aligned base lies in an earlier tile than its predecessor's: leading deletions)
-        // ---- the window: back along the reads of the run while they start beyond p - window.  The workgroup's 256 reads and the DEPTH_BACK
-        // reads in front of them are in LDS (one coalesced load each; a chain of dependent global loads per read made this kernel 0.8 ms on
-        // the benchmark shape); a window that reaches further back goes on in global memory, four reads a step
-        unsigned long long chars = me4.w >> 12;
-        depth = 1;
-        const unsigned long long pw = p;                                                    // a read is inside while start + window > p
-        uint32_t j = r;                                                                     // reads [j, r) have been looked at
-        bool out = false;
-        {
-            const uint32_t lds_lo = blk0 > DEPTH_BACK ? blk0 - DEPTH_BACK : 0u;            // first read held in LDS
-            while (j > lds_lo) {
-                const uint4 x = s_rd[j - 1u - lds_lo];
-                if (x.z != me4.z || (x.w & 0xfffu) != my_sample || (unsigned long long)x.x + window <= pw) { out = true; break; }
-                if (x.y > p) { ++depth; chars += x.w >> 12; }
-                --j;
-            }
-        }
-        while (!out && j > 0) {
-            const uint32_t n4 = j < 4u ? j : 4u;
-            uint4 x[4];
-#pragma unroll
-            for (uint32_t t = 0; t < 4u; ++t) x[t] = t < n4 ? p_rd[j - 1u - t] : make_uint4(0, 0, 0xffffffffu, 0xffffffffu);
-#pragma unroll
-            for (uint32_t t = 0; t < 4u; ++t) {
-                if (out) break;
-                if (x[t].z != me4.z || (x[t].w & 0xfffu) != my_sample || (unsigned long long)x[t].x + window <= pw) { out = true; break; }
-                if (x[t].y > p) { ++depth; chars += x[t].w >> 12; }
-            }
-            j -= n4;
-        }
-        for (uint32_t k = 0; k < n_out; ++k) {                                              // the round's far-reaching reads: alive here when of this run, before r, ending beyond p
-            const uint32_t o = outliers[k];
-            if (o < i && rec_sample[o] == my_sample && (uint32_t)(r_key[o] >> 32) == me4.z && r_end[o] > p) { ++depth; chars += r_maxc[o]; }
-        }
-        // first read of the run whose end lies beyond position 1 (the first line under metaSNV's `name 1 LEN` split): a read that starts at
-        // position >= 1 always qualifies, so only the reads at position 0 and the first one behind them can be it -- a handful of atomics per run
-        if (r_end[i] > 1u && (run_start || p == 0u || prev.x == 0u)) atomicMin(&run_f1[g], r);
-        spill = r_cnt[i].spill;
-        const uint32_t ov = ovr ? ovr[i] : 0u;
-        if (ov & 1u) { depth = ov >> 16; r_depth[i] = (uint16_t)depth; }
-        else {
-            r_depth[i] = (uint16_t)(depth < 0xffffu ? depth : 0xffffu);
-            uint32_t need = 0;
-            if (P.max_depth > 0 && depth - 1u > (uint32_t)P.max_depth) need |= NEED_CAP;         // live.size() > max_depth before the push
-            if (P.token_limit > 0 && chars >= (unsigned long long)P.token_limit) need |= NEED_TOKEN;
-            if (need) atomicOr(&acc[(size_t)my_sample * ACC_COPIES].need_host, need);
-            depth = depth < 0xffffu ? depth : 0xffffu;
-        }
-    }
-    // depth bounds per group: [2 gi] over all its reads (every read has a piece in its first tile), [2 gi + 1] over the reads that leave
-    // pieces in the tile behind.  A wavefront's reads nearly always share one group: one atomic per wavefront and bound then.
-    const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)gi);
-    if (__all(gi == g0 || !valid)) {
-        uint32_t a = valid ? depth : 0u, b = (valid && spill) ? depth : 0u;
-        for (int o = 32; o > 0; o >>= 1) { const uint32_t x = __shfl_xor(a, o), y = __shfl_xor(b, o); a = x > a ? x : a; b = y > b ? y : b; }
-        if ((threadIdx.x & 63u) == 0 && g0 != 0xffffffffu) { atomicMax(&grp_md[2u * g0], a); if (b) atomicMax(&grp_md[2u * g0 + 1u], b); }
-    } else if (valid) { atomicMax(&grp_md[2u * gi], depth); if (spill) atomicMax(&grp_md[2u * gi + 1u], depth); }
-}
+// longest possible pileup elements bounds the sample's base string there (snpCall's token limit).  Here, without a sort (rounds 1-4 merged
+// the starts and the ends of a round with a radix sort of 2 N keys): a read that is alive at the start p of read r began after p - W, W = the
+// longest reference span of a read of the round: the reads alive at r are r itself and those of the WINDOW of reads of its run -- (sample,
+// contig) -- that start in (p - W, p], before r, and end beyond p: a walk back over the records in front (msnv_depth2, below).  Reads that
+// span more than SPAN_OUT positions (a reference skip; none in a metaSNV run) do not widen the window: they are few, listed by themselves
+// and looked at by every read.
+constexpr uint32_t DEPTH_BACK = 256;                               // records in front of a workgroup's 256 that msnv_depth2's LDS window holds (round 5: 768; 0.65 -> 0.60 ms)
 struct DpRun { uint32_t sample; int32_t tid, first_any, first_from1; };
-__global__ void msnv_run_table(uint32_t n_runs, const uint32_t *run_first, const uint32_t *run_f1, const uint4 *p_rd, DpRun *runs) {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n_runs) return;
-    const uint32_t r = run_first[g];
-    DpRun o;
-    o.sample = p_rd[r].w & 0xfffu; o.tid = (int32_t)p_rd[r].z; o.first_any = (int32_t)p_rd[r].x;
-    const uint32_t f = run_f1[g];
-    if (f == 0xffffffffu) o.first_from1 = -1;
-    else { const int32_t q = (int32_t)p_rd[f].x; o.first_from1 = q > 1 ? q : 1; }
-    runs[g] = o;
-}
 // The (run, first tile) groups: where a group's pieces lie in tile order -- [a, b) the pieces in its own tile, [b, end) the ones its reads
 // leave in the tile behind -- and the depth bounds of the two parts, for the host; {pieces, next-tile pieces} before every group's first read
-// (grp_pre; entry n_groups: the round's totals), for the kernel that places the headers.
+// (grp_pre; entry n_groups: the round's totals), for the kernels that place the headers.
 struct DevGroupRec { uint32_t sample; int32_t tid; uint32_t tile, a, b, end, md_own, md_next; };
-__global__ void msnv_group_pre(uint32_t n_groups, const uint32_t *grp_first, uint32_t n_rec, const RecCnt *blk_pre, const RecCnt *r_cnt, uint2 *grp_pre) {
-    const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gi > n_groups) return;
-    const uint32_t f = gi < n_groups ? grp_first[gi] : n_rec;
-    RecCnt v = blk_pre[f / PB];
-    for (uint32_t j = f & ~(PB - 1u); j < f; ++j) { v.npiece += r_cnt[j].npiece; v.spill += r_cnt[j].spill; }
-    grp_pre[gi] = make_uint2(v.npiece, v.spill);
-}
-__global__ void msnv_group_table(uint32_t n_groups, const uint32_t *grp_first, const uint2 *grp_pre, const uint16_t *rec_sample, const unsigned long long *r_key, const uint32_t *r_ftile,
-                                 const uint32_t *grp_md, DevGroupRec *out) {
-    const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gi >= n_groups) return;
-    const uint32_t f = grp_first[gi];
-    const uint2 pf = grp_pre[gi], pe = grp_pre[gi + 1];
-    DevGroupRec o;
-    o.sample = rec_sample[f]; o.tid = (int32_t)(r_key[f] >> 32); o.tile = r_ftile[f];
-    o.a = pf.x; o.b = pe.x - (pe.y - pf.y); o.end = pe.x; o.md_own = grp_md[2u * gi]; o.md_next = grp_md[2u * gi + 1u];
-    out[gi] = o;
-}
-
 struct DpSampleDst { uint8_t *seq, *qual; unsigned long long pbase0; uint32_t cut_marks, pad; };      // where a sample's columns lie in the round's buffer, its first piece
 // ------------------------------------------------------------------------------------------ round 6: scan and measure in ONE walk
 // The quick scan's lane (one per sub-segment of a stream, above) has every record's header line in hand when it reads block_size; the
@@ -1104,7 +964,7 @@ __global__ __launch_bounds__(256) void msnv_scan_write2(const SubStream *ss, uin
                 if ((I.flags & 1u) || (bf & 4u)) atomicOr(&misc[MISC_SORT], 1u);
                 if (I.flags & 2u) { atomicMax(&overhang[I.over_tid], I.over_end); misc[MISC_OVERHANG] = 1u; }
                 if (I.flags & 4u) misc[MISC_OVERHANG] = 2u;             // (two contigs' worth in one sub-segment: the host takes the careful route)
-                if (I.maxc_big && P.token_limit > 0) need |= NEED_TOKEN;      // (an element longer than the slot holds: the host pre-pass counts exactly)
+                if (I.maxc_big && P.token_limit > 0) need |= NEED_TOKEN | NEED_BIGC;      // (an element longer than the slot holds: the host pre-pass counts exactly)
             }
         }
         const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)si);
@@ -1235,7 +1095,7 @@ __global__ __launch_bounds__(256) void msnv_tables_from_measure(uint32_t n_rec, 
             sf = (unsigned long long)(run ? 1u : 0u) << 32 | (grp ? 1u : 0u);
             const uint32_t span = r_end[i] - ((uint32_t)key & 0x7fffffffu);
             outl = span > span_out ? 1u : 0u;
-            if (r_maxc[i] >= MAXC_SAT && P.token_limit > 0) atomicOr(&acc[(size_t)s * ACC_COPIES].need_host, NEED_TOKEN);
+            if (r_maxc[i] >= MAXC_SAT && P.token_limit > 0) atomicOr(&acc[(size_t)s * ACC_COPIES].need_host, NEED_TOKEN | NEED_BIGC);
         }
         const uint32_t mc = r_maxc[i] < MAXC_SAT ? r_maxc[i] : MAXC_SAT;
         T.rd[i] = make_uint4((uint32_t)key, r_end[i], (uint32_t)(key >> 32), (s & 0xfffu) | outl << 12 | mc << 13);
@@ -1247,7 +1107,8 @@ __global__ __launch_bounds__(256) void msnv_tables_from_measure(uint32_t n_rec, 
 // records' tables).  A record that is no pileup read is stepped over by its neighbours' walks; everything else is msnv_depth's.
 __global__ __launch_bounds__(256) void msnv_depth2(uint32_t n_rec, const uint4 *rd, const uint8_t *r_flags, const unsigned long long *r_rg, const RecCnt *r_pre, const uint32_t *r_ftile,
                                                    const uint32_t *ovr, DpParams P, const uint32_t *misc_span, const uint32_t *outliers, const uint32_t *misc_nout,
-                                                   uint16_t *pdepth, const uint2 *grp_pre, uint32_t in_order, uint32_t *run_first, uint32_t *run_f1, uint32_t *grp_first, uint32_t *grp_md, DpAcc *acc) {
+                                                   uint16_t *pdepth, const uint2 *grp_pre, uint32_t in_order, uint32_t *run_first, uint32_t *run_f1, uint32_t *grp_first, uint32_t *grp_md, DpAcc *acc,
+                                                   uint32_t *r_depth0, uint32_t *hot, uint32_t *hot_n) {       // (the careful route's, may be NULL: the depth of every pileup read, the reads whose sample's base string may reach the token limit)
     __shared__ uint4 s_rd[DEPTH_BACK + 256];
     __shared__ uint8_t s_fl[DEPTH_BACK + 256];
     const uint32_t blk0 = blockIdx.x * blockDim.x, i = blk0 + threadIdx.x;
@@ -1302,12 +1163,17 @@ __global__ __launch_bounds__(256) void msnv_depth2(uint32_t n_rec, const uint4 *
         const RecCnt pa = r_pre[i], pb = r_pre[i + 1u];
         spill = pb.spill - pa.spill;
         const uint32_t ov = ovr ? ovr[i] : 0u;
-        if (ov & 1u) depth = ov >> 16;
+        if ((ov & 9u) == 1u) depth = ov >> 16;                                              // (the host pre-pass's; 9: msnv_cap_reads has decided who enters, the depth is this walk's)
         else {
-            uint32_t need = 0;
-            if (P.max_depth > 0 && depth - 1u > (uint32_t)P.max_depth) need |= NEED_CAP;         // live.size() > max_depth before the push
-            if (P.token_limit > 0 && chars >= (unsigned long long)P.token_limit) need |= NEED_TOKEN;
-            if (need) atomicOr(&acc[(size_t)my_sample * ACC_COPIES].need_host, need);
+            if (r_depth0) r_depth0[i] = depth;
+            const bool tok = P.token_limit > 0 && chars >= (unsigned long long)P.token_limit;
+            if (tok && hot) hot[atomicAdd(hot_n, 1u)] = i;
+            if (!(ov & 1u)) {
+                uint32_t need = 0;
+                if (P.max_depth > 0 && depth - 1u > (uint32_t)P.max_depth) need |= NEED_CAP;     // live.size() > max_depth before the push
+                if (tok) need |= NEED_TOKEN;
+                if (need) atomicOr(&acc[(size_t)my_sample * ACC_COPIES].need_host, need);
+            }
             depth = depth < 0xffffu ? depth : 0xffffu;
         }
         // the depth of every piece of this read, at the piece's header slot (round 6: the emit kernels do not wait for this kernel any more --
@@ -1334,6 +1200,194 @@ __global__ __launch_bounds__(256) void msnv_depth2(uint32_t n_rec, const uint4 *
             for (int o = 32; o > 0; o >>= 1) { const uint32_t x = __shfl_xor(a, o), y = __shfl_xor(b, o); a = x > a ? x : a; b = y > b ? y : b; }
             if ((threadIdx.x & 63u) == 0) { atomicMax(&grp_md[2u * g_any], a); if (b) atomicMax(&grp_md[2u * g_any + 1u], b); }
         } else if (valid) { atomicMax(&grp_md[2u * gi], depth); if (spill) atomicMax(&grp_md[2u * gi + 1u], depth); }
+    }
+}
+// ------------------------------------------------------------------------------------------ the depth cap and the token limit as kernels (round 6)
+// The two sequential edits that were the host pre-pass's alone (pack.cpp: filter_and_edit's heap, apply_token_limit), for the samples whose
+// records can trigger them (NEED_CAP / NEED_TOKEN, raised by msnv_depth2's bounds).
+//
+// mpileup -d (sam.c bam_plp_push [EXT], sample-local as pack.cpp restates it): a read that is not the first to start at its position is
+// dropped when more than max_depth reads that ENTERED are alive there.  Sequential -- a dropped read is not alive for the next one -- but only
+// where it can matter: msnv_depth2 has counted, for every read, the pileup reads alive at its start whether they entered or not (depth0); a
+// read with depth0 - 1 <= max_depth enters whatever was dropped before it.  The others ("uncertain": a deep stack's) are taken one by one,
+// by the sample's ONE wavefront: alive and entered = depth0 - 1 - (dropped reads still alive), the latter kept as a count and, per end
+// position, in a ring of CAP_RING positions in LDS (a read spans at most SPAN_OUT = CAP_RING positions here; a round with far-reaching reads
+// keeps the host pre-pass).  Out: the verdict per record in the host pre-pass's form, bit 3 = "the depth is not given: msnv_depth2 counts
+// it" -- the careful route's second pass measures with these verdicts, so the dropped reads are out of every later count, of the
+// overlapping-mate candidates (sam.c overlap_remove) and of the columns.
+constexpr uint32_t CAP_RING = SPAN_OUT;
+__global__ __launch_bounds__(64) void msnv_cap_reads(const uint32_t *samples, const uint32_t *rec_base, const uint4 *rd, const uint8_t *r_flags, const uint32_t *depth0, int max_depth, uint32_t *ovr, uint32_t *fail) {
+    __shared__ uint32_t ring[CAP_RING];                               // dropped reads that end at position e: ring[e mod CAP_RING], for e in (cur, cur + CAP_RING]
+    const uint32_t s = samples[blockIdx.x], lane = threadIdx.x;
+    const uint32_t rb = rec_base[s], re = rec_base[s + 1u];
+    for (uint32_t k = lane; k < CAP_RING; k += 64u) ring[k] = 0u;
+    __syncthreads();
+    uint32_t cur_tid = 0xffffffffu, cur = 0u, c = 0u;                 // c: dropped reads alive at `cur`
+    uint32_t prev_tid = 0xffffffffu, prev_pos = 0u; bool have_prev = false;      // the pileup read before, in file order
+    for (uint32_t base = rb; base < re; base += 64u) {
+        const uint32_t i = base + lane;
+        const bool valid = i < re;
+        const uint8_t fl = valid ? r_flags[i] : (uint8_t)0;
+        const uint4 x = valid ? rd[i] : make_uint4(0u, 0u, 0u, 0u);
+        const bool pile = (fl & RF_PILE) != 0;
+        const unsigned long long m = __ballot(pile), below = m & ((1ull << lane) - 1ull);
+        const int src = below ? 63 - __builtin_clzll(below) : 0;
+        uint32_t ptid = __shfl(x.z, src), ppos = __shfl(x.x, src);
+        bool hp = true;
+        if (!below) { ptid = prev_tid; ppos = prev_pos; hp = have_prev; }
+        const bool first_at = !hp || ptid != x.z || ppos != x.x;
+        const uint32_t d0 = pile ? depth0[i] : 0u;
+        const bool uncertain = pile && !first_at && max_depth > 0 && d0 - 1u > (uint32_t)max_depth;
+        if (m) { const int top = 63 - __builtin_clzll(m); prev_tid = __shfl(x.z, top); prev_pos = __shfl(x.x, top); have_prev = true; }
+        bool dropped = false;
+        unsigned long long um = __ballot(uncertain);
+        while (um) {
+            const int l = __builtin_ctzll(um);
+            um &= um - 1ull;
+            const uint32_t t_l = __shfl(x.z, l), p_l = __shfl(x.x, l), e_l = __shfl(x.y, l), d_l = __shfl(d0, l), w_l = __shfl(x.w, l);
+            if (t_l != cur_tid || p_l - cur >= CAP_RING) {                            // another contig, or beyond every end the ring holds
+                if (c) { for (uint32_t k = lane; k < CAP_RING; k += 64u) ring[k] = 0u; __syncthreads(); }
+                cur_tid = t_l; cur = p_l; c = 0u;
+            } else if (p_l > cur) {
+                if (c) {
+                    uint32_t gone = 0;
+                    for (uint32_t q = lane; q < p_l - cur; q += 64u) { const uint32_t k = (cur + 1u + q) & (CAP_RING - 1u); gone += ring[k]; ring[k] = 0u; }
+                    for (int o = 32; o > 0; o >>= 1) gone += __shfl_xor(gone, o);
+                    c -= gone;
+                    __syncthreads();
+                }
+                cur = p_l;
+            }
+            if (d_l - 1u - c > (uint32_t)max_depth) {                                 // pack.cpp: `live.size() > max_depth`
+                if ((w_l & 0x1000u) || e_l - p_l > CAP_RING) { if (lane == 0) *fail = 1u; }      // (a far-reaching read: not this kernel's)
+                else if (lane == 0) ring[e_l & (CAP_RING - 1u)] += 1u;
+                ++c;
+                if ((int)lane == l) dropped = true;
+                __syncthreads();
+            }
+        }
+        if (valid) ovr[i] = 1u | 8u | ((pile && !dropped) ? 2u : 0u) | ((fl & RF_COV) ? 4u : 0u);
+    }
+}
+// snpCall's token limit (call_vC.cpp:92-111,481-483; pack.cpp: apply_token_limit states what is counted): a sample's base string is cut
+// at token_limit characters, the bases behind the cut are never counted.  Which bases those are is a matter of ONE position: the elements of
+// the reads alive there, in file order, each [^ mapq] base|*|<> [+n ins | -n del] [$] unless its quality is below -Q.  msnv_depth2 lists the
+// read starts where the sum of the alive reads' longest elements reaches the limit (`hot`); the string can only be that long from the LAST
+// read start at such a position up to the next read start (no read arrives in between: the bound only falls).  A workgroup per listed
+// start: position after position, the records from the first one that can be alive here up to the start, 256 at a time: every thread finds
+// its read's element at the position (the CIGAR operation that holds it: pack.cpp's cursor, from the read's start), a scan of the elements'
+// lengths says where each begins, and a base whose character lies at or behind the limit gets bit 7 of its quality set -- the mark
+// piece_lane reads as "below every cutoff" (every quality of such a sample's pileup reads is clamped to 127 first: msnv_token_clamp; the
+// element in front of a deletion is judged by the quality of the NEXT base, which another position may be marking: bit 7 is masked out).
+__global__ void msnv_token_clamp(const uint8_t *tok_sample, const uint16_t *rec_sample, const uint8_t *r_flags, uint32_t n_rec, uint8_t *raw, const unsigned long long *rec_off) {
+    const uint32_t i = blockIdx.x * (blockDim.x / 64u) + threadIdx.x / 64u, lane = threadIdx.x & 63u;
+    if (i >= n_rec || !(r_flags[i] & RF_PILE) || !tok_sample[rec_sample[i]]) return;
+    const Rec r = rec_load(raw + rec_off[i], rec_off[i + 1u] - rec_off[i]);
+    uint8_t *q = raw + (r.qual - raw);
+    for (uint32_t j = lane; j < (uint32_t)r.l_seq; j += 64u) if (q[j] > 127u) q[j] = 127u;
+}
+__device__ __forceinline__ uint32_t decimal_digits_dev(uint32_t v) { uint32_t d = 1; while (v >= 10u) { v /= 10u; ++d; } return d; }
+__global__ __launch_bounds__(256) void msnv_token_cut(const uint32_t *hot, const uint32_t *hot_n, const uint8_t *tok_sample, const uint32_t *rec_base, const uint4 *rd, const uint8_t *r_flags,
+                                                      uint8_t *raw, const unsigned long long *rec_off, const uint32_t *misc_span, DpParams P) {
+    __shared__ uint32_t sh_a, sh_b, sh_lo;
+    __shared__ unsigned long long w_chars[4], w_bound[4];
+    const uint32_t n_hot = *hot_n, window = *misc_span, t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+    const unsigned long long limit = (unsigned long long)P.token_limit;
+    for (uint32_t h = blockIdx.x; h < n_hot; h += gridDim.x) {
+        const uint32_t i = hot[h];
+        const uint4 me = rd[i];
+        const uint32_t s = me.w & 0xfffu;
+        if (!tok_sample[s]) continue;
+        const uint32_t rb = rec_base[s], re = rec_base[s + 1u];
+        __syncthreads();
+        if (t == 0) {                                                                       // the next pileup read of the sample: another start at this position takes the position; else it bounds the stretch
+            uint32_t j = i + 1u;
+            while (j < re && !(r_flags[j] & RF_PILE)) ++j;
+            uint32_t a = 1u, b = 0xffffffffu;
+            if (j < re) { const uint4 y = rd[j]; if (y.z == me.z) { if (y.x == me.x) a = 0u; b = y.x; } }
+            sh_a = a; sh_b = b; sh_lo = rb;
+        }
+        __syncthreads();
+        if (!sh_a) continue;
+        const uint32_t p_end = sh_b;
+        // the first record that can be alive at the start: behind the last pileup read in front that lies outside the window (msnv_depth2's test)
+        for (uint32_t top = i; top > rb;) {
+            const uint32_t n = top - rb < 256u ? top - rb : 256u;
+            uint32_t found = 0;
+            if (t < n) {
+                const uint32_t j = top - 1u - t;
+                if (r_flags[j] & RF_PILE) { const uint4 y = rd[j]; if (y.z != me.z || (unsigned long long)y.x + window <= (unsigned long long)me.x) found = j + 1u; }
+            }
+            if (found) atomicMax(&sh_lo, found);
+            __syncthreads();
+            const bool done = sh_lo != rb;
+            __syncthreads();
+            if (done) break;
+            top -= n;
+        }
+        const uint32_t lo = sh_lo;
+        for (uint32_t p = me.x; p < p_end; ++p) {
+            unsigned long long off = 0, bound = 0;                                          // characters of the string in front of this chunk; sum of the alive reads' longest elements
+            for (uint32_t c0 = lo; c0 <= i; c0 += 256u) {
+                const uint32_t j = c0 + t;
+                uint32_t chars = 0, head2 = 0, maxc = 0; uint8_t *mark = nullptr;
+                if (j <= i && (r_flags[j] & RF_PILE)) {
+                    const uint4 y = rd[j];
+                    if (y.z == me.z && y.x <= p && y.y > p) {
+                        maxc = y.w >> 13;
+                        const uint8_t *rp = raw + rec_off[j];
+                        const Rec r = rec_load(rp, rec_off[j + 1u] - rec_off[j]);
+                        long long x = r.pos, q = 0; uint32_t k = 0, tt = 0; long long l = 0; bool found = false;
+                        for (; k < r.n_cigar; ++k) {
+                            const uint32_t cg = ld32(r.cigar + 4ull * k);
+                            tt = cg & 15u; l = cg >> 4;
+                            if (cg_ref(tt) && (long long)p < x + l) { found = true; break; }
+                            if (cg_ref(tt)) x += l;
+                            if (cg_query(tt)) q += l;
+                        }
+                        if (found) {
+                            const bool is_del = !cg_match(tt);
+                            const long long qpos = is_del ? q : q + ((long long)p - x);
+                            unsigned long long n_indel = 0;
+                            if (!is_del && x + l - 1 == (long long)p && k + 1u < r.n_cigar) {
+                                const uint32_t c2 = ld32(r.cigar + 4ull * (k + 1u)), t2 = c2 & 15u;
+                                if (t2 == C_D || t2 == C_I) n_indel = c2 >> 4;
+                                else if (t2 == C_P && k + 2u < r.n_cigar) {
+                                    for (uint32_t k3 = k + 2u; k3 < r.n_cigar; ++k3) {
+                                        const uint32_t c3 = ld32(r.cigar + 4ull * k3), t3 = c3 & 15u;
+                                        if (t3 == C_I) n_indel += c3 >> 4;
+                                        else if (t3 == C_D || t3 == C_M || t3 == C_N || t3 == C_EQ || t3 == C_X) break;
+                                    }
+                                }
+                            }
+                            uint8_t *qual = r.l_seq > 0 ? raw + (r.qual - raw) : nullptr;
+                            const int qv = (qual && qpos < (long long)r.l_seq) ? (int)(qual[qpos] & 0x7fu) : 0;
+                            if (!P.all_low && qv >= P.c_eff) {                                // (printed at all: bam_plcmd.c's -Q test)
+                                const bool head = p == (uint32_t)r.pos, tail = p == y.y - 1u;
+                                head2 = head ? 2u : 0u;
+                                const unsigned long long ch = head2 + 1ull + (n_indel ? 1ull + decimal_digits_dev((uint32_t)n_indel) + n_indel : 0ull) + (tail ? 1ull : 0ull);
+                                chars = (uint32_t)(ch < 0x7fffffffull ? ch : 0x7fffffffull);
+                                if (!is_del && qual) mark = qual + qpos;
+                            }
+                        }
+                    }
+                }
+                // where this thread's element begins: the chunk's elements in front of it
+                unsigned long long incl = chars, bsum = maxc;
+                for (int o = 1; o < 64; o <<= 1) { const unsigned long long v = __shfl_up(incl, o); if ((int)lane >= o) incl += v; }
+                for (int o = 32; o > 0; o >>= 1) bsum += __shfl_xor(bsum, o);
+                __syncthreads();
+                if (lane == 63u) { w_chars[wv] = incl; w_bound[wv] = bsum; }
+                __syncthreads();
+                unsigned long long before = off;
+                for (uint32_t w = 0; w < wv; ++w) before += w_chars[w];
+                const unsigned long long begin = before + incl - chars;
+                if (mark && begin + head2 >= limit) *mark = (uint8_t)(*mark | 0x80u);           // the base's own character is cut off
+                off += w_chars[0] + w_chars[1] + w_chars[2] + w_chars[3];
+                bound += w_bound[0] + w_bound[1] + w_bound[2] + w_bound[3];
+            }
+            if (bound < limit) break;                                                       // nothing arrives before p_end: the string stays below the limit from here on
+        }
     }
 }
 __global__ void msnv_run_table2(uint32_t n_runs, const uint32_t *run_first, const uint32_t *run_f1, const uint4 *rd, DpRun *runs) {
@@ -1652,9 +1706,9 @@ __device__ __forceinline__ void piece_lane(const Src &src, unsigned long long se
         const unsigned long long qp = qual_o + q0;
         const uint64_t qa = src.ld64(qp), qb = src.ld64(qp + 8), qc = src.ld64(qp + 16), qd = src.ld64(qp + 24);
         if (P.c_eff > 0) low = low_flags8(qa, (uint32_t)P.c_eff) | low_flags8(qb, (uint32_t)P.c_eff) << 8 | low_flags8(qc, (uint32_t)P.c_eff) << 16 | low_flags8(qd, (uint32_t)P.c_eff) << 24;
-        if (cut_marks) {                                                                    // 0xfe: behind snpCall's token limit (pack.cpp: QUAL_CUT), below every cutoff
-            const uint64_t q4[4] = {qa, qb, qc, qd};
-            for (uint32_t t = 0; t < 32u; ++t) if (((q4[t >> 3] >> (8u * (t & 7u))) & 0xffull) == 0xfeull) low |= 1u << t;
+        if (cut_marks) {                                                                    // bit 7: behind snpCall's token limit, below every cutoff (pack.cpp: QUAL_CUT = 0xfe, msnv_token_cut: quality | 0x80;
+            const uint64_t q4[4] = {qa, qb, qc, qd};                                        // every other quality of such a sample's pileup reads has been clamped to 127)
+            for (uint32_t t = 0; t < 32u; ++t) if ((q4[t >> 3] >> (8u * (t & 7u))) & 0x80ull) low |= 1u << t;
         }
     }
     // (no SEQ: quality 0 -- shipped only when the cutoff is 0, where it is not below it)
@@ -2028,26 +2082,6 @@ __global__ __launch_bounds__(256) void msnv_emit_block_slow(const EmitArgs A) {
         __syncthreads();
         if (r < nrec) emit_record(A, gsrc, gout, ro, s_pre[r], sub, f, smp, depth, i);
     }
-}
-
-// per sample: where its records' pieces / seq bytes / intervals start, and the first pileup read (one small copy instead of three per sample)
-struct DpSampleSum { unsigned long long sbase0, first_key, beyond_key; uint32_t pbase0, ibase0, first_end, pad; };
-__global__ void msnv_sample_bases(const uint32_t *rec_base, uint32_t n_samples, const RecCnt *blk_pre, const RecCnt *r_cnt,
-                                  const DpAcc *acc, const unsigned long long *r_key, const uint32_t *r_end, DpSampleSum *out, unsigned long long *sbase0) {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s > n_samples) return;
-    DpSampleSum o{};
-    const uint32_t i = rec_base[s];
-    RecCnt pre = blk_pre[i / PB];
-    for (uint32_t j = i & ~(PB - 1u); j < i; ++j) pre = cnt_add(pre, r_cnt[j]);
-    o.sbase0 = pre.seqb; o.pbase0 = pre.npiece; o.ibase0 = pre.niv;
-    sbase0[s] = o.sbase0;
-    if (s < n_samples) {
-        const DpAcc a = acc[(size_t)s * ACC_COPIES];              // (folded: msnv_acc_fold)
-        if (a.first_pile != ~0ull) { o.first_key = r_key[a.first_pile]; o.first_end = r_end[a.first_pile]; }
-        if (a.beyond != ~0ull) o.beyond_key = r_key[a.beyond];
-    }
-    out[s] = o;
 }
 
 // behind the last piece of every sample: 32 bytes of N and their flags (pack.cpp: pack_sample's tail padding)
@@ -2919,6 +2953,8 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
         uint32_t *d_recbase = nullptr; unsigned long long *d_send = nullptr;
         uint32_t *d_ovr = nullptr;
         bool have_ovr = false;
+        uint32_t *d_depth0 = nullptr, *d_hot = nullptr, *d_hotn = nullptr, *d_capfail = nullptr;      // (careful route: msnv_cap_reads / msnv_token_cut)
+        std::vector<uint32_t> dev_cap, dev_tok;                      // samples whose depth cap / token limit the kernels take
         DpSampleSum2 *d_sum = nullptr; unsigned long long *d_ss0 = nullptr, *d_pb = nullptr; uint32_t *d_slow = nullptr;
         uint64_t seq_bound = 0, qual_bound = 0;
         struct Held {                                                // the round's lasting buffers, this function's until the round is known to stand
@@ -2984,8 +3020,9 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
         auto launch_depth_stage = [&](hipStream_t sx) -> int {
             HIP_TRY(hipMemsetAsync(d_runf1, 0xff, ((uint64_t)n_runs + 1) * 4, sx));
             HIP_TRY(hipMemsetAsync(d_grpmd, 0, 2 * ((uint64_t)n_groups + 1) * 4, sx));
+            if (d_hotn) HIP_TRY(hipMemsetAsync(d_hotn, 0, 4, sx));
             if (NR) hipLaunchKernelGGL(msnv_depth2, grid_for(NR, 256), dim3(256), 0, sx, NR, TB.rd, TB.r_flags, TB.r_rg, TB.r_pre, TB.r_ftile, have_ovr ? d_ovr : nullptr, P, d_misc + MISC_SPAN, d_outl,
-                                       d_misc + MISC_NOUT, w_depth, d_grppre, in_order ? 1u : 0u, d_runfirst, d_runf1, d_grpfirst, d_grpmd, d_acc);
+                                       d_misc + MISC_NOUT, w_depth, d_grppre, in_order ? 1u : 0u, d_runfirst, d_runf1, d_grpfirst, d_grpmd, d_acc, d_depth0, d_hot, d_hotn);
             if (n_runs) hipLaunchKernelGGL(msnv_run_table2, grid_for(n_runs, 256), dim3(256), 0, sx, n_runs, d_runfirst, d_runf1, TB.rd, d_runs);
             hipLaunchKernelGGL(msnv_group_table2, grid_for((uint64_t)n_groups + 1, 256), dim3(256), 0, sx, n_groups, NR, d_grpfirst, TB.r_pre, TB.rd, TB.r_ftile, d_grpmd, (uint2 *)nullptr, d_groups);
             HIP_TRY(hipGetLastError());
@@ -3124,6 +3161,11 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
             DP_BUF(unsigned long long, d_rg, NRa);
             DP_BUF(unsigned long long, d_sf, NRa);
             d_ovr = d_ovr_;
+            DP_BUF(uint32_t, d_depth0_, NRa);
+            DP_BUF(uint32_t, d_hot_, NRa);
+            DP_BUF(uint32_t, d_hotn_, 2);
+            d_depth0 = d_depth0_; d_hot = d_hot_; d_hotn = d_hotn_; d_capfail = d_hotn_ + 1;
+            HIP_TRY(hipMemsetAsync(d_hotn_, 0, 8, st));
             TB = RdTables{SR.d_recoff, SR.d_recsample, d_recbase, d_rd, d_pre, d_ftile, d_flags, d_rg, nullptr, nullptr};
             HIP_TRY(hipMemcpyAsync(SR.d_recoff + NR, &end_all, 8, hipMemcpyHostToDevice, st));
             const size_t depth_bufs_from = pool.next;
@@ -3204,12 +3246,13 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
                 fin_trace("  pack: depth stage (sync)");
                 rec_base_h = SR.rec_base;
                 if (int rc = check_errors()) return rc;
-                if (pass == 1) break;
-                // ---- overlapping mates: the candidates grouped by (sample, name); nothing is edited yet (MSNV_OVERLAP=host: the host pre-pass does it)
+                // ---- overlapping mates: the candidates grouped by (sample, name); nothing is edited yet (MSNV_OVERLAP=host: the host pre-pass does it).
+                // The second pass lists them again when msnv_cap_reads has taken reads out: a dropped read is no candidate (sam.c overlap_remove)
                 const bool ovl_on_host = [] { const char *e = getenv("MSNV_OVERLAP"); return e && e[0] == 'h'; }();
                 bool any_ovl = false;
                 for (size_t s = 0; s < S; ++s) any_ovl |= !MP.ignore_overlaps && acc[s].n_ovl >= 2;
-                if (any_ovl && !ovl_on_host) {
+                if (pass == 1 && !dev_cap.empty()) { n_ovl_reads = 0; n_ovl_groups = 0; }
+                if (any_ovl && !ovl_on_host && (pass == 0 || !dev_cap.empty())) {
                     tm.start();
                     if (int rc = o_flag.alloc(NRa * 4)) return rc;
                     if (int rc = o_rank.alloc(NRa * 4)) return rc;
@@ -3248,11 +3291,32 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
                     }
                     T.ms_depth += tm.stop();
                 }
-                // ---- which samples need the sequential edits of the host stage?
+                if (pass == 1) {
+                    if (!dev_cap.empty()) {
+                        uint32_t cap_fail = 0;
+                        HIP_TRY(hipMemcpy(&cap_fail, d_capfail, 4, hipMemcpyDeviceToHost));
+                        if (cap_fail) return fail(MSNV_EINVAL, "internal: the depth-cap kernel met a read that spans more than its ring holds");
+                    }
+                    break;
+                }
+                // ---- which samples need the sequential edits?  The depth cap and the token limit are kernels (msnv_cap_reads, msnv_token_cut; round 6);
+                // the host pre-pass keeps what they do not take: a template with more alignments than the overlap kernel's slots, an element longer
+                // than the tables can say, a round with far-reaching reads (the cap kernel's ring, the token kernel's window) -- and MSNV_PREPASS=host
+                const bool prepass_on_host = [] { const char *e = getenv("MSNV_PREPASS"); return e && e[0] == 'h'; }();      // (read per round: the tests switch it)
+                const bool kernels_can = !prepass_on_host && misc_h[MISC_NOUT] == 0u && span_out == SPAN_OUT && misc_h[MISC_SPAN] <= CAP_RING;
                 std::vector<size_t> need;
-                for (size_t s = 0; s < S; ++s) if (acc[s].need_host || (ovl_on_host && !MP.ignore_overlaps && acc[s].n_ovl >= 2)) need.push_back(s);
+                for (size_t s = 0; s < S; ++s) {
+                    const uint32_t nh = acc[s].need_host;
+                    if ((nh & (NEED_OVL | NEED_BIGC)) || (nh && !kernels_can) || (ovl_on_host && !MP.ignore_overlaps && acc[s].n_ovl >= 2)) need.push_back(s);
+                    else {
+                        if (nh & NEED_CAP) dev_cap.push_back((uint32_t)s);
+                        if (nh & NEED_TOKEN) dev_tok.push_back((uint32_t)s);
+                    }
+                }
                 for (size_t s : need) host_sample[s] = 1;
-                if (need.empty()) break;
+                T.n_device_edit_samples += dev_tok.size();
+                for (uint32_t s : dev_cap) if (!(acc[s].need_host & NEED_TOKEN)) T.n_device_edit_samples += 1;
+                if (need.empty() && dev_cap.empty()) break;                // (the token limit alone: the reads msnv_depth2 has listed stand)
                 const double t0 = now_s();
                 T.n_prepass_samples += need.size();
                 std::vector<uint32_t> ovr_all((size_t)NR + 1, 0u);
@@ -3288,7 +3352,14 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
                 for (size_t k = 0; k < need.size(); ++k) if (!patched[k].empty()) HIP_TRY(hipMemcpy(raw + s_beg[need[k]], patched[k].data(), patched[k].size(), hipMemcpyHostToDevice));
                 HIP_TRY(hipMemcpy(d_ovr, ovr_all.data(), ((uint64_t)NR + 1) * 4, hipMemcpyHostToDevice));
                 have_ovr = true;
-                T.wall_prepass_s += now_s() - t0;
+                if (!need.empty()) T.wall_prepass_s += now_s() - t0;
+                if (!dev_cap.empty()) {                                    // who enters the pileup of these samples: a wavefront each (into d_ovr, behind the host's verdicts)
+                    DP_BUF(uint32_t, d_caplist, dev_cap.size());
+                    HIP_TRY(hipMemcpyAsync(d_caplist, dev_cap.data(), dev_cap.size() * 4, hipMemcpyHostToDevice, st));
+                    hipLaunchKernelGGL(msnv_cap_reads, dim3((unsigned)dev_cap.size()), dim3(64), 0, st, d_caplist, d_recbase, TB.rd, TB.r_flags, d_depth0, MP.max_depth, d_ovr, d_capfail);
+                    HIP_TRY(hipGetLastError());
+                    HIP_TRY(hipStreamSynchronize(st));                     // (dev_cap's bytes; the second pass takes the pool's buffers back)
+                }
             }
         }
         const uint64_t NB = ((uint64_t)NR + PB - 1) / PB;
@@ -3300,6 +3371,19 @@ int devpack_add_round(msnv_dataset &ds, size_t first, const uint8_t *const *stre
             hipLaunchKernelGGL(msnv_ovl_groups, grid_for(n_ovl_groups, 64), dim3(64), 0, st, o_starts.as<uint32_t>(), n_ovl_groups, n_ovl_reads, o_svals.as<uint32_t>(), raw, TB.rec_off, TB.rd,
                                TB.rec_sample, o_skip.as<uint8_t>());
             HIP_TRY(hipGetLastError());
+            T.ms_depth += tm.stop();
+        }
+        // ================================================================ snpCall's token limit: the bases behind the cut get their mark (behind the mates' edits: the -Q test sees them)
+        if (!dev_tok.empty()) {
+            tm.start();
+            std::vector<uint8_t> tk(S, 0);
+            for (uint32_t s : dev_tok) { tk[s] = 1; cut_marks[s] = 1; }
+            DP_BUF(uint8_t, d_tok, S);
+            HIP_TRY(hipMemcpyAsync(d_tok, tk.data(), S, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(msnv_token_clamp, grid_for((uint64_t)NR * 64u, 256), dim3(256), 0, st, d_tok, TB.rec_sample, TB.r_flags, NR, raw, TB.rec_off);
+            hipLaunchKernelGGL(msnv_token_cut, dim3(4096), dim3(256), 0, st, d_hot, d_hotn, d_tok, d_recbase, TB.rd, TB.r_flags, raw, TB.rec_off, d_misc + MISC_SPAN, P);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(st));                             // (tk's bytes)
             T.ms_depth += tm.stop();
         }
         if (route == 1) fin_trace("  pack: checks, overlaps");

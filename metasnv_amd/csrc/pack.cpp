@@ -338,7 +338,9 @@ static uint32_t max_element_chars(const RecView &r) {
         if (t == C_I) ins += c >> 4;                       // consecutive insertions around a P op print as one suffix
         else if (t == C_D) del = std::max<uint64_t>(del, c >> 4);
     }
-    return (uint32_t)std::min<uint64_t>(0x7fffffffu, 4 + 11 + std::max(ins, del));
+    // `^` mapq, the base, `$`; behind a base that ends an aligned block: sign, up to ten digits, the inserted / deleted bases (round 6: the 11 only
+    // for a read that has an indel at all -- a sample's string is "in reach" of the limit at 2 500 plain reads, not at 667)
+    return (uint32_t)std::min<uint64_t>(0x7fffffffu, 4 + ((ins | del) ? 11 + std::max(ins, del) : 0));
 }
 
 // The mark of a base whose character is cut off.  (It used to be quality 0 -- "the device leaves it out like a base below the cutoff" --

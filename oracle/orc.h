@@ -89,6 +89,8 @@ typedef struct {
     double calling_min_fraction;  /* -p, default 0.01  call_vC.cpp:30  */
     const char *fasta_path;       /* -f or NULL */
     const char *genes_path;       /* -g or NULL */
+    int    token_cap;             /* 0 = the reference's 10000 (call_vC.cpp:482); a smaller value is "snpCall with a shorter token buffer":
+                                     the parity fuzz uses it to reach the cut with shallow pileups (tests/fuzz_parity.py); never the reference's */
 } orc_snpcall_opts;
 
 void orc_snpcall_default_opts(orc_snpcall_opts *o);

@@ -355,7 +355,7 @@ static const gene_t *lookup_gene(const orc_snpcall *sc, long lP) {
 /* ------------------------------------------------------------------ API */
 void orc_snpcall_default_opts(orc_snpcall_opts *o) {
     o->min_coverage = 4; o->calling_threshold = 4; o->calling_min_fraction = 0.01;   /* :26-36 */
-    o->fasta_path = NULL; o->genes_path = NULL;
+    o->fasta_path = NULL; o->genes_path = NULL; o->token_cap = 0;
 }
 
 int orc_snpcall_begin(orc_snpcall **out, const orc_snpcall_opts *opts, FILE *pop_out, FILE *indiv_out) {
@@ -410,7 +410,8 @@ static int process_line(orc_snpcall *sc, char *line) {
     if (lLen > 0) line[--lLen] = '\0';                                  /* :475 */
     for (k = 0; k < 10; ++k) memset(sc->cnt[k], 0, ((size_t)sc->nrSamples + 1) * sizeof(long));   /* :477-479 */
 
-    rest = toksplit(line, '\t', tok, TOK_CAP);                          /* :483 */
+    const int tok_cap = (sc->opt.token_cap > 0 && sc->opt.token_cap < TOK_CAP) ? sc->opt.token_cap : TOK_CAP;   /* (tests only: orc.h) */
+    rest = toksplit(line, '\t', tok, tok_cap);                          /* :483 */
     while (*rest) {                                                      /* :490 */
         if (pos == 0) {
             if (strcmp(sc->name, tok) != 0) { free(sc->name); sc->name = strdup(tok); sc->genomeLoaded = 0; }
@@ -449,7 +450,7 @@ static int process_line(orc_snpcall *sc, char *line) {
             }
         }
         ++pos;
-        rest = toksplit(rest, '\t', tok, TOK_CAP);                       /* :540 */
+        rest = toksplit(rest, '\t', tok, tok_cap);                       /* :540 */
     }
 
     cov = get_sum(sc, "actgACTG,.", 0);                                  /* :545 */

@@ -44,7 +44,8 @@ if dom and "FETCH_SIZE" in pmc[dom[0]] and "WRITE_SIZE" in pmc[dom[0]]:
 # ---- the per-read stage (csrc/devpack.hip): HBM traffic of ONE build of the dataset from resident records = sum over its kernels of
 # (2 x FETCH_SIZE + WRITE_SIZE) per launch x launches per build (the bench builds the dataset three times: launches / 3)
 PACK = ("msnv_scan_sub", "msnv_scan_seams", "msnv_scan_write", "msnv_scan_segments", "msnv_compact_offsets", "msnv_measure_reads", "msnv_pile_gather", "msnv_depth", "msnv_run_table",
-        "msnv_group_pre", "msnv_group_table", "msnv_sample_bases", "msnv_emit_block", "msnv_emit_tail", "msnv_acc_fold", "msnv_acc_init", "rocprim")
+        "msnv_group_pre", "msnv_group_table", "msnv_sample_bases", "msnv_emit_block", "msnv_emit_tail", "msnv_acc_fold", "msnv_acc_init", "msnv_sub_bounds", "msnv_sample_layout",
+        "msnv_scan_check", "msnv_scan_fix", "msnv_tables_from_measure", "msnv_group_firsts", "rocprim")      # (substring match: msnv_scan_sub also takes msnv_scan_sub2, msnv_depth takes msnv_depth2 ...)
 builds = 3.0
 pk = {}
 for k, cs in pmc.items():

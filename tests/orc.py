@@ -27,7 +27,7 @@ class MpOpts(C.Structure):
 
 class ScOpts(C.Structure):
     _fields_ = [("min_coverage", C.c_int), ("calling_threshold", C.c_int), ("calling_min_fraction", C.c_double),
-                ("fasta_path", C.c_char_p), ("genes_path", C.c_char_p)]
+                ("fasta_path", C.c_char_p), ("genes_path", C.c_char_p), ("token_cap", C.c_int)]
 
 
 class OrcError(RuntimeError):

@@ -33,6 +33,10 @@ def run_oracle(names, lengths, seqs, samples, bed=None, params=None, ann=None, f
     mp = dict(min_baseq=p.min_baseq, flag_filter=p.flag_filter, count_orphans=p.count_orphans, max_depth=p.max_depth, min_mapq=p.min_mapq,
               ignore_overlaps=p.ignore_overlaps)
     sc = dict(min_coverage=p.min_coverage, calling_threshold=p.calling_threshold, calling_min_fraction=p.min_fraction)
+    if 0 < p.token_limit < 10000:
+        sc["token_cap"] = p.token_limit          # (a shorter token buffer than snpCall's: oracle/orc.h, the fuzz sweep)
+    elif p.token_limit != 10000:
+        raise NotImplementedError("the reference's token holds 10000 characters")
     pop, ind, nl, nb = orc.call(names, lengths, seqs, samples, bed=bed, fasta=fasta if ann else None, genes=ann, mp=mp, sc=sc)
     if not p.drop_first_line:
         raise NotImplementedError("the reference always drops the first line")

@@ -235,6 +235,64 @@ def test_overlapping_mates_are_edited_on_the_device():
     _same_dataset(syn.names, syn.lengths, syn.seqs, samples, params=core.default_params(max_depth=9))
 
 
+def _edit_stats(names, lengths, seqs, samples, params, **env):
+    ctx = core.Context(0)
+    try:
+        with _env(MSNV_PACK="device", **env):
+            ds = core.Dataset(ctx, names, lengths, seqs, params)
+            ds.add_samples_records(samples)
+            st = ds.pack_stats()
+            ds.close()
+        return st
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("kw", [dict(max_depth=9), dict(max_depth=3, count_orphans=1), dict(token_limit=60), dict(token_limit=45, min_baseq=0), dict(max_depth=12, token_limit=40),
+                                dict(max_depth=1, token_limit=41, ignore_overlaps=1)])
+def test_depth_cap_and_token_limit_run_as_kernels(kw):
+    """The two sequential edits that were the host pre-pass's alone -- mpileup's depth cap (-d) and snpCall's 10000-character token -- as kernels
+    (devpack.hip: msnv_cap_reads, msnv_token_cut): no sample takes the host pre-pass, the columns equal the host stage's byte for byte and the
+    calls equal the oracle's (with a token of the same length: oracle/orc.h token_cap); MSNV_PREPASS=host sends the samples through the host
+    pre-pass instead.  Paired reads (the overlapping-mate edits come in front of the token count; a capped read is no candidate), indels
+    (their suffixes count towards the token), clips, low qualities (elements below -Q are not printed)."""
+    syn, samples = synth_case(n_species=2, contig_len=5000, n_samples=5, mean_cov=30.0, sigma_cov=0.6, snv_density=0.03, frac_paired=0.6, frac_indel_reads=0.3, frac_clip_reads=0.1,
+                              frac_lowq=0.2, read_len=75, seed=606)
+    p = core.default_params(min_coverage=2, calling_threshold=2, **kw)
+    _same_dataset(syn.names, syn.lengths, syn.seqs, samples, params=p, many=True)
+    dev = _edit_stats(syn.names, syn.lengths, syn.seqs, samples, p)
+    assert dev["prepass_samples"] == 0 and dev["device_edit_samples"] >= 3, dev
+    host = _edit_stats(syn.names, syn.lengths, syn.seqs, samples, p, MSNV_PREPASS="host")
+    assert host["prepass_samples"] == dev["device_edit_samples"] and host["device_edit_samples"] == 0, host
+    with _env(MSNV_PREPASS="host"):
+        _same_dataset(syn.names, syn.lengths, syn.seqs, samples, params=p, many=True, check_oracle=False)
+
+
+def test_a_deep_stack_is_capped_and_cut_on_the_device():
+    """One position where 9000 reads start (test_overlap_host's stack: 3 characters per read start pass snpCall's REAL 10000-character token) beside
+    a deep plain pileup: the cap drops every read behind the 8000th, the token cuts the string -- both as kernels, against the oracle."""
+    import random
+    rnd = random.Random(5)
+    ref = "".join(rnd.choice("ACGT") for _ in range(1200))
+    recs = []
+    for k in range(9000):
+        q = list(ref[300:360])
+        if k % 3 == 0:
+            q[20] = "A" if ref[320] != "A" else "C"
+        recs.append(bt.make_record(0, 300, "60M", "".join(q), name="s%d" % k, qual=[rnd.choice([10, 20, 30, 40]) for _ in range(60)]))
+    for k in range(3000):                                           # reads that arrive while the stack is alive: all dropped by the cap, or cut
+        st = 301 + k % 50
+        q = list(ref[st:st + 50]); q[5] = "T" if ref[st + 5] != "T" else "G"
+        recs.append((st, bt.make_record(0, st, "20M2D30M", "".join(q[:20] + q[22:] + ["A", "C"]), name="t%d" % k)))
+    stack = [r for r in recs if not isinstance(r, tuple)] + [r for _, r in sorted([r for r in recs if isinstance(r, tuple)], key=lambda t: t[0])]
+    other = bt.records(bt.make_record(0, 290, "60M", ref[290:350], name="o1"), bt.make_record(0, 310, "60M", ref[310:370], name="o2"))
+    p = core.default_params(min_coverage=1, calling_threshold=2)
+    samples = [other, bt.records(*stack)]
+    _same_dataset(["c1"], [len(ref)], [ref], samples, params=p, many=True)
+    st = _edit_stats(["c1"], [len(ref)], [ref], samples, p)
+    assert st["prepass_samples"] == 0 and st["device_edit_samples"] == 1, st
+
+
 def test_errors_carry_the_host_stage_codes():
     from metasnv_amd import _lib
     ref = "ACGT" * 100
