@@ -18,6 +18,7 @@ def run_product(names, lengths, seqs, samples, bed=None, params=None, ann=None, 
         ds.add_sample_records(s)
     info = ds.finalize()
     st = ds.run()
+    info = dict(info, pack_stats=ds.pack_stats())        # (which route the per-read stage took: the tests of the depth cap / token limit look)
     with tempfile.TemporaryDirectory() as td:
         pp, ip = os.path.join(td, "called_SNPs"), os.path.join(td, "indiv_called")
         ds.write_calls(pp, ip, ann, fasta)

@@ -240,6 +240,8 @@ def test_token_limit_of_snpcall_cuts_a_deep_stack_like_the_reference():
     orac = run_oracle(["c1"], [len(ref)], [ref], [other, s], params=p)
     _assert_same(prod, orac)
     assert prod[0].count("\n") > 30
+    if os.environ.get("MSNV_PACK", "d")[0] != "h" and os.environ.get("MSNV_PREPASS", "d")[0] != "h":      # round 6: the cut is a kernel's (devpack.hip: msnv_token_cut), no sample goes through the host pre-pass
+        assert prod[2]["pack_stats"]["device_edit_samples"] == 1 and prod[2]["pack_stats"]["prepass_samples"] == 0, prod[2]["pack_stats"]
     p0 = core.default_params(min_coverage=1, calling_threshold=2, token_limit=0)         # every base counted: not what snpCall does
     assert run_product(["c1"], [len(ref)], [ref], [other, s], params=p0)[0] != prod[0]
 
@@ -277,6 +279,8 @@ def test_read_filters_orphans_mapq_and_depth_cap():
         orac = run_oracle(["ctg"], [len(ref)], [ref], samples, params=p)
         _assert_same(prod, orac)
         assert prod[2]["n_pileup_bases"] == orac[3], kw
+        if "max_depth" in kw and os.environ.get("MSNV_PACK", "d")[0] != "h" and os.environ.get("MSNV_PREPASS", "d")[0] != "h":      # round 6: the cap is a kernel's (msnv_cap_reads)
+            assert prod[2]["pack_stats"]["device_edit_samples"] >= 1 and prod[2]["pack_stats"]["prepass_samples"] == 0, (kw, prod[2]["pack_stats"])
     assert prod[0].count("\n") + prod[1].count("\n") > 0
 
 
