@@ -530,6 +530,19 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # (the builds above gave gigabytes of device and pinned memory back; the driver unmaps them in the background and GPU work that runs meanwhile
+    # is stalled for milliseconds at a time -- 0.43 vs 0.8-1.3 ms per step, every second run on a fresh box.  Let that pass, outside every timed region)
+    time.sleep(0.5)
+    ds.run()                               # (the first pass sizes the sparse buffers)
+    # (... and the clocks, which fell while the device idled, come back up: untimed batches of 20 passes in front of the W warmup steps, until two in a
+    # row take what the fastest one took -- three batches, 25 ms, as a rule; one run in ten needed more)
+    best, close = None, 0
+    for _ in range(25):
+        tb = time.perf_counter(); ds.run_many(20); tb = time.perf_counter() - tb
+        best = tb if best is None else min(best, tb)
+        close = close + 1 if tb <= 1.02 * best else 0
+        if close >= 2 and _ >= 2:
+            break
     for _ in range(a.warmup):
         ds.run()
     if not a.sync_each_step:
