@@ -899,6 +899,180 @@ __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a, NarrowL
     store_item_dirty(a.slot_dirty, w, dirty, tid);
 }
 
+// ------------------------------------------------------------------------------------------
+// msnv_pileup_tiles_lean (round 6): a SPARSE tile's whole-tile item at a cost proportional to its pieces, not to its 2 048 positions.
+// The item above zeroes four rows of bins, adds every piece's start / end and its low-quality bases to them, runs a prefix sum and the gates
+// over all 2 048 positions -- for a tile of the configs[3] shard that holds ~100 pieces and ~4 positions anyone will ever ask about: half of the
+// kernel's vector instructions were that per-tile work (profiles/r05_sparse_ablation.txt).  Here, for an item of ONE chunk (at most 128 pieces):
+//   * only the allele bins exist.  A piece's lanes XOR their 32 bases against the reference as before; a mismatching base above the -Q cutoff
+//     is added to its position's allele bytes, and the add that takes a position from "no allele with t reads" to "one with t" lists it
+//     (the atomic's return value says so: exactly one add per position does) -- the tile's CANDIDATES, a handful;
+//   * no start / end bins, no low-quality bins, no prefix sum: the coverage of a candidate is counted from the pieces that overlap it, out of
+//     the REGISTERS that still hold them -- every lane tests its 32 bases' range against the handful of candidates; a piece that covers one
+//     contributes unless its base there is below the cutoff (its flag bit) or neither the reference's nor one of A C G T (its nibble): what
+//     the bins' arithmetic says, byte for byte.  (First form: a wavefront per candidate over the item's headers, the covering pieces' bytes
+//     asked for from global memory -- two more links in every item's chain of dependent loads: 0.56 ms against the ordinary body's 0.43);
+//   * the gates and the calling rule of fused_tile_gate on those few positions, into the same record list.
+// More candidates than the list holds, or more than one chunk: the workgroup runs the item the ordinary way (the body above; items of 2 - 4
+// chunks through this code, the chunks asked for again for the candidates, took 0.436 ms against 0.382: their fetches stand in a row where the
+// ordinary body has the next chunk in flight).
+// The kernel is a launch of its own behind msnv_pileup_tiles_narrow32 (which keeps its registers: a run-time switch inside it costs the
+// dominant kernel its eight workgroups per CU); MSNV_LEAN=0 sends the whole-tile items through the old launch.
+__device__ __forceinline__ void lean_classify32(NarrowLds &L, const uint32_t lq_all, const uint4 sq, const uint32_t P0, const int vhi, const uint32_t ge) {
+    const uint32_t wi = P0 >> 3, sh = (P0 & 7u) * 4u;
+    const uint32_t w0 = L.ref[wi], w1 = L.ref[wi + 1], w2 = L.ref[wi + 2], w3 = L.ref[wi + 3], w4 = L.ref[wi + 4];
+    const uint32_t vmask = (vhi >= 32) ? 0xffffffffu : ((1u << vhi) - 1u);
+    const uint32_t lq = lq_all & vmask;
+    const uint32_t sw[4] = {sq.x, sq.y, sq.z, sq.w};
+    const uint32_t rw[4] = {__builtin_amdgcn_alignbit(w1, w0, sh), __builtin_amdgcn_alignbit(w2, w1, sh),
+                            __builtin_amdgcn_alignbit(w3, w2, sh), __builtin_amdgcn_alignbit(w4, w3, sh)};
+    const uint32_t v01 = (vhi > 0) ? 0x88888888u : 0u, v23 = (vhi > 16) ? 0x88888888u : 0u;      // (narrow_classify32: the padding behind a piece is reference-filled per 16 bases)
+    uint32_t e[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t x = sw[k] ^ rw[k];
+        e[k] = (((x & 0x77777777u) + 0x77777777u) | x) & (k < 2 ? v01 : v23);
+    }
+    uint32_t E = (e[0] >> 3) | (e[1] >> 2) | (e[2] >> 1) | e[3];
+    if constexpr (SEQ_ALIGN_LOG2 < 3) E &= L.emask[min(max(vhi, 0), 32)];
+    while (E) {
+        const uint32_t b = (uint32_t)__builtin_ctz(E);
+        E &= E - 1u;
+        const uint32_t k = b & 3u, j = (b >> 2) + 8u * k;
+        const unsigned long long pair = (k & 2u) ? ((unsigned long long)sw[3] << 32 | sw[2]) : ((unsigned long long)sw[1] << 32 | sw[0]);
+        if ((lq >> j) & 1u) continue;                                  // below the BQ cutoff: not counted anywhere
+        const uint32_t code = (uint32_t)(pair >> (((b & 1u) << 5) | (b & 28u))) & 0xfu;
+        if ((code & (code - 1u)) != 0u) continue;                      // neither A, C, G nor T: not counted (the candidates' coverage leaves it out)
+        const uint32_t p = P0 + j, inc = __umul24(code, 0x00204081u) & 0x01010101u;
+        const uint32_t old = atomicAdd(&L.al[p], inc), now = old + inc;
+        // bytes >= t: bit 7 of (byte & 0x7f) + (0x80 - t), or of the byte itself (fused_tile_gate)
+        if (((((now & 0x7f7f7f7fu) + ge) | now) & 0x80808080u) && !((((old & 0x7f7f7f7fu) + ge) | old) & 0x80808080u)) {
+            const uint32_t slot = atomicAdd(&L.evn, 1u);
+            if (slot < (uint32_t)N_EVCAP) L.ev[slot] = Pair32{p, 0u};                // (.y: its coverage, counted behind the barrier)
+        }
+    }
+}
+// true: the item is done (its record list written); false: the caller runs it the ordinary way
+__device__ __forceinline__ bool lean_tile(const PileupArgs &a, NarrowLds &L, const WorkItem &w) {
+    const int tid = threadIdx.x;
+    const int lane4 = tid & (N32_LANES - 1), grp = tid / N32_LANES, b0 = 32 * lane4;
+    const uint32_t t0 = w.tile * TILE;
+    const uint32_t sidx = a.tile_stage_idx[w.tile], vb = a.tile_vbeg[w.tile], ve = a.tile_vend[w.tile];      // (asked for now: the gate's links of the item's chain of dependent loads)
+    for (int i = tid; i < (int)(TILE / 8 + 4); i += N_NT) L.ref[i] = (i < (int)(TILE / 8)) ? a.ref4[(t0 >> 3) + i] : 0xffffffffu;
+    {
+        uint4 *z = reinterpret_cast<uint4 *>(L.al);
+#pragma unroll
+        for (int i = 0; i < (int)(TILE / 4) / N_NT; ++i) z[i * N_NT + tid] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    if (tid == 0) { L.evn = 0u; L.ev_base = 0u; }
+    if constexpr (SEQ_ALIGN_LOG2 < 3) {
+        if (tid < 33) {
+            uint32_t m = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int c = min(max(tid - 8 * k, 0), 8); m |= (c >= 8 ? 0xffffffffu : (1u << (4 * c)) - 1u) & (0x11111111u << k); }
+            L.emask[tid] = m;
+        }
+    }
+    const uint32_t ge = (0x80u - a.min_snvs) * 0x01010101u;
+    // a lane's share of a chunk: for each of the two pieces it has a part in, 32 bases, their low-quality flags, where they lie in the tile
+    uint4 sq[N32_ROUNDS]; uint32_t lq[N32_ROUNDS], P0[N32_ROUNDS]; int vh[N32_ROUNDS];
+    auto fetch = [&](const ChunkDesc &cd) {
+        const uint64_t sbase = cd.seq_base;
+        const uint8_t *seq = a.seq + sbase, *qlow = a.qual + (sbase >> 2);
+        const uint32_t qrem = 2u * ((uint32_t)sbase & 3u);
+        uint2 ql[N32_ROUNDS]; uint32_t qsh[N32_ROUNDS];
+#pragma unroll
+        for (int i = 0; i < N32_ROUNDS; ++i) {
+            const uint32_t slot = (uint32_t)(grp + i * N32_GROUPS);
+            const uint2 h = L.hdr[0][slot];                            // (all zero behind the chunk's last piece)
+            const uint32_t len = (h.x >> 11) & 0xffu, s = h.x & (TILE - 1u);
+            vh[i] = min(max((int)len - b0, 0), 32);
+            sq[i] = make_uint4(0u, 0u, 0u, 0u); ql[i] = make_uint2(0u, 0u); qsh[i] = 0u;
+            if (vh[i] > 0) {
+                const uint64_t so = ((uint64_t)(h.x >> 27) << 32 | h.y) << SEQ_ALIGN_LOG2;
+                const uint64_t qbit = (uint64_t)qrem + 2ull * so + (uint32_t)b0;
+                __builtin_memcpy(&ql[i], qlow + (qbit >> 3), 8);
+                qsh[i] = (uint32_t)qbit & 7u;
+                __builtin_memcpy(&sq[i], seq + so + (uint32_t)(b0 >> 1), 16);
+            }
+            P0[i] = vh[i] > 0 ? s + (uint32_t)b0 : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < N32_ROUNDS; ++i) lq[i] = lowq_bits(ql[i], qsh[i]);
+    };
+    {   // the item's ONE chunk: its headers through LDS (a load per piece; straight from global memory, four lanes a header: 0.394 ms against 0.382)
+        const uint32_t nrd = w.first.nrd_flags & 0xffffu;
+        uint2 hmine = make_uint2(0u, 0u);
+        if (tid < N_HCAP && (uint32_t)tid < nrd) hmine = *reinterpret_cast<const uint2 *>(a.hdr8m + w.first.hdr_base + (uint32_t)tid);
+        if (tid < N_HCAP) L.hdr[0][tid] = hmine;
+    }
+    __syncthreads();                                                 // (the bins are zero, the reference and the headers staged)
+    fetch(w.first);
+#pragma unroll
+    for (int i = 0; i < N32_ROUNDS; ++i)
+        if (__any(vh[i] > 0)) lean_classify32(L, lq[i], sq[i], P0[i], vh[i], ge);
+    __syncthreads();
+    const uint32_t n_cand = L.evn;
+    if (n_cand > (uint32_t)N_EVCAP) return false;
+    // ---- the candidates' coverage, from the registers that still hold the pieces: a lane whose 32 bases cover a candidate looks its base up
+    for (uint32_t ci = 0; ci < n_cand; ++ci) {
+        const uint32_t p = L.ev[ci].x;
+#pragma unroll
+        for (int i = 0; i < N32_ROUNDS; ++i) {
+            const uint32_t j = p - P0[i];
+            if (j < (uint32_t)vh[i]) {                                   // (unsigned: P0 <= p < P0 + my bases; a lane without bases has none)
+                const uint32_t word = j < 16u ? (j < 8u ? sq[i].x : sq[i].y) : (j < 24u ? sq[i].z : sq[i].w);
+                const uint32_t nib = (word >> (4u * (j & 7u))) & 15u, rc = (L.ref[p >> 3] >> (4u * (p & 7u))) & 15u;
+                if (!((lq[i] >> j) & 1u) && (nib == rc || (nib & (nib - 1u)) == 0u)) atomicAdd(&L.ev[ci].y, 1u);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- the gates and the calling rule (fused_tile_gate's, on the candidates alone): a thread per candidate
+    TileStage *const st = a.tile_stage + sidx;
+    if ((uint32_t)tid < n_cand) {
+        const uint32_t p = L.ev[tid].x, cov = L.ev[tid].y, word = L.al[p];
+        const uint32_t n[4] = {word & 0xffu, (word >> 8) & 0xffu, (word >> 16) & 0xffu, word >> 24};
+        if (!(cov == 0u || p < vb || p >= ve || (int)cov < a.min_cov || (int)(n[0] + n[1] + n[2] + n[3]) < (int)a.min_snvs)) {
+            const double lim = (double)(int)cov * a.min_frac;                 // call_vC.cpp:588
+            const uint32_t rc = (L.ref[p >> 3] >> (4u * (p & 7u))) & 15u;
+            const bool lc = (reinterpret_cast<const uint8_t *>(a.ref_lc)[(t0 + p) >> 3] >> (p & 7u)) & 1u;
+            const uint32_t solo = w.pair_hi - w.pair_lo == 1u ? 1u : 0u;
+            bool ok = false;
+            uint32_t pop = 0, ind = 0, elig = 0;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                if ((int)n[x] < (int)a.min_snvs) continue;
+                const bool is_pop = (double)n[x] >= lim;
+                ok = true;
+                if (lc && rc == (1u << x)) continue;                          // skip-same-base, case-sensitive (call_vC.cpp:580)
+                if (is_pop) pop |= 1u << x;
+                else if (solo) ind |= 1u << x;
+                else elig |= 1u << x;
+            }
+            if (ok) {
+                const uint32_t slot = atomicAdd(&L.ev_base, 1u);
+                if (slot < STAGE_CAP) st->rec[slot] = StageRec{p | (elig ? 1u << 11 : 0u) | (pop | ind << 4) << 16 | elig << 24, cov, word, 0u};
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t n_rec = L.ev_base;
+    if (n_rec > STAGE_CAP) return false;                                          // (the ordinary way counts again and takes the tile through fused_tile_spill)
+    if (tid == 0) st->count = n_rec;
+    return true;
+}
+__global__ __launch_bounds__(N_NT, MSNV_N32_WAVES) void msnv_pileup_tiles_lean(PileupArgs a) {
+    __shared__ NarrowLds L;
+    a.hdr8 = a.hdr8m;
+    a.work += a.n_fused_lo;                                       // (the whole-tile items: the last ones of the work list)
+    const WorkItem w = a.work[blockIdx.x];
+    const uint32_t nch = w.chunk_hi - w.chunk_lo;
+    if (nch == 1u && a.min_snvs >= 1u && a.min_snvs <= 127u && lean_tile(a, L, w)) return;
+    __syncthreads();
+    pileup_tiles_narrow32_body<true, true>(a, L);
+}
+
 // Work items [0, n_narrow) are ordinary ones; the items behind them hold MERGED groups of shallow (sample, tile) pairs: a chunk
 // holds pieces of several samples, one pass per group instead of one per pair, no per-sample coverage spill and no allele
 // events (narrow_pass).  A pair of ~20 pieces costs a chunk iteration and a pass over all 2048 positions whatever it holds
@@ -2706,9 +2880,12 @@ static int enqueue_pass(DeviceCols &d, const msnv_params &p, hipStream_t st, hip
         a.hdr8m = d.hdr8m; a.n_narrow = n_narrow;
         if (n_narrow && d.dense) hipLaunchKernelGGL(msnv_pileup_tiles_dense, dim3(n_narrow), dim3(N_NT), 0, st, a);      // (the dense layout never merges)
         else {
-            const uint32_t n_all = n_narrow + n_merged;       // (whole-tile items of a sparse cohort are the last items of the same launch)
+            // (whole-tile items of a sparse cohort are the last items of the work list: a launch of their own since round 6, msnv_pileup_tiles_lean)
+            const bool lean_off = [] { const char *e = getenv("MSNV_LEAN"); return e && e[0] == '0'; }();      // (read per pass: the tests switch it)
+            const uint32_t n_lean = (use_stage && !lean_off) ? d.n_work_fused : 0u, n_all = n_narrow + n_merged - n_lean;
             if (n_all && d.allele_planes) hipLaunchKernelGGL(msnv_pileup_tiles_narrow32_planes, dim3(n_all), dim3(N_NT), 0, st, a);
             else if (n_all) hipLaunchKernelGGL(msnv_pileup_tiles_narrow32, dim3(n_all), dim3(N_NT), 0, st, a);
+            if (n_lean) hipLaunchKernelGGL(msnv_pileup_tiles_lean, dim3(n_lean), dim3(N_NT), 0, st, a);
         }
         if (d.n_work > n_narrow + n_merged) {
             PileupArgs b = a;

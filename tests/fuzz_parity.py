@@ -37,6 +37,7 @@ def sweep(n_cases, seed, verbose=True):
         os.environ["MSNV_PACK"] = os.environ.get("FUZZ_PACK") or rk.choice(["device", "device", "device", "host"])
         os.environ["MSNV_SCAN_SEG_KB"] = rk.choice(["1", "8", "256"])
         os.environ["MSNV_SCAN_SUB"] = rk.choice(["64", "200", "4096", "4096"])       # (the quick record scan's sub-segments; a seam that does not hold falls back to the careful kernel)
+        os.environ["MSNV_LEAN"] = random.Random(kw["seed"] + 29).choice(["1", "1", "1", "0"])      # (whole-tile items: msnv_pileup_tiles_lean, or the ordinary body)
         os.environ["MSNV_MERGED_GATHER"] = rk.choice(["", "", "block"])                 # (sparse cohorts: the merged gather with a wavefront / a workgroup per group)
         if rk.random() < 0.15: os.environ["MSNV_SCAN"] = "segments"
         else: os.environ.pop("MSNV_SCAN", None)

@@ -373,15 +373,18 @@ def test_merged_groups_of_shallow_pairs(shallow_pieces, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fuse", ["1", "0"])
-def test_whole_tile_work_items(fuse, monkeypatch):
+@pytest.mark.parametrize("fuse,lean", [("1", "1"), ("1", "0"), ("0", "1")])
+def test_whole_tile_work_items(fuse, lean, monkeypatch):
     """Sparse cohorts: a tile whose pairs fit one merged group is piled up by ONE workgroup, which applies the gates and the calling
     rule itself and leaves a record list for the gate kernel (kernels.hip: fused_tile_gate; pack.cpp: fuse_tile).  MSNV_FUSE=1 forces
-    the path on cohorts of any shape, 0 switches it off.  Same bytes as the oracle for (a) a sparse cohort with a lower-case
+    the path on cohorts of any shape, 0 switches it off.  Round 6: a whole-tile item of one chunk costs what its pieces cost, not what 2 048
+    positions cost (msnv_pileup_tiles_lean: allele bins only, the candidates' coverage counted from the pieces in the registers); MSNV_LEAN=0
+    sends the items through the ordinary body.  Same bytes as the oracle for (a) a sparse cohort with a lower-case
     reference and a BED split, several thresholds; (b) SNVs so dense that tiles hold more candidates than a record list (those tiles
     go through the ordinary gate kernel: test_whole_tile_items_with_more_candidates_than_a_record_list); (c) a cohort where some tiles
     are fused and others hold deep / split pairs."""
     monkeypatch.setenv("MSNV_FUSE", fuse)
+    monkeypatch.setenv("MSNV_LEAN", lean)
     monkeypatch.setenv("MSNV_LAYOUT", "pieces")
     syn, samples = synth_case(n_species=9, contig_len=5000, n_samples=40, mean_cov=4.0, sigma_cov=0.6, snv_density=0.004, error_rate=0.004,
                               frac_absent=0.85, lowercase_ref=1, seed=6100)
