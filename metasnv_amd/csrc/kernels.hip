@@ -903,22 +903,20 @@ __device__ __forceinline__ void pileup_tiles_narrow32_body(PileupArgs a, NarrowL
 // msnv_pileup_tiles_lean (round 6): a SPARSE tile's whole-tile item at a cost proportional to its pieces, not to its 2 048 positions.
 // The item above zeroes four rows of bins, adds every piece's start / end and its low-quality bases to them, runs a prefix sum and the gates
 // over all 2 048 positions -- for a tile of the configs[3] shard that holds ~100 pieces and ~4 positions anyone will ever ask about: half of the
-// kernel's vector instructions were that per-tile work (profiles/r05_sparse_ablation.txt).  Here, for an item of ONE chunk (at most 128 pieces):
+// kernel's vector instructions were that per-tile work (profiles/r05_sparse_ablation.txt).  Here, for an item of at most LEAN_MAX_CHUNKS chunks:
 //   * only the allele bins exist.  A piece's lanes XOR their 32 bases against the reference as before; a mismatching base above the -Q cutoff
-//     is added to its position's allele bytes, and the add that takes a position from "no allele with t reads" to "one with t" lists it
-//     (the atomic's return value says so: exactly one add per position does) -- the tile's CANDIDATES, a handful;
+//     is added to its position's allele bytes, and the add that is an allele's t-th read lists the position (the atomic's return value
+//     says so) -- the tile's CANDIDATES, a handful;
 //   * no start / end bins, no low-quality bins, no prefix sum: the coverage of a candidate is counted from the pieces that overlap it, out of
 //     the REGISTERS that still hold them -- every lane tests its 32 bases' range against the handful of candidates; a piece that covers one
 //     contributes unless its base there is below the cutoff (its flag bit) or neither the reference's nor one of A C G T (its nibble): what
 //     the bins' arithmetic says, byte for byte.  (First form: a wavefront per candidate over the item's headers, the covering pieces' bytes
 //     asked for from global memory -- two more links in every item's chain of dependent loads: 0.56 ms against the ordinary body's 0.43);
 //   * the gates and the calling rule of fused_tile_gate on those few positions, into the same record list.
-// More candidates than the list holds, or more than one chunk: the workgroup runs the item the ordinary way (the body above; items of 2 - 4
-// chunks through this code, the chunks asked for again for the candidates, took 0.436 ms against 0.382: their fetches stand in a row where the
-// ordinary body has the next chunk in flight).
+// More candidates than the list holds, or more than LEAN_MAX_CHUNKS chunks: the workgroup runs the item the ordinary way (the body above).
 // The kernel is a launch of its own behind msnv_pileup_tiles_narrow32 (which keeps its registers: a run-time switch inside it costs the
 // dominant kernel its eight workgroups per CU); MSNV_LEAN=0 sends the whole-tile items through the old launch.
-__device__ __forceinline__ void lean_classify32(NarrowLds &L, const uint32_t lq_all, const uint4 sq, const uint32_t P0, const int vhi, const uint32_t ge) {
+__device__ __forceinline__ void lean_classify32(NarrowLds &L, const uint32_t lq_all, const uint4 sq, const uint32_t P0, const int vhi, const uint32_t t) {
     const uint32_t wi = P0 >> 3, sh = (P0 & 7u) * 4u;
     const uint32_t w0 = L.ref[wi], w1 = L.ref[wi + 1], w2 = L.ref[wi + 2], w3 = L.ref[wi + 3], w4 = L.ref[wi + 4];
     const uint32_t vmask = (vhi >= 32) ? 0xffffffffu : ((1u << vhi) - 1u);
@@ -942,18 +940,19 @@ __device__ __forceinline__ void lean_classify32(NarrowLds &L, const uint32_t lq_
         const unsigned long long pair = (k & 2u) ? ((unsigned long long)sw[3] << 32 | sw[2]) : ((unsigned long long)sw[1] << 32 | sw[0]);
         if ((lq >> j) & 1u) continue;                                  // below the BQ cutoff: not counted anywhere
         const uint32_t code = (uint32_t)(pair >> (((b & 1u) << 5) | (b & 28u))) & 0xfu;
-        if ((code & (code - 1u)) != 0u) continue;                      // neither A, C, G nor T: not counted (the candidates' coverage leaves it out)
-        const uint32_t p = P0 + j, inc = __umul24(code, 0x00204081u) & 0x01010101u;
-        const uint32_t old = atomicAdd(&L.al[p], inc), now = old + inc;
-        // bytes >= t: bit 7 of (byte & 0x7f) + (0x80 - t), or of the byte itself (fused_tile_gate)
-        if (((((now & 0x7f7f7f7fu) + ge) | now) & 0x80808080u) && !((((old & 0x7f7f7f7fu) + ge) | old) & 0x80808080u)) {
+        if ((code & (code - 1u)) != 0u || code == 0u) continue;        // neither A, C, G nor T: not counted (the candidates' coverage leaves it out); (0: never stored -- the packers write the reference's code for '=')
+        const uint32_t p = P0 + j, ash = (uint32_t)__builtin_ctz(code) << 3;
+        const uint32_t old = atomicAdd(&L.al[p], 1u << ash);
+        if (((old >> ash) & 0xffu) + 1u == t) {                           // this allele's t-th read: the position is listed (twice when two alleles get there: the gate keeps the first entry)
             const uint32_t slot = atomicAdd(&L.evn, 1u);
             if (slot < (uint32_t)N_EVCAP) L.ev[slot] = Pair32{p, 0u};                // (.y: its coverage, counted behind the barrier)
         }
     }
 }
 // true: the item is done (its record list written); false: the caller runs it the ordinary way
-__device__ __forceinline__ bool lean_tile(const PileupArgs &a, NarrowLds &L, const WorkItem &w) {
+constexpr uint32_t LEAN_MAX_CHUNKS = 2;          // the pieces of an item stay in the registers until its candidates are counted: two chunks' worth, 256 pieces (three: 64 VGPRs + 16 bytes
+                                                // of scratch a lane, six rounds of header decoding for every item: 0.391 ms against 0.366; one: 0.388)
+__device__ __forceinline__ bool lean_tile(const PileupArgs &a, NarrowLds &L, const WorkItem &w, const uint32_t nch) {
     const int tid = threadIdx.x;
     const int lane4 = tid & (N32_LANES - 1), grp = tid / N32_LANES, b0 = 32 * lane4;
     const uint32_t t0 = w.tile * TILE;
@@ -973,44 +972,52 @@ __device__ __forceinline__ bool lean_tile(const PileupArgs &a, NarrowLds &L, con
             L.emask[tid] = m;
         }
     }
-    const uint32_t ge = (0x80u - a.min_snvs) * 0x01010101u;
-    // a lane's share of a chunk: for each of the two pieces it has a part in, 32 bases, their low-quality flags, where they lie in the tile
-    uint4 sq[N32_ROUNDS]; uint32_t lq[N32_ROUNDS], P0[N32_ROUNDS]; int vh[N32_ROUNDS];
-    auto fetch = [&](const ChunkDesc &cd) {
-        const uint64_t sbase = cd.seq_base;
-        const uint8_t *seq = a.seq + sbase, *qlow = a.qual + (sbase >> 2);
-        const uint32_t qrem = 2u * ((uint32_t)sbase & 3u);
-        uint2 ql[N32_ROUNDS]; uint32_t qsh[N32_ROUNDS];
+    // a lane's share of the item: for each of the (two per chunk) pieces it has a part in, 32 bases, their low-quality flags, where they lie in the tile
+    constexpr int LR = N32_ROUNDS * (int)LEAN_MAX_CHUNKS;
+    uint4 sq[LR]; uint32_t lq[LR], P0[LR]; int vh[LR];
+    ChunkDesc cds[LEAN_MAX_CHUNKS];                                  // (a chunk's descriptor behind the first: one more link in that item's chain)
+    cds[0] = w.first;
 #pragma unroll
-        for (int i = 0; i < N32_ROUNDS; ++i) {
-            const uint32_t slot = (uint32_t)(grp + i * N32_GROUPS);
-            const uint2 h = L.hdr[0][slot];                            // (all zero behind the chunk's last piece)
-            const uint32_t len = (h.x >> 11) & 0xffu, s = h.x & (TILE - 1u);
-            vh[i] = min(max((int)len - b0, 0), 32);
-            sq[i] = make_uint4(0u, 0u, 0u, 0u); ql[i] = make_uint2(0u, 0u); qsh[i] = 0u;
-            if (vh[i] > 0) {
-                const uint64_t so = ((uint64_t)(h.x >> 27) << 32 | h.y) << SEQ_ALIGN_LOG2;
-                const uint64_t qbit = (uint64_t)qrem + 2ull * so + (uint32_t)b0;
-                __builtin_memcpy(&ql[i], qlow + (qbit >> 3), 8);
-                qsh[i] = (uint32_t)qbit & 7u;
-                __builtin_memcpy(&sq[i], seq + so + (uint32_t)(b0 >> 1), 16);
-            }
-            P0[i] = vh[i] > 0 ? s + (uint32_t)b0 : 0u;
+    for (uint32_t c = 1; c < LEAN_MAX_CHUNKS; ++c) { cds[c] = ChunkDesc{}; if (c < nch) cds[c] = a.chunks[w.chunk_lo + c]; }
+    // the headers through LDS (a load per piece; straight from global memory, four lanes a header: 0.394 ms against 0.382): the rows of the
+    // start / end bins this kernel does not use hold them, 128 to a chunk
+    static_assert(sizeof(L.start) + sizeof(L.end) >= LEAN_MAX_CHUNKS * N_HCAP * sizeof(uint2) && offsetof(NarrowLds, end) == sizeof(L.start), "the lean kernel's header staging");
+    uint2 *const hst = reinterpret_cast<uint2 *>(L.start);
+    if (tid < N_HCAP) {
+#pragma unroll
+        for (uint32_t c = 0; c < LEAN_MAX_CHUNKS; ++c) {
+            uint2 h = make_uint2(0u, 0u);
+            if ((uint32_t)tid < (cds[c].nrd_flags & 0xffffu)) h = *reinterpret_cast<const uint2 *>(a.hdr8m + cds[c].hdr_base + (uint32_t)tid);
+            hst[c * N_HCAP + (uint32_t)tid] = h;
         }
-#pragma unroll
-        for (int i = 0; i < N32_ROUNDS; ++i) lq[i] = lowq_bits(ql[i], qsh[i]);
-    };
-    {   // the item's ONE chunk: its headers through LDS (a load per piece; straight from global memory, four lanes a header: 0.394 ms against 0.382)
-        const uint32_t nrd = w.first.nrd_flags & 0xffffu;
-        uint2 hmine = make_uint2(0u, 0u);
-        if (tid < N_HCAP && (uint32_t)tid < nrd) hmine = *reinterpret_cast<const uint2 *>(a.hdr8m + w.first.hdr_base + (uint32_t)tid);
-        if (tid < N_HCAP) L.hdr[0][tid] = hmine;
     }
     __syncthreads();                                                 // (the bins are zero, the reference and the headers staged)
-    fetch(w.first);
+    {
+        uint2 ql[LR]; uint32_t qsh[LR];
 #pragma unroll
-    for (int i = 0; i < N32_ROUNDS; ++i)
-        if (__any(vh[i] > 0)) lean_classify32(L, lq[i], sq[i], P0[i], vh[i], ge);
+        for (int r = 0; r < LR; ++r) {
+            const uint64_t sbase = cds[r / N32_ROUNDS].seq_base;
+            const uint8_t *seq = a.seq + sbase, *qlow = a.qual + (sbase >> 2);
+            const uint32_t qrem = 2u * ((uint32_t)sbase & 3u);
+            const uint2 h = hst[(r / N32_ROUNDS) * N_HCAP + grp + (r % N32_ROUNDS) * N32_GROUPS];      // (all zero behind a chunk's last piece, and for the chunks an item does not have)
+            const uint32_t len = (h.x >> 11) & 0xffu, s = h.x & (TILE - 1u);
+            vh[r] = min(max((int)len - b0, 0), 32);
+            sq[r] = make_uint4(0u, 0u, 0u, 0u); ql[r] = make_uint2(0u, 0u); qsh[r] = 0u;
+            if (vh[r] > 0) {
+                const uint64_t so = ((uint64_t)(h.x >> 27) << 32 | h.y) << SEQ_ALIGN_LOG2;
+                const uint64_t qbit = (uint64_t)qrem + 2ull * so + (uint32_t)b0;
+                __builtin_memcpy(&ql[r], qlow + (qbit >> 3), 8);
+                qsh[r] = (uint32_t)qbit & 7u;
+                __builtin_memcpy(&sq[r], seq + so + (uint32_t)(b0 >> 1), 16);
+            }
+            P0[r] = vh[r] > 0 ? s + (uint32_t)b0 : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < LR; ++r) lq[r] = lowq_bits(ql[r], qsh[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < LR; ++r)
+        if (__any(vh[r] > 0)) lean_classify32(L, lq[r], sq[r], P0[r], vh[r], a.min_snvs);
     __syncthreads();
     const uint32_t n_cand = L.evn;
     if (n_cand > (uint32_t)N_EVCAP) return false;
@@ -1018,7 +1025,7 @@ __device__ __forceinline__ bool lean_tile(const PileupArgs &a, NarrowLds &L, con
     for (uint32_t ci = 0; ci < n_cand; ++ci) {
         const uint32_t p = L.ev[ci].x;
 #pragma unroll
-        for (int i = 0; i < N32_ROUNDS; ++i) {
+        for (int i = 0; i < LR; ++i) {
             const uint32_t j = p - P0[i];
             if (j < (uint32_t)vh[i]) {                                   // (unsigned: P0 <= p < P0 + my bases; a lane without bases has none)
                 const uint32_t word = j < 16u ? (j < 8u ? sq[i].x : sq[i].y) : (j < 24u ? sq[i].z : sq[i].w);
@@ -1033,7 +1040,9 @@ __device__ __forceinline__ bool lean_tile(const PileupArgs &a, NarrowLds &L, con
     if ((uint32_t)tid < n_cand) {
         const uint32_t p = L.ev[tid].x, cov = L.ev[tid].y, word = L.al[p];
         const uint32_t n[4] = {word & 0xffu, (word >> 8) & 0xffu, (word >> 16) & 0xffu, word >> 24};
-        if (!(cov == 0u || p < vb || p >= ve || (int)cov < a.min_cov || (int)(n[0] + n[1] + n[2] + n[3]) < (int)a.min_snvs)) {
+        bool twice = false;                                                       // (a position two alleles of which reached t: its first entry speaks)
+        for (uint32_t q = 0; q < (uint32_t)tid; ++q) twice |= L.ev[q].x == p;
+        if (!(twice || cov == 0u || p < vb || p >= ve || (int)cov < a.min_cov || (int)(n[0] + n[1] + n[2] + n[3]) < (int)a.min_snvs)) {
             const double lim = (double)(int)cov * a.min_frac;                 // call_vC.cpp:588
             const uint32_t rc = (L.ref[p >> 3] >> (4u * (p & 7u))) & 15u;
             const bool lc = (reinterpret_cast<const uint8_t *>(a.ref_lc)[(t0 + p) >> 3] >> (p & 7u)) & 1u;
@@ -1068,7 +1077,7 @@ __global__ __launch_bounds__(N_NT, MSNV_N32_WAVES) void msnv_pileup_tiles_lean(P
     a.work += a.n_fused_lo;                                       // (the whole-tile items: the last ones of the work list)
     const WorkItem w = a.work[blockIdx.x];
     const uint32_t nch = w.chunk_hi - w.chunk_lo;
-    if (nch == 1u && a.min_snvs >= 1u && a.min_snvs <= 127u && lean_tile(a, L, w)) return;
+    if (nch >= 1u && nch <= LEAN_MAX_CHUNKS && a.min_snvs >= 1u && a.min_snvs <= 127u && lean_tile(a, L, w, nch)) return;
     __syncthreads();
     pileup_tiles_narrow32_body<true, true>(a, L);
 }
