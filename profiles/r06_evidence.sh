@@ -27,5 +27,29 @@ except Exception as e:
     print(sys.argv[1], "FAILED", e)
 PY
 done
-tail -n 2 gpurun_out/${TAG}fin_fuzz.txt; tail -n 2 gpurun_out/${TAG}sparse_fuzz.txt; tail -n 2 gpurun_out/${TAG}careful_fuzz.txt
+# the sparse shard's kernels (msnv_pileup_tiles_lean since round 6) with MSNV_LEAN=0 beside them: statistics of a kernel trace, instruction counters in a pass of their own
+SB="python3 bench.py --workload config4shard --scale 0.1 --no-cpu-baseline --no-annotation --no-overlap-extra --steps 5 --warmup 2"
+for V in lean ordinary; do
+  if [ $V = ordinary ]; then export MSNV_LEAN=0; else unset MSNV_LEAN; fi
+  rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_sparse_$V -o t --output-format csv -- $SB > /dev/null 2>&1
+  cp $(find gpurun_out/${TAG}_sparse_$V -name '*kernel_stats.csv' | head -1) gpurun_out/${TAG}_sparse_${V}_kernel_stats.csv 2>/dev/null
+  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES -d gpurun_out/${TAG}_sparse_pmc_$V -o p --output-format csv -- $SB > /dev/null 2>&1
+done
+unset MSNV_LEAN
+python3 - $TAG > gpurun_out/${TAG}_sparse_counters.txt <<'PY'
+import csv, glob, re, collections, sys
+tag = sys.argv[1]
+for v in ("lean", "ordinary"):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob("gpurun_out/%s_sparse_pmc_%s/**/*counter_collection.csv" % (tag, v), recursive=True):
+        for r in csv.DictReader(open(f)):
+            m = re.search(r'(msnv_\w+)', r["Kernel_Name"])
+            if m: acc[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, cs in sorted(acc.items(), key=lambda kv: -sum(kv[1].get("SQ_INSTS_VALU", [0]))):
+        per = lambda c: sum(cs.get(c, [0.0])) / max(1, len(cs.get(c, [1])))
+        print("%-9s %-34s launches %3d  VALU %12.0f  SALU %12.0f  LDS %11.0f  waves %9.0f  VALU/wave %7.1f" % (v, k, len(cs["SQ_WAVES"]), per("SQ_INSTS_VALU"), per("SQ_INSTS_SALU"), per("SQ_INSTS_LDS"), per("SQ_WAVES"), per("SQ_INSTS_VALU") / max(1.0, per("SQ_WAVES"))))
+PY
+head -n 6 gpurun_out/${TAG}_sparse_counters.txt
+bash profiles/fuzz.sh ${TAG}token 1500 7373 > /dev/null 2>&1      # (the sweep shortens snpCall's token in 3 of 7 cases: msnv_cap_reads / msnv_token_cut against the oracle)
+tail -n 2 gpurun_out/${TAG}fin_fuzz.txt; tail -n 2 gpurun_out/${TAG}sparse_fuzz.txt; tail -n 2 gpurun_out/${TAG}careful_fuzz.txt; tail -n 2 gpurun_out/${TAG}token_fuzz.txt
 bash profiles/r06_base.sh ${TAG} > gpurun_out/${TAG}_r2c_kernels.txt 2>&1; tail -5 gpurun_out/${TAG}_r2c_kernels.txt
