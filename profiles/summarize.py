@@ -42,11 +42,13 @@ if dom and "FETCH_SIZE" in pmc[dom[0]] and "WRITE_SIZE" in pmc[dom[0]]:
                           "note": "FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of a wide coalesced stream "
                                   "(MI355X_MICROARCH.md section HBM), so reads are doubled; separate --pmc passes with --kernel-trace only"}
 # ---- the per-read stage (csrc/devpack.hip): HBM traffic of ONE build of the dataset from resident records = sum over its kernels of
-# (2 x FETCH_SIZE + WRITE_SIZE) per launch x launches per build (the bench builds the dataset three times: launches / 3)
+# (2 x FETCH_SIZE + WRITE_SIZE) per launch x launches per build (the bench builds the dataset several times: launches / builds)
 PACK = ("msnv_scan_sub", "msnv_scan_seams", "msnv_scan_write", "msnv_scan_segments", "msnv_compact_offsets", "msnv_measure_reads", "msnv_pile_gather", "msnv_depth", "msnv_run_table",
         "msnv_group_pre", "msnv_group_table", "msnv_sample_bases", "msnv_emit_block", "msnv_emit_tail", "msnv_acc_fold", "msnv_acc_init", "msnv_sub_bounds", "msnv_sample_layout",
         "msnv_scan_check", "msnv_scan_fix", "msnv_tables_from_measure", "msnv_group_firsts", "rocprim")      # (substring match: msnv_scan_sub also takes msnv_scan_sub2, msnv_depth takes msnv_depth2 ...)
-builds = 3.0
+# (the number of builds of the profiled bench command: one launch of msnv_sample_layout per round, one round per build on the benchmark shape --
+# three builds until round 5, seven since round 6)
+builds = float(max([cs["FETCH_SIZE"]["launches"] for k, cs in pmc.items() if "msnv_sample_layout" in k and "FETCH_SIZE" in cs] or [3]))
 pk = {}
 for k, cs in pmc.items():
     if not any(x in k for x in PACK) or "FETCH_SIZE" not in cs or "WRITE_SIZE" not in cs:
@@ -61,7 +63,7 @@ for k, cs in pmc.items():
 if pk:
     tot = sum(v["fetch_x2_bytes_per_build"] + v["write_bytes_per_build"] for v in pk.values())
     res["pack_traffic"] = {"kernels": pk, "total_bytes_per_build": tot,
-                           "note": "bench.py builds the dataset three times from records resident in HBM; rocPRIM scans of any other stage (finalize) are included; "
+                           "builds": builds, "note": "bench.py builds the dataset several times from records resident in HBM (`builds`); rocPRIM scans of any other stage (finalize) are included; "
                                    "compare with roofline_from_records.record_bytes_resident of the bench line"}
 json.dump(res, open(os.path.join(out_dir, tag + "_pmc.json"), "w"), indent=1)
 print(json.dumps(res.get("hbm_traffic", {}), indent=1))
