@@ -7,20 +7,25 @@
 // (M/=/X) segments, '=' -> reference base, and the -Q test of every base.  pack.cpp is the same stage on host threads (MSNV_PACK=host);
 // the two produce the same columns byte for byte (tests/test_gpu_devpack.py).
 //
-// Stages of one round of samples (all on the context's stream):
-//   msnv_scan_records     the block_size chain of every stream (one wavefront per stream walks it through LDS windows) -> record offsets
-//   msnv_measure_reads    one thread per record: header, CIGAR geometry, the read filters of both tools, qaCompute's statistics, the
-//                         number of pieces / seq bytes / M intervals the record will emit
-//   (depth)               pileup reads alive at every read start (mpileup -d, and the depth bound of the tile index): sort of
-//                         (contig run, end) keys + a search per read; upper bound of the sample's base-string length (snpCall's token limit)
-//   msnv_emit_headers     one thread per kept record: piece headers {position, seq offset, length}, qaCompute's {+1, -1} intervals
-//   msnv_emit_pieces      16 lanes per piece, 8 bases per lane: nibble swap (BAM stores base 2i in the HIGH nibble), '=' -> reference code,
-//                         "quality below the -Q cutoff" flag per base, mismatch sampling of every 16th piece
-//   (tile order)          stable sort of the headers by (sample, contig, tile): the pieces a read leaves in the NEXT tile move behind
-// The three SEQUENTIAL edits of the host stage -- depth cap, overlapping-mate quality tweak, snpCall's token limit -- stay a host
-// pre-pass (pack.cpp: host_prepass) that runs only for the samples whose records can trigger one of them (decided here, on the device:
-// some read starts above the cap; two or more reads pass htslib's overlap_push precondition; the upper bound of a base string reaches
-// the limit); it hands back the verdict per record and the edited qualities, and the kernels take it from there.
+// Stages of one round of samples (round 6; DESIGN.md section 3 has the table with the kernels' times).  The QUICK route, the default:
+//   msnv_scan_sub2        one LANE per sub-segment of a few kilobytes of a stream: guesses where the block_size chain enters its bytes, walks the
+//                         records that start there and MEASURES each as it goes (header, CIGAR geometry, the read filters of both tools,
+//                         qaCompute's statistics, the pieces / seq bytes / M intervals the record will emit) into a 32-byte slot
+//   msnv_scan_check / _fix2 / msnv_sub_bounds + ONE scan of the sub-segments' sums: the seams, what crosses them, the round's totals
+//                         -- the stage's one wait: the host sizes every buffer from them
+//   msnv_scan_write2      the records' tables in record order: offsets, {position, end, contig, sample}, places before every record
+//   msnv_depth2           pileup reads alive at every read start (mpileup -d, the depth bound of the tile index, the upper bound of a
+//                         sample's base string: snpCall's token limit) from a window of the records in front; on the second stream
+//   msnv_emit_block       a workgroup per 256 records, their bytes staged in LDS: piece headers, qaCompute's intervals, bases (nibble swap,
+//                         '=' -> reference code), "quality below the -Q cutoff" flags, mismatch sampling of every 16th piece, in TILE order
+//                         (the pieces a read leaves in the next tile are placed by counting); msnv_emit_block_slow takes what it lists
+// The CAREFUL route (msnv_scan_sub / msnv_scan_segments, msnv_measure_reads, msnv_tables_from_measure, a wait between the stages) takes the
+// rounds the quick one leaves: paired reads, chains that break, the general tile-order sort -- and the three SEQUENTIAL edits of the host
+// stage, all kernels now: the overlapping-mate quality tweak (msnv_ovl_*, round 4), mpileup's depth cap (msnv_cap_reads) and snpCall's token
+// limit (msnv_token_clamp, msnv_token_cut; round 6).  Which samples' records can trigger one is decided on the device (a read starts above
+// the cap; two or more reads pass htslib's overlap_push precondition; the upper bound of a base string reaches the limit).  The host
+// pre-pass (pack.cpp: host_prepass) keeps three corner cases (a template with more alignments than the overlap kernel's slots, reads that
+// span more than 16 384 reference positions, an indel of half a million bases) and MSNV_PREPASS=host.
 #include <algorithm>
 #include <chrono>
 #include <cstdint>
