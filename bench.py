@@ -230,7 +230,10 @@ def cpu_baseline_all_cores(orc, syn, samples, n_bases_whole):
     SPLIT | snpCall` per split, every split reading every BAM (/root/reference/metaSNV.py:196-215): the contigs are cut into one position range
     per core, each range is one thread's orc.call with that range as its BED (the C restatement holds no global state; ctypes drops the GIL)."""
     from concurrent.futures import ThreadPoolExecutor
-    cores = os.cpu_count() or 1
+    from metasnv_amd import core
+    # (the cores' worth of CPU time the process may use -- the container's cgroup quota, 16 on the pool's boxes whatever os.cpu_count() says: 256
+    # threads on 16 cores, each split walking every BAM, ran at HALF the one-core rate, profiles/r06_bench.json of the first closing run)
+    cores = max(1, min(os.cpu_count() or 1, core.host_cores()))
     total = sum(syn.lengths)
     per = max(1, -(-total // cores))
     beds = []
