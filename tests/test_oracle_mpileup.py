@@ -136,3 +136,21 @@ def test_cigar_in_the_cg_field_reads_like_the_plain_record():
     # a CG field that holds FEWER operations than the placeholder is not a real CIGAR: the record stays what it says (all clipped, ref-skip)
     odd = bt.make_record(0, 5, "30S30N", ref[5:35], name="odd", aux=b"CGBI" + __import__("struct").pack("<II", 1, 30 << 4))
     assert orc.qacompute(["c"], [len(ref)], bt.records(odd))[0] == orc.qacompute(["c"], [len(ref)], bt.records(bt.make_record(0, 5, "30S30N", ref[5:35], name="odd")))[0]
+
+
+def test_token_cap_of_the_oracle_is_the_references_unless_a_test_shortens_it():
+    """oracle/orc.h: orc_snpcall_opts.token_cap = 0 means snpCall's own 10000-character token (call_vC.cpp:482); the parity sweep shortens it so
+    that shallow random pileups reach the cut (tests/fuzz_parity.py).  Same answers for 0 and 10000; a token shorter than the base strings
+    drops the bases behind it, so some calls lose coverage or vanish."""
+    from metasnv_amd import core
+    sp = core.synth_params(n_species=1, contig_len=1500, n_samples=3, mean_cov=40.0, snv_density=0.02, seed=4711)
+    syn = core.Synth(sp)
+    samples = [syn.sample_records(i) for i in range(sp.n_samples)]
+    kw = dict(min_coverage=2, calling_threshold=2)
+    a = orc.call(syn.names, syn.lengths, syn.seqs, samples, sc=kw)
+    b = orc.call(syn.names, syn.lengths, syn.seqs, samples, sc=dict(kw, token_cap=10000))
+    c = orc.call(syn.names, syn.lengths, syn.seqs, samples, sc=dict(kw, token_cap=25))
+    assert a[:2] == b[:2] and a[0].count("\n") > 10
+    assert c[:2] != a[:2]
+    cov = lambda text: sum(int(x) for line in text.splitlines() for x in line.split("\t")[4].split("|"))
+    assert cov(c[0]) < cov(a[0])
