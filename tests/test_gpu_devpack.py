@@ -293,6 +293,36 @@ def test_a_deep_stack_is_capped_and_cut_on_the_device():
     assert st["prepass_samples"] == 0 and st["device_edit_samples"] == 1, st
 
 
+def test_samples_of_one_round_take_different_routes_through_the_sequential_edits():
+    """One round, four samples: (a) plain; (b) deeper than the cap AND beyond the (shortened) token: msnv_cap_reads + msnv_token_cut; (c) a template
+    with a dozen alignments under one name -- more than the overlap kernel's slots: the host pre-pass takes the whole sample, its depth cap and
+    token cut included; (d) proper pairs below every limit: the overlap kernel.  The verdicts of the host's samples and of the kernels' samples
+    share one table, the second pass measures with both; columns byte for byte against the host stage, calls against the oracle."""
+    import random
+    rnd = random.Random(77)
+    L = 3000
+    ref = "".join(rnd.choice("ACGT") for _ in range(L))
+
+    def read(pos, n, name, flag=0, mpos=-1, tlen=0, cigar=None, mut=0.02):
+        q = [c if rnd.random() > mut else rnd.choice("ACGT") for c in ref[pos:pos + n]]
+        return (pos, bt.make_record(0, pos, cigar or "%dM" % n, "".join(q), name=name, flag=flag, mtid=0 if mpos >= 0 else -1, mpos=mpos, tlen=tlen,
+                                    qual=[rnd.choice([5, 20, 30, 40]) for _ in range(n)]))
+
+    plain = [read(rnd.randrange(0, L - 80), 70, "a%d" % k) for k in range(300)]
+    deep = [read(500 + k // 6, 60, "b%d" % k, cigar="30M2D30M" if k % 5 == 0 else None) for k in range(400)] + [read(rnd.randrange(0, L - 80), 70, "bb%d" % k) for k in range(200)]
+    many = [read(900 + 3 * k, 60, "tmpl", flag=99 if k % 2 == 0 else 147, mpos=905, tlen=200) for k in range(12)] + \
+           [read(880 + k // 5, 50, "c%d" % k) for k in range(300)]
+    pairs = []
+    for k in range(150):
+        a = rnd.randrange(0, L - 200)
+        pairs.append(read(a, 70, "p%d" % k, flag=99, mpos=a + 40, tlen=110)); pairs.append(read(a + 40, 70, "p%d" % k, flag=147, mpos=a, tlen=-110))
+    samples = [bt.records(*[r for _, r in sorted(x, key=lambda t: t[0])]) for x in (plain, deep, many, pairs)]
+    p = core.default_params(min_coverage=2, calling_threshold=2, max_depth=25, token_limit=70)
+    _same_dataset(["c1"], [L], [ref], samples, params=p, many=True)
+    st = _edit_stats(["c1"], [L], [ref], samples, p)
+    assert st["prepass_samples"] == 1 and st["device_edit_samples"] >= 1, st
+
+
 def test_errors_carry_the_host_stage_codes():
     from metasnv_amd import _lib
     ref = "ACGT" * 100
