@@ -153,6 +153,10 @@ struct DevPackTables {
     struct Pending { bool active = false; size_t first = 0, n = 0; void *ev0 = nullptr, *ev1 = nullptr, *evh = nullptr, *evd = nullptr, *evd2 = nullptr, *evw = nullptr; bool has_evd = false; } pending;      // evd / evd2: around the depth stage on the second stream; evw: the records' tables are written      // evh: behind the small results the host takes while the emit kernels run
     bool      any_overhang_h = false; // some read of some round runs past its contig (msnv_measure_reads): finalize fetches `overhang`
     void     *cov_event = nullptr;   // recorded behind those kernels: what devfin_coverage waits for
+    // (round 6) the coverage index's pair tables cut on the device: the work memory of their counts, what the second step reads of it
+    struct CovT { uint32_t *tcont, *rid_t, *rowid, *row_sample, *row_contig, *item_off, *lo, *hi; unsigned long long *iv_start; };
+    void     *cov_tables = nullptr; CovT cov_t{}; uint32_t cov_item_intervals = 16384; bool cov_tables_done = false;
+    void     *fin_chunk_event = nullptr; bool fin_chunk_pending = false;      // behind the words devfin_chunks_launch's kernels leave in pinned memory
     void     *cov_job = nullptr, *cov_tmp = nullptr, *cov_runs = nullptr; bool cov_launched = false;   // finalize: the coverage index's kernels launched ahead of their results (devfin_coverage_launch)
     void     *fin_tile_base = nullptr;                     // finalize on the device: the contigs' first tiles (devfin_headers)
     void     *fin_list = nullptr, *fin_cbase = nullptr;   // finalize on the device: the narrow pairs' list and their chunk counts / scan, between devfin_chunk_counts and devfin_chunk_fill

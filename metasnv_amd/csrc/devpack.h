@@ -51,7 +51,7 @@ int devfin_chunk_fill(msnv_dataset &ds, DeviceCols &d, size_t n_pairs_listed, ui
 // the same without a wait (devpack.hip): item_first[wi] = index of narrow work item wi's first pair in the list (n_work_narrow + 1 entries); the chunks
 // go behind the `base` chunks the host wrote, `cap` of them at most; devfin_chunks_result (behind a wait for the stream) says how many there were
 int devfin_chunks_launch(msnv_dataset &ds, DeviceCols &d, const std::vector<uint32_t> &narrow_pairs, const std::vector<uint32_t> &item_first, uint32_t base, uint64_t cap);
-void devfin_chunks_result(const msnv_dataset &ds, uint64_t *n_chunks, bool *overflow);
+int devfin_chunks_result(msnv_dataset &ds, uint64_t *n_chunks, bool *overflow);
 int devfin_work_first(msnv_dataset &ds, DeviceCols &d, uint32_t n_items);                            // WorkItem::first of the narrow and merged items, from d.chunks
 int devfin_merged_headers(msnv_dataset &ds, DeviceCols &d, const std::vector<DevMergedSrc> &list);
 int devfin_coverage_launch(msnv_dataset &ds, DeviceCols &d);   // needs ds.tile_base / n_tiles; the kernels only (their results: devfin_coverage)

@@ -2329,7 +2329,8 @@ void devpack_release(msnv_dataset &ds) {
         t.pending.ev0 = t.pending.ev1 = t.pending.evh = t.pending.evd = t.pending.evd2 = t.pending.evw = nullptr;
     }
     if (t.cov_event) { (void)hipEventDestroy((hipEvent_t)t.cov_event); t.cov_event = nullptr; }
-    if (t.cov_job || !t.fin_keep.empty()) (void)hipDeviceSynchronize();
+    if (t.fin_chunk_event) { (void)hipEventDestroy((hipEvent_t)t.fin_chunk_event); t.fin_chunk_event = nullptr; t.fin_chunk_pending = false; }
+    if (t.cov_job || t.cov_tables || !t.fin_keep.empty()) (void)hipDeviceSynchronize();
     // everything of the pack goes back in ONE batch (one wait for the device instead of one per buffer: dev_free_batch)
     std::vector<void *> out;
     auto give = [&](void *p) { if (p) out.push_back(p); };
@@ -2344,6 +2345,7 @@ void devpack_release(msnv_dataset &ds) {
     t.contigs = nullptr; t.pref4 = nullptr; t.ready = false;
     std::vector<uint32_t>().swap(t.h_codes); std::vector<uint32_t>().swap(t.h_lc);
     give(t.cov_job); t.cov_job = nullptr; t.cov_runs = nullptr;
+    give(t.cov_tables); t.cov_tables = nullptr;
     give(t.cov_tmp); t.cov_tmp = nullptr;
     t.cov_launched = false;
     give(t.fin_tile_base); t.fin_tile_base = nullptr;
@@ -3873,6 +3875,76 @@ __global__ void msnv_fin_cov_dense_runs(const uint32_t *lo, const uint32_t *hi, 
     if (i >= n || !hi[i]) return;
     out[rid_excl[i]] = DevCovPair{(uint32_t)(i % n_tiles), (uint32_t)(i / n_tiles), lo[i], hi[i]};
 }
+// ---- the coverage index's pair tables on the device (round 6; pack.cpp: cov_index built them on the host behind finalize's last wait, 0.5 ms of
+// loops over the (sample, tile) runs on the benchmark shape).  The dense [sample][tile] table read TILE-major gives the pairs in their final
+// order (tiles ascending, samples ascending inside a tile) by one scan of its flags; the accumulator rows -- one per (sample, contig) that has
+// intervals -- by a scan of a presence table; the work items (pack.cpp's cut: COV_ITEM_PAIRS pairs, or fewer when one pair alone is deep) by a
+// thread per tile, counted first, written once the host has allocated the tables from the counts that come back with the index's own.
+__global__ void msnv_cov_flags_t(const uint32_t *hi, uint32_t n_samples, uint32_t n_tiles, const uint32_t *tcont, uint32_t n_contigs, uint32_t *flag_t, uint32_t *pres) {
+    const unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x, n = (unsigned long long)n_samples * n_tiles;
+    if (k > n) return;
+    uint32_t f = 0;
+    if (k < n) {
+        const uint32_t t = (uint32_t)(k / n_samples), sm = (uint32_t)(k % n_samples);
+        f = hi[(unsigned long long)sm * n_tiles + t] ? 1u : 0u;
+        if (f) pres[(unsigned long long)sm * n_contigs + tcont[t]] = 1u;
+    }
+    flag_t[k] = f;
+}
+__global__ void msnv_cov_count_items(const uint32_t *lo, const uint32_t *hi, uint32_t n_samples, uint32_t n_tiles, uint32_t item_intervals, uint32_t narrow_max, uint32_t *n_item, uint32_t *wide) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > n_tiles) return;
+    uint32_t items = 0;
+    if (t < n_tiles) {
+        unsigned long long acc = 0; uint32_t in_item = 0; bool w = false;
+        for (uint32_t sm = 0; sm < n_samples; ++sm) {
+            const uint32_t h = hi[(unsigned long long)sm * n_tiles + t];
+            if (!h) continue;
+            const uint32_t span = h - lo[(unsigned long long)sm * n_tiles + t];
+            w |= span > narrow_max;
+            acc += span; ++in_item;
+            if (acc >= item_intervals || in_item >= COV_ITEM_PAIRS) { ++items; acc = 0; in_item = 0; }
+        }
+        if (in_item) ++items;
+        if (w) *wide = 1u;
+    }
+    n_item[t] = items;
+}
+__global__ void msnv_cov_rows(const uint32_t *pres, const uint32_t *rowid, uint32_t n_samples, uint32_t n_contigs, uint32_t *row_sample, uint32_t *row_contig, uint32_t *row_start) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x, n = (unsigned long long)n_samples * n_contigs;
+    if (i > n) return;
+    if (i < n && pres[i]) { row_sample[rowid[i]] = (uint32_t)(i / n_contigs); row_contig[rowid[i]] = (uint32_t)(i % n_contigs); }
+    if (i % n_contigs == 0u || i == n) row_start[i / n_contigs] = rowid[i];            // (entry n_samples: the rows in all)
+}
+__global__ void msnv_cov_counts(const uint32_t *rid_t, unsigned long long n_tab, const uint32_t *rowid, unsigned long long n_sc, const uint32_t *item_off, uint32_t n_tiles, const uint32_t *wide, uint32_t *out) {
+    if (blockIdx.x || threadIdx.x) return;
+    out[0] = rid_t[n_tab]; out[1] = rowid[n_sc]; out[2] = item_off[n_tiles]; out[3] = *wide;
+}
+__global__ void msnv_cov_write_pairs(const uint32_t *lo, const uint32_t *hi, const uint32_t *rid_t, const uint32_t *rowid, const uint32_t *tcont, const unsigned long long *iv_start,
+                                     uint32_t n_samples, uint32_t n_tiles, uint32_t n_contigs, TilePair *pairs) {
+    const unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x, n = (unsigned long long)n_samples * n_tiles;
+    if (k >= n) return;
+    const uint32_t t = (uint32_t)(k / n_samples), sm = (uint32_t)(k % n_samples);
+    const uint32_t h = hi[(unsigned long long)sm * n_tiles + t];
+    if (!h) return;
+    const unsigned long long b = iv_start[sm];
+    pairs[rid_t[k]] = TilePair{sm, lo[(unsigned long long)sm * n_tiles + t], h, rowid[(unsigned long long)sm * n_contigs + tcont[t]], (uint32_t)b, (uint32_t)(b >> 32), 0u, 0u};
+}
+__global__ void msnv_cov_write_items(const TilePair *pairs, const uint32_t *rid_t, const uint32_t *item_off, uint32_t n_samples, uint32_t n_tiles, uint32_t item_intervals, WorkItem *work) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    const uint32_t p0 = rid_t[(unsigned long long)t * n_samples], p1 = rid_t[(unsigned long long)(t + 1u) * n_samples];
+    uint32_t w = item_off[t], first = p0; unsigned long long acc = 0;
+    for (uint32_t k = p0; k < p1; ++k) {
+        acc += pairs[k].read_hi - pairs[k].read_lo;
+        if (acc >= item_intervals || k + 1u - first >= COV_ITEM_PAIRS || k + 1u == p1) {
+            WorkItem it{};
+            it.tile = t; it.pair_lo = first; it.pair_hi = k + 1u;
+            work[w++] = it;
+            first = k + 1u; acc = 0;
+        }
+    }
+}
 __global__ void msnv_gather_u32(const uint32_t *src, const unsigned long long *idx, uint32_t n, uint32_t *out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = src[idx[i]];
@@ -3967,12 +4039,19 @@ int devfin_chunks_launch(msnv_dataset &ds, DeviceCols &d, const std::vector<uint
                        (uint32_t)std::min<uint64_t>(cap, 0xffffffffull), dres);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(res, dres, 8, hipMemcpyDeviceToHost, st));
+    // (an event behind the two words: devfin_chunks_result waits for IT.  Until the coverage tables moved to the device the host's half
+    // millisecond of loops over them stood between this launch and the read of the words -- a wait in fact, not in the code)
+    if (!T.fin_chunk_event) { hipEvent_t e = nullptr; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); T.fin_chunk_event = e; }
+    HIP_TRY(hipEventRecord((hipEvent_t)T.fin_chunk_event, st));
+    T.fin_chunk_pending = true;
     return MSNV_OK;
 }
-// behind a wait for the stream: the narrow chunks that were cut, and whether they all found room
-void devfin_chunks_result(const msnv_dataset &ds, uint64_t *n_chunks, bool *overflow) {
+// the narrow chunks that were cut, and whether they all found room (waits for the cut's last kernel)
+int devfin_chunks_result(msnv_dataset &ds, uint64_t *n_chunks, bool *overflow) {
+    if (ds.dp.fin_chunk_pending) { ds.dp.fin_chunk_pending = false; HIP_TRY(hipEventSynchronize((hipEvent_t)ds.dp.fin_chunk_event)); }
     const uint32_t *res = pin_fin_words(ds.dp) + (ds.samples.size() + 4);
     *n_chunks = res[0]; *overflow = res[1] != 0;
+    return MSNV_OK;
 }
 
 // ... and the form with ONE wait between counts and fill (exact sizes): counts (+ their exclusive scan, on the device) -> the host learns every
@@ -4060,7 +4139,7 @@ int devfin_coverage_launch(msnv_dataset &ds, DeviceCols &d) {
     const unsigned long long N = iv_start[S];
     const unsigned long long n_tab = (unsigned long long)S * ds.n_tiles;
     if (N > 0xfffffff0ull || !cov_dense_form(ds, N) || n_tab > (1ull << 24) || getenv("MSNV_COV_LATE")) return MSNV_OK;
-    if (int rc = pin_ensure(ds, (S + 16) * 4)) return rc;
+    if (int rc = pin_ensure(ds, (2 * S + 64) * 4)) return rc;
     auto up = [](unsigned long long b) { return (b + 255ull) & ~255ull; };
     const unsigned long long b_tb = up(std::max<size_t>(1, ds.tile_base.size()) * 4), b_ivs = up((S + 1) * 8), b_cvb = up((S + 4) * 4);
     const unsigned long long b_n = up((N + 1) * 4), b_t = up((n_tab + 1) * 4), b_r = up((n_tab + 1) * sizeof(DevCovPair));
@@ -4111,6 +4190,50 @@ int devfin_coverage_launch(msnv_dataset &ds, DeviceCols &d) {
     hipLaunchKernelGGL(msnv_fin_cov_dense_runs, grid_for(n_tab, 256), dim3(256), 0, st, lo, hi, rid, n_tab, ds.n_tiles, runs);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(pin_fin_words(T), cvb, (S + 3) * 4, hipMemcpyDeviceToHost, st));      // (pinned: the copy does not wait on the host)
+    // ---- the pair tables' counts (round 6: the tables themselves are written on the device once the host has allocated them, devfin_coverage)
+    T.cov_tables = nullptr;
+    {
+        const bool on_host = [] { const char *e = getenv("MSNV_COV_TABLES"); return e && e[0] == 'h'; }();
+        const size_t NC = ds.names.size(), nt = ds.n_tiles;
+        const unsigned long long n_sc = (unsigned long long)S * NC;
+        if (!on_host && NC && nt && ds.tile_contig.size() >= nt) {
+            const unsigned long long c_tc = up((nt + 1) * 4), c_ft = b_t, c_sc = up((n_sc + 1) * 4), c_it = up((nt + 2) * 4), c_rs = up((S + 2) * 4);
+            void *tb2 = nullptr;
+            if (int rc = dev_alloc(&tb2, c_tc + 2 * c_ft + 4 * c_sc + 2 * c_it + c_rs + 256, nullptr)) return rc;
+            T.cov_tables = tb2;
+            uint8_t *w = static_cast<uint8_t *>(tb2);
+            uint32_t *tcont = reinterpret_cast<uint32_t *>(w); w += c_tc;
+            uint32_t *flag_t = reinterpret_cast<uint32_t *>(w); w += c_ft;
+            uint32_t *rid_t = reinterpret_cast<uint32_t *>(w); w += c_ft;
+            uint32_t *pres = reinterpret_cast<uint32_t *>(w); w += c_sc;
+            uint32_t *rowid = reinterpret_cast<uint32_t *>(w); w += c_sc;
+            uint32_t *row_sample = reinterpret_cast<uint32_t *>(w); w += c_sc;
+            uint32_t *row_contig = reinterpret_cast<uint32_t *>(w); w += c_sc;
+            uint32_t *n_item = reinterpret_cast<uint32_t *>(w); w += c_it;
+            uint32_t *item_off = reinterpret_cast<uint32_t *>(w); w += c_it;
+            uint32_t *row_start = reinterpret_cast<uint32_t *>(w); w += c_rs;
+            uint32_t *counts = reinterpret_cast<uint32_t *>(w);            // [0] pairs [1] rows [2] work items [3] some pair is wide [4] scratch
+            T.cov_t = DevPackTables::CovT{tcont, rid_t, rowid, row_sample, row_contig, item_off, lo, hi, ivs};
+            HIP_TRY(hipMemcpyAsync(tcont, ds.tile_contig.data(), nt * 4, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemsetAsync(pres, 0, c_sc, st));
+            HIP_TRY(hipMemsetAsync(counts, 0, 32, st));
+            const uint32_t item_intervals = [] { const char *e = getenv("MSNV_COV_ITEM"); const long long v = e ? atoll(e) : 16384; return (uint32_t)std::min<long long>(v > 0 ? v : 16384, 0x7fffffffll); }();
+            const uint32_t narrow_max = [] { const char *e = getenv("MSNV_COV_NARROW_MAX"); const long long v = e ? atoll(e) : 32767; return (uint32_t)std::min<long long>(32767, std::max<long long>(1, v)); }();
+            T.cov_item_intervals = item_intervals;
+            hipLaunchKernelGGL(msnv_cov_flags_t, grid_for(n_tab + 1, 256), dim3(256), 0, st, hi, (uint32_t)S, ds.n_tiles, tcont, (uint32_t)NC, flag_t, pres);
+            HIP_TRY(hipGetLastError());
+            if (int rc = pr.scan32(flag_t, rid_t, n_tab + 1, false)) return rc;
+            if (int rc = pr.scan32(pres, rowid, n_sc + 1, false)) return rc;
+            hipLaunchKernelGGL(msnv_cov_count_items, grid_for(nt + 1, 64), dim3(64), 0, st, lo, hi, (uint32_t)S, ds.n_tiles, item_intervals, narrow_max, n_item, counts + 3);
+            HIP_TRY(hipGetLastError());
+            if (int rc = pr.scan32(n_item, item_off, nt + 1, false)) return rc;
+            hipLaunchKernelGGL(msnv_cov_rows, grid_for(n_sc + 1, 256), dim3(256), 0, st, pres, rowid, (uint32_t)S, (uint32_t)NC, row_sample, row_contig, row_start);
+            hipLaunchKernelGGL(msnv_cov_counts, dim3(1), dim3(64), 0, st, rid_t, n_tab, rowid, n_sc, item_off, ds.n_tiles, counts + 3, counts);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(pin_fin_words(T) + (S + 16), counts, 16, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(pin_fin_words(T) + (S + 24), row_start, (S + 1) * 4, hipMemcpyDeviceToHost, st));
+        }
+    }
     // an event behind the index's kernels: devfin_coverage waits for IT, not for the stream -- the chunk and header kernels finalize queues
     // behind these run while the host builds the coverage pair tables (round 6)
     if (!T.cov_event) { hipEvent_t e = nullptr; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); T.cov_event = e; }
@@ -4127,6 +4250,7 @@ int devfin_coverage(msnv_dataset &ds, DeviceCols &d, std::vector<uint64_t> &cvba
     for (size_t s = 0; s < S; ++s) iv_start[s + 1] = iv_start[s] + ds.samples[s].n_dev_iv;
     const unsigned long long N = iv_start[S];
     cvbase.assign(S + 1, 0); cp.clear();
+    ds.dp.cov_tables_done = false;
     if (ds.dp.cov_launched) {
         // the kernels were launched ahead (devfin_coverage_launch): their results are in the pinned words, the runs in HBM
         DevPackTables &T = ds.dp;
@@ -4137,6 +4261,44 @@ int devfin_coverage(msnv_dataset &ds, DeviceCols &d, std::vector<uint64_t> &cvba
         const uint32_t n_keep = (uint32_t)N, n_runs = pw[S + 2];
         d.n_cov_iv = n_keep;
         HIP_TRY(hipMemsetAsync(d.cov_iv + n_keep, 0, 4 * sizeof(Pair32), st));              // behind the last interval: what the idle lanes of msnv_coverage_tiles load
+        T.cov_tables_done = false;
+        if (T.cov_tables && pw[S + 16 + 3] == 0u) {
+            // the pair tables on the device: their sizes came with the index's counts; the rows' (sample, contig) names come down, nothing else
+            const uint32_t n_pairs = pw[S + 16], n_rows = pw[S + 17], n_work = pw[S + 18];
+            const size_t NC = ds.names.size();
+            static const bool guard = [] { const char *e = getenv("MSNV_GUARD_ALLOC"); return e && e[0] == '1'; }();
+            const uint64_t b_p = ((uint64_t)(n_pairs + 1) * sizeof(TilePair) + 255) & ~255ull, b_w = std::max<uint64_t>(16, (uint64_t)(n_work + 1) * sizeof(WorkItem));
+            if (guard) {
+                if (int rc = dev_alloc((void **)&d.cov_pairs, (uint64_t)(n_pairs + 1) * sizeof(TilePair), &d.device_bytes)) return rc;
+                if (int rc = dev_alloc((void **)&d.cov_work, b_w, &d.device_bytes)) return rc;
+            } else {
+                void *blk = nullptr;
+                if (int rc = dev_alloc(&blk, b_p + b_w + 256, &d.device_bytes)) return rc;
+                d.blocks.emplace_back(blk, b_p + b_w + 256);
+                d.cov_pairs = static_cast<TilePair *>(blk);
+                d.cov_work = reinterpret_cast<WorkItem *>(static_cast<uint8_t *>(blk) + b_p);
+            }
+            const DevPackTables::CovT &C = T.cov_t;
+            HIP_TRY(hipMemsetAsync(d.cov_pairs + n_pairs, 0, sizeof(TilePair), st));
+            HIP_TRY(hipMemsetAsync(d.cov_work + n_work, 0, sizeof(WorkItem), st));
+            const unsigned long long n_tab = (unsigned long long)S * ds.n_tiles;
+            if (n_pairs) {
+                hipLaunchKernelGGL(msnv_cov_write_pairs, grid_for(n_tab, 256), dim3(256), 0, st, C.lo, C.hi, C.rid_t, C.rowid, C.tcont, C.iv_start, (uint32_t)S, ds.n_tiles, (uint32_t)NC, d.cov_pairs);
+                hipLaunchKernelGGL(msnv_cov_write_items, grid_for(ds.n_tiles, 64), dim3(64), 0, st, d.cov_pairs, C.rid_t, C.item_off, (uint32_t)S, ds.n_tiles, T.cov_item_intervals, d.cov_work);
+                HIP_TRY(hipGetLastError());
+            }
+            ds.cov_row_sample.assign(n_rows, 0); ds.cov_row_contig.assign(n_rows, 0);
+            if (n_rows) {
+                HIP_TRY(hipMemcpy(ds.cov_row_sample.data(), C.row_sample, (size_t)n_rows * 4, hipMemcpyDeviceToHost));      // (blocking copies on the null stream: the context's stream is still busy, and not waited for)
+                HIP_TRY(hipMemcpy(ds.cov_row_contig.data(), C.row_contig, (size_t)n_rows * 4, hipMemcpyDeviceToHost));
+            }
+            ds.cov_row_start.assign(S + 1, 0);
+            for (size_t s = 0; s <= S; ++s) ds.cov_row_start[s] = pw[S + 24 + s];
+            d.n_cov_pairs = n_pairs; d.n_cov_work = n_work; d.n_cov_work_wide = 0; d.n_contigs = (uint32_t)NC;
+            T.cov_tables_done = true;
+            fin_trace("    cov: results of the kernels launched ahead, pair tables written there");
+            return MSNV_OK;
+        }
         cp.resize(n_runs);
         if (n_runs) HIP_TRY(hipMemcpy(cp.data(), T.cov_runs, (size_t)n_runs * sizeof(DevCovPair), hipMemcpyDeviceToHost));      // (a blocking copy on the null stream: the context's stream is still busy, and not waited for)
         // (the job's buffers go back with the pack's tables: a free here would wait for the device)

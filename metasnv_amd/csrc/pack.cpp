@@ -917,12 +917,14 @@ int finalize_dataset(msnv_dataset &ds) {
         std::vector<uint64_t> cvbase(S + 1, 0);
         struct CP { uint32_t tile, sample, lo, hi; };
         std::vector<CP> flat;                                        // all samples' (tile, sample) runs, sample after sample, tiles ascending inside a sample
+        bool tables_on_device = false;                               // (round 6: devfin_coverage has cut the pair tables, the rows and the work items in HBM)
         if (fast) {
             // the intervals are in HBM: filtered, made linear and grouped by (sample, tile) there (devpack.hip: devfin_coverage); the runs come
             // back sample-major with the tiles ascending, which is the order the loops below want
             std::vector<DevCovPair> cp;
             if (int rc = devfin_coverage(ds, *d, cvbase, cp)) return rc;
             if (!in_thread) lap("  devfin_coverage");
+            tables_on_device = ds.dp.cov_tables_done;
             flat.resize(cp.size());
             bool ordered = true;
             for (size_t i = 0; i < cp.size(); ++i) {
@@ -959,11 +961,14 @@ int finalize_dataset(msnv_dataset &ds) {
         }
         for (size_t s = 0; s < S; ++s) flat.insert(flat.end(), per[s].begin(), per[s].end());
         }
+        std::vector<TilePair> cpairs;
+        std::vector<WorkItem> cwork;
+        if (!tables_on_device) {
         // one pass for the tile counts, one for the pairs (sample order inside a tile comes with the order of `flat`) and the accumulator rows
         std::vector<uint32_t> cps(nt + 1, 0);
         for (const CP &p : flat) cps[p.tile + 1]++;
         for (uint64_t t = 0; t < nt; ++t) cps[t + 1] += cps[t];
-        std::vector<TilePair> cpairs(cps[nt]);
+        cpairs.resize(cps[nt]);
         {
             std::vector<uint32_t> fill(cps.begin(), cps.end() - 1);
             // blk_lo / nblk: absolute index of the sample's first interval (the kernel needs no per-sample base lookup)
@@ -984,7 +989,6 @@ int finalize_dataset(msnv_dataset &ds) {
             ds.cov_row_start[S] = ds.cov_row_sample.size();
         }
         if (!in_thread) lap("    cov tables: pairs by tile, rows");
-        std::vector<WorkItem> cwork;
         cwork.reserve(cpairs.size() / 2 + nt + 16);
         // a coverage work item = COV_ITEM_PAIRS consecutive pairs of a tile = one wavefront of msnv_coverage_tiles, which loads their
         // descriptors up front and a pair's intervals while it works on the pair before (fewer when one pair alone is deep:
@@ -1010,6 +1014,8 @@ int finalize_dataset(msnv_dataset &ds) {
             d->n_cov_work_wide = (uint32_t)(cwork.end() - first_wide);
         }
         if (!in_thread) lap("    cov tables: work items");
+        d->n_cov_pairs = (uint32_t)cpairs.size(); d->n_cov_work = (uint32_t)cwork.size();
+        }
         std::vector<uint32_t> tlen(nt + 1, 0), tcont(nt + 1, 0);
         for (uint64_t t = 0; t < nt; ++t) {
             const size_t c = ds.tile_contig[t];
@@ -1019,11 +1025,13 @@ int finalize_dataset(msnv_dataset &ds) {
         }
         if (!fast) d->n_cov_iv = iv.size();
         for (int k = 0; k < 4; ++k) iv.push_back(Pair32{0u, 0u});     // behind the last interval: what the idle lanes of msnv_coverage_tiles load, four at a time (they touch nothing)
-        d->n_cov_pairs = (uint32_t)cpairs.size(); d->n_cov_work = (uint32_t)cwork.size(); d->n_contigs = (uint32_t)NC;
+        d->n_contigs = (uint32_t)NC;
         if (!fast) if (int rc = A.add(&d->cov_iv, iv, &cov_bytes, 1)) return rc;
         if (int rc = A.add(&d->s_cov_base, cvbase, &cov_bytes)) return rc;
-        if (int rc = A.add(&d->cov_pairs, cpairs, &cov_bytes, 1)) return rc;
-        if (int rc = A.add(&d->cov_work, cwork, &cov_bytes, 1)) return rc;
+        if (!tables_on_device) {
+            if (int rc = A.add(&d->cov_pairs, cpairs, &cov_bytes, 1)) return rc;
+            if (int rc = A.add(&d->cov_work, cwork, &cov_bytes, 1)) return rc;
+        }
         if (int rc = A.add(&d->tile_len, tlen, &cov_bytes)) return rc;
         if (int rc = A.add(&d->tile_contig_dev, tcont, &cov_bytes)) return rc;
         return MSNV_OK;
@@ -1781,10 +1789,10 @@ int finalize_dataset(msnv_dataset &ds) {
         if (int rc = dev_alloc((void **)&d->cov_acc, d->cov_copies * acc_bytes, &d->device_bytes)) return rc;
     }
     lap("  coverage tables");
-    // ---- behind the last wait: how many chunks the narrow items got (cut in HBM, counted there)
+    // ---- the last wait: how many chunks the narrow items got (cut in HBM, counted there; an event behind the cut's kernels)
     if (chunks_on_device) {
         uint64_t n_narrow = 0; bool overflow = false;
-        devfin_chunks_result(ds, &n_narrow, &overflow);
+        if (int rc = devfin_chunks_result(ds, &n_narrow, &overflow)) return rc;
         if (overflow) {
             // (more chunks than the bound gave room for: once more with the exact number, which is known now)
             dev_free(d->chunks); d->chunks = nullptr;
@@ -1794,7 +1802,7 @@ int finalize_dataset(msnv_dataset &ds) {
             if (int rc = devfin_chunks_launch(ds, *d, narrow_pairs, item_first, (uint32_t)M, n_narrow)) return rc;
             if (int rc = devfin_work_first(ds, *d, d->n_work_narrow + d->n_work_merged)) return rc;
             if (int rc = dev_stream_wait(fin_stream)) return rc;
-            devfin_chunks_result(ds, &n_narrow, &overflow);
+            if (int rc = devfin_chunks_result(ds, &n_narrow, &overflow)) return rc;
             if (overflow) return fail(MSNV_EINVAL, "internal: the chunk count changed between two cuts of the same pairs");
         }
         d->n_chunks = M + n_narrow;
